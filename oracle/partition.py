@@ -1,0 +1,128 @@
+"""Partition naming, k1mer->partition table, read routing, per-partition k1-mer emit
+(rows a8-a11).  Test infrastructure (see oracle/__init__.py).  Follows
+kmers_for_component.py and weight_updated_graph.py.  gpmetis itself is external (METIS 5,
+unpinned): the partition vectors are inputs here.
+"""
+import math
+
+
+def n_partitions(num_contigs, partition_size):
+    """kmers_for_component.py:217."""
+    return min(int(math.ceil(float(num_contigs) / float(partition_size))), 100)
+
+
+def weight_updated_graph(metis_text, part, penalty=5):
+    """weight_updated_graph.py:24-42: multiply the weight of every edge cut by `part`
+    (list of partition ids, one per vertex) by `penalty`.  Returns the new METIS text."""
+    lines = metis_text.splitlines()
+    out = [lines[0] + "\n"]
+    for i, line in enumerate(lines[1:], start=1):
+        tok = line.split()
+        new = ""
+        for j in range(0, len(tok), 2):
+            nb = tok[j]
+            new += nb + "\t"
+            if int(part[i - 1]) != int(part[int(nb) - 1]):
+                new += str(penalty * int(tok[j + 1])) + "\t"
+            else:
+                new += tok[j + 1] + "\t"
+        out.append(new + "\n")
+    return "".join(out)
+
+
+def build_partitions(big_components, parts, parts_r2, remaining, allowed, K):
+    """kmers_for_component.py:244-305.
+      big_components : [contig list] per gpmetis'd component (file order)
+      parts/parts_r2 : [partition-id list] per component (first / second gpmetis run; r2 may be None)
+      remaining      : [contig list] per remaining_contigs{r}.txt
+      allowed        : {k1mer: int}
+    Returns (new_components {name: [contig...]} in creation order,
+             k1mers2component {k1mer: [set(names), weight]})."""
+    k1 = K + 1
+    new_components, k2c = {}, {}
+
+    def add(comp, contig):
+        new_components.setdefault(comp, []).append(contig)
+        for e in range(len(contig) - k1 + 1):
+            km = contig[e:e + k1]
+            if km not in k2c:
+                k2c[km] = [set([comp]), allowed.get(km, 0)]
+            else:
+                k2c[km][0].add(comp)
+
+    for i, contigs in enumerate(big_components):
+        for j, pid in enumerate(parts[i]):
+            add("c%d_%s" % (i + 1, pid), contigs[j])
+        if parts_r2 is not None:
+            for j, pid in enumerate(parts_r2[i]):
+                add("r2_c%d_%s" % (i + 1, pid), contigs[j])
+    for i, contigs in enumerate(remaining):
+        for c in contigs:
+            add("cremaining%d" % (i + 1), c)
+    return new_components, k2c
+
+
+def get_rmers(read, R):
+    """kmers_for_component.py:186-192: windows at 0,R,2R,... while i < len-R, plus the last."""
+    i, out = 0, []
+    while i < len(read) - R:
+        out.append(read[i:i + R])
+        i += R
+    out.append(read[-R:])
+    return out
+
+
+def get_comps(read, k2c, K):
+    """kmers_for_component.py:194-205: union of partitions hit by the probes."""
+    s = set()
+    for km in get_rmers(read, K + 1):
+        e = k2c.get(km)
+        if e is not None:
+            s |= e[0]
+    return s
+
+
+def route_reads(reads, new_components, k2c, K):
+    """SE routing, kmers_for_component.py:322-355 (double_stranded=False: reads already doubled).
+    Reads with any char outside ACTG are dropped (:336).  Returns {comp: [read...]} in input order."""
+    out = {c: [] for c in new_components}
+    for r in reads:
+        if r.strip("ACTG"):
+            continue
+        for c in get_comps(r, k2c, K):
+            out[c].append(r)
+    return out
+
+
+def route_reads_paired(reads1, reads2, new_components, k2c, K):
+    """PE routing, kmers_for_component.py:358-403: pair goes to the union over both mates."""
+    o1 = {c: [] for c in new_components}
+    o2 = {c: [] for c in new_components}
+    for a, b in zip(reads1, reads2):
+        if a.strip("ACTG") or b.strip("ACTG"):
+            continue
+        for c in get_comps(a, k2c, K) | get_comps(b, k2c, K):
+            o1[c].append(a)
+            o2[c].append(b)
+    return o1, o2
+
+
+def partition_k1mers(new_components, k2c, K):
+    """kmers_for_component.py:452-477: per partition, per contig, per k1-window in order:
+    (k1mer, weight).  Returns {comp: [(k1mer, w), ...]} (== component{comp}k1mers_allowed.dict)
+    and contig_weights {comp: [[w...] per contig]} (the --inMem form, :468-469)."""
+    k1 = K + 1
+    files, cw = {}, {}
+    for comp, contigs in new_components.items():
+        rows, ws = [], []
+        for contig in contigs:
+            wl = []
+            for i in range(len(contig) - k1 + 1):
+                km = contig[i:i + k1]
+                w = k2c[km][1]
+                wl.append(w)
+                rows.append((km, w))
+            ws.append(wl)
+        files[comp] = rows
+        cw[comp] = ws
+    return files, cw

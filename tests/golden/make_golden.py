@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the reference itself
+(translated at run time, see ref_harness.py) in THIS container.  Needs /root/reference;
+never runs on the GPU box.  Re-run:  python tests/golden/make_golden.py
+
+Fixture files (all plain data):
+  data/SE_read.fasta.gz, data/PE_read_{1,2}.fasta.gz   copies of the reference's sample inputs
+  data/<case>.npz                                      synthetic input reads (base codes)
+  <case>.json.gz                                       artefacts of every stage boundary
+  lp_kats.json                                         path_decompose known-answer cases
+Each artefact file carries a "standins" note: Jellyfish -> exact brute-force counter;
+gpmetis -> hand-written partition vectors; cvxopt -> stub + the oracle's pinned LP rule/RNG.
+"""
+import os, sys, json, gzip, hashlib, shutil, subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import ref_harness as H
+from shannon_amd import synth
+
+TMP = "/tmp/shannon_golden"
+STANDINS = ("jellyfish: exact brute-force k1-window counter, file written KMER-descending; "
+            "gpmetis: hand-written .part vectors (vertex i -> i % P; r2: (i // 2) % P); "
+            "cvxopt: numpy stub + oracle.lp.transport_vertex + oracle.lp.trial_costs (NOT real cvxopt)")
+
+
+def digest(obj):
+    return hashlib.sha256(json.dumps(obj, sort_keys=True).encode()).hexdigest()
+
+
+def tricky_transcriptome(seed, ng=3):
+    """Short exons (bridgeable X-nodes), shared exons, occasional repeated exon (cycles)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    isos = []
+    for g in range(ng):
+        ne = int(rng.integers(4, 9))
+        exons = [rng.integers(0, 4, size=int(rng.integers(30, 140)), dtype=np.uint8) for _ in range(ne)]
+        for _ in range(int(rng.integers(2, 5))):
+            order = [i for i in range(ne) if rng.random() < 0.75]
+            if rng.random() < 0.3 and len(order) > 2:
+                j = int(rng.integers(0, len(order)))
+                order.insert(int(rng.integers(0, len(order))), order[j])
+            if not order:
+                continue
+            iso = np.concatenate([exons[i] for i in order])
+            if len(iso) >= 320:
+                isos.append(iso)
+    return isos
+
+
+PART_HOOK = r'''
+import math
+_i = 1
+while os.path.exists(work + "/component%dcontigs.txt" % _i):
+    _n = len(open(work + "/component%dcontigs.txt" % _i).readlines())
+    _P = min(int(math.ceil(float(_n) / psize)), 100)
+    open(work + "/component%d.txt.part.%d" % (_i, _P), "w").write("".join("%d\n" % (v % _P) for v in range(_n)))
+    open(work + "/component%dr2.txt.part.%d" % (_i, _P), "w").write("".join("%d\n" % ((v // 2) % _P) for v in range(_n)))
+    _i += 1
+'''
+
+
+def slim(art, keep_full):
+    """Reduce an artefact dict to fixture size: big tables -> digests (+ full when small)."""
+    out = {"standins": STANDINS, "K": art["K"], "paired": art["paired"], "n_k1mers": art["n_k1mers"]}
+    counts = sorted(art["k1mer_counts"].items())
+    out["k1mer_counts_digest"] = digest(counts)
+    out["k1mer_total"] = int(sum(c for _, c in counts))
+    if keep_full:
+        out["k1mer_counts"] = counts
+    out["contigs"] = art["contigs"]
+    out["allowed_digest"] = digest(sorted(art["allowed"].items()))
+    out["n_allowed"] = len(art["allowed"])
+    out["single_contigs_fasta"] = art["single_contigs_fasta"]
+    out["remaining"] = art["remaining"]
+    out["big_components"] = art["big_components"]
+    out["components_broken"] = art["components_broken"]
+    out["partitions"] = {}
+    for c, p in art["partitions"].items():
+        q = {"reads_digest": digest(p["reads"]), "n_reads": len(p["reads"][0]), "read_names": p["read_names"],
+             "k1mers_digest": digest(p["k1mers"]), "n_k1mers": len(p["k1mers"]),
+             "graph": p["graph"], "single_rows": p["single_rows"], "raw_components": p["raw_components"],
+             "mb_log": [l.split(": ", 1)[-1] for l in p["mb_log"].splitlines()
+                        if "nodes after" in l or "Bridged" in l or "known paths:" in l or "mate paths" in l or "final nodes" in l]}
+        if "reconstructed_fasta" in p:
+            q["reconstructed_fasta"] = p["reconstructed_fasta"]
+        if keep_full or len(p["k1mers"]) < 20000:
+            q["k1mers"] = p["k1mers"]
+        out["partitions"][c] = q
+    return out
+
+
+def save(name, obj):
+    with gzip.open(os.path.join(HERE, name + ".json.gz"), "wt") as f:
+        json.dump(obj, f)
+
+
+def main():
+    shutil.rmtree(TMP, ignore_errors=True)
+    os.makedirs(TMP)
+    os.makedirs(os.path.join(HERE, "data"), exist_ok=True)
+    # --- the reference's own sample inputs (data files, copied as fixtures)
+    for fn in ("SE_read.fasta", "PE_read_1.fasta", "PE_read_2.fasta"):
+        with open(os.path.join(H.REF, "Samples", fn), "rb") as f, gzip.open(os.path.join(HERE, "data", fn + ".gz"), "wb") as g:
+            g.write(f.read())
+    se = os.path.join(H.REF, "Samples", "SE_read.fasta")
+    pe = [os.path.join(H.REF, "Samples", "PE_read_1.fasta"), os.path.join(H.REF, "Samples", "PE_read_2.fasta")]
+    manifest = {}
+    for name, files, K, paired in (("se_K24", [se], 24, False), ("se_K25", [se], 25, False), ("pe_K25", pe, 25, True)):
+        art = H.run_case(os.path.join(TMP, name), files, K, paired, run_sf=True, sf_seed=1)
+        save(name, slim(art, keep_full=False))
+        manifest[name] = {"inputs": [os.path.basename(f) + ".gz" for f in files], "K": K, "paired": paired, "sf_seed": 1}
+        print(name, "done", art["n_k1mers"])
+    # --- synthetic cases
+    syn = [("syn_pe_s0", 0, 2500, True, 25, 500), ("syn_se_s5", 5, 2500, False, 24, 500),
+           ("syn_pe_s12", 12, 2500, True, 25, 500), ("syn_se_s21", 21, 2500, False, 24, 500),
+           ("syn_pe_s20_K31", 20, 2500, True, 31, 500), ("syn_se_s7_K20", 7, 2500, False, 20, 500),
+           ("syn_part_s33", 33, 3000, True, 25, 1)]
+    for name, seed, npairs, paired, K, psize in syn:
+        isos = tricky_transcriptome(seed, 3 if psize > 10 else 6)
+        r1, r2 = synth.sample_pairs(isos, npairs, seed, err=[0.005, 0.0, 0.01][seed % 3])
+        np.savez_compressed(os.path.join(HERE, "data", name + ".npz"), r1=r1, r2=r2)
+        d = os.path.join(TMP, name + "_in")
+        os.makedirs(d)
+        synth.write_fasta(d + "/r1.fasta", r1)
+        synth.write_fasta(d + "/r2.fasta", r2)
+        hook = None
+        if psize < 10:
+            hook = os.path.join(d, "hook.py")
+            open(hook, "w").write(PART_HOOK)
+        art = H.run_case(os.path.join(TMP, name), [d + "/r1.fasta", d + "/r2.fasta"] if paired else [d + "/r1.fasta"],
+                         K, paired, partition_size=psize, part_hook=hook, run_sf=True, sf_seed=seed)
+        save(name, slim(art, keep_full=(name in ("syn_pe_s0", "syn_se_s7_K20"))))
+        manifest[name] = {"inputs": [name + ".npz"], "K": K, "paired": paired, "sf_seed": seed, "partition_size": psize}
+        print(name, "done", art["n_k1mers"], {c: p["graph"] and len(p["graph"]["nodes"]) for c, p in art["partitions"].items()})
+    json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1)
+    # --- LP known-answer cases through the reference's own path_decompose wrapper
+    tref = H.prepare_translated(os.path.join(TMP, "lp", "tref"))
+    code = r'''
+import sys, json
+import numpy as np
+import cvxopt
+from oracle import lp as olp
+import path_decompose_sparse as pds
+state = {"pid": 0, "trial": 0, "seed": 0}
+def fake_normal(mu, sigma, size):
+    v = np.array(olp.trial_costs(state["seed"], state["pid"], state["trial"], size[0]), dtype=float) / float(1 << 32)
+    state["trial"] += 1
+    return v.reshape(size)
+np.random.normal = fake_normal
+def lp_impl(c, A, b):
+    mn = A.shape[1]; n = int(round(A[0].sum())); m = mn // n
+    a_s = [float(v) for v in b.reshape(-1)[:m]]; b_s = [float(v) for v in b.reshape(-1)[m:]]
+    tot = 0.0
+    for v in a_s: tot += v
+    for v in b_s: tot -= v
+    b_s.append(tot if tot > 0 else 0.0)
+    cf = c.reshape(-1)
+    ci = [[int(round(cf[j * m + i] * (1 << 32))) for j in range(n)] for i in range(m)]
+    x = olp.transport_vertex(a_s, b_s, ci)
+    return np.array([x[k % m][k // m] for k in range(mn)], dtype=float).reshape(-1, 1)
+cvxopt.solvers.lp_impl = lp_impl
+rng = np.random.default_rng(99)
+kats = []
+for t in range(60):
+    m, n = int(rng.integers(1, 7)), int(rng.integers(1, 7))
+    if t < 8: m, n = [(1, 3), (3, 1), (2, 2), (3, 2), (2, 3), (4, 4), (5, 3), (6, 6)][t]
+    a = [float(v) for v in rng.integers(0 if t % 9 == 8 else 1, 40, m)]
+    if t % 2 == 0:
+        tot = int(sum(a)); cuts = np.sort(rng.integers(0, tot + 1, n - 1)); b = [float(v) for v in np.diff(np.concatenate([[0], cuts, [tot]]))]
+    else:
+        b = [float(v) + float(rng.random()) for v in rng.integers(1, 40, n)]
+    if t == 20: a = [0.0] * m
+    P = (rng.random((m, n)) < [0.0, 0.3, 0.7, 1.0][t % 4]).astype(int).tolist()
+    state.update(pid=t, trial=0, seed=1234)
+    ans, nu = pds.path_decompose(list(a), list(b), list(a), list(b), 0, cvxopt.matrix(np.array(P, dtype=float).reshape(m, n)), False, 10)
+    kats.append({"a": a, "b": b, "P": P, "seed": 1234, "pid": t, "answer": np.array(ans, dtype=float).reshape(m, n).tolist() if len(ans) else [], "non_unique": int(nu)})
+# the commented example of path_decompose_sparse.py:203-212
+for (a, b) in (([5., 7., 9.], [5., 16.]), ([5., 7., 9., 39.], [21., 11., 15., 13.])):
+    m, n = len(a), len(b)
+    state.update(pid=1000 + m, trial=0, seed=1234)
+    ans, nu = pds.path_decompose(list(a), list(b), list(a), list(b), 0, cvxopt.matrix(np.ones((m, n))), False, 3)
+    kats.append({"a": a, "b": b, "P": np.ones((m, n), dtype=int).tolist(), "seed": 1234, "pid": 1000 + m, "sparsity": 3, "answer": np.array(ans).tolist(), "non_unique": int(nu)})
+json.dump({"standins": "cvxopt stub + oracle.lp pinned LP rule and cost generator (NOT real cvxopt)", "kats": kats}, open(sys.argv[1], "w"))
+'''
+    H.run_py(tref, code, argv=[os.path.join(HERE, "lp_kats.json")])
+    print("lp kats done")
+
+
+if __name__ == "__main__":
+    main()

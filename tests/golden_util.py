@@ -1,0 +1,51 @@
+"""Helpers shared by the parity tests: load golden fixtures and their inputs (data only)."""
+import os, json, gzip, hashlib
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MANIFEST = json.load(open(os.path.join(GOLD, "manifest.json")))
+ALPHA = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def digest(obj):
+    return hashlib.sha256(json.dumps(obj, sort_keys=True).encode()).hexdigest()
+
+
+def load_case(name):
+    return json.load(gzip.open(os.path.join(GOLD, name + ".json.gz"), "rt"))
+
+
+def load_inputs(name):
+    """Returns list of read-string lists: [reads] (SE) or [reads1, reads2] (PE), as in the input files."""
+    m = MANIFEST[name]
+    out = []
+    if m["inputs"][0].endswith(".npz"):
+        z = np.load(os.path.join(GOLD, "data", m["inputs"][0]))
+        mats = [z["r1"], z["r2"]] if m["paired"] else [z["r1"]]
+        for mat in mats:
+            out.append([ALPHA[row].tobytes().decode() for row in mat])
+    else:
+        for fn in m["inputs"]:
+            with gzip.open(os.path.join(GOLD, "data", fn), "rt") as f:
+                out.append([l.strip() for l in f if l.strip() and l[0] != ">"])
+    return out
+
+
+def approx_eq(a, b, tol=1e-9):
+    if isinstance(a, float) or isinstance(b, float):
+        return abs(float(a) - float(b)) <= tol * max(1.0, abs(float(a)), abs(float(b)))
+    if isinstance(a, (list, tuple)):
+        return len(a) == len(b) and all(approx_eq(x, y, tol) for x, y in zip(a, b))
+    return a == b
+
+
+def parse_fasta(txt):
+    ls = txt.splitlines()
+    return [(ls[i], ls[i + 1]) for i in range(0, len(ls) - 1, 2)]
+
+
+def part_vectors(n_contigs, psize):
+    """The hand-written gpmetis stand-in of tests/golden/make_golden.py (PART_HOOK)."""
+    import math
+    P = min(int(math.ceil(float(n_contigs) / psize)), 100)
+    return [v % P for v in range(n_contigs)], [(v // 2) % P for v in range(n_contigs)]

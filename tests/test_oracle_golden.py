@@ -1,0 +1,134 @@
+"""CPU: the oracle (oracle/) against golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  Every stage boundary of the hot path, rows a1-a31."""
+import json, os
+import pytest
+from golden_util import *
+from oracle import seqs, count, extension, partition, mbgraph, sparse_flow, lp, post
+
+CASES = sorted(MANIFEST)
+
+
+def run_oracle_front(name):
+    g = load_case(name)
+    K, paired = g["K"], g["paired"]
+    inp = load_inputs(name)
+    dbl = list(seqs.double_strand_paired(*inp)) if paired else [seqs.double_strand_single(inp[0])]
+    tab = count.count_k1mers_dict([r for f in dbl for r in f], K + 1)
+    return g, K, paired, dbl, tab
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_pipeline_against_reference(name):
+    g, K, paired, dbl, tab = run_oracle_front(name)
+    psize = MANIFEST[name].get("partition_size", 500)
+    # a2: k1-mer table as a sorted multiset
+    assert len(tab) == g["n_k1mers"]
+    assert sum(tab.values()) == g["k1mer_total"]
+    assert digest(sorted([k, v] for k, v in tab.items())) == g["k1mer_counts_digest"]
+    # packed numpy counter agrees with the dict counter
+    keys, cnts = count.count_k1mers_packed([r for f in dbl for r in f], K + 1)
+    assert len(keys) == len(tab)
+    assert all(tab[count.key_to_str(k, K + 1)] == c for k, c in list(zip(keys, cnts))[::97])
+    # a3-a7
+    items = [(k, tab[k]) for k in sorted(tab, reverse=True)]
+    res = extension.run_correction(items, comp_size_threshold=psize)
+    assert res.contigs == g["contigs"]
+    assert len(res.allowed) == g["n_allowed"]
+    assert digest(sorted([k, v] for k, v in res.allowed.items())) == g["allowed_digest"]
+    assert "".join(">Single_%d\n%s\n" % (i, c) for i, c in enumerate(res.single_contigs)) == g["single_contigs_fasta"]
+    assert res.remaining == g["remaining"]
+    assert [b[0] for b in res.big_components] == [b["contigs"] for b in g["big_components"]]
+    assert [b[1] for b in res.big_components] == [b["metis"] for b in g["big_components"]]
+    # a8-a11
+    parts, parts2 = [], []
+    for (cl, metis), gb in zip(res.big_components, g["big_components"]):
+        p1, p2 = part_vectors(len(cl), psize)
+        parts.append(p1)
+        parts2.append(p2)
+        assert partition.weight_updated_graph(metis, p1, 5) == gb["metis_r2"]
+        assert partition.n_partitions(len(cl), psize) == max(p1) + 1
+    nc, k2c = partition.build_partitions([b[0] for b in res.big_components], parts, parts2 if parts else None,
+                                         res.remaining, res.allowed, K)
+    assert list(nc) == list(g["partitions"])
+    if paired:
+        o1, o2 = partition.route_reads_paired(dbl[0], dbl[1], nc, k2c, K)
+    else:
+        o1 = partition.route_reads(dbl[0], nc, k2c, K)
+    files, cw = partition.partition_k1mers(nc, k2c, K)
+    for comp, gp in g["partitions"].items():
+        reads = [o1[comp], o2[comp]] if paired else [o1[comp]]
+        assert len(reads[0]) == gp["n_reads"]
+        assert digest(reads) == gp["reads_digest"]
+        rows = [[a, str(b)] for a, b in files[comp]]
+        assert digest(rows) == gp["k1mers_digest"]
+        # a12-a24
+        gr, singles, comps = mbgraph.run_partition(files[comp], reads, K, paired)
+        can = mbgraph.canonical(singles, comps)
+        for k in can:
+            assert approx_eq(can[k], gp["graph"][k]), (comp, k)
+        mine_log = [l for l in gr.log]
+        ref_log = [l for l in gp["mb_log"] if not l.startswith("0") and l != "Finding known paths."]
+        assert [l for l in mine_log if "Bridged" in l] == [l for l in ref_log if "Bridged" in l]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_sparse_flow_against_reference(name):
+    """a25-a30 on the reference's own nodes/edges/paths tables (IDs and line order as written)."""
+    g = load_case(name)
+    seed = MANIFEST[name]["sf_seed"]
+    for comp, gp in g["partitions"].items():
+        mine = ""
+        for c, rc in enumerate(gp["raw_components"]):
+            tr = sparse_flow.sparse_flow_component(rc["nodes"], rc["edges"], rc["paths"], seed=seed, comp_id=c)
+            mine += sparse_flow.fasta_records("", str(c), tr)
+        mine += sparse_flow.single_nodes_fasta("", gp["single_rows"])
+        ref, mine = parse_fasta(gp["reconstructed_fasta"]), parse_fasta(mine)
+        assert len(ref) == len(mine)
+        for (h1, s1), (h2, s2) in zip(ref, mine):
+            assert s1 == s2
+            t1, t2 = h1.split("\t"), h2.split("\t")
+            assert t1[0] == t2[0] and t1[2:] == t2[2:]
+            if "Copycount" in t1[1]:
+                assert t1[1] == t2[1]
+            else:
+                assert abs(float(t1[1]) - float(t2[1])) <= 1e-9 * max(1.0, abs(float(t1[1])))
+
+
+def test_lp_kats():
+    """a28: wrapper logic of path_decompose against the reference's own wrapper (stub LP/RNG)."""
+    kats = json.load(open(os.path.join(GOLD, "lp_kats.json")))["kats"]
+    for k in kats:
+        ans, nu = lp.path_decompose(k["a"], k["b"], k["P"], seed=k["seed"], pid=k["pid"], sparsity=k.get("sparsity", 10))
+        assert approx_eq([list(r) for r in ans], k["answer"], 1e-12), k
+        assert nu == k["non_unique"]
+
+
+def test_lp_matches_highs_objective():
+    """The pinned LP rule returns an optimal flow: objective equals scipy-HiGHS (stand-in, not cvxopt)."""
+    import numpy as np
+    from scipy.optimize import linprog
+    rng = np.random.default_rng(3)
+    for t in range(60):
+        m, n = int(rng.integers(2, 7)), int(rng.integers(2, 7))
+        a = rng.integers(1, 20, m).astype(float)
+        tot = int(a.sum())
+        cuts = np.sort(rng.integers(0, tot + 1, n - 1))
+        b = np.diff(np.concatenate([[0], cuts, [tot]])).astype(float)
+        ci = [[lp.cell_cost(5, t, 0, j * m + i) * int(rng.random() < 0.7) for j in range(n)] for i in range(m)]
+        x = np.array(lp.transport_vertex(list(a), list(b), ci))
+        assert np.allclose(x.sum(1), a) and np.allclose(x.sum(0), b) and (x >= 0).all()
+        Aeq = []
+        for i in range(m):
+            r = np.zeros((m, n)); r[i, :] = 1; Aeq.append(r.ravel())
+        for j in range(n):
+            r = np.zeros((m, n)); r[:, j] = 1; Aeq.append(r.ravel())
+        c = np.array(ci, dtype=float) / 2 ** 32
+        res = linprog(c.ravel(), A_eq=np.array(Aeq), b_eq=np.concatenate([a, b]), bounds=(0, None), method="highs")
+        assert abs(res.fun - (c * x).sum()) < 1e-8
+
+
+def test_strand_symmetry_and_rc():
+    assert seqs.reverse_complement("ATCGGGG") == "CCCCGAT"          # mbgraph.py:69-70 doctest
+    g, K, paired, dbl, tab = run_oracle_front("pe_K25")
+    for k in list(tab)[::50]:
+        assert tab[k] == tab[seqs.reverse_complement(k)]
