@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/s through the Shannon hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" = one pass of the hot path over one batch of synthetic 2x100 bp reads already resident
+(2-bit packed) in HBM.  N=1 workload = BASELINE configs[1]: 10M reads (5M pairs), k=25 (-K 25,
+k1=26), one gene family.  N>1: every rank gets its own 10M-read shard (weak scaling) and the
+ranks exchange their (key,count) tables with one all-to-all over RCCL/xGMI.
+Prints ONE JSON line on rank 0.
+"""
+import argparse, json, os, sys, time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def gen_reads(n_pairs, seed, n_genes, device):
+    """synthetic pairs on the GPU (torch RNG; same model as shannon_amd/synth.py)."""
+    from shannon_amd import synth
+    iso, _ = synth.make_transcriptome(n_genes, seed)
+    lens = np.array([len(t) for t in iso], dtype=np.int64)
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    expr = rng.lognormal(0.0, 1.5, size=len(iso))
+    wts = expr * (lens - 300 + 1)
+    wts /= wts.sum()
+    g = torch.Generator(device=device)
+    g.manual_seed(seed + 2)
+    cat = torch.as_tensor(np.concatenate(iso), device=device)
+    offs = torch.as_tensor(np.concatenate([[0], np.cumsum(lens)[:-1]]), device=device)
+    tl = torch.as_tensor(lens, device=device)
+    out1, out2 = [], []
+    ar = torch.arange(100, device=device)
+    for s in range(0, n_pairs, 1 << 20):
+        n = min(1 << 20, n_pairs - s)
+        iso_i = torch.multinomial(torch.as_tensor(wts, device=device, dtype=torch.float32), n, replacement=True, generator=g)
+        start = (torch.rand(n, device=device, generator=g, dtype=torch.float64) * (tl[iso_i] - 299)).long() + offs[iso_i]
+        a = cat[start[:, None] + ar]
+        b = 3 - cat[(start + 299)[:, None] - ar]
+        for m in (a, b):
+            e = torch.rand(m.shape, device=device, generator=g) < 0.005
+            sub = torch.randint(1, 4, m.shape, device=device, generator=g, dtype=torch.uint8)
+            m[e] = (m[e] + sub[e]) & 3
+        out1.append(a.cpu())
+        out2.append(b.cpu())
+    return torch.cat(out1).numpy(), torch.cat(out2).numpy()
+
+
+def cpu_baseline(k1, seed, n_sample):
+    """The oracle's C restatement of the same stage, single host thread, bounded sample."""
+    from shannon_amd import synth
+    from oracle import build_c
+    (r1, r2), _ = synth.make_dataset(n_sample // 2, 1, seed)
+    codes = np.concatenate([r1, r2])
+    build_c.build()
+    t = time.time()
+    keys, cnts, nw = build_c.count_canonical(codes, k1, True)
+    dt = time.time() - t
+    return {"value": len(codes) / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+            "sample": "%d synthetic 100bp reads, same generator, stage=count (oracle/count_c.c radix sort + RLE), %.2fs" % (len(codes), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU (2 per pair)")
+    ap.add_argument("--K", type=int, default=25)
+    ap.add_argument("--genes", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    from shannon_amd import device, exchange
+    k1 = args.K + 1
+    dev = torch.device("cuda", local if world > 1 else 0)
+    seed = 20240501 + 1000 * rank
+    r1, r2 = gen_reads(args.reads // 2, seed, args.genes, dev)
+    ctx = device.Context(local if world > 1 else 0)
+    sets = [device.Reads.from_codes(ctx, r1), device.Reads.from_codes(ctx, r2)]
+    n_reads = len(sets[0]) + len(sets[1])
+    del r1, r2
+
+    def step():
+        t = device.count_k1mers(ctx, sets, k1, both_strands=True)
+        if world > 1:
+            owned = exchange.exchange_table(ctx, t)
+            t.close()
+            t = owned
+        return t
+
+    for _ in range(args.warmup):
+        step().close()
+    ctx.timer_reset()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ctx.sync()
+    t0 = time.time()
+    last = None
+    for _ in range(args.steps):
+        if last is not None:
+            last.close()
+        last = step()
+    ctx.sync()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    dt = time.time() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    timers = ctx.timers()
+    distinct, total = len(last), last.total
+    if rank == 0:
+        ms_step = 1000.0 * dt / args.steps
+        # dominant kernel group by HIP-event time on the ctx stream
+        groups = {k: v for k, v in timers.items() if k.startswith("count.") and k != "count.total"}
+        dom = max(groups, key=lambda k: groups[k][0])
+        W = 100 - k1 + 1
+        alg = {"count.hist1": 25.0, "count.scatter1": 25.0 + 8.0 * W, "count.hist2": 8.0 * W,
+               "count.scatter2": 16.0 * W, "count.buckets": 8.0 * W, "count.compact": 0.0}
+        launches = groups[dom][1]
+        avg_ms = groups[dom][0] / launches
+        reads_per_launch = n_reads * args.steps / launches
+        achieved = alg[dom] * reads_per_launch / (avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "reads/sec k-mer->graph->path-decompose, 2x100bp k=25",
+            "value": n_reads * world * args.steps / dt, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "10M synthetic 2x100bp paired reads per GPU, k=25 (k1=26), single gene family",
+                       "reads_per_gpu": n_reads, "K": args.K,
+                       "stages": "count (a1-a2: pack-resident reads -> canonical (K+1)-mer table%s); later rows of SURVEY 8a not in the timed step yet" % (", all-to-all exchange + reduce-by-key" if world > 1 else ""),
+                       "windows_per_step": total, "distinct_k1mers": distinct},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_read": alg[dom], "avg_launch_ms": avg_ms},
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(timers.items())},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(k1, 20240501, 1_000_000)
+        print(json.dumps(out), flush=True)
+    last.close()
+    ctx.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

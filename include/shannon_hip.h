@@ -1,0 +1,110 @@
+/*
+ * shannon_hip.h -- C ABI of libshannon_hip.so: the MI355X (gfx950) implementation of the
+ * Shannon RNA-Seq assembler hot path.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * The reference (sreeramkannan/Shannon, pure Python 2 + external programs) has no FFI of its
+ * own; each entry point below replaces the reference call site / external program cited next
+ * to it and is what a ctypes binding of that call site would bind.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative code on failure; shn_last_error()
+ *     returns the message of the last failure on the calling thread.  Nothing ever blocks on
+ *     stdin or calls exit() (the reference's pdb.set_trace()/raw_input() paths become errors).
+ *   - inputs are borrowed for the duration of the call; outputs are caller-allocated arrays or
+ *     opaque handles freed with the matching *_destroy.  Device buffers never escape except
+ *     through the explicit *_device_ptr accessors (for RCCL / torch interop).
+ *   - one shn_ctx per (device, stream); a context is used by one host thread at a time.
+ *   - base codes: A=0 C=1 G=2 T=3; k-mers are packed big-endian 2-bit (first base most
+ *     significant) in the low 2*k bits of a uint64, so integer order == string order.
+ */
+#ifndef SHANNON_HIP_H
+#define SHANNON_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct shn_ctx shn_ctx;
+typedef struct shn_reads shn_reads;
+typedef struct shn_table shn_table;
+
+#define SHN_OK 0
+#define SHN_ERR_ARG -1
+#define SHN_ERR_HIP -2
+#define SHN_ERR_NOMEM -3
+#define SHN_ERR_OVERFLOW -4
+#define SHN_ERR_INTERNAL -5
+
+#define SHN_ENC_ASCII 0 /* 'A','C','G','T' (either case); anything else is "non-ACGT" */
+#define SHN_ENC_CODES 1 /* 0..3; anything else is "non-ACGT"                          */
+
+const char* shn_last_error(void);
+const char* shn_version(void);
+
+/* ---- context ----------------------------------------------------------------------------- */
+/* `stream` is a hipStream_t (NULL = the device's default stream). */
+int shn_ctx_create(int device, void* stream, shn_ctx** out);
+void shn_ctx_destroy(shn_ctx* ctx);
+int shn_ctx_sync(shn_ctx* ctx);
+
+/* HIP-event timing on the context's stream (bench.py: per-kernel-group durations).
+ * shn_timer_begin/end bracket a region under `slot` (0..31); shn_timer_ms() synchronises and
+ * returns the accumulated milliseconds and number of regions since the last reset. */
+int shn_timer_reset(shn_ctx* ctx);
+int shn_timer_ms(shn_ctx* ctx, int slot, double* ms, uint64_t* n_regions);
+const char* shn_timer_name(int slot);
+
+/* ---- reads: upload + 2-bit pack on device --------------------------------------------------
+ * Replaces the read files the reference re-parses three times (jellyfish, shannon.py:439;
+ * kmers_for_component.py:329-403; multibridging.py:22-98) and rc_gnu.py/rc_s.py strand
+ * doubling (shannon.py:394-424): reverse complements are computed on chip, never stored.
+ *   bytes    host pointer, concatenated read bases (encoding `enc`)
+ *   offsets  host pointer to n_reads+1 byte offsets, or NULL for fixed-length reads
+ *   fixed_len read length when offsets == NULL                                            */
+int shn_reads_create(shn_ctx* ctx, const uint8_t* bytes, const uint64_t* offsets, uint64_t n_reads,
+                     uint32_t fixed_len, int enc, shn_reads** out);
+void shn_reads_destroy(shn_reads* r);
+uint64_t shn_reads_count(const shn_reads* r);
+uint64_t shn_reads_total_bases(const shn_reads* r);
+uint32_t shn_reads_max_len(const shn_reads* r);
+/* number of reads containing a non-ACGT character */
+uint64_t shn_reads_n_invalid(const shn_reads* r);
+
+/* ---- (K+1)-mer counting ----------------------------------------------------------------------
+ * Replaces `jellyfish count -m k1 ... ; jellyfish dump -c -t -L lower` (shannon.py:439-441;
+ * duplicate call site run_MB_SF_fn.py:177-184).  Counts every ACGT-only k1-window of every
+ * read of every set.  both_strands=1 folds a window and its reverse complement onto the
+ * canonical (smaller) key -- the count of x in the reference's strand-doubled input equals
+ * table[canon(x)] (x2 if x is its own reverse complement); both_strands=0 counts forward
+ * windows only (the reference's -s / --strand_specific mode).  2 <= k1 <= 32.             */
+int shn_count_k1mers(shn_ctx* ctx, shn_reads* const* sets, int n_sets, int k1, int both_strands,
+                     shn_table** out);
+void shn_table_destroy(shn_table* t);
+uint64_t shn_table_size(const shn_table* t);          /* number of distinct stored keys          */
+uint64_t shn_table_total(const shn_table* t);         /* number of windows counted               */
+int shn_table_k(const shn_table* t);
+int shn_table_canonical(const shn_table* t);
+/* copy the table to host arrays of shn_table_size() entries (order: bucket, then key) */
+int shn_table_download(shn_ctx* ctx, const shn_table* t, uint64_t* keys, uint32_t* counts);
+/* expanded to the reference's k1mer.dict_org content: every key of the strand-doubled input
+ * with count >= lower, sorted ascending.  Call with keys==NULL to get the size in *n.       */
+int shn_table_dump(shn_ctx* ctx, const shn_table* t, uint32_t lower, uint64_t* keys, uint32_t* counts,
+                   uint64_t* n);
+/* device-resident view for collectives (RCCL all-to-all of (key,count) shards) */
+int shn_table_device_ptrs(const shn_table* t, void** keys, void** counts);
+/* look up `n` keys (host array, already canonical if the table is) -> counts (0 if absent) */
+int shn_table_lookup(shn_ctx* ctx, const shn_table* t, const uint64_t* keys, uint64_t n, uint32_t* counts);
+
+/* Build a table from already-aggregated (key,count) pairs resident on the device, summing
+ * duplicates (the local reduce-by-key after the all-to-all bucket exchange). */
+int shn_table_from_pairs(shn_ctx* ctx, const void* dev_keys, const void* dev_counts, uint64_t n, int k1,
+                         int canonical, shn_table** out);
+/* Owner rank of each stored key for hash-sharding across GPUs: fills per-rank counts
+ * (host, n_ranks entries) and writes keys/counts grouped by rank into the device buffers. */
+int shn_table_shard(shn_ctx* ctx, const shn_table* t, int n_ranks, uint64_t* per_rank, void* dev_keys_out,
+                    void* dev_counts_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,63 @@
+"""ctypes binding of libshannon_hip.so (include/shannon_hip.h).  The product path has NO CPU
+fallback: if the library is missing or a call fails, a RuntimeError is raised."""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libshannon_hip.so")
+_lib = None
+
+u8p, u32p, u64p, dblp = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_double)
+vp, vpp = C.c_void_p, C.POINTER(C.c_void_p)
+
+SIGNATURES = {
+    "shn_last_error": (C.c_char_p, []),
+    "shn_version": (C.c_char_p, []),
+    "shn_ctx_create": (C.c_int, [C.c_int, vp, vpp]),
+    "shn_ctx_destroy": (None, [vp]),
+    "shn_ctx_sync": (C.c_int, [vp]),
+    "shn_timer_reset": (C.c_int, [vp]),
+    "shn_timer_ms": (C.c_int, [vp, C.c_int, dblp, u64p]),
+    "shn_timer_name": (C.c_char_p, [C.c_int]),
+    "shn_reads_create": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_int, vpp]),
+    "shn_reads_destroy": (None, [vp]),
+    "shn_reads_count": (C.c_uint64, [vp]),
+    "shn_reads_total_bases": (C.c_uint64, [vp]),
+    "shn_reads_max_len": (C.c_uint32, [vp]),
+    "shn_reads_n_invalid": (C.c_uint64, [vp]),
+    "shn_count_k1mers": (C.c_int, [vp, vpp, C.c_int, C.c_int, C.c_int, vpp]),
+    "shn_table_destroy": (None, [vp]),
+    "shn_table_size": (C.c_uint64, [vp]),
+    "shn_table_total": (C.c_uint64, [vp]),
+    "shn_table_k": (C.c_int, [vp]),
+    "shn_table_canonical": (C.c_int, [vp]),
+    "shn_table_download": (C.c_int, [vp, vp, vp, vp]),
+    "shn_table_dump": (C.c_int, [vp, vp, C.c_uint32, vp, vp, u64p]),
+    "shn_table_device_ptrs": (C.c_int, [vp, vpp, vpp]),
+    "shn_table_lookup": (C.c_int, [vp, vp, vp, C.c_uint64, vp]),
+    "shn_table_from_pairs": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vpp]),
+    "shn_table_shard": (C.c_int, [vp, vp, C.c_int, u64p, vp, vp]),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libshannon_hip.so not found at %s -- build it with `python -m shannon_amd.build` "
+                               "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        # torch bundles its own HIP runtime (soname libamdhip64.so.7); it must be the one already
+        # loaded when our library resolves libamdhip64.so.7, or two runtimes fight over the GPU.
+        import torch  # noqa: F401
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(l, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("libshannon_hip: %s (code %d)" % (lib().shn_last_error().decode(), rc))

@@ -1,0 +1,110 @@
+// Shared host/device helpers for libshannon_hip (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/shannon_hip.h"
+
+#define SHN_WAVE 64
+
+void shn_set_error(const std::string& msg);
+int shn_fail(int code, const std::string& msg);
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      return shn_fail(SHN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));        \
+  } while (0)
+
+enum {
+  T_PACK = 0, T_HIST1, T_SCATTER1, T_HIST2, T_SCATTER2, T_COUNT, T_COMPACT, T_COUNT_TOTAL, T_LOOKUP,
+  T_EXTEND, T_ROUTE, T_GRAPH, T_LP, T_N = 32
+};
+
+struct shn_ctx {
+  int device;
+  hipStream_t stream;
+  hipEvent_t ev0[T_N], ev1[T_N];
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[T_N];
+  double ms[T_N];
+  uint64_t regions[T_N];
+  bool timing;
+};
+
+// RAII-less region timer: records events on the ctx stream; durations are summed lazily.
+struct TimerRegion {
+  shn_ctx* c; int slot; hipEvent_t a, b;
+  TimerRegion(shn_ctx* ctx, int s);
+  ~TimerRegion();
+};
+
+struct shn_reads {
+  shn_ctx* ctx;
+  uint64_t n_reads;
+  uint32_t fixed_len;      // 0 => ragged
+  uint32_t max_len;
+  uint64_t total_bases;
+  uint64_t n_invalid;      // reads with >=1 non-ACGT base
+  uint32_t wpr;            // 64-bit words per read slot (fixed) -- ragged reads use woff
+  uint64_t n_words;
+  uint64_t* d_words;       // 2-bit bases, MSB-first, every read starts on a word boundary
+  uint64_t* d_mask;        // 1 bit per base (MSB-first in the same word geometry: bit for base j of
+                           // the read's word w is bit 63-(j%32)*... see pack kernel), NULL if no N
+  uint64_t* d_woff;        // ragged: word offset of each read (n_reads+1), else NULL
+  uint32_t* d_len;         // ragged: length of each read, else NULL
+  uint8_t* d_bad;          // per read: 1 if it contains a non-ACGT base (NULL if none)
+};
+
+struct shn_table {
+  shn_ctx* ctx;
+  int k;
+  int canonical;
+  uint64_t n;              // distinct keys
+  uint64_t total;          // windows counted
+  int bits;                // number of hash bits indexing buckets
+  uint64_t n_buckets;
+  uint64_t* d_keys;        // [n] grouped by bucket, ascending inside a bucket
+  uint32_t* d_counts;      // [n]
+  uint64_t* d_bucket_off;  // [n_buckets+1]
+};
+
+// ---------------------------------------------------------------- device helpers
+__host__ __device__ __forceinline__ uint64_t shn_mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+
+__device__ __forceinline__ uint64_t shn_revcomp(uint64_t key, int k) {
+  uint64_t v = __brevll(~key);
+  v = ((v >> 1) & 0x5555555555555555ULL) | ((v & 0x5555555555555555ULL) << 1);
+  return v >> (64 - 2 * k);
+}
+
+__host__ inline uint64_t shn_revcomp_host(uint64_t key, int k) {
+  uint64_t out = 0;
+  for (int i = 0; i < k; i++) { out = (out << 2) | (3 - (key & 3)); key >>= 2; }
+  return out;
+}
+
+// 2k-bit window starting at base `pos` of a read whose words start at `w` (MSB-first packing).
+__device__ __forceinline__ uint64_t shn_extract(const uint64_t* __restrict__ w, uint32_t pos, int k) {
+  uint32_t wi = pos >> 5, sh = (pos & 31) * 2;
+  uint64_t hi = w[wi];
+  uint64_t v = hi << sh;
+  if (sh + 2 * k > 64) v |= w[wi + 1] >> (64 - sh);   // sh > 0 here
+  return v >> (64 - 2 * k);
+}
+
+// k mask bits (1 = non-ACGT) starting at base `pos`; mask words hold 64 bases each, MSB-first.
+__device__ __forceinline__ uint64_t shn_extract_mask(const uint64_t* __restrict__ m, uint32_t pos, int k) {
+  uint32_t wi = pos >> 6, sh = pos & 63;
+  uint64_t v = m[wi] << sh;
+  if (sh + k > 64) v |= m[wi + 1] >> (64 - sh);
+  return v >> (64 - k);
+}
+
+static inline uint64_t cdiv(uint64_t a, uint64_t b) { return (a + b - 1) / b; }

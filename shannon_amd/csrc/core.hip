@@ -1,0 +1,263 @@
+// Context, error handling, event timers and the read uploader / 2-bit packer.
+#include "common.h"
+#include <cstring>
+#include <cstdio>
+
+static thread_local std::string g_err;
+void shn_set_error(const std::string& msg) { g_err = msg; }
+int shn_fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+extern "C" const char* shn_last_error(void) { return g_err.c_str(); }
+extern "C" const char* shn_version(void) { return "shannon_hip 0.1.0 (gfx950)"; }
+
+static const char* kTimerNames[T_N] = {
+  "pack", "count.hist1", "count.scatter1", "count.hist2", "count.scatter2", "count.buckets", "count.compact",
+  "count.total", "table.lookup", "extend", "route", "graph", "lp"};
+extern "C" const char* shn_timer_name(int slot) {
+  if (slot < 0 || slot >= T_N || !kTimerNames[slot]) return "";
+  return kTimerNames[slot];
+}
+
+TimerRegion::TimerRegion(shn_ctx* ctx, int s) : c(ctx), slot(s), a(nullptr), b(nullptr) {
+  if (!c->timing) return;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  hipEventRecord(a, c->stream);
+}
+TimerRegion::~TimerRegion() {
+  if (!a) return;
+  hipEventRecord(b, c->stream);
+  c->pending[slot].push_back({a, b});
+}
+
+extern "C" int shn_ctx_create(int device, void* stream, shn_ctx** out) {
+  if (!out) return shn_fail(SHN_ERR_ARG, "shn_ctx_create: out is NULL");
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) return shn_fail(SHN_ERR_ARG, "shn_ctx_create: no such device");
+  HIP_TRY(hipSetDevice(device));
+  shn_ctx* c = new shn_ctx();
+  c->device = device;
+  c->stream = (hipStream_t)stream;
+  c->timing = true;
+  for (int i = 0; i < T_N; i++) { c->ms[i] = 0; c->regions[i] = 0; }
+  *out = c;
+  return SHN_OK;
+}
+
+extern "C" void shn_ctx_destroy(shn_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  for (int i = 0; i < T_N; i++)
+    for (auto& p : c->pending[i]) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+  delete c;
+}
+
+extern "C" int shn_ctx_sync(shn_ctx* c) {
+  if (!c) return shn_fail(SHN_ERR_ARG, "ctx is NULL");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return SHN_OK;
+}
+
+static int drain_timers(shn_ctx* c) {
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int i = 0; i < T_N; i++) {
+    for (auto& p : c->pending[i]) {
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
+      c->ms[i] += ms;
+      c->regions[i]++;
+      hipEventDestroy(p.first);
+      hipEventDestroy(p.second);
+    }
+    c->pending[i].clear();
+  }
+  return SHN_OK;
+}
+
+extern "C" int shn_timer_reset(shn_ctx* c) {
+  if (!c) return shn_fail(SHN_ERR_ARG, "ctx is NULL");
+  int rc = drain_timers(c);
+  if (rc) return rc;
+  for (int i = 0; i < T_N; i++) { c->ms[i] = 0; c->regions[i] = 0; }
+  return SHN_OK;
+}
+
+extern "C" int shn_timer_ms(shn_ctx* c, int slot, double* ms, uint64_t* n_regions) {
+  if (!c || slot < 0 || slot >= T_N) return shn_fail(SHN_ERR_ARG, "shn_timer_ms: bad argument");
+  int rc = drain_timers(c);
+  if (rc) return rc;
+  if (ms) *ms = c->ms[slot];
+  if (n_regions) *n_regions = c->regions[slot];
+  return SHN_OK;
+}
+
+// ------------------------------------------------------------------------------------ packer
+__device__ __forceinline__ uint32_t enc_base(uint8_t b, int enc) {
+  if (enc == SHN_ENC_CODES) return b < 4 ? b : 4u;
+  switch (b) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return 4;
+  }
+}
+
+// One thread per 64-base group (two 2-bit words + one mask word) of one read.
+__global__ void pack_kernel(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ boff,
+                            const uint64_t* __restrict__ woff, uint64_t n_reads, uint32_t fixed_len, uint32_t wpr,
+                            int enc, uint64_t* __restrict__ words, uint64_t* __restrict__ mask,
+                            uint32_t* __restrict__ lens, uint64_t n_groups_fixed) {
+  uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t r, g, wbase, bstart;
+  uint32_t len;
+  if (boff == nullptr) {
+    uint32_t gpr = wpr / 2;
+    if (gid >= n_groups_fixed) return;
+    r = gid / gpr; g = gid % gpr;
+    wbase = r * wpr; bstart = r * (uint64_t)fixed_len; len = fixed_len;
+  } else {
+    // ragged: gid enumerates (read, group) through woff (binary search over reads)
+    uint64_t tw = woff[n_reads];
+    if (gid * 2 >= tw) return;
+    uint64_t lo = 0, hi = n_reads;            // largest r with woff[r] <= gid*2
+    while (hi - lo > 1) { uint64_t mid = (lo + hi) >> 1; if (woff[mid] <= gid * 2) lo = mid; else hi = mid; }
+    r = lo; wbase = woff[r]; g = (gid * 2 - wbase) / 2;
+    bstart = boff[r]; len = (uint32_t)(boff[r + 1] - boff[r]);
+    if (g == 0) lens[r] = len;
+  }
+  uint64_t w0 = 0, w1 = 0, m = 0;
+  uint32_t base0 = (uint32_t)g * 64;
+  for (uint32_t j = 0; j < 64; j++) {
+    uint32_t p = base0 + j;
+    uint32_t c = 0;
+    if (p < len) {
+      c = enc_base(bytes[bstart + p], enc);
+      if (c == 4) { m |= 1ULL << (63 - j); c = 0; }
+    }
+    if (j < 32) w0 |= (uint64_t)c << (62 - 2 * j);
+    else w1 |= (uint64_t)c << (62 - 2 * (j - 32));
+  }
+  words[wbase + 2 * g] = w0;
+  words[wbase + 2 * g + 1] = w1;
+  mask[wbase / 2 + g] = m;
+}
+
+__global__ void bad_reads_kernel(const uint64_t* __restrict__ mask, const uint64_t* __restrict__ woff,
+                                 uint64_t n_reads, uint32_t wpr, uint8_t* __restrict__ bad,
+                                 unsigned long long* __restrict__ n_bad) {
+  uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_reads) return;
+  uint64_t m0 = woff ? woff[r] / 2 : r * (wpr / 2);
+  uint64_t m1 = woff ? woff[r + 1] / 2 : (r + 1) * (wpr / 2);
+  uint64_t acc = 0;
+  for (uint64_t i = m0; i < m1; i++) acc |= mask[i];
+  bad[r] = acc ? 1 : 0;
+  if (acc) atomicAdd(n_bad, 1ULL);
+}
+
+extern "C" int shn_reads_create(shn_ctx* ctx, const uint8_t* bytes, const uint64_t* offsets, uint64_t n_reads,
+                                uint32_t fixed_len, int enc, shn_reads** out) {
+  if (!ctx || !out || (!bytes && n_reads)) return shn_fail(SHN_ERR_ARG, "shn_reads_create: NULL argument");
+  if (enc != SHN_ENC_ASCII && enc != SHN_ENC_CODES) return shn_fail(SHN_ERR_ARG, "shn_reads_create: bad encoding");
+  if (!offsets && fixed_len == 0 && n_reads) return shn_fail(SHN_ERR_ARG, "shn_reads_create: fixed_len is 0");
+  HIP_TRY(hipSetDevice(ctx->device));
+  shn_reads* r = new shn_reads();
+  memset(r, 0, sizeof(*r));
+  r->ctx = ctx;
+  r->n_reads = n_reads;
+  std::vector<uint64_t> woff;
+  uint64_t total_bytes;
+  if (offsets) {
+    woff.resize(n_reads + 1);
+    uint64_t w = 0;
+    uint32_t mx = 0;
+    for (uint64_t i = 0; i < n_reads; i++) {
+      if (offsets[i + 1] < offsets[i]) { delete r; return shn_fail(SHN_ERR_ARG, "shn_reads_create: offsets not monotone"); }
+      uint64_t len = offsets[i + 1] - offsets[i];
+      if (len > 0x7fffffffULL) { delete r; return shn_fail(SHN_ERR_ARG, "shn_reads_create: read too long"); }
+      woff[i] = w;
+      w += 2 * cdiv(len ? len : 1, 64);
+      if (len > mx) mx = (uint32_t)len;
+    }
+    woff[n_reads] = w;
+    r->n_words = w;
+    r->max_len = mx;
+    r->fixed_len = 0;
+    total_bytes = offsets[n_reads] - offsets[0];
+    r->total_bases = total_bytes;
+  } else {
+    r->fixed_len = fixed_len;
+    r->max_len = fixed_len;
+    r->wpr = (uint32_t)(2 * cdiv(fixed_len, 64));
+    r->n_words = n_reads * r->wpr;
+    total_bytes = n_reads * (uint64_t)fixed_len;
+    r->total_bases = total_bytes;
+  }
+  uint8_t* d_bytes = nullptr;
+  uint64_t* d_boff = nullptr;
+  hipStream_t s = ctx->stream;
+  auto cleanup = [&]() { if (d_bytes) hipFree(d_bytes); if (d_boff) hipFree(d_boff); };
+#define TRY2(e) do { hipError_t _e = (e); if (_e != hipSuccess) { cleanup(); shn_reads_destroy(r); \
+      return shn_fail(SHN_ERR_HIP, std::string(#e) + ": " + hipGetErrorString(_e)); } } while (0)
+  TRY2(hipMalloc(&r->d_words, (r->n_words + 2) * 8));
+  TRY2(hipMalloc(&r->d_mask, (r->n_words / 2 + 2) * 8));
+  TRY2(hipMemsetAsync(r->d_words, 0, (r->n_words + 2) * 8, s));
+  TRY2(hipMemsetAsync(r->d_mask, 0, (r->n_words / 2 + 2) * 8, s));
+  if (n_reads) {
+    TRY2(hipMalloc(&d_bytes, total_bytes ? total_bytes : 1));
+    TRY2(hipMemcpyAsync(d_bytes, bytes + (offsets ? offsets[0] : 0), total_bytes, hipMemcpyHostToDevice, s));
+    if (offsets) {
+      std::vector<uint64_t> rel(n_reads + 1);
+      for (uint64_t i = 0; i <= n_reads; i++) rel[i] = offsets[i] - offsets[0];
+      TRY2(hipMalloc(&d_boff, (n_reads + 1) * 8));
+      TRY2(hipMemcpyAsync(d_boff, rel.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, s));
+      TRY2(hipMalloc(&r->d_woff, (n_reads + 1) * 8));
+      TRY2(hipMemcpyAsync(r->d_woff, woff.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, s));
+      TRY2(hipMalloc(&r->d_len, n_reads * 4));
+      TRY2(hipStreamSynchronize(s));   // rel / woff are stack-owned vectors
+    }
+    {
+      TimerRegion t(ctx, T_PACK);
+      uint64_t n_groups = r->n_words / 2;
+      uint32_t blocks = (uint32_t)cdiv(n_groups, 256);
+      hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, s, d_bytes, d_boff, r->d_woff, n_reads, fixed_len,
+                         r->wpr, enc, r->d_words, r->d_mask, r->d_len, n_groups);
+      unsigned long long* d_nbad = nullptr;
+      TRY2(hipMalloc(&d_nbad, 8));
+      TRY2(hipMemsetAsync(d_nbad, 0, 8, s));
+      TRY2(hipMalloc(&r->d_bad, n_reads));
+      hipLaunchKernelGGL(bad_reads_kernel, dim3((uint32_t)cdiv(n_reads, 256)), dim3(256), 0, s, r->d_mask, r->d_woff,
+                         n_reads, r->wpr, r->d_bad, d_nbad);
+      unsigned long long nb = 0;
+      TRY2(hipMemcpyAsync(&nb, d_nbad, 8, hipMemcpyDeviceToHost, s));
+      TRY2(hipStreamSynchronize(s));
+      hipFree(d_nbad);
+      r->n_invalid = nb;
+    }
+    TRY2(hipGetLastError());
+  }
+  cleanup();
+#undef TRY2
+  *out = r;
+  return SHN_OK;
+}
+
+extern "C" void shn_reads_destroy(shn_reads* r) {
+  if (!r) return;
+  hipSetDevice(r->ctx->device);
+  if (r->d_words) hipFree(r->d_words);
+  if (r->d_mask) hipFree(r->d_mask);
+  if (r->d_woff) hipFree(r->d_woff);
+  if (r->d_len) hipFree(r->d_len);
+  if (r->d_bad) hipFree(r->d_bad);
+  delete r;
+}
+
+extern "C" uint64_t shn_reads_count(const shn_reads* r) { return r ? r->n_reads : 0; }
+extern "C" uint64_t shn_reads_total_bases(const shn_reads* r) { return r ? r->total_bases : 0; }
+extern "C" uint32_t shn_reads_max_len(const shn_reads* r) { return r ? r->max_len : 0; }
+extern "C" uint64_t shn_reads_n_invalid(const shn_reads* r) { return r ? r->n_invalid : 0; }

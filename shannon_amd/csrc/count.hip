@@ -1,0 +1,713 @@
+// (K+1)-mer counting on gfx950: replaces `jellyfish count | dump` (shannon.py:439-441).
+//
+// Pipeline (all HBM-bound byte/integer work, no MFMA):
+//   hist1     packed reads -> canonical keys (recomputed, never stored) -> level-1 bucket histogram
+//   scatter1  packed reads -> keys -> level-1 partitions   (keysA)      [8 B written per window]
+//   hist2     keysA        -> per-partition level-2 histogram
+//   scatter2  keysA        -> final buckets               (keysB)
+//   buckets   keysB        -> per-bucket LDS hash-aggregate + LDS bitonic sort -> (key,count) runs
+//   compact   runs         -> dense table (grouped by bucket, ascending inside a bucket)
+// Buckets are ranges of the top `bits` bits of murmur-fmix64(key); one bucket fits an LDS hash
+// table of CAP slots, so duplicates (heavy k-mers) cost no capacity, only LDS atomics.
+#include "common.h"
+#include <algorithm>
+#include <cstring>
+
+#define BLK 256
+#define CAP 2048            // LDS hash slots per final bucket
+#define CAP_LIMIT 1900      // distinct keys per bucket before we call it overflow
+#define TARGET_BUCKET 640   // average windows per final bucket
+#define TILE_IDS 65536      // window ids per block tile in hist1/scatter1
+#define TILE_KEYS 32768     // keys per block tile in hist2/scatter2
+#define EMPTY_KEY 0xFFFFFFFFFFFFFFFFULL
+
+struct ReadsView {
+  const uint64_t* words; const uint64_t* mask; const uint64_t* woff; const uint32_t* len;
+  uint64_t n_reads; uint32_t fixed_len, wpr, wmax, rt; int has_n;
+};
+
+__device__ __forceinline__ uint32_t bucket_of(uint64_t key, int bits) {
+  return bits ? (uint32_t)(shn_mix64(key) >> (64 - bits)) : 0u;
+}
+
+template <bool CANON>
+__device__ __forceinline__ bool gen_key(const ReadsView& v, uint64_t r, uint32_t pos, int k, uint64_t& key) {
+  uint32_t len = v.len ? v.len[r] : v.fixed_len;
+  if (pos + k > len) return false;
+  uint64_t wb = v.woff ? v.woff[r] : r * v.wpr;
+  if (v.has_n && shn_extract_mask(v.mask + wb / 2, pos, k)) return false;
+  key = shn_extract(v.words + wb, pos, k);
+  if (CANON) { uint64_t rc = shn_revcomp(key, k); key = rc < key ? rc : key; }
+  return true;
+}
+
+// ---------------------------------------------------------------- level 1 (from packed reads)
+template <bool CANON>
+__global__ __launch_bounds__(BLK) void hist1_kernel(ReadsView v, int k, int bits, int b2, uint64_t n_tiles,
+                                                    unsigned long long* __restrict__ hist1) {
+  extern __shared__ uint32_t lh[];
+  const int nb1 = 1 << (bits - b2);
+  for (int i = threadIdx.x; i < nb1; i += BLK) lh[i] = 0;
+  __syncthreads();
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    uint64_t r0 = tile * v.rt;
+    uint32_t nr = (uint32_t)min((uint64_t)v.rt, v.n_reads - r0);
+    uint32_t nid = nr * v.wmax;
+    for (uint32_t i = threadIdx.x; i < nid; i += BLK) {
+      uint32_t rl = i / v.wmax, pos = i - rl * v.wmax;
+      uint64_t key;
+      if (gen_key<CANON>(v, r0 + rl, pos, k, key)) atomicAdd(&lh[bucket_of(key, bits) >> b2], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nb1; i += BLK)
+    if (lh[i]) atomicAdd(&hist1[i], (unsigned long long)lh[i]);
+}
+
+template <bool CANON>
+__global__ __launch_bounds__(BLK) void scatter1_kernel(ReadsView v, int k, int bits, int b2, uint64_t n_tiles,
+                                                       unsigned long long* __restrict__ cursor1,
+                                                       uint64_t* __restrict__ out) {
+  extern __shared__ uint32_t lds[];
+  const int nb1 = 1 << (bits - b2);
+  unsigned long long* lbase = (unsigned long long*)lds;          // [nb1] reserved global bases
+  uint32_t* lh = (uint32_t*)(lbase + nb1);                        // [nb1] counts, then running ranks
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int i = threadIdx.x; i < nb1; i += BLK) lh[i] = 0;
+    __syncthreads();
+    uint64_t r0 = tile * v.rt;
+    uint32_t nr = (uint32_t)min((uint64_t)v.rt, v.n_reads - r0);
+    uint32_t nid = nr * v.wmax;
+    for (uint32_t i = threadIdx.x; i < nid; i += BLK) {
+      uint32_t rl = i / v.wmax, pos = i - rl * v.wmax;
+      uint64_t key;
+      if (gen_key<CANON>(v, r0 + rl, pos, k, key)) atomicAdd(&lh[bucket_of(key, bits) >> b2], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb1; i += BLK) {
+      uint32_t c = lh[i];
+      if (c) lbase[i] = atomicAdd(&cursor1[i], (unsigned long long)c);
+      lh[i] = 0;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nid; i += BLK) {
+      uint32_t rl = i / v.wmax, pos = i - rl * v.wmax;
+      uint64_t key;
+      if (gen_key<CANON>(v, r0 + rl, pos, k, key)) {
+        uint32_t p = bucket_of(key, bits) >> b2;
+        uint32_t rank = atomicAdd(&lh[p], 1u);
+        out[lbase[p] + rank] = key;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- levels from a key array
+// L1=true : one segment, digit = bucket >> b2 (used by the (key,count)-pairs path after the exchange)
+// L1=false: segment p = level-1 partition p, digit = bucket & (nb2-1)
+template <bool L1>
+__device__ __forceinline__ uint32_t digit_of(uint64_t key, int bits, int b2) {
+  uint32_t b = bucket_of(key, bits);
+  return L1 ? (b >> b2) : (b & ((1u << b2) - 1));
+}
+
+template <bool L1>
+__global__ __launch_bounds__(BLK) void hist_keys_kernel(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ segoff,
+                                                        int bits, int b2, uint32_t* __restrict__ hist) {
+  extern __shared__ uint32_t lh[];
+  const int nb = L1 ? (1 << (bits - b2)) : (1 << b2);
+  const uint32_t p = blockIdx.y;
+  const uint64_t s0 = segoff[p], s1 = segoff[p + 1];
+  uint64_t t0 = s0 + (uint64_t)blockIdx.x * TILE_KEYS;
+  if (t0 >= s1) return;
+  uint64_t t1 = min(t0 + TILE_KEYS, s1);
+  for (int i = threadIdx.x; i < nb; i += BLK) lh[i] = 0;
+  __syncthreads();
+  for (uint64_t i = t0 + threadIdx.x; i < t1; i += BLK)
+    atomicAdd(&lh[digit_of<L1>(keys[i], bits, b2)], 1u);
+  __syncthreads();
+  for (int i = threadIdx.x; i < nb; i += BLK)
+    if (lh[i]) atomicAdd(&hist[(uint64_t)p * nb + i], lh[i]);
+}
+
+// exclusive scan of each row of hist -> off (relative to the segment start) and cursor copy
+__global__ __launch_bounds__(BLK) void scan_rows_kernel(const uint32_t* __restrict__ hist2, int nb2,
+                                                        uint32_t* __restrict__ off2, uint32_t* __restrict__ cursor2) {
+  __shared__ uint32_t part[BLK];
+  const uint64_t row = (uint64_t)blockIdx.x * nb2;
+  const int per = (nb2 + BLK - 1) / BLK;
+  uint32_t s = 0;
+  for (int j = 0; j < per; j++) { int i = threadIdx.x * per + j; if (i < nb2) s += hist2[row + i]; }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { uint32_t a = 0; for (int i = 0; i < BLK; i++) { uint32_t t = part[i]; part[i] = a; a += t; } }
+  __syncthreads();
+  uint32_t a = part[threadIdx.x];
+  for (int j = 0; j < per; j++) {
+    int i = threadIdx.x * per + j;
+    if (i < nb2) { off2[row + i] = a; cursor2[row + i] = a; a += hist2[row + i]; }
+  }
+}
+
+template <bool L1, bool HASC>
+__global__ __launch_bounds__(BLK) void scatter_keys_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ cin,
+                                                           const uint64_t* __restrict__ segoff, int bits, int b2,
+                                                           uint32_t* __restrict__ cursor, uint64_t* __restrict__ out,
+                                                           uint32_t* __restrict__ cout) {
+  extern __shared__ uint32_t lds[];
+  const int nb = L1 ? (1 << (bits - b2)) : (1 << b2);
+  uint32_t* lh = lds;
+  uint32_t* lbase = lds + nb;
+  const uint32_t p = blockIdx.y;
+  const uint64_t s0 = segoff[p], s1 = segoff[p + 1];
+  uint64_t t0 = s0 + (uint64_t)blockIdx.x * TILE_KEYS;
+  if (t0 >= s1) return;
+  uint64_t t1 = min(t0 + TILE_KEYS, s1);
+  for (int i = threadIdx.x; i < nb; i += BLK) lh[i] = 0;
+  __syncthreads();
+  for (uint64_t i = t0 + threadIdx.x; i < t1; i += BLK)
+    atomicAdd(&lh[digit_of<L1>(keys[i], bits, b2)], 1u);
+  __syncthreads();
+  for (int i = threadIdx.x; i < nb; i += BLK) {
+    uint32_t c = lh[i];
+    if (c) lbase[i] = atomicAdd(&cursor[(uint64_t)p * nb + i], c);
+    lh[i] = 0;
+  }
+  __syncthreads();
+  for (uint64_t i = t0 + threadIdx.x; i < t1; i += BLK) {
+    uint64_t key = keys[i];
+    uint32_t q = digit_of<L1>(key, bits, b2);
+    uint32_t rank = atomicAdd(&lh[q], 1u);
+    out[s0 + lbase[q] + rank] = key;
+    if (HASC) cout[s0 + lbase[q] + rank] = cin[i];
+  }
+}
+
+// ---------------------------------------------------------------- final buckets
+// One block per final bucket: LDS hash-aggregate, compact, bitonic sort, write runs in place.
+template <bool HASC>
+__global__ __launch_bounds__(BLK) void buckets_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ cin,
+                                                      const uint64_t* __restrict__ off1,
+                                                      const uint32_t* __restrict__ off2, const uint32_t* __restrict__ hist2,
+                                                      int b2, uint64_t* __restrict__ out_keys, uint32_t* __restrict__ out_counts,
+                                                      uint32_t* __restrict__ ndist, uint32_t* __restrict__ overflow) {
+  __shared__ unsigned long long tk[CAP];
+  __shared__ uint32_t tc[CAP];
+  __shared__ unsigned long long ck[CAP];
+  __shared__ uint32_t cc[CAP];
+  __shared__ uint32_t lcount, lall;
+  const uint32_t b = blockIdx.x;
+  const uint32_t p = b >> b2;
+  const uint32_t n = hist2[b];
+  if (n == 0) { if (threadIdx.x == 0) ndist[b] = 0; return; }
+  const uint64_t s0 = off1[p] + off2[b];
+  for (int i = threadIdx.x; i < CAP; i += BLK) { tk[i] = EMPTY_KEY; tc[i] = 0; }
+  if (threadIdx.x == 0) { lcount = 0; lall = 0; }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < n; i += BLK) {
+    unsigned long long key = keys[s0 + i];
+    uint32_t w = HASC ? cin[s0 + i] : 1u;
+    if (key == EMPTY_KEY) { atomicAdd(&lall, w); continue; }      // k=32, non-canonical all-T
+    uint32_t slot = (uint32_t)(shn_mix64(key ^ 0x9E3779B97F4A7C15ULL)) & (CAP - 1);
+    for (int probe = 0; probe < CAP; probe++) {
+      unsigned long long prev = atomicCAS(&tk[slot], EMPTY_KEY, key);
+      if (prev == EMPTY_KEY || prev == key) { atomicAdd(&tc[slot], w); break; }
+      slot = (slot + 1) & (CAP - 1);
+      if (probe == CAP - 1) atomicExch(overflow, 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < CAP; i += BLK) {
+    if (tk[i] != EMPTY_KEY) { uint32_t pos = atomicAdd(&lcount, 1u); ck[pos] = tk[i]; cc[pos] = tc[i]; }
+  }
+  __syncthreads();
+  uint32_t nd = lcount;
+  if (nd > CAP_LIMIT) { if (threadIdx.x == 0) atomicExch(overflow, 1u); }
+  uint32_t m = 1;
+  while (m < nd) m <<= 1;
+  for (uint32_t i = nd + threadIdx.x; i < m; i += BLK) { ck[i] = EMPTY_KEY; cc[i] = 0; }
+  __syncthreads();
+  for (uint32_t kk = 2; kk <= m; kk <<= 1) {
+    for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = threadIdx.x; i < m; i += BLK) {
+        uint32_t x = i ^ j;
+        if (x > i) {
+          bool asc = (i & kk) == 0;
+          unsigned long long a = ck[i], c = ck[x];
+          if ((a > c) == asc) { ck[i] = c; ck[x] = a; uint32_t t = cc[i]; cc[i] = cc[x]; cc[x] = t; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (uint32_t i = threadIdx.x; i < nd; i += BLK) { out_keys[s0 + i] = ck[i]; out_counts[s0 + i] = cc[i]; }
+  if (lall) {   // the all-ones key sorts last
+    if (threadIdx.x == 0) { out_keys[s0 + nd] = EMPTY_KEY; out_counts[s0 + nd] = lall; }
+    nd += 1;
+  }
+  if (threadIdx.x == 0) ndist[b] = nd;
+}
+
+// ---------------------------------------------------------------- generic exclusive scan u32 -> u64
+__global__ __launch_bounds__(BLK) void scan_block_sums(const uint32_t* __restrict__ in, uint64_t n, uint64_t* __restrict__ sums) {
+  __shared__ unsigned long long red[BLK];
+  uint64_t base = (uint64_t)blockIdx.x * 1024;
+  unsigned long long s = 0;
+  for (int j = 0; j < 4; j++) { uint64_t i = base + threadIdx.x * 4 + j; if (i < n) s += in[i]; }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = BLK / 2; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
+  if (threadIdx.x == 0) sums[blockIdx.x] = red[0];
+}
+__global__ void scan_sums_serial(uint64_t* sums, uint64_t nblocks, uint64_t* total) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    uint64_t a = 0;
+    for (uint64_t i = 0; i < nblocks; i++) { uint64_t t = sums[i]; sums[i] = a; a += t; }
+    *total = a;
+  }
+}
+__global__ __launch_bounds__(BLK) void scan_apply(const uint32_t* __restrict__ in, uint64_t n, const uint64_t* __restrict__ sums,
+                                                  uint64_t* __restrict__ out, const uint64_t* __restrict__ total) {
+  __shared__ unsigned long long part[BLK];
+  uint64_t base = (uint64_t)blockIdx.x * 1024;
+  uint32_t v[4];
+  unsigned long long s = 0;
+  for (int j = 0; j < 4; j++) { uint64_t i = base + threadIdx.x * 4 + j; v[j] = i < n ? in[i] : 0; s += v[j]; }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { unsigned long long a = 0; for (int i = 0; i < BLK; i++) { unsigned long long t = part[i]; part[i] = a; a += t; } }
+  __syncthreads();
+  unsigned long long a = sums[blockIdx.x] + part[threadIdx.x];
+  for (int j = 0; j < 4; j++) { uint64_t i = base + threadIdx.x * 4 + j; if (i < n) out[i] = a; a += v[j]; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
+}
+
+__global__ __launch_bounds__(BLK) void compact_kernel(const uint64_t* __restrict__ run_keys, const uint32_t* __restrict__ run_counts,
+                                                      const uint64_t* __restrict__ off1, const uint32_t* __restrict__ off2,
+                                                      const uint32_t* __restrict__ ndist, const uint64_t* __restrict__ boff, int b2,
+                                                      uint64_t n_buckets, uint64_t* __restrict__ keys, uint32_t* __restrict__ counts) {
+  // one wave per bucket
+  uint64_t b = ((uint64_t)blockIdx.x * BLK + threadIdx.x) / SHN_WAVE;
+  if (b >= n_buckets) return;
+  uint32_t lane = threadIdx.x & (SHN_WAVE - 1);
+  uint32_t nd = ndist[b];
+  if (!nd) return;
+  uint64_t s0 = off1[b >> b2] + off2[b];
+  uint64_t d0 = boff[b];
+  for (uint32_t i = lane; i < nd; i += SHN_WAVE) { keys[d0 + i] = run_keys[s0 + i]; counts[d0 + i] = run_counts[s0 + i]; }
+}
+
+// ---------------------------------------------------------------- lookup
+__global__ void lookup_kernel(const uint64_t* __restrict__ tkeys, const uint32_t* __restrict__ tcounts,
+                              const uint64_t* __restrict__ boff, int bits, const uint64_t* __restrict__ q, uint64_t n,
+                              uint32_t* __restrict__ out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t key = q[i];
+  uint32_t b = bucket_of(key, bits);
+  uint64_t lo = boff[b], hi = boff[b + 1];
+  uint32_t res = 0;
+  while (lo < hi) {
+    uint64_t mid = (lo + hi) >> 1;
+    uint64_t v = tkeys[mid];
+    if (v == key) { res = tcounts[mid]; break; }
+    if (v < key) lo = mid + 1; else hi = mid;
+  }
+  out[i] = res;
+}
+
+// ================================================================ host side
+struct Ws {   // grow-only device workspace
+  void* p = nullptr; size_t cap = 0;
+  int get(size_t bytes, void** out) {
+    if (bytes > cap) {
+      if (p) hipFree(p);
+      p = nullptr; cap = 0;
+      hipError_t e = hipMalloc(&p, bytes);
+      if (e != hipSuccess) return shn_fail(SHN_ERR_NOMEM, std::string("hipMalloc workspace: ") + hipGetErrorString(e));
+      cap = bytes;
+    }
+    *out = p;
+    return SHN_OK;
+  }
+};
+static Ws g_ws[8];   // per-process (one ctx per process in practice: one process per GPU)
+
+static int device_scan(shn_ctx* ctx, const uint32_t* d_in, uint64_t n, uint64_t* d_out /* n+1 */, uint64_t* total_host) {
+  hipStream_t s = ctx->stream;
+  uint64_t nblocks = cdiv(n, 1024);
+  if (nblocks == 0) nblocks = 1;
+  void* sums;
+  int rc = g_ws[7].get((nblocks + 1) * 8, &sums);
+  if (rc) return rc;
+  uint64_t* d_sums = (uint64_t*)sums;
+  uint64_t* d_total = d_sums + nblocks;
+  hipLaunchKernelGGL(scan_block_sums, dim3((uint32_t)nblocks), dim3(BLK), 0, s, d_in, n, d_sums);
+  hipLaunchKernelGGL(scan_sums_serial, dim3(1), dim3(64), 0, s, d_sums, nblocks, d_total);
+  hipLaunchKernelGGL(scan_apply, dim3((uint32_t)nblocks), dim3(BLK), 0, s, d_in, n, d_sums, d_out, d_total);
+  HIP_TRY(hipMemcpyAsync(total_host, d_total, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return SHN_OK;
+}
+
+static ReadsView make_view(const shn_reads* r, int k) {
+  ReadsView v;
+  v.words = r->d_words; v.mask = r->d_mask; v.woff = r->d_woff; v.len = r->d_len;
+  v.n_reads = r->n_reads; v.fixed_len = r->fixed_len; v.wpr = r->wpr;
+  v.wmax = r->max_len >= (uint32_t)k ? r->max_len - k + 1 : 0;
+  v.rt = v.wmax ? std::max<uint32_t>(1, TILE_IDS / v.wmax) : 1;
+  v.has_n = r->n_invalid > 0;
+  return v;
+}
+
+static int build_from_keys(shn_ctx* ctx, uint64_t* keysA, uint64_t* keysB, uint32_t* tmpc, uint32_t* cntA, uint32_t* cntB,
+                           const std::vector<uint64_t>& off1h, int bits, int b2, int k, int canonical, uint64_t N,
+                           uint64_t total, shn_table** out, bool* overflowed);
+
+extern "C" int shn_count_k1mers(shn_ctx* ctx, shn_reads* const* sets, int n_sets, int k1, int both_strands, shn_table** out) {
+  if (!ctx || !sets || !out || n_sets <= 0) return shn_fail(SHN_ERR_ARG, "shn_count_k1mers: bad argument");
+  if (k1 < 2 || k1 > 32) return shn_fail(SHN_ERR_ARG, "shn_count_k1mers: k1 must be in [2,32]");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  TimerRegion ttot(ctx, T_COUNT_TOTAL);
+  uint64_t upper = 0;
+  std::vector<ReadsView> views;
+  for (int i = 0; i < n_sets; i++) {
+    if (!sets[i]) return shn_fail(SHN_ERR_ARG, "shn_count_k1mers: NULL read set");
+    ReadsView v = make_view(sets[i], k1);
+    views.push_back(v);
+    upper += v.n_reads * (uint64_t)v.wmax;
+  }
+  int bits = 0;
+  while (bits < 24 && (upper >> bits) > TARGET_BUCKET) bits++;
+  for (int attempt = 0; attempt < 4; attempt++) {
+    int b1 = (bits + 1) / 2, b2 = bits - b1;
+    int nb1 = 1 << b1;
+    void* p;
+    int rc = g_ws[0].get((size_t)nb1 * 16 + 64, &p);
+    if (rc) return rc;
+    unsigned long long* d_hist1 = (unsigned long long*)p;
+    unsigned long long* d_cursor1 = d_hist1 + nb1;
+    HIP_TRY(hipMemsetAsync(d_hist1, 0, (size_t)nb1 * 8, s));
+    {
+      TimerRegion t(ctx, T_HIST1);
+      for (auto& v : views) {
+        if (!v.wmax || !v.n_reads) continue;
+        uint64_t n_tiles = cdiv(v.n_reads, v.rt);
+        uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, 2048);
+        if (both_strands) hipLaunchKernelGGL(hist1_kernel<true>, dim3(grid), dim3(BLK), nb1 * 4, s, v, k1, bits, b2, n_tiles, d_hist1);
+        else hipLaunchKernelGGL(hist1_kernel<false>, dim3(grid), dim3(BLK), nb1 * 4, s, v, k1, bits, b2, n_tiles, d_hist1);
+      }
+    }
+    std::vector<uint64_t> h1(nb1), off1(nb1 + 1);
+    HIP_TRY(hipMemcpyAsync(h1.data(), d_hist1, (size_t)nb1 * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    uint64_t N = 0;
+    for (int i = 0; i < nb1; i++) { off1[i] = N; N += h1[i]; }
+    off1[nb1] = N;
+    HIP_TRY(hipMemcpyAsync(d_cursor1, off1.data(), (size_t)nb1 * 8, hipMemcpyHostToDevice, s));
+    void *pa, *pb, *pc;
+    if ((rc = g_ws[1].get((N + 2) * 8, &pa))) return rc;
+    if ((rc = g_ws[2].get((N + 2) * 8, &pb))) return rc;
+    if ((rc = g_ws[3].get((N + 2) * 4, &pc))) return rc;
+    uint64_t* keysA = (uint64_t*)pa;
+    uint64_t* keysB = (uint64_t*)pb;
+    {
+      TimerRegion t(ctx, T_SCATTER1);
+      for (auto& v : views) {
+        if (!v.wmax || !v.n_reads) continue;
+        uint64_t n_tiles = cdiv(v.n_reads, v.rt);
+        uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, 2048);
+        size_t sh = (size_t)nb1 * 4 + (size_t)nb1 * 8;
+        if (both_strands) hipLaunchKernelGGL(scatter1_kernel<true>, dim3(grid), dim3(BLK), sh, s, v, k1, bits, b2, n_tiles, d_cursor1, keysA);
+        else hipLaunchKernelGGL(scatter1_kernel<false>, dim3(grid), dim3(BLK), sh, s, v, k1, bits, b2, n_tiles, d_cursor1, keysA);
+      }
+    }
+    bool ov = false;
+    rc = build_from_keys(ctx, keysA, keysB, (uint32_t*)pc, nullptr, nullptr, off1, bits, b2, k1, both_strands ? 1 : 0, N, N, out, &ov);
+    if (rc) return rc;
+    if (!ov) return SHN_OK;
+    shn_table_destroy(*out);
+    *out = nullptr;
+    bits = std::min(24, bits + 2);
+  }
+  return shn_fail(SHN_ERR_OVERFLOW, "shn_count_k1mers: a final bucket exceeded the LDS hash capacity after 4 attempts");
+}
+
+// keysA holds N keys partitioned at level 1 (offsets off1h); produces the dense table.
+// cntA/cntB non-NULL: keys carry counts (pairs path); `total` = number of windows represented.
+static int build_from_keys(shn_ctx* ctx, uint64_t* keysA, uint64_t* keysB, uint32_t* tmpc, uint32_t* cntA, uint32_t* cntB,
+                           const std::vector<uint64_t>& off1h, int bits, int b2, int k, int canonical, uint64_t N,
+                           uint64_t total, shn_table** out, bool* overflowed) {
+  hipStream_t s = ctx->stream;
+  int b1 = bits - b2;
+  int nb1 = 1 << b1, nb2 = 1 << b2;
+  uint64_t nbk = (uint64_t)1 << bits;
+  uint64_t max1 = 0;
+  for (int i = 0; i < nb1; i++) max1 = std::max(max1, off1h[i + 1] - off1h[i]);
+  if (max1 >= 0xFFFFFFFFULL) return shn_fail(SHN_ERR_OVERFLOW, "level-1 partition larger than 2^32 keys");
+  void* p;
+  int rc;
+  size_t need = (size_t)(nb1 + 1) * 8 + nbk * 4 * 4 + 64 + (nbk + 2) * 8;
+  if ((rc = g_ws[4].get(need, &p))) return rc;
+  uint64_t* d_off1 = (uint64_t*)p;
+  uint64_t* d_boff = d_off1 + (nb1 + 1);
+  uint32_t* d_hist2 = (uint32_t*)(d_boff + nbk + 2);
+  uint32_t* d_off2 = d_hist2 + nbk;
+  uint32_t* d_cursor2 = d_off2 + nbk;
+  uint32_t* d_ndist = d_cursor2 + nbk;
+  uint32_t* d_ovf = d_ndist + nbk;
+  HIP_TRY(hipMemcpyAsync(d_off1, off1h.data(), (size_t)(nb1 + 1) * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(d_hist2, 0, nbk * 4, s));
+  HIP_TRY(hipMemsetAsync(d_ovf, 0, 4, s));
+  uint32_t tiles = (uint32_t)std::max<uint64_t>(1, cdiv(max1, TILE_KEYS));
+  {
+    TimerRegion t(ctx, T_HIST2);
+    hipLaunchKernelGGL(hist_keys_kernel<false>, dim3(tiles, nb1), dim3(BLK), nb2 * 4, s, keysA, d_off1, bits, b2, d_hist2);
+    hipLaunchKernelGGL(scan_rows_kernel, dim3(nb1), dim3(BLK), 0, s, d_hist2, nb2, d_off2, d_cursor2);
+  }
+  {
+    TimerRegion t(ctx, T_SCATTER2);
+    if (cntA) hipLaunchKernelGGL((scatter_keys_kernel<false, true>), dim3(tiles, nb1), dim3(BLK), nb2 * 8, s, keysA, cntA, d_off1, bits, b2, d_cursor2, keysB, cntB);
+    else hipLaunchKernelGGL((scatter_keys_kernel<false, false>), dim3(tiles, nb1), dim3(BLK), nb2 * 8, s, keysA, nullptr, d_off1, bits, b2, d_cursor2, keysB, nullptr);
+  }
+  {
+    TimerRegion t(ctx, T_COUNT);
+    if (cntA) hipLaunchKernelGGL(buckets_kernel<true>, dim3((uint32_t)nbk), dim3(BLK), 0, s, keysB, cntB, d_off1, d_off2, d_hist2, b2, keysA, tmpc, d_ndist, d_ovf);
+    else hipLaunchKernelGGL(buckets_kernel<false>, dim3((uint32_t)nbk), dim3(BLK), 0, s, keysB, nullptr, d_off1, d_off2, d_hist2, b2, keysA, tmpc, d_ndist, d_ovf);
+  }
+  uint64_t D = 0;
+  shn_table* t = new shn_table();
+  memset(t, 0, sizeof(*t));
+  t->ctx = ctx; t->k = k; t->canonical = canonical; t->bits = bits; t->n_buckets = nbk; t->total = total;
+  {
+    TimerRegion tr(ctx, T_COMPACT);
+    if ((rc = device_scan(ctx, d_ndist, nbk, d_boff, &D))) { delete t; return rc; }
+    uint32_t ovf = 0;
+    HIP_TRY(hipMemcpyAsync(&ovf, d_ovf, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *overflowed = ovf != 0;
+    t->n = D;
+    HIP_TRY(hipMalloc(&t->d_keys, (D + 1) * 8));
+    HIP_TRY(hipMalloc(&t->d_counts, (D + 1) * 4));
+    HIP_TRY(hipMalloc(&t->d_bucket_off, (nbk + 1) * 8));
+    HIP_TRY(hipMemcpyAsync(t->d_bucket_off, d_boff, (nbk + 1) * 8, hipMemcpyDeviceToDevice, s));
+    if (!ovf && D) {
+      uint32_t blocks = (uint32_t)cdiv(nbk * SHN_WAVE, BLK);
+      hipLaunchKernelGGL(compact_kernel, dim3(blocks), dim3(BLK), 0, s, keysA, tmpc, d_off1, d_off2, d_ndist, d_boff, b2, nbk, t->d_keys, t->d_counts);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  *out = t;
+  return SHN_OK;
+}
+
+extern "C" void shn_table_destroy(shn_table* t) {
+  if (!t) return;
+  hipSetDevice(t->ctx->device);
+  if (t->d_keys) hipFree(t->d_keys);
+  if (t->d_counts) hipFree(t->d_counts);
+  if (t->d_bucket_off) hipFree(t->d_bucket_off);
+  delete t;
+}
+extern "C" uint64_t shn_table_size(const shn_table* t) { return t ? t->n : 0; }
+extern "C" uint64_t shn_table_total(const shn_table* t) { return t ? t->total : 0; }
+extern "C" int shn_table_k(const shn_table* t) { return t ? t->k : 0; }
+extern "C" int shn_table_canonical(const shn_table* t) { return t ? t->canonical : 0; }
+
+extern "C" int shn_table_download(shn_ctx* ctx, const shn_table* t, uint64_t* keys, uint32_t* counts) {
+  if (!ctx || !t) return shn_fail(SHN_ERR_ARG, "shn_table_download: NULL argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (keys) HIP_TRY(hipMemcpyAsync(keys, t->d_keys, t->n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (counts) HIP_TRY(hipMemcpyAsync(counts, t->d_counts, t->n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return SHN_OK;
+}
+
+extern "C" int shn_table_dump(shn_ctx* ctx, const shn_table* t, uint32_t lower, uint64_t* keys, uint32_t* counts, uint64_t* n) {
+  if (!ctx || !t || !n) return shn_fail(SHN_ERR_ARG, "shn_table_dump: NULL argument");
+  std::vector<uint64_t> hk(t->n);
+  std::vector<uint32_t> hc(t->n);
+  int rc = shn_table_download(ctx, t, hk.data(), hc.data());
+  if (rc) return rc;
+  std::vector<std::pair<uint64_t, uint32_t>> v;
+  v.reserve(t->canonical ? 2 * t->n : t->n);
+  for (uint64_t i = 0; i < t->n; i++) {
+    uint64_t key = hk[i];
+    uint64_t c = hc[i];
+    if (t->canonical) {
+      uint64_t rc2 = shn_revcomp_host(key, t->k);
+      if (rc2 == key) { c *= 2; if (c >= lower) v.push_back({key, (uint32_t)std::min<uint64_t>(c, 0xFFFFFFFFULL)}); }
+      else if (c >= lower) { v.push_back({key, (uint32_t)c}); v.push_back({rc2, (uint32_t)c}); }
+    } else if (c >= lower) v.push_back({key, (uint32_t)c});
+  }
+  if (!keys || !counts) { *n = v.size(); return SHN_OK; }
+  if (*n < v.size()) return shn_fail(SHN_ERR_ARG, "shn_table_dump: output arrays too small");
+  std::sort(v.begin(), v.end());
+  for (size_t i = 0; i < v.size(); i++) { keys[i] = v[i].first; counts[i] = v[i].second; }
+  *n = v.size();
+  return SHN_OK;
+}
+
+extern "C" int shn_table_device_ptrs(const shn_table* t, void** keys, void** counts) {
+  if (!t) return shn_fail(SHN_ERR_ARG, "shn_table_device_ptrs: NULL table");
+  if (keys) *keys = t->d_keys;
+  if (counts) *counts = t->d_counts;
+  return SHN_OK;
+}
+
+extern "C" int shn_table_lookup(shn_ctx* ctx, const shn_table* t, const uint64_t* keys, uint64_t n, uint32_t* counts) {
+  if (!ctx || !t || (!keys && n) || (!counts && n)) return shn_fail(SHN_ERR_ARG, "shn_table_lookup: NULL argument");
+  if (!n) return SHN_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  uint64_t* dq; uint32_t* dc;
+  HIP_TRY(hipMalloc(&dq, n * 8));
+  HIP_TRY(hipMalloc(&dc, n * 4));
+  HIP_TRY(hipMemcpyAsync(dq, keys, n * 8, hipMemcpyHostToDevice, s));
+  {
+    TimerRegion tr(ctx, T_LOOKUP);
+    hipLaunchKernelGGL(lookup_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, t->d_counts, t->d_bucket_off, t->bits, dq, n, dc);
+  }
+  HIP_TRY(hipMemcpyAsync(counts, dc, n * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  hipFree(dq); hipFree(dc);
+  return SHN_OK;
+}
+
+// ---------------------------------------------------------------- (key,count) pairs path + sharding
+__global__ void sum_counts_kernel(const uint32_t* __restrict__ c, uint64_t n, unsigned long long* __restrict__ out) {
+  unsigned long long a = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) a += c[i];
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+  if ((threadIdx.x & 63) == 0 && a) atomicAdd(out, a);
+}
+
+extern "C" int shn_table_from_pairs(shn_ctx* ctx, const void* dev_keys, const void* dev_counts, uint64_t n, int k1,
+                                    int canonical, shn_table** out) {
+  if (!ctx || !out || (n && (!dev_keys || !dev_counts))) return shn_fail(SHN_ERR_ARG, "shn_table_from_pairs: NULL argument");
+  if (n >= 0xFFFFFFFFULL) return shn_fail(SHN_ERR_ARG, "shn_table_from_pairs: more than 2^32 pairs");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  TimerRegion ttot(ctx, T_COUNT_TOTAL);
+  const uint64_t* keys = (const uint64_t*)dev_keys;
+  const uint32_t* cnts = (const uint32_t*)dev_counts;
+  int bits = 0;
+  while (bits < 24 && (n >> bits) > TARGET_BUCKET) bits++;
+  for (int attempt = 0; attempt < 4; attempt++) {
+    int b1 = (bits + 1) / 2, b2 = bits - b1;
+    int nb1 = 1 << b1;
+    void *p, *pa, *pb, *pc, *pca, *pcb;
+    int rc;
+    if ((rc = g_ws[0].get((size_t)nb1 * 16 + 64, &p))) return rc;
+    if ((rc = g_ws[1].get((n + 2) * 8, &pa))) return rc;
+    if ((rc = g_ws[2].get((n + 2) * 8, &pb))) return rc;
+    if ((rc = g_ws[3].get((n + 2) * 4, &pc))) return rc;
+    if ((rc = g_ws[5].get((n + 2) * 4, &pca))) return rc;
+    if ((rc = g_ws[6].get((n + 2) * 4, &pcb))) return rc;
+    uint32_t* d_h = (uint32_t*)p;               // [nb1] hist, [nb1] off, [nb1] cursor, then seg[2] (u64) + total
+    uint32_t* d_o = d_h + nb1;
+    uint32_t* d_c = d_o + nb1;
+    uint64_t* d_seg = (uint64_t*)(d_c + nb1 + (nb1 & 1) + 2);
+    unsigned long long* d_tot = (unsigned long long*)(d_seg + 2);
+    uint64_t seg[2] = {0, n};
+    HIP_TRY(hipMemsetAsync(d_h, 0, (size_t)nb1 * 4, s));
+    HIP_TRY(hipMemsetAsync(d_tot, 0, 8, s));
+    HIP_TRY(hipMemcpyAsync(d_seg, seg, 16, hipMemcpyHostToDevice, s));
+    uint32_t tiles = (uint32_t)std::max<uint64_t>(1, cdiv(n, TILE_KEYS));
+    {
+      TimerRegion t(ctx, T_HIST1);
+      hipLaunchKernelGGL(hist_keys_kernel<true>, dim3(tiles, 1), dim3(BLK), nb1 * 4, s, keys, d_seg, bits, b2, d_h);
+      hipLaunchKernelGGL(scan_rows_kernel, dim3(1), dim3(BLK), 0, s, d_h, nb1, d_o, d_c);
+      hipLaunchKernelGGL(sum_counts_kernel, dim3(256), dim3(256), 0, s, cnts, n, d_tot);
+    }
+    std::vector<uint32_t> h(nb1);
+    unsigned long long total = 0;
+    HIP_TRY(hipMemcpyAsync(h.data(), d_h, (size_t)nb1 * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&total, d_tot, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::vector<uint64_t> off1(nb1 + 1);
+    uint64_t a = 0;
+    for (int i = 0; i < nb1; i++) { off1[i] = a; a += h[i]; }
+    off1[nb1] = a;
+    {
+      TimerRegion t(ctx, T_SCATTER1);
+      hipLaunchKernelGGL((scatter_keys_kernel<true, true>), dim3(tiles, 1), dim3(BLK), nb1 * 8, s, keys, cnts, d_seg, bits, b2, d_c,
+                         (uint64_t*)pa, (uint32_t*)pca);
+    }
+    bool ov = false;
+    rc = build_from_keys(ctx, (uint64_t*)pa, (uint64_t*)pb, (uint32_t*)pc, (uint32_t*)pca, (uint32_t*)pcb, off1, bits, b2, k1,
+                         canonical, n, total, out, &ov);
+    if (rc) return rc;
+    if (!ov) return SHN_OK;
+    shn_table_destroy(*out);
+    *out = nullptr;
+    bits = std::min(24, bits + 2);
+  }
+  return shn_fail(SHN_ERR_OVERFLOW, "shn_table_from_pairs: bucket overflow after 4 attempts");
+}
+
+#define SHARD_SALT 0xA24BAED4963EE407ULL
+__device__ __forceinline__ uint32_t owner_of(uint64_t key, int n_ranks) {
+  return (uint32_t)(shn_mix64(key ^ SHARD_SALT) % (uint64_t)n_ranks);
+}
+__global__ void shard_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n, int n_ranks, unsigned long long* __restrict__ hist) {
+  __shared__ uint32_t lh[64];
+  if (threadIdx.x < 64) lh[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    atomicAdd(&lh[owner_of(keys[i], n_ranks)], 1u);
+  __syncthreads();
+  if (threadIdx.x < n_ranks && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
+}
+__global__ void shard_scatter_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, uint64_t n, int n_ranks,
+                                     unsigned long long* __restrict__ cursor, uint64_t* __restrict__ ok, uint32_t* __restrict__ oc) {
+  // wave-aggregated reservation: lanes with the same owner share one atomic
+  for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n; base += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t i = base + threadIdx.x;
+    bool act = i < n;
+    uint64_t key = act ? keys[i] : 0;
+    uint32_t o = act ? owner_of(key, n_ranks) : 0xFFFFFFFFu;
+    for (int r = 0; r < n_ranks; r++) {
+      unsigned long long m = __ballot(act && o == (uint32_t)r);
+      if (!m) continue;
+      int lane = threadIdx.x & 63;
+      int leader = __ffsll((long long)m) - 1;
+      unsigned long long b = 0;
+      if (lane == leader) b = atomicAdd(&cursor[r], (unsigned long long)__popcll(m));
+      b = __shfl(b, leader, 64);
+      if (act && o == (uint32_t)r) {
+        uint64_t d = b + __popcll(m & ((1ULL << lane) - 1));
+        ok[d] = key; oc[d] = counts[i];
+      }
+    }
+  }
+}
+
+extern "C" int shn_table_shard(shn_ctx* ctx, const shn_table* t, int n_ranks, uint64_t* per_rank, void* dev_keys_out,
+                               void* dev_counts_out) {
+  if (!ctx || !t || !per_rank || n_ranks < 1 || n_ranks > 64) return shn_fail(SHN_ERR_ARG, "shn_table_shard: bad argument");
+  if (t->n && (!dev_keys_out || !dev_counts_out)) return shn_fail(SHN_ERR_ARG, "shn_table_shard: NULL output");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  void* p;
+  int rc;
+  if ((rc = g_ws[0].get(64 * 16 + 64, &p))) return rc;
+  unsigned long long* d_hist = (unsigned long long*)p;
+  unsigned long long* d_cur = d_hist + 64;
+  HIP_TRY(hipMemsetAsync(d_hist, 0, 64 * 8, s));
+  uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, cdiv(t->n, 256)), 2048);
+  hipLaunchKernelGGL(shard_hist_kernel, dim3(grid), dim3(256), 0, s, t->d_keys, t->n, n_ranks, d_hist);
+  unsigned long long h[64], c[64];
+  HIP_TRY(hipMemcpyAsync(h, d_hist, 64 * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  unsigned long long a = 0;
+  for (int i = 0; i < 64; i++) { c[i] = a; if (i < n_ranks) { per_rank[i] = h[i]; a += h[i]; } }
+  HIP_TRY(hipMemcpyAsync(d_cur, c, 64 * 8, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(shard_scatter_kernel, dim3(grid), dim3(256), 0, s, t->d_keys, t->d_counts, t->n, n_ranks, d_cur,
+                     (uint64_t*)dev_keys_out, (uint32_t*)dev_counts_out);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s));
+  return SHN_OK;
+}

@@ -1,0 +1,187 @@
+"""Host-side handles over the C ABI: Context, Reads (2-bit packed, device resident), Table."""
+import ctypes as C
+import numpy as np
+from . import _lib
+
+ENC_ASCII, ENC_CODES = 0, 1
+ALPHA = "ACGT"
+
+
+class Context(object):
+    def __init__(self, device=0, stream=None):
+        self.h = C.c_void_p()
+        _lib.check(_lib.lib().shn_ctx_create(int(device), C.c_void_p(stream or 0), C.byref(self.h)))
+        self.device = device
+
+    def sync(self):
+        _lib.check(_lib.lib().shn_ctx_sync(self.h))
+
+    def timer_reset(self):
+        _lib.check(_lib.lib().shn_timer_reset(self.h))
+
+    def timers(self):
+        """{name: (ms, n_regions)} of HIP-event timed kernel groups since the last reset."""
+        out = {}
+        for slot in range(32):
+            name = _lib.lib().shn_timer_name(slot).decode()
+            if not name:
+                continue
+            ms, n = C.c_double(), C.c_uint64()
+            _lib.check(_lib.lib().shn_timer_ms(self.h, slot, C.byref(ms), C.byref(n)))
+            if n.value:
+                out[name] = (ms.value, n.value)
+        return out
+
+    def close(self):
+        if self.h:
+            _lib.lib().shn_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Reads(object):
+    """A set of reads packed 2 bits/base in HBM (+1 bit/base non-ACGT mask)."""
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    @classmethod
+    def from_strings(cls, ctx, reads):
+        joined = "".join(reads).encode()
+        offs = np.zeros(len(reads) + 1, dtype=np.uint64)
+        if reads:
+            offs[1:] = np.cumsum([len(r) for r in reads], dtype=np.uint64)
+        buf = np.frombuffer(joined, dtype=np.uint8) if joined else np.zeros(1, np.uint8)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().shn_reads_create(ctx.h, buf.ctypes.data, offs.ctypes.data, len(reads), 0, ENC_ASCII, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_codes(cls, ctx, codes):
+        """codes: uint8 [n_reads, L] with values 0..3 (anything else = non-ACGT)."""
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        n, L = codes.shape
+        h = C.c_void_p()
+        _lib.check(_lib.lib().shn_reads_create(ctx.h, codes.ctypes.data, None, n, L, ENC_CODES, C.byref(h)))
+        return cls(ctx, h)
+
+    def __len__(self):
+        return int(_lib.lib().shn_reads_count(self.h))
+
+    @property
+    def n_invalid(self):
+        return int(_lib.lib().shn_reads_n_invalid(self.h))
+
+    @property
+    def max_len(self):
+        return int(_lib.lib().shn_reads_max_len(self.h))
+
+    def close(self):
+        if self.h:
+            _lib.lib().shn_reads_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Table(object):
+    """(key,count) table of distinct k1-mers on the device."""
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def __len__(self):
+        return int(_lib.lib().shn_table_size(self.h))
+
+    @property
+    def total(self):
+        return int(_lib.lib().shn_table_total(self.h))
+
+    @property
+    def k(self):
+        return int(_lib.lib().shn_table_k(self.h))
+
+    @property
+    def canonical(self):
+        return bool(_lib.lib().shn_table_canonical(self.h))
+
+    def download(self):
+        n = len(self)
+        keys = np.empty(n, dtype=np.uint64)
+        cnts = np.empty(n, dtype=np.uint32)
+        _lib.check(_lib.lib().shn_table_download(self.ctx.h, self.h, keys.ctypes.data, cnts.ctypes.data))
+        return keys, cnts
+
+    def dump(self, lower=1):
+        """Content of the reference's k1mer.dict_org (`jellyfish dump -c -t -L lower`,
+        shannon.py:441) as sorted (keys, counts) arrays: both strands expanded."""
+        n = C.c_uint64(0)
+        _lib.check(_lib.lib().shn_table_dump(self.ctx.h, self.h, lower, None, None, C.byref(n)))
+        keys = np.empty(n.value, dtype=np.uint64)
+        cnts = np.empty(n.value, dtype=np.uint32)
+        _lib.check(_lib.lib().shn_table_dump(self.ctx.h, self.h, lower, keys.ctypes.data, cnts.ctypes.data, C.byref(n)))
+        return keys[:n.value], cnts[:n.value]
+
+    def lookup(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        out = np.zeros(len(keys), dtype=np.uint32)
+        _lib.check(_lib.lib().shn_table_lookup(self.ctx.h, self.h, keys.ctypes.data, len(keys), out.ctypes.data))
+        return out
+
+    def device_ptrs(self):
+        k, c = C.c_void_p(), C.c_void_p()
+        _lib.check(_lib.lib().shn_table_device_ptrs(self.h, C.byref(k), C.byref(c)))
+        return k.value, c.value
+
+    def shard(self, n_ranks, dev_keys_ptr, dev_counts_ptr):
+        per = np.zeros(n_ranks, dtype=np.uint64)
+        _lib.check(_lib.lib().shn_table_shard(self.ctx.h, self.h, n_ranks, per.ctypes.data_as(_lib.u64p),
+                                              C.c_void_p(dev_keys_ptr), C.c_void_p(dev_counts_ptr)))
+        return per
+
+    @classmethod
+    def from_pairs(cls, ctx, dev_keys_ptr, dev_counts_ptr, n, k1, canonical):
+        h = C.c_void_p()
+        _lib.check(_lib.lib().shn_table_from_pairs(ctx.h, C.c_void_p(dev_keys_ptr), C.c_void_p(dev_counts_ptr), n, k1,
+                                                   1 if canonical else 0, C.byref(h)))
+        return cls(ctx, h)
+
+    def close(self):
+        if self.h:
+            _lib.lib().shn_table_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def count_k1mers(ctx, read_sets, k1, both_strands=True):
+    """Replaces `jellyfish count -m k1` (shannon.py:439).  read_sets: list of Reads."""
+    arr = (C.c_void_p * len(read_sets))(*[r.h for r in read_sets])
+    h = C.c_void_p()
+    _lib.check(_lib.lib().shn_count_k1mers(ctx.h, arr, len(read_sets), k1, 1 if both_strands else 0, C.byref(h)))
+    return Table(ctx, h)
+
+
+def key_to_str(key, k):
+    key = int(key)
+    return "".join(ALPHA[(key >> (2 * (k - 1 - i))) & 3] for i in range(k))
+
+
+def str_to_key(s):
+    v = 0
+    for c in s:
+        v = (v << 2) | ALPHA.index(c)
+    return v
