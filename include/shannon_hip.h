@@ -104,6 +104,28 @@ int shn_table_from_pairs(shn_ctx* ctx, const void* dev_keys, const void* dev_cou
 int shn_table_shard(shn_ctx* ctx, const shn_table* t, int n_ranks, uint64_t* per_rank, void* dev_keys_out,
                     void* dev_counts_out);
 
+/* ---- contig extension / k1-mer error correction ----------------------------------------------
+ * Replaces the hot loop of extension_correction.run_correction (extension_correction.py:334-354:
+ * load_kmers + lowComplexity filter :142-149,202-221; heaviest-first greedy extend :223-245 with
+ * ties A,G,C,T :10,159-166 and a global `traversed` set).  Seeds are all k1-mers of the
+ * strand-doubled input with weight >= min_weight, in (weight desc, k1-mer asc) order; walk r is
+ * the contig seeded by the r-th seed, or void if an earlier walk traversed its seed.  The
+ * accept filter / duplicate_check / contig graph (:358-513) run on the host over the emitted
+ * contigs (shannon_amd/extension_correction.py).                                              */
+typedef struct shn_ext shn_ext;
+int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight, int max_iterations, shn_ext** out);
+void shn_ext_destroy(shn_ext* e);
+uint64_t shn_ext_n_walks(const shn_ext* e);
+int shn_ext_iterations(const shn_ext* e);
+/* per walk (host arrays of shn_ext_n_walks entries): right/left extension lengths (n_right ==
+ * 0xFFFFFFFF marks a void walk) and the weight sum including the seed (tot_wt, :351)          */
+int shn_ext_stats(shn_ctx* ctx, const shn_ext* e, uint32_t* n_right, uint32_t* n_left, uint64_t* tot_weight);
+/* contig strings (ASCII) of the selected walk ranks, contig i at bases_out[offsets[i]..offsets[i+1]) */
+int shn_ext_emit(shn_ctx* ctx, const shn_ext* e, const uint32_t* ranks, uint64_t n_sel, const uint64_t* offsets,
+                 uint8_t* bases_out);
+/* weight (count in the strand-doubled input, 0 if absent or low-complexity) of k1-mer strings */
+int shn_ext_weights(shn_ctx* ctx, const shn_ext* e, const uint64_t* keys, uint64_t n, uint32_t* weights);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,4 +107,33 @@ __device__ __forceinline__ uint64_t shn_extract_mask(const uint64_t* __restrict_
   return v >> (64 - k);
 }
 
+__device__ __forceinline__ uint32_t shn_bucket_of(uint64_t key, int bits) {
+  return bits ? (uint32_t)(shn_mix64(key) >> (64 - bits)) : 0u;
+}
+
+// index of `key` in a table (grouped by bucket, ascending inside a bucket) or -1
+__device__ __forceinline__ int64_t shn_table_find(const uint64_t* __restrict__ tkeys, const uint64_t* __restrict__ boff,
+                                                  int bits, uint64_t key) {
+  uint32_t b = shn_bucket_of(key, bits);
+  uint64_t lo = boff[b], hi = boff[b + 1];
+  while (lo < hi) {
+    uint64_t mid = (lo + hi) >> 1;
+    uint64_t v = tkeys[mid];
+    if (v == key) return (int64_t)mid;
+    if (v < key) lo = mid + 1; else hi = mid;
+  }
+  return -1;
+}
+
+// grow-only device workspace slots shared by the translation units (one process per GPU)
+struct ShnWs {
+  void* p = nullptr; size_t cap = 0;
+  int get(size_t bytes, void** out);
+};
+extern ShnWs g_shn_ws[32];
+int shn_device_scan_u32(shn_ctx* ctx, const uint32_t* d_in, uint64_t n, uint64_t* d_out /* n+1 */, uint64_t* total_host);
+// stable LSD radix sort of (u64 key, u32 value) pairs on bits [bit_lo, bit_hi); result lands in keys/vals
+int shn_sort_pairs(shn_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t* keys_tmp, uint32_t* vals_tmp, uint64_t n,
+                   int bit_lo, int bit_hi);
+
 static inline uint64_t cdiv(uint64_t a, uint64_t b) { return (a + b - 1) / b; }

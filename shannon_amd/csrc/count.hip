@@ -26,9 +26,7 @@ struct ReadsView {
   uint64_t n_reads; uint32_t fixed_len, wpr, wmax, rt; int has_n;
 };
 
-__device__ __forceinline__ uint32_t bucket_of(uint64_t key, int bits) {
-  return bits ? (uint32_t)(shn_mix64(key) >> (64 - bits)) : 0u;
-}
+#define bucket_of shn_bucket_of
 
 template <bool CANON>
 __device__ __forceinline__ bool gen_key(const ReadsView& v, uint64_t r, uint32_t pos, int k, uint64_t& key) {
@@ -318,23 +316,21 @@ __global__ void lookup_kernel(const uint64_t* __restrict__ tkeys, const uint32_t
 }
 
 // ================================================================ host side
-struct Ws {   // grow-only device workspace
-  void* p = nullptr; size_t cap = 0;
-  int get(size_t bytes, void** out) {
-    if (bytes > cap) {
-      if (p) hipFree(p);
-      p = nullptr; cap = 0;
-      hipError_t e = hipMalloc(&p, bytes);
-      if (e != hipSuccess) return shn_fail(SHN_ERR_NOMEM, std::string("hipMalloc workspace: ") + hipGetErrorString(e));
-      cap = bytes;
-    }
-    *out = p;
-    return SHN_OK;
+int ShnWs::get(size_t bytes, void** out) {
+  if (bytes > cap) {
+    if (p) hipFree(p);
+    p = nullptr; cap = 0;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return shn_fail(SHN_ERR_NOMEM, std::string("hipMalloc workspace: ") + hipGetErrorString(e));
+    cap = bytes;
   }
-};
-static Ws g_ws[8];   // per-process (one ctx per process in practice: one process per GPU)
+  *out = p;
+  return SHN_OK;
+}
+ShnWs g_shn_ws[32];   // per-process (one process per GPU)
+#define g_ws g_shn_ws
 
-static int device_scan(shn_ctx* ctx, const uint32_t* d_in, uint64_t n, uint64_t* d_out /* n+1 */, uint64_t* total_host) {
+int shn_device_scan_u32(shn_ctx* ctx, const uint32_t* d_in, uint64_t n, uint64_t* d_out /* n+1 */, uint64_t* total_host) {
   hipStream_t s = ctx->stream;
   uint64_t nblocks = cdiv(n, 1024);
   if (nblocks == 0) nblocks = 1;
@@ -483,7 +479,7 @@ static int build_from_keys(shn_ctx* ctx, uint64_t* keysA, uint64_t* keysB, uint3
   t->ctx = ctx; t->k = k; t->canonical = canonical; t->bits = bits; t->n_buckets = nbk; t->total = total;
   {
     TimerRegion tr(ctx, T_COMPACT);
-    if ((rc = device_scan(ctx, d_ndist, nbk, d_boff, &D))) { delete t; return rc; }
+    if ((rc = shn_device_scan_u32(ctx, d_ndist, nbk, d_boff, &D))) { delete t; return rc; }
     uint32_t ovf = 0;
     HIP_TRY(hipMemcpyAsync(&ovf, d_ovf, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));

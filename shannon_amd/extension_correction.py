@@ -1,0 +1,221 @@
+"""Contig extension / error correction / contig-graph components -- host mirror of the
+reference's extension_correction.py (rows a3-a7) over the HIP walk kernel.
+
+Device (csrc/extend.hip): load_kmers + lowComplexity filter, seed ordering, the greedy
+bidirectional walks (the reference's dominant Python stage, extension_correction.py:334-354).
+Host (here): accept filter (:361), duplicate_check (:247-270), allowed set, contig graph by
+shared K-mers (:366-397), DFS components and the METIS / contig / remaining-bin files
+(:417-513) -- contig-level bookkeeping in the reference's own order.
+"""
+import ctypes as C
+import math
+import os
+import numpy as np
+from . import _lib, device
+
+UNCLAIMED = 0xFFFFFFFF
+
+
+class ExtensionResult(object):
+    """Same fields as the reference's in-memory/file products (see run_correction)."""
+    pass
+
+
+class Extension(object):
+    """Handle over shn_ext (device-resident walk state)."""
+
+    def __init__(self, ctx, table, min_weight=3, max_iterations=0):
+        self.ctx, self.table = ctx, table
+        self.h = C.c_void_p()
+        _lib.check(_lib.lib().shn_extend(ctx.h, table.h, int(min_weight), int(max_iterations), C.byref(self.h)))
+
+    @property
+    def n_walks(self):
+        return int(_lib.lib().shn_ext_n_walks(self.h))
+
+    @property
+    def iterations(self):
+        return int(_lib.lib().shn_ext_iterations(self.h))
+
+    def stats(self):
+        n = self.n_walks
+        nr = np.empty(n, np.uint32)
+        nl = np.empty(n, np.uint32)
+        tw = np.empty(n, np.uint64)
+        _lib.check(_lib.lib().shn_ext_stats(self.ctx.h, self.h, nr.ctypes.data, nl.ctypes.data, tw.ctypes.data))
+        return nr, nl, tw
+
+    def emit(self, ranks, lengths):
+        ranks = np.ascontiguousarray(ranks, dtype=np.uint32)
+        offs = np.zeros(len(ranks) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum(lengths, dtype=np.uint64)
+        buf = np.empty(int(offs[-1]) + 1, dtype=np.uint8)
+        _lib.check(_lib.lib().shn_ext_emit(self.ctx.h, self.h, ranks.ctypes.data, len(ranks), offs.ctypes.data, buf.ctypes.data))
+        s = buf[:int(offs[-1])].tobytes().decode()
+        return [s[int(offs[i]):int(offs[i + 1])] for i in range(len(ranks))]
+
+    def weights(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        out = np.zeros(len(keys), dtype=np.uint32)
+        _lib.check(_lib.lib().shn_ext_weights(self.ctx.h, self.h, keys.ctypes.data, len(keys), out.ctypes.data))
+        return out
+
+    def close(self):
+        if self.h:
+            _lib.lib().shn_ext_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_CODE = np.full(256, 255, dtype=np.uint8)
+for _i, _c in enumerate(b"ACGT"):
+    _CODE[_c] = _i
+
+
+def windows_to_keys(contig, k):
+    """All k-windows of an ACGT string as packed uint64 keys (vectorised)."""
+    c = _CODE[np.frombuffer(contig.encode(), dtype=np.uint8)].astype(np.uint64)
+    n = len(c) - k + 1
+    key = np.zeros(max(n, 0), dtype=np.uint64)
+    for j in range(k):
+        key = (key << np.uint64(2)) | c[j:j + n]
+    return key
+
+
+def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=500, r=15, f=0.5):
+    """extension_correction.run_correction (extension_correction.py:309-524) on a device k1-mer
+    table.  Returns an ExtensionResult: contigs, allowed {k1mer: int}, connections, components,
+    single_contigs, big_components [(contigs, metis_text)], remaining [[contig...]]."""
+    k1 = table.k
+    ext = Extension(ctx, table, min_weight)
+    nr, nl, tw = ext.stats()
+    live = np.nonzero(nr != UNCLAIMED)[0]                      # non-void walks, in seed order
+    length = k1 + nr[live].astype(np.int64) + nl[live].astype(np.int64)
+    cand = live[length >= min_length]                          # first clause of the accept filter (:361)
+    clen = length[length >= min_length]
+    thr = 2 * min_length * math.pow(min_weight, 1 / 4.0)
+    keep = []
+    for rnk, L in zip(cand.tolist(), clen.tolist()):
+        tot_kmer = int(nr[rnk]) + int(nl[rnk]) + 1
+        avg_wt = float(int(tw[rnk])) / max(1, tot_kmer)
+        if L * math.pow(avg_wt, 1 / 4.0) >= thr:
+            keep.append((rnk, L))
+    strings = ext.emit([x[0] for x in keep], [x[1] for x in keep]) if keep else []
+
+    # duplicate_check + contig graph, sequential over candidates in seed order (:358-397)
+    rmer_to_contig, cmer_to_contig, conn = {}, {}, {}
+    contigs = ["buffer"]
+    idx = 0
+    C_ = k1 - 1
+    for contig in strings:
+        L = len(contig)
+        dup_count, best, best_idx = {}, 0, -1
+        hits = []
+        for i in range(L - r + 1):
+            lst = rmer_to_contig.get(contig[i:i + r])
+            hits.append(lst)
+            if lst is not None:
+                for d in lst:
+                    c = dup_count.get(d, 0) + 1
+                    dup_count[d] = c
+                    if c >= best:
+                        best, best_idx = c, d
+        covered = np.zeros(L + 1, dtype=np.int32)
+        for i, lst in enumerate(hits):
+            if lst is not None and best_idx in lst:
+                covered[i] += 1
+                covered[i + r] -= 1
+        if int((np.cumsum(covered[:L]) > 0).sum()) > f * float(L):
+            continue
+        idx += 1
+        contigs.append(contig)
+        conn.setdefault(idx, {})
+        for i in range(L - C_ + 1):
+            cm = contig[i:i + C_]
+            lst = cmer_to_contig.get(cm)
+            if lst is not None:
+                for c2 in lst:
+                    if c2 != idx:
+                        conn[idx][c2] = conn[idx].get(c2, 0) + 1
+                        conn[c2][idx] = conn[c2].get(idx, 0) + 1
+            else:
+                lst = cmer_to_contig[cm] = []
+            lst.append(idx)
+        for i in range(L - r + 1):
+            rmer_to_contig.setdefault(contig[i:i + r], []).append(idx)
+
+    res = ExtensionResult()
+    res.k1 = k1
+    res.iterations = ext.iterations
+    res.n_walks = ext.n_walks
+    res.contigs = contigs[1:]
+    # allowed k1-mers with their integer weights (:366-369, :404-408): GPU table lookup
+    allowed = {}
+    if res.contigs:
+        keys = np.concatenate([windows_to_keys(c, k1) for c in res.contigs])
+        uk = np.unique(keys)
+        w = ext.weights(uk)
+        for key, wt in zip(uk.tolist(), w.tolist()):
+            allowed[device.key_to_str(key, k1)] = int(wt)
+    res.allowed = allowed
+    res.connections = conn
+    ext.close()
+
+    # DFS components (:417-434) and file products (:458-513)
+    comp_of, comps, seen = {}, {}, set()
+    for ci in conn:
+        if ci not in comp_of:
+            comps[ci] = []
+            stack = [ci]
+            seen.add(ci)
+            while stack:
+                cur = stack.pop()
+                comp_of[cur] = ci
+                comps[ci].append(cur)
+                for nb in conn[cur]:
+                    if nb not in seen:
+                        stack.append(nb)
+                        seen.add(nb)
+    res.components = comps
+    drawn = {c: set() for c in comps}
+    for a in conn:
+        for b in conn[a]:
+            drawn[comp_of[a]].add((min(a, b), max(a, b)))
+    res.single_contigs, res.big_components, res.remaining = [], [], [[]]
+    cur_size = 0
+    for comp, members in comps.items():
+        if len(members) == 1:
+            res.single_contigs.append(contigs[members[0]])
+        elif len(members) > comp_size_threshold:
+            code = {c: i + 1 for i, c in enumerate(members)}
+            lines = ["%d\t%d\t001\n" % (len(members), len(drawn[comp]))]
+            for c in members:
+                lines.append("".join("%d\t%d\t" % (code[c2], wt) for c2, wt in conn[c].items()) + "\n")
+            res.big_components.append(([contigs[c] for c in members], "".join(lines)))
+        else:
+            res.remaining[-1].extend(contigs[c] for c in members)
+            cur_size += len(members)
+            if cur_size > comp_size_threshold:
+                res.remaining.append([])
+                cur_size = 0
+    return res
+
+
+def write_outputs(res, directory, outfile=None):
+    """File tree of extension_correction.py:337,362,458-513."""
+    if outfile:
+        with open(outfile + "_contig", "w") as f:
+            f.write("".join(c + "\n" for c in res.contigs))
+    with open(os.path.join(directory, "reconstructed_single_contigs.fasta"), "w") as f:
+        for i, c in enumerate(res.single_contigs):
+            f.write(">Single_%d\n%s\n" % (i, c))
+    for n, (cl, metis) in enumerate(res.big_components):
+        open(os.path.join(directory, "component%d.txt" % (n + 1)), "w").write(metis)
+        open(os.path.join(directory, "component%dcontigs.txt" % (n + 1)), "w").write("".join(c + "\n" for c in cl))
+    for n, cl in enumerate(res.remaining):
+        open(os.path.join(directory, "remaining_contigs%d.txt" % (n + 1)), "w").write("".join(c + "\n" for c in cl))

@@ -1,0 +1,65 @@
+"""GPU parity: contig extension (rows a3-a7) -- HIP walk fixpoint + host bookkeeping vs the
+oracle and the reference's golden vectors."""
+import numpy as np
+import pytest
+from golden_util import *
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from shannon_amd import device
+    c = device.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("name", sorted(MANIFEST))
+def test_extension_matches_golden(ctx, name):
+    from shannon_amd import device, extension_correction as ec
+    g = load_case(name)
+    psize = MANIFEST[name].get("partition_size", 500)
+    sets = [device.Reads.from_strings(ctx, r) for r in load_inputs(name)]
+    t = device.count_k1mers(ctx, sets, g["K"] + 1)
+    res = ec.run_correction(ctx, t, 3, 75, psize)
+    assert res.contigs == g["contigs"]                      # ordered list, bit-exact
+    assert len(res.allowed) == g["n_allowed"]
+    assert digest(sorted([k, v] for k, v in res.allowed.items())) == g["allowed_digest"]
+    assert "".join(">Single_%d\n%s\n" % (i, c) for i, c in enumerate(res.single_contigs)) == g["single_contigs_fasta"]
+    assert res.remaining == g["remaining"]
+    assert [b[0] for b in res.big_components] == [b["contigs"] for b in g["big_components"]]
+    assert [b[1] for b in res.big_components] == [b["metis"] for b in g["big_components"]]
+    assert 1 <= res.iterations < 200
+
+
+def test_all_walks_match_oracle_sequential(ctx):
+    """Every walk (accepted or not) equals the sequential greedy of the oracle, on a noisy set."""
+    from shannon_amd import device, synth, extension_correction as ec
+    from oracle import count, extension
+    (r1, r2), _ = synth.make_dataset(4000, 2, seed=11)
+    codes = np.concatenate([r1, r2])
+    t = device.count_k1mers(ctx, [device.Reads.from_codes(ctx, codes)], 26)
+    ext = ec.Extension(ctx, t, 3)
+    nr, nl, tw = ext.stats()
+    live = np.nonzero(nr != ec.UNCLAIMED)[0]
+    lens = 26 + nr[live].astype(np.int64) + nl[live].astype(np.int64)
+    mine = ext.emit(live, lens)
+    keys, cnts = t.dump()
+    tab = {device.key_to_str(k, 26): int(c) for k, c in zip(keys, cnts)}
+    kmers, k1 = extension.load_kmers([(k, tab[k]) for k in sorted(tab, reverse=True)])
+    heaviest = sorted(kmers.items(), key=lambda kv: kv[1])
+    traversed, ref, refw = set(), [], []
+    while heaviest:
+        s, w = heaviest.pop()
+        if w < 3:
+            break
+        if s in traversed:
+            continue
+        traversed.add(s)
+        r, rw, _ = extension._extend(s, True, traversed, kmers, k1)
+        l, lw, _ = extension._extend(s, False, traversed, kmers, k1)
+        ref.append("".join(reversed(l)) + s + "".join(r))
+        refw.append(int(rw + lw + kmers[s]))
+    assert mine == ref
+    assert tw[live].tolist() == refw
