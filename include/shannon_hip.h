@@ -126,6 +126,23 @@ int shn_ext_emit(shn_ctx* ctx, const shn_ext* e, const uint32_t* ranks, uint64_t
 /* weight (count in the strand-doubled input, 0 if absent or low-complexity) of k1-mer strings */
 int shn_ext_weights(shn_ctx* ctx, const shn_ext* e, const uint64_t* keys, uint64_t n, uint32_t* weights);
 
+/* ---- read -> partition routing -----------------------------------------------------------------
+ * Replaces the read-streaming loops of kmers_for_component (kmers_for_component.py:322-403;
+ * get_rmers :186-192, get_comps :194-205).  `probe` maps every k1-mer of every partition's
+ * contigs (plain strings, k1mers2component :244-305) to value = set_id+1; set s holds partition
+ * ids set_members[set_off[s]..set_off[s+1]).  Doubled read index d: SE d<N -> R[d], d>=N ->
+ * RC(R[d-N]); PE d<N -> (R1[d], RC(R1[d])), d>=N -> (RC(R2[d-N]), R2[d-N]) (shannon.py:396-424 as
+ * written).  Result: (partition id, d) pairs sorted by partition then d == the order of the
+ * reference's reads{comp}.fasta files; reads with a non-ACGT base are dropped (:336,:376).   */
+typedef struct shn_routes shn_routes;
+int shn_table_create(shn_ctx* ctx, const uint64_t* keys, const uint32_t* values, uint64_t n, int k, int canonical,
+                     shn_table** out);
+int shn_route_reads(shn_ctx* ctx, const shn_reads* r1, const shn_reads* r2, int k1, const shn_table* probe,
+                    const uint32_t* set_off, const uint32_t* set_members, uint32_t n_sets, shn_routes** out);
+void shn_routes_destroy(shn_routes* r);
+uint64_t shn_routes_size(const shn_routes* r);
+int shn_routes_download(shn_ctx* ctx, const shn_routes* r, uint32_t* pid, uint32_t* ridx);
+
 #ifdef __cplusplus
 }
 #endif

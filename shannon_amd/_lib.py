@@ -37,6 +37,11 @@ SIGNATURES = {
     "shn_table_lookup": (C.c_int, [vp, vp, vp, C.c_uint64, vp]),
     "shn_table_from_pairs": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vpp]),
     "shn_table_shard": (C.c_int, [vp, vp, C.c_int, u64p, vp, vp]),
+    "shn_table_create": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vpp]),
+    "shn_route_reads": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, C.c_uint32, vpp]),
+    "shn_routes_destroy": (None, [vp]),
+    "shn_routes_size": (C.c_uint64, [vp]),
+    "shn_routes_download": (C.c_int, [vp, vp, vp, vp]),
     "shn_extend": (C.c_int, [vp, vp, C.c_uint32, C.c_int, vpp]),
     "shn_ext_destroy": (None, [vp]),
     "shn_ext_n_walks": (C.c_uint64, [vp]),

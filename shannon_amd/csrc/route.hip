@@ -1,0 +1,206 @@
+// Read -> partition routing on gfx950 (row a10): replaces the per-read Python loops of
+// kmers_for_component.py:322-403 (get_rmers :186-192, get_comps :194-205).
+//
+// The reference streams the strand-doubled read files; here the doubled index d enumerates
+//   SE:  d <  N : R[d]                       d >= N : RC(R[d-N])                (shannon.py:396-403)
+//   PE:  d <  N : (R1[d], RC(R1[d]))         d >= N : (RC(R2[d-N]), R2[d-N])    (shannon.py:413-424,
+//        reads_1 = R1 ++ RC(R2), reads_2 = RC(R1) ++ R2 -- reproduced as written)
+// and reverse complements are computed on chip from the packed forward reads.  A read (pair) with
+// any non-ACGT base is dropped (:336, :376).  Probes: k1-windows at 0,k1,2k1,... while i < len-k1,
+// plus the last window; the read goes to the union of the partition sets of the probes that hit.
+#include "common.h"
+#include <cstring>
+#include <algorithm>
+
+#define RBLK 256
+#define MAXP 32   // distinct partitions one read (pair) can hit: 2 mates x probes x set size, deduplicated
+
+struct RView {
+  const uint64_t* words; const uint64_t* woff; const uint32_t* len; const uint8_t* bad;
+  uint64_t n; uint32_t fixed_len, wpr;
+};
+
+__device__ __forceinline__ uint64_t probe_key(const RView& v, uint64_t r, uint32_t len, uint32_t pos, int k, bool rc) {
+  // k-window at offset pos of the read (rc=false) or of its reverse complement (rc=true)
+  uint64_t wb = v.woff ? v.woff[r] : r * v.wpr;
+  if (!rc) return shn_extract(v.words + wb, pos, k);
+  return shn_revcomp(shn_extract(v.words + wb, len - k - pos, k), k);
+}
+
+// collects the partitions hit by one read into loc[] (dedup), returns new count
+__device__ __forceinline__ int collect(const RView& v, uint64_t r, bool rc, int k, const uint64_t* __restrict__ tkeys,
+                                       const uint32_t* __restrict__ tvals, const uint64_t* __restrict__ boff, int bits,
+                                       const uint32_t* __restrict__ set_off, const uint32_t* __restrict__ set_mem,
+                                       uint32_t* loc, int nloc, uint32_t* overflow) {
+  uint32_t len = v.len ? v.len[r] : v.fixed_len;
+  if (len < (uint32_t)k) {
+    // get_rmers on a short read returns [read[-R:]] = the whole read, which is not a k1-mer key: no hit
+    return nloc;
+  }
+  uint32_t i = 0;
+  bool last_done = false;
+  while (true) {
+    uint32_t pos;
+    if (i < len - k) { pos = i; i += k; }
+    else if (!last_done) { pos = len - k; last_done = true; }
+    else break;
+    uint64_t key = probe_key(v, r, len, pos, k, rc);
+    int64_t j = shn_table_find(tkeys, boff, bits, key);
+    if (j >= 0) {
+      uint32_t sid = tvals[j] - 1;
+      for (uint32_t m = set_off[sid]; m < set_off[sid + 1]; m++) {
+        uint32_t p = set_mem[m];
+        bool seen = false;
+        for (int q = 0; q < nloc; q++) seen |= (loc[q] == p);
+        if (!seen) { if (nloc < MAXP) loc[nloc++] = p; else atomicExch(overflow, 1u); }
+      }
+    }
+  }
+  return nloc;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(RBLK) void route_kernel(RView a, RView b, int paired, int k, const uint64_t* __restrict__ tkeys,
+                                                     const uint32_t* __restrict__ tvals, const uint64_t* __restrict__ boff, int bits,
+                                                     const uint32_t* __restrict__ set_off, const uint32_t* __restrict__ set_mem,
+                                                     uint32_t* __restrict__ counts, const uint64_t* __restrict__ offs,
+                                                     uint64_t* __restrict__ out, uint32_t* __restrict__ overflow) {
+  uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t N = a.n;
+  if (d >= 2 * N) return;
+  uint32_t loc[MAXP];
+  int nloc = 0;
+  bool second = d >= N;
+  uint64_t i = second ? d - N : d;
+  bool dropped;
+  if (!paired) {
+    dropped = a.bad && a.bad[i];
+    if (!dropped) nloc = collect(a, i, second, k, tkeys, tvals, boff, bits, set_off, set_mem, loc, nloc, overflow);
+  } else {
+    const RView& src = second ? b : a;        // d<N: (R1, RC(R1)); d>=N: (RC(R2), R2)
+    dropped = src.bad && src.bad[i];
+    if (!dropped) {
+      nloc = collect(src, i, second, k, tkeys, tvals, boff, bits, set_off, set_mem, loc, nloc, overflow);   // mate 1
+      nloc = collect(src, i, !second, k, tkeys, tvals, boff, bits, set_off, set_mem, loc, nloc, overflow);  // mate 2
+    }
+  }
+  if (!FILL) { counts[d] = (uint32_t)nloc; return; }
+  uint64_t o = offs[d];
+  for (int q = 0; q < nloc; q++) out[o + q] = ((uint64_t)loc[q] << 32) | (uint64_t)(uint32_t)d;
+}
+
+__global__ void split_u64_kernel(const uint64_t* __restrict__ in, uint64_t n, uint32_t* __restrict__ hi, uint32_t* __restrict__ lo) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  hi[i] = (uint32_t)(in[i] >> 32);
+  lo[i] = (uint32_t)in[i];
+}
+
+static RView rview(const shn_reads* r) {
+  RView v;
+  v.words = r->d_words; v.woff = r->d_woff; v.len = r->d_len; v.bad = r->n_invalid ? r->d_bad : nullptr;
+  v.n = r->n_reads; v.fixed_len = r->fixed_len; v.wpr = r->wpr;
+  return v;
+}
+
+struct shn_routes {
+  shn_ctx* ctx;
+  uint64_t n;          // number of (partition, doubled read index) pairs
+  uint32_t* d_pid;     // sorted by (pid, read index)
+  uint32_t* d_ridx;
+};
+
+extern "C" void shn_routes_destroy(shn_routes* r) {
+  if (!r) return;
+  hipSetDevice(r->ctx->device);
+  if (r->d_pid) hipFree(r->d_pid);
+  if (r->d_ridx) hipFree(r->d_ridx);
+  delete r;
+}
+extern "C" uint64_t shn_routes_size(const shn_routes* r) { return r ? r->n : 0; }
+
+extern "C" int shn_routes_download(shn_ctx* ctx, const shn_routes* r, uint32_t* pid, uint32_t* ridx) {
+  if (!ctx || !r) return shn_fail(SHN_ERR_ARG, "shn_routes_download: NULL argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (pid) HIP_TRY(hipMemcpyAsync(pid, r->d_pid, r->n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (ridx) HIP_TRY(hipMemcpyAsync(ridx, r->d_ridx, r->n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return SHN_OK;
+}
+
+extern "C" int shn_route_reads(shn_ctx* ctx, const shn_reads* r1, const shn_reads* r2, int k1, const shn_table* probe,
+                               const uint32_t* set_off, const uint32_t* set_members, uint32_t n_sets, shn_routes** out) {
+  if (!ctx || !r1 || !probe || !set_off || !out) return shn_fail(SHN_ERR_ARG, "shn_route_reads: NULL argument");
+  if (r2 && r2->n_reads != r1->n_reads) return shn_fail(SHN_ERR_ARG, "shn_route_reads: mate files differ in length");
+  if (probe->canonical) return shn_fail(SHN_ERR_ARG, "shn_route_reads: probe table must hold plain (non-canonical) k1-mers");
+  if (2 * r1->n_reads >= 0xFFFFFFFFULL) return shn_fail(SHN_ERR_ARG, "shn_route_reads: too many reads for 32-bit doubled indices");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  TimerRegion treg(ctx, T_ROUTE);
+  uint64_t N2 = 2 * r1->n_reads;
+  uint32_t n_mem = set_off[n_sets];
+  void *pso, *pcnt, *poff, *pflag;
+  int rc;
+  if ((rc = g_shn_ws[14].get((size_t)(n_sets + 1 + n_mem + 1) * 4, &pso)) || (rc = g_shn_ws[15].get((N2 + 1) * 4, &pcnt)) ||
+      (rc = g_shn_ws[16].get((N2 + 2) * 8, &poff)) || (rc = g_shn_ws[17].get(64, &pflag))) return rc;
+  uint32_t* d_so = (uint32_t*)pso;
+  uint32_t* d_sm = d_so + n_sets + 1;
+  HIP_TRY(hipMemcpyAsync(d_so, set_off, (size_t)(n_sets + 1) * 4, hipMemcpyHostToDevice, s));
+  if (n_mem) HIP_TRY(hipMemcpyAsync(d_sm, set_members, (size_t)n_mem * 4, hipMemcpyHostToDevice, s));
+  uint32_t* d_ovf = (uint32_t*)pflag;
+  HIP_TRY(hipMemsetAsync(d_ovf, 0, 4, s));
+  RView a = rview(r1), b = r2 ? rview(r2) : rview(r1);
+  shn_routes* R = new shn_routes();
+  memset(R, 0, sizeof(*R));
+  R->ctx = ctx;
+  if (N2 == 0) { *out = R; return SHN_OK; }
+  uint32_t grid = (uint32_t)cdiv(N2, RBLK);
+  hipLaunchKernelGGL(route_kernel<false>, dim3(grid), dim3(RBLK), 0, s, a, b, r2 ? 1 : 0, k1, probe->d_keys, probe->d_counts,
+                     probe->d_bucket_off, probe->bits, d_so, d_sm, (uint32_t*)pcnt, nullptr, nullptr, d_ovf);
+  uint64_t total = 0;
+  if ((rc = shn_device_scan_u32(ctx, (uint32_t*)pcnt, N2, (uint64_t*)poff, &total))) { delete R; return rc; }
+  uint32_t ovf = 0;
+  HIP_TRY(hipMemcpyAsync(&ovf, d_ovf, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (ovf) { delete R; return shn_fail(SHN_ERR_OVERFLOW, "shn_route_reads: a read hit more than 32 partitions"); }
+  if (total >= 0xFFFFFFFFULL) { delete R; return shn_fail(SHN_ERR_OVERFLOW, "shn_route_reads: more than 2^32 routed pairs"); }
+  R->n = total;
+  void *pk, *pk2, *pv, *pv2;
+  if ((rc = g_shn_ws[9].get((total + 2) * 8, &pk)) || (rc = g_shn_ws[11].get((total + 2) * 8, &pk2)) ||
+      (rc = g_shn_ws[10].get((total + 2) * 4, &pv)) || (rc = g_shn_ws[12].get((total + 2) * 4, &pv2))) { delete R; return rc; }
+  if (total) {
+    hipLaunchKernelGGL(route_kernel<true>, dim3(grid), dim3(RBLK), 0, s, a, b, r2 ? 1 : 0, k1, probe->d_keys, probe->d_counts,
+                       probe->d_bucket_off, probe->bits, d_so, d_sm, nullptr, (const uint64_t*)poff, (uint64_t*)pk, d_ovf);
+    // pairs were written in doubled-read order; a stable sort on the partition id keeps that order
+    HIP_TRY(hipMemsetAsync(pv, 0, total * 4, s));
+    int pbits = 1;
+    while (pbits < 32 && (1ULL << pbits) < (uint64_t)n_mem + 2) pbits++;
+    if ((rc = shn_sort_pairs(ctx, (uint64_t*)pk, (uint32_t*)pv, (uint64_t*)pk2, (uint32_t*)pv2, total, 32, 32 + ((pbits + 7) / 8) * 8))) { delete R; return rc; }
+    HIP_TRY(hipMalloc(&R->d_pid, total * 4));
+    HIP_TRY(hipMalloc(&R->d_ridx, total * 4));
+    hipLaunchKernelGGL(split_u64_kernel, dim3((uint32_t)cdiv(total, 256)), dim3(256), 0, s, (const uint64_t*)pk, total, R->d_pid, R->d_ridx);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s));
+  *out = R;
+  return SHN_OK;
+}
+
+// Build a lookup table from host (key, value) pairs with unique keys (value stored in `counts`).
+extern "C" int shn_table_create(shn_ctx* ctx, const uint64_t* keys, const uint32_t* values, uint64_t n, int k, int canonical,
+                                shn_table** out) {
+  if (!ctx || !out || (n && (!keys || !values))) return shn_fail(SHN_ERR_ARG, "shn_table_create: NULL argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  uint64_t* dk = nullptr; uint32_t* dv = nullptr;
+  HIP_TRY(hipMalloc(&dk, (n + 1) * 8));
+  HIP_TRY(hipMalloc(&dv, (n + 1) * 4));
+  if (n) {
+    HIP_TRY(hipMemcpyAsync(dk, keys, n * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dv, values, n * 4, hipMemcpyHostToDevice, s));
+  }
+  int rc = shn_table_from_pairs(ctx, dk, dv, n, k, canonical, out);
+  hipStreamSynchronize(s);
+  hipFree(dk); hipFree(dv);
+  return rc;
+}

@@ -5,6 +5,7 @@ from . import _lib
 
 ENC_ASCII, ENC_CODES = 0, 1
 ALPHA = "ACGT"
+ALPHA_BYTES = np.frombuffer(b"ACGT", dtype=np.uint8)
 
 
 class Context(object):

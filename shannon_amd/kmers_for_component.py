@@ -1,0 +1,237 @@
+"""Partitioning + per-partition k1-mer / read routing -- host mirror of the reference's
+kmers_for_component.py (rows a8-a11) over the HIP routing kernel (csrc/route.hip).
+
+gpmetis (METIS 5, external, unpinned) is replaced by `partition_graph` below: a deterministic
+greedy graph-growing k-way partitioner honouring the same balance bound (ufactor).  Its output
+is not METIS's -- partitioned configurations are parity-checked given the same partition vector.
+"""
+import ctypes as C
+import math
+import numpy as np
+from . import _lib, device
+from .extension_correction import windows_to_keys
+
+
+def n_partitions(num_contigs, partition_size):
+    """kmers_for_component.py:217."""
+    return min(int(math.ceil(float(num_contigs) / float(partition_size))), 100)
+
+
+def parse_metis(text):
+    lines = text.splitlines()
+    n = int(lines[0].split()[0])
+    adj = []
+    for i in range(n):
+        tok = lines[1 + i].split() if 1 + i < len(lines) else []
+        adj.append([(int(tok[j]) - 1, int(tok[j + 1])) for j in range(0, len(tok), 2)])
+    return adj
+
+
+def partition_graph(metis_text, n_parts, ufactor=1000):
+    """Deterministic stand-in for `gpmetis -ufactor=U graph P` (kmers_for_component.py:221,234):
+    grow parts one at a time from the lowest-numbered free vertex, always absorbing the free
+    vertex with the largest total edge weight into the growing part (ties: lowest index), up to
+    ceil(n/P) vertices; leftovers go to the lightest part.  Balance: every part <= (1+U/1000)*n/P."""
+    adj = parse_metis(metis_text)
+    n = len(adj)
+    part = [-1] * n
+    target = int(math.ceil(n / float(n_parts)))
+    nxt = 0
+    sizes = [0] * n_parts
+    for p in range(n_parts):
+        while nxt < n and part[nxt] != -1:
+            nxt += 1
+        if nxt >= n:
+            break
+        gain = {nxt: 0}
+        while sizes[p] < target and gain:
+            v = min(gain, key=lambda x: (-gain[x], x))
+            del gain[v]
+            part[v] = p
+            sizes[p] += 1
+            for u, w in adj[v]:
+                if part[u] == -1:
+                    gain[u] = gain.get(u, 0) + w
+            if not gain and sizes[p] < target:
+                while nxt < n and part[nxt] != -1:
+                    nxt += 1
+                if nxt < n:
+                    gain[nxt] = 0
+    for v in range(n):
+        if part[v] == -1:
+            p = min(range(n_parts), key=lambda q: (sizes[q], q))
+            part[v] = p
+            sizes[p] += 1
+    return part
+
+
+def weight_updated_graph(metis_text, part, penalty=5):
+    """weight_updated_graph.py:24-42: multiply weights of edges cut by `part` by `penalty`."""
+    lines = metis_text.splitlines()
+    out = [lines[0] + "\n"]
+    for i, line in enumerate(lines[1:], start=1):
+        tok = line.split()
+        new = ""
+        for j in range(0, len(tok), 2):
+            nb = tok[j]
+            cut = int(part[i - 1]) != int(part[int(nb) - 1])
+            new += nb + "\t" + (str(penalty * int(tok[j + 1])) if cut else tok[j + 1]) + "\t"
+        out.append(new + "\n")
+    return "".join(out)
+
+
+def build_partitions(res, K, partition_size=500, overload=2, penalty=5, repartition=True, part_vectors=None):
+    """kmers_for_component.py:207-305.  `res`: ExtensionResult.  part_vectors: optional
+    [(part, part_r2)] per big component (to replay a given gpmetis output).  Returns
+    (new_components {name: [contig]}, components_broken {i: P})."""
+    ufactor = int(1000.0 * overload - 1000.0)
+    new_components, broken = {}, {}
+    for i, (contigs, metis) in enumerate(res.big_components):
+        P = n_partitions(len(contigs), partition_size)
+        broken[i] = P
+        if part_vectors is not None:
+            p1, p2 = part_vectors[i]
+        else:
+            p1 = partition_graph(metis, P, ufactor)
+            p2 = partition_graph(weight_updated_graph(metis, p1, penalty), P, ufactor) if repartition else None
+        for j, pid in enumerate(p1):
+            new_components.setdefault("c%d_%s" % (i + 1, pid), []).append(contigs[j])
+        if repartition and p2 is not None:
+            for j, pid in enumerate(p2):
+                new_components.setdefault("r2_c%d_%s" % (i + 1, pid), []).append(contigs[j])
+    for i, contigs in enumerate(res.remaining):
+        for c in contigs:
+            new_components.setdefault("cremaining%d" % (i + 1), []).append(c)
+    return new_components, broken
+
+
+class Routes(object):
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def download(self):
+        n = int(_lib.lib().shn_routes_size(self.h))
+        pid = np.empty(n, np.uint32)
+        ridx = np.empty(n, np.uint32)
+        _lib.check(_lib.lib().shn_routes_download(self.ctx.h, self.h, pid.ctypes.data, ridx.ctypes.data))
+        return pid, ridx
+
+    def close(self):
+        if self.h:
+            _lib.lib().shn_routes_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_table(ctx, keys, values, k, canonical=False):
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    values = np.ascontiguousarray(values, dtype=np.uint32)
+    h = C.c_void_p()
+    _lib.check(_lib.lib().shn_table_create(ctx.h, keys.ctypes.data, values.ctypes.data, len(keys), k, 1 if canonical else 0, C.byref(h)))
+    return device.Table(ctx, h)
+
+
+def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overload=2, penalty=5, repartition=True,
+                        part_vectors=None):
+    """Rows a8-a11.  reads1/reads2: device.Reads (reads2 None for single-end).  Returns dict with
+      new_components {name: [contig]}          (kmers_for_component.py:244-305)
+      k1mers {name: [(k1mer, weight)]}         (:452-477, == component{name}k1mers_allowed.dict)
+      contig_weights {name: [[w..] per contig]} (--inMem form :468-469)
+      routes {name: uint32 array of doubled read indices in input order}   (:322-403)
+    """
+    k1 = K + 1
+    comps, broken = build_partitions(res, K, partition_size, overload, penalty, repartition, part_vectors)
+    names = list(comps)
+    pid_of = {n: i for i, n in enumerate(names)}
+    # k1mers2component (:244-305): every k1-window of every partition contig -> set of partitions
+    key_sets = {}
+    files, cw = {}, {}
+    allk, allp = [], []
+    for name in names:
+        for contig in comps[name]:
+            ks = windows_to_keys(contig, k1)
+            allk.append(ks)
+            allp.append(np.full(len(ks), pid_of[name], dtype=np.uint32))
+    if allk:
+        allk = np.concatenate(allk)
+        allp = np.concatenate(allp)
+    else:
+        allk, allp = np.zeros(0, np.uint64), np.zeros(0, np.uint32)
+    order = np.lexsort((allp, allk))
+    sk, sp = allk[order], allp[order]
+    uk, start = np.unique(sk, return_index=True)
+    end = np.append(start[1:], len(sk))
+    set_ids, sets, set_index = np.zeros(len(uk), np.uint32), [], {}
+    for i, (a, b) in enumerate(zip(start.tolist(), end.tolist())):
+        tpl = tuple(np.unique(sp[a:b]).tolist())
+        sid = set_index.get(tpl)
+        if sid is None:
+            sid = set_index[tpl] = len(sets)
+            sets.append(tpl)
+        set_ids[i] = sid + 1
+    set_off = np.zeros(len(sets) + 1, dtype=np.uint32)
+    set_off[1:] = np.cumsum([len(s) for s in sets])
+    set_mem = np.array([p for s in sets for p in s], dtype=np.uint32) if sets else np.zeros(1, np.uint32)
+    probe = make_table(ctx, uk, set_ids, k1, canonical=False)
+    h = C.c_void_p()
+    _lib.check(_lib.lib().shn_route_reads(ctx.h, reads1.h, reads2.h if reads2 is not None else None, k1, probe.h,
+                                          set_off.ctypes.data, set_mem.ctypes.data, len(sets), C.byref(h)))
+    routes = Routes(ctx, h)
+    pid, ridx = routes.download()
+    routes.close()
+    probe.close()
+    bounds = np.searchsorted(pid, np.arange(len(names) + 1))
+    by_part = {n: ridx[bounds[i]:bounds[i + 1]] for i, n in enumerate(names)}
+    # per-partition k1-mer rows with weights from the allowed dict (:452-477)
+    for name in names:
+        rows, ws = [], []
+        for contig in comps[name]:
+            wl = []
+            for i in range(len(contig) - k1 + 1):
+                km = contig[i:i + k1]
+                w = res.allowed.get(km, 0)
+                wl.append(w)
+                rows.append((km, w))
+            ws.append(wl)
+        files[name] = rows
+        cw[name] = ws
+    return {"new_components": comps, "components_broken": broken, "k1mers": files, "contig_weights": cw, "routes": by_part}
+
+
+class ReadStore(object):
+    """Host copy of the input reads, addressed by the doubled index of the routing kernel."""
+
+    def __init__(self, r1, r2=None):
+        self.r1, self.r2 = r1, r2         # lists of strings or uint8 code matrices
+        self.n = len(r1)
+
+    @staticmethod
+    def _get(src, i):
+        s = src[i]
+        if isinstance(s, str):
+            return s
+        return device.ALPHA_BYTES[s].tobytes().decode()
+
+    @staticmethod
+    def _rc(s):
+        return s[::-1].translate(_RC)
+
+    def mate1(self, d):
+        """reads_1[d] (PE) / reads[d] (SE) of the strand-doubled input (shannon.py:396-424)."""
+        if self.r2 is None or d < self.n:
+            s = self._get(self.r1, d if d < self.n else d - self.n)
+            return s if d < self.n else self._rc(s)
+        return self._rc(self._get(self.r2, d - self.n))
+
+    def mate2(self, d):
+        if d < self.n:
+            return self._rc(self._get(self.r1, d))
+        return self._get(self.r2, d - self.n)
+
+
+_RC = str.maketrans("ACGTN", "TGCAN")

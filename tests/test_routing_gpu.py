@@ -1,0 +1,59 @@
+"""GPU parity: partitions, k1-mer emit and read routing (rows a8-a11) vs the reference goldens."""
+import numpy as np
+import pytest
+from golden_util import *
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from shannon_amd import device
+    c = device.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("name", sorted(MANIFEST))
+def test_routing_matches_golden(ctx, name):
+    from shannon_amd import device, extension_correction as ec, kmers_for_component as kfc
+    g = load_case(name)
+    K, paired = g["K"], g["paired"]
+    psize = MANIFEST[name].get("partition_size", 500)
+    inp = load_inputs(name)
+    sets = [device.Reads.from_strings(ctx, r) for r in inp]
+    t = device.count_k1mers(ctx, sets, K + 1)
+    res = ec.run_correction(ctx, t, 3, 75, psize)
+    pv = [part_vectors(len(cl), psize) for cl, _ in res.big_components] or None
+    for (cl, metis), gb, (p1, p2) in zip(res.big_components, g["big_components"], pv or []):
+        assert kfc.weight_updated_graph(metis, p1, 5) == gb["metis_r2"]
+    out = kfc.kmers_for_component(ctx, res, sets[0], sets[1] if paired else None, K, psize, part_vectors=pv)
+    assert list(out["new_components"]) == list(g["partitions"])
+    store = kfc.ReadStore(inp[0], inp[1] if paired else None)
+    for comp, gp in g["partitions"].items():
+        idx = out["routes"][comp]
+        assert len(idx) == gp["n_reads"]
+        reads = [[store.mate1(int(d)) for d in idx]]
+        if paired:
+            reads.append([store.mate2(int(d)) for d in idx])
+        assert digest(reads) == gp["reads_digest"]
+        assert digest([[a, str(b)] for a, b in out["k1mers"][comp]]) == gp["k1mers_digest"]
+
+
+def test_own_partitioner_is_balanced_and_deterministic():
+    from shannon_amd import kmers_for_component as kfc
+    rng = np.random.default_rng(0)
+    n = 300
+    adj = [dict() for _ in range(n)]
+    for _ in range(900):
+        a, b = int(rng.integers(0, n)), int(rng.integers(0, n))
+        if a != b:
+            w = int(rng.integers(1, 9))
+            adj[a][b] = w
+            adj[b][a] = w
+    text = "%d\t%d\t001\n" % (n, sum(len(d) for d in adj) // 2) + "".join(
+        "".join("%d\t%d\t" % (b + 1, w) for b, w in d.items()) + "\n" for d in adj)
+    p = kfc.partition_graph(text, 6, 1000)
+    assert p == kfc.partition_graph(text, 6, 1000)
+    sizes = np.bincount(p, minlength=6)
+    assert sizes.sum() == n and sizes.max() <= 2 * n / 6 and set(p) == set(range(6))
