@@ -143,6 +143,18 @@ void shn_routes_destroy(shn_routes* r);
 uint64_t shn_routes_size(const shn_routes* r);
 int shn_routes_download(shn_ctx* ctx, const shn_routes* r, uint32_t* pid, uint32_t* ridx);
 
+/* ---- sparse-flow node decomposition ------------------------------------------------------------
+ * Replaces the randomized trial loop of path_decompose (path_decompose_sparse.py:100-117): the
+ * <=100 cvxopt.solvers.lp calls per decomposed node (cvxopt: third party, version unpinned, not
+ * vendored -- the LP optimiser is this library's own rule).  Problem p is the m x n
+ * transportation problem with balanced+scaled marginals ab = [a_s (m), b_s (n)] and byte mask
+ * mask[j*m+i] = 1 where NO known path supports cell (i,j); trial t draws cost numerators from the
+ * counter-based stream (seed, pid[p], t, cell).  flows_out receives, per problem, trials*m*n
+ * doubles laid out [cell j*m+i][trial] (problems concatenated).  Thresholding / trial selection
+ * (:119-192) stay on the host (shannon_amd/sparse_flow.py).                                    */
+int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint32_t* m, const uint32_t* n, const uint32_t* trials,
+                       const uint64_t* pid, const double* ab, const uint8_t* mask, uint64_t seed, double* flows_out);
+
 #ifdef __cplusplus
 }
 #endif

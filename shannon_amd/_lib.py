@@ -42,6 +42,7 @@ SIGNATURES = {
     "shn_routes_destroy": (None, [vp]),
     "shn_routes_size": (C.c_uint64, [vp]),
     "shn_routes_download": (C.c_int, [vp, vp, vp, vp]),
+    "shn_lp_solve_batch": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_uint64, vp]),
     "shn_extend": (C.c_int, [vp, vp, C.c_uint32, C.c_int, vpp]),
     "shn_ext_destroy": (None, [vp]),
     "shn_ext_n_walks": (C.c_uint64, [vp]),

@@ -1,0 +1,91 @@
+"""CPU: the product's host-side graph / sparse-flow logic (shannon_amd/mbgraph.py,
+shannon_amd/sparse_flow.py) against the reference goldens.  Partition inputs come from the oracle
+front stages; the LP trials are solved by the oracle's transport_vertex here (the HIP kernel is
+checked against it bit for bit in tests/test_lp_gpu.py)."""
+import numpy as np
+import pytest
+from golden_util import *
+from oracle import seqs, count, extension, partition, lp as olp
+from shannon_amd import mbgraph, sparse_flow, kmers_for_component as kfc
+
+CASES = sorted(MANIFEST)
+
+
+def oracle_solve_batch(ctx, reqs, seed):
+    out = []
+    for q in reqs:
+        xs = np.zeros((q.m * q.n, q.trials))
+        for t in range(q.trials):
+            cc = olp.trial_costs(seed, q.pid, t, q.m * q.n)
+            c = [[(cc[j * q.m + i] if q.p[j * q.m + i] > 0 else 0) for j in range(q.n)] for i in range(q.m)]
+            x = olp.transport_vertex(q.a_s, q.b_s, c)
+            for k in range(q.m * q.n):
+                xs[k, t] = x[k % q.m][k // q.m]
+        out.append(xs)
+    return out
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_product_graph_stage(name):
+    g = load_case(name)
+    K, paired = g["K"], g["paired"]
+    psize = MANIFEST[name].get("partition_size", 500)
+    inp = load_inputs(name)
+    dbl = list(seqs.double_strand_paired(*inp)) if paired else [seqs.double_strand_single(inp[0])]
+    tab = count.count_k1mers_dict([r for f in dbl for r in f], K + 1)
+    res = extension.run_correction([(k, tab[k]) for k in sorted(tab, reverse=True)], comp_size_threshold=psize)
+    pv = [part_vectors(len(cl), psize) for cl, _ in res.big_components]
+    nc, k2c = partition.build_partitions([b[0] for b in res.big_components], [p[0] for p in pv], [p[1] for p in pv] if pv else None,
+                                         res.remaining, res.allowed, K)
+    if paired:
+        o1, o2 = partition.route_reads_paired(dbl[0], dbl[1], nc, k2c, K)
+    else:
+        o1 = partition.route_reads(dbl[0], nc, k2c, K)
+    files, _ = partition.partition_k1mers(nc, k2c, K)
+    for comp, gp in g["partitions"].items():
+        reads = [o1[comp], o2[comp]] if paired else [o1[comp]]
+        gr, singles, comps = mbgraph.run_partition(files[comp], reads, K, paired)
+        can = mbgraph.canonical(singles, comps)
+        for k in can:
+            assert approx_eq(can[k], gp["graph"][k]), (comp, k)
+        assert [l for l in gr.log if "Bridged" in l] == [l for l in gp["mb_log"] if "Bridged" in l]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_product_sparse_flow_host_logic(name, monkeypatch):
+    monkeypatch.setattr(sparse_flow, "solve_batch", oracle_solve_batch)
+    g = load_case(name)
+    seed = MANIFEST[name]["sf_seed"]
+    for comp, gp in g["partitions"].items():
+        comps = [(rc["nodes"], rc["edges"], rc["paths"]) for rc in gp["raw_components"]]
+        trs = sparse_flow.sparse_flow_components(None, comps, seed)
+        mine = "".join(sparse_flow.fasta_records("", str(c), tr) for c, tr in enumerate(trs))
+        mine += sparse_flow.single_nodes_fasta("", gp["single_rows"])
+        ref, mine = parse_fasta(gp["reconstructed_fasta"]), parse_fasta(mine)
+        assert len(ref) == len(mine)
+        for (h1, s1), (h2, s2) in zip(ref, mine):
+            assert s1 == s2
+            t1, t2 = h1.split("\t"), h2.split("\t")
+            assert t1[0] == t2[0] and t1[2:] == t2[2:]
+            if "Copycount" in t1[1]:
+                assert t1[1] == t2[1]
+            else:
+                assert abs(float(t1[1]) - float(t2[1])) <= 1e-9 * max(1.0, abs(float(t1[1])))
+
+
+def test_own_partitioner_is_balanced_and_deterministic():
+    rng = np.random.default_rng(0)
+    n = 300
+    adj = [dict() for _ in range(n)]
+    for _ in range(900):
+        a, b = int(rng.integers(0, n)), int(rng.integers(0, n))
+        if a != b:
+            w = int(rng.integers(1, 9))
+            adj[a][b] = w
+            adj[b][a] = w
+    text = "%d\t%d\t001\n" % (n, sum(len(d) for d in adj) // 2) + "".join(
+        "".join("%d\t%d\t" % (b + 1, w) for b, w in d.items()) + "\n" for d in adj)
+    p = kfc.partition_graph(text, 6, 1000)
+    assert p == kfc.partition_graph(text, 6, 1000)
+    sizes = np.bincount(p, minlength=6)
+    assert sizes.sum() == n and sizes.max() <= 2 * n / 6 and set(p) == set(range(6))

@@ -40,20 +40,3 @@ def test_routing_matches_golden(ctx, name):
         assert digest([[a, str(b)] for a, b in out["k1mers"][comp]]) == gp["k1mers_digest"]
 
 
-def test_own_partitioner_is_balanced_and_deterministic():
-    from shannon_amd import kmers_for_component as kfc
-    rng = np.random.default_rng(0)
-    n = 300
-    adj = [dict() for _ in range(n)]
-    for _ in range(900):
-        a, b = int(rng.integers(0, n)), int(rng.integers(0, n))
-        if a != b:
-            w = int(rng.integers(1, 9))
-            adj[a][b] = w
-            adj[b][a] = w
-    text = "%d\t%d\t001\n" % (n, sum(len(d) for d in adj) // 2) + "".join(
-        "".join("%d\t%d\t" % (b + 1, w) for b, w in d.items()) + "\n" for d in adj)
-    p = kfc.partition_graph(text, 6, 1000)
-    assert p == kfc.partition_graph(text, 6, 1000)
-    sizes = np.bincount(p, minlength=6)
-    assert sizes.sum() == n and sizes.max() <= 2 * n / 6 and set(p) == set(range(6))
