@@ -1,0 +1,35 @@
+"""End-to-end oracle: chains the stage oracles in the order of shannon.py:394-647.  Test
+infrastructure (see oracle/__init__.py)."""
+from . import seqs, count, extension, partition, mbgraph, sparse_flow, post
+
+
+def assemble(reads1, reads2=None, K=25, partition_size=500, sample="shannon", seed=0, part_vectors=None):
+    paired = reads2 is not None
+    dbl = list(seqs.double_strand_paired(reads1, reads2)) if paired else [seqs.double_strand_single(reads1)]
+    tab = count.count_k1mers_dict([r for f in dbl for r in f], K + 1)
+    res = extension.run_correction([(k, tab[k]) for k in sorted(tab, reverse=True)], comp_size_threshold=partition_size)
+    pv = part_vectors or []
+    nc, k2c = partition.build_partitions([b[0] for b in res.big_components], [p[0] for p in pv], [p[1] for p in pv] if pv else None,
+                                         res.remaining, res.allowed, K)
+    if paired:
+        o1, o2 = partition.route_reads_paired(dbl[0], dbl[1], nc, k2c, K)
+    else:
+        o1 = partition.route_reads(dbl[0], nc, k2c, K)
+    files, _ = partition.partition_k1mers(nc, k2c, K)
+    lines = []
+    for i, c in enumerate(res.single_contigs):
+        lines += [">Single_%d\n" % i, c + "\n"]
+    parts = {}
+    for name in nc:
+        reads = [o1[name], o2[name]] if paired else [o1[name]]
+        g, singles, comps = mbgraph.run_partition(files[name], reads, K, paired)
+        sname = "%s_%s" % (sample, name)
+        txt = ""
+        for c, comp in enumerate(comps):
+            tr = sparse_flow.sparse_flow_component(comp["nodes"], comp["edges"], comp["paths"], seed=seed, comp_id=c)
+            txt += sparse_flow.fasta_records(sname, str(c), tr)
+        txt += sparse_flow.single_nodes_fasta(sname, singles)
+        parts[name] = {"reconstructed_fasta": txt, "graph": mbgraph.canonical(singles, comps)}
+        lines += txt.splitlines(True)
+    return {"partitions": parts, "all_reconstructed": lines, "final": post.finalize(lines, True),
+            "contigs": res.contigs, "n_k1mers": len(tab)}

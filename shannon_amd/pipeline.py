@@ -1,0 +1,134 @@
+"""End-to-end hot path in memory: reads -> (K+1)-mer table -> contigs/partitions -> per-partition
+multibridged graph -> sparse-flow transcripts -> merged FASTA.  Mirrors the order of shannon.py
+(394-647) and run_MB_SF_fn.py (210-254) without the file round trips between stages (the
+reference's --inMem hand-off); `shannon.py` at the repo root adds the CLI and the OUT/ file tree.
+"""
+import time
+import numpy as np
+from . import device, extension_correction as ec, kmers_for_component as kfc, mbgraph, sparse_flow, post
+
+
+class Result(object):
+    pass
+
+
+def n_kmer_nodes(rows, K):
+    """#distinct K-mers among the k1-mer rows = len(Node.nodes) after loading (multibridging.py:383)."""
+    s = set()
+    for km, _ in rows:
+        s.add(km[:-1])
+        s.add(km[1:])
+    return len(s)
+
+
+def assemble(ctx, reads1, reads2=None, K=25, partition_size=500, min_weight=3, min_length=75, overload=2, penalty=5,
+             sample="shannon", seed=0, double_stranded=True, part_vectors=None, timings=None, hits_factory=None):
+    """reads1/reads2: lists of strings or uint8 code matrices (reads2 None = single-end).
+    Returns Result with .partitions {name: dict}, .all_reconstructed (lines), .final {name: seq}."""
+    T = timings if timings is not None else {}
+    paired = reads2 is not None
+
+    def tick(name, t0):
+        T[name] = T.get(name, 0.0) + time.time() - t0
+
+    t0 = time.time()
+    mk = (lambda r: device.Reads.from_strings(ctx, r)) if isinstance(reads1[0], str) else (lambda r: device.Reads.from_codes(ctx, r))
+    d1 = mk(reads1)
+    d2 = mk(reads2) if paired else None
+    store = kfc.ReadStore(reads1, reads2)
+    tick("upload+pack", t0)
+    return assemble_resident(ctx, d1, d2, store, K, partition_size, min_weight, min_length, overload, penalty, sample, seed,
+                             double_stranded, part_vectors, T, hits_factory)
+
+
+def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3, min_length=75, overload=2, penalty=5,
+                      sample="shannon", seed=0, double_stranded=True, part_vectors=None, timings=None, hits_factory=None):
+    """Same as assemble() with the reads already packed in HBM (d1/d2: device.Reads)."""
+    T = timings if timings is not None else {}
+    paired = d2 is not None
+
+    def tick(name, t0):
+        T[name] = T.get(name, 0.0) + time.time() - t0
+
+    R = Result()
+    t0 = time.time()
+    table = device.count_k1mers(ctx, [d1, d2] if paired else [d1], K + 1, both_strands=double_stranded)
+    R.n_k1mers, R.n_windows = len(table), table.total
+    tick("count", t0)
+    t0 = time.time()
+    res = ec.run_correction(ctx, table, min_weight, min_length, partition_size)
+    table.close()
+    R.extension = res
+    tick("extension", t0)
+    t0 = time.time()
+    part = kfc.kmers_for_component(ctx, res, d1, d2, K, partition_size, overload, penalty, True, part_vectors)
+    tick("partition+route", t0)
+    R.partitions = {}
+    lines = []
+    for i, c in enumerate(res.single_contigs):                      # reconstructed_single_contigs.fasta
+        lines += [">Single_%d\n" % i, c + "\n"]
+    sf_jobs = []
+    for name in part["new_components"]:
+        t0 = time.time()
+        rows = part["k1mers"][name]
+        cutoff = 10 * n_kmer_nodes(rows, K) + 1                      # multibridging.py:26-30, 385-391
+        idx = part["routes"][name][:cutoff]
+        r1 = [store.mate1(int(d)) for d in idx]
+        reads = [r1, [store.mate2(int(d)) for d in idx]] if paired else [r1]
+        tick("materialize reads", t0)
+        t0 = time.time()
+        g, singles, comps = mbgraph.run_partition(rows, reads, K, paired, hits_factory)
+        tick("graph", t0)
+        R.partitions[name] = {"n_reads_routed": len(part["routes"][name]), "n_k1mers": len(rows), "singles": singles,
+                              "components": comps, "log": g.log}
+        sf_jobs.append((name, singles, comps))
+    t0 = time.time()
+    flat = [(nd["nodes"], nd["edges"], nd["paths"]) for _, _, comps in sf_jobs for nd in comps]
+    # component c of partition p uses RNG stream id = its index within the partition (as one
+    # algorithm_SF.py process per component, run_MB_SF_fn.py:242-250)
+    trs_flat = []
+    if flat:
+        ids, gens_in = [], []
+        for _, _, comps in sf_jobs:
+            for c, nd in enumerate(comps):
+                ids.append(c)
+        trs_flat = _sparse_flow_with_ids(ctx, flat, ids, seed)
+    k = 0
+    for name, singles, comps in sf_jobs:
+        sname = "%s_%s" % (sample, name)
+        txt = ""
+        for c in range(len(comps)):
+            txt += sparse_flow.fasta_records(sname, str(c), trs_flat[k])
+            k += 1
+        txt += sparse_flow.single_nodes_fasta(sname, singles)
+        R.partitions[name]["reconstructed_fasta"] = txt
+        lines += txt.splitlines(True)
+    tick("sparse flow", t0)
+    t0 = time.time()
+    R.all_reconstructed = lines
+    R.final = post.finalize(lines, double_stranded)
+    tick("post", t0)
+    R.timings = T
+    return R
+
+
+def _sparse_flow_with_ids(ctx, components, comp_ids, seed):
+    gens = [sparse_flow.component_coroutine(nd, ed, pt, cid) for (nd, ed, pt), cid in zip(components, comp_ids)]
+    results = [None] * len(gens)
+    pending = {}
+    for c, g in enumerate(gens):
+        try:
+            pending[c] = next(g)
+        except StopIteration as stop:
+            results[c] = stop.value
+    while pending:
+        order = sorted(pending)
+        xs = sparse_flow.solve_batch(ctx, [pending[c] for c in order], seed)
+        nxt = {}
+        for c, x in zip(order, xs):
+            try:
+                nxt[c] = gens[c].send(sparse_flow.finish(pending[c], x))
+            except StopIteration as stop:
+                results[c] = stop.value
+        pending = nxt
+    return results

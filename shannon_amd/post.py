@@ -1,0 +1,87 @@
+"""Final merge / de-duplication -- host mirror of process_concatenated_fasta.py:6-32, the perl
+length sort (shannon.py:603) and faster_reps.py:60-131 (row a31).  Record order of the final file
+is dict order in the reference (faster_reps.py:121): consumers compare it as a set."""
+
+_RC = str.maketrans("ACGTN", "TGCAN")
+
+
+def rc(s):
+    return s[::-1].translate(_RC)
+
+
+def process_concatenated(lines, ds):
+    """process_concatenated_fasta.py:6-32 (lines carry their newlines)."""
+    out, contigs, seen, last = [], set(), {}, ""
+    for line in lines:
+        tok = line.split()
+        if tok[0][0] == ">":
+            if tok[0] in seen:
+                last = tok[0] + "_" + str(seen[tok[0]]) + "\t".join(tok[1:]) + "\n"
+                seen[tok[0]] += 1
+            else:
+                last = line
+                seen[tok[0]] = 1
+        elif len(line) > 200:
+            cur = line.strip()
+            if cur in contigs or (ds and rc(cur) in contigs):
+                continue
+            contigs.add(cur)
+            out += [last, line]
+    return out
+
+
+def length_sort(lines):
+    """shannon.py:603: hash keyed by header line, sorted by sequence length (ties: by header)."""
+    seqs = {}
+    for i in range(0, len(lines) - 1, 2):
+        seqs[lines[i]] = lines[i + 1]
+    out = []
+    for h in sorted(seqs, key=lambda h: (len(seqs[h]), h)):
+        out += [h, seqs[h]]
+    return out
+
+
+def find_reps(lines, ds, r=24):
+    """faster_reps.py:98-131 with duplicate_check_ends :60-92.  Returns {name: seq} kept."""
+    contigs, index, name = {}, {}, None
+    for line in lines:
+        if line[0] == ">":
+            name = line.strip().split()[0][1:]
+            continue
+        seq = line.strip()
+        contigs[name] = seq
+        for i in range(len(seq) - r + 1):
+            index.setdefault(seq[i:i + r], []).append((name, i))
+
+    def contained(cname, flip):
+        c = contigs[cname]
+        if flip:
+            c = rc(c)
+        first, last = index.get(c[:r]), index.get(c[-r:])
+        if first is None or last is None:
+            return False
+        pos = {}
+        for o, p in first:
+            if o != cname:
+                if o in pos:
+                    pos[o][0] = p
+                else:
+                    pos[o] = [p, -1]
+        for o, p in last:
+            if o != cname:
+                if o in pos:
+                    pos[o][1] = p
+                else:
+                    pos[o] = [-1, p]
+        for o, (p0, p1) in pos.items():
+            if p0 >= 0 and p1 >= 0 and abs((p1 - p0) - (len(c) - r)) < 3:
+                if len(c) < len(contigs[o]) or (len(c) == len(contigs[o]) and cname > o):
+                    return True
+        return False
+
+    return {n: s for n, s in contigs.items() if not (contained(n, False) or (ds and contained(n, True)))}
+
+
+def finalize(all_lines, ds=True):
+    """shannon.py:596-604."""
+    return find_reps(length_sort(process_concatenated(all_lines, ds)), ds)
