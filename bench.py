@@ -23,7 +23,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 def gen_reads(n_pairs, seed, n_genes, device):
     """synthetic pairs on the GPU (torch RNG; same model as shannon_amd/synth.py)."""
     from shannon_amd import synth
-    iso, _ = synth.make_transcriptome(n_genes, seed)
+    # config 2 ("single component"): one gene family rich enough to give a multi-contig component
+    kw = dict(n_isoforms=(4, 6), n_exons=(8, 12)) if n_genes == 1 else {}
+    iso, _ = synth.make_transcriptome(n_genes, seed, **kw)
     lens = np.array([len(t) for t in iso], dtype=np.int64)
     rng = np.random.Generator(np.random.PCG64(seed + 1))
     expr = rng.lognormal(0.0, 1.5, size=len(iso))
@@ -94,15 +96,25 @@ def main():
     ctx = device.Context(local if world > 1 else 0)
     sets = [device.Reads.from_codes(ctx, r1), device.Reads.from_codes(ctx, r2)]
     n_reads = len(sets[0]) + len(sets[1])
-    del r1, r2
+
+    from shannon_amd import pipeline, kmers_for_component as kfc
+    store = kfc.ReadStore(r1, r2)
+    stage_t = {}
+
+    class _Done(object):
+        def close(self):
+            pass
 
     def step():
-        t = device.count_k1mers(ctx, sets, k1, both_strands=True)
         if world > 1:
+            t = device.count_k1mers(ctx, sets, k1, both_strands=True)
             owned = exchange.exchange_table(ctx, t)
             t.close()
-            t = owned
-        return t
+            return owned
+        R = pipeline.assemble_resident(ctx, sets[0], sets[1], store, K=args.K, sample="bench", seed=1, timings=stage_t)
+        d = _Done()
+        d.R = R
+        return d
 
     for _ in range(args.warmup):
         step().close()
@@ -127,7 +139,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     timers = ctx.timers()
-    distinct, total = len(last), last.total
+    if world > 1:
+        distinct, total = len(last), last.total
+    else:
+        distinct, total = last.R.n_k1mers, last.R.n_windows
     if rank == 0:
         ms_step = 1000.0 * dt / args.steps
         # dominant kernel group by HIP-event time on the ctx stream
@@ -147,7 +162,13 @@ def main():
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "10M synthetic 2x100bp paired reads per GPU, k=25 (k1=26), single gene family",
                        "reads_per_gpu": n_reads, "K": args.K,
-                       "stages": "count (a1-a2: pack-resident reads -> canonical (K+1)-mer table%s); later rows of SURVEY 8a not in the timed step yet" % (", all-to-all exchange + reduce-by-key" if world > 1 else ""),
+                       "stages": ("count + all-to-all exchange + reduce-by-key ONLY (multi-GPU graph stages not built yet)" if world > 1 else
+                                  "full path a1-a31: count -> extension -> partition/route -> multibridged graph -> sparse flow -> merge"),
+                       "host_stage_seconds_per_step": {k: v / (args.steps + args.warmup) for k, v in stage_t.items()},
+                       "transcripts": (len(last.R.final) if world == 1 else None),
+                       "extension_iterations": (last.R.extension.iterations if world == 1 else None),
+                       "extension_walks": (last.R.extension.n_walks if world == 1 else None),
+                       "partitions": ({k: [v["n_reads_routed"], v["n_k1mers"]] for k, v in last.R.partitions.items()} if world == 1 else None),
                        "windows_per_step": total, "distinct_k1mers": distinct},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

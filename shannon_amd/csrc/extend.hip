@@ -14,6 +14,8 @@
 // as in the reference's strand-doubled input.
 #include "common.h"
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 
 #define EBLK 256
@@ -115,24 +117,29 @@ __global__ void ext_weightkey_kernel(const uint32_t* __restrict__ svals, const u
 }
 
 // One thread per walk.  EMIT: write the contig bases (ASCII) of the selected walks.
+// Per step ONE round of independent loads: for each of the 4 candidates (ids already in registers)
+// its claim (previous iteration + final), its claim in this iteration, its weight and its own
+// adjacency row (prefetched, so the next step needs no dependent load); the claim is published
+// with a fire-and-forget atomicMin.  The step latency is one L2/HBM round trip, not seven.
+struct Adj4 { int32_t v[4]; };
+
 template <bool EMIT>
 __global__ __launch_bounds__(EBLK) void ext_walk_kernel(const uint32_t* __restrict__ order, uint64_t n_walks,
                                                         const uint32_t* __restrict__ sel,   // EMIT: ranks to emit
                                                         const int32_t* __restrict__ adjR, const int32_t* __restrict__ adjL,
                                                         const uint32_t* __restrict__ weight, const uint32_t* __restrict__ claim_prev,
-                                                        uint32_t* __restrict__ claim_cur, uint32_t* __restrict__ nr_out,
-                                                        uint32_t* __restrict__ nl_out, uint64_t* __restrict__ totw_out,
-                                                        uint64_t* __restrict__ hash_io, uint32_t* __restrict__ changed,
-                                                        const uint64_t* __restrict__ tkeys, int k, const uint64_t* __restrict__ out_off,
-                                                        uint8_t* __restrict__ out_bases) {
+                                                        uint32_t first, uint32_t* __restrict__ claim_cur,
+                                                        uint32_t* __restrict__ nr_out, uint32_t* __restrict__ nl_out,
+                                                        uint64_t* __restrict__ totw_out, uint64_t* __restrict__ hash_io,
+                                                        uint32_t* __restrict__ changed, const uint64_t* __restrict__ tkeys, int k,
+                                                        const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out_bases) {
   uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_walks) return;
-  const uint32_t r = EMIT ? sel[t] : (uint32_t)t;
+  const uint32_t r = EMIT ? sel[t] : (uint32_t)t + first;
   const uint32_t o = order[r];
-  const char ALPHA[4] = {'A', 'C', 'G', 'T'};
-  const int BORDER[4] = {0, 2, 1, 3};          // BASES = ['A','G','C','T'] (extension_correction.py:10)
   uint32_t nr = 0, nl = 0;
   uint64_t tot = 0, h = 0x9E3779B97F4A7C15ULL;
+  // claim_prev holds the claims of the previous iteration merged with all final claims
   bool isvoid = claim_prev[o] < r;
   uint8_t* dst = nullptr;
   uint32_t nl_known = 0;
@@ -141,52 +148,66 @@ __global__ __launch_bounds__(EBLK) void ext_walk_kernel(const uint32_t* __restri
     dst = out_bases + out_off[t];
     nl_known = nl_out[r];
     uint64_t s = oriented_string(tkeys, o, k);
-    for (int j = 0; j < k; j++) dst[nl_known + j] = ALPHA[(s >> (2 * (k - 1 - j))) & 3];
+    for (int j = 0; j < k; j++) dst[nl_known + j] = "ACGT"[(s >> (2 * (k - 1 - j))) & 3];
   }
   if (!isvoid) {
     atomicMin(&claim_cur[o], r);
     tot = weight[o >> 1];
     for (int dir = 0; dir < 2; dir++) {
-      const int32_t* adj = dir == 0 ? adjR : adjL;
-      uint32_t cur = o;
+      const Adj4* adj = (const Adj4*)(dir == 0 ? adjR : adjL);
       uint32_t steps = 0;
+      Adj4 cand = adj[o];
       while (true) {
-        int32_t best = -1;
-        uint32_t bw = 0;
-        int bb = 0;
+        uint32_t cp[4], cc[4], w[4];
+        Adj4 nxt[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          int b = BORDER[q];
-          int32_t nb = adj[(uint64_t)cur * 4 + b];
-          if (nb < 0) continue;
-          if (claim_prev[nb] < r) continue;
-          uint32_t c = __hip_atomic_load(&claim_cur[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (c <= r) continue;
-          uint32_t w = weight[(uint32_t)nb >> 1];
-          if (best < 0 || w > bw) { best = nb; bw = w; bb = b; }
+        for (int b = 0; b < 4; b++) {
+          int32_t nb = cand.v[b];
+          uint32_t idx = nb < 0 ? o : (uint32_t)nb;        // harmless address for absent candidates
+          cp[b] = claim_prev[idx];
+          cc[b] = __hip_atomic_load(&claim_cur[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w[b] = weight[idx >> 1];
+          nxt[b] = adj[idx];
         }
+        int best = -1;
+        uint32_t bw = 0;
+        // BASES = ['A','G','C','T'] (extension_correction.py:10): codes 0,2,1,3; strict > keeps the first
+#define CONSIDER(b) if (cand.v[b] >= 0 && cp[b] >= r && cc[b] > r && (best < 0 || w[b] > bw)) { best = b; bw = w[b]; }
+        CONSIDER(0) CONSIDER(2) CONSIDER(1) CONSIDER(3)
+#undef CONSIDER
         if (best < 0) break;
-        uint32_t old = atomicMin(&claim_cur[best], r);
-        if (old < r) continue;                 // an earlier walk took it meanwhile: re-evaluate
+        uint32_t nbest = (uint32_t)cand.v[best];
+        __hip_atomic_fetch_min(&claim_cur[nbest], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (EMIT) {
-          if (dir == 0) dst[nl_known + k + steps] = ALPHA[bb];
-          else dst[nl_known - 1 - steps] = ALPHA[bb];
+          if (dir == 0) dst[nl_known + k + steps] = "ACGT"[best];
+          else dst[nl_known - 1 - steps] = "ACGT"[best];
         }
         steps++;
         tot += bw;
-        h = shn_mix64(h ^ (uint64_t)best);
-        cur = (uint32_t)best;
+        h = shn_mix64(h ^ (uint64_t)nbest);
+        cand = best == 0 ? nxt[0] : best == 1 ? nxt[1] : best == 2 ? nxt[2] : nxt[3];
       }
       if (dir == 0) nr = steps; else nl = steps;
     }
   }
   if (!EMIT) {
     uint64_t hh = isvoid ? 0ULL : (h | 1ULL);
-    if (hash_io[r] != hh) { hash_io[r] = hh; atomicExch(changed, 1u); }
+    if (hash_io[r] != hh) { hash_io[r] = hh; atomicMin(changed, r); }   // changed = lowest rank whose path changed
     nr_out[r] = isvoid ? UNCLAIMED : nr;
     nl_out[r] = nl;
     totw_out[r] = tot;
   }
+}
+
+// Freeze the claims of the walks that just became final into `fin`, and merge every final claim into
+// `cur`, which is the next iteration's claim_prev (final claims have rank < first <= any live walk).
+__global__ void ext_freeze_kernel(uint32_t* __restrict__ cur, uint32_t* __restrict__ fin, uint64_t n2, uint32_t newfirst) {
+  uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n2) return;
+  uint32_t c = cur[o];
+  uint32_t f = fin[o];
+  if (c < newfirst && c < f) { fin[o] = c; f = c; }
+  if (f < c) cur[o] = f;
 }
 
 extern "C" void shn_ext_destroy(shn_ext* e) {
@@ -218,6 +239,7 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
   TRYE(hipMalloc(&e->d_claim, (2 * n + 1) * 4));
   TRYE(hipMalloc(&e->d_claim2, (2 * n + 1) * 4));
   if (n) {
+    TimerRegion t1(ctx, T_EXT_PREP);
     hipLaunchKernelGGL(ext_prepare_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, t->d_counts, n, t->k,
                        t->canonical, e->d_weight, e->d_flags);
     hipLaunchKernelGGL(ext_adjacency_kernel, dim3((uint32_t)cdiv(n * 16, 256)), dim3(256), 0, s, t->d_keys, t->d_bucket_off,
@@ -239,10 +261,13 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
   TRYE(hipMemcpyAsync(&ns, d_cnt, 8, hipMemcpyDeviceToHost, s));
   TRYE(hipStreamSynchronize(s));
   e->n_seeds = ns;
-  if ((rc = shn_sort_pairs(ctx, skeys, svals, (uint64_t*)pk2, (uint32_t*)pv2, ns, 0, 2 * t->k))) { shn_ext_destroy(e); return rc; }
-  if (ns) {
-    hipLaunchKernelGGL(ext_weightkey_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, svals, e->d_weight, ns, skeys);
-    if ((rc = shn_sort_pairs(ctx, skeys, svals, (uint64_t*)pk2, (uint32_t*)pv2, ns, 0, 32))) { shn_ext_destroy(e); return rc; }
+  {
+    TimerRegion t2(ctx, T_EXT_SORT);
+    if ((rc = shn_sort_pairs(ctx, skeys, svals, (uint64_t*)pk2, (uint32_t*)pv2, ns, 0, 2 * t->k))) { shn_ext_destroy(e); return rc; }
+    if (ns) {
+      hipLaunchKernelGGL(ext_weightkey_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, svals, e->d_weight, ns, skeys);
+      if ((rc = shn_sort_pairs(ctx, skeys, svals, (uint64_t*)pk2, (uint32_t*)pv2, ns, 0, 32))) { shn_ext_destroy(e); return rc; }
+    }
   }
   TRYE(hipMalloc(&e->d_order, (ns + 1) * 4));
   TRYE(hipMalloc(&e->d_nr, (ns + 1) * 4));
@@ -252,26 +277,40 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
   TRYE(hipMemcpyAsync(e->d_order, svals, ns * 4, hipMemcpyDeviceToDevice, s));
   TRYE(hipMemsetAsync(e->d_hash, 0xFF, (ns + 1) * 8, s));
   TRYE(hipMemsetAsync(e->d_claim, 0xFF, (2 * n + 1) * 4, s));
-  uint32_t* prev = e->d_claim;
-  uint32_t* cur = e->d_claim2;
+  // d_claim accumulates FINAL claims; prev/cur hold the claims of the not-yet-final walks.
+  uint32_t *prev = nullptr, *cur = nullptr, *fin = e->d_claim;
+  void* pprev;
+  if ((rc = g_shn_ws[24].get((2 * n + 2) * 4, &pprev))) { shn_ext_destroy(e); return rc; }
+  prev = (uint32_t*)pprev;
+  cur = e->d_claim2;
+  TRYE(hipMemsetAsync(prev, 0xFF, (2 * n + 1) * 4, s));
   int it = 0;
+  uint32_t first = 0;                       // walks [0, first) are final
   bool converged = ns == 0;
   while (!converged && it < max_iterations) {
+    TimerRegion t3(ctx, T_EXT_WALK);
     TRYE(hipMemsetAsync(cur, 0xFF, (2 * n + 1) * 4, s));
-    TRYE(hipMemsetAsync(d_changed, 0, 4, s));
-    hipLaunchKernelGGL(ext_walk_kernel<false>, dim3((uint32_t)cdiv(ns, EBLK)), dim3(EBLK), 0, s, e->d_order, (uint64_t)ns, nullptr,
-                       e->d_adjR, e->d_adjL, e->d_weight, prev, cur, e->d_nr, e->d_nl, e->d_totw, e->d_hash, d_changed,
+    TRYE(hipMemsetAsync(d_changed, 0xFF, 4, s));
+    uint64_t nw = ns - first;
+    hipLaunchKernelGGL(ext_walk_kernel<false>, dim3((uint32_t)cdiv(nw, EBLK)), dim3(EBLK), 0, s, e->d_order, nw, nullptr,
+                       e->d_adjR, e->d_adjL, e->d_weight, prev, first, cur, e->d_nr, e->d_nl, e->d_totw, e->d_hash, d_changed,
                        t->d_keys, t->k, nullptr, nullptr);
     uint32_t ch = 0;
     TRYE(hipMemcpyAsync(&ch, d_changed, 4, hipMemcpyDeviceToHost, s));
     TRYE(hipStreamSynchronize(s));
     it++;
+    if (getenv("SHN_DEBUG")) fprintf(stderr, "[shn_extend] iteration %d: first=%u lowest_changed=%u walks=%llu\n", it, first, ch, (unsigned long long)nw);
+    // walk q = lowest rank that changed is final now (every lower rank was unchanged, hence final),
+    // and so is every walk below it: freeze [first, q] and never recompute them.
+    uint32_t newfirst = ch == UNCLAIMED ? (uint32_t)ns : ch + 1;
+    hipLaunchKernelGGL(ext_freeze_kernel, dim3((uint32_t)cdiv(2 * n, 256)), dim3(256), 0, s, cur, fin, 2 * n, newfirst);
+    first = newfirst;
     std::swap(prev, cur);
-    if (!ch) converged = true;
+    if (ch == UNCLAIMED) converged = true;
   }
   e->iterations = it;
   if (!converged) { shn_ext_destroy(e); return shn_fail(SHN_ERR_INTERNAL, "shn_extend: walk fixpoint did not converge"); }
-  if (prev != e->d_claim) std::swap(e->d_claim, e->d_claim2);   // d_claim = converged claims
+  e->d_claim2 = (cur == (uint32_t*)pprev) ? prev : cur;          // keep the malloc'd scratch (the other one is workspace)
   TRYE(hipGetLastError());
 #undef TRYE
   *out = e;
@@ -308,7 +347,7 @@ extern "C" int shn_ext_emit(shn_ctx* ctx, const shn_ext* e, const uint32_t* rank
   HIP_TRY(hipMemcpyAsync(d_off, offsets, (n_sel + 1) * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(e->d_claim2, 0xFF, (2 * e->n + 1) * 4, s));
   hipLaunchKernelGGL(ext_walk_kernel<true>, dim3((uint32_t)cdiv(n_sel, EBLK)), dim3(EBLK), 0, s, e->d_order, n_sel, d_sel,
-                     e->d_adjR, e->d_adjL, e->d_weight, e->d_claim, e->d_claim2, e->d_nr, e->d_nl, e->d_totw, e->d_hash,
+                     e->d_adjR, e->d_adjL, e->d_weight, e->d_claim, 0u, e->d_claim2, e->d_nr, e->d_nl, e->d_totw, e->d_hash,
                      nullptr, e->table->d_keys, e->k, d_off, d_out);
   HIP_TRY(hipMemcpyAsync(bases_out, d_out, total, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
