@@ -20,7 +20,7 @@ import torch
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def gen_reads(n_pairs, seed, n_genes, device):
+def gen_reads(n_pairs, seed, n_genes, device, read_seed=None):
     """synthetic pairs on the GPU (torch RNG; same model as shannon_amd/synth.py)."""
     from shannon_amd import synth
     # config 2 ("single component"): one gene family rich enough to give a multi-contig component
@@ -32,7 +32,7 @@ def gen_reads(n_pairs, seed, n_genes, device):
     wts = expr * (lens - 300 + 1)
     wts /= wts.sum()
     g = torch.Generator(device=device)
-    g.manual_seed(seed + 2)
+    g.manual_seed(seed + 2 if read_seed is None else read_seed)
     cat = torch.as_tensor(np.concatenate(iso), device=device)
     offs = torch.as_tensor(np.concatenate([[0], np.cumsum(lens)[:-1]]), device=device)
     tl = torch.as_tensor(lens, device=device)
@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--K", type=int, default=25)
     ap.add_argument("--genes", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-distributed", action="store_true", help="run the multi-GPU code path even with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -91,8 +92,8 @@ def main():
     from shannon_amd import device, exchange
     k1 = args.K + 1
     dev = torch.device("cuda", local if world > 1 else 0)
-    seed = 20240501 + 1000 * rank
-    r1, r2 = gen_reads(args.reads // 2, seed, args.genes, dev)
+    seed = 20240501
+    r1, r2 = gen_reads(args.reads // 2, seed, args.genes, dev, read_seed=seed + 2 + 1000 * rank)
     ctx = device.Context(local if world > 1 else 0)
     sets = [device.Reads.from_codes(ctx, r1), device.Reads.from_codes(ctx, r2)]
     n_reads = len(sets[0]) + len(sets[1])
@@ -105,12 +106,21 @@ def main():
         def close(self):
             pass
 
+    use_dist = world > 1 or args.force_distributed
+    if use_dist and dist is None:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from shannon_amd import distributed
+
     def step():
-        if world > 1:
-            t = device.count_k1mers(ctx, sets, k1, both_strands=True)
-            owned = exchange.exchange_table(ctx, t)
-            t.close()
-            return owned
+        if use_dist:
+            ops = distributed.GpuOps(ctx, sets[0], sets[1], store, args.K)
+            res = distributed.assemble_distributed(ops, args.K, 500, "bench", 1, timings=stage_t)
+            d = _Done()
+            d.res = res
+            return d
         R = pipeline.assemble_resident(ctx, sets[0], sets[1], store, K=args.K, sample="bench", seed=1, timings=stage_t)
         d = _Done()
         d.R = R
@@ -139,8 +149,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     timers = ctx.timers()
-    if world > 1:
-        distinct, total = len(last), last.total
+    if use_dist:
+        distinct, total = (last.res["n_k1mers"] if rank == 0 else 0), None
     else:
         distinct, total = last.R.n_k1mers, last.R.n_windows
     if rank == 0:
@@ -160,15 +170,16 @@ def main():
             "value": n_reads * world * args.steps / dt, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "10M synthetic 2x100bp paired reads per GPU, k=25 (k1=26), single gene family",
+            "config": {"workload": "10M synthetic 2x100bp paired reads per GPU, k=25 (k1=26), single gene family, 0.5% substitution errors (BASELINE configs[1])",
                        "reads_per_gpu": n_reads, "K": args.K,
-                       "stages": ("count + all-to-all exchange + reduce-by-key ONLY (multi-GPU graph stages not built yet)" if world > 1 else
+                       "stages": ("full path a1-a31, sharded: local count -> all-to-all bucket exchange -> replicated extension -> local routing -> "
+                                  "owner-side graph + sparse flow -> gather + merge on rank 0" if use_dist else
                                   "full path a1-a31: count -> extension -> partition/route -> multibridged graph -> sparse flow -> merge"),
                        "host_stage_seconds_per_step": {k: v / (args.steps + args.warmup) for k, v in stage_t.items()},
-                       "transcripts": (len(last.R.final) if world == 1 else None),
-                       "extension_iterations": (last.R.extension.iterations if world == 1 else None),
-                       "extension_walks": (last.R.extension.n_walks if world == 1 else None),
-                       "partitions": ({k: [v["n_reads_routed"], v["n_k1mers"]] for k, v in last.R.partitions.items()} if world == 1 else None),
+                       "transcripts": (len(last.res["final"]) if use_dist else len(last.R.final)),
+                       "extension_iterations": (None if use_dist else last.R.extension.iterations),
+                       "extension_walks": (None if use_dist else last.R.extension.n_walks),
+                       "partitions": (len(last.res["partitions"]) if use_dist else {k: [v["n_reads_routed"], v["n_k1mers"]] for k, v in last.R.partitions.items()}),
                        "windows_per_step": total, "distinct_k1mers": distinct},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
@@ -177,11 +188,19 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(k1, 20240501, 1_000_000)
-        print(json.dumps(out), flush=True)
+        final_line = json.dumps(out)
+    else:
+        final_line = None
     last.close()
     ctx.close()
     if dist:
         dist.destroy_process_group()
+    if final_line is not None:
+        # RCCL prints a version banner through C stdio; flush it first so the JSON is the last line
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(final_line, flush=True)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""shannon.py -- command line of the MI355X-native Shannon hot path.
+
+Keeps the reference CLI (sreeramkannan/Shannon shannon.py:145-321) for the flags that drive the
+hot path and produces the same products: OUT/shannon.fasta, OUT/log.txt, OUT/TEMP/ (shannon.py:
+634-638).  Flags that only select external tools outside the path (quorum, kallisto, --compare,
+--filter_FP) are accepted and reported as not built.
+
+    python shannon.py -o OUT --single reads.fasta            [-K 25] [--partition 500]
+    python shannon.py -o OUT --left r1.fasta --right r2.fasta [-s / --ss / --strand_specific]
+"""
+import os, sys, time, json
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+VERSION = "0.1.0-mi355x"
+
+
+def usage():
+    print(__doc__)
+
+
+def read_fasta(path):
+    """2-line or multi-line FASTA/FASTQ -> list of sequences (upper case kept as in the file)."""
+    seqs = []
+    with open(path) as f:
+        first = f.readline()
+        f.seek(0)
+        if first.startswith("@"):
+            lines = f.read().splitlines()
+            return [lines[i + 1].strip() for i in range(0, len(lines) - 1, 4)]
+        cur = None
+        for line in f:
+            if line.startswith(">"):
+                if cur is not None:
+                    seqs.append(cur)
+                cur = ""
+            elif cur is not None:
+                cur += line.strip()
+        if cur is not None:
+            seqs.append(cur)
+    return seqs
+
+
+def main(argv):
+    K, partition_size, nJobs = 24, 500, 1                     # shannon.py:58,65,67
+    out_dir, reads, double_stranded = None, [], True
+    min_weight, min_length = 3, 75                            # shannon.py:55-56
+    i = 1
+    ignored = []
+    while i < len(argv):
+        a = argv[i]
+        if a in ("--help", "-h"):
+            usage(); return 0
+        if a == "--version":
+            print(VERSION); return 0
+        if a == "-o":
+            out_dir = argv[i + 1]; i += 2; continue
+        if a == "--single":
+            reads = [argv[i + 1]]; i += 2; continue
+        if a == "--left":
+            reads = [argv[i + 1]] + reads[1:]; i += 2; continue
+        if a == "--right":
+            reads = reads[:1] + [argv[i + 1]]; i += 2; continue
+        if a == "-K":
+            K = int(argv[i + 1]); i += 2; continue
+        if a == "-p":
+            nJobs = int(argv[i + 1]); i += 2; continue
+        if a == "--partition":
+            partition_size = int(argv[i + 1]); i += 2; continue
+        if a == "--kmer_hard_cutoff":
+            min_weight = int(argv[i + 1]); i += 2; continue
+        if a in ("-s", "--ss", "--strand_specific"):
+            double_stranded = False; i += 1; continue
+        if a in ("--inMem", "--inDisk", "--fasta", "--fastq", "--only_reads"):
+            i += 1; continue
+        if a in ("--compare", "--kallisto_cutoff", "--kmer_soft_cutoff"):
+            ignored.append(a); i += 2; continue
+        ignored.append(a); i += 1
+    if out_dir is None or not reads:
+        print("ERROR: need -o OUT and --single F or --left F1 --right F2")
+        print("Try running python shannon.py --help for a short manual")
+        return 2
+    if os.path.exists(out_dir) and os.listdir(out_dir):
+        print("ERROR: output directory is not empty")              # shannon.py:255-257
+        return 2
+    if K + 1 > 32:
+        print("ERROR: K+1 must be <= 32"); return 2
+    os.makedirs(out_dir, exist_ok=True)
+    sample = os.path.basename(os.path.normpath(out_dir))
+    temp = os.path.join(out_dir, "TEMP")
+    os.makedirs(temp)
+    log = open(os.path.join(out_dir, "log.txt"), "w")
+
+    def say(msg):
+        line = "%s: %s" % (time.asctime(), msg)
+        print(line)
+        log.write(line + "\n")
+
+    from shannon_amd import device, pipeline
+    say("Starting Shannon run (MI355X hot path %s)" % VERSION)
+    if ignored:
+        say("flags outside the hot path ignored: " + " ".join(ignored))
+    r = [read_fasta(p) for p in reads]
+    paired = len(r) == 2
+    say("Processed No of reads:%d, Avg. Read length: %.2f" % (len(r[0]), sum(len(x) for x in r[0]) / max(1, len(r[0]))))
+    ctx = device.Context(0)
+    T = {}
+    R = pipeline.assemble(ctx, r[0], r[1] if paired else None, K=K, partition_size=partition_size, min_weight=min_weight,
+                          min_length=min_length, sample=sample, seed=0, double_stranded=double_stranded, timings=T)
+    say("%d K-mers loaded; %d contigs; %d partitions" % (R.n_k1mers, len(R.extension.contigs), len(R.partitions)))
+    # TEMP tree: the per-stage products of the reference (shannon.py:496-513, 584-595)
+    from shannon_amd import extension_correction as ec, mbgraph
+    ai = os.path.join(temp, sample + "_algo_input")
+    os.makedirs(ai)
+    ec.write_outputs(R.extension, temp, os.path.join(ai, "k1mer.dict"))
+    for name, p in R.partitions.items():
+        base = os.path.join(temp, "%s_%s" % (sample, name))
+        for sub in ("algo_output", "intermediate"):
+            os.makedirs(base + sub)
+        mbgraph.write_files(p["singles"], p["components"], base + "intermediate")
+        open(os.path.join(base + "algo_output", "reconstructed.fasta"), "w").write(p["reconstructed_fasta"])
+        say("%s has completed: %d transcripts" % (base, p["reconstructed_fasta"].count(">")))
+    alld = os.path.join(temp, sample + "_allalgo_output")
+    os.makedirs(alld)
+    open(os.path.join(alld, "all_reconstructed.fasta"), "w").write("".join(R.all_reconstructed))
+    with open(os.path.join(out_dir, "shannon.fasta"), "w") as f:
+        for name, seq in R.final.items():
+            f.write(">%s\n%s\n" % (name, seq))
+    say("All partitions completed: %d transcripts reconstructed" % len(R.final))
+    say("stage seconds: " + json.dumps({k: round(v, 4) for k, v in T.items()}))
+    log.close()
+    ctx.close()
+    print("-------------------------------------------------")
+    print(time.asctime() + ": Shannon Run Completed")
+    print("-------------------------------------------------")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv))

@@ -1,0 +1,219 @@
+"""Multi-GPU hot path on one node: one process per GPU, torch.distributed ("nccl" = RCCL over xGMI).
+
+Sharding.  Reads are split contiguously by index across ranks.
+  1. every rank counts its shard (canonical k1-mer table), shards the table by
+     owner = fmix64(key ^ SALT) mod W and ONE all-to-all(v) moves each (key,count) to its owner,
+     which reduces by key                                  -- the k-mer bucket exchange, the only
+                                                              all-to-all on the k-mer data path;
+  2. the owned shards (distinct k1-mers, small next to the reads) are all-gathered so every rank
+     holds the global table and runs the deterministic contig extension + partitioning
+     redundantly (the greedy extension is a global sequential order -- it does not shard);
+  3. every rank routes ITS reads against the replicated partition table; partitions are owned by
+     rank (partition index mod W); the reads a partition's graph may consume -- the first
+     10*#nodes+1 in the global strand-doubled order (multibridging.py:26-30) -- are sent to the
+     owner (tiny, because of that cap);
+  4. owners build the multibridged graph and run sparse flow for their partitions; rank 0 gathers
+     the per-partition FASTA and does the final merge.
+The result equals the single-GPU pipeline on the concatenated reads.
+
+`ops` abstracts the per-rank compute (GpuOps: HIP kernels through the C ABI; the CPU tests plug
+an oracle-backed implementation to exercise the collective choreography with gloo).
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+from . import exchange, mbgraph, sparse_flow, post
+from .pipeline import n_kmer_nodes
+
+
+def _all_gather_var(t, group=None):
+    """all-gather of 1-D tensors of different lengths (padded to the max)."""
+    W = dist.get_world_size(group)
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+    ns = [torch.zeros_like(n) for _ in range(W)]
+    dist.all_gather(ns, n, group=group)
+    ns = [int(x.item()) for x in ns]
+    mx = max(ns + [1])
+    pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
+    pad[:t.numel()] = t
+    outs = [torch.empty_like(pad) for _ in range(W)]
+    dist.all_gather(outs, pad, group=group)
+    return torch.cat([o[:k] for o, k in zip(outs, ns)]), ns
+
+
+def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0, part_vectors=None, group=None,
+                         timings=None):
+    """Returns on rank 0 a dict {partitions: {name: fasta}, all_reconstructed, final, contigs}; None elsewhere."""
+    import time
+    T = timings if timings is not None else {}
+
+    def tick(name, t0):
+        T[name] = T.get(name, 0.0) + time.time() - t0
+
+    W, rank = dist.get_world_size(group), dist.get_rank(group)
+    # ---- 1. local count + bucket exchange + reduce by key
+    t0 = time.time()
+    keys, counts, send = ops.local_pairs(W)
+    rk, rc, _ = exchange.all_to_all_pairs(keys, counts, send, group)
+    ok, oc = ops.reduce_pairs(rk, rc)
+    tick("count+exchange", t0)
+    # ---- 2. replicate the (small) distinct-k1-mer table, extension + partitioning on every rank
+    t0 = time.time()
+    gk, _ = _all_gather_var(ok, group)
+    gc, _ = _all_gather_var(oc, group)
+    table = ops.table_from_pairs(gk, gc)
+    tick("allgather table", t0)
+    t0 = time.time()
+    res = ops.extension(table, partition_size)
+    tick("extension", t0)
+    t0 = time.time()
+    part = ops.route(res, K, partition_size, part_vectors)
+    names = list(part["new_components"])
+    P = len(names)
+    # ---- 3. global strand-doubled order + per-partition cap
+    n_local = ops.n_reads()
+    nl = torch.tensor([n_local], dtype=torch.int64, device=ops.device)
+    nls = [torch.zeros_like(nl) for _ in range(W)]
+    dist.all_gather(nls, nl, group=group)
+    nls = [int(x.item()) for x in nls]
+    base, n_glob = sum(nls[:rank]), sum(nls)
+    cnt = np.zeros((P, 2), dtype=np.int64)          # routed reads of this rank: forward half / RC half
+    for i, nm in enumerate(names):
+        r = part["routes"][nm]
+        f = int(np.searchsorted(r, n_local))
+        cnt[i] = (f, len(r) - f)
+    ct = torch.as_tensor(cnt.reshape(-1), device=ops.device)
+    cts = [torch.zeros_like(ct) for _ in range(W)]
+    dist.all_gather(cts, ct, group=group)
+    allc = np.stack([c.cpu().numpy().reshape(P, 2) for c in cts])       # [W, P, 2]
+    # position of this rank's first forward / first RC routed read of partition p in the global order
+    fwd_before = allc[:rank, :, 0].sum(axis=0)
+    rc_before = allc[:, :, 0].sum(axis=0) + allc[:rank, :, 1].sum(axis=0)
+    send_lists = [[] for _ in range(W)]
+    for i, nm in enumerate(names):
+        cutoff = 10 * n_kmer_nodes(part["k1mers"][nm], K) + 1
+        r = part["routes"][nm]
+        f = int(cnt[i, 0])
+        keep_f = int(max(0, min(f, cutoff - fwd_before[i])))
+        keep_r = int(max(0, min(len(r) - f, cutoff - rc_before[i])))
+        owner = i % W
+        for d in r[:keep_f].tolist():
+            send_lists[owner].append((i, base + d, d))
+        for d in r[f:f + keep_r].tolist():
+            send_lists[owner].append((i, n_glob + base + (d - n_local), d))
+    paired = ops.paired
+    payload = [[(p, g, ops.mate1(d), ops.mate2(d) if paired else None) for p, g, d in lst] for lst in send_lists]
+    recv = [None] * W
+    dist.all_to_all_object_list(recv, payload, group=group) if hasattr(dist, "all_to_all_object_list") else _a2a_objects(recv, payload, group)
+    tick("route+read exchange", t0)
+    # ---- 4. owned partitions: graph + sparse flow
+    t0 = time.time()
+    mine = {}
+    for lst in recv:
+        for p, g, m1, m2 in lst:
+            mine.setdefault(p, []).append((g, m1, m2))
+    owned = [i for i in range(P) if i % W == rank]
+    jobs = []
+    for i in owned:
+        recs = sorted(mine.get(i, []))
+        reads = [[x[1] for x in recs], [x[2] for x in recs]] if paired else [[x[1] for x in recs]]
+        g_, singles, comps = mbgraph.run_partition(part["k1mers"][names[i]], reads, K, paired, ops.hits_factory())
+        jobs.append((i, singles, comps))
+    tick("graph", t0)
+    t0 = time.time()
+    flat = [(c["nodes"], c["edges"], c["paths"]) for _, _, comps in jobs for c in comps]
+    ids = [c for _, _, comps in jobs for c in range(len(comps))]
+    trs = ops.sparse_flow(flat, ids, seed) if flat else []
+    k = 0
+    texts = {}
+    for i, singles, comps in jobs:
+        sname = "%s_%s" % (sample, names[i])
+        txt = ""
+        for c in range(len(comps)):
+            txt += sparse_flow.fasta_records(sname, str(c), trs[k])
+            k += 1
+        txt += sparse_flow.single_nodes_fasta(sname, singles)
+        texts[i] = txt
+    tick("sparse flow", t0)
+    gathered = [None] * W
+    dist.all_gather_object(gathered, texts, group=group)
+    if rank != 0:
+        return None
+    merged = {}
+    for d in gathered:
+        merged.update(d)
+    lines = []
+    for i, c in enumerate(res.single_contigs):
+        lines += [">Single_%d\n" % i, c + "\n"]
+    parts = {}
+    for i, nm in enumerate(names):
+        parts[nm] = merged[i]
+        lines += merged[i].splitlines(True)
+    return {"partitions": parts, "all_reconstructed": lines, "final": post.finalize(lines, True), "contigs": res.contigs,
+            "n_k1mers": int(gk.numel())}
+
+
+def _a2a_objects(recv, payload, group):
+    """all-to-all of python objects via all_gather_object (small payloads only)."""
+    W, rank = dist.get_world_size(group), dist.get_rank(group)
+    everything = [None] * W
+    dist.all_gather_object(everything, payload, group=group)
+    for src in range(W):
+        recv[src] = everything[src][rank]
+
+
+class GpuOps(object):
+    """Per-rank compute on the local GPU through the C ABI."""
+
+    def __init__(self, ctx, d1, d2, store, K):
+        from . import device
+        self.ctx, self.d1, self.d2, self.store, self.K = ctx, d1, d2, store, K
+        self.paired = d2 is not None
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self._dev = device
+
+    def n_reads(self):
+        return len(self.d1)
+
+    def local_pairs(self, W):
+        t = self._dev.count_k1mers(self.ctx, [self.d1, self.d2] if self.paired else [self.d1], self.K + 1, True)
+        n = len(t)
+        dk = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+        dc = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        per = t.shard(W, dk.data_ptr(), dc.data_ptr())
+        t.close()
+        return dk, dc, per
+
+    def reduce_pairs(self, rk, rc):
+        torch.cuda.synchronize()
+        t = self._dev.Table.from_pairs(self.ctx, rk.data_ptr(), rc.data_ptr(), rk.numel(), self.K + 1, True)
+        k, c = t.download()
+        t.close()
+        return (torch.as_tensor(k.view(np.int64), device=self.device), torch.as_tensor(c.view(np.int32), device=self.device))
+
+    def table_from_pairs(self, gk, gc):
+        torch.cuda.synchronize()
+        return self._dev.Table.from_pairs(self.ctx, gk.data_ptr(), gc.data_ptr(), gk.numel(), self.K + 1, True)
+
+    def extension(self, table, partition_size):
+        from . import extension_correction as ec
+        res = ec.run_correction(self.ctx, table, 3, 75, partition_size)
+        table.close()
+        return res
+
+    def route(self, res, K, partition_size, part_vectors):
+        from . import kmers_for_component as kfc
+        return kfc.kmers_for_component(self.ctx, res, self.d1, self.d2, K, partition_size, part_vectors=part_vectors)
+
+    def mate1(self, d):
+        return self.store.mate1(d)
+
+    def mate2(self, d):
+        return self.store.mate2(d)
+
+    def hits_factory(self):
+        return None
+
+    def sparse_flow(self, flat, ids, seed):
+        from .pipeline import _sparse_flow_with_ids
+        return _sparse_flow_with_ids(self.ctx, flat, ids, seed)

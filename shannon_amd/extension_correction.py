@@ -100,54 +100,60 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     clen = length[length >= min_length]
     thr = 2 * min_length * math.pow(min_weight, 1 / 4.0)
     keep = []
-    for rnk, L in zip(cand.tolist(), clen.tolist()):
-        tot_kmer = int(nr[rnk]) + int(nl[rnk]) + 1
-        avg_wt = float(int(tw[rnk])) / max(1, tot_kmer)
+    ckm = (nr[cand].astype(np.int64) + nl[cand].astype(np.int64) + 1).tolist()
+    ctw = tw[cand].tolist()
+    for rnk, L, tot_kmer, tot in zip(cand.tolist(), clen.tolist(), ckm, ctw):
+        avg_wt = float(tot) / max(1, tot_kmer)
         if L * math.pow(avg_wt, 1 / 4.0) >= thr:
             keep.append((rnk, L))
     strings = ext.emit([x[0] for x in keep], [x[1] for x in keep]) if keep else []
 
-    # duplicate_check + contig graph, sequential over candidates in seed order (:358-397)
+    # duplicate_check + contig graph, sequential over candidates in seed order (:358-397).
+    # r-mers / K-mers are handled as packed integers; the tie rule of :258-259 (`>=`: the LAST
+    # contig to reach the running maximum wins) is evaluated on the flattened hit sequence.
     rmer_to_contig, cmer_to_contig, conn = {}, {}, {}
     contigs = ["buffer"]
     idx = 0
     C_ = k1 - 1
+    from itertools import chain
     for contig in strings:
         L = len(contig)
-        dup_count, best, best_idx = {}, 0, -1
-        hits = []
-        for i in range(L - r + 1):
-            lst = rmer_to_contig.get(contig[i:i + r])
-            hits.append(lst)
-            if lst is not None:
-                for d in lst:
-                    c = dup_count.get(d, 0) + 1
-                    dup_count[d] = c
-                    if c >= best:
-                        best, best_idx = c, d
-        covered = np.zeros(L + 1, dtype=np.int32)
-        for i, lst in enumerate(hits):
-            if lst is not None and best_idx in lst:
-                covered[i] += 1
-                covered[i + r] -= 1
-        if int((np.cumsum(covered[:L]) > 0).sum()) > f * float(L):
-            continue
+        rkeys = windows_to_keys(contig, r).tolist()
+        hits = [rmer_to_contig.get(x) for x in rkeys]
+        flat = list(chain.from_iterable(h for h in hits if h))
+        if flat:
+            occ = np.asarray(flat, dtype=np.int64)
+            cnt = np.bincount(occ)
+            top = np.nonzero(cnt == cnt.max())[0]
+            rev = occ[::-1]
+            best_idx = int(max(top, key=lambda c: len(occ) - 1 - int(np.argmax(rev == c))))
+            cov = np.zeros(L + 1, dtype=np.int32)
+            for i, h in enumerate(hits):
+                if h and best_idx in h:
+                    cov[i] += 1
+                    cov[i + r] -= 1
+            if int((np.cumsum(cov[:L]) > 0).sum()) > f * float(L):
+                continue
         idx += 1
         contigs.append(contig)
-        conn.setdefault(idx, {})
-        for i in range(L - C_ + 1):
-            cm = contig[i:i + C_]
+        mine = conn.setdefault(idx, {})
+        for cm in windows_to_keys(contig, C_).tolist():
             lst = cmer_to_contig.get(cm)
             if lst is not None:
                 for c2 in lst:
                     if c2 != idx:
-                        conn[idx][c2] = conn[idx].get(c2, 0) + 1
-                        conn[c2][idx] = conn[c2].get(idx, 0) + 1
+                        mine[c2] = mine.get(c2, 0) + 1
+                        o = conn[c2]
+                        o[idx] = o.get(idx, 0) + 1
             else:
                 lst = cmer_to_contig[cm] = []
             lst.append(idx)
-        for i in range(L - r + 1):
-            rmer_to_contig.setdefault(contig[i:i + r], []).append(idx)
+        for x in rkeys:
+            lst = rmer_to_contig.get(x)
+            if lst is None:
+                rmer_to_contig[x] = [idx]
+            else:
+                lst.append(idx)
 
     res = ExtensionResult()
     res.k1 = k1
@@ -158,10 +164,12 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     allowed = {}
     if res.contigs:
         keys = np.concatenate([windows_to_keys(c, k1) for c in res.contigs])
-        uk = np.unique(keys)
-        w = ext.weights(uk)
-        for key, wt in zip(uk.tolist(), w.tolist()):
-            allowed[device.key_to_str(key, k1)] = int(wt)
+        w = ext.weights(keys).tolist()
+        p = 0
+        for c in res.contigs:
+            for i in range(len(c) - k1 + 1):
+                allowed[c[i:i + k1]] = w[p]
+                p += 1
     res.allowed = allowed
     res.connections = conn
     ext.close()

@@ -1,0 +1,115 @@
+"""Worker for tests/test_distributed_cpu.py: runs shannon_amd.distributed.assemble_distributed with
+world_size>1 on the gloo backend, per-rank compute supplied by the oracle (no GPU here)."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import torch.distributed as dist
+from golden_util import MANIFEST, load_inputs, load_case, part_vectors
+from oracle import seqs, count, extension, partition, sparse_flow as osf
+from shannon_amd import distributed, exchange, kmers_for_component as kfc
+
+
+class OracleOps(object):
+    def __init__(self, r1, r2, K):
+        self.r1, self.r2, self.K = r1, r2, K
+        self.paired = r2 is not None
+        self.device = torch.device("cpu")
+        n = len(r1)
+        self.store = kfc.ReadStore(r1, r2)
+
+    def n_reads(self):
+        return len(self.r1)
+
+    def local_pairs(self, W):
+        k1 = self.K + 1
+        recs = list(self.r1) + (list(self.r2) if self.paired else [])
+        recs = recs + [seqs.reverse_complement(r) for r in recs]
+        keys, cnts = count.count_k1mers_packed(recs, k1)
+        canon = np.array([int(k) <= count.rc_key(k, k1) for k in keys], dtype=bool)
+        pal = np.array([int(k) == count.rc_key(k, k1) for k in keys], dtype=bool)
+        ck, cc = keys[canon], cnts[canon].astype(np.int64)
+        cc[pal[canon]] //= 2
+        own = exchange.owner_of(ck, W)
+        order = np.argsort(own, kind="stable")
+        per = np.bincount(own, minlength=W)
+        return torch.as_tensor(ck[order].view(np.int64)), torch.as_tensor(cc[order].astype(np.int32)), per
+
+    def reduce_pairs(self, rk, rc):
+        k = rk.numpy().view(np.uint64)
+        uk, inv = np.unique(k, return_inverse=True)
+        s = np.bincount(inv, weights=rc.numpy().astype(np.float64), minlength=len(uk)).astype(np.int32)
+        return torch.as_tensor(uk.view(np.int64)), torch.as_tensor(s)
+
+    def table_from_pairs(self, gk, gc):
+        k1 = self.K + 1
+        tab = {}
+        for k, c in zip(gk.numpy().view(np.uint64).tolist(), gc.numpy().tolist()):
+            r = count.rc_key(k, k1)
+            if r == k:
+                tab[count.key_to_str(k, k1)] = 2 * c
+            else:
+                tab[count.key_to_str(k, k1)] = c
+                tab[count.key_to_str(r, k1)] = c
+        return tab
+
+    def extension(self, tab, partition_size):
+        return extension.run_correction([(k, tab[k]) for k in sorted(tab, reverse=True)], comp_size_threshold=partition_size)
+
+    def route(self, res, K, partition_size, pv):
+        pv = pv or []
+        nc, k2c = partition.build_partitions([b[0] for b in res.big_components], [p[0] for p in pv], [p[1] for p in pv] if pv else None,
+                                             res.remaining, res.allowed, K)
+        files, _ = partition.partition_k1mers(nc, k2c, K)
+        routes = {n: [] for n in nc}
+        N = len(self.r1)
+        for d in range(2 * N):
+            a = self.store.mate1(d)
+            if a.strip("ACTG"):
+                continue
+            cs = partition.get_comps(a, k2c, K)
+            if self.paired:
+                b = self.store.mate2(d)
+                if b.strip("ACTG"):
+                    continue
+                cs = cs | partition.get_comps(b, k2c, K)
+            for c in cs:
+                routes[c].append(d)
+        return {"new_components": nc, "k1mers": files, "routes": {n: np.array(v, dtype=np.uint32) for n, v in routes.items()}}
+
+    def mate1(self, d):
+        return self.store.mate1(d)
+
+    def mate2(self, d):
+        return self.store.mate2(d)
+
+    def hits_factory(self):
+        return None
+
+    def sparse_flow(self, flat, ids, seed):
+        return [osf.sparse_flow_component(nd, ed, pt, seed=seed, comp_id=c) for (nd, ed, pt), c in zip(flat, ids)]
+
+
+def main():
+    name, out = sys.argv[1], sys.argv[2]
+    dist.init_process_group("gloo")
+    rank, W = dist.get_rank(), dist.get_world_size()
+    m = MANIFEST[name]
+    g = load_case(name)
+    inp = load_inputs(name)
+    n = len(inp[0])
+    lo, hi = rank * n // W, (rank + 1) * n // W
+    r1 = inp[0][lo:hi]
+    r2 = inp[1][lo:hi] if m["paired"] else None
+    psize = m.get("partition_size", 500)
+    pv = [part_vectors(len(b["contigs"]), psize) for b in g["big_components"]] or None
+    res = distributed.assemble_distributed(OracleOps(r1, r2, m["K"]), m["K"], psize, "s", m["sf_seed"], pv)
+    if rank == 0:
+        json.dump({"partitions": res["partitions"], "final": res["final"], "contigs": res["contigs"]}, open(out, "w"))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

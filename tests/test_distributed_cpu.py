@@ -1,0 +1,39 @@
+"""CPU, world_size 2 (gloo): the multi-GPU choreography of shannon_amd.distributed -- bucket
+exchange, table replication, global read order / caps, partition ownership, FASTA gather --
+reproduces the single-process result on the concatenated reads."""
+import json, os, subprocess, sys
+import numpy as np
+import pytest
+from golden_util import *
+from conftest import ROOT
+
+
+def test_owner_hash_matches_device_constant():
+    from shannon_amd import exchange
+    src = open(os.path.join(ROOT, "shannon_amd", "csrc", "count.hip")).read()
+    assert "#define SHARD_SALT 0x%XULL" % exchange.SHARD_SALT in src
+    o = exchange.owner_of(np.arange(1000, dtype=np.uint64), 8)
+    assert o.min() == 0 and o.max() == 7 and np.bincount(o).min() > 80
+
+
+@pytest.mark.parametrize("name,port", [("syn_pe_s0", 29611), ("syn_se_s5", 29612), ("syn_part_s33", 29613)])
+def test_two_ranks_equal_single_process(name, port, tmp_path):
+    from oracle import pipeline as opipe
+    out = str(tmp_path / "res.json")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), name, out],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:]
+    got = json.load(open(out))
+    m = MANIFEST[name]
+    g = load_case(name)
+    inp = load_inputs(name)
+    psize = m.get("partition_size", 500)
+    pv = [part_vectors(len(b["contigs"]), psize) for b in g["big_components"]] or None
+    ref = opipe.assemble(inp[0], inp[1] if m["paired"] else None, K=m["K"], partition_size=psize, sample="s", seed=m["sf_seed"], part_vectors=pv)
+    assert got["contigs"] == ref["contigs"]
+    assert list(got["partitions"]) == list(ref["partitions"])
+    for nm in ref["partitions"]:
+        assert got["partitions"][nm] == ref["partitions"][nm]["reconstructed_fasta"]
+    assert got["final"] == ref["final"]

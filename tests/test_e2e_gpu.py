@@ -50,3 +50,27 @@ def test_end_to_end_vs_oracle(ctx, name):
         for k in can:
             assert approx_eq(can[k], g["partitions"][p]["graph"][k])
     assert R.final == O["final"]                 # final shannon.fasta as {name: sequence}
+
+
+def test_cli_config1_samples_se(tmp_path):
+    """BASELINE configs[0]: Samples/SE_read.fasta, single-end, -K 25, through the shannon.py CLI."""
+    import gzip, subprocess, sys, os
+    from conftest import ROOT
+    from oracle import pipeline as opipe
+    fa = tmp_path / "SE_read.fasta"
+    with gzip.open(os.path.join(GOLD, "data", "SE_read.fasta.gz"), "rt") as f:
+        fa.write_text(f.read())
+    out = tmp_path / "OUT"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "shannon.py"), "-o", str(out), "--single", str(fa), "-K", "25"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:]
+    assert (out / "shannon.fasta").exists() and (out / "log.txt").exists() and (out / "TEMP").is_dir()
+    got = dict((h[1:], s) for h, s in parse_fasta((out / "shannon.fasta").read_text()))
+    ref = opipe.assemble(load_inputs("se_K25")[0], None, K=25, sample="OUT", seed=0)
+    assert got == ref["final"]
+    g = load_case("se_K25")
+    assert (out / "TEMP" / "OUT_algo_input" / "k1mer.dict_contig").read_text().split() == g["contigs"]
+    # a second run into the same non-empty directory is refused, as in shannon.py:255-257
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "shannon.py"), "-o", str(out), "--single", str(fa)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
+    assert p.returncode != 0 and "not empty" in p.stdout
