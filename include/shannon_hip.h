@@ -126,6 +126,16 @@ int shn_ext_emit(shn_ctx* ctx, const shn_ext* e, const uint32_t* ranks, uint64_t
 /* weight (count in the strand-doubled input, 0 if absent or low-complexity) of k1-mer strings */
 int shn_ext_weights(shn_ctx* ctx, const shn_ext* e, const uint64_t* keys, uint64_t n, uint32_t* weights);
 
+/* Host-side (CPU, native) contig bookkeeping of run_correction over the contigs emitted above:
+ * duplicate_check (extension_correction.py:247-270, r=15, f=0.5) and the contig graph by shared
+ * K-mers (:372-397), sequential in seed order as the reference.  accepted_out[i] = 1-based accepted
+ * index of candidate i or 0.  Call once with conn_nb == NULL to get *n_acc_out / *n_conn, then again
+ * with arrays conn_off[n_acc+1], conn_nb[n_conn], conn_w[n_conn]: neighbours of accepted contig a in
+ * the reference's dict insertion order.                                                          */
+int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint64_t n_cand, int k1, int r, double f,
+                     int32_t* accepted_out, uint64_t* n_acc_out, uint64_t* conn_off, int32_t* conn_nb, int32_t* conn_w,
+                     uint64_t* n_conn);
+
 /* ---- read -> partition routing -----------------------------------------------------------------
  * Replaces the read-streaming loops of kmers_for_component (kmers_for_component.py:322-403;
  * get_rmers :186-192, get_comps :194-205).  `probe` maps every k1-mer of every partition's
@@ -142,6 +152,17 @@ int shn_route_reads(shn_ctx* ctx, const shn_reads* r1, const shn_reads* r2, int 
 void shn_routes_destroy(shn_routes* r);
 uint64_t shn_routes_size(const shn_routes* r);
 int shn_routes_download(shn_ctx* ctx, const shn_routes* r, uint32_t* pid, uint32_t* ridx);
+
+/* ---- K-mer seed scans of reads against graph nodes -----------------------------------------------
+ * Replace the per-read Python loops of Read.find_bridging_reads (mbgraph.py:88-111) and known_paths
+ * (mbgraph.py:1355-1388).  `patterns`: plain K-mer keys -> value = id+1 (shn_table_create).
+ * shn_seed_scan: every read, every start in [1, len-K) (the reference's range(1, len(read)-K)) whose
+ * K-mer is a key -> (read, start, id), in (read, start) order; call with out_read == NULL for *n_hits.
+ * shn_seed_ends: table value (0 = absent) of the first and of the last K-mer of every read.      */
+int shn_seed_scan(shn_ctx* ctx, const shn_reads* reads, int K, const shn_table* patterns, uint64_t* n_hits,
+                  uint32_t* out_read, uint32_t* out_start, uint32_t* out_id);
+int shn_seed_ends(shn_ctx* ctx, const shn_reads* reads, int K, const shn_table* patterns, uint32_t* first_id,
+                  uint32_t* last_id);
 
 /* ---- sparse-flow node decomposition ------------------------------------------------------------
  * Replaces the randomized trial loop of path_decompose (path_decompose_sparse.py:100-117): the

@@ -43,6 +43,9 @@ SIGNATURES = {
     "shn_routes_size": (C.c_uint64, [vp]),
     "shn_routes_download": (C.c_int, [vp, vp, vp, vp]),
     "shn_lp_solve_batch": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_uint64, vp]),
+    "shn_contig_graph": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_int, C.c_double, vp, u64p, vp, vp, vp, u64p]),
+    "shn_seed_scan": (C.c_int, [vp, vp, C.c_int, vp, u64p, vp, vp, vp]),
+    "shn_seed_ends": (C.c_int, [vp, vp, C.c_int, vp, vp, vp]),
     "shn_extend": (C.c_int, [vp, vp, C.c_uint32, C.c_int, vpp]),
     "shn_ext_destroy": (None, [vp]),
     "shn_ext_n_walks": (C.c_uint64, [vp]),

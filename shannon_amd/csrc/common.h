@@ -42,6 +42,7 @@ struct TimerRegion {
 
 struct shn_reads {
   shn_ctx* ctx;
+  int device;
   uint64_t n_reads;
   uint32_t fixed_len;      // 0 => ragged
   uint32_t max_len;
@@ -59,6 +60,7 @@ struct shn_reads {
 
 struct shn_table {
   shn_ctx* ctx;
+  int device;
   int k;
   int canonical;
   uint64_t n;              // distinct keys

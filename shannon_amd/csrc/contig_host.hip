@@ -1,0 +1,116 @@
+// Host-side (C++) contig bookkeeping of extension_correction.run_correction, rows a5-a6:
+// duplicate_check (extension_correction.py:247-270) and the contig graph by shared K-mers
+// (:372-397), sequential over the candidate contigs in seed order exactly as the reference.
+// This is control logic over contig bases (the k-mer-level walks are on the GPU, extend.hip); it is
+// native code because at 10M reads ~2,000 candidate contigs x ~2,000 bases of Python dict work
+// were a third of the host time.
+#include "common.h"
+#include <unordered_map>
+#include <vector>
+#include <algorithm>
+#include <cstring>
+
+static inline int code_of(uint8_t c) {
+  switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; }
+}
+
+// packed keys of all k-windows of s[0..L) (assumes ACGT only)
+static void window_keys(const uint8_t* s, uint32_t L, int k, std::vector<uint64_t>& out) {
+  out.clear();
+  if ((int)L < k) return;
+  uint64_t mask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1), v = 0;
+  for (uint32_t i = 0; i < L; i++) {
+    v = ((v << 2) | (uint64_t)(code_of(s[i]) & 3)) & mask;
+    if ((int)i >= k - 1) out.push_back(v);
+  }
+}
+
+struct Conn { std::vector<int32_t> nb; std::vector<int32_t> w; std::unordered_map<int32_t, int32_t> pos; };
+
+// contigs: n_cand candidate strings (bases[off[i]..off[i+1])), in seed order.
+// accepted_out[i] = 1-based accepted index or 0.  Connections are returned as CSR in *insertion order*
+// (the order Python's dict would iterate): conn_off[n_acc+1], conn_nb[], conn_w[] (caller sizes conn_* with
+// the value returned in *n_conn after a first call with conn_nb == NULL).
+extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint64_t n_cand, int k1, int r, double f,
+                                int32_t* accepted_out, uint64_t* n_acc_out, uint64_t* conn_off, int32_t* conn_nb, int32_t* conn_w,
+                                uint64_t* n_conn) {
+  if (!bases || !off || !accepted_out || !n_acc_out || !n_conn) return shn_fail(SHN_ERR_ARG, "shn_contig_graph: NULL argument");
+  static thread_local std::vector<Conn> conns;         // kept between the sizing call and the fill call
+  static thread_local std::vector<int32_t> accepted;
+  static thread_local uint64_t cached_n = ~0ULL;
+  static thread_local const uint8_t* cached_ptr = nullptr;
+  if (!(conn_nb && cached_n == n_cand && cached_ptr == bases)) {
+    std::unordered_map<uint64_t, std::vector<int32_t>> rmer, cmer;
+    rmer.reserve(1 << 16); cmer.reserve(1 << 16);
+    conns.clear(); conns.emplace_back();                 // index 0 unused (contigs are 1-based)
+    accepted.assign(n_cand, 0);
+    std::vector<uint64_t> rk, ck;
+    std::vector<const std::vector<int32_t>*> hits;
+    std::unordered_map<int32_t, int32_t> dup;
+    std::vector<int32_t> cov;
+    const int C = k1 - 1;
+    int32_t idx = 0;
+    for (uint64_t c = 0; c < n_cand; c++) {
+      const uint8_t* s = bases + off[c];
+      uint32_t L = (uint32_t)(off[c + 1] - off[c]);
+      window_keys(s, L, r, rk);
+      hits.assign(rk.size(), nullptr);
+      dup.clear();
+      int32_t max_till_now = 0, best = -1;
+      for (size_t i = 0; i < rk.size(); i++) {
+        auto it = rmer.find(rk[i]);
+        if (it == rmer.end()) continue;
+        hits[i] = &it->second;
+        for (int32_t d : it->second) {
+          int32_t cnt = ++dup[d];
+          if (cnt >= max_till_now) { max_till_now = cnt; best = d; }      // `>=`: the latest wins (:258-259)
+        }
+      }
+      bool suspect = false;
+      if (best >= 0) {
+        cov.assign(L + 1, 0);
+        for (size_t i = 0; i < rk.size(); i++)
+          if (hits[i] && std::find(hits[i]->begin(), hits[i]->end(), best) != hits[i]->end()) { cov[i] += 1; cov[i + r] -= 1; }
+        int64_t run = 0, covered = 0;
+        for (uint32_t i = 0; i < L; i++) { run += cov[i]; if (run > 0) covered++; }
+        suspect = (double)covered > f * (double)L;
+      }
+      if (suspect) continue;
+      idx++;
+      accepted[c] = idx;
+      conns.emplace_back();
+      window_keys(s, L, C, ck);
+      for (uint64_t key : ck) {
+        auto& lst = cmer[key];
+        for (int32_t c2 : lst) {
+          if (c2 == idx) continue;
+          Conn& a = conns[idx];
+          auto pa = a.pos.find(c2);
+          if (pa == a.pos.end()) { a.pos[c2] = (int32_t)a.nb.size(); a.nb.push_back(c2); a.w.push_back(1); } else a.w[pa->second]++;
+          Conn& b = conns[c2];
+          auto pb = b.pos.find(idx);
+          if (pb == b.pos.end()) { b.pos[idx] = (int32_t)b.nb.size(); b.nb.push_back(idx); b.w.push_back(1); } else b.w[pb->second]++;
+        }
+        lst.push_back(idx);
+      }
+      for (uint64_t key : rk) rmer[key].push_back(idx);
+    }
+    cached_n = n_cand; cached_ptr = bases;
+  }
+  uint64_t n_acc = conns.size() - 1, total = 0;
+  for (uint64_t i = 1; i <= n_acc; i++) total += conns[i].nb.size();
+  *n_acc_out = n_acc;
+  *n_conn = total;
+  memcpy(accepted_out, accepted.data(), n_cand * sizeof(int32_t));
+  if (conn_nb && conn_w && conn_off) {
+    uint64_t p = 0;
+    for (uint64_t i = 1; i <= n_acc; i++) {
+      conn_off[i - 1] = p;
+      for (size_t j = 0; j < conns[i].nb.size(); j++) { conn_nb[p] = conns[i].nb[j]; conn_w[p] = conns[i].w[j]; p++; }
+    }
+    conn_off[n_acc] = p;
+    cached_n = ~0ULL; cached_ptr = nullptr;
+    conns.clear(); accepted.clear();
+  }
+  return SHN_OK;
+}

@@ -168,6 +168,7 @@ extern "C" int shn_reads_create(shn_ctx* ctx, const uint8_t* bytes, const uint64
   shn_reads* r = new shn_reads();
   memset(r, 0, sizeof(*r));
   r->ctx = ctx;
+  r->device = ctx->device;
   r->n_reads = n_reads;
   std::vector<uint64_t> woff;
   uint64_t total_bytes;
@@ -248,7 +249,7 @@ extern "C" int shn_reads_create(shn_ctx* ctx, const uint8_t* bytes, const uint64
 
 extern "C" void shn_reads_destroy(shn_reads* r) {
   if (!r) return;
-  hipSetDevice(r->ctx->device);
+  hipSetDevice(r->device);
   if (r->d_words) hipFree(r->d_words);
   if (r->d_mask) hipFree(r->d_mask);
   if (r->d_woff) hipFree(r->d_woff);

@@ -476,7 +476,7 @@ static int build_from_keys(shn_ctx* ctx, uint64_t* keysA, uint64_t* keysB, uint3
   uint64_t D = 0;
   shn_table* t = new shn_table();
   memset(t, 0, sizeof(*t));
-  t->ctx = ctx; t->k = k; t->canonical = canonical; t->bits = bits; t->n_buckets = nbk; t->total = total;
+  t->ctx = ctx; t->device = ctx->device; t->k = k; t->canonical = canonical; t->bits = bits; t->n_buckets = nbk; t->total = total;
   {
     TimerRegion tr(ctx, T_COMPACT);
     if ((rc = shn_device_scan_u32(ctx, d_ndist, nbk, d_boff, &D))) { delete t; return rc; }
@@ -501,7 +501,7 @@ static int build_from_keys(shn_ctx* ctx, uint64_t* keysA, uint64_t* keysB, uint3
 
 extern "C" void shn_table_destroy(shn_table* t) {
   if (!t) return;
-  hipSetDevice(t->ctx->device);
+  hipSetDevice(t->device);
   if (t->d_keys) hipFree(t->d_keys);
   if (t->d_counts) hipFree(t->d_counts);
   if (t->d_bucket_off) hipFree(t->d_bucket_off);

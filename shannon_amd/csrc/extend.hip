@@ -23,6 +23,7 @@
 
 struct shn_ext {
   shn_ctx* ctx;
+  int device;
   int k;
   uint64_t n;            // canonical entries
   uint64_t n_seeds;
@@ -212,7 +213,7 @@ __global__ void ext_freeze_kernel(uint32_t* __restrict__ cur, uint32_t* __restri
 
 extern "C" void shn_ext_destroy(shn_ext* e) {
   if (!e) return;
-  hipSetDevice(e->ctx->device);
+  hipSetDevice(e->device);
   void* ptrs[] = {e->d_weight, e->d_flags, e->d_adjR, e->d_adjL, e->d_order, e->d_claim, e->d_claim2, e->d_nr, e->d_nl,
                   e->d_totw, e->d_hash};
   for (void* p : ptrs) if (p) hipFree(p);
@@ -227,7 +228,7 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
   TimerRegion treg(ctx, T_EXTEND);
   shn_ext* e = new shn_ext();
   memset(e, 0, sizeof(*e));
-  e->ctx = ctx; e->k = t->k; e->n = t->n; e->min_weight = min_weight; e->table = t;
+  e->ctx = ctx; e->device = ctx->device; e->k = t->k; e->n = t->n; e->min_weight = min_weight; e->table = t;
   uint64_t n = t->n;
   if (max_iterations <= 0) max_iterations = 100000;
 #define TRYE(x) do { hipError_t _e = (x); if (_e != hipSuccess) { shn_ext_destroy(e); \

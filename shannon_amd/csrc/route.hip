@@ -105,6 +105,7 @@ static RView rview(const shn_reads* r) {
 
 struct shn_routes {
   shn_ctx* ctx;
+  int device;
   uint64_t n;          // number of (partition, doubled read index) pairs
   uint32_t* d_pid;     // sorted by (pid, read index)
   uint32_t* d_ridx;
@@ -112,7 +113,7 @@ struct shn_routes {
 
 extern "C" void shn_routes_destroy(shn_routes* r) {
   if (!r) return;
-  hipSetDevice(r->ctx->device);
+  hipSetDevice(r->device);
   if (r->d_pid) hipFree(r->d_pid);
   if (r->d_ridx) hipFree(r->d_ridx);
   delete r;
@@ -153,6 +154,7 @@ extern "C" int shn_route_reads(shn_ctx* ctx, const shn_reads* r1, const shn_read
   shn_routes* R = new shn_routes();
   memset(R, 0, sizeof(*R));
   R->ctx = ctx;
+  R->device = ctx->device;
   if (N2 == 0) { *out = R; return SHN_OK; }
   uint32_t grid = (uint32_t)cdiv(N2, RBLK);
   hipLaunchKernelGGL(route_kernel<false>, dim3(grid), dim3(RBLK), 0, s, a, b, r2 ? 1 : 0, k1, probe->d_keys, probe->d_counts,

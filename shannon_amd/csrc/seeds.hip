@@ -1,0 +1,115 @@
+// K-mer seed scans of reads against graph nodes (rows a17, a21): the inner loops of
+// Read.find_bridging_reads (mbgraph.py:88-111: every read x every offset 1..len-K-1 probed against the
+// first K bases of the X-nodes) and of known_paths (mbgraph.py:1355-1388: first and last K-mer of every
+// read probed against the index of all K-mers of all nodes).  The string comparisons that follow a
+// seed hit (Read.bridges, search_sequence) stay on the host: hits are few.
+#include "common.h"
+#include <cstring>
+
+#define SBLK2 256
+
+struct SView { const uint64_t* words; const uint64_t* woff; const uint32_t* len; uint64_t n; uint32_t fixed_len, wpr; };
+
+// mode 0: one thread per (read, 64-offset chunk); FILL writes (read, start, id) triples in (read, start) order
+template <bool FILL>
+__global__ __launch_bounds__(SBLK2) void seed_scan_kernel(SView v, int K, uint32_t max_win, const uint64_t* __restrict__ tkeys,
+                                                          const uint32_t* __restrict__ tvals, const uint64_t* __restrict__ boff, int bits,
+                                                          uint32_t* __restrict__ counts, const uint64_t* __restrict__ offs,
+                                                          uint32_t* __restrict__ o_read, uint32_t* __restrict__ o_start, uint32_t* __restrict__ o_id) {
+  uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= v.n * max_win) return;
+  uint64_t r = gid / max_win;
+  uint32_t start = (uint32_t)(gid - r * max_win) + 1;              // range(1, len - K)
+  uint32_t len = v.len ? v.len[r] : v.fixed_len;
+  uint32_t id = 0;
+  if (len > (uint32_t)K && start < len - K) {
+    uint64_t wb = v.woff ? v.woff[r] : r * v.wpr;
+    uint64_t key = shn_extract(v.words + wb, start, K);
+    int64_t j = shn_table_find(tkeys, boff, bits, key);
+    if (j >= 0) id = tvals[j];
+  }
+  if (!FILL) { counts[gid] = id ? 1u : 0u; return; }
+  if (id) { uint64_t o = offs[gid]; o_read[o] = (uint32_t)r; o_start[o] = start; o_id[o] = id - 1; }
+}
+
+// mode 1: first / last K-mer of every read
+__global__ void seed_ends_kernel(SView v, int K, const uint64_t* __restrict__ tkeys, const uint32_t* __restrict__ tvals,
+                                 const uint64_t* __restrict__ boff, int bits, uint32_t* __restrict__ first_id,
+                                 uint32_t* __restrict__ last_id) {
+  uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= v.n) return;
+  uint32_t len = v.len ? v.len[r] : v.fixed_len;
+  uint32_t a = 0, b = 0;
+  if (len >= (uint32_t)K) {
+    uint64_t wb = v.woff ? v.woff[r] : r * v.wpr;
+    int64_t j = shn_table_find(tkeys, boff, bits, shn_extract(v.words + wb, 0, K));
+    if (j >= 0) a = tvals[j];
+    j = shn_table_find(tkeys, boff, bits, shn_extract(v.words + wb, len - K, K));
+    if (j >= 0) b = tvals[j];
+  }
+  first_id[r] = a;
+  last_id[r] = b;
+}
+
+static SView sview(const shn_reads* r) {
+  SView v; v.words = r->d_words; v.woff = r->d_woff; v.len = r->d_len; v.n = r->n_reads; v.fixed_len = r->fixed_len; v.wpr = r->wpr;
+  return v;
+}
+
+// Interior seed hits: every read, every start in [1, len-K): pattern id (table value - 1) if the K-mer is a
+// key of `patterns`.  Call with out_read == NULL to get *n_hits, then with arrays of that size.
+extern "C" int shn_seed_scan(shn_ctx* ctx, const shn_reads* reads, int K, const shn_table* patterns, uint64_t* n_hits,
+                             uint32_t* out_read, uint32_t* out_start, uint32_t* out_id) {
+  if (!ctx || !reads || !patterns || !n_hits) return shn_fail(SHN_ERR_ARG, "shn_seed_scan: NULL argument");
+  if (reads->n_invalid) return shn_fail(SHN_ERR_ARG, "shn_seed_scan: reads contain non-ACGT bases");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  TimerRegion treg(ctx, T_SEEDS);
+  SView v = sview(reads);
+  uint32_t max_win = reads->max_len > (uint32_t)K + 1 ? reads->max_len - K - 1 : 0;
+  uint64_t total = v.n * max_win;
+  if (total == 0) { *n_hits = 0; return SHN_OK; }
+  void *pc, *po;
+  int rc;
+  if ((rc = g_shn_ws[25].get((total + 1) * 4, &pc)) || (rc = g_shn_ws[26].get((total + 2) * 8, &po))) return rc;
+  uint32_t grid = (uint32_t)cdiv(total, SBLK2);
+  hipLaunchKernelGGL(seed_scan_kernel<false>, dim3(grid), dim3(SBLK2), 0, s, v, K, max_win, patterns->d_keys, patterns->d_counts,
+                     patterns->d_bucket_off, patterns->bits, (uint32_t*)pc, nullptr, nullptr, nullptr, nullptr);
+  uint64_t nh = 0;
+  if ((rc = shn_device_scan_u32(ctx, (uint32_t*)pc, total, (uint64_t*)po, &nh))) return rc;
+  *n_hits = nh;
+  if (!out_read || nh == 0) return SHN_OK;
+  uint32_t *d_r, *d_s, *d_i;
+  HIP_TRY(hipMalloc(&d_r, nh * 4)); HIP_TRY(hipMalloc(&d_s, nh * 4)); HIP_TRY(hipMalloc(&d_i, nh * 4));
+  hipLaunchKernelGGL(seed_scan_kernel<true>, dim3(grid), dim3(SBLK2), 0, s, v, K, max_win, patterns->d_keys, patterns->d_counts,
+                     patterns->d_bucket_off, patterns->bits, nullptr, (const uint64_t*)po, d_r, d_s, d_i);
+  HIP_TRY(hipMemcpyAsync(out_read, d_r, nh * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(out_start, d_s, nh * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(out_id, d_i, nh * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  hipFree(d_r); hipFree(d_s); hipFree(d_i);
+  HIP_TRY(hipGetLastError());
+  return SHN_OK;
+}
+
+// first_id[r] / last_id[r] = table value (0 = absent) of the first / last K-mer of read r
+extern "C" int shn_seed_ends(shn_ctx* ctx, const shn_reads* reads, int K, const shn_table* patterns, uint32_t* first_id,
+                             uint32_t* last_id) {
+  if (!ctx || !reads || !patterns || !first_id || !last_id) return shn_fail(SHN_ERR_ARG, "shn_seed_ends: NULL argument");
+  if (reads->n_invalid) return shn_fail(SHN_ERR_ARG, "shn_seed_ends: reads contain non-ACGT bases");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  TimerRegion treg(ctx, T_SEEDS);
+  if (reads->n_reads == 0) return SHN_OK;
+  SView v = sview(reads);
+  uint32_t *d_a, *d_b;
+  HIP_TRY(hipMalloc(&d_a, v.n * 4)); HIP_TRY(hipMalloc(&d_b, v.n * 4));
+  hipLaunchKernelGGL(seed_ends_kernel, dim3((uint32_t)cdiv(v.n, 256)), dim3(256), 0, s, v, K, patterns->d_keys, patterns->d_counts,
+                     patterns->d_bucket_off, patterns->bits, d_a, d_b);
+  HIP_TRY(hipMemcpyAsync(first_id, d_a, v.n * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(last_id, d_b, v.n * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  hipFree(d_a); hipFree(d_b);
+  HIP_TRY(hipGetLastError());
+  return SHN_OK;
+}

@@ -212,7 +212,8 @@ class GpuOps(object):
         return self.store.mate2(d)
 
     def hits_factory(self):
-        return None
+        from . import graph_seeds
+        return graph_seeds.hits_factory(self.ctx)
 
     def sparse_flow(self, flat, ids, seed):
         from .pipeline import _sparse_flow_with_ids

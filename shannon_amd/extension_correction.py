@@ -108,52 +108,30 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
             keep.append((rnk, L))
     strings = ext.emit([x[0] for x in keep], [x[1] for x in keep]) if keep else []
 
-    # duplicate_check + contig graph, sequential over candidates in seed order (:358-397).
-    # r-mers / K-mers are handled as packed integers; the tie rule of :258-259 (`>=`: the LAST
-    # contig to reach the running maximum wins) is evaluated on the flattened hit sequence.
-    rmer_to_contig, cmer_to_contig, conn = {}, {}, {}
+    # duplicate_check + contig graph, sequential over candidates in seed order (:358-397): native host
+    # code (csrc/contig_host.hip, shn_contig_graph); neighbours come back in dict insertion order.
     contigs = ["buffer"]
-    idx = 0
-    C_ = k1 - 1
-    from itertools import chain
-    for contig in strings:
-        L = len(contig)
-        rkeys = windows_to_keys(contig, r).tolist()
-        hits = [rmer_to_contig.get(x) for x in rkeys]
-        flat = list(chain.from_iterable(h for h in hits if h))
-        if flat:
-            occ = np.asarray(flat, dtype=np.int64)
-            cnt = np.bincount(occ)
-            top = np.nonzero(cnt == cnt.max())[0]
-            rev = occ[::-1]
-            best_idx = int(max(top, key=lambda c: len(occ) - 1 - int(np.argmax(rev == c))))
-            cov = np.zeros(L + 1, dtype=np.int32)
-            for i, h in enumerate(hits):
-                if h and best_idx in h:
-                    cov[i] += 1
-                    cov[i + r] -= 1
-            if int((np.cumsum(cov[:L]) > 0).sum()) > f * float(L):
-                continue
-        idx += 1
-        contigs.append(contig)
-        mine = conn.setdefault(idx, {})
-        for cm in windows_to_keys(contig, C_).tolist():
-            lst = cmer_to_contig.get(cm)
-            if lst is not None:
-                for c2 in lst:
-                    if c2 != idx:
-                        mine[c2] = mine.get(c2, 0) + 1
-                        o = conn[c2]
-                        o[idx] = o.get(idx, 0) + 1
-            else:
-                lst = cmer_to_contig[cm] = []
-            lst.append(idx)
-        for x in rkeys:
-            lst = rmer_to_contig.get(x)
-            if lst is None:
-                rmer_to_contig[x] = [idx]
-            else:
-                lst.append(idx)
+    conn = {}
+    if strings:
+        joined = "".join(strings).encode()
+        offs = np.zeros(len(strings) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(x) for x in strings], dtype=np.uint64)
+        buf = np.frombuffer(joined, dtype=np.uint8)
+        acc = np.zeros(len(strings), dtype=np.int32)
+        n_acc, n_conn = C.c_uint64(0), C.c_uint64(0)
+        _lib.check(_lib.lib().shn_contig_graph(buf.ctypes.data, offs.ctypes.data, len(strings), k1, r, float(f), acc.ctypes.data,
+                                               C.byref(n_acc), None, None, None, C.byref(n_conn)))
+        coff = np.zeros(n_acc.value + 1, dtype=np.uint64)
+        cnb = np.zeros(max(1, n_conn.value), dtype=np.int32)
+        cw = np.zeros(max(1, n_conn.value), dtype=np.int32)
+        _lib.check(_lib.lib().shn_contig_graph(buf.ctypes.data, offs.ctypes.data, len(strings), k1, r, float(f), acc.ctypes.data,
+                                               C.byref(n_acc), coff.ctypes.data, cnb.ctypes.data, cw.ctypes.data, C.byref(n_conn)))
+        for i in np.nonzero(acc)[0].tolist():
+            contigs.append(strings[i])
+        coff = coff.tolist()
+        cnb, cw = cnb.tolist(), cw.tolist()
+        for a in range(n_acc.value):
+            conn[a + 1] = dict(zip(cnb[coff[a]:coff[a + 1]], cw[coff[a]:coff[a + 1]]))
 
     res = ExtensionResult()
     res.k1 = k1

@@ -46,6 +46,9 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
     """Same as assemble() with the reads already packed in HBM (d1/d2: device.Reads)."""
     T = timings if timings is not None else {}
     paired = d2 is not None
+    if hits_factory is None:
+        from . import graph_seeds
+        hits_factory = graph_seeds.hits_factory(ctx)
 
     def tick(name, t0):
         T[name] = T.get(name, 0.0) + time.time() - t0

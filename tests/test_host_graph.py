@@ -89,3 +89,49 @@ def test_own_partitioner_is_balanced_and_deterministic():
     assert p == kfc.partition_graph(text, 6, 1000)
     sizes = np.bincount(p, minlength=6)
     assert sizes.sum() == n and sizes.max() <= 2 * n / 6 and set(p) == set(range(6))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_native_contig_graph_matches_oracle(name):
+    """shn_contig_graph (native host code, no GPU needed): duplicate_check + contig graph in the
+    reference's order, fed with the oracle's unfiltered candidate contigs."""
+    import ctypes as C, math
+    from shannon_amd import _lib, build
+    build.build(verbose=False)
+    g = load_case(name)
+    K = g["K"]
+    inp = load_inputs(name)
+    dbl = list(seqs.double_strand_paired(*inp)) if g["paired"] else [seqs.double_strand_single(inp[0])]
+    tab = count.count_k1mers_dict([r for f in dbl for r in f], K + 1)
+    kmers, k1 = extension.load_kmers([(k, tab[k]) for k in sorted(tab, reverse=True)])
+    heaviest = sorted(kmers.items(), key=lambda kv: kv[1])
+    traversed, cands = set(), []
+    while heaviest:
+        s, w = heaviest.pop()
+        if w < 3:
+            break
+        if s in traversed:
+            continue
+        traversed.add(s)
+        r_, rw, rn = extension._extend(s, True, traversed, kmers, k1)
+        l_, lw, ln = extension._extend(s, False, traversed, kmers, k1)
+        contig = "".join(reversed(l_)) + s + "".join(r_)
+        avg = (rw + lw + kmers[s]) / max(1, rn + ln + 1)
+        if len(contig) >= 75 and len(contig) * math.pow(avg, 0.25) >= 2 * 75 * math.pow(3, 0.25):
+            cands.append(contig)
+    ref = extension.run_correction([(k, tab[k]) for k in sorted(tab, reverse=True)])
+    buf = np.frombuffer("".join(cands).encode(), dtype=np.uint8)
+    offs = np.zeros(len(cands) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(c) for c in cands])
+    acc = np.zeros(len(cands), dtype=np.int32)
+    na, nc = C.c_uint64(0), C.c_uint64(0)
+    L = _lib.lib()
+    _lib.check(L.shn_contig_graph(buf.ctypes.data, offs.ctypes.data, len(cands), k1, 15, 0.5, acc.ctypes.data, C.byref(na), None, None, None, C.byref(nc)))
+    coff = np.zeros(na.value + 1, dtype=np.uint64)
+    cnb = np.zeros(max(1, nc.value), dtype=np.int32)
+    cw = np.zeros(max(1, nc.value), dtype=np.int32)
+    _lib.check(L.shn_contig_graph(buf.ctypes.data, offs.ctypes.data, len(cands), k1, 15, 0.5, acc.ctypes.data, C.byref(na), coff.ctypes.data,
+                                  cnb.ctypes.data, cw.ctypes.data, C.byref(nc)))
+    assert [cands[i] for i in np.nonzero(acc)[0]] == ref.contigs
+    conn = {a + 1: list(zip(cnb[int(coff[a]):int(coff[a + 1])].tolist(), cw[int(coff[a]):int(coff[a + 1])].tolist())) for a in range(na.value)}
+    assert conn == {k: list(v.items()) for k, v in ref.connections.items()}      # same neighbours, weights AND insertion order
