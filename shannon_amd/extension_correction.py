@@ -37,6 +37,10 @@ class Extension(object):
     def iterations(self):
         return int(_lib.lib().shn_ext_iterations(self.h))
 
+    @property
+    def total_steps(self):
+        return int(_lib.lib().shn_ext_total_steps(self.h))
+
     def stats(self):
         n = self.n_walks
         nr = np.empty(n, np.uint32)
@@ -137,6 +141,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     res.k1 = k1
     res.iterations = ext.iterations
     res.n_walks = ext.n_walks
+    res.total_steps = ext.total_steps
     res.contigs = contigs[1:]
     # allowed k1-mers with their integer weights (:366-369, :404-408): GPU table lookup
     allowed = {}
