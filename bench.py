@@ -18,6 +18,9 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r01_*):
+# FETCH_SIZE doubled for the streaming reads as MI355X_MICROARCH.md (HBM) prescribes, WRITE_SIZE as read; 10M-read step.
+TRAFFIC = {}
 
 
 def gen_reads(n_pairs, seed, n_genes, device, read_seed=None):
@@ -155,16 +158,29 @@ def main():
         distinct, total = last.R.n_k1mers, last.R.n_windows
     if rank == 0:
         ms_step = 1000.0 * dt / args.steps
-        # dominant kernel group by HIP-event time on the ctx stream
-        groups = {k: v for k, v in timers.items() if k.startswith("count.") and k != "count.total"}
-        dom = max(groups, key=lambda k: groups[k][0])
+        # Kernel groups timed with HIP events on the context stream (shn_timer_*).  `roofline` describes the
+        # dominant group by time; algorithmic bytes per unit are the figures of DESIGN.md section 3.
         W = 100 - k1 + 1
         alg = {"count.hist1": 25.0, "count.scatter1": 25.0 + 8.0 * W, "count.hist2": 8.0 * W,
-               "count.scatter2": 16.0 * W, "count.buckets": 8.0 * W, "count.compact": 0.0}
+               "count.scatter2": 16.0 * W, "count.buckets": 8.0 * W, "count.compact": 0.0, "route": 192.0}
+        groups = {k: v for k, v in timers.items() if k in alg or k == "extend.walk"}
+        dom = max(groups, key=lambda k: groups[k][0])
         launches = groups[dom][1]
         avg_ms = groups[dom][0] / launches
-        reads_per_launch = n_reads * args.steps / launches
-        achieved = alg[dom] * reads_per_launch / (avg_ms * 1e-3) / 1e9
+        if dom == "extend.walk":
+            # latency-bound pointer chasing: 128 algorithmic bytes per walk step (adjacency row, 4 candidates'
+            # claims/weights, 4 prefetched rows); one "launch" = one fixpoint iteration
+            steps_total = last.R.extension.total_steps if not use_dist else 0
+            per_launch_bytes = 128.0 * steps_total / max(1, last.R.extension.iterations if not use_dist else 1)
+            unit_bytes = None
+        else:
+            per_launch_bytes = alg[dom] * n_reads * args.steps / launches
+            unit_bytes = alg[dom]
+        achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+        bw_groups = {k: v for k, v in groups.items() if k != "extend.walk"}
+        bdom = max(bw_groups, key=lambda k: bw_groups[k][0])
+        b_ms = bw_groups[bdom][0] / bw_groups[bdom][1]
+        b_ach = alg[bdom] * n_reads * args.steps / bw_groups[bdom][1] / (b_ms * 1e-3) / 1e9
         out = {
             "metric": "reads/sec k-mer->graph->path-decompose, 2x100bp k=25",
             "value": n_reads * world * args.steps / dt, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
@@ -182,8 +198,13 @@ def main():
                        "partitions": (len(last.res["partitions"]) if use_dist else {k: [v["n_reads_routed"], v["n_k1mers"]] for k, v in last.R.partitions.items()}),
                        "windows_per_step": total, "distinct_k1mers": distinct},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_read": alg[dom], "avg_launch_ms": avg_ms},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC.get(dom),
+                         "algorithmic_bytes_per_read": unit_bytes, "avg_launch_ms": avg_ms,
+                         "note": ("latency-bound walk fixpoint (pointer chasing); the dominant bandwidth-bound kernel is reported in "
+                                  "roofline_bandwidth_kernel" if dom == "extend.walk" else None)},
+            "roofline_bandwidth_kernel": {"bound": "hbm", "kernel": bdom, "achieved": b_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": b_ach / HBM_PEAK_GBS, "traffic": TRAFFIC.get(bdom),
+                                          "algorithmic_bytes_per_read": alg[bdom], "avg_launch_ms": b_ms},
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(timers.items())},
         }
         if not args.no_cpu_baseline:

@@ -165,6 +165,26 @@ int shn_seed_scan(shn_ctx* ctx, const shn_reads* reads, int K, const shn_table* 
 int shn_seed_ends(shn_ctx* ctx, const shn_reads* reads, int K, const shn_table* patterns, uint32_t* first_id,
                   uint32_t* last_id);
 
+/* ---- multibridged de-Bruijn graph of one partition (host, native) ----------------------------------
+ * Replaces multibridging.main for one partition (multibridging.py:327-400: load_single_jellyfish
+ * :145-172, load_reads / load_mated_reads :22-97, run :209-269, output_components :271-325 over the
+ * live methods of mbgraph.py).  `rows`: the n_rows k1-mers (K+1 bytes each, no separator) of the
+ * partition's k1mer file in file order; reads: ASCII, r_off[n_reads+1] (the first 10*#K-mer-nodes+1 are
+ * used, multibridging.py:26-30); Read.L = length of the first read.  The result is the content of
+ * single_nodes.txt and nodes/edges/paths{c}.txt, flattened: see shn_graph_sizes / shn_graph_export and
+ * shannon_amd/mbgraph_native.py.                                                                  */
+typedef struct shn_graph shn_graph;
+int shn_mbgraph_run(shn_ctx* ctx /* NULL: K-mer seed scans on the host instead of the GPU */, int K, const uint8_t* rows,
+                    uint64_t n_rows, const uint8_t* r1, const uint64_t* r1_off, const uint8_t* r2, const uint64_t* r2_off,
+                    uint64_t n_reads, int paired, shn_graph** out);
+void shn_graph_destroy(shn_graph* g);
+/* sizes[9] = n_singles, single bases, n_components, n_nodes, node bases, n_edges, n_paths, path ids, info ints */
+int shn_graph_sizes(const shn_graph* g, uint64_t* sizes);
+int shn_graph_export(const shn_graph* g, uint64_t* s_off, uint8_t* s_bases, double* s_cc, double* s_norm,
+                     uint64_t* comp_node_off, uint64_t* comp_edge_off, uint64_t* comp_path_off, uint64_t* n_off,
+                     uint8_t* n_bases, double* n_cc, uint8_t* n_cc_int, double* n_norm, int32_t* e_in, int32_t* e_out,
+                     int32_t* e_w, double* e_cc, double* e_norm, uint64_t* p_off, int32_t* p_ids, int32_t* info);
+
 /* ---- sparse-flow node decomposition ------------------------------------------------------------
  * Replaces the randomized trial loop of path_decompose (path_decompose_sparse.py:100-117): the
  * <=100 cvxopt.solvers.lp calls per decomposed node (cvxopt: third party, version unpinned, not

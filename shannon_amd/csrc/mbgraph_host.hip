@@ -1,0 +1,796 @@
+// Native host implementation of the multibridged de-Bruijn graph of one partition (rows a12-a24):
+// the same algorithm as shannon_amd/mbgraph.py (itself the index-based mirror of the reference's
+// multibridging.py:145-325 + mbgraph.py), in C++ because at realistic coverage the per-partition
+// graph surgery in Python was 2/3 of the whole step.  Control logic over small irregular graphs:
+// host code; the order-defining conventions (P1-P3) are identical to the Python mirror,
+// which stays as the readable specification and is cross-checked against this in the tests.
+#include "common.h"
+#include <string>
+#include <vector>
+#include <unordered_map>
+#include <map>
+#include <set>
+#include <algorithm>
+#include <cstring>
+#include <cmath>
+#include <array>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
+namespace {
+
+typedef std::pair<int, int> RI;   // (read id, index)
+
+static inline int base_code(char c) {
+  switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; }
+}
+
+// unique packed K-mer keys -> groups of occurrences (kept in insertion order inside a group)
+struct SeedIndex {
+  std::vector<uint64_t> keys;               // sorted unique
+  std::vector<uint32_t> goff;               // CSR into occ
+  std::vector<std::pair<int, int>> occ;     // (node, offset)
+  void build(std::vector<std::pair<uint64_t, std::pair<int, int>>>& items) {
+    std::stable_sort(items.begin(), items.end(), [](const std::pair<uint64_t, std::pair<int, int>>& a, const std::pair<uint64_t, std::pair<int, int>>& b) { return a.first < b.first; });
+    keys.clear(); goff.clear(); occ.clear();
+    for (size_t i = 0; i < items.size(); i++) {
+      if (i == 0 || items[i].first != items[i - 1].first) { keys.push_back(items[i].first); goff.push_back((uint32_t)occ.size()); }
+      occ.push_back(items[i].second);
+    }
+    goff.push_back((uint32_t)occ.size());
+  }
+  int find(uint64_t key) const {
+    auto it = std::lower_bound(keys.begin(), keys.end(), key);
+    return (it != keys.end() && *it == key) ? (int)(it - keys.begin()) : -1;
+  }
+};
+
+struct Graph {
+  shn_ctx* ctx = nullptr;                   // non-NULL: K-mer seed scans run on the GPU (csrc/seeds.hip)
+  int K, L, SIZE_THRESHOLD;
+  std::vector<std::string> bases;
+  std::vector<std::vector<int>> ine, oute;
+  std::vector<double> norm, cc, prev, cnt;
+  std::vector<char> cc_int;
+  std::vector<char> dead;
+  std::vector<std::vector<RI>> nreads;
+  std::vector<signed char> bridged;   // -1 None, 0 False, 1 True
+  std::vector<int> hash;
+  std::vector<int> order;
+  std::vector<int> es, ed, ew;
+  std::vector<double> ecc;
+  std::vector<std::string> rbases;
+  std::vector<double> rcc;
+  std::vector<int> rmate, rmp;        // rmp: 0 None, 1, 2
+  std::vector<std::vector<int>> rnodes;
+  std::vector<char> rhas;
+  std::unordered_map<std::string, int> rindex;
+  std::set<std::vector<int>> known_paths;
+  std::map<std::pair<int, int>, double> known_edges;
+  std::vector<int> bridged_log;
+  int n_known = 0, n_mate = 0;
+  int nodes_after[4] = {0, 0, 0, 0};  // condensing, suspicious, collapse, bridging
+  int final_nodes = 0;
+
+  int new_node(const std::string& b) {
+    int n = (int)bases.size();
+    bases.push_back(b);
+    ine.emplace_back(); oute.emplace_back();
+    norm.push_back(1.0); cc.push_back(0.0); prev.push_back(0.0); cnt.push_back(1.0); cc_int.push_back(0);
+    dead.push_back(0); nreads.emplace_back(); bridged.push_back(-1); hash.push_back(-2);
+    order.push_back(n);
+    return n;
+  }
+  int link(int a, int b, int w) {
+    int e = (int)es.size();
+    es.push_back(a); ed.push_back(b); ew.push_back(w); ecc.push_back(0.0);
+    oute[a].push_back(e); ine[b].push_back(e);
+    return e;
+  }
+  static void erase_first(std::vector<int>& v, int x) {
+    auto it = std::find(v.begin(), v.end(), x);
+    if (it != v.end()) v.erase(it);
+  }
+  void kill_edge(int e) {
+    erase_first(oute[es[e]], e);
+    erase_first(ine[ed[e]], e);
+    es[e] = -1; ed[e] = -1;
+  }
+  void kill_node(int n) { dead[n] = 1; }
+  void full_destroy(int n) {
+    std::vector<int> a = ine[n];
+    for (int e : a) kill_edge(e);
+    std::vector<int> b = oute[n];
+    for (int e : b) kill_edge(e);
+    nreads[n].clear();
+    kill_node(n);
+  }
+  void remove_destroyed() {
+    std::vector<int> o;
+    o.reserve(order.size());
+    for (int n : order) if (!dead[n]) o.push_back(n);
+    order.swap(o);
+  }
+  std::vector<int> succ(int n) const { std::vector<int> r; for (int e : oute[n]) r.push_back(ed[e]); return r; }
+  std::vector<int> pred(int n) const { std::vector<int> r; for (int e : ine[n]) r.push_back(es[e]); return r; }
+  bool is_xnode(int n) const { return ine[n].size() >= 2 && oute[n].size() >= 2; }
+  double avg_prev(int n) const { return prev[n] / cnt[n]; }
+
+  // ---- loading (multibridging.py:145-172, 22-30, 68-97; mbgraph.py:44-62)
+  void load_k1mers(const uint8_t* rows, uint64_t n_rows) {
+    std::unordered_map<std::string, int> idx;
+    idx.reserve(n_rows * 2);
+    const int k1 = K + 1;
+    for (uint64_t i = 0; i < n_rows; i++) {
+      std::string km((const char*)rows + i * k1, k1);
+      std::string a = km.substr(0, K), b = km.substr(1);
+      int na, nb;
+      auto ia = idx.find(a);
+      if (ia == idx.end()) { na = new_node(a); idx.emplace(a, na); } else na = ia->second;
+      auto ib = idx.find(b);
+      if (ib == idx.end()) { nb = new_node(b); idx.emplace(b, nb); } else nb = ib->second;
+      link(na, nb, K - 1);
+    }
+    for (int n : order) { double s = 0; for (int e : oute[n]) s += ew[e]; prev[n] = s; }
+  }
+  int add_read(const std::string& b) {
+    auto it = rindex.find(b);
+    if (it != rindex.end()) { rcc[it->second] += 1.0; return it->second; }
+    int r = (int)rbases.size();
+    rindex.emplace(b, r);
+    rbases.push_back(b); rcc.push_back(1.0); rmate.push_back(-1); rmp.push_back(0); rnodes.emplace_back(); rhas.push_back(0);
+    return r;
+  }
+
+  // ---- condensing (mbgraph.py:184-271, 479-498, 1315-1321)
+  int condense(int e) {
+    int s = es[e], d = ed[e], w = ew[e];
+    int c = new_node(bases[s] + bases[d].substr(w));
+    if (s != d) { cnt[c] = cnt[s] + cnt[d]; prev[c] = prev[s] + prev[d]; }
+    else { cnt[c] = cnt[s]; prev[c] = prev[s]; }
+    norm[c] = norm[s] + norm[d];
+    if (norm[c] == 0) cc[c] = cc[s] + cc[d];
+    else cc[c] = (cc[s] * norm[s] + cc[d] * norm[d]) / norm[c];
+    if (s == d) {
+      kill_edge(e);
+      { std::vector<int> t = oute[s]; for (int x : t) { int ne = link(c, ed[x], ew[x]); ecc[ne] = ecc[x]; kill_edge(x); } }
+      { std::vector<int> t = ine[s]; for (int x : t) { int ne = link(es[x], c, ew[x]); ecc[ne] = ecc[x]; kill_edge(x); } }
+      cc[c] = cc[s] / 2.0;
+      norm[c] = norm[s];
+      nreads[c] = nreads[s];
+      nreads[s].clear();
+      kill_node(s);
+      return c;
+    }
+    { std::vector<int> t = ine[s]; for (int x : t) { link(es[x], c, ew[x]); kill_edge(x); } }
+    { std::vector<int> t = oute[d]; for (int x : t) { link(c, ed[x], ew[x]); kill_edge(x); } }
+    int shift = (int)bases[s].size() - w;
+    std::set<RI> sset(nreads[s].begin(), nreads[s].end());
+    std::vector<RI> out(sset.begin(), sset.end());                 // P1: sorted by (read, index)
+    for (const RI& x : nreads[d]) { RI y(x.first, x.second - shift); if (!sset.count(y)) out.push_back(y); }
+    nreads[c].swap(out);
+    nreads[s].clear(); nreads[d].clear();
+    kill_edge(e);
+    kill_node(s); kill_node(d);
+    return c;
+  }
+  void local_condense_edge(int e) {
+    if (es[e] < 0) return;
+    if (oute[es[e]].size() > 1 || ine[ed[e]].size() > 1) return;
+    int c = condense(e);
+    std::vector<int> t = ine[c];
+    t.insert(t.end(), oute[c].begin(), oute[c].end());
+    for (int x : t) local_condense_edge(x);
+  }
+  void local_condense_node(int n) {
+    if (oute[n].size() == 1) local_condense_edge(oute[n][0]);
+    if (ine[n].size() == 1) local_condense_edge(ine[n][0]);
+  }
+  void condense_all() {
+    size_t i = 0;
+    while (i < order.size()) {
+      int n = order[i++];
+      if (oute[n].size() != 1) continue;
+      int e = oute[n][0], d = ed[e];
+      if (ine[d].size() == 1 && n != d) condense(e);
+    }
+    remove_destroyed();
+  }
+
+  // ---- error pruning (mbgraph.py:1169-1313)
+  bool is_suspicious(int n) const {
+    size_t ni = ine[n].size(), no = oute[n].size();
+    if ((int)bases[n].size() <= SIZE_THRESHOLD && (ni == 0 || no == 0)) return true;
+    if (avg_prev(n) >= 1) return false;
+    if (ni == 0 || no == 0) return true;
+    { double t = 0; for (int e : ine[n]) t += (double)oute[es[e]].size(); if (t / (double)ni < 2) return false; }
+    { double t = 0; for (int e : oute[n]) t += (double)ine[ed[e]].size(); if (t / (double)no < 2) return false; }
+    return true;
+  }
+  void destroy_suspicious() {
+    while (true) {
+      std::vector<int> sus;
+      for (int n : order) if (is_suspicious(n)) sus.push_back(n);
+      if (sus.empty()) return;
+      std::stable_sort(sus.begin(), sus.end(), [&](int a, int b) { return avg_prev(a) < avg_prev(b); });
+      for (int n : sus) {
+        if (dead[n]) continue;
+        std::vector<int> adj = pred(n), s2 = succ(n);
+        adj.insert(adj.end(), s2.begin(), s2.end());
+        full_destroy(n);
+        for (int a : adj) local_condense_node(a);
+      }
+      remove_destroyed();
+    }
+  }
+  bool similar(int a, int b) const {
+    if (dead[a] || dead[b]) return false;
+    const std::string &x = bases[a], &y = bases[b];
+    if (x.size() != y.size()) return false;
+    size_t mism = 0;
+    for (size_t i = 0; i < x.size(); i++) mism += x[i] != y[i];
+    if ((double)mism / (double)std::max<size_t>(x.size(), 1) >= 0.1) return false;
+    auto uniq = [](std::vector<int> v) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); return v; };
+    return uniq(succ(a)) == uniq(succ(b)) && uniq(pred(a)) == uniq(pred(b));
+  }
+  void collapse_all() {
+    while (true) {
+      bool collapsed = false;
+      for (size_t oi = 0; oi < order.size(); oi++) {
+        int n = order[oi];
+        std::vector<int> ss;
+        for (int s : succ(n)) if (!dead[s]) ss.push_back(s);
+        bool done = false;
+        for (size_t i = 0; i < ss.size() && !done; i++)
+          for (size_t j = i + 1; j < ss.size(); j++)
+            if (similar(ss[i], ss[j])) {
+              int a = ss[i], b = ss[j];
+              if (prev[a] < prev[b]) std::swap(a, b);
+              prev[a] += prev[b];
+              full_destroy(b);
+              collapsed = done = true;
+              break;
+            }
+      }
+      remove_destroyed();
+      if (!collapsed) return;
+    }
+  }
+
+  // ---- bridging (mbgraph.py:77-111, 450-628)
+  bool read_bridges(int r, int n, int index) const {
+    const std::string &rb = rbases[r], &nb = bases[n];
+    if (index <= 0 || (int)rb.size() <= index + (int)nb.size()) return false;
+    return rb.compare(index, nb.size(), nb) == 0;
+  }
+  // packed key of s[pos..pos+K) or false if it holds a non-ACGT character
+  bool key_at(const std::string& s, size_t pos, uint64_t& key) const {
+    key = 0;
+    for (int j = 0; j < K; j++) { int c = base_code(s[pos + j]); if (c < 0) return false; key = (key << 2) | (uint64_t)c; }
+    return true;
+  }
+  bool reads_all_acgt() const {
+    for (const std::string& r : rbases) for (char c : r) if (base_code(c) < 0) return false;
+    return true;
+  }
+  // device copy of the distinct reads + pattern table; returns false if the GPU path is not usable
+  bool gpu_patterns(const SeedIndex& si, shn_reads** dreads, shn_table** tab) {
+    if (!ctx || K > 32 || rbases.empty() || si.keys.empty() || !reads_all_acgt()) return false;
+    if (!*dreads) {
+      std::string buf;
+      std::vector<uint64_t> off(rbases.size() + 1, 0);
+      for (size_t i = 0; i < rbases.size(); i++) { buf += rbases[i]; off[i + 1] = buf.size(); }
+      if (shn_reads_create(ctx, (const uint8_t*)buf.data(), off.data(), rbases.size(), 0, SHN_ENC_ASCII, dreads)) return false;
+    }
+    std::vector<uint32_t> vals(si.keys.size());
+    for (size_t i = 0; i < vals.size(); i++) vals[i] = (uint32_t)i + 1;
+    return shn_table_create(ctx, si.keys.data(), vals.data(), si.keys.size(), K, 0, tab) == 0;
+  }
+  shn_reads* d_reads = nullptr;
+  void release_gpu() { if (d_reads) { shn_reads_destroy(d_reads); d_reads = nullptr; } }
+
+  void find_bridging_reads() {
+    std::vector<std::pair<uint64_t, std::pair<int, int>>> items;
+    for (int n : order) if (is_xnode(n)) { uint64_t key; if (key_at(bases[n], 0, key)) items.push_back({key, {n, 0}}); }
+    if (items.empty()) return;
+    SeedIndex si;
+    si.build(items);
+    shn_table* tab = nullptr;
+    if (gpu_patterns(si, &d_reads, &tab)) {
+      uint64_t nh = 0;
+      if (shn_seed_scan(ctx, d_reads, K, tab, &nh, nullptr, nullptr, nullptr) == 0 && nh) {
+        std::vector<uint32_t> hr(nh), hs(nh), hi(nh);
+        if (shn_seed_scan(ctx, d_reads, K, tab, &nh, hr.data(), hs.data(), hi.data()) == 0)
+          for (uint64_t h = 0; h < nh; h++)
+            for (uint32_t q = si.goff[hi[h]]; q < si.goff[hi[h] + 1]; q++) {
+              int x = si.occ[q].first;
+              if (read_bridges((int)hr[h], x, (int)hs[h])) nreads[x].push_back(RI((int)hr[h], (int)hs[h]));
+            }
+      }
+      shn_table_destroy(tab);
+      return;
+    }
+    const uint64_t mask = K == 32 ? ~0ULL : ((1ULL << (2 * K)) - 1);
+    for (int r = 0; r < (int)rbases.size(); r++) {
+      const std::string& rb = rbases[r];
+      uint64_t key = 0;
+      int valid = 0;
+      for (int i = 0; i < (int)rb.size(); i++) {
+        int c = base_code(rb[i]);
+        if (c < 0) { valid = 0; key = 0; continue; }
+        key = ((key << 2) | (uint64_t)c) & mask;
+        if (++valid < K) continue;
+        int s0 = i - K + 1;                                  // window start; the reference scans range(1, len-K)
+        if (s0 < 1 || s0 >= (int)rb.size() - K) continue;
+        int gi = si.find(key);
+        if (gi < 0) continue;
+        for (uint32_t q = si.goff[gi]; q < si.goff[gi + 1]; q++) {
+          int x = si.occ[q].first;
+          if (read_bridges(r, x, s0)) nreads[x].push_back(RI(r, s0));
+        }
+      }
+    }
+  }
+  void refresh_bridging_reads(int n) {
+    const std::string& nb = bases[n];
+    int lb = (int)nb.size();
+    std::set<RI> rs;
+    for (const RI& x : nreads[n]) {
+      int r = x.first, i = x.second;
+      if (i > 0 && (int)rbases[r].size() > i + lb && rbases[r].compare(i, lb, nb) == 0) rs.insert(x);
+    }
+    std::vector<RI> real;
+    for (const RI& x : rs) {
+      const std::string& rb = rbases[x.first];
+      int i = x.second;
+      bool bi = false, bo = false;
+      for (int e : ine[n]) { const std::string& pb = bases[es[e]]; if (rb[i - 1] == pb[pb.size() - ew[e] - 1]) bi = true; }
+      for (int e : oute[n]) { if (rb[i + lb] == bases[ed[e]][ew[e]]) bo = true; }
+      if (bi && bo) real.push_back(x);
+    }
+    nreads[n].swap(real);
+  }
+  bool is_bridged_xnode(int n) {
+    refresh_bridging_reads(n);
+    int lb = (int)bases[n].size();
+    std::set<char> inb, outb;
+    for (const RI& x : nreads[n]) { inb.insert(rbases[x.first][x.second - 1]); outb.insert(rbases[x.first][x.second + lb]); }
+    int bi = (int)ine[n].size() - (int)inb.size(), bo = (int)oute[n].size() - (int)outb.size();
+    return (bi == 0 && bo == 0) || (bi == 1 && bo == 1);
+  }
+  int bridging_step(int node) {
+    refresh_bridging_reads(node);
+    if (nreads[node].empty() || ine[node].size() < 2 || oute[node].size() < 2) return shn_fail(SHN_ERR_INTERNAL, "bridging_step: assertion failed");
+    const std::string nb = bases[node];
+    int lb = (int)nb.size();
+    std::vector<int> u_list, w_list;
+    int v_back = -1, v_forward = -1, loop_w = 0;
+    { std::vector<int> t = ine[node];
+      for (int e : t) {
+        int p = es[e], w = ew[e];
+        const std::string& pb = bases[p];
+        int u = new_node(std::string(1, pb[pb.size() - w - 1]) + nb);
+        link(p, u, w + 1);
+        for (const RI& x : nreads[node]) if (read_bridges(x.first, u, x.second - 1)) nreads[u].push_back(RI(x.first, x.second - 1));
+        bridged[u] = 0;
+        if (p == node) { v_back = u; loop_w = w; }
+        u_list.push_back(u);
+      } }
+    { std::vector<int> t = oute[node];
+      for (int e : t) {
+        int q = ed[e], w = ew[e];
+        int x = new_node(nb + std::string(1, bases[q][w]));
+        link(x, q, w + 1);
+        for (const RI& y : nreads[node]) if (read_bridges(y.first, x, y.second + 1)) nreads[x].push_back(RI(y.first, y.second + 1));
+        bridged[x] = 0;
+        if (q == node) v_forward = x;
+        w_list.push_back(x);
+      } }
+    { std::vector<int> t = ine[node]; for (int e : t) kill_edge(e); }
+    { std::vector<int> t = oute[node]; for (int e : t) kill_edge(e); }
+    if (v_back >= 0) {
+      if (v_forward < 0) return shn_fail(SHN_ERR_INTERNAL, "bridging_step: self loop without forward node");
+      link(v_forward, v_back, loop_w + 2);
+    }
+    std::map<int, int> links;
+    for (int n : u_list) links[n] = 0;
+    for (int n : w_list) links[n] = 0;
+    std::vector<RI> rl = nreads[node];
+    for (const RI& y : rl) {
+      const std::string& rb = rbases[y.first];
+      int i = y.second;
+      std::string bu = rb.substr(i - 1, lb + 1), bw = rb.substr(i, lb + 1);
+      std::vector<int> mu, mw;
+      for (int u : u_list) if (bases[u] == bu) mu.push_back(u);
+      for (int x : w_list) if (bases[x] == bw) mw.push_back(x);
+      if (mu.size() != 1 || mw.size() != 1) continue;
+      int u = mu[0], x = mw[0];
+      nreads[u].push_back(RI(y.first, i - 1));
+      nreads[x].push_back(RI(y.first, i));
+      bool prec = false;
+      for (int e : oute[u]) if (ed[e] == x) prec = true;
+      if (!prec) { link(u, x, lb); bridged[u] = 1; bridged[x] = 1; links[u]++; links[x]++; }
+    }
+    nreads[node].clear();
+    std::vector<int> ub_u, ub_w;
+    for (int u : u_list) if (bridged[u] != 1) ub_u.push_back(u);
+    for (int x : w_list) if (bridged[x] != 1) ub_w.push_back(x);
+    if (ub_u.size() == 1 && ub_w.size() == 1) { link(ub_u[0], ub_w[0], lb); links[ub_u[0]]++; links[ub_w[0]]++; }
+    else if (ub_u.size() + ub_w.size() != 0) return shn_fail(SHN_ERR_INTERNAL, "bridging_step: unbridged edges remain");
+    int link_count = 0;
+    for (auto& kv : links) link_count += kv.second;
+    std::vector<int> all = u_list;
+    all.insert(all.end(), w_list.begin(), w_list.end());
+    for (int n : all) prev[n] = ((double)links[n] / (double)link_count) * prev[node];
+    for (int n : all) {
+      std::vector<int> t = ine[n];
+      t.insert(t.end(), oute[n].begin(), oute[n].end());
+      for (int e : t) local_condense_edge(e);
+    }
+    kill_node(node);
+    return 0;
+  }
+  int bridge_all() {
+    while (true) {
+      std::vector<int> todo;
+      for (int n : order) if (is_xnode(n) && is_bridged_xnode(n)) todo.push_back(n);
+      for (int n : todo) { int rc = bridging_step(n); if (rc) return rc; }
+      bridged_log.push_back((int)todo.size());
+      remove_destroyed();
+      if (todo.empty()) return 0;
+    }
+  }
+
+  // ---- copy counts, cycles (mbgraph.py:735-767, 903-960, 1040-1049, 1133-1161, 1324-1331)
+  void find_approximate_copy_counts() {
+    known_paths.clear();
+    for (int n : order) { norm[n] = (double)((int)bases[n].size() - K + 1); cc[n] = prev[n] / norm[n]; cc_int[n] = 0; }
+    for (int n : order)
+      for (int e : oute[n]) {
+        int nm = std::max(L - ew[e] - 1, 0);
+        int a = es[e], b = ed[e];
+        double tot = cc[a] * norm[a] + cc[b] * norm[b];
+        ecc[e] = nm == 0 ? 0.0 : 0.5 * tot / (double)nm;
+      }
+  }
+  void disregard_loops() {
+    for (int n : order) { bool self = false; for (int e : oute[n]) if (ed[e] == n) self = true; if (self) { norm[n] = 0; cc[n] = 0; } }
+  }
+  bool reachable_cycle(int n, std::set<int>& no_cycles, std::vector<int>& trav, std::vector<int>& out) {
+    trav.push_back(n);
+    std::vector<int> ss = succ(n);
+    for (int m : ss) {
+      auto it = std::find(trav.begin(), trav.end(), m);
+      if (it != trav.end()) { out.assign(it, trav.end()); out.push_back(m); trav.pop_back(); return true; }
+      if (no_cycles.count(m)) continue;
+      if (reachable_cycle(m, no_cycles, trav, out)) { trav.pop_back(); return true; }
+    }
+    no_cycles.insert(n);
+    trav.pop_back();
+    return false;
+  }
+  bool find_cycle(std::set<int>& no_cycles, std::vector<int>& out) {
+    for (int n : order) {
+      if (no_cycles.count(n)) continue;
+      std::vector<int> trav;
+      if (reachable_cycle(n, no_cycles, trav, out)) return true;
+    }
+    return false;
+  }
+  int break_cycles() {
+    std::set<int> no_cycles;
+    std::vector<int> c;
+    while (find_cycle(no_cycles, c)) full_destroy(c[1]);
+    remove_destroyed();
+    condense_all();
+    std::set<int> chk;
+    if (find_cycle(chk, c)) return shn_fail(SHN_ERR_INTERNAL, "break_cycles: graph still cyclic");
+    return 0;
+  }
+
+  // ---- reads on the graph (mbgraph.py:1355-1441, 114-160, 839-880)
+  static bool compare(const std::string& a, size_t ao, const std::string& b, size_t bo) {
+    size_t n = std::min(a.size() - ao, b.size() - bo);
+    return a.compare(ao, n, b, bo, n) == 0;
+  }
+  void search_sequence(const std::string& seq, size_t so, int node, int i, int hops, std::vector<int>& cur, std::vector<std::vector<int>>& out) {
+    size_t nl = bases[node].size() - i;
+    cur.push_back(node);
+    if (hops <= 0 || seq.size() - so <= nl) { out.push_back(cur); cur.pop_back(); return; }
+    size_t so2 = so + nl;
+    for (int e : oute[node])
+      if (compare(seq, so2, bases[ed[e]], ew[e])) search_sequence(seq, so2, ed[e], ew[e], hops - 1, cur, out);
+    cur.pop_back();
+  }
+  void find_known_paths() {
+    known_paths.clear();
+    std::vector<std::pair<uint64_t, std::pair<int, int>>> items;
+    const uint64_t mask = K == 32 ? ~0ULL : ((1ULL << (2 * K)) - 1);
+    for (int n : order) {
+      const std::string& b = bases[n];
+      uint64_t key = 0;
+      int valid = 0;
+      for (int i = 0; i < (int)b.size(); i++) {
+        int c = base_code(b[i]);
+        if (c < 0) { valid = 0; key = 0; continue; }
+        key = ((key << 2) | (uint64_t)c) & mask;
+        if (++valid >= K) items.push_back({key, {n, i - K + 1}});
+      }
+    }
+    SeedIndex si;
+    si.build(items);
+    std::vector<uint32_t> first(rbases.size(), 0), last(rbases.size(), 0);     // group id + 1, 0 = absent
+    shn_table* tab = nullptr;
+    bool done = false;
+    if (gpu_patterns(si, &d_reads, &tab)) {
+      done = shn_seed_ends(ctx, d_reads, K, tab, first.data(), last.data()) == 0;
+      shn_table_destroy(tab);
+    }
+    if (!done)
+      for (int r = 0; r < (int)rbases.size(); r++) {
+        const std::string& rb = rbases[r];
+        uint64_t key;
+        if ((int)rb.size() < K) continue;
+        if (key_at(rb, 0, key)) first[r] = (uint32_t)(si.find(key) + 1);
+        if (key_at(rb, rb.size() - K, key)) last[r] = (uint32_t)(si.find(key) + 1);
+      }
+    release_gpu();
+    int cntp = 0;
+    for (int r = 0; r < (int)rbases.size(); r++) {
+      if (!first[r] || !last[r]) continue;
+      const std::string& rb = rbases[r];
+      uint32_t gi = first[r] - 1;
+      for (uint32_t q = si.goff[gi]; q < si.goff[gi + 1]; q++) {
+        int sn = si.occ[q].first, so = si.occ[q].second;
+        if (!compare(rb, 0, bases[sn], so)) continue;
+        std::vector<std::vector<int>> paths;
+        std::vector<int> cur;
+        search_sequence(rb, 0, sn, so, 30, cur, paths);
+        for (auto& p : paths) {
+          rnodes[r] = p; rhas[r] = 1;
+          for (size_t j = 0; j + 1 < p.size(); j++) known_edges[{p[j], p[j + 1]}] += rcc[r];
+          if (p.size() > 2) { known_paths.insert(p); cntp++; }
+        }
+      }
+    }
+    n_known = cntp;
+  }
+  void find_copy_counts() {
+    for (int n : order) {
+      double tot = 0;
+      bool any = false;
+      for (int e : oute[n]) {
+        auto it = known_edges.find({es[e], ed[e]});
+        double ec = 0;
+        if (it != known_edges.end()) { ec = it->second; any = true; }
+        tot += ec;
+        ecc[e] = ec / (double)std::max(L - ew[e] - 1, 1);
+      }
+      cc[n] = tot;
+      cc_int[n] = any ? 0 : 1;      // Python: `tot` stays the int 0 when no out-edge has a known count
+    }
+  }
+  void mate_search(int n, int goal, int max_len, int min_len, int hops, std::vector<int>& cur, std::vector<std::vector<int>>& out) {
+    if (max_len <= 0 || hops <= 0) return;
+    if (n == goal && min_len <= 1) { cur.push_back(goal); out.push_back(cur); cur.pop_back(); return; }
+    cur.push_back(n);
+    for (int e : oute[n]) {
+      int nl = (int)bases[n].size() - ew[e];
+      mate_search(ed[e], goal, max_len - nl, min_len - nl, hops - 1, cur, out);
+    }
+    cur.pop_back();
+  }
+  void find_mate_pairs() {
+    std::vector<std::pair<int, int>> pairs;
+    std::set<std::pair<int, int>> seen;
+    for (int r = 0; r < (int)rbases.size(); r++) {
+      if (rmp[r] != 1 || rmate[r] < 0) continue;
+      int m = rmate[r];
+      if (!rhas[r] || rnodes[r].empty() || !rhas[m] || rnodes[m].empty()) continue;
+      int a = rnodes[r].back(), b = rnodes[m].front();
+      if (a == b) continue;
+      bool adj = false;
+      for (int e : oute[a]) if (ed[e] == b) adj = true;
+      if (adj) continue;
+      if (seen.insert({a, b}).second) pairs.push_back({a, b});
+    }
+    int nmp = 0;
+    for (auto& ab : pairs) {
+      int a = ab.first, b = ab.second;
+      const int fringe = 1, min_l = 0 - fringe, max_l = 300 - fringe;
+      std::vector<std::vector<int>> paths;
+      for (int e : oute[a]) {
+        std::vector<int> cur(1, a);
+        mate_search(ed[e], b, max_l + ew[e], min_l + ew[e], 7, cur, paths);
+      }
+      if (paths.size() == 1 && paths[0].size() > 2) { nmp++; known_paths.insert(paths[0]); }
+    }
+    n_mate = nmp;
+  }
+
+  int run() {
+    const bool dbg = getenv("SHN_DEBUG") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
+    auto lap = [&](const char* what) { if (dbg) { double t = now(); fprintf(stderr, "[mbgraph] %-22s %8.3f s  nodes=%zu\n", what, t - t0, order.size()); t0 = t; } };
+    condense_all();
+    nodes_after[0] = (int)order.size();
+    lap("condense_all");
+    destroy_suspicious();
+    nodes_after[1] = (int)order.size();
+    lap("destroy_suspicious");
+    collapse_all();
+    nodes_after[2] = (int)order.size();
+    lap("collapse_all");
+    find_bridging_reads();
+    lap("find_bridging_reads");
+    int rc = bridge_all();
+    if (rc) return rc;
+    lap("bridge_all");
+    condense_all();
+    nodes_after[3] = (int)order.size();
+    find_approximate_copy_counts();
+    disregard_loops();
+    condense_all();
+    remove_destroyed();
+    lap("condense+copycounts");
+    if ((rc = break_cycles())) return rc;
+    lap("break_cycles");
+    find_approximate_copy_counts();
+    find_known_paths();
+    lap("find_known_paths");
+    find_copy_counts();
+    find_mate_pairs();
+    lap("copy counts+mates");
+    final_nodes = (int)order.size();
+    return 0;
+  }
+};
+
+}  // namespace
+
+struct shn_graph {
+  // flattened output_components (multibridging.py:271-325)
+  std::vector<uint64_t> s_off; std::string s_bases; std::vector<double> s_cc, s_norm;
+  std::vector<uint64_t> comp_node_off, comp_edge_off, comp_path_off;
+  std::vector<uint64_t> n_off; std::string n_bases; std::vector<double> n_cc, n_norm; std::vector<uint8_t> n_cc_int;
+  std::vector<int32_t> e_in, e_out, e_w; std::vector<double> e_cc, e_norm;
+  std::vector<uint64_t> p_off; std::vector<int32_t> p_ids;
+  std::vector<int32_t> info;   // nodes_after[4], final_nodes, n_known, n_mate, n_bridged_rounds, bridged...
+};
+
+extern "C" void shn_graph_destroy(shn_graph* g) { delete g; }
+
+// rows: n_rows k1-mers of K+1 bytes each (file order of component{c}k1mers_allowed.dict); reads: ASCII,
+// r_off[n_reads+1]; paired: second mate file r2/r2_off with the same count.  Read.L = length of the first read.
+extern "C" int shn_mbgraph_run(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n_rows, const uint8_t* r1, const uint64_t* r1_off,
+                               const uint8_t* r2, const uint64_t* r2_off, uint64_t n_reads, int paired, shn_graph** out) {
+  if (!out || (n_rows && !rows) || (n_reads && (!r1 || !r1_off)) || (paired && n_reads && (!r2 || !r2_off)))
+    return shn_fail(SHN_ERR_ARG, "shn_mbgraph_run: NULL argument");
+  Graph g;
+  g.ctx = ctx;
+  g.K = K;
+  g.L = n_reads ? (int)(r1_off[1] - r1_off[0]) : -1;
+  g.SIZE_THRESHOLD = g.L;
+  const bool dbg = getenv("SHN_DEBUG") != nullptr;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tt = now();
+  g.load_k1mers(rows, n_rows);
+  if (dbg) { fprintf(stderr, "[mbgraph] load_k1mers            %8.3f s  rows=%llu\n", now() - tt, (unsigned long long)n_rows); tt = now(); }
+  uint64_t cutoff = (uint64_t)g.order.size() * 10;
+  auto upper = [](std::string s) { for (auto& c : s) if (c >= 'a' && c <= 'z') c -= 32; return s; };
+  for (uint64_t i = 0; i < n_reads; i++) {
+    if (i > cutoff) break;
+    int a = g.add_read(upper(std::string((const char*)r1 + r1_off[i], r1_off[i + 1] - r1_off[i])));
+    if (paired) {
+      int b = g.add_read(upper(std::string((const char*)r2 + r2_off[i], r2_off[i + 1] - r2_off[i])));
+      g.rmp[a] = 1; g.rmp[b] = 2; g.rmate[a] = b; g.rmate[b] = a;
+    }
+  }
+  if (dbg) { fprintf(stderr, "[mbgraph] load reads             %8.3f s  reads=%llu distinct=%zu\n", now() - tt, (unsigned long long)n_reads, g.rbases.size()); tt = now(); }
+  int rc = g.run();
+  g.release_gpu();
+  tt = now();
+  if (rc) return rc;
+  // ---- output_components (add_component mbgraph.py:691-709, topological_sort :711-732, P2)
+  shn_graph* o = new shn_graph();
+  o->s_off.push_back(0); o->n_off.push_back(0); o->p_off.push_back(0);
+  o->comp_node_off.push_back(0); o->comp_edge_off.push_back(0); o->comp_path_off.push_back(0);
+  std::map<int, std::vector<const std::vector<int>*>> by_start;
+  for (auto& p : g.known_paths) by_start[p[0]].push_back(&p);
+  for (int src : g.order) {
+    if (g.dead[src]) continue;
+    std::set<int> seen;
+    std::set<int> edges;
+    std::vector<int> queue(1, src);
+    while (!queue.empty()) {
+      int n = queue.back(); queue.pop_back();
+      if (seen.count(n)) continue;
+      seen.insert(n);
+      for (int e : g.oute[n]) edges.insert(e);
+      for (int e : g.oute[n]) queue.push_back(g.ed[e]);
+      for (int e : g.ine[n]) queue.push_back(g.es[e]);
+    }
+    std::set<int> added;
+    std::vector<int> topo, fringe;
+    for (int n : seen) if (g.ine[n].empty()) fringe.push_back(n);      // `seen` iterates in creation (id) order
+    while (!fringe.empty()) {
+      int v = fringe.back(); fringe.pop_back();
+      if (added.count(v)) continue;
+      added.insert(v);
+      topo.push_back(v);
+      for (int e : g.oute[v]) {
+        int n = g.ed[e];
+        bool all = true;
+        for (int pe : g.ine[n]) if (!added.count(g.es[pe])) all = false;
+        if (all) fringe.push_back(n);
+      }
+    }
+    if (topo.size() == 1) {
+      g.hash[src] = -1;
+      o->s_bases += g.bases[src];
+      o->s_off.push_back(o->s_bases.size());
+      o->s_cc.push_back(g.cc[src]); o->s_norm.push_back(g.norm[src]);
+      g.dead[src] = 1;
+      continue;
+    }
+    for (size_t h = 0; h < topo.size(); h++) { g.hash[topo[h]] = (int)h; g.dead[topo[h]] = 1; }
+    for (int n : topo) {
+      o->n_bases += g.bases[n];
+      o->n_off.push_back(o->n_bases.size());
+      o->n_cc.push_back(g.cc[n]); o->n_norm.push_back(g.norm[n]); o->n_cc_int.push_back((uint8_t)g.cc_int[n]);
+    }
+    o->comp_node_off.push_back(o->n_cc.size());
+    for (int n : topo) {
+      auto it = by_start.find(n);
+      if (it == by_start.end()) continue;
+      std::vector<std::vector<int>> ps;
+      for (auto* p : it->second) { std::vector<int> h; for (int x : *p) h.push_back(g.hash[x]); ps.push_back(h); }
+      std::sort(ps.begin(), ps.end());
+      for (auto& h : ps) { for (int x : h) o->p_ids.push_back(x); o->p_off.push_back(o->p_ids.size()); }
+    }
+    o->comp_path_off.push_back(o->p_off.size() - 1);
+    std::vector<std::array<double, 5>> el;
+    for (int e : edges) if (g.ecc[e] > 0)
+      el.push_back({(double)g.hash[g.es[e]], (double)g.hash[g.ed[e]], (double)g.ew[e], g.ecc[e], (double)std::max(g.L - g.ew[e] - 1, 0)});
+    std::stable_sort(el.begin(), el.end(), [](const std::array<double, 5>& a, const std::array<double, 5>& b) {
+      if (a[0] != b[0]) return a[0] < b[0];
+      if (a[1] != b[1]) return a[1] < b[1];
+      return a[2] < b[2];
+    });
+    for (auto& x : el) { o->e_in.push_back((int)x[0]); o->e_out.push_back((int)x[1]); o->e_w.push_back((int)x[2]); o->e_cc.push_back(x[3]); o->e_norm.push_back(x[4]); }
+    o->comp_edge_off.push_back(o->e_in.size());
+  }
+  if (dbg) fprintf(stderr, "[mbgraph] output_components      %8.3f s\n", now() - tt);
+  for (int i = 0; i < 4; i++) o->info.push_back(g.nodes_after[i]);
+  o->info.push_back(g.final_nodes); o->info.push_back(g.n_known); o->info.push_back(g.n_mate);
+  o->info.push_back((int)g.bridged_log.size());
+  for (int b : g.bridged_log) o->info.push_back(b);
+  *out = o;
+  return SHN_OK;
+}
+
+// sizes: [n_singles, s_bases, n_comps, n_nodes, n_bases, n_edges, n_paths, n_path_ids, n_info]
+extern "C" int shn_graph_sizes(const shn_graph* g, uint64_t* sizes) {
+  if (!g || !sizes) return shn_fail(SHN_ERR_ARG, "shn_graph_sizes: NULL argument");
+  sizes[0] = g->s_cc.size(); sizes[1] = g->s_bases.size(); sizes[2] = g->comp_node_off.size() - 1; sizes[3] = g->n_cc.size();
+  sizes[4] = g->n_bases.size(); sizes[5] = g->e_in.size(); sizes[6] = g->p_off.size() - 1; sizes[7] = g->p_ids.size();
+  sizes[8] = g->info.size();
+  return SHN_OK;
+}
+
+extern "C" int shn_graph_export(const shn_graph* g, uint64_t* s_off, uint8_t* s_bases, double* s_cc, double* s_norm,
+                                uint64_t* comp_node_off, uint64_t* comp_edge_off, uint64_t* comp_path_off, uint64_t* n_off,
+                                uint8_t* n_bases, double* n_cc, uint8_t* n_cc_int, double* n_norm, int32_t* e_in, int32_t* e_out,
+                                int32_t* e_w, double* e_cc, double* e_norm, uint64_t* p_off, int32_t* p_ids, int32_t* info) {
+  if (!g) return shn_fail(SHN_ERR_ARG, "shn_graph_export: NULL graph");
+#define CP(dst, v) if (dst && !(v).empty()) memcpy(dst, (v).data(), (v).size() * sizeof((v)[0]))
+  CP(s_off, g->s_off); CP(s_bases, g->s_bases); CP(s_cc, g->s_cc); CP(s_norm, g->s_norm);
+  CP(comp_node_off, g->comp_node_off); CP(comp_edge_off, g->comp_edge_off); CP(comp_path_off, g->comp_path_off);
+  CP(n_off, g->n_off); CP(n_bases, g->n_bases); CP(n_cc, g->n_cc); CP(n_cc_int, g->n_cc_int); CP(n_norm, g->n_norm);
+  CP(e_in, g->e_in); CP(e_out, g->e_out); CP(e_w, g->e_w); CP(e_cc, g->e_cc); CP(e_norm, g->e_norm);
+  CP(p_off, g->p_off); CP(p_ids, g->p_ids); CP(info, g->info);
+#undef CP
+  return SHN_OK;
+}

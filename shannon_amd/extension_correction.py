@@ -91,26 +91,42 @@ def windows_to_keys(contig, k):
     return key
 
 
-def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=500, r=15, f=0.5):
+def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=500, r=15, f=0.5, want_allowed=True, timings=None):
     """extension_correction.run_correction (extension_correction.py:309-524) on a device k1-mer
     table.  Returns an ExtensionResult: contigs, allowed {k1mer: int}, connections, components,
     single_contigs, big_components [(contigs, metis_text)], remaining [[contig...]]."""
+    import time as _t
+    T = timings if timings is not None else {}
+    _t0 = [_t.time()]
+
+    def lap(name):
+        now = _t.time()
+        T[name] = T.get(name, 0.0) + now - _t0[0]
+        _t0[0] = now
+
     k1 = table.k
     ext = Extension(ctx, table, min_weight)
+    lap("ext.gpu_walks")
     nr, nl, tw = ext.stats()
     live = np.nonzero(nr != UNCLAIMED)[0]                      # non-void walks, in seed order
     length = k1 + nr[live].astype(np.int64) + nl[live].astype(np.int64)
     cand = live[length >= min_length]                          # first clause of the accept filter (:361)
     clen = length[length >= min_length]
     thr = 2 * min_length * math.pow(min_weight, 1 / 4.0)
-    keep = []
-    ckm = (nr[cand].astype(np.int64) + nl[cand].astype(np.int64) + 1).tolist()
-    ctw = tw[cand].tolist()
-    for rnk, L, tot_kmer, tot in zip(cand.tolist(), clen.tolist(), ckm, ctw):
-        avg_wt = float(tot) / max(1, tot_kmer)
-        if L * math.pow(avg_wt, 1 / 4.0) >= thr:
-            keep.append((rnk, L))
+    # second clause of :361, len * avg_wt**0.25 >= 2*min_length*min_weight**0.25: vectorised with a guard band;
+    # only candidates within 1e-9 (relative) of the threshold are decided with math.pow like the reference.
+    ckm = nr[cand].astype(np.int64) + nl[cand].astype(np.int64) + 1
+    avg = tw[cand].astype(np.float64) / np.maximum(1, ckm)
+    lhs = clen.astype(np.float64) * np.power(avg, 0.25)
+    sure = lhs >= thr * (1 + 1e-9)
+    maybe = (~sure) & (lhs >= thr * (1 - 1e-9))
+    for j in np.nonzero(maybe)[0].tolist():
+        a = float(int(tw[cand[j]])) / max(1, int(ckm[j]))
+        sure[j] = int(clen[j]) * math.pow(a, 1 / 4.0) >= thr
+    keep = list(zip(cand[sure].tolist(), clen[sure].tolist()))
+    lap("ext.filter")
     strings = ext.emit([x[0] for x in keep], [x[1] for x in keep]) if keep else []
+    lap("ext.emit")
 
     # duplicate_check + contig graph, sequential over candidates in seed order (:358-397): native host
     # code (csrc/contig_host.hip, shn_contig_graph); neighbours come back in dict insertion order.
@@ -137,6 +153,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
         for a in range(n_acc.value):
             conn[a + 1] = dict(zip(cnb[coff[a]:coff[a + 1]], cw[coff[a]:coff[a + 1]]))
 
+    lap("ext.contig_graph")
     res = ExtensionResult()
     res.k1 = k1
     res.iterations = ext.iterations
@@ -145,7 +162,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     res.contigs = contigs[1:]
     # allowed k1-mers with their integer weights (:366-369, :404-408): GPU table lookup
     allowed = {}
-    if res.contigs:
+    if res.contigs and want_allowed:
         keys = np.concatenate([windows_to_keys(c, k1) for c in res.contigs])
         w = ext.weights(keys).tolist()
         p = 0
@@ -194,6 +211,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
             if cur_size > comp_size_threshold:
                 res.remaining.append([])
                 cur_size = 0
+    lap("ext.components")
     return res
 
 

@@ -137,7 +137,7 @@ def make_table(ctx, keys, values, k, canonical=False):
 
 
 def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overload=2, penalty=5, repartition=True,
-                        part_vectors=None):
+                        part_vectors=None, want_rows=True):
     """Rows a8-a11.  reads1/reads2: device.Reads (reads2 None for single-end).  Returns dict with
       new_components {name: [contig]}          (kmers_for_component.py:244-305)
       k1mers {name: [(k1mer, weight)]}         (:452-477, == component{name}k1mers_allowed.dict)
@@ -162,13 +162,27 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
         allp = np.concatenate(allp)
     else:
         allk, allp = np.zeros(0, np.uint64), np.zeros(0, np.uint32)
+    # distinct (k1-mer, partition) pairs, grouped by k1-mer; a k1-mer lies on exactly one contig, so its set
+    # has one partition (remaining bin) or two (gpmetis run + r2 run): singleton sets are handled vectorised
     order = np.lexsort((allp, allk))
     sk, sp = allk[order], allp[order]
-    uk, start = np.unique(sk, return_index=True)
-    end = np.append(start[1:], len(sk))
+    if len(sk):
+        keepm = np.ones(len(sk), dtype=bool)
+        keepm[1:] = (sk[1:] != sk[:-1]) | (sp[1:] != sp[:-1])
+        sk, sp = sk[keepm], sp[keepm]
+    uk, start, cntk = np.unique(sk, return_index=True, return_counts=True)
     set_ids, sets, set_index = np.zeros(len(uk), np.uint32), [], {}
-    for i, (a, b) in enumerate(zip(start.tolist(), end.tolist())):
-        tpl = tuple(np.unique(sp[a:b]).tolist())
+    single = cntk == 1
+    if single.any():
+        pids = sp[start[single]]
+        upid, inv = np.unique(pids, return_inverse=True)
+        base = len(sets)
+        for pv in upid.tolist():
+            set_index[(pv,)] = len(sets)
+            sets.append((pv,))
+        set_ids[single] = (base + inv + 1).astype(np.uint32)
+    for i in np.nonzero(~single)[0].tolist():
+        tpl = tuple(sp[start[i]:start[i] + cntk[i]].tolist())
         sid = set_index.get(tpl)
         if sid is None:
             sid = set_index[tpl] = len(sets)
@@ -188,19 +202,33 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
     bounds = np.searchsorted(pid, np.arange(len(names) + 1))
     by_part = {n: ridx[bounds[i]:bounds[i + 1]] for i, n in enumerate(names)}
     # per-partition k1-mer rows with weights from the allowed dict (:452-477)
+    rows_bytes, n_nodes = {}, {}
     for name in names:
-        rows, ws = [], []
+        # fixed-width byte form of the k1-mer file (what the native graph stage consumes) + #distinct K-mers
+        chunks = []
         for contig in comps[name]:
-            wl = []
-            for i in range(len(contig) - k1 + 1):
-                km = contig[i:i + k1]
-                w = res.allowed.get(km, 0)
-                wl.append(w)
-                rows.append((km, w))
-            ws.append(wl)
-        files[name] = rows
-        cw[name] = ws
-    return {"new_components": comps, "components_broken": broken, "k1mers": files, "contig_weights": cw, "routes": by_part}
+            b = np.frombuffer(contig.encode(), dtype=np.uint8)
+            nwin = len(b) - k1 + 1
+            if nwin > 0:
+                chunks.append(np.lib.stride_tricks.sliding_window_view(b, k1).reshape(-1))
+        rb = np.concatenate(chunks) if chunks else np.zeros(0, np.uint8)
+        rows_bytes[name] = np.ascontiguousarray(rb)
+        kk = [windows_to_keys(c, K) for c in comps[name]]
+        n_nodes[name] = int(len(np.unique(np.concatenate(kk)))) if kk else 0
+        if want_rows:
+            rows, ws = [], []
+            for contig in comps[name]:
+                wl = []
+                for i in range(len(contig) - k1 + 1):
+                    km = contig[i:i + k1]
+                    w = res.allowed.get(km, 0)
+                    wl.append(w)
+                    rows.append((km, w))
+                ws.append(wl)
+            files[name] = rows
+            cw[name] = ws
+    return {"new_components": comps, "components_broken": broken, "k1mers": files, "contig_weights": cw, "routes": by_part,
+            "k1mer_bytes": rows_bytes, "n_kmer_nodes": n_nodes}
 
 
 class ReadStore(object):
@@ -220,6 +248,30 @@ class ReadStore(object):
     @staticmethod
     def _rc(s):
         return s[::-1].translate(_RC)
+
+    def gather(self, idx, mate):
+        """Reads `mate` (1 or 2) of the doubled indices `idx` as (uint8 ASCII buffer, uint64 offsets) -- the
+        byte layout shn_mbgraph_run takes.  Vectorised for code matrices."""
+        idx = np.asarray(idx, dtype=np.int64)
+        n = self.n
+        if len(idx) and not isinstance(self.r1[0], str):
+            second = idx >= n
+            i = np.where(second, idx - n, idx)
+            if mate == 1:
+                src_fwd = self.r1[i]                                    # d < n: R1[d]
+                other = (self.r2 if self.r2 is not None else self.r1)[i]  # d >= n: RC(R2[d-n]) (SE: RC(R[d-n]))
+                out = np.where(second[:, None], 3 - other[:, ::-1], src_fwd)
+            else:
+                out = np.where(second[:, None], self.r2[i], 3 - self.r1[i][:, ::-1])
+            L = out.shape[1]
+            buf = device.ALPHA_BYTES[out.astype(np.uint8)].reshape(-1)
+            return np.ascontiguousarray(buf), (np.arange(len(idx) + 1, dtype=np.uint64) * np.uint64(L))
+        strs = [self.mate1(int(d)) if mate == 1 else self.mate2(int(d)) for d in idx]
+        joined = "".join(strs).encode()
+        off = np.zeros(len(strs) + 1, dtype=np.uint64)
+        if strs:
+            off[1:] = np.cumsum([len(x) for x in strs], dtype=np.uint64)
+        return (np.frombuffer(joined, dtype=np.uint8) if joined else np.zeros(1, np.uint8)), off
 
     def mate1(self, d):
         """reads_1[d] (PE) / reads[d] (SE) of the strand-doubled input (shannon.py:396-424)."""

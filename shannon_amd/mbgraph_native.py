@@ -1,0 +1,67 @@
+"""ctypes front of the native multibridged-graph stage (csrc/mbgraph_host.hip, shn_mbgraph_run):
+same inputs / outputs as shannon_amd.mbgraph.run_partition, which remains the readable Python
+specification of the algorithm and is cross-checked against this in tests/test_host_graph.py."""
+import ctypes as C
+import numpy as np
+from . import _lib
+
+
+def _pack_reads(reads):
+    joined = "".join(reads).encode()
+    off = np.zeros(len(reads) + 1, dtype=np.uint64)
+    if reads:
+        off[1:] = np.cumsum([len(r) for r in reads], dtype=np.uint64)
+    return (np.frombuffer(joined, dtype=np.uint8) if joined else np.zeros(1, np.uint8)), off
+
+
+def run_partition_arrays(rows_bytes, n_rows, K, r1_buf, r1_off, r2_buf=None, r2_off=None, ctx=None):
+    """rows_bytes: uint8 array of n_rows*(K+1) bases; reads as (byte buffer, offsets).  Returns
+    (singles, comps, info) in the format of mbgraph.output_components."""
+    L = _lib.lib()
+    h = C.c_void_p()
+    n_reads = len(r1_off) - 1
+    paired = r2_buf is not None
+    _lib.check(L.shn_mbgraph_run(ctx.h if ctx is not None else None, K, rows_bytes.ctypes.data, n_rows, r1_buf.ctypes.data, r1_off.ctypes.data,
+                                 r2_buf.ctypes.data if paired else None, r2_off.ctypes.data if paired else None, n_reads,
+                                 1 if paired else 0, C.byref(h)))
+    sz = np.zeros(9, dtype=np.uint64)
+    _lib.check(L.shn_graph_sizes(h, sz.ctypes.data_as(_lib.u64p)))
+    ns, sb, nc, nn, nb, ne, npth, npid, ninfo = [int(x) for x in sz]
+    u64, f64, i32, u8 = np.uint64, np.float64, np.int32, np.uint8
+    s_off = np.zeros(ns + 1, u64); s_bases = np.zeros(max(sb, 1), u8); s_cc = np.zeros(max(ns, 1), f64); s_norm = np.zeros(max(ns, 1), f64)
+    cno = np.zeros(nc + 1, u64); ceo = np.zeros(nc + 1, u64); cpo = np.zeros(nc + 1, u64)
+    n_off = np.zeros(nn + 1, u64); n_bases = np.zeros(max(nb, 1), u8); n_cc = np.zeros(max(nn, 1), f64)
+    n_cci = np.zeros(max(nn, 1), u8); n_norm = np.zeros(max(nn, 1), f64)
+    e_in = np.zeros(max(ne, 1), i32); e_out = np.zeros(max(ne, 1), i32); e_w = np.zeros(max(ne, 1), i32)
+    e_cc = np.zeros(max(ne, 1), f64); e_norm = np.zeros(max(ne, 1), f64)
+    p_off = np.zeros(npth + 1, u64); p_ids = np.zeros(max(npid, 1), i32); info = np.zeros(max(ninfo, 1), i32)
+    arrs = [s_off, s_bases, s_cc, s_norm, cno, ceo, cpo, n_off, n_bases, n_cc, n_cci, n_norm, e_in, e_out, e_w, e_cc, e_norm,
+            p_off, p_ids, info]
+    _lib.check(L.shn_graph_export(h, *[a.ctypes.data for a in arrs]))
+    L.shn_graph_destroy(h)
+    sbs = s_bases.tobytes().decode()
+    singles = [(-1, sbs[int(s_off[i]):int(s_off[i + 1])], 0 if s_cc[i] == 0 else float(s_cc[i]), int(s_norm[i])) for i in range(ns)]
+    nbs = n_bases.tobytes().decode()
+    noff = n_off.tolist()
+    comps = []
+    for c in range(nc):
+        a, b = int(cno[c]), int(cno[c + 1])
+        nodes = [(i - a, nbs[noff[i]:noff[i + 1]], (0 if n_cci[i] else float(n_cc[i])), int(n_norm[i])) for i in range(a, b)]
+        ea, eb = int(ceo[c]), int(ceo[c + 1])
+        edges = [(int(e_in[i]), int(e_out[i]), int(e_w[i]), float(e_cc[i]), int(e_norm[i])) for i in range(ea, eb)]
+        pa, pb = int(cpo[c]), int(cpo[c + 1])
+        paths = [p_ids[int(p_off[i]):int(p_off[i + 1])].tolist() for i in range(pa, pb)]
+        comps.append({"nodes": nodes, "edges": edges, "paths": paths})
+    inf = info.tolist()
+    log = {"nodes_after": inf[:4], "final_nodes": inf[4], "known_paths": inf[5], "mate_paths": inf[6], "bridged": inf[8:8 + inf[7]]}
+    return singles, comps, log
+
+
+def run_partition(k1mer_rows, reads, K, paired=False, ctx=None):
+    """Drop-in for mbgraph.run_partition: k1mer_rows = [(k1mer, weight)], reads = [list] or [list1, list2]."""
+    rows = np.frombuffer("".join(k for k, _ in k1mer_rows).encode(), dtype=np.uint8) if k1mer_rows else np.zeros(1, np.uint8)
+    b1, o1 = _pack_reads(reads[0])
+    if paired:
+        b2, o2 = _pack_reads(reads[1])
+        return run_partition_arrays(rows, len(k1mer_rows), K, b1, o1, b2, o2, ctx=ctx)
+    return run_partition_arrays(rows, len(k1mer_rows), K, b1, o1, ctx=ctx)

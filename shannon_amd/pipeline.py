@@ -5,7 +5,7 @@ reference's --inMem hand-off); `shannon.py` at the repo root adds the CLI and th
 """
 import time
 import numpy as np
-from . import device, extension_correction as ec, kmers_for_component as kfc, mbgraph, sparse_flow, post
+from . import device, extension_correction as ec, kmers_for_component as kfc, mbgraph, mbgraph_native, sparse_flow, post
 
 
 class Result(object):
@@ -22,7 +22,8 @@ def n_kmer_nodes(rows, K):
 
 
 def assemble(ctx, reads1, reads2=None, K=25, partition_size=500, min_weight=3, min_length=75, overload=2, penalty=5,
-             sample="shannon", seed=0, double_stranded=True, part_vectors=None, timings=None, hits_factory=None):
+             sample="shannon", seed=0, double_stranded=True, part_vectors=None, timings=None, hits_factory=None,
+             native_graph=True):
     """reads1/reads2: lists of strings or uint8 code matrices (reads2 None = single-end).
     Returns Result with .partitions {name: dict}, .all_reconstructed (lines), .final {name: seq}."""
     T = timings if timings is not None else {}
@@ -38,11 +39,12 @@ def assemble(ctx, reads1, reads2=None, K=25, partition_size=500, min_weight=3, m
     store = kfc.ReadStore(reads1, reads2)
     tick("upload+pack", t0)
     return assemble_resident(ctx, d1, d2, store, K, partition_size, min_weight, min_length, overload, penalty, sample, seed,
-                             double_stranded, part_vectors, T, hits_factory)
+                             double_stranded, part_vectors, T, hits_factory, native_graph)
 
 
 def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3, min_length=75, overload=2, penalty=5,
-                      sample="shannon", seed=0, double_stranded=True, part_vectors=None, timings=None, hits_factory=None):
+                      sample="shannon", seed=0, double_stranded=True, part_vectors=None, timings=None, hits_factory=None,
+                      native_graph=True):
     """Same as assemble() with the reads already packed in HBM (d1/d2: device.Reads)."""
     T = timings if timings is not None else {}
     paired = d2 is not None
@@ -59,12 +61,13 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
     R.n_k1mers, R.n_windows = len(table), table.total
     tick("count", t0)
     t0 = time.time()
-    res = ec.run_correction(ctx, table, min_weight, min_length, partition_size)
+    res = ec.run_correction(ctx, table, min_weight, min_length, partition_size, want_allowed=not native_graph, timings=T)
     table.close()
     R.extension = res
     tick("extension", t0)
     t0 = time.time()
-    part = kfc.kmers_for_component(ctx, res, d1, d2, K, partition_size, overload, penalty, True, part_vectors)
+    part = kfc.kmers_for_component(ctx, res, d1, d2, K, partition_size, overload, penalty, True, part_vectors,
+                                   want_rows=not native_graph)
     tick("partition+route", t0)
     R.partitions = {}
     lines = []
@@ -73,17 +76,28 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
     sf_jobs = []
     for name in part["new_components"]:
         t0 = time.time()
-        rows = part["k1mers"][name]
-        cutoff = 10 * n_kmer_nodes(rows, K) + 1                      # multibridging.py:26-30, 385-391
+        cutoff = 10 * part["n_kmer_nodes"][name] + 1                 # multibridging.py:26-30, 385-391
         idx = part["routes"][name][:cutoff]
-        r1 = [store.mate1(int(d)) for d in idx]
-        reads = [r1, [store.mate2(int(d)) for d in idx]] if paired else [r1]
-        tick("materialize reads", t0)
-        t0 = time.time()
-        g, singles, comps = mbgraph.run_partition(rows, reads, K, paired, hits_factory)
+        if native_graph:
+            b1, o1 = store.gather(idx, 1)
+            b2, o2 = store.gather(idx, 2) if paired else (None, None)
+            tick("materialize reads", t0)
+            t0 = time.time()
+            rb = part["k1mer_bytes"][name]
+            singles, comps, glog = mbgraph_native.run_partition_arrays(rb if len(rb) else np.zeros(1, np.uint8), len(rb) // (K + 1), K,
+                                                                       b1, o1, b2, o2, ctx=ctx)
+            n_rows = len(rb) // (K + 1)
+        else:
+            rows = part["k1mers"][name]
+            r1 = [store.mate1(int(d)) for d in idx]
+            reads = [r1, [store.mate2(int(d)) for d in idx]] if paired else [r1]
+            tick("materialize reads", t0)
+            t0 = time.time()
+            g, singles, comps = mbgraph.run_partition(rows, reads, K, paired, hits_factory)
+            glog, n_rows = g.log, len(rows)
         tick("graph", t0)
-        R.partitions[name] = {"n_reads_routed": len(part["routes"][name]), "n_k1mers": len(rows), "singles": singles,
-                              "components": comps, "log": g.log}
+        R.partitions[name] = {"n_reads_routed": len(part["routes"][name]), "n_k1mers": n_rows, "singles": singles,
+                              "components": comps, "log": glog}
         sf_jobs.append((name, singles, comps))
     t0 = time.time()
     flat = [(nd["nodes"], nd["edges"], nd["paths"]) for _, _, comps in sf_jobs for nd in comps]

@@ -135,3 +135,35 @@ def test_native_contig_graph_matches_oracle(name):
     assert [cands[i] for i in np.nonzero(acc)[0]] == ref.contigs
     conn = {a + 1: list(zip(cnb[int(coff[a]):int(coff[a + 1])].tolist(), cw[int(coff[a]):int(coff[a + 1])].tolist())) for a in range(na.value)}
     assert conn == {k: list(v.items()) for k, v in ref.connections.items()}      # same neighbours, weights AND insertion order
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_native_graph_stage(name):
+    """shn_mbgraph_run (native host code) == the Python mirror == the reference goldens."""
+    from shannon_amd import mbgraph_native, build
+    build.build(verbose=False)
+    g = load_case(name)
+    K, paired = g["K"], g["paired"]
+    psize = MANIFEST[name].get("partition_size", 500)
+    inp = load_inputs(name)
+    dbl = list(seqs.double_strand_paired(*inp)) if paired else [seqs.double_strand_single(inp[0])]
+    tab = count.count_k1mers_dict([r for f in dbl for r in f], K + 1)
+    res = extension.run_correction([(k, tab[k]) for k in sorted(tab, reverse=True)], comp_size_threshold=psize)
+    pv = [part_vectors(len(cl), psize) for cl, _ in res.big_components]
+    nc, k2c = partition.build_partitions([b[0] for b in res.big_components], [p[0] for p in pv], [p[1] for p in pv] if pv else None,
+                                         res.remaining, res.allowed, K)
+    if paired:
+        o1, o2 = partition.route_reads_paired(dbl[0], dbl[1], nc, k2c, K)
+    else:
+        o1 = partition.route_reads(dbl[0], nc, k2c, K)
+    files, _ = partition.partition_k1mers(nc, k2c, K)
+    for comp, gp in g["partitions"].items():
+        reads = [o1[comp], o2[comp]] if paired else [o1[comp]]
+        singles, comps, log = mbgraph_native.run_partition(files[comp], reads, K, paired)
+        gr, s2, c2 = mbgraph.run_partition(files[comp], reads, K, paired)
+        assert singles == s2                       # identical to the Python mirror, IDs and order included
+        assert comps == c2
+        assert ["Bridged %d nodes" % b for b in log["bridged"]] == [l for l in gr.log if "Bridged" in l]
+        can = mbgraph.canonical(singles, comps)
+        for k in can:
+            assert approx_eq(can[k], gp["graph"][k]), (comp, k)
