@@ -388,13 +388,14 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
 
 // classify the walks for the next round and lay out the path pool: long walks (memo or length) go to the
 // wavefront kernel (dirty or not -- clean ones only copy their memo); dirty short walks go to the thread kernel
-__global__ void ext_plan_kernel(const uint32_t* __restrict__ nr, const uint32_t* __restrict__ nl, uint64_t ns,
+__global__ void ext_plan_kernel(const uint32_t* __restrict__ nr, const uint32_t* __restrict__ nl, uint64_t ns, uint32_t frozen,
                                 const uint32_t* __restrict__ pool_prev, const uint64_t* __restrict__ poff_prev,
                                 const uint8_t* __restrict__ pstored_prev, const uint8_t* __restrict__ dirty,
                                 uint8_t* __restrict__ is_long, uint32_t* __restrict__ long_list, uint32_t* __restrict__ short_list,
                                 uint64_t* __restrict__ poff, uint32_t* __restrict__ pcap, unsigned long long* __restrict__ counters,
                                 uint64_t pool_cap) {
-  uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // ns here = current rank limit (walks >= limit have not started yet); walks < frozen are final and never run
+  uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + frozen;
   if (r >= ns) return;
   uint32_t a = nr[r];
   uint32_t len = a == UNCLAIMED ? 0 : a + nl[r];
@@ -429,26 +430,30 @@ __global__ void ext_release_kernel(u64* __restrict__ claim, uint64_t n2, const u
 __global__ void ext_mark_kernel(const u64* __restrict__ claim, const u64* __restrict__ claim_old, uint64_t n2,
                                 const Adj4* __restrict__ adjR, const Adj4* __restrict__ adjL, const uint32_t* __restrict__ seed_rank,
                                 uint8_t* __restrict__ dirty, const uint8_t* __restrict__ ran, uint32_t* __restrict__ owned,
-                                unsigned long long* __restrict__ n_changed) {
+                                unsigned long long* __restrict__ n_changed, uint32_t frozen, uint32_t limit) {
   uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (y >= n2) return;
   uint32_t a = RANK(claim_old[y]), b = RANK(claim[y]);
   if (b != UNCLAIMED && ran[b]) atomicAdd(&owned[b], 1u);
   if (a == b) return;
   atomicAdd(n_changed, 1ULL);
-  if (a != UNCLAIMED) dirty[a] = 1;
-  if (b != UNCLAIMED) dirty[b] = 1;
+  // a walk depends only on lower ranks: walks below `frozen` are final whatever happens above them; walks at or
+  // above `limit` have not started (they all run when their phase opens)
+#define MARK(x) if ((x) >= frozen && (x) < limit) dirty[x] = 1
+  MARK(a);
+  MARK(b);
   uint32_t sr = seed_rank[y];
-  if (sr != UNCLAIMED) dirty[sr] = 1;
+  MARK(sr);
   Adj4 L = adjL[y], R = adjR[y];
 #pragma unroll
   for (int q = 0; q < 8; q++) {
     int32_t nb = q < 4 ? L.v[q] : R.v[q - 4];
     if (nb < 0) continue;
     uint32_t x = RANK(claim_old[nb]), z = RANK(claim[nb]);
-    if (x != UNCLAIMED) dirty[x] = 1;
-    if (z != UNCLAIMED) dirty[z] = 1;
+    MARK(x);
+    MARK(z);
   }
+#undef MARK
 }
 
 // A walk that ran this round must own exactly the k1-mers on the path it recorded; if a lower rank took one
@@ -606,7 +611,6 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
   uint8_t* ran = dirty + ns + 1;
   uint32_t* seed_rank = (uint32_t*)pseed;
   TRYE(hipMemsetAsync(pst_a, 0, 2 * (ns + 1), s));
-  TRYE(hipMemsetAsync(dirty, 1, ns + 1, s));                 // first round: every walk runs
   TRYE(hipMemsetAsync(seed_rank, 0xFF, (2 * n + 1) * 4, s));
   if (ns) hipLaunchKernelGGL(ext_seed_rank_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, e->d_order, (uint64_t)ns, seed_rank);
   hipStream_t aux = nullptr;
@@ -618,6 +622,12 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
   bool converged = ns == 0;
   unsigned long long last_long = 0;
   const uint32_t g2n = (uint32_t)cdiv(2 * n, 256);
+  // Rank phases: a walk depends only on lower ranks, so the fixpoint is reached block by block -- first the
+  // heaviest seeds (where the long, mutually dependent walks live), then geometrically larger blocks that see
+  // final lower ranks and settle in a few rounds.
+  uint32_t frozen = 0, limit = (uint32_t)std::min<unsigned long long>(ns, std::max<unsigned long long>(ns / 32, 4096));
+  TRYE(hipMemsetAsync(dirty, 0, ns + 1, s));
+  TRYE(hipMemsetAsync(dirty, 1, limit, s));
   while (!converged && it < max_iterations) {
     TimerRegion t3(ctx, T_EXT_WALK);
     // snapshot, then release the claims of the walks that re-run this round
@@ -625,8 +635,9 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
     hipLaunchKernelGGL(ext_release_kernel, dim3(g2n), dim3(256), 0, s, claim, 2 * n, dirty, (uint64_t)ns);
     TRYE(hipMemsetAsync(d_cnt + 2, 0, 24, s));
     TRYE(hipMemsetAsync(d_cnt + 6, 0, 16, s));
-    hipLaunchKernelGGL(ext_plan_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, e->d_nr, e->d_nl, (uint64_t)ns, pool_a, poff_a, pst_a,
-                       dirty, is_long, long_list, short_list, poff_b, pcap, d_cnt + 2, pool_cap);
+    if (limit > frozen)
+      hipLaunchKernelGGL(ext_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 256)), dim3(256), 0, s, e->d_nr, e->d_nl, (uint64_t)limit, frozen,
+                         pool_a, poff_a, pst_a, dirty, is_long, long_list, short_list, poff_b, pcap, d_cnt + 2, pool_cap);
     unsigned long long plan[3] = {0, 0, 0};
     TRYE(hipMemcpyAsync(plan, d_cnt + 2, 24, hipMemcpyDeviceToHost, s));
     TRYE(hipStreamSynchronize(s));
@@ -652,19 +663,27 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
     TRYE(hipMemsetAsync(dirty, 0, ns + 1, s));
     TRYE(hipMemsetAsync(owned, 0, (ns + 1) * 4, s));
     hipLaunchKernelGGL(ext_mark_kernel, dim3(g2n), dim3(256), 0, s, claim, snap, 2 * n, (const Adj4*)e->d_adjR, (const Adj4*)e->d_adjL,
-                       seed_rank, dirty, ran, owned, d_cnt + 6);
+                       seed_rank, dirty, ran, owned, d_cnt + 6, frozen, limit);
     hipLaunchKernelGGL(ext_verify_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, ran, owned, e->d_nr, e->d_nl, (uint64_t)ns, dirty,
                        d_cnt + 7);
     unsigned long long chg[2] = {0, 0};
     TRYE(hipMemcpyAsync(chg, d_cnt + 6, 16, hipMemcpyDeviceToHost, s));
     TRYE(hipStreamSynchronize(s));
     unsigned long long nchanged = chg[0] + chg[1];
-    if (getenv("SHN_EXT_ALLDIRTY")) TRYE(hipMemsetAsync(dirty, 1, ns + 1, s));    // debug: plain Jacobi, every walk every round
+    if (getenv("SHN_EXT_ALLDIRTY")) { TRYE(hipMemsetAsync(dirty, 0, ns + 1, s)); TRYE(hipMemsetAsync(dirty + frozen, 1, limit - frozen, s)); }
     it++;
     last_long = plan[0];
-    if (getenv("SHN_DEBUG")) fprintf(stderr, "[shn_extend] round %d: long=%llu short_dirty=%llu changed_kmers=%llu unstable=%llu\n", it, plan[0], plan[2], chg[0], chg[1]);
+    if (getenv("SHN_DEBUG")) fprintf(stderr, "[shn_extend] round %d [%u,%u): long=%llu short_dirty=%llu changed_kmers=%llu unstable=%llu\n", it, frozen, limit,
+                                     plan[0], plan[2], chg[0], chg[1]);
     std::swap(pool_a, pool_b); std::swap(poff_a, poff_b); std::swap(pst_a, pst_b);
-    if (nchanged == 0) converged = true;
+    if (nchanged == 0) {
+      if (limit >= ns) converged = true;
+      else {                                   // this block is final: open the next one
+        frozen = limit;
+        limit = (uint32_t)std::min<unsigned long long>(ns, (unsigned long long)limit * 4);
+        TRYE(hipMemsetAsync(dirty + frozen, 1, limit - frozen, s));
+      }
+    }
   }
   hipStreamSynchronize(aux);
   hipStreamDestroy(aux);
