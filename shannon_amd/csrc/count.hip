@@ -112,14 +112,14 @@ __device__ __forceinline__ uint32_t digit_of(uint64_t key, int bits, int b2) {
 
 template <bool L1>
 __global__ __launch_bounds__(BLK) void hist_keys_kernel(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ segoff,
-                                                        int bits, int b2, uint32_t* __restrict__ hist) {
+                                                        int bits, int b2, uint32_t* __restrict__ hist, uint32_t tile_keys) {
   extern __shared__ uint32_t lh[];
   const int nb = L1 ? (1 << (bits - b2)) : (1 << b2);
   const uint32_t p = blockIdx.y;
   const uint64_t s0 = segoff[p], s1 = segoff[p + 1];
-  uint64_t t0 = s0 + (uint64_t)blockIdx.x * TILE_KEYS;
+  uint64_t t0 = s0 + (uint64_t)blockIdx.x * tile_keys;
   if (t0 >= s1) return;
-  uint64_t t1 = min(t0 + TILE_KEYS, s1);
+  uint64_t t1 = min(t0 + (uint64_t)tile_keys, s1);
   for (int i = threadIdx.x; i < nb; i += BLK) lh[i] = 0;
   __syncthreads();
   for (uint64_t i = t0 + threadIdx.x; i < t1; i += BLK)
@@ -152,16 +152,16 @@ template <bool L1, bool HASC>
 __global__ __launch_bounds__(BLK) void scatter_keys_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ cin,
                                                            const uint64_t* __restrict__ segoff, int bits, int b2,
                                                            uint32_t* __restrict__ cursor, uint64_t* __restrict__ out,
-                                                           uint32_t* __restrict__ cout) {
+                                                           uint32_t* __restrict__ cout, uint32_t tile_keys) {
   extern __shared__ uint32_t lds[];
   const int nb = L1 ? (1 << (bits - b2)) : (1 << b2);
   uint32_t* lh = lds;
   uint32_t* lbase = lds + nb;
   const uint32_t p = blockIdx.y;
   const uint64_t s0 = segoff[p], s1 = segoff[p + 1];
-  uint64_t t0 = s0 + (uint64_t)blockIdx.x * TILE_KEYS;
+  uint64_t t0 = s0 + (uint64_t)blockIdx.x * tile_keys;
   if (t0 >= s1) return;
-  uint64_t t1 = min(t0 + TILE_KEYS, s1);
+  uint64_t t1 = min(t0 + (uint64_t)tile_keys, s1);
   for (int i = threadIdx.x; i < nb; i += BLK) lh[i] = 0;
   __syncthreads();
   for (uint64_t i = t0 + threadIdx.x; i < t1; i += BLK)
@@ -203,10 +203,33 @@ __global__ __launch_bounds__(BLK) void buckets_kernel(const uint64_t* __restrict
   for (int i = threadIdx.x; i < CAP; i += BLK) { tk[i] = EMPTY_KEY; tc[i] = 0; }
   if (threadIdx.x == 0) { lcount = 0; lall = 0; }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < n; i += BLK) {
-    unsigned long long key = keys[s0 + i];
-    uint32_t w = HASC ? cin[s0 + i] : 1u;
-    if (key == EMPTY_KEY) { atomicAdd(&lall, w); continue; }      // k=32, non-canonical all-T
+  for (uint32_t base = 0; base < n; base += BLK) {
+    const uint32_t i = base + threadIdx.x;
+    bool active = i < n;
+    unsigned long long key = active ? keys[s0 + i] : 0ULL;
+    uint32_t w = active ? (HASC ? cin[s0 + i] : 1u) : 0u;
+    if (active && key == EMPTY_KEY) { atomicAdd(&lall, w); active = false; }      // k=32, non-canonical all-T
+    // heavy k-mers (77,000x coverage in config[1]) would serialise on one LDS slot: two rounds of wave-level
+    // leader election fold the lanes holding the wave's first two distinct keys into one atomic each
+    const int lane = threadIdx.x & 63;
+    bool elect = active;                       // lanes whose key has not been looked at yet
+#pragma unroll
+    for (int round = 0; round < 2; round++) {
+      unsigned long long act = __ballot(elect);
+      if (!act) break;
+      int leader = __ffsll((long long)act) - 1;
+      unsigned long long lk = __shfl(key, leader, 64);
+      bool same = elect && key == lk;
+      unsigned long long m = __ballot(same);
+      if (__popcll(m) > 1) {
+        uint32_t tot = same ? w : 0u;
+        if (HASC) { for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64); }
+        else tot = (uint32_t)__popcll(m);
+        if (lane == leader) w = tot; else if (same) active = false;
+      }
+      if (same) elect = false;
+    }
+    if (!active) continue;
     uint32_t slot = (uint32_t)(shn_mix64(key ^ 0x9E3779B97F4A7C15ULL)) & (CAP - 1);
     for (int probe = 0; probe < CAP; probe++) {
       unsigned long long prev = atomicCAS(&tk[slot], EMPTY_KEY, key);
@@ -457,16 +480,18 @@ static int build_from_keys(shn_ctx* ctx, uint64_t* keysA, uint64_t* keysB, uint3
   HIP_TRY(hipMemcpyAsync(d_off1, off1h.data(), (size_t)(nb1 + 1) * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(d_hist2, 0, nbk * 4, s));
   HIP_TRY(hipMemsetAsync(d_ovf, 0, 4, s));
-  uint32_t tiles = (uint32_t)std::max<uint64_t>(1, cdiv(max1, TILE_KEYS));
+  // level-2 tile: long enough that a (tile, bucket) run is ~64 keys = 512 B (full lines for the L2 write combiner)
+  const uint32_t tile2 = TILE_KEYS;
+  uint32_t tiles = (uint32_t)std::max<uint64_t>(1, cdiv(max1, tile2));
   {
     TimerRegion t(ctx, T_HIST2);
-    hipLaunchKernelGGL(hist_keys_kernel<false>, dim3(tiles, nb1), dim3(BLK), nb2 * 4, s, keysA, d_off1, bits, b2, d_hist2);
+    hipLaunchKernelGGL(hist_keys_kernel<false>, dim3(tiles, nb1), dim3(BLK), nb2 * 4, s, keysA, d_off1, bits, b2, d_hist2, tile2);
     hipLaunchKernelGGL(scan_rows_kernel, dim3(nb1), dim3(BLK), 0, s, d_hist2, nb2, d_off2, d_cursor2);
   }
   {
     TimerRegion t(ctx, T_SCATTER2);
-    if (cntA) hipLaunchKernelGGL((scatter_keys_kernel<false, true>), dim3(tiles, nb1), dim3(BLK), nb2 * 8, s, keysA, cntA, d_off1, bits, b2, d_cursor2, keysB, cntB);
-    else hipLaunchKernelGGL((scatter_keys_kernel<false, false>), dim3(tiles, nb1), dim3(BLK), nb2 * 8, s, keysA, nullptr, d_off1, bits, b2, d_cursor2, keysB, nullptr);
+    if (cntA) hipLaunchKernelGGL((scatter_keys_kernel<false, true>), dim3(tiles, nb1), dim3(BLK), nb2 * 8, s, keysA, cntA, d_off1, bits, b2, d_cursor2, keysB, cntB, tile2);
+    else hipLaunchKernelGGL((scatter_keys_kernel<false, false>), dim3(tiles, nb1), dim3(BLK), nb2 * 8, s, keysA, nullptr, d_off1, bits, b2, d_cursor2, keysB, nullptr, tile2);
   }
   {
     TimerRegion t(ctx, T_COUNT);
@@ -614,7 +639,7 @@ extern "C" int shn_table_from_pairs(shn_ctx* ctx, const void* dev_keys, const vo
     uint32_t tiles = (uint32_t)std::max<uint64_t>(1, cdiv(n, TILE_KEYS));
     {
       TimerRegion t(ctx, T_HIST1);
-      hipLaunchKernelGGL(hist_keys_kernel<true>, dim3(tiles, 1), dim3(BLK), nb1 * 4, s, keys, d_seg, bits, b2, d_h);
+      hipLaunchKernelGGL(hist_keys_kernel<true>, dim3(tiles, 1), dim3(BLK), nb1 * 4, s, keys, d_seg, bits, b2, d_h, (uint32_t)TILE_KEYS);
       hipLaunchKernelGGL(scan_rows_kernel, dim3(1), dim3(BLK), 0, s, d_h, nb1, d_o, d_c);
       hipLaunchKernelGGL(sum_counts_kernel, dim3(256), dim3(256), 0, s, cnts, n, d_tot);
     }
@@ -630,7 +655,7 @@ extern "C" int shn_table_from_pairs(shn_ctx* ctx, const void* dev_keys, const vo
     {
       TimerRegion t(ctx, T_SCATTER1);
       hipLaunchKernelGGL((scatter_keys_kernel<true, true>), dim3(tiles, 1), dim3(BLK), nb1 * 8, s, keys, cnts, d_seg, bits, b2, d_c,
-                         (uint64_t*)pa, (uint32_t*)pca);
+                         (uint64_t*)pa, (uint32_t*)pca, (uint32_t)TILE_KEYS);
     }
     bool ov = false;
     rc = build_from_keys(ctx, (uint64_t*)pa, (uint64_t*)pb, (uint32_t*)pc, (uint32_t*)pca, (uint32_t*)pcb, off1, bits, b2, k1,

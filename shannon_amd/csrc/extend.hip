@@ -199,10 +199,11 @@ __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
       // round (EMIT: a scratch array for the own trail)
       bool isvoid = RANK(final_claim[o]) < r || (!EMIT && RANK(__hip_atomic_load(&A.claim[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < r);
       uint8_t* dst = nullptr;
-      uint32_t nl_known = 0;
+      uint32_t nl_known = 0, nr_known = 0;
       if (EMIT && !isvoid) {
         dst = out_bases + out_off[t];
         nl_known = A.nl_out[r];
+        nr_known = A.nr_out[r];
         uint64_t s = oriented_string(tkeys, o, k);
         for (int j = 0; j < k; j++) dst[nl_known + j] = "ACGT"[(s >> (2 * (k - 1 - j))) & 3];
       }
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
             pos++;
             __hip_atomic_fetch_min(&A.claim[nbest], CLAIM(r, pos), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (EMIT) {
-              const uint32_t lim = dir == 0 ? A.nr_out[r] : nl_known;
+              const uint32_t lim = dir == 0 ? nr_known : nl_known;
               if (steps >= lim) { atomicAdd(A.steps_counter, 1ULL); break; }      // re-walk left its recorded path: flag, do not write
               if (dir == 0) dst[nl_known + k + steps] = "ACGT"[best];
               else dst[nl_known - 1 - steps] = "ACGT"[best];
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
             tot += bw;
             cand = best == 0 ? nxt[0] : best == 1 ? nxt[1] : best == 2 ? nxt[2] : nxt[3];
           }
-          if (EMIT && steps != (dir == 0 ? A.nr_out[r] : nl_known)) atomicAdd(A.steps_counter, 1ULL << 32);
+          if (EMIT && steps != (dir == 0 ? nr_known : nl_known)) atomicAdd(A.steps_counter, 1ULL << 32);
           if (dir == 0) nr = steps; else nl = steps;
         }
       }
@@ -432,11 +433,14 @@ __global__ void ext_mark_kernel(const u64* __restrict__ claim, const u64* __rest
                                 uint8_t* __restrict__ dirty, const uint8_t* __restrict__ ran, uint32_t* __restrict__ owned,
                                 unsigned long long* __restrict__ n_changed, uint32_t frozen, uint32_t limit) {
   uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t a = UNCLAIMED, b = UNCLAIMED;
+  if (y < n2) { a = RANK(claim_old[y]); b = RANK(claim[y]); }
+  // one atomic per wavefront for the change counter (it was one per changed k1-mer on a single address)
+  unsigned long long chm = __ballot(a != b);
+  if (chm && (threadIdx.x & 63) == (uint32_t)(__ffsll((long long)chm) - 1)) atomicAdd(n_changed, (unsigned long long)__popcll(chm));
   if (y >= n2) return;
-  uint32_t a = RANK(claim_old[y]), b = RANK(claim[y]);
   if (b != UNCLAIMED && ran[b]) atomicAdd(&owned[b], 1u);
   if (a == b) return;
-  atomicAdd(n_changed, 1ULL);
   // a walk depends only on lower ranks: walks below `frozen` are final whatever happens above them; walks at or
   // above `limit` have not started (they all run when their phase opens)
 #define MARK(x) if ((x) >= frozen && (x) < limit) dirty[x] = 1

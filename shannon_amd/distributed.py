@@ -117,7 +117,7 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
     for i in owned:
         recs = sorted(mine.get(i, []))
         reads = [[x[1] for x in recs], [x[2] for x in recs]] if paired else [[x[1] for x in recs]]
-        g_, singles, comps = mbgraph.run_partition(part["k1mers"][names[i]], reads, K, paired, ops.hits_factory())
+        singles, comps = ops.graph(part["k1mers"][names[i]], reads, K, paired)
         jobs.append((i, singles, comps))
     tick("graph", t0)
     t0 = time.time()
@@ -211,9 +211,10 @@ class GpuOps(object):
     def mate2(self, d):
         return self.store.mate2(d)
 
-    def hits_factory(self):
-        from . import graph_seeds
-        return graph_seeds.hits_factory(self.ctx)
+    def graph(self, rows, reads, K, paired):
+        from . import mbgraph_native
+        singles, comps, _log = mbgraph_native.run_partition(rows, reads, K, paired, ctx=self.ctx)
+        return singles, comps
 
     def sparse_flow(self, flat, ids, seed):
         from .pipeline import _sparse_flow_with_ids

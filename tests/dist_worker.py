@@ -85,8 +85,10 @@ class OracleOps(object):
     def mate2(self, d):
         return self.store.mate2(d)
 
-    def hits_factory(self):
-        return None
+    def graph(self, rows, reads, K, paired):
+        from shannon_amd import mbgraph_native
+        singles, comps, _log = mbgraph_native.run_partition(rows, reads, K, paired)      # native host code, seed scans on the CPU
+        return singles, comps
 
     def sparse_flow(self, flat, ids, seed):
         return [osf.sparse_flow_component(nd, ed, pt, seed=seed, comp_id=c) for (nd, ed, pt), c in zip(flat, ids)]
