@@ -185,6 +185,12 @@ int shn_graph_export(const shn_graph* g, uint64_t* s_off, uint8_t* s_bases, doub
                      uint8_t* n_bases, double* n_cc, uint8_t* n_cc_int, double* n_norm, int32_t* e_in, int32_t* e_out,
                      int32_t* e_w, double* e_cc, double* e_norm, uint64_t* p_off, int32_t* p_ids, int32_t* info);
 
+/* ---- final containment de-duplication (host, native) ------------------------------------------------
+ * Replaces faster_reps.find_reps (faster_reps.py:98-131, duplicate_check_ends :60-92; called `-d` from
+ * shannon.py:604).  n FASTA records in file order (names without '>', sequences), r = 24.            */
+int shn_find_reps(const uint8_t* names, const uint64_t* name_off, const uint8_t* seqs, const uint64_t* seq_off, uint64_t n,
+                  int ds, int r, uint8_t* keep_out);
+
 /* ---- sparse-flow node decomposition ------------------------------------------------------------
  * Replaces the randomized trial loop of path_decompose (path_decompose_sparse.py:100-117): the
  * <=100 cvxopt.solvers.lp calls per decomposed node (cvxopt: third party, version unpinned, not

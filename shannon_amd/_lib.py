@@ -50,6 +50,7 @@ SIGNATURES = {
     "shn_graph_destroy": (None, [vp]),
     "shn_graph_sizes": (C.c_int, [vp, u64p]),
     "shn_graph_export": (C.c_int, [vp] + [vp] * 20),
+    "shn_find_reps": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp]),
     "shn_extend": (C.c_int, [vp, vp, C.c_uint32, C.c_int, vpp]),
     "shn_ext_destroy": (None, [vp]),
     "shn_ext_n_walks": (C.c_uint64, [vp]),

@@ -5,6 +5,7 @@
 // native code because at 10M reads ~2,000 candidate contigs x ~2,000 bases of Python dict work
 // were a third of the host time.
 #include "common.h"
+#include "flatmap.h"
 #include <unordered_map>
 #include <vector>
 #include <algorithm>
@@ -40,12 +41,12 @@ extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint6
   static thread_local uint64_t cached_n = ~0ULL;
   static thread_local const uint8_t* cached_ptr = nullptr;
   if (!(conn_nb && cached_n == n_cand && cached_ptr == bases)) {
-    std::unordered_map<uint64_t, std::vector<int32_t>> rmer, cmer;
-    rmer.reserve(1 << 16); cmer.reserve(1 << 16);
+    uint64_t total_bases = off[n_cand] - off[0];
+    FlatMultiMap rmer(total_bases / 2 + 1024), cmer(total_bases / 2 + 1024);
     conns.clear(); conns.emplace_back();                 // index 0 unused (contigs are 1-based)
     accepted.assign(n_cand, 0);
     std::vector<uint64_t> rk, ck;
-    std::vector<const std::vector<int32_t>*> hits;
+    std::vector<int32_t> hits;                              // first value index in rmer (or -1) per window
     std::unordered_map<int32_t, int32_t> dup;
     std::vector<int32_t> cov;
     const int C = k1 - 1;
@@ -54,14 +55,14 @@ extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint6
       const uint8_t* s = bases + off[c];
       uint32_t L = (uint32_t)(off[c + 1] - off[c]);
       window_keys(s, L, r, rk);
-      hits.assign(rk.size(), nullptr);
+      hits.assign(rk.size(), -1);
       dup.clear();
       int32_t max_till_now = 0, best = -1;
       for (size_t i = 0; i < rk.size(); i++) {
-        auto it = rmer.find(rk[i]);
-        if (it == rmer.end()) continue;
-        hits[i] = &it->second;
-        for (int32_t d : it->second) {
+        int32_t v = rmer.find(rk[i]);
+        hits[i] = v;
+        for (; v >= 0; v = rmer.next[v]) {
+          int32_t d = rmer.va[v];
           int32_t cnt = ++dup[d];
           if (cnt >= max_till_now) { max_till_now = cnt; best = d; }      // `>=`: the latest wins (:258-259)
         }
@@ -69,8 +70,11 @@ extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint6
       bool suspect = false;
       if (best >= 0) {
         cov.assign(L + 1, 0);
-        for (size_t i = 0; i < rk.size(); i++)
-          if (hits[i] && std::find(hits[i]->begin(), hits[i]->end(), best) != hits[i]->end()) { cov[i] += 1; cov[i + r] -= 1; }
+        for (size_t i = 0; i < rk.size(); i++) {
+          bool has = false;
+          for (int32_t v = hits[i]; v >= 0 && !has; v = rmer.next[v]) has = rmer.va[v] == best;
+          if (has) { cov[i] += 1; cov[i + r] -= 1; }
+        }
         int64_t run = 0, covered = 0;
         for (uint32_t i = 0; i < L; i++) { run += cov[i]; if (run > 0) covered++; }
         suspect = (double)covered > f * (double)L;
@@ -81,8 +85,8 @@ extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint6
       conns.emplace_back();
       window_keys(s, L, C, ck);
       for (uint64_t key : ck) {
-        auto& lst = cmer[key];
-        for (int32_t c2 : lst) {
+        for (int32_t v = cmer.find(key); v >= 0; v = cmer.next[v]) {
+          int32_t c2 = cmer.va[v];
           if (c2 == idx) continue;
           Conn& a = conns[idx];
           auto pa = a.pos.find(c2);
@@ -91,9 +95,9 @@ extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint6
           auto pb = b.pos.find(idx);
           if (pb == b.pos.end()) { b.pos[idx] = (int32_t)b.nb.size(); b.nb.push_back(idx); b.w.push_back(1); } else b.w[pb->second]++;
         }
-        lst.push_back(idx);
+        cmer.add(key, idx);
       }
-      for (uint64_t key : rk) rmer[key].push_back(idx);
+      for (uint64_t key : rk) rmer.add(key, idx);
     }
     cached_n = n_cand; cached_ptr = bases;
   }

@@ -1,0 +1,78 @@
+// Small open-addressing containers for the native host stages (no per-key heap allocation).
+#pragma once
+#include <stdint.h>
+#include <vector>
+#include <string>
+#include <cstring>
+
+static inline uint64_t fm_mix(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return x;
+}
+
+// uint64 key -> values (int32 pairs) in insertion order
+struct FlatMultiMap {
+  std::vector<uint64_t> keys;
+  std::vector<int32_t> head, tail;        // -1 = empty slot
+  std::vector<int32_t> va, vb, next;      // value pool: (a, b) + next index
+  size_t mask = 0, used = 0;
+  explicit FlatMultiMap(size_t expect = 1024) { size_t c = 1024; while (c < expect * 2) c <<= 1; resize(c); }
+  void resize(size_t c) {
+    std::vector<uint64_t> ok; ok.swap(keys);
+    std::vector<int32_t> oh, ot; oh.swap(head); ot.swap(tail);
+    keys.assign(c, 0); head.assign(c, -1); tail.assign(c, -1); mask = c - 1; used = 0;
+    for (size_t i = 0; i < oh.size(); i++) if (oh[i] >= 0) { size_t s = slot(ok[i]); keys[s] = ok[i]; head[s] = oh[i]; tail[s] = ot[i]; used++; }
+  }
+  size_t slot(uint64_t k) const { size_t s = fm_mix(k) & mask; while (head[s] >= 0 && keys[s] != k) s = (s + 1) & mask; return s; }
+  // first value index of k or -1; iterate with next[]
+  int32_t find(uint64_t k) const { size_t s = slot(k); return head[s]; }
+  void add(uint64_t k, int32_t a, int32_t b = 0) {
+    if ((used + 1) * 10 > (mask + 1) * 6) resize((mask + 1) * 2);
+    size_t s = slot(k);
+    int32_t v = (int32_t)va.size();
+    va.push_back(a); vb.push_back(b); next.push_back(-1);
+    if (head[s] < 0) { keys[s] = k; head[s] = v; tail[s] = v; used++; }
+    else { next[tail[s]] = v; tail[s] = v; }
+  }
+};
+
+// byte-string -> dense id (insertion order); strings live in one arena
+struct StringInterner {
+  std::vector<int32_t> table;             // -1 = empty, else id
+  std::vector<uint64_t> hashes;           // per id
+  std::vector<uint64_t> off;              // per id: arena offset (off[id+1] = end)
+  std::string arena;
+  size_t mask = 0;
+  explicit StringInterner(size_t expect = 1024) { size_t c = 1024; while (c < expect * 2) c <<= 1; table.assign(c, -1); mask = c - 1; off.push_back(0); }
+  static uint64_t hash(const char* p, size_t n) {
+    uint64_t h = 0x9E3779B97F4A7C15ULL ^ n;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t w; memcpy(&w, p + i, 8); h = fm_mix(h ^ w); }
+    uint64_t w = 0;
+    if (i < n) { memcpy(&w, p + i, n - i); h = fm_mix(h ^ w ^ 0xA5A5A5A5ULL); }
+    return h;
+  }
+  size_t size() const { return hashes.size(); }
+  const char* data(int32_t id) const { return arena.data() + off[id]; }
+  size_t len(int32_t id) const { return off[id + 1] - off[id]; }
+  // returns id; *is_new tells whether it was inserted now
+  int32_t intern(const char* p, size_t n, bool* is_new) {
+    if ((hashes.size() + 1) * 10 > (mask + 1) * 6) grow();
+    uint64_t h = hash(p, n);
+    size_t s = h & mask;
+    while (table[s] >= 0) {
+      int32_t id = table[s];
+      if (hashes[id] == h && len(id) == n && memcmp(data(id), p, n) == 0) { *is_new = false; return id; }
+      s = (s + 1) & mask;
+    }
+    int32_t id = (int32_t)hashes.size();
+    table[s] = id; hashes.push_back(h); arena.append(p, n); off.push_back(arena.size());
+    *is_new = true;
+    return id;
+  }
+  void grow() {
+    size_t c = (mask + 1) * 2;
+    table.assign(c, -1); mask = c - 1;
+    for (size_t id = 0; id < hashes.size(); id++) { size_t s = hashes[id] & mask; while (table[s] >= 0) s = (s + 1) & mask; table[s] = (int32_t)id; }
+  }
+};

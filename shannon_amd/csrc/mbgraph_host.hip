@@ -5,6 +5,7 @@
 // host code; the order-defining conventions (P1-P3) are identical to the Python mirror,
 // which stays as the readable specification and is cross-checked against this in the tests.
 #include "common.h"
+#include "flatmap.h"
 #include <string>
 #include <vector>
 #include <unordered_map>
@@ -65,7 +66,7 @@ struct Graph {
   std::vector<int> rmate, rmp;        // rmp: 0 None, 1, 2
   std::vector<std::vector<int>> rnodes;
   std::vector<char> rhas;
-  std::unordered_map<std::string, int> rindex;
+  StringInterner rindex{1 << 16};
   std::set<std::vector<int>> known_paths;
   std::map<std::pair<int, int>, double> known_edges;
   std::vector<int> bridged_log;
@@ -135,10 +136,9 @@ struct Graph {
     for (int n : order) { double s = 0; for (int e : oute[n]) s += ew[e]; prev[n] = s; }
   }
   int add_read(const std::string& b) {
-    auto it = rindex.find(b);
-    if (it != rindex.end()) { rcc[it->second] += 1.0; return it->second; }
-    int r = (int)rbases.size();
-    rindex.emplace(b, r);
+    bool is_new = false;
+    int r = rindex.intern(b.data(), b.size(), &is_new);
+    if (!is_new) { rcc[r] += 1.0; return r; }
     rbases.push_back(b); rcc.push_back(1.0); rmate.push_back(-1); rmp.push_back(0); rnodes.emplace_back(); rhas.push_back(0);
     return r;
   }

@@ -1,0 +1,99 @@
+// Native host implementation of the final containment de-duplication, faster_reps.find_reps
+// (faster_reps.py:98-131 with duplicate_check_ends :60-92), row a31: every 24-mer of every transcript is
+// indexed, a transcript is dropped when its first and last 24-mer lie on another transcript at the right
+// distance (|diff - (len-24)| < 3) and that one is longer (or equal and name-smaller).  Host code: the
+// record set is the assembler's output, not the read set; SURVEY.md 8f ranks a GPU version as "next".
+#include "common.h"
+#include "flatmap.h"
+#include <algorithm>
+
+static inline int pcode(uint8_t c) {
+  switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; }
+}
+
+// names/seqs: n records (ASCII, offsets n+1 each), in file order.  keep_out[i] = 1 if record i survives.
+// A name that occurs more than once behaves like the reference's dict (the later sequence replaces the
+// earlier one, keep_out of the earlier record is 0).  Returns SHN_ERR_ARG if a sequence holds a non-ACGT base.
+extern "C" int shn_find_reps(const uint8_t* names, const uint64_t* name_off, const uint8_t* seqs, const uint64_t* seq_off,
+                             uint64_t n, int ds, int r, uint8_t* keep_out) {
+  if ((n && (!names || !name_off || !seqs || !seq_off)) || !keep_out) return shn_fail(SHN_ERR_ARG, "shn_find_reps: NULL argument");
+  if (r < 1 || r > 32) return shn_fail(SHN_ERR_ARG, "shn_find_reps: r must be in [1,32]");
+  StringInterner ids(n + 16);
+  std::vector<int64_t> rec_of;                  // name id -> latest record
+  FlatMultiMap index((seq_off[n] - seq_off[0]) + 1024);
+  const uint64_t mask = r == 32 ? ~0ULL : ((1ULL << (2 * r)) - 1);
+  for (uint64_t i = 0; i < n; i++) {
+    bool is_new;
+    int32_t id = ids.intern((const char*)names + name_off[i], name_off[i + 1] - name_off[i], &is_new);
+    if (is_new) rec_of.push_back((int64_t)i); else rec_of[id] = (int64_t)i;
+    const uint8_t* s = seqs + seq_off[i];
+    uint64_t L = seq_off[i + 1] - seq_off[i], key = 0;
+    for (uint64_t p = 0; p < L; p++) {
+      int c = pcode(s[p]);
+      if (c < 0) return shn_fail(SHN_ERR_ARG, "shn_find_reps: non-ACGT base in a transcript");
+      key = ((key << 2) | (uint64_t)c) & mask;
+      if (p + 1 >= (uint64_t)r) index.add(key, id, (int32_t)(p + 1 - r));
+    }
+  }
+  auto key_of = [&](const uint8_t* s, uint64_t L, uint64_t pos, bool rc, uint64_t& key) {
+    // r-mer at `pos` of the sequence (rc: of its reverse complement)
+    key = 0;
+    for (int j = 0; j < r; j++) {
+      int c = rc ? 3 - pcode(s[L - 1 - (pos + j)]) : pcode(s[pos + j]);
+      key = (key << 2) | (uint64_t)c;
+    }
+  };
+  memset(keep_out, 0, n);
+  std::vector<std::pair<int32_t, std::pair<int64_t, int64_t>>> pos;    // (other name id, (first pos, last pos)) in first-seen order
+  for (size_t id = 0; id < rec_of.size(); id++) {
+    uint64_t i = (uint64_t)rec_of[id];
+    const uint8_t* s = seqs + seq_off[i];
+    uint64_t L = seq_off[i + 1] - seq_off[i];
+    bool drop = false;
+    for (int flip = 0; flip < (ds ? 2 : 1) && !drop; flip++) {
+      if (L < (uint64_t)r) continue;
+      uint64_t kf, kl;
+      key_of(s, L, 0, flip == 1, kf);
+      key_of(s, L, L - r, flip == 1, kl);
+      int32_t vf = index.find(kf), vl = index.find(kl);
+      if (vf < 0 || vl < 0) continue;
+      pos.clear();
+      auto slot = [&](int32_t o) -> std::pair<int64_t, int64_t>& {
+        for (auto& e : pos) if (e.first == o) return e.second;
+        pos.push_back({o, {-2, -2}});                      // -2 = "key not created by this list"
+        return pos.back().second;
+      };
+      for (int32_t v = vf; v >= 0; v = index.next[v]) {
+        int32_t o = index.va[v];
+        if (o == (int32_t)id) continue;
+        auto& e = slot(o);
+        if (e.first == -2 && e.second == -2) e = {index.vb[v], -1}; else e.first = index.vb[v];
+      }
+      for (int32_t v = vl; v >= 0; v = index.next[v]) {
+        int32_t o = index.va[v];
+        if (o == (int32_t)id) continue;
+        auto& e = slot(o);
+        if (e.first == -2 && e.second == -2) e = {-1, index.vb[v]}; else e.second = index.vb[v];
+      }
+      for (auto& e : pos) {
+        int64_t p0 = e.second.first, p1 = e.second.second;
+        if (p0 < 0 || p1 < 0) continue;
+        int64_t diff = p1 - p0;
+        int64_t d = diff - ((int64_t)L - r);
+        if (d < 0) d = -d;
+        if (d >= 3) continue;
+        uint64_t oi = (uint64_t)rec_of[e.first];
+        uint64_t OL = seq_off[oi + 1] - seq_off[oi];
+        bool name_gt = false;
+        if (L == OL) {
+          size_t la = ids.len((int32_t)id), lb = ids.len(e.first);
+          int c = memcmp(ids.data((int32_t)id), ids.data(e.first), std::min(la, lb));
+          name_gt = c > 0 || (c == 0 && la > lb);
+        }
+        if (L < OL || name_gt) { drop = true; break; }
+      }
+    }
+    if (!drop) keep_out[i] = 1;
+  }
+  return SHN_OK;
+}

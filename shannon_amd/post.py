@@ -41,8 +41,41 @@ def length_sort(lines):
     return out
 
 
+def find_reps_native(lines, ds, r=24):
+    """find_reps through the native host code (csrc/post_host.hip, shn_find_reps)."""
+    import numpy as np
+    from . import _lib
+    names, seqs = [], []
+    name = None
+    for line in lines:
+        if line[0] == ">":
+            name = line.strip().split()[0][1:]
+        else:
+            names.append(name)
+            seqs.append(line.strip())
+    if not names:
+        return {}
+
+    def pack(strs):
+        off = np.zeros(len(strs) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(x) for x in strs], dtype=np.uint64)
+        b = "".join(strs).encode()
+        return (np.frombuffer(b, dtype=np.uint8) if b else np.zeros(1, np.uint8)), off
+
+    nb, no = pack(names)
+    sb, so = pack(seqs)
+    keep = np.zeros(len(names), dtype=np.uint8)
+    _lib.check(_lib.lib().shn_find_reps(nb.ctypes.data, no.ctypes.data, sb.ctypes.data, so.ctypes.data, len(names), 1 if ds else 0, r,
+                                        keep.ctypes.data))
+    out = {}
+    for i in np.nonzero(keep)[0].tolist():
+        out[names[i]] = seqs[i]
+    return out
+
+
 def find_reps(lines, ds, r=24):
-    """faster_reps.py:98-131 with duplicate_check_ends :60-92.  Returns {name: seq} kept."""
+    """faster_reps.py:98-131 with duplicate_check_ends :60-92.  Returns {name: seq} kept.
+    (Readable Python form; finalize() uses find_reps_native.)"""
     contigs, index, name = {}, {}, None
     for line in lines:
         if line[0] == ">":
@@ -84,4 +117,10 @@ def find_reps(lines, ds, r=24):
 
 def finalize(all_lines, ds=True):
     """shannon.py:596-604."""
-    return find_reps(length_sort(process_concatenated(all_lines, ds)), ds)
+    srt = length_sort(process_concatenated(all_lines, ds))
+    try:
+        return find_reps_native(srt, ds)
+    except RuntimeError as e:
+        if "non-ACGT" not in str(e):
+            raise
+        return find_reps(srt, ds)          # transcripts with other characters: plain Python form

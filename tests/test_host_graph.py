@@ -167,3 +167,34 @@ def test_native_graph_stage(name):
         can = mbgraph.canonical(singles, comps)
         for k in can:
             assert approx_eq(can[k], gp["graph"][k]), (comp, k)
+
+
+def test_native_find_reps_matches_python_and_oracle():
+    """shn_find_reps (native) == shannon_amd.post.find_reps (Python) == oracle.post.find_reps."""
+    import random
+    from shannon_amd import post, build
+    from oracle import post as opost
+    build.build(verbose=False)
+    rnd = random.Random(11)
+    base = ["".join(rnd.choice("ACGT") for _ in range(rnd.randint(150, 700))) for _ in range(60)]
+    recs = []
+    for i, b in enumerate(base):
+        recs.append((">T%d x" % i, b))
+        if i % 3 == 0:
+            recs.append((">C%d" % i, b[7:-9] if len(b) > 260 else b))
+        if i % 4 == 0:
+            recs.append((">R%d" % i, seqs.reverse_complement(b)))
+        if i % 5 == 0:
+            recs.append((">Q%d" % i, seqs.reverse_complement(b[5:-3]) if len(b) > 240 else b))
+        if i % 7 == 0:
+            recs.append((">M%d" % i, b[:len(b) // 2] + "A" + b[len(b) // 2 + 1:]))
+        if i % 11 == 0:
+            recs.append((">T%d again" % i, b[3:]))                       # duplicate name -> dict overwrite
+    lines = [x for h, s_ in recs for x in (h + "\n", s_ + "\n")]
+    for ds in (True, False):
+        a = post.find_reps_native(lines, ds)
+        b = post.find_reps(lines, ds)
+        c = opost.find_reps(lines, ds)
+        assert a == b == c
+    full = post.finalize(lines, True)
+    assert full == opost.finalize(lines, True)
