@@ -176,7 +176,8 @@ int shn_seed_ends(shn_ctx* ctx, const shn_reads* reads, int K, const shn_table* 
 typedef struct shn_graph shn_graph;
 int shn_mbgraph_run(shn_ctx* ctx /* NULL: K-mer seed scans on the host instead of the GPU */, int K, const uint8_t* rows,
                     uint64_t n_rows, const uint8_t* r1, const uint64_t* r1_off, const uint8_t* r2, const uint64_t* r2_off,
-                    uint64_t n_reads, int paired, shn_graph** out);
+                    uint64_t n_reads, int paired, int enc /* SHN_ENC_* */, const uint8_t* rc1, const uint8_t* rc2 /* optional:
+                    1 = use the reverse complement of read i (strand-doubled view of the input) */, shn_graph** out);
 void shn_graph_destroy(shn_graph* g);
 /* sizes[9] = n_singles, single bases, n_components, n_nodes, node bases, n_edges, n_paths, path ids, info ints */
 int shn_graph_sizes(const shn_graph* g, uint64_t* sizes);

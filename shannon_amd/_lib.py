@@ -46,7 +46,7 @@ SIGNATURES = {
     "shn_contig_graph": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_int, C.c_double, vp, u64p, vp, vp, vp, u64p]),
     "shn_seed_scan": (C.c_int, [vp, vp, C.c_int, vp, u64p, vp, vp, vp]),
     "shn_seed_ends": (C.c_int, [vp, vp, C.c_int, vp, vp, vp]),
-    "shn_mbgraph_run": (C.c_int, [vp, C.c_int, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, C.c_int, vpp]),
+    "shn_mbgraph_run": (C.c_int, [vp, C.c_int, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, vpp]),
     "shn_graph_destroy": (None, [vp]),
     "shn_graph_sizes": (C.c_int, [vp, u64p]),
     "shn_graph_export": (C.c_int, [vp] + [vp] * 20),

@@ -47,6 +47,22 @@ struct SeedIndex {
   }
 };
 
+// read string living in the interner arena
+struct RStr {
+  const char* p; size_t n;
+  size_t size() const { return n; }
+  const char& operator[](size_t i) const { return p[i]; }
+  int compare(size_t pos, size_t len, const std::string& o) const {
+    size_t m = std::min(len, n - pos);
+    int c = memcmp(p + pos, o.data(), std::min(m, o.size()));
+    if (c) return c;
+    return m < o.size() ? -1 : (m > o.size() ? 1 : 0);
+  }
+  std::string substr(size_t pos, size_t len) const { return std::string(p + pos, std::min(len, n - pos)); }
+  const char* begin() const { return p; }
+  const char* end() const { return p + n; }
+};
+
 struct Graph {
   shn_ctx* ctx = nullptr;                   // non-NULL: K-mer seed scans run on the GPU (csrc/seeds.hip)
   int K, L, SIZE_THRESHOLD;
@@ -61,7 +77,8 @@ struct Graph {
   std::vector<int> order;
   std::vector<int> es, ed, ew;
   std::vector<double> ecc;
-  std::vector<std::string> rbases;
+  RStr rstr(int r) const { return RStr{rindex.data(r), rindex.len(r)}; }
+  size_t n_rd() const { return rindex.size(); }
   std::vector<double> rcc;
   std::vector<int> rmate, rmp;        // rmp: 0 None, 1, 2
   std::vector<std::vector<int>> rnodes;
@@ -82,6 +99,10 @@ struct Graph {
     dead.push_back(0); nreads.emplace_back(); bridged.push_back(-1); hash.push_back(-2);
     order.push_back(n);
     return n;
+  }
+  void reserve_nodes(size_t n) {
+    bases.reserve(n); ine.reserve(n); oute.reserve(n); norm.reserve(n); cc.reserve(n); prev.reserve(n); cnt.reserve(n);
+    cc_int.reserve(n); dead.reserve(n); nreads.reserve(n); bridged.reserve(n); hash.reserve(n); order.reserve(n);
   }
   int link(int a, int b, int w) {
     int e = (int)es.size();
@@ -120,17 +141,18 @@ struct Graph {
 
   // ---- loading (multibridging.py:145-172, 22-30, 68-97; mbgraph.py:44-62)
   void load_k1mers(const uint8_t* rows, uint64_t n_rows) {
-    std::unordered_map<std::string, int> idx;
-    idx.reserve(n_rows * 2);
+    StringInterner idx(n_rows * 2);               // K-mer -> node (node ids == intern ids: nodes are only made here)
+    idx.arena.reserve(n_rows * (size_t)K * 5 / 4);
     const int k1 = K + 1;
+    reserve_nodes(n_rows * 5 / 2);
+    es.reserve(n_rows * 4); ed.reserve(n_rows * 4); ew.reserve(n_rows * 4); ecc.reserve(n_rows * 4);
     for (uint64_t i = 0; i < n_rows; i++) {
-      std::string km((const char*)rows + i * k1, k1);
-      std::string a = km.substr(0, K), b = km.substr(1);
-      int na, nb;
-      auto ia = idx.find(a);
-      if (ia == idx.end()) { na = new_node(a); idx.emplace(a, na); } else na = ia->second;
-      auto ib = idx.find(b);
-      if (ib == idx.end()) { nb = new_node(b); idx.emplace(b, nb); } else nb = ib->second;
+      const char* km = (const char*)rows + i * k1;
+      bool fresh;
+      int na = idx.intern(km, K, &fresh);
+      if (fresh) new_node(std::string(km, K));
+      int nb = idx.intern(km + 1, K, &fresh);
+      if (fresh) new_node(std::string(km + 1, K));
       link(na, nb, K - 1);
     }
     for (int n : order) { double s = 0; for (int e : oute[n]) s += ew[e]; prev[n] = s; }
@@ -139,7 +161,7 @@ struct Graph {
     bool is_new = false;
     int r = rindex.intern(b.data(), b.size(), &is_new);
     if (!is_new) { rcc[r] += 1.0; return r; }
-    rbases.push_back(b); rcc.push_back(1.0); rmate.push_back(-1); rmp.push_back(0); rnodes.emplace_back(); rhas.push_back(0);
+    rcc.push_back(1.0); rmate.push_back(-1); rmp.push_back(0); rnodes.emplace_back(); rhas.push_back(0);
     return r;
   }
 
@@ -260,28 +282,25 @@ struct Graph {
 
   // ---- bridging (mbgraph.py:77-111, 450-628)
   bool read_bridges(int r, int n, int index) const {
-    const std::string &rb = rbases[r], &nb = bases[n];
+    const RStr rb = rstr(r); const std::string& nb = bases[n];
     if (index <= 0 || (int)rb.size() <= index + (int)nb.size()) return false;
     return rb.compare(index, nb.size(), nb) == 0;
   }
   // packed key of s[pos..pos+K) or false if it holds a non-ACGT character
-  bool key_at(const std::string& s, size_t pos, uint64_t& key) const {
+  template <class S> bool key_at(const S& s, size_t pos, uint64_t& key) const {
     key = 0;
     for (int j = 0; j < K; j++) { int c = base_code(s[pos + j]); if (c < 0) return false; key = (key << 2) | (uint64_t)c; }
     return true;
   }
   bool reads_all_acgt() const {
-    for (const std::string& r : rbases) for (char c : r) if (base_code(c) < 0) return false;
+    for (char c : rindex.arena) if (base_code(c) < 0) return false;
     return true;
   }
   // device copy of the distinct reads + pattern table; returns false if the GPU path is not usable
   bool gpu_patterns(const SeedIndex& si, shn_reads** dreads, shn_table** tab) {
-    if (!ctx || K > 32 || rbases.empty() || si.keys.empty() || !reads_all_acgt()) return false;
+    if (!ctx || K > 32 || n_rd() == 0 || si.keys.empty() || !reads_all_acgt()) return false;
     if (!*dreads) {
-      std::string buf;
-      std::vector<uint64_t> off(rbases.size() + 1, 0);
-      for (size_t i = 0; i < rbases.size(); i++) { buf += rbases[i]; off[i + 1] = buf.size(); }
-      if (shn_reads_create(ctx, (const uint8_t*)buf.data(), off.data(), rbases.size(), 0, SHN_ENC_ASCII, dreads)) return false;
+      if (shn_reads_create(ctx, (const uint8_t*)rindex.arena.data(), rindex.off.data(), n_rd(), 0, SHN_ENC_ASCII, dreads)) return false;
     }
     std::vector<uint32_t> vals(si.keys.size());
     for (size_t i = 0; i < vals.size(); i++) vals[i] = (uint32_t)i + 1;
@@ -312,8 +331,8 @@ struct Graph {
       return;
     }
     const uint64_t mask = K == 32 ? ~0ULL : ((1ULL << (2 * K)) - 1);
-    for (int r = 0; r < (int)rbases.size(); r++) {
-      const std::string& rb = rbases[r];
+    for (int r = 0; r < (int)n_rd(); r++) {
+      const RStr rb = rstr(r);
       uint64_t key = 0;
       int valid = 0;
       for (int i = 0; i < (int)rb.size(); i++) {
@@ -338,11 +357,11 @@ struct Graph {
     std::set<RI> rs;
     for (const RI& x : nreads[n]) {
       int r = x.first, i = x.second;
-      if (i > 0 && (int)rbases[r].size() > i + lb && rbases[r].compare(i, lb, nb) == 0) rs.insert(x);
+      if (i > 0 && (int)rstr(r).size() > i + lb && rstr(r).compare(i, lb, nb) == 0) rs.insert(x);
     }
     std::vector<RI> real;
     for (const RI& x : rs) {
-      const std::string& rb = rbases[x.first];
+      const RStr rb = rstr(x.first);
       int i = x.second;
       bool bi = false, bo = false;
       for (int e : ine[n]) { const std::string& pb = bases[es[e]]; if (rb[i - 1] == pb[pb.size() - ew[e] - 1]) bi = true; }
@@ -355,7 +374,7 @@ struct Graph {
     refresh_bridging_reads(n);
     int lb = (int)bases[n].size();
     std::set<char> inb, outb;
-    for (const RI& x : nreads[n]) { inb.insert(rbases[x.first][x.second - 1]); outb.insert(rbases[x.first][x.second + lb]); }
+    for (const RI& x : nreads[n]) { inb.insert(rstr(x.first)[x.second - 1]); outb.insert(rstr(x.first)[x.second + lb]); }
     int bi = (int)ine[n].size() - (int)inb.size(), bo = (int)oute[n].size() - (int)outb.size();
     return (bi == 0 && bo == 0) || (bi == 1 && bo == 1);
   }
@@ -398,7 +417,7 @@ struct Graph {
     for (int n : w_list) links[n] = 0;
     std::vector<RI> rl = nreads[node];
     for (const RI& y : rl) {
-      const std::string& rb = rbases[y.first];
+      const RStr rb = rstr(y.first);
       int i = y.second;
       std::string bu = rb.substr(i - 1, lb + 1), bw = rb.substr(i, lb + 1);
       std::vector<int> mu, mw;
@@ -490,11 +509,11 @@ struct Graph {
   }
 
   // ---- reads on the graph (mbgraph.py:1355-1441, 114-160, 839-880)
-  static bool compare(const std::string& a, size_t ao, const std::string& b, size_t bo) {
+  template <class S> static bool compare(const S& a, size_t ao, const std::string& b, size_t bo) {
     size_t n = std::min(a.size() - ao, b.size() - bo);
-    return a.compare(ao, n, b, bo, n) == 0;
+    return memcmp(&a[0] + ao, b.data() + bo, n) == 0;
   }
-  void search_sequence(const std::string& seq, size_t so, int node, int i, int hops, std::vector<int>& cur, std::vector<std::vector<int>>& out) {
+  template <class S> void search_sequence(const S& seq, size_t so, int node, int i, int hops, std::vector<int>& cur, std::vector<std::vector<int>>& out) {
     size_t nl = bases[node].size() - i;
     cur.push_back(node);
     if (hops <= 0 || seq.size() - so <= nl) { out.push_back(cur); cur.pop_back(); return; }
@@ -520,7 +539,7 @@ struct Graph {
     }
     SeedIndex si;
     si.build(items);
-    std::vector<uint32_t> first(rbases.size(), 0), last(rbases.size(), 0);     // group id + 1, 0 = absent
+    std::vector<uint32_t> first(n_rd(), 0), last(n_rd(), 0);     // group id + 1, 0 = absent
     shn_table* tab = nullptr;
     bool done = false;
     if (gpu_patterns(si, &d_reads, &tab)) {
@@ -528,8 +547,8 @@ struct Graph {
       shn_table_destroy(tab);
     }
     if (!done)
-      for (int r = 0; r < (int)rbases.size(); r++) {
-        const std::string& rb = rbases[r];
+      for (int r = 0; r < (int)n_rd(); r++) {
+        const RStr rb = rstr(r);
         uint64_t key;
         if ((int)rb.size() < K) continue;
         if (key_at(rb, 0, key)) first[r] = (uint32_t)(si.find(key) + 1);
@@ -537,9 +556,9 @@ struct Graph {
       }
     release_gpu();
     int cntp = 0;
-    for (int r = 0; r < (int)rbases.size(); r++) {
+    for (int r = 0; r < (int)n_rd(); r++) {
       if (!first[r] || !last[r]) continue;
-      const std::string& rb = rbases[r];
+      const RStr rb = rstr(r);
       uint32_t gi = first[r] - 1;
       for (uint32_t q = si.goff[gi]; q < si.goff[gi + 1]; q++) {
         int sn = si.occ[q].first, so = si.occ[q].second;
@@ -584,7 +603,7 @@ struct Graph {
   void find_mate_pairs() {
     std::vector<std::pair<int, int>> pairs;
     std::set<std::pair<int, int>> seen;
-    for (int r = 0; r < (int)rbases.size(); r++) {
+    for (int r = 0; r < (int)n_rd(); r++) {
       if (rmp[r] != 1 || rmate[r] < 0) continue;
       int m = rmate[r];
       if (!rhas[r] || rnodes[r].empty() || !rhas[m] || rnodes[m].empty()) continue;
@@ -664,8 +683,26 @@ extern "C" void shn_graph_destroy(shn_graph* g) { delete g; }
 
 // rows: n_rows k1-mers of K+1 bytes each (file order of component{c}k1mers_allowed.dict); reads: ASCII,
 // r_off[n_reads+1]; paired: second mate file r2/r2_off with the same count.  Read.L = length of the first read.
+// enc: SHN_ENC_ASCII or SHN_ENC_CODES (0..3); rc1/rc2 (optional, one byte per read): 1 = take the reverse
+// complement of that read (the strand-doubled view of the packed input, shannon.py:396-424)
+static void decode_read(std::string& s, const uint8_t* p, uint64_t n, int enc, bool rc) {
+  s.resize(n);
+  if (enc == SHN_ENC_CODES) {
+    if (!rc) for (uint64_t i = 0; i < n; i++) s[i] = p[i] < 4 ? "ACGT"[p[i]] : 'N';
+    else for (uint64_t i = 0; i < n; i++) { uint8_t c = p[n - 1 - i]; s[i] = c < 4 ? "TGCA"[c] : 'N'; }
+  } else {
+    auto up = [](uint8_t c) -> char { return (c >= 'a' && c <= 'z') ? (char)(c - 32) : (char)c; };
+    if (!rc) for (uint64_t i = 0; i < n; i++) s[i] = up(p[i]);
+    else for (uint64_t i = 0; i < n; i++) {
+      char c = up(p[n - 1 - i]);
+      s[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c;
+    }
+  }
+}
+
 extern "C" int shn_mbgraph_run(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n_rows, const uint8_t* r1, const uint64_t* r1_off,
-                               const uint8_t* r2, const uint64_t* r2_off, uint64_t n_reads, int paired, shn_graph** out) {
+                               const uint8_t* r2, const uint64_t* r2_off, uint64_t n_reads, int paired, int enc, const uint8_t* rc1,
+                               const uint8_t* rc2, shn_graph** out) {
   if (!out || (n_rows && !rows) || (n_reads && (!r1 || !r1_off)) || (paired && n_reads && (!r2 || !r2_off)))
     return shn_fail(SHN_ERR_ARG, "shn_mbgraph_run: NULL argument");
   Graph g;
@@ -679,16 +716,25 @@ extern "C" int shn_mbgraph_run(shn_ctx* ctx, int K, const uint8_t* rows, uint64_
   g.load_k1mers(rows, n_rows);
   if (dbg) { fprintf(stderr, "[mbgraph] load_k1mers            %8.3f s  rows=%llu\n", now() - tt, (unsigned long long)n_rows); tt = now(); }
   uint64_t cutoff = (uint64_t)g.order.size() * 10;
-  auto upper = [](std::string s) { for (auto& c : s) if (c >= 'a' && c <= 'z') c -= 32; return s; };
+  {
+    uint64_t used = std::min<uint64_t>(n_reads, cutoff + 1);
+    size_t bytes = used ? (size_t)(r1_off[used] - r1_off[0]) + (paired ? (size_t)(r2_off[used] - r2_off[0]) : 0) : 0;
+    g.rindex.arena.reserve(bytes);
+    size_t nr = (size_t)used * (paired ? 2 : 1);
+    g.rcc.reserve(nr); g.rmate.reserve(nr); g.rmp.reserve(nr); g.rnodes.reserve(nr); g.rhas.reserve(nr);
+  }
+  std::string tmp;
   for (uint64_t i = 0; i < n_reads; i++) {
     if (i > cutoff) break;
-    int a = g.add_read(upper(std::string((const char*)r1 + r1_off[i], r1_off[i + 1] - r1_off[i])));
+    decode_read(tmp, r1 + r1_off[i], r1_off[i + 1] - r1_off[i], enc, rc1 && rc1[i]);
+    int a = g.add_read(tmp);
     if (paired) {
-      int b = g.add_read(upper(std::string((const char*)r2 + r2_off[i], r2_off[i + 1] - r2_off[i])));
+      decode_read(tmp, r2 + r2_off[i], r2_off[i + 1] - r2_off[i], enc, rc2 && rc2[i]);
+      int b = g.add_read(tmp);
       g.rmp[a] = 1; g.rmp[b] = 2; g.rmate[a] = b; g.rmate[b] = a;
     }
   }
-  if (dbg) { fprintf(stderr, "[mbgraph] load reads             %8.3f s  reads=%llu distinct=%zu\n", now() - tt, (unsigned long long)n_reads, g.rbases.size()); tt = now(); }
+  if (dbg) { fprintf(stderr, "[mbgraph] load reads             %8.3f s  reads=%llu distinct=%zu\n", now() - tt, (unsigned long long)n_reads, g.n_rd()); tt = now(); }
   int rc = g.run();
   g.release_gpu();
   tt = now();

@@ -249,6 +249,28 @@ class ReadStore(object):
     def _rc(s):
         return s[::-1].translate(_RC)
 
+    def gather_codes(self, idx, mate):
+        """(codes buffer, offsets, rc flags, enc) of reads `mate` of the doubled indices -- rows are gathered as
+        stored; the reverse complement is left to the consumer (shn_mbgraph_run's rc flags)."""
+        idx = np.asarray(idx, dtype=np.int64)
+        n = self.n
+        if len(idx) == 0 or isinstance(self.r1[0], str):
+            b, o = self.gather(idx, mate)
+            return b, o, None, 0
+        second = idx >= n
+        i = np.where(second, idx - n, idx)
+        if self.r2 is None:
+            rows, rc = self.r1[i], second                                   # SE: R[d] / RC(R[d-n])
+        elif mate == 1:
+            rows = np.where(second[:, None], self.r2[i], self.r1[i])        # R1[d] / RC(R2[d-n])
+            rc = second
+        else:
+            rows = np.where(second[:, None], self.r2[i], self.r1[i])        # RC(R1[d]) / R2[d-n]
+            rc = ~second
+        L = rows.shape[1]
+        return (np.ascontiguousarray(rows, dtype=np.uint8).reshape(-1), np.arange(len(idx) + 1, dtype=np.uint64) * np.uint64(L),
+                np.ascontiguousarray(rc, dtype=np.uint8), 1)
+
     def gather(self, idx, mate):
         """Reads `mate` (1 or 2) of the doubled indices `idx` as (uint8 ASCII buffer, uint64 offsets) -- the
         byte layout shn_mbgraph_run takes.  Vectorised for code matrices."""

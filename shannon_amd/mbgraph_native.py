@@ -14,7 +14,7 @@ def _pack_reads(reads):
     return (np.frombuffer(joined, dtype=np.uint8) if joined else np.zeros(1, np.uint8)), off
 
 
-def run_partition_arrays(rows_bytes, n_rows, K, r1_buf, r1_off, r2_buf=None, r2_off=None, ctx=None):
+def run_partition_arrays(rows_bytes, n_rows, K, r1_buf, r1_off, r2_buf=None, r2_off=None, ctx=None, enc=0, rc1=None, rc2=None):
     """rows_bytes: uint8 array of n_rows*(K+1) bases; reads as (byte buffer, offsets).  Returns
     (singles, comps, info) in the format of mbgraph.output_components."""
     L = _lib.lib()
@@ -23,7 +23,8 @@ def run_partition_arrays(rows_bytes, n_rows, K, r1_buf, r1_off, r2_buf=None, r2_
     paired = r2_buf is not None
     _lib.check(L.shn_mbgraph_run(ctx.h if ctx is not None else None, K, rows_bytes.ctypes.data, n_rows, r1_buf.ctypes.data, r1_off.ctypes.data,
                                  r2_buf.ctypes.data if paired else None, r2_off.ctypes.data if paired else None, n_reads,
-                                 1 if paired else 0, C.byref(h)))
+                                 1 if paired else 0, enc, rc1.ctypes.data if rc1 is not None else None,
+                                 rc2.ctypes.data if rc2 is not None else None, C.byref(h)))
     sz = np.zeros(9, dtype=np.uint64)
     _lib.check(L.shn_graph_sizes(h, sz.ctypes.data_as(_lib.u64p)))
     ns, sb, nc, nn, nb, ne, npth, npid, ninfo = [int(x) for x in sz]

@@ -79,13 +79,13 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
         cutoff = 10 * part["n_kmer_nodes"][name] + 1                 # multibridging.py:26-30, 385-391
         idx = part["routes"][name][:cutoff]
         if native_graph:
-            b1, o1 = store.gather(idx, 1)
-            b2, o2 = store.gather(idx, 2) if paired else (None, None)
+            b1, o1, rc1, enc = store.gather_codes(idx, 1)
+            b2, o2, rc2, _e = store.gather_codes(idx, 2) if paired else (None, None, None, enc)
             tick("materialize reads", t0)
             t0 = time.time()
             rb = part["k1mer_bytes"][name]
             singles, comps, glog = mbgraph_native.run_partition_arrays(rb if len(rb) else np.zeros(1, np.uint8), len(rb) // (K + 1), K,
-                                                                       b1, o1, b2, o2, ctx=ctx)
+                                                                       b1, o1, b2, o2, ctx=ctx, enc=enc, rc1=rc1, rc2=rc2)
             n_rows = len(rb) // (K + 1)
         else:
             rows = part["k1mers"][name]
