@@ -18,9 +18,13 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, profiles/r01_*):
-# FETCH_SIZE doubled for the streaming reads as MI355X_MICROARCH.md (HBM) prescribes, WRITE_SIZE as read; 10M-read step.
-TRAFFIC = {}
+# HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes over this same command at the
+# default workload; tools/summarize_prof.py -> profiles/r01_traffic.json): 2 x FETCH_SIZE (gfx950 tallies 128-B
+# requests at 64 B, MI355X_MICROARCH.md HBM) + WRITE_SIZE.  Only valid for the default 10M-read workload.
+try:
+    TRAFFIC = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["traffic_bytes_per_launch"]
+except (OSError, ValueError, KeyError):
+    TRAFFIC = {}
 
 
 def gen_reads(n_pairs, seed, n_genes, device, read_seed=None):
@@ -56,18 +60,26 @@ def gen_reads(n_pairs, seed, n_genes, device, read_seed=None):
     return torch.cat(out1).numpy(), torch.cat(out2).numpy()
 
 
-def cpu_baseline(k1, seed, n_sample):
-    """The oracle's C restatement of the same stage, single host thread, bounded sample."""
-    from shannon_amd import synth
-    from oracle import build_c
-    (r1, r2), _ = synth.make_dataset(n_sample // 2, 1, seed)
-    codes = np.concatenate([r1, r2])
-    build_c.build()
+def cpu_baseline(k1, r1, r2, n_pairs):
+    """The CPU restatement of the reference (oracle/, pure Python like Shannon itself, one host thread) over a
+    bounded sample of the same reads, full path a1-a31; plus the C restatement of the counting stage alone."""
+    from oracle import pipeline as opipe, build_c
+    A = np.frombuffer(b"ACGT", np.uint8)
+    s1 = [A[r].tobytes().decode() for r in r1[:n_pairs]]
+    s2 = [A[r].tobytes().decode() for r in r2[:n_pairs]]
     t = time.time()
-    keys, cnts, nw = build_c.count_canonical(codes, k1, True)
+    opipe.assemble(s1, s2, K=k1 - 1)
     dt = time.time() - t
-    return {"value": len(codes) / dt, "unit": "reads/s", "cores": 1, "kind": "port",
-            "sample": "%d synthetic 100bp reads, same generator, stage=count (oracle/count_c.c radix sort + RLE), %.2fs" % (len(codes), dt)}
+    build_c.build()
+    codes = np.concatenate([r1[:500000], r2[:500000]])
+    t = time.time()
+    build_c.count_canonical(codes, k1, True)
+    dtc = time.time() - t
+    return {"value": 2 * n_pairs / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+            "sample": "first %d reads of the benchmark batch through oracle/pipeline.py (count -> extension -> partition -> graph -> "
+                      "sparse flow -> merge), %.1f s" % (2 * n_pairs, dt),
+            "count_stage_only": {"value": len(codes) / dtc, "unit": "reads/s", "cores": 1,
+                                 "sample": "%d reads, oracle/count_c.c (radix sort + run-length count), %.2f s" % (len(codes), dtc)}}
 
 
 def main():
@@ -158,29 +170,41 @@ def main():
         distinct, total = last.R.n_k1mers, last.R.n_windows
     if rank == 0:
         ms_step = 1000.0 * dt / args.steps
-        # Kernel groups timed with HIP events on the context stream (shn_timer_*).  `roofline` describes the
-        # dominant group by time; algorithmic bytes per unit are the figures of DESIGN.md section 3.
+        # Every timer below wraps exactly ONE kernel launch (HIP events on the stream it is launched on, shn_timer_*),
+        # so ms / launches is that kernel's average launch duration -- comparable with rocprofv3's AverageNs.
+        # Algorithmic bytes per unit are the figures of DESIGN.md section 3.
         W = 100 - k1 + 1
-        alg = {"count.hist1": 25.0, "count.scatter1": 25.0 + 8.0 * W, "count.hist2": 8.0 * W,
-               "count.scatter2": 16.0 * W, "count.buckets": 8.0 * W, "count.compact": 0.0, "route": 192.0}
-        groups = {k: v for k, v in timers.items() if k in alg or k == "extend.walk"}
-        dom = max(groups, key=lambda k: groups[k][0])
-        launches = groups[dom][1]
-        avg_ms = groups[dom][0] / launches
-        if dom == "extend.walk":
-            # latency-bound pointer chasing: 128 algorithmic bytes per walk step (adjacency row, 4 candidates'
-            # claims/weights, 4 prefetched rows); one "launch" = one fixpoint iteration
-            steps_total = last.R.extension.total_steps if not use_dist else 0
-            per_launch_bytes = 128.0 * steps_total / max(1, last.R.extension.iterations if not use_dist else 1)
-            unit_bytes = None
-        else:
-            per_launch_bytes = alg[dom] * n_reads * args.steps / launches
-            unit_bytes = alg[dom]
-        achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
-        bw_groups = {k: v for k, v in groups.items() if k != "extend.walk"}
-        bdom = max(bw_groups, key=lambda k: bw_groups[k][0])
-        b_ms = bw_groups[bdom][0] / bw_groups[bdom][1]
-        b_ach = alg[bdom] * n_reads * args.steps / bw_groups[bdom][1] / (b_ms * 1e-3) / 1e9
+        KERNEL = {"count.hist1": "hist1_kernel", "count.scatter1": "scatter1_kernel", "count.hist2": "hist_keys_kernel",
+                  "count.scatter2": "scatter_keys_kernel", "count.buckets": "buckets_kernel", "route": "route_kernel",
+                  "extend.walk_thread": "ext_walk_kernel", "extend.walk_wave": "ext_walk_long_kernel", "extend.mark": "ext_mark_kernel"}
+        per_read = {"count.hist1": 25.0, "count.scatter1": 25.0 + 8.0 * W, "count.hist2": 8.0 * W,
+                    "count.scatter2": 16.0 * W, "count.buckets": 8.0 * W, "route": 192.0}
+        ext = last.res["extension"] if use_dist else {k: getattr(last.R.extension, k) for k in ("iterations", "n_walks", "total_steps", "wave_steps")}
+        steps_all = ext["total_steps"] or 0
+        steps_wave = ext["wave_steps"] or 0
+        n_or = 2 * distinct                                   # oriented k1-mers
+        # bytes of ONE step of the pipeline (all launches of the kernel in that step)
+        per_step_bytes = {k: v * n_reads for k, v in per_read.items()}
+        per_step_bytes["extend.walk_thread"] = 152.0 * (steps_all - steps_wave)     # 4 candidates x (claim 8 + snapshot 8 + weight 4 + row 16) + claim 8
+        per_step_bytes["extend.walk_wave"] = 112.0 * steps_wave                      # same without the row prefetch, + memo entry
+        per_step_bytes["extend.mark"] = 16.0 * n_or * (ext["iterations"] or 0)
+        kt = {k: v for k, v in timers.items() if k in KERNEL}
+
+        def roof(name):
+            ms, launches = kt[name]
+            avg = ms / launches
+            bytes_launch = per_step_bytes[name] * args.steps / launches
+            ach = bytes_launch / (avg * 1e-3) / 1e9
+            tr = TRAFFIC.get(name) if (args.reads == 10_000_000 and args.genes == 1 and args.K == 25) else None
+            return {"bound": "hbm", "kernel": KERNEL[name], "timer": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": tr, "launches_per_step": launches / args.steps, "avg_launch_ms": avg,
+                    "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_bytes_per_read": per_read.get(name)}
+        dom = max(kt, key=lambda k: kt[k][0])
+        bdom = max((k for k in kt if k in per_read), key=lambda k: kt[k][0])
+        r_dom, r_bw = roof(dom), roof(bdom)
+        if dom.startswith("extend."):
+            r_dom["note"] = ("greedy walk fixpoint: dependent pointer chasing, one memory round trip per step -- latency-bound, not "
+                             "bandwidth-bound; the dominant streaming kernel is in roofline_bandwidth_kernel")
         out = {
             "metric": "reads/sec k-mer->graph->path-decompose, 2x100bp k=25",
             "value": n_reads * world * args.steps / dt, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
@@ -193,22 +217,17 @@ def main():
                                   "full path a1-a31: count -> extension -> partition/route -> multibridged graph -> sparse flow -> merge"),
                        "host_stage_seconds_per_step": {k: v / (args.steps + args.warmup) for k, v in stage_t.items()},
                        "transcripts": (len(last.res["final"]) if use_dist else len(last.R.final)),
-                       "extension_iterations": (None if use_dist else last.R.extension.iterations),
-                       "extension_walks": (None if use_dist else last.R.extension.n_walks),
+                       "extension_iterations": ext["iterations"], "extension_walks": ext["n_walks"],
+                       "extension_walk_steps": steps_all,
                        "partitions": (len(last.res["partitions"]) if use_dist else {k: [v["n_reads_routed"], v["n_k1mers"]] for k, v in last.R.partitions.items()}),
                        "windows_per_step": total, "distinct_k1mers": distinct},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC.get(dom),
-                         "algorithmic_bytes_per_read": unit_bytes, "avg_launch_ms": avg_ms,
-                         "note": ("latency-bound walk fixpoint (pointer chasing); the dominant bandwidth-bound kernel is reported in "
-                                  "roofline_bandwidth_kernel" if dom == "extend.walk" else None)},
-            "roofline_bandwidth_kernel": {"bound": "hbm", "kernel": bdom, "achieved": b_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "frac": b_ach / HBM_PEAK_GBS, "traffic": TRAFFIC.get(bdom),
-                                          "algorithmic_bytes_per_read": alg[bdom], "avg_launch_ms": b_ms},
+            "roofline": r_dom,
+            "roofline_bandwidth_kernel": r_bw,
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(timers.items())},
+            "kernel_launches_per_step": {k: v[1] / args.steps for k, v in sorted(timers.items())},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(k1, 20240501, 1_000_000)
+            out["cpu_baseline"] = cpu_baseline(k1, r1, r2, 50_000)
         final_line = json.dumps(out)
     else:
         final_line = None

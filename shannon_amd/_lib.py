@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libshannon_hip.so")
+LIB_PATH = os.environ.get("SHN_HIP_LIB") or os.path.join(_PKG, "libshannon_hip.so")     # SHN_HIP_LIB: A/B builds of the same ABI
 _lib = None
 
 u8p, u32p, u64p, dblp = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_double)
@@ -56,6 +56,7 @@ SIGNATURES = {
     "shn_ext_n_walks": (C.c_uint64, [vp]),
     "shn_ext_iterations": (C.c_int, [vp]),
     "shn_ext_total_steps": (C.c_uint64, [vp]),
+    "shn_ext_wave_steps": (C.c_uint64, [vp]),
     "shn_ext_stats": (C.c_int, [vp, vp, vp, vp, vp]),
     "shn_ext_emit": (C.c_int, [vp, vp, vp, C.c_uint64, vp, vp]),
     "shn_ext_weights": (C.c_int, [vp, vp, vp, C.c_uint64, vp]),

@@ -12,23 +12,28 @@ extern "C" const char* shn_version(void) { return "shannon_hip 0.1.0 (gfx950)"; 
 
 static const char* kTimerNames[T_N] = {
   "pack", "count.hist1", "count.scatter1", "count.hist2", "count.scatter2", "count.buckets", "count.compact",
-  "count.total", "table.lookup", "extend", "route", "graph", "lp", "extend.prepare", "extend.sort", "extend.walk", "graph.seeds"};
+  "count.total", "table.lookup", "extend", "route", "graph", "lp", "extend.prepare", "extend.sort", "extend.walk", "graph.seeds",
+  "extend.walk_thread", "extend.walk_wave", "extend.mark", "extend.emit", "table.build"};
 extern "C" const char* shn_timer_name(int slot) {
   if (slot < 0 || slot >= T_N || !kTimerNames[slot]) return "";
   return kTimerNames[slot];
 }
 
-TimerRegion::TimerRegion(shn_ctx* ctx, int s) : c(ctx), slot(s), a(nullptr), b(nullptr) {
+TimerRegion::TimerRegion(shn_ctx* ctx, int s) : TimerRegion(ctx, s, ctx->stream) {}
+TimerRegion::TimerRegion(shn_ctx* ctx, int s, hipStream_t stream) : c(ctx), slot(s), a(nullptr), b(nullptr), st(stream) {
   if (!c->timing) return;
   hipEventCreate(&a);
   hipEventCreate(&b);
-  hipEventRecord(a, c->stream);
+  hipEventRecord(a, st);
 }
 TimerRegion::~TimerRegion() {
   if (!a) return;
-  hipEventRecord(b, c->stream);
+  hipEventRecord(b, st);
   c->pending[slot].push_back({a, b});
 }
+
+TimingOff::TimingOff(shn_ctx* ctx) : c(ctx), old(ctx->timing) { c->timing = false; }
+TimingOff::~TimingOff() { c->timing = old; }
 
 extern "C" int shn_ctx_create(int device, void* stream, shn_ctx** out) {
   if (!out) return shn_fail(SHN_ERR_ARG, "shn_ctx_create: out is NULL");

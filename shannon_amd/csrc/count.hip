@@ -410,9 +410,9 @@ extern "C" int shn_count_k1mers(shn_ctx* ctx, shn_reads* const* sets, int n_sets
     unsigned long long* d_cursor1 = d_hist1 + nb1;
     HIP_TRY(hipMemsetAsync(d_hist1, 0, (size_t)nb1 * 8, s));
     {
-      TimerRegion t(ctx, T_HIST1);
       for (auto& v : views) {
         if (!v.wmax || !v.n_reads) continue;
+        TimerRegion t(ctx, T_HIST1);                 // one region per launch (bench.py compares with rocprofv3 per kernel)
         uint64_t n_tiles = cdiv(v.n_reads, v.rt);
         uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, 2048);
         if (both_strands) hipLaunchKernelGGL(hist1_kernel<true>, dim3(grid), dim3(BLK), nb1 * 4, s, v, k1, bits, b2, n_tiles, d_hist1);
@@ -433,9 +433,9 @@ extern "C" int shn_count_k1mers(shn_ctx* ctx, shn_reads* const* sets, int n_sets
     uint64_t* keysA = (uint64_t*)pa;
     uint64_t* keysB = (uint64_t*)pb;
     {
-      TimerRegion t(ctx, T_SCATTER1);
       for (auto& v : views) {
         if (!v.wmax || !v.n_reads) continue;
+        TimerRegion t(ctx, T_SCATTER1);
         uint64_t n_tiles = cdiv(v.n_reads, v.rt);
         uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, 2048);
         size_t sh = (size_t)nb1 * 4 + (size_t)nb1 * 8;
@@ -486,8 +486,8 @@ static int build_from_keys(shn_ctx* ctx, uint64_t* keysA, uint64_t* keysB, uint3
   {
     TimerRegion t(ctx, T_HIST2);
     hipLaunchKernelGGL(hist_keys_kernel<false>, dim3(tiles, nb1), dim3(BLK), nb2 * 4, s, keysA, d_off1, bits, b2, d_hist2, tile2);
-    hipLaunchKernelGGL(scan_rows_kernel, dim3(nb1), dim3(BLK), 0, s, d_hist2, nb2, d_off2, d_cursor2);
   }
+  hipLaunchKernelGGL(scan_rows_kernel, dim3(nb1), dim3(BLK), 0, s, d_hist2, nb2, d_off2, d_cursor2);
   {
     TimerRegion t(ctx, T_SCATTER2);
     if (cntA) hipLaunchKernelGGL((scatter_keys_kernel<false, true>), dim3(tiles, nb1), dim3(BLK), nb2 * 8, s, keysA, cntA, d_off1, bits, b2, d_cursor2, keysB, cntB, tile2);
@@ -611,7 +611,8 @@ extern "C" int shn_table_from_pairs(shn_ctx* ctx, const void* dev_keys, const vo
   if (n >= 0xFFFFFFFFULL) return shn_fail(SHN_ERR_ARG, "shn_table_from_pairs: more than 2^32 pairs");
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
-  TimerRegion ttot(ctx, T_COUNT_TOTAL);
+  TimerRegion ttot(ctx, T_TABLE_BUILD);           // small tables (probe / seed / exchanged shards): one region, kept apart
+  TimingOff toff(ctx);                            // from the per-kernel timers of the counting pass
   const uint64_t* keys = (const uint64_t*)dev_keys;
   const uint32_t* cnts = (const uint32_t*)dev_counts;
   int bits = 0;

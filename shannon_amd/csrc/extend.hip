@@ -22,6 +22,8 @@
 // as in the reference's strand-doubled input.
 #include "common.h"
 #include <cstring>
+#include <vector>
+#include <time.h>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -52,10 +54,8 @@ struct shn_ext {
   uint32_t* d_order;     // [n_seeds] oriented id of the seed with rank r
   u64* d_claim;          // [2n] converged claims: (rank of the owning walk) << 32 | (1 + step index on its path)
   u64* d_claim2;         // [2n] scratch
-  uint32_t* d_pool;      // stored paths of the long walks (converged iteration)
-  uint64_t* d_poff;      // [n_seeds] pool offset of walk r (valid when d_pstored[r])
-  uint8_t* d_pstored;    // [n_seeds]
   uint64_t total_steps;  // walk steps executed over all iterations (for the bench's byte model)
+  uint64_t wave_steps;   // ... of which by the wavefront kernel
   uint32_t* d_nr;        // [n_seeds] right steps (UNCLAIMED = void walk)
   uint32_t* d_nl;        // [n_seeds]
   uint64_t* d_totw;      // [n_seeds] sum of weights incl. the seed
@@ -147,7 +147,14 @@ struct WalkArgs {
   uint32_t* pool_cur; const uint64_t* poff_cur; const uint32_t* pcap_cur; uint8_t* pstored_cur;
   const uint8_t* is_long; const uint8_t* dirty;
   unsigned long long* steps_counter;
+  unsigned long long* wave_steps_counter;
 };
+
+// Claim `node` as step `pos` of walk r: atomic min on rank:pos, fire-and-forget (a returning atomic would put
+// a second memory round trip on every step; lost races are found after the round by ext_verify_kernel).
+__device__ __forceinline__ void claim_node(const WalkArgs& A, uint32_t node, uint32_t r, uint32_t pos) {
+  __hip_atomic_fetch_min(&A.claim[node], CLAIM(r, pos), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // One greedy decision (extension_correction.py:223-237): among the candidates that exist and are not
 // traversed pick the heaviest, ties in BASES order A,G,C,T (codes 0,2,1,3; strict >).  Traversed = claimed
@@ -155,7 +162,7 @@ struct WalkArgs {
 // the walk's old path -- own old position in [lo, hi] (taken from the pre-round snapshot).
 __device__ __forceinline__ int decide(const Adj4& cand, uint32_t r, uint32_t lo, uint32_t hi, const u64* claim,
                                       const u64* __restrict__ claim_old, const uint32_t* __restrict__ weight, uint32_t dummy,
-                                      uint32_t& bw) {
+                                      uint32_t& bw, u64& chosen_old) {
   u64 cl[4], co[4];
   uint32_t w[4];
 #pragma unroll
@@ -174,16 +181,13 @@ __device__ __forceinline__ int decide(const Adj4& cand, uint32_t r, uint32_t lo,
   }
   CONSIDER(0) CONSIDER(2) CONSIDER(1) CONSIDER(3)
 #undef CONSIDER
+  chosen_old = best < 0 ? UNCLAIMED64 : (best == 0 ? co[0] : best == 1 ? co[1] : best == 2 ? co[2] : co[3]);
   return best;
 }
 
 // ---- short walks: one thread per walk, one memory round trip per step (candidate rows prefetched).
-// EMIT: re-walk the selected final walks against the final claims and write their contig bases.
-template <bool EMIT>
 __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_walks, const uint32_t* __restrict__ list,
-                                                        const uint8_t* __restrict__ skip, const u64* __restrict__ final_claim,
-                                                        const uint64_t* __restrict__ tkeys, int k,
-                                                        const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out_bases) {
+                                                        const u64* __restrict__ snap) {
   __shared__ unsigned long long blk_steps;
   if (threadIdx.x == 0) blk_steps = 0;
   __syncthreads();
@@ -191,79 +195,56 @@ __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
   uint32_t mysteps = 0;
   if (t < n_walks) {
     const uint32_t r = list[t];
-    if (!(skip && skip[r])) {
-      const uint32_t o = A.order[r];
-      uint32_t nr = 0, nl = 0;
-      uint64_t tot = 0;
-      // final_claim: the pre-round snapshot (or, for EMIT, the converged claims); A.claim: live claims of this
-      // round (EMIT: a scratch array for the own trail)
-      bool isvoid = RANK(final_claim[o]) < r || (!EMIT && RANK(__hip_atomic_load(&A.claim[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < r);
-      uint8_t* dst = nullptr;
-      uint32_t nl_known = 0, nr_known = 0;
-      if (EMIT && !isvoid) {
-        dst = out_bases + out_off[t];
-        nl_known = A.nl_out[r];
-        nr_known = A.nr_out[r];
-        uint64_t s = oriented_string(tkeys, o, k);
-        for (int j = 0; j < k; j++) dst[nl_known + j] = "ACGT"[(s >> (2 * (k - 1 - j))) & 3];
-      }
-      if (!isvoid) {
-        atomicMin(&A.claim[o], CLAIM(r, 0));
-        tot = A.weight[o >> 1];
-        uint32_t pos = 0;
-        for (int dir = 0; dir < 2; dir++) {
-          const Adj4* adj = dir == 0 ? A.adjR : A.adjL;
-          uint32_t steps = 0;
-          Adj4 cand = adj[o];
-          while (true) {
-            u64 cl[4], cf[4];
-            uint32_t w[4];
-            Adj4 nxt[4];
+    const uint32_t o = A.order[r];
+    uint32_t nr = 0, nl = 0;
+    uint64_t tot = 0;
+    // snap: the pre-round snapshot; A.claim: live claims of this round
+    bool isvoid = RANK(snap[o]) < r || RANK(__hip_atomic_load(&A.claim[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < r;
+    if (!isvoid) {
+      claim_node(A, o, r, 0);
+      tot = A.weight[o >> 1];
+      uint32_t pos = 0;
+      for (int dir = 0; dir < 2; dir++) {
+        const Adj4* adj = dir == 0 ? A.adjR : A.adjL;
+        uint32_t steps = 0;
+        Adj4 cand = adj[o];
+        while (true) {
+          u64 cl[4], cf[4];
+          uint32_t w[4];
+          Adj4 nxt[4];
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-              uint32_t idx = cand.v[b] < 0 ? o : (uint32_t)cand.v[b];
-              cl[b] = __hip_atomic_load(&A.claim[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              cf[b] = final_claim[idx];
-              w[b] = A.weight[idx >> 1];
-              nxt[b] = adj[idx];
-            }
-            int best = -1;
-            uint32_t bw = 0;
-#define CONSIDER(b) if (cand.v[b] >= 0 && RANK(cl[b]) > r && RANK(cf[b]) >= r && (best < 0 || w[b] > bw)) { best = b; bw = w[b]; }
-            CONSIDER(0) CONSIDER(2) CONSIDER(1) CONSIDER(3)
-#undef CONSIDER
-            if (best < 0) break;
-            uint32_t nbest = (uint32_t)cand.v[best];
-            pos++;
-            __hip_atomic_fetch_min(&A.claim[nbest], CLAIM(r, pos), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (EMIT) {
-              const uint32_t lim = dir == 0 ? nr_known : nl_known;
-              if (steps >= lim) { atomicAdd(A.steps_counter, 1ULL); break; }      // re-walk left its recorded path: flag, do not write
-              if (dir == 0) dst[nl_known + k + steps] = "ACGT"[best];
-              else dst[nl_known - 1 - steps] = "ACGT"[best];
-            }
-            steps++;
-            tot += bw;
-            cand = best == 0 ? nxt[0] : best == 1 ? nxt[1] : best == 2 ? nxt[2] : nxt[3];
+          for (int b = 0; b < 4; b++) {
+            uint32_t idx = cand.v[b] < 0 ? o : (uint32_t)cand.v[b];
+            cl[b] = __hip_atomic_load(&A.claim[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cf[b] = snap[idx];
+            w[b] = A.weight[idx >> 1];
+            nxt[b] = adj[idx];
           }
-          if (EMIT && steps != (dir == 0 ? nr_known : nl_known)) atomicAdd(A.steps_counter, 1ULL << 32);
-          if (dir == 0) nr = steps; else nl = steps;
+          int best = -1;
+          uint32_t bw = 0;
+#define CONSIDER(b) if (cand.v[b] >= 0 && RANK(cl[b]) > r && RANK(cf[b]) >= r && (best < 0 || w[b] > bw)) { best = b; bw = w[b]; }
+          CONSIDER(0) CONSIDER(2) CONSIDER(1) CONSIDER(3)
+#undef CONSIDER
+          if (best < 0) break;
+          uint32_t nbest = (uint32_t)cand.v[best];
+          pos++;
+          claim_node(A, nbest, r, pos);
+          steps++;
+          tot += bw;
+          cand = best == 0 ? nxt[0] : best == 1 ? nxt[1] : best == 2 ? nxt[2] : nxt[3];
         }
-      }
-      if (!EMIT) {
-        A.nr_out[r] = isvoid ? UNCLAIMED : nr;
-        A.nl_out[r] = nl;
-        A.totw_out[r] = tot;
-        A.pstored_cur[r] = 0;
-        mysteps = nr + nl;
+        if (dir == 0) nr = steps; else nl = steps;
       }
     }
+    A.nr_out[r] = isvoid ? UNCLAIMED : nr;
+    A.nl_out[r] = nl;
+    A.totw_out[r] = tot;
+    A.pstored_cur[r] = 0;
+    mysteps = nr + nl;
   }
-  if (!EMIT) {
-    if (mysteps) atomicAdd(&blk_steps, (unsigned long long)mysteps);
-    __syncthreads();
-    if (threadIdx.x == 0 && blk_steps) atomicAdd(A.steps_counter, blk_steps);
-  }
+  if (mysteps) atomicAdd(&blk_steps, (unsigned long long)mysteps);
+  __syncthreads();
+  if (threadIdx.x == 0 && blk_steps) atomicAdd(A.steps_counter, blk_steps);
 }
 
 // ---- long walks: one wavefront per walk.  Clean walks only carry their memo forward; dirty walks re-check
@@ -300,7 +281,7 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
   }
   uint32_t ns = 0, nr_new = 0;
   uint64_t tot = A.weight[o >> 1];
-  if (lane == 0) atomicMin(&A.claim[o], CLAIM(r, 0));
+  if (lane == 0) claim_node(A, o, r, 0);
   for (int dir = 0; dir < 2; dir++) {
     const Adj4* adj = dir == 0 ? A.adjR : A.adjL;
     const uint32_t ob = dir == 0 ? 0 : oldR, oe = dir == 0 ? oldR : oldR + oldL;
@@ -309,6 +290,7 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
     while (true) {
       int32_t taken = -1;                     // node taken by a sequential / deviating step this round
       uint32_t taken_w = 0;
+      u64 taken_co = UNCLAIMED64;             // its snapshot claim (rejoin test)
       if (oi != NONE32) {
         const uint32_t nchunk = min(64u, oe - oi);          // real old steps covered by this round
         const uint32_t s = oi + lane;
@@ -316,11 +298,12 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
         const bool checked = (uint32_t)lane < nchunk || is_term;
         int32_t chosen = -1;
         uint32_t bw = 0;
+        u64 cco = UNCLAIMED64;
         if (checked) {
           uint32_t before = lane == 0 ? cur : oldp[s - 1];
-          Adj4 cand = adj[before];
-          int b = decide(cand, r, oi + 1, s, A.claim, A.claim_old, A.weight, o, bw);
-          chosen = b < 0 ? -1 : cand.v[b];
+          Adj4 cd = adj[before];
+          int b = decide(cd, r, oi + 1, s, A.claim, A.claim_old, A.weight, o, bw, cco);
+          chosen = b < 0 ? -1 : cd.v[b];
         }
         const int32_t expect = (checked && !is_term) ? (int32_t)oldp[s] : -1;
         const u64 bad = __ballot(checked && chosen != expect);
@@ -330,7 +313,7 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
         if ((uint32_t)lane < conf) {
           uint32_t node = oldp[s];
           uint32_t pos = ns + lane + 1;
-          __hip_atomic_fetch_min(&A.claim[node], CLAIM(r, pos), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          claim_node(A, node, r, pos);
           if (ns + lane < cap) newp[ns + lane] = node;
           myw = A.weight[node >> 1];
         }
@@ -345,32 +328,33 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
         }
         taken = __shfl(chosen, (int)m, 64);
         taken_w = __shfl(bw, (int)m, 64);
+        taken_co = __shfl(cco, (int)m, 64);
         if (taken < 0) break;                 // the walk now stops here
       } else {
+        // (prefetching the candidates' rows as the thread kernel does measured slower here: 64 lanes x 16 loads)
         Adj4 cand = adj[cur];
-        uint32_t bw = 0;
-        int b = decide(cand, r, 1, 0, A.claim, A.claim_old, A.weight, o, bw);
-        if (b < 0) break;
-        taken = cand.v[b];
-        taken_w = bw;
+        uint32_t bw2 = 0;
+        u64 cco2 = UNCLAIMED64;
+        int b2 = decide(cand, r, 1, 0, A.claim, A.claim_old, A.weight, o, bw2, cco2);
+        if (b2 < 0) break;
+        taken = cand.v[b2];
+        taken_w = bw2;
+        taken_co = cco2;
       }
       // take `taken` as the next step, then look for a rejoin with the old path
       {
         uint32_t pos = ns + 1;
         if (lane == 0) {
-          __hip_atomic_fetch_min(&A.claim[taken], CLAIM(r, pos), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          claim_node(A, (uint32_t)taken, r, pos);
           if (ns < cap) newp[ns] = (uint32_t)taken;
         }
         tot += taken_w;
         ns++;
         cur = (uint32_t)taken;
         oi = NONE32;
-        if (had) {
-          u64 cpv = A.claim_old[taken];
-          if (RANK(cpv) == r && POS(cpv) >= 1) {
-            uint32_t p = POS(cpv) - 1;
-            if (p >= ob && p < oe && oldp[p] == (uint32_t)taken) oi = p + 1;
-          }
+        if (had && RANK(taken_co) == r && POS(taken_co) >= 1) {
+          uint32_t p = POS(taken_co) - 1;
+          if (p >= ob && p < oe && oldp[p] == (uint32_t)taken) oi = p + 1;
         }
       }
     }
@@ -383,7 +367,7 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
     A.nl_out[r] = ns - nr_new;
     A.totw_out[r] = tot;
     A.pstored_cur[r] = keep ? 1 : 0;
-    if (ns) atomicAdd(A.steps_counter, (unsigned long long)ns);
+    if (ns) { atomicAdd(A.steps_counter, (unsigned long long)ns); atomicAdd(A.wave_steps_counter, (unsigned long long)ns); }
   }
 }
 
@@ -397,6 +381,9 @@ __global__ void ext_plan_kernel(const uint32_t* __restrict__ nr, const uint32_t*
                                 uint64_t pool_cap) {
   // ns here = current rank limit (walks >= limit have not started yet); walks < frozen are final and never run
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + frozen;
+  const bool isd = r < ns && dirty[r];
+  unsigned long long dm = __ballot(isd);
+  if (dm && (threadIdx.x & 63) == (uint32_t)(__ffsll((long long)dm) - 1)) atomicAdd(&counters[3], (unsigned long long)__popcll(dm));
   if (r >= ns) return;
   uint32_t a = nr[r];
   uint32_t len = a == UNCLAIMED ? 0 : a + nl[r];
@@ -435,40 +422,45 @@ __global__ void ext_mark_kernel(const u64* __restrict__ claim, const u64* __rest
   uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t a = UNCLAIMED, b = UNCLAIMED;
   if (y < n2) { a = RANK(claim_old[y]); b = RANK(claim[y]); }
-  // one atomic per wavefront for the change counter (it was one per changed k1-mer on a single address)
+  // one atomic per wavefront for the change counter
   unsigned long long chm = __ballot(a != b);
   if (chm && (threadIdx.x & 63) == (uint32_t)(__ffsll((long long)chm) - 1)) atomicAdd(n_changed, (unsigned long long)__popcll(chm));
-  if (y >= n2) return;
-  if (b != UNCLAIMED && ran[b]) atomicAdd(&owned[b], 1u);
+  if (b != UNCLAIMED && ran[b]) atomicAdd(&owned[b], 1u);      // for ext_verify_kernel
   if (a == b) return;
-  // a walk depends only on lower ranks: walks below `frozen` are final whatever happens above them; walks at or
-  // above `limit` have not started (they all run when their phase opens)
+  // Who has to look again?  Walk x treats y as traversed iff its owner's rank is below x, and removing a
+  // candidate it did not choose never changes a greedy choice -- so only walks for which y BECAME available
+  // (a < x < b) are affected: the walks that stood next to y (owners of its 8 neighbours) and the walk seeded
+  // on y (void while y belonged to a lower rank).  The old owner re-runs if it was robbed while it sat out this
+  // round (one that ran this round gave y up knowingly; one that lost it during its run is caught by the verify kernel); the
+  // new owner ran this round.  Walks below `frozen` are final, walks at or above `limit` have not started (they
+  // all run when their phase opens).
 #define MARK(x) if ((x) >= frozen && (x) < limit) dirty[x] = 1
-  MARK(a);
-  MARK(b);
+  if (a != UNCLAIMED && !ran[a]) MARK(a);
+  if (b < a) return;
+#define MARKX(x) if (a < (x) && (x) < b) MARK(x)
   uint32_t sr = seed_rank[y];
-  MARK(sr);
+  MARKX(sr);
   Adj4 L = adjL[y], R = adjR[y];
 #pragma unroll
   for (int q = 0; q < 8; q++) {
     int32_t nb = q < 4 ? L.v[q] : R.v[q - 4];
     if (nb < 0) continue;
     uint32_t x = RANK(claim_old[nb]), z = RANK(claim[nb]);
-    MARK(x);
-    MARK(z);
+    MARKX(x);
+    MARKX(z);
   }
+#undef MARKX
 #undef MARK
 }
 
 // A walk that ran this round must own exactly the k1-mers on the path it recorded; if a lower rank took one
-// of them back during the round (the walk saw it free for a moment) its record is stale: run it again.
+// of them during the round (the walk saw it free for a moment) its record is stale: run it again.
 __global__ void ext_verify_kernel(const uint8_t* __restrict__ ran, const uint32_t* __restrict__ owned, const uint32_t* __restrict__ nr,
-                                  const uint32_t* __restrict__ nl, uint64_t ns, uint8_t* __restrict__ dirty,
-                                  unsigned long long* __restrict__ n_unstable) {
+                                  const uint32_t* __restrict__ nl, uint64_t ns, uint8_t* __restrict__ dirty) {
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= ns || !ran[r]) return;
   uint32_t expect = nr[r] == UNCLAIMED ? 0u : nr[r] + nl[r] + 1u;
-  if (owned[r] != expect) { dirty[r] = 1; atomicAdd(n_unstable, 1ULL); }
+  if (owned[r] != expect) dirty[r] = 1;
 }
 
 __global__ void ext_seed_rank_kernel(const uint32_t* __restrict__ order, uint64_t ns, uint32_t* __restrict__ seed_rank) {
@@ -476,51 +468,39 @@ __global__ void ext_seed_rank_kernel(const uint32_t* __restrict__ order, uint64_
   if (r < ns) seed_rank[order[r]] = (uint32_t)r;
 }
 
-// copy the memo of every stored long walk into the ext-owned final pool (after convergence).  A memo is used
-// only if it is exactly the final path: header == final lengths and every node carries the claim (r, step+1).
-__global__ void ext_keep_final_kernel(const uint32_t* __restrict__ long_list, uint64_t n_long, const uint32_t* __restrict__ pool,
-                                      const uint64_t* __restrict__ poff, const uint8_t* __restrict__ pstored,
-                                      const uint32_t* __restrict__ nr, const uint32_t* __restrict__ nl, const u64* __restrict__ claim,
-                                      uint32_t* __restrict__ fpool, uint64_t* __restrict__ foff, uint8_t* __restrict__ fstored,
-                                      unsigned long long* __restrict__ cursor, uint64_t fcap, unsigned long long* __restrict__ n_bad) {
-  if (blockIdx.x >= n_long) return;
-  uint32_t r = long_list[blockIdx.x];
-  if (!pstored[r] || nr[r] == UNCLAIMED) return;
-  const uint32_t* h = pool + poff[r];
-  uint32_t len = h[0] + h[1];
-  __shared__ unsigned long long base;
-  __shared__ int ok;
-  if (threadIdx.x == 0) ok = (h[0] == nr[r] && h[1] == nl[r]) ? 1 : 0;
-  __syncthreads();
-  if (ok) for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) if (claim[h[2 + i]] != CLAIM(r, i + 1)) ok = 0;
-  __syncthreads();
-  if (!ok) { if (threadIdx.x == 0) atomicAdd(n_bad, 1ULL); return; }
-  if (threadIdx.x == 0) base = atomicAdd(cursor, (unsigned long long)len);
-  __syncthreads();
-  if (base + len > fcap) return;
-  for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) fpool[base + i] = h[2 + i];
-  if (threadIdx.x == 0) { foff[r] = base; fstored[r] = 1; }
-}
-
-// contig bases of a walk whose path is stored: one block per selected walk
-__global__ void ext_emit_stored_kernel(const uint32_t* __restrict__ sel, uint64_t n_sel, const uint32_t* __restrict__ order,
-                                       const uint8_t* __restrict__ pstored, const uint32_t* __restrict__ pool,
-                                       const uint64_t* __restrict__ poff, const uint32_t* __restrict__ nr_a,
-                                       const uint32_t* __restrict__ nl_a, const uint64_t* __restrict__ tkeys, int k,
-                                       const uint64_t* __restrict__ out_off, uint8_t* __restrict__ out_bases) {
-  uint64_t t = blockIdx.x;
-  if (t >= n_sel) return;
-  uint32_t r = sel[t];
-  if (!pstored[r] || nr_a[r] == UNCLAIMED) return;
-  uint32_t nr = nr_a[r], nl = nl_a[r];
-  uint8_t* dst = out_bases + out_off[t];
-  const uint32_t* p = pool + poff[r];
-  uint64_t s = oriented_string(tkeys, order[r], k);
-  for (uint32_t j = threadIdx.x; j < (uint32_t)k; j += blockDim.x) dst[nl + j] = "ACGT"[(s >> (2 * (k - 1 - j))) & 3];
-  for (uint32_t j = threadIdx.x; j < nr + nl; j += blockDim.x) {
-    uint64_t str = oriented_string(tkeys, p[j], k);
-    if (j < nr) dst[nl + k + j] = "ACGT"[str & 3];                       // appended base = last base of the k1-mer
-    else dst[nl - 1 - (j - nr)] = "ACGT"[(str >> (2 * (k - 1))) & 3];   // prepended base = first base
+// Contig bases straight from the converged claims: every oriented k1-mer knows its walk and its step index
+// (claim = rank << 32 | pos; pos 0 = seed, 1..nR right steps, nR+1..nR+nL left steps), so the contig of a
+// selected walk is a scatter -- no walking.  (extension_correction.py:223-245: a right step appends the last
+// base of the new k1-mer, a left step prepends its first base.)
+__global__ void ext_emit_claims_kernel(const u64* __restrict__ claim, uint64_t n2, const int32_t* __restrict__ sel_of_rank, uint64_t ns,
+                                       const uint32_t* __restrict__ nr_a, const uint32_t* __restrict__ nl_a,
+                                       const uint64_t* __restrict__ tkeys, int k, const uint64_t* __restrict__ out_off,
+                                       uint8_t* __restrict__ out_bases, unsigned long long* __restrict__ counters) {
+  uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int32_t t = -1;
+  uint32_t r = UNCLAIMED, pos = 0;
+  if (y < n2) {
+    u64 c = claim[y];
+    r = RANK(c); pos = POS(c);
+    if (r != UNCLAIMED && r < ns) t = sel_of_rank[r];
+  }
+  bool wrote = false, stray = false;
+  if (t >= 0) {
+    uint32_t nr = nr_a[r], nl = nl_a[r];
+    if (nr == UNCLAIMED || pos > nr + nl) stray = true;          // claim of a void walk / beyond its recorded path
+    else {
+      uint8_t* dst = out_bases + out_off[t];
+      uint64_t str = oriented_string(tkeys, (uint32_t)y, k);
+      if (pos == 0) for (int j = 0; j < k; j++) dst[nl + j] = "ACGT"[(str >> (2 * (k - 1 - j))) & 3];
+      else if (pos <= nr) dst[nl + k + (pos - 1)] = "ACGT"[str & 3];
+      else dst[nl - 1 - (pos - nr - 1)] = "ACGT"[(str >> (2 * (k - 1))) & 3];
+      wrote = true;
+    }
+  }
+  unsigned long long wm = __ballot(wrote), sm = __ballot(stray);
+  if ((threadIdx.x & 63) == 0) {
+    if (wm) atomicAdd(&counters[0], (unsigned long long)__popcll(wm));
+    if (sm) atomicAdd(&counters[1], (unsigned long long)__popcll(sm));
   }
 }
 
@@ -528,7 +508,7 @@ extern "C" void shn_ext_destroy(shn_ext* e) {
   if (!e) return;
   hipSetDevice(e->device);
   void* ptrs[] = {e->d_weight, e->d_flags, e->d_adjR, e->d_adjL, e->d_order, e->d_claim, e->d_claim2, e->d_nr, e->d_nl,
-                  e->d_totw, e->d_hash, e->d_pool, e->d_poff, e->d_pstored};
+                  e->d_totw, e->d_hash};
   for (void* p : ptrs) if (p) hipFree(p);
   delete e;
 }
@@ -586,16 +566,11 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
   TRYE(hipMalloc(&e->d_nr, (ns + 1) * 4));
   TRYE(hipMalloc(&e->d_nl, (ns + 1) * 4));
   TRYE(hipMalloc(&e->d_totw, (ns + 1) * 8));
-  TRYE(hipMalloc(&e->d_poff, (ns + 1) * 8));
-  TRYE(hipMalloc(&e->d_pstored, ns + 1));
   const uint64_t pool_cap = 6 * n + (1ULL << 20);
-  const uint64_t fcap = 2 * n + 16;                      // final paths are disjoint: at most one slot per oriented k1-mer
-  TRYE(hipMalloc(&e->d_pool, fcap * 4));
   TRYE(hipMemcpyAsync(e->d_order, svals, ns * 4, hipMemcpyDeviceToDevice, s));
   TRYE(hipMemsetAsync(e->d_nr, 0xFF, (ns + 1) * 4, s));
   TRYE(hipMemsetAsync(e->d_nl, 0, (ns + 1) * 4, s));
   TRYE(hipMemsetAsync(e->d_totw, 0, (ns + 1) * 8, s));
-  TRYE(hipMemsetAsync(e->d_pstored, 0, ns + 1, s));
   TRYE(hipMemsetAsync(e->d_claim, 0xFF, (2 * n + 1) * 8, s));
   // scratch: claim snapshot, two memo pools + per-walk plan arrays (double-buffered across rounds)
   void *ppool1, *ppool2, *pplan, *pseed;
@@ -629,65 +604,76 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
   // Rank phases: a walk depends only on lower ranks, so the fixpoint is reached block by block -- first the
   // heaviest seeds (where the long, mutually dependent walks live), then geometrically larger blocks that see
   // final lower ranks and settle in a few rounds.
-  uint32_t frozen = 0, limit = (uint32_t)std::min<unsigned long long>(ns, std::max<unsigned long long>(ns / 32, 4096));
+  unsigned long long lim0 = std::max<unsigned long long>(ns / 32, 4096), grow = 4;
+  if (getenv("SHN_EXT_LIMIT0")) lim0 = strtoull(getenv("SHN_EXT_LIMIT0"), nullptr, 10);
+  if (getenv("SHN_EXT_GROW")) grow = strtoull(getenv("SHN_EXT_GROW"), nullptr, 10);
+  uint32_t frozen = 0, limit = (uint32_t)std::min<unsigned long long>(ns, lim0);
   TRYE(hipMemsetAsync(dirty, 0, ns + 1, s));
   TRYE(hipMemsetAsync(dirty, 1, limit, s));
   while (!converged && it < max_iterations) {
+    // classify the walks of the open block; a block without dirty walks is consistent = final
+    TRYE(hipMemsetAsync(d_cnt + 2, 0, 32, s));
+    if (limit > frozen)
+      hipLaunchKernelGGL(ext_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 256)), dim3(256), 0, s, e->d_nr, e->d_nl, (uint64_t)limit, frozen,
+                         pool_a, poff_a, pst_a, dirty, is_long, long_list, short_list, poff_b, pcap, d_cnt + 2, pool_cap);
+    unsigned long long plan[4] = {0, 0, 0, 0};      // long walks (dirty or memo carriers), pool words, short dirty walks, dirty walks
+    TRYE(hipMemcpyAsync(plan, d_cnt + 2, 32, hipMemcpyDeviceToHost, s));
+    TRYE(hipStreamSynchronize(s));
+    if (plan[3] == 0) {
+      if (limit >= ns) { converged = true; break; }
+      frozen = limit;                                // this block is final: open the next one
+      limit = (uint32_t)std::min<unsigned long long>(ns, (unsigned long long)limit * grow);
+      TRYE(hipMemsetAsync(dirty + frozen, 1, limit - frozen, s));
+      continue;
+    }
     TimerRegion t3(ctx, T_EXT_WALK);
     // snapshot, then release the claims of the walks that re-run this round
     TRYE(hipMemcpyAsync(snap, claim, (2 * n + 1) * 8, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(ext_release_kernel, dim3(g2n), dim3(256), 0, s, claim, 2 * n, dirty, (uint64_t)ns);
-    TRYE(hipMemsetAsync(d_cnt + 2, 0, 24, s));
     TRYE(hipMemsetAsync(d_cnt + 6, 0, 16, s));
-    if (limit > frozen)
-      hipLaunchKernelGGL(ext_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 256)), dim3(256), 0, s, e->d_nr, e->d_nl, (uint64_t)limit, frozen,
-                         pool_a, poff_a, pst_a, dirty, is_long, long_list, short_list, poff_b, pcap, d_cnt + 2, pool_cap);
-    unsigned long long plan[3] = {0, 0, 0};
-    TRYE(hipMemcpyAsync(plan, d_cnt + 2, 24, hipMemcpyDeviceToHost, s));
-    TRYE(hipStreamSynchronize(s));
     WalkArgs A;
     A.order = e->d_order; A.adjR = (const Adj4*)e->d_adjR; A.adjL = (const Adj4*)e->d_adjL; A.weight = e->d_weight;
     A.claim = claim; A.claim_old = snap;
     A.nr_out = e->d_nr; A.nl_out = e->d_nl; A.totw_out = e->d_totw;
     A.pool_prev = pool_a; A.poff_prev = poff_a; A.pstored_prev = pst_a;
     A.pool_cur = pool_b; A.poff_cur = poff_b; A.pcap_cur = pcap; A.pstored_cur = pst_b;
-    A.is_long = is_long; A.dirty = dirty; A.steps_counter = d_cnt + 1;
+    A.is_long = is_long; A.dirty = dirty; A.steps_counter = d_cnt + 1; A.wave_steps_counter = d_cnt + 9;
     // long (wave per walk) and short (thread per walk) kernels are independent: overlap them on two streams
     if (plan[0]) {
       TRYE(hipEventRecord(ev_fork, s));
       TRYE(hipStreamWaitEvent(aux, ev_fork, 0));
-      hipLaunchKernelGGL(ext_walk_long_kernel, dim3((uint32_t)plan[0]), dim3(64), 0, aux, A, long_list);
+      { TimerRegion tk(ctx, T_EXT_WALK_WAVE, aux);
+        hipLaunchKernelGGL(ext_walk_long_kernel, dim3((uint32_t)plan[0]), dim3(64), 0, aux, A, long_list); }
       TRYE(hipEventRecord(ev_join, aux));
     }
-    if (plan[2]) hipLaunchKernelGGL(ext_walk_kernel<false>, dim3((uint32_t)cdiv(plan[2], EBLK)), dim3(EBLK), 0, s, A, (uint64_t)plan[2],
-                                    short_list, nullptr, snap, t->d_keys, t->k, nullptr, nullptr);
+    if (plan[2]) {
+      TimerRegion tk(ctx, T_EXT_WALK_THREAD);
+      hipLaunchKernelGGL(ext_walk_kernel, dim3((uint32_t)cdiv(plan[2], EBLK)), dim3(EBLK), 0, s, A, (uint64_t)plan[2], short_list, snap);
+    }
     if (plan[0]) TRYE(hipStreamWaitEvent(s, ev_join, 0));
-    // who has to run next round?
+    // who has to run next round?  walks whose view changed (mark) + walks that lost a claim race (verify)
     TRYE(hipMemcpyAsync(ran, dirty, ns + 1, hipMemcpyDeviceToDevice, s));
     TRYE(hipMemsetAsync(dirty, 0, ns + 1, s));
     TRYE(hipMemsetAsync(owned, 0, (ns + 1) * 4, s));
-    hipLaunchKernelGGL(ext_mark_kernel, dim3(g2n), dim3(256), 0, s, claim, snap, 2 * n, (const Adj4*)e->d_adjR, (const Adj4*)e->d_adjL,
-                       seed_rank, dirty, ran, owned, d_cnt + 6, frozen, limit);
-    hipLaunchKernelGGL(ext_verify_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, ran, owned, e->d_nr, e->d_nl, (uint64_t)ns, dirty,
-                       d_cnt + 7);
-    unsigned long long chg[2] = {0, 0};
-    TRYE(hipMemcpyAsync(chg, d_cnt + 6, 16, hipMemcpyDeviceToHost, s));
-    TRYE(hipStreamSynchronize(s));
-    unsigned long long nchanged = chg[0] + chg[1];
+    { TimerRegion tk(ctx, T_EXT_MARK);
+      hipLaunchKernelGGL(ext_mark_kernel, dim3(g2n), dim3(256), 0, s, claim, snap, 2 * n, (const Adj4*)e->d_adjR, (const Adj4*)e->d_adjL,
+                         seed_rank, dirty, ran, owned, d_cnt + 6, frozen, limit); }
+    hipLaunchKernelGGL(ext_verify_kernel, dim3((uint32_t)cdiv(limit, 256)), dim3(256), 0, s, ran, owned, e->d_nr, e->d_nl, (uint64_t)limit, dirty);
     if (getenv("SHN_EXT_ALLDIRTY")) { TRYE(hipMemsetAsync(dirty, 0, ns + 1, s)); TRYE(hipMemsetAsync(dirty + frozen, 1, limit - frozen, s)); }
     it++;
     last_long = plan[0];
-    if (getenv("SHN_DEBUG")) fprintf(stderr, "[shn_extend] round %d [%u,%u): long=%llu short_dirty=%llu changed_kmers=%llu unstable=%llu\n", it, frozen, limit,
-                                     plan[0], plan[2], chg[0], chg[1]);
-    std::swap(pool_a, pool_b); std::swap(poff_a, poff_b); std::swap(pst_a, pst_b);
-    if (nchanged == 0) {
-      if (limit >= ns) converged = true;
-      else {                                   // this block is final: open the next one
-        frozen = limit;
-        limit = (uint32_t)std::min<unsigned long long>(ns, (unsigned long long)limit * 4);
-        TRYE(hipMemsetAsync(dirty + frozen, 1, limit - frozen, s));
-      }
+    if (getenv("SHN_DEBUG")) {
+      unsigned long long chg = 0;
+      TRYE(hipMemcpyAsync(&chg, d_cnt + 6, 8, hipMemcpyDeviceToHost, s));
+      TRYE(hipStreamSynchronize(s));
+      static double t_prev = 0;
+      timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+      double tn = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+      fprintf(stderr, "[shn_extend] round %d [%u,%u): dirty=%llu long=%llu short_dirty=%llu changed_kmers=%llu  %.2f ms\n", it, frozen, limit,
+              plan[3], plan[0], plan[2], chg, it == 1 ? 0.0 : tn - t_prev);
+      t_prev = tn;
     }
+    std::swap(pool_a, pool_b); std::swap(poff_a, poff_b); std::swap(pst_a, pst_b);
   }
   hipStreamSynchronize(aux);
   hipStreamDestroy(aux);
@@ -695,15 +681,13 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
   hipEventDestroy(ev_join);
   e->iterations = it;
   if (!converged) { shn_ext_destroy(e); return shn_fail(SHN_ERR_INTERNAL, "shn_extend: walk fixpoint did not converge"); }
-  // keep the paths of the long walks for the emit (memo of the last round = pool_a after the swap)
-  if (last_long) hipLaunchKernelGGL(ext_keep_final_kernel, dim3((uint32_t)last_long), dim3(256), 0, s, long_list, (uint64_t)last_long, pool_a,
-                                    poff_a, pst_a, e->d_nr, e->d_nl, claim, e->d_pool, e->d_poff, e->d_pstored, d_cnt + 5, fcap, d_cnt + 8);
-  unsigned long long steps = 0, nbad = 0;
+  unsigned long long steps = 0, wsteps = 0;
   TRYE(hipMemcpyAsync(&steps, d_cnt + 1, 8, hipMemcpyDeviceToHost, s));
-  TRYE(hipMemcpyAsync(&nbad, d_cnt + 8, 8, hipMemcpyDeviceToHost, s));
+  TRYE(hipMemcpyAsync(&wsteps, d_cnt + 9, 8, hipMemcpyDeviceToHost, s));
   TRYE(hipStreamSynchronize(s));
-  if (getenv("SHN_DEBUG")) fprintf(stderr, "[shn_extend] converged after %d rounds; %llu long walks, %llu memos not final (re-walked at emit)\n", it, last_long, nbad);
+  if (getenv("SHN_DEBUG")) fprintf(stderr, "[shn_extend] converged after %d rounds; %llu long walks\n", it, last_long);
   e->total_steps = steps;
+  e->wave_steps = wsteps;
   TRYE(hipGetLastError());
 #undef TRYE
   *out = e;
@@ -713,6 +697,7 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
 extern "C" uint64_t shn_ext_n_walks(const shn_ext* e) { return e ? e->n_seeds : 0; }
 extern "C" int shn_ext_iterations(const shn_ext* e) { return e ? e->iterations : 0; }
 extern "C" uint64_t shn_ext_total_steps(const shn_ext* e) { return e ? e->total_steps : 0; }
+extern "C" uint64_t shn_ext_wave_steps(const shn_ext* e) { return e ? e->wave_steps : 0; }
 
 extern "C" int shn_ext_stats(shn_ctx* ctx, const shn_ext* e, uint32_t* n_right, uint32_t* n_left, uint64_t* tot_weight) {
   if (!ctx || !e) return shn_fail(SHN_ERR_ARG, "shn_ext_stats: NULL argument");
@@ -732,41 +717,44 @@ extern "C" int shn_ext_emit(shn_ctx* ctx, const shn_ext* e, const uint32_t* rank
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   TimerRegion treg(ctx, T_EXTEND);
-  uint64_t total = offsets[n_sel];
-  uint32_t* d_sel; uint64_t* d_off; uint8_t* d_out;
-  HIP_TRY(hipMalloc(&d_sel, n_sel * 4));
+  const uint64_t total = offsets[n_sel], ns = e->n_seeds;
+  // rank -> index in the selection; expected number of k1-mers of the selected walks
+  std::vector<int32_t> sel_of_rank(ns + 1, -1);
+  for (uint64_t t = 0; t < n_sel; t++) {
+    if (ranks[t] >= ns) return shn_fail(SHN_ERR_ARG, "shn_ext_emit: rank out of range");
+    if (sel_of_rank[ranks[t]] >= 0) return shn_fail(SHN_ERR_ARG, "shn_ext_emit: a walk is selected twice");
+    sel_of_rank[ranks[t]] = (int32_t)t;
+  }
+  unsigned long long expect = 0;
+  for (uint64_t t = 0; t < n_sel; t++) {
+    uint64_t len = offsets[t + 1] - offsets[t];
+    if (len < (uint64_t)e->k) return shn_fail(SHN_ERR_ARG, "shn_ext_emit: offsets do not fit the walk lengths");
+    expect += len - e->k + 1;
+  }
+  int32_t* d_sel; uint64_t* d_off; uint8_t* d_out; unsigned long long* d_cnt;
+  HIP_TRY(hipMalloc(&d_sel, (ns + 1) * 4));
   HIP_TRY(hipMalloc(&d_off, (n_sel + 1) * 8));
   HIP_TRY(hipMalloc(&d_out, total + 1));
-  HIP_TRY(hipMemcpyAsync(d_sel, ranks, n_sel * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMalloc(&d_cnt, 16));
+  HIP_TRY(hipMemcpyAsync(d_sel, sel_of_rank.data(), (ns + 1) * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_off, offsets, (n_sel + 1) * 8, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemsetAsync(e->d_claim2, 0xFF, (2 * e->n + 1) * 8, s));
-  WalkArgs A;
-  memset(&A, 0, sizeof(A));
-  A.order = e->d_order; A.adjR = (const Adj4*)e->d_adjR; A.adjL = (const Adj4*)e->d_adjL; A.weight = e->d_weight;
-  A.claim = e->d_claim2;                      // scratch: own trail of the re-walk
-  A.nr_out = e->d_nr; A.nl_out = e->d_nl; A.totw_out = e->d_totw;
-  unsigned long long* d_flag = nullptr;
-  HIP_TRY(hipMalloc(&d_flag, 8));
-  HIP_TRY(hipMemsetAsync(d_flag, 0, 8, s));
-  A.steps_counter = d_flag;                  // EMIT: counts re-walks that disagree with the recorded path
-  // walks with a stored path are expanded in parallel from the pool; the others are re-walked (they are short)
-  // Default: re-walk every selected walk against the final claims (verified deterministic).  The parallel
-  // expansion from the stored paths is experimental (SHN_EMIT_STORED=1): batched launches showed a 64-entry
-  // stale chunk in a few contigs that is not understood yet.
-  const bool seq_only = getenv("SHN_EMIT_STORED") == nullptr;
-  if (!seq_only)
-    hipLaunchKernelGGL(ext_emit_stored_kernel, dim3((uint32_t)n_sel), dim3(256), 0, s, d_sel, n_sel, e->d_order, e->d_pstored, e->d_pool,
-                       e->d_poff, e->d_nr, e->d_nl, e->table->d_keys, e->k, d_off, d_out);
-  hipLaunchKernelGGL(ext_walk_kernel<true>, dim3((uint32_t)cdiv(n_sel, EBLK)), dim3(EBLK), 0, s, A, n_sel, d_sel,
-                     seq_only ? nullptr : e->d_pstored, e->d_claim, e->table->d_keys, e->k, d_off, d_out);
+  HIP_TRY(hipMemsetAsync(d_cnt, 0, 16, s));
+  HIP_TRY(hipMemsetAsync(d_out, 0, total + 1, s));
+  {
+    TimerRegion tk(ctx, T_EXT_EMIT);
+    hipLaunchKernelGGL(ext_emit_claims_kernel, dim3((uint32_t)cdiv(2 * e->n, 256)), dim3(256), 0, s, e->d_claim, 2 * e->n, d_sel, ns,
+                       e->d_nr, e->d_nl, e->table->d_keys, e->k, d_off, d_out, d_cnt);
+  }
+  unsigned long long cnt[2] = {0, 0};
   HIP_TRY(hipMemcpyAsync(bases_out, d_out, total, hipMemcpyDeviceToHost, s));
-  unsigned long long flag = 0;
-  HIP_TRY(hipMemcpyAsync(&flag, d_flag, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(cnt, d_cnt, 16, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  hipFree(d_sel); hipFree(d_off); hipFree(d_out); hipFree(d_flag);
-  if (flag) return shn_fail(SHN_ERR_INTERNAL, "shn_ext_emit: a re-walked contig disagrees with its recorded path (overlong=" +
-                            std::to_string(flag & 0xFFFFFFFFULL) + ", length mismatches=" + std::to_string(flag >> 32) + ")");
+  hipFree(d_sel); hipFree(d_off); hipFree(d_out); hipFree(d_cnt);
   HIP_TRY(hipGetLastError());
+  // every base of every selected contig must have been written exactly once
+  if (cnt[1] || cnt[0] != expect)
+    return shn_fail(SHN_ERR_INTERNAL, "shn_ext_emit: claims do not match the recorded walks (k1-mers written " + std::to_string(cnt[0]) +
+                    ", expected " + std::to_string(expect) + ", stray claims " + std::to_string(cnt[1]) + ")");
   return SHN_OK;
 }
 

@@ -150,7 +150,8 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
         parts[nm] = merged[i]
         lines += merged[i].splitlines(True)
     return {"partitions": parts, "all_reconstructed": lines, "final": post.finalize(lines, True), "contigs": res.contigs,
-            "n_k1mers": int(gk.numel())}
+            "n_k1mers": int(gk.numel()),
+            "extension": {k: getattr(res, k, None) for k in ("iterations", "n_walks", "total_steps", "wave_steps")}}
 
 
 def _a2a_objects(recv, payload, group):

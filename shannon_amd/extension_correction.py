@@ -41,6 +41,10 @@ class Extension(object):
     def total_steps(self):
         return int(_lib.lib().shn_ext_total_steps(self.h))
 
+    @property
+    def wave_steps(self):
+        return int(_lib.lib().shn_ext_wave_steps(self.h))
+
     def stats(self):
         n = self.n_walks
         nr = np.empty(n, np.uint32)
@@ -159,6 +163,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     res.iterations = ext.iterations
     res.n_walks = ext.n_walks
     res.total_steps = ext.total_steps
+    res.wave_steps = ext.wave_steps
     res.contigs = contigs[1:]
     # allowed k1-mers with their integer weights (:366-369, :404-408): GPU table lookup
     allowed = {}

@@ -1,0 +1,9 @@
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/r1f; mkdir -p $O
+python bench.py --steps 5 --warmup 1 > $O/bench_final.json 2> $O/bench_final.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 > $O/kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 > $O/pf.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 > $O/pw.log 2>&1
+find $O -name "*.csv" | head -20
+# drop the bulky traces, keep stats + counters
+find $O -name "*kernel_trace.csv" -size +30M -delete
+tail -c 400 $O/bench_final.json
