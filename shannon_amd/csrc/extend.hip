@@ -32,7 +32,8 @@
 #define UNCLAIMED 0xFFFFFFFFu
 #define UNCLAIMED64 0xFFFFFFFFFFFFFFFFULL
 #define LONG_WALK 96          // walks at least this long (previous iteration) get a wavefront + path memo
-#define POOL_SLACK 256
+#define MEMO_MIN 64           // walks at least this long get a memo slot
+#define PROMOTE_STEPS 160     // a thread walker that gets this far hands over to a wavefront
 typedef unsigned long long u64;
 #define CLAIM(rank, pos) (((u64)(rank) << 32) | (u64)(uint32_t)(pos))
 #define RANK(c) ((uint32_t)((c) >> 32))
@@ -141,13 +142,17 @@ struct Adj4 { int32_t v[4]; };
 struct WalkArgs {
   const uint32_t* order; const Adj4* adjR; const Adj4* adjL; const uint32_t* weight;
   u64* claim;            // live claims: clean walks' + this round's (dirty walks released theirs before the round)
-  const u64* claim_old;  // snapshot taken before the round (memo positions of the walk's own old path)
+  const u64* claim_old;  // snapshot taken before the round
   uint32_t* nr_out; uint32_t* nl_out; uint64_t* totw_out;
-  const uint32_t* pool_prev; const uint64_t* poff_prev; const uint8_t* pstored_prev;
-  uint32_t* pool_cur; const uint64_t* poff_cur; const uint32_t* pcap_cur; uint8_t* pstored_cur;
-  const uint8_t* is_long; const uint8_t* dirty;
+  // memo: the path of the walk's last live run, rebuilt from the claims after every round it ran alive
+  // (ext_memo_plan_kernel + the scatter in ext_mark_kernel).  Hints only -- every use is validated.
+  const uint32_t* pool; const uint64_t* moff; const uint32_t* mR; const uint32_t* mL; const uint8_t* mvalid;
+  const u64* hint;       // per k1-mer: (walk, step) under which it was last written into a memo
   unsigned long long* steps_counter;
   unsigned long long* wave_steps_counter;
+  unsigned long long* dbg;     // [0] wave steps confirmed from an own memo [1] from a foreign memo
+  // a thread walker that turns out long hands its walk over to a wavefront (same round): where it stands
+  uint32_t* promo_list; unsigned long long* promo_count; uint32_t* res_cur; uint32_t* res_info;   // info = dir << 31 | steps so far
 };
 
 // Claim `node` as step `pos` of walk r: atomic min on rank:pos, fire-and-forget (a returning atomic would put
@@ -158,30 +163,28 @@ __device__ __forceinline__ void claim_node(const WalkArgs& A, uint32_t node, uin
 
 // One greedy decision (extension_correction.py:223-237): among the candidates that exist and are not
 // traversed pick the heaviest, ties in BASES order A,G,C,T (codes 0,2,1,3; strict >).  Traversed = claimed
-// by a rank <= r (lower ranks, or this walk's own trail of this round), or -- while re-checking a stretch of
-// the walk's old path -- own old position in [lo, hi] (taken from the pre-round snapshot).
-__device__ __forceinline__ int decide(const Adj4& cand, uint32_t r, uint32_t lo, uint32_t hi, const u64* claim,
-                                      const u64* __restrict__ claim_old, const uint32_t* __restrict__ weight, uint32_t dummy,
-                                      uint32_t& bw, u64& chosen_old) {
-  u64 cl[4], co[4];
+// live by a rank <= r (lower ranks of this round, or this walk's own trail), or claimed in the pre-round
+// snapshot by a lower rank.  `extra` returns the hint of the chosen candidate (rejoin test).
+template <bool HINT>
+__device__ __forceinline__ int decide(const Adj4& cand, uint32_t r, const u64* claim, const u64* __restrict__ claim_old,
+                                      const uint32_t* __restrict__ weight, const u64* __restrict__ hint, uint32_t dummy,
+                                      uint32_t& bw, u64& chosen_hint) {
+  u64 cl[4], co[4], ch[4];
   uint32_t w[4];
 #pragma unroll
   for (int b = 0; b < 4; b++) {
     uint32_t idx = cand.v[b] < 0 ? dummy : (uint32_t)cand.v[b];
     cl[b] = __hip_atomic_load(&claim[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     co[b] = claim_old[idx];
+    ch[b] = HINT ? hint[idx] : UNCLAIMED64;
     w[b] = weight[idx >> 1];
   }
   int best = -1;
   bw = 0;
-#define CONSIDER(b)                                                                                  \
-  if (cand.v[b] >= 0) {                                                                                \
-    bool trav = RANK(cl[b]) <= r || RANK(co[b]) < r || (RANK(co[b]) == r && POS(co[b]) >= lo && POS(co[b]) <= hi); \
-    if (!trav && (best < 0 || w[b] > bw)) { best = b; bw = w[b]; }                                     \
-  }
+#define CONSIDER(b) if (cand.v[b] >= 0 && RANK(cl[b]) > r && RANK(co[b]) >= r && (best < 0 || w[b] > bw)) { best = b; bw = w[b]; }
   CONSIDER(0) CONSIDER(2) CONSIDER(1) CONSIDER(3)
 #undef CONSIDER
-  chosen_old = best < 0 ? UNCLAIMED64 : (best == 0 ? co[0] : best == 1 ? co[1] : best == 2 ? co[2] : co[3]);
+  chosen_hint = best < 0 ? UNCLAIMED64 : (best == 0 ? ch[0] : best == 1 ? ch[1] : best == 2 ? ch[2] : ch[3]);
   return best;
 }
 
@@ -198,6 +201,7 @@ __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
     const uint32_t o = A.order[r];
     uint32_t nr = 0, nl = 0;
     uint64_t tot = 0;
+    bool promoted = false;
     // snap: the pre-round snapshot; A.claim: live claims of this round
     bool isvoid = RANK(snap[o]) < r || RANK(__hip_atomic_load(&A.claim[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < r;
     if (!isvoid) {
@@ -231,15 +235,22 @@ __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
           claim_node(A, nbest, r, pos);
           steps++;
           tot += bw;
+          if (pos >= PROMOTE_STEPS) {            // long after all: a wavefront takes over from here (memos, 64 steps a trip)
+            A.res_cur[r] = nbest;
+            A.res_info[r] = ((uint32_t)dir << 31) | pos;
+            A.promo_list[atomicAdd(A.promo_count, 1ULL)] = r;
+            promoted = true;
+            break;
+          }
           cand = best == 0 ? nxt[0] : best == 1 ? nxt[1] : best == 2 ? nxt[2] : nxt[3];
         }
         if (dir == 0) nr = steps; else nl = steps;
+        if (promoted) break;
       }
     }
     A.nr_out[r] = isvoid ? UNCLAIMED : nr;
     A.nl_out[r] = nl;
     A.totw_out[r] = tot;
-    A.pstored_cur[r] = 0;
     mysteps = nr + nl;
   }
   if (mysteps) atomicAdd(&blk_steps, (unsigned long long)mysteps);
@@ -247,163 +258,226 @@ __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
   if (threadIdx.x == 0 && blk_steps) atomicAdd(A.steps_counter, blk_steps);
 }
 
-// ---- long walks: one wavefront per walk.  Clean walks only carry their memo forward; dirty walks re-check
-// the old path 64 steps at a time and walk sequentially from the first changed decision until they rejoin it.
+// ---- long walks: one wavefront per dirty walk.  A memo (the path of some walk's last live run, own or foreign)
+// is re-checked 64 steps per memory round trip; the walk is sequential only from the first changed decision
+// until it meets a memo again -- its own, or the one of the walk whose territory it is taking over.
+// Memo entries are hints: an entry counts only if the k1-mer's hint says it sits at exactly that position of
+// that memo (so the validated entries of a chunk are pairwise distinct), and a changed decision is re-made
+// sequentially against the live claims, never taken from the speculative lane.
 #define NONE32 0xFFFFFFFFu
-__global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uint32_t* __restrict__ long_list) {
-  const uint32_t r = long_list[blockIdx.x];
+struct MemoCursor { const uint32_t* p; uint32_t owner, i, end; };
+
+// `node` was just reached going in direction dir; its hint says it is step POS of walk RANK's memo: follow that
+// memo from the next step if it runs in the same direction
+__device__ __forceinline__ bool memo_follow(const WalkArgs& A, uint64_t n_walks, u64 hh, uint32_t node, int dir, MemoCursor& mc) {
+  const uint32_t q = RANK(hh), pos = POS(hh);
+  if (q >= n_walks || !A.mvalid[q]) return false;
+  const uint32_t qR = A.mR[q], qL = A.mL[q];
+  const uint32_t* fp = A.pool + A.moff[q];
+  uint32_t start, end;
+  if (pos == 0) {
+    if (A.order[q] != node) return false;
+    start = dir == 0 ? 0 : qR; end = dir == 0 ? qR : qR + qL;
+  } else {
+    if (pos > qR + qL || fp[pos - 1] != node) return false;
+    const bool right = pos <= qR;
+    if (right != (dir == 0)) return false;
+    start = pos; end = right ? qR : qR + qL;
+  }
+  if (start >= end) return false;
+  mc.p = fp; mc.owner = q; mc.i = start; mc.end = end;
+  return true;
+}
+
+// RESUME: the walks of the list were started by the thread kernel this round (promo_list); go on where they stand.
+template <bool RESUME>
+__global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uint32_t* __restrict__ long_list, uint64_t n_walks,
+                                                           const unsigned long long* __restrict__ list_count) {
+  const unsigned long long n_list = RESUME ? *list_count : (unsigned long long)gridDim.x;
+  for (unsigned long long li = blockIdx.x; li < n_list; li += gridDim.x) {
+  const uint32_t r = long_list[li];
   const int lane = threadIdx.x;
   const uint32_t o = A.order[r];
-  // memo layout in the pool: [nR, nL, node of step 0, node of step 1, ...]
-  const bool had = A.pstored_prev[r] != 0;
-  const uint32_t* oldhdr = A.pool_prev + (had ? A.poff_prev[r] : 0);
-  const uint32_t* oldp = oldhdr + 2;
-  const uint32_t oldR = had ? oldhdr[0] : 0, oldL = had ? oldhdr[1] : 0;
-  uint32_t* newhdr = A.pool_cur + A.poff_cur[r];
-  uint32_t* newp = newhdr + 2;
-  const bool room = A.pcap_cur[r] >= 2;
-  const uint32_t cap = room ? A.pcap_cur[r] - 2 : 0;
-  const bool run = A.dirty[r] != 0;
-  const bool isvoid = run && (RANK(A.claim_old[o]) < r || RANK(__hip_atomic_load(&A.claim[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < r);
-  if (!run || isvoid) {
-    // clean (results unchanged) or seed currently traversed: keep the memo, the walk may need it later
-    bool keep = false;
-    if (had && room && oldR + oldL <= cap) {
-      for (uint32_t i = lane; i < oldR + oldL; i += 64) newp[i] = oldp[i];
-      if (lane == 0) { newhdr[0] = oldR; newhdr[1] = oldL; }
-      keep = true;
-    }
-    if (lane == 0) {
-      A.pstored_cur[r] = keep ? 1 : 0;
-      if (isvoid) { A.nr_out[r] = UNCLAIMED; A.nl_out[r] = 0; A.totw_out[r] = 0; }
-    }
-    return;
-  }
   uint32_t ns = 0, nr_new = 0;
-  uint64_t tot = A.weight[o >> 1];
-  if (lane == 0) claim_node(A, o, r, 0);
-  for (int dir = 0; dir < 2; dir++) {
+  uint64_t tot;
+  int dir0 = 0;
+  uint32_t cur0 = o;
+  if (RESUME) {
+    const uint32_t info = A.res_info[r];
+    dir0 = (int)(info >> 31);
+    ns = info & 0x7FFFFFFFu;
+    cur0 = A.res_cur[r];
+    nr_new = dir0 ? A.nr_out[r] : 0;
+    tot = A.totw_out[r];
+  } else {
+    const bool isvoid = RANK(A.claim_old[o]) < r || RANK(__hip_atomic_load(&A.claim[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < r;
+    if (isvoid) {                                 // seed currently traversed; the memo stays for later
+      if (lane == 0) { A.nr_out[r] = UNCLAIMED; A.nl_out[r] = 0; A.totw_out[r] = 0; }
+      continue;
+    }
+    tot = A.weight[o >> 1];
+    if (lane == 0) claim_node(A, o, r, 0);
+  }
+  const uint32_t ns_start = ns;
+  for (int dir = dir0; dir < 2; dir++) {
     const Adj4* adj = dir == 0 ? A.adjR : A.adjL;
-    const uint32_t ob = dir == 0 ? 0 : oldR, oe = dir == 0 ? oldR : oldR + oldL;
-    uint32_t cur = o;
-    uint32_t oi = had ? ob : NONE32;          // old step index expected to follow `cur`
+    uint32_t cur = (RESUME && dir == dir0) ? cur0 : o;
+    MemoCursor mc;
+    // own memo first (its steps of this direction), else whatever memo the k1-mer was last written into
+    bool following = (RESUME && dir == dir0) ? memo_follow(A, n_walks, A.hint[cur], cur, dir, mc)
+                                             : (memo_follow(A, n_walks, CLAIM(r, 0), o, dir, mc) || memo_follow(A, n_walks, A.hint[o], o, dir, mc));
+    uint32_t cool = 0;                        // sequential steps to take before trusting a memo again
+    Adj4 cand = {{-1, -1, -1, -1}};           // row of `cur` while walking sequentially
+    bool have_cand = false;
     while (true) {
-      int32_t taken = -1;                     // node taken by a sequential / deviating step this round
-      uint32_t taken_w = 0;
-      u64 taken_co = UNCLAIMED64;             // its snapshot claim (rejoin test)
-      if (oi != NONE32) {
-        const uint32_t nchunk = min(64u, oe - oi);          // real old steps covered by this round
-        const uint32_t s = oi + lane;
-        const bool is_term = (uint32_t)lane == nchunk && nchunk < 64u;   // one past the old end: must decide "stop"
+      if (following) {
+        const uint32_t nchunk = min(64u, mc.end - mc.i);    // memo steps covered by this trip
+        const uint32_t s = mc.i + lane;
+        const bool is_term = (uint32_t)lane == nchunk && nchunk < 64u;   // one past the memo's end: would decide "stop"
         const bool checked = (uint32_t)lane < nchunk || is_term;
-        int32_t chosen = -1;
-        uint32_t bw = 0;
-        u64 cco = UNCLAIMED64;
+        bool ok = false;
         if (checked) {
-          uint32_t before = lane == 0 ? cur : oldp[s - 1];
-          Adj4 cd = adj[before];
-          int b = decide(cd, r, oi + 1, s, A.claim, A.claim_old, A.weight, o, bw, cco);
-          chosen = b < 0 ? -1 : cd.v[b];
+          const uint32_t before = lane == 0 ? cur : mc.p[s - 1];
+          const uint32_t expect = is_term ? NONE32 : mc.p[s];
+          // memo position of entry s is s+1 (pos 0 = seed); lane-1 vouches for `before`
+          bool valid = before != NONE32 && (is_term || (expect != NONE32 && A.hint[expect] == CLAIM(mc.owner, s + 1)));
+          if (valid) {
+            Adj4 cd = adj[before];
+            uint32_t bw; u64 hh;
+            int b = decide<false>(cd, r, A.claim, A.claim_old, A.weight, A.hint, o, bw, hh);
+            uint32_t chosen = b < 0 ? NONE32 : (uint32_t)cd.v[b];
+            ok = chosen == expect;
+          }
         }
-        const int32_t expect = (checked && !is_term) ? (int32_t)oldp[s] : -1;
-        const u64 bad = __ballot(checked && chosen != expect);
+        const u64 bad = __ballot(checked && !ok);
         const uint32_t m = bad ? (uint32_t)(__ffsll((long long)bad) - 1) : 64u;
-        const uint32_t conf = min(m, nchunk);               // confirmed old steps: lanes [0, conf)
+        const uint32_t conf = min(m, nchunk);               // confirmed memo steps: lanes [0, conf)
         uint64_t myw = 0;
         if ((uint32_t)lane < conf) {
-          uint32_t node = oldp[s];
-          uint32_t pos = ns + lane + 1;
-          claim_node(A, node, r, pos);
-          if (ns + lane < cap) newp[ns + lane] = node;
+          uint32_t node = mc.p[s];
+          claim_node(A, node, r, ns + lane + 1);
           myw = A.weight[node >> 1];
         }
         for (int off = 32; off > 0; off >>= 1) myw += __shfl_xor(myw, off, 64);
         tot += myw;
-        if (conf > 0) cur = oldp[oi + conf - 1];
+        if (conf > 0) cur = mc.p[mc.i + conf - 1];
+        if (A.dbg && lane == 0 && conf) atomicAdd(&A.dbg[mc.owner == r ? 0 : 1], (unsigned long long)conf);
         ns += conf;
-        oi += conf;
+        mc.i += conf;
         if (m == 64u) {
-          if (nchunk < 64u) break;            // terminal lane agreed: the old path is still complete
+          if (nchunk < 64u) break;            // the terminal lane agreed: the walk ends where the memo ends
           continue;
         }
-        taken = __shfl(chosen, (int)m, 64);
-        taken_w = __shfl(bw, (int)m, 64);
-        taken_co = __shfl(cco, (int)m, 64);
-        if (taken < 0) break;                 // the walk now stops here
-      } else {
-        // (prefetching the candidates' rows as the thread kernel does measured slower here: 64 lanes x 16 loads)
-        Adj4 cand = adj[cur];
-        uint32_t bw2 = 0;
-        u64 cco2 = UNCLAIMED64;
-        int b2 = decide(cand, r, 1, 0, A.claim, A.claim_old, A.weight, o, bw2, cco2);
-        if (b2 < 0) break;
-        taken = cand.v[b2];
-        taken_w = bw2;
-        taken_co = cco2;
+        following = false;                    // decision m changed (or its entry is not trustworthy): go on sequentially
+        have_cand = false;
+        if (conf == 0) cool = 2;
+        continue;
       }
-      // take `taken` as the next step, then look for a rejoin with the old path
-      {
-        uint32_t pos = ns + 1;
-        if (lane == 0) {
-          claim_node(A, (uint32_t)taken, r, pos);
-          if (ns < cap) newp[ns] = (uint32_t)taken;
-        }
-        tot += taken_w;
-        ns++;
-        cur = (uint32_t)taken;
-        oi = NONE32;
-        if (had && RANK(taken_co) == r && POS(taken_co) >= 1) {
-          uint32_t p = POS(taken_co) - 1;
-          if (p >= ob && p < oe && oldp[p] == (uint32_t)taken) oi = p + 1;
-        }
+      // sequential step from `cur`: lanes 0..3 each fetch one candidate (claims, weight, hint and its own row, one
+      // memory round trip), the decision is made by everybody from the shuffled weights
+      if (!have_cand) cand = adj[cur];
+      const int myc = lane == 0 ? cand.v[0] : lane == 1 ? cand.v[1] : lane == 2 ? cand.v[2] : lane == 3 ? cand.v[3] : -1;
+      u64 hmy = UNCLAIMED64;
+      uint32_t wmy = 0;
+      Adj4 row = {{-1, -1, -1, -1}};
+      bool avail = false;
+      if (myc >= 0) {
+        u64 cl = __hip_atomic_load(&A.claim[myc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u64 co = A.claim_old[myc];
+        hmy = A.hint[myc];
+        wmy = A.weight[(uint32_t)myc >> 1];
+        row = adj[myc];
+        avail = RANK(cl) > r && RANK(co) >= r;
       }
+      const uint32_t am = (uint32_t)(__ballot(avail) & 0xFull);
+      if (!am) break;
+      const uint32_t w0 = __shfl(wmy, 0, 64), w1 = __shfl(wmy, 1, 64), w2 = __shfl(wmy, 2, 64), w3 = __shfl(wmy, 3, 64);
+      int best = -1;
+      uint32_t bw = 0;
+#define CONSIDER(b, wb) if ((am >> b) & 1u) { if (best < 0 || wb > bw) { best = b; bw = wb; } }
+      CONSIDER(0, w0) CONSIDER(2, w2) CONSIDER(1, w1) CONSIDER(3, w3)
+#undef CONSIDER
+      const uint32_t taken = (uint32_t)__shfl(myc, best, 64);
+      const u64 hh = ((u64)(uint32_t)__shfl((int)(hmy >> 32), best, 64) << 32) | (u64)(uint32_t)__shfl((int)(uint32_t)hmy, best, 64);
+      cand.v[0] = __shfl(row.v[0], best, 64); cand.v[1] = __shfl(row.v[1], best, 64);
+      cand.v[2] = __shfl(row.v[2], best, 64); cand.v[3] = __shfl(row.v[3], best, 64);
+      have_cand = true;
+      if (lane == 0) claim_node(A, taken, r, ns + 1);
+      tot += bw;
+      ns++;
+      cur = taken;
+      if (cool) cool--;
+      else following = memo_follow(A, n_walks, hh, taken, dir, mc);
     }
     if (dir == 0) nr_new = ns;
   }
-  const bool keep = room && ns <= cap;
   if (lane == 0) {
-    if (keep) { newhdr[0] = nr_new; newhdr[1] = ns - nr_new; }
     A.nr_out[r] = nr_new;
     A.nl_out[r] = ns - nr_new;
     A.totw_out[r] = tot;
-    A.pstored_cur[r] = keep ? 1 : 0;
-    if (ns) { atomicAdd(A.steps_counter, (unsigned long long)ns); atomicAdd(A.wave_steps_counter, (unsigned long long)ns); }
+    const uint32_t mine = ns - ns_start;
+    if (mine) { atomicAdd(A.steps_counter, (unsigned long long)mine); atomicAdd(A.wave_steps_counter, (unsigned long long)mine); }
+  }
   }
 }
 
-// classify the walks for the next round and lay out the path pool: long walks (memo or length) go to the
-// wavefront kernel (dirty or not -- clean ones only copy their memo); dirty short walks go to the thread kernel
+// classify the dirty walks of the open block: long ones (memo or recorded length) go to the wavefront kernel,
+// the others to the thread kernel.  counters: [0] long [1] unused [2] short [3] dirty walks
 __global__ void ext_plan_kernel(const uint32_t* __restrict__ nr, const uint32_t* __restrict__ nl, uint64_t ns, uint32_t frozen,
-                                const uint32_t* __restrict__ pool_prev, const uint64_t* __restrict__ poff_prev,
-                                const uint8_t* __restrict__ pstored_prev, const uint8_t* __restrict__ dirty,
-                                uint8_t* __restrict__ is_long, uint32_t* __restrict__ long_list, uint32_t* __restrict__ short_list,
-                                uint64_t* __restrict__ poff, uint32_t* __restrict__ pcap, unsigned long long* __restrict__ counters,
-                                uint64_t pool_cap) {
+                                const uint8_t* __restrict__ mvalid, const uint32_t* __restrict__ mR, const uint32_t* __restrict__ mL,
+                                const uint8_t* __restrict__ dirty, uint32_t* __restrict__ long_list, uint32_t* __restrict__ short_list,
+                                unsigned long long* __restrict__ counters) {
   // ns here = current rank limit (walks >= limit have not started yet); walks < frozen are final and never run
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + frozen;
   const bool isd = r < ns && dirty[r];
   unsigned long long dm = __ballot(isd);
   if (dm && (threadIdx.x & 63) == (uint32_t)(__ffsll((long long)dm) - 1)) atomicAdd(&counters[3], (unsigned long long)__popcll(dm));
-  if (r >= ns) return;
-  uint32_t a = nr[r];
-  uint32_t len = a == UNCLAIMED ? 0 : a + nl[r];
-  bool memo = pstored_prev[r] != 0;
-  if (memo) { const uint32_t* h = pool_prev + poff_prev[r]; len = max(len, h[0] + h[1]); }
-  uint8_t lg = 0;
-  if (memo || len >= LONG_WALK) {
-    uint64_t cap = (uint64_t)len + POOL_SLACK + 2;
-    unsigned long long off = atomicAdd(&counters[1], (unsigned long long)cap);
-    bool fits = off + cap <= pool_cap;
-    unsigned long long idx = atomicAdd(&counters[0], 1ULL);
-    long_list[idx] = (uint32_t)r;
-    poff[r] = fits ? off : 0;
-    pcap[r] = fits ? (uint32_t)cap : 0;
-    lg = 1;
-  } else if (dirty[r]) {
-    unsigned long long idx = atomicAdd(&counters[2], 1ULL);
-    short_list[idx] = (uint32_t)r;
+  bool lg = false;
+  if (isd) {
+    uint32_t a = nr[r];
+    uint32_t len = a == UNCLAIMED ? 0 : a + nl[r];
+    if (mvalid[r]) len = max(len, mR[r] + mL[r]);
+    lg = len >= LONG_WALK;
   }
-  is_long[r] = lg;
+  // one atomic per wavefront and list
+  const int lane = threadIdx.x & 63;
+  const unsigned long long below = (1ULL << lane) - 1ULL;
+  const unsigned long long lm = __ballot(isd && lg), sm = __ballot(isd && !lg);
+  unsigned long long lbase = 0, sbase = 0;
+  if (lane == 0) {
+    if (lm) lbase = atomicAdd(&counters[0], (unsigned long long)__popcll(lm));
+    if (sm) sbase = atomicAdd(&counters[2], (unsigned long long)__popcll(sm));
+  }
+  lbase = __shfl((long long)lbase, 0, 64);
+  sbase = __shfl((long long)sbase, 0, 64);
+  if (isd && lg) long_list[lbase + __popcll(lm & below)] = (uint32_t)r;
+  if (isd && !lg) short_list[sbase + __popcll(sm & below)] = (uint32_t)r;
+}
+
+// after the walkers: give every walk that ran alive and is long enough a memo slot for its new path (filled from
+// the claims by ext_mark_kernel).  A slot is reused while the path fits; slots are never handed out twice, so a
+// fresh slot still holds the NONE32 fill of the pool.
+__global__ void ext_memo_plan_kernel(const uint8_t* __restrict__ ran, const uint32_t* __restrict__ nr, const uint32_t* __restrict__ nl,
+                                     uint32_t frozen, uint32_t limit, uint64_t* __restrict__ moff, uint32_t* __restrict__ mcap,
+                                     uint32_t* __restrict__ mR, uint32_t* __restrict__ mL, uint8_t* __restrict__ mvalid,
+                                     uint8_t* __restrict__ fill, unsigned long long* __restrict__ cursor, uint64_t pool_cap) {
+  uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + frozen;
+  if (r >= limit) return;
+  uint8_t f = 0;
+  if (ran[r] && nr[r] != UNCLAIMED) {
+    uint32_t len = nr[r] + nl[r];
+    if (len >= MEMO_MIN) {
+      bool have = mvalid[r] && len <= mcap[r];
+      if (!have) {
+        uint64_t cap = (uint64_t)len + len / 4 + 64;
+        unsigned long long off = atomicAdd(cursor, (unsigned long long)cap);
+        if (off + cap <= pool_cap) { moff[r] = off; mcap[r] = (uint32_t)cap; have = true; }
+        else mvalid[r] = 0;
+      }
+      if (have) { mR[r] = nr[r]; mL[r] = nl[r]; mvalid[r] = 1; f = 1; }
+    }
+  }
+  fill[r] = f;
 }
 
 // drop the claims of the walks that are about to re-run
@@ -414,26 +488,38 @@ __global__ void ext_release_kernel(u64* __restrict__ claim, uint64_t n2, const u
   if (rk != UNCLAIMED && rk < ns && dirty[rk]) claim[o] = UNCLAIMED64;
 }
 
-// after a round: every k1-mer whose owner changed dirties the walks that looked at it
+// after a round: every k1-mer whose owner changed dirties the walks that looked at it; the k1-mers of the walks
+// that got a memo slot are written into it (memo + hint)
 __global__ void ext_mark_kernel(const u64* __restrict__ claim, const u64* __restrict__ claim_old, uint64_t n2,
                                 const Adj4* __restrict__ adjR, const Adj4* __restrict__ adjL, const uint32_t* __restrict__ seed_rank,
                                 uint8_t* __restrict__ dirty, const uint8_t* __restrict__ ran, uint32_t* __restrict__ owned,
-                                unsigned long long* __restrict__ n_changed, uint32_t frozen, uint32_t limit) {
+                                unsigned long long* __restrict__ n_changed, uint32_t frozen, uint32_t limit,
+                                const uint8_t* __restrict__ fill, const uint64_t* __restrict__ moff, uint32_t* __restrict__ pool,
+                                u64* __restrict__ hint) {
   uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t a = UNCLAIMED, b = UNCLAIMED;
-  if (y < n2) { a = RANK(claim_old[y]); b = RANK(claim[y]); }
+  u64 cy = UNCLAIMED64;
+  if (y < n2) { a = RANK(claim_old[y]); cy = claim[y]; b = RANK(cy); }
   // one atomic per wavefront for the change counter
   unsigned long long chm = __ballot(a != b);
   if (chm && (threadIdx.x & 63) == (uint32_t)(__ffsll((long long)chm) - 1)) atomicAdd(n_changed, (unsigned long long)__popcll(chm));
-  if (b != UNCLAIMED && ran[b]) atomicAdd(&owned[b], 1u);      // for ext_verify_kernel
+  if (y >= n2) return;
+  if (b != UNCLAIMED && ran[b]) {
+    atomicAdd(&owned[b], 1u);                                   // for ext_verify_kernel
+    if (fill[b]) {
+      uint32_t pos = POS(cy);
+      if (pos >= 1) pool[moff[b] + pos - 1] = (uint32_t)y;
+      hint[y] = cy;
+    }
+  }
   if (a == b) return;
   // Who has to look again?  Walk x treats y as traversed iff its owner's rank is below x, and removing a
   // candidate it did not choose never changes a greedy choice -- so only walks for which y BECAME available
   // (a < x < b) are affected: the walks that stood next to y (owners of its 8 neighbours) and the walk seeded
   // on y (void while y belonged to a lower rank).  The old owner re-runs if it was robbed while it sat out this
-  // round (one that ran this round gave y up knowingly; one that lost it during its run is caught by the verify kernel); the
-  // new owner ran this round.  Walks below `frozen` are final, walks at or above `limit` have not started (they
-  // all run when their phase opens).
+  // round (one that ran this round gave y up knowingly; one that lost it during its run is caught by the verify
+  // kernel); the new owner ran this round.  Walks below `frozen` are final, walks at or above `limit` have not
+  // started (they all run when their phase opens).
 #define MARK(x) if ((x) >= frozen && (x) < limit) dirty[x] = 1
   if (a != UNCLAIMED && !ran[a]) MARK(a);
   if (b < a) return;
@@ -566,30 +652,38 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
   TRYE(hipMalloc(&e->d_nr, (ns + 1) * 4));
   TRYE(hipMalloc(&e->d_nl, (ns + 1) * 4));
   TRYE(hipMalloc(&e->d_totw, (ns + 1) * 8));
-  const uint64_t pool_cap = 6 * n + (1ULL << 20);
+  const uint64_t pool_cap = 24 * n + (1ULL << 20);         // memo slots are never recycled within a call
   TRYE(hipMemcpyAsync(e->d_order, svals, ns * 4, hipMemcpyDeviceToDevice, s));
   TRYE(hipMemsetAsync(e->d_nr, 0xFF, (ns + 1) * 4, s));
   TRYE(hipMemsetAsync(e->d_nl, 0, (ns + 1) * 4, s));
   TRYE(hipMemsetAsync(e->d_totw, 0, (ns + 1) * 8, s));
   TRYE(hipMemsetAsync(e->d_claim, 0xFF, (2 * n + 1) * 8, s));
-  // scratch: claim snapshot, two memo pools + per-walk plan arrays (double-buffered across rounds)
-  void *ppool1, *ppool2, *pplan, *pseed;
-  if ((rc = g_shn_ws[27].get(pool_cap * 4, &ppool2)) || (rc = g_shn_ws[29].get(pool_cap * 4, &ppool1)) ||
-      (rc = g_shn_ws[28].get((ns + 1) * (8 + 8 + 4 + 4 + 4 + 4 + 1 + 1 + 1 + 1 + 1) + 64, &pplan)) ||
+  // scratch: claim snapshot (d_claim2), memo pool + per-k1-mer hints, per-walk plan arrays
+  void *ppool, *phint, *pplan, *pseed;
+  if ((rc = g_shn_ws[27].get(pool_cap * 4, &ppool)) || (rc = g_shn_ws[29].get((2 * n + 2) * 8, &phint)) ||
+      (rc = g_shn_ws[28].get((ns + 1) * (8 + 4 * 9 + 1 + 1 + 1 + 1) + 64, &pplan)) ||
       (rc = g_shn_ws[24].get((2 * n + 2) * 4, &pseed))) { shn_ext_destroy(e); return rc; }
   u64 *claim = e->d_claim, *snap = e->d_claim2;
-  uint32_t* pool_a = (uint32_t*)ppool1; uint32_t* pool_b = (uint32_t*)ppool2;
-  uint64_t* poff_a = (uint64_t*)pplan; uint64_t* poff_b = poff_a + ns + 1;
-  uint32_t* pcap = (uint32_t*)(poff_b + ns + 1);
-  uint32_t* long_list = pcap + ns + 1;
+  uint32_t* pool = (uint32_t*)ppool;
+  u64* hint = (u64*)phint;
+  uint64_t* moff = (uint64_t*)pplan;
+  uint32_t* mcap = (uint32_t*)(moff + ns + 1);
+  uint32_t* mR = mcap + ns + 1;
+  uint32_t* mL = mR + ns + 1;
+  uint32_t* long_list = mL + ns + 1;
   uint32_t* short_list = long_list + ns + 1;
-  uint32_t* owned = short_list + ns + 1;
-  uint8_t* pst_a = (uint8_t*)(owned + ns + 1); uint8_t* pst_b = pst_a + ns + 1;
-  uint8_t* is_long = pst_b + ns + 1;
-  uint8_t* dirty = is_long + ns + 1;
+  uint32_t* promo_list = short_list + ns + 1;
+  uint32_t* res_cur = promo_list + ns + 1;
+  uint32_t* res_info = res_cur + ns + 1;
+  uint32_t* owned = res_info + ns + 1;
+  uint8_t* mvalid = (uint8_t*)(owned + ns + 1);
+  uint8_t* fill = mvalid + ns + 1;
+  uint8_t* dirty = fill + ns + 1;
   uint8_t* ran = dirty + ns + 1;
   uint32_t* seed_rank = (uint32_t*)pseed;
-  TRYE(hipMemsetAsync(pst_a, 0, 2 * (ns + 1), s));
+  TRYE(hipMemsetAsync(mvalid, 0, 2 * (ns + 1), s));
+  TRYE(hipMemsetAsync(pool, 0xFF, pool_cap * 4, s));            // NONE32: "no entry"
+  TRYE(hipMemsetAsync(hint, 0xFF, (2 * n + 1) * 8, s));
   TRYE(hipMemsetAsync(seed_rank, 0xFF, (2 * n + 1) * 4, s));
   if (ns) hipLaunchKernelGGL(ext_seed_rank_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, e->d_order, (uint64_t)ns, seed_rank);
   hipStream_t aux = nullptr;
@@ -599,7 +693,7 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
   TRYE(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
   int it = 0;
   bool converged = ns == 0;
-  unsigned long long last_long = 0;
+
   const uint32_t g2n = (uint32_t)cdiv(2 * n, 256);
   // Rank phases: a walk depends only on lower ranks, so the fixpoint is reached block by block -- first the
   // heaviest seeds (where the long, mutually dependent walks live), then geometrically larger blocks that see
@@ -610,13 +704,14 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
   uint32_t frozen = 0, limit = (uint32_t)std::min<unsigned long long>(ns, lim0);
   TRYE(hipMemsetAsync(dirty, 0, ns + 1, s));
   TRYE(hipMemsetAsync(dirty, 1, limit, s));
+  TRYE(hipMemsetAsync(d_cnt + 10, 0, 8, s));                     // memo pool cursor
   while (!converged && it < max_iterations) {
-    // classify the walks of the open block; a block without dirty walks is consistent = final
+    // classify the dirty walks of the open block; a block without dirty walks is consistent = final
     TRYE(hipMemsetAsync(d_cnt + 2, 0, 32, s));
     if (limit > frozen)
       hipLaunchKernelGGL(ext_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 256)), dim3(256), 0, s, e->d_nr, e->d_nl, (uint64_t)limit, frozen,
-                         pool_a, poff_a, pst_a, dirty, is_long, long_list, short_list, poff_b, pcap, d_cnt + 2, pool_cap);
-    unsigned long long plan[4] = {0, 0, 0, 0};      // long walks (dirty or memo carriers), pool words, short dirty walks, dirty walks
+                         mvalid, mR, mL, dirty, long_list, short_list, d_cnt + 2);
+    unsigned long long plan[4] = {0, 0, 0, 0};      // long dirty walks, -, short dirty walks, dirty walks
     TRYE(hipMemcpyAsync(plan, d_cnt + 2, 32, hipMemcpyDeviceToHost, s));
     TRYE(hipStreamSynchronize(s));
     if (plan[3] == 0) {
@@ -631,49 +726,58 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
     TRYE(hipMemcpyAsync(snap, claim, (2 * n + 1) * 8, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(ext_release_kernel, dim3(g2n), dim3(256), 0, s, claim, 2 * n, dirty, (uint64_t)ns);
     TRYE(hipMemsetAsync(d_cnt + 6, 0, 16, s));
+    TRYE(hipMemsetAsync(d_cnt + 13, 0, 8, s));
     WalkArgs A;
     A.order = e->d_order; A.adjR = (const Adj4*)e->d_adjR; A.adjL = (const Adj4*)e->d_adjL; A.weight = e->d_weight;
     A.claim = claim; A.claim_old = snap;
     A.nr_out = e->d_nr; A.nl_out = e->d_nl; A.totw_out = e->d_totw;
-    A.pool_prev = pool_a; A.poff_prev = poff_a; A.pstored_prev = pst_a;
-    A.pool_cur = pool_b; A.poff_cur = poff_b; A.pcap_cur = pcap; A.pstored_cur = pst_b;
-    A.is_long = is_long; A.dirty = dirty; A.steps_counter = d_cnt + 1; A.wave_steps_counter = d_cnt + 9;
+    A.pool = pool; A.moff = moff; A.mR = mR; A.mL = mL; A.mvalid = mvalid; A.hint = hint;
+    A.promo_list = promo_list; A.promo_count = d_cnt + 13; A.res_cur = res_cur; A.res_info = res_info;
+    A.steps_counter = d_cnt + 1; A.wave_steps_counter = d_cnt + 9; A.dbg = getenv("SHN_DEBUG") ? d_cnt + 11 : nullptr;
     // long (wave per walk) and short (thread per walk) kernels are independent: overlap them on two streams
     if (plan[0]) {
       TRYE(hipEventRecord(ev_fork, s));
       TRYE(hipStreamWaitEvent(aux, ev_fork, 0));
       { TimerRegion tk(ctx, T_EXT_WALK_WAVE, aux);
-        hipLaunchKernelGGL(ext_walk_long_kernel, dim3((uint32_t)plan[0]), dim3(64), 0, aux, A, long_list); }
+        hipLaunchKernelGGL(ext_walk_long_kernel<false>, dim3((uint32_t)plan[0]), dim3(64), 0, aux, A, long_list, (uint64_t)ns, (const unsigned long long*)nullptr); }
       TRYE(hipEventRecord(ev_join, aux));
     }
     if (plan[2]) {
       TimerRegion tk(ctx, T_EXT_WALK_THREAD);
       hipLaunchKernelGGL(ext_walk_kernel, dim3((uint32_t)cdiv(plan[2], EBLK)), dim3(EBLK), 0, s, A, (uint64_t)plan[2], short_list, snap);
     }
+    if (plan[2]) {                              // walks the thread kernel handed over (the count stays on the device)
+      TimerRegion tk(ctx, T_EXT_WALK_WAVE);
+      hipLaunchKernelGGL(ext_walk_long_kernel<true>, dim3((uint32_t)std::min<unsigned long long>(plan[2], 8192ULL)), dim3(64), 0, s, A, promo_list,
+                         (uint64_t)ns, (const unsigned long long*)(d_cnt + 13));
+    }
     if (plan[0]) TRYE(hipStreamWaitEvent(s, ev_join, 0));
-    // who has to run next round?  walks whose view changed (mark) + walks that lost a claim race (verify)
+    // who has to run next round?  walks whose view changed (mark) + walks that lost a claim race (verify);
+    // the walks that ran get their memo rebuilt from the claims
     TRYE(hipMemcpyAsync(ran, dirty, ns + 1, hipMemcpyDeviceToDevice, s));
     TRYE(hipMemsetAsync(dirty, 0, ns + 1, s));
     TRYE(hipMemsetAsync(owned, 0, (ns + 1) * 4, s));
+    hipLaunchKernelGGL(ext_memo_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 256)), dim3(256), 0, s, ran, e->d_nr, e->d_nl, frozen, limit,
+                       moff, mcap, mR, mL, mvalid, fill, d_cnt + 10, pool_cap);
     { TimerRegion tk(ctx, T_EXT_MARK);
       hipLaunchKernelGGL(ext_mark_kernel, dim3(g2n), dim3(256), 0, s, claim, snap, 2 * n, (const Adj4*)e->d_adjR, (const Adj4*)e->d_adjL,
-                         seed_rank, dirty, ran, owned, d_cnt + 6, frozen, limit); }
+                         seed_rank, dirty, ran, owned, d_cnt + 6, frozen, limit, fill, moff, pool, hint); }
     hipLaunchKernelGGL(ext_verify_kernel, dim3((uint32_t)cdiv(limit, 256)), dim3(256), 0, s, ran, owned, e->d_nr, e->d_nl, (uint64_t)limit, dirty);
     if (getenv("SHN_EXT_ALLDIRTY")) { TRYE(hipMemsetAsync(dirty, 0, ns + 1, s)); TRYE(hipMemsetAsync(dirty + frozen, 1, limit - frozen, s)); }
     it++;
-    last_long = plan[0];
+
     if (getenv("SHN_DEBUG")) {
-      unsigned long long chg = 0;
+      unsigned long long chg = 0, cur = 0;
       TRYE(hipMemcpyAsync(&chg, d_cnt + 6, 8, hipMemcpyDeviceToHost, s));
+      TRYE(hipMemcpyAsync(&cur, d_cnt + 10, 8, hipMemcpyDeviceToHost, s));
       TRYE(hipStreamSynchronize(s));
       static double t_prev = 0;
       timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
       double tn = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
-      fprintf(stderr, "[shn_extend] round %d [%u,%u): dirty=%llu long=%llu short_dirty=%llu changed_kmers=%llu  %.2f ms\n", it, frozen, limit,
-              plan[3], plan[0], plan[2], chg, it == 1 ? 0.0 : tn - t_prev);
+      fprintf(stderr, "[shn_extend] round %d [%u,%u): dirty=%llu long=%llu short=%llu changed_kmers=%llu pool=%.1f%%  %.2f ms\n", it, frozen, limit,
+              plan[3], plan[0], plan[2], chg, 100.0 * (double)cur / (double)pool_cap, it == 1 ? 0.0 : tn - t_prev);
       t_prev = tn;
     }
-    std::swap(pool_a, pool_b); std::swap(poff_a, poff_b); std::swap(pst_a, pst_b);
   }
   hipStreamSynchronize(aux);
   hipStreamDestroy(aux);
@@ -685,7 +789,12 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
   TRYE(hipMemcpyAsync(&steps, d_cnt + 1, 8, hipMemcpyDeviceToHost, s));
   TRYE(hipMemcpyAsync(&wsteps, d_cnt + 9, 8, hipMemcpyDeviceToHost, s));
   TRYE(hipStreamSynchronize(s));
-  if (getenv("SHN_DEBUG")) fprintf(stderr, "[shn_extend] converged after %d rounds; %llu long walks\n", it, last_long);
+  if (getenv("SHN_DEBUG")) {
+    unsigned long long dbg[2] = {0, 0};
+    TRYE(hipMemcpy(dbg, d_cnt + 11, 16, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[shn_extend] converged after %d rounds; steps: %llu total, %llu in the wave kernel (%llu from own memos, %llu from foreign memos)\n",
+            it, steps, wsteps, dbg[0], dbg[1]);
+  }
   e->total_steps = steps;
   e->wave_steps = wsteps;
   TRYE(hipGetLastError());
