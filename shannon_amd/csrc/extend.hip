@@ -119,13 +119,20 @@ __global__ void ext_seed_kernel(const uint64_t* __restrict__ tkeys, const uint32
                                 const uint8_t* __restrict__ flags, uint64_t n, int k, int canonical, uint32_t min_weight,
                                 uint64_t* __restrict__ skeys, uint32_t* __restrict__ svals, unsigned long long* __restrict__ counter) {
   uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (o >= 2 * n) return;
+  bool is_seed = false;
   uint64_t i = o >> 1;
-  uint8_t f = flags[i];
-  if (f & 2) return;
-  if ((o & 1) && ((f & 1) || !canonical)) return;
-  if (weight[i] < min_weight) return;
-  unsigned long long p = atomicAdd(counter, 1ULL);
+  if (o < 2 * n) {
+    uint8_t f = flags[i];
+    is_seed = !(f & 2) && !((o & 1) && ((f & 1) || !canonical)) && weight[i] >= min_weight;
+  }
+  // one atomic per wavefront (the order of the seeds does not matter: they are sorted next)
+  const int lane = threadIdx.x & 63;
+  const unsigned long long m = __ballot(is_seed);
+  unsigned long long base = 0;
+  if (lane == 0 && m) base = atomicAdd(counter, (unsigned long long)__popcll(m));
+  base = __shfl((long long)base, 0, 64);
+  if (!is_seed) return;
+  unsigned long long p = base + __popcll(m & ((1ULL << lane) - 1ULL));
   skeys[p] = (o & 1) ? shn_revcomp(tkeys[i], k) : tkeys[i];
   svals[p] = (uint32_t)o;
 }
@@ -416,7 +423,7 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
     A.nl_out[r] = ns - nr_new;
     A.totw_out[r] = tot;
     const uint32_t mine = ns - ns_start;
-    if (mine) { atomicAdd(A.steps_counter, (unsigned long long)mine); atomicAdd(A.wave_steps_counter, (unsigned long long)mine); }
+    if (mine) atomicAdd(&A.wave_steps_counter[blockIdx.x & 63], (unsigned long long)mine);   // 64 slots: no single hot address
   }
   }
 }
@@ -496,47 +503,54 @@ __global__ void ext_mark_kernel(const u64* __restrict__ claim, const u64* __rest
                                 unsigned long long* __restrict__ n_changed, uint32_t frozen, uint32_t limit,
                                 const uint8_t* __restrict__ fill, const uint64_t* __restrict__ moff, uint32_t* __restrict__ pool,
                                 u64* __restrict__ hint) {
-  uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t a = UNCLAIMED, b = UNCLAIMED;
-  u64 cy = UNCLAIMED64;
-  if (y < n2) { a = RANK(claim_old[y]); cy = claim[y]; b = RANK(cy); }
-  // one atomic per wavefront for the change counter
-  unsigned long long chm = __ballot(a != b);
-  if (chm && (threadIdx.x & 63) == (uint32_t)(__ffsll((long long)chm) - 1)) atomicAdd(n_changed, (unsigned long long)__popcll(chm));
-  if (y >= n2) return;
-  if (b != UNCLAIMED && ran[b]) {
-    atomicAdd(&owned[b], 1u);                                   // for ext_verify_kernel
-    if (fill[b]) {
-      uint32_t pos = POS(cy);
-      if (pos >= 1) pool[moff[b] + pos - 1] = (uint32_t)y;
-      hint[y] = cy;
+  // grid-stride: the change counter costs one atomic per block (one per wavefront on a single address was the
+  // most expensive thing in this kernel)
+  uint32_t my_changed = 0;
+  for (uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; y < n2; y += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t a = RANK(claim_old[y]);
+    const u64 cy = claim[y];
+    const uint32_t b = RANK(cy);
+    if (b != UNCLAIMED && ran[b]) {
+      atomicAdd(&owned[b], 1u);                                   // for ext_verify_kernel
+      if (fill[b]) {
+        uint32_t pos = POS(cy);
+        if (pos >= 1) pool[moff[b] + pos - 1] = (uint32_t)y;
+        hint[y] = cy;
+      }
     }
-  }
-  if (a == b) return;
-  // Who has to look again?  Walk x treats y as traversed iff its owner's rank is below x, and removing a
-  // candidate it did not choose never changes a greedy choice -- so only walks for which y BECAME available
-  // (a < x < b) are affected: the walks that stood next to y (owners of its 8 neighbours) and the walk seeded
-  // on y (void while y belonged to a lower rank).  The old owner re-runs if it was robbed while it sat out this
-  // round (one that ran this round gave y up knowingly; one that lost it during its run is caught by the verify
-  // kernel); the new owner ran this round.  Walks below `frozen` are final, walks at or above `limit` have not
-  // started (they all run when their phase opens).
+    if (a == b) continue;
+    my_changed++;
+    // Who has to look again?  Walk x treats y as traversed iff its owner's rank is below x, and removing a
+    // candidate it did not choose never changes a greedy choice -- so only walks for which y BECAME available
+    // (a < x < b) are affected: the walks that stood next to y (owners of its 8 neighbours) and the walk seeded
+    // on y (void while y belonged to a lower rank).  The old owner re-runs if it was robbed while it sat out this
+    // round (one that ran this round gave y up knowingly; one that lost it during its run is caught by the verify
+    // kernel); the new owner ran this round.  Walks below `frozen` are final, walks at or above `limit` have not
+    // started (they all run when their phase opens).
 #define MARK(x) if ((x) >= frozen && (x) < limit) dirty[x] = 1
-  if (a != UNCLAIMED && !ran[a]) MARK(a);
-  if (b < a) return;
+    if (a != UNCLAIMED && !ran[a]) MARK(a);
+    if (b < a) continue;
 #define MARKX(x) if (a < (x) && (x) < b) MARK(x)
-  uint32_t sr = seed_rank[y];
-  MARKX(sr);
-  Adj4 L = adjL[y], R = adjR[y];
+    uint32_t sr = seed_rank[y];
+    MARKX(sr);
+    Adj4 L = adjL[y], R = adjR[y];
 #pragma unroll
-  for (int q = 0; q < 8; q++) {
-    int32_t nb = q < 4 ? L.v[q] : R.v[q - 4];
-    if (nb < 0) continue;
-    uint32_t x = RANK(claim_old[nb]), z = RANK(claim[nb]);
-    MARKX(x);
-    MARKX(z);
-  }
+    for (int q = 0; q < 8; q++) {
+      int32_t nb = q < 4 ? L.v[q] : R.v[q - 4];
+      if (nb < 0) continue;
+      uint32_t x = RANK(claim_old[nb]), z = RANK(claim[nb]);
+      MARKX(x);
+      MARKX(z);
+    }
 #undef MARKX
 #undef MARK
+  }
+  __shared__ unsigned long long blk_changed;
+  if (threadIdx.x == 0) blk_changed = 0;
+  __syncthreads();
+  if (my_changed) atomicAdd(&blk_changed, (unsigned long long)my_changed);
+  __syncthreads();
+  if (threadIdx.x == 0 && blk_changed) atomicAdd(n_changed, blk_changed);
 }
 
 // A walk that ran this round must own exactly the k1-mers on the path it recorded; if a lower rank took one
@@ -562,32 +576,29 @@ __global__ void ext_emit_claims_kernel(const u64* __restrict__ claim, uint64_t n
                                        const uint32_t* __restrict__ nr_a, const uint32_t* __restrict__ nl_a,
                                        const uint64_t* __restrict__ tkeys, int k, const uint64_t* __restrict__ out_off,
                                        uint8_t* __restrict__ out_bases, unsigned long long* __restrict__ counters) {
-  uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  int32_t t = -1;
-  uint32_t r = UNCLAIMED, pos = 0;
-  if (y < n2) {
-    u64 c = claim[y];
-    r = RANK(c); pos = POS(c);
-    if (r != UNCLAIMED && r < ns) t = sel_of_rank[r];
+  uint32_t n_wrote = 0, n_stray = 0;
+  for (uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; y < n2; y += (uint64_t)gridDim.x * blockDim.x) {
+    const u64 c = claim[y];
+    const uint32_t r = RANK(c), pos = POS(c);
+    if (r == UNCLAIMED || r >= ns) continue;
+    const int32_t t = sel_of_rank[r];
+    if (t < 0) continue;
+    const uint32_t nr = nr_a[r], nl = nl_a[r];
+    if (nr == UNCLAIMED || pos > nr + nl) { n_stray++; continue; }    // claim of a void walk / beyond its recorded path
+    uint8_t* dst = out_bases + out_off[t];
+    const uint64_t str = oriented_string(tkeys, (uint32_t)y, k);
+    if (pos == 0) for (int j = 0; j < k; j++) dst[nl + j] = "ACGT"[(str >> (2 * (k - 1 - j))) & 3];
+    else if (pos <= nr) dst[nl + k + (pos - 1)] = "ACGT"[str & 3];
+    else dst[nl - 1 - (pos - nr - 1)] = "ACGT"[(str >> (2 * (k - 1))) & 3];
+    n_wrote++;
   }
-  bool wrote = false, stray = false;
-  if (t >= 0) {
-    uint32_t nr = nr_a[r], nl = nl_a[r];
-    if (nr == UNCLAIMED || pos > nr + nl) stray = true;          // claim of a void walk / beyond its recorded path
-    else {
-      uint8_t* dst = out_bases + out_off[t];
-      uint64_t str = oriented_string(tkeys, (uint32_t)y, k);
-      if (pos == 0) for (int j = 0; j < k; j++) dst[nl + j] = "ACGT"[(str >> (2 * (k - 1 - j))) & 3];
-      else if (pos <= nr) dst[nl + k + (pos - 1)] = "ACGT"[str & 3];
-      else dst[nl - 1 - (pos - nr - 1)] = "ACGT"[(str >> (2 * (k - 1))) & 3];
-      wrote = true;
-    }
-  }
-  unsigned long long wm = __ballot(wrote), sm = __ballot(stray);
-  if ((threadIdx.x & 63) == 0) {
-    if (wm) atomicAdd(&counters[0], (unsigned long long)__popcll(wm));
-    if (sm) atomicAdd(&counters[1], (unsigned long long)__popcll(sm));
-  }
+  __shared__ unsigned long long blk[2];
+  if (threadIdx.x < 2) blk[threadIdx.x] = 0;
+  __syncthreads();
+  if (n_wrote) atomicAdd(&blk[0], (unsigned long long)n_wrote);
+  if (n_stray) atomicAdd(&blk[1], (unsigned long long)n_stray);
+  __syncthreads();
+  if (threadIdx.x < 2 && blk[threadIdx.x]) atomicAdd(&counters[threadIdx.x], blk[threadIdx.x]);
 }
 
 extern "C" void shn_ext_destroy(shn_ext* e) {
@@ -630,10 +641,10 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
   int rc;
   if ((rc = g_shn_ws[9].get((2 * n + 2) * 8, &pk)) || (rc = g_shn_ws[10].get((2 * n + 2) * 4, &pv)) ||
       (rc = g_shn_ws[11].get((2 * n + 2) * 8, &pk2)) || (rc = g_shn_ws[12].get((2 * n + 2) * 4, &pv2)) ||
-      (rc = g_shn_ws[13].get(256, &pc))) { shn_ext_destroy(e); return rc; }
+      (rc = g_shn_ws[13].get(2048, &pc))) { shn_ext_destroy(e); return rc; }
   uint64_t* skeys = (uint64_t*)pk; uint32_t* svals = (uint32_t*)pv;
   unsigned long long* d_cnt = (unsigned long long*)pc;      // [0] seeds [1] steps [2..4] plan (long, pool, short) [5] final pool [6] changed
-  TRYE(hipMemsetAsync(d_cnt, 0, 128, s));
+  TRYE(hipMemsetAsync(d_cnt, 0, 2048, s));
   if (n) hipLaunchKernelGGL(ext_seed_kernel, dim3((uint32_t)cdiv(2 * n, 256)), dim3(256), 0, s, t->d_keys, e->d_weight, e->d_flags, n,
                             t->k, t->canonical, min_weight, skeys, svals, d_cnt);
   unsigned long long ns = 0;
@@ -733,7 +744,7 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
     A.nr_out = e->d_nr; A.nl_out = e->d_nl; A.totw_out = e->d_totw;
     A.pool = pool; A.moff = moff; A.mR = mR; A.mL = mL; A.mvalid = mvalid; A.hint = hint;
     A.promo_list = promo_list; A.promo_count = d_cnt + 13; A.res_cur = res_cur; A.res_info = res_info;
-    A.steps_counter = d_cnt + 1; A.wave_steps_counter = d_cnt + 9; A.dbg = getenv("SHN_DEBUG") ? d_cnt + 11 : nullptr;
+    A.steps_counter = d_cnt + 1; A.wave_steps_counter = d_cnt + 64; A.dbg = getenv("SHN_DEBUG") ? d_cnt + 11 : nullptr;
     // long (wave per walk) and short (thread per walk) kernels are independent: overlap them on two streams
     if (plan[0]) {
       TRYE(hipEventRecord(ev_fork, s));
@@ -760,7 +771,7 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
     hipLaunchKernelGGL(ext_memo_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 256)), dim3(256), 0, s, ran, e->d_nr, e->d_nl, frozen, limit,
                        moff, mcap, mR, mL, mvalid, fill, d_cnt + 10, pool_cap);
     { TimerRegion tk(ctx, T_EXT_MARK);
-      hipLaunchKernelGGL(ext_mark_kernel, dim3(g2n), dim3(256), 0, s, claim, snap, 2 * n, (const Adj4*)e->d_adjR, (const Adj4*)e->d_adjL,
+      hipLaunchKernelGGL(ext_mark_kernel, dim3(std::min<uint32_t>(g2n, 4096u)), dim3(256), 0, s, claim, snap, 2 * n, (const Adj4*)e->d_adjR, (const Adj4*)e->d_adjL,
                          seed_rank, dirty, ran, owned, d_cnt + 6, frozen, limit, fill, moff, pool, hint); }
     hipLaunchKernelGGL(ext_verify_kernel, dim3((uint32_t)cdiv(limit, 256)), dim3(256), 0, s, ran, owned, e->d_nr, e->d_nl, (uint64_t)limit, dirty);
     if (getenv("SHN_EXT_ALLDIRTY")) { TRYE(hipMemsetAsync(dirty, 0, ns + 1, s)); TRYE(hipMemsetAsync(dirty + frozen, 1, limit - frozen, s)); }
@@ -785,10 +796,12 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
   hipEventDestroy(ev_join);
   e->iterations = it;
   if (!converged) { shn_ext_destroy(e); return shn_fail(SHN_ERR_INTERNAL, "shn_extend: walk fixpoint did not converge"); }
-  unsigned long long steps = 0, wsteps = 0;
-  TRYE(hipMemcpyAsync(&steps, d_cnt + 1, 8, hipMemcpyDeviceToHost, s));
-  TRYE(hipMemcpyAsync(&wsteps, d_cnt + 9, 8, hipMemcpyDeviceToHost, s));
+  unsigned long long steps = 0, wsteps = 0, wslots[64];
+  TRYE(hipMemcpyAsync(&steps, d_cnt + 1, 8, hipMemcpyDeviceToHost, s));          // thread-kernel steps
+  TRYE(hipMemcpyAsync(wslots, d_cnt + 64, 64 * 8, hipMemcpyDeviceToHost, s));    // wavefront-kernel steps
   TRYE(hipStreamSynchronize(s));
+  for (int i = 0; i < 64; i++) wsteps += wslots[i];
+  steps += wsteps;
   if (getenv("SHN_DEBUG")) {
     unsigned long long dbg[2] = {0, 0};
     TRYE(hipMemcpy(dbg, d_cnt + 11, 16, hipMemcpyDeviceToHost));
@@ -851,7 +864,7 @@ extern "C" int shn_ext_emit(shn_ctx* ctx, const shn_ext* e, const uint32_t* rank
   HIP_TRY(hipMemsetAsync(d_out, 0, total + 1, s));
   {
     TimerRegion tk(ctx, T_EXT_EMIT);
-    hipLaunchKernelGGL(ext_emit_claims_kernel, dim3((uint32_t)cdiv(2 * e->n, 256)), dim3(256), 0, s, e->d_claim, 2 * e->n, d_sel, ns,
+    hipLaunchKernelGGL(ext_emit_claims_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(2 * e->n, 256), 4096)), dim3(256), 0, s, e->d_claim, 2 * e->n, d_sel, ns,
                        e->d_nr, e->d_nl, e->table->d_keys, e->k, d_off, d_out, d_cnt);
   }
   unsigned long long cnt[2] = {0, 0};
