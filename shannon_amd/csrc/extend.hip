@@ -31,9 +31,9 @@
 #define EBLK 256
 #define UNCLAIMED 0xFFFFFFFFu
 #define UNCLAIMED64 0xFFFFFFFFFFFFFFFFULL
-#define LONG_WALK 96          // walks at least this long (previous iteration) get a wavefront + path memo
-#define MEMO_MIN 64           // walks at least this long get a memo slot
-#define PROMOTE_STEPS 160     // a thread walker that gets this far hands over to a wavefront
+#define LONG_WALK 32          // dirty walks at least this long (last run or memo) get a wavefront
+#define MEMO_MIN 16           // walks at least this long get a memo slot
+#define PROMOTE_STEPS 64      // a thread walker that gets this far hands over to a wavefront
 typedef unsigned long long u64;
 #define CLAIM(rank, pos) (((u64)(rank) << 32) | (u64)(uint32_t)(pos))
 #define RANK(c) ((uint32_t)((c) >> 32))
@@ -160,6 +160,7 @@ struct WalkArgs {
   unsigned long long* dbg;     // [0] wave steps confirmed from an own memo [1] from a foreign memo
   // a thread walker that turns out long hands its walk over to a wavefront (same round): where it stands
   uint32_t* promo_list; unsigned long long* promo_count; uint32_t* res_cur; uint32_t* res_info;   // info = dir << 31 | steps so far
+  uint32_t promote_steps;
 };
 
 // Claim `node` as step `pos` of walk r: atomic min on rank:pos, fire-and-forget (a returning atomic would put
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
           claim_node(A, nbest, r, pos);
           steps++;
           tot += bw;
-          if (pos >= PROMOTE_STEPS) {            // long after all: a wavefront takes over from here (memos, 64 steps a trip)
+          if (pos >= A.promote_steps) {            // long after all: a wavefront takes over from here (memos, 64 steps a trip)
             A.res_cur[r] = nbest;
             A.res_info[r] = ((uint32_t)dir << 31) | pos;
             A.promo_list[atomicAdd(A.promo_count, 1ULL)] = r;
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
 __global__ void ext_plan_kernel(const uint32_t* __restrict__ nr, const uint32_t* __restrict__ nl, uint64_t ns, uint32_t frozen,
                                 const uint8_t* __restrict__ mvalid, const uint32_t* __restrict__ mR, const uint32_t* __restrict__ mL,
                                 const uint8_t* __restrict__ dirty, uint32_t* __restrict__ long_list, uint32_t* __restrict__ short_list,
-                                unsigned long long* __restrict__ counters) {
+                                unsigned long long* __restrict__ counters, uint32_t long_walk) {
   // ns here = current rank limit (walks >= limit have not started yet); walks < frozen are final and never run
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + frozen;
   const bool isd = r < ns && dirty[r];
@@ -444,7 +445,7 @@ __global__ void ext_plan_kernel(const uint32_t* __restrict__ nr, const uint32_t*
     uint32_t a = nr[r];
     uint32_t len = a == UNCLAIMED ? 0 : a + nl[r];
     if (mvalid[r]) len = max(len, mR[r] + mL[r]);
-    lg = len >= LONG_WALK;
+    lg = len >= long_walk;
   }
   // one atomic per wavefront and list
   const int lane = threadIdx.x & 63;
@@ -467,13 +468,14 @@ __global__ void ext_plan_kernel(const uint32_t* __restrict__ nr, const uint32_t*
 __global__ void ext_memo_plan_kernel(const uint8_t* __restrict__ ran, const uint32_t* __restrict__ nr, const uint32_t* __restrict__ nl,
                                      uint32_t frozen, uint32_t limit, uint64_t* __restrict__ moff, uint32_t* __restrict__ mcap,
                                      uint32_t* __restrict__ mR, uint32_t* __restrict__ mL, uint8_t* __restrict__ mvalid,
-                                     uint8_t* __restrict__ fill, unsigned long long* __restrict__ cursor, uint64_t pool_cap) {
+                                     uint8_t* __restrict__ fill, unsigned long long* __restrict__ cursor, uint64_t pool_cap,
+                                     uint32_t memo_min) {
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + frozen;
   if (r >= limit) return;
   uint8_t f = 0;
   if (ran[r] && nr[r] != UNCLAIMED) {
     uint32_t len = nr[r] + nl[r];
-    if (len >= MEMO_MIN) {
+    if (len >= memo_min) {
       bool have = mvalid[r] && len <= mcap[r];
       if (!have) {
         uint64_t cap = (uint64_t)len + len / 4 + 64;
@@ -716,12 +718,15 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
   TRYE(hipMemsetAsync(dirty, 0, ns + 1, s));
   TRYE(hipMemsetAsync(dirty, 1, limit, s));
   TRYE(hipMemsetAsync(d_cnt + 10, 0, 8, s));                     // memo pool cursor
+  auto tune = [](const char* name, uint32_t dflt) { const char* v = getenv(name); return v ? (uint32_t)strtoul(v, nullptr, 10) : dflt; };
+  const uint32_t long_walk = tune("SHN_EXT_LONG_WALK", LONG_WALK), memo_min = tune("SHN_EXT_MEMO_MIN", MEMO_MIN),
+                 promote_steps = tune("SHN_EXT_PROMOTE", PROMOTE_STEPS);
   while (!converged && it < max_iterations) {
     // classify the dirty walks of the open block; a block without dirty walks is consistent = final
     TRYE(hipMemsetAsync(d_cnt + 2, 0, 32, s));
     if (limit > frozen)
       hipLaunchKernelGGL(ext_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 256)), dim3(256), 0, s, e->d_nr, e->d_nl, (uint64_t)limit, frozen,
-                         mvalid, mR, mL, dirty, long_list, short_list, d_cnt + 2);
+                         mvalid, mR, mL, dirty, long_list, short_list, d_cnt + 2, long_walk);
     unsigned long long plan[4] = {0, 0, 0, 0};      // long dirty walks, -, short dirty walks, dirty walks
     TRYE(hipMemcpyAsync(plan, d_cnt + 2, 32, hipMemcpyDeviceToHost, s));
     TRYE(hipStreamSynchronize(s));
@@ -743,6 +748,7 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
     A.claim = claim; A.claim_old = snap;
     A.nr_out = e->d_nr; A.nl_out = e->d_nl; A.totw_out = e->d_totw;
     A.pool = pool; A.moff = moff; A.mR = mR; A.mL = mL; A.mvalid = mvalid; A.hint = hint;
+    A.promote_steps = promote_steps;
     A.promo_list = promo_list; A.promo_count = d_cnt + 13; A.res_cur = res_cur; A.res_info = res_info;
     A.steps_counter = d_cnt + 1; A.wave_steps_counter = d_cnt + 64; A.dbg = getenv("SHN_DEBUG") ? d_cnt + 11 : nullptr;
     // long (wave per walk) and short (thread per walk) kernels are independent: overlap them on two streams
@@ -769,7 +775,7 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
     TRYE(hipMemsetAsync(dirty, 0, ns + 1, s));
     TRYE(hipMemsetAsync(owned, 0, (ns + 1) * 4, s));
     hipLaunchKernelGGL(ext_memo_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 256)), dim3(256), 0, s, ran, e->d_nr, e->d_nl, frozen, limit,
-                       moff, mcap, mR, mL, mvalid, fill, d_cnt + 10, pool_cap);
+                       moff, mcap, mR, mL, mvalid, fill, d_cnt + 10, pool_cap, memo_min);
     { TimerRegion tk(ctx, T_EXT_MARK);
       hipLaunchKernelGGL(ext_mark_kernel, dim3(std::min<uint32_t>(g2n, 4096u)), dim3(256), 0, s, claim, snap, 2 * n, (const Adj4*)e->d_adjR, (const Adj4*)e->d_adjL,
                          seed_rank, dirty, ran, owned, d_cnt + 6, frozen, limit, fill, moff, pool, hint); }
