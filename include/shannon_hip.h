@@ -127,6 +127,11 @@ int shn_ext_emit(shn_ctx* ctx, const shn_ext* e, const uint32_t* ranks, uint64_t
                  uint8_t* bases_out);
 /* weight (count in the strand-doubled input, 0 if absent or low-complexity) of k1-mer strings */
 int shn_ext_weights(shn_ctx* ctx, const shn_ext* e, const uint64_t* keys, uint64_t n, uint32_t* weights);
+/* The non-void walks only, in seed order (rank ascending): rank[], n_right[], n_left[], tot_weight[] -- the inputs of the
+ * accept filter of extension_correction.py:361.  Call with rank == NULL to get *n_live, then with arrays of that size
+ * (*n_live = capacity on entry).                                                                                       */
+int shn_ext_live_stats(shn_ctx* ctx, const shn_ext* e, uint64_t* n_live, uint32_t* rank, uint32_t* n_right, uint32_t* n_left,
+                       uint64_t* tot_weight);
 
 /* Host-side (CPU, native) contig bookkeeping of run_correction over the contigs emitted above:
  * duplicate_check (extension_correction.py:247-270, r=15, f=0.5) and the contig graph by shared

@@ -57,6 +57,7 @@ SIGNATURES = {
     "shn_ext_iterations": (C.c_int, [vp]),
     "shn_ext_total_steps": (C.c_uint64, [vp]),
     "shn_ext_wave_steps": (C.c_uint64, [vp]),
+    "shn_ext_live_stats": (C.c_int, [vp, vp, u64p, vp, vp, vp, vp]),
     "shn_ext_stats": (C.c_int, [vp, vp, vp, vp, vp]),
     "shn_ext_emit": (C.c_int, [vp, vp, vp, C.c_uint64, vp, vp]),
     "shn_ext_weights": (C.c_int, [vp, vp, vp, C.c_uint64, vp]),

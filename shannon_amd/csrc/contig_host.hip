@@ -47,7 +47,7 @@ extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint6
     accepted.assign(n_cand, 0);
     std::vector<uint64_t> rk, ck;
     std::vector<int32_t> hits;                              // first value index in rmer (or -1) per window
-    std::unordered_map<int32_t, int32_t> dup;
+    std::vector<int32_t> dupcnt(1, 0), touched;             // per accepted contig: shared r-mers with the candidate
     std::vector<int32_t> cov;
     const int C = k1 - 1;
     int32_t idx = 0;
@@ -56,17 +56,19 @@ extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint6
       uint32_t L = (uint32_t)(off[c + 1] - off[c]);
       window_keys(s, L, r, rk);
       hits.assign(rk.size(), -1);
-      dup.clear();
       int32_t max_till_now = 0, best = -1;
       for (size_t i = 0; i < rk.size(); i++) {
         int32_t v = rmer.find(rk[i]);
         hits[i] = v;
         for (; v >= 0; v = rmer.next[v]) {
           int32_t d = rmer.va[v];
-          int32_t cnt = ++dup[d];
+          if (dupcnt[d] == 0) touched.push_back(d);
+          int32_t cnt = ++dupcnt[d];
           if (cnt >= max_till_now) { max_till_now = cnt; best = d; }      // `>=`: the latest wins (:258-259)
         }
       }
+      for (int32_t d : touched) dupcnt[d] = 0;
+      touched.clear();
       bool suspect = false;
       if (best >= 0) {
         cov.assign(L + 1, 0);
@@ -82,6 +84,7 @@ extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint6
       if (suspect) continue;
       idx++;
       accepted[c] = idx;
+      dupcnt.push_back(0);
       conns.emplace_back();
       window_keys(s, L, C, ck);
       for (uint64_t key : ck) {

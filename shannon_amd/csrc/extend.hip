@@ -838,6 +838,55 @@ extern "C" int shn_ext_stats(shn_ctx* ctx, const shn_ext* e, uint32_t* n_right, 
   return SHN_OK;
 }
 
+// ---- the non-void walks only (a few percent of the seeds), in seed order: what the accept filter needs
+__global__ void ext_live_flag_kernel(const uint32_t* __restrict__ nr, uint64_t ns, uint32_t* __restrict__ flag) {
+  uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < ns) flag[r] = nr[r] != UNCLAIMED ? 1u : 0u;
+}
+__global__ void ext_live_gather_kernel(const uint32_t* __restrict__ nr, const uint32_t* __restrict__ nl, const uint64_t* __restrict__ totw,
+                                       const uint64_t* __restrict__ pos, uint64_t ns, uint32_t* __restrict__ o_rank,
+                                       uint32_t* __restrict__ o_nr, uint32_t* __restrict__ o_nl, uint64_t* __restrict__ o_tw) {
+  uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= ns || nr[r] == UNCLAIMED) return;
+  uint64_t p = pos[r];
+  o_rank[p] = (uint32_t)r; o_nr[p] = nr[r]; o_nl[p] = nl[r]; o_tw[p] = totw[r];
+}
+
+extern "C" int shn_ext_live_stats(shn_ctx* ctx, const shn_ext* e, uint64_t* n_live, uint32_t* rank, uint32_t* n_right, uint32_t* n_left,
+                                  uint64_t* tot_weight) {
+  if (!ctx || !e || !n_live) return shn_fail(SHN_ERR_ARG, "shn_ext_live_stats: NULL argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const uint64_t ns = e->n_seeds;
+  if (!ns) { *n_live = 0; return SHN_OK; }
+  void *pf, *pp, *po;
+  int rc;
+  if ((rc = g_shn_ws[9].get((ns + 1) * 4, &pf)) || (rc = g_shn_ws[11].get((ns + 2) * 8, &pp))) return rc;
+  uint32_t* flag = (uint32_t*)pf;
+  uint64_t* pos = (uint64_t*)pp;
+  hipLaunchKernelGGL(ext_live_flag_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, e->d_nr, ns, flag);
+  uint64_t total = 0;
+  if ((rc = shn_device_scan_u32(ctx, flag, ns, pos, &total))) return rc;
+  if (!rank) { *n_live = total; return SHN_OK; }                  // sizing call
+  if (*n_live < total) return shn_fail(SHN_ERR_ARG, "shn_ext_live_stats: output arrays too small");
+  *n_live = total;
+  if (!total) return SHN_OK;
+  if ((rc = g_shn_ws[10].get(total * 20 + 64, &po))) return rc;
+  uint64_t* o_tw = (uint64_t*)po;
+  uint32_t* o_rank = (uint32_t*)(o_tw + total);
+  uint32_t* o_nr = o_rank + total;
+  uint32_t* o_nl = o_nr + total;
+  hipLaunchKernelGGL(ext_live_gather_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, e->d_nr, e->d_nl, e->d_totw, pos, ns, o_rank, o_nr,
+                     o_nl, o_tw);
+  HIP_TRY(hipMemcpyAsync(rank, o_rank, total * 4, hipMemcpyDeviceToHost, s));
+  if (n_right) HIP_TRY(hipMemcpyAsync(n_right, o_nr, total * 4, hipMemcpyDeviceToHost, s));
+  if (n_left) HIP_TRY(hipMemcpyAsync(n_left, o_nl, total * 4, hipMemcpyDeviceToHost, s));
+  if (tot_weight) HIP_TRY(hipMemcpyAsync(tot_weight, o_tw, total * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipGetLastError());
+  return SHN_OK;
+}
+
 extern "C" int shn_ext_emit(shn_ctx* ctx, const shn_ext* e, const uint32_t* ranks, uint64_t n_sel, const uint64_t* offsets,
                             uint8_t* bases_out) {
   if (!ctx || !e || (n_sel && (!ranks || !offsets || !bases_out))) return shn_fail(SHN_ERR_ARG, "shn_ext_emit: NULL argument");

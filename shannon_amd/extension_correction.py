@@ -53,6 +53,18 @@ class Extension(object):
         _lib.check(_lib.lib().shn_ext_stats(self.ctx.h, self.h, nr.ctypes.data, nl.ctypes.data, tw.ctypes.data))
         return nr, nl, tw
 
+    def live_stats(self):
+        """(rank, nr, nl, tot_weight) of the non-void walks, in seed order."""
+        L = _lib.lib()
+        n = C.c_uint64(0)
+        _lib.check(L.shn_ext_live_stats(self.ctx.h, self.h, C.byref(n), None, None, None, None))
+        m = n.value
+        rank = np.empty(max(m, 1), np.uint32); nr = np.empty(max(m, 1), np.uint32)
+        nl = np.empty(max(m, 1), np.uint32); tw = np.empty(max(m, 1), np.uint64)
+        if m:
+            _lib.check(L.shn_ext_live_stats(self.ctx.h, self.h, C.byref(n), rank.ctypes.data, nr.ctypes.data, nl.ctypes.data, tw.ctypes.data))
+        return rank[:m], nr[:m], nl[:m], tw[:m]
+
     def emit(self, ranks, lengths):
         ranks = np.ascontiguousarray(ranks, dtype=np.uint32)
         offs = np.zeros(len(ranks) + 1, dtype=np.uint64)
@@ -111,21 +123,21 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     k1 = table.k
     ext = Extension(ctx, table, min_weight)
     lap("ext.gpu_walks")
-    nr, nl, tw = ext.stats()
-    live = np.nonzero(nr != UNCLAIMED)[0]                      # non-void walks, in seed order
-    length = k1 + nr[live].astype(np.int64) + nl[live].astype(np.int64)
-    cand = live[length >= min_length]                          # first clause of the accept filter (:361)
-    clen = length[length >= min_length]
+    live, nr, nl, tw = ext.live_stats()                        # non-void walks, in seed order (compacted on the GPU)
+    length = k1 + nr.astype(np.int64) + nl.astype(np.int64)
+    sel = length >= min_length                                 # first clause of the accept filter (:361)
+    cand, clen = live[sel], length[sel]
     thr = 2 * min_length * math.pow(min_weight, 1 / 4.0)
     # second clause of :361, len * avg_wt**0.25 >= 2*min_length*min_weight**0.25: vectorised with a guard band;
     # only candidates within 1e-9 (relative) of the threshold are decided with math.pow like the reference.
-    ckm = nr[cand].astype(np.int64) + nl[cand].astype(np.int64) + 1
-    avg = tw[cand].astype(np.float64) / np.maximum(1, ckm)
+    ckm = nr[sel].astype(np.int64) + nl[sel].astype(np.int64) + 1
+    ctw = tw[sel]
+    avg = ctw.astype(np.float64) / np.maximum(1, ckm)
     lhs = clen.astype(np.float64) * np.power(avg, 0.25)
     sure = lhs >= thr * (1 + 1e-9)
     maybe = (~sure) & (lhs >= thr * (1 - 1e-9))
     for j in np.nonzero(maybe)[0].tolist():
-        a = float(int(tw[cand[j]])) / max(1, int(ckm[j]))
+        a = float(int(ctw[j])) / max(1, int(ckm[j]))
         sure[j] = int(clen[j]) * math.pow(a, 1 / 4.0) >= thr
     keep = list(zip(cand[sure].tolist(), clen[sure].tolist()))
     lap("ext.filter")
