@@ -143,6 +143,7 @@ def main():
 
     for _ in range(args.warmup):
         step().close()
+    stage_t.clear()                      # host stage times: timed steps only
     ctx.timer_reset()
     if dist:
         dist.barrier()
@@ -215,7 +216,7 @@ def main():
                        "stages": ("full path a1-a31, sharded: local count -> all-to-all bucket exchange -> replicated extension -> local routing -> "
                                   "owner-side graph + sparse flow -> gather + merge on rank 0" if use_dist else
                                   "full path a1-a31: count -> extension -> partition/route -> multibridged graph -> sparse flow -> merge"),
-                       "host_stage_seconds_per_step": {k: v / (args.steps + args.warmup) for k, v in stage_t.items()},
+                       "host_stage_seconds_per_step": {k: v / args.steps for k, v in stage_t.items()},
                        "transcripts": (len(last.res["final"]) if use_dist else len(last.R.final)),
                        "extension_iterations": ext["iterations"], "extension_walks": ext["n_walks"],
                        "extension_walk_steps": steps_all,

@@ -42,7 +42,10 @@ extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint6
   static thread_local const uint8_t* cached_ptr = nullptr;
   if (!(conn_nb && cached_n == n_cand && cached_ptr == bases)) {
     uint64_t total_bases = off[n_cand] - off[0];
-    FlatMultiMap rmer(total_bases / 2 + 1024), cmer(total_bases / 2 + 1024);
+    // only accepted contigs enter the indexes (a few percent of the candidate bases): start small so that the
+    // probes of the rejected candidates stay in cache; the maps grow on demand
+    (void)total_bases;
+    FlatMultiMap rmer(1 << 14), cmer(1 << 14);
     conns.clear(); conns.emplace_back();                 // index 0 unused (contigs are 1-based)
     accepted.assign(n_cand, 0);
     std::vector<uint64_t> rk, ck;
