@@ -273,27 +273,34 @@ __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
 // that memo (so the validated entries of a chunk are pairwise distinct), and a changed decision is re-made
 // sequentially against the live claims, never taken from the speculative lane.
 #define NONE32 0xFFFFFFFFu
-struct MemoCursor { const uint32_t* p; uint32_t owner, i, end; };
+struct MemoCursor { const uint32_t* p; uint32_t owner; int32_t i; uint32_t n; int32_t step; bool term; };
+// i = memo index of the next expected step, n = entries left, step = +1 / -1 (a memo can be followed against the
+// direction its walk took), term = the segment ends where that walk ended (then "stop" is the expected decision)
 
-// `node` was just reached going in direction dir; its hint says it is step POS of walk RANK's memo: follow that
-// memo from the next step if it runs in the same direction
+// `node` was just reached going in direction dir; its hint says it is step POS of walk RANK's memo: follow that memo
 __device__ __forceinline__ bool memo_follow(const WalkArgs& A, uint64_t n_walks, u64 hh, uint32_t node, int dir, MemoCursor& mc) {
   const uint32_t q = RANK(hh), pos = POS(hh);
-  if (q >= n_walks || !A.mvalid[q]) return false;
+#define WHY(i) do { if (A.dbg && threadIdx.x == 0) atomicAdd(&A.dbg[i], 1ULL); } while (0)
+  if (q >= n_walks) { WHY(2); return false; }                     // never written into a memo
+  if (!A.mvalid[q]) { WHY(3); return false; }
   const uint32_t qR = A.mR[q], qL = A.mL[q];
   const uint32_t* fp = A.pool + A.moff[q];
-  uint32_t start, end;
-  if (pos == 0) {
-    if (A.order[q] != node) return false;
-    start = dir == 0 ? 0 : qR; end = dir == 0 ? qR : qR + qL;
+  int32_t i, step;
+  uint32_t n;
+  bool term;
+  if (pos == 0) {                                                   // q's seed: its part of my direction, forwards
+    if (A.order[q] != node) { WHY(4); return false; }
+    i = dir == 0 ? 0 : (int32_t)qR; n = dir == 0 ? qR : qL; step = 1; term = true;
   } else {
-    if (pos > qR + qL || fp[pos - 1] != node) return false;
+    if (pos > qR + qL || fp[pos - 1] != node) { WHY(4); return false; }      // the memo has moved on
     const bool right = pos <= qR;
-    if (right != (dir == 0)) return false;
-    start = pos; end = right ? qR : qR + qL;
+    if (right == (dir == 0)) { i = (int32_t)pos; n = (right ? qR : qR + qL) - pos; step = 1; term = true; }
+    else { i = (int32_t)pos - 2; n = right ? pos - 1 : pos - 1 - qR; step = -1; term = false; WHY(5); }   // back along q's path
   }
-  if (start >= end) return false;
-  mc.p = fp; mc.owner = q; mc.i = start; mc.end = end;
+  if (n == 0 && !term) { WHY(6); return false; }
+  WHY(7);
+#undef WHY
+  mc.p = fp; mc.owner = q; mc.i = i; mc.n = n; mc.step = step; mc.term = term;
   return true;
 }
 
@@ -339,16 +346,16 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
     bool have_cand = false;
     while (true) {
       if (following) {
-        const uint32_t nchunk = min(64u, mc.end - mc.i);    // memo steps covered by this trip
-        const uint32_t s = mc.i + lane;
-        const bool is_term = (uint32_t)lane == nchunk && nchunk < 64u;   // one past the memo's end: would decide "stop"
+        const uint32_t nchunk = min(64u, mc.n);             // memo steps covered by this trip
+        const int32_t s = mc.i + lane * mc.step;            // memo index of this lane's step
+        const bool is_term = mc.term && (uint32_t)lane == nchunk && nchunk < 64u;   // one past the walk's end: would decide "stop"
         const bool checked = (uint32_t)lane < nchunk || is_term;
         bool ok = false;
         if (checked) {
-          const uint32_t before = lane == 0 ? cur : mc.p[s - 1];
+          const uint32_t before = lane == 0 ? cur : mc.p[s - mc.step];
           const uint32_t expect = is_term ? NONE32 : mc.p[s];
           // memo position of entry s is s+1 (pos 0 = seed); lane-1 vouches for `before`
-          bool valid = before != NONE32 && (is_term || (expect != NONE32 && A.hint[expect] == CLAIM(mc.owner, s + 1)));
+          bool valid = before != NONE32 && (is_term || (expect != NONE32 && A.hint[expect] == CLAIM(mc.owner, (uint32_t)s + 1)));
           if (valid) {
             Adj4 cd = adj[before];
             uint32_t bw; u64 hh;
@@ -368,16 +375,22 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
         }
         for (int off = 32; off > 0; off >>= 1) myw += __shfl_xor(myw, off, 64);
         tot += myw;
-        if (conf > 0) cur = mc.p[mc.i + conf - 1];
+        if (conf > 0) cur = mc.p[mc.i + ((int32_t)conf - 1) * mc.step];
         if (A.dbg && lane == 0 && conf) atomicAdd(&A.dbg[mc.owner == r ? 0 : 1], (unsigned long long)conf);
         ns += conf;
-        mc.i += conf;
+        mc.i += (int32_t)conf * mc.step;
+        mc.n -= conf;
         if (m == 64u) {
-          if (nchunk < 64u) break;            // the terminal lane agreed: the walk ends where the memo ends
+          if (nchunk < 64u) {
+            if (mc.term) break;               // the terminal lane agreed: the walk ends where the memo's walk ended
+            following = false;                // a segment followed backwards just runs out: go on from its last k1-mer
+            have_cand = false;
+          }
           continue;
         }
         following = false;                    // decision m changed (or its entry is not trustworthy): go on sequentially
         have_cand = false;
+        if (A.dbg && lane == 0) atomicAdd(&A.dbg[conf == 0 ? 8 : 9], 1ULL);
         if (conf == 0) cool = 2;
         continue;
       }
@@ -478,7 +491,7 @@ __global__ void ext_memo_plan_kernel(const uint8_t* __restrict__ ran, const uint
     if (len >= memo_min) {
       bool have = mvalid[r] && len <= mcap[r];
       if (!have) {
-        uint64_t cap = (uint64_t)len + len / 4 + 64;
+        uint64_t cap = (uint64_t)len + len / 4 + 8;
         unsigned long long off = atomicAdd(cursor, (unsigned long long)cap);
         if (off + cap <= pool_cap) { moff[r] = off; mcap[r] = (uint32_t)cap; have = true; }
         else mvalid[r] = 0;
@@ -750,7 +763,7 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
     A.pool = pool; A.moff = moff; A.mR = mR; A.mL = mL; A.mvalid = mvalid; A.hint = hint;
     A.promote_steps = promote_steps;
     A.promo_list = promo_list; A.promo_count = d_cnt + 13; A.res_cur = res_cur; A.res_info = res_info;
-    A.steps_counter = d_cnt + 1; A.wave_steps_counter = d_cnt + 64; A.dbg = getenv("SHN_DEBUG") ? d_cnt + 11 : nullptr;
+    A.steps_counter = d_cnt + 1; A.wave_steps_counter = d_cnt + 64; A.dbg = getenv("SHN_DEBUG") ? d_cnt + 32 : nullptr;
     // long (wave per walk) and short (thread per walk) kernels are independent: overlap them on two streams
     if (plan[0]) {
       TRYE(hipEventRecord(ev_fork, s));
@@ -809,10 +822,12 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
   for (int i = 0; i < 64; i++) wsteps += wslots[i];
   steps += wsteps;
   if (getenv("SHN_DEBUG")) {
-    unsigned long long dbg[2] = {0, 0};
-    TRYE(hipMemcpy(dbg, d_cnt + 11, 16, hipMemcpyDeviceToHost));
+    unsigned long long dbg[10];
+    TRYE(hipMemcpy(dbg, d_cnt + 32, 80, hipMemcpyDeviceToHost));
     fprintf(stderr, "[shn_extend] converged after %d rounds; steps: %llu total, %llu in the wave kernel (%llu from own memos, %llu from foreign memos)\n",
             it, steps, wsteps, dbg[0], dbg[1]);
+    fprintf(stderr, "[shn_extend] memo_follow: no hint %llu, owner without memo %llu, memo moved on %llu, followed backwards %llu, nothing left %llu, followed %llu; "
+            "chunks broken at the first step %llu, later %llu\n", dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7], dbg[8], dbg[9]);
   }
   e->total_steps = steps;
   e->wave_steps = wsteps;
