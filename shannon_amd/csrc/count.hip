@@ -10,6 +10,7 @@
 // Buckets are ranges of the top `bits` bits of murmur-fmix64(key); one bucket fits an LDS hash
 // table of CAP slots, so duplicates (heavy k-mers) cost no capacity, only LDS atomics.
 #include "common.h"
+#include <cmath>
 #include <algorithm>
 #include <cstring>
 
@@ -39,13 +40,20 @@ __device__ __forceinline__ bool gen_key(const ReadsView& v, uint64_t r, uint32_t
   return true;
 }
 
+
 // ---------------------------------------------------------------- level 1 (from packed reads)
+// Besides the level-1 histogram the pass fills a HyperLogLog sketch (2^12 registers) of the keys: the number of
+// DISTINCT k-mers decides how many final buckets are needed (a bucket's LDS table holds distinct keys), and at
+// high coverage that is orders of magnitude below the number of windows.
+#define HLL_BITS 12
 template <bool CANON>
 __global__ __launch_bounds__(BLK) void hist1_kernel(ReadsView v, int k, int bits, int b2, uint64_t n_tiles,
-                                                    unsigned long long* __restrict__ hist1) {
+                                                    unsigned long long* __restrict__ hist1, uint32_t* __restrict__ hll) {
   extern __shared__ uint32_t lh[];
+  __shared__ uint32_t lreg[1 << HLL_BITS];
   const int nb1 = 1 << (bits - b2);
   for (int i = threadIdx.x; i < nb1; i += BLK) lh[i] = 0;
+  for (int i = threadIdx.x; i < (1 << HLL_BITS); i += BLK) lreg[i] = 0;
   __syncthreads();
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     uint64_t r0 = tile * v.rt;
@@ -54,12 +62,22 @@ __global__ __launch_bounds__(BLK) void hist1_kernel(ReadsView v, int k, int bits
     for (uint32_t i = threadIdx.x; i < nid; i += BLK) {
       uint32_t rl = i / v.wmax, pos = i - rl * v.wmax;
       uint64_t key;
-      if (gen_key<CANON>(v, r0 + rl, pos, k, key)) atomicAdd(&lh[bucket_of(key, bits) >> b2], 1u);
+      if (gen_key<CANON>(v, r0 + rl, pos, k, key)) {
+        const uint64_t h = shn_mix64(key);
+        atomicAdd(&lh[bits ? (uint32_t)(h >> (64 - bits)) >> b2 : 0u], 1u);
+        // register = low 12 bits, rank = leading zeros of the next 40 bits + 1 (the bucket uses the top bits)
+        const uint32_t reg = (uint32_t)h & ((1u << HLL_BITS) - 1);
+        const uint64_t rest = (h >> HLL_BITS) & ((1ULL << 40) - 1);
+        const uint32_t rho = rest ? (uint32_t)(__clzll((long long)rest) - 24 + 1) : 41u;
+        if (lreg[reg] < rho) atomicMax(&lreg[reg], rho);
+      }
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < nb1; i += BLK)
     if (lh[i]) atomicAdd(&hist1[i], (unsigned long long)lh[i]);
+  for (int i = threadIdx.x; i < (1 << HLL_BITS); i += BLK)
+    if (lreg[i]) atomicMax(&hll[i], lreg[i]);
 }
 
 template <bool CANON>
@@ -398,30 +416,62 @@ extern "C" int shn_count_k1mers(shn_ctx* ctx, shn_reads* const* sets, int n_sets
     views.push_back(v);
     upper += v.n_reads * (uint64_t)v.wmax;
   }
-  int bits = 0;
-  while (bits < 24 && (upper >> bits) > TARGET_BUCKET) bits++;
+  // bits_n: enough buckets if every window were a distinct key (the histogram pass runs at this resolution);
+  // the final number of buckets follows the HyperLogLog estimate of the distinct keys and only grows on overflow
+  int bits_n = 0;
+  while (bits_n < 24 && (upper >> bits_n) > TARGET_BUCKET) bits_n++;
+  int bits = -1;                                  // chosen after the first histogram pass
+  int bits_hist = -1;                             // resolution of the histogram held in h1_fine
+  std::vector<uint64_t> h1_fine;
   for (int attempt = 0; attempt < 4; attempt++) {
-    int b1 = (bits + 1) / 2, b2 = bits - b1;
-    int nb1 = 1 << b1;
+    int rc;
     void* p;
-    int rc = g_ws[0].get((size_t)nb1 * 16 + 64, &p);
-    if (rc) return rc;
-    unsigned long long* d_hist1 = (unsigned long long*)p;
-    unsigned long long* d_cursor1 = d_hist1 + nb1;
-    HIP_TRY(hipMemsetAsync(d_hist1, 0, (size_t)nb1 * 8, s));
-    {
+    if (bits < 0 || bits > bits_hist) {
+      // (re)compute the level-1 histogram (+ sketch) at resolution max(bits, bits_n)
+      bits_hist = std::max(bits, bits_n);
+      const int hb1 = (bits_hist + 1) / 2, hb2 = bits_hist - hb1;
+      const int hnb1 = 1 << hb1;
+      if ((rc = g_ws[0].get((size_t)hnb1 * 16 + 64 + (4u << HLL_BITS), &p))) return rc;
+      unsigned long long* d_h = (unsigned long long*)p;
+      uint32_t* d_hll = (uint32_t*)(d_h + 2 * (size_t)hnb1 + 8);
+      HIP_TRY(hipMemsetAsync(d_h, 0, (size_t)hnb1 * 8, s));
+      HIP_TRY(hipMemsetAsync(d_hll, 0, 4u << HLL_BITS, s));
       for (auto& v : views) {
         if (!v.wmax || !v.n_reads) continue;
         TimerRegion t(ctx, T_HIST1);                 // one region per launch (bench.py compares with rocprofv3 per kernel)
         uint64_t n_tiles = cdiv(v.n_reads, v.rt);
         uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, 2048);
-        if (both_strands) hipLaunchKernelGGL(hist1_kernel<true>, dim3(grid), dim3(BLK), nb1 * 4, s, v, k1, bits, b2, n_tiles, d_hist1);
-        else hipLaunchKernelGGL(hist1_kernel<false>, dim3(grid), dim3(BLK), nb1 * 4, s, v, k1, bits, b2, n_tiles, d_hist1);
+        if (both_strands) hipLaunchKernelGGL(hist1_kernel<true>, dim3(grid), dim3(BLK), hnb1 * 4, s, v, k1, bits_hist, hb2, n_tiles, d_h, d_hll);
+        else hipLaunchKernelGGL(hist1_kernel<false>, dim3(grid), dim3(BLK), hnb1 * 4, s, v, k1, bits_hist, hb2, n_tiles, d_h, d_hll);
+      }
+      h1_fine.resize(hnb1);
+      std::vector<uint32_t> regs(1u << HLL_BITS);
+      HIP_TRY(hipMemcpyAsync(h1_fine.data(), d_h, (size_t)hnb1 * 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(regs.data(), d_hll, 4u << HLL_BITS, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      if (bits < 0) {
+        const double m = (double)(1u << HLL_BITS);
+        double z = 0;
+        uint32_t zeros = 0;
+        for (uint32_t rg : regs) { z += std::ldexp(1.0, -(int)rg); zeros += rg == 0; }
+        double est = (0.7213 / (1.0 + 1.079 / m)) * m * m / z;
+        if (est < 2.5 * m && zeros) est = m * std::log(m / (double)zeros);       // small-range correction
+        // ~600 distinct keys per bucket (a bucket's LDS table takes CAP_LIMIT = 1900), 25 % head room on the
+        // estimate; never more buckets than the all-distinct rule gives, never fewer than 2^10 when there is work
+        const double want = est * 1.25 / 600.0;
+        bits = 0;
+        while (bits < bits_n && (double)(1ULL << bits) < want) bits++;
+        if (upper > (1ULL << 20)) bits = std::max(bits, std::min(bits_n, 10));
       }
     }
-    std::vector<uint64_t> h1(nb1), off1(nb1 + 1);
-    HIP_TRY(hipMemcpyAsync(h1.data(), d_hist1, (size_t)nb1 * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    const int b1 = (bits + 1) / 2, b2 = bits - b1;
+    const int nb1 = 1 << b1;
+    // level-1 digits are prefixes of the finer ones: fold the fine histogram
+    const int hb1 = (bits_hist + 1) / 2;
+    std::vector<uint64_t> h1(nb1, 0), off1(nb1 + 1);
+    for (size_t i = 0; i < h1_fine.size(); i++) h1[i >> (hb1 - b1)] += h1_fine[i];
+    if ((rc = g_ws[0].get((size_t)(1 << hb1) * 16 + 64 + (4u << HLL_BITS), &p))) return rc;
+    unsigned long long* d_cursor1 = (unsigned long long*)p + (size_t)(1 << hb1);
     uint64_t N = 0;
     for (int i = 0; i < nb1; i++) { off1[i] = N; N += h1[i]; }
     off1[nb1] = N;

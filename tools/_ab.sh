@@ -1,9 +1,13 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r1f
-for cfg in "32 16 64" "32 4 64" "16 2 32" "32 16 64" "32 4 64" "16 2 32"; do
-  set -- $cfg
-  SHN_EXT_LONG_WALK=$1 SHN_EXT_MEMO_MIN=$2 SHN_EXT_PROMOTE=$3 timeout 120 python bench.py --no-cpu-baseline --steps 4 --warmup 1 2>/dev/null | python -c "
+python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+for v in 1 2; do
+  timeout 120 python bench.py --no-cpu-baseline --steps 4 --warmup 1 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 k = d['kernel_ms_per_step']
-print('$cfg', round(d['ms_per_step'],1), d['config']['extension_iterations'], d['config']['transcripts'], 'ext', round(k['extend'],1), 'thread', round(k['extend.walk_thread'],1), 'wave', round(k['extend.walk_wave'],1), 'mark', round(k['extend.mark'],1), 'walk', round(k['extend.walk'],1))"
+print(round(d['ms_per_step'],1), d['config']['extension_iterations'], d['config']['transcripts'], {x: round(k[x], 2) for x in k if x.startswith('count') or x in ('extend', 'extend.prepare', 'route')}, d['config']['host_stage_seconds_per_step'])"
 done
+python bench.py --no-cpu-baseline --reads 2000000 --genes 300 --steps 2 --warmup 1 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('300 genes', round(d['ms_per_step'],1), d['config']['transcripts'], d['config']['host_stage_seconds_per_step'])"
