@@ -56,9 +56,9 @@ struct StringInterner {
   const char* data(int32_t id) const { return arena.data() + off[id]; }
   size_t len(int32_t id) const { return off[id + 1] - off[id]; }
   // returns id; *is_new tells whether it was inserted now
-  int32_t intern(const char* p, size_t n, bool* is_new) {
+  int32_t intern(const char* p, size_t n, bool* is_new) { return intern_hashed(p, n, hash(p, n), is_new); }
+  int32_t intern_hashed(const char* p, size_t n, uint64_t h, bool* is_new) {   // h = hash(p, n), computed elsewhere
     if ((hashes.size() + 1) * 10 > (mask + 1) * 6) grow();
-    uint64_t h = hash(p, n);
     size_t s = h & mask;
     while (table[s] >= 0) {
       int32_t id = table[s];

@@ -6,6 +6,7 @@
 // which stays as the readable specification and is cross-checked against this in the tests.
 #include "common.h"
 #include "flatmap.h"
+#include <thread>
 #include <string>
 #include <vector>
 #include <unordered_map>
@@ -157,9 +158,9 @@ struct Graph {
     }
     for (int n : order) { double s = 0; for (int e : oute[n]) s += ew[e]; prev[n] = s; }
   }
-  int add_read(const std::string& b) {
+  int add_read(const char* b, size_t n, uint64_t h) {
     bool is_new = false;
-    int r = rindex.intern(b.data(), b.size(), &is_new);
+    int r = rindex.intern_hashed(b, n, h, &is_new);
     if (!is_new) { rcc[r] += 1.0; return r; }
     rcc.push_back(1.0); rmate.push_back(-1); rmp.push_back(0); rnodes.emplace_back(); rhas.push_back(0);
     return r;
@@ -685,8 +686,7 @@ extern "C" void shn_graph_destroy(shn_graph* g) { delete g; }
 // r_off[n_reads+1]; paired: second mate file r2/r2_off with the same count.  Read.L = length of the first read.
 // enc: SHN_ENC_ASCII or SHN_ENC_CODES (0..3); rc1/rc2 (optional, one byte per read): 1 = take the reverse
 // complement of that read (the strand-doubled view of the packed input, shannon.py:396-424)
-static void decode_read(std::string& s, const uint8_t* p, uint64_t n, int enc, bool rc) {
-  s.resize(n);
+static void decode_read(char* s, const uint8_t* p, uint64_t n, int enc, bool rc) {
   if (enc == SHN_ENC_CODES) {
     if (!rc) for (uint64_t i = 0; i < n; i++) s[i] = p[i] < 4 ? "ACGT"[p[i]] : 'N';
     else for (uint64_t i = 0; i < n; i++) { uint8_t c = p[n - 1 - i]; s[i] = c < 4 ? "TGCA"[c] : 'N'; }
@@ -723,15 +723,46 @@ extern "C" int shn_mbgraph_run(shn_ctx* ctx, int K, const uint8_t* rows, uint64_
     size_t nr = (size_t)used * (paired ? 2 : 1);
     g.rcc.reserve(nr); g.rmate.reserve(nr); g.rmp.reserve(nr); g.rnodes.reserve(nr); g.rhas.reserve(nr);
   }
-  std::string tmp;
-  for (uint64_t i = 0; i < n_reads; i++) {
-    if (i > cutoff) break;
-    decode_read(tmp, r1 + r1_off[i], r1_off[i + 1] - r1_off[i], enc, rc1 && rc1[i]);
-    int a = g.add_read(tmp);
-    if (paired) {
-      decode_read(tmp, r2 + r2_off[i], r2_off[i + 1] - r2_off[i], enc, rc2 && rc2[i]);
-      int b = g.add_read(tmp);
-      g.rmp[a] = 1; g.rmp[b] = 2; g.rmate[a] = b; g.rmate[b] = a;
+  {
+    // decode + hash on several host threads (independent per read), then intern sequentially in file order
+    const uint64_t used = std::min<uint64_t>(n_reads, cutoff + 1);
+    const int nm = paired ? 2 : 1;
+    std::vector<uint64_t> doff((size_t)used * nm + 1, 0);
+    for (uint64_t i = 0; i < used; i++) {
+      doff[i * nm + 1] = doff[i * nm] + (r1_off[i + 1] - r1_off[i]);
+      if (paired) doff[i * nm + 2] = doff[i * nm + 1] + (r2_off[i + 1] - r2_off[i]);
+    }
+    std::vector<char> text(doff.back() + 1);
+    std::vector<uint64_t> hashes((size_t)used * nm);
+    auto work = [&](uint64_t lo, uint64_t hi) {
+      for (uint64_t i = lo; i < hi; i++) {
+        char* d1 = text.data() + doff[i * nm];
+        const uint64_t n1 = r1_off[i + 1] - r1_off[i];
+        decode_read(d1, r1 + r1_off[i], n1, enc, rc1 && rc1[i]);
+        hashes[i * nm] = StringInterner::hash(d1, n1);
+        if (paired) {
+          char* d2 = text.data() + doff[i * nm + 1];
+          const uint64_t n2 = r2_off[i + 1] - r2_off[i];
+          decode_read(d2, r2 + r2_off[i], n2, enc, rc2 && rc2[i]);
+          hashes[i * nm + 1] = StringInterner::hash(d2, n2);
+        }
+      }
+    };
+    unsigned nt = std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+    if (used < 65536) nt = 1;
+    if (nt <= 1) work(0, used);
+    else {
+      std::vector<std::thread> th;
+      const uint64_t per = (used + nt - 1) / nt;
+      for (unsigned t = 0; t < nt; t++) { uint64_t lo = t * per, hi = std::min<uint64_t>(used, lo + per); if (lo < hi) th.emplace_back(work, lo, hi); }
+      for (auto& t : th) t.join();
+    }
+    for (uint64_t i = 0; i < used; i++) {
+      int a = g.add_read(text.data() + doff[i * nm], doff[i * nm + 1] - doff[i * nm], hashes[i * nm]);
+      if (paired) {
+        int b = g.add_read(text.data() + doff[i * nm + 1], doff[i * nm + 2] - doff[i * nm + 1], hashes[i * nm + 1]);
+        g.rmp[a] = 1; g.rmp[b] = 2; g.rmate[a] = b; g.rmate[b] = a;
+      }
     }
   }
   if (dbg) { fprintf(stderr, "[mbgraph] load reads             %8.3f s  reads=%llu distinct=%zu\n", now() - tt, (unsigned long long)n_reads, g.n_rd()); tt = now(); }

@@ -258,15 +258,21 @@ class ReadStore(object):
             b, o = self.gather(idx, mate)
             return b, o, None, 0
         second = idx >= n
-        i = np.where(second, idx - n, idx)
+        # one gather per source matrix straight into the output (idx is ascending: forward half first)
+        L0 = self.r1.shape[1]
+        rows = np.empty((len(idx), L0), dtype=np.uint8)
+        fwd, bwd = np.nonzero(~second)[0], np.nonzero(second)[0]
+        src2 = self.r1 if self.r2 is None else self.r2
+        if len(fwd):
+            rows[fwd] = self.r1[idx[fwd]]
+        if len(bwd):
+            rows[bwd] = src2[idx[bwd] - n]
         if self.r2 is None:
-            rows, rc = self.r1[i], second                                   # SE: R[d] / RC(R[d-n])
+            rc = second                                                     # SE: R[d] / RC(R[d-n])
         elif mate == 1:
-            rows = np.where(second[:, None], self.r2[i], self.r1[i])        # R1[d] / RC(R2[d-n])
-            rc = second
+            rc = second                                                     # R1[d] / RC(R2[d-n])
         else:
-            rows = np.where(second[:, None], self.r2[i], self.r1[i])        # RC(R1[d]) / R2[d-n]
-            rc = ~second
+            rc = ~second                                                    # RC(R1[d]) / R2[d-n]
         L = rows.shape[1]
         return (np.ascontiguousarray(rows, dtype=np.uint8).reshape(-1), np.arange(len(idx) + 1, dtype=np.uint64) * np.uint64(L),
                 np.ascontiguousarray(rc, dtype=np.uint8), 1)

@@ -80,7 +80,11 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
         idx = part["routes"][name][:cutoff]
         if native_graph:
             b1, o1, rc1, enc = store.gather_codes(idx, 1)
-            b2, o2, rc2, _e = store.gather_codes(idx, 2) if paired else (None, None, None, enc)
+            if paired and rc1 is not None:
+                # the second mates are the same stored rows read on the other strand (shannon.py:413-424)
+                b2, o2, rc2 = b1, o1, (1 - rc1).astype(np.uint8)
+            else:
+                b2, o2, rc2, _e = store.gather_codes(idx, 2) if paired else (None, None, None, enc)
             tick("materialize reads", t0)
             t0 = time.time()
             rb = part["k1mer_bytes"][name]

@@ -1,13 +1,6 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r1f
-python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-for v in 1 2; do
-  timeout 120 python bench.py --no-cpu-baseline --steps 4 --warmup 1 2>/dev/null | python -c "
-import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-k = d['kernel_ms_per_step']
-print(round(d['ms_per_step'],1), d['config']['extension_iterations'], d['config']['transcripts'], {x: round(k[x], 2) for x in k if x.startswith('count') or x in ('extend', 'extend.prepare', 'route')}, d['config']['host_stage_seconds_per_step'])"
-done
-python bench.py --no-cpu-baseline --reads 2000000 --genes 300 --steps 2 --warmup 1 2>/dev/null | python -c "
+python bench.py --no-cpu-baseline --reads 2000000 --genes 300 --steps 2 --warmup 1 2>gpurun_out/r1f/g300.err | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('300 genes', round(d['ms_per_step'],1), d['config']['transcripts'], d['config']['host_stage_seconds_per_step'])"
+grep "mbgraph\] load" gpurun_out/r1f/g300.err | tail -4
