@@ -7,6 +7,7 @@
 #include "common.h"
 #include "flatmap.h"
 #include <thread>
+#include <mutex>
 #include <string>
 #include <vector>
 #include <unordered_map>
@@ -63,6 +64,9 @@ struct RStr {
   const char* begin() const { return p; }
   const char* end() const { return p + n; }
 };
+
+// several partitions may run on host threads at once; their GPU sections take turns
+static std::mutex g_gpu_mutex;
 
 struct Graph {
   shn_ctx* ctx = nullptr;                   // non-NULL: K-mer seed scans run on the GPU (csrc/seeds.hip)
@@ -308,7 +312,7 @@ struct Graph {
     return shn_table_create(ctx, si.keys.data(), vals.data(), si.keys.size(), K, 0, tab) == 0;
   }
   shn_reads* d_reads = nullptr;
-  void release_gpu() { if (d_reads) { shn_reads_destroy(d_reads); d_reads = nullptr; } }
+  void release_gpu() { if (d_reads) { std::lock_guard<std::mutex> lk(g_gpu_mutex); shn_reads_destroy(d_reads); d_reads = nullptr; } }
 
   void find_bridging_reads() {
     std::vector<std::pair<uint64_t, std::pair<int, int>>> items;
@@ -317,19 +321,30 @@ struct Graph {
     SeedIndex si;
     si.build(items);
     shn_table* tab = nullptr;
-    if (gpu_patterns(si, &d_reads, &tab)) {
+    {
+      // GPU section (one partition at a time: the device workspaces and the context's stream are shared)
+      bool gpu_ok = false;
       uint64_t nh = 0;
-      if (shn_seed_scan(ctx, d_reads, K, tab, &nh, nullptr, nullptr, nullptr) == 0 && nh) {
-        std::vector<uint32_t> hr(nh), hs(nh), hi(nh);
-        if (shn_seed_scan(ctx, d_reads, K, tab, &nh, hr.data(), hs.data(), hi.data()) == 0)
-          for (uint64_t h = 0; h < nh; h++)
-            for (uint32_t q = si.goff[hi[h]]; q < si.goff[hi[h] + 1]; q++) {
-              int x = si.occ[q].first;
-              if (read_bridges((int)hr[h], x, (int)hs[h])) nreads[x].push_back(RI((int)hr[h], (int)hs[h]));
-            }
+      std::vector<uint32_t> hr, hs, hi;
+      {
+        std::lock_guard<std::mutex> lk(g_gpu_mutex);
+        if (gpu_patterns(si, &d_reads, &tab)) {
+          gpu_ok = shn_seed_scan(ctx, d_reads, K, tab, &nh, nullptr, nullptr, nullptr) == 0;
+          if (gpu_ok && nh) {
+            hr.resize(nh); hs.resize(nh); hi.resize(nh);
+            gpu_ok = shn_seed_scan(ctx, d_reads, K, tab, &nh, hr.data(), hs.data(), hi.data()) == 0;
+          }
+          shn_table_destroy(tab);
+        }
       }
-      shn_table_destroy(tab);
-      return;
+      if (gpu_ok) {
+        for (uint64_t h = 0; h < nh; h++)
+          for (uint32_t q = si.goff[hi[h]]; q < si.goff[hi[h] + 1]; q++) {
+            int x = si.occ[q].first;
+            if (read_bridges((int)hr[h], x, (int)hs[h])) nreads[x].push_back(RI((int)hr[h], (int)hs[h]));
+          }
+        return;
+      }
     }
     const uint64_t mask = K == 32 ? ~0ULL : ((1ULL << (2 * K)) - 1);
     for (int r = 0; r < (int)n_rd(); r++) {
@@ -543,9 +558,12 @@ struct Graph {
     std::vector<uint32_t> first(n_rd(), 0), last(n_rd(), 0);     // group id + 1, 0 = absent
     shn_table* tab = nullptr;
     bool done = false;
-    if (gpu_patterns(si, &d_reads, &tab)) {
-      done = shn_seed_ends(ctx, d_reads, K, tab, first.data(), last.data()) == 0;
-      shn_table_destroy(tab);
+    {
+      std::lock_guard<std::mutex> lk(g_gpu_mutex);
+      if (gpu_patterns(si, &d_reads, &tab)) {
+        done = shn_seed_ends(ctx, d_reads, K, tab, first.data(), last.data()) == 0;
+        shn_table_destroy(tab);
+      }
     }
     if (!done)
       for (int r = 0; r < (int)n_rd(); r++) {

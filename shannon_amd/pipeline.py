@@ -44,8 +44,9 @@ def assemble(ctx, reads1, reads2=None, K=25, partition_size=500, min_weight=3, m
 
 def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3, min_length=75, overload=2, penalty=5,
                       sample="shannon", seed=0, double_stranded=True, part_vectors=None, timings=None, hits_factory=None,
-                      native_graph=True):
-    """Same as assemble() with the reads already packed in HBM (d1/d2: device.Reads)."""
+                      native_graph=True, graph_threads=8):
+    """Same as assemble() with the reads already packed in HBM (d1/d2: device.Reads).  graph_threads: partitions whose
+    graph stage may run concurrently on host threads."""
     T = timings if timings is not None else {}
     paired = d2 is not None
     if hits_factory is None:
@@ -74,7 +75,10 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
     for i, c in enumerate(res.single_contigs):                      # reconstructed_single_contigs.fasta
         lines += [">Single_%d\n" % i, c + "\n"]
     sf_jobs = []
-    for name in part["new_components"]:
+
+    def one_partition(name):
+        """multibridged graph of one partition (multibridging.main for `name`); returns its record + timings"""
+        tt = {}
         t0 = time.time()
         cutoff = 10 * part["n_kmer_nodes"][name] + 1                 # multibridging.py:26-30, 385-391
         idx = part["routes"][name][:cutoff]
@@ -85,7 +89,7 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
                 b2, o2, rc2 = b1, o1, (1 - rc1).astype(np.uint8)
             else:
                 b2, o2, rc2, _e = store.gather_codes(idx, 2) if paired else (None, None, None, enc)
-            tick("materialize reads", t0)
+            tt["materialize reads"] = time.time() - t0
             t0 = time.time()
             rb = part["k1mer_bytes"][name]
             singles, comps, glog = mbgraph_native.run_partition_arrays(rb if len(rb) else np.zeros(1, np.uint8), len(rb) // (K + 1), K,
@@ -95,14 +99,31 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
             rows = part["k1mers"][name]
             r1 = [store.mate1(int(d)) for d in idx]
             reads = [r1, [store.mate2(int(d)) for d in idx]] if paired else [r1]
-            tick("materialize reads", t0)
+            tt["materialize reads"] = time.time() - t0
             t0 = time.time()
             g, singles, comps = mbgraph.run_partition(rows, reads, K, paired, hits_factory)
             glog, n_rows = g.log, len(rows)
-        tick("graph", t0)
-        R.partitions[name] = {"n_reads_routed": len(part["routes"][name]), "n_k1mers": n_rows, "singles": singles,
-                              "components": comps, "log": glog}
-        sf_jobs.append((name, singles, comps))
+        tt["graph"] = time.time() - t0
+        return {"n_reads_routed": len(part["routes"][name]), "n_k1mers": n_rows, "singles": singles, "components": comps,
+                "log": glog}, tt
+
+    names = list(part["new_components"])
+    t_graph = time.time()
+    if native_graph and len(names) > 1:
+        # partitions are independent (one multibridging process each in the reference, run_MB_SF_fn.py:219-253): the
+        # native stage releases the GIL, its GPU sections take turns
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(names), graph_threads)) as pool:
+            results = list(pool.map(one_partition, names))
+    else:
+        results = [one_partition(nm) for nm in names]
+    wall = time.time() - t_graph
+    busy = sum(sum(tt.values()) for _, tt in results) or 1.0
+    for name, (rec, tt) in zip(names, results):
+        for k_, v in tt.items():                                      # wall time of the stage, split like the thread time
+            T[k_] = T.get(k_, 0.0) + v * wall / busy
+        R.partitions[name] = rec
+        sf_jobs.append((name, rec["singles"], rec["components"]))
     t0 = time.time()
     flat = [(nd["nodes"], nd["edges"], nd["paths"]) for _, _, comps in sf_jobs for nd in comps]
     # component c of partition p uses RNG stream id = its index within the partition (as one
