@@ -136,6 +136,13 @@ __device__ __forceinline__ int64_t shn_table_find(const uint64_t* __restrict__ t
 }
 
 // grow-only device workspace slots shared by the translation units (one process per GPU)
+// Caching device allocator for the per-call objects (tables, extension state, routes): a freed block is kept and
+// handed out again to the next request it fits (hipMalloc/hipFree of hundreds of MB cost milliseconds per step).
+hipError_t shn_dev_malloc_raw(void** p, size_t bytes);
+void shn_dev_free(void* p);
+void shn_dev_trim();                         // give the cached blocks back to the driver
+template <class T> static inline hipError_t shn_dev_malloc(T** p, size_t bytes) { return shn_dev_malloc_raw((void**)p, bytes); }
+
 struct ShnWs {
   void* p = nullptr; size_t cap = 0;
   int get(size_t bytes, void** out);

@@ -1,5 +1,7 @@
 // Context, error handling, event timers and the read uploader / 2-bit packer.
 #include "common.h"
+#include <mutex>
+#include <vector>
 #include <cstring>
 #include <cstdio>
 
@@ -32,6 +34,44 @@ TimerRegion::~TimerRegion() {
   c->pending[slot].push_back({a, b});
 }
 
+namespace {
+struct DevBlock { void* p; size_t cap; bool used; };
+std::vector<DevBlock> g_blocks;
+std::mutex g_blocks_mu;
+}
+hipError_t shn_dev_malloc_raw(void** p, size_t bytes) {
+  if (bytes == 0) bytes = 1;
+  {
+    std::lock_guard<std::mutex> lk(g_blocks_mu);
+    int best = -1;
+    for (size_t i = 0; i < g_blocks.size(); i++)
+      if (!g_blocks[i].used && g_blocks[i].cap >= bytes && g_blocks[i].cap <= 2 * bytes + (1u << 20) &&
+          (best < 0 || g_blocks[i].cap < g_blocks[best].cap)) best = (int)i;
+    if (best >= 0) { g_blocks[best].used = true; *p = g_blocks[best].p; return hipSuccess; }
+  }
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) {                       // make room: drop what the cache holds and try once more
+    shn_dev_trim();
+    e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return e;
+  }
+  std::lock_guard<std::mutex> lk(g_blocks_mu);
+  g_blocks.push_back({*p, bytes, true});
+  return hipSuccess;
+}
+void shn_dev_free(void* p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(g_blocks_mu);
+  for (auto& b : g_blocks) if (b.p == p) { b.used = false; return; }
+  hipFree(p);                                  // not ours (should not happen)
+}
+void shn_dev_trim() {
+  std::lock_guard<std::mutex> lk(g_blocks_mu);
+  std::vector<DevBlock> keep;
+  for (auto& b : g_blocks) { if (b.used) keep.push_back(b); else hipFree(b.p); }
+  g_blocks.swap(keep);
+}
+
 TimingOff::TimingOff(shn_ctx* ctx) : c(ctx), old(ctx->timing) { c->timing = false; }
 TimingOff::~TimingOff() { c->timing = old; }
 
@@ -56,6 +96,7 @@ extern "C" void shn_ctx_destroy(shn_ctx* c) {
   hipStreamSynchronize(c->stream);
   for (int i = 0; i < T_N; i++)
     for (auto& p : c->pending[i]) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+  shn_dev_trim();
   delete c;
 }
 

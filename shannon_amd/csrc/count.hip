@@ -560,9 +560,9 @@ static int build_from_keys(shn_ctx* ctx, uint64_t* keysA, uint64_t* keysB, uint3
     HIP_TRY(hipStreamSynchronize(s));
     *overflowed = ovf != 0;
     t->n = D;
-    HIP_TRY(hipMalloc(&t->d_keys, (D + 1) * 8));
-    HIP_TRY(hipMalloc(&t->d_counts, (D + 1) * 4));
-    HIP_TRY(hipMalloc(&t->d_bucket_off, (nbk + 1) * 8));
+    HIP_TRY(shn_dev_malloc(&t->d_keys, (D + 1) * 8));
+    HIP_TRY(shn_dev_malloc(&t->d_counts, (D + 1) * 4));
+    HIP_TRY(shn_dev_malloc(&t->d_bucket_off, (nbk + 1) * 8));
     HIP_TRY(hipMemcpyAsync(t->d_bucket_off, d_boff, (nbk + 1) * 8, hipMemcpyDeviceToDevice, s));
     if (!ovf && D) {
       uint32_t blocks = (uint32_t)cdiv(nbk * SHN_WAVE, BLK);
@@ -577,9 +577,9 @@ static int build_from_keys(shn_ctx* ctx, uint64_t* keysA, uint64_t* keysB, uint3
 extern "C" void shn_table_destroy(shn_table* t) {
   if (!t) return;
   hipSetDevice(t->device);
-  if (t->d_keys) hipFree(t->d_keys);
-  if (t->d_counts) hipFree(t->d_counts);
-  if (t->d_bucket_off) hipFree(t->d_bucket_off);
+  shn_dev_free(t->d_keys);
+  shn_dev_free(t->d_counts);
+  shn_dev_free(t->d_bucket_off);
   delete t;
 }
 extern "C" uint64_t shn_table_size(const shn_table* t) { return t ? t->n : 0; }

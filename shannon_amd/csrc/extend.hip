@@ -621,7 +621,7 @@ extern "C" void shn_ext_destroy(shn_ext* e) {
   hipSetDevice(e->device);
   void* ptrs[] = {e->d_weight, e->d_flags, e->d_adjR, e->d_adjL, e->d_order, e->d_claim, e->d_claim2, e->d_nr, e->d_nl,
                   e->d_totw, e->d_hash};
-  for (void* p : ptrs) if (p) hipFree(p);
+  for (void* p : ptrs) if (p) shn_dev_free(p);
   delete e;
 }
 
@@ -638,12 +638,12 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
   if (max_iterations <= 0) max_iterations = 100000;
 #define TRYE(x) do { hipError_t _e = (x); if (_e != hipSuccess) { shn_ext_destroy(e); \
       return shn_fail(SHN_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(_e)); } } while (0)
-  TRYE(hipMalloc(&e->d_weight, (n + 1) * 4));
-  TRYE(hipMalloc(&e->d_flags, n + 1));
-  TRYE(hipMalloc(&e->d_adjR, (2 * n + 1) * 16));
-  TRYE(hipMalloc(&e->d_adjL, (2 * n + 1) * 16));
-  TRYE(hipMalloc(&e->d_claim, (2 * n + 1) * 8));
-  TRYE(hipMalloc(&e->d_claim2, (2 * n + 1) * 8));
+  TRYE(shn_dev_malloc(&e->d_weight, (n + 1) * 4));
+  TRYE(shn_dev_malloc(&e->d_flags, n + 1));
+  TRYE(shn_dev_malloc(&e->d_adjR, (2 * n + 1) * 16));
+  TRYE(shn_dev_malloc(&e->d_adjL, (2 * n + 1) * 16));
+  TRYE(shn_dev_malloc(&e->d_claim, (2 * n + 1) * 8));
+  TRYE(shn_dev_malloc(&e->d_claim2, (2 * n + 1) * 8));
   if (n) {
     TimerRegion t1(ctx, T_EXT_PREP);
     hipLaunchKernelGGL(ext_prepare_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, t->d_counts, n, t->k,
@@ -674,10 +674,10 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
       if ((rc = shn_sort_pairs(ctx, skeys, svals, (uint64_t*)pk2, (uint32_t*)pv2, ns, 0, 32))) { shn_ext_destroy(e); return rc; }
     }
   }
-  TRYE(hipMalloc(&e->d_order, (ns + 1) * 4));
-  TRYE(hipMalloc(&e->d_nr, (ns + 1) * 4));
-  TRYE(hipMalloc(&e->d_nl, (ns + 1) * 4));
-  TRYE(hipMalloc(&e->d_totw, (ns + 1) * 8));
+  TRYE(shn_dev_malloc(&e->d_order, (ns + 1) * 4));
+  TRYE(shn_dev_malloc(&e->d_nr, (ns + 1) * 4));
+  TRYE(shn_dev_malloc(&e->d_nl, (ns + 1) * 4));
+  TRYE(shn_dev_malloc(&e->d_totw, (ns + 1) * 8));
   const uint64_t pool_cap = 24 * n + (1ULL << 20);         // memo slots are never recycled within a call
   TRYE(hipMemcpyAsync(e->d_order, svals, ns * 4, hipMemcpyDeviceToDevice, s));
   TRYE(hipMemsetAsync(e->d_nr, 0xFF, (ns + 1) * 4, s));
@@ -924,10 +924,10 @@ extern "C" int shn_ext_emit(shn_ctx* ctx, const shn_ext* e, const uint32_t* rank
     expect += len - e->k + 1;
   }
   int32_t* d_sel; uint64_t* d_off; uint8_t* d_out; unsigned long long* d_cnt;
-  HIP_TRY(hipMalloc(&d_sel, (ns + 1) * 4));
-  HIP_TRY(hipMalloc(&d_off, (n_sel + 1) * 8));
-  HIP_TRY(hipMalloc(&d_out, total + 1));
-  HIP_TRY(hipMalloc(&d_cnt, 16));
+  HIP_TRY(shn_dev_malloc(&d_sel, (ns + 1) * 4));
+  HIP_TRY(shn_dev_malloc(&d_off, (n_sel + 1) * 8));
+  HIP_TRY(shn_dev_malloc(&d_out, total + 1));
+  HIP_TRY(shn_dev_malloc(&d_cnt, 16));
   HIP_TRY(hipMemcpyAsync(d_sel, sel_of_rank.data(), (ns + 1) * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_off, offsets, (n_sel + 1) * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(d_cnt, 0, 16, s));
@@ -941,7 +941,7 @@ extern "C" int shn_ext_emit(shn_ctx* ctx, const shn_ext* e, const uint32_t* rank
   HIP_TRY(hipMemcpyAsync(bases_out, d_out, total, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(cnt, d_cnt, 16, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  hipFree(d_sel); hipFree(d_off); hipFree(d_out); hipFree(d_cnt);
+  shn_dev_free(d_sel); shn_dev_free(d_off); shn_dev_free(d_out); shn_dev_free(d_cnt);
   HIP_TRY(hipGetLastError());
   // every base of every selected contig must have been written exactly once
   if (cnt[1] || cnt[0] != expect)
@@ -968,13 +968,13 @@ extern "C" int shn_ext_weights(shn_ctx* ctx, const shn_ext* e, const uint64_t* k
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   uint64_t* dq; uint32_t* dw;
-  HIP_TRY(hipMalloc(&dq, n * 8));
-  HIP_TRY(hipMalloc(&dw, n * 4));
+  HIP_TRY(shn_dev_malloc(&dq, n * 8));
+  HIP_TRY(shn_dev_malloc(&dw, n * 4));
   HIP_TRY(hipMemcpyAsync(dq, keys, n * 8, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(ext_weight_lookup_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, e->table->d_keys,
                      e->table->d_bucket_off, e->table->bits, e->d_weight, e->d_flags, e->k, e->table->canonical, dq, n, dw);
   HIP_TRY(hipMemcpyAsync(weights, dw, n * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  hipFree(dq); hipFree(dw);
+  shn_dev_free(dq); shn_dev_free(dw);
   return SHN_OK;
 }

@@ -114,8 +114,8 @@ struct shn_routes {
 extern "C" void shn_routes_destroy(shn_routes* r) {
   if (!r) return;
   hipSetDevice(r->device);
-  if (r->d_pid) hipFree(r->d_pid);
-  if (r->d_ridx) hipFree(r->d_ridx);
+  if (r->d_pid) shn_dev_free(r->d_pid);
+  if (r->d_ridx) shn_dev_free(r->d_ridx);
   delete r;
 }
 extern "C" uint64_t shn_routes_size(const shn_routes* r) { return r ? r->n : 0; }
@@ -178,8 +178,8 @@ extern "C" int shn_route_reads(shn_ctx* ctx, const shn_reads* r1, const shn_read
     int pbits = 1;
     while (pbits < 32 && (1ULL << pbits) < (uint64_t)n_mem + 2) pbits++;
     if ((rc = shn_sort_pairs(ctx, (uint64_t*)pk, (uint32_t*)pv, (uint64_t*)pk2, (uint32_t*)pv2, total, 32, 32 + ((pbits + 7) / 8) * 8))) { delete R; return rc; }
-    HIP_TRY(hipMalloc(&R->d_pid, total * 4));
-    HIP_TRY(hipMalloc(&R->d_ridx, total * 4));
+    HIP_TRY(shn_dev_malloc(&R->d_pid, total * 4));
+    HIP_TRY(shn_dev_malloc(&R->d_ridx, total * 4));
     hipLaunchKernelGGL(split_u64_kernel, dim3((uint32_t)cdiv(total, 256)), dim3(256), 0, s, (const uint64_t*)pk, total, R->d_pid, R->d_ridx);
   }
   HIP_TRY(hipGetLastError());
@@ -195,14 +195,14 @@ extern "C" int shn_table_create(shn_ctx* ctx, const uint64_t* keys, const uint32
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   uint64_t* dk = nullptr; uint32_t* dv = nullptr;
-  HIP_TRY(hipMalloc(&dk, (n + 1) * 8));
-  HIP_TRY(hipMalloc(&dv, (n + 1) * 4));
+  HIP_TRY(shn_dev_malloc(&dk, (n + 1) * 8));
+  HIP_TRY(shn_dev_malloc(&dv, (n + 1) * 4));
   if (n) {
     HIP_TRY(hipMemcpyAsync(dk, keys, n * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(dv, values, n * 4, hipMemcpyHostToDevice, s));
   }
   int rc = shn_table_from_pairs(ctx, dk, dv, n, k, canonical, out);
   hipStreamSynchronize(s);
-  hipFree(dk); hipFree(dv);
+  shn_dev_free(dk); shn_dev_free(dv);
   return rc;
 }
