@@ -478,15 +478,20 @@ __global__ void ext_plan_kernel(const uint32_t* __restrict__ nr, const uint32_t*
 // after the walkers: give every walk that ran alive and is long enough a memo slot for its new path (filled from
 // the claims by ext_mark_kernel).  A slot is reused while the path fits; slots are never handed out twice, so a
 // fresh slot still holds the NONE32 fill of the pool.
-__global__ void ext_memo_plan_kernel(const uint8_t* __restrict__ ran, const uint32_t* __restrict__ nr, const uint32_t* __restrict__ nl,
+__global__ void ext_memo_plan_kernel(uint8_t* __restrict__ ran, uint8_t* __restrict__ dirty, uint32_t* __restrict__ owned,
+                                     const uint32_t* __restrict__ nr, const uint32_t* __restrict__ nl,
                                      uint32_t frozen, uint32_t limit, uint64_t* __restrict__ moff, uint32_t* __restrict__ mcap,
                                      uint32_t* __restrict__ mR, uint32_t* __restrict__ mL, uint8_t* __restrict__ mvalid,
                                      uint8_t* __restrict__ fill, unsigned long long* __restrict__ cursor, uint64_t pool_cap,
                                      uint32_t memo_min) {
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + frozen;
   if (r >= limit) return;
+  const uint8_t did_run = dirty[r];              // end-of-round bookkeeping: who ran, clean slate for the marks
+  ran[r] = did_run;
+  dirty[r] = 0;
+  owned[r] = 0;
   uint8_t f = 0;
-  if (ran[r] && nr[r] != UNCLAIMED) {
+  if (did_run && nr[r] != UNCLAIMED) {
     uint32_t len = nr[r] + nl[r];
     if (len >= memo_min) {
       bool have = mvalid[r] && len <= mcap[r];
@@ -502,11 +507,15 @@ __global__ void ext_memo_plan_kernel(const uint8_t* __restrict__ ran, const uint
   fill[r] = f;
 }
 
-// drop the claims of the walks that are about to re-run
-__global__ void ext_release_kernel(u64* __restrict__ claim, uint64_t n2, const uint8_t* __restrict__ dirty, uint64_t ns) {
+// start of a round: snapshot the claims, drop the claims of the walks that are about to re-run, clear the round's counters
+__global__ void ext_round_begin_kernel(u64* __restrict__ claim, u64* __restrict__ snap, uint64_t n2, const uint8_t* __restrict__ dirty,
+                                       uint64_t ns, unsigned long long* __restrict__ d_cnt) {
   uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o == 0) { d_cnt[6] = 0; d_cnt[7] = 0; d_cnt[13] = 0; }      // changed k1-mers, (spare), walks handed over
   if (o >= n2) return;
-  uint32_t rk = RANK(claim[o]);
+  const u64 c = claim[o];
+  snap[o] = c;
+  const uint32_t rk = RANK(c);
   if (rk != UNCLAIMED && rk < ns && dirty[rk]) claim[o] = UNCLAIMED64;
 }
 
@@ -728,8 +737,9 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
   if (getenv("SHN_EXT_LIMIT0")) lim0 = strtoull(getenv("SHN_EXT_LIMIT0"), nullptr, 10);
   if (getenv("SHN_EXT_GROW")) grow = strtoull(getenv("SHN_EXT_GROW"), nullptr, 10);
   uint32_t frozen = 0, limit = (uint32_t)std::min<unsigned long long>(ns, lim0);
-  TRYE(hipMemsetAsync(dirty, 0, ns + 1, s));
+  TRYE(hipMemsetAsync(dirty, 0, 2 * (ns + 1), s));               // dirty + ran
   TRYE(hipMemsetAsync(dirty, 1, limit, s));
+  TRYE(hipMemsetAsync(owned, 0, (ns + 1) * 4, s));
   TRYE(hipMemsetAsync(d_cnt + 10, 0, 8, s));                     // memo pool cursor
   auto tune = [](const char* name, uint32_t dflt) { const char* v = getenv(name); return v ? (uint32_t)strtoul(v, nullptr, 10) : dflt; };
   const uint32_t long_walk = tune("SHN_EXT_LONG_WALK", LONG_WALK), memo_min = tune("SHN_EXT_MEMO_MIN", MEMO_MIN),
@@ -747,15 +757,13 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
       if (limit >= ns) { converged = true; break; }
       frozen = limit;                                // this block is final: open the next one
       limit = (uint32_t)std::min<unsigned long long>(ns, (unsigned long long)limit * grow);
+      TRYE(hipMemsetAsync(ran, 0, frozen, s));       // frozen walks never run again
       TRYE(hipMemsetAsync(dirty + frozen, 1, limit - frozen, s));
       continue;
     }
     TimerRegion t3(ctx, T_EXT_WALK);
     // snapshot, then release the claims of the walks that re-run this round
-    TRYE(hipMemcpyAsync(snap, claim, (2 * n + 1) * 8, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(ext_release_kernel, dim3(g2n), dim3(256), 0, s, claim, 2 * n, dirty, (uint64_t)ns);
-    TRYE(hipMemsetAsync(d_cnt + 6, 0, 16, s));
-    TRYE(hipMemsetAsync(d_cnt + 13, 0, 8, s));
+    hipLaunchKernelGGL(ext_round_begin_kernel, dim3(g2n), dim3(256), 0, s, claim, snap, 2 * n, dirty, (uint64_t)ns, d_cnt);
     WalkArgs A;
     A.order = e->d_order; A.adjR = (const Adj4*)e->d_adjR; A.adjL = (const Adj4*)e->d_adjL; A.weight = e->d_weight;
     A.claim = claim; A.claim_old = snap;
@@ -784,10 +792,7 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
     if (plan[0]) TRYE(hipStreamWaitEvent(s, ev_join, 0));
     // who has to run next round?  walks whose view changed (mark) + walks that lost a claim race (verify);
     // the walks that ran get their memo rebuilt from the claims
-    TRYE(hipMemcpyAsync(ran, dirty, ns + 1, hipMemcpyDeviceToDevice, s));
-    TRYE(hipMemsetAsync(dirty, 0, ns + 1, s));
-    TRYE(hipMemsetAsync(owned, 0, (ns + 1) * 4, s));
-    hipLaunchKernelGGL(ext_memo_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 256)), dim3(256), 0, s, ran, e->d_nr, e->d_nl, frozen, limit,
+    hipLaunchKernelGGL(ext_memo_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 256)), dim3(256), 0, s, ran, dirty, owned, e->d_nr, e->d_nl, frozen, limit,
                        moff, mcap, mR, mL, mvalid, fill, d_cnt + 10, pool_cap, memo_min);
     { TimerRegion tk(ctx, T_EXT_MARK);
       hipLaunchKernelGGL(ext_mark_kernel, dim3(std::min<uint32_t>(g2n, 4096u)), dim3(256), 0, s, claim, snap, 2 * n, (const Adj4*)e->d_adjR, (const Adj4*)e->d_adjL,
