@@ -27,17 +27,30 @@ except (OSError, ValueError, KeyError):
     TRAFFIC = {}
 
 
-def gen_reads(n_pairs, seed, n_genes, device, read_seed=None):
-    """synthetic pairs on the GPU (torch RNG; same model as shannon_amd/synth.py)."""
+def gen_reads(n_pairs, seed, n_genes, device, read_seed=None, families=0):
+    """synthetic pairs on the GPU (torch RNG; same model as shannon_amd/synth.py).
+    families > 0: that many gene families of the configs[1] kind (rich in isoforms) instead of n_genes plain genes."""
     from shannon_amd import synth
     # config 2 ("single component"): one gene family rich enough to give a multi-contig component
-    kw = dict(n_isoforms=(4, 6), n_exons=(8, 12)) if n_genes == 1 else {}
-    iso, _ = synth.make_transcriptome(n_genes, seed, **kw)
-    lens = np.array([len(t) for t in iso], dtype=np.int64)
-    rng = np.random.Generator(np.random.PCG64(seed + 1))
-    expr = rng.lognormal(0.0, 1.5, size=len(iso))
-    wts = expr * (lens - 300 + 1)
-    wts /= wts.sum()
+    if families:
+        # every family is built like the configs[1] one (family 0 IS the configs[1] gene) and gets the same share of reads
+        iso, wl = [], []
+        for f in range(families):
+            fi, _ = synth.make_transcriptome(1, seed + 7919 * f, n_isoforms=(4, 6), n_exons=(8, 12))
+            fl = np.array([len(t) for t in fi], dtype=np.int64)
+            w = np.random.Generator(np.random.PCG64(seed + 1 + 7919 * f)).lognormal(0.0, 1.5, size=len(fi)) * (fl - 300 + 1)
+            iso += fi
+            wl.append(w / w.sum() / families)
+        lens = np.array([len(t) for t in iso], dtype=np.int64)
+        wts = np.concatenate(wl)
+    else:
+        kw = dict(n_isoforms=(4, 6), n_exons=(8, 12)) if n_genes == 1 else {}
+        iso, _ = synth.make_transcriptome(n_genes, seed, **kw)
+        lens = np.array([len(t) for t in iso], dtype=np.int64)
+        rng = np.random.Generator(np.random.PCG64(seed + 1))
+        expr = rng.lognormal(0.0, 1.5, size=len(iso))
+        wts = expr * (lens - 300 + 1)
+        wts /= wts.sum()
     g = torch.Generator(device=device)
     g.manual_seed(seed + 2 if read_seed is None else read_seed)
     cat = torch.as_tensor(np.concatenate(iso), device=device)
@@ -90,6 +103,7 @@ def main():
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU (2 per pair)")
     ap.add_argument("--K", type=int, default=25)
     ap.add_argument("--genes", type=int, default=1)
+    ap.add_argument("--families", type=int, default=0, help="gene families of the configs[1] kind (default: one per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-distributed", action="store_true", help="run the multi-GPU code path even with one rank")
     args = ap.parse_args()
@@ -108,7 +122,11 @@ def main():
     k1 = args.K + 1
     dev = torch.device("cuda", local if world > 1 else 0)
     seed = 20240501
-    r1, r2 = gen_reads(args.reads // 2, seed, args.genes, dev, read_seed=seed + 2 + 1000 * rank)
+    # Weak scaling keeps the per-gene depth of configs[1]: the N-rank job is N gene families x 10M reads, and every
+    # rank holds a 10M-read slice of that mixture (reads are sharded by index, not by gene).  Adding ranks to ONE
+    # family instead would multiply its coverage (616,000x at N=8) -- a different, degenerate assembly problem.
+    families = args.families if args.families else (world if (args.genes == 1 and world > 1) else 0)
+    r1, r2 = gen_reads(args.reads // 2, seed, args.genes, dev, read_seed=seed + 2 + 1000 * rank, families=families)
     ctx = device.Context(local if world > 1 else 0)
     sets = [device.Reads.from_codes(ctx, r1), device.Reads.from_codes(ctx, r2)]
     n_reads = len(sets[0]) + len(sets[1])
@@ -211,7 +229,9 @@ def main():
             "value": n_reads * world * args.steps / dt, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "10M synthetic 2x100bp paired reads per GPU, k=25 (k1=26), single gene family, 0.5% substitution errors (BASELINE configs[1])",
+            "config": {"workload": ("10M synthetic 2x100bp paired reads per GPU, k=25 (k1=26), %s, 0.5%% substitution errors (BASELINE configs[1]%s)"
+                                    % (("%d gene families, one per rank's worth of reads, every rank holding a slice of the mixture" % families, " per family")
+                                       if families > 1 else ("single gene family", ""))),
                        "reads_per_gpu": n_reads, "K": args.K,
                        "stages": ("full path a1-a31, sharded: local count -> all-to-all bucket exchange -> replicated extension -> local routing -> "
                                   "owner-side graph + sparse flow -> gather + merge on rank 0" if use_dist else

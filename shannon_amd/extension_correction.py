@@ -107,6 +107,25 @@ def windows_to_keys(contig, k):
     return key
 
 
+def windows_to_keys_many(contigs, k):
+    """All k-windows of every string, concatenated in order (one vectorised pass over the joined strings), and the
+    number of windows of each string."""
+    lens = np.array([len(c) for c in contigs], dtype=np.int64)
+    nwin = np.maximum(lens - k + 1, 0)
+    total = int(lens.sum())
+    if total < k or not nwin.any():
+        return np.zeros(0, dtype=np.uint64), nwin
+    c = _CODE[np.frombuffer("".join(contigs).encode(), dtype=np.uint8)].astype(np.uint64)
+    n = total - k + 1
+    key = np.zeros(n, dtype=np.uint64)
+    for j in range(k):
+        key = (key << np.uint64(2)) | c[j:j + n]
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]])                  # start of each string in the joined text
+    wbefore = np.concatenate([[0], np.cumsum(nwin)[:-1]])
+    idx = np.repeat(off - wbefore, nwin) + np.arange(int(nwin.sum()), dtype=np.int64)   # windows that stay inside a string
+    return key[idx], nwin
+
+
 def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=500, r=15, f=0.5, want_allowed=True, timings=None):
     """extension_correction.run_correction (extension_correction.py:309-524) on a device k1-mer
     table.  Returns an ExtensionResult: contigs, allowed {k1mer: int}, connections, components,
@@ -180,7 +199,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     # allowed k1-mers with their integer weights (:366-369, :404-408): GPU table lookup
     allowed = {}
     if res.contigs and want_allowed:
-        keys = np.concatenate([windows_to_keys(c, k1) for c in res.contigs])
+        keys, _nw = windows_to_keys_many(res.contigs, k1)
         w = ext.weights(keys).tolist()
         p = 0
         for c in res.contigs:

@@ -9,7 +9,7 @@ import ctypes as C
 import math
 import numpy as np
 from . import _lib, device
-from .extension_correction import windows_to_keys
+from .extension_correction import windows_to_keys, windows_to_keys_many
 
 
 def n_partitions(num_contigs, partition_size):
@@ -153,10 +153,9 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
     files, cw = {}, {}
     allk, allp = [], []
     for name in names:
-        for contig in comps[name]:
-            ks = windows_to_keys(contig, k1)
-            allk.append(ks)
-            allp.append(np.full(len(ks), pid_of[name], dtype=np.uint32))
+        ks, _nw = windows_to_keys_many(comps[name], k1)
+        allk.append(ks)
+        allp.append(np.full(len(ks), pid_of[name], dtype=np.uint32))
     if allk:
         allk = np.concatenate(allk)
         allp = np.concatenate(allp)
@@ -213,8 +212,8 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
                 chunks.append(np.lib.stride_tricks.sliding_window_view(b, k1).reshape(-1))
         rb = np.concatenate(chunks) if chunks else np.zeros(0, np.uint8)
         rows_bytes[name] = np.ascontiguousarray(rb)
-        kk = [windows_to_keys(c, K) for c in comps[name]]
-        n_nodes[name] = int(len(np.unique(np.concatenate(kk)))) if kk else 0
+        kk, _nw = windows_to_keys_many(comps[name], K)
+        n_nodes[name] = int(len(np.unique(kk)))
         if want_rows:
             rows, ws = [], []
             for contig in comps[name]:

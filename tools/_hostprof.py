@@ -4,15 +4,16 @@ import numpy as np, torch
 import bench
 from shannon_amd import device, pipeline, kmers_for_component as kfc
 dev = torch.device("cuda", 0)
-r1, r2 = bench.gen_reads(5_000_000, 20240501, 1, dev)
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+r1, r2 = bench.gen_reads(5_000_000 * F, 20240501, 1, dev, families=F)
 ctx = device.Context(0)
 d1, d2 = device.Reads.from_codes(ctx, r1), device.Reads.from_codes(ctx, r2)
 store = kfc.ReadStore(r1, r2)
-for _ in range(2):
-    pipeline.assemble_resident(ctx, d1, d2, store, K=25, sample="bench", seed=1)
+pipeline.assemble_resident(ctx, d1, d2, store, K=25, sample="bench", seed=1)
 pr = cProfile.Profile()
 pr.enable()
-for _ in range(3):
-    pipeline.assemble_resident(ctx, d1, d2, store, K=25, sample="bench", seed=1)
+T = {}
+pipeline.assemble_resident(ctx, d1, d2, store, K=25, sample="bench", seed=1, timings=T)
 pr.disable()
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
+print(T)
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(22)
