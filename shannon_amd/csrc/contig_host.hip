@@ -10,6 +10,9 @@
 #include <vector>
 #include <algorithm>
 #include <cstring>
+#include <chrono>
+#include <cstdlib>
+#include <cstdio>
 
 static inline int code_of(uint8_t c) {
   switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; }
@@ -26,7 +29,7 @@ static void window_keys(const uint8_t* s, uint32_t L, int k, std::vector<uint64_
   }
 }
 
-struct Conn { std::vector<int32_t> nb; std::vector<int32_t> w; std::unordered_map<int32_t, int32_t> pos; };
+struct Conn { std::vector<int32_t> nb; std::vector<int32_t> w; };      // neighbours in dict insertion order + weights
 
 // contigs: n_cand candidate strings (bases[off[i]..off[i+1])), in seed order.
 // accepted_out[i] = 1-based accepted index or 0.  Connections are returned as CSR in *insertion order*
@@ -51,20 +54,28 @@ extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint6
     std::vector<uint64_t> rk, ck;
     std::vector<int32_t> hits;                              // first value index in rmer (or -1) per window
     std::vector<int32_t> dupcnt(1, 0), touched;             // per accepted contig: shared r-mers with the candidate
+    std::vector<int32_t> connw(1, 0), newnb;                // per accepted contig: shared K-mers with the new contig
     std::vector<int32_t> cov;
     const int C = k1 - 1;
     int32_t idx = 0;
+    const bool dbg = getenv("SHN_DEBUG") != nullptr;
+    double tph[4] = {0, 0, 0, 0};
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    uint64_t n_entries = 0;
     for (uint64_t c = 0; c < n_cand; c++) {
       const uint8_t* s = bases + off[c];
       uint32_t L = (uint32_t)(off[c + 1] - off[c]);
+      double t0 = dbg ? now() : 0;
       window_keys(s, L, r, rk);
       hits.assign(rk.size(), -1);
       int32_t max_till_now = 0, best = -1;
       for (size_t i = 0; i < rk.size(); i++) {
+        if (i + 12 < rk.size()) rmer.prefetch(rk[i + 12]);
         int32_t v = rmer.find(rk[i]);
         hits[i] = v;
-        for (; v >= 0; v = rmer.next[v]) {
-          int32_t d = rmer.va[v];
+        for (; v >= 0; v = rmer.nxt(v)) {
+          int32_t d = rmer.va(v);
+          n_entries++;
           if (dupcnt[d] == 0) touched.push_back(d);
           int32_t cnt = ++dupcnt[d];
           if (cnt >= max_till_now) { max_till_now = cnt; best = d; }      // `>=`: the latest wins (:258-259)
@@ -72,40 +83,62 @@ extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint6
       }
       for (int32_t d : touched) dupcnt[d] = 0;
       touched.clear();
+      if (dbg) { double t1 = now(); tph[0] += t1 - t0; t0 = t1; }
       bool suspect = false;
       if (best >= 0) {
         cov.assign(L + 1, 0);
         for (size_t i = 0; i < rk.size(); i++) {
           bool has = false;
-          for (int32_t v = hits[i]; v >= 0 && !has; v = rmer.next[v]) has = rmer.va[v] == best;
+          for (int32_t v = hits[i]; v >= 0 && !has; v = rmer.nxt(v)) has = rmer.va(v) == best;
           if (has) { cov[i] += 1; cov[i + r] -= 1; }
         }
         int64_t run = 0, covered = 0;
         for (uint32_t i = 0; i < L; i++) { run += cov[i]; if (run > 0) covered++; }
         suspect = (double)covered > f * (double)L;
       }
+      if (dbg) { double t1 = now(); tph[1] += t1 - t0; t0 = t1; }
       if (suspect) continue;
       idx++;
       accepted[c] = idx;
       dupcnt.push_back(0);
       conns.emplace_back();
+      // contig_connections (:372-397): every earlier contig sharing a K-mer gets +1 per shared position pair, both
+      // ways.  The new contig's own dict fills in first-seen order (flat counters, no per-contig hash map); in an
+      // earlier contig's dict the new contig can only be the most recent entry.
       window_keys(s, L, C, ck);
-      for (uint64_t key : ck) {
-        for (int32_t v = cmer.find(key); v >= 0; v = cmer.next[v]) {
-          int32_t c2 = cmer.va[v];
+      connw.push_back(0);
+      newnb.clear();
+      for (size_t ki = 0; ki < ck.size(); ki++) {
+        const uint64_t key = ck[ki];
+        if (ki + 12 < ck.size()) cmer.prefetch(ck[ki + 12]);
+        // insert first (one probe): the entries that were there before are the earlier contigs and this contig's own
+        // earlier occurrences of the K-mer (skipped)
+        const int32_t mine = (int32_t)cmer.ents.size();
+        for (int32_t v = cmer.add(key, idx); v >= 0 && v != mine; v = cmer.nxt(v)) {
+          int32_t c2 = cmer.va(v);
           if (c2 == idx) continue;
-          Conn& a = conns[idx];
-          auto pa = a.pos.find(c2);
-          if (pa == a.pos.end()) { a.pos[c2] = (int32_t)a.nb.size(); a.nb.push_back(c2); a.w.push_back(1); } else a.w[pa->second]++;
+          if (connw[c2]++ == 0) newnb.push_back(c2);
           Conn& b = conns[c2];
-          auto pb = b.pos.find(idx);
-          if (pb == b.pos.end()) { b.pos[idx] = (int32_t)b.nb.size(); b.nb.push_back(idx); b.w.push_back(1); } else b.w[pb->second]++;
+          if (!b.nb.empty() && b.nb.back() == idx) b.w.back()++;
+          else { b.nb.push_back(idx); b.w.push_back(1); }
         }
-        cmer.add(key, idx);
       }
-      for (uint64_t key : rk) rmer.add(key, idx);
+      {
+        Conn& a = conns[idx];
+        a.nb = newnb;
+        a.w.resize(newnb.size());
+        for (size_t j = 0; j < newnb.size(); j++) { a.w[j] = connw[newnb[j]]; connw[newnb[j]] = 0; }
+      }
+      if (dbg) { double t1 = now(); tph[2] += t1 - t0; t0 = t1; }
+      for (size_t i = 0; i < rk.size(); i++) {
+        if (i + 12 < rk.size()) rmer.prefetch(rk[i + 12]);
+        rmer.add(rk[i], idx);
+      }
+      if (dbg) { double t1 = now(); tph[3] += t1 - t0; }
     }
     cached_n = n_cand; cached_ptr = bases;
+    if (dbg) fprintf(stderr, "[contig_graph] lookup %.3f s (%llu list entries), coverage %.3f s, connections %.3f s, index insert %.3f s\n", tph[0],
+                     (unsigned long long)n_entries, tph[1], tph[2], tph[3]);
   }
   uint64_t n_acc = conns.size() - 1, total = 0;
   for (uint64_t i = 1; i <= n_acc; i++) total += conns[i].nb.size();

@@ -10,29 +10,37 @@ static inline uint64_t fm_mix(uint64_t x) {
   return x;
 }
 
-// uint64 key -> values (int32 pairs) in insertion order
+// uint64 key -> values (int32 pairs) in insertion order.  Slots and values are arrays of structs: one cache line per
+// probe and per value (the maps of the host stages are far larger than the caches).
 struct FlatMultiMap {
-  std::vector<uint64_t> keys;
-  std::vector<int32_t> head, tail;        // -1 = empty slot
-  std::vector<int32_t> va, vb, next;      // value pool: (a, b) + next index
+  struct Slot { uint64_t key; int32_t head, tail; };      // head == -1: empty
+  struct Ent { int32_t a, b, next; };
+  std::vector<Slot> slots;
+  std::vector<Ent> ents;
   size_t mask = 0, used = 0;
   explicit FlatMultiMap(size_t expect = 1024) { size_t c = 1024; while (c < expect * 2) c <<= 1; resize(c); }
   void resize(size_t c) {
-    std::vector<uint64_t> ok; ok.swap(keys);
-    std::vector<int32_t> oh, ot; oh.swap(head); ot.swap(tail);
-    keys.assign(c, 0); head.assign(c, -1); tail.assign(c, -1); mask = c - 1; used = 0;
-    for (size_t i = 0; i < oh.size(); i++) if (oh[i] >= 0) { size_t s = slot(ok[i]); keys[s] = ok[i]; head[s] = oh[i]; tail[s] = ot[i]; used++; }
+    std::vector<Slot> old; old.swap(slots);
+    slots.assign(c, Slot{0, -1, -1}); mask = c - 1; used = 0;
+    for (const Slot& o : old) if (o.head >= 0) { slots[slot(o.key)] = o; used++; }
   }
-  size_t slot(uint64_t k) const { size_t s = fm_mix(k) & mask; while (head[s] >= 0 && keys[s] != k) s = (s + 1) & mask; return s; }
-  // first value index of k or -1; iterate with next[]
-  int32_t find(uint64_t k) const { size_t s = slot(k); return head[s]; }
-  void add(uint64_t k, int32_t a, int32_t b = 0) {
+  size_t slot(uint64_t k) const { size_t s = fm_mix(k) & mask; while (slots[s].head >= 0 && slots[s].key != k) s = (s + 1) & mask; return s; }
+  void prefetch(uint64_t k) const { __builtin_prefetch(&slots[fm_mix(k) & mask]); }
+  // first value index of k or -1; iterate with nxt()
+  int32_t find(uint64_t k) const { return slots[slot(k)].head; }
+  int32_t va(int32_t v) const { return ents[v].a; }
+  int32_t vb(int32_t v) const { return ents[v].b; }
+  int32_t nxt(int32_t v) const { return ents[v].next; }
+  // append (a, b) to k's list and return the head the list had BEFORE (or -1): one probe for "look up, then insert"
+  int32_t add(uint64_t k, int32_t a, int32_t b = 0) {
     if ((used + 1) * 10 > (mask + 1) * 6) resize((mask + 1) * 2);
-    size_t s = slot(k);
-    int32_t v = (int32_t)va.size();
-    va.push_back(a); vb.push_back(b); next.push_back(-1);
-    if (head[s] < 0) { keys[s] = k; head[s] = v; tail[s] = v; used++; }
-    else { next[tail[s]] = v; tail[s] = v; }
+    Slot& sl = slots[slot(k)];
+    const int32_t before = sl.head;
+    int32_t v = (int32_t)ents.size();
+    ents.push_back(Ent{a, b, -1});
+    if (sl.head < 0) { sl.key = k; sl.head = v; sl.tail = v; used++; }
+    else { ents[sl.tail].next = v; sl.tail = v; }
+    return before;
   }
 };
 

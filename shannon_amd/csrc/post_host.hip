@@ -63,17 +63,17 @@ extern "C" int shn_find_reps(const uint8_t* names, const uint64_t* name_off, con
         pos.push_back({o, {-2, -2}});                      // -2 = "key not created by this list"
         return pos.back().second;
       };
-      for (int32_t v = vf; v >= 0; v = index.next[v]) {
-        int32_t o = index.va[v];
+      for (int32_t v = vf; v >= 0; v = index.nxt(v)) {
+        int32_t o = index.va(v);
         if (o == (int32_t)id) continue;
         auto& e = slot(o);
-        if (e.first == -2 && e.second == -2) e = {index.vb[v], -1}; else e.first = index.vb[v];
+        if (e.first == -2 && e.second == -2) e = {index.vb(v), -1}; else e.first = index.vb(v);
       }
-      for (int32_t v = vl; v >= 0; v = index.next[v]) {
-        int32_t o = index.va[v];
+      for (int32_t v = vl; v >= 0; v = index.nxt(v)) {
+        int32_t o = index.va(v);
         if (o == (int32_t)id) continue;
         auto& e = slot(o);
-        if (e.first == -2 && e.second == -2) e = {-1, index.vb[v]}; else e.second = index.vb[v];
+        if (e.first == -2 && e.second == -2) e = {-1, index.vb(v)}; else e.second = index.vb(v);
       }
       for (auto& e : pos) {
         int64_t p0 = e.second.first, p1 = e.second.second;

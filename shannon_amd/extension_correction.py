@@ -9,7 +9,7 @@ shared K-mers (:366-397), DFS components and the METIS / contig / remaining-bin 
 """
 import ctypes as C
 import math
-import os
+import os, sys
 import numpy as np
 from . import _lib, device
 
@@ -183,6 +183,11 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
                                                C.byref(n_acc), coff.ctypes.data, cnb.ctypes.data, cw.ctypes.data, C.byref(n_conn)))
         for i in np.nonzero(acc)[0].tolist():
             contigs.append(strings[i])
+        if os.environ.get("SHN_DEBUG"):
+            pos = np.nonzero(acc)[0]
+            dec = np.histogram(pos, bins=10, range=(0, max(1, len(strings))))[0].tolist()
+            sys.stderr.write("[contig_graph] candidates %d (%d bases), accepted %d; accepted per decile of the seed order: %s\n"
+                             % (len(strings), int(offs[-1]), len(pos), dec))
         coff = coff.tolist()
         cnb, cw = cnb.tolist(), cw.tolist()
         for a in range(n_acc.value):
