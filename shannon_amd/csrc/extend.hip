@@ -125,14 +125,21 @@ __global__ void ext_seed_kernel(const uint64_t* __restrict__ tkeys, const uint32
     uint8_t f = flags[i];
     is_seed = !(f & 2) && !((o & 1) && ((f & 1) || !canonical)) && weight[i] >= min_weight;
   }
-  // one atomic per wavefront (the order of the seeds does not matter: they are sorted next)
-  const int lane = threadIdx.x & 63;
+  // one atomic per block of 1024 (the order of the seeds does not matter: they are sorted next)
+  __shared__ uint32_t wcnt[16];
+  __shared__ unsigned long long bbase;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const unsigned long long m = __ballot(is_seed);
-  unsigned long long base = 0;
-  if (lane == 0 && m) base = atomicAdd(counter, (unsigned long long)__popcll(m));
-  base = __shfl((long long)base, 0, 64);
+  if (lane == 0) wcnt[wid] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) { uint32_t c = wcnt[w]; wcnt[w] = tot; tot += c; }
+    bbase = tot ? atomicAdd(counter, (unsigned long long)tot) : 0ULL;
+  }
+  __syncthreads();
   if (!is_seed) return;
-  unsigned long long p = base + __popcll(m & ((1ULL << lane) - 1ULL));
+  unsigned long long p = bbase + wcnt[wid] + __popcll(m & ((1ULL << lane) - 1ULL));
   skeys[p] = (o & 1) ? shn_revcomp(tkeys[i], k) : tkeys[i];
   svals[p] = (uint32_t)o;
 }
@@ -669,7 +676,7 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
   uint64_t* skeys = (uint64_t*)pk; uint32_t* svals = (uint32_t*)pv;
   unsigned long long* d_cnt = (unsigned long long*)pc;      // [0] seeds [1] steps [2..4] plan (long, pool, short) [5] final pool [6] changed
   TRYE(hipMemsetAsync(d_cnt, 0, 2048, s));
-  if (n) hipLaunchKernelGGL(ext_seed_kernel, dim3((uint32_t)cdiv(2 * n, 256)), dim3(256), 0, s, t->d_keys, e->d_weight, e->d_flags, n,
+  if (n) hipLaunchKernelGGL(ext_seed_kernel, dim3((uint32_t)cdiv(2 * n, 1024)), dim3(1024), 0, s, t->d_keys, e->d_weight, e->d_flags, n,
                             t->k, t->canonical, min_weight, skeys, svals, d_cnt);
   unsigned long long ns = 0;
   TRYE(hipMemcpyAsync(&ns, d_cnt, 8, hipMemcpyDeviceToHost, s));
@@ -726,6 +733,8 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
   TRYE(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
   TRYE(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
   TRYE(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  static thread_local unsigned long long* plan = nullptr;      // long dirty walks, -, short dirty walks, dirty walks
+  if (!plan) TRYE(hipHostMalloc((void**)&plan, 64));
   int it = 0;
   bool converged = ns == 0;
 
@@ -750,7 +759,7 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
     if (limit > frozen)
       hipLaunchKernelGGL(ext_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 256)), dim3(256), 0, s, e->d_nr, e->d_nl, (uint64_t)limit, frozen,
                          mvalid, mR, mL, dirty, long_list, short_list, d_cnt + 2, long_walk);
-    unsigned long long plan[4] = {0, 0, 0, 0};      // long dirty walks, -, short dirty walks, dirty walks
+    // (pinned host memory: a pageable destination costs a staging copy kernel per round)
     TRYE(hipMemcpyAsync(plan, d_cnt + 2, 32, hipMemcpyDeviceToHost, s));
     TRYE(hipStreamSynchronize(s));
     if (plan[3] == 0) {

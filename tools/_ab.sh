@@ -1,10 +1,9 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r1f
-python -m pytest tests/test_e2e_gpu.py tests/test_routing_gpu.py tests/test_extension_gpu.py -x -q -m gpu 2>&1 | tail -3
-SHN_DEBUG=1 python bench.py --no-cpu-baseline --reads 80000000 --families 8 --steps 1 --warmup 1 2>/dev/null | python -c "
+python -m pytest tests/test_extension_gpu.py tests/test_e2e_gpu.py -x -q -m gpu 2>&1 | tail -3
+for v in 1 2 3; do
+  timeout 120 python bench.py --no-cpu-baseline --steps 5 --warmup 1 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('8 families', round(d['ms_per_step'],1), d['config']['transcripts'], d['config']['host_stage_seconds_per_step'])"
-python bench.py --no-cpu-baseline --reads 2000000 --genes 300 --steps 2 --warmup 1 2>/dev/null | python -c "
-import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('300 genes', round(d['ms_per_step'],1), d['config']['transcripts'], d['config']['host_stage_seconds_per_step'])"
+k = d['kernel_ms_per_step']
+print(round(d['ms_per_step'],1), d['config']['extension_iterations'], d['config']['transcripts'], 'ext', round(k['extend'],1), 'walk', round(k['extend.walk'],1), 'gpu_walks', round(d['config']['host_stage_seconds_per_step']['ext.gpu_walks'], 4))"
+done
