@@ -1,0 +1,48 @@
+"""The multi-GPU code path (shannon_amd.distributed.assemble_distributed with GpuOps: HIP kernels through the C ABI,
+collectives on the "nccl" = RCCL backend) run as a one-rank job on cuda:0 and compared with the single-process
+pipeline on the same inputs.  (world_size 2 is covered on CPU with gloo in test_distributed_cpu.py.)"""
+import os
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def group():
+    import torch, torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    torch.cuda.set_device(0)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    if created:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("paired,n_genes,seed", [(True, 3, 11), (False, 2, 5), (True, 12, 4)])
+def test_distributed_path_matches_single_process(group, paired, n_genes, seed):
+    from shannon_amd import device, synth, pipeline, distributed, kmers_for_component as kfc
+    (q1, q2), _ = synth.make_dataset(12000, n_genes, seed=seed)
+    if not paired:
+        q1, q2 = np.concatenate([q1, q2]), None
+    ctx = device.Context(0)
+    d1 = device.Reads.from_codes(ctx, q1)
+    d2 = device.Reads.from_codes(ctx, q2) if paired else None
+    store = kfc.ReadStore(q1, q2)
+    try:
+        ref = pipeline.assemble_resident(ctx, d1, d2, store, K=25, sample="t", seed=1)
+        ops = distributed.GpuOps(ctx, d1, d2, store, 25)
+        got = distributed.assemble_distributed(ops, 25, 500, "t", 1)
+        assert got["contigs"] == ref.extension.contigs
+        assert list(got["partitions"]) == list(ref.partitions)
+        for name in ref.partitions:
+            assert got["partitions"][name] == ref.partitions[name]["reconstructed_fasta"]
+        assert got["final"] == ref.final
+    finally:
+        d1.close()
+        if d2 is not None:
+            d2.close()
+        ctx.close()
