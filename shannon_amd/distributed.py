@@ -23,7 +23,6 @@ import numpy as np
 import torch
 import torch.distributed as dist
 from . import exchange, mbgraph, sparse_flow, post
-from .pipeline import n_kmer_nodes
 
 
 def _all_gather_var(t, group=None):
@@ -89,20 +88,19 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
     # position of this rank's first forward / first RC routed read of partition p in the global order
     fwd_before = allc[:rank, :, 0].sum(axis=0)
     rc_before = allc[:, :, 0].sum(axis=0) + allc[:rank, :, 1].sum(axis=0)
-    send_lists = [[] for _ in range(W)]
+    paired = ops.paired
+    payload = [[] for _ in range(W)]                # per destination rank: (partition, global doubled indices, reads)
     for i, nm in enumerate(names):
-        cutoff = 10 * n_kmer_nodes(part["k1mers"][nm], K) + 1
-        r = part["routes"][nm]
+        cutoff = 10 * ops.n_nodes(part, nm, K) + 1
+        r = np.asarray(part["routes"][nm], dtype=np.int64)
         f = int(cnt[i, 0])
         keep_f = int(max(0, min(f, cutoff - fwd_before[i])))
         keep_r = int(max(0, min(len(r) - f, cutoff - rc_before[i])))
-        owner = i % W
-        for d in r[:keep_f].tolist():
-            send_lists[owner].append((i, base + d, d))
-        for d in r[f:f + keep_r].tolist():
-            send_lists[owner].append((i, n_glob + base + (d - n_local), d))
-    paired = ops.paired
-    payload = [[(p, g, ops.mate1(d), ops.mate2(d) if paired else None) for p, g, d in lst] for lst in send_lists]
+        if keep_f + keep_r == 0:
+            continue
+        sel = np.concatenate([r[:keep_f], r[f:f + keep_r]])
+        gidx = np.concatenate([base + r[:keep_f], n_glob + base + (r[f:f + keep_r] - n_local)])
+        payload[i % W].append((i, gidx, ops.collect(sel)))
     recv = [None] * W
     dist.all_to_all_object_list(recv, payload, group=group) if hasattr(dist, "all_to_all_object_list") else _a2a_objects(recv, payload, group)
     tick("route+read exchange", t0)
@@ -110,15 +108,21 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
     t0 = time.time()
     mine = {}
     for lst in recv:
-        for p, g, m1, m2 in lst:
-            mine.setdefault(p, []).append((g, m1, m2))
+        for p, gidx, data in lst:
+            mine.setdefault(p, []).append((gidx, data))
     owned = [i for i in range(P) if i % W == rank]
-    jobs = []
-    for i in owned:
-        recs = sorted(mine.get(i, []))
-        reads = [[x[1] for x in recs], [x[2] for x in recs]] if paired else [[x[1] for x in recs]]
-        singles, comps = ops.graph(part["k1mers"][names[i]], reads, K, paired)
-        jobs.append((i, singles, comps))
+
+    def one(i):
+        singles, comps = ops.graph(part, names[i], mine.get(i, []), K, paired)      # pieces: [(global indices, reads)] per source rank
+        return (i, singles, comps)
+
+    nthreads = min(len(owned), getattr(ops, "graph_threads", 1))
+    if nthreads > 1:                      # owned partitions are independent; the native stage releases the GIL
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=nthreads) as pool:
+            jobs = list(pool.map(one, owned))
+    else:
+        jobs = [one(i) for i in owned]
     tick("graph", t0)
     t0 = time.time()
     flat = [(c["nodes"], c["edges"], c["paths"]) for _, _, comps in jobs for c in comps]
@@ -196,25 +200,44 @@ class GpuOps(object):
         torch.cuda.synchronize()
         return self._dev.Table.from_pairs(self.ctx, gk.data_ptr(), gc.data_ptr(), gk.numel(), self.K + 1, True)
 
+    graph_threads = 8
+
     def extension(self, table, partition_size):
         from . import extension_correction as ec
-        res = ec.run_correction(self.ctx, table, 3, 75, partition_size)
+        res = ec.run_correction(self.ctx, table, 3, 75, partition_size, want_allowed=False)
         table.close()
         return res
 
     def route(self, res, K, partition_size, part_vectors):
         from . import kmers_for_component as kfc
-        return kfc.kmers_for_component(self.ctx, res, self.d1, self.d2, K, partition_size, part_vectors=part_vectors)
+        return kfc.kmers_for_component(self.ctx, res, self.d1, self.d2, K, partition_size, part_vectors=part_vectors, want_rows=False)
 
-    def mate1(self, d):
-        return self.store.mate1(d)
+    def n_nodes(self, part, name, K):
+        return part["n_kmer_nodes"][name]
 
-    def mate2(self, d):
-        return self.store.mate2(d)
+    def collect(self, sel):
+        """the reads of the doubled indices `sel` as they travel to a partition's owner: stored code rows + strand
+        flags of the first mates (second mates: same rows, opposite strand)"""
+        buf, off, rc1, enc = self.store.gather_codes(sel, 1)
+        L = int(off[1] - off[0]) if len(off) > 1 else 0
+        return (buf.reshape(len(sel), L), rc1)
 
-    def graph(self, rows, reads, K, paired):
+    def graph(self, part, name, pieces, K, paired):
         from . import mbgraph_native
-        singles, comps, _log = mbgraph_native.run_partition(rows, reads, K, paired, ctx=self.ctx)
+        rb = part["k1mer_bytes"][name]                     # the partition's k1-mer file as fixed-width rows
+        if pieces:
+            gidx = np.concatenate([g for g, _ in pieces])
+            rows = np.concatenate([d[0] for _, d in pieces])
+            rc1 = np.concatenate([d[1] for _, d in pieces])
+            order = np.argsort(gidx, kind="stable")            # global strand-doubled order = the reference's file order
+            rows, rc1 = np.ascontiguousarray(rows[order]), np.ascontiguousarray(rc1[order])
+        else:
+            rows, rc1 = np.zeros((0, 1), np.uint8), np.zeros(0, np.uint8)
+        off = np.arange(len(rows) + 1, dtype=np.uint64) * np.uint64(rows.shape[1])
+        b1 = rows.reshape(-1) if rows.size else np.zeros(1, np.uint8)
+        singles, comps, _log = mbgraph_native.run_partition_arrays(rb if len(rb) else np.zeros(1, np.uint8), len(rb) // (K + 1), K,
+                                                                   b1, off, b1 if paired else None, off if paired else None, ctx=self.ctx,
+                                                                   enc=1, rc1=rc1, rc2=(1 - rc1).astype(np.uint8) if paired else None)
         return singles, comps
 
     def sparse_flow(self, flat, ids, seed):

@@ -79,15 +79,18 @@ class OracleOps(object):
                 routes[c].append(d)
         return {"new_components": nc, "k1mers": files, "routes": {n: np.array(v, dtype=np.uint32) for n, v in routes.items()}}
 
-    def mate1(self, d):
-        return self.store.mate1(d)
+    def collect(self, sel):
+        return [(self.store.mate1(int(d)), self.store.mate2(int(d)) if self.paired else None) for d in sel]
 
-    def mate2(self, d):
-        return self.store.mate2(d)
+    def n_nodes(self, part, name, K):
+        from shannon_amd.pipeline import n_kmer_nodes
+        return n_kmer_nodes(part["k1mers"][name], K)
 
-    def graph(self, rows, reads, K, paired):
+    def graph(self, part, name, pieces, K, paired):
         from shannon_amd import mbgraph_native
-        singles, comps, _log = mbgraph_native.run_partition(rows, reads, K, paired)      # native host code, seed scans on the CPU
+        recs = sorted((int(g), m) for gidx, data in pieces for g, m in zip(gidx.tolist(), data))
+        reads = [[m[0] for _, m in recs], [m[1] for _, m in recs]] if paired else [[m[0] for _, m in recs]]
+        singles, comps, _log = mbgraph_native.run_partition(part["k1mers"][name], reads, K, paired)   # native host code, seed scans on the CPU
         return singles, comps
 
     def sparse_flow(self, flat, ids, seed):
