@@ -130,6 +130,13 @@ int shn_ext_weights(shn_ctx* ctx, const shn_ext* e, const uint64_t* keys, uint64
 /* The non-void walks only, in seed order (rank ascending): rank[], n_right[], n_left[], tot_weight[] -- the inputs of the
  * accept filter of extension_correction.py:361.  Call with rank == NULL to get *n_live, then with arrays of that size
  * (*n_live = capacity on entry).                                                                                       */
+/* Sharded variant: the connected components of the k1-mer graph are dealt to `world` ranks (the large ones balanced by
+ * size, the rest by hash; every rank computes the same assignment from the same table) and only the seeds of `rank`'s
+ * components walk.  Walks never leave their component, so the union of the shards' walks is the unsharded result.
+ * shn_ext_seed_info: seed k1-mer (packed) and seed weight of walks -- (weight desc, k1-mer asc) is the global walk order
+ * that merges the shards (extension_correction.py:334-345).                                                             */
+int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min_weight, int max_iterations, int world, int rank, shn_ext** out);
+int shn_ext_seed_info(shn_ctx* ctx, const shn_ext* e, const uint32_t* ranks, uint64_t n, uint64_t* keys, uint32_t* weights);
 int shn_ext_live_stats(shn_ctx* ctx, const shn_ext* e, uint64_t* n_live, uint32_t* rank, uint32_t* n_right, uint32_t* n_left,
                        uint64_t* tot_weight);
 

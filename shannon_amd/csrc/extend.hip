@@ -115,15 +115,76 @@ __global__ void ext_adjacency_kernel(const uint64_t* __restrict__ tkeys, const u
   (dir == 0 ? adjR : adjL)[o * 4 + b] = res;
 }
 
+// ---- connected components of the k1-mer graph (vertices = canonical k1-mers, edges = the adjacency rows).
+// A walk never leaves its component, so the components can be extended independently -- on different GPUs.
+// Lock-free union-find: roots only ever link to smaller ids (no cycles), finds halve paths as they go.
+__device__ __forceinline__ uint32_t cc_find(uint32_t* lab, uint32_t x) {
+  uint32_t cur = x;
+  while (true) {
+    uint32_t p = __hip_atomic_load(&lab[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p == cur) return cur;
+    uint32_t gp = __hip_atomic_load(&lab[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gp != p) __hip_atomic_store(&lab[cur], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    cur = p;
+  }
+}
+__global__ void cc_init_kernel(uint32_t* __restrict__ lab, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) lab[i] = (uint32_t)i;
+}
+__global__ void cc_union_kernel(const int32_t* __restrict__ adjR, uint64_t n2, uint32_t* lab) {
+  uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (oriented k1-mer, appended base)
+  if (gid >= n2 * 4) return;
+  int32_t t = adjR[gid];
+  if (t < 0) return;
+  uint32_t u = (uint32_t)(gid >> 3), v = (uint32_t)t >> 1;             // canonical indices
+  if (u == v) return;
+  while (true) {
+    uint32_t ru = cc_find(lab, u), rv = cc_find(lab, v);
+    if (ru == rv) break;
+    uint32_t hi = ru > rv ? ru : rv, lo = ru > rv ? rv : ru;
+    if (atomicCAS(&lab[hi], hi, lo) == hi) break;
+  }
+}
+__global__ void cc_flatten_kernel(uint32_t* lab, uint64_t n) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { uint32_t r = cc_find(lab, (uint32_t)i); lab[i] = r; }
+}
+// size estimate of the components from every 64th k1-mer (a full count would hammer a handful of addresses)
+__global__ void cc_sample_kernel(const uint32_t* __restrict__ lab, uint64_t n, uint32_t* __restrict__ size_s) {
+  uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 64;
+  if (i < n) atomicAdd(&size_s[lab[i]], 1u);
+}
+// owner of every root by hash; roots of big components are listed for the host to balance
+__global__ void cc_owner_kernel(const uint32_t* __restrict__ lab, const uint32_t* __restrict__ size_s, uint64_t n, uint32_t world,
+                                uint8_t* __restrict__ owner_root, uint32_t* __restrict__ big_root, uint32_t* __restrict__ big_size,
+                                unsigned long long* __restrict__ n_big, uint32_t big_cap) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (lab[i] != (uint32_t)i) { owner_root[i] = 0xFF; return; }
+  owner_root[i] = (uint8_t)(shn_mix64((uint64_t)i ^ 0x5851F42D4C957F2DULL) % world);
+  if (size_s[i] >= 16) {
+    unsigned long long p = atomicAdd(n_big, 1ULL);
+    if (p < big_cap) { big_root[p] = (uint32_t)i; big_size[p] = size_s[i]; }
+  }
+}
+__global__ void cc_assign_kernel(const uint32_t* __restrict__ big_root, const uint8_t* __restrict__ big_owner, uint32_t n_big,
+                                 uint8_t* __restrict__ owner_root) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n_big) owner_root[big_root[j]] = big_owner[j];
+}
+
 __global__ void ext_seed_kernel(const uint64_t* __restrict__ tkeys, const uint32_t* __restrict__ weight,
                                 const uint8_t* __restrict__ flags, uint64_t n, int k, int canonical, uint32_t min_weight,
-                                uint64_t* __restrict__ skeys, uint32_t* __restrict__ svals, unsigned long long* __restrict__ counter) {
+                                uint64_t* __restrict__ skeys, uint32_t* __restrict__ svals, unsigned long long* __restrict__ counter,
+                                const uint32_t* __restrict__ lab, const uint8_t* __restrict__ owner_root, uint32_t my_rank) {
   uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool is_seed = false;
   uint64_t i = o >> 1;
   if (o < 2 * n) {
     uint8_t f = flags[i];
     is_seed = !(f & 2) && !((o & 1) && ((f & 1) || !canonical)) && weight[i] >= min_weight;
+    if (is_seed && lab) is_seed = owner_root[lab[i]] == my_rank;           // sharded: only the seeds of this rank's components
   }
   // one atomic per block of 1024 (the order of the seeds does not matter: they are sorted next)
   __shared__ uint32_t wcnt[16];
@@ -642,7 +703,13 @@ extern "C" void shn_ext_destroy(shn_ext* e) {
 }
 
 extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight, int max_iterations, shn_ext** out) {
+  return shn_extend_sharded(ctx, t, min_weight, max_iterations, 1, 0, out);
+}
+
+extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min_weight, int max_iterations, int world, int rank,
+                                  shn_ext** out) {
   if (!ctx || !t || !out) return shn_fail(SHN_ERR_ARG, "shn_extend: NULL argument");
+  if (world < 1 || world > 255 || rank < 0 || rank >= world) return shn_fail(SHN_ERR_ARG, "shn_extend_sharded: bad world/rank");
   if (2 * t->n >= 0x7FFFFFFFULL) return shn_fail(SHN_ERR_ARG, "shn_extend: table too large for 31-bit oriented ids");
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
@@ -676,8 +743,50 @@ extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight,
   uint64_t* skeys = (uint64_t*)pk; uint32_t* svals = (uint32_t*)pv;
   unsigned long long* d_cnt = (unsigned long long*)pc;      // [0] seeds [1] steps [2..4] plan (long, pool, short) [5] final pool [6] changed
   TRYE(hipMemsetAsync(d_cnt, 0, 2048, s));
+  // sharded: label the connected components, give every component to one rank (the big ones balanced by size,
+  // the rest by hash -- the same on every rank), keep only this rank's seeds
+  uint32_t* d_lab = nullptr;
+  uint8_t* d_owner_root = nullptr;
+  if (world > 1 && n) {
+    void *pl, *po, *pz, *pb;
+    const uint32_t big_cap = 1u << 16;
+    if ((rc = g_shn_ws[14].get((n + 1) * 4, &pl)) || (rc = g_shn_ws[15].get(n + 1, &po)) || (rc = g_shn_ws[16].get((n + 1) * 4, &pz)) ||
+        (rc = g_shn_ws[17].get((size_t)big_cap * 9 + 64, &pb))) { shn_ext_destroy(e); return rc; }
+    d_lab = (uint32_t*)pl; d_owner_root = (uint8_t*)po;
+    uint32_t* d_size = (uint32_t*)pz;
+    uint32_t* d_big_root = (uint32_t*)pb; uint32_t* d_big_size = d_big_root + big_cap; uint8_t* d_big_owner = (uint8_t*)(d_big_size + big_cap);
+    hipLaunchKernelGGL(cc_init_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, d_lab, n);
+    hipLaunchKernelGGL(cc_union_kernel, dim3((uint32_t)cdiv(2 * n * 4, 256)), dim3(256), 0, s, (const int32_t*)e->d_adjR, 2 * n, d_lab);
+    hipLaunchKernelGGL(cc_flatten_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, d_lab, n);
+    TRYE(hipMemsetAsync(d_size, 0, (n + 1) * 4, s));
+    hipLaunchKernelGGL(cc_sample_kernel, dim3((uint32_t)cdiv(cdiv(n, 64), 256)), dim3(256), 0, s, d_lab, n, d_size);
+    hipLaunchKernelGGL(cc_owner_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, d_lab, d_size, n, (uint32_t)world, d_owner_root,
+                       d_big_root, d_big_size, d_cnt + 20, big_cap);
+    unsigned long long nb = 0;
+    TRYE(hipMemcpyAsync(&nb, d_cnt + 20, 8, hipMemcpyDeviceToHost, s));
+    TRYE(hipStreamSynchronize(s));
+    nb = std::min<unsigned long long>(nb, big_cap);
+    if (nb) {
+      std::vector<uint32_t> br(nb), bs(nb);
+      TRYE(hipMemcpy(br.data(), d_big_root, nb * 4, hipMemcpyDeviceToHost));
+      TRYE(hipMemcpy(bs.data(), d_big_size, nb * 4, hipMemcpyDeviceToHost));
+      std::vector<uint32_t> ord(nb);
+      for (uint32_t j = 0; j < nb; j++) ord[j] = j;
+      std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return bs[a] != bs[b] ? bs[a] > bs[b] : br[a] < br[b]; });
+      std::vector<uint64_t> load(world, 0);
+      std::vector<uint8_t> bo(nb);
+      for (uint32_t j : ord) {                                  // largest first onto the least loaded rank
+        int best = 0;
+        for (int w = 1; w < world; w++) if (load[w] < load[best]) best = w;
+        bo[j] = (uint8_t)best;
+        load[best] += bs[j];
+      }
+      TRYE(hipMemcpy(d_big_owner, bo.data(), nb, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(cc_assign_kernel, dim3((uint32_t)cdiv(nb, 256)), dim3(256), 0, s, d_big_root, d_big_owner, (uint32_t)nb, d_owner_root);
+    }
+  }
   if (n) hipLaunchKernelGGL(ext_seed_kernel, dim3((uint32_t)cdiv(2 * n, 1024)), dim3(1024), 0, s, t->d_keys, e->d_weight, e->d_flags, n,
-                            t->k, t->canonical, min_weight, skeys, svals, d_cnt);
+                            t->k, t->canonical, min_weight, skeys, svals, d_cnt, d_lab, d_owner_root, (uint32_t)rank);
   unsigned long long ns = 0;
   TRYE(hipMemcpyAsync(&ns, d_cnt, 8, hipMemcpyDeviceToHost, s));
   TRYE(hipStreamSynchronize(s));
@@ -913,6 +1022,34 @@ extern "C" int shn_ext_live_stats(shn_ctx* ctx, const shn_ext* e, uint64_t* n_li
   if (tot_weight) HIP_TRY(hipMemcpyAsync(tot_weight, o_tw, total * 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipGetLastError());
+  return SHN_OK;
+}
+
+// seed string (oriented k1-mer key) and seed weight of the given walks: the global order of the walks is
+// (weight descending, key ascending), which is what merges the candidates of several shards
+__global__ void ext_seed_info_kernel(const uint32_t* __restrict__ ranks, uint64_t n, const uint32_t* __restrict__ order,
+                                     const uint64_t* __restrict__ tkeys, const uint32_t* __restrict__ weight, int k,
+                                     uint64_t* __restrict__ keys, uint32_t* __restrict__ w) {
+  uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  uint32_t o = order[ranks[j]];
+  keys[j] = oriented_string(tkeys, o, k);
+  w[j] = weight[o >> 1];
+}
+extern "C" int shn_ext_seed_info(shn_ctx* ctx, const shn_ext* e, const uint32_t* ranks, uint64_t n, uint64_t* keys, uint32_t* weights) {
+  if (!ctx || !e || (n && (!ranks || !keys || !weights))) return shn_fail(SHN_ERR_ARG, "shn_ext_seed_info: NULL argument");
+  if (!n) return SHN_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  for (uint64_t j = 0; j < n; j++) if (ranks[j] >= e->n_seeds) return shn_fail(SHN_ERR_ARG, "shn_ext_seed_info: rank out of range");
+  uint32_t *dr, *dw; uint64_t* dk;
+  HIP_TRY(shn_dev_malloc(&dr, n * 4)); HIP_TRY(shn_dev_malloc(&dw, n * 4)); HIP_TRY(shn_dev_malloc(&dk, n * 8));
+  HIP_TRY(hipMemcpyAsync(dr, ranks, n * 4, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(ext_seed_info_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, dr, n, e->d_order, e->table->d_keys, e->d_weight, e->k, dk, dw);
+  HIP_TRY(hipMemcpyAsync(keys, dk, n * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(weights, dw, n * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  shn_dev_free(dr); shn_dev_free(dw); shn_dev_free(dk);
   return SHN_OK;
 }
 

@@ -63,7 +63,7 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
     table = ops.table_from_pairs(gk, gc)
     tick("allgather table", t0)
     t0 = time.time()
-    res = ops.extension(table, partition_size)
+    res = ops.extension(table, partition_size, group) if getattr(ops, "sharded_extension", False) else ops.extension(table, partition_size)
     tick("extension", t0)
     t0 = time.time()
     part = ops.route(res, K, partition_size, part_vectors)
@@ -201,10 +201,22 @@ class GpuOps(object):
         return self._dev.Table.from_pairs(self.ctx, gk.data_ptr(), gc.data_ptr(), gk.numel(), self.K + 1, True)
 
     graph_threads = 8
+    sharded_extension = True
 
-    def extension(self, table, partition_size):
+    def extension(self, table, partition_size, group=None):
+        """replicated table -> the walks sharded by connected component of the k1-mer graph, the candidate contigs
+        all-gathered (a few MB), the sequential contig stages replicated"""
         from . import extension_correction as ec
-        res = ec.run_correction(self.ctx, table, 3, 75, partition_size, want_allowed=False)
+        W, rank = dist.get_world_size(group), dist.get_rank(group)
+
+        def merge(local):
+            if W == 1:
+                return local
+            parts = [None] * W
+            dist.all_gather_object(parts, local, group=group)
+            return [c for p in parts for c in p]
+
+        res = ec.run_correction(self.ctx, table, 3, 75, partition_size, want_allowed=False, shard=(W, rank), merge=merge)
         table.close()
         return res
 

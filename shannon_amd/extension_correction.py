@@ -24,10 +24,24 @@ class ExtensionResult(object):
 class Extension(object):
     """Handle over shn_ext (device-resident walk state)."""
 
-    def __init__(self, ctx, table, min_weight=3, max_iterations=0):
+    def __init__(self, ctx, table, min_weight=3, max_iterations=0, shard=None):
+        """shard = (world, rank): only the walks of the connected components dealt to `rank` (shn_extend_sharded)."""
         self.ctx, self.table = ctx, table
         self.h = C.c_void_p()
-        _lib.check(_lib.lib().shn_extend(ctx.h, table.h, int(min_weight), int(max_iterations), C.byref(self.h)))
+        if shard is None or shard[0] <= 1:
+            _lib.check(_lib.lib().shn_extend(ctx.h, table.h, int(min_weight), int(max_iterations), C.byref(self.h)))
+        else:
+            _lib.check(_lib.lib().shn_extend_sharded(ctx.h, table.h, int(min_weight), int(max_iterations), int(shard[0]), int(shard[1]),
+                                                    C.byref(self.h)))
+
+    def seed_info(self, ranks):
+        """(seed k1-mer key, seed weight) of the given walks: (weight desc, key asc) is the global walk order."""
+        ranks = np.ascontiguousarray(ranks, dtype=np.uint32)
+        keys = np.empty(max(len(ranks), 1), np.uint64)
+        w = np.empty(max(len(ranks), 1), np.uint32)
+        if len(ranks):
+            _lib.check(_lib.lib().shn_ext_seed_info(self.ctx.h, self.h, ranks.ctypes.data, len(ranks), keys.ctypes.data, w.ctypes.data))
+        return keys[:len(ranks)], w[:len(ranks)]
 
     @property
     def n_walks(self):
@@ -126,10 +140,13 @@ def windows_to_keys_many(contigs, k):
     return key[idx], nwin
 
 
-def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=500, r=15, f=0.5, want_allowed=True, timings=None):
+def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=500, r=15, f=0.5, want_allowed=True, timings=None,
+                   shard=None, merge=None):
     """extension_correction.run_correction (extension_correction.py:309-524) on a device k1-mer
     table.  Returns an ExtensionResult: contigs, allowed {k1mer: int}, connections, components,
-    single_contigs, big_components [(contigs, metis_text)], remaining [[contig...]]."""
+    single_contigs, big_components [(contigs, metis_text)], remaining [[contig...]].
+    shard = (world, rank) + merge(local) -> global: the walks are sharded by connected component; `merge` receives this
+    rank's candidates [(seed weight, seed key, contig)] and returns the candidates of all ranks (any order)."""
     import time as _t
     T = timings if timings is not None else {}
     _t0 = [_t.time()]
@@ -140,7 +157,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
         _t0[0] = now
 
     k1 = table.k
-    ext = Extension(ctx, table, min_weight)
+    ext = Extension(ctx, table, min_weight, shard=shard)
     lap("ext.gpu_walks")
     live, nr, nl, tw = ext.live_stats()                        # non-void walks, in seed order (compacted on the GPU)
     length = k1 + nr.astype(np.int64) + nl.astype(np.int64)
@@ -161,6 +178,12 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     keep = list(zip(cand[sure].tolist(), clen[sure].tolist()))
     lap("ext.filter")
     strings = ext.emit([x[0] for x in keep], [x[1] for x in keep]) if keep else []
+    if merge is not None:
+        # candidates of all shards in the global walk order (weight descending, seed k1-mer ascending; :334-345)
+        skey, sw = ext.seed_info([x[0] for x in keep])
+        allc = merge(list(zip(sw.tolist(), skey.tolist(), strings)))
+        allc.sort(key=lambda c: (-c[0], c[1]))
+        strings = [c[2] for c in allc]
     lap("ext.emit")
 
     # duplicate_check + contig graph, sequential over candidates in seed order (:358-397): native host

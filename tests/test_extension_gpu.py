@@ -100,3 +100,31 @@ def test_multigene_walks_match_oracle_and_are_deterministic(ctx):
         refw.append(int(rw + lw + kmers[s]))
     assert outs[0][0] == ref
     assert outs[0][1] == refw
+
+
+@pytest.mark.parametrize("world", [2, 3, 7])
+def test_component_sharded_walks_union_is_the_unsharded_result(ctx, world):
+    """shn_extend_sharded: the connected components of the k1-mer graph are dealt to `world` ranks; the candidates of
+    all ranks, merged in the global walk order, are exactly the unsharded candidates, and so is everything after."""
+    from shannon_amd import device, synth, extension_correction as ec
+    (r1, r2), _ = synth.make_dataset(60000, 20, seed=78)
+    codes = np.concatenate([r1, r2])
+    t = device.count_k1mers(ctx, [device.Reads.from_codes(ctx, codes)], 26)
+    try:
+        ref = ec.run_correction(ctx, t, 3, 75, 500, want_allowed=False)
+        whole = []
+        ec.run_correction(ctx, t, 3, 75, 500, want_allowed=False, shard=(1, 0), merge=lambda loc: (whole.extend(loc), list(loc))[1])
+        assert whole == sorted(whole, key=lambda c: (-c[0], c[1])) and len(whole) > 20
+        pieces = []
+        for rank in range(world):
+            ec.run_correction(ctx, t, 3, 75, 500, want_allowed=False, shard=(world, rank),
+                              merge=lambda loc: (pieces.append(list(loc)), list(loc))[1])
+        assert sum(1 for p in pieces if p) >= 2                      # the work really is spread
+        merged = sorted((c for p in pieces for c in p), key=lambda c: (-c[0], c[1]))
+        assert merged == whole
+        # and a rank that merges everybody's candidates finishes exactly like the unsharded run
+        res = ec.run_correction(ctx, t, 3, 75, 500, want_allowed=False, shard=(world, 0), merge=lambda loc: list(merged))
+        assert res.contigs == ref.contigs and res.connections == ref.connections
+        assert res.single_contigs == ref.single_contigs and res.remaining == ref.remaining
+    finally:
+        t.close()
