@@ -180,7 +180,18 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
             set_index[(pv,)] = len(sets)
             sets.append((pv,))
         set_ids[single] = (base + inv + 1).astype(np.uint32)
-    for i in np.nonzero(~single)[0].tolist():
+    double = cntk == 2                               # gpmetis run + r2 run: the common multi-partition case, vectorised
+    if double.any():
+        p0, p1 = sp[start[double]].astype(np.int64), sp[start[double] + 1].astype(np.int64)
+        code = p0 * (len(names) + 1) + p1
+        ucode, inv = np.unique(code, return_inverse=True)
+        base = len(sets)
+        for cv in ucode.tolist():
+            tpl = (cv // (len(names) + 1), cv % (len(names) + 1))
+            set_index[tpl] = len(sets)
+            sets.append(tpl)
+        set_ids[double] = (base + inv + 1).astype(np.uint32)
+    for i in np.nonzero(cntk > 2)[0].tolist():
         tpl = tuple(sp[start[i]:start[i] + cntk[i]].tolist())
         sid = set_index.get(tpl)
         if sid is None:
