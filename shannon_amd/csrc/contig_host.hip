@@ -73,7 +73,7 @@ extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint6
         if (i + 12 < rk.size()) rmer.prefetch(rk[i + 12]);
         int32_t v = rmer.find(rk[i]);
         hits[i] = v;
-        for (; v >= 0; v = rmer.nxt(v)) {
+        for (; v != -1; v = rmer.nxt(v)) {
           int32_t d = rmer.va(v);
           n_entries++;
           if (dupcnt[d] == 0) touched.push_back(d);
@@ -89,7 +89,7 @@ extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint6
         cov.assign(L + 1, 0);
         for (size_t i = 0; i < rk.size(); i++) {
           bool has = false;
-          for (int32_t v = hits[i]; v >= 0 && !has; v = rmer.nxt(v)) has = rmer.va(v) == best;
+          for (int32_t v = hits[i]; v != -1 && !has; v = rmer.nxt(v)) has = rmer.va(v) == best;
           if (has) { cov[i] += 1; cov[i + r] -= 1; }
         }
         int64_t run = 0, covered = 0;
@@ -113,8 +113,8 @@ extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint6
         if (ki + 12 < ck.size()) cmer.prefetch(ck[ki + 12]);
         // insert first (one probe): the entries that were there before are the earlier contigs and this contig's own
         // earlier occurrences of the K-mer (skipped)
-        const int32_t mine = (int32_t)cmer.ents.size();
-        for (int32_t v = cmer.add(key, idx); v >= 0 && v != mine; v = cmer.nxt(v)) {
+        int32_t mine = -1;
+        for (int32_t v = cmer.add(key, idx, 0, &mine); v != -1 && v != mine; v = cmer.nxt(v)) {
           int32_t c2 = cmer.va(v);
           if (c2 == idx) continue;
           if (connw[c2]++ == 0) newnb.push_back(c2);

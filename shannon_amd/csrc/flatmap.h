@@ -4,43 +4,55 @@
 #include <vector>
 #include <string>
 #include <cstring>
+#include <climits>
+#include <cstdint>
 
 static inline uint64_t fm_mix(uint64_t x) {
   x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
   return x;
 }
 
-// uint64 key -> values (int32 pairs) in insertion order.  Slots and values are arrays of structs: one cache line per
-// probe and per value (the maps of the host stages are far larger than the caches).
+// uint64 key -> values (int32 pairs) in insertion order.  Slots and values are arrays of structs, and the FIRST value of
+// a key lives in its slot: a probe of a key with one value (the common case) touches one cache line (the maps of the
+// host stages are far larger than the caches).  Value handles: v >= 0 pool entry, v <= -2 the inline value of slot
+// -(v+2), -1 end of list.
 struct FlatMultiMap {
-  struct Slot { uint64_t key; int32_t head, tail; };      // head == -1: empty
+  struct Slot { uint64_t key; int32_t a, b; int32_t next, tail; };      // next == INT32_MIN: empty slot; next = -1: single value
   struct Ent { int32_t a, b, next; };
+  static constexpr int32_t EMPTY = INT32_MIN;
   std::vector<Slot> slots;
   std::vector<Ent> ents;
   size_t mask = 0, used = 0;
   explicit FlatMultiMap(size_t expect = 1024) { size_t c = 1024; while (c < expect * 2) c <<= 1; resize(c); }
   void resize(size_t c) {
     std::vector<Slot> old; old.swap(slots);
-    slots.assign(c, Slot{0, -1, -1}); mask = c - 1; used = 0;
-    for (const Slot& o : old) if (o.head >= 0) { slots[slot(o.key)] = o; used++; }
+    slots.assign(c, Slot{0, 0, 0, EMPTY, -1}); mask = c - 1; used = 0;
+    for (const Slot& o : old) if (o.next != EMPTY) { slots[slot(o.key)] = o; used++; }
   }
-  size_t slot(uint64_t k) const { size_t s = fm_mix(k) & mask; while (slots[s].head >= 0 && slots[s].key != k) s = (s + 1) & mask; return s; }
+  size_t slot(uint64_t k) const { size_t s = fm_mix(k) & mask; while (slots[s].next != EMPTY && slots[s].key != k) s = (s + 1) & mask; return s; }
   void prefetch(uint64_t k) const { __builtin_prefetch(&slots[fm_mix(k) & mask]); }
-  // first value index of k or -1; iterate with nxt()
-  int32_t find(uint64_t k) const { return slots[slot(k)].head; }
-  int32_t va(int32_t v) const { return ents[v].a; }
-  int32_t vb(int32_t v) const { return ents[v].b; }
-  int32_t nxt(int32_t v) const { return ents[v].next; }
-  // append (a, b) to k's list and return the head the list had BEFORE (or -1): one probe for "look up, then insert"
-  int32_t add(uint64_t k, int32_t a, int32_t b = 0) {
+  // first value handle of k or -1; iterate with nxt()
+  int32_t find(uint64_t k) const { size_t s = slot(k); return slots[s].next == EMPTY ? -1 : -(int32_t)s - 2; }
+  int32_t va(int32_t v) const { return v >= 0 ? ents[v].a : slots[(size_t)(-(v + 2))].a; }
+  int32_t vb(int32_t v) const { return v >= 0 ? ents[v].b : slots[(size_t)(-(v + 2))].b; }
+  int32_t nxt(int32_t v) const { return v >= 0 ? ents[v].next : slots[(size_t)(-(v + 2))].next; }
+  // append (a, b) to k's list; returns the first handle the list had BEFORE (or -1) and, in *mine, the handle of the new
+  // value: one probe for "look up, then insert" (iterate from the returned handle until *mine)
+  int32_t add(uint64_t k, int32_t a, int32_t b = 0, int32_t* mine = nullptr) {
     if ((used + 1) * 10 > (mask + 1) * 6) resize((mask + 1) * 2);
-    Slot& sl = slots[slot(k)];
-    const int32_t before = sl.head;
-    int32_t v = (int32_t)ents.size();
+    const size_t s = slot(k);
+    Slot& sl = slots[s];
+    if (sl.next == EMPTY) {
+      sl.key = k; sl.a = a; sl.b = b; sl.next = -1; sl.tail = -1; used++;
+      if (mine) *mine = -(int32_t)s - 2;
+      return -1;
+    }
+    const int32_t v = (int32_t)ents.size();
     ents.push_back(Ent{a, b, -1});
-    if (sl.head < 0) { sl.key = k; sl.head = v; sl.tail = v; used++; }
-    else { ents[sl.tail].next = v; sl.tail = v; }
-    return before;
+    if (sl.tail < 0) sl.next = v; else ents[sl.tail].next = v;
+    sl.tail = v;
+    if (mine) *mine = v;
+    return -(int32_t)s - 2;
   }
 };
 

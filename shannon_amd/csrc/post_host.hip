@@ -56,20 +56,20 @@ extern "C" int shn_find_reps(const uint8_t* names, const uint64_t* name_off, con
       key_of(s, L, 0, flip == 1, kf);
       key_of(s, L, L - r, flip == 1, kl);
       int32_t vf = index.find(kf), vl = index.find(kl);
-      if (vf < 0 || vl < 0) continue;
+      if (vf == -1 || vl == -1) continue;
       pos.clear();
       auto slot = [&](int32_t o) -> std::pair<int64_t, int64_t>& {
         for (auto& e : pos) if (e.first == o) return e.second;
         pos.push_back({o, {-2, -2}});                      // -2 = "key not created by this list"
         return pos.back().second;
       };
-      for (int32_t v = vf; v >= 0; v = index.nxt(v)) {
+      for (int32_t v = vf; v != -1; v = index.nxt(v)) {
         int32_t o = index.va(v);
         if (o == (int32_t)id) continue;
         auto& e = slot(o);
         if (e.first == -2 && e.second == -2) e = {index.vb(v), -1}; else e.first = index.vb(v);
       }
-      for (int32_t v = vl; v >= 0; v = index.nxt(v)) {
+      for (int32_t v = vl; v != -1; v = index.nxt(v)) {
         int32_t o = index.va(v);
         if (o == (int32_t)id) continue;
         auto& e = slot(o);
