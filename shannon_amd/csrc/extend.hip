@@ -9,13 +9,20 @@
 // result is the unique fixpoint (walk 0 is right after one iteration, walk r once every walk < r
 // it touches is right), so iterating until no walk changes reproduces the reference exactly.
 //
-// The iteration is change-driven (a worklist): claims persist in one array; after a round every k1-mer
-// whose owner changed marks as dirty the walks that examined it -- the old and new owners of the k1-mer and
-// of its 8 neighbours, and the walk seeded on it.  Only dirty walks run in the next round, after their old
-// claims have been released; the round count stays the dependency depth of the data, but a round costs the
-// affected walks, not all of them.  A consistent state (no dirty walk) is the unique fixpoint = the
-// sequential result.  Long walks keep their previous path (memo): a wavefront re-checks 64 consecutive old
-// steps at once and walks sequentially only from the first changed decision until the path rejoins.
+// The iteration is change-driven (a worklist): claims persist in one array; after a round every k1-mer whose
+// owner changed marks as dirty the walks whose view it changes -- the walks standing next to it (owners of its 8
+// neighbours) and the walk seeded on it, and only those for which it BECAME available (old owner < walk < new
+// owner).  Only dirty walks run in the next round, after their old claims have been released; the round count
+// stays the dependency depth of the data, but a round costs the affected walks, not all of them.  A consistent
+// state (no dirty walk) is the unique fixpoint = the sequential result.
+// Memos: after every round the path of each walk that ran alive is rebuilt from the claims into a memo slot, and
+// every k1-mer remembers the (walk, step) it was written under (hint).  A wavefront re-checks 64 memo steps per
+// memory round trip -- of its own memo, or of the memo of whatever walk last owned the k1-mer it reached, in either
+// direction -- and walks sequentially only in between.  Memos are hints: every entry is validated against the
+// hint of its k1-mer, and a changed decision is re-made against the live claims.
+// Short walks run one per thread; one that turns out long hands over to a wavefront in the same round.
+// shn_extend_sharded: walks never leave their connected component of the k1-mer graph, so the components (GPU
+// union-find over the adjacency rows) can be dealt to several ranks.
 //
 // Oriented k1-mers: the count table stores canonical keys; oriented id o = 2*i + s is the string
 // key_i (s=0) or its reverse complement (s=1; unused for palindromes).  Both strands are walked,
@@ -60,7 +67,6 @@ struct shn_ext {
   uint32_t* d_nr;        // [n_seeds] right steps (UNCLAIMED = void walk)
   uint32_t* d_nl;        // [n_seeds]
   uint64_t* d_totw;      // [n_seeds] sum of weights incl. the seed
-  uint64_t* d_hash;      // [n_seeds] path hash of the last iteration
 };
 
 __device__ __forceinline__ uint64_t oriented_string(const uint64_t* __restrict__ tkeys, uint32_t o, int k) {
@@ -240,19 +246,16 @@ __device__ __forceinline__ void claim_node(const WalkArgs& A, uint32_t node, uin
 // One greedy decision (extension_correction.py:223-237): among the candidates that exist and are not
 // traversed pick the heaviest, ties in BASES order A,G,C,T (codes 0,2,1,3; strict >).  Traversed = claimed
 // live by a rank <= r (lower ranks of this round, or this walk's own trail), or claimed in the pre-round
-// snapshot by a lower rank.  `extra` returns the hint of the chosen candidate (rejoin test).
-template <bool HINT>
+// snapshot by a lower rank.
 __device__ __forceinline__ int decide(const Adj4& cand, uint32_t r, const u64* claim, const u64* __restrict__ claim_old,
-                                      const uint32_t* __restrict__ weight, const u64* __restrict__ hint, uint32_t dummy,
-                                      uint32_t& bw, u64& chosen_hint) {
-  u64 cl[4], co[4], ch[4];
+                                      const uint32_t* __restrict__ weight, uint32_t dummy, uint32_t& bw) {
+  u64 cl[4], co[4];
   uint32_t w[4];
 #pragma unroll
   for (int b = 0; b < 4; b++) {
     uint32_t idx = cand.v[b] < 0 ? dummy : (uint32_t)cand.v[b];
     cl[b] = __hip_atomic_load(&claim[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     co[b] = claim_old[idx];
-    ch[b] = HINT ? hint[idx] : UNCLAIMED64;
     w[b] = weight[idx >> 1];
   }
   int best = -1;
@@ -260,7 +263,6 @@ __device__ __forceinline__ int decide(const Adj4& cand, uint32_t r, const u64* c
 #define CONSIDER(b) if (cand.v[b] >= 0 && RANK(cl[b]) > r && RANK(co[b]) >= r && (best < 0 || w[b] > bw)) { best = b; bw = w[b]; }
   CONSIDER(0) CONSIDER(2) CONSIDER(1) CONSIDER(3)
 #undef CONSIDER
-  chosen_hint = best < 0 ? UNCLAIMED64 : (best == 0 ? ch[0] : best == 1 ? ch[1] : best == 2 ? ch[2] : ch[3]);
   return best;
 }
 
@@ -426,8 +428,8 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
           bool valid = before != NONE32 && (is_term || (expect != NONE32 && A.hint[expect] == CLAIM(mc.owner, (uint32_t)s + 1)));
           if (valid) {
             Adj4 cd = adj[before];
-            uint32_t bw; u64 hh;
-            int b = decide<false>(cd, r, A.claim, A.claim_old, A.weight, A.hint, o, bw, hh);
+            uint32_t bw;
+            int b = decide(cd, r, A.claim, A.claim_old, A.weight, o, bw);
             uint32_t chosen = b < 0 ? NONE32 : (uint32_t)cd.v[b];
             ok = chosen == expect;
           }
@@ -697,7 +699,7 @@ extern "C" void shn_ext_destroy(shn_ext* e) {
   if (!e) return;
   hipSetDevice(e->device);
   void* ptrs[] = {e->d_weight, e->d_flags, e->d_adjR, e->d_adjL, e->d_order, e->d_claim, e->d_claim2, e->d_nr, e->d_nl,
-                  e->d_totw, e->d_hash};
+                  e->d_totw};
   for (void* p : ptrs) if (p) shn_dev_free(p);
   delete e;
 }
