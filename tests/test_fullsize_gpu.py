@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N_READS = 10_000_000
 K = 25
 K1 = K + 1
+K1S = [26, 32]          # -K 25 (BASELINE) and -K 31 (64-bit keys, configs[4])
 
 
 def _rc_keys(keys, k):
@@ -56,7 +57,8 @@ def _brute_count(codes, key, k):
     return total
 
 
-def test_fullsize_count_properties(batch):
+@pytest.mark.parametrize("K1", K1S)
+def test_fullsize_count_properties(batch, K1):
     from shannon_amd import device
     ctx, r1, r2, d1, d2 = batch
     W = 100 - K1 + 1
@@ -95,7 +97,8 @@ def test_fullsize_count_properties(batch):
         t.close(); ta.close(); tb.close()
 
 
-def test_fullsize_extension_properties(batch):
+@pytest.mark.parametrize("K1", K1S)
+def test_fullsize_extension_properties(batch, K1):
     from shannon_amd import device, extension_correction as ec
     ctx, r1, r2, d1, d2 = batch
     t = device.count_k1mers(ctx, [d1, d2], K1, both_strands=True)
