@@ -228,7 +228,7 @@ struct WalkArgs {
   // memo: the path of the walk's last live run, rebuilt from the claims after every round it ran alive
   // (ext_memo_plan_kernel + the scatter in ext_mark_kernel).  Hints only -- every use is validated.
   const uint32_t* pool; const uint64_t* moff; const uint32_t* mR; const uint32_t* mL; const uint8_t* mvalid;
-  const u64* hint;       // per k1-mer: (walk, step) under which it was last written into a memo
+  const uint32_t* hint;  // per k1-mer: where it was last written into a memo (pool index << 2 | kind), NOHINT if never
   unsigned long long* steps_counter;
   unsigned long long* wave_steps_counter;
   unsigned long long* dbg;     // [0] wave steps confirmed from an own memo [1] from a foreign memo
@@ -270,7 +270,8 @@ __device__ __forceinline__ int decide(const Adj4& cand, uint32_t r, const u64* c
 __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_walks, const uint32_t* __restrict__ list,
                                                         const u64* __restrict__ snap) {
   __shared__ unsigned long long blk_steps;
-  if (threadIdx.x == 0) blk_steps = 0;
+  __shared__ uint32_t blk_promo[EBLK], n_promo, promo_base;      // walks handed over: one global atomic per block
+  if (threadIdx.x == 0) { blk_steps = 0; n_promo = 0; }
   __syncthreads();
   uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t mysteps = 0;
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
           if (pos >= A.promote_steps) {            // long after all: a wavefront takes over from here (memos, 64 steps a trip)
             A.res_cur[r] = nbest;
             A.res_info[r] = ((uint32_t)dir << 31) | pos;
-            A.promo_list[atomicAdd(A.promo_count, 1ULL)] = r;
+            blk_promo[atomicAdd(&n_promo, 1u)] = r;
             promoted = true;
             break;
           }
@@ -333,7 +334,12 @@ __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
   }
   if (mysteps) atomicAdd(&blk_steps, (unsigned long long)mysteps);
   __syncthreads();
-  if (threadIdx.x == 0 && blk_steps) atomicAdd(A.steps_counter, blk_steps);
+  if (threadIdx.x == 0) {
+    if (blk_steps) atomicAdd(A.steps_counter, blk_steps);
+    promo_base = n_promo ? (uint32_t)atomicAdd(A.promo_count, (unsigned long long)n_promo) : 0u;
+  }
+  __syncthreads();
+  if (threadIdx.x < n_promo) A.promo_list[promo_base + threadIdx.x] = blk_promo[threadIdx.x];
 }
 
 // ---- long walks: one wavefront per dirty walk.  A memo (the path of some walk's last live run, own or foreign)
@@ -343,34 +349,34 @@ __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
 // that memo (so the validated entries of a chunk are pairwise distinct), and a changed decision is re-made
 // sequentially against the live claims, never taken from the speculative lane.
 #define NONE32 0xFFFFFFFFu
-struct MemoCursor { const uint32_t* p; uint32_t owner; int32_t i; uint32_t n; int32_t step; bool term; };
-// i = memo index of the next expected step, n = entries left, step = +1 / -1 (a memo can be followed against the
-// direction its walk took), term = the segment ends where that walk ended (then "stop" is the expected decision)
+__device__ __forceinline__ bool is_term_any(bool term, bool at_mark) { return term && at_mark; }
+// Memo slots are never rewritten: a walk that runs again gets a new slot, so a hint always leads to an intact old path.
+//   slot = [MARK][nR | HI][seed][R_1 .. R_nR][MARK][L_1 .. L_nL][MARK]       (HI = top bit; k1-mer ids are < 2^31)
+// Every word with the top bit set ends a segment: marks, the header, and the NONE32 holes of steps that were robbed.
+#define MEMO_MARK 0xFFFFFFFEu
+#define MEMO_HI 0x80000000u
+#define NOHINT 0xFFFFFFFFu
+#define HINT_R 0u
+#define HINT_L 1u
+#define HINT_SEED 2u
+struct MemoCursor { int64_t i; int32_t step; bool term; };
+// i = pool index of the next expected step, step = +1 / -1 (a memo can be followed against the direction its walk
+// took), term = the segment ends where that walk ended (then "stop" is the expected decision at its mark)
 
-// `node` was just reached going in direction dir; its hint says it is step POS of walk RANK's memo: follow that memo
-__device__ __forceinline__ bool memo_follow(const WalkArgs& A, uint64_t n_walks, u64 hh, uint32_t node, int dir, MemoCursor& mc) {
-  const uint32_t q = RANK(hh), pos = POS(hh);
-#define WHY(i) do { if (A.dbg && threadIdx.x == 0) atomicAdd(&A.dbg[i], 1ULL); } while (0)
-  if (q >= n_walks) { WHY(2); return false; }                     // never written into a memo
-  if (!A.mvalid[q]) { WHY(3); return false; }
-  const uint32_t qR = A.mR[q], qL = A.mL[q];
-  const uint32_t* fp = A.pool + A.moff[q];
-  int32_t i, step;
-  uint32_t n;
-  bool term;
-  if (pos == 0) {                                                   // q's seed: its part of my direction, forwards
-    if (A.order[q] != node) { WHY(4); return false; }
-    i = dir == 0 ? 0 : (int32_t)qR; n = dir == 0 ? qR : qL; step = 1; term = true;
-  } else {
-    if (pos > qR + qL || fp[pos - 1] != node) { WHY(4); return false; }      // the memo has moved on
-    const bool right = pos <= qR;
-    if (right == (dir == 0)) { i = (int32_t)pos; n = (right ? qR : qR + qL) - pos; step = 1; term = true; }
-    else { i = (int32_t)pos - 2; n = right ? pos - 1 : pos - 1 - qR; step = -1; term = false; WHY(5); }   // back along q's path
-  }
-  if (n == 0 && !term) { WHY(6); return false; }
+// `node` was just reached going in direction dir; its hint says where it sits in some memo: follow that memo
+__device__ __forceinline__ bool memo_follow(const WalkArgs& A, uint32_t hh, uint32_t node, int dir, MemoCursor& mc, uint32_t* why = nullptr) {
+#define WHY(i) do { if (A.dbg && threadIdx.x == 0) atomicAdd(&A.dbg[i], 1ULL); if (why) why[i]++; } while (0)
+  if (hh == NOHINT) { WHY(2); return false; }                     // never written into a memo
+  const int64_t idx = (int64_t)(hh >> 2);
+  const uint32_t kind = hh & 3u;
+  if (A.pool[idx] != node) { WHY(4); return false; }              // (cannot happen while slots are not recycled)
+  if (kind == HINT_SEED) {                                          // the walk's part of my direction, forwards
+    const uint32_t nR = A.pool[idx - 1] & ~MEMO_HI;
+    mc.i = dir == 0 ? idx + 1 : idx + 2 + (int64_t)nR; mc.step = 1; mc.term = true;
+  } else if ((kind == HINT_R) == (dir == 0)) { mc.i = idx + 1; mc.step = 1; mc.term = true; }
+  else { mc.i = idx - 1; mc.step = -1; mc.term = false; WHY(5); }    // back along that walk's path (its seed included)
   WHY(7);
 #undef WHY
-  mc.p = fp; mc.owner = q; mc.i = i; mc.n = n; mc.step = step; mc.term = term;
   return true;
 }
 
@@ -404,34 +410,44 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
     if (lane == 0) claim_node(A, o, r, 0);
   }
   const uint32_t ns_start = ns;
+  uint32_t nseq = 0;                          // sequential steps (debug statistics)
+  uint32_t why[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int dir = dir0; dir < 2; dir++) {
     const Adj4* adj = dir == 0 ? A.adjR : A.adjL;
     uint32_t cur = (RESUME && dir == dir0) ? cur0 : o;
     MemoCursor mc;
     // own memo first (its steps of this direction), else whatever memo the k1-mer was last written into
-    bool following = (RESUME && dir == dir0) ? memo_follow(A, n_walks, A.hint[cur], cur, dir, mc)
-                                             : (memo_follow(A, n_walks, CLAIM(r, 0), o, dir, mc) || memo_follow(A, n_walks, A.hint[o], o, dir, mc));
+    bool following;
+    if (RESUME && dir == dir0) following = memo_follow(A, A.hint[cur], cur, dir, mc);
+    else {
+      const uint32_t own = A.mvalid[r] ? (uint32_t)(((A.moff[r] + 2) << 2) | HINT_SEED) : NOHINT;
+      following = memo_follow(A, own, o, dir, mc) || memo_follow(A, A.hint[o], o, dir, mc);
+    }
     uint32_t cool = 0;                        // sequential steps to take before trusting a memo again
     Adj4 cand = {{-1, -1, -1, -1}};           // row of `cur` while walking sequentially
     bool have_cand = false;
     while (true) {
       if (following) {
-        const uint32_t nchunk = min(64u, mc.n);             // memo steps covered by this trip
-        const int32_t s = mc.i + lane * mc.step;            // memo index of this lane's step
-        const bool is_term = mc.term && (uint32_t)lane == nchunk && nchunk < 64u;   // one past the walk's end: would decide "stop"
+        // 64 memo steps per trip.  A word with the top bit set (mark, header, hole) ends the segment; going backwards
+        // the segment also ends after the memo walk's seed (the word before a seed is its header).
+        const int64_t pi = mc.i + (int64_t)lane * mc.step;  // pool index of this lane's step
+        const uint32_t mine = A.pool[pi];
+        const u64 stopm = __ballot((mine & MEMO_HI) != 0);
+        const uint32_t nchunk = stopm ? (uint32_t)(__ffsll((long long)stopm) - 1) : 64u;   // steps before the first stop word
+        const bool at_mark = nchunk < 64u && __shfl(mine, (int)nchunk, 64) == MEMO_MARK;
+        const bool is_term = mc.term && at_mark && (uint32_t)lane == nchunk;    // the memo walk stopped here: would I?
         const bool checked = (uint32_t)lane < nchunk || is_term;
         bool ok = false;
         if (checked) {
-          const uint32_t before = lane == 0 ? cur : mc.p[s - mc.step];
-          const uint32_t expect = is_term ? NONE32 : mc.p[s];
-          // memo position of entry s is s+1 (pos 0 = seed); lane-1 vouches for `before`
-          bool valid = before != NONE32 && (is_term || (expect != NONE32 && A.hint[expect] == CLAIM(mc.owner, (uint32_t)s + 1)));
+          const uint32_t before = lane == 0 ? cur : A.pool[pi - mc.step];
+          // an entry counts only if its k1-mer's hint points at exactly this pool word (validated entries are distinct)
+          bool valid = is_term || (A.hint[mine] >> 2) == (uint32_t)pi;
           if (valid) {
             Adj4 cd = adj[before];
             uint32_t bw;
             int b = decide(cd, r, A.claim, A.claim_old, A.weight, o, bw);
             uint32_t chosen = b < 0 ? NONE32 : (uint32_t)cd.v[b];
-            ok = chosen == expect;
+            ok = chosen == (is_term ? NONE32 : mine);
           }
         }
         const u64 bad = __ballot(checked && !ok);
@@ -439,21 +455,19 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
         const uint32_t conf = min(m, nchunk);               // confirmed memo steps: lanes [0, conf)
         uint64_t myw = 0;
         if ((uint32_t)lane < conf) {
-          uint32_t node = mc.p[s];
-          claim_node(A, node, r, ns + lane + 1);
-          myw = A.weight[node >> 1];
+          claim_node(A, mine, r, ns + lane + 1);
+          myw = A.weight[mine >> 1];
         }
         for (int off = 32; off > 0; off >>= 1) myw += __shfl_xor(myw, off, 64);
         tot += myw;
-        if (conf > 0) cur = mc.p[mc.i + ((int32_t)conf - 1) * mc.step];
-        if (A.dbg && lane == 0 && conf) atomicAdd(&A.dbg[mc.owner == r ? 0 : 1], (unsigned long long)conf);
+        if (conf > 0) cur = __shfl(mine, (int)conf - 1, 64);
+        if (A.dbg && lane == 0 && conf) atomicAdd(&A.dbg[1], (unsigned long long)conf);
         ns += conf;
-        mc.i += (int32_t)conf * mc.step;
-        mc.n -= conf;
+        mc.i += (int64_t)conf * mc.step;
         if (m == 64u) {
           if (nchunk < 64u) {
-            if (mc.term) break;               // the terminal lane agreed: the walk ends where the memo's walk ended
-            following = false;                // a segment followed backwards just runs out: go on from its last k1-mer
+            if (is_term_any(mc.term, at_mark)) break;      // the terminal lane agreed: the walk ends where the memo's walk ended
+            following = false;                // the segment just runs out (hole, or followed backwards): go on from its last k1-mer
             have_cand = false;
           }
           continue;
@@ -468,7 +482,7 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
       // memory round trip), the decision is made by everybody from the shuffled weights
       if (!have_cand) cand = adj[cur];
       const int myc = lane == 0 ? cand.v[0] : lane == 1 ? cand.v[1] : lane == 2 ? cand.v[2] : lane == 3 ? cand.v[3] : -1;
-      u64 hmy = UNCLAIMED64;
+      uint32_t hmy = NOHINT;
       uint32_t wmy = 0;
       Adj4 row = {{-1, -1, -1, -1}};
       bool avail = false;
@@ -489,18 +503,24 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
       CONSIDER(0, w0) CONSIDER(2, w2) CONSIDER(1, w1) CONSIDER(3, w3)
 #undef CONSIDER
       const uint32_t taken = (uint32_t)__shfl(myc, best, 64);
-      const u64 hh = ((u64)(uint32_t)__shfl((int)(hmy >> 32), best, 64) << 32) | (u64)(uint32_t)__shfl((int)(uint32_t)hmy, best, 64);
+      const uint32_t hh = (uint32_t)__shfl((int)hmy, best, 64);
       cand.v[0] = __shfl(row.v[0], best, 64); cand.v[1] = __shfl(row.v[1], best, 64);
       cand.v[2] = __shfl(row.v[2], best, 64); cand.v[3] = __shfl(row.v[3], best, 64);
       have_cand = true;
       if (lane == 0) claim_node(A, taken, r, ns + 1);
       tot += bw;
       ns++;
+      nseq++;
       cur = taken;
       if (cool) cool--;
-      else following = memo_follow(A, n_walks, hh, taken, dir, mc);
+      else following = memo_follow(A, hh, taken, dir, mc, why);
     }
     if (dir == 0) nr_new = ns;
+  }
+  if (A.dbg && lane == 0) {
+    atomicMax(&A.dbg[10], ((unsigned long long)nseq << 48) | ((unsigned long long)min(why[2], 4095u) << 36) | ((unsigned long long)min(why[3], 4095u) << 24) |
+                              ((unsigned long long)min(why[4], 4095u) << 12) | (unsigned long long)min(why[7], 4095u));
+    atomicMax(&A.dbg[11], (unsigned long long)(ns - ns_start));
   }
   if (lane == 0) {
     A.nr_out[r] = nr_new;
@@ -545,15 +565,14 @@ __global__ void ext_plan_kernel(const uint32_t* __restrict__ nr, const uint32_t*
   if (isd && !lg) short_list[sbase + __popcll(sm & below)] = (uint32_t)r;
 }
 
-// after the walkers: give every walk that ran alive and is long enough a memo slot for its new path (filled from
-// the claims by ext_mark_kernel).  A slot is reused while the path fits; slots are never handed out twice, so a
-// fresh slot still holds the NONE32 fill of the pool.
+// after the walkers: every walk that ran alive and is long enough gets a NEW memo slot for its new path (filled from
+// the claims by ext_mark_kernel); old slots stay as they are -- the hints of k1-mers the walk no longer owns still lead
+// to an intact path.  When the pool is full, no more memos are made (they only save time).
 __global__ void ext_memo_plan_kernel(uint8_t* __restrict__ ran, uint8_t* __restrict__ dirty, uint32_t* __restrict__ owned,
-                                     const uint32_t* __restrict__ nr, const uint32_t* __restrict__ nl,
-                                     uint32_t frozen, uint32_t limit, uint64_t* __restrict__ moff, uint32_t* __restrict__ mcap,
-                                     uint32_t* __restrict__ mR, uint32_t* __restrict__ mL, uint8_t* __restrict__ mvalid,
-                                     uint8_t* __restrict__ fill, unsigned long long* __restrict__ cursor, uint64_t pool_cap,
-                                     uint32_t memo_min) {
+                                     const uint32_t* __restrict__ nr, const uint32_t* __restrict__ nl, const uint32_t* __restrict__ order,
+                                     uint32_t frozen, uint32_t limit, uint64_t* __restrict__ moff, uint32_t* __restrict__ mR,
+                                     uint32_t* __restrict__ mL, uint8_t* __restrict__ mvalid, uint8_t* __restrict__ fill,
+                                     uint32_t* __restrict__ pool, unsigned long long* __restrict__ cursor, uint64_t pool_cap, uint32_t memo_min) {
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + frozen;
   if (r >= limit) return;
   const uint8_t did_run = dirty[r];              // end-of-round bookkeeping: who ran, clean slate for the marks
@@ -562,16 +581,15 @@ __global__ void ext_memo_plan_kernel(uint8_t* __restrict__ ran, uint8_t* __restr
   owned[r] = 0;
   uint8_t f = 0;
   if (did_run && nr[r] != UNCLAIMED) {
-    uint32_t len = nr[r] + nl[r];
-    if (len >= memo_min) {
-      bool have = mvalid[r] && len <= mcap[r];
-      if (!have) {
-        uint64_t cap = (uint64_t)len + len / 4 + 8;
-        unsigned long long off = atomicAdd(cursor, (unsigned long long)cap);
-        if (off + cap <= pool_cap) { moff[r] = off; mcap[r] = (uint32_t)cap; have = true; }
-        else mvalid[r] = 0;
+    const uint32_t R = nr[r], L = nl[r];
+    if (R + L >= memo_min) {
+      const uint64_t cap = (uint64_t)R + L + 5;
+      const unsigned long long off = atomicAdd(cursor, (unsigned long long)cap);
+      if (off + cap + 64 <= pool_cap) {
+        pool[off] = MEMO_MARK; pool[off + 1] = R | MEMO_HI; pool[off + 2] = order[r];
+        pool[off + 3 + R] = MEMO_MARK; pool[off + 4 + R + L] = MEMO_MARK;
+        moff[r] = off; mR[r] = R; mL[r] = L; mvalid[r] = 1; f = 1;
       }
-      if (have) { mR[r] = nr[r]; mL[r] = nl[r]; mvalid[r] = 1; f = 1; }
     }
   }
   fill[r] = f;
@@ -595,8 +613,8 @@ __global__ void ext_mark_kernel(const u64* __restrict__ claim, const u64* __rest
                                 const Adj4* __restrict__ adjR, const Adj4* __restrict__ adjL, const uint32_t* __restrict__ seed_rank,
                                 uint8_t* __restrict__ dirty, const uint8_t* __restrict__ ran, uint32_t* __restrict__ owned,
                                 unsigned long long* __restrict__ n_changed, uint32_t frozen, uint32_t limit,
-                                const uint8_t* __restrict__ fill, const uint64_t* __restrict__ moff, uint32_t* __restrict__ pool,
-                                u64* __restrict__ hint) {
+                                const uint8_t* __restrict__ fill, const uint64_t* __restrict__ moff, const uint32_t* __restrict__ mR,
+                                uint32_t* __restrict__ pool, uint32_t* __restrict__ hint) {
   // grid-stride: the change counter costs one atomic per block (one per wavefront on a single address was the
   // most expensive thing in this kernel)
   uint32_t my_changed = 0;
@@ -606,10 +624,11 @@ __global__ void ext_mark_kernel(const u64* __restrict__ claim, const u64* __rest
     const uint32_t b = RANK(cy);
     if (b != UNCLAIMED && ran[b]) {
       atomicAdd(&owned[b], 1u);                                   // for ext_verify_kernel
-      if (fill[b]) {
-        uint32_t pos = POS(cy);
-        if (pos >= 1) pool[moff[b] + pos - 1] = (uint32_t)y;
-        hint[y] = cy;
+      if (fill[b]) {                                              // slot layout: see MemoCursor
+        const uint32_t pos = POS(cy), R = mR[b];
+        const uint64_t idx = moff[b] + (pos <= R ? 2 : 3) + pos;
+        if (pos) pool[idx] = (uint32_t)y;
+        hint[y] = (uint32_t)(idx << 2) | (pos == 0 ? HINT_SEED : pos <= R ? HINT_R : HINT_L);
       }
     }
     if (a == b) continue;
@@ -805,7 +824,9 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   TRYE(shn_dev_malloc(&e->d_nr, (ns + 1) * 4));
   TRYE(shn_dev_malloc(&e->d_nl, (ns + 1) * 4));
   TRYE(shn_dev_malloc(&e->d_totw, (ns + 1) * 8));
-  const uint64_t pool_cap = 24 * n + (1ULL << 20);         // memo slots are never recycled within a call
+  // memo slots are never recycled within a call (a word per step ever walked by a memo-bearing walk); pool
+  // indices live in 30 bits of a hint
+  const uint64_t pool_cap = std::min<uint64_t>(24 * n + (1ULL << 20), (1ULL << 30) - 1);
   TRYE(hipMemcpyAsync(e->d_order, svals, ns * 4, hipMemcpyDeviceToDevice, s));
   TRYE(hipMemsetAsync(e->d_nr, 0xFF, (ns + 1) * 4, s));
   TRYE(hipMemsetAsync(e->d_nl, 0, (ns + 1) * 4, s));
@@ -813,12 +834,12 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   TRYE(hipMemsetAsync(e->d_claim, 0xFF, (2 * n + 1) * 8, s));
   // scratch: claim snapshot (d_claim2), memo pool + per-k1-mer hints, per-walk plan arrays
   void *ppool, *phint, *pplan, *pseed;
-  if ((rc = g_shn_ws[27].get(pool_cap * 4, &ppool)) || (rc = g_shn_ws[29].get((2 * n + 2) * 8, &phint)) ||
+  if ((rc = g_shn_ws[27].get(pool_cap * 4, &ppool)) || (rc = g_shn_ws[29].get((2 * n + 2) * 4, &phint)) ||
       (rc = g_shn_ws[28].get((ns + 1) * (8 + 4 * 9 + 1 + 1 + 1 + 1) + 64, &pplan)) ||
       (rc = g_shn_ws[24].get((2 * n + 2) * 4, &pseed))) { shn_ext_destroy(e); return rc; }
   u64 *claim = e->d_claim, *snap = e->d_claim2;
   uint32_t* pool = (uint32_t*)ppool;
-  u64* hint = (u64*)phint;
+  uint32_t* hint = (uint32_t*)phint;
   uint64_t* moff = (uint64_t*)pplan;
   uint32_t* mcap = (uint32_t*)(moff + ns + 1);
   uint32_t* mR = mcap + ns + 1;
@@ -836,7 +857,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   uint32_t* seed_rank = (uint32_t*)pseed;
   TRYE(hipMemsetAsync(mvalid, 0, 2 * (ns + 1), s));
   TRYE(hipMemsetAsync(pool, 0xFF, pool_cap * 4, s));            // NONE32: "no entry"
-  TRYE(hipMemsetAsync(hint, 0xFF, (2 * n + 1) * 8, s));
+  TRYE(hipMemsetAsync(hint, 0xFF, (2 * n + 1) * 4, s));
   TRYE(hipMemsetAsync(seed_rank, 0xFF, (2 * n + 1) * 4, s));
   if (ns) hipLaunchKernelGGL(ext_seed_rank_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, e->d_order, (uint64_t)ns, seed_rank);
   hipStream_t aux = nullptr;
@@ -860,7 +881,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   TRYE(hipMemsetAsync(dirty, 0, 2 * (ns + 1), s));               // dirty + ran
   TRYE(hipMemsetAsync(dirty, 1, limit, s));
   TRYE(hipMemsetAsync(owned, 0, (ns + 1) * 4, s));
-  TRYE(hipMemsetAsync(d_cnt + 10, 0, 8, s));                     // memo pool cursor
+  { const unsigned long long c0 = 64;                            // memo pool cursor: 64 words of NONE32 padding in front
+    TRYE(hipMemcpy(d_cnt + 10, &c0, 8, hipMemcpyHostToDevice)); }
   auto tune = [](const char* name, uint32_t dflt) { const char* v = getenv(name); return v ? (uint32_t)strtoul(v, nullptr, 10) : dflt; };
   const uint32_t long_walk = tune("SHN_EXT_LONG_WALK", LONG_WALK), memo_min = tune("SHN_EXT_MEMO_MIN", MEMO_MIN),
                  promote_steps = tune("SHN_EXT_PROMOTE", PROMOTE_STEPS);
@@ -912,25 +934,27 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     if (plan[0]) TRYE(hipStreamWaitEvent(s, ev_join, 0));
     // who has to run next round?  walks whose view changed (mark) + walks that lost a claim race (verify);
     // the walks that ran get their memo rebuilt from the claims
-    hipLaunchKernelGGL(ext_memo_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 256)), dim3(256), 0, s, ran, dirty, owned, e->d_nr, e->d_nl, frozen, limit,
-                       moff, mcap, mR, mL, mvalid, fill, d_cnt + 10, pool_cap, memo_min);
+    hipLaunchKernelGGL(ext_memo_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 256)), dim3(256), 0, s, ran, dirty, owned, e->d_nr, e->d_nl, e->d_order, frozen, limit,
+                       moff, mR, mL, mvalid, fill, pool, d_cnt + 10, pool_cap, memo_min);
     { TimerRegion tk(ctx, T_EXT_MARK);
       hipLaunchKernelGGL(ext_mark_kernel, dim3(std::min<uint32_t>(g2n, 4096u)), dim3(256), 0, s, claim, snap, 2 * n, (const Adj4*)e->d_adjR, (const Adj4*)e->d_adjL,
-                         seed_rank, dirty, ran, owned, d_cnt + 6, frozen, limit, fill, moff, pool, hint); }
+                         seed_rank, dirty, ran, owned, d_cnt + 6, frozen, limit, fill, moff, mR, pool, hint); }
     hipLaunchKernelGGL(ext_verify_kernel, dim3((uint32_t)cdiv(limit, 256)), dim3(256), 0, s, ran, owned, e->d_nr, e->d_nl, (uint64_t)limit, dirty);
     if (getenv("SHN_EXT_ALLDIRTY")) { TRYE(hipMemsetAsync(dirty, 0, ns + 1, s)); TRYE(hipMemsetAsync(dirty + frozen, 1, limit - frozen, s)); }
     it++;
 
     if (getenv("SHN_DEBUG")) {
-      unsigned long long chg = 0, cur = 0;
+      unsigned long long chg = 0, cur = 0, mx[2] = {0, 0};
       TRYE(hipMemcpyAsync(&chg, d_cnt + 6, 8, hipMemcpyDeviceToHost, s));
       TRYE(hipMemcpyAsync(&cur, d_cnt + 10, 8, hipMemcpyDeviceToHost, s));
+      TRYE(hipMemcpyAsync(mx, d_cnt + 42, 16, hipMemcpyDeviceToHost, s));
+      TRYE(hipMemsetAsync(d_cnt + 42, 0, 16, s));
       TRYE(hipStreamSynchronize(s));
       static double t_prev = 0;
       timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
       double tn = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
-      fprintf(stderr, "[shn_extend] round %d [%u,%u): dirty=%llu long=%llu short=%llu changed_kmers=%llu pool=%.1f%%  %.2f ms\n", it, frozen, limit,
-              plan[3], plan[0], plan[2], chg, 100.0 * (double)cur / (double)pool_cap, it == 1 ? 0.0 : tn - t_prev);
+      fprintf(stderr, "[shn_extend] round %d [%u,%u): dirty=%llu long=%llu short=%llu changed_kmers=%llu pool=%.1f%% longest wavefront walk: %llu steps, most sequential: %llu (no hint %llu, owner without memo %llu, memo moved on %llu, followed %llu)  %.2f ms\n", it, frozen, limit,
+              plan[3], plan[0], plan[2], chg, 100.0 * (double)cur / (double)pool_cap, mx[1], mx[0] >> 48, (mx[0] >> 36) & 4095, (mx[0] >> 24) & 4095, (mx[0] >> 12) & 4095, mx[0] & 4095, it == 1 ? 0.0 : tn - t_prev);
       t_prev = tn;
     }
   }
