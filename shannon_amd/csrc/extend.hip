@@ -38,9 +38,9 @@
 #define EBLK 256
 #define UNCLAIMED 0xFFFFFFFFu
 #define UNCLAIMED64 0xFFFFFFFFFFFFFFFFULL
-#define LONG_WALK 32          // dirty walks at least this long (last run or memo) get a wavefront
-#define MEMO_MIN 16           // walks at least this long get a memo slot
-#define PROMOTE_STEPS 64      // a thread walker that gets this far hands over to a wavefront
+#define LONG_WALK 8           // dirty walks at least this long (last run or memo) get a wavefront
+#define MEMO_MIN 1            // walks at least this long get a memo slot
+#define PROMOTE_STEPS 16      // a thread walker that gets this far hands over to a wavefront
 typedef unsigned long long u64;
 #define CLAIM(rank, pos) (((u64)(rank) << 32) | (u64)(uint32_t)(pos))
 #define RANK(c) ((uint32_t)((c) >> 32))
