@@ -826,7 +826,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   TRYE(shn_dev_malloc(&e->d_totw, (ns + 1) * 8));
   // memo slots are never recycled within a call (a word per step ever walked by a memo-bearing walk); pool
   // indices live in 30 bits of a hint
-  const uint64_t pool_cap = std::min<uint64_t>(24 * n + (1ULL << 20), (1ULL << 30) - 1);
+  uint64_t pool_cap = std::min<uint64_t>(24 * n + (1ULL << 20), (1ULL << 30) - 1);
+  if (getenv("SHN_EXT_POOL_WORDS")) pool_cap = std::max<uint64_t>(256, std::min<uint64_t>(pool_cap, strtoull(getenv("SHN_EXT_POOL_WORDS"), nullptr, 10)));   // (tests: a full pool only costs time)
   TRYE(hipMemcpyAsync(e->d_order, svals, ns * 4, hipMemcpyDeviceToDevice, s));
   TRYE(hipMemsetAsync(e->d_nr, 0xFF, (ns + 1) * 4, s));
   TRYE(hipMemsetAsync(e->d_nl, 0, (ns + 1) * 4, s));

@@ -128,3 +128,18 @@ def test_component_sharded_walks_union_is_the_unsharded_result(ctx, world):
         assert res.single_contigs == ref.single_contigs and res.remaining == ref.remaining
     finally:
         t.close()
+
+
+@pytest.mark.parametrize("words", [256, 5000, 200000])
+def test_full_memo_pool_only_costs_time(ctx, words, monkeypatch):
+    """Memos are speculation: with a memo pool too small to hold them the walks are the same."""
+    from shannon_amd import device, synth, extension_correction as ec
+    (r1, r2), _ = synth.make_dataset(60000, 20, seed=79)
+    t = device.count_k1mers(ctx, [device.Reads.from_codes(ctx, np.concatenate([r1, r2]))], 26)
+    try:
+        ref = ec.run_correction(ctx, t, 3, 75, 500, want_allowed=False)
+        monkeypatch.setenv("SHN_EXT_POOL_WORDS", str(words))
+        got = ec.run_correction(ctx, t, 3, 75, 500, want_allowed=False)
+        assert got.contigs == ref.contigs and got.connections == ref.connections
+    finally:
+        t.close()
