@@ -149,6 +149,9 @@ int shn_ext_live_stats(shn_ctx* ctx, const shn_ext* e, uint64_t* n_live, uint32_
 int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint64_t n_cand, int k1, int r, double f,
                      int32_t* accepted_out, uint64_t* n_acc_out, uint64_t* conn_off, int32_t* conn_nb, int32_t* conn_w,
                      uint64_t* n_conn);
+/* hit count of the `best` contig (max_till_now, :255-259; 0 = no shared r-mer) of every candidate of the calling thread's
+ * last shn_contig_graph call                                                                                            */
+int shn_contig_best_counts(int32_t* out, uint64_t n_cand);
 
 /* ---- read -> partition routing -----------------------------------------------------------------
  * Replaces the read-streaming loops of kmers_for_component (kmers_for_component.py:322-403;
@@ -175,6 +178,11 @@ int shn_routes_download(shn_ctx* ctx, const shn_routes* r, uint32_t* pid, uint32
  * shn_seed_ends: table value (0 = absent) of the first and of the last K-mer of every read.      */
 int shn_seed_scan(shn_ctx* ctx, const shn_reads* reads, int K, const shn_table* patterns, uint64_t* n_hits,
                   uint32_t* out_read, uint32_t* out_start, uint32_t* out_id);
+/* r-mer join of two sets of sequences on the device: every window of every sequence of `cands` against every occurrence
+ * of the same r-mer in the sequences of `foreign` -> (candidate, window start, foreign sequence) triples in (candidate,
+ * start) order.  Call with out_cand == NULL for *n_hits.  Guard of the component-sharded duplicate_check. */
+int shn_rmer_join(shn_ctx* ctx, const shn_reads* cands, const shn_reads* foreign, int r, uint64_t* n_hits, uint32_t* out_cand,
+                  uint32_t* out_start, uint32_t* out_foreign);
 int shn_seed_ends(shn_ctx* ctx, const shn_reads* reads, int K, const shn_table* patterns, uint32_t* first_id,
                   uint32_t* last_id);
 

@@ -45,6 +45,8 @@ SIGNATURES = {
     "shn_lp_solve_batch": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_uint64, vp]),
     "shn_contig_graph": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_int, C.c_double, vp, u64p, vp, vp, vp, u64p]),
     "shn_seed_scan": (C.c_int, [vp, vp, C.c_int, vp, u64p, vp, vp, vp]),
+    "shn_rmer_join": (C.c_int, [vp, vp, vp, C.c_int, u64p, vp, vp, vp]),
+    "shn_contig_best_counts": (C.c_int, [vp, C.c_uint64]),
     "shn_seed_ends": (C.c_int, [vp, vp, C.c_int, vp, vp, vp]),
     "shn_mbgraph_run": (C.c_int, [vp, C.c_int, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, vpp]),
     "shn_graph_destroy": (None, [vp]),

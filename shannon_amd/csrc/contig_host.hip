@@ -29,6 +29,9 @@ static void window_keys(const uint8_t* s, uint32_t L, int k, std::vector<uint64_
   }
 }
 
+// per candidate of the last shn_contig_graph call of this thread: the hit count of its `best` contig (0: no hit)
+static thread_local std::vector<int32_t> g_best_counts;
+
 struct Conn { std::vector<int32_t> nb; std::vector<int32_t> w; };      // neighbours in dict insertion order + weights
 
 // contigs: n_cand candidate strings (bases[off[i]..off[i+1])), in seed order.
@@ -41,6 +44,7 @@ extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint6
   if (!bases || !off || !accepted_out || !n_acc_out || !n_conn) return shn_fail(SHN_ERR_ARG, "shn_contig_graph: NULL argument");
   static thread_local std::vector<Conn> conns;         // kept between the sizing call and the fill call
   static thread_local std::vector<int32_t> accepted;
+  std::vector<int32_t>& bestcnt = g_best_counts;
   static thread_local uint64_t cached_n = ~0ULL;
   static thread_local const uint8_t* cached_ptr = nullptr;
   if (!(conn_nb && cached_n == n_cand && cached_ptr == bases)) {
@@ -51,6 +55,7 @@ extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint6
     FlatMultiMap rmer(1 << 14), cmer(1 << 14);
     conns.clear(); conns.emplace_back();                 // index 0 unused (contigs are 1-based)
     accepted.assign(n_cand, 0);
+    bestcnt.assign(n_cand, 0);
     std::vector<uint64_t> rk, ck;
     std::vector<int32_t> hits;                              // first value index in rmer (or -1) per window
     std::vector<int32_t> dupcnt(1, 0), touched;             // per accepted contig: shared r-mers with the candidate
@@ -84,6 +89,7 @@ extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint6
       for (int32_t d : touched) dupcnt[d] = 0;
       touched.clear();
       if (dbg) { double t1 = now(); tph[0] += t1 - t0; t0 = t1; }
+      bestcnt[c] = max_till_now;
       bool suspect = false;
       if (best >= 0) {
         cov.assign(L + 1, 0);
@@ -155,5 +161,14 @@ extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint6
     cached_n = ~0ULL; cached_ptr = nullptr;
     conns.clear(); accepted.clear();
   }
+  return SHN_OK;
+}
+
+// hit count of the `best` contig (max_till_now, extension_correction.py:255-259) of every candidate of this thread's
+// last shn_contig_graph call: what the component-sharded duplicate check needs to rule out interference from other shards
+extern "C" int shn_contig_best_counts(int32_t* out, uint64_t n_cand) {
+  if (!out) return shn_fail(SHN_ERR_ARG, "shn_contig_best_counts: NULL argument");
+  if (g_best_counts.size() != n_cand) return shn_fail(SHN_ERR_ARG, "shn_contig_best_counts: no matching shn_contig_graph call");
+  memcpy(out, g_best_counts.data(), n_cand * sizeof(int32_t));
   return SHN_OK;
 }

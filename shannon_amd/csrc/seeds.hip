@@ -5,13 +5,15 @@
 // seed hit (Read.bridges, search_sequence) stay on the host: hits are few.
 #include "common.h"
 #include <cstring>
+#include <algorithm>
 
 #define SBLK2 256
 
 struct SView { const uint64_t* words; const uint64_t* woff; const uint32_t* len; uint64_t n; uint32_t fixed_len, wpr; };
 
-// mode 0: one thread per (read, 64-offset chunk); FILL writes (read, start, id) triples in (read, start) order
-template <bool FILL>
+// mode 0: one thread per (read, offset); FILL writes (read, start, id) triples in (read, start) order.
+// ALL: every window 0..len-K (contig-against-contig 15-mer joins) instead of the interior starts 1..len-K-1
+template <bool FILL, bool ALL>
 __global__ __launch_bounds__(SBLK2) void seed_scan_kernel(SView v, int K, uint32_t max_win, const uint64_t* __restrict__ tkeys,
                                                           const uint32_t* __restrict__ tvals, const uint64_t* __restrict__ boff, int bits,
                                                           uint32_t* __restrict__ counts, const uint64_t* __restrict__ offs,
@@ -19,10 +21,10 @@ __global__ __launch_bounds__(SBLK2) void seed_scan_kernel(SView v, int K, uint32
   uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= v.n * max_win) return;
   uint64_t r = gid / max_win;
-  uint32_t start = (uint32_t)(gid - r * max_win) + 1;              // range(1, len - K)
+  uint32_t start = (uint32_t)(gid - r * max_win) + (ALL ? 0u : 1u);   // range(1, len - K), or every window
   uint32_t len = v.len ? v.len[r] : v.fixed_len;
   uint32_t id = 0;
-  if (len > (uint32_t)K && start < len - K) {
+  if (ALL ? (len >= (uint32_t)K && start <= len - K) : (len > (uint32_t)K && start < len - K)) {
     uint64_t wb = v.woff ? v.woff[r] : r * v.wpr;
     uint64_t key = shn_extract(v.words + wb, start, K);
     int64_t j = shn_table_find(tkeys, boff, bits, key);
@@ -58,22 +60,23 @@ static SView sview(const shn_reads* r) {
 
 // Interior seed hits: every read, every start in [1, len-K): pattern id (table value - 1) if the K-mer is a
 // key of `patterns`.  Call with out_read == NULL to get *n_hits, then with arrays of that size.
-extern "C" int shn_seed_scan(shn_ctx* ctx, const shn_reads* reads, int K, const shn_table* patterns, uint64_t* n_hits,
-                             uint32_t* out_read, uint32_t* out_start, uint32_t* out_id) {
+template <bool ALL>
+static int seed_scan_impl(shn_ctx* ctx, const shn_reads* reads, int K, const shn_table* patterns, uint64_t* n_hits,
+                          uint32_t* out_read, uint32_t* out_start, uint32_t* out_id) {
   if (!ctx || !reads || !patterns || !n_hits) return shn_fail(SHN_ERR_ARG, "shn_seed_scan: NULL argument");
   if (reads->n_invalid) return shn_fail(SHN_ERR_ARG, "shn_seed_scan: reads contain non-ACGT bases");
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   TimerRegion treg(ctx, T_SEEDS);
   SView v = sview(reads);
-  uint32_t max_win = reads->max_len > (uint32_t)K + 1 ? reads->max_len - K - 1 : 0;
+  uint32_t max_win = ALL ? (reads->max_len >= (uint32_t)K ? reads->max_len - K + 1 : 0) : (reads->max_len > (uint32_t)K + 1 ? reads->max_len - K - 1 : 0);
   uint64_t total = v.n * max_win;
   if (total == 0) { *n_hits = 0; return SHN_OK; }
   void *pc, *po;
   int rc;
   if ((rc = g_shn_ws[25].get((total + 1) * 4, &pc)) || (rc = g_shn_ws[26].get((total + 2) * 8, &po))) return rc;
   uint32_t grid = (uint32_t)cdiv(total, SBLK2);
-  hipLaunchKernelGGL(seed_scan_kernel<false>, dim3(grid), dim3(SBLK2), 0, s, v, K, max_win, patterns->d_keys, patterns->d_counts,
+  hipLaunchKernelGGL((seed_scan_kernel<false, ALL>), dim3(grid), dim3(SBLK2), 0, s, v, K, max_win, patterns->d_keys, patterns->d_counts,
                      patterns->d_bucket_off, patterns->bits, (uint32_t*)pc, nullptr, nullptr, nullptr, nullptr);
   uint64_t nh = 0;
   if ((rc = shn_device_scan_u32(ctx, (uint32_t*)pc, total, (uint64_t*)po, &nh))) return rc;
@@ -81,7 +84,7 @@ extern "C" int shn_seed_scan(shn_ctx* ctx, const shn_reads* reads, int K, const 
   if (!out_read || nh == 0) return SHN_OK;
   uint32_t *d_r, *d_s, *d_i;
   HIP_TRY(hipMalloc(&d_r, nh * 4)); HIP_TRY(hipMalloc(&d_s, nh * 4)); HIP_TRY(hipMalloc(&d_i, nh * 4));
-  hipLaunchKernelGGL(seed_scan_kernel<true>, dim3(grid), dim3(SBLK2), 0, s, v, K, max_win, patterns->d_keys, patterns->d_counts,
+  hipLaunchKernelGGL((seed_scan_kernel<true, ALL>), dim3(grid), dim3(SBLK2), 0, s, v, K, max_win, patterns->d_keys, patterns->d_counts,
                      patterns->d_bucket_off, patterns->bits, nullptr, (const uint64_t*)po, d_r, d_s, d_i);
   HIP_TRY(hipMemcpyAsync(out_read, d_r, nh * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(out_start, d_s, nh * 4, hipMemcpyDeviceToHost, s));
@@ -92,6 +95,10 @@ extern "C" int shn_seed_scan(shn_ctx* ctx, const shn_reads* reads, int K, const 
   return SHN_OK;
 }
 
+extern "C" int shn_seed_scan(shn_ctx* ctx, const shn_reads* reads, int K, const shn_table* patterns, uint64_t* n_hits,
+                             uint32_t* out_read, uint32_t* out_start, uint32_t* out_id) {
+  return seed_scan_impl<false>(ctx, reads, K, patterns, n_hits, out_read, out_start, out_id);
+}
 // first_id[r] / last_id[r] = table value (0 = absent) of the first / last K-mer of read r
 extern "C" int shn_seed_ends(shn_ctx* ctx, const shn_reads* reads, int K, const shn_table* patterns, uint32_t* first_id,
                              uint32_t* last_id) {
@@ -110,6 +117,101 @@ extern "C" int shn_seed_ends(shn_ctx* ctx, const shn_reads* reads, int K, const 
   HIP_TRY(hipMemcpyAsync(last_id, d_b, v.n * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   hipFree(d_a); hipFree(d_b);
+  HIP_TRY(hipGetLastError());
+  return SHN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// r-mer join of two sets of sequences: every window of every sequence of `cands` against every occurrence of the same
+// r-mer in the sequences of `foreign` -> (candidate, window start, foreign sequence) triples.  This feeds the guard of the
+// component-sharded duplicate check.  Device: window keys of the foreign sequences sorted by key, every
+// candidate window binary-searches its run.
+__global__ void fs_keys_kernel(SView v, int K, uint32_t max_win, uint64_t* __restrict__ keys, uint32_t* __restrict__ ids,
+                               const uint64_t* __restrict__ offs, uint32_t* __restrict__ counts) {
+  uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= v.n * max_win) return;
+  uint64_t r = gid / max_win;
+  uint32_t start = (uint32_t)(gid - r * max_win);
+  uint32_t len = v.len ? v.len[r] : v.fixed_len;
+  bool have = len >= (uint32_t)K && start <= len - K;
+  if (counts) { counts[gid] = have ? 1u : 0u; return; }
+  if (!have) return;
+  uint64_t wb = v.woff ? v.woff[r] : r * v.wpr;
+  uint64_t o = offs[gid];
+  keys[o] = shn_extract(v.words + wb, start, K);
+  ids[o] = (uint32_t)r;
+}
+__device__ __forceinline__ uint64_t fs_lower_bound(const uint64_t* __restrict__ a, uint64_t n, uint64_t key) {
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+// FILL = false: counts[gid] = number of foreign occurrences of this candidate window; true: write the triples
+template <bool FILL>
+__global__ void fs_join_kernel(SView v, int K, uint32_t max_win, const uint64_t* __restrict__ fkeys, const uint32_t* __restrict__ fids,
+                               uint64_t nf, uint32_t* __restrict__ counts, const uint64_t* __restrict__ offs, uint32_t* __restrict__ o_cand,
+                               uint32_t* __restrict__ o_start, uint32_t* __restrict__ o_fid) {
+  uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= v.n * max_win) return;
+  uint64_t r = gid / max_win;
+  uint32_t start = (uint32_t)(gid - r * max_win);
+  uint32_t len = v.len ? v.len[r] : v.fixed_len;
+  uint32_t c = 0;
+  if (len >= (uint32_t)K && start <= len - K) {
+    uint64_t wb = v.woff ? v.woff[r] : r * v.wpr;
+    uint64_t key = shn_extract(v.words + wb, start, K);
+    uint64_t lo = fs_lower_bound(fkeys, nf, key);
+    uint64_t o = FILL ? offs[gid] : 0;
+    for (uint64_t j = lo; j < nf && fkeys[j] == key; j++) {
+      if (FILL) { o_cand[o + c] = (uint32_t)r; o_start[o + c] = start; o_fid[o + c] = fids[j]; }
+      c++;
+    }
+  }
+  if (!FILL) counts[gid] = c;
+}
+
+// Call with out_cand == NULL for *n_hits, then with arrays of that size.  Triples come in (candidate, start) order.
+extern "C" int shn_rmer_join(shn_ctx* ctx, const shn_reads* cands, const shn_reads* foreign, int r, uint64_t* n_hits,
+                             uint32_t* out_cand, uint32_t* out_start, uint32_t* out_foreign) {
+  if (!ctx || !cands || !foreign || !n_hits) return shn_fail(SHN_ERR_ARG, "shn_rmer_join: NULL argument");
+  if (r < 1 || r > 32) return shn_fail(SHN_ERR_ARG, "shn_rmer_join: r must be in [1,32]");
+  if (cands->n_invalid || foreign->n_invalid) return shn_fail(SHN_ERR_ARG, "shn_rmer_join: non-ACGT bases");
+  *n_hits = 0;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  TimerRegion treg(ctx, T_SEEDS);
+  SView vf = sview(foreign), vc = sview(cands);
+  const uint32_t wf = foreign->max_len >= (uint32_t)r ? foreign->max_len - r + 1 : 0, wc = cands->max_len >= (uint32_t)r ? cands->max_len - r + 1 : 0;
+  const uint64_t tf = vf.n * wf, tc = vc.n * wc;
+  if (!tf || !tc) return SHN_OK;
+  int rc;
+  void *pc, *po;
+  if ((rc = g_shn_ws[25].get((std::max(tf, tc) + 1) * 4, &pc)) || (rc = g_shn_ws[26].get((std::max(tf, tc) + 2) * 8, &po))) return rc;
+  uint32_t* d_cnt = (uint32_t*)pc; uint64_t* d_off = (uint64_t*)po;
+  hipLaunchKernelGGL(fs_keys_kernel, dim3((uint32_t)cdiv(tf, SBLK2)), dim3(SBLK2), 0, s, vf, r, wf, nullptr, nullptr, nullptr, d_cnt);
+  uint64_t nf = 0;
+  if ((rc = shn_device_scan_u32(ctx, d_cnt, tf, d_off, &nf))) return rc;
+  if (!nf) return SHN_OK;
+  uint64_t *fk = nullptr, *fk2 = nullptr; uint32_t *fi = nullptr, *fi2 = nullptr, *oc = nullptr, *os = nullptr, *of = nullptr;
+  auto cleanup = [&]() { shn_dev_free(fk); shn_dev_free(fk2); shn_dev_free(fi); shn_dev_free(fi2); shn_dev_free(oc); shn_dev_free(os); shn_dev_free(of); };
+  if (shn_dev_malloc(&fk, nf * 8) != hipSuccess || shn_dev_malloc(&fk2, nf * 8) != hipSuccess || shn_dev_malloc(&fi, nf * 4) != hipSuccess ||
+      shn_dev_malloc(&fi2, nf * 4) != hipSuccess) { cleanup(); return shn_fail(SHN_ERR_NOMEM, "shn_rmer_join: out of device memory"); }
+  hipLaunchKernelGGL(fs_keys_kernel, dim3((uint32_t)cdiv(tf, SBLK2)), dim3(SBLK2), 0, s, vf, r, wf, fk, fi, (const uint64_t*)d_off, nullptr);
+  if ((rc = shn_sort_pairs(ctx, fk, fi, fk2, fi2, nf, 0, 2 * r))) { cleanup(); return rc; }
+  hipLaunchKernelGGL(fs_join_kernel<false>, dim3((uint32_t)cdiv(tc, SBLK2)), dim3(SBLK2), 0, s, vc, r, wc, fk, fi, nf, d_cnt, nullptr, nullptr, nullptr, nullptr);
+  uint64_t nh = 0;
+  if ((rc = shn_device_scan_u32(ctx, d_cnt, tc, d_off, &nh))) { cleanup(); return rc; }
+  *n_hits = nh;
+  if (!out_cand || !nh) { cleanup(); return SHN_OK; }
+  if (shn_dev_malloc(&oc, nh * 4) != hipSuccess || shn_dev_malloc(&os, nh * 4) != hipSuccess || shn_dev_malloc(&of, nh * 4) != hipSuccess) {
+    cleanup(); return shn_fail(SHN_ERR_NOMEM, "shn_rmer_join: out of device memory"); }
+  hipLaunchKernelGGL(fs_join_kernel<true>, dim3((uint32_t)cdiv(tc, SBLK2)), dim3(SBLK2), 0, s, vc, r, wc, fk, fi, nf, nullptr, (const uint64_t*)d_off, oc, os, of);
+  hipError_t e = hipMemcpyAsync(out_cand, oc, nh * 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(out_start, os, nh * 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(out_foreign, of, nh * 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  cleanup();
+  if (e != hipSuccess) return shn_fail(SHN_ERR_HIP, hipGetErrorString(e));
   HIP_TRY(hipGetLastError());
   return SHN_OK;
 }

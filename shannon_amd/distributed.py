@@ -204,19 +204,28 @@ class GpuOps(object):
     sharded_extension = True
 
     def extension(self, table, partition_size, group=None):
-        """replicated table -> the walks sharded by connected component of the k1-mer graph, the candidate contigs
-        all-gathered (a few MB), the sequential contig stages replicated"""
+        """replicated table -> walks AND contig stages sharded by connected component of the k1-mer graph; the accepted
+        contigs + their connections (a few MB) are all-gathered and merged in the global walk order"""
         from . import extension_correction as ec
         W, rank = dist.get_world_size(group), dist.get_rank(group)
 
-        def merge(local):
-            if W == 1:
-                return local
-            parts = [None] * W
-            dist.all_gather_object(parts, local, group=group)
-            return [c for p in parts for c in p]
+        class Gather(object):                     # the collectives of the sharded contig stage
+            world, rank = W, None
 
-        res = ec.run_correction(self.ctx, table, 3, 75, partition_size, want_allowed=False, shard=(W, rank), merge=merge)
+            @staticmethod
+            def all_gather(obj):
+                parts = [None] * W
+                dist.all_gather_object(parts, obj, group=group)
+                return parts
+
+            @staticmethod
+            def all_reduce_max(v):
+                t = torch.tensor([int(v)], dtype=torch.int64, device=self.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+                return int(t.item())
+
+        Gather.rank = rank
+        res = ec.run_correction(self.ctx, table, 3, 75, partition_size, want_allowed=False, shard=(W, rank), gather=Gather)
         table.close()
         return res
 

@@ -140,13 +140,109 @@ def windows_to_keys_many(contigs, k):
     return key[idx], nwin
 
 
+def contig_stage(strings, k1, r=15, f=0.5):
+    """duplicate_check + contig graph over candidate contigs in seed order (:358-397), native host code (csrc/contig_host.hip,
+    shn_contig_graph).  Returns (acc, coff, cnb, cw): acc[i] = 1-based accepted index of candidate i or 0; neighbours of
+    accepted contig a (0-based) are cnb[coff[a]:coff[a+1]] (1-based accepted indices, dict insertion order) with weights cw."""
+    if not strings:
+        return np.zeros(0, np.int32), [0], [], []
+    joined = "".join(strings).encode()
+    offs = np.zeros(len(strings) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(x) for x in strings], dtype=np.uint64)
+    buf = np.frombuffer(joined, dtype=np.uint8)
+    acc = np.zeros(len(strings), dtype=np.int32)
+    n_acc, n_conn = C.c_uint64(0), C.c_uint64(0)
+    _lib.check(_lib.lib().shn_contig_graph(buf.ctypes.data, offs.ctypes.data, len(strings), k1, r, float(f), acc.ctypes.data,
+                                           C.byref(n_acc), None, None, None, C.byref(n_conn)))
+    coff = np.zeros(n_acc.value + 1, dtype=np.uint64)
+    cnb = np.zeros(max(1, n_conn.value), dtype=np.int32)
+    cw = np.zeros(max(1, n_conn.value), dtype=np.int32)
+    _lib.check(_lib.lib().shn_contig_graph(buf.ctypes.data, offs.ctypes.data, len(strings), k1, r, float(f), acc.ctypes.data,
+                                           C.byref(n_acc), coff.ctypes.data, cnb.ctypes.data, cw.ctypes.data, C.byref(n_conn)))
+    if os.environ.get("SHN_DEBUG"):
+        pos = np.nonzero(acc)[0]
+        dec = np.histogram(pos, bins=10, range=(0, max(1, len(strings))))[0].tolist()
+        sys.stderr.write("[contig_graph] candidates %d (%d bases), accepted %d; accepted per decile of the seed order: %s\n"
+                         % (len(strings), int(offs[-1]), len(pos), dec))
+    return acc, coff.tolist(), cnb[:n_conn.value].tolist(), cw[:n_conn.value].tolist()
+
+
+def contig_best_counts(n_cand):
+    """hit count of the `best` contig of every candidate of the last contig_stage call (shn_contig_best_counts)"""
+    out = np.zeros(max(n_cand, 1), dtype=np.int32)
+    if n_cand:
+        _lib.check(_lib.lib().shn_contig_best_counts(out.ctypes.data, n_cand))
+    return out[:n_cand]
+
+
+def rmer_join(ctx, candidates, foreign_contigs, r=15):
+    """(candidate index, window start, foreign index) of every r-mer window of a candidate that occurs in a foreign contig,
+    once per occurrence -- exactly the increments duplicate_check would make (sort/join on the GPU, shn_rmer_join)."""
+    z = np.zeros(0, np.uint32)
+    if not candidates or not foreign_contigs:
+        return z, z, z
+    a = device.Reads.from_strings(ctx, candidates)
+    b = device.Reads.from_strings(ctx, foreign_contigs)
+    try:
+        L = _lib.lib()
+        n = C.c_uint64(0)
+        _lib.check(L.shn_rmer_join(ctx.h, a.h, b.h, int(r), C.byref(n), None, None, None))
+        if not n.value:
+            return z, z, z
+        hc = np.empty(n.value, np.uint32); hs = np.empty(n.value, np.uint32); hf = np.empty(n.value, np.uint32)
+        _lib.check(L.shn_rmer_join(ctx.h, a.h, b.h, int(r), C.byref(n), hc.ctypes.data, hs.ctypes.data, hf.ctypes.data))
+        return hc, hs, hf
+    finally:
+        a.close()
+        b.close()
+
+
+def foreign_interference(ctx, local, acc, best_count, foreign, r=15, f=0.5):
+    """Number of local candidates whose duplicate_check decision could differ once the accepted contigs of the OTHER shards
+    are taken into account.  local / foreign: [(seed weight, seed key, contig)]; acc[i] != 0: candidate i was accepted by the
+    shard-local pass, best_count[i]: hit count of its `best` contig there.  Only foreign contigs EARLIER in the global walk
+    order (weight desc, key asc) can matter.  With M = best_count: a rejected candidate is safe while every foreign contig has
+    fewer hits than M (it can never be the last to reach the running maximum, :255-259); an accepted one is safe while every
+    foreign contig with >= M hits covers at most f*len of it (whichever becomes `best`, the candidate is still accepted)."""
+    strings = [c[2] for c in local]
+    hc, hs, hf = rmer_join(ctx, strings, [c[2] for c in foreign], r)
+    if not len(hc):
+        return 0
+    wl = np.array([c[0] for c in local], dtype=np.int64); kl = np.array([c[1] for c in local], dtype=np.uint64)
+    wf = np.array([c[0] for c in foreign], dtype=np.int64); kf = np.array([c[1] for c in foreign], dtype=np.uint64)
+    earlier = (wf[hf] > wl[hc]) | ((wf[hf] == wl[hc]) & (kf[hf] < kl[hc]))
+    hc, hs, hf = hc[earlier].astype(np.int64), hs[earlier].astype(np.int64), hf[earlier].astype(np.int64)
+    if not len(hc):
+        return 0
+    pair = hc * np.int64(len(foreign)) + hf
+    order = np.lexsort((hs, pair))
+    pair, hs, hc = pair[order], hs[order], hc[order]
+    head = np.concatenate([[True], pair[1:] != pair[:-1]])
+    idx = np.nonzero(head)[0]
+    count = np.diff(np.concatenate([idx, [len(pair)]]))
+    step = np.minimum(np.diff(hs, append=hs[-1] + r), r)          # bases a window adds before the next one of the same pair starts
+    last = np.concatenate([head[1:], [True]])
+    step[last] = r
+    cover = np.add.reduceat(step, idx)
+    pc = hc[idx]                                                   # candidate of every pair
+    M = np.asarray(best_count, dtype=np.int64)[pc]
+    accepted = np.asarray(acc)[pc] != 0
+    lens = np.array([len(x) for x in strings], dtype=np.float64)[pc]
+    bad = np.where(accepted, (count >= M) & (cover > f * lens), count >= M)
+    return int(len(np.unique(pc[bad])))
+
+
 def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=500, r=15, f=0.5, want_allowed=True, timings=None,
-                   shard=None, merge=None):
+                   shard=None, merge=None, gather=None):
     """extension_correction.run_correction (extension_correction.py:309-524) on a device k1-mer
     table.  Returns an ExtensionResult: contigs, allowed {k1mer: int}, connections, components,
     single_contigs, big_components [(contigs, metis_text)], remaining [[contig...]].
     shard = (world, rank) + merge(local) -> global: the walks are sharded by connected component; `merge` receives this
-    rank's candidates [(seed weight, seed key, contig)] and returns the candidates of all ranks (any order)."""
+    rank's candidates [(seed weight, seed key, contig)] and returns the candidates of all ranks (any order).
+    gather (instead of merge): an object with .world, .rank, .all_gather(obj) -> [obj per rank], .all_reduce_max(int): the
+    contig stages are sharded as well -- every rank decides its own candidates, a GPU r-mer join against the other shards'
+    accepted contigs proves that none of them could have changed a duplicate_check decision (foreign_interference), else all
+    ranks fall back to the global sequential pass."""
     import time as _t
     T = timings if timings is not None else {}
     _t0 = [_t.time()]
@@ -178,42 +274,49 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     keep = list(zip(cand[sure].tolist(), clen[sure].tolist()))
     lap("ext.filter")
     strings = ext.emit([x[0] for x in keep], [x[1] for x in keep]) if keep else []
-    if merge is not None:
+    contigs = ["buffer"]
+    conn = {}
+    sharded_contigs = False
+    if gather is not None and gather.world > 1:
+        skey, sw = ext.seed_info([x[0] for x in keep])
+        local = list(zip(sw.tolist(), skey.tolist(), strings))
+        lap("ext.emit")
+        acc, coff, cnb, cw = contig_stage(strings, k1, r, f)
+        bestc = contig_best_counts(len(strings))
+        mine = [local[i] for i in np.nonzero(acc)[0].tolist()]              # accepted here, local order
+        everybody = gather.all_gather(mine)
+        foreign = [c for rk, lst in enumerate(everybody) if rk != gather.rank for c in lst]
+        unsafe = foreign_interference(ctx, local, acc, bestc, foreign, r, f)
+        if gather.all_reduce_max(1 if unsafe else 0) == 0:
+            sharded_contigs = True
+            conns = gather.all_gather((coff, cnb, cw))
+            items = sorted(((c[0], c[1], rk, j) for rk, lst in enumerate(everybody) for j, c in enumerate(lst)), key=lambda t: (-t[0], t[1]))
+            gid = {(rk, j): g + 1 for g, (_w, _k, rk, j) in enumerate(items)}    # global 1-based accepted index
+            for _w, _k, rk, j in items:
+                contigs.append(everybody[rk][j][2])
+            for _w, _k, rk, j in items:
+                o, nb_, w_ = conns[rk]
+                conn[gid[(rk, j)]] = {gid[(rk, q - 1)]: ww for q, ww in zip(nb_[o[j]:o[j + 1]], w_[o[j]:o[j + 1]])}
+        else:
+            allc = [c for lst in gather.all_gather(local) for c in lst]
+            allc.sort(key=lambda c: (-c[0], c[1]))
+            strings = [c[2] for c in allc]
+    elif merge is not None:
         # candidates of all shards in the global walk order (weight descending, seed k1-mer ascending; :334-345)
         skey, sw = ext.seed_info([x[0] for x in keep])
         allc = merge(list(zip(sw.tolist(), skey.tolist(), strings)))
         allc.sort(key=lambda c: (-c[0], c[1]))
         strings = [c[2] for c in allc]
-    lap("ext.emit")
+        lap("ext.emit")
+    else:
+        lap("ext.emit")
 
-    # duplicate_check + contig graph, sequential over candidates in seed order (:358-397): native host
-    # code (csrc/contig_host.hip, shn_contig_graph); neighbours come back in dict insertion order.
-    contigs = ["buffer"]
-    conn = {}
-    if strings:
-        joined = "".join(strings).encode()
-        offs = np.zeros(len(strings) + 1, dtype=np.uint64)
-        offs[1:] = np.cumsum([len(x) for x in strings], dtype=np.uint64)
-        buf = np.frombuffer(joined, dtype=np.uint8)
-        acc = np.zeros(len(strings), dtype=np.int32)
-        n_acc, n_conn = C.c_uint64(0), C.c_uint64(0)
-        _lib.check(_lib.lib().shn_contig_graph(buf.ctypes.data, offs.ctypes.data, len(strings), k1, r, float(f), acc.ctypes.data,
-                                               C.byref(n_acc), None, None, None, C.byref(n_conn)))
-        coff = np.zeros(n_acc.value + 1, dtype=np.uint64)
-        cnb = np.zeros(max(1, n_conn.value), dtype=np.int32)
-        cw = np.zeros(max(1, n_conn.value), dtype=np.int32)
-        _lib.check(_lib.lib().shn_contig_graph(buf.ctypes.data, offs.ctypes.data, len(strings), k1, r, float(f), acc.ctypes.data,
-                                               C.byref(n_acc), coff.ctypes.data, cnb.ctypes.data, cw.ctypes.data, C.byref(n_conn)))
+    # duplicate_check + contig graph, sequential over candidates in seed order (:358-397)
+    if not sharded_contigs:
+        acc, coff, cnb, cw = contig_stage(strings, k1, r, f)
         for i in np.nonzero(acc)[0].tolist():
             contigs.append(strings[i])
-        if os.environ.get("SHN_DEBUG"):
-            pos = np.nonzero(acc)[0]
-            dec = np.histogram(pos, bins=10, range=(0, max(1, len(strings))))[0].tolist()
-            sys.stderr.write("[contig_graph] candidates %d (%d bases), accepted %d; accepted per decile of the seed order: %s\n"
-                             % (len(strings), int(offs[-1]), len(pos), dec))
-        coff = coff.tolist()
-        cnb, cw = cnb.tolist(), cw.tolist()
-        for a in range(n_acc.value):
+        for a in range(len(coff) - 1):
             conn[a + 1] = dict(zip(cnb[coff[a]:coff[a + 1]], cw[coff[a]:coff[a + 1]]))
 
     lap("ext.contig_graph")

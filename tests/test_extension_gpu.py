@@ -143,3 +143,110 @@ def test_full_memo_pool_only_costs_time(ctx, words, monkeypatch):
         assert got.contigs == ref.contigs and got.connections == ref.connections
     finally:
         t.close()
+
+
+class _Abort(Exception):
+    pass
+
+
+def _run_virtual_ranks(world, run):
+    """Emulates `world` ranks on one GPU: run(rank, gather) is executed rank after rank; the collectives are replayed --
+    every pass completes one more collective for all ranks, until a pass runs through."""
+    history = []                                      # completed collectives: ("gather", [obj per rank]) / ("max", value)
+    while True:
+        pending, results = {}, {}
+        for rank in range(world):
+            calls = [0]
+
+            class G(object):
+                pass
+            g = G()
+            g.world, g.rank = world, rank
+
+            def collective(kind, obj, rank=rank, calls=calls):
+                k = calls[0]
+                calls[0] += 1
+                if k < len(history):
+                    assert history[k][0] == kind
+                    return history[k][1]
+                pending[rank] = (kind, obj)
+                raise _Abort()
+            g.all_gather = lambda obj, c=collective: c("gather", obj)
+            g.all_reduce_max = lambda v, c=collective: c("max", v)
+            try:
+                results[rank] = run(rank, g)
+            except _Abort:
+                pass
+        if len(results) == world:
+            return results, history
+        assert len(pending) == world and len({k for k, _ in pending.values()}) == 1      # every rank is at the same collective
+        kind = pending[0][0]
+        history.append((kind, [pending[r][1] for r in range(world)] if kind == "gather" else max(pending[r][1] for r in range(world))))
+
+
+@pytest.mark.parametrize("world,limit_override", [(2, None), (5, None), (3, -1)])
+def test_component_sharded_contig_stages_equal_the_global_pass(ctx, world, limit_override, monkeypatch):
+    """Walks and contig stages sharded by component (duplicate_check per shard + GPU join against the other shards'
+    accepted contigs) give the contigs, connections and components of the unsharded run -- also when the guard trips
+    and every rank falls back to the global pass (limit_override = -1 forces that)."""
+    from shannon_amd import device, synth, extension_correction as ec
+    (r1, r2), _ = synth.make_dataset(60000, 20, seed=80)
+    t = device.count_k1mers(ctx, [device.Reads.from_codes(ctx, np.concatenate([r1, r2]))], 26)
+    try:
+        ref = ec.run_correction(ctx, t, 3, 75, 500, want_allowed=False)
+        if limit_override is not None:
+            monkeypatch.setattr(ec, "foreign_interference", lambda *a, **k: 1)
+        results, history = _run_virtual_ranks(world, lambda rank, g: ec.run_correction(ctx, t, 3, 75, 500, want_allowed=False,
+                                                                                       shard=(world, rank), gather=g))
+        assert history[1] == ("max", 0 if limit_override is None else 1)
+        for rank in range(world):
+            res = results[rank]
+            assert res.contigs == ref.contigs
+            assert res.connections == ref.connections and [list(v) for v in res.connections.values()] == [list(v) for v in ref.connections.values()]
+            assert res.components == ref.components
+            assert res.single_contigs == ref.single_contigs and res.remaining == ref.remaining and res.big_components == ref.big_components
+    finally:
+        t.close()
+
+
+def test_rmer_join_counts_like_duplicate_check(ctx):
+    from shannon_amd import extension_correction as ec
+    rng = np.random.default_rng(3)
+    A = "ACGT"
+    contigs = ["".join(A[c] for c in rng.integers(0, 4, n)) for n in (120, 200, 90)]
+    contigs.append(contigs[1] + "A" + contigs[1])                                     # every occurrence counts
+    cand = [contigs[0][10:70] + "".join(A[c] for c in rng.integers(0, 4, 40)),
+            "".join(A[c] for c in rng.integers(0, 4, 100)),
+            contigs[2][:40] + contigs[1][50:80]]
+    hc, hs, hf = ec.rmer_join(ctx, cand, contigs, 15)
+    got = sorted(zip(hc.tolist(), hs.tolist(), hf.tolist()))
+    ref = []
+    for ci, c in enumerate(cand):
+        for i in range(len(c) - 14):
+            for di, d in enumerate(contigs):
+                for j in range(len(d) - 14):
+                    if d[j:j + 15] == c[i:i + 15]:
+                        ref.append((ci, i, di))
+    assert got == sorted(ref) and len(ref) > 100
+    assert len(ec.rmer_join(ctx, [], contigs, 15)[0]) == 0 and len(ec.rmer_join(ctx, cand, [], 15)[0]) == 0
+
+
+def test_foreign_interference_rules(ctx):
+    """the guard of the sharded duplicate check on hand-made cases (r = 15, f = 0.5)"""
+    from shannon_amd import extension_correction as ec
+    rng = np.random.default_rng(4)
+    A = "ACGT"
+    rnd = lambda n: "".join(A[c] for c in rng.integers(0, 4, n))
+    d = rnd(300)
+    # accepted candidate that a foreign earlier contig covers by more than half -> unsafe; by less than half -> safe
+    other = lambda b: A[(A.index(b) + 1) % 4]        # a base that breaks the match right after the shared stretch
+    c_big = d[20:100] + other(d[100]) + rnd(39)      # 80 of 120 bases shared
+    c_small = d[20:45] + other(d[45]) + rnd(94)      # 25 of 120 bases shared (11 windows)
+    local = [(50, 5, c_big), (40, 6, c_small)]
+    foreign_early, foreign_late = [(90, 1, d)], [(10, 1, d)]
+    assert ec.foreign_interference(ctx, local, [1, 2], [0, 0], foreign_early) == 1
+    assert ec.foreign_interference(ctx, local[1:], [1], [0], foreign_early) == 0
+    assert ec.foreign_interference(ctx, local, [1, 2], [0, 0], foreign_late) == 0        # later in the walk order: irrelevant
+    # rejected candidate: safe while the foreign contig has fewer hits than its own best contig
+    assert ec.foreign_interference(ctx, local[1:], [0], [12], foreign_early) == 0       # 11 foreign hits < 12
+    assert ec.foreign_interference(ctx, local[1:], [0], [11], foreign_early) == 1       # tie: the foreign one could be the last
