@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstring>
 #include <chrono>
+#include <thread>
 #include <cstdlib>
 #include <cstdio>
 
@@ -56,57 +57,55 @@ extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint6
     conns.clear(); conns.emplace_back();                 // index 0 unused (contigs are 1-based)
     accepted.assign(n_cand, 0);
     bestcnt.assign(n_cand, 0);
-    std::vector<uint64_t> rk, ck;
-    std::vector<int32_t> hits;                              // first value index in rmer (or -1) per window
-    std::vector<int32_t> dupcnt(1, 0), touched;             // per accepted contig: shared r-mers with the candidate
-    std::vector<int32_t> connw(1, 0), newnb;                // per accepted contig: shared K-mers with the new contig
-    std::vector<int32_t> cov;
     const int C = k1 - 1;
     int32_t idx = 0;
     const bool dbg = getenv("SHN_DEBUG") != nullptr;
-    double tph[4] = {0, 0, 0, 0};
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    uint64_t n_entries = 0;
-    for (uint64_t c = 0; c < n_cand; c++) {
+    double t_eval = 0, t_accept = 0;
+    uint64_t n_evals = 0, n_batches = 0;
+
+    // duplicate_check of one candidate against the current index (read-only on the shared state)
+    struct Scratch { std::vector<uint64_t> rk; std::vector<int32_t> hits, dupcnt, touched, cov; };
+    auto evaluate = [&](uint64_t c, Scratch& z, int32_t& best_count) -> bool {
       const uint8_t* s = bases + off[c];
-      uint32_t L = (uint32_t)(off[c + 1] - off[c]);
-      double t0 = dbg ? now() : 0;
-      window_keys(s, L, r, rk);
-      hits.assign(rk.size(), -1);
+      const uint32_t L = (uint32_t)(off[c + 1] - off[c]);
+      window_keys(s, L, r, z.rk);
+      z.hits.assign(z.rk.size(), -1);
+      if (z.dupcnt.size() < (size_t)idx + 1) z.dupcnt.resize((size_t)idx + 1, 0);
       int32_t max_till_now = 0, best = -1;
-      for (size_t i = 0; i < rk.size(); i++) {
-        if (i + 12 < rk.size()) rmer.prefetch(rk[i + 12]);
-        int32_t v = rmer.find(rk[i]);
-        hits[i] = v;
+      for (size_t i = 0; i < z.rk.size(); i++) {
+        if (i + 12 < z.rk.size()) rmer.prefetch(z.rk[i + 12]);
+        int32_t v = rmer.find(z.rk[i]);
+        z.hits[i] = v;
         for (; v != -1; v = rmer.nxt(v)) {
           int32_t d = rmer.va(v);
-          n_entries++;
-          if (dupcnt[d] == 0) touched.push_back(d);
-          int32_t cnt = ++dupcnt[d];
+          if (z.dupcnt[d] == 0) z.touched.push_back(d);
+          int32_t cnt = ++z.dupcnt[d];
           if (cnt >= max_till_now) { max_till_now = cnt; best = d; }      // `>=`: the latest wins (:258-259)
         }
       }
-      for (int32_t d : touched) dupcnt[d] = 0;
-      touched.clear();
-      if (dbg) { double t1 = now(); tph[0] += t1 - t0; t0 = t1; }
-      bestcnt[c] = max_till_now;
-      bool suspect = false;
-      if (best >= 0) {
-        cov.assign(L + 1, 0);
-        for (size_t i = 0; i < rk.size(); i++) {
-          bool has = false;
-          for (int32_t v = hits[i]; v != -1 && !has; v = rmer.nxt(v)) has = rmer.va(v) == best;
-          if (has) { cov[i] += 1; cov[i + r] -= 1; }
-        }
-        int64_t run = 0, covered = 0;
-        for (uint32_t i = 0; i < L; i++) { run += cov[i]; if (run > 0) covered++; }
-        suspect = (double)covered > f * (double)L;
+      for (int32_t d : z.touched) z.dupcnt[d] = 0;
+      z.touched.clear();
+      best_count = max_till_now;
+      if (best < 0) return false;
+      z.cov.assign(L + 1, 0);
+      for (size_t i = 0; i < z.rk.size(); i++) {
+        bool has = false;
+        for (int32_t v = z.hits[i]; v != -1 && !has; v = rmer.nxt(v)) has = rmer.va(v) == best;
+        if (has) { z.cov[i] += 1; z.cov[i + r] -= 1; }
       }
-      if (dbg) { double t1 = now(); tph[1] += t1 - t0; t0 = t1; }
-      if (suspect) continue;
+      int64_t run = 0, covered = 0;
+      for (uint32_t i = 0; i < L; i++) { run += z.cov[i]; if (run > 0) covered++; }
+      return (double)covered > f * (double)L;                          // suspect
+    };
+
+    std::vector<uint64_t> ck, rk2;
+    std::vector<int32_t> connw(1, 0), newnb;                // per accepted contig: shared K-mers with the new contig
+    auto accept = [&](uint64_t c) {
+      const uint8_t* s = bases + off[c];
+      const uint32_t L = (uint32_t)(off[c + 1] - off[c]);
       idx++;
       accepted[c] = idx;
-      dupcnt.push_back(0);
       conns.emplace_back();
       // contig_connections (:372-397): every earlier contig sharing a K-mer gets +1 per shared position pair, both
       // ways.  The new contig's own dict fills in first-seen order (flat counters, no per-contig hash map); in an
@@ -129,22 +128,61 @@ extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint6
           else { b.nb.push_back(idx); b.w.push_back(1); }
         }
       }
-      {
-        Conn& a = conns[idx];
-        a.nb = newnb;
-        a.w.resize(newnb.size());
-        for (size_t j = 0; j < newnb.size(); j++) { a.w[j] = connw[newnb[j]]; connw[newnb[j]] = 0; }
+      Conn& a = conns[idx];
+      a.nb = newnb;
+      a.w.resize(newnb.size());
+      for (size_t j = 0; j < newnb.size(); j++) { a.w[j] = connw[newnb[j]]; connw[newnb[j]] = 0; }
+      window_keys(s, L, r, rk2);
+      for (size_t i = 0; i < rk2.size(); i++) {
+        if (i + 12 < rk2.size()) rmer.prefetch(rk2[i + 12]);
+        rmer.add(rk2[i], idx);
       }
-      if (dbg) { double t1 = now(); tph[2] += t1 - t0; t0 = t1; }
-      for (size_t i = 0; i < rk.size(); i++) {
-        if (i + 12 < rk.size()) rmer.prefetch(rk[i + 12]);
-        rmer.add(rk[i], idx);
+    };
+
+    // Candidates are decided in seed order, but a run of candidates with no acceptance among them can be evaluated
+    // in parallel against the same index (evaluation is read-only): batches grow while nothing is accepted (duplicates
+    // dominate the tail of the seed order) and shrink when something is.  The first accepted candidate of a batch ends
+    // it -- the ones after it are evaluated again against the enlarged index.
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned n_threads = std::min(16u, hw);
+    std::vector<Scratch> scratch(n_threads);
+    std::vector<uint8_t> susp;
+    uint64_t pos = 0, B = 1;
+    while (pos < n_cand) {
+      const uint64_t end = std::min<uint64_t>(n_cand, pos + B);
+      const uint64_t nb = end - pos;
+      susp.assign(nb, 0);
+      double t0 = dbg ? now() : 0;
+      if (nb < 64 || n_threads == 1) {
+        for (uint64_t c = pos; c < end; c++) {
+          susp[c - pos] = evaluate(c, scratch[0], bestcnt[c]) ? 1 : 0;
+          n_evals++;
+          if (!susp[c - pos]) { susp.resize(c - pos + 1); break; }         // the rest would be stale anyway
+        }
+      } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < n_threads; t++)
+          th.emplace_back([&, t]() { for (uint64_t c = pos + t; c < end; c += n_threads) susp[c - pos] = evaluate(c, scratch[t], bestcnt[c]) ? 1 : 0; });
+        for (auto& x : th) x.join();
+        n_evals += nb;
       }
-      if (dbg) { double t1 = now(); tph[3] += t1 - t0; }
+      n_batches++;
+      if (dbg) { double t1 = now(); t_eval += t1 - t0; t0 = t1; }
+      uint64_t j = 0;
+      while (j < susp.size() && susp[j]) j++;
+      if (j < susp.size()) {                        // candidate pos+j is accepted; everything after it is looked at again
+        accept(pos + j);
+        pos += j + 1;
+        B = std::max<uint64_t>(1, B / 2);
+      } else {
+        pos += susp.size();
+        B = std::min<uint64_t>(B * 2, 1024);
+      }
+      if (dbg) t_accept += now() - t0;
     }
+    if (dbg) fprintf(stderr, "[contig_graph] %llu candidates: %llu evaluations in %llu batches (%u threads) %.3f s, inserts %.3f s\n",
+                     (unsigned long long)n_cand, (unsigned long long)n_evals, (unsigned long long)n_batches, n_threads, t_eval, t_accept);
     cached_n = n_cand; cached_ptr = bases;
-    if (dbg) fprintf(stderr, "[contig_graph] lookup %.3f s (%llu list entries), coverage %.3f s, connections %.3f s, index insert %.3f s\n", tph[0],
-                     (unsigned long long)n_entries, tph[1], tph[2], tph[3]);
   }
   uint64_t n_acc = conns.size() - 1, total = 0;
   for (uint64_t i = 1; i <= n_acc; i++) total += conns[i].nb.size();
