@@ -71,7 +71,8 @@ def main(argv):
         if a == "--kmer_hard_cutoff":
             min_weight = int(argv[i + 1]); i += 2; continue
         if a in ("-s", "--ss", "--strand_specific"):
-            double_stranded = False; i += 1; continue
+            # accepted by the reference CLI (shannon.py:166-207); this build only has the double-stranded path
+            sys.exit("shannon.py: strand-specific input (%s) is not supported by this build (double-stranded reads only)" % a)
         if a in ("--inMem", "--inDisk", "--fasta", "--fastq", "--only_reads"):
             i += 1; continue
         if a in ("--compare", "--kallisto_cutoff", "--kmer_soft_cutoff"):

@@ -47,6 +47,10 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
                       native_graph=True, graph_threads=8):
     """Same as assemble() with the reads already packed in HBM (d1/d2: device.Reads).  graph_threads: partitions whose
     graph stage may run concurrently on host threads."""
+    if not double_stranded:
+        # shannon.py:394-424 prepares strand-specific input differently (no doubling; PE: reads_2 = RC(R2)) and routing /
+        # graph reads follow that layout; only the strand-doubled layout is built and pinned against the reference.
+        raise NotImplementedError("strand-specific input (-s / --ss) is not built: only the default double-stranded path is")
     T = timings if timings is not None else {}
     paired = d2 is not None
     if hits_factory is None:
