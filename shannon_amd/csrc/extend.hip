@@ -532,6 +532,120 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
   }
 }
 
+// ---- fixpoint audit, after the last block settles (always on; one pass over the claims, no walking): the claims are
+// the fixpoint iff every claimed k1-mer is what its walk's greedy rule picks at the step before it, every walk ends
+// where its rule finds nothing, and every walk owns exactly its recorded steps.  For walk r at step p a k1-mer is
+// traversed if a lower rank owns it or r owns it at a step <= p.  A walk that fails is made dirty and the rounds go
+// on with every block reopened -- the rounds' change tracking is an optimisation, this is the definition.
+__device__ __forceinline__ int audit_decide(const Adj4& cd, uint32_t r, uint32_t p, const u64* __restrict__ claim,
+                                            const uint32_t* __restrict__ weight) {
+  int best = -1;
+  uint32_t bw = 0;
+#pragma unroll
+  for (int bi = 0; bi < 4; bi++) {
+    const int b = bi == 0 ? 0 : bi == 1 ? 2 : bi == 2 ? 1 : 3;          // BASES order A,G,C,T
+    if (cd.v[b] < 0) continue;
+    const u64 c = claim[cd.v[b]];
+    const bool avail = RANK(c) > r || (RANK(c) == r && POS(c) > p);
+    const uint32_t w = weight[(uint32_t)cd.v[b] >> 1];
+    if (avail && (best < 0 || w > bw)) { best = b; bw = w; }
+  }
+  return best;
+}
+
+__global__ void ext_audit_nodes_kernel(const u64* __restrict__ claim, uint64_t n2, const Adj4* __restrict__ adjR, const Adj4* __restrict__ adjL,
+                                       const uint32_t* __restrict__ weight, const uint32_t* __restrict__ order,
+                                       const uint32_t* __restrict__ nr_a, const uint32_t* __restrict__ nl_a, uint64_t ns,
+                                       uint32_t* __restrict__ owned, uint8_t* __restrict__ dirty, unsigned long long* __restrict__ counters) {
+  for (uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; y < n2; y += (uint64_t)gridDim.x * blockDim.x) {
+    const u64 c = claim[y];
+    const uint32_t r = RANK(c), p = POS(c);
+    if (r == UNCLAIMED) continue;
+    if (r >= ns) { atomicAdd(&counters[0], 1ULL); continue; }
+    atomicAdd(&owned[r], 1u);
+    const uint32_t nr = nr_a[r], nl = nl_a[r];
+    bool bad = false;
+    if (nr == UNCLAIMED || p > nr + nl) bad = true;                     // claim of a void walk / beyond its record
+    else {
+      if (p == 0) bad = order[r] != (uint32_t)y;
+      else {
+        // the step before: position p-1 going right, and the seed again for the first step to the left
+        const bool right = p <= nr;
+        const u64 want = CLAIM(r, p == nr + 1 ? 0u : p - 1);
+        const Adj4 back = right ? adjL[y] : adjR[y];
+        int32_t x = -1;
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (back.v[q] >= 0 && claim[back.v[q]] == want) x = back.v[q];
+        if (x < 0) bad = true;
+        else {
+          const Adj4 cd = right ? adjR[x] : adjL[x];
+          const int b = audit_decide(cd, r, p - 1, claim, weight);
+          bad = b < 0 || cd.v[b] != (int32_t)y;
+        }
+      }
+      if (!bad && p == nr) bad = audit_decide(adjR[y], r, nr, claim, weight) >= 0;                      // right end
+      if (!bad && (nl ? p == nr + nl : p == 0)) bad = audit_decide(adjL[y], r, nr + nl, claim, weight) >= 0;   // left end
+    }
+    if (bad) { dirty[r] = 1; atomicAdd(&counters[0], 1ULL); }
+  }
+}
+
+__global__ void ext_audit_walks_kernel(const u64* __restrict__ claim, const uint32_t* __restrict__ order, const uint32_t* __restrict__ nr_a,
+                                       const uint32_t* __restrict__ nl_a, uint64_t ns, const uint32_t* __restrict__ owned,
+                                       uint8_t* __restrict__ dirty, unsigned long long* __restrict__ counters) {
+  uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= ns) return;
+  const u64 cs = claim[order[r]];
+  const uint32_t nr = nr_a[r];
+  const bool bad = nr == UNCLAIMED ? !(RANK(cs) < r && owned[r] == 0) : (cs != CLAIM((uint32_t)r, 0) || owned[r] != nr + nl_a[r] + 1u);
+  if (bad) { dirty[r] = 1; atomicAdd(&counters[1], 1ULL); }
+}
+
+// ---- audit (SHN_EXT_AUDIT=1, tests and stress runs): re-derive every walk from the converged claims alone, one thread
+// per walk.  For walk r a k1-mer is traversed if a lower rank owns it or r owns it at a position already passed; the
+// greedy choice at every step must be the k1-mer r owns at the next position, and the walk must end where its
+// recorded counts say.  counters: [0] walks that disagree [1] the lowest such rank
+__global__ void ext_audit_kernel(WalkArgs A, uint64_t ns, unsigned long long* __restrict__ counters) {
+  uint64_t r64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r64 >= ns) return;
+  const uint32_t r = (uint32_t)r64;
+  const uint32_t o = A.order[r];
+  const u64 cs = A.claim[o];
+  const uint32_t nr = A.nr_out[r], nl = A.nl_out[r];
+  bool bad = false;
+  if (nr == UNCLAIMED) bad = !(RANK(cs) < r);
+  else if (cs != CLAIM(r, 0)) bad = true;
+  else {
+    uint32_t pos = 0;
+    uint64_t tot = A.weight[o >> 1];
+    for (int dir = 0; dir < 2 && !bad; dir++) {
+      const Adj4* adj = dir == 0 ? A.adjR : A.adjL;
+      const uint32_t end = dir == 0 ? nr : nr + nl;
+      uint32_t cur = o;
+      while (true) {
+        Adj4 cd = adj[cur];
+        int best = -1;
+        uint32_t bw = 0;
+        for (int bi = 0; bi < 4; bi++) {
+          const int b = bi == 0 ? 0 : bi == 1 ? 2 : bi == 2 ? 1 : 3;
+          if (cd.v[b] < 0) continue;
+          const u64 c = A.claim[cd.v[b]];
+          const bool avail = RANK(c) > r || (RANK(c) == r && POS(c) > pos);
+          const uint32_t w = A.weight[(uint32_t)cd.v[b] >> 1];
+          if (avail && (best < 0 || w > bw)) { best = b; bw = w; }
+        }
+        if (best < 0) { if (pos != end) bad = true; break; }
+        if (pos == end) { bad = true; break; }                // the recorded walk stopped, the rule goes on
+        const uint32_t nx = (uint32_t)cd.v[best];
+        if (A.claim[nx] != CLAIM(r, pos + 1)) { bad = true; break; }
+        pos++; tot += bw; cur = nx;
+      }
+    }
+    if (!bad && tot != A.totw_out[r]) bad = true;
+  }
+  if (bad) { atomicAdd(&counters[0], 1ULL); atomicMin(&counters[1], (unsigned long long)r); }
+}
+
 // classify the dirty walks of the open block: long ones (memo or recorded length) go to the wavefront kernel,
 // the others to the thread kernel.  counters: [0] long [1] unused [2] short [3] dirty walks
 __global__ void ext_plan_kernel(const uint32_t* __restrict__ nr, const uint32_t* __restrict__ nl, uint64_t ns, uint32_t frozen,
@@ -868,7 +982,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   TRYE(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
   static thread_local unsigned long long* plan = nullptr;      // long dirty walks, -, short dirty walks, dirty walks
   if (!plan) TRYE(hipHostMalloc((void**)&plan, 64));
-  int it = 0;
+  int it = 0, repairs = 0;
   bool converged = ns == 0;
 
   const uint32_t g2n = (uint32_t)cdiv(2 * n, 256);
@@ -897,7 +1011,27 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     TRYE(hipMemcpyAsync(plan, d_cnt + 2, 32, hipMemcpyDeviceToHost, s));
     TRYE(hipStreamSynchronize(s));
     if (plan[3] == 0) {
-      if (limit >= ns) { converged = true; break; }
+      if (limit >= ns) {
+        // every block is settled: audit the claims (see ext_audit_nodes_kernel); a walk that is not at its fixpoint
+        // re-runs with all blocks open.  Never seen to fire in testing except by fault injection (SHN_EXT_FAULT).
+        TimerRegion ta(ctx, T_EXT_MARK);
+        TRYE(hipMemsetAsync(owned, 0, (ns + 1) * 4, s));
+        TRYE(hipMemsetAsync(d_cnt + 48, 0, 16, s));
+        hipLaunchKernelGGL(ext_audit_nodes_kernel, dim3(std::min<uint32_t>(g2n, 4096u)), dim3(256), 0, s, claim, 2 * n, (const Adj4*)e->d_adjR,
+                           (const Adj4*)e->d_adjL, e->d_weight, e->d_order, e->d_nr, e->d_nl, (uint64_t)ns, owned, dirty, d_cnt + 48);
+        hipLaunchKernelGGL(ext_audit_walks_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, claim, e->d_order, e->d_nr, e->d_nl, (uint64_t)ns,
+                           owned, dirty, d_cnt + 48);
+        TRYE(hipMemcpyAsync(plan + 4, d_cnt + 48, 16, hipMemcpyDeviceToHost, s));
+        TRYE(hipStreamSynchronize(s));
+        if (plan[4] == 0 && plan[5] == 0) { converged = true; break; }
+        fprintf(stderr, "[shn_extend] fixpoint audit after %d rounds: %llu k1-mers / %llu walks disagree with the greedy rule; reopening all blocks\n",
+                it, plan[4], plan[5]);
+        if (++repairs > 16) break;
+        frozen = 0;
+        TRYE(hipMemsetAsync(ran, 0, ns + 1, s));
+        TRYE(hipMemsetAsync(owned, 0, (ns + 1) * 4, s));
+        continue;
+      }
       frozen = limit;                                // this block is final: open the next one
       limit = (uint32_t)std::min<unsigned long long>(ns, (unsigned long long)limit * grow);
       TRYE(hipMemsetAsync(ran, 0, frozen, s));       // frozen walks never run again
@@ -941,6 +1075,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       hipLaunchKernelGGL(ext_mark_kernel, dim3(std::min<uint32_t>(g2n, 4096u)), dim3(256), 0, s, claim, snap, 2 * n, (const Adj4*)e->d_adjR, (const Adj4*)e->d_adjL,
                          seed_rank, dirty, ran, owned, d_cnt + 6, frozen, limit, fill, moff, mR, pool, hint); }
     hipLaunchKernelGGL(ext_verify_kernel, dim3((uint32_t)cdiv(limit, 256)), dim3(256), 0, s, ran, owned, e->d_nr, e->d_nl, (uint64_t)limit, dirty);
+    if (getenv("SHN_EXT_FAULT") && it + 1 == atoi(getenv("SHN_EXT_FAULT"))) TRYE(hipMemsetAsync(dirty, 0, ns + 1, s));   // (tests: lose every mark of this round)
     if (getenv("SHN_EXT_ALLDIRTY")) { TRYE(hipMemsetAsync(dirty, 0, ns + 1, s)); TRYE(hipMemsetAsync(dirty + frozen, 1, limit - frozen, s)); }
     it++;
 
@@ -963,6 +1098,21 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   hipStreamDestroy(aux);
   hipEventDestroy(ev_fork);
   hipEventDestroy(ev_join);
+  if (converged && ns && getenv("SHN_EXT_AUDIT")) {
+    WalkArgs A;
+    memset(&A, 0, sizeof(A));
+    A.order = e->d_order; A.adjR = (const Adj4*)e->d_adjR; A.adjL = (const Adj4*)e->d_adjL; A.weight = e->d_weight;
+    A.claim = claim; A.nr_out = e->d_nr; A.nl_out = e->d_nl; A.totw_out = e->d_totw;
+    unsigned long long au[2] = {0, ~0ULL};
+    TRYE(hipMemcpy(d_cnt + 48, au, 16, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(ext_audit_kernel, dim3((uint32_t)cdiv(ns, 64)), dim3(64), 0, s, A, (uint64_t)ns, d_cnt + 48);
+    TRYE(hipStreamSynchronize(s));
+    TRYE(hipMemcpy(au, d_cnt + 48, 16, hipMemcpyDeviceToHost));
+    if (au[0]) {
+      fprintf(stderr, "[shn_extend] AUDIT: %llu walks are not at their fixpoint, lowest rank %llu of %llu (rounds %d)\n", au[0], au[1], ns, it);
+      if (atoi(getenv("SHN_EXT_AUDIT")) > 1) { shn_ext_destroy(e); return shn_fail(SHN_ERR_INTERNAL, "shn_extend: audit failed"); }
+    }
+  }
   e->iterations = it;
   if (!converged) { shn_ext_destroy(e); return shn_fail(SHN_ERR_INTERNAL, "shn_extend: walk fixpoint did not converge"); }
   unsigned long long steps = 0, wsteps = 0, wslots[64];

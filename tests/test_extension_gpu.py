@@ -145,6 +145,32 @@ def test_full_memo_pool_only_costs_time(ctx, words, monkeypatch):
         t.close()
 
 
+@pytest.mark.parametrize("lost_round", [1, 3, 6, 12])
+def test_fixpoint_audit_repairs_lost_marks(ctx, lost_round, monkeypatch, capfd):
+    """The rounds' change tracking is an optimisation; the audit after the last block is the definition of the
+    fixpoint.  Fault injection: every dirty mark of one round is dropped (blocks settle too early) -- the audit has to
+    see it, reopen the blocks and end on the same walks.  SHN_EXT_AUDIT=2 re-derives every walk sequentially from the
+    final claims (one thread per walk) and fails the call if one differs."""
+    from shannon_amd import device, synth, extension_correction as ec
+    (r1, r2), _ = synth.make_dataset(60000, 20, seed=78)
+    t = device.count_k1mers(ctx, [device.Reads.from_codes(ctx, np.concatenate([r1, r2]))], 26)
+    try:
+        monkeypatch.setenv("SHN_EXT_AUDIT", "2")
+        e = ec.Extension(ctx, t, 3)
+        ref = e.stats()
+        e.close()
+        assert "fixpoint audit" not in capfd.readouterr().err          # a healthy run never trips the audit
+        monkeypatch.setenv("SHN_EXT_FAULT", str(lost_round))
+        e = ec.Extension(ctx, t, 3)
+        got = e.stats()
+        e.close()
+        assert "reopening all blocks" in capfd.readouterr().err
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b)
+    finally:
+        t.close()
+
+
 class _Abort(Exception):
     pass
 
