@@ -112,10 +112,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # SHN_BENCH_BACKEND=gloo: development aid -- several ranks on ONE GPU (collectives staged through host memory,
+    # exchange.coll_device), to exercise the N-rank code path on a 1-GPU box.  Its numbers mean nothing.
+    backend = os.environ.get("SHN_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
+        if backend == "gloo":
+            local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
     from shannon_amd import device, exchange
@@ -178,7 +186,7 @@ def main():
     if dist:
         dist.barrier()
     dt = time.time() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
@@ -214,7 +222,7 @@ def main():
             avg = ms / launches
             bytes_launch = per_step_bytes[name] * args.steps / launches
             ach = bytes_launch / (avg * 1e-3) / 1e9
-            tr = TRAFFIC.get(name) if (args.reads == 10_000_000 and args.genes == 1 and args.K == 25) else None
+            tr = TRAFFIC.get(name) if (args.reads == 10_000_000 and args.genes == 1 and args.K == 25 and world == 1) else None   # PMC passes were taken at N=1
             return {"bound": "hbm", "kernel": KERNEL[name], "timer": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": tr, "launches_per_step": launches / args.steps, "avg_launch_ms": avg,
                     "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_bytes_per_read": per_read.get(name)}

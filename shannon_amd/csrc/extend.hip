@@ -55,6 +55,7 @@ struct shn_ext {
   int iterations;
   uint32_t min_weight;
   const shn_table* table;
+  shn_table* owned_table; // sharded: the k1-mers of this rank's components (table points at it)
   uint32_t* d_weight;    // [n] weight of the string in the doubled input (count, x2 for palindromes)
   uint8_t* d_flags;      // [n] bit0 palindrome, bit1 low complexity
   int32_t* d_adjR;       // [2n*4] oriented id reached by appending base b, or -1
@@ -182,15 +183,13 @@ __global__ void cc_assign_kernel(const uint32_t* __restrict__ big_root, const ui
 
 __global__ void ext_seed_kernel(const uint64_t* __restrict__ tkeys, const uint32_t* __restrict__ weight,
                                 const uint8_t* __restrict__ flags, uint64_t n, int k, int canonical, uint32_t min_weight,
-                                uint64_t* __restrict__ skeys, uint32_t* __restrict__ svals, unsigned long long* __restrict__ counter,
-                                const uint32_t* __restrict__ lab, const uint8_t* __restrict__ owner_root, uint32_t my_rank) {
+                                uint64_t* __restrict__ skeys, uint32_t* __restrict__ svals, unsigned long long* __restrict__ counter) {
   uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool is_seed = false;
   uint64_t i = o >> 1;
   if (o < 2 * n) {
     uint8_t f = flags[i];
     is_seed = !(f & 2) && !((o & 1) && ((f & 1) || !canonical)) && weight[i] >= min_weight;
-    if (is_seed && lab) is_seed = owner_root[lab[i]] == my_rank;           // sharded: only the seeds of this rank's components
   }
   // one atomic per block of 1024 (the order of the seeds does not matter: they are sorted next)
   __shared__ uint32_t wcnt[16];
@@ -828,12 +827,114 @@ __global__ void ext_emit_claims_kernel(const u64* __restrict__ claim, uint64_t n
   if (threadIdx.x < 2 && blk[threadIdx.x]) atomicAdd(&counters[threadIdx.x], blk[threadIdx.x]);
 }
 
+// ---- component shard of a k1-mer table: the walks of a connected component of the k1-mer graph touch no other
+// component, so a rank that is given whole components needs only their k1-mers.  Labels the components (lock-free
+// union-find over the adjacency rows), gives every component to one rank (the big ones balanced by sampled size,
+// the rest by hash -- the same on every rank) and compacts this rank's k1-mers into a table of their own (same
+// bucket grid, so lookups work unchanged).  Everything after that is the unsharded algorithm on the small table.
+__global__ void shard_select_kernel(const uint32_t* __restrict__ lab, const uint8_t* __restrict__ owner_root, uint64_t n, uint32_t my_rank,
+                                    uint32_t* __restrict__ sel) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) sel[i] = owner_root[lab[i]] == my_rank ? 1u : 0u;
+}
+__global__ void shard_compact_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ sel,
+                                     const uint64_t* __restrict__ pos, uint64_t n, uint64_t* __restrict__ okeys, uint32_t* __restrict__ ocounts) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && sel[i]) { okeys[pos[i]] = keys[i]; ocounts[pos[i]] = counts[i]; }
+}
+__global__ void shard_offsets_kernel(const uint64_t* __restrict__ boff, uint64_t n_buckets, const uint64_t* __restrict__ pos,
+                                     uint64_t* __restrict__ oboff) {
+  uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b <= n_buckets) oboff[b] = pos[boff[b]];        // pos has n+1 entries: pos[n] = number of selected k1-mers
+}
+
+static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank, shn_table** out) {
+  hipStream_t s = ctx->stream;
+  const uint64_t n = t->n;
+  uint32_t* d_weight = nullptr; uint8_t* d_flags = nullptr; int32_t *d_adjR = nullptr, *d_adjL = nullptr;
+  shn_table* sub = nullptr;
+  auto cleanup = [&]() { if (d_weight) shn_dev_free(d_weight); if (d_flags) shn_dev_free(d_flags); if (d_adjR) shn_dev_free(d_adjR); if (d_adjL) shn_dev_free(d_adjL); };
+#define TRYS(x) do { hipError_t _e = (x); if (_e != hipSuccess) { cleanup(); if (sub) shn_table_destroy(sub); \
+      return shn_fail(SHN_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(_e)); } } while (0)
+  TRYS(shn_dev_malloc(&d_weight, (n + 1) * 4));
+  TRYS(shn_dev_malloc(&d_flags, n + 1));
+  TRYS(shn_dev_malloc(&d_adjR, (2 * n + 1) * 16));
+  TRYS(shn_dev_malloc(&d_adjL, (2 * n + 1) * 16));
+  {
+    TimerRegion t1(ctx, T_EXT_PREP);
+    hipLaunchKernelGGL(ext_prepare_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, t->d_counts, n, t->k, t->canonical, d_weight, d_flags);
+    hipLaunchKernelGGL(ext_adjacency_kernel, dim3((uint32_t)cdiv(n * 16, 256)), dim3(256), 0, s, t->d_keys, t->d_bucket_off, t->bits, d_flags, n, t->k,
+                       t->canonical, d_adjR, d_adjL);
+  }
+  void *pl, *po, *pz, *pb, *pc, *pp;
+  const uint32_t big_cap = 1u << 16;
+  int rc;
+  if ((rc = g_shn_ws[14].get((n + 1) * 4, &pl)) || (rc = g_shn_ws[15].get(n + 1, &po)) || (rc = g_shn_ws[16].get((n + 1) * 4, &pz)) ||
+      (rc = g_shn_ws[17].get((size_t)big_cap * 9 + 64, &pb)) || (rc = g_shn_ws[13].get(2048, &pc)) || (rc = g_shn_ws[9].get((2 * n + 2) * 8, &pp))) { cleanup(); return rc; }
+  uint32_t* d_lab = (uint32_t*)pl; uint8_t* d_owner_root = (uint8_t*)po;
+  uint32_t* d_size = (uint32_t*)pz;
+  uint32_t* d_big_root = (uint32_t*)pb; uint32_t* d_big_size = d_big_root + big_cap; uint8_t* d_big_owner = (uint8_t*)(d_big_size + big_cap);
+  unsigned long long* d_cnt = (unsigned long long*)pc;
+  uint64_t* d_pos = (uint64_t*)pp;
+  TRYS(hipMemsetAsync(d_cnt, 0, 2048, s));
+  hipLaunchKernelGGL(cc_init_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, d_lab, n);
+  hipLaunchKernelGGL(cc_union_kernel, dim3((uint32_t)cdiv(2 * n * 4, 256)), dim3(256), 0, s, (const int32_t*)d_adjR, 2 * n, d_lab);
+  hipLaunchKernelGGL(cc_flatten_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, d_lab, n);
+  TRYS(hipMemsetAsync(d_size, 0, (n + 1) * 4, s));
+  hipLaunchKernelGGL(cc_sample_kernel, dim3((uint32_t)cdiv(cdiv(n, 64), 256)), dim3(256), 0, s, d_lab, n, d_size);
+  hipLaunchKernelGGL(cc_owner_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, d_lab, d_size, n, (uint32_t)world, d_owner_root,
+                     d_big_root, d_big_size, d_cnt + 20, big_cap);
+  unsigned long long nb = 0;
+  TRYS(hipMemcpyAsync(&nb, d_cnt + 20, 8, hipMemcpyDeviceToHost, s));
+  TRYS(hipStreamSynchronize(s));
+  nb = std::min<unsigned long long>(nb, big_cap);
+  if (nb) {
+    std::vector<uint32_t> br(nb), bs(nb);
+    TRYS(hipMemcpy(br.data(), d_big_root, nb * 4, hipMemcpyDeviceToHost));
+    TRYS(hipMemcpy(bs.data(), d_big_size, nb * 4, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> ord(nb);
+    for (uint32_t j = 0; j < nb; j++) ord[j] = j;
+    std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return bs[a] != bs[b] ? bs[a] > bs[b] : br[a] < br[b]; });
+    std::vector<uint64_t> load(world, 0);
+    std::vector<uint8_t> bo(nb);
+    for (uint32_t j : ord) {                                  // largest first onto the least loaded rank
+      int best = 0;
+      for (int w = 1; w < world; w++) if (load[w] < load[best]) best = w;
+      bo[j] = (uint8_t)best;
+      load[best] += bs[j];
+    }
+    TRYS(hipMemcpy(d_big_owner, bo.data(), nb, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(cc_assign_kernel, dim3((uint32_t)cdiv(nb, 256)), dim3(256), 0, s, d_big_root, d_big_owner, (uint32_t)nb, d_owner_root);
+  }
+  // this rank's k1-mers, in table order (bucket by bucket, ascending inside a bucket)
+  uint32_t* d_sel = d_size;                                   // (the sampled sizes are done with)
+  hipLaunchKernelGGL(shard_select_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, d_lab, d_owner_root, n, (uint32_t)rank, d_sel);
+  uint64_t n_sub = 0;
+  if ((rc = shn_device_scan_u32(ctx, d_sel, n, d_pos, &n_sub))) { cleanup(); return rc; }
+  sub = new shn_table();
+  memset(sub, 0, sizeof(*sub));
+  sub->ctx = t->ctx; sub->device = t->device; sub->k = t->k; sub->canonical = t->canonical; sub->n = n_sub; sub->total = 0;
+  sub->bits = t->bits; sub->n_buckets = t->n_buckets;
+  TRYS(shn_dev_malloc(&sub->d_keys, (n_sub + 1) * 8));
+  TRYS(shn_dev_malloc(&sub->d_counts, (n_sub + 1) * 4));
+  TRYS(shn_dev_malloc(&sub->d_bucket_off, (t->n_buckets + 1) * 8));
+  hipLaunchKernelGGL(shard_compact_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, t->d_counts, d_sel, d_pos, n, sub->d_keys, sub->d_counts);
+  hipLaunchKernelGGL(shard_offsets_kernel, dim3((uint32_t)cdiv(t->n_buckets + 1, 256)), dim3(256), 0, s, t->d_bucket_off, t->n_buckets, d_pos, sub->d_bucket_off);
+  TRYS(hipStreamSynchronize(s));
+  TRYS(hipGetLastError());
+#undef TRYS
+  cleanup();
+  *out = sub;
+  return SHN_OK;
+}
+
 extern "C" void shn_ext_destroy(shn_ext* e) {
   if (!e) return;
   hipSetDevice(e->device);
   void* ptrs[] = {e->d_weight, e->d_flags, e->d_adjR, e->d_adjL, e->d_order, e->d_claim, e->d_claim2, e->d_nr, e->d_nl,
                   e->d_totw};
   for (void* p : ptrs) if (p) shn_dev_free(p);
+  if (e->owned_table) shn_table_destroy(e->owned_table);
   delete e;
 }
 
@@ -848,6 +949,16 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   if (2 * t->n >= 0x7FFFFFFFULL) return shn_fail(SHN_ERR_ARG, "shn_extend: table too large for 31-bit oriented ids");
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
+  if (world > 1 && t->n) {
+    shn_table* sub = nullptr;
+    int rcs;
+    { TimerRegion treg(ctx, T_EXTEND); rcs = component_shard(ctx, t, world, rank, &sub); }
+    if (rcs) return rcs;
+    rcs = shn_extend_sharded(ctx, sub, min_weight, max_iterations, 1, 0, out);
+    if (rcs) { shn_table_destroy(sub); return rcs; }
+    (*out)->owned_table = sub;
+    return SHN_OK;
+  }
   TimerRegion treg(ctx, T_EXTEND);
   shn_ext* e = new shn_ext();
   memset(e, 0, sizeof(*e));
@@ -878,50 +989,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   uint64_t* skeys = (uint64_t*)pk; uint32_t* svals = (uint32_t*)pv;
   unsigned long long* d_cnt = (unsigned long long*)pc;      // [0] seeds [1] steps [2..4] plan (long, pool, short) [5] final pool [6] changed
   TRYE(hipMemsetAsync(d_cnt, 0, 2048, s));
-  // sharded: label the connected components, give every component to one rank (the big ones balanced by size,
-  // the rest by hash -- the same on every rank), keep only this rank's seeds
-  uint32_t* d_lab = nullptr;
-  uint8_t* d_owner_root = nullptr;
-  if (world > 1 && n) {
-    void *pl, *po, *pz, *pb;
-    const uint32_t big_cap = 1u << 16;
-    if ((rc = g_shn_ws[14].get((n + 1) * 4, &pl)) || (rc = g_shn_ws[15].get(n + 1, &po)) || (rc = g_shn_ws[16].get((n + 1) * 4, &pz)) ||
-        (rc = g_shn_ws[17].get((size_t)big_cap * 9 + 64, &pb))) { shn_ext_destroy(e); return rc; }
-    d_lab = (uint32_t*)pl; d_owner_root = (uint8_t*)po;
-    uint32_t* d_size = (uint32_t*)pz;
-    uint32_t* d_big_root = (uint32_t*)pb; uint32_t* d_big_size = d_big_root + big_cap; uint8_t* d_big_owner = (uint8_t*)(d_big_size + big_cap);
-    hipLaunchKernelGGL(cc_init_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, d_lab, n);
-    hipLaunchKernelGGL(cc_union_kernel, dim3((uint32_t)cdiv(2 * n * 4, 256)), dim3(256), 0, s, (const int32_t*)e->d_adjR, 2 * n, d_lab);
-    hipLaunchKernelGGL(cc_flatten_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, d_lab, n);
-    TRYE(hipMemsetAsync(d_size, 0, (n + 1) * 4, s));
-    hipLaunchKernelGGL(cc_sample_kernel, dim3((uint32_t)cdiv(cdiv(n, 64), 256)), dim3(256), 0, s, d_lab, n, d_size);
-    hipLaunchKernelGGL(cc_owner_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, d_lab, d_size, n, (uint32_t)world, d_owner_root,
-                       d_big_root, d_big_size, d_cnt + 20, big_cap);
-    unsigned long long nb = 0;
-    TRYE(hipMemcpyAsync(&nb, d_cnt + 20, 8, hipMemcpyDeviceToHost, s));
-    TRYE(hipStreamSynchronize(s));
-    nb = std::min<unsigned long long>(nb, big_cap);
-    if (nb) {
-      std::vector<uint32_t> br(nb), bs(nb);
-      TRYE(hipMemcpy(br.data(), d_big_root, nb * 4, hipMemcpyDeviceToHost));
-      TRYE(hipMemcpy(bs.data(), d_big_size, nb * 4, hipMemcpyDeviceToHost));
-      std::vector<uint32_t> ord(nb);
-      for (uint32_t j = 0; j < nb; j++) ord[j] = j;
-      std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return bs[a] != bs[b] ? bs[a] > bs[b] : br[a] < br[b]; });
-      std::vector<uint64_t> load(world, 0);
-      std::vector<uint8_t> bo(nb);
-      for (uint32_t j : ord) {                                  // largest first onto the least loaded rank
-        int best = 0;
-        for (int w = 1; w < world; w++) if (load[w] < load[best]) best = w;
-        bo[j] = (uint8_t)best;
-        load[best] += bs[j];
-      }
-      TRYE(hipMemcpy(d_big_owner, bo.data(), nb, hipMemcpyHostToDevice));
-      hipLaunchKernelGGL(cc_assign_kernel, dim3((uint32_t)cdiv(nb, 256)), dim3(256), 0, s, d_big_root, d_big_owner, (uint32_t)nb, d_owner_root);
-    }
-  }
   if (n) hipLaunchKernelGGL(ext_seed_kernel, dim3((uint32_t)cdiv(2 * n, 1024)), dim3(1024), 0, s, t->d_keys, e->d_weight, e->d_flags, n,
-                            t->k, t->canonical, min_weight, skeys, svals, d_cnt, d_lab, d_owner_root, (uint32_t)rank);
+                            t->k, t->canonical, min_weight, skeys, svals, d_cnt);
   unsigned long long ns = 0;
   TRYE(hipMemcpyAsync(&ns, d_cnt, 8, hipMemcpyDeviceToHost, s));
   TRYE(hipStreamSynchronize(s));
@@ -1292,6 +1361,7 @@ __global__ void ext_weight_lookup_kernel(const uint64_t* __restrict__ tkeys, con
 
 extern "C" int shn_ext_weights(shn_ctx* ctx, const shn_ext* e, const uint64_t* keys, uint64_t n, uint32_t* weights) {
   if (!ctx || !e || (n && (!keys || !weights))) return shn_fail(SHN_ERR_ARG, "shn_ext_weights: NULL argument");
+  if (e->owned_table) return shn_fail(SHN_ERR_ARG, "shn_ext_weights: not available on a component shard (it holds only this rank's k1-mers)");
   if (!n) return SHN_OK;
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;

@@ -28,16 +28,17 @@ from . import exchange, mbgraph, sparse_flow, post
 def _all_gather_var(t, group=None):
     """all-gather of 1-D tensors of different lengths (padded to the max)."""
     W = dist.get_world_size(group)
-    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+    cdev = exchange.coll_device(t.device, group)
+    n = torch.tensor([t.numel()], dtype=torch.int64, device=cdev)
     ns = [torch.zeros_like(n) for _ in range(W)]
     dist.all_gather(ns, n, group=group)
     ns = [int(x.item()) for x in ns]
     mx = max(ns + [1])
-    pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
-    pad[:t.numel()] = t
+    pad = torch.zeros(mx, dtype=t.dtype, device=cdev)
+    pad[:t.numel()] = t.to(cdev)
     outs = [torch.empty_like(pad) for _ in range(W)]
     dist.all_gather(outs, pad, group=group)
-    return torch.cat([o[:k] for o, k in zip(outs, ns)]), ns
+    return torch.cat([o[:k] for o, k in zip(outs, ns)]).to(t.device), ns
 
 
 def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0, part_vectors=None, group=None,
@@ -71,7 +72,8 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
     P = len(names)
     # ---- 3. global strand-doubled order + per-partition cap
     n_local = ops.n_reads()
-    nl = torch.tensor([n_local], dtype=torch.int64, device=ops.device)
+    cdev = exchange.coll_device(ops.device, group)
+    nl = torch.tensor([n_local], dtype=torch.int64, device=cdev)
     nls = [torch.zeros_like(nl) for _ in range(W)]
     dist.all_gather(nls, nl, group=group)
     nls = [int(x.item()) for x in nls]
@@ -81,7 +83,7 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
         r = part["routes"][nm]
         f = int(np.searchsorted(r, n_local))
         cnt[i] = (f, len(r) - f)
-    ct = torch.as_tensor(cnt.reshape(-1), device=ops.device)
+    ct = torch.as_tensor(cnt.reshape(-1), device=cdev)
     cts = [torch.zeros_like(ct) for _ in range(W)]
     dist.all_gather(cts, ct, group=group)
     allc = np.stack([c.cpu().numpy().reshape(P, 2) for c in cts])       # [W, P, 2]
@@ -220,7 +222,7 @@ class GpuOps(object):
 
             @staticmethod
             def all_reduce_max(v):
-                t = torch.tensor([int(v)], dtype=torch.int64, device=self.device)
+                t = torch.tensor([int(v)], dtype=torch.int64, device=exchange.coll_device(self.device, group))
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
                 return int(t.item())
 

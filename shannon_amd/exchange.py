@@ -30,22 +30,29 @@ def owner_of(keys, world):
         return (fmix64_np(np.asarray(keys, dtype=np.uint64) ^ np.uint64(SHARD_SALT)) % np.uint64(world)).astype(np.int64)
 
 
+def coll_device(dev, group=None):
+    """Where the tensors of a collective live: on their own device with RCCL ("nccl"), in host memory with gloo
+    (CPU tests, and GPU tests in which several ranks share one GPU -- RCCL refuses two ranks on one device)."""
+    return torch.device("cpu") if dist.get_backend(group) == "gloo" else torch.device(dev)
+
+
 def all_to_all_pairs(keys, counts, send_counts, group=None):
     """keys (int64) / counts (int32) tensors grouped by destination rank with `send_counts`
     entries each.  Returns (recv_keys, recv_counts, recv_counts_per_rank)."""
     world = dist.get_world_size(group)
     dev = keys.device
-    sc = torch.as_tensor(np.asarray(send_counts, dtype=np.int64), device=dev)
-    rc = torch.empty(world, dtype=torch.int64, device=dev)
+    cdev = coll_device(dev, group)
+    sc = torch.as_tensor(np.asarray(send_counts, dtype=np.int64), device=cdev)
+    rc = torch.empty(world, dtype=torch.int64, device=cdev)
     dist.all_to_all_single(rc, sc, group=group)
     rcl = [int(v) for v in rc.cpu().tolist()]
     scl = [int(v) for v in np.asarray(send_counts).tolist()]
     n_in = sum(rcl)
-    rk = torch.empty(n_in, dtype=torch.int64, device=dev)
-    rcn = torch.empty(n_in, dtype=torch.int32, device=dev)
-    dist.all_to_all_single(rk, keys[:sum(scl)], rcl, scl, group=group)
-    dist.all_to_all_single(rcn, counts[:sum(scl)], rcl, scl, group=group)
-    return rk, rcn, rcl
+    rk = torch.empty(n_in, dtype=torch.int64, device=cdev)
+    rcn = torch.empty(n_in, dtype=torch.int32, device=cdev)
+    dist.all_to_all_single(rk, keys[:sum(scl)].to(cdev), rcl, scl, group=group)
+    dist.all_to_all_single(rcn, counts[:sum(scl)].to(cdev), rcl, scl, group=group)
+    return rk.to(dev), rcn.to(dev), rcl
 
 
 def exchange_table(ctx, table, group=None):

@@ -46,3 +46,41 @@ def test_distributed_path_matches_single_process(group, paired, n_genes, seed):
         if d2 is not None:
             d2.close()
         ctx.close()
+
+
+@pytest.mark.parametrize("world,paired,n_genes,seed,port", [(2, True, 3, 11, 29621), (3, True, 12, 4, 29622), (2, False, 2, 5, 29623),
+                                                            (4, True, 40, 8, 29624)])
+def test_ranks_sharing_one_gpu_equal_single_process(world, paired, n_genes, seed, port, tmp_path):
+    """world_size > 1 with the product's per-rank compute (GpuOps): every rank holds a slice of the reads and runs its HIP
+    kernels on cuda:0; the collectives go through gloo (RCCL does not take two ranks on one device).  Covers the sharded
+    walks + sharded contig stages, the capped read exchange and partition ownership against the single-process result."""
+    import json, subprocess, sys
+    from conftest import ROOT
+    from shannon_amd import device, synth, pipeline, kmers_for_component as kfc
+    n_pairs = 12000
+    out = str(tmp_path / "res.json")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_gpu_worker.py"),
+                        "1" if paired else "0", str(n_genes), str(seed), str(n_pairs), out],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:]
+    got = json.load(open(out))
+    (q1, q2), _ = synth.make_dataset(n_pairs, n_genes, seed=seed)
+    if not paired:
+        q1, q2 = np.concatenate([q1, q2]), None
+    ctx = device.Context(0)
+    d1 = device.Reads.from_codes(ctx, q1)
+    d2 = device.Reads.from_codes(ctx, q2) if paired else None
+    try:
+        ref = pipeline.assemble_resident(ctx, d1, d2, kfc.ReadStore(q1, q2), K=25, sample="t", seed=1)
+        assert got["contigs"] == ref.extension.contigs
+        assert list(got["partitions"]) == list(ref.partitions)
+        for name in ref.partitions:
+            assert got["partitions"][name] == ref.partitions[name]["reconstructed_fasta"]
+        assert got["final"] == ref.final
+    finally:
+        d1.close()
+        if d2 is not None:
+            d2.close()
+        ctx.close()
