@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--force-distributed", action="store_true", help="run the multi-GPU code path even with one rank")
     args = ap.parse_args()
 
+    if os.environ.get("SHN_BENCH_WATCHDOG"):          # development aid: dump every thread's stack if the run takes longer
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["SHN_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -134,10 +137,30 @@ def main():
     # rank holds a 10M-read slice of that mixture (reads are sharded by index, not by gene).  Adding ranks to ONE
     # family instead would multiply its coverage (616,000x at N=8) -- a different, degenerate assembly problem.
     families = args.families if args.families else (world if (args.genes == 1 and world > 1) else 0)
+    lock = None
+    if world > 1 and backend == "gloo" and os.environ.get("SHN_BENCH_SERIALIZE", "1") == "1":
+        import fcntl
+
+        class _FileLock(object):          # ranks sharing the GPU compute one at a time: per-stage times as if each had its own
+            def __init__(self, path):
+                self.f = open(path, "w")
+
+            def acquire(self):
+                fcntl.flock(self.f, fcntl.LOCK_EX)
+
+            def release(self):
+                fcntl.flock(self.f, fcntl.LOCK_UN)
+        lock = _FileLock("/tmp/shn_bench_lock_%s" % os.environ.get("MASTER_PORT", "0"))
+
+    if lock:
+        lock.acquire()
     r1, r2 = gen_reads(args.reads // 2, seed, args.genes, dev, read_seed=seed + 2 + 1000 * rank, families=families)
     ctx = device.Context(local if world > 1 else 0)
     sets = [device.Reads.from_codes(ctx, r1), device.Reads.from_codes(ctx, r2)]
     n_reads = len(sets[0]) + len(sets[1])
+    if lock:
+        ctx.sync()
+        lock.release()
 
     from shannon_amd import pipeline, kmers_for_component as kfc
     store = kfc.ReadStore(r1, r2)
@@ -158,7 +181,7 @@ def main():
     def step():
         if use_dist:
             ops = distributed.GpuOps(ctx, sets[0], sets[1], store, args.K)
-            res = distributed.assemble_distributed(ops, args.K, 500, "bench", 1, timings=stage_t)
+            res = distributed.assemble_distributed(ops, args.K, 500, "bench", 1, timings=stage_t, lock=lock)
             d = _Done()
             d.res = res
             return d
@@ -191,6 +214,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     timers = ctx.timers()
+    stage_max = None
+    if dist and world > 1:                 # slowest rank per stage (the stage dict of rank 0 alone hides imbalance)
+        allst = [None] * world
+        dist.all_gather_object(allst, dict(stage_t))
+        stage_max = {k: max(d.get(k, 0.0) for d in allst) / args.steps for k in allst[0]}
     if use_dist:
         distinct, total = (last.res["n_k1mers"] if rank == 0 else 0), None
     else:
@@ -245,6 +273,7 @@ def main():
                                   "owner-side graph + sparse flow -> gather + merge on rank 0" if use_dist else
                                   "full path a1-a31: count -> extension -> partition/route -> multibridged graph -> sparse flow -> merge"),
                        "host_stage_seconds_per_step": {k: v / args.steps for k, v in stage_t.items()},
+                       "host_stage_seconds_per_step_slowest_rank": stage_max,
                        "transcripts": (len(last.res["final"]) if use_dist else len(last.R.final)),
                        "extension_iterations": ext["iterations"], "extension_walks": ext["n_walks"],
                        "extension_walk_steps": steps_all,

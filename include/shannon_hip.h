@@ -70,6 +70,11 @@ uint32_t shn_reads_max_len(const shn_reads* r);
 /* number of reads containing a non-ACGT character */
 uint64_t shn_reads_n_invalid(const shn_reads* r);
 
+/* Host utility: dst row i = src row idx[i] (rows of row_bytes bytes; src has n_src_rows rows), on `threads` host threads.
+ * Used for the capped read sets of a partition (kmers_for_component.py:322-403 writes them to per-component files;
+ * here they are gathered from the resident read matrix).  SHN_ERR_ARG on an index out of range.                          */
+int shn_gather_rows(const uint8_t* src, uint64_t n_src_rows, uint64_t row_bytes, const int64_t* idx, uint64_t n, uint8_t* dst, int threads);
+
 /* ---- (K+1)-mer counting ----------------------------------------------------------------------
  * Replaces `jellyfish count -m k1 ... ; jellyfish dump -c -t -L lower` (shannon.py:439-441;
  * duplicate call site run_MB_SF_fn.py:177-184).  Counts every ACGT-only k1-window of every

@@ -25,6 +25,7 @@ SIGNATURES = {
     "shn_reads_total_bases": (C.c_uint64, [vp]),
     "shn_reads_max_len": (C.c_uint32, [vp]),
     "shn_reads_n_invalid": (C.c_uint64, [vp]),
+    "shn_gather_rows": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp, C.c_int]),
     "shn_count_k1mers": (C.c_int, [vp, vpp, C.c_int, C.c_int, C.c_int, vpp]),
     "shn_table_destroy": (None, [vp]),
     "shn_table_size": (C.c_uint64, [vp]),
@@ -89,3 +90,17 @@ def lib():
 def check(rc):
     if rc != 0:
         raise RuntimeError("libshannon_hip: %s (code %d)" % (lib().shn_last_error().decode(), rc))
+
+
+def gather_rows(src, idx, out=None, threads=8):
+    """out[i] = src[idx[i]] for a C-contiguous 2-D uint8 matrix, on host threads (shn_gather_rows)."""
+    import numpy as np
+    src = np.ascontiguousarray(src)
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    if out is None:
+        out = np.empty((len(idx), src.shape[1]), dtype=src.dtype)
+    assert src.ndim == 2 and out.flags["C_CONTIGUOUS"] and out.shape == (len(idx), src.shape[1]) and out.dtype == src.dtype
+    rb = src.shape[1] * src.itemsize
+    if len(idx) and rb:
+        check(lib().shn_gather_rows(src.ctypes.data, src.shape[0], rb, idx.ctypes.data, len(idx), out.ctypes.data, int(threads)))
+    return out

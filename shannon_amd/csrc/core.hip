@@ -4,6 +4,7 @@
 #include <vector>
 #include <cstring>
 #include <cstdio>
+#include <thread>
 
 static thread_local std::string g_err;
 void shn_set_error(const std::string& msg) { g_err = msg; }
@@ -308,3 +309,23 @@ extern "C" uint64_t shn_reads_count(const shn_reads* r) { return r ? r->n_reads 
 extern "C" uint64_t shn_reads_total_bases(const shn_reads* r) { return r ? r->total_bases : 0; }
 extern "C" uint32_t shn_reads_max_len(const shn_reads* r) { return r ? r->max_len : 0; }
 extern "C" uint64_t shn_reads_n_invalid(const shn_reads* r) { return r ? r->n_invalid : 0; }
+
+
+// ---- host utility: dst[i] = src row idx[i] (rows of row_bytes bytes), split over host threads.  The read rows that
+// travel to a partition's owner and their re-ordering there are 100+ MB gathers; numpy does them on one thread.
+extern "C" int shn_gather_rows(const uint8_t* src, uint64_t n_src_rows, uint64_t row_bytes, const int64_t* idx, uint64_t n, uint8_t* dst,
+                               int threads) {
+  if ((n && (!src || !idx || !dst)) || !row_bytes) return shn_fail(SHN_ERR_ARG, "shn_gather_rows: NULL argument");
+  for (uint64_t i = 0; i < n; i++)
+    if (idx[i] < 0 || (uint64_t)idx[i] >= n_src_rows) return shn_fail(SHN_ERR_ARG, "shn_gather_rows: row index out of range");
+  const uint64_t per_thread_min = (1ULL << 20) / row_bytes + 1;          // at least ~1 MB per thread
+  int T = (int)std::min<uint64_t>((uint64_t)std::max(1, threads), n / per_thread_min + 1);
+  auto work = [&](uint64_t a, uint64_t b) {
+    for (uint64_t i = a; i < b; i++) memcpy(dst + i * row_bytes, src + (uint64_t)idx[i] * row_bytes, row_bytes);
+  };
+  if (T <= 1) { work(0, n); return SHN_OK; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; t++) th.emplace_back(work, n * t / T, n * (t + 1) / T);
+  for (auto& x : th) x.join();
+  return SHN_OK;
+}

@@ -90,6 +90,13 @@ struct StringInterner {
     *is_new = true;
     return id;
   }
+  // two-stage software prefetch for a stream of lookups with known hashes: first the slot, a few items later what the slot leads to
+  void prefetch_slot(uint64_t h) const { __builtin_prefetch(&table[h & mask]); }
+  void prefetch_entry(uint64_t h) const {
+    int32_t id = table[h & mask];
+    if (id >= 0) { __builtin_prefetch(&hashes[id]); __builtin_prefetch(&off[id]); __builtin_prefetch(arena.data() + off[id]); }
+  }
+  void reserve(size_t expect) { while ((expect + 1) * 10 > (mask + 1) * 6) grow(); }
   void grow() {
     size_t c = (mask + 1) * 2;
     table.assign(c, -1); mask = c - 1;

@@ -734,24 +734,44 @@ extern "C" int shn_mbgraph_run(shn_ctx* ctx, int K, const uint8_t* rows, uint64_
   g.load_k1mers(rows, n_rows);
   if (dbg) { fprintf(stderr, "[mbgraph] load_k1mers            %8.3f s  rows=%llu\n", now() - tt, (unsigned long long)n_rows); tt = now(); }
   uint64_t cutoff = (uint64_t)g.order.size() * 10;
+  // Scratch kept between calls (at the read cap these buffers are 100s of MB, and fresh pages cost more than the work done
+  // in them): decode buffers and the read arena.  A free list, not thread_local: Python's partition workers are short-lived.
+  struct Scratch { std::vector<uint64_t> doff, hashes; std::vector<char> text; std::string arena; };
+  static std::mutex scratch_mu;
+  static std::vector<Scratch*> scratch_free;
+  Scratch* sc = nullptr;
+  { std::lock_guard<std::mutex> lk(scratch_mu); if (!scratch_free.empty()) { sc = scratch_free.back(); scratch_free.pop_back(); } }
+  if (!sc) sc = new Scratch();
+  struct Giveback {
+    Scratch* s; std::string* arena;
+    ~Giveback() { arena->clear(); s->arena.swap(*arena); std::lock_guard<std::mutex> lk(scratch_mu); if (scratch_free.size() < 16) scratch_free.push_back(s); else delete s; }
+  } giveback{sc, &g.rindex.arena};
+  g.rindex.arena.swap(sc->arena);
+  g.rindex.arena.clear();
   {
     uint64_t used = std::min<uint64_t>(n_reads, cutoff + 1);
     size_t bytes = used ? (size_t)(r1_off[used] - r1_off[0]) + (paired ? (size_t)(r2_off[used] - r2_off[0]) : 0) : 0;
     g.rindex.arena.reserve(bytes);
     size_t nr = (size_t)used * (paired ? 2 : 1);
+    g.rindex.reserve(nr);
     g.rcc.reserve(nr); g.rmate.reserve(nr); g.rmp.reserve(nr); g.rnodes.reserve(nr); g.rhas.reserve(nr);
   }
   {
     // decode + hash on several host threads (independent per read), then intern sequentially in file order
     const uint64_t used = std::min<uint64_t>(n_reads, cutoff + 1);
     const int nm = paired ? 2 : 1;
-    std::vector<uint64_t> doff((size_t)used * nm + 1, 0);
+    // (scratch kept per host thread between calls: at the read cap these are 100s of MB, and fresh pages cost more than the decode)
+    std::vector<uint64_t>&doff = sc->doff, &hashes = sc->hashes;
+    std::vector<char>& text = sc->text;
+    doff.resize((size_t)used * nm + 1);
+    doff[0] = 0;
     for (uint64_t i = 0; i < used; i++) {
       doff[i * nm + 1] = doff[i * nm] + (r1_off[i + 1] - r1_off[i]);
       if (paired) doff[i * nm + 2] = doff[i * nm + 1] + (r2_off[i + 1] - r2_off[i]);
     }
-    std::vector<char> text(doff.back() + 1);
-    std::vector<uint64_t> hashes((size_t)used * nm);
+    if (text.size() < doff.back() + 1) text.resize(doff.back() + 1);
+    hashes.resize((size_t)used * nm);
+    double t_dec = now();
     auto work = [&](uint64_t lo, uint64_t hi) {
       for (uint64_t i = lo; i < hi; i++) {
         char* d1 = text.data() + doff[i * nm];
@@ -775,7 +795,15 @@ extern "C" int shn_mbgraph_run(shn_ctx* ctx, int K, const uint8_t* rows, uint64_
       for (unsigned t = 0; t < nt; t++) { uint64_t lo = t * per, hi = std::min<uint64_t>(used, lo + per); if (lo < hi) th.emplace_back(work, lo, hi); }
       for (auto& t : th) t.join();
     }
+    if (dbg) fprintf(stderr, "[mbgraph]   offsets+decode+hash   %8.3f s\n", now() - t_dec);
+    const uint64_t nh = used * nm;
     for (uint64_t i = 0; i < used; i++) {
+      // the interner is a few hundred MB at the cap: every probe is a chain of cache misses unless fetched ahead
+      for (int m = 0; m < nm; m++) {
+        const uint64_t j = i * nm + m;
+        if (j + 24 < nh) g.rindex.prefetch_slot(hashes[j + 24]);
+        if (j + 12 < nh) g.rindex.prefetch_entry(hashes[j + 12]);
+      }
       int a = g.add_read(text.data() + doff[i * nm], doff[i * nm + 1] - doff[i * nm], hashes[i * nm]);
       if (paired) {
         int b = g.add_read(text.data() + doff[i * nm + 1], doff[i * nm + 2] - doff[i * nm + 1], hashes[i * nm + 1]);

@@ -41,37 +41,69 @@ def _all_gather_var(t, group=None):
     return torch.cat([o[:k] for o, k in zip(outs, ns)]).to(t.device), ns
 
 
+class _NoLock(object):
+    def acquire(self):
+        pass
+
+    def release(self):
+        pass
+
+
 def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0, part_vectors=None, group=None,
-                         timings=None):
-    """Returns on rank 0 a dict {partitions: {name: fasta}, all_reconstructed, final, contigs}; None elsewhere."""
+                         timings=None, lock=None):
+    """Returns on rank 0 a dict {partitions: {name: fasta}, all_reconstructed, final, contigs}; None elsewhere.
+    timings: seconds per stage, compute ("count", "extension", ...) and collectives ("x:...") apart.
+    lock (development aid): held while this rank computes, released around every collective -- with several ranks on
+    ONE GPU it serialises the compute, so the per-stage compute times are those of a rank that has a GPU to itself."""
     import time
     T = timings if timings is not None else {}
+    lock = lock or _NoLock()
+    ops.lock = lock
+    ops.timings = T                     # sub-stages of the extension land in the same dict ("ext.*")
 
     def tick(name, t0):
         T[name] = T.get(name, 0.0) + time.time() - t0
 
     W, rank = dist.get_world_size(group), dist.get_rank(group)
     # ---- 1. local count + bucket exchange + reduce by key
+    lock.acquire()
     t0 = time.time()
     keys, counts, send = ops.local_pairs(W)
+    tick("count", t0)
+    lock.release()
+    t0 = time.time()
     rk, rc, _ = exchange.all_to_all_pairs(keys, counts, send, group)
+    tick("x:bucket exchange", t0)
+    lock.acquire()
+    t0 = time.time()
     ok, oc = ops.reduce_pairs(rk, rc)
-    tick("count+exchange", t0)
+    tick("reduce", t0)
+    lock.release()
     # ---- 2. replicate the (small) distinct-k1-mer table, extension + partitioning on every rank
     t0 = time.time()
     gk, _ = _all_gather_var(ok, group)
     gc, _ = _all_gather_var(oc, group)
+    tick("x:allgather table", t0)
+    lock.acquire()
+    t0 = time.time()
     table = ops.table_from_pairs(gk, gc)
-    tick("allgather table", t0)
+    tick("table", t0)
     t0 = time.time()
     res = ops.extension(table, partition_size, group) if getattr(ops, "sharded_extension", False) else ops.extension(table, partition_size)
     tick("extension", t0)
+    w = getattr(ops, "coll_wait", 0.0)       # the sharded contig stage's object collectives, reported apart
+    if w:
+        T["extension"] -= w
+        T["x:contig gathers"] = T.get("x:contig gathers", 0.0) + w
     t0 = time.time()
     part = ops.route(res, K, partition_size, part_vectors)
     names = list(part["new_components"])
     P = len(names)
     # ---- 3. global strand-doubled order + per-partition cap
     n_local = ops.n_reads()
+    tick("partition+route", t0)
+    lock.release()
+    t0 = time.time()
     cdev = exchange.coll_device(ops.device, group)
     nl = torch.tensor([n_local], dtype=torch.int64, device=cdev)
     nls = [torch.zeros_like(nl) for _ in range(W)]
@@ -87,6 +119,9 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
     cts = [torch.zeros_like(ct) for _ in range(W)]
     dist.all_gather(cts, ct, group=group)
     allc = np.stack([c.cpu().numpy().reshape(P, 2) for c in cts])       # [W, P, 2]
+    tick("x:route counts", t0)
+    lock.acquire()
+    t0 = time.time()
     # position of this rank's first forward / first RC routed read of partition p in the global order
     fwd_before = allc[:rank, :, 0].sum(axis=0)
     rc_before = allc[:, :, 0].sum(axis=0) + allc[:rank, :, 1].sum(axis=0)
@@ -103,10 +138,18 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
         sel = np.concatenate([r[:keep_f], r[f:f + keep_r]])
         gidx = np.concatenate([base + r[:keep_f], n_glob + base + (r[f:f + keep_r] - n_local)])
         payload[i % W].append((i, gidx, ops.collect(sel)))
-    recv = [None] * W
-    dist.all_to_all_object_list(recv, payload, group=group) if hasattr(dist, "all_to_all_object_list") else _a2a_objects(recv, payload, group)
-    tick("route+read exchange", t0)
+    tick("collect reads", t0)
+    lock.release()
+    t0 = time.time()
+    if getattr(ops, "array_payload", False):        # code rows + flags: one all-to-all(v) of bytes
+        got = exchange.all_to_all_bytes([exchange.pack_read_pieces(items) for items in payload], ops.device, group)
+        recv = [exchange.unpack_read_pieces(b) for b in got]
+    else:                                           # python objects (the oracle-backed test ops): small inputs only
+        recv = [None] * W
+        _a2a_objects(recv, payload, group)
+    tick("x:read exchange", t0)
     # ---- 4. owned partitions: graph + sparse flow
+    lock.acquire()
     t0 = time.time()
     mine = {}
     for lst in recv:
@@ -141,10 +184,15 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
         txt += sparse_flow.single_nodes_fasta(sname, singles)
         texts[i] = txt
     tick("sparse flow", t0)
+    lock.release()
+    t0 = time.time()
     gathered = [None] * W
     dist.all_gather_object(gathered, texts, group=group)
+    tick("x:gather fasta", t0)
     if rank != 0:
         return None
+    lock.acquire()
+    t0 = time.time()
     merged = {}
     for d in gathered:
         merged.update(d)
@@ -155,7 +203,10 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
     for i, nm in enumerate(names):
         parts[nm] = merged[i]
         lines += merged[i].splitlines(True)
-    return {"partitions": parts, "all_reconstructed": lines, "final": post.finalize(lines, True), "contigs": res.contigs,
+    final = post.finalize(lines, True)
+    tick("merge (rank 0)", t0)
+    lock.release()
+    return {"partitions": parts, "all_reconstructed": lines, "final": final, "contigs": res.contigs,
             "n_k1mers": int(gk.numel()),
             "extension": {k: getattr(res, k, None) for k in ("iterations", "n_walks", "total_steps", "wave_steps")}}
 
@@ -204,12 +255,16 @@ class GpuOps(object):
 
     graph_threads = 8
     sharded_extension = True
+    array_payload = True               # collect() returns (code rows, strand flags): travels as bytes, not as pickles
 
     def extension(self, table, partition_size, group=None):
         """replicated table -> walks AND contig stages sharded by connected component of the k1-mer graph; the accepted
         contigs + their connections (a few MB) are all-gathered and merged in the global walk order"""
+        import time
         from . import extension_correction as ec
         W, rank = dist.get_world_size(group), dist.get_rank(group)
+        lock = getattr(self, "lock", None) or _NoLock()
+        self.coll_wait = 0.0               # seconds inside the contig stage's collectives (waiting for the slowest rank included)
 
         class Gather(object):                     # the collectives of the sharded contig stage
             world, rank = W, None
@@ -217,23 +272,33 @@ class GpuOps(object):
             @staticmethod
             def all_gather(obj):
                 parts = [None] * W
+                lock.release()
+                t0 = time.time()
                 dist.all_gather_object(parts, obj, group=group)
+                self.coll_wait += time.time() - t0
+                lock.acquire()
                 return parts
 
             @staticmethod
             def all_reduce_max(v):
                 t = torch.tensor([int(v)], dtype=torch.int64, device=exchange.coll_device(self.device, group))
+                lock.release()
+                t0 = time.time()
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+                self.coll_wait += time.time() - t0
+                lock.acquire()
                 return int(t.item())
 
         Gather.rank = rank
-        res = ec.run_correction(self.ctx, table, 3, 75, partition_size, want_allowed=False, shard=(W, rank), gather=Gather)
+        res = ec.run_correction(self.ctx, table, 3, 75, partition_size, want_allowed=False, shard=(W, rank), gather=Gather,
+                                timings=getattr(self, "timings", None))
         table.close()
         return res
 
     def route(self, res, K, partition_size, part_vectors):
         from . import kmers_for_component as kfc
-        return kfc.kmers_for_component(self.ctx, res, self.d1, self.d2, K, partition_size, part_vectors=part_vectors, want_rows=False)
+        return kfc.kmers_for_component(self.ctx, res, self.d1, self.d2, K, partition_size, part_vectors=part_vectors, want_rows=False,
+                                       timings=getattr(self, "timings", None))
 
     def n_nodes(self, part, name, K):
         return part["n_kmer_nodes"][name]
@@ -248,12 +313,18 @@ class GpuOps(object):
     def graph(self, part, name, pieces, K, paired):
         from . import mbgraph_native
         rb = part["k1mer_bytes"][name]                     # the partition's k1-mer file as fixed-width rows
-        if pieces:
-            gidx = np.concatenate([g for g, _ in pieces])
-            rows = np.concatenate([d[0] for _, d in pieces])
-            rc1 = np.concatenate([d[1] for _, d in pieces])
-            order = np.argsort(gidx, kind="stable")            # global strand-doubled order = the reference's file order
-            rows, rc1 = np.ascontiguousarray(rows[order]), np.ascontiguousarray(rc1[order])
+        if any(len(p[0]) for p in pieces):
+            # global strand-doubled order = the reference's file order
+            pieces = [p for p in pieces if len(p[0])]
+            one = len(pieces) == 1                                    # (no copy of a 100 MB piece)
+            gidx = pieces[0][0] if one else np.concatenate([g for g, _ in pieces])
+            rows = np.ascontiguousarray(pieces[0][1][0] if one else np.concatenate([d[0] for _, d in pieces]))
+            rc1 = np.ascontiguousarray(pieces[0][1][1] if one else np.concatenate([d[1] for _, d in pieces]))
+            if len(gidx) > 1 and not bool((gidx[1:] > gidx[:-1]).all()):      # (one source rank: already in order)
+                from . import _lib
+                order = np.argsort(gidx, kind="stable")
+                rows = _lib.gather_rows(rows, order)
+                rc1 = np.ascontiguousarray(rc1[order])
         else:
             rows, rc1 = np.zeros((0, 1), np.uint8), np.zeros(0, np.uint8)
         off = np.arange(len(rows) + 1, dtype=np.uint64) * np.uint64(rows.shape[1])

@@ -67,3 +67,49 @@ def exchange_table(ctx, table, group=None):
     rk, rcn, _ = all_to_all_pairs(dk, dc, per, group)
     torch.cuda.synchronize()
     return device.Table.from_pairs(ctx, rk.data_ptr(), rcn.data_ptr(), rk.numel(), table.k, table.canonical)
+
+
+def all_to_all_bytes(bufs, device, group=None):
+    """bufs[d] = contiguous uint8 numpy array for rank d.  One all-to-all(v) of bytes (RCCL: staged through device
+    memory; gloo: host memory).  Returns the arrays received, indexed by source rank."""
+    world = dist.get_world_size(group)
+    cdev = coll_device(device, group)
+    sc = [int(b.size) for b in bufs]
+    st = torch.tensor(sc, dtype=torch.int64, device=cdev)
+    rt = torch.empty(world, dtype=torch.int64, device=cdev)
+    dist.all_to_all_single(rt, st, group=group)
+    rc = [int(v) for v in rt.cpu().tolist()]
+    send = torch.from_numpy(np.concatenate(bufs) if sum(sc) else np.zeros(0, np.uint8)).to(cdev)
+    recv = torch.empty(sum(rc), dtype=torch.uint8, device=cdev)
+    dist.all_to_all_single(recv, send, rc, sc, group=group)
+    out = recv.cpu().numpy()
+    offs = np.concatenate([[0], np.cumsum(rc)]).astype(np.int64)
+    return [out[offs[i]:offs[i + 1]] for i in range(world)]
+
+
+def pack_read_pieces(items):
+    """items: [(partition index, global doubled indices int64[n], (rows uint8[n, L], rc flags uint8[n]))] -> one uint8 array."""
+    head = [len(items)]
+    body = []
+    for p, gidx, (rows, rc1) in items:
+        n, L = int(rows.shape[0]), int(rows.shape[1]) if rows.ndim == 2 else 0
+        head += [int(p), n, L]
+        body += [np.ascontiguousarray(gidx, dtype=np.int64).view(np.uint8).reshape(-1), np.ascontiguousarray(rows, dtype=np.uint8).reshape(-1),
+                 np.ascontiguousarray(rc1, dtype=np.uint8).reshape(-1)]
+    return np.concatenate([np.asarray(head, dtype=np.int64).view(np.uint8)] + body)
+
+
+def unpack_read_pieces(buf):
+    """inverse of pack_read_pieces (views into buf)."""
+    if buf.size == 0:
+        return []
+    n_items = int(buf[:8].view(np.int64)[0])
+    head = buf[8:8 + 24 * n_items].view(np.int64).reshape(n_items, 3)
+    pos = 8 + 24 * n_items
+    out = []
+    for p, n, L in head.tolist():
+        gidx = buf[pos:pos + 8 * n].view(np.int64); pos += 8 * n
+        rows = buf[pos:pos + n * L].reshape(n, L); pos += n * L
+        rc1 = buf[pos:pos + n]; pos += n
+        out.append((p, gidx, (rows, rc1)))
+    return out

@@ -284,12 +284,18 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
         acc, coff, cnb, cw = contig_stage(strings, k1, r, f)
         bestc = contig_best_counts(len(strings))
         mine = [local[i] for i in np.nonzero(acc)[0].tolist()]              # accepted here, local order
+        lap("ext.contig_graph")
         everybody = gather.all_gather(mine)
+        lap("ext.gathers")
         foreign = [c for rk, lst in enumerate(everybody) if rk != gather.rank for c in lst]
         unsafe = foreign_interference(ctx, local, acc, bestc, foreign, r, f)
-        if gather.all_reduce_max(1 if unsafe else 0) == 0:
+        lap("ext.guard")
+        safe = gather.all_reduce_max(1 if unsafe else 0) == 0
+        lap("ext.gathers")
+        if safe:
             sharded_contigs = True
             conns = gather.all_gather((coff, cnb, cw))
+            lap("ext.gathers")
             items = sorted(((c[0], c[1], rk, j) for rk, lst in enumerate(everybody) for j, c in enumerate(lst)), key=lambda t: (-t[0], t[1]))
             gid = {(rk, j): g + 1 for g, (_w, _k, rk, j) in enumerate(items)}    # global 1-based accepted index
             for _w, _k, rk, j in items:
@@ -297,6 +303,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
             for _w, _k, rk, j in items:
                 o, nb_, w_ = conns[rk]
                 conn[gid[(rk, j)]] = {gid[(rk, q - 1)]: ww for q, ww in zip(nb_[o[j]:o[j + 1]], w_[o[j]:o[j + 1]])}
+            lap("ext.merge")
         else:
             allc = [c for lst in gather.all_gather(local) for c in lst]
             allc.sort(key=lambda c: (-c[0], c[1]))

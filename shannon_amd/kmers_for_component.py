@@ -137,16 +137,26 @@ def make_table(ctx, keys, values, k, canonical=False):
 
 
 def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overload=2, penalty=5, repartition=True,
-                        part_vectors=None, want_rows=True):
+                        part_vectors=None, want_rows=True, timings=None):
     """Rows a8-a11.  reads1/reads2: device.Reads (reads2 None for single-end).  Returns dict with
       new_components {name: [contig]}          (kmers_for_component.py:244-305)
       k1mers {name: [(k1mer, weight)]}         (:452-477, == component{name}k1mers_allowed.dict)
       contig_weights {name: [[w..] per contig]} (--inMem form :468-469)
       routes {name: uint32 array of doubled read indices in input order}   (:322-403)
     """
+    import time as _t
+    _t0 = [_t.time()]
+
+    def lap(name):
+        if timings is not None:
+            now = _t.time()
+            timings[name] = timings.get(name, 0.0) + now - _t0[0]
+            _t0[0] = now
+
     k1 = K + 1
     comps, broken = build_partitions(res, K, partition_size, overload, penalty, repartition, part_vectors)
     names = list(comps)
+    lap("route.partitions")
     pid_of = {n: i for i, n in enumerate(names)}
     # k1mers2component (:244-305): every k1-window of every partition contig -> set of partitions
     key_sets = {}
@@ -201,16 +211,19 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
     set_off = np.zeros(len(sets) + 1, dtype=np.uint32)
     set_off[1:] = np.cumsum([len(s) for s in sets])
     set_mem = np.array([p for s in sets for p in s], dtype=np.uint32) if sets else np.zeros(1, np.uint32)
+    lap("route.k1mer map")
     probe = make_table(ctx, uk, set_ids, k1, canonical=False)
     h = C.c_void_p()
     _lib.check(_lib.lib().shn_route_reads(ctx.h, reads1.h, reads2.h if reads2 is not None else None, k1, probe.h,
                                           set_off.ctypes.data, set_mem.ctypes.data, len(sets), C.byref(h)))
+    lap("route.kernel")
     routes = Routes(ctx, h)
     pid, ridx = routes.download()
     routes.close()
     probe.close()
     bounds = np.searchsorted(pid, np.arange(len(names) + 1))
     by_part = {n: ridx[bounds[i]:bounds[i + 1]] for i, n in enumerate(names)}
+    lap("route.download")
     # per-partition k1-mer rows with weights from the allowed dict (:452-477)
     rows_bytes, n_nodes = {}, {}
     for name in names:
@@ -237,6 +250,7 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
                 ws.append(wl)
             files[name] = rows
             cw[name] = ws
+    lap("route.rows")
     return {"new_components": comps, "components_broken": broken, "k1mers": files, "contig_weights": cw, "routes": by_part,
             "k1mer_bytes": rows_bytes, "n_kmer_nodes": n_nodes}
 
@@ -271,12 +285,18 @@ class ReadStore(object):
         # one gather per source matrix straight into the output (idx is ascending: forward half first)
         L0 = self.r1.shape[1]
         rows = np.empty((len(idx), L0), dtype=np.uint8)
-        fwd, bwd = np.nonzero(~second)[0], np.nonzero(second)[0]
         src2 = self.r1 if self.r2 is None else self.r2
-        if len(fwd):
-            rows[fwd] = self.r1[idx[fwd]]
-        if len(bwd):
-            rows[bwd] = src2[idx[bwd] - n]
+        f = int(np.searchsorted(idx, n)) if (len(idx) < 2 or bool((idx[1:] >= idx[:-1]).all())) else -1
+        if f >= 0 and len(idx) >= 4096 and self.r1.flags["C_CONTIGUOUS"] and src2.flags["C_CONTIGUOUS"] and self.r1.dtype == np.uint8:
+            from . import _lib                                           # ascending: forward half, then RC half -- two threaded gathers
+            _lib.gather_rows(self.r1, idx[:f], rows[:f])
+            _lib.gather_rows(src2, idx[f:] - n, rows[f:])
+        else:
+            fwd, bwd = np.nonzero(~second)[0], np.nonzero(second)[0]
+            if len(fwd):
+                rows[fwd] = self.r1[idx[fwd]]
+            if len(bwd):
+                rows[bwd] = src2[idx[bwd] - n]
         if self.r2 is None:
             rc = second                                                     # SE: R[d] / RC(R[d-n])
         elif mate == 1:
