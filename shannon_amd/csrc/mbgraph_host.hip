@@ -5,6 +5,7 @@
 // host code; the order-defining conventions (P1-P3) are identical to the Python mirror,
 // which stays as the readable specification and is cross-checked against this in the tests.
 #include "common.h"
+#include <atomic>
 #include "flatmap.h"
 #include <thread>
 #include <mutex>
@@ -297,9 +298,13 @@ struct Graph {
     for (int j = 0; j < K; j++) { int c = base_code(s[pos + j]); if (c < 0) return false; key = (key << 2) | (uint64_t)c; }
     return true;
   }
-  bool reads_all_acgt() const {
-    for (char c : rindex.arena) if (base_code(c) < 0) return false;
-    return true;
+  int acgt_known = -1;        // set while the reads are loaded (a scan of the arena is 10s of ms at the read cap); -1 = scan
+  bool reads_all_acgt() {
+    if (acgt_known < 0) {
+      acgt_known = 1;
+      for (char c : rindex.arena) if (base_code(c) < 0) { acgt_known = 0; break; }
+    }
+    return acgt_known == 1;
   }
   // device copy of the distinct reads + pattern table; returns false if the GPU path is not usable
   bool gpu_patterns(const SeedIndex& si, shn_reads** dreads, shn_table** tab) {
@@ -772,19 +777,25 @@ extern "C" int shn_mbgraph_run(shn_ctx* ctx, int K, const uint8_t* rows, uint64_
     if (text.size() < doff.back() + 1) text.resize(doff.back() + 1);
     hashes.resize((size_t)used * nm);
     double t_dec = now();
+    std::atomic<int> non_acgt{0};
     auto work = [&](uint64_t lo, uint64_t hi) {
+      bool bad = false;
+      auto check = [&](const char* d, uint64_t n) { for (uint64_t j = 0; j < n; j++) bad |= !(d[j] == 'A' || d[j] == 'C' || d[j] == 'G' || d[j] == 'T'); };
       for (uint64_t i = lo; i < hi; i++) {
         char* d1 = text.data() + doff[i * nm];
         const uint64_t n1 = r1_off[i + 1] - r1_off[i];
         decode_read(d1, r1 + r1_off[i], n1, enc, rc1 && rc1[i]);
+        check(d1, n1);
         hashes[i * nm] = StringInterner::hash(d1, n1);
         if (paired) {
           char* d2 = text.data() + doff[i * nm + 1];
           const uint64_t n2 = r2_off[i + 1] - r2_off[i];
           decode_read(d2, r2 + r2_off[i], n2, enc, rc2 && rc2[i]);
+          check(d2, n2);
           hashes[i * nm + 1] = StringInterner::hash(d2, n2);
         }
       }
+      if (bad) non_acgt.store(1);
     };
     unsigned nt = std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
     if (used < 65536) nt = 1;
@@ -795,6 +806,7 @@ extern "C" int shn_mbgraph_run(shn_ctx* ctx, int K, const uint8_t* rows, uint64_
       for (unsigned t = 0; t < nt; t++) { uint64_t lo = t * per, hi = std::min<uint64_t>(used, lo + per); if (lo < hi) th.emplace_back(work, lo, hi); }
       for (auto& t : th) t.join();
     }
+    g.acgt_known = non_acgt.load() ? 0 : 1;
     if (dbg) fprintf(stderr, "[mbgraph]   offsets+decode+hash   %8.3f s\n", now() - t_dec);
     const uint64_t nh = used * nm;
     for (uint64_t i = 0; i < used; i++) {
