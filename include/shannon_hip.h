@@ -73,6 +73,11 @@ uint64_t shn_reads_n_invalid(const shn_reads* r);
 /* Host utility: dst row i = src row idx[i] (rows of row_bytes bytes; src has n_src_rows rows), on `threads` host threads.
  * Used for the capped read sets of a partition (kmers_for_component.py:322-403 writes them to per-component files;
  * here they are gathered from the resident read matrix).  SHN_ERR_ARG on an index out of range.                          */
+/* Host utility: all k-windows of n_strings ACGT strings (text + offsets), in order, as packed keys (keys_out, may be NULL;
+ * k <= 32) and/or k-byte rows (rows_out, may be NULL).  What k1mers2component / the per-component k1-mer files
+ * (kmers_for_component.py:244-305, 452-477) enumerate.  SHN_ERR_ARG on a base outside ACGT.                              */
+int shn_string_windows(const uint8_t* text, const uint64_t* off, uint64_t n_strings, int k, uint64_t* keys_out, uint8_t* rows_out);
+
 int shn_gather_rows(const uint8_t* src, uint64_t n_src_rows, uint64_t row_bytes, const int64_t* idx, uint64_t n, uint8_t* dst, int threads);
 
 /* ---- (K+1)-mer counting ----------------------------------------------------------------------

@@ -25,6 +25,7 @@ SIGNATURES = {
     "shn_reads_total_bases": (C.c_uint64, [vp]),
     "shn_reads_max_len": (C.c_uint32, [vp]),
     "shn_reads_n_invalid": (C.c_uint64, [vp]),
+    "shn_string_windows": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp, vp]),
     "shn_gather_rows": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp, C.c_int]),
     "shn_count_k1mers": (C.c_int, [vp, vpp, C.c_int, C.c_int, C.c_int, vpp]),
     "shn_table_destroy": (None, [vp]),
@@ -87,9 +88,13 @@ def lib():
     return _lib
 
 
+class ShannonError(RuntimeError):
+    """a call into libshannon_hip returned an error code"""
+
+
 def check(rc):
     if rc != 0:
-        raise RuntimeError("libshannon_hip: %s (code %d)" % (lib().shn_last_error().decode(), rc))
+        raise ShannonError("libshannon_hip: %s (code %d)" % (lib().shn_last_error().decode(), rc))
 
 
 def gather_rows(src, idx, out=None, threads=8):
@@ -104,3 +109,21 @@ def gather_rows(src, idx, out=None, threads=8):
     if len(idx) and rb:
         check(lib().shn_gather_rows(src.ctypes.data, src.shape[0], rb, idx.ctypes.data, len(idx), out.ctypes.data, int(threads)))
     return out
+
+
+def string_windows(strings, k, want_keys=True, want_rows=False):
+    """(keys uint64[n_windows] or None, rows uint8[n_windows * k] or None, windows per string) of all k-windows of ACGT
+    strings, in order (shn_string_windows).  Raises ShannonError on a base outside ACGT."""
+    import numpy as np
+    lens = np.array([len(c) for c in strings], dtype=np.int64)
+    nwin = np.maximum(lens - k + 1, 0)
+    total = int(nwin.sum())
+    text = np.frombuffer("".join(strings).encode(), dtype=np.uint8)
+    off = np.zeros(len(strings) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    keys = np.empty(total, dtype=np.uint64) if want_keys else None
+    rows = np.empty(total * k, dtype=np.uint8) if want_rows else None
+    if total:
+        check(lib().shn_string_windows(text.ctypes.data, off.ctypes.data, len(strings), int(k),
+                                       keys.ctypes.data if want_keys else None, rows.ctypes.data if want_rows else None))
+    return keys, rows, nwin

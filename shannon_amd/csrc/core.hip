@@ -329,3 +329,31 @@ extern "C" int shn_gather_rows(const uint8_t* src, uint64_t n_src_rows, uint64_t
   for (auto& x : th) x.join();
   return SHN_OK;
 }
+
+
+// ---- host utility: every k-window of every string (ASCII ACGT, strings given by offsets into one text), in order: as
+// packed 2-bit keys (keys_out, k <= 32) and/or as fixed-width byte rows (rows_out, k bytes per window).  The partition
+// stage needs both for every partition contig (k1mers2component, kmers_for_component.py:244-305; the k1-mer files,
+// :452-477).  Returns SHN_ERR_ARG on a base outside ACGT (the caller then takes its general path).
+extern "C" int shn_string_windows(const uint8_t* text, const uint64_t* off, uint64_t n_strings, int k, uint64_t* keys_out, uint8_t* rows_out) {
+  if ((n_strings && (!text || !off)) || k < 1 || (keys_out && k > 32)) return shn_fail(SHN_ERR_ARG, "shn_string_windows: bad argument");
+  const uint64_t mask = k == 32 ? ~0ULL : ((1ULL << (2 * k)) - 1);
+  uint64_t w = 0;
+  for (uint64_t i = 0; i < n_strings; i++) {
+    const uint8_t* s = text + off[i];
+    const uint64_t L = off[i + 1] - off[i];
+    uint64_t key = 0;
+    for (uint64_t p = 0; p < L; p++) {
+      int c;
+      switch (s[p]) { case 'A': c = 0; break; case 'C': c = 1; break; case 'G': c = 2; break; case 'T': c = 3; break;
+                      default: return shn_fail(SHN_ERR_ARG, "shn_string_windows: base outside ACGT"); }
+      key = ((key << 2) | (uint64_t)c) & mask;
+      if (p + 1 >= (uint64_t)k) {
+        if (keys_out) keys_out[w] = key;
+        if (rows_out) memcpy(rows_out + w * (uint64_t)k, s + p + 1 - k, (size_t)k);
+        w++;
+      }
+    }
+  }
+  return SHN_OK;
+}

@@ -129,6 +129,12 @@ def windows_to_keys_many(contigs, k):
     total = int(lens.sum())
     if total < k or not nwin.any():
         return np.zeros(0, dtype=np.uint64), nwin
+    if k <= 32 and total >= 4096:
+        try:                                         # native pass (shn_string_windows); non-ACGT text takes the general path below
+            keys, _rows, nw = _lib.string_windows(contigs, k)
+            return keys, nw
+        except _lib.ShannonError:
+            pass
     c = _CODE[np.frombuffer("".join(contigs).encode(), dtype=np.uint8)].astype(np.uint64)
     n = total - k + 1
     key = np.zeros(n, dtype=np.uint64)

@@ -173,13 +173,28 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
         allk, allp = np.zeros(0, np.uint64), np.zeros(0, np.uint32)
     # distinct (k1-mer, partition) pairs, grouped by k1-mer; a k1-mer lies on exactly one contig, so its set
     # has one partition (remaining bin) or two (gpmetis run + r2 run): singleton sets are handled vectorised
-    order = np.lexsort((allp, allk))
-    sk, sp = allk[order], allp[order]
+    pbits = max(1, int(len(names)).bit_length())
+    if 2 * k1 + pbits <= 64:
+        # one sort of (k1-mer << pbits | partition) instead of an indirect two-key sort
+        code = np.sort((allk << np.uint64(pbits)) | allp.astype(np.uint64))
+        if len(code):
+            code = code[np.concatenate([[True], code[1:] != code[:-1]])]
+        sk, sp = code >> np.uint64(pbits), (code & np.uint64((1 << pbits) - 1)).astype(np.uint32)
+    else:
+        order = np.lexsort((allp, allk))
+        sk, sp = allk[order], allp[order]
+        if len(sk):
+            keepm = np.ones(len(sk), dtype=bool)
+            keepm[1:] = (sk[1:] != sk[:-1]) | (sp[1:] != sp[:-1])
+            sk, sp = sk[keepm], sp[keepm]
+    # sk is sorted: group boundaries instead of np.unique's second sort
     if len(sk):
-        keepm = np.ones(len(sk), dtype=bool)
-        keepm[1:] = (sk[1:] != sk[:-1]) | (sp[1:] != sp[:-1])
-        sk, sp = sk[keepm], sp[keepm]
-    uk, start, cntk = np.unique(sk, return_index=True, return_counts=True)
+        first = np.concatenate([[True], sk[1:] != sk[:-1]])
+        start = np.nonzero(first)[0]
+        uk = sk[start]
+        cntk = np.diff(np.concatenate([start, [len(sk)]]))
+    else:
+        uk, start, cntk = np.zeros(0, np.uint64), np.zeros(0, np.int64), np.zeros(0, np.int64)
     set_ids, sets, set_index = np.zeros(len(uk), np.uint32), [], {}
     single = cntk == 1
     if single.any():
@@ -228,16 +243,24 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
     rows_bytes, n_nodes = {}, {}
     for name in names:
         # fixed-width byte form of the k1-mer file (what the native graph stage consumes) + #distinct K-mers
-        chunks = []
-        for contig in comps[name]:
-            b = np.frombuffer(contig.encode(), dtype=np.uint8)
-            nwin = len(b) - k1 + 1
-            if nwin > 0:
-                chunks.append(np.lib.stride_tricks.sliding_window_view(b, k1).reshape(-1))
-        rb = np.concatenate(chunks) if chunks else np.zeros(0, np.uint8)
+        rb = None
+        if comps[name]:
+            try:                                     # native pass over the joined contigs (shn_string_windows)
+                _k, rb, _nw = _lib.string_windows(comps[name], k1, want_keys=False, want_rows=True)
+            except _lib.ShannonError:
+                rb = None
+        if rb is None:
+            chunks = []
+            for contig in comps[name]:
+                b = np.frombuffer(contig.encode(), dtype=np.uint8)
+                nwin = len(b) - k1 + 1
+                if nwin > 0:
+                    chunks.append(np.lib.stride_tricks.sliding_window_view(b, k1).reshape(-1))
+            rb = np.concatenate(chunks) if chunks else np.zeros(0, np.uint8)
         rows_bytes[name] = np.ascontiguousarray(rb)
         kk, _nw = windows_to_keys_many(comps[name], K)
-        n_nodes[name] = int(len(np.unique(kk)))
+        kk = np.sort(kk)
+        n_nodes[name] = int((kk[1:] != kk[:-1]).sum()) + 1 if len(kk) else 0
         if want_rows:
             rows, ws = [], []
             for contig in comps[name]:
