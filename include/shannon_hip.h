@@ -179,6 +179,12 @@ int shn_route_reads(shn_ctx* ctx, const shn_reads* r1, const shn_reads* r2, int 
 void shn_routes_destroy(shn_routes* r);
 uint64_t shn_routes_size(const shn_routes* r);
 int shn_routes_download(shn_ctx* ctx, const shn_routes* r, uint32_t* pid, uint32_t* ridx);
+/* Routes are sorted by (partition, doubled read index).  start[p] (n_parts+1 entries) = first route of partition p;
+ * below[p] = how many routes of partition p have a read index < split (the forward half of the strand-doubled order).
+ * With shn_routes_download_range a caller fetches only the capped prefix a partition's graph may consume
+ * (multibridging.py:26-30) instead of every route.                                                                       */
+int shn_routes_bounds(shn_ctx* ctx, const shn_routes* r, uint32_t n_parts, uint32_t split, uint64_t* start, uint64_t* below);
+int shn_routes_download_range(shn_ctx* ctx, const shn_routes* r, uint64_t lo, uint64_t n, uint32_t* ridx);
 
 /* ---- K-mer seed scans of reads against graph nodes -----------------------------------------------
  * Replace the per-read Python loops of Read.find_bridging_reads (mbgraph.py:88-111) and known_paths

@@ -100,11 +100,12 @@ __global__ void ext_prepare_kernel(const uint64_t* __restrict__ tkeys, const uin
 __global__ void ext_adjacency_kernel(const uint64_t* __restrict__ tkeys, const uint64_t* __restrict__ boff, int bits,
                                      const uint8_t* __restrict__ flags, uint64_t n, int k, int canonical,
                                      int32_t* __restrict__ adjR, int32_t* __restrict__ adjL) {
-  uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (oriented, dir, base)
-  if (gid >= n * 16) return;
+  // one thread per (oriented, dir, base); adjL == nullptr: right rows only (all the component labelling needs), n * 8 threads
+  uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n * (adjL ? 16 : 8)) return;
   uint32_t b = gid & 3;
-  uint32_t dir = (gid >> 2) & 1;
-  uint64_t o = gid >> 3;
+  uint32_t dir = adjL ? (gid >> 2) & 1 : 0;
+  uint64_t o = adjL ? gid >> 3 : gid >> 2;
   uint64_t i = o >> 1;
   int32_t res = -1;
   uint8_t f = flags[i];
@@ -859,12 +860,12 @@ static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank
   TRYS(shn_dev_malloc(&d_weight, (n + 1) * 4));
   TRYS(shn_dev_malloc(&d_flags, n + 1));
   TRYS(shn_dev_malloc(&d_adjR, (2 * n + 1) * 16));
-  TRYS(shn_dev_malloc(&d_adjL, (2 * n + 1) * 16));
   {
     TimerRegion t1(ctx, T_EXT_PREP);
     hipLaunchKernelGGL(ext_prepare_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, t->d_counts, n, t->k, t->canonical, d_weight, d_flags);
-    hipLaunchKernelGGL(ext_adjacency_kernel, dim3((uint32_t)cdiv(n * 16, 256)), dim3(256), 0, s, t->d_keys, t->d_bucket_off, t->bits, d_flags, n, t->k,
-                       t->canonical, d_adjR, d_adjL);
+    // right rows of both orientations hold every edge of the (undirected) k1-mer graph: the left rows are not needed here
+    hipLaunchKernelGGL(ext_adjacency_kernel, dim3((uint32_t)cdiv(n * 8, 256)), dim3(256), 0, s, t->d_keys, t->d_bucket_off, t->bits, d_flags, n, t->k,
+                       t->canonical, d_adjR, (int32_t*)nullptr);
   }
   void *pl, *po, *pz, *pb, *pc, *pp;
   const uint32_t big_cap = 1u << 16;

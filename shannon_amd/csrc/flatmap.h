@@ -63,6 +63,7 @@ struct StringInterner {
   std::vector<uint64_t> off;              // per id: arena offset (off[id+1] = end)
   std::string arena;
   size_t mask = 0;
+  bool bulk_loaded = false;               // entries were appended without going through the probe table
   explicit StringInterner(size_t expect = 1024) { size_t c = 1024; while (c < expect * 2) c <<= 1; table.assign(c, -1); mask = c - 1; off.push_back(0); }
   static uint64_t hash(const char* p, size_t n) {
     uint64_t h = 0x9E3779B97F4A7C15ULL ^ n;
@@ -78,6 +79,7 @@ struct StringInterner {
   // returns id; *is_new tells whether it was inserted now
   int32_t intern(const char* p, size_t n, bool* is_new) { return intern_hashed(p, n, hash(p, n), is_new); }
   int32_t intern_hashed(const char* p, size_t n, uint64_t h, bool* is_new) {   // h = hash(p, n), computed elsewhere
+    if (bulk_loaded) { fprintf(stderr, "StringInterner: intern after a bulk load\n"); abort(); }
     if ((hashes.size() + 1) * 10 > (mask + 1) * 6) grow();
     size_t s = h & mask;
     while (table[s] >= 0) {

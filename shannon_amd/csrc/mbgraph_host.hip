@@ -741,7 +741,7 @@ extern "C" int shn_mbgraph_run(shn_ctx* ctx, int K, const uint8_t* rows, uint64_
   uint64_t cutoff = (uint64_t)g.order.size() * 10;
   // Scratch kept between calls (at the read cap these buffers are 100s of MB, and fresh pages cost more than the work done
   // in them): decode buffers and the read arena.  A free list, not thread_local: Python's partition workers are short-lived.
-  struct Scratch { std::vector<uint64_t> doff, hashes; std::vector<char> text; std::string arena; };
+  struct Scratch { std::vector<uint64_t> doff, hashes; std::vector<char> text; std::string arena; std::vector<uint32_t> first; std::vector<int32_t> idmap; };
   static std::mutex scratch_mu;
   static std::vector<Scratch*> scratch_free;
   Scratch* sc = nullptr;
@@ -798,7 +798,9 @@ extern "C" int shn_mbgraph_run(shn_ctx* ctx, int K, const uint8_t* rows, uint64_
       if (bad) non_acgt.store(1);
     };
     unsigned nt = std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
-    if (used < 65536) nt = 1;
+    uint64_t bulk_min = 1u << 17;                       // reads from which the duplicates are found in parallel (tests lower it)
+    if (getenv("SHN_GRAPH_BULK_MIN")) { bulk_min = strtoull(getenv("SHN_GRAPH_BULK_MIN"), nullptr, 10); nt = std::max(nt, 4u); }
+    if (used < 65536 && used * nm < bulk_min) nt = 1;
     if (nt <= 1) work(0, used);
     else {
       std::vector<std::thread> th;
@@ -809,13 +811,57 @@ extern "C" int shn_mbgraph_run(shn_ctx* ctx, int K, const uint8_t* rows, uint64_
     g.acgt_known = non_acgt.load() ? 0 : 1;
     if (dbg) fprintf(stderr, "[mbgraph]   offsets+decode+hash   %8.3f s\n", now() - t_dec);
     const uint64_t nh = used * nm;
-    for (uint64_t i = 0; i < used; i++) {
-      // the interner is a few hundred MB at the cap: every probe is a chain of cache misses unless fetched ahead
-      for (int m = 0; m < nm; m++) {
-        const uint64_t j = i * nm + m;
-        if (j + 24 < nh) g.rindex.prefetch_slot(hashes[j + 24]);
-        if (j + 12 < nh) g.rindex.prefetch_entry(hashes[j + 12]);
+    if (nt > 1 && nh >= bulk_min) {
+      // Large read sets: the duplicates are found by `nt` host threads, each owning the strings whose hash falls into its
+      // shard (private open-addressing table: string -> index of its first occurrence); ids are then handed out in file
+      // order of first occurrence by one linear pass -- the same ids, counts and mates as interning one read at a time.
+      std::vector<uint32_t>& first = sc->first;
+      first.resize(nh);
+      auto dedup = [&](unsigned t) {
+        uint64_t mine = 0;
+        for (uint64_t j = 0; j < nh; j++) mine += ((hashes[j] >> 40) % nt) == t;
+        size_t cap = 1024;
+        while (cap < mine * 2) cap <<= 1;
+        std::vector<uint32_t> tab(cap, 0xFFFFFFFFu);
+        const size_t m = cap - 1;
+        for (uint64_t j = 0; j < nh; j++) {
+          const uint64_t h = hashes[j];
+          if (((h >> 40) % nt) != t) continue;
+          const char* p = text.data() + doff[j];
+          const uint64_t n = doff[j + 1] - doff[j];
+          size_t sl = (size_t)h & m;
+          while (true) {
+            const uint32_t q = tab[sl];
+            if (q == 0xFFFFFFFFu) { tab[sl] = (uint32_t)j; first[j] = (uint32_t)j; break; }
+            if (hashes[q] == h && doff[q + 1] - doff[q] == n && memcmp(text.data() + doff[q], p, n) == 0) { first[j] = q; break; }
+            sl = (sl + 1) & m;
+          }
+        }
+      };
+      { std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back(dedup, t);
+        for (auto& t : th) t.join(); }
+      std::vector<int32_t>& idmap = sc->idmap;
+      idmap.resize(nh);
+      StringInterner& R = g.rindex;
+      for (uint64_t j = 0; j < nh; j++) {
+        if (first[j] == (uint32_t)j) {
+          const int32_t id = (int32_t)R.hashes.size();
+          R.hashes.push_back(hashes[j]);
+          R.arena.append(text.data() + doff[j], doff[j + 1] - doff[j]);
+          R.off.push_back(R.arena.size());
+          g.rcc.push_back(1.0); g.rmate.push_back(-1); g.rmp.push_back(0); g.rnodes.emplace_back(); g.rhas.push_back(0);
+          idmap[j] = id;
+        } else {
+          const int32_t id = idmap[first[j]];
+          g.rcc[id] += 1.0;
+          idmap[j] = id;
+        }
+        if (paired && (j & 1)) { const int a = idmap[j - 1], b = idmap[j]; g.rmp[a] = 1; g.rmp[b] = 2; g.rmate[a] = b; g.rmate[b] = a; }
       }
+      R.bulk_loaded = true;                 // (its probe table was bypassed: no interning by string after this)
+    } else
+    for (uint64_t i = 0; i < used; i++) {
       int a = g.add_read(text.data() + doff[i * nm], doff[i * nm + 1] - doff[i * nm], hashes[i * nm]);
       if (paired) {
         int b = g.add_read(text.data() + doff[i * nm + 1], doff[i * nm + 2] - doff[i * nm + 1], hashes[i * nm + 1]);

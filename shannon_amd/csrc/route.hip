@@ -129,6 +129,46 @@ extern "C" int shn_routes_download(shn_ctx* ctx, const shn_routes* r, uint32_t* 
   return SHN_OK;
 }
 
+// Routes are sorted by (partition, doubled read index): where every partition starts, and how many of its routes lie
+// below `split` (= the forward half of the strand-doubled order) -- one thread per partition, two binary searches.
+__global__ void routes_bounds_kernel(const uint32_t* __restrict__ pid, const uint32_t* __restrict__ ridx, uint64_t n, uint32_t n_parts,
+                                     uint32_t split, uint64_t* __restrict__ start, uint64_t* __restrict__ below) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > n_parts) return;
+  auto lower_pid = [&](uint32_t v) { uint64_t lo = 0, hi = n; while (lo < hi) { uint64_t m = (lo + hi) >> 1; if (pid[m] < v) lo = m + 1; else hi = m; } return lo; };
+  const uint64_t a = lower_pid(p);
+  start[p] = a;
+  if (p == n_parts) return;
+  const uint64_t b = lower_pid(p + 1);
+  uint64_t lo = a, hi = b;
+  while (lo < hi) { uint64_t m = (lo + hi) >> 1; if (ridx[m] < split) lo = m + 1; else hi = m; }
+  below[p] = lo - a;
+}
+
+extern "C" int shn_routes_bounds(shn_ctx* ctx, const shn_routes* r, uint32_t n_parts, uint32_t split, uint64_t* start, uint64_t* below) {
+  if (!ctx || !r || !start || !below) return shn_fail(SHN_ERR_ARG, "shn_routes_bounds: NULL argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  uint64_t* d = nullptr;
+  HIP_TRY(shn_dev_malloc(&d, (size_t)(2 * n_parts + 2) * 8));
+  hipLaunchKernelGGL(routes_bounds_kernel, dim3((n_parts + 1 + 63) / 64), dim3(64), 0, s, r->d_pid, r->d_ridx, r->n, n_parts, split, d, d + n_parts + 1);
+  HIP_TRY(hipMemcpyAsync(start, d, (size_t)(n_parts + 1) * 8, hipMemcpyDeviceToHost, s));
+  if (n_parts) HIP_TRY(hipMemcpyAsync(below, d + n_parts + 1, (size_t)n_parts * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  shn_dev_free(d);
+  HIP_TRY(hipGetLastError());
+  return SHN_OK;
+}
+
+extern "C" int shn_routes_download_range(shn_ctx* ctx, const shn_routes* r, uint64_t lo, uint64_t n, uint32_t* ridx) {
+  if (!ctx || !r || (n && !ridx)) return shn_fail(SHN_ERR_ARG, "shn_routes_download_range: NULL argument");
+  if (lo + n > r->n) return shn_fail(SHN_ERR_ARG, "shn_routes_download_range: range outside the routes");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (n) HIP_TRY(hipMemcpyAsync(ridx, r->d_ridx + lo, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return SHN_OK;
+}
+
 extern "C" int shn_route_reads(shn_ctx* ctx, const shn_reads* r1, const shn_reads* r2, int k1, const shn_table* probe,
                                const uint32_t* set_off, const uint32_t* set_members, uint32_t n_sets, shn_routes** out) {
   if (!ctx || !r1 || !probe || !set_off || !out) return shn_fail(SHN_ERR_ARG, "shn_route_reads: NULL argument");

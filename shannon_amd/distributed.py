@@ -113,7 +113,7 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
     cnt = np.zeros((P, 2), dtype=np.int64)          # routed reads of this rank: forward half / RC half
     for i, nm in enumerate(names):
         r = part["routes"][nm]
-        f = int(np.searchsorted(r, n_local))
+        f = r.count_below_split() if hasattr(r, "count_below_split") else int(np.searchsorted(r, n_local))
         cnt[i] = (f, len(r) - f)
     ct = torch.as_tensor(cnt.reshape(-1), device=cdev)
     cts = [torch.zeros_like(ct) for _ in range(W)]
@@ -129,14 +129,15 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
     payload = [[] for _ in range(W)]                # per destination rank: (partition, global doubled indices, reads)
     for i, nm in enumerate(names):
         cutoff = 10 * ops.n_nodes(part, nm, K) + 1
-        r = np.asarray(part["routes"][nm], dtype=np.int64)
+        r = part["routes"][nm]                      # array, or a RouteView: only the kept prefixes are fetched
         f = int(cnt[i, 0])
         keep_f = int(max(0, min(f, cutoff - fwd_before[i])))
         keep_r = int(max(0, min(len(r) - f, cutoff - rc_before[i])))
         if keep_f + keep_r == 0:
             continue
-        sel = np.concatenate([r[:keep_f], r[f:f + keep_r]])
-        gidx = np.concatenate([base + r[:keep_f], n_glob + base + (r[f:f + keep_r] - n_local)])
+        rf, rr = np.asarray(r[:keep_f], dtype=np.int64), np.asarray(r[f:f + keep_r], dtype=np.int64)
+        sel = np.concatenate([rf, rr])
+        gidx = np.concatenate([base + rf, n_glob + base + (rr - n_local)])
         payload[i % W].append((i, gidx, ops.collect(sel)))
     tick("collect reads", t0)
     lock.release()
@@ -245,9 +246,12 @@ class GpuOps(object):
     def reduce_pairs(self, rk, rc):
         torch.cuda.synchronize()
         t = self._dev.Table.from_pairs(self.ctx, rk.data_ptr(), rc.data_ptr(), rk.numel(), self.K + 1, True)
-        k, c = t.download()
+        n = len(t)
+        dk = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
+        dc = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        t.shard(1, dk.data_ptr(), dc.data_ptr())           # the reduced pairs stay on the device (a one-way "shard")
         t.close()
-        return (torch.as_tensor(k.view(np.int64), device=self.device), torch.as_tensor(c.view(np.int32), device=self.device))
+        return dk[:n], dc[:n]
 
     def table_from_pairs(self, gk, gc):
         torch.cuda.synchronize()
@@ -298,7 +302,7 @@ class GpuOps(object):
     def route(self, res, K, partition_size, part_vectors):
         from . import kmers_for_component as kfc
         return kfc.kmers_for_component(self.ctx, res, self.d1, self.d2, K, partition_size, part_vectors=part_vectors, want_rows=False,
-                                       timings=getattr(self, "timings", None))
+                                       timings=getattr(self, "timings", None), lazy_routes=True)
 
     def n_nodes(self, part, name, K):
         return part["n_kmer_nodes"][name]

@@ -116,6 +116,17 @@ class Routes(object):
         _lib.check(_lib.lib().shn_routes_download(self.ctx.h, self.h, pid.ctypes.data, ridx.ctypes.data))
         return pid, ridx
 
+    def bounds(self, n_parts, split):
+        start = np.zeros(n_parts + 1, np.uint64)
+        below = np.zeros(max(n_parts, 1), np.uint64)
+        _lib.check(_lib.lib().shn_routes_bounds(self.ctx.h, self.h, int(n_parts), int(split), start.ctypes.data, below.ctypes.data))
+        return start.astype(np.int64), below[:n_parts].astype(np.int64)
+
+    def download_range(self, lo, n):
+        out = np.empty(int(n), np.uint32)
+        _lib.check(_lib.lib().shn_routes_download_range(self.ctx.h, self.h, int(lo), int(n), out.ctypes.data))
+        return out
+
     def close(self):
         if self.h:
             _lib.lib().shn_routes_destroy(self.h)
@@ -128,6 +139,29 @@ class Routes(object):
             pass
 
 
+class RouteView(object):
+    """The routes of one partition left on the device: length, forward-half count and slices on demand (a partition's
+    graph consumes only a capped prefix of each half; the routes of a highly expressed contig run into the millions)."""
+
+    def __init__(self, routes, lo, n, below):
+        self.routes, self.lo, self.n, self.below = routes, int(lo), int(n), int(below)
+
+    def __len__(self):
+        return self.n
+
+    def count_below_split(self):
+        return self.below
+
+    def __getitem__(self, sl):
+        assert isinstance(sl, slice) and sl.step in (None, 1)
+        a, b, _ = sl.indices(self.n)
+        return self.routes.download_range(self.lo + a, max(0, b - a))
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.routes.download_range(self.lo, self.n)
+        return a if dtype is None else a.astype(dtype)
+
+
 def make_table(ctx, keys, values, k, canonical=False):
     keys = np.ascontiguousarray(keys, dtype=np.uint64)
     values = np.ascontiguousarray(values, dtype=np.uint32)
@@ -137,7 +171,7 @@ def make_table(ctx, keys, values, k, canonical=False):
 
 
 def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overload=2, penalty=5, repartition=True,
-                        part_vectors=None, want_rows=True, timings=None):
+                        part_vectors=None, want_rows=True, timings=None, lazy_routes=False):
     """Rows a8-a11.  reads1/reads2: device.Reads (reads2 None for single-end).  Returns dict with
       new_components {name: [contig]}          (kmers_for_component.py:244-305)
       k1mers {name: [(k1mer, weight)]}         (:452-477, == component{name}k1mers_allowed.dict)
@@ -233,11 +267,15 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
                                           set_off.ctypes.data, set_mem.ctypes.data, len(sets), C.byref(h)))
     lap("route.kernel")
     routes = Routes(ctx, h)
-    pid, ridx = routes.download()
-    routes.close()
+    if lazy_routes:                                   # routes stay on the device; RouteView fetches what is asked for
+        start, below = routes.bounds(len(names), len(reads1))
+        by_part = {n: RouteView(routes, start[i], start[i + 1] - start[i], below[i]) for i, n in enumerate(names)}
+    else:
+        pid, ridx = routes.download()
+        routes.close()
+        bounds = np.searchsorted(pid, np.arange(len(names) + 1))
+        by_part = {n: ridx[bounds[i]:bounds[i + 1]] for i, n in enumerate(names)}
     probe.close()
-    bounds = np.searchsorted(pid, np.arange(len(names) + 1))
-    by_part = {n: ridx[bounds[i]:bounds[i + 1]] for i, n in enumerate(names)}
     lap("route.download")
     # per-partition k1-mer rows with weights from the allowed dict (:452-477)
     rows_bytes, n_nodes = {}, {}

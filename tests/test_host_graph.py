@@ -169,6 +169,14 @@ def test_native_graph_stage(name):
             assert approx_eq(can[k], gp["graph"][k]), (comp, k)
 
 
+@pytest.mark.parametrize("name", CASES[:3])
+def test_native_graph_stage_parallel_read_dedup(name, monkeypatch):
+    """Large read sets are de-duplicated by several host threads (hash-sharded) and numbered in file order afterwards;
+    forced here on the small golden cases: same graph as reading one read at a time."""
+    monkeypatch.setenv("SHN_GRAPH_BULK_MIN", "1")
+    test_native_graph_stage(name)
+
+
 def test_native_find_reps_matches_python_and_oracle():
     """shn_find_reps (native) == shannon_amd.post.find_reps (Python) == oracle.post.find_reps."""
     import random

@@ -40,3 +40,25 @@ def test_routing_matches_golden(ctx, name):
         assert digest([[a, str(b)] for a, b in out["k1mers"][comp]]) == gp["k1mers_digest"]
 
 
+
+
+def test_lazy_routes_equal_downloaded_routes(ctx):
+    """kmers_for_component(lazy_routes=True) leaves the routes on the device (RouteView: length, forward-half count and
+    slices on demand) -- the same routes as the full download."""
+    from shannon_amd import device, synth, extension_correction as ec, kmers_for_component as kfc
+    (r1, r2), _ = synth.make_dataset(12000, 12, seed=4)
+    d1, d2 = device.Reads.from_codes(ctx, r1), device.Reads.from_codes(ctx, r2)
+    t = device.count_k1mers(ctx, [d1, d2], 26, True)
+    try:
+        res = ec.run_correction(ctx, t, 3, 75, 500, want_allowed=False)
+        full = kfc.kmers_for_component(ctx, res, d1, d2, 25, 500, want_rows=False)
+        lazy = kfc.kmers_for_component(ctx, res, d1, d2, 25, 500, want_rows=False, lazy_routes=True)
+        assert list(full["routes"]) == list(lazy["routes"]) and len(full["routes"]) > 0
+        for name, r in full["routes"].items():
+            v = lazy["routes"][name]
+            assert len(v) == len(r) and v.count_below_split() == int(np.searchsorted(r, len(d1)))
+            assert np.array_equal(np.asarray(v), r)
+            a, b = len(r) // 3, 2 * len(r) // 3
+            assert np.array_equal(v[a:b], r[a:b]) and np.array_equal(v[:5], r[:5]) and len(v[len(r):]) == 0
+    finally:
+        t.close(); d1.close(); d2.close()
