@@ -299,12 +299,25 @@ __global__ __launch_bounds__(BLK) void scan_block_sums(const uint32_t* __restric
   for (int st = BLK / 2; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
   if (threadIdx.x == 0) sums[blockIdx.x] = red[0];
 }
-__global__ void scan_sums_serial(uint64_t* sums, uint64_t nblocks, uint64_t* total) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    uint64_t a = 0;
-    for (uint64_t i = 0; i < nblocks; i++) { uint64_t t = sums[i]; sums[i] = a; a += t; }
-    *total = a;
+// exclusive scan of the block sums in place, one block: every thread scans a contiguous chunk, the chunk totals are
+// scanned in LDS (a single thread walking the whole array was 74 us per call, and the radix sort calls it per pass)
+__global__ __launch_bounds__(1024) void scan_sums_serial(uint64_t* sums, uint64_t nblocks, uint64_t* total) {
+  __shared__ unsigned long long part[1024];
+  const uint64_t per = (nblocks + 1023) / 1024;
+  const uint64_t lo = min(nblocks, (uint64_t)threadIdx.x * per), hi = min(nblocks, lo + per);
+  unsigned long long s = 0;
+  for (uint64_t i = lo; i < hi; i++) s += sums[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = 1; st < 1024; st <<= 1) {                    // inclusive Hillis-Steele scan
+    unsigned long long v = threadIdx.x >= (unsigned)st ? part[threadIdx.x - st] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
   }
+  unsigned long long a = part[threadIdx.x] - s;
+  for (uint64_t i = lo; i < hi; i++) { uint64_t t = sums[i]; sums[i] = a; a += t; }
+  if (threadIdx.x == 1023) *total = part[1023];
 }
 __global__ __launch_bounds__(BLK) void scan_apply(const uint32_t* __restrict__ in, uint64_t n, const uint64_t* __restrict__ sums,
                                                   uint64_t* __restrict__ out, const uint64_t* __restrict__ total) {
@@ -381,10 +394,12 @@ int shn_device_scan_u32(shn_ctx* ctx, const uint32_t* d_in, uint64_t n, uint64_t
   uint64_t* d_sums = (uint64_t*)sums;
   uint64_t* d_total = d_sums + nblocks;
   hipLaunchKernelGGL(scan_block_sums, dim3((uint32_t)nblocks), dim3(BLK), 0, s, d_in, n, d_sums);
-  hipLaunchKernelGGL(scan_sums_serial, dim3(1), dim3(64), 0, s, d_sums, nblocks, d_total);
+  hipLaunchKernelGGL(scan_sums_serial, dim3(1), dim3(1024), 0, s, d_sums, nblocks, d_total);
   hipLaunchKernelGGL(scan_apply, dim3((uint32_t)nblocks), dim3(BLK), 0, s, d_in, n, d_sums, d_out, d_total);
-  HIP_TRY(hipMemcpyAsync(total_host, d_total, 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  if (total_host) {                                          // (nullptr: the caller only needs out[] on the device -- no host sync)
+    HIP_TRY(hipMemcpyAsync(total_host, d_total, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
   return SHN_OK;
 }
 

@@ -648,15 +648,13 @@ __global__ void ext_audit_kernel(WalkArgs A, uint64_t ns, unsigned long long* __
 
 // classify the dirty walks of the open block: long ones (memo or recorded length) go to the wavefront kernel,
 // the others to the thread kernel.  counters: [0] long [1] unused [2] short [3] dirty walks
-__global__ void ext_plan_kernel(const uint32_t* __restrict__ nr, const uint32_t* __restrict__ nl, uint64_t ns, uint32_t frozen,
+__global__ __launch_bounds__(1024) void ext_plan_kernel(const uint32_t* __restrict__ nr, const uint32_t* __restrict__ nl, uint64_t ns, uint32_t frozen,
                                 const uint8_t* __restrict__ mvalid, const uint32_t* __restrict__ mR, const uint32_t* __restrict__ mL,
                                 const uint8_t* __restrict__ dirty, uint32_t* __restrict__ long_list, uint32_t* __restrict__ short_list,
                                 unsigned long long* __restrict__ counters, uint32_t long_walk) {
   // ns here = current rank limit (walks >= limit have not started yet); walks < frozen are final and never run
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + frozen;
   const bool isd = r < ns && dirty[r];
-  unsigned long long dm = __ballot(isd);
-  if (dm && (threadIdx.x & 63) == (uint32_t)(__ffsll((long long)dm) - 1)) atomicAdd(&counters[3], (unsigned long long)__popcll(dm));
   bool lg = false;
   if (isd) {
     uint32_t a = nr[r];
@@ -664,19 +662,27 @@ __global__ void ext_plan_kernel(const uint32_t* __restrict__ nr, const uint32_t*
     if (mvalid[r]) len = max(len, mR[r] + mL[r]);
     lg = len >= long_walk;
   }
-  // one atomic per wavefront and list
-  const int lane = threadIdx.x & 63;
+  // one atomic per block of 1024 and list (one per wavefront on three single addresses was 39 us per launch)
+  __shared__ uint32_t wl[16], wsh[16];
+  __shared__ unsigned long long bl, bs;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const unsigned long long below = (1ULL << lane) - 1ULL;
   const unsigned long long lm = __ballot(isd && lg), sm = __ballot(isd && !lg);
-  unsigned long long lbase = 0, sbase = 0;
-  if (lane == 0) {
-    if (lm) lbase = atomicAdd(&counters[0], (unsigned long long)__popcll(lm));
-    if (sm) sbase = atomicAdd(&counters[2], (unsigned long long)__popcll(sm));
+  if (lane == 0) { wl[wid] = (uint32_t)__popcll(lm); wsh[wid] = (uint32_t)__popcll(sm); }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tl = 0, ts = 0;
+    const int nw = (int)(blockDim.x >> 6);
+    for (int w = 0; w < nw; w++) { tl += wl[w]; ts += wsh[w]; }
+    bl = tl ? atomicAdd(&counters[0], (unsigned long long)tl) : 0ULL;
+    bs = ts ? atomicAdd(&counters[2], (unsigned long long)ts) : 0ULL;
+    if (tl + ts) atomicAdd(&counters[3], (unsigned long long)(tl + ts));
   }
-  lbase = __shfl((long long)lbase, 0, 64);
-  sbase = __shfl((long long)sbase, 0, 64);
-  if (isd && lg) long_list[lbase + __popcll(lm & below)] = (uint32_t)r;
-  if (isd && !lg) short_list[sbase + __popcll(sm & below)] = (uint32_t)r;
+  __syncthreads();
+  uint32_t ol = 0, os = 0;
+  for (int w = 0; w < wid; w++) { ol += wl[w]; os += wsh[w]; }
+  if (isd && lg) long_list[bl + ol + __popcll(lm & below)] = (uint32_t)r;
+  if (isd && !lg) short_list[bs + os + __popcll(sm & below)] = (uint32_t)r;
 }
 
 // after the walkers: every walk that ran alive and is long enough gets a NEW memo slot for its new path (filled from
@@ -1075,7 +1081,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     // classify the dirty walks of the open block; a block without dirty walks is consistent = final
     TRYE(hipMemsetAsync(d_cnt + 2, 0, 32, s));
     if (limit > frozen)
-      hipLaunchKernelGGL(ext_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 256)), dim3(256), 0, s, e->d_nr, e->d_nl, (uint64_t)limit, frozen,
+      hipLaunchKernelGGL(ext_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 1024)), dim3(1024), 0, s, e->d_nr, e->d_nl, (uint64_t)limit, frozen,
                          mvalid, mR, mL, dirty, long_list, short_list, d_cnt + 2, long_walk);
     // (pinned host memory: a pageable destination costs a staging copy kernel per round)
     TRYE(hipMemcpyAsync(plan, d_cnt + 2, 32, hipMemcpyDeviceToHost, s));

@@ -67,8 +67,7 @@ int shn_sort_pairs(shn_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t* keys_
   int passes = 0;
   for (int shift = bit_lo; shift < bit_hi; shift += 8) {
     hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(SBLK), 0, s, ki, n, shift, nblocks, gh);
-    uint64_t total = 0;
-    if ((rc = shn_device_scan_u32(ctx, gh, (uint64_t)256 * nblocks, goff, &total))) return rc;
+    if ((rc = shn_device_scan_u32(ctx, gh, (uint64_t)256 * nblocks, goff, nullptr))) return rc;
     hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblocks), dim3(SBLK), 0, s, ki, vi, n, shift, nblocks, goff, ko, vo);
     std::swap(ki, ko);
     std::swap(vi, vo);
