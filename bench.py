@@ -285,7 +285,7 @@ def main():
             "kernel_launches_per_step": {k: v[1] / args.steps for k, v in sorted(timers.items())},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(k1, r1, r2, 50_000)
+            out["cpu_baseline"] = cpu_baseline(k1, r1, r2, 75_000)        # ~11 s of one core + 1.4 s for the counting stage alone
         final_line = json.dumps(out)
     else:
         final_line = None
