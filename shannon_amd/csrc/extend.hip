@@ -266,6 +266,25 @@ __device__ __forceinline__ int decide(const Adj4& cand, uint32_t r, const u64* c
   return best;
 }
 
+// the greedy choice of walk r standing at step p, from the claims alone (for walk r a k1-mer is traversed iff a lower rank
+// owns it or r owns it at a step <= p); used by the precise marks of ext_mark_kernel and by the fixpoint audit
+__device__ __forceinline__ int audit_decide(const Adj4& cd, uint32_t r, uint32_t p, const u64* __restrict__ claim,
+                                            const uint32_t* __restrict__ weight) {
+  int best = -1;
+  uint32_t bw = 0;
+#pragma unroll
+  for (int bi = 0; bi < 4; bi++) {
+    const int b = bi == 0 ? 0 : bi == 1 ? 2 : bi == 2 ? 1 : 3;          // BASES order A,G,C,T
+    if (cd.v[b] < 0) continue;
+    const u64 c = claim[cd.v[b]];
+    const bool avail = RANK(c) > r || (RANK(c) == r && POS(c) > p);
+    const uint32_t w = weight[(uint32_t)cd.v[b] >> 1];
+    if (avail && (best < 0 || w > bw)) { best = b; bw = w; }
+  }
+  return best;
+}
+
+
 // ---- short walks: one thread per walk, one memory round trip per step (candidate rows prefetched).
 __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_walks, const uint32_t* __restrict__ list,
                                                         const u64* __restrict__ snap) {
@@ -537,22 +556,6 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
 // where its rule finds nothing, and every walk owns exactly its recorded steps.  For walk r at step p a k1-mer is
 // traversed if a lower rank owns it or r owns it at a step <= p.  A walk that fails is made dirty and the rounds go
 // on with every block reopened -- the rounds' change tracking is an optimisation, this is the definition.
-__device__ __forceinline__ int audit_decide(const Adj4& cd, uint32_t r, uint32_t p, const u64* __restrict__ claim,
-                                            const uint32_t* __restrict__ weight) {
-  int best = -1;
-  uint32_t bw = 0;
-#pragma unroll
-  for (int bi = 0; bi < 4; bi++) {
-    const int b = bi == 0 ? 0 : bi == 1 ? 2 : bi == 2 ? 1 : 3;          // BASES order A,G,C,T
-    if (cd.v[b] < 0) continue;
-    const u64 c = claim[cd.v[b]];
-    const bool avail = RANK(c) > r || (RANK(c) == r && POS(c) > p);
-    const uint32_t w = weight[(uint32_t)cd.v[b] >> 1];
-    if (avail && (best < 0 || w > bw)) { best = b; bw = w; }
-  }
-  return best;
-}
-
 __global__ void ext_audit_nodes_kernel(const u64* __restrict__ claim, uint64_t n2, const Adj4* __restrict__ adjR, const Adj4* __restrict__ adjL,
                                        const uint32_t* __restrict__ weight, const uint32_t* __restrict__ order,
                                        const uint32_t* __restrict__ nr_a, const uint32_t* __restrict__ nl_a, uint64_t ns,
@@ -734,7 +737,8 @@ __global__ void ext_mark_kernel(const u64* __restrict__ claim, const u64* __rest
                                 uint8_t* __restrict__ dirty, const uint8_t* __restrict__ ran, uint32_t* __restrict__ owned,
                                 unsigned long long* __restrict__ n_changed, uint32_t frozen, uint32_t limit,
                                 const uint8_t* __restrict__ fill, const uint64_t* __restrict__ moff, const uint32_t* __restrict__ mR,
-                                uint32_t* __restrict__ pool, uint32_t* __restrict__ hint) {
+                                uint32_t* __restrict__ pool, uint32_t* __restrict__ hint,
+                                const uint32_t* __restrict__ nr_a, const uint32_t* __restrict__ nl_a, const uint32_t* __restrict__ weight, int precise) {
   // grid-stride: the change counter costs one atomic per block (one per wavefront on a single address was the
   // most expensive thing in this kernel)
   uint32_t my_changed = 0;
@@ -771,9 +775,25 @@ __global__ void ext_mark_kernel(const u64* __restrict__ claim, const u64* __rest
     for (int q = 0; q < 8; q++) {
       int32_t nb = q < 4 ? L.v[q] : R.v[q - 4];
       if (nb < 0) continue;
-      uint32_t x = RANK(claim_old[nb]), z = RANK(claim[nb]);
-      MARKX(x);
-      MARKX(z);
+      const u64 cz = claim[nb];
+      const uint32_t z = RANK(cz);
+      if (!precise) { uint32_t x = RANK(claim_old[nb]); MARKX(x); MARKX(z); continue; }
+      // Precise: y became available to the walk z that stands next to it (a < z < b).  z has to look again only if its greedy
+      // choice at nb, re-made from the final claims, is not the step it recorded there -- the same test the fixpoint audit
+      // applies to every k1-mer, here applied where something changed.  (A former owner of nb either re-ran or was robbed
+      // while it sat out and is marked at nb itself.)
+      if (!(a < z && z < b) || z < frozen || z >= limit || dirty[z]) continue;
+      const uint32_t pos = POS(cz), nrz = nr_a[z], nlz = nl_a[z];
+      if (nrz == UNCLAIMED || pos > nrz + nlz) { dirty[z] = 1; continue; }
+      const bool dirR = q < 4;                                   // y is a right candidate of nb (nb is a left neighbour of y)
+      if (dirR ? pos > nrz : (pos != 0 && pos <= nrz)) continue;  // z left nb in the other direction: it never looked at y from here
+      const uint32_t thr = dirR ? pos : (pos == 0 ? nrz : pos);   // own steps up to here count as traversed
+      const bool has_next = dirR ? pos < nrz : (pos == 0 ? nlz > 0 : pos < nrz + nlz);
+      const uint32_t next_pos = dirR ? pos + 1 : (pos == 0 ? nrz + 1 : pos + 1);
+      const Adj4 cd = dirR ? adjR[nb] : adjL[nb];
+      const int bsel = audit_decide(cd, z, thr, claim, weight);
+      const bool same = has_next ? (bsel >= 0 && claim[cd.v[bsel]] == CLAIM(z, next_pos)) : bsel < 0;
+      if (!same) dirty[z] = 1;
     }
 #undef MARKX
 #undef MARK
@@ -1075,6 +1095,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   { const unsigned long long c0 = 64;                            // memo pool cursor: 64 words of NONE32 padding in front
     TRYE(hipMemcpy(d_cnt + 10, &c0, 8, hipMemcpyHostToDevice)); }
   auto tune = [](const char* name, uint32_t dflt) { const char* v = getenv(name); return v ? (uint32_t)strtoul(v, nullptr, 10) : dflt; };
+  const int precise_marks = (int)tune("SHN_EXT_PRECISE", 1);       // 0: the conservative rule (every walk standing next to a freed k1-mer)
   const uint32_t long_walk = tune("SHN_EXT_LONG_WALK", LONG_WALK), memo_min = tune("SHN_EXT_MEMO_MIN", MEMO_MIN),
                  promote_steps = tune("SHN_EXT_PROMOTE", PROMOTE_STEPS);
   while (!converged && it < max_iterations) {
@@ -1149,7 +1170,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
                        moff, mR, mL, mvalid, fill, pool, d_cnt + 10, pool_cap, memo_min);
     { TimerRegion tk(ctx, T_EXT_MARK);
       hipLaunchKernelGGL(ext_mark_kernel, dim3(std::min<uint32_t>(g2n, 4096u)), dim3(256), 0, s, claim, snap, 2 * n, (const Adj4*)e->d_adjR, (const Adj4*)e->d_adjL,
-                         seed_rank, dirty, ran, owned, d_cnt + 6, frozen, limit, fill, moff, mR, pool, hint); }
+                         seed_rank, dirty, ran, owned, d_cnt + 6, frozen, limit, fill, moff, mR, pool, hint, e->d_nr, e->d_nl, e->d_weight, precise_marks); }
     hipLaunchKernelGGL(ext_verify_kernel, dim3((uint32_t)cdiv(limit, 256)), dim3(256), 0, s, ran, owned, e->d_nr, e->d_nl, (uint64_t)limit, dirty);
     if (getenv("SHN_EXT_FAULT") && it + 1 == atoi(getenv("SHN_EXT_FAULT"))) TRYE(hipMemsetAsync(dirty, 0, ns + 1, s));   // (tests: lose every mark of this round)
     if (getenv("SHN_EXT_ALLDIRTY")) { TRYE(hipMemsetAsync(dirty, 0, ns + 1, s)); TRYE(hipMemsetAsync(dirty + frozen, 1, limit - frozen, s)); }
