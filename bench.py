@@ -284,7 +284,7 @@ def main():
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(timers.items())},
             "kernel_launches_per_step": {k: v[1] / args.steps for k, v in sorted(timers.items())},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 of the N=1 run only
             out["cpu_baseline"] = cpu_baseline(k1, r1, r2, 75_000)        # ~11 s of one core + 1.4 s for the counting stage alone
         final_line = json.dumps(out)
     else:
