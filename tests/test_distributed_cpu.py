@@ -37,3 +37,22 @@ def test_two_ranks_equal_single_process(name, port, tmp_path):
     for nm in ref["partitions"]:
         assert got["partitions"][nm] == ref["partitions"][nm]["reconstructed_fasta"]
     assert got["final"] == ref["final"]
+
+
+def test_read_pieces_travel_as_bytes():
+    """The capped read sets of the partitions go to their owners as one byte buffer per destination (exchange.pack_read_pieces
+    / unpack_read_pieces around all_to_all_bytes): round trip, empty pieces and empty buffers included."""
+    from shannon_amd import exchange
+    rng = np.random.default_rng(5)
+    items = []
+    for p, n in ((3, 5), (0, 0), (9, 1000)):
+        items.append((p, np.sort(rng.integers(0, 1 << 40, n)).astype(np.int64),
+                      (rng.integers(0, 4, (n, 100), dtype=np.uint8), rng.integers(0, 2, n, dtype=np.uint8))))
+    buf = exchange.pack_read_pieces(items)
+    assert buf.dtype == np.uint8 and buf.ndim == 1
+    back = exchange.unpack_read_pieces(buf)
+    assert [b[0] for b in back] == [3, 0, 9]
+    for (p, g, (rows, rc)), (p2, g2, (rows2, rc2)) in zip(items, back):
+        assert np.array_equal(g, g2) and np.array_equal(rows, rows2) and np.array_equal(rc, rc2) and rows2.shape == rows.shape
+    assert exchange.unpack_read_pieces(exchange.pack_read_pieces([])) == []
+    assert exchange.unpack_read_pieces(np.zeros(0, np.uint8)) == []
