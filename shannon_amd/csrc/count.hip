@@ -94,10 +94,19 @@ __global__ __launch_bounds__(BLK) void scatter1_kernel(ReadsView v, int k, int b
     uint64_t r0 = tile * v.rt;
     uint32_t nr = (uint32_t)min((uint64_t)v.rt, v.n_reads - r0);
     uint32_t nid = nr * v.wmax;
-    for (uint32_t i = threadIdx.x; i < nid; i += BLK) {
-      uint32_t rl = i / v.wmax, pos = i - rl * v.wmax;
-      uint64_t key;
-      if (gen_key<CANON>(v, r0 + rl, pos, k, key)) atomicAdd(&lh[bucket_of(key, bits) >> b2], 1u);
+    // four windows per thread and trip: the key generation, the LDS atomics and the stores of the four are independent,
+    // so their latencies overlap (the loop is latency-bound at full occupancy)
+    for (uint32_t i0 = threadIdx.x; i0 < nid; i0 += 4 * BLK) {
+      uint64_t key[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t i = i0 + u * BLK;
+        const uint32_t rl = i / v.wmax, pos = i - rl * v.wmax;
+        ok[u] = i < nid && gen_key<CANON>(v, r0 + rl, pos, k, key[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (ok[u]) atomicAdd(&lh[bucket_of(key[u], bits) >> b2], 1u);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nb1; i += BLK) {
@@ -106,14 +115,21 @@ __global__ __launch_bounds__(BLK) void scatter1_kernel(ReadsView v, int k, int b
       lh[i] = 0;
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nid; i += BLK) {
-      uint32_t rl = i / v.wmax, pos = i - rl * v.wmax;
-      uint64_t key;
-      if (gen_key<CANON>(v, r0 + rl, pos, k, key)) {
-        uint32_t p = bucket_of(key, bits) >> b2;
-        uint32_t rank = atomicAdd(&lh[p], 1u);
-        out[lbase[p] + rank] = key;
+    for (uint32_t i0 = threadIdx.x; i0 < nid; i0 += 4 * BLK) {
+      uint64_t key[4];
+      uint32_t p[4], rank[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t i = i0 + u * BLK;
+        const uint32_t rl = i / v.wmax, pos = i - rl * v.wmax;
+        ok[u] = i < nid && gen_key<CANON>(v, r0 + rl, pos, k, key[u]);
+        p[u] = ok[u] ? bucket_of(key[u], bits) >> b2 : 0u;
       }
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (ok[u]) rank[u] = atomicAdd(&lh[p[u]], 1u);
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (ok[u]) out[lbase[p[u]] + rank[u]] = key[u];
     }
     __syncthreads();
   }
@@ -502,7 +518,7 @@ extern "C" int shn_count_k1mers(shn_ctx* ctx, shn_reads* const* sets, int n_sets
         if (!v.wmax || !v.n_reads) continue;
         TimerRegion t(ctx, T_SCATTER1);
         uint64_t n_tiles = cdiv(v.n_reads, v.rt);
-        uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, 2048);
+        uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, getenv("SHN_COUNT_GRID1") ? strtoull(getenv("SHN_COUNT_GRID1"), nullptr, 10) : 4096);   // (2048: +0.7 ms; 512: +3 ms -- occupancy, not L2 write combining, is what matters)
         size_t sh = (size_t)nb1 * 4 + (size_t)nb1 * 8;
         if (both_strands) hipLaunchKernelGGL(scatter1_kernel<true>, dim3(grid), dim3(BLK), sh, s, v, k1, bits, b2, n_tiles, d_cursor1, keysA);
         else hipLaunchKernelGGL(scatter1_kernel<false>, dim3(grid), dim3(BLK), sh, s, v, k1, bits, b2, n_tiles, d_cursor1, keysA);

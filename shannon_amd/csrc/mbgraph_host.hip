@@ -800,7 +800,7 @@ extern "C" int shn_mbgraph_run(shn_ctx* ctx, int K, const uint8_t* rows, uint64_
     unsigned nt = std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
     uint64_t bulk_min = 1u << 17;                       // reads from which the duplicates are found in parallel (tests lower it)
     if (getenv("SHN_GRAPH_BULK_MIN")) { bulk_min = strtoull(getenv("SHN_GRAPH_BULK_MIN"), nullptr, 10); nt = std::max(nt, 4u); }
-    if (used < 65536 && used * nm < bulk_min) nt = 1;
+    if (used * nm < bulk_min) nt = used < 4096 ? 1 : std::min<unsigned>(nt, (unsigned)(used / 2048));   // small sets: a few threads for the decode only
     if (nt <= 1) work(0, used);
     else {
       std::vector<std::thread> th;
