@@ -741,7 +741,7 @@ extern "C" int shn_mbgraph_run(shn_ctx* ctx, int K, const uint8_t* rows, uint64_
   uint64_t cutoff = (uint64_t)g.order.size() * 10;
   // Scratch kept between calls (at the read cap these buffers are 100s of MB, and fresh pages cost more than the work done
   // in them): decode buffers and the read arena.  A free list, not thread_local: Python's partition workers are short-lived.
-  struct Scratch { std::vector<uint64_t> doff, hashes; std::vector<char> text; std::string arena; std::vector<uint32_t> first; std::vector<int32_t> idmap; };
+  struct Scratch { std::vector<uint64_t> doff, hashes; std::vector<char> text; std::string arena; std::vector<uint32_t> first, cnt, last; std::vector<int32_t> idmap; };
   static std::mutex scratch_mu;
   static std::vector<Scratch*> scratch_free;
   Scratch* sc = nullptr;
@@ -797,7 +797,7 @@ extern "C" int shn_mbgraph_run(shn_ctx* ctx, int K, const uint8_t* rows, uint64_
       }
       if (bad) non_acgt.store(1);
     };
-    unsigned nt = std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+    unsigned nt = std::min<unsigned>(32, std::max<unsigned>(1, std::thread::hardware_concurrency() / 8));   // (8 ranks share a node's cores)
     uint64_t bulk_min = 1u << 17;                       // reads from which the duplicates are found in parallel (tests lower it)
     if (getenv("SHN_GRAPH_BULK_MIN")) { bulk_min = strtoull(getenv("SHN_GRAPH_BULK_MIN"), nullptr, 10); nt = std::max(nt, 4u); }
     if (used * nm < bulk_min) nt = used < 4096 ? 1 : std::min<unsigned>(nt, (unsigned)(used / 2048));   // small sets: a few threads for the decode only
@@ -811,55 +811,96 @@ extern "C" int shn_mbgraph_run(shn_ctx* ctx, int K, const uint8_t* rows, uint64_
     g.acgt_known = non_acgt.load() ? 0 : 1;
     if (dbg) fprintf(stderr, "[mbgraph]   offsets+decode+hash   %8.3f s\n", now() - t_dec);
     const uint64_t nh = used * nm;
-    if (nt > 1 && nh >= bulk_min) {
-      // Large read sets: the duplicates are found by `nt` host threads, each owning the strings whose hash falls into its
-      // shard (private open-addressing table: string -> index of its first occurrence); ids are then handed out in file
-      // order of first occurrence by one linear pass -- the same ids, counts and mates as interning one read at a time.
-      std::vector<uint32_t>& first = sc->first;
-      first.resize(nh);
-      auto dedup = [&](unsigned t) {
-        uint64_t mine = 0;
-        for (uint64_t j = 0; j < nh; j++) mine += ((hashes[j] >> 40) % nt) == t;
-        size_t cap = 1024;
-        while (cap < mine * 2) cap <<= 1;
+    if (nt > 1 && nh >= bulk_min && g.rindex.size() == 0) {
+      // Large read sets, all on `nt` host threads: (1) the duplicates -- every thread owns the strings whose hash falls into
+      // its shard (private open-addressing table: string -> index of its first occurrence, with its number of occurrences
+      // and its last occurrence); (2) ids in file order of first occurrence = a prefix sum over the "first occurrence"
+      // flags, the strings copied to their place in the arena in parallel; (3) every read's id; (4) mates: interning one
+      // pair after the other leaves every read with the role and mate of its LAST occurrence.  Same ids, counts and mates
+      // as reading one read at a time (test_native_graph_stage_parallel_read_dedup).
+      std::vector<uint32_t>&first = sc->first, &cnt = sc->cnt, &last = sc->last;
+      first.resize(nh); cnt.resize(nh); last.resize(nh);
+      auto run_threads = [&](auto&& fn) {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; t++) th.emplace_back(fn, t);
+        for (auto& t : th) t.join();
+      };
+      run_threads([&](unsigned t) {
+        size_t cap = 1024;                                      // shards of a hash are even: 2.5x the mean share is ample
+        while (cap < (nh / nt + 1) * 5 / 2) cap <<= 1;
         std::vector<uint32_t> tab(cap, 0xFFFFFFFFu);
-        const size_t m = cap - 1;
+        uint64_t used_slots = 0;
         for (uint64_t j = 0; j < nh; j++) {
           const uint64_t h = hashes[j];
           if (((h >> 40) % nt) != t) continue;
+          if (used_slots * 10 > cap * 8) {                       // (a pathological hash distribution: grow and re-insert)
+            std::vector<uint32_t> old;
+            old.swap(tab);
+            cap <<= 1;
+            tab.assign(cap, 0xFFFFFFFFu);
+            for (uint32_t q : old) if (q != 0xFFFFFFFFu) { size_t sl = (size_t)hashes[q] & (cap - 1); while (tab[sl] != 0xFFFFFFFFu) sl = (sl + 1) & (cap - 1); tab[sl] = q; }
+          }
+          const size_t m = cap - 1;
           const char* p = text.data() + doff[j];
           const uint64_t n = doff[j + 1] - doff[j];
           size_t sl = (size_t)h & m;
           while (true) {
             const uint32_t q = tab[sl];
-            if (q == 0xFFFFFFFFu) { tab[sl] = (uint32_t)j; first[j] = (uint32_t)j; break; }
-            if (hashes[q] == h && doff[q + 1] - doff[q] == n && memcmp(text.data() + doff[q], p, n) == 0) { first[j] = q; break; }
+            if (q == 0xFFFFFFFFu) { tab[sl] = (uint32_t)j; first[j] = (uint32_t)j; cnt[j] = 1; last[j] = (uint32_t)j; used_slots++; break; }
+            if (hashes[q] == h && doff[q + 1] - doff[q] == n && memcmp(text.data() + doff[q], p, n) == 0) { first[j] = q; cnt[q]++; last[q] = (uint32_t)j; break; }
             sl = (sl + 1) & m;
           }
         }
-      };
-      { std::vector<std::thread> th;
-        for (unsigned t = 0; t < nt; t++) th.emplace_back(dedup, t);
-        for (auto& t : th) t.join(); }
+      });
+      if (dbg) fprintf(stderr, "[mbgraph]   + duplicates found     %8.3f s\n", now() - t_dec);
       std::vector<int32_t>& idmap = sc->idmap;
       idmap.resize(nh);
       StringInterner& R = g.rindex;
-      for (uint64_t j = 0; j < nh; j++) {
-        if (first[j] == (uint32_t)j) {
-          const int32_t id = (int32_t)R.hashes.size();
-          R.hashes.push_back(hashes[j]);
-          R.arena.append(text.data() + doff[j], doff[j + 1] - doff[j]);
-          R.off.push_back(R.arena.size());
-          g.rcc.push_back(1.0); g.rmate.push_back(-1); g.rmp.push_back(0); g.rnodes.emplace_back(); g.rhas.push_back(0);
-          idmap[j] = id;
-        } else {
-          const int32_t id = idmap[first[j]];
-          g.rcc[id] += 1.0;
-          idmap[j] = id;
+      // (2) chunk c of the reads: how many first occurrences, how many bytes
+      std::vector<uint64_t> nf(nt + 1, 0), nbytes(nt + 1, 0);
+      auto lo_of = [&](unsigned c) { return nh * c / nt; };
+      run_threads([&](unsigned c) {
+        uint64_t f = 0, by = 0;
+        for (uint64_t j = lo_of(c); j < lo_of(c + 1); j++) if (first[j] == (uint32_t)j) { f++; by += doff[j + 1] - doff[j]; }
+        nf[c + 1] = f; nbytes[c + 1] = by;
+      });
+      for (unsigned c = 0; c < nt; c++) { nf[c + 1] += nf[c]; nbytes[c + 1] += nbytes[c]; }
+      const uint64_t nd = nf[nt];
+      R.hashes.resize(nd);
+      R.off.resize(nd + 1);
+      R.off[0] = 0;
+      R.arena.resize(nbytes[nt]);
+      g.rcc.resize(nd); g.rmate.resize(nd, -1); g.rmp.resize(nd, 0); g.rnodes.resize(nd); g.rhas.resize(nd, 0);
+      char* arena = &R.arena[0];
+      run_threads([&](unsigned c) {
+        uint64_t id = nf[c], at = nbytes[c];
+        for (uint64_t j = lo_of(c); j < lo_of(c + 1); j++) {
+          if (first[j] != (uint32_t)j) continue;
+          const uint64_t n = doff[j + 1] - doff[j];
+          memcpy(arena + at, text.data() + doff[j], n);
+          at += n;
+          R.hashes[id] = hashes[j];
+          R.off[id + 1] = at;
+          g.rcc[id] = (double)cnt[j];
+          idmap[j] = (int32_t)id;
+          id++;
         }
-        if (paired && (j & 1)) { const int a = idmap[j - 1], b = idmap[j]; g.rmp[a] = 1; g.rmp[b] = 2; g.rmate[a] = b; g.rmate[b] = a; }
-      }
+      });
+      run_threads([&](unsigned c) {                                  // (3) (a first occurrence precedes its duplicates, all are numbered by now)
+        for (uint64_t j = lo_of(c); j < lo_of(c + 1); j++) if (first[j] != (uint32_t)j) idmap[j] = idmap[first[j]];
+      });
+      if (paired)
+        run_threads([&](unsigned c) {                                // (4)
+          for (uint64_t j = lo_of(c); j < lo_of(c + 1); j++) {
+            if (first[j] != (uint32_t)j) continue;
+            const uint32_t l = last[j];
+            const int32_t id = idmap[j];
+            g.rmp[id] = (l & 1) ? 2 : 1;
+            g.rmate[id] = idmap[l ^ 1u];
+          }
+        });
       R.bulk_loaded = true;                 // (its probe table was bypassed: no interning by string after this)
+      if (dbg) fprintf(stderr, "[mbgraph]   + numbered in order    %8.3f s\n", now() - t_dec);
     } else
     for (uint64_t i = 0; i < used; i++) {
       int a = g.add_read(text.data() + doff[i * nm], doff[i * nm + 1] - doff[i * nm], hashes[i * nm]);
