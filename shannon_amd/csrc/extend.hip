@@ -746,7 +746,7 @@ __global__ void ext_mark_kernel(const u64* __restrict__ claim, const u64* __rest
     const uint32_t a = RANK(claim_old[y]);
     const u64 cy = claim[y];
     const uint32_t b = RANK(cy);
-    if (b != UNCLAIMED && ran[b]) {
+    if (b >= frozen && b < limit && ran[b]) {                     // (only walks of the open block can have run)
       atomicAdd(&owned[b], 1u);                                   // for ext_verify_kernel
       if (fill[b]) {                                              // slot layout: see MemoCursor
         const uint32_t pos = POS(cy), R = mR[b];
