@@ -132,6 +132,16 @@ uint64_t shn_ext_wave_steps(const shn_ext* e);    /* ... of which by the wavefro
 /* per walk (host arrays of shn_ext_n_walks entries): right/left extension lengths (n_right ==
  * 0xFFFFFFFF marks a void walk) and the weight sum including the seed (tot_wt, :351)          */
 int shn_ext_stats(shn_ctx* ctx, const shn_ext* e, uint32_t* n_right, uint32_t* n_left, uint64_t* tot_weight);
+/* The same for the walks lo <= rank < lo + n only.                                                                          */
+int shn_ext_stats_range(shn_ctx* ctx, const shn_ext* e, uint64_t lo, uint64_t n, uint32_t* n_right, uint32_t* n_left, uint64_t* tot_weight);
+/* Pipelining hook (per calling thread; NULL clears it): shn_extend / shn_extend_sharded call `cb(user, ext, lo, hi, status)` on
+ * the calling thread whenever the walks lo <= rank < hi are final -- the reference's loop (extension_correction.py:334-369)
+ * finishes contigs in exactly this order, so the caller can run duplicate_check / contig_connections (shn_cgraph_add) on them
+ * while the later, lighter seeds are still being walked.  status: 0 a block, 1 the last block, -1 everything handed over so
+ * far is void (the fixpoint audit reopened the blocks).  `ext` is valid for shn_ext_stats_range / shn_ext_emit /
+ * shn_ext_seed_info during the call-back only.                                                                                */
+typedef void (*shn_block_cb)(void* user, shn_ext* ext, uint64_t lo, uint64_t hi, int status);
+void shn_ext_set_block_callback(shn_block_cb cb, void* user);
 /* contig strings (ASCII) of the selected walk ranks, contig i at bases_out[offsets[i]..offsets[i+1]) */
 int shn_ext_emit(shn_ctx* ctx, const shn_ext* e, const uint32_t* ranks, uint64_t n_sel, const uint64_t* offsets,
                  uint8_t* bases_out);
@@ -162,6 +172,16 @@ int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint64_t n_cand,
 /* hit count of the `best` contig (max_till_now, :255-259; 0 = no shared r-mer) of every candidate of the calling thread's
  * last shn_contig_graph call                                                                                            */
 int shn_contig_best_counts(int32_t* out, uint64_t n_cand);
+
+/* The same stage fed in several calls (candidates still in seed order): the pipelined extension hands over the candidates
+ * of every rank block as soon as that block is final.  shn_cgraph_add: accepted_out[i] = 1-based accepted index (counted
+ * over all calls) or 0; best_counts_out may be NULL.  Sizes, then export of the connections as in shn_contig_graph.        */
+typedef struct shn_cgraph shn_cgraph;
+int shn_cgraph_create(int k1, int r, double f, shn_cgraph** out);
+void shn_cgraph_destroy(shn_cgraph* g);
+int shn_cgraph_add(shn_cgraph* g, const uint8_t* bases, const uint64_t* off, uint64_t n_cand, int32_t* accepted_out, int32_t* best_counts_out);
+int shn_cgraph_sizes(const shn_cgraph* g, uint64_t* n_acc, uint64_t* n_conn);
+int shn_cgraph_export(const shn_cgraph* g, uint64_t* conn_off, int32_t* conn_nb, int32_t* conn_w);
 
 /* ---- read -> partition routing -----------------------------------------------------------------
  * Replaces the read-streaming loops of kmers_for_component (kmers_for_component.py:322-403;

@@ -67,6 +67,13 @@ SIGNATURES = {
     "shn_ext_seed_info": (C.c_int, [vp, vp, vp, C.c_uint64, vp, vp]),
     "shn_ext_live_stats": (C.c_int, [vp, vp, u64p, vp, vp, vp, vp]),
     "shn_ext_stats": (C.c_int, [vp, vp, vp, vp, vp]),
+    "shn_ext_stats_range": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, vp, vp, vp]),
+    "shn_ext_set_block_callback": (None, [vp, vp]),
+    "shn_cgraph_create": (C.c_int, [C.c_int, C.c_int, C.c_double, vpp]),
+    "shn_cgraph_destroy": (None, [vp]),
+    "shn_cgraph_add": (C.c_int, [vp, vp, vp, C.c_uint64, vp, vp]),
+    "shn_cgraph_sizes": (C.c_int, [vp, vp, vp]),
+    "shn_cgraph_export": (C.c_int, [vp, vp, vp, vp]),
     "shn_ext_emit": (C.c_int, [vp, vp, vp, C.c_uint64, vp, vp]),
     "shn_ext_weights": (C.c_int, [vp, vp, vp, C.c_uint64, vp]),
 }

@@ -35,35 +35,27 @@ static thread_local std::vector<int32_t> g_best_counts;
 
 struct Conn { std::vector<int32_t> nb; std::vector<int32_t> w; };      // neighbours in dict insertion order + weights
 
-// contigs: n_cand candidate strings (bases[off[i]..off[i+1])), in seed order.
-// accepted_out[i] = 1-based accepted index or 0.  Connections are returned as CSR in *insertion order*
-// (the order Python's dict would iterate): conn_off[n_acc+1], conn_nb[], conn_w[] (caller sizes conn_* with
-// the value returned in *n_conn after a first call with conn_nb == NULL).
-extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint64_t n_cand, int k1, int r, double f,
-                                int32_t* accepted_out, uint64_t* n_acc_out, uint64_t* conn_off, int32_t* conn_nb, int32_t* conn_w,
-                                uint64_t* n_conn) {
-  if (!bases || !off || !accepted_out || !n_acc_out || !n_conn) return shn_fail(SHN_ERR_ARG, "shn_contig_graph: NULL argument");
-  static thread_local std::vector<Conn> conns;         // kept between the sizing call and the fill call
-  static thread_local std::vector<int32_t> accepted;
-  std::vector<int32_t>& bestcnt = g_best_counts;
-  static thread_local uint64_t cached_n = ~0ULL;
-  static thread_local const uint8_t* cached_ptr = nullptr;
-  if (!(conn_nb && cached_n == n_cand && cached_ptr == bases)) {
-    uint64_t total_bases = off[n_cand] - off[0];
-    // only accepted contigs enter the indexes (a few percent of the candidate bases): start small so that the
-    // probes of the rejected candidates stay in cache; the maps grow on demand
-    (void)total_bases;
-    FlatMultiMap rmer(1 << 14), cmer(1 << 14);
-    conns.clear(); conns.emplace_back();                 // index 0 unused (contigs are 1-based)
-    accepted.assign(n_cand, 0);
-    bestcnt.assign(n_cand, 0);
+// The contig stage as an object: candidates arrive in seed order, in one call or in several (the pipelined extension hands
+// over the candidates of every rank block as soon as that block is final) -- the state between calls is the state the
+// reference's loop carries from one contig to the next (extension_correction.py:358-397).
+struct shn_cgraph {
+  int k1, r;
+  double f;
+  FlatMultiMap rmer{1 << 14}, cmer{1 << 14};   // only accepted contigs enter the indexes: start small, grow on demand
+  std::vector<Conn> conns;                     // index 0 unused (contigs are 1-based)
+  std::vector<int32_t> connw{0};               // scratch counters, one per accepted contig (index 0 unused)
+  int32_t idx = 0;
+  uint64_t n_evals = 0, n_batches = 0, n_cand_total = 0;
+  double t_eval = 0, t_accept = 0;
+  shn_cgraph(int k1_, int r_, double f_) : k1(k1_), r(r_), f(f_) { conns.emplace_back(); }
+
+  // accepted[i] = 1-based accepted index of candidate i or 0; bestcnt[i] = hit count of its `best` contig
+  void add(const uint8_t* bases, const uint64_t* off, uint64_t n_cand, int32_t* accepted, int32_t* bestcnt) {
     const int C = k1 - 1;
-    int32_t idx = 0;
     const bool dbg = getenv("SHN_DEBUG") != nullptr;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_eval = 0, t_accept = 0;
-    uint64_t n_evals = 0, n_batches = 0;
-
+    for (uint64_t i = 0; i < n_cand; i++) { accepted[i] = 0; bestcnt[i] = 0; }
+    n_cand_total += n_cand;
     // duplicate_check of one candidate against the current index (read-only on the shared state)
     struct Scratch { std::vector<uint64_t> rk; std::vector<int32_t> hits, dupcnt, touched, cov; };
     auto evaluate = [&](uint64_t c, Scratch& z, int32_t& best_count) -> bool {
@@ -100,7 +92,7 @@ extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint6
     };
 
     std::vector<uint64_t> ck, rk2;
-    std::vector<int32_t> connw(1, 0), newnb;                // per accepted contig: shared K-mers with the new contig
+    std::vector<int32_t> newnb;                             // (connw, a member: per accepted contig, shared K-mers with the new contig)
     auto accept = [&](uint64_t c) {
       const uint8_t* s = bases + off[c];
       const uint32_t L = (uint32_t)(off[c + 1] - off[c]);
@@ -180,26 +172,77 @@ extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint6
       }
       if (dbg) t_accept += now() - t0;
     }
-    if (dbg) fprintf(stderr, "[contig_graph] %llu candidates: %llu evaluations in %llu batches (%u threads) %.3f s, inserts %.3f s\n",
-                     (unsigned long long)n_cand, (unsigned long long)n_evals, (unsigned long long)n_batches, n_threads, t_eval, t_accept);
+  }
+};
+
+extern "C" int shn_cgraph_create(int k1, int r, double f, shn_cgraph** out) {
+  if (!out || k1 < 2 || r < 1) return shn_fail(SHN_ERR_ARG, "shn_cgraph_create: bad argument");
+  *out = new shn_cgraph(k1, r, f);
+  return SHN_OK;
+}
+extern "C" void shn_cgraph_destroy(shn_cgraph* g) { delete g; }
+extern "C" int shn_cgraph_add(shn_cgraph* g, const uint8_t* bases, const uint64_t* off, uint64_t n_cand, int32_t* accepted_out, int32_t* best_counts_out) {
+  if (!g || (n_cand && (!bases || !off || !accepted_out))) return shn_fail(SHN_ERR_ARG, "shn_cgraph_add: NULL argument");
+  std::vector<int32_t> tmp;
+  if (!best_counts_out) { tmp.resize(n_cand + 1); best_counts_out = tmp.data(); }
+  g->add(bases, off, n_cand, accepted_out, best_counts_out);
+  return SHN_OK;
+}
+extern "C" int shn_cgraph_sizes(const shn_cgraph* g, uint64_t* n_acc, uint64_t* n_conn) {
+  if (!g || !n_acc || !n_conn) return shn_fail(SHN_ERR_ARG, "shn_cgraph_sizes: NULL argument");
+  uint64_t total = 0;
+  for (size_t i = 1; i < g->conns.size(); i++) total += g->conns[i].nb.size();
+  *n_acc = g->conns.size() - 1;
+  *n_conn = total;
+  return SHN_OK;
+}
+// connections as CSR in *insertion order* (the order Python's dict would iterate): conn_off[n_acc+1], conn_nb[], conn_w[]
+extern "C" int shn_cgraph_export(const shn_cgraph* g, uint64_t* conn_off, int32_t* conn_nb, int32_t* conn_w) {
+  if (!g || !conn_off || !conn_nb || !conn_w) return shn_fail(SHN_ERR_ARG, "shn_cgraph_export: NULL argument");
+  uint64_t p = 0;
+  const uint64_t n_acc = g->conns.size() - 1;
+  for (uint64_t i = 1; i <= n_acc; i++) {
+    conn_off[i - 1] = p;
+    for (size_t j = 0; j < g->conns[i].nb.size(); j++) { conn_nb[p] = g->conns[i].nb[j]; conn_w[p] = g->conns[i].w[j]; p++; }
+  }
+  conn_off[n_acc] = p;
+  if (getenv("SHN_DEBUG"))
+    fprintf(stderr, "[contig_graph] %llu candidates: %llu evaluations in %llu batches, %.3f s, inserts %.3f s\n",
+            (unsigned long long)g->n_cand_total, (unsigned long long)g->n_evals, (unsigned long long)g->n_batches, g->t_eval, g->t_accept);
+  return SHN_OK;
+}
+
+// contigs: n_cand candidate strings (bases[off[i]..off[i+1])), in seed order, in one call.
+// accepted_out[i] = 1-based accepted index or 0.  Connections are returned as CSR in *insertion order*
+// (caller sizes conn_* with the value returned in *n_conn after a first call with conn_nb == NULL).
+extern "C" int shn_contig_graph(const uint8_t* bases, const uint64_t* off, uint64_t n_cand, int k1, int r, double f,
+                                int32_t* accepted_out, uint64_t* n_acc_out, uint64_t* conn_off, int32_t* conn_nb, int32_t* conn_w,
+                                uint64_t* n_conn) {
+  if (!bases || !off || !accepted_out || !n_acc_out || !n_conn) return shn_fail(SHN_ERR_ARG, "shn_contig_graph: NULL argument");
+  static thread_local shn_cgraph* cached = nullptr;      // kept between the sizing call and the fill call
+  static thread_local std::vector<int32_t> accepted;
+  static thread_local uint64_t cached_n = ~0ULL;
+  static thread_local const uint8_t* cached_ptr = nullptr;
+  if (!(conn_nb && cached && cached_n == n_cand && cached_ptr == bases)) {
+    delete cached;
+    cached = new shn_cgraph(k1, r, f);
+    accepted.assign(n_cand + 1, 0);
+    g_best_counts.assign(n_cand, 0);
+    std::vector<int32_t> bc(n_cand + 1, 0);
+    cached->add(bases, off, n_cand, accepted.data(), bc.data());
+    for (uint64_t i = 0; i < n_cand; i++) g_best_counts[i] = bc[i];
     cached_n = n_cand; cached_ptr = bases;
   }
-  uint64_t n_acc = conns.size() - 1, total = 0;
-  for (uint64_t i = 1; i <= n_acc; i++) total += conns[i].nb.size();
-  *n_acc_out = n_acc;
-  *n_conn = total;
+  int rc = shn_cgraph_sizes(cached, n_acc_out, n_conn);
+  if (rc) return rc;
   memcpy(accepted_out, accepted.data(), n_cand * sizeof(int32_t));
   if (conn_nb && conn_w && conn_off) {
-    uint64_t p = 0;
-    for (uint64_t i = 1; i <= n_acc; i++) {
-      conn_off[i - 1] = p;
-      for (size_t j = 0; j < conns[i].nb.size(); j++) { conn_nb[p] = conns[i].nb[j]; conn_w[p] = conns[i].w[j]; p++; }
-    }
-    conn_off[n_acc] = p;
-    cached_n = ~0ULL; cached_ptr = nullptr;
-    conns.clear(); accepted.clear();
+    rc = shn_cgraph_export(cached, conn_off, conn_nb, conn_w);
+    delete cached;
+    cached = nullptr; cached_n = ~0ULL; cached_ptr = nullptr;
+    accepted.clear();
   }
-  return SHN_OK;
+  return rc;
 }
 
 // hit count of the `best` contig (max_till_now, extension_correction.py:255-259) of every candidate of this thread's

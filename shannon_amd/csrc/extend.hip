@@ -825,6 +825,13 @@ __global__ void ext_seed_rank_kernel(const uint32_t* __restrict__ order, uint64_
 // (claim = rank << 32 | pos; pos 0 = seed, 1..nR right steps, nR+1..nR+nL left steps), so the contig of a
 // selected walk is a scatter -- no walking.  (extension_correction.py:223-245: a right step appends the last
 // base of the new k1-mer, a left step prepends its first base.)
+__global__ void ext_select_kernel(const uint32_t* __restrict__ ranks, uint64_t n_sel, int32_t* __restrict__ sel_of_rank,
+                                  unsigned long long* __restrict__ n_twice) {
+  uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_sel) return;
+  if (atomicCAS((int*)&sel_of_rank[ranks[t]], -1, (int)t) != -1) atomicAdd(n_twice, 1ULL);
+}
+
 __global__ void ext_emit_claims_kernel(const u64* __restrict__ claim, uint64_t n2, const int32_t* __restrict__ sel_of_rank, uint64_t ns,
                                        const uint32_t* __restrict__ nr_a, const uint32_t* __restrict__ nl_a,
                                        const uint64_t* __restrict__ tkeys, int k, const uint64_t* __restrict__ out_off,
@@ -965,6 +972,16 @@ extern "C" void shn_ext_destroy(shn_ext* e) {
   delete e;
 }
 
+// Pipelining hook: called from inside shn_extend, on the calling thread, whenever the walks of a rank block are final
+// (lo <= rank < hi; their claims never change again), so that the caller can take their contigs and start the contig stage
+// while the later blocks are still iterating.  status 0 = a block, 1 = the last block, -1 = the fixpoint audit reopened
+// the blocks: everything handed over so far is void.  The shn_ext passed is valid for shn_ext_stats_range / shn_ext_emit /
+// shn_ext_seed_info during the call-back.
+typedef void (*shn_block_cb)(void* user, shn_ext* e, uint64_t lo, uint64_t hi, int status);
+static thread_local shn_block_cb g_block_cb = nullptr;
+static thread_local void* g_block_user = nullptr;
+extern "C" void shn_ext_set_block_callback(shn_block_cb cb, void* user) { g_block_cb = cb; g_block_user = user; }
+
 extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight, int max_iterations, shn_ext** out) {
   return shn_extend_sharded(ctx, t, min_weight, max_iterations, 1, 0, out);
 }
@@ -1088,6 +1105,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   unsigned long long lim0 = std::max<unsigned long long>(ns / 32, 4096), grow = 4;
   if (getenv("SHN_EXT_LIMIT0")) lim0 = strtoull(getenv("SHN_EXT_LIMIT0"), nullptr, 10);
   if (getenv("SHN_EXT_GROW")) grow = strtoull(getenv("SHN_EXT_GROW"), nullptr, 10);
+  const unsigned long long tail_div = getenv("SHN_EXT_TAIL") ? strtoull(getenv("SHN_EXT_TAIL"), nullptr, 10) : 8;   // last block = ns / 8 walks (0: off)
   uint32_t frozen = 0, limit = (uint32_t)std::min<unsigned long long>(ns, lim0);
   TRYE(hipMemsetAsync(dirty, 0, 2 * (ns + 1), s));               // dirty + ran
   TRYE(hipMemsetAsync(dirty, 1, limit, s));
@@ -1120,7 +1138,12 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
                            owned, dirty, d_cnt + 48);
         TRYE(hipMemcpyAsync(plan + 4, d_cnt + 48, 16, hipMemcpyDeviceToHost, s));
         TRYE(hipStreamSynchronize(s));
-        if (plan[4] == 0 && plan[5] == 0) { converged = true; break; }
+        if (plan[4] == 0 && plan[5] == 0) {
+          converged = true;
+          if (g_block_cb) g_block_cb(g_block_user, e, frozen, ns, 1);
+          break;
+        }
+        if (g_block_cb) g_block_cb(g_block_user, e, 0, 0, -1);
         fprintf(stderr, "[shn_extend] fixpoint audit after %d rounds: %llu k1-mers / %llu walks disagree with the greedy rule; reopening all blocks\n",
                 it, plan[4], plan[5]);
         if (++repairs > 16) break;
@@ -1129,8 +1152,12 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
         TRYE(hipMemsetAsync(owned, 0, (ns + 1) * 4, s));
         continue;
       }
+      if (g_block_cb && repairs == 0) g_block_cb(g_block_user, e, frozen, limit, 0);
       frozen = limit;                                // this block is final: open the next one
-      limit = (uint32_t)std::min<unsigned long long>(ns, (unsigned long long)limit * grow);
+      // geometric blocks up to half of the walks, then blocks of ns / tail_div: the light half of the seed order settles in
+      // a few cheap rounds per block, and what a block call-back receives early can be worked on beside the later blocks
+      if (tail_div && (unsigned long long)frozen * 2 >= ns) limit = (uint32_t)std::min<unsigned long long>(ns, (unsigned long long)frozen + std::max<unsigned long long>(1, ns / tail_div));
+      else limit = (uint32_t)std::min<unsigned long long>(ns, (unsigned long long)limit * grow);
       TRYE(hipMemsetAsync(ran, 0, frozen, s));       // frozen walks never run again
       TRYE(hipMemsetAsync(dirty + frozen, 1, limit - frozen, s));
       continue;
@@ -1239,6 +1266,19 @@ extern "C" int shn_ext_iterations(const shn_ext* e) { return e ? e->iterations :
 extern "C" uint64_t shn_ext_total_steps(const shn_ext* e) { return e ? e->total_steps : 0; }
 extern "C" uint64_t shn_ext_wave_steps(const shn_ext* e) { return e ? e->wave_steps : 0; }
 
+extern "C" int shn_ext_stats_range(shn_ctx* ctx, const shn_ext* e, uint64_t lo, uint64_t n, uint32_t* n_right, uint32_t* n_left, uint64_t* tot_weight) {
+  if (!ctx || !e || (n && (!n_right || !n_left || !tot_weight))) return shn_fail(SHN_ERR_ARG, "shn_ext_stats_range: NULL argument");
+  if (lo + n > e->n_seeds) return shn_fail(SHN_ERR_ARG, "shn_ext_stats_range: range outside the walks");
+  if (!n) return SHN_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  HIP_TRY(hipMemcpyAsync(n_right, e->d_nr + lo, n * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(n_left, e->d_nl + lo, n * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(tot_weight, e->d_totw + lo, n * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return SHN_OK;
+}
+
 extern "C" int shn_ext_stats(shn_ctx* ctx, const shn_ext* e, uint32_t* n_right, uint32_t* n_left, uint64_t* tot_weight) {
   if (!ctx || !e) return shn_fail(SHN_ERR_ARG, "shn_ext_stats: NULL argument");
   HIP_TRY(hipSetDevice(ctx->device));
@@ -1335,39 +1375,40 @@ extern "C" int shn_ext_emit(shn_ctx* ctx, const shn_ext* e, const uint32_t* rank
   hipStream_t s = ctx->stream;
   TimerRegion treg(ctx, T_EXTEND);
   const uint64_t total = offsets[n_sel], ns = e->n_seeds;
-  // rank -> index in the selection; expected number of k1-mers of the selected walks
-  std::vector<int32_t> sel_of_rank(ns + 1, -1);
-  for (uint64_t t = 0; t < n_sel; t++) {
+  // rank -> index in the selection (built on the device: the map has one entry per walk, the selection is small);
+  // expected number of k1-mers of the selected walks
+  for (uint64_t t = 0; t < n_sel; t++)
     if (ranks[t] >= ns) return shn_fail(SHN_ERR_ARG, "shn_ext_emit: rank out of range");
-    if (sel_of_rank[ranks[t]] >= 0) return shn_fail(SHN_ERR_ARG, "shn_ext_emit: a walk is selected twice");
-    sel_of_rank[ranks[t]] = (int32_t)t;
-  }
   unsigned long long expect = 0;
   for (uint64_t t = 0; t < n_sel; t++) {
     uint64_t len = offsets[t + 1] - offsets[t];
     if (len < (uint64_t)e->k) return shn_fail(SHN_ERR_ARG, "shn_ext_emit: offsets do not fit the walk lengths");
     expect += len - e->k + 1;
   }
-  int32_t* d_sel; uint64_t* d_off; uint8_t* d_out; unsigned long long* d_cnt;
+  int32_t* d_sel; uint64_t* d_off; uint8_t* d_out; unsigned long long* d_cnt; uint32_t* d_ranks;
   HIP_TRY(shn_dev_malloc(&d_sel, (ns + 1) * 4));
   HIP_TRY(shn_dev_malloc(&d_off, (n_sel + 1) * 8));
   HIP_TRY(shn_dev_malloc(&d_out, total + 1));
-  HIP_TRY(shn_dev_malloc(&d_cnt, 16));
-  HIP_TRY(hipMemcpyAsync(d_sel, sel_of_rank.data(), (ns + 1) * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(shn_dev_malloc(&d_cnt, 32));
+  HIP_TRY(shn_dev_malloc(&d_ranks, (n_sel + 1) * 4));
+  HIP_TRY(hipMemsetAsync(d_sel, 0xFF, (ns + 1) * 4, s));                    // -1: not selected
+  HIP_TRY(hipMemcpyAsync(d_ranks, ranks, n_sel * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_off, offsets, (n_sel + 1) * 8, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemsetAsync(d_cnt, 0, 16, s));
+  HIP_TRY(hipMemsetAsync(d_cnt, 0, 32, s));
+  hipLaunchKernelGGL(ext_select_kernel, dim3((uint32_t)cdiv(n_sel, 256)), dim3(256), 0, s, d_ranks, n_sel, d_sel, d_cnt + 2);
   HIP_TRY(hipMemsetAsync(d_out, 0, total + 1, s));
   {
     TimerRegion tk(ctx, T_EXT_EMIT);
     hipLaunchKernelGGL(ext_emit_claims_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(2 * e->n, 256), 4096)), dim3(256), 0, s, e->d_claim, 2 * e->n, d_sel, ns,
                        e->d_nr, e->d_nl, e->table->d_keys, e->k, d_off, d_out, d_cnt);
   }
-  unsigned long long cnt[2] = {0, 0};
+  unsigned long long cnt[3] = {0, 0, 0};
   HIP_TRY(hipMemcpyAsync(bases_out, d_out, total, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(cnt, d_cnt, 16, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(cnt, d_cnt, 24, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  shn_dev_free(d_sel); shn_dev_free(d_off); shn_dev_free(d_out); shn_dev_free(d_cnt);
+  shn_dev_free(d_sel); shn_dev_free(d_off); shn_dev_free(d_out); shn_dev_free(d_cnt); shn_dev_free(d_ranks);
   HIP_TRY(hipGetLastError());
+  if (cnt[2]) return shn_fail(SHN_ERR_ARG, "shn_ext_emit: a walk is selected twice");
   // every base of every selected contig must have been written exactly once
   if (cnt[1] || cnt[0] != expect)
     return shn_fail(SHN_ERR_INTERNAL, "shn_ext_emit: claims do not match the recorded walks (k1-mers written " + std::to_string(cnt[0]) +

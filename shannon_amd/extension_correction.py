@@ -24,15 +24,45 @@ class ExtensionResult(object):
 class Extension(object):
     """Handle over shn_ext (device-resident walk state)."""
 
-    def __init__(self, ctx, table, min_weight=3, max_iterations=0, shard=None):
-        """shard = (world, rank): only the walks of the connected components dealt to `rank` (shn_extend_sharded)."""
+    BLOCK_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int)
+
+    def __init__(self, ctx, table, min_weight=3, max_iterations=0, shard=None, on_block=None):
+        """shard = (world, rank): only the walks of the connected components dealt to `rank` (shn_extend_sharded).
+        on_block(view, lo, hi, status): called during the call whenever the walks lo <= rank < hi are final (status 0 / 1 =
+        last block / -1 = everything handed over so far is void); `view` is an Extension over the unfinished handle, good
+        for stats_range / emit / seed_info inside the call-back only (shn_ext_set_block_callback)."""
         self.ctx, self.table = ctx, table
         self.h = C.c_void_p()
-        if shard is None or shard[0] <= 1:
-            _lib.check(_lib.lib().shn_extend(ctx.h, table.h, int(min_weight), int(max_iterations), C.byref(self.h)))
-        else:
-            _lib.check(_lib.lib().shn_extend_sharded(ctx.h, table.h, int(min_weight), int(max_iterations), int(shard[0]), int(shard[1]),
-                                                    C.byref(self.h)))
+        cb = None
+        if on_block is not None:
+            def _cb(_user, eptr, lo, hi, status):
+                on_block(Extension.view(ctx, eptr), int(lo), int(hi), int(status))
+            cb = Extension.BLOCK_CB(_cb)
+            _lib.lib().shn_ext_set_block_callback(C.cast(cb, C.c_void_p), None)
+        try:
+            if shard is None or shard[0] <= 1:
+                _lib.check(_lib.lib().shn_extend(ctx.h, table.h, int(min_weight), int(max_iterations), C.byref(self.h)))
+            else:
+                _lib.check(_lib.lib().shn_extend_sharded(ctx.h, table.h, int(min_weight), int(max_iterations), int(shard[0]), int(shard[1]),
+                                                        C.byref(self.h)))
+        finally:
+            if cb is not None:
+                _lib.lib().shn_ext_set_block_callback(None, None)
+
+    @classmethod
+    def view(cls, ctx, handle):
+        """A non-owning Extension over a shn_ext pointer (inside a block call-back)."""
+        v = cls.__new__(cls)
+        v.ctx, v.table, v.h, v.borrowed = ctx, None, C.c_void_p(handle), True
+        return v
+
+    def stats_range(self, lo, n):
+        nr = np.empty(max(n, 1), np.uint32)
+        nl = np.empty(max(n, 1), np.uint32)
+        tw = np.empty(max(n, 1), np.uint64)
+        if n:
+            _lib.check(_lib.lib().shn_ext_stats_range(self.ctx.h, self.h, int(lo), int(n), nr.ctypes.data, nl.ctypes.data, tw.ctypes.data))
+        return nr[:n], nl[:n], tw[:n]
 
     def seed_info(self, ranks):
         """(seed k1-mer key, seed weight) of the given walks: (weight desc, key asc) is the global walk order."""
@@ -95,9 +125,9 @@ class Extension(object):
         return out
 
     def close(self):
-        if self.h:
+        if self.h and not getattr(self, "borrowed", False):
             _lib.lib().shn_ext_destroy(self.h)
-            self.h = C.c_void_p()
+        self.h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -144,6 +174,67 @@ def windows_to_keys_many(contigs, k):
     wbefore = np.concatenate([[0], np.cumsum(nwin)[:-1]])
     idx = np.repeat(off - wbefore, nwin) + np.arange(int(nwin.sum()), dtype=np.int64)   # windows that stay inside a string
     return key[idx], nwin
+
+
+class ContigGraph(object):
+    """duplicate_check + contig graph fed in several calls, candidates in seed order (shn_cgraph)."""
+
+    def __init__(self, k1, r=15, f=0.5):
+        self.h = C.c_void_p()
+        _lib.check(_lib.lib().shn_cgraph_create(int(k1), int(r), float(f), C.byref(self.h)))
+
+    def add(self, strings):
+        """-> acc: 1-based accepted index (over all calls) of every candidate, or 0"""
+        if not strings:
+            return np.zeros(0, np.int32)
+        joined = "".join(strings).encode()
+        offs = np.zeros(len(strings) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(x) for x in strings], dtype=np.uint64)
+        buf = np.frombuffer(joined, dtype=np.uint8)
+        acc = np.zeros(len(strings), dtype=np.int32)
+        _lib.check(_lib.lib().shn_cgraph_add(self.h, buf.ctypes.data, offs.ctypes.data, len(strings), acc.ctypes.data, None))
+        return acc
+
+    def connections(self):
+        n_acc, n_conn = C.c_uint64(0), C.c_uint64(0)
+        _lib.check(_lib.lib().shn_cgraph_sizes(self.h, C.byref(n_acc), C.byref(n_conn)))
+        coff = np.zeros(n_acc.value + 1, dtype=np.uint64)
+        cnb = np.zeros(max(1, n_conn.value), dtype=np.int32)
+        cw = np.zeros(max(1, n_conn.value), dtype=np.int32)
+        _lib.check(_lib.lib().shn_cgraph_export(self.h, coff.ctypes.data, cnb.ctypes.data, cw.ctypes.data))
+        return coff.tolist(), cnb[:n_conn.value].tolist(), cw[:n_conn.value].tolist()
+
+    def close(self):
+        if self.h:
+            _lib.lib().shn_cgraph_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def accept_filter(live, nr, nl, tw, k1, min_length, min_weight):
+    """The accept filter of the extension loop (extension_correction.py:361) over non-void walks: ranks + contig lengths of
+    the walks that pass, in seed order."""
+    length = k1 + nr.astype(np.int64) + nl.astype(np.int64)
+    sel = length >= min_length                                 # first clause of the accept filter (:361)
+    cand, clen = live[sel], length[sel]
+    thr = 2 * min_length * math.pow(min_weight, 1 / 4.0)
+    # second clause of :361, len * avg_wt**0.25 >= 2*min_length*min_weight**0.25: vectorised with a guard band;
+    # only candidates within 1e-9 (relative) of the threshold are decided with math.pow like the reference.
+    ckm = nr[sel].astype(np.int64) + nl[sel].astype(np.int64) + 1
+    ctw = tw[sel]
+    avg = ctw.astype(np.float64) / np.maximum(1, ckm)
+    lhs = clen.astype(np.float64) * np.power(avg, 0.25)
+    sure = lhs >= thr * (1 + 1e-9)
+    maybe = (~sure) & (lhs >= thr * (1 - 1e-9))
+    for j in np.nonzero(maybe)[0].tolist():
+        a = float(int(ctw[j])) / max(1, int(ckm[j]))
+        sure[j] = int(clen[j]) * math.pow(a, 1 / 4.0) >= thr
+    return list(zip(cand[sure].tolist(), clen[sure].tolist()))
 
 
 def contig_stage(strings, k1, r=15, f=0.5):
@@ -259,27 +350,77 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
         _t0[0] = now
 
     k1 = table.k
-    ext = Extension(ctx, table, min_weight, shard=shard)
+    UNCL = 0xFFFFFFFF
+    # Pipelined (single GPU, no sharding): the rank blocks of the walks become final one after the other, heaviest seeds
+    # first -- the order in which the reference's loop finishes contigs.  The candidates of a final block are filtered and
+    # emitted inside the walk call (block call-back) and handed to a host thread that runs duplicate_check +
+    # contig_connections on them while the GPU iterates on the later blocks.
+    pipe = None
+    if (shard is None or shard[0] <= 1) and merge is None and gather is None and os.environ.get("SHN_EXT_PIPELINE", "1") != "0":
+        import threading, queue
+
+        class _Pipe(object):
+            pass
+        pipe = _Pipe()
+        pipe.q, pipe.void, pipe.error, pipe.cb_seconds, pipe.accepted, pipe.cg = queue.Queue(), False, None, 0.0, [], None
+        pipe.n_blocks, pipe.busy, pipe.t_start = 0, 0.0, _t.time()
+
+        def _worker():
+            try:
+                pipe.cg = ContigGraph(k1, r, f)
+                while True:
+                    item = pipe.q.get()
+                    if item is None:
+                        break
+                    w0 = _t.time()
+                    acc = pipe.cg.add(item)
+                    pipe.accepted += [item[i] for i in np.nonzero(acc)[0].tolist()]
+                    pipe.busy += _t.time() - w0
+                    if os.environ.get("SHN_DEBUG"):
+                        sys.stderr.write("[pipeline] contig stage: %d candidates (%d bases) %.1f ms, started %.1f ms after the walks began\n"
+                                         % (len(item), sum(len(x) for x in item), (_t.time() - w0) * 1e3, (w0 - pipe.t_start) * 1e3))
+            except BaseException as ex:                       # surfaced on the main thread after the walks
+                pipe.error = ex
+        pipe.thread = threading.Thread(target=_worker, daemon=True)
+        pipe.thread.start()
+
+        def _on_block(view, lo, hi, status):
+            c0 = _t.time()
+            try:
+                if status < 0:
+                    pipe.void = True
+                elif not pipe.void and pipe.error is None and hi > lo:
+                    bnr, bnl, btw = view.stats_range(lo, hi - lo)
+                    alive = np.nonzero(bnr != UNCL)[0]
+                    keep_b = accept_filter((alive + lo).astype(np.uint32), bnr[alive], bnl[alive], btw[alive], k1, min_length, min_weight)
+                    if keep_b:
+                        pipe.q.put(view.emit([x[0] for x in keep_b], [x[1] for x in keep_b]))
+                    pipe.n_blocks += 1
+                    if os.environ.get("SHN_DEBUG"):
+                        sys.stderr.write("[pipeline] block [%d,%d) final %.1f ms after the walks began: %d live walks, %d candidates, call-back %.1f ms\n"
+                                         % (lo, hi, (c0 - pipe.t_start) * 1e3, len(alive), len(keep_b), (_t.time() - c0) * 1e3))
+            except BaseException as ex:                       # (an exception cannot cross the C frames of the walk call)
+                pipe.error = ex
+            pipe.cb_seconds += _t.time() - c0
+    ext = Extension(ctx, table, min_weight, shard=shard, on_block=_on_block if pipe is not None else None)
     lap("ext.gpu_walks")
-    live, nr, nl, tw = ext.live_stats()                        # non-void walks, in seed order (compacted on the GPU)
-    length = k1 + nr.astype(np.int64) + nl.astype(np.int64)
-    sel = length >= min_length                                 # first clause of the accept filter (:361)
-    cand, clen = live[sel], length[sel]
-    thr = 2 * min_length * math.pow(min_weight, 1 / 4.0)
-    # second clause of :361, len * avg_wt**0.25 >= 2*min_length*min_weight**0.25: vectorised with a guard band;
-    # only candidates within 1e-9 (relative) of the threshold are decided with math.pow like the reference.
-    ckm = nr[sel].astype(np.int64) + nl[sel].astype(np.int64) + 1
-    ctw = tw[sel]
-    avg = ctw.astype(np.float64) / np.maximum(1, ckm)
-    lhs = clen.astype(np.float64) * np.power(avg, 0.25)
-    sure = lhs >= thr * (1 + 1e-9)
-    maybe = (~sure) & (lhs >= thr * (1 - 1e-9))
-    for j in np.nonzero(maybe)[0].tolist():
-        a = float(int(ctw[j])) / max(1, int(ckm[j]))
-        sure[j] = int(clen[j]) * math.pow(a, 1 / 4.0) >= thr
-    keep = list(zip(cand[sure].tolist(), clen[sure].tolist()))
+    if pipe is not None:
+        pipe.q.put(None)
+        T["ext.gpu_walks"] -= pipe.cb_seconds
+        T["ext.filter+emit (inside the walks)"] = T.get("ext.filter+emit (inside the walks)", 0.0) + pipe.cb_seconds
+        pipe.thread.join()
+        if pipe.error is not None:
+            raise pipe.error
+        if pipe.void:                                  # the fixpoint audit reopened blocks: what was handed over is void
+            pipe.cg.close()
+            pipe = None
+    if pipe is not None:
+        keep = None
+    else:
+        live, nr, nl, tw = ext.live_stats()                        # non-void walks, in seed order (compacted on the GPU)
+        keep = accept_filter(live, nr, nl, tw, k1, min_length, min_weight)
     lap("ext.filter")
-    strings = ext.emit([x[0] for x in keep], [x[1] for x in keep]) if keep else []
+    strings = (ext.emit([x[0] for x in keep], [x[1] for x in keep]) if keep else []) if pipe is None else None
     contigs = ["buffer"]
     conn = {}
     sharded_contigs = False
@@ -325,7 +466,14 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
         lap("ext.emit")
 
     # duplicate_check + contig graph, sequential over candidates in seed order (:358-397)
-    if not sharded_contigs:
+    if pipe is not None:                               # already done, beside the walks
+        coff, cnb, cw = pipe.cg.connections()
+        pipe.cg.close()
+        contigs += pipe.accepted
+        for a in range(len(coff) - 1):
+            conn[a + 1] = dict(zip(cnb[coff[a]:coff[a + 1]], cw[coff[a]:coff[a + 1]]))
+        T["ext.contig_graph (beside the walks)"] = T.get("ext.contig_graph (beside the walks)", 0.0) + pipe.busy
+    elif not sharded_contigs:
         acc, coff, cnb, cw = contig_stage(strings, k1, r, f)
         for i in np.nonzero(acc)[0].tolist():
             contigs.append(strings[i])

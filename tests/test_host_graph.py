@@ -206,3 +206,32 @@ def test_native_find_reps_matches_python_and_oracle():
         assert a == b == c
     full = post.finalize(lines, True)
     assert full == opost.finalize(lines, True)
+
+
+@pytest.mark.parametrize("name", CASES[:4])
+def test_contig_graph_fed_in_pieces_equals_one_call(name):
+    """shn_cgraph (the contig stage fed block by block by the pipelined extension) == shn_contig_graph on all candidates."""
+    from shannon_amd import build, extension_correction as ec
+    build.build(verbose=False)
+    g = load_case(name)
+    inp = load_inputs(name)
+    K = g["K"]
+    dbl = list(seqs.double_strand_paired(*inp)) if g["paired"] else [seqs.double_strand_single(inp[0])]
+    tab = count.count_k1mers_dict([r for f in dbl for r in f], K + 1)
+    cands = extension.candidate_contigs([(k, tab[k]) for k in sorted(tab, reverse=True)]) if hasattr(extension, "candidate_contigs") else None
+    if cands is None:                                    # any strings in a fixed order will do: accepted contigs + variants of them
+        res = extension.run_correction([(k, tab[k]) for k in sorted(tab, reverse=True)])
+        rng = np.random.default_rng(7)
+        cands = []
+        for c in res.contigs:
+            cands.append(c)
+            if len(c) > 120:
+                cands += [c[10:-10], c[: len(c) // 2] + "".join("ACGT"[i] for i in rng.integers(0, 4, 40)) + c[len(c) // 2:]]
+    acc, coff, cnb, cw = ec.contig_stage(cands, K + 1)
+    cg = ec.ContigGraph(K + 1)
+    cuts = [0, len(cands) // 5, len(cands) // 5, len(cands) // 2, len(cands)]
+    accs = [cg.add(cands[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    got = np.concatenate(accs) if accs else np.zeros(0, np.int32)
+    assert np.array_equal(got, acc)
+    assert cg.connections() == (coff, cnb, cw)
+    cg.close()
