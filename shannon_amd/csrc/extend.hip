@@ -1156,7 +1156,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       frozen = limit;                                // this block is final: open the next one
       // geometric blocks up to half of the walks, then blocks of ns / tail_div: the light half of the seed order settles in
       // a few cheap rounds per block, and what a block call-back receives early can be worked on beside the later blocks
-      if (tail_div && (unsigned long long)frozen * 2 >= ns) limit = (uint32_t)std::min<unsigned long long>(ns, (unsigned long long)frozen + std::max<unsigned long long>(1, ns / tail_div));
+      if (tail_div && ((unsigned long long)frozen + ns / 16) * 2 >= ns) limit = (uint32_t)std::min<unsigned long long>(ns, (unsigned long long)frozen + std::max<unsigned long long>(1, ns / tail_div));
       else limit = (uint32_t)std::min<unsigned long long>(ns, (unsigned long long)limit * grow);
       TRYE(hipMemsetAsync(ran, 0, frozen, s));       // frozen walks never run again
       TRYE(hipMemsetAsync(dirty + frozen, 1, limit - frozen, s));

@@ -186,13 +186,15 @@ class ContigGraph(object):
     def add(self, strings):
         """-> acc: 1-based accepted index (over all calls) of every candidate, or 0"""
         if not strings:
+            self.best = np.zeros(0, np.int32)
             return np.zeros(0, np.int32)
         joined = "".join(strings).encode()
         offs = np.zeros(len(strings) + 1, dtype=np.uint64)
         offs[1:] = np.cumsum([len(x) for x in strings], dtype=np.uint64)
         buf = np.frombuffer(joined, dtype=np.uint8)
         acc = np.zeros(len(strings), dtype=np.int32)
-        _lib.check(_lib.lib().shn_cgraph_add(self.h, buf.ctypes.data, offs.ctypes.data, len(strings), acc.ctypes.data, None))
+        self.best = np.zeros(len(strings), dtype=np.int32)      # hit count of every candidate's `best` contig (0: no hit)
+        _lib.check(_lib.lib().shn_cgraph_add(self.h, buf.ctypes.data, offs.ctypes.data, len(strings), acc.ctypes.data, self.best.ctypes.data))
         return acc
 
     def connections(self):
@@ -356,7 +358,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     # emitted inside the walk call (block call-back) and handed to a host thread that runs duplicate_check +
     # contig_connections on them while the GPU iterates on the later blocks.
     pipe = None
-    if (shard is None or shard[0] <= 1) and merge is None and gather is None and os.environ.get("SHN_EXT_PIPELINE", "1") != "0":
+    if merge is None and os.environ.get("SHN_EXT_PIPELINE", "1") != "0":
         import threading, queue
 
         class _Pipe(object):
@@ -364,6 +366,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
         pipe = _Pipe()
         pipe.q, pipe.void, pipe.error, pipe.cb_seconds, pipe.accepted, pipe.cg = queue.Queue(), False, None, 0.0, [], None
         pipe.n_blocks, pipe.busy, pipe.t_start = 0, 0.0, _t.time()
+        pipe.strings, pipe.ranks, pipe.acc, pipe.best = [], [], [], []     # every candidate handed over, in seed order
 
         def _worker():
             try:
@@ -375,6 +378,9 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
                     w0 = _t.time()
                     acc = pipe.cg.add(item)
                     pipe.accepted += [item[i] for i in np.nonzero(acc)[0].tolist()]
+                    pipe.strings += item
+                    pipe.acc.append(acc)
+                    pipe.best.append(pipe.cg.best)
                     pipe.busy += _t.time() - w0
                     if os.environ.get("SHN_DEBUG"):
                         sys.stderr.write("[pipeline] contig stage: %d candidates (%d bases) %.1f ms, started %.1f ms after the walks began\n"
@@ -394,6 +400,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
                     alive = np.nonzero(bnr != UNCL)[0]
                     keep_b = accept_filter((alive + lo).astype(np.uint32), bnr[alive], bnl[alive], btw[alive], k1, min_length, min_weight)
                     if keep_b:
+                        pipe.ranks += [x[0] for x in keep_b]
                         pipe.q.put(view.emit([x[0] for x in keep_b], [x[1] for x in keep_b]))
                     pipe.n_blocks += 1
                     if os.environ.get("SHN_DEBUG"):
@@ -402,10 +409,19 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
             except BaseException as ex:                       # (an exception cannot cross the C frames of the walk call)
                 pipe.error = ex
             pipe.cb_seconds += _t.time() - c0
-    ext = Extension(ctx, table, min_weight, shard=shard, on_block=_on_block if pipe is not None else None)
+    if pipe is not None:
+        # the call-back needs the interpreter lock while the worker may hold it between its native calls: hand it over
+        # quickly (the default switch interval of 5 ms would stall the walk loop once per block)
+        _swi = sys.getswitchinterval()
+        sys.setswitchinterval(2e-4)
+    try:
+        ext = Extension(ctx, table, min_weight, shard=shard, on_block=_on_block if pipe is not None else None)
+    finally:
+        if pipe is not None:
+            pipe.q.put(None)
+            sys.setswitchinterval(_swi)
     lap("ext.gpu_walks")
     if pipe is not None:
-        pipe.q.put(None)
         T["ext.gpu_walks"] -= pipe.cb_seconds
         T["ext.filter+emit (inside the walks)"] = T.get("ext.filter+emit (inside the walks)", 0.0) + pipe.cb_seconds
         pipe.thread.join()
@@ -425,11 +441,21 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     conn = {}
     sharded_contigs = False
     if gather is not None and gather.world > 1:
-        skey, sw = ext.seed_info([x[0] for x in keep])
+        if pipe is not None:                           # the shard's contig stage ran beside its walks
+            strings = pipe.strings
+            skey, sw = ext.seed_info(pipe.ranks)
+            acc = np.concatenate(pipe.acc) if pipe.acc else np.zeros(0, np.int32)
+            bestc = np.concatenate(pipe.best) if pipe.best else np.zeros(0, np.int32)
+            coff, cnb, cw = pipe.cg.connections()
+            pipe.cg.close()
+            T["ext.contig_graph (beside the walks)"] = T.get("ext.contig_graph (beside the walks)", 0.0) + pipe.busy
+            pipe = None
+        else:
+            skey, sw = ext.seed_info([x[0] for x in keep])
+            acc, coff, cnb, cw = contig_stage(strings, k1, r, f)
+            bestc = contig_best_counts(len(strings))
         local = list(zip(sw.tolist(), skey.tolist(), strings))
         lap("ext.emit")
-        acc, coff, cnb, cw = contig_stage(strings, k1, r, f)
-        bestc = contig_best_counts(len(strings))
         mine = [local[i] for i in np.nonzero(acc)[0].tolist()]              # accepted here, local order
         lap("ext.contig_graph")
         everybody = gather.all_gather(mine)
