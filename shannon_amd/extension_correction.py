@@ -406,6 +406,10 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
                     if os.environ.get("SHN_DEBUG"):
                         sys.stderr.write("[pipeline] block [%d,%d) final %.1f ms after the walks began: %d live walks, %d candidates, call-back %.1f ms\n"
                                          % (lo, hi, (c0 - pipe.t_start) * 1e3, len(alive), len(keep_b), (_t.time() - c0) * 1e3))
+            except _lib.ShannonError:
+                # a block that is not at its fixpoint after all (its claims do not match its walks): the audit at the end of
+                # the walks reopens it; what was handed over is void and the stage runs after the walks
+                pipe.void = True
             except BaseException as ex:                       # (an exception cannot cross the C frames of the walk call)
                 pipe.error = ex
             pipe.cb_seconds += _t.time() - c0

@@ -276,3 +276,30 @@ def test_foreign_interference_rules(ctx):
     # rejected candidate: safe while the foreign contig has fewer hits than its own best contig
     assert ec.foreign_interference(ctx, local[1:], [0], [12], foreign_early) == 0       # 11 foreign hits < 12
     assert ec.foreign_interference(ctx, local[1:], [0], [11], foreign_early) == 1       # tie: the foreign one could be the last
+
+
+@pytest.mark.parametrize("lost_round", [1, 3, 7])
+def test_pipelined_contig_stage_survives_a_reopened_fixpoint(ctx, lost_round, monkeypatch, capfd):
+    """The contig stage runs beside the walks on the blocks that are already final.  If the fixpoint audit then reopens the
+    blocks (forced here by dropping one round's marks), what was handed over is void: the result must still be the one of
+    the plain, unpipelined run."""
+    from shannon_amd import device, synth, extension_correction as ec
+    (r1, r2), _ = synth.make_dataset(60000, 20, seed=81)
+    t = device.count_k1mers(ctx, [device.Reads.from_codes(ctx, np.concatenate([r1, r2]))], 26)
+    try:
+        monkeypatch.setenv("SHN_EXT_PIPELINE", "0")
+        ref = ec.run_correction(ctx, t, 3, 75, 500, want_allowed=False)
+        monkeypatch.setenv("SHN_EXT_PIPELINE", "1")
+        T = {}
+        got = ec.run_correction(ctx, t, 3, 75, 500, want_allowed=False, timings=T)
+        assert "ext.contig_graph (beside the walks)" in T                      # the pipelined path was taken
+        assert got.contigs == ref.contigs and got.connections == ref.connections and got.components == ref.components
+        capfd.readouterr()
+        monkeypatch.setenv("SHN_EXT_FAULT", str(lost_round))
+        T = {}
+        got = ec.run_correction(ctx, t, 3, 75, 500, want_allowed=False, timings=T)
+        assert "reopening all blocks" in capfd.readouterr().err
+        assert "ext.contig_graph (beside the walks)" not in T                  # ... and abandoned
+        assert got.contigs == ref.contigs and got.connections == ref.connections and got.components == ref.components
+    finally:
+        t.close()
