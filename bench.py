@@ -229,10 +229,11 @@ def main():
         # so ms / launches is that kernel's average launch duration -- comparable with rocprofv3's AverageNs.
         # Algorithmic bytes per unit are the figures of DESIGN.md section 3.
         W = 100 - k1 + 1
-        KERNEL = {"count.hist1": "hist1_kernel", "count.scatter1": "scatter1_kernel", "count.hist2": "hist_keys_kernel",
+        KERNEL = {"count.direct": "count_direct_kernel", "count.hist1": "hist1_kernel", "count.scatter1": "scatter1_kernel", "count.hist2": "hist_keys_kernel",
                   "count.scatter2": "scatter_keys_kernel", "count.buckets": "buckets_kernel", "route": "route_kernel",
                   "extend.walk_thread": "ext_walk_kernel", "extend.walk_wave": "ext_walk_long_kernel", "extend.mark": "ext_mark_kernel"}
-        per_read = {"count.hist1": 25.0, "count.scatter1": 25.0 + 8.0 * W, "count.hist2": 8.0 * W,
+        per_read = {"count.direct": 25.0 + 12.0 * distinct / max(1, n_reads),    # packed read in, (key, count) of the distinct k1-mers out
+                    "count.hist1": 25.0, "count.scatter1": 25.0 + 8.0 * W, "count.hist2": 8.0 * W,
                     "count.scatter2": 16.0 * W, "count.buckets": 8.0 * W, "route": 192.0}
         ext = last.res["extension"] if use_dist else {k: getattr(last.R.extension, k) for k in ("iterations", "n_walks", "total_steps", "wave_steps")}
         steps_all = ext["total_steps"] or 0

@@ -10,6 +10,7 @@
 // Buckets are ranges of the top `bits` bits of murmur-fmix64(key); one bucket fits an LDS hash
 // table of CAP slots, so duplicates (heavy k-mers) cost no capacity, only LDS atomics.
 #include "common.h"
+#include <atomic>
 #include <cmath>
 #include <algorithm>
 #include <cstring>
@@ -385,6 +386,74 @@ __global__ void lookup_kernel(const uint64_t* __restrict__ tkeys, const uint32_t
   out[i] = res;
 }
 
+// ---------------------------------------------------------------- one-pass counting into a global hash table
+// For inputs whose distinct k-mers are few next to the windows (deep coverage: 4.9 M of 750 M on BASELINE configs[1]) the
+// partition pipeline above moves every window through HBM three times.  Here a block aggregates a tile of windows in an LDS
+// hash table (heavy k-mers collapse there) and adds what is left -- (key, count) pairs -- to ONE open-addressing table in
+// HBM with device-scope atomics (CAS on the key word, add on the count); the table's pairs then go through the pairs path
+// (build_from_keys with counts) to become the same bucketed, sorted table.  A probe of the idea measured 14 ms against
+// 25 ms (tools/probes/atomic_table_probe.hip).  The table is sized from the window count and grown on overflow; inputs
+// with many distinct keys fall back to the partition pipeline.
+#define DSLOTS 8192          // LDS slots per block (key 8 B + count 4 B)
+__device__ __forceinline__ bool gtable_add(unsigned long long* __restrict__ gkeys, uint32_t* __restrict__ gcounts, uint64_t mask,
+                                           uint64_t key, uint32_t c) {
+  const unsigned long long kk = (unsigned long long)key + 1ULL;      // stored key + 1: 0 = empty slot (a key is < 2^64 - 1: k <= 32 ... all-T at k = 32 wraps, see host)
+  uint64_t s = shn_mix64(key) & mask;
+  for (int probe = 0; probe < 256; probe++) {
+    unsigned long long cur = __hip_atomic_load(&gkeys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == 0) { unsigned long long old = atomicCAS(&gkeys[s], 0ULL, kk); cur = old == 0 ? kk : old; }
+    if (cur == kk) { atomicAdd(&gcounts[s], c); return true; }
+    s = (s + 1) & mask;
+  }
+  return false;
+}
+template <bool CANON>
+__global__ __launch_bounds__(1024) void count_direct_kernel(ReadsView v, int k, uint64_t n_tiles, unsigned long long* __restrict__ gkeys,
+                                                            uint32_t* __restrict__ gcounts, uint64_t mask, uint32_t* __restrict__ overflow) {
+  __shared__ unsigned long long lk[DSLOTS];
+  __shared__ uint32_t lc[DSLOTS];
+  bool lost = false;
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // (a table that turned out too small makes every insertion walk its whole probe limit: stop as soon as anybody lost a window)
+    if (__hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    for (int j = threadIdx.x; j < DSLOTS; j += blockDim.x) { lk[j] = 0; lc[j] = 0; }
+    __syncthreads();
+    const uint64_t r0 = tile * v.rt;
+    const uint32_t nr = (uint32_t)min((uint64_t)v.rt, v.n_reads - r0);
+    const uint32_t nid = nr * v.wmax;
+    for (uint32_t i = threadIdx.x; i < nid; i += blockDim.x) {
+      const uint32_t rl = i / v.wmax, pos = i - rl * v.wmax;
+      uint64_t key;
+      if (!gen_key<CANON>(v, r0 + rl, pos, k, key)) continue;
+      const unsigned long long kk = (unsigned long long)key + 1ULL;
+      uint32_t s = (uint32_t)(shn_mix64(key) >> 40) & (DSLOTS - 1);
+      bool done = false;
+#pragma unroll 1
+      for (int probe = 0; probe < 8 && !done; probe++) {          // a few probes in LDS, then straight to the global table
+        unsigned long long cur = lk[s];
+        if (cur == 0) { unsigned long long old = atomicCAS(&lk[s], 0ULL, kk); cur = old == 0 ? kk : old; }
+        if (cur == kk) { atomicAdd(&lc[s], 1u); done = true; }
+        s = (s + 1) & (DSLOTS - 1);
+      }
+      if (!done && !gtable_add(gkeys, gcounts, mask, key, 1)) { lost = true; atomicOr(overflow, 1u); }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < DSLOTS; j += blockDim.x)
+      if (lk[j] && !gtable_add(gkeys, gcounts, mask, (uint64_t)(lk[j] - 1ULL), lc[j])) lost = true;
+    __syncthreads();
+  }
+  if (lost) atomicOr(overflow, 1u);
+}
+__global__ void gtable_flag_kernel(const unsigned long long* __restrict__ gkeys, uint64_t slots, uint32_t* __restrict__ flag) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < slots) flag[i] = gkeys[i] != 0 ? 1u : 0u;
+}
+__global__ void gtable_compact_kernel(const unsigned long long* __restrict__ gkeys, const uint32_t* __restrict__ gcounts, uint64_t slots,
+                                      const uint64_t* __restrict__ pos, uint64_t* __restrict__ okeys, uint32_t* __restrict__ ocounts) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < slots && gkeys[i]) { okeys[pos[i]] = (uint64_t)(gkeys[i] - 1ULL); ocounts[pos[i]] = gcounts[i]; }
+}
+
 // ================================================================ host side
 int ShnWs::get(size_t bytes, void** out) {
   if (bytes > cap) {
@@ -446,6 +515,58 @@ extern "C" int shn_count_k1mers(shn_ctx* ctx, shn_reads* const* sets, int n_sets
     ReadsView v = make_view(sets[i], k1);
     views.push_back(v);
     upper += v.n_reads * (uint64_t)v.wmax;
+  }
+  // One-pass path first (see count_direct_kernel): worth it when the table is small next to the windows; the size is a
+  // guess (windows / 32, at most 2^24 slots to begin with) corrected by what earlier calls of this process needed.
+  {
+    static std::atomic<int> learned_log2{0};               // slots that sufficed last time (0: none yet)
+    const int mode = getenv("SHN_COUNT_DIRECT") ? atoi(getenv("SHN_COUNT_DIRECT")) : 1;      // 0 off, 1 large inputs, 2 always (tests)
+    const bool want = mode != 0 && (upper >= (1ULL << 22) || mode == 2) && k1 < 32 && upper > 0;
+    int lg = learned_log2.load();
+    if (!lg) { lg = 20; while (lg < 24 && (1ULL << lg) < upper / 32) lg++; }
+    if (getenv("SHN_COUNT_DIRECT_LOG2")) lg = atoi(getenv("SHN_COUNT_DIRECT_LOG2"));          // (tests: start too small, grow)
+    for (int attempt = 0; want && attempt < 8 && lg <= 27; attempt++) {
+      const uint64_t slots = 1ULL << lg;
+      unsigned long long* gk = nullptr; uint32_t* gc = nullptr; uint32_t* flag = nullptr; uint64_t* pos = nullptr; uint32_t* d_ov = nullptr;
+      uint64_t* pk = nullptr; uint32_t* pcn = nullptr;
+      auto freeall = [&]() { if (gk) shn_dev_free(gk); if (gc) shn_dev_free(gc); if (flag) shn_dev_free(flag); if (pos) shn_dev_free(pos);
+                             if (d_ov) shn_dev_free(d_ov); if (pk) shn_dev_free(pk); if (pcn) shn_dev_free(pcn); };
+#define TRYD(x) do { hipError_t _e = (x); if (_e != hipSuccess) { freeall(); return shn_fail(SHN_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(_e)); } } while (0)
+      TRYD(shn_dev_malloc(&gk, slots * 8)); TRYD(shn_dev_malloc(&gc, slots * 4)); TRYD(shn_dev_malloc(&flag, (slots + 1) * 4));
+      TRYD(shn_dev_malloc(&pos, (slots + 2) * 8)); TRYD(shn_dev_malloc(&d_ov, 64));
+      TRYD(hipMemsetAsync(gk, 0, slots * 8, s)); TRYD(hipMemsetAsync(gc, 0, slots * 4, s)); TRYD(hipMemsetAsync(d_ov, 0, 64, s));
+      for (auto& v : views) {
+        if (!v.wmax || !v.n_reads) continue;
+        TimerRegion t(ctx, T_COUNT_DIRECT);
+        uint64_t n_tiles = cdiv(v.n_reads, v.rt);
+        uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, 2048);
+        if (both_strands) hipLaunchKernelGGL(count_direct_kernel<true>, dim3(grid), dim3(1024), 0, s, v, k1, n_tiles, gk, gc, slots - 1, d_ov);
+        else hipLaunchKernelGGL(count_direct_kernel<false>, dim3(grid), dim3(1024), 0, s, v, k1, n_tiles, gk, gc, slots - 1, d_ov);
+      }
+      hipLaunchKernelGGL(gtable_flag_kernel, dim3((uint32_t)cdiv(slots, 256)), dim3(256), 0, s, gk, slots, flag);
+      uint64_t nd = 0;
+      int rcd = shn_device_scan_u32(ctx, flag, slots, pos, &nd);
+      if (rcd) { freeall(); return rcd; }
+      uint32_t ov = 0;
+      TRYD(hipMemcpy(&ov, d_ov, 4, hipMemcpyDeviceToHost));
+      if (ov || nd * 10 > slots * 6) {                      // too full (long probe chains) or lost windows: a bigger table, or give up
+        freeall();
+        if (mode != 2 && nd * 10 > slots * 6 && !ov && (nd << 5) > upper) break;      // many distinct keys for the windows: the partition pipeline is the better tool
+        lg += ov ? 3 : 2;
+        continue;
+      }
+      TRYD(shn_dev_malloc(&pk, (nd + 1) * 8)); TRYD(shn_dev_malloc(&pcn, (nd + 1) * 4));
+      hipLaunchKernelGGL(gtable_compact_kernel, dim3((uint32_t)cdiv(slots, 256)), dim3(256), 0, s, gk, gc, slots, pos, pk, pcn);
+      shn_table* tb = nullptr;
+      int rcp = shn_table_from_pairs(ctx, pk, pcn, nd, k1, both_strands ? 1 : 0, &tb);
+      TRYD(hipStreamSynchronize(s));
+      freeall();
+#undef TRYD
+      if (rcp) return rcp;
+      if (!getenv("SHN_COUNT_DIRECT_LOG2")) learned_log2.store(lg);
+      *out = tb;
+      return SHN_OK;
+    }
   }
   // bits_n: enough buckets if every window were a distinct key (the histogram pass runs at this resolution);
   // the final number of buckets follows the HyperLogLog estimate of the distinct keys and only grows on overflow
