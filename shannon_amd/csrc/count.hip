@@ -817,8 +817,11 @@ extern "C" int shn_table_from_pairs(shn_ctx* ctx, const void* dev_keys, const vo
   TimingOff toff(ctx);                            // from the per-kernel timers of the counting pass
   const uint64_t* keys = (const uint64_t*)dev_keys;
   const uint32_t* cnts = (const uint32_t*)dev_counts;
+  // ~100 keys per bucket: a lookup is a binary search inside its bucket (7 steps instead of 10 at 640 per bucket), and
+  // the adjacency, routing and seed kernels are made of lookups
   int bits = 0;
-  while (bits < 24 && (n >> bits) > TARGET_BUCKET) bits++;
+  const uint64_t per_bucket = getenv("SHN_TABLE_BUCKET") ? strtoull(getenv("SHN_TABLE_BUCKET"), nullptr, 10) : 96;
+  while (bits < 24 && (n >> bits) > per_bucket) bits++;
   for (int attempt = 0; attempt < 4; attempt++) {
     int b1 = (bits + 1) / 2, b2 = bits - b1;
     int nb1 = 1 << b1;
