@@ -183,6 +183,21 @@ int shn_cgraph_add(shn_cgraph* g, const uint8_t* bases, const uint64_t* off, uin
 int shn_cgraph_sizes(const shn_cgraph* g, uint64_t* n_acc, uint64_t* n_conn);
 int shn_cgraph_export(const shn_cgraph* g, uint64_t* conn_off, int32_t* conn_nb, int32_t* conn_w);
 
+/* The same stage in one call with the bulk of the work on the GPU (csrc/contig_gpu.hip), for inputs with hundreds of thousands of
+ * candidates: the r-mers of all candidates are sorted on the device and candidates sharing an r-mer are clustered -- duplicate_check
+ * (extension_correction.py:247-270) only ever compares a candidate with accepted contigs of its own cluster, so the clusters are
+ * decided independently (in seed order inside a cluster); contig_connections (:372-397) come from a device sort of the accepted
+ * contigs' K-mers, replayed on the host over the K-mers that occur in two contigs.  Same outputs as shn_cgraph_add on a fresh
+ * graph; *out is read with shn_cgraph_sizes / shn_cgraph_export and freed with shn_cgraph_destroy.                              */
+int shn_contig_stage(shn_ctx* ctx, const uint8_t* bases, const uint64_t* off, uint64_t n_cand, int k1, int r, double f,
+                     int32_t* accepted_out, int32_t* best_counts_out, shn_cgraph** out);
+/* Connected components of the contig graph by the reference's depth-first search (extension_correction.py:417-434) over the
+ * connections CSR of shn_cgraph_export: comp_of[a-1] = root contig of contig a (1-based), members[] = the components' contigs in the
+ * order the DFS pops them, component j at members[comp_off[j]..comp_off[j+1]), comp_edges[j] = its number of undirected edges
+ * (the E of the METIS header, :446-456).  comp_off: n_acc+1 entries, comp_edges: n_acc entries.                               */
+int shn_contig_components(uint64_t n_acc, const uint64_t* conn_off, const int32_t* conn_nb, int32_t* comp_of, int32_t* members,
+                          uint64_t* comp_off, uint64_t* comp_edges, uint64_t* n_comp_out);
+
 /* ---- read -> partition routing -----------------------------------------------------------------
  * Replaces the read-streaming loops of kmers_for_component (kmers_for_component.py:322-403;
  * get_rmers :186-192, get_comps :194-205).  `probe` maps every k1-mer of every partition's

@@ -74,6 +74,8 @@ SIGNATURES = {
     "shn_cgraph_add": (C.c_int, [vp, vp, vp, C.c_uint64, vp, vp]),
     "shn_cgraph_sizes": (C.c_int, [vp, vp, vp]),
     "shn_cgraph_export": (C.c_int, [vp, vp, vp, vp]),
+    "shn_contig_stage": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, C.c_double, vp, vp, vpp]),
+    "shn_contig_components": (C.c_int, [C.c_uint64, vp, vp, vp, vp, vp, vp, u64p]),
     "shn_ext_emit": (C.c_int, [vp, vp, vp, C.c_uint64, vp, vp]),
     "shn_ext_weights": (C.c_int, [vp, vp, vp, C.c_uint64, vp]),
 }

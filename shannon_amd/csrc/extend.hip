@@ -101,8 +101,9 @@ __global__ void ext_adjacency_kernel(const uint64_t* __restrict__ tkeys, const u
                                      const uint8_t* __restrict__ flags, uint64_t n, int k, int canonical,
                                      int32_t* __restrict__ adjR, int32_t* __restrict__ adjL) {
   // one thread per (oriented, dir, base); adjL == nullptr: right rows only (all the component labelling needs), n * 8 threads
-  uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= n * (adjL ? 16 : 8)) return;
+  // grid-stride: n * 16 exceeds the 2^32 work-items one dispatch can carry once the table passes 2^28 k1-mers
+  const uint64_t total = n * (adjL ? 16 : 8);
+  for (uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (uint64_t)gridDim.x * blockDim.x) {
   uint32_t b = gid & 3;
   uint32_t dir = adjL ? (gid >> 2) & 1 : 0;
   uint64_t o = adjL ? gid >> 3 : gid >> 2;
@@ -121,6 +122,7 @@ __global__ void ext_adjacency_kernel(const uint64_t* __restrict__ tkeys, const u
     if (j >= 0 && !(flags[j] & 2)) res = (int32_t)(2 * j + strand);
   }
   (dir == 0 ? adjR : adjL)[o * 4 + b] = res;
+  }
 }
 
 // ---- connected components of the k1-mer graph (vertices = canonical k1-mers, edges = the adjacency rows).
@@ -141,17 +143,18 @@ __global__ void cc_init_kernel(uint32_t* __restrict__ lab, uint64_t n) {
   if (i < n) lab[i] = (uint32_t)i;
 }
 __global__ void cc_union_kernel(const int32_t* __restrict__ adjR, uint64_t n2, uint32_t* lab) {
-  uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per (oriented k1-mer, appended base)
-  if (gid >= n2 * 4) return;
-  int32_t t = adjR[gid];
-  if (t < 0) return;
-  uint32_t u = (uint32_t)(gid >> 3), v = (uint32_t)t >> 1;             // canonical indices
-  if (u == v) return;
-  while (true) {
-    uint32_t ru = cc_find(lab, u), rv = cc_find(lab, v);
-    if (ru == rv) break;
-    uint32_t hi = ru > rv ? ru : rv, lo = ru > rv ? rv : ru;
-    if (atomicCAS(&lab[hi], hi, lo) == hi) break;
+  // one item per (oriented k1-mer, appended base); grid-stride (n2 * 4 can exceed the 2^32 work-items of a dispatch)
+  for (uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < n2 * 4; gid += (uint64_t)gridDim.x * blockDim.x) {
+    int32_t t = adjR[gid];
+    if (t < 0) continue;
+    uint32_t u = (uint32_t)(gid >> 3), v = (uint32_t)t >> 1;             // canonical indices
+    if (u == v) continue;
+    while (true) {
+      uint32_t ru = cc_find(lab, u), rv = cc_find(lab, v);
+      if (ru == rv) break;
+      uint32_t hi = ru > rv ? ru : rv, lo = ru > rv ? rv : ru;
+      if (atomicCAS(&lab[hi], hi, lo) == hi) break;
+    }
   }
 }
 __global__ void cc_flatten_kernel(uint32_t* lab, uint64_t n) {
@@ -897,7 +900,7 @@ static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank
     TimerRegion t1(ctx, T_EXT_PREP);
     hipLaunchKernelGGL(ext_prepare_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, t->d_counts, n, t->k, t->canonical, d_weight, d_flags);
     // right rows of both orientations hold every edge of the (undirected) k1-mer graph: the left rows are not needed here
-    hipLaunchKernelGGL(ext_adjacency_kernel, dim3((uint32_t)cdiv(n * 8, 256)), dim3(256), 0, s, t->d_keys, t->d_bucket_off, t->bits, d_flags, n, t->k,
+    hipLaunchKernelGGL(ext_adjacency_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off, t->bits, d_flags, n, t->k,
                        t->canonical, d_adjR, (int32_t*)nullptr);
   }
   void *pl, *po, *pz, *pb, *pc, *pp;
@@ -912,7 +915,7 @@ static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank
   uint64_t* d_pos = (uint64_t*)pp;
   TRYS(hipMemsetAsync(d_cnt, 0, 2048, s));
   hipLaunchKernelGGL(cc_init_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, d_lab, n);
-  hipLaunchKernelGGL(cc_union_kernel, dim3((uint32_t)cdiv(2 * n * 4, 256)), dim3(256), 0, s, (const int32_t*)d_adjR, 2 * n, d_lab);
+  hipLaunchKernelGGL(cc_union_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(2 * n * 4, 256), 1u << 22)), dim3(256), 0, s, (const int32_t*)d_adjR, 2 * n, d_lab);
   hipLaunchKernelGGL(cc_flatten_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, d_lab, n);
   TRYS(hipMemsetAsync(d_size, 0, (n + 1) * 4, s));
   hipLaunchKernelGGL(cc_sample_kernel, dim3((uint32_t)cdiv(cdiv(n, 64), 256)), dim3(256), 0, s, d_lab, n, d_size);
@@ -1021,8 +1024,9 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     TimerRegion t1(ctx, T_EXT_PREP);
     hipLaunchKernelGGL(ext_prepare_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, t->d_counts, n, t->k,
                        t->canonical, e->d_weight, e->d_flags);
-    hipLaunchKernelGGL(ext_adjacency_kernel, dim3((uint32_t)cdiv(n * 16, 256)), dim3(256), 0, s, t->d_keys, t->d_bucket_off,
+    hipLaunchKernelGGL(ext_adjacency_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 16, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off,
                        t->bits, e->d_flags, n, t->k, t->canonical, e->d_adjR, e->d_adjL);
+    TRYE(hipGetLastError());
   }
   // seeds: compact, sort by string then (stable) by weight descending
   void *pk, *pv, *pk2, *pv2, *pc;
@@ -1116,15 +1120,23 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   const int precise_marks = (int)tune("SHN_EXT_PRECISE", 1);       // 0: the conservative rule (every walk standing next to a freed k1-mer)
   const uint32_t long_walk = tune("SHN_EXT_LONG_WALK", LONG_WALK), memo_min = tune("SHN_EXT_MEMO_MIN", MEMO_MIN),
                  promote_steps = tune("SHN_EXT_PROMOTE", PROMOTE_STEPS);
+  // Bulk rounds: with hundreds of thousands of dirty walks the GPU is throughput-bound, not latency-bound, and one thread
+  // per walk (one memory round trip per step, every lane busy) beats a wavefront per walk by an order of magnitude; memos
+  // (which serve the latency-bound re-runs of a few long walks) are not made in such a round.  The expected number of
+  // dirty walks is the block size when a block opens, else the count of the round before.
+  const unsigned long long bulk_min = getenv("SHN_EXT_BULK") ? strtoull(getenv("SHN_EXT_BULK"), nullptr, 10) : 262144ULL;
+  unsigned long long expect_dirty = limit;
   while (!converged && it < max_iterations) {
+    const bool bulk = bulk_min && expect_dirty >= bulk_min;
     // classify the dirty walks of the open block; a block without dirty walks is consistent = final
     TRYE(hipMemsetAsync(d_cnt + 2, 0, 32, s));
     if (limit > frozen)
       hipLaunchKernelGGL(ext_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 1024)), dim3(1024), 0, s, e->d_nr, e->d_nl, (uint64_t)limit, frozen,
-                         mvalid, mR, mL, dirty, long_list, short_list, d_cnt + 2, long_walk);
+                         mvalid, mR, mL, dirty, long_list, short_list, d_cnt + 2, bulk ? 0xFFFFFFFFu : long_walk);
     // (pinned host memory: a pageable destination costs a staging copy kernel per round)
     TRYE(hipMemcpyAsync(plan, d_cnt + 2, 32, hipMemcpyDeviceToHost, s));
     TRYE(hipStreamSynchronize(s));
+    expect_dirty = plan[3];
     if (plan[3] == 0) {
       if (limit >= ns) {
         // every block is settled: audit the claims (see ext_audit_nodes_kernel); a walk that is not at its fixpoint
@@ -1148,6 +1160,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
                 it, plan[4], plan[5]);
         if (++repairs > 16) break;
         frozen = 0;
+        expect_dirty = plan[4] + plan[5];
         TRYE(hipMemsetAsync(ran, 0, ns + 1, s));
         TRYE(hipMemsetAsync(owned, 0, (ns + 1) * 4, s));
         continue;
@@ -1160,6 +1173,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       else limit = (uint32_t)std::min<unsigned long long>(ns, (unsigned long long)limit * grow);
       TRYE(hipMemsetAsync(ran, 0, frozen, s));       // frozen walks never run again
       TRYE(hipMemsetAsync(dirty + frozen, 1, limit - frozen, s));
+      expect_dirty = limit - frozen;
       continue;
     }
     TimerRegion t3(ctx, T_EXT_WALK);
@@ -1170,7 +1184,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     A.claim = claim; A.claim_old = snap;
     A.nr_out = e->d_nr; A.nl_out = e->d_nl; A.totw_out = e->d_totw;
     A.pool = pool; A.moff = moff; A.mR = mR; A.mL = mL; A.mvalid = mvalid; A.hint = hint;
-    A.promote_steps = promote_steps;
+    A.promote_steps = bulk ? 0xFFFFFFFFu : promote_steps;
     A.promo_list = promo_list; A.promo_count = d_cnt + 13; A.res_cur = res_cur; A.res_info = res_info;
     A.steps_counter = d_cnt + 1; A.wave_steps_counter = d_cnt + 64; A.dbg = getenv("SHN_DEBUG") ? d_cnt + 32 : nullptr;
     // long (wave per walk) and short (thread per walk) kernels are independent: overlap them on two streams
@@ -1194,7 +1208,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     // who has to run next round?  walks whose view changed (mark) + walks that lost a claim race (verify);
     // the walks that ran get their memo rebuilt from the claims
     hipLaunchKernelGGL(ext_memo_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 256)), dim3(256), 0, s, ran, dirty, owned, e->d_nr, e->d_nl, e->d_order, frozen, limit,
-                       moff, mR, mL, mvalid, fill, pool, d_cnt + 10, pool_cap, memo_min);
+                       moff, mR, mL, mvalid, fill, pool, d_cnt + 10, pool_cap, bulk ? 0xFFFFFFFFu : memo_min);
     { TimerRegion tk(ctx, T_EXT_MARK);
       hipLaunchKernelGGL(ext_mark_kernel, dim3(std::min<uint32_t>(g2n, 4096u)), dim3(256), 0, s, claim, snap, 2 * n, (const Adj4*)e->d_adjR, (const Adj4*)e->d_adjL,
                          seed_rank, dirty, ran, owned, d_cnt + 6, frozen, limit, fill, moff, mR, pool, hint, e->d_nr, e->d_nl, e->d_weight, precise_marks); }

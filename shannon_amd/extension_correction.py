@@ -17,8 +17,26 @@ UNCLAIMED = 0xFFFFFFFF
 
 
 class ExtensionResult(object):
-    """Same fields as the reference's in-memory/file products (see run_correction)."""
-    pass
+    """Same fields as the reference's in-memory/file products (see run_correction).  The contig graph is held as CSR
+    (conn_off / conn_nb / conn_w, neighbours in the reference's dict insertion order) and the components as flat arrays;
+    `connections` ({contig: {neighbour: weight}}) and `components` ({root: [members]}) are the reference's dicts, built on
+    first use (tests, small inputs)."""
+    _conn = None
+    _comps = None
+
+    @property
+    def connections(self):
+        if self._conn is None:
+            off, nb, w = self.conn_off, self.conn_nb, self.conn_w
+            self._conn = {a + 1: dict(zip(nb[off[a]:off[a + 1]], w[off[a]:off[a + 1]])) for a in range(len(off) - 1)}
+        return self._conn
+
+    @property
+    def components(self):
+        if self._comps is None:
+            m, o = self.comp_members, self.comp_off
+            self._comps = {m[o[j]]: m[o[j]:o[j + 1]] for j in range(len(o) - 1)}
+        return self._comps
 
 
 class Extension(object):
@@ -109,14 +127,18 @@ class Extension(object):
             _lib.check(L.shn_ext_live_stats(self.ctx.h, self.h, C.byref(n), rank.ctypes.data, nr.ctypes.data, nl.ctypes.data, tw.ctypes.data))
         return rank[:m], nr[:m], nl[:m], tw[:m]
 
-    def emit(self, ranks, lengths):
+    def emit_raw(self, ranks, lengths):
+        """(ASCII bases uint8[total], offsets uint64[n+1]) of the contigs of the selected walks"""
         ranks = np.ascontiguousarray(ranks, dtype=np.uint32)
         offs = np.zeros(len(ranks) + 1, dtype=np.uint64)
         offs[1:] = np.cumsum(lengths, dtype=np.uint64)
         buf = np.empty(int(offs[-1]) + 1, dtype=np.uint8)
         _lib.check(_lib.lib().shn_ext_emit(self.ctx.h, self.h, ranks.ctypes.data, len(ranks), offs.ctypes.data, buf.ctypes.data))
-        s = buf[:int(offs[-1])].tobytes().decode()
-        return [s[int(offs[i]):int(offs[i + 1])] for i in range(len(ranks))]
+        return buf[:int(offs[-1])], offs
+
+    def emit(self, ranks, lengths):
+        buf, offs = self.emit_raw(ranks, lengths)
+        return split_strings(buf, offs)
 
     def weights(self, keys):
         keys = np.ascontiguousarray(keys, dtype=np.uint64)
@@ -174,6 +196,50 @@ def windows_to_keys_many(contigs, k):
     wbefore = np.concatenate([[0], np.cumsum(nwin)[:-1]])
     idx = np.repeat(off - wbefore, nwin) + np.arange(int(nwin.sum()), dtype=np.int64)   # windows that stay inside a string
     return key[idx], nwin
+
+
+def split_strings(buf, offs):
+    s = buf.tobytes().decode()
+    o = offs.tolist()
+    return [s[o[i]:o[i + 1]] for i in range(len(o) - 1)]
+
+
+def contig_stage_gpu(ctx, buf, offs, k1, r=15, f=0.5):
+    """duplicate_check + contig graph of candidates in seed order with the bulk of the work on the GPU (shn_contig_stage).
+    buf/offs: ASCII bases + offsets.  Returns (acc, best, coff, cnb, cw) as numpy arrays (see contig_stage)."""
+    n = len(offs) - 1
+    acc = np.zeros(max(n, 1), dtype=np.int32)
+    best = np.zeros(max(n, 1), dtype=np.int32)
+    h = C.c_void_p()
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    _lib.check(_lib.lib().shn_contig_stage(ctx.h, buf.ctypes.data, offs.ctypes.data, n, int(k1), int(r), float(f), acc.ctypes.data,
+                                           best.ctypes.data, C.byref(h)))
+    try:
+        n_acc, n_conn = C.c_uint64(0), C.c_uint64(0)
+        _lib.check(_lib.lib().shn_cgraph_sizes(h, C.byref(n_acc), C.byref(n_conn)))
+        coff = np.zeros(n_acc.value + 1, dtype=np.uint64)
+        cnb = np.zeros(max(1, n_conn.value), dtype=np.int32)
+        cw = np.zeros(max(1, n_conn.value), dtype=np.int32)
+        _lib.check(_lib.lib().shn_cgraph_export(h, coff.ctypes.data, cnb.ctypes.data, cw.ctypes.data))
+    finally:
+        _lib.lib().shn_cgraph_destroy(h)
+    return acc[:n], best[:n], coff, cnb[:n_conn.value], cw[:n_conn.value]
+
+
+def contig_components(coff, cnb):
+    """The reference's DFS components over the connections CSR (shn_contig_components): (comp_of, members, comp_off, comp_edges)."""
+    n = len(coff) - 1
+    coff = np.ascontiguousarray(coff, dtype=np.uint64)
+    cnb = np.ascontiguousarray(cnb, dtype=np.int32)
+    comp_of = np.zeros(max(n, 1), np.int32)
+    members = np.zeros(max(n, 1), np.int32)
+    comp_off = np.zeros(n + 2, np.uint64)
+    comp_edges = np.zeros(max(n, 1), np.uint64)
+    nc = C.c_uint64(0)
+    _lib.check(_lib.lib().shn_contig_components(n, coff.ctypes.data, cnb.ctypes.data if len(cnb) else None, comp_of.ctypes.data, members.ctypes.data,
+                                                comp_off.ctypes.data, comp_edges.ctypes.data, C.byref(nc)))
+    return comp_of[:n], members[:n], comp_off[:nc.value + 1], comp_edges[:nc.value]
 
 
 class ContigGraph(object):
