@@ -305,39 +305,35 @@ def accept_filter(live, nr, nl, tw, k1, min_length, min_weight):
     return list(zip(cand[sure].tolist(), clen[sure].tolist()))
 
 
+_last_best = [np.zeros(0, np.int32)]
+
+
 def contig_stage(strings, k1, r=15, f=0.5):
     """duplicate_check + contig graph over candidate contigs in seed order (:358-397), native host code (csrc/contig_host.hip,
-    shn_contig_graph).  Returns (acc, coff, cnb, cw): acc[i] = 1-based accepted index of candidate i or 0; neighbours of
+    the shn_cgraph handle).  Returns (acc, coff, cnb, cw): acc[i] = 1-based accepted index of candidate i or 0; neighbours of
     accepted contig a (0-based) are cnb[coff[a]:coff[a+1]] (1-based accepted indices, dict insertion order) with weights cw."""
     if not strings:
+        _last_best[0] = np.zeros(0, np.int32)
         return np.zeros(0, np.int32), [0], [], []
-    joined = "".join(strings).encode()
-    offs = np.zeros(len(strings) + 1, dtype=np.uint64)
-    offs[1:] = np.cumsum([len(x) for x in strings], dtype=np.uint64)
-    buf = np.frombuffer(joined, dtype=np.uint8)
-    acc = np.zeros(len(strings), dtype=np.int32)
-    n_acc, n_conn = C.c_uint64(0), C.c_uint64(0)
-    _lib.check(_lib.lib().shn_contig_graph(buf.ctypes.data, offs.ctypes.data, len(strings), k1, r, float(f), acc.ctypes.data,
-                                           C.byref(n_acc), None, None, None, C.byref(n_conn)))
-    coff = np.zeros(n_acc.value + 1, dtype=np.uint64)
-    cnb = np.zeros(max(1, n_conn.value), dtype=np.int32)
-    cw = np.zeros(max(1, n_conn.value), dtype=np.int32)
-    _lib.check(_lib.lib().shn_contig_graph(buf.ctypes.data, offs.ctypes.data, len(strings), k1, r, float(f), acc.ctypes.data,
-                                           C.byref(n_acc), coff.ctypes.data, cnb.ctypes.data, cw.ctypes.data, C.byref(n_conn)))
+    cg = ContigGraph(k1, r, f)
+    try:
+        acc = cg.add(strings)
+        _last_best[0] = cg.best
+        coff, cnb, cw = cg.connections()
+    finally:
+        cg.close()
     if os.environ.get("SHN_DEBUG"):
         pos = np.nonzero(acc)[0]
         dec = np.histogram(pos, bins=10, range=(0, max(1, len(strings))))[0].tolist()
         sys.stderr.write("[contig_graph] candidates %d (%d bases), accepted %d; accepted per decile of the seed order: %s\n"
-                         % (len(strings), int(offs[-1]), len(pos), dec))
-    return acc, coff.tolist(), cnb[:n_conn.value].tolist(), cw[:n_conn.value].tolist()
+                         % (len(strings), sum(len(x) for x in strings), len(pos), dec))
+    return acc, coff, cnb, cw
 
 
 def contig_best_counts(n_cand):
-    """hit count of the `best` contig of every candidate of the last contig_stage call (shn_contig_best_counts)"""
-    out = np.zeros(max(n_cand, 1), dtype=np.int32)
-    if n_cand:
-        _lib.check(_lib.lib().shn_contig_best_counts(out.ctypes.data, n_cand))
-    return out[:n_cand]
+    """hit count of the `best` contig of every candidate of the last contig_stage call"""
+    assert len(_last_best[0]) == n_cand
+    return _last_best[0]
 
 
 def rmer_join(ctx, candidates, foreign_contigs, r=15):
@@ -424,7 +420,11 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     # emitted inside the walk call (block call-back) and handed to a host thread that runs duplicate_check +
     # contig_connections on them while the GPU iterates on the later blocks.
     pipe = None
-    if merge is None and os.environ.get("SHN_EXT_PIPELINE", "1") != "0":
+    # Large tables (BASELINE configs[2]: 20,000 genes, several 10^5 candidate contigs): the contig stage runs after the walks with
+    # its sorts on the GPU (contig_stage_gpu) instead of beside them on one host thread.  SHN_CONTIG_GPU=1 / 0 forces / forbids it.
+    _cg = os.environ.get("SHN_CONTIG_GPU", "")
+    gpu_contigs = merge is None and (gather is None or gather.world <= 1) and (_cg == "1" or (_cg != "0" and len(table) >= 20_000_000))
+    if merge is None and not gpu_contigs and os.environ.get("SHN_EXT_PIPELINE", "1") != "0":
         import threading, queue
 
         class _Pipe(object):
@@ -506,11 +506,25 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
         live, nr, nl, tw = ext.live_stats()                        # non-void walks, in seed order (compacted on the GPU)
         keep = accept_filter(live, nr, nl, tw, k1, min_length, min_weight)
     lap("ext.filter")
-    strings = (ext.emit([x[0] for x in keep], [x[1] for x in keep]) if keep else []) if pipe is None else None
+    csr = None                                         # (coff, cnb, cw): connections in dict insertion order, 1-based neighbours
     contigs = ["buffer"]
-    conn = {}
+    conn = None
     sharded_contigs = False
-    if gather is not None and gather.world > 1:
+    if gpu_contigs:
+        buf, offs = ext.emit_raw([x[0] for x in keep], [x[1] for x in keep]) if keep else (np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+        lap("ext.emit")
+        acc, _best, coff, cnb, cw = contig_stage_gpu(ctx, buf, offs, k1, r, f)
+        csr = (coff, cnb, cw)
+        text = buf.tobytes().decode()
+        o = offs.tolist()
+        contigs += [text[o[i]:o[i + 1]] for i in np.nonzero(acc)[0].tolist()]
+        del text
+        strings = None
+    else:
+        strings = (ext.emit([x[0] for x in keep], [x[1] for x in keep]) if keep else []) if pipe is None else None
+    if gpu_contigs:
+        pass
+    elif gather is not None and gather.world > 1:
         if pipe is not None:                           # the shard's contig stage ran beside its walks
             strings = pipe.strings
             skey, sw = ext.seed_info(pipe.ranks)
@@ -537,6 +551,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
         lap("ext.gathers")
         if safe:
             sharded_contigs = True
+            conn = {}
             conns = gather.all_gather((coff, cnb, cw))
             lap("ext.gathers")
             items = sorted(((c[0], c[1], rk, j) for rk, lst in enumerate(everybody) for j, c in enumerate(lst)), key=lambda t: (-t[0], t[1]))
@@ -562,20 +577,26 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
         lap("ext.emit")
 
     # duplicate_check + contig graph, sequential over candidates in seed order (:358-397)
-    if pipe is not None:                               # already done, beside the walks
-        coff, cnb, cw = pipe.cg.connections()
+    if gpu_contigs:
+        pass
+    elif pipe is not None:                             # already done, beside the walks
+        csr = pipe.cg.connections()
         pipe.cg.close()
         contigs += pipe.accepted
-        for a in range(len(coff) - 1):
-            conn[a + 1] = dict(zip(cnb[coff[a]:coff[a + 1]], cw[coff[a]:coff[a + 1]]))
         T["ext.contig_graph (beside the walks)"] = T.get("ext.contig_graph (beside the walks)", 0.0) + pipe.busy
     elif not sharded_contigs:
         acc, coff, cnb, cw = contig_stage(strings, k1, r, f)
         for i in np.nonzero(acc)[0].tolist():
             contigs.append(strings[i])
-        for a in range(len(coff) - 1):
-            conn[a + 1] = dict(zip(cnb[coff[a]:coff[a + 1]], cw[coff[a]:coff[a + 1]]))
-
+        csr = (coff, cnb, cw)
+    if csr is None:                                    # merged shards: the dicts in global order -> CSR
+        coff, cnb, cw = [0], [], []
+        for a in range(1, len(contigs)):
+            d = conn.get(a, {})
+            cnb += list(d.keys())
+            cw += list(d.values())
+            coff.append(len(cnb))
+        csr = (coff, cnb, cw)
     lap("ext.contig_graph")
     res = ExtensionResult()
     res.k1 = k1
@@ -595,43 +616,33 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
                 allowed[c[i:i + k1]] = w[p]
                 p += 1
     res.allowed = allowed
-    res.connections = conn
     ext.close()
 
-    # DFS components (:417-434) and file products (:458-513)
-    comp_of, comps, seen = {}, {}, set()
-    for ci in conn:
-        if ci not in comp_of:
-            comps[ci] = []
-            stack = [ci]
-            seen.add(ci)
-            while stack:
-                cur = stack.pop()
-                comp_of[cur] = ci
-                comps[ci].append(cur)
-                for nb in conn[cur]:
-                    if nb not in seen:
-                        stack.append(nb)
-                        seen.add(nb)
-    res.components = comps
-    drawn = {c: set() for c in comps}
-    for a in conn:
-        for b in conn[a]:
-            drawn[comp_of[a]].add((min(a, b), max(a, b)))
+    # DFS components (:417-434, native: shn_contig_components) and file products (:458-513)
+    coff_a = np.asarray(csr[0], dtype=np.uint64)
+    cnb_a = np.asarray(csr[1], dtype=np.int32)
+    cw_a = np.asarray(csr[2], dtype=np.int32)
+    _comp_of, members, comp_off, comp_edges = contig_components(coff_a, cnb_a)
+    res.conn_off, res.conn_nb, res.conn_w = coff_a.tolist(), cnb_a.tolist(), cw_a.tolist()
+    res.comp_members, res.comp_off = members.tolist(), comp_off.tolist()
+    mem, co = res.comp_members, res.comp_off
+    sizes = np.diff(comp_off.astype(np.int64)) if len(comp_off) > 1 else np.zeros(0, np.int64)
     res.single_contigs, res.big_components, res.remaining = [], [], [[]]
     cur_size = 0
-    for comp, members in comps.items():
-        if len(members) == 1:
-            res.single_contigs.append(contigs[members[0]])
-        elif len(members) > comp_size_threshold:
-            code = {c: i + 1 for i, c in enumerate(members)}
-            lines = ["%d\t%d\t001\n" % (len(members), len(drawn[comp]))]
-            for c in members:
-                lines.append("".join("%d\t%d\t" % (code[c2], wt) for c2, wt in conn[c].items()) + "\n")
-            res.big_components.append(([contigs[c] for c in members], "".join(lines)))
+    for j, sz in enumerate(sizes.tolist()):
+        if sz == 1:
+            res.single_contigs.append(contigs[mem[co[j]]])
+        elif sz > comp_size_threshold:
+            mm = mem[co[j]:co[j + 1]]
+            code = {c: i + 1 for i, c in enumerate(mm)}
+            lines = ["%d\t%d\t001\n" % (sz, int(comp_edges[j]))]
+            o, nb_, w_ = res.conn_off, res.conn_nb, res.conn_w
+            for c in mm:
+                lines.append("".join("%d\t%d\t" % (code[c2], wt) for c2, wt in zip(nb_[o[c - 1]:o[c]], w_[o[c - 1]:o[c]])) + "\n")
+            res.big_components.append(([contigs[c] for c in mm], "".join(lines)))
         else:
-            res.remaining[-1].extend(contigs[c] for c in members)
-            cur_size += len(members)
+            res.remaining[-1].extend(contigs[c] for c in mem[co[j]:co[j + 1]])
+            cur_size += sz
             if cur_size > comp_size_threshold:
                 res.remaining.append([])
                 cur_size = 0

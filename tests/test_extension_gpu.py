@@ -303,3 +303,58 @@ def test_pipelined_contig_stage_survives_a_reopened_fixpoint(ctx, lost_round, mo
         assert got.contigs == ref.contigs and got.connections == ref.connections and got.components == ref.components
     finally:
         t.close()
+
+
+def _variants(contigs, seed=5):
+    """accepted contigs + near-copies, substrings and chimeras of them: clusters of several candidates, duplicates to
+    reject, contigs that share K-mers at their ends"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i, c in enumerate(contigs):
+        out.append(c)
+        if len(c) > 120:
+            out.append(c[10:-10])
+            mid = len(c) // 2
+            out.append(c[:mid] + "".join("ACGT"[j] for j in rng.integers(0, 4, 40)) + c[mid:])
+        if i and len(c) > 60 and len(contigs[i - 1]) > 60:
+            out.append(contigs[i - 1][-50:] + c[:50] + "".join("ACGT"[j] for j in rng.integers(0, 4, 30)))
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(MANIFEST))
+def test_gpu_contig_stage_equals_the_sequential_stage(ctx, name):
+    """shn_contig_stage (r-mer clusters and K-mer joins on the GPU) == shn_cgraph (the reference's sequential loop, checked
+    against the oracle on the CPU): accepted flags, best-hit counts, connections with weights and insertion order."""
+    from shannon_amd import extension_correction as ec
+    g = load_case(name)
+    for cands in (g["contigs"], _variants(g["contigs"]), _variants(g["contigs"], 9)[::-1]):
+        if not cands:
+            continue
+        acc, coff, cnb, cw = ec.contig_stage(cands, g["K"] + 1)
+        best = ec.contig_best_counts(len(cands))
+        buf = np.frombuffer("".join(cands).encode(), np.uint8)
+        offs = np.zeros(len(cands) + 1, np.uint64)
+        offs[1:] = np.cumsum([len(c) for c in cands])
+        acc2, best2, coff2, cnb2, cw2 = ec.contig_stage_gpu(ctx, buf, offs, g["K"] + 1)
+        assert np.array_equal(acc, acc2) and np.array_equal(best, best2)
+        assert coff2.tolist() == coff and cnb2.tolist() == cnb and cw2.tolist() == cw
+
+
+def test_gpu_contig_stage_on_many_genes(ctx):
+    """300 genes: a few thousand candidates in many small clusters, through run_correction both ways"""
+    from shannon_amd import device, synth, extension_correction as ec
+    import os
+    (r1, r2), _ = synth.make_dataset(150000, 300, seed=21)
+    t = device.count_k1mers(ctx, [device.Reads.from_codes(ctx, r1), device.Reads.from_codes(ctx, r2)], 26)
+    os.environ["SHN_CONTIG_GPU"] = "0"
+    try:
+        ref = ec.run_correction(ctx, t, 3, 75, 50)
+        os.environ["SHN_CONTIG_GPU"] = "1"
+        got = ec.run_correction(ctx, t, 3, 75, 50)
+    finally:
+        del os.environ["SHN_CONTIG_GPU"]
+    assert len(ref.contigs) > 500
+    assert got.contigs == ref.contigs and got.connections == ref.connections
+    assert [list(v) for v in got.connections.values()] == [list(v) for v in ref.connections.values()]
+    assert got.components == ref.components and got.single_contigs == ref.single_contigs
+    assert got.remaining == ref.remaining and got.big_components == ref.big_components and got.allowed == ref.allowed
