@@ -73,6 +73,15 @@ def gen_reads(n_pairs, seed, n_genes, device, read_seed=None, families=0):
     return torch.cat(out1).numpy(), torch.cat(out2).numpy()
 
 
+def _final_sha(final):
+    """order-free digest of the final transcript set (run-to-run determinism is checked with it)"""
+    import hashlib
+    h = hashlib.sha256()
+    for sq in sorted(final.values()):
+        h.update(sq.encode() + b"\n")
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(k1, r1, r2, n_pairs):
     """The CPU restatement of the reference (oracle/, pure Python like Shannon itself, one host thread) over a
     bounded sample of the same reads, full path a1-a31; plus the C restatement of the counting stage alone."""
@@ -276,6 +285,7 @@ def main():
                        "host_stage_seconds_per_step": {k: v / args.steps for k, v in stage_t.items()},
                        "host_stage_seconds_per_step_slowest_rank": stage_max,
                        "transcripts": (len(last.res["final"]) if use_dist else len(last.R.final)),
+                       "transcripts_sha256_16": _final_sha(last.res["final"] if use_dist else last.R.final),
                        "extension_iterations": ext["iterations"], "extension_walks": ext["n_walks"],
                        "extension_walk_steps": steps_all,
                        "partitions": (len(last.res["partitions"]) if use_dist else {k: [v["n_reads_routed"], v["n_k1mers"]] for k, v in last.R.partitions.items()}),

@@ -31,6 +31,7 @@ struct shn_ctx {
   double ms[T_N];
   uint64_t regions[T_N];
   bool timing;
+  int count_direct_log2;   // one-pass counting: table size that sufficed last time (0 none yet, -1 gave up), shn_count_k1mers
 };
 
 // RAII-less region timer: records events on the ctx stream; durations are summed lazily.
@@ -148,6 +149,7 @@ struct ShnWs {
   int get(size_t bytes, void** out);
 };
 extern ShnWs g_shn_ws[32];
+void shn_ws_trim_if_large(hipStream_t stream);       // end of a stage: give workspace slots back when they hold > 1/4 of the device
 int shn_device_scan_u32(shn_ctx* ctx, const uint32_t* d_in, uint64_t n, uint64_t* d_out /* n+1 */, uint64_t* total_host);
 // stable LSD radix sort of (u64 key, u32 value) pairs on bits [bit_lo, bit_hi); result lands in keys/vals
 int shn_sort_pairs(shn_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t* keys_tmp, uint32_t* vals_tmp, uint64_t n,

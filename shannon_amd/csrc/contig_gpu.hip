@@ -2,11 +2,17 @@
 // candidate contigs: duplicate_check (extension_correction.py:247-270) and contig_connections (:372-397), same results
 // as the sequential stage of contig_host.hip (shn_contig_graph), with the bulk of the work on the GPU.
 //
-// duplicate_check of a candidate only ever looks at accepted contigs that share an r-mer with it.  So: the r-mers of ALL
-// candidates are sorted on the GPU and candidates sharing an r-mer are united (lock-free union-find) -- a candidate's
-// decision depends on the candidates of its own cluster only.  A cluster of one is accepted outright; the other
-// clusters are decided independently of each other, each sequentially in seed order with the reference's rule (a
-// small index per cluster), on host threads.  At 20,000 genes nearly every cluster is one contig or a handful.
+// duplicate_check: whether candidate c is a duplicate depends only on the ACCEPTED earlier candidates -- their r-mer hit counts
+// in c, the one with the most hits (ties: the one whose last hit comes last, `>=` at :258) and how much of c its shared r-mers
+// cover.  The sequential result is the only assignment acc[] with acc[c] = decide(c | acc[< c]).  Here the r-mers of ALL
+// candidates are sorted once on the GPU; candidates are taken in seed-order blocks, and inside a block the decisions are iterated
+// (all candidates of the block at once, against the frozen decisions of the earlier blocks and the tentative ones of the block)
+// until none changes -- the fixpoint of a block on top of a final prefix is the sequential result.  Per round: compact the
+// sorted entries of accepted candidates, every window of the block walks the accepted entries of its run and adds (candidate,
+// parent) hits to a pair table (count, last hit position), the best parent of a candidate is a 64-bit atomicMax over its pairs,
+// a second pass marks the windows that hit it, coverage is summed per candidate.  Variants of a highly expressed transcript
+// come long after it in the seed order (their weight is the error rate times its weight), so they meet it frozen and fall in
+// their block's first round.
 // contig_connections: the K-mers of the accepted contigs are sorted on the GPU; only K-mers occurring in two different
 // contigs matter, those runs are compacted and sent to the host, which replays the reference's loop over them
 // (neighbour lists in dict insertion order, weights counted per position pair).
@@ -53,38 +59,98 @@ __global__ void cg_keys_kernel(const uint8_t* __restrict__ bases, const uint32_t
   }
 }
 
-__device__ __forceinline__ uint32_t cg_find(uint32_t* lab, uint32_t x) {
-  uint32_t cur = x;
-  while (true) {
-    uint32_t p = __hip_atomic_load(&lab[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (p == cur) return cur;
-    uint32_t gp = __hip_atomic_load(&lab[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (gp != p) __hip_atomic_store(&lab[cur], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    cur = p;
+// candidate id + accepted flag of every sorted entry
+__global__ void cg_scid_kernel(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ cid, uint64_t n, uint32_t* __restrict__ scid) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) scid[i] = cid[vals[i]];
+}
+__global__ void cg_accflag_kernel(const uint32_t* __restrict__ scid, const uint8_t* __restrict__ acc, uint64_t n, uint32_t* __restrict__ flag) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) flag[i] = acc[scid[i]];
+}
+__global__ void cg_acc_compact_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ scid, const uint32_t* __restrict__ flag,
+                                      const uint64_t* __restrict__ apos, uint64_t n, uint64_t* __restrict__ akey, uint32_t* __restrict__ acand) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    if (flag[i]) { akey[apos[i]] = keys[i]; acand[apos[i]] = scid[i]; }
+}
+
+// (candidate, parent) -> hit count and position of the last hit.  Open addressing; key = (c + 1) << 32 | p, 0 = empty.
+struct PairSlot { unsigned long long key; uint32_t count; uint32_t last; };
+__device__ __forceinline__ bool pair_add(PairSlot* __restrict__ tab, uint64_t mask, uint32_t c, uint32_t p, uint32_t pos) {
+  const unsigned long long kk = ((unsigned long long)(c + 1) << 32) | p;
+  uint64_t s = shn_mix64(kk) & mask;
+  for (int probe = 0; probe < 1024; probe++) {
+    unsigned long long cur = __hip_atomic_load(&tab[s].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == 0) { unsigned long long old = atomicCAS(&tab[s].key, 0ULL, kk); cur = old == 0 ? kk : old; }
+    if (cur == kk) { atomicAdd(&tab[s].count, 1u); atomicMax(&tab[s].last, pos); return true; }
+    s = (s + 1) & mask;
   }
+  return false;
 }
-__global__ void cg_iota_kernel(uint32_t* __restrict__ lab, uint64_t n) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) lab[i] = (uint32_t)i;
-}
-// neighbours in the sorted order with equal keys and different contigs: unite the contigs (roots link to smaller ids)
-__global__ void cg_union_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint64_t n,
-                                const uint32_t* __restrict__ cid, uint32_t* lab) {
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 1; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    if (keys[i] != keys[i - 1]) continue;
-    const uint32_t u = cid[vals[i]], v = cid[vals[i - 1]];
-    if (u == v) continue;
-    while (true) {
-      const uint32_t ru = cg_find(lab, u), rv = cg_find(lab, v);
-      if (ru == rv) break;
-      const uint32_t hi = ru > rv ? ru : rv, lo = ru > rv ? rv : ru;
-      if (atomicCAS(&lab[hi], hi, lo) == hi) break;
+// every window of the open block [lo, hi): the accepted entries of its run that come before it are its hits (:250-259)
+__global__ void cg_hits_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ scid,
+                               const uint64_t* __restrict__ apos, uint64_t n, const uint64_t* __restrict__ off, uint32_t lo, uint32_t hi,
+                               const uint64_t* __restrict__ akey, const uint32_t* __restrict__ acand, PairSlot* __restrict__ tab, uint64_t mask,
+                               uint32_t* __restrict__ overflow) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t c = scid[i];
+    if (c < lo || c >= hi) continue;
+    const uint64_t key = keys[i];
+    const uint32_t pos = (uint32_t)(vals[i] - off[c]);
+    for (uint64_t j = apos[i]; j-- > 0 && akey[j] == key;) {
+      const uint32_t p = acand[j];
+      if (p == c) continue;                       // the candidate's own earlier windows (it is not in the index while it is checked)
+      if (!pair_add(tab, mask, c, p, pos)) atomicOr(overflow, 1u);
     }
   }
 }
-__global__ void cg_flatten_kernel(uint32_t* lab, uint64_t n) {
-  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) lab[i] = cg_find(lab, (uint32_t)i);
+// best parent of every candidate: most hits; among equals the one whose last hit comes last (`>=`: the latest wins, :258-259),
+// two parents hitting in the same window are listed in acceptance order, so the later candidate wins.
+// pack: count (22 bits) | last hit position (21) | parent (21)
+__global__ void cg_best_kernel(const PairSlot* __restrict__ tab, uint64_t slots, unsigned long long* __restrict__ best) {
+  for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < slots; s += (uint64_t)gridDim.x * blockDim.x) {
+    const unsigned long long k = tab[s].key;
+    if (!k) continue;
+    const uint32_t c = (uint32_t)(k >> 32) - 1, p = (uint32_t)k;
+    const uint32_t cnt = tab[s].count > 0x3FFFFFu ? 0x3FFFFFu : tab[s].count;
+    atomicMax(&best[c], ((unsigned long long)cnt << 42) | ((unsigned long long)tab[s].last << 21) | (unsigned long long)p);
+  }
+}
+// windows of the open block whose r-mer occurs in the candidate's best parent (:262-265)
+__global__ void cg_cover_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ scid,
+                                const uint64_t* __restrict__ apos, uint64_t n, uint32_t lo, uint32_t hi, const uint64_t* __restrict__ akey,
+                                const uint32_t* __restrict__ acand, const unsigned long long* __restrict__ best, uint8_t* __restrict__ hit) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t c = scid[i];
+    if (c < lo || c >= hi) continue;
+    const unsigned long long b = best[c];
+    if (!b) continue;
+    const uint32_t bp = (uint32_t)(b & 0x1FFFFFu);
+    const uint64_t key = keys[i];
+    for (uint64_t j = apos[i]; j-- > 0 && akey[j] == key;)
+      if (acand[j] == bp) { hit[vals[i]] = 1; break; }
+  }
+}
+// covered bases of a candidate = bases under at least one hit window (a[i:i+r] = 1, :264-265)
+__global__ void cg_covsum_kernel(const uint8_t* __restrict__ hit, const uint32_t* __restrict__ cid, const uint64_t* __restrict__ off,
+                                 uint64_t g_lo, uint64_t g_hi, int r, uint32_t* __restrict__ cov) {
+  for (uint64_t g = g_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < g_hi; g += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t c = cid[g];
+    const uint64_t first = off[c];
+    bool covered = false;
+    for (int d = 0; d < r && !covered; d++) { if (g < first + (uint64_t)d) break; covered = hit[g - d] != 0; }
+    if (covered) atomicAdd(&cov[c], 1u);
+  }
+}
+// new decisions of the block; counts the candidates whose decision changed
+__global__ void cg_decide_kernel(const unsigned long long* __restrict__ best, const uint32_t* __restrict__ cov, const uint64_t* __restrict__ off,
+                                 uint32_t lo, uint32_t hi, double f, uint8_t* __restrict__ acc, int32_t* __restrict__ best_count,
+                                 unsigned long long* __restrict__ n_changed) {
+  const uint32_t c = lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= hi) return;
+  const uint32_t M = (uint32_t)(best[c] >> 42);
+  const bool suspect = M > 0 && (double)cov[c] > f * (double)(off[c + 1] - off[c]);
+  const uint8_t a = suspect ? 0 : 1;
+  best_count[c] = (int32_t)M;
+  if (a != acc[c]) { acc[c] = a; atomicAdd(n_changed, 1ULL); }
 }
 
 // runs of equal keys that span two different contigs: flag every entry of such a run (the sort is stable and the
@@ -168,110 +234,114 @@ extern "C" int shn_contig_stage(shn_ctx* ctx, const uint8_t* bases, const uint64
   hipStream_t s = ctx->stream;
   TimerRegion treg(ctx, T_CONTIG);
   DevBufs bufs;
-  uint8_t* d_bases; uint64_t* d_off; uint32_t *d_cid, *d_lab;
+  uint8_t* d_bases; uint64_t* d_off; uint32_t* d_cid;
   HIP_TRY(bufs.get(&d_bases, total + 64));
   HIP_TRY(bufs.get(&d_off, (n_cand + 1) * 8));
   HIP_TRY(bufs.get(&d_cid, (total + 1) * 4));
-  HIP_TRY(bufs.get(&d_lab, (n_cand + 1) * 4));
   HIP_TRY(hipMemcpyAsync(d_bases, bases, total, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_off, off, (n_cand + 1) * 8, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(cg_cid_kernel, dim3((uint32_t)cdiv(n_cand * 64, CG_BLK)), dim3(CG_BLK), 0, s, d_off, n_cand, d_cid);
-  hipLaunchKernelGGL(cg_iota_kernel, dim3((uint32_t)cdiv(n_cand, CG_BLK)), dim3(CG_BLK), 0, s, d_lab, n_cand);
 
-  // ---- clusters of candidates that share an r-mer
-  std::vector<uint32_t> lab(n_cand);
+  // ---- duplicate_check: seed-order blocks, each iterated to its fixpoint on top of the frozen earlier blocks
+  std::vector<uint8_t> acc(n_cand, 0);
+  uint32_t max_len = 0;
+  for (uint64_t c = 0; c < n_cand; c++) max_len = std::max<uint32_t>(max_len, (uint32_t)(off[c + 1] - off[c]));
+  if (n_cand >= (1u << 21) || max_len >= (1u << 21)) {
+    // beyond the 21-bit fields of the packed "best parent" word: the sequential stage
+    G->add(bases, off, n_cand, accepted_out, best_counts_out);
+    *out = G; guard.g = nullptr;
+    return SHN_OK;
+  }
+  uint64_t n_rounds = 0, n_blocks = 0;
   {
     DevBufs tmp;
     uint64_t* keys; uint32_t* vals; uint64_t nv = 0;
     int rc = sorted_windows(ctx, tmp, d_bases, d_off, d_cid, nullptr, total, r, &keys, &vals, &nv);
     if (rc) return rc;
-    if (nv > 1) hipLaunchKernelGGL(cg_union_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, keys, vals, nv, d_cid, d_lab);
-    hipLaunchKernelGGL(cg_flatten_kernel, dim3((uint32_t)cdiv(n_cand, CG_BLK)), dim3(CG_BLK), 0, s, d_lab, n_cand);
-    HIP_TRY(hipMemcpyAsync(lab.data(), d_lab, n_cand * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-  }
-  lap("r-mer sort + clusters (GPU)");
-
-  // ---- duplicate_check per cluster (members ascending = seed order), clusters in parallel on host threads
-  std::vector<uint32_t> csize(n_cand, 0), cstart(n_cand + 1, 0), members(n_cand);
-  for (uint64_t c = 0; c < n_cand; c++) csize[lab[c]]++;
-  for (uint64_t c = 0; c < n_cand; c++) cstart[c + 1] = cstart[c] + csize[c];
-  { std::vector<uint32_t> cur(cstart.begin(), cstart.end() - 1);
-    for (uint64_t c = 0; c < n_cand; c++) members[cur[lab[c]]++] = (uint32_t)c; }
-  std::vector<uint8_t> acc(n_cand, 0);
-  std::vector<uint32_t> multi;                       // roots of the clusters with more than one candidate
-  uint64_t multi_bases = 0, biggest = 0;
-  for (uint64_t c = 0; c < n_cand; c++) {
-    if (csize[c] == 1) acc[members[cstart[c]]] = 1;
-    else if (csize[c] > 1) { multi.push_back((uint32_t)c); biggest = std::max<uint64_t>(biggest, csize[c]); }
-  }
-  // heaviest clusters first (by number of members; a work queue hands them out)
-  std::sort(multi.begin(), multi.end(), [&](uint32_t a, uint32_t b) { return csize[a] != csize[b] ? csize[a] > csize[b] : a < b; });
-  {
-    std::atomic<size_t> next{0};
-    auto worker = [&]() {
-      FlatMultiMap rmer(1 << 10);
-      std::vector<uint64_t> rk;
-      std::vector<int32_t> hits, dupcnt, touched, cov;
+    lap("r-mer sort (GPU)");
+    uint8_t *d_acc, *d_hit; uint32_t *d_scid, *d_flag, *d_acand, *d_cov, *d_ovf; uint64_t *d_apos, *d_akey; int32_t* d_bestc;
+    unsigned long long *d_best, *d_chg;
+    HIP_TRY(tmp.get(&d_acc, n_cand + 1)); HIP_TRY(tmp.get(&d_hit, total + 64)); HIP_TRY(tmp.get(&d_scid, (nv + 1) * 4));
+    HIP_TRY(tmp.get(&d_flag, (nv + 1) * 4)); HIP_TRY(tmp.get(&d_acand, (nv + 1) * 4)); HIP_TRY(tmp.get(&d_cov, (n_cand + 1) * 4));
+    HIP_TRY(tmp.get(&d_ovf, 64)); HIP_TRY(tmp.get(&d_apos, (nv + 2) * 8)); HIP_TRY(tmp.get(&d_akey, (nv + 1) * 8));
+    HIP_TRY(tmp.get(&d_bestc, (n_cand + 1) * 4)); HIP_TRY(tmp.get(&d_best, (n_cand + 1) * 8)); HIP_TRY(tmp.get(&d_chg, 64));
+    HIP_TRY(hipMemsetAsync(d_acc, 0, n_cand + 1, s));
+    HIP_TRY(hipMemsetAsync(d_bestc, 0, (n_cand + 1) * 4, s));
+    if (nv) hipLaunchKernelGGL(cg_scid_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, vals, d_cid, nv, d_scid);
+    int lg_slots = 22;
+    while (lg_slots < 28 && (1ULL << lg_slots) < nv / 4) lg_slots++;
+    if (getenv("SHN_CONTIG_PAIR_LOG2")) lg_slots = atoi(getenv("SHN_CONTIG_PAIR_LOG2"));     // (tests: start too small, grow)
+    PairSlot* d_tab = nullptr;
+    HIP_TRY(tmp.get(&d_tab, sizeof(PairSlot) << lg_slots));
+    uint64_t blk0 = std::max<uint64_t>(1024, n_cand / 256);
+    if (getenv("SHN_CONTIG_BLOCK0")) blk0 = std::max<uint64_t>(1, strtoull(getenv("SHN_CONTIG_BLOCK0"), nullptr, 10));
+    uint64_t lo = 0, bsize = blk0;
+    while (lo < n_cand) {
+      uint64_t hi = std::min<uint64_t>(n_cand, lo + bsize);
+      // the candidates of the block start as "not accepted": the first round meets the frozen earlier blocks only
+      int round = 0;
       while (true) {
-        const size_t q = next.fetch_add(1);
-        if (q >= multi.size()) break;
-        const uint32_t root = multi[q];
-        rmer = FlatMultiMap((size_t)1 << 10);
-        int32_t idx = 0;                             // accepted so far in this cluster (local 1-based index, seed order)
-        for (uint32_t m = cstart[root]; m < cstart[root + 1]; m++) {
-          const uint32_t c = members[m];
-          const uint8_t* sq = bases + off[c];
-          const uint32_t L = (uint32_t)(off[c + 1] - off[c]);
-          window_keys(sq, L, r, rk);
-          hits.assign(rk.size(), -1);
-          if (dupcnt.size() < (size_t)idx + 1) dupcnt.resize((size_t)idx + 1, 0);
-          int32_t max_till_now = 0, best = -1;
-          for (size_t i = 0; i < rk.size(); i++) {
-            int32_t v = rmer.find(rk[i]);
-            hits[i] = v;
-            for (; v != -1; v = rmer.nxt(v)) {
-              const int32_t d = rmer.va(v);
-              if (dupcnt[d] == 0) touched.push_back(d);
-              const int32_t cnt = ++dupcnt[d];
-              if (cnt >= max_till_now) { max_till_now = cnt; best = d; }      // `>=`: the latest wins (:258-259)
-            }
+        unsigned long long changed = 0;
+        uint64_t na = 0;
+        if (nv) {
+          hipLaunchKernelGGL(cg_accflag_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, d_scid, d_acc, nv, d_flag);
+          if ((rc = shn_device_scan_u32(ctx, d_flag, nv, d_apos, &na))) return rc;
+          if (na) hipLaunchKernelGGL(cg_acc_compact_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, keys, d_scid, d_flag, d_apos, nv, d_akey, d_acand);
+        }
+        HIP_TRY(hipMemsetAsync(d_best + lo, 0, (hi - lo) * 8, s));
+        HIP_TRY(hipMemsetAsync(d_cov + lo, 0, (hi - lo) * 4, s));
+        HIP_TRY(hipMemsetAsync(d_hit + off[lo], 0, off[hi] - off[lo], s));
+        HIP_TRY(hipMemsetAsync(d_chg, 0, 8, s));
+        if (na) {
+          while (true) {                             // (the pair table grows until the round's pairs fit)
+            HIP_TRY(hipMemsetAsync(d_tab, 0, sizeof(PairSlot) << lg_slots, s));
+            HIP_TRY(hipMemsetAsync(d_ovf, 0, 4, s));
+            hipLaunchKernelGGL(cg_hits_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, keys, vals, d_scid, d_apos, nv, d_off, (uint32_t)lo, (uint32_t)hi,
+                               d_akey, d_acand, d_tab, (1ULL << lg_slots) - 1, d_ovf);
+            uint32_t ovf = 0;
+            HIP_TRY(hipMemcpyAsync(&ovf, d_ovf, 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (!ovf) break;
+            if (lg_slots >= 31) return shn_fail(SHN_ERR_OVERFLOW, "shn_contig_stage: pair table beyond 2^31 slots");
+            lg_slots += 2;
+            HIP_TRY(tmp.get(&d_tab, sizeof(PairSlot) << lg_slots));
           }
-          for (int32_t d : touched) dupcnt[d] = 0;
-          touched.clear();
-          best_counts_out[c] = max_till_now;
-          bool suspect = false;
-          if (best >= 0) {
-            cov.assign(L + 1, 0);
-            for (size_t i = 0; i < rk.size(); i++) {
-              bool has = false;
-              for (int32_t v = hits[i]; v != -1 && !has; v = rmer.nxt(v)) has = rmer.va(v) == best;
-              if (has) { cov[i] += 1; cov[i + r] -= 1; }
-            }
-            int64_t run = 0, covered = 0;
-            for (uint32_t i = 0; i < L; i++) { run += cov[i]; if (run > 0) covered++; }
-            suspect = (double)covered > f * (double)L;
-          }
-          if (!suspect) {
-            acc[c] = 1;
-            idx++;
-            for (size_t i = 0; i < rk.size(); i++) rmer.add(rk[i], idx);
-          }
+          hipLaunchKernelGGL(cg_best_kernel, dim3(grid_for(1ULL << lg_slots)), dim3(CG_BLK), 0, s, d_tab, 1ULL << lg_slots, d_best);
+          hipLaunchKernelGGL(cg_cover_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, keys, vals, d_scid, d_apos, nv, (uint32_t)lo, (uint32_t)hi, d_akey, d_acand,
+                             d_best, d_hit);
+          hipLaunchKernelGGL(cg_covsum_kernel, dim3(grid_for(off[hi] - off[lo])), dim3(CG_BLK), 0, s, d_hit, d_cid, d_off, off[lo], off[hi], r, d_cov);
+        }
+        hipLaunchKernelGGL(cg_decide_kernel, dim3((uint32_t)cdiv(hi - lo, CG_BLK)), dim3(CG_BLK), 0, s, d_best, d_cov, d_off, (uint32_t)lo, (uint32_t)hi, f,
+                           d_acc, d_bestc, d_chg);
+        HIP_TRY(hipMemcpyAsync(&changed, d_chg, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        n_rounds++;
+        round++;
+        if (dbg) fprintf(stderr, "[contig_stage]   block [%llu,%llu) round %d: %llu accepted entries, %llu decisions changed\n", (unsigned long long)lo,
+                         (unsigned long long)hi, round, (unsigned long long)na, changed);
+        if (!changed) break;
+        if (round >= 64 && hi - lo > 1) {
+          // a long dependency chain inside the block: go on with its first half (its fixpoint does not depend on the rest);
+          // the candidates cut off go back to "not accepted" and come with the next block
+          hi = lo + (hi - lo) / 2;
+          HIP_TRY(hipMemsetAsync(d_acc + hi, 0, n_cand - hi, s));
+          round = 0;
         }
       }
-    };
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned nt = (unsigned)std::min<size_t>(std::min(64u, hw), std::max<size_t>(1, multi.size()));
-    if (nt <= 1) worker();
-    else { std::vector<std::thread> th; for (unsigned t = 0; t < nt; t++) th.emplace_back(worker); for (auto& x : th) x.join(); }
+      n_blocks++;
+      lo = hi;
+      bsize = std::min<uint64_t>(bsize * 2, std::max<uint64_t>(blk0, n_cand / 4));
+    }
+    HIP_TRY(hipMemcpyAsync(acc.data(), d_acc, n_cand, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(best_counts_out, d_bestc, n_cand * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
   }
   std::vector<int32_t> use(n_cand);
   int32_t n_acc = 0;
   for (uint64_t c = 0; c < n_cand; c++) { use[c] = acc[c] ? ++n_acc : 0; accepted_out[c] = use[c]; }
-  if (dbg) fprintf(stderr, "[contig_stage] %llu candidates (%llu bases): %zu clusters of >1 (largest %llu), accepted %d\n",
-                   (unsigned long long)n_cand, (unsigned long long)total, multi.size(), (unsigned long long)biggest, n_acc);
-  (void)multi_bases;
-  lap("duplicate_check per cluster (host)");
+  if (dbg) fprintf(stderr, "[contig_stage] %llu candidates (%llu bases): %llu blocks, %llu rounds, accepted %d\n",
+                   (unsigned long long)n_cand, (unsigned long long)total, (unsigned long long)n_blocks, (unsigned long long)n_rounds, n_acc);
+  lap("duplicate_check rounds (GPU)");
 
   // ---- contig_connections: K-mers occurring in two different accepted contigs
   G->idx = n_acc;

@@ -86,6 +86,7 @@ extern "C" int shn_ctx_create(int device, void* stream, shn_ctx** out) {
   c->device = device;
   c->stream = (hipStream_t)stream;
   c->timing = true;
+  c->count_direct_log2 = 0;
   for (int i = 0; i < T_N; i++) { c->ms[i] = 0; c->regions[i] = 0; }
   *out = c;
   return SHN_OK;

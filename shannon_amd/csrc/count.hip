@@ -412,12 +412,15 @@ __global__ __launch_bounds__(1024) void count_direct_kernel(ReadsView v, int k, 
                                                             uint32_t* __restrict__ gcounts, uint64_t mask, uint32_t* __restrict__ overflow) {
   __shared__ unsigned long long lk[DSLOTS];
   __shared__ uint32_t lc[DSLOTS];
+  __shared__ uint32_t stop;
   bool lost = false;
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    // (a table that turned out too small makes every insertion walk its whole probe limit: stop as soon as anybody lost a window)
-    if (__hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    // (a table that turned out too small makes every insertion walk its whole probe limit: stop as soon as anybody lost a
+    // window -- decided by one thread for the whole block, so that every wavefront takes the same way past the barriers)
+    if (threadIdx.x == 0) stop = __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int j = threadIdx.x; j < DSLOTS; j += blockDim.x) { lk[j] = 0; lc[j] = 0; }
     __syncthreads();
+    if (stop) break;
     const uint64_t r0 = tile * v.rt;
     const uint32_t nr = (uint32_t)min((uint64_t)v.rt, v.n_reads - r0);
     const uint32_t nid = nr * v.wmax;
@@ -467,6 +470,16 @@ int ShnWs::get(size_t bytes, void** out) {
   return SHN_OK;
 }
 ShnWs g_shn_ws[32];   // per-process (one process per GPU)
+// The slots are grow-only so that a steady-state step allocates nothing -- fine while they hold a few GB.  At 100M reads the
+// counting pipeline's key buffers alone are 2 x 60 GB; a stage that ends holding more than a quarter of the device in
+// workspace slots gives the large ones back (called at the end of shn_count_k1mers / shn_extend, never inside a stage).
+void shn_ws_trim_if_large(hipStream_t stream) {
+  size_t held = 0, free_b = 0, total_b = 0;
+  for (auto& w : g_shn_ws) held += w.cap;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || held * 4 < total_b) return;
+  hipStreamSynchronize(stream);                   // (kernels of the ending stage may still read the slots)
+  for (auto& w : g_shn_ws) if (w.cap >= ((size_t)1 << 30)) { hipFree(w.p); w.p = nullptr; w.cap = 0; }
+}
 #define g_ws g_shn_ws
 
 int shn_device_scan_u32(shn_ctx* ctx, const uint32_t* d_in, uint64_t n, uint64_t* d_out /* n+1 */, uint64_t* total_host) {
@@ -519,10 +532,11 @@ extern "C" int shn_count_k1mers(shn_ctx* ctx, shn_reads* const* sets, int n_sets
   // One-pass path first (see count_direct_kernel): worth it when the table is small next to the windows; the size is a
   // guess (windows / 32, at most 2^24 slots to begin with) corrected by what earlier calls of this process needed.
   {
-    static std::atomic<int> learned_log2{0};               // slots that sufficed last time (0: none yet)
+    int& learned_log2 = ctx->count_direct_log2;            // slots that sufficed last time on this context (0: none yet; -1: the
+                                                           // one-pass path gave up on this context's input -- do not try again)
     const int mode = getenv("SHN_COUNT_DIRECT") ? atoi(getenv("SHN_COUNT_DIRECT")) : 1;      // 0 off, 1 large inputs, 2 always (tests)
-    const bool want = mode != 0 && (upper >= (1ULL << 22) || mode == 2) && k1 < 32 && upper > 0;
-    int lg = learned_log2.load();
+    const bool want = mode != 0 && (upper >= (1ULL << 22) || mode == 2) && k1 < 32 && upper > 0 && (learned_log2 >= 0 || mode == 2);
+    int lg = learned_log2 > 0 ? learned_log2 : 0;
     if (!lg) { lg = 20; while (lg < 24 && (1ULL << lg) < upper / 32) lg++; }
     if (getenv("SHN_COUNT_DIRECT_LOG2")) lg = atoi(getenv("SHN_COUNT_DIRECT_LOG2"));          // (tests: start too small, grow)
     for (int attempt = 0; want && attempt < 8 && lg <= 27; attempt++) {
@@ -551,7 +565,8 @@ extern "C" int shn_count_k1mers(shn_ctx* ctx, shn_reads* const* sets, int n_sets
       TRYD(hipMemcpy(&ov, d_ov, 4, hipMemcpyDeviceToHost));
       if (ov || nd * 10 > slots * 6) {                      // too full (long probe chains) or lost windows: a bigger table, or give up
         freeall();
-        if (mode != 2 && nd * 10 > slots * 6 && !ov && (nd << 5) > upper) break;      // many distinct keys for the windows: the partition pipeline is the better tool
+        if (mode != 2 && nd * 10 > slots * 6 && !ov && (nd << 5) > upper) { learned_log2 = -1; break; }      // many distinct keys for the windows: the partition pipeline is the better tool
+        if (mode != 2 && lg + (ov ? 3 : 2) > 27) learned_log2 = -1;
         lg += ov ? 3 : 2;
         continue;
       }
@@ -563,7 +578,7 @@ extern "C" int shn_count_k1mers(shn_ctx* ctx, shn_reads* const* sets, int n_sets
       freeall();
 #undef TRYD
       if (rcp) return rcp;
-      if (!getenv("SHN_COUNT_DIRECT_LOG2")) learned_log2.store(lg);
+      if (!getenv("SHN_COUNT_DIRECT_LOG2")) learned_log2 = lg;
       *out = tb;
       return SHN_OK;
     }
@@ -648,7 +663,7 @@ extern "C" int shn_count_k1mers(shn_ctx* ctx, shn_reads* const* sets, int n_sets
     bool ov = false;
     rc = build_from_keys(ctx, keysA, keysB, (uint32_t*)pc, nullptr, nullptr, off1, bits, b2, k1, both_strands ? 1 : 0, N, N, out, &ov);
     if (rc) return rc;
-    if (!ov) return SHN_OK;
+    if (!ov) { shn_ws_trim_if_large(s); return SHN_OK; }
     shn_table_destroy(*out);
     *out = nullptr;
     bits = std::min(24, bits + 2);
@@ -867,7 +882,7 @@ extern "C" int shn_table_from_pairs(shn_ctx* ctx, const void* dev_keys, const vo
     rc = build_from_keys(ctx, (uint64_t*)pa, (uint64_t*)pb, (uint32_t*)pc, (uint32_t*)pca, (uint32_t*)pcb, off1, bits, b2, k1,
                          canonical, n, total, out, &ov);
     if (rc) return rc;
-    if (!ov) return SHN_OK;
+    if (!ov) { shn_ws_trim_if_large(s); return SHN_OK; }
     shn_table_destroy(*out);
     *out = nullptr;
     bits = std::min(24, bits + 2);

@@ -1253,6 +1253,13 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   }
   e->iterations = it;
   if (!converged) { shn_ext_destroy(e); return shn_fail(SHN_ERR_INTERNAL, "shn_extend: walk fixpoint did not converge"); }
+  // what is left to do with the result (stats, emit, seed info, weights) reads the claims, the walk records and the table: the
+  // adjacency rows and the snapshot (2/3 of the state) go back to the allocator now
+  TRYE(hipStreamSynchronize(s));
+  shn_dev_free(e->d_adjR); e->d_adjR = nullptr;
+  shn_dev_free(e->d_adjL); e->d_adjL = nullptr;
+  shn_dev_free(e->d_claim2); e->d_claim2 = nullptr;
+  shn_ws_trim_if_large(s);
   unsigned long long steps = 0, wsteps = 0, wslots[64];
   TRYE(hipMemcpyAsync(&steps, d_cnt + 1, 8, hipMemcpyDeviceToHost, s));          // thread-kernel steps
   TRYE(hipMemcpyAsync(wslots, d_cnt + 64, 64 * 8, hipMemcpyDeviceToHost, s));    // wavefront-kernel steps

@@ -797,7 +797,10 @@ extern "C" int shn_mbgraph_run(shn_ctx* ctx, int K, const uint8_t* rows, uint64_
       }
       if (bad) non_acgt.store(1);
     };
-    unsigned nt = std::min<unsigned>(32, std::max<unsigned>(1, std::thread::hardware_concurrency() / 8));   // (8 ranks share a node's cores)
+    // (8 ranks share a node's cores; partitions running at the same time in this process share this rank's part)
+    static std::atomic<int> active_calls{0};
+    struct Active { std::atomic<int>& a; int n; Active(std::atomic<int>& x) : a(x), n(++x) {} ~Active() { --a; } } active(active_calls);
+    unsigned nt = std::min<unsigned>(32, std::max<unsigned>(1, std::thread::hardware_concurrency() / 8 / (unsigned)std::max(1, active.n / 2)));
     uint64_t bulk_min = 1u << 17;                       // reads from which the duplicates are found in parallel (tests lower it)
     if (getenv("SHN_GRAPH_BULK_MIN")) { bulk_min = strtoull(getenv("SHN_GRAPH_BULK_MIN"), nullptr, 10); nt = std::max(nt, 4u); }
     if (used * nm < bulk_min) nt = used < 4096 ? 1 : std::min<unsigned>(nt, (unsigned)(used / 2048));   // small sets: a few threads for the decode only

@@ -44,7 +44,7 @@ def assemble(ctx, reads1, reads2=None, K=25, partition_size=500, min_weight=3, m
 
 def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3, min_length=75, overload=2, penalty=5,
                       sample="shannon", seed=0, double_stranded=True, part_vectors=None, timings=None, hits_factory=None,
-                      native_graph=True, graph_threads=8):
+                      native_graph=True, graph_threads=None):
     """Same as assemble() with the reads already packed in HBM (d1/d2: device.Reads).  graph_threads: partitions whose
     graph stage may run concurrently on host threads."""
     if not double_stranded:
@@ -53,6 +53,9 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
         raise NotImplementedError("strand-specific input (-s / --ss) is not built: only the default double-stranded path is")
     T = timings if timings is not None else {}
     paired = d2 is not None
+    if graph_threads is None:                   # a rank's share of the host cores (8 ranks per node), at least 8
+        import os
+        graph_threads = int(os.environ.get("SHN_GRAPH_THREADS", 0)) or max(8, min(64, (os.cpu_count() or 8) // 4))
     if hits_factory is None:
         from . import graph_seeds
         hits_factory = graph_seeds.hits_factory(ctx)

@@ -322,10 +322,16 @@ def _variants(contigs, seed=5):
 
 
 @pytest.mark.parametrize("name", sorted(MANIFEST))
-def test_gpu_contig_stage_equals_the_sequential_stage(ctx, name):
-    """shn_contig_stage (r-mer clusters and K-mer joins on the GPU) == shn_cgraph (the reference's sequential loop, checked
-    against the oracle on the CPU): accepted flags, best-hit counts, connections with weights and insertion order."""
+@pytest.mark.parametrize("block0,pair_log2", [(None, None), (7, None), (1, 4)])
+def test_gpu_contig_stage_equals_the_sequential_stage(ctx, name, block0, pair_log2, monkeypatch):
+    """shn_contig_stage (duplicate_check as block-wise rounds over one device sort of the r-mers, K-mer join on the GPU) ==
+    shn_cgraph (the reference's sequential loop, checked against the oracle on the CPU): accepted flags, best-hit counts,
+    connections with weights and insertion order.  Also with tiny blocks and a pair table that has to grow."""
     from shannon_amd import extension_correction as ec
+    if block0 is not None:
+        monkeypatch.setenv("SHN_CONTIG_BLOCK0", str(block0))
+    if pair_log2 is not None:
+        monkeypatch.setenv("SHN_CONTIG_PAIR_LOG2", str(pair_log2))
     g = load_case(name)
     for cands in (g["contigs"], _variants(g["contigs"]), _variants(g["contigs"], 9)[::-1]):
         if not cands:
