@@ -58,9 +58,12 @@ def gen_reads(n_pairs, seed, n_genes, device, read_seed=None, families=0):
     tl = torch.as_tensor(lens, device=device)
     out1, out2 = [], []
     ar = torch.arange(100, device=device)
+    # isoform of every fragment by inverse CDF (float64): reproducible run to run (torch.multinomial on the device was not --
+    # the same seed gave tables of 724,313,063 or 724,313,437 distinct k1-mers on different boxes)
+    cdf = torch.as_tensor(np.cumsum(wts / wts.sum()), device=device, dtype=torch.float64)
     for s in range(0, n_pairs, 1 << 20):
         n = min(1 << 20, n_pairs - s)
-        iso_i = torch.multinomial(torch.as_tensor(wts, device=device, dtype=torch.float32), n, replacement=True, generator=g)
+        iso_i = torch.searchsorted(cdf, torch.rand(n, device=device, generator=g, dtype=torch.float64)).clamp_(max=len(lens) - 1)
         start = (torch.rand(n, device=device, generator=g, dtype=torch.float64) * (tl[iso_i] - 299)).long() + offs[iso_i]
         a = cat[start[:, None] + ar]
         b = 3 - cat[(start + 299)[:, None] - ar]

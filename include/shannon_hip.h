@@ -251,6 +251,22 @@ int shn_mbgraph_run(shn_ctx* ctx /* NULL: K-mer seed scans on the host instead o
                     uint64_t n_reads, int paired, int enc /* SHN_ENC_* */, const uint8_t* rc1, const uint8_t* rc2 /* optional:
                     1 = use the reverse complement of read i (strand-doubled view of the input) */, shn_graph** out);
 void shn_graph_destroy(shn_graph* g);
+/* Unitig contraction of the raw K-mer graphs of ALL partitions in one batch on the GPU (csrc/graph_gpu.hip): load_single_jellyfish
+ * (multibridging.py:145-172) + the first Node.condense_all (mbgraph.py:479-498, Edge.condense :184-257).  bases / off: the contigs of
+ * all partitions one after the other (ASCII; a partition's contigs in the order of its k1-mer file), part_of[c] = partition of contig c
+ * (ascending).  The nodes come out in the creation order of the sequential code and every node's edge lists in the order its merges
+ * leave them, so the graph stage continues bit-identically (shn_mbgraph_run_unitigs; SHN_GRAPH_CHECK=1 builds both and compares).    */
+typedef struct shn_unitigs shn_unitigs;
+int shn_unitigs_build(shn_ctx* ctx, const uint8_t* bases, const uint64_t* off, uint64_t n_contigs, const uint32_t* part_of, uint32_t n_parts,
+                      int K, shn_unitigs** out);
+void shn_unitigs_destroy(shn_unitigs* u);
+/* distinct K-mers of partition `part` (the node count after loading: the read cap is 10 x this, multibridging.py:26-30, 385-391) */
+uint64_t shn_unitigs_n_kmers(const shn_unitigs* u, uint32_t part);
+/* shn_mbgraph_run on partition `part` of `ug`.  rows / n_rows (may be NULL / 0): the partition's k1-mers, needed only for a partition
+ * that holds a cycle of condensable edges (built by the sequential code) and for SHN_GRAPH_CHECK=1.                               */
+int shn_mbgraph_run_unitigs(shn_ctx* ctx, const shn_unitigs* ug, uint32_t part, const uint8_t* rows, uint64_t n_rows, const uint8_t* r1,
+                            const uint64_t* r1_off, const uint8_t* r2, const uint64_t* r2_off, uint64_t n_reads, int paired, int enc,
+                            const uint8_t* rc1, const uint8_t* rc2, shn_graph** out);
 /* sizes[9] = n_singles, single bases, n_components, n_nodes, node bases, n_edges, n_paths, path ids, info ints */
 int shn_graph_sizes(const shn_graph* g, uint64_t* sizes);
 int shn_graph_export(const shn_graph* g, uint64_t* s_off, uint8_t* s_bases, double* s_cc, double* s_norm,

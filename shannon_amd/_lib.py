@@ -54,6 +54,10 @@ SIGNATURES = {
     "shn_seed_ends": (C.c_int, [vp, vp, C.c_int, vp, vp, vp]),
     "shn_mbgraph_run": (C.c_int, [vp, C.c_int, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, vpp]),
     "shn_graph_destroy": (None, [vp]),
+    "shn_unitigs_build": (C.c_int, [vp, vp, vp, C.c_uint64, vp, C.c_uint32, C.c_int, vpp]),
+    "shn_unitigs_destroy": (None, [vp]),
+    "shn_unitigs_n_kmers": (C.c_uint64, [vp, C.c_uint32]),
+    "shn_mbgraph_run_unitigs": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, vpp]),
     "shn_graph_sizes": (C.c_int, [vp, u64p]),
     "shn_graph_export": (C.c_int, [vp] + [vp] * 20),
     "shn_find_reps": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp]),

@@ -7,6 +7,7 @@
 #include "common.h"
 #include <atomic>
 #include "flatmap.h"
+#include "unitigs.h"
 #include <thread>
 #include <mutex>
 #include <string>
@@ -96,6 +97,7 @@ struct Graph {
   int n_known = 0, n_mate = 0;
   int nodes_after[4] = {0, 0, 0, 0};  // condensing, suspicious, collapse, bridging
   int final_nodes = 0;
+  bool precondensed = false;          // loaded from GPU unitigs: the first condense_all is already done
 
   int new_node(const std::string& b) {
     int n = (int)bases.size();
@@ -162,6 +164,49 @@ struct Graph {
       link(na, nb, K - 1);
     }
     for (int n : order) { double s = 0; for (int e : oute[n]) s += ew[e]; prev[n] = s; }
+  }
+  // The same state as load_k1mers + the first condense_all, from the unitigs the GPU contracted (csrc/graph_gpu.hip): final
+  // nodes in creation order, edges in id order, every node's out-/in-list in the order the sequential merges leave it.
+  // bases / base_off: the partition's nodes; n_len = K-mers per node; tail_out = out-degree of the node's last K-mer.
+  void load_unitigs(const char* ub, const uint64_t* base_off, const uint32_t* n_len, const uint32_t* tail_out, uint64_t n_nodes,
+                    const uint32_t* e_src, const uint32_t* e_dst, const uint32_t* e_out_rank, const uint32_t* e_in_rank, uint64_t n_edges) {
+    reserve_nodes(n_nodes * 2 + 16);
+    es.reserve(n_edges * 3); ed.reserve(n_edges * 3); ew.reserve(n_edges * 3); ecc.reserve(n_edges * 3);
+    for (uint64_t i = 0; i < n_nodes; i++) {
+      const int n = new_node(std::string(ub + base_off[i], base_off[i + 1] - base_off[i]));
+      const double m = (double)n_len[i];
+      cnt[n] = m; norm[n] = m;                                       // sums of the K-mers' 1.0s
+      prev[n] = (double)(K - 1) * ((m - 1.0) + (double)tail_out[i]);  // sum of (K-1) * out-degree over the K-mers (multibridging.py:169 quirk)
+    }
+    std::vector<uint32_t> odeg(n_nodes, 0), ideg(n_nodes, 0);
+    for (uint64_t x = 0; x < n_edges; x++) { odeg[e_src[x]]++; ideg[e_dst[x]]++; }
+    for (uint64_t i = 0; i < n_nodes; i++) { oute[i].assign(odeg[i], -1); ine[i].assign(ideg[i], -1); }
+    for (uint64_t x = 0; x < n_edges; x++) {
+      const int e = (int)es.size();
+      es.push_back((int)e_src[x]); ed.push_back((int)e_dst[x]); ew.push_back(K - 1); ecc.push_back(0.0);
+      oute[e_src[x]][e_out_rank[x]] = e;
+      ine[e_dst[x]][e_in_rank[x]] = e;
+    }
+  }
+  // order-sensitive signature of the graph (development check of load_unitigs against load_k1mers + condense_all)
+  std::string signature() const {
+    std::vector<int> idx(bases.size(), -1);
+    for (size_t i = 0; i < order.size(); i++) idx[order[i]] = (int)i;
+    std::string sg;
+    char buf[96];
+    for (int n : order) {
+      sg += bases[n];
+      snprintf(buf, sizeof buf, "|%.17g|%.17g|%.17g|%.17g|o", cnt[n], prev[n], norm[n], cc[n]);
+      sg += buf;
+      for (int e : oute[n]) { snprintf(buf, sizeof buf, " %d:%d", idx[ed[e]], ew[e]); sg += buf; }
+      sg += "|i";
+      for (int e : ine[n]) { snprintf(buf, sizeof buf, " %d:%d", idx[es[e]], ew[e]); sg += buf; }
+      sg += "\n";
+    }
+    // edge ids in creation order (relative): the pairs (source, destination) of the live edges by id
+    sg += "E";
+    for (size_t e = 0; e < es.size(); e++) if (es[e] >= 0) { snprintf(buf, sizeof buf, " %d>%d", idx[es[e]], idx[ed[e]]); sg += buf; }
+    return sg;
   }
   int add_read(const char* b, size_t n, uint64_t h) {
     bool is_new = false;
@@ -657,7 +702,7 @@ struct Graph {
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
     auto lap = [&](const char* what) { if (dbg) { double t = now(); fprintf(stderr, "[mbgraph] %-22s %8.3f s  nodes=%zu\n", what, t - t0, order.size()); t0 = t; } };
-    condense_all();
+    if (!precondensed) condense_all();
     nodes_after[0] = (int)order.size();
     lap("condense_all");
     destroy_suspicious();
@@ -723,9 +768,28 @@ static void decode_read(char* s, const uint8_t* p, uint64_t n, int enc, bool rc)
   }
 }
 
+static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n_rows, const shn_unitigs* ug, uint32_t part, const uint8_t* r1,
+                           const uint64_t* r1_off, const uint8_t* r2, const uint64_t* r2_off, uint64_t n_reads, int paired, int enc,
+                           const uint8_t* rc1, const uint8_t* rc2, shn_graph** out);
+
 extern "C" int shn_mbgraph_run(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n_rows, const uint8_t* r1, const uint64_t* r1_off,
                                const uint8_t* r2, const uint64_t* r2_off, uint64_t n_reads, int paired, int enc, const uint8_t* rc1,
                                const uint8_t* rc2, shn_graph** out) {
+  return mbgraph_run_impl(ctx, K, rows, n_rows, nullptr, 0, r1, r1_off, r2, r2_off, n_reads, paired, enc, rc1, rc2, out);
+}
+// The same with the partition's K-mer graph already contracted on the GPU (shn_unitigs_build, partition `part` of `ug`).
+// rows / n_rows (optional): the partition's k1-mers as for shn_mbgraph_run -- needed when the partition holds a cycle of
+// condensable edges (left to the sequential code) and for the development check SHN_GRAPH_CHECK=1 (both ways, compared).
+extern "C" int shn_mbgraph_run_unitigs(shn_ctx* ctx, const shn_unitigs* ug, uint32_t part, const uint8_t* rows, uint64_t n_rows, const uint8_t* r1,
+                                       const uint64_t* r1_off, const uint8_t* r2, const uint64_t* r2_off, uint64_t n_reads, int paired, int enc,
+                                       const uint8_t* rc1, const uint8_t* rc2, shn_graph** out) {
+  if (!ug || part >= ug->n_parts) return shn_fail(SHN_ERR_ARG, "shn_mbgraph_run_unitigs: bad unitigs / partition");
+  return mbgraph_run_impl(ctx, ug->K, rows, n_rows, ug, part, r1, r1_off, r2, r2_off, n_reads, paired, enc, rc1, rc2, out);
+}
+
+static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n_rows, const shn_unitigs* ug, uint32_t part, const uint8_t* r1,
+                           const uint64_t* r1_off, const uint8_t* r2, const uint64_t* r2_off, uint64_t n_reads, int paired, int enc,
+                           const uint8_t* rc1, const uint8_t* rc2, shn_graph** out) {
   if (!out || (n_rows && !rows) || (n_reads && (!r1 || !r1_off)) || (paired && n_reads && (!r2 || !r2_off)))
     return shn_fail(SHN_ERR_ARG, "shn_mbgraph_run: NULL argument");
   Graph g;
@@ -736,9 +800,37 @@ extern "C" int shn_mbgraph_run(shn_ctx* ctx, int K, const uint8_t* rows, uint64_
   const bool dbg = getenv("SHN_DEBUG") != nullptr;
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double tt = now();
-  g.load_k1mers(rows, n_rows);
+  uint64_t n_kmer_nodes = 0;
+  if (ug && !ug->cyclic[part]) {
+    const uint64_t n0 = ug->node_off[part], n1 = ug->node_off[part + 1], e0 = ug->edge_off[part], e1 = ug->edge_off[part + 1];
+    g.load_unitigs(ug->bases.data(), ug->base_off.data() + n0, ug->n_len.data() + n0, ug->n_tail_out.data() + n0, n1 - n0,
+                   ug->e_src.data() + e0, ug->e_dst.data() + e0, ug->e_out_rank.data() + e0, ug->e_in_rank.data() + e0, e1 - e0);
+    g.precondensed = true;
+    n_kmer_nodes = ug->n_kmers[part];
+    if (getenv("SHN_GRAPH_CHECK")) {
+      if (!rows && n_rows == 0 && n1 != n0) return shn_fail(SHN_ERR_ARG, "SHN_GRAPH_CHECK needs the k1-mer rows");
+      Graph h;
+      h.K = K;
+      h.load_k1mers(rows, n_rows);
+      const uint64_t hk = h.order.size();
+      h.condense_all();
+      if (hk != n_kmer_nodes || h.signature() != g.signature()) {
+        if (getenv("SHN_GRAPH_CHECK_DUMP")) {
+          FILE* fa = fopen((std::string(getenv("SHN_GRAPH_CHECK_DUMP")) + ".host").c_str(), "w"); if (fa) { fputs(h.signature().c_str(), fa); fclose(fa); }
+          FILE* fb = fopen((std::string(getenv("SHN_GRAPH_CHECK_DUMP")) + ".gpu").c_str(), "w"); if (fb) { fputs(g.signature().c_str(), fb); fclose(fb); }
+        }
+        return shn_fail(SHN_ERR_INTERNAL, "SHN_GRAPH_CHECK: GPU unitigs differ from load_k1mers + condense_all (partition " + std::to_string(part) + ": " +
+                        std::to_string(n_kmer_nodes) + " / " + std::to_string(hk) + " K-mers, " + std::to_string(g.order.size()) + " / " +
+                        std::to_string(h.order.size()) + " nodes)");
+      }
+    }
+  } else {
+    if (ug && !rows && ug->node_off[part + 1] != ug->node_off[part]) return shn_fail(SHN_ERR_ARG, "shn_mbgraph_run_unitigs: cyclic partition needs the k1-mer rows");
+    g.load_k1mers(rows, n_rows);
+    n_kmer_nodes = g.order.size();
+  }
   if (dbg) { fprintf(stderr, "[mbgraph] load_k1mers            %8.3f s  rows=%llu\n", now() - tt, (unsigned long long)n_rows); tt = now(); }
-  uint64_t cutoff = (uint64_t)g.order.size() * 10;
+  uint64_t cutoff = n_kmer_nodes * 10;
   // Scratch kept between calls (at the read cap these buffers are 100s of MB, and fresh pages cost more than the work done
   // in them): decode buffers and the read arena.  A free list, not thread_local: Python's partition workers are short-lived.
   struct Scratch { std::vector<uint64_t> doff, hashes; std::vector<char> text; std::string arena; std::vector<uint32_t> first, cnt, last; std::vector<int32_t> idmap; };

@@ -14,17 +14,55 @@ def _pack_reads(reads):
     return (np.frombuffer(joined, dtype=np.uint8) if joined else np.zeros(1, np.uint8)), off
 
 
-def run_partition_arrays(rows_bytes, n_rows, K, r1_buf, r1_off, r2_buf=None, r2_off=None, ctx=None, enc=0, rc1=None, rc2=None):
-    """rows_bytes: uint8 array of n_rows*(K+1) bases; reads as (byte buffer, offsets).  Returns
+class Unitigs(object):
+    """The K-mer graphs of all partitions contracted to unitigs in one batch on the GPU (shn_unitigs_build): replaces
+    load_single_jellyfish + the first condense_all of every partition (multibridging.py:145-172, mbgraph.py:479-498)."""
+
+    def __init__(self, ctx, partition_contigs, K):
+        """partition_contigs: [[contig, ...] per partition] (the order of the partition's k1-mer file)"""
+        flat = [c for cl in partition_contigs for c in cl]
+        text = np.frombuffer("".join(flat).encode(), dtype=np.uint8) if flat else np.zeros(1, np.uint8)
+        off = np.zeros(len(flat) + 1, dtype=np.uint64)
+        if flat:
+            off[1:] = np.cumsum([len(c) for c in flat], dtype=np.uint64)
+        part_of = np.repeat(np.arange(len(partition_contigs), dtype=np.uint32), [len(cl) for cl in partition_contigs]) if flat else np.zeros(1, np.uint32)
+        part_of = np.ascontiguousarray(part_of, dtype=np.uint32)
+        self.h = C.c_void_p()
+        self.n_parts = len(partition_contigs)
+        _lib.check(_lib.lib().shn_unitigs_build(ctx.h, text.ctypes.data, off.ctypes.data, len(flat), part_of.ctypes.data, self.n_parts, int(K),
+                                                C.byref(self.h)))
+
+    def n_kmers(self, part):
+        return int(_lib.lib().shn_unitigs_n_kmers(self.h, int(part)))
+
+    def close(self):
+        if self.h:
+            _lib.lib().shn_unitigs_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def run_partition_arrays(rows_bytes, n_rows, K, r1_buf, r1_off, r2_buf=None, r2_off=None, ctx=None, enc=0, rc1=None, rc2=None, unitigs=None,
+                         part=0):
+    """rows_bytes: uint8 array of n_rows*(K+1) bases; reads as (byte buffer, offsets).  unitigs / part: the partition's
+    K-mer graph already contracted on the GPU (rows_bytes may then be None).  Returns
     (singles, comps, info) in the format of mbgraph.output_components."""
     L = _lib.lib()
     h = C.c_void_p()
     n_reads = len(r1_off) - 1
     paired = r2_buf is not None
-    _lib.check(L.shn_mbgraph_run(ctx.h if ctx is not None else None, K, rows_bytes.ctypes.data, n_rows, r1_buf.ctypes.data, r1_off.ctypes.data,
-                                 r2_buf.ctypes.data if paired else None, r2_off.ctypes.data if paired else None, n_reads,
-                                 1 if paired else 0, enc, rc1.ctypes.data if rc1 is not None else None,
-                                 rc2.ctypes.data if rc2 is not None else None, C.byref(h)))
+    rows_ptr = rows_bytes.ctypes.data if rows_bytes is not None else None
+    tail = (r1_buf.ctypes.data, r1_off.ctypes.data, r2_buf.ctypes.data if paired else None, r2_off.ctypes.data if paired else None, n_reads,
+            1 if paired else 0, enc, rc1.ctypes.data if rc1 is not None else None, rc2.ctypes.data if rc2 is not None else None, C.byref(h))
+    if unitigs is not None:
+        _lib.check(L.shn_mbgraph_run_unitigs(ctx.h if ctx is not None else None, unitigs.h, int(part), rows_ptr, n_rows if rows_bytes is not None else 0, *tail))
+    else:
+        _lib.check(L.shn_mbgraph_run(ctx.h if ctx is not None else None, K, rows_ptr, n_rows, *tail))
     sz = np.zeros(9, dtype=np.uint64)
     _lib.check(L.shn_graph_sizes(h, sz.ctypes.data_as(_lib.u64p)))
     ns, sb, nc, nn, nb, ne, npth, npid, ninfo = [int(x) for x in sz]

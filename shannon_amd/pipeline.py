@@ -3,6 +3,7 @@ multibridged graph -> sparse-flow transcripts -> merged FASTA.  Mirrors the orde
 (394-647) and run_MB_SF_fn.py (210-254) without the file round trips between stages (the
 reference's --inMem hand-off); `shannon.py` at the repo root adds the CLI and the OUT/ file tree.
 """
+import os
 import time
 import numpy as np
 from . import device, extension_correction as ec, kmers_for_component as kfc, mbgraph, mbgraph_native, sparse_flow, post
@@ -83,11 +84,22 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
         lines += [">Single_%d\n" % i, c + "\n"]
     sf_jobs = []
 
+    names = list(part["new_components"])
+    unitigs = None
+    if native_graph and names and K <= 31 and os.environ.get("SHN_GRAPH_GPU", "1") != "0":
+        # the raw K-mer graphs of all partitions, contracted to unitigs in one batch on the GPU
+        t0 = time.time()
+        unitigs = mbgraph_native.Unitigs(ctx, [part["new_components"][nm] for nm in names], K)
+        tick("graph unitigs (GPU)", t0)
+    part_index = {nm: i for i, nm in enumerate(names)}
+    check_rows = os.environ.get("SHN_GRAPH_CHECK")
+
     def one_partition(name):
         """multibridged graph of one partition (multibridging.main for `name`); returns its record + timings"""
         tt = {}
         t0 = time.time()
-        cutoff = 10 * part["n_kmer_nodes"][name] + 1                 # multibridging.py:26-30, 385-391
+        n_kmers = unitigs.n_kmers(part_index[name]) if unitigs is not None else part["n_kmer_nodes"][name]
+        cutoff = 10 * n_kmers + 1                                    # multibridging.py:26-30, 385-391
         idx = part["routes"][name][:cutoff]
         if native_graph:
             b1, o1, rc1, enc = store.gather_codes(idx, 1)
@@ -98,10 +110,11 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
                 b2, o2, rc2, _e = store.gather_codes(idx, 2) if paired else (None, None, None, enc)
             tt["materialize reads"] = time.time() - t0
             t0 = time.time()
-            rb = part["k1mer_bytes"][name]
-            singles, comps, glog = mbgraph_native.run_partition_arrays(rb if len(rb) else np.zeros(1, np.uint8), len(rb) // (K + 1), K,
-                                                                       b1, o1, b2, o2, ctx=ctx, enc=enc, rc1=rc1, rc2=rc2)
+            rb = part["k1mer_bytes"][name]() if callable(part["k1mer_bytes"][name]) else part["k1mer_bytes"][name]
             n_rows = len(rb) // (K + 1)
+            singles, comps, glog = mbgraph_native.run_partition_arrays(rb if len(rb) else np.zeros(1, np.uint8), n_rows, K,
+                                                                       b1, o1, b2, o2, ctx=ctx, enc=enc, rc1=rc1, rc2=rc2,
+                                                                       unitigs=unitigs, part=part_index[name])
         else:
             rows = part["k1mers"][name]
             r1 = [store.mate1(int(d)) for d in idx]
@@ -114,7 +127,6 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
         return {"n_reads_routed": len(part["routes"][name]), "n_k1mers": n_rows, "singles": singles, "components": comps,
                 "log": glog}, tt
 
-    names = list(part["new_components"])
     t_graph = time.time()
     if native_graph and len(names) > 1:
         # partitions are independent (one multibridging process each in the reference, run_MB_SF_fn.py:219-253): the
@@ -124,6 +136,8 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
             results = list(pool.map(one_partition, names))
     else:
         results = [one_partition(nm) for nm in names]
+    if unitigs is not None:
+        unitigs.close()
     wall = time.time() - t_graph
     busy = sum(sum(tt.values()) for _, tt in results) or 1.0
     for name, (rec, tt) in zip(names, results):
