@@ -145,11 +145,12 @@ void shn_dev_trim();                         // give the cached blocks back to t
 template <class T> static inline hipError_t shn_dev_malloc(T** p, size_t bytes) { return shn_dev_malloc_raw((void**)p, bytes); }
 
 struct ShnWs {
-  void* p = nullptr; size_t cap = 0;
+  void* p = nullptr; size_t cap = 0; uint64_t stage = 0;
   int get(size_t bytes, void** out);
 };
+void shn_stage_begin();                      // a top-level GPU stage starts (workspace slots used before it become reclaimable)
+size_t shn_ws_release_idle();                // frees the slots not used by the current stage; returns the bytes given back
 extern ShnWs g_shn_ws[32];
-void shn_ws_trim_if_large(hipStream_t stream);       // end of a stage: give workspace slots back when they hold > 1/4 of the device
 int shn_device_scan_u32(shn_ctx* ctx, const uint32_t* d_in, uint64_t n, uint64_t* d_out /* n+1 */, uint64_t* total_host);
 // stable LSD radix sort of (u64 key, u32 value) pairs on bits [bit_lo, bit_hi); result lands in keys/vals
 int shn_sort_pairs(shn_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t* keys_tmp, uint32_t* vals_tmp, uint64_t n,

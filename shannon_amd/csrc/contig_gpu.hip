@@ -232,6 +232,7 @@ extern "C" int shn_contig_stage(shn_ctx* ctx, const uint8_t* bases, const uint64
   if (total >= 0xFFFFFFF0ULL || n_cand >= 0x7FFFFFF0ULL) return shn_fail(SHN_ERR_OVERFLOW, "shn_contig_stage: more than 2^32 contig bases");
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
+  shn_stage_begin();
   TimerRegion treg(ctx, T_CONTIG);
   DevBufs bufs;
   uint8_t* d_bases; uint64_t* d_off; uint32_t* d_cid;

@@ -51,9 +51,15 @@ hipError_t shn_dev_malloc_raw(void** p, size_t bytes) {
     if (best >= 0) { g_blocks[best].used = true; *p = g_blocks[best].p; return hipSuccess; }
   }
   hipError_t e = hipMalloc(p, bytes);
-  if (e != hipSuccess) {                       // make room: drop what the cache holds and try once more
+  if (e != hipSuccess) {                       // make room: drop what the cache holds, then the workspaces of earlier stages
+    (void)hipGetLastError();
     shn_dev_trim();
     e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      shn_ws_release_idle();
+      e = hipMalloc(p, bytes);
+    }
     if (e != hipSuccess) return e;
   }
   std::lock_guard<std::mutex> lk(g_blocks_mu);

@@ -458,28 +458,37 @@ __global__ void gtable_compact_kernel(const unsigned long long* __restrict__ gke
 }
 
 // ================================================================ host side
+// Stages (the top-level entry points: count, extend, route, contig stage, unitigs ...) run one after the other on a GPU; a
+// slot remembers the stage that used it last.  When an allocation fails, what the slots of EARLIER stages hold is given back
+// and the allocation is tried again -- hipMalloc of tens of GB costs seconds here (tools/probes/malloc_probe.hip), so nothing
+// is freed as long as everything fits.
+static std::atomic<uint64_t> g_stage{1};
+void shn_stage_begin() { g_stage.fetch_add(1); }
+size_t shn_ws_release_idle() {
+  size_t freed = 0;
+  const uint64_t now = g_stage.load();
+  for (auto& w : g_shn_ws) if (w.p && w.stage < now) { hipFree(w.p); freed += w.cap; w.p = nullptr; w.cap = 0; }
+  return freed;
+}
 int ShnWs::get(size_t bytes, void** out) {
+  stage = g_stage.load();
   if (bytes > cap) {
     if (p) hipFree(p);
     p = nullptr; cap = 0;
     hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) return shn_fail(SHN_ERR_NOMEM, std::string("hipMalloc workspace: ") + hipGetErrorString(e));
+    if (e != hipSuccess) {                       // make room: cached blocks, then the slots of earlier stages
+      (void)hipGetLastError();
+      shn_dev_trim();
+      shn_ws_release_idle();
+      e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess) { p = nullptr; return shn_fail(SHN_ERR_NOMEM, std::string("hipMalloc workspace: ") + hipGetErrorString(e)); }
     cap = bytes;
   }
   *out = p;
   return SHN_OK;
 }
 ShnWs g_shn_ws[32];   // per-process (one process per GPU)
-// The slots are grow-only so that a steady-state step allocates nothing -- fine while they hold a few GB.  At 100M reads the
-// counting pipeline's key buffers alone are 2 x 60 GB; a stage that ends holding more than a quarter of the device in
-// workspace slots gives the large ones back (called at the end of shn_count_k1mers / shn_extend, never inside a stage).
-void shn_ws_trim_if_large(hipStream_t stream) {
-  size_t held = 0, free_b = 0, total_b = 0;
-  for (auto& w : g_shn_ws) held += w.cap;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || held * 4 < total_b) return;
-  hipStreamSynchronize(stream);                   // (kernels of the ending stage may still read the slots)
-  for (auto& w : g_shn_ws) if (w.cap >= ((size_t)1 << 30)) { hipFree(w.p); w.p = nullptr; w.cap = 0; }
-}
 #define g_ws g_shn_ws
 
 int shn_device_scan_u32(shn_ctx* ctx, const uint32_t* d_in, uint64_t n, uint64_t* d_out /* n+1 */, uint64_t* total_host) {
@@ -519,6 +528,7 @@ extern "C" int shn_count_k1mers(shn_ctx* ctx, shn_reads* const* sets, int n_sets
   if (!ctx || !sets || !out || n_sets <= 0) return shn_fail(SHN_ERR_ARG, "shn_count_k1mers: bad argument");
   if (k1 < 2 || k1 > 32) return shn_fail(SHN_ERR_ARG, "shn_count_k1mers: k1 must be in [2,32]");
   HIP_TRY(hipSetDevice(ctx->device));
+  shn_stage_begin();
   hipStream_t s = ctx->stream;
   TimerRegion ttot(ctx, T_COUNT_TOTAL);
   uint64_t upper = 0;
@@ -663,7 +673,7 @@ extern "C" int shn_count_k1mers(shn_ctx* ctx, shn_reads* const* sets, int n_sets
     bool ov = false;
     rc = build_from_keys(ctx, keysA, keysB, (uint32_t*)pc, nullptr, nullptr, off1, bits, b2, k1, both_strands ? 1 : 0, N, N, out, &ov);
     if (rc) return rc;
-    if (!ov) { shn_ws_trim_if_large(s); return SHN_OK; }
+    if (!ov) return SHN_OK;
     shn_table_destroy(*out);
     *out = nullptr;
     bits = std::min(24, bits + 2);
@@ -882,7 +892,7 @@ extern "C" int shn_table_from_pairs(shn_ctx* ctx, const void* dev_keys, const vo
     rc = build_from_keys(ctx, (uint64_t*)pa, (uint64_t*)pb, (uint32_t*)pc, (uint32_t*)pca, (uint32_t*)pcb, off1, bits, b2, k1,
                          canonical, n, total, out, &ov);
     if (rc) return rc;
-    if (!ov) { shn_ws_trim_if_large(s); return SHN_OK; }
+    if (!ov) return SHN_OK;
     shn_table_destroy(*out);
     *out = nullptr;
     bits = std::min(24, bits + 2);

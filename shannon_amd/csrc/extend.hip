@@ -208,7 +208,7 @@ __global__ void ext_seed_kernel(const uint64_t* __restrict__ tkeys, const uint32
     bbase = tot ? atomicAdd(counter, (unsigned long long)tot) : 0ULL;
   }
   __syncthreads();
-  if (!is_seed) return;
+  if (!is_seed || !skeys) return;                  // skeys == NULL: count only
   unsigned long long p = bbase + wcnt[wid] + __popcll(m & ((1ULL << lane) - 1ULL));
   skeys[p] = (o & 1) ? shn_revcomp(tkeys[i], k) : tkeys[i];
   svals[p] = (uint32_t)o;
@@ -995,6 +995,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   if (world < 1 || world > 255 || rank < 0 || rank >= world) return shn_fail(SHN_ERR_ARG, "shn_extend_sharded: bad world/rank");
   if (2 * t->n >= 0x7FFFFFFFULL) return shn_fail(SHN_ERR_ARG, "shn_extend: table too large for 31-bit oriented ids");
   HIP_TRY(hipSetDevice(ctx->device));
+  shn_stage_begin();
   hipStream_t s = ctx->stream;
   if (world > 1 && t->n) {
     shn_table* sub = nullptr;
@@ -1031,17 +1032,22 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   // seeds: compact, sort by string then (stable) by weight descending
   void *pk, *pv, *pk2, *pv2, *pc;
   int rc;
-  if ((rc = g_shn_ws[9].get((2 * n + 2) * 8, &pk)) || (rc = g_shn_ws[10].get((2 * n + 2) * 4, &pv)) ||
-      (rc = g_shn_ws[11].get((2 * n + 2) * 8, &pk2)) || (rc = g_shn_ws[12].get((2 * n + 2) * 4, &pv2)) ||
-      (rc = g_shn_ws[13].get(2048, &pc))) { shn_ext_destroy(e); return rc; }
-  uint64_t* skeys = (uint64_t*)pk; uint32_t* svals = (uint32_t*)pv;
+  if ((rc = g_shn_ws[13].get(2048, &pc))) { shn_ext_destroy(e); return rc; }
   unsigned long long* d_cnt = (unsigned long long*)pc;      // [0] seeds [1] steps [2..4] plan (long, pool, short) [5] final pool [6] changed
+  // the seeds are counted first: the sort buffers are sized for them, not for every oriented k1-mer (at 20,000 genes 13 % of
+  // the table are seeds -- 30 GB less)
   TRYE(hipMemsetAsync(d_cnt, 0, 2048, s));
   if (n) hipLaunchKernelGGL(ext_seed_kernel, dim3((uint32_t)cdiv(2 * n, 1024)), dim3(1024), 0, s, t->d_keys, e->d_weight, e->d_flags, n,
-                            t->k, t->canonical, min_weight, skeys, svals, d_cnt);
+                            t->k, t->canonical, min_weight, (uint64_t*)nullptr, (uint32_t*)nullptr, d_cnt);
   unsigned long long ns = 0;
   TRYE(hipMemcpyAsync(&ns, d_cnt, 8, hipMemcpyDeviceToHost, s));
   TRYE(hipStreamSynchronize(s));
+  if ((rc = g_shn_ws[9].get((ns + 2) * 8, &pk)) || (rc = g_shn_ws[10].get((ns + 2) * 4, &pv)) ||
+      (rc = g_shn_ws[11].get((ns + 2) * 8, &pk2)) || (rc = g_shn_ws[12].get((ns + 2) * 4, &pv2))) { shn_ext_destroy(e); return rc; }
+  uint64_t* skeys = (uint64_t*)pk; uint32_t* svals = (uint32_t*)pv;
+  TRYE(hipMemsetAsync(d_cnt, 0, 2048, s));
+  if (n) hipLaunchKernelGGL(ext_seed_kernel, dim3((uint32_t)cdiv(2 * n, 1024)), dim3(1024), 0, s, t->d_keys, e->d_weight, e->d_flags, n,
+                            t->k, t->canonical, min_weight, skeys, svals, d_cnt);
   e->n_seeds = ns;
   {
     TimerRegion t2(ctx, T_EXT_SORT);
@@ -1259,7 +1265,6 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   shn_dev_free(e->d_adjR); e->d_adjR = nullptr;
   shn_dev_free(e->d_adjL); e->d_adjL = nullptr;
   shn_dev_free(e->d_claim2); e->d_claim2 = nullptr;
-  shn_ws_trim_if_large(s);
   unsigned long long steps = 0, wsteps = 0, wslots[64];
   TRYE(hipMemcpyAsync(&steps, d_cnt + 1, 8, hipMemcpyDeviceToHost, s));          // thread-kernel steps
   TRYE(hipMemcpyAsync(wslots, d_cnt + 64, 64 * 8, hipMemcpyDeviceToHost, s));    // wavefront-kernel steps

@@ -308,6 +308,7 @@ extern "C" int shn_unitigs_build(shn_ctx* ctx, const uint8_t* bases, const uint6
     if (part_of[c] >= n_parts || (c && part_of[c] < part_of[c - 1])) return shn_fail(SHN_ERR_ARG, "shn_unitigs_build: part_of must be ascending and < n_parts");
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
+  shn_stage_begin();
   TimerRegion treg(ctx, T_GRAPH_GPU);
   // table regions: a power of two >= 2 x the K-windows of the partition
   std::vector<uint64_t> tab_off(n_parts + 1, 0), win(n_parts, 0), first_base(n_parts + 1, total);
@@ -525,15 +526,8 @@ extern "C" int shn_unitigs_build(shn_ctx* ctx, const uint8_t* bases, const uint6
   for (uint32_t p = 0; p < n_parts; p++) {
     const uint64_t lo = eoff[p], n = eoff[p + 1] - lo;
     if (!n) continue;
-    // edge ids: by the time the edge was last re-created (never: row order first)
-    idx.resize(n);
-    for (uint64_t i = 0; i < n; i++) idx[i] = (uint32_t)i;
-    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) {
-      return std::max(key_out[lo + x], key_in[lo + x]) < std::max(key_out[lo + y], key_in[lo + y]); });
-    std::vector<uint32_t> new_of(n);
-    for (uint64_t i = 0; i < n; i++) { new_of[idx[i]] = (uint32_t)i; U->e_src[lo + i] = local_of[h_esrc[lo + idx[i]]]; U->e_dst[lo + i] = local_of[h_edst[lo + idx[i]]]; }
-    // out-list rank: the edges of one source ordered by (key_out, row); in-list rank likewise
-    std::vector<uint32_t> byo(idx.size()), byi(idx.size());
+    // list ranks (in row-index space): the edges of one source ordered by (key_out, row); of one destination by (key_in, row)
+    std::vector<uint32_t> byo(n), byi(n), orank(n), irank(n);
     for (uint64_t i = 0; i < n; i++) byo[i] = byi[i] = (uint32_t)i;                      // row order
     std::stable_sort(byo.begin(), byo.end(), [&](uint32_t x, uint32_t y) {
       if (h_esrc[lo + x] != h_esrc[lo + y]) return h_esrc[lo + x] < h_esrc[lo + y];
@@ -541,8 +535,25 @@ extern "C" int shn_unitigs_build(shn_ctx* ctx, const uint8_t* bases, const uint6
     std::stable_sort(byi.begin(), byi.end(), [&](uint32_t x, uint32_t y) {
       if (h_edst[lo + x] != h_edst[lo + y]) return h_edst[lo + x] < h_edst[lo + y];
       return key_in[lo + x] < key_in[lo + y]; });
-    for (uint64_t i = 0, r = 0; i < n; i++) { r = (i && h_esrc[lo + byo[i]] == h_esrc[lo + byo[i - 1]]) ? r + 1 : 0; U->e_out_rank[lo + new_of[byo[i]]] = (uint32_t)r; }
-    for (uint64_t i = 0, r = 0; i < n; i++) { r = (i && h_edst[lo + byi[i]] == h_edst[lo + byi[i - 1]]) ? r + 1 : 0; U->e_in_rank[lo + new_of[byi[i]]] = (uint32_t)r; }
+    for (uint64_t i = 0, r = 0; i < n; i++) { r = (i && h_esrc[lo + byo[i]] == h_esrc[lo + byo[i - 1]]) ? r + 1 : 0; orank[byo[i]] = (uint32_t)r; }
+    for (uint64_t i = 0, r = 0; i < n; i++) { r = (i && h_edst[lo + byi[i]] == h_edst[lo + byi[i - 1]]) ? r + 1 : 0; irank[byi[i]] = (uint32_t)r; }
+    // edge ids: by the merge that re-created the edge last.  A merge first re-creates the in-edges of its first node (in
+    // in-list order), then the out-edges of its second node (in out-list order); edges never re-created keep row order, first.
+    std::vector<uint64_t> ekey(n);
+    std::vector<uint32_t> etie(n);
+    for (uint64_t i = 0; i < n; i++) {
+      const uint64_t a = key_out[lo + i] * 2, b = key_in[lo + i] ? key_in[lo + i] * 2 + 1 : 0;     // phase bit: head merge (in-edges) before tail absorption
+      ekey[i] = std::max(a, b);
+      etie[i] = ekey[i] == 0 ? (uint32_t)i : (a > b ? irank[i] : orank[i]);
+    }
+    idx.resize(n);
+    for (uint64_t i = 0; i < n; i++) idx[i] = (uint32_t)i;
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return ekey[x] != ekey[y] ? ekey[x] < ekey[y] : etie[x] < etie[y]; });
+    for (uint64_t i = 0; i < n; i++) {
+      const uint32_t x = idx[i];
+      U->e_src[lo + i] = local_of[h_esrc[lo + x]]; U->e_dst[lo + i] = local_of[h_edst[lo + x]];
+      U->e_out_rank[lo + i] = orank[x]; U->e_in_rank[lo + i] = irank[x];
+    }
   }
   lap("host assembly");
   *out = U;

@@ -6,6 +6,9 @@
 #include "common.h"
 #include "flatmap.h"
 #include <algorithm>
+#include <atomic>
+#include <thread>
+#include <vector>
 
 static inline int pcode(uint8_t c) {
   switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; }
@@ -20,29 +23,89 @@ extern "C" int shn_find_reps(const uint8_t* names, const uint64_t* name_off, con
   if (r < 1 || r > 32) return shn_fail(SHN_ERR_ARG, "shn_find_reps: r must be in [1,32]");
   StringInterner ids(n + 16);
   std::vector<int64_t> rec_of;                  // name id -> latest record
-  FlatMultiMap index((seq_off[n] - seq_off[0]) + 1024);
+  std::vector<int32_t> id_of(n);
   const uint64_t mask = r == 32 ? ~0ULL : ((1ULL << (2 * r)) - 1);
   for (uint64_t i = 0; i < n; i++) {
     bool is_new;
     int32_t id = ids.intern((const char*)names + name_off[i], name_off[i + 1] - name_off[i], &is_new);
     if (is_new) rec_of.push_back((int64_t)i); else rec_of[id] = (int64_t)i;
-    const uint8_t* s = seqs + seq_off[i];
-    uint64_t L = seq_off[i + 1] - seq_off[i], key = 0;
-    for (uint64_t p = 0; p < L; p++) {
-      int c = pcode(s[p]);
-      if (c < 0) return shn_fail(SHN_ERR_ARG, "shn_find_reps: non-ACGT base in a transcript");
-      key = ((key << 2) | (uint64_t)c) & mask;
-      if (p + 1 >= (uint64_t)r) index.add(key, id, (int32_t)(p + 1 - r));
-    }
+    id_of[i] = id;
   }
   auto key_of = [&](const uint8_t* s, uint64_t L, uint64_t pos, bool rc, uint64_t& key) {
     // r-mer at `pos` of the sequence (rc: of its reverse complement)
     key = 0;
     for (int j = 0; j < r; j++) {
       int c = rc ? 3 - pcode(s[L - 1 - (pos + j)]) : pcode(s[pos + j]);
-      key = (key << 2) | (uint64_t)c;
+      key = (key << 2) | (uint64_t)(c & 3);
     }
   };
+  // The reference indexes every r-mer of every transcript (faster_reps.py:104-112) but only ever looks up the first and the
+  // last r-mer of each record, plain and reverse-complemented.  So: those (at most 4 per record) form a small query set, all
+  // records are scanned on host threads for occurrences of query keys (a rolling key, a probe of a cache-resident set), and
+  // only these occurrences enter the index -- in record order, as the reference appends them.
+  {
+    std::atomic<int> bad{0};
+    const unsigned nt0 = std::max(1u, std::min(32u, std::thread::hardware_concurrency() / 4));
+    const unsigned nt = n < 4096 ? 1 : nt0;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t]() {
+      for (uint64_t i = n * t / nt; i < n * (t + 1) / nt; i++)
+        for (uint64_t p = seq_off[i]; p < seq_off[i + 1]; p++) if (pcode(seqs[p]) < 0) { bad.store(1); return; }
+    });
+    for (auto& x : th) x.join();
+    if (bad.load()) return shn_fail(SHN_ERR_ARG, "shn_find_reps: non-ACGT base in a transcript");
+  }
+  size_t qcap = 1024;
+  while (qcap < rec_of.size() * 16) qcap <<= 1;
+  std::vector<uint64_t> qset(qcap, ~0ULL);        // open addressing; ~0 = empty (an r-mer of r < 32 never is; r = 32: all-T handled below)
+  bool q_all_t = false;
+  auto q_add = [&](uint64_t key) {
+    if (key == ~0ULL) { q_all_t = true; return; }
+    size_t sl = fm_mix(key) & (qcap - 1);
+    while (qset[sl] != ~0ULL && qset[sl] != key) sl = (sl + 1) & (qcap - 1);
+    qset[sl] = key;
+  };
+  auto q_has = [&](uint64_t key) -> bool {
+    if (key == ~0ULL) return q_all_t;
+    size_t sl = fm_mix(key) & (qcap - 1);
+    while (qset[sl] != ~0ULL) { if (qset[sl] == key) return true; sl = (sl + 1) & (qcap - 1); }
+    return false;
+  };
+  for (size_t id = 0; id < rec_of.size(); id++) {
+    const uint64_t i = (uint64_t)rec_of[id];
+    const uint8_t* s = seqs + seq_off[i];
+    const uint64_t L = seq_off[i + 1] - seq_off[i];
+    if (L < (uint64_t)r) continue;
+    for (int flip = 0; flip < (ds ? 2 : 1); flip++) {
+      uint64_t kf, kl;
+      key_of(s, L, 0, flip == 1, kf);
+      key_of(s, L, L - r, flip == 1, kl);
+      q_add(kf); q_add(kl);
+    }
+  }
+  struct Occ { uint64_t key; int32_t id, pos; };
+  const unsigned nthr = n < 4096 ? 1 : std::max(1u, std::min(32u, std::thread::hardware_concurrency() / 4));
+  std::vector<std::vector<Occ>> found(nthr);
+  {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nthr; t++) th.emplace_back([&, t]() {
+      std::vector<Occ>& out = found[t];
+      for (uint64_t i = n * t / nthr; i < n * (t + 1) / nthr; i++) {
+        const uint8_t* s = seqs + seq_off[i];
+        const uint64_t L = seq_off[i + 1] - seq_off[i];
+        uint64_t key = 0;
+        for (uint64_t p = 0; p < L; p++) {
+          key = ((key << 2) | (uint64_t)pcode(s[p])) & mask;
+          if (p + 1 >= (uint64_t)r && q_has(key)) out.push_back(Occ{key, id_of[i], (int32_t)(p + 1 - r)});
+        }
+      }
+    });
+    for (auto& x : th) x.join();
+  }
+  size_t n_occ = 0;
+  for (auto& v : found) n_occ += v.size();
+  FlatMultiMap index(n_occ + 1024);
+  for (auto& v : found) for (const Occ& o : v) index.add(o.key, o.id, o.pos);
   memset(keep_out, 0, n);
   std::vector<std::pair<int32_t, std::pair<int64_t, int64_t>>> pos;    // (other name id, (first pos, last pos)) in first-seen order
   for (size_t id = 0; id < rec_of.size(); id++) {

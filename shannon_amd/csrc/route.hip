@@ -176,6 +176,7 @@ extern "C" int shn_route_reads(shn_ctx* ctx, const shn_reads* r1, const shn_read
   if (probe->canonical) return shn_fail(SHN_ERR_ARG, "shn_route_reads: probe table must hold plain (non-canonical) k1-mers");
   if (2 * r1->n_reads >= 0xFFFFFFFFULL) return shn_fail(SHN_ERR_ARG, "shn_route_reads: too many reads for 32-bit doubled indices");
   HIP_TRY(hipSetDevice(ctx->device));
+  shn_stage_begin();
   hipStream_t s = ctx->stream;
   TimerRegion treg(ctx, T_ROUTE);
   uint64_t N2 = 2 * r1->n_reads;

@@ -171,7 +171,7 @@ def make_table(ctx, keys, values, k, canonical=False):
 
 
 def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overload=2, penalty=5, repartition=True,
-                        part_vectors=None, want_rows=True, timings=None, lazy_routes=False):
+                        part_vectors=None, want_rows=True, timings=None, lazy_routes=False, lazy_graph_inputs=False):
     """Rows a8-a11.  reads1/reads2: device.Reads (reads2 None for single-end).  Returns dict with
       new_components {name: [contig]}          (kmers_for_component.py:244-305)
       k1mers {name: [(k1mer, weight)]}         (:452-477, == component{name}k1mers_allowed.dict)
@@ -278,8 +278,14 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
     probe.close()
     lap("route.download")
     # per-partition k1-mer rows with weights from the allowed dict (:452-477)
-    rows_bytes, n_nodes = {}, {}
+    rows_bytes, n_nodes, n_rows_of = {}, {}, {}
     for name in names:
+        n_rows_of[name] = int(sum(max(len(c) - k1 + 1, 0) for c in comps[name]))
+        if lazy_graph_inputs and not want_rows:
+            # the graph stage takes its K-mer graph from the GPU unitig builder (which also counts the distinct K-mers);
+            # the byte rows are made on demand (a partition with a cycle of condensable edges, SHN_GRAPH_CHECK)
+            rows_bytes[name] = (lambda nm=name: _rows_bytes(comps[nm], k1))
+            continue
         # fixed-width byte form of the k1-mer file (what the native graph stage consumes) + #distinct K-mers
         rb = None
         if comps[name]:
@@ -313,7 +319,23 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
             cw[name] = ws
     lap("route.rows")
     return {"new_components": comps, "components_broken": broken, "k1mers": files, "contig_weights": cw, "routes": by_part,
-            "k1mer_bytes": rows_bytes, "n_kmer_nodes": n_nodes}
+            "k1mer_bytes": rows_bytes, "n_kmer_nodes": n_nodes, "n_k1mer_rows": n_rows_of}
+
+
+def _rows_bytes(contigs, k1):
+    """fixed-width byte form of a partition's k1-mer file: every k1-window of every contig, in order"""
+    if not contigs:
+        return np.zeros(0, np.uint8)
+    try:
+        _k, rb, _nw = _lib.string_windows(contigs, k1, want_keys=False, want_rows=True)
+        return np.ascontiguousarray(rb)
+    except _lib.ShannonError:
+        chunks = []
+        for contig in contigs:
+            b = np.frombuffer(contig.encode(), dtype=np.uint8)
+            if len(b) - k1 + 1 > 0:
+                chunks.append(np.lib.stride_tricks.sliding_window_view(b, k1).reshape(-1))
+        return np.ascontiguousarray(np.concatenate(chunks)) if chunks else np.zeros(0, np.uint8)
 
 
 class ReadStore(object):

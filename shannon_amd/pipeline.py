@@ -6,7 +6,7 @@ reference's --inMem hand-off); `shannon.py` at the repo root adds the CLI and th
 import os
 import time
 import numpy as np
-from . import device, extension_correction as ec, kmers_for_component as kfc, mbgraph, mbgraph_native, sparse_flow, post
+from . import _lib, device, extension_correction as ec, kmers_for_component as kfc, mbgraph, mbgraph_native, sparse_flow, post
 
 
 class Result(object):
@@ -75,8 +75,9 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
     R.extension = res
     tick("extension", t0)
     t0 = time.time()
+    gpu_unitigs = native_graph and K <= 31 and os.environ.get("SHN_GRAPH_GPU", "1") != "0"
     part = kfc.kmers_for_component(ctx, res, d1, d2, K, partition_size, overload, penalty, True, part_vectors,
-                                   want_rows=not native_graph)
+                                   want_rows=not native_graph, timings=T, lazy_graph_inputs=gpu_unitigs)
     tick("partition+route", t0)
     R.partitions = {}
     lines = []
@@ -86,7 +87,7 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
 
     names = list(part["new_components"])
     unitigs = None
-    if native_graph and names and K <= 31 and os.environ.get("SHN_GRAPH_GPU", "1") != "0":
+    if gpu_unitigs and names:
         # the raw K-mer graphs of all partitions, contracted to unitigs in one batch on the GPU
         t0 = time.time()
         unitigs = mbgraph_native.Unitigs(ctx, [part["new_components"][nm] for nm in names], K)
@@ -110,11 +111,24 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
                 b2, o2, rc2, _e = store.gather_codes(idx, 2) if paired else (None, None, None, enc)
             tt["materialize reads"] = time.time() - t0
             t0 = time.time()
-            rb = part["k1mer_bytes"][name]() if callable(part["k1mer_bytes"][name]) else part["k1mer_bytes"][name]
-            n_rows = len(rb) // (K + 1)
-            singles, comps, glog = mbgraph_native.run_partition_arrays(rb if len(rb) else np.zeros(1, np.uint8), n_rows, K,
-                                                                       b1, o1, b2, o2, ctx=ctx, enc=enc, rc1=rc1, rc2=rc2,
-                                                                       unitigs=unitigs, part=part_index[name])
+            def rows_now():
+                rb_ = part["k1mer_bytes"][name]
+                return rb_() if callable(rb_) else rb_
+            # with GPU unitigs the k1-mer rows are only needed for a partition holding a cycle of condensable edges (built by
+            # the sequential code) and for the development check SHN_GRAPH_CHECK=1
+            rb = rows_now() if (unitigs is None or check_rows) else None
+            try:
+                singles, comps, glog = mbgraph_native.run_partition_arrays(None if rb is None else (rb if len(rb) else np.zeros(1, np.uint8)),
+                                                                           0 if rb is None else len(rb) // (K + 1), K, b1, o1, b2, o2, ctx=ctx,
+                                                                           enc=enc, rc1=rc1, rc2=rc2, unitigs=unitigs, part=part_index[name])
+            except _lib.ShannonError as ex:
+                if rb is not None or "needs the k1-mer rows" not in str(ex):
+                    raise
+                rb = rows_now()
+                singles, comps, glog = mbgraph_native.run_partition_arrays(rb if len(rb) else np.zeros(1, np.uint8), len(rb) // (K + 1), K, b1, o1, b2,
+                                                                           o2, ctx=ctx, enc=enc, rc1=rc1, rc2=rc2, unitigs=unitigs,
+                                                                           part=part_index[name])
+            n_rows = part["n_k1mer_rows"][name]
         else:
             rows = part["k1mers"][name]
             r1 = [store.mate1(int(d)) for d in idx]

@@ -204,6 +204,15 @@ def test_native_find_reps_matches_python_and_oracle():
         b = post.find_reps(lines, ds)
         c = opost.find_reps(lines, ds)
         assert a == b == c
+    # enough records for the threaded scan of the native code (the occurrences must come out in record order)
+    big = []
+    for rep in range(60):
+        for h, s_ in recs:
+            big.append((h.split()[0] + "_%d" % rep + h[len(h.split()[0]):], s_[rep % 5:] if len(s_) > 300 else s_))
+    lines = [x for h, s_ in big for x in (h + "\n", s_ + "\n")]
+    assert len(big) > 4096
+    for ds in (True, False):
+        assert post.find_reps_native(lines, ds) == post.find_reps(lines, ds)
     full = post.finalize(lines, True)
     assert full == opost.finalize(lines, True)
 
