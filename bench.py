@@ -5,9 +5,11 @@
     (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" = one pass of the hot path over one batch of synthetic 2x100 bp reads already resident
-(2-bit packed) in HBM.  N=1 workload = BASELINE configs[1]: 10M reads (5M pairs), k=25 (-K 25,
-k1=26), one gene family.  N>1: every rank gets its own 10M-read shard (weak scaling) and the
-ranks exchange their (key,count) tables with one all-to-all over RCCL/xGMI.
+(2-bit packed) in HBM.  N=1 workload = BASELINE configs[2], the largest single-GPU configuration:
+100M reads (50M pairs), k=25 (-K 25, k1=26), 20,000 genes, multi-component, --partition 500
+(`--config 1` = configs[1]: 10M reads of one gene family).  N>1: every rank gets its own 10M-read
+shard of the configs[1] kind (weak scaling) and the ranks exchange their (key,count) tables with one
+all-to-all over RCCL/xGMI.
 Prints ONE JSON line on rank 0.
 """
 import argparse, json, os, sys, time
@@ -21,10 +23,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes over this same command at the
 # default workload; tools/summarize_prof.py -> profiles/r01_traffic.json): 2 x FETCH_SIZE (gfx950 tallies 128-B
 # requests at 64 B, MI355X_MICROARCH.md HBM) + WRITE_SIZE.  Only valid for the default 10M-read workload.
-try:
-    TRAFFIC = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["traffic_bytes_per_launch"]
-except (OSError, ValueError, KeyError):
-    TRAFFIC = {}
+TRAFFIC = {}
+for _cfg, _fn in ((1, "r01_traffic.json"), (2, "r02_traffic_config2.json")):
+    try:
+        TRAFFIC["config%d" % _cfg] = json.load(open(os.path.join(ROOT, "profiles", _fn)))["traffic_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
 
 
 def gen_reads(n_pairs, seed, n_genes, device, read_seed=None, families=0):
@@ -112,9 +116,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU (2 per pair)")
+    ap.add_argument("--config", type=int, default=0, help="BASELINE.json configs[i]: 1 = 10M reads / one gene family, 2 = 100M reads / "
+                                                          "20,000 genes (default: 2 on one GPU, 1 per rank on several)")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (2 per pair); default from --config")
     ap.add_argument("--K", type=int, default=25)
-    ap.add_argument("--genes", type=int, default=1)
+    ap.add_argument("--genes", type=int, default=0, help="genes of the synthetic transcriptome; default from --config")
     ap.add_argument("--families", type=int, default=0, help="gene families of the configs[1] kind (default: one per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-distributed", action="store_true", help="run the multi-GPU code path even with one rank")
@@ -126,6 +132,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not args.config:
+        args.config = 2 if (world == 1 and not args.genes and not args.reads and not args.families) else 1
+    preset = {1: (1, 10_000_000), 2: (20000, 100_000_000)}[args.config]
+    args.genes = args.genes or preset[0]
+    args.reads = args.reads or preset[1]
+    is_config = (args.genes, args.reads) == preset and args.K == 25 and not args.families
     dist = None
     # SHN_BENCH_BACKEND=gloo: development aid -- several ranks on ONE GPU (collectives staged through host memory,
     # exchange.coll_device), to exercise the N-rank code path on a 1-GPU box.  Its numbers mean nothing.
@@ -263,7 +275,7 @@ def main():
             avg = ms / launches
             bytes_launch = per_step_bytes[name] * args.steps / launches
             ach = bytes_launch / (avg * 1e-3) / 1e9
-            tr = TRAFFIC.get(name) if (args.reads == 10_000_000 and args.genes == 1 and args.K == 25 and world == 1) else None   # PMC passes were taken at N=1
+            tr = TRAFFIC.get("config%d" % args.config, {}).get(name) if (is_config and world == 1) else None   # PMC passes were taken at N=1
             return {"bound": "hbm", "kernel": KERNEL[name], "timer": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": tr, "launches_per_step": launches / args.steps, "avg_launch_ms": avg,
                     "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_bytes_per_read": per_read.get(name)}
@@ -278,9 +290,15 @@ def main():
             "value": n_reads * world * args.steps / dt, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": ("10M synthetic 2x100bp paired reads per GPU, k=25 (k1=26), %s, 0.5%% substitution errors (BASELINE configs[1]%s)"
-                                    % (("%d gene families, one per rank's worth of reads, every rank holding a slice of the mixture" % families, " per family")
-                                       if families > 1 else ("single gene family", ""))),
+            "config": {"workload": (("100M synthetic 2x100bp paired reads (50M pairs), k=25 (k1=26), 20,000 genes (1-6 isoforms of 3-12 exons, lognormal "
+                                     "expression), 0.5% substitution errors, multi-component, --partition 500 (BASELINE configs[2])")
+                                    if (args.config == 2 and is_config) else
+                                    ("10M synthetic 2x100bp paired reads per GPU, k=25 (k1=26), %s, 0.5%% substitution errors (BASELINE configs[1]%s)"
+                                     % (("%d gene families, one per rank's worth of reads, every rank holding a slice of the mixture" % families, " per family")
+                                        if families > 1 else ("single gene family", ""))) if is_config or families else
+                                    ("%d synthetic 2x100bp paired reads per GPU, K=%d, %d genes (a tuning input, none of BASELINE's configs)"
+                                     % (n_reads, args.K, args.genes))),
+                       "baseline_config": args.config if is_config else None,
                        "reads_per_gpu": n_reads, "K": args.K,
                        "stages": ("full path a1-a31, sharded: local count -> all-to-all bucket exchange -> replicated extension -> local routing -> "
                                   "owner-side graph + sparse flow -> gather + merge on rank 0" if use_dist else

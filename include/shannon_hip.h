@@ -209,6 +209,17 @@ int shn_contig_components(uint64_t n_acc, const uint64_t* conn_off, const int32_
 typedef struct shn_routes shn_routes;
 int shn_table_create(shn_ctx* ctx, const uint64_t* keys, const uint32_t* values, uint64_t n, int k, int canonical,
                      shn_table** out);
+/* k1mers2component on the GPU (kmers_for_component.py:244-305): the probe table + partition sets from the partition contigs in one
+ * call (csrc/probe_gpu.hip).  bases / off: the contigs of all partitions one after the other (ASCII), part_of[c] = partition of
+ * contig c (ascending).  Set p (p < n_parts) is {p}; the sets of k1-mers that occur in several partitions follow.              */
+typedef struct shn_probe shn_probe;
+int shn_probe_build(shn_ctx* ctx, const uint8_t* bases, const uint64_t* off, uint64_t n_contigs, const uint32_t* part_of, uint32_t n_parts,
+                    int k1, shn_probe** out);
+void shn_probe_destroy(shn_probe* p);
+const shn_table* shn_probe_table(const shn_probe* p);        /* owned by the probe */
+uint32_t shn_probe_n_sets(const shn_probe* p);
+uint64_t shn_probe_n_members(const shn_probe* p);
+int shn_probe_sets(const shn_probe* p, uint32_t* set_off /* n_sets + 1 */, uint32_t* set_mem /* n_members */);
 int shn_route_reads(shn_ctx* ctx, const shn_reads* r1, const shn_reads* r2, int k1, const shn_table* probe,
                     const uint32_t* set_off, const uint32_t* set_members, uint32_t n_sets, shn_routes** out);
 void shn_routes_destroy(shn_routes* r);

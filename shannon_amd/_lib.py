@@ -40,6 +40,12 @@ SIGNATURES = {
     "shn_table_from_pairs": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vpp]),
     "shn_table_shard": (C.c_int, [vp, vp, C.c_int, u64p, vp, vp]),
     "shn_table_create": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vpp]),
+    "shn_probe_build": (C.c_int, [vp, vp, vp, C.c_uint64, vp, C.c_uint32, C.c_int, vpp]),
+    "shn_probe_destroy": (None, [vp]),
+    "shn_probe_table": (vp, [vp]),
+    "shn_probe_n_sets": (C.c_uint32, [vp]),
+    "shn_probe_n_members": (C.c_uint64, [vp]),
+    "shn_probe_sets": (C.c_int, [vp, vp, vp]),
     "shn_route_reads": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, C.c_uint32, vpp]),
     "shn_routes_destroy": (None, [vp]),
     "shn_routes_size": (C.c_uint64, [vp]),

@@ -157,3 +157,15 @@ int shn_sort_pairs(shn_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t* keys_
                    int bit_lo, int bit_hi);
 
 static inline uint64_t cdiv(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+// device buffers of one call, given back to the caching allocator when the call ends
+struct ShnDevBufs {
+  std::vector<void*> p;
+  template <class T> hipError_t get(T** out, size_t bytes) { hipError_t e = shn_dev_malloc(out, bytes); if (e == hipSuccess) p.push_back((void*)*out); return e; }
+  ~ShnDevBufs() { for (void* q : p) shn_dev_free(q); }
+};
+// contig texts on the device (csrc/contig_gpu.hip): cid[g] = contig of base g; the k-windows of the selected contigs (use ==
+// NULL: all) as (packed key, base index of the window start) pairs sorted by key, stable (so by contig, position inside a run)
+void shn_contig_ids(hipStream_t s, const uint64_t* d_off, uint64_t n_contigs, uint32_t* d_cid);
+int shn_sorted_windows(shn_ctx* ctx, ShnDevBufs& bufs, const uint8_t* d_bases, const uint64_t* d_off, const uint32_t* d_cid, const int32_t* d_use,
+                       uint64_t total, int k, uint64_t** keys, uint32_t** vals, uint64_t* n_out);

@@ -171,16 +171,16 @@ __global__ void cg_compact_kernel(const uint64_t* __restrict__ keys, const uint3
     if (flag[i]) { okeys[pos[i]] = keys[i]; ovals[pos[i]] = vals[i]; }
 }
 
-struct DevBufs {
-  std::vector<void*> p;
-  template <class T> hipError_t get(T** out, size_t bytes) { hipError_t e = shn_dev_malloc(out, bytes); if (e == hipSuccess) p.push_back((void*)*out); return e; }
-  ~DevBufs() { for (void* q : p) shn_dev_free(q); }
-};
-
 static inline uint32_t grid_for(uint64_t n) { return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(cdiv(n, CG_BLK), 1), 1u << 20); }
 
+}  // namespace
+
+void shn_contig_ids(hipStream_t s, const uint64_t* d_off, uint64_t n_contigs, uint32_t* d_cid) {
+  if (n_contigs) hipLaunchKernelGGL(cg_cid_kernel, dim3((uint32_t)cdiv(n_contigs * 64, CG_BLK)), dim3(CG_BLK), 0, s, d_off, n_contigs, d_cid);
+}
+
 // sorted (key, base index) pairs of all k-windows of the selected contigs; device arrays in *keys / *vals (owned by bufs)
-static int sorted_windows(shn_ctx* ctx, DevBufs& bufs, const uint8_t* d_bases, const uint64_t* d_off, const uint32_t* d_cid,
+int shn_sorted_windows(shn_ctx* ctx, ShnDevBufs& bufs, const uint8_t* d_bases, const uint64_t* d_off, const uint32_t* d_cid,
                           const int32_t* d_use, uint64_t total, int k, uint64_t** keys, uint32_t** vals, uint64_t* n_out) {
   hipStream_t s = ctx->stream;
   uint32_t* d_flag; uint64_t* d_pos; unsigned long long* d_bad;
@@ -207,8 +207,6 @@ static int sorted_windows(shn_ctx* ctx, DevBufs& bufs, const uint8_t* d_bases, c
   return SHN_OK;
 }
 
-}  // namespace
-
 // Same contract as shn_cgraph_add on a fresh graph: candidates in seed order in one call; accepted_out[i] = 1-based accepted
 // index or 0, best_counts_out[i] (may be NULL) = hit count of the candidate's `best` contig; *out receives the contig graph
 // (shn_cgraph_sizes / shn_cgraph_export / shn_cgraph_destroy).
@@ -234,14 +232,14 @@ extern "C" int shn_contig_stage(shn_ctx* ctx, const uint8_t* bases, const uint64
   hipStream_t s = ctx->stream;
   shn_stage_begin();
   TimerRegion treg(ctx, T_CONTIG);
-  DevBufs bufs;
+  ShnDevBufs bufs;
   uint8_t* d_bases; uint64_t* d_off; uint32_t* d_cid;
   HIP_TRY(bufs.get(&d_bases, total + 64));
   HIP_TRY(bufs.get(&d_off, (n_cand + 1) * 8));
   HIP_TRY(bufs.get(&d_cid, (total + 1) * 4));
   HIP_TRY(hipMemcpyAsync(d_bases, bases, total, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_off, off, (n_cand + 1) * 8, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(cg_cid_kernel, dim3((uint32_t)cdiv(n_cand * 64, CG_BLK)), dim3(CG_BLK), 0, s, d_off, n_cand, d_cid);
+  shn_contig_ids(s, d_off, n_cand, d_cid);
 
   // ---- duplicate_check: seed-order blocks, each iterated to its fixpoint on top of the frozen earlier blocks
   std::vector<uint8_t> acc(n_cand, 0);
@@ -255,9 +253,9 @@ extern "C" int shn_contig_stage(shn_ctx* ctx, const uint8_t* bases, const uint64
   }
   uint64_t n_rounds = 0, n_blocks = 0;
   {
-    DevBufs tmp;
+    ShnDevBufs tmp;
     uint64_t* keys; uint32_t* vals; uint64_t nv = 0;
-    int rc = sorted_windows(ctx, tmp, d_bases, d_off, d_cid, nullptr, total, r, &keys, &vals, &nv);
+    int rc = shn_sorted_windows(ctx, tmp, d_bases, d_off, d_cid, nullptr, total, r, &keys, &vals, &nv);
     if (rc) return rc;
     lap("r-mer sort (GPU)");
     uint8_t *d_acc, *d_hit; uint32_t *d_scid, *d_flag, *d_acand, *d_cov, *d_ovf; uint64_t *d_apos, *d_akey; int32_t* d_bestc;
@@ -353,9 +351,9 @@ extern "C" int shn_contig_stage(shn_ctx* ctx, const uint8_t* bases, const uint64
     int32_t* d_use;
     HIP_TRY(bufs.get(&d_use, n_cand * 4));
     HIP_TRY(hipMemcpyAsync(d_use, use.data(), n_cand * 4, hipMemcpyHostToDevice, s));
-    DevBufs tmp;
+    ShnDevBufs tmp;
     uint64_t* keys; uint32_t* vals; uint64_t nv = 0;
-    int rc = sorted_windows(ctx, tmp, d_bases, d_off, d_cid, d_use, total, C, &keys, &vals, &nv);
+    int rc = shn_sorted_windows(ctx, tmp, d_bases, d_off, d_cid, d_use, total, C, &keys, &vals, &nv);
     if (rc) return rc;
     uint64_t ns = 0;
     std::vector<uint64_t> hk; std::vector<uint32_t> hg;

@@ -192,9 +192,54 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
     names = list(comps)
     lap("route.partitions")
     pid_of = {n: i for i, n in enumerate(names)}
-    # k1mers2component (:244-305): every k1-window of every partition contig -> set of partitions
-    key_sets = {}
     files, cw = {}, {}
+    import os
+    n_windows = sum(max(len(c) - k1 + 1, 0) for name in names for c in comps[name])
+    _pg = os.environ.get("SHN_PROBE_GPU", "")
+    probe_h = None
+    if k1 <= 32 and (_pg == "1" or (_pg != "0" and n_windows >= (1 << 20))):
+        # k1mers2component on the GPU (shn_probe_build): one device sort of the k1-windows of all partition contigs
+        flat = [c for name in names for c in comps[name]]
+        text = np.frombuffer("".join(flat).encode(), dtype=np.uint8) if flat else np.zeros(1, np.uint8)
+        off = np.zeros(len(flat) + 1, dtype=np.uint64)
+        if flat:
+            off[1:] = np.cumsum([len(c) for c in flat], dtype=np.uint64)
+        part_of = np.ascontiguousarray(np.repeat(np.arange(len(names), dtype=np.uint32), [len(comps[name]) for name in names]), dtype=np.uint32) \
+            if flat else np.zeros(1, np.uint32)
+        probe_h = C.c_void_p()
+        _lib.check(_lib.lib().shn_probe_build(ctx.h, text.ctypes.data, off.ctypes.data, len(flat), part_of.ctypes.data, len(names), int(k1),
+                                              C.byref(probe_h)))
+        n_sets = int(_lib.lib().shn_probe_n_sets(probe_h))
+        set_off = np.zeros(n_sets + 1, dtype=np.uint32)
+        set_mem = np.zeros(max(int(_lib.lib().shn_probe_n_members(probe_h)), 1), dtype=np.uint32)
+        _lib.check(_lib.lib().shn_probe_sets(probe_h, set_off.ctypes.data, set_mem.ctypes.data))
+        lap("route.k1mer map")
+        h = C.c_void_p()
+        try:
+            _lib.check(_lib.lib().shn_route_reads(ctx.h, reads1.h, reads2.h if reads2 is not None else None, k1,
+                                                  C.c_void_p(_lib.lib().shn_probe_table(probe_h)), set_off.ctypes.data, set_mem.ctypes.data, n_sets,
+                                                  C.byref(h)))
+        finally:
+            _lib.lib().shn_probe_destroy(probe_h)
+        lap("route.kernel")
+    if probe_h is None:
+        h = _host_probe_and_route(ctx, comps, names, pid_of, reads1, reads2, k1, lap)
+    routes = Routes(ctx, h)
+    if lazy_routes:                                   # routes stay on the device; RouteView fetches what is asked for
+        start, below = routes.bounds(len(names), len(reads1))
+        by_part = {n: RouteView(routes, start[i], start[i + 1] - start[i], below[i]) for i, n in enumerate(names)}
+    else:
+        pid, ridx = routes.download()
+        routes.close()
+        bounds = np.searchsorted(pid, np.arange(len(names) + 1))
+        by_part = {n: ridx[bounds[i]:bounds[i + 1]] for i, n in enumerate(names)}
+    lap("route.download")
+    return _finish_partitions(res, comps, broken, names, by_part, files, cw, k1, K, want_rows, lazy_graph_inputs, lap)
+
+
+def _host_probe_and_route(ctx, comps, names, pid_of, reads1, reads2, k1, lap):
+    """k1mers2component with numpy (small inputs; the readable form of csrc/probe_gpu.hip) + the routing kernel; returns the
+    shn_routes handle"""
     allk, allp = [], []
     for name in names:
         ks, _nw = windows_to_keys_many(comps[name], k1)
@@ -263,20 +308,16 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
     lap("route.k1mer map")
     probe = make_table(ctx, uk, set_ids, k1, canonical=False)
     h = C.c_void_p()
-    _lib.check(_lib.lib().shn_route_reads(ctx.h, reads1.h, reads2.h if reads2 is not None else None, k1, probe.h,
-                                          set_off.ctypes.data, set_mem.ctypes.data, len(sets), C.byref(h)))
+    try:
+        _lib.check(_lib.lib().shn_route_reads(ctx.h, reads1.h, reads2.h if reads2 is not None else None, k1, probe.h,
+                                              set_off.ctypes.data, set_mem.ctypes.data, len(sets), C.byref(h)))
+    finally:
+        probe.close()
     lap("route.kernel")
-    routes = Routes(ctx, h)
-    if lazy_routes:                                   # routes stay on the device; RouteView fetches what is asked for
-        start, below = routes.bounds(len(names), len(reads1))
-        by_part = {n: RouteView(routes, start[i], start[i + 1] - start[i], below[i]) for i, n in enumerate(names)}
-    else:
-        pid, ridx = routes.download()
-        routes.close()
-        bounds = np.searchsorted(pid, np.arange(len(names) + 1))
-        by_part = {n: ridx[bounds[i]:bounds[i + 1]] for i, n in enumerate(names)}
-    probe.close()
-    lap("route.download")
+    return h
+
+
+def _finish_partitions(res, comps, broken, names, by_part, files, cw, k1, K, want_rows, lazy_graph_inputs, lap):
     # per-partition k1-mer rows with weights from the allowed dict (:452-477)
     rows_bytes, n_nodes, n_rows_of = {}, {}, {}
     for name in names:

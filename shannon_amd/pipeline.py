@@ -147,7 +147,10 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
         # native stage releases the GIL, its GPU sections take turns
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(len(names), graph_threads)) as pool:
-            results = list(pool.map(one_partition, names))
+            # the partitions with the most routed reads first (the reference's size-sorted job list, shannon.py:546-551)
+            by_size = sorted(names, key=lambda nm: -len(part["routes"][nm]))
+            futs = {nm: pool.submit(one_partition, nm) for nm in by_size}
+            results = [futs[nm].result() for nm in names]
     else:
         results = [one_partition(nm) for nm in names]
     if unitigs is not None:

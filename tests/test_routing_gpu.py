@@ -15,8 +15,11 @@ def ctx():
 
 
 @pytest.mark.parametrize("name", sorted(MANIFEST))
-def test_routing_matches_golden(ctx, name):
+@pytest.mark.parametrize("probe_gpu", ["0", "1"])
+def test_routing_matches_golden(ctx, name, probe_gpu, monkeypatch):
+    """probe_gpu: k1mers2component by numpy on the host / by the device sort of csrc/probe_gpu.hip"""
     from shannon_amd import device, extension_correction as ec, kmers_for_component as kfc
+    monkeypatch.setenv("SHN_PROBE_GPU", probe_gpu)
     g = load_case(name)
     K, paired = g["K"], g["paired"]
     psize = MANIFEST[name].get("partition_size", 500)
