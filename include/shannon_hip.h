@@ -285,6 +285,27 @@ int shn_graph_export(const shn_graph* g, uint64_t* s_off, uint8_t* s_bases, doub
                      uint8_t* n_bases, double* n_cc, uint8_t* n_cc_int, double* n_norm, int32_t* e_in, int32_t* e_out,
                      int32_t* e_w, double* e_cc, double* e_norm, uint64_t* p_off, int32_t* p_ids, int32_t* info);
 
+/* The inverse of shn_graph_export (sizes[9] as shn_graph_sizes; arrays as shn_graph_export without `info`): a graph object from
+ * flattened nodes / edges / paths tables, e.g. the reference's own files.                                                       */
+int shn_graph_from_tables(const uint64_t* sizes, const uint64_t* s_off, const uint8_t* s_bases, const double* s_cc, const double* s_norm,
+                          const uint64_t* comp_node_off, const uint64_t* comp_edge_off, const uint64_t* comp_path_off, const uint64_t* n_off,
+                          const uint8_t* n_bases, const double* n_cc, const uint8_t* n_cc_int, const double* n_norm, const int32_t* e_in,
+                          const int32_t* e_out, const int32_t* e_w, const double* e_cc, const double* e_norm, const uint64_t* p_off,
+                          const int32_t* p_ids, shn_graph** out);
+
+/* ---- sparse-flow transcript reconstruction (host, native, over the LP kernel below) ------------------------------------------
+ * Replaces algorithm_SF.py for every component of every partition (algorithm_SF.py:74-613: ParseNodeFile / ParseEdgeFile /
+ * ParseKnownPathsFile, findStartAndEnd2, algorithm2 with path_decompose, read_Y_paths, single_nodes_to_fasta; one process per
+ * component in the reference, run_MB_SF_fn.py:239-254).  graphs[g] = the graph of partition g, snames[g] = "<sample>_<partition>".
+ * All components advance together; the decompositions that need LP trials form one shn_lp_solve_batch per round (component c
+ * of a partition draws its costs from the problem ids (c << 20) + call number).  Text g = reconstructed_comp_*.fasta of
+ * partition g concatenated in component order, then reconstructed_comp_-1.fasta (its single nodes).                              */
+typedef struct shn_sflow shn_sflow;
+int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uint32_t n_graphs, const char* const* snames, uint64_t seed, shn_sflow** out);
+void shn_sflow_destroy(shn_sflow* s);
+uint64_t shn_sflow_text_size(const shn_sflow* s, uint32_t g);
+int shn_sflow_text(const shn_sflow* s, uint32_t g, uint8_t* out);
+
 /* ---- final containment de-duplication (host, native) ------------------------------------------------
  * Replaces faster_reps.find_reps (faster_reps.py:98-131, duplicate_check_ends :60-92; called `-d` from
  * shannon.py:604).  n FASTA records in file order (names without '>', sequences), r = 24.            */

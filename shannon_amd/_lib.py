@@ -66,6 +66,11 @@ SIGNATURES = {
     "shn_mbgraph_run_unitigs": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, vpp]),
     "shn_graph_sizes": (C.c_int, [vp, u64p]),
     "shn_graph_export": (C.c_int, [vp] + [vp] * 20),
+    "shn_graph_from_tables": (C.c_int, [vp] * 20 + [vpp]),
+    "shn_sparse_flow": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint64, vpp]),
+    "shn_sflow_destroy": (None, [vp]),
+    "shn_sflow_text_size": (C.c_uint64, [vp, C.c_uint32]),
+    "shn_sflow_text": (C.c_int, [vp, C.c_uint32, vp]),
     "shn_find_reps": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp]),
     "shn_extend": (C.c_int, [vp, vp, C.c_uint32, C.c_int, vpp]),
     "shn_ext_destroy": (None, [vp]),

@@ -524,6 +524,17 @@ static int build_from_keys(shn_ctx* ctx, uint64_t* keysA, uint64_t* keysB, uint3
                            const std::vector<uint64_t>& off1h, int bits, int b2, int k, int canonical, uint64_t N,
                            uint64_t total, shn_table** out, bool* overflowed);
 
+static int count_views(shn_ctx* ctx, const std::vector<ReadsView>& views, uint64_t upper, int k1, int both_strands, shn_table** out);
+
+// reads [r0, r0 + n) of a view
+static ReadsView sub_view(const ReadsView& v, uint64_t r0, uint64_t n) {
+  ReadsView w = v;
+  w.n_reads = n;
+  if (v.woff) { w.woff = v.woff + r0; w.len = v.len + r0; }
+  else { w.words = v.words + r0 * v.wpr; if (v.mask) w.mask = v.mask + r0 * v.wpr / 2; }     // (wpr is even: reads start on even word boundaries)
+  return w;
+}
+
 extern "C" int shn_count_k1mers(shn_ctx* ctx, shn_reads* const* sets, int n_sets, int k1, int both_strands, shn_table** out) {
   if (!ctx || !sets || !out || n_sets <= 0) return shn_fail(SHN_ERR_ARG, "shn_count_k1mers: bad argument");
   if (k1 < 2 || k1 > 32) return shn_fail(SHN_ERR_ARG, "shn_count_k1mers: k1 must be in [2,32]");
@@ -539,6 +550,68 @@ extern "C" int shn_count_k1mers(shn_ctx* ctx, shn_reads* const* sets, int n_sets
     views.push_back(v);
     upper += v.n_reads * (uint64_t)v.wmax;
   }
+  // The partition pipeline holds two 8-byte key buffers + one 4-byte count buffer for all windows at once: 20 B x 7.5 G windows
+  // = 150 GB at 100 M reads, half the device for the whole run (hipMalloc of such blocks costs seconds, so they are never given
+  // back).  Beyond 2^31 windows the reads are counted in chunks of at most that many windows, each chunk to its own table, and
+  // the tables' (key, count) pairs are reduced by key (the pairs path of the exchange step) -- a few GB of extra traffic.
+  uint64_t chunk_windows = 1ULL << 31;
+  if (getenv("SHN_COUNT_CHUNK")) chunk_windows = std::max<uint64_t>(1, strtoull(getenv("SHN_COUNT_CHUNK"), nullptr, 10));   // (tests)
+  if (upper <= chunk_windows) return count_views(ctx, views, upper, k1, both_strands, out);
+  std::vector<shn_table*> parts;
+  auto drop = [&]() { for (shn_table* t : parts) shn_table_destroy(t); parts.clear(); };
+  {
+    std::vector<ReadsView> cur;
+    uint64_t cur_w = 0;
+    auto flush = [&]() -> int {
+      if (cur.empty()) return SHN_OK;
+      shn_table* t = nullptr;
+      int rc = count_views(ctx, cur, cur_w, k1, both_strands, &t);
+      if (rc) return rc;
+      parts.push_back(t);
+      cur.clear(); cur_w = 0;
+      return SHN_OK;
+    };
+    for (const ReadsView& v : views) {
+      if (!v.wmax || !v.n_reads) continue;
+      uint64_t r0 = 0;
+      while (r0 < v.n_reads) {
+        const uint64_t room = (chunk_windows - cur_w) / v.wmax;
+        if (room == 0) { int rc = flush(); if (rc) { drop(); return rc; } continue; }
+        const uint64_t n = std::min<uint64_t>(v.n_reads - r0, std::max<uint64_t>(room, 1));
+        cur.push_back(sub_view(v, r0, n));
+        cur_w += n * v.wmax;
+        r0 += n;
+        if (cur_w >= chunk_windows) { int rc = flush(); if (rc) { drop(); return rc; } }
+      }
+    }
+    int rc = flush();
+    if (rc) { drop(); return rc; }
+  }
+  uint64_t np = 0;
+  for (shn_table* t : parts) np += t->n;
+  uint64_t* pk = nullptr; uint32_t* pc = nullptr;
+  if (shn_dev_malloc(&pk, (np + 1) * 8) != hipSuccess || shn_dev_malloc(&pc, (np + 1) * 4) != hipSuccess) {
+    shn_dev_free(pk); shn_dev_free(pc); drop();
+    return shn_fail(SHN_ERR_NOMEM, "shn_count_k1mers: out of device memory for the chunk tables");
+  }
+  uint64_t at = 0;
+  for (shn_table* t : parts) {
+    if (t->n) {
+      hipMemcpyAsync(pk + at, t->d_keys, t->n * 8, hipMemcpyDeviceToDevice, s);
+      hipMemcpyAsync(pc + at, t->d_counts, t->n * 4, hipMemcpyDeviceToDevice, s);
+    }
+    at += t->n;
+  }
+  hipStreamSynchronize(s);
+  drop();
+  int rc = shn_table_from_pairs(ctx, pk, pc, np, k1, both_strands ? 1 : 0, out);
+  hipStreamSynchronize(s);
+  shn_dev_free(pk); shn_dev_free(pc);
+  return rc;
+}
+
+static int count_views(shn_ctx* ctx, const std::vector<ReadsView>& views, uint64_t upper, int k1, int both_strands, shn_table** out) {
+  hipStream_t s = ctx->stream;
   // One-pass path first (see count_direct_kernel): worth it when the table is small next to the windows; the size is a
   // guess (windows / 32, at most 2^24 slots to begin with) corrected by what earlier calls of this process needed.
   {

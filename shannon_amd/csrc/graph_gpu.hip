@@ -281,6 +281,28 @@ __global__ void ug_edges_kernel(const uint32_t* __restrict__ flag, const uint64_
   }
 }
 
+// out-degree of a chain's last K-mer, recorded at its head
+__global__ void ug_tail_out_kernel(const uint32_t* __restrict__ jump, const uint32_t* __restrict__ dist, const uint32_t* __restrict__ clen,
+                                   const uint32_t* __restrict__ pred, const uint32_t* __restrict__ outdeg, uint64_t nn, uint32_t* __restrict__ tail_out) {
+  UG_FOR(u, nn) { const uint32_t h = jump[u]; if (pred[h] == UG_NONE && dist[u] + 1 == clen[h]) tail_out[h] = outdeg[u]; }
+}
+// the final nodes (chain heads) compacted in K-mer id order = partition by partition
+__global__ void ug_head_compact_kernel(const uint32_t* __restrict__ hflag, const uint64_t* __restrict__ hpos, const uint64_t* __restrict__ stamp,
+                                       const uint64_t* __restrict__ thead, const uint64_t* __restrict__ ttail, const uint32_t* __restrict__ clen,
+                                       const uint32_t* __restrict__ tail_out, const uint32_t* __restrict__ part_of_node, const uint64_t* __restrict__ boff,
+                                       uint64_t nn, uint64_t* __restrict__ o_stamp, uint64_t* __restrict__ o_thead, uint64_t* __restrict__ o_ttail,
+                                       uint32_t* __restrict__ o_clen, uint32_t* __restrict__ o_tail_out, uint32_t* __restrict__ o_part, uint64_t* __restrict__ o_boff) {
+  UG_FOR(u, nn) if (hflag[u]) {
+    const uint64_t i = hpos[u];
+    o_stamp[i] = stamp[u]; o_thead[i] = thead[u]; o_ttail[i] = ttail[u]; o_clen[i] = clen[u]; o_tail_out[i] = tail_out[u];
+    o_part[i] = part_of_node[u]; o_boff[i] = boff[u];
+  }
+}
+// edges as (compact head index of the source chain, of the destination chain)
+__global__ void ug_edge_heads_kernel(uint32_t* __restrict__ e_src, uint32_t* __restrict__ e_dst, const uint64_t* __restrict__ hpos, uint64_t ne) {
+  UG_FOR(x, ne) { e_src[x] = (uint32_t)hpos[e_src[x]]; e_dst[x] = (uint32_t)hpos[e_dst[x]]; }
+}
+
 }  // namespace
 
 extern "C" void shn_unitigs_destroy(shn_unitigs* u) { delete u; }
@@ -464,37 +486,41 @@ extern "C" int shn_unitigs_build(shn_ctx* ctx, const uint8_t* bases, const uint6
     HIP_TRY(B.get(&d_esrc, ne * 4)); HIP_TRY(B.get(&d_edst, ne * 4));
     hipLaunchKernelGGL(ug_edges_kernel, dim3(ug_grid(total)), dim3(UG_BLK), 0, s, d_eflag, d_epos, d_wslot, d_slot_node, jump, total, d_esrc, d_edst);
   }
-  // download: per K-mer node the arrays the host needs to assemble the partitions
-  std::vector<uint32_t> h_hflag(nn), h_clen(nn), h_outdeg(nn), h_part(nn), h_jump(nn), h_dist(nn), h_esrc(ne), h_edst(ne), h_succ(nn);
-  std::vector<uint64_t> h_stamp(nn), h_thead(nn), h_ttail(nn), h_boff(nn + 1);
+  // the final nodes' records, compacted on the device (chain heads in K-mer id order, i.e. partition by partition)
+  uint32_t *d_tail_out, *d_oclen, *d_otail, *d_opart; uint64_t *d_ostamp, *d_othead, *d_ottail, *d_oboff;
+  HIP_TRY(B.get(&d_tail_out, nn * 4));
+  HIP_TRY(hipMemsetAsync(d_tail_out, 0, nn * 4, s));
+  hipLaunchKernelGGL(ug_tail_out_kernel, dim3(ug_grid(nn)), dim3(UG_BLK), 0, s, jump, dist, d_clen, d_pred, d_outdeg, nn, d_tail_out);
+  HIP_TRY(B.get(&d_oclen, (nf + 1) * 4)); HIP_TRY(B.get(&d_otail, (nf + 1) * 4)); HIP_TRY(B.get(&d_opart, (nf + 1) * 4));
+  HIP_TRY(B.get(&d_ostamp, (nf + 1) * 8)); HIP_TRY(B.get(&d_othead, (nf + 1) * 8)); HIP_TRY(B.get(&d_ottail, (nf + 1) * 8)); HIP_TRY(B.get(&d_oboff, (nf + 1) * 8));
+  hipLaunchKernelGGL(ug_head_compact_kernel, dim3(ug_grid(nn)), dim3(UG_BLK), 0, s, d_hflag, d_hpos, d_fin_stamp, d_fin_thead, d_fin_ttail, d_clen, d_tail_out,
+                     d_node_part, d_boff, nn, d_ostamp, d_othead, d_ottail, d_oclen, d_otail, d_opart, d_oboff);
+  if (ne) hipLaunchKernelGGL(ug_edge_heads_kernel, dim3(ug_grid(ne)), dim3(UG_BLK), 0, s, d_esrc, d_edst, d_hpos, ne);
+  std::vector<uint32_t> h_clen(nf), tail_out(nf), h_part(nf), h_esrc(ne), h_edst(ne);
+  std::vector<uint64_t> h_stamp(nf), h_thead(nf), h_ttail(nf), h_boff(nf);
   std::string obases(nb, '\0');
-  HIP_TRY(hipMemcpyAsync(h_hflag.data(), d_hflag, nn * 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(h_clen.data(), d_clen, nn * 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(h_outdeg.data(), d_outdeg, nn * 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(h_part.data(), d_node_part, nn * 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(h_jump.data(), jump, nn * 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(h_dist.data(), dist, nn * 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(h_stamp.data(), d_fin_stamp, nn * 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(h_thead.data(), d_fin_thead, nn * 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(h_ttail.data(), d_fin_ttail, nn * 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(h_boff.data(), d_boff, (nn + 1) * 8, hipMemcpyDeviceToHost, s));
+  if (nf) {
+    HIP_TRY(hipMemcpyAsync(h_clen.data(), d_oclen, nf * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(tail_out.data(), d_otail, nf * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h_part.data(), d_opart, nf * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h_stamp.data(), d_ostamp, nf * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h_thead.data(), d_othead, nf * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h_ttail.data(), d_ottail, nf * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(h_boff.data(), d_oboff, nf * 8, hipMemcpyDeviceToHost, s));
+  }
   if (nb) HIP_TRY(hipMemcpyAsync(&obases[0], d_obases, nb, hipMemcpyDeviceToHost, s));
   if (ne) { HIP_TRY(hipMemcpyAsync(h_esrc.data(), d_esrc, ne * 4, hipMemcpyDeviceToHost, s)); HIP_TRY(hipMemcpyAsync(h_edst.data(), d_edst, ne * 4, hipMemcpyDeviceToHost, s)); }
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipGetLastError());
   lap("products + download");
-  // ---- host: final nodes of every partition in creation order, edges with their list ranks
-  // tail out-degree of a chain: the out-degree of its last K-mer = head + (len - 1) along the chain; the last K-mer is the
-  // one with dist == len - 1: found through the K-mer list
-  std::vector<uint32_t> tail_out(nn, 0);
-  for (uint64_t u = 0; u < nn; u++) { const uint32_t h = h_jump[u]; if (h_hflag[h] && h_dist[u] + 1 == h_clen[h]) tail_out[h] = h_outdeg[u]; }
+  // ---- host: final nodes of every partition in creation order, edges with their list ranks (everything below is indexed
+  // by compact head index: heads come partition by partition)
   std::vector<uint64_t> heads_of_part_off(n_parts + 1, 0);
-  for (uint64_t u = 0; u < nn; u++) if (h_hflag[u]) heads_of_part_off[h_part[u] + 1]++;
+  for (uint64_t i = 0; i < nf; i++) heads_of_part_off[h_part[i] + 1]++;
   for (uint32_t p = 0; p < n_parts; p++) heads_of_part_off[p + 1] += heads_of_part_off[p];
   std::vector<uint32_t> heads(nf);
-  { std::vector<uint64_t> curp(heads_of_part_off.begin(), heads_of_part_off.end() - 1);
-    for (uint64_t u = 0; u < nn; u++) if (h_hflag[u]) heads[curp[h_part[u]]++] = (uint32_t)u; }
-  std::vector<uint32_t> local_of(nn, UG_NONE);           // chain head -> index among its partition's final nodes
+  for (uint64_t i = 0; i < nf; i++) heads[i] = (uint32_t)i;
+  std::vector<uint32_t> local_of(nf, UG_NONE);           // compact head index -> index among its partition's final nodes
   U->n_len.resize(nf); U->n_tail_out.resize(nf); U->base_off.assign(nf + 1, 0);
   U->bases.resize(nb);
   uint64_t bat = 0;

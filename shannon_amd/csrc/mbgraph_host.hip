@@ -8,6 +8,7 @@
 #include <atomic>
 #include "flatmap.h"
 #include "unitigs.h"
+#include "graph_result.h"
 #include <thread>
 #include <mutex>
 #include <string>
@@ -738,16 +739,6 @@ struct Graph {
 
 }  // namespace
 
-struct shn_graph {
-  // flattened output_components (multibridging.py:271-325)
-  std::vector<uint64_t> s_off; std::string s_bases; std::vector<double> s_cc, s_norm;
-  std::vector<uint64_t> comp_node_off, comp_edge_off, comp_path_off;
-  std::vector<uint64_t> n_off; std::string n_bases; std::vector<double> n_cc, n_norm; std::vector<uint8_t> n_cc_int;
-  std::vector<int32_t> e_in, e_out, e_w; std::vector<double> e_cc, e_norm;
-  std::vector<uint64_t> p_off; std::vector<int32_t> p_ids;
-  std::vector<int32_t> info;   // nodes_after[4], final_nodes, n_known, n_mate, n_bridged_rounds, bridged...
-};
-
 extern "C" void shn_graph_destroy(shn_graph* g) { delete g; }
 
 // rows: n_rows k1-mers of K+1 bytes each (file order of component{c}k1mers_allowed.dict); reads: ASCII,
@@ -1109,5 +1100,27 @@ extern "C" int shn_graph_export(const shn_graph* g, uint64_t* s_off, uint8_t* s_
   CP(e_in, g->e_in); CP(e_out, g->e_out); CP(e_w, g->e_w); CP(e_cc, g->e_cc); CP(e_norm, g->e_norm);
   CP(p_off, g->p_off); CP(p_ids, g->p_ids); CP(info, g->info);
 #undef CP
+  return SHN_OK;
+}
+
+// The inverse of shn_graph_export: a shn_graph from flattened component tables (sizes[9] as shn_graph_sizes; arrays as
+// shn_graph_export, info may be NULL) -- lets the native sparse-flow stage run on tables that did not come from
+// shn_mbgraph_run (the reference's own nodes / edges / paths files in the tests).
+extern "C" int shn_graph_from_tables(const uint64_t* sizes, const uint64_t* s_off, const uint8_t* s_bases, const double* s_cc, const double* s_norm,
+                                     const uint64_t* comp_node_off, const uint64_t* comp_edge_off, const uint64_t* comp_path_off, const uint64_t* n_off,
+                                     const uint8_t* n_bases, const double* n_cc, const uint8_t* n_cc_int, const double* n_norm, const int32_t* e_in,
+                                     const int32_t* e_out, const int32_t* e_w, const double* e_cc, const double* e_norm, const uint64_t* p_off,
+                                     const int32_t* p_ids, shn_graph** out) {
+  if (!sizes || !out) return shn_fail(SHN_ERR_ARG, "shn_graph_from_tables: NULL argument");
+  shn_graph* g = new shn_graph();
+  const uint64_t ns = sizes[0], sb = sizes[1], nc = sizes[2], nn = sizes[3], nb = sizes[4], ne = sizes[5], np = sizes[6], npid = sizes[7];
+  g->s_off.assign(s_off, s_off + ns + 1); g->s_bases.assign((const char*)s_bases, sb); g->s_cc.assign(s_cc, s_cc + ns); g->s_norm.assign(s_norm, s_norm + ns);
+  g->comp_node_off.assign(comp_node_off, comp_node_off + nc + 1); g->comp_edge_off.assign(comp_edge_off, comp_edge_off + nc + 1);
+  g->comp_path_off.assign(comp_path_off, comp_path_off + nc + 1);
+  g->n_off.assign(n_off, n_off + nn + 1); g->n_bases.assign((const char*)n_bases, nb); g->n_cc.assign(n_cc, n_cc + nn); g->n_norm.assign(n_norm, n_norm + nn);
+  g->n_cc_int.assign(n_cc_int, n_cc_int + nn);
+  g->e_in.assign(e_in, e_in + ne); g->e_out.assign(e_out, e_out + ne); g->e_w.assign(e_w, e_w + ne); g->e_cc.assign(e_cc, e_cc + ne); g->e_norm.assign(e_norm, e_norm + ne);
+  g->p_off.assign(p_off, p_off + np + 1); g->p_ids.assign(p_ids, p_ids + npid);
+  *out = g;
   return SHN_OK;
 }

@@ -47,22 +47,34 @@ class Unitigs(object):
             pass
 
 
-def run_partition_arrays(rows_bytes, n_rows, K, r1_buf, r1_off, r2_buf=None, r2_off=None, ctx=None, enc=0, rc1=None, rc2=None, unitigs=None,
-                         part=0):
-    """rows_bytes: uint8 array of n_rows*(K+1) bases; reads as (byte buffer, offsets).  unitigs / part: the partition's
-    K-mer graph already contracted on the GPU (rows_bytes may then be None).  Returns
-    (singles, comps, info) in the format of mbgraph.output_components."""
+class GraphHandle(object):
+    """The multibridged graph of one partition as the native object (shn_graph): exported to Python tables on demand,
+    consumed in place by the native sparse-flow stage (sparse_flow_native)."""
+
+    def __init__(self, h):
+        self.h = h
+        self._tables = None
+
+    def tables(self):
+        """(singles, comps, log) in the format of mbgraph.output_components"""
+        if self._tables is None:
+            self._tables = _export(self.h)
+        return self._tables
+
+    def close(self):
+        if self.h:
+            _lib.lib().shn_graph_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _export(h):
     L = _lib.lib()
-    h = C.c_void_p()
-    n_reads = len(r1_off) - 1
-    paired = r2_buf is not None
-    rows_ptr = rows_bytes.ctypes.data if rows_bytes is not None else None
-    tail = (r1_buf.ctypes.data, r1_off.ctypes.data, r2_buf.ctypes.data if paired else None, r2_off.ctypes.data if paired else None, n_reads,
-            1 if paired else 0, enc, rc1.ctypes.data if rc1 is not None else None, rc2.ctypes.data if rc2 is not None else None, C.byref(h))
-    if unitigs is not None:
-        _lib.check(L.shn_mbgraph_run_unitigs(ctx.h if ctx is not None else None, unitigs.h, int(part), rows_ptr, n_rows if rows_bytes is not None else 0, *tail))
-    else:
-        _lib.check(L.shn_mbgraph_run(ctx.h if ctx is not None else None, K, rows_ptr, n_rows, *tail))
     sz = np.zeros(9, dtype=np.uint64)
     _lib.check(L.shn_graph_sizes(h, sz.ctypes.data_as(_lib.u64p)))
     ns, sb, nc, nn, nb, ne, npth, npid, ninfo = [int(x) for x in sz]
@@ -77,7 +89,6 @@ def run_partition_arrays(rows_bytes, n_rows, K, r1_buf, r1_off, r2_buf=None, r2_
     arrs = [s_off, s_bases, s_cc, s_norm, cno, ceo, cpo, n_off, n_bases, n_cc, n_cci, n_norm, e_in, e_out, e_w, e_cc, e_norm,
             p_off, p_ids, info]
     _lib.check(L.shn_graph_export(h, *[a.ctypes.data for a in arrs]))
-    L.shn_graph_destroy(h)
     sbs = s_bases.tobytes().decode()
     singles = [(-1, sbs[int(s_off[i]):int(s_off[i + 1])], 0 if s_cc[i] == 0 else float(s_cc[i]), int(s_norm[i])) for i in range(ns)]
     nbs = n_bases.tobytes().decode()
@@ -92,8 +103,93 @@ def run_partition_arrays(rows_bytes, n_rows, K, r1_buf, r1_off, r2_buf=None, r2_
         paths = [p_ids[int(p_off[i]):int(p_off[i + 1])].tolist() for i in range(pa, pb)]
         comps.append({"nodes": nodes, "edges": edges, "paths": paths})
     inf = info.tolist()
-    log = {"nodes_after": inf[:4], "final_nodes": inf[4], "known_paths": inf[5], "mate_paths": inf[6], "bridged": inf[8:8 + inf[7]]}
+    log = ({"nodes_after": inf[:4], "final_nodes": inf[4], "known_paths": inf[5], "mate_paths": inf[6], "bridged": inf[8:8 + inf[7]]}
+           if ninfo >= 8 else {})
     return singles, comps, log
+
+
+def graph_from_tables(singles, comps):
+    """GraphHandle from Python tables (the inverse of GraphHandle.tables): [(id, bases, cc, norm)] single rows and
+    [{"nodes": [(id, bases, cc, norm)], "edges": [(in, out, w, cc, norm)], "paths": [[ids]]}] components
+    (shn_graph_from_tables) -- e.g. the reference's own nodes / edges / paths files."""
+    u64, f64, i32, u8 = np.uint64, np.float64, np.int32, np.uint8
+    sb = "".join(r[1] for r in singles).encode()
+    s_off = np.zeros(len(singles) + 1, u64)
+    s_off[1:] = np.cumsum([len(r[1]) for r in singles], dtype=u64) if singles else []
+    s_cc = np.array([float(r[2]) for r in singles] + [0.0], f64)
+    s_norm = np.array([float(r[3]) for r in singles] + [0.0], f64)
+    cno, ceo, cpo, n_len, nb, n_cc, n_cci, n_norm = [0], [0], [0], [], [], [], [], []
+    e_in, e_out, e_w, e_cc, e_norm, p_off, p_ids = [], [], [], [], [], [0], []
+    for comp in comps:
+        for _id, bases, cc, norm in comp["nodes"]:
+            nb.append(bases); n_len.append(len(bases)); n_cc.append(float(cc)); n_norm.append(float(norm))
+            n_cci.append(1 if (isinstance(cc, int) and cc == 0) else 0)
+        for a, b, w, cc, norm in comp["edges"]:
+            e_in.append(int(a)); e_out.append(int(b)); e_w.append(int(w)); e_cc.append(float(cc)); e_norm.append(float(norm))
+        for pth in comp["paths"]:
+            p_ids += [int(x) for x in pth]
+            p_off.append(len(p_ids))
+        cno.append(len(n_len)); ceo.append(len(e_in)); cpo.append(len(p_off) - 1)
+    nbb = "".join(nb).encode()
+    n_off = np.zeros(len(n_len) + 1, u64)
+    if n_len:
+        n_off[1:] = np.cumsum(n_len, dtype=u64)
+    sizes = np.array([len(singles), len(sb), len(comps), len(n_len), len(nbb), len(e_in), len(p_off) - 1, len(p_ids), 0], u64)
+    arrs = [sizes, s_off, np.frombuffer(sb + b"\0", u8), s_cc, s_norm, np.array(cno, u64), np.array(ceo, u64), np.array(cpo, u64), n_off,
+            np.frombuffer(nbb + b"\0", u8), np.array(n_cc + [0.0], f64), np.array(n_cci + [0], u8), np.array(n_norm + [0.0], f64),
+            np.array(e_in + [0], i32), np.array(e_out + [0], i32), np.array(e_w + [0], i32), np.array(e_cc + [0.0], f64),
+            np.array(e_norm + [0.0], f64), np.array(p_off, u64), np.array(p_ids + [0], i32)]
+    h = C.c_void_p()
+    _lib.check(_lib.lib().shn_graph_from_tables(*[a.ctypes.data for a in arrs], C.byref(h)))
+    return GraphHandle(h)
+
+
+def sparse_flow_native(ctx, graphs, snames, seed):
+    """The native sparse-flow stage (shn_sparse_flow) over the graphs of several partitions: [reconstructed FASTA text]."""
+    if not graphs:
+        return []
+    arr = (C.c_void_p * len(graphs))(*[g.h for g in graphs])
+    names = (C.c_char_p * len(graphs))(*[s.encode() for s in snames])
+    h = C.c_void_p()
+    _lib.check(_lib.lib().shn_sparse_flow(ctx.h, arr, len(graphs), names, C.c_uint64(int(seed)), C.byref(h)))
+    try:
+        out = []
+        for i in range(len(graphs)):
+            n = int(_lib.lib().shn_sflow_text_size(h, i))
+            buf = np.empty(max(n, 1), np.uint8)
+            if n:
+                _lib.check(_lib.lib().shn_sflow_text(h, i, buf.ctypes.data))
+            out.append(buf[:n].tobytes().decode())
+        return out
+    finally:
+        _lib.lib().shn_sflow_destroy(h)
+
+
+def run_partition_handle(rows_bytes, n_rows, K, r1_buf, r1_off, r2_buf=None, r2_off=None, ctx=None, enc=0, rc1=None, rc2=None, unitigs=None,
+                         part=0):
+    """rows_bytes: uint8 array of n_rows*(K+1) bases; reads as (byte buffer, offsets).  unitigs / part: the partition's
+    K-mer graph already contracted on the GPU (rows_bytes may then be None).  Returns the GraphHandle."""
+    L = _lib.lib()
+    h = C.c_void_p()
+    n_reads = len(r1_off) - 1
+    paired = r2_buf is not None
+    rows_ptr = rows_bytes.ctypes.data if rows_bytes is not None else None
+    tail = (r1_buf.ctypes.data, r1_off.ctypes.data, r2_buf.ctypes.data if paired else None, r2_off.ctypes.data if paired else None, n_reads,
+            1 if paired else 0, enc, rc1.ctypes.data if rc1 is not None else None, rc2.ctypes.data if rc2 is not None else None, C.byref(h))
+    if unitigs is not None:
+        _lib.check(L.shn_mbgraph_run_unitigs(ctx.h if ctx is not None else None, unitigs.h, int(part), rows_ptr, n_rows if rows_bytes is not None else 0, *tail))
+    else:
+        _lib.check(L.shn_mbgraph_run(ctx.h if ctx is not None else None, K, rows_ptr, n_rows, *tail))
+    return GraphHandle(h)
+
+
+def run_partition_arrays(*args, **kw):
+    """run_partition_handle + tables: (singles, comps, info) in the format of mbgraph.output_components."""
+    g = run_partition_handle(*args, **kw)
+    try:
+        return g.tables()
+    finally:
+        g.close()
 
 
 def run_partition(k1mer_rows, reads, K, paired=False, ctx=None):

@@ -13,6 +13,22 @@ class Result(object):
     pass
 
 
+class PartitionRecord(dict):
+    """Record of one partition: n_reads_routed, n_k1mers, reconstructed_fasta as plain entries; `singles`, `components`
+    and `log` (the tables of mbgraph.output_components) are exported from the native graph object on first access."""
+
+    def __init__(self, n_reads_routed, n_k1mers, graph):
+        dict.__init__(self, n_reads_routed=n_reads_routed, n_k1mers=n_k1mers)
+        self.graph = graph
+
+    def __missing__(self, key):
+        if key in ("singles", "components", "log") and self.graph is not None:
+            singles, comps, log = self.graph.tables()
+            dict.update(self, singles=singles, components=comps, log=log)
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+
 def n_kmer_nodes(rows, K):
     """#distinct K-mers among the k1-mer rows = len(Node.nodes) after loading (multibridging.py:383)."""
     s = set()
@@ -118,17 +134,18 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
             # the sequential code) and for the development check SHN_GRAPH_CHECK=1
             rb = rows_now() if (unitigs is None or check_rows) else None
             try:
-                singles, comps, glog = mbgraph_native.run_partition_arrays(None if rb is None else (rb if len(rb) else np.zeros(1, np.uint8)),
-                                                                           0 if rb is None else len(rb) // (K + 1), K, b1, o1, b2, o2, ctx=ctx,
-                                                                           enc=enc, rc1=rc1, rc2=rc2, unitigs=unitigs, part=part_index[name])
+                gh = mbgraph_native.run_partition_handle(None if rb is None else (rb if len(rb) else np.zeros(1, np.uint8)),
+                                                         0 if rb is None else len(rb) // (K + 1), K, b1, o1, b2, o2, ctx=ctx,
+                                                         enc=enc, rc1=rc1, rc2=rc2, unitigs=unitigs, part=part_index[name])
             except _lib.ShannonError as ex:
                 if rb is not None or "needs the k1-mer rows" not in str(ex):
                     raise
                 rb = rows_now()
-                singles, comps, glog = mbgraph_native.run_partition_arrays(rb if len(rb) else np.zeros(1, np.uint8), len(rb) // (K + 1), K, b1, o1, b2,
-                                                                           o2, ctx=ctx, enc=enc, rc1=rc1, rc2=rc2, unitigs=unitigs,
-                                                                           part=part_index[name])
+                gh = mbgraph_native.run_partition_handle(rb if len(rb) else np.zeros(1, np.uint8), len(rb) // (K + 1), K, b1, o1, b2,
+                                                         o2, ctx=ctx, enc=enc, rc1=rc1, rc2=rc2, unitigs=unitigs, part=part_index[name])
             n_rows = part["n_k1mer_rows"][name]
+            tt["graph"] = time.time() - t0
+            return PartitionRecord(len(part["routes"][name]), n_rows, gh), tt
         else:
             rows = part["k1mers"][name]
             r1 = [store.mate1(int(d)) for d in idx]
@@ -161,8 +178,24 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
         for k_, v in tt.items():                                      # wall time of the stage, split like the thread time
             T[k_] = T.get(k_, 0.0) + v * wall / busy
         R.partitions[name] = rec
-        sf_jobs.append((name, rec["singles"], rec["components"]))
     t0 = time.time()
+    if native_graph and os.environ.get("SHN_SFLOW_NATIVE", "1") != "0":
+        # all components of all partitions through the native sparse-flow stage (shn_sparse_flow) in one call; the graphs
+        # stay native objects (exported to Python tables only if somebody asks a PartitionRecord for them)
+        texts = mbgraph_native.sparse_flow_native(ctx, [R.partitions[nm].graph for nm in names], ["%s_%s" % (sample, nm) for nm in names], seed)
+        for name, txt in zip(names, texts):
+            R.partitions[name]["reconstructed_fasta"] = txt
+            lines += txt.splitlines(True)
+        tick("sparse flow", t0)
+        t0 = time.time()
+        R.all_reconstructed = lines
+        R.final = post.finalize(lines, double_stranded)
+        tick("post", t0)
+        R.timings = T
+        return R
+    for name in names:
+        rec = R.partitions[name]
+        sf_jobs.append((name, rec["singles"], rec["components"]))
     flat = [(nd["nodes"], nd["edges"], nd["paths"]) for _, _, comps in sf_jobs for nd in comps]
     # component c of partition p uses RNG stream id = its index within the partition (as one
     # algorithm_SF.py process per component, run_MB_SF_fn.py:242-250)

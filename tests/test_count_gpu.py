@@ -130,3 +130,41 @@ def test_one_pass_counting_equals_the_partition_pipeline(both, with_n, log2, mon
         t0.close(); t1.close(); d.close()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("chunk,ragged", [(700000, False), (123457, False), (250000, True)])
+def test_chunked_counting_equals_one_pass_over_all_reads(chunk, ragged, monkeypatch):
+    """Beyond 2^31 windows (BASELINE configs[2]: 7.5 G) the reads are counted chunk by chunk and the chunk tables are reduced by
+    key; forced here with a small chunk, over two read sets, fixed-length and ragged reads, with N bases."""
+    from shannon_amd import device
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 4, 5000, dtype=np.uint8)
+    sets_np = []
+    for n in (9000, 6000):
+        starts = rng.integers(0, len(base) - 100, n)
+        reads = base[starts[:, None] + np.arange(100)]
+        err = rng.random(reads.shape) < 0.01
+        reads = np.where(err, (reads + rng.integers(1, 4, reads.shape)) & 3, reads).astype(np.uint8)
+        reads[rng.random(reads.shape) < 0.001] = 4
+        sets_np.append(reads)
+    ctx = device.Context(0)
+    try:
+        if ragged:
+            A = np.frombuffer(b"ACGTN", np.uint8)
+            ds = [device.Reads.from_strings(ctx, [A[r[: 60 + (i * 7) % 41]].tobytes().decode() for i, r in enumerate(m)]) for m in sets_np]
+        else:
+            ds = [device.Reads.from_codes(ctx, m) for m in sets_np]
+        monkeypatch.setenv("SHN_COUNT_DIRECT", "0")
+        t0 = device.count_k1mers(ctx, ds, 26, True)
+        monkeypatch.setenv("SHN_COUNT_CHUNK", str(chunk))
+        t1 = device.count_k1mers(ctx, ds, 26, True)
+        k0, c0 = t0.download()
+        k1, c1 = t1.download()
+        o0, o1 = np.argsort(k0), np.argsort(k1)
+        assert np.array_equal(k0[o0], k1[o1]) and np.array_equal(c0[o0], c1[o1]) and t0.total == t1.total
+        for t in (t0, t1):
+            t.close()
+        for d in ds:
+            d.close()
+    finally:
+        ctx.close()
