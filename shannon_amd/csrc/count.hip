@@ -669,7 +669,7 @@ static int count_views(shn_ctx* ctx, const std::vector<ReadsView>& views, uint64
   // bits_n: enough buckets if every window were a distinct key (the histogram pass runs at this resolution);
   // the final number of buckets follows the HyperLogLog estimate of the distinct keys and only grows on overflow
   int bits_n = 0;
-  while (bits_n < 24 && (upper >> bits_n) > TARGET_BUCKET) bits_n++;
+  while (bits_n < 23 && (upper >> bits_n) > TARGET_BUCKET) bits_n++;
   int bits = -1;                                  // chosen after the first histogram pass
   int bits_hist = -1;                             // resolution of the histogram held in h1_fine
   std::vector<uint64_t> h1_fine;
@@ -749,7 +749,7 @@ static int count_views(shn_ctx* ctx, const std::vector<ReadsView>& views, uint64
     if (!ov) return SHN_OK;
     shn_table_destroy(*out);
     *out = nullptr;
-    bits = std::min(24, bits + 2);
+    bits = std::min(23, bits + 2);
   }
   return shn_fail(SHN_ERR_OVERFLOW, "shn_count_k1mers: a final bucket exceeded the LDS hash capacity after 4 attempts");
 }
@@ -919,7 +919,7 @@ extern "C" int shn_table_from_pairs(shn_ctx* ctx, const void* dev_keys, const vo
   // the adjacency, routing and seed kernels are made of lookups
   int bits = 0;
   const uint64_t per_bucket = getenv("SHN_TABLE_BUCKET") ? strtoull(getenv("SHN_TABLE_BUCKET"), nullptr, 10) : 96;
-  while (bits < 24 && (n >> bits) > per_bucket) bits++;
+  while (bits < 23 && (n >> bits) > per_bucket) bits++;        // (2^24 buckets x 256 threads would be 2^32 work-items: one too many for a dispatch)
   for (int attempt = 0; attempt < 4; attempt++) {
     int b1 = (bits + 1) / 2, b2 = bits - b1;
     int nb1 = 1 << b1;
@@ -968,7 +968,7 @@ extern "C" int shn_table_from_pairs(shn_ctx* ctx, const void* dev_keys, const vo
     if (!ov) return SHN_OK;
     shn_table_destroy(*out);
     *out = nullptr;
-    bits = std::min(24, bits + 2);
+    bits = std::min(23, bits + 2);
   }
   return shn_fail(SHN_ERR_OVERFLOW, "shn_table_from_pairs: bucket overflow after 4 attempts");
 }

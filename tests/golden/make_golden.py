@@ -93,36 +93,74 @@ def slim(art, keep_full):
     return out
 
 
+OUT = HERE           # --check writes to a scratch directory instead and compares
+ONLY = None          # --only a,b: just these cases
+
+
 def save(name, obj):
-    with gzip.open(os.path.join(HERE, name + ".json.gz"), "wt") as f:
-        json.dump(obj, f)
+    with gzip.GzipFile(os.path.join(OUT, name + ".json.gz"), "wb", mtime=0) as f:
+        f.write(json.dumps(obj).encode())
+
+
+def rcc(a):
+    return (3 - a[::-1]).astype(np.uint8)
+
+
+def hairpin_transcriptome(seed):
+    """A gene whose transcript holds an inverted repeat X s Q rc(Q) rc(s) rc(X), with the palindromic middle Q rc(Q) (120 bp, longer
+    than a read: an X-node no read bridges) shared with a second gene.  The reference pairs every read with its own reverse
+    complement (shannon.py:413-424 as written), so find_mate_pairs (mbgraph.py:114-160) only finds a path when a read and its
+    reverse complement lie on the same strand's graph -- here they do: last node of the read's path, the shared middle, first node
+    of the reverse complement's path.  Plus two ordinary tricky genes."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    r = lambda n: rng.integers(0, 4, n, dtype=np.uint8)
+    X, s1, Q, A, B, C, D = r(130), r(20), r(60), r(160), r(160), r(200), r(200)
+    M = np.concatenate([Q, rcc(Q)])
+    H = np.concatenate([X, s1, M, rcc(s1), rcc(X)])
+    return [np.concatenate([A, H, B]), np.concatenate([C, M, D])] + tricky_transcriptome(seed + 1, 2)
 
 
 def main():
+    global OUT, ONLY
+    check = "--check" in sys.argv
+    if "--only" in sys.argv:
+        ONLY = set(sys.argv[sys.argv.index("--only") + 1].split(","))
+    if check:
+        OUT = os.path.join(TMP + "_check")
+        shutil.rmtree(OUT, ignore_errors=True)
+        os.makedirs(os.path.join(OUT, "data"))
+    want = lambda name: ONLY is None or name in ONLY
     shutil.rmtree(TMP, ignore_errors=True)
     os.makedirs(TMP)
-    os.makedirs(os.path.join(HERE, "data"), exist_ok=True)
+    os.makedirs(os.path.join(OUT, "data"), exist_ok=True)
     # --- the reference's own sample inputs (data files, copied as fixtures)
     for fn in ("SE_read.fasta", "PE_read_1.fasta", "PE_read_2.fasta"):
-        with open(os.path.join(H.REF, "Samples", fn), "rb") as f, gzip.open(os.path.join(HERE, "data", fn + ".gz"), "wb") as g:
+        with open(os.path.join(H.REF, "Samples", fn), "rb") as f, gzip.GzipFile(os.path.join(OUT, "data", fn + ".gz"), "wb", mtime=0) as g:
             g.write(f.read())
     se = os.path.join(H.REF, "Samples", "SE_read.fasta")
     pe = [os.path.join(H.REF, "Samples", "PE_read_1.fasta"), os.path.join(H.REF, "Samples", "PE_read_2.fasta")]
     manifest = {}
     for name, files, K, paired in (("se_K24", [se], 24, False), ("se_K25", [se], 25, False), ("pe_K25", pe, 25, True)):
+        manifest[name] = {"inputs": [os.path.basename(f) + ".gz" for f in files], "K": K, "paired": paired, "sf_seed": 1}
+        if not want(name):
+            continue
         art = H.run_case(os.path.join(TMP, name), files, K, paired, run_sf=True, sf_seed=1)
         save(name, slim(art, keep_full=False))
-        manifest[name] = {"inputs": [os.path.basename(f) + ".gz" for f in files], "K": K, "paired": paired, "sf_seed": 1}
         print(name, "done", art["n_k1mers"])
     # --- synthetic cases
     syn = [("syn_pe_s0", 0, 2500, True, 25, 500), ("syn_se_s5", 5, 2500, False, 24, 500),
            ("syn_pe_s12", 12, 2500, True, 25, 500), ("syn_se_s21", 21, 2500, False, 24, 500),
            ("syn_pe_s20_K31", 20, 2500, True, 31, 500), ("syn_se_s7_K20", 7, 2500, False, 20, 500),
-           ("syn_part_s33", 33, 3000, True, 25, 1)]
+           ("syn_part_s33", 33, 3000, True, 25, 1),
+           # find_mate_pairs adds paths (mbgraph.py:151-160); the second one is a K=31 case with a multi-node partition
+           ("syn_pe_hairpin", 40, 4000, True, 25, 500), ("syn_pe_hairpin_K31", 41, 4000, True, 31, 500)]
     for name, seed, npairs, paired, K, psize in syn:
-        isos = tricky_transcriptome(seed, 3 if psize > 10 else 6)
+        manifest[name] = {"inputs": [name + ".npz"], "K": K, "paired": paired, "sf_seed": seed, "partition_size": psize}
+        if not want(name):
+            continue
+        isos = hairpin_transcriptome(seed) if "hairpin" in name else tricky_transcriptome(seed, 3 if psize > 10 else 6)
         r1, r2 = synth.sample_pairs(isos, npairs, seed, err=[0.005, 0.0, 0.01][seed % 3])
-        np.savez_compressed(os.path.join(HERE, "data", name + ".npz"), r1=r1, r2=r2)
+        np.savez_compressed(os.path.join(OUT, "data", name + ".npz"), r1=r1, r2=r2)
         d = os.path.join(TMP, name + "_in")
         os.makedirs(d)
         synth.write_fasta(d + "/r1.fasta", r1)
@@ -134,9 +172,10 @@ def main():
         art = H.run_case(os.path.join(TMP, name), [d + "/r1.fasta", d + "/r2.fasta"] if paired else [d + "/r1.fasta"],
                          K, paired, partition_size=psize, part_hook=hook, run_sf=True, sf_seed=seed)
         save(name, slim(art, keep_full=(name in ("syn_pe_s0", "syn_se_s7_K20"))))
-        manifest[name] = {"inputs": [name + ".npz"], "K": K, "paired": paired, "sf_seed": seed, "partition_size": psize}
         print(name, "done", art["n_k1mers"], {c: p["graph"] and len(p["graph"]["nodes"]) for c, p in art["partitions"].items()})
-    json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1)
+    json.dump(manifest, open(os.path.join(OUT, "manifest.json"), "w"), indent=1)
+    if ONLY is not None and "lp_kats" not in ONLY:
+        return finish_check(check)
     # --- LP known-answer cases through the reference's own path_decompose wrapper
     tref = H.prepare_translated(os.path.join(TMP, "lp", "tref"))
     code = r'''
@@ -186,9 +225,31 @@ for (a, b) in (([5., 7., 9.], [5., 16.]), ([5., 7., 9., 39.], [21., 11., 15., 13
     kats.append({"a": a, "b": b, "P": np.ones((m, n), dtype=int).tolist(), "seed": 1234, "pid": 1000 + m, "sparsity": 3, "answer": np.array(ans).tolist(), "non_unique": int(nu)})
 json.dump({"standins": "cvxopt stub + oracle.lp pinned LP rule and cost generator (NOT real cvxopt)", "kats": kats}, open(sys.argv[1], "w"))
 '''
-    H.run_py(tref, code, argv=[os.path.join(HERE, "lp_kats.json")])
+    H.run_py(tref, code, argv=[os.path.join(OUT, "lp_kats.json")])
     print("lp kats done")
+    return finish_check(check)
+
+
+def finish_check(check):
+    """--check: every regenerated artefact must equal the committed one (content of the gzip members, not their headers)"""
+    if not check:
+        return 0
+    bad = []
+    for root, _d, files in os.walk(OUT):
+        for fn in files:
+            new = os.path.join(root, fn)
+            old = os.path.join(HERE, os.path.relpath(new, OUT))
+            rd = (lambda p: gzip.open(p, "rb").read()) if fn.endswith(".gz") else (lambda p: open(p, "rb").read())
+            if fn.endswith(".npz"):
+                a, b = np.load(new), np.load(old) if os.path.exists(old) else None
+                same = b is not None and all(np.array_equal(a[k], b[k]) for k in a.files)
+            else:
+                same = os.path.exists(old) and rd(new) == rd(old)
+            if not same:
+                bad.append(os.path.relpath(new, OUT))
+    print("CHECK:", "all regenerated fixtures equal the committed ones" if not bad else "DIFFERENT: " + ", ".join(sorted(bad)))
+    return 1 if bad else 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

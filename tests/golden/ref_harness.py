@@ -106,6 +106,17 @@ def jellyfish_standin(reads_files, k1, out_path, lower=1):
     return cnt
 
 
+def _no_aslr():
+    """The reference iterates sets of Node / Edge / Read objects, i.e. in address order (mbgraph.py: Node.nodes, read sets):
+    node ids, edge line order and, for one fixture, the transcripts themselves then depend on where the allocator put things.
+    With address-space randomisation off (setarch -R) and a fixed PYTHONHASHSEED a run is reproducible, so the generator is
+    idempotent (make_golden.py --check).  SHN_GOLDEN_ASLR=keep runs without it."""
+    if os.environ.get("SHN_GOLDEN_ASLR") == "keep" or not shutil.which("setarch"):
+        return []
+    import platform
+    return ["setarch", platform.machine(), "-R"]
+
+
 def run_py(tref, code, cwd=None, env_extra=None, argv=()):
     env = dict(os.environ)
     env["PYTHONPATH"] = tref + os.pathsep + os.path.join(HERE, "cvxopt_stub") + os.pathsep + \
@@ -113,7 +124,7 @@ def run_py(tref, code, cwd=None, env_extra=None, argv=()):
     env.setdefault("PYTHONHASHSEED", "0")
     if env_extra:
         env.update(env_extra)
-    p = subprocess.run([sys.executable, "-W", "ignore", "-c", code, *argv], cwd=cwd, env=env,
+    p = subprocess.run(_no_aslr() + [sys.executable, "-W", "ignore", "-c", code, *argv], cwd=cwd, env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     if p.returncode != 0:
         raise RuntimeError("reference run failed:\n" + p.stdout[-3000:] + "\n" + p.stderr[-3000:])
@@ -164,7 +175,7 @@ def run_algorithm_sf(tref, prefix, comp, seed=0, comp_rng=0):
     env = dict(os.environ)
     env["PYTHONPATH"] = os.pathsep.join([tref, os.path.join(HERE, "cvxopt_stub"), os.path.dirname(os.path.dirname(HERE))])
     env.setdefault("PYTHONHASHSEED", "0")
-    p = subprocess.run([sys.executable, "-W", "ignore", os.path.join(HERE, "sf_runner.py"), tref, str(seed), str(comp_rng),
+    p = subprocess.run(_no_aslr() + [sys.executable, "-W", "ignore", os.path.join(HERE, "sf_runner.py"), tref, str(seed), str(comp_rng),
                         str(comp), prefix], cwd=os.path.dirname(prefix.rstrip("/")) or ".", env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     if p.returncode != 0:
