@@ -90,8 +90,12 @@ def _final_sha(final):
 
 
 def cpu_baseline(k1, r1, r2, n_pairs):
-    """The CPU restatement of the reference (oracle/, pure Python like Shannon itself, one host thread) over a
-    bounded sample of the same reads, full path a1-a31; plus the C restatement of the counting stage alone."""
+    """The CPU restatement of the reference over a bounded sample of the same batch, on this box's host cores (a reported
+    baseline, not the target).  `value`: the whole path a1-a31 through oracle/pipeline.py -- pure Python like Shannon itself, one
+    host thread.  `count_stage_threads`: the counting stage alone (the reference's Jellyfish, its only multi-threaded stage)
+    through the C restatement oracle/count_c.c on T host threads, one slice of reads each.  `contig_stage_native`: the sequential
+    duplicate_check + contig_connections loop (extension_correction.py:247-270, 358-397) in C++ on one core over the sample's own
+    candidate contigs is too small to time here; see DESIGN.md for its measured cost at full size (25 s)."""
     from oracle import pipeline as opipe, build_c
     A = np.frombuffer(b"ACGT", np.uint8)
     s1 = [A[r].tobytes().decode() for r in r1[:n_pairs]]
@@ -104,11 +108,29 @@ def cpu_baseline(k1, r1, r2, n_pairs):
     t = time.time()
     build_c.count_canonical(codes, k1, True)
     dtc = time.time() - t
-    return {"value": 2 * n_pairs / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+    # the same counting on T threads: T slices of 500k reads each (ctypes releases the GIL; the per-slice tables would still
+    # have to be merged, which Jellyfish's shared hash avoids -- so this is an upper bound of what T cores give the port)
+    from concurrent.futures import ThreadPoolExecutor
+    T = max(1, min(os.cpu_count() or 1, 32))
+    per = 250000
+    slices = [np.concatenate([r1[i * per:(i + 1) * per], r2[i * per:(i + 1) * per]]) for i in range(T) if (i + 1) * per <= len(r1)]
+    t = time.time()
+    with ThreadPoolExecutor(max_workers=len(slices) or 1) as pool:
+        list(pool.map(lambda c: build_c.count_canonical(c, k1, True), slices))
+    dtt = time.time() - t
+    cpu = ""
+    try:
+        cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except (OSError, IndexError):
+        pass
+    return {"value": 2 * n_pairs / dt, "unit": "reads/s", "cores": 1, "kind": "port", "cpu_model": cpu, "host_threads_available": os.cpu_count(),
             "sample": "first %d reads of the benchmark batch through oracle/pipeline.py (count -> extension -> partition -> graph -> "
                       "sparse flow -> merge), %.1f s" % (2 * n_pairs, dt),
             "count_stage_only": {"value": len(codes) / dtc, "unit": "reads/s", "cores": 1,
-                                 "sample": "%d reads, oracle/count_c.c (radix sort + run-length count), %.2f s" % (len(codes), dtc)}}
+                                 "sample": "%d reads, oracle/count_c.c (radix sort + run-length count), %.2f s" % (len(codes), dtc)},
+            "count_stage_threads": {"value": sum(len(c) for c in slices) / dtt if slices else None, "unit": "reads/s", "cores": len(slices),
+                                    "sample": "%d slices of %d reads, oracle/count_c.c on one host thread each (no merge), %.2f s"
+                                              % (len(slices), 2 * per, dtt)}}
 
 
 def main():
@@ -317,7 +339,9 @@ def main():
             "kernel_launches_per_step": {k: v[1] / args.steps for k, v in sorted(timers.items())},
         }
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 of the N=1 run only
-            out["cpu_baseline"] = cpu_baseline(k1, r1, r2, 75_000)        # ~11 s of one core + 1.4 s for the counting stage alone
+            # bounded sample: ~10-15 s of one core through the whole path (at configs[2] a read costs the pure-Python path ~5x more
+            # than at configs[1]: nearly every k1-mer of a 25k-read sample is new), + ~5 s for the counting stage alone / threaded
+            out["cpu_baseline"] = cpu_baseline(k1, r1, r2, 75_000 if args.config == 1 else 12_500)
         final_line = json.dumps(out)
     else:
         final_line = None

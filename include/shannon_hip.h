@@ -285,6 +285,17 @@ int shn_graph_export(const shn_graph* g, uint64_t* s_off, uint8_t* s_bases, doub
                      uint8_t* n_bases, double* n_cc, uint8_t* n_cc_int, double* n_norm, int32_t* e_in, int32_t* e_out,
                      int32_t* e_w, double* e_cc, double* e_norm, uint64_t* p_off, int32_t* p_ids, int32_t* info);
 
+/* shn_mbgraph_run_unitigs with the partition's reads known as rows of the resident input: src_a / src_b = the packed read sets of the
+ * run (src_b NULL for single-end), didx[i] = doubled read index of read i (the numbering of shn_route_reads).  The device copy of
+ * the distinct reads the seed scans need is then gathered from the resident sets (shn_reads_gather) instead of uploaded as text.  */
+int shn_mbgraph_run_resident(shn_ctx* ctx, const shn_unitigs* ug, uint32_t part, const uint8_t* rows, uint64_t n_rows, const shn_reads* src_a,
+                             const shn_reads* src_b, const uint32_t* didx, const uint8_t* r1, const uint64_t* r1_off, const uint8_t* r2,
+                             const uint64_t* r2_off, uint64_t n_reads, int paired, int enc, const uint8_t* rc1, const uint8_t* rc2,
+                             shn_graph** out);
+/* Rows of resident fixed-length read sets as a new read set: read i = row rows[i] of set a (flags[i] bit 0 clear) or b (set),
+ * reverse-complemented if bit 1 is set; the selected rows must hold ACGT only.                                                   */
+int shn_reads_gather(shn_ctx* ctx, const shn_reads* a, const shn_reads* b, const uint32_t* rows, const uint8_t* flags, uint64_t n,
+                     shn_reads** out);
 /* The inverse of shn_graph_export (sizes[9] as shn_graph_sizes; arrays as shn_graph_export without `info`): a graph object from
  * flattened nodes / edges / paths tables, e.g. the reference's own files.                                                       */
 int shn_graph_from_tables(const uint64_t* sizes, const uint64_t* s_off, const uint8_t* s_bases, const double* s_cc, const double* s_norm,

@@ -47,7 +47,7 @@ def main(argv):
     out_dir, reads, double_stranded = None, [], True
     min_weight, min_length = 3, 75                            # shannon.py:55-56
     i = 1
-    ignored = []
+    ignored, noted = [], []
     while i < len(argv):
         a = argv[i]
         if a in ("--help", "-h"):
@@ -73,9 +73,17 @@ def main(argv):
         if a in ("-s", "--ss", "--strand_specific"):
             # accepted by the reference CLI (shannon.py:166-207); this build only has the double-stranded path
             sys.exit("shannon.py: strand-specific input (%s) is not supported by this build (double-stranded reads only)" % a)
-        if a in ("--inMem", "--inDisk", "--fasta", "--fastq", "--only_reads"):
+        if a in ("--inMem", "--fasta", "--fastq"):
             i += 1; continue
-        if a in ("--compare", "--kallisto_cutoff", "--kmer_soft_cutoff"):
+        if a in ("--inDisk", "--only_reads"):
+            noted.append("%s: the stages hand their data over in memory (the reference's --inMem contract); TEMP/ holds the per-stage "
+                         "products but not reads{comp}.fasta / component*k1mers_allowed.dict (shannon_amd/reference_api.py writes those "
+                         "when a single stage is driven through the reference's file interface)" % a)
+            i += 1; continue
+        if a == "--kmer_soft_cutoff":
+            noted.append("--kmer_soft_cutoff %s: not used by the hot path (the reference passes it to jellyfish dump -L only with --filter_FP)" % argv[i + 1])
+            i += 2; continue
+        if a in ("--compare", "--kallisto_cutoff"):
             ignored.append(a); i += 2; continue
         ignored.append(a); i += 1
     if out_dir is None or not reads:
@@ -101,7 +109,11 @@ def main(argv):
     from shannon_amd import device, pipeline
     say("Starting Shannon run (MI355X hot path %s)" % VERSION)
     if ignored:
-        say("flags outside the hot path ignored: " + " ".join(ignored))
+        say("WARNING: flags outside the hot path ignored: " + " ".join(ignored))
+    if nJobs != 1:
+        noted.append("-p %d: partitions run concurrently on host threads and the GPU inside one process; the value is not used" % nJobs)
+    for msg in noted:
+        say("NOTE: " + msg)
     r = [read_fasta(p) for p in reads]
     paired = len(r) == 2
     say("Processed No of reads:%d, Avg. Read length: %.2f" % (len(r[0]), sum(len(x) for x in r[0]) / max(1, len(r[0]))))

@@ -65,6 +65,7 @@ struct shn_reads {
   uint64_t* d_woff;        // ragged: word offset of each read (n_reads+1), else NULL
   uint32_t* d_len;         // ragged: length of each read, else NULL
   uint8_t* d_bad;          // per read: 1 if it contains a non-ACGT base (NULL if none)
+  bool cached;             // device arrays come from the caching allocator (shn_reads_gather), not hipMalloc
 };
 
 struct shn_table {

@@ -35,6 +35,10 @@ TimerRegion::~TimerRegion() {
   c->pending[slot].push_back({a, b});
 }
 
+// Invariant of the caching allocator (shared by every context and host thread of the process, one process per GPU): a block is
+// handed to the next caller as soon as it is freed, with no stream ordering -- so a caller frees a block only after the stream
+// that used it has been synchronized (every entry point of this library ends with hipStreamSynchronize before its frees; the
+// graph threads allocate inside g_gpu_mutex sections that end synchronized).  shn_dev_trim only releases blocks nobody holds.
 namespace {
 struct DevBlock { void* p; size_t cap; bool used; };
 std::vector<DevBlock> g_blocks;
@@ -301,9 +305,67 @@ extern "C" int shn_reads_create(shn_ctx* ctx, const uint8_t* bytes, const uint64
   return SHN_OK;
 }
 
+// Rows of resident fixed-length read sets as a new read set, without a trip through the host: read i = row rows[i] of set a
+// (flags[i] bit 0 clear) or b (set), reverse-complemented if bit 1 is set.  The graph stage builds its distinct-read set this
+// way (the reads of a partition are rows of the input the routing kernel selected; uploading their text again was the
+// serialized part of the stage).  The selected rows must hold ACGT only (routed reads do, kmers_for_component.py:336,376).
+__global__ void reads_gather_kernel(const uint64_t* __restrict__ wa, const uint64_t* __restrict__ wb, uint32_t wpr, uint32_t L,
+                                    const uint32_t* __restrict__ rows, const uint8_t* __restrict__ flags, uint64_t n, uint64_t* __restrict__ out) {
+  for (uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < n * wpr; gid += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t i = gid / wpr;
+    const uint32_t w = (uint32_t)(gid - i * wpr);
+    const uint8_t f = flags[i];
+    const uint64_t* src = ((f & 1) ? wb : wa) + (uint64_t)rows[i] * wpr;
+    uint64_t v = 0;
+    if (!(f & 2)) v = src[w];
+    else {
+      for (uint32_t j = 0; j < 32; j++) {
+        const uint32_t p = 32 * w + j;
+        if (p >= L) break;
+        const uint32_t q = L - 1 - p;
+        const uint64_t base = (src[q >> 5] >> (62 - 2 * (q & 31))) & 3ULL;
+        v |= (3ULL - base) << (62 - 2 * j);
+      }
+    }
+    out[gid] = v;
+  }
+}
+extern "C" int shn_reads_gather(shn_ctx* ctx, const shn_reads* a, const shn_reads* b, const uint32_t* rows, const uint8_t* flags, uint64_t n,
+                                shn_reads** out) {
+  if (!ctx || !a || !out || (n && (!rows || !flags))) return shn_fail(SHN_ERR_ARG, "shn_reads_gather: NULL argument");
+  if (!a->fixed_len || (b && (b->fixed_len != a->fixed_len || b->wpr != a->wpr))) return shn_fail(SHN_ERR_ARG, "shn_reads_gather: fixed-length read sets of one length only");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  shn_reads* r = new shn_reads();
+  memset(r, 0, sizeof(*r));
+  r->ctx = ctx; r->device = ctx->device; r->n_reads = n; r->fixed_len = a->fixed_len; r->max_len = a->fixed_len; r->wpr = a->wpr;
+  r->n_words = n * a->wpr; r->total_bases = n * (uint64_t)a->fixed_len; r->cached = true;
+  uint32_t* d_rows = nullptr; uint8_t* d_flags = nullptr;
+  auto fail = [&](hipError_t e) { shn_dev_free(d_rows); shn_dev_free(d_flags); shn_reads_destroy(r); return shn_fail(SHN_ERR_HIP, std::string("shn_reads_gather: ") + hipGetErrorString(e)); };
+  hipError_t e;
+  if ((e = shn_dev_malloc(&r->d_words, (r->n_words + 2) * 8)) != hipSuccess) return fail(e);
+  if ((e = shn_dev_malloc(&r->d_mask, (r->n_words / 2 + 2) * 8)) != hipSuccess) return fail(e);
+  if ((e = shn_dev_malloc(&d_rows, (n + 1) * 4)) != hipSuccess) return fail(e);
+  if ((e = shn_dev_malloc(&d_flags, n + 1)) != hipSuccess) return fail(e);
+  if ((e = hipMemsetAsync(r->d_mask, 0, (r->n_words / 2 + 2) * 8, s)) != hipSuccess) return fail(e);
+  if ((e = hipMemsetAsync(r->d_words + r->n_words, 0, 16, s)) != hipSuccess) return fail(e);
+  if (n) {
+    if ((e = hipMemcpyAsync(d_rows, rows, n * 4, hipMemcpyHostToDevice, s)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpyAsync(d_flags, flags, n, hipMemcpyHostToDevice, s)) != hipSuccess) return fail(e);
+    hipLaunchKernelGGL(reads_gather_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(r->n_words, 256), 1u << 20)), dim3(256), 0, s, a->d_words,
+                       b ? b->d_words : a->d_words, a->wpr, a->fixed_len, d_rows, d_flags, n, r->d_words);
+  }
+  if ((e = hipStreamSynchronize(s)) != hipSuccess) return fail(e);
+  shn_dev_free(d_rows); shn_dev_free(d_flags);
+  HIP_TRY(hipGetLastError());
+  *out = r;
+  return SHN_OK;
+}
+
 extern "C" void shn_reads_destroy(shn_reads* r) {
   if (!r) return;
   hipSetDevice(r->device);
+  if (r->cached) { shn_dev_free(r->d_words); shn_dev_free(r->d_mask); delete r; return; }
   if (r->d_words) hipFree(r->d_words);
   if (r->d_mask) hipFree(r->d_mask);
   if (r->d_woff) hipFree(r->d_woff);

@@ -657,7 +657,8 @@ static int count_views(shn_ctx* ctx, const std::vector<ReadsView>& views, uint64
       hipLaunchKernelGGL(gtable_compact_kernel, dim3((uint32_t)cdiv(slots, 256)), dim3(256), 0, s, gk, gc, slots, pos, pk, pcn);
       shn_table* tb = nullptr;
       int rcp = shn_table_from_pairs(ctx, pk, pcn, nd, k1, both_strands ? 1 : 0, &tb);
-      TRYD(hipStreamSynchronize(s));
+      { hipError_t es = hipStreamSynchronize(s);
+        if (es != hipSuccess) { freeall(); if (!rcp) shn_table_destroy(tb); return shn_fail(SHN_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(es)); } }
       freeall();
 #undef TRYD
       if (rcp) return rcp;
@@ -806,14 +807,17 @@ static int build_from_keys(shn_ctx* ctx, uint64_t* keysA, uint64_t* keysB, uint3
     TimerRegion tr(ctx, T_COMPACT);
     if ((rc = shn_device_scan_u32(ctx, d_ndist, nbk, d_boff, &D))) { delete t; return rc; }
     uint32_t ovf = 0;
-    HIP_TRY(hipMemcpyAsync(&ovf, d_ovf, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    { hipError_t e1 = hipMemcpyAsync(&ovf, d_ovf, 4, hipMemcpyDeviceToHost, s);
+      if (e1 == hipSuccess) e1 = hipStreamSynchronize(s);
+      if (e1 != hipSuccess) { delete t; return shn_fail(SHN_ERR_HIP, std::string("build_from_keys: ") + hipGetErrorString(e1)); } }
     *overflowed = ovf != 0;
     t->n = D;
-    HIP_TRY(shn_dev_malloc(&t->d_keys, (D + 1) * 8));
-    HIP_TRY(shn_dev_malloc(&t->d_counts, (D + 1) * 4));
-    HIP_TRY(shn_dev_malloc(&t->d_bucket_off, (nbk + 1) * 8));
-    HIP_TRY(hipMemcpyAsync(t->d_bucket_off, d_boff, (nbk + 1) * 8, hipMemcpyDeviceToDevice, s));
+#define TRYT(x) do { hipError_t _e = (x); if (_e != hipSuccess) { shn_table_destroy(t); return shn_fail(SHN_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(_e)); } } while (0)
+    TRYT(shn_dev_malloc(&t->d_keys, (D + 1) * 8));
+    TRYT(shn_dev_malloc(&t->d_counts, (D + 1) * 4));
+    TRYT(shn_dev_malloc(&t->d_bucket_off, (nbk + 1) * 8));
+    TRYT(hipMemcpyAsync(t->d_bucket_off, d_boff, (nbk + 1) * 8, hipMemcpyDeviceToDevice, s));
+#undef TRYT
     if (!ovf && D) {
       uint32_t blocks = (uint32_t)cdiv(nbk * SHN_WAVE, BLK);
       hipLaunchKernelGGL(compact_kernel, dim3(blocks), dim3(BLK), 0, s, keysA, tmpc, d_off1, d_off2, d_ndist, d_boff, b2, nbk, t->d_keys, t->d_counts);

@@ -157,6 +157,34 @@ __global__ void cc_union_kernel(const int32_t* __restrict__ adjR, uint64_t n2, u
     }
   }
 }
+// contig_connections joins contigs that share a K-mer (extension_correction.py:372-390): besides adjacent k1-mers those are
+// k1-mers with the same K-suffix (x.m, x'.m) or the same K-prefix (m.y, m.y') -- not adjacent, and only joined through a
+// common neighbour if that neighbour exists and is not low-complexity (a transcript's last K-mer before a poly-A tail is
+// the typical exception).  So the component labelling also unites every k1-mer with its (up to six) siblings.
+__global__ void cc_sibling_kernel(const uint64_t* __restrict__ tkeys, const uint64_t* __restrict__ boff, int bits, const uint8_t* __restrict__ flags,
+                                  uint64_t n, int k, int canonical, uint32_t* lab) {
+  for (uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < n * 8; gid += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t i = gid >> 3;
+    const uint32_t which = (uint32_t)(gid & 7);            // bit 2: replace the first / the last base; bits 0-1: the base
+    if (flags[i] & 2) continue;
+    const uint64_t str = tkeys[i];
+    const uint32_t b = which & 3;
+    uint64_t sib;
+    if (which & 4) { if ((str & 3) == b) continue; sib = (str & ~3ULL) | b; }
+    else { const int sh = 2 * (k - 1); if (((str >> sh) & 3) == b) continue; sib = (str & ~(3ULL << sh)) | ((uint64_t)b << sh); }
+    uint64_t canon = sib;
+    if (canonical) { const uint64_t rc = shn_revcomp(sib, k); if (rc < sib) canon = rc; }
+    const int64_t j = shn_table_find(tkeys, boff, bits, canon);
+    if (j < 0 || (flags[j] & 2) || (uint64_t)j == i) continue;
+    const uint32_t u = (uint32_t)i, v = (uint32_t)j;
+    while (true) {
+      const uint32_t ru = cc_find(lab, u), rv = cc_find(lab, v);
+      if (ru == rv) break;
+      const uint32_t hi = ru > rv ? ru : rv, lo = ru > rv ? rv : ru;
+      if (atomicCAS(&lab[hi], hi, lo) == hi) break;
+    }
+  }
+}
 __global__ void cc_flatten_kernel(uint32_t* lab, uint64_t n) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { uint32_t r = cc_find(lab, (uint32_t)i); lab[i] = r; }
@@ -916,6 +944,8 @@ static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank
   TRYS(hipMemsetAsync(d_cnt, 0, 2048, s));
   hipLaunchKernelGGL(cc_init_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, d_lab, n);
   hipLaunchKernelGGL(cc_union_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(2 * n * 4, 256), 1u << 22)), dim3(256), 0, s, (const int32_t*)d_adjR, 2 * n, d_lab);
+  hipLaunchKernelGGL(cc_sibling_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off, t->bits,
+                     d_flags, n, t->k, t->canonical, d_lab);
   hipLaunchKernelGGL(cc_flatten_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, d_lab, n);
   TRYS(hipMemsetAsync(d_size, 0, (n + 1) * 4, s));
   hipLaunchKernelGGL(cc_sample_kernel, dim3((uint32_t)cdiv(cdiv(n, 64), 256)), dim3(256), 0, s, d_lab, n, d_size);
@@ -924,7 +954,9 @@ static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank
   unsigned long long nb = 0;
   TRYS(hipMemcpyAsync(&nb, d_cnt + 20, 8, hipMemcpyDeviceToHost, s));
   TRYS(hipStreamSynchronize(s));
-  nb = std::min<unsigned long long>(nb, big_cap);
+  // more large components than the list holds: which ones got recorded depends on the arrival order of the atomics, i.e. could
+  // differ from rank to rank -- every root then keeps its hash owner (the same on every rank), no balancing
+  if (nb > big_cap) nb = 0;
   if (nb) {
     std::vector<uint32_t> br(nb), bs(nb);
     TRYS(hipMemcpy(br.data(), d_big_root, nb * 4, hipMemcpyDeviceToHost));

@@ -89,7 +89,7 @@ struct Graph {
   size_t n_rd() const { return rindex.size(); }
   std::vector<double> rcc;
   std::vector<int> rmate, rmp;        // rmp: 0 None, 1, 2
-  std::vector<std::vector<int>> rnodes;
+  std::vector<int> rfirst, rlast;       // first / last node of the read's (last) path: all find_mate_pairs reads of Read.nodes
   std::vector<char> rhas;
   StringInterner rindex{1 << 16};
   std::set<std::vector<int>> known_paths;
@@ -213,7 +213,7 @@ struct Graph {
     bool is_new = false;
     int r = rindex.intern_hashed(b, n, h, &is_new);
     if (!is_new) { rcc[r] += 1.0; return r; }
-    rcc.push_back(1.0); rmate.push_back(-1); rmp.push_back(0); rnodes.emplace_back(); rhas.push_back(0);
+    rcc.push_back(1.0); rmate.push_back(-1); rmp.push_back(0); rfirst.push_back(-1); rlast.push_back(-1); rhas.push_back(0);
     return r;
   }
 
@@ -356,13 +356,19 @@ struct Graph {
   bool gpu_patterns(const SeedIndex& si, shn_reads** dreads, shn_table** tab) {
     if (!ctx || K > 32 || n_rd() == 0 || si.keys.empty() || !reads_all_acgt()) return false;
     if (!*dreads) {
-      if (shn_reads_create(ctx, (const uint8_t*)rindex.arena.data(), rindex.off.data(), n_rd(), 0, SHN_ENC_ASCII, dreads)) return false;
+      // the distinct reads as rows of the resident input (device gather; 5 bytes per read cross the bus), else their text
+      if (src_a && origin_row.size() == n_rd()) {
+        if (shn_reads_gather(ctx, src_a, src_b, origin_row.data(), origin_flag.data(), n_rd(), dreads)) return false;
+      } else if (shn_reads_create(ctx, (const uint8_t*)rindex.arena.data(), rindex.off.data(), n_rd(), 0, SHN_ENC_ASCII, dreads)) return false;
     }
     std::vector<uint32_t> vals(si.keys.size());
     for (size_t i = 0; i < vals.size(); i++) vals[i] = (uint32_t)i + 1;
     return shn_table_create(ctx, si.keys.data(), vals.data(), si.keys.size(), K, 0, tab) == 0;
   }
   shn_reads* d_reads = nullptr;
+  const shn_reads *src_a = nullptr, *src_b = nullptr;      // the resident input read sets the partition's reads are rows of
+  std::vector<uint32_t> origin_row;                        // per distinct read: row in its set, and
+  std::vector<uint8_t> origin_flag;                        // bit 0: set b, bit 1: reverse complement
   void release_gpu() { if (d_reads) { std::lock_guard<std::mutex> lk(g_gpu_mutex); shn_reads_destroy(d_reads); d_reads = nullptr; } }
 
   void find_bridging_reads() {
@@ -626,6 +632,8 @@ struct Graph {
       }
     release_gpu();
     int cntp = 0;
+    std::vector<std::vector<int>> paths;
+    std::vector<int> cur;
     for (int r = 0; r < (int)n_rd(); r++) {
       if (!first[r] || !last[r]) continue;
       const RStr rb = rstr(r);
@@ -633,11 +641,15 @@ struct Graph {
       for (uint32_t q = si.goff[gi]; q < si.goff[gi + 1]; q++) {
         int sn = si.occ[q].first, so = si.occ[q].second;
         if (!compare(rb, 0, bases[sn], so)) continue;
-        std::vector<std::vector<int>> paths;
-        std::vector<int> cur;
+        if (rb.size() <= bases[sn].size() - (size_t)so) {
+          // the read lies inside this node (nearly all reads do): its only path is [sn] -- no edges, no known path
+          rfirst[r] = sn; rlast[r] = sn; rhas[r] = 1;
+          continue;
+        }
+        paths.clear(); cur.clear();
         search_sequence(rb, 0, sn, so, 30, cur, paths);
         for (auto& p : paths) {
-          rnodes[r] = p; rhas[r] = 1;
+          rfirst[r] = p.front(); rlast[r] = p.back(); rhas[r] = 1;
           for (size_t j = 0; j + 1 < p.size(); j++) known_edges[{p[j], p[j + 1]}] += rcc[r];
           if (p.size() > 2) { known_paths.insert(p); cntp++; }
         }
@@ -676,8 +688,8 @@ struct Graph {
     for (int r = 0; r < (int)n_rd(); r++) {
       if (rmp[r] != 1 || rmate[r] < 0) continue;
       int m = rmate[r];
-      if (!rhas[r] || rnodes[r].empty() || !rhas[m] || rnodes[m].empty()) continue;
-      int a = rnodes[r].back(), b = rnodes[m].front();
+      if (!rhas[r] || !rhas[m]) continue;
+      int a = rlast[r], b = rfirst[m];
       if (a == b) continue;
       bool adj = false;
       for (int e : oute[a]) if (ed[e] == b) adj = true;
@@ -761,7 +773,8 @@ static void decode_read(char* s, const uint8_t* p, uint64_t n, int enc, bool rc)
 
 static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n_rows, const shn_unitigs* ug, uint32_t part, const uint8_t* r1,
                            const uint64_t* r1_off, const uint8_t* r2, const uint64_t* r2_off, uint64_t n_reads, int paired, int enc,
-                           const uint8_t* rc1, const uint8_t* rc2, shn_graph** out);
+                           const uint8_t* rc1, const uint8_t* rc2, shn_graph** out, const shn_reads* src_a = nullptr, const shn_reads* src_b = nullptr,
+                           const uint32_t* didx = nullptr);
 
 extern "C" int shn_mbgraph_run(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n_rows, const uint8_t* r1, const uint64_t* r1_off,
                                const uint8_t* r2, const uint64_t* r2_off, uint64_t n_reads, int paired, int enc, const uint8_t* rc1,
@@ -778,9 +791,22 @@ extern "C" int shn_mbgraph_run_unitigs(shn_ctx* ctx, const shn_unitigs* ug, uint
   return mbgraph_run_impl(ctx, ug->K, rows, n_rows, ug, part, r1, r1_off, r2, r2_off, n_reads, paired, enc, rc1, rc2, out);
 }
 
+// The same again with the partition's reads known as rows of the resident input: src_a / src_b = the packed read sets of the run
+// (src_b NULL for single-end), didx[i] = doubled read index of read i (shn_route_reads' numbering: SE d < N -> R[d], d >= N ->
+// RC(R[d-N]); PE d < N -> (R1[d], RC(R1[d])), d >= N -> (RC(R2[d-N]), R2[d-N])).  The read text (r1 / r2) is still what the host
+// side of the stage works on; the device copy of the distinct reads is gathered from the resident sets instead of uploaded.
+extern "C" int shn_mbgraph_run_resident(shn_ctx* ctx, const shn_unitigs* ug, uint32_t part, const uint8_t* rows, uint64_t n_rows, const shn_reads* src_a,
+                                        const shn_reads* src_b, const uint32_t* didx, const uint8_t* r1, const uint64_t* r1_off, const uint8_t* r2,
+                                        const uint64_t* r2_off, uint64_t n_reads, int paired, int enc, const uint8_t* rc1, const uint8_t* rc2,
+                                        shn_graph** out) {
+  if (!ug || part >= ug->n_parts) return shn_fail(SHN_ERR_ARG, "shn_mbgraph_run_resident: bad unitigs / partition");
+  return mbgraph_run_impl(ctx, ug->K, rows, n_rows, ug, part, r1, r1_off, r2, r2_off, n_reads, paired, enc, rc1, rc2, out, src_a, src_b, didx);
+}
+
 static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n_rows, const shn_unitigs* ug, uint32_t part, const uint8_t* r1,
                            const uint64_t* r1_off, const uint8_t* r2, const uint64_t* r2_off, uint64_t n_reads, int paired, int enc,
-                           const uint8_t* rc1, const uint8_t* rc2, shn_graph** out) {
+                           const uint8_t* rc1, const uint8_t* rc2, shn_graph** out, const shn_reads* src_a, const shn_reads* src_b,
+                           const uint32_t* didx) {
   if (!out || (n_rows && !rows) || (n_reads && (!r1 || !r1_off)) || (paired && n_reads && (!r2 || !r2_off)))
     return shn_fail(SHN_ERR_ARG, "shn_mbgraph_run: NULL argument");
   Graph g;
@@ -791,6 +817,22 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
   const bool dbg = getenv("SHN_DEBUG") != nullptr;
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double tt = now();
+  // origin of read slot j = i * nm + mate (mate 0 / 1) in the resident input, for the device gather of the distinct reads
+  const bool resident = ctx && src_a && didx && src_a->fixed_len && (!paired || (src_b && src_b->fixed_len == src_a->fixed_len)) &&
+                        n_reads && (uint64_t)(r1_off[1] - r1_off[0]) == src_a->fixed_len && getenv("SHN_GRAPH_RESIDENT_READS") == nullptr;
+  if (resident) { g.src_a = src_a; g.src_b = paired ? src_b : nullptr; }
+  const uint64_t N_in = src_a ? src_a->n_reads : 0;
+  auto origin_of = [&](uint64_t j, uint32_t& row, uint8_t& flag) {
+    const int nm_ = paired ? 2 : 1;
+    const uint64_t i = j / nm_;
+    const int mate = (int)(j % nm_);
+    const uint64_t d = didx[i];
+    const bool second = d >= N_in;
+    row = (uint32_t)(second ? d - N_in : d);
+    if (!paired) flag = second ? 2 : 0;
+    else if (mate == 0) flag = second ? (1 | 2) : 0;              // R1[d] / RC(R2[d-N])
+    else flag = second ? 1 : 2;                                     // RC(R1[d]) / R2[d-N]
+  };
   uint64_t n_kmer_nodes = 0;
   if (ug && !ug->cyclic[part]) {
     const uint64_t n0 = ug->node_off[part], n1 = ug->node_off[part + 1], e0 = ug->edge_off[part], e1 = ug->edge_off[part + 1];
@@ -842,7 +884,7 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
     g.rindex.arena.reserve(bytes);
     size_t nr = (size_t)used * (paired ? 2 : 1);
     g.rindex.reserve(nr);
-    g.rcc.reserve(nr); g.rmate.reserve(nr); g.rmp.reserve(nr); g.rnodes.reserve(nr); g.rhas.reserve(nr);
+    g.rcc.reserve(nr); g.rmate.reserve(nr); g.rmp.reserve(nr); g.rfirst.reserve(nr); g.rlast.reserve(nr); g.rhas.reserve(nr);
   }
   {
     // decode + hash on several host threads (independent per read), then intern sequentially in file order
@@ -956,7 +998,8 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
       R.off.resize(nd + 1);
       R.off[0] = 0;
       R.arena.resize(nbytes[nt]);
-      g.rcc.resize(nd); g.rmate.resize(nd, -1); g.rmp.resize(nd, 0); g.rnodes.resize(nd); g.rhas.resize(nd, 0);
+      g.rcc.resize(nd); g.rmate.resize(nd, -1); g.rmp.resize(nd, 0); g.rfirst.resize(nd, -1); g.rlast.resize(nd, -1); g.rhas.resize(nd, 0);
+      if (resident) { g.origin_row.resize(nd); g.origin_flag.resize(nd); }
       char* arena = &R.arena[0];
       run_threads([&](unsigned c) {
         uint64_t id = nf[c], at = nbytes[c];
@@ -969,6 +1012,7 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
           R.off[id + 1] = at;
           g.rcc[id] = (double)cnt[j];
           idmap[j] = (int32_t)id;
+          if (resident) origin_of(j, g.origin_row[id], g.origin_flag[id]);
           id++;
         }
       });
@@ -989,9 +1033,14 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
       if (dbg) fprintf(stderr, "[mbgraph]   + numbered in order    %8.3f s\n", now() - t_dec);
     } else
     for (uint64_t i = 0; i < used; i++) {
+      auto note = [&](int r, uint64_t j) {
+        if (resident && (size_t)r == g.origin_row.size()) { uint32_t row; uint8_t fl; origin_of(j, row, fl); g.origin_row.push_back(row); g.origin_flag.push_back(fl); }
+      };
       int a = g.add_read(text.data() + doff[i * nm], doff[i * nm + 1] - doff[i * nm], hashes[i * nm]);
+      note(a, i * nm);
       if (paired) {
         int b = g.add_read(text.data() + doff[i * nm + 1], doff[i * nm + 2] - doff[i * nm + 1], hashes[i * nm + 1]);
+        note(b, i * nm + 1);
         g.rmp[a] = 1; g.rmp[b] = 2; g.rmate[a] = b; g.rmate[b] = a;
       }
     }

@@ -166,9 +166,10 @@ def sparse_flow_native(ctx, graphs, snames, seed):
 
 
 def run_partition_handle(rows_bytes, n_rows, K, r1_buf, r1_off, r2_buf=None, r2_off=None, ctx=None, enc=0, rc1=None, rc2=None, unitigs=None,
-                         part=0):
+                         part=0, resident=None):
     """rows_bytes: uint8 array of n_rows*(K+1) bases; reads as (byte buffer, offsets).  unitigs / part: the partition's
-    K-mer graph already contracted on the GPU (rows_bytes may then be None).  Returns the GraphHandle."""
+    K-mer graph already contracted on the GPU (rows_bytes may then be None).  resident = (reads1, reads2 or None, doubled read
+    indices uint32): the reads are rows of these device-resident sets (shn_mbgraph_run_resident).  Returns the GraphHandle."""
     L = _lib.lib()
     h = C.c_void_p()
     n_reads = len(r1_off) - 1
@@ -176,7 +177,13 @@ def run_partition_handle(rows_bytes, n_rows, K, r1_buf, r1_off, r2_buf=None, r2_
     rows_ptr = rows_bytes.ctypes.data if rows_bytes is not None else None
     tail = (r1_buf.ctypes.data, r1_off.ctypes.data, r2_buf.ctypes.data if paired else None, r2_off.ctypes.data if paired else None, n_reads,
             1 if paired else 0, enc, rc1.ctypes.data if rc1 is not None else None, rc2.ctypes.data if rc2 is not None else None, C.byref(h))
-    if unitigs is not None:
+    if unitigs is not None and resident is not None and ctx is not None:
+        d1, d2, didx = resident
+        didx = np.ascontiguousarray(didx, dtype=np.uint32)
+        assert len(didx) == n_reads
+        _lib.check(L.shn_mbgraph_run_resident(ctx.h, unitigs.h, int(part), rows_ptr, n_rows if rows_bytes is not None else 0, d1.h,
+                                              d2.h if d2 is not None else None, didx.ctypes.data, *tail))
+    elif unitigs is not None:
         _lib.check(L.shn_mbgraph_run_unitigs(ctx.h if ctx is not None else None, unitigs.h, int(part), rows_ptr, n_rows if rows_bytes is not None else 0, *tail))
     else:
         _lib.check(L.shn_mbgraph_run(ctx.h if ctx is not None else None, K, rows_ptr, n_rows, *tail))

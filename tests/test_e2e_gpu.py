@@ -74,3 +74,27 @@ def test_cli_config1_samples_se(tmp_path):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "shannon.py"), "-o", str(out), "--single", str(fa)],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
     assert p.returncode != 0 and "not empty" in p.stdout
+
+
+def test_graph_reads_gathered_on_the_device_equal_uploaded_text(ctx, monkeypatch):
+    """With code-matrix input the graph stage builds the device copy of a partition's distinct reads by gathering rows of the
+    resident packed input (shn_reads_gather, reverse complements on chip) instead of uploading their text: same graphs, same
+    transcripts -- paired and single-end, several partitions."""
+    import numpy as np
+    from shannon_amd import pipeline, synth
+    (r1, r2), _ = synth.make_dataset(30000, 40, seed=31)
+    for paired in (True, False):
+        outs = []
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("SHN_GRAPH_RESIDENT_READS", "0")
+            else:
+                monkeypatch.delenv("SHN_GRAPH_RESIDENT_READS", raising=False)
+            R = pipeline.assemble(ctx, r1, r2 if paired else None, K=25, partition_size=8, sample="s", seed=2)
+            outs.append(R)
+        a, b = outs
+        assert len(a.partitions) > 1 and list(a.partitions) == list(b.partitions)
+        for p in a.partitions:
+            assert a.partitions[p]["reconstructed_fasta"] == b.partitions[p]["reconstructed_fasta"]
+            assert a.partitions[p]["components"] == b.partitions[p]["components"] and a.partitions[p]["singles"] == b.partitions[p]["singles"]
+        assert a.final == b.final and len(a.final) > 10

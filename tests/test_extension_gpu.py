@@ -235,6 +235,39 @@ def test_component_sharded_contig_stages_equal_the_global_pass(ctx, world, limit
         t.close()
 
 
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_sharded_contig_stage_keeps_connections_through_shared_end_kmers(ctx, world):
+    """Unrelated genes whose transcripts END (or START) in the same K-mer: their last k1-mers x.m / x'.m are not adjacent and have
+    no common successor, yet contig_connections joins the contigs through the shared K-mer m (extension_correction.py:372-390).
+    The component labelling unites such sibling k1-mers, so the contigs land on one rank and the sharded result keeps the edge."""
+    from shannon_amd import device, synth, extension_correction as ec
+    rng = np.random.Generator(np.random.PCG64(123))
+    tail, head = rng.integers(0, 4, 25, dtype=np.uint8), rng.integers(0, 4, 25, dtype=np.uint8)
+    isos = []
+    for gix in range(12):
+        body = rng.integers(0, 4, int(rng.integers(420, 700)), dtype=np.uint8)
+        if gix < 4:
+            body = np.concatenate([body, tail])                 # four genes end in the same 25-mer
+        elif gix < 7:
+            body = np.concatenate([head, body])                 # three start with the same 25-mer
+        isos.append(body)
+    r1, r2 = synth.sample_pairs(isos, 40000, 7, err=0.002)
+    t = device.count_k1mers(ctx, [device.Reads.from_codes(ctx, np.concatenate([r1, r2]))], 26)
+    try:
+        ref = ec.run_correction(ctx, t, 3, 75, 500, want_allowed=False)
+        shared = [a for a, d in ref.connections.items() if d]
+        assert len(shared) >= 4                                  # the end-sharing contigs are connected in the unsharded run
+        results, history = _run_virtual_ranks(world, lambda rank, g: ec.run_correction(ctx, t, 3, 75, 500, want_allowed=False,
+                                                                                       shard=(world, rank), gather=g))
+        for rank in range(world):
+            res = results[rank]
+            assert res.contigs == ref.contigs
+            assert res.connections == ref.connections and [list(v) for v in res.connections.values()] == [list(v) for v in ref.connections.values()]
+            assert res.components == ref.components and res.single_contigs == ref.single_contigs and res.remaining == ref.remaining
+    finally:
+        t.close()
+
+
 def test_rmer_join_counts_like_duplicate_check(ctx):
     from shannon_amd import extension_correction as ec
     rng = np.random.default_rng(3)

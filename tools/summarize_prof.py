@@ -14,6 +14,7 @@ TIMER_KERNEL = {"count.direct": "count_direct_kernel", "count.hist1": "hist1_ker
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*", "", name)
     name = name.replace("void ", "")
     return name[:70]
