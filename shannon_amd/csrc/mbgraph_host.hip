@@ -11,6 +11,7 @@
 #include "graph_result.h"
 #include <thread>
 #include <mutex>
+#include <condition_variable>
 #include <string>
 #include <vector>
 #include <unordered_map>
@@ -70,6 +71,20 @@ struct RStr {
 
 // several partitions may run on host threads at once; their GPU sections take turns
 static std::mutex g_gpu_mutex;
+
+// Host-thread budget shared by the partitions of a process.  The multi-threaded phases of a partition (read decode, duplicate
+// search, numbering, path classification) take as many tokens as they start threads; with 64 partitions beginning at once and up
+// to 32 threads each the cores were oversubscribed five-fold and every phase ran ten times slower than alone -- the largest
+// partition, which bounds the stage, included.  Partitions are started largest first, so the large ones get their threads first.
+struct ThreadBudget {
+  std::mutex mu; std::condition_variable cv; int avail;
+  ThreadBudget() { const int hw = (int)std::thread::hardware_concurrency(); avail = std::max(8, hw - hw / 16); if (getenv("SHN_GRAPH_HOST_THREADS")) avail = std::max(1, atoi(getenv("SHN_GRAPH_HOST_THREADS"))); total = avail; }
+  int total;
+  void acquire(int n) { n = std::min(n, total); std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return avail >= n; }); avail -= n; }
+  void release(int n) { n = std::min(n, total); { std::lock_guard<std::mutex> lk(mu); avail += n; } cv.notify_all(); }
+};
+static ThreadBudget g_host_threads;
+struct BudgetGuard { int n; explicit BudgetGuard(int k) : n(k) { g_host_threads.acquire(n); } ~BudgetGuard() { g_host_threads.release(n); } };
 
 struct Graph {
   shn_ctx* ctx = nullptr;                   // non-NULL: K-mer seed scans run on the GPU (csrc/seeds.hip)
@@ -634,8 +649,39 @@ struct Graph {
     int cntp = 0;
     std::vector<std::vector<int>> paths;
     std::vector<int> cur;
+    // Nearly every read lies inside one node: its only path is that node, it adds no known edge and no known path.  Those reads
+    // are settled on host threads; the reads that cross node boundaries (`slow`) go through search_sequence one after the
+    // other in read order, as the sums of known_edges require.
+    std::vector<char> slow(n_rd(), 0);
+    {
+      const unsigned ntp = (unsigned)std::min<size_t>(16, std::max<size_t>(1, n_rd() >> 18));
+      auto classify = [&](size_t lo, size_t hi) {
+        for (size_t r = lo; r < hi; r++) {
+          if (!first[r] || !last[r]) continue;
+          const RStr rb = rstr((int)r);
+          const uint32_t gi = first[r] - 1;
+          int fn = -1;
+          bool any = false, need = false;
+          for (uint32_t q = si.goff[gi]; q < si.goff[gi + 1] && !need; q++) {
+            const int sn = si.occ[q].first, so = si.occ[q].second;
+            if (!compare(rb, 0, bases[sn], so)) continue;
+            if (rb.size() <= bases[sn].size() - (size_t)so) { fn = sn; any = true; }
+            else need = true;
+          }
+          if (need) slow[r] = 1;
+          else if (any) { rfirst[r] = fn; rlast[r] = fn; rhas[r] = 1; }
+        }
+      };
+      BudgetGuard budget((int)ntp);
+      if (ntp <= 1) classify(0, n_rd());
+      else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < ntp; t++) th.emplace_back(classify, n_rd() * t / ntp, n_rd() * (t + 1) / ntp);
+        for (auto& x : th) x.join();
+      }
+    }
     for (int r = 0; r < (int)n_rd(); r++) {
-      if (!first[r] || !last[r]) continue;
+      if (!slow[r]) continue;
       const RStr rb = rstr(r);
       uint32_t gi = first[r] - 1;
       for (uint32_t q = si.goff[gi]; q < si.goff[gi + 1]; q++) {
@@ -714,7 +760,7 @@ struct Graph {
     const bool dbg = getenv("SHN_DEBUG") != nullptr;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
-    auto lap = [&](const char* what) { if (dbg) { double t = now(); fprintf(stderr, "[mbgraph] %-22s %8.3f s  nodes=%zu\n", what, t - t0, order.size()); t0 = t; } };
+    auto lap = [&](const char* what) { if (dbg) { double t = now(); fprintf(stderr, "[mbgraph] %-22s %8.3f s  nodes=%zu reads=%zu\n", what, t - t0, order.size(), n_rd()); t0 = t; } };
     if (!precondensed) condense_all();
     nodes_after[0] = (int)order.size();
     lap("condense_all");
@@ -866,24 +912,48 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
   uint64_t cutoff = n_kmer_nodes * 10;
   // Scratch kept between calls (at the read cap these buffers are 100s of MB, and fresh pages cost more than the work done
   // in them): decode buffers and the read arena.  A free list, not thread_local: Python's partition workers are short-lived.
-  struct Scratch { std::vector<uint64_t> doff, hashes; std::vector<char> text; std::string arena; std::vector<uint32_t> first, cnt, last; std::vector<int32_t> idmap; };
+  // (also the per-read arrays of the graph: a partition at the read cap touches ~1.5 GB here, and with 64 partitions starting at
+  // once the page faults of fresh memory were most of the largest partition's "load reads".)  The list keeps one object per
+  // partition thread; a call takes the smallest one that is large enough, else the largest.
+  struct Scratch {
+    std::vector<uint64_t> doff, hashes; std::vector<char> text; std::string arena; std::vector<uint32_t> first, cnt, last; std::vector<int32_t> idmap;
+    std::vector<double> rcc; std::vector<int> rmate, rmp, rfirst, rlast; std::vector<char> rhas; std::vector<uint64_t> r_hashes, r_off;
+  };
   static std::mutex scratch_mu;
   static std::vector<Scratch*> scratch_free;
   Scratch* sc = nullptr;
-  { std::lock_guard<std::mutex> lk(scratch_mu); if (!scratch_free.empty()) { sc = scratch_free.back(); scratch_free.pop_back(); } }
+  const size_t need_text = (size_t)std::min<uint64_t>(n_reads, cutoff + 1) * (paired ? 2 : 1) * (n_reads ? (size_t)(r1_off[1] - r1_off[0]) : 0);
+  { std::lock_guard<std::mutex> lk(scratch_mu);
+    int pick = -1;
+    for (size_t i = 0; i < scratch_free.size(); i++) {
+      const size_t c = scratch_free[i]->text.capacity();
+      if (pick < 0) { pick = (int)i; continue; }
+      const size_t pc = scratch_free[pick]->text.capacity();
+      if (pc >= need_text ? (c >= need_text && c < pc) : c > pc) pick = (int)i;
+    }
+    if (pick >= 0) { sc = scratch_free[pick]; scratch_free.erase(scratch_free.begin() + pick); } }
   if (!sc) sc = new Scratch();
   struct Giveback {
-    Scratch* s; std::string* arena;
-    ~Giveback() { arena->clear(); s->arena.swap(*arena); std::lock_guard<std::mutex> lk(scratch_mu); if (scratch_free.size() < 16) scratch_free.push_back(s); else delete s; }
-  } giveback{sc, &g.rindex.arena};
+    Scratch* s; Graph* g;
+    ~Giveback() {
+      g->rindex.arena.clear(); s->arena.swap(g->rindex.arena);
+      s->rcc.swap(g->rcc); s->rmate.swap(g->rmate); s->rmp.swap(g->rmp); s->rfirst.swap(g->rfirst); s->rlast.swap(g->rlast); s->rhas.swap(g->rhas);
+      s->r_hashes.swap(g->rindex.hashes); s->r_off.swap(g->rindex.off);
+      std::lock_guard<std::mutex> lk(scratch_mu);
+      if (scratch_free.size() < 192) scratch_free.push_back(s); else delete s;
+    }
+  } giveback{sc, &g};
   g.rindex.arena.swap(sc->arena);
   g.rindex.arena.clear();
+  sc->rcc.clear(); sc->rmate.clear(); sc->rmp.clear(); sc->rfirst.clear(); sc->rlast.clear(); sc->rhas.clear(); sc->r_hashes.clear(); sc->r_off.assign(1, 0);
+  g.rcc.swap(sc->rcc); g.rmate.swap(sc->rmate); g.rmp.swap(sc->rmp); g.rfirst.swap(sc->rfirst); g.rlast.swap(sc->rlast); g.rhas.swap(sc->rhas);
+  g.rindex.hashes.swap(sc->r_hashes); g.rindex.off.swap(sc->r_off);
   {
     uint64_t used = std::min<uint64_t>(n_reads, cutoff + 1);
     size_t bytes = used ? (size_t)(r1_off[used] - r1_off[0]) + (paired ? (size_t)(r2_off[used] - r2_off[0]) : 0) : 0;
     g.rindex.arena.reserve(bytes);
     size_t nr = (size_t)used * (paired ? 2 : 1);
-    g.rindex.reserve(nr);
+    if (nr < (1u << 17)) g.rindex.reserve(nr);          // (large sets are numbered in bulk and never use the interner's probe table)
     g.rcc.reserve(nr); g.rmate.reserve(nr); g.rmp.reserve(nr); g.rfirst.reserve(nr); g.rlast.reserve(nr); g.rhas.reserve(nr);
   }
   {
@@ -925,10 +995,16 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
     // (8 ranks share a node's cores; partitions running at the same time in this process share this rank's part)
     static std::atomic<int> active_calls{0};
     struct Active { std::atomic<int>& a; int n; Active(std::atomic<int>& x) : a(x), n(++x) {} ~Active() { --a; } } active(active_calls);
-    unsigned nt = std::min<unsigned>(32, std::max<unsigned>(1, std::thread::hardware_concurrency() / 8 / (unsigned)std::max(1, active.n / 2)));
+    // The partitions of a run differ in size by an order of magnitude and the largest ones are started first (pipeline.py): the
+    // stage ends when the largest partition does, so its read set gets threads in proportion to its size (one per 256 Ki
+    // reads, at most 32 and at most a quarter of the cores), whatever else is running; small sets share what is left.
+    const unsigned hwc = std::max(1u, std::thread::hardware_concurrency());
+    unsigned nt = std::min<unsigned>(32, std::max<unsigned>(1, hwc / 8 / (unsigned)std::max(1, active.n / 2)));
+    nt = std::max<unsigned>(nt, (unsigned)std::min<uint64_t>(std::min<uint64_t>(32, std::max(1u, hwc / 4)), (used * (paired ? 2 : 1)) >> 18));
     uint64_t bulk_min = 1u << 17;                       // reads from which the duplicates are found in parallel (tests lower it)
     if (getenv("SHN_GRAPH_BULK_MIN")) { bulk_min = strtoull(getenv("SHN_GRAPH_BULK_MIN"), nullptr, 10); nt = std::max(nt, 4u); }
     if (used * nm < bulk_min) nt = used < 4096 ? 1 : std::min<unsigned>(nt, (unsigned)(used / 2048));   // small sets: a few threads for the decode only
+    BudgetGuard budget((int)nt);                          // held until the reads are numbered
     if (nt <= 1) work(0, used);
     else {
       std::vector<std::thread> th;
@@ -937,7 +1013,7 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
       for (auto& t : th) t.join();
     }
     g.acgt_known = non_acgt.load() ? 0 : 1;
-    if (dbg) fprintf(stderr, "[mbgraph]   offsets+decode+hash   %8.3f s\n", now() - t_dec);
+    if (dbg) fprintf(stderr, "[mbgraph]   offsets+decode+hash   %8.3f s  used=%llu nt=%u\n", now() - t_dec, (unsigned long long)used, nt);
     const uint64_t nh = used * nm;
     if (nt > 1 && nh >= bulk_min && g.rindex.size() == 0) {
       // Large read sets, all on `nt` host threads: (1) the duplicates -- every thread owns the strings whose hash falls into
@@ -980,7 +1056,7 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
           }
         }
       });
-      if (dbg) fprintf(stderr, "[mbgraph]   + duplicates found     %8.3f s\n", now() - t_dec);
+      if (dbg) fprintf(stderr, "[mbgraph]   + duplicates found     %8.3f s  used=%llu\n", now() - t_dec, (unsigned long long)used);
       std::vector<int32_t>& idmap = sc->idmap;
       idmap.resize(nh);
       StringInterner& R = g.rindex;
@@ -1030,7 +1106,7 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
           }
         });
       R.bulk_loaded = true;                 // (its probe table was bypassed: no interning by string after this)
-      if (dbg) fprintf(stderr, "[mbgraph]   + numbered in order    %8.3f s\n", now() - t_dec);
+      if (dbg) fprintf(stderr, "[mbgraph]   + numbered in order    %8.3f s  used=%llu\n", now() - t_dec, (unsigned long long)used);
     } else
     for (uint64_t i = 0; i < used; i++) {
       auto note = [&](int r, uint64_t j) {

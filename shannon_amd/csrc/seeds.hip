@@ -82,15 +82,15 @@ static int seed_scan_impl(shn_ctx* ctx, const shn_reads* reads, int K, const shn
   if ((rc = shn_device_scan_u32(ctx, (uint32_t*)pc, total, (uint64_t*)po, &nh))) return rc;
   *n_hits = nh;
   if (!out_read || nh == 0) return SHN_OK;
-  uint32_t *d_r, *d_s, *d_i;
-  HIP_TRY(hipMalloc(&d_r, nh * 4)); HIP_TRY(hipMalloc(&d_s, nh * 4)); HIP_TRY(hipMalloc(&d_i, nh * 4));
+  uint32_t *d_r = nullptr, *d_s = nullptr, *d_i = nullptr;       // (from the caching allocator: this runs once per partition, under the GPU mutex)
+  ShnDevBufs hb;
+  HIP_TRY(hb.get(&d_r, nh * 4)); HIP_TRY(hb.get(&d_s, nh * 4)); HIP_TRY(hb.get(&d_i, nh * 4));
   hipLaunchKernelGGL((seed_scan_kernel<true, ALL>), dim3(grid), dim3(SBLK2), 0, s, v, K, max_win, patterns->d_keys, patterns->d_counts,
                      patterns->d_bucket_off, patterns->bits, nullptr, (const uint64_t*)po, d_r, d_s, d_i);
   HIP_TRY(hipMemcpyAsync(out_read, d_r, nh * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(out_start, d_s, nh * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(out_id, d_i, nh * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  hipFree(d_r); hipFree(d_s); hipFree(d_i);
   HIP_TRY(hipGetLastError());
   return SHN_OK;
 }
@@ -109,14 +109,14 @@ extern "C" int shn_seed_ends(shn_ctx* ctx, const shn_reads* reads, int K, const 
   TimerRegion treg(ctx, T_SEEDS);
   if (reads->n_reads == 0) return SHN_OK;
   SView v = sview(reads);
-  uint32_t *d_a, *d_b;
-  HIP_TRY(hipMalloc(&d_a, v.n * 4)); HIP_TRY(hipMalloc(&d_b, v.n * 4));
+  uint32_t *d_a = nullptr, *d_b = nullptr;
+  ShnDevBufs hb;
+  HIP_TRY(hb.get(&d_a, v.n * 4)); HIP_TRY(hb.get(&d_b, v.n * 4));
   hipLaunchKernelGGL(seed_ends_kernel, dim3((uint32_t)cdiv(v.n, 256)), dim3(256), 0, s, v, K, patterns->d_keys, patterns->d_counts,
                      patterns->d_bucket_off, patterns->bits, d_a, d_b);
   HIP_TRY(hipMemcpyAsync(first_id, d_a, v.n * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(last_id, d_b, v.n * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  hipFree(d_a); hipFree(d_b);
   HIP_TRY(hipGetLastError());
   return SHN_OK;
 }

@@ -111,9 +111,19 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
     part_index = {nm: i for i, nm in enumerate(names)}
     check_rows = os.environ.get("SHN_GRAPH_CHECK")
 
+    timeline = {} if os.environ.get("SHN_DEBUG_PARTS") else None
+
     def one_partition(name):
         """multibridged graph of one partition (multibridging.main for `name`); returns its record + timings"""
-        tt = {}
+        rec, tt = _one_partition(name)
+        if timeline is not None:
+            timeline[name] = (tt.pop("_t0") - t_graph, time.time() - t_graph, dict(tt), len(part["routes"][name]))
+        else:
+            tt.pop("_t0", None)
+        return rec, tt
+
+    def _one_partition(name):
+        tt = {"_t0": time.time()}
         t0 = time.time()
         n_kmers = unitigs.n_kmers(part_index[name]) if unitigs is not None else part["n_kmer_nodes"][name]
         cutoff = 10 * n_kmers + 1                                    # multibridging.py:26-30, 385-391
@@ -175,6 +185,11 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
     if unitigs is not None:
         unitigs.close()
     wall = time.time() - t_graph
+    if timeline is not None:
+        import sys
+        for nm, (a, b, tt_, nr) in sorted(timeline.items(), key=lambda kv: -kv[1][1])[:12]:
+            sys.stderr.write("[parts] %-16s start %6.2f end %6.2f  routed %8d  %s\n" % (nm, a, b, nr, {k: round(v, 2) for k, v in tt_.items()}))
+        sys.stderr.write("[parts] stage wall %.2f s, %d partitions, %d threads\n" % (wall, len(names), graph_threads))
     busy = sum(sum(tt.values()) for _, tt in results) or 1.0
     for name, (rec, tt) in zip(names, results):
         for k_, v in tt.items():                                      # wall time of the stage, split like the thread time
