@@ -46,6 +46,9 @@ const char* shn_version(void);
 int shn_ctx_create(int device, void* stream, shn_ctx** out);
 void shn_ctx_destroy(shn_ctx* ctx);
 int shn_ctx_sync(shn_ctx* ctx);
+/* A second context on the device of `parent` with a stream of its own (destroyed with it), for a host thread that works beside the
+ * owner of `parent`; event timing is off on it.                                                                                 */
+int shn_ctx_fork(const shn_ctx* parent, shn_ctx** out);
 
 /* HIP-event timing on the context's stream (bench.py: per-kernel-group durations).
  * shn_timer_begin/end bracket a region under `slot` (0..31); shn_timer_ms() synchronises and

@@ -23,6 +23,12 @@ enum {
   T_EXTEND, T_ROUTE, T_GRAPH, T_LP, T_EXT_PREP, T_EXT_SORT, T_EXT_WALK, T_SEEDS, T_EXT_WALK_THREAD, T_EXT_WALK_WAVE, T_EXT_MARK, T_EXT_EMIT, T_TABLE_BUILD, T_COUNT_DIRECT, T_CONTIG, T_GRAPH_GPU, T_N = 32
 };
 
+// grow-only device workspace slot (process-wide ones: g_shn_ws below; per-context ones: shn_ctx::cws)
+struct ShnWs {
+  void* p = nullptr; size_t cap = 0; uint64_t stage = 0;
+  int get(size_t bytes, void** out);
+};
+
 struct shn_ctx {
   int device;
   hipStream_t stream;
@@ -31,7 +37,10 @@ struct shn_ctx {
   double ms[T_N];
   uint64_t regions[T_N];
   bool timing;
+  bool owns_stream;        // shn_ctx_fork: the stream is destroyed with the context
   int count_direct_log2;   // one-pass counting: table size that sufficed last time (0 none yet, -1 gave up), shn_count_k1mers
+  ShnWs cws[4];            // per-context workspaces of the calls several host threads make at the same time, each on its own
+                           // context / stream (the graph threads' seed scans): [0] scan block sums, [1] [2] seed-scan counts / offsets
 };
 
 // RAII-less region timer: records events on the ctx stream; durations are summed lazily.
@@ -145,10 +154,6 @@ void shn_dev_free(void* p);
 void shn_dev_trim();                         // give the cached blocks back to the driver
 template <class T> static inline hipError_t shn_dev_malloc(T** p, size_t bytes) { return shn_dev_malloc_raw((void**)p, bytes); }
 
-struct ShnWs {
-  void* p = nullptr; size_t cap = 0; uint64_t stage = 0;
-  int get(size_t bytes, void** out);
-};
 void shn_stage_begin();                      // a top-level GPU stage starts (workspace slots used before it become reclaimable)
 size_t shn_ws_release_idle();                // frees the slots not used by the current stage; returns the bytes given back
 extern ShnWs g_shn_ws[32];

@@ -97,6 +97,7 @@ extern "C" int shn_ctx_create(int device, void* stream, shn_ctx** out) {
   c->stream = (hipStream_t)stream;
   c->timing = true;
   c->count_direct_log2 = 0;
+  c->owns_stream = false;
   for (int i = 0; i < T_N; i++) { c->ms[i] = 0; c->regions[i] = 0; }
   *out = c;
   return SHN_OK;
@@ -108,8 +109,24 @@ extern "C" void shn_ctx_destroy(shn_ctx* c) {
   hipStreamSynchronize(c->stream);
   for (int i = 0; i < T_N; i++)
     for (auto& p : c->pending[i]) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-  shn_dev_trim();
+  if (c->owns_stream && c->stream) hipStreamDestroy(c->stream);
+  for (auto& w : c->cws) if (w.p) { hipFree(w.p); w.p = nullptr; w.cap = 0; }
+  if (!c->owns_stream) shn_dev_trim();         // (a forked context goes with its host thread, in the middle of a run)
   delete c;
+}
+
+// A second context on the same device with a stream of its own, for a host thread that works beside the owner of `parent`
+// (the graph threads: their seed scans overlap on the GPU instead of taking turns).  Event timing is off on it.
+extern "C" int shn_ctx_fork(const shn_ctx* parent, shn_ctx** out) {
+  if (!parent || !out) return shn_fail(SHN_ERR_ARG, "shn_ctx_fork: NULL argument");
+  HIP_TRY(hipSetDevice(parent->device));
+  hipStream_t st = nullptr;
+  HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  shn_ctx* c = new shn_ctx();
+  c->device = parent->device; c->stream = st; c->timing = false; c->count_direct_log2 = 0; c->owns_stream = true;
+  for (int i = 0; i < T_N; i++) { c->ms[i] = 0; c->regions[i] = 0; }
+  *out = c;
+  return SHN_OK;
 }
 
 extern "C" int shn_ctx_sync(shn_ctx* c) {

@@ -496,7 +496,7 @@ int shn_device_scan_u32(shn_ctx* ctx, const uint32_t* d_in, uint64_t n, uint64_t
   uint64_t nblocks = cdiv(n, 1024);
   if (nblocks == 0) nblocks = 1;
   void* sums;
-  int rc = g_ws[7].get((nblocks + 1) * 8, &sums);
+  int rc = ctx->cws[0].get((nblocks + 1) * 8, &sums);         // (per context: scans of different host threads / streams do not share it)
   if (rc) return rc;
   uint64_t* d_sums = (uint64_t*)sums;
   uint64_t* d_total = d_sums + nblocks;

@@ -11,6 +11,7 @@
 #include "graph_result.h"
 #include <thread>
 #include <mutex>
+#include <sys/mman.h>
 #include <condition_variable>
 #include <string>
 #include <vector>
@@ -69,8 +70,8 @@ struct RStr {
   const char* end() const { return p + n; }
 };
 
-// several partitions may run on host threads at once; their GPU sections take turns
-static std::mutex g_gpu_mutex;
+// several partitions run on host threads at once; every thread has a context / stream of its own (ThreadCtx below), the
+// calls its GPU sections make use per-call or per-context buffers only, so the sections overlap on the device
 
 // Host-thread budget shared by the partitions of a process.  The multi-threaded phases of a partition (read decode, duplicate
 // search, numbering, path classification) take as many tokens as they start threads; with 64 partitions beginning at once and up
@@ -80,11 +81,35 @@ struct ThreadBudget {
   std::mutex mu; std::condition_variable cv; int avail;
   ThreadBudget() { const int hw = (int)std::thread::hardware_concurrency(); avail = std::max(8, hw - hw / 16); if (getenv("SHN_GRAPH_HOST_THREADS")) avail = std::max(1, atoi(getenv("SHN_GRAPH_HOST_THREADS"))); total = avail; }
   int total;
-  void acquire(int n) { n = std::min(n, total); std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return avail >= n; }); avail -= n; }
+  // large requests (the large partitions, which bound the stage) never wait -- they may overdraw the budget; small ones wait for it
+  void acquire(int n) { n = std::min(n, total); std::unique_lock<std::mutex> lk(mu); if (n < 8) cv.wait(lk, [&] { return avail >= n; }); avail -= n; }
   void release(int n) { n = std::min(n, total); { std::lock_guard<std::mutex> lk(mu); avail += n; } cv.notify_all(); }
 };
 static ThreadBudget g_host_threads;
-struct BudgetGuard { int n; explicit BudgetGuard(int k) : n(k) { g_host_threads.acquire(n); } ~BudgetGuard() { g_host_threads.release(n); } };
+struct BudgetGuard {
+  int n; double waited;
+  explicit BudgetGuard(int k) : n(k) {
+    auto t0 = std::chrono::steady_clock::now();
+    g_host_threads.acquire(n);
+    waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  ~BudgetGuard() { g_host_threads.release(n); }
+};
+
+// a context of its own (same device, own stream) for every graph thread: their GPU sections overlap instead of taking turns
+struct ThreadCtx {
+  shn_ctx* c = nullptr; const shn_ctx* parent = nullptr;
+  shn_ctx* get(shn_ctx* p) {
+    if (!p) return nullptr;
+    if (c && parent == p) return c;
+    if (c) { shn_ctx_destroy(c); c = nullptr; }
+    if (shn_ctx_fork(p, &c)) { c = nullptr; return p; }
+    parent = p;
+    return c;
+  }
+  ~ThreadCtx() { if (c) shn_ctx_destroy(c); }
+};
+static thread_local ThreadCtx t_ctx;
 
 struct Graph {
   shn_ctx* ctx = nullptr;                   // non-NULL: K-mer seed scans run on the GPU (csrc/seeds.hip)
@@ -384,7 +409,7 @@ struct Graph {
   const shn_reads *src_a = nullptr, *src_b = nullptr;      // the resident input read sets the partition's reads are rows of
   std::vector<uint32_t> origin_row;                        // per distinct read: row in its set, and
   std::vector<uint8_t> origin_flag;                        // bit 0: set b, bit 1: reverse complement
-  void release_gpu() { if (d_reads) { std::lock_guard<std::mutex> lk(g_gpu_mutex); shn_reads_destroy(d_reads); d_reads = nullptr; } }
+  void release_gpu() { if (d_reads) { shn_reads_destroy(d_reads); d_reads = nullptr; } }
 
   void find_bridging_reads() {
     std::vector<std::pair<uint64_t, std::pair<int, int>>> items;
@@ -394,12 +419,11 @@ struct Graph {
     si.build(items);
     shn_table* tab = nullptr;
     {
-      // GPU section (one partition at a time: the device workspaces and the context's stream are shared)
+      // GPU section (on this thread's own context / stream)
       bool gpu_ok = false;
       uint64_t nh = 0;
       std::vector<uint32_t> hr, hs, hi;
       {
-        std::lock_guard<std::mutex> lk(g_gpu_mutex);
         if (gpu_patterns(si, &d_reads, &tab)) {
           gpu_ok = shn_seed_scan(ctx, d_reads, K, tab, &nh, nullptr, nullptr, nullptr) == 0;
           if (gpu_ok && nh) {
@@ -631,7 +655,6 @@ struct Graph {
     shn_table* tab = nullptr;
     bool done = false;
     {
-      std::lock_guard<std::mutex> lk(g_gpu_mutex);
       if (gpu_patterns(si, &d_reads, &tab)) {
         done = shn_seed_ends(ctx, d_reads, K, tab, first.data(), last.data()) == 0;
         shn_table_destroy(tab);
@@ -856,7 +879,7 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
   if (!out || (n_rows && !rows) || (n_reads && (!r1 || !r1_off)) || (paired && n_reads && (!r2 || !r2_off)))
     return shn_fail(SHN_ERR_ARG, "shn_mbgraph_run: NULL argument");
   Graph g;
-  g.ctx = ctx;
+  g.ctx = t_ctx.get(ctx);
   g.K = K;
   g.L = n_reads ? (int)(r1_off[1] - r1_off[0]) : -1;
   g.SIZE_THRESHOLD = g.L;
@@ -969,8 +992,15 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
       doff[i * nm + 1] = doff[i * nm] + (r1_off[i + 1] - r1_off[i]);
       if (paired) doff[i * nm + 2] = doff[i * nm + 1] + (r2_off[i + 1] - r2_off[i]);
     }
-    if (text.size() < doff.back() + 1) text.resize(doff.back() + 1);
+    auto huge = [](const void* p, size_t bytes) {                 // transparent huge pages for the large scratch buffers (THP in madvise mode)
+      if (bytes < (8u << 20)) return;
+      const uintptr_t a = ((uintptr_t)p + 4095) & ~(uintptr_t)4095, e = ((uintptr_t)p + bytes) & ~(uintptr_t)4095;
+      if (e > a) madvise((void*)a, e - a, MADV_HUGEPAGE);
+    };
+    if (text.size() < doff.back() + 1) { text.clear(); text.reserve(doff.back() + 1); huge(text.data(), text.capacity()); text.resize(doff.back() + 1); }
+    if (hashes.capacity() < (size_t)used * nm) { hashes.clear(); hashes.reserve((size_t)used * nm); huge(hashes.data(), hashes.capacity() * 8); }
     hashes.resize((size_t)used * nm);
+    if (g.rindex.arena.capacity() >= (8u << 20)) huge(g.rindex.arena.data(), g.rindex.arena.capacity());
     double t_dec = now();
     std::atomic<int> non_acgt{0};
     auto work = [&](uint64_t lo, uint64_t hi) {
@@ -1013,7 +1043,7 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
       for (auto& t : th) t.join();
     }
     g.acgt_known = non_acgt.load() ? 0 : 1;
-    if (dbg) fprintf(stderr, "[mbgraph]   offsets+decode+hash   %8.3f s  used=%llu nt=%u\n", now() - t_dec, (unsigned long long)used, nt);
+    if (dbg) fprintf(stderr, "[mbgraph]   offsets+decode+hash   %8.3f s  used=%llu nt=%u (waited %.3f s for threads)\n", now() - t_dec, (unsigned long long)used, nt, budget.waited);
     const uint64_t nh = used * nm;
     if (nt > 1 && nh >= bulk_min && g.rindex.size() == 0) {
       // Large read sets, all on `nt` host threads: (1) the duplicates -- every thread owns the strings whose hash falls into

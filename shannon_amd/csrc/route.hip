@@ -235,6 +235,54 @@ extern "C" int shn_table_create(shn_ctx* ctx, const uint64_t* keys, const uint32
   if (!ctx || !out || (n && (!keys || !values))) return shn_fail(SHN_ERR_ARG, "shn_table_create: NULL argument");
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
+  if (n <= (1u << 22) && !getenv("SHN_TABLE_DEVICE_BUILD")) {
+    // Small dictionaries (the graph stage's K-mer seed tables: a few 10^5 keys, one or two per partition, made by many host threads
+    // at once) are laid out on the host -- bucket = top bits of fmix64(key), ascending inside a bucket, duplicates summed -- and
+    // uploaded: three copies on the caller's stream instead of the dozen launches and syncs of the device pipeline, and no use of
+    // the process-wide workspaces, so that calls of different threads (each on its own context) overlap.
+    int bits = 0;
+    while (bits < 23 && (n >> bits) > 96) bits++;
+    const uint64_t nbk = 1ULL << bits;
+    std::vector<uint32_t> bucket(n);
+    std::vector<uint64_t> boff(nbk + 1, 0);
+    for (uint64_t i = 0; i < n; i++) { bucket[i] = bits ? (uint32_t)(shn_mix64(keys[i]) >> (64 - bits)) : 0u; boff[bucket[i] + 1]++; }
+    for (uint64_t b = 0; b < nbk; b++) boff[b + 1] += boff[b];
+    std::vector<uint64_t> cur(boff.begin(), boff.end() - 1), sk(n);
+    std::vector<uint32_t> sv(n);
+    for (uint64_t i = 0; i < n; i++) { const uint64_t at = cur[bucket[i]]++; sk[at] = keys[i]; sv[at] = values[i]; }
+    std::vector<uint32_t> idx;
+    uint64_t total = 0, w = 0;
+    std::vector<uint64_t> nboff(nbk + 1, 0);
+    for (uint64_t b = 0; b < nbk; b++) {
+      const uint64_t lo = boff[b], hi = boff[b + 1];
+      idx.resize(hi - lo);
+      for (uint64_t i = 0; i < hi - lo; i++) idx[i] = (uint32_t)i;
+      std::sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return sk[lo + x] < sk[lo + y]; });
+      nboff[b] = w;
+      // (in place: w never passes the read position of the bucket being written)
+      std::vector<uint64_t> tk(hi - lo); std::vector<uint32_t> tv(hi - lo);
+      for (uint64_t i = 0; i < hi - lo; i++) { tk[i] = sk[lo + idx[i]]; tv[i] = sv[lo + idx[i]]; }
+      for (uint64_t i = 0; i < hi - lo; i++) {
+        total += tv[i];
+        if (w > nboff[b] && sk[w - 1] == tk[i]) sv[w - 1] += tv[i];
+        else { sk[w] = tk[i]; sv[w] = tv[i]; w++; }
+      }
+    }
+    nboff[nbk] = w;
+    shn_table* t = new shn_table();
+    memset(t, 0, sizeof(*t));
+    t->ctx = ctx; t->device = ctx->device; t->k = k; t->canonical = canonical; t->bits = bits; t->n_buckets = nbk; t->total = total; t->n = w;
+    hipError_t e = shn_dev_malloc(&t->d_keys, (w + 1) * 8);
+    if (e == hipSuccess) e = shn_dev_malloc(&t->d_counts, (w + 1) * 4);
+    if (e == hipSuccess) e = shn_dev_malloc(&t->d_bucket_off, (nbk + 1) * 8);
+    if (e == hipSuccess && w) e = hipMemcpyAsync(t->d_keys, sk.data(), w * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && w) e = hipMemcpyAsync(t->d_counts, sv.data(), w * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(t->d_bucket_off, nboff.data(), (nbk + 1) * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { shn_table_destroy(t); return shn_fail(SHN_ERR_HIP, std::string("shn_table_create: ") + hipGetErrorString(e)); }
+    *out = t;
+    return SHN_OK;
+  }
   uint64_t* dk = nullptr; uint32_t* dv = nullptr;
   HIP_TRY(shn_dev_malloc(&dk, (n + 1) * 8));
   HIP_TRY(shn_dev_malloc(&dv, (n + 1) * 4));

@@ -74,7 +74,7 @@ static int seed_scan_impl(shn_ctx* ctx, const shn_reads* reads, int K, const shn
   if (total == 0) { *n_hits = 0; return SHN_OK; }
   void *pc, *po;
   int rc;
-  if ((rc = g_shn_ws[25].get((total + 1) * 4, &pc)) || (rc = g_shn_ws[26].get((total + 2) * 8, &po))) return rc;
+  if ((rc = ctx->cws[1].get((total + 1) * 4, &pc)) || (rc = ctx->cws[2].get((total + 2) * 8, &po))) return rc;
   uint32_t grid = (uint32_t)cdiv(total, SBLK2);
   hipLaunchKernelGGL((seed_scan_kernel<false, ALL>), dim3(grid), dim3(SBLK2), 0, s, v, K, max_win, patterns->d_keys, patterns->d_counts,
                      patterns->d_bucket_off, patterns->bits, (uint32_t*)pc, nullptr, nullptr, nullptr, nullptr);

@@ -385,6 +385,45 @@ class ReadStore(object):
     def __init__(self, r1, r2=None):
         self.r1, self.r2 = r1, r2         # lists of strings or uint8 code matrices
         self.n = len(r1)
+        # Row buffers handed to the graph stage are recycled (release()): a partition at the read cap gathers 400 MB of rows, a run
+        # at 100 M reads 24 GB per step, and with 64 partition threads faulting fresh pages in at the same time the kernel's
+        # address-space lock, not the work, set the pace of the stage.
+        import threading
+        self._pool, self._pool_lock, self._off = [], threading.Lock(), None
+
+    def _rows_buffer(self, n_rows, L):
+        need = n_rows * L
+        with self._pool_lock:
+            best = -1
+            for i, b in enumerate(self._pool):
+                if len(b) >= need and (best < 0 or len(b) < len(self._pool[best])):
+                    best = i
+            buf = self._pool.pop(best) if best >= 0 else None
+        if buf is None:
+            buf = np.empty(max(need, 1 << 20), dtype=np.uint8)
+            try:                                     # transparent huge pages where the system offers them on request (madvise mode)
+                import ctypes as _C
+                _C.CDLL(None).madvise(_C.c_void_p(buf.ctypes.data & ~4095), _C.c_size_t(buf.nbytes), 14)
+            except Exception:
+                pass
+        return buf
+
+    def release(self, flat_rows):
+        """give a buffer of gather_codes back (the flat array it returned, or its base)"""
+        b = flat_rows
+        while getattr(b, "base", None) is not None and isinstance(b.base, np.ndarray):
+            b = b.base
+        if isinstance(b, np.ndarray) and b.dtype == np.uint8 and b.ndim == 1:
+            with self._pool_lock:
+                if len(self._pool) < 256:
+                    self._pool.append(b)
+
+    def _offsets(self, n_rows, L):
+        o = self._off
+        if o is None or len(o) < n_rows + 1 or o[1] != L:
+            o = np.arange(max(n_rows + 1, 1 << 16), dtype=np.uint64) * np.uint64(L)
+            self._off = o
+        return o[:n_rows + 1]
 
     @staticmethod
     def _get(src, i):
@@ -408,7 +447,7 @@ class ReadStore(object):
         second = idx >= n
         # one gather per source matrix straight into the output (idx is ascending: forward half first)
         L0 = self.r1.shape[1]
-        rows = np.empty((len(idx), L0), dtype=np.uint8)
+        rows = self._rows_buffer(len(idx), L0)[:len(idx) * L0].reshape(len(idx), L0)
         src2 = self.r1 if self.r2 is None else self.r2
         f = int(np.searchsorted(idx, n)) if (len(idx) < 2 or bool((idx[1:] >= idx[:-1]).all())) else -1
         if f >= 0 and len(idx) >= 4096 and self.r1.flags["C_CONTIGUOUS"] and src2.flags["C_CONTIGUOUS"] and self.r1.dtype == np.uint8:
@@ -428,8 +467,7 @@ class ReadStore(object):
         else:
             rc = ~second                                                    # RC(R1[d]) / R2[d-n]
         L = rows.shape[1]
-        return (np.ascontiguousarray(rows, dtype=np.uint8).reshape(-1), np.arange(len(idx) + 1, dtype=np.uint64) * np.uint64(L),
-                np.ascontiguousarray(rc, dtype=np.uint8), 1)
+        return (rows.reshape(-1), self._offsets(len(idx), L), np.ascontiguousarray(rc, dtype=np.uint8), 1)
 
     def gather(self, idx, mate):
         """Reads `mate` (1 or 2) of the doubled indices `idx` as (uint8 ASCII buffer, uint64 offsets) -- the

@@ -156,6 +156,10 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
                                                          o2, ctx=ctx, enc=enc, rc1=rc1, rc2=rc2, unitigs=unitigs, part=part_index[name],
                                                          resident=res_src)
             n_rows = part["n_k1mer_rows"][name]
+            if enc == 1:
+                store.release(b1)
+                if b2 is not None and b2 is not b1:
+                    store.release(b2)
             tt["graph"] = time.time() - t0
             return PartitionRecord(len(part["routes"][name]), n_rows, gh), tt
         else:
