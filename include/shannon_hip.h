@@ -295,6 +295,19 @@ int shn_mbgraph_run_resident(shn_ctx* ctx, const shn_unitigs* ug, uint32_t part,
                              const shn_reads* src_b, const uint32_t* didx, const uint8_t* r1, const uint64_t* r1_off, const uint8_t* r2,
                              const uint64_t* r2_off, uint64_t n_reads, int paired, int enc, const uint8_t* rc1, const uint8_t* rc2,
                              shn_graph** out);
+/* The same with the reads named by their rows only: host_a / host_b = the run's reads as host code matrices (uint8 codes 0..3,
+ * [reads of the set][read length]; what src_a / src_b hold packed), didx / n_reads as above.  load_reads / load_mated_reads
+ * (multibridging.py:185-236) then run as shn_reads_dedup on the device; the host decodes the text of the distinct reads from
+ * the matrices.  Fails on a routed read with a base outside ACGT (routed reads have none, kmers_for_component.py:336,376).     */
+int shn_mbgraph_run_rows(shn_ctx* ctx, const shn_unitigs* ug, uint32_t part, const uint8_t* rows, uint64_t n_rows, const shn_reads* src_a,
+                         const shn_reads* src_b, const uint8_t* host_a, const uint8_t* host_b, const uint32_t* didx, uint64_t n_reads,
+                         int paired, shn_graph** out);
+/* The distinct reads among the slots of a partition's routed reads (slot j = read j / nm of didx, mate j % nm; nm = 2 if paired),
+ * numbered in order of first occurrence as Read.reads numbers them (mbgraph.py:56-70): slot_out[id] = first slot, count_out[id] =
+ * copies, and for pairs role_out[id] (1 / 2) and mate_out[id] of the read's LAST occurrence (multibridging.py:214-236; single-end:
+ * 0 / -1).  Host output arrays need room for n * nm entries.                                                                     */
+int shn_reads_dedup(shn_ctx* ctx, const shn_reads* a, const shn_reads* b, const uint32_t* didx, uint64_t n, int paired, uint64_t* n_distinct,
+                    uint32_t* slot_out, uint32_t* count_out, int32_t* mate_out, uint8_t* role_out);
 /* Rows of resident fixed-length read sets as a new read set: read i = row rows[i] of set a (flags[i] bit 0 clear) or b (set),
  * reverse-complemented if bit 1 is set; the selected rows must hold ACGT only.                                                   */
 int shn_reads_gather(shn_ctx* ctx, const shn_reads* a, const shn_reads* b, const uint32_t* rows, const uint8_t* flags, uint64_t n,

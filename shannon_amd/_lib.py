@@ -67,6 +67,8 @@ SIGNATURES = {
     "shn_mbgraph_run_unitigs": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, vpp]),
     "shn_graph_sizes": (C.c_int, [vp, u64p]),
     "shn_graph_export": (C.c_int, [vp] + [vp] * 20),
+    "shn_mbgraph_run_rows": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, vp, vp, C.c_uint64, C.c_int, vpp]),
+    "shn_reads_dedup": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_int, vp, vp, vp, vp, vp]),
     "shn_mbgraph_run_resident": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, vpp]),
     "shn_reads_gather": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, vpp]),
     "shn_graph_from_tables": (C.c_int, [vp] * 20 + [vpp]),

@@ -843,7 +843,9 @@ static void decode_read(char* s, const uint8_t* p, uint64_t n, int enc, bool rc)
 static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n_rows, const shn_unitigs* ug, uint32_t part, const uint8_t* r1,
                            const uint64_t* r1_off, const uint8_t* r2, const uint64_t* r2_off, uint64_t n_reads, int paired, int enc,
                            const uint8_t* rc1, const uint8_t* rc2, shn_graph** out, const shn_reads* src_a = nullptr, const shn_reads* src_b = nullptr,
-                           const uint32_t* didx = nullptr);
+                           const uint32_t* didx = nullptr, const uint8_t* host_a = nullptr, const uint8_t* host_b = nullptr);
+extern "C" int shn_reads_dedup(shn_ctx* ctx, const shn_reads* a, const shn_reads* b, const uint32_t* didx, uint64_t n, int paired,
+                               uint64_t* n_distinct, uint32_t* slot_out, uint32_t* count_out, int32_t* mate_out, uint8_t* role_out);
 
 extern "C" int shn_mbgraph_run(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n_rows, const uint8_t* r1, const uint64_t* r1_off,
                                const uint8_t* r2, const uint64_t* r2_off, uint64_t n_reads, int paired, int enc, const uint8_t* rc1,
@@ -872,23 +874,39 @@ extern "C" int shn_mbgraph_run_resident(shn_ctx* ctx, const shn_unitigs* ug, uin
   return mbgraph_run_impl(ctx, ug->K, rows, n_rows, ug, part, r1, r1_off, r2, r2_off, n_reads, paired, enc, rc1, rc2, out, src_a, src_b, didx);
 }
 
+// The partition's reads named only by their rows: host_a / host_b = the run's reads as host code matrices (uint8 codes 0-3,
+// [n_reads of the set][read length], the same reads as src_a / src_b hold packed on the device), didx as above.  The distinct
+// reads are found on the device (shn_reads_dedup) and only their text is decoded on the host, straight from the matrices: no
+// per-partition copy of the routed reads exists anywhere.
+extern "C" int shn_mbgraph_run_rows(shn_ctx* ctx, const shn_unitigs* ug, uint32_t part, const uint8_t* rows, uint64_t n_rows, const shn_reads* src_a,
+                                    const shn_reads* src_b, const uint8_t* host_a, const uint8_t* host_b, const uint32_t* didx, uint64_t n_reads,
+                                    int paired, shn_graph** out) {
+  if (!ug || part >= ug->n_parts) return shn_fail(SHN_ERR_ARG, "shn_mbgraph_run_rows: bad unitigs / partition");
+  if (!ctx || !src_a || !host_a || (n_reads && !didx) || (paired && (!src_b || !host_b)) || !src_a->fixed_len ||
+      (paired && src_b->fixed_len != src_a->fixed_len))
+    return shn_fail(SHN_ERR_ARG, "shn_mbgraph_run_rows: needs a context, fixed-length resident read sets and their host matrices");
+  return mbgraph_run_impl(ctx, ug->K, rows, n_rows, ug, part, nullptr, nullptr, nullptr, nullptr, n_reads, paired, SHN_ENC_CODES, nullptr, nullptr, out,
+                          src_a, src_b, didx, host_a, host_b);
+}
+
 static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n_rows, const shn_unitigs* ug, uint32_t part, const uint8_t* r1,
                            const uint64_t* r1_off, const uint8_t* r2, const uint64_t* r2_off, uint64_t n_reads, int paired, int enc,
                            const uint8_t* rc1, const uint8_t* rc2, shn_graph** out, const shn_reads* src_a, const shn_reads* src_b,
-                           const uint32_t* didx) {
-  if (!out || (n_rows && !rows) || (n_reads && (!r1 || !r1_off)) || (paired && n_reads && (!r2 || !r2_off)))
+                           const uint32_t* didx, const uint8_t* host_a, const uint8_t* host_b) {
+  if (!out || (n_rows && !rows) || (!host_a && ((n_reads && (!r1 || !r1_off)) || (paired && n_reads && (!r2 || !r2_off)))))
     return shn_fail(SHN_ERR_ARG, "shn_mbgraph_run: NULL argument");
   Graph g;
   g.ctx = t_ctx.get(ctx);
   g.K = K;
-  g.L = n_reads ? (int)(r1_off[1] - r1_off[0]) : -1;
+  const uint64_t read_len0 = !n_reads ? 0 : host_a ? src_a->fixed_len : (uint64_t)(r1_off[1] - r1_off[0]);
+  g.L = n_reads ? (int)read_len0 : -1;
   g.SIZE_THRESHOLD = g.L;
   const bool dbg = getenv("SHN_DEBUG") != nullptr;
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double tt = now();
   // origin of read slot j = i * nm + mate (mate 0 / 1) in the resident input, for the device gather of the distinct reads
   const bool resident = ctx && src_a && didx && src_a->fixed_len && (!paired || (src_b && src_b->fixed_len == src_a->fixed_len)) &&
-                        n_reads && (uint64_t)(r1_off[1] - r1_off[0]) == src_a->fixed_len && getenv("SHN_GRAPH_RESIDENT_READS") == nullptr;
+                        n_reads && read_len0 == src_a->fixed_len && (host_a || getenv("SHN_GRAPH_RESIDENT_READS") == nullptr);
   if (resident) { g.src_a = src_a; g.src_b = paired ? src_b : nullptr; }
   const uint64_t N_in = src_a ? src_a->n_reads : 0;
   auto origin_of = [&](uint64_t j, uint32_t& row, uint8_t& flag) {
@@ -941,17 +959,25 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
   struct Scratch {
     std::vector<uint64_t> doff, hashes; std::vector<char> text; std::string arena; std::vector<uint32_t> first, cnt, last; std::vector<int32_t> idmap;
     std::vector<double> rcc; std::vector<int> rmate, rmp, rfirst, rlast; std::vector<char> rhas; std::vector<uint64_t> r_hashes, r_off;
+    std::vector<uint8_t> role;
+    size_t room() const { return std::max(text.capacity(), arena.capacity()); }
   };
   static std::mutex scratch_mu;
   static std::vector<Scratch*> scratch_free;
   Scratch* sc = nullptr;
-  const size_t need_text = (size_t)std::min<uint64_t>(n_reads, cutoff + 1) * (paired ? 2 : 1) * (n_reads ? (size_t)(r1_off[1] - r1_off[0]) : 0);
+  // the distinct reads found on the device: with the host matrices always, with gathered rows for large sets
+  uint64_t bulk_min = 1u << 17;                         // reads from which the duplicates are found in parallel (tests lower it)
+  if (getenv("SHN_GRAPH_BULK_MIN")) bulk_min = strtoull(getenv("SHN_GRAPH_BULK_MIN"), nullptr, 10);
+  const char* dd_env = getenv("SHN_GRAPH_DEVICE_DEDUP");
+  const bool dev_dedup = resident && (host_a || ((!dd_env || dd_env[0] != '0') && enc == SHN_ENC_CODES &&
+                                                 std::min<uint64_t>(n_reads, cutoff + 1) * (paired ? 2 : 1) >= bulk_min));
+  const size_t need_text = (size_t)std::min<uint64_t>(n_reads, cutoff + 1) * (paired ? 2 : 1) * (size_t)read_len0 / (dev_dedup ? 2 : 1);
   { std::lock_guard<std::mutex> lk(scratch_mu);
     int pick = -1;
     for (size_t i = 0; i < scratch_free.size(); i++) {
-      const size_t c = scratch_free[i]->text.capacity();
+      const size_t c = scratch_free[i]->room();
       if (pick < 0) { pick = (int)i; continue; }
-      const size_t pc = scratch_free[pick]->text.capacity();
+      const size_t pc = scratch_free[pick]->room();
       if (pc >= need_text ? (c >= need_text && c < pc) : c > pc) pick = (int)i;
     }
     if (pick >= 0) { sc = scratch_free[pick]; scratch_free.erase(scratch_free.begin() + pick); } }
@@ -971,7 +997,63 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
   sc->rcc.clear(); sc->rmate.clear(); sc->rmp.clear(); sc->rfirst.clear(); sc->rlast.clear(); sc->rhas.clear(); sc->r_hashes.clear(); sc->r_off.assign(1, 0);
   g.rcc.swap(sc->rcc); g.rmate.swap(sc->rmate); g.rmp.swap(sc->rmp); g.rfirst.swap(sc->rfirst); g.rlast.swap(sc->rlast); g.rhas.swap(sc->rhas);
   g.rindex.hashes.swap(sc->r_hashes); g.rindex.off.swap(sc->r_off);
-  {
+  if (dev_dedup) {
+    const uint64_t used = std::min<uint64_t>(n_reads, cutoff + 1);
+    const int nm = paired ? 2 : 1;
+    const uint64_t nh = used * nm, Lr = read_len0;
+    double t_dec = now();
+    std::vector<uint32_t>&slot = sc->first, &cnt = sc->cnt;
+    std::vector<int32_t>& mate = sc->idmap;
+    std::vector<uint8_t>& role = sc->role;
+    slot.resize(nh); cnt.resize(nh); mate.resize(nh); role.resize(nh);
+    uint64_t nd = 0;
+    int rcd = shn_reads_dedup(g.ctx, src_a, paired ? src_b : nullptr, didx, used, paired, &nd, slot.data(), cnt.data(), mate.data(), role.data());
+    if (rcd) return rcd;
+    if (dbg) fprintf(stderr, "[mbgraph]   distinct reads (GPU)   %8.3f s  used=%llu distinct=%llu\n", now() - t_dec, (unsigned long long)used, (unsigned long long)nd);
+    StringInterner& R = g.rindex;
+    R.hashes.assign(nd, 0);
+    R.off.resize(nd + 1);
+    if (R.arena.capacity() < nd * Lr) { R.arena.reserve(nd * Lr); if (nd * Lr >= (8u << 20)) { const uintptr_t a = ((uintptr_t)R.arena.data() + 4095) & ~(uintptr_t)4095; madvise((void*)a, (nd * Lr) & ~(size_t)4095, MADV_HUGEPAGE); } }
+    R.arena.resize(nd * Lr);
+    g.rcc.resize(nd); g.rmate.resize(nd); g.rmp.resize(nd); g.rfirst.assign(nd, -1); g.rlast.assign(nd, -1); g.rhas.assign(nd, 0);
+    g.origin_row.resize(nd); g.origin_flag.resize(nd);
+    const unsigned hwc = std::max(1u, std::thread::hardware_concurrency());
+    unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(32, std::max(1u, hwc / 4)), nd >> 15));
+    BudgetGuard budget((int)nt);
+    std::atomic<int> non_acgt{0};
+    char* arena = &R.arena[0];
+    auto work = [&](uint64_t lo, uint64_t hi) {
+      bool bad = false;
+      for (uint64_t id = lo; id < hi; id++) {
+        const uint64_t j = slot[id];
+        uint32_t row; uint8_t fl;
+        origin_of(j, row, fl);
+        g.origin_row[id] = row; g.origin_flag[id] = fl;
+        const uint8_t* p; bool rc; int e = enc;
+        if (host_a) { p = ((fl & 1) ? host_b : host_a) + (uint64_t)row * Lr; rc = (fl & 2) != 0; e = SHN_ENC_CODES; }
+        else { const uint64_t i = j / nm; if (j % nm == 0) { p = r1 + r1_off[i]; rc = rc1 && rc1[i]; } else { p = r2 + r2_off[i]; rc = rc2 && rc2[i]; } }
+        char* d = arena + id * Lr;
+        decode_read(d, p, Lr, e, rc);
+        for (uint64_t q = 0; q < Lr; q++) bad |= !(d[q] == 'A' || d[q] == 'C' || d[q] == 'G' || d[q] == 'T');
+        R.off[id + 1] = (id + 1) * Lr;
+        g.rcc[id] = (double)cnt[id];
+        g.rmate[id] = mate[id];
+        g.rmp[id] = role[id];
+      }
+      if (bad) non_acgt.store(1);
+    };
+    R.off[0] = 0;
+    if (nt <= 1) work(0, nd);
+    else {
+      std::vector<std::thread> th;
+      for (unsigned t = 0; t < nt; t++) th.emplace_back(work, nd * t / nt, nd * (t + 1) / nt);
+      for (auto& t : th) t.join();
+    }
+    if (non_acgt.load()) return shn_fail(SHN_ERR_ARG, "shn_mbgraph_run: a routed read holds a base outside ACGT (the packed rows cannot tell such reads apart)");
+    g.acgt_known = 1;
+    R.bulk_loaded = true;
+    if (dbg) fprintf(stderr, "[mbgraph]   + text of the distinct %8.3f s  nt=%u (waited %.3f s for threads)\n", now() - t_dec, nt, budget.waited);
+  } else {
     uint64_t used = std::min<uint64_t>(n_reads, cutoff + 1);
     size_t bytes = used ? (size_t)(r1_off[used] - r1_off[0]) + (paired ? (size_t)(r2_off[used] - r2_off[0]) : 0) : 0;
     g.rindex.arena.reserve(bytes);
@@ -979,7 +1061,7 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
     if (nr < (1u << 17)) g.rindex.reserve(nr);          // (large sets are numbered in bulk and never use the interner's probe table)
     g.rcc.reserve(nr); g.rmate.reserve(nr); g.rmp.reserve(nr); g.rfirst.reserve(nr); g.rlast.reserve(nr); g.rhas.reserve(nr);
   }
-  {
+  if (!dev_dedup) {
     // decode + hash on several host threads (independent per read), then intern sequentially in file order
     const uint64_t used = std::min<uint64_t>(n_reads, cutoff + 1);
     const int nm = paired ? 2 : 1;
@@ -1031,8 +1113,7 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
     const unsigned hwc = std::max(1u, std::thread::hardware_concurrency());
     unsigned nt = std::min<unsigned>(32, std::max<unsigned>(1, hwc / 8 / (unsigned)std::max(1, active.n / 2)));
     nt = std::max<unsigned>(nt, (unsigned)std::min<uint64_t>(std::min<uint64_t>(32, std::max(1u, hwc / 4)), (used * (paired ? 2 : 1)) >> 18));
-    uint64_t bulk_min = 1u << 17;                       // reads from which the duplicates are found in parallel (tests lower it)
-    if (getenv("SHN_GRAPH_BULK_MIN")) { bulk_min = strtoull(getenv("SHN_GRAPH_BULK_MIN"), nullptr, 10); nt = std::max(nt, 4u); }
+    if (getenv("SHN_GRAPH_BULK_MIN")) nt = std::max(nt, 4u);
     if (used * nm < bulk_min) nt = used < 4096 ? 1 : std::min<unsigned>(nt, (unsigned)(used / 2048));   // small sets: a few threads for the decode only
     BudgetGuard budget((int)nt);                          // held until the reads are numbered
     if (nt <= 1) work(0, used);

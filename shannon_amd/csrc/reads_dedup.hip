@@ -1,0 +1,178 @@
+// The distinct reads of a partition, found on the device.
+//
+// multibridging.py:185-236 (load_reads / load_mated_reads) reads one read (pair) after the other into Read.reads, a dictionary
+// string -> Read: a string seen before only has its copy count raised (mbgraph.py:56-70), and for pairs every occurrence sets the
+// two reads' mate / mate_pair fields again, so each distinct read ends with the role and mate of its LAST occurrence.  The native
+// graph stage keeps the reads as ids in order of first occurrence.  At BASELINE configs[2] the 111 partitions hold 240 M read
+// slots (the largest 8 M, 3.6 M of them distinct); decoding, hashing and de-duplicating them on host threads was the longest
+// part of the stage.  Here the slots are rows of the packed read sets already resident on the device (slot j = read j / nm of
+// the partition's routed list, mate j % nm; shn_route_reads' doubled numbering names the row and the strand), so the same
+// answer is an open-addressing insert keyed by the packed words, two atomics per slot and one prefix sum:
+//   dd_insert   every slot looks its 2-bit words up (CAS into an empty slot, else compare words with the slot's
+//               representative; equal -> atomicMin of the slot index, so the representative ends as the FIRST occurrence)
+//   dd_tally    count and last occurrence per first occurrence; flag = "is a first occurrence"
+//   (scan)      id = number of first occurrences before the slot = the sequential numbering
+//   dd_emit     per distinct read: its first slot, count, and (pairs) role + mate id of its last occurrence
+// Output order and values equal the host code they replace (mbgraph_host.hip, bulk numbering) and the one-at-a-time interner
+// (tests/test_host_graph.py, tests/test_e2e_gpu.py).
+#include "common.h"
+
+#include <algorithm>
+#include <string>
+
+namespace {
+
+struct SlotSrc {
+  const uint64_t* wa; const uint64_t* wb; const uint32_t* didx; uint64_t n_in; uint32_t wpr, L; int paired;
+};
+
+// words of slot j (see shn_mbgraph_run_resident for the numbering): SE d < N -> R[d], d >= N -> RC(R[d-N]);
+// PE d < N -> (R1[d], RC(R1[d])), d >= N -> (RC(R2[d-N]), R2[d-N])
+__device__ __forceinline__ void slot_origin(const SlotSrc& S, uint64_t j, const uint64_t*& src, bool& rc) {
+  const uint64_t i = S.paired ? (j >> 1) : j;
+  const int mate = S.paired ? (int)(j & 1) : 0;
+  const uint64_t d = S.didx[i];
+  const bool second = d >= S.n_in;
+  const uint64_t row = second ? d - S.n_in : d;
+  bool setb;
+  if (!S.paired) { setb = false; rc = second; }
+  else if (mate == 0) { setb = second; rc = second; }
+  else { setb = second; rc = !second; }
+  src = (setb ? S.wb : S.wa) + row * S.wpr;
+}
+__device__ __forceinline__ uint64_t slot_word(const SlotSrc& S, const uint64_t* src, bool rc, uint32_t w) {
+  if (!rc) return src[w];
+  uint64_t v = 0;
+  for (uint32_t t = 0; t < 32; t++) {
+    const uint32_t p = 32 * w + t;
+    if (p >= S.L) break;
+    const uint32_t q = S.L - 1 - p;
+    const uint64_t base = (src[q >> 5] >> (62 - 2 * (q & 31))) & 3ULL;
+    v |= (3ULL - base) << (62 - 2 * t);
+  }
+  return v;
+}
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return x;
+}
+
+constexpr uint32_t EMPTY = 0xFFFFFFFFu;
+constexpr int MAXW = 16;                                  // reads of up to 512 bases
+
+__global__ void dd_insert(SlotSrc S, uint64_t nh, uint32_t* __restrict__ tab, uint64_t mask, uint32_t* __restrict__ slot_of) {
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nh; j += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t* src; bool rc;
+    slot_origin(S, j, src, rc);
+    uint64_t w[MAXW];
+    uint64_t h = 0x9E3779B97F4A7C15ULL;
+    for (uint32_t t = 0; t < S.wpr; t++) { w[t] = slot_word(S, src, rc, t); h = mix64(h ^ w[t]) + 0x9E3779B97F4A7C15ULL * (t + 1); }
+    uint64_t s = h & mask;
+    while (true) {
+      uint32_t cur = tab[s];
+      if (cur == EMPTY) {
+        cur = atomicCAS(&tab[s], EMPTY, (uint32_t)j);
+        if (cur == EMPTY) { slot_of[j] = (uint32_t)s; break; }
+      }
+      const uint64_t* osrc; bool orc;
+      slot_origin(S, cur, osrc, orc);
+      bool same = true;
+      for (uint32_t t = 0; t < S.wpr && same; t++) same = slot_word(S, osrc, orc, t) == w[t];
+      if (same) { atomicMin(&tab[s], (uint32_t)j); slot_of[j] = (uint32_t)s; break; }
+      s = (s + 1) & mask;
+    }
+  }
+}
+
+__global__ void dd_tally(uint64_t nh, const uint32_t* __restrict__ tab, const uint32_t* __restrict__ slot_of, uint32_t* __restrict__ first,
+                         uint32_t* __restrict__ cnt, uint32_t* __restrict__ last, uint32_t* __restrict__ flag) {
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nh; j += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t f = tab[slot_of[j]];
+    first[j] = f;
+    atomicAdd(&cnt[f], 1u);
+    atomicMax(&last[f], (uint32_t)j);
+    flag[j] = f == (uint32_t)j;
+  }
+}
+
+__global__ void dd_emit(uint64_t nh, int paired, const uint32_t* __restrict__ first, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ last,
+                        const uint64_t* __restrict__ pos, uint32_t* __restrict__ o_slot, uint32_t* __restrict__ o_cnt, int32_t* __restrict__ o_mate,
+                        uint8_t* __restrict__ o_role) {
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nh; j += (uint64_t)gridDim.x * blockDim.x) {
+    if (first[j] != (uint32_t)j) continue;
+    const uint64_t id = pos[j];
+    o_slot[id] = (uint32_t)j;
+    o_cnt[id] = cnt[j];
+    if (paired) {
+      const uint32_t l = last[j];
+      o_role[id] = (l & 1) ? 2 : 1;
+      o_mate[id] = (int32_t)pos[first[l ^ 1u]];
+    } else { o_role[id] = 0; o_mate[id] = -1; }
+  }
+}
+
+}  // namespace
+
+// a / b: the resident fixed-length read sets (b NULL for single-end); didx[n]: doubled read indices of the partition's reads
+// (host); outputs (host, room for n * nm entries each): slot_out[id] = first slot of distinct read id, count_out, mate_out
+// (-1 single-end), role_out (0 / 1 / 2); *n_distinct = number of distinct reads.
+extern "C" int shn_reads_dedup(shn_ctx* ctx, const shn_reads* a, const shn_reads* b, const uint32_t* didx, uint64_t n, int paired,
+                               uint64_t* n_distinct, uint32_t* slot_out, uint32_t* count_out, int32_t* mate_out, uint8_t* role_out) {
+  if (!ctx || !a || !n_distinct || (n && (!didx || !slot_out || !count_out || !mate_out || !role_out)) || (paired && !b))
+    return shn_fail(SHN_ERR_ARG, "shn_reads_dedup: NULL argument");
+  if (!a->fixed_len || a->wpr > (uint32_t)MAXW || (b && (b->fixed_len != a->fixed_len || b->wpr != a->wpr)))
+    return shn_fail(SHN_ERR_ARG, "shn_reads_dedup: fixed-length read sets of one length (<= 512 bases) only");
+  const uint64_t nm = paired ? 2 : 1, nh = n * nm;
+  *n_distinct = 0;
+  if (!nh) return SHN_OK;
+  if (nh >= (1ULL << 31)) return shn_fail(SHN_ERR_ARG, "shn_reads_dedup: more than 2^31 read slots");
+  const uint64_t n_in = a->n_reads;
+  for (uint64_t i = 0; i < n; i++) {
+    const uint64_t d = didx[i];
+    const uint64_t lim = (d >= n_in) ? (paired ? b->n_reads : a->n_reads) + n_in : n_in;
+    if (d >= lim) return shn_fail(SHN_ERR_ARG, "shn_reads_dedup: read index out of range");
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  uint64_t T = 1024;
+  while (T < 2 * nh) T <<= 1;
+  ShnDevBufs bufs;
+  uint32_t *d_idx = nullptr, *d_tab = nullptr, *d_slot = nullptr, *d_first = nullptr, *d_cnt = nullptr, *d_last = nullptr, *d_flag = nullptr;
+  uint64_t* d_pos = nullptr;
+  uint32_t *d_oslot = nullptr, *d_ocnt = nullptr; int32_t* d_omate = nullptr; uint8_t* d_orole = nullptr;
+#define TRYD(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return shn_fail(SHN_ERR_HIP, std::string("shn_reads_dedup: ") + hipGetErrorString(e_)); } while (0)
+  TRYD(bufs.get(&d_idx, n * 4));
+  TRYD(bufs.get(&d_tab, T * 4));
+  TRYD(bufs.get(&d_slot, nh * 4));
+  TRYD(bufs.get(&d_first, nh * 4));
+  TRYD(bufs.get(&d_cnt, nh * 4));
+  TRYD(bufs.get(&d_last, nh * 4));
+  TRYD(bufs.get(&d_flag, nh * 4));
+  TRYD(bufs.get(&d_pos, (nh + 1) * 8));
+  TRYD(hipMemcpyAsync(d_idx, didx, n * 4, hipMemcpyHostToDevice, s));
+  TRYD(hipMemsetAsync(d_tab, 0xFF, T * 4, s));
+  TRYD(hipMemsetAsync(d_cnt, 0, nh * 4, s));
+  TRYD(hipMemsetAsync(d_last, 0, nh * 4, s));
+  SlotSrc S{a->d_words, b ? b->d_words : a->d_words, d_idx, n_in, a->wpr, a->fixed_len, paired ? 1 : 0};
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(cdiv(nh, 256), 1u << 20);
+  hipLaunchKernelGGL(dd_insert, dim3(grid), dim3(256), 0, s, S, nh, d_tab, T - 1, d_slot);
+  hipLaunchKernelGGL(dd_tally, dim3(grid), dim3(256), 0, s, nh, d_tab, d_slot, d_first, d_cnt, d_last, d_flag);
+  TRYD(hipGetLastError());
+  uint64_t nd = 0;
+  int rc = shn_device_scan_u32(ctx, d_flag, nh, d_pos, &nd);
+  if (rc) return rc;
+  TRYD(bufs.get(&d_oslot, nd * 4));
+  TRYD(bufs.get(&d_ocnt, nd * 4));
+  TRYD(bufs.get(&d_omate, nd * 4));
+  TRYD(bufs.get(&d_orole, nd));
+  hipLaunchKernelGGL(dd_emit, dim3(grid), dim3(256), 0, s, nh, paired ? 1 : 0, d_first, d_cnt, d_last, d_pos, d_oslot, d_ocnt, d_omate, d_orole);
+  TRYD(hipGetLastError());
+  TRYD(hipMemcpyAsync(slot_out, d_oslot, nd * 4, hipMemcpyDeviceToHost, s));
+  TRYD(hipMemcpyAsync(count_out, d_ocnt, nd * 4, hipMemcpyDeviceToHost, s));
+  TRYD(hipMemcpyAsync(mate_out, d_omate, nd * 4, hipMemcpyDeviceToHost, s));
+  TRYD(hipMemcpyAsync(role_out, d_orole, nd, hipMemcpyDeviceToHost, s));
+  TRYD(hipStreamSynchronize(s));
+#undef TRYD
+  *n_distinct = nd;
+  return SHN_OK;
+}

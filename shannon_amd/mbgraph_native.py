@@ -165,6 +165,34 @@ def sparse_flow_native(ctx, graphs, snames, seed):
         _lib.lib().shn_sflow_destroy(h)
 
 
+def run_partition_rows(ctx, unitigs, part, d1, d2, host1, host2, didx, rows_bytes=None, n_rows=0):
+    """multibridging.main for partition `part` with its reads named by their rows (shn_mbgraph_run_rows): d1 / d2 the resident
+    packed read sets, host1 / host2 the same reads as C-contiguous uint8 code matrices, didx the doubled read indices."""
+    h = C.c_void_p()
+    didx = np.ascontiguousarray(didx, dtype=np.uint32)
+    paired = d2 is not None
+    for m in (host1, host2) if paired else (host1,):
+        if not (isinstance(m, np.ndarray) and m.dtype == np.uint8 and m.ndim == 2 and m.flags["C_CONTIGUOUS"]):
+            raise ValueError("run_partition_rows: host reads must be C-contiguous uint8 code matrices")
+    _lib.check(_lib.lib().shn_mbgraph_run_rows(ctx.h, unitigs.h, int(part), rows_bytes.ctypes.data if rows_bytes is not None else None,
+                                               n_rows if rows_bytes is not None else 0, d1.h, d2.h if paired else None, host1.ctypes.data,
+                                               host2.ctypes.data if paired else None, didx.ctypes.data, len(didx), 1 if paired else 0, C.byref(h)))
+    return GraphHandle(h)
+
+
+def reads_dedup(ctx, d1, d2, didx):
+    """shn_reads_dedup: (first slot, copies, mate id, role) of the distinct reads among the partition's read slots."""
+    didx = np.ascontiguousarray(didx, dtype=np.uint32)
+    nm = 2 if d2 is not None else 1
+    nh = max(len(didx) * nm, 1)
+    slot, cnt, mate, role = np.empty(nh, np.uint32), np.empty(nh, np.uint32), np.empty(nh, np.int32), np.empty(nh, np.uint8)
+    nd = C.c_uint64()
+    _lib.check(_lib.lib().shn_reads_dedup(ctx.h, d1.h, d2.h if d2 is not None else None, didx.ctypes.data, len(didx), 1 if d2 is not None else 0,
+                                          C.byref(nd), slot.ctypes.data, cnt.ctypes.data, mate.ctypes.data, role.ctypes.data))
+    n = nd.value
+    return slot[:n], cnt[:n], mate[:n], role[:n]
+
+
 def run_partition_handle(rows_bytes, n_rows, K, r1_buf, r1_off, r2_buf=None, r2_off=None, ctx=None, enc=0, rc1=None, rc2=None, unitigs=None,
                          part=0, resident=None):
     """rows_bytes: uint8 array of n_rows*(K+1) bases; reads as (byte buffer, offsets).  unitigs / part: the partition's

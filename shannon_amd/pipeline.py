@@ -113,6 +113,12 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
 
     timeline = {} if os.environ.get("SHN_DEBUG_PARTS") else None
 
+    def _matrix(m):
+        return isinstance(m, np.ndarray) and m.dtype == np.uint8 and m.ndim == 2 and m.flags["C_CONTIGUOUS"]
+    # reads kept as code matrices + GPU unitigs: partitions name their reads by rows (SHN_GRAPH_ROWS=0: gather them on the host)
+    rows_mode = (unitigs is not None and d1 is not None and _matrix(store.r1) and (not paired or _matrix(store.r2)) and
+                 (not paired or d2 is not None) and os.environ.get("SHN_GRAPH_ROWS", "1") != "0")
+
     def one_partition(name):
         """multibridged graph of one partition (multibridging.main for `name`); returns its record + timings"""
         rec, tt = _one_partition(name)
@@ -128,6 +134,25 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
         n_kmers = unitigs.n_kmers(part_index[name]) if unitigs is not None else part["n_kmer_nodes"][name]
         cutoff = 10 * n_kmers + 1                                    # multibridging.py:26-30, 385-391
         idx = part["routes"][name][:cutoff]
+        if native_graph and rows_mode and len(idx):
+            # the reads named by their rows: distinct reads found on the device, their text decoded from the host matrices
+            rb = None
+            if check_rows:
+                rb_ = part["k1mer_bytes"][name]
+                rb = rb_() if callable(rb_) else rb_
+            def run_rows(rb):
+                return mbgraph_native.run_partition_rows(ctx, unitigs, part_index[name], d1, d2, store.r1, store.r2 if paired else None,
+                                                         np.asarray(idx, dtype=np.uint32), rb if (rb is not None and len(rb)) else None,
+                                                         0 if rb is None else len(rb) // (K + 1))
+            try:
+                gh = run_rows(rb)
+            except _lib.ShannonError as ex:
+                if rb is not None or "needs the k1-mer rows" not in str(ex):
+                    raise
+                rb_ = part["k1mer_bytes"][name]
+                gh = run_rows(rb_() if callable(rb_) else rb_)
+            tt["graph"] = time.time() - t0
+            return PartitionRecord(len(part["routes"][name]), part["n_k1mer_rows"][name], gh), tt
         if native_graph:
             b1, o1, rc1, enc = store.gather_codes(idx, 1)
             if paired and rc1 is not None:

@@ -85,16 +85,63 @@ def test_graph_reads_gathered_on_the_device_equal_uploaded_text(ctx, monkeypatch
     (r1, r2), _ = synth.make_dataset(30000, 40, seed=31)
     for paired in (True, False):
         outs = []
-        for off in (False, True):
-            if off:
-                monkeypatch.setenv("SHN_GRAPH_RESIDENT_READS", "0")
-            else:
-                monkeypatch.delenv("SHN_GRAPH_RESIDENT_READS", raising=False)
+        # rows named on the device (shn_mbgraph_run_rows) / rows gathered on the host + device copy gathered / text uploaded /
+        # rows gathered on the host, distinct reads found on the device
+        for env in ({}, {"SHN_GRAPH_ROWS": "0"}, {"SHN_GRAPH_ROWS": "0", "SHN_GRAPH_RESIDENT_READS": "0"},
+                    {"SHN_GRAPH_ROWS": "0", "SHN_GRAPH_BULK_MIN": "64"}, {"SHN_GRAPH_ROWS": "0", "SHN_GRAPH_BULK_MIN": "64", "SHN_GRAPH_DEVICE_DEDUP": "0"}):
+            for k in ("SHN_GRAPH_ROWS", "SHN_GRAPH_RESIDENT_READS", "SHN_GRAPH_BULK_MIN", "SHN_GRAPH_DEVICE_DEDUP"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
             R = pipeline.assemble(ctx, r1, r2 if paired else None, K=25, partition_size=8, sample="s", seed=2)
             outs.append(R)
-        a, b = outs
-        assert len(a.partitions) > 1 and list(a.partitions) == list(b.partitions)
-        for p in a.partitions:
-            assert a.partitions[p]["reconstructed_fasta"] == b.partitions[p]["reconstructed_fasta"]
-            assert a.partitions[p]["components"] == b.partitions[p]["components"] and a.partitions[p]["singles"] == b.partitions[p]["singles"]
-        assert a.final == b.final and len(a.final) > 10
+        a = outs[0]
+        for b in outs[1:]:
+            assert len(a.partitions) > 1 and list(a.partitions) == list(b.partitions)
+            for p in a.partitions:
+                assert a.partitions[p]["reconstructed_fasta"] == b.partitions[p]["reconstructed_fasta"]
+                assert a.partitions[p]["components"] == b.partitions[p]["components"] and a.partitions[p]["singles"] == b.partitions[p]["singles"]
+            assert a.final == b.final and len(a.final) > 10
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_distinct_reads_found_on_the_device_equal_the_read_dictionary(ctx, paired):
+    """shn_reads_dedup against Read.reads filled one read (pair) at a time (mbgraph.py:56-70, multibridging.py:185-236): ids in
+    order of first occurrence, copy counts, and for pairs the role and mate of each read's LAST occurrence."""
+    import numpy as np
+    from shannon_amd import device, mbgraph_native
+    rng = np.random.RandomState(5 + paired)
+    n, L = 3000, 77
+    pool = rng.randint(0, 4, size=(40, L)).astype(np.uint8)
+    pool[7] = (3 - pool[6][::-1])                                   # a read and its reverse complement, and a palindrome-free pool otherwise
+    m1 = pool[rng.randint(0, 40, size=n)].copy()
+    m2 = pool[rng.randint(0, 40, size=n)].copy()
+    d1 = device.Reads.from_codes(ctx, m1)
+    d2 = device.Reads.from_codes(ctx, m2) if paired else None
+    didx = np.sort(rng.choice(2 * n, size=2500, replace=False)).astype(np.uint32)
+    slot, cnt, mate, role = mbgraph_native.reads_dedup(ctx, d1, d2, didx)
+    rc = lambda r: (3 - r[::-1])
+    def text(d, mt):
+        second = d >= n
+        i = d - n if second else d
+        if not paired:
+            r = rc(m1[i]) if second else m1[i]
+        elif mt == 0:
+            r = rc(m2[i]) if second else m1[i]
+        else:
+            r = m2[i] if second else rc(m1[i])
+        return r.tobytes()
+    ids, first, counts, mates, roles = {}, [], [], [], []
+    for i, d in enumerate(didx):
+        got = []
+        for mt in range(2 if paired else 1):
+            t = text(int(d), mt)
+            if t not in ids:
+                ids[t] = len(ids); first.append(i * (2 if paired else 1) + mt); counts.append(0); mates.append(-1); roles.append(0)
+            counts[ids[t]] += 1
+            got.append(ids[t])
+        if paired:
+            a, b = got
+            roles[a] = 1; roles[b] = 2; mates[a] = b; mates[b] = a
+    assert len(ids) < len(didx) and len(slot) == len(ids)
+    assert slot.tolist() == first and cnt.tolist() == counts and mate.tolist() == mates and role.tolist() == roles
