@@ -97,6 +97,7 @@ def cpu_baseline(k1, r1, r2, n_pairs):
     duplicate_check + contig_connections loop (extension_correction.py:247-270, 358-397) in C++ on one core over the sample's own
     candidate contigs is too small to time here; see DESIGN.md for its measured cost at full size (25 s)."""
     from oracle import pipeline as opipe, build_c
+    from shannon_amd import _lib
     A = np.frombuffer(b"ACGT", np.uint8)
     s1 = [A[r].tobytes().decode() for r in r1[:n_pairs]]
     s2 = [A[r].tobytes().decode() for r in r2[:n_pairs]]
@@ -111,7 +112,7 @@ def cpu_baseline(k1, r1, r2, n_pairs):
     # the same counting on T threads: T slices of 500k reads each (ctypes releases the GIL; the per-slice tables would still
     # have to be merged, which Jellyfish's shared hash avoids -- so this is an upper bound of what T cores give the port)
     from concurrent.futures import ThreadPoolExecutor
-    T = max(1, min(os.cpu_count() or 1, 32))
+    T = max(1, min(_lib.host_cpus(), 32))
     per = 250000
     slices = [np.concatenate([r1[i * per:(i + 1) * per], r2[i * per:(i + 1) * per]]) for i in range(T) if (i + 1) * per <= len(r1)]
     t = time.time()
@@ -123,7 +124,7 @@ def cpu_baseline(k1, r1, r2, n_pairs):
         cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except (OSError, IndexError):
         pass
-    return {"value": 2 * n_pairs / dt, "unit": "reads/s", "cores": 1, "kind": "port", "cpu_model": cpu, "host_threads_available": os.cpu_count(),
+    return {"value": 2 * n_pairs / dt, "unit": "reads/s", "cores": 1, "kind": "port", "cpu_model": cpu, "host_threads_available": os.cpu_count(), "host_cpus_allowed": _lib.host_cpus(),
             "sample": "first %d reads of the benchmark batch through oracle/pipeline.py (count -> extension -> partition -> graph -> "
                       "sparse flow -> merge), %.1f s" % (2 * n_pairs, dt),
             "count_stage_only": {"value": len(codes) / dtc, "unit": "reads/s", "cores": 1,

@@ -308,6 +308,9 @@ int shn_mbgraph_run_rows(shn_ctx* ctx, const shn_unitigs* ug, uint32_t part, con
  * 0 / -1).  Host output arrays need room for n * nm entries.                                                                     */
 int shn_reads_dedup(shn_ctx* ctx, const shn_reads* a, const shn_reads* b, const uint32_t* didx, uint64_t n, int paired, uint64_t* n_distinct,
                     uint32_t* slot_out, uint32_t* count_out, int32_t* mate_out, uint8_t* role_out);
+/* Host threads the library keeps busy at most: min(hardware threads, affinity mask, cgroup CPU quota); SHN_HOST_CPUS overrides.
+ * (-- ; the reference takes its process count from --nprocs, shannon.py:99.)                                                   */
+int shn_host_cpus(void);
 /* Rows of resident fixed-length read sets as a new read set: read i = row rows[i] of set a (flags[i] bit 0 clear) or b (set),
  * reverse-complemented if bit 1 is set; the selected rows must hold ACGT only.                                                   */
 int shn_reads_gather(shn_ctx* ctx, const shn_reads* a, const shn_reads* b, const uint32_t* rows, const uint8_t* flags, uint64_t n,

@@ -68,6 +68,7 @@ SIGNATURES = {
     "shn_graph_sizes": (C.c_int, [vp, u64p]),
     "shn_graph_export": (C.c_int, [vp] + [vp] * 20),
     "shn_mbgraph_run_rows": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, vp, vp, C.c_uint64, C.c_int, vpp]),
+    "shn_host_cpus": (C.c_int, []),
     "shn_reads_dedup": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_int, vp, vp, vp, vp, vp]),
     "shn_mbgraph_run_resident": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, vpp]),
     "shn_reads_gather": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, vpp]),
@@ -126,6 +127,11 @@ class ShannonError(RuntimeError):
 def check(rc):
     if rc != 0:
         raise ShannonError("libshannon_hip: %s (code %d)" % (lib().shn_last_error().decode(), rc))
+
+
+def host_cpus():
+    """CPUs this process may keep busy (hardware threads, affinity mask, cgroup quota; SHN_HOST_CPUS overrides)."""
+    return int(lib().shn_host_cpus())
 
 
 def gather_rows(src, idx, out=None, threads=8):

@@ -157,6 +157,7 @@ template <class T> static inline hipError_t shn_dev_malloc(T** p, size_t bytes) 
 void shn_stage_begin();                      // a top-level GPU stage starts (workspace slots used before it become reclaimable)
 size_t shn_ws_release_idle();                // frees the slots not used by the current stage; returns the bytes given back
 extern ShnWs g_shn_ws[32];
+extern "C" int shn_host_cpus(void);
 int shn_device_scan_u32(shn_ctx* ctx, const uint32_t* d_in, uint64_t n, uint64_t* d_out /* n+1 */, uint64_t* total_host);
 // stable LSD radix sort of (u64 key, u32 value) pairs on bits [bit_lo, bit_hi); result lands in keys/vals
 int shn_sort_pairs(shn_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t* keys_tmp, uint32_t* vals_tmp, uint64_t n,

@@ -132,7 +132,7 @@ struct shn_cgraph {
     // in parallel against the same index (evaluation is read-only): batches grow while nothing is accepted (duplicates
     // dominate the tail of the seed order) and shrink when something is.  The first accepted candidate of a batch ends
     // it -- the ones after it are evaluated again against the enlarged index.
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned hw = (unsigned)shn_host_cpus();
     const unsigned n_threads = std::min(16u, hw);
     std::vector<Scratch> scratch(n_threads);
     std::vector<uint8_t> susp;

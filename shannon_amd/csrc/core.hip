@@ -1,5 +1,6 @@
 // Context, error handling, event timers and the read uploader / 2-bit packer.
 #include "common.h"
+#include <sched.h>
 #include <mutex>
 #include <vector>
 #include <cstring>
@@ -396,6 +397,42 @@ extern "C" uint64_t shn_reads_total_bases(const shn_reads* r) { return r ? r->to
 extern "C" uint32_t shn_reads_max_len(const shn_reads* r) { return r ? r->max_len : 0; }
 extern "C" uint64_t shn_reads_n_invalid(const shn_reads* r) { return r ? r->n_invalid : 0; }
 
+
+// ---- host threads this process may keep busy: the smallest of the hardware threads, the affinity mask and the cgroup CPU
+// quota (cpu.max: a container that sees 256 hardware threads may be allowed 16 CPUs' worth of time per period -- running more
+// threads than that does not add throughput, it gets every thread of the process throttled until the next period, the
+// serial chains of the graph stage included).  SHN_HOST_CPUS overrides.  Every thread count of the host stages derives from it.
+extern "C" int shn_host_cpus(void) {
+  static int cached = 0;
+  if (cached) return cached;
+  int n = (int)std::max(1u, std::thread::hardware_concurrency());
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = std::min(n, c); }
+  auto quota = [&](const char* path, bool v2) {
+    FILE* f = fopen(path, "r");
+    if (!f) return;
+    char a[64] = {0}, b[64] = {0};
+    if (v2) {
+      if (fscanf(f, "%63s %63s", a, b) == 2 && strcmp(a, "max") != 0) {
+        const double q = atof(a), per = atof(b);
+        if (q > 0 && per > 0) n = std::min(n, std::max(1, (int)(q / per + 0.999)));
+      }
+    } else if (fscanf(f, "%63s", a) == 1) {
+      const double q = atof(a);
+      FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+      double per = 100000;
+      if (g) { if (fscanf(g, "%63s", b) == 1 && atof(b) > 0) per = atof(b); fclose(g); }
+      if (q > 0) n = std::min(n, std::max(1, (int)(q / per + 0.999)));
+    }
+    fclose(f);
+  };
+  quota("/sys/fs/cgroup/cpu.max", true);
+  quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", false);
+  if (const char* e = getenv("SHN_HOST_CPUS")) { const int v = atoi(e); if (v > 0) n = v; }
+  cached = std::max(1, n);
+  return cached;
+}
 
 // ---- host utility: dst[i] = src row idx[i] (rows of row_bytes bytes), split over host threads.  The read rows that
 // travel to a partition's owner and their re-ordering there are 100+ MB gathers; numpy does them on one thread.

@@ -79,7 +79,7 @@ struct RStr {
 // partition, which bounds the stage, included.  Partitions are started largest first, so the large ones get their threads first.
 struct ThreadBudget {
   std::mutex mu; std::condition_variable cv; int avail;
-  ThreadBudget() { const int hw = (int)std::thread::hardware_concurrency(); avail = std::max(8, hw - hw / 16); if (getenv("SHN_GRAPH_HOST_THREADS")) avail = std::max(1, atoi(getenv("SHN_GRAPH_HOST_THREADS"))); total = avail; }
+  ThreadBudget() { const int hw = shn_host_cpus(); avail = std::max(4, hw); if (getenv("SHN_GRAPH_HOST_THREADS")) avail = std::max(1, atoi(getenv("SHN_GRAPH_HOST_THREADS"))); total = avail; }
   int total;
   // large requests (the large partitions, which bound the stage) never wait -- they may overdraw the budget; small ones wait for it
   void acquire(int n) { n = std::min(n, total); std::unique_lock<std::mutex> lk(mu); if (n < 8) cv.wait(lk, [&] { return avail >= n; }); avail -= n; }
@@ -677,7 +677,7 @@ struct Graph {
     // other in read order, as the sums of known_edges require.
     std::vector<char> slow(n_rd(), 0);
     {
-      const unsigned ntp = (unsigned)std::min<size_t>(16, std::max<size_t>(1, n_rd() >> 18));
+      const unsigned ntp = (unsigned)std::min<size_t>(std::min<size_t>(16, std::max(1, shn_host_cpus() / 2)), std::max<size_t>(1, n_rd() >> 18));
       auto classify = [&](size_t lo, size_t hi) {
         for (size_t r = lo; r < hi; r++) {
           if (!first[r] || !last[r]) continue;
@@ -1017,8 +1017,8 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
     R.arena.resize(nd * Lr);
     g.rcc.resize(nd); g.rmate.resize(nd); g.rmp.resize(nd); g.rfirst.assign(nd, -1); g.rlast.assign(nd, -1); g.rhas.assign(nd, 0);
     g.origin_row.resize(nd); g.origin_flag.resize(nd);
-    const unsigned hwc = std::max(1u, std::thread::hardware_concurrency());
-    unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(32, std::max(1u, hwc / 4)), nd >> 15));
+    const unsigned hwc = (unsigned)shn_host_cpus();
+    unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(32, std::max(1u, hwc / 2)), nd >> 15));
     BudgetGuard budget((int)nt);
     std::atomic<int> non_acgt{0};
     char* arena = &R.arena[0];
@@ -1110,9 +1110,9 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
     // The partitions of a run differ in size by an order of magnitude and the largest ones are started first (pipeline.py): the
     // stage ends when the largest partition does, so its read set gets threads in proportion to its size (one per 256 Ki
     // reads, at most 32 and at most a quarter of the cores), whatever else is running; small sets share what is left.
-    const unsigned hwc = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned hwc = (unsigned)shn_host_cpus();
     unsigned nt = std::min<unsigned>(32, std::max<unsigned>(1, hwc / 8 / (unsigned)std::max(1, active.n / 2)));
-    nt = std::max<unsigned>(nt, (unsigned)std::min<uint64_t>(std::min<uint64_t>(32, std::max(1u, hwc / 4)), (used * (paired ? 2 : 1)) >> 18));
+    nt = std::max<unsigned>(nt, (unsigned)std::min<uint64_t>(std::min<uint64_t>(32, std::max(1u, hwc / 2)), (used * (paired ? 2 : 1)) >> 18));
     if (getenv("SHN_GRAPH_BULK_MIN")) nt = std::max(nt, 4u);
     if (used * nm < bulk_min) nt = used < 4096 ? 1 : std::min<unsigned>(nt, (unsigned)(used / 2048));   // small sets: a few threads for the decode only
     BudgetGuard budget((int)nt);                          // held until the reads are numbered

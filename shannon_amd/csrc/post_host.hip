@@ -45,7 +45,7 @@ extern "C" int shn_find_reps(const uint8_t* names, const uint64_t* name_off, con
   // only these occurrences enter the index -- in record order, as the reference appends them.
   {
     std::atomic<int> bad{0};
-    const unsigned nt0 = std::max(1u, std::min(32u, std::thread::hardware_concurrency() / 4));
+    const unsigned nt0 = std::max(1u, std::min(32u, (unsigned)shn_host_cpus()));
     const unsigned nt = n < 4096 ? 1 : nt0;
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t]() {
@@ -84,7 +84,7 @@ extern "C" int shn_find_reps(const uint8_t* names, const uint64_t* name_off, con
     }
   }
   struct Occ { uint64_t key; int32_t id, pos; };
-  const unsigned nthr = n < 4096 ? 1 : std::max(1u, std::min(32u, std::thread::hardware_concurrency() / 4));
+  const unsigned nthr = n < 4096 ? 1 : std::max(1u, std::min(32u, (unsigned)shn_host_cpus()));
   std::vector<std::vector<Occ>> found(nthr);
   {
     std::vector<std::thread> th;

@@ -18,6 +18,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 
 namespace {
@@ -134,6 +135,9 @@ extern "C" int shn_reads_dedup(shn_ctx* ctx, const shn_reads* a, const shn_reads
   }
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
+  const bool dbg = getenv("SHN_DEBUG") != nullptr;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t0 = now(), t_alloc = 0, t_up = 0, t_k = 0, t_scan = 0, t_alloc2 = 0;
   uint64_t T = 1024;
   while (T < 2 * nh) T <<= 1;
   ShnDevBufs bufs;
@@ -149,7 +153,9 @@ extern "C" int shn_reads_dedup(shn_ctx* ctx, const shn_reads* a, const shn_reads
   TRYD(bufs.get(&d_last, nh * 4));
   TRYD(bufs.get(&d_flag, nh * 4));
   TRYD(bufs.get(&d_pos, (nh + 1) * 8));
+  t_alloc = now() - t0;
   TRYD(hipMemcpyAsync(d_idx, didx, n * 4, hipMemcpyHostToDevice, s));
+  t_up = now() - t0;
   TRYD(hipMemsetAsync(d_tab, 0xFF, T * 4, s));
   TRYD(hipMemsetAsync(d_cnt, 0, nh * 4, s));
   TRYD(hipMemsetAsync(d_last, 0, nh * 4, s));
@@ -159,12 +165,15 @@ extern "C" int shn_reads_dedup(shn_ctx* ctx, const shn_reads* a, const shn_reads
   hipLaunchKernelGGL(dd_tally, dim3(grid), dim3(256), 0, s, nh, d_tab, d_slot, d_first, d_cnt, d_last, d_flag);
   TRYD(hipGetLastError());
   uint64_t nd = 0;
+  if (dbg) { hipStreamSynchronize(s); t_k = now() - t0; }
   int rc = shn_device_scan_u32(ctx, d_flag, nh, d_pos, &nd);
   if (rc) return rc;
+  t_scan = now() - t0;
   TRYD(bufs.get(&d_oslot, nd * 4));
   TRYD(bufs.get(&d_ocnt, nd * 4));
   TRYD(bufs.get(&d_omate, nd * 4));
   TRYD(bufs.get(&d_orole, nd));
+  t_alloc2 = now() - t0;
   hipLaunchKernelGGL(dd_emit, dim3(grid), dim3(256), 0, s, nh, paired ? 1 : 0, d_first, d_cnt, d_last, d_pos, d_oslot, d_ocnt, d_omate, d_orole);
   TRYD(hipGetLastError());
   TRYD(hipMemcpyAsync(slot_out, d_oslot, nd * 4, hipMemcpyDeviceToHost, s));
@@ -173,6 +182,8 @@ extern "C" int shn_reads_dedup(shn_ctx* ctx, const shn_reads* a, const shn_reads
   TRYD(hipMemcpyAsync(role_out, d_orole, nd, hipMemcpyDeviceToHost, s));
   TRYD(hipStreamSynchronize(s));
 #undef TRYD
+  if (dbg) fprintf(stderr, "[dedup] slots=%llu distinct=%llu: alloc %.3f upload %.3f kernels %.3f scan %.3f alloc2 %.3f done %.3f s\n", (unsigned long long)nh,
+                   (unsigned long long)nd, t_alloc, t_up, t_k, t_scan, t_alloc2, now() - t0);
   *n_distinct = nd;
   return SHN_OK;
 }

@@ -412,7 +412,7 @@ extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uin
     c.all.push_back(c.E);
     c.pfn.resize(c.nodes.size());
   };
-  const unsigned nt = comps.size() < 256 ? 1 : std::max(1u, std::min(32u, std::thread::hardware_concurrency() / 4));
+  const unsigned nt = comps.size() < 256 ? 1 : std::max(1u, std::min(32u, (unsigned)shn_host_cpus()));
   auto parallel = [&](auto&& fn) {
     if (nt <= 1) { for (size_t k = 0; k < comps.size(); k++) fn(k); return; }
     std::atomic<size_t> next{0};

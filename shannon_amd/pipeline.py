@@ -72,7 +72,9 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
     paired = d2 is not None
     if graph_threads is None:                   # a rank's share of the host cores (8 ranks per node), at least 8
         import os
-        graph_threads = int(os.environ.get("SHN_GRAPH_THREADS", 0)) or max(8, min(64, (os.cpu_count() or 8) // 4))
+        # partition threads: all the CPUs a small allowance grants (a cgroup quota of 16 CPUs: 16), a quarter of a whole machine
+        cpus = _lib.host_cpus()
+        graph_threads = int(os.environ.get("SHN_GRAPH_THREADS", 0)) or (max(4, cpus) if cpus <= 32 else min(64, cpus // 4))
     if hits_factory is None:
         from . import graph_seeds
         hits_factory = graph_seeds.hits_factory(ctx)
