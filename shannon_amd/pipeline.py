@@ -61,9 +61,10 @@ def assemble(ctx, reads1, reads2=None, K=25, partition_size=500, min_weight=3, m
 
 def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3, min_length=75, overload=2, penalty=5,
                       sample="shannon", seed=0, double_stranded=True, part_vectors=None, timings=None, hits_factory=None,
-                      native_graph=True, graph_threads=None):
+                      native_graph=True, graph_threads=None, keep_partitioning=False):
     """Same as assemble() with the reads already packed in HBM (d1/d2: device.Reads).  graph_threads: partitions whose
-    graph stage may run concurrently on host threads."""
+    graph stage may run concurrently on host threads.  keep_partitioning: leave the partition stage's tables (partition ->
+    contigs, routed read indices) on the result as `.partitioning` (tests/test_fullsize_gpu.py reads them)."""
     if not double_stranded:
         # shannon.py:394-424 prepares strand-specific input differently (no doubling; PE: reads_2 = RC(R2)) and routing /
         # graph reads follow that layout; only the strand-doubled layout is built and pinned against the reference.
@@ -97,6 +98,8 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
     part = kfc.kmers_for_component(ctx, res, d1, d2, K, partition_size, overload, penalty, True, part_vectors,
                                    want_rows=not native_graph, timings=T, lazy_graph_inputs=gpu_unitigs)
     tick("partition+route", t0)
+    if keep_partitioning:
+        R.partitioning = part
     R.partitions = {}
     lines = []
     for i, c in enumerate(res.single_contigs):                      # reconstructed_single_contigs.fasta

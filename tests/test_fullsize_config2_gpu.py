@@ -1,0 +1,206 @@
+"""BASELINE configs[2] at its full size on one GPU -- 100 M synthetic 2x100 bp reads of 20,000 genes, k = 25, --partition 500 --
+checked through properties that do not need an oracle run of that size (the oracle takes days there): conservation and
+linearity of the counts, a sub-batch against the C restatement, exclusivity of the contigs' k1-mers, partition cover and bin
+sizes, the routing rule on sampled reads (both directions), recovery of the planted transcripts, and run-to-run identity of the
+whole output.  The batch is bench.py's (same generator, same seed): the digest of the transcripts is the one its JSON line prints."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+K, K1, N_PAIRS, N_GENES, SEED = 25, 26, 50_000_000, 20000, 20240501
+_RC = str.maketrans("ACGT", "TGCA")
+
+
+def rc(s):
+    return s[::-1].translate(_RC)
+
+
+def canon_keys(keys, k):
+    """canonical form of packed k-mers (2 bits per base, first base in the high bits)"""
+    keys = keys.astype(np.uint64)
+    r = np.zeros_like(keys)
+    x = keys.copy()
+    for _ in range(k):
+        r = (r << np.uint64(2)) | (np.uint64(3) - (x & np.uint64(3)))
+        x >>= np.uint64(2)
+    return np.minimum(keys, r)
+
+
+class Full(object):
+    pass
+
+
+@pytest.fixture(scope="module")
+def full():
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from shannon_amd import device, pipeline, kmers_for_component as kfc
+    F = Full()
+    dev = torch.device("cuda", 0)
+    F.r1, F.r2 = bench.gen_reads(N_PAIRS, SEED, N_GENES, dev, read_seed=SEED + 2)
+    torch.cuda.empty_cache()
+    F.ctx = device.Context(0)
+    F.d1, F.d2 = device.Reads.from_codes(F.ctx, F.r1), device.Reads.from_codes(F.ctx, F.r2)
+    F.store = kfc.ReadStore(F.r1, F.r2)
+    F.run = lambda **kw: pipeline.assemble_resident(F.ctx, F.d1, F.d2, F.store, K=K, sample="bench", seed=1, **kw)
+    F.R = F.run(keep_partitioning=True)
+    F.sha = bench._final_sha(F.R.final)
+    yield F
+    F.ctx.close()
+
+
+def test_counts_are_conserved_and_additive(full):
+    """Every window of every read is counted once (no read holds an N): the counts sum to reads x (L - k1 + 1); and the table of
+    the batch is the sum of the tables of its halves, key by key (100,000 sampled keys + keys absent from one half)."""
+    from shannon_amd import device
+    F = full
+    L = F.r1.shape[1]
+    t = device.count_k1mers(F.ctx, [F.d1, F.d2], K1, both_strands=True)
+    assert t.total == 2 * N_PAIRS * (L - K1 + 1) == F.R.n_windows
+    assert len(t) == F.R.n_k1mers
+    keys, cnts = t.download()
+    assert int(cnts.astype(np.uint64).sum()) == t.total               # canonical table: one entry per strand pair
+    h = N_PAIRS // 2
+    halves = []
+    for sl in (slice(0, h), slice(h, N_PAIRS)):
+        a, b = device.Reads.from_codes(F.ctx, F.r1[sl]), device.Reads.from_codes(F.ctx, F.r2[sl])
+        halves.append(device.count_k1mers(F.ctx, [a, b], K1, both_strands=True))
+        a.close(); b.close()
+    assert halves[0].total + halves[1].total == t.total
+    sel = keys[:: max(1, len(keys) // 100000)]
+    assert np.array_equal(t.lookup(sel).astype(np.uint64), halves[0].lookup(sel).astype(np.uint64) + halves[1].lookup(sel).astype(np.uint64))
+    k0, c0 = halves[0].download()
+    sel0 = k0[:: max(1, len(k0) // 100000)]
+    assert np.array_equal(t.lookup(sel0).astype(np.uint64), c0[:: max(1, len(k0) // 100000)].astype(np.uint64) + halves[1].lookup(sel0).astype(np.uint64))
+    for x in halves:
+        x.close()
+    t.close()
+
+
+def test_a_sub_batch_counts_like_the_c_restatement(full):
+    """the first 250,000 pairs through the device counter and through oracle/count_c.c: the same table"""
+    from shannon_amd import device
+    from oracle import build_c
+    F = full
+    n = 250000
+    build_c.build()
+    codes = np.concatenate([F.r1[:n], F.r2[:n]])
+    ok, oc, nw = build_c.count_canonical(codes, K1, True)
+    a, b = device.Reads.from_codes(F.ctx, F.r1[:n]), device.Reads.from_codes(F.ctx, F.r2[:n])
+    t = device.count_k1mers(F.ctx, [a, b], K1, both_strands=True)
+    keys, cnts = t.download()
+    o = np.argsort(keys, kind="stable")
+    assert t.total == nw and np.array_equal(keys[o], ok) and np.array_equal(cnts[o].astype(np.uint64), oc.astype(np.uint64))
+    t.close(); a.close(); b.close()
+
+
+def test_contigs_own_their_k1mers(full):
+    """Walks claim k1-mers exclusively (extension_correction.py:223-245: a traversed k1-mer string is never taken again): no k1-mer
+    occurs twice among the contigs.  The two strands are walked as separate strings (the dictionary holds both), so a
+    canonical k1-mer occurs at most twice."""
+    from shannon_amd import _lib
+    F = full
+    contigs = F.R.extension.contigs
+    assert len(contigs) > 50000 and min(len(c) for c in contigs) >= 75
+    keys, _rows, nwin = _lib.string_windows(contigs, K1, want_keys=True)
+    assert len(np.unique(keys)) == len(keys) == int(nwin.sum())
+    _u, mult = np.unique(canon_keys(keys, K1), return_counts=True)
+    assert int(mult.max()) <= 2
+
+
+def test_partitions_cover_the_contigs_once(full):
+    """Every contig of a multi-contig component lies in exactly one partition; the bins of small components close as soon as they
+    exceed --partition (extension_correction.py:436-452), so a bin holds at most partition + largest small component contigs."""
+    F = full
+    P = F.R.partitioning
+    ext = F.R.extension
+    parts = {nm: cs for nm, cs in P["new_components"].items() if not nm.startswith("r2_")}
+    placed = [c for cs in parts.values() for c in cs]
+    assert len(placed) == len(set(placed)) == len(ext.contigs) - len(ext.single_contigs)
+    assert set(placed) | set(ext.single_contigs) == set(ext.contigs)
+    sizes = np.diff(np.asarray(ext.comp_off))
+    small_max = int(sizes[sizes <= 500].max())
+    for nm, cs in parts.items():
+        if nm.startswith("cremaining"):
+            assert len(cs) <= 500 + small_max
+    closed = [len(cs) for nm, cs in parts.items() if nm.startswith("cremaining")][:-1]
+    assert all(n > 500 for n in closed)
+    # a big component is split into ceil-sized parts within gpmetis' balance bound (ufactor = 1000 x (overload - 1))
+    for i, (contigs, _m) in enumerate(ext.big_components):
+        ps = [len(cs) for nm, cs in parts.items() if nm.startswith("c%d_" % (i + 1))]
+        assert sum(ps) == len(contigs) and max(ps) <= 2.0 * len(contigs) / len(ps) + 1
+    assert list(F.R.partitions) == list(P["new_components"])
+
+
+def test_routed_reads_hit_their_partition_and_only_they_do(full):
+    """kmers_for_component.py:186-205, 358-403: a pair belongs to a partition iff one of its probes (the k1-windows at 0, k1, 2 k1,
+    ... and the last one, of either mate) is a k1-mer of one of the partition's contigs.  Checked on the largest, a middle and
+    the smallest partition: 2,000 routed pairs each, and 20,000 pairs drawn from the whole batch (strand-doubled numbering)."""
+    F = full
+    P = F.R.partitioning
+    names = sorted(P["routes"], key=lambda nm: len(P["routes"][nm]))
+    rng = np.random.default_rng(7)
+    L = F.r1.shape[1]
+    starts = list(range(0, L - K1, K1)) + [L - K1]
+    for nm in (names[-1], names[len(names) // 2], names[0]):
+        kset = set()
+        for c in P["new_components"][nm]:
+            for i in range(len(c) - K1 + 1):
+                kset.add(c[i:i + K1])
+        idx = np.asarray(P["routes"][nm])
+        assert (np.diff(idx.astype(np.int64)) > 0).all()                  # file order, every pair once
+
+        def hits(d):
+            return any(m[s:s + K1] in kset for m in (F.store.mate1(int(d)), F.store.mate2(int(d))) for s in starts)
+        for d in rng.choice(idx, size=min(2000, len(idx)), replace=False):
+            assert hits(d)
+        routed = set(idx.tolist())
+        n_in = 0
+        for d in rng.integers(0, 2 * N_PAIRS, size=20000):
+            assert hits(d) == (int(d) in routed)
+            n_in += int(d) in routed
+    total = sum(len(v) for v in P["routes"].values())
+    assert total >= 0.5 * 2 * N_PAIRS                                     # (measured: 67 M of the 100 M strand-doubled pairs are routed)
+
+
+def test_planted_transcripts_come_back(full):
+    """The batch was sampled from 20,000 known transcripts (0.5 % substitutions per base): what the run reports is made of their
+    k1-mers (precision), covers most of them (recall), and a good part of them comes back base for base, on either strand."""
+    from shannon_amd import synth, _lib
+    F = full
+    iso, _ = synth.make_transcriptome(N_GENES, SEED)
+    A = np.frombuffer(b"ACGT", np.uint8)
+    truth = [A[t].tobytes().decode() for t in iso]
+    out = sorted(set(F.R.final.values()))
+    tk = np.unique(canon_keys(_lib.string_windows(truth, K1)[0], K1))
+    ok = canon_keys(_lib.string_windows(out, K1)[0], K1)
+    pos = np.minimum(np.searchsorted(tk, ok), len(tk) - 1)
+    precision = float((tk[pos] == ok).mean())
+    ou = np.unique(ok)
+    pos = np.minimum(np.searchsorted(ou, tk), len(ou) - 1)
+    recall = float((ou[pos] == tk).mean())
+    outs = set(out)
+    exact = sum(1 for t in truth if t in outs or rc(t) in outs)
+    print("planted transcripts: precision %.4f recall %.4f exact %d of %d, %d reported" % (precision, recall, exact, len(truth), len(out)))
+    # measured: precision 0.9956, recall 0.9518, 5,185 of the 69,488 isoforms base for base, 40.6 k transcripts reported
+    assert precision >= 0.99 and recall >= 0.93 and exact >= 0.06 * len(truth)
+
+
+def test_a_second_run_gives_the_same_bytes(full):
+    """the whole output twice: same contigs, same partitions, same transcripts, same abundances -- and the digest bench.py reports"""
+    import bench
+    F = full
+    R2 = F.run()
+    assert R2.extension.contigs == F.R.extension.contigs
+    assert list(R2.partitions) == list(F.R.partitions)
+    for nm in F.R.partitions:
+        assert R2.partitions[nm]["reconstructed_fasta"] == F.R.partitions[nm]["reconstructed_fasta"]
+    assert R2.final == F.R.final
+    assert bench._final_sha(R2.final) == F.sha == "88b09b08debe39f0"
