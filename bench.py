@@ -89,6 +89,43 @@ def _final_sha(final):
     return h.hexdigest()[:16]
 
 
+def ingest_rate(ctx, r1, r2, n_pairs):
+    """SURVEY 8 row f2 beside the resident number: the first n_pairs pairs of the batch written as two 2-line FASTA texts in host
+    memory (what the reference is handed as files, here already in the page cache), timed through shn_reads_ingest (host-thread
+    parse -> pinned double buffers -> H2D -> pack_kernel, host code matrix included).  Returns the dict of the JSON line."""
+    from shannon_amd import device
+    A = np.frombuffer(b"ACGT", np.uint8)
+
+    def fasta(codes):
+        n, L = codes.shape
+        w = 1 + 9 + 1                                         # ">%09d\n"
+        rec = np.empty((n, w + L + 1), np.uint8)
+        rec[:, 0] = ord(">")
+        idx = np.arange(n, dtype=np.int64)
+        for d in range(9):
+            rec[:, 9 - d] = 48 + (idx // 10 ** d) % 10
+        rec[:, 10] = 10
+        rec[:, w:w + L] = A[codes]
+        rec[:, w + L] = 10
+        return rec.reshape(-1)
+    texts = [fasta(r1[:n_pairs]), fasta(r2[:n_pairs])]
+    device.Reads.ingest(ctx, texts[0][:len(texts[0]) // 8])[0].close()     # first-use costs (pinned buffers, kernels) outside
+    t = time.time()
+    got = [device.Reads.ingest(ctx, x) for x in texts]
+    dt = time.time() - t
+    ok = all(np.array_equal(g[1][::997], c[:n_pairs][::997]) for g, c in zip(got, (r1, r2)))
+    for g in got:
+        g[0].close()
+    nb = sum(len(x) for x in texts)
+    return {"reads_per_s": 2 * n_pairs / dt, "text_GB_per_s": nb / dt / 1e9, "seconds": dt, "host_cpus": _host_cpus(), "matrix_ok": bool(ok),
+            "sample": "first %d pairs of the batch as two 2-line FASTA texts in host memory (%.2f GB), shn_reads_ingest incl. the host code matrix" % (n_pairs, nb / 1e9)}
+
+
+def _host_cpus():
+    from shannon_amd import _lib
+    return _lib.host_cpus()
+
+
 def cpu_baseline(k1, r1, r2, n_pairs):
     """The CPU restatement of the reference over a bounded sample of the same batch, on this box's host cores (a reported
     baseline, not the target).  `value`: the whole path a1-a31 through oracle/pipeline.py -- pure Python like Shannon itself, one
@@ -339,6 +376,12 @@ def main():
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(timers.items())},
             "kernel_launches_per_step": {k: v[1] / args.steps for k, v in sorted(timers.items())},
         }
+        if world == 1 and not use_dist:
+            # ingest-inclusive rate: the resident step plus reading the batch from FASTA text at the measured ingest rate (no overlap
+            # between ingest and the step assumed)
+            ing = ingest_rate(ctx, r1, r2, min(len(r1), 5_000_000))
+            out["ingest"] = ing
+            out["value_with_ingest"] = 1.0 / (1.0 / out["value"] + 1.0 / ing["reads_per_s"])
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 of the N=1 run only
             # bounded sample: ~10-15 s of one core through the whole path (at configs[2] a read costs the pure-Python path ~5x more
             # than at configs[1]: nearly every k1-mer of a 25k-read sample is new), + ~5 s for the counting stage alone / threaded

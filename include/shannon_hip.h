@@ -308,6 +308,14 @@ int shn_mbgraph_run_rows(shn_ctx* ctx, const shn_unitigs* ug, uint32_t part, con
  * 0 / -1).  Host output arrays need room for n * nm entries.                                                                     */
 int shn_reads_dedup(shn_ctx* ctx, const shn_reads* a, const shn_reads* b, const uint32_t* didx, uint64_t n, int paired, uint64_t* n_distinct,
                     uint32_t* slot_out, uint32_t* count_out, int32_t* mate_out, uint8_t* role_out);
+/* A read file's text straight into a packed read set (the reference reads every second line of its 2-line FASTA
+ * in Python, rc_gnu.py:15-20, kmers_for_component.py:329-403): text / n_bytes = the file (2-line FASTA records or 4-line FASTQ
+ * records; format 0 = by the first character, 1 FASTA, 2 FASTQ).  Host threads parse byte ranges into pinned double buffers
+ * while the previous group is copied and packed.  *n_reads_out / *read_len_out are always set; codes_out (optional, codes_cap
+ * bytes) receives the [n_reads][read_len] code matrix (0..3, 4 = other); out NULL = scan / matrix only.  Reads of different
+ * lengths, multi-line FASTA and malformed records are refused (SHN_ERR_ARG, message "shn_reads_ingest: unsupported: ...").      */
+int shn_reads_ingest(shn_ctx* ctx, const uint8_t* text, uint64_t n_bytes, int format, uint8_t* codes_out, uint64_t codes_cap,
+                     uint64_t* n_reads_out, uint32_t* read_len_out, shn_reads** out);
 /* Host threads the library keeps busy at most: min(hardware threads, affinity mask, cgroup CPU quota); SHN_HOST_CPUS overrides.
  * (-- ; the reference takes its process count from --nprocs, shannon.py:99.)                                                   */
 int shn_host_cpus(void);

@@ -106,7 +106,7 @@ def main(argv):
         print(line)
         log.write(line + "\n")
 
-    from shannon_amd import device, pipeline
+    from shannon_amd import device, pipeline, _lib
     say("Starting Shannon run (MI355X hot path %s)" % VERSION)
     if ignored:
         say("WARNING: flags outside the hot path ignored: " + " ".join(ignored))
@@ -114,13 +114,33 @@ def main(argv):
         noted.append("-p %d: partitions run concurrently on host threads and the GPU inside one process; the value is not used" % nJobs)
     for msg in noted:
         say("NOTE: " + msg)
-    r = [read_fasta(p) for p in reads]
-    paired = len(r) == 2
-    say("Processed No of reads:%d, Avg. Read length: %.2f" % (len(r[0]), sum(len(x) for x in r[0]) / max(1, len(r[0]))))
     ctx = device.Context(0)
     T = {}
-    R = pipeline.assemble(ctx, r[0], r[1] if paired else None, K=K, partition_size=partition_size, min_weight=min_weight,
-                          min_length=min_length, sample=sample, seed=0, double_stranded=double_stranded, timings=T)
+    paired = len(reads) == 2
+    # the files straight into HBM (shn_reads_ingest: 2-line FASTA / FASTQ, reads of one length, ACGT only); anything else is
+    # read record by record
+    import time as _t
+    t0 = _t.time()
+    sets = None
+    try:
+        got = [device.Reads.ingest(ctx, p) for p in reads]
+        if all(g[0].n_invalid == 0 for g in got) and len(set(g[1].shape[1] for g in got)) == 1 and len(set(len(g[0]) for g in got)) == 1:
+            sets, r = [g[0] for g in got], [g[1] for g in got]
+    except _lib.ShannonError as ex:
+        if "unsupported" not in str(ex):
+            raise
+    if sets is None:
+        r = [read_fasta(p) for p in reads]
+    T["ingest"] = _t.time() - t0
+    say("Processed No of reads:%d, Avg. Read length: %.2f" % (len(r[0]), (sum(len(x) for x in r[0]) / max(1, len(r[0]))) if sets is None else r[0].shape[1]))
+    if sets is not None:
+        from shannon_amd import kmers_for_component as kfc
+        R = pipeline.assemble_resident(ctx, sets[0], sets[1] if paired else None, kfc.ReadStore(r[0], r[1] if paired else None), K=K,
+                                       partition_size=partition_size, min_weight=min_weight, min_length=min_length, sample=sample, seed=0,
+                                       double_stranded=double_stranded, timings=T)
+    else:
+        R = pipeline.assemble(ctx, r[0], r[1] if paired else None, K=K, partition_size=partition_size, min_weight=min_weight,
+                              min_length=min_length, sample=sample, seed=0, double_stranded=double_stranded, timings=T)
     say("%d K-mers loaded; %d contigs; %d partitions" % (R.n_k1mers, len(R.extension.contigs), len(R.partitions)))
     # TEMP tree: the per-stage products of the reference (shannon.py:496-513, 584-595)
     from shannon_amd import extension_correction as ec, mbgraph

@@ -323,6 +323,36 @@ extern "C" int shn_reads_create(shn_ctx* ctx, const uint8_t* bytes, const uint64
   return SHN_OK;
 }
 
+// pieces of shn_reads_create for callers that fill a fixed-length read set group by group (ingest.hip)
+int shn_pack_fixed_codes(shn_ctx* ctx, const uint8_t* d_codes, uint64_t n, uint32_t L, uint32_t wpr, uint64_t* d_words, uint64_t* d_mask,
+                         hipStream_t s) {
+  if (!n) return SHN_OK;
+  TimerRegion t(ctx, T_PACK, s);
+  const uint64_t n_groups = n * (wpr / 2);
+  hipLaunchKernelGGL(pack_kernel, dim3((uint32_t)cdiv(n_groups, 256)), dim3(256), 0, s, d_codes, (const uint64_t*)nullptr, (const uint64_t*)nullptr, n, L,
+                     wpr, SHN_ENC_CODES, d_words, d_mask, (uint32_t*)nullptr, n_groups);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SHN_OK : shn_fail(SHN_ERR_HIP, std::string("pack_kernel: ") + hipGetErrorString(e));
+}
+int shn_reads_finish_fixed(shn_ctx* ctx, shn_reads* r) {
+  hipStream_t s = ctx->stream;
+  unsigned long long* d_nbad = nullptr;
+  HIP_TRY(hipMalloc(&d_nbad, 8));
+  hipError_t e = hipMemsetAsync(d_nbad, 0, 8, s);
+  if (e == hipSuccess) e = hipMalloc(&r->d_bad, r->n_reads ? r->n_reads : 1);
+  unsigned long long nb = 0;
+  if (e == hipSuccess && r->n_reads) {
+    hipLaunchKernelGGL(bad_reads_kernel, dim3((uint32_t)cdiv(r->n_reads, 256)), dim3(256), 0, s, r->d_mask, (const uint64_t*)nullptr, r->n_reads, r->wpr,
+                       r->d_bad, d_nbad);
+    e = hipMemcpyAsync(&nb, d_nbad, 8, hipMemcpyDeviceToHost, s);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  hipFree(d_nbad);
+  if (e != hipSuccess) return shn_fail(SHN_ERR_HIP, std::string("shn_reads_finish_fixed: ") + hipGetErrorString(e));
+  r->n_invalid = nb;
+  return SHN_OK;
+}
+
 // Rows of resident fixed-length read sets as a new read set, without a trip through the host: read i = row rows[i] of set a
 // (flags[i] bit 0 clear) or b (set), reverse-complemented if bit 1 is set.  The graph stage builds its distinct-read set this
 // way (the reads of a partition are rows of the input the routing kernel selected; uploading their text again was the

@@ -1,0 +1,230 @@
+// Read files straight into HBM: SURVEY §8 row f2 (the reference reads its FASTA line by line in Python -- rc_gnu.py:15-20
+// find_L takes every second line as a read, kmers_for_component.py:329-403 and multibridging.py:185-236 do the same -- and
+// converts FASTQ to that form first).
+//
+// shn_reads_ingest takes the text of a read file (2-line FASTA records "name line, sequence line", or 4-line FASTQ records) and
+// leaves the reads 2-bit packed on the device, and optionally as a host code matrix (what ReadStore / shn_mbgraph_run_rows read
+// the graph stage's read text from):
+//   pass 1  host threads scan byte ranges of the text (cut at record starts) for newlines: records and read length per range
+//   pass 2  groups of ranges are parsed into one of two pinned staging buffers (codes 0..3, 4 = anything else) while the
+//           previous group is on its way: hipMemcpyAsync -> pack_kernel into the read set's final arrays, one launch per group
+// Only reads of one length take this path (fixed-length read sets are what the routing / graph stages address by row);
+// anything else -- ragged reads, multi-line FASTA, a malformed record -- is refused with SHN_ERR_ARG and a message starting
+// "shn_reads_ingest: unsupported", and the caller reads the file the slow way.
+#include "common.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+int shn_pack_fixed_codes(shn_ctx* ctx, const uint8_t* d_codes, uint64_t n, uint32_t L, uint32_t wpr, uint64_t* d_words, uint64_t* d_mask,
+                         hipStream_t s);
+int shn_reads_finish_fixed(shn_ctx* ctx, shn_reads* r);
+
+namespace {
+
+struct Range {
+  uint64_t b0 = 0, b1 = 0, n_rec = 0, rec0 = 0;
+  uint32_t min_len = 0xFFFFFFFFu, max_len = 0;
+  int bad = 0;            // 1: a record does not start with the record character, 2: truncated record
+};
+
+inline uint64_t line_end(const uint8_t* t, uint64_t n, uint64_t p) {       // index of the '\n' ending the line at p (n if none)
+  const void* q = memchr(t + p, '\n', n - p);
+  return q ? (uint64_t)((const uint8_t*)q - t) : n;
+}
+
+// first record start at or after pos
+uint64_t align_record(const uint8_t* t, uint64_t n, uint64_t pos, bool fastq) {
+  if (pos == 0) return 0;
+  uint64_t q = pos;
+  if (t[pos - 1] != '\n') { q = line_end(t, n, pos); if (q >= n) return n; q++; }
+  while (q < n) {
+    if (!fastq) { if (t[q] == '>') return q; }
+    else if (t[q] == '@') {                                 // a quality line may start with '@' too: the line after next must be "+..."
+      uint64_t e1 = line_end(t, n, q);
+      if (e1 < n) { uint64_t e2 = line_end(t, n, e1 + 1); if (e2 + 1 < n && t[e2 + 1] == '+') return q; }
+    }
+    q = line_end(t, n, q);
+    if (q >= n) return n;
+    q++;
+  }
+  return n;
+}
+
+// visits the records of [b0, b1): fn(seq_start, seq_len); returns false on a malformed record
+template <class F> int walk_records(const uint8_t* t, uint64_t n, uint64_t b0, uint64_t b1, bool fastq, F&& fn) {
+  uint64_t p = b0;
+  const uint8_t mark = fastq ? '@' : '>';
+  while (p < b1) {
+    if (t[p] != mark) {
+      if (t[p] == '\n' || t[p] == '\r') { p++; continue; }        // blank lines between records (and at the end of the file)
+      return 1;
+    }
+    uint64_t e = line_end(t, n, p);
+    if (e >= n) return 2;
+    const uint64_t s = e + 1;
+    e = line_end(t, n, s);
+    uint64_t len = e - s;
+    if (len && t[s + len - 1] == '\r') len--;
+    fn(s, len);
+    p = e + 1;
+    if (fastq) {
+      if (p >= n || t[p] != '+') return 2;
+      e = line_end(t, n, p);
+      if (e >= n) return 2;
+      e = line_end(t, n, e + 1);
+      p = e + 1;
+    }
+  }
+  return 0;
+}
+
+struct Lut { uint8_t v[256]; Lut() { memset(v, 4, 256); v['A'] = v['a'] = 0; v['C'] = v['c'] = 1; v['G'] = v['g'] = 2; v['T'] = v['t'] = 3; } };
+const Lut kLut;
+
+}  // namespace
+
+// text / n_bytes: the file; format: 0 = by the first character ('>' FASTA, '@' FASTQ), 1 FASTA, 2 FASTQ; codes_out: NULL or room
+// for codes_cap bytes, filled with the [n_reads][read length] code matrix (fails if too small: size it with a first call that
+// passes out = NULL, which only scans); out: the packed read set (NULL: scan only).
+extern "C" int shn_reads_ingest(shn_ctx* ctx, const uint8_t* text, uint64_t n_bytes, int format, uint8_t* codes_out, uint64_t codes_cap,
+                                uint64_t* n_reads_out, uint32_t* read_len_out, shn_reads** out) {
+  if ((n_bytes && !text) || !n_reads_out || !read_len_out || (out && !ctx)) return shn_fail(SHN_ERR_ARG, "shn_reads_ingest: NULL argument");
+  *n_reads_out = 0; *read_len_out = 0;
+  if (out) *out = nullptr;
+  uint64_t lead = 0;
+  while (lead < n_bytes && (text[lead] == '\n' || text[lead] == '\r')) lead++;
+  if (lead >= n_bytes) return shn_fail(SHN_ERR_ARG, "shn_reads_ingest: unsupported: no records");
+  if (format == 0) format = text[lead] == '@' ? 2 : 1;
+  if (format != 1 && format != 2) return shn_fail(SHN_ERR_ARG, "shn_reads_ingest: bad format");
+  const bool fastq = format == 2;
+  const unsigned T = (unsigned)std::max(1, std::min(shn_host_cpus(), 64));
+  // ranges of ~16 MB of text, cut at record starts
+  uint64_t range_bytes = 16u << 20;
+  if (const char* e = getenv("SHN_INGEST_RANGE_BYTES")) range_bytes = std::max<uint64_t>(1, strtoull(e, nullptr, 10));     // (tests: many small ranges)
+  const uint64_t n_ranges = std::max<uint64_t>(1, std::min<uint64_t>(n_bytes / range_bytes + 1, 1u << 20));
+  std::vector<Range> R(n_ranges);
+  {
+    std::atomic<uint64_t> next{0};
+    auto cut = [&]() { for (uint64_t i; (i = next.fetch_add(1)) < n_ranges;) R[i].b0 = align_record(text, n_bytes, i == 0 ? lead : n_bytes / n_ranges * i, fastq); };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < std::min<uint64_t>(T, n_ranges); t++) th.emplace_back(cut);
+    cut();
+    for (auto& x : th) x.join();
+    for (uint64_t i = 0; i < n_ranges; i++) R[i].b1 = i + 1 < n_ranges ? R[i + 1].b0 : n_bytes;
+  }
+  {
+    std::atomic<uint64_t> next{0};
+    auto scan = [&]() {
+      for (uint64_t i; (i = next.fetch_add(1)) < n_ranges;) {
+        Range& r = R[i];
+        if (r.b0 >= r.b1) continue;
+        r.bad = walk_records(text, n_bytes, r.b0, r.b1, fastq, [&](uint64_t, uint64_t len) {
+          r.n_rec++; r.min_len = std::min<uint32_t>(r.min_len, (uint32_t)std::min<uint64_t>(len, 0xFFFFFFFEu)); r.max_len = std::max<uint32_t>(r.max_len, (uint32_t)std::min<uint64_t>(len, 0xFFFFFFFEu)); });
+      }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < std::min<uint64_t>(T, n_ranges); t++) th.emplace_back(scan);
+    scan();
+    for (auto& x : th) x.join();
+  }
+  uint64_t N = 0;
+  uint32_t mn = 0xFFFFFFFFu, mx = 0;
+  for (auto& r : R) {
+    if (r.bad) return shn_fail(SHN_ERR_ARG, r.bad == 1 ? "shn_reads_ingest: unsupported: a record does not start with its marker (multi-line FASTA?)"
+                                                       : "shn_reads_ingest: unsupported: truncated record");
+    r.rec0 = N; N += r.n_rec;
+    if (r.n_rec) { mn = std::min(mn, r.min_len); mx = std::max(mx, r.max_len); }
+  }
+  if (!N) return shn_fail(SHN_ERR_ARG, "shn_reads_ingest: unsupported: no records");
+  if (mn != mx || mx == 0) return shn_fail(SHN_ERR_ARG, "shn_reads_ingest: unsupported: reads of different lengths (" + std::to_string(mn) + " .. " + std::to_string(mx) + ")");
+  const uint32_t L = mx;
+  *n_reads_out = N; *read_len_out = L;
+  if (!out && !codes_out) return SHN_OK;
+  if (codes_out && codes_cap < N * (uint64_t)L) return shn_fail(SHN_ERR_ARG, "shn_reads_ingest: codes_out too small");
+  auto parse = [&](const Range& r, uint8_t* dst_a, uint8_t* dst_b) {             // dst_*: row 0 = record r.rec0 (either may be NULL)
+    uint64_t k = 0;
+    walk_records(text, n_bytes, r.b0, r.b1, fastq, [&](uint64_t s, uint64_t) {
+      const uint8_t* p = text + s;
+      if (dst_a) { uint8_t* d = dst_a + k * L; for (uint32_t j = 0; j < L; j++) d[j] = kLut.v[p[j]]; if (dst_b) memcpy(dst_b + k * L, d, L); }
+      else { uint8_t* d = dst_b + k * L; for (uint32_t j = 0; j < L; j++) d[j] = kLut.v[p[j]]; }
+      k++;
+    });
+  };
+  if (!out) {                                                                   // host matrix only
+    std::atomic<uint64_t> next{0};
+    auto work = [&]() { for (uint64_t i; (i = next.fetch_add(1)) < n_ranges;) if (R[i].n_rec) parse(R[i], nullptr, codes_out + R[i].rec0 * L); };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < std::min<uint64_t>(T, n_ranges); t++) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+    return SHN_OK;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  shn_reads* r = new shn_reads();
+  memset(r, 0, sizeof(*r));
+  r->ctx = ctx; r->device = ctx->device; r->n_reads = N; r->fixed_len = L; r->max_len = L;
+  r->wpr = (uint32_t)(2 * cdiv(L, 64)); r->n_words = N * r->wpr; r->total_bases = N * (uint64_t)L;
+  // staging: groups of consecutive ranges of at most `cap` records
+  uint64_t cap = 0;
+  for (auto& x : R) cap = std::max(cap, x.n_rec);
+  uint64_t stage_bytes = 256ull << 20;
+  if (const char* e = getenv("SHN_INGEST_STAGE_BYTES")) stage_bytes = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+  cap = std::max<uint64_t>(cap, std::min<uint64_t>(N, stage_bytes / L + 1));
+  uint8_t* pin[2] = {nullptr, nullptr};
+  uint8_t* dst[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  hipStream_t s = ctx->stream;
+  auto cleanup = [&]() {
+    for (int b = 0; b < 2; b++) { if (pin[b]) hipHostFree(pin[b]); if (dst[b]) hipFree(dst[b]); if (ev[b]) hipEventDestroy(ev[b]); }
+  };
+#define TRYI(e) do { hipError_t _e = (e); if (_e != hipSuccess) { cleanup(); shn_reads_destroy(r); \
+      return shn_fail(SHN_ERR_HIP, std::string("shn_reads_ingest: ") + #e + ": " + hipGetErrorString(_e)); } } while (0)
+  TRYI(hipMalloc(&r->d_words, (r->n_words + 2) * 8));
+  TRYI(hipMalloc(&r->d_mask, (r->n_words / 2 + 2) * 8));
+  TRYI(hipMemsetAsync(r->d_words + r->n_words, 0, 16, s));
+  TRYI(hipMemsetAsync(r->d_mask + r->n_words / 2, 0, 16, s));
+  for (int b = 0; b < 2; b++) {
+    TRYI(hipHostMalloc(&pin[b], cap * L, hipHostMallocDefault));
+    TRYI(hipMalloc(&dst[b], cap * L));
+    TRYI(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
+  }
+  uint64_t i0 = 0;
+  int b = 0;
+  bool used[2] = {false, false};
+  while (i0 < n_ranges) {
+    uint64_t i1 = i0, n_grp = 0;
+    while (i1 < n_ranges && n_grp + R[i1].n_rec <= cap) { n_grp += R[i1].n_rec; i1++; }
+    if (n_grp) {
+      if (used[b]) TRYI(hipEventSynchronize(ev[b]));
+      const uint64_t base = R[i0].rec0;
+      std::atomic<uint64_t> next{i0};
+      auto work = [&]() {
+        for (uint64_t i; (i = next.fetch_add(1)) < i1;)
+          if (R[i].n_rec) parse(R[i], pin[b] + (R[i].rec0 - base) * L, codes_out ? codes_out + R[i].rec0 * L : nullptr);
+      };
+      std::vector<std::thread> th;
+      for (unsigned t = 1; t < std::min<uint64_t>(T, i1 - i0); t++) th.emplace_back(work);
+      work();
+      for (auto& x : th) x.join();
+      TRYI(hipMemcpyAsync(dst[b], pin[b], n_grp * L, hipMemcpyHostToDevice, s));
+      int rc = shn_pack_fixed_codes(ctx, dst[b], n_grp, L, r->wpr, r->d_words + base * r->wpr, r->d_mask + base * (r->wpr / 2), s);
+      if (rc) { cleanup(); shn_reads_destroy(r); return rc; }
+      TRYI(hipEventRecord(ev[b], s));
+      used[b] = true;
+      b ^= 1;
+    }
+    i0 = i1;
+  }
+  TRYI(hipStreamSynchronize(s));
+#undef TRYI
+  cleanup();
+  int rc = shn_reads_finish_fixed(ctx, r);
+  if (rc) { shn_reads_destroy(r); return rc; }
+  *out = r;
+  return SHN_OK;
+}

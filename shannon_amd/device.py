@@ -71,6 +71,31 @@ class Reads(object):
         _lib.check(_lib.lib().shn_reads_create(ctx.h, codes.ctypes.data, None, n, L, ENC_CODES, C.byref(h)))
         return cls(ctx, h)
 
+    @classmethod
+    def ingest(cls, ctx, source, fmt=0, want_codes=True):
+        """A read file (path, .gz too; or its text as bytes / a uint8 array) through shn_reads_ingest: (Reads, code matrix or
+        None).  2-line FASTA or 4-line FASTQ with reads of one length; anything else raises ShannonError("... unsupported ...")
+        and the caller reads the file record by record."""
+        if isinstance(source, str):
+            if source.endswith(".gz"):
+                import gzip
+                with gzip.open(source, "rb") as f:
+                    text = np.frombuffer(f.read(), dtype=np.uint8)
+            else:
+                import os
+                text = np.memmap(source, dtype=np.uint8, mode="r") if os.path.getsize(source) else np.zeros(0, np.uint8)
+        else:
+            text = np.frombuffer(source, dtype=np.uint8) if isinstance(source, (bytes, bytearray, memoryview)) else np.ascontiguousarray(source, dtype=np.uint8)
+        n, L = C.c_uint64(), C.c_uint32()
+        ptr = text.ctypes.data if len(text) else None
+        # the code matrix is smaller than the text: room for the text's size is enough (pages never written stay untouched)
+        buf = np.empty(max(len(text), 1), dtype=np.uint8) if want_codes else None
+        h = C.c_void_p()
+        _lib.check(_lib.lib().shn_reads_ingest(ctx.h if ctx is not None else None, ptr, len(text), int(fmt), buf.ctypes.data if want_codes else None,
+                                               len(buf) if want_codes else 0, C.byref(n), C.byref(L), C.byref(h) if ctx is not None else None))
+        codes = buf[:n.value * L.value].reshape(n.value, L.value) if want_codes else None
+        return (cls(ctx, h) if ctx is not None else None), codes
+
     def __len__(self):
         return int(_lib.lib().shn_reads_count(self.h))
 

@@ -76,6 +76,31 @@ def test_cli_config1_samples_se(tmp_path):
     assert p.returncode != 0 and "not empty" in p.stdout
 
 
+def test_cli_samples_pe(tmp_path):
+    """Samples/PE_read_1.fasta + PE_read_2.fasta through the shannon.py CLI (--left / --right, -K 25): the final FASTA and the
+    contig file equal the oracle's run and the reference's golden contigs; the TEMP tree has the reference's layout."""
+    import gzip, subprocess, sys, os
+    from conftest import ROOT
+    from oracle import pipeline as opipe
+    files = []
+    for nm in ("PE_read_1.fasta", "PE_read_2.fasta"):
+        fa = tmp_path / nm
+        with gzip.open(os.path.join(GOLD, "data", nm + ".gz"), "rt") as f:
+            fa.write_text(f.read())
+        files.append(str(fa))
+    out = tmp_path / "OUTPE"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "shannon.py"), "-o", str(out), "--left", files[0], "--right", files[1], "-K", "25"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:]
+    got = dict((h[1:], s) for h, s in parse_fasta((out / "shannon.fasta").read_text()))
+    inp = load_inputs("pe_K25")
+    ref = opipe.assemble(inp[0], inp[1], K=25, sample="OUTPE", seed=0)
+    assert got == ref["final"] and len(got) > 0
+    g = load_case("pe_K25")
+    assert (out / "TEMP" / "OUTPE_algo_input" / "k1mer.dict_contig").read_text().split() == g["contigs"]
+    assert (out / "log.txt").exists()
+
+
 def test_graph_reads_gathered_on_the_device_equal_uploaded_text(ctx, monkeypatch):
     """With code-matrix input the graph stage builds the device copy of a partition's distinct reads by gathering rows of the
     resident packed input (shn_reads_gather, reverse complements on chip) instead of uploading their text: same graphs, same
