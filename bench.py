@@ -121,6 +121,28 @@ def ingest_rate(ctx, r1, r2, n_pairs):
             "sample": "first %d pairs of the batch as two 2-line FASTA texts in host memory (%.2f GB), shn_reads_ingest incl. the host code matrix" % (n_pairs, nb / 1e9)}
 
 
+def native_graph_baseline(R, store, K):
+    """one partition of the run (the one of median size) through the native graph stage WITHOUT the device --
+    shn_mbgraph_run with ctx = NULL: K-mer graph built and condensed sequentially, seeds matched on the host -- i.e. the reference's
+    multibridging.main for that partition restated in C++ on this box's host cores."""
+    from shannon_amd import mbgraph_native, kmers_for_component as kfc
+    P = R.partitioning
+    names = sorted(P["routes"], key=lambda nm: len(P["routes"][nm]))
+    nm = names[len(names) // 2]
+    contigs = P["new_components"][nm]
+    rows = kfc._rows_bytes(contigs, K + 1)
+    n_rows = len(rows) // (K + 1)
+    idx = P["routes"][nm]
+    b1, o1, rc1, enc = store.gather_codes(idx, 1)
+    b2, o2, rc2 = b1, o1, (1 - rc1).astype(np.uint8)
+    t = time.time()
+    g = mbgraph_native.run_partition_handle(rows, n_rows, K, b1, o1, b2, o2, ctx=None, enc=enc, rc1=rc1, rc2=rc2)
+    dt = time.time() - t
+    g.close()
+    return {"partition": nm, "contigs": len(contigs), "k1mers": n_rows, "pairs_routed": int(len(idx)), "seconds": dt, "pairs_per_s": len(idx) / dt,
+            "note": "shn_mbgraph_run(ctx=NULL) on the host only; the whole run has %d partitions and %d routed pairs" % (len(names), sum(len(v) for v in P["routes"].values()))}
+
+
 def _host_cpus():
     from shannon_amd import _lib
     return _lib.host_cpus()
@@ -182,6 +204,8 @@ def main():
     ap.add_argument("--K", type=int, default=25)
     ap.add_argument("--genes", type=int, default=0, help="genes of the synthetic transcriptome; default from --config")
     ap.add_argument("--families", type=int, default=0, help="gene families of the configs[1] kind (default: one per rank)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="several GPUs: weak = every rank gets the config's reads (default), strong = the config's reads are split over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-distributed", action="store_true", help="run the multi-GPU code path even with one rank")
     args = ap.parse_args()
@@ -193,11 +217,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not args.config:
-        args.config = 2 if (world == 1 and not args.genes and not args.reads and not args.families) else 1
+        args.config = 2 if ((world == 1 or args.scaling == "strong") and not args.genes and not args.reads and not args.families) else 1
     preset = {1: (1, 10_000_000), 2: (20000, 100_000_000)}[args.config]
     args.genes = args.genes or preset[0]
     args.reads = args.reads or preset[1]
     is_config = (args.genes, args.reads) == preset and args.K == 25 and not args.families
+    if args.scaling == "strong" and world > 1:
+        args.reads = 2 * ((args.reads // 2) // world)          # the same batch size for the whole job, a slice per rank
     dist = None
     # SHN_BENCH_BACKEND=gloo: development aid -- several ranks on ONE GPU (collectives staged through host memory,
     # exchange.coll_device), to exercise the N-rank code path on a 1-GPU box.  Its numbers mean nothing.
@@ -269,7 +295,7 @@ def main():
             d = _Done()
             d.res = res
             return d
-        R = pipeline.assemble_resident(ctx, sets[0], sets[1], store, K=args.K, sample="bench", seed=1, timings=stage_t)
+        R = pipeline.assemble_resident(ctx, sets[0], sets[1], store, K=args.K, sample="bench", seed=1, timings=stage_t, keep_partitioning=True)
         d = _Done()
         d.R = R
         return d
@@ -348,7 +374,7 @@ def main():
         out = {
             "metric": "reads/sec k-mer->graph->path-decompose, 2x100bp k=25",
             "value": n_reads * world * args.steps / dt, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": (("100M synthetic 2x100bp paired reads (50M pairs), k=25 (k1=26), 20,000 genes (1-6 isoforms of 3-12 exons, lognormal "
                                      "expression), 0.5% substitution errors, multi-component, --partition 500 (BASELINE configs[2])")
@@ -386,6 +412,8 @@ def main():
             # bounded sample: ~10-15 s of one core through the whole path (at configs[2] a read costs the pure-Python path ~5x more
             # than at configs[1]: nearly every k1-mer of a 25k-read sample is new), + ~5 s for the counting stage alone / threaded
             out["cpu_baseline"] = cpu_baseline(k1, r1, r2, 75_000 if args.config == 1 else 12_500)
+            if not use_dist:
+                out["cpu_baseline"]["graph_stage_native_host_only"] = native_graph_baseline(last.R, store, args.K)
         final_line = json.dumps(out)
     else:
         final_line = None

@@ -8,8 +8,8 @@ Sharding.  Reads are split contiguously by index across ranks.
   2. the owned shards (distinct k1-mers, small next to the reads) are all-gathered so every rank
      holds the global table and runs the deterministic contig extension + partitioning
      redundantly (the greedy extension is a global sequential order -- it does not shard);
-  3. every rank routes ITS reads against the replicated partition table; partitions are owned by
-     rank (partition index mod W); the reads a partition's graph may consume -- the first
+  3. every rank routes ITS reads against the replicated partition table; partitions are dealt to
+     ranks by the number of reads their graphs consume (deal_partitions); the reads a partition's graph may consume -- the first
      10*#nodes+1 in the global strand-doubled order (multibridging.py:26-30) -- are sent to the
      owner (tiny, because of that cap);
   4. owners build the multibridged graph and run sparse flow for their partitions; rank 0 gathers
@@ -33,12 +33,38 @@ def _all_gather_var(t, group=None):
     ns = [torch.zeros_like(n) for _ in range(W)]
     dist.all_gather(ns, n, group=group)
     ns = [int(x.item()) for x in ns]
-    mx = max(ns + [1])
-    pad = torch.zeros(mx, dtype=t.dtype, device=cdev)
-    pad[:t.numel()] = t.to(cdev)
-    outs = [torch.empty_like(pad) for _ in range(W)]
-    dist.all_gather(outs, pad, group=group)
-    return torch.cat([o[:k] for o, k in zip(outs, ns)]).to(t.device), ns
+    if W == 1:
+        return t, ns
+    # in rounds of at most exchange.chunk_elems() elements per rank (see there), each round padded to its longest piece
+    C = exchange.chunk_elems()
+    out = torch.empty(sum(ns), dtype=t.dtype, device=cdev)
+    off = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+    src = t.to(cdev)
+    for j in range((max(ns + [1]) + C - 1) // C):
+        lens = [int(min(max(k - j * C, 0), C)) for k in ns]
+        mx = max(lens + [1])
+        pad = torch.zeros(mx, dtype=t.dtype, device=cdev)
+        mine = lens[dist.get_rank(group)]
+        pad[:mine] = src[j * C: j * C + mine]
+        outs = [torch.empty_like(pad) for _ in range(W)]
+        dist.all_gather(outs, pad, group=group)
+        for r in range(W):
+            if lens[r]:
+                out[int(off[r]) + j * C: int(off[r]) + j * C + lens[r]] = outs[r][:lens[r]]
+    return out.to(t.device), ns
+
+
+def deal_partitions(load, W):
+    """owner[i] of partition i: partitions in order of decreasing load, each to the rank with the least load so far (ties: the
+    lowest rank, the lowest partition index first) -- identical on every rank."""
+    load = np.asarray(load, dtype=np.int64)
+    owner = np.zeros(len(load), dtype=np.int64)
+    acc = np.zeros(W, dtype=np.int64)
+    for i in np.argsort(-load, kind="stable").tolist():
+        r = int(np.argmin(acc))
+        owner[i] = r
+        acc[r] += load[i]
+    return owner
 
 
 class _NoLock(object):
@@ -126,9 +152,13 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
     fwd_before = allc[:rank, :, 0].sum(axis=0)
     rc_before = allc[:, :, 0].sum(axis=0) + allc[:rank, :, 1].sum(axis=0)
     paired = ops.paired
+    # owner of every partition: largest first onto the least loaded rank (load = the reads its graph will consume, known to
+    # every rank from the gathered counts) -- the reference's size-sorted job list (shannon.py:546-551) dealt over the ranks
+    cutoffs = np.array([10 * ops.n_nodes(part, nm, K) + 1 for nm in names], dtype=np.int64)
+    owner = deal_partitions(np.minimum(allc.sum(axis=(0, 2)), cutoffs) + 1, W)
     payload = [[] for _ in range(W)]                # per destination rank: (partition, global doubled indices, reads)
     for i, nm in enumerate(names):
-        cutoff = 10 * ops.n_nodes(part, nm, K) + 1
+        cutoff = int(cutoffs[i])
         r = part["routes"][nm]                      # array, or a RouteView: only the kept prefixes are fetched
         f = int(cnt[i, 0])
         keep_f = int(max(0, min(f, cutoff - fwd_before[i])))
@@ -138,13 +168,13 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
         rf, rr = np.asarray(r[:keep_f], dtype=np.int64), np.asarray(r[f:f + keep_r], dtype=np.int64)
         sel = np.concatenate([rf, rr])
         gidx = np.concatenate([base + rf, n_glob + base + (rr - n_local)])
-        payload[i % W].append((i, gidx, ops.collect(sel)))
+        payload[int(owner[i])].append((i, gidx, ops.collect(sel)))
     tick("collect reads", t0)
     lock.release()
     t0 = time.time()
-    if getattr(ops, "array_payload", False):        # code rows + flags: one all-to-all(v) of bytes
-        got = exchange.all_to_all_bytes([exchange.pack_read_pieces(items) for items in payload], ops.device, group)
-        recv = [exchange.unpack_read_pieces(b) for b in got]
+    if getattr(ops, "array_payload", False):        # code rows + flags: one all-to-all(v) of bytes; what a rank owns itself stays put
+        got = exchange.all_to_all_bytes([exchange.pack_read_pieces(items if d != rank else []) for d, items in enumerate(payload)], ops.device, group)
+        recv = [exchange.unpack_read_pieces(b) if src != rank else payload[rank] for src, b in enumerate(got)]
     else:                                           # python objects (the oracle-backed test ops): small inputs only
         recv = [None] * W
         _a2a_objects(recv, payload, group)
@@ -156,7 +186,14 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
     for lst in recv:
         for p, gidx, data in lst:
             mine.setdefault(p, []).append((gidx, data))
-    owned = [i for i in range(P) if i % W == rank]
+    owned = sorted((i for i in range(P) if int(owner[i]) == rank), key=lambda i: -int(min(allc[:, i, :].sum(), cutoffs[i])))
+
+    if hasattr(ops, "graph_batch"):
+        # the owned partitions through the single-GPU graph stage: GPU unitigs, distinct reads found on the device, native sparse flow
+        texts = ops.graph_batch(part, names, owned, mine, K, paired, sample, seed, T)
+        if texts is not None:
+            lock.release()
+            return _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick)
 
     def one(i):
         singles, comps = ops.graph(part, names[i], mine.get(i, []), K, paired)      # pieces: [(global indices, reads)] per source rank
@@ -186,6 +223,12 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
         texts[i] = txt
     tick("sparse flow", t0)
     lock.release()
+    return _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick)
+
+
+def _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick):
+    """the per-partition FASTA of every owner to rank 0, which merges (shannon.py:584-604)"""
+    import time
     t0 = time.time()
     gathered = [None] * W
     dist.all_gather_object(gathered, texts, group=group)
@@ -294,18 +337,106 @@ class GpuOps(object):
                 return int(t.item())
 
         Gather.rank = rank
+        import os
+        _cg = os.environ.get("SHN_CONTIG_GPU", "")
+        if W > 1 and (_cg == "1" or (_cg != "0" and len(table) >= 20_000_000)):
+            # a large table (BASELINE configs[2] and beyond): the contig stage of the shards is the sequential host code, the
+            # replicated one runs on the GPU (contig_stage_gpu) in a tenth of the time -- every rank extends the whole table
+            res = ec.run_correction(self.ctx, table, 3, 75, partition_size, want_allowed=False, timings=getattr(self, "timings", None))
+            table.close()
+            return res
         res = ec.run_correction(self.ctx, table, 3, 75, partition_size, want_allowed=False, shard=(W, rank), gather=Gather,
                                 timings=getattr(self, "timings", None))
         table.close()
         return res
 
     def route(self, res, K, partition_size, part_vectors):
-        from . import kmers_for_component as kfc
-        return kfc.kmers_for_component(self.ctx, res, self.d1, self.d2, K, partition_size, part_vectors=part_vectors, want_rows=False,
-                                       timings=getattr(self, "timings", None), lazy_routes=True)
+        from . import kmers_for_component as kfc, mbgraph_native
+        import os
+        self.unitigs, self.part_index = None, None
+        gpu_graph = K <= 31 and os.environ.get("SHN_GRAPH_GPU", "1") != "0"
+        part = kfc.kmers_for_component(self.ctx, res, self.d1, self.d2, K, partition_size, part_vectors=part_vectors, want_rows=False,
+                                       timings=getattr(self, "timings", None), lazy_routes=True, lazy_graph_inputs=gpu_graph)
+        names = list(part["new_components"])
+        if gpu_graph and names:
+            # the raw K-mer graphs of ALL partitions contracted on every rank (a tenth of a second at 111 partitions): every rank
+            # needs every partition's K-mer count for the read caps, the owners need the unitigs
+            self.unitigs = mbgraph_native.Unitigs(self.ctx, [part["new_components"][nm] for nm in names], K)
+            self.part_index = {nm: i for i, nm in enumerate(names)}
+        return part
 
     def n_nodes(self, part, name, K):
+        if self.unitigs is not None:
+            return self.unitigs.n_kmers(self.part_index[name])
         return part["n_kmer_nodes"][name]
+
+    @staticmethod
+    def _merge_pieces(pieces):
+        """the pieces of one partition from their source ranks -> (code rows, strand flags) in the global strand-doubled order"""
+        pieces = [p for p in pieces if len(p[0])]
+        if not pieces:
+            return np.zeros((0, 1), np.uint8), np.zeros(0, np.uint8)
+        one = len(pieces) == 1                                    # (no copy of a 100 MB piece)
+        gidx = pieces[0][0] if one else np.concatenate([g for g, _ in pieces])
+        rows = np.ascontiguousarray(pieces[0][1][0] if one else np.concatenate([d[0] for _, d in pieces]))
+        rc1 = np.ascontiguousarray(pieces[0][1][1] if one else np.concatenate([d[1] for _, d in pieces]))
+        if len(gidx) > 1 and not bool((gidx[1:] > gidx[:-1]).all()):      # (one source rank: already in order)
+            from . import _lib
+            order = np.argsort(gidx, kind="stable")
+            rows = _lib.gather_rows(rows, order)
+            rc1 = np.ascontiguousarray(rc1[order])
+        return rows, rc1
+
+    def graph_batch(self, part, names, owned, mine, K, paired, sample, seed, T):
+        """multibridging.main + algorithm_SF for the owned partitions, as the single-GPU pipeline runs them: the received code rows
+        become a resident read set of their own (row i forward = doubled index i, reverse strand = n + i), the distinct reads are
+        found on the device (shn_mbgraph_run_rows), all components go through shn_sparse_flow in one call.  {partition: FASTA}."""
+        import time, threading
+        from concurrent.futures import ThreadPoolExecutor
+        from . import mbgraph_native, _lib
+        if self.unitigs is None:
+            return None
+        t0 = time.time()
+        up = threading.Lock()
+
+        def one(i):
+            rows, rc1 = self._merge_pieces(mine.get(i, []))
+            rb = None
+            for _attempt in (0, 1):
+                try:
+                    if len(rows) == 0:
+                        z, o = np.zeros(1, np.uint8), np.zeros(1, np.uint64)
+                        return mbgraph_native.run_partition_handle(rb, 0 if rb is None else len(rb) // (K + 1), K, z, o, z if paired else None,
+                                                                   o if paired else None, ctx=self.ctx, unitigs=self.unitigs, part=i)
+                    with up:
+                        d = self._dev.Reads.from_codes(self.ctx, rows)
+                    n = len(rows)
+                    didx = (np.arange(n, dtype=np.int64) + np.where(rc1 != 0, n, 0)).astype(np.uint32)
+                    try:
+                        return mbgraph_native.run_partition_rows(self.ctx, self.unitigs, i, d, d if paired else None, rows, rows if paired else None,
+                                                                 didx, rb, 0 if rb is None else len(rb) // (K + 1))
+                    finally:
+                        d.close()
+                except _lib.ShannonError as ex:
+                    if rb is not None or "needs the k1-mer rows" not in str(ex):
+                        raise
+                    rb_ = part["k1mer_bytes"][names[i]]                  # a partition holding a cycle of condensable edges
+                    rb = rb_() if callable(rb_) else rb_
+        nthreads = max(1, min(len(owned), _lib.host_cpus()))
+        if nthreads > 1:
+            with ThreadPoolExecutor(max_workers=nthreads) as pool:
+                graphs = list(pool.map(one, owned))
+        else:
+            graphs = [one(i) for i in owned]
+        T["graph"] = T.get("graph", 0.0) + time.time() - t0
+        t0 = time.time()
+        texts = mbgraph_native.sparse_flow_native(self.ctx, graphs, ["%s_%s" % (sample, names[i]) for i in owned], seed) if owned else []
+        for g in graphs:
+            g.close()
+        self.unitigs.close()
+        self.unitigs = None
+        T["sparse flow"] = T.get("sparse flow", 0.0) + time.time() - t0
+        return {i: txt for i, txt in zip(owned, texts)}
 
     def collect(self, sel):
         """the reads of the doubled indices `sel` as they travel to a partition's owner: stored code rows + strand

@@ -36,6 +36,46 @@ def coll_device(dev, group=None):
     return torch.device("cpu") if dist.get_backend(group) == "gloo" else torch.device(dev)
 
 
+def chunk_elems():
+    """Elements one rank sends to one peer in a single collective call.  A 100 M-read batch has 724 M distinct k1-mers: its
+    bucket exchange moves 5.8 GB of keys, and one all_to_all_single of that size came back with half of the pairs (element /
+    byte counts past 2^32 inside the call) -- so every variable-size collective here goes in rounds of at most this many
+    elements per (source, destination) pair.  SHN_COLL_CHUNK overrides (the CPU tests force several rounds with it)."""
+    import os
+    return max(1, int(os.environ.get("SHN_COLL_CHUNK", 1 << 26)))
+
+
+def all_to_all_v(send, scl, rcl, cdev, group=None):
+    """all-to-all(v) of a 1-D tensor: `send` grouped by destination with scl[d] elements each, rcl[s] elements expected from
+    rank s; in rounds of chunk_elems() per pair.  Returns the received tensor (grouped by source) on cdev."""
+    world = dist.get_world_size(group)
+    C = chunk_elems()
+    n_in = sum(rcl)
+    out = torch.empty(n_in, dtype=send.dtype, device=cdev)
+    rounds = (max(list(scl) + list(rcl) + [0]) + C - 1) // C
+    rt = torch.tensor([rounds], dtype=torch.int64, device=cdev)
+    dist.all_reduce(rt, op=dist.ReduceOp.MAX, group=group)
+    rounds = int(rt.item())
+    if rounds <= 1:
+        dist.all_to_all_single(out, send[:sum(scl)].to(cdev), list(rcl), list(scl), group=group)
+        return out
+    soff = np.concatenate([[0], np.cumsum(scl)]).astype(np.int64)
+    roff = np.concatenate([[0], np.cumsum(rcl)]).astype(np.int64)
+    for j in range(rounds):
+        sj = [int(min(max(scl[d] - j * C, 0), C)) for d in range(world)]
+        rj = [int(min(max(rcl[d] - j * C, 0), C)) for d in range(world)]
+        pieces = [send[int(soff[d]) + j * C: int(soff[d]) + j * C + sj[d]] for d in range(world) if sj[d]]
+        sb = (torch.cat(pieces) if pieces else send[:0]).to(cdev)
+        rb = torch.empty(sum(rj), dtype=send.dtype, device=cdev)
+        dist.all_to_all_single(rb, sb, rj, sj, group=group)
+        at = 0
+        for d in range(world):
+            if rj[d]:
+                out[int(roff[d]) + j * C: int(roff[d]) + j * C + rj[d]] = rb[at:at + rj[d]]
+                at += rj[d]
+    return out
+
+
 def all_to_all_pairs(keys, counts, send_counts, group=None):
     """keys (int64) / counts (int32) tensors grouped by destination rank with `send_counts`
     entries each.  Returns (recv_keys, recv_counts, recv_counts_per_rank)."""
@@ -47,11 +87,10 @@ def all_to_all_pairs(keys, counts, send_counts, group=None):
     dist.all_to_all_single(rc, sc, group=group)
     rcl = [int(v) for v in rc.cpu().tolist()]
     scl = [int(v) for v in np.asarray(send_counts).tolist()]
-    n_in = sum(rcl)
-    rk = torch.empty(n_in, dtype=torch.int64, device=cdev)
-    rcn = torch.empty(n_in, dtype=torch.int32, device=cdev)
-    dist.all_to_all_single(rk, keys[:sum(scl)].to(cdev), rcl, scl, group=group)
-    dist.all_to_all_single(rcn, counts[:sum(scl)].to(cdev), rcl, scl, group=group)
+    if world == 1:                                  # nothing travels
+        return keys[:scl[0]], counts[:scl[0]], rcl
+    rk = all_to_all_v(keys, scl, rcl, cdev, group)
+    rcn = all_to_all_v(counts, scl, rcl, cdev, group)
     return rk.to(dev), rcn.to(dev), rcl
 
 
@@ -79,9 +118,8 @@ def all_to_all_bytes(bufs, device, group=None):
     rt = torch.empty(world, dtype=torch.int64, device=cdev)
     dist.all_to_all_single(rt, st, group=group)
     rc = [int(v) for v in rt.cpu().tolist()]
-    send = torch.from_numpy(np.concatenate(bufs) if sum(sc) else np.zeros(0, np.uint8)).to(cdev)
-    recv = torch.empty(sum(rc), dtype=torch.uint8, device=cdev)
-    dist.all_to_all_single(recv, send, rc, sc, group=group)
+    send = torch.from_numpy(np.concatenate(bufs) if sum(sc) else np.zeros(0, np.uint8))
+    recv = all_to_all_v(send, sc, rc, cdev, group)
     out = recv.cpu().numpy()
     offs = np.concatenate([[0], np.cumsum(rc)]).astype(np.int64)
     return [out[offs[i]:offs[i + 1]] for i in range(world)]

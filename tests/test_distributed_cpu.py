@@ -1,4 +1,4 @@
-"""CPU, world_size 2 (gloo): the multi-GPU choreography of shannon_amd.distributed -- bucket
+"""CPU, world_size 2 and 3 (gloo): the multi-GPU choreography of shannon_amd.distributed -- bucket
 exchange, table replication, global read order / caps, partition ownership, FASTA gather --
 reproduces the single-process result on the concatenated reads."""
 import json, os, subprocess, sys
@@ -16,12 +16,24 @@ def test_owner_hash_matches_device_constant():
     assert o.min() == 0 and o.max() == 7 and np.bincount(o).min() > 80
 
 
-@pytest.mark.parametrize("name,port", [("syn_pe_s0", 29611), ("syn_se_s5", 29612), ("syn_part_s33", 29613)])
-def test_two_ranks_equal_single_process(name, port, tmp_path):
+def test_partitions_are_dealt_by_load():
+    from shannon_amd import distributed
+    o = distributed.deal_partitions([5, 100, 7, 7, 60, 1], 3)
+    acc = np.bincount(o, weights=[5, 100, 7, 7, 60, 1], minlength=3)
+    assert o[1] == 0 and o[4] == 1 and acc.max() == 100 and acc.min() >= 19
+    assert distributed.deal_partitions([], 4).tolist() == [] and distributed.deal_partitions([3, 3, 3], 1).tolist() == [0, 0, 0]
+
+
+@pytest.mark.parametrize("name,port,world,chunk", [("syn_pe_s0", 29611, 2, None), ("syn_se_s5", 29612, 2, None), ("syn_part_s33", 29613, 2, "997"),
+                                                   ("syn_part_s33", 29614, 3, None), ("syn_pe_s0", 29615, 3, "500")])
+def test_ranks_equal_single_process(name, port, world, chunk, tmp_path):
+    """world_size 2 and 3 (gloo); chunk: every variable-size collective in rounds of that many elements (exchange.chunk_elems)"""
     from oracle import pipeline as opipe
     out = str(tmp_path / "res.json")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+    if chunk:
+        env["SHN_COLL_CHUNK"] = chunk
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
                         "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), name, out],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:]
