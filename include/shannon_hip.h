@@ -316,6 +316,18 @@ int shn_reads_dedup(shn_ctx* ctx, const shn_reads* a, const shn_reads* b, const 
  * lengths, multi-line FASTA and malformed records are refused (SHN_ERR_ARG, message "shn_reads_ingest: unsupported: ...").      */
 int shn_reads_ingest(shn_ctx* ctx, const uint8_t* text, uint64_t n_bytes, int format, uint8_t* codes_out, uint64_t codes_cap,
                      uint64_t* n_reads_out, uint32_t* read_len_out, shn_reads** out);
+/* The whole final merge over the text of all_reconstructed.fasta: process_concatenated_fasta.py:6-32 (rename repeated names, drop
+ * sequences of < 200 bases and sequences seen before on either strand), the length sort of shannon.py:603 and shn_find_reps
+ * (faster_reps.py:60-131).  The survivors in sorted order: shn_post_count / _sizes / _export (names, name_off[n+1], seqs,
+ * seq_off[n+1]).  SHN_ERR_ARG on a base outside ACGT (as shn_find_reps) or an empty line.                                       */
+typedef struct shn_post shn_post;
+int shn_post_finalize(const uint8_t* text, uint64_t n_bytes, int ds, int r, shn_post** out);
+/* ... over the concatenation of several buffers (per-partition FASTA texts) */
+int shn_post_finalize_bufs(const uint8_t* const* bufs, const uint64_t* lens, uint64_t n_bufs, int ds, int r, shn_post** out);
+uint64_t shn_post_count(const shn_post* p);
+int shn_post_sizes(const shn_post* p, uint64_t* name_bytes, uint64_t* seq_bytes);
+int shn_post_export(const shn_post* p, uint8_t* names, uint64_t* name_off, uint8_t* seqs, uint64_t* seq_off);
+void shn_post_destroy(shn_post* p);
 /* Host threads the library keeps busy at most: min(hardware threads, affinity mask, cgroup CPU quota); SHN_HOST_CPUS overrides.
  * (-- ; the reference takes its process count from --nprocs, shannon.py:99.)                                                   */
 int shn_host_cpus(void);

@@ -10,24 +10,37 @@
 #include <thread>
 #include <vector>
 
-static inline int pcode(uint8_t c) {
-  switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; }
-}
+struct PCodeLut { int8_t v[256]; PCodeLut() { memset(v, -1, 256); v['A'] = 0; v['C'] = 1; v['G'] = 2; v['T'] = 3; } };
+static const PCodeLut kPCode;
+static inline int pcode(uint8_t c) { return kPCode.v[c]; }                // (a table: a switch mispredicts on every other base)
 
 // names/seqs: n records (ASCII, offsets n+1 each), in file order.  keep_out[i] = 1 if record i survives.
 // A name that occurs more than once behaves like the reference's dict (the later sequence replaces the
 // earlier one, keep_out of the earlier record is 0).  Returns SHN_ERR_ARG if a sequence holds a non-ACGT base.
+static int find_reps_core(const uint8_t* const* nptr, const uint64_t* nlen, const uint8_t* const* sptr, const uint64_t* slen, uint64_t n, int ds, int r,
+                          uint8_t* keep_out);
 extern "C" int shn_find_reps(const uint8_t* names, const uint64_t* name_off, const uint8_t* seqs, const uint64_t* seq_off,
                              uint64_t n, int ds, int r, uint8_t* keep_out) {
   if ((n && (!names || !name_off || !seqs || !seq_off)) || !keep_out) return shn_fail(SHN_ERR_ARG, "shn_find_reps: NULL argument");
+  std::vector<const uint8_t*> np_(n), sp_(n);
+  std::vector<uint64_t> nl_(n), sl_(n);
+  for (uint64_t i = 0; i < n; i++) { np_[i] = names + name_off[i]; nl_[i] = name_off[i + 1] - name_off[i]; sp_[i] = seqs + seq_off[i]; sl_[i] = seq_off[i + 1] - seq_off[i]; }
+  return find_reps_core(np_.data(), nl_.data(), sp_.data(), sl_.data(), n, ds, r, keep_out);
+}
+// (records given by pointer + length: shn_post_finalize hands over lines of the text it was given, without packing them)
+static int find_reps_core(const uint8_t* const* nptr, const uint64_t* nlen, const uint8_t* const* sptr, const uint64_t* slen, uint64_t n, int ds, int r,
+                          uint8_t* keep_out) {
   if (r < 1 || r > 32) return shn_fail(SHN_ERR_ARG, "shn_find_reps: r must be in [1,32]");
+  const bool dbgf = getenv("SHN_DEBUG") != nullptr;
+  auto nowf = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
+  const double tf0 = nowf();
   StringInterner ids(n + 16);
   std::vector<int64_t> rec_of;                  // name id -> latest record
   std::vector<int32_t> id_of(n);
   const uint64_t mask = r == 32 ? ~0ULL : ((1ULL << (2 * r)) - 1);
   for (uint64_t i = 0; i < n; i++) {
     bool is_new;
-    int32_t id = ids.intern((const char*)names + name_off[i], name_off[i + 1] - name_off[i], &is_new);
+    int32_t id = ids.intern((const char*)nptr[i], nlen[i], &is_new);
     if (is_new) rec_of.push_back((int64_t)i); else rec_of[id] = (int64_t)i;
     id_of[i] = id;
   }
@@ -50,31 +63,37 @@ extern "C" int shn_find_reps(const uint8_t* names, const uint64_t* name_off, con
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t]() {
       for (uint64_t i = n * t / nt; i < n * (t + 1) / nt; i++)
-        for (uint64_t p = seq_off[i]; p < seq_off[i + 1]; p++) if (pcode(seqs[p]) < 0) { bad.store(1); return; }
+        for (uint64_t p = 0; p < slen[i]; p++) if (pcode(sptr[i][p]) < 0) { bad.store(1); return; }
     });
     for (auto& x : th) x.join();
     if (bad.load()) return shn_fail(SHN_ERR_ARG, "shn_find_reps: non-ACGT base in a transcript");
   }
+  const double tf1 = nowf();
   size_t qcap = 1024;
   while (qcap < rec_of.size() * 16) qcap <<= 1;
   std::vector<uint64_t> qset(qcap, ~0ULL);        // open addressing; ~0 = empty (an r-mer of r < 32 never is; r = 32: all-T handled below)
   bool q_all_t = false;
+  // in front of the set a 1 MB bit table that stays in a core's cache: 19 of 20 window positions end there
+  std::vector<uint64_t> qbits(1u << 17, 0);
   auto q_add = [&](uint64_t key) {
     if (key == ~0ULL) { q_all_t = true; return; }
+    { const uint64_t h = fm_mix(key) >> 41; qbits[h >> 6] |= 1ULL << (h & 63); }
     size_t sl = fm_mix(key) & (qcap - 1);
     while (qset[sl] != ~0ULL && qset[sl] != key) sl = (sl + 1) & (qcap - 1);
     qset[sl] = key;
   };
   auto q_has = [&](uint64_t key) -> bool {
     if (key == ~0ULL) return q_all_t;
-    size_t sl = fm_mix(key) & (qcap - 1);
+    const uint64_t hm = fm_mix(key);
+    { const uint64_t h = hm >> 41; if (!((qbits[h >> 6] >> (h & 63)) & 1)) return false; }
+    size_t sl = hm & (qcap - 1);
     while (qset[sl] != ~0ULL) { if (qset[sl] == key) return true; sl = (sl + 1) & (qcap - 1); }
     return false;
   };
   for (size_t id = 0; id < rec_of.size(); id++) {
     const uint64_t i = (uint64_t)rec_of[id];
-    const uint8_t* s = seqs + seq_off[i];
-    const uint64_t L = seq_off[i + 1] - seq_off[i];
+    const uint8_t* s = sptr[i];
+    const uint64_t L = slen[i];
     if (L < (uint64_t)r) continue;
     for (int flip = 0; flip < (ds ? 2 : 1); flip++) {
       uint64_t kf, kl;
@@ -83,6 +102,7 @@ extern "C" int shn_find_reps(const uint8_t* names, const uint64_t* name_off, con
       q_add(kf); q_add(kl);
     }
   }
+  const double tf2 = nowf();
   struct Occ { uint64_t key; int32_t id, pos; };
   const unsigned nthr = n < 4096 ? 1 : std::max(1u, std::min(32u, (unsigned)shn_host_cpus()));
   std::vector<std::vector<Occ>> found(nthr);
@@ -91,8 +111,8 @@ extern "C" int shn_find_reps(const uint8_t* names, const uint64_t* name_off, con
     for (unsigned t = 0; t < nthr; t++) th.emplace_back([&, t]() {
       std::vector<Occ>& out = found[t];
       for (uint64_t i = n * t / nthr; i < n * (t + 1) / nthr; i++) {
-        const uint8_t* s = seqs + seq_off[i];
-        const uint64_t L = seq_off[i + 1] - seq_off[i];
+        const uint8_t* s = sptr[i];
+        const uint64_t L = slen[i];
         uint64_t key = 0;
         for (uint64_t p = 0; p < L; p++) {
           key = ((key << 2) | (uint64_t)pcode(s[p])) & mask;
@@ -102,16 +122,18 @@ extern "C" int shn_find_reps(const uint8_t* names, const uint64_t* name_off, con
     });
     for (auto& x : th) x.join();
   }
+  const double tf3 = nowf();
   size_t n_occ = 0;
   for (auto& v : found) n_occ += v.size();
   FlatMultiMap index(n_occ + 1024);
   for (auto& v : found) for (const Occ& o : v) index.add(o.key, o.id, o.pos);
   memset(keep_out, 0, n);
+  const double tf4 = nowf();
   std::vector<std::pair<int32_t, std::pair<int64_t, int64_t>>> pos;    // (other name id, (first pos, last pos)) in first-seen order
   for (size_t id = 0; id < rec_of.size(); id++) {
     uint64_t i = (uint64_t)rec_of[id];
-    const uint8_t* s = seqs + seq_off[i];
-    uint64_t L = seq_off[i + 1] - seq_off[i];
+    const uint8_t* s = sptr[i];
+    uint64_t L = slen[i];
     bool drop = false;
     for (int flip = 0; flip < (ds ? 2 : 1) && !drop; flip++) {
       if (L < (uint64_t)r) continue;
@@ -146,7 +168,7 @@ extern "C" int shn_find_reps(const uint8_t* names, const uint64_t* name_off, con
         if (d < 0) d = -d;
         if (d >= 3) continue;
         uint64_t oi = (uint64_t)rec_of[e.first];
-        uint64_t OL = seq_off[oi + 1] - seq_off[oi];
+        uint64_t OL = slen[oi];
         bool name_gt = false;
         if (L == OL) {
           size_t la = ids.len((int32_t)id), lb = ids.len(e.first);
@@ -158,5 +180,172 @@ extern "C" int shn_find_reps(const uint8_t* names, const uint64_t* name_off, con
     }
     if (!drop) keep_out[i] = 1;
   }
+  if (dbgf) fprintf(stderr, "[find_reps] names+check %.3f, query set %.3f, scan %.3f, index %.3f (%zu occurrences), decide %.3f s\n", tf1 - tf0, tf2 - tf1,
+                    tf3 - tf2, tf4 - tf3, n_occ, nowf() - tf4);
+  return SHN_OK;
+}
+
+// ---- the whole merge in one call: process_concatenated_fasta.py:6-32, the length sort of shannon.py:603 and find_reps above,
+// over the text of all_reconstructed.fasta (every partition's reconstructed.fasta + reconstructed_single_contigs.fasta).  At
+// BASELINE configs[2] that file has 120 k records / 150 MB; the line-by-line Python form of these three steps was 0.6 s of
+// the step.  Semantics kept, quirks included: a repeated name N becomes "N_<count>" glued to its remaining header fields
+// (no separator), sequences of at most 199 bases (line length <= 200 with its newline) are dropped, a sequence (or, double
+// stranded, its reverse complement) seen before is dropped, a header line seen twice keeps its last sequence, records are
+// ordered by (sequence line length, header line).
+#include <string_view>
+#include <unordered_map>
+#include <unordered_set>
+#include <string>
+
+struct shn_post {
+  std::string names, seqs;
+  std::vector<uint64_t> name_off{0}, seq_off{0};
+};
+
+extern "C" void shn_post_destroy(shn_post* p) { delete p; }
+extern "C" uint64_t shn_post_count(const shn_post* p) { return p ? p->name_off.size() - 1 : 0; }
+extern "C" int shn_post_sizes(const shn_post* p, uint64_t* name_bytes, uint64_t* seq_bytes) {
+  if (!p || !name_bytes || !seq_bytes) return shn_fail(SHN_ERR_ARG, "shn_post_sizes: NULL argument");
+  *name_bytes = p->names.size(); *seq_bytes = p->seqs.size();
+  return SHN_OK;
+}
+extern "C" int shn_post_export(const shn_post* p, uint8_t* names, uint64_t* name_off, uint8_t* seqs, uint64_t* seq_off) {
+  if (!p || !names || !name_off || !seqs || !seq_off) return shn_fail(SHN_ERR_ARG, "shn_post_export: NULL argument");
+  memcpy(names, p->names.data(), p->names.size());
+  memcpy(seqs, p->seqs.data(), p->seqs.size());
+  memcpy(name_off, p->name_off.data(), p->name_off.size() * 8);
+  memcpy(seq_off, p->seq_off.data(), p->seq_off.size() * 8);
+  return SHN_OK;
+}
+
+extern "C" int shn_post_finalize_bufs(const uint8_t* const* bufs, const uint64_t* lens, uint64_t n_bufs, int ds, int r, shn_post** out);
+extern "C" int shn_post_finalize(const uint8_t* text, uint64_t n_bytes, int ds, int r, shn_post** out) {
+  if ((n_bytes && !text) || !out) return shn_fail(SHN_ERR_ARG, "shn_post_finalize: NULL argument");
+  return shn_post_finalize_bufs(&text, &n_bytes, 1, ds, r, out);
+}
+// the same over the concatenation of several buffers (the per-partition FASTA texts as they come out of shn_sparse_flow)
+extern "C" int shn_post_finalize_bufs(const uint8_t* const* bufs, const uint64_t* lens, uint64_t n_bufs, int ds, int r, shn_post** out) {
+  if (!out || (n_bufs && (!bufs || !lens))) return shn_fail(SHN_ERR_ARG, "shn_post_finalize: NULL argument");
+  for (uint64_t i = 0; i < n_bufs; i++) if (lens[i] && !bufs[i]) return shn_fail(SHN_ERR_ARG, "shn_post_finalize: NULL buffer");
+  // a buffer that does not end its last line would run into the next one: join them all in that (unusual) case
+  std::string joined;
+  std::vector<std::pair<const uint8_t*, uint64_t>> pieces;
+  bool clean = true;
+  for (uint64_t i = 0; i + 1 < n_bufs; i++) if (lens[i] && bufs[i][lens[i] - 1] != '\n') clean = false;
+  if (clean) { for (uint64_t i = 0; i < n_bufs; i++) if (lens[i]) pieces.push_back({bufs[i], lens[i]}); }
+  else {
+    for (uint64_t i = 0; i < n_bufs; i++) joined.append((const char*)bufs[i], lens[i]);
+    pieces.push_back({(const uint8_t*)joined.data(), joined.size()});
+  }
+  typedef std::string_view SV;
+  auto is_ws = [](uint8_t c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; };
+  auto strip = [&](SV s) { size_t a = 0, b = s.size(); while (a < b && is_ws((uint8_t)s[a])) a++; while (b > a && is_ws((uint8_t)s[b - 1])) b--; return s.substr(a, b - a); };
+  // ---- process_concatenated
+  std::vector<std::string> own;                        // renamed header lines (stable addresses: reserved below)
+  std::vector<std::pair<SV, SV>> recs;                 // (header line, sequence line), lines with their newline
+  {
+    uint64_t n_lines = 0;
+    for (auto& pc : pieces) { n_lines++; for (uint64_t p = 0; p < pc.second; p++) n_lines += pc.first[p] == '\n'; }
+    own.reserve(n_lines + 2);
+  }
+  const double tq0 = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }();
+  std::unordered_map<SV, uint64_t> seen;
+  std::unordered_set<SV> contigs;
+  std::vector<std::string> rc_hold;
+  SV last;
+  std::string rcbuf;
+  uint8_t comp[256];
+  for (int c = 0; c < 256; c++) comp[c] = (uint8_t)c;
+  comp['A'] = 'T'; comp['C'] = 'G'; comp['G'] = 'C'; comp['T'] = 'A';
+  for (auto& pc : pieces) {
+  const uint8_t* text = pc.first;
+  const uint64_t n_bytes = pc.second;
+  for (uint64_t p = 0; p < n_bytes;) {
+    const void* q = memchr(text + p, '\n', n_bytes - p);
+    const uint64_t e = q ? (uint64_t)((const uint8_t*)q - text) + 1 : n_bytes;
+    const SV line((const char*)text + p, e - p);
+    p = e;
+    // tok = line.split()
+    size_t a = 0;
+    while (a < line.size() && is_ws((uint8_t)line[a])) a++;
+    if (a == line.size()) return shn_fail(SHN_ERR_ARG, "shn_post_finalize: empty line");           // (tok[0] raises in the reference)
+    if (line[a] == '>') {
+      size_t b = a;
+      while (b < line.size() && !is_ws((uint8_t)line[b])) b++;
+      const SV tok0 = line.substr(a, b - a);
+      auto it = seen.find(tok0);
+      if (it != seen.end()) {
+        std::string nl(tok0);
+        nl += "_" + std::to_string(it->second);
+        bool first = true;
+        for (size_t c = b; c < line.size();) {
+          while (c < line.size() && is_ws((uint8_t)line[c])) c++;
+          size_t d = c;
+          while (d < line.size() && !is_ws((uint8_t)line[d])) d++;
+          if (d > c) { if (!first) nl += "\t"; nl.append(line.data() + c, d - c); first = false; }
+          c = d;
+        }
+        nl += "\n";
+        it->second++;
+        own.push_back(std::move(nl));
+        last = SV(own.back());
+      } else { seen.emplace(tok0, 1); last = line; }
+    } else if (line.size() > 200) {
+      const SV cur = strip(line);
+      if (contigs.count(cur)) continue;
+      if (ds) {
+        rcbuf.resize(cur.size());
+        { const char* src = cur.data() + cur.size() - 1; char* dst = &rcbuf[0];
+          for (size_t i = 0, m = cur.size(); i < m; i++) dst[i] = (char)comp[(uint8_t)src[-(ptrdiff_t)i]]; }
+        if (contigs.count(SV(rcbuf))) continue;
+      }
+      contigs.insert(cur);
+      recs.push_back({last, line});
+    }
+  }
+  }
+  const bool dbgp = getenv("SHN_DEBUG") != nullptr;
+  auto nowp = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
+  const double tp0 = nowp();
+  // ---- length sort: a dict keyed by header line (the last sequence of a repeated header line wins), by (len(seq line), header line)
+  std::unordered_map<SV, uint32_t> by_header;
+  std::vector<uint32_t> order;
+  for (uint32_t i = 0; i < recs.size(); i++) {
+    auto it = by_header.find(recs[i].first);
+    if (it == by_header.end()) { by_header.emplace(recs[i].first, (uint32_t)order.size()); order.push_back(i); }
+    else order[it->second] = i;
+  }
+  std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+    if (recs[x].second.size() != recs[y].second.size()) return recs[x].second.size() < recs[y].second.size();
+    return recs[x].first < recs[y].first;
+  });
+  // ---- find_reps over (name = first field without '>', stripped sequence)
+  const uint64_t n = order.size();
+  std::vector<const uint8_t*> nptr(n), sptr(n);
+  std::vector<uint64_t> nlen(n), slen(n);
+  for (uint64_t i = 0; i < n; i++) {
+    const SV h = strip(recs[order[i]].first);
+    size_t b = 0;
+    while (b < h.size() && !is_ws((uint8_t)h[b])) b++;
+    nptr[i] = (const uint8_t*)h.data() + 1; nlen[i] = b - 1;
+    const SV sq = strip(recs[order[i]].second);
+    sptr[i] = (const uint8_t*)sq.data(); slen[i] = sq.size();
+  }
+  std::vector<uint8_t> keep(n + 1, 0);
+  const double tp1 = nowp();
+  if (n) {
+    int rc = find_reps_core(nptr.data(), nlen.data(), sptr.data(), slen.data(), n, ds, r, keep.data());
+    if (rc) return rc;
+  }
+  shn_post* o = new shn_post();
+  for (uint64_t i = 0; i < n; i++) {
+    if (!keep[i]) continue;
+    o->names.append((const char*)nptr[i], nlen[i]);
+    o->seqs.append((const char*)sptr[i], slen[i]);
+    o->name_off.push_back(o->names.size());
+    o->seq_off.push_back(o->seqs.size());
+  }
+  *out = o;
+  if (dbgp) fprintf(stderr, "[post] lines %.3f s (from after the newline count), sort+pack %.3f s, find_reps %.3f s, %llu records\n", tp0 - tq0, tp1 - tp0, nowp() - tp1, (unsigned long long)n);
   return SHN_OK;
 }

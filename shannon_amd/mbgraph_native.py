@@ -144,8 +144,9 @@ def graph_from_tables(singles, comps):
     return GraphHandle(h)
 
 
-def sparse_flow_native(ctx, graphs, snames, seed):
-    """The native sparse-flow stage (shn_sparse_flow) over the graphs of several partitions: [reconstructed FASTA text]."""
+def sparse_flow_native(ctx, graphs, snames, seed, raw=False):
+    """The native sparse-flow stage (shn_sparse_flow) over the graphs of several partitions: [reconstructed FASTA text]
+    (raw: as uint8 arrays, undecoded)."""
     if not graphs:
         return []
     arr = (C.c_void_p * len(graphs))(*[g.h for g in graphs])
@@ -159,7 +160,7 @@ def sparse_flow_native(ctx, graphs, snames, seed):
             buf = np.empty(max(n, 1), np.uint8)
             if n:
                 _lib.check(_lib.lib().shn_sflow_text(h, i, buf.ctypes.data))
-            out.append(buf[:n].tobytes().decode())
+            out.append(buf[:n] if raw else buf[:n].tobytes().decode())
         return out
     finally:
         _lib.lib().shn_sflow_destroy(h)

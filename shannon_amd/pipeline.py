@@ -10,7 +10,22 @@ from . import _lib, device, extension_correction as ec, kmers_for_component as k
 
 
 class Result(object):
-    pass
+    """.partitions {name: record}, .final {name: sequence}, .all_reconstructed (the lines of all_reconstructed.fasta; joined from
+    the partitions' texts on first use), .extension, .timings ..."""
+    _texts = None
+
+    @property
+    def all_reconstructed(self):
+        if self.__dict__.get("_lines") is None and self._texts is not None:
+            lines = []
+            for t in self._texts:
+                lines += (t if isinstance(t, str) else bytes(t).decode()).splitlines(True)
+            self.__dict__["_lines"] = lines
+        return self.__dict__.get("_lines")
+
+    @all_reconstructed.setter
+    def all_reconstructed(self, lines):
+        self.__dict__["_lines"] = lines
 
 
 class PartitionRecord(dict):
@@ -22,6 +37,9 @@ class PartitionRecord(dict):
         self.graph = graph
 
     def __missing__(self, key):
+        if key == "reconstructed_fasta" and getattr(self, "fasta_raw", None) is not None:
+            dict.__setitem__(self, key, bytes(self.fasta_raw).decode())
+            return dict.__getitem__(self, key)
         if key in ("singles", "components", "log") and self.graph is not None:
             singles, comps, log = self.graph.tables()
             dict.update(self, singles=singles, components=comps, log=log)
@@ -233,14 +251,22 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
     if native_graph and os.environ.get("SHN_SFLOW_NATIVE", "1") != "0":
         # all components of all partitions through the native sparse-flow stage (shn_sparse_flow) in one call; the graphs
         # stay native objects (exported to Python tables only if somebody asks a PartitionRecord for them)
-        texts = mbgraph_native.sparse_flow_native(ctx, [R.partitions[nm].graph for nm in names], ["%s_%s" % (sample, nm) for nm in names], seed)
+        texts = mbgraph_native.sparse_flow_native(ctx, [R.partitions[nm].graph for nm in names], ["%s_%s" % (sample, nm) for nm in names], seed,
+                                                  raw=True)
         for name, txt in zip(names, texts):
-            R.partitions[name]["reconstructed_fasta"] = txt
-            lines += txt.splitlines(True)
+            R.partitions[name].fasta_raw = txt                     # decoded when somebody reads ["reconstructed_fasta"]
         tick("sparse flow", t0)
         t0 = time.time()
-        R.all_reconstructed = lines
-        R.final = post.finalize(lines, double_stranded)
+        R._texts = ["".join(lines)] + texts                        # all_reconstructed.fasta: single contigs, then the partitions
+        if os.environ.get("SHN_POST_NATIVE", "1") != "0":
+            try:
+                R.final = post.finalize_texts(R._texts, double_stranded)
+            except _lib.ShannonError as ex:
+                if "non-ACGT" not in str(ex) and "empty line" not in str(ex):
+                    raise
+                R.final = post.finalize(R.all_reconstructed, double_stranded)
+        else:
+            R.final = post.finalize(R.all_reconstructed, double_stranded)
         tick("post", t0)
         R.timings = T
         return R

@@ -115,8 +115,53 @@ def find_reps(lines, ds, r=24):
     return {n: s for n, s in contigs.items() if not (contained(n, False) or (ds and contained(n, True)))}
 
 
+def finalize_native(all_lines, ds=True, r=24):
+    """process_concatenated + length_sort + find_reps in one native call (shn_post_finalize) over the joined text; all_lines:
+    a list of lines, or one str / bytes"""
+    blob = ("".join(all_lines) if not isinstance(all_lines, (bytes, str)) else all_lines)
+    return finalize_texts([blob], ds, r)
+
+
+def finalize_texts(texts, ds=True, r=24):
+    """the same over the concatenation of several texts (str, bytes or uint8 arrays: the per-partition FASTA as it leaves the
+    native sparse-flow stage), without joining them (shn_post_finalize_bufs)"""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    bufs = []
+    for t in texts:
+        if isinstance(t, str):
+            t = t.encode()
+        bufs.append(np.frombuffer(t, dtype=np.uint8) if isinstance(t, (bytes, bytearray, memoryview)) else np.ascontiguousarray(t, dtype=np.uint8))
+    ptrs = (C.c_void_p * max(len(bufs), 1))(*[b.ctypes.data if len(b) else None for b in bufs])
+    lens = (C.c_uint64 * max(len(bufs), 1))(*[len(b) for b in bufs])
+    L = _lib.lib()
+    h = C.c_void_p()
+    _lib.check(L.shn_post_finalize_bufs(ptrs, lens, len(bufs), 1 if ds else 0, r, C.byref(h)))
+    try:
+        n = int(L.shn_post_count(h))
+        nb, sb = C.c_uint64(), C.c_uint64()
+        _lib.check(L.shn_post_sizes(h, C.byref(nb), C.byref(sb)))
+        names, seqs = np.empty(max(nb.value, 1), np.uint8), np.empty(max(sb.value, 1), np.uint8)
+        no, so = np.empty(n + 1, np.uint64), np.empty(n + 1, np.uint64)
+        _lib.check(L.shn_post_export(h, names.ctypes.data, no.ctypes.data, seqs.ctypes.data, so.ctypes.data))
+    finally:
+        L.shn_post_destroy(h)
+    nt, st = names.tobytes().decode(), seqs.tobytes().decode()
+    no, so = no.tolist(), so.tolist()
+    return {nt[no[i]:no[i + 1]]: st[so[i]:so[i + 1]] for i in range(n)}
+
+
 def finalize(all_lines, ds=True):
     """shannon.py:596-604."""
+    import os
+    from . import _lib
+    if os.environ.get("SHN_POST_NATIVE", "1") != "0":
+        try:
+            return finalize_native(all_lines, ds)
+        except _lib.ShannonError as e:
+            if "non-ACGT" not in str(e) and "empty line" not in str(e):
+                raise
     srt = length_sort(process_concatenated(all_lines, ds))
     try:
         return find_reps_native(srt, ds)

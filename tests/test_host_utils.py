@@ -34,3 +34,46 @@ def test_string_windows_match_the_vectorised_path():
         assert np.array_equal(k2, exp) and np.array_equal(nw2, nwin)
     with pytest.raises(_lib.ShannonError):
         _lib.string_windows(["ACGTNACGT"], 3)
+
+
+def _random_fasta(seed, n=400):
+    """records with everything process_concatenated / find_reps care about: repeated names, short sequences, repeated and
+    reverse-complemented sequences, containments (a prefix / suffix / middle of a longer record), repeated header lines"""
+    rng = np.random.default_rng(seed)
+    rc = lambda s: s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+    seqs = ["".join("ACGT"[i] for i in rng.integers(0, 4, size=int(L))) for L in rng.integers(150, 900, size=n // 2)]
+    lines = []
+    for i in range(n):
+        kind = rng.integers(0, 8)
+        base = seqs[int(rng.integers(0, len(seqs)))]
+        if kind == 0:
+            s = base
+        elif kind == 1:
+            s = rc(base)
+        elif kind == 2 and len(base) > 450:
+            a = int(rng.integers(0, 100)); s = base[a:a + 300 + int(rng.integers(0, 50))]
+        elif kind == 3 and len(base) > 450:
+            s = rc(base[:250 + int(rng.integers(0, 100))])
+        elif kind == 4 and len(base) > 450:
+            s = base[-(220 + int(rng.integers(0, 100))):]
+        else:
+            s = "".join("ACGT"[j] for j in rng.integers(0, 4, size=int(rng.integers(150, 700))))
+        name = ">s_c%d_%d" % (rng.integers(0, 40), rng.integers(0, 6))
+        lines += ["%s\t%.6f\tpath=[%d]\n" % (name, rng.random() * 50, i) if rng.random() < 0.8 else name + "\n", s + "\n"]
+    lines += [lines[0], lines[3]]                    # a header line seen twice, with another sequence
+    return lines
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("ds", [True, False])
+def test_native_merge_equals_the_python_form(seed, ds):
+    """shn_post_finalize against process_concatenated + length_sort + find_reps (the readable Python forms of
+    process_concatenated_fasta.py:6-32, shannon.py:603, faster_reps.py:60-131)"""
+    from shannon_amd import post
+    lines = _random_fasta(seed)
+    want = post.find_reps(post.length_sort(post.process_concatenated(lines, ds)), ds)
+    got = post.finalize_native(lines, ds)
+    assert got == want and list(got) == [k for k in got]
+    assert 0 < len(got) < len(lines) // 2
+    assert post.finalize(lines, ds) == want
+    assert post.finalize_native([], ds) == {} and post.finalize_native([">a\n", "ACGT\n"], ds) == {}
