@@ -397,7 +397,7 @@ __global__ void lookup_kernel(const uint64_t* __restrict__ tkeys, const uint32_t
 #define DSLOTS 12288         // LDS slots per block (key 8 B + count 4 B = 144 KB of the 160 KB; 8192: +9 % time, 4096: +60 % in the probe)
 __device__ __forceinline__ bool gtable_add(unsigned long long* __restrict__ gkeys, uint32_t* __restrict__ gcounts, uint64_t mask,
                                            uint64_t key, uint32_t c) {
-  const unsigned long long kk = (unsigned long long)key + 1ULL;      // stored key + 1: 0 = empty slot (a key is < 2^64 - 1: k <= 32 ... all-T at k = 32 wraps, see host)
+  const unsigned long long kk = (unsigned long long)key + 1ULL;      // stored key + 1: 0 = empty slot (all-T at k = 32 would wrap: canonical counting never stores it, see host)
   uint64_t s = shn_mix64(key) & mask;
   for (int probe = 0; probe < 256; probe++) {
     unsigned long long cur = __hip_atomic_load(&gkeys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -618,7 +618,9 @@ static int count_views(shn_ctx* ctx, const std::vector<ReadsView>& views, uint64
     int& learned_log2 = ctx->count_direct_log2;            // slots that sufficed last time on this context (0: none yet; -1: the
                                                            // one-pass path gave up on this context's input -- do not try again)
     const int mode = getenv("SHN_COUNT_DIRECT") ? atoi(getenv("SHN_COUNT_DIRECT")) : 1;      // 0 off, 1 large inputs, 2 always (tests)
-    const bool want = mode != 0 && (upper >= (1ULL << 22) || mode == 2) && k1 < 32 && upper > 0 && (learned_log2 >= 0 || mode == 2);
+    // (stored key + 1: k1 = 32 is fine for canonical counting -- the one key that would wrap, all-T, is never the canonical form of
+    // a pair, its reverse complement all-A is)
+    const bool want = mode != 0 && (upper >= (1ULL << 22) || mode == 2) && (k1 < 32 || both_strands) && upper > 0 && (learned_log2 >= 0 || mode == 2);
     int lg = learned_log2 > 0 ? learned_log2 : 0;
     if (!lg) { lg = 20; while (lg < 24 && (1ULL << lg) < upper / 32) lg++; }
     if (getenv("SHN_COUNT_DIRECT_LOG2")) lg = atoi(getenv("SHN_COUNT_DIRECT_LOG2"));          // (tests: start too small, grow)

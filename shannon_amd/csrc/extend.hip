@@ -1144,10 +1144,13 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   // Rank phases: a walk depends only on lower ranks, so the fixpoint is reached block by block -- first the
   // heaviest seeds (where the long, mutually dependent walks live), then geometrically larger blocks that see
   // final lower ranks and settle in a few rounds.
-  unsigned long long lim0 = std::max<unsigned long long>(ns / 32, 4096), grow = 4;
+  // (many seeds -- BASELINE configs[2]: 186 M over 20,000 genes -- interfere locally: fewer, larger blocks; every round costs two
+  // passes over all claims whatever it re-runs.  tools/ext_blocks_probe.py: 51 rounds / 2.27 s -> 32 rounds / 2.15 s)
+  const bool many = ns >= (1ULL << 24);
+  unsigned long long lim0 = std::max<unsigned long long>(ns / (many ? 8 : 32), 4096), grow = 4;
   if (getenv("SHN_EXT_LIMIT0")) lim0 = strtoull(getenv("SHN_EXT_LIMIT0"), nullptr, 10);
   if (getenv("SHN_EXT_GROW")) grow = strtoull(getenv("SHN_EXT_GROW"), nullptr, 10);
-  const unsigned long long tail_div = getenv("SHN_EXT_TAIL") ? strtoull(getenv("SHN_EXT_TAIL"), nullptr, 10) : 8;   // last block = ns / 8 walks (0: off)
+  const unsigned long long tail_div = getenv("SHN_EXT_TAIL") ? strtoull(getenv("SHN_EXT_TAIL"), nullptr, 10) : (many ? 0 : 8);   // last blocks = ns / 8 walks (0: off)
   uint32_t frozen = 0, limit = (uint32_t)std::min<unsigned long long>(ns, lim0);
   TRYE(hipMemsetAsync(dirty, 0, 2 * (ns + 1), s));               // dirty + ran
   TRYE(hipMemsetAsync(dirty, 1, limit, s));

@@ -101,6 +101,10 @@ struct ThreadCtx {
   shn_ctx* c = nullptr; const shn_ctx* parent = nullptr;
   shn_ctx* get(shn_ctx* p) {
     if (!p) return nullptr;
+    // SHN_GRAPH_FORK=0 (with SHN_GRAPH_THREADS=1): everything on the caller's context and stream -- rocprofv3's kernel trace
+    // aborts (stream_stack.cpp) when threads it has not seen create streams; tools/profile_r02.sh profiles that way
+    static const bool no_fork = getenv("SHN_GRAPH_FORK") && getenv("SHN_GRAPH_FORK")[0] == '0';
+    if (no_fork) return p;
     if (c && parent == p) return c;
     if (c) { shn_ctx_destroy(c); c = nullptr; }
     if (shn_ctx_fork(p, &c)) { c = nullptr; return p; }

@@ -223,7 +223,7 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
                 "log": glog}, tt
 
     t_graph = time.time()
-    if native_graph and len(names) > 1:
+    if native_graph and len(names) > 1 and graph_threads > 1:
         # partitions are independent (one multibridging process each in the reference, run_MB_SF_fn.py:219-253): the
         # native stage releases the GIL, its GPU sections take turns
         from concurrent.futures import ThreadPoolExecutor

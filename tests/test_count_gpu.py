@@ -99,8 +99,9 @@ def test_pairs_and_shard_roundtrip(ctx):
     assert t2.total == 2 * t.total
 
 
-@pytest.mark.parametrize("both,with_n,log2", [(True, False, None), (False, True, None), (True, True, 8), (True, False, 12)])
-def test_one_pass_counting_equals_the_partition_pipeline(both, with_n, log2, monkeypatch):
+@pytest.mark.parametrize("both,with_n,log2,K1", [(True, False, None, 26), (False, True, None, 26), (True, True, 8, 26), (True, False, 12, 26),
+                                                 (True, True, None, 32), (True, False, 10, 32)])
+def test_one_pass_counting_equals_the_partition_pipeline(both, with_n, log2, K1, monkeypatch):
     """Large inputs are counted in one pass into a global hash table (LDS pre-aggregation + device-scope atomics) whose
     pairs then take the pairs path; forced here on a small input, also with a table that starts far too small and has to
     grow: the same table as the partition pipeline."""
@@ -111,18 +112,20 @@ def test_one_pass_counting_equals_the_partition_pipeline(both, with_n, log2, mon
     reads = base[starts[:, None] + np.arange(100)]
     err = rng.random(reads.shape) < 0.01
     reads = np.where(err, (reads + rng.integers(1, 4, reads.shape)) & 3, reads).astype(np.uint8)
+    reads[:50] = 3                                        # poly-T reads: at k1 = 32 the all-ones key, stored as its reverse complement
+    reads[50:80] = 0
     if with_n:
         reads[rng.random(reads.shape) < 0.002] = 4
     ctx = device.Context(0)
     try:
         d = device.Reads.from_codes(ctx, reads)
         monkeypatch.setenv("SHN_COUNT_DIRECT", "0")
-        t0 = device.count_k1mers(ctx, [d], 26, both)
+        t0 = device.count_k1mers(ctx, [d], K1, both)
         k0, c0 = t0.download()
         monkeypatch.setenv("SHN_COUNT_DIRECT", "2")
         if log2 is not None:
             monkeypatch.setenv("SHN_COUNT_DIRECT_LOG2", str(log2))
-        t1 = device.count_k1mers(ctx, [d], 26, both)
+        t1 = device.count_k1mers(ctx, [d], K1, both)
         k1, c1 = t1.download()
         o0, o1 = np.argsort(k0), np.argsort(k1)
         assert np.array_equal(k0[o0], k1[o1]) and np.array_equal(c0[o0], c1[o1])
