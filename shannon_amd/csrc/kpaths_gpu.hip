@@ -1,0 +1,150 @@
+// known_paths, the part every read goes through (mbgraph.py:1355-1388, known_paths -> search_sequence at :114-160): a read whose
+// first K-mer occurs in node n at offset o and whose text equals the node's from there lies inside that node if it ends before
+// the node does -- its only path is [n], it adds no known edge and no known path; otherwise it runs on into the node's
+// successors and has to be searched.  Nearly every read is of the first kind (96 % at BASELINE configs[2]).  The host stage
+// used to index every K-mer of every node (a 600 k-item sort per partition: 7 of the graph stage's 31 thread-seconds per
+// step), look up every read's first and last K-mer on the device and compare every read with its node on host threads
+// (4 thread-seconds).  Here the whole test runs where the reads already are:
+//   kp_items      one item per base position of the concatenated node texts: packed K-mer at that position (or "none")
+//   shn_sort_pairs  stable by key: the occurrences of a K-mer in insertion order (node order, then offset)
+//   kp_classify   per read: first / last K-mer by binary search; the occurrences of the first K-mer in order, text compared
+//                 base by base against the node -> 0 (nothing to do), 1 + node (inside that node), 2 (search on the host)
+// The host keeps the sequential part: reads of kind 2, in read order, against an index of just their first K-mers.
+#include "common.h"
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+int shn_sort_pairs(shn_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t* keys_tmp, uint32_t* vals_tmp, uint64_t n, int bit_lo, int bit_hi);
+
+namespace {
+
+__device__ __forceinline__ int kp_code(uint8_t c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
+__device__ __forceinline__ uint32_t kp_node_of(const uint64_t* __restrict__ off, uint32_t n_nodes, uint64_t p) {   // largest i with off[i] <= p
+  uint32_t lo = 0, hi = n_nodes;
+  while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (off[mid] <= p) lo = mid; else hi = mid; }
+  return lo;
+}
+
+__global__ void kp_items(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ off, uint32_t n_nodes, uint64_t total, int K,
+                         uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, unsigned long long* __restrict__ counters) {
+  const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= total) return;
+  const uint32_t nd = kp_node_of(off, n_nodes, p);
+  uint64_t key = 1ULL << (2 * K);                                  // "no K-mer starts here": sorts behind every K-mer
+  if (p + (uint64_t)K <= off[nd + 1]) {
+    uint64_t k = 0;
+    bool ok = true;
+    for (int j = 0; j < K; j++) { const int c = kp_code(bases[p + j]); if (c < 0) { ok = false; break; } k = (k << 2) | (uint64_t)c; }
+    if (ok) { key = k; atomicAdd(&counters[0], 1ULL); } else atomicAdd(&counters[1], 1ULL);
+  }
+  keys[p] = key;
+  vals[p] = (uint32_t)p;
+}
+
+struct RView { const uint64_t* words; const uint64_t* woff; const uint32_t* len; uint64_t n; uint32_t fixed_len, wpr; };
+
+__device__ __forceinline__ uint64_t kp_lower_bound(const uint64_t* __restrict__ a, uint64_t n, uint64_t key) {
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+__global__ void kp_classify(RView v, int K, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint64_t n_items,
+                            const uint8_t* __restrict__ bases, const uint64_t* __restrict__ off, uint32_t n_nodes, uint8_t* __restrict__ state,
+                            int32_t* __restrict__ node_out) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= v.n) return;
+  const uint32_t L = v.len ? v.len[r] : v.fixed_len;
+  uint8_t st = 0;
+  int32_t fn = -1;
+  if (L >= (uint32_t)K) {
+    const uint64_t* w = v.words + (v.woff ? v.woff[r] : r * v.wpr);
+    const uint64_t kf = shn_extract(w, 0, K), kl = shn_extract(w, L - K, K);
+    const uint64_t lo = kp_lower_bound(keys, n_items, kf);
+    const uint64_t ll = kp_lower_bound(keys, n_items, kl);
+    if (lo < n_items && keys[lo] == kf && ll < n_items && keys[ll] == kl) {
+      bool any = false, need = false;
+      for (uint64_t j = lo; j < n_items && keys[j] == kf && !need; j++) {
+        const uint64_t p = vals[j];
+        const uint32_t nd = kp_node_of(off, n_nodes, p);
+        const uint64_t left = off[nd + 1] - p;                       // bases of the node from the occurrence on
+        const uint32_t n = (uint32_t)min((uint64_t)L, left);
+        bool same = true;
+        for (uint32_t i = K; i < n && same; i++) {                   // (the first K bases are the K-mer itself)
+          const uint32_t rb = (uint32_t)((w[i >> 5] >> (62 - 2 * (i & 31))) & 3ULL);
+          same = kp_code(bases[p + i]) == (int)rb;
+        }
+        if (!same) continue;
+        if ((uint64_t)L <= left) { fn = (int32_t)nd; any = true; }
+        else need = true;
+      }
+      st = need ? 2 : any ? 1 : 0;
+    }
+  }
+  state[r] = st;
+  node_out[r] = fn;
+}
+
+std::mutex g_sort_mu;            // shn_sort_pairs keeps its histogram in a process-wide workspace
+
+}  // namespace
+
+// reads: the distinct reads of the partition (ACGT only); node_bases / node_off: the texts of the partition's nodes one after
+// the other, in the order the host's seed index would list them; state_out[r] / node_out[r] as described above (node = index
+// into that order).  SHN_ERR_ARG if a node holds a base outside ACGT or K > 31.
+extern "C" int shn_known_paths_scan(shn_ctx* ctx, const shn_reads* reads, int K, const uint8_t* node_bases, const uint64_t* node_off,
+                                    uint64_t n_nodes, uint8_t* state_out, int32_t* node_out) {
+  if (!ctx || !reads || !node_off || (n_nodes && !node_bases) || (reads->n_reads && (!state_out || !node_out)))
+    return shn_fail(SHN_ERR_ARG, "shn_known_paths_scan: NULL argument");
+  if (K < 1 || K > 31) return shn_fail(SHN_ERR_ARG, "shn_known_paths_scan: K must be in [1,31]");
+  if (reads->n_invalid) return shn_fail(SHN_ERR_ARG, "shn_known_paths_scan: reads contain non-ACGT bases");
+  const uint64_t nr = reads->n_reads, total = n_nodes ? node_off[n_nodes] : 0;
+  if (!nr) return SHN_OK;
+  if (!total || n_nodes >= 0x7FFFFFFFULL || total >= 0xFFFFFFFFULL) {
+    if (total) return shn_fail(SHN_ERR_ARG, "shn_known_paths_scan: too many nodes / bases");
+    std::fill(state_out, state_out + nr, (uint8_t)0);
+    for (uint64_t i = 0; i < nr; i++) node_out[i] = -1;
+    return SHN_OK;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  TimerRegion treg(ctx, T_SEEDS);
+  ShnDevBufs bufs;
+  uint8_t *d_bases = nullptr, *d_state = nullptr;
+  uint64_t *d_off = nullptr, *d_keys = nullptr, *d_ktmp = nullptr;
+  uint32_t *d_vals = nullptr, *d_vtmp = nullptr;
+  int32_t* d_node = nullptr;
+  unsigned long long* d_cnt = nullptr;
+#define TRYK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return shn_fail(SHN_ERR_HIP, std::string("shn_known_paths_scan: ") + hipGetErrorString(e_)); } while (0)
+  TRYK(bufs.get(&d_bases, total + 8));
+  TRYK(bufs.get(&d_off, (n_nodes + 1) * 8));
+  TRYK(bufs.get(&d_keys, (total + 1) * 8)); TRYK(bufs.get(&d_ktmp, (total + 1) * 8));
+  TRYK(bufs.get(&d_vals, (total + 1) * 4)); TRYK(bufs.get(&d_vtmp, (total + 1) * 4));
+  TRYK(bufs.get(&d_state, nr + 1)); TRYK(bufs.get(&d_node, (nr + 1) * 4));
+  TRYK(bufs.get(&d_cnt, 16));
+  TRYK(hipMemcpyAsync(d_bases, node_bases, total, hipMemcpyHostToDevice, s));
+  TRYK(hipMemcpyAsync(d_off, node_off, (n_nodes + 1) * 8, hipMemcpyHostToDevice, s));
+  TRYK(hipMemsetAsync(d_cnt, 0, 16, s));
+  hipLaunchKernelGGL(kp_items, dim3((uint32_t)cdiv(total, 256)), dim3(256), 0, s, d_bases, d_off, (uint32_t)n_nodes, total, K, d_keys, d_vals, d_cnt);
+  unsigned long long cnt[2] = {0, 0};
+  {
+    std::lock_guard<std::mutex> lk(g_sort_mu);
+    int rc = shn_sort_pairs(ctx, d_keys, d_vals, d_ktmp, d_vtmp, total, 0, 2 * K + 1);
+    if (rc) return rc;
+    TRYK(hipMemcpyAsync(cnt, d_cnt, 16, hipMemcpyDeviceToHost, s));
+    TRYK(hipStreamSynchronize(s));
+  }
+  if (cnt[1]) return shn_fail(SHN_ERR_ARG, "shn_known_paths_scan: a node holds a base outside ACGT");
+  RView v{reads->d_words, reads->d_woff, reads->d_len, nr, reads->fixed_len, reads->wpr};
+  hipLaunchKernelGGL(kp_classify, dim3((uint32_t)cdiv(nr, 256)), dim3(256), 0, s, v, K, d_keys, d_vals, (uint64_t)cnt[0], d_bases, d_off, (uint32_t)n_nodes,
+                     d_state, d_node);
+  TRYK(hipGetLastError());
+  TRYK(hipMemcpyAsync(state_out, d_state, nr, hipMemcpyDeviceToHost, s));
+  TRYK(hipMemcpyAsync(node_out, d_node, nr * 4, hipMemcpyDeviceToHost, s));
+  TRYK(hipStreamSynchronize(s));
+#undef TRYK
+  return SHN_OK;
+}

@@ -26,6 +26,9 @@
 #include <cstdio>
 #include <cstdlib>
 
+extern "C" int shn_known_paths_scan(shn_ctx* ctx, const shn_reads* reads, int K, const uint8_t* node_bases, const uint64_t* node_off,
+                                    uint64_t n_nodes, uint8_t* state_out, int32_t* node_out);
+
 namespace {
 
 typedef std::pair<int, int> RI;   // (read id, index)
@@ -397,14 +400,16 @@ struct Graph {
     return acgt_known == 1;
   }
   // device copy of the distinct reads + pattern table; returns false if the GPU path is not usable
+  // the distinct reads on the device: rows of the resident input (device gather; 5 bytes per read cross the bus), else their text
+  bool ensure_dreads(shn_reads** dreads) {
+    if (!ctx || n_rd() == 0 || !reads_all_acgt()) return false;
+    if (*dreads) return true;
+    if (src_a && origin_row.size() == n_rd()) return shn_reads_gather(ctx, src_a, src_b, origin_row.data(), origin_flag.data(), n_rd(), dreads) == 0;
+    return shn_reads_create(ctx, (const uint8_t*)rindex.arena.data(), rindex.off.data(), n_rd(), 0, SHN_ENC_ASCII, dreads) == 0;
+  }
   bool gpu_patterns(const SeedIndex& si, shn_reads** dreads, shn_table** tab) {
     if (!ctx || K > 32 || n_rd() == 0 || si.keys.empty() || !reads_all_acgt()) return false;
-    if (!*dreads) {
-      // the distinct reads as rows of the resident input (device gather; 5 bytes per read cross the bus), else their text
-      if (src_a && origin_row.size() == n_rd()) {
-        if (shn_reads_gather(ctx, src_a, src_b, origin_row.data(), origin_flag.data(), n_rd(), dreads)) return false;
-      } else if (shn_reads_create(ctx, (const uint8_t*)rindex.arena.data(), rindex.off.data(), n_rd(), 0, SHN_ENC_ASCII, dreads)) return false;
-    }
+    if (!ensure_dreads(dreads)) return false;
     std::vector<uint32_t> vals(si.keys.size());
     for (size_t i = 0; i < vals.size(); i++) vals[i] = (uint32_t)i + 1;
     return shn_table_create(ctx, si.keys.data(), vals.data(), si.keys.size(), K, 0, tab) == 0;
@@ -640,8 +645,80 @@ struct Graph {
   }
   void find_known_paths() {
     known_paths.clear();
-    std::vector<std::pair<uint64_t, std::pair<int, int>>> items;
+    const bool dbgk = getenv("SHN_DEBUG") != nullptr;
+    auto nowk = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tk0 = nowk(), tk1 = 0, tk2 = 0, tk3 = 0;
     const uint64_t mask = K == 32 ? ~0ULL : ((1ULL << (2 * K)) - 1);
+    // ---- device path (kpaths_gpu.hip): every read is classified where the reads are; the host searches only the reads that run
+    // past the end of the node they start in, against an index of just their first K-mers
+    { const char* kv = getenv("SHN_GRAPH_KP_GPU");
+      if (ctx && K <= 31 && !(kv && kv[0] == '0') && n_rd() && ensure_dreads(&d_reads)) {
+        std::string nb;
+        std::vector<uint64_t> noff(1, 0);
+        { size_t tot = 0; for (int n : order) tot += bases[n].size(); nb.reserve(tot); noff.reserve(order.size() + 1); }
+        for (int n : order) { nb += bases[n]; noff.push_back(nb.size()); }
+        std::vector<uint8_t> st(n_rd());
+        std::vector<int32_t> nd(n_rd());
+        tk1 = nowk();
+        const int rcs = shn_known_paths_scan(ctx, d_reads, K, (const uint8_t*)nb.data(), noff.data(), order.size(), st.data(), nd.data());
+        release_gpu();
+        tk2 = nowk();
+        if (rcs == 0) {
+          // occurrences (node, offset), in index order, of the first K-mers of the reads left to search
+          std::unordered_map<uint64_t, std::vector<std::pair<int, int>>> occ_of;
+          std::vector<uint64_t> bits(1u << 12, 0);                        // 2^18-bit filter in front of the map
+          size_t n_slow = 0;
+          for (size_t r = 0; r < n_rd(); r++) {
+            if (st[r] == 1) { const int n = order[nd[r]]; rfirst[r] = n; rlast[r] = n; rhas[r] = 1; }
+            else if (st[r] == 2) {
+              uint64_t key;
+              n_slow++;
+              if (key_at(rstr((int)r), 0, key)) { occ_of[key]; const uint64_t h = fm_mix(key) >> 46; bits[h >> 6] |= 1ULL << (h & 63); }
+            }
+          }
+          if (n_slow)
+            for (int n : order) {
+              const std::string& b = bases[n];
+              uint64_t key = 0;
+              for (int i = 0; i < (int)b.size(); i++) {
+                key = ((key << 2) | (uint64_t)base_code(b[i])) & mask;
+                if (i + 1 < K) continue;
+                const uint64_t h = fm_mix(key) >> 46;
+                if (!((bits[h >> 6] >> (h & 63)) & 1)) continue;
+                auto it = occ_of.find(key);
+                if (it != occ_of.end()) it->second.push_back({n, i - K + 1});
+              }
+            }
+          tk3 = nowk();
+          int cntp = 0;
+          std::vector<std::vector<int>> paths;
+          std::vector<int> cur;
+          for (size_t r = 0; r < n_rd(); r++) {
+            if (st[r] != 2) continue;
+            const RStr rb = rstr((int)r);
+            uint64_t key;
+            if (!key_at(rb, 0, key)) continue;
+            for (const auto& oc : occ_of[key]) {
+              const int sn = oc.first, so = oc.second;
+              if (!compare(rb, 0, bases[sn], so)) continue;
+              if (rb.size() <= bases[sn].size() - (size_t)so) { rfirst[r] = sn; rlast[r] = sn; rhas[r] = 1; continue; }
+              paths.clear(); cur.clear();
+              search_sequence(rb, 0, sn, so, 30, cur, paths);
+              for (auto& p : paths) {
+                rfirst[r] = p.front(); rlast[r] = p.back(); rhas[r] = 1;
+                for (size_t j = 0; j + 1 < p.size(); j++) known_edges[{p[j], p[j + 1]}] += rcc[r];
+                if (p.size() > 2) { known_paths.insert(p); cntp++; }
+              }
+            }
+          }
+          n_known = cntp;
+          if (dbgk) fprintf(stderr, "[mbgraph]   kp (device) node text %.3f s scan %.3f s slow index %.3f s search %.3f s  (%zu bases, %zu reads, %zu slow)\n", tk1 - tk0,
+                            tk2 - tk1, tk3 - tk2, nowk() - tk3, nb.size(), n_rd(), n_slow);
+          return;
+        }
+      } }
+    tk0 = nowk();
+    std::vector<std::pair<uint64_t, std::pair<int, int>>> items;
     for (int n : order) {
       const std::string& b = bases[n];
       uint64_t key = 0;
@@ -658,6 +735,7 @@ struct Graph {
     std::vector<uint32_t> first(n_rd(), 0), last(n_rd(), 0);     // group id + 1, 0 = absent
     shn_table* tab = nullptr;
     bool done = false;
+    tk1 = nowk();
     {
       if (gpu_patterns(si, &d_reads, &tab)) {
         done = shn_seed_ends(ctx, d_reads, K, tab, first.data(), last.data()) == 0;
@@ -673,6 +751,7 @@ struct Graph {
         if (key_at(rb, rb.size() - K, key)) last[r] = (uint32_t)(si.find(key) + 1);
       }
     release_gpu();
+    tk2 = nowk();
     int cntp = 0;
     std::vector<std::vector<int>> paths;
     std::vector<int> cur;
@@ -707,8 +786,11 @@ struct Graph {
         for (auto& x : th) x.join();
       }
     }
+    tk3 = nowk();
+    size_t n_slow = 0;
     for (int r = 0; r < (int)n_rd(); r++) {
       if (!slow[r]) continue;
+      n_slow++;
       const RStr rb = rstr(r);
       uint32_t gi = first[r] - 1;
       for (uint32_t q = si.goff[gi]; q < si.goff[gi + 1]; q++) {
@@ -729,6 +811,8 @@ struct Graph {
       }
     }
     n_known = cntp;
+    if (dbgk) fprintf(stderr, "[mbgraph]   kp index %.3f s gpu %.3f s classify %.3f s slow %.3f s  (%zu patterns, %zu reads, %zu slow)\n", tk1 - tk0, tk2 - tk1, tk3 - tk2,
+                      nowk() - tk3, items.size(), n_rd(), n_slow);
   }
   void find_copy_counts() {
     for (int n : order) {
@@ -850,6 +934,7 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
                            const uint32_t* didx = nullptr, const uint8_t* host_a = nullptr, const uint8_t* host_b = nullptr);
 extern "C" int shn_reads_dedup(shn_ctx* ctx, const shn_reads* a, const shn_reads* b, const uint32_t* didx, uint64_t n, int paired,
                                uint64_t* n_distinct, uint32_t* slot_out, uint32_t* count_out, int32_t* mate_out, uint8_t* role_out);
+
 
 extern "C" int shn_mbgraph_run(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n_rows, const uint8_t* r1, const uint64_t* r1_off,
                                const uint8_t* r2, const uint64_t* r2_off, uint64_t n_reads, int paired, int enc, const uint8_t* rc1,
