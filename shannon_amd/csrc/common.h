@@ -146,6 +146,52 @@ __device__ __forceinline__ int64_t shn_table_find(const uint64_t* __restrict__ t
   return -1;
 }
 
+// The same for callers that know the key width (2k bits).  The keys of a bucket are a uniform sample of the key range (the bucket
+// is picked by a hash of the key, the order inside is by key), so the key's top bits give its rank within +-sqrt(n): the search
+// starts there and gallops outwards.  A bucket of ~90 keys spans 11 64-byte sectors; bisection touches 4-5 of them, this 1-2.
+// Measured at BASELINE configs[2]: route_kernel (mostly hits) 126 -> 102 ms; ext_adjacency_kernel (mostly misses, 16 look-ups per
+// k1-mer side by side in a wavefront) 540 -> 610 ms -- it keeps the bisection.
+__device__ __forceinline__ int64_t shn_table_find_k(const uint64_t* __restrict__ tkeys, const uint64_t* __restrict__ boff,
+                                                    int bits, uint64_t key, int kbits) {
+  const uint32_t b = shn_bucket_of(key, bits);
+  uint64_t lo = boff[b], hi = boff[b + 1];
+  if (lo >= hi) return -1;
+  const uint64_t n = hi - lo;
+  const uint64_t f = kbits >= 16 ? (key >> (kbits - 16)) & 0xFFFFULL : (key << (16 - kbits)) & 0xFFFFULL;
+  uint64_t g = lo + ((f * n) >> 16);
+  if (g >= hi) g = hi - 1;
+  uint64_t v = tkeys[g];
+  if (v == key) return (int64_t)g;
+  if (v < key) {
+    lo = g + 1;
+    for (uint64_t step = 1; lo < hi; step <<= 1) {
+      const uint64_t r = g + step;
+      if (r >= hi) break;
+      v = tkeys[r];
+      if (v == key) return (int64_t)r;
+      if (v > key) { hi = r; break; }
+      lo = r + 1;
+    }
+  } else {
+    hi = g;
+    for (uint64_t step = 1; lo < hi; step <<= 1) {
+      if (g < lo + step) break;
+      const uint64_t l = g - step;
+      v = tkeys[l];
+      if (v == key) return (int64_t)l;
+      if (v < key) { lo = l + 1; break; }
+      hi = l;
+    }
+  }
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    v = tkeys[mid];
+    if (v == key) return (int64_t)mid;
+    if (v < key) lo = mid + 1; else hi = mid;
+  }
+  return -1;
+}
+
 // grow-only device workspace slots shared by the translation units (one process per GPU)
 // Caching device allocator for the per-call objects (tables, extension state, routes): a freed block is kept and
 // handed out again to the next request it fits (hipMalloc/hipFree of hundreds of MB cost milliseconds per step).

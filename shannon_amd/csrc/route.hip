@@ -45,7 +45,7 @@ __device__ __forceinline__ int collect(const RView& v, uint64_t r, bool rc, int 
     else if (!last_done) { pos = len - k; last_done = true; }
     else break;
     uint64_t key = probe_key(v, r, len, pos, k, rc);
-    int64_t j = shn_table_find(tkeys, boff, bits, key);
+    int64_t j = shn_table_find_k(tkeys, boff, bits, key, 2 * k);
     if (j >= 0) {
       uint32_t sid = tvals[j] - 1;
       for (uint32_t m = set_off[sid]; m < set_off[sid + 1]; m++) {
