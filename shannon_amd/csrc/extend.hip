@@ -750,20 +750,21 @@ __global__ void ext_memo_plan_kernel(uint8_t* __restrict__ ran, uint8_t* __restr
 }
 
 // start of a round: snapshot the claims, drop the claims of the walks that are about to re-run, clear the round's counters
+// (copy == 0: the snapshot is already the claims -- ext_mark_kernel brought it up to date where the last round changed something)
 __global__ void ext_round_begin_kernel(u64* __restrict__ claim, u64* __restrict__ snap, uint64_t n2, const uint8_t* __restrict__ dirty,
-                                       uint64_t ns, unsigned long long* __restrict__ d_cnt) {
+                                       uint64_t ns, unsigned long long* __restrict__ d_cnt, int copy) {
   uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (o == 0) { d_cnt[6] = 0; d_cnt[7] = 0; d_cnt[13] = 0; }      // changed k1-mers, (spare), walks handed over
   if (o >= n2) return;
   const u64 c = claim[o];
-  snap[o] = c;
+  if (copy) snap[o] = c;
   const uint32_t rk = RANK(c);
   if (rk != UNCLAIMED && rk < ns && dirty[rk]) claim[o] = UNCLAIMED64;
 }
 
 // after a round: every k1-mer whose owner changed dirties the walks that looked at it; the k1-mers of the walks
 // that got a memo slot are written into it (memo + hint)
-__global__ void ext_mark_kernel(const u64* __restrict__ claim, const u64* __restrict__ claim_old, uint64_t n2,
+__global__ void ext_mark_kernel(const u64* __restrict__ claim, u64* claim_old, uint64_t n2,
                                 const Adj4* __restrict__ adjR, const Adj4* __restrict__ adjL, const uint32_t* __restrict__ seed_rank,
                                 uint8_t* __restrict__ dirty, const uint8_t* __restrict__ ran, uint32_t* __restrict__ owned,
                                 unsigned long long* __restrict__ n_changed, uint32_t frozen, uint32_t limit,
@@ -774,9 +775,13 @@ __global__ void ext_mark_kernel(const u64* __restrict__ claim, const u64* __rest
   // most expensive thing in this kernel)
   uint32_t my_changed = 0;
   for (uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; y < n2; y += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t a = RANK(claim_old[y]);
+    const u64 oy = claim_old[y];
+    const uint32_t a = RANK(oy);
     const u64 cy = claim[y];
     const uint32_t b = RANK(cy);
+    // precise marks read the snapshot only at y itself: bring it up to date here, and the next round's begin pass has nothing
+    // to copy (8 of the 32 bytes the two passes move per k1-mer and round)
+    if (precise && oy != cy) claim_old[y] = cy;
     if (b >= frozen && b < limit && ran[b]) {                     // (only walks of the open block can have run)
       atomicAdd(&owned[b], 1u);                                   // for ext_verify_kernel
       if (fill[b]) {                                              // slot layout: see MemoCursor
@@ -1139,6 +1144,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   if (!plan) TRYE(hipHostMalloc((void**)&plan, 64));
   int it = 0, repairs = 0;
   bool converged = ns == 0;
+  bool snap_current = false;              // the snapshot equals the claims (after a round with precise marks)
 
   const uint32_t g2n = (uint32_t)cdiv(2 * n, 256);
   // Rank phases: a walk depends only on lower ranks, so the fixpoint is reached block by block -- first the
@@ -1219,7 +1225,9 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     }
     TimerRegion t3(ctx, T_EXT_WALK);
     // snapshot, then release the claims of the walks that re-run this round
-    hipLaunchKernelGGL(ext_round_begin_kernel, dim3(g2n), dim3(256), 0, s, claim, snap, 2 * n, dirty, (uint64_t)ns, d_cnt);
+    hipLaunchKernelGGL(ext_round_begin_kernel, dim3(g2n), dim3(256), 0, s, claim, snap, 2 * n, dirty, (uint64_t)ns, d_cnt,
+                       (!precise_marks || !snap_current) ? 1 : 0);
+    snap_current = true;
     WalkArgs A;
     A.order = e->d_order; A.adjR = (const Adj4*)e->d_adjR; A.adjL = (const Adj4*)e->d_adjL; A.weight = e->d_weight;
     A.claim = claim; A.claim_old = snap;
