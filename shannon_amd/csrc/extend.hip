@@ -317,6 +317,10 @@ __device__ __forceinline__ int audit_decide(const Adj4& cd, uint32_t r, uint32_t
 
 
 // ---- short walks: one thread per walk, one memory round trip per step (candidate rows prefetched).
+// FRESH: the first round of a block that has just opened -- none of its walks has run before, so the snapshot holds nothing but
+// the claims of final walks, which the live claims hold too: the snapshot is not read (a quarter of a step's memory accesses,
+// in the rounds that make most of the steps).
+template <bool FRESH>
 __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_walks, const uint32_t* __restrict__ list,
                                                         const u64* __restrict__ snap) {
   __shared__ unsigned long long blk_steps;
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
     uint64_t tot = 0;
     bool promoted = false;
     // snap: the pre-round snapshot; A.claim: live claims of this round
-    bool isvoid = RANK(snap[o]) < r || RANK(__hip_atomic_load(&A.claim[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < r;
+    bool isvoid = (!FRESH && RANK(snap[o]) < r) || RANK(__hip_atomic_load(&A.claim[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < r;
     if (!isvoid) {
       claim_node(A, o, r, 0);
       tot = A.weight[o >> 1];
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
           for (int b = 0; b < 4; b++) {
             uint32_t idx = cand.v[b] < 0 ? o : (uint32_t)cand.v[b];
             cl[b] = __hip_atomic_load(&A.claim[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            cf[b] = snap[idx];
+            cf[b] = FRESH ? UNCLAIMED64 : snap[idx];
             w[b] = A.weight[idx >> 1];
             nxt[b] = adj[idx];
           }
@@ -1145,6 +1149,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   int it = 0, repairs = 0;
   bool converged = ns == 0;
   bool snap_current = false;              // the snapshot equals the claims (after a round with precise marks)
+  bool fresh_block = true;                // the open block has not run a round yet (and no repair has reopened earlier blocks)
 
   const uint32_t g2n = (uint32_t)cdiv(2 * n, 256);
   // Rank phases: a walk depends only on lower ranks, so the fixpoint is reached block by block -- first the
@@ -1206,6 +1211,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
         fprintf(stderr, "[shn_extend] fixpoint audit after %d rounds: %llu k1-mers / %llu walks disagree with the greedy rule; reopening all blocks\n",
                 it, plan[4], plan[5]);
         if (++repairs > 16) break;
+        fresh_block = false;
         frozen = 0;
         expect_dirty = plan[4] + plan[5];
         TRYE(hipMemsetAsync(ran, 0, ns + 1, s));
@@ -1221,6 +1227,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       TRYE(hipMemsetAsync(ran, 0, frozen, s));       // frozen walks never run again
       TRYE(hipMemsetAsync(dirty + frozen, 1, limit - frozen, s));
       expect_dirty = limit - frozen;
+      fresh_block = repairs == 0;
       continue;
     }
     TimerRegion t3(ctx, T_EXT_WALK);
@@ -1246,7 +1253,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     }
     if (plan[2]) {
       TimerRegion tk(ctx, T_EXT_WALK_THREAD);
-      hipLaunchKernelGGL(ext_walk_kernel, dim3((uint32_t)cdiv(plan[2], EBLK)), dim3(EBLK), 0, s, A, (uint64_t)plan[2], short_list, snap);
+      if (fresh_block) hipLaunchKernelGGL(ext_walk_kernel<true>, dim3((uint32_t)cdiv(plan[2], EBLK)), dim3(EBLK), 0, s, A, (uint64_t)plan[2], short_list, snap);
+      else hipLaunchKernelGGL(ext_walk_kernel<false>, dim3((uint32_t)cdiv(plan[2], EBLK)), dim3(EBLK), 0, s, A, (uint64_t)plan[2], short_list, snap);
     }
     if (plan[2]) {                              // walks the thread kernel handed over (the count stays on the device)
       TimerRegion tk(ctx, T_EXT_WALK_WAVE);
@@ -1254,6 +1262,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
                          (uint64_t)ns, (const unsigned long long*)(d_cnt + 13));
     }
     if (plan[0]) TRYE(hipStreamWaitEvent(s, ev_join, 0));
+    fresh_block = false;
     // who has to run next round?  walks whose view changed (mark) + walks that lost a claim race (verify);
     // the walks that ran get their memo rebuilt from the claims
     hipLaunchKernelGGL(ext_memo_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 256)), dim3(256), 0, s, ran, dirty, owned, e->d_nr, e->d_nl, e->d_order, frozen, limit,
