@@ -118,6 +118,20 @@ struct ThreadCtx {
 };
 static thread_local ThreadCtx t_ctx;
 
+static void decode_read(char* s, const uint8_t* p, uint64_t n, int enc, bool rc) {
+  if (enc == SHN_ENC_CODES) {
+    if (!rc) for (uint64_t i = 0; i < n; i++) s[i] = p[i] < 4 ? "ACGT"[p[i]] : 'N';
+    else for (uint64_t i = 0; i < n; i++) { uint8_t c = p[n - 1 - i]; s[i] = c < 4 ? "TGCA"[c] : 'N'; }
+  } else {
+    auto up = [](uint8_t c) -> char { return (c >= 'a' && c <= 'z') ? (char)(c - 32) : (char)c; };
+    if (!rc) for (uint64_t i = 0; i < n; i++) s[i] = up(p[i]);
+    else for (uint64_t i = 0; i < n; i++) {
+      char c = up(p[n - 1 - i]);
+      s[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c;
+    }
+  }
+}
+
 struct Graph {
   shn_ctx* ctx = nullptr;                   // non-NULL: K-mer seed scans run on the GPU (csrc/seeds.hip)
   int K, L, SIZE_THRESHOLD;
@@ -132,7 +146,39 @@ struct Graph {
   std::vector<int> order;
   std::vector<int> es, ed, ew;
   std::vector<double> ecc;
-  RStr rstr(int r) const { return RStr{rindex.data(r), rindex.len(r)}; }
+  // Lazy read text (reads named by rows of the host code matrices, shn_mbgraph_run_rows): nearly every read is settled on the
+  // device (distinct reads, bridging seeds, the in-node test of known_paths); the text of a read is decoded from its row the first
+  // time host code asks for it -- bridging hits, reads that run past their node: a few per cent of the reads.  Host code that reads
+  // text from several threads calls ensure_all_text() first.
+  const uint8_t *lz_a = nullptr, *lz_b = nullptr;
+  uint32_t lz_L = 0;
+  char* lz_buf = nullptr;
+  mutable std::vector<uint64_t> lz_done;
+  void decode_lazy(int r) const {
+    const uint8_t* p = ((origin_flag[r] & 1) ? lz_b : lz_a) + (uint64_t)origin_row[r] * lz_L;
+    decode_read(lz_buf + (size_t)r * lz_L, p, lz_L, SHN_ENC_CODES, (origin_flag[r] & 2) != 0);
+    lz_done[(size_t)r >> 6] |= 1ULL << (r & 63);
+  }
+  void ensure_all_text() const {
+    if (!lz_buf) return;
+    const size_t n = n_rd();
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::max(1, shn_host_cpus() / 2), n >> 16));
+    auto work = [&](size_t lo, size_t hi) {                       // (whole 64-read words per thread: the done bits are not shared)
+      for (size_t r = lo; r < hi; r++) if (!((lz_done[r >> 6] >> (r & 63)) & 1)) decode_lazy((int)r);
+    };
+    if (nt <= 1) { work(0, n); return; }
+    std::vector<std::thread> th;
+    const size_t words = (n + 63) / 64;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back(work, std::min(n, words * t / nt * 64), std::min(n, words * (t + 1) / nt * 64));
+    for (auto& x : th) x.join();
+  }
+  RStr rstr(int r) const {
+    if (lz_buf) {
+      if (!((lz_done[(size_t)r >> 6] >> (r & 63)) & 1)) decode_lazy(r);
+      return RStr{lz_buf + (size_t)r * lz_L, lz_L};
+    }
+    return RStr{rindex.data(r), rindex.len(r)};
+  }
   size_t n_rd() const { return rindex.size(); }
   std::vector<double> rcc;
   std::vector<int> rmate, rmp;        // rmp: 0 None, 1, 2
@@ -718,6 +764,7 @@ struct Graph {
         }
       } }
     tk0 = nowk();
+    ensure_all_text();                                   // (the host form reads every read's text, on several threads)
     std::vector<std::pair<uint64_t, std::pair<int, int>>> items;
     for (int n : order) {
       const std::string& b = bases[n];
@@ -914,19 +961,6 @@ extern "C" void shn_graph_destroy(shn_graph* g) { delete g; }
 // r_off[n_reads+1]; paired: second mate file r2/r2_off with the same count.  Read.L = length of the first read.
 // enc: SHN_ENC_ASCII or SHN_ENC_CODES (0..3); rc1/rc2 (optional, one byte per read): 1 = take the reverse
 // complement of that read (the strand-doubled view of the packed input, shannon.py:396-424)
-static void decode_read(char* s, const uint8_t* p, uint64_t n, int enc, bool rc) {
-  if (enc == SHN_ENC_CODES) {
-    if (!rc) for (uint64_t i = 0; i < n; i++) s[i] = p[i] < 4 ? "ACGT"[p[i]] : 'N';
-    else for (uint64_t i = 0; i < n; i++) { uint8_t c = p[n - 1 - i]; s[i] = c < 4 ? "TGCA"[c] : 'N'; }
-  } else {
-    auto up = [](uint8_t c) -> char { return (c >= 'a' && c <= 'z') ? (char)(c - 32) : (char)c; };
-    if (!rc) for (uint64_t i = 0; i < n; i++) s[i] = up(p[i]);
-    else for (uint64_t i = 0; i < n; i++) {
-      char c = up(p[n - 1 - i]);
-      s[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c;
-    }
-  }
-}
 
 static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n_rows, const shn_unitigs* ug, uint32_t part, const uint8_t* r1,
                            const uint64_t* r1_off, const uint8_t* r2, const uint64_t* r2_off, uint64_t n_reads, int paired, int enc,
@@ -1101,16 +1135,23 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
     if (dbg) fprintf(stderr, "[mbgraph]   distinct reads (GPU)   %8.3f s  used=%llu distinct=%llu\n", now() - t_dec, (unsigned long long)used, (unsigned long long)nd);
     StringInterner& R = g.rindex;
     R.hashes.assign(nd, 0);
+    const char* lzv = getenv("SHN_GRAPH_LAZY_TEXT");
+    const bool lazy = host_a && !(lzv && lzv[0] == '0') && src_a->n_invalid == 0 && (!paired || src_b->n_invalid == 0);
+    if (lazy) {
+      if (sc->text.size() < nd * Lr + 1) { sc->text.clear(); sc->text.resize(nd * Lr + 1); }
+      g.lz_a = host_a; g.lz_b = host_b; g.lz_L = (uint32_t)Lr; g.lz_buf = sc->text.data();
+      g.lz_done.assign((nd + 63) / 64, 0);
+    }
     R.off.resize(nd + 1);
-    if (R.arena.capacity() < nd * Lr) { R.arena.reserve(nd * Lr); if (nd * Lr >= (8u << 20)) { const uintptr_t a = ((uintptr_t)R.arena.data() + 4095) & ~(uintptr_t)4095; madvise((void*)a, (nd * Lr) & ~(size_t)4095, MADV_HUGEPAGE); } }
-    R.arena.resize(nd * Lr);
+    if (!lazy && R.arena.capacity() < nd * Lr) { R.arena.reserve(nd * Lr); if (nd * Lr >= (8u << 20)) { const uintptr_t a = ((uintptr_t)R.arena.data() + 4095) & ~(uintptr_t)4095; madvise((void*)a, (nd * Lr) & ~(size_t)4095, MADV_HUGEPAGE); } }
+    if (!lazy) R.arena.resize(nd * Lr);
     g.rcc.resize(nd); g.rmate.resize(nd); g.rmp.resize(nd); g.rfirst.assign(nd, -1); g.rlast.assign(nd, -1); g.rhas.assign(nd, 0);
     g.origin_row.resize(nd); g.origin_flag.resize(nd);
     const unsigned hwc = (unsigned)shn_host_cpus();
     unsigned nt = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(32, std::max(1u, hwc / 2)), nd >> 15));
     BudgetGuard budget((int)nt);
     std::atomic<int> non_acgt{0};
-    char* arena = &R.arena[0];
+    char* arena = lazy ? nullptr : &R.arena[0];
     auto work = [&](uint64_t lo, uint64_t hi) {
       bool bad = false;
       for (uint64_t id = lo; id < hi; id++) {
@@ -1118,6 +1159,7 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
         uint32_t row; uint8_t fl;
         origin_of(j, row, fl);
         g.origin_row[id] = row; g.origin_flag[id] = fl;
+        if (lazy) { g.rcc[id] = (double)cnt[id]; g.rmate[id] = mate[id]; g.rmp[id] = role[id]; continue; }
         const uint8_t* p; bool rc; int e = enc;
         if (host_a) { p = ((fl & 1) ? host_b : host_a) + (uint64_t)row * Lr; rc = (fl & 2) != 0; e = SHN_ENC_CODES; }
         else { const uint64_t i = j / nm; if (j % nm == 0) { p = r1 + r1_off[i]; rc = rc1 && rc1[i]; } else { p = r2 + r2_off[i]; rc = rc2 && rc2[i]; } }

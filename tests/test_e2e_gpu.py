@@ -114,8 +114,9 @@ def test_graph_reads_gathered_on_the_device_equal_uploaded_text(ctx, monkeypatch
         # rows gathered on the host, distinct reads found on the device
         for env in ({}, {"SHN_GRAPH_ROWS": "0"}, {"SHN_GRAPH_ROWS": "0", "SHN_GRAPH_RESIDENT_READS": "0"},
                     {"SHN_GRAPH_ROWS": "0", "SHN_GRAPH_BULK_MIN": "64"}, {"SHN_GRAPH_ROWS": "0", "SHN_GRAPH_BULK_MIN": "64", "SHN_GRAPH_DEVICE_DEDUP": "0"},
-                    {"SHN_GRAPH_KP_GPU": "0"}):                      # known_paths' in-node test on host threads instead of the device
-            for k in ("SHN_GRAPH_ROWS", "SHN_GRAPH_RESIDENT_READS", "SHN_GRAPH_BULK_MIN", "SHN_GRAPH_DEVICE_DEDUP", "SHN_GRAPH_KP_GPU"):
+                    {"SHN_GRAPH_KP_GPU": "0"},                       # known_paths' in-node test on host threads instead of the device
+                    {"SHN_GRAPH_LAZY_TEXT": "0"}):                   # the text of every distinct read decoded up front
+            for k in ("SHN_GRAPH_ROWS", "SHN_GRAPH_RESIDENT_READS", "SHN_GRAPH_BULK_MIN", "SHN_GRAPH_DEVICE_DEDUP", "SHN_GRAPH_KP_GPU", "SHN_GRAPH_LAZY_TEXT"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
