@@ -5,10 +5,12 @@
 // used to index every K-mer of every node (a 600 k-item sort per partition: 7 of the graph stage's 31 thread-seconds per
 // step), look up every read's first and last K-mer on the device and compare every read with its node on host threads
 // (4 thread-seconds).  Here the whole test runs where the reads already are:
-//   kp_items      one item per base position of the concatenated node texts: packed K-mer at that position (or "none")
-//   shn_sort_pairs  stable by key: the occurrences of a K-mer in insertion order (node order, then offset)
-//   kp_classify   per read: first / last K-mer by binary search; the occurrences of the first K-mer in order, text compared
-//                 base by base against the node -> 0 (nothing to do), 1 + node (inside that node), 2 (search on the host)
+//   kp_insert     one thread per base position of the concatenated node texts: its K-mer into an open-addressing table, a count
+//                 per K-mer;  scan;  kp_fill: the positions of every K-mer side by side
+//   kp_classify   per read: first / last K-mer looked up; the occurrences of the first K-mer by ascending position (= the order of
+//                 the host's index: node order, then offset), text compared base by base against the node
+//                 -> 0 (nothing to do), 1 + node (inside that node), 2 (search on the host)
+// (a first version sorted the (K-mer, position) items: 35 launches per partition against 5)
 // The host keeps the sequential part: reads of kind 2, in read order, against an index of just their first K-mers.
 #include "common.h"
 
@@ -16,8 +18,6 @@
 #include <cstring>
 #include <mutex>
 #include <string>
-
-int shn_sort_pairs(shn_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t* keys_tmp, uint32_t* vals_tmp, uint64_t n, int bit_lo, int bit_hi);
 
 namespace {
 
@@ -28,33 +28,65 @@ __device__ __forceinline__ uint32_t kp_node_of(const uint64_t* __restrict__ off,
   return lo;
 }
 
-__global__ void kp_items(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ off, uint32_t n_nodes, uint64_t total, int K,
-                         uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, unsigned long long* __restrict__ counters) {
+constexpr uint64_t KP_EMPTY = ~0ULL;                             // (a K-mer of K <= 31 bases is < 2^62)
+__device__ __forceinline__ uint64_t kp_mix(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return x;
+}
+
+// one thread per base position of the concatenated node texts: the K-mer starting there (if it lies inside its node) enters an
+// open-addressing table; slot_of[p] = its slot (the K-mer's group), cnt[slot] = occurrences
+__global__ void kp_insert(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ off, uint32_t n_nodes, uint64_t total, int K,
+                          unsigned long long* hkeys, uint64_t mask, uint32_t* __restrict__ cnt, uint32_t* __restrict__ slot_of,
+                          unsigned long long* __restrict__ counters) {
   const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= total) return;
   const uint32_t nd = kp_node_of(off, n_nodes, p);
-  uint64_t key = 1ULL << (2 * K);                                  // "no K-mer starts here": sorts behind every K-mer
+  uint32_t slot = 0xFFFFFFFFu;
   if (p + (uint64_t)K <= off[nd + 1]) {
     uint64_t k = 0;
     bool ok = true;
     for (int j = 0; j < K; j++) { const int c = kp_code(bases[p + j]); if (c < 0) { ok = false; break; } k = (k << 2) | (uint64_t)c; }
-    if (ok) { key = k; atomicAdd(&counters[0], 1ULL); } else atomicAdd(&counters[1], 1ULL);
+    if (!ok) atomicAdd(&counters[1], 1ULL);
+    else {
+      uint64_t s = kp_mix(k) & mask;
+      while (true) {
+        unsigned long long cur = hkeys[s];
+        if (cur == KP_EMPTY) { const unsigned long long old = atomicCAS(&hkeys[s], KP_EMPTY, (unsigned long long)k); cur = old == KP_EMPTY ? k : old; }
+        if (cur == k) break;
+        s = (s + 1) & mask;
+      }
+      slot = (uint32_t)s;
+      atomicAdd(&cnt[s], 1u);
+    }
   }
-  keys[p] = key;
-  vals[p] = (uint32_t)p;
+  slot_of[p] = slot;
+}
+// the occurrences of every K-mer side by side (in any order: the reader takes them by ascending position)
+__global__ void kp_fill(const uint32_t* __restrict__ slot_of, uint64_t total, const uint64_t* __restrict__ goff, uint32_t* __restrict__ fill,
+                        uint32_t* __restrict__ occ) {
+  const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= total) return;
+  const uint32_t s = slot_of[p];
+  if (s == 0xFFFFFFFFu) return;
+  occ[goff[s] + atomicAdd(&fill[s], 1u)] = (uint32_t)p;
 }
 
 struct RView { const uint64_t* words; const uint64_t* woff; const uint32_t* len; uint64_t n; uint32_t fixed_len, wpr; };
 
-__device__ __forceinline__ uint64_t kp_lower_bound(const uint64_t* __restrict__ a, uint64_t n, uint64_t key) {
-  uint64_t lo = 0, hi = n;
-  while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
-  return lo;
+__device__ __forceinline__ int64_t kp_find(const unsigned long long* __restrict__ hkeys, uint64_t mask, uint64_t key) {
+  uint64_t s = kp_mix(key) & mask;
+  while (true) {
+    const unsigned long long cur = hkeys[s];
+    if (cur == key) return (int64_t)s;
+    if (cur == KP_EMPTY) return -1;
+    s = (s + 1) & mask;
+  }
 }
 
-__global__ void kp_classify(RView v, int K, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint64_t n_items,
-                            const uint8_t* __restrict__ bases, const uint64_t* __restrict__ off, uint32_t n_nodes, uint8_t* __restrict__ state,
-                            int32_t* __restrict__ node_out) {
+__global__ void kp_classify(RView v, int K, const unsigned long long* __restrict__ hkeys, uint64_t mask, const uint64_t* __restrict__ goff,
+                            const uint32_t* __restrict__ occ, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ off, uint32_t n_nodes,
+                            uint8_t* __restrict__ state, int32_t* __restrict__ node_out) {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= v.n) return;
   const uint32_t L = v.len ? v.len[r] : v.fixed_len;
@@ -63,12 +95,15 @@ __global__ void kp_classify(RView v, int K, const uint64_t* __restrict__ keys, c
   if (L >= (uint32_t)K) {
     const uint64_t* w = v.words + (v.woff ? v.woff[r] : r * v.wpr);
     const uint64_t kf = shn_extract(w, 0, K), kl = shn_extract(w, L - K, K);
-    const uint64_t lo = kp_lower_bound(keys, n_items, kf);
-    const uint64_t ll = kp_lower_bound(keys, n_items, kl);
-    if (lo < n_items && keys[lo] == kf && ll < n_items && keys[ll] == kl) {
+    const int64_t sf = kp_find(hkeys, mask, kf);
+    if (sf >= 0 && kp_find(hkeys, mask, kl) >= 0) {
       bool any = false, need = false;
-      for (uint64_t j = lo; j < n_items && keys[j] == kf && !need; j++) {
-        const uint64_t p = vals[j];
+      const uint64_t g0 = goff[sf], g1 = goff[sf + 1];
+      int64_t last = -1;                                             // occurrences in index order = by ascending position
+      for (uint64_t it = g0; it < g1 && !need; it++) {
+        uint64_t p = ~0ULL;
+        for (uint64_t j = g0; j < g1; j++) { const uint64_t q = occ[j]; if ((int64_t)q > last && q < p) p = q; }
+        last = (int64_t)p;
         const uint32_t nd = kp_node_of(off, n_nodes, p);
         const uint64_t left = off[nd + 1] - p;                       // bases of the node from the occurrence on
         const uint32_t n = (uint32_t)min((uint64_t)L, left);
@@ -87,8 +122,6 @@ __global__ void kp_classify(RView v, int K, const uint64_t* __restrict__ keys, c
   state[r] = st;
   node_out[r] = fn;
 }
-
-std::mutex g_sort_mu;            // shn_sort_pairs keeps its histogram in a process-wide workspace
 
 }  // namespace
 
@@ -113,38 +146,42 @@ extern "C" int shn_known_paths_scan(shn_ctx* ctx, const shn_reads* reads, int K,
   hipStream_t s = ctx->stream;
   TimerRegion treg(ctx, T_SEEDS);
   ShnDevBufs bufs;
+  uint64_t T = 1024;
+  while (T < 2 * total) T <<= 1;
   uint8_t *d_bases = nullptr, *d_state = nullptr;
-  uint64_t *d_off = nullptr, *d_keys = nullptr, *d_ktmp = nullptr;
-  uint32_t *d_vals = nullptr, *d_vtmp = nullptr;
+  uint64_t *d_off = nullptr, *d_goff = nullptr;
+  unsigned long long *d_hkeys = nullptr, *d_cnt2 = nullptr;
+  uint32_t *d_cnt = nullptr, *d_fill = nullptr, *d_slot = nullptr, *d_occ = nullptr;
   int32_t* d_node = nullptr;
-  unsigned long long* d_cnt = nullptr;
 #define TRYK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return shn_fail(SHN_ERR_HIP, std::string("shn_known_paths_scan: ") + hipGetErrorString(e_)); } while (0)
   TRYK(bufs.get(&d_bases, total + 8));
   TRYK(bufs.get(&d_off, (n_nodes + 1) * 8));
-  TRYK(bufs.get(&d_keys, (total + 1) * 8)); TRYK(bufs.get(&d_ktmp, (total + 1) * 8));
-  TRYK(bufs.get(&d_vals, (total + 1) * 4)); TRYK(bufs.get(&d_vtmp, (total + 1) * 4));
+  TRYK(bufs.get(&d_hkeys, T * 8));
+  TRYK(bufs.get(&d_cnt, (T + 1) * 4)); TRYK(bufs.get(&d_fill, (T + 1) * 4));
+  TRYK(bufs.get(&d_goff, (T + 2) * 8));
+  TRYK(bufs.get(&d_slot, (total + 1) * 4)); TRYK(bufs.get(&d_occ, (total + 1) * 4));
   TRYK(bufs.get(&d_state, nr + 1)); TRYK(bufs.get(&d_node, (nr + 1) * 4));
-  TRYK(bufs.get(&d_cnt, 16));
+  TRYK(bufs.get(&d_cnt2, 16));
   TRYK(hipMemcpyAsync(d_bases, node_bases, total, hipMemcpyHostToDevice, s));
   TRYK(hipMemcpyAsync(d_off, node_off, (n_nodes + 1) * 8, hipMemcpyHostToDevice, s));
-  TRYK(hipMemsetAsync(d_cnt, 0, 16, s));
-  hipLaunchKernelGGL(kp_items, dim3((uint32_t)cdiv(total, 256)), dim3(256), 0, s, d_bases, d_off, (uint32_t)n_nodes, total, K, d_keys, d_vals, d_cnt);
-  unsigned long long cnt[2] = {0, 0};
-  {
-    std::lock_guard<std::mutex> lk(g_sort_mu);
-    int rc = shn_sort_pairs(ctx, d_keys, d_vals, d_ktmp, d_vtmp, total, 0, 2 * K + 1);
-    if (rc) return rc;
-    TRYK(hipMemcpyAsync(cnt, d_cnt, 16, hipMemcpyDeviceToHost, s));
-    TRYK(hipStreamSynchronize(s));
-  }
-  if (cnt[1]) return shn_fail(SHN_ERR_ARG, "shn_known_paths_scan: a node holds a base outside ACGT");
+  TRYK(hipMemsetAsync(d_cnt2, 0, 16, s));
+  TRYK(hipMemsetAsync(d_hkeys, 0xFF, T * 8, s));
+  TRYK(hipMemsetAsync(d_cnt, 0, (T + 1) * 4, s));
+  TRYK(hipMemsetAsync(d_fill, 0, (T + 1) * 4, s));
+  const uint32_t gp = (uint32_t)cdiv(total, 256);
+  hipLaunchKernelGGL(kp_insert, dim3(gp), dim3(256), 0, s, d_bases, d_off, (uint32_t)n_nodes, total, K, d_hkeys, T - 1, d_cnt, d_slot, d_cnt2);
+  { int rc = shn_device_scan_u32(ctx, d_cnt, T, d_goff, nullptr); if (rc) return rc; }
+  hipLaunchKernelGGL(kp_fill, dim3(gp), dim3(256), 0, s, d_slot, total, d_goff, d_fill, d_occ);
   RView v{reads->d_words, reads->d_woff, reads->d_len, nr, reads->fixed_len, reads->wpr};
-  hipLaunchKernelGGL(kp_classify, dim3((uint32_t)cdiv(nr, 256)), dim3(256), 0, s, v, K, d_keys, d_vals, (uint64_t)cnt[0], d_bases, d_off, (uint32_t)n_nodes,
+  hipLaunchKernelGGL(kp_classify, dim3((uint32_t)cdiv(nr, 256)), dim3(256), 0, s, v, K, d_hkeys, T - 1, d_goff, d_occ, d_bases, d_off, (uint32_t)n_nodes,
                      d_state, d_node);
   TRYK(hipGetLastError());
+  unsigned long long cnt[2] = {0, 0};
+  TRYK(hipMemcpyAsync(cnt, d_cnt2, 16, hipMemcpyDeviceToHost, s));
   TRYK(hipMemcpyAsync(state_out, d_state, nr, hipMemcpyDeviceToHost, s));
   TRYK(hipMemcpyAsync(node_out, d_node, nr * 4, hipMemcpyDeviceToHost, s));
   TRYK(hipStreamSynchronize(s));
+  if (cnt[1]) return shn_fail(SHN_ERR_ARG, "shn_known_paths_scan: a node holds a base outside ACGT");
 #undef TRYK
   return SHN_OK;
 }
