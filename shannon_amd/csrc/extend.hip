@@ -125,6 +125,43 @@ __global__ void ext_adjacency_kernel(const uint64_t* __restrict__ tkeys, const u
   }
 }
 
+// Both rows of both orientations from 8 look-ups per canonical k1-mer instead of 16: the right candidates of the reverse-
+// complement orientation are the reverse complements of the forward orientation's left candidates (rc(s)[1:] + b = rc(comp(b) +
+// s[:-1])) and vice versa -- the same table entry j, the other orientation (the same one if entry j is its own reverse
+// complement).  One thread per (canonical k1-mer, dir, base).
+__global__ void ext_adjacency_half_kernel(const uint64_t* __restrict__ tkeys, const uint64_t* __restrict__ boff, int bits,
+                                          const uint8_t* __restrict__ flags, uint64_t n, int k, int canonical,
+                                          int32_t* __restrict__ adjR, int32_t* __restrict__ adjL) {
+  const uint64_t total = n * 8;
+  const uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+  for (uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t b = gid & 3;
+    const uint32_t dir = (gid >> 2) & 1;
+    const uint64_t i = gid >> 3;
+    const uint8_t f = flags[i];
+    const bool dead0 = (f & 2) != 0;                                    // forward orientation
+    const bool dead1 = dead0 || (f & 1) || !canonical;                  // reverse-complement orientation (absent for palindromes)
+    int32_t res = -1, der = -1;
+    if (!dead0) {
+      const uint64_t str = tkeys[i];
+      const uint64_t nb = dir == 0 ? (((str << 2) | b) & mask) : ((str >> 2) | ((uint64_t)b << (2 * (k - 1))));
+      uint64_t canon = nb;
+      uint32_t strand = 0;
+      if (canonical) { const uint64_t rc = shn_revcomp(nb, k); if (rc < nb) { canon = rc; strand = 1; } }
+      const int64_t j = shn_table_find(tkeys, boff, bits, canon);
+      if (j >= 0) {
+        const uint8_t fj = flags[j];
+        if (!(fj & 2)) {
+          res = (int32_t)(2 * j + strand);
+          der = (fj & 1) ? res : (int32_t)(2 * j + (1 - strand));        // the candidate's other orientation
+        }
+      }
+    }
+    (dir == 0 ? adjR : adjL)[(2 * i) * 4 + b] = res;
+    (dir == 0 ? adjL : adjR)[(2 * i + 1) * 4 + (3 - b)] = dead1 ? -1 : der;
+  }
+}
+
 // ---- connected components of the k1-mer graph (vertices = canonical k1-mers, edges = the adjacency rows).
 // A walk never leaves its component, so the components can be extended independently -- on different GPUs.
 // Lock-free union-find: roots only ever link to smaller ids (no cycles), finds halve paths as they go.
@@ -1066,8 +1103,12 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     TimerRegion t1(ctx, T_EXT_PREP);
     hipLaunchKernelGGL(ext_prepare_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, t->d_counts, n, t->k,
                        t->canonical, e->d_weight, e->d_flags);
-    hipLaunchKernelGGL(ext_adjacency_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 16, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off,
-                       t->bits, e->d_flags, n, t->k, t->canonical, e->d_adjR, e->d_adjL);
+    if (getenv("SHN_EXT_ADJ_FULL"))                 // (development: all 16 look-ups per k1-mer)
+      hipLaunchKernelGGL(ext_adjacency_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 16, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off,
+                         t->bits, e->d_flags, n, t->k, t->canonical, e->d_adjR, e->d_adjL);
+    else
+      hipLaunchKernelGGL(ext_adjacency_half_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off,
+                         t->bits, e->d_flags, n, t->k, t->canonical, e->d_adjR, e->d_adjL);
     TRYE(hipGetLastError());
   }
   // seeds: compact, sort by string then (stable) by weight descending
