@@ -287,6 +287,7 @@ __global__ void ext_weightkey_kernel(const uint32_t* __restrict__ svals, const u
 }
 
 struct Adj4 { int32_t v[4]; };
+#define CHUNK_SHIFT 6
 
 struct WalkArgs {
   const uint32_t* order; const Adj4* adjR; const Adj4* adjL; const uint32_t* weight;
@@ -303,12 +304,14 @@ struct WalkArgs {
   // a thread walker that turns out long hands its walk over to a wavefront (same round): where it stands
   uint32_t* promo_list; unsigned long long* promo_count; uint32_t* res_cur; uint32_t* res_info;   // info = dir << 31 | steps so far
   uint32_t promote_steps;
+  uint8_t* chunk;        // per 4096 oriented k1-mers: "a claim in here was written this round" (the mark pass visits only those)
 };
 
 // Claim `node` as step `pos` of walk r: atomic min on rank:pos, fire-and-forget (a returning atomic would put
 // a second memory round trip on every step; lost races are found after the round by ext_verify_kernel).
 __device__ __forceinline__ void claim_node(const WalkArgs& A, uint32_t node, uint32_t r, uint32_t pos) {
   __hip_atomic_fetch_min(&A.claim[node], CLAIM(r, pos), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (A.chunk) A.chunk[node >> CHUNK_SHIFT] = 1;
 }
 
 // One greedy decision (extension_correction.py:223-237): among the candidates that exist and are not
@@ -793,14 +796,14 @@ __global__ void ext_memo_plan_kernel(uint8_t* __restrict__ ran, uint8_t* __restr
 // start of a round: snapshot the claims, drop the claims of the walks that are about to re-run, clear the round's counters
 // (copy == 0: the snapshot is already the claims -- ext_mark_kernel brought it up to date where the last round changed something)
 __global__ void ext_round_begin_kernel(u64* __restrict__ claim, u64* __restrict__ snap, uint64_t n2, const uint8_t* __restrict__ dirty,
-                                       uint64_t ns, unsigned long long* __restrict__ d_cnt, int copy) {
+                                       uint64_t ns, unsigned long long* __restrict__ d_cnt, int copy, uint8_t* __restrict__ chunk) {
   uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (o == 0) { d_cnt[6] = 0; d_cnt[7] = 0; d_cnt[13] = 0; }      // changed k1-mers, (spare), walks handed over
   if (o >= n2) return;
   const u64 c = claim[o];
   if (copy) snap[o] = c;
   const uint32_t rk = RANK(c);
-  if (rk != UNCLAIMED && rk < ns && dirty[rk]) claim[o] = UNCLAIMED64;
+  if (rk != UNCLAIMED && rk < ns && dirty[rk]) { claim[o] = UNCLAIMED64; if (chunk) chunk[o >> CHUNK_SHIFT] = 1; }
 }
 
 // after a round: every k1-mer whose owner changed dirties the walks that looked at it; the k1-mers of the walks
@@ -811,11 +814,22 @@ __global__ void ext_mark_kernel(const u64* __restrict__ claim, u64* claim_old, u
                                 unsigned long long* __restrict__ n_changed, uint32_t frozen, uint32_t limit,
                                 const uint8_t* __restrict__ fill, const uint64_t* __restrict__ moff, const uint32_t* __restrict__ mR,
                                 uint32_t* __restrict__ pool, uint32_t* __restrict__ hint,
-                                const uint32_t* __restrict__ nr_a, const uint32_t* __restrict__ nl_a, const uint32_t* __restrict__ weight, int precise) {
+                                const uint32_t* __restrict__ nr_a, const uint32_t* __restrict__ nl_a, const uint32_t* __restrict__ weight, int precise,
+                                const uint8_t* __restrict__ chunk) {
   // grid-stride: the change counter costs one atomic per block (one per wavefront on a single address was the
-  // most expensive thing in this kernel)
+  // most expensive thing in this kernel).  A wavefront takes chunks of 64 k1-mers (one 512-byte run of claims) and, in rounds
+  // that re-run few walks (chunk != NULL), skips those no claim was written in this round (claim_node and the release of the
+  // begin pass flag them): where nothing was written nothing changed, and every k1-mer of a walk that ran was written.  The
+  // k1-mers of a walk are scattered over the table, so the flags have to be this fine to leave chunks out: a round of 3,000
+  // walks of 2,000 steps touches a quarter of them.
   uint32_t my_changed = 0;
-  for (uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; y < n2; y += (uint64_t)gridDim.x * blockDim.x) {
+  const uint64_t n_chunks = (n2 + (1ULL << CHUNK_SHIFT) - 1) >> CHUNK_SHIFT;
+  const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  for (uint64_t ch = wave; ch < n_chunks; ch += n_waves) {
+  if (chunk && !chunk[ch]) continue;
+  {
+    const uint64_t y = (ch << CHUNK_SHIFT) + (threadIdx.x & 63);
+    if (y >= n2) continue;
     const u64 oy = claim_old[y];
     const uint32_t a = RANK(oy);
     const u64 cy = claim[y];
@@ -874,6 +888,7 @@ __global__ void ext_mark_kernel(const u64* __restrict__ claim, u64* claim_old, u
     }
 #undef MARKX
 #undef MARK
+  }
   }
   __shared__ unsigned long long blk_changed;
   if (threadIdx.x == 0) blk_changed = 0;
@@ -1189,6 +1204,11 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   if (!plan) TRYE(hipHostMalloc((void**)&plan, 64));
   int it = 0, repairs = 0;
   bool converged = ns == 0;
+  uint8_t* chunk = nullptr;               // see ext_mark_kernel
+  const uint64_t n_chunks = ((2 * n) >> CHUNK_SHIFT) + 2;
+  TRYE(shn_dev_malloc(&chunk, n_chunks));
+  struct ChunkFree { uint8_t* p; ~ChunkFree() { shn_dev_free(p); } } chunk_free{chunk};
+  TRYE(hipMemsetAsync(chunk, 0, n_chunks, s));
   bool snap_current = false;              // the snapshot equals the claims (after a round with precise marks)
   bool fresh_block = true;                // the open block has not run a round yet (and no repair has reopened earlier blocks)
 
@@ -1274,7 +1294,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     TimerRegion t3(ctx, T_EXT_WALK);
     // snapshot, then release the claims of the walks that re-run this round
     hipLaunchKernelGGL(ext_round_begin_kernel, dim3(g2n), dim3(256), 0, s, claim, snap, 2 * n, dirty, (uint64_t)ns, d_cnt,
-                       (!precise_marks || !snap_current) ? 1 : 0);
+                       (!precise_marks || !snap_current) ? 1 : 0, bulk ? (uint8_t*)nullptr : chunk);
     snap_current = true;
     WalkArgs A;
     A.order = e->d_order; A.adjR = (const Adj4*)e->d_adjR; A.adjL = (const Adj4*)e->d_adjL; A.weight = e->d_weight;
@@ -1283,6 +1303,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     A.pool = pool; A.moff = moff; A.mR = mR; A.mL = mL; A.mvalid = mvalid; A.hint = hint;
     A.promote_steps = bulk ? 0xFFFFFFFFu : promote_steps;
     A.promo_list = promo_list; A.promo_count = d_cnt + 13; A.res_cur = res_cur; A.res_info = res_info;
+    A.chunk = bulk ? nullptr : chunk;          // (bulk rounds write nearly everywhere: their mark pass is dense, the walkers do not flag)
     A.steps_counter = d_cnt + 1; A.wave_steps_counter = d_cnt + 64; A.dbg = getenv("SHN_DEBUG") ? d_cnt + 32 : nullptr;
     // long (wave per walk) and short (thread per walk) kernels are independent: overlap them on two streams
     if (plan[0]) {
@@ -1310,7 +1331,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
                        moff, mR, mL, mvalid, fill, pool, d_cnt + 10, pool_cap, bulk ? 0xFFFFFFFFu : memo_min);
     { TimerRegion tk(ctx, T_EXT_MARK);
       hipLaunchKernelGGL(ext_mark_kernel, dim3(std::min<uint32_t>(g2n, 4096u)), dim3(256), 0, s, claim, snap, 2 * n, (const Adj4*)e->d_adjR, (const Adj4*)e->d_adjL,
-                         seed_rank, dirty, ran, owned, d_cnt + 6, frozen, limit, fill, moff, mR, pool, hint, e->d_nr, e->d_nl, e->d_weight, precise_marks); }
+                         seed_rank, dirty, ran, owned, d_cnt + 6, frozen, limit, fill, moff, mR, pool, hint, e->d_nr, e->d_nl, e->d_weight, precise_marks, bulk ? (const uint8_t*)nullptr : chunk);
+      if (!bulk) TRYE(hipMemsetAsync(chunk, 0, n_chunks, s)); }
     hipLaunchKernelGGL(ext_verify_kernel, dim3((uint32_t)cdiv(limit, 256)), dim3(256), 0, s, ran, owned, e->d_nr, e->d_nl, (uint64_t)limit, dirty);
     if (getenv("SHN_EXT_FAULT") && it + 1 == atoi(getenv("SHN_EXT_FAULT"))) TRYE(hipMemsetAsync(dirty, 0, ns + 1, s));   // (tests: lose every mark of this round)
     if (getenv("SHN_EXT_ALLDIRTY")) { TRYE(hipMemsetAsync(dirty, 0, ns + 1, s)); TRYE(hipMemsetAsync(dirty + frozen, 1, limit - frozen, s)); }
