@@ -109,7 +109,7 @@ def ingest_rate(ctx, r1, r2, n_pairs):
         rec[:, w + L] = 10
         return rec.reshape(-1)
     texts = [fasta(r1[:n_pairs]), fasta(r2[:n_pairs])]
-    device.Reads.ingest(ctx, texts[0][:len(texts[0]) // 8])[0].close()     # first-use costs (pinned buffers, kernels) outside
+    device.Reads.ingest(ctx, texts[0])[0].close()                          # first-use costs (pinning the staging pair, kernels) outside
     t = time.time()
     got = [device.Reads.ingest(ctx, x) for x in texts]
     dt = time.time() - t

@@ -15,7 +15,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -83,9 +85,6 @@ template <class F> int walk_records(const uint8_t* t, uint64_t n, uint64_t b0, u
   return 0;
 }
 
-struct Lut { uint8_t v[256]; Lut() { memset(v, 4, 256); v['A'] = v['a'] = 0; v['C'] = v['c'] = 1; v['G'] = v['g'] = 2; v['T'] = v['t'] = 3; } };
-const Lut kLut;
-
 }  // namespace
 
 // text / n_bytes: the file; format: 0 = by the first character ('>' FASTA, '@' FASTQ), 1 FASTA, 2 FASTQ; codes_out: NULL or room
@@ -102,6 +101,10 @@ extern "C" int shn_reads_ingest(shn_ctx* ctx, const uint8_t* text, uint64_t n_by
   if (format == 0) format = text[lead] == '@' ? 2 : 1;
   if (format != 1 && format != 2) return shn_fail(SHN_ERR_ARG, "shn_reads_ingest: bad format");
   const bool fastq = format == 2;
+  const bool dbg = getenv("SHN_DEBUG") != nullptr;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_0 = now();
+  double t_scan = 0, t_alloc = 0, t_parse = 0, t_wait = 0;
   const unsigned T = (unsigned)std::max(1, std::min(shn_host_cpus(), 64));
   // ranges of ~16 MB of text, cut at record starts
   uint64_t range_bytes = 16u << 20;
@@ -144,14 +147,24 @@ extern "C" int shn_reads_ingest(shn_ctx* ctx, const uint8_t* text, uint64_t n_by
   if (mn != mx || mx == 0) return shn_fail(SHN_ERR_ARG, "shn_reads_ingest: unsupported: reads of different lengths (" + std::to_string(mn) + " .. " + std::to_string(mx) + ")");
   const uint32_t L = mx;
   *n_reads_out = N; *read_len_out = L;
+  t_scan = now() - t_0;
   if (!out && !codes_out) return SHN_OK;
   if (codes_out && codes_cap < N * (uint64_t)L) return shn_fail(SHN_ERR_ARG, "shn_reads_ingest: codes_out too small");
+  // base -> code without a table (a table look-up per base does not vectorise and was the bound of the whole ingest): bits 1-2 of
+  // 'A' 'C' 'G' 'T' (either case) are 0 1 3 2; x ^ (x >> 1) puts G and T in order; anything else becomes 4
+  auto encode = [](const uint8_t* __restrict__ p, uint8_t* __restrict__ d, uint32_t n) {
+    for (uint32_t j = 0; j < n; j++) {
+      const uint8_t c = p[j], u = (uint8_t)(c & 0xDF), t = (uint8_t)((c >> 1) & 3);
+      const uint8_t ok = (uint8_t)((u == 'A') | (u == 'C') | (u == 'G') | (u == 'T'));
+      d[j] = ok ? (uint8_t)(t ^ (t >> 1)) : (uint8_t)4;
+    }
+  };
   auto parse = [&](const Range& r, uint8_t* dst_a, uint8_t* dst_b) {             // dst_*: row 0 = record r.rec0 (either may be NULL)
     uint64_t k = 0;
     walk_records(text, n_bytes, r.b0, r.b1, fastq, [&](uint64_t s, uint64_t) {
       const uint8_t* p = text + s;
-      if (dst_a) { uint8_t* d = dst_a + k * L; for (uint32_t j = 0; j < L; j++) d[j] = kLut.v[p[j]]; if (dst_b) memcpy(dst_b + k * L, d, L); }
-      else { uint8_t* d = dst_b + k * L; for (uint32_t j = 0; j < L; j++) d[j] = kLut.v[p[j]]; }
+      if (dst_a) { uint8_t* d = dst_a + k * L; encode(p, d, L); if (dst_b) memcpy(dst_b + k * L, d, L); }
+      else encode(p, dst_b + k * L, L);
       k++;
     });
   };
@@ -175,12 +188,18 @@ extern "C" int shn_reads_ingest(shn_ctx* ctx, const uint8_t* text, uint64_t n_by
   uint64_t stage_bytes = 256ull << 20;
   if (const char* e = getenv("SHN_INGEST_STAGE_BYTES")) stage_bytes = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
   cap = std::max<uint64_t>(cap, std::min<uint64_t>(N, stage_bytes / L + 1));
+  // the pinned pair is kept between calls (pinning and unpinning 0.5 GB cost 70 of the 100 ms a 5 M-read file took); one ingest
+  // at a time uses it
+  static std::mutex pin_mu;
+  static uint8_t* pin_keep[2] = {nullptr, nullptr};
+  static size_t pin_cap = 0;
+  std::lock_guard<std::mutex> pin_lock(pin_mu);
   uint8_t* pin[2] = {nullptr, nullptr};
   uint8_t* dst[2] = {nullptr, nullptr};
   hipEvent_t ev[2] = {nullptr, nullptr};
   hipStream_t s = ctx->stream;
   auto cleanup = [&]() {
-    for (int b = 0; b < 2; b++) { if (pin[b]) hipHostFree(pin[b]); if (dst[b]) hipFree(dst[b]); if (ev[b]) hipEventDestroy(ev[b]); }
+    for (int b = 0; b < 2; b++) { if (dst[b]) shn_dev_free(dst[b]); if (ev[b]) hipEventDestroy(ev[b]); }
   };
 #define TRYI(e) do { hipError_t _e = (e); if (_e != hipSuccess) { cleanup(); shn_reads_destroy(r); \
       return shn_fail(SHN_ERR_HIP, std::string("shn_reads_ingest: ") + #e + ": " + hipGetErrorString(_e)); } } while (0)
@@ -188,11 +207,18 @@ extern "C" int shn_reads_ingest(shn_ctx* ctx, const uint8_t* text, uint64_t n_by
   TRYI(hipMalloc(&r->d_mask, (r->n_words / 2 + 2) * 8));
   TRYI(hipMemsetAsync(r->d_words + r->n_words, 0, 16, s));
   TRYI(hipMemsetAsync(r->d_mask + r->n_words / 2, 0, 16, s));
+  if (pin_cap < cap * L) {
+    for (int b = 0; b < 2; b++) { if (pin_keep[b]) hipHostFree(pin_keep[b]); pin_keep[b] = nullptr; }
+    pin_cap = 0;
+    for (int b = 0; b < 2; b++) TRYI(hipHostMalloc(&pin_keep[b], cap * L, hipHostMallocDefault));
+    pin_cap = cap * L;
+  }
   for (int b = 0; b < 2; b++) {
-    TRYI(hipHostMalloc(&pin[b], cap * L, hipHostMallocDefault));
-    TRYI(hipMalloc(&dst[b], cap * L));
+    pin[b] = pin_keep[b];
+    TRYI(shn_dev_malloc(&dst[b], cap * L));
     TRYI(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
   }
+  t_alloc = now() - t_0 - t_scan;
   uint64_t i0 = 0;
   int b = 0;
   bool used[2] = {false, false};
@@ -200,8 +226,9 @@ extern "C" int shn_reads_ingest(shn_ctx* ctx, const uint8_t* text, uint64_t n_by
     uint64_t i1 = i0, n_grp = 0;
     while (i1 < n_ranges && n_grp + R[i1].n_rec <= cap) { n_grp += R[i1].n_rec; i1++; }
     if (n_grp) {
-      if (used[b]) TRYI(hipEventSynchronize(ev[b]));
+      { const double tw = now(); if (used[b]) TRYI(hipEventSynchronize(ev[b])); t_wait += now() - tw; }
       const uint64_t base = R[i0].rec0;
+      const double tp = now();
       std::atomic<uint64_t> next{i0};
       auto work = [&]() {
         for (uint64_t i; (i = next.fetch_add(1)) < i1;)
@@ -211,6 +238,7 @@ extern "C" int shn_reads_ingest(shn_ctx* ctx, const uint8_t* text, uint64_t n_by
       for (unsigned t = 1; t < std::min<uint64_t>(T, i1 - i0); t++) th.emplace_back(work);
       work();
       for (auto& x : th) x.join();
+      t_parse += now() - tp;
       TRYI(hipMemcpyAsync(dst[b], pin[b], n_grp * L, hipMemcpyHostToDevice, s));
       int rc = shn_pack_fixed_codes(ctx, dst[b], n_grp, L, r->wpr, r->d_words + base * r->wpr, r->d_mask + base * (r->wpr / 2), s);
       if (rc) { cleanup(); shn_reads_destroy(r); return rc; }
@@ -220,9 +248,12 @@ extern "C" int shn_reads_ingest(shn_ctx* ctx, const uint8_t* text, uint64_t n_by
     }
     i0 = i1;
   }
-  TRYI(hipStreamSynchronize(s));
+  { const double tw = now(); TRYI(hipStreamSynchronize(s)); t_wait += now() - tw; }
 #undef TRYI
+  const double t_c = now();
   cleanup();
+  if (dbg) fprintf(stderr, "[ingest] %llu reads of %u: scan %.3f s, allocations %.3f s, parse %.3f s, waiting for copies %.3f s, frees %.3f s, total %.3f s\n",
+                   (unsigned long long)N, L, t_scan, t_alloc, t_parse, t_wait, now() - t_c, now() - t_0);
   int rc = shn_reads_finish_fixed(ctx, r);
   if (rc) { shn_reads_destroy(r); return rc; }
   *out = r;
