@@ -17,37 +17,58 @@ __global__ __launch_bounds__(SBLK) void sort_hist_kernel(const uint64_t* __restr
   gh[(uint64_t)threadIdx.x * nblocks + blockIdx.x] = lh[threadIdx.x];
 }
 
+// Stable scatter of one 8-bit digit.  A tile of 4096 items is split among the block's 4 wavefronts, 1024 consecutive items each,
+// taken 64 at a time: the lanes of a wavefront that hold the same digit find each other with 8 ballots (one per digit bit), a
+// lane's rank among them is a popcount, and a per-wavefront LDS counter carries the digit's count from one 64-item row to the next.
+// After a barrier the counts of the wavefronts before it and the tile's global offset complete a position.  (The first version
+// let thread d walk all 4096 digits of the tile to place the items of digit d: 1 M LDS reads per tile, 480 GB/s per pass.)
 __global__ __launch_bounds__(SBLK) void sort_scatter_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                             uint64_t n, int shift, uint32_t nblocks,
                                                             const uint64_t* __restrict__ goff, uint64_t* __restrict__ ok,
                                                             uint32_t* __restrict__ ov) {
-  __shared__ uint32_t dig[STILE / 4];    // 4 digits per word
-  __shared__ uint32_t pos[STILE];
-  uint64_t t0 = (uint64_t)blockIdx.x * STILE, t1 = min(t0 + STILE, n);
-  uint32_t cnt = (uint32_t)(t1 - t0);
-  uint8_t* d8 = (uint8_t*)dig;
-  for (uint32_t i = threadIdx.x; i < STILE; i += SBLK) d8[i] = i < cnt ? (uint8_t)((keys[t0 + i] >> shift) & 255) : 0;
-  __syncthreads();
-  // thread d assigns, in tile order, the output slots of the items whose digit is d (stable)
-  {
-    const uint32_t d = threadIdx.x;
-    uint64_t base = goff[(uint64_t)d * nblocks + blockIdx.x];
-    uint32_t run = 0;
-    uint32_t words = (cnt + 3) / 4;
-    for (uint32_t w = 0; w < words; w++) {
-      uint32_t x = dig[w];
+  __shared__ uint32_t cnt[SBLK / 64][256];
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (uint32_t i = lane; i < 256; i += 64) cnt[wv][i] = 0;
+  const uint64_t t0 = (uint64_t)blockIdx.x * STILE + (uint64_t)wv * (STILE / (SBLK / 64));
+  const unsigned long long lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;          // lanes before this one
+  constexpr int ROWS = STILE / SBLK;                                            // 16 rows of 64 items per wavefront
+  uint64_t k[ROWS];
+  uint32_t v[ROWS], rank[ROWS];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        uint32_t i = w * 4 + j;
-        if (((x >> (8 * j)) & 255) == d && i < cnt) { pos[i] = (uint32_t)(base - t0 * 0 + run); run++; }
-      }
+  for (int row = 0; row < ROWS; row++) {
+    const uint64_t i = t0 + (uint64_t)row * 64 + lane;
+    const bool have = i < n;
+    k[row] = have ? keys[i] : 0;
+    v[row] = have ? vals[i] : 0;
+    const uint32_t d = (uint32_t)((k[row] >> shift) & 255);
+    unsigned long long same = __ballot(have);
+#pragma unroll
+    for (int bit = 0; bit < 8; bit++) {
+      const unsigned long long m = __ballot(((d >> bit) & 1) != 0);
+      same &= ((d >> bit) & 1) ? m : ~m;
     }
+    const uint32_t before = cnt[wv][d];                                       // (every lane of a digit group reads the same counter ...
+    rank[row] = before + (uint32_t)__popcll(same & lt);
+    if (have && (same & lt) == 0) cnt[wv][d] = before + (uint32_t)__popcll(same);   // ... and its first lane moves it on)
   }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < cnt; i += SBLK) {
-    uint32_t p = pos[i];
-    ok[p] = keys[t0 + i];
-    ov[p] = vals[t0 + i];
+  // counts of the wavefronts before this one, per digit (256 digits x 4 wavefronts: every thread folds one digit)
+  __shared__ uint32_t base[SBLK / 64][256];
+  {
+    const uint32_t d = threadIdx.x;
+    uint32_t run = 0;
+#pragma unroll
+    for (int w = 0; w < SBLK / 64; w++) { base[w][d] = run; run += cnt[w][d]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int row = 0; row < ROWS; row++) {
+    const uint64_t i = t0 + (uint64_t)row * 64 + lane;
+    if (i >= n) continue;
+    const uint32_t d = (uint32_t)((k[row] >> shift) & 255);
+    const uint64_t p = goff[(uint64_t)d * nblocks + blockIdx.x] + base[wv][d] + rank[row];
+    ok[p] = k[row];
+    ov[p] = v[row];
   }
 }
 
