@@ -343,11 +343,17 @@ __global__ __launch_bounds__(BLK) void scan_apply(const uint32_t* __restrict__ i
   uint32_t v[4];
   unsigned long long s = 0;
   for (int j = 0; j < 4; j++) { uint64_t i = base + threadIdx.x * 4 + j; v[j] = i < n ? in[i] : 0; s += v[j]; }
-  part[threadIdx.x] = s;
+  // exclusive scan of the 256 thread sums: shuffles inside a wavefront, the four wavefront totals through LDS (one thread walking
+  // all 256 partial sums was most of this kernel)
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  unsigned long long inc = s;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const unsigned long long t = __shfl_up(inc, d, 64); if (lane >= (uint32_t)d) inc += t; }
+  if (lane == 63) part[wv] = inc;
   __syncthreads();
-  if (threadIdx.x == 0) { unsigned long long a = 0; for (int i = 0; i < BLK; i++) { unsigned long long t = part[i]; part[i] = a; a += t; } }
-  __syncthreads();
-  unsigned long long a = sums[blockIdx.x] + part[threadIdx.x];
+  unsigned long long wbase = 0;
+  for (uint32_t w = 0; w < wv; w++) wbase += part[w];
+  unsigned long long a = sums[blockIdx.x] + wbase + (inc - s);
   for (int j = 0; j < 4; j++) { uint64_t i = base + threadIdx.x * 4 + j; if (i < n) out[i] = a; a += v[j]; }
   if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
 }
