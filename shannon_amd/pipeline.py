@@ -79,10 +79,11 @@ def assemble(ctx, reads1, reads2=None, K=25, partition_size=500, min_weight=3, m
 
 def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3, min_length=75, overload=2, penalty=5,
                       sample="shannon", seed=0, double_stranded=True, part_vectors=None, timings=None, hits_factory=None,
-                      native_graph=True, graph_threads=None, keep_partitioning=False):
+                      native_graph=True, graph_threads=None, keep_partitioning=False, defer_back=False):
     """Same as assemble() with the reads already packed in HBM (d1/d2: device.Reads).  graph_threads: partitions whose
     graph stage may run concurrently on host threads.  keep_partitioning: leave the partition stage's tables (partition ->
-    contigs, routed read indices) on the result as `.partitioning` (tests/test_fullsize_gpu.py reads them)."""
+    contigs, routed read indices) on the result as `.partitioning` (tests/test_fullsize_gpu.py reads them).  defer_back: run count,
+    extension, partitioning / routing and the unitig batch now and return a function that does the rest (see `back`)."""
     if not double_stranded:
         # shannon.py:394-424 prepares strand-specific input differently (no doubling; PE: reads_2 = RC(R2)) and routing /
         # graph reads follow that layout; only the strand-doubled layout is built and pinned against the reference.
@@ -131,175 +132,184 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
         t0 = time.time()
         unitigs = mbgraph_native.Unitigs(ctx, [part["new_components"][nm] for nm in names], K)
         tick("graph unitigs (GPU)", t0)
-    part_index = {nm: i for i, nm in enumerate(names)}
-    check_rows = os.environ.get("SHN_GRAPH_CHECK")
+    def back(bctx=None):
+        """the host-bound half of the step -- graph stage, sparse flow, merge -- on context bctx (default: the caller's): with
+        defer_back the caller may run it on another thread and context while it starts the next batch's counting / extension
+        (bench.py --overlap); everything it touches on the device from then on is its own (forked graph contexts, LP batches)"""
+        ctx_b = bctx if bctx is not None else ctx
+        part_index = {nm: i for i, nm in enumerate(names)}
+        check_rows = os.environ.get("SHN_GRAPH_CHECK")
 
-    timeline = {} if os.environ.get("SHN_DEBUG_PARTS") else None
+        timeline = {} if os.environ.get("SHN_DEBUG_PARTS") else None
 
-    def _matrix(m):
-        return isinstance(m, np.ndarray) and m.dtype == np.uint8 and m.ndim == 2 and m.flags["C_CONTIGUOUS"]
-    # reads kept as code matrices + GPU unitigs: partitions name their reads by rows (SHN_GRAPH_ROWS=0: gather them on the host)
-    rows_mode = (unitigs is not None and d1 is not None and _matrix(store.r1) and (not paired or _matrix(store.r2)) and
-                 (not paired or d2 is not None) and os.environ.get("SHN_GRAPH_ROWS", "1") != "0")
+        def _matrix(m):
+            return isinstance(m, np.ndarray) and m.dtype == np.uint8 and m.ndim == 2 and m.flags["C_CONTIGUOUS"]
+        # reads kept as code matrices + GPU unitigs: partitions name their reads by rows (SHN_GRAPH_ROWS=0: gather them on the host)
+        rows_mode = (unitigs is not None and d1 is not None and _matrix(store.r1) and (not paired or _matrix(store.r2)) and
+                     (not paired or d2 is not None) and os.environ.get("SHN_GRAPH_ROWS", "1") != "0")
 
-    def one_partition(name):
-        """multibridged graph of one partition (multibridging.main for `name`); returns its record + timings"""
-        rec, tt = _one_partition(name)
-        if timeline is not None:
-            timeline[name] = (tt.pop("_t0") - t_graph, time.time() - t_graph, dict(tt), len(part["routes"][name]))
-        else:
-            tt.pop("_t0", None)
-        return rec, tt
-
-    def _one_partition(name):
-        tt = {"_t0": time.time()}
-        t0 = time.time()
-        n_kmers = unitigs.n_kmers(part_index[name]) if unitigs is not None else part["n_kmer_nodes"][name]
-        cutoff = 10 * n_kmers + 1                                    # multibridging.py:26-30, 385-391
-        idx = part["routes"][name][:cutoff]
-        if native_graph and rows_mode and len(idx):
-            # the reads named by their rows: distinct reads found on the device, their text decoded from the host matrices
-            rb = None
-            if check_rows:
-                rb_ = part["k1mer_bytes"][name]
-                rb = rb_() if callable(rb_) else rb_
-            def run_rows(rb):
-                return mbgraph_native.run_partition_rows(ctx, unitigs, part_index[name], d1, d2, store.r1, store.r2 if paired else None,
-                                                         np.asarray(idx, dtype=np.uint32), rb if (rb is not None and len(rb)) else None,
-                                                         0 if rb is None else len(rb) // (K + 1))
-            try:
-                gh = run_rows(rb)
-            except _lib.ShannonError as ex:
-                if rb is not None or "needs the k1-mer rows" not in str(ex):
-                    raise
-                rb_ = part["k1mer_bytes"][name]
-                gh = run_rows(rb_() if callable(rb_) else rb_)
-            tt["graph"] = time.time() - t0
-            return PartitionRecord(len(part["routes"][name]), part["n_k1mer_rows"][name], gh), tt
-        if native_graph:
-            b1, o1, rc1, enc = store.gather_codes(idx, 1)
-            if paired and rc1 is not None:
-                # the second mates are the same stored rows read on the other strand (shannon.py:413-424)
-                b2, o2, rc2 = b1, o1, (1 - rc1).astype(np.uint8)
+        def one_partition(name):
+            """multibridged graph of one partition (multibridging.main for `name`); returns its record + timings"""
+            rec, tt = _one_partition(name)
+            if timeline is not None:
+                timeline[name] = (tt.pop("_t0") - t_graph, time.time() - t_graph, dict(tt), len(part["routes"][name]))
             else:
-                b2, o2, rc2, _e = store.gather_codes(idx, 2) if paired else (None, None, None, enc)
-            tt["materialize reads"] = time.time() - t0
-            t0 = time.time()
-            def rows_now():
-                rb_ = part["k1mer_bytes"][name]
-                return rb_() if callable(rb_) else rb_
-            # with GPU unitigs the k1-mer rows are only needed for a partition holding a cycle of condensable edges (built by
-            # the sequential code) and for the development check SHN_GRAPH_CHECK=1
-            rb = rows_now() if (unitigs is None or check_rows) else None
-            res_src = (d1, d2, np.asarray(idx, dtype=np.uint32)) if (enc == 1 and len(idx)) else None     # code matrices resident on the device
-            try:
-                gh = mbgraph_native.run_partition_handle(None if rb is None else (rb if len(rb) else np.zeros(1, np.uint8)),
-                                                         0 if rb is None else len(rb) // (K + 1), K, b1, o1, b2, o2, ctx=ctx,
-                                                         enc=enc, rc1=rc1, rc2=rc2, unitigs=unitigs, part=part_index[name], resident=res_src)
-            except _lib.ShannonError as ex:
-                if rb is not None or "needs the k1-mer rows" not in str(ex):
-                    raise
-                rb = rows_now()
-                gh = mbgraph_native.run_partition_handle(rb if len(rb) else np.zeros(1, np.uint8), len(rb) // (K + 1), K, b1, o1, b2,
-                                                         o2, ctx=ctx, enc=enc, rc1=rc1, rc2=rc2, unitigs=unitigs, part=part_index[name],
-                                                         resident=res_src)
-            n_rows = part["n_k1mer_rows"][name]
-            if enc == 1:
-                store.release(b1)
-                if b2 is not None and b2 is not b1:
-                    store.release(b2)
-            tt["graph"] = time.time() - t0
-            return PartitionRecord(len(part["routes"][name]), n_rows, gh), tt
-        else:
-            rows = part["k1mers"][name]
-            r1 = [store.mate1(int(d)) for d in idx]
-            reads = [r1, [store.mate2(int(d)) for d in idx]] if paired else [r1]
-            tt["materialize reads"] = time.time() - t0
-            t0 = time.time()
-            g, singles, comps = mbgraph.run_partition(rows, reads, K, paired, hits_factory)
-            glog, n_rows = g.log, len(rows)
-        tt["graph"] = time.time() - t0
-        return {"n_reads_routed": len(part["routes"][name]), "n_k1mers": n_rows, "singles": singles, "components": comps,
-                "log": glog}, tt
+                tt.pop("_t0", None)
+            return rec, tt
 
-    t_graph = time.time()
-    if native_graph and len(names) > 1 and graph_threads > 1:
-        # partitions are independent (one multibridging process each in the reference, run_MB_SF_fn.py:219-253): the
-        # native stage releases the GIL, its GPU sections take turns
-        from concurrent.futures import ThreadPoolExecutor
-        with ThreadPoolExecutor(max_workers=min(len(names), graph_threads)) as pool:
-            # the partitions with the most routed reads first (the reference's size-sorted job list, shannon.py:546-551)
-            by_size = sorted(names, key=lambda nm: -len(part["routes"][nm]))
-            futs = {nm: pool.submit(one_partition, nm) for nm in by_size}
-            results = [futs[nm].result() for nm in names]
-    else:
-        results = [one_partition(nm) for nm in names]
-    if unitigs is not None:
-        unitigs.close()
-    wall = time.time() - t_graph
-    if timeline is not None:
-        import sys
-        for nm, (a, b, tt_, nr) in sorted(timeline.items(), key=lambda kv: -kv[1][1])[:12]:
-            sys.stderr.write("[parts] %-16s start %6.2f end %6.2f  routed %8d  %s\n" % (nm, a, b, nr, {k: round(v, 2) for k, v in tt_.items()}))
-        sys.stderr.write("[parts] stage wall %.2f s, %d partitions, %d threads\n" % (wall, len(names), graph_threads))
-    busy = sum(sum(tt.values()) for _, tt in results) or 1.0
-    for name, (rec, tt) in zip(names, results):
-        for k_, v in tt.items():                                      # wall time of the stage, split like the thread time
-            T[k_] = T.get(k_, 0.0) + v * wall / busy
-        R.partitions[name] = rec
-    t0 = time.time()
-    if native_graph and os.environ.get("SHN_SFLOW_NATIVE", "1") != "0":
-        # all components of all partitions through the native sparse-flow stage (shn_sparse_flow) in one call; the graphs
-        # stay native objects (exported to Python tables only if somebody asks a PartitionRecord for them)
-        texts = mbgraph_native.sparse_flow_native(ctx, [R.partitions[nm].graph for nm in names], ["%s_%s" % (sample, nm) for nm in names], seed,
-                                                  raw=True)
-        for name, txt in zip(names, texts):
-            R.partitions[name].fasta_raw = txt                     # decoded when somebody reads ["reconstructed_fasta"]
+        def _one_partition(name):
+            tt = {"_t0": time.time()}
+            t0 = time.time()
+            n_kmers = unitigs.n_kmers(part_index[name]) if unitigs is not None else part["n_kmer_nodes"][name]
+            cutoff = 10 * n_kmers + 1                                    # multibridging.py:26-30, 385-391
+            idx = part["routes"][name][:cutoff]
+            if native_graph and rows_mode and len(idx):
+                # the reads named by their rows: distinct reads found on the device, their text decoded from the host matrices
+                rb = None
+                if check_rows:
+                    rb_ = part["k1mer_bytes"][name]
+                    rb = rb_() if callable(rb_) else rb_
+                def run_rows(rb):
+                    return mbgraph_native.run_partition_rows(ctx_b, unitigs, part_index[name], d1, d2, store.r1, store.r2 if paired else None,
+                                                             np.asarray(idx, dtype=np.uint32), rb if (rb is not None and len(rb)) else None,
+                                                             0 if rb is None else len(rb) // (K + 1))
+                try:
+                    gh = run_rows(rb)
+                except _lib.ShannonError as ex:
+                    if rb is not None or "needs the k1-mer rows" not in str(ex):
+                        raise
+                    rb_ = part["k1mer_bytes"][name]
+                    gh = run_rows(rb_() if callable(rb_) else rb_)
+                tt["graph"] = time.time() - t0
+                return PartitionRecord(len(part["routes"][name]), part["n_k1mer_rows"][name], gh), tt
+            if native_graph:
+                b1, o1, rc1, enc = store.gather_codes(idx, 1)
+                if paired and rc1 is not None:
+                    # the second mates are the same stored rows read on the other strand (shannon.py:413-424)
+                    b2, o2, rc2 = b1, o1, (1 - rc1).astype(np.uint8)
+                else:
+                    b2, o2, rc2, _e = store.gather_codes(idx, 2) if paired else (None, None, None, enc)
+                tt["materialize reads"] = time.time() - t0
+                t0 = time.time()
+                def rows_now():
+                    rb_ = part["k1mer_bytes"][name]
+                    return rb_() if callable(rb_) else rb_
+                # with GPU unitigs the k1-mer rows are only needed for a partition holding a cycle of condensable edges (built by
+                # the sequential code) and for the development check SHN_GRAPH_CHECK=1
+                rb = rows_now() if (unitigs is None or check_rows) else None
+                res_src = (d1, d2, np.asarray(idx, dtype=np.uint32)) if (enc == 1 and len(idx)) else None     # code matrices resident on the device
+                try:
+                    gh = mbgraph_native.run_partition_handle(None if rb is None else (rb if len(rb) else np.zeros(1, np.uint8)),
+                                                             0 if rb is None else len(rb) // (K + 1), K, b1, o1, b2, o2, ctx=ctx_b,
+                                                             enc=enc, rc1=rc1, rc2=rc2, unitigs=unitigs, part=part_index[name], resident=res_src)
+                except _lib.ShannonError as ex:
+                    if rb is not None or "needs the k1-mer rows" not in str(ex):
+                        raise
+                    rb = rows_now()
+                    gh = mbgraph_native.run_partition_handle(rb if len(rb) else np.zeros(1, np.uint8), len(rb) // (K + 1), K, b1, o1, b2,
+                                                             o2, ctx=ctx_b, enc=enc, rc1=rc1, rc2=rc2, unitigs=unitigs, part=part_index[name],
+                                                             resident=res_src)
+                n_rows = part["n_k1mer_rows"][name]
+                if enc == 1:
+                    store.release(b1)
+                    if b2 is not None and b2 is not b1:
+                        store.release(b2)
+                tt["graph"] = time.time() - t0
+                return PartitionRecord(len(part["routes"][name]), n_rows, gh), tt
+            else:
+                rows = part["k1mers"][name]
+                r1 = [store.mate1(int(d)) for d in idx]
+                reads = [r1, [store.mate2(int(d)) for d in idx]] if paired else [r1]
+                tt["materialize reads"] = time.time() - t0
+                t0 = time.time()
+                g, singles, comps = mbgraph.run_partition(rows, reads, K, paired, hits_factory)
+                glog, n_rows = g.log, len(rows)
+            tt["graph"] = time.time() - t0
+            return {"n_reads_routed": len(part["routes"][name]), "n_k1mers": n_rows, "singles": singles, "components": comps,
+                    "log": glog}, tt
+
+        t_graph = time.time()
+        if native_graph and len(names) > 1 and graph_threads > 1:
+            # partitions are independent (one multibridging process each in the reference, run_MB_SF_fn.py:219-253): the
+            # native stage releases the GIL, its GPU sections take turns
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(len(names), graph_threads)) as pool:
+                # the partitions with the most routed reads first (the reference's size-sorted job list, shannon.py:546-551)
+                by_size = sorted(names, key=lambda nm: -len(part["routes"][nm]))
+                futs = {nm: pool.submit(one_partition, nm) for nm in by_size}
+                results = [futs[nm].result() for nm in names]
+        else:
+            results = [one_partition(nm) for nm in names]
+        if unitigs is not None:
+            unitigs.close()
+        wall = time.time() - t_graph
+        if timeline is not None:
+            import sys
+            for nm, (a, b, tt_, nr) in sorted(timeline.items(), key=lambda kv: -kv[1][1])[:12]:
+                sys.stderr.write("[parts] %-16s start %6.2f end %6.2f  routed %8d  %s\n" % (nm, a, b, nr, {k: round(v, 2) for k, v in tt_.items()}))
+            sys.stderr.write("[parts] stage wall %.2f s, %d partitions, %d threads\n" % (wall, len(names), graph_threads))
+        busy = sum(sum(tt.values()) for _, tt in results) or 1.0
+        for name, (rec, tt) in zip(names, results):
+            for k_, v in tt.items():                                      # wall time of the stage, split like the thread time
+                T[k_] = T.get(k_, 0.0) + v * wall / busy
+            R.partitions[name] = rec
+        t0 = time.time()
+        if native_graph and os.environ.get("SHN_SFLOW_NATIVE", "1") != "0":
+            # all components of all partitions through the native sparse-flow stage (shn_sparse_flow) in one call; the graphs
+            # stay native objects (exported to Python tables only if somebody asks a PartitionRecord for them)
+            texts = mbgraph_native.sparse_flow_native(ctx_b, [R.partitions[nm].graph for nm in names], ["%s_%s" % (sample, nm) for nm in names], seed,
+                                                      raw=True)
+            for name, txt in zip(names, texts):
+                R.partitions[name].fasta_raw = txt                     # decoded when somebody reads ["reconstructed_fasta"]
+            tick("sparse flow", t0)
+            t0 = time.time()
+            R._texts = ["".join(lines)] + texts                        # all_reconstructed.fasta: single contigs, then the partitions
+            if os.environ.get("SHN_POST_NATIVE", "1") != "0":
+                try:
+                    R.final = post.finalize_texts(R._texts, double_stranded)
+                except _lib.ShannonError as ex:
+                    if "non-ACGT" not in str(ex) and "empty line" not in str(ex):
+                        raise
+                    R.final = post.finalize(R.all_reconstructed, double_stranded)
+            else:
+                R.final = post.finalize(R.all_reconstructed, double_stranded)
+            tick("post", t0)
+            R.timings = T
+            return R
+        for name in names:
+            rec = R.partitions[name]
+            sf_jobs.append((name, rec["singles"], rec["components"]))
+        flat = [(nd["nodes"], nd["edges"], nd["paths"]) for _, _, comps in sf_jobs for nd in comps]
+        # component c of partition p uses RNG stream id = its index within the partition (as one
+        # algorithm_SF.py process per component, run_MB_SF_fn.py:242-250)
+        trs_flat = []
+        if flat:
+            ids, gens_in = [], []
+            for _, _, comps in sf_jobs:
+                for c, nd in enumerate(comps):
+                    ids.append(c)
+            trs_flat = _sparse_flow_with_ids(ctx_b, flat, ids, seed)
+        k = 0
+        for name, singles, comps in sf_jobs:
+            sname = "%s_%s" % (sample, name)
+            txt = ""
+            for c in range(len(comps)):
+                txt += sparse_flow.fasta_records(sname, str(c), trs_flat[k])
+                k += 1
+            txt += sparse_flow.single_nodes_fasta(sname, singles)
+            R.partitions[name]["reconstructed_fasta"] = txt
+            lines.extend(txt.splitlines(True))
         tick("sparse flow", t0)
         t0 = time.time()
-        R._texts = ["".join(lines)] + texts                        # all_reconstructed.fasta: single contigs, then the partitions
-        if os.environ.get("SHN_POST_NATIVE", "1") != "0":
-            try:
-                R.final = post.finalize_texts(R._texts, double_stranded)
-            except _lib.ShannonError as ex:
-                if "non-ACGT" not in str(ex) and "empty line" not in str(ex):
-                    raise
-                R.final = post.finalize(R.all_reconstructed, double_stranded)
-        else:
-            R.final = post.finalize(R.all_reconstructed, double_stranded)
+        R.all_reconstructed = lines
+        R.final = post.finalize(lines, double_stranded)
         tick("post", t0)
         R.timings = T
         return R
-    for name in names:
-        rec = R.partitions[name]
-        sf_jobs.append((name, rec["singles"], rec["components"]))
-    flat = [(nd["nodes"], nd["edges"], nd["paths"]) for _, _, comps in sf_jobs for nd in comps]
-    # component c of partition p uses RNG stream id = its index within the partition (as one
-    # algorithm_SF.py process per component, run_MB_SF_fn.py:242-250)
-    trs_flat = []
-    if flat:
-        ids, gens_in = [], []
-        for _, _, comps in sf_jobs:
-            for c, nd in enumerate(comps):
-                ids.append(c)
-        trs_flat = _sparse_flow_with_ids(ctx, flat, ids, seed)
-    k = 0
-    for name, singles, comps in sf_jobs:
-        sname = "%s_%s" % (sample, name)
-        txt = ""
-        for c in range(len(comps)):
-            txt += sparse_flow.fasta_records(sname, str(c), trs_flat[k])
-            k += 1
-        txt += sparse_flow.single_nodes_fasta(sname, singles)
-        R.partitions[name]["reconstructed_fasta"] = txt
-        lines += txt.splitlines(True)
-    tick("sparse flow", t0)
-    t0 = time.time()
-    R.all_reconstructed = lines
-    R.final = post.finalize(lines, double_stranded)
-    tick("post", t0)
-    R.timings = T
-    return R
+
+    if defer_back:
+        return back
+    return back()
 
 
 def _sparse_flow_with_ids(ctx, components, comp_ids, seed):

@@ -172,3 +172,38 @@ def test_distinct_reads_found_on_the_device_equal_the_read_dictionary(ctx, paire
             roles[a] = 1; roles[b] = 2; mates[a] = b; mates[b] = a
     assert len(ids) < len(didx) and len(slot) == len(ids)
     assert slot.tolist() == first and cnt.tolist() == counts and mate.tolist() == mates and role.tolist() == roles
+
+
+def test_two_batches_in_flight_give_the_sequential_results(ctx):
+    """pipeline.assemble_resident(defer_back=True): the host-bound half of a step (graph stage, sparse flow, merge) runs on a second
+    thread and context while the next batch's counting / extension runs on the first -- bench.py --overlap-steps.  Every batch's
+    output equals the one-batch-at-a-time run."""
+    from concurrent.futures import ThreadPoolExecutor
+    from shannon_amd import device, pipeline, synth, kmers_for_component as kfc
+    batches = []
+    for seed in (31, 32):
+        (r1, r2), _ = synth.make_dataset(30000, 40, seed=seed)
+        batches.append((device.Reads.from_codes(ctx, r1), device.Reads.from_codes(ctx, r2), kfc.ReadStore(r1, r2)))
+    want = [pipeline.assemble_resident(ctx, d1, d2, st, K=25, partition_size=8, sample="s", seed=2) for d1, d2, st in batches]
+    ctx_b = device.Context(0)
+    pool = ThreadPoolExecutor(max_workers=1)
+    try:
+        got, prev = [], None
+        for rep in range(3):
+            for d1, d2, st in batches:
+                fin = pipeline.assemble_resident(ctx, d1, d2, st, K=25, partition_size=8, sample="s", seed=2, defer_back=True)
+                if prev is not None:
+                    got.append(prev.result())
+                prev = pool.submit(fin, ctx_b)
+        got.append(prev.result())
+    finally:
+        pool.shutdown(wait=True)
+        ctx_b.close()
+    assert len(got) == 6
+    for i, R in enumerate(got):
+        W = want[i % 2]
+        assert R.final == W.final and R.extension.contigs == W.extension.contigs and list(R.partitions) == list(W.partitions)
+        for p in W.partitions:
+            assert R.partitions[p]["reconstructed_fasta"] == W.partitions[p]["reconstructed_fasta"]
+    for d1, d2, _st in batches:
+        d1.close(); d2.close()
