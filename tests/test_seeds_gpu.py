@@ -34,3 +34,64 @@ def test_seed_scans_match_host():
     assert b.tolist() == [pats.get(rb[-K:], -1) + 1 if len(rb) >= K else 0 for rb in reads]
     rd.close(); tab.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("K,seed", [(25, 1), (31, 2), (12, 3)])
+def test_known_paths_scan_equals_the_index_walk(K, seed):
+    """shn_known_paths_scan against the host rule it replaces (mbgraph.py:1355-1388 / search_sequence :114-160, the part every read
+    goes through): look the read's first K-mer up in the index of all K-mers of all nodes (occurrences in node order, then offset);
+    an occurrence whose node text equals the read's from there on counts -- inside the node if the read ends before the node does
+    (the last such node wins), otherwise the read has to be searched; reads whose first or last K-mer is in no node are skipped."""
+    import ctypes as C
+    from shannon_amd import device, _lib
+    rng = np.random.default_rng(seed)
+    ctx = device.Context(0)
+    base = "".join("ACGT"[i] for i in rng.integers(0, 4, 3000))
+    nodes = []
+    for _ in range(60):                                              # overlapping pieces of one sequence + repeats of a few
+        a = int(rng.integers(0, len(base) - 200)); nodes.append(base[a:a + int(rng.integers(K, 200))])
+    nodes += nodes[:5] + [nodes[7][3:], nodes[9][:-4]]
+    L = 70
+    reads = []
+    for _ in range(4000):
+        kind = rng.integers(0, 4)
+        if kind == 0:                                                # inside a node
+            n = nodes[int(rng.integers(0, len(nodes)))]
+            if len(n) >= L:
+                a = int(rng.integers(0, len(n) - L + 1)); reads.append(n[a:a + L]); continue
+        if kind == 1:                                                # from the underlying sequence: often runs past a node's end
+            a = int(rng.integers(0, len(base) - L)); reads.append(base[a:a + L]); continue
+        if kind == 2:                                                # one substitution
+            a = int(rng.integers(0, len(base) - L)); r = list(base[a:a + L]); j = int(rng.integers(0, L)); r[j] = "ACGT"[("ACGT".index(r[j]) + 1) % 4]
+            reads.append("".join(r)); continue
+        reads.append("".join("ACGT"[i] for i in rng.integers(0, 4, L)))
+    index = {}
+    for ni, n in enumerate(nodes):
+        for o in range(len(n) - K + 1):
+            index.setdefault(n[o:o + K], []).append((ni, o))
+    want_state, want_node = [], []
+    for r in reads:
+        st, fn = 0, -1
+        if r[:K] in index and r[-K:] in index:
+            anyin, need = False, False
+            for ni, o in index[r[:K]]:
+                n = nodes[ni]
+                m = min(len(r), len(n) - o)
+                if r[:m] != n[o:o + m]:
+                    continue
+                if len(r) <= len(n) - o:
+                    fn, anyin = ni, True
+                else:
+                    need = True
+                    break
+            st = 2 if need else 1 if anyin else 0
+        want_state.append(st); want_node.append(fn)
+    d = device.Reads.from_strings(ctx, reads)
+    text = np.frombuffer("".join(nodes).encode(), np.uint8)
+    off = np.zeros(len(nodes) + 1, np.uint64); off[1:] = np.cumsum([len(n) for n in nodes])
+    state = np.empty(len(reads), np.uint8); node = np.empty(len(reads), np.int32)
+    _lib.check(_lib.lib().shn_known_paths_scan(ctx.h, d.h, K, text.ctypes.data, off.ctypes.data, len(nodes), state.ctypes.data, node.ctypes.data))
+    assert state.tolist() == want_state
+    assert [n if s == 1 else -1 for n, s in zip(node.tolist(), state.tolist())] == [n if s == 1 else -1 for n, s in zip(want_node, want_state)]
+    assert set(want_state) == {0, 1, 2}
+    d.close(); ctx.close()
