@@ -162,6 +162,10 @@ int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min_weight, in
 int shn_ext_seed_info(shn_ctx* ctx, const shn_ext* e, const uint32_t* ranks, uint64_t n, uint64_t* keys, uint32_t* weights);
 int shn_ext_live_stats(shn_ctx* ctx, const shn_ext* e, uint64_t* n_live, uint32_t* rank, uint32_t* n_right, uint32_t* n_left,
                        uint64_t* tot_weight);
+/* ... restricted to walks of at least min_steps steps (contig length k1 + steps): the first clause of the accept filter,
+ * extension_correction.py:361, applied before the download.                                                                      */
+int shn_ext_live_stats_min(shn_ctx* ctx, const shn_ext* e, uint32_t min_steps, uint64_t* n_live, uint32_t* rank, uint32_t* n_right,
+                           uint32_t* n_left, uint64_t* tot_weight);
 
 /* Host-side (CPU, native) contig bookkeeping of run_correction over the contigs emitted above:
  * duplicate_check (extension_correction.py:247-270, r=15, f=0.5) and the contig graph by shared

@@ -1432,21 +1432,31 @@ extern "C" int shn_ext_stats(shn_ctx* ctx, const shn_ext* e, uint32_t* n_right, 
 }
 
 // ---- the non-void walks only (a few percent of the seeds), in seed order: what the accept filter needs
-__global__ void ext_live_flag_kernel(const uint32_t* __restrict__ nr, uint64_t ns, uint32_t* __restrict__ flag) {
+__global__ void ext_live_flag_kernel(const uint32_t* __restrict__ nr, const uint32_t* __restrict__ nl, uint64_t ns, uint32_t min_steps,
+                                     uint32_t* __restrict__ flag) {
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < ns) flag[r] = nr[r] != UNCLAIMED ? 1u : 0u;
+  if (r < ns) { const uint32_t a = nr[r]; flag[r] = (a != UNCLAIMED && (uint64_t)a + nl[r] >= min_steps) ? 1u : 0u; }
 }
 __global__ void ext_live_gather_kernel(const uint32_t* __restrict__ nr, const uint32_t* __restrict__ nl, const uint64_t* __restrict__ totw,
                                        const uint64_t* __restrict__ pos, uint64_t ns, uint32_t* __restrict__ o_rank,
                                        uint32_t* __restrict__ o_nr, uint32_t* __restrict__ o_nl, uint64_t* __restrict__ o_tw) {
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= ns || nr[r] == UNCLAIMED) return;
+  if (r >= ns) return;
   uint64_t p = pos[r];
+  if (pos[r + 1] == p) return;                                  // not selected by the flag pass
   o_rank[p] = (uint32_t)r; o_nr[p] = nr[r]; o_nl[p] = nl[r]; o_tw[p] = totw[r];
 }
 
+extern "C" int shn_ext_live_stats_min(shn_ctx* ctx, const shn_ext* e, uint32_t min_steps, uint64_t* n_live, uint32_t* rank, uint32_t* n_right,
+                                      uint32_t* n_left, uint64_t* tot_weight);
 extern "C" int shn_ext_live_stats(shn_ctx* ctx, const shn_ext* e, uint64_t* n_live, uint32_t* rank, uint32_t* n_right, uint32_t* n_left,
                                   uint64_t* tot_weight) {
+  return shn_ext_live_stats_min(ctx, e, 0, n_live, rank, n_right, n_left, tot_weight);
+}
+// ... of the non-void walks of at least min_steps steps (the first clause of the accept filter, extension_correction.py:361, is a
+// bound on the contig length k1 + steps: at BASELINE configs[2] it leaves 0.7 M of tens of millions of live walks to download)
+extern "C" int shn_ext_live_stats_min(shn_ctx* ctx, const shn_ext* e, uint32_t min_steps, uint64_t* n_live, uint32_t* rank, uint32_t* n_right,
+                                      uint32_t* n_left, uint64_t* tot_weight) {
   if (!ctx || !e || !n_live) return shn_fail(SHN_ERR_ARG, "shn_ext_live_stats: NULL argument");
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
@@ -1457,7 +1467,7 @@ extern "C" int shn_ext_live_stats(shn_ctx* ctx, const shn_ext* e, uint64_t* n_li
   if ((rc = g_shn_ws[9].get((ns + 1) * 4, &pf)) || (rc = g_shn_ws[11].get((ns + 2) * 8, &pp))) return rc;
   uint32_t* flag = (uint32_t*)pf;
   uint64_t* pos = (uint64_t*)pp;
-  hipLaunchKernelGGL(ext_live_flag_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, e->d_nr, ns, flag);
+  hipLaunchKernelGGL(ext_live_flag_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, e->d_nr, e->d_nl, ns, min_steps, flag);
   uint64_t total = 0;
   if ((rc = shn_device_scan_u32(ctx, flag, ns, pos, &total))) return rc;
   if (!rank) { *n_live = total; return SHN_OK; }                  // sizing call

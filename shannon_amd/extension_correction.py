@@ -115,16 +115,17 @@ class Extension(object):
         _lib.check(_lib.lib().shn_ext_stats(self.ctx.h, self.h, nr.ctypes.data, nl.ctypes.data, tw.ctypes.data))
         return nr, nl, tw
 
-    def live_stats(self):
-        """(rank, nr, nl, tot_weight) of the non-void walks, in seed order."""
+    def live_stats(self, min_steps=0):
+        """(rank, nr, nl, tot_weight) of the non-void walks (of at least min_steps steps), in seed order."""
         L = _lib.lib()
         n = C.c_uint64(0)
-        _lib.check(L.shn_ext_live_stats(self.ctx.h, self.h, C.byref(n), None, None, None, None))
+        ms = int(max(0, min_steps))
+        _lib.check(L.shn_ext_live_stats_min(self.ctx.h, self.h, ms, C.byref(n), None, None, None, None))
         m = n.value
         rank = np.empty(max(m, 1), np.uint32); nr = np.empty(max(m, 1), np.uint32)
         nl = np.empty(max(m, 1), np.uint32); tw = np.empty(max(m, 1), np.uint64)
         if m:
-            _lib.check(L.shn_ext_live_stats(self.ctx.h, self.h, C.byref(n), rank.ctypes.data, nr.ctypes.data, nl.ctypes.data, tw.ctypes.data))
+            _lib.check(L.shn_ext_live_stats_min(self.ctx.h, self.h, ms, C.byref(n), rank.ctypes.data, nr.ctypes.data, nl.ctypes.data, tw.ctypes.data))
         return rank[:m], nr[:m], nl[:m], tw[:m]
 
     def emit_raw(self, ranks, lengths):
@@ -503,7 +504,8 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     if pipe is not None:
         keep = None
     else:
-        live, nr, nl, tw = ext.live_stats()                        # non-void walks, in seed order (compacted on the GPU)
+        # non-void walks long enough for the accept filter's length clause, in seed order (compacted on the GPU)
+        live, nr, nl, tw = ext.live_stats(min_length - k1)
         keep = accept_filter(live, nr, nl, tw, k1, min_length, min_weight)
     lap("ext.filter")
     csr = None                                         # (coff, cnb, cw): connections in dict insertion order, 1-based neighbours
