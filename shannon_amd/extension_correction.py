@@ -285,7 +285,7 @@ class ContigGraph(object):
             pass
 
 
-def accept_filter(live, nr, nl, tw, k1, min_length, min_weight):
+def accept_filter(live, nr, nl, tw, k1, min_length, min_weight, arrays=False):
     """The accept filter of the extension loop (extension_correction.py:361) over non-void walks: ranks + contig lengths of
     the walks that pass, in seed order."""
     length = k1 + nr.astype(np.int64) + nl.astype(np.int64)
@@ -303,6 +303,8 @@ def accept_filter(live, nr, nl, tw, k1, min_length, min_weight):
     for j in np.nonzero(maybe)[0].tolist():
         a = float(int(ctw[j])) / max(1, int(ckm[j]))
         sure[j] = int(clen[j]) * math.pow(a, 1 / 4.0) >= thr
+    if arrays:                                                 # (hundreds of thousands of candidates: no Python lists)
+        return cand[sure].astype(np.uint32), clen[sure].astype(np.int64)
     return list(zip(cand[sure].tolist(), clen[sure].tolist()))
 
 
@@ -506,21 +508,25 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     else:
         # non-void walks long enough for the accept filter's length clause, in seed order (compacted on the GPU)
         live, nr, nl, tw = ext.live_stats(min_length - k1)
-        keep = accept_filter(live, nr, nl, tw, k1, min_length, min_weight)
+        if gpu_contigs:
+            keep_r, keep_l = accept_filter(live, nr, nl, tw, k1, min_length, min_weight, arrays=True)
+            keep = None
+        else:
+            keep = accept_filter(live, nr, nl, tw, k1, min_length, min_weight)
     lap("ext.filter")
     csr = None                                         # (coff, cnb, cw): connections in dict insertion order, 1-based neighbours
     contigs = ["buffer"]
     conn = None
     sharded_contigs = False
     if gpu_contigs:
-        buf, offs = ext.emit_raw([x[0] for x in keep], [x[1] for x in keep]) if keep else (np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+        buf, offs = ext.emit_raw(keep_r, keep_l) if len(keep_r) else (np.zeros(0, np.uint8), np.zeros(1, np.uint64))
         lap("ext.emit")
         acc, _best, coff, cnb, cw = contig_stage_gpu(ctx, buf, offs, k1, r, f)
         csr = (coff, cnb, cw)
-        text = buf.tobytes().decode()
-        o = offs.tolist()
-        contigs += [text[o[i]:o[i + 1]] for i in np.nonzero(acc)[0].tolist()]
-        del text
+        raw = buf.tobytes()                                # (only the accepted tenth is ever turned into strings)
+        ai = np.nonzero(acc)[0]
+        contigs += [raw[a:b].decode() for a, b in zip(offs[ai].tolist(), offs[ai + 1].tolist())]
+        del raw
         strings = None
     else:
         strings = (ext.emit([x[0] for x in keep], [x[1] for x in keep]) if keep else []) if pipe is None else None
