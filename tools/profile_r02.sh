@@ -8,9 +8,9 @@ cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"; export TMPDIR=/tmp; O=gpurun_out/r0
 if [ -z "$SKIP_BENCH" ]; then python bench.py --steps 20 --warmup 5 > $O/bench_config2.json 2> $O/bench_config2.err; fi
 # (the profiled passes run the graph stage on one thread and one stream: rocprofv3 aborts when threads it has not seen create streams)
 export SHN_GRAPH_THREADS=1 SHN_GRAPH_FORK=0
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 > $O/kt.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 > $O/pf.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 > $O/pw.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- python3 bench.py --no-cpu-baseline --overlap-steps 0 --steps 2 --warmup 1 > $O/kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 bench.py --no-cpu-baseline --overlap-steps 0 --steps 1 --warmup 0 > $O/pf.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 bench.py --no-cpu-baseline --overlap-steps 0 --steps 1 --warmup 0 > $O/pw.log 2>&1
 find $O -name "*kernel_trace.csv" -size +20M -delete          # keep stats + counters, drop bulky traces
 find $O -name "*.csv" | head -20
 tail -c 600 $O/bench_config2.json
