@@ -403,7 +403,9 @@ __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
           CONSIDER(0) CONSIDER(2) CONSIDER(1) CONSIDER(3)
 #undef CONSIDER
           if (best < 0) break;
-          uint32_t nbest = (uint32_t)cand.v[best];
+          // (selected with compares, not indexed: a run-time index puts the rows into scratch memory -- 96 bytes per lane of private
+          // memory traffic on every step)
+          uint32_t nbest = (uint32_t)(best == 0 ? cand.v[0] : best == 1 ? cand.v[1] : best == 2 ? cand.v[2] : cand.v[3]);
           pos++;
           claim_node(A, nbest, r, pos);
           steps++;
@@ -415,7 +417,8 @@ __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
             promoted = true;
             break;
           }
-          cand = best == 0 ? nxt[0] : best == 1 ? nxt[1] : best == 2 ? nxt[2] : nxt[3];
+#pragma unroll
+          for (int q = 0; q < 4; q++) cand.v[q] = best == 0 ? nxt[0].v[q] : best == 1 ? nxt[1].v[q] : best == 2 ? nxt[2].v[q] : nxt[3].v[q];   // (word by word: a select between structs goes through memory)
         }
         if (dir == 0) nr = steps; else nl = steps;
         if (promoted) break;
