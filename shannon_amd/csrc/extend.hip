@@ -287,6 +287,9 @@ __global__ void ext_weightkey_kernel(const uint32_t* __restrict__ svals, const u
 }
 
 struct Adj4 { int32_t v[4]; };
+// entry b of a row, b known only at run time: picked with compares (an indexed access makes the compiler keep the row in
+// scratch memory)
+__device__ __forceinline__ int32_t adj_get(const Adj4& a, int b) { return b == 0 ? a.v[0] : b == 1 ? a.v[1] : b == 2 ? a.v[2] : a.v[3]; }
 #define CHUNK_SHIFT 6
 
 struct WalkArgs {
@@ -461,8 +464,9 @@ struct MemoCursor { int64_t i; int32_t step; bool term; };
 // took), term = the segment ends where that walk ended (then "stop" is the expected decision at its mark)
 
 // `node` was just reached going in direction dir; its hint says where it sits in some memo: follow that memo
-__device__ __forceinline__ bool memo_follow(const WalkArgs& A, uint32_t hh, uint32_t node, int dir, MemoCursor& mc, uint32_t* why = nullptr) {
-#define WHY(i) do { if (A.dbg && threadIdx.x == 0) atomicAdd(&A.dbg[i], 1ULL); if (why) why[i]++; } while (0)
+struct WhyStat { uint32_t c2 = 0, c4 = 0, c5 = 0, c7 = 0; };      // (named fields, not an array: an array whose address is passed on lives in scratch)
+__device__ __forceinline__ bool memo_follow(const WalkArgs& A, uint32_t hh, uint32_t node, int dir, MemoCursor& mc, WhyStat* why = nullptr) {
+#define WHY(i) do { if (A.dbg && threadIdx.x == 0) atomicAdd(&A.dbg[i], 1ULL); if (why) why->c##i++; } while (0)
   if (hh == NOHINT) { WHY(2); return false; }                     // never written into a memo
   const int64_t idx = (int64_t)(hh >> 2);
   const uint32_t kind = hh & 3u;
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
   }
   const uint32_t ns_start = ns;
   uint32_t nseq = 0;                          // sequential steps (debug statistics)
-  uint32_t why[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  WhyStat why;
   for (int dir = dir0; dir < 2; dir++) {
     const Adj4* adj = dir == 0 ? A.adjR : A.adjL;
     uint32_t cur = (RESUME && dir == dir0) ? cur0 : o;
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
             Adj4 cd = adj[before];
             uint32_t bw;
             int b = decide(cd, r, A.claim, A.claim_old, A.weight, o, bw);
-            uint32_t chosen = b < 0 ? NONE32 : (uint32_t)cd.v[b];
+            uint32_t chosen = b < 0 ? NONE32 : (uint32_t)adj_get(cd, b);
             ok = chosen == (is_term ? NONE32 : mine);
           }
         }
@@ -610,13 +614,13 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
       nseq++;
       cur = taken;
       if (cool) cool--;
-      else following = memo_follow(A, hh, taken, dir, mc, why);
+      else following = memo_follow(A, hh, taken, dir, mc, &why);
     }
     if (dir == 0) nr_new = ns;
   }
   if (A.dbg && lane == 0) {
-    atomicMax(&A.dbg[10], ((unsigned long long)nseq << 48) | ((unsigned long long)min(why[2], 4095u) << 36) | ((unsigned long long)min(why[3], 4095u) << 24) |
-                              ((unsigned long long)min(why[4], 4095u) << 12) | (unsigned long long)min(why[7], 4095u));
+    atomicMax(&A.dbg[10], ((unsigned long long)nseq << 48) | ((unsigned long long)min(why.c2, 4095u) << 36) |
+                              ((unsigned long long)min(why.c4, 4095u) << 12) | (unsigned long long)min(why.c7, 4095u));
     atomicMax(&A.dbg[11], (unsigned long long)(ns - ns_start));
   }
   if (lane == 0) {
@@ -661,7 +665,7 @@ __global__ void ext_audit_nodes_kernel(const u64* __restrict__ claim, uint64_t n
         else {
           const Adj4 cd = right ? adjR[x] : adjL[x];
           const int b = audit_decide(cd, r, p - 1, claim, weight);
-          bad = b < 0 || cd.v[b] != (int32_t)y;
+          bad = b < 0 || adj_get(cd, b) != (int32_t)y;
         }
       }
       if (!bad && p == nr) bad = audit_decide(adjR[y], r, nr, claim, weight) >= 0;                      // right end
@@ -707,6 +711,7 @@ __global__ void ext_audit_kernel(WalkArgs A, uint64_t ns, unsigned long long* __
         Adj4 cd = adj[cur];
         int best = -1;
         uint32_t bw = 0;
+#pragma unroll
         for (int bi = 0; bi < 4; bi++) {
           const int b = bi == 0 ? 0 : bi == 1 ? 2 : bi == 2 ? 1 : 3;
           if (cd.v[b] < 0) continue;
@@ -717,7 +722,7 @@ __global__ void ext_audit_kernel(WalkArgs A, uint64_t ns, unsigned long long* __
         }
         if (best < 0) { if (pos != end) bad = true; break; }
         if (pos == end) { bad = true; break; }                // the recorded walk stopped, the rule goes on
-        const uint32_t nx = (uint32_t)cd.v[best];
+        const uint32_t nx = (uint32_t)adj_get(cd, best);
         if (A.claim[nx] != CLAIM(r, pos + 1)) { bad = true; break; }
         pos++; tot += bw; cur = nx;
       }
@@ -886,7 +891,7 @@ __global__ void ext_mark_kernel(const u64* __restrict__ claim, u64* claim_old, u
       const uint32_t next_pos = dirR ? pos + 1 : (pos == 0 ? nrz + 1 : pos + 1);
       const Adj4 cd = dirR ? adjR[nb] : adjL[nb];
       const int bsel = audit_decide(cd, z, thr, claim, weight);
-      const bool same = has_next ? (bsel >= 0 && claim[cd.v[bsel]] == CLAIM(z, next_pos)) : bsel < 0;
+      const bool same = has_next ? (bsel >= 0 && claim[adj_get(cd, bsel)] == CLAIM(z, next_pos)) : bsel < 0;
       if (!same) dirty[z] = 1;
     }
 #undef MARKX
