@@ -125,13 +125,45 @@ __global__ void ext_adjacency_kernel(const uint64_t* __restrict__ tkeys, const u
   }
 }
 
+// ---- a 64-byte record per bucket in front of the table for the adjacency build: { first key index << 20 | keys, 7 separators }
+// (separator i = the key at position ((i + 1) n) / 8 of the bucket).  A look-up reads the record (one sector), counts the
+// separators <= key and bisects the eighth of the bucket they point at (~11 keys of a ~90-key bucket: 1-2 sectors) -- two
+// dependent round trips and 2-3 sectors instead of eight and ~5; the build is bound by exactly those (5.8 G look-ups, 2.9 TB/s of
+// sector fetches at configs[2]).
+__global__ void ext_bucket_index_kernel(const uint64_t* __restrict__ tkeys, const uint64_t* __restrict__ boff, uint64_t n_buckets,
+                                        unsigned long long* __restrict__ recs, uint32_t* __restrict__ too_big) {
+  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_buckets) return;
+  const uint64_t lo = boff[b], n = boff[b + 1] - lo;
+  if (n >= (1ULL << 20)) { atomicExch(too_big, 1u); return; }
+  unsigned long long* r = recs + b * 8;
+  r[0] = (lo << 20) | n;
+  for (uint64_t i = 0; i < 7; i++) r[1 + i] = n ? tkeys[lo + ((i + 1) * n) / 8] : ~0ULL;
+}
+__device__ __forceinline__ int64_t ext_find_indexed(const uint64_t* __restrict__ tkeys, const unsigned long long* __restrict__ recs, int bits,
+                                                    uint64_t key) {
+  const ulonglong2* r = (const ulonglong2*)(recs + (uint64_t)shn_bucket_of(key, bits) * 8);
+  const ulonglong2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+  const uint64_t lo = r0.x >> 20, n = r0.x & 0xFFFFFULL;
+  if (!n) return -1;
+  const uint32_t j = (uint32_t)(key >= r0.y) + (key >= r1.x) + (key >= r1.y) + (key >= r2.x) + (key >= r2.y) + (key >= r3.x) + (key >= r3.y);
+  uint64_t a = lo + ((uint64_t)j * n) / 8, e = lo + ((uint64_t)(j + 1) * n) / 8;
+  while (a < e) {
+    const uint64_t mid = (a + e) >> 1;
+    const uint64_t v = tkeys[mid];
+    if (v == key) return (int64_t)mid;
+    if (v < key) a = mid + 1; else e = mid;
+  }
+  return -1;
+}
+
 // Both rows of both orientations from 8 look-ups per canonical k1-mer instead of 16: the right candidates of the reverse-
 // complement orientation are the reverse complements of the forward orientation's left candidates (rc(s)[1:] + b = rc(comp(b) +
 // s[:-1])) and vice versa -- the same table entry j, the other orientation (the same one if entry j is its own reverse
 // complement).  One thread per (canonical k1-mer, dir, base).
 __global__ void ext_adjacency_half_kernel(const uint64_t* __restrict__ tkeys, const uint64_t* __restrict__ boff, int bits,
                                           const uint8_t* __restrict__ flags, uint64_t n, int k, int canonical,
-                                          int32_t* __restrict__ adjR, int32_t* __restrict__ adjL) {
+                                          int32_t* __restrict__ adjR, int32_t* __restrict__ adjL, const unsigned long long* __restrict__ recs) {
   const uint64_t total = n * 8;
   const uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
   for (uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (uint64_t)gridDim.x * blockDim.x) {
@@ -148,7 +180,7 @@ __global__ void ext_adjacency_half_kernel(const uint64_t* __restrict__ tkeys, co
       uint64_t canon = nb;
       uint32_t strand = 0;
       if (canonical) { const uint64_t rc = shn_revcomp(nb, k); if (rc < nb) { canon = rc; strand = 1; } }
-      const int64_t j = shn_table_find(tkeys, boff, bits, canon);
+      const int64_t j = recs ? ext_find_indexed(tkeys, recs, bits, canon) : shn_table_find(tkeys, boff, bits, canon);
       if (j >= 0) {
         const uint8_t fj = flags[j];
         if (!(fj & 2)) {
@@ -1129,9 +1161,24 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     if (getenv("SHN_EXT_ADJ_FULL"))                 // (development: all 16 look-ups per k1-mer)
       hipLaunchKernelGGL(ext_adjacency_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 16, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off,
                          t->bits, e->d_flags, n, t->k, t->canonical, e->d_adjR, e->d_adjL);
-    else
+    else {
+      // large tables: a separator record per bucket first (see ext_find_indexed); SHN_EXT_BUCKET_INDEX=0 / 1 forbids / forces it
+      unsigned long long* recs = nullptr;
+      uint32_t* d_big = nullptr;
+      const char* bi = getenv("SHN_EXT_BUCKET_INDEX");
+      const bool want_index = bi ? bi[0] != '0' : (n >= (1ULL << 24) && n / t->n_buckets >= 24);
+      if (want_index && shn_dev_malloc(&recs, t->n_buckets * 64) == hipSuccess && shn_dev_malloc(&d_big, 64) == hipSuccess) {
+        TRYE(hipMemsetAsync(d_big, 0, 4, s));
+        hipLaunchKernelGGL(ext_bucket_index_kernel, dim3((uint32_t)cdiv(t->n_buckets, 256)), dim3(256), 0, s, t->d_keys, t->d_bucket_off, t->n_buckets, recs, d_big);
+        uint32_t big = 0;
+        TRYE(hipMemcpyAsync(&big, d_big, 4, hipMemcpyDeviceToHost, s));
+        TRYE(hipStreamSynchronize(s));
+        if (big) { shn_dev_free(recs); recs = nullptr; }
+      } else if (recs) { shn_dev_free(recs); recs = nullptr; }
       hipLaunchKernelGGL(ext_adjacency_half_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off,
-                         t->bits, e->d_flags, n, t->k, t->canonical, e->d_adjR, e->d_adjL);
+                         t->bits, e->d_flags, n, t->k, t->canonical, e->d_adjR, e->d_adjL, (const unsigned long long*)recs);
+      if (recs || d_big) { TRYE(hipStreamSynchronize(s)); shn_dev_free(recs); shn_dev_free(d_big); }
+    }
     TRYE(hipGetLastError());
   }
   // seeds: compact, sort by string then (stable) by weight descending
