@@ -16,8 +16,8 @@
 #include <cstring>
 
 #define BLK 256
-#define CAP 2048            // LDS hash slots per final bucket
-#define CAP_LIMIT 1900      // distinct keys per bucket before we call it overflow
+#define CAP 1024            // LDS hash slots per final bucket (2048: 48 KB of LDS per block = 3 blocks per CU; 1024: 6)
+#define CAP_LIMIT 950       // distinct keys per bucket before we call it overflow
 #define TARGET_BUCKET 640   // average windows per final bucket
 #define TILE_IDS 65536      // window ids per block tile in hist1/scatter1
 #define TILE_KEYS 32768     // keys per block tile in hist2/scatter2
@@ -715,9 +715,9 @@ static int count_views(shn_ctx* ctx, const std::vector<ReadsView>& views, uint64
         for (uint32_t rg : regs) { z += std::ldexp(1.0, -(int)rg); zeros += rg == 0; }
         double est = (0.7213 / (1.0 + 1.079 / m)) * m * m / z;
         if (est < 2.5 * m && zeros) est = m * std::log(m / (double)zeros);       // small-range correction
-        // ~600 distinct keys per bucket (a bucket's LDS table takes CAP_LIMIT = 1900), 25 % head room on the
+        // ~300 distinct keys per bucket (a bucket's LDS table takes CAP_LIMIT = 950), 25 % head room on the
         // estimate; never more buckets than the all-distinct rule gives, never fewer than 2^10 when there is work
-        const double want = est * 1.25 / 600.0;
+        const double want = est * 1.25 / 300.0;
         bits = 0;
         while (bits < bits_n && (double)(1ULL << bits) < want) bits++;
         if (upper > (1ULL << 20)) bits = std::max(bits, std::min(bits_n, 10));
