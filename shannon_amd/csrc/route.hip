@@ -64,10 +64,19 @@ __global__ __launch_bounds__(RBLK) void route_kernel(RView a, RView b, int paire
                                                      const uint32_t* __restrict__ tvals, const uint64_t* __restrict__ boff, int bits,
                                                      const uint32_t* __restrict__ set_off, const uint32_t* __restrict__ set_mem,
                                                      uint32_t* __restrict__ counts, const uint64_t* __restrict__ offs,
-                                                     uint64_t* __restrict__ out, uint32_t* __restrict__ overflow) {
+                                                     uint64_t* __restrict__ out, uint32_t* __restrict__ overflow, uint2* __restrict__ first2) {
   uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t N = a.n;
   if (d >= 2 * N) return;
+  // the counting pass leaves the first two partitions of every pair behind: the filling pass probes again only for the pairs
+  // that hit more (nearly every pair hits one partition or none; the probes are the cost of this kernel)
+  if (FILL && first2) {
+    const uint32_t n = counts[d];
+    if (n <= 2) {
+      if (n) { const uint2 f = first2[d]; const uint64_t o = offs[d]; out[o] = ((uint64_t)f.x << 32) | (uint64_t)(uint32_t)d; if (n > 1) out[o + 1] = ((uint64_t)f.y << 32) | (uint64_t)(uint32_t)d; }
+      return;
+    }
+  }
   uint32_t loc[MAXP];
   int nloc = 0;
   bool second = d >= N;
@@ -84,7 +93,7 @@ __global__ __launch_bounds__(RBLK) void route_kernel(RView a, RView b, int paire
       nloc = collect(src, i, !second, k, tkeys, tvals, boff, bits, set_off, set_mem, loc, nloc, overflow);  // mate 2
     }
   }
-  if (!FILL) { counts[d] = (uint32_t)nloc; return; }
+  if (!FILL) { counts[d] = (uint32_t)nloc; if (first2) first2[d] = make_uint2(nloc > 0 ? loc[0] : 0u, nloc > 1 ? loc[1] : 0u); return; }
   uint64_t o = offs[d];
   for (int q = 0; q < nloc; q++) out[o + q] = ((uint64_t)loc[q] << 32) | (uint64_t)(uint32_t)d;
 }
@@ -198,8 +207,10 @@ extern "C" int shn_route_reads(shn_ctx* ctx, const shn_reads* r1, const shn_read
   R->device = ctx->device;
   if (N2 == 0) { *out = R; return SHN_OK; }
   uint32_t grid = (uint32_t)cdiv(N2, RBLK);
+  void* pf2 = nullptr;
+  uint2* d_first2 = g_shn_ws[30].get((N2 + 1) * 8, &pf2) == 0 ? (uint2*)pf2 : nullptr;          // (without it the second pass probes again)
   hipLaunchKernelGGL(route_kernel<false>, dim3(grid), dim3(RBLK), 0, s, a, b, r2 ? 1 : 0, k1, probe->d_keys, probe->d_counts,
-                     probe->d_bucket_off, probe->bits, d_so, d_sm, (uint32_t*)pcnt, nullptr, nullptr, d_ovf);
+                     probe->d_bucket_off, probe->bits, d_so, d_sm, (uint32_t*)pcnt, nullptr, nullptr, d_ovf, d_first2);
   uint64_t total = 0;
   if ((rc = shn_device_scan_u32(ctx, (uint32_t*)pcnt, N2, (uint64_t*)poff, &total))) { delete R; return rc; }
   uint32_t ovf = 0;
@@ -213,7 +224,7 @@ extern "C" int shn_route_reads(shn_ctx* ctx, const shn_reads* r1, const shn_read
       (rc = g_shn_ws[10].get((total + 2) * 4, &pv)) || (rc = g_shn_ws[12].get((total + 2) * 4, &pv2))) { delete R; return rc; }
   if (total) {
     hipLaunchKernelGGL(route_kernel<true>, dim3(grid), dim3(RBLK), 0, s, a, b, r2 ? 1 : 0, k1, probe->d_keys, probe->d_counts,
-                       probe->d_bucket_off, probe->bits, d_so, d_sm, nullptr, (const uint64_t*)poff, (uint64_t*)pk, d_ovf);
+                       probe->d_bucket_off, probe->bits, d_so, d_sm, (uint32_t*)pcnt, (const uint64_t*)poff, (uint64_t*)pk, d_ovf, d_first2);
     // pairs were written in doubled-read order; a stable sort on the partition id keeps that order
     HIP_TRY(hipMemsetAsync(pv, 0, total * 4, s));
     int pbits = 1;
