@@ -229,10 +229,11 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
         start, below = routes.bounds(len(names), len(reads1))
         by_part = {n: RouteView(routes, start[i], start[i + 1] - start[i], below[i]) for i, n in enumerate(names)}
     else:
-        pid, ridx = routes.download()
+        # (the partition column is not fetched: the routes are sorted by partition and the device knows where each one starts)
+        start, _below = routes.bounds(len(names), len(reads1))
+        ridx = routes.download_range(0, int(start[len(names)]))
         routes.close()
-        bounds = np.searchsorted(pid, np.arange(len(names) + 1))
-        by_part = {n: ridx[bounds[i]:bounds[i + 1]] for i, n in enumerate(names)}
+        by_part = {n: ridx[int(start[i]):int(start[i + 1])] for i, n in enumerate(names)}
     lap("route.download")
     return _finish_partitions(res, comps, broken, names, by_part, files, cw, k1, K, want_rows, lazy_graph_inputs, lap)
 
