@@ -17,7 +17,7 @@ extern "C" const char* shn_version(void) { return "shannon_hip 0.1.0 (gfx950)"; 
 static const char* kTimerNames[T_N] = {
   "pack", "count.hist1", "count.scatter1", "count.hist2", "count.scatter2", "count.buckets", "count.compact",
   "count.total", "table.lookup", "extend", "route", "graph", "lp", "extend.prepare", "extend.sort", "extend.walk", "graph.seeds",
-  "extend.walk_thread", "extend.walk_wave", "extend.mark", "extend.emit", "table.build", "count.direct", "contig.stage", "graph.unitigs"};
+  "extend.walk_thread", "extend.walk_wave", "extend.mark", "extend.emit", "table.build", "count.direct", "contig.stage", "graph.unitigs", "extend.adjacency"};
 extern "C" const char* shn_timer_name(int slot) {
   if (slot < 0 || slot >= T_N || !kTimerNames[slot]) return "";
   return kTimerNames[slot];

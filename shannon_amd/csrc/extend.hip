@@ -1175,8 +1175,9 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
         TRYE(hipStreamSynchronize(s));
         if (big) { shn_dev_free(recs); recs = nullptr; }
       } else if (recs) { shn_dev_free(recs); recs = nullptr; }
-      hipLaunchKernelGGL(ext_adjacency_half_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off,
-                         t->bits, e->d_flags, n, t->k, t->canonical, e->d_adjR, e->d_adjL, (const unsigned long long*)recs);
+      { TimerRegion ta(ctx, T_EXT_ADJ);                  // (one launch: bench.py's roofline entry for this kernel)
+        hipLaunchKernelGGL(ext_adjacency_half_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off,
+                           t->bits, e->d_flags, n, t->k, t->canonical, e->d_adjR, e->d_adjL, (const unsigned long long*)recs); }
       if (recs || d_big) { TRYE(hipStreamSynchronize(s)); shn_dev_free(recs); shn_dev_free(d_big); }
     }
     TRYE(hipGetLastError());
