@@ -101,7 +101,8 @@ def test_cli_samples_pe(tmp_path):
     assert (out / "log.txt").exists()
 
 
-def test_graph_reads_gathered_on_the_device_equal_uploaded_text(ctx, monkeypatch):
+@pytest.mark.parametrize("K", [25, 31])
+def test_graph_reads_gathered_on_the_device_equal_uploaded_text(ctx, monkeypatch, K):
     """With code-matrix input the graph stage builds the device copy of a partition's distinct reads by gathering rows of the
     resident packed input (shn_reads_gather, reverse complements on chip) instead of uploading their text: same graphs, same
     transcripts -- paired and single-end, several partitions."""
@@ -120,7 +121,7 @@ def test_graph_reads_gathered_on_the_device_equal_uploaded_text(ctx, monkeypatch
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
-            R = pipeline.assemble(ctx, r1, r2 if paired else None, K=25, partition_size=8, sample="s", seed=2)
+            R = pipeline.assemble(ctx, r1, r2 if paired else None, K=K, partition_size=8, sample="s", seed=2)
             outs.append(R)
         a = outs[0]
         for b in outs[1:]:
