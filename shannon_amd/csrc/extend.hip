@@ -836,14 +836,17 @@ __global__ void ext_memo_plan_kernel(uint8_t* __restrict__ ran, uint8_t* __restr
 // start of a round: snapshot the claims, drop the claims of the walks that are about to re-run, clear the round's counters
 // (copy == 0: the snapshot is already the claims -- ext_mark_kernel brought it up to date where the last round changed something)
 __global__ void ext_round_begin_kernel(u64* __restrict__ claim, u64* __restrict__ snap, uint64_t n2, const uint8_t* __restrict__ dirty,
-                                       uint64_t ns, unsigned long long* __restrict__ d_cnt, int copy, uint8_t* __restrict__ chunk) {
+                                       uint64_t ns, unsigned long long* __restrict__ d_cnt, int copy, uint8_t* __restrict__ chunk,
+                                       uint32_t frozen, uint32_t limit) {
   uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (o == 0) { d_cnt[6] = 0; d_cnt[7] = 0; d_cnt[13] = 0; }      // changed k1-mers, (spare), walks handed over
   if (o >= n2) return;
   const u64 c = claim[o];
   if (copy) snap[o] = c;
   const uint32_t rk = RANK(c);
-  if (rk != UNCLAIMED && rk < ns && dirty[rk]) { claim[o] = UNCLAIMED64; if (chunk) chunk[o >> CHUNK_SHIFT] = 1; }
+  // (only walks of the open block can be dirty: the flag of a final walk's k1-mer -- most claimed k1-mers in the later blocks --
+  // is not looked up: a random byte read per claimed k1-mer otherwise)
+  if (rk >= frozen && rk < limit && rk < ns && dirty[rk]) { claim[o] = UNCLAIMED64; if (chunk) chunk[o >> CHUNK_SHIFT] = 1; }
 }
 
 // after a round: every k1-mer whose owner changed dirties the walks that looked at it; the k1-mers of the walks
@@ -1350,7 +1353,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     TimerRegion t3(ctx, T_EXT_WALK);
     // snapshot, then release the claims of the walks that re-run this round
     hipLaunchKernelGGL(ext_round_begin_kernel, dim3(g2n), dim3(256), 0, s, claim, snap, 2 * n, dirty, (uint64_t)ns, d_cnt,
-                       (!precise_marks || !snap_current) ? 1 : 0, bulk ? (uint8_t*)nullptr : chunk);
+                       (!precise_marks || !snap_current) ? 1 : 0, bulk ? (uint8_t*)nullptr : chunk, frozen, limit);
     snap_current = true;
     WalkArgs A;
     A.order = e->d_order; A.adjR = (const Adj4*)e->d_adjR; A.adjL = (const Adj4*)e->d_adjL; A.weight = e->d_weight;
