@@ -157,13 +157,36 @@ __device__ __forceinline__ int64_t ext_find_indexed(const uint64_t* __restrict__
   return -1;
 }
 
+// ---- and a blocked Bloom filter in front of that: ~70 % of the look-ups of the adjacency build miss (a k1-mer has 8 possible
+// neighbours and typically 2), and a miss costs the record and the keys (2-3 sectors) like a hit.  One 64-bit word per key,
+// three bits in it, 16 bits of filter per key: a miss is one 8-byte load with probability ~0.99.
+__device__ __forceinline__ void bloom_pos(uint64_t key, uint64_t n_words, uint64_t& word, unsigned long long& mask) {
+  const uint64_t h = shn_mix64(key ^ 0x51A7C0DE5EEDULL);
+  word = (h >> 24) % n_words;
+  mask = (1ULL << (h & 63)) | (1ULL << ((h >> 6) & 63)) | (1ULL << ((h >> 12) & 63));
+}
+__global__ void ext_bloom_build_kernel(const uint64_t* __restrict__ tkeys, const uint8_t* __restrict__ flags, uint64_t n,
+                                       unsigned long long* __restrict__ bits, uint64_t n_words) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || (flags[i] & 2)) return;
+  uint64_t word; unsigned long long mask;
+  bloom_pos(tkeys[i], n_words, word, mask);
+  atomicOr(&bits[word], mask);                                   // (the three bits of a key share one word: one atomic per key)
+}
+__device__ __forceinline__ bool bloom_may_have(const unsigned long long* __restrict__ bits, uint64_t n_words, uint64_t key) {
+  uint64_t word; unsigned long long mask;
+  bloom_pos(key, n_words, word, mask);
+  return (bits[word] & mask) == mask;
+}
+
 // Both rows of both orientations from 8 look-ups per canonical k1-mer instead of 16: the right candidates of the reverse-
 // complement orientation are the reverse complements of the forward orientation's left candidates (rc(s)[1:] + b = rc(comp(b) +
 // s[:-1])) and vice versa -- the same table entry j, the other orientation (the same one if entry j is its own reverse
 // complement).  One thread per (canonical k1-mer, dir, base).
 __global__ void ext_adjacency_half_kernel(const uint64_t* __restrict__ tkeys, const uint64_t* __restrict__ boff, int bits,
                                           const uint8_t* __restrict__ flags, uint64_t n, int k, int canonical,
-                                          int32_t* __restrict__ adjR, int32_t* __restrict__ adjL, const unsigned long long* __restrict__ recs) {
+                                          int32_t* __restrict__ adjR, int32_t* __restrict__ adjL, const unsigned long long* __restrict__ recs,
+                                          const unsigned long long* __restrict__ bloom, uint64_t bloom_blocks) {
   const uint64_t total = n * 8;
   const uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
   for (uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (uint64_t)gridDim.x * blockDim.x) {
@@ -180,7 +203,8 @@ __global__ void ext_adjacency_half_kernel(const uint64_t* __restrict__ tkeys, co
       uint64_t canon = nb;
       uint32_t strand = 0;
       if (canonical) { const uint64_t rc = shn_revcomp(nb, k); if (rc < nb) { canon = rc; strand = 1; } }
-      const int64_t j = recs ? ext_find_indexed(tkeys, recs, bits, canon) : shn_table_find(tkeys, boff, bits, canon);
+      const int64_t j = (bloom && !bloom_may_have(bloom, bloom_blocks, canon)) ? -1
+                        : recs ? ext_find_indexed(tkeys, recs, bits, canon) : shn_table_find(tkeys, boff, bits, canon);
       if (j >= 0) {
         const uint8_t fj = flags[j];
         if (!(fj & 2)) {
@@ -1178,10 +1202,17 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
         TRYE(hipStreamSynchronize(s));
         if (big) { shn_dev_free(recs); recs = nullptr; }
       } else if (recs) { shn_dev_free(recs); recs = nullptr; }
+      unsigned long long* bloom = nullptr;
+      const uint64_t bloom_blocks = n / 4 + 1;             // 64-bit words: 16 bits per key
+      const char* bl = getenv("SHN_EXT_BLOOM");
+      if ((bl ? bl[0] != '0' : recs != nullptr) && shn_dev_malloc(&bloom, bloom_blocks * 8) == hipSuccess) {
+        TRYE(hipMemsetAsync(bloom, 0, bloom_blocks * 8, s));
+        hipLaunchKernelGGL(ext_bloom_build_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, e->d_flags, n, bloom, bloom_blocks);
+      }
       { TimerRegion ta(ctx, T_EXT_ADJ);                  // (one launch: bench.py's roofline entry for this kernel)
         hipLaunchKernelGGL(ext_adjacency_half_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off,
-                           t->bits, e->d_flags, n, t->k, t->canonical, e->d_adjR, e->d_adjL, (const unsigned long long*)recs); }
-      if (recs || d_big) { TRYE(hipStreamSynchronize(s)); shn_dev_free(recs); shn_dev_free(d_big); }
+                           t->bits, e->d_flags, n, t->k, t->canonical, e->d_adjR, e->d_adjL, (const unsigned long long*)recs, (const unsigned long long*)bloom, bloom_blocks); }
+      if (recs || d_big || bloom) { TRYE(hipStreamSynchronize(s)); shn_dev_free(recs); shn_dev_free(d_big); shn_dev_free(bloom); }
     }
     TRYE(hipGetLastError());
   }
