@@ -250,21 +250,59 @@ extern "C" int shn_post_finalize_bufs(const uint8_t* const* bufs, const uint64_t
   }
   const double tq0 = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }();
   std::unordered_map<SV, uint64_t> seen;
-  std::unordered_set<SV> contigs;
-  std::vector<std::string> rc_hold;
-  SV last;
-  std::string rcbuf;
   uint8_t comp[256];
   for (int c = 0; c < 256; c++) comp[c] = (uint8_t)c;
   comp['A'] = 'T'; comp['C'] = 'G'; comp['G'] = 'C'; comp['T'] = 'A';
+  auto revcomp_into = [&](SV cur, std::string& buf) {
+    buf.resize(cur.size());
+    const char* src = cur.data() + cur.size() - 1; char* dst = &buf[0];
+    for (size_t i = 0, m = cur.size(); i < m; i++) dst[i] = (char)comp[(uint8_t)src[-(ptrdiff_t)i]];
+  };
+  // lines first (one pass of memchr), then the hashes of every sequence line and of its reverse complement on host threads (the
+  // hashing of 60-150 MB of sequence was most of this function); the order-dependent part -- names, first-come dedup -- follows
+  // sequentially on the hashes
+  std::vector<SV> lines;
   for (auto& pc : pieces) {
-  const uint8_t* text = pc.first;
-  const uint64_t n_bytes = pc.second;
-  for (uint64_t p = 0; p < n_bytes;) {
-    const void* q = memchr(text + p, '\n', n_bytes - p);
-    const uint64_t e = q ? (uint64_t)((const uint8_t*)q - text) + 1 : n_bytes;
-    const SV line((const char*)text + p, e - p);
-    p = e;
+    const uint8_t* text = pc.first;
+    const uint64_t n_bytes = pc.second;
+    for (uint64_t p = 0; p < n_bytes;) {
+      const void* q = memchr(text + p, '\n', n_bytes - p);
+      const uint64_t e = q ? (uint64_t)((const uint8_t*)q - text) + 1 : n_bytes;
+      lines.push_back(SV((const char*)text + p, e - p));
+      p = e;
+    }
+  }
+  std::vector<uint64_t> hf(lines.size(), 0), hr(lines.size(), 0);
+  {
+    const unsigned nt = lines.size() < 2048 ? 1 : (unsigned)std::max(1, std::min(16, shn_host_cpus()));
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+      std::string buf;
+      for (size_t i0; (i0 = next.fetch_add(256)) < lines.size();)
+        for (size_t i = i0; i < std::min(lines.size(), i0 + 256); i++) {
+          const SV line = lines[i];
+          size_t a = 0;
+          while (a < line.size() && is_ws((uint8_t)line[a])) a++;
+          if (a == line.size() || line[a] == '>' || line.size() <= 200) continue;
+          const SV cur = strip(line);
+          hf[i] = StringInterner::hash(cur.data(), cur.size());
+          if (ds) { revcomp_into(cur, buf); hr[i] = StringInterner::hash(buf.data(), buf.size()); }
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+  }
+  struct HKey { SV sv; uint64_t h; };
+  struct HHash { size_t operator()(const HKey& k) const { return (size_t)k.h; } };
+  struct HEq { bool operator()(const HKey& a, const HKey& b) const { return a.sv == b.sv; } };
+  std::unordered_set<HKey, HHash, HEq> contigs;
+  std::unordered_set<uint64_t> contig_hashes;           // (a reverse complement is only written out when its hash has been seen)
+  SV last;
+  std::string rcbuf;
+  for (size_t li = 0; li < lines.size(); li++) {
+    const SV line = lines[li];
     // tok = line.split()
     size_t a = 0;
     while (a < line.size() && is_ws((uint8_t)line[a])) a++;
@@ -292,17 +330,15 @@ extern "C" int shn_post_finalize_bufs(const uint8_t* const* bufs, const uint64_t
       } else { seen.emplace(tok0, 1); last = line; }
     } else if (line.size() > 200) {
       const SV cur = strip(line);
-      if (contigs.count(cur)) continue;
-      if (ds) {
-        rcbuf.resize(cur.size());
-        { const char* src = cur.data() + cur.size() - 1; char* dst = &rcbuf[0];
-          for (size_t i = 0, m = cur.size(); i < m; i++) dst[i] = (char)comp[(uint8_t)src[-(ptrdiff_t)i]]; }
-        if (contigs.count(SV(rcbuf))) continue;
+      if (contigs.count(HKey{cur, hf[li]})) continue;
+      if (ds && contig_hashes.count(hr[li])) {
+        revcomp_into(cur, rcbuf);
+        if (contigs.count(HKey{SV(rcbuf), hr[li]})) continue;
       }
-      contigs.insert(cur);
+      contigs.insert(HKey{cur, hf[li]});
+      contig_hashes.insert(hf[li]);
       recs.push_back({last, line});
     }
-  }
   }
   const bool dbgp = getenv("SHN_DEBUG") != nullptr;
   auto nowp = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
