@@ -7,10 +7,12 @@
 // cover.  The sequential result is the only assignment acc[] with acc[c] = decide(c | acc[< c]).  Here the r-mers of ALL
 // candidates are sorted once on the GPU; candidates are taken in seed-order blocks, and inside a block the decisions are iterated
 // (all candidates of the block at once, against the frozen decisions of the earlier blocks and the tentative ones of the block)
-// until none changes -- the fixpoint of a block on top of a final prefix is the sequential result.  Per round: compact the
-// sorted entries of accepted candidates, every window of the block walks the accepted entries of its run and adds (candidate,
-// parent) hits to a pair table (count, last hit position), the best parent of a candidate is a 64-bit atomicMax over its pairs,
-// a second pass marks the windows that hit it, coverage is summed per candidate.  Variants of a highly expressed transcript
+// until none changes -- the fixpoint of a block on top of a final prefix is the sequential result.  Per block: the index of the
+// block = the sorted entries of the accepted earlier candidates and of all the block's own (a look-up skips the block's candidates
+// that are not accepted at the moment).  Per round: every window of the block walks the entries of its run before it and adds
+// (candidate, parent) hits to a pair table (count, last hit position), the best parent of a candidate is a 64-bit atomicMax over
+// its pairs, a second pass marks the windows that hit it, coverage is summed per candidate.  After a block's first round only the
+// candidates behind a changed decision in one of their runs are evaluated again.  Variants of a highly expressed transcript
 // come long after it in the seed order (their weight is the error rate times its weight), so they meet it frozen and fall in
 // their block's first round.
 // contig_connections: the K-mers of the accepted contigs are sorted on the GPU; only K-mers occurring in two different
@@ -63,13 +65,42 @@ __global__ void cg_keys_kernel(const uint8_t* __restrict__ bases, const uint32_t
 __global__ void cg_scid_kernel(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ cid, uint64_t n, uint32_t* __restrict__ scid) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) scid[i] = cid[vals[i]];
 }
-__global__ void cg_accflag_kernel(const uint32_t* __restrict__ scid, const uint8_t* __restrict__ acc, uint64_t n, uint32_t* __restrict__ flag) {
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) flag[i] = acc[scid[i]];
+// the index of a block [lo, hi): the entries of the accepted candidates before it (final) and ALL entries of the block's own
+// candidates (tentative: a look-up skips those whose candidate is not accepted at the moment) -- built once per block
+__global__ void cg_accflag_kernel(const uint32_t* __restrict__ scid, const uint8_t* __restrict__ acc, uint64_t n, uint32_t lo, uint32_t hi,
+                                  uint32_t* __restrict__ flag) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t c = scid[i];
+    flag[i] = c < lo ? acc[c] : c < hi ? 1u : 0u;
+  }
+}
+// rounds after a block's first: only the candidates that share an r-mer with an earlier candidate of the block whose decision
+// changed in the last round can come out differently (decide(c) reads the decisions of the candidates before c in c's runs and
+// nothing else) -- the entries of the changed candidates flag the candidates behind them in their runs
+__global__ void cg_affected_kernel(const uint64_t* __restrict__ akey, const uint32_t* __restrict__ acand, uint64_t na, uint32_t lo,
+                                   const uint8_t* __restrict__ chg, uint8_t* __restrict__ aff) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t d = acand[i];
+    if (d < lo || !chg[d]) continue;
+    const uint64_t key = akey[i];
+    for (uint64_t j = i + 1; j < na && akey[j] == key; j++) {
+      const uint32_t c = acand[j];
+      if (c != d) aff[c] = 1;
+    }
+  }
+}
+// the per-candidate state of the candidates evaluated this round back to zero
+__global__ void cg_clear_kernel(const uint8_t* __restrict__ aff, const uint32_t* __restrict__ cid, uint64_t g_lo, uint64_t g_hi, uint32_t lo, uint32_t hi,
+                                uint8_t* __restrict__ hit, unsigned long long* __restrict__ best, uint32_t* __restrict__ cov) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t g = g_lo + t; g < g_hi; g += stride) if (aff[cid[g]]) hit[g] = 0;
+  for (uint64_t c = lo + t; c < hi; c += stride) if (aff[c]) { best[c] = 0; cov[c] = 0; }
 }
 __global__ void cg_acc_compact_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ scid, const uint32_t* __restrict__ flag,
-                                      const uint64_t* __restrict__ apos, uint64_t n, uint64_t* __restrict__ akey, uint32_t* __restrict__ acand) {
+                                      const uint32_t* __restrict__ vals, const uint64_t* __restrict__ apos, uint64_t n, uint64_t* __restrict__ akey,
+                                      uint32_t* __restrict__ acand, uint32_t* __restrict__ aval) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-    if (flag[i]) { akey[apos[i]] = keys[i]; acand[apos[i]] = scid[i]; }
+    if (flag[i]) { akey[apos[i]] = keys[i]; acand[apos[i]] = scid[i]; aval[apos[i]] = vals[i]; }
 }
 
 // (candidate, parent) -> hit count and position of the last hit.  Open addressing; key = (c + 1) << 32 | p, 0 = empty.
@@ -85,19 +116,20 @@ __device__ __forceinline__ bool pair_add(PairSlot* __restrict__ tab, uint64_t ma
   }
   return false;
 }
-// every window of the open block [lo, hi): the accepted entries of its run that come before it are its hits (:250-259)
-__global__ void cg_hits_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ scid,
-                               const uint64_t* __restrict__ apos, uint64_t n, const uint64_t* __restrict__ off, uint32_t lo, uint32_t hi,
-                               const uint64_t* __restrict__ akey, const uint32_t* __restrict__ acand, PairSlot* __restrict__ tab, uint64_t mask,
-                               uint32_t* __restrict__ overflow) {
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t c = scid[i];
-    if (c < lo || c >= hi) continue;
-    const uint64_t key = keys[i];
-    const uint32_t pos = (uint32_t)(vals[i] - off[c]);
-    for (uint64_t j = apos[i]; j-- > 0 && akey[j] == key;) {
+// every window of the open block (an index entry of a candidate >= lo): the accepted entries of its run that come before it are its
+// hits (:250-259)
+__global__ void cg_hits_kernel(const uint64_t* __restrict__ akey, const uint32_t* __restrict__ acand, const uint32_t* __restrict__ aval, uint64_t na,
+                               const uint64_t* __restrict__ off, uint32_t lo, const uint8_t* __restrict__ acc, const uint8_t* __restrict__ aff,
+                               PairSlot* __restrict__ tab, uint64_t mask, uint32_t* __restrict__ overflow) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t c = acand[i];
+    if (c < lo || !aff[c]) continue;
+    const uint64_t key = akey[i];
+    const uint32_t pos = (uint32_t)(aval[i] - off[c]);
+    for (uint64_t j = i; j-- > 0 && akey[j] == key;) {
       const uint32_t p = acand[j];
       if (p == c) continue;                       // the candidate's own earlier windows (it is not in the index while it is checked)
+      if (p >= lo && !acc[p]) continue;           // a candidate of the block that is not accepted at the moment
       if (!pair_add(tab, mask, c, p, pos)) atomicOr(overflow, 1u);
     }
   }
@@ -115,42 +147,55 @@ __global__ void cg_best_kernel(const PairSlot* __restrict__ tab, uint64_t slots,
   }
 }
 // windows of the open block whose r-mer occurs in the candidate's best parent (:262-265)
-__global__ void cg_cover_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ scid,
-                                const uint64_t* __restrict__ apos, uint64_t n, uint32_t lo, uint32_t hi, const uint64_t* __restrict__ akey,
-                                const uint32_t* __restrict__ acand, const unsigned long long* __restrict__ best, uint8_t* __restrict__ hit) {
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t c = scid[i];
-    if (c < lo || c >= hi) continue;
+__global__ void cg_cover_kernel(const uint64_t* __restrict__ akey, const uint32_t* __restrict__ acand, const uint32_t* __restrict__ aval, uint64_t na,
+                                uint32_t lo, const unsigned long long* __restrict__ best, const uint8_t* __restrict__ aff, uint8_t* __restrict__ hit) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t c = acand[i];
+    if (c < lo || !aff[c]) continue;
     const unsigned long long b = best[c];
     if (!b) continue;
     const uint32_t bp = (uint32_t)(b & 0x1FFFFFu);
-    const uint64_t key = keys[i];
-    for (uint64_t j = apos[i]; j-- > 0 && akey[j] == key;)
-      if (acand[j] == bp) { hit[vals[i]] = 1; break; }
+    const uint64_t key = akey[i];
+    for (uint64_t j = i; j-- > 0 && akey[j] == key;)
+      if (acand[j] == bp) { hit[aval[i]] = 1; break; }
   }
 }
 // covered bases of a candidate = bases under at least one hit window (a[i:i+r] = 1, :264-265)
 __global__ void cg_covsum_kernel(const uint8_t* __restrict__ hit, const uint32_t* __restrict__ cid, const uint64_t* __restrict__ off,
-                                 uint64_t g_lo, uint64_t g_hi, int r, uint32_t* __restrict__ cov) {
-  for (uint64_t g = g_lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < g_hi; g += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t c = cid[g];
-    const uint64_t first = off[c];
+                                 uint64_t g_lo, uint64_t g_hi, int r, const uint8_t* __restrict__ aff, uint32_t* __restrict__ cov) {
+  // (every lane of a wavefront takes part in every trip: the 64 bases of a trip mostly belong to one candidate, whose count is
+  // then added once)
+  const uint64_t span = g_hi - g_lo, stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < ((span + stride - 1) / stride) * stride; t += stride) {
+    const uint64_t g = g_lo + t;
+    const bool live = t < span;
+    const uint32_t c = live ? cid[g] : 0xFFFFFFFFu;
     bool covered = false;
-    for (int d = 0; d < r && !covered; d++) { if (g < first + (uint64_t)d) break; covered = hit[g - d] != 0; }
-    if (covered) atomicAdd(&cov[c], 1u);
+    if (live && aff[c]) {
+      const uint64_t first = off[c];
+      for (int d = 0; d < r && !covered; d++) { if (g < first + (uint64_t)d) break; covered = hit[g - d] != 0; }
+    }
+    const uint32_t c0 = __builtin_amdgcn_readfirstlane(c);
+    if (__ballot(c != c0) == 0) {
+      const unsigned long long m = __ballot(covered);
+      if (m && (threadIdx.x & 63) == 0 && c0 != 0xFFFFFFFFu) atomicAdd(&cov[c0], (uint32_t)__popcll(m));
+    } else if (covered) atomicAdd(&cov[c], 1u);
   }
 }
 // new decisions of the block; counts the candidates whose decision changed
 __global__ void cg_decide_kernel(const unsigned long long* __restrict__ best, const uint32_t* __restrict__ cov, const uint64_t* __restrict__ off,
-                                 uint32_t lo, uint32_t hi, double f, uint8_t* __restrict__ acc, int32_t* __restrict__ best_count,
-                                 unsigned long long* __restrict__ n_changed) {
+                                 uint32_t lo, uint32_t hi, double f, const uint8_t* __restrict__ aff, uint8_t* __restrict__ acc,
+                                 uint8_t* __restrict__ chg, int32_t* __restrict__ best_count, unsigned long long* __restrict__ n_changed) {
   const uint32_t c = lo + blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= hi) return;
+  if (!aff[c]) { chg[c] = 0; return; }
   const uint32_t M = (uint32_t)(best[c] >> 42);
   const bool suspect = M > 0 && (double)cov[c] > f * (double)(off[c + 1] - off[c]);
   const uint8_t a = suspect ? 0 : 1;
   best_count[c] = (int32_t)M;
-  if (a != acc[c]) { acc[c] = a; atomicAdd(n_changed, 1ULL); }
+  const bool changed = a != acc[c];
+  chg[c] = changed ? 1 : 0;
+  if (changed) { acc[c] = a; atomicAdd(n_changed, 1ULL); }
 }
 
 // runs of equal keys that span two different contigs: flag every entry of such a run (the sort is stable and the
@@ -264,6 +309,11 @@ extern "C" int shn_contig_stage(shn_ctx* ctx, const uint8_t* bases, const uint64
     HIP_TRY(tmp.get(&d_flag, (nv + 1) * 4)); HIP_TRY(tmp.get(&d_acand, (nv + 1) * 4)); HIP_TRY(tmp.get(&d_cov, (n_cand + 1) * 4));
     HIP_TRY(tmp.get(&d_ovf, 64)); HIP_TRY(tmp.get(&d_apos, (nv + 2) * 8)); HIP_TRY(tmp.get(&d_akey, (nv + 1) * 8));
     HIP_TRY(tmp.get(&d_bestc, (n_cand + 1) * 4)); HIP_TRY(tmp.get(&d_best, (n_cand + 1) * 8)); HIP_TRY(tmp.get(&d_chg, 64));
+    uint8_t *d_aff, *d_chgf; uint32_t* d_aval;
+    HIP_TRY(tmp.get(&d_aval, (nv + 1) * 4));
+    HIP_TRY(tmp.get(&d_aff, n_cand + 1)); HIP_TRY(tmp.get(&d_chgf, n_cand + 1));
+    HIP_TRY(hipMemsetAsync(d_chgf, 0, n_cand + 1, s));
+    const bool incremental = !getenv("SHN_CONTIG_INCREMENTAL") || atoi(getenv("SHN_CONTIG_INCREMENTAL")) != 0;
     HIP_TRY(hipMemsetAsync(d_acc, 0, n_cand + 1, s));
     HIP_TRY(hipMemsetAsync(d_bestc, 0, (n_cand + 1) * 4, s));
     if (nv) hipLaunchKernelGGL(cg_scid_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, vals, d_cid, nv, d_scid);
@@ -279,24 +329,32 @@ extern "C" int shn_contig_stage(shn_ctx* ctx, const uint8_t* bases, const uint64
       uint64_t hi = std::min<uint64_t>(n_cand, lo + bsize);
       // the candidates of the block start as "not accepted": the first round meets the frozen earlier blocks only
       int round = 0;
+      uint64_t na = 0;
+      if (nv) {
+        hipLaunchKernelGGL(cg_accflag_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, d_scid, d_acc, nv, (uint32_t)lo, (uint32_t)hi, d_flag);
+        if ((rc = shn_device_scan_u32(ctx, d_flag, nv, d_apos, &na))) return rc;
+        if (na) hipLaunchKernelGGL(cg_acc_compact_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, keys, d_scid, d_flag, vals, d_apos, nv, d_akey, d_acand, d_aval);
+      }
+      HIP_TRY(hipMemsetAsync(d_aff + lo, 1, hi - lo, s));
       while (true) {
         unsigned long long changed = 0;
-        uint64_t na = 0;
-        if (nv) {
-          hipLaunchKernelGGL(cg_accflag_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, d_scid, d_acc, nv, d_flag);
-          if ((rc = shn_device_scan_u32(ctx, d_flag, nv, d_apos, &na))) return rc;
-          if (na) hipLaunchKernelGGL(cg_acc_compact_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, keys, d_scid, d_flag, d_apos, nv, d_akey, d_acand);
+        if (round == 0 || !incremental) {
+          HIP_TRY(hipMemsetAsync(d_best + lo, 0, (hi - lo) * 8, s));
+          HIP_TRY(hipMemsetAsync(d_cov + lo, 0, (hi - lo) * 4, s));
+          HIP_TRY(hipMemsetAsync(d_hit + off[lo], 0, off[hi] - off[lo], s));
+        } else {
+          HIP_TRY(hipMemsetAsync(d_aff + lo, 0, hi - lo, s));
+          hipLaunchKernelGGL(cg_affected_kernel, dim3(grid_for(na)), dim3(CG_BLK), 0, s, d_akey, d_acand, na, (uint32_t)lo, d_chgf, d_aff);
+          hipLaunchKernelGGL(cg_clear_kernel, dim3(grid_for(off[hi] - off[lo])), dim3(CG_BLK), 0, s, d_aff, d_cid, off[lo], off[hi], (uint32_t)lo, (uint32_t)hi,
+                             d_hit, d_best, d_cov);
         }
-        HIP_TRY(hipMemsetAsync(d_best + lo, 0, (hi - lo) * 8, s));
-        HIP_TRY(hipMemsetAsync(d_cov + lo, 0, (hi - lo) * 4, s));
-        HIP_TRY(hipMemsetAsync(d_hit + off[lo], 0, off[hi] - off[lo], s));
         HIP_TRY(hipMemsetAsync(d_chg, 0, 8, s));
         if (na) {
           while (true) {                             // (the pair table grows until the round's pairs fit)
             HIP_TRY(hipMemsetAsync(d_tab, 0, sizeof(PairSlot) << lg_slots, s));
             HIP_TRY(hipMemsetAsync(d_ovf, 0, 4, s));
-            hipLaunchKernelGGL(cg_hits_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, keys, vals, d_scid, d_apos, nv, d_off, (uint32_t)lo, (uint32_t)hi,
-                               d_akey, d_acand, d_tab, (1ULL << lg_slots) - 1, d_ovf);
+            hipLaunchKernelGGL(cg_hits_kernel, dim3(grid_for(na)), dim3(CG_BLK), 0, s, d_akey, d_acand, d_aval, na, d_off, (uint32_t)lo, d_acc, d_aff,
+                               d_tab, (1ULL << lg_slots) - 1, d_ovf);
             uint32_t ovf = 0;
             HIP_TRY(hipMemcpyAsync(&ovf, d_ovf, 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
@@ -306,12 +364,11 @@ extern "C" int shn_contig_stage(shn_ctx* ctx, const uint8_t* bases, const uint64
             HIP_TRY(tmp.get(&d_tab, sizeof(PairSlot) << lg_slots));
           }
           hipLaunchKernelGGL(cg_best_kernel, dim3(grid_for(1ULL << lg_slots)), dim3(CG_BLK), 0, s, d_tab, 1ULL << lg_slots, d_best);
-          hipLaunchKernelGGL(cg_cover_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, keys, vals, d_scid, d_apos, nv, (uint32_t)lo, (uint32_t)hi, d_akey, d_acand,
-                             d_best, d_hit);
-          hipLaunchKernelGGL(cg_covsum_kernel, dim3(grid_for(off[hi] - off[lo])), dim3(CG_BLK), 0, s, d_hit, d_cid, d_off, off[lo], off[hi], r, d_cov);
+          hipLaunchKernelGGL(cg_cover_kernel, dim3(grid_for(na)), dim3(CG_BLK), 0, s, d_akey, d_acand, d_aval, na, (uint32_t)lo, d_best, d_aff, d_hit);
+          hipLaunchKernelGGL(cg_covsum_kernel, dim3(grid_for(off[hi] - off[lo])), dim3(CG_BLK), 0, s, d_hit, d_cid, d_off, off[lo], off[hi], r, d_aff, d_cov);
         }
         hipLaunchKernelGGL(cg_decide_kernel, dim3((uint32_t)cdiv(hi - lo, CG_BLK)), dim3(CG_BLK), 0, s, d_best, d_cov, d_off, (uint32_t)lo, (uint32_t)hi, f,
-                           d_acc, d_bestc, d_chg);
+                           d_aff, d_acc, d_chgf, d_bestc, d_chg);
         HIP_TRY(hipMemcpyAsync(&changed, d_chg, 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         n_rounds++;
@@ -322,8 +379,10 @@ extern "C" int shn_contig_stage(shn_ctx* ctx, const uint8_t* bases, const uint64
         if (round >= 64 && hi - lo > 1) {
           // a long dependency chain inside the block: go on with its first half (its fixpoint does not depend on the rest);
           // the candidates cut off go back to "not accepted" and come with the next block
+          HIP_TRY(hipMemsetAsync(d_aff + lo + (hi - lo) / 2, 0, hi - (lo + (hi - lo) / 2), s));
           hi = lo + (hi - lo) / 2;
           HIP_TRY(hipMemsetAsync(d_acc + hi, 0, n_cand - hi, s));
+          HIP_TRY(hipMemsetAsync(d_aff + lo, 1, hi - lo, s));         // (everything of the half is looked at again: the candidates cut off were in its hits)
           round = 0;
         }
       }
