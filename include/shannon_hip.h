@@ -335,9 +335,11 @@ void shn_post_destroy(shn_post* p);
 /* known_paths' test of every read (mbgraph.py:1355-1388, 114-160) on the device: reads = the partition's distinct reads, node_bases /
  * node_off = the texts of its nodes one after the other.  state_out[r]: 0 nothing to do (first or last K-mer in no node, or no
  * occurrence matches), 1 the read lies inside node node_out[r] (index into the given order), 2 the read runs past the end of a
- * node it matches and has to be searched on the host.  K <= 31, ACGT only.                                                       */
+ * node it matches and has to be searched on the host; with offset_out != NULL also 3: the same, and the read's first K-mer occurs
+ * exactly once in the nodes -- in node node_out[r] at offset offset_out[r] (the host needs no index of its own for these).
+ * K <= 31, ACGT only.                                                                                                            */
 int shn_known_paths_scan(shn_ctx* ctx, const shn_reads* reads, int K, const uint8_t* node_bases, const uint64_t* node_off, uint64_t n_nodes,
-                         uint8_t* state_out, int32_t* node_out);
+                         uint8_t* state_out, int32_t* node_out, uint32_t* offset_out);
 /* Host threads the library keeps busy at most: min(hardware threads, affinity mask, cgroup CPU quota); SHN_HOST_CPUS overrides.
  * (-- ; the reference takes its process count from --nprocs, shannon.py:99.)                                                   */
 int shn_host_cpus(void);

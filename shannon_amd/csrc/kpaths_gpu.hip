@@ -9,9 +9,11 @@
 //                 per K-mer;  scan;  kp_fill: the positions of every K-mer side by side
 //   kp_classify   per read: first / last K-mer looked up; the occurrences of the first K-mer by ascending position (= the order of
 //                 the host's index: node order, then offset), text compared base by base against the node
-//                 -> 0 (nothing to do), 1 + node (inside that node), 2 (search on the host)
+//                 -> 0 (nothing to do), 1 + node (inside that node), 2 (search on the host), 3 + node + offset (search on the host
+//                 from the K-mer's only occurrence)
 // (a first version sorted the (K-mer, position) items: 35 launches per partition against 5)
-// The host keeps the sequential part: reads of kind 2, in read order, against an index of just their first K-mers.
+// The host keeps the sequential part: reads of kind 2 and 3, in read order; those of kind 2 (rare: a K-mer occurs once in a de Bruijn
+// graph until bridging copies nodes) against an index of just their first K-mers.
 #include "common.h"
 
 #include <algorithm>
@@ -86,12 +88,13 @@ __device__ __forceinline__ int64_t kp_find(const unsigned long long* __restrict_
 
 __global__ void kp_classify(RView v, int K, const unsigned long long* __restrict__ hkeys, uint64_t mask, const uint64_t* __restrict__ goff,
                             const uint32_t* __restrict__ occ, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ off, uint32_t n_nodes,
-                            uint8_t* __restrict__ state, int32_t* __restrict__ node_out) {
+                            uint8_t* __restrict__ state, int32_t* __restrict__ node_out, uint32_t* __restrict__ off_out) {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= v.n) return;
   const uint32_t L = v.len ? v.len[r] : v.fixed_len;
   uint8_t st = 0;
   int32_t fn = -1;
+  uint32_t fo = 0;
   if (L >= (uint32_t)K) {
     const uint64_t* w = v.words + (v.woff ? v.woff[r] : r * v.wpr);
     const uint64_t kf = shn_extract(w, 0, K), kl = shn_extract(w, L - K, K);
@@ -114,13 +117,18 @@ __global__ void kp_classify(RView v, int K, const unsigned long long* __restrict
         }
         if (!same) continue;
         if ((uint64_t)L <= left) { fn = (int32_t)nd; any = true; }
-        else need = true;
+        else {
+          need = true;
+          // the K-mer's only occurrence: the host starts its search right there, without an index of its own
+          if (off_out && g1 - g0 == 1) { fn = (int32_t)nd; fo = (uint32_t)(p - off[nd]); }
+        }
       }
-      st = need ? 2 : any ? 1 : 0;
+      st = need ? (off_out && g1 - g0 == 1 ? 3 : 2) : any ? 1 : 0;
     }
   }
   state[r] = st;
   node_out[r] = fn;
+  if (off_out) off_out[r] = fo;
 }
 
 }  // namespace
@@ -129,7 +137,7 @@ __global__ void kp_classify(RView v, int K, const unsigned long long* __restrict
 // the other, in the order the host's seed index would list them; state_out[r] / node_out[r] as described above (node = index
 // into that order).  SHN_ERR_ARG if a node holds a base outside ACGT or K > 31.
 extern "C" int shn_known_paths_scan(shn_ctx* ctx, const shn_reads* reads, int K, const uint8_t* node_bases, const uint64_t* node_off,
-                                    uint64_t n_nodes, uint8_t* state_out, int32_t* node_out) {
+                                    uint64_t n_nodes, uint8_t* state_out, int32_t* node_out, uint32_t* offset_out) {
   if (!ctx || !reads || !node_off || (n_nodes && !node_bases) || (reads->n_reads && (!state_out || !node_out)))
     return shn_fail(SHN_ERR_ARG, "shn_known_paths_scan: NULL argument");
   if (K < 1 || K > 31) return shn_fail(SHN_ERR_ARG, "shn_known_paths_scan: K must be in [1,31]");
@@ -140,6 +148,7 @@ extern "C" int shn_known_paths_scan(shn_ctx* ctx, const shn_reads* reads, int K,
     if (total) return shn_fail(SHN_ERR_ARG, "shn_known_paths_scan: too many nodes / bases");
     std::fill(state_out, state_out + nr, (uint8_t)0);
     for (uint64_t i = 0; i < nr; i++) node_out[i] = -1;
+    if (offset_out) std::fill(offset_out, offset_out + nr, 0u);
     return SHN_OK;
   }
   HIP_TRY(hipSetDevice(ctx->device));
@@ -153,6 +162,7 @@ extern "C" int shn_known_paths_scan(shn_ctx* ctx, const shn_reads* reads, int K,
   unsigned long long *d_hkeys = nullptr, *d_cnt2 = nullptr;
   uint32_t *d_cnt = nullptr, *d_fill = nullptr, *d_slot = nullptr, *d_occ = nullptr;
   int32_t* d_node = nullptr;
+  uint32_t* d_ofs = nullptr;
 #define TRYK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return shn_fail(SHN_ERR_HIP, std::string("shn_known_paths_scan: ") + hipGetErrorString(e_)); } while (0)
   TRYK(bufs.get(&d_bases, total + 8));
   TRYK(bufs.get(&d_off, (n_nodes + 1) * 8));
@@ -162,6 +172,7 @@ extern "C" int shn_known_paths_scan(shn_ctx* ctx, const shn_reads* reads, int K,
   TRYK(bufs.get(&d_slot, (total + 1) * 4)); TRYK(bufs.get(&d_occ, (total + 1) * 4));
   TRYK(bufs.get(&d_state, nr + 1)); TRYK(bufs.get(&d_node, (nr + 1) * 4));
   TRYK(bufs.get(&d_cnt2, 16));
+  if (offset_out) TRYK(bufs.get(&d_ofs, (nr + 1) * 4));
   TRYK(hipMemcpyAsync(d_bases, node_bases, total, hipMemcpyHostToDevice, s));
   TRYK(hipMemcpyAsync(d_off, node_off, (n_nodes + 1) * 8, hipMemcpyHostToDevice, s));
   TRYK(hipMemsetAsync(d_cnt2, 0, 16, s));
@@ -174,12 +185,13 @@ extern "C" int shn_known_paths_scan(shn_ctx* ctx, const shn_reads* reads, int K,
   hipLaunchKernelGGL(kp_fill, dim3(gp), dim3(256), 0, s, d_slot, total, d_goff, d_fill, d_occ);
   RView v{reads->d_words, reads->d_woff, reads->d_len, nr, reads->fixed_len, reads->wpr};
   hipLaunchKernelGGL(kp_classify, dim3((uint32_t)cdiv(nr, 256)), dim3(256), 0, s, v, K, d_hkeys, T - 1, d_goff, d_occ, d_bases, d_off, (uint32_t)n_nodes,
-                     d_state, d_node);
+                     d_state, d_node, offset_out ? d_ofs : nullptr);
   TRYK(hipGetLastError());
   unsigned long long cnt[2] = {0, 0};
   TRYK(hipMemcpyAsync(cnt, d_cnt2, 16, hipMemcpyDeviceToHost, s));
   TRYK(hipMemcpyAsync(state_out, d_state, nr, hipMemcpyDeviceToHost, s));
   TRYK(hipMemcpyAsync(node_out, d_node, nr * 4, hipMemcpyDeviceToHost, s));
+  if (offset_out) TRYK(hipMemcpyAsync(offset_out, d_ofs, nr * 4, hipMemcpyDeviceToHost, s));
   TRYK(hipStreamSynchronize(s));
   if (cnt[1]) return shn_fail(SHN_ERR_ARG, "shn_known_paths_scan: a node holds a base outside ACGT");
 #undef TRYK

@@ -27,7 +27,7 @@
 #include <cstdlib>
 
 extern "C" int shn_known_paths_scan(shn_ctx* ctx, const shn_reads* reads, int K, const uint8_t* node_bases, const uint64_t* node_off,
-                                    uint64_t n_nodes, uint8_t* state_out, int32_t* node_out);
+                                    uint64_t n_nodes, uint8_t* state_out, int32_t* node_out, uint32_t* offset_out);
 
 namespace {
 
@@ -705,24 +705,27 @@ struct Graph {
         for (int n : order) { nb += bases[n]; noff.push_back(nb.size()); }
         std::vector<uint8_t> st(n_rd());
         std::vector<int32_t> nd(n_rd());
+        std::vector<uint32_t> no(n_rd());
         tk1 = nowk();
-        const int rcs = shn_known_paths_scan(ctx, d_reads, K, (const uint8_t*)nb.data(), noff.data(), order.size(), st.data(), nd.data());
+        const int rcs = shn_known_paths_scan(ctx, d_reads, K, (const uint8_t*)nb.data(), noff.data(), order.size(), st.data(), nd.data(), no.data());
         release_gpu();
         tk2 = nowk();
         if (rcs == 0) {
-          // occurrences (node, offset), in index order, of the first K-mers of the reads left to search
+          // occurrences (node, offset), in index order, of the first K-mers of the reads left to search whose K-mer occurs more
+          // than once (state 2: none in most partitions -- the K-mers of a de Bruijn graph are distinct until bridging copies nodes)
           std::unordered_map<uint64_t, std::vector<std::pair<int, int>>> occ_of;
           std::vector<uint64_t> bits(1u << 12, 0);                        // 2^18-bit filter in front of the map
-          size_t n_slow = 0;
+          size_t n_slow = 0, n_multi = 0;
           for (size_t r = 0; r < n_rd(); r++) {
             if (st[r] == 1) { const int n = order[nd[r]]; rfirst[r] = n; rlast[r] = n; rhas[r] = 1; }
+            else if (st[r] == 3) n_slow++;
             else if (st[r] == 2) {
               uint64_t key;
-              n_slow++;
+              n_slow++; n_multi++;
               if (key_at(rstr((int)r), 0, key)) { occ_of[key]; const uint64_t h = fm_mix(key) >> 46; bits[h >> 6] |= 1ULL << (h & 63); }
             }
           }
-          if (n_slow)
+          if (n_multi)
             for (int n : order) {
               const std::string& b = bases[n];
               uint64_t key = 0;
@@ -739,12 +742,14 @@ struct Graph {
           int cntp = 0;
           std::vector<std::vector<int>> paths;
           std::vector<int> cur;
+          std::vector<std::pair<int, int>> one(1);
           for (size_t r = 0; r < n_rd(); r++) {
-            if (st[r] != 2) continue;
+            if (st[r] < 2) continue;
             const RStr rb = rstr((int)r);
             uint64_t key;
             if (!key_at(rb, 0, key)) continue;
-            for (const auto& oc : occ_of[key]) {
+            if (st[r] == 3) one[0] = {order[nd[r]], (int)no[r]};
+            for (const auto& oc : st[r] == 3 ? one : occ_of[key]) {
               const int sn = oc.first, so = oc.second;
               if (!compare(rb, 0, bases[sn], so)) continue;
               if (rb.size() <= bases[sn].size() - (size_t)so) { rfirst[r] = sn; rlast[r] = sn; rhas[r] = 1; continue; }

@@ -10,6 +10,9 @@
 #include <algorithm>
 #include <atomic>
 #include <charconv>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -352,6 +355,10 @@ extern "C" int shn_sflow_text(const shn_sflow* s, uint32_t g, uint8_t* out) {
 extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uint32_t n_graphs, const char* const* snames, uint64_t seed, shn_sflow** out) {
   if (!ctx || !out || (n_graphs && (!graphs || !snames))) return shn_fail(SHN_ERR_ARG, "shn_sparse_flow: NULL argument");
   *out = nullptr;
+  const bool dbg = getenv("SHN_DEBUG") != nullptr;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_lap = now(), t_adv = 0, t_lp = 0, t_fin = 0, t_pack = 0;
+  auto lap = [&](const char* what) { if (dbg) { const double t = now(); fprintf(stderr, "[sflow] %-28s %8.3f s\n", what, t - t_lap); t_lap = t; } };
   std::vector<Component> comps;
   std::vector<uint32_t> comp_graph;
   std::vector<int> comp_index;
@@ -421,12 +428,15 @@ extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uin
     for (auto& x : th) x.join();
   };
   parallel(build);
+  lap("build components");
+  int n_round = 0;
   // rounds: every component runs to its next decomposition that needs LP trials; all of them go to the device in one batch
   std::vector<size_t> active(comps.size());
   for (size_t k = 0; k < comps.size(); k++) active[k] = k;
   std::vector<uint8_t> wants(comps.size(), 0);
   while (!active.empty()) {
-    parallel([&](size_t k) { if (k < comps.size()) {} });      // (keeps the thread pool warm; the work is below)
+    double tr0 = now();
+    n_round++;
     // advance the active components (independent of each other)
     {
       std::atomic<size_t> next{0};
@@ -436,6 +446,7 @@ extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uin
     }
     std::vector<size_t> pend;
     for (size_t k : active) if (wants[k]) pend.push_back(k);
+    t_adv += now() - tr0; tr0 = now();
     if (pend.empty()) break;
     std::vector<uint32_t> m(pend.size()), n(pend.size()), tr(pend.size());
     std::vector<uint64_t> pid(pend.size());
@@ -451,8 +462,10 @@ extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uin
       ooff[i + 1] = ooff[i] + (uint64_t)q.m * q.n * q.trials;
     }
     std::vector<double> flows(ooff.back());
+    t_pack += now() - tr0; tr0 = now();
     int rc = shn_lp_solve_batch(ctx, (uint32_t)pend.size(), m.data(), n.data(), tr.data(), pid.data(), ab.data(), mask.data(), seed, flows.data());
     if (rc) return rc;
+    t_lp += now() - tr0; tr0 = now();
     {
       std::atomic<size_t> next{0};
       auto work = [&]() { while (true) { const size_t i0 = next.fetch_add(16); if (i0 >= pend.size()) break; for (size_t i = i0; i < std::min(pend.size(), i0 + 16); i++) { Component& c = comps[pend[i]]; finish(c, flows.data() + ooff[i]); apply_flow(c); } } };
@@ -460,21 +473,34 @@ extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uin
       else { std::vector<std::thread> th; for (unsigned t = 0; t < nt; t++) th.emplace_back(work); for (auto& x : th) x.join(); }
     }
     active.swap(pend);
+    t_fin += now() - tr0;
   }
+  if (dbg) fprintf(stderr, "[sflow] %zu components, %d rounds: advance %.3f s, pack %.3f s, LP batches %.3f s, finish+apply %.3f s\n", comps.size(), n_round, t_adv,
+                   t_pack, t_lp, t_fin);
+  t_lap = now();
   // transcripts of every component, then the partition texts
   {
     std::vector<std::string> names(n_graphs);
     for (uint32_t g = 0; g < n_graphs; g++) names[g] = snames[g] ? snames[g] : "";
     parallel([&](size_t k) { emit(comps[k], names[comp_graph[k]], comp_index[k]); });
   }
+  lap("emit");
   shn_sflow* R = new shn_sflow();
   R->text.assign(n_graphs, std::string());
-  for (size_t k = 0; k < comps.size(); k++) R->text[comp_graph[k]] += comps[k].fasta;
-  for (uint32_t g = 0; g < n_graphs; g++) {
+  // the text of a partition: its components' transcripts, then its single nodes -- partitions side by side on the host threads
+  std::vector<size_t> first_comp(n_graphs + 1, comps.size());
+  for (size_t k = comps.size(); k-- > 0;) first_comp[comp_graph[k]] = k;
+  for (uint32_t g = n_graphs; g-- > 0;) if (first_comp[g] == comps.size()) first_comp[g] = first_comp[g + 1];
+  auto text_of = [&](uint32_t g) {
     // single_nodes_to_fasta -- including its quirk of not skipping the header line of single_nodes.txt
     const shn_graph* G = graphs[g];
     const std::string sname = snames[g] ? snames[g] : "";
     std::string& t = R->text[g];
+    size_t bytes = 64 + sname.size();
+    for (size_t k = first_comp[g]; k < first_comp[g + 1]; k++) bytes += comps[k].fasta.size();
+    bytes += G->s_bases.size() + (G->s_off.size()) * (48 + sname.size());
+    t.reserve(bytes);
+    for (size_t k = first_comp[g]; k < first_comp[g + 1]; k++) t += comps[k].fasta;
     t += ">Shannon_" + sname + "_single_0\t Copycount:Copycount\nBases\n";
     for (size_t i = 0; i + 1 < G->s_off.size(); i++) {
       const double cc = G->s_cc[i];
@@ -482,7 +508,17 @@ extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uin
       t.append(G->s_bases, G->s_off[i], G->s_off[i + 1] - G->s_off[i]);
       t += "\n";
     }
+  };
+  {
+    std::atomic<uint32_t> next{0};
+    auto work = [&]() { for (uint32_t g; (g = next.fetch_add(1)) < n_graphs;) text_of(g); };
+    if (nt <= 1 || n_graphs < 4) work();
+    else { std::vector<std::thread> th; for (unsigned t = 0; t < std::min<unsigned>(nt, n_graphs); t++) th.emplace_back(work); for (auto& x : th) x.join(); }
   }
+  lap("partition texts");
+  // (the components hold ~10^2 small vectors each: given back on the host threads, not one after the other when `comps` goes out of scope)
+  parallel([&](size_t k) { Component gone; std::swap(gone, comps[k]); });
+  lap("free components");
   *out = R;
   return SHN_OK;
 }

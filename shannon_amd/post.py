@@ -147,9 +147,10 @@ def finalize_texts(texts, ds=True, r=24):
         _lib.check(L.shn_post_export(h, names.ctypes.data, no.ctypes.data, seqs.ctypes.data, so.ctypes.data))
     finally:
         L.shn_post_destroy(h)
-    nt, st = names.tobytes().decode(), seqs.tobytes().decode()
+    # (every name / sequence decoded straight from its slice of the exported buffers: one copy of the text, not three)
+    mn, ms = memoryview(names), memoryview(seqs)
     no, so = no.tolist(), so.tolist()
-    return {nt[no[i]:no[i + 1]]: st[so[i]:so[i + 1]] for i in range(n)}
+    return {str(mn[no[i]:no[i + 1]], "ascii"): str(ms[so[i]:so[i + 1]], "ascii") for i in range(n)}
 
 
 def finalize(all_lines, ds=True):

@@ -90,8 +90,18 @@ def test_known_paths_scan_equals_the_index_walk(K, seed):
     text = np.frombuffer("".join(nodes).encode(), np.uint8)
     off = np.zeros(len(nodes) + 1, np.uint64); off[1:] = np.cumsum([len(n) for n in nodes])
     state = np.empty(len(reads), np.uint8); node = np.empty(len(reads), np.int32)
-    _lib.check(_lib.lib().shn_known_paths_scan(ctx.h, d.h, K, text.ctypes.data, off.ctypes.data, len(nodes), state.ctypes.data, node.ctypes.data))
+    _lib.check(_lib.lib().shn_known_paths_scan(ctx.h, d.h, K, text.ctypes.data, off.ctypes.data, len(nodes), state.ctypes.data, node.ctypes.data, None))
     assert state.tolist() == want_state
+    # with offsets: a read to search whose first K-mer occurs exactly once comes back as 3 with that occurrence
+    state3 = np.empty(len(reads), np.uint8); node3 = np.empty(len(reads), np.int32); ofs3 = np.empty(len(reads), np.uint32)
+    _lib.check(_lib.lib().shn_known_paths_scan(ctx.h, d.h, K, text.ctypes.data, off.ctypes.data, len(nodes), state3.ctypes.data, node3.ctypes.data,
+                                               ofs3.ctypes.data))
+    for r, s2, s3, n3, o3 in zip(reads, state.tolist(), state3.tolist(), node3.tolist(), ofs3.tolist()):
+        if s2 == 2 and len(index[r[:K]]) == 1:
+            assert s3 == 3 and (n3, o3) == index[r[:K]][0]
+        else:
+            assert s3 == s2
+    assert 3 in state3 and 2 in state3
     assert [n if s == 1 else -1 for n, s in zip(node.tolist(), state.tolist())] == [n if s == 1 else -1 for n, s in zip(want_node, want_state)]
     assert set(want_state) == {0, 1, 2}
     d.close(); ctx.close()
