@@ -793,10 +793,13 @@ __global__ void ext_audit_kernel(WalkArgs A, uint64_t ns, unsigned long long* __
 __global__ __launch_bounds__(1024) void ext_plan_kernel(const uint32_t* __restrict__ nr, const uint32_t* __restrict__ nl, uint64_t ns, uint32_t frozen,
                                 const uint8_t* __restrict__ mvalid, const uint32_t* __restrict__ mR, const uint32_t* __restrict__ mL,
                                 const uint8_t* __restrict__ dirty, uint32_t* __restrict__ long_list, uint32_t* __restrict__ short_list,
-                                unsigned long long* __restrict__ counters, uint32_t long_walk) {
+                                unsigned long long* __restrict__ counters, uint32_t long_walk, uint8_t* __restrict__ coarse) {
   // ns here = current rank limit (walks >= limit have not started yet); walks < frozen are final and never run
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + frozen;
   const bool isd = r < ns && dirty[r];
+  // coarse[i]: one of the 64 walks frozen + 64 i .. is dirty (the begin pass asks it before dirty[]: 1/64 of the bytes, they stay
+  // in the L2 while the claims stream past)
+  { const unsigned long long anyd = __ballot(isd); if ((threadIdx.x & 63) == 0) coarse[(r - frozen) >> 6] = anyd ? 1 : 0; }
   bool lg = false;
   if (isd) {
     uint32_t a = nr[r];
@@ -861,7 +864,7 @@ __global__ void ext_memo_plan_kernel(uint8_t* __restrict__ ran, uint8_t* __restr
 // (copy == 0: the snapshot is already the claims -- ext_mark_kernel brought it up to date where the last round changed something)
 __global__ void ext_round_begin_kernel(u64* __restrict__ claim, u64* __restrict__ snap, uint64_t n2, const uint8_t* __restrict__ dirty,
                                        uint64_t ns, unsigned long long* __restrict__ d_cnt, int copy, uint8_t* __restrict__ chunk,
-                                       uint32_t frozen, uint32_t limit) {
+                                       uint32_t frozen, uint32_t limit, const uint8_t* __restrict__ coarse) {
   uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (o == 0) { d_cnt[6] = 0; d_cnt[7] = 0; d_cnt[13] = 0; }      // changed k1-mers, (spare), walks handed over
   if (o >= n2) return;
@@ -870,7 +873,7 @@ __global__ void ext_round_begin_kernel(u64* __restrict__ claim, u64* __restrict_
   const uint32_t rk = RANK(c);
   // (only walks of the open block can be dirty: the flag of a final walk's k1-mer -- most claimed k1-mers in the later blocks --
   // is not looked up: a random byte read per claimed k1-mer otherwise)
-  if (rk >= frozen && rk < limit && rk < ns && dirty[rk]) { claim[o] = UNCLAIMED64; if (chunk) chunk[o >> CHUNK_SHIFT] = 1; }
+  if (rk >= frozen && rk < limit && rk < ns && coarse[(rk - frozen) >> 6] && dirty[rk]) { claim[o] = UNCLAIMED64; if (chunk) chunk[o >> CHUNK_SHIFT] = 1; }
 }
 
 // after a round: every k1-mer whose owner changed dirties the walks that looked at it; the k1-mers of the walks
@@ -1299,6 +1302,9 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   TRYE(shn_dev_malloc(&chunk, n_chunks));
   struct ChunkFree { uint8_t* p; ~ChunkFree() { shn_dev_free(p); } } chunk_free{chunk};
   TRYE(hipMemsetAsync(chunk, 0, n_chunks, s));
+  uint8_t* coarse = nullptr;              // see ext_plan_kernel
+  TRYE(shn_dev_malloc(&coarse, (size_t)ns / 64 + 64));
+  struct CoarseFree { uint8_t* p; ~CoarseFree() { shn_dev_free(p); } } coarse_free{coarse};
   bool snap_current = false;              // the snapshot equals the claims (after a round with precise marks)
   bool fresh_block = true;                // the open block has not run a round yet (and no repair has reopened earlier blocks)
 
@@ -1335,7 +1341,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     TRYE(hipMemsetAsync(d_cnt + 2, 0, 32, s));
     if (limit > frozen)
       hipLaunchKernelGGL(ext_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 1024)), dim3(1024), 0, s, e->d_nr, e->d_nl, (uint64_t)limit, frozen,
-                         mvalid, mR, mL, dirty, long_list, short_list, d_cnt + 2, bulk ? 0xFFFFFFFFu : long_walk);
+                         mvalid, mR, mL, dirty, long_list, short_list, d_cnt + 2, bulk ? 0xFFFFFFFFu : long_walk, coarse);
     // (pinned host memory: a pageable destination costs a staging copy kernel per round)
     TRYE(hipMemcpyAsync(plan, d_cnt + 2, 32, hipMemcpyDeviceToHost, s));
     TRYE(hipStreamSynchronize(s));
@@ -1383,8 +1389,11 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     }
     TimerRegion t3(ctx, T_EXT_WALK);
     // snapshot, then release the claims of the walks that re-run this round
+    // (a block that has just opened holds no claims yet: with the snapshot up to date there is nothing to release and nothing to copy)
+    if (fresh_block && precise_marks && snap_current) { TRYE(hipMemsetAsync(d_cnt + 6, 0, 16, s)); TRYE(hipMemsetAsync(d_cnt + 13, 0, 8, s)); }
+    else
     hipLaunchKernelGGL(ext_round_begin_kernel, dim3(g2n), dim3(256), 0, s, claim, snap, 2 * n, dirty, (uint64_t)ns, d_cnt,
-                       (!precise_marks || !snap_current) ? 1 : 0, bulk ? (uint8_t*)nullptr : chunk, frozen, limit);
+                       (!precise_marks || !snap_current) ? 1 : 0, bulk ? (uint8_t*)nullptr : chunk, frozen, limit, coarse);
     snap_current = true;
     WalkArgs A;
     A.order = e->d_order; A.adjR = (const Adj4*)e->d_adjR; A.adjL = (const Adj4*)e->d_adjL; A.weight = e->d_weight;
