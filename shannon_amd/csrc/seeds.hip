@@ -11,27 +11,44 @@
 
 struct SView { const uint64_t* words; const uint64_t* woff; const uint32_t* len; uint64_t n; uint32_t fixed_len, wpr; };
 
-// mode 0: one thread per (read, offset); FILL writes (read, start, id) triples in (read, start) order.
+// mode 0: one thread per (read, offset).  The hits are few (the patterns are the K-mers at the start of the graph's x-nodes): the first
+// pass leaves one count per block of 256 windows, the second repeats the look-ups and writes the (read, start, id) triples in (read,
+// start) order -- position inside the block by ballot / prefix.  (A count per window was 12 bytes of traffic per window for the
+// count, its scan and the offsets read back; the look-ups themselves hit a table that fits the L2.)
 // ALL: every window 0..len-K (contig-against-contig 15-mer joins) instead of the interior starts 1..len-K-1
 template <bool FILL, bool ALL>
 __global__ __launch_bounds__(SBLK2) void seed_scan_kernel(SView v, int K, uint32_t max_win, const uint64_t* __restrict__ tkeys,
                                                           const uint32_t* __restrict__ tvals, const uint64_t* __restrict__ boff, int bits,
                                                           uint32_t* __restrict__ counts, const uint64_t* __restrict__ offs,
                                                           uint32_t* __restrict__ o_read, uint32_t* __restrict__ o_start, uint32_t* __restrict__ o_id) {
-  uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= v.n * max_win) return;
-  uint64_t r = gid / max_win;
-  uint32_t start = (uint32_t)(gid - r * max_win) + (ALL ? 0u : 1u);   // range(1, len - K), or every window
-  uint32_t len = v.len ? v.len[r] : v.fixed_len;
-  uint32_t id = 0;
-  if (ALL ? (len >= (uint32_t)K && start <= len - K) : (len > (uint32_t)K && start < len - K)) {
-    uint64_t wb = v.woff ? v.woff[r] : r * v.wpr;
-    uint64_t key = shn_extract(v.words + wb, start, K);
-    int64_t j = shn_table_find(tkeys, boff, bits, key);
-    if (j >= 0) id = tvals[j];
+  __shared__ uint32_t wtot[SBLK2 / 64];
+  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t r = 0;
+  uint32_t start = 0, id = 0;
+  if (gid < v.n * max_win) {
+    r = gid / max_win;
+    start = (uint32_t)(gid - r * max_win) + (ALL ? 0u : 1u);   // range(1, len - K), or every window
+    const uint32_t len = v.len ? v.len[r] : v.fixed_len;
+    if (ALL ? (len >= (uint32_t)K && start <= len - K) : (len > (uint32_t)K && start < len - K)) {
+      const uint64_t wb = v.woff ? v.woff[r] : r * v.wpr;
+      const uint64_t key = shn_extract(v.words + wb, start, K);
+      const int64_t j = shn_table_find(tkeys, boff, bits, key);
+      if (j >= 0) id = tvals[j];
+    }
   }
-  if (!FILL) { counts[gid] = id ? 1u : 0u; return; }
-  if (id) { uint64_t o = offs[gid]; o_read[o] = (uint32_t)r; o_start[o] = start; o_id[o] = id - 1; }
+  const unsigned long long m = __ballot(id != 0);
+  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) wtot[wv] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (!FILL) {
+    if (threadIdx.x == 0) { uint32_t t = 0; for (int w = 0; w < SBLK2 / 64; w++) t += wtot[w]; counts[blockIdx.x] = t; }
+    return;
+  }
+  if (id) {
+    uint64_t o = offs[blockIdx.x] + (uint64_t)__popcll(m & ((1ULL << lane) - 1ULL));
+    for (uint32_t w = 0; w < wv; w++) o += wtot[w];
+    o_read[o] = (uint32_t)r; o_start[o] = start; o_id[o] = id - 1;
+  }
 }
 
 // mode 1: first / last K-mer of every read
@@ -74,14 +91,23 @@ static int seed_scan_impl(shn_ctx* ctx, const shn_reads* reads, int K, const shn
   if (total == 0) { *n_hits = 0; return SHN_OK; }
   void *pc, *po;
   int rc;
-  if ((rc = ctx->cws[1].get((total + 1) * 4, &pc)) || (rc = ctx->cws[2].get((total + 2) * 8, &po))) return rc;
-  uint32_t grid = (uint32_t)cdiv(total, SBLK2);
-  hipLaunchKernelGGL((seed_scan_kernel<false, ALL>), dim3(grid), dim3(SBLK2), 0, s, v, K, max_win, patterns->d_keys, patterns->d_counts,
-                     patterns->d_bucket_off, patterns->bits, (uint32_t*)pc, nullptr, nullptr, nullptr, nullptr);
+  const uint32_t grid = (uint32_t)cdiv(total, SBLK2);
+  if ((rc = ctx->cws[1].get(((size_t)grid + 1) * 4, &pc)) || (rc = ctx->cws[2].get(((size_t)grid + 2) * 8, &po))) return rc;
+  // (the call that asks for the number of hits and the one that fetches them come in pairs: the second finds the block offsets of
+  // the first in the context's workspace -- same reads, same patterns, nothing in between on this context)
+  static thread_local struct { const shn_ctx* ctx; const shn_reads* reads; const shn_table* pat; uint64_t total, n_reads, n_pat, nh; int K; bool all; } last = {};
   uint64_t nh = 0;
-  if ((rc = shn_device_scan_u32(ctx, (uint32_t*)pc, total, (uint64_t*)po, &nh))) return rc;
+  if (out_read && last.ctx == ctx && last.reads == reads && last.pat == patterns && last.total == total && last.n_reads == reads->n_reads &&
+      last.n_pat == patterns->n && last.K == K && last.all == ALL) nh = last.nh;
+  else {
+    hipLaunchKernelGGL((seed_scan_kernel<false, ALL>), dim3(grid), dim3(SBLK2), 0, s, v, K, max_win, patterns->d_keys, patterns->d_counts,
+                       patterns->d_bucket_off, patterns->bits, (uint32_t*)pc, nullptr, nullptr, nullptr, nullptr);
+    if ((rc = shn_device_scan_u32(ctx, (uint32_t*)pc, grid, (uint64_t*)po, &nh))) return rc;
+  }
+  last.ctx = nullptr;                                            // (one use)
   *n_hits = nh;
-  if (!out_read || nh == 0) return SHN_OK;
+  if (!out_read) { last = {ctx, reads, patterns, total, reads->n_reads, patterns->n, nh, K, ALL}; return SHN_OK; }
+  if (nh == 0) return SHN_OK;
   uint32_t *d_r = nullptr, *d_s = nullptr, *d_i = nullptr;       // (from the caching allocator: this runs once per partition, under the GPU mutex)
   ShnDevBufs hb;
   HIP_TRY(hb.get(&d_r, nh * 4)); HIP_TRY(hb.get(&d_s, nh * 4)); HIP_TRY(hb.get(&d_i, nh * 4));
