@@ -523,9 +523,9 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
         lap("ext.emit")
         acc, _best, coff, cnb, cw = contig_stage_gpu(ctx, buf, offs, k1, r, f)
         csr = (coff, cnb, cw)
-        raw = buf.tobytes()                                # (only the accepted tenth is ever turned into strings)
+        raw = memoryview(np.ascontiguousarray(buf))        # (only the accepted tenth is ever turned into strings, slice by slice)
         ai = np.nonzero(acc)[0]
-        contigs += [raw[a:b].decode() for a, b in zip(offs[ai].tolist(), offs[ai + 1].tolist())]
+        contigs += [str(raw[a:b], "ascii") for a, b in zip(offs[ai].tolist(), offs[ai + 1].tolist())]
         del raw
         strings = None
     else:
