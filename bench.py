@@ -16,6 +16,7 @@ import argparse, json, os, sys, time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import shannon_amd                      # (first: the package sets the allocator up before anything allocates much)
 import numpy as np
 import torch
 

@@ -3,3 +3,26 @@ path: (K+1)-mer counting -> contig / multibridged de-Bruijn graph -> sparse-flow
 decomposition.  Python host layer over a C-ABI shared library of hand-written HIP kernels
 (shannon_amd/csrc, include/shannon_hip.h)."""
 __version__ = "0.1.0"
+
+
+def _malloc_tune():
+    """The same allocator settings libshannon_hip.so applies when it is loaded (csrc/core.hip, shn_malloc_tune), applied as soon as
+    the package is imported: blocks up to 32 MB come from the heap and freed memory stays there, so that the host stages do not pay
+    for fresh zero pages every step.  SHN_MALLOC_TUNE=0 switches it off; MALLOC_*_ environment settings win."""
+    import ctypes, os
+    if os.environ.get("SHN_MALLOC_TUNE", "1") == "0":
+        return
+    try:
+        libc = ctypes.CDLL(None)
+        M_TRIM_THRESHOLD, M_TOP_PAD, M_MMAP_THRESHOLD = -1, -2, -3
+        if "MALLOC_MMAP_THRESHOLD_" not in os.environ:
+            libc.mallopt(M_MMAP_THRESHOLD, 32 << 20)
+        if "MALLOC_TRIM_THRESHOLD_" not in os.environ:
+            libc.mallopt(M_TRIM_THRESHOLD, -1)                    # (size_t) -1: the heap is never trimmed
+        if "MALLOC_TOP_PAD_" not in os.environ:
+            libc.mallopt(M_TOP_PAD, 256 << 20)
+    except (OSError, AttributeError):
+        pass
+
+
+_malloc_tune()

@@ -432,6 +432,20 @@ extern "C" uint64_t shn_reads_n_invalid(const shn_reads* r) { return r ? r->n_in
 // quota (cpu.max: a container that sees 256 hardware threads may be allowed 16 CPUs' worth of time per period -- running more
 // threads than that does not add throughput, it gets every thread of the process throttled until the next period, the
 // serial chains of the graph stage included).  SHN_HOST_CPUS overrides.  Every thread count of the host stages derives from it.
+// The host stages (graph threads, sparse flow, merge, the numpy buffers between them) allocate and free hundreds of blocks of
+// 0.1-30 MB per step.  glibc serves those by mmap and gives them back on free: every step pays the page faults of fresh zero
+// pages again (~90 ms of a 3.2 s step at BASELINE configs[2]).  Loading the library raises the mmap threshold to its maximum and
+// keeps freed memory in the heap; SHN_MALLOC_TUNE=0 leaves the allocator as it is (MALLOC_*_ environment settings win as usual).
+#include <malloc.h>
+#include <climits>
+__attribute__((constructor)) static void shn_malloc_tune() {
+  const char* v = getenv("SHN_MALLOC_TUNE");
+  if (v && v[0] == '0') return;
+  if (!getenv("MALLOC_MMAP_THRESHOLD_")) mallopt(M_MMAP_THRESHOLD, 32 << 20);
+  if (!getenv("MALLOC_TRIM_THRESHOLD_")) mallopt(M_TRIM_THRESHOLD, -1);          // (size_t) -1: the heap is never trimmed
+  if (!getenv("MALLOC_TOP_PAD_")) mallopt(M_TOP_PAD, 256 << 20);
+}
+
 extern "C" int shn_host_cpus(void) {
   static int cached = 0;
   if (cached) return cached;

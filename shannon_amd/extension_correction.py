@@ -128,12 +128,20 @@ class Extension(object):
             _lib.check(L.shn_ext_live_stats_min(self.ctx.h, self.h, ms, C.byref(n), rank.ctypes.data, nr.ctypes.data, nl.ctypes.data, tw.ctypes.data))
         return rank[:m], nr[:m], nl[:m], tw[:m]
 
-    def emit_raw(self, ranks, lengths):
-        """(ASCII bases uint8[total], offsets uint64[n+1]) of the contigs of the selected walks"""
+    def emit_raw(self, ranks, lengths, reuse=False):
+        """(ASCII bases uint8[total], offsets uint64[n+1]) of the contigs of the selected walks.  reuse: the bases land in a
+        buffer this thread keeps from call to call (valid until its next such call) -- 300 MB of fresh pages per step cost more
+        than the copy into them."""
         ranks = np.ascontiguousarray(ranks, dtype=np.uint32)
         offs = np.zeros(len(ranks) + 1, dtype=np.uint64)
         offs[1:] = np.cumsum(lengths, dtype=np.uint64)
-        buf = np.empty(int(offs[-1]) + 1, dtype=np.uint8)
+        need = int(offs[-1]) + 1
+        if reuse:
+            buf = getattr(_EMIT_TLS, "buf", None)
+            if buf is None or len(buf) < need:
+                buf = _EMIT_TLS.buf = np.empty(need + need // 8, dtype=np.uint8)
+        else:
+            buf = np.empty(need, dtype=np.uint8)
         _lib.check(_lib.lib().shn_ext_emit(self.ctx.h, self.h, ranks.ctypes.data, len(ranks), offs.ctypes.data, buf.ctypes.data))
         return buf[:int(offs[-1])], offs
 
@@ -158,6 +166,9 @@ class Extension(object):
         except Exception:
             pass
 
+
+import threading as _threading
+_EMIT_TLS = _threading.local()
 
 _CODE = np.full(256, 255, dtype=np.uint8)
 for _i, _c in enumerate(b"ACGT"):
@@ -519,7 +530,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     conn = None
     sharded_contigs = False
     if gpu_contigs:
-        buf, offs = ext.emit_raw(keep_r, keep_l) if len(keep_r) else (np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+        buf, offs = ext.emit_raw(keep_r, keep_l, reuse=True) if len(keep_r) else (np.zeros(0, np.uint8), np.zeros(1, np.uint64))
         lap("ext.emit")
         acc, _best, coff, cnb, cw = contig_stage_gpu(ctx, buf, offs, k1, r, f)
         csr = (coff, cnb, cw)
