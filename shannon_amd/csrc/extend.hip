@@ -346,7 +346,7 @@ struct Adj4 { int32_t v[4]; };
 // entry b of a row, b known only at run time: picked with compares (an indexed access makes the compiler keep the row in
 // scratch memory)
 __device__ __forceinline__ int32_t adj_get(const Adj4& a, int b) { return b == 0 ? a.v[0] : b == 1 ? a.v[1] : b == 2 ? a.v[2] : a.v[3]; }
-#define CHUNK_SHIFT 6
+#define CHUNK_SHIFT 4          // 16 oriented k1-mers = one 128-byte line of claims per flag
 
 struct WalkArgs {
   const uint32_t* order; const Adj4* adjR; const Adj4* adjL; const uint32_t* weight;
@@ -363,7 +363,7 @@ struct WalkArgs {
   // a thread walker that turns out long hands its walk over to a wavefront (same round): where it stands
   uint32_t* promo_list; unsigned long long* promo_count; uint32_t* res_cur; uint32_t* res_info;   // info = dir << 31 | steps so far
   uint32_t promote_steps;
-  uint8_t* chunk;        // per 4096 oriented k1-mers: "a claim in here was written this round" (the mark pass visits only those)
+  uint8_t* chunk;        // per 2^CHUNK_SHIFT oriented k1-mers: "a claim in here was written this round" (the mark pass visits only those)
 };
 
 // Claim `node` as step `pos` of walk r: atomic min on rank:pos, fire-and-forget (a returning atomic would put
@@ -887,19 +887,17 @@ __global__ void ext_mark_kernel(const u64* __restrict__ claim, u64* claim_old, u
                                 const uint32_t* __restrict__ nr_a, const uint32_t* __restrict__ nl_a, const uint32_t* __restrict__ weight, int precise,
                                 const uint8_t* __restrict__ chunk) {
   // grid-stride: the change counter costs one atomic per block (one per wavefront on a single address was the
-  // most expensive thing in this kernel).  A wavefront takes chunks of 64 k1-mers (one 512-byte run of claims) and, in rounds
-  // that re-run few walks (chunk != NULL), skips those no claim was written in this round (claim_node and the release of the
-  // begin pass flag them): where nothing was written nothing changed, and every k1-mer of a walk that ran was written.  The
-  // k1-mers of a walk are scattered over the table, so the flags have to be this fine to leave chunks out: a round of 3,000
-  // walks of 2,000 steps touches a quarter of them.
+  // most expensive thing in this kernel).  A wavefront takes 64 k1-mers at a time and, in rounds that re-run few walks
+  // (chunk != NULL), looks only at the 128-byte lines of claims (16 k1-mers, one flag) a claim was written in this round
+  // (claim_node and the release of the begin pass flag them): where nothing was written nothing changed, and every k1-mer of a
+  // walk that ran was written.  The k1-mers of a walk are scattered over the table, so the flags have to be this fine: with a flag
+  // per 64 k1-mers a round of 500 k short walks read 3 GB of claims and snapshot for its 3 M written k1-mers.
   uint32_t my_changed = 0;
-  const uint64_t n_chunks = (n2 + (1ULL << CHUNK_SHIFT) - 1) >> CHUNK_SHIFT;
+  const uint64_t n_groups = (n2 + 63) >> 6;
   const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-  for (uint64_t ch = wave; ch < n_chunks; ch += n_waves) {
-  if (chunk && !chunk[ch]) continue;
-  {
-    const uint64_t y = (ch << CHUNK_SHIFT) + (threadIdx.x & 63);
-    if (y >= n2) continue;
+  const uint32_t lane = threadIdx.x & 63;
+  // the part every written k1-mer goes through; true: its owner changed to a higher rank (or nobody) -- the walks around it have to be looked at (mark_around)
+  auto mark_node = [&](const uint64_t y, uint32_t& a_out) -> bool {
     const u64 oy = claim_old[y];
     const uint32_t a = RANK(oy);
     const u64 cy = claim[y];
@@ -916,7 +914,7 @@ __global__ void ext_mark_kernel(const u64* __restrict__ claim, u64* claim_old, u
         hint[y] = (uint32_t)(idx << 2) | (pos == 0 ? HINT_SEED : pos <= R ? HINT_R : HINT_L);
       }
     }
-    if (a == b) continue;
+    if (a == b) return false;
     my_changed++;
     // Who has to look again?  Walk x treats y as traversed iff its owner's rank is below x, and removing a
     // candidate it did not choose never changes a greedy choice -- so only walks for which y BECAME available
@@ -927,7 +925,11 @@ __global__ void ext_mark_kernel(const u64* __restrict__ claim, u64* claim_old, u
     // started (they all run when their phase opens).
 #define MARK(x) if ((x) >= frozen && (x) < limit) dirty[x] = 1
     if (a != UNCLAIMED && !ran[a]) MARK(a);
-    if (b < a) continue;
+    a_out = a;
+    return b >= a;
+  };
+  auto mark_around = [&](const uint64_t y, const uint32_t a) {
+    const uint32_t b = RANK(claim[y]);
 #define MARKX(x) if (a < (x) && (x) < b) MARK(x)
     uint32_t sr = seed_rank[y];
     MARKX(sr);
@@ -958,7 +960,32 @@ __global__ void ext_mark_kernel(const u64* __restrict__ claim, u64* claim_old, u
     }
 #undef MARKX
 #undef MARK
-  }
+  };
+  if (!chunk) {
+    for (uint64_t ch = wave; ch < n_groups; ch += n_waves) {
+      const uint64_t y = (ch << 6) + lane;
+      uint32_t a;
+      if (y < n2 && mark_node(y, a)) mark_around(y, a);
+    }
+  } else {
+    // 64 groups of 64 k1-mers per trip: every lane fetches the four line flags of one group, the wavefront then visits the groups
+    // that have one set.  (Putting the k1-mers whose surroundings have to be looked at on a list for a second launch, 64 to a
+    // wavefront, was slower: 235 against 210 ms per step -- the pass is bound by its random accesses, not by their latency.)
+    static_assert(CHUNK_SHIFT == 4, "four line flags per group of 64 k1-mers");
+    const uint64_t n_super = (n_groups + 63) >> 6;
+    for (uint64_t sg = wave; sg < n_super; sg += n_waves) {
+      const uint64_t g = (sg << 6) + lane;
+      const uint32_t fl = g < n_groups ? *(const uint32_t*)(chunk + g * 4) : 0u;
+      unsigned long long todo = __ballot(fl != 0);
+      while (todo) {
+        const int j = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const uint32_t flj = (uint32_t)__shfl((int)fl, j, 64);
+        const uint64_t y = ((((sg << 6) + (uint64_t)j)) << 6) + lane;
+        uint32_t a = 0;
+        if (y < n2 && ((flj >> (8 * (lane >> 4))) & 0xFFu) && mark_node(y, a)) mark_around(y, a);
+      }
+    }
   }
   __shared__ unsigned long long blk_changed;
   if (threadIdx.x == 0) blk_changed = 0;
@@ -1298,7 +1325,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   int it = 0, repairs = 0;
   bool converged = ns == 0;
   uint8_t* chunk = nullptr;               // see ext_mark_kernel
-  const uint64_t n_chunks = ((2 * n) >> CHUNK_SHIFT) + 2;
+  const uint64_t n_chunks = ((2 * n) >> CHUNK_SHIFT) + 16;
   TRYE(shn_dev_malloc(&chunk, n_chunks));
   struct ChunkFree { uint8_t* p; ~ChunkFree() { shn_dev_free(p); } } chunk_free{chunk};
   TRYE(hipMemsetAsync(chunk, 0, n_chunks, s));
