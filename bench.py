@@ -230,6 +230,10 @@ def cpu_baseline(k1, r1, r2, n_pairs):
 
 
 def main():
+    # stdout carries the JSON line and nothing else: whatever libraries print through C stdio (RCCL's version banner) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -467,11 +471,10 @@ def main():
     if dist:
         dist.destroy_process_group()
     if final_line is not None:
-        # RCCL prints a version banner through C stdio; flush it first so the JSON is the last line
         import ctypes
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
-        print(final_line, flush=True)
+        os.write(json_fd, (final_line + "\n").encode())
 
 
 if __name__ == "__main__":
