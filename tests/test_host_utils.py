@@ -77,3 +77,15 @@ def test_native_merge_equals_the_python_form(seed, ds):
     assert 0 < len(got) < len(lines) // 2
     assert post.finalize(lines, ds) == want
     assert post.finalize_native([], ds) == {} and post.finalize_native([">a\n", "ACGT\n"], ds) == {}
+
+
+def test_allocator_setup_can_be_switched_off():
+    """importing the package applies the allocator settings (mallopt) unless SHN_MALLOC_TUNE=0; either way the import works and
+    the library loads"""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for v in ("0", "1"):
+        env = dict(os.environ, SHN_MALLOC_TUNE=v, PYTHONPATH=root)
+        out = subprocess.run([sys.executable, "-c", "import shannon_amd; from shannon_amd import _lib; print(_lib.host_cpus() >= 1)"],
+                             env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and out.stdout.strip() == "True", out.stderr
