@@ -340,7 +340,8 @@ void shn_post_destroy(shn_post* p);
  * K <= 31, ACGT only.                                                                                                            */
 int shn_known_paths_scan(shn_ctx* ctx, const shn_reads* reads, int K, const uint8_t* node_bases, const uint64_t* node_off, uint64_t n_nodes,
                          uint8_t* state_out, int32_t* node_out, uint32_t* offset_out);
-/* Host threads the library keeps busy at most: min(hardware threads, affinity mask, cgroup CPU quota); SHN_HOST_CPUS overrides.
+/* Host threads the library keeps busy at most: min(hardware threads, affinity mask, cgroup CPU quota) / ranks on the node
+ * (LOCAL_WORLD_SIZE or SHN_LOCAL_RANKS); SHN_HOST_CPUS overrides.
  * (-- ; the reference takes its process count from --nprocs, shannon.py:99.)                                                   */
 int shn_host_cpus(void);
 /* Rows of resident fixed-length read sets as a new read set: read i = row rows[i] of set a (flags[i] bit 0 clear) or b (set),

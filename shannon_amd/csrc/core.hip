@@ -431,7 +431,8 @@ extern "C" uint64_t shn_reads_n_invalid(const shn_reads* r) { return r ? r->n_in
 // ---- host threads this process may keep busy: the smallest of the hardware threads, the affinity mask and the cgroup CPU
 // quota (cpu.max: a container that sees 256 hardware threads may be allowed 16 CPUs' worth of time per period -- running more
 // threads than that does not add throughput, it gets every thread of the process throttled until the next period, the
-// serial chains of the graph stage included).  SHN_HOST_CPUS overrides.  Every thread count of the host stages derives from it.
+// serial chains of the graph stage included), divided by the ranks of the node.  SHN_HOST_CPUS overrides.  Every thread count of
+// the host stages derives from it.
 // The host stages (graph threads, sparse flow, merge, the numpy buffers between them) allocate and free hundreds of blocks of
 // 0.1-30 MB per step.  glibc serves those by mmap and gives them back on free: every step pays the page faults of fresh zero
 // pages again (~90 ms of a 3.2 s step at BASELINE configs[2]).  Loading the library raises the mmap threshold to its maximum and
@@ -473,6 +474,10 @@ extern "C" int shn_host_cpus(void) {
   };
   quota("/sys/fs/cgroup/cpu.max", true);
   quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", false);
+  // one process per GPU: the ranks of a node share the allowance (LOCAL_WORLD_SIZE is torchrun's count of them; SHN_LOCAL_RANKS
+  // for other launchers) -- eight ranks each sizing its pools for the whole quota is the oversubscription described above
+  for (const char* name : {"SHN_LOCAL_RANKS", "LOCAL_WORLD_SIZE"})
+    if (const char* e = getenv(name)) { const int v = atoi(e); if (v > 1) { n = std::max(1, n / v); break; } }
   if (const char* e = getenv("SHN_HOST_CPUS")) { const int v = atoi(e); if (v > 0) n = v; }
   cached = std::max(1, n);
   return cached;
