@@ -324,6 +324,7 @@ extern "C" int shn_contig_stage(shn_ctx* ctx, const uint8_t* bases, const uint64
     HIP_TRY(tmp.get(&d_tab, sizeof(PairSlot) << lg_slots));
     uint64_t blk0 = std::max<uint64_t>(1024, n_cand / 16);          // (n / 256: 23 rounds, 0.75 s at 731 k candidates; n / 16: 0.66 s; one block: 0.68 s)
     if (getenv("SHN_CONTIG_BLOCK0")) blk0 = std::max<uint64_t>(1, strtoull(getenv("SHN_CONTIG_BLOCK0"), nullptr, 10));
+    const int max_rounds = getenv("SHN_CONTIG_MAX_ROUNDS") ? std::max(1, atoi(getenv("SHN_CONTIG_MAX_ROUNDS"))) : 64;   // (tests: halve blocks early)
     uint64_t lo = 0, bsize = blk0;
     while (lo < n_cand) {
       uint64_t hi = std::min<uint64_t>(n_cand, lo + bsize);
@@ -376,7 +377,7 @@ extern "C" int shn_contig_stage(shn_ctx* ctx, const uint8_t* bases, const uint64
         if (dbg) fprintf(stderr, "[contig_stage]   block [%llu,%llu) round %d: %llu accepted entries, %llu decisions changed\n", (unsigned long long)lo,
                          (unsigned long long)hi, round, (unsigned long long)na, changed);
         if (!changed) break;
-        if (round >= 64 && hi - lo > 1) {
+        if (round >= max_rounds && hi - lo > 1) {
           // a long dependency chain inside the block: go on with its first half (its fixpoint does not depend on the rest);
           // the candidates cut off go back to "not accepted" and come with the next block
           HIP_TRY(hipMemsetAsync(d_aff + lo + (hi - lo) / 2, 0, hi - (lo + (hi - lo) / 2), s));

@@ -355,13 +355,16 @@ def _variants(contigs, seed=5):
 
 
 @pytest.mark.parametrize("name", sorted(MANIFEST))
-@pytest.mark.parametrize("block0,pair_log2", [(None, None), (7, None), (1, 4), (-7, None)])
+@pytest.mark.parametrize("block0,pair_log2", [(None, None), (7, None), (1, 4), (-7, None), (1000, -2)])
 def test_gpu_contig_stage_equals_the_sequential_stage(ctx, name, block0, pair_log2, monkeypatch):
     """shn_contig_stage (duplicate_check as block-wise rounds over one device sort of the r-mers, K-mer join on the GPU) ==
     shn_cgraph (the reference's sequential loop, checked against the oracle on the CPU): accepted flags, best-hit counts,
     connections with weights and insertion order.  Also with tiny blocks and a pair table that has to grow; -7: blocks of 7 with
     every candidate of a block evaluated in every round (the default re-evaluates only those behind a changed decision)."""
     from shannon_amd import extension_correction as ec
+    if pair_log2 is not None and pair_log2 < 0:                      # (1000, -2): large blocks given up after 2 rounds and halved
+        monkeypatch.setenv("SHN_CONTIG_MAX_ROUNDS", str(-pair_log2))
+        pair_log2 = None
     if block0 is not None and block0 < 0:
         monkeypatch.setenv("SHN_CONTIG_INCREMENTAL", "0")
         block0 = -block0
