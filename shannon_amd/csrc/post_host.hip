@@ -56,18 +56,8 @@ static int find_reps_core(const uint8_t* const* nptr, const uint64_t* nlen, cons
   // last r-mer of each record, plain and reverse-complemented.  So: those (at most 4 per record) form a small query set, all
   // records are scanned on host threads for occurrences of query keys (a rolling key, a probe of a cache-resident set), and
   // only these occurrences enter the index -- in record order, as the reference appends them.
-  {
-    std::atomic<int> bad{0};
-    const unsigned nt0 = std::max(1u, std::min(32u, (unsigned)shn_host_cpus()));
-    const unsigned nt = n < 4096 ? 1 : nt0;
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; t++) th.emplace_back([&, t]() {
-      for (uint64_t i = n * t / nt; i < n * (t + 1) / nt; i++)
-        for (uint64_t p = 0; p < slen[i]; p++) if (pcode(sptr[i][p]) < 0) { bad.store(1); return; }
-    });
-    for (auto& x : th) x.join();
-    if (bad.load()) return shn_fail(SHN_ERR_ARG, "shn_find_reps: non-ACGT base in a transcript");
-  }
+  // (bases outside ACGT are looked for by the scan below, which reads every base anyway)
+  std::atomic<int> bad{0};
   const double tf1 = nowf();
   size_t qcap = 1024;
   while (qcap < rec_of.size() * 16) qcap <<= 1;
@@ -114,14 +104,19 @@ static int find_reps_core(const uint8_t* const* nptr, const uint64_t* nlen, cons
         const uint8_t* s = sptr[i];
         const uint64_t L = slen[i];
         uint64_t key = 0;
+        int any_bad = 0;
         for (uint64_t p = 0; p < L; p++) {
-          key = ((key << 2) | (uint64_t)pcode(s[p])) & mask;
+          const int c = pcode(s[p]);
+          any_bad |= c;                                   // (-1 sets the sign bit)
+          key = ((key << 2) | (uint64_t)(c & 3)) & mask;
           if (p + 1 >= (uint64_t)r && q_has(key)) out.push_back(Occ{key, id_of[i], (int32_t)(p + 1 - r)});
         }
+        if (any_bad < 0) { bad.store(1); return; }
       }
     });
     for (auto& x : th) x.join();
   }
+  if (bad.load()) return shn_fail(SHN_ERR_ARG, "shn_find_reps: non-ACGT base in a transcript");
   const double tf3 = nowf();
   size_t n_occ = 0;
   for (auto& v : found) n_occ += v.size();

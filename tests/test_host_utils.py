@@ -89,3 +89,18 @@ def test_allocator_setup_can_be_switched_off():
         out = subprocess.run([sys.executable, "-c", "import shannon_amd; from shannon_amd import _lib; print(_lib.host_cpus() >= 1)"],
                              env=env, capture_output=True, text=True, timeout=120)
         assert out.returncode == 0 and out.stdout.strip() == "True", out.stderr
+
+
+def test_native_merge_refuses_other_characters_and_the_python_form_takes_over():
+    """a transcript with a base outside ACGT: the native merge says so (found by its scan), post.finalize falls back to the Python form"""
+    from shannon_amd import post, _lib
+    rng = np.random.default_rng(1)
+    lines = []
+    for i in range(30):
+        s = "".join("ACGT"[j] for j in rng.integers(0, 4, int(rng.integers(250, 600))))
+        if i == 7:
+            s = s[:100] + "N" + s[101:]
+        lines += [">t%d\t1.0\n" % i, s + "\n"]
+    with pytest.raises(_lib.ShannonError, match="non-ACGT"):
+        post.finalize_texts(["".join(lines)], True)
+    assert post.finalize(lines, True) == post.find_reps(post.length_sort(post.process_concatenated(lines, True)), True)
