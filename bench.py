@@ -7,10 +7,16 @@
 A "step" = one pass of the hot path over one batch of synthetic 2x100 bp reads already resident
 (2-bit packed) in HBM.  N=1 workload = BASELINE configs[2], the largest single-GPU configuration:
 100M reads (50M pairs), k=25 (-K 25, k1=26), 20,000 genes, multi-component, --partition 500
-(`--config 1` = configs[1]: 10M reads of one gene family).  N>1: every rank gets its own 10M-read
-shard of the configs[1] kind (weak scaling) and the ranks exchange their (key,count) tables with one
-all-to-all over RCCL/xGMI.
-Prints ONE JSON line on rank 0.
+(`--config 1` = configs[1]: 10M reads of one gene family; `--config 4s` = the one-GPU slice of
+configs[4]: 100M reads, -K 31, exons up to 5 kb).  N>1 (default `--scaling strong`): the SAME
+configs[2] batch hash-sharded over the N ranks = BASELINE configs[3] -- every rank generates its
+own contiguous slice of the batch's 250,000-pair chunks (a chunk's reads depend only on the seed and
+the chunk's index, so the union over the ranks is the N=1 batch and the transcripts' digest is the
+N=1 digest), the ranks exchange their (key,count) buckets with one all-to-all over RCCL/xGMI.
+`--scaling weak`: N gene families of the configs[1] kind, 10M reads per rank.
+`python bench.py --gpus N` with no WORLD_SIZE in the environment starts the N ranks itself (fresh
+child processes through torch.distributed.run, from a parent that has made no GPU call) and relays
+rank 0's JSON line.  Prints ONE JSON line on rank 0.
 """
 import argparse, json, os, sys, time
 
@@ -25,15 +31,34 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # default workload; tools/summarize_prof.py -> profiles/r01_traffic.json): 2 x FETCH_SIZE (gfx950 tallies 128-B
 # requests at 64 B, MI355X_MICROARCH.md HBM) + WRITE_SIZE.  Only valid for the default 10M-read workload.
 TRAFFIC = {}
-for _cfg, _fn in ((1, "r01_traffic.json"), (2, "r02_traffic_config2.json")):
+for _cfg, _fn in (("1", "r01_traffic.json"), ("2", "r02_traffic_config2.json")):
     try:
-        TRAFFIC["config%d" % _cfg] = json.load(open(os.path.join(ROOT, "profiles", _fn)))["traffic_bytes_per_launch"]
+        TRAFFIC["config%s" % _cfg] = json.load(open(os.path.join(ROOT, "profiles", _fn)))["traffic_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
 
 
-def gen_reads(n_pairs, seed, n_genes, device, read_seed=None, families=0):
-    """synthetic pairs on the GPU (torch RNG; same model as shannon_amd/synth.py).
+CHUNK_PAIRS = 250_000          # the batch is generated in chunks of this many pairs; a chunk depends on (seed, chunk index) only
+
+
+def chunk_range(total_pairs, world, rank):
+    """(first chunk, pairs) of the contiguous slice of the batch's chunks that rank `rank` of `world` generates and holds"""
+    n_chunks = (total_pairs + CHUNK_PAIRS - 1) // CHUNK_PAIRS
+    lo, hi = rank * n_chunks // world, (rank + 1) * n_chunks // world
+    return lo, min(total_pairs, hi * CHUNK_PAIRS) - min(total_pairs, lo * CHUNK_PAIRS)
+
+
+def _chunk_seed(read_seed, chunk):
+    z = (read_seed * 0x9E3779B97F4A7C15 + (chunk + 1) * 0xD1B54A32D192ED03) & ((1 << 64) - 1)
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & ((1 << 64) - 1)
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & ((1 << 64) - 1)
+    return (z ^ (z >> 31)) & ((1 << 62) - 1)
+
+
+def gen_reads(n_pairs, seed, n_genes, device, read_seed=None, families=0, first_chunk=0, exon_len=(80, 600)):
+    """synthetic pairs on the GPU (torch RNG; same model as shannon_amd/synth.py), generated in chunks of CHUNK_PAIRS pairs:
+    chunk c (counted from first_chunk) is drawn from a generator seeded with (read_seed, c) alone, so any rank can produce any
+    slice of the batch and the union of the ranks' slices is the one-GPU batch.
     families > 0: that many gene families of the configs[1] kind (rich in isoforms) instead of n_genes plain genes."""
     from shannon_amd import synth
     # config 2 ("single component"): one gene family rich enough to give a multi-contig component
@@ -50,24 +75,26 @@ def gen_reads(n_pairs, seed, n_genes, device, read_seed=None, families=0):
         wts = np.concatenate(wl)
     else:
         kw = dict(n_isoforms=(4, 6), n_exons=(8, 12)) if n_genes == 1 else {}
-        iso, _ = synth.make_transcriptome(n_genes, seed, **kw)
+        iso, _ = synth.make_transcriptome(n_genes, seed, exon_len=exon_len, **kw)
         lens = np.array([len(t) for t in iso], dtype=np.int64)
         rng = np.random.Generator(np.random.PCG64(seed + 1))
         expr = rng.lognormal(0.0, 1.5, size=len(iso))
         wts = expr * (lens - 300 + 1)
         wts /= wts.sum()
+    read_seed = seed + 2 if read_seed is None else read_seed
     g = torch.Generator(device=device)
-    g.manual_seed(seed + 2 if read_seed is None else read_seed)
     cat = torch.as_tensor(np.concatenate(iso), device=device)
     offs = torch.as_tensor(np.concatenate([[0], np.cumsum(lens)[:-1]]), device=device)
     tl = torch.as_tensor(lens, device=device)
-    out1, out2 = [], []
+    out1 = np.empty((n_pairs, 100), dtype=np.uint8)
+    out2 = np.empty((n_pairs, 100), dtype=np.uint8)
     ar = torch.arange(100, device=device)
     # isoform of every fragment by inverse CDF (float64): reproducible run to run (torch.multinomial on the device was not --
     # the same seed gave tables of 724,313,063 or 724,313,437 distinct k1-mers on different boxes)
     cdf = torch.as_tensor(np.cumsum(wts / wts.sum()), device=device, dtype=torch.float64)
-    for s in range(0, n_pairs, 1 << 20):
-        n = min(1 << 20, n_pairs - s)
+    for c, s in enumerate(range(0, n_pairs, CHUNK_PAIRS)):
+        n = min(CHUNK_PAIRS, n_pairs - s)
+        g.manual_seed(_chunk_seed(read_seed, first_chunk + c))
         iso_i = torch.searchsorted(cdf, torch.rand(n, device=device, generator=g, dtype=torch.float64)).clamp_(max=len(lens) - 1)
         start = (torch.rand(n, device=device, generator=g, dtype=torch.float64) * (tl[iso_i] - 299)).long() + offs[iso_i]
         a = cat[start[:, None] + ar]
@@ -76,9 +103,9 @@ def gen_reads(n_pairs, seed, n_genes, device, read_seed=None, families=0):
             e = torch.rand(m.shape, device=device, generator=g) < 0.005
             sub = torch.randint(1, 4, m.shape, device=device, generator=g, dtype=torch.uint8)
             m[e] = (m[e] + sub[e]) & 3
-        out1.append(a.cpu())
-        out2.append(b.cpu())
-    return torch.cat(out1).numpy(), torch.cat(out2).numpy()
+        out1[s:s + n] = a.cpu().numpy()
+        out2[s:s + n] = b.cpu().numpy()
+    return out1, out2
 
 
 def _final_sha(final):
@@ -229,30 +256,87 @@ def cpu_baseline(k1, r1, r2, n_pairs):
                                               % (len(slices), 2 * per, dtt)}}
 
 
-def main():
-    # stdout carries the JSON line and nothing else: whatever libraries print through C stdio (RCCL's version banner) goes to stderr
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
+PRESETS = {"1": dict(genes=1, reads=10_000_000, K=25, exon_len=(80, 600)),
+           "2": dict(genes=20000, reads=100_000_000, K=25, exon_len=(80, 600)),
+           # the one-GPU slice of configs[4] (500M reads, k=31, 8 GPUs): a fifth of its reads and of its genes (the per-gene depth
+           # of configs[4]), exons up to 5 kb so that the unitigs get long
+           "4s": dict(genes=4000, reads=100_000_000, K=31, exon_len=(80, 5000))}
+
+
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=0, help="BASELINE.json configs[i]: 1 = 10M reads / one gene family, 2 = 100M reads / "
-                                                          "20,000 genes (default: 2 on one GPU, 1 per rank on several)")
-    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (2 per pair); default from --config")
-    ap.add_argument("--K", type=int, default=25)
+    ap.add_argument("--config", default="", choices=["", "0", "1", "2", "4s"],
+                    help="BASELINE.json configs[i]: 1 = 10M reads / one gene family, 2 = 100M reads / 20,000 genes (on N GPUs with "
+                         "--scaling strong: configs[3]), 4s = the one-GPU slice of configs[4]: 100M reads, -K 31, 4,000 genes with exons "
+                         "up to 5 kb (default: 2; 1 per rank with --scaling weak on several GPUs)")
+    ap.add_argument("--reads", type=int, default=0, help="reads of the batch (2 per pair; per GPU with --scaling weak); default from --config")
+    ap.add_argument("--K", type=int, default=0)
     ap.add_argument("--genes", type=int, default=0, help="genes of the synthetic transcriptome; default from --config")
-    ap.add_argument("--families", type=int, default=0, help="gene families of the configs[1] kind (default: one per rank)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="several GPUs: weak = every rank gets the config's reads (default), strong = the config's reads are split over the ranks")
+    ap.add_argument("--families", type=int, default=0, help="gene families of the configs[1] kind (default with --scaling weak: one per rank)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="several GPUs: strong (default) = the config's batch is split over the ranks (configs[2] on N GPUs = BASELINE "
+                         "configs[3]); weak = every rank gets the config's reads (N gene families of the configs[1] kind by default)")
     ap.add_argument("--overlap-steps", type=int, default=-1,
                     help="one GPU: after the timed steps, that many more with two batches in flight (the host-bound half of a step on a second "
                          "context and thread beside the next batch's GPU-bound half); reported as `overlap`, never as `value` (default: 6 at "
                          "the default workload, 0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-distributed", action="store_true", help="run the multi-GPU code path even with one rank")
-    args = ap.parse_args()
+    return ap
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv, json_fd):
+    """`python bench.py --gpus N` outside a torch.distributed launch: start the N ranks as fresh child processes (one per GPU,
+    torch.distributed.run on 127.0.0.1) from this parent, which has made no GPU call (argparse and subprocess only -- a process
+    that has initialised the GPU must never be replaced or forked into ranks), relay rank 0's JSON line, and fail when a child
+    fails.  Returns the exit code."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL between processes needs it on this stack
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env, cwd=ROOT)
+    line = None
+    for raw in proc.stdout:                                    # the ranks' stdout: the JSON line of rank 0 and nothing else
+        txt = raw.decode(errors="replace")
+        if txt.lstrip().startswith("{") and '"metric"' in txt:
+            line = txt.strip()
+        else:
+            sys.stderr.write(txt)
+    rc = proc.wait()
+    if rc != 0:
+        sys.stderr.write("bench.py: the %d-rank launch failed with exit code %d\n" % (n, rc))
+        return rc
+    if line is None:
+        sys.stderr.write("bench.py: the %d-rank launch printed no JSON line\n" % n)
+        return 1
+    os.write(json_fd, (line + "\n").encode())
+    return 0
+
+
+def main():
+    # stdout carries the JSON line and nothing else: whatever libraries print through C stdio (RCCL's version banner) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    args = build_parser().parse_args()
+    if args.config == "0":
+        args.config = ""
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], json_fd))
 
     if os.environ.get("SHN_BENCH_WATCHDOG"):          # development aid: dump every thread's stack if the run takes longer
         import faulthandler
@@ -260,14 +344,44 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and not (args.gpus == 1 and world == 1):
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
+        sys.exit(2)
+    if args.scaling is None:
+        args.scaling = "weak" if args.families else "strong"
     if not args.config:
-        args.config = 2 if ((world == 1 or args.scaling == "strong") and not args.genes and not args.reads and not args.families) else 1
-    preset = {1: (1, 10_000_000), 2: (20000, 100_000_000)}[args.config]
-    args.genes = args.genes or preset[0]
-    args.reads = args.reads or preset[1]
-    is_config = (args.genes, args.reads) == preset and args.K == 25 and not args.families
+        args.config = "1" if (world > 1 and args.scaling == "weak" and not (args.genes or args.reads)) else "2"
+    preset = PRESETS[args.config]
+    args.genes = args.genes or preset["genes"]
+    args.reads = args.reads or preset["reads"]
+    args.K = args.K or preset["K"]
+    exon_len = preset["exon_len"]
+    is_config = (args.genes, args.reads, args.K) == (preset["genes"], preset["reads"], preset["K"]) and not args.families
+    total_reads = args.reads                                   # of the whole job's batch (strong) / per rank (weak)
+    first_chunk = 0
     if args.scaling == "strong" and world > 1:
-        args.reads = 2 * ((args.reads // 2) // world)          # the same batch size for the whole job, a slice per rank
+        first_chunk, pairs = chunk_range(args.reads // 2, world, rank)
+        args.reads = 2 * pairs                                 # this rank's slice of the one batch
+    if os.environ.get("SHN_BENCH_LAUNCH_PROBE"):
+        # CPU test of the launcher (tests/test_bench_launcher.py): the ranks meet over gloo, rank 0 prints what the launch resolved
+        # to; nothing touches the GPU.  "fail": rank 1 exits non-zero -- the launcher must report it.
+        import torch.distributed as dist
+        if os.environ["SHN_BENCH_LAUNCH_PROBE"] == "fail" and rank == world - 1:
+            sys.exit(3)
+        if world > 1:
+            dist.init_process_group("gloo")
+            one = torch.ones(1, dtype=torch.int64)
+            dist.all_reduce(one)
+            seen = int(one.item())
+            dist.destroy_process_group()
+        else:
+            seen = 1
+        if rank == 0:
+            os.write(json_fd, (json.dumps({"metric": "launch probe", "n_gpus": world, "rccl_ranks": seen, "scaling": args.scaling,
+                                           "config": args.config, "K": args.K, "genes": args.genes, "reads_of_the_job": total_reads,
+                                           "reads_of_rank0": args.reads, "first_chunk": first_chunk, "steps": args.steps,
+                                           "warmup": args.warmup}) + "\n").encode())
+        return
     dist = None
     # SHN_BENCH_BACKEND=gloo: development aid -- several ranks on ONE GPU (collectives staged through host memory,
     # exchange.coll_device), to exercise the N-rank code path on a 1-GPU box.  Its numbers mean nothing.
@@ -275,7 +389,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         if backend == "gloo":
-            local = local % torch.cuda.device_count()
+            local = local % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
         if backend == "gloo":
             dist.init_process_group("gloo")
@@ -290,7 +404,7 @@ def main():
     # Weak scaling keeps the per-gene depth of configs[1]: the N-rank job is N gene families x 10M reads, and every
     # rank holds a 10M-read slice of that mixture (reads are sharded by index, not by gene).  Adding ranks to ONE
     # family instead would multiply its coverage (616,000x at N=8) -- a different, degenerate assembly problem.
-    families = args.families if args.families else (world if (args.genes == 1 and world > 1) else 0)
+    families = args.families if args.families else (world if (args.genes == 1 and world > 1 and args.scaling == "weak") else 0)
     lock = None
     if world > 1 and backend == "gloo" and os.environ.get("SHN_BENCH_SERIALIZE", "1") == "1":
         import fcntl
@@ -308,7 +422,9 @@ def main():
 
     if lock:
         lock.acquire()
-    r1, r2 = gen_reads(args.reads // 2, seed, args.genes, dev, read_seed=seed + 2 + 1000 * rank, families=families)
+    # strong: this rank's chunks of the one batch (read seed shared); weak: a batch of its own per rank
+    r1, r2 = gen_reads(args.reads // 2, seed, args.genes, dev, read_seed=seed + 2 + (0 if args.scaling == "strong" else 1000 * rank),
+                       families=families, first_chunk=first_chunk, exon_len=exon_len)
     ctx = device.Context(local if world > 1 else 0)
     sets = [device.Reads.from_codes(ctx, r1), device.Reads.from_codes(ctx, r2)]
     n_reads = len(sets[0]) + len(sets[1])
@@ -348,6 +464,7 @@ def main():
         step().close()
     stage_t.clear()                      # host stage times: timed steps only
     ctx.timer_reset()
+    exchange.stats_reset()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -367,8 +484,16 @@ def main():
     if dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
+    job_reads = n_reads
+    if dist and world > 1:                 # reads of the whole job (the ranks' slices of a strong-scaling batch differ by a chunk)
+        nt = torch.tensor([n_reads], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(nt, op=dist.ReduceOp.SUM)
+        job_reads = int(nt.item())
     timers = ctx.timers()
     stage_max = None
+    coll = None
+    if use_dist:
+        coll = exchange.stats_snapshot()
     if dist and world > 1:                 # slowest rank per stage (the stage dict of rank 0 alone hides imbalance)
         allst = [None] * world
         dist.all_gather_object(allst, dict(stage_t))
@@ -407,7 +532,7 @@ def main():
             avg = ms / launches
             bytes_launch = per_step_bytes[name] * args.steps / launches
             ach = bytes_launch / (avg * 1e-3) / 1e9
-            tr = TRAFFIC.get("config%d" % args.config, {}).get(name) if (is_config and world == 1) else None   # PMC passes were taken at N=1
+            tr = TRAFFIC.get("config%s" % args.config, {}).get(name) if (is_config and world == 1) else None   # PMC passes were taken at N=1
             return {"bound": "hbm", "kernel": KERNEL[name], "timer": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": tr, "launches_per_step": launches / args.steps, "avg_launch_ms": avg,
                     "algorithmic_bytes_per_launch": bytes_launch, "algorithmic_bytes_per_read": per_read.get(name)}
@@ -417,21 +542,36 @@ def main():
         if dom.startswith("extend."):
             r_dom["note"] = ("greedy walk fixpoint: dependent pointer chasing, one memory round trip per step -- latency-bound, not "
                              "bandwidth-bound; the dominant streaming kernel is in roofline_bandwidth_kernel")
+        what = {"1": "10M synthetic 2x100bp paired reads, k=25 (k1=26), single gene family, 0.5% substitution errors (BASELINE configs[1])",
+                "2": "100M synthetic 2x100bp paired reads (50M pairs), k=25 (k1=26), 20,000 genes (1-6 isoforms of 3-12 exons, lognormal "
+                     "expression), 0.5% substitution errors, multi-component, --partition 500 (BASELINE configs[2])",
+                "4s": "100M synthetic 2x100bp paired reads (50M pairs), k=31 (k1=32), 4,000 genes with exons of 80-5,000 bp (long unitigs), "
+                      "0.5% substitution errors, --partition 500 (one-GPU slice of BASELINE configs[4]: a fifth of its reads and genes)"}[args.config]
+        if not is_config and not families:
+            workload = ("%d synthetic 2x100bp paired reads%s, K=%d, %d genes (a tuning input, none of BASELINE's configs)"
+                        % (total_reads, " per GPU" if (world > 1 and args.scaling == "weak") else "", args.K, args.genes))
+        elif world > 1 and args.scaling == "strong":
+            workload = ("%s hash-sharded across %d GPUs with the RCCL all-to-all bucket exchange: every rank holds a contiguous slice of the "
+                        "batch's chunks%s" % (what, world, " (BASELINE configs[3])" if args.config == "2" else ""))
+        elif families > 1:
+            workload = ("10M synthetic 2x100bp paired reads per GPU, k=25 (k1=26), %d gene families, one per rank's worth of reads, every rank "
+                        "holding a slice of the mixture, 0.5%% substitution errors (BASELINE configs[1] per family)" % families)
+        elif world > 1:
+            workload = what + ", one such batch per GPU (weak scaling)"
+        else:
+            workload = what
         out = {
-            "metric": "reads/sec k-mer->graph->path-decompose, 2x100bp k=25",
-            "value": n_reads * world * args.steps / dt, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
+            "metric": "reads/sec k-mer->graph->path-decompose, 2x100bp k=%d" % args.K,
+            "value": job_reads * args.steps / dt, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": (("100M synthetic 2x100bp paired reads (50M pairs), k=25 (k1=26), 20,000 genes (1-6 isoforms of 3-12 exons, lognormal "
-                                     "expression), 0.5% substitution errors, multi-component, --partition 500 (BASELINE configs[2])")
-                                    if (args.config == 2 and is_config) else
-                                    ("10M synthetic 2x100bp paired reads per GPU, k=25 (k1=26), %s, 0.5%% substitution errors (BASELINE configs[1]%s)"
-                                     % (("%d gene families, one per rank's worth of reads, every rank holding a slice of the mixture" % families, " per family")
-                                        if families > 1 else ("single gene family", ""))) if is_config or families else
-                                    ("%d synthetic 2x100bp paired reads per GPU, K=%d, %d genes (a tuning input, none of BASELINE's configs)"
-                                     % (n_reads, args.K, args.genes))),
-                       "baseline_config": args.config if is_config else None,
-                       "reads_per_gpu": n_reads, "K": args.K,
+            "config": {"workload": workload,
+                       "baseline_config": (("3" if (args.config == "2" and world > 1 and args.scaling == "strong") else args.config) if is_config else None),
+                       "reads_per_gpu": n_reads, "reads_of_the_job": job_reads, "K": args.K,
+                       "rccl_ranks": (dist.get_world_size() if dist else 1), "collective_backend": (dist.get_backend() if dist else None),
+                       "collectives_per_step": ({k: {"calls": v["calls"] / args.steps, "bytes_sent": v["bytes_sent"] / args.steps,
+                                                     "bytes_received": v["bytes_received"] / args.steps, "seconds": v["seconds"] / args.steps}
+                                                 for k, v in coll.items()} if coll is not None else None),
                        "stages": ("full path a1-a31, sharded: local count -> all-to-all bucket exchange -> replicated extension -> local routing -> "
                                   "owner-side graph + sparse flow -> gather + merge on rank 0" if use_dist else
                                   "full path a1-a31: count -> extension -> partition/route -> multibridged graph -> sparse flow -> merge"),
@@ -454,13 +594,13 @@ def main():
             ing = ingest_rate(ctx, r1, r2, min(len(r1), 5_000_000))
             out["ingest"] = ing
             out["value_with_ingest"] = 1.0 / (1.0 / out["value"] + 1.0 / ing["reads_per_s"])
-        n_ov = args.overlap_steps if args.overlap_steps >= 0 else (6 if (is_config and args.config == 2) else 0)
+        n_ov = args.overlap_steps if args.overlap_steps >= 0 else (6 if (is_config and args.config == "2") else 0)
         if world == 1 and not use_dist and n_ov > 0:
             out["overlap"] = overlapped_steps(ctx, sets, store, args.K, n_ov, out["config"]["transcripts_sha256_16"], n_reads)
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 of the N=1 run only
             # bounded sample: ~10-15 s of one core through the whole path (at configs[2] a read costs the pure-Python path ~5x more
             # than at configs[1]: nearly every k1-mer of a 25k-read sample is new), + ~5 s for the counting stage alone / threaded
-            out["cpu_baseline"] = cpu_baseline(k1, r1, r2, 75_000 if args.config == 1 else 12_500)
+            out["cpu_baseline"] = cpu_baseline(k1, r1, r2, 75_000 if args.config == "1" else 12_500)
             if not use_dist:
                 out["cpu_baseline"]["graph_stage_native_host_only"] = native_graph_baseline(last.R, store, args.K)
         final_line = json.dumps(out)

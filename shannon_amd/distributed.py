@@ -25,8 +25,21 @@ import torch.distributed as dist
 from . import exchange, mbgraph, sparse_flow, post
 
 
-def _all_gather_var(t, group=None):
+def _all_gather_var(t, group=None, name="table all-gather (owned k1-mer shards)"):
     """all-gather of 1-D tensors of different lengths (padded to the max)."""
+    import time
+    t_begin = time.time()
+    out, ns = _all_gather_var_(t, group)
+    if dist.get_world_size(group) > 1:
+        if out.device.type == "cuda":
+            torch.cuda.synchronize()
+        me = dist.get_rank(group)
+        es = t.element_size()
+        exchange.note(name, es * ns[me] * (len(ns) - 1), es * (sum(ns) - ns[me]), time.time() - t_begin)
+    return out, ns
+
+
+def _all_gather_var_(t, group=None):
     W = dist.get_world_size(group)
     cdev = exchange.coll_device(t.device, group)
     n = torch.tensor([t.numel()], dtype=torch.int64, device=cdev)
@@ -230,8 +243,7 @@ def _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick):
     """the per-partition FASTA of every owner to rank 0, which merges (shannon.py:584-604)"""
     import time
     t0 = time.time()
-    gathered = [None] * W
-    dist.all_gather_object(gathered, texts, group=group)
+    gathered = exchange.all_gather_object(texts, group, "FASTA gather (per-partition transcripts to rank 0)")
     tick("x:gather fasta", t0)
     if rank != 0:
         return None
@@ -318,10 +330,9 @@ class GpuOps(object):
 
             @staticmethod
             def all_gather(obj):
-                parts = [None] * W
                 lock.release()
                 t0 = time.time()
-                dist.all_gather_object(parts, obj, group=group)
+                parts = exchange.all_gather_object(obj, group, "contig gathers (accepted contigs + connections of the shards)")
                 self.coll_wait += time.time() - t0
                 lock.acquire()
                 return parts

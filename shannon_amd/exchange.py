@@ -13,6 +13,42 @@ import torch.distributed as dist
 SHARD_SALT = 0xA24BAED4963EE407
 M64 = (1 << 64) - 1
 
+# per-collective tallies of this rank (bench.py prints them per step): name -> calls, bytes sent to / received from OTHER ranks,
+# seconds inside the calls (waiting for the slowest rank included)
+_STATS = {}
+
+
+def stats_reset():
+    _STATS.clear()
+
+
+def stats_snapshot():
+    return {k: dict(v) for k, v in _STATS.items()}
+
+
+def note(name, sent, received, seconds, calls=1):
+    if not name:
+        return
+    e = _STATS.setdefault(name, {"calls": 0, "bytes_sent": 0, "bytes_received": 0, "seconds": 0.0})
+    e["calls"] += calls
+    e["bytes_sent"] += int(sent)
+    e["bytes_received"] += int(received)
+    e["seconds"] += float(seconds)
+
+
+def all_gather_object(obj, group=None, name="objects"):
+    """dist.all_gather_object with its pickled size tallied (small control payloads: contigs, FASTA texts, stage dicts)"""
+    import pickle, time
+    W = dist.get_world_size(group)
+    parts = [None] * W
+    t0 = time.time()
+    dist.all_gather_object(parts, obj, group=group)
+    if W > 1:
+        mine = len(pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL))
+        other = sum(len(pickle.dumps(p, protocol=pickle.HIGHEST_PROTOCOL)) for i, p in enumerate(parts) if i != dist.get_rank(group))
+        note(name, mine * (W - 1), other, time.time() - t0)
+    return parts
+
 
 def fmix64_np(x):
     x = x.astype(np.uint64).copy()
@@ -45,9 +81,21 @@ def chunk_elems():
     return max(1, int(os.environ.get("SHN_COLL_CHUNK", 1 << 26)))
 
 
-def all_to_all_v(send, scl, rcl, cdev, group=None):
+def all_to_all_v(send, scl, rcl, cdev, group=None, name=None):
     """all-to-all(v) of a 1-D tensor: `send` grouped by destination with scl[d] elements each, rcl[s] elements expected from
     rank s; in rounds of chunk_elems() per pair.  Returns the received tensor (grouped by source) on cdev."""
+    import time
+    t_begin = time.time()
+    out = _all_to_all_v(send, scl, rcl, cdev, group)
+    if cdev.type == "cuda":
+        torch.cuda.synchronize()
+    me = dist.get_rank(group)
+    es = send.element_size()
+    note(name, es * (sum(scl) - scl[me]), es * (sum(rcl) - rcl[me]), time.time() - t_begin)
+    return out
+
+
+def _all_to_all_v(send, scl, rcl, cdev, group=None):
     world = dist.get_world_size(group)
     C = chunk_elems()
     n_in = sum(rcl)
@@ -76,7 +124,7 @@ def all_to_all_v(send, scl, rcl, cdev, group=None):
     return out
 
 
-def all_to_all_pairs(keys, counts, send_counts, group=None):
+def all_to_all_pairs(keys, counts, send_counts, group=None, name="bucket exchange (k1-mer keys + counts, all-to-all)"):
     """keys (int64) / counts (int32) tensors grouped by destination rank with `send_counts`
     entries each.  Returns (recv_keys, recv_counts, recv_counts_per_rank)."""
     world = dist.get_world_size(group)
@@ -89,8 +137,8 @@ def all_to_all_pairs(keys, counts, send_counts, group=None):
     scl = [int(v) for v in np.asarray(send_counts).tolist()]
     if world == 1:                                  # nothing travels
         return keys[:scl[0]], counts[:scl[0]], rcl
-    rk = all_to_all_v(keys, scl, rcl, cdev, group)
-    rcn = all_to_all_v(counts, scl, rcl, cdev, group)
+    rk = all_to_all_v(keys, scl, rcl, cdev, group, name)
+    rcn = all_to_all_v(counts, scl, rcl, cdev, group, name)
     return rk.to(dev), rcn.to(dev), rcl
 
 
@@ -108,7 +156,7 @@ def exchange_table(ctx, table, group=None):
     return device.Table.from_pairs(ctx, rk.data_ptr(), rcn.data_ptr(), rk.numel(), table.k, table.canonical)
 
 
-def all_to_all_bytes(bufs, device, group=None):
+def all_to_all_bytes(bufs, device, group=None, name="read exchange (capped reads to partition owners, all-to-all)"):
     """bufs[d] = contiguous uint8 numpy array for rank d.  One all-to-all(v) of bytes (RCCL: staged through device
     memory; gloo: host memory).  Returns the arrays received, indexed by source rank."""
     world = dist.get_world_size(group)
@@ -119,7 +167,7 @@ def all_to_all_bytes(bufs, device, group=None):
     dist.all_to_all_single(rt, st, group=group)
     rc = [int(v) for v in rt.cpu().tolist()]
     send = torch.from_numpy(np.concatenate(bufs) if sum(sc) else np.zeros(0, np.uint8))
-    recv = all_to_all_v(send, sc, rc, cdev, group)
+    recv = all_to_all_v(send, sc, rc, cdev, group, name)
     out = recv.cpu().numpy()
     offs = np.concatenate([[0], np.cumsum(rc)]).astype(np.int64)
     return [out[offs[i]:offs[i + 1]] for i in range(world)]
