@@ -465,6 +465,7 @@ def main():
     stage_t.clear()                      # host stage times: timed steps only
     ctx.timer_reset()
     exchange.stats_reset()
+    ctx.lp_stats(reset=True)
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -490,6 +491,12 @@ def main():
         dist.all_reduce(nt, op=dist.ReduceOp.SUM)
         job_reads = int(nt.item())
     timers = ctx.timers()
+    lp = ctx.lp_stats()
+    if dist and world > 1:                 # the owners of the partitions run the sparse flow: census over all ranks
+        keys = [k for k in sorted(lp) if k != "rule"]
+        lt = torch.tensor([lp[k] for k in keys], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(lt, op=dist.ReduceOp.SUM)
+        lp.update({k: int(v) for k, v in zip(keys, lt.tolist())})
     stage_max = None
     coll = None
     if use_dist:
@@ -579,6 +586,11 @@ def main():
                        "host_stage_seconds_per_step_slowest_rank": stage_max,
                        "transcripts": (len(last.res["final"]) if use_dist else len(last.R.final)),
                        "transcripts_sha256_16": _final_sha(last.res["final"] if use_dist else last.R.final),
+                       # row a28 census: path_decompose calls that reached the LP trials, and those of them in which the optimal face of a
+                       # trial was not a point (there the interior-point limit -- the analytic centre -- differs from a vertex)
+                       "lp_rule": lp["rule"], "lp_calls": lp["lp_calls"] / args.steps, "lp_degenerate": lp["lp_degenerate"] / args.steps,
+                       "lp_trials": lp["lp_trials"] / args.steps, "lp_degenerate_trials": lp["lp_degenerate_trials"] / args.steps,
+                       "lp_newton_steps": lp["newton_steps"] / args.steps, "lp_not_converged": lp["not_converged"], "lp_too_large_trials": lp["too_large_trials"],
                        "extension_iterations": ext["iterations"], "extension_walks": ext["n_walks"],
                        "extension_walk_steps": steps_all,
                        "partitions": (len(last.res["partitions"]) if use_dist else {k: [v["n_reads_routed"], v["n_k1mers"]] for k, v in last.R.partitions.items()}),

@@ -378,14 +378,28 @@ int shn_find_reps(const uint8_t* names, const uint64_t* name_off, const uint8_t*
 /* ---- sparse-flow node decomposition ------------------------------------------------------------
  * Replaces the randomized trial loop of path_decompose (path_decompose_sparse.py:100-117): the
  * <=100 cvxopt.solvers.lp calls per decomposed node (cvxopt: third party, version unpinned, not
- * vendored -- the LP optimiser is this library's own rule).  Problem p is the m x n
+ * vendored).  cvxopt.solvers.lp is an interior-point method; what is restated is its limit: the flows
+ * on the unsupported cells from an exact vertex of the trial LP (they are the same all over the
+ * optimal face), the flows on the supported (zero-cost) cells at the ANALYTIC CENTRE of the optimal
+ * face (oracle/lp.py: transport_vertex + face_center, bit for bit).  Problem p is the m x n
  * transportation problem with balanced+scaled marginals ab = [a_s (m), b_s (n)] and byte mask
  * mask[j*m+i] = 1 where NO known path supports cell (i,j); trial t draws cost numerators from the
  * counter-based stream (seed, pid[p], t, cell).  flows_out receives, per problem, trials*m*n
  * doubles laid out [cell j*m+i][trial] (problems concatenated).  Thresholding / trial selection
- * (:119-192) stay on the host (shannon_amd/sparse_flow.py).                                    */
+ * (:119-192) stay on the host (shannon_amd/sparse_flow.py, csrc/sflow_host.hip).               */
 int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint32_t* m, const uint32_t* n, const uint32_t* trials,
                        const uint64_t* pid, const double* ab, const uint8_t* mask, uint64_t seed, double* flows_out);
+/* The rule of the trial LPs on a context: SHN_LP_RULE_CENTER (default; the interior-point limit above) or SHN_LP_RULE_VERTEX
+ * (the vertex itself: the rule of rounds 1-2, kept behind this switch; SHN_LP_RULE=vertex in the environment selects it for
+ * every new context).                                                                                                          */
+#define SHN_LP_RULE_VERTEX 0
+#define SHN_LP_RULE_CENTER 1
+int shn_lp_set_rule(shn_ctx* ctx, int rule);
+/* Census of the LP calls of a context since its creation / the last reset: out8 = { problems (path_decompose calls that reached
+ * the trial loop), problems with a degenerate optimal face in at least one trial (the centre differs from the vertex), trials,
+ * trials with a degenerate face, Newton steps, classes that did not converge in 100 steps, trials of problems with more than 64
+ * rows + columns (vertex kept), the rule in force }.                                                                            */
+int shn_lp_stats(shn_ctx* ctx, uint64_t* out8, int reset);
 
 #ifdef __cplusplus
 }

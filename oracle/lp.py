@@ -1,17 +1,30 @@
 """Sparse-flow node decomposition oracle (row a28).  Test infrastructure (see
 oracle/__init__.py).  Restates path_decompose_sparse.py:15-193.
 
-THIRD-PARTY ARITHMETIC, PARITY UNPINNED: the reference solves each trial LP with
-cvxopt.solvers.lp (interior point; cvxopt is imported at path_decompose_sparse.py:29 and
-algorithm_SF.py:12, no version pinned anywhere, not vendored, not installable here) and draws
-unseeded numpy.random.normal costs (:107).  On a degenerate optimal face cvxopt returns the
-analytic centre; this build *defines* its own rule instead:
+THIRD-PARTY ARITHMETIC: the reference solves each trial LP with cvxopt.solvers.lp (a primal-dual
+INTERIOR-POINT method; cvxopt is imported at path_decompose_sparse.py:29 and algorithm_SF.py:12, no
+version pinned anywhere, not vendored, not installable here) and draws unseeded numpy.random.normal
+costs (:107).  Supported cells cost nothing (p = 1 - P, :74-84, :107-109), so the optimal face of a
+trial is normally NOT a point, and an interior-point method does not return a vertex of it: its
+iterates follow the central path, whose limit is the ANALYTIC CENTRE of the optimal face.  That limit
+is what is restated here (round 3; rounds 1-2 returned a vertex, which loses transcripts: m = n = 2,
+P all ones, a = b = (10, 10) gives 5/5/5/5 -> four clones, a vertex gives two):
 
   * costs: counter-based generator, |Irwin-Hall(12) - 6| from splitmix64 hashes of
     (seed, problem id, trial, cell) -- integer arithmetic only, so CPU and GPU agree bit for bit;
-  * LP: the transportation problem  min c.x, row sums a, column sums b, x >= 0  is solved to an
-    exact *vertex* by successive shortest paths with Jacobi Bellman-Ford rounds and
-    lowest-index tie-breaks (spec below; the HIP kernel implements the identical sequence).
+  * the flows on the UNSUPPORTED cells: with generic costs they are the same in every optimal
+    solution, so an exact vertex of  min c.x, row sums a, column sums b, x >= 0  (successive shortest
+    paths, Jacobi Bellman-Ford rounds, lowest-index tie-breaks: transport_vertex) gives them;
+  * the flows on the SUPPORTED cells: the optimal face is the transportation polytope of what is
+    left of the marginals over the supported cells; face_center puts them at its analytic centre
+    (max sum log x over the cells that can be positive on the face: 1 / x_ij = u_i + v_j), found by
+    an infeasible-start Newton iteration written out operation by operation (+ - * / and compares on
+    IEEE doubles, no fused multiply-add), so that the HIP kernel (csrc/lp.hip) repeats it bit for bit.
+  rule="vertex" (SHN_LP_RULE=vertex in the product) keeps the rounds 1-2 rule.
+
+What pins it without cvxopt (tests/test_lp_center.py, labelled "not cvxopt"): closed forms (2x2; complete
+supports with equal marginals), and a dense log-barrier path-following solve of the SAME LP in numpy
+(c.x / mu - sum log x with mu -> 0), whose limit is the centre by definition -- agreement to 1e-6.
 
 Everything around the LP (balancing, scaling, thresholds, trial selection, top-`sparsity`
 truncation) follows the reference line by line and is pinned against it in tests/golden.
@@ -143,15 +156,258 @@ def transport_vertex(a, b, c):
     return x
 
 
+def face_center(x, sup, stats=None):
+    """x: m x n vertex flows (transport_vertex); sup[i][j] truthy = supported (zero-cost) cell.  Returns x with the supported
+    cells moved to the analytic centre of the optimal face  {y >= 0 on supported cells : row / column sums of the supported
+    cells as in x}  (the unsupported cells keep their flows).
+
+    Spec (shared with shannon_amd/csrc/lp.hip: lp_center):
+      nodes: rows 0..m-1, columns m..m+n-1.  Residual digraph: row i -> column j for every supported cell, column j -> row i
+      for every supported cell with x[i][j] > 0.  reach = its reflexive transitive closure; two nodes are in one class when
+      each reaches the other; label = smallest node of the class.  A supported cell can be positive somewhere on the face
+      iff its row and column are in one class (a cycle of the residual digraph passes through it).
+      For every class with rows R (ascending) and columns C (ascending), E = its supported cells in row-major order:
+        |E| <= |R| + |C| - 1 (a tree: the face is a point there): nothing to do;
+        else center_component.
+    """
+    m, n = len(x), len(x[0])
+    N = m + n
+    if N > 64:                                   # (bit masks of 64 nodes; larger nodes keep the vertex -- counted)
+        if stats is not None:
+            stats["too_large"] = stats.get("too_large", 0) + 1
+        return x
+    reach = [0] * N
+    for i in range(m):
+        r = 1 << i
+        for j in range(n):
+            if sup[i][j]:
+                r |= 1 << (m + j)
+        reach[i] = r
+    for j in range(n):
+        r = 1 << (m + j)
+        for i in range(m):
+            if sup[i][j] and x[i][j] > 0:
+                r |= 1 << i
+        reach[m + j] = r
+    changed = True
+    while changed:
+        changed = False
+        for u in range(N):
+            r = reach[u]
+            acc = r
+            for v in range(N):
+                if (r >> v) & 1:
+                    acc |= reach[v]
+            if acc != r:
+                reach[u] = acc
+                changed = True
+    label = [0] * N
+    for u in range(N):
+        for v in range(N):
+            if (reach[u] >> v) & 1 and (reach[v] >> u) & 1:
+                label[u] = v
+                break
+    out = [row[:] for row in x]
+    for L in range(m):
+        if label[L] != L:
+            continue
+        R = [i for i in range(m) if label[i] == L]
+        Cc = [j for j in range(n) if label[m + j] == L]
+        if not Cc:
+            continue
+        E = [(i, j) for i in R for j in Cc if sup[i][j]]
+        if len(E) <= len(R) + len(Cc) - 1:
+            continue
+        if stats is not None:
+            stats["components"] = stats.get("components", 0) + 1
+        center_component(out, R, Cc, E, stats)
+    return out
+
+
+NEWTON_MAX = 100
+NEWTON_TOL2 = 1e-20        # squared residual norm (normalised problem) after which one last full step is taken
+
+
+def center_component(x, R, Cc, E, stats=None):
+    """Analytic centre of { y_e > 0, e in E : sum over row i = ra_i, sum over column j = rb_j }  (ra, rb: the sums of x over
+    E), written back into x.  Infeasible-start Newton (Boyd & Vandenberghe 10.3.2) on  min -sum log y  s.t. A y = b, the
+    constraint of the LAST column of C dropped (implied), in the normalised variable y = x / s, s = T / |E|:
+      start  y_e = ra_i rb_j / (T s),  nu = 0;
+      step   D_i = sum_row y^2, W_ij = y_ij^2, g_i = 2 sum_row y - ra_i / s   (rows),  the same per kept column;
+             w_cols from the Schur complement  S = D_c - W' D_r^-1 W,  h = g_c - W' D_r^-1 g_r  (Gaussian elimination, no
+             pivoting: S is symmetric positive definite), w_rows = (g_r - W w_c) / D_r;
+             dy = y - y^2 (w_row + w_col),  dnu = w - nu;
+      t = 1, halved while some y + t dy <= 0, then while |r(y + t dy, nu + t dnu)|^2 > (1 - 0.01 t)^2 |r|^2  (t >= 2^-40);
+      r = (-1 / y + nu_row + nu_col ;  sums - b);  stop after the step that follows |r|^2 <= 1e-20, or after 100 steps.
+    Every sum runs in ascending order of its index (cells of a row by column, of a column by row; rows before columns)."""
+    nr, nc = len(R), len(Cc)
+    q = nc - 1
+    ri = {i: k for k, i in enumerate(R)}
+    ci = {j: k for k, j in enumerate(Cc)}
+    ne = len(E)
+    er = [ri[i] for i, j in E]
+    ec = [ci[j] for i, j in E]
+    ra = [0.0] * nr
+    rb = [0.0] * nc
+    for e in range(ne):
+        v = x[E[e][0]][E[e][1]]
+        ra[er[e]] += v
+    for k in range(nc):                                   # column sums in ascending row order (E is row-major)
+        acc = 0.0
+        for e in range(ne):
+            if ec[e] == k:
+                acc += x[E[e][0]][E[e][1]]
+        rb[k] = acc
+    T = 0.0
+    for v in ra:
+        T += v
+    s = T / ne
+    an = [v / s for v in ra]
+    bn = [v / s for v in rb]
+    Tn = T / s
+    y = [an[er[e]] * bn[ec[e]] / Tn for e in range(ne)]
+    nu_r = [0.0] * nr
+    nu_c = [0.0] * nc                                      # nu_c[q] (dropped column) stays 0
+
+    def residual2(yy, nr_, nc_):
+        acc = 0.0
+        for e in range(ne):
+            d = nr_[er[e]] + nc_[ec[e]] - 1.0 / yy[e]
+            acc += d * d
+        for k in range(nr):
+            sm = 0.0
+            for e in range(ne):
+                if er[e] == k:
+                    sm += yy[e]
+            d = sm - an[k]
+            acc += d * d
+        for k in range(q):
+            sm = 0.0
+            for e in range(ne):
+                if ec[e] == k:
+                    sm += yy[e]
+            d = sm - bn[k]
+            acc += d * d
+        return acc
+
+    r2 = residual2(y, nu_r, nu_c)
+    last = False
+    its = 0
+    for its in range(1, NEWTON_MAX + 1):
+        Dr = [0.0] * nr
+        Dc = [0.0] * nc
+        gr = [0.0] * nr
+        gc = [0.0] * nc
+        y2 = [v * v for v in y]
+        for e in range(ne):
+            Dr[er[e]] += y2[e]
+            gr[er[e]] += y[e]
+        for k in range(nc):
+            a1 = 0.0
+            a2 = 0.0
+            for e in range(ne):
+                if ec[e] == k:
+                    a1 += y2[e]
+                    a2 += y[e]
+            Dc[k] = a1
+            gc[k] = a2
+        for k in range(nr):
+            gr[k] = 2.0 * gr[k] - an[k]
+        for k in range(nc):
+            gc[k] = 2.0 * gc[k] - bn[k]
+        # Schur complement on the kept columns
+        S = [[0.0] * q for _ in range(q)]
+        h = [0.0] * q
+        for k in range(q):
+            S[k][k] = Dc[k]
+            h[k] = gc[k]
+        for i in range(nr):                                # rows ascending; within a row cells ascending
+            cells = [e for e in range(ne) if er[e] == i]
+            inv = 1.0 / Dr[i]
+            for e1 in cells:
+                k1 = ec[e1]
+                if k1 >= q:
+                    continue
+                f = y2[e1] * inv
+                h[k1] -= f * gr[i]
+                for e2 in cells:
+                    k2 = ec[e2]
+                    if k2 >= q:
+                        continue
+                    S[k1][k2] -= f * y2[e2]
+        # Gaussian elimination without pivoting
+        for k in range(q):
+            piv = S[k][k]
+            for r_ in range(k + 1, q):
+                f = S[r_][k] / piv
+                if f != 0.0:
+                    for c_ in range(k + 1, q):
+                        S[r_][c_] -= f * S[k][c_]
+                    h[r_] -= f * h[k]
+        wc = [0.0] * nc
+        for k in range(q - 1, -1, -1):
+            acc = h[k]
+            for c_ in range(k + 1, q):
+                acc -= S[k][c_] * wc[c_]
+            wc[k] = acc / S[k][k]
+        wr = [0.0] * nr
+        for i in range(nr):
+            acc = gr[i]
+            for e in range(ne):
+                if er[e] == i and ec[e] < q:
+                    acc -= y2[e] * wc[ec[e]]
+            wr[i] = acc / Dr[i]
+        dy = [y[e] - y2[e] * (wr[er[e]] + wc[ec[e]]) for e in range(ne)]
+        t = 1.0
+        tmin = 1.0 / float(1 << 40)
+        while t >= tmin:
+            ok = True
+            for e in range(ne):
+                if not (y[e] + t * dy[e] > 0.0):
+                    ok = False
+                    break
+            if ok:
+                break
+            t *= 0.5
+        while True:
+            yn = [y[e] + t * dy[e] for e in range(ne)]
+            nrn = [nu_r[k] + t * (wr[k] - nu_r[k]) for k in range(nr)]
+            ncn = [nu_c[k] + t * (wc[k] - nu_c[k]) for k in range(nc)]
+            r2n = residual2(yn, nrn, ncn)
+            f = 1.0 - 0.01 * t
+            if r2n <= f * f * r2 or t < tmin:
+                break
+            t *= 0.5
+        y, nu_r, nu_c, r2 = yn, nrn, ncn, r2n
+        if last:
+            break
+        if r2 <= NEWTON_TOL2:
+            last = True
+    if stats is not None:
+        stats["newton_steps"] = stats.get("newton_steps", 0) + its
+        if not last:
+            stats["not_converged"] = stats.get("not_converged", 0) + 1
+    for e in range(ne):
+        x[E[e][0]][E[e][1]] = y[e] * s
+
+
+def transport_center(a, b, c, sup, stats=None):
+    """one trial of the restated interior-point limit: unsupported flows from the exact vertex, supported flows at the analytic
+    centre of the optimal face"""
+    return face_center(transport_vertex(a, b, c), sup, stats)
+
+
 def n_trials(m, n):
     """path_decompose_sparse.py:100."""
     return int(round(min(2 * m * n * max(m, n), 100)))
 
 
-def path_decompose(a, b, P, seed=0, pid=0, sparsity=10, solver=None, cost_fn=None):
+def path_decompose(a, b, P, seed=0, pid=0, sparsity=10, solver=None, cost_fn=None, rule="center", stats=None):
     """path_decompose_sparse.py:15-193 with overwrite_norm=False, use_GLPK=False.
     a, b: lists of floats; P: m x n 0/1 (list of lists); returns (answer m x n list of lists, non_unique).
-    """
+    rule: "center" = the interior-point limit (vertex flows on unsupported cells + analytic centre of the optimal face),
+    "vertex" = the rule of rounds 1-2.  stats (dict): lp_calls, lp_degenerate (calls in which a trial's optimal face was not a
+    point), newton_steps."""
     m, n = len(a), len(b)
     if m == 0 or n == 0:
         return [], 0                                            # :38-39
@@ -202,10 +458,21 @@ def path_decompose(a, b, P, seed=0, pid=0, sparsity=10, solver=None, cost_fn=Non
     curr_mult = 0
     curr_on_unknown = 0.0
     mn = m * n
+    sup = [[not (p[j * m + i] > 0) for j in range(n)] for i in range(m)]
+    memo = {}                                                   # (speed only: equal vertices have equal centres)
+    cst = {}
     for ctr in range(trials):
         cc = (cost_fn or trial_costs)(seed, pid, ctr, mn)
         c = [[(cc[j * m + i] if p[j * m + i] > 0 else 0) for j in range(n)] for i in range(m)]
-        xs = (solver or transport_vertex)(a_s, b_s, c)
+        if solver is not None:
+            xs = solver(a_s, b_s, c)
+        else:
+            xs = transport_vertex(a_s, b_s, c)
+            if rule == "center":
+                key = tuple(v for row in xs for v in row)
+                if key not in memo:
+                    memo[key] = face_center(xs, sup, cst)
+                xs = memo[key]
         temp = [xs[k % m][k // m] * scale for k in range(mn)]   # temp_sol[j*m+i]
         for i in range(m):
             for j in range(n):
@@ -236,6 +503,13 @@ def path_decompose(a, b, P, seed=0, pid=0, sparsity=10, solver=None, cost_fn=Non
                 sc += v
             if (abs(st - sc) < tol and dot < curr_on_unknown) or st > sc:
                 curr_ans, curr_on_unknown = temp, dot
+    if stats is not None:
+        stats["lp_calls"] = stats.get("lp_calls", 0) + 1
+        if cst.get("components", 0):
+            stats["lp_degenerate"] = stats.get("lp_degenerate", 0) + 1
+        for k in ("newton_steps", "not_converged", "too_large"):
+            if cst.get(k):
+                stats[k] = stats.get(k, 0) + cst[k]
     answer = [[float(curr_ans[j * m + i]) for j in range(n)] for i in range(m)]
     non_unique = 1 if curr_mult > 1 else 0
     if sparsity and m * n > sparsity:                           # :180-192

@@ -54,6 +54,8 @@ SIGNATURES = {
     "shn_routes_bounds": (C.c_int, [vp, vp, C.c_uint32, C.c_uint32, vp, vp]),
     "shn_routes_download_range": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, vp]),
     "shn_lp_solve_batch": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_uint64, vp]),
+    "shn_lp_set_rule": (C.c_int, [vp, C.c_int]),
+    "shn_lp_stats": (C.c_int, [vp, vp, C.c_int]),
     "shn_contig_graph": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_int, C.c_double, vp, u64p, vp, vp, vp, u64p]),
     "shn_seed_scan": (C.c_int, [vp, vp, C.c_int, vp, u64p, vp, vp, vp]),
     "shn_rmer_join": (C.c_int, [vp, vp, vp, C.c_int, u64p, vp, vp, vp]),

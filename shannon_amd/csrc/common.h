@@ -39,8 +39,11 @@ struct shn_ctx {
   bool timing;
   bool owns_stream;        // shn_ctx_fork: the stream is destroyed with the context
   int count_direct_log2;   // one-pass counting: table size that sufficed last time (0 none yet, -1 gave up), shn_count_k1mers
-  ShnWs cws[4];            // per-context workspaces of the calls several host threads make at the same time, each on its own
-                           // context / stream (the graph threads' seed scans): [0] scan block sums, [1] [2] seed-scan counts / offsets
+  ShnWs cws[12];           // per-context workspaces of the calls several host threads make at the same time, each on its own
+                           // context / stream (the graph threads' seed scans): [0] scan block sums, [1] [2] seed-scan counts / offsets,
+                           // [4..11] the LP batches of the sparse flow (two batches may be in flight on two contexts)
+  int lp_rule;             // SHN_LP_RULE_CENTER (default) / SHN_LP_RULE_VERTEX (SHN_LP_RULE=vertex in the environment, shn_lp_set_rule)
+  uint64_t lp_stats[8];    // shn_lp_stats
 };
 
 // RAII-less region timer: records events on the ctx stream; durations are summed lazily.
@@ -211,11 +214,15 @@ int shn_sort_pairs(shn_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t* keys_
 
 static inline uint64_t cdiv(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
-// device buffers of one call, given back to the caching allocator when the call ends
+// device buffers of one call, given back to the caching allocator when the call ends -- after the stream that used them has
+// been synchronized (a block given back goes straight to the next caller, another host thread's stream perhaps; on the success
+// path the call has synchronized already and this costs nothing, on an early error return kernels may still be queued)
 struct ShnDevBufs {
   std::vector<void*> p;
+  hipStream_t stream;
+  explicit ShnDevBufs(hipStream_t s) : stream(s) {}
   template <class T> hipError_t get(T** out, size_t bytes) { hipError_t e = shn_dev_malloc(out, bytes); if (e == hipSuccess) p.push_back((void*)*out); return e; }
-  ~ShnDevBufs() { for (void* q : p) shn_dev_free(q); }
+  ~ShnDevBufs() { if (!p.empty()) (void)hipStreamSynchronize(stream); for (void* q : p) shn_dev_free(q); }
 };
 // contig texts on the device (csrc/contig_gpu.hip): cid[g] = contig of base g; the k-windows of the selected contigs (use ==
 // NULL: all) as (packed key, base index of the window start) pairs sorted by key, stable (so by contig, position inside a run)

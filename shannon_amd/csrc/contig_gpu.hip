@@ -277,7 +277,7 @@ extern "C" int shn_contig_stage(shn_ctx* ctx, const uint8_t* bases, const uint64
   hipStream_t s = ctx->stream;
   shn_stage_begin();
   TimerRegion treg(ctx, T_CONTIG);
-  ShnDevBufs bufs;
+  ShnDevBufs bufs(s);
   uint8_t* d_bases; uint64_t* d_off; uint32_t* d_cid;
   HIP_TRY(bufs.get(&d_bases, total + 64));
   HIP_TRY(bufs.get(&d_off, (n_cand + 1) * 8));
@@ -298,7 +298,7 @@ extern "C" int shn_contig_stage(shn_ctx* ctx, const uint8_t* bases, const uint64
   }
   uint64_t n_rounds = 0, n_blocks = 0;
   {
-    ShnDevBufs tmp;
+    ShnDevBufs tmp(s);
     uint64_t* keys; uint32_t* vals; uint64_t nv = 0;
     int rc = shn_sorted_windows(ctx, tmp, d_bases, d_off, d_cid, nullptr, total, r, &keys, &vals, &nv);
     if (rc) return rc;
@@ -411,7 +411,7 @@ extern "C" int shn_contig_stage(shn_ctx* ctx, const uint8_t* bases, const uint64
     int32_t* d_use;
     HIP_TRY(bufs.get(&d_use, n_cand * 4));
     HIP_TRY(hipMemcpyAsync(d_use, use.data(), n_cand * 4, hipMemcpyHostToDevice, s));
-    ShnDevBufs tmp;
+    ShnDevBufs tmp(s);
     uint64_t* keys; uint32_t* vals; uint64_t nv = 0;
     int rc = shn_sorted_windows(ctx, tmp, d_bases, d_off, d_cid, d_use, total, C, &keys, &vals, &nv);
     if (rc) return rc;

@@ -38,8 +38,9 @@ TimerRegion::~TimerRegion() {
 
 // Invariant of the caching allocator (shared by every context and host thread of the process, one process per GPU): a block is
 // handed to the next caller as soon as it is freed, with no stream ordering -- so a caller frees a block only after the stream
-// that used it has been synchronized (every entry point of this library ends with hipStreamSynchronize before its frees; the
-// graph threads allocate inside g_gpu_mutex sections that end synchronized).  shn_dev_trim only releases blocks nobody holds.
+// that used it has been synchronized (every entry point of this library ends with hipStreamSynchronize before its frees, on its
+// error paths too: ShnDevBufs synchronizes its stream before it gives its blocks back; the graph threads work on forked contexts
+// with streams of their own).  shn_dev_trim only releases blocks nobody holds.
 namespace {
 struct DevBlock { void* p; size_t cap; bool used; };
 std::vector<DevBlock> g_blocks;
@@ -100,6 +101,9 @@ extern "C" int shn_ctx_create(int device, void* stream, shn_ctx** out) {
   c->count_direct_log2 = 0;
   c->owns_stream = false;
   for (int i = 0; i < T_N; i++) { c->ms[i] = 0; c->regions[i] = 0; }
+  const char* rule = getenv("SHN_LP_RULE");
+  c->lp_rule = (rule && !strcmp(rule, "vertex")) ? SHN_LP_RULE_VERTEX : SHN_LP_RULE_CENTER;
+  for (auto& v : c->lp_stats) v = 0;
   *out = c;
   return SHN_OK;
 }
@@ -126,6 +130,8 @@ extern "C" int shn_ctx_fork(const shn_ctx* parent, shn_ctx** out) {
   shn_ctx* c = new shn_ctx();
   c->device = parent->device; c->stream = st; c->timing = false; c->count_direct_log2 = 0; c->owns_stream = true;
   for (int i = 0; i < T_N; i++) { c->ms[i] = 0; c->regions[i] = 0; }
+  c->lp_rule = parent->lp_rule;
+  for (auto& v : c->lp_stats) v = 0;
   *out = c;
   return SHN_OK;
 }

@@ -10,6 +10,7 @@
 // Buckets are ranges of the top `bits` bits of murmur-fmix64(key); one bucket fits an LDS hash
 // table of CAP slots, so duplicates (heavy k-mers) cost no capacity, only LDS atomics.
 #include "common.h"
+#include <mutex>
 #include <atomic>
 #include <cmath>
 #include <algorithm>
@@ -468,15 +469,27 @@ __global__ void gtable_compact_kernel(const unsigned long long* __restrict__ gke
 // slot remembers the stage that used it last.  When an allocation fails, what the slots of EARLIER stages hold is given back
 // and the allocation is tried again -- hipMalloc of tens of GB costs seconds here (tools/probes/malloc_probe.hip), so nothing
 // is freed as long as everything fits.
+// Who may use what, now that two batches can be in flight (the deferred back half of a step -- graph, sparse flow, merge -- on a
+// second context and host thread beside the next step's front half) and the graph threads run on forked contexts: the
+// process-wide slots g_shn_ws[] belong to the top-level stages of the FRONT half only (count, extension, contig stage, probe
+// table, routing, unitigs: one after the other on one host thread); everything the back half and the graph threads call (seed
+// scans, the device scan, the LP batches) keeps its workspaces in its own context (shn_ctx::cws), which shn_ws_release_idle
+// never touches.  get / release are serialised by g_ws_mu, so a slot's pointer and capacity are never written by two threads.
 static std::atomic<uint64_t> g_stage{1};
+static std::mutex g_ws_mu;
 void shn_stage_begin() { g_stage.fetch_add(1); }
-size_t shn_ws_release_idle() {
+static size_t ws_release_idle_locked() {
   size_t freed = 0;
   const uint64_t now = g_stage.load();
   for (auto& w : g_shn_ws) if (w.p && w.stage < now) { hipFree(w.p); freed += w.cap; w.p = nullptr; w.cap = 0; }
   return freed;
 }
+size_t shn_ws_release_idle() {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  return ws_release_idle_locked();
+}
 int ShnWs::get(size_t bytes, void** out) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
   stage = g_stage.load();
   if (bytes > cap) {
     if (p) hipFree(p);
@@ -485,7 +498,7 @@ int ShnWs::get(size_t bytes, void** out) {
     if (e != hipSuccess) {                       // make room: cached blocks, then the slots of earlier stages
       (void)hipGetLastError();
       shn_dev_trim();
-      shn_ws_release_idle();
+      ws_release_idle_locked();
       e = hipMalloc(&p, bytes);
     }
     if (e != hipSuccess) { p = nullptr; return shn_fail(SHN_ERR_NOMEM, std::string("hipMalloc workspace: ") + hipGetErrorString(e)); }

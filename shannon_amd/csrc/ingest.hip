@@ -198,7 +198,8 @@ extern "C" int shn_reads_ingest(shn_ctx* ctx, const uint8_t* text, uint64_t n_by
   uint8_t* dst[2] = {nullptr, nullptr};
   hipEvent_t ev[2] = {nullptr, nullptr};
   hipStream_t s = ctx->stream;
-  auto cleanup = [&]() {
+  auto cleanup = [&]() {                       // (the staging blocks go back to the allocator only after the stream has drained)
+    (void)hipStreamSynchronize(s);
     for (int b = 0; b < 2; b++) { if (dst[b]) shn_dev_free(dst[b]); if (ev[b]) hipEventDestroy(ev[b]); }
   };
 #define TRYI(e) do { hipError_t _e = (e); if (_e != hipSuccess) { cleanup(); shn_reads_destroy(r); \

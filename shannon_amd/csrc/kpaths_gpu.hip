@@ -154,7 +154,7 @@ extern "C" int shn_known_paths_scan(shn_ctx* ctx, const shn_reads* reads, int K,
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   TimerRegion treg(ctx, T_SEEDS);
-  ShnDevBufs bufs;
+  ShnDevBufs bufs(s);
   uint64_t T = 1024;
   while (T < 2 * total) T <<= 1;
   uint8_t *d_bases = nullptr, *d_state = nullptr;

@@ -3,11 +3,19 @@
 //
 // Each trial is a tiny transportation problem  min c.x, row sums a, column sums b, x >= 0  with
 // cost numerators c = |Irwin-Hall(12) - 6| * 2^32 on unsupported cells, 0 on supported cells
-// (counter-based splitmix64 stream -- integer arithmetic, identical on CPU and GPU).  It is solved
-// by successive shortest paths with Jacobi Bellman-Ford rounds and lowest-index tie-breaks; the
-// exact sequence is specified in oracle/lp.py:transport_vertex and restated here.  The trials of
-// one node run in the lanes of a wavefront (lane = trial): same m, n, a, b, support mask, different
-// costs.  All per-trial state lives in a [element][trial] workspace so lane accesses coalesce.
+// (counter-based splitmix64 stream -- integer arithmetic, identical on CPU and GPU).  cvxopt solves
+// it with an interior-point method, whose limit on a degenerate optimal face (the normal case: supported
+// cells cost nothing) is the face's analytic centre.  That limit is computed here in two kernels:
+//   lp_trials_kernel   an exact vertex by successive shortest paths with Jacobi Bellman-Ford rounds and
+//                      lowest-index tie-breaks (oracle/lp.py:transport_vertex) -- it fixes the flows on the
+//                      unsupported cells, which are the same all over the optimal face;
+//   lp_center_kernel   the supported cells moved to the analytic centre of the face: classes of the residual
+//                      digraph (which cells can be positive), then an infeasible-start Newton iteration per class
+//                      with more cells than a tree (oracle/lp.py:face_center / center_component, repeated
+//                      operation by operation: IEEE doubles, -ffp-contract=off, so the two agree bit for bit).
+// The trials of one node run in the lanes of a wavefront (lane = trial): same m, n, a, b, support mask,
+// different costs.  All per-trial state lives in a [element][trial] workspace so lane accesses coalesce.
+// SHN_LP_RULE=vertex (or shn_lp_set_rule) keeps the vertex as the answer (the rule of rounds 1-2).
 // No MFMA: no dense contraction anywhere.
 #include "common.h"
 
@@ -40,6 +48,8 @@ struct LpProblem {
   uint64_t mask_off;   // bytes: p[j*m+i] (1 = unsupported)
   uint64_t ws_off;     // 8-byte words of workspace for this problem
   uint64_t out_off;    // doubles: [cell k = j*m+i][trial]
+  uint64_t ws2_off;    // 8-byte words of the centre kernel's workspace for this problem
+  uint64_t stat_off;   // first trial of this problem in the per-trial statistics
 };
 
 // workspace layout per problem (T = trials), all [elem][trial]:
@@ -134,6 +144,235 @@ __global__ __launch_bounds__(LBLK) void lp_trials_kernel(const LpProblem* __rest
 #undef CX
 }
 
+#define NEWTON_MAX 100
+#define NEWTON_TOL2 1e-20
+
+// per-trial words of the centre kernel's own workspace: y, y2, dy, yn [mn each] | S [n*n] | 14 vectors of <= max(m, n) + 1
+__host__ __device__ __forceinline__ uint64_t lp_ws2_words(uint64_t m, uint64_t n) { return 4 * m * n + n * n + 14 * (m + n + 1); }
+
+// oracle/lp.py:face_center + center_component for the trial of this lane.  X is the vertex left by lp_trials_kernel.
+// stat[4 * trial + 0..3]: classes centred, Newton steps, classes not converged, 1 if m + n > 64 (vertex kept)
+__global__ __launch_bounds__(LBLK) void lp_center_kernel(const LpProblem* __restrict__ probs, const uint32_t* __restrict__ block_prob,
+                                                         const uint32_t* __restrict__ block_first, const uint8_t* __restrict__ masks,
+                                                         uint64_t* __restrict__ ws, uint64_t* __restrict__ ws2, double* __restrict__ out,
+                                                         uint32_t* __restrict__ stat) {
+  const LpProblem P = probs[block_prob[blockIdx.x]];
+  const uint32_t t = block_first[blockIdx.x] + threadIdx.x;
+  if (t >= P.trials) return;
+  const uint32_t m = P.m, n = P.n, T = P.trials, mn = m * n, N = m + n;
+  const uint8_t* pm = masks + P.mask_off;
+  int64_t* C = (int64_t*)(ws + P.ws_off);                   // reused: the cells of the class being centred
+  double* X = (double*)(C + (uint64_t)mn * T);
+  double* ra_ = X + (uint64_t)mn * T;
+  double* rb_ = ra_ + (uint64_t)m * T;
+  uint64_t* reach = (uint64_t*)(rb_ + (uint64_t)n * T);     // ds | dt : N words
+  int64_t* label = (int64_t*)(reach + (uint64_t)N * T);     // ps | pt : N words
+  double* W = (double*)(ws2 + P.ws2_off);
+  double* y = W;
+  double* y2 = y + (uint64_t)mn * T;
+  double* dy = y2 + (uint64_t)mn * T;
+  double* yn = dy + (uint64_t)mn * T;
+  double* S = yn + (uint64_t)mn * T;
+  double* vec = S + (uint64_t)n * n * T;
+  const uint64_t VL = (uint64_t)(N + 1) * T;                // one vector slot (any of them holds m or n + 1 entries)
+  double *an = vec, *bn = vec + VL, *nur = vec + 2 * VL, *nuc = vec + 3 * VL, *nrn = vec + 4 * VL, *ncn = vec + 5 * VL, *Dr = vec + 6 * VL,
+         *Dc = vec + 7 * VL, *gr = vec + 8 * VL, *gc = vec + 9 * VL, *wr = vec + 10 * VL, *wc = vec + 11 * VL, *h = vec + 12 * VL;
+  int64_t* rstart = (int64_t*)(vec + 13 * VL);              // first cell of every local row (E is row-major), nr + 1 entries
+#define AT(arr, e) arr[(uint64_t)(e) * T + t]
+#define CX(i, j) ((uint64_t)((j) * m + (i)))
+  uint32_t st_comp = 0, st_steps = 0, st_bad = 0, st_large = 0;
+  double* o = out + P.out_off;
+  if (N > 64) {
+    st_large = 1;
+  } else {
+    // ---- classes of the residual digraph
+    for (uint32_t i = 0; i < m; i++) {
+      uint64_t r = 1ULL << i;
+      for (uint32_t j = 0; j < n; j++) if (!pm[CX(i, j)]) r |= 1ULL << (m + j);
+      AT(reach, i) = r;
+    }
+    for (uint32_t j = 0; j < n; j++) {
+      uint64_t r = 1ULL << (m + j);
+      for (uint32_t i = 0; i < m; i++) if (!pm[CX(i, j)] && AT(X, CX(i, j)) > 0) r |= 1ULL << i;
+      AT(reach, m + j) = r;
+    }
+    for (bool changed = true; changed;) {
+      changed = false;
+      for (uint32_t u = 0; u < N; u++) {
+        const uint64_t r = AT(reach, u);
+        uint64_t acc = r;
+        for (uint32_t v = 0; v < N; v++) if ((r >> v) & 1) acc |= AT(reach, v);
+        if (acc != r) { AT(reach, u) = acc; changed = true; }
+      }
+    }
+    for (uint32_t u = 0; u < N; u++) {
+      const uint64_t r = AT(reach, u);
+      int64_t l = u;
+      for (uint32_t v = 0; v < N; v++) if (((r >> v) & 1) && ((AT(reach, v) >> u) & 1)) { l = v; break; }
+      AT(label, u) = l;
+    }
+    // ---- every class with more supported cells than a tree
+    for (uint32_t L = 0; L < m; L++) {
+      if (AT(label, L) != (int64_t)L) continue;
+      uint32_t nr = 0, nc = 0, ne = 0;
+      for (uint32_t j = 0; j < n; j++) if (AT(label, m + j) == (int64_t)L) nc++;
+      if (!nc) continue;
+      // cells in row-major order: packed (i, j, local row, local column), 16 bits each
+      for (uint32_t i = 0; i < m; i++) {
+        if (AT(label, i) != (int64_t)L) continue;
+        AT(rstart, nr) = ne;
+        uint32_t cl = 0;
+        for (uint32_t j = 0; j < n; j++) {
+          if (AT(label, m + j) != (int64_t)L) continue;
+          if (!pm[CX(i, j)]) { AT(C, ne) = (int64_t)((uint64_t)i | ((uint64_t)j << 16) | ((uint64_t)nr << 32) | ((uint64_t)cl << 48)); ne++; }
+          cl++;
+        }
+        nr++;
+      }
+      AT(rstart, nr) = ne;
+      if (ne <= nr + nc - 1) continue;
+      st_comp++;
+      const uint32_t q = nc - 1;
+#define EI(e) ((uint32_t)((uint64_t)AT(C, e) & 0xFFFF))
+#define EJ(e) ((uint32_t)(((uint64_t)AT(C, e) >> 16) & 0xFFFF))
+#define ER(e) ((uint32_t)(((uint64_t)AT(C, e) >> 32) & 0xFFFF))
+#define EC(e) ((uint32_t)(((uint64_t)AT(C, e) >> 48) & 0xFFFF))
+      for (uint32_t k = 0; k < nr; k++) AT(an, k) = 0.0;
+      for (uint32_t k = 0; k < nc; k++) AT(bn, k) = 0.0;
+      for (uint32_t e = 0; e < ne; e++) {
+        const double v = AT(X, CX(EI(e), EJ(e)));
+        AT(an, ER(e)) += v;
+        AT(bn, EC(e)) += v;
+      }
+      double Tt = 0.0;
+      for (uint32_t k = 0; k < nr; k++) Tt += AT(an, k);
+      const double sc = Tt / (double)ne;
+      for (uint32_t k = 0; k < nr; k++) AT(an, k) = AT(an, k) / sc;
+      for (uint32_t k = 0; k < nc; k++) AT(bn, k) = AT(bn, k) / sc;
+      const double Tn = Tt / sc;
+      for (uint32_t e = 0; e < ne; e++) AT(y, e) = AT(an, ER(e)) * AT(bn, EC(e)) / Tn;
+      for (uint32_t k = 0; k < nr; k++) AT(nur, k) = 0.0;
+      for (uint32_t k = 0; k < nc; k++) AT(nuc, k) = 0.0;
+      // |r|^2 of (yy, nr_, nc_): dual part cell by cell, then the rows, then the kept columns (sums over e ascending)
+#define RESIDUAL2(yy, nr_, nc_, res)                                                             \
+      {                                                                                            \
+        double acc_ = 0.0;                                                                         \
+        for (uint32_t e = 0; e < ne; e++) {                                                        \
+          const double d_ = AT(nr_, ER(e)) + AT(nc_, EC(e)) - 1.0 / AT(yy, e);                     \
+          acc_ += d_ * d_;                                                                         \
+        }                                                                                          \
+        for (uint32_t k = 0; k < nr; k++) AT(gr, k) = 0.0;                                         \
+        for (uint32_t k = 0; k < nc; k++) AT(gc, k) = 0.0;                                         \
+        for (uint32_t e = 0; e < ne; e++) { AT(gr, ER(e)) += AT(yy, e); AT(gc, EC(e)) += AT(yy, e); } \
+        for (uint32_t k = 0; k < nr; k++) { const double d_ = AT(gr, k) - AT(an, k); acc_ += d_ * d_; } \
+        for (uint32_t k = 0; k < q; k++) { const double d_ = AT(gc, k) - AT(bn, k); acc_ += d_ * d_; }  \
+        res = acc_;                                                                                \
+      }
+      double r2;
+      RESIDUAL2(y, nur, nuc, r2);
+      bool last = false;
+      uint32_t its = 0;
+      for (its = 1; its <= NEWTON_MAX; its++) {
+        for (uint32_t k = 0; k < nr; k++) { AT(Dr, k) = 0.0; AT(gr, k) = 0.0; }
+        for (uint32_t k = 0; k < nc; k++) { AT(Dc, k) = 0.0; AT(gc, k) = 0.0; }
+        for (uint32_t e = 0; e < ne; e++) {
+          const double v = AT(y, e), v2 = v * v;
+          AT(y2, e) = v2;
+          AT(Dr, ER(e)) += v2; AT(gr, ER(e)) += v;
+          AT(Dc, EC(e)) += v2; AT(gc, EC(e)) += v;
+        }
+        for (uint32_t k = 0; k < nr; k++) AT(gr, k) = 2.0 * AT(gr, k) - AT(an, k);
+        for (uint32_t k = 0; k < nc; k++) AT(gc, k) = 2.0 * AT(gc, k) - AT(bn, k);
+        // Schur complement on the kept columns
+#define SS(a_, b_) AT(S, (a_) * q + (b_))
+        for (uint32_t k = 0; k < q; k++) {
+          for (uint32_t k2 = 0; k2 < q; k2++) SS(k, k2) = 0.0;
+          SS(k, k) = AT(Dc, k);
+          AT(h, k) = AT(gc, k);
+        }
+        for (uint32_t i = 0; i < nr; i++) {
+          const uint32_t e0 = (uint32_t)AT(rstart, i), e1 = (uint32_t)AT(rstart, i + 1);
+          const double inv = 1.0 / AT(Dr, i);
+          const double gri = AT(gr, i);
+          for (uint32_t ea = e0; ea < e1; ea++) {
+            const uint32_t k1 = EC(ea);
+            if (k1 >= q) continue;
+            const double f = AT(y2, ea) * inv;
+            AT(h, k1) -= f * gri;
+            for (uint32_t eb = e0; eb < e1; eb++) {
+              const uint32_t k2 = EC(eb);
+              if (k2 >= q) continue;
+              SS(k1, k2) -= f * AT(y2, eb);
+            }
+          }
+        }
+        for (uint32_t k = 0; k < q; k++) {
+          const double piv = SS(k, k);
+          for (uint32_t r_ = k + 1; r_ < q; r_++) {
+            const double f = SS(r_, k) / piv;
+            if (f != 0.0) {
+              for (uint32_t c_ = k + 1; c_ < q; c_++) SS(r_, c_) -= f * SS(k, c_);
+              AT(h, r_) -= f * AT(h, k);
+            }
+          }
+        }
+        for (uint32_t k = 0; k < nc; k++) AT(wc, k) = 0.0;
+        for (int32_t k = (int32_t)q - 1; k >= 0; k--) {
+          double acc = AT(h, k);
+          for (uint32_t c_ = k + 1; c_ < q; c_++) acc -= SS(k, c_) * AT(wc, c_);
+          AT(wc, k) = acc / SS(k, k);
+        }
+        for (uint32_t i = 0; i < nr; i++) {
+          double acc = AT(gr, i);
+          for (uint32_t e = (uint32_t)AT(rstart, i); e < (uint32_t)AT(rstart, i + 1); e++)
+            if (EC(e) < q) acc -= AT(y2, e) * AT(wc, EC(e));
+          AT(wr, i) = acc / AT(Dr, i);
+        }
+        for (uint32_t e = 0; e < ne; e++) AT(dy, e) = AT(y, e) - AT(y2, e) * (AT(wr, ER(e)) + AT(wc, EC(e)));
+        double tt = 1.0;
+        const double tmin = 1.0 / 1099511627776.0;           // 2^-40
+        while (tt >= tmin) {
+          bool ok = true;
+          for (uint32_t e = 0; e < ne; e++) if (!(AT(y, e) + tt * AT(dy, e) > 0.0)) { ok = false; break; }
+          if (ok) break;
+          tt *= 0.5;
+        }
+        double r2n;
+        for (;;) {
+          for (uint32_t e = 0; e < ne; e++) AT(yn, e) = AT(y, e) + tt * AT(dy, e);
+          for (uint32_t k = 0; k < nr; k++) AT(nrn, k) = AT(nur, k) + tt * (AT(wr, k) - AT(nur, k));
+          for (uint32_t k = 0; k < nc; k++) AT(ncn, k) = AT(nuc, k) + tt * (AT(wc, k) - AT(nuc, k));
+          RESIDUAL2(yn, nrn, ncn, r2n);
+          const double f = 1.0 - 0.01 * tt;
+          if (r2n <= f * f * r2 || tt < tmin) break;
+          tt *= 0.5;
+        }
+        for (uint32_t e = 0; e < ne; e++) AT(y, e) = AT(yn, e);
+        for (uint32_t k = 0; k < nr; k++) AT(nur, k) = AT(nrn, k);
+        for (uint32_t k = 0; k < nc; k++) AT(nuc, k) = AT(ncn, k);
+        r2 = r2n;
+        if (last) break;
+        if (r2 <= NEWTON_TOL2) last = true;
+      }
+      if (its > NEWTON_MAX) its = NEWTON_MAX;
+      st_steps += its;
+      if (!last) st_bad++;
+      for (uint32_t e = 0; e < ne; e++) AT(X, CX(EI(e), EJ(e))) = AT(y, e) * sc;
+#undef SS
+#undef RESIDUAL2
+#undef EI
+#undef EJ
+#undef ER
+#undef EC
+    }
+  }
+  for (uint32_t k = 0; k < mn; k++) o[(uint64_t)k * T + t] = AT(X, k);
+  uint32_t* sp = stat + 4 * (P.stat_off + t);
+  sp[0] = st_comp; sp[1] = st_steps; sp[2] = st_bad; sp[3] = st_large;
+#undef AT
+#undef CX
+}
+
 // n_problems problems; for problem p: m[p], n[p], trials[p], pid[p]; a_s/b_s concatenated in `ab`
 // (m+n doubles per problem), unsupported-cell masks concatenated in `mask` (m*n bytes, index j*m+i).
 // flows_out: for problem p, trials[p]*m*n doubles laid out [cell][trial], problems concatenated.
@@ -144,27 +383,34 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
   if (!n_problems) return SHN_OK;
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
+  const bool center = ctx->lp_rule != SHN_LP_RULE_VERTEX;
   std::vector<LpProblem> probs(n_problems);
   std::vector<uint32_t> bprob, bfirst;
-  uint64_t in_off = 0, mask_off = 0, ws_off = 0, out_off = 0;
+  uint64_t in_off = 0, mask_off = 0, ws_off = 0, out_off = 0, ws2_off = 0, stat_off = 0;
   for (uint32_t p = 0; p < n_problems; p++) {
     if (m[p] == 0 || n[p] == 0 || trials[p] == 0) return shn_fail(SHN_ERR_ARG, "shn_lp_solve_batch: empty problem");
+    if (m[p] >= 65536 || n[p] >= 65536) return shn_fail(SHN_ERR_ARG, "shn_lp_solve_batch: more than 65535 rows or columns");
     LpProblem& P = probs[p];
     P.m = m[p]; P.n = n[p]; P.trials = trials[p]; P.pad = 0; P.pid = pid[p];
-    P.in_off = in_off; P.mask_off = mask_off; P.ws_off = ws_off; P.out_off = out_off;
+    P.in_off = in_off; P.mask_off = mask_off; P.ws_off = ws_off; P.out_off = out_off; P.ws2_off = ws2_off; P.stat_off = stat_off;
     uint64_t mn = (uint64_t)m[p] * n[p];
     in_off += m[p] + n[p];
     mask_off += mn;
     ws_off += (2 * mn + 3ULL * (m[p] + n[p])) * trials[p];
+    if (center && m[p] + n[p] <= 64) ws2_off += lp_ws2_words(m[p], n[p]) * trials[p];
+    stat_off += trials[p];
     out_off += mn * trials[p];
     for (uint32_t f = 0; f < trials[p]; f += LBLK) { bprob.push_back(p); bfirst.push_back(f); }
   }
   TimerRegion treg(ctx, T_LP);
-  void *pp, *pb, *pin, *pm, *pws, *pout;
+  // per-context workspaces: two batches may be in flight on two contexts (the deferred back half of a step beside the next
+  // step's front half), and shn_ws_release_idle never touches a context's own slots
+  void *pp, *pb, *pin, *pm, *pws, *pout, *pws2, *pst;
   int rc;
-  if ((rc = g_shn_ws[18].get(probs.size() * sizeof(LpProblem), &pp)) || (rc = g_shn_ws[19].get(bprob.size() * 8 + 16, &pb)) ||
-      (rc = g_shn_ws[20].get(in_off * 8 + 16, &pin)) || (rc = g_shn_ws[21].get(mask_off + 16, &pm)) ||
-      (rc = g_shn_ws[22].get(ws_off * 8 + 16, &pws)) || (rc = g_shn_ws[23].get(out_off * 8 + 16, &pout))) return rc;
+  if ((rc = ctx->cws[4].get(probs.size() * sizeof(LpProblem), &pp)) || (rc = ctx->cws[5].get(bprob.size() * 8 + 16, &pb)) ||
+      (rc = ctx->cws[6].get(in_off * 8 + 16, &pin)) || (rc = ctx->cws[7].get(mask_off + 16, &pm)) ||
+      (rc = ctx->cws[8].get(ws_off * 8 + 16, &pws)) || (rc = ctx->cws[9].get(out_off * 8 + 16, &pout)) ||
+      (rc = ctx->cws[10].get(ws2_off * 8 + 16, &pws2)) || (rc = ctx->cws[11].get(stat_off * 16 + 16, &pst))) return rc;
   uint32_t* d_bprob = (uint32_t*)pb;
   uint32_t* d_bfirst = d_bprob + bprob.size();
   HIP_TRY(hipMemcpyAsync(pp, probs.data(), probs.size() * sizeof(LpProblem), hipMemcpyHostToDevice, s));
@@ -174,8 +420,47 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
   HIP_TRY(hipMemcpyAsync(pm, mask, mask_off, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(lp_trials_kernel, dim3((uint32_t)bprob.size()), dim3(LBLK), 0, s, (const LpProblem*)pp, d_bprob, d_bfirst,
                      (const double*)pin, (const uint8_t*)pm, seed, (uint64_t*)pws, (double*)pout);
+  std::vector<uint32_t> stat;
+  if (center) {
+    hipLaunchKernelGGL(lp_center_kernel, dim3((uint32_t)bprob.size()), dim3(LBLK), 0, s, (const LpProblem*)pp, d_bprob, d_bfirst,
+                       (const uint8_t*)pm, (uint64_t*)pws, (uint64_t*)pws2, (double*)pout, (uint32_t*)pst);
+    stat.resize(4 * stat_off);
+    HIP_TRY(hipMemcpyAsync(stat.data(), pst, stat.size() * 4, hipMemcpyDeviceToHost, s));
+  }
   HIP_TRY(hipMemcpyAsync(flows_out, pout, out_off * 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipGetLastError());
+  // census (bench.py: lp_calls / lp_degenerate): a problem is degenerate when the optimal face of one of its trials was not a point
+  ctx->lp_stats[0] += n_problems;
+  ctx->lp_stats[2] += stat_off;
+  if (center) {
+    uint64_t t0 = 0;
+    for (uint32_t p = 0; p < n_problems; p++) {
+      bool deg = false;
+      for (uint32_t t = 0; t < trials[p]; t++) {
+        const uint32_t* sp = &stat[4 * (t0 + t)];
+        if (sp[0]) { deg = true; ctx->lp_stats[3]++; }
+        ctx->lp_stats[4] += sp[1];
+        ctx->lp_stats[5] += sp[2];
+        ctx->lp_stats[6] += sp[3];
+      }
+      if (deg) ctx->lp_stats[1]++;
+      t0 += trials[p];
+    }
+  }
+  return SHN_OK;
+}
+
+extern "C" int shn_lp_set_rule(shn_ctx* ctx, int rule) {
+  if (!ctx || (rule != SHN_LP_RULE_VERTEX && rule != SHN_LP_RULE_CENTER)) return shn_fail(SHN_ERR_ARG, "shn_lp_set_rule: bad argument");
+  ctx->lp_rule = rule;
+  return SHN_OK;
+}
+
+extern "C" int shn_lp_stats(shn_ctx* ctx, uint64_t* out8, int reset) {
+  if (!ctx || !out8) return shn_fail(SHN_ERR_ARG, "shn_lp_stats: NULL argument");
+  for (int i = 0; i < 8; i++) out8[i] = ctx->lp_stats[i];
+  out8[7] = (uint64_t)ctx->lp_rule;
+  if (reset) for (int i = 0; i < 7; i++) ctx->lp_stats[i] = 0;
   return SHN_OK;
 }

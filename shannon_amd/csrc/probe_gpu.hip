@@ -84,7 +84,7 @@ extern "C" int shn_probe_build(shn_ctx* ctx, const uint8_t* bases, const uint64_
   P->set_mem.resize(n_parts);
   for (uint32_t p = 0; p <= n_parts; p++) P->set_off[p] = p;
   for (uint32_t p = 0; p < n_parts; p++) P->set_mem[p] = p;
-  ShnDevBufs B;
+  ShnDevBufs B(ctx->stream);
   uint64_t* ukeys = nullptr; uint32_t* uvals = nullptr;
   uint64_t nu = 0;
   if (total) {

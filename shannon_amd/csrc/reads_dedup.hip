@@ -140,7 +140,7 @@ extern "C" int shn_reads_dedup(shn_ctx* ctx, const shn_reads* a, const shn_reads
   double t0 = now(), t_alloc = 0, t_up = 0, t_k = 0, t_scan = 0, t_alloc2 = 0;
   uint64_t T = 1024;
   while (T < 2 * nh) T <<= 1;
-  ShnDevBufs bufs;
+  ShnDevBufs bufs(s);
   uint32_t *d_idx = nullptr, *d_tab = nullptr, *d_slot = nullptr, *d_first = nullptr, *d_cnt = nullptr, *d_last = nullptr, *d_flag = nullptr;
   uint64_t* d_pos = nullptr;
   uint32_t *d_oslot = nullptr, *d_ocnt = nullptr; int32_t* d_omate = nullptr; uint8_t* d_orole = nullptr;

@@ -109,7 +109,7 @@ static int seed_scan_impl(shn_ctx* ctx, const shn_reads* reads, int K, const shn
   if (!out_read) { last = {ctx, reads, patterns, total, reads->n_reads, patterns->n, nh, K, ALL}; return SHN_OK; }
   if (nh == 0) return SHN_OK;
   uint32_t *d_r = nullptr, *d_s = nullptr, *d_i = nullptr;       // (from the caching allocator: this runs once per partition, under the GPU mutex)
-  ShnDevBufs hb;
+  ShnDevBufs hb(ctx->stream);
   HIP_TRY(hb.get(&d_r, nh * 4)); HIP_TRY(hb.get(&d_s, nh * 4)); HIP_TRY(hb.get(&d_i, nh * 4));
   hipLaunchKernelGGL((seed_scan_kernel<true, ALL>), dim3(grid), dim3(SBLK2), 0, s, v, K, max_win, patterns->d_keys, patterns->d_counts,
                      patterns->d_bucket_off, patterns->bits, nullptr, (const uint64_t*)po, d_r, d_s, d_i);
@@ -136,7 +136,7 @@ extern "C" int shn_seed_ends(shn_ctx* ctx, const shn_reads* reads, int K, const 
   if (reads->n_reads == 0) return SHN_OK;
   SView v = sview(reads);
   uint32_t *d_a = nullptr, *d_b = nullptr;
-  ShnDevBufs hb;
+  ShnDevBufs hb(ctx->stream);
   HIP_TRY(hb.get(&d_a, v.n * 4)); HIP_TRY(hb.get(&d_b, v.n * 4));
   hipLaunchKernelGGL(seed_ends_kernel, dim3((uint32_t)cdiv(v.n, 256)), dim3(256), 0, s, v, K, patterns->d_keys, patterns->d_counts,
                      patterns->d_bucket_off, patterns->bits, d_a, d_b);

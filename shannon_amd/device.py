@@ -33,6 +33,22 @@ class Context(object):
                 out[name] = (ms.value, n.value)
         return out
 
+    LP_RULES = {"vertex": 0, "center": 1}
+
+    def set_lp_rule(self, rule):
+        """'center' (default): the trial LPs of path_decompose return the interior-point limit (analytic centre of the optimal
+        face); 'vertex': the vertex rule of rounds 1-2 (shn_lp_set_rule)."""
+        _lib.check(_lib.lib().shn_lp_set_rule(self.h, self.LP_RULES[rule]))
+
+    def lp_stats(self, reset=False):
+        """census of the LP calls of this context (shn_lp_stats)"""
+        out = (C.c_uint64 * 8)()
+        _lib.check(_lib.lib().shn_lp_stats(self.h, out, 1 if reset else 0))
+        names = ("lp_calls", "lp_degenerate", "lp_trials", "lp_degenerate_trials", "newton_steps", "not_converged", "too_large_trials", "rule")
+        d = {k: int(v) for k, v in zip(names, out)}
+        d["rule"] = "center" if d["rule"] else "vertex"
+        return d
+
     def close(self):
         if self.h:
             _lib.lib().shn_ctx_destroy(self.h)

@@ -24,7 +24,8 @@ from shannon_amd import synth
 TMP = "/tmp/shannon_golden"
 STANDINS = ("jellyfish: exact brute-force k1-window counter, file written KMER-descending; "
             "gpmetis: hand-written .part vectors (vertex i -> i % P; r2: (i // 2) % P); "
-            "cvxopt: numpy stub + oracle.lp.transport_vertex + oracle.lp.trial_costs (NOT real cvxopt)")
+            "cvxopt: numpy stub + oracle.lp.transport_center (vertex on the unsupported cells, analytic centre of the optimal face "
+            "on the supported ones: the limit of an interior-point method) + oracle.lp.trial_costs (NOT real cvxopt)")
 
 
 def digest(obj):
@@ -199,7 +200,7 @@ def lp_impl(c, A, b):
     b_s.append(tot if tot > 0 else 0.0)
     cf = c.reshape(-1)
     ci = [[int(round(cf[j * m + i] * (1 << 32))) for j in range(n)] for i in range(m)]
-    x = olp.transport_vertex(a_s, b_s, ci)
+    x = olp.transport_center(a_s, b_s, ci, [[cf[j * m + i] == 0 for j in range(n)] for i in range(m)])
     return np.array([x[k % m][k // m] for k in range(mn)], dtype=float).reshape(-1, 1)
 cvxopt.solvers.lp_impl = lp_impl
 rng = np.random.default_rng(99)
@@ -223,30 +224,61 @@ for (a, b) in (([5., 7., 9.], [5., 16.]), ([5., 7., 9., 39.], [21., 11., 15., 13
     state.update(pid=1000 + m, trial=0, seed=1234)
     ans, nu = pds.path_decompose(list(a), list(b), list(a), list(b), 0, cvxopt.matrix(np.ones((m, n))), False, 3)
     kats.append({"a": a, "b": b, "P": np.ones((m, n), dtype=int).tolist(), "seed": 1234, "pid": 1000 + m, "sparsity": 3, "answer": np.array(ans).tolist(), "non_unique": int(nu)})
-json.dump({"standins": "cvxopt stub + oracle.lp pinned LP rule and cost generator (NOT real cvxopt)", "kats": kats}, open(sys.argv[1], "w"))
+json.dump({"standins": "cvxopt stub + oracle.lp.transport_center (interior-point limit) and cost generator (NOT real cvxopt)", "kats": kats}, open(sys.argv[1], "w"))
 '''
     H.run_py(tref, code, argv=[os.path.join(OUT, "lp_kats.json")])
     print("lp kats done")
     return finish_check(check)
 
 
+def canonical_case(obj):
+    """ID-free form of a case fixture: what must be reproducible in ANY environment.  The reference numbers nodes and orders edge
+    lines by iterating sets of objects, i.e. by address; the raw tables (IDs, line order, the ->S->id paths of the headers) are
+    only reproducible under the pinned environment of ref_harness.run_py.  Canonical: everything but the raw tables, with the
+    transcripts as the sorted multiset of (sequence, abundance rounded to 9 significant digits)."""
+    out = json.loads(json.dumps(obj))
+    for q in out.get("partitions", {}).values():
+        q.pop("raw_components", None)
+        q["single_rows"] = sorted([r[1:] for r in q.get("single_rows", [])])
+        if "reconstructed_fasta" in q:
+            recs, lines = [], q["reconstructed_fasta"].splitlines()
+            for h, sq in zip(lines[0::2], lines[1::2]):
+                f = h.split("\t")
+                w = f[1].split("Copycount:")[-1] if len(f) > 1 else ""
+                try:
+                    w = "%.9g" % float(w)
+                except ValueError:
+                    pass
+                recs.append([sq, w])
+            q["reconstructed_fasta"] = sorted(recs)
+    return out
+
+
 def finish_check(check):
-    """--check: every regenerated artefact must equal the committed one (content of the gzip members, not their headers)"""
+    """--check: every regenerated artefact must equal the committed one in canonical (ID-free) form -- in any environment -- and,
+    under the pinned environment of ref_harness.run_py, byte for byte (content of the gzip members, not their headers); a raw
+    difference with equal canonical forms is reported and does not fail the check."""
     if not check:
         return 0
-    bad = []
+    bad, raw_only = [], []
     for root, _d, files in os.walk(OUT):
         for fn in files:
             new = os.path.join(root, fn)
             old = os.path.join(HERE, os.path.relpath(new, OUT))
             rd = (lambda p: gzip.open(p, "rb").read()) if fn.endswith(".gz") else (lambda p: open(p, "rb").read())
-            if fn.endswith(".npz"):
-                a, b = np.load(new), np.load(old) if os.path.exists(old) else None
-                same = b is not None and all(np.array_equal(a[k], b[k]) for k in a.files)
-            else:
-                same = os.path.exists(old) and rd(new) == rd(old)
-            if not same:
+            if not os.path.exists(old):
                 bad.append(os.path.relpath(new, OUT))
+            elif fn.endswith(".npz"):
+                a, b = np.load(new), np.load(old)
+                if not all(np.array_equal(a[k], b[k]) for k in a.files):
+                    bad.append(os.path.relpath(new, OUT))
+            elif rd(new) != rd(old):
+                if fn.endswith(".json.gz") and canonical_case(json.loads(rd(new))) == canonical_case(json.loads(rd(old))):
+                    raw_only.append(os.path.relpath(new, OUT))
+                else:
+                    bad.append(os.path.relpath(new, OUT))
+    if raw_only:
+        print("CHECK: node ids / line order of the raw tables differ (address order), canonical content equal:", ", ".join(sorted(raw_only)))
     print("CHECK:", "all regenerated fixtures equal the committed ones" if not bad else "DIFFERENT: " + ", ".join(sorted(bad)))
     return 1 if bad else 0
 

@@ -20,9 +20,10 @@ replaced by stand-ins, each labelled in the fixture metadata:
                   order, which pins the seed order to (weight desc, KMER asc) -- SURVEY 8c.
   * gpmetis    -> `true` + a hand-written componentN.txt.part.P (partition given, not computed)
   * cvxopt     -> tests/golden/cvxopt_stub (numpy-backed `matrix`; `solvers.lp` delegates to a
-                  pluggable solver -- the oracle's pinned vertex rule -- and numpy.random.normal
-                  is replaced by the oracle's counter-based generator).  LP fixtures are
-                  therefore "reference control flow + pinned LP/RNG", not real cvxopt.
+                  pluggable solver -- the oracle's restatement of the interior-point limit,
+                  oracle/lp.py:transport_center -- and numpy.random.normal is replaced by the
+                  oracle's counter-based generator).  LP fixtures are therefore "reference
+                  control flow + restated LP limit + pinned RNG", not real cvxopt.
 """
 import os, sys, subprocess, shutil, glob, json, collections
 
@@ -117,11 +118,17 @@ def _no_aslr():
     return ["setarch", platform.machine(), "-R"]
 
 
+def pinned_env(tref):
+    """The environment every reference process runs in: nothing of the caller's shell (the size of the environment block moves
+    the stack and, through it, the addresses the allocator hands out -- and the reference's set iteration follows addresses), so
+    that the raw tables of the fixtures are reproducible from any shell (make_golden.py --check)."""
+    return {"PATH": "/usr/local/sbin:/usr/local/bin:/usr/sbin:/usr/bin:/sbin:/bin", "HOME": "/tmp", "LANG": "C", "LC_ALL": "C",
+            "PYTHONHASHSEED": "0", "PYTHONDONTWRITEBYTECODE": "1", "OMP_NUM_THREADS": "1", "OPENBLAS_NUM_THREADS": "1",
+            "PYTHONPATH": os.pathsep.join([tref, os.path.join(HERE, "cvxopt_stub"), os.path.dirname(os.path.dirname(HERE))])}
+
+
 def run_py(tref, code, cwd=None, env_extra=None, argv=()):
-    env = dict(os.environ)
-    env["PYTHONPATH"] = tref + os.pathsep + os.path.join(HERE, "cvxopt_stub") + os.pathsep + \
-        os.path.dirname(os.path.dirname(HERE)) + os.pathsep + env.get("PYTHONPATH", "")
-    env.setdefault("PYTHONHASHSEED", "0")
+    env = pinned_env(tref)
     if env_extra:
         env.update(env_extra)
     p = subprocess.run(_no_aslr() + [sys.executable, "-W", "ignore", "-c", code, *argv], cwd=cwd, env=env,
@@ -172,9 +179,9 @@ def run_multibridging(tref, pdir, K, paired, hashseed="0"):
 def run_algorithm_sf(tref, prefix, comp, seed=0, comp_rng=0):
     """run_MB_SF_fn.py:239-250: `algorithm_SF.py <comp> <prefix>` (script, runs on import),
     through tests/golden/sf_runner.py (stub cvxopt + pinned LP/RNG)."""
-    env = dict(os.environ)
-    env["PYTHONPATH"] = os.pathsep.join([tref, os.path.join(HERE, "cvxopt_stub"), os.path.dirname(os.path.dirname(HERE))])
-    env.setdefault("PYTHONHASHSEED", "0")
+    env = pinned_env(tref)
+    if os.environ.get("SHN_LP_RULE"):
+        env["SHN_LP_RULE"] = os.environ["SHN_LP_RULE"]
     p = subprocess.run(_no_aslr() + [sys.executable, "-W", "ignore", os.path.join(HERE, "sf_runner.py"), tref, str(seed), str(comp_rng),
                         str(comp), prefix], cwd=os.path.dirname(prefix.rstrip("/")) or ".", env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)

@@ -1,6 +1,6 @@
 """Runs the translated algorithm_SF.py script for one component with the stub cvxopt, the
-oracle's pinned LP rule plugged into solvers.lp, and numpy.random.normal replaced by the
-oracle's counter-based cost generator.  GOLDEN-VECTOR HARNESS ONLY.
+oracle's restatement of the interior-point limit (oracle/lp.py: transport_center) plugged into
+solvers.lp, and numpy.random.normal replaced by the oracle's counter-based cost generator.  GOLDEN-VECTOR HARNESS ONLY.
 usage: sf_runner.py <tref> <seed> <comp_id_for_rng> <comp> <prefix>"""
 import sys, os, runpy
 import numpy as np
@@ -49,7 +49,10 @@ def lp_impl(c, A, b):
     b_s.append(tot if tot > 0 else 0.0)
     cf = c.reshape(-1)
     ci = [[int(round(cf[j * m + i] * (1 << 32))) for j in range(n)] for i in range(m)]
-    x = olp.transport_vertex(a_s, b_s, ci)
+    if os.environ.get("SHN_LP_RULE") == "vertex":
+        x = olp.transport_vertex(a_s, b_s, ci)
+    else:                                        # the interior-point limit: supported (zero-cost) cells at the centre of the optimal face
+        x = olp.transport_center(a_s, b_s, ci, [[cf[j * m + i] == 0 for j in range(n)] for i in range(m)])
     return np.array([x[k % m][k // m] for k in range(mn)], dtype=float).reshape(-1, 1)
 
 

@@ -15,15 +15,16 @@ def ctx():
     c.close()
 
 
-def test_lp_batch_bit_exact(ctx):
+def _requests(n_cases=120):
     from shannon_amd import sparse_flow
-    from oracle import lp as olp
     rng = np.random.default_rng(5)
     reqs = []
-    for t in range(120):
+    for t in range(n_cases):
         m, n = int(rng.integers(2, 9)), int(rng.integers(2, 9))
         if t == 0:
             m, n = 17, 23
+        if t == 1:
+            m, n = 40, 30                      # more than 64 rows + columns: the vertex is kept (and counted)
         a = [float(v) for v in rng.integers(0, 30, m)]
         if sum(a) == 0:
             a[0] = 3.0
@@ -32,21 +33,82 @@ def test_lp_batch_bit_exact(ctx):
         b = [float(v) for v in np.diff(np.concatenate([[0], cuts, [tot]]))]
         if t % 3 == 0:
             b = [v + float(rng.random()) for v in b]
-        P = (rng.random((m, n)) < [0.0, 0.3, 0.8][t % 3]).astype(int).tolist()
+        P = (rng.random((m, n)) < [0.0, 0.3, 0.8, 1.0][t % 4]).astype(int).tolist()
         kind, *rest = sparse_flow.prepare(a, b, P, 1000 + t, 10)
         if kind == "lp":
             reqs.append(rest[0])
+    return reqs
+
+
+def test_lp_batch_bit_exact(ctx):
+    """every trial of 120 random decompositions: the kernels' flows (vertex, then the supported cells at the analytic centre of
+    the optimal face) equal oracle/lp.py:transport_center bit for bit; the census counts what the oracle counts"""
+    from shannon_amd import sparse_flow
+    from oracle import lp as olp
+    reqs = _requests()
+    ctx.lp_stats(reset=True)
     xs = sparse_flow.solve_batch(ctx, reqs, 77)
+    st = ctx.lp_stats()
+    assert st["rule"] == "center" and st["lp_calls"] == len(reqs) and st["not_converged"] == 0
+    n_deg, n_deg_trials, steps, large = 0, 0, 0, 0
     for q, x in zip(reqs, xs):
+        sup = [[not (q.p[j * q.m + i] > 0) for j in range(q.n)] for i in range(q.m)]
+        memo, deg = {}, False
         for t in range(q.trials):
             cc = olp.trial_costs(77, q.pid, t, q.m * q.n)
             c = [[(cc[j * q.m + i] if q.p[j * q.m + i] > 0 else 0) for j in range(q.n)] for i in range(q.m)]
-            ref = olp.transport_vertex(q.a_s, q.b_s, c)
+            v = olp.transport_vertex(q.a_s, q.b_s, c)
+            key = tuple(w for row in v for w in row)
+            if key not in memo:
+                o = {}
+                memo[key] = (olp.face_center(v, sup, o), o)
+            ref, o = memo[key]
+            n_deg_trials += 1 if o.get("components") else 0
+            deg |= bool(o.get("components"))
+            steps += o.get("newton_steps", 0)
+            large += o.get("too_large", 0)
             flat = np.array([ref[k % q.m][k // q.m] for k in range(q.m * q.n)])
-            assert np.array_equal(flat, x[:, t]), (q.m, q.n, t)      # bit-exact
-        ans, nu = sparse_flow.finish(q, x)
-        # full path_decompose vs oracle
-        P = [[1 - int(q.p[j * q.m + i]) for j in range(q.n)] for i in range(q.m)]
+            assert np.array_equal(flat, x[:, t]), (q.m, q.n, t, np.abs(flat - x[:, t]).max())      # bit-exact
+        n_deg += deg
+    assert (st["lp_degenerate"], st["lp_degenerate_trials"], st["newton_steps"], st["too_large_trials"]) == (n_deg, n_deg_trials, steps, large)
+    assert n_deg > 20 and large > 0
+
+
+def test_vertex_rule_behind_the_switch(ctx):
+    """shn_lp_set_rule(vertex): the flows are the vertex of rounds 1-2, bit for bit"""
+    from shannon_amd import sparse_flow
+    from oracle import lp as olp
+    reqs = _requests(30)
+    ctx.set_lp_rule("vertex")
+    try:
+        xs = sparse_flow.solve_batch(ctx, reqs, 78)
+        assert ctx.lp_stats()["rule"] == "vertex"
+    finally:
+        ctx.set_lp_rule("center")
+    for q, x in zip(reqs, xs):
+        for t in range(0, q.trials, 7):
+            cc = olp.trial_costs(78, q.pid, t, q.m * q.n)
+            c = [[(cc[j * q.m + i] if q.p[j * q.m + i] > 0 else 0) for j in range(q.n)] for i in range(q.m)]
+            ref = olp.transport_vertex(q.a_s, q.b_s, c)
+            assert np.array_equal(np.array([ref[k % q.m][k // q.m] for k in range(q.m * q.n)]), x[:, t])
+
+
+def test_whole_path_decompose_equals_the_oracle(ctx):
+    """prepare -> kernels -> finish against oracle.lp.path_decompose (thresholds, trial selection, top-10) on the same cases"""
+    from shannon_amd import sparse_flow
+    from oracle import lp as olp
+    rng = np.random.default_rng(11)
+    for t in range(60):
+        m, n = int(rng.integers(2, 7)), int(rng.integers(2, 7))
+        a = [float(v) for v in rng.integers(1, 40, m)]
+        b = [float(v) + (float(rng.random()) if t % 2 else 0.0) for v in rng.integers(1, 40, n)]
+        P = (rng.random((m, n)) < [0.2, 0.6, 1.0][t % 3]).astype(int).tolist()
+        want = olp.path_decompose(a, b, P, seed=5, pid=t, sparsity=10)
+        kind, *rest = sparse_flow.prepare(a, b, P, t, 10)
+        assert kind == "lp"
+        x = sparse_flow.solve_batch(ctx, [rest[0]], 5)[0]
+        ans, nu = sparse_flow.finish(rest[0], x)
+        assert [list(r) for r in ans] == want[0] and nu == want[1], (t, ans, want)
 
 
 def test_path_decompose_kats_gpu(ctx):
