@@ -22,7 +22,9 @@ import argparse, json, os, sys, time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import shannon_amd                      # (first: the package sets the allocator up before anything allocates much)
+import shannon_amd
+if os.environ.get("SHN_MALLOC_TUNE", "1") != "0":
+    shannon_amd.malloc_tune()           # this program owns its process: heap-served blocks, no trimming (before anything allocates much)
 import numpy as np
 import torch
 

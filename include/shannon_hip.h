@@ -344,6 +344,10 @@ int shn_known_paths_scan(shn_ctx* ctx, const shn_reads* reads, int K, const uint
  * (LOCAL_WORLD_SIZE or SHN_LOCAL_RANKS); SHN_HOST_CPUS overrides.
  * (-- ; the reference takes its process count from --nprocs, shannon.py:99.)                                                   */
 int shn_host_cpus(void);
+/* OPT-IN, process-wide: glibc's allocator serves blocks up to 32 MB from the heap and never trims it (mallopt), so that the host
+ * stages do not pay for fresh zero pages every batch.  For programs that own their process (bench.py, shannon.py); also applied
+ * when the library is loaded with SHN_MALLOC_TUNE=1 in the environment.  An embedding application is otherwise left alone.   */
+void shn_malloc_tune_now(void);
 /* Rows of resident fixed-length read sets as a new read set: read i = row rows[i] of set a (flags[i] bit 0 clear) or b (set),
  * reverse-complemented if bit 1 is set; the selected rows must hold ACGT only.                                                   */
 int shn_reads_gather(shn_ctx* ctx, const shn_reads* a, const shn_reads* b, const uint32_t* rows, const uint8_t* flags, uint64_t n,

@@ -21,9 +21,10 @@ def usage():
 
 
 def read_fasta(path):
-    """2-line or multi-line FASTA/FASTQ -> list of sequences (upper case kept as in the file)."""
+    """2-line or multi-line FASTA/FASTQ (plain or .gz) -> list of sequences (upper case kept as in the file)."""
+    import gzip
     seqs = []
-    with open(path) as f:
+    with (gzip.open(path, "rt") if path.endswith(".gz") else open(path)) as f:
         first = f.readline()
         f.seek(0)
         if first.startswith("@"):
@@ -48,8 +49,12 @@ def main(argv):
     min_weight, min_length = 3, 75                            # shannon.py:55-56
     i = 1
     ignored, noted = [], []
+    takes_value = ("-o", "--single", "--left", "--right", "-K", "-p", "--partition", "--kmer_hard_cutoff")
     while i < len(argv):
         a = argv[i]
+        if a in takes_value and i + 1 >= len(argv):
+            print("ERROR: %s needs a value" % a)
+            return 2
         if a in ("--help", "-h"):
             usage(); return 0
         if a == "--version":
@@ -81,7 +86,8 @@ def main(argv):
                          "when a single stage is driven through the reference's file interface)" % a)
             i += 1; continue
         if a == "--kmer_soft_cutoff":
-            noted.append("--kmer_soft_cutoff %s: not used by the hot path (the reference passes it to jellyfish dump -L only with --filter_FP)" % argv[i + 1])
+            noted.append("--kmer_soft_cutoff %s: not used by the hot path (the reference passes it to jellyfish dump -L only with --filter_FP)"
+                         % (argv[i + 1] if i + 1 < len(argv) else "(no value)"))
             i += 2; continue
         if a in ("--compare", "--kallisto_cutoff"):
             ignored.append(a); i += 2; continue
@@ -106,6 +112,9 @@ def main(argv):
         print(line)
         log.write(line + "\n")
 
+    import shannon_amd
+    if os.environ.get("SHN_MALLOC_TUNE", "1") != "0":
+        shannon_amd.malloc_tune()                              # (this program owns its process)
     from shannon_amd import device, pipeline, _lib
     say("Starting Shannon run (MI355X hot path %s)" % VERSION)
     if ignored:
@@ -121,15 +130,18 @@ def main(argv):
     # read record by record
     import time as _t
     t0 = _t.time()
-    sets = None
+    sets, got = None, []
     try:
-        got = [device.Reads.ingest(ctx, p) for p in reads]
+        for p in reads:                                        # (a list built step by step: what was ingested before a refusal is closed below)
+            got.append(device.Reads.ingest(ctx, p))
         if all(g[0].n_invalid == 0 for g in got) and len(set(g[1].shape[1] for g in got)) == 1 and len(set(len(g[0]) for g in got)) == 1:
             sets, r = [g[0] for g in got], [g[1] for g in got]
     except _lib.ShannonError as ex:
         if "unsupported" not in str(ex):
             raise
     if sets is None:
+        for g in got:                                          # ingested but declined (reads with N, unequal mates): free the device copies
+            g[0].close()
         r = [read_fasta(p) for p in reads]
     T["ingest"] = _t.time() - t0
     say("Processed No of reads:%d, Avg. Read length: %.2f" % (len(r[0]), (sum(len(x) for x in r[0]) / max(1, len(r[0]))) if sets is None else r[0].shape[1]))

@@ -5,13 +5,12 @@ decomposition.  Python host layer over a C-ABI shared library of hand-written HI
 __version__ = "0.1.0"
 
 
-def _malloc_tune():
-    """The same allocator settings libshannon_hip.so applies when it is loaded (csrc/core.hip, shn_malloc_tune), applied as soon as
-    the package is imported: blocks up to 32 MB come from the heap and freed memory stays there, so that the host stages do not pay
-    for fresh zero pages every step.  SHN_MALLOC_TUNE=0 switches it off; MALLOC_*_ environment settings win."""
+def malloc_tune():
+    """OPT-IN process-wide allocator settings for programs that own their process (bench.py, shannon.py call this; an application
+    that embeds the package or the library is left alone): blocks up to 32 MB come from the heap and freed memory stays there, so
+    that the host stages do not pay for fresh zero pages every step (~4 % of a step at BASELINE configs[2]).  Also applied at
+    import / library load when SHN_MALLOC_TUNE=1 is in the environment; MALLOC_*_ environment settings win."""
     import ctypes, os
-    if os.environ.get("SHN_MALLOC_TUNE", "1") == "0":
-        return
     try:
         libc = ctypes.CDLL(None)
         M_TRIM_THRESHOLD, M_TOP_PAD, M_MMAP_THRESHOLD = -1, -2, -3
@@ -25,4 +24,6 @@ def _malloc_tune():
         pass
 
 
-_malloc_tune()
+import os as _os
+if _os.environ.get("SHN_MALLOC_TUNE", "0") == "1":
+    malloc_tune()

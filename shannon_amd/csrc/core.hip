@@ -441,13 +441,20 @@ extern "C" uint64_t shn_reads_n_invalid(const shn_reads* r) { return r ? r->n_in
 // the host stages derives from it.
 // The host stages (graph threads, sparse flow, merge, the numpy buffers between them) allocate and free hundreds of blocks of
 // 0.1-30 MB per step.  glibc serves those by mmap and gives them back on free: every step pays the page faults of fresh zero
-// pages again (~90 ms of a 3.2 s step at BASELINE configs[2]).  Loading the library raises the mmap threshold to its maximum and
-// keeps freed memory in the heap; SHN_MALLOC_TUNE=0 leaves the allocator as it is (MALLOC_*_ environment settings win as usual).
+// pages again (~90 ms of a 3.2 s step at BASELINE configs[2]).  OPT-IN (an embedding application's allocator is not this library's
+// to change): with SHN_MALLOC_TUNE=1 in the environment, loading the library raises the mmap threshold to its maximum and keeps
+// freed memory in the heap (MALLOC_*_ environment settings win as usual); bench.py and shannon.py ask for it, shn_malloc_tune_now()
+// is the call for a host program that wants it.
 #include <malloc.h>
 #include <climits>
+static void shn_malloc_tune_apply();
 __attribute__((constructor)) static void shn_malloc_tune() {
   const char* v = getenv("SHN_MALLOC_TUNE");
-  if (v && v[0] == '0') return;
+  if (!v || v[0] != '1') return;
+  shn_malloc_tune_apply();
+}
+extern "C" void shn_malloc_tune_now(void) { shn_malloc_tune_apply(); }
+static void shn_malloc_tune_apply() {
   if (!getenv("MALLOC_MMAP_THRESHOLD_")) mallopt(M_MMAP_THRESHOLD, 32 << 20);
   if (!getenv("MALLOC_TRIM_THRESHOLD_")) mallopt(M_TRIM_THRESHOLD, -1);          // (size_t) -1: the heap is never trimmed
   if (!getenv("MALLOC_TOP_PAD_")) mallopt(M_TOP_PAD, 256 << 20);

@@ -203,10 +203,14 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
 
     if hasattr(ops, "graph_batch"):
         # the owned partitions through the single-GPU graph stage: GPU unitigs, distinct reads found on the device, native sparse flow
-        texts = ops.graph_batch(part, names, owned, mine, K, paired, sample, seed, T)
+        err = None
+        try:
+            texts = ops.graph_batch(part, names, owned, mine, K, paired, sample, seed, T)
+        except Exception as ex:                     # told to every rank below: nobody waits in the gather for a rank that has left
+            texts, err = {}, "%s: %s" % (type(ex).__name__, ex)
         if texts is not None:
             lock.release()
-            return _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick)
+            return _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick, error=err)
 
     def one(i):
         singles, comps = ops.graph(part, names[i], mine.get(i, []), K, paired)      # pieces: [(global indices, reads)] per source rank
@@ -239,12 +243,17 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
     return _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick)
 
 
-def _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick):
-    """the per-partition FASTA of every owner to rank 0, which merges (shannon.py:584-604)"""
+def _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick, error=None):
+    """the per-partition FASTA of every owner to rank 0, which merges (shannon.py:584-604).  error: what went wrong in this rank's
+    graph stage, if anything -- it travels with the gather, so every rank raises together and none is left waiting."""
     import time
     t0 = time.time()
-    gathered = exchange.all_gather_object(texts, group, "FASTA gather (per-partition transcripts to rank 0)")
+    gathered = exchange.all_gather_object({"error": error, "texts": texts}, group, "FASTA gather (per-partition transcripts to rank 0)")
     tick("x:gather fasta", t0)
+    errors = ["rank %d: %s" % (r, d["error"]) for r, d in enumerate(gathered) if d["error"]]
+    if errors:
+        raise RuntimeError("graph stage failed on " + "; ".join(errors))
+    gathered = [d["texts"] for d in gathered]
     if rank != 0:
         return None
     lock.acquire()
@@ -436,20 +445,27 @@ class GpuOps(object):
                     rb_ = part["k1mer_bytes"][names[i]]                  # a partition holding a cycle of condensable edges
                     rb = rb_() if callable(rb_) else rb_
         nthreads = max(1, min(len(owned), _lib.host_cpus()))
-        if nthreads > 1:
-            with ThreadPoolExecutor(max_workers=nthreads) as pool:
-                graphs = list(pool.map(one, owned))
-        else:
-            graphs = [one(i) for i in owned]
-        T["graph"] = T.get("graph", 0.0) + time.time() - t0
-        t0 = time.time()
-        texts = mbgraph_native.sparse_flow_native(self.ctx, graphs, ["%s_%s" % (sample, names[i]) for i in owned], seed) if owned else []
-        for g in graphs:
-            g.close()
-        self.unitigs.close()
-        self.unitigs = None
-        T["sparse flow"] = T.get("sparse flow", 0.0) + time.time() - t0
-        return {i: txt for i, txt in zip(owned, texts)}
+        graphs, futs = [], []
+        try:
+            if nthreads > 1:
+                with ThreadPoolExecutor(max_workers=nthreads) as pool:
+                    futs = [pool.submit(one, i) for i in owned]
+                    graphs = [f.result() for f in futs]
+            else:
+                for i in owned:
+                    graphs.append(one(i))
+            T["graph"] = T.get("graph", 0.0) + time.time() - t0
+            t0 = time.time()
+            texts = mbgraph_native.sparse_flow_native(self.ctx, graphs, ["%s_%s" % (sample, names[i]) for i in owned], seed) if owned else []
+            T["sparse flow"] = T.get("sparse flow", 0.0) + time.time() - t0
+            return {i: txt for i, txt in zip(owned, texts)}
+        finally:
+            # whatever happened: the graphs built so far and the unitigs go back now (a failing partition must not leave them to
+            # the garbage collector; the caller tells the other ranks before the gather, _gather_and_merge)
+            for g in (graphs or [f.result() for f in futs if f.done() and not f.cancelled() and f.exception() is None]):
+                g.close()
+            self.unitigs.close()
+            self.unitigs = None
 
     def collect(self, sel):
         """the reads of the doubled indices `sel` as they travel to a partition's owner: stored code rows + strand

@@ -319,20 +319,18 @@ def accept_filter(live, nr, nl, tw, k1, min_length, min_weight, arrays=False):
     return list(zip(cand[sure].tolist(), clen[sure].tolist()))
 
 
-_last_best = [np.zeros(0, np.int32)]
-
-
-def contig_stage(strings, k1, r=15, f=0.5):
+def contig_stage(strings, k1, r=15, f=0.5, want_best=False):
     """duplicate_check + contig graph over candidate contigs in seed order (:358-397), native host code (csrc/contig_host.hip,
     the shn_cgraph handle).  Returns (acc, coff, cnb, cw): acc[i] = 1-based accepted index of candidate i or 0; neighbours of
-    accepted contig a (0-based) are cnb[coff[a]:coff[a+1]] (1-based accepted indices, dict insertion order) with weights cw."""
+    accepted contig a (0-based) are cnb[coff[a]:coff[a+1]] (1-based accepted indices, dict insertion order) with weights cw.
+    want_best: a fifth item, the hit count of the `best` contig of every candidate (the sharded stage's guard needs it)."""
     if not strings:
-        _last_best[0] = np.zeros(0, np.int32)
-        return np.zeros(0, np.int32), [0], [], []
+        out = (np.zeros(0, np.int32), [0], [], [])
+        return out + (np.zeros(0, np.int32),) if want_best else out
     cg = ContigGraph(k1, r, f)
     try:
         acc = cg.add(strings)
-        _last_best[0] = cg.best
+        best = cg.best
         coff, cnb, cw = cg.connections()
     finally:
         cg.close()
@@ -341,13 +339,7 @@ def contig_stage(strings, k1, r=15, f=0.5):
         dec = np.histogram(pos, bins=10, range=(0, max(1, len(strings))))[0].tolist()
         sys.stderr.write("[contig_graph] candidates %d (%d bases), accepted %d; accepted per decile of the seed order: %s\n"
                          % (len(strings), sum(len(x) for x in strings), len(pos), dec))
-    return acc, coff, cnb, cw
-
-
-def contig_best_counts(n_cand):
-    """hit count of the `best` contig of every candidate of the last contig_stage call"""
-    assert len(_last_best[0]) == n_cand
-    return _last_best[0]
+    return (acc, coff, cnb, cw, best) if want_best else (acc, coff, cnb, cw)
 
 
 def rmer_join(ctx, candidates, foreign_contigs, r=15):
@@ -555,8 +547,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
             pipe = None
         else:
             skey, sw = ext.seed_info([x[0] for x in keep])
-            acc, coff, cnb, cw = contig_stage(strings, k1, r, f)
-            bestc = contig_best_counts(len(strings))
+            acc, coff, cnb, cw, bestc = contig_stage(strings, k1, r, f, want_best=True)
         local = list(zip(sw.tolist(), skey.tolist(), strings))
         lap("ext.emit")
         mine = [local[i] for i in np.nonzero(acc)[0].tolist()]              # accepted here, local order

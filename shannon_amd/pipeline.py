@@ -229,19 +229,31 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
                     "log": glog}, tt
 
         t_graph = time.time()
-        if native_graph and len(names) > 1 and graph_threads > 1:
-            # partitions are independent (one multibridging process each in the reference, run_MB_SF_fn.py:219-253): the
-            # native stage releases the GIL, its GPU sections take turns
-            from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(max_workers=min(len(names), graph_threads)) as pool:
-                # the partitions with the most routed reads first (the reference's size-sorted job list, shannon.py:546-551)
-                by_size = sorted(names, key=lambda nm: -len(part["routes"][nm]))
-                futs = {nm: pool.submit(one_partition, nm) for nm in by_size}
-                results = [futs[nm].result() for nm in names]
-        else:
-            results = [one_partition(nm) for nm in names]
-        if unitigs is not None:
-            unitigs.close()
+        results, futs = [], {}
+        try:
+            if native_graph and len(names) > 1 and graph_threads > 1:
+                # partitions are independent (one multibridging process each in the reference, run_MB_SF_fn.py:219-253): the
+                # native stage releases the GIL, its GPU sections take turns
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=min(len(names), graph_threads)) as pool:
+                    # the partitions with the most routed reads first (the reference's size-sorted job list, shannon.py:546-551)
+                    by_size = sorted(names, key=lambda nm: -len(part["routes"][nm]))
+                    futs = {nm: pool.submit(one_partition, nm) for nm in by_size}
+                    results = [futs[nm].result() for nm in names]
+            else:
+                for nm in names:
+                    results.append(one_partition(nm))
+        except BaseException:
+            # a partition failed: the graphs already built go back now (device + host memory), not when the collector finds them
+            built = [f.result()[0] for f in futs.values() if f.done() and not f.cancelled() and f.exception() is None] or [r[0] for r in results]
+            for rec in built:
+                g = getattr(rec, "graph", None)
+                if g is not None:
+                    g.close()
+            raise
+        finally:
+            if unitigs is not None:
+                unitigs.close()
         wall = time.time() - t_graph
         if timeline is not None:
             import sys
@@ -270,6 +282,10 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
                 except _lib.ShannonError as ex:
                     if "non-ACGT" not in str(ex) and "empty line" not in str(ex):
                         raise
+                    import sys
+                    sys.stderr.write("[shannon_amd] the native merge declined the transcripts (%s): merging with the Python form "
+                                     "(post.finalize), about 2x slower\n" % str(ex)[:200])
+                    T["post fell back to python"] = T.get("post fell back to python", 0) + 1
                     R.final = post.finalize(R.all_reconstructed, double_stranded)
             else:
                 R.final = post.finalize(R.all_reconstructed, double_stranded)

@@ -213,20 +213,19 @@ def algorithm_sf(comp, prefix, seed=0, ctx=None):
     return txt
 
 
-_pd_calls = [0]
-
-
 def path_decompose(a, b, a_true, b_true, overwrite_norm, P, use_GLPK=False, sparsity=False, seed=0, ctx=None):
     """path_decompose_sparse.py:15-193: decomposes the flows a (in-edges) and b (out-edges) of a node into an m x n flow matrix of
     few non-zero cells outside the support P.  Returns [ndarray(m, n), non_unique].  a_true / b_true / overwrite_norm / use_GLPK
-    are accepted and unused, as in the reference's live code path.  The LP optimiser is this library's own rule (exact vertex by
-    successive shortest paths, costs from a counter-based stream seeded by `seed` and the call number) -- cvxopt is not a
-    dependency; see DESIGN.md "parity unpinned"."""
+    are accepted and unused, as in the reference's live code path.  cvxopt is not a dependency: the trial LPs return the limit of
+    its interior-point method (exact vertex flows on the unsupported cells, analytic centre of the optimal face on the supported
+    ones; csrc/lp.hip == oracle/lp.py bit for bit), costs from a counter-based stream seeded by `seed` and the call number."""
     ctx = ctx or default_context()
     m, n = len(a), len(b)
     Pm = [[int(round(float(P[i, j] if hasattr(P, "shape") else P[i][j]))) for j in range(n)] for i in range(m)] if m and n else []
-    kind, *rest = sparse_flow.prepare([float(v) for v in a], [float(v) for v in b], Pm, _pd_calls[0], int(sparsity) if sparsity else 0)
-    _pd_calls[0] += 1
+    # (the call number that seeds the cost stream is kept per context, not in a module global: contexts may work side by side)
+    call = getattr(ctx, "_pd_calls", 0)
+    ctx._pd_calls = call + 1
+    kind, *rest = sparse_flow.prepare([float(v) for v in a], [float(v) for v in b], Pm, call, int(sparsity) if sparsity else 0)
     if kind == "done":
         ans = rest[0]
         return [np.array(ans, dtype=float).reshape(m, n) if m and n else np.zeros((0, 0)), rest[1] if len(rest) > 1 else 0]

@@ -110,7 +110,24 @@ def main():
     r2 = inp[1][lo:hi] if m["paired"] else None
     psize = m.get("partition_size", 500)
     pv = [part_vectors(len(b["contigs"]), psize) for b in g["big_components"]] or None
-    res = distributed.assemble_distributed(OracleOps(r1, r2, m["K"]), m["K"], psize, "s", m["sf_seed"], pv)
+    ops = OracleOps(r1, r2, m["K"])
+    if len(sys.argv) > 3:                    # a rank whose graph stage fails: every rank must raise together (no rank left in the gather)
+        fail = int(sys.argv[3])
+
+        def graph_batch(*a, **k):
+            if rank == fail:
+                raise RuntimeError("boom on purpose")
+            return None
+        ops.graph_batch = graph_batch
+        try:
+            distributed.assemble_distributed(ops, m["K"], psize, "s", m["sf_seed"], pv)
+            msg = "no error"
+        except RuntimeError as ex:
+            msg = str(ex)
+        open(out + ".rank%d" % rank, "w").write(msg)
+        dist.destroy_process_group()
+        return
+    res = distributed.assemble_distributed(ops, m["K"], psize, "s", m["sf_seed"], pv)
     if rank == 0:
         json.dump({"partitions": res["partitions"], "final": res["final"], "contigs": res["contigs"]}, open(out, "w"))
     dist.destroy_process_group()

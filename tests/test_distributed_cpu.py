@@ -51,6 +51,18 @@ def test_ranks_equal_single_process(name, port, world, chunk, tmp_path):
     assert got["final"] == ref["final"]
 
 
+def test_a_failing_graph_stage_is_told_to_every_rank(tmp_path):
+    """rank 1's graph stage raises: the error travels with the FASTA gather, all ranks raise the same message, none hangs"""
+    out = str(tmp_path / "res.json")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29616", os.path.join(ROOT, "tests", "dist_worker.py"), "syn_se_s5", out, "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), timeout=300)
+    assert p.returncode == 0, p.stdout[-3000:]
+    for r in (0, 1):
+        msg = open(out + ".rank%d" % r).read()
+        assert "graph stage failed on rank 1" in msg and "boom on purpose" in msg, msg
+
+
 def test_read_pieces_travel_as_bytes():
     """The capped read sets of the partitions go to their owners as one byte buffer per destination (exchange.pack_read_pieces
     / unpack_read_pieces around all_to_all_bytes): round trip, empty pieces and empty buffers included."""

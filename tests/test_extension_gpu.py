@@ -376,8 +376,7 @@ def test_gpu_contig_stage_equals_the_sequential_stage(ctx, name, block0, pair_lo
     for cands in (g["contigs"], _variants(g["contigs"]), _variants(g["contigs"], 9)[::-1]):
         if not cands:
             continue
-        acc, coff, cnb, cw = ec.contig_stage(cands, g["K"] + 1)
-        best = ec.contig_best_counts(len(cands))
+        acc, coff, cnb, cw, best = ec.contig_stage(cands, g["K"] + 1, want_best=True)
         buf = np.frombuffer("".join(cands).encode(), np.uint8)
         offs = np.zeros(len(cands) + 1, np.uint64)
         offs[1:] = np.cumsum([len(c) for c in cands])

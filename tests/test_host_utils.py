@@ -80,15 +80,27 @@ def test_native_merge_equals_the_python_form(seed, ds):
 
 
 def test_allocator_setup_can_be_switched_off():
-    """importing the package applies the allocator settings (mallopt) unless SHN_MALLOC_TUNE=0; either way the import works and
-    the library loads"""
+    """the allocator settings (mallopt) are opt-in: importing the package / loading the library leaves glibc's defaults alone
+    (M_MMAP_THRESHOLD: a 4 MB block is mmapped, i.e. malloc_stats' mmap tally grows) unless SHN_MALLOC_TUNE=1 or an explicit
+    shannon_amd.malloc_tune() / shn_malloc_tune_now(); either way the import works and the library loads"""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for v in ("0", "1"):
-        env = dict(os.environ, SHN_MALLOC_TUNE=v, PYTHONPATH=root)
-        out = subprocess.run([sys.executable, "-c", "import shannon_amd; from shannon_amd import _lib; print(_lib.host_cpus() >= 1)"],
-                             env=env, capture_output=True, text=True, timeout=120)
-        assert out.returncode == 0 and out.stdout.strip() == "True", out.stderr
+    code = ("import ctypes, shannon_amd; from shannon_amd import _lib; ok = _lib.host_cpus() >= 1\n"
+            "%s\n"
+            "libc = ctypes.CDLL(None); libc.mallinfo2.restype = type('MI', (ctypes.Structure,), {'_fields_': [(n, ctypes.c_size_t) for n in "
+            "('arena','ordblks','smblks','hblks','hblkhd','usmblks','fsmblks','uordblks','fordblks','keepcost')]})\n"
+            "libc.malloc.restype = ctypes.c_void_p; before = libc.mallinfo2().hblks; p = libc.malloc(4 << 20); after = libc.mallinfo2().hblks\n"
+            "print(ok, after > before)")
+    for env_v, call, mmapped in ((None, "", True), ("0", "", True), ("1", "", False), (None, "shannon_amd.malloc_tune()", False),
+                                 (None, "_lib.lib().shn_malloc_tune_now()", False)):
+        env = dict(os.environ, PYTHONPATH=root)
+        env.pop("SHN_MALLOC_TUNE", None)
+        for k in ("MALLOC_MMAP_THRESHOLD_", "MALLOC_TRIM_THRESHOLD_", "MALLOC_TOP_PAD_"):
+            env.pop(k, None)
+        if env_v is not None:
+            env["SHN_MALLOC_TUNE"] = env_v
+        out = subprocess.run([sys.executable, "-c", code % call], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0 and out.stdout.split() == ["True", str(mmapped)], (env_v, call, out.stdout, out.stderr)
 
 
 def test_native_merge_refuses_other_characters_and_the_python_form_takes_over():
