@@ -520,7 +520,7 @@ def main():
         KERNEL = {"count.direct": "count_direct_kernel", "count.hist1": "hist1_kernel", "count.scatter1": "scatter1_kernel", "count.hist2": "hist_keys_kernel",
                   "count.scatter2": "scatter_keys_kernel", "count.buckets": "buckets_kernel", "route": "route_kernel",
                   "extend.walk_thread": "ext_walk_kernel", "extend.walk_wave": "ext_walk_long_kernel", "extend.mark": "ext_mark_kernel",
-                  "extend.adjacency": "ext_adjacency_half_kernel"}
+                  "extend.adjacency": "ext_records_kernel"}
         per_read = {"count.direct": 25.0 + 12.0 * distinct / max(1, n_reads),    # packed read in, (key, count) of the distinct k1-mers out
                     "count.hist1": 25.0, "count.scatter1": 25.0 + 8.0 * W, "count.hist2": 8.0 * W,
                     "count.scatter2": 16.0 * W, "count.buckets": 8.0 * W, "route": 192.0}
@@ -533,7 +533,7 @@ def main():
         per_step_bytes["extend.walk_thread"] = 152.0 * (steps_all - steps_wave)     # 4 candidates x (claim 8 + snapshot 8 + weight 4 + row 16) + claim 8
         per_step_bytes["extend.walk_wave"] = 112.0 * steps_wave                      # same without the row prefetch, + memo entry
         per_step_bytes["extend.mark"] = 16.0 * n_or * (ext["iterations"] or 0)
-        per_step_bytes["extend.adjacency"] = (8 * 8.0 + 4 * 16.0 + 8.0) * distinct       # per k1-mer: 8 keys looked up, 4 rows written, its own key
+        per_step_bytes["extend.adjacency"] = (8 * 8.0 + 2 * 64.0 + 8.0) * distinct       # per k1-mer: 8 keys looked up, its two 64-byte records written, its own key
         kt = {k: v for k, v in timers.items() if k in KERNEL}
 
         def roof(name):

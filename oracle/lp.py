@@ -163,7 +163,7 @@ def face_center(x, sup, stats=None):
 
     Spec (shared with shannon_amd/csrc/lp.hip: lp_center):
       nodes: rows 0..m-1, columns m..m+n-1.  Residual digraph: row i -> column j for every supported cell, column j -> row i
-      for every supported cell with x[i][j] > 0.  reach = its reflexive transitive closure; two nodes are in one class when
+      for every supported cell with x[i][j] > 1e-6 max x.  reach = its reflexive transitive closure; two nodes are in one class when
       each reaches the other; label = smallest node of the class.  A supported cell can be positive somewhere on the face
       iff its row and column are in one class (a cycle of the residual digraph passes through it).
       For every class with rows R (ascending) and columns C (ascending), E = its supported cells in row-major order:
@@ -176,6 +176,15 @@ def face_center(x, sup, stats=None):
         if stats is not None:
             stats["too_large"] = stats.get("too_large", 0) + 1
         return x
+    # flows at or below FLOW_EPS x the largest flow are rounding residue of the balancing (an "empty" implied last column holds
+    # 2e-14 of 100): they open no arc -- nothing below 1e-3 of the total flow survives the thresholds of :126-137 anyway, and a
+    # class whose marginals spanned more than six orders of magnitude would be beyond what the Newton iteration resolves
+    xmax = 0.0
+    for i in range(m):
+        for j in range(n):
+            if x[i][j] > xmax:
+                xmax = x[i][j]
+    eps = FLOW_EPS * xmax
     reach = [0] * N
     for i in range(m):
         r = 1 << i
@@ -186,7 +195,7 @@ def face_center(x, sup, stats=None):
     for j in range(n):
         r = 1 << (m + j)
         for i in range(m):
-            if sup[i][j] and x[i][j] > 0:
+            if sup[i][j] and x[i][j] > eps:
                 r |= 1 << i
         reach[m + j] = r
     changed = True
@@ -225,7 +234,8 @@ def face_center(x, sup, stats=None):
 
 
 NEWTON_MAX = 100
-NEWTON_TOL2 = 1e-20        # squared residual norm (normalised problem) after which one last full step is taken
+NEWTON_TOL2 = 1e-20        # squared residual norm (normalised problem) at which the iteration has converged
+FLOW_EPS = 1e-6            # x the largest flow: smaller flows open no arc of the residual digraph
 
 
 def center_component(x, R, Cc, E, stats=None):
@@ -238,7 +248,8 @@ def center_component(x, R, Cc, E, stats=None):
              pivoting: S is symmetric positive definite), w_rows = (g_r - W w_c) / D_r;
              dy = y - y^2 (w_row + w_col),  dnu = w - nu;
       t = 1, halved while some y + t dy <= 0, then while |r(y + t dy, nu + t dnu)|^2 > (1 - 0.01 t)^2 |r|^2  (t >= 2^-40);
-      r = (-1 / y + nu_row + nu_col ;  sums - b);  stop after the step that follows |r|^2 <= 1e-20, or after 100 steps.
+      r = (-1 / y + nu_row + nu_col ;  sums - b);  converged with the step that reaches |r|^2 <= 1e-20.  A pivot that is not
+      positive, no admissible t, or 100 steps without convergence: the class keeps its vertex flows (counted).
     Every sum runs in ascending order of its index (cells of a row by column, of a column by row; rows before columns)."""
     nr, nc = len(R), len(Cc)
     q = nc - 1
@@ -291,7 +302,7 @@ def center_component(x, R, Cc, E, stats=None):
         return acc
 
     r2 = residual2(y, nu_r, nu_c)
-    last = False
+    done = False                # |r|^2 <= 1e-20 reached: converged
     its = 0
     for its in range(1, NEWTON_MAX + 1):
         Dr = [0.0] * nr
@@ -315,11 +326,11 @@ def center_component(x, R, Cc, E, stats=None):
             gr[k] = 2.0 * gr[k] - an[k]
         for k in range(nc):
             gc[k] = 2.0 * gc[k] - bn[k]
-        # Schur complement on the kept columns
+        # Schur complement on the kept columns.  Its diagonal as  sum_i y_ik^2 (sum of the OTHER cells' y^2 of row i) / D_i : the form
+        # D_c - sum_i y_ik^4 / D_i cancels to nothing when a row's other cells are small
         S = [[0.0] * q for _ in range(q)]
         h = [0.0] * q
         for k in range(q):
-            S[k][k] = Dc[k]
             h[k] = gc[k]
         for i in range(nr):                                # rows ascending; within a row cells ascending
             cells = [e for e in range(ne) if er[e] == i]
@@ -330,20 +341,29 @@ def center_component(x, R, Cc, E, stats=None):
                     continue
                 f = y2[e1] * inv
                 h[k1] -= f * gr[i]
+                oth = 0.0
                 for e2 in cells:
-                    k2 = ec[e2]
-                    if k2 >= q:
-                        continue
-                    S[k1][k2] -= f * y2[e2]
+                    if e2 != e1:
+                        oth += y2[e2]
+                        k2 = ec[e2]
+                        if k2 < q:
+                            S[k1][k2] -= f * y2[e2]
+                S[k1][k1] += f * oth
         # Gaussian elimination without pivoting
+        fail = False
         for k in range(q):
             piv = S[k][k]
+            if not (piv > 0.0):
+                fail = True
+                break
             for r_ in range(k + 1, q):
                 f = S[r_][k] / piv
                 if f != 0.0:
                     for c_ in range(k + 1, q):
                         S[r_][c_] -= f * S[k][c_]
                     h[r_] -= f * h[k]
+        if fail:
+            break
         wc = [0.0] * nc
         for k in range(q - 1, -1, -1):
             acc = h[k]
@@ -360,6 +380,7 @@ def center_component(x, R, Cc, E, stats=None):
         dy = [y[e] - y2[e] * (wr[er[e]] + wc[ec[e]]) for e in range(ne)]
         t = 1.0
         tmin = 1.0 / float(1 << 40)
+        ok = False
         while t >= tmin:
             ok = True
             for e in range(ne):
@@ -369,24 +390,33 @@ def center_component(x, R, Cc, E, stats=None):
             if ok:
                 break
             t *= 0.5
+        if not ok:
+            fail = True
+            break
         while True:
             yn = [y[e] + t * dy[e] for e in range(ne)]
             nrn = [nu_r[k] + t * (wr[k] - nu_r[k]) for k in range(nr)]
             ncn = [nu_c[k] + t * (wc[k] - nu_c[k]) for k in range(nc)]
             r2n = residual2(yn, nrn, ncn)
             f = 1.0 - 0.01 * t
-            if r2n <= f * f * r2 or t < tmin:
+            if r2n <= f * f * r2:
                 break
             t *= 0.5
-        y, nu_r, nu_c, r2 = yn, nrn, ncn, r2n
-        if last:
+            if t < tmin:
+                fail = True
+                break
+        if fail:
             break
+        y, nu_r, nu_c, r2 = yn, nrn, ncn, r2n
         if r2 <= NEWTON_TOL2:
-            last = True
+            done = True
+            break
     if stats is not None:
         stats["newton_steps"] = stats.get("newton_steps", 0) + its
-        if not last:
+        if not done:
             stats["not_converged"] = stats.get("not_converged", 0) + 1
+    if not done:
+        return                  # (a pivot that is not positive, no admissible step, or 100 steps: the class keeps its vertex flows)
     for e in range(ne):
         x[E[e][0]][E[e][1]] = y[e] * s
 

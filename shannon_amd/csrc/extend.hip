@@ -36,8 +36,14 @@
 #include <algorithm>
 
 #define EBLK 256
+// the thread walkers run in workgroups of ONE wavefront: a workgroup keeps its place on the CU (8 per CU at 256 threads) until its
+// last wavefront has ended, and a walk kernel's wavefronts end at very different times (each runs as long as its longest walk) --
+// measured with 256-thread workgroups: 1,750 of 8,192 wavefront slots in use on average over a bulk round
+#define WBLK 64
 #define UNCLAIMED 0xFFFFFFFFu
+#define NONE32 0xFFFFFFFFu
 #define UNCLAIMED64 0xFFFFFFFFFFFFFFFFULL
+#define NOHINT_WORD 0xFFFFFFFFu   // = NOHINT (defined with the memo machinery below)
 #define LONG_WALK 8           // dirty walks at least this long (last run or memo) get a wavefront
 #define MEMO_MIN 1            // walks at least this long get a memo slot
 #define PROMOTE_STEPS 16      // a thread walker that gets this far hands over to a wavefront
@@ -45,6 +51,30 @@ typedef unsigned long long u64;
 #define CLAIM(rank, pos) (((u64)(rank) << 32) | (u64)(uint32_t)(pos))
 #define RANK(c) ((uint32_t)((c) >> 32))
 #define POS(c) ((uint32_t)(c))
+
+struct Adj4 { int32_t v[4]; };
+// Everything about an oriented k1-mer that does not change while the walks iterate, in ONE 64-byte line: both adjacency rows, its
+// weight, and the two words the mark pass keeps per k1-mer (memo hint, rank of the walk seeded on it).  A walk step used to touch
+// four arrays per candidate (claims, snapshot, weights, rows); the rows and the weight of a candidate -- and whatever the mark
+// pass needs around a changed k1-mer -- now come with one sector.  The bulk rounds are bound by the NUMBER of random 64-byte
+// sectors the chip serves (~30 G/s measured, at any lane occupancy), so sectors per step is what the layout is chosen for.
+// The claims and their snapshot stay compact arrays of their own: the begin / mark / audit / emit passes stream them.
+struct __attribute__((aligned(64))) Rec {
+  Adj4 R;                // oriented id reached by appending base b, or -1
+  Adj4 L;                // ... by prepending base b
+  uint32_t weight;       // weight of the string in the doubled input
+  uint32_t hint;         // where this k1-mer was last written into a memo (pool index << 2 | kind), NOHINT if never
+  uint32_t seed_rank;    // rank of the walk seeded on it, 0xFFFFFFFF if it is not a seed
+  uint32_t pad[5];
+};
+static_assert(sizeof(Rec) == 64, "one line per oriented k1-mer");
+// rows of one direction / the weights / the hints, indexed by oriented id (strided views of the record array)
+struct RowView { const char* p; __device__ __forceinline__ Adj4 operator[](uint32_t i) const { return *(const Adj4*)(p + ((uint64_t)i << 6)); } };
+struct WordView { const char* p; __device__ __forceinline__ uint32_t operator[](uint32_t i) const { return *(const uint32_t*)(p + ((uint64_t)i << 6)); } };
+__host__ __device__ __forceinline__ RowView rows_R(const Rec* r) { return RowView{(const char*)r}; }
+__host__ __device__ __forceinline__ RowView rows_L(const Rec* r) { return RowView{(const char*)r + 16}; }
+__host__ __device__ __forceinline__ WordView words_weight(const Rec* r) { return WordView{(const char*)r + 32}; }
+__host__ __device__ __forceinline__ WordView words_hint(const Rec* r) { return WordView{(const char*)r + 36}; }
 
 struct shn_ext {
   shn_ctx* ctx;
@@ -58,8 +88,7 @@ struct shn_ext {
   shn_table* owned_table; // sharded: the k1-mers of this rank's components (table points at it)
   uint32_t* d_weight;    // [n] weight of the string in the doubled input (count, x2 for palindromes)
   uint8_t* d_flags;      // [n] bit0 palindrome, bit1 low complexity
-  int32_t* d_adjR;       // [2n*4] oriented id reached by appending base b, or -1
-  int32_t* d_adjL;       // [2n*4] oriented id reached by prepending base b, or -1
+  Rec* d_rec;            // [2n] per oriented k1-mer: adjacency rows, weight, memo hint, seed rank (see Rec)
   uint32_t* d_order;     // [n_seeds] oriented id of the seed with rank r
   u64* d_claim;          // [2n] converged claims: (rank of the owning walk) << 32 | (1 + step index on its path)
   u64* d_claim2;         // [2n] scratch
@@ -179,42 +208,74 @@ __device__ __forceinline__ bool bloom_may_have(const unsigned long long* __restr
   return (bits[word] & mask) == mask;
 }
 
-// Both rows of both orientations from 8 look-ups per canonical k1-mer instead of 16: the right candidates of the reverse-
+// The records of both orientations of every canonical k1-mer from 8 look-ups instead of 16: the right candidates of the reverse-
 // complement orientation are the reverse complements of the forward orientation's left candidates (rc(s)[1:] + b = rc(comp(b) +
 // s[:-1])) and vice versa -- the same table entry j, the other orientation (the same one if entry j is its own reverse
-// complement).  One thread per (canonical k1-mer, dir, base).
-__global__ void ext_adjacency_half_kernel(const uint64_t* __restrict__ tkeys, const uint64_t* __restrict__ boff, int bits,
-                                          const uint8_t* __restrict__ flags, uint64_t n, int k, int canonical,
-                                          int32_t* __restrict__ adjR, int32_t* __restrict__ adjL, const unsigned long long* __restrict__ recs,
-                                          const unsigned long long* __restrict__ bloom, uint64_t bloom_blocks) {
-  const uint64_t total = n * 8;
+// complement).  Two threads per canonical k1-mer (one per direction, four look-ups each); they exchange their halves by shuffle
+// and each writes one whole 64-byte record (four 16-byte stores, 4 KB contiguous per wavefront).
+struct __attribute__((aligned(16))) Quad { uint32_t a, b, c, d; };
+__global__ void ext_records_kernel(const uint64_t* __restrict__ tkeys, const uint64_t* __restrict__ boff, int bits,
+                                   const uint8_t* __restrict__ flags, const uint32_t* __restrict__ weight, uint64_t n, int k, int canonical,
+                                   Rec* __restrict__ rec, const unsigned long long* __restrict__ recs,
+                                   const unsigned long long* __restrict__ bloom, uint64_t bloom_blocks) {
+  const uint64_t total = n * 2;
+  const uint64_t rounded = (total + 63) & ~63ULL;                       // whole wavefronts take part in the shuffles
   const uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
-  for (uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t b = gid & 3;
-    const uint32_t dir = (gid >> 2) & 1;
-    const uint64_t i = gid >> 3;
-    const uint8_t f = flags[i];
+  for (uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < rounded; gid += (uint64_t)gridDim.x * blockDim.x) {
+    const bool in = gid < total;
+    const uint32_t dir = gid & 1;
+    const uint64_t i = in ? gid >> 1 : 0;
+    const uint8_t f = in ? flags[i] : (uint8_t)2;
     const bool dead0 = (f & 2) != 0;                                    // forward orientation
     const bool dead1 = dead0 || (f & 1) || !canonical;                  // reverse-complement orientation (absent for palindromes)
-    int32_t res = -1, der = -1;
+    int32_t res[4] = {-1, -1, -1, -1}, der[4] = {-1, -1, -1, -1};
     if (!dead0) {
       const uint64_t str = tkeys[i];
-      const uint64_t nb = dir == 0 ? (((str << 2) | b) & mask) : ((str >> 2) | ((uint64_t)b << (2 * (k - 1))));
-      uint64_t canon = nb;
-      uint32_t strand = 0;
-      if (canonical) { const uint64_t rc = shn_revcomp(nb, k); if (rc < nb) { canon = rc; strand = 1; } }
-      const int64_t j = (bloom && !bloom_may_have(bloom, bloom_blocks, canon)) ? -1
-                        : recs ? ext_find_indexed(tkeys, recs, bits, canon) : shn_table_find(tkeys, boff, bits, canon);
-      if (j >= 0) {
+      uint64_t canon[4];
+      uint32_t strand[4];
+      bool may[4];
+#pragma unroll
+      for (int b = 0; b < 4; b++) {                                     // the four filter words first: independent loads
+        const uint64_t nb = dir == 0 ? (((str << 2) | (uint64_t)b) & mask) : ((str >> 2) | ((uint64_t)b << (2 * (k - 1))));
+        canon[b] = nb; strand[b] = 0;
+        if (canonical) { const uint64_t rc = shn_revcomp(nb, k); if (rc < nb) { canon[b] = rc; strand[b] = 1; } }
+        may[b] = !bloom || bloom_may_have(bloom, bloom_blocks, canon[b]);
+      }
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        if (!may[b]) continue;
+        const int64_t j = recs ? ext_find_indexed(tkeys, recs, bits, canon[b]) : shn_table_find(tkeys, boff, bits, canon[b]);
+        if (j < 0) continue;
         const uint8_t fj = flags[j];
-        if (!(fj & 2)) {
-          res = (int32_t)(2 * j + strand);
-          der = (fj & 1) ? res : (int32_t)(2 * j + (1 - strand));        // the candidate's other orientation
-        }
+        if (fj & 2) continue;
+        res[b] = (int32_t)(2 * j + strand[b]);
+        der[b] = (fj & 1) ? res[b] : (int32_t)(2 * j + (1 - strand[b]));   // the candidate's other orientation
       }
     }
-    (dir == 0 ? adjR : adjL)[(2 * i) * 4 + b] = res;
-    (dir == 0 ? adjL : adjR)[(2 * i + 1) * 4 + (3 - b)] = dead1 ? -1 : der;
+    // thread dir = 0 writes the forward record (its own right row + the partner's left row); thread dir = 1 the reverse-
+    // complement record: as left row the partner's derived candidates, as right row its own, both mirrored (base b <-> 3 - b)
+    int32_t got[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) got[b] = __shfl_xor(dir == 0 ? der[b] : res[b], 1, 64);
+    if (!in) continue;
+    Quad q0, q1, q2, q3;
+    uint64_t o;
+    if (dir == 0) {
+      o = 2 * i;
+      q0 = Quad{(uint32_t)res[0], (uint32_t)res[1], (uint32_t)res[2], (uint32_t)res[3]};
+      q1 = Quad{(uint32_t)got[0], (uint32_t)got[1], (uint32_t)got[2], (uint32_t)got[3]};
+    } else {
+      o = 2 * i + 1;
+      if (dead1) { q0 = Quad{~0u, ~0u, ~0u, ~0u}; q1 = q0; }
+      else {
+        q0 = Quad{(uint32_t)der[3], (uint32_t)der[2], (uint32_t)der[1], (uint32_t)der[0]};      // right row of rc = mirrored left candidates
+        q1 = Quad{(uint32_t)got[3], (uint32_t)got[2], (uint32_t)got[1], (uint32_t)got[0]};      // left row of rc = mirrored right candidates
+      }
+    }
+    q2 = Quad{weight[i], NOHINT_WORD, 0xFFFFFFFFu, 0u};
+    q3 = Quad{~0u, ~0u, 0u, 0u};                       // (first two words: see WalkArgs::xrec)
+    Quad* dst = (Quad*)(rec + o);
+    dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3;
   }
 }
 
@@ -342,21 +403,20 @@ __global__ void ext_weightkey_kernel(const uint32_t* __restrict__ svals, const u
   wkeys[i] = (uint64_t)(0xFFFFFFFFu - weight[svals[i] >> 1]);   // ascending sort => weight descending
 }
 
-struct Adj4 { int32_t v[4]; };
 // entry b of a row, b known only at run time: picked with compares (an indexed access makes the compiler keep the row in
 // scratch memory)
 __device__ __forceinline__ int32_t adj_get(const Adj4& a, int b) { return b == 0 ? a.v[0] : b == 1 ? a.v[1] : b == 2 ? a.v[2] : a.v[3]; }
 #define CHUNK_SHIFT 4          // 16 oriented k1-mers = one 128-byte line of claims per flag
 
 struct WalkArgs {
-  const uint32_t* order; const Adj4* adjR; const Adj4* adjL; const uint32_t* weight;
+  const uint32_t* order; RowView adjR; RowView adjL; WordView weight;   // weight: by ORIENTED id (views of the record array)
   u64* claim;            // live claims: clean walks' + this round's (dirty walks released theirs before the round)
   const u64* claim_old;  // snapshot taken before the round
   uint32_t* nr_out; uint32_t* nl_out; uint64_t* totw_out;
   // memo: the path of the walk's last live run, rebuilt from the claims after every round it ran alive
   // (ext_memo_plan_kernel + the scatter in ext_mark_kernel).  Hints only -- every use is validated.
   const uint32_t* pool; const uint64_t* moff; const uint32_t* mR; const uint32_t* mL; const uint8_t* mvalid;
-  const uint32_t* hint;  // per k1-mer: where it was last written into a memo (pool index << 2 | kind), NOHINT if never
+  WordView hint;         // per k1-mer: where it was last written into a memo (pool index << 2 | kind), NOHINT if never
   unsigned long long* steps_counter;
   unsigned long long* wave_steps_counter;
   unsigned long long* dbg;     // [0] wave steps confirmed from an own memo [1] from a foreign memo
@@ -364,11 +424,15 @@ struct WalkArgs {
   uint32_t* promo_list; unsigned long long* promo_count; uint32_t* res_cur; uint32_t* res_info;   // info = dir << 31 | steps so far
   uint32_t promote_steps;
   uint8_t* chunk;        // per 2^CHUNK_SHIFT oriented k1-mers: "a claim in here was written this round" (the mark pass visits only those)
+  char* xrec;            // EXPERIMENT (SHN_EXT_XCLAIM=1, timing only): the thread walker keeps its claims in the records' spare words
+  int xplain;            // EXPERIMENT (SHN_EXT_XPLAIN=1, timing only): claims written with plain stores instead of atomic min
 };
+#define XCLAIM(A, idx) ((A).xrec ? (u64*)((A).xrec + ((uint64_t)(idx) << 6) + 48) : &(A).claim[idx])
 
 // Claim `node` as step `pos` of walk r: atomic min on rank:pos, fire-and-forget (a returning atomic would put
 // a second memory round trip on every step; lost races are found after the round by ext_verify_kernel).
 __device__ __forceinline__ void claim_node(const WalkArgs& A, uint32_t node, uint32_t r, uint32_t pos) {
+  if (A.xplain) { A.claim[node] = CLAIM(r, pos); return; }
   __hip_atomic_fetch_min(&A.claim[node], CLAIM(r, pos), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (A.chunk) A.chunk[node >> CHUNK_SHIFT] = 1;
 }
@@ -378,7 +442,7 @@ __device__ __forceinline__ void claim_node(const WalkArgs& A, uint32_t node, uin
 // live by a rank <= r (lower ranks of this round, or this walk's own trail), or claimed in the pre-round
 // snapshot by a lower rank.
 __device__ __forceinline__ int decide(const Adj4& cand, uint32_t r, const u64* claim, const u64* __restrict__ claim_old,
-                                      const uint32_t* __restrict__ weight, uint32_t dummy, uint32_t& bw) {
+                                      const WordView weight, uint32_t dummy, uint32_t& bw) {
   u64 cl[4], co[4];
   uint32_t w[4];
 #pragma unroll
@@ -386,7 +450,7 @@ __device__ __forceinline__ int decide(const Adj4& cand, uint32_t r, const u64* c
     uint32_t idx = cand.v[b] < 0 ? dummy : (uint32_t)cand.v[b];
     cl[b] = __hip_atomic_load(&claim[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     co[b] = claim_old[idx];
-    w[b] = weight[idx >> 1];
+    w[b] = weight[idx];
   }
   int best = -1;
   bw = 0;
@@ -399,7 +463,7 @@ __device__ __forceinline__ int decide(const Adj4& cand, uint32_t r, const u64* c
 // the greedy choice of walk r standing at step p, from the claims alone (for walk r a k1-mer is traversed iff a lower rank
 // owns it or r owns it at a step <= p); used by the precise marks of ext_mark_kernel and by the fixpoint audit
 __device__ __forceinline__ int audit_decide(const Adj4& cd, uint32_t r, uint32_t p, const u64* __restrict__ claim,
-                                            const uint32_t* __restrict__ weight) {
+                                            const WordView weight) {
   int best = -1;
   uint32_t bw = 0;
 #pragma unroll
@@ -408,7 +472,7 @@ __device__ __forceinline__ int audit_decide(const Adj4& cd, uint32_t r, uint32_t
     if (cd.v[b] < 0) continue;
     const u64 c = claim[cd.v[b]];
     const bool avail = RANK(c) > r || (RANK(c) == r && POS(c) > p);
-    const uint32_t w = weight[(uint32_t)cd.v[b] >> 1];
+    const uint32_t w = weight[(uint32_t)cd.v[b]];
     if (avail && (best < 0 || w > bw)) { best = b; bw = w; }
   }
   return best;
@@ -420,10 +484,10 @@ __device__ __forceinline__ int audit_decide(const Adj4& cd, uint32_t r, uint32_t
 // the claims of final walks, which the live claims hold too: the snapshot is not read (a quarter of a step's memory accesses,
 // in the rounds that make most of the steps).
 template <bool FRESH>
-__global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_walks, const uint32_t* __restrict__ list,
+__global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_walks, const uint32_t* __restrict__ list,
                                                         const u64* __restrict__ snap) {
   __shared__ unsigned long long blk_steps;
-  __shared__ uint32_t blk_promo[EBLK], n_promo, promo_base;      // walks handed over: one global atomic per block
+  __shared__ uint32_t blk_promo[WBLK], n_promo, promo_base;      // walks handed over: one global atomic per block
   if (threadIdx.x == 0) { blk_steps = 0; n_promo = 0; }
   __syncthreads();
   uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -431,17 +495,18 @@ __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
   if (t < n_walks) {
     const uint32_t r = list[t];
     const uint32_t o = A.order[r];
+    const unsigned long long t_begin = A.dbg ? __builtin_amdgcn_s_memrealtime() : 0ULL;      // (100 MHz)
     uint32_t nr = 0, nl = 0;
     uint64_t tot = 0;
     bool promoted = false;
     // snap: the pre-round snapshot; A.claim: live claims of this round
-    bool isvoid = (!FRESH && RANK(snap[o]) < r) || RANK(__hip_atomic_load(&A.claim[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < r;
+    bool isvoid = (!FRESH && RANK(snap[o]) < r) || RANK(__hip_atomic_load(XCLAIM(A, o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < r;
     if (!isvoid) {
-      claim_node(A, o, r, 0);
-      tot = A.weight[o >> 1];
-      uint32_t pos = 0;
+      if (A.xrec) __hip_atomic_fetch_min(XCLAIM(A, o), CLAIM(r, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else claim_node(A, o, r, 0);
+      tot = A.weight[o];
+      uint32_t pos = 0, pend = NONE32;
       for (int dir = 0; dir < 2; dir++) {
-        const Adj4* adj = dir == 0 ? A.adjR : A.adjL;
+        const RowView adj = dir == 0 ? A.adjR : A.adjL;
         uint32_t steps = 0;
         Adj4 cand = adj[o];
         while (true) {
@@ -451,10 +516,17 @@ __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
 #pragma unroll
           for (int b = 0; b < 4; b++) {
             uint32_t idx = cand.v[b] < 0 ? o : (uint32_t)cand.v[b];
-            cl[b] = __hip_atomic_load(&A.claim[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cl[b] = __hip_atomic_load(XCLAIM(A, idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             cf[b] = FRESH ? UNCLAIMED64 : snap[idx];
-            w[b] = A.weight[idx >> 1];
+            w[b] = A.weight[idx];
             nxt[b] = adj[idx];
+          }
+          // the claim of the step just taken goes out BEHIND the loads of this step: vector memory operations of a wavefront
+          // return in issue order (one counter for loads, stores and atomics), so a claim issued in front of the loads would put
+          // the latency of a memory-side atomic on every step of the walk -- and a bulk round lasts as long as its longest walk
+          if (pend != NONE32) {
+            if (A.xrec) __hip_atomic_fetch_min(XCLAIM(A, pend), CLAIM(r, pos), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else claim_node(A, pend, r, pos);
+            pend = NONE32;
           }
           int best = -1;
           uint32_t bw = 0;
@@ -466,10 +538,12 @@ __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
           // memory traffic on every step)
           uint32_t nbest = (uint32_t)(best == 0 ? cand.v[0] : best == 1 ? cand.v[1] : best == 2 ? cand.v[2] : cand.v[3]);
           pos++;
-          claim_node(A, nbest, r, pos);
+          pend = nbest;                            // claimed at the top of the next trip (or below, when the walk stops here)
           steps++;
           tot += bw;
           if (pos >= A.promote_steps) {            // long after all: a wavefront takes over from here (memos, 64 steps a trip)
+            claim_node(A, nbest, r, pos);
+            pend = NONE32;
             A.res_cur[r] = nbest;
             A.res_info[r] = ((uint32_t)dir << 31) | pos;
             blk_promo[atomicAdd(&n_promo, 1u)] = r;
@@ -479,6 +553,10 @@ __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
 #pragma unroll
           for (int q = 0; q < 4; q++) cand.v[q] = best == 0 ? nxt[0].v[q] : best == 1 ? nxt[1].v[q] : best == 2 ? nxt[2].v[q] : nxt[3].v[q];   // (word by word: a select between structs goes through memory)
         }
+        if (pend != NONE32) {                        // the last step of this direction
+          if (A.xrec) __hip_atomic_fetch_min(XCLAIM(A, pend), CLAIM(r, pos), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else claim_node(A, pend, r, pos);
+          pend = NONE32;
+        }
         if (dir == 0) nr = steps; else nl = steps;
         if (promoted) break;
       }
@@ -487,6 +565,8 @@ __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
     A.nl_out[r] = nl;
     A.totw_out[r] = tot;
     mysteps = nr + nl;
+    // debug: the longest walk of the launch and how long it took (steps << 32 | ticks of 10 ns): a bulk round cannot end before it
+    if (A.dbg && mysteps >= 64) atomicMax(&A.dbg[12], ((unsigned long long)mysteps << 32) | ((__builtin_amdgcn_s_memrealtime() - t_begin) & 0xFFFFFFFFULL));
   }
   if (mysteps) atomicAdd(&blk_steps, (unsigned long long)mysteps);
   __syncthreads();
@@ -498,13 +578,133 @@ __global__ __launch_bounds__(EBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
   if (threadIdx.x < n_promo) A.promo_list[promo_base + threadIdx.x] = blk_promo[threadIdx.x];
 }
 
+// ---- the same walks on persistent lanes (the default): a wavefront of the kernel above runs as long as its longest walk, and the
+// lengths of walks that start side by side in the seed order are geometric-like (a walk runs until it meets the territory of a
+// lower rank: half of them stop within a step, one in a thousand goes on for thousands) -- measured on the final paths of a
+// 5,000-gene input: 2-3 % of the lane-steps of a wavefront do work.  Here a lane whose walk has ended takes the next walk of the
+// list at once: the list is handed out in rank order, 64 walks per atomic (a wavefront-local cursor, lanes served by ballot /
+// prefix), so every lane has a memory round trip in flight until the list is exhausted.  The low ranks also start first now --
+// closer to the sequential order, in which no step is ever wasted: fewer walks run into territory they lose again.
+// The result does not depend on any of this (the rounds iterate to the fixpoint whatever the order of events inside a round).
+template <bool FRESH>
+__global__ __launch_bounds__(WBLK) void ext_walk_refill_kernel(WalkArgs A, uint64_t n_walks, const uint32_t* __restrict__ list,
+                                                               const u64* __restrict__ snap, unsigned long long* __restrict__ queue,
+                                                               unsigned long long* __restrict__ trips_counter) {
+  __shared__ unsigned long long blk_steps, blk_trips;
+  if (threadIdx.x == 0) { blk_steps = 0; blk_trips = 0; }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const unsigned long long below = (1ULL << lane) - 1ULL;
+  bool active = false;
+  uint32_t r = 0, o = 0, pos = 0, steps = 0, nr = 0;
+  int dir = 0;
+  uint64_t tot = 0;
+  Adj4 cand = {{-1, -1, -1, -1}};
+  uint64_t wbase = 0;                       // wavefront-uniform: the part of the list this wavefront holds
+  uint32_t wleft = 0;
+  bool exhausted = false;
+  uint32_t mysteps = 0, trips = 0;
+  for (;;) {
+    const unsigned long long idle = __ballot(!active);
+    if (idle && !exhausted) {
+      if (wleft == 0) {
+        unsigned long long b = 0;
+        if (lane == 0) b = atomicAdd(queue, 64ULL);
+        b = (unsigned long long)__shfl((long long)b, 0, 64);
+        if (b >= n_walks) exhausted = true;
+        else { wbase = b; wleft = (uint32_t)(n_walks - b < 64 ? n_walks - b : 64); }
+      }
+      if (wleft) {
+        const uint32_t mine = (uint32_t)__popcll(idle & below);
+        if (!active && mine < wleft) {
+          r = list[wbase + mine];
+          o = A.order[r];
+          const bool isvoid = (!FRESH && RANK(snap[o]) < r) || RANK(__hip_atomic_load(&A.claim[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < r;
+          if (isvoid) { A.nr_out[r] = UNCLAIMED; A.nl_out[r] = 0; A.totw_out[r] = 0; }
+          else {
+            claim_node(A, o, r, 0);
+            tot = A.weight[o];
+            pos = 0; steps = 0; nr = 0; dir = 0;
+            cand = A.adjR[o];
+            active = true;
+          }
+        }
+        const uint32_t need = (uint32_t)__popcll(idle);
+        const uint32_t taken = need < wleft ? need : wleft;
+        wbase += taken; wleft -= taken;
+      }
+    }
+    const unsigned long long act = __ballot(active);
+    if (!act) { if (exhausted) break; continue; }
+    trips++;
+    if (active) {
+      const RowView adj = dir == 0 ? A.adjR : A.adjL;
+      u64 cl[4], cf[4];
+      uint32_t w[4];
+      Adj4 nxt[4];
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const uint32_t idx = cand.v[b] < 0 ? o : (uint32_t)cand.v[b];
+        cl[b] = __hip_atomic_load(&A.claim[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cf[b] = FRESH ? UNCLAIMED64 : snap[idx];
+        w[b] = A.weight[idx];
+        nxt[b] = adj[idx];
+      }
+      int best = -1;
+      uint32_t bw = 0;
+#define CONSIDER(b) if (cand.v[b] >= 0 && RANK(cl[b]) > r && RANK(cf[b]) >= r && (best < 0 || w[b] > bw)) { best = b; bw = w[b]; }
+      CONSIDER(0) CONSIDER(2) CONSIDER(1) CONSIDER(3)
+#undef CONSIDER
+      bool ended = false;                              // this walk is done with (or handed over)
+      if (best < 0) {
+        if (dir == 0) { nr = steps; steps = 0; dir = 1; cand = A.adjL[o]; }
+        else { A.nr_out[r] = nr; A.nl_out[r] = steps; A.totw_out[r] = tot; ended = true; }
+      } else {
+        const uint32_t nbest = (uint32_t)(best == 0 ? cand.v[0] : best == 1 ? cand.v[1] : best == 2 ? cand.v[2] : cand.v[3]);
+        pos++;
+        claim_node(A, nbest, r, pos);
+        steps++;
+        mysteps++;
+        tot += bw;
+        if (pos >= A.promote_steps) {                  // long after all: a wavefront takes over from here (memos, 64 steps a trip)
+          A.res_cur[r] = nbest;
+          A.res_info[r] = ((uint32_t)dir << 31) | pos;
+          A.nr_out[r] = dir == 0 ? steps : nr;
+          A.nl_out[r] = dir == 0 ? 0 : steps;
+          A.totw_out[r] = tot;
+          ended = true;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; q++) cand.v[q] = best == 0 ? nxt[0].v[q] : best == 1 ? nxt[1].v[q] : best == 2 ? nxt[2].v[q] : nxt[3].v[q];
+        }
+      }
+      const bool promo = ended && best >= 0;
+      const unsigned long long pm = __ballot(promo);   // (only the active lanes take part: the idle ones are outside this branch)
+      if (pm) {
+        unsigned long long pbase = 0;
+        const int leader = __ffsll((long long)pm) - 1;
+        if (lane == leader) pbase = atomicAdd(A.promo_count, (unsigned long long)__popcll(pm));
+        pbase = (unsigned long long)__shfl((long long)pbase, leader, 64);
+        if (promo) A.promo_list[pbase + __popcll(pm & below)] = r;
+      }
+      if (ended) active = false;
+    }
+  }
+  if (mysteps) atomicAdd(&blk_steps, (unsigned long long)mysteps);
+  if (lane == 0 && trips) atomicAdd(&blk_trips, (unsigned long long)trips);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (blk_steps) atomicAdd(A.steps_counter, blk_steps);
+    if (blk_trips) atomicAdd(trips_counter, blk_trips);
+  }
+}
+
 // ---- long walks: one wavefront per dirty walk.  A memo (the path of some walk's last live run, own or foreign)
 // is re-checked 64 steps per memory round trip; the walk is sequential only from the first changed decision
 // until it meets a memo again -- its own, or the one of the walk whose territory it is taking over.
 // Memo entries are hints: an entry counts only if the k1-mer's hint says it sits at exactly that position of
 // that memo (so the validated entries of a chunk are pairwise distinct), and a changed decision is re-made
 // sequentially against the live claims, never taken from the speculative lane.
-#define NONE32 0xFFFFFFFFu
 __device__ __forceinline__ bool is_term_any(bool term, bool at_mark) { return term && at_mark; }
 // Memo slots are never rewritten: a walk that runs again gets a new slot, so a hint always leads to an intact old path.
 //   slot = [MARK][nR | HI][seed][R_1 .. R_nR][MARK][L_1 .. L_nL][MARK]       (HI = top bit; k1-mer ids are < 2^31)
@@ -563,14 +763,14 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
       if (lane == 0) { A.nr_out[r] = UNCLAIMED; A.nl_out[r] = 0; A.totw_out[r] = 0; }
       continue;
     }
-    tot = A.weight[o >> 1];
+    tot = A.weight[o];
     if (lane == 0) claim_node(A, o, r, 0);
   }
   const uint32_t ns_start = ns;
   uint32_t nseq = 0;                          // sequential steps (debug statistics)
   WhyStat why;
   for (int dir = dir0; dir < 2; dir++) {
-    const Adj4* adj = dir == 0 ? A.adjR : A.adjL;
+    const RowView adj = dir == 0 ? A.adjR : A.adjL;
     uint32_t cur = (RESUME && dir == dir0) ? cur0 : o;
     MemoCursor mc;
     // own memo first (its steps of this direction), else whatever memo the k1-mer was last written into
@@ -613,7 +813,7 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
         uint64_t myw = 0;
         if ((uint32_t)lane < conf) {
           claim_node(A, mine, r, ns + lane + 1);
-          myw = A.weight[mine >> 1];
+          myw = A.weight[mine];
         }
         for (int off = 32; off > 0; off >>= 1) myw += __shfl_xor(myw, off, 64);
         tot += myw;
@@ -647,7 +847,7 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
         u64 cl = __hip_atomic_load(&A.claim[myc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         u64 co = A.claim_old[myc];
         hmy = A.hint[myc];
-        wmy = A.weight[(uint32_t)myc >> 1];
+        wmy = A.weight[(uint32_t)myc];
         row = adj[myc];
         avail = RANK(cl) > r && RANK(co) >= r;
       }
@@ -694,8 +894,8 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
 // where its rule finds nothing, and every walk owns exactly its recorded steps.  For walk r at step p a k1-mer is
 // traversed if a lower rank owns it or r owns it at a step <= p.  A walk that fails is made dirty and the rounds go
 // on with every block reopened -- the rounds' change tracking is an optimisation, this is the definition.
-__global__ void ext_audit_nodes_kernel(const u64* __restrict__ claim, uint64_t n2, const Adj4* __restrict__ adjR, const Adj4* __restrict__ adjL,
-                                       const uint32_t* __restrict__ weight, const uint32_t* __restrict__ order,
+__global__ void ext_audit_nodes_kernel(const u64* __restrict__ claim, uint64_t n2, const RowView adjR, const RowView adjL,
+                                       const WordView weight, const uint32_t* __restrict__ order,
                                        const uint32_t* __restrict__ nr_a, const uint32_t* __restrict__ nl_a, uint64_t ns,
                                        uint32_t* __restrict__ owned, uint8_t* __restrict__ dirty, unsigned long long* __restrict__ counters) {
   for (uint64_t y = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; y < n2; y += (uint64_t)gridDim.x * blockDim.x) {
@@ -758,9 +958,9 @@ __global__ void ext_audit_kernel(WalkArgs A, uint64_t ns, unsigned long long* __
   else if (cs != CLAIM(r, 0)) bad = true;
   else {
     uint32_t pos = 0;
-    uint64_t tot = A.weight[o >> 1];
+    uint64_t tot = A.weight[o];
     for (int dir = 0; dir < 2 && !bad; dir++) {
-      const Adj4* adj = dir == 0 ? A.adjR : A.adjL;
+      const RowView adj = dir == 0 ? A.adjR : A.adjL;
       const uint32_t end = dir == 0 ? nr : nr + nl;
       uint32_t cur = o;
       while (true) {
@@ -773,7 +973,7 @@ __global__ void ext_audit_kernel(WalkArgs A, uint64_t ns, unsigned long long* __
           if (cd.v[b] < 0) continue;
           const u64 c = A.claim[cd.v[b]];
           const bool avail = RANK(c) > r || (RANK(c) == r && POS(c) > pos);
-          const uint32_t w = A.weight[(uint32_t)cd.v[b] >> 1];
+          const uint32_t w = A.weight[(uint32_t)cd.v[b]];
           if (avail && (best < 0 || w > bw)) { best = b; bw = w; }
         }
         if (best < 0) { if (pos != end) bad = true; break; }
@@ -878,14 +1078,15 @@ __global__ void ext_round_begin_kernel(u64* __restrict__ claim, u64* __restrict_
 
 // after a round: every k1-mer whose owner changed dirties the walks that looked at it; the k1-mers of the walks
 // that got a memo slot are written into it (memo + hint)
-__global__ void ext_mark_kernel(const u64* __restrict__ claim, u64* claim_old, uint64_t n2,
-                                const Adj4* __restrict__ adjR, const Adj4* __restrict__ adjL, const uint32_t* __restrict__ seed_rank,
+__global__ void ext_mark_kernel(const u64* __restrict__ claim, u64* claim_old, uint64_t n2, Rec* __restrict__ rec,
                                 uint8_t* __restrict__ dirty, const uint8_t* __restrict__ ran, uint32_t* __restrict__ owned,
                                 unsigned long long* __restrict__ n_changed, uint32_t frozen, uint32_t limit,
                                 const uint8_t* __restrict__ fill, const uint64_t* __restrict__ moff, const uint32_t* __restrict__ mR,
-                                uint32_t* __restrict__ pool, uint32_t* __restrict__ hint,
-                                const uint32_t* __restrict__ nr_a, const uint32_t* __restrict__ nl_a, const uint32_t* __restrict__ weight, int precise,
+                                uint32_t* __restrict__ pool,
+                                const uint32_t* __restrict__ nr_a, const uint32_t* __restrict__ nl_a, int precise,
                                 const uint8_t* __restrict__ chunk) {
+  const RowView adjR = rows_R(rec), adjL = rows_L(rec);
+  const WordView weight = words_weight(rec);
   // grid-stride: the change counter costs one atomic per block (one per wavefront on a single address was the
   // most expensive thing in this kernel).  A wavefront takes 64 k1-mers at a time and, in rounds that re-run few walks
   // (chunk != NULL), looks only at the 128-byte lines of claims (16 k1-mers, one flag) a claim was written in this round
@@ -911,7 +1112,7 @@ __global__ void ext_mark_kernel(const u64* __restrict__ claim, u64* claim_old, u
         const uint32_t pos = POS(cy), R = mR[b];
         const uint64_t idx = moff[b] + (pos <= R ? 2 : 3) + pos;
         if (pos) pool[idx] = (uint32_t)y;
-        hint[y] = (uint32_t)(idx << 2) | (pos == 0 ? HINT_SEED : pos <= R ? HINT_R : HINT_L);
+        rec[y].hint = (uint32_t)(idx << 2) | (pos == 0 ? HINT_SEED : pos <= R ? HINT_R : HINT_L);
       }
     }
     if (a == b) return false;
@@ -931,7 +1132,7 @@ __global__ void ext_mark_kernel(const u64* __restrict__ claim, u64* claim_old, u
   auto mark_around = [&](const uint64_t y, const uint32_t a) {
     const uint32_t b = RANK(claim[y]);
 #define MARKX(x) if (a < (x) && (x) < b) MARK(x)
-    uint32_t sr = seed_rank[y];
+    const uint32_t sr = rec[y].seed_rank;                        // (the same line as the two rows)
     MARKX(sr);
     Adj4 L = adjL[y], R = adjR[y];
 #pragma unroll
@@ -1005,9 +1206,9 @@ __global__ void ext_verify_kernel(const uint8_t* __restrict__ ran, const uint32_
   if (owned[r] != expect) dirty[r] = 1;
 }
 
-__global__ void ext_seed_rank_kernel(const uint32_t* __restrict__ order, uint64_t ns, uint32_t* __restrict__ seed_rank) {
+__global__ void ext_seed_rank_kernel(const uint32_t* __restrict__ order, uint64_t ns, Rec* __restrict__ rec) {
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < ns) seed_rank[order[r]] = (uint32_t)r;
+  if (r < ns) rec[order[r]].seed_rank = (uint32_t)r;
 }
 
 // Contig bases straight from the converged claims: every oriented k1-mer knows its walk and its step index
@@ -1158,8 +1359,7 @@ static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank
 extern "C" void shn_ext_destroy(shn_ext* e) {
   if (!e) return;
   hipSetDevice(e->device);
-  void* ptrs[] = {e->d_weight, e->d_flags, e->d_adjR, e->d_adjL, e->d_order, e->d_claim, e->d_claim2, e->d_nr, e->d_nl,
-                  e->d_totw};
+  void* ptrs[] = {e->d_weight, e->d_flags, e->d_rec, e->d_order, e->d_claim, e->d_claim2, e->d_nr, e->d_nl, e->d_totw};
   for (void* p : ptrs) if (p) shn_dev_free(p);
   if (e->owned_table) shn_table_destroy(e->owned_table);
   delete e;
@@ -1207,18 +1407,14 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       return shn_fail(SHN_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(_e)); } } while (0)
   TRYE(shn_dev_malloc(&e->d_weight, (n + 1) * 4));
   TRYE(shn_dev_malloc(&e->d_flags, n + 1));
-  TRYE(shn_dev_malloc(&e->d_adjR, (2 * n + 1) * 16));
-  TRYE(shn_dev_malloc(&e->d_adjL, (2 * n + 1) * 16));
+  TRYE(shn_dev_malloc(&e->d_rec, (2 * n + 1) * sizeof(Rec)));
   TRYE(shn_dev_malloc(&e->d_claim, (2 * n + 1) * 8));
   TRYE(shn_dev_malloc(&e->d_claim2, (2 * n + 1) * 8));
   if (n) {
     TimerRegion t1(ctx, T_EXT_PREP);
     hipLaunchKernelGGL(ext_prepare_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, t->d_counts, n, t->k,
                        t->canonical, e->d_weight, e->d_flags);
-    if (getenv("SHN_EXT_ADJ_FULL"))                 // (development: all 16 look-ups per k1-mer)
-      hipLaunchKernelGGL(ext_adjacency_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 16, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off,
-                         t->bits, e->d_flags, n, t->k, t->canonical, e->d_adjR, e->d_adjL);
-    else {
+    {
       // large tables: a separator record per bucket first (see ext_find_indexed); SHN_EXT_BUCKET_INDEX=0 / 1 forbids / forces it
       unsigned long long* recs = nullptr;
       uint32_t* d_big = nullptr;
@@ -1240,8 +1436,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
         hipLaunchKernelGGL(ext_bloom_build_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, e->d_flags, n, bloom, bloom_blocks);
       }
       { TimerRegion ta(ctx, T_EXT_ADJ);                  // (one launch: bench.py's roofline entry for this kernel)
-        hipLaunchKernelGGL(ext_adjacency_half_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off,
-                           t->bits, e->d_flags, n, t->k, t->canonical, e->d_adjR, e->d_adjL, (const unsigned long long*)recs, (const unsigned long long*)bloom, bloom_blocks); }
+        hipLaunchKernelGGL(ext_records_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 2, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off,
+                           t->bits, e->d_flags, e->d_weight, n, t->k, t->canonical, e->d_rec, (const unsigned long long*)recs, (const unsigned long long*)bloom, bloom_blocks); }
       if (recs || d_big || bloom) { TRYE(hipStreamSynchronize(s)); shn_dev_free(recs); shn_dev_free(d_big); shn_dev_free(bloom); }
     }
     TRYE(hipGetLastError());
@@ -1288,13 +1484,11 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   TRYE(hipMemsetAsync(e->d_totw, 0, (ns + 1) * 8, s));
   TRYE(hipMemsetAsync(e->d_claim, 0xFF, (2 * n + 1) * 8, s));
   // scratch: claim snapshot (d_claim2), memo pool + per-k1-mer hints, per-walk plan arrays
-  void *ppool, *phint, *pplan, *pseed;
-  if ((rc = g_shn_ws[27].get(pool_cap * 4, &ppool)) || (rc = g_shn_ws[29].get((2 * n + 2) * 4, &phint)) ||
-      (rc = g_shn_ws[28].get((ns + 1) * (8 + 4 * 9 + 1 + 1 + 1 + 1) + 64, &pplan)) ||
-      (rc = g_shn_ws[24].get((2 * n + 2) * 4, &pseed))) { shn_ext_destroy(e); return rc; }
+  void *ppool, *pplan;
+  if ((rc = g_shn_ws[27].get(pool_cap * 4, &ppool)) ||
+      (rc = g_shn_ws[28].get((ns + 1) * (8 + 4 * 9 + 1 + 1 + 1 + 1) + 64, &pplan))) { shn_ext_destroy(e); return rc; }
   u64 *claim = e->d_claim, *snap = e->d_claim2;
   uint32_t* pool = (uint32_t*)ppool;
-  uint32_t* hint = (uint32_t*)phint;
   uint64_t* moff = (uint64_t*)pplan;
   uint32_t* mcap = (uint32_t*)(moff + ns + 1);
   uint32_t* mR = mcap + ns + 1;
@@ -1309,12 +1503,10 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   uint8_t* fill = mvalid + ns + 1;
   uint8_t* dirty = fill + ns + 1;
   uint8_t* ran = dirty + ns + 1;
-  uint32_t* seed_rank = (uint32_t*)pseed;
   TRYE(hipMemsetAsync(mvalid, 0, 2 * (ns + 1), s));
   TRYE(hipMemsetAsync(pool, 0xFF, pool_cap * 4, s));            // NONE32: "no entry"
-  TRYE(hipMemsetAsync(hint, 0xFF, (2 * n + 1) * 4, s));
-  TRYE(hipMemsetAsync(seed_rank, 0xFF, (2 * n + 1) * 4, s));
-  if (ns) hipLaunchKernelGGL(ext_seed_rank_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, e->d_order, (uint64_t)ns, seed_rank);
+  // (hints and seed ranks live in the records: ext_records_kernel wrote "none" into both)
+  if (ns) hipLaunchKernelGGL(ext_seed_rank_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, e->d_order, (uint64_t)ns, e->d_rec);
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   TRYE(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
@@ -1361,6 +1553,10 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   // (which serve the latency-bound re-runs of a few long walks) are not made in such a round.  The expected number of
   // dirty walks is the block size when a block opens, else the count of the round before.
   const unsigned long long bulk_min = getenv("SHN_EXT_BULK") ? strtoull(getenv("SHN_EXT_BULK"), nullptr, 10) : 262144ULL;
+  // thread walker on persistent lanes (ext_walk_refill_kernel; SHN_EXT_REFILL=0: one walk per thread, ext_walk_kernel)
+  const bool refill = tune("SHN_EXT_REFILL", 0) != 0;
+  int n_cu = 256;
+  { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
   unsigned long long expect_dirty = limit;
   while (!converged && it < max_iterations) {
     const bool bulk = bulk_min && expect_dirty >= bulk_min;
@@ -1380,8 +1576,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
         TimerRegion ta(ctx, T_EXT_MARK);
         TRYE(hipMemsetAsync(owned, 0, (ns + 1) * 4, s));
         TRYE(hipMemsetAsync(d_cnt + 48, 0, 16, s));
-        hipLaunchKernelGGL(ext_audit_nodes_kernel, dim3(std::min<uint32_t>(g2n, 4096u)), dim3(256), 0, s, claim, 2 * n, (const Adj4*)e->d_adjR,
-                           (const Adj4*)e->d_adjL, e->d_weight, e->d_order, e->d_nr, e->d_nl, (uint64_t)ns, owned, dirty, d_cnt + 48);
+        hipLaunchKernelGGL(ext_audit_nodes_kernel, dim3(std::min<uint32_t>(g2n, 4096u)), dim3(256), 0, s, claim, 2 * n, rows_R(e->d_rec),
+                           rows_L(e->d_rec), words_weight(e->d_rec), e->d_order, e->d_nr, e->d_nl, (uint64_t)ns, owned, dirty, d_cnt + 48);
         hipLaunchKernelGGL(ext_audit_walks_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, claim, e->d_order, e->d_nr, e->d_nl, (uint64_t)ns,
                            owned, dirty, d_cnt + 48);
         TRYE(hipMemcpyAsync(plan + 4, d_cnt + 48, 16, hipMemcpyDeviceToHost, s));
@@ -1423,14 +1619,16 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
                        (!precise_marks || !snap_current) ? 1 : 0, bulk ? (uint8_t*)nullptr : chunk, frozen, limit, coarse);
     snap_current = true;
     WalkArgs A;
-    A.order = e->d_order; A.adjR = (const Adj4*)e->d_adjR; A.adjL = (const Adj4*)e->d_adjL; A.weight = e->d_weight;
+    A.order = e->d_order; A.adjR = rows_R(e->d_rec); A.adjL = rows_L(e->d_rec); A.weight = words_weight(e->d_rec);
     A.claim = claim; A.claim_old = snap;
     A.nr_out = e->d_nr; A.nl_out = e->d_nl; A.totw_out = e->d_totw;
-    A.pool = pool; A.moff = moff; A.mR = mR; A.mL = mL; A.mvalid = mvalid; A.hint = hint;
+    A.pool = pool; A.moff = moff; A.mR = mR; A.mL = mL; A.mvalid = mvalid; A.hint = words_hint(e->d_rec);
     A.promote_steps = bulk ? 0xFFFFFFFFu : promote_steps;
     A.promo_list = promo_list; A.promo_count = d_cnt + 13; A.res_cur = res_cur; A.res_info = res_info;
     A.chunk = bulk ? nullptr : chunk;          // (bulk rounds write nearly everywhere: their mark pass is dense, the walkers do not flag)
-    A.steps_counter = d_cnt + 1; A.wave_steps_counter = d_cnt + 64; A.dbg = getenv("SHN_DEBUG") ? d_cnt + 32 : nullptr;
+    A.xrec = getenv("SHN_EXT_XCLAIM") ? (char*)e->d_rec : nullptr;
+    A.xplain = getenv("SHN_EXT_XPLAIN") ? 1 : 0;
+    A.steps_counter = d_cnt + 1; A.wave_steps_counter = d_cnt + 64; A.dbg = (getenv("SHN_DEBUG") || getenv("SHN_EXT_XTIME")) ? d_cnt + 32 : nullptr;
     // long (wave per walk) and short (thread per walk) kernels are independent: overlap them on two streams
     if (plan[0]) {
       TRYE(hipEventRecord(ev_fork, s));
@@ -1439,10 +1637,28 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
         hipLaunchKernelGGL(ext_walk_long_kernel<false>, dim3((uint32_t)plan[0]), dim3(64), 0, aux, A, long_list, (uint64_t)ns, (const unsigned long long*)nullptr); }
       TRYE(hipEventRecord(ev_join, aux));
     }
+    double x_t0 = 0;
+    if (getenv("SHN_EXT_XCLAIM") || getenv("SHN_EXT_XTIME")) { TRYE(hipStreamSynchronize(s)); timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); x_t0 = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
     if (plan[2]) {
+      if (refill) TRYE(hipMemsetAsync(d_cnt + 14, 0, 8, s));                 // the list's queue head
       TimerRegion tk(ctx, T_EXT_WALK_THREAD);
-      if (fresh_block) hipLaunchKernelGGL(ext_walk_kernel<true>, dim3((uint32_t)cdiv(plan[2], EBLK)), dim3(EBLK), 0, s, A, (uint64_t)plan[2], short_list, snap);
-      else hipLaunchKernelGGL(ext_walk_kernel<false>, dim3((uint32_t)cdiv(plan[2], EBLK)), dim3(EBLK), 0, s, A, (uint64_t)plan[2], short_list, snap);
+      if (refill) {
+        // persistent lanes: enough blocks to fill the chip (8 of 256 threads per CU), each lane takes walks until the list is empty
+        const uint32_t grid = (uint32_t)std::min<unsigned long long>(cdiv(plan[2], WBLK), (unsigned long long)n_cu * 32);
+        if (fresh_block) hipLaunchKernelGGL(ext_walk_refill_kernel<true>, dim3(grid), dim3(WBLK), 0, s, A, (uint64_t)plan[2], short_list, snap, d_cnt + 14, d_cnt + 15);
+        else hipLaunchKernelGGL(ext_walk_refill_kernel<false>, dim3(grid), dim3(WBLK), 0, s, A, (uint64_t)plan[2], short_list, snap, d_cnt + 14, d_cnt + 15);
+      }
+      else if (fresh_block) hipLaunchKernelGGL(ext_walk_kernel<true>, dim3((uint32_t)cdiv(plan[2], WBLK)), dim3(WBLK), 0, s, A, (uint64_t)plan[2], short_list, snap);
+      else hipLaunchKernelGGL(ext_walk_kernel<false>, dim3((uint32_t)cdiv(plan[2], WBLK)), dim3(WBLK), 0, s, A, (uint64_t)plan[2], short_list, snap);
+    }
+    if (x_t0 > 0) {
+      TRYE(hipStreamSynchronize(s)); timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+      unsigned long long st = 0, lw = 0; TRYE(hipMemcpy(&st, d_cnt + 1, 8, hipMemcpyDeviceToHost));
+      if (A.dbg) { TRYE(hipMemcpy(&lw, d_cnt + 44, 8, hipMemcpyDeviceToHost)); TRYE(hipMemset(d_cnt + 44, 0, 8)); }
+      fprintf(stderr, "[shn_extend] XTIME round %d: thread walker %llu walks, %.2f ms, steps so far %llu; longest walk %llu steps in %.2f ms (%.2f us per step)%s\n", it + 1, plan[2],
+              ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6 - x_t0, st, lw >> 32, (double)(lw & 0xFFFFFFFFULL) * 1e-5, (lw >> 32) ? (double)(lw & 0xFFFFFFFFULL) * 1e-2 / (double)(lw >> 32) : 0.0,
+              A.xrec ? "  (claims in the records: timing experiment, the result is garbage)" : "");
+      if (A.xrec || (A.xplain && it + 1 >= 9)) { shn_ext_destroy(e); return shn_fail(SHN_ERR_INTERNAL, "SHN_EXT_XCLAIM / XPLAIN: timing experiment done"); }
     }
     if (plan[2]) {                              // walks the thread kernel handed over (the count stays on the device)
       TimerRegion tk(ctx, T_EXT_WALK_WAVE);
@@ -1456,8 +1672,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     hipLaunchKernelGGL(ext_memo_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 256)), dim3(256), 0, s, ran, dirty, owned, e->d_nr, e->d_nl, e->d_order, frozen, limit,
                        moff, mR, mL, mvalid, fill, pool, d_cnt + 10, pool_cap, bulk ? 0xFFFFFFFFu : memo_min);
     { TimerRegion tk(ctx, T_EXT_MARK);
-      hipLaunchKernelGGL(ext_mark_kernel, dim3(std::min<uint32_t>(g2n, 4096u)), dim3(256), 0, s, claim, snap, 2 * n, (const Adj4*)e->d_adjR, (const Adj4*)e->d_adjL,
-                         seed_rank, dirty, ran, owned, d_cnt + 6, frozen, limit, fill, moff, mR, pool, hint, e->d_nr, e->d_nl, e->d_weight, precise_marks, bulk ? (const uint8_t*)nullptr : chunk);
+      hipLaunchKernelGGL(ext_mark_kernel, dim3(std::min<uint32_t>(g2n, 4096u)), dim3(256), 0, s, claim, snap, 2 * n, e->d_rec,
+                         dirty, ran, owned, d_cnt + 6, frozen, limit, fill, moff, mR, pool, e->d_nr, e->d_nl, precise_marks, bulk ? (const uint8_t*)nullptr : chunk);
       if (!bulk) TRYE(hipMemsetAsync(chunk, 0, n_chunks, s)); }
     hipLaunchKernelGGL(ext_verify_kernel, dim3((uint32_t)cdiv(limit, 256)), dim3(256), 0, s, ran, owned, e->d_nr, e->d_nl, (uint64_t)limit, dirty);
     if (getenv("SHN_EXT_FAULT") && it + 1 == atoi(getenv("SHN_EXT_FAULT"))) TRYE(hipMemsetAsync(dirty, 0, ns + 1, s));   // (tests: lose every mark of this round)
@@ -1465,7 +1681,9 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     it++;
 
     if (getenv("SHN_DEBUG")) {
-      unsigned long long chg = 0, cur = 0, mx[2] = {0, 0};
+      unsigned long long chg = 0, cur = 0, mx[2] = {0, 0}, st_tr[2] = {0, 0};
+      TRYE(hipMemcpyAsync(&st_tr[0], d_cnt + 1, 8, hipMemcpyDeviceToHost, s));
+      TRYE(hipMemcpyAsync(&st_tr[1], d_cnt + 15, 8, hipMemcpyDeviceToHost, s));
       TRYE(hipMemcpyAsync(&chg, d_cnt + 6, 8, hipMemcpyDeviceToHost, s));
       TRYE(hipMemcpyAsync(&cur, d_cnt + 10, 8, hipMemcpyDeviceToHost, s));
       TRYE(hipMemcpyAsync(mx, d_cnt + 42, 16, hipMemcpyDeviceToHost, s));
@@ -1474,8 +1692,12 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       static double t_prev = 0;
       timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
       double tn = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
-      fprintf(stderr, "[shn_extend] round %d [%u,%u): dirty=%llu long=%llu short=%llu changed_kmers=%llu pool=%.1f%% longest wavefront walk: %llu steps, most sequential: %llu (no hint %llu, owner without memo %llu, memo moved on %llu, followed %llu)  %.2f ms\n", it, frozen, limit,
-              plan[3], plan[0], plan[2], chg, 100.0 * (double)cur / (double)pool_cap, mx[1], mx[0] >> 48, (mx[0] >> 36) & 4095, (mx[0] >> 24) & 4095, (mx[0] >> 12) & 4095, mx[0] & 4095, it == 1 ? 0.0 : tn - t_prev);
+      static unsigned long long st_prev[2] = {0, 0};
+      if (it == 1) { st_prev[0] = st_prev[1] = 0; }
+      fprintf(stderr, "[shn_extend] round %d [%u,%u): dirty=%llu long=%llu short=%llu changed_kmers=%llu pool=%.1f%% longest wavefront walk: %llu steps, most sequential: %llu (no hint %llu, owner without memo %llu, memo moved on %llu, followed %llu)  thread steps %llu in %llu wavefront trips (lanes busy %.3f)  %.2f ms\n", it, frozen, limit,
+              plan[3], plan[0], plan[2], chg, 100.0 * (double)cur / (double)pool_cap, mx[1], mx[0] >> 48, (mx[0] >> 36) & 4095, (mx[0] >> 24) & 4095, (mx[0] >> 12) & 4095, mx[0] & 4095,
+              st_tr[0] - st_prev[0], st_tr[1] - st_prev[1], (double)(st_tr[0] - st_prev[0]) / (64.0 * (double)std::max<unsigned long long>(1, st_tr[1] - st_prev[1])), it == 1 ? 0.0 : tn - t_prev);
+      st_prev[0] = st_tr[0]; st_prev[1] = st_tr[1];
       t_prev = tn;
     }
   }
@@ -1486,7 +1708,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   if (converged && ns && getenv("SHN_EXT_AUDIT")) {
     WalkArgs A;
     memset(&A, 0, sizeof(A));
-    A.order = e->d_order; A.adjR = (const Adj4*)e->d_adjR; A.adjL = (const Adj4*)e->d_adjL; A.weight = e->d_weight;
+    A.order = e->d_order; A.adjR = rows_R(e->d_rec); A.adjL = rows_L(e->d_rec); A.weight = words_weight(e->d_rec);
     A.claim = claim; A.nr_out = e->d_nr; A.nl_out = e->d_nl; A.totw_out = e->d_totw;
     unsigned long long au[2] = {0, ~0ULL};
     TRYE(hipMemcpy(d_cnt + 48, au, 16, hipMemcpyHostToDevice));
@@ -1501,10 +1723,9 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   e->iterations = it;
   if (!converged) { shn_ext_destroy(e); return shn_fail(SHN_ERR_INTERNAL, "shn_extend: walk fixpoint did not converge"); }
   // what is left to do with the result (stats, emit, seed info, weights) reads the claims, the walk records and the table: the
-  // adjacency rows and the snapshot (2/3 of the state) go back to the allocator now
+  // records and the snapshot (most of the state) go back to the allocator now
   TRYE(hipStreamSynchronize(s));
-  shn_dev_free(e->d_adjR); e->d_adjR = nullptr;
-  shn_dev_free(e->d_adjL); e->d_adjL = nullptr;
+  shn_dev_free(e->d_rec); e->d_rec = nullptr;
   shn_dev_free(e->d_claim2); e->d_claim2 = nullptr;
   unsigned long long steps = 0, wsteps = 0, wslots[64];
   TRYE(hipMemcpyAsync(&steps, d_cnt + 1, 8, hipMemcpyDeviceToHost, s));          // thread-kernel steps

@@ -146,6 +146,7 @@ __global__ __launch_bounds__(LBLK) void lp_trials_kernel(const LpProblem* __rest
 
 #define NEWTON_MAX 100
 #define NEWTON_TOL2 1e-20
+#define FLOW_EPS 1e-6
 
 // per-trial words of the centre kernel's own workspace: y, y2, dy, yn [mn each] | S [n*n] | 14 vectors of <= max(m, n) + 1
 __host__ __device__ __forceinline__ uint64_t lp_ws2_words(uint64_t m, uint64_t n) { return 4 * m * n + n * n + 14 * (m + n + 1); }
@@ -185,7 +186,11 @@ __global__ __launch_bounds__(LBLK) void lp_center_kernel(const LpProblem* __rest
   if (N > 64) {
     st_large = 1;
   } else {
-    // ---- classes of the residual digraph
+    // ---- classes of the residual digraph (flows at or below 1e-6 of the largest flow open no arc: rounding residue of the balancing)
+    double xmax = 0.0;
+    for (uint32_t i = 0; i < m; i++)
+      for (uint32_t j = 0; j < n; j++) { const double v = AT(X, CX(i, j)); if (v > xmax) xmax = v; }
+    const double eps = FLOW_EPS * xmax;
     for (uint32_t i = 0; i < m; i++) {
       uint64_t r = 1ULL << i;
       for (uint32_t j = 0; j < n; j++) if (!pm[CX(i, j)]) r |= 1ULL << (m + j);
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(LBLK) void lp_center_kernel(const LpProblem* __rest
     }
     for (uint32_t j = 0; j < n; j++) {
       uint64_t r = 1ULL << (m + j);
-      for (uint32_t i = 0; i < m; i++) if (!pm[CX(i, j)] && AT(X, CX(i, j)) > 0) r |= 1ULL << i;
+      for (uint32_t i = 0; i < m; i++) if (!pm[CX(i, j)] && AT(X, CX(i, j)) > eps) r |= 1ULL << i;
       AT(reach, m + j) = r;
     }
     for (bool changed = true; changed;) {
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(LBLK) void lp_center_kernel(const LpProblem* __rest
       }
       double r2;
       RESIDUAL2(y, nur, nuc, r2);
-      bool last = false;
+      bool done = false;
       uint32_t its = 0;
       for (its = 1; its <= NEWTON_MAX; its++) {
         for (uint32_t k = 0; k < nr; k++) { AT(Dr, k) = 0.0; AT(gr, k) = 0.0; }
@@ -283,11 +288,10 @@ __global__ __launch_bounds__(LBLK) void lp_center_kernel(const LpProblem* __rest
         }
         for (uint32_t k = 0; k < nr; k++) AT(gr, k) = 2.0 * AT(gr, k) - AT(an, k);
         for (uint32_t k = 0; k < nc; k++) AT(gc, k) = 2.0 * AT(gc, k) - AT(bn, k);
-        // Schur complement on the kept columns
+        // Schur complement on the kept columns; its diagonal in the cancellation-free form (see oracle/lp.py)
 #define SS(a_, b_) AT(S, (a_) * q + (b_))
         for (uint32_t k = 0; k < q; k++) {
           for (uint32_t k2 = 0; k2 < q; k2++) SS(k, k2) = 0.0;
-          SS(k, k) = AT(Dc, k);
           AT(h, k) = AT(gc, k);
         }
         for (uint32_t i = 0; i < nr; i++) {
@@ -299,15 +303,21 @@ __global__ __launch_bounds__(LBLK) void lp_center_kernel(const LpProblem* __rest
             if (k1 >= q) continue;
             const double f = AT(y2, ea) * inv;
             AT(h, k1) -= f * gri;
+            double oth = 0.0;
             for (uint32_t eb = e0; eb < e1; eb++) {
+              if (eb == ea) continue;
+              const double v2 = AT(y2, eb);
+              oth += v2;
               const uint32_t k2 = EC(eb);
-              if (k2 >= q) continue;
-              SS(k1, k2) -= f * AT(y2, eb);
+              if (k2 < q) SS(k1, k2) -= f * v2;
             }
+            SS(k1, k1) += f * oth;
           }
         }
+        bool fail = false;
         for (uint32_t k = 0; k < q; k++) {
           const double piv = SS(k, k);
+          if (!(piv > 0.0)) { fail = true; break; }
           for (uint32_t r_ = k + 1; r_ < q; r_++) {
             const double f = SS(r_, k) / piv;
             if (f != 0.0) {
@@ -316,6 +326,7 @@ __global__ __launch_bounds__(LBLK) void lp_center_kernel(const LpProblem* __rest
             }
           }
         }
+        if (fail) break;
         for (uint32_t k = 0; k < nc; k++) AT(wc, k) = 0.0;
         for (int32_t k = (int32_t)q - 1; k >= 0; k--) {
           double acc = AT(h, k);
@@ -331,12 +342,14 @@ __global__ __launch_bounds__(LBLK) void lp_center_kernel(const LpProblem* __rest
         for (uint32_t e = 0; e < ne; e++) AT(dy, e) = AT(y, e) - AT(y2, e) * (AT(wr, ER(e)) + AT(wc, EC(e)));
         double tt = 1.0;
         const double tmin = 1.0 / 1099511627776.0;           // 2^-40
+        bool ok = false;
         while (tt >= tmin) {
-          bool ok = true;
+          ok = true;
           for (uint32_t e = 0; e < ne; e++) if (!(AT(y, e) + tt * AT(dy, e) > 0.0)) { ok = false; break; }
           if (ok) break;
           tt *= 0.5;
         }
+        if (!ok) break;
         double r2n;
         for (;;) {
           for (uint32_t e = 0; e < ne; e++) AT(yn, e) = AT(y, e) + tt * AT(dy, e);
@@ -344,20 +357,21 @@ __global__ __launch_bounds__(LBLK) void lp_center_kernel(const LpProblem* __rest
           for (uint32_t k = 0; k < nc; k++) AT(ncn, k) = AT(nuc, k) + tt * (AT(wc, k) - AT(nuc, k));
           RESIDUAL2(yn, nrn, ncn, r2n);
           const double f = 1.0 - 0.01 * tt;
-          if (r2n <= f * f * r2 || tt < tmin) break;
+          if (r2n <= f * f * r2) break;
           tt *= 0.5;
+          if (tt < tmin) { fail = true; break; }
         }
+        if (fail) break;
         for (uint32_t e = 0; e < ne; e++) AT(y, e) = AT(yn, e);
         for (uint32_t k = 0; k < nr; k++) AT(nur, k) = AT(nrn, k);
         for (uint32_t k = 0; k < nc; k++) AT(nuc, k) = AT(ncn, k);
         r2 = r2n;
-        if (last) break;
-        if (r2 <= NEWTON_TOL2) last = true;
+        if (r2 <= NEWTON_TOL2) { done = true; break; }
       }
       if (its > NEWTON_MAX) its = NEWTON_MAX;
       st_steps += its;
-      if (!last) st_bad++;
-      for (uint32_t e = 0; e < ne; e++) AT(X, CX(EI(e), EJ(e))) = AT(y, e) * sc;
+      if (!done) st_bad++;                    // (the class keeps its vertex flows)
+      else for (uint32_t e = 0; e < ne; e++) AT(X, CX(EI(e), EJ(e))) = AT(y, e) * sc;
 #undef SS
 #undef RESIDUAL2
 #undef EI

@@ -11,7 +11,7 @@ import csv, sys, re, collections, json
 TIMER_KERNEL = {"count.direct": "count_direct_kernel", "count.hist1": "hist1_kernel", "count.scatter1": "scatter1_kernel", "count.hist2": "hist_keys_kernel<false>",
                 "count.scatter2": "scatter_keys_kernel<false, false>", "count.buckets": "buckets_kernel<false>", "route": "route_kernel",
                 "extend.walk_thread": "ext_walk_kernel", "extend.walk_wave": "ext_walk_long_kernel", "extend.mark": "ext_mark_kernel",
-                "extend.adjacency": "ext_adjacency_half_kernel"}
+                "extend.adjacency": "ext_records_kernel"}
 
 
 def short(name):
