@@ -273,7 +273,7 @@ __global__ void ext_records_kernel(const uint64_t* __restrict__ tkeys, const uin
       }
     }
     q2 = Quad{weight[i], NOHINT_WORD, 0xFFFFFFFFu, 0u};
-    q3 = Quad{~0u, ~0u, 0u, 0u};                       // (first two words: see WalkArgs::xrec)
+    q3 = Quad{0u, 0u, 0u, 0u};
     Quad* dst = (Quad*)(rec + o);
     dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3;
   }
@@ -424,15 +424,11 @@ struct WalkArgs {
   uint32_t* promo_list; unsigned long long* promo_count; uint32_t* res_cur; uint32_t* res_info;   // info = dir << 31 | steps so far
   uint32_t promote_steps;
   uint8_t* chunk;        // per 2^CHUNK_SHIFT oriented k1-mers: "a claim in here was written this round" (the mark pass visits only those)
-  char* xrec;            // EXPERIMENT (SHN_EXT_XCLAIM=1, timing only): the thread walker keeps its claims in the records' spare words
-  int xplain;            // EXPERIMENT (SHN_EXT_XPLAIN=1, timing only): claims written with plain stores instead of atomic min
 };
-#define XCLAIM(A, idx) ((A).xrec ? (u64*)((A).xrec + ((uint64_t)(idx) << 6) + 48) : &(A).claim[idx])
 
 // Claim `node` as step `pos` of walk r: atomic min on rank:pos, fire-and-forget (a returning atomic would put
 // a second memory round trip on every step; lost races are found after the round by ext_verify_kernel).
 __device__ __forceinline__ void claim_node(const WalkArgs& A, uint32_t node, uint32_t r, uint32_t pos) {
-  if (A.xplain) { A.claim[node] = CLAIM(r, pos); return; }
   __hip_atomic_fetch_min(&A.claim[node], CLAIM(r, pos), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (A.chunk) A.chunk[node >> CHUNK_SHIFT] = 1;
 }
@@ -500,9 +496,9 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
     uint64_t tot = 0;
     bool promoted = false;
     // snap: the pre-round snapshot; A.claim: live claims of this round
-    bool isvoid = (!FRESH && RANK(snap[o]) < r) || RANK(__hip_atomic_load(XCLAIM(A, o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < r;
+    bool isvoid = (!FRESH && RANK(snap[o]) < r) || RANK(__hip_atomic_load(&A.claim[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < r;
     if (!isvoid) {
-      if (A.xrec) __hip_atomic_fetch_min(XCLAIM(A, o), CLAIM(r, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else claim_node(A, o, r, 0);
+      claim_node(A, o, r, 0);
       tot = A.weight[o];
       uint32_t pos = 0, pend = NONE32;
       for (int dir = 0; dir < 2; dir++) {
@@ -516,7 +512,7 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
 #pragma unroll
           for (int b = 0; b < 4; b++) {
             uint32_t idx = cand.v[b] < 0 ? o : (uint32_t)cand.v[b];
-            cl[b] = __hip_atomic_load(XCLAIM(A, idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cl[b] = __hip_atomic_load(&A.claim[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             cf[b] = FRESH ? UNCLAIMED64 : snap[idx];
             w[b] = A.weight[idx];
             nxt[b] = adj[idx];
@@ -525,7 +521,7 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
           // return in issue order (one counter for loads, stores and atomics), so a claim issued in front of the loads would put
           // the latency of a memory-side atomic on every step of the walk -- and a bulk round lasts as long as its longest walk
           if (pend != NONE32) {
-            if (A.xrec) __hip_atomic_fetch_min(XCLAIM(A, pend), CLAIM(r, pos), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else claim_node(A, pend, r, pos);
+            claim_node(A, pend, r, pos);
             pend = NONE32;
           }
           int best = -1;
@@ -554,7 +550,7 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
           for (int q = 0; q < 4; q++) cand.v[q] = best == 0 ? nxt[0].v[q] : best == 1 ? nxt[1].v[q] : best == 2 ? nxt[2].v[q] : nxt[3].v[q];   // (word by word: a select between structs goes through memory)
         }
         if (pend != NONE32) {                        // the last step of this direction
-          if (A.xrec) __hip_atomic_fetch_min(XCLAIM(A, pend), CLAIM(r, pos), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else claim_node(A, pend, r, pos);
+          claim_node(A, pend, r, pos);
           pend = NONE32;
         }
         if (dir == 0) nr = steps; else nl = steps;
@@ -1626,8 +1622,6 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     A.promote_steps = bulk ? 0xFFFFFFFFu : promote_steps;
     A.promo_list = promo_list; A.promo_count = d_cnt + 13; A.res_cur = res_cur; A.res_info = res_info;
     A.chunk = bulk ? nullptr : chunk;          // (bulk rounds write nearly everywhere: their mark pass is dense, the walkers do not flag)
-    A.xrec = getenv("SHN_EXT_XCLAIM") ? (char*)e->d_rec : nullptr;
-    A.xplain = getenv("SHN_EXT_XPLAIN") ? 1 : 0;
     A.steps_counter = d_cnt + 1; A.wave_steps_counter = d_cnt + 64; A.dbg = (getenv("SHN_DEBUG") || getenv("SHN_EXT_XTIME")) ? d_cnt + 32 : nullptr;
     // long (wave per walk) and short (thread per walk) kernels are independent: overlap them on two streams
     if (plan[0]) {
@@ -1638,7 +1632,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       TRYE(hipEventRecord(ev_join, aux));
     }
     double x_t0 = 0;
-    if (getenv("SHN_EXT_XCLAIM") || getenv("SHN_EXT_XTIME")) { TRYE(hipStreamSynchronize(s)); timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); x_t0 = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+    if (getenv("SHN_EXT_XTIME")) {   // (development: time of every thread-walker launch)
+       TRYE(hipStreamSynchronize(s)); timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); x_t0 = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
     if (plan[2]) {
       if (refill) TRYE(hipMemsetAsync(d_cnt + 14, 0, 8, s));                 // the list's queue head
       TimerRegion tk(ctx, T_EXT_WALK_THREAD);
@@ -1655,10 +1650,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       TRYE(hipStreamSynchronize(s)); timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
       unsigned long long st = 0, lw = 0; TRYE(hipMemcpy(&st, d_cnt + 1, 8, hipMemcpyDeviceToHost));
       if (A.dbg) { TRYE(hipMemcpy(&lw, d_cnt + 44, 8, hipMemcpyDeviceToHost)); TRYE(hipMemset(d_cnt + 44, 0, 8)); }
-      fprintf(stderr, "[shn_extend] XTIME round %d: thread walker %llu walks, %.2f ms, steps so far %llu; longest walk %llu steps in %.2f ms (%.2f us per step)%s\n", it + 1, plan[2],
-              ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6 - x_t0, st, lw >> 32, (double)(lw & 0xFFFFFFFFULL) * 1e-5, (lw >> 32) ? (double)(lw & 0xFFFFFFFFULL) * 1e-2 / (double)(lw >> 32) : 0.0,
-              A.xrec ? "  (claims in the records: timing experiment, the result is garbage)" : "");
-      if (A.xrec || (A.xplain && it + 1 >= 9)) { shn_ext_destroy(e); return shn_fail(SHN_ERR_INTERNAL, "SHN_EXT_XCLAIM / XPLAIN: timing experiment done"); }
+      fprintf(stderr, "[shn_extend] XTIME round %d: thread walker %llu walks, %.2f ms, steps so far %llu; longest walk %llu steps in %.2f ms (%.2f us per step)\n", it + 1, plan[2],
+              ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6 - x_t0, st, lw >> 32, (double)(lw & 0xFFFFFFFFULL) * 1e-5, (lw >> 32) ? (double)(lw & 0xFFFFFFFFULL) * 1e-2 / (double)(lw >> 32) : 0.0);
     }
     if (plan[2]) {                              // walks the thread kernel handed over (the count stays on the device)
       TimerRegion tk(ctx, T_EXT_WALK_WAVE);
