@@ -213,6 +213,45 @@ def _host_cpus():
     return _lib.host_cpus()
 
 
+def native_front_baseline(k1, r1, r2, n_pairs):
+    """the two stages that dominate the reference's run time -- counting (its Jellyfish) and the greedy extension (its
+    Python loop) -- plus the accept filter / duplicate_check / contig graph, natively on ONE host core over the first n_pairs pairs
+    of the batch: oracle/count_c.c, oracle/ext_c.c (C restatements, pinned in tests/test_oracle_c.py) and the sequential contig
+    stage of the product's native host code (shn_contig_graph: the reference's loop in C++)."""
+    import math
+    from oracle import build_c
+    from shannon_amd import extension_correction as ec
+    codes = np.concatenate([r1[:n_pairs], r2[:n_pairs]])
+    t = time.time()
+    keys, cnts, nw = build_c.count_canonical(codes, k1, True)
+    t_count = time.time() - t
+    t = time.time()
+    seed, nr, nl, tw, bases = build_c.extend(keys, cnts, k1, 3, strings=False)
+    t_ext = time.time() - t
+    # accept filter (extension_correction.py:361) on the arrays, then the candidates' strings for the native contig stage
+    L = k1 + nr.astype(np.int64) + nl.astype(np.int64)
+    nk = (nr.astype(np.int64) + nl.astype(np.int64) + 1)
+    sure = (L >= 75) & (L * np.power(tw.astype(np.float64) / np.maximum(1, nk), 0.25) >= 2 * 75 * math.pow(3, 0.25))
+    A = np.frombuffer(b"ACGT", np.uint8)
+    off = np.concatenate([[0], np.cumsum(nr.astype(np.int64) + nl.astype(np.int64))])
+    cands = []
+    for i in np.nonzero(sure)[0].tolist():
+        s = int(seed[i])
+        a, b, at = int(nr[i]), int(nl[i]), int(off[i])
+        cands.append(A[bases[at + a:at + a + b][::-1]].tobytes().decode() + "".join("ACGT"[(s >> (2 * (k1 - 1 - j))) & 3] for j in range(k1)) +
+                     A[bases[at:at + a]].tobytes().decode())
+    t = time.time()
+    acc = ec.contig_stage(cands, k1)[0] if cands else np.zeros(0, np.int32)
+    t_contig = time.time() - t
+    tot = t_count + t_ext + t_contig
+    return {"value": 2 * n_pairs / tot, "unit": "reads/s", "cores": 1, "kind": "port",
+            "sample": "first %d reads of the batch: count (oracle/count_c.c) %.2f s, greedy extension (oracle/ext_c.c) %.2f s over %d distinct "
+                      "canonical k1-mers -> %d walks, accept filter + duplicate_check + contig graph (shn_contig_graph, host C++) %.2f s -> %d "
+                      "contigs; the graph / sparse-flow / merge stages are not in this figure (graph_stage_native_host_only has one partition)"
+                      % (2 * n_pairs, t_count, t_ext, len(keys), len(seed), t_contig, int((np.asarray(acc) > 0).sum())),
+            "seconds": {"count": t_count, "extension": t_ext, "contig stage": t_contig}}
+
+
 def cpu_baseline(k1, r1, r2, n_pairs):
     """The CPU restatement of the reference over a bounded sample of the same batch, on this box's host cores (a reported
     baseline, not the target).  `value`: the whole path a1-a31 through oracle/pipeline.py -- pure Python like Shannon itself, one
@@ -548,6 +587,20 @@ def main():
         dom = max(kt, key=lambda k: kt[k][0])
         bdom = max((k for k in kt if k in per_read), key=lambda k: kt[k][0])
         r_dom, r_bw = roof(dom), roof(bdom)
+        # every timed kernel against the HBM roof (algorithmic bytes of DESIGN.md section 3 / SURVEY 8d, time from the HIP-event timers)
+        kernel_table = []
+        for name in sorted(kt, key=lambda k: -kt[k][0]):
+            q = roof(name)
+            kernel_table.append({"kernel": q["kernel"], "timer": name, "ms_per_step": kt[name][0] / args.steps, "launches_per_step": q["launches_per_step"],
+                                 "algorithmic_GB_per_step": per_step_bytes[name] / 1e9, "algorithmic_bytes_per_read": per_step_bytes[name] / max(1, n_reads),
+                                 "achieved_GBs": q["achieved"], "frac_of_hbm_peak": q["frac"], "traffic_bytes_per_launch_pmc": q["traffic"]})
+        # the whole path against the HBM roof on the survey's byte model -- 2.5 KB per 100 bp read (1.23 KB of it counting)
+        BYTES_PER_READ_8D = 2500.0
+        e2e_gbs = job_reads * args.steps / dt * BYTES_PER_READ_8D / 1e9
+        roofline_e2e = {"bound": "hbm", "achieved": e2e_gbs, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": e2e_gbs / (HBM_PEAK_GBS * world),
+                        "algorithmic_bytes_per_read": BYTES_PER_READ_8D,
+                        "note": "reads/s x 2.5 KB per read (SURVEY 8d byte model) / (n_gpus x 8 TB/s); the path is not HBM-bound end to end at this "
+                                "byte model -- the per-kernel fractions are in kernel_table"}
         if dom.startswith("extend."):
             r_dom["note"] = ("greedy walk fixpoint: dependent pointer chasing, one memory round trip per step -- latency-bound, not "
                              "bandwidth-bound; the dominant streaming kernel is in roofline_bandwidth_kernel")
@@ -599,6 +652,8 @@ def main():
                        "windows_per_step": total, "distinct_k1mers": distinct},
             "roofline": r_dom,
             "roofline_bandwidth_kernel": r_bw,
+            "roofline_e2e": roofline_e2e,
+            "kernel_table": kernel_table,
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(timers.items())},
             "kernel_launches_per_step": {k: v[1] / args.steps for k, v in sorted(timers.items())},
         }
@@ -615,6 +670,7 @@ def main():
             # bounded sample: ~10-15 s of one core through the whole path (at configs[2] a read costs the pure-Python path ~5x more
             # than at configs[1]: nearly every k1-mer of a 25k-read sample is new), + ~5 s for the counting stage alone / threaded
             out["cpu_baseline"] = cpu_baseline(k1, r1, r2, 75_000 if args.config == "1" else 12_500)
+            out["cpu_baseline"]["native_front_one_core"] = native_front_baseline(k1, r1, r2, min(len(r1), 500_000))
             if not use_dist:
                 out["cpu_baseline"]["graph_stage_native_host_only"] = native_graph_baseline(last.R, store, args.K)
         final_line = json.dumps(out)

@@ -53,23 +53,11 @@ class ExtensionResult(object):
     pass
 
 
-def run_correction(items, min_weight=3, min_length=75, comp_size_threshold=500, r=15, f=0.5):
-    """extension_correction.py:309-524.  Returns an ExtensionResult with
-      contigs            accepted contigs in acceptance order (== k1mer.dict_contig lines)
-      allowed            {k1mer: int weight}                      (:404-408)
-      connections        {idx: {idx2: w}} 1-based contig indices  (:372-389)
-      components         {root: [idx...]} DFS order               (:417-434)
-      single_contigs     [contig]  -> reconstructed_single_contigs.fasta (>Single_i) (:467-473)
-      big_components     [(contig list, metis_text)] -> component{n}.txt / component{n}contigs.txt
-      remaining          [[contig...], ...] -> remaining_contigs{r}.txt (possibly a trailing [])
-    """
-    kmers, k1 = load_kmers(items)
+def python_walks(kmers, k1, min_weight):
+    """extension_correction.py:334-354: the seed loop.  Yields (contig, total weight, number of k1-mers) per seed that is not
+    traversed yet, heaviest first."""
     heaviest = sorted(kmers.items(), key=lambda kv: kv[1])          # :334 (stable)
-    traversed, allowed = set(), set()
-    rmer_to_contig, cmer_to_contig = {}, {}
-    contig_connections = {}
-    contigs = ["buffer"]
-    contig_index = 0
+    traversed = set()
     while heaviest:
         start, w = heaviest.pop()                                   # :344
         if w < min_weight:
@@ -79,10 +67,29 @@ def run_correction(items, min_weight=3, min_length=75, comp_size_threshold=500, 
         traversed.add(start)
         rext, rw, rn = _extend(start, True, traversed, kmers, k1)
         lext, lw, ln = _extend(start, False, traversed, kmers, k1)
-        tot_wt = rw + lw + kmers[start]
-        tot_kmer = rn + ln + 1
+        yield "".join(reversed(lext)) + start + "".join(rext), rw + lw + kmers[start], rn + ln + 1
+
+
+def run_correction(items, min_weight=3, min_length=75, comp_size_threshold=500, r=15, f=0.5, walks=None):
+    """extension_correction.py:309-524.  walks: the seed loop's products from elsewhere (the C restatement oracle/ext_c.c through
+    build_c.extend: the same walks, found in seconds where the Python loop takes minutes) instead of python_walks.
+    Returns an ExtensionResult with
+      contigs            accepted contigs in acceptance order (== k1mer.dict_contig lines)
+      allowed            {k1mer: int weight}                      (:404-408)
+      connections        {idx: {idx2: w}} 1-based contig indices  (:372-389)
+      components         {root: [idx...]} DFS order               (:417-434)
+      single_contigs     [contig]  -> reconstructed_single_contigs.fasta (>Single_i) (:467-473)
+      big_components     [(contig list, metis_text)] -> component{n}.txt / component{n}contigs.txt
+      remaining          [[contig...], ...] -> remaining_contigs{r}.txt (possibly a trailing [])
+    """
+    kmers, k1 = load_kmers(items)
+    allowed = set()
+    rmer_to_contig, cmer_to_contig = {}, {}
+    contig_connections = {}
+    contigs = ["buffer"]
+    contig_index = 0
+    for contig, tot_wt, tot_kmer in (walks if walks is not None else python_walks(kmers, k1, min_weight)):
         avg_wt = tot_wt / max(1, tot_kmer)
-        contig = "".join(reversed(lext)) + start + "".join(rext)
         # duplicate_check, :247-270
         dup_count = {}
         max_till_now, max_idx = 0, -1

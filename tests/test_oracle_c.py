@@ -1,0 +1,61 @@
+"""The C restatements of the oracle (oracle/count_c.c, oracle/ext_c.c: counting and the greedy extension, the two stages that
+dominate the reference's run time) against the Python restatement and the reference's own artefacts (tests/golden): the same k1-mer
+table, the same walks in the same order, the same accepted contigs.  They are what lets the oracle check the HIP path at sizes the
+pure-Python loops cannot reach (tests/test_midsize_gpu.py) and what bench.py times as the native CPU baseline."""
+import numpy as np
+import pytest
+from golden_util import *
+from oracle import seqs, count, extension, build_c
+
+CASES = sorted(MANIFEST)
+
+
+def canonical_table(tab, k1):
+    """{k1-mer string: count} of the strand-doubled input -> (canonical keys ascending, counts): what oracle_count_canonical returns"""
+    keys, cnts = [], []
+    for s, c in tab.items():
+        k = count.str_to_key(s)
+        r = count.rc_key(k, k1)
+        if k < r:
+            keys.append(k); cnts.append(c)
+        elif k == r:
+            keys.append(k); cnts.append(c // 2)          # a palindrome is counted on both strands of the doubled input
+    o = np.argsort(np.array(keys, dtype=np.uint64))
+    return np.array(keys, dtype=np.uint64)[o], np.array(cnts, dtype=np.uint32)[o]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_c_extension_equals_the_python_oracle_and_the_reference(name):
+    g = load_case(name)
+    K, paired = g["K"], g["paired"]
+    inp = load_inputs(name)
+    dbl = list(seqs.double_strand_paired(*inp)) if paired else [seqs.double_strand_single(inp[0])]
+    tab = count.count_k1mers_dict([r for f in dbl for r in f], K + 1)
+    items = [(k, tab[k]) for k in sorted(tab, reverse=True)]
+    kmers, k1 = extension.load_kmers(items)
+    want = list(extension.python_walks(kmers, k1, 3))
+    keys, cnts = canonical_table(tab, K + 1)
+    got = build_c.extend(keys, cnts, K + 1, 3)
+    assert len(got) == len(want)
+    assert got == [(c, int(w), n) for c, w, n in want]           # the same walks, in the same (seed) order
+    psize = MANIFEST[name].get("partition_size", 500)
+    res = extension.run_correction(items, comp_size_threshold=psize, walks=got)
+    assert res.contigs == g["contigs"]                           # ... and the reference's accepted contigs
+
+
+def test_c_counter_feeds_the_c_extension():
+    """codes -> count_c -> ext_c on a synthetic paired input == the Python oracle on the same reads"""
+    from shannon_amd import synth
+    (r1, r2), _ = synth.make_dataset(3000, 3, seed=17)
+    codes = np.concatenate([r1, r2])
+    keys, cnts, nw = build_c.count_canonical(codes, 26, True)
+    A = np.frombuffer(b"ACGT", np.uint8)
+    s1 = [A[r].tobytes().decode() for r in r1]
+    s2 = [A[r].tobytes().decode() for r in r2]
+    dbl = list(seqs.double_strand_paired(s1, s2))
+    tab = count.count_k1mers_dict([r for f in dbl for r in f], 26)
+    k2, c2 = canonical_table(tab, 26)
+    assert np.array_equal(keys, k2) and np.array_equal(cnts, c2)
+    kmers, k1 = extension.load_kmers([(k, tab[k]) for k in sorted(tab, reverse=True)])
+    want = [(c, int(w), n) for c, w, n in extension.python_walks(kmers, k1, 3)]
+    assert build_c.extend(keys, cnts, 26, 3) == want
