@@ -82,6 +82,12 @@ uint64_t shn_reads_n_invalid(const shn_reads* r);
 int shn_string_windows(const uint8_t* text, const uint64_t* off, uint64_t n_strings, int k, uint64_t* keys_out, uint8_t* rows_out);
 
 int shn_gather_rows(const uint8_t* src, uint64_t n_src_rows, uint64_t row_bytes, const int64_t* idx, uint64_t n, uint8_t* dst, int threads);
+/* Host utility: segment i of dst (dst_off[i] .. dst_off[i+1]) = segment order[i] of src (src_off has n_src + 1 entries), on
+ * `threads` host threads.  Merges the candidate contigs of the ranks' shards into the global seed order (weight descending,
+ * seed k1-mer ascending: the order of the loop of extension_correction.py:334-354).  SHN_ERR_ARG on an index out of range or
+ * on segments of different lengths.                                                                                          */
+int shn_gather_segments(const uint8_t* src, const uint64_t* src_off, uint64_t n_src, const int64_t* order, uint64_t n, uint8_t* dst,
+                        const uint64_t* dst_off, int threads);
 
 /* ---- (K+1)-mer counting ----------------------------------------------------------------------
  * Replaces `jellyfish count -m k1 ... ; jellyfish dump -c -t -L lower` (shannon.py:439-441;

@@ -28,6 +28,7 @@ SIGNATURES = {
     "shn_reads_n_invalid": (C.c_uint64, [vp]),
     "shn_string_windows": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp, vp]),
     "shn_gather_rows": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp, C.c_int]),
+    "shn_gather_segments": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, C.c_int]),
     "shn_count_k1mers": (C.c_int, [vp, vpp, C.c_int, C.c_int, C.c_int, vpp]),
     "shn_table_destroy": (None, [vp]),
     "shn_table_size": (C.c_uint64, [vp]),
@@ -158,6 +159,23 @@ def gather_rows(src, idx, out=None, threads=8):
     if len(idx) and rb:
         check(lib().shn_gather_rows(src.ctypes.data, src.shape[0], rb, idx.ctypes.data, len(idx), out.ctypes.data, int(threads)))
     return out
+
+
+def gather_segments(src, src_off, order, threads=8):
+    """(dst, dst_off): segment i of dst = segment order[i] of src (byte segments given by offsets), on host threads
+    (shn_gather_segments)."""
+    import numpy as np
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    src_off = np.ascontiguousarray(src_off, dtype=np.uint64)
+    order = np.ascontiguousarray(order, dtype=np.int64)
+    lens = (src_off[1:] - src_off[:-1])[order] if len(order) else np.zeros(0, np.uint64)
+    dst_off = np.zeros(len(order) + 1, dtype=np.uint64)
+    dst_off[1:] = np.cumsum(lens, dtype=np.uint64)
+    dst = np.empty(int(dst_off[-1]), dtype=np.uint8)
+    if len(order):
+        check(lib().shn_gather_segments(src.ctypes.data, src_off.ctypes.data, len(src_off) - 1, order.ctypes.data, len(order), dst.ctypes.data,
+                                        dst_off.ctypes.data, int(threads)))
+    return dst, dst_off
 
 
 def string_windows(strings, k, want_keys=True, want_rows=False):

@@ -515,6 +515,26 @@ extern "C" int shn_gather_rows(const uint8_t* src, uint64_t n_src_rows, uint64_t
   return SHN_OK;
 }
 
+// ---- host utility: segment i of dst = segment order[i] of src (segments given by offset arrays), split over host threads.  The
+// candidate contigs of all ranks are merged into the global seed order this way (300 MB at BASELINE configs[2]).
+extern "C" int shn_gather_segments(const uint8_t* src, const uint64_t* src_off, uint64_t n_src, const int64_t* order, uint64_t n, uint8_t* dst,
+                                   const uint64_t* dst_off, int threads) {
+  if (n && (!src || !src_off || !order || !dst || !dst_off)) return shn_fail(SHN_ERR_ARG, "shn_gather_segments: NULL argument");
+  for (uint64_t i = 0; i < n; i++) {
+    if (order[i] < 0 || (uint64_t)order[i] >= n_src) return shn_fail(SHN_ERR_ARG, "shn_gather_segments: segment index out of range");
+    if (dst_off[i + 1] - dst_off[i] != src_off[order[i] + 1] - src_off[order[i]]) return shn_fail(SHN_ERR_ARG, "shn_gather_segments: segment lengths differ");
+  }
+  const uint64_t total = n ? dst_off[n] - dst_off[0] : 0;
+  int T = (int)std::min<uint64_t>((uint64_t)std::max(1, threads), total / (1ULL << 20) + 1);
+  auto work = [&](uint64_t a, uint64_t b) {
+    for (uint64_t i = a; i < b; i++) memcpy(dst + dst_off[i], src + src_off[order[i]], dst_off[i + 1] - dst_off[i]);
+  };
+  if (T <= 1) { work(0, n); return SHN_OK; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; t++) th.emplace_back(work, n * t / T, n * (t + 1) / T);
+  for (auto& x : th) x.join();
+  return SHN_OK;
+}
 
 // ---- host utility: every k-window of every string (ASCII ACGT, strings given by offsets into one text), in order: as
 // packed 2-bit keys (keys_out, k <= 32) and/or as fixed-width byte rows (rows_out, k bytes per window).  The partition

@@ -399,7 +399,8 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
   hipStream_t s = ctx->stream;
   const bool center = ctx->lp_rule != SHN_LP_RULE_VERTEX;
   std::vector<LpProblem> probs(n_problems);
-  std::vector<uint32_t> bprob, bfirst;
+  std::vector<uint32_t> bprob, bfirst, cprob, cfirst;       // blocks of the vertex kernel / of the centre kernel
+  uint64_t n_large_trials = 0;
   uint64_t in_off = 0, mask_off = 0, ws_off = 0, out_off = 0, ws2_off = 0, stat_off = 0;
   for (uint32_t p = 0; p < n_problems; p++) {
     if (m[p] == 0 || n[p] == 0 || trials[p] == 0) return shn_fail(SHN_ERR_ARG, "shn_lp_solve_batch: empty problem");
@@ -411,22 +412,44 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
     in_off += m[p] + n[p];
     mask_off += mn;
     ws_off += (2 * mn + 3ULL * (m[p] + n[p])) * trials[p];
-    if (center && m[p] + n[p] <= 64) ws2_off += lp_ws2_words(m[p], n[p]) * trials[p];
     stat_off += trials[p];
     out_off += mn * trials[p];
     for (uint32_t f = 0; f < trials[p]; f += LBLK) { bprob.push_back(p); bfirst.push_back(f); }
+    // the centre kernel has work only where the supported cells of the problem hold a cycle (rows and columns as vertices, a
+    // supported cell as an edge): on a forest every class is a tree and its face a point.  At BASELINE configs[2] 9,000
+    // problems per step, a handful with a cycle.
+    if (center && m[p] + n[p] <= 64) {
+      int par[64];
+      for (uint32_t v = 0; v < m[p] + n[p]; v++) par[v] = (int)v;
+      auto find = [&](int v) { while (par[v] != v) { par[v] = par[par[v]]; v = par[v]; } return v; };
+      bool cyc = false;
+      const uint8_t* pm = mask + P.mask_off;
+      for (uint32_t j = 0; j < n[p] && !cyc; j++)
+        for (uint32_t i = 0; i < m[p]; i++) {
+          if (pm[(uint64_t)j * m[p] + i]) continue;
+          const int a = find((int)i), b = find((int)(m[p] + j));
+          if (a == b) { cyc = true; break; }
+          par[a] = b;
+        }
+      if (cyc) {
+        ws2_off += lp_ws2_words(m[p], n[p]) * trials[p];            // (P.ws2_off was taken before: this problem's share follows)
+        for (uint32_t f = 0; f < trials[p]; f += LBLK) { cprob.push_back(p); cfirst.push_back(f); }
+      }
+    } else if (center) n_large_trials += trials[p];
   }
   TimerRegion treg(ctx, T_LP);
   // per-context workspaces: two batches may be in flight on two contexts (the deferred back half of a step beside the next
   // step's front half), and shn_ws_release_idle never touches a context's own slots
   void *pp, *pb, *pin, *pm, *pws, *pout, *pws2, *pst;
   int rc;
-  if ((rc = ctx->cws[4].get(probs.size() * sizeof(LpProblem), &pp)) || (rc = ctx->cws[5].get(bprob.size() * 8 + 16, &pb)) ||
+  if ((rc = ctx->cws[4].get(probs.size() * sizeof(LpProblem), &pp)) || (rc = ctx->cws[5].get((bprob.size() + cprob.size()) * 8 + 16, &pb)) ||
       (rc = ctx->cws[6].get(in_off * 8 + 16, &pin)) || (rc = ctx->cws[7].get(mask_off + 16, &pm)) ||
       (rc = ctx->cws[8].get(ws_off * 8 + 16, &pws)) || (rc = ctx->cws[9].get(out_off * 8 + 16, &pout)) ||
       (rc = ctx->cws[10].get(ws2_off * 8 + 16, &pws2)) || (rc = ctx->cws[11].get(stat_off * 16 + 16, &pst))) return rc;
   uint32_t* d_bprob = (uint32_t*)pb;
   uint32_t* d_bfirst = d_bprob + bprob.size();
+  uint32_t* d_cprob = d_bfirst + bprob.size();
+  uint32_t* d_cfirst = d_cprob + cprob.size();
   HIP_TRY(hipMemcpyAsync(pp, probs.data(), probs.size() * sizeof(LpProblem), hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_bprob, bprob.data(), bprob.size() * 4, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_bfirst, bfirst.data(), bfirst.size() * 4, hipMemcpyHostToDevice, s));
@@ -435,8 +458,11 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
   hipLaunchKernelGGL(lp_trials_kernel, dim3((uint32_t)bprob.size()), dim3(LBLK), 0, s, (const LpProblem*)pp, d_bprob, d_bfirst,
                      (const double*)pin, (const uint8_t*)pm, seed, (uint64_t*)pws, (double*)pout);
   std::vector<uint32_t> stat;
-  if (center) {
-    hipLaunchKernelGGL(lp_center_kernel, dim3((uint32_t)bprob.size()), dim3(LBLK), 0, s, (const LpProblem*)pp, d_bprob, d_bfirst,
+  if (center && !cprob.empty()) {
+    HIP_TRY(hipMemcpyAsync(d_cprob, cprob.data(), cprob.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_cfirst, cfirst.data(), cfirst.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(pst, 0, stat_off * 16, s));                     // (trials the centre kernel does not visit: nothing centred)
+    hipLaunchKernelGGL(lp_center_kernel, dim3((uint32_t)cprob.size()), dim3(LBLK), 0, s, (const LpProblem*)pp, d_cprob, d_cfirst,
                        (const uint8_t*)pm, (uint64_t*)pws, (uint64_t*)pws2, (double*)pout, (uint32_t*)pst);
     stat.resize(4 * stat_off);
     HIP_TRY(hipMemcpyAsync(stat.data(), pst, stat.size() * 4, hipMemcpyDeviceToHost, s));
@@ -447,7 +473,8 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
   // census (bench.py: lp_calls / lp_degenerate): a problem is degenerate when the optimal face of one of its trials was not a point
   ctx->lp_stats[0] += n_problems;
   ctx->lp_stats[2] += stat_off;
-  if (center) {
+  ctx->lp_stats[6] += n_large_trials;
+  if (!stat.empty()) {
     uint64_t t0 = 0;
     for (uint32_t p = 0; p < n_problems; p++) {
       bool deg = false;
@@ -456,7 +483,6 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
         if (sp[0]) { deg = true; ctx->lp_stats[3]++; }
         ctx->lp_stats[4] += sp[1];
         ctx->lp_stats[5] += sp[2];
-        ctx->lp_stats[6] += sp[3];
       }
       if (deg) ctx->lp_stats[1]++;
       t0 += trials[p];

@@ -521,12 +521,20 @@ struct Graph {
   void refresh_bridging_reads(int n) {
     const std::string& nb = bases[n];
     int lb = (int)nb.size();
-    std::set<RI> rs;
+    // (the reference collects them in a set and the pinned order P1 walks it sorted: a sorted vector without repeats is the same
+    // sequence -- the lists of a highly expressed X-node hold 10^5 reads, and a tree insert per read was most of bridge_all)
+    std::vector<RI> rs;
+    rs.reserve(nreads[n].size());
     for (const RI& x : nreads[n]) {
       int r = x.first, i = x.second;
-      if (i > 0 && (int)rstr(r).size() > i + lb && rstr(r).compare(i, lb, nb) == 0) rs.insert(x);
+      if (i <= 0) continue;
+      const RStr rb = rstr(r);
+      if ((int)rb.size() > i + lb && rb.compare(i, lb, nb) == 0) rs.push_back(x);
     }
+    if (!std::is_sorted(rs.begin(), rs.end())) std::sort(rs.begin(), rs.end());
+    rs.erase(std::unique(rs.begin(), rs.end()), rs.end());
     std::vector<RI> real;
+    real.reserve(rs.size());
     for (const RI& x : rs) {
       const RStr rb = rstr(x.first);
       int i = x.second;
@@ -540,9 +548,15 @@ struct Graph {
   bool is_bridged_xnode(int n) {
     refresh_bridging_reads(n);
     int lb = (int)bases[n].size();
-    std::set<char> inb, outb;
-    for (const RI& x : nreads[n]) { inb.insert(rstr(x.first)[x.second - 1]); outb.insert(rstr(x.first)[x.second + lb]); }
-    int bi = (int)ine[n].size() - (int)inb.size(), bo = (int)oute[n].size() - (int)outb.size();
+    bool inb[256] = {false}, outb[256] = {false};                  // (the distinct characters before / behind the node in its reads)
+    int n_in = 0, n_out = 0;
+    for (const RI& x : nreads[n]) {
+      const RStr rb = rstr(x.first);
+      const unsigned char a = (unsigned char)rb[x.second - 1], b = (unsigned char)rb[x.second + lb];
+      if (!inb[a]) { inb[a] = true; n_in++; }
+      if (!outb[b]) { outb[b] = true; n_out++; }
+    }
+    int bi = (int)ine[n].size() - n_in, bo = (int)oute[n].size() - n_out;
     return (bi == 0 && bo == 0) || (bi == 1 && bo == 1);
   }
   int bridging_step(int node) {
@@ -586,12 +600,11 @@ struct Graph {
     for (const RI& y : rl) {
       const RStr rb = rstr(y.first);
       int i = y.second;
-      std::string bu = rb.substr(i - 1, lb + 1), bw = rb.substr(i, lb + 1);
-      std::vector<int> mu, mw;
-      for (int u : u_list) if (bases[u] == bu) mu.push_back(u);
-      for (int x : w_list) if (bases[x] == bw) mw.push_back(x);
-      if (mu.size() != 1 || mw.size() != 1) continue;
-      int u = mu[0], x = mw[0];
+      // exactly one u-node spelling the read from i - 1 and one w-node spelling it from i (all of them are lb + 1 bases long)
+      int u = -1, x = -1, nu = 0, nw = 0;
+      for (int uu : u_list) if (rb.size() >= (size_t)(i + lb) && (int)bases[uu].size() == lb + 1 && memcmp(rb.p + i - 1, bases[uu].data(), (size_t)lb + 1) == 0) { u = uu; nu++; }
+      for (int xx : w_list) if (rb.size() >= (size_t)(i + lb + 1) && (int)bases[xx].size() == lb + 1 && memcmp(rb.p + i, bases[xx].data(), (size_t)lb + 1) == 0) { x = xx; nw++; }
+      if (nu != 1 || nw != 1) continue;
       nreads[u].push_back(RI(y.first, i - 1));
       nreads[x].push_back(RI(y.first, i));
       bool prec = false;

@@ -357,16 +357,9 @@ class GpuOps(object):
                 return int(t.item())
 
         Gather.rank = rank
-        import os
-        _cg = os.environ.get("SHN_CONTIG_GPU", "")
-        if W > 1 and (_cg == "1" or (_cg != "0" and len(table) >= 100_000_000)):
-            # a large, diverse table (BASELINE configs[2] and beyond: 10^8+ k1-mers, 10^5+ candidate contigs): the contig stage of
-            # the shards is the sequential host code, the replicated one runs on the GPU (contig_stage_gpu) in a tenth of the
-            # time -- every rank extends the whole table.  (A few deep gene families per rank -- the weak-scaling workload, 5 M
-            # k1-mers per family -- stay sharded: their walks, not their contig stage, are the cost.)
-            res = ec.run_correction(self.ctx, table, 3, 75, partition_size, want_allowed=False, timings=getattr(self, "timings", None))
-            table.close()
-            return res
+        # (a large, diverse table -- BASELINE configs[2] and beyond: 10^8+ k1-mers, 10^5+ candidate contigs -- takes the path
+        # "sharded walks + one replicated GPU contig stage" inside run_correction; a few deep gene families per rank -- the
+        # weak-scaling workload, 5 M k1-mers per family -- keep their contig stages sharded too: SHN_CONTIG_GPU=1 / 0 forces either)
         res = ec.run_correction(self.ctx, table, 3, 75, partition_size, want_allowed=False, shard=(W, rank), gather=Gather,
                                 timings=getattr(self, "timings", None))
         table.close()

@@ -429,8 +429,13 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     # Large tables (BASELINE configs[2]: 20,000 genes, several 10^5 candidate contigs): the contig stage runs after the walks with
     # its sorts on the GPU (contig_stage_gpu) instead of beside them on one host thread.  SHN_CONTIG_GPU=1 / 0 forces / forbids it.
     _cg = os.environ.get("SHN_CONTIG_GPU", "")
-    gpu_contigs = merge is None and (gather is None or gather.world <= 1) and (_cg == "1" or (_cg != "0" and len(table) >= 20_000_000))
-    if merge is None and not gpu_contigs and os.environ.get("SHN_EXT_PIPELINE", "1") != "0":
+    big = _cg == "1" or (_cg != "0" and len(table) >= 20_000_000)
+    gpu_contigs = merge is None and (gather is None or gather.world <= 1) and big
+    # ... and on several ranks: the walks sharded by connected component, the candidates of all shards gathered (0.3 GB at BASELINE
+    # configs[2]) and merged into the global seed order on every rank, ONE replicated GPU contig stage over them -- instead of every
+    # rank walking the whole table (the shards' own contig stage is the sequential host loop: 25 s at that size)
+    gpu_sharded = merge is None and gather is not None and gather.world > 1 and big
+    if merge is None and not gpu_contigs and not gpu_sharded and os.environ.get("SHN_EXT_PIPELINE", "1") != "0":
         import threading, queue
 
         class _Pipe(object):
@@ -511,7 +516,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     else:
         # non-void walks long enough for the accept filter's length clause, in seed order (compacted on the GPU)
         live, nr, nl, tw = ext.live_stats(min_length - k1)
-        if gpu_contigs:
+        if gpu_contigs or gpu_sharded:
             keep_r, keep_l = accept_filter(live, nr, nl, tw, k1, min_length, min_weight, arrays=True)
             keep = None
         else:
@@ -521,9 +526,26 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     contigs = ["buffer"]
     conn = None
     sharded_contigs = False
-    if gpu_contigs:
+    if gpu_contigs or gpu_sharded:
         buf, offs = ext.emit_raw(keep_r, keep_l, reuse=True) if len(keep_r) else (np.zeros(0, np.uint8), np.zeros(1, np.uint64))
         lap("ext.emit")
+        if gpu_sharded:
+            # every rank's candidates -> the same merged list everywhere, in the order of the reference's seed loop
+            # (weight descending, seed k1-mer ascending; a seed lies in exactly one shard, so the keys are distinct)
+            skey, sw = ext.seed_info(keep_r)
+            parts = gather.all_gather((np.asarray(sw, dtype=np.int64), np.asarray(skey, dtype=np.uint64), np.asarray(offs, dtype=np.uint64),
+                                       np.ascontiguousarray(buf[:int(offs[-1])])))
+            lap("ext.gathers")
+            w_all = np.concatenate([p[0] for p in parts])
+            k_all = np.concatenate([p[1] for p in parts])
+            base, segs = 0, []
+            for p in parts:
+                segs.append(p[2][:-1].astype(np.uint64) + np.uint64(base))
+                base += int(p[2][-1])
+            src_off = np.concatenate(segs + [np.array([base], dtype=np.uint64)])
+            order = np.lexsort((k_all, -w_all))
+            buf, offs = _lib.gather_segments(np.concatenate([p[3] for p in parts]), src_off, order, threads=_lib.host_cpus())
+            lap("ext.merge")
         acc, _best, coff, cnb, cw = contig_stage_gpu(ctx, buf, offs, k1, r, f)
         csr = (coff, cnb, cw)
         raw = memoryview(np.ascontiguousarray(buf))        # (only the accepted tenth is ever turned into strings, slice by slice)
@@ -533,7 +555,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
         strings = None
     else:
         strings = (ext.emit([x[0] for x in keep], [x[1] for x in keep]) if keep else []) if pipe is None else None
-    if gpu_contigs:
+    if gpu_contigs or gpu_sharded:
         pass
     elif gather is not None and gather.world > 1:
         if pipe is not None:                           # the shard's contig stage ran beside its walks
@@ -587,7 +609,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
         lap("ext.emit")
 
     # duplicate_check + contig graph, sequential over candidates in seed order (:358-397)
-    if gpu_contigs:
+    if gpu_contigs or gpu_sharded:
         pass
     elif pipe is not None:                             # already done, beside the walks
         csr = pipe.cg.connections()

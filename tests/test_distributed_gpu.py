@@ -48,18 +48,23 @@ def test_distributed_path_matches_single_process(group, paired, n_genes, seed):
         ctx.close()
 
 
-@pytest.mark.parametrize("world,paired,n_genes,seed,port", [(2, True, 3, 11, 29621), (3, True, 12, 4, 29622), (2, False, 2, 5, 29623),
-                                                            (4, True, 40, 8, 29624)])
-def test_ranks_sharing_one_gpu_equal_single_process(world, paired, n_genes, seed, port, tmp_path):
+@pytest.mark.parametrize("world,paired,n_genes,seed,port,big", [(2, True, 3, 11, 29621, False), (3, True, 12, 4, 29622, False), (2, False, 2, 5, 29623, False),
+                                                                (4, True, 40, 8, 29624, False), (2, True, 40, 8, 29625, True), (3, True, 12, 4, 29626, True),
+                                                                (4, False, 30, 6, 29627, True)])
+def test_ranks_sharing_one_gpu_equal_single_process(world, paired, n_genes, seed, port, big, tmp_path):
     """world_size > 1 with the product's per-rank compute (GpuOps): every rank holds a slice of the reads and runs its HIP
     kernels on cuda:0; the collectives go through gloo (RCCL does not take two ranks on one device).  Covers the sharded
-    walks + sharded contig stages, the capped read exchange and partition ownership against the single-process result."""
+    walks + sharded contig stages, the capped read exchange and partition ownership against the single-process result.
+    big: the path of large tables (BASELINE configs[3]: >= 20 M k1-mers) forced with SHN_CONTIG_GPU=1 -- walks sharded by
+    component, the candidates of all shards gathered and merged, one replicated GPU contig stage."""
     import json, subprocess, sys
     from conftest import ROOT
     from shannon_amd import device, synth, pipeline, kmers_for_component as kfc
     n_pairs = 12000
     out = str(tmp_path / "res.json")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    if big:
+        env["SHN_CONTIG_GPU"] = "1"
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
                         "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_gpu_worker.py"),
                         "1" if paired else "0", str(n_genes), str(seed), str(n_pairs), out],
