@@ -574,6 +574,12 @@ def main():
         per_step_bytes["extend.mark"] = 16.0 * n_or * (ext["iterations"] or 0)
         per_step_bytes["extend.adjacency"] = (8 * 8.0 + 2 * 64.0 + 8.0) * distinct       # per k1-mer: 8 keys looked up, its two 64-byte records written, its own key
         kt = {k: v for k, v in timers.items() if k in KERNEL}
+        # the key array goes through one or two levels below level 1 (csrc/count.hip: at most 256 streams per level): the bytes of
+        # the hist2 / scatter2 launches of a step are those of as many passes over the keys
+        if "count.buckets" in timers and "count.scatter2" in timers:
+            levels = max(1.0, timers["count.scatter2"][1] / max(1, timers["count.buckets"][1]))
+            per_step_bytes["count.hist2"] *= levels
+            per_step_bytes["count.scatter2"] *= levels
 
         def roof(name):
             ms, launches = kt[name]

@@ -138,31 +138,31 @@ __global__ __launch_bounds__(BLK) void scatter1_kernel(ReadsView v, int k, int b
 }
 
 // ---------------------------------------------------------------- levels from a key array
-// L1=true : one segment, digit = bucket >> b2 (used by the (key,count)-pairs path after the exchange)
-// L1=false: segment p = level-1 partition p, digit = bucket & (nb2-1)
-template <bool L1>
-__device__ __forceinline__ uint32_t digit_of(uint64_t key, int bits, int b2) {
-  uint32_t b = bucket_of(key, bits);
-  return L1 ? (b >> b2) : (b & ((1u << b2) - 1));
+// A level partitions every SEGMENT of the key array (segoff[p] .. segoff[p+1]) by one digit of the keys' bucket id:
+// digit = (bucket >> shift) & (nb - 1).  No level fans out into more than 256 streams: a block then writes runs of >= 1 KB per
+// stream and tile, which the L2 merges into whole lines -- with 2,048-4,096 streams (two levels of 11-12 bits at 2^23 buckets) a
+// run was 16 keys, the lines left the L2 half written and the scatter kernels wrote 3-3.6 times their bytes.
+__device__ __forceinline__ uint32_t digit_at(uint64_t key, int bits, int shift, uint32_t nb) {
+  return (bucket_of(key, bits) >> shift) & (nb - 1);
 }
 
-template <bool L1>
-__global__ __launch_bounds__(BLK) void hist_keys_kernel(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ segoff,
-                                                        int bits, int b2, uint32_t* __restrict__ hist, uint32_t tile_keys) {
+__global__ __launch_bounds__(BLK) void hist_keys_kernel(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ segoff, uint32_t n_seg,
+                                                        int bits, int shift, uint32_t nb, uint32_t* __restrict__ hist, uint32_t tile_keys) {
   extern __shared__ uint32_t lh[];
-  const int nb = L1 ? (1 << (bits - b2)) : (1 << b2);
-  const uint32_t p = blockIdx.y;
-  const uint64_t s0 = segoff[p], s1 = segoff[p + 1];
-  uint64_t t0 = s0 + (uint64_t)blockIdx.x * tile_keys;
-  if (t0 >= s1) return;
-  uint64_t t1 = min(t0 + (uint64_t)tile_keys, s1);
-  for (int i = threadIdx.x; i < nb; i += BLK) lh[i] = 0;
-  __syncthreads();
-  for (uint64_t i = t0 + threadIdx.x; i < t1; i += BLK)
-    atomicAdd(&lh[digit_of<L1>(keys[i], bits, b2)], 1u);
-  __syncthreads();
-  for (int i = threadIdx.x; i < nb; i += BLK)
-    if (lh[i]) atomicAdd(&hist[(uint64_t)p * nb + i], lh[i]);
+  for (uint32_t p = blockIdx.y; p < n_seg; p += gridDim.y) {
+    const uint64_t s0 = segoff[p], s1 = segoff[p + 1];
+    uint64_t t0 = s0 + (uint64_t)blockIdx.x * tile_keys;
+    if (t0 >= s1) continue;                                  // (uniform over the block)
+    uint64_t t1 = min(t0 + (uint64_t)tile_keys, s1);
+    for (uint32_t i = threadIdx.x; i < nb; i += BLK) lh[i] = 0;
+    __syncthreads();
+    for (uint64_t i = t0 + threadIdx.x; i < t1; i += BLK)
+      atomicAdd(&lh[digit_at(keys[i], bits, shift, nb)], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nb; i += BLK)
+      if (lh[i]) atomicAdd(&hist[(uint64_t)p * nb + i], lh[i]);
+    __syncthreads();
+  }
 }
 
 // exclusive scan of each row of hist -> off (relative to the segment start) and cursor copy
@@ -184,38 +184,48 @@ __global__ __launch_bounds__(BLK) void scan_rows_kernel(const uint32_t* __restri
   }
 }
 
-template <bool L1, bool HASC>
+template <bool HASC>
 __global__ __launch_bounds__(BLK) void scatter_keys_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ cin,
-                                                           const uint64_t* __restrict__ segoff, int bits, int b2,
+                                                           const uint64_t* __restrict__ segoff, uint32_t n_seg, int bits, int shift, uint32_t nb,
                                                            uint32_t* __restrict__ cursor, uint64_t* __restrict__ out,
                                                            uint32_t* __restrict__ cout, uint32_t tile_keys) {
   extern __shared__ uint32_t lds[];
-  const int nb = L1 ? (1 << (bits - b2)) : (1 << b2);
   uint32_t* lh = lds;
   uint32_t* lbase = lds + nb;
-  const uint32_t p = blockIdx.y;
-  const uint64_t s0 = segoff[p], s1 = segoff[p + 1];
-  uint64_t t0 = s0 + (uint64_t)blockIdx.x * tile_keys;
-  if (t0 >= s1) return;
-  uint64_t t1 = min(t0 + (uint64_t)tile_keys, s1);
-  for (int i = threadIdx.x; i < nb; i += BLK) lh[i] = 0;
-  __syncthreads();
-  for (uint64_t i = t0 + threadIdx.x; i < t1; i += BLK)
-    atomicAdd(&lh[digit_of<L1>(keys[i], bits, b2)], 1u);
-  __syncthreads();
-  for (int i = threadIdx.x; i < nb; i += BLK) {
-    uint32_t c = lh[i];
-    if (c) lbase[i] = atomicAdd(&cursor[(uint64_t)p * nb + i], c);
-    lh[i] = 0;
+  for (uint32_t p = blockIdx.y; p < n_seg; p += gridDim.y) {
+    const uint64_t s0 = segoff[p], s1 = segoff[p + 1];
+    uint64_t t0 = s0 + (uint64_t)blockIdx.x * tile_keys;
+    if (t0 >= s1) continue;
+    uint64_t t1 = min(t0 + (uint64_t)tile_keys, s1);
+    for (uint32_t i = threadIdx.x; i < nb; i += BLK) lh[i] = 0;
+    __syncthreads();
+    for (uint64_t i = t0 + threadIdx.x; i < t1; i += BLK)
+      atomicAdd(&lh[digit_at(keys[i], bits, shift, nb)], 1u);
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nb; i += BLK) {
+      uint32_t c = lh[i];
+      if (c) lbase[i] = atomicAdd(&cursor[(uint64_t)p * nb + i], c);
+      lh[i] = 0;
+    }
+    __syncthreads();
+    for (uint64_t i = t0 + threadIdx.x; i < t1; i += BLK) {
+      uint64_t key = keys[i];
+      uint32_t q = digit_at(key, bits, shift, nb);
+      uint32_t rank = atomicAdd(&lh[q], 1u);
+      out[s0 + lbase[q] + rank] = key;
+      if (HASC) cout[s0 + lbase[q] + rank] = cin[i];
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  for (uint64_t i = t0 + threadIdx.x; i < t1; i += BLK) {
-    uint64_t key = keys[i];
-    uint32_t q = digit_of<L1>(key, bits, b2);
-    uint32_t rank = atomicAdd(&lh[q], 1u);
-    out[s0 + lbase[q] + rank] = key;
-    if (HASC) cout[s0 + lbase[q] + rank] = cin[i];
-  }
+}
+
+// absolute start of every segment of the NEXT level: the segments of a level are the (segment, digit) pairs of the one before
+__global__ void next_segments_kernel(const uint64_t* __restrict__ segoff, uint32_t n_seg, const uint32_t* __restrict__ off_rel, uint32_t nb,
+                                     uint64_t* __restrict__ out) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t n = (uint64_t)n_seg * nb;
+  if (q < n) out[q] = segoff[q / nb] + off_rel[q];
+  else if (q == n) out[q] = segoff[n_seg];
 }
 
 // ---------------------------------------------------------------- final buckets
@@ -736,7 +746,11 @@ static int count_views(shn_ctx* ctx, const std::vector<ReadsView>& views, uint64
         if (upper > (1ULL << 20)) bits = std::max(bits, std::min(bits_n, 10));
       }
     }
-    const int b1 = (bits + 1) / 2, b2 = bits - b1;
+    int b1 = (bits + 1) / 2;
+    if (getenv("SHN_COUNT_B1")) b1 = std::max(1, std::min(std::min(bits, (bits_hist + 1) / 2), atoi(getenv("SHN_COUNT_B1"))));      // (experiments; any split gives
+                                                                          // the same table; level 1 is a prefix of the histogram's digit)
+    if (bits - b1 > 15) b1 = bits - 15;
+    const int b2 = bits - b1;
     const int nb1 = 1 << b1;
     // level-1 digits are prefixes of the finer ones: fold the fine histogram
     const int hb1 = (bits_hist + 1) / 2;
@@ -790,7 +804,16 @@ static int build_from_keys(shn_ctx* ctx, uint64_t* keysA, uint64_t* keysB, uint3
   if (max1 >= 0xFFFFFFFFULL) return shn_fail(SHN_ERR_OVERFLOW, "level-1 partition larger than 2^32 keys");
   void* p;
   int rc;
-  size_t need = (size_t)(nb1 + 1) * 8 + nbk * 4 * 4 + 64 + (nbk + 2) * 8;
+  // below level 1: one level of b2 bits while that is at most 256 streams... up to 2^11 for small inputs (their tiles are short
+  // either way); else a middle level and a last level of at most 8 bits each (bits <= 23, b1 >= 8 there: b2 <= 15)
+  // (SHN_COUNT_LEVELS=3 forces the middle level -- measured at BASELINE configs[2], see DESIGN.md 3.1: two passes of 256 streams
+  // below level 1 are faster per pass (65 against 100 ms) and slower together)
+  const char* lv = getenv("SHN_COUNT_LEVELS");
+  const bool three = b2 > 11 || (lv && atoi(lv) == 3 && b2 > 1);
+  const int b3 = three ? b2 / 2 : b2, bm = b2 - b3;              // last level, middle level (bm = 0: none)
+  const uint32_t nbm = 1u << bm, nb3 = 1u << b3;
+  const uint32_t n_seg3 = (uint32_t)nb1 * nbm;                    // segments of the last level
+  size_t need = (size_t)(nb1 + 1) * 8 + nbk * 4 * 4 + 64 + (nbk + 2) * 8 + (three ? ((size_t)n_seg3 + 2) * 8 + (size_t)n_seg3 * 12 : 0);
   if ((rc = g_ws[4].get(need, &p))) return rc;
   uint64_t* d_off1 = (uint64_t*)p;
   uint64_t* d_boff = d_off1 + (nb1 + 1);
@@ -799,26 +822,62 @@ static int build_from_keys(shn_ctx* ctx, uint64_t* keysA, uint64_t* keysB, uint3
   uint32_t* d_cursor2 = d_off2 + nbk;
   uint32_t* d_ndist = d_cursor2 + nbk;
   uint32_t* d_ovf = d_ndist + nbk;
+  uint64_t* d_seg3 = (uint64_t*)(d_ovf + 16);                     // (three levels) absolute starts of the last level's segments
+  uint32_t* d_histm = (uint32_t*)(d_seg3 + n_seg3 + 2);
+  uint32_t* d_offm = d_histm + n_seg3;
+  uint32_t* d_cursorm = d_offm + n_seg3;
   HIP_TRY(hipMemcpyAsync(d_off1, off1h.data(), (size_t)(nb1 + 1) * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(d_hist2, 0, nbk * 4, s));
   HIP_TRY(hipMemsetAsync(d_ovf, 0, 4, s));
-  // level-2 tile: long enough that a (tile, bucket) run is ~64 keys = 512 B (full lines for the L2 write combiner)
   const uint32_t tile2 = TILE_KEYS;
-  uint32_t tiles = (uint32_t)std::max<uint64_t>(1, cdiv(max1, tile2));
-  {
-    TimerRegion t(ctx, T_HIST2);
-    hipLaunchKernelGGL(hist_keys_kernel<false>, dim3(tiles, nb1), dim3(BLK), nb2 * 4, s, keysA, d_off1, bits, b2, d_hist2, tile2);
+  const uint64_t *segs = d_off1;                                  // segments of the last level and where their keys are
+  uint32_t n_segs = (uint32_t)nb1;
+  uint64_t max_seg = max1;
+  uint64_t *kin = keysA, *kout = keysB;
+  uint32_t *cin_ = cntA, *cout_ = cntB;
+  if (three) {
+    HIP_TRY(hipMemsetAsync(d_histm, 0, (size_t)n_seg3 * 4, s));
+    const uint32_t tiles = (uint32_t)std::max<uint64_t>(1, cdiv(max1, tile2));
+    {
+      TimerRegion t(ctx, T_HIST2);
+      hipLaunchKernelGGL(hist_keys_kernel, dim3(tiles, (uint32_t)nb1), dim3(BLK), nbm * 4, s, kin, d_off1, (uint32_t)nb1, bits, b3, nbm, d_histm, tile2);
+    }
+    hipLaunchKernelGGL(scan_rows_kernel, dim3((uint32_t)nb1), dim3(BLK), 0, s, d_histm, (int)nbm, d_offm, d_cursorm);
+    {
+      TimerRegion t(ctx, T_SCATTER2);
+      if (cntA) hipLaunchKernelGGL((scatter_keys_kernel<true>), dim3(tiles, (uint32_t)nb1), dim3(BLK), nbm * 8, s, kin, cin_, d_off1, (uint32_t)nb1, bits, b3, nbm, d_cursorm, kout, cout_, tile2);
+      else hipLaunchKernelGGL((scatter_keys_kernel<false>), dim3(tiles, (uint32_t)nb1), dim3(BLK), nbm * 8, s, kin, nullptr, d_off1, (uint32_t)nb1, bits, b3, nbm, d_cursorm, kout, nullptr, tile2);
+    }
+    hipLaunchKernelGGL(next_segments_kernel, dim3((uint32_t)cdiv((uint64_t)n_seg3 + 1, 256)), dim3(256), 0, s, d_off1, (uint32_t)nb1, d_offm, nbm, d_seg3);
+    // the largest segment of the last level sizes its grid
+    std::vector<uint32_t> hm(n_seg3);
+    HIP_TRY(hipMemcpyAsync(hm.data(), d_histm, (size_t)n_seg3 * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    max_seg = 0;
+    for (uint32_t v : hm) max_seg = std::max<uint64_t>(max_seg, v);
+    segs = d_seg3; n_segs = n_seg3;
+    std::swap(kin, kout); std::swap(cin_, cout_);
   }
-  hipLaunchKernelGGL(scan_rows_kernel, dim3(nb1), dim3(BLK), 0, s, d_hist2, nb2, d_off2, d_cursor2);
   {
-    TimerRegion t(ctx, T_SCATTER2);
-    if (cntA) hipLaunchKernelGGL((scatter_keys_kernel<false, true>), dim3(tiles, nb1), dim3(BLK), nb2 * 8, s, keysA, cntA, d_off1, bits, b2, d_cursor2, keysB, cntB, tile2);
-    else hipLaunchKernelGGL((scatter_keys_kernel<false, false>), dim3(tiles, nb1), dim3(BLK), nb2 * 8, s, keysA, nullptr, d_off1, bits, b2, d_cursor2, keysB, nullptr, tile2);
+    const uint32_t tiles = (uint32_t)std::max<uint64_t>(1, cdiv(max_seg, tile2));
+    const uint32_t gy = std::min<uint32_t>(n_segs, 32768u);
+    {
+      TimerRegion t(ctx, T_HIST2);
+      hipLaunchKernelGGL(hist_keys_kernel, dim3(tiles, gy), dim3(BLK), nb3 * 4, s, kin, segs, n_segs, bits, 0, nb3, d_hist2, tile2);
+    }
+    hipLaunchKernelGGL(scan_rows_kernel, dim3(n_segs), dim3(BLK), 0, s, d_hist2, (int)nb3, d_off2, d_cursor2);
+    {
+      TimerRegion t(ctx, T_SCATTER2);
+      if (cntA) hipLaunchKernelGGL((scatter_keys_kernel<true>), dim3(tiles, gy), dim3(BLK), nb3 * 8, s, kin, cin_, segs, n_segs, bits, 0, nb3, d_cursor2, kout, cout_, tile2);
+      else hipLaunchKernelGGL((scatter_keys_kernel<false>), dim3(tiles, gy), dim3(BLK), nb3 * 8, s, kin, nullptr, segs, n_segs, bits, 0, nb3, d_cursor2, kout, nullptr, tile2);
+    }
+    std::swap(kin, kout); std::swap(cin_, cout_);
   }
+  // kin: the keys grouped by final bucket; kout / tmpc take the (key, count) runs of the buckets
   {
     TimerRegion t(ctx, T_COUNT);
-    if (cntA) hipLaunchKernelGGL(buckets_kernel<true>, dim3((uint32_t)nbk), dim3(BLK), 0, s, keysB, cntB, d_off1, d_off2, d_hist2, b2, keysA, tmpc, d_ndist, d_ovf);
-    else hipLaunchKernelGGL(buckets_kernel<false>, dim3((uint32_t)nbk), dim3(BLK), 0, s, keysB, nullptr, d_off1, d_off2, d_hist2, b2, keysA, tmpc, d_ndist, d_ovf);
+    if (cntA) hipLaunchKernelGGL(buckets_kernel<true>, dim3((uint32_t)nbk), dim3(BLK), 0, s, kin, cin_, segs, d_off2, d_hist2, b3, kout, tmpc, d_ndist, d_ovf);
+    else hipLaunchKernelGGL(buckets_kernel<false>, dim3((uint32_t)nbk), dim3(BLK), 0, s, kin, nullptr, segs, d_off2, d_hist2, b3, kout, tmpc, d_ndist, d_ovf);
   }
   uint64_t D = 0;
   shn_table* t = new shn_table();
@@ -841,7 +900,7 @@ static int build_from_keys(shn_ctx* ctx, uint64_t* keysA, uint64_t* keysB, uint3
 #undef TRYT
     if (!ovf && D) {
       uint32_t blocks = (uint32_t)cdiv(nbk * SHN_WAVE, BLK);
-      hipLaunchKernelGGL(compact_kernel, dim3(blocks), dim3(BLK), 0, s, keysA, tmpc, d_off1, d_off2, d_ndist, d_boff, b2, nbk, t->d_keys, t->d_counts);
+      hipLaunchKernelGGL(compact_kernel, dim3(blocks), dim3(BLK), 0, s, kout, tmpc, segs, d_off2, d_ndist, d_boff, b3, nbk, t->d_keys, t->d_counts);
     }
   }
   HIP_TRY(hipGetLastError());
@@ -946,7 +1005,10 @@ extern "C" int shn_table_from_pairs(shn_ctx* ctx, const void* dev_keys, const vo
   const uint64_t per_bucket = getenv("SHN_TABLE_BUCKET") ? strtoull(getenv("SHN_TABLE_BUCKET"), nullptr, 10) : 96;
   while (bits < 23 && (n >> bits) > per_bucket) bits++;        // (2^24 buckets x 256 threads would be 2^32 work-items: one too many for a dispatch)
   for (int attempt = 0; attempt < 4; attempt++) {
-    int b1 = (bits + 1) / 2, b2 = bits - b1;
+    int b1 = (bits + 1) / 2;
+    if (getenv("SHN_COUNT_B1")) b1 = std::max(1, std::min(bits, atoi(getenv("SHN_COUNT_B1"))));
+    if (bits - b1 > 15) b1 = bits - 15;
+    int b2 = bits - b1;
     int nb1 = 1 << b1;
     void *p, *pa, *pb, *pc, *pca, *pcb;
     int rc;
@@ -968,7 +1030,7 @@ extern "C" int shn_table_from_pairs(shn_ctx* ctx, const void* dev_keys, const vo
     uint32_t tiles = (uint32_t)std::max<uint64_t>(1, cdiv(n, TILE_KEYS));
     {
       TimerRegion t(ctx, T_HIST1);
-      hipLaunchKernelGGL(hist_keys_kernel<true>, dim3(tiles, 1), dim3(BLK), nb1 * 4, s, keys, d_seg, bits, b2, d_h, (uint32_t)TILE_KEYS);
+      hipLaunchKernelGGL(hist_keys_kernel, dim3(tiles, 1), dim3(BLK), nb1 * 4, s, keys, d_seg, 1u, bits, b2, (uint32_t)nb1, d_h, (uint32_t)TILE_KEYS);
       hipLaunchKernelGGL(scan_rows_kernel, dim3(1), dim3(BLK), 0, s, d_h, nb1, d_o, d_c);
       hipLaunchKernelGGL(sum_counts_kernel, dim3(256), dim3(256), 0, s, cnts, n, d_tot);
     }
@@ -983,7 +1045,7 @@ extern "C" int shn_table_from_pairs(shn_ctx* ctx, const void* dev_keys, const vo
     off1[nb1] = a;
     {
       TimerRegion t(ctx, T_SCATTER1);
-      hipLaunchKernelGGL((scatter_keys_kernel<true, true>), dim3(tiles, 1), dim3(BLK), nb1 * 8, s, keys, cnts, d_seg, bits, b2, d_c,
+      hipLaunchKernelGGL((scatter_keys_kernel<true>), dim3(tiles, 1), dim3(BLK), nb1 * 8, s, keys, cnts, d_seg, 1u, bits, b2, (uint32_t)nb1, d_c,
                          (uint64_t*)pa, (uint32_t*)pca, (uint32_t)TILE_KEYS);
     }
     bool ov = false;
