@@ -522,20 +522,20 @@ def main():
     if dist:
         dist.barrier()
     dt = time.time() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if (dist and dist.get_backend() == "gloo") else dev)
     if dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     job_reads = n_reads
     if dist and world > 1:                 # reads of the whole job (the ranks' slices of a strong-scaling batch differ by a chunk)
-        nt = torch.tensor([n_reads], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        nt = torch.tensor([n_reads], dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(nt, op=dist.ReduceOp.SUM)
         job_reads = int(nt.item())
     timers = ctx.timers()
     lp = ctx.lp_stats()
     if dist and world > 1:                 # the owners of the partitions run the sparse flow: census over all ranks
         keys = [k for k in sorted(lp) if k != "rule"]
-        lt = torch.tensor([lp[k] for k in keys], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        lt = torch.tensor([lp[k] for k in keys], dtype=torch.int64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(lt, op=dist.ReduceOp.SUM)
         lp.update({k: int(v) for k, v in zip(keys, lt.tolist())})
     stage_max = None

@@ -126,34 +126,6 @@ __global__ void ext_prepare_kernel(const uint64_t* __restrict__ tkeys, const uin
   flags[i] = f;
 }
 
-__global__ void ext_adjacency_kernel(const uint64_t* __restrict__ tkeys, const uint64_t* __restrict__ boff, int bits,
-                                     const uint8_t* __restrict__ flags, uint64_t n, int k, int canonical,
-                                     int32_t* __restrict__ adjR, int32_t* __restrict__ adjL) {
-  // one thread per (oriented, dir, base); adjL == nullptr: right rows only (all the component labelling needs), n * 8 threads
-  // grid-stride: n * 16 exceeds the 2^32 work-items one dispatch can carry once the table passes 2^28 k1-mers
-  const uint64_t total = n * (adjL ? 16 : 8);
-  for (uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (uint64_t)gridDim.x * blockDim.x) {
-  uint32_t b = gid & 3;
-  uint32_t dir = adjL ? (gid >> 2) & 1 : 0;
-  uint64_t o = adjL ? gid >> 3 : gid >> 2;
-  uint64_t i = o >> 1;
-  int32_t res = -1;
-  uint8_t f = flags[i];
-  bool dead = (f & 2) || ((o & 1) && ((f & 1) || !canonical));
-  if (!dead) {
-    uint64_t str = (o & 1) ? shn_revcomp(tkeys[i], k) : tkeys[i];
-    uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
-    uint64_t nb = dir == 0 ? (((str << 2) | b) & mask) : ((str >> 2) | ((uint64_t)b << (2 * (k - 1))));
-    uint64_t canon = nb;
-    uint32_t strand = 0;
-    if (canonical) { uint64_t rc = shn_revcomp(nb, k); if (rc < nb) { canon = rc; strand = 1; } }
-    int64_t j = shn_table_find(tkeys, boff, bits, canon);
-    if (j >= 0 && !(flags[j] & 2)) res = (int32_t)(2 * j + strand);
-  }
-  (dir == 0 ? adjR : adjL)[o * 4 + b] = res;
-  }
-}
-
 // ---- a 64-byte record per bucket in front of the table for the adjacency build: { first key index << 20 | keys, 7 separators }
 // (separator i = the key at position ((i + 1) n) / 8 of the bucket).  A look-up reads the record (one sector), counts the
 // separators <= key and bisects the eighth of the bucket they point at (~11 keys of a ~90-key bucket: 1-2 sectors) -- two
@@ -294,47 +266,41 @@ __global__ void cc_init_kernel(uint32_t* __restrict__ lab, uint64_t n) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) lab[i] = (uint32_t)i;
 }
-__global__ void cc_union_kernel(const int32_t* __restrict__ adjR, uint64_t n2, uint32_t* lab) {
-  // one item per (oriented k1-mer, appended base); grid-stride (n2 * 4 can exceed the 2^32 work-items of a dispatch)
-  for (uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < n2 * 4; gid += (uint64_t)gridDim.x * blockDim.x) {
-    int32_t t = adjR[gid];
-    if (t < 0) continue;
-    uint32_t u = (uint32_t)(gid >> 3), v = (uint32_t)t >> 1;             // canonical indices
-    if (u == v) continue;
-    while (true) {
-      uint32_t ru = cc_find(lab, u), rv = cc_find(lab, v);
-      if (ru == rv) break;
-      uint32_t hi = ru > rv ? ru : rv, lo = ru > rv ? rv : ru;
-      if (atomicCAS(&lab[hi], hi, lo) == hi) break;
-    }
+__device__ __forceinline__ void cc_unite(uint32_t* lab, uint32_t u, uint32_t v) {
+  while (true) {
+    const uint32_t ru = cc_find(lab, u), rv = cc_find(lab, v);
+    if (ru == rv) return;
+    const uint32_t hi = ru > rv ? ru : rv, lo = ru > rv ? rv : ru;
+    if (atomicCAS(&lab[hi], hi, lo) == hi) return;
   }
 }
-// contig_connections joins contigs that share a K-mer (extension_correction.py:372-390): besides adjacent k1-mers those are
-// k1-mers with the same K-suffix (x.m, x'.m) or the same K-prefix (m.y, m.y') -- not adjacent, and only joined through a
-// common neighbour if that neighbour exists and is not low-complexity (a transcript's last K-mer before a poly-A tail is
-// the typical exception).  So the component labelling also unites every k1-mer with its (up to six) siblings.
-__global__ void cc_sibling_kernel(const uint64_t* __restrict__ tkeys, const uint64_t* __restrict__ boff, int bits, const uint8_t* __restrict__ flags,
-                                  uint64_t n, int k, int canonical, uint32_t* lab) {
-  for (uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < n * 8; gid += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t i = gid >> 3;
-    const uint32_t which = (uint32_t)(gid & 7);            // bit 2: replace the first / the last base; bits 0-1: the base
+// Every edge of the k1-mer graph straight from the table, no adjacency rows in between: one thread per (canonical k1-mer, which),
+// which = 0..7: the eight neighbours of its forward orientation (append / prepend a base: the other orientation has the same
+// ones), which = 8..15: its siblings.  contig_connections joins contigs that share a K-mer (extension_correction.py:372-390):
+// besides adjacent k1-mers those are k1-mers with the same K-suffix (x.m, x'.m) or the same K-prefix (m.y, m.y') -- not adjacent,
+// and only joined through a common neighbour if that neighbour exists and is not low-complexity (a transcript's last K-mer before
+// a poly-A tail is the typical exception).  So the labelling also unites every k1-mer with its (up to six) siblings.
+// Look-ups as in the records kernel: Bloom filter, then the bucket's separator record.
+__global__ void cc_edges_kernel(const uint64_t* __restrict__ tkeys, const uint64_t* __restrict__ boff, int bits, const uint8_t* __restrict__ flags,
+                                uint64_t n, int k, int canonical, uint32_t* lab, const unsigned long long* __restrict__ recs,
+                                const unsigned long long* __restrict__ bloom, uint64_t bloom_blocks) {
+  const uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+  for (uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < n * 16; gid += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t i = gid >> 4;
+    const uint32_t which = (uint32_t)(gid & 15);
     if (flags[i] & 2) continue;
     const uint64_t str = tkeys[i];
     const uint32_t b = which & 3;
-    uint64_t sib;
-    if (which & 4) { if ((str & 3) == b) continue; sib = (str & ~3ULL) | b; }
-    else { const int sh = 2 * (k - 1); if (((str >> sh) & 3) == b) continue; sib = (str & ~(3ULL << sh)) | ((uint64_t)b << sh); }
-    uint64_t canon = sib;
-    if (canonical) { const uint64_t rc = shn_revcomp(sib, k); if (rc < sib) canon = rc; }
-    const int64_t j = shn_table_find(tkeys, boff, bits, canon);
+    uint64_t other;
+    if (which < 8) other = (which & 4) ? ((str >> 2) | ((uint64_t)b << (2 * (k - 1)))) : (((str << 2) | b) & mask);
+    else if (which & 4) { if ((str & 3) == b) continue; other = (str & ~3ULL) | b; }
+    else { const int sh = 2 * (k - 1); if (((str >> sh) & 3) == b) continue; other = (str & ~(3ULL << sh)) | ((uint64_t)b << sh); }
+    uint64_t canon = other;
+    if (canonical) { const uint64_t rc = shn_revcomp(other, k); if (rc < other) canon = rc; }
+    if (bloom && !bloom_may_have(bloom, bloom_blocks, canon)) continue;
+    const int64_t j = recs ? ext_find_indexed(tkeys, recs, bits, canon) : shn_table_find(tkeys, boff, bits, canon);
     if (j < 0 || (flags[j] & 2) || (uint64_t)j == i) continue;
-    const uint32_t u = (uint32_t)i, v = (uint32_t)j;
-    while (true) {
-      const uint32_t ru = cc_find(lab, u), rv = cc_find(lab, v);
-      if (ru == rv) break;
-      const uint32_t hi = ru > rv ? ru : rv, lo = ru > rv ? rv : ru;
-      if (atomicCAS(&lab[hi], hi, lo) == hi) break;
-    }
+    cc_unite(lab, (uint32_t)i, (uint32_t)j);
   }
 }
 __global__ void cc_flatten_kernel(uint32_t* lab, uint64_t n) {
@@ -1266,24 +1232,22 @@ __global__ void shard_offsets_kernel(const uint64_t* __restrict__ boff, uint64_t
   if (b <= n_buckets) oboff[b] = pos[boff[b]];        // pos has n+1 entries: pos[n] = number of selected k1-mers
 }
 
+static int build_lookup_aids(shn_ctx* ctx, const shn_table* t, const uint8_t* d_flags, unsigned long long** recs_out, unsigned long long** bloom_out,
+                             uint64_t* bloom_blocks_out);
 static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank, shn_table** out) {
   hipStream_t s = ctx->stream;
   const uint64_t n = t->n;
-  uint32_t* d_weight = nullptr; uint8_t* d_flags = nullptr; int32_t *d_adjR = nullptr, *d_adjL = nullptr;
+  uint32_t* d_weight = nullptr; uint8_t* d_flags = nullptr;
+  unsigned long long *recs = nullptr, *bloom = nullptr;
+  uint64_t bloom_blocks = 0;
   shn_table* sub = nullptr;
-  auto cleanup = [&]() { if (d_weight) shn_dev_free(d_weight); if (d_flags) shn_dev_free(d_flags); if (d_adjR) shn_dev_free(d_adjR); if (d_adjL) shn_dev_free(d_adjL); };
+  auto cleanup = [&]() { if (d_weight) shn_dev_free(d_weight); if (d_flags) shn_dev_free(d_flags); if (recs) shn_dev_free(recs); if (bloom) shn_dev_free(bloom); };
 #define TRYS(x) do { hipError_t _e = (x); if (_e != hipSuccess) { cleanup(); if (sub) shn_table_destroy(sub); \
       return shn_fail(SHN_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(_e)); } } while (0)
   TRYS(shn_dev_malloc(&d_weight, (n + 1) * 4));
   TRYS(shn_dev_malloc(&d_flags, n + 1));
-  TRYS(shn_dev_malloc(&d_adjR, (2 * n + 1) * 16));
-  {
-    TimerRegion t1(ctx, T_EXT_PREP);
-    hipLaunchKernelGGL(ext_prepare_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, t->d_counts, n, t->k, t->canonical, d_weight, d_flags);
-    // right rows of both orientations hold every edge of the (undirected) k1-mer graph: the left rows are not needed here
-    hipLaunchKernelGGL(ext_adjacency_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off, t->bits, d_flags, n, t->k,
-                       t->canonical, d_adjR, (int32_t*)nullptr);
-  }
+  hipLaunchKernelGGL(ext_prepare_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, t->d_counts, n, t->k, t->canonical, d_weight, d_flags);
+  { int rca = build_lookup_aids(ctx, t, d_flags, &recs, &bloom, &bloom_blocks); if (rca) { cleanup(); return rca; } }
   void *pl, *po, *pz, *pb, *pc, *pp;
   const uint32_t big_cap = 1u << 16;
   int rc;
@@ -1296,9 +1260,9 @@ static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank
   uint64_t* d_pos = (uint64_t*)pp;
   TRYS(hipMemsetAsync(d_cnt, 0, 2048, s));
   hipLaunchKernelGGL(cc_init_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, d_lab, n);
-  hipLaunchKernelGGL(cc_union_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(2 * n * 4, 256), 1u << 22)), dim3(256), 0, s, (const int32_t*)d_adjR, 2 * n, d_lab);
-  hipLaunchKernelGGL(cc_sibling_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off, t->bits,
-                     d_flags, n, t->k, t->canonical, d_lab);
+  { TimerRegion t1(ctx, T_EXT_PREP);
+    hipLaunchKernelGGL(cc_edges_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 16, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off, t->bits,
+                       d_flags, n, t->k, t->canonical, d_lab, (const unsigned long long*)recs, (const unsigned long long*)bloom, bloom_blocks); }
   hipLaunchKernelGGL(cc_flatten_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, d_lab, n);
   TRYS(hipMemsetAsync(d_size, 0, (n + 1) * 4, s));
   hipLaunchKernelGGL(cc_sample_kernel, dim3((uint32_t)cdiv(cdiv(n, 64), 256)), dim3(256), 0, s, d_lab, n, d_size);
@@ -1347,6 +1311,39 @@ static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank
 #undef TRYS
   cleanup();
   *out = sub;
+  return SHN_OK;
+}
+
+// the aids of the table look-ups of the records / labelling kernels: a separator record per bucket (large tables; see
+// ext_find_indexed; SHN_EXT_BUCKET_INDEX=0 / 1 forbids / forces it) and a Bloom filter in front (SHN_EXT_BLOOM).  Either may
+// come back NULL; the caller frees both after the stream has drained.
+static int build_lookup_aids(shn_ctx* ctx, const shn_table* t, const uint8_t* d_flags, unsigned long long** recs_out, unsigned long long** bloom_out,
+                             uint64_t* bloom_blocks_out) {
+  hipStream_t s = ctx->stream;
+  const uint64_t n = t->n;
+  unsigned long long* recs = nullptr;
+  uint32_t* d_big = nullptr;
+  const char* bi = getenv("SHN_EXT_BUCKET_INDEX");
+  const bool want_index = bi ? bi[0] != '0' : (n >= (1ULL << 24) && n / t->n_buckets >= 24);
+  if (want_index && shn_dev_malloc(&recs, t->n_buckets * 64) == hipSuccess && shn_dev_malloc(&d_big, 64) == hipSuccess) {
+    uint32_t big = 0;
+    hipError_t e = hipMemsetAsync(d_big, 0, 4, s);
+    hipLaunchKernelGGL(ext_bucket_index_kernel, dim3((uint32_t)cdiv(t->n_buckets, 256)), dim3(256), 0, s, t->d_keys, t->d_bucket_off, t->n_buckets, recs, d_big);
+    if (e == hipSuccess) e = hipMemcpyAsync(&big, d_big, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { shn_dev_free(recs); shn_dev_free(d_big); return shn_fail(SHN_ERR_HIP, std::string("build_lookup_aids: ") + hipGetErrorString(e)); }
+    if (big) { shn_dev_free(recs); recs = nullptr; }
+  } else if (recs) { shn_dev_free(recs); recs = nullptr; }
+  if (d_big) shn_dev_free(d_big);
+  unsigned long long* bloom = nullptr;
+  const uint64_t bloom_blocks = n / 4 + 1;             // 64-bit words: 16 bits per key
+  const char* bl = getenv("SHN_EXT_BLOOM");
+  if ((bl ? bl[0] != '0' : recs != nullptr) && shn_dev_malloc(&bloom, bloom_blocks * 8) == hipSuccess) {
+    hipError_t e = hipMemsetAsync(bloom, 0, bloom_blocks * 8, s);
+    if (e != hipSuccess) { shn_dev_free(recs); shn_dev_free(bloom); return shn_fail(SHN_ERR_HIP, std::string("build_lookup_aids: ") + hipGetErrorString(e)); }
+    hipLaunchKernelGGL(ext_bloom_build_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, d_flags, n, bloom, bloom_blocks);
+  }
+  *recs_out = recs; *bloom_out = bloom; *bloom_blocks_out = bloom_blocks;
   return SHN_OK;
 }
 
@@ -1409,30 +1406,13 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     hipLaunchKernelGGL(ext_prepare_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, t->d_counts, n, t->k,
                        t->canonical, e->d_weight, e->d_flags);
     {
-      // large tables: a separator record per bucket first (see ext_find_indexed); SHN_EXT_BUCKET_INDEX=0 / 1 forbids / forces it
-      unsigned long long* recs = nullptr;
-      uint32_t* d_big = nullptr;
-      const char* bi = getenv("SHN_EXT_BUCKET_INDEX");
-      const bool want_index = bi ? bi[0] != '0' : (n >= (1ULL << 24) && n / t->n_buckets >= 24);
-      if (want_index && shn_dev_malloc(&recs, t->n_buckets * 64) == hipSuccess && shn_dev_malloc(&d_big, 64) == hipSuccess) {
-        TRYE(hipMemsetAsync(d_big, 0, 4, s));
-        hipLaunchKernelGGL(ext_bucket_index_kernel, dim3((uint32_t)cdiv(t->n_buckets, 256)), dim3(256), 0, s, t->d_keys, t->d_bucket_off, t->n_buckets, recs, d_big);
-        uint32_t big = 0;
-        TRYE(hipMemcpyAsync(&big, d_big, 4, hipMemcpyDeviceToHost, s));
-        TRYE(hipStreamSynchronize(s));
-        if (big) { shn_dev_free(recs); recs = nullptr; }
-      } else if (recs) { shn_dev_free(recs); recs = nullptr; }
-      unsigned long long* bloom = nullptr;
-      const uint64_t bloom_blocks = n / 4 + 1;             // 64-bit words: 16 bits per key
-      const char* bl = getenv("SHN_EXT_BLOOM");
-      if ((bl ? bl[0] != '0' : recs != nullptr) && shn_dev_malloc(&bloom, bloom_blocks * 8) == hipSuccess) {
-        TRYE(hipMemsetAsync(bloom, 0, bloom_blocks * 8, s));
-        hipLaunchKernelGGL(ext_bloom_build_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, e->d_flags, n, bloom, bloom_blocks);
-      }
+      unsigned long long *recs = nullptr, *bloom = nullptr;
+      uint64_t bloom_blocks = 0;
+      { int rca = build_lookup_aids(ctx, t, e->d_flags, &recs, &bloom, &bloom_blocks); if (rca) { shn_ext_destroy(e); return rca; } }
       { TimerRegion ta(ctx, T_EXT_ADJ);                  // (one launch: bench.py's roofline entry for this kernel)
         hipLaunchKernelGGL(ext_records_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off,
                            t->bits, e->d_flags, e->d_weight, n, t->k, t->canonical, e->d_rec, (const unsigned long long*)recs, (const unsigned long long*)bloom, bloom_blocks); }
-      if (recs || d_big || bloom) { TRYE(hipStreamSynchronize(s)); shn_dev_free(recs); shn_dev_free(d_big); shn_dev_free(bloom); }
+      if (recs || bloom) { TRYE(hipStreamSynchronize(s)); shn_dev_free(recs); shn_dev_free(bloom); }
     }
     TRYE(hipGetLastError());
   }

@@ -42,3 +42,40 @@ def test_every_walk_equals_the_c_oracle(K):
     assert got == [c for c, _, _ in want]
     print("K=%d: %d k1-mers, %d walks (%d seeds, %d rounds, %d steps) equal the C oracle" % (K, len(ok), len(want), ext.n_walks, ext.iterations, ext.total_steps))
     ext.close(); t.close(); d1.close(); d2.close(); ctx.close()
+
+
+def test_gpu_contig_stage_and_bulk_walker_equal_the_sequential_stage_at_10m_reads():
+    """10 M reads of 2,000 genes (73 M k1-mers: above the 20 M at which the product switches to the GPU contig stage, bulk rounds of
+    the thread walker on 23 M seeds): the contig stage both ways -- the reference's sequential loop in native host code beside the
+    walks (SHN_CONTIG_GPU=0) and the fixpoint rounds on the device after them (SHN_CONTIG_GPU=1: what BASELINE configs[2] runs) -- each
+    twice: contigs, contig connections and components identical in all four runs.  (tools/check_contig_paths.py as a test.)"""
+    import hashlib
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from shannon_amd import device, extension_correction as ec
+    r1, r2 = bench.gen_reads(5_000_000, 20240501, 2000, torch.device("cuda", 0))
+    ctx = device.Context(0)
+    sets = [device.Reads.from_codes(ctx, r1), device.Reads.from_codes(ctx, r2)]
+    table = device.count_k1mers(ctx, sets, 26, True)
+    assert len(table) >= 20_000_000
+    sigs = []
+    old = os.environ.get("SHN_CONTIG_GPU")
+    try:
+        for mode in ("0", "1", "0", "1"):
+            os.environ["SHN_CONTIG_GPU"] = mode
+            res = ec.run_correction(ctx, table, 3, 75, 500, want_allowed=False)
+            hc = hashlib.sha256(np.asarray(res.conn_off, np.int64).tobytes() + np.asarray(res.conn_nb, np.int64).tobytes() +
+                                np.asarray(res.conn_w, np.int64).tobytes()).hexdigest()
+            sigs.append((hashlib.sha256("\n".join(res.contigs).encode()).hexdigest(), hc,
+                         hashlib.sha256(np.asarray(res.comp_members, np.int64).tobytes()).hexdigest(), len(res.contigs)))
+    finally:
+        if old is None:
+            os.environ.pop("SHN_CONTIG_GPU", None)
+        else:
+            os.environ["SHN_CONTIG_GPU"] = old
+    assert len(set(sigs)) == 1 and sigs[0][3] > 5000, sigs
+    table.close()
+    for x in sets:
+        x.close()
+    ctx.close()
