@@ -334,6 +334,12 @@ typedef struct shn_post shn_post;
 int shn_post_finalize(const uint8_t* text, uint64_t n_bytes, int ds, int r, shn_post** out);
 /* ... over the concatenation of several buffers (per-partition FASTA texts) */
 int shn_post_finalize_bufs(const uint8_t* const* bufs, const uint64_t* lens, uint64_t n_bufs, int ds, int r, shn_post** out);
+/* The same with the two passes over the bases of the transcripts on the device of `ctx` (csrc/post_gpu.hip; SURVEY 8f row 1:
+ * process_concatenated_fasta.py:26-31 and faster_reps.py:104-116 on the GPU): 128-bit fingerprints of every sequence line and of
+ * its reverse complement (every match is confirmed on the text), and the scan of the surviving records for the occurrences of
+ * their first / last r-mers.  Names, first-come-first-served and the containment rule stay sequential host code.  Same result
+ * as shn_post_finalize_bufs, byte for byte.                                                                                    */
+int shn_post_finalize_dev(shn_ctx* ctx, const uint8_t* const* bufs, const uint64_t* lens, uint64_t n_bufs, int ds, int r, shn_post** out);
 uint64_t shn_post_count(const shn_post* p);
 int shn_post_sizes(const shn_post* p, uint64_t* name_bytes, uint64_t* seq_bytes);
 int shn_post_export(const shn_post* p, uint8_t* names, uint64_t* name_off, uint8_t* seqs, uint64_t* seq_off);

@@ -5,6 +5,7 @@
 // record set is the assembler's output, not the read set; SURVEY.md 8f ranks a GPU version as "next".
 #include "common.h"
 #include "flatmap.h"
+#include "post_dev.h"
 #include <algorithm>
 #include <atomic>
 #include <thread>
@@ -18,7 +19,7 @@ static inline int pcode(uint8_t c) { return kPCode.v[c]; }                // (a 
 // A name that occurs more than once behaves like the reference's dict (the later sequence replaces the
 // earlier one, keep_out of the earlier record is 0).  Returns SHN_ERR_ARG if a sequence holds a non-ACGT base.
 static int find_reps_core(const uint8_t* const* nptr, const uint64_t* nlen, const uint8_t* const* sptr, const uint64_t* slen, uint64_t n, int ds, int r,
-                          uint8_t* keep_out);
+                          uint8_t* keep_out, PostDev* dev = nullptr, const uint64_t* goff = nullptr);
 extern "C" int shn_find_reps(const uint8_t* names, const uint64_t* name_off, const uint8_t* seqs, const uint64_t* seq_off,
                              uint64_t n, int ds, int r, uint8_t* keep_out) {
   if ((n && (!names || !name_off || !seqs || !seq_off)) || !keep_out) return shn_fail(SHN_ERR_ARG, "shn_find_reps: NULL argument");
@@ -28,8 +29,9 @@ extern "C" int shn_find_reps(const uint8_t* names, const uint64_t* name_off, con
   return find_reps_core(np_.data(), nl_.data(), sp_.data(), sl_.data(), n, ds, r, keep_out);
 }
 // (records given by pointer + length: shn_post_finalize hands over lines of the text it was given, without packing them)
+// dev + goff (global offset of every record's sequence in the uploaded text): the scan for the query r-mers runs on the device
 static int find_reps_core(const uint8_t* const* nptr, const uint64_t* nlen, const uint8_t* const* sptr, const uint64_t* slen, uint64_t n, int ds, int r,
-                          uint8_t* keep_out) {
+                          uint8_t* keep_out, PostDev* dev, const uint64_t* goff) {
   if (r < 1 || r > 32) return shn_fail(SHN_ERR_ARG, "shn_find_reps: r must be in [1,32]");
   const bool dbgf = getenv("SHN_DEBUG") != nullptr;
   auto nowf = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
@@ -65,7 +67,9 @@ static int find_reps_core(const uint8_t* const* nptr, const uint64_t* nlen, cons
   bool q_all_t = false;
   // in front of the set a 1 MB bit table that stays in a core's cache: 19 of 20 window positions end there
   std::vector<uint64_t> qbits(1u << 17, 0);
+  std::vector<uint64_t> qlist;                    // (device scan: the query keys as a list)
   auto q_add = [&](uint64_t key) {
+    if (dev) qlist.push_back(key);
     if (key == ~0ULL) { q_all_t = true; return; }
     { const uint64_t h = fm_mix(key) >> 41; qbits[h >> 6] |= 1ULL << (h & 63); }
     size_t sl = fm_mix(key) & (qcap - 1);
@@ -96,7 +100,28 @@ static int find_reps_core(const uint8_t* const* nptr, const uint64_t* nlen, cons
   struct Occ { uint64_t key; int32_t id, pos; };
   const unsigned nthr = n < 4096 ? 1 : std::max(1u, std::min(32u, (unsigned)shn_host_cpus()));
   std::vector<std::vector<Occ>> found(nthr);
-  {
+  bool scanned = false;
+  if (dev && goff && r < 32 && n) {
+    // the occurrences from the device, in record order and by position inside a record -- the order the host scan appends them in
+    std::vector<uint32_t> lens(n);
+    bool fits = true;
+    for (uint64_t i = 0; i < n; i++) { if (slen[i] > 0xFFFFFFF0ULL) fits = false; lens[i] = (uint32_t)slen[i]; }
+    if (fits) {
+      std::vector<uint32_t> hr, hp;
+      std::vector<uint64_t> hk;
+      int dbad = 0;
+      uint64_t total = 0;
+      for (uint64_t i = 0; i < n; i++) total += slen[i];
+      const int rcs = post_dev_scan(dev, goff, lens.data(), n, r, qlist.data(), qlist.size(), std::min<uint64_t>(total + 1, 1ULL << 24), hr, hp, hk, &dbad);
+      if (rcs == SHN_OK) {
+        if (dbad) return shn_fail(SHN_ERR_ARG, "shn_find_reps: non-ACGT base in a transcript");
+        found[0].reserve(hr.size());
+        for (size_t h = 0; h < hr.size(); h++) found[0].push_back(Occ{hk[h], id_of[hr[h]], (int32_t)hp[h]});
+        scanned = true;
+      } else if (rcs != SHN_ERR_OVERFLOW) return rcs;          // (more hits than the buffer: the host scan takes over)
+    }
+  }
+  if (!scanned) {
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nthr; t++) th.emplace_back([&, t]() {
       std::vector<Occ>& out = found[t];
@@ -213,13 +238,22 @@ extern "C" int shn_post_export(const shn_post* p, uint8_t* names, uint64_t* name
   return SHN_OK;
 }
 
-extern "C" int shn_post_finalize_bufs(const uint8_t* const* bufs, const uint64_t* lens, uint64_t n_bufs, int ds, int r, shn_post** out);
+static int post_finalize_impl(shn_ctx* ctx, const uint8_t* const* bufs, const uint64_t* lens, uint64_t n_bufs, int ds, int r, shn_post** out);
+extern "C" int shn_post_finalize_bufs(const uint8_t* const* bufs, const uint64_t* lens, uint64_t n_bufs, int ds, int r, shn_post** out) {
+  return post_finalize_impl(nullptr, bufs, lens, n_bufs, ds, r, out);
+}
+// the same with the two passes over the bases on the device of `ctx` (csrc/post_gpu.hip): fingerprints of every sequence line and
+// of its reverse complement, and the scan of the surviving records for the query r-mers of find_reps
+extern "C" int shn_post_finalize_dev(shn_ctx* ctx, const uint8_t* const* bufs, const uint64_t* lens, uint64_t n_bufs, int ds, int r, shn_post** out) {
+  if (!ctx) return shn_fail(SHN_ERR_ARG, "shn_post_finalize_dev: ctx is NULL");
+  return post_finalize_impl(ctx, bufs, lens, n_bufs, ds, r, out);
+}
 extern "C" int shn_post_finalize(const uint8_t* text, uint64_t n_bytes, int ds, int r, shn_post** out) {
   if ((n_bytes && !text) || !out) return shn_fail(SHN_ERR_ARG, "shn_post_finalize: NULL argument");
   return shn_post_finalize_bufs(&text, &n_bytes, 1, ds, r, out);
 }
 // the same over the concatenation of several buffers (the per-partition FASTA texts as they come out of shn_sparse_flow)
-extern "C" int shn_post_finalize_bufs(const uint8_t* const* bufs, const uint64_t* lens, uint64_t n_bufs, int ds, int r, shn_post** out) {
+static int post_finalize_impl(shn_ctx* ctx, const uint8_t* const* bufs, const uint64_t* lens, uint64_t n_bufs, int ds, int r, shn_post** out) {
   if (!out || (n_bufs && (!bufs || !lens))) return shn_fail(SHN_ERR_ARG, "shn_post_finalize: NULL argument");
   for (uint64_t i = 0; i < n_bufs; i++) if (lens[i] && !bufs[i]) return shn_fail(SHN_ERR_ARG, "shn_post_finalize: NULL buffer");
   // a buffer that does not end its last line would run into the next one: join them all in that (unusual) case
@@ -238,6 +272,7 @@ extern "C" int shn_post_finalize_bufs(const uint8_t* const* bufs, const uint64_t
   // ---- process_concatenated
   std::vector<std::string> own;                        // renamed header lines (stable addresses: reserved below)
   std::vector<std::pair<SV, SV>> recs;                 // (header line, sequence line), lines with their newline
+  std::vector<uint32_t> rec_li;                        // ... and the index of the sequence line
   {
     uint64_t n_lines = 0;
     for (auto& pc : pieces) { n_lines++; for (uint64_t p = 0; p < pc.second; p++) n_lines += pc.first[p] == '\n'; }
@@ -257,18 +292,50 @@ extern "C" int shn_post_finalize_bufs(const uint8_t* const* bufs, const uint64_t
   // hashing of 60-150 MB of sequence was most of this function); the order-dependent part -- names, first-come dedup -- follows
   // sequentially on the hashes
   std::vector<SV> lines;
-  for (auto& pc : pieces) {
-    const uint8_t* text = pc.first;
-    const uint64_t n_bytes = pc.second;
-    for (uint64_t p = 0; p < n_bytes;) {
-      const void* q = memchr(text + p, '\n', n_bytes - p);
-      const uint64_t e = q ? (uint64_t)((const uint8_t*)q - text) + 1 : n_bytes;
-      lines.push_back(SV((const char*)text + p, e - p));
-      p = e;
+  std::vector<uint64_t> line_goff;                    // offset of every line in the concatenation of the pieces (= the uploaded text)
+  {
+    uint64_t base = 0;
+    for (auto& pc : pieces) {
+      const uint8_t* text = pc.first;
+      const uint64_t n_bytes = pc.second;
+      for (uint64_t p = 0; p < n_bytes;) {
+        const void* q = memchr(text + p, '\n', n_bytes - p);
+        const uint64_t e = q ? (uint64_t)((const uint8_t*)q - text) + 1 : n_bytes;
+        lines.push_back(SV((const char*)text + p, e - p));
+        line_goff.push_back(base + p);
+        p = e;
+      }
+      base += n_bytes;
     }
   }
+  // device: the text goes up once; the sequence lines' fingerprints (plain and reverse-complemented, 128 bits each) replace the
+  // host hashes.  A fingerprint match is always confirmed on the text below, so it can only cost time, never an answer.
+  PostDev* dev = nullptr;
+  struct DevFree { PostDev*& d; ~DevFree() { if (d) post_dev_destroy(d); } } dev_free{dev};
+  std::vector<uint64_t> fp;                           // per line: 4 words (0 for lines that are not sequence lines)
+  bool use_fp = false;
+  if (ctx && !lines.empty()) {
+    int rcd = post_dev_create(ctx, pieces, &dev);
+    if (rcd) return rcd;
+    std::vector<uint64_t> so; std::vector<uint32_t> sl; std::vector<uint32_t> which;
+    for (size_t i = 0; i < lines.size(); i++) {
+      const SV line = lines[i];
+      size_t a = 0;
+      while (a < line.size() && is_ws((uint8_t)line[a])) a++;
+      if (a == line.size() || line[a] == '>' || line.size() <= 200) continue;
+      const SV cur = strip(line);
+      so.push_back(line_goff[i] + (uint64_t)(cur.data() - line.data())); sl.push_back((uint32_t)cur.size()); which.push_back((uint32_t)i);
+    }
+    std::vector<uint64_t> got(so.size() * 4);
+    rcd = post_dev_fingerprints(dev, so.data(), sl.data(), so.size(), got.data());
+    if (rcd) return rcd;
+    fp.assign(lines.size() * 4, 0);
+    for (size_t j = 0; j < which.size(); j++) memcpy(&fp[(size_t)which[j] * 4], &got[j * 4], 32);
+    use_fp = true;
+  }
   std::vector<uint64_t> hf(lines.size(), 0), hr(lines.size(), 0);
-  {
+  if (use_fp) { for (size_t i = 0; i < lines.size(); i++) { hf[i] = fp[4 * i] ^ (fp[4 * i + 1] * 0x9E3779B97F4A7C15ULL); hr[i] = fp[4 * i + 2] ^ (fp[4 * i + 3] * 0x9E3779B97F4A7C15ULL); } }
+  else {
     const unsigned nt = lines.size() < 2048 ? 1 : (unsigned)std::max(1, std::min(16, shn_host_cpus()));
     std::atomic<size_t> next{0};
     auto work = [&]() {
@@ -333,6 +400,7 @@ extern "C" int shn_post_finalize_bufs(const uint8_t* const* bufs, const uint64_t
       contigs.insert(HKey{cur, hf[li]});
       contig_hashes.insert(hf[li]);
       recs.push_back({last, line});
+      rec_li.push_back((uint32_t)li);
     }
   }
   const bool dbgp = getenv("SHN_DEBUG") != nullptr;
@@ -353,19 +421,21 @@ extern "C" int shn_post_finalize_bufs(const uint8_t* const* bufs, const uint64_t
   // ---- find_reps over (name = first field without '>', stripped sequence)
   const uint64_t n = order.size();
   std::vector<const uint8_t*> nptr(n), sptr(n);
-  std::vector<uint64_t> nlen(n), slen(n);
+  std::vector<uint64_t> nlen(n), slen(n), sgoff(n);
   for (uint64_t i = 0; i < n; i++) {
     const SV h = strip(recs[order[i]].first);
     size_t b = 0;
     while (b < h.size() && !is_ws((uint8_t)h[b])) b++;
     nptr[i] = (const uint8_t*)h.data() + 1; nlen[i] = b - 1;
-    const SV sq = strip(recs[order[i]].second);
+    const SV ln = recs[order[i]].second;
+    const SV sq = strip(ln);
     sptr[i] = (const uint8_t*)sq.data(); slen[i] = sq.size();
+    sgoff[i] = line_goff[rec_li[order[i]]] + (uint64_t)(sq.data() - ln.data());
   }
   std::vector<uint8_t> keep(n + 1, 0);
   const double tp1 = nowp();
   if (n) {
-    int rc = find_reps_core(nptr.data(), nlen.data(), sptr.data(), slen.data(), n, ds, r, keep.data());
+    int rc = find_reps_core(nptr.data(), nlen.data(), sptr.data(), slen.data(), n, ds, r, keep.data(), dev, sgoff.data());
     if (rc) return rc;
   }
   shn_post* o = new shn_post();

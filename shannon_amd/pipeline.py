@@ -278,7 +278,7 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
             R._texts = ["".join(lines)] + texts                        # all_reconstructed.fasta: single contigs, then the partitions
             if os.environ.get("SHN_POST_NATIVE", "1") != "0":
                 try:
-                    R.final = post.finalize_texts(R._texts, double_stranded)
+                    R.final = post.finalize_texts(R._texts, double_stranded, ctx=ctx_b)
                 except _lib.ShannonError as ex:
                     if "non-ACGT" not in str(ex) and "empty line" not in str(ex):
                         raise

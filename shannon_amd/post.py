@@ -122,9 +122,11 @@ def finalize_native(all_lines, ds=True, r=24):
     return finalize_texts([blob], ds, r)
 
 
-def finalize_texts(texts, ds=True, r=24):
+def finalize_texts(texts, ds=True, r=24, ctx=None):
     """the same over the concatenation of several texts (str, bytes or uint8 arrays: the per-partition FASTA as it leaves the
-    native sparse-flow stage), without joining them (shn_post_finalize_bufs)"""
+    native sparse-flow stage), without joining them (shn_post_finalize_bufs).  ctx (device.Context): the two passes over the
+    bases -- sequence / reverse-complement fingerprints and the scan for the query 24-mers -- run on the device
+    (shn_post_finalize_dev); SHN_POST_GPU=0 keeps them on the host threads."""
     import ctypes as C
     import numpy as np
     from . import _lib
@@ -137,7 +139,11 @@ def finalize_texts(texts, ds=True, r=24):
     lens = (C.c_uint64 * max(len(bufs), 1))(*[len(b) for b in bufs])
     L = _lib.lib()
     h = C.c_void_p()
-    _lib.check(L.shn_post_finalize_bufs(ptrs, lens, len(bufs), 1 if ds else 0, r, C.byref(h)))
+    import os
+    if ctx is not None and r < 32 and os.environ.get("SHN_POST_GPU", "1") != "0":
+        _lib.check(L.shn_post_finalize_dev(ctx.h, ptrs, lens, len(bufs), 1 if ds else 0, r, C.byref(h)))
+    else:
+        _lib.check(L.shn_post_finalize_bufs(ptrs, lens, len(bufs), 1 if ds else 0, r, C.byref(h)))
     try:
         n = int(L.shn_post_count(h))
         nb, sb = C.c_uint64(), C.c_uint64()
