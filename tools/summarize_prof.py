@@ -8,8 +8,8 @@ reads; for the gather-dominated walk kernels it is an upper bound."""
 import csv, sys, re, collections, json
 
 # bench.py timer name -> kernel name prefix in the profile
-TIMER_KERNEL = {"count.direct": "count_direct_kernel", "count.hist1": "hist1_kernel", "count.scatter1": "scatter1_kernel", "count.hist2": "hist_keys_kernel<false>",
-                "count.scatter2": "scatter_keys_kernel<false, false>", "count.buckets": "buckets_kernel<false>", "route": "route_kernel",
+TIMER_KERNEL = {"count.direct": "count_direct_kernel", "count.hist1": "hist1_kernel", "count.scatter1": "scatter1_kernel", "count.hist2": "hist_keys_kernel",
+                "count.scatter2": "scatter_keys_kernel<false>", "count.buckets": "buckets_kernel<false>", "route": "route_kernel",
                 "extend.walk_thread": "ext_walk_kernel", "extend.walk_wave": "ext_walk_long_kernel", "extend.mark": "ext_mark_kernel",
                 "extend.adjacency": "ext_records_kernel"}
 
