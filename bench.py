@@ -31,9 +31,10 @@ import torch
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes over this same command at the
 # default workload; tools/summarize_prof.py -> profiles/r01_traffic.json): 2 x FETCH_SIZE (gfx950 tallies 128-B
-# requests at 64 B, MI355X_MICROARCH.md HBM) + WRITE_SIZE.  Only valid for the default 10M-read workload.
+# requests at 64 B, MI355X_MICROARCH.md HBM; profiles/r03_fetch_calibration.txt: on this chip EVERY read request the L2 sends to
+# memory is a 128-byte one, random 8-byte gathers included) + WRITE_SIZE.  Valid for the named workload only.
 TRAFFIC = {}
-for _cfg, _fn in (("1", "r01_traffic.json"), ("2", "r02_traffic_config2.json")):
+for _cfg, _fn in (("1", "r01_traffic.json"), ("2", "r03_traffic_config2.json"), ("4s", "r03_traffic_config4s.json")):
     try:
         TRAFFIC["config%s" % _cfg] = json.load(open(os.path.join(ROOT, "profiles", _fn)))["traffic_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
