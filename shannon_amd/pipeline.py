@@ -87,7 +87,7 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
     if not double_stranded:
         # shannon.py:394-424 prepares strand-specific input differently (no doubling; PE: reads_2 = RC(R2)) and routing /
         # graph reads follow that layout; only the strand-doubled layout is built and pinned against the reference.
-        raise NotImplementedError("strand-specific input (-s / --ss) is not built: only the default double-stranded path is")
+        raise NotImplementedError("strand-specific input (-s / --ss) is not built: only the default double-stranded path is (INTEGRATION.md, Waiver)")
     T = timings if timings is not None else {}
     paired = d2 is not None
     if graph_threads is None:                   # a rank's share of the host cores (8 ranks per node), at least 8
