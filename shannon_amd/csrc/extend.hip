@@ -126,126 +126,120 @@ __global__ void ext_prepare_kernel(const uint64_t* __restrict__ tkeys, const uin
   flags[i] = f;
 }
 
-// ---- a 64-byte record per bucket in front of the table for the adjacency build: { first key index << 20 | keys, 7 separators }
-// (separator i = the key at position ((i + 1) n) / 8 of the bucket).  A look-up reads the record (one sector), counts the
-// separators <= key and bisects the eighth of the bucket they point at (~11 keys of a ~90-key bucket: 1-2 sectors) -- two
-// dependent round trips and 2-3 sectors instead of eight and ~5; the build is bound by exactly those (5.8 G look-ups, 2.9 TB/s of
-// sector fetches at configs[2]).
-__global__ void ext_bucket_index_kernel(const uint64_t* __restrict__ tkeys, const uint64_t* __restrict__ boff, uint64_t n_buckets,
-                                        unsigned long long* __restrict__ recs, uint32_t* __restrict__ too_big) {
-  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= n_buckets) return;
-  const uint64_t lo = boff[b], n = boff[b + 1] - lo;
-  if (n >= (1ULL << 20)) { atomicExch(too_big, 1u); return; }
-  unsigned long long* r = recs + b * 8;
-  r[0] = (lo << 20) | n;
-  for (uint64_t i = 0; i < 7; i++) r[1 + i] = n ? tkeys[lo + ((i + 1) * n) / 8] : ~0ULL;
-}
-__device__ __forceinline__ int64_t ext_find_indexed(const uint64_t* __restrict__ tkeys, const unsigned long long* __restrict__ recs, int bits,
-                                                    uint64_t key) {
-  const ulonglong2* r = (const ulonglong2*)(recs + (uint64_t)shn_bucket_of(key, bits) * 8);
-  const ulonglong2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
-  const uint64_t lo = r0.x >> 20, n = r0.x & 0xFFFFFULL;
-  if (!n) return -1;
-  const uint32_t j = (uint32_t)(key >= r0.y) + (key >= r1.x) + (key >= r1.y) + (key >= r2.x) + (key >= r2.y) + (key >= r3.x) + (key >= r3.y);
-  uint64_t a = lo + ((uint64_t)j * n) / 8, e = lo + ((uint64_t)(j + 1) * n) / 8;
-  while (a < e) {
-    const uint64_t mid = (a + e) >> 1;
-    const uint64_t v = tkeys[mid];
-    if (v == key) return (int64_t)mid;
-    if (v < key) a = mid + 1; else e = mid;
-  }
-  return -1;
-}
-
-// ---- and a blocked Bloom filter in front of that: ~70 % of the look-ups of the adjacency build miss (a k1-mer has 8 possible
-// neighbours and typically 2), and a miss costs the record and the keys (2-3 sectors) like a hit.  One 64-bit word per key,
-// three bits in it, 16 bits of filter per key: a miss is one 8-byte load with probability ~0.99.
-__device__ __forceinline__ void bloom_pos(uint64_t key, uint64_t n_words, uint64_t& word, unsigned long long& mask) {
-  const uint64_t h = shn_mix64(key ^ 0x51A7C0DE5EEDULL);
-  word = (h >> 24) % n_words;
-  mask = (1ULL << (h & 63)) | (1ULL << ((h >> 6) & 63)) | (1ULL << ((h >> 12) & 63));
-}
-__global__ void ext_bloom_build_kernel(const uint64_t* __restrict__ tkeys, const uint8_t* __restrict__ flags, uint64_t n,
-                                       unsigned long long* __restrict__ bits, uint64_t n_words) {
+// ---- the dictionary of the adjacency build: one 128-byte line per bucket -- ten keys (80 bytes), their ten id words (40 bytes),
+// the number of keys that hashed here (4 bytes) -- so that a look-up, hit or miss, is ONE fetch.  HBM serves 128 bytes per request
+// whatever is asked for (profiles/r03_fetch_calibration.txt), and the build makes 5.8 G look-ups at configs[2] of which 70 % miss:
+// through the count table (bucket offsets -> bisection of a ~90-key bucket) a look-up was ~5 fetches, with a Bloom filter and a
+// separator record per bucket in front (round 2) 1 for most misses and 3 for a hit -- 1.5 TB per launch, the kernel sat at the
+// HBM limit.  Five keys per line on average: a bucket overflows with probability 1.4 %; what does not fit is found through the
+// count table (the line's count says that there is more).  id word = table index | palindrome << 31; low-complexity k1-mers are
+// not entered (load_kmers drops them, extension_correction.py:202-221).  An empty slot holds key 0 = AAA...A, which is
+// low-complexity and therefore never a valid answer.
+#define FD_SLOTS 10
+#define FD_PER_LINE 5
+#define FD_PAL 0x80000000u
+// (the hash of the count table's buckets, so that the build -- which goes through the table in bucket order -- fills the lines
+// front to back: its atomics stay in the L2 and the lines stream out once; with a hash of its own the build was 724 M random
+// read-modify-writes, 70 ms)
+__device__ __forceinline__ uint64_t fd_bucket(uint64_t key, uint64_t n_lines) { return __umul64hi(shn_mix64(key), n_lines); }
+__global__ void fd_build_kernel(const uint64_t* __restrict__ tkeys, const uint8_t* __restrict__ flags, uint64_t n,
+                                unsigned long long* __restrict__ lines, uint64_t n_lines) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || (flags[i] & 2)) return;
-  uint64_t word; unsigned long long mask;
-  bloom_pos(tkeys[i], n_words, word, mask);
-  atomicOr(&bits[word], mask);                                   // (the three bits of a key share one word: one atomic per key)
+  if (i >= n) return;
+  const uint8_t f = flags[i];
+  if (f & 2) return;
+  const uint64_t key = tkeys[i];
+  unsigned long long* line = lines + fd_bucket(key, n_lines) * 16;
+  const uint32_t slot = atomicAdd((uint32_t*)line + 30, 1u);
+  if (slot < FD_SLOTS) { line[slot] = key; ((uint32_t*)line)[20 + slot] = (uint32_t)i | ((f & 1) ? FD_PAL : 0u); }
 }
-__device__ __forceinline__ bool bloom_may_have(const unsigned long long* __restrict__ bits, uint64_t n_words, uint64_t key) {
-  uint64_t word; unsigned long long mask;
-  bloom_pos(key, n_words, word, mask);
-  return (bits[word] & mask) == mask;
+// One look-up by the eight lanes g0 .. g0+7 of a wavefront (p = lane - g0; all eight pass the same key): lane p holds bytes
+// 16 p .. 16 p + 15 of the line -- one coalesced 128-byte request.  Returns the id word or 0xFFFFFFFF, the same in all eight lanes.
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t x, int src) {
+  return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(x >> 32), src, 64) << 32) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)x, src, 64);
+}
+__device__ __forceinline__ ulonglong2 fd_load(const unsigned long long* __restrict__ lines, uint64_t n_lines, uint64_t key, int p) {
+  return ((const ulonglong2*)(lines + fd_bucket(key, n_lines) * 16))[p];
+}
+__device__ __forceinline__ uint32_t fd_match(const ulonglong2 v, uint64_t key, int p, int g0, const uint64_t* __restrict__ tkeys,
+                                             const uint64_t* __restrict__ boff, int bits, const uint8_t* __restrict__ flags) {
+  const bool ok = p < 5 && key != 0;
+  const unsigned long long m0 = (__ballot(ok && v.x == key) >> g0) & 0xFFULL, m1 = (__ballot(ok && v.y == key) >> g0) & 0xFFULL;
+  if (m0 | m1) {
+    const int slot = m0 ? 2 * (__ffsll((long long)m0) - 1) : 2 * (__ffsll((long long)m1) - 1) + 1;
+    // id words: bytes 80 .. 119 = words 20 .. 29: lane 5 + slot / 4, its word slot % 4
+    const uint32_t w = (slot & 2) ? ((slot & 1) ? (uint32_t)(v.y >> 32) : (uint32_t)v.y) : ((slot & 1) ? (uint32_t)(v.x >> 32) : (uint32_t)v.x);
+    return (uint32_t)__shfl((int)w, g0 + 5 + (slot >> 2), 64);
+  }
+  const uint32_t cnt = (uint32_t)__shfl((int)(uint32_t)(v.y >> 0), g0 + 7, 64) ;   // word 30 = low half of lane 7's second word
+  if (cnt <= FD_SLOTS || key == 0) return 0xFFFFFFFFu;
+  const int64_t j = shn_table_find(tkeys, boff, bits, key);        // (the bucket overflowed: rare)
+  if (j < 0) return 0xFFFFFFFFu;
+  const uint8_t fj = flags[j];
+  return (fj & 2) ? 0xFFFFFFFFu : ((uint32_t)j | ((fj & 1) ? FD_PAL : 0u));
 }
 
 // The records of both orientations of every canonical k1-mer from 8 look-ups instead of 16: the right candidates of the reverse-
 // complement orientation are the reverse complements of the forward orientation's left candidates (rc(s)[1:] + b = rc(comp(b) +
 // s[:-1])) and vice versa -- the same table entry j, the other orientation (the same one if entry j is its own reverse
-// complement).  Two threads per canonical k1-mer (one per direction, four look-ups each); they exchange their halves by shuffle
-// and each writes one whole 64-byte record (four 16-byte stores, 4 KB contiguous per wavefront).
+// complement).  Eight lanes per canonical k1-mer: they make its eight look-ups together, one after the other (every look-up one
+// 128-byte request of the eight lanes, all eight requests in flight before the first is looked at), and then write the two
+// records -- 128 contiguous bytes -- 16 bytes each.
 struct __attribute__((aligned(16))) Quad { uint32_t a, b, c, d; };
-// One thread per (canonical k1-mer, direction, base) -- eight look-ups side by side, as many independent round trips in flight as
-// the chip takes -- then the eight lanes of a k1-mer hand their results to two of them by shuffle, and those write one whole
-// 64-byte record each (four 16-byte stores).  (Two threads per k1-mer with four look-ups each were 20 % slower: the bisections of
-// a thread's hits run one after the other.)
 __global__ void ext_records_kernel(const uint64_t* __restrict__ tkeys, const uint64_t* __restrict__ boff, int bits,
                                    const uint8_t* __restrict__ flags, const uint32_t* __restrict__ weight, uint64_t n, int k, int canonical,
-                                   Rec* __restrict__ rec, const unsigned long long* __restrict__ recs,
-                                   const unsigned long long* __restrict__ bloom, uint64_t bloom_blocks) {
+                                   Rec* __restrict__ rec, const unsigned long long* __restrict__ lines, uint64_t n_lines) {
   const uint64_t total = n * 8;
-  const uint64_t rounded = (total + 63) & ~63ULL;                       // whole wavefronts take part in the shuffles
+  const uint64_t rounded = (total + 63) & ~63ULL;                       // whole wavefronts take part in the ballots and shuffles
   const uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
-  const int lane = threadIdx.x & 63, g0 = lane & ~7;
+  const int lane = threadIdx.x & 63, g0 = lane & ~7, p = lane & 7;
   for (uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < rounded; gid += (uint64_t)gridDim.x * blockDim.x) {
     const bool in = gid < total;
-    const uint32_t b = gid & 3;
-    const uint32_t dir = (gid >> 2) & 1;
     const uint64_t i = in ? gid >> 3 : 0;
     const uint8_t f = in ? flags[i] : (uint8_t)2;
     const bool dead0 = (f & 2) != 0;                                    // forward orientation
     const bool dead1 = dead0 || (f & 1) || !canonical;                  // reverse-complement orientation (absent for palindromes)
-    int32_t res = -1, der = -1;
-    if (!dead0) {
-      const uint64_t str = tkeys[i];
-      const uint64_t nb = dir == 0 ? (((str << 2) | b) & mask) : ((str >> 2) | ((uint64_t)b << (2 * (k - 1))));
-      uint64_t canon = nb;
-      uint32_t strand = 0;
-      if (canonical) { const uint64_t rc = shn_revcomp(nb, k); if (rc < nb) { canon = rc; strand = 1; } }
-      const int64_t j = (bloom && !bloom_may_have(bloom, bloom_blocks, canon)) ? -1
-                        : recs ? ext_find_indexed(tkeys, recs, bits, canon) : shn_table_find(tkeys, boff, bits, canon);
-      if (j >= 0) {
-        const uint8_t fj = flags[j];
-        if (!(fj & 2)) {
-          res = (int32_t)(2 * j + strand);
-          der = (fj & 1) ? res : (int32_t)(2 * j + (1 - strand));        // the candidate's other orientation
-        }
-      }
+    const uint64_t str = tkeys[i];
+    // look-up q: q = 0..3 append base q, q = 4..7 prepend base q - 4; lane q prepares it (key, strand, line), the group shares
+    uint64_t mykey; uint32_t mystrand = 0;
+    {
+      const uint64_t b = (uint64_t)(p & 3);
+      mykey = p < 4 ? (((str << 2) | b) & mask) : ((str >> 2) | (b << (2 * (k - 1))));
+      if (canonical) { const uint64_t rc = shn_revcomp(mykey, k); if (rc < mykey) { mykey = rc; mystrand = 1; } }
+      if (dead0) mykey = 0;                                             // (no look-up is needed: key 0 is never found)
     }
-    // lanes g0 .. g0+3: direction 0 (append), bases 0..3; lanes g0+4 .. g0+7: direction 1 (prepend)
-    int32_t r8[8], d8[8];
+    const uint64_t myline = fd_bucket(mykey, n_lines);
+    const uint32_t strands = (uint32_t)((__ballot(mystrand != 0) >> g0) & 0xFFULL);
+    uint64_t key[8];
+    ulonglong2 v[8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) { r8[q] = __shfl(res, g0 + q, 64); d8[q] = __shfl(der, g0 + q, 64); }
-    if (!in || b != 0) continue;
-    Quad q0, q1;
-    uint64_t o;
-    if (dir == 0) {                    // the forward record: right row = the append candidates, left row = the prepend candidates
-      o = 2 * i;
-      q0 = Quad{(uint32_t)r8[0], (uint32_t)r8[1], (uint32_t)r8[2], (uint32_t)r8[3]};
-      q1 = Quad{(uint32_t)r8[4], (uint32_t)r8[5], (uint32_t)r8[6], (uint32_t)r8[7]};
-    } else {                           // the reverse-complement record: both rows from the other orientations, mirrored (base b <-> 3 - b)
-      o = 2 * i + 1;
-      if (dead1) { q0 = Quad{~0u, ~0u, ~0u, ~0u}; q1 = q0; }
-      else {
-        q0 = Quad{(uint32_t)d8[7], (uint32_t)d8[6], (uint32_t)d8[5], (uint32_t)d8[4]};          // its right row: the prepend candidates' other orientations
-        q1 = Quad{(uint32_t)d8[3], (uint32_t)d8[2], (uint32_t)d8[1], (uint32_t)d8[0]};          // its left row: the append candidates' other orientations
-      }
+    for (int q = 0; q < 8; q++) {
+      key[q] = shfl_u64(mykey, g0 + q);
+      v[q] = ((const ulonglong2*)(lines + shfl_u64(myline, g0 + q) * 16))[p];
     }
-    Quad* dst = (Quad*)(rec + o);
-    dst[0] = q0; dst[1] = q1;
-    dst[2] = Quad{weight[i], NOHINT_WORD, 0xFFFFFFFFu, 0u};
-    dst[3] = Quad{0u, 0u, 0u, 0u};
+    uint32_t r8[8], d8[8];                                              // the candidate (oriented id), its other orientation
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const uint32_t w = fd_match(v[q], key[q], p, g0, tkeys, boff, bits, flags);
+      if (w == 0xFFFFFFFFu) { r8[q] = d8[q] = 0xFFFFFFFFu; continue; }
+      const uint32_t j = w & ~FD_PAL;
+      const uint32_t st = (strands >> q) & 1u;
+      r8[q] = 2 * j + st;
+      d8[q] = (w & FD_PAL) ? r8[q] : 2 * j + (1 - st);
+    }
+    if (!in) continue;
+    // lane p writes bytes 16 p .. of the pair of records (forward, reverse complement)
+    Quad out;
+    const Quad none = Quad{~0u, ~0u, ~0u, ~0u};
+    switch (p) {
+      case 0: out = Quad{r8[0], r8[1], r8[2], r8[3]}; break;           // forward: right row = the append candidates
+      case 1: out = Quad{r8[4], r8[5], r8[6], r8[7]}; break;           //          left row = the prepend candidates
+      case 4: out = dead1 ? none : Quad{d8[7], d8[6], d8[5], d8[4]}; break;   // reverse complement: right row = the prepend candidates' other orientations, mirrored (base b <-> 3 - b)
+      case 5: out = dead1 ? none : Quad{d8[3], d8[2], d8[1], d8[0]}; break;   //                     left row = the append candidates' ...
+      case 2: case 6: out = Quad{weight[i], NOHINT_WORD, 0xFFFFFFFFu, 0u}; break;
+      default: out = Quad{0u, 0u, 0u, 0u}; break;
+    }
+    ((Quad*)(rec + 2 * i))[p] = out;
   }
 }
 
@@ -280,27 +274,44 @@ __device__ __forceinline__ void cc_unite(uint32_t* lab, uint32_t u, uint32_t v) 
 // besides adjacent k1-mers those are k1-mers with the same K-suffix (x.m, x'.m) or the same K-prefix (m.y, m.y') -- not adjacent,
 // and only joined through a common neighbour if that neighbour exists and is not low-complexity (a transcript's last K-mer before
 // a poly-A tail is the typical exception).  So the labelling also unites every k1-mer with its (up to six) siblings.
-// Look-ups as in the records kernel: Bloom filter, then the bucket's separator record.
+// Look-ups as in the records kernel: eight lanes per canonical k1-mer, through the one-line dictionary.
 __global__ void cc_edges_kernel(const uint64_t* __restrict__ tkeys, const uint64_t* __restrict__ boff, int bits, const uint8_t* __restrict__ flags,
-                                uint64_t n, int k, int canonical, uint32_t* lab, const unsigned long long* __restrict__ recs,
-                                const unsigned long long* __restrict__ bloom, uint64_t bloom_blocks) {
+                                uint64_t n, int k, int canonical, uint32_t* lab, const unsigned long long* __restrict__ lines, uint64_t n_lines) {
   const uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
-  for (uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < n * 16; gid += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t i = gid >> 4;
-    const uint32_t which = (uint32_t)(gid & 15);
-    if (flags[i] & 2) continue;
+  const uint64_t total = n * 8, rounded = (total + 63) & ~63ULL;
+  const int lane = threadIdx.x & 63, g0 = lane & ~7, p = lane & 7;
+  for (uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < rounded; gid += (uint64_t)gridDim.x * blockDim.x) {
+    const bool in = gid < total;
+    const uint64_t i = in ? gid >> 3 : 0;
+    const bool dead = !in || (flags[i] & 2);
     const uint64_t str = tkeys[i];
-    const uint32_t b = which & 3;
-    uint64_t other;
-    if (which < 8) other = (which & 4) ? ((str >> 2) | ((uint64_t)b << (2 * (k - 1)))) : (((str << 2) | b) & mask);
-    else if (which & 4) { if ((str & 3) == b) continue; other = (str & ~3ULL) | b; }
-    else { const int sh = 2 * (k - 1); if (((str >> sh) & 3) == b) continue; other = (str & ~(3ULL << sh)) | ((uint64_t)b << sh); }
-    uint64_t canon = other;
-    if (canonical) { const uint64_t rc = shn_revcomp(other, k); if (rc < other) canon = rc; }
-    if (bloom && !bloom_may_have(bloom, bloom_blocks, canon)) continue;
-    const int64_t j = recs ? ext_find_indexed(tkeys, recs, bits, canon) : shn_table_find(tkeys, boff, bits, canon);
-    if (j < 0 || (flags[j] & 2) || (uint64_t)j == i) continue;
-    cc_unite(lab, (uint32_t)i, (uint32_t)j);
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      uint64_t mykey;
+      {
+        const uint64_t b = (uint64_t)(p & 3);
+        bool skip = dead;
+        if (half == 0) mykey = (p & 4) ? ((str >> 2) | (b << (2 * (k - 1)))) : (((str << 2) | b) & mask);
+        else if (p & 4) { skip |= (str & 3) == b; mykey = (str & ~3ULL) | b; }
+        else { const int sh = 2 * (k - 1); skip |= ((str >> sh) & 3) == b; mykey = (str & ~(3ULL << sh)) | (b << sh); }
+        if (canonical) { const uint64_t rc = shn_revcomp(mykey, k); if (rc < mykey) mykey = rc; }
+        if (skip) mykey = 0;
+      }
+      const uint64_t myline = fd_bucket(mykey, n_lines);
+      uint64_t key[8];
+      ulonglong2 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        key[q] = shfl_u64(mykey, g0 + q);
+        v[q] = ((const ulonglong2*)(lines + shfl_u64(myline, g0 + q) * 16))[p];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const uint32_t w = fd_match(v[q], key[q], p, g0, tkeys, boff, bits, flags);
+        // (lane q of the group does the union: eight independent ones side by side)
+        if (w != 0xFFFFFFFFu && p == q && (uint64_t)(w & ~FD_PAL) != i) cc_unite(lab, (uint32_t)i, w & ~FD_PAL);
+      }
+    }
   }
 }
 __global__ void cc_flatten_kernel(uint32_t* lab, uint64_t n) {
@@ -1232,22 +1243,21 @@ __global__ void shard_offsets_kernel(const uint64_t* __restrict__ boff, uint64_t
   if (b <= n_buckets) oboff[b] = pos[boff[b]];        // pos has n+1 entries: pos[n] = number of selected k1-mers
 }
 
-static int build_lookup_aids(shn_ctx* ctx, const shn_table* t, const uint8_t* d_flags, unsigned long long** recs_out, unsigned long long** bloom_out,
-                             uint64_t* bloom_blocks_out);
+static int build_fine_dict(shn_ctx* ctx, const shn_table* t, const uint8_t* d_flags, unsigned long long** lines_out, uint64_t* n_lines_out);
 static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank, shn_table** out) {
   hipStream_t s = ctx->stream;
   const uint64_t n = t->n;
   uint32_t* d_weight = nullptr; uint8_t* d_flags = nullptr;
-  unsigned long long *recs = nullptr, *bloom = nullptr;
-  uint64_t bloom_blocks = 0;
+  unsigned long long* lines = nullptr;
+  uint64_t n_lines = 0;
   shn_table* sub = nullptr;
-  auto cleanup = [&]() { if (d_weight) shn_dev_free(d_weight); if (d_flags) shn_dev_free(d_flags); if (recs) shn_dev_free(recs); if (bloom) shn_dev_free(bloom); };
+  auto cleanup = [&]() { if (d_weight) shn_dev_free(d_weight); if (d_flags) shn_dev_free(d_flags); if (lines) shn_dev_free(lines); };
 #define TRYS(x) do { hipError_t _e = (x); if (_e != hipSuccess) { cleanup(); if (sub) shn_table_destroy(sub); \
       return shn_fail(SHN_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(_e)); } } while (0)
   TRYS(shn_dev_malloc(&d_weight, (n + 1) * 4));
   TRYS(shn_dev_malloc(&d_flags, n + 1));
   hipLaunchKernelGGL(ext_prepare_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, t->d_counts, n, t->k, t->canonical, d_weight, d_flags);
-  { int rca = build_lookup_aids(ctx, t, d_flags, &recs, &bloom, &bloom_blocks); if (rca) { cleanup(); return rca; } }
+  { int rca = build_fine_dict(ctx, t, d_flags, &lines, &n_lines); if (rca) { cleanup(); return rca; } }
   void *pl, *po, *pz, *pb, *pc, *pp;
   const uint32_t big_cap = 1u << 16;
   int rc;
@@ -1261,8 +1271,8 @@ static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank
   TRYS(hipMemsetAsync(d_cnt, 0, 2048, s));
   hipLaunchKernelGGL(cc_init_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, d_lab, n);
   { TimerRegion t1(ctx, T_EXT_PREP);
-    hipLaunchKernelGGL(cc_edges_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 16, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off, t->bits,
-                       d_flags, n, t->k, t->canonical, d_lab, (const unsigned long long*)recs, (const unsigned long long*)bloom, bloom_blocks); }
+    hipLaunchKernelGGL(cc_edges_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off, t->bits,
+                       d_flags, n, t->k, t->canonical, d_lab, (const unsigned long long*)lines, n_lines); }
   hipLaunchKernelGGL(cc_flatten_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, d_lab, n);
   TRYS(hipMemsetAsync(d_size, 0, (n + 1) * 4, s));
   hipLaunchKernelGGL(cc_sample_kernel, dim3((uint32_t)cdiv(cdiv(n, 64), 256)), dim3(256), 0, s, d_lab, n, d_size);
@@ -1314,36 +1324,17 @@ static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank
   return SHN_OK;
 }
 
-// the aids of the table look-ups of the records / labelling kernels: a separator record per bucket (large tables; see
-// ext_find_indexed; SHN_EXT_BUCKET_INDEX=0 / 1 forbids / forces it) and a Bloom filter in front (SHN_EXT_BLOOM).  Either may
-// come back NULL; the caller frees both after the stream has drained.
-static int build_lookup_aids(shn_ctx* ctx, const shn_table* t, const uint8_t* d_flags, unsigned long long** recs_out, unsigned long long** bloom_out,
-                             uint64_t* bloom_blocks_out) {
+// the dictionary of the records / labelling kernels (see fd_build_kernel); the caller frees it after the stream has drained
+static int build_fine_dict(shn_ctx* ctx, const shn_table* t, const uint8_t* d_flags, unsigned long long** lines_out, uint64_t* n_lines_out) {
   hipStream_t s = ctx->stream;
   const uint64_t n = t->n;
-  unsigned long long* recs = nullptr;
-  uint32_t* d_big = nullptr;
-  const char* bi = getenv("SHN_EXT_BUCKET_INDEX");
-  const bool want_index = bi ? bi[0] != '0' : (n >= (1ULL << 24) && n / t->n_buckets >= 24);
-  if (want_index && shn_dev_malloc(&recs, t->n_buckets * 64) == hipSuccess && shn_dev_malloc(&d_big, 64) == hipSuccess) {
-    uint32_t big = 0;
-    hipError_t e = hipMemsetAsync(d_big, 0, 4, s);
-    hipLaunchKernelGGL(ext_bucket_index_kernel, dim3((uint32_t)cdiv(t->n_buckets, 256)), dim3(256), 0, s, t->d_keys, t->d_bucket_off, t->n_buckets, recs, d_big);
-    if (e == hipSuccess) e = hipMemcpyAsync(&big, d_big, 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) { shn_dev_free(recs); shn_dev_free(d_big); return shn_fail(SHN_ERR_HIP, std::string("build_lookup_aids: ") + hipGetErrorString(e)); }
-    if (big) { shn_dev_free(recs); recs = nullptr; }
-  } else if (recs) { shn_dev_free(recs); recs = nullptr; }
-  if (d_big) shn_dev_free(d_big);
-  unsigned long long* bloom = nullptr;
-  const uint64_t bloom_blocks = n / 4 + 1;             // 64-bit words: 16 bits per key
-  const char* bl = getenv("SHN_EXT_BLOOM");
-  if ((bl ? bl[0] != '0' : recs != nullptr) && shn_dev_malloc(&bloom, bloom_blocks * 8) == hipSuccess) {
-    hipError_t e = hipMemsetAsync(bloom, 0, bloom_blocks * 8, s);
-    if (e != hipSuccess) { shn_dev_free(recs); shn_dev_free(bloom); return shn_fail(SHN_ERR_HIP, std::string("build_lookup_aids: ") + hipGetErrorString(e)); }
-    hipLaunchKernelGGL(ext_bloom_build_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, d_flags, n, bloom, bloom_blocks);
-  }
-  *recs_out = recs; *bloom_out = bloom; *bloom_blocks_out = bloom_blocks;
+  const uint64_t n_lines = n / FD_PER_LINE + 1;
+  unsigned long long* lines = nullptr;
+  hipError_t e = shn_dev_malloc(&lines, n_lines * 128);
+  if (e == hipSuccess) e = hipMemsetAsync(lines, 0, n_lines * 128, s);
+  if (e != hipSuccess) { if (lines) shn_dev_free(lines); return shn_fail(SHN_ERR_HIP, std::string("build_fine_dict: ") + hipGetErrorString(e)); }
+  if (n) hipLaunchKernelGGL(fd_build_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, d_flags, n, lines, n_lines);
+  *lines_out = lines; *n_lines_out = n_lines;
   return SHN_OK;
 }
 
@@ -1406,13 +1397,13 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     hipLaunchKernelGGL(ext_prepare_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, t->d_counts, n, t->k,
                        t->canonical, e->d_weight, e->d_flags);
     {
-      unsigned long long *recs = nullptr, *bloom = nullptr;
-      uint64_t bloom_blocks = 0;
-      { int rca = build_lookup_aids(ctx, t, e->d_flags, &recs, &bloom, &bloom_blocks); if (rca) { shn_ext_destroy(e); return rca; } }
+      unsigned long long* lines = nullptr;
+      uint64_t n_lines = 0;
+      { int rca = build_fine_dict(ctx, t, e->d_flags, &lines, &n_lines); if (rca) { shn_ext_destroy(e); return rca; } }
       { TimerRegion ta(ctx, T_EXT_ADJ);                  // (one launch: bench.py's roofline entry for this kernel)
         hipLaunchKernelGGL(ext_records_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off,
-                           t->bits, e->d_flags, e->d_weight, n, t->k, t->canonical, e->d_rec, (const unsigned long long*)recs, (const unsigned long long*)bloom, bloom_blocks); }
-      if (recs || bloom) { TRYE(hipStreamSynchronize(s)); shn_dev_free(recs); shn_dev_free(bloom); }
+                           t->bits, e->d_flags, e->d_weight, n, t->k, t->canonical, e->d_rec, (const unsigned long long*)lines, n_lines); }
+      TRYE(hipStreamSynchronize(s)); shn_dev_free(lines);
     }
     TRYE(hipGetLastError());
   }
