@@ -133,6 +133,7 @@ static void decode_read(char* s, const uint8_t* p, uint64_t n, int enc, bool rc)
 }
 
 struct Graph {
+  bool laps = false;                        // print the time of every phase (SHN_DEBUG / SHN_GRAPH_LAPS)
   shn_ctx* ctx = nullptr;                   // non-NULL: K-mer seed scans run on the GPU (csrc/seeds.hip)
   int K, L, SIZE_THRESHOLD;
   std::vector<std::string> bases;
@@ -704,7 +705,7 @@ struct Graph {
   }
   void find_known_paths() {
     known_paths.clear();
-    const bool dbgk = getenv("SHN_DEBUG") != nullptr;
+    const bool dbgk = laps;
     auto nowk = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tk0 = nowk(), tk1 = 0, tk2 = 0, tk3 = 0;
     const uint64_t mask = K == 32 ? ~0ULL : ((1ULL << (2 * K)) - 1);
@@ -933,7 +934,7 @@ struct Graph {
   }
 
   int run() {
-    const bool dbg = getenv("SHN_DEBUG") != nullptr;
+    const bool dbg = laps;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
     auto lap = [&](const char* what) { if (dbg) { double t = now(); fprintf(stderr, "[mbgraph] %-22s %8.3f s  nodes=%zu reads=%zu\n", what, t - t0, order.size(), n_rd()); t0 = t; } };
@@ -1042,7 +1043,9 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
   const uint64_t read_len0 = !n_reads ? 0 : host_a ? src_a->fixed_len : (uint64_t)(r1_off[1] - r1_off[0]);
   g.L = n_reads ? (int)read_len0 : -1;
   g.SIZE_THRESHOLD = g.L;
-  const bool dbg = getenv("SHN_DEBUG") != nullptr;
+  // SHN_DEBUG: the laps of every partition; SHN_GRAPH_LAPS=n: of the partitions with at least n routed reads
+  const bool dbg = getenv("SHN_DEBUG") != nullptr || (getenv("SHN_GRAPH_LAPS") && n_reads >= strtoull(getenv("SHN_GRAPH_LAPS"), nullptr, 10));
+  g.laps = dbg;
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double tt = now();
   // origin of read slot j = i * nm + mate (mate 0 / 1) in the resident input, for the device gather of the distinct reads

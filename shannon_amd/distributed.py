@@ -19,10 +19,11 @@ The result equals the single-GPU pipeline on the concatenated reads.
 `ops` abstracts the per-rank compute (GpuOps: HIP kernels through the C ABI; the CPU tests plug
 an oracle-backed implementation to exercise the collective choreography with gloo).
 """
+from collections.abc import Mapping
 import numpy as np
 import torch
 import torch.distributed as dist
-from . import exchange, mbgraph, sparse_flow, post
+from . import exchange, mbgraph, sparse_flow, post, _lib
 
 
 def _all_gather_var(t, group=None, name="table all-gather (owned k1-mer shards)"):
@@ -90,7 +91,7 @@ class _NoLock(object):
 
 def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0, part_vectors=None, group=None,
                          timings=None, lock=None):
-    """Returns on rank 0 a dict {partitions: {name: fasta}, all_reconstructed, final, contigs}; None elsewhere.
+    """Returns on rank 0 a dict {partitions: {name: fasta}, final, contigs, ...}; None elsewhere.
     timings: seconds per stage, compute ("count", "extension", ...) and collectives ("x:...") apart.
     lock (development aid): held while this rank computes, released around every collective -- with several ranks on
     ONE GPU it serialises the compute, so the per-stage compute times are those of a rank that has a GPU to itself."""
@@ -181,7 +182,12 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
         rf, rr = np.asarray(r[:keep_f], dtype=np.int64), np.asarray(r[f:f + keep_r], dtype=np.int64)
         sel = np.concatenate([rf, rr])
         gidx = np.concatenate([base + rf, n_glob + base + (rr - n_local)])
-        payload[int(owner[i])].append((i, gidx, ops.collect(sel)))
+        if int(owner[i]) == rank and getattr(ops, "resident_rows", False) and int(allc[:, i, :].sum()) == int(cnt[i].sum()):
+            # every routed read of this partition is a row of this rank's own resident input, and this rank owns the partition:
+            # nothing is collected -- the graph stage names the reads by their rows, as the single-GPU pipeline does
+            payload[rank].append((i, gidx, LocalRows(sel)))
+        else:
+            payload[int(owner[i])].append((i, gidx, ops.collect(sel)))
     tick("collect reads", t0)
     lock.release()
     t0 = time.time()
@@ -210,7 +216,7 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
             texts, err = {}, "%s: %s" % (type(ex).__name__, ex)
         if texts is not None:
             lock.release()
-            return _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick, error=err)
+            return _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick, error=err, ops=ops)
 
     def one(i):
         singles, comps = ops.graph(part, names[i], mine.get(i, []), K, paired)      # pieces: [(global indices, reads)] per source rank
@@ -240,38 +246,90 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
         texts[i] = txt
     tick("sparse flow", t0)
     lock.release()
-    return _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick)
+    return _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick, ops=ops)
 
 
-def _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick, error=None):
+class LocalRows(object):
+    """the reads of a partition as doubled read indices into the owner's own resident input (no rows collected)"""
+    def __init__(self, sel):
+        self.sel = np.ascontiguousarray(sel, dtype=np.uint32)
+
+    def __len__(self):
+        return len(self.sel)
+
+
+class _Texts(Mapping):
+    """{partition name: reconstructed FASTA}; the texts stay the byte arrays they arrived as until somebody reads one"""
+    def __init__(self, names, arrays):
+        self._names, self._a = list(names), dict(zip(names, arrays))
+
+    def __getitem__(self, k):
+        return bytes(memoryview(self._a[k])).decode()
+
+    def __iter__(self):
+        return iter(self._names)
+
+    def __len__(self):
+        return len(self._names)
+
+
+def _as_bytes(t):
+    return np.frombuffer(t.encode(), dtype=np.uint8) if isinstance(t, str) else np.ascontiguousarray(t, dtype=np.uint8)
+
+
+def _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick, error=None, ops=None):
     """the per-partition FASTA of every owner to rank 0, which merges (shannon.py:584-604).  error: what went wrong in this rank's
     graph stage, if anything -- it travels with the gather, so every rank raises together and none is left waiting."""
     import time
     t0 = time.time()
-    gathered = exchange.all_gather_object({"error": error, "texts": texts}, group, "FASTA gather (per-partition transcripts to rank 0)")
-    tick("x:gather fasta", t0)
-    errors = ["rank %d: %s" % (r, d["error"]) for r, d in enumerate(gathered) if d["error"]]
+    # what went wrong, if anything (a few bytes per rank); then the texts as bytes to rank 0 -- what rank 0 produced itself stays put
+    errs = exchange.all_gather_object(error, group, "FASTA gather (status of the ranks)")
+    errors = ["rank %d: %s" % (r, e) for r, e in enumerate(errs) if e]
     if errors:
+        tick("x:gather fasta", t0)
         raise RuntimeError("graph stage failed on " + "; ".join(errors))
-    gathered = [d["texts"] for d in gathered]
+    mine = {int(i): _as_bytes(t) for i, t in texts.items()}
+    merged = {}
+    if W > 1:
+        if rank != 0:
+            idx = sorted(mine)
+            head = np.asarray([len(idx)] + [v for i in idx for v in (i, mine[i].size)], dtype=np.int64).view(np.uint8)
+            out = np.concatenate([head] + [mine[i] for i in idx])
+        bufs = [out if (d == 0 and rank != 0) else np.zeros(0, np.uint8) for d in range(W)]
+        got = exchange.all_to_all_bytes(bufs, getattr(ops, "device", None), group, "FASTA gather (per-partition transcripts to rank 0)")
+        if rank == 0:
+            for src, b in enumerate(got):
+                if src == 0 or b.size == 0:
+                    continue
+                n = int(b[:8].view(np.int64)[0])
+                head = b[8:8 + 16 * n].view(np.int64).reshape(n, 2)
+                pos = 8 + 16 * n
+                for i, sz in head.tolist():
+                    merged[int(i)] = b[pos:pos + sz]
+                    pos += sz
+    tick("x:gather fasta", t0)
     if rank != 0:
         return None
     lock.acquire()
     t0 = time.time()
-    merged = {}
-    for d in gathered:
-        merged.update(d)
-    lines = []
-    for i, c in enumerate(res.single_contigs):
-        lines += [">Single_%d\n" % i, c + "\n"]
-    parts = {}
-    for i, nm in enumerate(names):
-        parts[nm] = merged[i]
-        lines += merged[i].splitlines(True)
-    final = post.finalize(lines, True)
+    merged.update(mine)
+    single = "".join(">Single_%d\n%s\n" % (i, c) for i, c in enumerate(res.single_contigs))
+    order = [merged[i] for i in range(len(names))]
+    # the merge over the texts as they are (process_concatenated_fasta.py + faster_reps.py: post.finalize_texts, on the device when
+    # the ops have a context); transcripts with characters outside ACGT go through the Python form
+    try:
+        final = post.finalize_texts([single] + order, True, ctx=getattr(ops, "ctx", None))
+    except _lib.ShannonError as ex:
+        if "non-ACGT" not in str(ex) and "empty line" not in str(ex):
+            raise
+        lines = single.splitlines(True)
+        for a in order:
+            lines += bytes(memoryview(a)).decode().splitlines(True)
+        final = post.finalize(lines, True)
+    parts = _Texts(names, order)
     tick("merge (rank 0)", t0)
     lock.release()
-    return {"partitions": parts, "all_reconstructed": lines, "final": final, "contigs": res.contigs,
+    return {"partitions": parts, "final": final, "contigs": res.contigs,
             "n_k1mers": int(gk.numel()),
             "extension": {k: getattr(res, k, None) for k in ("iterations", "n_walks", "total_steps", "wave_steps")}}
 
@@ -323,6 +381,15 @@ class GpuOps(object):
 
     graph_threads = 8
     sharded_extension = True
+
+    @property
+    def resident_rows(self):
+        """a partition whose routed reads are all rows of this rank's resident input is handed to the graph stage by rows"""
+        def _matrix(m):
+            return isinstance(m, np.ndarray) and m.dtype == np.uint8 and m.ndim == 2 and m.flags["C_CONTIGUOUS"]
+        import os
+        return (self.unitigs is not None and _matrix(getattr(self.store, "r1", None)) and (not self.paired or _matrix(getattr(self.store, "r2", None)))
+                and os.environ.get("SHN_GRAPH_ROWS", "1") != "0")
     array_payload = True               # collect() returns (code rows, strand flags): travels as bytes, not as pickles
 
     def extension(self, table, partition_size, group=None):
@@ -415,10 +482,16 @@ class GpuOps(object):
         up = threading.Lock()
 
         def one(i):
-            rows, rc1 = self._merge_pieces(mine.get(i, []))
+            pieces = mine.get(i, [])
+            local = pieces[0][1] if (len(pieces) == 1 and isinstance(pieces[0][1], LocalRows)) else None
+            rows, rc1 = (np.zeros((0, 1), np.uint8), np.zeros(0, np.uint8)) if local is not None else self._merge_pieces(pieces)
             rb = None
             for _attempt in (0, 1):
                 try:
+                    if local is not None and len(local):
+                        # this rank's own reads, named by their rows in its resident input (as pipeline.assemble_resident does)
+                        return mbgraph_native.run_partition_rows(self.ctx, self.unitigs, i, self.d1, self.d2 if paired else None, self.store.r1,
+                                                                 self.store.r2 if paired else None, local.sel, rb, 0 if rb is None else len(rb) // (K + 1))
                     if len(rows) == 0:
                         z, o = np.zeros(1, np.uint8), np.zeros(1, np.uint64)
                         return mbgraph_native.run_partition_handle(rb, 0 if rb is None else len(rb) // (K + 1), K, z, o, z if paired else None,
@@ -449,7 +522,7 @@ class GpuOps(object):
                     graphs.append(one(i))
             T["graph"] = T.get("graph", 0.0) + time.time() - t0
             t0 = time.time()
-            texts = mbgraph_native.sparse_flow_native(self.ctx, graphs, ["%s_%s" % (sample, names[i]) for i in owned], seed) if owned else []
+            texts = mbgraph_native.sparse_flow_native(self.ctx, graphs, ["%s_%s" % (sample, names[i]) for i in owned], seed, raw=True) if owned else []
             T["sparse flow"] = T.get("sparse flow", 0.0) + time.time() - t0
             return {i: txt for i, txt in zip(owned, texts)}
         finally:

@@ -28,7 +28,7 @@ def main():
     ops = distributed.GpuOps(ctx, d1, d2, kfc.ReadStore(q1, q2), 25)
     res = distributed.assemble_distributed(ops, 25, 500, "t", 1)
     if rank == 0:
-        json.dump({"partitions": res["partitions"], "final": res["final"], "contigs": res["contigs"]}, open(out, "w"))
+        json.dump({"partitions": dict(res["partitions"]), "final": res["final"], "contigs": res["contigs"]}, open(out, "w"))
     dist.barrier()
     d1.close()
     if d2 is not None:

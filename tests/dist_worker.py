@@ -129,7 +129,7 @@ def main():
         return
     res = distributed.assemble_distributed(ops, m["K"], psize, "s", m["sf_seed"], pv)
     if rank == 0:
-        json.dump({"partitions": res["partitions"], "final": res["final"], "contigs": res["contigs"]}, open(out, "w"))
+        json.dump({"partitions": dict(res["partitions"]), "final": res["final"], "contigs": res["contigs"]}, open(out, "w"))
     dist.destroy_process_group()
 
 

@@ -21,6 +21,7 @@ T.clear()
 pr = cProfile.Profile()
 t0 = time.time()
 pr.enable()
+os.environ["SHN_GRAPH_LAPS"] = os.environ.get("LAPS_MIN", "3000000")
 R = pipeline.assemble_resident(ctx, sets[0], sets[1], store, K=K, sample="bench", seed=1, timings=T, keep_partitioning=True)
 pr.disable()
 print("step %.3f s, %d transcripts" % (time.time() - t0, len(R.final)))
