@@ -399,13 +399,25 @@ struct WalkArgs {
   uint32_t* promo_list; unsigned long long* promo_count; uint32_t* res_cur; uint32_t* res_info;   // info = dir << 31 | steps so far
   uint32_t promote_steps;
   uint8_t* chunk;        // per 2^CHUNK_SHIFT oriented k1-mers: "a claim in here was written this round" (the mark pass visits only those)
+  uint8_t* robbed;       // per walk: a claim of its record is not (or no longer) its own -- see note_claim
 };
 
-// Claim `node` as step `pos` of walk r: atomic min on rank:pos, fire-and-forget (a returning atomic would put
-// a second memory round trip on every step; lost races are found after the round by ext_verify_kernel).
-__device__ __forceinline__ void claim_node(const WalkArgs& A, uint32_t node, uint32_t r, uint32_t pos) {
-  __hip_atomic_fetch_min(&A.claim[node], CLAIM(r, pos), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Claim `node` as step `pos` of walk r: atomic min on rank:pos.  Returns what stood there before; the caller hands it to note_claim
+// -- one step later in the thread walkers, where the answer has long arrived behind the loads of the next step (memory operations
+// of a wavefront return in issue order), so the atomic's round trip is on nobody's critical path.
+__device__ __forceinline__ u64 claim_node(const WalkArgs& A, uint32_t node, uint32_t r, uint32_t pos) {
+  const u64 old = __hip_atomic_fetch_min(&A.claim[node], CLAIM(r, pos), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (A.chunk) A.chunk[node >> CHUNK_SHIFT] = 1;
+  return old;
+}
+// What a claim found: a lower rank (it got there between this walk's look and its claim: the walk's record holds a k1-mer it does
+// not own) or a higher one (robbed: THAT walk's record is stale, if it ran this round -- one that sat out is found by the mark
+// pass through the snapshot).  Either way the walk has to run again: ext_verify_kernel reads the flags.  (Until round 3 the mark
+// pass counted the k1-mers every walk owned, one random atomic per claimed k1-mer, and the verify kernel compared the count with
+// the record.)
+__device__ __forceinline__ void note_claim(const WalkArgs& A, u64 old, uint32_t r) {
+  const uint32_t x = RANK(old);
+  if (x != UNCLAIMED && x != r) A.robbed[x < r ? r : x] = 1;
 }
 
 // One greedy decision (extension_correction.py:223-237): among the candidates that exist and are not
@@ -473,7 +485,7 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
     // snap: the pre-round snapshot; A.claim: live claims of this round
     bool isvoid = (!FRESH && RANK(snap[o]) < r) || RANK(__hip_atomic_load(&A.claim[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < r;
     if (!isvoid) {
-      claim_node(A, o, r, 0);
+      u64 seen = claim_node(A, o, r, 0);             // what the last claim found; looked at one step later
       tot = A.weight[o];
       uint32_t pos = 0, pend = NONE32;
       for (int dir = 0; dir < 2; dir++) {
@@ -495,8 +507,9 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
           // the claim of the step just taken goes out BEHIND the loads of this step: vector memory operations of a wavefront
           // return in issue order (one counter for loads, stores and atomics), so a claim issued in front of the loads would put
           // the latency of a memory-side atomic on every step of the walk -- and a bulk round lasts as long as its longest walk
+          u64 found = UNCLAIMED64;
           if (pend != NONE32) {
-            claim_node(A, pend, r, pos);
+            found = claim_node(A, pend, r, pos);
             pend = NONE32;
           }
           int best = -1;
@@ -504,6 +517,9 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
 #define CONSIDER(b) if (cand.v[b] >= 0 && RANK(cl[b]) > r && RANK(cf[b]) >= r && (best < 0 || w[b] > bw)) { best = b; bw = w[b]; }
           CONSIDER(0) CONSIDER(2) CONSIDER(1) CONSIDER(3)
 #undef CONSIDER
+          // (what the claim BEFORE this step's found: it was issued in front of this step's loads, which have just been used)
+          note_claim(A, seen, r);
+          seen = found;
           if (best < 0) break;
           // (selected with compares, not indexed: a run-time index puts the rows into scratch memory -- 96 bytes per lane of private
           // memory traffic on every step)
@@ -513,7 +529,8 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
           steps++;
           tot += bw;
           if (pos >= A.promote_steps) {            // long after all: a wavefront takes over from here (memos, 64 steps a trip)
-            claim_node(A, nbest, r, pos);
+            note_claim(A, seen, r);
+            seen = claim_node(A, nbest, r, pos);
             pend = NONE32;
             A.res_cur[r] = nbest;
             A.res_info[r] = ((uint32_t)dir << 31) | pos;
@@ -525,12 +542,14 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
           for (int q = 0; q < 4; q++) cand.v[q] = best == 0 ? nxt[0].v[q] : best == 1 ? nxt[1].v[q] : best == 2 ? nxt[2].v[q] : nxt[3].v[q];   // (word by word: a select between structs goes through memory)
         }
         if (pend != NONE32) {                        // the last step of this direction
-          claim_node(A, pend, r, pos);
+          note_claim(A, seen, r);
+          seen = claim_node(A, pend, r, pos);
           pend = NONE32;
         }
         if (dir == 0) nr = steps; else nl = steps;
         if (promoted) break;
       }
+      note_claim(A, seen, r);
     }
     A.nr_out[r] = isvoid ? UNCLAIMED : nr;
     A.nl_out[r] = nl;
@@ -593,7 +612,7 @@ __global__ __launch_bounds__(WBLK) void ext_walk_refill_kernel(WalkArgs A, uint6
           const bool isvoid = (!FRESH && RANK(snap[o]) < r) || RANK(__hip_atomic_load(&A.claim[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < r;
           if (isvoid) { A.nr_out[r] = UNCLAIMED; A.nl_out[r] = 0; A.totw_out[r] = 0; }
           else {
-            claim_node(A, o, r, 0);
+            note_claim(A, claim_node(A, o, r, 0), r);
             tot = A.weight[o];
             pos = 0; steps = 0; nr = 0; dir = 0;
             cand = A.adjR[o];
@@ -633,7 +652,7 @@ __global__ __launch_bounds__(WBLK) void ext_walk_refill_kernel(WalkArgs A, uint6
       } else {
         const uint32_t nbest = (uint32_t)(best == 0 ? cand.v[0] : best == 1 ? cand.v[1] : best == 2 ? cand.v[2] : cand.v[3]);
         pos++;
-        claim_node(A, nbest, r, pos);
+        note_claim(A, claim_node(A, nbest, r, pos), r);
         steps++;
         mysteps++;
         tot += bw;
@@ -721,6 +740,7 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
   uint64_t tot;
   int dir0 = 0;
   uint32_t cur0 = o;
+  u64 seen = UNCLAIMED64;                     // per lane: what its last claim found, looked at when it claims again (note_claim)
   if (RESUME) {
     const uint32_t info = A.res_info[r];
     dir0 = (int)(info >> 31);
@@ -735,7 +755,7 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
       continue;
     }
     tot = A.weight[o];
-    if (lane == 0) claim_node(A, o, r, 0);
+    if (lane == 0) seen = claim_node(A, o, r, 0);
   }
   const uint32_t ns_start = ns;
   uint32_t nseq = 0;                          // sequential steps (debug statistics)
@@ -783,7 +803,8 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
         const uint32_t conf = min(m, nchunk);               // confirmed memo steps: lanes [0, conf)
         uint64_t myw = 0;
         if ((uint32_t)lane < conf) {
-          claim_node(A, mine, r, ns + lane + 1);
+          note_claim(A, seen, r);
+          seen = claim_node(A, mine, r, ns + lane + 1);
           myw = A.weight[mine];
         }
         for (int off = 32; off > 0; off >>= 1) myw += __shfl_xor(myw, off, 64);
@@ -835,7 +856,7 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
       cand.v[0] = __shfl(row.v[0], best, 64); cand.v[1] = __shfl(row.v[1], best, 64);
       cand.v[2] = __shfl(row.v[2], best, 64); cand.v[3] = __shfl(row.v[3], best, 64);
       have_cand = true;
-      if (lane == 0) claim_node(A, taken, r, ns + 1);
+      if (lane == 0) { note_claim(A, seen, r); seen = claim_node(A, taken, r, ns + 1); }
       tot += bw;
       ns++;
       nseq++;
@@ -845,6 +866,7 @@ __global__ __launch_bounds__(64) void ext_walk_long_kernel(WalkArgs A, const uin
     }
     if (dir == 0) nr_new = ns;
   }
+  note_claim(A, seen, r);
   if (A.dbg && lane == 0) {
     atomicMax(&A.dbg[10], ((unsigned long long)nseq << 48) | ((unsigned long long)min(why.c2, 4095u) << 36) |
                               ((unsigned long long)min(why.c4, 4095u) << 12) | (unsigned long long)min(why.c7, 4095u));
@@ -1004,7 +1026,7 @@ __global__ __launch_bounds__(1024) void ext_plan_kernel(const uint32_t* __restri
 // after the walkers: every walk that ran alive and is long enough gets a NEW memo slot for its new path (filled from
 // the claims by ext_mark_kernel); old slots stay as they are -- the hints of k1-mers the walk no longer owns still lead
 // to an intact path.  When the pool is full, no more memos are made (they only save time).
-__global__ void ext_memo_plan_kernel(uint8_t* __restrict__ ran, uint8_t* __restrict__ dirty, uint32_t* __restrict__ owned,
+__global__ void ext_memo_plan_kernel(uint8_t* __restrict__ ran, uint8_t* __restrict__ dirty,
                                      const uint32_t* __restrict__ nr, const uint32_t* __restrict__ nl, const uint32_t* __restrict__ order,
                                      uint32_t frozen, uint32_t limit, uint64_t* __restrict__ moff, uint32_t* __restrict__ mR,
                                      uint32_t* __restrict__ mL, uint8_t* __restrict__ mvalid, uint8_t* __restrict__ fill,
@@ -1014,7 +1036,6 @@ __global__ void ext_memo_plan_kernel(uint8_t* __restrict__ ran, uint8_t* __restr
   const uint8_t did_run = dirty[r];              // end-of-round bookkeeping: who ran, clean slate for the marks
   ran[r] = did_run;
   dirty[r] = 0;
-  owned[r] = 0;
   uint8_t f = 0;
   if (did_run && nr[r] != UNCLAIMED) {
     const uint32_t R = nr[r], L = nl[r];
@@ -1050,9 +1071,9 @@ __global__ void ext_round_begin_kernel(u64* __restrict__ claim, u64* __restrict_
 // after a round: every k1-mer whose owner changed dirties the walks that looked at it; the k1-mers of the walks
 // that got a memo slot are written into it (memo + hint)
 __global__ void ext_mark_kernel(const u64* __restrict__ claim, u64* claim_old, uint64_t n2, Rec* __restrict__ rec,
-                                uint8_t* __restrict__ dirty, const uint8_t* __restrict__ ran, uint32_t* __restrict__ owned,
+                                uint8_t* __restrict__ dirty, const uint8_t* __restrict__ ran,
                                 unsigned long long* __restrict__ n_changed, uint32_t frozen, uint32_t limit,
-                                const uint8_t* __restrict__ fill, const uint64_t* __restrict__ moff, const uint32_t* __restrict__ mR,
+                                const uint8_t* __restrict__ fill /* NULL: no walk got a memo slot this round */, const uint64_t* __restrict__ moff, const uint32_t* __restrict__ mR,
                                 uint32_t* __restrict__ pool,
                                 const uint32_t* __restrict__ nr_a, const uint32_t* __restrict__ nl_a, int precise,
                                 const uint8_t* __restrict__ chunk) {
@@ -1077,14 +1098,13 @@ __global__ void ext_mark_kernel(const u64* __restrict__ claim, u64* claim_old, u
     // precise marks read the snapshot only at y itself: bring it up to date here, and the next round's begin pass has nothing
     // to copy (8 of the 32 bytes the two passes move per k1-mer and round)
     if (precise && oy != cy) claim_old[y] = cy;
-    if (b >= frozen && b < limit && ran[b]) {                     // (only walks of the open block can have run)
-      atomicAdd(&owned[b], 1u);                                   // for ext_verify_kernel
-      if (fill[b]) {                                              // slot layout: see MemoCursor
-        const uint32_t pos = POS(cy), R = mR[b];
-        const uint64_t idx = moff[b] + (pos <= R ? 2 : 3) + pos;
-        if (pos) pool[idx] = (uint32_t)y;
-        rec[y].hint = (uint32_t)(idx << 2) | (pos == 0 ? HINT_SEED : pos <= R ? HINT_R : HINT_L);
-      }
+    // (only walks of the open block can have run; a walk that got a slot ran.  In a bulk round nobody gets one, and a claimed
+    // k1-mer whose owner did not change costs nothing beyond the two streams)
+    if (fill && b >= frozen && b < limit && fill[b]) {            // slot layout: see MemoCursor
+      const uint32_t pos = POS(cy), R = mR[b];
+      const uint64_t idx = moff[b] + (pos <= R ? 2 : 3) + pos;
+      if (pos) pool[idx] = (uint32_t)y;
+      rec[y].hint = (uint32_t)(idx << 2) | (pos == 0 ? HINT_SEED : pos <= R ? HINT_R : HINT_L);
     }
     if (a == b) return false;
     my_changed++;
@@ -1167,14 +1187,12 @@ __global__ void ext_mark_kernel(const u64* __restrict__ claim, u64* claim_old, u
   if (threadIdx.x == 0 && blk_changed) atomicAdd(n_changed, blk_changed);
 }
 
-// A walk that ran this round must own exactly the k1-mers on the path it recorded; if a lower rank took one
-// of them during the round (the walk saw it free for a moment) its record is stale: run it again.
-__global__ void ext_verify_kernel(const uint8_t* __restrict__ ran, const uint32_t* __restrict__ owned, const uint32_t* __restrict__ nr,
-                                  const uint32_t* __restrict__ nl, uint64_t ns, uint8_t* __restrict__ dirty) {
+// A walk that ran this round must own exactly the k1-mers on the path it recorded; if a lower rank took one of them during the
+// round (before or after the walk claimed it: note_claim saw either) its record is stale: run it again.
+__global__ void ext_verify_kernel(const uint8_t* __restrict__ ran, uint8_t* __restrict__ robbed, uint64_t ns, uint8_t* __restrict__ dirty) {
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= ns || !ran[r]) return;
-  uint32_t expect = nr[r] == UNCLAIMED ? 0u : nr[r] + nl[r] + 1u;
-  if (owned[r] != expect) dirty[r] = 1;
+  if (r >= ns) return;
+  if (robbed[r]) { robbed[r] = 0; if (ran[r]) dirty[r] = 1; }
 }
 
 __global__ void ext_seed_rank_kernel(const uint32_t* __restrict__ order, uint64_t ns, Rec* __restrict__ rec) {
@@ -1451,7 +1469,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   // scratch: claim snapshot (d_claim2), memo pool + per-k1-mer hints, per-walk plan arrays
   void *ppool, *pplan;
   if ((rc = g_shn_ws[27].get(pool_cap * 4, &ppool)) ||
-      (rc = g_shn_ws[28].get((ns + 1) * (8 + 4 * 9 + 1 + 1 + 1 + 1) + 64, &pplan))) { shn_ext_destroy(e); return rc; }
+      (rc = g_shn_ws[28].get((ns + 1) * (8 + 4 * 9 + 1 + 1 + 1 + 1 + 1) + 64, &pplan))) { shn_ext_destroy(e); return rc; }
   u64 *claim = e->d_claim, *snap = e->d_claim2;
   uint32_t* pool = (uint32_t*)ppool;
   uint64_t* moff = (uint64_t*)pplan;
@@ -1468,6 +1486,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   uint8_t* fill = mvalid + ns + 1;
   uint8_t* dirty = fill + ns + 1;
   uint8_t* ran = dirty + ns + 1;
+  uint8_t* robbed = ran + ns + 1;
+  TRYE(hipMemsetAsync(robbed, 0, ns + 1, s));
   TRYE(hipMemsetAsync(mvalid, 0, 2 * (ns + 1), s));
   TRYE(hipMemsetAsync(pool, 0xFF, pool_cap * 4, s));            // NONE32: "no entry"
   // (hints and seed ranks live in the records: ext_records_kernel wrote "none" into both)
@@ -1591,6 +1611,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     A.promote_steps = bulk ? 0xFFFFFFFFu : promote_steps;
     A.promo_list = promo_list; A.promo_count = d_cnt + 13; A.res_cur = res_cur; A.res_info = res_info;
     A.chunk = bulk ? nullptr : chunk;          // (bulk rounds write nearly everywhere: their mark pass is dense, the walkers do not flag)
+    A.robbed = robbed;
     A.steps_counter = d_cnt + 1; A.wave_steps_counter = d_cnt + 64; A.dbg = (getenv("SHN_DEBUG") || getenv("SHN_EXT_XTIME")) ? d_cnt + 32 : nullptr;
     // long (wave per walk) and short (thread per walk) kernels are independent: overlap them on two streams
     if (plan[0]) {
@@ -1631,13 +1652,14 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     fresh_block = false;
     // who has to run next round?  walks whose view changed (mark) + walks that lost a claim race (verify);
     // the walks that ran get their memo rebuilt from the claims
-    hipLaunchKernelGGL(ext_memo_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 256)), dim3(256), 0, s, ran, dirty, owned, e->d_nr, e->d_nl, e->d_order, frozen, limit,
+    hipLaunchKernelGGL(ext_memo_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 256)), dim3(256), 0, s, ran, dirty, e->d_nr, e->d_nl, e->d_order, frozen, limit,
                        moff, mR, mL, mvalid, fill, pool, d_cnt + 10, pool_cap, bulk ? 0xFFFFFFFFu : memo_min);
     { TimerRegion tk(ctx, T_EXT_MARK);
       hipLaunchKernelGGL(ext_mark_kernel, dim3(std::min<uint32_t>(g2n, 4096u)), dim3(256), 0, s, claim, snap, 2 * n, e->d_rec,
-                         dirty, ran, owned, d_cnt + 6, frozen, limit, fill, moff, mR, pool, e->d_nr, e->d_nl, precise_marks, bulk ? (const uint8_t*)nullptr : chunk);
+                         dirty, ran, d_cnt + 6, frozen, limit, bulk ? (const uint8_t*)nullptr : (const uint8_t*)fill, moff, mR, pool, e->d_nr, e->d_nl, precise_marks,
+                         bulk ? (const uint8_t*)nullptr : chunk);
       if (!bulk) TRYE(hipMemsetAsync(chunk, 0, n_chunks, s)); }
-    hipLaunchKernelGGL(ext_verify_kernel, dim3((uint32_t)cdiv(limit, 256)), dim3(256), 0, s, ran, owned, e->d_nr, e->d_nl, (uint64_t)limit, dirty);
+    hipLaunchKernelGGL(ext_verify_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, ran, robbed, (uint64_t)ns, dirty);
     if (getenv("SHN_EXT_FAULT") && it + 1 == atoi(getenv("SHN_EXT_FAULT"))) TRYE(hipMemsetAsync(dirty, 0, ns + 1, s));   // (tests: lose every mark of this round)
     if (getenv("SHN_EXT_ALLDIRTY")) { TRYE(hipMemsetAsync(dirty, 0, ns + 1, s)); TRYE(hipMemsetAsync(dirty + frozen, 1, limit - frozen, s)); }
     it++;
