@@ -342,33 +342,34 @@ __global__ void cc_assign_kernel(const uint32_t* __restrict__ big_root, const ui
   if (j < n_big) owner_root[big_root[j]] = big_owner[j];
 }
 
-__global__ void ext_seed_kernel(const uint64_t* __restrict__ tkeys, const uint32_t* __restrict__ weight,
+// The seeds (oriented k1-mers of weight >= min_weight; low-complexity ones and the second orientation of a palindrome left out) in
+// two passes without a shared cursor: the count pass leaves one count per block, a scan turns them into bases, the write pass
+// recomputes and writes -- in table order, whatever the scheduling.  (One atomic per block on ONE address was 17 ms per pass at
+// 1.4 M blocks.)  One thread per canonical k1-mer, both orientations.
+__global__ __launch_bounds__(1024) void ext_seed_kernel(const uint64_t* __restrict__ tkeys, const uint32_t* __restrict__ weight,
                                 const uint8_t* __restrict__ flags, uint64_t n, int k, int canonical, uint32_t min_weight,
-                                uint64_t* __restrict__ skeys, uint32_t* __restrict__ svals, unsigned long long* __restrict__ counter) {
-  uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  bool is_seed = false;
-  uint64_t i = o >> 1;
-  if (o < 2 * n) {
-    uint8_t f = flags[i];
-    is_seed = !(f & 2) && !((o & 1) && ((f & 1) || !canonical)) && weight[i] >= min_weight;
+                                uint32_t* __restrict__ block_count, const uint64_t* __restrict__ block_base,
+                                uint64_t* __restrict__ skeys, uint32_t* __restrict__ svals) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool s0 = false, s1 = false;
+  if (i < n) {
+    const uint8_t f = flags[i];
+    s0 = !(f & 2) && weight[i] >= min_weight;
+    s1 = s0 && !(f & 1) && canonical;
   }
-  // one atomic per block of 1024 (the order of the seeds does not matter: they are sorted next)
   __shared__ uint32_t wcnt[16];
-  __shared__ unsigned long long bbase;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const unsigned long long m = __ballot(is_seed);
-  if (lane == 0) wcnt[wid] = (uint32_t)__popcll(m);
+  const unsigned long long m0 = __ballot(s0), m1 = __ballot(s1), below = (1ULL << lane) - 1ULL;
+  if (lane == 0) wcnt[wid] = (uint32_t)(__popcll(m0) + __popcll(m1));
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t tot = 0;
-    for (int w = 0; w < (int)(blockDim.x >> 6); w++) { uint32_t c = wcnt[w]; wcnt[w] = tot; tot += c; }
-    bbase = tot ? atomicAdd(counter, (unsigned long long)tot) : 0ULL;
-  }
-  __syncthreads();
-  if (!is_seed || !skeys) return;                  // skeys == NULL: count only
-  unsigned long long p = bbase + wcnt[wid] + __popcll(m & ((1ULL << lane) - 1ULL));
-  skeys[p] = (o & 1) ? shn_revcomp(tkeys[i], k) : tkeys[i];
-  svals[p] = (uint32_t)o;
+  uint32_t before = 0, total = 0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); w++) { const uint32_t c = wcnt[w]; if (w < wid) before += c; total += c; }
+  if (!skeys) { if (threadIdx.x == 0) block_count[blockIdx.x] = total; return; }
+  if (!s0) return;
+  uint64_t p = block_base[blockIdx.x] + before + (uint32_t)(__popcll(m0 & below) + __popcll(m1 & below));
+  const uint64_t key = tkeys[i];
+  skeys[p] = key; svals[p] = (uint32_t)(2 * i);
+  if (s1) { skeys[p + 1] = shn_revcomp(key, k); svals[p + 1] = (uint32_t)(2 * i + 1); }
 }
 
 __global__ void ext_weightkey_kernel(const uint32_t* __restrict__ svals, const uint32_t* __restrict__ weight, uint64_t ns,
@@ -1057,15 +1058,27 @@ __global__ void ext_memo_plan_kernel(uint8_t* __restrict__ ran, uint8_t* __restr
 __global__ void ext_round_begin_kernel(u64* __restrict__ claim, u64* __restrict__ snap, uint64_t n2, const uint8_t* __restrict__ dirty,
                                        uint64_t ns, unsigned long long* __restrict__ d_cnt, int copy, uint8_t* __restrict__ chunk,
                                        uint32_t frozen, uint32_t limit, const uint8_t* __restrict__ coarse) {
-  uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (o == 0) { d_cnt[6] = 0; d_cnt[7] = 0; d_cnt[13] = 0; }      // changed k1-mers, (spare), walks handed over
-  if (o >= n2) return;
-  const u64 c = claim[o];
-  if (copy) snap[o] = c;
-  const uint32_t rk = RANK(c);
+  // four claims per thread, as two 16-byte loads (n2 is padded to a multiple of 4 by the allocation; the claims are 16-byte aligned):
+  // with one 8-byte load per thread the pass ran at 3 TB/s
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) { d_cnt[6] = 0; d_cnt[7] = 0; d_cnt[13] = 0; }      // changed k1-mers, (spare), walks handed over
+  const uint64_t o0 = t * 4;
+  if (o0 >= n2) return;
+  ulonglong2 c01 = ((const ulonglong2*)(claim + o0))[0], c23 = ((const ulonglong2*)(claim + o0))[1];
+  if (copy) { ((ulonglong2*)(snap + o0))[0] = c01; ((ulonglong2*)(snap + o0))[1] = c23; }
   // (only walks of the open block can be dirty: the flag of a final walk's k1-mer -- most claimed k1-mers in the later blocks --
   // is not looked up: a random byte read per claimed k1-mer otherwise)
-  if (rk >= frozen && rk < limit && rk < ns && coarse[(rk - frozen) >> 6] && dirty[rk]) { claim[o] = UNCLAIMED64; if (chunk) chunk[o >> CHUNK_SHIFT] = 1; }
+  u64 c[4] = {c01.x, c01.y, c23.x, c23.y};
+  bool any = false;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const uint32_t rk = RANK(c[q]);
+    if (o0 + q < n2 && rk >= frozen && rk < limit && rk < ns && coarse[(rk - frozen) >> 6] && dirty[rk]) { c[q] = UNCLAIMED64; any = true; }
+  }
+  if (any) {
+    ((ulonglong2*)(claim + o0))[0] = ulonglong2{c[0], c[1]}; ((ulonglong2*)(claim + o0))[1] = ulonglong2{c[2], c[3]};
+    if (chunk) chunk[o0 >> CHUNK_SHIFT] = 1;
+  }
 }
 
 // after a round: every k1-mer whose owner changed dirties the walks that looked at it; the k1-mers of the walks
@@ -1408,8 +1421,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   TRYE(shn_dev_malloc(&e->d_weight, (n + 1) * 4));
   TRYE(shn_dev_malloc(&e->d_flags, n + 1));
   TRYE(shn_dev_malloc(&e->d_rec, (2 * n + 1) * sizeof(Rec)));
-  TRYE(shn_dev_malloc(&e->d_claim, (2 * n + 1) * 8));
-  TRYE(shn_dev_malloc(&e->d_claim2, (2 * n + 1) * 8));
+  TRYE(shn_dev_malloc(&e->d_claim, (2 * n + 4) * 8));      // (+4: the begin pass reads four claims per thread)
+  TRYE(shn_dev_malloc(&e->d_claim2, (2 * n + 4) * 8));
   if (n) {
     TimerRegion t1(ctx, T_EXT_PREP);
     hipLaunchKernelGGL(ext_prepare_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, t->d_counts, n, t->k,
@@ -1433,17 +1446,20 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   // the seeds are counted first: the sort buffers are sized for them, not for every oriented k1-mer (at 20,000 genes 13 % of
   // the table are seeds -- 30 GB less)
   TRYE(hipMemsetAsync(d_cnt, 0, 2048, s));
-  if (n) hipLaunchKernelGGL(ext_seed_kernel, dim3((uint32_t)cdiv(2 * n, 1024)), dim3(1024), 0, s, t->d_keys, e->d_weight, e->d_flags, n,
-                            t->k, t->canonical, min_weight, (uint64_t*)nullptr, (uint32_t*)nullptr, d_cnt);
-  unsigned long long ns = 0;
-  TRYE(hipMemcpyAsync(&ns, d_cnt, 8, hipMemcpyDeviceToHost, s));
-  TRYE(hipStreamSynchronize(s));
+  const uint64_t n_sblk = cdiv(n, 1024);
+  uint32_t* d_bcnt = nullptr; uint64_t* d_bbase = nullptr;
+  struct SeedScratch { uint32_t** a; uint64_t** b; ~SeedScratch() { if (*a) shn_dev_free(*a); if (*b) shn_dev_free(*b); } } seed_scratch{&d_bcnt, &d_bbase};
+  TRYE(shn_dev_malloc(&d_bcnt, (n_sblk + 1) * 4));
+  TRYE(shn_dev_malloc(&d_bbase, (n_sblk + 2) * 8));
+  if (n) hipLaunchKernelGGL(ext_seed_kernel, dim3((uint32_t)n_sblk), dim3(1024), 0, s, t->d_keys, e->d_weight, e->d_flags, n,
+                            t->k, t->canonical, min_weight, d_bcnt, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr);
+  uint64_t ns = 0;
+  if (n && (rc = shn_device_scan_u32(ctx, d_bcnt, n_sblk, d_bbase, &ns))) { shn_ext_destroy(e); return rc; }
   if ((rc = g_shn_ws[9].get((ns + 2) * 8, &pk)) || (rc = g_shn_ws[10].get((ns + 2) * 4, &pv)) ||
       (rc = g_shn_ws[11].get((ns + 2) * 8, &pk2)) || (rc = g_shn_ws[12].get((ns + 2) * 4, &pv2))) { shn_ext_destroy(e); return rc; }
   uint64_t* skeys = (uint64_t*)pk; uint32_t* svals = (uint32_t*)pv;
-  TRYE(hipMemsetAsync(d_cnt, 0, 2048, s));
-  if (n) hipLaunchKernelGGL(ext_seed_kernel, dim3((uint32_t)cdiv(2 * n, 1024)), dim3(1024), 0, s, t->d_keys, e->d_weight, e->d_flags, n,
-                            t->k, t->canonical, min_weight, skeys, svals, d_cnt);
+  if (n) hipLaunchKernelGGL(ext_seed_kernel, dim3((uint32_t)n_sblk), dim3(1024), 0, s, t->d_keys, e->d_weight, e->d_flags, n,
+                            t->k, t->canonical, min_weight, d_bcnt, (const uint64_t*)d_bbase, skeys, svals);
   e->n_seeds = ns;
   {
     TimerRegion t2(ctx, T_EXT_SORT);
@@ -1465,7 +1481,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   TRYE(hipMemsetAsync(e->d_nr, 0xFF, (ns + 1) * 4, s));
   TRYE(hipMemsetAsync(e->d_nl, 0, (ns + 1) * 4, s));
   TRYE(hipMemsetAsync(e->d_totw, 0, (ns + 1) * 8, s));
-  TRYE(hipMemsetAsync(e->d_claim, 0xFF, (2 * n + 1) * 8, s));
+  TRYE(hipMemsetAsync(e->d_claim, 0xFF, (2 * n + 4) * 8, s));
   // scratch: claim snapshot (d_claim2), memo pool + per-k1-mer hints, per-walk plan arrays
   void *ppool, *pplan;
   if ((rc = g_shn_ws[27].get(pool_cap * 4, &ppool)) ||
@@ -1600,7 +1616,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     // (a block that has just opened holds no claims yet: with the snapshot up to date there is nothing to release and nothing to copy)
     if (fresh_block && precise_marks && snap_current) { TRYE(hipMemsetAsync(d_cnt + 6, 0, 16, s)); TRYE(hipMemsetAsync(d_cnt + 13, 0, 8, s)); }
     else
-    hipLaunchKernelGGL(ext_round_begin_kernel, dim3(g2n), dim3(256), 0, s, claim, snap, 2 * n, dirty, (uint64_t)ns, d_cnt,
+    hipLaunchKernelGGL(ext_round_begin_kernel, dim3((uint32_t)cdiv(cdiv(2 * n, 4), 256)), dim3(256), 0, s, claim, snap, 2 * n, dirty, (uint64_t)ns, d_cnt,
                        (!precise_marks || !snap_current) ? 1 : 0, bulk ? (uint8_t*)nullptr : chunk, frozen, limit, coarse);
     snap_current = true;
     WalkArgs A;
