@@ -235,6 +235,12 @@ uint64_t shn_probe_n_members(const shn_probe* p);
 int shn_probe_sets(const shn_probe* p, uint32_t* set_off /* n_sets + 1 */, uint32_t* set_mem /* n_members */);
 int shn_route_reads(shn_ctx* ctx, const shn_reads* r1, const shn_reads* r2, int k1, const shn_table* probe,
                     const uint32_t* set_off, const uint32_t* set_members, uint32_t n_sets, shn_routes** out);
+/* The same for a strand-specific run (-s / --ss / --strand_specific, shannon.py:407-411): the read files the routing loops stream
+ * (kmers_for_component.py:322-403, always with double_stranded = False after shannon.py:427) are then `reads` (single-end) or
+ * reads_1 and RC(reads_2) (paired), NOT strand-doubled -- strand_specific != 0: a route (partition, d) has d < N, a pair is
+ * (r1[d], RC(r2[d])) and matches through the k1-mers of r1[d] and of RC(r2[d]).  strand_specific == 0: shn_route_reads.          */
+int shn_route_reads_mode(shn_ctx* ctx, const shn_reads* r1, const shn_reads* r2, int k1, const shn_table* probe,
+                         const uint32_t* set_off, const uint32_t* set_members, uint32_t n_sets, int strand_specific, shn_routes** out);
 void shn_routes_destroy(shn_routes* r);
 uint64_t shn_routes_size(const shn_routes* r);
 int shn_routes_download(shn_ctx* ctx, const shn_routes* r, uint32_t* pid, uint32_t* ridx);
@@ -329,7 +335,8 @@ int shn_reads_ingest(shn_ctx* ctx, const uint8_t* text, uint64_t n_bytes, int fo
 /* The whole final merge over the text of all_reconstructed.fasta: process_concatenated_fasta.py:6-32 (rename repeated names, drop
  * sequences of < 200 bases and sequences seen before on either strand), the length sort of shannon.py:603 and shn_find_reps
  * (faster_reps.py:60-131).  The survivors in sorted order: shn_post_count / _sizes / _export (names, name_off[n+1], seqs,
- * seq_off[n+1]).  SHN_ERR_ARG on a base outside ACGT (as shn_find_reps) or an empty line.                                       */
+ * seq_off[n+1]).  SHN_ERR_ARG on a base outside ACGT (as shn_find_reps) or an empty line.  `ds` is the strandedness of the run
+ * (0 with -s / --ss): process_concatenated_fasta.py gets it (shannon.py:596); faster_reps.py always runs with -d (:604).          */
 typedef struct shn_post shn_post;
 int shn_post_finalize(const uint8_t* text, uint64_t n_bytes, int ds, int r, shn_post** out);
 /* ... over the concatenation of several buffers (per-partition FASTA texts) */

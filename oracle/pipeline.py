@@ -3,9 +3,15 @@ infrastructure (see oracle/__init__.py)."""
 from . import seqs, count, extension, partition, mbgraph, sparse_flow, post
 
 
-def assemble(reads1, reads2=None, K=25, partition_size=500, sample="shannon", seed=0, part_vectors=None):
+def assemble(reads1, reads2=None, K=25, partition_size=500, sample="shannon", seed=0, part_vectors=None, double_stranded=True):
+    """double_stranded=False: the -s / --ss run -- after the read files are made the reference sets double_stranded = False for
+    every later stage in both modes (shannon.py:427); only the read files differ (:394-424), and process_concatenated_fasta at
+    the end, which gets the user's flag (:596)."""
     paired = reads2 is not None
-    dbl = list(seqs.double_strand_paired(reads1, reads2)) if paired else [seqs.double_strand_single(reads1)]
+    if double_stranded:
+        dbl = list(seqs.double_strand_paired(reads1, reads2)) if paired else [seqs.double_strand_single(reads1)]
+    else:
+        dbl = seqs.strand_specific(reads1, reads2)
     tab = count.count_k1mers_dict([r for f in dbl for r in f], K + 1)
     res = extension.run_correction([(k, tab[k]) for k in sorted(tab, reverse=True)], comp_size_threshold=partition_size)
     pv = part_vectors or []
@@ -31,5 +37,5 @@ def assemble(reads1, reads2=None, K=25, partition_size=500, sample="shannon", se
         txt += sparse_flow.single_nodes_fasta(sname, singles)
         parts[name] = {"reconstructed_fasta": txt, "graph": mbgraph.canonical(singles, comps)}
         lines += txt.splitlines(True)
-    return {"partitions": parts, "all_reconstructed": lines, "final": post.finalize(lines, True),
+    return {"partitions": parts, "all_reconstructed": lines, "final": post.finalize(lines, double_stranded),
             "contigs": res.contigs, "n_k1mers": len(tab)}

@@ -97,5 +97,6 @@ def find_reps(lines, ds, r=24):
 
 
 def finalize(all_reconstructed_lines, ds=True):
-    """shannon.py:596-604: process_concatenated -> length sort -> faster_reps -d."""
-    return find_reps(length_sort(process_concatenated(all_reconstructed_lines, ds)), ds)
+    """shannon.py:596-604: process_concatenated (with the user's strandedness, original_ds) -> length sort -> faster_reps, which
+    the reference always calls with -d (:604), whatever the strandedness of the run."""
+    return find_reps(length_sort(process_concatenated(all_reconstructed_lines, ds)), True)

@@ -19,6 +19,14 @@ def double_strand_paired(r1, r2):
             [reverse_complement(r) for r in r1] + list(r2))
 
 
+def strand_specific(r1, r2=None):
+    """shannon.py:394-424 with -s / --ss / --strand_specific: the reads as they are; of a pair, the second mate reverse-
+    complemented (:407-411).  No strand doubling.  Returns the list of read files: [reads] or [reads_1, reads_2]."""
+    if r2 is None:
+        return [list(r1)]
+    return [list(r1), [reverse_complement(s) for s in r2]]
+
+
 def find_L(reads):
     """rc_gnu.py:15-20: (N, average read length as float)."""
     n = len(reads)

@@ -76,8 +76,8 @@ def main(argv):
         if a == "--kmer_hard_cutoff":
             min_weight = int(argv[i + 1]); i += 2; continue
         if a in ("-s", "--ss", "--strand_specific"):
-            # accepted by the reference CLI (shannon.py:166-207); this build only has the double-stranded path
-            sys.exit("shannon.py: strand-specific input (%s) is not supported by this build (double-stranded reads only)" % a)
+            # shannon.py:166-207, 407-411: no strand doubling; of a pair, RC(reads_2) stands for reads_2
+            double_stranded = False; i += 1; continue
         if a in ("--inMem", "--fasta", "--fastq"):
             i += 1; continue
         if a in ("--inDisk", "--only_reads"):

@@ -49,6 +49,7 @@ SIGNATURES = {
     "shn_probe_n_members": (C.c_uint64, [vp]),
     "shn_probe_sets": (C.c_int, [vp, vp, vp]),
     "shn_route_reads": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, C.c_uint32, vpp]),
+    "shn_route_reads_mode": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, C.c_uint32, C.c_int, vpp]),
     "shn_routes_destroy": (None, [vp]),
     "shn_routes_size": (C.c_uint64, [vp]),
     "shn_routes_download": (C.c_int, [vp, vp, vp, vp]),

@@ -435,7 +435,9 @@ static int post_finalize_impl(shn_ctx* ctx, const uint8_t* const* bufs, const ui
   std::vector<uint8_t> keep(n + 1, 0);
   const double tp1 = nowp();
   if (n) {
-    int rc = find_reps_core(nptr.data(), nlen.data(), sptr.data(), slen.data(), n, ds, r, keep.data(), dev, sgoff.data());
+    // (faster_reps.py is always run with -d, whatever the strandedness of the run: shannon.py:604; `ds` is the user's flag, which
+    // process_concatenated_fasta.py gets, :596)
+    int rc = find_reps_core(nptr.data(), nlen.data(), sptr.data(), slen.data(), n, 1, r, keep.data(), dev, sgoff.data());
     if (rc) return rc;
   }
   shn_post* o = new shn_post();

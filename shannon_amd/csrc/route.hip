@@ -60,7 +60,7 @@ __device__ __forceinline__ int collect(const RView& v, uint64_t r, bool rc, int 
 }
 
 template <bool FILL>
-__global__ __launch_bounds__(RBLK) void route_kernel(RView a, RView b, int paired, int k, const uint64_t* __restrict__ tkeys,
+__global__ __launch_bounds__(RBLK) void route_kernel(RView a, RView b, int paired, int ss, int k, const uint64_t* __restrict__ tkeys,
                                                      const uint32_t* __restrict__ tvals, const uint64_t* __restrict__ boff, int bits,
                                                      const uint32_t* __restrict__ set_off, const uint32_t* __restrict__ set_mem,
                                                      uint32_t* __restrict__ counts, const uint64_t* __restrict__ offs,
@@ -82,7 +82,14 @@ __global__ __launch_bounds__(RBLK) void route_kernel(RView a, RView b, int paire
   bool second = d >= N;
   uint64_t i = second ? d - N : d;
   bool dropped;
-  if (!paired) {
+  if (ss) {
+    // -s / --ss (shannon.py:407-411): the read files are reads (SE) or reads_1 and RC(reads_2) (PE), not doubled: index d < N only
+    dropped = second || (a.bad && a.bad[i]) || (paired && b.bad && b.bad[i]);
+    if (!dropped) {
+      nloc = collect(a, i, false, k, tkeys, tvals, boff, bits, set_off, set_mem, loc, nloc, overflow);
+      if (paired) nloc = collect(b, i, true, k, tkeys, tvals, boff, bits, set_off, set_mem, loc, nloc, overflow);
+    }
+  } else if (!paired) {
     dropped = a.bad && a.bad[i];
     if (!dropped) nloc = collect(a, i, second, k, tkeys, tvals, boff, bits, set_off, set_mem, loc, nloc, overflow);
   } else {
@@ -180,6 +187,10 @@ extern "C" int shn_routes_download_range(shn_ctx* ctx, const shn_routes* r, uint
 
 extern "C" int shn_route_reads(shn_ctx* ctx, const shn_reads* r1, const shn_reads* r2, int k1, const shn_table* probe,
                                const uint32_t* set_off, const uint32_t* set_members, uint32_t n_sets, shn_routes** out) {
+  return shn_route_reads_mode(ctx, r1, r2, k1, probe, set_off, set_members, n_sets, 0, out);
+}
+extern "C" int shn_route_reads_mode(shn_ctx* ctx, const shn_reads* r1, const shn_reads* r2, int k1, const shn_table* probe,
+                                    const uint32_t* set_off, const uint32_t* set_members, uint32_t n_sets, int strand_specific, shn_routes** out) {
   if (!ctx || !r1 || !probe || !set_off || !out) return shn_fail(SHN_ERR_ARG, "shn_route_reads: NULL argument");
   if (r2 && r2->n_reads != r1->n_reads) return shn_fail(SHN_ERR_ARG, "shn_route_reads: mate files differ in length");
   if (probe->canonical) return shn_fail(SHN_ERR_ARG, "shn_route_reads: probe table must hold plain (non-canonical) k1-mers");
@@ -209,7 +220,7 @@ extern "C" int shn_route_reads(shn_ctx* ctx, const shn_reads* r1, const shn_read
   uint32_t grid = (uint32_t)cdiv(N2, RBLK);
   void* pf2 = nullptr;
   uint2* d_first2 = g_shn_ws[30].get((N2 + 1) * 8, &pf2) == 0 ? (uint2*)pf2 : nullptr;          // (without it the second pass probes again)
-  hipLaunchKernelGGL(route_kernel<false>, dim3(grid), dim3(RBLK), 0, s, a, b, r2 ? 1 : 0, k1, probe->d_keys, probe->d_counts,
+  hipLaunchKernelGGL(route_kernel<false>, dim3(grid), dim3(RBLK), 0, s, a, b, r2 ? 1 : 0, strand_specific ? 1 : 0, k1, probe->d_keys, probe->d_counts,
                      probe->d_bucket_off, probe->bits, d_so, d_sm, (uint32_t*)pcnt, nullptr, nullptr, d_ovf, d_first2);
   uint64_t total = 0;
   if ((rc = shn_device_scan_u32(ctx, (uint32_t*)pcnt, N2, (uint64_t*)poff, &total))) { delete R; return rc; }
@@ -223,7 +234,7 @@ extern "C" int shn_route_reads(shn_ctx* ctx, const shn_reads* r1, const shn_read
   if ((rc = g_shn_ws[9].get((total + 2) * 8, &pk)) || (rc = g_shn_ws[11].get((total + 2) * 8, &pk2)) ||
       (rc = g_shn_ws[10].get((total + 2) * 4, &pv)) || (rc = g_shn_ws[12].get((total + 2) * 4, &pv2))) { delete R; return rc; }
   if (total) {
-    hipLaunchKernelGGL(route_kernel<true>, dim3(grid), dim3(RBLK), 0, s, a, b, r2 ? 1 : 0, k1, probe->d_keys, probe->d_counts,
+    hipLaunchKernelGGL(route_kernel<true>, dim3(grid), dim3(RBLK), 0, s, a, b, r2 ? 1 : 0, strand_specific ? 1 : 0, k1, probe->d_keys, probe->d_counts,
                        probe->d_bucket_off, probe->bits, d_so, d_sm, (uint32_t*)pcnt, (const uint64_t*)poff, (uint64_t*)pk, d_ovf, d_first2);
     // pairs were written in doubled-read order; a stable sort on the partition id keeps that order
     HIP_TRY(hipMemsetAsync(pv, 0, total * 4, s));

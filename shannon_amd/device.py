@@ -217,6 +217,43 @@ def count_k1mers(ctx, read_sets, k1, both_strands=True):
     return Table(ctx, h)
 
 
+def revcomp_keys(keys, k):
+    """reverse complements of packed k-mers (numpy; 2 bits per base, first base in the high bits)"""
+    keys = np.asarray(keys, dtype=np.uint64).copy()
+    out = np.zeros(len(keys), dtype=np.uint64)
+    three, two = np.uint64(3), np.uint64(2)
+    for _ in range(k):
+        out = (out << two) | (three - (keys & three))
+        keys >>= two
+    return out
+
+
+def count_k1mers_strand_specific(ctx, d1, d2, k1):
+    """The table of a strand-specific run (-s / --ss / --strand_specific): `jellyfish count` without -C (shannon.py:436-439 after
+    :427) over `reads` (single-end) or over reads_1 and RC(reads_2) (paired, :407-411) -- forward k1-mers only; the k1-mers of
+    RC(reads_2) are the reverse complements of the forward k1-mers of reads_2.  A plain (non-canonical) table."""
+    t1 = count_k1mers(ctx, [d1], k1, both_strands=False)
+    if d2 is None:
+        return t1
+    t2 = count_k1mers(ctx, [d2], k1, both_strands=False)
+    try:
+        ka, ca = t1.download()
+        kb, cb = t2.download()
+    finally:
+        t1.close()
+        t2.close()
+    keys = np.concatenate([ka, revcomp_keys(kb, k1)])
+    cnts = np.concatenate([ca, cb]).astype(np.uint64)
+    uk, inv = np.unique(keys, return_inverse=True)
+    tot = np.zeros(len(uk), dtype=np.uint64)
+    np.add.at(tot, inv, cnts)
+    h = C.c_void_p()
+    uk = np.ascontiguousarray(uk, dtype=np.uint64)
+    vals = np.ascontiguousarray(np.minimum(tot, np.uint64(0xFFFFFFFF)), dtype=np.uint32)
+    _lib.check(_lib.lib().shn_table_create(ctx.h, uk.ctypes.data, vals.ctypes.data, len(uk), k1, 0, C.byref(h)))
+    return Table(ctx, h)
+
+
 def key_to_str(key, k):
     key = int(key)
     return "".join(ALPHA[(key >> (2 * (k - 1 - i))) & 3] for i in range(k))

@@ -171,8 +171,9 @@ def make_table(ctx, keys, values, k, canonical=False):
 
 
 def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overload=2, penalty=5, repartition=True,
-                        part_vectors=None, want_rows=True, timings=None, lazy_routes=False, lazy_graph_inputs=False):
-    """Rows a8-a11.  reads1/reads2: device.Reads (reads2 None for single-end).  Returns dict with
+                        part_vectors=None, want_rows=True, timings=None, lazy_routes=False, lazy_graph_inputs=False, strand_specific=False):
+    """Rows a8-a11.  reads1/reads2: device.Reads (reads2 None for single-end).  strand_specific (-s / --ss, shannon.py:407-411):
+    the read files are reads / (reads_1, RC(reads_2)), not strand-doubled -- routes hold plain read indices.  Returns dict with
       new_components {name: [contig]}          (kmers_for_component.py:244-305)
       k1mers {name: [(k1mer, weight)]}         (:452-477, == component{name}k1mers_allowed.dict)
       contig_weights {name: [[w..] per contig]} (--inMem form :468-469)
@@ -216,14 +217,14 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
         lap("route.k1mer map")
         h = C.c_void_p()
         try:
-            _lib.check(_lib.lib().shn_route_reads(ctx.h, reads1.h, reads2.h if reads2 is not None else None, k1,
-                                                  C.c_void_p(_lib.lib().shn_probe_table(probe_h)), set_off.ctypes.data, set_mem.ctypes.data, n_sets,
-                                                  C.byref(h)))
+            _lib.check(_lib.lib().shn_route_reads_mode(ctx.h, reads1.h, reads2.h if reads2 is not None else None, k1,
+                                                       C.c_void_p(_lib.lib().shn_probe_table(probe_h)), set_off.ctypes.data, set_mem.ctypes.data, n_sets,
+                                                       1 if strand_specific else 0, C.byref(h)))
         finally:
             _lib.lib().shn_probe_destroy(probe_h)
         lap("route.kernel")
     if probe_h is None:
-        h = _host_probe_and_route(ctx, comps, names, pid_of, reads1, reads2, k1, lap)
+        h = _host_probe_and_route(ctx, comps, names, pid_of, reads1, reads2, k1, lap, strand_specific)
     routes = Routes(ctx, h)
     if lazy_routes:                                   # routes stay on the device; RouteView fetches what is asked for
         start, below = routes.bounds(len(names), len(reads1))
@@ -238,7 +239,7 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
     return _finish_partitions(res, comps, broken, names, by_part, files, cw, k1, K, want_rows, lazy_graph_inputs, lap)
 
 
-def _host_probe_and_route(ctx, comps, names, pid_of, reads1, reads2, k1, lap):
+def _host_probe_and_route(ctx, comps, names, pid_of, reads1, reads2, k1, lap, strand_specific=False):
     """k1mers2component with numpy (small inputs; the readable form of csrc/probe_gpu.hip) + the routing kernel; returns the
     shn_routes handle"""
     allk, allp = [], []
@@ -310,8 +311,8 @@ def _host_probe_and_route(ctx, comps, names, pid_of, reads1, reads2, k1, lap):
     probe = make_table(ctx, uk, set_ids, k1, canonical=False)
     h = C.c_void_p()
     try:
-        _lib.check(_lib.lib().shn_route_reads(ctx.h, reads1.h, reads2.h if reads2 is not None else None, k1, probe.h,
-                                              set_off.ctypes.data, set_mem.ctypes.data, len(sets), C.byref(h)))
+        _lib.check(_lib.lib().shn_route_reads_mode(ctx.h, reads1.h, reads2.h if reads2 is not None else None, k1, probe.h,
+                                                   set_off.ctypes.data, set_mem.ctypes.data, len(sets), 1 if strand_specific else 0, C.byref(h)))
     finally:
         probe.close()
     lap("route.kernel")
@@ -436,6 +437,25 @@ class ReadStore(object):
     @staticmethod
     def _rc(s):
         return s[::-1].translate(_RC)
+
+    def gather_codes_ss(self, idx, mate):
+        """gather_codes for a strand-specific run (-s, shannon.py:407-411): `idx` are plain read indices; mate 1 = reads_1[i] as
+        stored, mate 2 = RC(reads_2[i]) (rows as stored + the rc flag set)."""
+        idx = np.asarray(idx, dtype=np.int64)
+        src = self.r1 if mate == 1 else self.r2
+        if len(idx) == 0 or isinstance(src[0], str):
+            seqs = [self._get(src, int(i)) for i in idx]
+            if mate == 2:
+                seqs = [self._rc(q) for q in seqs]
+            off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+            if seqs:
+                off[1:] = np.cumsum([len(q) for q in seqs], dtype=np.uint64)
+            buf = np.frombuffer("".join(seqs).encode(), dtype=np.uint8) if seqs else np.zeros(1, np.uint8)
+            return buf, off, None, 0
+        rows = np.ascontiguousarray(src[idx])
+        L = rows.shape[1]
+        rc = np.full(len(idx), 1 if mate == 2 else 0, dtype=np.uint8)
+        return (rows.reshape(-1), np.arange(len(idx) + 1, dtype=np.uint64) * np.uint64(L), rc, 1)
 
     def gather_codes(self, idx, mate):
         """(codes buffer, offsets, rc flags, enc) of reads `mate` of the doubled indices -- rows are gathered as

@@ -84,10 +84,11 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
     graph stage may run concurrently on host threads.  keep_partitioning: leave the partition stage's tables (partition ->
     contigs, routed read indices) on the result as `.partitioning` (tests/test_fullsize_gpu.py reads them).  defer_back: run count,
     extension, partitioning / routing and the unitig batch now and return a function that does the rest (see `back`)."""
-    if not double_stranded:
-        # shannon.py:394-424 prepares strand-specific input differently (no doubling; PE: reads_2 = RC(R2)) and routing /
-        # graph reads follow that layout; only the strand-doubled layout is built and pinned against the reference.
-        raise NotImplementedError("strand-specific input (-s / --ss) is not built: only the default double-stranded path is (INTEGRATION.md, Waiver)")
+    # double_stranded=False: -s / --ss / --strand_specific.  shannon.py:394-424 then leaves single-end reads as they are and
+    # reverse-complements the second mates, without doubling; from :427 on double_stranded is False in BOTH modes, so only the read
+    # set differs: forward counting (d2: its reverse complements), routes of plain read indices, pairs (R1[i], RC(R2[i])) in the
+    # graph stage; process_concatenated_fasta (:596) gets the user's flag.
+    ss = not double_stranded
     T = timings if timings is not None else {}
     paired = d2 is not None
     if graph_threads is None:                   # a rank's share of the host cores (8 ranks per node), at least 8
@@ -104,7 +105,8 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
 
     R = Result()
     t0 = time.time()
-    table = device.count_k1mers(ctx, [d1, d2] if paired else [d1], K + 1, both_strands=double_stranded)
+    table = (device.count_k1mers_strand_specific(ctx, d1, d2, K + 1) if ss else
+             device.count_k1mers(ctx, [d1, d2] if paired else [d1], K + 1, both_strands=True))
     R.n_k1mers, R.n_windows = len(table), table.total
     tick("count", t0)
     t0 = time.time()
@@ -115,7 +117,7 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
     t0 = time.time()
     gpu_unitigs = native_graph and K <= 31 and os.environ.get("SHN_GRAPH_GPU", "1") != "0"
     part = kfc.kmers_for_component(ctx, res, d1, d2, K, partition_size, overload, penalty, True, part_vectors,
-                                   want_rows=not native_graph, timings=T, lazy_graph_inputs=gpu_unitigs)
+                                   want_rows=not native_graph, timings=T, lazy_graph_inputs=gpu_unitigs, strand_specific=ss)
     tick("partition+route", t0)
     if keep_partitioning:
         R.partitioning = part
@@ -145,8 +147,9 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
         def _matrix(m):
             return isinstance(m, np.ndarray) and m.dtype == np.uint8 and m.ndim == 2 and m.flags["C_CONTIGUOUS"]
         # reads kept as code matrices + GPU unitigs: partitions name their reads by rows (SHN_GRAPH_ROWS=0: gather them on the host)
+        # (strand-specific runs hand the reads over as gathered rows + strand flags: the rows mode knows the doubled layout only)
         rows_mode = (unitigs is not None and d1 is not None and _matrix(store.r1) and (not paired or _matrix(store.r2)) and
-                     (not paired or d2 is not None) and os.environ.get("SHN_GRAPH_ROWS", "1") != "0")
+                     (not paired or d2 is not None) and os.environ.get("SHN_GRAPH_ROWS", "1") != "0" and not ss)
 
         def one_partition(name):
             """multibridged graph of one partition (multibridging.main for `name`); returns its record + timings"""
@@ -183,8 +186,14 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
                 tt["graph"] = time.time() - t0
                 return PartitionRecord(len(part["routes"][name]), part["n_k1mer_rows"][name], gh), tt
             if native_graph:
-                b1, o1, rc1, enc = store.gather_codes(idx, 1)
-                if paired and rc1 is not None:
+                if ss:
+                    b1, o1, rc1, enc = store.gather_codes_ss(idx, 1)
+                    b2, o2, rc2, _e = store.gather_codes_ss(idx, 2) if paired else (None, None, None, enc)
+                else:
+                    b1, o1, rc1, enc = store.gather_codes(idx, 1)
+                if ss:
+                    pass
+                elif paired and rc1 is not None:
                     # the second mates are the same stored rows read on the other strand (shannon.py:413-424)
                     b2, o2, rc2 = b1, o1, (1 - rc1).astype(np.uint8)
                 else:
@@ -197,7 +206,7 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
                 # with GPU unitigs the k1-mer rows are only needed for a partition holding a cycle of condensable edges (built by
                 # the sequential code) and for the development check SHN_GRAPH_CHECK=1
                 rb = rows_now() if (unitigs is None or check_rows) else None
-                res_src = (d1, d2, np.asarray(idx, dtype=np.uint32)) if (enc == 1 and len(idx)) else None     # code matrices resident on the device
+                res_src = (d1, d2, np.asarray(idx, dtype=np.uint32)) if (enc == 1 and len(idx) and not ss) else None     # code matrices resident on the device
                 try:
                     gh = mbgraph_native.run_partition_handle(None if rb is None else (rb if len(rb) else np.zeros(1, np.uint8)),
                                                              0 if rb is None else len(rb) // (K + 1), K, b1, o1, b2, o2, ctx=ctx_b,
@@ -210,7 +219,7 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
                                                              o2, ctx=ctx_b, enc=enc, rc1=rc1, rc2=rc2, unitigs=unitigs, part=part_index[name],
                                                              resident=res_src)
                 n_rows = part["n_k1mer_rows"][name]
-                if enc == 1:
+                if enc == 1 and not ss:
                     store.release(b1)
                     if b2 is not None and b2 is not b1:
                         store.release(b2)
@@ -218,8 +227,12 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
                 return PartitionRecord(len(part["routes"][name]), n_rows, gh), tt
             else:
                 rows = part["k1mers"][name]
-                r1 = [store.mate1(int(d)) for d in idx]
-                reads = [r1, [store.mate2(int(d)) for d in idx]] if paired else [r1]
+                if ss:
+                    r1 = [store._get(store.r1, int(d)) for d in idx]
+                    reads = [r1, [store._rc(store._get(store.r2, int(d))) for d in idx]] if paired else [r1]
+                else:
+                    r1 = [store.mate1(int(d)) for d in idx]
+                    reads = [r1, [store.mate2(int(d)) for d in idx]] if paired else [r1]
                 tt["materialize reads"] = time.time() - t0
                 t0 = time.time()
                 g, singles, comps = mbgraph.run_partition(rows, reads, K, paired, hits_factory)

@@ -169,10 +169,11 @@ def finalize(all_lines, ds=True):
         except _lib.ShannonError as e:
             if "non-ACGT" not in str(e) and "empty line" not in str(e):
                 raise
+    # (ds = the user's strandedness, which process_concatenated_fasta.py gets, shannon.py:596; faster_reps.py always runs with -d, :604)
     srt = length_sort(process_concatenated(all_lines, ds))
     try:
-        return find_reps_native(srt, ds)
+        return find_reps_native(srt, True)
     except RuntimeError as e:
         if "non-ACGT" not in str(e):
             raise
-        return find_reps(srt, ds)          # transcripts with other characters: plain Python form
+        return find_reps(srt, True)          # transcripts with other characters: plain Python form

@@ -154,9 +154,14 @@ def main():
            ("syn_pe_s20_K31", 20, 2500, True, 31, 500), ("syn_se_s7_K20", 7, 2500, False, 20, 500),
            ("syn_part_s33", 33, 3000, True, 25, 1),
            # find_mate_pairs adds paths (mbgraph.py:151-160); the second one is a K=31 case with a multi-node partition
-           ("syn_pe_hairpin", 40, 4000, True, 25, 500), ("syn_pe_hairpin_K31", 41, 4000, True, 31, 500)]
+           ("syn_pe_hairpin", 40, 4000, True, 25, 500), ("syn_pe_hairpin_K31", 41, 4000, True, 31, 500),
+           # -s / --ss / --strand_specific (shannon.py:407-411): no strand doubling; of a pair, RC(R2) stands for R2
+           ("syn_se_ss_s53", 53, 2500, False, 25, 500), ("syn_pe_ss_s69", 69, 2500, True, 25, 500), ("syn_pe_ss_s71", 71, 2500, True, 25, 500)]
     for name, seed, npairs, paired, K, psize in syn:
+        ss = "_ss_" in name
         manifest[name] = {"inputs": [name + ".npz"], "K": K, "paired": paired, "sf_seed": seed, "partition_size": psize}
+        if ss:
+            manifest[name]["strand_specific"] = True
         if not want(name):
             continue
         isos = hairpin_transcriptome(seed) if "hairpin" in name else tricky_transcriptome(seed, 3 if psize > 10 else 6)
@@ -171,7 +176,7 @@ def main():
             hook = os.path.join(d, "hook.py")
             open(hook, "w").write(PART_HOOK)
         art = H.run_case(os.path.join(TMP, name), [d + "/r1.fasta", d + "/r2.fasta"] if paired else [d + "/r1.fasta"],
-                         K, paired, partition_size=psize, part_hook=hook, run_sf=True, sf_seed=seed)
+                         K, paired, partition_size=psize, part_hook=hook, run_sf=True, sf_seed=seed, double_stranded=not ss)
         save(name, slim(art, keep_full=(name in ("syn_pe_s0", "syn_se_s7_K20"))))
         print(name, "done", art["n_k1mers"], {c: p["graph"] and len(p["graph"]["nodes"]) for c, p in art["partitions"].items()})
     json.dump(manifest, open(os.path.join(OUT, "manifest.json"), "w"), indent=1)

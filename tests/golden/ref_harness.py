@@ -234,16 +234,29 @@ def canonical_graph(inter_dir):
             "paths": sorted(paths)}
 
 
+def strand_specific_files(reads_files, outdir):
+    """shannon.py:394-424 with -s / --ss / --strand_specific (double_stranded=False): single-end reads are taken as they are;
+    of a pair, the second mate is reverse-complemented (rc_gnu, :407-411) -- no strand doubling.  Returns new reads_files."""
+    os.makedirs(outdir, exist_ok=True)
+    if len(reads_files) == 1:
+        return list(reads_files)
+    rc2 = os.path.join(outdir, "rc_2.fasta")
+    subprocess.run([sys.executable, os.path.join(os.path.dirname(outdir), "tref", "rc_s.py"), reads_files[1], rc2], check=True)
+    return [reads_files[0], rc2]
+
+
 def run_case(root, reads_files, K, paired, partition_size=500, part_hook=None, hashseed="0",
-             run_sf=False, sf_seed=0):
+             run_sf=False, sf_seed=0, double_stranded=True):
     """Run the translated reference end-to-end (shannon.py:394-566 order) on `reads_files`.
-    Returns a dict of artefacts (all plain data)."""
+    Returns a dict of artefacts (all plain data).  double_stranded=False: the -s run (after the read files are made,
+    shannon.py:427 sets double_stranded = False for every later stage in BOTH modes: only the read files differ, and
+    process_concatenated_fasta at the end, which gets the user's flag)."""
     shutil.rmtree(root, ignore_errors=True)
     os.makedirs(root)
     tref = prepare_translated(os.path.join(root, "tref"))
     work = os.path.join(root, "work")
     os.makedirs(os.path.join(work, "s_algo_input"))
-    rf = double_strand_files(reads_files, os.path.join(root, "dbl"))
+    rf = double_strand_files(reads_files, os.path.join(root, "dbl")) if double_stranded else strand_specific_files(reads_files, os.path.join(root, "dbl"))
     cnt = jellyfish_standin(rf, K + 1, os.path.join(work, "s_algo_input", "k1mer.dict_org"))
     run_extension_and_partition(tref, work, rf, K, paired, partition_size, part_hook, hashseed=hashseed)
     art = {"K": K, "paired": paired, "n_k1mers": len(cnt)}

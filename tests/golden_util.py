@@ -31,6 +31,34 @@ def load_inputs(name):
     return out
 
 
+def strand_specific(name):
+    """the case was generated with -s / --ss (shannon.py:407-411: no strand doubling, RC(R2) stands for R2)"""
+    return bool(MANIFEST[name].get("strand_specific"))
+
+
+DS_CASES = sorted(n for n in MANIFEST if not MANIFEST[n].get("strand_specific"))
+SS_CASES = sorted(n for n in MANIFEST if MANIFEST[n].get("strand_specific"))
+
+
+def read_files(name, inp):
+    """the read files the stages after shannon.py:424 see: strand-doubled (default) or as -s leaves them"""
+    from oracle import seqs
+    paired = MANIFEST[name]["paired"]
+    if strand_specific(name):
+        return seqs.strand_specific(inp[0], inp[1] if paired else None)
+    return list(seqs.double_strand_paired(*inp)) if paired else [seqs.double_strand_single(inp[0])]
+
+
+def count_case(ctx, name, sets):
+    """the k1-mer table of a golden case on the device: canonical counting of the doubled input, or -- strand-specific cases --
+    forward counting of reads / (reads_1, RC(reads_2))"""
+    from shannon_amd import device
+    k1 = MANIFEST[name]["K"] + 1
+    if strand_specific(name):
+        return device.count_k1mers_strand_specific(ctx, sets[0], sets[1] if MANIFEST[name]["paired"] else None, k1)
+    return device.count_k1mers(ctx, sets, k1, both_strands=True)
+
+
 def approx_eq(a, b, tol=1e-9):
     if isinstance(a, float) or isinstance(b, float):
         return abs(float(a) - float(b)) <= tol * max(1.0, abs(float(a)), abs(float(b)))

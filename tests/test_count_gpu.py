@@ -27,14 +27,14 @@ def test_count_matches_golden(ctx, name):
     g = load_case(name)
     inp = load_inputs(name)
     sets = [device.Reads.from_strings(ctx, r) for r in inp]
-    t = device.count_k1mers(ctx, sets, g["K"] + 1, both_strands=True)
+    t = count_case(ctx, name, sets)
     keys, cnts = t.dump(lower=1)
     assert len(keys) == g["n_k1mers"]
     assert int(cnts.astype(np.uint64).sum()) == g["k1mer_total"]
     rows = [[device.key_to_str(k, g["K"] + 1), int(c)] for k, c in zip(keys, cnts)]
     assert digest(rows) == g["k1mer_counts_digest"]      # bit-exact sorted multiset
     # and against the oracle restatement on the strand-doubled records
-    dbl = list(seqs.double_strand_paired(*inp)) if g["paired"] else [seqs.double_strand_single(inp[0])]
+    dbl = read_files(name, inp)
     ok, oc = oracle_table([r for f in dbl for r in f], g["K"] + 1)
     assert np.array_equal(ok, keys) and np.array_equal(oc, cnts.astype(np.uint64))
 

@@ -36,10 +36,11 @@ def test_end_to_end_vs_oracle(ctx, name):
     inp = load_inputs(name)
     psize = m.get("partition_size", 500)
     pv = [part_vectors(len(b["contigs"]), psize) for b in g["big_components"]] or None
+    ds = not strand_specific(name)                          # -s / --ss cases: shannon.py:407-411
     R = pipeline.assemble(ctx, inp[0], inp[1] if m["paired"] else None, K=m["K"], partition_size=psize, sample="s",
-                          seed=m["sf_seed"], part_vectors=pv)
+                          seed=m["sf_seed"], part_vectors=pv, double_stranded=ds)
     O = opipe.assemble(inp[0], inp[1] if m["paired"] else None, K=m["K"], partition_size=psize, sample="s",
-                       seed=m["sf_seed"], part_vectors=pv)
+                       seed=m["sf_seed"], part_vectors=pv, double_stranded=ds)
     assert R.extension.contigs == O["contigs"] == g["contigs"]
     assert list(R.partitions) == list(O["partitions"]) == list(g["partitions"])
     for p in R.partitions:
@@ -74,6 +75,30 @@ def test_cli_config1_samples_se(tmp_path):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "shannon.py"), "-o", str(out), "--single", str(fa)],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
     assert p.returncode != 0 and "not empty" in p.stdout
+
+
+@pytest.mark.parametrize("flag", ["-s", "--strand_specific"])
+def test_cli_strand_specific_pe(tmp_path, flag):
+    """-s / --ss / --strand_specific (shannon.py:407-411) through the CLI on a paired case whose reference run was made with
+    double_stranded = False: the contig file equals the reference's, the final FASTA the oracle's run of the same mode."""
+    import subprocess, sys, os
+    from conftest import ROOT
+    from oracle import pipeline as opipe
+    name = "syn_pe_ss_s69"
+    inp = load_inputs(name)
+    files = []
+    for m, reads in enumerate(inp):
+        fa = tmp_path / ("r%d.fasta" % (m + 1))
+        fa.write_text("".join(">%d\n%s\n" % (i, s) for i, s in enumerate(reads)))
+        files.append(str(fa))
+    out = tmp_path / "OUTSS"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "shannon.py"), "-o", str(out), "--left", files[0], "--right", files[1], "-K", "25", flag],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:]
+    got = dict((h[1:], s) for h, s in parse_fasta((out / "shannon.fasta").read_text()))
+    ref = opipe.assemble(inp[0], inp[1], K=25, sample="OUTSS", seed=0, double_stranded=False)
+    assert got == ref["final"] and len(got) > 0
+    assert (out / "TEMP" / "OUTSS_algo_input" / "k1mer.dict_contig").read_text().split() == load_case(name)["contigs"]
 
 
 def test_cli_samples_pe(tmp_path):

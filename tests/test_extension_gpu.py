@@ -21,7 +21,7 @@ def test_extension_matches_golden(ctx, name):
     g = load_case(name)
     psize = MANIFEST[name].get("partition_size", 500)
     sets = [device.Reads.from_strings(ctx, r) for r in load_inputs(name)]
-    t = device.count_k1mers(ctx, sets, g["K"] + 1)
+    t = count_case(ctx, name, sets)
     res = ec.run_correction(ctx, t, 3, 75, psize)
     assert res.contigs == g["contigs"]                      # ordered list, bit-exact
     assert len(res.allowed) == g["n_allowed"]

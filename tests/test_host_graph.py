@@ -31,7 +31,7 @@ def test_product_graph_stage(name):
     K, paired = g["K"], g["paired"]
     psize = MANIFEST[name].get("partition_size", 500)
     inp = load_inputs(name)
-    dbl = list(seqs.double_strand_paired(*inp)) if paired else [seqs.double_strand_single(inp[0])]
+    dbl = read_files(name, inp)
     tab = count.count_k1mers_dict([r for f in dbl for r in f], K + 1)
     res = extension.run_correction([(k, tab[k]) for k in sorted(tab, reverse=True)], comp_size_threshold=psize)
     pv = [part_vectors(len(cl), psize) for cl, _ in res.big_components]
@@ -101,7 +101,7 @@ def test_native_contig_graph_matches_oracle(name):
     g = load_case(name)
     K = g["K"]
     inp = load_inputs(name)
-    dbl = list(seqs.double_strand_paired(*inp)) if g["paired"] else [seqs.double_strand_single(inp[0])]
+    dbl = read_files(name, inp)
     tab = count.count_k1mers_dict([r for f in dbl for r in f], K + 1)
     kmers, k1 = extension.load_kmers([(k, tab[k]) for k in sorted(tab, reverse=True)])
     heaviest = sorted(kmers.items(), key=lambda kv: kv[1])
@@ -146,7 +146,7 @@ def test_native_graph_stage(name):
     K, paired = g["K"], g["paired"]
     psize = MANIFEST[name].get("partition_size", 500)
     inp = load_inputs(name)
-    dbl = list(seqs.double_strand_paired(*inp)) if paired else [seqs.double_strand_single(inp[0])]
+    dbl = read_files(name, inp)
     tab = count.count_k1mers_dict([r for f in dbl for r in f], K + 1)
     res = extension.run_correction([(k, tab[k]) for k in sorted(tab, reverse=True)], comp_size_threshold=psize)
     pv = [part_vectors(len(cl), psize) for cl, _ in res.big_components]
@@ -225,7 +225,7 @@ def test_contig_graph_fed_in_pieces_equals_one_call(name):
     g = load_case(name)
     inp = load_inputs(name)
     K = g["K"]
-    dbl = list(seqs.double_strand_paired(*inp)) if g["paired"] else [seqs.double_strand_single(inp[0])]
+    dbl = read_files(name, inp)
     tab = count.count_k1mers_dict([r for f in dbl for r in f], K + 1)
     cands = extension.candidate_contigs([(k, tab[k]) for k in sorted(tab, reverse=True)]) if hasattr(extension, "candidate_contigs") else None
     if cands is None:                                    # any strings in a fixed order will do: accepted contigs + variants of them

@@ -12,7 +12,7 @@ def run_oracle_front(name):
     g = load_case(name)
     K, paired = g["K"], g["paired"]
     inp = load_inputs(name)
-    dbl = list(seqs.double_strand_paired(*inp)) if paired else [seqs.double_strand_single(inp[0])]
+    dbl = read_files(name, inp)
     tab = count.count_k1mers_dict([r for f in dbl for r in f], K + 1)
     return g, K, paired, dbl, tab
 
