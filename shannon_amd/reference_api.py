@@ -89,8 +89,8 @@ def kmers_for_component(k1mer_dictionary, kmer_directory, reads, reads_files, di
                         gpmetis_path="gpmetis", penalty=5, only_reads=False, inMem=False, nJobs=1, ctx=None, part_vectors=None):
     """kmers_for_component.py:144-558.  Reads component{i}contigs.txt + component{i}.txt (METIS) and remaining_contigs{i}.txt from
     directory_name, partitions the big components (gpmetis is replaced by the deterministic partitioner of
-    shannon_amd/kmers_for_component.py; `part_vectors` replays given gpmetis vectors), routes the reads of reads_files (already
-    strand-doubled, as shannon.py:394-424 writes them) and writes reads{comp}.fasta (paired: reads{comp}_1.fasta / _2.fasta) and
+    shannon_amd/kmers_for_component.py; `part_vectors` replays given gpmetis vectors), routes the reads of reads_files (as
+    shannon.py:394-424 wrote them; double_stranded=False -- what shannon.py passes -- routes them as they are) and writes reads{comp}.fasta (paired: reads{comp}_1.fasta / _2.fasta) and
     component{comp}k1mers_allowed.dict.  Returns [components_broken, new_comps, contig_weights, rps] (:558)."""
     ctx = ctx or default_context()
     res = ec.ExtensionResult()
@@ -105,27 +105,39 @@ def kmers_for_component(k1mer_dictionary, kmer_directory, reads, reads_files, di
     while os.path.exists(os.path.join(directory_name, "remaining_contigs%d.txt" % i)):
         res.remaining.append(open(os.path.join(directory_name, "remaining_contigs%d.txt" % i)).read().split())
         i += 1
-    # the read files hold the strand-doubled reads: the first half are the reads as given, the second half the other strand
     files = [_read_fasta(p) for p in reads_files] if reads_files else [list(r) for r in reads]
-    n_half = len(files[0]) // 2 if double_stranded else len(files[0])
-    if paired_end:
-        # reads_1 = R1 ++ RC(R2), reads_2 = RC(R1) ++ R2 (shannon.py:413-424)
-        r1, r2 = files[0][:n_half], files[1][n_half:]
-    else:
-        r1, r2 = files[0][:n_half], None
     if not double_stranded:
-        raise NotImplementedError("strand-specific read layout is not built (double-stranded only)")
-    d1 = device.Reads.from_strings(ctx, r1)
-    d2 = device.Reads.from_strings(ctx, r2) if r2 is not None else None
-    out = kfc.kmers_for_component(ctx, res, d1, d2, K, partition_size, overload, penalty, repartition, part_vectors, want_rows=True)
+        # what shannon.py really passes (double_stranded is False from :427 on, in both modes): the files are routed as they are --
+        # strand-doubled by :394-424 in the default mode, reads / (reads_1, RC(reads_2)) with -s -- read i of a pair file with
+        # read i of the other, forward k1-mers only (kmers_for_component.py:186-205, 322-403).  shn_route_reads_mode(strand_specific)
+        # takes the reverse complement of the second file's reads itself: it is handed their reverse complements.
+        r1 = files[0]
+        r2 = [kfc.ReadStore._rc(q) for q in files[1]] if paired_end else None
+        d1 = device.Reads.from_strings(ctx, r1)
+        d2 = device.Reads.from_strings(ctx, r2) if r2 is not None else None
+        out = kfc.kmers_for_component(ctx, res, d1, d2, K, partition_size, overload, penalty, repartition, part_vectors, want_rows=True,
+                                      strand_specific=True)
+        mates = lambda idx: ([files[0][int(d)] for d in idx], [files[1][int(d)] for d in idx] if paired_end else None)
+    else:
+        # double_stranded=True: the read files hold the strand-doubled reads (the first half are the reads as given, the second half
+        # the other strand) and are un-doubled for the kernels, which double on chip
+        n_half = len(files[0]) // 2
+        if paired_end:
+            # reads_1 = R1 ++ RC(R2), reads_2 = RC(R1) ++ R2 (shannon.py:413-424)
+            r1, r2 = files[0][:n_half], files[1][n_half:]
+        else:
+            r1, r2 = files[0][:n_half], None
+        d1 = device.Reads.from_strings(ctx, r1)
+        d2 = device.Reads.from_strings(ctx, r2) if r2 is not None else None
+        out = kfc.kmers_for_component(ctx, res, d1, d2, K, partition_size, overload, penalty, repartition, part_vectors, want_rows=True)
+        store = kfc.ReadStore(r1, r2)
+        mates = lambda idx: ([store.mate1(int(d)) for d in idx], [store.mate2(int(d)) for d in idx] if paired_end else None)
     d1.close()
     if d2 is not None:
         d2.close()
-    store = kfc.ReadStore(r1, r2)
     rps = {}
     for comp, idx in out["routes"].items():
-        m1 = [store.mate1(int(d)) for d in idx]
-        m2 = [store.mate2(int(d)) for d in idx] if paired_end else None
+        m1, m2 = mates(idx)
         if inMem:
             rps[comp] = [m1, m2] if paired_end else [m1]
         else:

@@ -31,8 +31,12 @@ def _canonical_from_files(inter):
     return {"single_nodes": sorted(singles), "nodes": sorted(nodes), "edges": sorted(edges), "paths": sorted(paths)}, c
 
 
-@pytest.mark.parametrize("name", ["syn_pe_s0", "syn_se_s7_K20", "syn_pe_hairpin"])
-def test_reference_entry_points_through_files(name, tmp_path):
+# ds_arg: the `double_stranded` argument of kmers_for_component.  shannon.py passes False in both modes (it is reset at :427): the
+# files are then routed as they are -- doubled (default mode) or reads / (reads_1, RC(reads_2)) (-s cases); True: files known to be
+# strand-doubled
+@pytest.mark.parametrize("name,ds_arg", [("syn_pe_s0", True), ("syn_pe_s0", False), ("syn_se_s7_K20", True), ("syn_se_s7_K20", False),
+                                         ("syn_pe_hairpin", True), ("syn_pe_ss_s69", False), ("syn_se_ss_s53", False)])
+def test_reference_entry_points_through_files(name, ds_arg, tmp_path):
     from shannon_amd import reference_api as api
     from oracle import seqs, count
     g = load_case(name)
@@ -43,7 +47,7 @@ def test_reference_entry_points_through_files(name, tmp_path):
     ai = os.path.join(work, "s_algo_input")
     os.makedirs(ai)
     # shannon.py:394-441: strand-doubled read files + the Jellyfish dump (exact counter, KMER-descending: the pinned order)
-    dbl = list(seqs.double_strand_paired(*inp)) if paired else [seqs.double_strand_single(inp[0])]
+    dbl = read_files(name, inp)
     rf = []
     for i, reads in enumerate(dbl):
         p = os.path.join(work, "reads_%d.fasta" % (i + 1))
@@ -58,8 +62,9 @@ def test_reference_entry_points_through_files(name, tmp_path):
     assert digest(sorted([k, v] for k, v in allowed.items())) == g["allowed_digest"]
     assert open(os.path.join(work, "reconstructed_single_contigs.fasta")).read() == g["single_contigs_fasta"]
     from shannon_amd import pipeline
-    R = pipeline.assemble(api.default_context(), inp[0], inp[1] if paired else None, K=K, sample="p", seed=m["sf_seed"])
-    r = api.kmers_for_component(allowed, ai, reads, rf, work, "contigs.txt", True, True, paired, True, 500, 2, K, "true", 5, False, False, 1)
+    R = pipeline.assemble(api.default_context(), inp[0], inp[1] if paired else None, K=K, sample="p", seed=m["sf_seed"],
+                          double_stranded=not strand_specific(name))
+    r = api.kmers_for_component(allowed, ai, reads, rf, work, "contigs.txt", True, ds_arg, paired, True, 500, 2, K, "true", 5, False, False, 1)
     assert list(r[1]) == list(g["partitions"])
     for comp, gp in g["partitions"].items():
         files = [os.path.join(work, "reads%s_%s.fasta" % (comp, x)) for x in ("1", "2")] if paired else [os.path.join(work, "reads%s.fasta" % comp)]
