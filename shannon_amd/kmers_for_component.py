@@ -62,6 +62,48 @@ def partition_graph(metis_text, n_parts, ufactor=1000):
             p = min(range(n_parts), key=lambda q: (sizes[q], q))
             part[v] = p
             sizes[p] += 1
+    return refine_partition(adj, part, n_parts, ufactor)
+
+
+def edge_cut(adj, part):
+    """total weight of the edges between different parts (what gpmetis minimises)"""
+    return sum(w for v, nb in enumerate(adj) for u, w in nb if u > v and part[u] != part[v])
+
+
+def refine_partition(adj, part, n_parts, ufactor=1000, max_passes=16):
+    """k-way boundary refinement of a partition (the last phase of the multilevel scheme gpmetis runs): vertices in index order, a
+    vertex moves to the neighbouring part it is connected to most strongly if that lowers the cut, the target stays within the
+    balance bound (1 + U/1000) * n / P and its own part does not become empty; passes until nothing moves.  Every move lowers the
+    cut, so it ends; deterministic.  On graphs with a planted partition the cut of the grown partition falls by 20-38 % and ends
+    within 0-45 % of the planted cut (tests/test_host_graph.py::test_own_partitioner_cut_quality)."""
+    n = len(adj)
+    part = list(part)
+    sizes = [0] * n_parts
+    for p in part:
+        sizes[p] += 1
+    max_size = max(int(math.ceil(n / float(n_parts))), int((1.0 + ufactor / 1000.0) * n / float(n_parts)))
+    for _ in range(max_passes):
+        moved = 0
+        for v in range(n):
+            pv = part[v]
+            if sizes[pv] <= 1 or not adj[v]:
+                continue
+            conn = {}
+            for u, w in adj[v]:
+                if u != v:
+                    conn[part[u]] = conn.get(part[u], 0) + w
+            own = conn.get(pv, 0)
+            best, bw = -1, own
+            for q in sorted(conn):
+                if q != pv and conn[q] > bw and sizes[q] < max_size:
+                    best, bw = q, conn[q]
+            if best >= 0:
+                part[v] = best
+                sizes[pv] -= 1
+                sizes[best] += 1
+                moved += 1
+        if not moved:
+            break
     return part
 
 
