@@ -1554,6 +1554,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   // (which serve the latency-bound re-runs of a few long walks) are not made in such a round.  The expected number of
   // dirty walks is the block size when a block opens, else the count of the round before.
   const unsigned long long bulk_min = getenv("SHN_EXT_BULK") ? strtoull(getenv("SHN_EXT_BULK"), nullptr, 10) : 262144ULL;
+  const unsigned long long dense_min = getenv("SHN_EXT_DENSE") ? strtoull(getenv("SHN_EXT_DENSE"), nullptr, 10) : (4ULL << 20);   // (BASELINE configs[2]: 262144 -> 954 ms, 2 M or 16 M -> 900 ms per extension)
   // thread walker on persistent lanes (ext_walk_refill_kernel; SHN_EXT_REFILL=0: one walk per thread, ext_walk_kernel)
   const bool refill = tune("SHN_EXT_REFILL", 0) != 0;
   int n_cu = 256;
@@ -1561,6 +1562,10 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   unsigned long long expect_dirty = limit;
   while (!converged && it < max_iterations) {
     const bool bulk = bulk_min && expect_dirty >= bulk_min;
+    // dense: the begin / mark passes stream all claims (rounds that write nearly everywhere); else they follow the 128-byte-line
+    // flags the walkers and the release leave behind.  A bulk round of a few hundred thousand walks writes a few million
+    // k1-mers: far fewer lines than the 23 GB of claims and snapshot the dense passes read.
+    const bool dense = bulk && expect_dirty >= dense_min;
     // classify the dirty walks of the open block; a block without dirty walks is consistent = final
     TRYE(hipMemsetAsync(d_cnt + 2, 0, 32, s));
     if (limit > frozen)
@@ -1617,7 +1622,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     if (fresh_block && precise_marks && snap_current) { TRYE(hipMemsetAsync(d_cnt + 6, 0, 16, s)); TRYE(hipMemsetAsync(d_cnt + 13, 0, 8, s)); }
     else
     hipLaunchKernelGGL(ext_round_begin_kernel, dim3((uint32_t)cdiv(cdiv(2 * n, 4), 256)), dim3(256), 0, s, claim, snap, 2 * n, dirty, (uint64_t)ns, d_cnt,
-                       (!precise_marks || !snap_current) ? 1 : 0, bulk ? (uint8_t*)nullptr : chunk, frozen, limit, coarse);
+                       (!precise_marks || !snap_current) ? 1 : 0, dense ? (uint8_t*)nullptr : chunk, frozen, limit, coarse);
     snap_current = true;
     WalkArgs A;
     A.order = e->d_order; A.adjR = rows_R(e->d_rec); A.adjL = rows_L(e->d_rec); A.weight = words_weight(e->d_rec);
@@ -1626,7 +1631,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     A.pool = pool; A.moff = moff; A.mR = mR; A.mL = mL; A.mvalid = mvalid; A.hint = words_hint(e->d_rec);
     A.promote_steps = bulk ? 0xFFFFFFFFu : promote_steps;
     A.promo_list = promo_list; A.promo_count = d_cnt + 13; A.res_cur = res_cur; A.res_info = res_info;
-    A.chunk = bulk ? nullptr : chunk;          // (bulk rounds write nearly everywhere: their mark pass is dense, the walkers do not flag)
+    A.chunk = dense ? nullptr : chunk;         // (dense rounds write nearly everywhere: their mark pass is dense, the walkers do not flag)
     A.robbed = robbed;
     A.steps_counter = d_cnt + 1; A.wave_steps_counter = d_cnt + 64; A.dbg = (getenv("SHN_DEBUG") || getenv("SHN_EXT_XTIME")) ? d_cnt + 32 : nullptr;
     // long (wave per walk) and short (thread per walk) kernels are independent: overlap them on two streams
@@ -1673,8 +1678,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     { TimerRegion tk(ctx, T_EXT_MARK);
       hipLaunchKernelGGL(ext_mark_kernel, dim3(std::min<uint32_t>(g2n, 4096u)), dim3(256), 0, s, claim, snap, 2 * n, e->d_rec,
                          dirty, ran, d_cnt + 6, frozen, limit, bulk ? (const uint8_t*)nullptr : (const uint8_t*)fill, moff, mR, pool, e->d_nr, e->d_nl, precise_marks,
-                         bulk ? (const uint8_t*)nullptr : chunk);
-      if (!bulk) TRYE(hipMemsetAsync(chunk, 0, n_chunks, s)); }
+                         dense ? (const uint8_t*)nullptr : chunk);
+      if (!dense) TRYE(hipMemsetAsync(chunk, 0, n_chunks, s)); }
     hipLaunchKernelGGL(ext_verify_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, ran, robbed, (uint64_t)ns, dirty);
     if (getenv("SHN_EXT_FAULT") && it + 1 == atoi(getenv("SHN_EXT_FAULT"))) TRYE(hipMemsetAsync(dirty, 0, ns + 1, s));   // (tests: lose every mark of this round)
     if (getenv("SHN_EXT_ALLDIRTY")) { TRYE(hipMemsetAsync(dirty, 0, ns + 1, s)); TRYE(hipMemsetAsync(dirty + frozen, 1, limit - frozen, s)); }
