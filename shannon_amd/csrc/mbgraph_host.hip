@@ -757,6 +757,24 @@ struct Graph {
           std::vector<std::vector<int>> paths;
           std::vector<int> cur;
           std::vector<std::pair<int, int>> one(1);
+          // the sums per edge and the set of paths are kept in hash tables while the reads go by (10^5 reads of a highly expressed
+          // transcript name the same few edges and paths: a tree look-up with a dozen dependent misses per read was most of this
+          // loop) and go into the ordered containers afterwards; the copy counts of reads are whole numbers, so the order of the
+          // additions does not show in the sums
+          std::unordered_map<uint64_t, double> edge_sum;
+          std::unordered_map<uint64_t, std::vector<std::vector<int>>> path_seen;
+          auto note_path = [&](const std::vector<int>& p, double w) {
+            for (size_t j = 0; j + 1 < p.size(); j++) edge_sum[((uint64_t)(uint32_t)p[j] << 32) | (uint32_t)p[j + 1]] += w;
+            if (p.size() > 2) {
+              cntp++;
+              uint64_t h = 0xcbf29ce484222325ULL;
+              for (int v : p) h = (h ^ (uint64_t)(uint32_t)v) * 0x100000001b3ULL;
+              auto& lst = path_seen[h];
+              bool have = false;
+              for (const auto& q : lst) if (q == p) { have = true; break; }
+              if (!have) { lst.push_back(p); known_paths.insert(p); }
+            }
+          };
           for (size_t r = 0; r < n_rd(); r++) {
             if (st[r] < 2) continue;
             const RStr rb = rstr((int)r);
@@ -771,11 +789,11 @@ struct Graph {
               search_sequence(rb, 0, sn, so, 30, cur, paths);
               for (auto& p : paths) {
                 rfirst[r] = p.front(); rlast[r] = p.back(); rhas[r] = 1;
-                for (size_t j = 0; j + 1 < p.size(); j++) known_edges[{p[j], p[j + 1]}] += rcc[r];
-                if (p.size() > 2) { known_paths.insert(p); cntp++; }
+                note_path(p, rcc[r]);
               }
             }
           }
+          for (const auto& kv : edge_sum) known_edges[{(int)(uint32_t)(kv.first >> 32), (int)(uint32_t)kv.first}] += kv.second;
           n_known = cntp;
           if (dbgk) fprintf(stderr, "[mbgraph]   kp (device) node text %.3f s scan %.3f s slow index %.3f s search %.3f s  (%zu bases, %zu reads, %zu slow)\n", tk1 - tk0,
                             tk2 - tk1, tk3 - tk2, nowk() - tk3, nb.size(), n_rd(), n_slow);
