@@ -564,7 +564,7 @@ def main():
         per_read = {"count.direct": 25.0 + 12.0 * distinct / max(1, n_reads),    # packed read in, (key, count) of the distinct k1-mers out
                     "count.hist1": 25.0, "count.scatter1": 25.0 + 8.0 * W, "count.hist2": 8.0 * W,
                     "count.scatter2": 16.0 * W, "count.buckets": 8.0 * W, "route": 192.0}
-        ext = last.res["extension"] if use_dist else {k: getattr(last.R.extension, k) for k in ("iterations", "n_walks", "total_steps", "wave_steps")}
+        ext = last.res["extension"] if use_dist else {k: getattr(last.R.extension, k, None) for k in ("iterations", "n_walks", "total_steps", "wave_steps", "dense_rounds")}
         steps_all = ext["total_steps"] or 0
         steps_wave = ext["wave_steps"] or 0
         n_or = 2 * distinct                                   # oriented k1-mers
@@ -572,7 +572,9 @@ def main():
         per_step_bytes = {k: v * n_reads for k, v in per_read.items()}
         per_step_bytes["extend.walk_thread"] = 152.0 * (steps_all - steps_wave)     # 4 candidates x (claim 8 + snapshot 8 + weight 4 + row 16) + claim 8
         per_step_bytes["extend.walk_wave"] = 112.0 * steps_wave                      # same without the row prefetch, + memo entry
-        per_step_bytes["extend.mark"] = 16.0 * n_or * (ext["iterations"] or 0)
+        # mark pass: claim + snapshot of every oriented k1-mer in the rounds that stream them (dense), one flag byte per 16 k1-mers in the others
+        dense_r = ext.get("dense_rounds") if ext.get("dense_rounds") is not None else (ext["iterations"] or 0)
+        per_step_bytes["extend.mark"] = 16.0 * n_or * dense_r + (n_or / 16.0) * max(0, (ext["iterations"] or 0) - dense_r)
         per_step_bytes["extend.adjacency"] = (8 * 8.0 + 2 * 64.0 + 8.0) * distinct       # per k1-mer: 8 keys looked up, its two 64-byte records written, its own key
         kt = {k: v for k, v in timers.items() if k in KERNEL}
         # the key array goes through one or two levels below level 1 (csrc/count.hip: at most 256 streams per level): the bytes of
@@ -654,7 +656,7 @@ def main():
                        "lp_trials": lp["lp_trials"] / args.steps, "lp_degenerate_trials": lp["lp_degenerate_trials"] / args.steps,
                        "lp_newton_steps": lp["newton_steps"] / args.steps, "lp_not_converged": lp["not_converged"], "lp_too_large_trials": lp["too_large_trials"],
                        "extension_iterations": ext["iterations"], "extension_walks": ext["n_walks"],
-                       "extension_walk_steps": steps_all,
+                       "extension_walk_steps": steps_all, "extension_dense_rounds": ext.get("dense_rounds"),
                        "partitions": (len(last.res["partitions"]) if use_dist else {k: [v["n_reads_routed"], v["n_k1mers"]] for k, v in last.R.partitions.items()}),
                        "windows_per_step": total, "distinct_k1mers": distinct},
             "roofline": r_dom,

@@ -138,6 +138,7 @@ uint64_t shn_ext_n_walks(const shn_ext* e);
 int shn_ext_iterations(const shn_ext* e);
 uint64_t shn_ext_total_steps(const shn_ext* e);   /* walk steps executed over all fixpoint iterations */
 uint64_t shn_ext_wave_steps(const shn_ext* e);    /* ... of which by the wavefront (long-walk) kernel */
+int shn_ext_dense_rounds(const shn_ext* e);       /* rounds whose begin / mark passes streamed every claim (the others followed line flags) */
 /* per walk (host arrays of shn_ext_n_walks entries): right/left extension lengths (n_right ==
  * 0xFFFFFFFF marks a void walk) and the weight sum including the seed (tot_wt, :351)          */
 int shn_ext_stats(shn_ctx* ctx, const shn_ext* e, uint32_t* n_right, uint32_t* n_left, uint64_t* tot_weight);

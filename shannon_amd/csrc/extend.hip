@@ -94,6 +94,7 @@ struct shn_ext {
   u64* d_claim2;         // [2n] scratch
   uint64_t total_steps;  // walk steps executed over all iterations (for the bench's byte model)
   uint64_t wave_steps;   // ... of which by the wavefront kernel
+  int dense_rounds;      // rounds whose begin / mark passes streamed all claims
   uint32_t* d_nr;        // [n_seeds] right steps (UNCLAIMED = void walk)
   uint32_t* d_nl;        // [n_seeds]
   uint64_t* d_totw;      // [n_seeds] sum of weights incl. the seed
@@ -1671,6 +1672,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     }
     if (plan[0]) TRYE(hipStreamWaitEvent(s, ev_join, 0));
     fresh_block = false;
+    if (dense) e->dense_rounds++;
     // who has to run next round?  walks whose view changed (mark) + walks that lost a claim race (verify);
     // the walks that ran get their memo rebuilt from the claims
     hipLaunchKernelGGL(ext_memo_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 256)), dim3(256), 0, s, ran, dirty, e->d_nr, e->d_nl, e->d_order, frozen, limit,
@@ -1758,6 +1760,7 @@ extern "C" uint64_t shn_ext_n_walks(const shn_ext* e) { return e ? e->n_seeds : 
 extern "C" int shn_ext_iterations(const shn_ext* e) { return e ? e->iterations : 0; }
 extern "C" uint64_t shn_ext_total_steps(const shn_ext* e) { return e ? e->total_steps : 0; }
 extern "C" uint64_t shn_ext_wave_steps(const shn_ext* e) { return e ? e->wave_steps : 0; }
+extern "C" int shn_ext_dense_rounds(const shn_ext* e) { return e ? e->dense_rounds : 0; }
 
 extern "C" int shn_ext_stats_range(shn_ctx* ctx, const shn_ext* e, uint64_t lo, uint64_t n, uint32_t* n_right, uint32_t* n_left, uint64_t* tot_weight) {
   if (!ctx || !e || (n && (!n_right || !n_left || !tot_weight))) return shn_fail(SHN_ERR_ARG, "shn_ext_stats_range: NULL argument");

@@ -331,7 +331,7 @@ def _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick, error=N
     lock.release()
     return {"partitions": parts, "final": final, "contigs": res.contigs,
             "n_k1mers": int(gk.numel()),
-            "extension": {k: getattr(res, k, None) for k in ("iterations", "n_walks", "total_steps", "wave_steps")}}
+            "extension": {k: getattr(res, k, None) for k in ("iterations", "n_walks", "total_steps", "wave_steps", "dense_rounds")}}
 
 
 def _a2a_objects(recv, payload, group):

@@ -107,6 +107,10 @@ class Extension(object):
     def wave_steps(self):
         return int(_lib.lib().shn_ext_wave_steps(self.h))
 
+    @property
+    def dense_rounds(self):
+        return int(_lib.lib().shn_ext_dense_rounds(self.h))
+
     def stats(self):
         n = self.n_walks
         nr = np.empty(n, np.uint32)
@@ -636,6 +640,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     res.n_walks = ext.n_walks
     res.total_steps = ext.total_steps
     res.wave_steps = ext.wave_steps
+    res.dense_rounds = ext.dense_rounds
     res.contigs = contigs[1:]
     # allowed k1-mers with their integer weights (:366-369, :404-408): GPU table lookup
     allowed = {}
