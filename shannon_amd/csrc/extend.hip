@@ -91,7 +91,7 @@ struct shn_ext {
   Rec* d_rec;            // [2n] per oriented k1-mer: adjacency rows, weight, memo hint, seed rank (see Rec)
   uint32_t* d_order;     // [n_seeds] oriented id of the seed with rank r
   u64* d_claim;          // [2n] converged claims: (rank of the owning walk) << 32 | (1 + step index on its path)
-  u64* d_claim2;         // [2n] scratch
+  u64* d_claim2;         // [2n] scratch (the second half of the block d_claim starts: freed with it)
   uint64_t total_steps;  // walk steps executed over all iterations (for the bench's byte model)
   uint64_t wave_steps;   // ... of which by the wavefront kernel
   int dense_rounds;      // rounds whose begin / mark passes streamed all claims
@@ -1275,7 +1275,9 @@ __global__ void shard_offsets_kernel(const uint64_t* __restrict__ boff, uint64_t
   if (b <= n_buckets) oboff[b] = pos[boff[b]];        // pos has n+1 entries: pos[n] = number of selected k1-mers
 }
 
-static int build_fine_dict(shn_ctx* ctx, const shn_table* t, const uint8_t* d_flags, unsigned long long** lines_out, uint64_t* n_lines_out);
+static int build_fine_dict(shn_ctx* ctx, const shn_table* t, const uint8_t* d_flags, unsigned long long** lines_out, uint64_t* n_lines_out,
+                           void* room = nullptr);
+static inline uint64_t fine_dict_lines(uint64_t n) { return n / FD_PER_LINE + 1; }
 static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank, shn_table** out) {
   hipStream_t s = ctx->stream;
   const uint64_t n = t->n;
@@ -1356,15 +1358,19 @@ static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank
   return SHN_OK;
 }
 
-// the dictionary of the records / labelling kernels (see fd_build_kernel); the caller frees it after the stream has drained
-static int build_fine_dict(shn_ctx* ctx, const shn_table* t, const uint8_t* d_flags, unsigned long long** lines_out, uint64_t* n_lines_out) {
+// the dictionary of the records / labelling kernels (see fd_build_kernel).  room: memory of at least fine_dict_lines(n) * 128 bytes
+// to build it in (shn_extend: the claims and their snapshot are not in use yet -- the dictionary is 23 GB at 907 M k1-mers, and a
+// block of its own on top of the records put the steady state of the K = 31 slice over the device: every step then paid for
+// hipMalloc again); NULL: a block of its own, which the caller frees after the stream has drained
+static int build_fine_dict(shn_ctx* ctx, const shn_table* t, const uint8_t* d_flags, unsigned long long** lines_out, uint64_t* n_lines_out,
+                           void* room) {
   hipStream_t s = ctx->stream;
   const uint64_t n = t->n;
-  const uint64_t n_lines = n / FD_PER_LINE + 1;
-  unsigned long long* lines = nullptr;
-  hipError_t e = shn_dev_malloc(&lines, n_lines * 128);
+  const uint64_t n_lines = fine_dict_lines(n);
+  unsigned long long* lines = (unsigned long long*)room;
+  hipError_t e = lines ? hipSuccess : shn_dev_malloc(&lines, n_lines * 128);
   if (e == hipSuccess) e = hipMemsetAsync(lines, 0, n_lines * 128, s);
-  if (e != hipSuccess) { if (lines) shn_dev_free(lines); return shn_fail(SHN_ERR_HIP, std::string("build_fine_dict: ") + hipGetErrorString(e)); }
+  if (e != hipSuccess) { if (lines && !room) shn_dev_free(lines); return shn_fail(SHN_ERR_HIP, std::string("build_fine_dict: ") + hipGetErrorString(e)); }
   if (n) hipLaunchKernelGGL(fd_build_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, d_flags, n, lines, n_lines);
   *lines_out = lines; *n_lines_out = n_lines;
   return SHN_OK;
@@ -1373,7 +1379,7 @@ static int build_fine_dict(shn_ctx* ctx, const shn_table* t, const uint8_t* d_fl
 extern "C" void shn_ext_destroy(shn_ext* e) {
   if (!e) return;
   hipSetDevice(e->device);
-  void* ptrs[] = {e->d_weight, e->d_flags, e->d_rec, e->d_order, e->d_claim, e->d_claim2, e->d_nr, e->d_nl, e->d_totw};
+  void* ptrs[] = {e->d_weight, e->d_flags, e->d_rec, e->d_order, e->d_claim, e->d_nr, e->d_nl, e->d_totw};
   for (void* p : ptrs) if (p) shn_dev_free(p);
   if (e->owned_table) shn_table_destroy(e->owned_table);
   delete e;
@@ -1422,8 +1428,12 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   TRYE(shn_dev_malloc(&e->d_weight, (n + 1) * 4));
   TRYE(shn_dev_malloc(&e->d_flags, n + 1));
   TRYE(shn_dev_malloc(&e->d_rec, (2 * n + 1) * sizeof(Rec)));
-  TRYE(shn_dev_malloc(&e->d_claim, (2 * n + 4) * 8));      // (+4: the begin pass reads four claims per thread)
-  TRYE(shn_dev_malloc(&e->d_claim2, (2 * n + 4) * 8));
+  // claims and snapshot in one block ((+4: the begin pass reads four claims per thread); the dictionary of the records kernel is
+  // built in it first, see build_fine_dict)
+  const uint64_t claim_words = (2 * n + 4 + 31) & ~31ULL;
+  { u64* both = nullptr;
+    TRYE(shn_dev_malloc(&both, std::max<uint64_t>(2 * claim_words * 8, fine_dict_lines(n) * 128)));
+    e->d_claim = both; e->d_claim2 = both + claim_words; }
   if (n) {
     TimerRegion t1(ctx, T_EXT_PREP);
     hipLaunchKernelGGL(ext_prepare_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, t->d_counts, n, t->k,
@@ -1431,11 +1441,11 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     {
       unsigned long long* lines = nullptr;
       uint64_t n_lines = 0;
-      { int rca = build_fine_dict(ctx, t, e->d_flags, &lines, &n_lines); if (rca) { shn_ext_destroy(e); return rca; } }
+      { int rca = build_fine_dict(ctx, t, e->d_flags, &lines, &n_lines, e->d_claim); if (rca) { shn_ext_destroy(e); return rca; } }
       { TimerRegion ta(ctx, T_EXT_ADJ);                  // (one launch: bench.py's roofline entry for this kernel)
         hipLaunchKernelGGL(ext_records_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off,
                            t->bits, e->d_flags, e->d_weight, n, t->k, t->canonical, e->d_rec, (const unsigned long long*)lines, n_lines); }
-      TRYE(hipStreamSynchronize(s)); shn_dev_free(lines);
+      (void)lines;                                       // (lives in the claims' block: overwritten when the claims are initialised below)
     }
     TRYE(hipGetLastError());
   }
@@ -1733,7 +1743,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   // records and the snapshot (most of the state) go back to the allocator now
   TRYE(hipStreamSynchronize(s));
   shn_dev_free(e->d_rec); e->d_rec = nullptr;
-  shn_dev_free(e->d_claim2); e->d_claim2 = nullptr;
+  e->d_claim2 = nullptr;                                   // (not used any more; its memory goes back with the claims')
   unsigned long long steps = 0, wsteps = 0, wslots[64];
   TRYE(hipMemcpyAsync(&steps, d_cnt + 1, 8, hipMemcpyDeviceToHost, s));          // thread-kernel steps
   TRYE(hipMemcpyAsync(wslots, d_cnt + 64, 64 * 8, hipMemcpyDeviceToHost, s));    // wavefront-kernel steps
