@@ -744,6 +744,7 @@ static int count_views(shn_ctx* ctx, const std::vector<ReadsView>& views, uint64
         bits = 0;
         while (bits < bits_n && (double)(1ULL << bits) < want) bits++;
         if (upper > (1ULL << 20)) bits = std::max(bits, std::min(bits_n, 10));
+        if (getenv("SHN_COUNT_BITS")) bits = std::max(0, std::min(bits_n, atoi(getenv("SHN_COUNT_BITS"))));      // (experiments: any grid gives the same table content)
       }
     }
     int b1 = (bits + 1) / 2;
