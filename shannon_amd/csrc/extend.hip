@@ -402,6 +402,7 @@ struct WalkArgs {
   uint32_t promote_steps;
   uint8_t* chunk;        // per 2^CHUNK_SHIFT oriented k1-mers: "a claim in here was written this round" (the mark pass visits only those)
   uint8_t* robbed;       // per walk: a claim of its record is not (or no longer) its own -- see note_claim
+  int seed_check;        // thread walkers: look at the own seed's claim on every step and stop when a lower rank has taken it
 };
 
 // Claim `node` as step `pos` of walk r: atomic min on rank:pos.  Returns what stood there before; the caller hands it to note_claim
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
       u64 seen = claim_node(A, o, r, 0);             // what the last claim found; looked at one step later
       tot = A.weight[o];
       uint32_t pos = 0, pend = NONE32;
+      bool gave_up = false;
       for (int dir = 0; dir < 2; dir++) {
         const RowView adj = dir == 0 ? A.adjR : A.adjL;
         uint32_t steps = 0;
@@ -506,6 +508,12 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
             w[b] = A.weight[idx];
             nxt[b] = adj[idx];
           }
+          // the walk's own seed (one line, in the L2 from the second step on): once a lower rank has taken it this walk is void in
+          // the end -- 98.6 % of the walks of BASELINE configs[2] are -- and whatever it goes on to claim is wasted; it stops, is
+          // flagged like any robbed walk and looks again next round
+          // (seed_check 2 -- experiment: the walk's robbed flag instead, set by whoever took ANY of its k1-mers)
+          const u64 cseed = A.seed_check == 1 ? __hip_atomic_load(&A.claim[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                            : A.seed_check == 2 ? (*(volatile const uint8_t*)&A.robbed[r] ? 0ULL : CLAIM(r, 0)) : CLAIM(r, 0);
           // the claim of the step just taken goes out BEHIND the loads of this step: vector memory operations of a wavefront
           // return in issue order (one counter for loads, stores and atomics), so a claim issued in front of the loads would put
           // the latency of a memory-side atomic on every step of the walk -- and a bulk round lasts as long as its longest walk
@@ -522,6 +530,7 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
           // (what the claim BEFORE this step's found: it was issued in front of this step's loads, which have just been used)
           note_claim(A, seen, r);
           seen = found;
+          if (RANK(cseed) < r) { A.robbed[r] = 1; gave_up = true; break; }
           if (best < 0) break;
           // (selected with compares, not indexed: a run-time index puts the rows into scratch memory -- 96 bytes per lane of private
           // memory traffic on every step)
@@ -549,7 +558,7 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
           pend = NONE32;
         }
         if (dir == 0) nr = steps; else nl = steps;
-        if (promoted) break;
+        if (promoted || gave_up) break;
       }
       note_claim(A, seen, r);
     }
@@ -1568,6 +1577,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   const unsigned long long dense_min = getenv("SHN_EXT_DENSE") ? strtoull(getenv("SHN_EXT_DENSE"), nullptr, 10) : (4ULL << 20);   // (BASELINE configs[2]: 262144 -> 954 ms, 2 M or 16 M -> 900 ms per extension)
   // thread walker on persistent lanes (ext_walk_refill_kernel; SHN_EXT_REFILL=0: one walk per thread, ext_walk_kernel)
   const bool refill = tune("SHN_EXT_REFILL", 0) != 0;
+  const int seed_check = (int)tune("SHN_EXT_SEEDCHECK", 1);
   int n_cu = 256;
   { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
   unsigned long long expect_dirty = limit;
@@ -1644,6 +1654,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     A.promo_list = promo_list; A.promo_count = d_cnt + 13; A.res_cur = res_cur; A.res_info = res_info;
     A.chunk = dense ? nullptr : chunk;         // (dense rounds write nearly everywhere: their mark pass is dense, the walkers do not flag)
     A.robbed = robbed;
+    A.seed_check = seed_check;
     A.steps_counter = d_cnt + 1; A.wave_steps_counter = d_cnt + 64; A.dbg = (getenv("SHN_DEBUG") || getenv("SHN_EXT_XTIME")) ? d_cnt + 32 : nullptr;
     // long (wave per walk) and short (thread per walk) kernels are independent: overlap them on two streams
     if (plan[0]) {
