@@ -651,13 +651,18 @@ __global__ __launch_bounds__(WBLK) void ext_walk_refill_kernel(WalkArgs A, uint6
         w[b] = A.weight[idx];
         nxt[b] = adj[idx];
       }
+      const u64 cseed = A.seed_check ? __hip_atomic_load(&A.claim[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : CLAIM(r, 0);
       int best = -1;
       uint32_t bw = 0;
 #define CONSIDER(b) if (cand.v[b] >= 0 && RANK(cl[b]) > r && RANK(cf[b]) >= r && (best < 0 || w[b] > bw)) { best = b; bw = w[b]; }
       CONSIDER(0) CONSIDER(2) CONSIDER(1) CONSIDER(3)
 #undef CONSIDER
       bool ended = false;                              // this walk is done with (or handed over)
-      if (best < 0) {
+      if (RANK(cseed) < r) {                           // the seed went to a lower rank: void in the end (see ext_walk_kernel)
+        A.robbed[r] = 1;
+        A.nr_out[r] = dir == 0 ? steps : nr; A.nl_out[r] = dir == 0 ? 0 : steps; A.totw_out[r] = tot;
+        ended = true; best = -1;
+      } else if (best < 0) {
         if (dir == 0) { nr = steps; steps = 0; dir = 1; cand = A.adjL[o]; }
         else { A.nr_out[r] = nr; A.nl_out[r] = steps; A.totw_out[r] = tot; ended = true; }
       } else {
