@@ -469,7 +469,10 @@ __device__ __forceinline__ int audit_decide(const Adj4& cd, uint32_t r, uint32_t
 // FRESH: the first round of a block that has just opened -- none of its walks has run before, so the snapshot holds nothing but
 // the claims of final walks, which the live claims hold too: the snapshot is not read (a quarter of a step's memory accesses,
 // in the rounds that make most of the steps).
-template <bool FRESH>
+// RESUME: the walks of the list were handed over by an earlier pass of this round (a bulk round can run in passes: every walk up to
+// 64 steps, the survivors -- packed side by side again -- up to 512, ...: a wavefront holds its slot as long as its longest walk,
+// and the slots, not the steps, are what a round of millions of walks runs out of); they go on where they stand (res_cur / res_info).
+template <bool FRESH, bool RESUME = false>
 __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_walks, const uint32_t* __restrict__ list,
                                                         const u64* __restrict__ snap) {
   __shared__ unsigned long long blk_steps;
@@ -482,20 +485,32 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
     const uint32_t r = list[t];
     const uint32_t o = A.order[r];
     const unsigned long long t_begin = A.dbg ? __builtin_amdgcn_s_memrealtime() : 0ULL;      // (100 MHz)
-    uint32_t nr = 0, nl = 0;
+    uint32_t nr = 0, nl = 0, resumed_at = 0;
     uint64_t tot = 0;
     bool promoted = false;
     // snap: the pre-round snapshot; A.claim: live claims of this round
-    bool isvoid = (!FRESH && RANK(snap[o]) < r) || RANK(__hip_atomic_load(&A.claim[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < r;
+    bool isvoid = !RESUME && ((!FRESH && RANK(snap[o]) < r) || RANK(__hip_atomic_load(&A.claim[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < r);
     if (!isvoid) {
-      u64 seen = claim_node(A, o, r, 0);             // what the last claim found; looked at one step later
-      tot = A.weight[o];
+      u64 seen = UNCLAIMED64;                        // what the last claim found; looked at one step later
       uint32_t pos = 0, pend = NONE32;
+      int dir0 = 0;
+      uint32_t cur0 = o, steps0 = 0;
+      if (RESUME) {
+        const uint32_t info = A.res_info[r];
+        dir0 = (int)(info >> 31); pos = info & 0x7FFFFFFFu; cur0 = A.res_cur[r];
+        resumed_at = pos;
+        nr = dir0 ? A.nr_out[r] : 0;
+        steps0 = dir0 ? pos - nr : pos;
+        tot = A.totw_out[r];
+      } else {
+        seen = claim_node(A, o, r, 0);
+        tot = A.weight[o];
+      }
       bool gave_up = false;
-      for (int dir = 0; dir < 2; dir++) {
+      for (int dir = dir0; dir < 2; dir++) {
         const RowView adj = dir == 0 ? A.adjR : A.adjL;
-        uint32_t steps = 0;
-        Adj4 cand = adj[o];
+        uint32_t steps = (RESUME && dir == dir0) ? steps0 : 0;
+        Adj4 cand = adj[(RESUME && dir == dir0) ? cur0 : o];
         while (true) {
           u64 cl[4], cf[4];
           uint32_t w[4];
@@ -565,7 +580,7 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
     A.nr_out[r] = isvoid ? UNCLAIMED : nr;
     A.nl_out[r] = nl;
     A.totw_out[r] = tot;
-    mysteps = nr + nl;
+    mysteps = nr + nl - resumed_at;
     // debug: the longest walk of the launch and how long it took (steps << 32 | ticks of 10 ns): a bulk round cannot end before it
     if (A.dbg && mysteps >= 64) atomicMax(&A.dbg[12], ((unsigned long long)mysteps << 32) | ((__builtin_amdgcn_s_memrealtime() - t_begin) & 0xFFFFFFFFULL));
   }
@@ -1583,6 +1598,12 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   // thread walker on persistent lanes (ext_walk_refill_kernel; SHN_EXT_REFILL=0: one walk per thread, ext_walk_kernel)
   const bool refill = tune("SHN_EXT_REFILL", 0) != 0;
   const int seed_check = (int)tune("SHN_EXT_SEEDCHECK", 1);
+  // bulk rounds in passes (see ext_walk_kernel, RESUME): SHN_EXT_PASSES = the step limits of the passes, e.g. "64,512,4096"; "" / "0": one pass
+  std::vector<uint32_t> pass_limits;
+  { const char* pv = getenv("SHN_EXT_PASSES");
+    std::string ps = pv ? pv : "";
+    size_t at = 0;
+    while (at < ps.size()) { size_t e2 = ps.find(',', at); if (e2 == std::string::npos) e2 = ps.size(); const unsigned long v = strtoul(ps.substr(at, e2 - at).c_str(), nullptr, 10); if (v) pass_limits.push_back((uint32_t)v); at = e2 + 1; } }
   int n_cu = 256;
   { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
   unsigned long long expect_dirty = limit;
@@ -1655,7 +1676,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     A.claim = claim; A.claim_old = snap;
     A.nr_out = e->d_nr; A.nl_out = e->d_nl; A.totw_out = e->d_totw;
     A.pool = pool; A.moff = moff; A.mR = mR; A.mL = mL; A.mvalid = mvalid; A.hint = words_hint(e->d_rec);
-    A.promote_steps = bulk ? 0xFFFFFFFFu : promote_steps;
+    const bool in_passes = bulk && !refill && !pass_limits.empty();
+    A.promote_steps = in_passes ? pass_limits[0] : bulk ? 0xFFFFFFFFu : promote_steps;
     A.promo_list = promo_list; A.promo_count = d_cnt + 13; A.res_cur = res_cur; A.res_info = res_info;
     A.chunk = dense ? nullptr : chunk;         // (dense rounds write nearly everywhere: their mark pass is dense, the walkers do not flag)
     A.robbed = robbed;
@@ -1684,6 +1706,26 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       else if (fresh_block) hipLaunchKernelGGL(ext_walk_kernel<true>, dim3((uint32_t)cdiv(plan[2], WBLK)), dim3(WBLK), 0, s, A, (uint64_t)plan[2], short_list, snap);
       else hipLaunchKernelGGL(ext_walk_kernel<false>, dim3((uint32_t)cdiv(plan[2], WBLK)), dim3(WBLK), 0, s, A, (uint64_t)plan[2], short_list, snap);
     }
+    if (plan[2] && in_passes) {
+      // the later passes of a bulk round: the walks the pass before handed over, side by side again, up to the next limit
+      uint32_t *in_list = promo_list, *out_list = long_list;             // (a bulk round has no wavefront walks: their list is free)
+      unsigned long long *in_cnt = d_cnt + 13, *out_cnt = d_cnt + 16;
+      for (size_t p = 1; ; p++) {
+        unsigned long long c = 0;
+        TRYE(hipMemcpyAsync(plan + 6, in_cnt, 8, hipMemcpyDeviceToHost, s));
+        TRYE(hipStreamSynchronize(s));
+        c = plan[6];
+        if (!c) break;
+        TRYE(hipMemsetAsync(out_cnt, 0, 8, s));
+        A.promote_steps = p < pass_limits.size() ? pass_limits[p] : 0xFFFFFFFFu;
+        A.promo_list = out_list; A.promo_count = out_cnt;
+        { TimerRegion tk(ctx, T_EXT_WALK_THREAD);
+          if (fresh_block) hipLaunchKernelGGL((ext_walk_kernel<true, true>), dim3((uint32_t)cdiv(c, WBLK)), dim3(WBLK), 0, s, A, (uint64_t)c, (const uint32_t*)in_list, snap);
+          else hipLaunchKernelGGL((ext_walk_kernel<false, true>), dim3((uint32_t)cdiv(c, WBLK)), dim3(WBLK), 0, s, A, (uint64_t)c, (const uint32_t*)in_list, snap); }
+        std::swap(in_list, out_list); std::swap(in_cnt, out_cnt);
+      }
+      A.promo_list = promo_list; A.promo_count = d_cnt + 13;
+    }
     if (x_t0 > 0) {
       TRYE(hipStreamSynchronize(s)); timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
       unsigned long long st = 0, lw = 0; TRYE(hipMemcpy(&st, d_cnt + 1, 8, hipMemcpyDeviceToHost));
@@ -1691,7 +1733,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       fprintf(stderr, "[shn_extend] XTIME round %d: thread walker %llu walks, %.2f ms, steps so far %llu; longest walk %llu steps in %.2f ms (%.2f us per step)\n", it + 1, plan[2],
               ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6 - x_t0, st, lw >> 32, (double)(lw & 0xFFFFFFFFULL) * 1e-5, (lw >> 32) ? (double)(lw & 0xFFFFFFFFULL) * 1e-2 / (double)(lw >> 32) : 0.0);
     }
-    if (plan[2]) {                              // walks the thread kernel handed over (the count stays on the device)
+    if (plan[2] && !in_passes) {                // walks the thread kernel handed over (the count stays on the device)
       TimerRegion tk(ctx, T_EXT_WALK_WAVE);
       hipLaunchKernelGGL(ext_walk_long_kernel<true>, dim3((uint32_t)std::min<unsigned long long>(plan[2], 8192ULL)), dim3(64), 0, s, A, promo_list,
                          (uint64_t)ns, (const unsigned long long*)(d_cnt + 13));
