@@ -679,7 +679,7 @@ def main():
             # bounded sample: ~10-15 s of one core through the whole path (at configs[2] a read costs the pure-Python path ~5x more
             # than at configs[1]: nearly every k1-mer of a 25k-read sample is new), + ~5 s for the counting stage alone / threaded
             out["cpu_baseline"] = cpu_baseline(k1, r1, r2, 75_000 if args.config == "1" else 12_500)
-            out["cpu_baseline"]["native_front_one_core"] = native_front_baseline(k1, r1, r2, min(len(r1), 500_000))
+            out["cpu_baseline"]["native_front_one_core"] = native_front_baseline(k1, r1, r2, min(len(r1), 250_000))      # (0.5 M reads: ~20 s of one core)
             if not use_dist:
                 out["cpu_baseline"]["graph_stage_native_host_only"] = native_graph_baseline(last.R, store, args.K)
         final_line = json.dumps(out)
