@@ -775,7 +775,7 @@ static int count_views(shn_ctx* ctx, const std::vector<ReadsView>& views, uint64
         TimerRegion t(ctx, T_SCATTER1);
         uint64_t n_tiles = cdiv(v.n_reads, v.rt);
         uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, getenv("SHN_COUNT_GRID1") ? strtoull(getenv("SHN_COUNT_GRID1"), nullptr, 10) : 4096);   // (2048: +0.7 ms; 512: +3 ms -- occupancy, not L2 write combining, is what matters)
-        size_t sh = (size_t)nb1 * 4 + (size_t)nb1 * 8;
+        size_t sh = (size_t)nb1 * 4 + (size_t)nb1 * 8 + (getenv("SHN_COUNT_LDS_PAD1") ? strtoull(getenv("SHN_COUNT_LDS_PAD1"), nullptr, 10) : 0);      // (experiments: residency)
         if (both_strands) hipLaunchKernelGGL(scatter1_kernel<true>, dim3(grid), dim3(BLK), sh, s, v, k1, bits, b2, n_tiles, d_cursor1, keysA);
         else hipLaunchKernelGGL(scatter1_kernel<false>, dim3(grid), dim3(BLK), sh, s, v, k1, bits, b2, n_tiles, d_cursor1, keysA);
       }
@@ -830,7 +830,8 @@ static int build_from_keys(shn_ctx* ctx, uint64_t* keysA, uint64_t* keysB, uint3
   HIP_TRY(hipMemcpyAsync(d_off1, off1h.data(), (size_t)(nb1 + 1) * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(d_hist2, 0, nbk * 4, s));
   HIP_TRY(hipMemsetAsync(d_ovf, 0, 4, s));
-  const uint32_t tile2 = TILE_KEYS;
+  const uint32_t tile2 = getenv("SHN_COUNT_TILE2") ? (uint32_t)strtoul(getenv("SHN_COUNT_TILE2"), nullptr, 10) : TILE_KEYS;
+  const size_t pad2 = getenv("SHN_COUNT_LDS_PAD2") ? strtoull(getenv("SHN_COUNT_LDS_PAD2"), nullptr, 10) : 0;      // (experiments: residency of the scatter blocks)
   const uint64_t *segs = d_off1;                                  // segments of the last level and where their keys are
   uint32_t n_segs = (uint32_t)nb1;
   uint64_t max_seg = max1;
@@ -846,8 +847,8 @@ static int build_from_keys(shn_ctx* ctx, uint64_t* keysA, uint64_t* keysB, uint3
     hipLaunchKernelGGL(scan_rows_kernel, dim3((uint32_t)nb1), dim3(BLK), 0, s, d_histm, (int)nbm, d_offm, d_cursorm);
     {
       TimerRegion t(ctx, T_SCATTER2);
-      if (cntA) hipLaunchKernelGGL((scatter_keys_kernel<true>), dim3(tiles, (uint32_t)nb1), dim3(BLK), nbm * 8, s, kin, cin_, d_off1, (uint32_t)nb1, bits, b3, nbm, d_cursorm, kout, cout_, tile2);
-      else hipLaunchKernelGGL((scatter_keys_kernel<false>), dim3(tiles, (uint32_t)nb1), dim3(BLK), nbm * 8, s, kin, nullptr, d_off1, (uint32_t)nb1, bits, b3, nbm, d_cursorm, kout, nullptr, tile2);
+      if (cntA) hipLaunchKernelGGL((scatter_keys_kernel<true>), dim3(tiles, (uint32_t)nb1), dim3(BLK), nbm * 8 + pad2, s, kin, cin_, d_off1, (uint32_t)nb1, bits, b3, nbm, d_cursorm, kout, cout_, tile2);
+      else hipLaunchKernelGGL((scatter_keys_kernel<false>), dim3(tiles, (uint32_t)nb1), dim3(BLK), nbm * 8 + pad2, s, kin, nullptr, d_off1, (uint32_t)nb1, bits, b3, nbm, d_cursorm, kout, nullptr, tile2);
     }
     hipLaunchKernelGGL(next_segments_kernel, dim3((uint32_t)cdiv((uint64_t)n_seg3 + 1, 256)), dim3(256), 0, s, d_off1, (uint32_t)nb1, d_offm, nbm, d_seg3);
     // the largest segment of the last level sizes its grid
@@ -869,8 +870,8 @@ static int build_from_keys(shn_ctx* ctx, uint64_t* keysA, uint64_t* keysB, uint3
     hipLaunchKernelGGL(scan_rows_kernel, dim3(n_segs), dim3(BLK), 0, s, d_hist2, (int)nb3, d_off2, d_cursor2);
     {
       TimerRegion t(ctx, T_SCATTER2);
-      if (cntA) hipLaunchKernelGGL((scatter_keys_kernel<true>), dim3(tiles, gy), dim3(BLK), nb3 * 8, s, kin, cin_, segs, n_segs, bits, 0, nb3, d_cursor2, kout, cout_, tile2);
-      else hipLaunchKernelGGL((scatter_keys_kernel<false>), dim3(tiles, gy), dim3(BLK), nb3 * 8, s, kin, nullptr, segs, n_segs, bits, 0, nb3, d_cursor2, kout, nullptr, tile2);
+      if (cntA) hipLaunchKernelGGL((scatter_keys_kernel<true>), dim3(tiles, gy), dim3(BLK), nb3 * 8 + pad2, s, kin, cin_, segs, n_segs, bits, 0, nb3, d_cursor2, kout, cout_, tile2);
+      else hipLaunchKernelGGL((scatter_keys_kernel<false>), dim3(tiles, gy), dim3(BLK), nb3 * 8 + pad2, s, kin, nullptr, segs, n_segs, bits, 0, nb3, d_cursor2, kout, nullptr, tile2);
     }
     std::swap(kin, kout); std::swap(cin_, cout_);
   }
