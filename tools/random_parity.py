@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Development aid: random synthetic inputs through the product pipeline (code matrices: reads named by rows, distinct reads and
 known_paths on the device, lazy text, native sparse flow and merge) and through the oracle pipeline (oracle/, pure Python, strings);
-contigs, partitions and final transcripts must be equal.  python tools/random_parity.py [n_cases] [first_seed]"""
+contigs, partitions and final transcripts must be equal.  python tools/random_parity.py [n_cases] [first_seed] [big]
+PARITY_SS=1: every case strand-specific (-s); PARITY_SS=mix: every third."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -21,11 +22,12 @@ def run_case(ctx, seed, big=False):
         K = int(rng.choice([25, 25, 25, 31, 20]))
         paired = bool(rng.integers(0, 2))
         psize = int(rng.choice([4, 8, 500]))
+        ss = os.environ.get("PARITY_SS", "") == "1" or (os.environ.get("PARITY_SS", "") == "mix" and seed % 3 == 0)      # -s / --ss (shannon.py:407-411)
         (r1, r2), _ = synth.make_dataset(n_pairs, n_genes, seed=seed)
         s1 = [A[r].tobytes().decode() for r in r1]
         s2 = [A[r].tobytes().decode() for r in r2]
         t = time.time()
-        R = pipeline.assemble(ctx, r1, r2 if paired else None, K=K, partition_size=psize, sample="s", seed=seed % 7)
+        R = pipeline.assemble(ctx, r1, r2 if paired else None, K=K, partition_size=psize, sample="s", seed=seed % 7, double_stranded=not ss)
         tg = time.time() - t
         # components larger than --partition are cut by the library's gpmetis stand-in (kmers_for_component.partition_graph); the
         # oracle takes the cut as an input, like the golden cases do with gpmetis' own output
@@ -35,7 +37,8 @@ def run_case(ctx, seed, big=False):
             p1 = kfc.partition_graph(metis, P, 1000)
             pv.append((p1, kfc.partition_graph(kfc.weight_updated_graph(metis, p1, 5), P, 1000)))
         t = time.time()
-        O = opipe.assemble(s1, s2 if paired else None, K=K, partition_size=psize, sample="s", seed=seed % 7, part_vectors=pv or None)
+        O = opipe.assemble(s1, s2 if paired else None, K=K, partition_size=psize, sample="s", seed=seed % 7, part_vectors=pv or None,
+                           double_stranded=not ss)
         to = time.time() - t
         ok = (R.extension.contigs == O["contigs"] and list(R.partitions) == list(O["partitions"]) and R.final == O["final"])
         if ok:
@@ -44,7 +47,7 @@ def run_case(ctx, seed, big=False):
                 b = [l for l in O["partitions"][p]["reconstructed_fasta"].splitlines() if not l.startswith(">")]
                 ok = ok and a == b
         return ok, ("seed %d: pairs %d genes %d K %d %s partition %d: contigs %d partitions %d transcripts %d  %s  (product %.2f s, oracle %.1f s)"
-                    % (seed, n_pairs, n_genes, K, "PE" if paired else "SE", psize, len(O["contigs"]), len(O["partitions"]), len(O["final"]),
+                    % (seed, n_pairs, n_genes, K, ("PE" if paired else "SE") + (" -s" if ss else ""), psize, len(O["contigs"]), len(O["partitions"]), len(O["final"]),
                        "equal" if ok else "DIFFERENT", tg, to))
 
 
