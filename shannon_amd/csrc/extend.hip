@@ -1739,12 +1739,19 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
                          (uint64_t)ns, (const unsigned long long*)(d_cnt + 13));
     }
     if (plan[0]) TRYE(hipStreamWaitEvent(s, ev_join, 0));
+    // A block's first round when it is a bulk round: no walk of the block held a claim before it, so every change is
+    // "nobody -> a walk of the block" -- nothing the mark pass would mark (a k1-mer only BECOMES available to somebody when a lower
+    // rank gives it up), no memo slots to fill; what is left of the pass is bringing the snapshot up to date, which the next begin
+    // pass does while it streams the claims anyway (copy = 1): the pass is skipped (3 x 25 ms at BASELINE configs[2]).
+    const bool skip_mark = fresh_block && bulk && precise_marks && tune("SHN_EXT_FRESH_MARK", 0) == 0;
     fresh_block = false;
     if (dense) e->dense_rounds++;
     // who has to run next round?  walks whose view changed (mark) + walks that lost a claim race (verify);
     // the walks that ran get their memo rebuilt from the claims
     hipLaunchKernelGGL(ext_memo_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 256)), dim3(256), 0, s, ran, dirty, e->d_nr, e->d_nl, e->d_order, frozen, limit,
                        moff, mR, mL, mvalid, fill, pool, d_cnt + 10, pool_cap, bulk ? 0xFFFFFFFFu : memo_min);
+    if (skip_mark) { snap_current = false; if (!dense) TRYE(hipMemsetAsync(chunk, 0, n_chunks, s)); }
+    else
     { TimerRegion tk(ctx, T_EXT_MARK);
       hipLaunchKernelGGL(ext_mark_kernel, dim3(std::min<uint32_t>(g2n, 4096u)), dim3(256), 0, s, claim, snap, 2 * n, e->d_rec,
                          dirty, ran, d_cnt + 6, frozen, limit, bulk ? (const uint8_t*)nullptr : (const uint8_t*)fill, moff, mR, pool, e->d_nr, e->d_nl, precise_marks,
