@@ -242,15 +242,11 @@ def count_k1mers_strand_specific(ctx, d1, d2, k1):
     finally:
         t1.close()
         t2.close()
-    keys = np.concatenate([ka, revcomp_keys(kb, k1)])
-    cnts = np.concatenate([ca, cb]).astype(np.uint64)
-    uk, inv = np.unique(keys, return_inverse=True)
-    tot = np.zeros(len(uk), dtype=np.uint64)
-    np.add.at(tot, inv, cnts)
+    # (shn_table_create sums the counts of equal keys: a k1-mer of reads_1 that is also one of RC(reads_2))
+    keys = np.ascontiguousarray(np.concatenate([ka, revcomp_keys(kb, k1)]), dtype=np.uint64)
+    vals = np.ascontiguousarray(np.concatenate([ca, cb]), dtype=np.uint32)
     h = C.c_void_p()
-    uk = np.ascontiguousarray(uk, dtype=np.uint64)
-    vals = np.ascontiguousarray(np.minimum(tot, np.uint64(0xFFFFFFFF)), dtype=np.uint32)
-    _lib.check(_lib.lib().shn_table_create(ctx.h, uk.ctypes.data, vals.ctypes.data, len(uk), k1, 0, C.byref(h)))
+    _lib.check(_lib.lib().shn_table_create(ctx.h, keys.ctypes.data, vals.ctypes.data, len(keys), k1, 0, C.byref(h)))
     return Table(ctx, h)
 
 
