@@ -23,6 +23,9 @@
 // atomics, chains by pointer jumping (list ranking), chain-major layout by a scan, then the rounds as scans / segmented
 // maxima over the shrinking group array.  Everything is integer work bound by random HBM accesses.
 #include "common.h"
+#include <functional>
+#include <thread>
+#include <atomic>
 #include "unitigs.h"
 #include <algorithm>
 #include <chrono>
@@ -523,11 +526,24 @@ extern "C" int shn_unitigs_build(shn_ctx* ctx, const uint8_t* bases, const uint6
   std::vector<uint32_t> local_of(nf, UG_NONE);           // compact head index -> index among its partition's final nodes
   U->n_len.resize(nf); U->n_tail_out.resize(nf); U->base_off.assign(nf + 1, 0);
   U->bases.resize(nb);
-  uint64_t bat = 0;
-  for (uint32_t p = 0; p < n_parts; p++) {
+  // (the partitions are independent: host threads take them in turn; where a partition's bases start follows from the lengths)
+  std::vector<uint64_t> part_bases(n_parts + 1, 0);
+  for (uint64_t i = 0; i < nf; i++) part_bases[h_part[i] + 1] += (uint64_t)K + h_clen[i] - 1;
+  for (uint32_t p = 0; p < n_parts; p++) part_bases[p + 1] += part_bases[p];
+  const unsigned n_host = (unsigned)std::max(1, std::min<int>(shn_host_cpus(), 16));
+  auto over_parts = [&](const std::function<void(uint32_t)>& body) {
+    std::atomic<uint32_t> next{0};
+    auto work = [&]() { for (uint32_t p; (p = next.fetch_add(1)) < n_parts;) body(p); };
+    if (n_host <= 1 || n_parts < 4 || nf < 4096) { work(); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < std::min<unsigned>(n_host, n_parts); t++) th.emplace_back(work);
+    for (auto& x : th) x.join();
+  };
+  over_parts([&](uint32_t p) {
     auto b = heads.begin() + heads_of_part_off[p], e = heads.begin() + heads_of_part_off[p + 1];
     std::sort(b, e, [&](uint32_t x, uint32_t y) { return h_stamp[x] < h_stamp[y]; });
     U->node_off[p] = heads_of_part_off[p];
+    uint64_t bat = part_bases[p];
     for (auto it = b; it != e; ++it) {
       const uint64_t i = (uint64_t)(it - heads.begin());
       const uint32_t h = *it;
@@ -537,7 +553,8 @@ extern "C" int shn_unitigs_build(shn_ctx* ctx, const uint8_t* bases, const uint6
       U->base_off[i] = bat; bat += len;
       U->n_len[i] = h_clen[h]; U->n_tail_out[i] = tail_out[h];
     }
-  }
+  });
+  const uint64_t bat = part_bases[n_parts];
   U->node_off[n_parts] = nf;
   U->base_off[nf] = bat;
   // edges, grouped by partition (rows come partition by partition already), in edge-id order
@@ -546,12 +563,12 @@ extern "C" int shn_unitigs_build(shn_ctx* ctx, const uint8_t* bases, const uint6
   for (uint32_t p = 0; p < n_parts; p++) eoff[p + 1] += eoff[p];
   U->edge_off = eoff;
   U->e_src.resize(ne); U->e_dst.resize(ne); U->e_out_rank.resize(ne); U->e_in_rank.resize(ne);
-  std::vector<uint32_t> idx;
   std::vector<uint64_t> key_out(ne), key_in(ne);
   for (uint64_t x = 0; x < ne; x++) { key_out[x] = h_thead[h_edst[x]]; key_in[x] = h_ttail[h_esrc[x]]; }
-  for (uint32_t p = 0; p < n_parts; p++) {
+  over_parts([&](uint32_t p) {
     const uint64_t lo = eoff[p], n = eoff[p + 1] - lo;
-    if (!n) continue;
+    if (!n) return;
+    std::vector<uint32_t> idx;
     // list ranks (in row-index space): the edges of one source ordered by (key_out, row); of one destination by (key_in, row)
     std::vector<uint32_t> byo(n), byi(n), orank(n), irank(n);
     for (uint64_t i = 0; i < n; i++) byo[i] = byi[i] = (uint32_t)i;                      // row order
@@ -580,7 +597,7 @@ extern "C" int shn_unitigs_build(shn_ctx* ctx, const uint8_t* bases, const uint6
       U->e_src[lo + i] = local_of[h_esrc[lo + x]]; U->e_dst[lo + i] = local_of[h_edst[lo + x]];
       U->e_out_rank[lo + i] = orank[x]; U->e_in_rank[lo + i] = irank[x];
     }
-  }
+  });
   lap("host assembly");
   *out = U;
   guard.u = nullptr;
