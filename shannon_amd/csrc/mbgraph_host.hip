@@ -546,7 +546,22 @@ struct Graph {
     }
     nreads[n].swap(real);
   }
+  // bridge_all asks every X-node in every pass; the answer depends on the node's edge lists (edge ids: an edge never changes its
+  // ends or its weight), on its bridging reads (which only this function filters, idempotently, between two passes -- bridging
+  // appends reads to the NEW nodes it makes) and on texts that never change: an X-node whose edge lists and read count are what
+  // they were at the last call gets the last answer, without going through its 10^3-10^5 reads again
+  struct BridgedMemo { std::vector<int> in, out; size_t n_reads = (size_t)-1; bool answer = false; };
+  std::vector<BridgedMemo> bridged_memo;
   bool is_bridged_xnode(int n) {
+    if (bridged_memo.size() < bases.size()) bridged_memo.resize(bases.size());
+    BridgedMemo& memo = bridged_memo[n];
+    if (memo.n_reads == nreads[n].size() && memo.in == ine[n] && memo.out == oute[n]) return memo.answer;
+    const bool ans = is_bridged_xnode_now(n);
+    BridgedMemo& m2 = bridged_memo[n];
+    m2.in = ine[n]; m2.out = oute[n]; m2.n_reads = nreads[n].size(); m2.answer = ans;
+    return ans;
+  }
+  bool is_bridged_xnode_now(int n) {
     refresh_bridging_reads(n);
     int lb = (int)bases[n].size();
     bool inb[256] = {false}, outb[256] = {false};                  // (the distinct characters before / behind the node in its reads)
