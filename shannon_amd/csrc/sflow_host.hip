@@ -17,6 +17,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -516,8 +517,23 @@ extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uin
     else { std::vector<std::thread> th; for (unsigned t = 0; t < std::min<unsigned>(nt, n_graphs); t++) th.emplace_back(work); for (auto& x : th) x.join(); }
   }
   lap("partition texts");
-  // (the components hold ~10^2 small vectors each: given back on the host threads, not one after the other when `comps` goes out of scope)
-  parallel([&](size_t k) { Component gone; std::swap(gone, comps[k]); });
+  // The components hold ~10^2 small vectors each (26 ms to give back on 16 threads at BASELINE configs[2]): they go to a
+  // background thread, which frees them while the caller merges the transcripts; the thread of the call before is joined first, the
+  // last one when the library is unloaded.  SHN_SFLOW_FREE_NOW=1: on the host threads, before returning.
+  if (getenv("SHN_SFLOW_FREE_NOW")) parallel([&](size_t k) { Component gone; std::swap(gone, comps[k]); });
+  else {
+    struct Reaper {
+      std::mutex mu; std::thread t;
+      ~Reaper() { if (t.joinable()) t.join(); }
+      void take(std::vector<Component>* v) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (t.joinable()) t.join();
+        t = std::thread([v]() { delete v; });
+      }
+    };
+    static Reaper reaper;
+    reaper.take(new std::vector<Component>(std::move(comps)));
+  }
   lap("free components");
   *out = R;
   return SHN_OK;

@@ -443,7 +443,7 @@ class GpuOps(object):
         if gpu_graph and names:
             # the raw K-mer graphs of ALL partitions contracted on every rank (a tenth of a second at 111 partitions): every rank
             # needs every partition's K-mer count for the read caps, the owners need the unitigs
-            self.unitigs = mbgraph_native.Unitigs(self.ctx, [part["new_components"][nm] for nm in names], K)
+            self.unitigs = mbgraph_native.Unitigs(self.ctx, [part["new_components"][nm] for nm in names], K, flat_text=part.get("flat_text"))
             self.part_index = {nm: i for i, nm in enumerate(names)}
         return part
 

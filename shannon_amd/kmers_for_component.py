@@ -240,6 +240,7 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
     n_windows = sum(max(len(c) - k1 + 1, 0) for name in names for c in comps[name])
     _pg = os.environ.get("SHN_PROBE_GPU", "")
     probe_h = None
+    flat_text = None
     if k1 <= 32 and (_pg == "1" or (_pg != "0" and n_windows >= (1 << 20))):
         # k1mers2component on the GPU (shn_probe_build): one device sort of the k1-windows of all partition contigs
         flat = [c for name in names for c in comps[name]]
@@ -249,6 +250,7 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
             off[1:] = np.cumsum([len(c) for c in flat], dtype=np.uint64)
         part_of = np.ascontiguousarray(np.repeat(np.arange(len(names), dtype=np.uint32), [len(comps[name]) for name in names]), dtype=np.uint32) \
             if flat else np.zeros(1, np.uint32)
+        flat_text = (text, off, part_of, len(flat))          # (the unitig batch of the graph stage takes the same contigs in the same order)
         probe_h = C.c_void_p()
         _lib.check(_lib.lib().shn_probe_build(ctx.h, text.ctypes.data, off.ctypes.data, len(flat), part_of.ctypes.data, len(names), int(k1),
                                               C.byref(probe_h)))
@@ -278,7 +280,9 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
         routes.close()
         by_part = {n: ridx[int(start[i]):int(start[i + 1])] for i, n in enumerate(names)}
     lap("route.download")
-    return _finish_partitions(res, comps, broken, names, by_part, files, cw, k1, K, want_rows, lazy_graph_inputs, lap)
+    out = _finish_partitions(res, comps, broken, names, by_part, files, cw, k1, K, want_rows, lazy_graph_inputs, lap)
+    out["flat_text"] = flat_text
+    return out
 
 
 def _host_probe_and_route(ctx, comps, names, pid_of, reads1, reads2, k1, lap, strand_specific=False):

@@ -18,15 +18,22 @@ class Unitigs(object):
     """The K-mer graphs of all partitions contracted to unitigs in one batch on the GPU (shn_unitigs_build): replaces
     load_single_jellyfish + the first condense_all of every partition (multibridging.py:145-172, mbgraph.py:479-498)."""
 
-    def __init__(self, ctx, partition_contigs, K):
-        """partition_contigs: [[contig, ...] per partition] (the order of the partition's k1-mer file)"""
-        flat = [c for cl in partition_contigs for c in cl]
-        text = np.frombuffer("".join(flat).encode(), dtype=np.uint8) if flat else np.zeros(1, np.uint8)
-        off = np.zeros(len(flat) + 1, dtype=np.uint64)
-        if flat:
-            off[1:] = np.cumsum([len(c) for c in flat], dtype=np.uint64)
-        part_of = np.repeat(np.arange(len(partition_contigs), dtype=np.uint32), [len(cl) for cl in partition_contigs]) if flat else np.zeros(1, np.uint32)
-        part_of = np.ascontiguousarray(part_of, dtype=np.uint32)
+    def __init__(self, ctx, partition_contigs, K, flat_text=None):
+        """partition_contigs: [[contig, ...] per partition] (the order of the partition's k1-mer file).  flat_text (optional):
+        (text, off, part_of, n_contigs) of exactly these contigs in this order, as kmers_for_component already laid them out for
+        the probe table (joining and encoding 80 MB of Python strings a second time was a third of this constructor)"""
+        n_flat = sum(len(cl) for cl in partition_contigs)
+        if flat_text is not None and flat_text[3] == n_flat and n_flat:
+            text, off, part_of = flat_text[0], flat_text[1], flat_text[2]
+            flat = range(n_flat)
+        else:
+            flat = [c for cl in partition_contigs for c in cl]
+            text = np.frombuffer("".join(flat).encode(), dtype=np.uint8) if flat else np.zeros(1, np.uint8)
+            off = np.zeros(len(flat) + 1, dtype=np.uint64)
+            if flat:
+                off[1:] = np.cumsum([len(c) for c in flat], dtype=np.uint64)
+            part_of = np.repeat(np.arange(len(partition_contigs), dtype=np.uint32), [len(cl) for cl in partition_contigs]) if flat else np.zeros(1, np.uint32)
+            part_of = np.ascontiguousarray(part_of, dtype=np.uint32)
         self.h = C.c_void_p()
         self.n_parts = len(partition_contigs)
         _lib.check(_lib.lib().shn_unitigs_build(ctx.h, text.ctypes.data, off.ctypes.data, len(flat), part_of.ctypes.data, self.n_parts, int(K),

@@ -132,7 +132,7 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
     if gpu_unitigs and names:
         # the raw K-mer graphs of all partitions, contracted to unitigs in one batch on the GPU
         t0 = time.time()
-        unitigs = mbgraph_native.Unitigs(ctx, [part["new_components"][nm] for nm in names], K)
+        unitigs = mbgraph_native.Unitigs(ctx, [part["new_components"][nm] for nm in names], K, flat_text=part.get("flat_text"))
         tick("graph unitigs (GPU)", t0)
     def back(bctx=None):
         """the host-bound half of the step -- graph stage, sparse flow, merge -- on context bctx (default: the caller's): with
