@@ -122,9 +122,8 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
     if keep_partitioning:
         R.partitioning = part
     R.partitions = {}
-    lines = []
-    for i, c in enumerate(res.single_contigs):                      # reconstructed_single_contigs.fasta
-        lines += [">Single_%d\n" % i, c + "\n"]
+    # reconstructed_single_contigs.fasta: one text (the native merge takes texts); its lines only for the Python forms of the back half
+    single_text = "".join([">Single_%d\n%s\n" % (i, c) for i, c in enumerate(res.single_contigs)])
     sf_jobs = []
 
     names = list(part["new_components"])
@@ -288,7 +287,7 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
                 R.partitions[name].fasta_raw = txt                     # decoded when somebody reads ["reconstructed_fasta"]
             tick("sparse flow", t0)
             t0 = time.time()
-            R._texts = ["".join(lines)] + texts                        # all_reconstructed.fasta: single contigs, then the partitions
+            R._texts = [single_text] + texts                           # all_reconstructed.fasta: single contigs, then the partitions
             if os.environ.get("SHN_POST_NATIVE", "1") != "0":
                 try:
                     R.final = post.finalize_texts(R._texts, double_stranded, ctx=ctx_b)
@@ -305,6 +304,7 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
             tick("post", t0)
             R.timings = T
             return R
+        lines = single_text.splitlines(True)
         for name in names:
             rec = R.partitions[name]
             sf_jobs.append((name, rec["singles"], rec["components"]))
