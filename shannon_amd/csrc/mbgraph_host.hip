@@ -334,9 +334,14 @@ struct Graph {
     { std::vector<int> t = ine[s]; for (int x : t) { link(es[x], c, ew[x]); kill_edge(x); } }
     { std::vector<int> t = oute[d]; for (int x : t) { link(c, ed[x], ew[x]); kill_edge(x); } }
     int shift = (int)bases[s].size() - w;
-    std::set<RI> sset(nreads[s].begin(), nreads[s].end());
-    std::vector<RI> out(sset.begin(), sset.end());                 // P1: sorted by (read, index)
-    for (const RI& x : nreads[d]) { RI y(x.first, x.second - shift); if (!sset.count(y)) out.push_back(y); }
+    // P1: the source's reads sorted by (read, index), without repeats; then the destination's that are not among them (a sorted
+    // vector + bisection: a tree node per read was most of bridge_all for the X-nodes of a highly expressed transcript)
+    std::vector<RI> out(nreads[s]);
+    if (!std::is_sorted(out.begin(), out.end())) std::sort(out.begin(), out.end());
+    out.erase(std::unique(out.begin(), out.end()), out.end());
+    const size_t n_src = out.size();
+    out.reserve(n_src + nreads[d].size());
+    for (const RI& x : nreads[d]) { RI y(x.first, x.second - shift); if (!std::binary_search(out.begin(), out.begin() + (ptrdiff_t)n_src, y)) out.push_back(y); }
     nreads[c].swap(out);
     nreads[s].clear(); nreads[d].clear();
     kill_edge(e);
@@ -576,7 +581,11 @@ struct Graph {
     return (bi == 0 && bo == 0) || (bi == 1 && bo == 1);
   }
   int bridging_step(int node) {
-    refresh_bridging_reads(node);
+    // (bridge_all has just asked is_bridged_xnode about this node: unless a bridging step in between touched its edges, its reads
+    // are filtered already)
+    if (!((size_t)node < bridged_memo.size() && bridged_memo[node].n_reads == nreads[node].size() && bridged_memo[node].in == ine[node] &&
+          bridged_memo[node].out == oute[node]))
+      refresh_bridging_reads(node);
     if (nreads[node].empty() || ine[node].size() < 2 || oute[node].size() < 2) return shn_fail(SHN_ERR_INTERNAL, "bridging_step: assertion failed");
     const std::string nb = bases[node];
     int lb = (int)nb.size();
@@ -586,9 +595,12 @@ struct Graph {
       for (int e : t) {
         int p = es[e], w = ew[e];
         const std::string& pb = bases[p];
-        int u = new_node(std::string(1, pb[pb.size() - w - 1]) + nb);
+        const char cp = pb[pb.size() - w - 1];
+        int u = new_node(std::string(1, cp) + nb);
         link(p, u, w + 1);
-        for (const RI& x : nreads[node]) if (read_bridges(x.first, u, x.second - 1)) nreads[u].push_back(RI(x.first, x.second - 1));
+        // read_bridges(read, u, i - 1) for a read the refresh above left in the list (i > 0, the read longer than i + lb, its text equal
+        // to the node's from i on): the read reaches one base further back and that base is u's first -- no text to compare again
+        for (const RI& x : nreads[node]) if (x.second - 1 > 0 && rstr(x.first)[x.second - 1] == cp) nreads[u].push_back(RI(x.first, x.second - 1));
         bridged[u] = 0;
         if (p == node) { v_back = u; loop_w = w; }
         u_list.push_back(u);
@@ -618,8 +630,9 @@ struct Graph {
       int i = y.second;
       // exactly one u-node spelling the read from i - 1 and one w-node spelling it from i (all of them are lb + 1 bases long)
       int u = -1, x = -1, nu = 0, nw = 0;
-      for (int uu : u_list) if (rb.size() >= (size_t)(i + lb) && (int)bases[uu].size() == lb + 1 && memcmp(rb.p + i - 1, bases[uu].data(), (size_t)lb + 1) == 0) { u = uu; nu++; }
-      for (int xx : w_list) if (rb.size() >= (size_t)(i + lb + 1) && (int)bases[xx].size() == lb + 1 && memcmp(rb.p + i, bases[xx].data(), (size_t)lb + 1) == 0) { x = xx; nw++; }
+      // (the u-nodes are `base + node text`, the w-nodes `node text + base`, and the read equals the node text from i on: one base decides)
+      for (int uu : u_list) if (rb.size() >= (size_t)(i + lb) && (int)bases[uu].size() == lb + 1 && rb[i - 1] == bases[uu][0]) { u = uu; nu++; }
+      for (int xx : w_list) if (rb.size() >= (size_t)(i + lb + 1) && (int)bases[xx].size() == lb + 1 && rb[i + lb] == bases[xx][lb]) { x = xx; nw++; }
       if (nu != 1 || nw != 1) continue;
       nreads[u].push_back(RI(y.first, i - 1));
       nreads[x].push_back(RI(y.first, i));

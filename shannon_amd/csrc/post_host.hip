@@ -273,11 +273,6 @@ static int post_finalize_impl(shn_ctx* ctx, const uint8_t* const* bufs, const ui
   std::vector<std::string> own;                        // renamed header lines (stable addresses: reserved below)
   std::vector<std::pair<SV, SV>> recs;                 // (header line, sequence line), lines with their newline
   std::vector<uint32_t> rec_li;                        // ... and the index of the sequence line
-  {
-    uint64_t n_lines = 0;
-    for (auto& pc : pieces) { n_lines++; for (uint64_t p = 0; p < pc.second; p++) n_lines += pc.first[p] == '\n'; }
-    own.reserve(n_lines + 2);
-  }
   const double tq0 = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }();
   std::unordered_map<SV, uint64_t> seen;
   uint8_t comp[256];
@@ -308,6 +303,7 @@ static int post_finalize_impl(shn_ctx* ctx, const uint8_t* const* bufs, const ui
       base += n_bytes;
     }
   }
+  own.reserve(lines.size() + 2);                      // (renamed header lines: at most one per line; the reservation keeps their addresses)
   // device: the text goes up once; the sequence lines' fingerprints (plain and reverse-complemented, 128 bits each) replace the
   // host hashes.  A fingerprint match is always confirmed on the text below, so it can only cost time, never an answer.
   PostDev* dev = nullptr;
