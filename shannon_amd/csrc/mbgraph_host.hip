@@ -87,7 +87,12 @@ struct ThreadBudget {
   // large requests (the large partitions, which bound the stage) never wait -- they may overdraw the budget; small ones wait for it
   void acquire(int n) { n = std::min(n, total); std::unique_lock<std::mutex> lk(mu); if (n < 8) cv.wait(lk, [&] { return avail >= n; }); avail -= n; }
   void release(int n) { n = std::min(n, total); { std::lock_guard<std::mutex> lk(mu); avail += n; } cv.notify_all(); }
+  // as many of the n wanted as are free right now (at least 1: the caller's own thread), without waiting and without overdrawing:
+  // for phases that are worth spreading only when the machine is otherwise idle (the last, largest partition of a stage)
+  // (the partitions that are running right now each keep a core busy themselves: `others`)
+  int take_free(int n, int others) { std::lock_guard<std::mutex> lk(mu); const int got = std::max(1, std::min(n, avail - others)); avail -= got; return got; }
 };
+static std::atomic<int> g_partitions_running{0};      // partitions inside mbgraph_run_impl right now
 static ThreadBudget g_host_threads;
 struct BudgetGuard {
   int n; double waited;
@@ -651,22 +656,35 @@ struct Graph {
     std::vector<int> all = u_list;
     all.insert(all.end(), w_list.begin(), w_list.end());
     for (int n : all) prev[n] = ((double)links[n] / (double)link_count) * prev[node];
+    const double tc0 = laps ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
     for (int n : all) {
       std::vector<int> t = ine[n];
       t.insert(t.end(), oute[n].begin(), oute[n].end());
       for (int e : t) local_condense_edge(e);
     }
+    if (laps) t_condense += std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - tc0;
     kill_node(node);
     return 0;
   }
+  double t_condense = 0;
   int bridge_all() {
+    auto nowb = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_ask = 0, t_step = 0;
+    size_t n_ask = 0;
     while (true) {
       std::vector<int> todo;
-      for (int n : order) if (is_xnode(n) && is_bridged_xnode(n)) todo.push_back(n);
+      double t0 = nowb();
+      for (int n : order) if (is_xnode(n)) { n_ask++; if (is_bridged_xnode(n)) todo.push_back(n); }
+      double t1 = nowb();
       for (int n : todo) { int rc = bridging_step(n); if (rc) return rc; }
+      t_ask += t1 - t0; t_step += nowb() - t1;
       bridged_log.push_back((int)todo.size());
       remove_destroyed();
-      if (todo.empty()) return 0;
+      if (todo.empty()) {
+        if (laps) fprintf(stderr, "[mbgraph]   bridge_all: %zu passes, is_bridged_xnode %.3f s (%zu questions), bridging_step %.3f s (%.3f s of it condensing)\n",
+                          bridged_log.size(), t_ask, n_ask, t_step, t_condense);
+        return 0;
+      }
     }
   }
 
@@ -781,47 +799,69 @@ struct Graph {
               }
             }
           tk3 = nowk();
-          int cntp = 0;
-          std::vector<std::vector<int>> paths;
-          std::vector<int> cur;
-          std::vector<std::pair<int, int>> one(1);
-          // the sums per edge and the set of paths are kept in hash tables while the reads go by (10^5 reads of a highly expressed
-          // transcript name the same few edges and paths: a tree look-up with a dozen dependent misses per read was most of this
-          // loop) and go into the ordered containers afterwards; the copy counts of reads are whole numbers, so the order of the
-          // additions does not show in the sums
-          std::unordered_map<uint64_t, double> edge_sum;
-          std::unordered_map<uint64_t, std::vector<std::vector<int>>> path_seen;
-          auto note_path = [&](const std::vector<int>& p, double w) {
-            for (size_t j = 0; j + 1 < p.size(); j++) edge_sum[((uint64_t)(uint32_t)p[j] << 32) | (uint32_t)p[j + 1]] += w;
-            if (p.size() > 2) {
-              cntp++;
-              uint64_t h = 0xcbf29ce484222325ULL;
-              for (int v : p) h = (h ^ (uint64_t)(uint32_t)v) * 0x100000001b3ULL;
-              auto& lst = path_seen[h];
-              bool have = false;
-              for (const auto& q : lst) if (q == p) { have = true; break; }
-              if (!have) { lst.push_back(p); known_paths.insert(p); }
-            }
+          // The reads left to search, on host threads (slices of whole 64-read words: the lazily decoded text keeps one done bit per
+          // read).  Per thread: the sums per edge and the paths seen go through hash tables while the reads go by (10^5 reads of a highly
+          // expressed transcript name the same few edges and paths) and are merged afterwards; the copy counts of reads are whole
+          // numbers, so neither the order of the additions nor the cut into slices shows in the sums; a read's first / last node is its own.
+          struct Local {
+            std::unordered_map<uint64_t, double> edge_sum;
+            std::unordered_map<uint64_t, std::vector<std::vector<int>>> path_seen;
+            std::vector<std::vector<int>> fresh;                           // distinct paths of this slice
+            int cntp = 0;
           };
-          for (size_t r = 0; r < n_rd(); r++) {
-            if (st[r] < 2) continue;
-            const RStr rb = rstr((int)r);
-            uint64_t key;
-            if (!key_at(rb, 0, key)) continue;
-            if (st[r] == 3) one[0] = {order[nd[r]], (int)no[r]};
-            for (const auto& oc : st[r] == 3 ? one : occ_of[key]) {
-              const int sn = oc.first, so = oc.second;
-              if (!compare(rb, 0, bases[sn], so)) continue;
-              if (rb.size() <= bases[sn].size() - (size_t)so) { rfirst[r] = sn; rlast[r] = sn; rhas[r] = 1; continue; }
-              paths.clear(); cur.clear();
-              search_sequence(rb, 0, sn, so, 30, cur, paths);
-              for (auto& p : paths) {
-                rfirst[r] = p.front(); rlast[r] = p.back(); rhas[r] = 1;
-                note_path(p, rcc[r]);
+          auto search_slice = [&](size_t lo, size_t hi, Local& L) {
+            std::vector<std::vector<int>> paths;
+            std::vector<int> cur;
+            std::vector<std::pair<int, int>> one(1);
+            static const std::vector<std::pair<int, int>> none;
+            for (size_t r = lo; r < hi; r++) {
+              if (st[r] < 2) continue;
+              const RStr rb = rstr((int)r);
+              uint64_t key;
+              if (!key_at(rb, 0, key)) continue;
+              const std::vector<std::pair<int, int>>* occs = &one;
+              if (st[r] == 3) one[0] = {order[nd[r]], (int)no[r]};
+              else { auto it = occ_of.find(key); occs = it == occ_of.end() ? &none : &it->second; }
+              for (const auto& oc : *occs) {
+                const int sn = oc.first, so = oc.second;
+                if (!compare(rb, 0, bases[sn], so)) continue;
+                if (rb.size() <= bases[sn].size() - (size_t)so) { rfirst[r] = sn; rlast[r] = sn; rhas[r] = 1; continue; }
+                paths.clear(); cur.clear();
+                search_sequence(rb, 0, sn, so, 30, cur, paths);
+                for (auto& p : paths) {
+                  rfirst[r] = p.front(); rlast[r] = p.back(); rhas[r] = 1;
+                  for (size_t j = 0; j + 1 < p.size(); j++) L.edge_sum[((uint64_t)(uint32_t)p[j] << 32) | (uint32_t)p[j + 1]] += rcc[r];
+                  if (p.size() > 2) {
+                    L.cntp++;
+                    uint64_t h = 0xcbf29ce484222325ULL;
+                    for (int v : p) h = (h ^ (uint64_t)(uint32_t)v) * 0x100000001b3ULL;
+                    auto& lst = L.path_seen[h];
+                    bool have = false;
+                    for (const auto& q : lst) if (q == p) { have = true; break; }
+                    if (!have) { lst.push_back(p); L.fresh.push_back(p); }
+                  }
+                }
               }
             }
+          };
+          const size_t words = (n_rd() + 63) / 64;
+          const unsigned want = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(16, std::max(1, shn_host_cpus())), n_slow >> 12));
+          const unsigned nts = want > 1 ? (unsigned)g_host_threads.take_free((int)want, g_partitions_running.load() - 1) : 1u;      // (what is free right now: no waiting, no overdraft)
+          struct GiveBack { unsigned n; ~GiveBack() { if (n) g_host_threads.release((int)n); } } give_back{want > 1 ? nts : 0u};
+          std::vector<Local> locals(nts);
+          if (nts <= 1) search_slice(0, n_rd(), locals[0]);
+          else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nts; t++)
+              th.emplace_back(search_slice, std::min(n_rd(), words * t / nts * 64), std::min(n_rd(), words * (t + 1) / nts * 64), std::ref(locals[t]));
+            for (auto& x : th) x.join();
           }
-          for (const auto& kv : edge_sum) known_edges[{(int)(uint32_t)(kv.first >> 32), (int)(uint32_t)kv.first}] += kv.second;
+          int cntp = 0;
+          for (Local& L : locals) {
+            cntp += L.cntp;
+            for (const auto& kv : L.edge_sum) known_edges[{(int)(uint32_t)(kv.first >> 32), (int)(uint32_t)kv.first}] += kv.second;
+            for (auto& p : L.fresh) known_paths.insert(std::move(p));
+          }
           n_known = cntp;
           if (dbgk) fprintf(stderr, "[mbgraph]   kp (device) node text %.3f s scan %.3f s slow index %.3f s search %.3f s  (%zu bases, %zu reads, %zu slow)\n", tk1 - tk0,
                             tk2 - tk1, tk3 - tk2, nowk() - tk3, nb.size(), n_rd(), n_slow);
@@ -1083,6 +1123,7 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
                            const uint32_t* didx, const uint8_t* host_a, const uint8_t* host_b) {
   if (!out || (n_rows && !rows) || (!host_a && ((n_reads && (!r1 || !r1_off)) || (paired && n_reads && (!r2 || !r2_off)))))
     return shn_fail(SHN_ERR_ARG, "shn_mbgraph_run: NULL argument");
+  struct Running { Running() { g_partitions_running.fetch_add(1); } ~Running() { g_partitions_running.fetch_sub(1); } } running;
   Graph g;
   g.ctx = t_ctx.get(ctx);
   g.K = K;
