@@ -528,6 +528,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     lap("ext.filter")
     csr = None                                         # (coff, cnb, cw): connections in dict insertion order, 1-based neighbours
     contigs = ["buffer"]
+    contig_raw = None
     conn = None
     sharded_contigs = False
     if gpu_contigs or gpu_sharded:
@@ -552,10 +553,16 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
             lap("ext.merge")
         acc, _best, coff, cnb, cw = contig_stage_gpu(ctx, buf, offs, k1, r, f)
         csr = (coff, cnb, cw)
-        raw = memoryview(np.ascontiguousarray(buf))        # (only the accepted tenth is ever turned into strings, slice by slice)
+        buf = np.ascontiguousarray(buf)
+        raw = memoryview(buf)                              # (only the accepted tenth is ever turned into strings, slice by slice)
         ai = np.nonzero(acc)[0]
+        n_before = len(contigs)
         contigs += [str(raw[a:b], "ascii") for a, b in zip(offs[ai].tolist(), offs[ai + 1].tolist())]
         del raw
+        if n_before == 1:
+            # the accepted contigs as bytes (candidate buffer, its offsets, accepted candidate per contig): what lays contig text out
+            # for the device again (kmers_for_component) gathers segments instead of joining and encoding 80 MB of strings
+            contig_raw = (buf, np.asarray(offs, dtype=np.uint64), ai.astype(np.int64))
         strings = None
     else:
         strings = (ext.emit([x[0] for x in keep], [x[1] for x in keep]) if keep else []) if pipe is None else None
@@ -642,6 +649,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     res.wave_steps = ext.wave_steps
     res.dense_rounds = ext.dense_rounds
     res.contigs = contigs[1:]
+    res.contig_raw = contig_raw
     # allowed k1-mers with their integer weights (:366-369, :404-408): GPU table lookup
     allowed = {}
     if res.contigs and want_allowed:
