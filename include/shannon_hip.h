@@ -88,6 +88,11 @@ int shn_gather_rows(const uint8_t* src, uint64_t n_src_rows, uint64_t row_bytes,
  * on segments of different lengths.                                                                                          */
 int shn_gather_segments(const uint8_t* src, const uint64_t* src_off, uint64_t n_src, const int64_t* order, uint64_t n, uint8_t* dst,
                         const uint64_t* dst_off, int threads);
+/* Host utility: a two-line FASTA from byte segments -- record i = ">" prefix i "\n" segment order[i] "\n" (the file
+ * reconstructed_single_contigs.fasta of extension_correction.py:506-513 from the candidate buffer of the contig stage, without a
+ * Python string per contig).  dst == NULL: only *dst_len is set.                                                               */
+int shn_fasta_records(const uint8_t* src, const uint64_t* src_off, uint64_t n_src, const int64_t* order, uint64_t n, const char* prefix,
+                      uint8_t* dst, uint64_t dst_cap, uint64_t* dst_len);
 
 /* ---- (K+1)-mer counting ----------------------------------------------------------------------
  * Replaces `jellyfish count -m k1 ... ; jellyfish dump -c -t -L lower` (shannon.py:439-441;

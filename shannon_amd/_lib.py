@@ -29,6 +29,7 @@ SIGNATURES = {
     "shn_string_windows": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp, vp]),
     "shn_gather_rows": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, vp, C.c_int]),
     "shn_gather_segments": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, C.c_int]),
+    "shn_fasta_records": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64, C.c_char_p, vp, C.c_uint64, u64p]),
     "shn_count_k1mers": (C.c_int, [vp, vpp, C.c_int, C.c_int, C.c_int, vpp]),
     "shn_table_destroy": (None, [vp]),
     "shn_table_size": (C.c_uint64, [vp]),
@@ -179,6 +180,20 @@ def gather_segments(src, src_off, order, threads=8):
         check(lib().shn_gather_segments(src.ctypes.data, src_off.ctypes.data, len(src_off) - 1, order.ctypes.data, len(order), dst.ctypes.data,
                                         dst_off.ctypes.data, int(threads)))
     return dst, dst_off
+
+
+def fasta_records(src, src_off, order, prefix):
+    """uint8 array: the two-line FASTA whose record i is ">" + prefix + str(i), then segment order[i] of src (shn_fasta_records)"""
+    import numpy as np
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    src_off = np.ascontiguousarray(src_off, dtype=np.uint64)
+    order = np.ascontiguousarray(order, dtype=np.int64)
+    n = C.c_uint64(0)
+    args = (src.ctypes.data, src_off.ctypes.data, len(src_off) - 1, order.ctypes.data, len(order), prefix.encode())
+    check(lib().shn_fasta_records(*args, None, 0, C.byref(n)))
+    dst = np.empty(max(int(n.value), 1), dtype=np.uint8)
+    check(lib().shn_fasta_records(*args, dst.ctypes.data, int(n.value), C.byref(n)))
+    return dst[:int(n.value)]
 
 
 def string_windows(strings, k, want_keys=True, want_rows=False):

@@ -536,6 +536,37 @@ extern "C" int shn_gather_segments(const uint8_t* src, const uint64_t* src_off, 
   return SHN_OK;
 }
 
+// ---- host utility: a two-line FASTA from byte segments: record i = ">" prefix i "\n" + segment order[i] of src + "\n" (the
+// reconstructed_single_contigs.fasta of extension_correction.py:506-513 straight from the candidate buffer of the contig stage).
+// dst == NULL: only *dst_len (the size) is set.
+extern "C" int shn_fasta_records(const uint8_t* src, const uint64_t* src_off, uint64_t n_src, const int64_t* order, uint64_t n, const char* prefix,
+                                 uint8_t* dst, uint64_t dst_cap, uint64_t* dst_len) {
+  if (!dst_len || !prefix || (n && (!src || !src_off || !order))) return shn_fail(SHN_ERR_ARG, "shn_fasta_records: NULL argument");
+  const size_t lp = strlen(prefix);
+  uint64_t need = 0;
+  for (uint64_t i = 0; i < n; i++) {
+    if (order[i] < 0 || (uint64_t)order[i] >= n_src) return shn_fail(SHN_ERR_ARG, "shn_fasta_records: segment index out of range");
+    uint64_t digits = 1; for (uint64_t v = i; v >= 10; v /= 10) digits++;
+    need += 1 + lp + digits + 1 + (src_off[order[i] + 1] - src_off[order[i]]) + 1;
+  }
+  *dst_len = need;
+  if (!dst) return SHN_OK;
+  if (dst_cap < need) return shn_fail(SHN_ERR_ARG, "shn_fasta_records: destination too small");
+  uint8_t* w = dst;
+  char num[24];
+  for (uint64_t i = 0; i < n; i++) {
+    *w++ = '>';
+    memcpy(w, prefix, lp); w += lp;
+    const int nd = snprintf(num, sizeof num, "%llu", (unsigned long long)i);
+    memcpy(w, num, (size_t)nd); w += nd;
+    *w++ = '\n';
+    const uint64_t len = src_off[order[i] + 1] - src_off[order[i]];
+    memcpy(w, src + src_off[order[i]], len); w += len;
+    *w++ = '\n';
+  }
+  return SHN_OK;
+}
+
 // ---- host utility: every k-window of every string (ASCII ACGT, strings given by offsets into one text), in order: as
 // packed 2-bit keys (keys_out, k <= 32) and/or as fixed-width byte rows (rows_out, k bytes per window).  The partition
 // stage needs both for every partition contig (k1mers2component, kmers_for_component.py:244-305; the k1-mer files,

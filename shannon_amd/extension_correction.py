@@ -673,10 +673,12 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     mem, co = res.comp_members, res.comp_off
     sizes = np.diff(comp_off.astype(np.int64)) if len(comp_off) > 1 else np.zeros(0, np.int64)
     res.single_contigs, res.big_components, res.remaining = [], [], [[]]
+    res.single_ids = []                               # index in res.contigs of every single contig
     cur_size = 0
     for j, sz in enumerate(sizes.tolist()):
         if sz == 1:
             res.single_contigs.append(contigs[mem[co[j]]])
+            res.single_ids.append(mem[co[j]] - 1)
         elif sz > comp_size_threshold:
             mm = mem[co[j]:co[j + 1]]
             code = {c: i + 1 for i, c in enumerate(mm)}

@@ -123,7 +123,11 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
         R.partitioning = part
     R.partitions = {}
     # reconstructed_single_contigs.fasta: one text (the native merge takes texts); its lines only for the Python forms of the back half
-    single_text = "".join([">Single_%d\n%s\n" % (i, c) for i, c in enumerate(res.single_contigs)])
+    raw, ids = getattr(res, "contig_raw", None), getattr(res, "single_ids", None)
+    if raw is not None and ids is not None and len(ids) == len(res.single_contigs) and len(raw[2]) == len(res.contigs):
+        single_text = _lib.fasta_records(raw[0], raw[1], raw[2][np.asarray(ids, dtype=np.int64)], "Single_")      # (bytes, from the contig stage's buffer)
+    else:
+        single_text = "".join([">Single_%d\n%s\n" % (i, c) for i, c in enumerate(res.single_contigs)])
     sf_jobs = []
 
     names = list(part["new_components"])
@@ -304,7 +308,7 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
             tick("post", t0)
             R.timings = T
             return R
-        lines = single_text.splitlines(True)
+        lines = (single_text if isinstance(single_text, str) else bytes(single_text).decode()).splitlines(True)
         for name in names:
             rec = R.partitions[name]
             sf_jobs.append((name, rec["singles"], rec["components"]))
