@@ -8,6 +8,7 @@ Fixture files (all plain data):
   data/<case>.npz                                      synthetic input reads (base codes)
   <case>.json.gz                                       artefacts of every stage boundary
   lp_kats.json                                         path_decompose known-answer cases
+  post_adversarial.json.gz                             final merge (a31) of the adversarial inputs of tests/post_cases.py
 Each artefact file carries a "standins" note: Jellyfish -> exact brute-force counter;
 gpmetis -> hand-written partition vectors; cvxopt -> stub + the oracle's pinned LP rule/RNG.
 """
@@ -91,6 +92,11 @@ def slim(art, keep_full):
         if keep_full or len(p["k1mers"]) < 20000:
             q["k1mers"] = p["k1mers"]
         out["partitions"][c] = q
+    if "final" in art:
+        # row a31 through the reference's own chain (ref_harness.run_final): the concatenation it was given and the final
+        # shannon.fasta as {name: sequence}, under the user's strandedness ("ds") and under -s ("ss")
+        out["all_reconstructed"] = art["all_reconstructed"]
+        out["final"] = art["final"]
     return out
 
 
@@ -180,6 +186,20 @@ def main():
         save(name, slim(art, keep_full=(name in ("syn_pe_s0", "syn_se_s7_K20"))))
         print(name, "done", art["n_k1mers"], {c: p["graph"] and len(p["graph"]["nodes"]) for c, p in art["partitions"].items()})
     json.dump(manifest, open(os.path.join(OUT, "manifest.json"), "w"), indent=1)
+    if want("post_adversarial"):
+        # --- row a31 alone: adversarial concatenations (tests/post_cases.py) through the reference's own
+        # process_concatenated_fasta -> perl sort -> faster_reps -d chain, both strand settings
+        sys.path.insert(0, os.path.dirname(HERE))
+        import post_cases
+        tref = H.prepare_translated(os.path.join(TMP, "post", "tref"))
+        adv = {"standins": "none: the reference's process_concatenated_fasta.py and faster_reps.py (translated at run time) and perl"}
+        for seed in post_cases.SEEDS:
+            text = "".join(post_cases.adversarial(seed))
+            adv[str(seed)] = {"input_sha256": hashlib.sha256(text.encode()).hexdigest(),
+                              "ds": H.run_final(tref, os.path.join(TMP, "post", "ds%d" % seed), text, True),
+                              "ss": H.run_final(tref, os.path.join(TMP, "post", "ss%d" % seed), text, False)}
+        save("post_adversarial", adv)
+        print("post_adversarial done", {k: (len(v["ds"]), len(v["ss"])) for k, v in adv.items() if k != "standins"})
     if ONLY is not None and "lp_kats" not in ONLY:
         return finish_check(check)
     # --- LP known-answer cases through the reference's own path_decompose wrapper
@@ -256,6 +276,10 @@ def canonical_case(obj):
                     pass
                 recs.append([sq, w])
             q["reconstructed_fasta"] = sorted(recs)
+    if "final" in out:                  # names carry component numbers (address order): the sequences are what is canonical
+        ls = out.pop("all_reconstructed").splitlines()
+        out["all_reconstructed"] = sorted(ls[1::2])
+        out["final"] = {k: sorted(v.values()) for k, v in out["final"].items()}
     return out
 
 

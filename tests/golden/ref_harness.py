@@ -312,4 +312,39 @@ def run_case(root, reads_files, K, paired, partition_size=500, part_hook=None, h
                 txt += open(fpath).read()          # run_MB_SF_fn.py:254
             part["reconstructed_fasta"] = txt
         art["partitions"][comp] = part
+    if run_sf:
+        # shannon.py:584-595: `cat reconstructed_single_contigs.fasta <every partition's algo_output/reconstructed.fasta>`
+        # (run_MB_SF_fn.py:254 has already appended the reconstructed_comp_*.fasta files to the latter)
+        art["all_reconstructed"] = art["single_contigs_fasta"] + "".join(art["partitions"][c]["reconstructed_fasta"] for c in kfc[1])
+        art["final"] = {key: run_final(tref, os.path.join(root, "final_" + key), art["all_reconstructed"], ds)
+                        for key, ds in (("ds", True), ("ss", False))}
     return art
+
+
+PERL_SORT = ("while (<>) {$h=$_; $s=<>; $seqs{$h}=$s;} foreach $header (sort {length($seqs{$a}) <=> length($seqs{$b})} "
+             "keys %seqs) {print $header.$seqs{$header}}")        # the one-liner of shannon.py:603, verbatim
+
+
+def run_final(tref, work, all_text, ds):
+    """Row a31 through the reference itself: process_concatenated_fasta(all_reconstructed.fasta, reconstructed_org.fasta, ds)
+    (shannon.py:596; process_concatenated_fasta.py:6-32), the perl length sort (shannon.py:603; perl is on this image) and
+    `faster_reps.py -d sorted out` (shannon.py:604; faster_reps.py:98-131) -- always -d, whatever `ds`.  Returns the final
+    file as {name: sequence}.  The kept set does not depend on the order perl's hash puts equal lengths in (faster_reps keys
+    its tables by name and walks each 24-mer's hits per contig in position order); PERL_HASH_SEED is pinned anyway."""
+    os.makedirs(work, exist_ok=True)
+    f_all, f_org = os.path.join(work, "all_reconstructed.fasta"), os.path.join(work, "reconstructed_org.fasta")
+    f_sorted, f_out = os.path.join(work, "reconstructed_sorted.fasta"), os.path.join(work, "reconstructed.fasta")
+    open(f_all, "w").write(all_text)
+    run_py(tref, "import sys; from process_concatenated_fasta import process_concatenated_fasta as p; "
+                 "p(sys.argv[1], sys.argv[2], sys.argv[3] == '1')", argv=[f_all, f_org, "1" if ds else "0"])
+    env = dict(pinned_env(tref), PERL_HASH_SEED="0", PERL_PERTURB_KEYS="0")
+    with open(f_org, "rb") as i, open(f_sorted, "wb") as o:
+        subprocess.run(["perl", "-e", PERL_SORT], stdin=i, stdout=o, env=env, check=True)
+    p = subprocess.run([sys.executable, "-W", "ignore", os.path.join(tref, "faster_reps.py"), "-d", f_sorted, f_out],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    if p.returncode != 0:
+        raise RuntimeError("faster_reps failed:\n" + p.stderr[-3000:])
+    ls = open(f_out).read().splitlines()
+    names = [l[1:] for l in ls[0::2]]
+    assert all(l[0] == ">" for l in ls[0::2]) and len(set(names)) == len(names)
+    return dict(zip(names, ls[1::2]))

@@ -51,6 +51,14 @@ def test_end_to_end_vs_oracle(ctx, name):
         for k in can:
             assert approx_eq(can[k], g["partitions"][p]["graph"][k])
     assert R.final == O["final"]                 # final shannon.fasta as {name: sequence}
+    # ... and the reference's own final file (process_concatenated_fasta -> perl sort -> faster_reps -d on the reference run's
+    # concatenation, ref_harness.run_final): the sequences -- the names carry the reference's address-ordered component numbers
+    key = "ds" if ds else "ss"
+    assert sorted(R.final.values()) == sorted(g["final"][key].values())
+    # the device merge on the reference's own concatenation: names too
+    from shannon_amd import post
+    for k2, d2 in (("ds", True), ("ss", False)):
+        assert post.finalize_texts([g["all_reconstructed"]], d2, ctx=ctx) == g["final"][k2]
 
 
 def test_cli_config1_samples_se(tmp_path):

@@ -116,3 +116,23 @@ def test_native_merge_refuses_other_characters_and_the_python_form_takes_over():
     with pytest.raises(_lib.ShannonError, match="non-ACGT"):
         post.finalize_texts(["".join(lines)], True)
     assert post.finalize(lines, True) == post.find_reps(post.length_sort(post.process_concatenated(lines, True)), True)
+
+
+def test_native_merge_equals_the_reference_chain():
+    """a31, host form of the product (shn_post_finalize_bufs) and its readable Python form against what the reference's own
+    process_concatenated_fasta -> perl sort -> faster_reps -d chain produced (tests/golden: ref_harness.run_final): the adversarial
+    concatenations and the concatenation of every golden run, under both strand settings"""
+    from shannon_amd import post
+    from golden_util import load_case, MANIFEST
+    from post_cases import adversarial, SEEDS
+    g = load_case("post_adversarial")
+    for seed in SEEDS:
+        lines = adversarial(seed)
+        for key, ds in (("ds", True), ("ss", False)):
+            assert post.finalize_texts(["".join(lines)], ds) == g[str(seed)][key]
+            if seed == 1:
+                assert post.find_reps(post.length_sort(post.process_concatenated(lines, ds)), True) == g[str(seed)][key]
+    for name in sorted(MANIFEST):
+        c = load_case(name)
+        for key, ds in (("ds", True), ("ss", False)):
+            assert post.finalize_texts([c["all_reconstructed"]], ds) == c["final"][key], (name, key)

@@ -132,3 +132,43 @@ def test_strand_symmetry_and_rc():
     g, K, paired, dbl, tab = run_oracle_front("pe_K25")
     for k in list(tab)[::50]:
         assert tab[k] == tab[seqs.reverse_complement(k)]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_final_merge_against_reference(name):
+    """a31: the reference's own process_concatenated_fasta -> perl length sort -> faster_reps -d chain (ref_harness.run_final) on
+    the concatenation the reference run produced, under both strand settings: names and sequences equal."""
+    g = load_case(name)
+    lines = g["all_reconstructed"].splitlines(True)
+    assert len(lines) >= 2
+    for key, ds in (("ds", True), ("ss", False)):
+        assert post.finalize(lines, ds) == g["final"][key], key
+
+
+def test_final_merge_adversarial_against_reference():
+    """a31 on the adversarial concatenations of tests/post_cases.py (+-3 containment, reverse-complement duplicates, name-greater
+    ties, repeated headers, the 200-base cut), which went through the same reference chain."""
+    import hashlib
+    from post_cases import adversarial, SEEDS
+    g = load_case("post_adversarial")
+    for seed in SEEDS:
+        lines = adversarial(seed)
+        assert hashlib.sha256("".join(lines).encode()).hexdigest() == g[str(seed)]["input_sha256"]
+        for key, ds in (("ds", True), ("ss", False)):
+            want = g[str(seed)][key]
+            assert 20 < len(want) < len(lines) // 2
+            assert post.finalize(lines, ds) == want, (seed, key)
+
+
+@pytest.mark.parametrize("name", ["se_K24", "syn_se_s5", "syn_pe_hairpin", "syn_pe_ss_s69", "syn_part_s33"])
+def test_oracle_pipeline_final_against_reference(name):
+    """the chained oracle (oracle/pipeline.py) from the input reads to the final file against the reference's final file: the
+    sequences (names carry the reference's address-ordered component numbers)"""
+    from oracle import pipeline as opipe
+    m, g, inp = MANIFEST[name], load_case(name), load_inputs(name)
+    psize = m.get("partition_size", 500)
+    pv = [part_vectors(len(b["contigs"]), psize) for b in g["big_components"]] or None
+    ds = not strand_specific(name)
+    O = opipe.assemble(inp[0], inp[1] if m["paired"] else None, K=m["K"], partition_size=psize, sample="", seed=m["sf_seed"],
+                       part_vectors=pv, double_stranded=ds)
+    assert sorted(O["final"].values()) == sorted(g["final"]["ds" if ds else "ss"].values())
