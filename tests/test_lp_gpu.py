@@ -178,6 +178,18 @@ def test_native_sparse_flow_equals_python_mirror_and_golden(ctx, name):
             assert t1[2:] == t2[2:]
             if "Copycount" not in t1[1]:
                 assert abs(float(t1[1]) - float(t2[1])) <= 1e-6 * max(1.0, abs(float(t1[1])))
+    # ... and on to the final file (a31): the reference's tables through the native sparse flow under the fixture's sample name (""),
+    # concatenated behind reconstructed_single_contigs.fasta like shannon.py:584-595 and merged on the device: the reference's own
+    # final file (process_concatenated_fasta -> perl sort -> faster_reps -d, ref_harness.run_final), names included
+    from shannon_amd import post
+    graphs = [mbgraph_native.graph_from_tables([tuple(r) for r in gp["single_rows"]],
+                                               [{"nodes": rc["nodes"], "edges": rc["edges"], "paths": rc["paths"]} for rc in gp["raw_components"]])
+              for gp in g["partitions"].values()]
+    texts = mbgraph_native.sparse_flow_native(ctx, graphs, [""] * len(graphs), seed)
+    for gh in graphs:
+        gh.close()
+    for k2, d2 in (("ds", True), ("ss", False)):
+        assert post.finalize_texts([g["single_contigs_fasta"]] + texts, d2, ctx=ctx) == g["final"][k2]
 
 
 def test_python_float_repr_of_the_native_stage(ctx):
