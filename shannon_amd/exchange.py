@@ -36,17 +36,44 @@ def note(name, sent, received, seconds, calls=1):
     e["seconds"] += float(seconds)
 
 
+def coll_stats():
+    """SHN_COLL_STATS=1: exact byte tallies (objects are pickled a second time to be measured) and a device synchronize after
+    every all-to-all so that its seconds are the collective's own.  Off (default): seconds of the host call only, bytes from the
+    arrays' sizes -- nothing extra inside a timed step."""
+    import os
+    return os.environ.get("SHN_COLL_STATS", "0") == "1"
+
+
+def _payload_bytes(obj):
+    """bytes of the numpy / bytes / str payload of a control object (what dominates its pickle), without pickling it"""
+    if isinstance(obj, np.ndarray):
+        return obj.nbytes
+    if isinstance(obj, (bytes, bytearray, str)):
+        return len(obj)
+    if isinstance(obj, dict):
+        return sum(_payload_bytes(v) for v in obj.values())
+    if isinstance(obj, (list, tuple)):
+        return sum(_payload_bytes(v) for v in obj)
+    return 8
+
+
 def all_gather_object(obj, group=None, name="objects"):
-    """dist.all_gather_object with its pickled size tallied (small control payloads: contigs, FASTA texts, stage dicts)"""
-    import pickle, time
+    """dist.all_gather_object with its size tallied (small control payloads: contigs, FASTA texts, stage dicts); the seconds are
+    taken as the collective returns, the bytes from the payload arrays (pickled sizes only under SHN_COLL_STATS=1)"""
+    import time
     W = dist.get_world_size(group)
     parts = [None] * W
     t0 = time.time()
     dist.all_gather_object(parts, obj, group=group)
+    seconds = time.time() - t0
     if W > 1:
-        mine = len(pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL))
-        other = sum(len(pickle.dumps(p, protocol=pickle.HIGHEST_PROTOCOL)) for i, p in enumerate(parts) if i != dist.get_rank(group))
-        note(name, mine * (W - 1), other, time.time() - t0)
+        me = dist.get_rank(group)
+        if coll_stats():
+            import pickle
+            size = lambda o: len(pickle.dumps(o, protocol=pickle.HIGHEST_PROTOCOL))
+        else:
+            size = _payload_bytes
+        note(name, size(obj) * (W - 1), sum(size(p) for i, p in enumerate(parts) if i != me), seconds)
     return parts
 
 
@@ -87,7 +114,7 @@ def all_to_all_v(send, scl, rcl, cdev, group=None, name=None):
     import time
     t_begin = time.time()
     out = _all_to_all_v(send, scl, rcl, cdev, group)
-    if cdev.type == "cuda":
+    if cdev.type == "cuda" and coll_stats():
         torch.cuda.synchronize()
     me = dist.get_rank(group)
     es = send.element_size()

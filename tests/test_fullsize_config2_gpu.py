@@ -225,3 +225,90 @@ def test_a_second_run_gives_the_same_bytes(full):
     want = json.load(open(DIGESTS)).get(F.cfg)                            # the digest the committed bench line of this config prints
     print("config %s transcripts_sha256_16 %s (recorded: %s)" % (F.cfg, F.sha, want))
     assert want is None or F.sha == want
+
+
+ORACLE_CAP = 100_000       # routed pairs: what oracle/mbgraph.py (pure Python, ~80 us per pair + ~20 us per k1-mer row) finishes in seconds
+
+
+def _partition_inputs(F, nm):
+    """exactly what multibridging.main gets for partition nm: its k1-mer rows in file order (the weights never reach the output,
+    multibridging.py:169 / mbgraph.py:735-767) and its reads up to the cutoff of multibridging.py:26-30, as strings"""
+    from shannon_amd import pipeline
+    P, K1 = F.R.partitioning, F.K1
+    rb = P["k1mer_bytes"][nm]
+    rb = rb() if callable(rb) else rb
+    rows = [(bytes(rb[i:i + K1]).decode(), 1) for i in range(0, len(rb), K1)]
+    cutoff = 10 * pipeline.n_kmer_nodes(rows, F.K) + 1
+    idx = P["routes"][nm][:cutoff]
+    return rows, [[F.store.mate1(int(d)) for d in idx], [F.store.mate2(int(d)) for d in idx]]
+
+
+def test_partitions_of_the_run_through_the_oracle(full):
+    """The back half at full size against the oracle: partitions of THIS run picked by rule among those with at most ORACLE_CAP routed
+    pairs -- the smallest, the median, the one that bridged the most X-nodes, the one with the most known paths, the one with the
+    most mate paths -- each with exactly its k1-mer rows and capped reads through oracle.mbgraph.run_partition (multibridging.py:
+    209-269) and oracle.sparse_flow (algorithm_SF.py:373-613): canonical graph equal, transcripts equal record by record,
+    abundances to 1e-6."""
+    import time
+    from oracle import mbgraph as omb, sparse_flow as osf
+    from shannon_amd import mbgraph
+    from golden_util import approx_eq
+    from test_e2e_gpu import cmp_fasta
+    F = full
+    P = F.R.partitioning
+    small = sorted((nm for nm in P["routes"] if len(P["routes"][nm]) <= ORACLE_CAP), key=lambda nm: len(P["routes"][nm]))
+    assert len(small) >= 5
+    log = {nm: F.R.partitions[nm]["log"] for nm in small}
+    picks = {}
+    for why, nm in (("smallest", small[0]), ("median under the cap", small[len(small) // 2]),
+                    ("most bridged X-nodes", max(small, key=lambda nm: (sum(log[nm]["bridged"]), len(P["routes"][nm])))),
+                    ("most known paths", max(small, key=lambda nm: (log[nm]["known_paths"], len(P["routes"][nm])))),
+                    ("most mate paths", max(small, key=lambda nm: (log[nm]["mate_paths"], len(P["routes"][nm]))))):
+        picks.setdefault(nm, why)
+    if len(picks) < 4:                                         # rules that coincide: fill up with the largest ones under the cap
+        for nm in reversed(small):
+            picks.setdefault(nm, "largest under the cap")
+            if len(picks) >= 4:
+                break
+    for nm, why in picks.items():
+        t0 = time.time()
+        rows, reads = _partition_inputs(F, nm)
+        g, singles, comps = omb.run_partition(rows, reads, F.K, True)
+        rec = F.R.partitions[nm]
+        can_o, can_p = omb.canonical(singles, comps), mbgraph.canonical(rec["singles"], rec["components"])
+        for k in can_o:
+            assert approx_eq(can_p[k], can_o[k]), (nm, why, k)
+        assert [l for l in g.log if "Bridged" in l] == ["Bridged %d nodes" % b for b in rec["log"]["bridged"]]
+        sname = "bench_%s" % nm
+        txt = ""
+        for c, comp in enumerate(comps):
+            tr = osf.sparse_flow_component(comp["nodes"], comp["edges"], comp["paths"], seed=1, comp_id=c)
+            txt += osf.fasta_records(sname, str(c), tr)
+        txt += osf.single_nodes_fasta(sname, singles)
+        cmp_fasta(rec["reconstructed_fasta"], txt)
+        print("config %s partition %s (%s): %d k1-mer rows, %d pairs, %d components, %d single nodes, %d transcripts == oracle; log %s (%.1f s)"
+              % (F.cfg, nm, why, len(rows), len(reads[0]), len(comps), len(singles), txt.count(">"), [l for l in g.log if "Bridged" in l or "paths" in l], time.time() - t0))
+
+
+def test_a_median_partition_on_the_host_only_path(full):
+    """the partition of median size (400 k-1 M routed pairs: beyond the Python oracle) through the native graph stage WITHOUT the
+    device (shn_mbgraph_run, ctx = NULL: K-mer graph built and condensed sequentially from the k1-mer rows, reads as gathered text,
+    seeds matched on the host) against the run's own record of it (unitigs on the GPU, distinct reads and seed scans on the device,
+    reads named by rows): the same canonical graph.  Two code paths of the product, not an oracle -- but independent ones."""
+    from shannon_amd import mbgraph, mbgraph_native, kmers_for_component as kfc
+    from golden_util import approx_eq
+    F = full
+    P = F.R.partitioning
+    names = sorted(P["routes"], key=lambda nm: len(P["routes"][nm]))
+    nm = names[len(names) // 2]
+    rows = kfc._rows_bytes(P["new_components"][nm], F.K1)
+    idx = P["routes"][nm]
+    b1, o1, rc1, enc = F.store.gather_codes(idx, 1)
+    g = mbgraph_native.run_partition_handle(rows, len(rows) // F.K1, F.K, b1, o1, b1, o1, ctx=None, enc=enc, rc1=rc1, rc2=(1 - rc1).astype(np.uint8))
+    singles, comps, _log = g.tables()
+    g.close()
+    rec = F.R.partitions[nm]
+    a, b = mbgraph.canonical(singles, comps), mbgraph.canonical(rec["singles"], rec["components"])
+    for k in a:
+        assert approx_eq(a[k], b[k]), (nm, k)
+    print("config %s partition %s: %d pairs, host-only graph == the run's (%d nodes)" % (F.cfg, nm, len(idx), len(a["nodes"])))

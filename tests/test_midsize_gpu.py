@@ -79,3 +79,87 @@ def test_gpu_contig_stage_and_bulk_walker_equal_the_sequential_stage_at_10m_read
     for x in sets:
         x.close()
     ctx.close()
+
+
+def oracle_front(r1, r2, K):
+    """the chained oracle up to the partitions' inputs: C count + C walks (oracle/count_c.c, oracle/ext_c.c), then the oracle's
+    Python from the walks on: accept filter, duplicate_check, contig graph, components, partitions, read routing, k1-mer files"""
+    from oracle import build_c, extension, partition, seqs
+    from golden_util import part_vectors
+    k1 = K + 1
+    ok, oc, nw = build_c.count_canonical(np.concatenate([r1, r2]), k1, True)
+    walks = build_c.extend(ok, oc, k1, 3)
+    # the dictionary run_correction reads when the walks are given: the weights of the k1-mers of walks that can be accepted
+    A = np.frombuffer(b"ACGT", np.uint8)
+    code = np.zeros(256, np.uint64)
+    for i, ch in enumerate(b"ACGT"):
+        code[ch] = i
+    items = {}
+    pw = (np.uint64(4) ** np.arange(k1 - 1, -1, -1, dtype=np.uint64)).astype(np.uint64)
+    for contig, _w, _n in walks:
+        if len(contig) < 75:
+            continue
+        c = code[np.frombuffer(contig.encode(), np.uint8)]
+        fw = np.lib.stride_tricks.sliding_window_view(c, k1) @ pw
+        rv = np.lib.stride_tricks.sliding_window_view(np.uint64(3) - c, k1) @ pw[::-1]
+        cnt = oc[np.searchsorted(ok, np.minimum(fw, rv))].tolist()
+        for i, w in enumerate(cnt):
+            items[contig[i:i + k1]] = w
+    res = extension.run_correction(sorted(items.items(), reverse=True), walks=walks)
+    pv = [part_vectors(len(b[0]), 500) for b in res.big_components] or None
+    nc, k2c = partition.build_partitions([b[0] for b in res.big_components], [p[0] for p in pv] if pv else [], [p[1] for p in pv] if pv else None,
+                                         res.remaining, res.allowed, K)
+    s1 = [A[r].tobytes().decode() for r in r1]
+    s2 = [A[r].tobytes().decode() for r in r2]
+    d1, d2 = seqs.double_strand_paired(s1, s2)
+    o1, o2 = partition.route_reads_paired(d1, d2, nc, k2c, K)
+    files, _ = partition.partition_k1mers(nc, k2c, K)
+    return ok, walks, res, pv, nc, o1, o2, files
+
+
+def test_whole_path_equals_the_oracle_at_a_million_reads():
+    """1 M reads (500 k pairs) of 500 genes, K = 25, through the WHOLE path on the device and through the chained oracle: the front
+    through the C restatements (oracle/count_c.c, oracle/ext_c.c: the table and every walk), then the oracle's Python from the walks
+    on -- accept filter, duplicate_check, contig graph, components (extension.run_correction(walks=...)), partitions, read routing,
+    multibridged graph (mbgraph.run_partition), sparse flow, final merge.  Contigs, partitions, every partition's canonical graph,
+    transcripts record by record (abundances to 1e-6) and the final file equal.  (The goldens reach 28 k pairs, the full-size runs are
+    checked through properties and a few partitions: this is the one run of 10^6 reads compared stage by stage.)"""
+    import time
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from shannon_amd import device, pipeline, mbgraph
+    from oracle import build_c, extension, partition, mbgraph as omb, sparse_flow as osf, post as opost, seqs
+    from golden_util import approx_eq, part_vectors
+    from test_e2e_gpu import cmp_fasta
+    K, k1 = 25, 26
+    r1, r2 = bench.gen_reads(500_000, 20240501, 500, torch.device("cuda", 0), read_seed=7)
+    t0 = time.time()
+    ok, walks, res, pv, nc, o1, o2, files = oracle_front(r1, r2, K)
+    t_front = time.time() - t0
+    ctx = device.Context(0)
+    R = pipeline.assemble(ctx, r1, r2, K=K, sample="mid", seed=1, part_vectors=pv)
+    assert R.extension.contigs == res.contigs and len(res.contigs) > 500
+    assert list(R.partitions) == list(nc)
+    lines = [">Single_%d\n%s\n" % (i, c) for i, c in enumerate(res.single_contigs)]
+    lines = "".join(lines).splitlines(True)
+    n_routed = 0
+    for name in nc:
+        assert R.partitions[name]["n_reads_routed"] == len(o1[name])
+        n_routed += len(o1[name])
+        g, singles, comps = omb.run_partition(files[name], [o1[name], o2[name]], K, True)
+        rec = R.partitions[name]
+        a, b = omb.canonical(singles, comps), mbgraph.canonical(rec["singles"], rec["components"])
+        for k in a:
+            assert approx_eq(b[k], a[k]), (name, k)
+        sname = "mid_%s" % name
+        txt = ""
+        for c, comp in enumerate(comps):
+            txt += osf.fasta_records(sname, str(c), osf.sparse_flow_component(comp["nodes"], comp["edges"], comp["paths"], seed=1, comp_id=c))
+        txt += osf.single_nodes_fasta(sname, singles)
+        cmp_fasta(rec["reconstructed_fasta"], txt)
+        lines += txt.splitlines(True)
+    assert R.final == opost.finalize(lines, True)
+    print("1 M reads: %d k1-mers, %d walks, %d contigs, %d partitions, %d routed pairs, %d final transcripts == oracle (oracle front %.0f s, all %.0f s)"
+          % (len(ok), len(walks), len(res.contigs), len(nc), n_routed, len(R.final), t_front, time.time() - t0))
+    ctx.close()

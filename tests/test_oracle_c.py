@@ -59,3 +59,30 @@ def test_c_counter_feeds_the_c_extension():
     kmers, k1 = extension.load_kmers([(k, tab[k]) for k in sorted(tab, reverse=True)])
     want = [(c, int(w), n) for c, w, n in extension.python_walks(kmers, k1, 3)]
     assert build_c.extend(keys, cnts, 26, 3) == want
+
+
+def test_oracle_front_over_c_walks_equals_the_python_oracle():
+    """the chained oracle that tests/test_midsize_gpu.py runs at 10^6 reads (C count + C walks, then run_correction(walks=...) over the
+    dictionary restricted to the k1-mers of acceptable walks) against the plain Python oracle pipeline on a small batch: same
+    contigs, allowed dictionary, partitions, routed reads and k1-mer files"""
+    from shannon_amd import synth
+    from oracle import partition
+    from test_midsize_gpu import oracle_front
+    iso, _ = synth.make_transcriptome(12, 5)
+    r1, r2 = synth.sample_pairs(iso, 6000, 5)
+    K = 25
+    ok, walks, res, pv, nc, o1, o2, files = oracle_front(r1, r2, K)
+    A = np.frombuffer(b"ACGT", np.uint8)
+    s1 = [A[r].tobytes().decode() for r in r1]
+    s2 = [A[r].tobytes().decode() for r in r2]
+    dbl = list(seqs.double_strand_paired(s1, s2))
+    tab = count.count_k1mers_dict([r for f in dbl for r in f], K + 1)
+    want = extension.run_correction([(k, tab[k]) for k in sorted(tab, reverse=True)])
+    assert res.contigs == want.contigs and len(want.contigs) > 20
+    assert res.allowed == want.allowed
+    assert res.single_contigs == want.single_contigs and res.remaining == want.remaining
+    nc2, k2c2 = partition.build_partitions([], [], None, want.remaining, want.allowed, K)
+    assert list(nc) == list(nc2) and all(nc[n] == nc2[n] for n in nc)
+    w1, w2 = partition.route_reads_paired(dbl[0], dbl[1], nc2, k2c2, K)
+    assert o1 == w1 and o2 == w2
+    assert files == partition.partition_k1mers(nc2, k2c2, K)[0]
