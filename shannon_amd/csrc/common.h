@@ -20,7 +20,8 @@ int shn_fail(int code, const std::string& msg);
 
 enum {
   T_PACK = 0, T_HIST1, T_SCATTER1, T_HIST2, T_SCATTER2, T_COUNT, T_COMPACT, T_COUNT_TOTAL, T_LOOKUP,
-  T_EXTEND, T_ROUTE, T_GRAPH, T_LP, T_EXT_PREP, T_EXT_SORT, T_EXT_WALK, T_SEEDS, T_EXT_WALK_THREAD, T_EXT_WALK_WAVE, T_EXT_MARK, T_EXT_EMIT, T_TABLE_BUILD, T_COUNT_DIRECT, T_CONTIG, T_GRAPH_GPU, T_EXT_ADJ, T_N = 32
+  T_EXTEND, T_ROUTE, T_GRAPH, T_LP, T_EXT_PREP, T_EXT_SORT, T_EXT_WALK, T_SEEDS, T_EXT_WALK_THREAD, T_EXT_WALK_WAVE, T_EXT_MARK, T_EXT_EMIT, T_TABLE_BUILD, T_COUNT_DIRECT, T_CONTIG, T_GRAPH_GPU, T_EXT_ADJ,
+  T_SK_HIST, T_SK_EMIT, T_SK_HIST2, T_SK_SCATTER2, T_SK_BUCKETS, T_N = 32
 };
 
 // grow-only device workspace slot (process-wide ones: g_shn_ws below; per-context ones: shn_ctx::cws)
@@ -38,6 +39,7 @@ struct shn_ctx {
   uint64_t regions[T_N];
   bool timing;
   bool owns_stream;        // shn_ctx_fork: the stream is destroyed with the context
+  double sk_pool_ratio;    // super-k-mer counting: (key, count) pairs per window the buckets emitted last time on this context (0: none yet)
   int count_direct_log2;   // one-pass counting: table size that sufficed last time (0 none yet, -1 gave up), shn_count_k1mers
   ShnWs cws[12];           // per-context workspaces of the calls several host threads make at the same time, each on its own
                            // context / stream (the graph threads' seed scans): [0] scan block sums, [1] [2] seed-scan counts / offsets,

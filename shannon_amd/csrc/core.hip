@@ -17,7 +17,8 @@ extern "C" const char* shn_version(void) { return "shannon_hip 0.1.0 (gfx950)"; 
 static const char* kTimerNames[T_N] = {
   "pack", "count.hist1", "count.scatter1", "count.hist2", "count.scatter2", "count.buckets", "count.compact",
   "count.total", "table.lookup", "extend", "route", "graph", "lp", "extend.prepare", "extend.sort", "extend.walk", "graph.seeds",
-  "extend.walk_thread", "extend.walk_wave", "extend.mark", "extend.emit", "table.build", "count.direct", "contig.stage", "graph.unitigs", "extend.adjacency"};
+  "extend.walk_thread", "extend.walk_wave", "extend.mark", "extend.emit", "table.build", "count.direct", "contig.stage", "graph.unitigs", "extend.adjacency",
+  "count.sk_hist", "count.sk_emit", "count.sk_hist2", "count.sk_scatter2", "count.sk_buckets"};
 extern "C" const char* shn_timer_name(int slot) {
   if (slot < 0 || slot >= T_N || !kTimerNames[slot]) return "";
   return kTimerNames[slot];
@@ -99,6 +100,7 @@ extern "C" int shn_ctx_create(int device, void* stream, shn_ctx** out) {
   c->stream = (hipStream_t)stream;
   c->timing = true;
   c->count_direct_log2 = 0;
+  c->sk_pool_ratio = 0;
   c->owns_stream = false;
   for (int i = 0; i < T_N; i++) { c->ms[i] = 0; c->regions[i] = 0; }
   const char* rule = getenv("SHN_LP_RULE");
@@ -128,7 +130,7 @@ extern "C" int shn_ctx_fork(const shn_ctx* parent, shn_ctx** out) {
   hipStream_t st = nullptr;
   HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   shn_ctx* c = new shn_ctx();
-  c->device = parent->device; c->stream = st; c->timing = false; c->count_direct_log2 = 0; c->owns_stream = true;
+  c->device = parent->device; c->stream = st; c->timing = false; c->count_direct_log2 = 0; c->sk_pool_ratio = 0; c->owns_stream = true;
   for (int i = 0; i < T_N; i++) { c->ms[i] = 0; c->regions[i] = 0; }
   c->lp_rule = parent->lp_rule;
   for (auto& v : c->lp_stats) v = 0;

@@ -24,10 +24,7 @@
 #define TILE_KEYS 32768     // keys per block tile in hist2/scatter2
 #define EMPTY_KEY 0xFFFFFFFFFFFFFFFFULL
 
-struct ReadsView {
-  const uint64_t* words; const uint64_t* mask; const uint64_t* woff; const uint32_t* len;
-  uint64_t n_reads; uint32_t fixed_len, wpr, wmax, rt; int has_n;
-};
+#include "count_views.h"
 
 #define bucket_of shn_bucket_of
 
@@ -586,6 +583,13 @@ extern "C" int shn_count_k1mers(shn_ctx* ctx, shn_reads* const* sets, int n_sets
   uint64_t chunk_windows = 1ULL << 31;
   if (getenv("SHN_COUNT_CHUNK")) chunk_windows = std::max<uint64_t>(1, strtoull(getenv("SHN_COUNT_CHUNK"), nullptr, 10));   // (tests)
   if (upper <= chunk_windows) return count_views(ctx, views, upper, k1, both_strands, out);
+  {
+    // inputs of this size go through the super-k-mer path in one piece (its records are a quarter of the windows' keys); what it
+    // does not take (k1 < 20, forward counting at k1 = 32) is counted in chunks below
+    int handled = 0;
+    int rc = shn_count_superkmers(ctx, views, upper, k1, both_strands, out, &handled);
+    if (rc || handled) return rc;
+  }
   std::vector<shn_table*> parts;
   auto drop = [&]() { for (shn_table* t : parts) shn_table_destroy(t); parts.clear(); };
   {
@@ -697,6 +701,11 @@ static int count_views(shn_ctx* ctx, const std::vector<ReadsView>& views, uint64
       *out = tb;
       return SHN_OK;
     }
+  }
+  {
+    int handled = 0;
+    int rc = shn_count_superkmers(ctx, views, upper, k1, both_strands, out, &handled);
+    if (rc || handled) return rc;
   }
   // bits_n: enough buckets if every window were a distinct key (the histogram pass runs at this resolution);
   // the final number of buckets follows the HyperLogLog estimate of the distinct keys and only grows on overflow

@@ -1,0 +1,478 @@
+// (K+1)-mer counting through super-k-mers (the path of large, diverse inputs; count.hip has the one-pass path in front of it and
+// the partition pipeline behind it).  Replaces `jellyfish count | dump` (shannon.py:439-441) like the rest of count.hip.
+//
+// The partition pipeline moves every window of every read through HBM as an 8-byte key, twice written and three times read:
+// ~3 KB per 100-base read where SURVEY 8d's model has 1.2 KB.  Here the windows travel as the reads' own 2-bit text: consecutive
+// windows of a read that share their minimizer (the m-mer of smallest hash inside the window, m = 13; canonical, so both strands
+// of a k1-mer pick the same one) are ONE 16-byte record -- up to 48 bases and the window count -- and all records of a minimizer
+// land in the same bucket.  A 100-base read makes ~11 records (176 bytes) instead of 75 keys (600 bytes), and its windows are
+// only expanded to keys inside the bucket kernel, in LDS:
+//   sk_scan<false>   packed reads -> minimizers -> records per level-1 bucket (histogram only)
+//   sk_scan<true>    the same pass, records staged in LDS and written to their level-1 partitions
+//   skr_hist/scatter level 2: records to their final buckets (2^bits of them, ~3,500 windows each)
+//   sk_buckets       one block per bucket: windows -> canonical keys -> LDS hash table -> (key, count) pairs; a table that fills
+//                    up (a deeply covered locus drags its sequencing errors along: thousands of distinct keys) is written out
+//                    and started again, so the pairs of a bucket may repeat a key
+//   pairs path       shn_table_from_pairs reduces the pairs by key into the table every consumer expects (hash buckets, sorted)
+// Every kernel is byte / integer work; nothing here is a contraction (no MFMA).
+#include "count_views.h"
+#include <algorithm>
+#include <cstring>
+#include <cstdlib>
+
+#define SK_BLK 256
+#define SK_RCAP 3072                                   // records staged in LDS per block of sk_scan<true>
+#define SK_CHECK 4                                     // the staging buffer is looked at every SK_CHECK bases
+#define SK_FLUSH_AT (SK_RCAP - (SK_CHECK + 1) * SK_BLK)   // a thread closes at most one record per base, and one at its read's end
+#define SK_TILE 32768                                  // records per block tile of the level-2 kernels
+#define SK_CAP 2048                                    // LDS hash slots of a bucket block (24 KB)
+#define SK_SPILL 1280                                  // distinct keys at which the table is written out (one more round adds <= 32 x 18)
+#define SK_EMPTY 0xFFFFFFFFFFFFFFFFULL
+#define SK_MIN_K 20
+
+struct SkParams { int k, m, w, bits, b1, b2; };
+
+struct __attribute__((aligned(16))) SkRec { uint64_t hi; uint32_t lo; uint32_t meta; };   // bases 0..31, bases 32..47, windows | bucket << 5
+
+// order of the m-mers: a bijection of their 2m <= 32 bits (murmur3's finaliser), so two different m-mers never tie
+__device__ __forceinline__ uint32_t sk_order(uint32_t x) {
+  x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+  return x;
+}
+// the bucket of a minimizer: a second mix of its order value (minimizers are the SMALL order values: their top bits are no use)
+__device__ __forceinline__ uint32_t sk_bucket(uint32_t ord, int bits) {
+  uint32_t x = ord * 0x9E3779B1u;
+  x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12; x *= 0x297a2d39u; x ^= x >> 15;
+  return bits ? x >> (32 - bits) : 0u;
+}
+
+// 96 bits of a read's 2-bit text from base p on (words beyond the read's own are taken as 0)
+__device__ __forceinline__ void sk_extract96(const uint64_t* __restrict__ w, uint32_t nw, uint32_t p, uint64_t& hi, uint32_t& lo) {
+  const uint32_t wi = p >> 5, sh = (p & 31) * 2;
+  const uint64_t a = w[wi], b = wi + 1 < nw ? w[wi + 1] : 0ULL, c = (sh && wi + 2 < nw) ? w[wi + 2] : 0ULL;
+  hi = sh ? (a << sh) | (b >> (64 - sh)) : a;
+  const uint64_t l = sh ? (b << sh) | (c >> (64 - sh)) : b;
+  lo = (uint32_t)(l >> 32);
+}
+// window j of a record: the 2k bits from base j on
+__device__ __forceinline__ uint64_t sk_window(uint64_t hi, uint32_t lo, int j, int k) {
+  const int sh = 2 * j;                                 // <= 34
+  const uint64_t v = sh ? (hi << sh) | (((uint64_t)lo << 32) >> (64 - sh)) : hi;
+  return v >> (64 - 2 * k);
+}
+
+// ---------------------------------------------------------------- reads -> records
+// One thread per read, one base per step: the m-mer ending at the base (forward and reverse complement rolled along) and its
+// order value.  The minimum over the last w order values without a data-dependent rescan (a wavefront whose 64 reads rescan at
+// different steps pays for a rescan at EVERY step): the m-mers are taken in blocks of w; `pref` is the running minimum of the
+// current block, suf[t] the minimum of positions t.. of the block before (made by one backward pass when a block ends -- the
+// same step in every lane); the window ending at position t of a block spans suf[t + 1] and pref.  A window is complete with its
+// last m-mer; a run of at most w windows with the same minimizer is a record (2 k1 - m <= 48 bases).  Windows holding a base
+// outside ACGT belong to no record (jellyfish / extension_correction count ACGT-only windows).  Read r writes its records to its
+// own S slots (cnt[r] of them used); a read with more goes on in the overflow list.
+template <bool CANON>
+__global__ __launch_bounds__(SK_BLK) void sk_scan_kernel(ReadsView v, SkParams P, uint32_t max_len, SkRec* __restrict__ slots, uint32_t S,
+                                                         uint8_t* __restrict__ cnt, SkRec* __restrict__ ovf, unsigned long long* __restrict__ ovf_cursor,
+                                                         uint64_t ovf_cap) {
+  extern __shared__ uint32_t sk_lds[];
+  uint32_t* raw = sk_lds;                                                // [w][SK_BLK] order values of the current block
+  uint32_t* suf = raw + P.w * SK_BLK;                                    // [w][SK_BLK] suffix minima of the block before
+  const int tid = threadIdx.x;
+  const int k = P.k, m = P.m, w = P.w;
+  const uint32_t mmask = m == 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+  const uint64_t n_tiles = (v.n_reads + SK_BLK - 1) / SK_BLK;
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint64_t r = tile * SK_BLK + tid;
+    if (r >= v.n_reads) continue;                                        // (no barrier in this kernel: the LDS columns are private)
+    const uint32_t len = v.len ? v.len[r] : v.fixed_len;
+    const uint64_t wb = v.woff ? v.woff[r] : r * v.wpr;
+    const uint32_t nw = v.woff ? (uint32_t)(v.woff[r + 1] - v.woff[r]) : v.wpr;
+    const uint64_t* rw = v.words + wb;
+    SkRec* mine = slots + r * S;
+    uint64_t cur = 0, curm = 0;
+    uint32_t f = 0, rr = 0, pref = 0xFFFFFFFFu, run_ord = 0, nrec = 0;
+    int lastN = -1, t = 0, p0 = 0;
+    bool open = false;
+
+    auto emit = [&](int a, int b, uint32_t ord) {                        // windows a..b of this read, minimizer order value ord
+      SkRec rec;
+      sk_extract96(rw, nw, (uint32_t)a, rec.hi, rec.lo);
+      rec.meta = (uint32_t)(b - a + 1) | (sk_bucket(ord, P.bits) << 5);
+      if (nrec < S) mine[nrec] = rec;
+      else {
+        const unsigned long long at = atomicAdd(ovf_cursor, 1ULL);
+        if (at < ovf_cap) ovf[at] = rec;
+      }
+      nrec++;
+    };
+
+    const uint32_t stop = len < max_len ? len : max_len;
+    for (uint32_t j = 0; j < stop; j++) {
+      if ((j & 31) == 0) cur = rw[j >> 5];
+      const uint32_t b = (uint32_t)(cur >> (62 - 2 * (j & 31))) & 3u;
+      if (v.has_n) {
+        if ((j & 63) == 0) curm = v.mask[wb / 2 + (j >> 6)];
+        if ((curm >> (63 - (j & 63))) & 1ULL) lastN = (int)j;
+      }
+      f = ((f << 2) | b) & mmask;
+      rr = (rr >> 2) | ((3u - b) << (2 * (m - 1)));
+      if ((int)j < m - 1) continue;
+      const int i = (int)j - m + 1;                                      // index of the m-mer that ends here; t = i mod w
+      const uint32_t ord = sk_order(CANON ? (f < rr ? f : rr) : f);
+      raw[t * SK_BLK + tid] = ord;
+      pref = t == 0 ? ord : (ord < pref ? ord : pref);
+      if (i >= w - 1) {
+        uint32_t wmin = pref;
+        if (t != w - 1) { const uint32_t sv = suf[(t + 1) * SK_BLK + tid]; wmin = sv < wmin ? sv : wmin; }
+        const int p = i - w + 1;                                         // the window that is complete now
+        const bool valid = lastN < p;
+        if (open && (!valid || wmin != run_ord || p - p0 >= w)) { emit(p0, p - 1, run_ord); open = false; }
+        if (valid && !open) { open = true; p0 = p; run_ord = wmin; }
+      }
+      if (t == w - 1) {                                                  // the block is complete: its suffix minima, for the next one
+        uint32_t sm = 0xFFFFFFFFu;
+        for (int tt = w - 1; tt >= 0; tt--) { const uint32_t x = raw[tt * SK_BLK + tid]; sm = x < sm ? x : sm; suf[tt * SK_BLK + tid] = sm; }
+        t = 0;
+      } else t++;
+    }
+    if (open) emit(p0, (int)len - k, run_ord);
+    cnt[r] = (uint8_t)(nrec < S ? nrec : S);
+  }
+}
+
+// ---------------------------------------------------------------- records to their buckets, one digit of the bucket id per pass
+// Segment p of the input (segoff[p] .. segoff[p + 1]) is partitioned by digit = (bucket >> shift) & (nb - 1).  cnt != NULL: the
+// input is the slot array of a read set -- item g is slot g % S of read g / S, used iff g % S < cnt[g / S]; cnt == NULL: a list of
+// records, every entry with windows counts.
+__device__ __forceinline__ bool skr_item(const SkRec* __restrict__ recs, const uint8_t* __restrict__ cnt, uint32_t S, uint64_t g, uint32_t& meta) {
+  if (cnt) { const uint64_t r = g / S; if ((uint32_t)(g - r * S) >= cnt[r]) return false; }
+  meta = recs[g].meta;
+  return cnt || meta != 0;                              // (a list: an entry without windows is an unused one)
+}
+__global__ __launch_bounds__(SK_BLK) void skr_hist_kernel(const SkRec* __restrict__ recs, const uint8_t* __restrict__ cnt, uint32_t S,
+                                                          const uint64_t* __restrict__ segoff, uint32_t n_seg, int shift, uint32_t nb,
+                                                          uint32_t* __restrict__ hist) {
+  extern __shared__ uint32_t skh[];
+  for (uint32_t p = blockIdx.y; p < n_seg; p += gridDim.y) {
+    const uint64_t s0 = segoff[p], s1 = segoff[p + 1];
+    const uint64_t t0 = s0 + (uint64_t)blockIdx.x * SK_TILE;
+    if (t0 >= s1) continue;
+    const uint64_t t1 = min(t0 + (uint64_t)SK_TILE, s1);
+    for (uint32_t i = threadIdx.x; i < nb; i += SK_BLK) skh[i] = 0;
+    __syncthreads();
+    for (uint64_t i = t0 + threadIdx.x; i < t1; i += SK_BLK) {
+      uint32_t meta;
+      if (skr_item(recs, cnt, S, i, meta)) atomicAdd(&skh[((meta >> 5) >> shift) & (nb - 1)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nb; i += SK_BLK) if (skh[i]) atomicAdd(&hist[(uint64_t)p * nb + i], skh[i]);
+    __syncthreads();
+  }
+}
+// exclusive scan of each row of hist (one block per row) -> off (relative to the segment start) and a cursor copy
+__global__ __launch_bounds__(SK_BLK) void skr_scan_rows_kernel(const uint32_t* __restrict__ hist, uint32_t nb2, uint32_t* __restrict__ off,
+                                                               uint32_t* __restrict__ cursor) {
+  __shared__ uint32_t part[SK_BLK];
+  const uint64_t row = (uint64_t)blockIdx.x * nb2;
+  const uint32_t per = (nb2 + SK_BLK - 1) / SK_BLK;
+  uint32_t s = 0;
+  for (uint32_t j = 0; j < per; j++) { const uint32_t i = threadIdx.x * per + j; if (i < nb2) s += hist[row + i]; }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { uint32_t a = 0; for (int i = 0; i < SK_BLK; i++) { const uint32_t t = part[i]; part[i] = a; a += t; } }
+  __syncthreads();
+  uint32_t a = part[threadIdx.x];
+  for (uint32_t j = 0; j < per; j++) {
+    const uint32_t i = threadIdx.x * per + j;
+    if (i < nb2) { off[row + i] = a; cursor[row + i] = a; a += hist[row + i]; }
+  }
+}
+// out_seg != NULL: the output of segment p starts at out_seg[p] (level 1: the slot arrays of several read sets into ONE record
+// array); else at the segment's own start
+__global__ __launch_bounds__(SK_BLK) void skr_scatter_kernel(const SkRec* __restrict__ recs, const uint8_t* __restrict__ cnt, uint32_t S,
+                                                             const uint64_t* __restrict__ segoff, uint32_t n_seg, int shift, uint32_t nb,
+                                                             uint32_t* __restrict__ cursor, const uint64_t* __restrict__ out_seg, SkRec* __restrict__ out) {
+  extern __shared__ uint32_t sks[];
+  uint32_t* lh = sks;
+  uint32_t* lbase = sks + nb;
+  for (uint32_t p = blockIdx.y; p < n_seg; p += gridDim.y) {
+    const uint64_t s0 = segoff[p], s1 = segoff[p + 1];
+    const uint64_t t0 = s0 + (uint64_t)blockIdx.x * SK_TILE;
+    if (t0 >= s1) continue;
+    const uint64_t t1 = min(t0 + (uint64_t)SK_TILE, s1);
+    const uint64_t o0 = out_seg ? out_seg[p] : s0;
+    for (uint32_t i = threadIdx.x; i < nb; i += SK_BLK) lh[i] = 0;
+    __syncthreads();
+    for (uint64_t i = t0 + threadIdx.x; i < t1; i += SK_BLK) {
+      uint32_t meta;
+      if (skr_item(recs, cnt, S, i, meta)) atomicAdd(&lh[((meta >> 5) >> shift) & (nb - 1)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nb; i += SK_BLK) {
+      const uint32_t c = lh[i];
+      if (c) lbase[i] = atomicAdd(&cursor[(uint64_t)p * nb + i], c);
+      lh[i] = 0;
+    }
+    __syncthreads();
+    for (uint64_t i = t0 + threadIdx.x; i < t1; i += SK_BLK) {
+      uint32_t meta;
+      if (!skr_item(recs, cnt, S, i, meta)) continue;
+      const SkRec rec = recs[i];
+      const uint32_t q = ((meta >> 5) >> shift) & (nb - 1);
+      const uint32_t rank = atomicAdd(&lh[q], 1u);
+      out[o0 + lbase[q] + rank] = rec;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------- final buckets: windows -> keys -> LDS hash table -> pairs
+// One block per bucket, eight lanes per record (lane q takes windows q, q + 8, ...).  Heavy keys would serialise on one LDS slot:
+// two rounds of wave-level leader election fold the lanes holding the wave's first two distinct keys into one atomic each (as
+// in buckets_kernel of count.hip).  The table is written to the pool -- a run reserved with one atomic -- at the end, and
+// whenever it holds SK_SPILL distinct keys.
+template <bool CANON>
+__global__ __launch_bounds__(SK_BLK) void sk_buckets_kernel(const SkRec* __restrict__ recs, const uint64_t* __restrict__ off1,
+                                                            const uint32_t* __restrict__ off2, const uint32_t* __restrict__ hist2, int b2, int k, int w,
+                                                            uint64_t* __restrict__ pool_keys, uint32_t* __restrict__ pool_counts,
+                                                            unsigned long long* __restrict__ pool_cursor, uint64_t pool_cap) {
+  __shared__ unsigned long long tk[SK_CAP];
+  __shared__ uint32_t tc[SK_CAP];
+  __shared__ uint32_t lnew, lpos;
+  __shared__ unsigned long long lbase;
+  const uint32_t b = blockIdx.x;
+  const uint32_t n = hist2[b];
+  if (n == 0) return;
+  const uint64_t s0 = off1[b >> b2] + off2[b];
+  const int tid = threadIdx.x, lane = tid & 63, q = tid & 7, grp = tid >> 3;
+  for (int i = tid; i < SK_CAP; i += SK_BLK) { tk[i] = SK_EMPTY; tc[i] = 0; }
+  if (tid == 0) { lnew = 0; lpos = 0; }
+  __syncthreads();
+  const int iters = (w + 7) >> 3;
+
+  auto spill = [&]() {                                                   // block-wide: table -> pool, table cleared
+    const uint32_t nd = lnew;
+    if (tid == 0) lbase = atomicAdd(pool_cursor, (unsigned long long)nd);
+    __syncthreads();
+    const unsigned long long base = lbase;
+    const bool fits = base + nd <= pool_cap;
+    for (int i = tid; i < SK_CAP; i += SK_BLK) {
+      const unsigned long long key = tk[i];
+      if (key != SK_EMPTY) {
+        if (fits) { const uint32_t pos = atomicAdd(&lpos, 1u); pool_keys[base + pos] = key; pool_counts[base + pos] = tc[i]; }
+        tk[i] = SK_EMPTY; tc[i] = 0;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) { lnew = 0; lpos = 0; }
+    __syncthreads();
+  };
+
+  for (uint32_t base = 0; base < n; base += SK_BLK / 8) {
+    __syncthreads();
+    const bool full = lnew > SK_SPILL;
+    __syncthreads();
+    if (full) spill();
+    const uint32_t ri = base + grp;
+    SkRec rec;
+    rec.hi = 0; rec.lo = 0; rec.meta = 0;
+    if (ri < n) rec = recs[s0 + ri];
+    const int nwin = (int)(rec.meta & 31u);
+    for (int it = 0; it < iters; it++) {
+      const int j = q + 8 * it;
+      bool active = j < nwin;
+      unsigned long long key = 0;
+      if (active) {
+        key = sk_window(rec.hi, rec.lo, j, k);
+        if (CANON) { const uint64_t rc = shn_revcomp(key, k); key = rc < key ? rc : key; }
+      }
+      uint32_t wgt = active ? 1u : 0u;
+      bool elect = active;
+#pragma unroll
+      for (int round = 0; round < 2; round++) {
+        const unsigned long long act = __ballot(elect);
+        if (!act) break;
+        const int leader = __ffsll((long long)act) - 1;
+        const unsigned long long lk = __shfl(key, leader, 64);
+        const bool same = elect && key == lk;
+        const unsigned long long msk = __ballot(same);
+        if (__popcll(msk) > 1) {
+          if (lane == leader) wgt = (uint32_t)__popcll(msk); else if (same) active = false;
+        }
+        if (same) elect = false;
+      }
+      if (!active) continue;
+      uint32_t slot = (uint32_t)(shn_mix64(key ^ 0x9E3779B97F4A7C15ULL)) & (SK_CAP - 1);
+      for (int probe = 0; probe < SK_CAP; probe++) {
+        const unsigned long long prev = atomicCAS(&tk[slot], SK_EMPTY, key);
+        if (prev == SK_EMPTY) { atomicAdd(&lnew, 1u); atomicAdd(&tc[slot], wgt); break; }
+        if (prev == key) { atomicAdd(&tc[slot], wgt); break; }
+        slot = (slot + 1) & (SK_CAP - 1);
+      }
+    }
+  }
+  __syncthreads();
+  if (lnew) spill();
+}
+
+// ================================================================ host side
+int shn_count_superkmers(shn_ctx* ctx, const std::vector<ReadsView>& views, uint64_t upper, int k1, int both_strands, shn_table** out, int* handled) {
+  *handled = 0;
+  const int mode = getenv("SHN_COUNT_SK") ? atoi(getenv("SHN_COUNT_SK")) : 1;          // 0 off, 1 large inputs, 2 always (tests)
+  if (mode == 0 || k1 < SK_MIN_K || (k1 == 32 && !both_strands) || upper == 0) return SHN_OK;
+  if (mode != 2 && upper < (1ULL << 22)) return SHN_OK;
+  hipStream_t s = ctx->stream;
+  SkParams P;
+  P.k = k1;
+  P.m = std::max(13, 2 * k1 - 48);
+  P.w = k1 - P.m + 1;
+  int bits = 6;
+  while (bits < 22 && (upper >> bits) > 3500) bits++;
+  if (getenv("SHN_COUNT_SK_BITS")) bits = std::max(4, std::min(22, atoi(getenv("SHN_COUNT_SK_BITS"))));      // (tests / experiments: any grid gives the same table)
+  P.bits = bits;
+  P.b1 = (bits + 1) / 2;
+  P.b2 = bits - P.b1;
+  const uint32_t nb1 = 1u << P.b1, nb2 = 1u << P.b2;
+  const uint64_t nbk = 1ULL << bits;
+  // the reads' slot arrays: S slots per read, a fifth more than the ~2 / (w + 1) records per window a read makes on average
+  struct ViewPlan { uint64_t slot0, read0; uint32_t S, max_len; };
+  std::vector<ViewPlan> plan(views.size());
+  uint64_t n_slots = 0, n_reads = 0;
+  for (size_t i = 0; i < views.size(); i++) {
+    const ReadsView& v = views[i];
+    const double expect = 2.0 * v.wmax / (P.w + 1) + 1.0;
+    uint32_t S = ((uint32_t)(expect * 1.35 + 1.999) + 3u) & ~3u;
+    S = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(S, 252), std::max<uint32_t>(v.wmax, 1)));
+    if (getenv("SHN_COUNT_SK_SLOTS")) S = (uint32_t)std::max(1, std::min(252, atoi(getenv("SHN_COUNT_SK_SLOTS"))));     // (tests: reads that overflow their slots)
+    plan[i] = ViewPlan{n_slots, n_reads, S, v.wmax ? v.wmax + (uint32_t)k1 - 1 : 0u};
+    if (v.wmax && v.n_reads) { n_slots += v.n_reads * S; n_reads += v.n_reads; }
+  }
+  const uint64_t ovf_cap = n_reads / 2 + 4096;
+  int rc;
+  void *p, *pslots, *pcnt;
+  // small arrays: level-1 histogram / offsets / cursors (u32), segment starts (u64), level-2 histogram / offsets / cursors, cursors of the
+  // overflow list and of the pool
+  const size_t small = (size_t)nb1 * 4 * 3 + 64 + ((size_t)nb1 + 4) * 8 + nbk * 4 * 3 + 64 + (views.size() + 2) * 16;
+  if ((rc = g_shn_ws[22].get(small, &p))) return rc;
+  if ((rc = g_shn_ws[18].get((n_slots + ovf_cap + 2) * sizeof(SkRec), &pslots))) return rc;
+  if ((rc = g_shn_ws[23].get(n_reads + 64, &pcnt))) return rc;
+  uint32_t* d_hist1 = (uint32_t*)p;
+  uint32_t* d_offr1 = d_hist1 + nb1;
+  uint32_t* d_cursor1 = d_offr1 + nb1;
+  unsigned long long* d_cursors = (unsigned long long*)(d_cursor1 + nb1 + ((nb1 & 1) ? 1 : 0));   // [0] overflow list, [1] pool, [4] = 0: where level 1's output starts
+  uint64_t* d_seg = (uint64_t*)(d_cursors + 8);                          // [nb1 + 1] starts of the level-1 partitions
+  uint32_t* d_hist2 = (uint32_t*)(d_seg + nb1 + 4);
+  uint32_t* d_off2 = d_hist2 + nbk;
+  uint32_t* d_cursor2 = d_off2 + nbk;
+  uint64_t* d_pairs = (uint64_t*)(d_cursor2 + nbk + (nbk & 1));          // {0, items} per level-1 launch
+  SkRec* slots = (SkRec*)pslots;
+  SkRec* ovf = slots + n_slots;
+  uint8_t* d_cnt = (uint8_t*)pcnt;
+  HIP_TRY(hipMemsetAsync(d_hist1, 0, (size_t)nb1 * 4, s));
+  HIP_TRY(hipMemsetAsync(d_cursors, 0, 64, s));
+  HIP_TRY(hipMemsetAsync(ovf, 0, ovf_cap * sizeof(SkRec), s));            // (an unused overflow entry has meta 0 = no windows)
+  const size_t lds_scan = (size_t)2 * P.w * SK_BLK * 4;
+  for (size_t i = 0; i < views.size(); i++) {
+    const ReadsView& v = views[i];
+    if (!v.wmax || !v.n_reads) continue;
+    TimerRegion t(ctx, T_SK_EMIT);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(cdiv(v.n_reads, SK_BLK), 1u << 20);
+    if (both_strands) hipLaunchKernelGGL(sk_scan_kernel<true>, dim3(grid), dim3(SK_BLK), lds_scan, s, v, P, plan[i].max_len, slots + plan[i].slot0, plan[i].S,
+                                         d_cnt + plan[i].read0, ovf, d_cursors, ovf_cap);
+    else hipLaunchKernelGGL(sk_scan_kernel<false>, dim3(grid), dim3(SK_BLK), lds_scan, s, v, P, plan[i].max_len, slots + plan[i].slot0, plan[i].S,
+                            d_cnt + plan[i].read0, ovf, d_cursors, ovf_cap);
+  }
+  // level 1: the slot arrays (one launch per read set) and the overflow list into the partitions of ONE record array
+  std::vector<uint64_t> pairs(2 * (views.size() + 1), 0);
+  for (size_t i = 0; i <= views.size(); i++) pairs[2 * i + 1] = i == views.size() ? ovf_cap : ((views[i].wmax && views[i].n_reads) ? views[i].n_reads * plan[i].S : 0);
+  HIP_TRY(hipMemcpyAsync(d_pairs, pairs.data(), pairs.size() * 8, hipMemcpyHostToDevice, s));
+  auto level1 = [&](bool scatter, SkRec* recsA) {
+    for (size_t i = 0; i <= views.size(); i++) {
+      const bool is_ovf = i == views.size();
+      const uint64_t n = pairs[2 * i + 1];
+      if (!n) continue;
+      const SkRec* in = is_ovf ? ovf : slots + plan[i].slot0;
+      const uint8_t* c = is_ovf ? nullptr : d_cnt + plan[i].read0;
+      const uint32_t S = is_ovf ? 1u : plan[i].S;
+      const uint32_t tiles = (uint32_t)std::max<uint64_t>(1, cdiv(n, SK_TILE));
+      if (!scatter) hipLaunchKernelGGL(skr_hist_kernel, dim3(tiles, 1), dim3(SK_BLK), nb1 * 4, s, in, c, S, d_pairs + 2 * i, 1u, P.b2, nb1, d_hist1);
+      else hipLaunchKernelGGL(skr_scatter_kernel, dim3(tiles, 1), dim3(SK_BLK), nb1 * 8, s, in, c, S, d_pairs + 2 * i, 1u, P.b2, nb1, d_cursor1,
+                              (const uint64_t*)(d_cursors + 4), recsA);
+    }
+  };
+  {
+    TimerRegion t(ctx, T_SK_HIST);
+    level1(false, nullptr);
+  }
+  std::vector<uint32_t> h1(nb1);
+  unsigned long long ovf_used = 0;
+  HIP_TRY(hipMemcpyAsync(h1.data(), d_hist1, (size_t)nb1 * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(&ovf_used, d_cursors, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipGetLastError());
+  if (ovf_used > ovf_cap) return SHN_OK;                                 // (reads that make far more records than their windows let expect: the partition pipeline takes them)
+  std::vector<uint64_t> off1(nb1 + 1);
+  std::vector<uint32_t> off1r(nb1);
+  uint64_t NR = 0, max1 = 0;
+  for (uint32_t i = 0; i < nb1; i++) { off1[i] = NR; NR += h1[i]; max1 = std::max<uint64_t>(max1, h1[i]); }
+  off1[nb1] = NR;
+  if (NR >= 0xFFFFFFFFULL) return SHN_OK;                                // (2^32 records: leave it to the chunked pipeline)
+  for (uint32_t i = 0; i < nb1; i++) off1r[i] = (uint32_t)off1[i];
+  void* pa;
+  if ((rc = g_shn_ws[19].get((NR + 2) * sizeof(SkRec), &pa))) return rc;
+  SkRec* recsA = (SkRec*)pa;
+  SkRec* recsB = slots;                                                  // (level 2 writes where the slots were: n_slots + overflow >= NR)
+  HIP_TRY(hipMemcpyAsync(d_cursor1, off1r.data(), (size_t)nb1 * 4, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_seg, off1.data(), (size_t)(nb1 + 1) * 8, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(d_hist2, 0, nbk * 4, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  {
+    TimerRegion t(ctx, T_SK_HIST);
+    level1(true, recsA);
+  }
+  const uint32_t tiles = (uint32_t)std::max<uint64_t>(1, cdiv(max1, SK_TILE));
+  {
+    TimerRegion t(ctx, T_SK_HIST2);
+    hipLaunchKernelGGL(skr_hist_kernel, dim3(tiles, nb1), dim3(SK_BLK), nb2 * 4, s, recsA, (const uint8_t*)nullptr, 1u, d_seg, nb1, 0, nb2, d_hist2);
+  }
+  hipLaunchKernelGGL(skr_scan_rows_kernel, dim3(nb1), dim3(SK_BLK), 0, s, d_hist2, nb2, d_off2, d_cursor2);
+  {
+    TimerRegion t(ctx, T_SK_SCATTER2);
+    hipLaunchKernelGGL(skr_scatter_kernel, dim3(tiles, nb1), dim3(SK_BLK), nb2 * 8, s, recsA, (const uint8_t*)nullptr, 1u, d_seg, nb1, 0, nb2, d_cursor2,
+                       (const uint64_t*)nullptr, recsB);
+  }
+  // the pool of (key, count) pairs: sized from what the buckets emitted per window last time on this context (an eighth of the
+  // windows to begin with); a pool that turns out too small is made as large as the cursor says and the bucket kernel runs again
+  double ratio = ctx->sk_pool_ratio > 0 ? ctx->sk_pool_ratio * 1.05 : 0.125;
+  if (getenv("SHN_COUNT_SK_POOL")) ratio = atof(getenv("SHN_COUNT_SK_POOL"));                                  // (tests: start too small)
+  uint64_t cap = std::min<uint64_t>(upper, (uint64_t)((double)upper * ratio) + 4096);
+  uint64_t np = 0;
+  void *pk = nullptr, *pc = nullptr;
+  for (int attempt = 0; attempt < 3; attempt++) {
+    if ((rc = g_shn_ws[20].get((cap + 2) * 8, &pk))) return rc;
+    if ((rc = g_shn_ws[21].get((cap + 2) * 4, &pc))) return rc;
+    HIP_TRY(hipMemsetAsync(d_cursors + 1, 0, 8, s));
+    {
+      TimerRegion t(ctx, T_SK_BUCKETS);
+      if (both_strands) hipLaunchKernelGGL(sk_buckets_kernel<true>, dim3((uint32_t)nbk), dim3(SK_BLK), 0, s, recsB, d_seg, d_off2, d_hist2, P.b2, k1, P.w,
+                                           (uint64_t*)pk, (uint32_t*)pc, d_cursors + 1, cap);
+      else hipLaunchKernelGGL(sk_buckets_kernel<false>, dim3((uint32_t)nbk), dim3(SK_BLK), 0, s, recsB, d_seg, d_off2, d_hist2, P.b2, k1, P.w,
+                              (uint64_t*)pk, (uint32_t*)pc, d_cursors + 1, cap);
+    }
+    unsigned long long used = 0;
+    HIP_TRY(hipMemcpyAsync(&used, d_cursors + 1, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipGetLastError());
+    np = used;
+    if (np <= cap) break;
+    if (attempt == 2) return shn_fail(SHN_ERR_OVERFLOW, "shn_count_k1mers: the pair pool of the super-k-mer path stayed too small");
+    cap = std::min<uint64_t>(upper, np + np / 64 + 4096);
+  }
+  if (!getenv("SHN_COUNT_SK_POOL")) ctx->sk_pool_ratio = (double)np / (double)upper;
+  if (np >= 0xFFFFFFFFULL) return SHN_OK;                                // (more pairs than the pairs path takes: the chunked pipeline)
+  rc = shn_table_from_pairs(ctx, pk, pc, np, k1, both_strands ? 1 : 0, out);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(s));
+  *handled = 1;
+  return SHN_OK;
+}

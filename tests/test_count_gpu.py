@@ -171,3 +171,85 @@ def test_chunked_counting_equals_one_pass_over_all_reads(chunk, ragged, monkeypa
             d.close()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("K1,both,ragged,with_n,bits,pool,slots", [(26, True, False, False, None, None, None), (26, True, True, True, 6, None, None),
+                                                                    (26, False, False, True, None, "0.0001", None), (20, True, False, False, 9, None, None),
+                                                                    (31, True, True, True, None, None, None), (32, True, False, True, 5, None, None),
+                                                                    (31, False, False, False, 12, "0.01", None), (23, False, True, True, 4, None, None),
+                                                                    (26, True, False, True, 7, None, 11), (26, True, True, False, None, None, 12)])
+def test_superkmer_counting_equals_the_partition_pipeline(K1, both, ragged, with_n, bits, pool, slots, monkeypatch):
+    """Large diverse inputs are counted through super-k-mers (csrc/count_sk.hip: minimizer runs of a read's windows travel as 16-byte
+    records, windows are expanded to keys in the bucket kernel's LDS, the buckets' pairs are reduced by the pairs path); forced
+    here on small inputs -- fixed-length and ragged reads (some shorter than k1, some exactly k1), N bases, poly-A / poly-T reads,
+    heavy duplicates, canonical and forward counting, k1 = 20 .. 32, several bucket grids, a pair pool that starts too small, reads
+    with more records than slots (the overflow list): the same table as the partition pipeline, and as the oracle."""
+    from shannon_amd import device
+    from oracle import count
+    rng = np.random.default_rng(K1 * 7 + (3 if both else 0))
+    base = rng.integers(0, 4, 4000, dtype=np.uint8)
+    starts = rng.integers(0, len(base) - 100, 30000)
+    reads = base[starts[:, None] + np.arange(100)]
+    err = rng.random(reads.shape) < 0.01
+    reads = np.where(err, (reads + rng.integers(1, 4, reads.shape)) & 3, reads).astype(np.uint8)
+    reads[:40] = 3
+    reads[40:70] = 0
+    reads[70:400] = reads[70]                             # one read 330 times
+    if with_n:
+        reads[rng.random(reads.shape) < 0.002] = 4
+    ctx = device.Context(0)
+    try:
+        if ragged:
+            A = np.frombuffer(b"ACGTN", np.uint8)
+            lens = [K1 - 1, K1, K1 + 1, 100, 47] + [int(x) for x in rng.integers(K1 - 3, 101, len(reads) - 5)]
+            strings = [A[r[:n]].tobytes().decode() for r, n in zip(reads, lens)]
+            d = device.Reads.from_strings(ctx, strings)
+            recs = strings
+        else:
+            d = device.Reads.from_codes(ctx, reads)
+            recs = None
+        monkeypatch.setenv("SHN_COUNT_DIRECT", "0")
+        monkeypatch.setenv("SHN_COUNT_SK", "0")
+        t0 = device.count_k1mers(ctx, [d], K1, both)
+        k0, c0 = t0.download()
+        monkeypatch.setenv("SHN_COUNT_SK", "2")
+        if bits is not None:
+            monkeypatch.setenv("SHN_COUNT_SK_BITS", str(bits))
+        if pool is not None:
+            monkeypatch.setenv("SHN_COUNT_SK_POOL", pool)
+        if slots is not None:
+            monkeypatch.setenv("SHN_COUNT_SK_SLOTS", str(slots))
+        t1 = device.count_k1mers(ctx, [d], K1, both)
+        assert "count.sk_buckets" in ctx.timers()
+        k1, c1 = t1.download()
+        o0, o1 = np.argsort(k0), np.argsort(k1)
+        assert np.array_equal(k0[o0], k1[o1]) and np.array_equal(c0[o0], c1[o1]) and t0.total == t1.total and len(k1) > 1000
+        if not ragged:
+            codes = np.where(reads == 4, 255, reads).astype(np.uint8)
+            if both:
+                rc = np.where(codes[:, ::-1] == 255, 255, 3 - codes[:, ::-1]).astype(np.uint8)
+                ok, oc = count.count_k1mers_matrix(np.concatenate([codes, rc]), K1)
+                keys, cnts = t1.dump(lower=1)
+            else:
+                ok, oc = count.count_k1mers_matrix(codes, K1)
+                keys, cnts = t1.dump(lower=1)
+            assert np.array_equal(ok, keys) and np.array_equal(oc.astype(np.uint64), cnts.astype(np.uint64))
+        t0.close(); t1.close(); d.close()
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("name", ["se_K24", "pe_K25", "syn_pe_s20_K31", "syn_pe_ss_s69"])
+def test_superkmer_counting_matches_golden(ctx, name, monkeypatch):
+    """the reference's own k1-mer tables (golden fixtures) through the super-k-mer path"""
+    from shannon_amd import device
+    monkeypatch.setenv("SHN_COUNT_DIRECT", "0")
+    monkeypatch.setenv("SHN_COUNT_SK", "2")
+    g = load_case(name)
+    inp = load_inputs(name)
+    sets = [device.Reads.from_strings(ctx, r) for r in inp]
+    t = count_case(ctx, name, sets)
+    keys, cnts = t.dump(lower=1)
+    assert len(keys) == g["n_k1mers"] and int(cnts.astype(np.uint64).sum()) == g["k1mer_total"]
+    rows = [[device.key_to_str(k, g["K"] + 1), int(c)] for k, c in zip(keys, cnts)]
+    assert digest(rows) == g["k1mer_counts_digest"]
