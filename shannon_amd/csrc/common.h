@@ -21,7 +21,7 @@ int shn_fail(int code, const std::string& msg);
 enum {
   T_PACK = 0, T_HIST1, T_SCATTER1, T_HIST2, T_SCATTER2, T_COUNT, T_COMPACT, T_COUNT_TOTAL, T_LOOKUP,
   T_EXTEND, T_ROUTE, T_GRAPH, T_LP, T_EXT_PREP, T_EXT_SORT, T_EXT_WALK, T_SEEDS, T_EXT_WALK_THREAD, T_EXT_WALK_WAVE, T_EXT_MARK, T_EXT_EMIT, T_TABLE_BUILD, T_COUNT_DIRECT, T_CONTIG, T_GRAPH_GPU, T_EXT_ADJ,
-  T_SK_HIST, T_SK_EMIT, T_SK_HIST2, T_SK_SCATTER2, T_SK_BUCKETS, T_N = 32
+  T_SK_HIST, T_SK_EMIT, T_SK_HIST2, T_SK_SCATTER2, T_SK_BUCKETS, T_SK_BIG, T_N = 32
 };
 
 // grow-only device workspace slot (process-wide ones: g_shn_ws below; per-context ones: shn_ctx::cws)
@@ -94,6 +94,10 @@ struct shn_table {
   uint64_t* d_keys;        // [n] grouped by bucket, ascending inside a bucket
   uint32_t* d_counts;      // [n]
   uint64_t* d_bucket_off;  // [n_buckets+1]
+  int layout;              // 0: buckets = top `bits` bits of fmix64(key) (every table made from pairs); 1: buckets = shn_minimizer_bucket
+                           // (the tables of the super-k-mer counting path, count_sk.hip): k1-mers that overlap by k1 - 1 bases mostly share
+                           // their minimizer, so a k1-mer and its 8 neighbours mostly lie in ONE bucket
+  int sk_m;                // layout 1: length of the minimizer
 };
 
 // ---------------------------------------------------------------- device helpers
@@ -137,6 +141,51 @@ __device__ __forceinline__ uint32_t shn_bucket_of(uint64_t key, int bits) {
   return bits ? (uint32_t)(shn_mix64(key) >> (64 - bits)) : 0u;
 }
 
+// ---- minimizers (count_sk.hip makes the tables of layout 1 with them; their consumers find a key's bucket with them)
+// order of the m-mers: a bijection of their 2m <= 32 bits (murmur3's finaliser), so two different m-mers never tie
+__host__ __device__ __forceinline__ uint32_t shn_sk_order(uint32_t x) {
+  x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+  return x;
+}
+// the bucket of a minimizer: a second mix of its order value (minimizers are the SMALL order values: their top bits are no use)
+__host__ __device__ __forceinline__ uint32_t shn_sk_bucket(uint32_t ord, int bits) {
+  uint32_t x = ord * 0x9E3779B1u;
+  x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12; x *= 0x297a2d39u; x ^= x >> 15;
+  return bits ? x >> (32 - bits) : 0u;
+}
+__device__ __forceinline__ uint32_t shn_revcomp32(uint32_t v, int m) {
+  uint32_t x = __brev(~v);
+  x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+  return x >> (32 - 2 * m);
+}
+// smallest order value among the k - m + 1 m-mers of a k-mer (canon: of their canonical forms -- the same for both strands)
+__device__ __forceinline__ uint32_t shn_minimizer_order(uint64_t key, int k, int m, int canon) {
+  const uint32_t mmask = m == 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+  uint32_t best = 0xFFFFFFFFu;
+  for (int i = 0; i <= k - m; i++) {
+    const uint32_t f = (uint32_t)(key >> (2 * (k - m - i))) & mmask;
+    uint32_t c = f;
+    if (canon) { const uint32_t r = shn_revcomp32(f, m); c = r < f ? r : f; }
+    const uint32_t o = shn_sk_order(c);
+    best = o < best ? o : best;
+  }
+  return best;
+}
+__device__ __forceinline__ uint32_t shn_minimizer_bucket(uint64_t key, int k, int m, int canon, int bits) {
+  return shn_sk_bucket(shn_minimizer_order(key, k, m, canon), bits);
+}
+
+// A table as its consumers see it: keys grouped by bucket, ascending inside a bucket; the bucket of a key by the table's layout.
+struct TabIdx {
+  const uint64_t* keys; const uint64_t* boff; int bits, layout, k, m, canon;
+};
+static inline TabIdx shn_tab_idx(const shn_table* t) {
+  TabIdx T; T.keys = t->d_keys; T.boff = t->d_bucket_off; T.bits = t->bits; T.layout = t->layout; T.k = t->k; T.m = t->sk_m; T.canon = t->canonical;
+  return T;
+}
+__device__ __forceinline__ uint32_t shn_tab_bucket(const TabIdx& T, uint64_t key);
+__device__ __forceinline__ int64_t shn_tab_find(const TabIdx& T, uint64_t key);
+
 // index of `key` in a table (grouped by bucket, ascending inside a bucket) or -1
 __device__ __forceinline__ int64_t shn_table_find(const uint64_t* __restrict__ tkeys, const uint64_t* __restrict__ boff,
                                                   int bits, uint64_t key) {
@@ -145,6 +194,21 @@ __device__ __forceinline__ int64_t shn_table_find(const uint64_t* __restrict__ t
   while (lo < hi) {
     uint64_t mid = (lo + hi) >> 1;
     uint64_t v = tkeys[mid];
+    if (v == key) return (int64_t)mid;
+    if (v < key) lo = mid + 1; else hi = mid;
+  }
+  return -1;
+}
+
+__device__ __forceinline__ uint32_t shn_tab_bucket(const TabIdx& T, uint64_t key) {
+  return T.layout ? shn_minimizer_bucket(key, T.k, T.m, T.canon, T.bits) : shn_bucket_of(key, T.bits);
+}
+__device__ __forceinline__ int64_t shn_tab_find(const TabIdx& T, uint64_t key) {
+  const uint32_t b = shn_tab_bucket(T, key);
+  uint64_t lo = T.boff[b], hi = T.boff[b + 1];
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    const uint64_t v = T.keys[mid];
     if (v == key) return (int64_t)mid;
     if (v < key) lo = mid + 1; else hi = mid;
   }

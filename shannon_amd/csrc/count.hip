@@ -382,22 +382,12 @@ __global__ __launch_bounds__(BLK) void compact_kernel(const uint64_t* __restrict
 }
 
 // ---------------------------------------------------------------- lookup
-__global__ void lookup_kernel(const uint64_t* __restrict__ tkeys, const uint32_t* __restrict__ tcounts,
-                              const uint64_t* __restrict__ boff, int bits, const uint64_t* __restrict__ q, uint64_t n,
+__global__ void lookup_kernel(TabIdx T, const uint32_t* __restrict__ tcounts, const uint64_t* __restrict__ q, uint64_t n,
                               uint32_t* __restrict__ out) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  uint64_t key = q[i];
-  uint32_t b = bucket_of(key, bits);
-  uint64_t lo = boff[b], hi = boff[b + 1];
-  uint32_t res = 0;
-  while (lo < hi) {
-    uint64_t mid = (lo + hi) >> 1;
-    uint64_t v = tkeys[mid];
-    if (v == key) { res = tcounts[mid]; break; }
-    if (v < key) lo = mid + 1; else hi = mid;
-  }
-  out[i] = res;
+  const int64_t j = shn_tab_find(T, q[i]);
+  out[i] = j >= 0 ? tcounts[j] : 0u;
 }
 
 // ---------------------------------------------------------------- one-pass counting into a global hash table
@@ -984,7 +974,7 @@ extern "C" int shn_table_lookup(shn_ctx* ctx, const shn_table* t, const uint64_t
   HIP_TRY(hipMemcpyAsync(dq, keys, n * 8, hipMemcpyHostToDevice, s));
   {
     TimerRegion tr(ctx, T_LOOKUP);
-    hipLaunchKernelGGL(lookup_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, t->d_counts, t->d_bucket_off, t->bits, dq, n, dc);
+    hipLaunchKernelGGL(lookup_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, shn_tab_idx(t), t->d_counts, dq, n, dc);
   }
   HIP_TRY(hipMemcpyAsync(counts, dc, n * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));

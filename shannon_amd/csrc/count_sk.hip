@@ -28,23 +28,15 @@
 #define SK_CAP 2048                                    // LDS hash slots of a bucket block (24 KB)
 #define SK_SPILL 1280                                  // distinct keys at which the table is written out (one more round adds <= 32 x 18)
 #define SK_EMPTY 0xFFFFFFFFFFFFFFFFULL
+#define SK_RANK_MAX 512                                // buckets of at most this many distinct keys are ordered by counting, larger ones by a bitonic sort
 #define SK_MIN_K 20
 
 struct SkParams { int k, m, w, bits, b1, b2; };
 
 struct __attribute__((aligned(16))) SkRec { uint64_t hi; uint32_t lo; uint32_t meta; };   // bases 0..31, bases 32..47, windows | bucket << 5
 
-// order of the m-mers: a bijection of their 2m <= 32 bits (murmur3's finaliser), so two different m-mers never tie
-__device__ __forceinline__ uint32_t sk_order(uint32_t x) {
-  x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
-  return x;
-}
-// the bucket of a minimizer: a second mix of its order value (minimizers are the SMALL order values: their top bits are no use)
-__device__ __forceinline__ uint32_t sk_bucket(uint32_t ord, int bits) {
-  uint32_t x = ord * 0x9E3779B1u;
-  x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12; x *= 0x297a2d39u; x ^= x >> 15;
-  return bits ? x >> (32 - bits) : 0u;
-}
+#define sk_order shn_sk_order
+#define sk_bucket shn_sk_bucket
 
 // 96 bits of a read's 2-bit text from base p on (words beyond the read's own are taken as 0)
 __device__ __forceinline__ void sk_extract96(const uint64_t* __restrict__ w, uint32_t nw, uint32_t p, uint64_t& hi, uint32_t& lo) {
@@ -315,6 +307,191 @@ __global__ __launch_bounds__(SK_BLK) void sk_buckets_kernel(const SkRec* __restr
   if (lnew) spill();
 }
 
+// ---------------------------------------------------------------- final buckets, sorted: the table itself (layout 1)
+// The same insertion, but the bucket's distinct keys leave the block SORTED, as a run of the table: buckets of minimizers ARE the
+// buckets of the table (shn_table::layout 1), nothing is re-partitioned by key afterwards.  The table of a block holds CAP slots;
+// a bucket with more distinct keys than that (a deeply covered locus drags its sequencing errors along: ~1.4 distinct k1-mers per
+// read that covers it) is put on a list and done again by a block with a table of 8,192 slots, and what does not fit there is
+// counted in passes over ranges of the key (the top 2, 4, ... bits): a pass holds complete counts of its range, and the passes'
+// sorted runs follow each other in key order.  The runs are reserved in a pool with one atomic per bucket and copied into bucket
+// order afterwards (sk_gather_kernel).
+template <bool CANON, int THREADS, int CAP>
+__global__ __launch_bounds__(THREADS) void sk_buckets_sorted_kernel(const SkRec* __restrict__ recs, const uint64_t* __restrict__ off1,
+                                                                    const uint32_t* __restrict__ off2, const uint32_t* __restrict__ hist2, int b2, int k, int w,
+                                                                    const uint32_t* __restrict__ list, uint32_t* __restrict__ defer,
+                                                                    uint64_t* __restrict__ pool_keys, uint32_t* __restrict__ pool_counts,
+                                                                    unsigned long long* __restrict__ cursors, uint64_t pool_cap,
+                                                                    uint64_t* __restrict__ run_off, uint32_t* __restrict__ ndist) {
+  extern __shared__ unsigned long long skb_lds[];
+  unsigned long long* tk = skb_lds;                                      // [CAP]
+  uint32_t* tc = (uint32_t*)(tk + CAP);                                  // [CAP]
+  uint16_t* idx = (uint16_t*)(tc + CAP);                                 // [CAP]
+  __shared__ uint32_t lnew, lover, lpos;
+  __shared__ unsigned long long lbase;
+  const uint32_t b = list ? list[blockIdx.x] : blockIdx.x;
+  const uint32_t n = hist2[b];
+  const int tid = threadIdx.x, lane = tid & 63, q = tid & 7, grp = tid >> 3;
+  if (n == 0) { if (tid == 0) { ndist[b] = 0; run_off[b] = 0; } return; }
+  const uint64_t s0 = off1[b >> b2] + off2[b];
+  const int iters = (w + 7) >> 3;
+  const uint32_t limit = (uint32_t)(CAP - (THREADS / 8) * w - 64);       // distinct keys a pass may reach before its last round
+
+  // one pass over the bucket's records: the keys whose top `sbits` bits are `cls` into the (cleared) table; lover: it got too full
+  auto pass = [&](uint32_t cls, int sbits) {
+    for (int i = tid; i < CAP; i += THREADS) { tk[i] = SK_EMPTY; tc[i] = 0; }
+    if (tid == 0) { lnew = 0; lover = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += THREADS / 8) {
+      __syncthreads();
+      const bool full = lnew > limit;
+      __syncthreads();
+      if (full) { if (tid == 0) lover = 1; break; }
+      const uint32_t ri = base + grp;
+      SkRec rec;
+      rec.hi = 0; rec.lo = 0; rec.meta = 0;
+      if (ri < n) rec = recs[s0 + ri];
+      const int nwin = (int)(rec.meta & 31u);
+      for (int it = 0; it < iters; it++) {
+        const int j = q + 8 * it;
+        bool active = j < nwin;
+        unsigned long long key = 0;
+        if (active) {
+          key = sk_window(rec.hi, rec.lo, j, k);
+          if (CANON) { const uint64_t rc = shn_revcomp(key, k); key = rc < key ? rc : key; }
+          if (sbits && (uint32_t)(key >> (2 * k - sbits)) != cls) active = false;
+        }
+        uint32_t wgt = active ? 1u : 0u;
+        bool elect = active;
+#pragma unroll
+        for (int round = 0; round < 2; round++) {
+          const unsigned long long act = __ballot(elect);
+          if (!act) break;
+          const int leader = __ffsll((long long)act) - 1;
+          const unsigned long long lk = __shfl(key, leader, 64);
+          const bool same = elect && key == lk;
+          const unsigned long long msk = __ballot(same);
+          if (__popcll(msk) > 1) {
+            if (lane == leader) wgt = (uint32_t)__popcll(msk); else if (same) active = false;
+          }
+          if (same) elect = false;
+        }
+        if (!active) continue;
+        uint32_t slot = (uint32_t)(shn_mix64(key ^ 0x9E3779B97F4A7C15ULL)) & (CAP - 1);
+        for (int probe = 0; probe < CAP; probe++) {
+          const unsigned long long prev = atomicCAS(&tk[slot], SK_EMPTY, key);
+          if (prev == SK_EMPTY) { atomicAdd(&lnew, 1u); atomicAdd(&tc[slot], wgt); break; }
+          if (prev == key) { atomicAdd(&tc[slot], wgt); break; }
+          slot = (slot + 1) & (CAP - 1);
+        }
+      }
+    }
+    __syncthreads();
+  };
+  // the table's keys, sorted, to pool[at ..)
+  auto output = [&](uint64_t at) {
+    const uint32_t nd = lnew;
+    if (tid == 0) lpos = 0;
+    __syncthreads();
+    if (nd <= SK_RANK_MAX) {
+      // few keys (the usual bucket holds ~170): every key counts the keys below it -- nd broadcast reads, no barrier -- and goes
+      // straight to its place in the run; a bitonic sort of 256 keys is 36 barriers
+      unsigned long long* dk = (unsigned long long*)idx;
+      uint32_t* dc = (uint32_t*)(dk + SK_RANK_MAX);
+      for (int i = tid; i < CAP; i += THREADS) {
+        const unsigned long long key = tk[i];
+        if (key != SK_EMPTY) { const uint32_t e = atomicAdd(&lpos, 1u); dk[e] = key; dc[e] = tc[i]; }
+      }
+      __syncthreads();
+      for (uint32_t e = tid; e < nd; e += THREADS) {
+        const unsigned long long key = dk[e];
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < nd; j++) r += dk[j] < key ? 1u : 0u;
+        pool_keys[at + r] = key; pool_counts[at + r] = dc[e];
+      }
+      __syncthreads();
+      return;
+    }
+    for (int i = tid; i < CAP; i += THREADS) if (tk[i] != SK_EMPTY) idx[atomicAdd(&lpos, 1u)] = (uint16_t)i;
+    uint32_t m2 = 1;
+    while (m2 < nd) m2 <<= 1;
+    __syncthreads();
+    for (uint32_t i = nd + tid; i < m2; i += THREADS) idx[i] = 0xFFFFu;              // (beyond CAP: sorts last)
+    __syncthreads();
+    for (uint32_t kk = 2; kk <= m2; kk <<= 1) {
+      for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+        for (uint32_t i = tid; i < m2; i += THREADS) {
+          const uint32_t x = i ^ j;
+          if (x > i) {
+            const uint16_t ia = idx[i], ib = idx[x];
+            const unsigned long long ka = ia == 0xFFFFu ? SK_EMPTY : tk[ia], kb = ib == 0xFFFFu ? SK_EMPTY : tk[ib];
+            const bool asc = (i & kk) == 0;
+            if ((ka > kb) == asc) { idx[i] = ib; idx[x] = ia; }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (uint32_t i = tid; i < nd; i += THREADS) { const uint16_t ii = idx[i]; pool_keys[at + i] = tk[ii]; pool_counts[at + i] = tc[ii]; }
+    __syncthreads();
+  };
+
+  int sbits = 0;
+  uint32_t total = 0;
+  for (;;) {                                                             // the number of range passes in which everything fits, and the distinct keys
+    total = 0;
+    bool ok = true;
+    for (uint32_t cls = 0; cls < (1u << sbits); cls++) {
+      pass(cls, sbits);
+      if (lover) { ok = false; break; }
+      total += lnew;
+      if (sbits == 0) break;
+      __syncthreads();
+    }
+    if (ok) break;
+    if (defer) {                                                         // a block with a larger table does this bucket
+      if (tid == 0) { const unsigned long long at = atomicAdd(&cursors[2], 1ULL); defer[at] = b; ndist[b] = 0; run_off[b] = 0; }
+      return;
+    }
+    sbits += 2;
+    if (sbits > 16 || sbits > 2 * k) {                                   // (65,536 ranges and still too many keys in one: give up, the caller falls back)
+      if (tid == 0) { atomicAdd(&cursors[3], 1ULL); ndist[b] = 0; run_off[b] = 0; }
+      return;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) lbase = atomicAdd(&cursors[1], (unsigned long long)total);
+  __syncthreads();
+  const unsigned long long base = lbase;
+  if (base + total > pool_cap) { if (tid == 0) { ndist[b] = 0; run_off[b] = 0; } return; }      // (the host sees the cursor and runs again with a larger pool)
+  if (tid == 0) { ndist[b] = total; run_off[b] = base; }
+  if (sbits == 0) { output(base); return; }
+  uint64_t at = base;
+  for (uint32_t cls = 0; cls < (1u << sbits); cls++) {
+    pass(cls, sbits);
+    const uint32_t nd = lnew;
+    output(at);
+    at += nd;
+  }
+}
+// the buckets' runs from the pool into bucket order: one wavefront per bucket
+__global__ __launch_bounds__(SK_BLK) void sk_gather_kernel(const uint64_t* __restrict__ pool_keys, const uint32_t* __restrict__ pool_counts,
+                                                           const uint64_t* __restrict__ run_off, const uint32_t* __restrict__ ndist,
+                                                           const uint64_t* __restrict__ boff, uint64_t n_buckets, uint64_t* __restrict__ keys,
+                                                           uint32_t* __restrict__ counts) {
+  const uint64_t b = ((uint64_t)blockIdx.x * SK_BLK + threadIdx.x) / SHN_WAVE;
+  if (b >= n_buckets) return;
+  const uint32_t lane = threadIdx.x & (SHN_WAVE - 1);
+  const uint32_t nd = ndist[b];
+  const uint64_t s0 = run_off[b], d0 = boff[b];
+  for (uint32_t i = lane; i < nd; i += SHN_WAVE) { keys[d0 + i] = pool_keys[s0 + i]; counts[d0 + i] = pool_counts[s0 + i]; }
+}
+__global__ void sk_sum_counts_kernel(const uint32_t* __restrict__ c, uint64_t n, unsigned long long* __restrict__ out) {
+  unsigned long long a = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) a += c[i];
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+  if ((threadIdx.x & 63) == 0 && a) atomicAdd(out, a);
+}
+
 // ================================================================ host side
 int shn_count_superkmers(shn_ctx* ctx, const std::vector<ReadsView>& views, uint64_t upper, int k1, int both_strands, shn_table** out, int* handled) {
   *handled = 0;
@@ -442,12 +619,86 @@ int shn_count_superkmers(shn_ctx* ctx, const std::vector<ReadsView>& views, uint
                        (const uint64_t*)nullptr, recsB);
   }
   // the pool of (key, count) pairs: sized from what the buckets emitted per window last time on this context (an eighth of the
-  // windows to begin with); a pool that turns out too small is made as large as the cursor says and the bucket kernel runs again
+  // windows to begin with); a pool that turns out too small is made as large as the cursor says and the bucket kernels run again
   double ratio = ctx->sk_pool_ratio > 0 ? ctx->sk_pool_ratio * 1.05 : 0.125;
   if (getenv("SHN_COUNT_SK_POOL")) ratio = atof(getenv("SHN_COUNT_SK_POOL"));                                  // (tests: start too small)
   uint64_t cap = std::min<uint64_t>(upper, (uint64_t)((double)upper * ratio) + 4096);
   uint64_t np = 0;
   void *pk = nullptr, *pc = nullptr;
+  // layout 1 (default): the buckets' sorted runs ARE the table; SHN_COUNT_SK_LAYOUT=0 (and the fallback of a bucket that 65,536 key
+  // ranges do not split): unsorted pairs, reduced and re-partitioned by key through the pairs path
+  bool sorted = !(getenv("SHN_COUNT_SK_LAYOUT") && atoi(getenv("SHN_COUNT_SK_LAYOUT")) == 0);
+  if (sorted) {
+    void* pr;
+    if ((rc = g_shn_ws[24].get(nbk * 16 + 64, &pr))) return rc;
+    uint64_t* d_run_off = (uint64_t*)pr;
+    uint32_t* d_ndist = (uint32_t*)(d_run_off + nbk);
+    uint32_t* d_defer = d_ndist + nbk;
+    constexpr int BIG_T = 1024, BIG_CAP = 8192;
+    const size_t lds_small = (size_t)SK_CAP * 12 + std::max<size_t>((size_t)SK_CAP * 2, (size_t)SK_RANK_MAX * 12), lds_big = (size_t)BIG_CAP * 14;
+    HIP_TRY(hipFuncSetAttribute((const void*)sk_buckets_sorted_kernel<true, BIG_T, BIG_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+    HIP_TRY(hipFuncSetAttribute((const void*)sk_buckets_sorted_kernel<false, BIG_T, BIG_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+    unsigned long long cur[4] = {0, 0, 0, 0};
+    for (int attempt = 0; attempt < 3 && sorted; attempt++) {
+      if ((rc = g_shn_ws[20].get((cap + 2) * 8, &pk))) return rc;
+      if ((rc = g_shn_ws[21].get((cap + 2) * 4, &pc))) return rc;
+      HIP_TRY(hipMemsetAsync(d_cursors + 1, 0, 24, s));
+      {
+        TimerRegion t(ctx, T_SK_BUCKETS);
+        if (both_strands) hipLaunchKernelGGL((sk_buckets_sorted_kernel<true, SK_BLK, SK_CAP>), dim3((uint32_t)nbk), dim3(SK_BLK), lds_small, s, recsB, d_seg, d_off2, d_hist2,
+                                             P.b2, k1, P.w, (const uint32_t*)nullptr, d_defer, (uint64_t*)pk, (uint32_t*)pc, d_cursors, cap, d_run_off, d_ndist);
+        else hipLaunchKernelGGL((sk_buckets_sorted_kernel<false, SK_BLK, SK_CAP>), dim3((uint32_t)nbk), dim3(SK_BLK), lds_small, s, recsB, d_seg, d_off2, d_hist2,
+                                P.b2, k1, P.w, (const uint32_t*)nullptr, d_defer, (uint64_t*)pk, (uint32_t*)pc, d_cursors, cap, d_run_off, d_ndist);
+        HIP_TRY(hipMemcpyAsync(cur, d_cursors, 32, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (getenv("SHN_COUNT_SK_DEBUG")) fprintf(stderr, "[sk] buckets %llu, deferred %llu, pool after the small tables %llu of %llu\n", (unsigned long long)nbk, cur[2], cur[1], (unsigned long long)cap);
+        if (cur[2]) {
+          TimerRegion tb(ctx, T_SK_BIG);
+          if (both_strands) hipLaunchKernelGGL((sk_buckets_sorted_kernel<true, BIG_T, BIG_CAP>), dim3((uint32_t)cur[2]), dim3(BIG_T), lds_big, s, recsB, d_seg, d_off2, d_hist2,
+                                               P.b2, k1, P.w, (const uint32_t*)d_defer, (uint32_t*)nullptr, (uint64_t*)pk, (uint32_t*)pc, d_cursors, cap, d_run_off, d_ndist);
+          else hipLaunchKernelGGL((sk_buckets_sorted_kernel<false, BIG_T, BIG_CAP>), dim3((uint32_t)cur[2]), dim3(BIG_T), lds_big, s, recsB, d_seg, d_off2, d_hist2,
+                                  P.b2, k1, P.w, (const uint32_t*)d_defer, (uint32_t*)nullptr, (uint64_t*)pk, (uint32_t*)pc, d_cursors, cap, d_run_off, d_ndist);
+          HIP_TRY(hipMemcpyAsync(cur, d_cursors, 32, hipMemcpyDeviceToHost, s));
+          HIP_TRY(hipStreamSynchronize(s));
+        }
+      }
+      HIP_TRY(hipGetLastError());
+      if (cur[3]) { sorted = false; break; }                             // a bucket no key range splits: the pairs path takes this input
+      np = cur[1];
+      if (np <= cap) break;
+      if (attempt == 2) return shn_fail(SHN_ERR_OVERFLOW, "shn_count_k1mers: the pair pool of the super-k-mer path stayed too small");
+      cap = std::min<uint64_t>(upper, np + np / 64 + 4096);
+    }
+    if (sorted) {
+      if (!getenv("SHN_COUNT_SK_POOL")) ctx->sk_pool_ratio = (double)np / (double)upper;
+      shn_table* t = new shn_table();
+      memset(t, 0, sizeof(*t));
+      t->ctx = ctx; t->device = ctx->device; t->k = k1; t->canonical = both_strands ? 1 : 0; t->bits = bits; t->n_buckets = nbk;
+      t->layout = 1; t->sk_m = P.m; t->n = np;
+#define TRYT(x) do { hipError_t _e = (x); if (_e != hipSuccess) { shn_table_destroy(t); return shn_fail(SHN_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(_e)); } } while (0)
+      TRYT(shn_dev_malloc(&t->d_keys, (np + 1) * 8));
+      TRYT(shn_dev_malloc(&t->d_counts, (np + 1) * 4));
+      TRYT(shn_dev_malloc(&t->d_bucket_off, (nbk + 1) * 8));
+      uint64_t D = 0;
+      { TimerRegion tr(ctx, T_COMPACT);
+        if ((rc = shn_device_scan_u32(ctx, d_ndist, nbk, t->d_bucket_off, &D))) { shn_table_destroy(t); return rc; }
+        if (D != np) { shn_table_destroy(t); return shn_fail(SHN_ERR_OVERFLOW, "shn_count_k1mers: super-k-mer buckets and pool disagree"); }
+        if (np) hipLaunchKernelGGL(sk_gather_kernel, dim3((uint32_t)cdiv(nbk * SHN_WAVE, SK_BLK)), dim3(SK_BLK), 0, s, (const uint64_t*)pk, (const uint32_t*)pc,
+                                   (const uint64_t*)d_run_off, (const uint32_t*)d_ndist, (const uint64_t*)t->d_bucket_off, nbk, t->d_keys, t->d_counts);
+        TRYT(hipMemsetAsync(d_cursors + 5, 0, 8, s));
+        if (np) hipLaunchKernelGGL(sk_sum_counts_kernel, dim3(1024), dim3(256), 0, s, (const uint32_t*)pc, np, d_cursors + 5);
+        unsigned long long tot = 0;
+        TRYT(hipMemcpyAsync(&tot, d_cursors + 5, 8, hipMemcpyDeviceToHost, s));
+        TRYT(hipStreamSynchronize(s));
+        TRYT(hipGetLastError());
+        t->total = tot;
+      }
+#undef TRYT
+      *out = t;
+      *handled = 1;
+      return SHN_OK;
+    }
+  }
   for (int attempt = 0; attempt < 3; attempt++) {
     if ((rc = g_shn_ws[20].get((cap + 2) * 8, &pk))) return rc;
     if ((rc = g_shn_ws[21].get((cap + 2) * 4, &pc))) return rc;
@@ -468,7 +719,6 @@ int shn_count_superkmers(shn_ctx* ctx, const std::vector<ReadsView>& views, uint
     if (attempt == 2) return shn_fail(SHN_ERR_OVERFLOW, "shn_count_k1mers: the pair pool of the super-k-mer path stayed too small");
     cap = std::min<uint64_t>(upper, np + np / 64 + 4096);
   }
-  if (!getenv("SHN_COUNT_SK_POOL")) ctx->sk_pool_ratio = (double)np / (double)upper;
   if (np >= 0xFFFFFFFFULL) return SHN_OK;                                // (more pairs than the pairs path takes: the chunked pipeline)
   rc = shn_table_from_pairs(ctx, pk, pc, np, k1, both_strands ? 1 : 0, out);
   if (rc) return rc;

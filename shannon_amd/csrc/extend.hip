@@ -137,44 +137,68 @@ __global__ void ext_prepare_kernel(const uint64_t* __restrict__ tkeys, const uin
 // not entered (load_kmers drops them, extension_correction.py:202-221).  An empty slot holds key 0 = AAA...A, which is
 // low-complexity and therefore never a valid answer.
 #define FD_SLOTS 10
-#define FD_PER_LINE 5
+#define FD_PER_LINE 4         // keys per line on average: a line overflows with probability 0.3 % (5: 1.4 %)
+#define FD_HOPS 4             // what does not fit its line goes into the next ones
 #define FD_PAL 0x80000000u
 // (the hash of the count table's buckets, so that the build -- which goes through the table in bucket order -- fills the lines
 // front to back: its atomics stay in the L2 and the lines stream out once; with a hash of its own the build was 724 M random
 // read-modify-writes, 70 ms)
-__device__ __forceinline__ uint64_t fd_bucket(uint64_t key, uint64_t n_lines) { return __umul64hi(shn_mix64(key), n_lines); }
-__global__ void fd_build_kernel(const uint64_t* __restrict__ tkeys, const uint8_t* __restrict__ flags, uint64_t n,
+// (tables of layout 1 -- buckets of minimizers: a bucket's keys spread over the bucket's own stretch of lines, so the build still
+// streams, and since a k1-mer's eight neighbours mostly share its minimizer, their look-ups mostly fall into the stretch the block
+// is working through -- lines the L2 already holds)
+__device__ __forceinline__ uint64_t fd_bucket(const TabIdx& T, uint64_t key, uint64_t n_lines) {
+  const uint64_t h = shn_mix64(key);
+  if (!T.layout) return __umul64hi(h, n_lines);
+  // (buckets of minimizers differ in size by orders of magnitude: a bucket's lines are its share of the table -- one line per
+  // FD_PER_LINE keys, from where its keys begin -- and the key picks one of them)
+  const uint32_t b = shn_tab_bucket(T, key);
+  const uint64_t lo = T.boff[b], hi = T.boff[b + 1];
+  return lo / FD_PER_LINE + b + __umul64hi(h, (hi - lo) / FD_PER_LINE + 1);
+}
+// the same with the key's bucket known (layout 1)
+__device__ __forceinline__ uint64_t fd_line_in_bucket(const TabIdx& T, uint32_t b, uint64_t key) {
+  const uint64_t lo = T.boff[b], hi = T.boff[b + 1];
+  return lo / FD_PER_LINE + b + __umul64hi(shn_mix64(key), (hi - lo) / FD_PER_LINE + 1);
+}
+__global__ void fd_build_kernel(const TabIdx T, const uint8_t* __restrict__ flags, uint64_t n,
                                 unsigned long long* __restrict__ lines, uint64_t n_lines) {
+  const uint64_t* __restrict__ tkeys = T.keys;
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint8_t f = flags[i];
   if (f & 2) return;
   const uint64_t key = tkeys[i];
-  unsigned long long* line = lines + fd_bucket(key, n_lines) * 16;
-  const uint32_t slot = atomicAdd((uint32_t*)line + 30, 1u);
-  if (slot < FD_SLOTS) { line[slot] = key; ((uint32_t*)line)[20 + slot] = (uint32_t)i | ((f & 1) ? FD_PAL : 0u); }
+  // (a full line sends the entry on to the next one -- the count word tallies the attempts, so a look-up that finds more than
+  // FD_SLOTS there goes on as well; the dictionary ends in FD_HOPS spare lines)
+  unsigned long long* line = lines + fd_bucket(T, key, n_lines) * 16;
+  for (int hop = 0; hop < FD_HOPS; hop++, line += 16) {
+    const uint32_t slot = atomicAdd((uint32_t*)line + 30, 1u);
+    if (slot < FD_SLOTS) { line[slot] = key; ((uint32_t*)line)[20 + slot] = (uint32_t)i | ((f & 1) ? FD_PAL : 0u); break; }
+  }
 }
 // One look-up by the eight lanes g0 .. g0+7 of a wavefront (p = lane - g0; all eight pass the same key): lane p holds bytes
 // 16 p .. 16 p + 15 of the line -- one coalesced 128-byte request.  Returns the id word or 0xFFFFFFFF, the same in all eight lanes.
 __device__ __forceinline__ uint64_t shfl_u64(uint64_t x, int src) {
   return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(x >> 32), src, 64) << 32) | (uint64_t)(uint32_t)__shfl((int)(uint32_t)x, src, 64);
 }
-__device__ __forceinline__ ulonglong2 fd_load(const unsigned long long* __restrict__ lines, uint64_t n_lines, uint64_t key, int p) {
-  return ((const ulonglong2*)(lines + fd_bucket(key, n_lines) * 16))[p];
-}
-__device__ __forceinline__ uint32_t fd_match(const ulonglong2 v, uint64_t key, int p, int g0, const uint64_t* __restrict__ tkeys,
-                                             const uint64_t* __restrict__ boff, int bits, const uint8_t* __restrict__ flags) {
-  const bool ok = p < 5 && key != 0;
-  const unsigned long long m0 = (__ballot(ok && v.x == key) >> g0) & 0xFFULL, m1 = (__ballot(ok && v.y == key) >> g0) & 0xFFULL;
-  if (m0 | m1) {
-    const int slot = m0 ? 2 * (__ffsll((long long)m0) - 1) : 2 * (__ffsll((long long)m1) - 1) + 1;
-    // id words: bytes 80 .. 119 = words 20 .. 29: lane 5 + slot / 4, its word slot % 4
-    const uint32_t w = (slot & 2) ? ((slot & 1) ? (uint32_t)(v.y >> 32) : (uint32_t)v.y) : ((slot & 1) ? (uint32_t)(v.x >> 32) : (uint32_t)v.x);
-    return (uint32_t)__shfl((int)w, g0 + 5 + (slot >> 2), 64);
+__device__ __forceinline__ uint32_t fd_match(ulonglong2 v, const unsigned long long* __restrict__ lines, uint64_t line, uint64_t key, int p, int g0,
+                                             const TabIdx& T, const uint8_t* __restrict__ flags) {
+  for (int hop = 0;; hop++) {
+    const bool ok = p < 5 && key != 0;
+    const unsigned long long m0 = (__ballot(ok && v.x == key) >> g0) & 0xFFULL, m1 = (__ballot(ok && v.y == key) >> g0) & 0xFFULL;
+    if (m0 | m1) {
+      const int slot = m0 ? 2 * (__ffsll((long long)m0) - 1) : 2 * (__ffsll((long long)m1) - 1) + 1;
+      // id words: bytes 80 .. 119 = words 20 .. 29: lane 5 + slot / 4, its word slot % 4
+      const uint32_t w = (slot & 2) ? ((slot & 1) ? (uint32_t)(v.y >> 32) : (uint32_t)v.y) : ((slot & 1) ? (uint32_t)(v.x >> 32) : (uint32_t)v.x);
+      return (uint32_t)__shfl((int)w, g0 + 5 + (slot >> 2), 64);
+    }
+    const uint32_t cnt = (uint32_t)__shfl((int)(uint32_t)(v.y >> 0), g0 + 7, 64) ;   // word 30 = low half of lane 7's second word
+    if (cnt <= FD_SLOTS || key == 0) return 0xFFFFFFFFu;
+    if (hop == FD_HOPS - 1) break;
+    line++;                                                          // (the line overflowed, 0.3 % of them do: the next one -- one more fetch of the eight lanes)
+    v = ((const ulonglong2*)(lines + line * 16))[p];
   }
-  const uint32_t cnt = (uint32_t)__shfl((int)(uint32_t)(v.y >> 0), g0 + 7, 64) ;   // word 30 = low half of lane 7's second word
-  if (cnt <= FD_SLOTS || key == 0) return 0xFFFFFFFFu;
-  const int64_t j = shn_table_find(tkeys, boff, bits, key);        // (the bucket overflowed: rare)
+  const int64_t j = shn_tab_find(T, key);                           // (FD_HOPS full lines in a row)
   if (j < 0) return 0xFFFFFFFFu;
   const uint8_t fj = flags[j];
   return (fj & 2) ? 0xFFFFFFFFu : ((uint32_t)j | ((fj & 1) ? FD_PAL : 0u));
@@ -187,9 +211,9 @@ __device__ __forceinline__ uint32_t fd_match(const ulonglong2 v, uint64_t key, i
 // 128-byte request of the eight lanes, all eight requests in flight before the first is looked at), and then write the two
 // records -- 128 contiguous bytes -- 16 bytes each.
 struct __attribute__((aligned(16))) Quad { uint32_t a, b, c, d; };
-__global__ void ext_records_kernel(const uint64_t* __restrict__ tkeys, const uint64_t* __restrict__ boff, int bits,
-                                   const uint8_t* __restrict__ flags, const uint32_t* __restrict__ weight, uint64_t n, int k, int canonical,
+__global__ void ext_records_kernel(const TabIdx T, const uint8_t* __restrict__ flags, const uint32_t* __restrict__ weight, uint64_t n, int k, int canonical,
                                    Rec* __restrict__ rec, const unsigned long long* __restrict__ lines, uint64_t n_lines) {
+  const uint64_t* __restrict__ tkeys = T.keys;
   const uint64_t total = n * 8;
   const uint64_t rounded = (total + 63) & ~63ULL;                       // whole wavefronts take part in the ballots and shuffles
   const uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
@@ -209,7 +233,38 @@ __global__ void ext_records_kernel(const uint64_t* __restrict__ tkeys, const uin
       if (canonical) { const uint64_t rc = shn_revcomp(mykey, k); if (rc < mykey) { mykey = rc; mystrand = 1; } }
       if (dead0) mykey = 0;                                             // (no look-up is needed: key 0 is never found)
     }
-    const uint64_t myline = fd_bucket(mykey, n_lines);
+    uint64_t myline;
+    if (T.layout) {
+      // The minimizers of the eight neighbours from the k1-mer's own m-mers: the four successors share its m-mers 1 .. w - 1, the
+      // four predecessors its m-mers 0 .. w - 2, and each adds one m-mer of its own (its last / first).  The eight lanes split the
+      // k1-mer's w m-mers between them (a minimizer is the same on both strands, so the stored orientation serves); a look-up made
+      // from scratch costs w order values per neighbour, and the kernel was bound by exactly that arithmetic.
+      const int m = T.m, w = k - m + 1;
+      const uint32_t mmask = m == 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+      uint32_t smin = 0xFFFFFFFFu, pmin = 0xFFFFFFFFu;                  // over m-mers 1 .. w - 1 / 0 .. w - 2
+      for (int pos = p; pos < w; pos += 8) {
+        const uint32_t f = (uint32_t)(str >> (2 * (k - m - pos))) & mmask;
+        uint32_t c = f;
+        if (canonical) { const uint32_t r = shn_revcomp32(f, m); c = r < f ? r : f; }
+        const uint32_t o = shn_sk_order(c);
+        if (pos >= 1) smin = o < smin ? o : smin;
+        if (pos <= w - 2) pmin = o < pmin ? o : pmin;
+      }
+#pragma unroll
+      for (int d = 1; d < 8; d <<= 1) {
+        const uint32_t a = (uint32_t)__shfl_xor((int)smin, d, 64), b2 = (uint32_t)__shfl_xor((int)pmin, d, 64);
+        smin = a < smin ? a : smin; pmin = b2 < pmin ? b2 : pmin;
+      }
+      const uint32_t nb = (uint32_t)(p & 3);
+      const uint32_t f = p < 4 ? ((((uint32_t)str & (mmask >> 2)) << 2) | nb)                          // the successor's last m-mer
+                               : ((nb << (2 * (m - 1))) | ((uint32_t)(str >> (2 * (k - m + 1))) & (mmask >> 2)));   // the predecessor's first
+      uint32_t c = f;
+      if (canonical) { const uint32_t r = shn_revcomp32(f, m); c = r < f ? r : f; }
+      uint32_t o = shn_sk_order(c);
+      const uint32_t shared = p < 4 ? smin : pmin;
+      o = shared < o ? shared : o;
+      myline = fd_line_in_bucket(T, shn_sk_bucket(o, T.bits), mykey);
+    } else myline = fd_bucket(T, mykey, n_lines);
     const uint32_t strands = (uint32_t)((__ballot(mystrand != 0) >> g0) & 0xFFULL);
     uint64_t key[8];
     ulonglong2 v[8];
@@ -221,7 +276,7 @@ __global__ void ext_records_kernel(const uint64_t* __restrict__ tkeys, const uin
     uint32_t r8[8], d8[8];                                              // the candidate (oriented id), its other orientation
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-      const uint32_t w = fd_match(v[q], key[q], p, g0, tkeys, boff, bits, flags);
+      const uint32_t w = fd_match(v[q], lines, shfl_u64(myline, g0 + q), key[q], p, g0, T, flags);
       if (w == 0xFFFFFFFFu) { r8[q] = d8[q] = 0xFFFFFFFFu; continue; }
       const uint32_t j = w & ~FD_PAL;
       const uint32_t st = (strands >> q) & 1u;
@@ -276,8 +331,9 @@ __device__ __forceinline__ void cc_unite(uint32_t* lab, uint32_t u, uint32_t v) 
 // and only joined through a common neighbour if that neighbour exists and is not low-complexity (a transcript's last K-mer before
 // a poly-A tail is the typical exception).  So the labelling also unites every k1-mer with its (up to six) siblings.
 // Look-ups as in the records kernel: eight lanes per canonical k1-mer, through the one-line dictionary.
-__global__ void cc_edges_kernel(const uint64_t* __restrict__ tkeys, const uint64_t* __restrict__ boff, int bits, const uint8_t* __restrict__ flags,
+__global__ void cc_edges_kernel(const TabIdx T, const uint8_t* __restrict__ flags,
                                 uint64_t n, int k, int canonical, uint32_t* lab, const unsigned long long* __restrict__ lines, uint64_t n_lines) {
+  const uint64_t* __restrict__ tkeys = T.keys;
   const uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
   const uint64_t total = n * 8, rounded = (total + 63) & ~63ULL;
   const int lane = threadIdx.x & 63, g0 = lane & ~7, p = lane & 7;
@@ -298,7 +354,7 @@ __global__ void cc_edges_kernel(const uint64_t* __restrict__ tkeys, const uint64
         if (canonical) { const uint64_t rc = shn_revcomp(mykey, k); if (rc < mykey) mykey = rc; }
         if (skip) mykey = 0;
       }
-      const uint64_t myline = fd_bucket(mykey, n_lines);
+      const uint64_t myline = fd_bucket(T, mykey, n_lines);
       uint64_t key[8];
       ulonglong2 v[8];
 #pragma unroll
@@ -308,7 +364,7 @@ __global__ void cc_edges_kernel(const uint64_t* __restrict__ tkeys, const uint64
       }
 #pragma unroll
       for (int q = 0; q < 8; q++) {
-        const uint32_t w = fd_match(v[q], key[q], p, g0, tkeys, boff, bits, flags);
+        const uint32_t w = fd_match(v[q], lines, shfl_u64(myline, g0 + q), key[q], p, g0, T, flags);
         // (lane q of the group does the union: eight independent ones side by side)
         if (w != 0xFFFFFFFFu && p == q && (uint64_t)(w & ~FD_PAL) != i) cc_unite(lab, (uint32_t)i, w & ~FD_PAL);
       }
@@ -1306,7 +1362,7 @@ __global__ void shard_offsets_kernel(const uint64_t* __restrict__ boff, uint64_t
 
 static int build_fine_dict(shn_ctx* ctx, const shn_table* t, const uint8_t* d_flags, unsigned long long** lines_out, uint64_t* n_lines_out,
                            void* room = nullptr);
-static inline uint64_t fine_dict_lines(uint64_t n) { return n / FD_PER_LINE + 1; }
+static inline uint64_t fine_dict_lines(const shn_table* t) { return t->n / FD_PER_LINE + 1 + (t->layout ? t->n_buckets + 1 : 0) + FD_HOPS; }
 static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank, shn_table** out) {
   hipStream_t s = ctx->stream;
   const uint64_t n = t->n;
@@ -1334,7 +1390,7 @@ static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank
   TRYS(hipMemsetAsync(d_cnt, 0, 2048, s));
   hipLaunchKernelGGL(cc_init_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, d_lab, n);
   { TimerRegion t1(ctx, T_EXT_PREP);
-    hipLaunchKernelGGL(cc_edges_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off, t->bits,
+    hipLaunchKernelGGL(cc_edges_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, shn_tab_idx(t),
                        d_flags, n, t->k, t->canonical, d_lab, (const unsigned long long*)lines, n_lines); }
   hipLaunchKernelGGL(cc_flatten_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, d_lab, n);
   TRYS(hipMemsetAsync(d_size, 0, (n + 1) * 4, s));
@@ -1373,7 +1429,7 @@ static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank
   sub = new shn_table();
   memset(sub, 0, sizeof(*sub));
   sub->ctx = t->ctx; sub->device = t->device; sub->k = t->k; sub->canonical = t->canonical; sub->n = n_sub; sub->total = 0;
-  sub->bits = t->bits; sub->n_buckets = t->n_buckets;
+  sub->bits = t->bits; sub->n_buckets = t->n_buckets; sub->layout = t->layout; sub->sk_m = t->sk_m;
   TRYS(shn_dev_malloc(&sub->d_keys, (n_sub + 1) * 8));
   TRYS(shn_dev_malloc(&sub->d_counts, (n_sub + 1) * 4));
   TRYS(shn_dev_malloc(&sub->d_bucket_off, (t->n_buckets + 1) * 8));
@@ -1395,13 +1451,13 @@ static int build_fine_dict(shn_ctx* ctx, const shn_table* t, const uint8_t* d_fl
                            void* room) {
   hipStream_t s = ctx->stream;
   const uint64_t n = t->n;
-  const uint64_t n_lines = fine_dict_lines(n);
+  const uint64_t n_lines = fine_dict_lines(t);
   unsigned long long* lines = (unsigned long long*)room;
   hipError_t e = lines ? hipSuccess : shn_dev_malloc(&lines, n_lines * 128);
   if (e == hipSuccess) e = hipMemsetAsync(lines, 0, n_lines * 128, s);
   if (e != hipSuccess) { if (lines && !room) shn_dev_free(lines); return shn_fail(SHN_ERR_HIP, std::string("build_fine_dict: ") + hipGetErrorString(e)); }
-  if (n) hipLaunchKernelGGL(fd_build_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, d_flags, n, lines, n_lines);
-  *lines_out = lines; *n_lines_out = n_lines;
+  if (n) hipLaunchKernelGGL(fd_build_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, shn_tab_idx(t), d_flags, n, lines, n_lines - FD_HOPS);
+  *lines_out = lines; *n_lines_out = n_lines - FD_HOPS;          // (the look-ups hash into all but the spare lines at the end)
   return SHN_OK;
 }
 
@@ -1461,7 +1517,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   // built in it first, see build_fine_dict)
   const uint64_t claim_words = (2 * n + 4 + 31) & ~31ULL;
   { u64* both = nullptr;
-    TRYE(shn_dev_malloc(&both, std::max<uint64_t>(2 * claim_words * 8, fine_dict_lines(n) * 128)));
+    TRYE(shn_dev_malloc(&both, std::max<uint64_t>(2 * claim_words * 8, fine_dict_lines(t) * 128)));
     e->d_claim = both; e->d_claim2 = both + claim_words; }
   if (n) {
     TimerRegion t1(ctx, T_EXT_PREP);
@@ -1472,8 +1528,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       uint64_t n_lines = 0;
       { int rca = build_fine_dict(ctx, t, e->d_flags, &lines, &n_lines, e->d_claim); if (rca) { shn_ext_destroy(e); return rca; } }
       { TimerRegion ta(ctx, T_EXT_ADJ);                  // (one launch: bench.py's roofline entry for this kernel)
-        hipLaunchKernelGGL(ext_records_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, t->d_keys, t->d_bucket_off,
-                           t->bits, e->d_flags, e->d_weight, n, t->k, t->canonical, e->d_rec, (const unsigned long long*)lines, n_lines); }
+        hipLaunchKernelGGL(ext_records_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, shn_tab_idx(t),
+                           e->d_flags, e->d_weight, n, t->k, t->canonical, e->d_rec, (const unsigned long long*)lines, n_lines); }
       (void)lines;                                       // (lives in the claims' block: overwritten when the claims are initialised below)
     }
     TRYE(hipGetLastError());
@@ -1998,14 +2054,14 @@ extern "C" int shn_ext_emit(shn_ctx* ctx, const shn_ext* e, const uint32_t* rank
 }
 
 // weights of arbitrary k1-mer strings in the doubled input (for the `allowed` dict, :404-408)
-__global__ void ext_weight_lookup_kernel(const uint64_t* __restrict__ tkeys, const uint64_t* __restrict__ boff, int bits,
+__global__ void ext_weight_lookup_kernel(const TabIdx T,
                                          const uint32_t* __restrict__ weight, const uint8_t* __restrict__ flags, int k, int canonical,
                                          const uint64_t* __restrict__ q, uint64_t nq, uint32_t* __restrict__ out) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nq) return;
   uint64_t key = q[i];
   if (canonical) { uint64_t rc = shn_revcomp(key, k); key = rc < key ? rc : key; }
-  int64_t j = shn_table_find(tkeys, boff, bits, key);
+  int64_t j = shn_tab_find(T, key);
   out[i] = (j >= 0 && !(flags[j] & 2)) ? weight[j] : 0;
 }
 
@@ -2019,8 +2075,8 @@ extern "C" int shn_ext_weights(shn_ctx* ctx, const shn_ext* e, const uint64_t* k
   HIP_TRY(shn_dev_malloc(&dq, n * 8));
   HIP_TRY(shn_dev_malloc(&dw, n * 4));
   HIP_TRY(hipMemcpyAsync(dq, keys, n * 8, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(ext_weight_lookup_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, e->table->d_keys,
-                     e->table->d_bucket_off, e->table->bits, e->d_weight, e->d_flags, e->k, e->table->canonical, dq, n, dw);
+  hipLaunchKernelGGL(ext_weight_lookup_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, shn_tab_idx(e->table),
+                     e->d_weight, e->d_flags, e->k, e->table->canonical, dq, n, dw);
   HIP_TRY(hipMemcpyAsync(weights, dw, n * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   shn_dev_free(dq); shn_dev_free(dw);

@@ -248,3 +248,31 @@ def test_two_batches_in_flight_give_the_sequential_results(ctx):
             assert R.partitions[p]["reconstructed_fasta"] == W.partitions[p]["reconstructed_fasta"]
     for d1, d2, _st in batches:
         d1.close(); d2.close()
+
+
+@pytest.mark.parametrize("name", ["se_K24", "pe_K25", "syn_pe_s0", "syn_pe_hairpin_K31", "syn_pe_ss_s71", "syn_part_s33"])
+def test_end_to_end_on_a_minimizer_bucketed_table(ctx, name, monkeypatch):
+    """The counting path of large inputs (super-k-mers, csrc/count_sk.hip) hands the extension a table whose buckets are buckets of
+    minimizers (shn_table layout 1: a k1-mer and its neighbours mostly share a bucket); forced here on the golden inputs: the same
+    contigs, partitions, transcripts and final file as the reference / the oracle."""
+    from shannon_amd import pipeline
+    from oracle import pipeline as opipe
+    monkeypatch.setenv("SHN_COUNT_DIRECT", "0")
+    monkeypatch.setenv("SHN_COUNT_SK", "2")
+    m = MANIFEST[name]
+    g = load_case(name)
+    inp = load_inputs(name)
+    psize = m.get("partition_size", 500)
+    pv = [part_vectors(len(b["contigs"]), psize) for b in g["big_components"]] or None
+    ds = not strand_specific(name)
+    ctx.timer_reset()
+    R = pipeline.assemble(ctx, inp[0], inp[1] if m["paired"] else None, K=m["K"], partition_size=psize, sample="s",
+                          seed=m["sf_seed"], part_vectors=pv, double_stranded=ds)
+    assert "count.sk_buckets" in ctx.timers() or not ds          # (strand-specific runs merge two tables through the pairs path)
+    assert R.extension.contigs == g["contigs"]
+    assert list(R.partitions) == list(g["partitions"])
+    O = opipe.assemble(inp[0], inp[1] if m["paired"] else None, K=m["K"], partition_size=psize, sample="s",
+                       seed=m["sf_seed"], part_vectors=pv, double_stranded=ds)
+    for p in R.partitions:
+        cmp_fasta(R.partitions[p]["reconstructed_fasta"], O["partitions"][p]["reconstructed_fasta"])
+    assert R.final == O["final"]
