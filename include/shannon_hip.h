@@ -338,6 +338,13 @@ int shn_reads_dedup(shn_ctx* ctx, const shn_reads* a, const shn_reads* b, const 
  * lengths, multi-line FASTA and malformed records are refused (SHN_ERR_ARG, message "shn_reads_ingest: unsupported: ...").      */
 int shn_reads_ingest(shn_ctx* ctx, const uint8_t* text, uint64_t n_bytes, int format, uint8_t* codes_out, uint64_t codes_cap,
                      uint64_t* n_reads_out, uint32_t* read_len_out, shn_reads** out);
+/* The same for reads of ANY lengths (the reference's Samples/SE_read.fasta: 48-51 bases; kmers_for_component.py:329-403 and
+ * multibridging.py:22-98 take whatever the lines hold): codes_out receives the reads' codes one after the other (codes_cap bytes of
+ * room; the text's size always suffices), offsets_out their n_reads + 1 offsets.  Bases outside ACGT are kept as code 4 (the packed
+ * set marks them and the reads that hold them, as shn_reads_create does).  out == NULL and codes_out == NULL: scan only.           */
+int shn_reads_ingest_ragged(shn_ctx* ctx, const uint8_t* text, uint64_t n_bytes, int format, uint8_t* codes_out, uint64_t codes_cap,
+                            uint64_t* offsets_out, uint64_t offsets_cap, uint64_t* n_reads_out, uint32_t* max_len_out,
+                            uint64_t* total_bases_out, shn_reads** out);
 /* The whole final merge over the text of all_reconstructed.fasta: process_concatenated_fasta.py:6-32 (rename repeated names, drop
  * sequences of < 200 bases and sequences seen before on either strand), the length sort of shannon.py:603 and shn_find_reps
  * (faster_reps.py:60-131).  The survivors in sorted order: shn_post_count / _sizes / _export (names, name_off[n+1], seqs,

@@ -126,25 +126,31 @@ def main(argv):
     ctx = device.Context(0)
     T = {}
     paired = len(reads) == 2
-    # the files straight into HBM (shn_reads_ingest: 2-line FASTA / FASTQ, reads of one length, ACGT only); anything else is
-    # read record by record
+    # the files straight into HBM (shn_reads_ingest / shn_reads_ingest_ragged: 2-line FASTA / 4-line FASTQ, reads of any lengths,
+    # bases outside ACGT kept and marked); only what that refuses (multi-line FASTA, malformed records) is read record by record
     import time as _t
+    import numpy as np
     t0 = _t.time()
     sets, got = None, []
     try:
         for p in reads:                                        # (a list built step by step: what was ingested before a refusal is closed below)
             got.append(device.Reads.ingest(ctx, p))
-        if all(g[0].n_invalid == 0 for g in got) and len(set(g[1].shape[1] for g in got)) == 1 and len(set(len(g[0]) for g in got)) == 1:
+        if len(set(len(g[0]) for g in got)) == 1:
             sets, r = [g[0] for g in got], [g[1] for g in got]
+            if any(isinstance(x, device.RaggedCodes) for x in r):      # one mate file ragged, the other not: both as flat codes + offsets
+                r = [x if isinstance(x, device.RaggedCodes) else
+                     device.RaggedCodes(x.reshape(-1), np.arange(x.shape[0] + 1, dtype=np.uint64) * np.uint64(x.shape[1])) for x in r]
     except _lib.ShannonError as ex:
         if "unsupported" not in str(ex):
             raise
     if sets is None:
-        for g in got:                                          # ingested but declined (reads with N, unequal mates): free the device copies
+        for g in got:                                          # ingested but declined (mate files of different sizes): free the device copies
             g[0].close()
         r = [read_fasta(p) for p in reads]
+    T["ingest path"] = "device" if sets is not None else "python"
     T["ingest"] = _t.time() - t0
-    say("Processed No of reads:%d, Avg. Read length: %.2f" % (len(r[0]), (sum(len(x) for x in r[0]) / max(1, len(r[0]))) if sets is None else r[0].shape[1]))
+    avg_len = (sum(len(x) for x in r[0]) / max(1, len(r[0]))) if sets is None else (r[0].total_bases / max(1, len(r[0])) if isinstance(r[0], device.RaggedCodes) else r[0].shape[1])
+    say("Processed No of reads:%d, Avg. Read length: %.2f (read files through the %s ingest)" % (len(r[0]), avg_len, T["ingest path"]))
     if sets is not None:
         from shannon_amd import kmers_for_component as kfc
         R = pipeline.assemble_resident(ctx, sets[0], sets[1] if paired else None, kfc.ReadStore(r[0], r[1] if paired else None), K=K,
@@ -173,7 +179,7 @@ def main(argv):
         for name, seq in R.final.items():
             f.write(">%s\n%s\n" % (name, seq))
     say("All partitions completed: %d transcripts reconstructed" % len(R.final))
-    say("stage seconds: " + json.dumps({k: round(v, 4) for k, v in T.items()}))
+    say("stage seconds: " + json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in T.items()}))
     log.close()
     ctx.close()
     print("-------------------------------------------------")

@@ -84,6 +84,7 @@ SIGNATURES = {
     "shn_post_export": (C.c_int, [vp, vp, vp, vp, vp]),
     "shn_post_destroy": (None, [vp]),
     "shn_reads_ingest": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint64, vp, vp, vpp]),
+    "shn_reads_ingest_ragged": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vpp]),
     "shn_reads_dedup": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_int, vp, vp, vp, vp, vp]),
     "shn_mbgraph_run_resident": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, vpp]),
     "shn_reads_gather": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, vpp]),

@@ -8,9 +8,11 @@
 //   pass 1  host threads scan byte ranges of the text (cut at record starts) for newlines: records and read length per range
 //   pass 2  groups of ranges are parsed into one of two pinned staging buffers (codes 0..3, 4 = anything else) while the
 //           previous group is on its way: hipMemcpyAsync -> pack_kernel into the read set's final arrays, one launch per group
-// Only reads of one length take this path (fixed-length read sets are what the routing / graph stages address by row);
-// anything else -- ragged reads, multi-line FASTA, a malformed record -- is refused with SHN_ERR_ARG and a message starting
-// "shn_reads_ingest: unsupported", and the caller reads the file the slow way.
+// shn_reads_ingest takes reads of one length (fixed-length read sets are what the routing / graph stages address by row);
+// shn_reads_ingest_ragged takes reads of any lengths (the reference's own Samples/SE_read.fasta has 48-51 bases per read): the same
+// scan and the same threaded parse into ONE flat code array with per-read offsets, packed by the ragged path of shn_reads_create.
+// Bases outside ACGT are kept (code 4: the packed set's mask / bad-read flags); multi-line FASTA or a malformed record is refused
+// with SHN_ERR_ARG and a message starting "shn_reads_ingest: unsupported", and the caller reads the file record by record.
 #include "common.h"
 
 #include <algorithm>
@@ -259,4 +261,77 @@ extern "C" int shn_reads_ingest(shn_ctx* ctx, const uint8_t* text, uint64_t n_by
   if (rc) { shn_reads_destroy(r); return rc; }
   *out = r;
   return SHN_OK;
+}
+
+
+// Reads of any lengths.  codes_out: room for codes_cap bytes (the text's size is always enough), filled with the reads' codes one
+// after the other; offsets_out: n_reads + 1 entries (offsets_cap of them available).  out == NULL and codes_out == NULL: scan only
+// (n_reads, max_len, total_bases).  Otherwise both codes_out and offsets_out are needed (the packed set is made from them).
+extern "C" int shn_reads_ingest_ragged(shn_ctx* ctx, const uint8_t* text, uint64_t n_bytes, int format, uint8_t* codes_out, uint64_t codes_cap,
+                                       uint64_t* offsets_out, uint64_t offsets_cap, uint64_t* n_reads_out, uint32_t* max_len_out,
+                                       uint64_t* total_bases_out, shn_reads** out) {
+  if ((n_bytes && !text) || !n_reads_out || !max_len_out || !total_bases_out || (out && !ctx))
+    return shn_fail(SHN_ERR_ARG, "shn_reads_ingest_ragged: NULL argument");
+  *n_reads_out = 0; *max_len_out = 0; *total_bases_out = 0;
+  if (out) *out = nullptr;
+  uint64_t lead = 0;
+  while (lead < n_bytes && (text[lead] == '\n' || text[lead] == '\r')) lead++;
+  if (lead >= n_bytes) return shn_fail(SHN_ERR_ARG, "shn_reads_ingest: unsupported: no records");
+  if (format == 0) format = text[lead] == '@' ? 2 : 1;
+  if (format != 1 && format != 2) return shn_fail(SHN_ERR_ARG, "shn_reads_ingest: bad format");
+  const bool fastq = format == 2;
+  const unsigned T = (unsigned)std::max(1, std::min(shn_host_cpus(), 64));
+  uint64_t range_bytes = 16u << 20;
+  if (const char* e = getenv("SHN_INGEST_RANGE_BYTES")) range_bytes = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+  const uint64_t n_ranges = std::max<uint64_t>(1, std::min<uint64_t>(n_bytes / range_bytes + 1, 1u << 20));
+  struct RRange { uint64_t b0 = 0, b1 = 0, n_rec = 0, rec0 = 0, bases = 0, base0 = 0; uint32_t max_len = 0; int bad = 0; };
+  std::vector<RRange> R(n_ranges);
+  auto on_threads = [&](auto&& fn) {
+    std::atomic<uint64_t> next{0};
+    auto work = [&]() { for (uint64_t i; (i = next.fetch_add(1)) < n_ranges;) fn(i); };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < std::min<uint64_t>(T, n_ranges); t++) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+  };
+  on_threads([&](uint64_t i) { R[i].b0 = align_record(text, n_bytes, i == 0 ? lead : n_bytes / n_ranges * i, fastq); });
+  for (uint64_t i = 0; i < n_ranges; i++) R[i].b1 = i + 1 < n_ranges ? R[i + 1].b0 : n_bytes;
+  on_threads([&](uint64_t i) {
+    RRange& r = R[i];
+    if (r.b0 >= r.b1) return;
+    r.bad = walk_records(text, n_bytes, r.b0, r.b1, fastq, [&](uint64_t, uint64_t len) {
+      r.n_rec++; r.bases += len; r.max_len = std::max<uint32_t>(r.max_len, (uint32_t)std::min<uint64_t>(len, 0xFFFFFFFEu)); });
+  });
+  uint64_t N = 0, B = 0;
+  uint32_t mx = 0;
+  for (auto& r : R) {
+    if (r.bad) return shn_fail(SHN_ERR_ARG, r.bad == 1 ? "shn_reads_ingest: unsupported: a record does not start with its marker (multi-line FASTA?)"
+                                                       : "shn_reads_ingest: unsupported: truncated record");
+    r.rec0 = N; r.base0 = B; N += r.n_rec; B += r.bases;
+    mx = std::max(mx, r.max_len);
+  }
+  if (!N) return shn_fail(SHN_ERR_ARG, "shn_reads_ingest: unsupported: no records");
+  *n_reads_out = N; *max_len_out = mx; *total_bases_out = B;
+  if (!out && !codes_out) return SHN_OK;
+  if (!codes_out || !offsets_out) return shn_fail(SHN_ERR_ARG, "shn_reads_ingest_ragged: codes_out and offsets_out are both needed");
+  if (codes_cap < B || offsets_cap < N + 1) return shn_fail(SHN_ERR_ARG, "shn_reads_ingest_ragged: output arrays too small");
+  on_threads([&](uint64_t i) {
+    const RRange& r = R[i];
+    if (!r.n_rec) return;
+    uint64_t k = r.rec0, at = r.base0;
+    walk_records(text, n_bytes, r.b0, r.b1, fastq, [&](uint64_t s, uint64_t len) {
+      offsets_out[k++] = at;
+      const uint8_t* p = text + s;
+      uint8_t* d = codes_out + at;
+      for (uint64_t j = 0; j < len; j++) {
+        const uint8_t c = p[j], u = (uint8_t)(c & 0xDF), t = (uint8_t)((c >> 1) & 3);
+        const uint8_t ok = (uint8_t)((u == 'A') | (u == 'C') | (u == 'G') | (u == 'T'));
+        d[j] = ok ? (uint8_t)(t ^ (t >> 1)) : (uint8_t)4;
+      }
+      at += len;
+    });
+  });
+  offsets_out[N] = B;
+  if (!out) return SHN_OK;
+  return shn_reads_create(ctx, codes_out, offsets_out, N, 0, SHN_ENC_CODES, out);
 }

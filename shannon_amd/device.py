@@ -5,7 +5,7 @@ from . import _lib
 
 ENC_ASCII, ENC_CODES = 0, 1
 ALPHA = "ACGT"
-ALPHA_BYTES = np.frombuffer(b"ACGT", dtype=np.uint8)
+ALPHA_BYTES = np.frombuffer(b"ACGTN", dtype=np.uint8)        # (code 4 = a base outside ACGT)
 
 
 class Context(object):
@@ -61,6 +61,37 @@ class Context(object):
             pass
 
 
+class RaggedCodes(object):
+    """Reads of different lengths as base codes (0..3, 4 = other) one after the other + offsets: what shn_reads_ingest_ragged
+    leaves on the host.  Indexes like a list of code arrays (ReadStore decodes them where text is needed)."""
+
+    def __init__(self, codes, off):
+        self.codes, self.off = codes, off
+
+    def __len__(self):
+        return len(self.off) - 1
+
+    def __getitem__(self, i):
+        return self.codes[int(self.off[i]):int(self.off[i + 1])]
+
+    @property
+    def total_bases(self):
+        return int(self.off[-1])
+
+    def take(self, idx):
+        """(codes of reads idx one after the other, their offsets uint64[len(idx) + 1])"""
+        idx = np.asarray(idx, dtype=np.int64)
+        starts = self.off[idx].astype(np.int64)
+        lens = (self.off[idx + 1] - self.off[idx]).astype(np.int64)
+        o = np.zeros(len(idx) + 1, dtype=np.uint64)
+        o[1:] = np.cumsum(lens, dtype=np.uint64)
+        total = int(o[-1])
+        if not total:
+            return np.zeros(1, np.uint8), o
+        src = np.arange(total, dtype=np.int64) + np.repeat(starts - o[:-1].astype(np.int64), lens)
+        return np.ascontiguousarray(self.codes[src]), o
+
+
 class Reads(object):
     """A set of reads packed 2 bits/base in HBM (+1 bit/base non-ACGT mask)."""
 
@@ -90,8 +121,9 @@ class Reads(object):
     @classmethod
     def ingest(cls, ctx, source, fmt=0, want_codes=True):
         """A read file (path, .gz too; or its text as bytes / a uint8 array) through shn_reads_ingest: (Reads, code matrix or
-        None).  2-line FASTA or 4-line FASTQ with reads of one length; anything else raises ShannonError("... unsupported ...")
-        and the caller reads the file record by record."""
+        None) for reads of one length, (Reads, RaggedCodes or None) for reads of different lengths (shn_reads_ingest_ragged).
+        2-line FASTA or 4-line FASTQ; anything else (multi-line FASTA, a malformed record) raises ShannonError("... unsupported
+        ...") and the caller reads the file record by record."""
         if isinstance(source, str):
             if source.endswith(".gz"):
                 import gzip
@@ -107,10 +139,28 @@ class Reads(object):
         # the code matrix is smaller than the text: room for the text's size is enough (pages never written stay untouched)
         buf = np.empty(max(len(text), 1), dtype=np.uint8) if want_codes else None
         h = C.c_void_p()
-        _lib.check(_lib.lib().shn_reads_ingest(ctx.h if ctx is not None else None, ptr, len(text), int(fmt), buf.ctypes.data if want_codes else None,
-                                               len(buf) if want_codes else 0, C.byref(n), C.byref(L), C.byref(h) if ctx is not None else None))
+        try:
+            _lib.check(_lib.lib().shn_reads_ingest(ctx.h if ctx is not None else None, ptr, len(text), int(fmt), buf.ctypes.data if want_codes else None,
+                                                   len(buf) if want_codes else 0, C.byref(n), C.byref(L), C.byref(h) if ctx is not None else None))
+        except _lib.ShannonError as ex:
+            if "reads of different lengths" not in str(ex):
+                raise
+            return cls._ingest_ragged(ctx, text, fmt)
         codes = buf[:n.value * L.value].reshape(n.value, L.value) if want_codes else None
         return (cls(ctx, h) if ctx is not None else None), codes
+
+    @classmethod
+    def _ingest_ragged(cls, ctx, text, fmt):
+        n, mx, tot = C.c_uint64(), C.c_uint32(), C.c_uint64()
+        ptr = text.ctypes.data if len(text) else None
+        L = _lib.lib()
+        _lib.check(L.shn_reads_ingest_ragged(None, ptr, len(text), int(fmt), None, 0, None, 0, C.byref(n), C.byref(mx), C.byref(tot), None))       # scan: sizes
+        codes = np.empty(max(tot.value, 1), dtype=np.uint8)
+        off = np.empty(n.value + 1, dtype=np.uint64)
+        h = C.c_void_p()
+        _lib.check(L.shn_reads_ingest_ragged(ctx.h if ctx is not None else None, ptr, len(text), int(fmt), codes.ctypes.data, len(codes), off.ctypes.data,
+                                             len(off), C.byref(n), C.byref(mx), C.byref(tot), C.byref(h) if ctx is not None else None))
+        return (cls(ctx, h) if ctx is not None else None), RaggedCodes(codes[:tot.value], off)
 
     def __len__(self):
         return int(_lib.lib().shn_reads_count(self.h))

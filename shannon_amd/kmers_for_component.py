@@ -490,7 +490,36 @@ class ReadStore(object):
         s = src[i]
         if isinstance(s, str):
             return s
-        return device.ALPHA_BYTES[s].tobytes().decode()
+        return device.ALPHA_BYTES[np.minimum(s, 4)].tobytes().decode()
+
+    @property
+    def ragged(self):
+        """the reads are device.RaggedCodes (reads of different lengths from shn_reads_ingest_ragged)"""
+        return isinstance(self.r1, device.RaggedCodes)
+
+    def _gather_ragged(self, idx, mate, ss):
+        """gather_codes / gather_codes_ss over RaggedCodes: the reads' codes as stored, one after the other, + offsets + rc flags"""
+        idx = np.asarray(idx, dtype=np.int64)
+        n = self.n
+        if ss:
+            src = self.r1 if mate == 1 else self.r2
+            buf, off = src.take(idx)
+            return buf, off, np.full(len(idx), 1 if mate == 2 else 0, dtype=np.uint8), 1
+        second = idx >= n
+        src2 = self.r1 if self.r2 is None else self.r2
+        if len(idx) < 2 or bool((idx[1:] >= idx[:-1]).all()):          # ascending (how the routes come): forward half, then RC half
+            f = int(np.searchsorted(idx, n))
+            b1, o1 = self.r1.take(idx[:f])
+            b2, o2 = src2.take(idx[f:] - n)
+            buf = np.concatenate([b1[:int(o1[-1])], b2[:int(o2[-1])]]) if (int(o1[-1]) + int(o2[-1])) else np.zeros(1, np.uint8)
+            off = np.concatenate([o1, o2[1:] + o1[-1]])
+        else:
+            parts = [(src2 if s2 else self.r1)[int(d - n if s2 else d)] for d, s2 in zip(idx.tolist(), second.tolist())]
+            off = np.zeros(len(parts) + 1, dtype=np.uint64)
+            off[1:] = np.cumsum([len(x) for x in parts], dtype=np.uint64)
+            buf = np.concatenate(parts) if parts else np.zeros(1, np.uint8)
+        rc = second if (self.r2 is None or mate == 1) else ~second
+        return np.ascontiguousarray(buf), off, np.ascontiguousarray(rc, dtype=np.uint8), 1
 
     @staticmethod
     def _rc(s):
@@ -501,6 +530,8 @@ class ReadStore(object):
         stored, mate 2 = RC(reads_2[i]) (rows as stored + the rc flag set)."""
         idx = np.asarray(idx, dtype=np.int64)
         src = self.r1 if mate == 1 else self.r2
+        if self.ragged and len(idx):
+            return self._gather_ragged(idx, mate, True)
         if len(idx) == 0 or isinstance(src[0], str):
             seqs = [self._get(src, int(i)) for i in idx]
             if mate == 2:
@@ -520,6 +551,8 @@ class ReadStore(object):
         stored; the reverse complement is left to the consumer (shn_mbgraph_run's rc flags)."""
         idx = np.asarray(idx, dtype=np.int64)
         n = self.n
+        if self.ragged and len(idx):
+            return self._gather_ragged(idx, mate, False)
         if len(idx) == 0 or isinstance(self.r1[0], str):
             b, o = self.gather(idx, mate)
             return b, o, None, 0
@@ -553,7 +586,7 @@ class ReadStore(object):
         byte layout shn_mbgraph_run takes.  Vectorised for code matrices."""
         idx = np.asarray(idx, dtype=np.int64)
         n = self.n
-        if len(idx) and not isinstance(self.r1[0], str):
+        if len(idx) and not isinstance(self.r1[0], str) and not self.ragged:
             second = idx >= n
             i = np.where(second, idx - n, idx)
             if mate == 1:

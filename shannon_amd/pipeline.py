@@ -209,7 +209,7 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
                 # with GPU unitigs the k1-mer rows are only needed for a partition holding a cycle of condensable edges (built by
                 # the sequential code) and for the development check SHN_GRAPH_CHECK=1
                 rb = rows_now() if (unitigs is None or check_rows) else None
-                res_src = (d1, d2, np.asarray(idx, dtype=np.uint32)) if (enc == 1 and len(idx) and not ss) else None     # code matrices resident on the device
+                res_src = (d1, d2, np.asarray(idx, dtype=np.uint32)) if (enc == 1 and len(idx) and not ss and not getattr(store, "ragged", False)) else None     # code matrices resident on the device
                 try:
                     gh = mbgraph_native.run_partition_handle(None if rb is None else (rb if len(rb) else np.zeros(1, np.uint8)),
                                                              0 if rb is None else len(rb) // (K + 1), K, b1, o1, b2, o2, ctx=ctx_b,

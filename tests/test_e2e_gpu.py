@@ -86,6 +86,8 @@ def test_cli_config1_samples_se(tmp_path):
     assert got == ref["final"]
     g = load_case("se_K25")
     assert (out / "TEMP" / "OUT_algo_input" / "k1mer.dict_contig").read_text().split() == g["contigs"]
+    # reads of 48-51 bases: the device ingest takes them as codes + offsets (shn_reads_ingest_ragged), no Python read loop
+    assert "through the device ingest" in (out / "log.txt").read_text()
     # a second run into the same non-empty directory is refused, as in shannon.py:255-257
     p = subprocess.run([sys.executable, os.path.join(ROOT, "shannon.py"), "-o", str(out), "--single", str(fa)],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
@@ -138,7 +140,8 @@ def test_cli_samples_pe(tmp_path):
     assert got == ref["final"] and len(got) > 0
     g = load_case("pe_K25")
     assert (out / "TEMP" / "OUTPE_algo_input" / "k1mer.dict_contig").read_text().split() == g["contigs"]
-    assert (out / "log.txt").exists()
+    # the files went through the device ingest although 1,098 / 1,552 of their reads hold an N (kept and marked, not refused)
+    assert "through the device ingest" in (out / "log.txt").read_text()
 
 
 @pytest.mark.parametrize("K", [25, 31])

@@ -28,3 +28,25 @@ def test_ingested_reads_count_like_uploaded_ones(monkeypatch, fastq):
         assert a.total == b.total and np.array_equal(ka, kb) and np.array_equal(ca, cb)
         a.close(); b.close()
     d.close(); ref.close(); ctx.close()
+
+
+def test_ragged_reads_with_n_through_the_device_ingest_count_like_uploaded_strings():
+    """reads of different lengths with bases outside ACGT (shn_reads_ingest_ragged): the packed set counts like the same reads
+    uploaded as strings, and the reference's own Samples/SE_read.fasta (48-51 bases per read) goes through it"""
+    import gzip, os
+    from golden_util import GOLD
+    from test_ingest import make_ragged
+    ctx = device.Context(0)
+    try:
+        text, reads = make_ragged(4000, seed=8)
+        d, rc = device.Reads.ingest(ctx, (text + "\n").encode())
+        assert isinstance(rc, device.RaggedCodes) and len(d) == 4000 and d.n_invalid == sum(1 for r in reads if set(r.upper()) - set("ACGT"))
+        want = device.count_k1mers(ctx, [device.Reads.from_strings(ctx, reads)], 21, True)
+        got = device.count_k1mers(ctx, [d], 21, True)
+        assert got.dump(lower=1)[0].tolist() == want.dump(lower=1)[0].tolist() and got.total == want.total and len(got) > 100
+        with gzip.open(os.path.join(GOLD, "data", "SE_read.fasta.gz"), "rb") as f:
+            se = f.read()
+        d2, rc2 = device.Reads.ingest(ctx, se)
+        assert isinstance(rc2, device.RaggedCodes) and len(d2) == 6995 and 48 <= d2.max_len <= 51
+    finally:
+        ctx.close()
