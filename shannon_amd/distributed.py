@@ -90,12 +90,19 @@ class _NoLock(object):
 
 
 def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0, part_vectors=None, group=None,
-                         timings=None, lock=None):
+                         timings=None, lock=None, double_stranded=True):
     """Returns on rank 0 a dict {partitions: {name: fasta}, final, contigs, ...}; None elsewhere.
+    double_stranded=False (-s / --ss / --strand_specific, shannon.py:407-411) is NOT available on the N-rank path: its read
+    numbering, the per-partition cap and the exchange of the capped reads are all built on the strand-doubled order of the default
+    mode; a strand-specific run is a one-GPU run (pipeline.assemble / shannon.py).  Asking for it raises instead of quietly
+    assembling double-stranded.
     timings: seconds per stage, compute ("count", "extension", ...) and collectives ("x:...") apart.
     lock (development aid): held while this rank computes, released around every collective -- with several ranks on
     ONE GPU it serialises the compute, so the per-stage compute times are those of a rank that has a GPU to itself."""
     import time
+    if not double_stranded:
+        raise NotImplementedError("assemble_distributed: -s / --strand_specific runs are not sharded over ranks (the N-rank path is built on "
+                                  "the strand-doubled read order); run them on one GPU (pipeline.assemble, shannon.py)")
     T = timings if timings is not None else {}
     lock = lock or _NoLock()
     ops.lock = lock

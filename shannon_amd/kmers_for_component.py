@@ -2,8 +2,9 @@
 kmers_for_component.py (rows a8-a11) over the HIP routing kernel (csrc/route.hip).
 
 gpmetis (METIS 5, external, unpinned) is replaced by `partition_graph` below: a deterministic
-greedy graph-growing k-way partitioner honouring the same balance bound (ufactor).  Its output
-is not METIS's -- partitioned configurations are parity-checked given the same partition vector.
+multilevel k-way partitioner (heavy-edge-matching coarsening, greedy growing on the coarsest graph,
+boundary refinement on every level) honouring the same balance bound (ufactor).  Its output is not
+METIS's -- partitioned configurations are parity-checked given the same partition vector.
 """
 import ctypes as C
 import math
@@ -28,14 +29,25 @@ def parse_metis(text):
 
 
 def partition_graph(metis_text, n_parts, ufactor=1000):
-    """Deterministic stand-in for `gpmetis -ufactor=U graph P` (kmers_for_component.py:221,234):
-    grow parts one at a time from the lowest-numbered free vertex, always absorbing the free
-    vertex with the largest total edge weight into the growing part (ties: lowest index), up to
-    ceil(n/P) vertices; leftovers go to the lightest part.  Balance: every part <= (1+U/1000)*n/P."""
+    """Deterministic stand-in for `gpmetis -ufactor=U graph P` (kmers_for_component.py:221,234), built like METIS itself -- a
+    multilevel k-way scheme: (1) coarsening by heavy-edge matching (vertices in index order, each unmatched vertex pairs with the
+    unmatched neighbour behind its heaviest edge; matched pairs become one vertex, parallel edges add up) until the graph is small;
+    (2) an initial partition of the coarsest graph by greedy graph growing on vertex weights; (3) projection back level by level,
+    with a k-way boundary refinement on every level.  Balance: every part holds at most (1 + U/1000) * n / P vertices.  The output
+    is not METIS's digit for digit (gpmetis is external, randomised and unpinned: parity cases replay a given partition vector);
+    on planted partitions it ends within a few per cent of the planted cut (tests/test_host_graph.py)."""
     adj = parse_metis(metis_text)
+    return multilevel_partition(adj, n_parts, ufactor)
+
+
+def _grow_partition(adj, vw, n_parts):
+    """greedy graph growing on vertex weights: parts one at a time from the lowest-numbered free vertex, always absorbing the free
+    vertex with the largest total edge weight into the growing part (ties: lowest index), up to ceil(W / P) weight; leftovers go
+    to the lightest part"""
     n = len(adj)
     part = [-1] * n
-    target = int(math.ceil(n / float(n_parts)))
+    total = sum(vw)
+    target = int(math.ceil(total / float(n_parts)))
     nxt = 0
     sizes = [0] * n_parts
     for p in range(n_parts):
@@ -48,7 +60,7 @@ def partition_graph(metis_text, n_parts, ufactor=1000):
             v = min(gain, key=lambda x: (-gain[x], x))
             del gain[v]
             part[v] = p
-            sizes[p] += 1
+            sizes[p] += vw[v]
             for u, w in adj[v]:
                 if part[u] == -1:
                     gain[u] = gain.get(u, 0) + w
@@ -61,8 +73,73 @@ def partition_graph(metis_text, n_parts, ufactor=1000):
         if part[v] == -1:
             p = min(range(n_parts), key=lambda q: (sizes[q], q))
             part[v] = p
-            sizes[p] += 1
-    return refine_partition(adj, part, n_parts, ufactor)
+            sizes[p] += vw[v]
+    return part
+
+
+def multilevel_partition(adj, n_parts, ufactor=1000, coarse_min=None):
+    n = len(adj)
+    if n_parts <= 1 or n == 0:
+        return [0] * n
+    levels = []                                   # (adjacency, vertex weights, map to the next coarser level)
+    cur, vw = adj, [1] * n
+    stop = coarse_min if coarse_min is not None else max(20 * n_parts, 64)
+    max_vw = max(1, int(1.5 * n / float(stop)))   # (no coarse vertex heavier than that: the initial partition must still balance)
+    while len(cur) > stop:
+        cadj, cvw, cmap = _coarsen_bounded(cur, vw, max_vw)
+        if len(cadj) > 0.95 * len(cur):           # (nothing left to match)
+            break
+        levels.append((cur, vw, cmap))
+        cur, vw = cadj, cvw
+    part = _grow_partition(cur, vw, n_parts)
+    part = refine_partition(cur, part, n_parts, ufactor, vw=vw, total=n)
+    for fine_adj, fine_vw, cmap in reversed(levels):
+        part = [part[cmap[v]] for v in range(len(fine_adj))]
+        part = refine_partition(fine_adj, part, n_parts, ufactor, vw=fine_vw, total=n)
+    # (a part the refinement emptied -- possible on tiny graphs -- takes the lightest boundary vertex of the largest part back)
+    sizes = [0] * n_parts
+    for p in part:
+        sizes[p] += 1
+    for q in range(n_parts):
+        if sizes[q] == 0:
+            big = max(range(n_parts), key=lambda x: (sizes[x], -x))
+            v = next(i for i in range(n) if part[i] == big)
+            part[v] = q
+            sizes[big] -= 1
+            sizes[q] += 1
+    return part
+
+
+def _coarsen_bounded(adj, vw, max_vw):
+    """_coarsen, with pairs heavier than max_vw left unmatched"""
+    n = len(adj)
+    match = [-1] * n
+    cmap = [-1] * n
+    nc = 0
+    for v in range(n):
+        if match[v] != -1:
+            continue
+        best, bw = -1, -1
+        for u, w in adj[v]:
+            if u != v and match[u] == -1 and vw[u] + vw[v] <= max_vw and (w > bw or (w == bw and u < best)):
+                best, bw = u, w
+        match[v] = best if best >= 0 else v
+        cmap[v] = nc
+        if best >= 0:
+            match[best] = v
+            cmap[best] = nc
+        nc += 1
+    cvw = [0] * nc
+    cadj = [dict() for _ in range(nc)]
+    for v in range(n):
+        cv = cmap[v]
+        cvw[cv] += vw[v]
+        d = cadj[cv]
+        for u, w in adj[v]:
+            cu = cmap[u]
+            if cu != cv:
+                d[cu] = d.get(cu, 0) + w
+    return [sorted(d.items()) for d in cadj], cvw, cmap
 
 
 def edge_cut(adj, part):
@@ -70,23 +147,28 @@ def edge_cut(adj, part):
     return sum(w for v, nb in enumerate(adj) for u, w in nb if u > v and part[u] != part[v])
 
 
-def refine_partition(adj, part, n_parts, ufactor=1000, max_passes=16):
-    """k-way boundary refinement of a partition (the last phase of the multilevel scheme gpmetis runs): vertices in index order, a
-    vertex moves to the neighbouring part it is connected to most strongly if that lowers the cut, the target stays within the
-    balance bound (1 + U/1000) * n / P and its own part does not become empty; passes until nothing moves.  Every move lowers the
-    cut, so it ends; deterministic.  On graphs with a planted partition the cut of the grown partition falls by 20-38 % and ends
-    within 0-45 % of the planted cut (tests/test_host_graph.py::test_own_partitioner_cut_quality)."""
+def refine_partition(adj, part, n_parts, ufactor=1000, max_passes=16, vw=None, total=None):
+    """k-way boundary refinement of a partition (the uncoarsening phase of the multilevel scheme gpmetis runs): vertices in index
+    order, a vertex moves to the neighbouring part it is connected to most strongly if that lowers the cut, the target stays within
+    the balance bound (1 + U/1000) * n / P (in vertex weight: vw, on the coarse levels) and its own part does not become empty;
+    passes until nothing moves.  Every move lowers the cut, so it ends; deterministic."""
     n = len(adj)
     part = list(part)
+    if vw is None:
+        vw = [1] * n
+    if total is None:
+        total = sum(vw)
     sizes = [0] * n_parts
-    for p in part:
-        sizes[p] += 1
-    max_size = max(int(math.ceil(n / float(n_parts))), int((1.0 + ufactor / 1000.0) * n / float(n_parts)))
+    cnt = [0] * n_parts
+    for v, p in enumerate(part):
+        sizes[p] += vw[v]
+        cnt[p] += 1
+    max_size = max(int(math.ceil(total / float(n_parts))), int((1.0 + ufactor / 1000.0) * total / float(n_parts)))
     for _ in range(max_passes):
         moved = 0
         for v in range(n):
             pv = part[v]
-            if sizes[pv] <= 1 or not adj[v]:
+            if cnt[pv] <= 1 or not adj[v]:
                 continue
             conn = {}
             for u, w in adj[v]:
@@ -95,12 +177,14 @@ def refine_partition(adj, part, n_parts, ufactor=1000, max_passes=16):
             own = conn.get(pv, 0)
             best, bw = -1, own
             for q in sorted(conn):
-                if q != pv and conn[q] > bw and sizes[q] < max_size:
+                if q != pv and conn[q] > bw and sizes[q] + vw[v] <= max_size:
                     best, bw = q, conn[q]
             if best >= 0:
                 part[v] = best
-                sizes[pv] -= 1
-                sizes[best] += 1
+                sizes[pv] -= vw[v]
+                sizes[best] += vw[v]
+                cnt[pv] -= 1
+                cnt[best] += 1
                 moved += 1
         if not moved:
             break

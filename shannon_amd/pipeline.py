@@ -192,6 +192,7 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
                 if ss:
                     b1, o1, rc1, enc = store.gather_codes_ss(idx, 1)
                     b2, o2, rc2, _e = store.gather_codes_ss(idx, 2) if paired else (None, None, None, enc)
+                    assert _e == enc, "both mates' reads must be stored the same way (strings, code matrices or codes + offsets)"
                 else:
                     b1, o1, rc1, enc = store.gather_codes(idx, 1)
                 if ss:

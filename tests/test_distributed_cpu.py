@@ -80,3 +80,10 @@ def test_read_pieces_travel_as_bytes():
         assert np.array_equal(g, g2) and np.array_equal(rows, rows2) and np.array_equal(rc, rc2) and rows2.shape == rows.shape
     assert exchange.unpack_read_pieces(exchange.pack_read_pieces([])) == []
     assert exchange.unpack_read_pieces(np.zeros(0, np.uint8)) == []
+
+
+def test_strand_specific_is_refused_on_the_n_rank_path():
+    """-s / --ss is a one-GPU mode: the N-rank path says so instead of assembling double-stranded"""
+    from shannon_amd import distributed
+    with pytest.raises(NotImplementedError, match="strand_specific"):
+        distributed.assemble_distributed(object(), double_stranded=False)

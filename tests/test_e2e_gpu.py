@@ -279,3 +279,39 @@ def test_end_to_end_on_a_minimizer_bucketed_table(ctx, name, monkeypatch):
     for p in R.partitions:
         cmp_fasta(R.partitions[p]["reconstructed_fasta"], O["partitions"][p]["reconstructed_fasta"])
     assert R.final == O["final"]
+
+
+def test_own_partitioner_through_the_pipeline(ctx):
+    """a8 with the partition COMPUTED (no gpmetis output to replay): 60 genes sharing three repeated elements give two contig
+    components of ~120 contigs (the strands' twins); with --partition 10 they go through the product's multilevel partitioner, twice
+    (the second time on the penalised graph, kmers_for_component.py:207-237).  The oracle pipeline given exactly those partition
+    vectors produces the same partitions, transcripts and final file -- and every part is non-empty and within gpmetis' balance
+    bound."""
+    import numpy as np
+    from shannon_amd import pipeline, synth, kmers_for_component as kfc
+    from oracle import pipeline as opipe
+    rng = np.random.Generator(np.random.PCG64(17))
+    S = [rng.integers(0, 4, 120, dtype=np.uint8) for _ in range(3)]
+    iso = []
+    for i in range(60):
+        iso.append(np.concatenate([rng.integers(0, 4, int(rng.integers(200, 400)), dtype=np.uint8), S[i % 3],
+                                   rng.integers(0, 4, int(rng.integers(200, 400)), dtype=np.uint8),
+                                   S[(i + 1) % 3] if i % 4 == 0 else rng.integers(0, 4, 5, dtype=np.uint8), rng.integers(0, 4, 150, dtype=np.uint8)]))
+    r1, r2 = synth.sample_pairs(iso, 40000, 5, err=0.003)
+    A = np.frombuffer(b"ACGT", np.uint8)
+    s1, s2 = [A[r].tobytes().decode() for r in r1], [A[r].tobytes().decode() for r in r2]
+    psize = 10
+    R = pipeline.assemble(ctx, s1, s2, K=25, partition_size=psize, sample="s", seed=3)
+    big = R.extension.big_components
+    assert len(big) == 2 and min(len(c) for c, _m in big) > 100
+    pv = []
+    for contigs, metis in big:
+        P = kfc.n_partitions(len(contigs), psize)
+        p1 = kfc.partition_graph(metis, P, 1000)
+        pv.append((p1, kfc.partition_graph(kfc.weight_updated_graph(metis, p1, 5), P, 1000)))
+        assert set(p1) == set(range(P)) and max(np.bincount(p1)) <= 2.0 * len(contigs) / P + 1
+    O = opipe.assemble(s1, s2, K=25, partition_size=psize, sample="s", seed=3, part_vectors=pv)
+    assert list(R.partitions) == list(O["partitions"]) and sum(1 for p in R.partitions if p.startswith("r2_c")) >= 10
+    for p in R.partitions:
+        cmp_fasta(R.partitions[p]["reconstructed_fasta"], O["partitions"][p]["reconstructed_fasta"])
+    assert R.final == O["final"] and len(R.final) >= 40

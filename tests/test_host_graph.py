@@ -93,32 +93,37 @@ def test_own_partitioner_is_balanced_and_deterministic():
 
 def test_own_partitioner_cut_quality():
     """The gpmetis stand-in against what bounds it (a8: gpmetis itself is external and heuristic -- parity unpinned; this measures
-    the quality of the stand-in): on graphs with a planted partition (dense inside the groups, sparse between them, vertices in
-    random order) the edge cut of partition_graph is far below that of a random balanced partition and close to the planted one;
-    the refinement never raises the cut of the grown partition and the balance bound holds."""
+    the quality of the stand-in, a multilevel scheme like METIS's own): on graphs with a planted partition (dense inside the groups,
+    sparse between them, vertices in random order; up to 6,000 contigs in 12 parts) the edge cut of partition_graph is within 15 %
+    of the planted cut (the one-level greedy growth + refinement of rounds 1-3 ended 45 % above it at 1,000 vertices), far below a
+    random balanced partition's, the balance bound holds, and the refinement never raises the cut of what it is given."""
     import math
-    for seed, n, P, p_in, p_out in ((1, 400, 4, 0.06, 0.002), (2, 600, 6, 0.05, 0.003), (3, 1000, 10, 0.04, 0.001)):
+    for seed, n, P, p_in, p_out in ((1, 400, 4, 0.06, 0.002), (2, 600, 6, 0.05, 0.003), (3, 1000, 10, 0.04, 0.001), (4, 6000, 12, 0.012, 0.0002)):
         rng = np.random.default_rng(seed)
         group = rng.permutation(n) % P
+        M = rng.random((n, n))
+        E = np.triu(M < np.where(group[:, None] == group[None, :], p_in, p_out), 1)
+        ai, bi = np.nonzero(E)
+        ws = rng.integers(1, 9, len(ai))
         adj = [dict() for _ in range(n)]
-        for a in range(n):
-            for b in range(a + 1, n):
-                if rng.random() < (p_in if group[a] == group[b] else p_out):
-                    w = int(rng.integers(1, 9))
-                    adj[a][b] = w
-                    adj[b][a] = w
+        for a, b, w in zip(ai.tolist(), bi.tolist(), ws.tolist()):
+            adj[a][b] = w
+            adj[b][a] = w
         text = "%d\t%d\t001\n" % (n, sum(len(d) for d in adj) // 2) + "".join(
             "".join("%d\t%d\t" % (b + 1, w) for b, w in d.items()) + "\n" for d in adj)
         al = kfc.parse_metis(text)
         mine = kfc.partition_graph(text, P, 1000)
+        assert mine == kfc.partition_graph(text, P, 1000)                                   # deterministic
         cut = kfc.edge_cut(al, mine)
         planted = kfc.edge_cut(al, [int(g) for g in group])
         rnd = kfc.edge_cut(al, [int(x) for x in rng.permutation(n) % P])
-        total = kfc.edge_cut(al, list(range(n)))
         sizes = np.bincount(mine, minlength=P)
         assert sizes.sum() == n and sizes.min() >= 1 and sizes.max() <= 2.0 * n / P
-        assert cut <= 1.35 * planted + 0.02 * total, (seed, cut, planted, rnd, total)      # near the planted cut ...
-        assert cut <= 0.5 * rnd, (seed, cut, planted, rnd)                                 # ... and far below a random partition's
+        assert cut <= 1.15 * planted, (seed, cut, planted, rnd)                             # near the planted cut ...
+        assert cut <= 0.5 * rnd, (seed, cut, planted, rnd)                                  # ... and far below a random partition's
+        # the one-level scheme of rounds 1-3 (growth + refinement, no coarsening) is what the levels improve on
+        flat = kfc.edge_cut(al, kfc.refine_partition(al, kfc._grow_partition(al, [1] * n, P), P, 1000))
+        assert cut <= flat * 1.02, (seed, cut, flat)
         # the refinement only ever lowers the cut of what it is given
         assert kfc.edge_cut(al, kfc.refine_partition(al, [int(x) for x in rng.permutation(n) % P], P, 1000)) <= rnd
 

@@ -34,6 +34,7 @@ def test_ragged_reads_with_n_through_the_device_ingest_count_like_uploaded_strin
     """reads of different lengths with bases outside ACGT (shn_reads_ingest_ragged): the packed set counts like the same reads
     uploaded as strings, and the reference's own Samples/SE_read.fasta (48-51 bases per read) goes through it"""
     import gzip, os
+    from shannon_amd import device
     from golden_util import GOLD
     from test_ingest import make_ragged
     ctx = device.Context(0)
