@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # requests at 64 B, MI355X_MICROARCH.md HBM; profiles/r03_fetch_calibration.txt: on this chip EVERY read request the L2 sends to
 # memory is a 128-byte one, random 8-byte gathers included) + WRITE_SIZE.  Valid for the named workload only.
 TRAFFIC = {}
-for _cfg, _fn in (("1", "r01_traffic.json"), ("2", "r03_traffic_config2.json"), ("4s", "r03_traffic_config4s.json")):
+for _cfg, _fn in (("1", "r01_traffic.json"), ("2", "r04_traffic_config2.json"), ("4s", "r04_traffic_config4s.json")):
     try:
         TRAFFIC["config%s" % _cfg] = json.load(open(os.path.join(ROOT, "profiles", _fn)))["traffic_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
@@ -251,6 +251,118 @@ def native_front_baseline(k1, r1, r2, n_pairs):
                       "contigs; the graph / sparse-flow / merge stages are not in this figure (graph_stage_native_host_only has one partition)"
                       % (2 * n_pairs, t_count, t_ext, len(keys), len(seed), t_contig, int((np.asarray(acc) > 0).sum())),
             "seconds": {"count": t_count, "extension": t_ext, "contig stage": t_contig}}
+
+
+def cpu_whole_path_native(K, r1, r2, n_pairs):
+    """SURVEY 8d's CPU baseline: the WHOLE path a1-a31 on this box's host cores over the first n_pairs pairs of the batch, native
+    wherever a native host form exists, no device anywhere:
+      count          oracle/count_c.c (radix sort + run-length count; the reference's Jellyfish)                 one thread | T slices
+      extension      oracle/ext_c.c (the greedy walks in seed order; the reference's Python loop)                 one thread
+      contig stage   oracle/extension.py over those walks (accept filter, duplicate_check, contig graph, components: Python --
+                     no native host form of it takes walks)                                                        one thread
+      partitions     oracle/partition.py (bins of components), reads routed by its numpy form route_pairs_matrix  one thread
+      graph          shn_mbgraph_run(ctx = NULL) per partition: K-mer graph built and condensed sequentially, seeds matched on the
+                     host -- the reference's multibridging.main restated in C++                                   one thread | T threads
+      sparse flow    oracle/sparse_flow.py + oracle/lp.py over the exported tables (Python: the LP trials have no host form
+                     outside the oracle)                                                                            one thread
+      merge          shn_post_finalize_bufs (host C++)                                                             host threads
+    Returns the one-thread figure as `value` and the figure with the two stages that parallelise run on T threads."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import build_c, extension as oext, partition as opart, sparse_flow as osf
+    from shannon_amd import _lib, mbgraph_native, post, kmers_for_component as kfc
+    k1 = K + 1
+    a1, a2 = np.ascontiguousarray(r1[:n_pairs]), np.ascontiguousarray(r2[:n_pairs])
+    sec = {}
+    t = time.time()
+    codes = np.concatenate([a1, a2])
+    keys, cnts, nw = build_c.count_canonical(codes, k1, True)
+    sec["count"] = time.time() - t
+    t = time.time()
+    walks = build_c.extend(keys, cnts, k1, 3)
+    sec["extension"] = time.time() - t
+    t = time.time()
+    code = np.zeros(256, np.uint64)
+    for i, ch in enumerate(b"ACGT"):
+        code[ch] = i
+    pw = (np.uint64(4) ** np.arange(k1 - 1, -1, -1, dtype=np.uint64)).astype(np.uint64)
+    items = {}
+    for contig, _w, _n in walks:                     # the dictionary run_correction reads when the walks are given: the k1-mers of acceptable walks
+        if len(contig) < 75:
+            continue
+        c = code[np.frombuffer(contig.encode(), np.uint8)]
+        fw = np.lib.stride_tricks.sliding_window_view(c, k1) @ pw
+        rv = np.lib.stride_tricks.sliding_window_view(np.uint64(3) - c, k1) @ pw[::-1]
+        for i, w in enumerate(cnts[np.searchsorted(keys, np.minimum(fw, rv))].tolist()):
+            items[contig[i:i + k1]] = w
+    res = oext.run_correction(sorted(items.items(), reverse=True), walks=walks)
+    sec["contig stage"] = time.time() - t
+    t = time.time()
+    pv = []
+    for contigs, metis in res.big_components:
+        P = kfc.n_partitions(len(contigs), 500)
+        p1 = kfc.partition_graph(metis, P, 1000)
+        pv.append((p1, kfc.partition_graph(kfc.weight_updated_graph(metis, p1, 5), P, 1000)))
+    nc, _k2c = opart.build_partitions([b[0] for b in res.big_components], [p[0] for p in pv], [p[1] for p in pv] if pv else None, res.remaining, res.allowed, K)
+    routes = opart.route_pairs_matrix(a1, a2, nc, K)
+    sec["partition+route"] = time.time() - t
+    store = kfc.ReadStore(a1, a2)
+    names = [nm for nm in nc]
+
+    def graph_of(nm):
+        rows = kfc._rows_bytes(nc[nm], k1)
+        n_rows = len(rows) // k1
+        kk = np.unique(np.concatenate([np.lib.stride_tricks.sliding_window_view(code[np.frombuffer(c.encode(), np.uint8)], K) @ pw[1:] for c in nc[nm] if len(c) >= K])) if nc[nm] else np.zeros(0)
+        idx = routes[nm][:10 * len(kk) + 1]                             # multibridging.py:26-30
+        b1, o1, rc1, enc = store.gather_codes(idx, 1)
+        g = mbgraph_native.run_partition_handle(rows if n_rows else np.zeros(1, np.uint8), n_rows, K, b1, o1, b1, o1, ctx=None, enc=enc, rc1=rc1,
+                                                rc2=(1 - rc1).astype(np.uint8) if rc1 is not None else None)
+        tabs = g.tables()
+        g.close()
+        return tabs
+    t = time.time()
+    tables = [graph_of(nm) for nm in names]
+    sec["graph"] = time.time() - t
+    T = max(1, min(_lib.host_cpus(), 32))
+    t = time.time()
+    with ThreadPoolExecutor(max_workers=min(T, max(1, len(names)))) as pool:
+        list(pool.map(graph_of, names))
+    graph_T = time.time() - t
+    t = time.time()
+    texts = ["".join(">Single_%d\n%s\n" % (i, c) for i, c in enumerate(res.single_contigs))]
+    for nm, (singles, comps, _log) in zip(names, tables):
+        txt = ""
+        for c, comp in enumerate(comps):
+            txt += osf.fasta_records("cpu_%s" % nm, str(c), osf.sparse_flow_component(comp["nodes"], comp["edges"], comp["paths"], seed=1, comp_id=c))
+        texts.append(txt + osf.single_nodes_fasta("cpu_%s" % nm, singles))
+    sec["sparse flow"] = time.time() - t
+    t = time.time()
+    final = post.finalize_texts(texts, True)
+    sec["merge"] = time.time() - t
+    # counting on T threads: T slices of the sample, one C call each (no merge of the slice tables: an upper bound of what T cores give)
+    per = max(1, n_pairs // T)
+    slices = [np.concatenate([a1[i * per:(i + 1) * per], a2[i * per:(i + 1) * per]]) for i in range(T) if (i + 1) * per <= n_pairs]
+    t = time.time()
+    with ThreadPoolExecutor(max_workers=len(slices) or 1) as pool:
+        list(pool.map(lambda c: build_c.count_canonical(c, k1, True), slices))
+    count_T = time.time() - t
+    tot = sum(sec.values())
+    tot_T = tot - sec["count"] - sec["graph"] + count_T + graph_T
+    cpu = ""
+    try:
+        cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except (OSError, IndexError):
+        pass
+    return {"value": 2 * n_pairs / tot, "unit": "reads/s", "cores": 1, "kind": "port", "cpu_model": cpu, "host_threads_available": os.cpu_count(),
+            "host_cpus_allowed": _lib.host_cpus(),
+            "sample": "first %d reads of the benchmark batch through the whole path a1-a31 on the host, native where a native host form exists "
+                      "(oracle/count_c.c, oracle/ext_c.c, shn_mbgraph_run(ctx=NULL) for all %d partitions, shn_post_finalize_bufs; the contig "
+                      "stage, partitions / routing (numpy) and the sparse flow + LP trials through oracle/*.py): %d distinct k1-mers, %d walks, %d "
+                      "contigs, %d routed pairs, %d transcripts, %.1f s on one thread"
+                      % (2 * n_pairs, len(names), len(keys), len(walks), len(res.contigs), sum(len(v) for v in routes.values()), len(final), tot),
+            "seconds": {k: round(v, 3) for k, v in sec.items()},
+            "threads": {"value": 2 * n_pairs / tot_T, "unit": "reads/s", "cores": T,
+                        "sample": "the same with the two stages that parallelise on %d threads: counting as %d slices (%.2f s, tables unmerged) and the "
+                                  "graph stage one partition per thread (%.2f s); the other stages are sequential in the reference too" % (T, len(slices), count_T, graph_T)}}
 
 
 def cpu_baseline(k1, r1, r2, n_pairs):
@@ -560,10 +672,18 @@ def main():
         KERNEL = {"count.direct": "count_direct_kernel", "count.hist1": "hist1_kernel", "count.scatter1": "scatter1_kernel", "count.hist2": "hist_keys_kernel",
                   "count.scatter2": "scatter_keys_kernel", "count.buckets": "buckets_kernel", "route": "route_kernel",
                   "extend.walk_thread": "ext_walk_kernel", "extend.walk_wave": "ext_walk_long_kernel", "extend.mark": "ext_mark_kernel",
-                  "extend.adjacency": "ext_records_kernel"}
+                  "extend.adjacency": "ext_records_kernel",
+                  # the super-k-mer counting path (csrc/count_sk.hip)
+                  "count.sk_emit": "sk_scan_kernel", "count.sk_hist": "skr_hist_kernel + skr_scatter_kernel (level 1)", "count.sk_hist2": "skr_hist_kernel",
+                  "count.sk_scatter2": "skr_scatter_kernel", "count.sk_buckets": "sk_buckets_sorted_kernel"}
+        # records of the super-k-mer path: a read of W windows makes ~2 W / (w + 1) + 1 records of 16 bytes (w = k1 - m + 1 m-mers per window, m = 13)
+        sk_w = k1 - max(13, 2 * k1 - 48) + 1
+        rec_bytes = 16.0 * (2.0 * W / (sk_w + 1) + 1.0)
         per_read = {"count.direct": 25.0 + 12.0 * distinct / max(1, n_reads),    # packed read in, (key, count) of the distinct k1-mers out
                     "count.hist1": 25.0, "count.scatter1": 25.0 + 8.0 * W, "count.hist2": 8.0 * W,
-                    "count.scatter2": 16.0 * W, "count.buckets": 8.0 * W, "route": 192.0}
+                    "count.scatter2": 16.0 * W, "count.buckets": 8.0 * W, "route": 192.0,
+                    "count.sk_emit": 25.0 + rec_bytes, "count.sk_hist": 2.0 * rec_bytes, "count.sk_hist2": rec_bytes, "count.sk_scatter2": 2.0 * rec_bytes,
+                    "count.sk_buckets": rec_bytes + 12.0 * distinct / max(1, n_reads)}
         ext = last.res["extension"] if use_dist else {k: getattr(last.R.extension, k, None) for k in ("iterations", "n_walks", "total_steps", "wave_steps", "dense_rounds")}
         steps_all = ext["total_steps"] or 0
         steps_wave = ext["wave_steps"] or 0
@@ -662,6 +782,12 @@ def main():
             "roofline": r_dom,
             "roofline_bandwidth_kernel": r_bw,
             "roofline_e2e": roofline_e2e,
+            # the counting stage as a whole on SURVEY 8d's counting bytes (read the packed read once, emit every k1-mer key once and read
+            # it once: 25 + 16 W bytes per read), time = the stage's event timer
+            "roofline_count_stage": ({"bound": "hbm", "timer": "count.total", "algorithmic_bytes_per_read": 25.0 + 16.0 * W,
+                                      "achieved": (25.0 + 16.0 * W) * n_reads / (timers["count.total"][0] / args.steps * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                      "unit": "GB/s", "frac": (25.0 + 16.0 * W) * n_reads / (timers["count.total"][0] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "ms_per_step": timers["count.total"][0] / args.steps} if "count.total" in timers else None),
             "kernel_table": kernel_table,
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(timers.items())},
             "kernel_launches_per_step": {k: v[1] / args.steps for k, v in sorted(timers.items())},
@@ -678,10 +804,10 @@ def main():
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 of the N=1 run only
             # bounded sample: ~10-15 s of one core through the whole path (at configs[2] a read costs the pure-Python path ~5x more
             # than at configs[1]: nearly every k1-mer of a 25k-read sample is new), + ~5 s for the counting stage alone / threaded
-            out["cpu_baseline"] = cpu_baseline(k1, r1, r2, 75_000 if args.config == "1" else 12_500)
-            out["cpu_baseline"]["native_front_one_core"] = native_front_baseline(k1, r1, r2, min(len(r1), 250_000))      # (0.5 M reads: ~20 s of one core)
-            if not use_dist:
-                out["cpu_baseline"]["graph_stage_native_host_only"] = native_graph_baseline(last.R, store, args.K)
+            # ~25 s of host work: 1 M reads through the whole path, native where a native host form exists
+            out["cpu_baseline"] = cpu_whole_path_native(args.K, r1, r2, min(len(r1), 500_000))
+            # the pure-Python port (oracle/pipeline.py: pure Python like Shannon itself) on a small sample, for scale
+            out["cpu_baseline"]["python_port"] = cpu_baseline(k1, r1, r2, 25_000 if args.config == "1" else 6_000)
         final_line = json.dumps(out)
     else:
         final_line = None

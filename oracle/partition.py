@@ -126,3 +126,65 @@ def partition_k1mers(new_components, k2c, K):
         files[comp] = rows
         cw[comp] = ws
     return files, cw
+
+
+def route_pairs_matrix(r1, r2, new_components, K):
+    """route_reads_paired over equal-length reads held as code matrices (uint8 [n, L], values 0..3; anything else = a base outside
+    ACGT: the pair is dropped, :376), vectorised: the strand-doubled pair d is (R1[d], RC(R2'[d]))... exactly the files of
+    shannon.py:413-424 -- mate 1 of pair d < n is R1[d], of pair d >= n it is RC(R2[d - n]); mate 2 is RC(R1[d]) / R2[d - n] -- and
+    the probes of a mate are its k1-windows at 0, k1, 2 k1, ... and its last one (get_rmers).  Returns {comp: ascending doubled
+    indices of the pairs routed to it} -- the same pairs, in the same (file) order, as route_reads_paired gives as strings
+    (tests/test_oracle_c.py)."""
+    import numpy as np
+    k1 = K + 1
+    n, L = r1.shape
+    names = list(new_components)
+    pw = (np.uint64(4) ** np.arange(k1 - 1, -1, -1, dtype=np.uint64)).astype(np.uint64)
+    keys, owner = [], []
+    code = np.zeros(256, np.uint64)
+    for i, ch in enumerate(b"ACGT"):
+        code[ch] = i
+    for ci, comp in enumerate(names):
+        for contig in new_components[comp]:
+            if len(contig) >= k1:
+                c = code[np.frombuffer(contig.encode(), np.uint8)]
+                kk = np.lib.stride_tricks.sliding_window_view(c, k1) @ pw
+                keys.append(kk)
+                owner.append(np.full(len(kk), ci, np.int64))
+    out = {c: np.zeros(0, np.int64) for c in names}
+    if not keys or L < k1:
+        return out
+    keys, owner = np.concatenate(keys), np.concatenate(owner)
+    o = np.argsort(keys, kind="stable")
+    keys, owner = keys[o], owner[o]
+    starts = list(range(0, L - k1, k1)) + [L - k1]                      # get_rmers: while i < len - R, then the last
+    # (the strand-doubled pair d < n is R1[d] with its own reverse complement, pair n + i is RC(R2[i]) with R2[i]: a base outside
+    # ACGT drops the pairs made of THAT read)
+    hits = []                                                            # (doubled index, comp) of every probe that hits
+    for mat, fwd_base, rc_base in ((r1, 0, n), (r2, n, 0)):             # a forward probe of R1[i] belongs to pair i (mate 1), a probe of RC(R1[i]) to pair i too (mate 2);
+        m64 = np.minimum(mat, 3).astype(np.uint64)                      # of R2[i]: forward -> pair n + i (mate 2), RC -> pair n + i (mate 1)
+        good = (mat < 4).all(axis=1)
+        for p in starts:
+            fw = m64[:, p:p + k1] @ pw
+            q = L - k1 - p                                               # RC(read)[p : p + k1] = rc(read[q : q + k1])
+            rv = (np.uint64(3) - m64[:, q:q + k1]) @ pw[::-1]
+            for kk in (fw, rv):
+                pos = np.searchsorted(keys, kk)
+                pos2 = np.minimum(pos, len(keys) - 1)
+                hit = (keys[pos2] == kk) & good
+                idx = np.nonzero(hit)[0]
+                # a k1-mer may lie in several partitions (the r2_ round): all the entries with this key
+                while len(idx):
+                    hits.append(np.stack([idx + (fwd_base if mat is r1 else n), owner[pos2[idx]]], axis=1))
+                    pos2 = pos2.copy()
+                    nxt = pos2[idx] + 1
+                    ok = (nxt < len(keys))
+                    ok[ok] &= keys[nxt[ok]] == kk[idx[ok]]
+                    idx = idx[ok]
+                    pos2[idx] = nxt[ok]
+    if not hits:
+        return out
+    h = np.unique(np.concatenate(hits), axis=0)
+    for ci, comp in enumerate(names):
+        out[comp] = np.sort(h[h[:, 1] == ci, 0])
+    return out

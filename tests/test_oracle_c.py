@@ -86,3 +86,32 @@ def test_oracle_front_over_c_walks_equals_the_python_oracle():
     w1, w2 = partition.route_reads_paired(dbl[0], dbl[1], nc2, k2c2, K)
     assert o1 == w1 and o2 == w2
     assert files == partition.partition_k1mers(nc2, k2c2, K)[0]
+
+
+def test_vectorised_routing_equals_the_python_routing():
+    """oracle.partition.route_pairs_matrix (numpy over code matrices: what bench.py's CPU baseline routes a million reads with)
+    against route_reads_paired over the strand-doubled strings: the same pairs in the same order, several partitions, k1-mers that
+    lie in two partitions, reads with a base outside ACGT"""
+    from shannon_amd import synth
+    from oracle import partition
+    from test_midsize_gpu import oracle_front
+    iso, _ = synth.make_transcriptome(30, 5)
+    r1, r2 = synth.sample_pairs(iso, 12000, 5)
+    ok, walks, res, pv, nc, o1, o2, files = oracle_front(r1, r2, 25)
+    r1 = r1.copy(); r2 = r2.copy()
+    r1[5, 7] = 4; r2[9, 3] = 4; r1[100, 99] = 4
+    A = np.frombuffer(b"ACGTN", np.uint8)
+    d1, d2 = seqs.double_strand_paired([A[r].tobytes().decode() for r in r1], [A[r].tobytes().decode() for r in r2])
+    # partitions of three contigs each, and every contig a second time in an "r2_" partition (k1-mers with two owners)
+    contigs = [c for lst in res.remaining for c in lst]
+    assert len(contigs) >= 12
+    big = [contigs]
+    parts = [[i // 3 for i in range(len(contigs))]]
+    parts2 = [[(i // 2) % 4 for i in range(len(contigs))]]
+    nc2, k2c2 = partition.build_partitions(big, parts, parts2, [], res.allowed, 25)
+    w1, w2 = partition.route_reads_paired(d1, d2, nc2, k2c2, 25)
+    got = partition.route_pairs_matrix(r1, r2, nc2, 25)
+    assert len(nc2) >= 8 and sum(len(v) for v in got.values()) > 10000
+    for c in nc2:
+        idx = got[c].tolist()
+        assert [d1[i] for i in idx] == w1[c] and [d2[i] for i in idx] == w2[c], c
