@@ -743,12 +743,9 @@ static int count_views(shn_ctx* ctx, const std::vector<ReadsView>& views, uint64
         bits = 0;
         while (bits < bits_n && (double)(1ULL << bits) < want) bits++;
         if (upper > (1ULL << 20)) bits = std::max(bits, std::min(bits_n, 10));
-        if (getenv("SHN_COUNT_BITS")) bits = std::max(0, std::min(bits_n, atoi(getenv("SHN_COUNT_BITS"))));      // (experiments: any grid gives the same table content)
       }
     }
     int b1 = (bits + 1) / 2;
-    if (getenv("SHN_COUNT_B1")) b1 = std::max(1, std::min(std::min(bits, (bits_hist + 1) / 2), atoi(getenv("SHN_COUNT_B1"))));      // (experiments; any split gives
-                                                                          // the same table; level 1 is a prefix of the histogram's digit)
     if (bits - b1 > 15) b1 = bits - 15;
     const int b2 = bits - b1;
     const int nb1 = 1 << b1;
@@ -773,8 +770,8 @@ static int count_views(shn_ctx* ctx, const std::vector<ReadsView>& views, uint64
         if (!v.wmax || !v.n_reads) continue;
         TimerRegion t(ctx, T_SCATTER1);
         uint64_t n_tiles = cdiv(v.n_reads, v.rt);
-        uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, getenv("SHN_COUNT_GRID1") ? strtoull(getenv("SHN_COUNT_GRID1"), nullptr, 10) : 4096);   // (2048: +0.7 ms; 512: +3 ms -- occupancy, not L2 write combining, is what matters)
-        size_t sh = (size_t)nb1 * 4 + (size_t)nb1 * 8 + (getenv("SHN_COUNT_LDS_PAD1") ? strtoull(getenv("SHN_COUNT_LDS_PAD1"), nullptr, 10) : 0);      // (experiments: residency)
+        uint32_t grid = (uint32_t)std::min<uint64_t>(n_tiles, 4096);   // (2048: +0.7 ms; 512: +3 ms -- occupancy, not L2 write combining, is what matters)
+        size_t sh = (size_t)nb1 * 4 + (size_t)nb1 * 8;
         if (both_strands) hipLaunchKernelGGL(scatter1_kernel<true>, dim3(grid), dim3(BLK), sh, s, v, k1, bits, b2, n_tiles, d_cursor1, keysA);
         else hipLaunchKernelGGL(scatter1_kernel<false>, dim3(grid), dim3(BLK), sh, s, v, k1, bits, b2, n_tiles, d_cursor1, keysA);
       }
@@ -806,10 +803,7 @@ static int build_from_keys(shn_ctx* ctx, uint64_t* keysA, uint64_t* keysB, uint3
   int rc;
   // below level 1: one level of b2 bits while that is at most 256 streams... up to 2^11 for small inputs (their tiles are short
   // either way); else a middle level and a last level of at most 8 bits each (bits <= 23, b1 >= 8 there: b2 <= 15)
-  // (SHN_COUNT_LEVELS=3 forces the middle level -- measured at BASELINE configs[2], see DESIGN.md 3.1: two passes of 256 streams
-  // below level 1 are faster per pass (65 against 100 ms) and slower together)
-  const char* lv = getenv("SHN_COUNT_LEVELS");
-  const bool three = b2 > 11 || (lv && atoi(lv) == 3 && b2 > 1);
+  const bool three = b2 > 11;
   const int b3 = three ? b2 / 2 : b2, bm = b2 - b3;              // last level, middle level (bm = 0: none)
   const uint32_t nbm = 1u << bm, nb3 = 1u << b3;
   const uint32_t n_seg3 = (uint32_t)nb1 * nbm;                    // segments of the last level
@@ -829,8 +823,8 @@ static int build_from_keys(shn_ctx* ctx, uint64_t* keysA, uint64_t* keysB, uint3
   HIP_TRY(hipMemcpyAsync(d_off1, off1h.data(), (size_t)(nb1 + 1) * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(d_hist2, 0, nbk * 4, s));
   HIP_TRY(hipMemsetAsync(d_ovf, 0, 4, s));
-  const uint32_t tile2 = getenv("SHN_COUNT_TILE2") ? (uint32_t)strtoul(getenv("SHN_COUNT_TILE2"), nullptr, 10) : TILE_KEYS;
-  const size_t pad2 = getenv("SHN_COUNT_LDS_PAD2") ? strtoull(getenv("SHN_COUNT_LDS_PAD2"), nullptr, 10) : 0;      // (experiments: residency of the scatter blocks)
+  const uint32_t tile2 = TILE_KEYS;
+  const size_t pad2 = 0;
   const uint64_t *segs = d_off1;                                  // segments of the last level and where their keys are
   uint32_t n_segs = (uint32_t)nb1;
   uint64_t max_seg = max1;
@@ -1003,11 +997,10 @@ extern "C" int shn_table_from_pairs(shn_ctx* ctx, const void* dev_keys, const vo
   // ~100 keys per bucket: a lookup is a binary search inside its bucket (7 steps instead of 10 at 640 per bucket), and
   // the adjacency, routing and seed kernels are made of lookups
   int bits = 0;
-  const uint64_t per_bucket = getenv("SHN_TABLE_BUCKET") ? strtoull(getenv("SHN_TABLE_BUCKET"), nullptr, 10) : 96;
+  const uint64_t per_bucket = 96;
   while (bits < 23 && (n >> bits) > per_bucket) bits++;        // (2^24 buckets x 256 threads would be 2^32 work-items: one too many for a dispatch)
   for (int attempt = 0; attempt < 4; attempt++) {
     int b1 = (bits + 1) / 2;
-    if (getenv("SHN_COUNT_B1")) b1 = std::max(1, std::min(bits, atoi(getenv("SHN_COUNT_B1"))));
     if (bits - b1 > 15) b1 = bits - 15;
     int b2 = bits - b1;
     int nb1 = 1 << b1;

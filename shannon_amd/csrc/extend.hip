@@ -525,10 +525,7 @@ __device__ __forceinline__ int audit_decide(const Adj4& cd, uint32_t r, uint32_t
 // FRESH: the first round of a block that has just opened -- none of its walks has run before, so the snapshot holds nothing but
 // the claims of final walks, which the live claims hold too: the snapshot is not read (a quarter of a step's memory accesses,
 // in the rounds that make most of the steps).
-// RESUME: the walks of the list were handed over by an earlier pass of this round (a bulk round can run in passes: every walk up to
-// 64 steps, the survivors -- packed side by side again -- up to 512, ...: a wavefront holds its slot as long as its longest walk,
-// and the slots, not the steps, are what a round of millions of walks runs out of); they go on where they stand (res_cur / res_info).
-template <bool FRESH, bool RESUME = false>
+template <bool FRESH>
 __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_walks, const uint32_t* __restrict__ list,
                                                         const u64* __restrict__ snap) {
   __shared__ unsigned long long blk_steps;
@@ -541,32 +538,20 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
     const uint32_t r = list[t];
     const uint32_t o = A.order[r];
     const unsigned long long t_begin = A.dbg ? __builtin_amdgcn_s_memrealtime() : 0ULL;      // (100 MHz)
-    uint32_t nr = 0, nl = 0, resumed_at = 0;
+    uint32_t nr = 0, nl = 0;
     uint64_t tot = 0;
     bool promoted = false;
     // snap: the pre-round snapshot; A.claim: live claims of this round
-    bool isvoid = !RESUME && ((!FRESH && RANK(snap[o]) < r) || RANK(__hip_atomic_load(&A.claim[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < r);
+    bool isvoid = (!FRESH && RANK(snap[o]) < r) || RANK(__hip_atomic_load(&A.claim[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < r;
     if (!isvoid) {
-      u64 seen = UNCLAIMED64;                        // what the last claim found; looked at one step later
+      u64 seen = claim_node(A, o, r, 0);             // what the last claim found; looked at one step later
       uint32_t pos = 0, pend = NONE32;
-      int dir0 = 0;
-      uint32_t cur0 = o, steps0 = 0;
-      if (RESUME) {
-        const uint32_t info = A.res_info[r];
-        dir0 = (int)(info >> 31); pos = info & 0x7FFFFFFFu; cur0 = A.res_cur[r];
-        resumed_at = pos;
-        nr = dir0 ? A.nr_out[r] : 0;
-        steps0 = dir0 ? pos - nr : pos;
-        tot = A.totw_out[r];
-      } else {
-        seen = claim_node(A, o, r, 0);
-        tot = A.weight[o];
-      }
+      tot = A.weight[o];
       bool gave_up = false;
-      for (int dir = dir0; dir < 2; dir++) {
+      for (int dir = 0; dir < 2; dir++) {
         const RowView adj = dir == 0 ? A.adjR : A.adjL;
-        uint32_t steps = (RESUME && dir == dir0) ? steps0 : 0;
-        Adj4 cand = adj[(RESUME && dir == dir0) ? cur0 : o];
+        uint32_t steps = 0;
+        Adj4 cand = adj[o];
         while (true) {
           u64 cl[4], cf[4];
           uint32_t w[4];
@@ -636,7 +621,7 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
     A.nr_out[r] = isvoid ? UNCLAIMED : nr;
     A.nl_out[r] = nl;
     A.totw_out[r] = tot;
-    mysteps = nr + nl - resumed_at;
+    mysteps = nr + nl;
     // debug: the longest walk of the launch and how long it took (steps << 32 | ticks of 10 ns): a bulk round cannot end before it
     if (A.dbg && mysteps >= 64) atomicMax(&A.dbg[12], ((unsigned long long)mysteps << 32) | ((__builtin_amdgcn_s_memrealtime() - t_begin) & 0xFFFFFFFFULL));
   }
@@ -648,132 +633,6 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
   }
   __syncthreads();
   if (threadIdx.x < n_promo) A.promo_list[promo_base + threadIdx.x] = blk_promo[threadIdx.x];
-}
-
-// ---- the same walks on persistent lanes (the default): a wavefront of the kernel above runs as long as its longest walk, and the
-// lengths of walks that start side by side in the seed order are geometric-like (a walk runs until it meets the territory of a
-// lower rank: half of them stop within a step, one in a thousand goes on for thousands) -- measured on the final paths of a
-// 5,000-gene input: 2-3 % of the lane-steps of a wavefront do work.  Here a lane whose walk has ended takes the next walk of the
-// list at once: the list is handed out in rank order, 64 walks per atomic (a wavefront-local cursor, lanes served by ballot /
-// prefix), so every lane has a memory round trip in flight until the list is exhausted.  The low ranks also start first now --
-// closer to the sequential order, in which no step is ever wasted: fewer walks run into territory they lose again.
-// The result does not depend on any of this (the rounds iterate to the fixpoint whatever the order of events inside a round).
-template <bool FRESH>
-__global__ __launch_bounds__(WBLK) void ext_walk_refill_kernel(WalkArgs A, uint64_t n_walks, const uint32_t* __restrict__ list,
-                                                               const u64* __restrict__ snap, unsigned long long* __restrict__ queue,
-                                                               unsigned long long* __restrict__ trips_counter) {
-  __shared__ unsigned long long blk_steps, blk_trips;
-  if (threadIdx.x == 0) { blk_steps = 0; blk_trips = 0; }
-  __syncthreads();
-  const int lane = threadIdx.x & 63;
-  const unsigned long long below = (1ULL << lane) - 1ULL;
-  bool active = false;
-  uint32_t r = 0, o = 0, pos = 0, steps = 0, nr = 0;
-  int dir = 0;
-  uint64_t tot = 0;
-  Adj4 cand = {{-1, -1, -1, -1}};
-  uint64_t wbase = 0;                       // wavefront-uniform: the part of the list this wavefront holds
-  uint32_t wleft = 0;
-  bool exhausted = false;
-  uint32_t mysteps = 0, trips = 0;
-  for (;;) {
-    const unsigned long long idle = __ballot(!active);
-    if (idle && !exhausted) {
-      if (wleft == 0) {
-        unsigned long long b = 0;
-        if (lane == 0) b = atomicAdd(queue, 64ULL);
-        b = (unsigned long long)__shfl((long long)b, 0, 64);
-        if (b >= n_walks) exhausted = true;
-        else { wbase = b; wleft = (uint32_t)(n_walks - b < 64 ? n_walks - b : 64); }
-      }
-      if (wleft) {
-        const uint32_t mine = (uint32_t)__popcll(idle & below);
-        if (!active && mine < wleft) {
-          r = list[wbase + mine];
-          o = A.order[r];
-          const bool isvoid = (!FRESH && RANK(snap[o]) < r) || RANK(__hip_atomic_load(&A.claim[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < r;
-          if (isvoid) { A.nr_out[r] = UNCLAIMED; A.nl_out[r] = 0; A.totw_out[r] = 0; }
-          else {
-            note_claim(A, claim_node(A, o, r, 0), r);
-            tot = A.weight[o];
-            pos = 0; steps = 0; nr = 0; dir = 0;
-            cand = A.adjR[o];
-            active = true;
-          }
-        }
-        const uint32_t need = (uint32_t)__popcll(idle);
-        const uint32_t taken = need < wleft ? need : wleft;
-        wbase += taken; wleft -= taken;
-      }
-    }
-    const unsigned long long act = __ballot(active);
-    if (!act) { if (exhausted) break; continue; }
-    trips++;
-    if (active) {
-      const RowView adj = dir == 0 ? A.adjR : A.adjL;
-      u64 cl[4], cf[4];
-      uint32_t w[4];
-      Adj4 nxt[4];
-#pragma unroll
-      for (int b = 0; b < 4; b++) {
-        const uint32_t idx = cand.v[b] < 0 ? o : (uint32_t)cand.v[b];
-        cl[b] = __hip_atomic_load(&A.claim[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        cf[b] = FRESH ? UNCLAIMED64 : snap[idx];
-        w[b] = A.weight[idx];
-        nxt[b] = adj[idx];
-      }
-      const u64 cseed = A.seed_check ? __hip_atomic_load(&A.claim[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : CLAIM(r, 0);
-      int best = -1;
-      uint32_t bw = 0;
-#define CONSIDER(b) if (cand.v[b] >= 0 && RANK(cl[b]) > r && RANK(cf[b]) >= r && (best < 0 || w[b] > bw)) { best = b; bw = w[b]; }
-      CONSIDER(0) CONSIDER(2) CONSIDER(1) CONSIDER(3)
-#undef CONSIDER
-      bool ended = false;                              // this walk is done with (or handed over)
-      if (RANK(cseed) < r) {                           // the seed went to a lower rank: void in the end (see ext_walk_kernel)
-        A.robbed[r] = 1;
-        A.nr_out[r] = dir == 0 ? steps : nr; A.nl_out[r] = dir == 0 ? 0 : steps; A.totw_out[r] = tot;
-        ended = true; best = -1;
-      } else if (best < 0) {
-        if (dir == 0) { nr = steps; steps = 0; dir = 1; cand = A.adjL[o]; }
-        else { A.nr_out[r] = nr; A.nl_out[r] = steps; A.totw_out[r] = tot; ended = true; }
-      } else {
-        const uint32_t nbest = (uint32_t)(best == 0 ? cand.v[0] : best == 1 ? cand.v[1] : best == 2 ? cand.v[2] : cand.v[3]);
-        pos++;
-        note_claim(A, claim_node(A, nbest, r, pos), r);
-        steps++;
-        mysteps++;
-        tot += bw;
-        if (pos >= A.promote_steps) {                  // long after all: a wavefront takes over from here (memos, 64 steps a trip)
-          A.res_cur[r] = nbest;
-          A.res_info[r] = ((uint32_t)dir << 31) | pos;
-          A.nr_out[r] = dir == 0 ? steps : nr;
-          A.nl_out[r] = dir == 0 ? 0 : steps;
-          A.totw_out[r] = tot;
-          ended = true;
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; q++) cand.v[q] = best == 0 ? nxt[0].v[q] : best == 1 ? nxt[1].v[q] : best == 2 ? nxt[2].v[q] : nxt[3].v[q];
-        }
-      }
-      const bool promo = ended && best >= 0;
-      const unsigned long long pm = __ballot(promo);   // (only the active lanes take part: the idle ones are outside this branch)
-      if (pm) {
-        unsigned long long pbase = 0;
-        const int leader = __ffsll((long long)pm) - 1;
-        if (lane == leader) pbase = atomicAdd(A.promo_count, (unsigned long long)__popcll(pm));
-        pbase = (unsigned long long)__shfl((long long)pbase, leader, 64);
-        if (promo) A.promo_list[pbase + __popcll(pm & below)] = r;
-      }
-      if (ended) active = false;
-    }
-  }
-  if (mysteps) atomicAdd(&blk_steps, (unsigned long long)mysteps);
-  if (lane == 0 && trips) atomicAdd(&blk_trips, (unsigned long long)trips);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    if (blk_steps) atomicAdd(A.steps_counter, blk_steps);
-    if (blk_trips) atomicAdd(trips_counter, blk_trips);
-  }
 }
 
 // ---- long walks: one wavefront per dirty walk.  A memo (the path of some walk's last live run, own or foreign)
@@ -1651,17 +1510,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   // dirty walks is the block size when a block opens, else the count of the round before.
   const unsigned long long bulk_min = getenv("SHN_EXT_BULK") ? strtoull(getenv("SHN_EXT_BULK"), nullptr, 10) : 262144ULL;
   const unsigned long long dense_min = getenv("SHN_EXT_DENSE") ? strtoull(getenv("SHN_EXT_DENSE"), nullptr, 10) : (4ULL << 20);   // (BASELINE configs[2]: 262144 -> 954 ms, 2 M or 16 M -> 900 ms per extension)
-  // thread walker on persistent lanes (ext_walk_refill_kernel; SHN_EXT_REFILL=0: one walk per thread, ext_walk_kernel)
-  const bool refill = tune("SHN_EXT_REFILL", 0) != 0;
   const int seed_check = (int)tune("SHN_EXT_SEEDCHECK", 1);
-  // bulk rounds in passes (see ext_walk_kernel, RESUME): SHN_EXT_PASSES = the step limits of the passes, e.g. "64,512,4096"; "" / "0": one pass
-  std::vector<uint32_t> pass_limits;
-  { const char* pv = getenv("SHN_EXT_PASSES");
-    std::string ps = pv ? pv : "";
-    size_t at = 0;
-    while (at < ps.size()) { size_t e2 = ps.find(',', at); if (e2 == std::string::npos) e2 = ps.size(); const unsigned long v = strtoul(ps.substr(at, e2 - at).c_str(), nullptr, 10); if (v) pass_limits.push_back((uint32_t)v); at = e2 + 1; } }
-  int n_cu = 256;
-  { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
   unsigned long long expect_dirty = limit;
   while (!converged && it < max_iterations) {
     const bool bulk = bulk_min && expect_dirty >= bulk_min;
@@ -1732,8 +1581,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     A.claim = claim; A.claim_old = snap;
     A.nr_out = e->d_nr; A.nl_out = e->d_nl; A.totw_out = e->d_totw;
     A.pool = pool; A.moff = moff; A.mR = mR; A.mL = mL; A.mvalid = mvalid; A.hint = words_hint(e->d_rec);
-    const bool in_passes = bulk && !refill && !pass_limits.empty();
-    A.promote_steps = in_passes ? pass_limits[0] : bulk ? 0xFFFFFFFFu : promote_steps;
+    A.promote_steps = bulk ? 0xFFFFFFFFu : promote_steps;
     A.promo_list = promo_list; A.promo_count = d_cnt + 13; A.res_cur = res_cur; A.res_info = res_info;
     A.chunk = dense ? nullptr : chunk;         // (dense rounds write nearly everywhere: their mark pass is dense, the walkers do not flag)
     A.robbed = robbed;
@@ -1751,36 +1599,9 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     if (getenv("SHN_EXT_XTIME")) {   // (development: time of every thread-walker launch)
        TRYE(hipStreamSynchronize(s)); timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); x_t0 = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
     if (plan[2]) {
-      if (refill) TRYE(hipMemsetAsync(d_cnt + 14, 0, 8, s));                 // the list's queue head
       TimerRegion tk(ctx, T_EXT_WALK_THREAD);
-      if (refill) {
-        // persistent lanes: enough blocks to fill the chip (8 of 256 threads per CU), each lane takes walks until the list is empty
-        const uint32_t grid = (uint32_t)std::min<unsigned long long>(cdiv(plan[2], WBLK), (unsigned long long)n_cu * 32);
-        if (fresh_block) hipLaunchKernelGGL(ext_walk_refill_kernel<true>, dim3(grid), dim3(WBLK), 0, s, A, (uint64_t)plan[2], short_list, snap, d_cnt + 14, d_cnt + 15);
-        else hipLaunchKernelGGL(ext_walk_refill_kernel<false>, dim3(grid), dim3(WBLK), 0, s, A, (uint64_t)plan[2], short_list, snap, d_cnt + 14, d_cnt + 15);
-      }
-      else if (fresh_block) hipLaunchKernelGGL(ext_walk_kernel<true>, dim3((uint32_t)cdiv(plan[2], WBLK)), dim3(WBLK), 0, s, A, (uint64_t)plan[2], short_list, snap);
+      if (fresh_block) hipLaunchKernelGGL(ext_walk_kernel<true>, dim3((uint32_t)cdiv(plan[2], WBLK)), dim3(WBLK), 0, s, A, (uint64_t)plan[2], short_list, snap);
       else hipLaunchKernelGGL(ext_walk_kernel<false>, dim3((uint32_t)cdiv(plan[2], WBLK)), dim3(WBLK), 0, s, A, (uint64_t)plan[2], short_list, snap);
-    }
-    if (plan[2] && in_passes) {
-      // the later passes of a bulk round: the walks the pass before handed over, side by side again, up to the next limit
-      uint32_t *in_list = promo_list, *out_list = long_list;             // (a bulk round has no wavefront walks: their list is free)
-      unsigned long long *in_cnt = d_cnt + 13, *out_cnt = d_cnt + 16;
-      for (size_t p = 1; ; p++) {
-        unsigned long long c = 0;
-        TRYE(hipMemcpyAsync(plan + 6, in_cnt, 8, hipMemcpyDeviceToHost, s));
-        TRYE(hipStreamSynchronize(s));
-        c = plan[6];
-        if (!c) break;
-        TRYE(hipMemsetAsync(out_cnt, 0, 8, s));
-        A.promote_steps = p < pass_limits.size() ? pass_limits[p] : 0xFFFFFFFFu;
-        A.promo_list = out_list; A.promo_count = out_cnt;
-        { TimerRegion tk(ctx, T_EXT_WALK_THREAD);
-          if (fresh_block) hipLaunchKernelGGL((ext_walk_kernel<true, true>), dim3((uint32_t)cdiv(c, WBLK)), dim3(WBLK), 0, s, A, (uint64_t)c, (const uint32_t*)in_list, snap);
-          else hipLaunchKernelGGL((ext_walk_kernel<false, true>), dim3((uint32_t)cdiv(c, WBLK)), dim3(WBLK), 0, s, A, (uint64_t)c, (const uint32_t*)in_list, snap); }
-        std::swap(in_list, out_list); std::swap(in_cnt, out_cnt);
-      }
-      A.promo_list = promo_list; A.promo_count = d_cnt + 13;
     }
     if (x_t0 > 0) {
       TRYE(hipStreamSynchronize(s)); timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -1789,7 +1610,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       fprintf(stderr, "[shn_extend] XTIME round %d: thread walker %llu walks, %.2f ms, steps so far %llu; longest walk %llu steps in %.2f ms (%.2f us per step)\n", it + 1, plan[2],
               ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6 - x_t0, st, lw >> 32, (double)(lw & 0xFFFFFFFFULL) * 1e-5, (lw >> 32) ? (double)(lw & 0xFFFFFFFFULL) * 1e-2 / (double)(lw >> 32) : 0.0);
     }
-    if (plan[2] && !in_passes) {                // walks the thread kernel handed over (the count stays on the device)
+    if (plan[2]) {                              // walks the thread kernel handed over (the count stays on the device)
       TimerRegion tk(ctx, T_EXT_WALK_WAVE);
       hipLaunchKernelGGL(ext_walk_long_kernel<true>, dim3((uint32_t)std::min<unsigned long long>(plan[2], 8192ULL)), dim3(64), 0, s, A, promo_list,
                          (uint64_t)ns, (const unsigned long long*)(d_cnt + 13));
@@ -1799,7 +1620,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     // "nobody -> a walk of the block" -- nothing the mark pass would mark (a k1-mer only BECOMES available to somebody when a lower
     // rank gives it up), no memo slots to fill; what is left of the pass is bringing the snapshot up to date, which the next begin
     // pass does while it streams the claims anyway (copy = 1): the pass is skipped (3 x 25 ms at BASELINE configs[2]).
-    const bool skip_mark = fresh_block && bulk && precise_marks && tune("SHN_EXT_FRESH_MARK", 0) == 0;
+    const bool skip_mark = fresh_block && bulk && precise_marks;
     fresh_block = false;
     if (dense) e->dense_rounds++;
     // who has to run next round?  walks whose view changed (mark) + walks that lost a claim race (verify);

@@ -177,13 +177,15 @@ def test_chunked_counting_equals_one_pass_over_all_reads(chunk, ragged, monkeypa
                                                                     (26, False, False, True, None, "0.0001", None), (20, True, False, False, 9, None, None),
                                                                     (31, True, True, True, None, None, None), (32, True, False, True, 5, None, None),
                                                                     (31, False, False, False, 12, "0.01", None), (23, False, True, True, 4, None, None),
-                                                                    (26, True, False, True, 7, None, 11), (26, True, True, False, None, None, 12)])
+                                                                    (26, True, False, True, 7, None, 11), (26, True, True, False, None, None, 12),
+                                                                    (26, True, False, True, 8, None, -1), (32, True, True, True, None, "0.001", -1)])
 def test_superkmer_counting_equals_the_partition_pipeline(K1, both, ragged, with_n, bits, pool, slots, monkeypatch):
     """Large diverse inputs are counted through super-k-mers (csrc/count_sk.hip: minimizer runs of a read's windows travel as 16-byte
     records, windows are expanded to keys in the bucket kernel's LDS, the buckets' pairs are reduced by the pairs path); forced
     here on small inputs -- fixed-length and ragged reads (some shorter than k1, some exactly k1), N bases, poly-A / poly-T reads,
     heavy duplicates, canonical and forward counting, k1 = 20 .. 32, several bucket grids, a pair pool that starts too small, reads
-    with more records than slots (the overflow list): the same table as the partition pipeline, and as the oracle."""
+    with more records than slots (the overflow list), the buckets' pairs through the pairs path instead of straight into the table:
+    the same table as the partition pipeline, and as the oracle."""
     from shannon_amd import device
     from oracle import count
     rng = np.random.default_rng(K1 * 7 + (3 if both else 0))
@@ -217,8 +219,10 @@ def test_superkmer_counting_equals_the_partition_pipeline(K1, both, ragged, with
             monkeypatch.setenv("SHN_COUNT_SK_BITS", str(bits))
         if pool is not None:
             monkeypatch.setenv("SHN_COUNT_SK_POOL", pool)
-        if slots is not None:
+        if slots is not None and slots > 0:
             monkeypatch.setenv("SHN_COUNT_SK_SLOTS", str(slots))
+        if slots == -1:                                   # the pairs path behind the buckets (the fallback of a bucket no key range splits)
+            monkeypatch.setenv("SHN_COUNT_SK_LAYOUT", "0")
         t1 = device.count_k1mers(ctx, [d], K1, both)
         assert "count.sk_buckets" in ctx.timers()
         k1, c1 = t1.download()

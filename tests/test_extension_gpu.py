@@ -405,12 +405,11 @@ def test_gpu_contig_stage_on_many_genes(ctx):
     assert got.remaining == ref.remaining and got.big_components == ref.big_components and got.allowed == ref.allowed
 
 
-@pytest.mark.parametrize("env", [{"SHN_EXT_BULK": "1"}, {"SHN_EXT_BULK": "1", "SHN_EXT_DENSE": "1"}, {"SHN_EXT_BULK": "1", "SHN_EXT_DENSE": "1000000000"},
-                                 {"SHN_EXT_BULK": "1", "SHN_EXT_PASSES": "4,32"}, {"SHN_EXT_BULK": "1", "SHN_EXT_SEEDCHECK": "0"}, {"SHN_EXT_BULK": "1", "SHN_EXT_REFILL": "1"}])
+@pytest.mark.parametrize("env", [{"SHN_EXT_BULK": "1"}, {"SHN_EXT_BULK": "1", "SHN_EXT_DENSE": "1"}, {"SHN_EXT_BULK": "1", "SHN_EXT_DENSE": "1000000000"}])
 def test_bulk_rounds_give_the_same_contigs(ctx, env, monkeypatch):
     """Every round as a bulk round (thread walker only, no snapshot reads in a block's first round), with the begin / mark passes
-    as they come, all dense or all following the line flags; in passes (every walk 4 steps, the survivors 32, the rest to the
-    end); without the seed check; on persistent lanes: the same walks, contigs and connections as the default path of a small table."""
+    as they come, all dense or all following the line flags: the same walks, contigs and connections as the default path of a
+    small table."""
     from shannon_amd import device, synth, extension_correction as ec
     (r1, r2), _ = synth.make_dataset(60000, 20, seed=91)
     t = device.count_k1mers(ctx, [device.Reads.from_codes(ctx, np.concatenate([r1, r2]))], 26)

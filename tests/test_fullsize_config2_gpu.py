@@ -26,14 +26,14 @@ def rc(s):
 
 
 def canon_keys(keys, k):
-    """canonical form of packed k-mers (2 bits per base, first base in the high bits)"""
+    """canonical form of packed k-mers (2 bits per base, first base in the high bits): complement, then the 2-bit groups reversed
+    by swapping neighbours, nibbles and bytes"""
     keys = keys.astype(np.uint64)
-    r = np.zeros_like(keys)
-    x = keys.copy()
-    for _ in range(k):
-        r = (r << np.uint64(2)) | (np.uint64(3) - (x & np.uint64(3)))
-        x >>= np.uint64(2)
-    return np.minimum(keys, r)
+    x = ~keys
+    x = ((x >> np.uint64(2)) & np.uint64(0x3333333333333333)) | ((x & np.uint64(0x3333333333333333)) << np.uint64(2))
+    x = ((x >> np.uint64(4)) & np.uint64(0x0F0F0F0F0F0F0F0F)) | ((x & np.uint64(0x0F0F0F0F0F0F0F0F)) << np.uint64(4))
+    x = x.byteswap() >> np.uint64(64 - 2 * k)
+    return np.minimum(keys, x)
 
 
 class Full(object):

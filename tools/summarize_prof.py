@@ -11,7 +11,9 @@ import csv, sys, re, collections, json
 TIMER_KERNEL = {"count.direct": "count_direct_kernel", "count.hist1": "hist1_kernel", "count.scatter1": "scatter1_kernel", "count.hist2": "hist_keys_kernel",
                 "count.scatter2": "scatter_keys_kernel<false>", "count.buckets": "buckets_kernel<false>", "route": "route_kernel",
                 "extend.walk_thread": "ext_walk_kernel", "extend.walk_wave": "ext_walk_long_kernel", "extend.mark": "ext_mark_kernel",
-                "extend.adjacency": "ext_records_kernel"}
+                "extend.adjacency": "ext_records_kernel",
+                "count.sk_emit": "sk_scan_kernel", "count.sk_hist2": "skr_hist_kernel", "count.sk_scatter2": "skr_scatter_kernel",
+                "count.sk_buckets": "sk_buckets_sorted_kernel"}
 
 
 def short(name):
