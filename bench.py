@@ -258,9 +258,9 @@ def cpu_whole_path_native(K, r1, r2, n_pairs):
     wherever a native host form exists, no device anywhere:
       count          oracle/count_c.c (radix sort + run-length count; the reference's Jellyfish)                 one thread | T slices
       extension      oracle/ext_c.c (the greedy walks in seed order; the reference's Python loop)                 one thread
-      contig stage   oracle/extension.py over those walks (accept filter, duplicate_check, contig graph, components: Python --
-                     no native host form of it takes walks)                                                        one thread
-      partitions     oracle/partition.py (bins of components), reads routed by its numpy form route_pairs_matrix  one thread
+      contig stage   accept filter (numpy), duplicate_check + contig graph + components in host C++ (shn_cgraph,
+                     shn_contig_components: the reference's sequential loops)                                      one thread
+      partitions     oracle/partition.py (partitions' contigs), reads routed by its numpy form route_pairs_matrix one thread
       graph          shn_mbgraph_run(ctx = NULL) per partition: K-mer graph built and condensed sequentially, seeds matched on the
                      host -- the reference's multibridging.main restated in C++                                   one thread | T threads
       sparse flow    oracle/sparse_flow.py + oracle/lp.py over the exported tables (Python: the LP trials have no host form
@@ -268,8 +268,9 @@ def cpu_whole_path_native(K, r1, r2, n_pairs):
       merge          shn_post_finalize_bufs (host C++)                                                             host threads
     Returns the one-thread figure as `value` and the figure with the two stages that parallelise run on T threads."""
     from concurrent.futures import ThreadPoolExecutor
-    from oracle import build_c, extension as oext, partition as opart, sparse_flow as osf
-    from shannon_amd import _lib, mbgraph_native, post, kmers_for_component as kfc
+    import math
+    from oracle import build_c, partition as opart, sparse_flow as osf
+    from shannon_amd import _lib, mbgraph_native, post, kmers_for_component as kfc, extension_correction as ec
     k1 = K + 1
     a1, a2 = np.ascontiguousarray(r1[:n_pairs]), np.ascontiguousarray(r2[:n_pairs])
     sec = {}
@@ -278,35 +279,70 @@ def cpu_whole_path_native(K, r1, r2, n_pairs):
     keys, cnts, nw = build_c.count_canonical(codes, k1, True)
     sec["count"] = time.time() - t
     t = time.time()
-    walks = build_c.extend(keys, cnts, k1, 3)
+    seed, nr, nl, tw, bases = build_c.extend(keys, cnts, k1, 3, strings=False)
     sec["extension"] = time.time() - t
     t = time.time()
-    code = np.zeros(256, np.uint64)
-    for i, ch in enumerate(b"ACGT"):
-        code[ch] = i
-    pw = (np.uint64(4) ** np.arange(k1 - 1, -1, -1, dtype=np.uint64)).astype(np.uint64)
-    items = {}
-    for contig, _w, _n in walks:                     # the dictionary run_correction reads when the walks are given: the k1-mers of acceptable walks
-        if len(contig) < 75:
-            continue
-        c = code[np.frombuffer(contig.encode(), np.uint8)]
-        fw = np.lib.stride_tricks.sliding_window_view(c, k1) @ pw
-        rv = np.lib.stride_tricks.sliding_window_view(np.uint64(3) - c, k1) @ pw[::-1]
-        for i, w in enumerate(cnts[np.searchsorted(keys, np.minimum(fw, rv))].tolist()):
-            items[contig[i:i + k1]] = w
-    res = oext.run_correction(sorted(items.items(), reverse=True), walks=walks)
+    # accept filter (extension_correction.py:361) on the arrays, the candidates' strings, then duplicate_check + contig graph +
+    # components in native host code (shn_cgraph / shn_contig_components: the reference's sequential loops in C++) and the file
+    # products of extension_correction.py:458-513 (single contigs, bins of small components, components above --partition)
+    Lc = k1 + nr.astype(np.int64) + nl.astype(np.int64)
+    nk = nr.astype(np.int64) + nl.astype(np.int64) + 1
+    sure = (Lc >= 75) & (Lc * np.power(tw.astype(np.float64) / np.maximum(1, nk), 0.25) >= 2 * 75 * math.pow(3, 0.25))
+    A = np.frombuffer(b"ACGT", np.uint8)
+    off = np.concatenate([[0], np.cumsum(nr.astype(np.int64) + nl.astype(np.int64))])
+    cands = []
+    for i in np.nonzero(sure)[0].tolist():
+        sd = int(seed[i])
+        a_, b_, at = int(nr[i]), int(nl[i]), int(off[i])
+        cands.append(A[bases[at + a_:at + a_ + b_][::-1]].tobytes().decode() + "".join("ACGT"[(sd >> (2 * (k1 - 1 - j))) & 3] for j in range(k1)) +
+                     A[bases[at:at + a_]].tobytes().decode())
+    acc, coff, cnb, cw = ec.contig_stage(cands, k1) if cands else (np.zeros(0, np.int32), [0], [], [])
+    contigs = ["buffer"] + [cands[i] for i in np.nonzero(np.asarray(acc))[0].tolist()]
+    coff_a, cnb_a, cw_a = np.asarray(coff, dtype=np.uint64), np.asarray(cnb, dtype=np.int32), np.asarray(cw, dtype=np.int32)
+    _co, members, comp_off, comp_edges = ec.contig_components(coff_a, cnb_a)
+    mem, co = members.tolist(), comp_off.tolist()
+    single_contigs, big_components, remaining, cur_size = [], [], [[]], 0
+    for j, sz in enumerate(np.diff(comp_off.astype(np.int64)).tolist() if len(comp_off) > 1 else []):
+        if sz == 1:
+            single_contigs.append(contigs[mem[co[j]]])
+        elif sz > 500:
+            mm = mem[co[j]:co[j + 1]]
+            code_ = {c: i + 1 for i, c in enumerate(mm)}
+            lines = ["%d\t%d\t001\n" % (sz, int(comp_edges[j]))]
+            o_, nb_, w_ = coff_a.tolist(), cnb_a.tolist(), cw_a.tolist()
+            for c in mm:
+                lines.append("".join("%d\t%d\t" % (code_[c2], wt) for c2, wt in zip(nb_[o_[c - 1]:o_[c]], w_[o_[c - 1]:o_[c]])) + "\n")
+            big_components.append(([contigs[c] for c in mm], "".join(lines)))
+        else:
+            remaining[-1].extend(contigs[c] for c in mem[co[j]:co[j + 1]])
+            cur_size += sz
+            if cur_size > 500:
+                remaining.append([])
+                cur_size = 0
     sec["contig stage"] = time.time() - t
     t = time.time()
     pv = []
-    for contigs, metis in res.big_components:
-        P = kfc.n_partitions(len(contigs), 500)
+    for bc, metis in big_components:
+        P = kfc.n_partitions(len(bc), 500)
         p1 = kfc.partition_graph(metis, P, 1000)
         pv.append((p1, kfc.partition_graph(kfc.weight_updated_graph(metis, p1, 5), P, 1000)))
-    nc, _k2c = opart.build_partitions([b[0] for b in res.big_components], [p[0] for p in pv], [p[1] for p in pv] if pv else None, res.remaining, res.allowed, K)
+    nc = {}                                          # partition -> contigs, named and ordered as kmers_for_component.py:244-305 names them
+    for i, (bc, _m) in enumerate(big_components):
+        for j, pid in enumerate(pv[i][0]):
+            nc.setdefault("c%d_%s" % (i + 1, pid), []).append(bc[j])
+        for j, pid in enumerate(pv[i][1]):
+            nc.setdefault("r2_c%d_%s" % (i + 1, pid), []).append(bc[j])
+    for i, lst in enumerate(remaining):
+        for c in lst:
+            nc.setdefault("cremaining%d" % (i + 1), []).append(c)
     routes = opart.route_pairs_matrix(a1, a2, nc, K)
     sec["partition+route"] = time.time() - t
     store = kfc.ReadStore(a1, a2)
     names = [nm for nm in nc]
+    code = np.zeros(256, np.uint64)
+    for i, ch in enumerate(b"ACGT"):
+        code[ch] = i
+    pw = (np.uint64(4) ** np.arange(k1 - 1, -1, -1, dtype=np.uint64)).astype(np.uint64)
 
     def graph_of(nm):
         rows = kfc._rows_bytes(nc[nm], k1)
@@ -328,7 +364,7 @@ def cpu_whole_path_native(K, r1, r2, n_pairs):
         list(pool.map(graph_of, names))
     graph_T = time.time() - t
     t = time.time()
-    texts = ["".join(">Single_%d\n%s\n" % (i, c) for i, c in enumerate(res.single_contigs))]
+    texts = ["".join(">Single_%d\n%s\n" % (i, c) for i, c in enumerate(single_contigs))]
     for nm, (singles, comps, _log) in zip(names, tables):
         txt = ""
         for c, comp in enumerate(comps):
@@ -355,10 +391,10 @@ def cpu_whole_path_native(K, r1, r2, n_pairs):
     return {"value": 2 * n_pairs / tot, "unit": "reads/s", "cores": 1, "kind": "port", "cpu_model": cpu, "host_threads_available": os.cpu_count(),
             "host_cpus_allowed": _lib.host_cpus(),
             "sample": "first %d reads of the benchmark batch through the whole path a1-a31 on the host, native where a native host form exists "
-                      "(oracle/count_c.c, oracle/ext_c.c, shn_mbgraph_run(ctx=NULL) for all %d partitions, shn_post_finalize_bufs; the contig "
-                      "stage, partitions / routing (numpy) and the sparse flow + LP trials through oracle/*.py): %d distinct k1-mers, %d walks, %d "
+                      "(oracle/count_c.c, oracle/ext_c.c, shn_cgraph + shn_contig_components, shn_mbgraph_run(ctx=NULL) for all %d partitions, "
+                      "shn_post_finalize_bufs; routing in numpy, the sparse flow + LP trials through oracle/*.py): %d distinct k1-mers, %d walks, %d "
                       "contigs, %d routed pairs, %d transcripts, %.1f s on one thread"
-                      % (2 * n_pairs, len(names), len(keys), len(walks), len(res.contigs), sum(len(v) for v in routes.values()), len(final), tot),
+                      % (2 * n_pairs, len(names), len(keys), len(seed), len(contigs) - 1, sum(len(v) for v in routes.values()), len(final), tot),
             "seconds": {k: round(v, 3) for k, v in sec.items()},
             "threads": {"value": 2 * n_pairs / tot_T, "unit": "reads/s", "cores": T,
                         "sample": "the same with the two stages that parallelise on %d threads: counting as %d slices (%.2f s, tables unmerged) and the "
@@ -804,8 +840,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 of the N=1 run only
             # bounded sample: ~10-15 s of one core through the whole path (at configs[2] a read costs the pure-Python path ~5x more
             # than at configs[1]: nearly every k1-mer of a 25k-read sample is new), + ~5 s for the counting stage alone / threaded
-            # ~25 s of host work: 1 M reads through the whole path, native where a native host form exists
-            out["cpu_baseline"] = cpu_whole_path_native(args.K, r1, r2, min(len(r1), 500_000))
+            # ~30 s of host work: 0.5 M reads through the whole path, native where a native host form exists (at 1 M reads
+            # of this 20,000-gene batch the greedy extension alone takes one core 45 s: 33 M distinct k1-mers at 2x coverage)
+            out["cpu_baseline"] = cpu_whole_path_native(args.K, r1, r2, min(len(r1), 250_000))
             # the pure-Python port (oracle/pipeline.py: pure Python like Shannon itself) on a small sample, for scale
             out["cpu_baseline"]["python_port"] = cpu_baseline(k1, r1, r2, 25_000 if args.config == "1" else 6_000)
         final_line = json.dumps(out)
