@@ -299,113 +299,6 @@ __global__ void ext_records_kernel(const TabIdx T, const uint8_t* __restrict__ f
   }
 }
 
-// The same over a table of layout 1, bucket by bucket: one wavefront per bucket of minimizers.  Six of seven look-ups of a k1-mer go
-// to its own bucket, i.e. to the bucket's own stretch of the dictionary (~43 lines): the wavefront copies that stretch into LDS
-// once (up to FDC_LINES lines of it; a larger bucket's further lines stay in HBM) and serves those look-ups from there -- what
-// is left for HBM per k1-mer is its own key, its two records and the one look-up in seven that leaves the bucket.
-#define FDC_LINES 64
-__global__ __launch_bounds__(256) void ext_records_l1_kernel(const TabIdx T, const uint8_t* __restrict__ flags, const uint32_t* __restrict__ weight, int k,
-                                                             int canonical, Rec* __restrict__ rec, const unsigned long long* __restrict__ lines,
-                                                             uint64_t n_buckets) {
-  __shared__ ulonglong2 cache[4][FDC_LINES * 8];
-  const uint64_t* __restrict__ tkeys = T.keys;
-  const uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, g0 = lane & ~7, p = lane & 7;
-  const int m = T.m, w = k - m + 1;
-  const uint32_t mmask = m == 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
-  ulonglong2* mine = cache[wv];
-  for (uint64_t b = (uint64_t)blockIdx.x * 4 + wv; b < n_buckets; b += (uint64_t)gridDim.x * 4) {
-    const uint64_t lo = T.boff[b], hi = T.boff[b + 1];
-    if (lo >= hi) continue;                                             // (uniform over the wavefront)
-    const uint64_t first = lo / FD_PER_LINE + b, nl = (hi - lo) / FD_PER_LINE + 1;
-    const uint32_t ncache = (uint32_t)(nl < FDC_LINES ? nl : FDC_LINES);
-    __builtin_amdgcn_wave_barrier();                                    // (the look-ups of the bucket before are done with the cache)
-    for (uint32_t j = lane; j < ncache * 8; j += 64) mine[j] = ((const ulonglong2*)(lines + first * 16))[j];
-    __builtin_amdgcn_s_waitcnt(0);                                      // (the copy has landed before any lane reads it)
-    __builtin_amdgcn_wave_barrier();
-    for (uint64_t i0 = lo; i0 < hi; i0 += 8) {
-      const uint64_t i = i0 + (uint64_t)(lane >> 3);
-      const bool in = i < hi;
-      const uint8_t f = in ? flags[i] : (uint8_t)2;
-      const bool dead0 = (f & 2) != 0;
-      const bool dead1 = dead0 || (f & 1) || !canonical;
-      const uint64_t str = in ? tkeys[i] : 0ULL;
-      uint64_t mykey; uint32_t mystrand = 0;
-      {
-        const uint64_t nb = (uint64_t)(p & 3);
-        mykey = p < 4 ? (((str << 2) | nb) & mask) : ((str >> 2) | (nb << (2 * (k - 1))));
-        if (canonical) { const uint64_t rc = shn_revcomp(mykey, k); if (rc < mykey) { mykey = rc; mystrand = 1; } }
-        if (dead0) mykey = 0;
-      }
-      // the neighbour's minimizer from the k1-mer's own m-mers (see ext_records_kernel)
-      uint32_t smin = 0xFFFFFFFFu, pmin = 0xFFFFFFFFu;
-      for (int pos = p; pos < w; pos += 8) {
-        const uint32_t ff = (uint32_t)(str >> (2 * (k - m - pos))) & mmask;
-        uint32_t c = ff;
-        if (canonical) { const uint32_t r = shn_revcomp32(ff, m); c = r < ff ? r : ff; }
-        const uint32_t o = shn_sk_order(c);
-        if (pos >= 1) smin = o < smin ? o : smin;
-        if (pos <= w - 2) pmin = o < pmin ? o : pmin;
-      }
-#pragma unroll
-      for (int d = 1; d < 8; d <<= 1) {
-        const uint32_t a = (uint32_t)__shfl_xor((int)smin, d, 64), b2 = (uint32_t)__shfl_xor((int)pmin, d, 64);
-        smin = a < smin ? a : smin; pmin = b2 < pmin ? b2 : pmin;
-      }
-      uint64_t myline;
-      int mylocal = -1;                                                 // line of the wavefront's cache, or -1: fetch it
-      {
-        const uint32_t nb = (uint32_t)(p & 3);
-        const uint32_t ff = p < 4 ? ((((uint32_t)str & (mmask >> 2)) << 2) | nb)
-                                  : ((nb << (2 * (m - 1))) | ((uint32_t)(str >> (2 * (k - m + 1))) & (mmask >> 2)));
-        uint32_t c = ff;
-        if (canonical) { const uint32_t r = shn_revcomp32(ff, m); c = r < ff ? r : ff; }
-        uint32_t o = shn_sk_order(c);
-        const uint32_t shared = p < 4 ? smin : pmin;
-        o = shared < o ? shared : o;
-        const uint32_t nbk = shn_sk_bucket(o, T.bits);
-        if ((uint64_t)nbk == b) {
-          const uint64_t li = __umul64hi(shn_mix64(mykey), nl);
-          myline = first + li;
-          if (li < ncache) mylocal = (int)li;
-        } else myline = fd_line_in_bucket(T, nbk, mykey);
-      }
-      const uint32_t strands = (uint32_t)((__ballot(mystrand != 0) >> g0) & 0xFFULL);
-      uint64_t key[8];
-      ulonglong2 v[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        key[q] = shfl_u64(mykey, g0 + q);
-        const int loc = __shfl(mylocal, g0 + q, 64);
-        if (loc >= 0) v[q] = mine[loc * 8 + p];
-        else v[q] = ((const ulonglong2*)(lines + shfl_u64(myline, g0 + q) * 16))[p];
-      }
-      uint32_t r8[8], d8[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        const uint32_t ww = fd_match(v[q], lines, shfl_u64(myline, g0 + q), key[q], p, g0, T, flags);
-        if (ww == 0xFFFFFFFFu) { r8[q] = d8[q] = 0xFFFFFFFFu; continue; }
-        const uint32_t j = ww & ~FD_PAL;
-        const uint32_t st = (strands >> q) & 1u;
-        r8[q] = 2 * j + st;
-        d8[q] = (ww & FD_PAL) ? r8[q] : 2 * j + (1 - st);
-      }
-      if (!in) continue;
-      Quad out;
-      const Quad none = Quad{~0u, ~0u, ~0u, ~0u};
-      switch (p) {
-        case 0: out = Quad{r8[0], r8[1], r8[2], r8[3]}; break;
-        case 1: out = Quad{r8[4], r8[5], r8[6], r8[7]}; break;
-        case 4: out = dead1 ? none : Quad{d8[7], d8[6], d8[5], d8[4]}; break;
-        case 5: out = dead1 ? none : Quad{d8[3], d8[2], d8[1], d8[0]}; break;
-        case 2: case 6: out = Quad{weight[i], NOHINT_WORD, 0xFFFFFFFFu, 0u}; break;
-        default: out = Quad{0u, 0u, 0u, 0u}; break;
-      }
-      ((Quad*)(rec + 2 * i))[p] = out;
-    }
-  }
-}
-
 // ---- connected components of the k1-mer graph (vertices = canonical k1-mers, edges = the adjacency rows).
 // A walk never leaves its component, so the components can be extended independently -- on different GPUs.
 // Lock-free union-find: roots only ever link to smaller ids (no cycles), finds halve paths as they go.
@@ -1494,9 +1387,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       uint64_t n_lines = 0;
       { int rca = build_fine_dict(ctx, t, e->d_flags, &lines, &n_lines, e->d_claim); if (rca) { shn_ext_destroy(e); return rca; } }
       { TimerRegion ta(ctx, T_EXT_ADJ);                  // (one launch: bench.py's roofline entry for this kernel)
-        if (t->layout) hipLaunchKernelGGL(ext_records_l1_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(t->n_buckets, 4), 1u << 20)), dim3(256), 0, s, shn_tab_idx(t),
-                                          e->d_flags, e->d_weight, t->k, t->canonical, e->d_rec, (const unsigned long long*)lines, t->n_buckets);
-        else hipLaunchKernelGGL(ext_records_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, shn_tab_idx(t),
+        hipLaunchKernelGGL(ext_records_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, shn_tab_idx(t),
                            e->d_flags, e->d_weight, n, t->k, t->canonical, e->d_rec, (const unsigned long long*)lines, n_lines); }
       (void)lines;                                       // (lives in the claims' block: overwritten when the claims are initialised below)
     }
