@@ -54,10 +54,18 @@ struct LpProblem {
 
 // workspace layout per problem (T = trials), all [elem][trial]:
 //   C[mn] int64 | X[mn] double | ra[m] | rb[n] | ds[m] int64 | dt[n] int64 | ps[m] int64 | pt[n] int64
+// LDS = true: the trial's state (2 mn + 3 (m + n) words per lane) lives in LDS, [element][lane] -- the successive-shortest-path loops
+// are chains of dependent reads and writes of that state, and through HBM a launch of tiny problems took 0.65 ms (71 ms per step of
+// BASELINE configs[2] over its 109 dependent batches).  The host puts a problem on this kernel when 64 lanes of its state fit
+// LP_LDS_WORDS words; the vertex goes back to the HBM workspace at the end (lp_center_kernel starts from it).  Same operations in
+// the same order: the same bits.
+#define LP_LDS_WORDS 8192          // 64 KB of LDS per block: problems with 2 mn + 3 (m + n) <= 128 words per trial (m = n = 6)
+template <bool LDS>
 __global__ __launch_bounds__(LBLK) void lp_trials_kernel(const LpProblem* __restrict__ probs, const uint32_t* __restrict__ block_prob,
                                                          const uint32_t* __restrict__ block_first, const double* __restrict__ in,
                                                          const uint8_t* __restrict__ masks, uint64_t seed,
                                                          uint64_t* __restrict__ ws, double* __restrict__ out) {
+  extern __shared__ uint64_t lp_lds[];
   const LpProblem P = probs[block_prob[blockIdx.x]];
   const uint32_t t = block_first[blockIdx.x] + threadIdx.x;
   if (t >= P.trials) return;
@@ -65,15 +73,17 @@ __global__ __launch_bounds__(LBLK) void lp_trials_kernel(const LpProblem* __rest
   const double* a_s = in + P.in_off;
   const double* b_s = a_s + m;
   const uint8_t* pm = masks + P.mask_off;
-  int64_t* C = (int64_t*)(ws + P.ws_off);
-  double* X = (double*)(C + (uint64_t)mn * T);
-  double* ra = X + (uint64_t)mn * T;
-  double* rb = ra + (uint64_t)m * T;
-  int64_t* ds = (int64_t*)(rb + (uint64_t)n * T);
-  int64_t* dt = ds + (uint64_t)m * T;
-  int64_t* ps = dt + (uint64_t)n * T;
-  int64_t* pt = ps + (uint64_t)m * T;
-#define AT(arr, e) arr[(uint64_t)(e) * T + t]
+  const uint64_t TS = LDS ? (uint64_t)LBLK : (uint64_t)T;              // stride between the elements of an array
+  const uint64_t tl = LDS ? (uint64_t)threadIdx.x : (uint64_t)t;       // this trial's column
+  int64_t* C = LDS ? (int64_t*)lp_lds : (int64_t*)(ws + P.ws_off);
+  double* X = (double*)(C + (uint64_t)mn * TS);
+  double* ra = X + (uint64_t)mn * TS;
+  double* rb = ra + (uint64_t)m * TS;
+  int64_t* ds = (int64_t*)(rb + (uint64_t)n * TS);
+  int64_t* dt = ds + (uint64_t)m * TS;
+  int64_t* ps = dt + (uint64_t)n * TS;
+  int64_t* pt = ps + (uint64_t)m * TS;
+#define AT(arr, e) arr[(uint64_t)(e) * TS + tl]
 #define CX(i, j) ((uint64_t)((j) * m + (i)))
   for (uint32_t k = 0; k < mn; k++) {
     AT(C, k) = pm[k] ? lp_cell_cost(seed, P.pid, t, k) : 0;
@@ -140,6 +150,10 @@ __global__ __launch_bounds__(LBLK) void lp_trials_kernel(const LpProblem* __rest
   }
   double* o = out + P.out_off;
   for (uint32_t k = 0; k < mn; k++) o[(uint64_t)k * T + t] = AT(X, k);
+  if (LDS) {                                                            // the vertex, where lp_center_kernel looks for it
+    double* Xg = (double*)(ws + P.ws_off) + (uint64_t)mn * T;
+    for (uint32_t k = 0; k < mn; k++) Xg[(uint64_t)k * T + t] = AT(X, k);
+  }
 #undef AT
 #undef CX
 }
@@ -399,7 +413,8 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
   hipStream_t s = ctx->stream;
   const bool center = ctx->lp_rule != SHN_LP_RULE_VERTEX;
   std::vector<LpProblem> probs(n_problems);
-  std::vector<uint32_t> bprob, bfirst, cprob, cfirst;       // blocks of the vertex kernel / of the centre kernel
+  std::vector<uint32_t> bprob, bfirst, lprob, lfirst, cprob, cfirst;       // blocks of the vertex kernel (state in HBM / in LDS) / of the centre kernel
+  uint64_t lds_words = 0;
   uint64_t n_large_trials = 0;
   uint64_t in_off = 0, mask_off = 0, ws_off = 0, out_off = 0, ws2_off = 0, stat_off = 0;
   for (uint32_t p = 0; p < n_problems; p++) {
@@ -414,7 +429,8 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
     ws_off += (2 * mn + 3ULL * (m[p] + n[p])) * trials[p];
     stat_off += trials[p];
     out_off += mn * trials[p];
-    for (uint32_t f = 0; f < trials[p]; f += LBLK) { bprob.push_back(p); bfirst.push_back(f); }
+    const bool in_lds = (2 * mn + 3ULL * (m[p] + n[p])) * LBLK <= LP_LDS_WORDS;
+    for (uint32_t f = 0; f < trials[p]; f += LBLK) { (in_lds ? lprob : bprob).push_back(p); (in_lds ? lfirst : bfirst).push_back(f); lds_words = in_lds ? std::max<uint64_t>(lds_words, (2 * mn + 3ULL * (m[p] + n[p])) * LBLK) : lds_words; }
     // the centre kernel has work only where the supported cells of the problem hold a cycle (rows and columns as vertices, a
     // supported cell as an edge): on a forest every class is a tree and its face a point.  At BASELINE configs[2] 9,000
     // problems per step, a handful with a cycle.
@@ -442,7 +458,7 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
   // step's front half), and shn_ws_release_idle never touches a context's own slots
   void *pp, *pb, *pin, *pm, *pws, *pout, *pws2, *pst;
   int rc;
-  if ((rc = ctx->cws[4].get(probs.size() * sizeof(LpProblem), &pp)) || (rc = ctx->cws[5].get((bprob.size() + cprob.size()) * 8 + 16, &pb)) ||
+  if ((rc = ctx->cws[4].get(probs.size() * sizeof(LpProblem), &pp)) || (rc = ctx->cws[5].get((bprob.size() + lprob.size() + cprob.size()) * 8 + 16, &pb)) ||
       (rc = ctx->cws[6].get(in_off * 8 + 16, &pin)) || (rc = ctx->cws[7].get(mask_off + 16, &pm)) ||
       (rc = ctx->cws[8].get(ws_off * 8 + 16, &pws)) || (rc = ctx->cws[9].get(out_off * 8 + 16, &pout)) ||
       (rc = ctx->cws[10].get(ws2_off * 8 + 16, &pws2)) || (rc = ctx->cws[11].get(stat_off * 16 + 16, &pst))) return rc;
@@ -450,13 +466,27 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
   uint32_t* d_bfirst = d_bprob + bprob.size();
   uint32_t* d_cprob = d_bfirst + bprob.size();
   uint32_t* d_cfirst = d_cprob + cprob.size();
+  uint32_t* d_lprob = d_cfirst + cprob.size();
+  uint32_t* d_lfirst = d_lprob + lprob.size();
   HIP_TRY(hipMemcpyAsync(pp, probs.data(), probs.size() * sizeof(LpProblem), hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(d_bprob, bprob.data(), bprob.size() * 4, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(d_bfirst, bfirst.data(), bfirst.size() * 4, hipMemcpyHostToDevice, s));
+  if (!bprob.empty()) {
+    HIP_TRY(hipMemcpyAsync(d_bprob, bprob.data(), bprob.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_bfirst, bfirst.data(), bfirst.size() * 4, hipMemcpyHostToDevice, s));
+  }
+  if (!lprob.empty()) {
+    HIP_TRY(hipMemcpyAsync(d_lprob, lprob.data(), lprob.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_lfirst, lfirst.data(), lfirst.size() * 4, hipMemcpyHostToDevice, s));
+  }
   HIP_TRY(hipMemcpyAsync(pin, ab, in_off * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(pm, mask, mask_off, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(lp_trials_kernel, dim3((uint32_t)bprob.size()), dim3(LBLK), 0, s, (const LpProblem*)pp, d_bprob, d_bfirst,
-                     (const double*)pin, (const uint8_t*)pm, seed, (uint64_t*)pws, (double*)pout);
+  if (!lprob.empty()) {
+    if (lds_words * 8 > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)lp_trials_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LP_LDS_WORDS * 8)));
+    hipLaunchKernelGGL(lp_trials_kernel<true>, dim3((uint32_t)lprob.size()), dim3(LBLK), lds_words * 8, s, (const LpProblem*)pp, d_lprob, d_lfirst,
+                       (const double*)pin, (const uint8_t*)pm, seed, (uint64_t*)pws, (double*)pout);
+  }
+  if (!bprob.empty())
+    hipLaunchKernelGGL(lp_trials_kernel<false>, dim3((uint32_t)bprob.size()), dim3(LBLK), 0, s, (const LpProblem*)pp, d_bprob, d_bfirst,
+                       (const double*)pin, (const uint8_t*)pm, seed, (uint64_t*)pws, (double*)pout);
   std::vector<uint32_t> stat;
   if (center && !cprob.empty()) {
     HIP_TRY(hipMemcpyAsync(d_cprob, cprob.data(), cprob.size() * 4, hipMemcpyHostToDevice, s));
