@@ -115,28 +115,38 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
     # ---- 1. local count + bucket exchange + reduce by key
     lock.acquire()
     t0 = time.time()
-    keys, counts, send = ops.local_pairs(W)
-    tick("count", t0)
-    lock.release()
+    if W == 1 and hasattr(ops, "local_table"):
+        # one rank: nothing to exchange, reduce or gather -- the counted table IS the table (it used to be exported to pairs, reduced
+        # into a table, exported again and rebuilt: two passes through the pairs path, 0.2 s at configs[2])
+        table = ops.local_table()
+        tick("count", t0)
+        gk = None
+    else:
+        keys, counts, send = ops.local_pairs(W)
+        tick("count", t0)
+        lock.release()
+        t0 = time.time()
+        rk, rc, _ = exchange.all_to_all_pairs(keys, counts, send, group)
+        tick("x:bucket exchange", t0)
+        lock.acquire()
+        t0 = time.time()
+        ok, oc = ops.reduce_pairs(rk, rc)
+        tick("reduce", t0)
+        lock.release()
+        # ---- 2. replicate the (small) distinct-k1-mer table, extension + partitioning on every rank
+        t0 = time.time()
+        gk, _ = _all_gather_var(ok, group)
+        gc, _ = _all_gather_var(oc, group)
+        tick("x:allgather table", t0)
+        lock.acquire()
+        t0 = time.time()
+        table = ops.table_from_pairs(gk, gc)
+        tick("table", t0)
     t0 = time.time()
-    rk, rc, _ = exchange.all_to_all_pairs(keys, counts, send, group)
-    tick("x:bucket exchange", t0)
-    lock.acquire()
-    t0 = time.time()
-    ok, oc = ops.reduce_pairs(rk, rc)
-    tick("reduce", t0)
-    lock.release()
-    # ---- 2. replicate the (small) distinct-k1-mer table, extension + partitioning on every rank
-    t0 = time.time()
-    gk, _ = _all_gather_var(ok, group)
-    gc, _ = _all_gather_var(oc, group)
-    tick("x:allgather table", t0)
-    lock.acquire()
-    t0 = time.time()
-    table = ops.table_from_pairs(gk, gc)
-    tick("table", t0)
-    t0 = time.time()
+    n_table = len(table) if gk is None else None
     res = ops.extension(table, partition_size, group) if getattr(ops, "sharded_extension", False) else ops.extension(table, partition_size)
+    if n_table is not None:
+        res.n_k1mers_table = n_table
     tick("extension", t0)
     w = getattr(ops, "coll_wait", 0.0)       # the sharded contig stage's object collectives, reported apart
     if w:
@@ -337,7 +347,7 @@ def _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick, error=N
     tick("merge (rank 0)", t0)
     lock.release()
     return {"partitions": parts, "final": final, "contigs": res.contigs,
-            "n_k1mers": int(gk.numel()),
+            "n_k1mers": int(gk.numel()) if gk is not None else int(getattr(res, "n_k1mers_table", 0)),
             "extension": {k: getattr(res, k, None) for k in ("iterations", "n_walks", "total_steps", "wave_steps", "dense_rounds")}}
 
 
@@ -371,6 +381,10 @@ class GpuOps(object):
         per = t.shard(W, dk.data_ptr(), dc.data_ptr())
         t.close()
         return dk, dc, per
+
+    def local_table(self):
+        """one-rank job: the counted table itself (no export to pairs)"""
+        return self._dev.count_k1mers(self.ctx, [self.d1, self.d2] if self.paired else [self.d1], self.K + 1, True)
 
     def reduce_pairs(self, rk, rc):
         torch.cuda.synchronize()
