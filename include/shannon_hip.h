@@ -372,6 +372,15 @@ void shn_post_destroy(shn_post* p);
  * K <= 31, ACGT only.                                                                                                            */
 int shn_known_paths_scan(shn_ctx* ctx, const shn_reads* reads, int K, const uint8_t* node_bases, const uint64_t* node_off, uint64_t n_nodes,
                          uint8_t* state_out, int32_t* node_out, uint32_t* offset_out);
+/* The same, and the reads of state 3 searched on the device (search_sequence, mbgraph.py:114-160): edge_off[n_nodes + 1] / edge_dst /
+ * edge_ov = the out-edges of the nodes in list order (destination = index into the node order, the offset into the destination at
+ * which it continues the source).  A read searched there gets state 4; its paths are records [read, length, node indices ...] in
+ * paths_out (paths_cap 32-bit words), in the order the reference's recursion enumerates them; a reader walks the records by their
+ * lengths up to *paths_used words and stops at a length of 0.  Reads whose search is deeper than 12 nodes or finds no room keep
+ * state 3 (the caller searches them itself).                                                                                        */
+int shn_known_paths_search(shn_ctx* ctx, const shn_reads* reads, int K, const uint8_t* node_bases, const uint64_t* node_off, uint64_t n_nodes,
+                           const uint32_t* edge_off, const uint32_t* edge_dst, const uint32_t* edge_ov, uint8_t* state_out, int32_t* node_out,
+                           uint32_t* offset_out, int32_t* paths_out, uint64_t paths_cap, uint64_t* paths_used);
 /* Host threads the library keeps busy at most: min(hardware threads, affinity mask, cgroup CPU quota) / ranks on the node
  * (LOCAL_WORLD_SIZE or SHN_LOCAL_RANKS); SHN_HOST_CPUS overrides.
  * (-- ; the reference takes its process count from --nprocs, shannon.py:99.)                                                   */

@@ -76,6 +76,7 @@ SIGNATURES = {
     "shn_host_cpus": (C.c_int, []),
     "shn_malloc_tune_now": (None, []),
     "shn_known_paths_scan": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_uint64, vp, vp, vp]),
+    "shn_known_paths_search": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp, C.c_uint64, vp]),
     "shn_post_finalize": (C.c_int, [vp, C.c_uint64, C.c_int, C.c_int, vpp]),
     "shn_post_finalize_bufs": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_int, vpp]),
     "shn_post_finalize_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vpp]),

@@ -131,13 +131,92 @@ __global__ void kp_classify(RView v, int K, const unsigned long long* __restrict
   if (off_out) off_out[r] = fo;
 }
 
+
+// ---- the search itself for the reads of state 3 (search_sequence, mbgraph.py:114-160 / mbgraph_host.hip): from the node and offset
+// the read's first K-mer fixed, the read is followed node by node over the out-edges (in list order; an edge (dst, ov) is taken
+// when the node text of dst from ov on agrees with the rest of the read), every complete way is a path.  One thread per read,
+// depth first with an explicit stack -- twice: first counting the words its paths need, then, after ONE atomic reserved them,
+// writing them: [read, length, nodes ...] records in the order the host's recursion would have produced them.  A read whose
+// search runs deeper than KP_DEPTH nodes or finds no room keeps state 3 and is searched on the host as before.
+#define KP_DEPTH 12
+#define KP_HOPS 30
+struct KpGraph { const uint8_t* bases; const uint64_t* off; const uint32_t* eoff; const uint32_t* edst; const uint32_t* eov; };
+
+__device__ __forceinline__ bool kp_agree(const uint64_t* __restrict__ w, uint32_t L, uint32_t so, const KpGraph& G, uint32_t node, uint32_t i) {
+  // compare(seq, so, bases[node], i): the common length of the two tails
+  const uint64_t nb = G.off[node + 1] - G.off[node];
+  if ((uint64_t)i > nb) return false;
+  const uint32_t n = (uint32_t)min((uint64_t)(L - so), nb - i);
+  const uint8_t* b = G.bases + G.off[node] + i;
+  for (uint32_t q = 0; q < n; q++) {
+    const uint32_t p = so + q;
+    const uint32_t rb = (uint32_t)((w[p >> 5] >> (62 - 2 * (p & 31))) & 3ULL);
+    if (kp_code(b[q]) != (int)rb) return false;
+  }
+  return true;
+}
+
+// one depth-first run; out == NULL: only counts.  Returns the words of all records, or -1 when the stack is too shallow.
+__device__ int kp_dfs(const uint64_t* __restrict__ w, uint32_t L, const KpGraph& G, uint32_t r, uint32_t node0, uint32_t i0, int32_t* __restrict__ out) {
+  uint32_t st_node[KP_DEPTH], st_so[KP_DEPTH], st_e[KP_DEPTH];
+  int depth = 0, words = 0;
+  st_node[0] = node0; st_so[0] = 0; st_e[0] = 0xFFFFFFFFu;           // e = 0xFFFFFFFF: the node has just been entered
+  uint32_t st_i[KP_DEPTH];                                             // offset into the node at which the read continues
+  st_i[0] = i0;
+  while (depth >= 0) {
+    const uint32_t node = st_node[depth];
+    const uint32_t nl = (uint32_t)(G.off[node + 1] - G.off[node]) - st_i[depth];
+    if (st_e[depth] == 0xFFFFFFFFu) {
+      const int hops = KP_HOPS - depth;
+      if (hops <= 0 || L - st_so[depth] <= nl) {                       // the read ends in this node (or the hop limit): a path
+        if (out) { out[words] = (int32_t)r; out[words + 1] = depth + 1; for (int d = 0; d <= depth; d++) out[words + 2 + d] = (int32_t)st_node[d]; }
+        words += depth + 3;
+        depth--;
+        continue;
+      }
+      st_e[depth] = G.eoff[node];
+    }
+    const uint32_t so2 = st_so[depth] + nl;
+    bool went = false;
+    while (st_e[depth] < G.eoff[node + 1]) {
+      const uint32_t e = st_e[depth]++;
+      const uint32_t dst = G.edst[e], ov = G.eov[e];
+      if (!kp_agree(w, L, so2, G, dst, ov)) continue;
+      if (depth + 1 >= KP_DEPTH) return -1;
+      depth++;
+      st_node[depth] = dst; st_so[depth] = so2; st_i[depth] = ov; st_e[depth] = 0xFFFFFFFFu;
+      went = true;
+      break;
+    }
+    if (!went) depth--;
+  }
+  return words;
+}
+
+__global__ void kp_search(RView v, KpGraph G, uint8_t* __restrict__ state, const int32_t* __restrict__ node_out, const uint32_t* __restrict__ off_out,
+                          int32_t* __restrict__ paths, uint64_t cap, unsigned long long* __restrict__ cursor) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= v.n || state[r] != 3) return;
+  const uint32_t L = v.len ? v.len[r] : v.fixed_len;
+  const uint64_t* w = v.words + (v.woff ? v.woff[r] : r * v.wpr);
+  const int need = kp_dfs(w, L, G, (uint32_t)r, (uint32_t)node_out[r], off_out[r], nullptr);
+  if (need < 0) return;
+  if (need == 0) { state[r] = 4; return; }                            // (no way through the graph: nothing to record)
+  const unsigned long long at = atomicAdd(cursor, (unsigned long long)need);
+  if (at + (unsigned long long)need > cap) return;                    // (no room: the host searches this read)
+  kp_dfs(w, L, G, (uint32_t)r, (uint32_t)node_out[r], off_out[r], paths + at);
+  state[r] = 4;
+}
+
 }  // namespace
 
 // reads: the distinct reads of the partition (ACGT only); node_bases / node_off: the texts of the partition's nodes one after
 // the other, in the order the host's seed index would list them; state_out[r] / node_out[r] as described above (node = index
 // into that order).  SHN_ERR_ARG if a node holds a base outside ACGT or K > 31.
-extern "C" int shn_known_paths_scan(shn_ctx* ctx, const shn_reads* reads, int K, const uint8_t* node_bases, const uint64_t* node_off,
-                                    uint64_t n_nodes, uint8_t* state_out, int32_t* node_out, uint32_t* offset_out) {
+static int kp_scan_impl(shn_ctx* ctx, const shn_reads* reads, int K, const uint8_t* node_bases, const uint64_t* node_off,
+                        uint64_t n_nodes, uint8_t* state_out, int32_t* node_out, uint32_t* offset_out,
+                        const uint32_t* edge_off, const uint32_t* edge_dst, const uint32_t* edge_ov, int32_t* paths_out, uint64_t paths_cap, uint64_t* paths_used) {
+  if (paths_used) *paths_used = 0;
   if (!ctx || !reads || !node_off || (n_nodes && !node_bases) || (reads->n_reads && (!state_out || !node_out)))
     return shn_fail(SHN_ERR_ARG, "shn_known_paths_scan: NULL argument");
   if (K < 1 || K > 31) return shn_fail(SHN_ERR_ARG, "shn_known_paths_scan: K must be in [1,31]");
@@ -187,6 +266,21 @@ extern "C" int shn_known_paths_scan(shn_ctx* ctx, const shn_reads* reads, int K,
   hipLaunchKernelGGL(kp_classify, dim3((uint32_t)cdiv(nr, 256)), dim3(256), 0, s, v, K, d_hkeys, T - 1, d_goff, d_occ, d_bases, d_off, (uint32_t)n_nodes,
                      d_state, d_node, offset_out ? d_ofs : nullptr);
   TRYK(hipGetLastError());
+  int32_t* d_paths = nullptr;
+  const bool search = offset_out && edge_off && paths_out && paths_cap && paths_used;
+  if (search) {
+    const uint64_t ne = edge_off[n_nodes];
+    uint32_t *d_eoff = nullptr, *d_edst = nullptr, *d_eov = nullptr;
+    TRYK(bufs.get(&d_eoff, (n_nodes + 1) * 4)); TRYK(bufs.get(&d_edst, (ne + 1) * 4)); TRYK(bufs.get(&d_eov, (ne + 1) * 4));
+    TRYK(bufs.get(&d_paths, (paths_cap + 1) * 4));
+    TRYK(hipMemsetAsync(d_paths, 0, (paths_cap + 1) * 4, s));             // (a reader walks the records by their lengths and stops at a length of 0)
+    TRYK(hipMemcpyAsync(d_eoff, edge_off, (n_nodes + 1) * 4, hipMemcpyHostToDevice, s));
+    if (ne) { TRYK(hipMemcpyAsync(d_edst, edge_dst, ne * 4, hipMemcpyHostToDevice, s)); TRYK(hipMemcpyAsync(d_eov, edge_ov, ne * 4, hipMemcpyHostToDevice, s)); }
+    KpGraph G{d_bases, d_off, d_eoff, d_edst, d_eov};
+    hipLaunchKernelGGL(kp_search, dim3((uint32_t)cdiv(nr, 64)), dim3(64), 0, s, v, G, d_state, (const int32_t*)d_node, (const uint32_t*)d_ofs, d_paths, paths_cap,
+                       d_cnt2 + 0);
+    TRYK(hipGetLastError());
+  }
   unsigned long long cnt[2] = {0, 0};
   TRYK(hipMemcpyAsync(cnt, d_cnt2, 16, hipMemcpyDeviceToHost, s));
   TRYK(hipMemcpyAsync(state_out, d_state, nr, hipMemcpyDeviceToHost, s));
@@ -194,6 +288,30 @@ extern "C" int shn_known_paths_scan(shn_ctx* ctx, const shn_reads* reads, int K,
   if (offset_out) TRYK(hipMemcpyAsync(offset_out, d_ofs, nr * 4, hipMemcpyDeviceToHost, s));
   TRYK(hipStreamSynchronize(s));
   if (cnt[1]) return shn_fail(SHN_ERR_ARG, "shn_known_paths_scan: a node holds a base outside ACGT");
+  if (search) {
+    // (the cursor counts what was asked for: once a request does not fit, none after it does; the records lie below it, the buffer
+    // was zeroed, so the reader stops at the first record of length 0)
+    const uint64_t used = std::min<uint64_t>(cnt[0], paths_cap);
+    if (used) TRYK(hipMemcpy(paths_out, d_paths, used * 4, hipMemcpyDeviceToHost));
+    *paths_used = used;
+  }
 #undef TRYK
   return SHN_OK;
+}
+
+extern "C" int shn_known_paths_scan(shn_ctx* ctx, const shn_reads* reads, int K, const uint8_t* node_bases, const uint64_t* node_off,
+                                    uint64_t n_nodes, uint8_t* state_out, int32_t* node_out, uint32_t* offset_out) {
+  return kp_scan_impl(ctx, reads, K, node_bases, node_off, n_nodes, state_out, node_out, offset_out, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+}
+
+// The same, and the reads of state 3 searched on the device (kp_search): edge_off[n_nodes + 1] / edge_dst / edge_ov = the out-edges of
+// the nodes in list order (destination as an index into the given node order, offset into the destination at which it continues
+// the source: search_sequence's `ew`).  A read searched there gets state 4; its paths are records [read, length, node indices ...]
+// in paths_out (paths_cap words), in the order search_sequence enumerates them, the records of one read in ascending position; a
+// reader walks the records by their lengths up to `*paths_used` words and stops at a length of 0 (a request that found no room).
+extern "C" int shn_known_paths_search(shn_ctx* ctx, const shn_reads* reads, int K, const uint8_t* node_bases, const uint64_t* node_off, uint64_t n_nodes,
+                                      const uint32_t* edge_off, const uint32_t* edge_dst, const uint32_t* edge_ov, uint8_t* state_out, int32_t* node_out,
+                                      uint32_t* offset_out, int32_t* paths_out, uint64_t paths_cap, uint64_t* paths_used) {
+  if (!edge_off || !offset_out || !paths_out || !paths_used) return shn_fail(SHN_ERR_ARG, "shn_known_paths_search: NULL argument");
+  return kp_scan_impl(ctx, reads, K, node_bases, node_off, n_nodes, state_out, node_out, offset_out, edge_off, edge_dst, edge_ov, paths_out, paths_cap, paths_used);
 }

@@ -766,8 +766,27 @@ struct Graph {
         std::vector<uint8_t> st(n_rd());
         std::vector<int32_t> nd(n_rd());
         std::vector<uint32_t> no(n_rd());
+        // the out-edges of the nodes in list order, for the device's search of the reads that run past their first node (kp_search):
+        // destination as an index into `order`, and the offset into the destination at which it continues the source
+        std::vector<uint32_t> eoff(order.size() + 1, 0), edst, eov;
+        {
+          std::unordered_map<int, uint32_t> pos_of;
+          pos_of.reserve(order.size() * 2);
+          for (size_t q = 0; q < order.size(); q++) pos_of[order[q]] = (uint32_t)q;
+          for (size_t q = 0; q < order.size(); q++) {
+            for (int e : oute[order[q]]) { edst.push_back(pos_of[ed[e]]); eov.push_back((uint32_t)ew[e]); }
+            eoff[q + 1] = (uint32_t)edst.size();
+          }
+        }
+        // room for the records [read, length, nodes ...] of the searched reads: a few words per read that runs on (4 % of the reads do)
+        std::vector<int32_t> precs(std::max<size_t>(1u << 16, n_rd() / 2 + 4096));
+        uint64_t precs_used = 0;
         tk1 = nowk();
-        const int rcs = shn_known_paths_scan(ctx, d_reads, K, (const uint8_t*)nb.data(), noff.data(), order.size(), st.data(), nd.data(), no.data());
+        static const bool kp_dev_search = !(getenv("SHN_GRAPH_KP_SEARCH") && getenv("SHN_GRAPH_KP_SEARCH")[0] == '0');
+        const int rcs = kp_dev_search
+            ? shn_known_paths_search(ctx, d_reads, K, (const uint8_t*)nb.data(), noff.data(), order.size(), eoff.data(), edst.data(), eov.data(), st.data(),
+                                     nd.data(), no.data(), precs.data(), precs.size(), &precs_used)
+            : shn_known_paths_scan(ctx, d_reads, K, (const uint8_t*)nb.data(), noff.data(), order.size(), st.data(), nd.data(), no.data());
         release_gpu();
         tk2 = nowk();
         if (rcs == 0) {
@@ -815,7 +834,7 @@ struct Graph {
             std::vector<std::pair<int, int>> one(1);
             static const std::vector<std::pair<int, int>> none;
             for (size_t r = lo; r < hi; r++) {
-              if (st[r] < 2) continue;
+              if (st[r] < 2 || st[r] == 4) continue;            // (4: searched on the device, its paths come in the records)
               const RStr rb = rstr((int)r);
               uint64_t key;
               if (!key_at(rb, 0, key)) continue;
@@ -861,6 +880,23 @@ struct Graph {
             cntp += L.cntp;
             for (const auto& kv : L.edge_sum) known_edges[{(int)(uint32_t)(kv.first >> 32), (int)(uint32_t)kv.first}] += kv.second;
             for (auto& p : L.fresh) known_paths.insert(std::move(p));
+          }
+          // the reads the device searched (state 4): their paths as it enumerated them, a read's records in the recursion's order (the
+          // last one names its first / last node, mbgraph.py:1379-1384); the sums are of whole numbers, so no order shows in them
+          {
+            std::unordered_map<uint64_t, double> edge_sum;
+            std::vector<int> pth;
+            for (uint64_t at = 0; at + 2 <= precs_used;) {
+              const int32_t r = precs[at], len = precs[at + 1];
+              if (len <= 0 || at + 2 + (uint64_t)len > precs_used) break;
+              pth.resize((size_t)len);
+              for (int32_t j = 0; j < len; j++) pth[(size_t)j] = order[(size_t)precs[at + 2 + (uint64_t)j]];
+              at += 2 + (uint64_t)len;
+              rfirst[r] = pth.front(); rlast[r] = pth.back(); rhas[r] = 1;
+              for (size_t j = 0; j + 1 < pth.size(); j++) edge_sum[((uint64_t)(uint32_t)pth[j] << 32) | (uint32_t)pth[j + 1]] += rcc[r];
+              if (pth.size() > 2) { cntp++; known_paths.insert(pth); }
+            }
+            for (const auto& kv : edge_sum) known_edges[{(int)(uint32_t)(kv.first >> 32), (int)(uint32_t)kv.first}] += kv.second;
           }
           n_known = cntp;
           if (dbgk) fprintf(stderr, "[mbgraph]   kp (device) node text %.3f s scan %.3f s slow index %.3f s search %.3f s  (%zu bases, %zu reads, %zu slow)\n", tk1 - tk0,
