@@ -43,15 +43,10 @@ __device__ __forceinline__ void slot_origin(const SlotSrc& S, uint64_t j, const 
 }
 __device__ __forceinline__ uint64_t slot_word(const SlotSrc& S, const uint64_t* src, bool rc, uint32_t w) {
   if (!rc) return src[w];
-  uint64_t v = 0;
-  for (uint32_t t = 0; t < 32; t++) {
-    const uint32_t p = 32 * w + t;
-    if (p >= S.L) break;
-    const uint32_t q = S.L - 1 - p;
-    const uint64_t base = (src[q >> 5] >> (62 - 2 * (q & 31))) & 3ULL;
-    v |= (3ULL - base) << (62 - 2 * t);
-  }
-  return v;
+  // bases [32 w, 32 w + nb) of the reverse complement = the complement of bases [L - 32 w - nb, L - 32 w) read backwards
+  if (32 * w >= S.L) return 0;
+  const uint32_t nb = min(32u, S.L - 32 * w);
+  return shn_revcomp(shn_extract(src, S.L - 32 * w - nb, (int)nb), (int)nb) << (64 - 2 * nb);
 }
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {
   x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
@@ -61,13 +56,19 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
 constexpr int MAXW = 16;                                  // reads of up to 512 bases
 
+// MW: compile-time bound of the words per read (the words of a slot stay in registers: a run-time bound put them in scratch)
+template <int MW>
 __global__ void dd_insert(SlotSrc S, uint64_t nh, uint32_t* __restrict__ tab, uint64_t mask, uint32_t* __restrict__ slot_of) {
   for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nh; j += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t* src; bool rc;
     slot_origin(S, j, src, rc);
-    uint64_t w[MAXW];
+    uint64_t w[MW];
     uint64_t h = 0x9E3779B97F4A7C15ULL;
-    for (uint32_t t = 0; t < S.wpr; t++) { w[t] = slot_word(S, src, rc, t); h = mix64(h ^ w[t]) + 0x9E3779B97F4A7C15ULL * (t + 1); }
+#pragma unroll
+    for (uint32_t t = 0; t < (uint32_t)MW; t++) {
+      w[t] = 0;
+      if (t < S.wpr) { w[t] = slot_word(S, src, rc, t); h = mix64(h ^ w[t]) + 0x9E3779B97F4A7C15ULL * (t + 1); }
+    }
     uint64_t s = h & mask;
     while (true) {
       uint32_t cur = tab[s];
@@ -78,7 +79,8 @@ __global__ void dd_insert(SlotSrc S, uint64_t nh, uint32_t* __restrict__ tab, ui
       const uint64_t* osrc; bool orc;
       slot_origin(S, cur, osrc, orc);
       bool same = true;
-      for (uint32_t t = 0; t < S.wpr && same; t++) same = slot_word(S, osrc, orc, t) == w[t];
+#pragma unroll
+      for (uint32_t t = 0; t < (uint32_t)MW; t++) if (t < S.wpr && same) same = slot_word(S, osrc, orc, t) == w[t];
       if (same) { atomicMin(&tab[s], (uint32_t)j); slot_of[j] = (uint32_t)s; break; }
       s = (s + 1) & mask;
     }
@@ -161,7 +163,8 @@ extern "C" int shn_reads_dedup(shn_ctx* ctx, const shn_reads* a, const shn_reads
   TRYD(hipMemsetAsync(d_last, 0, nh * 4, s));
   SlotSrc S{a->d_words, b ? b->d_words : a->d_words, d_idx, n_in, a->wpr, a->fixed_len, paired ? 1 : 0};
   const uint32_t grid = (uint32_t)std::min<uint64_t>(cdiv(nh, 256), 1u << 20);
-  hipLaunchKernelGGL(dd_insert, dim3(grid), dim3(256), 0, s, S, nh, d_tab, T - 1, d_slot);
+  if (a->wpr <= 4) hipLaunchKernelGGL(dd_insert<4>, dim3(grid), dim3(256), 0, s, S, nh, d_tab, T - 1, d_slot);
+  else hipLaunchKernelGGL(dd_insert<MAXW>, dim3(grid), dim3(256), 0, s, S, nh, d_tab, T - 1, d_slot);
   hipLaunchKernelGGL(dd_tally, dim3(grid), dim3(256), 0, s, nh, d_tab, d_slot, d_first, d_cnt, d_last, d_flag);
   TRYD(hipGetLastError());
   uint64_t nd = 0;

@@ -51,6 +51,64 @@ __global__ __launch_bounds__(SBLK2) void seed_scan_kernel(SView v, int K, uint32
   }
 }
 
+// mode 0, interior starts only (find_bridging_reads): ONE thread per read with a rolling K-mer.  The patterns are few (the K-mers
+// at the start of the graph's x-nodes: 10^2-10^4 per partition) and the windows many (74 per 100-base read), so in front of the
+// table stands a 2^18-bit filter held in the LDS: 98-99 % of the windows end at one LDS read.  A read's hits are written one after
+// the other from the read's own offset: (read, start) order without ballots; the FILL pass skips the reads without a hit.
+// (the form above -- a thread per window, two passes of table look-ups -- was 83 ms per step at BASELINE configs[2])
+#define SEED_BM_BITS 18
+#define SEED_BM_WORDS (1u << (SEED_BM_BITS - 5))
+__device__ __forceinline__ uint32_t seed_bm_hash(uint64_t key) {
+  const uint32_t x = ((uint32_t)key * 0x9E3779B1u) ^ ((uint32_t)(key >> 32) * 0x85EBCA6Bu);
+  return x >> (32 - SEED_BM_BITS);
+}
+__global__ void seed_bm_build_kernel(const uint64_t* __restrict__ keys, uint64_t n, uint32_t* __restrict__ bm) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t h = seed_bm_hash(keys[i]);
+  atomicOr(&bm[h >> 5], 1u << (h & 31));
+}
+template <bool FILL>
+__global__ __launch_bounds__(SBLK2) void seed_scan_reads_kernel(SView v, int K, const uint32_t* __restrict__ bm_g, const uint64_t* __restrict__ tkeys,
+                                                                const uint32_t* __restrict__ tvals, const uint64_t* __restrict__ boff, int bits,
+                                                                uint32_t* __restrict__ counts, const uint64_t* __restrict__ offs,
+                                                                uint32_t* __restrict__ o_read, uint32_t* __restrict__ o_start, uint32_t* __restrict__ o_id) {
+  __shared__ uint32_t bm[SEED_BM_WORDS];
+  for (uint32_t i = threadIdx.x; i < SEED_BM_WORDS; i += SBLK2) bm[i] = bm_g[i];
+  __syncthreads();
+  const uint64_t mask = K == 32 ? ~0ULL : ((1ULL << (2 * K)) - 1);
+  for (uint64_t r = (uint64_t)blockIdx.x * SBLK2 + threadIdx.x; r < v.n; r += (uint64_t)gridDim.x * SBLK2) {
+    uint64_t o = 0;
+    if (FILL) { o = offs[r]; if (offs[r + 1] == o) continue; }
+    const uint32_t len = v.len ? v.len[r] : v.fixed_len;
+    uint32_t c = 0;
+    if (len >= (uint32_t)K + 2) {                                   // starts 1 .. len-K-1 (range(1, len - K))
+      const uint64_t* __restrict__ w = v.words + (v.woff ? v.woff[r] : r * v.wpr);
+      uint64_t key = shn_extract(w, 1, K);
+      uint32_t p = (uint32_t)K + 1;                                  // the base the next start brings in
+      uint64_t cur = w[p >> 5];
+      const uint32_t last = len - (uint32_t)K - 1;
+      for (uint32_t start = 1; start <= last; start++) {
+        const uint32_t h = seed_bm_hash(key);
+        if ((bm[h >> 5] >> (h & 31)) & 1u) {
+          const int64_t j = shn_table_find(tkeys, boff, bits, key);
+          const uint32_t id = j >= 0 ? tvals[j] : 0u;
+          if (id) {
+            if (FILL) { o_read[o + c] = (uint32_t)r; o_start[o + c] = start; o_id[o + c] = id - 1; }
+            c++;
+          }
+        }
+        if (start < last) {
+          key = ((key << 2) | ((cur >> (62 - 2 * (p & 31))) & 3ULL)) & mask;
+          p++;
+          if ((p & 31) == 0) cur = w[p >> 5];
+        }
+      }
+    }
+    if (!FILL) counts[r] = c;
+  }
+}
+
 // mode 1: first / last K-mer of every read
 __global__ void seed_ends_kernel(SView v, int K, const uint64_t* __restrict__ tkeys, const uint32_t* __restrict__ tvals,
                                  const uint64_t* __restrict__ boff, int bits, uint32_t* __restrict__ first_id,
@@ -91,18 +149,29 @@ static int seed_scan_impl(shn_ctx* ctx, const shn_reads* reads, int K, const shn
   if (total == 0) { *n_hits = 0; return SHN_OK; }
   void *pc, *po;
   int rc;
-  const uint32_t grid = (uint32_t)cdiv(total, SBLK2);
-  if ((rc = ctx->cws[1].get(((size_t)grid + 1) * 4, &pc)) || (rc = ctx->cws[2].get(((size_t)grid + 2) * 8, &po))) return rc;
-  // (the call that asks for the number of hits and the one that fetches them come in pairs: the second finds the block offsets of
-  // the first in the context's workspace -- same reads, same patterns, nothing in between on this context)
+  // interior starts: a thread per read behind an LDS filter (seed_scan_reads_kernel); every window: a thread per window
+  const bool per_read = !ALL && getenv("SHN_SEED_PER_WINDOW") == nullptr;
+  const uint32_t grid = per_read ? (uint32_t)std::min<uint64_t>(cdiv(v.n, SBLK2), 4096) : (uint32_t)cdiv(total, SBLK2);
+  const uint64_t n_cnt = per_read ? v.n : grid;                 // counts: per read / per block of 256 windows
+  if ((rc = ctx->cws[1].get((n_cnt + 1) * 4, &pc)) || (rc = ctx->cws[2].get((n_cnt + 2) * 8, &po))) return rc;
+  void* pbm = nullptr;
+  if (per_read && (rc = ctx->cws[3].get(SEED_BM_WORDS * 4, &pbm))) return rc;
+  // (the call that asks for the number of hits and the one that fetches them come in pairs: the second finds the offsets (and the
+  // filter) of the first in the context's workspace -- same reads, same patterns, nothing in between on this context)
   static thread_local struct { const shn_ctx* ctx; const shn_reads* reads; const shn_table* pat; uint64_t total, n_reads, n_pat, nh; int K; bool all; } last = {};
   uint64_t nh = 0;
   if (out_read && last.ctx == ctx && last.reads == reads && last.pat == patterns && last.total == total && last.n_reads == reads->n_reads &&
       last.n_pat == patterns->n && last.K == K && last.all == ALL) nh = last.nh;
   else {
-    hipLaunchKernelGGL((seed_scan_kernel<false, ALL>), dim3(grid), dim3(SBLK2), 0, s, v, K, max_win, patterns->d_keys, patterns->d_counts,
-                       patterns->d_bucket_off, patterns->bits, (uint32_t*)pc, nullptr, nullptr, nullptr, nullptr);
-    if ((rc = shn_device_scan_u32(ctx, (uint32_t*)pc, grid, (uint64_t*)po, &nh))) return rc;
+    if (per_read) {
+      HIP_TRY(hipMemsetAsync(pbm, 0, SEED_BM_WORDS * 4, s));
+      if (patterns->n) hipLaunchKernelGGL(seed_bm_build_kernel, dim3((uint32_t)cdiv(patterns->n, 256)), dim3(256), 0, s, patterns->d_keys, patterns->n, (uint32_t*)pbm);
+      hipLaunchKernelGGL((seed_scan_reads_kernel<false>), dim3(grid), dim3(SBLK2), 0, s, v, K, (const uint32_t*)pbm, patterns->d_keys, patterns->d_counts,
+                         patterns->d_bucket_off, patterns->bits, (uint32_t*)pc, nullptr, nullptr, nullptr, nullptr);
+    } else
+      hipLaunchKernelGGL((seed_scan_kernel<false, ALL>), dim3(grid), dim3(SBLK2), 0, s, v, K, max_win, patterns->d_keys, patterns->d_counts,
+                         patterns->d_bucket_off, patterns->bits, (uint32_t*)pc, nullptr, nullptr, nullptr, nullptr);
+    if ((rc = shn_device_scan_u32(ctx, (uint32_t*)pc, n_cnt, (uint64_t*)po, &nh))) return rc;
   }
   last.ctx = nullptr;                                            // (one use)
   *n_hits = nh;
@@ -111,8 +180,12 @@ static int seed_scan_impl(shn_ctx* ctx, const shn_reads* reads, int K, const shn
   uint32_t *d_r = nullptr, *d_s = nullptr, *d_i = nullptr;       // (from the caching allocator: this runs once per partition, under the GPU mutex)
   ShnDevBufs hb(ctx->stream);
   HIP_TRY(hb.get(&d_r, nh * 4)); HIP_TRY(hb.get(&d_s, nh * 4)); HIP_TRY(hb.get(&d_i, nh * 4));
-  hipLaunchKernelGGL((seed_scan_kernel<true, ALL>), dim3(grid), dim3(SBLK2), 0, s, v, K, max_win, patterns->d_keys, patterns->d_counts,
-                     patterns->d_bucket_off, patterns->bits, nullptr, (const uint64_t*)po, d_r, d_s, d_i);
+  if (per_read)
+    hipLaunchKernelGGL((seed_scan_reads_kernel<true>), dim3(grid), dim3(SBLK2), 0, s, v, K, (const uint32_t*)pbm, patterns->d_keys, patterns->d_counts,
+                       patterns->d_bucket_off, patterns->bits, nullptr, (const uint64_t*)po, d_r, d_s, d_i);
+  else
+    hipLaunchKernelGGL((seed_scan_kernel<true, ALL>), dim3(grid), dim3(SBLK2), 0, s, v, K, max_win, patterns->d_keys, patterns->d_counts,
+                       patterns->d_bucket_off, patterns->bits, nullptr, (const uint64_t*)po, d_r, d_s, d_i);
   HIP_TRY(hipMemcpyAsync(out_read, d_r, nh * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(out_start, d_s, nh * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(out_id, d_i, nh * 4, hipMemcpyDeviceToHost, s));
