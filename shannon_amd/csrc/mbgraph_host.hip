@@ -123,10 +123,30 @@ struct ThreadCtx {
 };
 static thread_local ThreadCtx t_ctx;
 
+// eight 2-bit codes (one per byte, all < 4) -> their letters: 'A' + 2 b0 + 6 b1 + 11 (b0 & b1) = A, C, G, T (no carry leaves a byte)
+static inline uint64_t codes8_to_ascii(uint64_t x) {
+  const uint64_t b0 = x & 0x0101010101010101ULL, b1 = (x >> 1) & 0x0101010101010101ULL;
+  return 0x4141414141414141ULL + 2 * b0 + 6 * b1 + 11 * (b0 & b1);
+}
 static void decode_read(char* s, const uint8_t* p, uint64_t n, int enc, bool rc) {
   if (enc == SHN_ENC_CODES) {
-    if (!rc) for (uint64_t i = 0; i < n; i++) s[i] = p[i] < 4 ? "ACGT"[p[i]] : 'N';
-    else for (uint64_t i = 0; i < n; i++) { uint8_t c = p[n - 1 - i]; s[i] = c < 4 ? "TGCA"[c] : 'N'; }
+    // eight bases at a time where all eight are ACGT (a byte >= 4 anywhere in the word: the word goes base by base)
+    uint64_t i = 0;
+    if (!rc) {
+      for (; i + 8 <= n; i += 8) {
+        uint64_t x; memcpy(&x, p + i, 8);
+        if (x & 0xFCFCFCFCFCFCFCFCULL) { for (uint64_t j = i; j < i + 8; j++) s[j] = p[j] < 4 ? "ACGT"[p[j]] : 'N'; continue; }
+        x = codes8_to_ascii(x); memcpy(s + i, &x, 8);
+      }
+      for (; i < n; i++) s[i] = p[i] < 4 ? "ACGT"[p[i]] : 'N';
+    } else {
+      for (; i + 8 <= n; i += 8) {
+        uint64_t x; memcpy(&x, p + n - 8 - i, 8);
+        if (x & 0xFCFCFCFCFCFCFCFCULL) { for (uint64_t j = i; j < i + 8; j++) { const uint8_t c = p[n - 1 - j]; s[j] = c < 4 ? "TGCA"[c] : 'N'; } continue; }
+        x = codes8_to_ascii(__builtin_bswap64(0x0303030303030303ULL - x)); memcpy(s + i, &x, 8);
+      }
+      for (; i < n; i++) { uint8_t c = p[n - 1 - i]; s[i] = c < 4 ? "TGCA"[c] : 'N'; }
+    }
   } else {
     auto up = [](uint8_t c) -> char { return (c >= 'a' && c <= 'z') ? (char)(c - 32) : (char)c; };
     if (!rc) for (uint64_t i = 0; i < n; i++) s[i] = up(p[i]);
@@ -184,6 +204,20 @@ struct Graph {
       return RStr{lz_buf + (size_t)r * lz_L, lz_L};
     }
     return RStr{rindex.data(r), rindex.len(r)};
+  }
+  // the text of read r is about to be asked for: its cache lines (or, not yet decoded, the lines of its row) on their way
+  void prefetch_read(int r) const {
+    if (lz_buf) {
+      if (!((lz_done[(size_t)r >> 6] >> (r & 63)) & 1)) {
+        const uint8_t* p = ((origin_flag[r] & 1) ? lz_b : lz_a) + (uint64_t)origin_row[r] * lz_L;
+        __builtin_prefetch(p); __builtin_prefetch(p + 64);
+        return;
+      }
+      const char* t = lz_buf + (size_t)r * lz_L;
+      __builtin_prefetch(t); __builtin_prefetch(t + 64);
+      return;
+    }
+    __builtin_prefetch(rindex.data(r));
   }
   size_t n_rd() const { return rindex.size(); }
   std::vector<double> rcc;
@@ -341,13 +375,24 @@ struct Graph {
     int shift = (int)bases[s].size() - w;
     // P1: the source's reads sorted by (read, index), without repeats; then the destination's that are not among them (a sorted
     // vector + bisection: a tree node per read was most of bridge_all for the X-nodes of a highly expressed transcript)
+    const double tcs0 = laps ? tnow() : 0.0;
     std::vector<RI> out(nreads[s]);
     if (!std::is_sorted(out.begin(), out.end())) std::sort(out.begin(), out.end());
     out.erase(std::unique(out.begin(), out.end()), out.end());
     const size_t n_src = out.size();
     out.reserve(n_src + nreads[d].size());
-    for (const RI& x : nreads[d]) { RI y(x.first, x.second - shift); if (!std::binary_search(out.begin(), out.begin() + (ptrdiff_t)n_src, y)) out.push_back(y); }
+    if (std::is_sorted(nreads[d].begin(), nreads[d].end())) {
+      // (both lists ascending -- the shift keeps the order: one pass with a cursor into the source's part instead of a bisection per read)
+      size_t a = 0;
+      for (const RI& x : nreads[d]) {
+        const RI y(x.first, x.second - shift);
+        while (a < n_src && out[a] < y) a++;
+        if (!(a < n_src && out[a] == y)) out.push_back(y);
+      }
+    } else
+      for (const RI& x : nreads[d]) { RI y(x.first, x.second - shift); if (!std::binary_search(out.begin(), out.begin() + (ptrdiff_t)n_src, y)) out.push_back(y); }
     nreads[c].swap(out);
+    if (laps) { t_cond_sort += tnow() - tcs0; v_cond += nreads[c].size(); }
     nreads[s].clear(); nreads[d].clear();
     kill_edge(e);
     kill_node(s); kill_node(d);
@@ -490,21 +535,29 @@ struct Graph {
       uint64_t nh = 0;
       std::vector<uint32_t> hr, hs, hi;
       {
+        const double tf0 = laps ? tnow() : 0.0;
+        double tf1 = tf0, tf2 = tf0;
         if (gpu_patterns(si, &d_reads, &tab)) {
+          if (laps) tf1 = tnow();
           gpu_ok = shn_seed_scan(ctx, d_reads, K, tab, &nh, nullptr, nullptr, nullptr) == 0;
+          if (laps) tf2 = tnow();
           if (gpu_ok && nh) {
             hr.resize(nh); hs.resize(nh); hi.resize(nh);
             gpu_ok = shn_seed_scan(ctx, d_reads, K, tab, &nh, hr.data(), hs.data(), hi.data()) == 0;
           }
           shn_table_destroy(tab);
         }
+        if (laps) fprintf(stderr, "[mbgraph]   find_bridging_reads: reads + patterns on the device %.3f s, count pass %.3f s, fill pass + download %.3f s (%llu hits, %zu patterns)\n",
+                          tf1 - tf0, tf2 - tf1, tnow() - tf2, (unsigned long long)nh, si.keys.size());
       }
       if (gpu_ok) {
-        for (uint64_t h = 0; h < nh; h++)
+        for (uint64_t h = 0; h < nh; h++) {
+          if (h + 12 < nh) prefetch_read((int)hr[h + 12]);
           for (uint32_t q = si.goff[hi[h]]; q < si.goff[hi[h] + 1]; q++) {
             int x = si.occ[q].first;
             if (read_bridges((int)hr[h], x, (int)hs[h])) nreads[x].push_back(RI((int)hr[h], (int)hs[h]));
           }
+        }
         return;
       }
     }
@@ -530,13 +583,18 @@ struct Graph {
     }
   }
   void refresh_bridging_reads(int n) {
+    const double tr0 = laps ? tnow() : 0.0;
+    struct Lap { Graph* g; double t0; size_t v; ~Lap() { if (g->laps) { g->t_refresh += tnow() - t0; g->n_refresh++; g->v_refresh += v; } } } lap_{this, tr0, nreads[n].size()};
     const std::string& nb = bases[n];
     int lb = (int)nb.size();
     // (the reference collects them in a set and the pinned order P1 walks it sorted: a sorted vector without repeats is the same
     // sequence -- the lists of a highly expressed X-node hold 10^5 reads, and a tree insert per read was most of bridge_all)
     std::vector<RI> rs;
     rs.reserve(nreads[n].size());
-    for (const RI& x : nreads[n]) {
+    const std::vector<RI>& in_list = nreads[n];
+    for (size_t q = 0; q < in_list.size(); q++) {
+      if (q + 8 < in_list.size()) prefetch_read(in_list[q + 8].first);
+      const RI& x = in_list[q];
       int r = x.first, i = x.second;
       if (i <= 0) continue;
       const RStr rb = rstr(r);
@@ -544,15 +602,18 @@ struct Graph {
     }
     if (!std::is_sorted(rs.begin(), rs.end())) std::sort(rs.begin(), rs.end());
     rs.erase(std::unique(rs.begin(), rs.end()), rs.end());
+    // the characters the neighbours put in front of / behind the node (the same for every read of the list)
+    bool in_ch[256] = {false}, out_ch[256] = {false};
+    if (!rs.empty()) {
+      for (int e : ine[n]) { const std::string& pb = bases[es[e]]; in_ch[(unsigned char)pb[pb.size() - ew[e] - 1]] = true; }
+      for (int e : oute[n]) out_ch[(unsigned char)bases[ed[e]][ew[e]]] = true;
+    }
     std::vector<RI> real;
     real.reserve(rs.size());
     for (const RI& x : rs) {
       const RStr rb = rstr(x.first);
-      int i = x.second;
-      bool bi = false, bo = false;
-      for (int e : ine[n]) { const std::string& pb = bases[es[e]]; if (rb[i - 1] == pb[pb.size() - ew[e] - 1]) bi = true; }
-      for (int e : oute[n]) { if (rb[i + lb] == bases[ed[e]][ew[e]]) bo = true; }
-      if (bi && bo) real.push_back(x);
+      const int i = x.second;
+      if (in_ch[(unsigned char)rb[i - 1]] && out_ch[(unsigned char)rb[i + lb]]) real.push_back(x);
     }
     nreads[n].swap(real);
   }
@@ -596,6 +657,8 @@ struct Graph {
     int lb = (int)nb.size();
     std::vector<int> u_list, w_list;
     int v_back = -1, v_forward = -1, loop_w = 0;
+    double tb0 = laps ? tnow() : 0.0;
+    if (laps) { n_steps++; v_bs += nreads[node].size(); }
     { std::vector<int> t = ine[node];
       for (int e : t) {
         int p = es[e], w = ew[e];
@@ -610,6 +673,7 @@ struct Graph {
         if (p == node) { v_back = u; loop_w = w; }
         u_list.push_back(u);
       } }
+    if (laps) { const double t = tnow(); t_bs_in += t - tb0; tb0 = t; }
     { std::vector<int> t = oute[node];
       for (int e : t) {
         int q = ed[e], w = ew[e];
@@ -620,6 +684,7 @@ struct Graph {
         if (q == node) v_forward = x;
         w_list.push_back(x);
       } }
+    if (laps) { const double t = tnow(); t_bs_out += t - tb0; tb0 = t; }
     { std::vector<int> t = ine[node]; for (int e : t) kill_edge(e); }
     { std::vector<int> t = oute[node]; for (int e : t) kill_edge(e); }
     if (v_back >= 0) {
@@ -646,6 +711,7 @@ struct Graph {
       if (!prec) { link(u, x, lb); bridged[u] = 1; bridged[x] = 1; links[u]++; links[x]++; }
     }
     nreads[node].clear();
+    if (laps) { const double t = tnow(); t_bs_rl += t - tb0; tb0 = t; }
     std::vector<int> ub_u, ub_w;
     for (int u : u_list) if (bridged[u] != 1) ub_u.push_back(u);
     for (int x : w_list) if (bridged[x] != 1) ub_w.push_back(x);
@@ -666,7 +732,9 @@ struct Graph {
     kill_node(node);
     return 0;
   }
-  double t_condense = 0;
+  double t_condense = 0, t_refresh = 0, t_bs_in = 0, t_bs_out = 0, t_bs_rl = 0, t_cond_sort = 0;
+  size_t n_refresh = 0, v_refresh = 0, v_bs = 0, v_cond = 0, n_steps = 0;
+  static double tnow() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
   int bridge_all() {
     auto nowb = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_ask = 0, t_step = 0;
@@ -683,6 +751,8 @@ struct Graph {
       if (todo.empty()) {
         if (laps) fprintf(stderr, "[mbgraph]   bridge_all: %zu passes, is_bridged_xnode %.3f s (%zu questions), bridging_step %.3f s (%.3f s of it condensing)\n",
                           bridged_log.size(), t_ask, n_ask, t_step, t_condense);
+        if (laps) fprintf(stderr, "[mbgraph]   bridge_all: refresh %.3f s (%zu calls, %zu reads), steps %zu (%zu reads): in %.3f out %.3f distribute %.3f s; condense read lists %.3f s (%zu reads)\n",
+                          t_refresh, n_refresh, v_refresh, n_steps, v_bs, t_bs_in, t_bs_out, t_bs_rl, t_cond_sort, v_cond);
         return 0;
       }
     }
@@ -795,13 +865,37 @@ struct Graph {
           std::unordered_map<uint64_t, std::vector<std::pair<int, int>>> occ_of;
           std::vector<uint64_t> bits(1u << 12, 0);                        // 2^18-bit filter in front of the map
           size_t n_slow = 0, n_multi = 0;
-          for (size_t r = 0; r < n_rd(); r++) {
-            if (st[r] == 1) { const int n = order[nd[r]]; rfirst[r] = n; rlast[r] = n; rhas[r] = 1; }
-            else if (st[r] == 3) n_slow++;
-            else if (st[r] == 2) {
-              uint64_t key;
-              n_slow++; n_multi++;
-              if (key_at(rstr((int)r), 0, key)) { occ_of[key]; const uint64_t h = fm_mix(key) >> 46; bits[h >> 6] |= 1ULL << (h & 63); }
+          {
+            // the reads inside one node get that node as first / last (a pass over every read: on the threads that are free right now)
+            const size_t nr = n_rd();
+            const unsigned want0 = (unsigned)std::max<size_t>(1, std::min<size_t>(8, nr >> 19));
+            const unsigned nt0 = want0 > 1 ? (unsigned)g_host_threads.take_free((int)want0, g_partitions_running.load() - 1) : 1u;
+            struct GiveBack0 { unsigned n; ~GiveBack0() { if (n) g_host_threads.release((int)n); } } give_back0{want0 > 1 ? nt0 : 0u};
+            std::vector<size_t> slow_of(nt0, 0);
+            std::vector<std::vector<uint32_t>> multi_of(nt0);
+            auto settle = [&](unsigned t, size_t lo, size_t hi) {
+              size_t ns = 0;
+              for (size_t r = lo; r < hi; r++) {
+                const uint8_t v = st[r];
+                if (v == 1) { const int n = order[nd[r]]; rfirst[r] = n; rlast[r] = n; rhas[r] = 1; }
+                else if (v == 3) ns++;
+                else if (v == 2) { ns++; multi_of[t].push_back((uint32_t)r); }
+              }
+              slow_of[t] = ns;
+            };
+            if (nt0 <= 1) settle(0, 0, nr);
+            else {
+              std::vector<std::thread> th;
+              for (unsigned t = 0; t < nt0; t++) th.emplace_back(settle, t, nr * t / nt0, nr * (t + 1) / nt0);
+              for (auto& x : th) x.join();
+            }
+            for (unsigned t = 0; t < nt0; t++) {
+              n_slow += slow_of[t];
+              for (uint32_t r : multi_of[t]) {
+                uint64_t key;
+                n_multi++;
+                if (key_at(rstr((int)r), 0, key)) { occ_of[key]; const uint64_t h = fm_mix(key) >> 46; bits[h >> 6] |= 1ULL << (h & 63); }
+              }
             }
           }
           if (n_multi)
@@ -885,6 +979,7 @@ struct Graph {
           // last one names its first / last node, mbgraph.py:1379-1384); the sums are of whole numbers, so no order shows in them
           {
             std::unordered_map<uint64_t, double> edge_sum;
+            std::unordered_map<uint64_t, std::vector<std::vector<int>>> dev_seen;
             std::vector<int> pth;
             for (uint64_t at = 0; at + 2 <= precs_used;) {
               const int32_t r = precs[at], len = precs[at + 1];
@@ -894,7 +989,16 @@ struct Graph {
               at += 2 + (uint64_t)len;
               rfirst[r] = pth.front(); rlast[r] = pth.back(); rhas[r] = 1;
               for (size_t j = 0; j + 1 < pth.size(); j++) edge_sum[((uint64_t)(uint32_t)pth[j] << 32) | (uint32_t)pth[j + 1]] += rcc[r];
-              if (pth.size() > 2) { cntp++; known_paths.insert(pth); }
+              if (pth.size() > 2) {
+                cntp++;
+                // (the 10^4-10^5 reads of a highly expressed transcript name the same few paths: a hash table in front of the ordered set)
+                uint64_t h = 0xcbf29ce484222325ULL;
+                for (int v : pth) h = (h ^ (uint64_t)(uint32_t)v) * 0x100000001b3ULL;
+                auto& lst = dev_seen[h];
+                bool have = false;
+                for (const auto& q : lst) if (q == pth) { have = true; break; }
+                if (!have) { lst.push_back(pth); known_paths.insert(pth); }
+              }
             }
             for (const auto& kv : edge_sum) known_edges[{(int)(uint32_t)(kv.first >> 32), (int)(uint32_t)kv.first}] += kv.second;
           }

@@ -276,7 +276,8 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
             import sys
             for nm, (a, b, tt_, nr) in sorted(timeline.items(), key=lambda kv: -kv[1][1])[:12]:
                 sys.stderr.write("[parts] %-16s start %6.2f end %6.2f  routed %8d  %s\n" % (nm, a, b, nr, {k: round(v, 2) for k, v in tt_.items()}))
-            sys.stderr.write("[parts] stage wall %.2f s, %d partitions, %d threads\n" % (wall, len(names), graph_threads))
+            sys.stderr.write("[parts] stage wall %.2f s, %d partitions, %d threads, %.2f thread-seconds\n"
+                             % (wall, len(names), graph_threads, sum(b - a for a, b, _t, _n in timeline.values())))
         busy = sum(sum(tt.values()) for _, tt in results) or 1.0
         for name, (rec, tt) in zip(names, results):
             for k_, v in tt.items():                                      # wall time of the stage, split like the thread time
