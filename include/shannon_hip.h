@@ -324,6 +324,12 @@ int shn_mbgraph_run_resident(shn_ctx* ctx, const shn_unitigs* ug, uint32_t part,
 int shn_mbgraph_run_rows(shn_ctx* ctx, const shn_unitigs* ug, uint32_t part, const uint8_t* rows, uint64_t n_rows, const shn_reads* src_a,
                          const shn_reads* src_b, const uint8_t* host_a, const uint8_t* host_b, const uint32_t* didx, uint64_t n_reads,
                          int paired, shn_graph** out);
+/* shn_mbgraph_run_rows with the routed reads named once more by where they already lie on the device: entries [route_lo, route_lo +
+ * n_reads) of `routes` (shn_route_reads' result: the reads{comp}.fasta lists of kmers_for_component.py:322-403, never written); didx
+ * = the same indices on the host.  The duplicate search (multibridging.py:185-236) then reads the list in place.                    */
+int shn_mbgraph_run_routes(shn_ctx* ctx, const shn_unitigs* ug, uint32_t part, const uint8_t* rows, uint64_t n_rows, const shn_reads* src_a,
+                           const shn_reads* src_b, const uint8_t* host_a, const uint8_t* host_b, const uint32_t* didx, const shn_routes* routes,
+                           uint64_t route_lo, uint64_t n_reads, int paired, shn_graph** out);
 /* The distinct reads among the slots of a partition's routed reads (slot j = read j / nm of didx, mate j % nm; nm = 2 if paired),
  * numbered in order of first occurrence as Read.reads numbers them (mbgraph.py:56-70): slot_out[id] = first slot, count_out[id] =
  * copies, and for pairs role_out[id] (1 / 2) and mate_out[id] of the read's LAST occurrence (multibridging.py:214-236; single-end:

@@ -73,6 +73,7 @@ SIGNATURES = {
     "shn_graph_sizes": (C.c_int, [vp, u64p]),
     "shn_graph_export": (C.c_int, [vp] + [vp] * 20),
     "shn_mbgraph_run_rows": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, vp, vp, C.c_uint64, C.c_int, vpp]),
+    "shn_mbgraph_run_routes": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_int, vpp]),
     "shn_host_cpus": (C.c_int, []),
     "shn_malloc_tune_now": (None, []),
     "shn_known_paths_scan": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_uint64, vp, vp, vp]),

@@ -1,5 +1,6 @@
 // Context, error handling, event timers and the read uploader / 2-bit packer.
 #include "common.h"
+#include "graph_dev.h"
 #include <sched.h>
 #include <mutex>
 #include <vector>
@@ -374,21 +375,17 @@ __global__ void reads_gather_kernel(const uint64_t* __restrict__ wa, const uint6
     const uint64_t* src = ((f & 1) ? wb : wa) + (uint64_t)rows[i] * wpr;
     uint64_t v = 0;
     if (!(f & 2)) v = src[w];
-    else {
-      for (uint32_t j = 0; j < 32; j++) {
-        const uint32_t p = 32 * w + j;
-        if (p >= L) break;
-        const uint32_t q = L - 1 - p;
-        const uint64_t base = (src[q >> 5] >> (62 - 2 * (q & 31))) & 3ULL;
-        v |= (3ULL - base) << (62 - 2 * j);
-      }
+    else if (32 * w < L) {
+      // bases [32 w, 32 w + nb) of the reverse complement = the complement of bases [L - 32 w - nb, L - 32 w) read backwards
+      const uint32_t nb = min(32u, L - 32 * w);
+      v = shn_revcomp(shn_extract(src, L - 32 * w - nb, (int)nb), (int)nb) << (64 - 2 * nb);
     }
     out[gid] = v;
   }
 }
-extern "C" int shn_reads_gather(shn_ctx* ctx, const shn_reads* a, const shn_reads* b, const uint32_t* rows, const uint8_t* flags, uint64_t n,
-                                shn_reads** out) {
-  if (!ctx || !a || !out || (n && (!rows || !flags))) return shn_fail(SHN_ERR_ARG, "shn_reads_gather: NULL argument");
+// rows / flags on the host (uploaded) or already on the device (d_rows / d_flags: graph_dev.h, the result of the duplicate search)
+static int reads_gather_impl(shn_ctx* ctx, const shn_reads* a, const shn_reads* b, const uint32_t* rows, const uint8_t* flags, const uint32_t* dev_rows,
+                             const uint8_t* dev_flags, uint64_t n, shn_reads** out) {
   if (!a->fixed_len || (b && (b->fixed_len != a->fixed_len || b->wpr != a->wpr))) return shn_fail(SHN_ERR_ARG, "shn_reads_gather: fixed-length read sets of one length only");
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
@@ -401,21 +398,34 @@ extern "C" int shn_reads_gather(shn_ctx* ctx, const shn_reads* a, const shn_read
   hipError_t e;
   if ((e = shn_dev_malloc(&r->d_words, (r->n_words + 2) * 8)) != hipSuccess) return fail(e);
   if ((e = shn_dev_malloc(&r->d_mask, (r->n_words / 2 + 2) * 8)) != hipSuccess) return fail(e);
-  if ((e = shn_dev_malloc(&d_rows, (n + 1) * 4)) != hipSuccess) return fail(e);
-  if ((e = shn_dev_malloc(&d_flags, n + 1)) != hipSuccess) return fail(e);
+  if (!dev_rows) {
+    if ((e = shn_dev_malloc(&d_rows, (n + 1) * 4)) != hipSuccess) return fail(e);
+    if ((e = shn_dev_malloc(&d_flags, n + 1)) != hipSuccess) return fail(e);
+  }
   if ((e = hipMemsetAsync(r->d_mask, 0, (r->n_words / 2 + 2) * 8, s)) != hipSuccess) return fail(e);
   if ((e = hipMemsetAsync(r->d_words + r->n_words, 0, 16, s)) != hipSuccess) return fail(e);
   if (n) {
-    if ((e = hipMemcpyAsync(d_rows, rows, n * 4, hipMemcpyHostToDevice, s)) != hipSuccess) return fail(e);
-    if ((e = hipMemcpyAsync(d_flags, flags, n, hipMemcpyHostToDevice, s)) != hipSuccess) return fail(e);
+    if (!dev_rows) {
+      if ((e = hipMemcpyAsync(d_rows, rows, n * 4, hipMemcpyHostToDevice, s)) != hipSuccess) return fail(e);
+      if ((e = hipMemcpyAsync(d_flags, flags, n, hipMemcpyHostToDevice, s)) != hipSuccess) return fail(e);
+    }
     hipLaunchKernelGGL(reads_gather_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(r->n_words, 256), 1u << 20)), dim3(256), 0, s, a->d_words,
-                       b ? b->d_words : a->d_words, a->wpr, a->fixed_len, d_rows, d_flags, n, r->d_words);
+                       b ? b->d_words : a->d_words, a->wpr, a->fixed_len, dev_rows ? dev_rows : d_rows, dev_flags ? dev_flags : d_flags, n, r->d_words);
   }
   if ((e = hipStreamSynchronize(s)) != hipSuccess) return fail(e);
   shn_dev_free(d_rows); shn_dev_free(d_flags);
   HIP_TRY(hipGetLastError());
   *out = r;
   return SHN_OK;
+}
+extern "C" int shn_reads_gather(shn_ctx* ctx, const shn_reads* a, const shn_reads* b, const uint32_t* rows, const uint8_t* flags, uint64_t n,
+                                shn_reads** out) {
+  if (!ctx || !a || !out || (n && (!rows || !flags))) return shn_fail(SHN_ERR_ARG, "shn_reads_gather: NULL argument");
+  return reads_gather_impl(ctx, a, b, rows, flags, nullptr, nullptr, n, out);
+}
+int shn_reads_gather_dev(shn_ctx* ctx, const shn_reads* a, const shn_reads* b, const uint32_t* d_rows, const uint8_t* d_flags, uint64_t n, shn_reads** out) {
+  if (!ctx || !a || !out || (n && (!d_rows || !d_flags))) return shn_fail(SHN_ERR_ARG, "shn_reads_gather_dev: NULL argument");
+  return reads_gather_impl(ctx, a, b, nullptr, nullptr, d_rows, d_flags, n, out);
 }
 
 extern "C" void shn_reads_destroy(shn_reads* r) {

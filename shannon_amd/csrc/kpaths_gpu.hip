@@ -15,6 +15,7 @@
 // The host keeps the sequential part: reads of kind 2 and 3, in read order; those of kind 2 (rare: a K-mer occurs once in a de Bruijn
 // graph until bridging copies nodes) against an index of just their first K-mers.
 #include "common.h"
+#include "graph_dev.h"
 
 #include <algorithm>
 #include <cstring>
@@ -88,7 +89,8 @@ __device__ __forceinline__ int64_t kp_find(const unsigned long long* __restrict_
 
 __global__ void kp_classify(RView v, int K, const unsigned long long* __restrict__ hkeys, uint64_t mask, const uint64_t* __restrict__ goff,
                             const uint32_t* __restrict__ occ, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ off, uint32_t n_nodes,
-                            uint8_t* __restrict__ state, int32_t* __restrict__ node_out, uint32_t* __restrict__ off_out) {
+                            uint8_t* __restrict__ state, int32_t* __restrict__ node_out, uint32_t* __restrict__ off_out,
+                            int32_t* __restrict__ first_out, int32_t* __restrict__ last_out) {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= v.n) return;
   const uint32_t L = v.len ? v.len[r] : v.fixed_len;
@@ -129,6 +131,7 @@ __global__ void kp_classify(RView v, int K, const unsigned long long* __restrict
   state[r] = st;
   node_out[r] = fn;
   if (off_out) off_out[r] = fo;
+  if (first_out) { first_out[r] = st == 1 ? fn : -1; last_out[r] = st == 1 ? fn : -1; }     // (a read inside one node: that node is its path)
 }
 
 
@@ -157,7 +160,8 @@ __device__ __forceinline__ bool kp_agree(const uint64_t* __restrict__ w, uint32_
 }
 
 // one depth-first run; out == NULL: only counts.  Returns the words of all records, or -1 when the stack is too shallow.
-__device__ int kp_dfs(const uint64_t* __restrict__ w, uint32_t L, const KpGraph& G, uint32_t r, uint32_t node0, uint32_t i0, int32_t* __restrict__ out) {
+__device__ int kp_dfs(const uint64_t* __restrict__ w, uint32_t L, const KpGraph& G, uint32_t r, uint32_t node0, uint32_t i0, int32_t* __restrict__ out,
+                      int32_t* last_end = nullptr) {
   uint32_t st_node[KP_DEPTH], st_so[KP_DEPTH], st_e[KP_DEPTH];
   int depth = 0, words = 0;
   st_node[0] = node0; st_so[0] = 0; st_e[0] = 0xFFFFFFFFu;           // e = 0xFFFFFFFF: the node has just been entered
@@ -170,6 +174,7 @@ __device__ int kp_dfs(const uint64_t* __restrict__ w, uint32_t L, const KpGraph&
       const int hops = KP_HOPS - depth;
       if (hops <= 0 || L - st_so[depth] <= nl) {                       // the read ends in this node (or the hop limit): a path
         if (out) { out[words] = (int32_t)r; out[words + 1] = depth + 1; for (int d = 0; d <= depth; d++) out[words + 2 + d] = (int32_t)st_node[d]; }
+        if (last_end) *last_end = (int32_t)node;
         words += depth + 3;
         depth--;
         continue;
@@ -206,6 +211,114 @@ __global__ void kp_search(RView v, KpGraph G, uint8_t* __restrict__ state, const
   if (at + (unsigned long long)need > cap) return;                    // (no room: the host searches this read)
   kp_dfs(w, L, G, (uint32_t)r, (uint32_t)node_out[r], off_out[r], paths + at);
   state[r] = 4;
+}
+
+
+// ---- the device-resident form (graph_dev.h): state, node, offset, first / last node never leave the device; the reads whose first
+// K-mer occurs more than once (state 2) are searched here too -- from every occurrence, in index order, as the host's loop does
+struct KpIndex { const unsigned long long* hkeys; uint64_t mask; const uint64_t* goff; const uint32_t* occ; uint32_t n_nodes; int K; };
+
+// all paths of read r (state 3: from its K-mer's only occurrence; state 2: from every occurrence by ascending position) -> words of
+// their records (-1: a search ran too deep); first / last = the ends of the read's LAST path in that order, or the node the read lies
+// inside at its last such occurrence (mbgraph.py:1379-1384 sets Read.nodes again with every path)
+__device__ int kp_read_paths(const uint64_t* __restrict__ w, uint32_t L, const KpGraph& G, const KpIndex& X, uint32_t r, uint32_t st, uint32_t node0,
+                             uint32_t off0, const uint8_t* __restrict__ bases, int32_t* __restrict__ out, int32_t& first, int32_t& last) {
+  first = -1; last = -1;
+  if (st == 3) {
+    int32_t le = -1;
+    const int words = kp_dfs(w, L, G, r, node0, off0, out, &le);
+    if (words > 0) { first = (int32_t)node0; last = le; }
+    return words;
+  }
+  const int64_t sf = kp_find(X.hkeys, X.mask, shn_extract(w, 0, X.K));
+  if (sf < 0) return 0;
+  const uint64_t g0 = X.goff[sf], g1 = X.goff[sf + 1];
+  int words = 0;
+  int64_t lastp = -1;
+  for (uint64_t it = g0; it < g1; it++) {
+    uint64_t p = ~0ULL;
+    for (uint64_t j = g0; j < g1; j++) { const uint64_t q = X.occ[j]; if ((int64_t)q > lastp && q < p) p = q; }
+    lastp = (int64_t)p;
+    const uint32_t nd = kp_node_of(G.off, X.n_nodes, p);
+    const uint64_t left = G.off[nd + 1] - p;
+    const uint32_t n = (uint32_t)min((uint64_t)L, left);
+    bool same = true;
+    for (uint32_t i = X.K; i < n && same; i++) {
+      const uint32_t rb = (uint32_t)((w[i >> 5] >> (62 - 2 * (i & 31))) & 3ULL);
+      same = kp_code(bases[p + i]) == (int)rb;
+    }
+    if (!same) continue;
+    if ((uint64_t)L <= left) { first = (int32_t)nd; last = (int32_t)nd; continue; }
+    int32_t le = -1;
+    const int wds = kp_dfs(w, L, G, r, nd, (uint32_t)(p - G.off[nd]), out ? out + words : nullptr, &le);
+    if (wds < 0) return -1;
+    if (wds > 0) { first = (int32_t)nd; last = le; }
+    words += wds;
+  }
+  return words;
+}
+
+// counters: [0] words of records asked for, [1] nodes with a base outside ACGT (kp_insert), [2] reads with records, [3] reads left to the host
+__global__ void kp_search_all(RView v, KpGraph G, KpIndex X, uint8_t* __restrict__ state, const int32_t* __restrict__ node_out,
+                              const uint32_t* __restrict__ off_out, int32_t* __restrict__ paths, uint64_t cap, unsigned long long* __restrict__ counters,
+                              int32_t* __restrict__ d_first, int32_t* __restrict__ d_last, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ rec_cnt,
+                              uint64_t rec_cap, KpSlow* __restrict__ left, uint64_t left_cap) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= v.n) return;
+  const uint32_t st = state[r];
+  if (st != 2 && st != 3) return;
+  const uint32_t L = v.len ? v.len[r] : v.fixed_len;
+  const uint64_t* w = v.words + (v.woff ? v.woff[r] : r * v.wpr);
+  const uint32_t node0 = (uint32_t)node_out[r], off0 = off_out[r];
+  int32_t f, l;
+  const int need = kp_read_paths(w, L, G, X, (uint32_t)r, st, node0, off0, G.bases, nullptr, f, l);
+  bool done = need == 0;
+  if (need > 0) {
+    const unsigned long long at = atomicAdd(&counters[0], (unsigned long long)need);
+    if (at + (unsigned long long)need <= cap) {
+      const unsigned long long q = atomicAdd(&counters[2], 1ULL);
+      if (q < rec_cap) {
+        kp_read_paths(w, L, G, X, (uint32_t)r, st, node0, off0, G.bases, paths + at, f, l);
+        rec_cnt[2 * q] = (uint32_t)r; rec_cnt[2 * q + 1] = cnt[r];
+        done = true;
+      }
+    }
+  }
+  if (done) { state[r] = 4; d_first[r] = f; d_last[r] = l; return; }
+  const unsigned long long q = atomicAdd(&counters[3], 1ULL);
+  if (q < left_cap) left[q] = KpSlow{(uint32_t)r, st, node0, off0, cnt[r]};
+}
+
+__global__ void kp_patch(const int32_t* __restrict__ patches, uint64_t n, int32_t* __restrict__ first, int32_t* __restrict__ last) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t r = patches[3 * i];
+  first[r] = patches[3 * i + 1]; last[r] = patches[3 * i + 2];
+}
+// find_mate_pairs' pass over the reads (mbgraph.py:839-880 / mbgraph_host.hip): first mates whose last node and whose mate's first node
+// differ and are not joined by an edge; every distinct (a, b) once (a hash set; counters[1] set: the set overflowed)
+__global__ void kp_mates(uint64_t nr, const int32_t* __restrict__ mate, const uint8_t* __restrict__ role, const int32_t* __restrict__ first,
+                         const int32_t* __restrict__ last, const uint32_t* __restrict__ eoff, const uint32_t* __restrict__ edst,
+                         unsigned long long* __restrict__ set, uint64_t mask, uint32_t* __restrict__ pairs, uint64_t cap, unsigned long long* __restrict__ counters) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nr || role[r] != 1) return;
+  const int32_t m = mate[r];
+  if (m < 0) return;
+  const int32_t a = last[r], b = first[m];
+  if (a < 0 || first[r] < 0 || b < 0 || last[m] < 0 || a == b) return;
+  for (uint32_t e = eoff[a]; e < eoff[a + 1]; e++) if (edst[e] == (uint32_t)b) return;
+  const unsigned long long key = ((unsigned long long)(uint32_t)a << 32) | (uint32_t)b;
+  uint64_t s = kp_mix(key) & mask;
+  for (int probe = 0; probe < 4096; probe++) {
+    unsigned long long cur = set[s];
+    if (cur == KP_EMPTY) { const unsigned long long old = atomicCAS(&set[s], KP_EMPTY, key); cur = old == KP_EMPTY ? KP_EMPTY : old; if (old == KP_EMPTY) {
+        const unsigned long long q = atomicAdd(&counters[0], 1ULL);
+        if (q < cap) { pairs[2 * q] = (uint32_t)a; pairs[2 * q + 1] = (uint32_t)b; } else atomicAdd(&counters[1], 1ULL);
+        return; } }
+    if (cur == key) return;
+    s = (s + 1) & mask;
+  }
+  atomicAdd(&counters[1], 1ULL);
 }
 
 }  // namespace
@@ -264,7 +377,7 @@ static int kp_scan_impl(shn_ctx* ctx, const shn_reads* reads, int K, const uint8
   hipLaunchKernelGGL(kp_fill, dim3(gp), dim3(256), 0, s, d_slot, total, d_goff, d_fill, d_occ);
   RView v{reads->d_words, reads->d_woff, reads->d_len, nr, reads->fixed_len, reads->wpr};
   hipLaunchKernelGGL(kp_classify, dim3((uint32_t)cdiv(nr, 256)), dim3(256), 0, s, v, K, d_hkeys, T - 1, d_goff, d_occ, d_bases, d_off, (uint32_t)n_nodes,
-                     d_state, d_node, offset_out ? d_ofs : nullptr);
+                     d_state, d_node, offset_out ? d_ofs : nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
   TRYK(hipGetLastError());
   int32_t* d_paths = nullptr;
   const bool search = offset_out && edge_off && paths_out && paths_cap && paths_used;
@@ -314,4 +427,125 @@ extern "C" int shn_known_paths_search(shn_ctx* ctx, const shn_reads* reads, int 
                                       uint32_t* offset_out, int32_t* paths_out, uint64_t paths_cap, uint64_t* paths_used) {
   if (!edge_off || !offset_out || !paths_out || !paths_used) return shn_fail(SHN_ERR_ARG, "shn_known_paths_search: NULL argument");
   return kp_scan_impl(ctx, reads, K, node_bases, node_off, n_nodes, state_out, node_out, offset_out, edge_off, edge_dst, edge_ov, paths_out, paths_cap, paths_used);
+}
+
+// ---- graph_dev.h: known_paths with its per-read state left on the device
+void shn_kp_destroy(shn_kp* kp) {
+  if (!kp) return;
+  if (kp->ctx) hipSetDevice(kp->ctx->device);
+  shn_dev_free(kp->d_first); shn_dev_free(kp->d_last); shn_dev_free(kp->d_eoff); shn_dev_free(kp->d_edst);
+  delete kp;
+}
+
+int shn_known_paths_dev(shn_ctx* ctx, const shn_reads* reads, int K, const uint8_t* node_bases, const uint64_t* node_off, uint64_t n_nodes,
+                        const uint32_t* edge_off, const uint32_t* edge_dst, const uint32_t* edge_ov, const shn_dedup* dd, std::vector<KpSlow>* left,
+                        std::vector<int32_t>* records, std::vector<uint32_t>* rec_cnt, shn_kp** kp_out) {
+  if (!ctx || !reads || !node_off || !edge_off || !dd || !left || !records || !rec_cnt || !kp_out || (n_nodes && !node_bases))
+    return shn_fail(SHN_ERR_ARG, "shn_known_paths_dev: NULL argument");
+  if (K < 1 || K > 31) return shn_fail(SHN_ERR_ARG, "shn_known_paths_dev: K must be in [1,31]");
+  if (reads->n_invalid) return shn_fail(SHN_ERR_ARG, "shn_known_paths_dev: reads contain non-ACGT bases");
+  const uint64_t nr = reads->n_reads, total = n_nodes ? node_off[n_nodes] : 0;
+  if (nr != dd->n_distinct) return shn_fail(SHN_ERR_ARG, "shn_known_paths_dev: the reads are not the distinct reads of the duplicate search");
+  left->clear(); records->clear(); rec_cnt->clear();
+  *kp_out = nullptr;
+  if (!nr || !total || n_nodes >= 0x7FFFFFFFULL || total >= 0xFFFFFFFFULL) return shn_fail(SHN_ERR_ARG, "shn_known_paths_dev: no reads / no nodes / too many bases");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  TimerRegion treg(ctx, T_SEEDS);
+  ShnDevBufs bufs(s);
+  uint64_t T = 1024;
+  while (T < 2 * total) T <<= 1;
+  const uint64_t ne = edge_off[n_nodes];
+  const uint64_t paths_cap = std::max<uint64_t>(1u << 16, nr / 2 + 4096), rec_cap = paths_cap / 3 + 1, left_cap = std::max<uint64_t>(1u << 16, nr / 8);
+  shn_kp* kp = new shn_kp();
+  kp->ctx = ctx; kp->n_reads = nr; kp->n_nodes = n_nodes;
+  uint8_t *d_bases = nullptr, *d_state = nullptr;
+  uint64_t *d_off = nullptr, *d_goff = nullptr;
+  unsigned long long *d_hkeys = nullptr, *d_cnt2 = nullptr;
+  uint32_t *d_cnt = nullptr, *d_fill = nullptr, *d_slot = nullptr, *d_occ = nullptr, *d_ofs = nullptr, *d_eov = nullptr, *d_rec_cnt = nullptr;
+  int32_t *d_node = nullptr, *d_paths = nullptr;
+  KpSlow* d_left = nullptr;
+#define TRYK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { shn_kp_destroy(kp); return shn_fail(SHN_ERR_HIP, std::string("shn_known_paths_dev: ") + hipGetErrorString(e_)); } } while (0)
+  TRYK(shn_dev_malloc(&kp->d_first, (nr + 1) * 4)); TRYK(shn_dev_malloc(&kp->d_last, (nr + 1) * 4));
+  TRYK(shn_dev_malloc(&kp->d_eoff, (n_nodes + 1) * 4)); TRYK(shn_dev_malloc(&kp->d_edst, (ne + 1) * 4));
+  TRYK(bufs.get(&d_bases, total + 8));
+  TRYK(bufs.get(&d_off, (n_nodes + 1) * 8));
+  TRYK(bufs.get(&d_hkeys, T * 8));
+  TRYK(bufs.get(&d_cnt, (T + 1) * 4)); TRYK(bufs.get(&d_fill, (T + 1) * 4));
+  TRYK(bufs.get(&d_goff, (T + 2) * 8));
+  TRYK(bufs.get(&d_slot, (total + 1) * 4)); TRYK(bufs.get(&d_occ, (total + 1) * 4));
+  TRYK(bufs.get(&d_state, nr + 1)); TRYK(bufs.get(&d_node, (nr + 1) * 4)); TRYK(bufs.get(&d_ofs, (nr + 1) * 4));
+  TRYK(bufs.get(&d_cnt2, 32));
+  TRYK(bufs.get(&d_eov, (ne + 1) * 4));
+  TRYK(bufs.get(&d_paths, (paths_cap + 1) * 4)); TRYK(bufs.get(&d_rec_cnt, (rec_cap + 1) * 8)); TRYK(bufs.get(&d_left, (left_cap + 1) * sizeof(KpSlow)));
+  TRYK(hipMemcpyAsync(d_bases, node_bases, total, hipMemcpyHostToDevice, s));
+  TRYK(hipMemcpyAsync(d_off, node_off, (n_nodes + 1) * 8, hipMemcpyHostToDevice, s));
+  TRYK(hipMemcpyAsync(kp->d_eoff, edge_off, (n_nodes + 1) * 4, hipMemcpyHostToDevice, s));
+  if (ne) { TRYK(hipMemcpyAsync(kp->d_edst, edge_dst, ne * 4, hipMemcpyHostToDevice, s)); TRYK(hipMemcpyAsync(d_eov, edge_ov, ne * 4, hipMemcpyHostToDevice, s)); }
+  TRYK(hipMemsetAsync(d_cnt2, 0, 32, s));
+  TRYK(hipMemsetAsync(d_hkeys, 0xFF, T * 8, s));
+  TRYK(hipMemsetAsync(d_cnt, 0, (T + 1) * 4, s));
+  TRYK(hipMemsetAsync(d_fill, 0, (T + 1) * 4, s));
+  TRYK(hipMemsetAsync(d_paths, 0, (paths_cap + 1) * 4, s));            // (a reader walks the records by their lengths and stops at a length of 0)
+  const uint32_t gp = (uint32_t)cdiv(total, 256);
+  hipLaunchKernelGGL(kp_insert, dim3(gp), dim3(256), 0, s, d_bases, d_off, (uint32_t)n_nodes, total, K, d_hkeys, T - 1, d_cnt, d_slot, d_cnt2);
+  { int rc = shn_device_scan_u32(ctx, d_cnt, T, d_goff, nullptr); if (rc) { shn_kp_destroy(kp); return rc; } }
+  hipLaunchKernelGGL(kp_fill, dim3(gp), dim3(256), 0, s, d_slot, total, d_goff, d_fill, d_occ);
+  RView v{reads->d_words, reads->d_woff, reads->d_len, nr, reads->fixed_len, reads->wpr};
+  hipLaunchKernelGGL(kp_classify, dim3((uint32_t)cdiv(nr, 256)), dim3(256), 0, s, v, K, d_hkeys, T - 1, d_goff, d_occ, d_bases, d_off, (uint32_t)n_nodes,
+                     d_state, d_node, d_ofs, kp->d_first, kp->d_last);
+  KpGraph G{d_bases, d_off, kp->d_eoff, kp->d_edst, d_eov};
+  KpIndex X{d_hkeys, T - 1, d_goff, d_occ, (uint32_t)n_nodes, K};
+  // (kp_insert's count of bad nodes sits in d_cnt2[1]; the search keeps its own counters in [0], [2], [3])
+  hipLaunchKernelGGL(kp_search_all, dim3((uint32_t)cdiv(nr, 64)), dim3(64), 0, s, v, G, X, d_state, (const int32_t*)d_node, (const uint32_t*)d_ofs, d_paths, paths_cap,
+                     d_cnt2, kp->d_first, kp->d_last, (const uint32_t*)dd->d_cnt, d_rec_cnt, rec_cap, d_left, left_cap);
+  TRYK(hipGetLastError());
+  unsigned long long cnt[4] = {0, 0, 0, 0};
+  TRYK(hipMemcpyAsync(cnt, d_cnt2, 32, hipMemcpyDeviceToHost, s));
+  TRYK(hipStreamSynchronize(s));
+  if (cnt[1]) { shn_kp_destroy(kp); return shn_fail(SHN_ERR_ARG, "shn_known_paths_dev: a node holds a base outside ACGT"); }
+  if (cnt[3] > left_cap) { shn_kp_destroy(kp); return shn_fail(SHN_ERR_INTERNAL, "shn_known_paths_dev: more reads left to the host than expected"); }
+  const uint64_t used = std::min<uint64_t>(cnt[0], paths_cap), n_rec = std::min<uint64_t>(cnt[2], rec_cap);
+  records->resize(used); rec_cnt->resize(2 * n_rec); left->resize(cnt[3]);
+  if (used) TRYK(hipMemcpyAsync(records->data(), d_paths, used * 4, hipMemcpyDeviceToHost, s));
+  if (n_rec) TRYK(hipMemcpyAsync(rec_cnt->data(), d_rec_cnt, n_rec * 8, hipMemcpyDeviceToHost, s));
+  if (cnt[3]) TRYK(hipMemcpyAsync(left->data(), d_left, cnt[3] * sizeof(KpSlow), hipMemcpyDeviceToHost, s));
+  TRYK(hipStreamSynchronize(s));
+#undef TRYK
+  *kp_out = kp;
+  return SHN_OK;
+}
+
+int shn_kp_mate_pairs(shn_kp* kp, const shn_dedup* dd, const int32_t* patches, uint64_t n_patches, std::vector<uint32_t>* pairs_out) {
+  if (!kp || !dd || !pairs_out || (n_patches && !patches)) return shn_fail(SHN_ERR_ARG, "shn_kp_mate_pairs: NULL argument");
+  pairs_out->clear();
+  if (!dd->paired || !kp->n_reads) return SHN_OK;
+  shn_ctx* ctx = kp->ctx;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  ShnDevBufs bufs(s);
+  uint64_t T = 1u << 16;
+  while (T < 64 * kp->n_nodes && T < (1u << 24)) T <<= 1;
+  const uint64_t cap = T / 2;
+  int32_t* d_patch = nullptr; unsigned long long *d_set = nullptr, *d_cnt = nullptr; uint32_t* d_pairs = nullptr;
+#define TRYM(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return shn_fail(SHN_ERR_HIP, std::string("shn_kp_mate_pairs: ") + hipGetErrorString(e_)); } while (0)
+  TRYM(bufs.get(&d_set, T * 8)); TRYM(bufs.get(&d_cnt, 16)); TRYM(bufs.get(&d_pairs, (cap + 1) * 8));
+  TRYM(hipMemsetAsync(d_set, 0xFF, T * 8, s)); TRYM(hipMemsetAsync(d_cnt, 0, 16, s));
+  if (n_patches) {
+    for (uint64_t i = 0; i < n_patches; i++) if (patches[3 * i] < 0 || (uint64_t)patches[3 * i] >= kp->n_reads) return shn_fail(SHN_ERR_ARG, "shn_kp_mate_pairs: patch of a read that does not exist");
+    TRYM(bufs.get(&d_patch, n_patches * 12));
+    TRYM(hipMemcpyAsync(d_patch, patches, n_patches * 12, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(kp_patch, dim3((uint32_t)cdiv(n_patches, 256)), dim3(256), 0, s, (const int32_t*)d_patch, n_patches, kp->d_first, kp->d_last);
+  }
+  hipLaunchKernelGGL(kp_mates, dim3((uint32_t)cdiv(kp->n_reads, 256)), dim3(256), 0, s, kp->n_reads, (const int32_t*)dd->d_mate, (const uint8_t*)dd->d_role,
+                     (const int32_t*)kp->d_first, (const int32_t*)kp->d_last, (const uint32_t*)kp->d_eoff, (const uint32_t*)kp->d_edst, d_set, T - 1, d_pairs, cap, d_cnt);
+  TRYM(hipGetLastError());
+  unsigned long long cnt[2] = {0, 0};
+  TRYM(hipMemcpyAsync(cnt, d_cnt, 16, hipMemcpyDeviceToHost, s));
+  TRYM(hipStreamSynchronize(s));
+  if (cnt[1]) return shn_fail(SHN_ERR_INTERNAL, "shn_kp_mate_pairs: more distinct node pairs than the set holds");
+  pairs_out->resize(2 * cnt[0]);
+  if (cnt[0]) { TRYM(hipMemcpyAsync(pairs_out->data(), d_pairs, cnt[0] * 8, hipMemcpyDeviceToHost, s)); TRYM(hipStreamSynchronize(s)); }
+#undef TRYM
+  return SHN_OK;
 }

@@ -7,6 +7,7 @@
 #include "common.h"
 #include <atomic>
 #include "flatmap.h"
+#include "graph_dev.h"
 #include "unitigs.h"
 #include "graph_result.h"
 #include <thread>
@@ -219,7 +220,29 @@ struct Graph {
     }
     __builtin_prefetch(rindex.data(r));
   }
-  size_t n_rd() const { return rindex.size(); }
+  // device-resident read attributes (graph_dev.h): copies, mates, roles, known-path states stay on the device; the host vectors
+  // rcc / rmate / rmp / rfirst / rlast / rhas are then EMPTY until need_host_attrs() fetches them for a host form that wants them
+  shn_dedup* dd = nullptr;
+  shn_kp* kp = nullptr;
+  bool dev_attrs = false;
+  size_t n_rd_dev = 0;
+  std::vector<uint32_t> mate_cand;                  // (a, b) node pairs of find_mate_pairs' pass over the reads, made on the device
+  bool mate_cand_ready = false;
+  int attrs_rc = 0;                                 // a failed fetch of the host arrays (find_known_paths is void)
+  size_t n_rd() const { return dev_attrs || dd ? n_rd_dev : rindex.size(); }
+  int need_host_attrs() {
+    if (!dev_attrs) return 0;
+    const size_t nd = n_rd_dev;
+    std::vector<uint32_t> c(nd); std::vector<int32_t> m(nd); std::vector<uint8_t> ro(nd);
+    int rc = shn_dedup_attrs(dd, c.data(), m.data(), ro.data());
+    if (rc) return rc;
+    rcc.resize(nd); rmate.resize(nd); rmp.resize(nd); rfirst.assign(nd, -1); rlast.assign(nd, -1); rhas.assign(nd, 0);
+    for (size_t i = 0; i < nd; i++) { rcc[i] = (double)c[i]; rmate[i] = m[i]; rmp[i] = ro[i]; }
+    dev_attrs = false;
+    return 0;
+  }
+  void release_dev_attrs() { if (kp) { shn_kp_destroy(kp); kp = nullptr; } if (dd) { shn_dedup_destroy(dd); dd = nullptr; } }
+  ~Graph() { release_dev_attrs(); }
   std::vector<double> rcc;
   std::vector<int> rmate, rmp;        // rmp: 0 None, 1, 2
   std::vector<int> rfirst, rlast;       // first / last node of the read's (last) path: all find_mate_pairs reads of Read.nodes
@@ -506,6 +529,7 @@ struct Graph {
   bool ensure_dreads(shn_reads** dreads) {
     if (!ctx || n_rd() == 0 || !reads_all_acgt()) return false;
     if (*dreads) return true;
+    if (src_a && dd && dd->n_distinct == n_rd()) return shn_reads_gather_dev(ctx, src_a, src_b, dd->d_row, dd->d_flag, n_rd(), dreads) == 0;
     if (src_a && origin_row.size() == n_rd()) return shn_reads_gather(ctx, src_a, src_b, origin_row.data(), origin_flag.data(), n_rd(), dreads) == 0;
     return shn_reads_create(ctx, (const uint8_t*)rindex.arena.data(), rindex.off.data(), n_rd(), 0, SHN_ENC_ASCII, dreads) == 0;
   }
@@ -852,6 +876,110 @@ struct Graph {
         std::vector<int32_t> precs(std::max<size_t>(1u << 16, n_rd() / 2 + 4096));
         uint64_t precs_used = 0;
         tk1 = nowk();
+        if (dev_attrs) {
+          // everything per read stays on the device: the host gets the reads left to search, the records of the reads searched
+          // there and (below, after its own searches) the node pairs of find_mate_pairs
+          std::vector<KpSlow> left;
+          std::vector<int32_t> recs;
+          std::vector<uint32_t> rec_cnt;
+          if (kp) { shn_kp_destroy(kp); kp = nullptr; }
+          const int rcf = shn_known_paths_dev(ctx, d_reads, K, (const uint8_t*)nb.data(), noff.data(), order.size(), eoff.data(), edst.data(), eov.data(), dd, &left,
+                                              &recs, &rec_cnt, &kp);
+          release_gpu();
+          tk2 = nowk();
+          if (rcf == 0) {
+            std::unordered_map<int, int> pos_in_order;
+            std::unordered_map<uint32_t, uint32_t> cnt_of;
+            cnt_of.reserve(rec_cnt.size());
+            for (size_t i = 0; i + 1 < rec_cnt.size(); i += 2) cnt_of[rec_cnt[i]] = rec_cnt[i + 1];
+            int cntp = 0;
+            std::unordered_map<uint64_t, double> edge_sum;
+            std::unordered_map<uint64_t, std::vector<std::vector<int>>> seen;
+            auto add_path = [&](const std::vector<int>& pth, double copies) {
+              for (size_t j = 0; j + 1 < pth.size(); j++) edge_sum[((uint64_t)(uint32_t)pth[j] << 32) | (uint32_t)pth[j + 1]] += copies;
+              if (pth.size() > 2) {
+                cntp++;
+                uint64_t h = 0xcbf29ce484222325ULL;
+                for (int v : pth) h = (h ^ (uint64_t)(uint32_t)v) * 0x100000001b3ULL;
+                auto& lst = seen[h];
+                bool have = false;
+                for (const auto& q : lst) if (q == pth) { have = true; break; }
+                if (!have) { lst.push_back(pth); known_paths.insert(pth); }
+              }
+            };
+            std::vector<int> pth;
+            for (uint64_t at = 0; at + 2 <= recs.size();) {
+              const int32_t r = recs[at], len = recs[at + 1];
+              if (len <= 0 || at + 2 + (uint64_t)len > recs.size()) break;
+              pth.resize((size_t)len);
+              for (int32_t j = 0; j < len; j++) pth[(size_t)j] = order[(size_t)recs[at + 2 + (uint64_t)j]];
+              at += 2 + (uint64_t)len;
+              add_path(pth, (double)cnt_of[(uint32_t)r]);
+            }
+            tk3 = nowk();
+            // the reads the device left (a search deeper than its stack, no room for the records): the host's search, one by one
+            std::vector<int32_t> patches;
+            if (!left.empty()) {
+              for (size_t q = 0; q < order.size(); q++) pos_in_order[order[q]] = (int)q;
+              std::sort(left.begin(), left.end(), [](const KpSlow& a, const KpSlow& b) { return a.read < b.read; });
+              // occurrences (node, offset), in index order, of the first K-mers of the reads of state 2
+              std::unordered_map<uint64_t, std::vector<std::pair<int, int>>> occ_of;
+              for (const KpSlow& sl : left) if (sl.state == 2) { uint64_t key; if (key_at(rstr((int)sl.read), 0, key)) occ_of[key]; }
+              if (!occ_of.empty())
+                for (int n : order) {
+                  const std::string& b = bases[n];
+                  uint64_t key = 0;
+                  for (int i = 0; i < (int)b.size(); i++) {
+                    key = ((key << 2) | (uint64_t)base_code(b[i])) & mask;
+                    if (i + 1 < K) continue;
+                    auto it = occ_of.find(key);
+                    if (it != occ_of.end()) it->second.push_back({n, i - K + 1});
+                  }
+                }
+              std::vector<std::vector<int>> paths;
+              std::vector<int> cur;
+              std::vector<std::pair<int, int>> one(1);
+              static const std::vector<std::pair<int, int>> none;
+              for (const KpSlow& sl : left) {
+                const int r = (int)sl.read;
+                const RStr rb = rstr(r);
+                uint64_t key;
+                if (!key_at(rb, 0, key)) continue;
+                const std::vector<std::pair<int, int>>* occs = &one;
+                if (sl.state == 3) one[0] = {order[sl.node], (int)sl.offset};
+                else { auto it = occ_of.find(key); occs = it == occ_of.end() ? &none : &it->second; }
+                int pf = -1, pl = -1;
+                for (const auto& oc : *occs) {
+                  const int sn = oc.first, so = oc.second;
+                  if (!compare(rb, 0, bases[sn], so)) continue;
+                  if (rb.size() <= bases[sn].size() - (size_t)so) { pf = sn; pl = sn; continue; }
+                  paths.clear(); cur.clear();
+                  search_sequence(rb, 0, sn, so, 30, cur, paths);
+                  for (auto& p : paths) { pf = p.front(); pl = p.back(); add_path(p, (double)sl.cnt); }
+                }
+                patches.push_back(r); patches.push_back(pf < 0 ? -1 : pos_in_order[pf]); patches.push_back(pl < 0 ? -1 : pos_in_order[pl]);
+              }
+            }
+            for (const auto& kv : edge_sum) known_edges[{(int)(uint32_t)(kv.first >> 32), (int)(uint32_t)kv.first}] += kv.second;
+            n_known = cntp;
+            // find_mate_pairs' pass over the reads, where their first / last nodes are (the graph does not change in between)
+            mate_cand.clear();
+            mate_cand_ready = shn_kp_mate_pairs(kp, dd, patches.data(), patches.size() / 3, &mate_cand) == 0;
+            if (mate_cand_ready) {
+              for (uint32_t& x : mate_cand) x = (uint32_t)order[x];
+              shn_kp_destroy(kp); kp = nullptr;
+              if (dbgk) fprintf(stderr, "[mbgraph]   kp (device, resident) node text %.3f s scan + search %.3f s records %.3f s left to the host + mate pairs %.3f s  (%zu bases, %zu reads, %zu with records, %zu left, %zu node pairs)\n",
+                                tk1 - tk0, tk2 - tk1, tk3 - tk2, nowk() - tk3, nb.size(), n_rd(), rec_cnt.size() / 2, left.size(), mate_cand.size() / 2);
+              return;
+            }
+            // (the pairs could not be made on the device: the host's pass needs first / last per read -- start over with host arrays)
+            known_paths.clear(); known_edges.clear(); n_known = 0;
+          }
+          if (kp) { shn_kp_destroy(kp); kp = nullptr; }
+          if ((attrs_rc = need_host_attrs())) return;
+          if (!ensure_dreads(&d_reads)) { attrs_rc = shn_fail(SHN_ERR_INTERNAL, "find_known_paths: the distinct reads could not be gathered again"); return; }
+          tk1 = nowk();
+        }
         static const bool kp_dev_search = !(getenv("SHN_GRAPH_KP_SEARCH") && getenv("SHN_GRAPH_KP_SEARCH")[0] == '0');
         const int rcs = kp_dev_search
             ? shn_known_paths_search(ctx, d_reads, K, (const uint8_t*)nb.data(), noff.data(), order.size(), eoff.data(), edst.data(), eov.data(), st.data(),
@@ -1009,6 +1137,7 @@ struct Graph {
         }
       } }
     tk0 = nowk();
+    if ((attrs_rc = need_host_attrs())) return;          // (the host form works on per-read arrays of its own)
     ensure_all_text();                                   // (the host form reads every read's text, on several threads)
     std::vector<std::pair<uint64_t, std::pair<int, int>>> items;
     for (int n : order) {
@@ -1134,6 +1263,11 @@ struct Graph {
   void find_mate_pairs() {
     std::vector<std::pair<int, int>> pairs;
     std::set<std::pair<int, int>> seen;
+    if (dev_attrs && mate_cand_ready) {
+      // (made on the device right after the known-paths search, kpaths_gpu.hip: distinct (a, b), not adjacent, in no particular
+      // order -- the loop below only counts and fills a set)
+      for (size_t i = 0; i + 1 < mate_cand.size(); i += 2) if (seen.insert({(int)mate_cand[i], (int)mate_cand[i + 1]}).second) pairs.push_back({(int)mate_cand[i], (int)mate_cand[i + 1]});
+    } else
     for (int r = 0; r < (int)n_rd(); r++) {
       if (rmp[r] != 1 || rmate[r] < 0) continue;
       int m = rmate[r];
@@ -1189,8 +1323,10 @@ struct Graph {
     lap("break_cycles");
     find_approximate_copy_counts();
     find_known_paths();
+    if (attrs_rc) return attrs_rc;
     lap("find_known_paths");
     find_copy_counts();
+    if (dev_attrs && !mate_cand_ready && (rc = need_host_attrs())) return rc;
     find_mate_pairs();
     lap("copy counts+mates");
     final_nodes = (int)order.size();
@@ -1210,7 +1346,7 @@ extern "C" void shn_graph_destroy(shn_graph* g) { delete g; }
 static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n_rows, const shn_unitigs* ug, uint32_t part, const uint8_t* r1,
                            const uint64_t* r1_off, const uint8_t* r2, const uint64_t* r2_off, uint64_t n_reads, int paired, int enc,
                            const uint8_t* rc1, const uint8_t* rc2, shn_graph** out, const shn_reads* src_a = nullptr, const shn_reads* src_b = nullptr,
-                           const uint32_t* didx = nullptr, const uint8_t* host_a = nullptr, const uint8_t* host_b = nullptr);
+                           const uint32_t* didx = nullptr, const uint8_t* host_a = nullptr, const uint8_t* host_b = nullptr, const uint32_t* d_didx = nullptr);
 extern "C" int shn_reads_dedup(shn_ctx* ctx, const shn_reads* a, const shn_reads* b, const uint32_t* didx, uint64_t n, int paired,
                                uint64_t* n_distinct, uint32_t* slot_out, uint32_t* count_out, int32_t* mate_out, uint8_t* role_out);
 
@@ -1246,21 +1382,42 @@ extern "C" int shn_mbgraph_run_resident(shn_ctx* ctx, const shn_unitigs* ug, uin
 // [n_reads of the set][read length], the same reads as src_a / src_b hold packed on the device), didx as above.  The distinct
 // reads are found on the device (shn_reads_dedup) and only their text is decoded on the host, straight from the matrices: no
 // per-partition copy of the routed reads exists anywhere.
-extern "C" int shn_mbgraph_run_rows(shn_ctx* ctx, const shn_unitigs* ug, uint32_t part, const uint8_t* rows, uint64_t n_rows, const shn_reads* src_a,
-                                    const shn_reads* src_b, const uint8_t* host_a, const uint8_t* host_b, const uint32_t* didx, uint64_t n_reads,
-                                    int paired, shn_graph** out) {
+static int mbgraph_run_rows_impl(shn_ctx* ctx, const shn_unitigs* ug, uint32_t part, const uint8_t* rows, uint64_t n_rows, const shn_reads* src_a,
+                                 const shn_reads* src_b, const uint8_t* host_a, const uint8_t* host_b, const uint32_t* didx, const uint32_t* d_didx,
+                                 uint64_t n_reads, int paired, shn_graph** out) {
   if (!ug || part >= ug->n_parts) return shn_fail(SHN_ERR_ARG, "shn_mbgraph_run_rows: bad unitigs / partition");
   if (!ctx || !src_a || !host_a || (n_reads && !didx) || (paired && (!src_b || !host_b)) || !src_a->fixed_len ||
       (paired && src_b->fixed_len != src_a->fixed_len))
     return shn_fail(SHN_ERR_ARG, "shn_mbgraph_run_rows: needs a context, fixed-length resident read sets and their host matrices");
-  return mbgraph_run_impl(ctx, ug->K, rows, n_rows, ug, part, nullptr, nullptr, nullptr, nullptr, n_reads, paired, SHN_ENC_CODES, nullptr, nullptr, out,
-                          src_a, src_b, didx, host_a, host_b);
+  const bool dbg = getenv("SHN_GRAPH_LAPS") && n_reads >= strtoull(getenv("SHN_GRAPH_LAPS"), nullptr, 10);
+  const double t0 = dbg ? Graph::tnow() : 0.0;
+  const int rc = mbgraph_run_impl(ctx, ug->K, rows, n_rows, ug, part, nullptr, nullptr, nullptr, nullptr, n_reads, paired, SHN_ENC_CODES, nullptr, nullptr, out,
+                                  src_a, src_b, didx, host_a, host_b, d_didx);
+  if (dbg) fprintf(stderr, "[mbgraph] the call (partition %u), its clean-up included %8.3f s\n", part, Graph::tnow() - t0);
+  return rc;
+}
+extern "C" int shn_mbgraph_run_rows(shn_ctx* ctx, const shn_unitigs* ug, uint32_t part, const uint8_t* rows, uint64_t n_rows, const shn_reads* src_a,
+                                    const shn_reads* src_b, const uint8_t* host_a, const uint8_t* host_b, const uint32_t* didx, uint64_t n_reads,
+                                    int paired, shn_graph** out) {
+  return mbgraph_run_rows_impl(ctx, ug, part, rows, n_rows, src_a, src_b, host_a, host_b, didx, nullptr, n_reads, paired, out);
+}
+// The same with the partition's routed reads named a second time by where they already lie on the device: entries [route_lo,
+// route_lo + n_reads) of the routes shn_route_reads left there (didx = the same indices on the host) -- the duplicate search then
+// reads them in place instead of uploading the list again (0.5 GB per step at BASELINE configs[2], in 111 pieces).
+extern "C" int shn_mbgraph_run_routes(shn_ctx* ctx, const shn_unitigs* ug, uint32_t part, const uint8_t* rows, uint64_t n_rows, const shn_reads* src_a,
+                                      const shn_reads* src_b, const uint8_t* host_a, const uint8_t* host_b, const uint32_t* didx, const shn_routes* routes,
+                                      uint64_t route_lo, uint64_t n_reads, int paired, shn_graph** out) {
+  if (!routes) return shn_fail(SHN_ERR_ARG, "shn_mbgraph_run_routes: routes is NULL");
+  const uint32_t* d = nullptr;
+  int rc = shn_routes_device_slice(routes, route_lo, n_reads, &d);
+  if (rc) return rc;
+  return mbgraph_run_rows_impl(ctx, ug, part, rows, n_rows, src_a, src_b, host_a, host_b, didx, d, n_reads, paired, out);
 }
 
 static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n_rows, const shn_unitigs* ug, uint32_t part, const uint8_t* r1,
                            const uint64_t* r1_off, const uint8_t* r2, const uint64_t* r2_off, uint64_t n_reads, int paired, int enc,
                            const uint8_t* rc1, const uint8_t* rc2, shn_graph** out, const shn_reads* src_a, const shn_reads* src_b,
-                           const uint32_t* didx, const uint8_t* host_a, const uint8_t* host_b) {
+                           const uint32_t* didx, const uint8_t* host_a, const uint8_t* host_b, const uint32_t* d_didx) {
   if (!out || (n_rows && !rows) || (!host_a && ((n_reads && (!r1 || !r1_off)) || (paired && n_reads && (!r2 || !r2_off)))))
     return shn_fail(SHN_ERR_ARG, "shn_mbgraph_run: NULL argument");
   struct Running { Running() { g_partitions_running.fetch_add(1); } ~Running() { g_partitions_running.fetch_sub(1); } } running;
@@ -1368,7 +1525,28 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
   sc->rcc.clear(); sc->rmate.clear(); sc->rmp.clear(); sc->rfirst.clear(); sc->rlast.clear(); sc->rhas.clear(); sc->r_hashes.clear(); sc->r_off.assign(1, 0);
   g.rcc.swap(sc->rcc); g.rmate.swap(sc->rmate); g.rmp.swap(sc->rmp); g.rfirst.swap(sc->rfirst); g.rlast.swap(sc->rlast); g.rhas.swap(sc->rhas);
   g.rindex.hashes.swap(sc->r_hashes); g.rindex.off.swap(sc->r_off);
-  if (dev_dedup) {
+  // the fast form of the rows mode (graph_dev.h): the duplicate search leaves its arrays on the device, the host gets rows + strands
+  // (for the lazily decoded text) and nothing else per read.  SHN_GRAPH_DEV_ATTRS=0: the host-array form below.
+  const char* dav = getenv("SHN_GRAPH_DEV_ATTRS");
+  const bool lazy_ok = host_a && !(getenv("SHN_GRAPH_LAZY_TEXT") && getenv("SHN_GRAPH_LAZY_TEXT")[0] == '0') && src_a && src_a->n_invalid == 0 &&
+                       (!paired || (src_b && src_b->n_invalid == 0));
+  if (dev_dedup && lazy_ok && g.ctx && K <= 31 && !(dav && dav[0] == '0')) {
+    const uint64_t used = std::min<uint64_t>(n_reads, cutoff + 1);
+    const uint64_t Lr = read_len0;
+    double t_dec = now();
+    int rcd = shn_reads_dedup_dev(g.ctx, src_a, paired ? src_b : nullptr, didx, d_didx, used, paired, &g.dd);
+    if (rcd) return rcd;
+    const uint64_t nd = g.dd->n_distinct;
+    g.n_rd_dev = nd; g.dev_attrs = true;
+    if (dbg) fprintf(stderr, "[mbgraph]   distinct reads (GPU)   %8.3f s  used=%llu distinct=%llu (attributes stay on the device)\n", now() - t_dec, (unsigned long long)used, (unsigned long long)nd);
+    if (sc->text.size() < nd * Lr + 1) { sc->text.clear(); sc->text.resize(nd * Lr + 1); }
+    g.lz_a = host_a; g.lz_b = host_b; g.lz_L = (uint32_t)Lr; g.lz_buf = sc->text.data();
+    g.lz_done.assign((nd + 63) / 64, 0);
+    g.origin_row.resize(nd); g.origin_flag.resize(nd);
+    if ((rcd = shn_dedup_origin(g.dd, g.origin_row.data(), g.origin_flag.data()))) return rcd;
+    g.acgt_known = 1;
+    if (dbg) fprintf(stderr, "[mbgraph]   + rows of the distinct  %8.3f s\n", now() - t_dec);
+  } else if (dev_dedup) {
     const uint64_t used = std::min<uint64_t>(n_reads, cutoff + 1);
     const int nm = paired ? 2 : 1;
     const uint64_t nh = used * nm, Lr = read_len0;

@@ -16,6 +16,7 @@
 // Output order and values equal the host code they replace (mbgraph_host.hip, bulk numbering) and the one-at-a-time interner
 // (tests/test_host_graph.py, tests/test_e2e_gpu.py).
 #include "common.h"
+#include "graph_dev.h"
 
 #include <algorithm>
 #include <chrono>
@@ -100,17 +101,29 @@ __global__ void dd_tally(uint64_t nh, const uint32_t* __restrict__ tab, const ui
 
 __global__ void dd_emit(uint64_t nh, int paired, const uint32_t* __restrict__ first, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ last,
                         const uint64_t* __restrict__ pos, uint32_t* __restrict__ o_slot, uint32_t* __restrict__ o_cnt, int32_t* __restrict__ o_mate,
-                        uint8_t* __restrict__ o_role) {
+                        uint8_t* __restrict__ o_role, SlotSrc S, uint32_t* __restrict__ o_row, uint8_t* __restrict__ o_flag) {
   for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nh; j += (uint64_t)gridDim.x * blockDim.x) {
     if (first[j] != (uint32_t)j) continue;
     const uint64_t id = pos[j];
-    o_slot[id] = (uint32_t)j;
+    if (o_slot) o_slot[id] = (uint32_t)j;
     o_cnt[id] = cnt[j];
     if (paired) {
       const uint32_t l = last[j];
       o_role[id] = (l & 1) ? 2 : 1;
       o_mate[id] = (int32_t)pos[first[l ^ 1u]];
     } else { o_role[id] = 0; o_mate[id] = -1; }
+    if (o_row) {
+      // the slot's place in the resident input (mbgraph_run_impl's origin_of): row, bit 0 = set b, bit 1 = reverse complement
+      const uint64_t i = S.paired ? (j >> 1) : j;
+      const uint64_t d = S.didx[i];
+      const bool second = d >= S.n_in;
+      o_row[id] = (uint32_t)(second ? d - S.n_in : d);
+      uint8_t fl;
+      if (!S.paired) fl = second ? 2 : 0;
+      else if ((j & 1) == 0) fl = second ? 3 : 0;
+      else fl = second ? 1 : 2;
+      o_flag[id] = fl;
+    }
   }
 }
 
@@ -177,7 +190,7 @@ extern "C" int shn_reads_dedup(shn_ctx* ctx, const shn_reads* a, const shn_reads
   TRYD(bufs.get(&d_omate, nd * 4));
   TRYD(bufs.get(&d_orole, nd));
   t_alloc2 = now() - t0;
-  hipLaunchKernelGGL(dd_emit, dim3(grid), dim3(256), 0, s, nh, paired ? 1 : 0, d_first, d_cnt, d_last, d_pos, d_oslot, d_ocnt, d_omate, d_orole);
+  hipLaunchKernelGGL(dd_emit, dim3(grid), dim3(256), 0, s, nh, paired ? 1 : 0, d_first, d_cnt, d_last, d_pos, d_oslot, d_ocnt, d_omate, d_orole, S, (uint32_t*)nullptr, (uint8_t*)nullptr);
   TRYD(hipGetLastError());
   TRYD(hipMemcpyAsync(slot_out, d_oslot, nd * 4, hipMemcpyDeviceToHost, s));
   TRYD(hipMemcpyAsync(count_out, d_ocnt, nd * 4, hipMemcpyDeviceToHost, s));
@@ -188,5 +201,87 @@ extern "C" int shn_reads_dedup(shn_ctx* ctx, const shn_reads* a, const shn_reads
   if (dbg) fprintf(stderr, "[dedup] slots=%llu distinct=%llu: alloc %.3f upload %.3f kernels %.3f scan %.3f alloc2 %.3f done %.3f s\n", (unsigned long long)nh,
                    (unsigned long long)nd, t_alloc, t_up, t_k, t_scan, t_alloc2, now() - t0);
   *n_distinct = nd;
+  return SHN_OK;
+}
+
+// ---- the same search with its result left on the device (graph_dev.h)
+void shn_dedup_destroy(shn_dedup* d) {
+  if (!d) return;
+  if (d->ctx) hipSetDevice(d->ctx->device);
+  shn_dev_free(d->d_cnt); shn_dev_free(d->d_mate); shn_dev_free(d->d_role); shn_dev_free(d->d_row); shn_dev_free(d->d_flag);
+  delete d;
+}
+int shn_reads_dedup_dev(shn_ctx* ctx, const shn_reads* a, const shn_reads* b, const uint32_t* didx, const uint32_t* d_didx, uint64_t n, int paired,
+                        shn_dedup** out) {
+  if (!ctx || !a || !out || (n && !didx && !d_didx) || (paired && !b)) return shn_fail(SHN_ERR_ARG, "shn_reads_dedup_dev: NULL argument");
+  if (!a->fixed_len || a->wpr > (uint32_t)MAXW || (b && (b->fixed_len != a->fixed_len || b->wpr != a->wpr)))
+    return shn_fail(SHN_ERR_ARG, "shn_reads_dedup_dev: fixed-length read sets of one length (<= 512 bases) only");
+  const uint64_t nm = paired ? 2 : 1, nh = n * nm;
+  if (nh >= (1ULL << 31)) return shn_fail(SHN_ERR_ARG, "shn_reads_dedup_dev: more than 2^31 read slots");
+  const uint64_t n_in = a->n_reads;
+  if (!d_didx)                                                   // (indices from the host are checked; a slice of shn_routes is the library's own)
+    for (uint64_t i = 0; i < n; i++) {
+      const uint64_t d = didx[i];
+      const uint64_t lim = (d >= n_in) ? (paired ? b->n_reads : a->n_reads) + n_in : n_in;
+      if (d >= lim) return shn_fail(SHN_ERR_ARG, "shn_reads_dedup_dev: read index out of range");
+    }
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  shn_dedup* D = new shn_dedup();
+  D->ctx = ctx; D->n_slots = nh; D->paired = paired ? 1 : 0;
+  if (!nh) { *out = D; return SHN_OK; }
+  uint64_t T = 1024;
+  while (T < 2 * nh) T <<= 1;
+  ShnDevBufs bufs(s);
+  uint32_t *d_idx = nullptr, *d_tab = nullptr, *d_slot = nullptr, *d_first = nullptr, *d_cnt = nullptr, *d_last = nullptr, *d_flag = nullptr;
+  uint64_t* d_pos = nullptr;
+#define TRYD(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { shn_dedup_destroy(D); return shn_fail(SHN_ERR_HIP, std::string("shn_reads_dedup_dev: ") + hipGetErrorString(e_)); } } while (0)
+  if (!d_didx) { TRYD(bufs.get(&d_idx, n * 4)); TRYD(hipMemcpyAsync(d_idx, didx, n * 4, hipMemcpyHostToDevice, s)); }
+  TRYD(bufs.get(&d_tab, T * 4));
+  TRYD(bufs.get(&d_slot, nh * 4));
+  TRYD(bufs.get(&d_first, nh * 4));
+  TRYD(bufs.get(&d_cnt, nh * 4));
+  TRYD(bufs.get(&d_last, nh * 4));
+  TRYD(bufs.get(&d_flag, nh * 4));
+  TRYD(bufs.get(&d_pos, (nh + 1) * 8));
+  TRYD(hipMemsetAsync(d_tab, 0xFF, T * 4, s));
+  TRYD(hipMemsetAsync(d_cnt, 0, nh * 4, s));
+  TRYD(hipMemsetAsync(d_last, 0, nh * 4, s));
+  SlotSrc S{a->d_words, b ? b->d_words : a->d_words, d_didx ? d_didx : d_idx, n_in, a->wpr, a->fixed_len, paired ? 1 : 0};
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(cdiv(nh, 256), 1u << 20);
+  if (a->wpr <= 4) hipLaunchKernelGGL(dd_insert<4>, dim3(grid), dim3(256), 0, s, S, nh, d_tab, T - 1, d_slot);
+  else hipLaunchKernelGGL(dd_insert<MAXW>, dim3(grid), dim3(256), 0, s, S, nh, d_tab, T - 1, d_slot);
+  hipLaunchKernelGGL(dd_tally, dim3(grid), dim3(256), 0, s, nh, d_tab, d_slot, d_first, d_cnt, d_last, d_flag);
+  TRYD(hipGetLastError());
+  uint64_t nd = 0;
+  { int rc = shn_device_scan_u32(ctx, d_flag, nh, d_pos, &nd); if (rc) { shn_dedup_destroy(D); return rc; } }
+  D->n_distinct = nd;
+  TRYD(shn_dev_malloc(&D->d_cnt, (nd + 1) * 4)); TRYD(shn_dev_malloc(&D->d_mate, (nd + 1) * 4)); TRYD(shn_dev_malloc(&D->d_role, nd + 1));
+  TRYD(shn_dev_malloc(&D->d_row, (nd + 1) * 4)); TRYD(shn_dev_malloc(&D->d_flag, nd + 1));
+  hipLaunchKernelGGL(dd_emit, dim3(grid), dim3(256), 0, s, nh, paired ? 1 : 0, d_first, d_cnt, d_last, d_pos, (uint32_t*)nullptr, D->d_cnt, D->d_mate, D->d_role, S,
+                     D->d_row, D->d_flag);
+  TRYD(hipGetLastError());
+  TRYD(hipStreamSynchronize(s));
+#undef TRYD
+  *out = D;
+  return SHN_OK;
+}
+int shn_dedup_origin(const shn_dedup* d, uint32_t* row_out, uint8_t* flag_out) {
+  if (!d || (d->n_distinct && (!row_out || !flag_out))) return shn_fail(SHN_ERR_ARG, "shn_dedup_origin: NULL argument");
+  if (!d->n_distinct) return SHN_OK;
+  HIP_TRY(hipSetDevice(d->ctx->device));
+  HIP_TRY(hipMemcpyAsync(row_out, d->d_row, d->n_distinct * 4, hipMemcpyDeviceToHost, d->ctx->stream));
+  HIP_TRY(hipMemcpyAsync(flag_out, d->d_flag, d->n_distinct, hipMemcpyDeviceToHost, d->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(d->ctx->stream));
+  return SHN_OK;
+}
+int shn_dedup_attrs(const shn_dedup* d, uint32_t* cnt_out, int32_t* mate_out, uint8_t* role_out) {
+  if (!d || (d->n_distinct && (!cnt_out || !mate_out || !role_out))) return shn_fail(SHN_ERR_ARG, "shn_dedup_attrs: NULL argument");
+  if (!d->n_distinct) return SHN_OK;
+  HIP_TRY(hipSetDevice(d->ctx->device));
+  HIP_TRY(hipMemcpyAsync(cnt_out, d->d_cnt, d->n_distinct * 4, hipMemcpyDeviceToHost, d->ctx->stream));
+  HIP_TRY(hipMemcpyAsync(mate_out, d->d_mate, d->n_distinct * 4, hipMemcpyDeviceToHost, d->ctx->stream));
+  HIP_TRY(hipMemcpyAsync(role_out, d->d_role, d->n_distinct, hipMemcpyDeviceToHost, d->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(d->ctx->stream));
   return SHN_OK;
 }

@@ -127,6 +127,14 @@ struct shn_routes {
   uint32_t* d_ridx;
 };
 
+// (internal, graph_dev.h) entries [lo, lo + n) of the routed read indices where they lie on the device
+int shn_routes_device_slice(const shn_routes* r, uint64_t lo, uint64_t n, const uint32_t** out) {
+  if (!r || !out) return shn_fail(SHN_ERR_ARG, "shn_routes_device_slice: NULL argument");
+  if (lo + n > r->n) return shn_fail(SHN_ERR_ARG, "shn_routes_device_slice: range outside the routes");
+  *out = r->d_ridx + lo;
+  return SHN_OK;
+}
+
 extern "C" void shn_routes_destroy(shn_routes* r) {
   if (!r) return;
   hipSetDevice(r->device);

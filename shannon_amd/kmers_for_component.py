@@ -373,11 +373,14 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
         # (the partition column is not fetched: the routes are sorted by partition and the device knows where each one starts)
         start, _below = routes.bounds(len(names), len(reads1))
         ridx = routes.download_range(0, int(start[len(names)]))
-        routes.close()
         by_part = {n: ridx[int(start[i]):int(start[i + 1])] for i, n in enumerate(names)}
     lap("route.download")
     out = _finish_partitions(res, comps, broken, names, by_part, files, cw, k1, K, want_rows, lazy_graph_inputs, lap)
     out["flat_text"] = flat_text
+    if not lazy_routes:
+        # the routes also stay where the routing left them (1 GB at BASELINE configs[2]; freed with this dict): the graph stage's
+        # duplicate search reads a partition's list in place (shn_mbgraph_run_routes) -- {name: first entry of the partition}
+        out["routes_dev"] = (routes, {n: int(start[i]) for i, n in enumerate(names)})
     return out
 
 

@@ -175,10 +175,12 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
                 if check_rows:
                     rb_ = part["k1mer_bytes"][name]
                     rb = rb_() if callable(rb_) else rb_
+                rdev = part.get("routes_dev")                             # (the same list, still on the device: idx is a prefix of the partition's)
                 def run_rows(rb):
                     return mbgraph_native.run_partition_rows(ctx_b, unitigs, part_index[name], d1, d2, store.r1, store.r2 if paired else None,
                                                              np.asarray(idx, dtype=np.uint32), rb if (rb is not None and len(rb)) else None,
-                                                             0 if rb is None else len(rb) // (K + 1))
+                                                             0 if rb is None else len(rb) // (K + 1),
+                                                             routes=(rdev[0], rdev[1][name]) if (rdev is not None and name in rdev[1]) else None)
                 try:
                     gh = run_rows(rb)
                 except _lib.ShannonError as ex:
