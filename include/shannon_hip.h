@@ -210,6 +210,16 @@ int shn_cgraph_export(const shn_cgraph* g, uint64_t* conn_off, int32_t* conn_nb,
  * graph; *out is read with shn_cgraph_sizes / shn_cgraph_export and freed with shn_cgraph_destroy.                              */
 int shn_contig_stage(shn_ctx* ctx, const uint8_t* bases, const uint64_t* off, uint64_t n_cand, int k1, int r, double f,
                      int32_t* accepted_out, int32_t* best_counts_out, shn_cgraph** out);
+/* The same two steps without the candidates' text crossing the bus twice: shn_ext_emit_device leaves the text of the selected walks
+ * (extension_correction.py:334-354, the contigs before the accept decisions of :358-397) on the device as a shn_devtext,
+ * shn_contig_stage_device reads it there, shn_devtext_segments fetches the pieces idx[0..n_idx) of the n_off - 1 pieces the offsets
+ * cut it into (the accepted contigs), one after the other.                                                                     */
+typedef struct shn_devtext shn_devtext;
+int shn_ext_emit_device(shn_ctx* ctx, const shn_ext* e, const uint32_t* ranks, uint64_t n_sel, const uint64_t* offsets, shn_devtext** out);
+int shn_contig_stage_device(shn_ctx* ctx, const shn_devtext* text, const uint64_t* off, uint64_t n_cand, int k1, int r, double f,
+                            int32_t* accepted_out, int32_t* best_counts_out, shn_cgraph** out);
+int shn_devtext_segments(shn_ctx* ctx, const shn_devtext* text, const uint64_t* off, uint64_t n_off, const int64_t* idx, uint64_t n_idx, uint8_t* out);
+void shn_devtext_destroy(shn_devtext* t);
 /* Connected components of the contig graph by the reference's depth-first search (extension_correction.py:417-434) over the
  * connections CSR of shn_cgraph_export: comp_of[a-1] = root contig of contig a (1-based), members[] = the components' contigs in the
  * order the DFS pops them, component j at members[comp_off[j]..comp_off[j+1]), comp_edges[j] = its number of undirected edges
@@ -416,6 +426,10 @@ int shn_graph_from_tables(const uint64_t* sizes, const uint64_t* s_off, const ui
  * partition g concatenated in component order, then reconstructed_comp_-1.fasta (its single nodes).                              */
 typedef struct shn_sflow shn_sflow;
 int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uint32_t n_graphs, const char* const* snames, uint64_t seed, shn_sflow** out);
+/* The same as one of several calls host threads make at once (run_MB_SF_fn.py:242-250 starts one algorithm_SF.py process per
+ * component; here: one call per partition, right behind its graph stage): the LP batches go to the calling thread's own stream.  The
+ * results equal those of ONE shn_sparse_flow over all the graphs.                                                              */
+int shn_sparse_flow_thread(shn_ctx* ctx, const shn_graph* const* graphs, uint32_t n_graphs, const char* const* snames, uint64_t seed, shn_sflow** out);
 void shn_sflow_destroy(shn_sflow* s);
 uint64_t shn_sflow_text_size(const shn_sflow* s, uint32_t g);
 int shn_sflow_text(const shn_sflow* s, uint32_t g, uint8_t* out);

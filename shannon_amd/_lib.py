@@ -92,6 +92,7 @@ SIGNATURES = {
     "shn_reads_gather": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, vpp]),
     "shn_graph_from_tables": (C.c_int, [vp] * 20 + [vpp]),
     "shn_sparse_flow": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint64, vpp]),
+    "shn_sparse_flow_thread": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint64, vpp]),
     "shn_sflow_destroy": (None, [vp]),
     "shn_sflow_text_size": (C.c_uint64, [vp, C.c_uint32]),
     "shn_sflow_text": (C.c_int, [vp, C.c_uint32, vp]),
@@ -118,6 +119,10 @@ SIGNATURES = {
     "shn_contig_stage": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, C.c_double, vp, vp, vpp]),
     "shn_contig_components": (C.c_int, [C.c_uint64, vp, vp, vp, vp, vp, vp, u64p]),
     "shn_ext_emit": (C.c_int, [vp, vp, vp, C.c_uint64, vp, vp]),
+    "shn_ext_emit_device": (C.c_int, [vp, vp, vp, C.c_uint64, vp, vpp]),
+    "shn_contig_stage_device": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, C.c_double, vp, vp, vpp]),
+    "shn_devtext_segments": (C.c_int, [vp, vp, vp, C.c_uint64, vp, C.c_uint64, vp]),
+    "shn_devtext_destroy": (None, [vp]),
     "shn_ext_weights": (C.c_int, [vp, vp, vp, C.c_uint64, vp]),
 }
 

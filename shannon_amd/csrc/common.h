@@ -82,6 +82,9 @@ struct shn_reads {
   bool cached;             // device arrays come from the caching allocator (shn_reads_gather), not hipMalloc
 };
 
+// text on the device (the candidate contigs as shn_ext_emit_device leaves them): n bytes + 64 zeroed
+struct shn_devtext { shn_ctx* ctx; uint8_t* d; uint64_t n; };
+
 struct shn_table {
   shn_ctx* ctx;
   int device;
@@ -273,6 +276,7 @@ void shn_stage_begin();                      // a top-level GPU stage starts (wo
 size_t shn_ws_release_idle();                // frees the slots not used by the current stage; returns the bytes given back
 extern ShnWs g_shn_ws[32];
 extern "C" int shn_host_cpus(void);
+shn_ctx* shn_thread_ctx(shn_ctx* parent);      // core.hip: the calling host thread's own fork (stream) of a context
 int shn_device_scan_u32(shn_ctx* ctx, const uint32_t* d_in, uint64_t n, uint64_t* d_out /* n+1 */, uint64_t* total_host);
 // stable LSD radix sort of (u64 key, u32 value) pairs on bits [bit_lo, bit_hi); result lands in keys/vals
 int shn_sort_pairs(shn_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t* keys_tmp, uint32_t* vals_tmp, uint64_t n,

@@ -255,9 +255,10 @@ int shn_sorted_windows(shn_ctx* ctx, ShnDevBufs& bufs, const uint8_t* d_bases, c
 // Same contract as shn_cgraph_add on a fresh graph: candidates in seed order in one call; accepted_out[i] = 1-based accepted
 // index or 0, best_counts_out[i] (may be NULL) = hit count of the candidate's `best` contig; *out receives the contig graph
 // (shn_cgraph_sizes / shn_cgraph_export / shn_cgraph_destroy).
-extern "C" int shn_contig_stage(shn_ctx* ctx, const uint8_t* bases, const uint64_t* off, uint64_t n_cand, int k1, int r, double f,
-                                int32_t* accepted_out, int32_t* best_counts_out, shn_cgraph** out) {
-  if (!ctx || !out || k1 < 2 || k1 > 33 || r < 1 || r > 32 || (n_cand && (!bases || !off || !accepted_out)))
+// bases: the candidates' text on the host (uploaded), or dev_text: the same text already on the device (>= total + 64 bytes)
+static int contig_stage_impl(shn_ctx* ctx, const uint8_t* bases, const uint8_t* dev_text, const uint64_t* off, uint64_t n_cand, int k1, int r, double f,
+                             int32_t* accepted_out, int32_t* best_counts_out, shn_cgraph** out) {
+  if (!ctx || !out || k1 < 2 || k1 > 33 || r < 1 || r > 32 || (n_cand && ((!bases && !dev_text) || !off || !accepted_out)))
     return shn_fail(SHN_ERR_ARG, "shn_contig_stage: bad argument");
   *out = nullptr;
   const bool dbg = getenv("SHN_DEBUG") != nullptr;
@@ -279,10 +280,11 @@ extern "C" int shn_contig_stage(shn_ctx* ctx, const uint8_t* bases, const uint64
   TimerRegion treg(ctx, T_CONTIG);
   ShnDevBufs bufs(s);
   uint8_t* d_bases; uint64_t* d_off; uint32_t* d_cid;
-  HIP_TRY(bufs.get(&d_bases, total + 64));
+  if (dev_text) d_bases = const_cast<uint8_t*>(dev_text);            // (read only from here on)
+  else HIP_TRY(bufs.get(&d_bases, total + 64));
   HIP_TRY(bufs.get(&d_off, (n_cand + 1) * 8));
   HIP_TRY(bufs.get(&d_cid, (total + 1) * 4));
-  HIP_TRY(hipMemcpyAsync(d_bases, bases, total, hipMemcpyHostToDevice, s));
+  if (!dev_text) HIP_TRY(hipMemcpyAsync(d_bases, bases, total, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_off, off, (n_cand + 1) * 8, hipMemcpyHostToDevice, s));
   shn_contig_ids(s, d_off, n_cand, d_cid);
 
@@ -292,6 +294,13 @@ extern "C" int shn_contig_stage(shn_ctx* ctx, const uint8_t* bases, const uint64
   for (uint64_t c = 0; c < n_cand; c++) max_len = std::max<uint32_t>(max_len, (uint32_t)(off[c + 1] - off[c]));
   if (n_cand >= (1u << 21) || max_len >= (1u << 21)) {
     // beyond the 21-bit fields of the packed "best parent" word: the sequential stage
+    std::vector<uint8_t> fetched;
+    if (!bases) {
+      fetched.resize(total);
+      HIP_TRY(hipMemcpyAsync(fetched.data(), d_bases, total, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      bases = fetched.data();
+    }
     G->add(bases, off, n_cand, accepted_out, best_counts_out);
     *out = G; guard.g = nullptr;
     return SHN_OK;
@@ -481,5 +490,59 @@ extern "C" int shn_contig_stage(shn_ctx* ctx, const uint8_t* bases, const uint64
   HIP_TRY(hipGetLastError());
   *out = G;
   guard.g = nullptr;
+  return SHN_OK;
+}
+
+extern "C" int shn_contig_stage(shn_ctx* ctx, const uint8_t* bases, const uint64_t* off, uint64_t n_cand, int k1, int r, double f,
+                                int32_t* accepted_out, int32_t* best_counts_out, shn_cgraph** out) {
+  if (n_cand && !bases) return shn_fail(SHN_ERR_ARG, "shn_contig_stage: bad argument");
+  return contig_stage_impl(ctx, bases, nullptr, off, n_cand, k1, r, f, accepted_out, best_counts_out, out);
+}
+// The candidates' text where shn_ext_emit_device left it: no copy of the 0.3 GB of candidate contigs to the host and back (only the
+// accepted tenth is ever needed there: shn_devtext_segments).
+extern "C" int shn_contig_stage_device(shn_ctx* ctx, const shn_devtext* text, const uint64_t* off, uint64_t n_cand, int k1, int r, double f,
+                                       int32_t* accepted_out, int32_t* best_counts_out, shn_cgraph** out) {
+  if (n_cand && (!text || !text->d || !off || text->n < off[n_cand])) return shn_fail(SHN_ERR_ARG, "shn_contig_stage_device: the text does not cover the offsets");
+  return contig_stage_impl(ctx, nullptr, text ? text->d : nullptr, off, n_cand, k1, r, f, accepted_out, best_counts_out, out);
+}
+extern "C" void shn_devtext_destroy(shn_devtext* t) {
+  if (!t) return;
+  if (t->ctx) hipSetDevice(t->ctx->device);
+  shn_dev_free(t->d);
+  delete t;
+}
+__global__ void devtext_segments_kernel(const uint8_t* __restrict__ src, const uint64_t* __restrict__ seg /* src begin, dst begin per segment; [n] = total */,
+                                        uint64_t n_seg, uint64_t total, uint8_t* __restrict__ dst) {
+  // one thread per output byte: its segment by bisection over the destination offsets
+  for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t lo = 0, hi = n_seg;
+    while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (seg[2 * mid + 1] <= g) lo = mid; else hi = mid; }
+    dst[g] = src[seg[2 * lo] + (g - seg[2 * lo + 1])];
+  }
+}
+// segments idx[0..n_idx) (of the n_off - 1 pieces the offsets `off` cut the text into) one after the other into out (host)
+extern "C" int shn_devtext_segments(shn_ctx* ctx, const shn_devtext* text, const uint64_t* off, uint64_t n_off, const int64_t* idx, uint64_t n_idx, uint8_t* out) {
+  if (!ctx || !text || (n_idx && (!off || !idx || !out))) return shn_fail(SHN_ERR_ARG, "shn_devtext_segments: NULL argument");
+  if (!n_idx) return SHN_OK;
+  std::vector<uint64_t> seg(2 * n_idx + 2);
+  uint64_t total = 0;
+  for (uint64_t i = 0; i < n_idx; i++) {
+    if (idx[i] < 0 || (uint64_t)idx[i] + 1 >= n_off || off[idx[i] + 1] < off[idx[i]] || off[idx[i] + 1] > text->n) return shn_fail(SHN_ERR_ARG, "shn_devtext_segments: segment outside the text");
+    seg[2 * i] = off[idx[i]]; seg[2 * i + 1] = total;
+    total += off[idx[i] + 1] - off[idx[i]];
+  }
+  seg[2 * n_idx] = 0; seg[2 * n_idx + 1] = total;
+  if (!total) return SHN_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  ShnDevBufs bufs(s);
+  uint64_t* d_seg; uint8_t* d_dst;
+  HIP_TRY(bufs.get(&d_seg, seg.size() * 8)); HIP_TRY(bufs.get(&d_dst, total));
+  HIP_TRY(hipMemcpyAsync(d_seg, seg.data(), seg.size() * 8, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(devtext_segments_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(total, 256), 1u << 16)), dim3(256), 0, s, (const uint8_t*)text->d, (const uint64_t*)d_seg,
+                     n_idx, total, d_dst);
+  HIP_TRY(hipMemcpyAsync(out, d_dst, total, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipGetLastError());
   return SHN_OK;
 }

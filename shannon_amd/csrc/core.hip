@@ -139,6 +139,28 @@ extern "C" int shn_ctx_fork(const shn_ctx* parent, shn_ctx** out) {
   return SHN_OK;
 }
 
+// A context of its own (same device, own stream) for the calling host thread: the partitions of the graph stage run on host
+// threads at once, and so do their sparse-flow calls; with a stream each, their GPU sections overlap instead of taking turns.
+// The fork lives as long as the thread (or until the thread asks for a fork of another parent).  NULL parent -> NULL.
+// SHN_GRAPH_FORK=0 (with SHN_GRAPH_THREADS=1): everything on the caller's context and stream -- rocprofv3's kernel trace aborts
+// (stream_stack.cpp) when threads it has not seen create streams; tools/profile_r0x.sh profile that way.
+struct ShnThreadCtx {
+  shn_ctx* c = nullptr; const shn_ctx* parent = nullptr;
+  ~ShnThreadCtx() { if (c) shn_ctx_destroy(c); }
+};
+static thread_local ShnThreadCtx t_thread_ctx;
+shn_ctx* shn_thread_ctx(shn_ctx* p) {
+  if (!p) return nullptr;
+  static const bool no_fork = getenv("SHN_GRAPH_FORK") && getenv("SHN_GRAPH_FORK")[0] == '0';
+  if (no_fork) return p;
+  ShnThreadCtx& t = t_thread_ctx;
+  if (t.c && t.parent == p) return t.c;
+  if (t.c) { shn_ctx_destroy(t.c); t.c = nullptr; }
+  if (shn_ctx_fork(p, &t.c)) { t.c = nullptr; return p; }
+  t.parent = p;
+  return t.c;
+}
+
 extern "C" int shn_ctx_sync(shn_ctx* c) {
   if (!c) return shn_fail(SHN_ERR_ARG, "ctx is NULL");
   HIP_TRY(hipSetDevice(c->device));

@@ -1825,9 +1825,11 @@ extern "C" int shn_ext_seed_info(shn_ctx* ctx, const shn_ext* e, const uint32_t*
   return SHN_OK;
 }
 
-extern "C" int shn_ext_emit(shn_ctx* ctx, const shn_ext* e, const uint32_t* ranks, uint64_t n_sel, const uint64_t* offsets,
-                            uint8_t* bases_out) {
-  if (!ctx || !e || (n_sel && (!ranks || !offsets || !bases_out))) return shn_fail(SHN_ERR_ARG, "shn_ext_emit: NULL argument");
+// bases_out: the contigs' text on the host; dev_out (instead): the text stays on the device (total + 64 bytes, the tail zeroed; the
+// caller frees it with shn_dev_free) -- the GPU contig stage reads it there
+static int ext_emit_impl(shn_ctx* ctx, const shn_ext* e, const uint32_t* ranks, uint64_t n_sel, const uint64_t* offsets, uint8_t* bases_out, uint8_t** dev_out) {
+  if (!ctx || !e || (n_sel && (!ranks || !offsets || (!bases_out && !dev_out)))) return shn_fail(SHN_ERR_ARG, "shn_ext_emit: NULL argument");
+  if (dev_out) *dev_out = nullptr;
   if (!n_sel) return SHN_OK;
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
@@ -1846,7 +1848,7 @@ extern "C" int shn_ext_emit(shn_ctx* ctx, const shn_ext* e, const uint32_t* rank
   int32_t* d_sel; uint64_t* d_off; uint8_t* d_out; unsigned long long* d_cnt; uint32_t* d_ranks;
   HIP_TRY(shn_dev_malloc(&d_sel, (ns + 1) * 4));
   HIP_TRY(shn_dev_malloc(&d_off, (n_sel + 1) * 8));
-  HIP_TRY(shn_dev_malloc(&d_out, total + 1));
+  HIP_TRY(shn_dev_malloc(&d_out, total + 64));
   HIP_TRY(shn_dev_malloc(&d_cnt, 32));
   HIP_TRY(shn_dev_malloc(&d_ranks, (n_sel + 1) * 4));
   HIP_TRY(hipMemsetAsync(d_sel, 0xFF, (ns + 1) * 4, s));                    // -1: not selected
@@ -1854,23 +1856,42 @@ extern "C" int shn_ext_emit(shn_ctx* ctx, const shn_ext* e, const uint32_t* rank
   HIP_TRY(hipMemcpyAsync(d_off, offsets, (n_sel + 1) * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemsetAsync(d_cnt, 0, 32, s));
   hipLaunchKernelGGL(ext_select_kernel, dim3((uint32_t)cdiv(n_sel, 256)), dim3(256), 0, s, d_ranks, n_sel, d_sel, d_cnt + 2);
-  HIP_TRY(hipMemsetAsync(d_out, 0, total + 1, s));
+  HIP_TRY(hipMemsetAsync(d_out, 0, total + 64, s));
   {
     TimerRegion tk(ctx, T_EXT_EMIT);
     hipLaunchKernelGGL(ext_emit_claims_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(2 * e->n, 256), 4096)), dim3(256), 0, s, e->d_claim, 2 * e->n, d_sel, ns,
                        e->d_nr, e->d_nl, e->table->d_keys, e->k, d_off, d_out, d_cnt);
   }
   unsigned long long cnt[3] = {0, 0, 0};
-  HIP_TRY(hipMemcpyAsync(bases_out, d_out, total, hipMemcpyDeviceToHost, s));
+  if (bases_out) HIP_TRY(hipMemcpyAsync(bases_out, d_out, total, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(cnt, d_cnt, 24, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  shn_dev_free(d_sel); shn_dev_free(d_off); shn_dev_free(d_out); shn_dev_free(d_cnt); shn_dev_free(d_ranks);
+  shn_dev_free(d_sel); shn_dev_free(d_off); shn_dev_free(d_cnt); shn_dev_free(d_ranks);
+  struct FreeOut { uint8_t* p; ~FreeOut() { if (p) shn_dev_free(p); } } free_out{d_out};
   HIP_TRY(hipGetLastError());
   if (cnt[2]) return shn_fail(SHN_ERR_ARG, "shn_ext_emit: a walk is selected twice");
   // every base of every selected contig must have been written exactly once
   if (cnt[1] || cnt[0] != expect)
     return shn_fail(SHN_ERR_INTERNAL, "shn_ext_emit: claims do not match the recorded walks (k1-mers written " + std::to_string(cnt[0]) +
                     ", expected " + std::to_string(expect) + ", stray claims " + std::to_string(cnt[1]) + ")");
+  if (dev_out) { *dev_out = d_out; free_out.p = nullptr; }
+  return SHN_OK;
+}
+extern "C" int shn_ext_emit(shn_ctx* ctx, const shn_ext* e, const uint32_t* ranks, uint64_t n_sel, const uint64_t* offsets,
+                            uint8_t* bases_out) {
+  if (n_sel && !bases_out) return shn_fail(SHN_ERR_ARG, "shn_ext_emit: NULL argument");
+  return ext_emit_impl(ctx, e, ranks, n_sel, offsets, bases_out, nullptr);
+}
+// the same with the text left on the device (shn_devtext: what shn_contig_stage_device reads; shn_devtext_segments fetches pieces)
+extern "C" int shn_ext_emit_device(shn_ctx* ctx, const shn_ext* e, const uint32_t* ranks, uint64_t n_sel, const uint64_t* offsets, shn_devtext** out) {
+  if (!out) return shn_fail(SHN_ERR_ARG, "shn_ext_emit_device: NULL argument");
+  *out = nullptr;
+  uint8_t* d = nullptr;
+  int rc = ext_emit_impl(ctx, e, ranks, n_sel, offsets, nullptr, &d);
+  if (rc) return rc;
+  shn_devtext* t = new shn_devtext();
+  t->ctx = ctx; t->d = d; t->n = n_sel ? offsets[n_sel] : 0;
+  *out = t;
   return SHN_OK;
 }
 

@@ -74,6 +74,16 @@ struct RStr {
   const char* end() const { return p + n; }
 };
 
+// ascending order for a list that is usually ascending already or two ascending runs one after the other (a bridging step hands a
+// new node the reads of the old one twice, each time in order): a merge instead of a sort
+template <class V> static void sort_runs(V& v) {
+  auto b = v.begin(), e = v.end();
+  auto p = std::is_sorted_until(b, e);
+  if (p == e) return;
+  if (std::is_sorted(p, e)) { std::inplace_merge(b, p, e); return; }
+  std::sort(b, e);
+}
+
 // several partitions run on host threads at once; every thread has a context / stream of its own (ThreadCtx below), the
 // calls its GPU sections make use per-call or per-context buffers only, so the sections overlap on the device
 
@@ -105,24 +115,7 @@ struct BudgetGuard {
   ~BudgetGuard() { g_host_threads.release(n); }
 };
 
-// a context of its own (same device, own stream) for every graph thread: their GPU sections overlap instead of taking turns
-struct ThreadCtx {
-  shn_ctx* c = nullptr; const shn_ctx* parent = nullptr;
-  shn_ctx* get(shn_ctx* p) {
-    if (!p) return nullptr;
-    // SHN_GRAPH_FORK=0 (with SHN_GRAPH_THREADS=1): everything on the caller's context and stream -- rocprofv3's kernel trace
-    // aborts (stream_stack.cpp) when threads it has not seen create streams; tools/profile_r02.sh profiles that way
-    static const bool no_fork = getenv("SHN_GRAPH_FORK") && getenv("SHN_GRAPH_FORK")[0] == '0';
-    if (no_fork) return p;
-    if (c && parent == p) return c;
-    if (c) { shn_ctx_destroy(c); c = nullptr; }
-    if (shn_ctx_fork(p, &c)) { c = nullptr; return p; }
-    parent = p;
-    return c;
-  }
-  ~ThreadCtx() { if (c) shn_ctx_destroy(c); }
-};
-static thread_local ThreadCtx t_ctx;
+// a context of its own (same device, own stream) for every graph thread: shn_thread_ctx (core.hip)
 
 // eight 2-bit codes (one per byte, all < 4) -> their letters: 'A' + 2 b0 + 6 b1 + 11 (b0 & b1) = A, C, G, T (no carry leaves a byte)
 static inline uint64_t codes8_to_ascii(uint64_t x) {
@@ -400,7 +393,7 @@ struct Graph {
     // vector + bisection: a tree node per read was most of bridge_all for the X-nodes of a highly expressed transcript)
     const double tcs0 = laps ? tnow() : 0.0;
     std::vector<RI> out(nreads[s]);
-    if (!std::is_sorted(out.begin(), out.end())) std::sort(out.begin(), out.end());
+    sort_runs(out);
     out.erase(std::unique(out.begin(), out.end()), out.end());
     const size_t n_src = out.size();
     out.reserve(n_src + nreads[d].size());
@@ -624,7 +617,7 @@ struct Graph {
       const RStr rb = rstr(r);
       if ((int)rb.size() > i + lb && rb.compare(i, lb, nb) == 0) rs.push_back(x);
     }
-    if (!std::is_sorted(rs.begin(), rs.end())) std::sort(rs.begin(), rs.end());
+    sort_runs(rs);
     rs.erase(std::unique(rs.begin(), rs.end()), rs.end());
     // the characters the neighbours put in front of / behind the node (the same for every read of the list)
     bool in_ch[256] = {false}, out_ch[256] = {false};
@@ -980,7 +973,7 @@ struct Graph {
           if (!ensure_dreads(&d_reads)) { attrs_rc = shn_fail(SHN_ERR_INTERNAL, "find_known_paths: the distinct reads could not be gathered again"); return; }
           tk1 = nowk();
         }
-        static const bool kp_dev_search = !(getenv("SHN_GRAPH_KP_SEARCH") && getenv("SHN_GRAPH_KP_SEARCH")[0] == '0');
+        const bool kp_dev_search = !(getenv("SHN_GRAPH_KP_SEARCH") && getenv("SHN_GRAPH_KP_SEARCH")[0] == '0');
         const int rcs = kp_dev_search
             ? shn_known_paths_search(ctx, d_reads, K, (const uint8_t*)nb.data(), noff.data(), order.size(), eoff.data(), edst.data(), eov.data(), st.data(),
                                      nd.data(), no.data(), precs.data(), precs.size(), &precs_used)
@@ -1422,7 +1415,7 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
     return shn_fail(SHN_ERR_ARG, "shn_mbgraph_run: NULL argument");
   struct Running { Running() { g_partitions_running.fetch_add(1); } ~Running() { g_partitions_running.fetch_sub(1); } } running;
   Graph g;
-  g.ctx = t_ctx.get(ctx);
+  g.ctx = shn_thread_ctx(ctx);
   g.K = K;
   const uint64_t read_len0 = !n_reads ? 0 : host_a ? src_a->fixed_len : (uint64_t)(r1_off[1] - r1_off[0]);
   g.L = n_reads ? (int)read_len0 : -1;

@@ -353,6 +353,16 @@ extern "C" int shn_sflow_text(const shn_sflow* s, uint32_t g, uint8_t* out) {
 // graphs[g]: the multibridged graph of partition g (shn_mbgraph_run*); snames[g]: "<sample>_<partition>" (NUL-terminated).
 // Text g = the reconstructed FASTA of partition g: the records of its components in order (component c uses the LP problem
 // ids (c << 20) + call number), then its single nodes (single_nodes_to_fasta, algorithm_SF.py:74-88).
+extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uint32_t n_graphs, const char* const* snames, uint64_t seed, shn_sflow** out);
+static thread_local bool t_sflow_beside = false;     // this thread is one of several inside shn_sparse_flow: no helper threads of its own for small inputs
+// One of several calls made by host threads at the same time (a partition's components right behind its graph stage, while other
+// partitions are still at theirs): the LP batches run on the calling thread's own stream and workspaces (shn_thread_ctx).  The
+// answers are those of one call over all graphs: a component's random costs depend on its index inside its own graph only.
+extern "C" int shn_sparse_flow_thread(shn_ctx* ctx, const shn_graph* const* graphs, uint32_t n_graphs, const char* const* snames, uint64_t seed, shn_sflow** out) {
+  if (!ctx) return shn_fail(SHN_ERR_ARG, "shn_sparse_flow_thread: ctx is NULL");
+  struct Flag { Flag() { t_sflow_beside = true; } ~Flag() { t_sflow_beside = false; } } flag;
+  return shn_sparse_flow(shn_thread_ctx(ctx), graphs, n_graphs, snames, seed, out);
+}
 extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uint32_t n_graphs, const char* const* snames, uint64_t seed, shn_sflow** out) {
   if (!ctx || !out || (n_graphs && (!graphs || !snames))) return shn_fail(SHN_ERR_ARG, "shn_sparse_flow: NULL argument");
   *out = nullptr;
@@ -420,7 +430,7 @@ extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uin
     c.all.push_back(c.E);
     c.pfn.resize(c.nodes.size());
   };
-  const unsigned nt = comps.size() < 256 ? 1 : std::max(1u, std::min(32u, (unsigned)shn_host_cpus()));
+  const unsigned nt = comps.size() < (t_sflow_beside ? 4096u : 256u) ? 1 : std::max(1u, std::min(32u, (unsigned)shn_host_cpus()));
   auto parallel = [&](auto&& fn) {
     if (nt <= 1) { for (size_t k = 0; k < comps.size(); k++) fn(k); return; }
     std::atomic<size_t> next{0};

@@ -149,6 +149,15 @@ class Extension(object):
         _lib.check(_lib.lib().shn_ext_emit(self.ctx.h, self.h, ranks.ctypes.data, len(ranks), offs.ctypes.data, buf.ctypes.data))
         return buf[:int(offs[-1])], offs
 
+    def emit_device(self, ranks, lengths):
+        """(DevText, offsets uint64[n+1]): the contigs of the selected walks, their text left on the device (shn_ext_emit_device)."""
+        ranks = np.ascontiguousarray(ranks, dtype=np.uint32)
+        offs = np.zeros(len(ranks) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum(lengths, dtype=np.uint64)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().shn_ext_emit_device(self.ctx.h, self.h, ranks.ctypes.data, len(ranks), offs.ctypes.data, C.byref(h)))
+        return DevText(self.ctx, h), offs
+
     def emit(self, ranks, lengths):
         buf, offs = self.emit_raw(ranks, lengths)
         return split_strings(buf, offs)
@@ -220,17 +229,52 @@ def split_strings(buf, offs):
     return [s[o[i]:o[i + 1]] for i in range(len(o) - 1)]
 
 
+class DevText(object):
+    """text left on the device (shn_devtext): the candidate contigs between shn_ext_emit_device and shn_contig_stage_device"""
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def segments(self, offs, idx):
+        """(bytes uint8[sum of lengths], offsets uint64[len(idx)+1]) of the pieces idx of the text cut at offs"""
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        lens = (offs[idx + 1] - offs[idx]) if len(idx) else np.zeros(0, np.uint64)
+        out_off = np.zeros(len(idx) + 1, dtype=np.uint64)
+        out_off[1:] = np.cumsum(lens, dtype=np.uint64)
+        out = np.empty(max(1, int(out_off[-1])), dtype=np.uint8)
+        if len(idx):
+            _lib.check(_lib.lib().shn_devtext_segments(self.ctx.h, self.h, offs.ctypes.data, len(offs), idx.ctypes.data, len(idx), out.ctypes.data))
+        return out[:int(out_off[-1])], out_off
+
+    def close(self):
+        if self.h:
+            _lib.lib().shn_devtext_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def contig_stage_gpu(ctx, buf, offs, k1, r=15, f=0.5):
     """duplicate_check + contig graph of candidates in seed order with the bulk of the work on the GPU (shn_contig_stage).
-    buf/offs: ASCII bases + offsets.  Returns (acc, best, coff, cnb, cw) as numpy arrays (see contig_stage)."""
+    buf/offs: ASCII bases (a host array, or a DevText: shn_contig_stage_device) + offsets.  Returns (acc, best, coff, cnb, cw) as
+    numpy arrays (see contig_stage)."""
     n = len(offs) - 1
     acc = np.zeros(max(n, 1), dtype=np.int32)
     best = np.zeros(max(n, 1), dtype=np.int32)
     h = C.c_void_p()
-    buf = np.ascontiguousarray(buf, dtype=np.uint8)
     offs = np.ascontiguousarray(offs, dtype=np.uint64)
-    _lib.check(_lib.lib().shn_contig_stage(ctx.h, buf.ctypes.data, offs.ctypes.data, n, int(k1), int(r), float(f), acc.ctypes.data,
-                                           best.ctypes.data, C.byref(h)))
+    if isinstance(buf, DevText):
+        _lib.check(_lib.lib().shn_contig_stage_device(ctx.h, buf.h, offs.ctypes.data, n, int(k1), int(r), float(f), acc.ctypes.data,
+                                                      best.ctypes.data, C.byref(h)))
+    else:
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        _lib.check(_lib.lib().shn_contig_stage(ctx.h, buf.ctypes.data, offs.ctypes.data, n, int(k1), int(r), float(f), acc.ctypes.data,
+                                               best.ctypes.data, C.byref(h)))
     try:
         n_acc, n_conn = C.c_uint64(0), C.c_uint64(0)
         _lib.check(_lib.lib().shn_cgraph_sizes(h, C.byref(n_acc), C.byref(n_conn)))
@@ -520,6 +564,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     else:
         # non-void walks long enough for the accept filter's length clause, in seed order (compacted on the GPU)
         live, nr, nl, tw = ext.live_stats(min_length - k1)
+        lap("ext.filter.stats")
         if gpu_contigs or gpu_sharded:
             keep_r, keep_l = accept_filter(live, nr, nl, tw, k1, min_length, min_weight, arrays=True)
             keep = None
@@ -531,9 +576,17 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     contig_raw = None
     conn = None
     sharded_contigs = False
-    if gpu_contigs or gpu_sharded:
+    dev_text = None
+    if gpu_contigs and not gpu_sharded and len(keep_r) and os.environ.get("SHN_EXT_EMIT_DEVICE", "1") != "0":
+        # one rank: the candidates' text never leaves the device (0.3 GB at BASELINE configs[2], once down and once up before);
+        # the accepted contigs are fetched afterwards
+        dev_text, offs = ext.emit_device(keep_r, keep_l)
+        buf = dev_text
+        lap("ext.emit")
+    elif gpu_contigs or gpu_sharded:
         buf, offs = ext.emit_raw(keep_r, keep_l, reuse=True) if len(keep_r) else (np.zeros(0, np.uint8), np.zeros(1, np.uint64))
         lap("ext.emit")
+    if gpu_contigs or gpu_sharded:
         if gpu_sharded:
             # every rank's candidates -> the same merged list everywhere, in the order of the reference's seed loop
             # (weight descending, seed k1-mer ascending; a seed lies in exactly one shard, so the keys are distinct)
@@ -553,9 +606,14 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
             lap("ext.merge")
         acc, _best, coff, cnb, cw = contig_stage_gpu(ctx, buf, offs, k1, r, f)
         csr = (coff, cnb, cw)
+        ai = np.nonzero(acc)[0]
+        if dev_text is not None:
+            # the accepted contigs only, one after the other: from here on they are "the candidates", all of them accepted
+            buf, offs = dev_text.segments(offs, ai)
+            dev_text.close()
+            ai = np.arange(len(ai), dtype=np.int64)
         buf = np.ascontiguousarray(buf)
         raw = memoryview(buf)                              # (only the accepted tenth is ever turned into strings, slice by slice)
-        ai = np.nonzero(acc)[0]
         n_before = len(contigs)
         contigs += [str(raw[a:b], "ascii") for a, b in zip(offs[ai].tolist(), offs[ai + 1].tolist())]
         del raw

@@ -151,15 +151,17 @@ def graph_from_tables(singles, comps):
     return GraphHandle(h)
 
 
-def sparse_flow_native(ctx, graphs, snames, seed, raw=False):
+def sparse_flow_native(ctx, graphs, snames, seed, raw=False, threaded=False):
     """The native sparse-flow stage (shn_sparse_flow) over the graphs of several partitions: [reconstructed FASTA text]
-    (raw: as uint8 arrays, undecoded)."""
+    (raw: as uint8 arrays, undecoded).  threaded: one of several calls running at once, on the calling thread's own stream
+    (shn_sparse_flow_thread)."""
     if not graphs:
         return []
     arr = (C.c_void_p * len(graphs))(*[g.h for g in graphs])
     names = (C.c_char_p * len(graphs))(*[s.encode() for s in snames])
     h = C.c_void_p()
-    _lib.check(_lib.lib().shn_sparse_flow(ctx.h, arr, len(graphs), names, C.c_uint64(int(seed)), C.byref(h)))
+    fn = _lib.lib().shn_sparse_flow_thread if threaded else _lib.lib().shn_sparse_flow
+    _lib.check(fn(ctx.h, arr, len(graphs), names, C.c_uint64(int(seed)), C.byref(h)))
     try:
         out = []
         for i in range(len(graphs)):

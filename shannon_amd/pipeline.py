@@ -154,9 +154,40 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
         rows_mode = (unitigs is not None and d1 is not None and _matrix(store.r1) and (not paired or _matrix(store.r2)) and
                      (not paired or d2 is not None) and os.environ.get("SHN_GRAPH_ROWS", "1") != "0" and not ss)
 
+        # the sparse flow of a partition right behind its graph, on the same thread (one algorithm_SF.py process per component in
+        # the reference, run_MB_SF_fn.py:242-250): the small partitions are through theirs while the largest is still at its graph
+        sflow_beside = (native_graph and len(names) > 1 and graph_threads > 1 and os.environ.get("SHN_SFLOW_NATIVE", "1") != "0" and
+                        os.environ.get("SHN_SFLOW_BESIDE", "1") != "0")
+
+        # (the few partitions with the most reads -- their graphs take longest -- each run their own sparse flow; all the others go
+        # through ONE call, made by the thread that finishes the last of their graphs: a call's cost is its dependent LP rounds, and
+        # a hundred small calls keep sixteen threads waiting on a hundred times as many tiny batches)
+        import threading
+        n_routed = {nm: len(part["routes"][nm]) for nm in names}
+        big_cut = max(n_routed.values()) // 4 if names else 0
+        big = set(nm for nm in names if n_routed[nm] >= max(1, big_cut)) if sflow_beside else set()
+        small_lock, small_done, small_recs = threading.Lock(), [0], {}
+        n_small = len(names) - len(big)
+
         def one_partition(name):
             """multibridged graph of one partition (multibridging.main for `name`); returns its record + timings"""
             rec, tt = _one_partition(name)
+            if sflow_beside and getattr(rec, "graph", None) is not None:
+                t1 = time.time()
+                if name in big:
+                    rec.fasta_raw = mbgraph_native.sparse_flow_native(ctx_b, [rec.graph], ["%s_%s" % (sample, name)], seed, raw=True, threaded=True)[0]
+                else:
+                    with small_lock:
+                        small_recs[name] = rec
+                        small_done[0] += 1
+                        last = small_done[0] == n_small
+                    if last:
+                        order_s = [nm for nm in names if nm in small_recs]
+                        txts = mbgraph_native.sparse_flow_native(ctx_b, [small_recs[nm].graph for nm in order_s], ["%s_%s" % (sample, nm) for nm in order_s],
+                                                                 seed, raw=True, threaded=True)
+                        for nm, txt in zip(order_s, txts):
+                            small_recs[nm].fasta_raw = txt
+                tt["sparse flow"] = time.time() - t1
             if timeline is not None:
                 timeline[name] = (tt.pop("_t0") - t_graph, time.time() - t_graph, dict(tt), len(part["routes"][name]))
             else:
@@ -289,10 +320,13 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
         if native_graph and os.environ.get("SHN_SFLOW_NATIVE", "1") != "0":
             # all components of all partitions through the native sparse-flow stage (shn_sparse_flow) in one call; the graphs
             # stay native objects (exported to Python tables only if somebody asks a PartitionRecord for them)
-            texts = mbgraph_native.sparse_flow_native(ctx_b, [R.partitions[nm].graph for nm in names], ["%s_%s" % (sample, nm) for nm in names], seed,
-                                                      raw=True)
-            for name, txt in zip(names, texts):
-                R.partitions[name].fasta_raw = txt                     # decoded when somebody reads ["reconstructed_fasta"]
+            if sflow_beside and all(getattr(R.partitions[nm], "fasta_raw", None) is not None for nm in names):
+                texts = [R.partitions[nm].fasta_raw for nm in names]
+            else:
+                texts = mbgraph_native.sparse_flow_native(ctx_b, [R.partitions[nm].graph for nm in names], ["%s_%s" % (sample, nm) for nm in names], seed,
+                                                          raw=True)
+                for name, txt in zip(names, texts):
+                    R.partitions[name].fasta_raw = txt                 # decoded when somebody reads ["reconstructed_fasta"]
             tick("sparse flow", t0)
             t0 = time.time()
             R._texts = [single_text] + texts                           # all_reconstructed.fasta: single contigs, then the partitions
