@@ -30,6 +30,23 @@ struct ShnWs {
   int get(size_t bytes, void** out);
 };
 
+// grow-only pinned host buffer (staging of many small pieces as ONE transfer)
+struct ShnPinned {
+  void* p = nullptr; size_t cap = 0;
+  int get(size_t bytes, void** out) {
+    if (bytes > cap) {
+      if (p) (void)hipHostFree(p);
+      p = nullptr; cap = 0;
+      const size_t want = bytes + bytes / 2 + 4096;
+      if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return shn_fail(SHN_ERR_NOMEM, "hipHostMalloc (staging buffer)"); }
+      cap = want;
+    }
+    *out = p;
+    return 0;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 struct shn_ctx {
   int device;
   hipStream_t stream;
@@ -44,6 +61,7 @@ struct shn_ctx {
   ShnWs cws[12];           // per-context workspaces of the calls several host threads make at the same time, each on its own
                            // context / stream (the graph threads' seed scans): [0] scan block sums, [1] [2] seed-scan counts / offsets,
                            // [4..11] the LP batches of the sparse flow (two batches may be in flight on two contexts)
+  ShnPinned hpin[2];       // pinned staging of the LP batches: [0] what goes up, [1] what comes back
   int lp_rule;             // SHN_LP_RULE_CENTER (default) / SHN_LP_RULE_VERTEX (SHN_LP_RULE=vertex in the environment, shn_lp_set_rule)
   uint64_t lp_stats[8];    // shn_lp_stats
 };

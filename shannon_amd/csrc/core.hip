@@ -119,6 +119,7 @@ extern "C" void shn_ctx_destroy(shn_ctx* c) {
     for (auto& p : c->pending[i]) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
   if (c->owns_stream && c->stream) hipStreamDestroy(c->stream);
   for (auto& w : c->cws) if (w.p) { hipFree(w.p); w.p = nullptr; w.cap = 0; }
+  for (auto& h : c->hpin) h.release();
   if (!c->owns_stream) shn_dev_trim();         // (a forked context goes with its host thread, in the middle of a run)
   delete c;
 }
@@ -154,7 +155,7 @@ shn_ctx* shn_thread_ctx(shn_ctx* p) {
   static const bool no_fork = getenv("SHN_GRAPH_FORK") && getenv("SHN_GRAPH_FORK")[0] == '0';
   if (no_fork) return p;
   ShnThreadCtx& t = t_thread_ctx;
-  if (t.c && t.parent == p) return t.c;
+  if (t.c && t.parent == p) { t.c->lp_rule = p->lp_rule; return t.c; }      // (the rule may have been set on the parent since the fork)
   if (t.c) { shn_ctx_destroy(t.c); t.c = nullptr; }
   if (shn_ctx_fork(p, &t.c)) { t.c = nullptr; return p; }
   t.parent = p;

@@ -18,6 +18,7 @@
 // SHN_LP_RULE=vertex (or shn_lp_set_rule) keeps the vertex as the answer (the rule of rounds 1-2).
 // No MFMA: no dense contraction anywhere.
 #include "common.h"
+#include <cstring>
 
 #define LBLK 64
 #define LP_INF (1LL << 62)
@@ -456,29 +457,38 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
   TimerRegion treg(ctx, T_LP);
   // per-context workspaces: two batches may be in flight on two contexts (the deferred back half of a step beside the next
   // step's front half), and shn_ws_release_idle never touches a context's own slots
-  void *pp, *pb, *pin, *pm, *pws, *pout, *pws2, *pst;
+  // ONE image of everything that goes up (problems, block lists, a / b, masks) in pinned memory and one transfer of it, one
+  // transfer back (flows + the centre kernel's statistics): a batch used to be seven small pageable copies up and two down, and
+  // the 110 dependent batches of a step are mostly the latency of their copies (0.54 ms per batch on the stream, 0.1 of it kernels)
+  void *pup, *pws, *pdown, *pws2;
   int rc;
-  if ((rc = ctx->cws[4].get(probs.size() * sizeof(LpProblem), &pp)) || (rc = ctx->cws[5].get((bprob.size() + lprob.size() + cprob.size()) * 8 + 16, &pb)) ||
-      (rc = ctx->cws[6].get(in_off * 8 + 16, &pin)) || (rc = ctx->cws[7].get(mask_off + 16, &pm)) ||
-      (rc = ctx->cws[8].get(ws_off * 8 + 16, &pws)) || (rc = ctx->cws[9].get(out_off * 8 + 16, &pout)) ||
-      (rc = ctx->cws[10].get(ws2_off * 8 + 16, &pws2)) || (rc = ctx->cws[11].get(stat_off * 16 + 16, &pst))) return rc;
-  uint32_t* d_bprob = (uint32_t*)pb;
+  auto al = [](uint64_t x) { return (x + 15) & ~15ULL; };
+  const uint64_t o_probs = 0, o_blocks = al(o_probs + probs.size() * sizeof(LpProblem)),
+                 o_in = al(o_blocks + (bprob.size() + lprob.size() + cprob.size()) * 8), o_mask = al(o_in + in_off * 8), up_bytes = al(o_mask + mask_off) + 16;
+  const uint64_t o_out = 0, o_stat = al(out_off * 8), down_bytes = o_stat + stat_off * 16 + 16;
+  void *h_up, *h_down;
+  if ((rc = ctx->cws[4].get(up_bytes, &pup)) || (rc = ctx->cws[8].get(ws_off * 8 + 16, &pws)) || (rc = ctx->cws[9].get(down_bytes, &pdown)) ||
+      (rc = ctx->cws[10].get(ws2_off * 8 + 16, &pws2)) || (rc = ctx->hpin[0].get(up_bytes, &h_up)) || (rc = ctx->hpin[1].get(down_bytes, &h_down))) return rc;
+  uint8_t* hu = (uint8_t*)h_up;
+  memcpy(hu + o_probs, probs.data(), probs.size() * sizeof(LpProblem));
+  uint32_t* hb = (uint32_t*)(hu + o_blocks);
+  auto put = [&](const std::vector<uint32_t>& v) { if (!v.empty()) memcpy(hb, v.data(), v.size() * 4); hb += v.size(); };
+  put(bprob); put(bfirst); put(cprob); put(cfirst); put(lprob); put(lfirst);
+  memcpy(hu + o_in, ab, in_off * 8);
+  memcpy(hu + o_mask, mask, mask_off);
+  uint8_t* du = (uint8_t*)pup;
+  void* pp = du + o_probs;
+  uint32_t* d_bprob = (uint32_t*)(du + o_blocks);
   uint32_t* d_bfirst = d_bprob + bprob.size();
   uint32_t* d_cprob = d_bfirst + bprob.size();
   uint32_t* d_cfirst = d_cprob + cprob.size();
   uint32_t* d_lprob = d_cfirst + cprob.size();
   uint32_t* d_lfirst = d_lprob + lprob.size();
-  HIP_TRY(hipMemcpyAsync(pp, probs.data(), probs.size() * sizeof(LpProblem), hipMemcpyHostToDevice, s));
-  if (!bprob.empty()) {
-    HIP_TRY(hipMemcpyAsync(d_bprob, bprob.data(), bprob.size() * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_bfirst, bfirst.data(), bfirst.size() * 4, hipMemcpyHostToDevice, s));
-  }
-  if (!lprob.empty()) {
-    HIP_TRY(hipMemcpyAsync(d_lprob, lprob.data(), lprob.size() * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_lfirst, lfirst.data(), lfirst.size() * 4, hipMemcpyHostToDevice, s));
-  }
-  HIP_TRY(hipMemcpyAsync(pin, ab, in_off * 8, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(pm, mask, mask_off, hipMemcpyHostToDevice, s));
+  void* pin = du + o_in;
+  void* pm = du + o_mask;
+  void* pout = (uint8_t*)pdown + o_out;
+  void* pst = (uint8_t*)pdown + o_stat;
+  HIP_TRY(hipMemcpyAsync(pup, h_up, up_bytes - 16, hipMemcpyHostToDevice, s));
   if (!lprob.empty()) {
     if (lds_words * 8 > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)lp_trials_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LP_LDS_WORDS * 8)));
     hipLaunchKernelGGL(lp_trials_kernel<true>, dim3((uint32_t)lprob.size()), dim3(LBLK), lds_words * 8, s, (const LpProblem*)pp, d_lprob, d_lfirst,
@@ -487,19 +497,18 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
   if (!bprob.empty())
     hipLaunchKernelGGL(lp_trials_kernel<false>, dim3((uint32_t)bprob.size()), dim3(LBLK), 0, s, (const LpProblem*)pp, d_bprob, d_bfirst,
                        (const double*)pin, (const uint8_t*)pm, seed, (uint64_t*)pws, (double*)pout);
-  std::vector<uint32_t> stat;
-  if (center && !cprob.empty()) {
-    HIP_TRY(hipMemcpyAsync(d_cprob, cprob.data(), cprob.size() * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d_cfirst, cfirst.data(), cfirst.size() * 4, hipMemcpyHostToDevice, s));
+  const bool with_stat = center && !cprob.empty();
+  if (with_stat) {
     HIP_TRY(hipMemsetAsync(pst, 0, stat_off * 16, s));                     // (trials the centre kernel does not visit: nothing centred)
     hipLaunchKernelGGL(lp_center_kernel, dim3((uint32_t)cprob.size()), dim3(LBLK), 0, s, (const LpProblem*)pp, d_cprob, d_cfirst,
                        (const uint8_t*)pm, (uint64_t*)pws, (uint64_t*)pws2, (double*)pout, (uint32_t*)pst);
-    stat.resize(4 * stat_off);
-    HIP_TRY(hipMemcpyAsync(stat.data(), pst, stat.size() * 4, hipMemcpyDeviceToHost, s));
   }
-  HIP_TRY(hipMemcpyAsync(flows_out, pout, out_off * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h_down, pdown, with_stat ? o_stat + stat_off * 16 : out_off * 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipGetLastError());
+  memcpy(flows_out, (const uint8_t*)h_down + o_out, out_off * 8);
+  std::vector<uint32_t> stat;
+  if (with_stat) { stat.resize(4 * stat_off); memcpy(stat.data(), (const uint8_t*)h_down + o_stat, stat.size() * 4); }
   // census (bench.py: lp_calls / lp_degenerate): a problem is degenerate when the optimal face of one of its trials was not a point
   ctx->lp_stats[0] += n_problems;
   ctx->lp_stats[2] += stat_off;

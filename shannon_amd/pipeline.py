@@ -47,6 +47,19 @@ class PartitionRecord(dict):
         raise KeyError(key)
 
 
+_POOLS = {}
+
+
+def _graph_pool(n_threads):
+    """the host threads of the graph stage, kept from call to call: every thread owns a stream and device workspaces of its own
+    (shn_thread_ctx) that go with it -- a fresh pool per step created and freed them sixteen times a step"""
+    from concurrent.futures import ThreadPoolExecutor
+    pool = _POOLS.get(n_threads)
+    if pool is None:
+        pool = _POOLS[n_threads] = ThreadPoolExecutor(max_workers=n_threads, thread_name_prefix="shn-graph")
+    return pool
+
+
 def n_kmer_nodes(rows, K):
     """#distinct K-mers among the k1-mer rows = len(Node.nodes) after loading (multibridging.py:383)."""
     s = set()
@@ -284,17 +297,22 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
             if native_graph and len(names) > 1 and graph_threads > 1:
                 # partitions are independent (one multibridging process each in the reference, run_MB_SF_fn.py:219-253): the
                 # native stage releases the GIL, its GPU sections take turns
-                from concurrent.futures import ThreadPoolExecutor
-                with ThreadPoolExecutor(max_workers=min(len(names), graph_threads)) as pool:
-                    # the partitions with the most routed reads first (the reference's size-sorted job list, shannon.py:546-551)
-                    by_size = sorted(names, key=lambda nm: -len(part["routes"][nm]))
-                    futs = {nm: pool.submit(one_partition, nm) for nm in by_size}
-                    results = [futs[nm].result() for nm in names]
+                pool = _graph_pool(graph_threads)
+                # the partitions with the most routed reads first (the reference's size-sorted job list, shannon.py:546-551)
+                by_size = sorted(names, key=lambda nm: -len(part["routes"][nm]))
+                futs = {nm: pool.submit(one_partition, nm) for nm in by_size}
+                results = [futs[nm].result() for nm in names]
             else:
                 for nm in names:
                     results.append(one_partition(nm))
         except BaseException:
-            # a partition failed: the graphs already built go back now (device + host memory), not when the collector finds them
+            # a partition failed: nothing of this step may still run on the pool's threads when the inputs go away below
+            if futs:
+                import concurrent.futures as _cf
+                for f_ in futs.values():
+                    f_.cancel()
+                _cf.wait(list(futs.values()))
+            # ... and the graphs already built go back now (device + host memory), not when the collector finds them
             built = [f.result()[0] for f in futs.values() if f.done() and not f.cancelled() and f.exception() is None] or [r[0] for r in results]
             for rec in built:
                 g = getattr(rec, "graph", None)
