@@ -26,8 +26,22 @@
 #define SK_FLUSH_AT (SK_RCAP - (SK_CHECK + 1) * SK_BLK)   // a thread closes at most one record per base, and one at its read's end
 #define SK_TILE 32768                                  // records per block tile of the level-2 kernels
 #define SK_CAP 2048                                    // LDS hash slots of a bucket block (24 KB)
+#ifndef SK_SCAP
+#define SK_SCAP 2048                                   // ... of a block of the sorted-bucket kernel (layout 1)
+#endif
+#ifndef SK_STHREADS
+#define SK_STHREADS 256                                // threads of such a block
+#endif
+#ifndef SK_T1CAP
+#define SK_T1CAP 1024
+#endif
+#ifndef SK_T2THREADS
+#define SK_T2THREADS 256
+#endif
 #define SK_SPILL 1280                                  // distinct keys at which the table is written out (one more round adds <= 32 x 18)
 #define SK_EMPTY 0xFFFFFFFFFFFFFFFFULL
+#define SK_REGIONS 256                                 // stretches of the pair pool, a cursor each (sk_buckets_sorted_kernel)
+#define SK_RSTRIDE 16                                  // ... the cursors 128 bytes apart
 #define SK_RANK_MAX 512                                // buckets of at most this many distinct keys are ordered by counting, larger ones by a bitonic sort
 #define SK_MIN_K 20
 
@@ -52,6 +66,9 @@ __device__ __forceinline__ uint64_t sk_window(uint64_t hi, uint32_t lo, int j, i
   const uint64_t v = sh ? (hi << sh) | (((uint64_t)lo << 32) >> (64 - sh)) : hi;
   return v >> (64 - 2 * k);
 }
+
+// slot of a key in a bucket block's LDS table
+__device__ __forceinline__ uint32_t sk_slot_hash(uint64_t key) { return (uint32_t)shn_mix64(key ^ 0x9E3779B97F4A7C15ULL); }
 
 // ---------------------------------------------------------------- reads -> records
 // One thread per read, one base per step: the m-mer ending at the base (forward and reverse complement rolled along) and its
@@ -228,6 +245,7 @@ __global__ __launch_bounds__(SK_BLK) void sk_buckets_kernel(const SkRec* __restr
                                                             const uint32_t* __restrict__ off2, const uint32_t* __restrict__ hist2, int b2, int k, int w,
                                                             uint64_t* __restrict__ pool_keys, uint32_t* __restrict__ pool_counts,
                                                             unsigned long long* __restrict__ pool_cursor, uint64_t pool_cap) {
+  constexpr int FOLD_ROUNDS_ = 2;
   __shared__ unsigned long long tk[SK_CAP];
   __shared__ uint32_t tc[SK_CAP];
   __shared__ uint32_t lnew, lpos;
@@ -281,7 +299,7 @@ __global__ __launch_bounds__(SK_BLK) void sk_buckets_kernel(const SkRec* __restr
       uint32_t wgt = active ? 1u : 0u;
       bool elect = active;
 #pragma unroll
-      for (int round = 0; round < 2; round++) {
+      for (int round = 0; round < FOLD_ROUNDS_; round++) {
         const unsigned long long act = __ballot(elect);
         if (!act) break;
         const int leader = __ffsll((long long)act) - 1;
@@ -315,12 +333,13 @@ __global__ __launch_bounds__(SK_BLK) void sk_buckets_kernel(const SkRec* __restr
 // counted in passes over ranges of the key (the top 2, 4, ... bits): a pass holds complete counts of its range, and the passes'
 // sorted runs follow each other in key order.  The runs are reserved in a pool with one atomic per bucket and copied into bucket
 // order afterwards (sk_gather_kernel).
-template <bool CANON, int THREADS, int CAP>
+template <bool CANON, int THREADS, int CAP, int FOLD_ROUNDS_>
 __global__ __launch_bounds__(THREADS) void sk_buckets_sorted_kernel(const SkRec* __restrict__ recs, const uint64_t* __restrict__ off1,
                                                                     const uint32_t* __restrict__ off2, const uint32_t* __restrict__ hist2, int b2, int k, int w,
-                                                                    const uint32_t* __restrict__ list, uint32_t* __restrict__ defer,
+                                                                    const uint32_t* __restrict__ list, uint32_t* __restrict__ defer, int defer_cursor,
                                                                     uint64_t* __restrict__ pool_keys, uint32_t* __restrict__ pool_counts,
-                                                                    unsigned long long* __restrict__ cursors, uint64_t pool_cap,
+                                                                    unsigned long long* __restrict__ cursors, uint64_t region_cap,
+                                                                    unsigned long long* __restrict__ rcur,
                                                                     uint64_t* __restrict__ run_off, uint32_t* __restrict__ ndist) {
   extern __shared__ unsigned long long skb_lds[];
   unsigned long long* tk = skb_lds;                                      // [CAP]
@@ -363,7 +382,7 @@ __global__ __launch_bounds__(THREADS) void sk_buckets_sorted_kernel(const SkRec*
         uint32_t wgt = active ? 1u : 0u;
         bool elect = active;
 #pragma unroll
-        for (int round = 0; round < 2; round++) {
+        for (int round = 0; round < FOLD_ROUNDS_; round++) {
           const unsigned long long act = __ballot(elect);
           if (!act) break;
           const int leader = __ffsll((long long)act) - 1;
@@ -376,7 +395,7 @@ __global__ __launch_bounds__(THREADS) void sk_buckets_sorted_kernel(const SkRec*
           if (same) elect = false;
         }
         if (!active) continue;
-        uint32_t slot = (uint32_t)(shn_mix64(key ^ 0x9E3779B97F4A7C15ULL)) & (CAP - 1);
+        uint32_t slot = sk_slot_hash(key) & (CAP - 1);
         for (int probe = 0; probe < CAP; probe++) {
           const unsigned long long prev = atomicCAS(&tk[slot], SK_EMPTY, key);
           if (prev == SK_EMPTY) { atomicAdd(&lnew, 1u); atomicAdd(&tc[slot], wgt); break; }
@@ -449,7 +468,7 @@ __global__ __launch_bounds__(THREADS) void sk_buckets_sorted_kernel(const SkRec*
     }
     if (ok) break;
     if (defer) {                                                         // a block with a larger table does this bucket
-      if (tid == 0) { const unsigned long long at = atomicAdd(&cursors[2], 1ULL); defer[at] = b; ndist[b] = 0; run_off[b] = 0; }
+      if (tid == 0) { const unsigned long long at = atomicAdd(&cursors[defer_cursor], 1ULL); defer[at] = b; ndist[b] = 0; run_off[b] = 0; }
       return;
     }
     sbits += 2;
@@ -459,10 +478,14 @@ __global__ __launch_bounds__(THREADS) void sk_buckets_sorted_kernel(const SkRec*
     }
     __syncthreads();
   }
-  if (tid == 0) lbase = atomicAdd(&cursors[1], (unsigned long long)total);
+  // the run's place in the pool: the pool is SK_REGIONS stretches with a cursor each (bucket b uses stretch b mod SK_REGIONS).  One
+  // cursor for all meant four million returning atomics on one address per launch -- they are served one after the other where the
+  // address lives, and the kernel waited for them
+  const uint32_t reg = b & (SK_REGIONS - 1);
+  if (tid == 0) lbase = atomicAdd(&rcur[reg * SK_RSTRIDE], (unsigned long long)total);
   __syncthreads();
-  const unsigned long long base = lbase;
-  if (base + total > pool_cap) { if (tid == 0) { ndist[b] = 0; run_off[b] = 0; } return; }      // (the host sees the cursor and runs again with a larger pool)
+  const unsigned long long in_reg = lbase, base = (unsigned long long)reg * region_cap + in_reg;
+  if (in_reg + total > region_cap) { if (tid == 0) { ndist[b] = 0; run_off[b] = 0; } return; }   // (the host sees the cursors and runs again with a larger pool)
   if (tid == 0) { ndist[b] = total; run_off[b] = base; }
   if (sbits == 0) { output(base); return; }
   uint64_t at = base;
@@ -630,44 +653,68 @@ int shn_count_superkmers(shn_ctx* ctx, const std::vector<ReadsView>& views, uint
   bool sorted = !(getenv("SHN_COUNT_SK_LAYOUT") && atoi(getenv("SHN_COUNT_SK_LAYOUT")) == 0);
   if (sorted) {
     void* pr;
-    if ((rc = g_shn_ws[24].get(nbk * 16 + 64, &pr))) return rc;
+    if ((rc = g_shn_ws[24].get(nbk * 20 + 64, &pr))) return rc;
     uint64_t* d_run_off = (uint64_t*)pr;
     uint32_t* d_ndist = (uint32_t*)(d_run_off + nbk);
     uint32_t* d_defer = d_ndist + nbk;
-    constexpr int BIG_T = 1024, BIG_CAP = 8192;
-    const size_t lds_small = (size_t)SK_CAP * 12 + std::max<size_t>((size_t)SK_CAP * 2, (size_t)SK_RANK_MAX * 12), lds_big = (size_t)BIG_CAP * 14;
-    HIP_TRY(hipFuncSetAttribute((const void*)sk_buckets_sorted_kernel<true, BIG_T, BIG_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
-    HIP_TRY(hipFuncSetAttribute((const void*)sk_buckets_sorted_kernel<false, BIG_T, BIG_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
-    unsigned long long cur[4] = {0, 0, 0, 0};
+    uint32_t* d_defer2 = d_defer + nbk;
+    // Three sizes of table.  A block's time is latency (the bucket's offsets, its records, the pool cursor: dependent round trips)
+    // hidden by the blocks beside it, and the LDS a table takes sets how many are beside it: 1,024 slots (18 KB, eight blocks per
+    // CU) do the 93 % of the buckets with at most 512 distinct keys in half the time 2,048 slots (30 KB, five blocks) took for all
+    // of them; the rest go to 2,048 slots, what does not fit there (a deeply covered locus) to blocks of 1,024 threads and 8,192
+    // slots, which fold equal keys of a wavefront before they reach the table.  (measured: tools/count_time.py)
+    constexpr int T1_CAP = SK_T1CAP, T2_CAP = SK_SCAP, BIG_T = 1024, BIG_CAP = 8192;
+    const size_t lds_t1 = (size_t)T1_CAP * 12 + std::max<size_t>((size_t)T1_CAP * 2, (size_t)SK_RANK_MAX * 12),
+                 lds_t2 = (size_t)T2_CAP * 12 + std::max<size_t>((size_t)T2_CAP * 2, (size_t)SK_RANK_MAX * 12), lds_big = (size_t)BIG_CAP * 14;
+    HIP_TRY(hipFuncSetAttribute((const void*)sk_buckets_sorted_kernel<true, BIG_T, BIG_CAP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+    HIP_TRY(hipFuncSetAttribute((const void*)sk_buckets_sorted_kernel<false, BIG_T, BIG_CAP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+    unsigned long long cur[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void* prc;
+    if ((rc = g_shn_ws[29].get((size_t)SK_REGIONS * SK_RSTRIDE * 8, &prc))) return rc;
+    unsigned long long* d_rcur = (unsigned long long*)prc;
+    std::vector<unsigned long long> h_rcur((size_t)SK_REGIONS * SK_RSTRIDE);
     for (int attempt = 0; attempt < 3 && sorted; attempt++) {
-      if ((rc = g_shn_ws[20].get((cap + 2) * 8, &pk))) return rc;
-      if ((rc = g_shn_ws[21].get((cap + 2) * 4, &pc))) return rc;
-      HIP_TRY(hipMemsetAsync(d_cursors + 1, 0, 24, s));
+      const uint64_t region_cap = cap / SK_REGIONS + 64;
+      if ((rc = g_shn_ws[20].get((region_cap * SK_REGIONS + 2) * 8, &pk))) return rc;
+      if ((rc = g_shn_ws[21].get((region_cap * SK_REGIONS + 2) * 4, &pc))) return rc;
+      HIP_TRY(hipMemsetAsync(d_cursors + 1, 0, 56, s));                  // [1] unused, [2] / [6] buckets put off to the next size, [3] given up, [5] sum of counts
+      HIP_TRY(hipMemsetAsync(d_rcur, 0, (size_t)SK_REGIONS * SK_RSTRIDE * 8, s));
       {
         TimerRegion t(ctx, T_SK_BUCKETS);
-        if (both_strands) hipLaunchKernelGGL((sk_buckets_sorted_kernel<true, SK_BLK, SK_CAP>), dim3((uint32_t)nbk), dim3(SK_BLK), lds_small, s, recsB, d_seg, d_off2, d_hist2,
-                                             P.b2, k1, P.w, (const uint32_t*)nullptr, d_defer, (uint64_t*)pk, (uint32_t*)pc, d_cursors, cap, d_run_off, d_ndist);
-        else hipLaunchKernelGGL((sk_buckets_sorted_kernel<false, SK_BLK, SK_CAP>), dim3((uint32_t)nbk), dim3(SK_BLK), lds_small, s, recsB, d_seg, d_off2, d_hist2,
-                                P.b2, k1, P.w, (const uint32_t*)nullptr, d_defer, (uint64_t*)pk, (uint32_t*)pc, d_cursors, cap, d_run_off, d_ndist);
-        HIP_TRY(hipMemcpyAsync(cur, d_cursors, 32, hipMemcpyDeviceToHost, s));
+#define SK_LAUNCH(CANON_, T_, CAP_, FOLD_, GRID_, LDS_, LIST_, DEFER_, DCUR_) \
+        hipLaunchKernelGGL((sk_buckets_sorted_kernel<CANON_, T_, CAP_, FOLD_>), dim3((uint32_t)(GRID_)), dim3(T_), LDS_, s, recsB, d_seg, d_off2, d_hist2, P.b2, k1, P.w, \
+                           (const uint32_t*)(LIST_), (uint32_t*)(DEFER_), DCUR_, (uint64_t*)pk, (uint32_t*)pc, d_cursors, region_cap, d_rcur, d_run_off, d_ndist)
+        if (both_strands) SK_LAUNCH(true, SK_STHREADS, T1_CAP, 0, nbk, lds_t1, nullptr, d_defer, 2);
+        else SK_LAUNCH(false, SK_STHREADS, T1_CAP, 0, nbk, lds_t1, nullptr, d_defer, 2);
+        HIP_TRY(hipMemcpyAsync(cur, d_cursors, 64, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (getenv("SHN_COUNT_SK_DEBUG")) fprintf(stderr, "[sk] buckets %llu, deferred %llu, pool after the small tables %llu of %llu\n", (unsigned long long)nbk, cur[2], cur[1], (unsigned long long)cap);
-        if (cur[2]) {
-          TimerRegion tb(ctx, T_SK_BIG);
-          if (both_strands) hipLaunchKernelGGL((sk_buckets_sorted_kernel<true, BIG_T, BIG_CAP>), dim3((uint32_t)cur[2]), dim3(BIG_T), lds_big, s, recsB, d_seg, d_off2, d_hist2,
-                                               P.b2, k1, P.w, (const uint32_t*)d_defer, (uint32_t*)nullptr, (uint64_t*)pk, (uint32_t*)pc, d_cursors, cap, d_run_off, d_ndist);
-          else hipLaunchKernelGGL((sk_buckets_sorted_kernel<false, BIG_T, BIG_CAP>), dim3((uint32_t)cur[2]), dim3(BIG_T), lds_big, s, recsB, d_seg, d_off2, d_hist2,
-                                  P.b2, k1, P.w, (const uint32_t*)d_defer, (uint32_t*)nullptr, (uint64_t*)pk, (uint32_t*)pc, d_cursors, cap, d_run_off, d_ndist);
-          HIP_TRY(hipMemcpyAsync(cur, d_cursors, 32, hipMemcpyDeviceToHost, s));
+        const unsigned long long n_t2 = cur[2];
+        if (n_t2) {
+          if (both_strands) SK_LAUNCH(true, SK_T2THREADS, T2_CAP, 0, n_t2, lds_t2, d_defer, d_defer2, 6);
+          else SK_LAUNCH(false, SK_T2THREADS, T2_CAP, 0, n_t2, lds_t2, d_defer, d_defer2, 6);
+          HIP_TRY(hipMemcpyAsync(cur, d_cursors, 64, hipMemcpyDeviceToHost, s));
           HIP_TRY(hipStreamSynchronize(s));
         }
+        if (getenv("SHN_COUNT_SK_DEBUG")) fprintf(stderr, "[sk] buckets %llu, %llu of them to 2,048 slots, %llu to 8,192; pool of %llu pairs in %d stretches\n", (unsigned long long)nbk, n_t2, cur[6], (unsigned long long)cap, SK_REGIONS);
+        if (cur[6]) {
+          TimerRegion tb(ctx, T_SK_BIG);
+          if (both_strands) SK_LAUNCH(true, BIG_T, BIG_CAP, 2, cur[6], lds_big, d_defer2, nullptr, 2);
+          else SK_LAUNCH(false, BIG_T, BIG_CAP, 2, cur[6], lds_big, d_defer2, nullptr, 2);
+          HIP_TRY(hipMemcpyAsync(cur, d_cursors, 64, hipMemcpyDeviceToHost, s));
+          HIP_TRY(hipStreamSynchronize(s));
+        }
+#undef SK_LAUNCH
       }
       HIP_TRY(hipGetLastError());
       if (cur[3]) { sorted = false; break; }                             // a bucket no key range splits: the pairs path takes this input
-      np = cur[1];
-      if (np <= cap) break;
+      HIP_TRY(hipMemcpyAsync(h_rcur.data(), d_rcur, h_rcur.size() * 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      unsigned long long fullest = 0;
+      np = 0;
+      for (int r_ = 0; r_ < SK_REGIONS; r_++) { const unsigned long long u = h_rcur[(size_t)r_ * SK_RSTRIDE]; np += u; fullest = std::max(fullest, u); }
+      if (fullest <= region_cap) break;
       if (attempt == 2) return shn_fail(SHN_ERR_OVERFLOW, "shn_count_k1mers: the pair pool of the super-k-mer path stayed too small");
-      cap = std::min<uint64_t>(upper, np + np / 64 + 4096);
+      cap = std::max<uint64_t>(np + np / 64 + 4096, (fullest + fullest / 64 + 64) * SK_REGIONS);          // (every stretch as large as the fullest asked for)
     }
     if (sorted) {
       if (!getenv("SHN_COUNT_SK_POOL")) ctx->sk_pool_ratio = (double)np / (double)upper;
@@ -686,7 +733,7 @@ int shn_count_superkmers(shn_ctx* ctx, const std::vector<ReadsView>& views, uint
         if (np) hipLaunchKernelGGL(sk_gather_kernel, dim3((uint32_t)cdiv(nbk * SHN_WAVE, SK_BLK)), dim3(SK_BLK), 0, s, (const uint64_t*)pk, (const uint32_t*)pc,
                                    (const uint64_t*)d_run_off, (const uint32_t*)d_ndist, (const uint64_t*)t->d_bucket_off, nbk, t->d_keys, t->d_counts);
         TRYT(hipMemsetAsync(d_cursors + 5, 0, 8, s));
-        if (np) hipLaunchKernelGGL(sk_sum_counts_kernel, dim3(1024), dim3(256), 0, s, (const uint32_t*)pc, np, d_cursors + 5);
+        if (np) hipLaunchKernelGGL(sk_sum_counts_kernel, dim3(1024), dim3(256), 0, s, (const uint32_t*)t->d_counts, np, d_cursors + 5);   // (the pool has gaps between its stretches: the table's counts)
         unsigned long long tot = 0;
         TRYT(hipMemcpyAsync(&tot, d_cursors + 5, 8, hipMemcpyDeviceToHost, s));
         TRYT(hipStreamSynchronize(s));
