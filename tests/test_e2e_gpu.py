@@ -161,9 +161,10 @@ def test_graph_reads_gathered_on_the_device_equal_uploaded_text(ctx, monkeypatch
                     {"SHN_GRAPH_KP_GPU": "0"},                       # known_paths' in-node test on host threads instead of the device
                     {"SHN_GRAPH_LAZY_TEXT": "0"},                    # the text of every distinct read decoded up front
                     {"SHN_GRAPH_DEV_ATTRS": "0"},                    # copies / mates / path states per read in host arrays (the form before graph_dev.h)
-                    {"SHN_GRAPH_DEV_ATTRS": "0", "SHN_GRAPH_KP_SEARCH": "0"}):
+                    {"SHN_GRAPH_DEV_ATTRS": "0", "SHN_GRAPH_KP_SEARCH": "0"},
+                    {"SHN_SFLOW_BESIDE": "0"}):                      # one sparse-flow call over all partitions after the graph stage (default: beside it)
             for k in ("SHN_GRAPH_ROWS", "SHN_GRAPH_RESIDENT_READS", "SHN_GRAPH_BULK_MIN", "SHN_GRAPH_DEVICE_DEDUP", "SHN_GRAPH_KP_GPU", "SHN_GRAPH_LAZY_TEXT",
-                      "SHN_GRAPH_DEV_ATTRS", "SHN_GRAPH_KP_SEARCH"):
+                      "SHN_GRAPH_DEV_ATTRS", "SHN_GRAPH_KP_SEARCH", "SHN_SFLOW_BESIDE"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
