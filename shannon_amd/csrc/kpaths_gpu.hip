@@ -90,7 +90,8 @@ __device__ __forceinline__ int64_t kp_find(const unsigned long long* __restrict_
 __global__ void kp_classify(RView v, int K, const unsigned long long* __restrict__ hkeys, uint64_t mask, const uint64_t* __restrict__ goff,
                             const uint32_t* __restrict__ occ, const uint8_t* __restrict__ bases, const uint64_t* __restrict__ off, uint32_t n_nodes,
                             uint8_t* __restrict__ state, int32_t* __restrict__ node_out, uint32_t* __restrict__ off_out,
-                            int32_t* __restrict__ first_out, int32_t* __restrict__ last_out) {
+                            int32_t* __restrict__ first_out, int32_t* __restrict__ last_out, uint32_t* __restrict__ slow_list = nullptr,
+                            unsigned long long* __restrict__ slow_count = nullptr) {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= v.n) return;
   const uint32_t L = v.len ? v.len[r] : v.fixed_len;
@@ -132,6 +133,8 @@ __global__ void kp_classify(RView v, int K, const unsigned long long* __restrict
   node_out[r] = fn;
   if (off_out) off_out[r] = fo;
   if (first_out) { first_out[r] = st == 1 ? fn : -1; last_out[r] = st == 1 ? fn : -1; }     // (a read inside one node: that node is its path)
+  // the reads left to search (4 % of them), side by side for kp_search_all: a wavefront of 64 searches instead of 64 reads of which 2 search
+  if (slow_list && st >= 2) slow_list[atomicAdd(slow_count, 1ULL)] = (uint32_t)r;
 }
 
 
@@ -262,11 +265,13 @@ __device__ int kp_read_paths(const uint64_t* __restrict__ w, uint32_t L, const K
 __global__ void kp_search_all(RView v, KpGraph G, KpIndex X, uint8_t* __restrict__ state, const int32_t* __restrict__ node_out,
                               const uint32_t* __restrict__ off_out, int32_t* __restrict__ paths, uint64_t cap, unsigned long long* __restrict__ counters,
                               int32_t* __restrict__ d_first, int32_t* __restrict__ d_last, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ rec_cnt,
-                              uint64_t rec_cap, KpSlow* __restrict__ left, uint64_t left_cap) {
-  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= v.n) return;
+                              uint64_t rec_cap, KpSlow* __restrict__ left, uint64_t left_cap, const uint32_t* __restrict__ slow_list,
+                              const unsigned long long* __restrict__ slow_count) {
+  const uint64_t n_slow = *slow_count;
+  for (uint64_t it = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; it < n_slow; it += (uint64_t)gridDim.x * blockDim.x) {
+  const uint64_t r = slow_list[it];
   const uint32_t st = state[r];
-  if (st != 2 && st != 3) return;
+  if (st != 2 && st != 3) continue;
   const uint32_t L = v.len ? v.len[r] : v.fixed_len;
   const uint64_t* w = v.words + (v.woff ? v.woff[r] : r * v.wpr);
   const uint32_t node0 = (uint32_t)node_out[r], off0 = off_out[r];
@@ -284,9 +289,10 @@ __global__ void kp_search_all(RView v, KpGraph G, KpIndex X, uint8_t* __restrict
       }
     }
   }
-  if (done) { state[r] = 4; d_first[r] = f; d_last[r] = l; return; }
+  if (done) { state[r] = 4; d_first[r] = f; d_last[r] = l; continue; }
   const unsigned long long q = atomicAdd(&counters[3], 1ULL);
   if (q < left_cap) left[q] = KpSlow{(uint32_t)r, st, node0, off0, cnt[r]};
+  }
 }
 
 __global__ void kp_patch(const int32_t* __restrict__ patches, uint64_t n, int32_t* __restrict__ first, int32_t* __restrict__ last) {
@@ -475,14 +481,16 @@ int shn_known_paths_dev(shn_ctx* ctx, const shn_reads* reads, int K, const uint8
   TRYK(bufs.get(&d_goff, (T + 2) * 8));
   TRYK(bufs.get(&d_slot, (total + 1) * 4)); TRYK(bufs.get(&d_occ, (total + 1) * 4));
   TRYK(bufs.get(&d_state, nr + 1)); TRYK(bufs.get(&d_node, (nr + 1) * 4)); TRYK(bufs.get(&d_ofs, (nr + 1) * 4));
-  TRYK(bufs.get(&d_cnt2, 32));
+  TRYK(bufs.get(&d_cnt2, 64));
+  uint32_t* d_slow = nullptr;
+  TRYK(bufs.get(&d_slow, (nr + 1) * 4));
   TRYK(bufs.get(&d_eov, (ne + 1) * 4));
   TRYK(bufs.get(&d_paths, (paths_cap + 1) * 4)); TRYK(bufs.get(&d_rec_cnt, (rec_cap + 1) * 8)); TRYK(bufs.get(&d_left, (left_cap + 1) * sizeof(KpSlow)));
   TRYK(hipMemcpyAsync(d_bases, node_bases, total, hipMemcpyHostToDevice, s));
   TRYK(hipMemcpyAsync(d_off, node_off, (n_nodes + 1) * 8, hipMemcpyHostToDevice, s));
   TRYK(hipMemcpyAsync(kp->d_eoff, edge_off, (n_nodes + 1) * 4, hipMemcpyHostToDevice, s));
   if (ne) { TRYK(hipMemcpyAsync(kp->d_edst, edge_dst, ne * 4, hipMemcpyHostToDevice, s)); TRYK(hipMemcpyAsync(d_eov, edge_ov, ne * 4, hipMemcpyHostToDevice, s)); }
-  TRYK(hipMemsetAsync(d_cnt2, 0, 32, s));
+  TRYK(hipMemsetAsync(d_cnt2, 0, 64, s));
   TRYK(hipMemsetAsync(d_hkeys, 0xFF, T * 8, s));
   TRYK(hipMemsetAsync(d_cnt, 0, (T + 1) * 4, s));
   TRYK(hipMemsetAsync(d_fill, 0, (T + 1) * 4, s));
@@ -493,12 +501,13 @@ int shn_known_paths_dev(shn_ctx* ctx, const shn_reads* reads, int K, const uint8
   hipLaunchKernelGGL(kp_fill, dim3(gp), dim3(256), 0, s, d_slot, total, d_goff, d_fill, d_occ);
   RView v{reads->d_words, reads->d_woff, reads->d_len, nr, reads->fixed_len, reads->wpr};
   hipLaunchKernelGGL(kp_classify, dim3((uint32_t)cdiv(nr, 256)), dim3(256), 0, s, v, K, d_hkeys, T - 1, d_goff, d_occ, d_bases, d_off, (uint32_t)n_nodes,
-                     d_state, d_node, d_ofs, kp->d_first, kp->d_last);
+                     d_state, d_node, d_ofs, kp->d_first, kp->d_last, d_slow, d_cnt2 + 4);
   KpGraph G{d_bases, d_off, kp->d_eoff, kp->d_edst, d_eov};
   KpIndex X{d_hkeys, T - 1, d_goff, d_occ, (uint32_t)n_nodes, K};
   // (kp_insert's count of bad nodes sits in d_cnt2[1]; the search keeps its own counters in [0], [2], [3])
-  hipLaunchKernelGGL(kp_search_all, dim3((uint32_t)cdiv(nr, 64)), dim3(64), 0, s, v, G, X, d_state, (const int32_t*)d_node, (const uint32_t*)d_ofs, d_paths, paths_cap,
-                     d_cnt2, kp->d_first, kp->d_last, (const uint32_t*)dd->d_cnt, d_rec_cnt, rec_cap, d_left, left_cap);
+  hipLaunchKernelGGL(kp_search_all, dim3((uint32_t)std::min<uint64_t>(cdiv(nr, 64), 16384)), dim3(64), 0, s, v, G, X, d_state, (const int32_t*)d_node, (const uint32_t*)d_ofs, d_paths, paths_cap,
+                     d_cnt2, kp->d_first, kp->d_last, (const uint32_t*)dd->d_cnt, d_rec_cnt, rec_cap, d_left, left_cap, (const uint32_t*)d_slow,
+                     (const unsigned long long*)(d_cnt2 + 4));
   TRYK(hipGetLastError());
   unsigned long long cnt[4] = {0, 0, 0, 0};
   TRYK(hipMemcpyAsync(cnt, d_cnt2, 32, hipMemcpyDeviceToHost, s));

@@ -92,17 +92,20 @@ class _NoLock(object):
 def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0, part_vectors=None, group=None,
                          timings=None, lock=None, double_stranded=True):
     """Returns on rank 0 a dict {partitions: {name: fasta}, final, contigs, ...}; None elsewhere.
-    double_stranded=False (-s / --ss / --strand_specific, shannon.py:407-411) is NOT available on the N-rank path: its read
-    numbering, the per-partition cap and the exchange of the capped reads are all built on the strand-doubled order of the default
-    mode; a strand-specific run is a one-GPU run (pipeline.assemble / shannon.py).  Asking for it raises instead of quietly
-    assembling double-stranded.
+    double_stranded=False (-s / --ss / --strand_specific, shannon.py:407-411): the reads are not strand-doubled -- forward counting
+    of reads_1 and RC(reads_2), routes of plain read indices (the global order is the global read index, there is no
+    reverse-complement half), pairs (reads_1[i], RC(reads_2[i])) at the owners, process_concatenated_fasta with the user's flag
+    (:596).  The ops say whether they can (`ops.strand_specific`, set here); ops without the attribute `supports_strand_specific`
+    are refused rather than run double-stranded.
     timings: seconds per stage, compute ("count", "extension", ...) and collectives ("x:...") apart.
     lock (development aid): held while this rank computes, released around every collective -- with several ranks on
     ONE GPU it serialises the compute, so the per-stage compute times are those of a rank that has a GPU to itself."""
     import time
-    if not double_stranded:
-        raise NotImplementedError("assemble_distributed: -s / --strand_specific runs are not sharded over ranks (the N-rank path is built on "
-                                  "the strand-doubled read order); run them on one GPU (pipeline.assemble, shannon.py)")
+    ss = not double_stranded
+    if ss and not getattr(ops, "supports_strand_specific", False):
+        raise NotImplementedError("assemble_distributed: these ops do not implement -s / --strand_specific (forward counting, plain read "
+                                  "indices, pairs of reads_1 and RC(reads_2)); a strand_specific run needs ops that do (GpuOps does)")
+    ops.strand_specific = ss
     T = timings if timings is not None else {}
     lock = lock or _NoLock()
     ops.lock = lock
@@ -199,7 +202,7 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
         rf, rr = np.asarray(r[:keep_f], dtype=np.int64), np.asarray(r[f:f + keep_r], dtype=np.int64)
         sel = np.concatenate([rf, rr])
         gidx = np.concatenate([base + rf, n_glob + base + (rr - n_local)])
-        if int(owner[i]) == rank and getattr(ops, "resident_rows", False) and int(allc[:, i, :].sum()) == int(cnt[i].sum()):
+        if not ss and int(owner[i]) == rank and getattr(ops, "resident_rows", False) and int(allc[:, i, :].sum()) == int(cnt[i].sum()):
             # every routed read of this partition is a row of this rank's own resident input, and this rank owns the partition:
             # nothing is collected -- the graph stage names the reads by their rows, as the single-GPU pipeline does
             payload[rank].append((i, gidx, LocalRows(sel)))
@@ -233,7 +236,7 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
             texts, err = {}, "%s: %s" % (type(ex).__name__, ex)
         if texts is not None:
             lock.release()
-            return _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick, error=err, ops=ops)
+            return _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick, error=err, ops=ops, double_stranded=double_stranded)
 
     def one(i):
         singles, comps = ops.graph(part, names[i], mine.get(i, []), K, paired)      # pieces: [(global indices, reads)] per source rank
@@ -263,7 +266,7 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
         texts[i] = txt
     tick("sparse flow", t0)
     lock.release()
-    return _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick, ops=ops)
+    return _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick, ops=ops, double_stranded=double_stranded)
 
 
 class LocalRows(object):
@@ -294,7 +297,7 @@ def _as_bytes(t):
     return np.frombuffer(t.encode(), dtype=np.uint8) if isinstance(t, str) else np.ascontiguousarray(t, dtype=np.uint8)
 
 
-def _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick, error=None, ops=None):
+def _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick, error=None, ops=None, double_stranded=True):
     """the per-partition FASTA of every owner to rank 0, which merges (shannon.py:584-604).  error: what went wrong in this rank's
     graph stage, if anything -- it travels with the gather, so every rank raises together and none is left waiting."""
     import time
@@ -335,14 +338,14 @@ def _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick, error=N
     # the merge over the texts as they are (process_concatenated_fasta.py + faster_reps.py: post.finalize_texts, on the device when
     # the ops have a context); transcripts with characters outside ACGT go through the Python form
     try:
-        final = post.finalize_texts([single] + order, True, ctx=getattr(ops, "ctx", None))
+        final = post.finalize_texts([single] + order, double_stranded, ctx=getattr(ops, "ctx", None))
     except _lib.ShannonError as ex:
         if "non-ACGT" not in str(ex) and "empty line" not in str(ex):
             raise
         lines = single.splitlines(True)
         for a in order:
             lines += bytes(memoryview(a)).decode().splitlines(True)
-        final = post.finalize(lines, True)
+        final = post.finalize(lines, double_stranded)
     parts = _Texts(names, order)
     tick("merge (rank 0)", t0)
     lock.release()
@@ -370,11 +373,19 @@ class GpuOps(object):
         self.device = torch.device("cuda", torch.cuda.current_device())
         self._dev = device
 
+    supports_strand_specific = True
+    strand_specific = False              # set by assemble_distributed
+
     def n_reads(self):
         return len(self.d1)
 
+    def _count(self):
+        if self.strand_specific:         # forward counting of reads_1 and RC(reads_2): a table of plain (not canonical) k1-mers
+            return self._dev.count_k1mers_strand_specific(self.ctx, self.d1, self.d2, self.K + 1)
+        return self._dev.count_k1mers(self.ctx, [self.d1, self.d2] if self.paired else [self.d1], self.K + 1, True)
+
     def local_pairs(self, W):
-        t = self._dev.count_k1mers(self.ctx, [self.d1, self.d2] if self.paired else [self.d1], self.K + 1, True)
+        t = self._count()
         n = len(t)
         dk = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
         dc = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
@@ -384,11 +395,11 @@ class GpuOps(object):
 
     def local_table(self):
         """one-rank job: the counted table itself (no export to pairs)"""
-        return self._dev.count_k1mers(self.ctx, [self.d1, self.d2] if self.paired else [self.d1], self.K + 1, True)
+        return self._count()
 
     def reduce_pairs(self, rk, rc):
         torch.cuda.synchronize()
-        t = self._dev.Table.from_pairs(self.ctx, rk.data_ptr(), rc.data_ptr(), rk.numel(), self.K + 1, True)
+        t = self._dev.Table.from_pairs(self.ctx, rk.data_ptr(), rc.data_ptr(), rk.numel(), self.K + 1, not self.strand_specific)
         n = len(t)
         dk = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
         dc = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
@@ -398,7 +409,7 @@ class GpuOps(object):
 
     def table_from_pairs(self, gk, gc):
         torch.cuda.synchronize()
-        return self._dev.Table.from_pairs(self.ctx, gk.data_ptr(), gc.data_ptr(), gk.numel(), self.K + 1, True)
+        return self._dev.Table.from_pairs(self.ctx, gk.data_ptr(), gc.data_ptr(), gk.numel(), self.K + 1, not self.strand_specific)
 
     graph_threads = 8
     sharded_extension = True
@@ -459,7 +470,8 @@ class GpuOps(object):
         self.unitigs, self.part_index = None, None
         gpu_graph = K <= 31 and os.environ.get("SHN_GRAPH_GPU", "1") != "0"
         part = kfc.kmers_for_component(self.ctx, res, self.d1, self.d2, K, partition_size, part_vectors=part_vectors, want_rows=False,
-                                       timings=getattr(self, "timings", None), lazy_routes=True, lazy_graph_inputs=gpu_graph)
+                                       timings=getattr(self, "timings", None), lazy_routes=True, lazy_graph_inputs=gpu_graph,
+                                       strand_specific=self.strand_specific)
         names = list(part["new_components"])
         if gpu_graph and names:
             # the raw K-mer graphs of ALL partitions contracted on every rank (a tenth of a second at 111 partitions): every rank
@@ -509,6 +521,17 @@ class GpuOps(object):
             rb = None
             for _attempt in (0, 1):
                 try:
+                    if self.strand_specific and len(rows):
+                        # -s: the rows hold reads_1[i] and, for pairs, reads_2[i] side by side (collect); the second mate is read on its
+                        # reverse strand (rc2 = 1): the pairs (reads_1[i], RC(reads_2[i])) of shannon.py:407-411, not strand-doubled
+                        n, L2 = rows.shape
+                        L = L2 // 2 if paired else L2
+                        b1 = np.ascontiguousarray(rows[:, :L]).reshape(-1)
+                        o1 = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+                        b2 = np.ascontiguousarray(rows[:, L:]).reshape(-1) if paired else None
+                        return mbgraph_native.run_partition_handle(rb, 0 if rb is None else len(rb) // (K + 1), K, b1, o1, b2, o1 if paired else None,
+                                                                   ctx=self.ctx, enc=1, rc1=np.zeros(n, np.uint8), rc2=np.ones(n, np.uint8) if paired else None,
+                                                                   unitigs=self.unitigs, part=i)
                     if local is not None and len(local):
                         # this rank's own reads, named by their rows in its resident input (as pipeline.assemble_resident does)
                         return mbgraph_native.run_partition_rows(self.ctx, self.unitigs, i, self.d1, self.d2 if paired else None, self.store.r1,
@@ -557,6 +580,17 @@ class GpuOps(object):
     def collect(self, sel):
         """the reads of the doubled indices `sel` as they travel to a partition's owner: stored code rows + strand
         flags of the first mates (second mates: same rows, opposite strand)"""
+        if self.strand_specific:
+            # plain read indices: reads_1[i] as stored and, for pairs, reads_2[i] as stored beside it (the owner reads it reversed)
+            b1, o1, _rc, enc = self.store.gather_codes_ss(sel, 1)
+            if enc != 1:
+                raise ValueError("GpuOps: -s on the N-rank path needs the reads stored as code matrices")
+            L = int(o1[1] - o1[0]) if len(o1) > 1 else 0
+            rows = b1.reshape(len(sel), L)
+            if self.paired:
+                b2, o2, _rc2, _e = self.store.gather_codes_ss(sel, 2)
+                rows = np.concatenate([rows, b2.reshape(len(sel), L)], axis=1)
+            return (np.ascontiguousarray(rows), np.zeros(len(sel), np.uint8))
         buf, off, rc1, enc = self.store.gather_codes(sel, 1)
         L = int(off[1] - off[0]) if len(off) > 1 else 0
         return (buf.reshape(len(sel), L), rc1)
@@ -578,6 +612,17 @@ class GpuOps(object):
                 rc1 = np.ascontiguousarray(rc1[order])
         else:
             rows, rc1 = np.zeros((0, 1), np.uint8), np.zeros(0, np.uint8)
+        if self.strand_specific and len(rows):
+            # -s: reads_1[i] | reads_2[i] side by side (collect), the second mate read on its reverse strand
+            n, L2 = rows.shape
+            L = L2 // 2 if paired else L2
+            off = np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+            b1 = np.ascontiguousarray(rows[:, :L]).reshape(-1)
+            b2 = np.ascontiguousarray(rows[:, L:]).reshape(-1) if paired else None
+            singles, comps, _log = mbgraph_native.run_partition_arrays(rb if len(rb) else np.zeros(1, np.uint8), len(rb) // (K + 1), K, b1, off, b2,
+                                                                       off if paired else None, ctx=self.ctx, enc=1, rc1=np.zeros(n, np.uint8),
+                                                                       rc2=np.ones(n, np.uint8) if paired else None)
+            return singles, comps
         off = np.arange(len(rows) + 1, dtype=np.uint64) * np.uint64(rows.shape[1])
         b1 = rows.reshape(-1) if rows.size else np.zeros(1, np.uint8)
         singles, comps, _log = mbgraph_native.run_partition_arrays(rb if len(rb) else np.zeros(1, np.uint8), len(rb) // (K + 1), K,

@@ -11,6 +11,7 @@ import torch.distributed as dist
 
 def main():
     paired, n_genes, seed, n_pairs, out = sys.argv[1] == "1", int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    ss = len(sys.argv) > 6 and sys.argv[6] == "ss"             # -s / --strand_specific
     from shannon_amd import device, synth, distributed, kmers_for_component as kfc
     dist.init_process_group("gloo")
     rank, W = dist.get_rank(), dist.get_world_size()
@@ -26,7 +27,7 @@ def main():
     d1 = device.Reads.from_codes(ctx, q1)
     d2 = device.Reads.from_codes(ctx, q2) if paired else None
     ops = distributed.GpuOps(ctx, d1, d2, kfc.ReadStore(q1, q2), 25)
-    res = distributed.assemble_distributed(ops, 25, 500, "t", 1)
+    res = distributed.assemble_distributed(ops, 25, 500, "t", 1, double_stranded=not ss)
     if rank == 0:
         json.dump({"partitions": dict(res["partitions"]), "final": res["final"], "contigs": res["contigs"]}, open(out, "w"))
     dist.barrier()

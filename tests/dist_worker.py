@@ -20,11 +20,22 @@ class OracleOps(object):
         n = len(r1)
         self.store = kfc.ReadStore(r1, r2)
 
+    supports_strand_specific = True
+    strand_specific = False              # set by assemble_distributed
+
     def n_reads(self):
         return len(self.r1)
 
     def local_pairs(self, W):
         k1 = self.K + 1
+        if self.strand_specific:         # forward counting of reads_1 and RC(reads_2): every key as it is
+            recs = [r for f in seqs.strand_specific(list(self.r1), list(self.r2) if self.paired else None) for r in f]
+            ck, cc = count.count_k1mers_packed(recs, k1)
+            cc = cc.astype(np.int64)
+            own = exchange.owner_of(ck, W)
+            order = np.argsort(own, kind="stable")
+            per = np.bincount(own, minlength=W)
+            return torch.as_tensor(ck[order].view(np.int64)), torch.as_tensor(cc[order].astype(np.int32)), per
         recs = list(self.r1) + (list(self.r2) if self.paired else [])
         recs = recs + [seqs.reverse_complement(r) for r in recs]
         keys, cnts = count.count_k1mers_packed(recs, k1)
@@ -46,6 +57,8 @@ class OracleOps(object):
     def table_from_pairs(self, gk, gc):
         k1 = self.K + 1
         tab = {}
+        if self.strand_specific:
+            return {count.key_to_str(k, k1): c for k, c in zip(gk.numpy().view(np.uint64).tolist(), gc.numpy().tolist())}
         for k, c in zip(gk.numpy().view(np.uint64).tolist(), gc.numpy().tolist()):
             r = count.rc_key(k, k1)
             if r == k:
@@ -65,6 +78,20 @@ class OracleOps(object):
         files, _ = partition.partition_k1mers(nc, k2c, K)
         routes = {n: [] for n in nc}
         N = len(self.r1)
+        if self.strand_specific:         # plain read indices; the pair of read d is (reads_1[d], RC(reads_2[d]))
+            for d in range(N):
+                a = self.r1[d]
+                if a.strip("ACTG"):
+                    continue
+                cs = partition.get_comps(a, k2c, K)
+                if self.paired:
+                    b = seqs.reverse_complement(self.r2[d])
+                    if b.strip("ACTG"):
+                        continue
+                    cs = cs | partition.get_comps(b, k2c, K)
+                for c in cs:
+                    routes[c].append(d)
+            return {"new_components": nc, "k1mers": files, "routes": {n: np.array(v, dtype=np.uint32) for n, v in routes.items()}}
         for d in range(2 * N):
             a = self.store.mate1(d)
             if a.strip("ACTG"):
@@ -80,6 +107,8 @@ class OracleOps(object):
         return {"new_components": nc, "k1mers": files, "routes": {n: np.array(v, dtype=np.uint32) for n, v in routes.items()}}
 
     def collect(self, sel):
+        if self.strand_specific:
+            return [(self.r1[int(d)], seqs.reverse_complement(self.r2[int(d)]) if self.paired else None) for d in sel]
         return [(self.store.mate1(int(d)), self.store.mate2(int(d)) if self.paired else None) for d in sel]
 
     def n_nodes(self, part, name, K):
@@ -127,7 +156,7 @@ def main():
         open(out + ".rank%d" % rank, "w").write(msg)
         dist.destroy_process_group()
         return
-    res = distributed.assemble_distributed(ops, m["K"], psize, "s", m["sf_seed"], pv)
+    res = distributed.assemble_distributed(ops, m["K"], psize, "s", m["sf_seed"], pv, double_stranded=not m.get("strand_specific"))
     if rank == 0:
         json.dump({"partitions": dict(res["partitions"]), "final": res["final"], "contigs": res["contigs"]}, open(out, "w"))
     dist.destroy_process_group()

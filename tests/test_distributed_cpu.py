@@ -25,7 +25,8 @@ def test_partitions_are_dealt_by_load():
 
 
 @pytest.mark.parametrize("name,port,world,chunk", [("syn_pe_s0", 29611, 2, None), ("syn_se_s5", 29612, 2, None), ("syn_part_s33", 29613, 2, "997"),
-                                                   ("syn_part_s33", 29614, 3, None), ("syn_pe_s0", 29615, 3, "500")])
+                                                   ("syn_part_s33", 29614, 3, None), ("syn_pe_s0", 29615, 3, "500"),
+                                                   ("syn_pe_ss_s69", 29617, 2, None), ("syn_se_ss_s53", 29618, 3, None)])     # -s / --strand_specific
 def test_ranks_equal_single_process(name, port, world, chunk, tmp_path):
     """world_size 2 and 3 (gloo); chunk: every variable-size collective in rounds of that many elements (exchange.chunk_elems)"""
     from oracle import pipeline as opipe
@@ -43,7 +44,8 @@ def test_ranks_equal_single_process(name, port, world, chunk, tmp_path):
     inp = load_inputs(name)
     psize = m.get("partition_size", 500)
     pv = [part_vectors(len(b["contigs"]), psize) for b in g["big_components"]] or None
-    ref = opipe.assemble(inp[0], inp[1] if m["paired"] else None, K=m["K"], partition_size=psize, sample="s", seed=m["sf_seed"], part_vectors=pv)
+    ref = opipe.assemble(inp[0], inp[1] if m["paired"] else None, K=m["K"], partition_size=psize, sample="s", seed=m["sf_seed"], part_vectors=pv,
+                         double_stranded=not m.get("strand_specific"))
     assert got["contigs"] == ref["contigs"]
     assert list(got["partitions"]) == list(ref["partitions"])
     for nm in ref["partitions"]:
@@ -82,8 +84,9 @@ def test_read_pieces_travel_as_bytes():
     assert exchange.unpack_read_pieces(np.zeros(0, np.uint8)) == []
 
 
-def test_strand_specific_is_refused_on_the_n_rank_path():
-    """-s / --ss is a one-GPU mode: the N-rank path says so instead of assembling double-stranded"""
+def test_strand_specific_is_refused_by_ops_that_do_not_implement_it():
+    """-s / --ss on the N-rank path needs ops that count forward, route plain indices and pair reads_1 with RC(reads_2): ops that
+    do not say they do are refused instead of run double-stranded"""
     from shannon_amd import distributed
     with pytest.raises(NotImplementedError, match="strand_specific"):
         distributed.assemble_distributed(object(), double_stranded=False)

@@ -48,15 +48,19 @@ def test_distributed_path_matches_single_process(group, paired, n_genes, seed):
         ctx.close()
 
 
-@pytest.mark.parametrize("world,paired,n_genes,seed,port,big", [(2, True, 3, 11, 29621, False), (3, True, 12, 4, 29622, False), (2, False, 2, 5, 29623, False),
-                                                                (4, True, 40, 8, 29624, False), (2, True, 40, 8, 29625, True), (3, True, 12, 4, 29626, True),
-                                                                (4, False, 30, 6, 29627, True)])
-def test_ranks_sharing_one_gpu_equal_single_process(world, paired, n_genes, seed, port, big, tmp_path):
+@pytest.mark.parametrize("world,paired,n_genes,seed,port,big,ss", [(2, True, 3, 11, 29621, False, False), (3, True, 12, 4, 29622, False, False),
+                                                                   (2, False, 2, 5, 29623, False, False), (4, True, 40, 8, 29624, False, False),
+                                                                   (2, True, 40, 8, 29625, True, False), (3, True, 12, 4, 29626, True, False),
+                                                                   (4, False, 30, 6, 29627, True, False),
+                                                                   (2, True, 12, 4, 29628, False, True), (3, False, 6, 5, 29629, False, True),     # -s / --strand_specific
+                                                                   (2, True, 40, 8, 29630, True, True)])
+def test_ranks_sharing_one_gpu_equal_single_process(world, paired, n_genes, seed, port, big, ss, tmp_path):
     """world_size > 1 with the product's per-rank compute (GpuOps): every rank holds a slice of the reads and runs its HIP
     kernels on cuda:0; the collectives go through gloo (RCCL does not take two ranks on one device).  Covers the sharded
     walks + sharded contig stages, the capped read exchange and partition ownership against the single-process result.
     big: the path of large tables (BASELINE configs[3]: >= 20 M k1-mers) forced with SHN_CONTIG_GPU=1 -- walks sharded by
-    component, the candidates of all shards gathered and merged, one replicated GPU contig stage."""
+    component, the candidates of all shards gathered and merged, one replicated GPU contig stage.  ss: -s / --strand_specific
+    (forward counting, plain read indices, pairs of reads_1 and RC(reads_2) at the owners)."""
     import json, subprocess, sys
     from conftest import ROOT
     from shannon_amd import device, synth, pipeline, kmers_for_component as kfc
@@ -67,7 +71,7 @@ def test_ranks_sharing_one_gpu_equal_single_process(world, paired, n_genes, seed
         env["SHN_CONTIG_GPU"] = "1"
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
                         "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_gpu_worker.py"),
-                        "1" if paired else "0", str(n_genes), str(seed), str(n_pairs), out],
+                        "1" if paired else "0", str(n_genes), str(seed), str(n_pairs), out] + (["ss"] if ss else []),
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:]
     got = json.load(open(out))
@@ -78,7 +82,7 @@ def test_ranks_sharing_one_gpu_equal_single_process(world, paired, n_genes, seed
     d1 = device.Reads.from_codes(ctx, q1)
     d2 = device.Reads.from_codes(ctx, q2) if paired else None
     try:
-        ref = pipeline.assemble_resident(ctx, d1, d2, kfc.ReadStore(q1, q2), K=25, sample="t", seed=1)
+        ref = pipeline.assemble_resident(ctx, d1, d2, kfc.ReadStore(q1, q2), K=25, sample="t", seed=1, double_stranded=not ss)
         assert got["contigs"] == ref.extension.contigs
         assert list(got["partitions"]) == list(ref.partitions)
         for name in ref.partitions:
