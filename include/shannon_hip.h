@@ -376,6 +376,17 @@ int shn_post_finalize_bufs(const uint8_t* const* bufs, const uint64_t* lens, uin
  * their first / last r-mers.  Names, first-come-first-served and the containment rule stay sequential host code.  Same result
  * as shn_post_finalize_bufs, byte for byte.                                                                                    */
 int shn_post_finalize_dev(shn_ctx* ctx, const uint8_t* const* bufs, const uint64_t* lens, uint64_t n_bufs, int ds, int r, shn_post** out);
+/* The same merge fed piece by piece: piece `index` of all_reconstructed.fasta (shannon.py:584-595 concatenates the partitions'
+ * reconstructed.fasta files and the single contigs) is handed over as soon as it exists, by any host thread -- its lines are found,
+ * its bytes uploaded, its sequences fingerprinted right then; shn_post_stream_finish runs the order-dependent rules
+ * (process_concatenated_fasta.py:6-32, the sort of shannon.py:603, faster_reps.py:60-131) over the pieces in index order.  A piece
+ * must end its last line and stay in place until the stream is finished or destroyed; capacity = bytes of device text to reserve
+ * (shn_post_stream_add returns SHN_ERR_OVERFLOW beyond it).  Result: as shn_post_finalize_dev over the pieces in index order.      */
+typedef struct shn_post_stream shn_post_stream;
+int shn_post_stream_begin(shn_ctx* ctx, uint64_t capacity, shn_post_stream** out);
+int shn_post_stream_add(shn_post_stream* ps, uint64_t index, const uint8_t* text, uint64_t n_bytes);
+int shn_post_stream_finish(shn_post_stream* ps, int ds, int r, shn_post** out);
+void shn_post_stream_destroy(shn_post_stream* ps);
 uint64_t shn_post_count(const shn_post* p);
 int shn_post_sizes(const shn_post* p, uint64_t* name_bytes, uint64_t* seq_bytes);
 int shn_post_export(const shn_post* p, uint8_t* names, uint64_t* name_off, uint8_t* seqs, uint64_t* seq_off);

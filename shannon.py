@@ -175,9 +175,13 @@ def main(argv):
     alld = os.path.join(temp, sample + "_allalgo_output")
     os.makedirs(alld)
     open(os.path.join(alld, "all_reconstructed.fasta"), "w").write("".join(R.all_reconstructed))
-    with open(os.path.join(out_dir, "shannon.fasta"), "w") as f:
-        for name, seq in R.final.items():
-            f.write(">%s\n%s\n" % (name, seq))
+    if hasattr(R.final, "fasta"):                                   # (the native merge's buffers: the file's text without a string per record)
+        with open(os.path.join(out_dir, "shannon.fasta"), "wb") as f:
+            f.write(R.final.fasta())
+    else:
+        with open(os.path.join(out_dir, "shannon.fasta"), "w") as f:
+            for name, seq in R.final.items():
+                f.write(">%s\n%s\n" % (name, seq))
     say("All partitions completed: %d transcripts reconstructed" % len(R.final))
     say("stage seconds: " + json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in T.items()}))
     log.close()

@@ -81,6 +81,10 @@ SIGNATURES = {
     "shn_post_finalize": (C.c_int, [vp, C.c_uint64, C.c_int, C.c_int, vpp]),
     "shn_post_finalize_bufs": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_int, vpp]),
     "shn_post_finalize_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vpp]),
+    "shn_post_stream_begin": (C.c_int, [vp, C.c_uint64, vpp]),
+    "shn_post_stream_add": (C.c_int, [vp, C.c_uint64, vp, C.c_uint64]),
+    "shn_post_stream_finish": (C.c_int, [vp, C.c_int, C.c_int, vpp]),
+    "shn_post_stream_destroy": (None, [vp]),
     "shn_post_count": (C.c_uint64, [vp]),
     "shn_post_sizes": (C.c_int, [vp, vp, vp]),
     "shn_post_export": (C.c_int, [vp, vp, vp, vp, vp]),

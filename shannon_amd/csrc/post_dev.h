@@ -13,9 +13,14 @@ struct PostDev;
 // uploads the pieces back to back; byte g of the concatenation is what the offsets below refer to
 int post_dev_create(shn_ctx* ctx, const std::vector<std::pair<const uint8_t*, uint64_t>>& pieces, PostDev** out);
 void post_dev_destroy(PostDev* d);
+// room for `cap` bytes, filled piece by piece (post_dev_upload: bytes [at, at + n) of the device text, on the stream of `on`)
+int post_dev_create_cap(shn_ctx* ctx, uint64_t cap, PostDev** out);
+int post_dev_upload(PostDev* d, shn_ctx* on, uint64_t at, const uint8_t* src, uint64_t n);
+uint64_t post_dev_capacity(const PostDev* d);
 // for n ranges (offset, length) of the text: out[4 i .. 4 i + 3] = fingerprint of the bytes (two words), of their reverse
 // complement (two words; complement of A C G T, other bytes as they are)
-int post_dev_fingerprints(PostDev* d, const uint64_t* off, const uint32_t* len, uint64_t n, uint64_t* out);
+// on: the context (stream) to run on, default the text's own; other_out[i] = 1: range i holds a byte outside ACGT
+int post_dev_fingerprints(PostDev* d, const uint64_t* off, const uint32_t* len, uint64_t n, uint64_t* out, shn_ctx* on = nullptr, uint8_t* other_out = nullptr);
 // occurrences of the r-mers `queries` (packed 2 bits per base, A C G T = 0 1 2 3; r < 32) in n ranges: (range, position, key),
 // sorted by (range, position).  *bad: a range holds a byte outside ACGT.  SHN_ERR_OVERFLOW when there are more hits than `cap`.
 int post_dev_scan(PostDev* d, const uint64_t* off, const uint32_t* len, uint64_t n, int r, const uint64_t* queries, uint64_t nq, uint64_t cap,

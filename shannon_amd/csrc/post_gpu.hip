@@ -32,6 +32,23 @@ int post_dev_create(shn_ctx* ctx, const std::vector<std::pair<const uint8_t*, ui
   return SHN_OK;
 }
 
+int post_dev_create_cap(shn_ctx* ctx, uint64_t cap, PostDev** out) {
+  if (!ctx || !out) return shn_fail(SHN_ERR_ARG, "post_dev_create_cap: NULL argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  PostDev* d = new PostDev{ctx, nullptr, cap};
+  if (shn_dev_malloc(&d->d_text, cap + 64) != hipSuccess) { delete d; return shn_fail(SHN_ERR_NOMEM, "post_dev_create_cap: out of device memory"); }
+  *out = d;
+  return SHN_OK;
+}
+uint64_t post_dev_capacity(const PostDev* d) { return d ? d->n_bytes : 0; }
+int post_dev_upload(PostDev* d, shn_ctx* on, uint64_t at, const uint8_t* src, uint64_t n) {
+  if (!d || !on || (n && !src) || at + n > d->n_bytes) return shn_fail(SHN_ERR_ARG, "post_dev_upload: bad argument");
+  if (!n) return SHN_OK;
+  HIP_TRY(hipSetDevice(on->device));
+  HIP_TRY(hipMemcpyAsync(d->d_text + at, src, n, hipMemcpyHostToDevice, on->stream));
+  return SHN_OK;
+}
+
 void post_dev_destroy(PostDev* d) {
   if (!d) return;
   hipSetDevice(d->ctx->device);
@@ -49,15 +66,17 @@ __host__ __device__ __forceinline__ uint64_t fp_term(uint64_t pos, uint32_t byte
 __device__ __forceinline__ uint32_t comp_byte(uint32_t c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c; }
 
 __global__ __launch_bounds__(64) void post_fp_kernel(const uint8_t* __restrict__ text, const uint64_t* __restrict__ off, const uint32_t* __restrict__ len,
-                                                     uint64_t n, uint64_t* __restrict__ out) {
+                                                     uint64_t n, uint64_t* __restrict__ out, uint8_t* __restrict__ other) {
   for (uint64_t i = blockIdx.x; i < n; i += gridDim.x) {
     const uint8_t* s = text + off[i];
     const uint32_t L = len[i];
     uint64_t f1 = 0, f2 = 0, r1 = 0, r2 = 0;
+    bool odd = false;                                                    // a byte outside ACGT (its complement is itself)
     for (uint32_t p = threadIdx.x; p < L; p += 64) {
       const uint32_t c = s[p];
       f1 += fp_term(p, c, FP_S1); f2 += fp_term(p, c, FP_S2);
       const uint32_t cc = comp_byte(c);
+      odd |= cc == c;
       r1 += fp_term(L - 1 - p, cc, FP_S1); r2 += fp_term(L - 1 - p, cc, FP_S2);
     }
     for (int o = 32; o > 0; o >>= 1) { f1 += __shfl_xor(f1, o, 64); f2 += __shfl_xor(f2, o, 64); r1 += __shfl_xor(r1, o, 64); r2 += __shfl_xor(r2, o, 64); }
@@ -65,21 +84,25 @@ __global__ __launch_bounds__(64) void post_fp_kernel(const uint8_t* __restrict__
       const uint64_t l1 = shn_mix64((uint64_t)L ^ FP_S1), l2 = shn_mix64((uint64_t)L ^ FP_S2);
       out[4 * i] = f1 ^ l1; out[4 * i + 1] = f2 ^ l2; out[4 * i + 2] = r1 ^ l1; out[4 * i + 3] = r2 ^ l2;
     }
+    const unsigned long long any_odd = __ballot(odd);
+    if (other && threadIdx.x == 0) other[i] = any_odd ? 1 : 0;
   }
 }
 
-int post_dev_fingerprints(PostDev* d, const uint64_t* off, const uint32_t* len, uint64_t n, uint64_t* out) {
+int post_dev_fingerprints(PostDev* d, const uint64_t* off, const uint32_t* len, uint64_t n, uint64_t* out, shn_ctx* on, uint8_t* other_out) {
   if (!d || (n && (!off || !len || !out))) return shn_fail(SHN_ERR_ARG, "post_dev_fingerprints: NULL argument");
   if (!n) return SHN_OK;
-  hipStream_t s = d->ctx->stream;
+  HIP_TRY(hipSetDevice(d->ctx->device));
+  hipStream_t s = on ? on->stream : d->ctx->stream;
   ShnDevBufs bufs(s);
-  uint64_t *d_off, *d_out; uint32_t* d_len;
-  if (bufs.get(&d_off, n * 8) != hipSuccess || bufs.get(&d_len, n * 4) != hipSuccess || bufs.get(&d_out, n * 32) != hipSuccess)
+  uint64_t *d_off, *d_out; uint32_t* d_len; uint8_t* d_other;
+  if (bufs.get(&d_off, n * 8) != hipSuccess || bufs.get(&d_len, n * 4) != hipSuccess || bufs.get(&d_out, n * 32) != hipSuccess || bufs.get(&d_other, n + 1) != hipSuccess)
     return shn_fail(SHN_ERR_NOMEM, "post_dev_fingerprints: out of device memory");
   HIP_TRY(hipMemcpyAsync(d_off, off, n * 8, hipMemcpyHostToDevice, s));
   HIP_TRY(hipMemcpyAsync(d_len, len, n * 4, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(post_fp_kernel, dim3((uint32_t)std::min<uint64_t>(n, 1u << 20)), dim3(64), 0, s, d->d_text, d_off, d_len, n, d_out);
+  hipLaunchKernelGGL(post_fp_kernel, dim3((uint32_t)std::min<uint64_t>(n, 1u << 20)), dim3(64), 0, s, d->d_text, d_off, d_len, n, d_out, d_other);
   HIP_TRY(hipMemcpyAsync(out, d_out, n * 32, hipMemcpyDeviceToHost, s));
+  if (other_out) HIP_TRY(hipMemcpyAsync(other_out, d_other, n, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipGetLastError());
   return SHN_OK;

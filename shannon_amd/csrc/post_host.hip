@@ -212,6 +212,8 @@ static int find_reps_core(const uint8_t* const* nptr, const uint64_t* nlen, cons
 // (no separator), sequences of at most 199 bases (line length <= 200 with its newline) are dropped, a sequence (or, double
 // stranded, its reverse complement) seen before is dropped, a header line seen twice keeps its last sequence, records are
 // ordered by (sequence line length, header line).
+#include <map>
+#include <mutex>
 #include <string_view>
 #include <unordered_map>
 #include <unordered_set>
@@ -252,6 +254,109 @@ extern "C" int shn_post_finalize(const uint8_t* text, uint64_t n_bytes, int ds, 
   if ((n_bytes && !text) || !out) return shn_fail(SHN_ERR_ARG, "shn_post_finalize: NULL argument");
   return shn_post_finalize_bufs(&text, &n_bytes, 1, ds, r, out);
 }
+// ---- the merge in pieces.  A piece = one text of all_reconstructed.fasta (the single contigs, one partition's transcripts) whose last
+// line ends: its lines are found, its bytes go to the device, its sequence lines are fingerprinted -- independent of every other piece,
+// so a partition's piece is prepared by the host thread that has just made it, beside the graph stage of the partitions still
+// running (shn_post_stream_add); the order-dependent rules run over the pieces in index order at the end (shn_post_stream_finish).
+typedef std::string_view SV;
+static inline bool post_is_ws(uint8_t c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
+static inline SV post_strip(SV s) { size_t a = 0, b = s.size(); while (a < b && post_is_ws((uint8_t)s[a])) a++; while (b > a && post_is_ws((uint8_t)s[b - 1])) b--; return s.substr(a, b - a); }
+struct PostPiece {
+  const uint8_t* text = nullptr; uint64_t n = 0, dev_base = 0;
+  std::vector<SV> lines;
+  std::vector<uint64_t> line_goff;        // offset of every line in the device text
+  std::vector<uint64_t> fp;               // 4 words per line (0 for lines that are not sequence lines); empty: no device
+  std::vector<uint8_t> acgt;              // per line: 1 = a sequence line of A C G T only (known from the fingerprint pass)
+};
+// dev == NULL: lines only.  on: the context whose stream carries the upload and the fingerprint kernel.
+static int post_prep_piece(PostDev* dev, shn_ctx* on, PostPiece& P) {
+  const uint8_t* text = P.text;
+  for (uint64_t p = 0; p < P.n;) {
+    const void* q = memchr(text + p, '\n', P.n - p);
+    const uint64_t e = q ? (uint64_t)((const uint8_t*)q - text) + 1 : P.n;
+    P.lines.push_back(SV((const char*)text + p, e - p));
+    P.line_goff.push_back(P.dev_base + p);
+    p = e;
+  }
+  if (!dev || P.lines.empty()) return SHN_OK;
+  int rcd = post_dev_upload(dev, on, P.dev_base, P.text, P.n);
+  if (rcd) return rcd;
+  std::vector<uint64_t> so; std::vector<uint32_t> sl; std::vector<uint32_t> which;
+  for (size_t i = 0; i < P.lines.size(); i++) {
+    const SV line = P.lines[i];
+    size_t a = 0;
+    while (a < line.size() && post_is_ws((uint8_t)line[a])) a++;
+    if (a == line.size() || line[a] == '>' || line.size() <= 200) continue;
+    const SV cur = post_strip(line);
+    so.push_back(P.line_goff[i] + (uint64_t)(cur.data() - line.data())); sl.push_back((uint32_t)cur.size()); which.push_back((uint32_t)i);
+  }
+  std::vector<uint64_t> got(so.size() * 4);
+  std::vector<uint8_t> other(so.size() + 1);
+  rcd = post_dev_fingerprints(dev, so.data(), sl.data(), so.size(), got.data(), on, other.data());
+  if (rcd) return rcd;
+  P.fp.assign(P.lines.size() * 4, 0);
+  P.acgt.assign(P.lines.size(), 0);
+  for (size_t j = 0; j < which.size(); j++) { memcpy(&P.fp[(size_t)which[j] * 4], &got[j * 4], 32); P.acgt[which[j]] = other[j] ? 0 : 1; }
+  if (so.empty()) { HIP_TRY(hipStreamSynchronize(on->stream)); }          // (the fingerprint call waits for the stream; without one the upload is waited for here)
+  return SHN_OK;
+}
+static int post_finalize_lines(std::vector<SV>& lines, std::vector<uint64_t>& line_goff, std::vector<uint64_t>& fp, bool use_fp, PostDev* dev, int ds, int r,
+                               shn_post** out, const std::vector<uint8_t>* acgt = nullptr);
+
+struct shn_post_stream {
+  shn_ctx* ctx = nullptr;
+  PostDev* dev = nullptr;
+  std::mutex mu;
+  uint64_t cursor = 0;
+  std::map<uint64_t, PostPiece*> pieces;
+  ~shn_post_stream() { for (auto& kv : pieces) delete kv.second; if (dev) post_dev_destroy(dev); }
+};
+extern "C" void shn_post_stream_destroy(shn_post_stream* ps) { delete ps; }
+extern "C" int shn_post_stream_begin(shn_ctx* ctx, uint64_t capacity, shn_post_stream** out) {
+  if (!ctx || !out) return shn_fail(SHN_ERR_ARG, "shn_post_stream_begin: NULL argument");
+  *out = nullptr;
+  shn_post_stream* ps = new shn_post_stream();
+  ps->ctx = ctx;
+  int rc = post_dev_create_cap(ctx, std::max<uint64_t>(capacity, 1u << 20), &ps->dev);
+  if (rc) { delete ps; return rc; }
+  *out = ps;
+  return SHN_OK;
+}
+// piece `index` of the concatenation (any order, any host thread, every index once); the text must stay where it is until the
+// stream is finished or destroyed.  SHN_ERR_OVERFLOW: no room left in the device text (the caller merges in one piece instead).
+extern "C" int shn_post_stream_add(shn_post_stream* ps, uint64_t index, const uint8_t* text, uint64_t n_bytes) {
+  if (!ps || (n_bytes && !text)) return shn_fail(SHN_ERR_ARG, "shn_post_stream_add: NULL argument");
+  if (n_bytes && text[n_bytes - 1] != '\n') return shn_fail(SHN_ERR_ARG, "shn_post_stream_add: a piece must end its last line");
+  PostPiece* P = new PostPiece();
+  P->text = text; P->n = n_bytes;
+  {
+    std::lock_guard<std::mutex> lk(ps->mu);
+    if (ps->pieces.count(index)) { delete P; return shn_fail(SHN_ERR_ARG, "shn_post_stream_add: piece given twice"); }
+    if (ps->cursor + n_bytes > post_dev_capacity(ps->dev)) { delete P; return shn_fail(SHN_ERR_OVERFLOW, "shn_post_stream_add: the device text is full"); }
+    P->dev_base = ps->cursor;
+    ps->cursor += n_bytes;
+    ps->pieces[index] = P;
+  }
+  return post_prep_piece(ps->dev, shn_thread_ctx(ps->ctx), *P);
+}
+extern "C" int shn_post_stream_finish(shn_post_stream* ps, int ds, int r, shn_post** out) {
+  if (!ps || !out) return shn_fail(SHN_ERR_ARG, "shn_post_stream_finish: NULL argument");
+  std::vector<SV> lines;
+  std::vector<uint64_t> line_goff, fp;
+  std::vector<uint8_t> acgt;
+  size_t nl = 0;
+  for (auto& kv : ps->pieces) nl += kv.second->lines.size();
+  lines.reserve(nl); line_goff.reserve(nl); fp.reserve(nl * 4);
+  for (auto& kv : ps->pieces) {                                          // (a std::map: in index order)
+    PostPiece& P = *kv.second;
+    lines.insert(lines.end(), P.lines.begin(), P.lines.end());
+    line_goff.insert(line_goff.end(), P.line_goff.begin(), P.line_goff.end());
+    if (P.fp.size() == P.lines.size() * 4) fp.insert(fp.end(), P.fp.begin(), P.fp.end()); else fp.insert(fp.end(), P.lines.size() * 4, 0);
+    if (P.acgt.size() == P.lines.size()) acgt.insert(acgt.end(), P.acgt.begin(), P.acgt.end()); else acgt.insert(acgt.end(), P.lines.size(), 0);
+  }
+  return post_finalize_lines(lines, line_goff, fp, true, ps->dev, ds, r, out, &acgt);
+}
+
 // the same over the concatenation of several buffers (the per-partition FASTA texts as they come out of shn_sparse_flow)
 static int post_finalize_impl(shn_ctx* ctx, const uint8_t* const* bufs, const uint64_t* lens, uint64_t n_bufs, int ds, int r, shn_post** out) {
   if (!out || (n_bufs && (!bufs || !lens))) return shn_fail(SHN_ERR_ARG, "shn_post_finalize: NULL argument");
@@ -266,9 +371,34 @@ static int post_finalize_impl(shn_ctx* ctx, const uint8_t* const* bufs, const ui
     for (uint64_t i = 0; i < n_bufs; i++) joined.append((const char*)bufs[i], lens[i]);
     pieces.push_back({(const uint8_t*)joined.data(), joined.size()});
   }
-  typedef std::string_view SV;
-  auto is_ws = [](uint8_t c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; };
-  auto strip = [&](SV s) { size_t a = 0, b = s.size(); while (a < b && is_ws((uint8_t)s[a])) a++; while (b > a && is_ws((uint8_t)s[b - 1])) b--; return s.substr(a, b - a); };
+  uint64_t total = 0;
+  for (auto& pc : pieces) total += pc.second;
+  PostDev* dev = nullptr;
+  struct DevFree { PostDev*& d; ~DevFree() { if (d) post_dev_destroy(d); } } dev_free{dev};
+  if (ctx && total) { int rcd = post_dev_create_cap(ctx, total, &dev); if (rcd) return rcd; }
+  std::vector<SV> lines;
+  std::vector<uint64_t> line_goff, fp;
+  std::vector<uint8_t> acgt;
+  uint64_t base = 0;
+  for (auto& pc : pieces) {
+    PostPiece P;
+    P.text = pc.first; P.n = pc.second; P.dev_base = base;
+    base += pc.second;
+    int rcd = post_prep_piece(dev, ctx, P);
+    if (rcd) return rcd;
+    lines.insert(lines.end(), P.lines.begin(), P.lines.end());
+    line_goff.insert(line_goff.end(), P.line_goff.begin(), P.line_goff.end());
+    if (dev) {
+      if (P.fp.size() == P.lines.size() * 4) fp.insert(fp.end(), P.fp.begin(), P.fp.end()); else fp.insert(fp.end(), P.lines.size() * 4, 0);
+      if (P.acgt.size() == P.lines.size()) acgt.insert(acgt.end(), P.acgt.begin(), P.acgt.end()); else acgt.insert(acgt.end(), P.lines.size(), 0);
+    }
+  }
+  return post_finalize_lines(lines, line_goff, fp, dev != nullptr, dev, ds, r, out, dev ? &acgt : nullptr);
+}
+static int post_finalize_lines(std::vector<SV>& lines, std::vector<uint64_t>& line_goff, std::vector<uint64_t>& fp, bool use_fp, PostDev* dev, int ds, int r,
+                               shn_post** out, const std::vector<uint8_t>* acgt) {
+  auto is_ws = [](uint8_t c) { return post_is_ws(c); };
+  auto strip = [&](SV s) { return post_strip(s); };
   // ---- process_concatenated
   std::vector<std::string> own;                        // renamed header lines (stable addresses: reserved below)
   std::vector<std::pair<SV, SV>> recs;                 // (header line, sequence line), lines with their newline
@@ -283,52 +413,7 @@ static int post_finalize_impl(shn_ctx* ctx, const uint8_t* const* bufs, const ui
     const char* src = cur.data() + cur.size() - 1; char* dst = &buf[0];
     for (size_t i = 0, m = cur.size(); i < m; i++) dst[i] = (char)comp[(uint8_t)src[-(ptrdiff_t)i]];
   };
-  // lines first (one pass of memchr), then the hashes of every sequence line and of its reverse complement on host threads (the
-  // hashing of 60-150 MB of sequence was most of this function); the order-dependent part -- names, first-come dedup -- follows
-  // sequentially on the hashes
-  std::vector<SV> lines;
-  std::vector<uint64_t> line_goff;                    // offset of every line in the concatenation of the pieces (= the uploaded text)
-  {
-    uint64_t base = 0;
-    for (auto& pc : pieces) {
-      const uint8_t* text = pc.first;
-      const uint64_t n_bytes = pc.second;
-      for (uint64_t p = 0; p < n_bytes;) {
-        const void* q = memchr(text + p, '\n', n_bytes - p);
-        const uint64_t e = q ? (uint64_t)((const uint8_t*)q - text) + 1 : n_bytes;
-        lines.push_back(SV((const char*)text + p, e - p));
-        line_goff.push_back(base + p);
-        p = e;
-      }
-      base += n_bytes;
-    }
-  }
   own.reserve(lines.size() + 2);                      // (renamed header lines: at most one per line; the reservation keeps their addresses)
-  // device: the text goes up once; the sequence lines' fingerprints (plain and reverse-complemented, 128 bits each) replace the
-  // host hashes.  A fingerprint match is always confirmed on the text below, so it can only cost time, never an answer.
-  PostDev* dev = nullptr;
-  struct DevFree { PostDev*& d; ~DevFree() { if (d) post_dev_destroy(d); } } dev_free{dev};
-  std::vector<uint64_t> fp;                           // per line: 4 words (0 for lines that are not sequence lines)
-  bool use_fp = false;
-  if (ctx && !lines.empty()) {
-    int rcd = post_dev_create(ctx, pieces, &dev);
-    if (rcd) return rcd;
-    std::vector<uint64_t> so; std::vector<uint32_t> sl; std::vector<uint32_t> which;
-    for (size_t i = 0; i < lines.size(); i++) {
-      const SV line = lines[i];
-      size_t a = 0;
-      while (a < line.size() && is_ws((uint8_t)line[a])) a++;
-      if (a == line.size() || line[a] == '>' || line.size() <= 200) continue;
-      const SV cur = strip(line);
-      so.push_back(line_goff[i] + (uint64_t)(cur.data() - line.data())); sl.push_back((uint32_t)cur.size()); which.push_back((uint32_t)i);
-    }
-    std::vector<uint64_t> got(so.size() * 4);
-    rcd = post_dev_fingerprints(dev, so.data(), sl.data(), so.size(), got.data());
-    if (rcd) return rcd;
-    fp.assign(lines.size() * 4, 0);
-    for (size_t j = 0; j < which.size(); j++) memcpy(&fp[(size_t)which[j] * 4], &got[j * 4], 32);
-    use_fp = true;
-  }
   std::vector<uint64_t> hf(lines.size(), 0), hr(lines.size(), 0);
   if (use_fp) { for (size_t i = 0; i < lines.size(); i++) { hf[i] = fp[4 * i] ^ (fp[4 * i + 1] * 0x9E3779B97F4A7C15ULL); hr[i] = fp[4 * i + 2] ^ (fp[4 * i + 3] * 0x9E3779B97F4A7C15ULL); } }
   else {
@@ -352,13 +437,45 @@ static int post_finalize_impl(shn_ctx* ctx, const uint8_t* const* bufs, const ui
     work();
     for (auto& x : th) x.join();
   }
-  struct HKey { SV sv; uint64_t h; };
-  struct HHash { size_t operator()(const HKey& k) const { return (size_t)k.h; } };
-  struct HEq { bool operator()(const HKey& a, const HKey& b) const { return a.sv == b.sv; } };
-  std::unordered_set<HKey, HHash, HEq> contigs;
-  std::unordered_set<uint64_t> contig_hashes;           // (a reverse complement is only written out when its hash has been seen)
-  SV last;
+  // (open-addressing tables: the node-based std containers were a cache miss per operation, six operations per record)
+  StringInterner seen_names(lines.size() / 2 + 16);       // first token of a header line -> id; seen_count[id] = times met
+  std::vector<uint64_t> seen_count;
+  FlatMultiMap contigs(lines.size() / 2 + 16);            // hash of a kept sequence -> the lines that hold it (confirmed on the text)
   std::string rcbuf;
+  auto kept_has = [&](uint64_t h, SV what) {
+    for (int32_t v = contigs.find(h); v != -1; v = contigs.nxt(v)) if (strip(lines[(size_t)contigs.va(v)]) == what) return true;
+    return false;
+  };
+  // "is the reverse complement of `cur` a kept sequence" without writing it out, eight bases at a time -- for sequences of A C G T
+  // only (the fingerprint pass says which lines are): the complement of a letter is the letter ^ 0x15 (A <-> T) or ^ 0x04 (C <-> G),
+  // and bit 1 tells the two pairs apart.  Half of the records of a double-stranded run are the reverse complements of earlier ones;
+  // the byte-wise reverse complement of each was most of this loop.
+  auto rc_equal = [](SV a, SV b) {
+    const size_t L = a.size();
+    if (b.size() != L) return false;
+    size_t i = 0;
+    for (; i + 8 <= L; i += 8) {
+      uint64_t wa, wb;
+      memcpy(&wa, a.data() + i, 8); memcpy(&wb, b.data() + L - 8 - i, 8);
+      wb = __builtin_bswap64(wb);
+      const uint64_t bit1 = (wb >> 1) & 0x0101010101010101ULL;
+      if ((wb ^ 0x1515151515151515ULL ^ (bit1 * 0x11)) != wa) return false;
+    }
+    for (; i < L; i++) { const uint8_t c = (uint8_t)b[L - 1 - i]; const uint8_t cc = (uint8_t)(c ^ 0x15 ^ (((c >> 1) & 1) * 0x11)); if (cc != (uint8_t)a[i]) return false; }
+    return true;
+  };
+  auto kept_has_rc = [&](uint64_t h, SV cur, size_t li) {
+    bool all_fast = acgt && (*acgt)[li];
+    if (all_fast)
+      for (int32_t v = contigs.find(h); v != -1; v = contigs.nxt(v)) if (!(*acgt)[(size_t)contigs.va(v)]) { all_fast = false; break; }
+    if (all_fast) {
+      for (int32_t v = contigs.find(h); v != -1; v = contigs.nxt(v)) if (rc_equal(cur, strip(lines[(size_t)contigs.va(v)]))) return true;
+      return false;
+    }
+    revcomp_into(cur, rcbuf);
+    return kept_has(h, SV(rcbuf));
+  };
+  SV last;
   for (size_t li = 0; li < lines.size(); li++) {
     const SV line = lines[li];
     // tok = line.split()
@@ -369,10 +486,11 @@ static int post_finalize_impl(shn_ctx* ctx, const uint8_t* const* bufs, const ui
       size_t b = a;
       while (b < line.size() && !is_ws((uint8_t)line[b])) b++;
       const SV tok0 = line.substr(a, b - a);
-      auto it = seen.find(tok0);
-      if (it != seen.end()) {
+      bool is_new = false;
+      const int32_t id = seen_names.intern(tok0.data(), tok0.size(), &is_new);
+      if (!is_new) {
         std::string nl(tok0);
-        nl += "_" + std::to_string(it->second);
+        nl += "_" + std::to_string(seen_count[(size_t)id]);
         bool first = true;
         for (size_t c = b; c < line.size();) {
           while (c < line.size() && is_ws((uint8_t)line[c])) c++;
@@ -382,19 +500,15 @@ static int post_finalize_impl(shn_ctx* ctx, const uint8_t* const* bufs, const ui
           c = d;
         }
         nl += "\n";
-        it->second++;
+        seen_count[(size_t)id]++;
         own.push_back(std::move(nl));
         last = SV(own.back());
-      } else { seen.emplace(tok0, 1); last = line; }
+      } else { seen_count.push_back(1); last = line; }
     } else if (line.size() > 200) {
       const SV cur = strip(line);
-      if (contigs.count(HKey{cur, hf[li]})) continue;
-      if (ds && contig_hashes.count(hr[li])) {
-        revcomp_into(cur, rcbuf);
-        if (contigs.count(HKey{SV(rcbuf), hr[li]})) continue;
-      }
-      contigs.insert(HKey{cur, hf[li]});
-      contig_hashes.insert(hf[li]);
+      if (kept_has(hf[li], cur)) continue;
+      if (ds && contigs.find(hr[li]) != -1 && kept_has_rc(hr[li], cur, li)) continue;
+      contigs.add(hf[li], (int32_t)li);
       recs.push_back({last, line});
       rec_li.push_back((uint32_t)li);
     }
@@ -403,12 +517,13 @@ static int post_finalize_impl(shn_ctx* ctx, const uint8_t* const* bufs, const ui
   auto nowp = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
   const double tp0 = nowp();
   // ---- length sort: a dict keyed by header line (the last sequence of a repeated header line wins), by (len(seq line), header line)
-  std::unordered_map<SV, uint32_t> by_header;
+  StringInterner by_header(recs.size() + 16);           // header line -> position in `order` (ids are given in order of first occurrence)
   std::vector<uint32_t> order;
   for (uint32_t i = 0; i < recs.size(); i++) {
-    auto it = by_header.find(recs[i].first);
-    if (it == by_header.end()) { by_header.emplace(recs[i].first, (uint32_t)order.size()); order.push_back(i); }
-    else order[it->second] = i;
+    bool is_new = false;
+    const int32_t id = by_header.intern(recs[i].first.data(), recs[i].first.size(), &is_new);
+    if (is_new) order.push_back(i);
+    else order[(size_t)id] = i;
   }
   std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
     if (recs[x].second.size() != recs[y].second.size()) return recs[x].second.size() < recs[y].second.size();

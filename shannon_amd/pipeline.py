@@ -181,6 +181,23 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
         big = set(nm for nm in names if n_routed[nm] >= max(1, big_cut)) if sflow_beside else set()
         small_lock, small_done, small_recs = threading.Lock(), [0], {}
         n_small = len(names) - len(big)
+        # ... and the merge takes every text as a piece the moment it exists (post.PostStream: lines, upload, fingerprints beside the
+        # graph stage; the order-dependent rules at the end).  Piece 0 = the single contigs, piece 1 + i = partition i.
+        pstream, ps_failed, post_futs = None, [], []
+        if (sflow_beside and os.environ.get("SHN_POST_NATIVE", "1") != "0" and os.environ.get("SHN_POST_GPU", "1") != "0" and
+                os.environ.get("SHN_POST_STREAM", "1") != "0"):
+            try:
+                pstream = post.PostStream(ctx_b)
+            except _lib.ShannonError:
+                pstream = None
+
+        def post_piece(index, text):
+            if pstream is None or ps_failed:
+                return
+            try:
+                pstream.add(index, text)
+            except _lib.ShannonError as ex:                   # (no room, a last line without its end, ...: the merge in one piece below)
+                ps_failed.append(str(ex))
 
         def one_partition(name):
             """multibridged graph of one partition (multibridging.main for `name`); returns its record + timings"""
@@ -189,6 +206,7 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
                 t1 = time.time()
                 if name in big:
                     rec.fasta_raw = mbgraph_native.sparse_flow_native(ctx_b, [rec.graph], ["%s_%s" % (sample, name)], seed, raw=True, threaded=True)[0]
+                    post_piece(1 + part_index[name], rec.fasta_raw)
                 else:
                     with small_lock:
                         small_recs[name] = rec
@@ -200,6 +218,10 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
                                                                  seed, raw=True, threaded=True)
                         for nm, txt in zip(order_s, txts):
                             small_recs[nm].fasta_raw = txt
+                        if pstream is not None:               # (their pieces on whatever threads are free)
+                            pool_ = _graph_pool(graph_threads)
+                            with small_lock:
+                                post_futs.extend(pool_.submit(post_piece, 1 + part_index[nm], txt) for nm, txt in zip(order_s, txts))
                 tt["sparse flow"] = time.time() - t1
             if timeline is not None:
                 timeline[name] = (tt.pop("_t0") - t_graph, time.time() - t_graph, dict(tt), len(part["routes"][name]))
@@ -301,7 +323,11 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
                 # the partitions with the most routed reads first (the reference's size-sorted job list, shannon.py:546-551)
                 by_size = sorted(names, key=lambda nm: -len(part["routes"][nm]))
                 futs = {nm: pool.submit(one_partition, nm) for nm in by_size}
+                if pstream is not None:
+                    post_futs.append(pool.submit(post_piece, 0, single_text))
                 results = [futs[nm].result() for nm in names]
+                for f_ in list(post_futs):
+                    f_.result()
             else:
                 for nm in names:
                     results.append(one_partition(nm))
@@ -309,9 +335,11 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
             # a partition failed: nothing of this step may still run on the pool's threads when the inputs go away below
             if futs:
                 import concurrent.futures as _cf
-                for f_ in futs.values():
+                for f_ in list(futs.values()) + list(post_futs):
                     f_.cancel()
-                _cf.wait(list(futs.values()))
+                _cf.wait(list(futs.values()) + list(post_futs))
+            if pstream is not None:
+                pstream.close()
             # ... and the graphs already built go back now (device + host memory), not when the collector finds them
             built = [f.result()[0] for f in futs.values() if f.done() and not f.cancelled() and f.exception() is None] or [r[0] for r in results]
             for rec in built:
@@ -348,9 +376,13 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
             tick("sparse flow", t0)
             t0 = time.time()
             R._texts = [single_text] + texts                           # all_reconstructed.fasta: single contigs, then the partitions
+            streamed = pstream is not None and not ps_failed and len(pstream.keep) == len(names) + 1
+            if pstream is not None and not streamed:
+                pstream.close()
             if os.environ.get("SHN_POST_NATIVE", "1") != "0":
                 try:
-                    R.final = post.finalize_texts(R._texts, double_stranded, ctx=ctx_b)
+                    R.final = (pstream.finish(double_stranded, lazy=True) if streamed else
+                               post.finalize_texts(R._texts, double_stranded, ctx=ctx_b, lazy=True))
                 except _lib.ShannonError as ex:
                     if "non-ACGT" not in str(ex) and "empty line" not in str(ex):
                         raise

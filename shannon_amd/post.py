@@ -122,7 +122,159 @@ def finalize_native(all_lines, ds=True, r=24):
     return finalize_texts([blob], ds, r)
 
 
-def finalize_texts(texts, ds=True, r=24, ctx=None):
+class FinalTranscripts(object):
+    """{name: sequence} of the final file over the buffers the native merge exported (names, sequences, their offsets): a
+    read-only mapping whose strings are made when somebody asks for them -- 44,000 transcripts of 1.5 kb were 40-80 ms of str()
+    per step for a dict nobody may ever index.  Iteration, len(), [], in, .get(), .items(), .values(), == with any mapping work;
+    fasta() is the text of the final file."""
+
+    def __init__(self, names, name_off, seqs, seq_off):
+        self._n, self._no, self._s, self._so = names, name_off, seqs, seq_off
+        self._index = None
+
+    def __len__(self):
+        return len(self._no) - 1
+
+    def _name(self, i):
+        return str(memoryview(self._n)[int(self._no[i]):int(self._no[i + 1])], "ascii")
+
+    def _seq(self, i):
+        return str(memoryview(self._s)[int(self._so[i]):int(self._so[i + 1])], "ascii")
+
+    def __iter__(self):
+        return (self._name(i) for i in range(len(self)))
+
+    def keys(self):
+        return list(iter(self))
+
+    def values(self):
+        return [self._seq(i) for i in range(len(self))]
+
+    def items(self):
+        return [(self._name(i), self._seq(i)) for i in range(len(self))]
+
+    def _idx(self):
+        if self._index is None:
+            self._index = {self._name(i): i for i in range(len(self))}
+        return self._index
+
+    def __contains__(self, k):
+        return k in self._idx()
+
+    def __getitem__(self, k):
+        return self._seq(self._idx()[k])
+
+    def get(self, k, default=None):
+        i = self._idx().get(k)
+        return default if i is None else self._seq(i)
+
+    def __eq__(self, other):
+        try:
+            return dict(self.items()) == dict(other.items())
+        except AttributeError:
+            return NotImplemented
+
+    def __ne__(self, other):
+        r = self.__eq__(other)
+        return r if r is NotImplemented else not r
+
+    __hash__ = None
+
+    def __repr__(self):
+        return "FinalTranscripts(%d records)" % len(self)
+
+    def fasta(self):
+        """the final file (shannon.py:604): >name / sequence lines, as bytes"""
+        import numpy as np
+        n = len(self)
+        if not n:
+            return b""
+        no, so = np.asarray(self._no, dtype=np.int64), np.asarray(self._so, dtype=np.int64)
+        nl, sl = no[1:] - no[:-1], so[1:] - so[:-1]
+        rec = nl + sl + 3                                     # '>' name '\n' sequence '\n'
+        start = np.zeros(n + 1, dtype=np.int64)
+        start[1:] = np.cumsum(rec)
+        out = np.empty(int(start[-1]), dtype=np.uint8)
+        out[start[:-1]] = ord(">")
+        out[start[:-1] + 1 + nl] = 10
+        out[start[1:] - 1] = 10
+        # names and sequences: positions of their bytes in `out`
+        name_pos = np.repeat(start[:-1] + 1 - no[:-1], nl) + np.arange(int(no[-1]), dtype=np.int64)
+        out[name_pos] = np.asarray(self._n[:int(no[-1])])
+        seq_pos = np.repeat(start[:-1] + 2 + nl - so[:-1], sl) + np.arange(int(so[-1]), dtype=np.int64)
+        out[seq_pos] = np.asarray(self._s[:int(so[-1])])
+        return out.tobytes()
+
+
+def _export_post(h, lazy=False):
+    """the survivors of a native merge (shn_post handle) as {name: sequence} (lazy: a FinalTranscripts over the exported buffers);
+    frees the handle"""
+    import ctypes as C
+    import numpy as np
+    from . import _lib
+    L = _lib.lib()
+    try:
+        n = int(L.shn_post_count(h))
+        nb, sb = C.c_uint64(), C.c_uint64()
+        _lib.check(L.shn_post_sizes(h, C.byref(nb), C.byref(sb)))
+        names, seqs = np.empty(max(nb.value, 1), np.uint8), np.empty(max(sb.value, 1), np.uint8)
+        no, so = np.empty(n + 1, np.uint64), np.empty(n + 1, np.uint64)
+        _lib.check(L.shn_post_export(h, names.ctypes.data, no.ctypes.data, seqs.ctypes.data, so.ctypes.data))
+    finally:
+        L.shn_post_destroy(h)
+    if lazy:
+        return FinalTranscripts(names, no, seqs, so)
+    mn, ms = memoryview(names), memoryview(seqs)
+    no, so = no.tolist(), so.tolist()
+    return {str(mn[no[i]:no[i + 1]], "ascii"): str(ms[so[i]:so[i + 1]], "ascii") for i in range(n)}
+
+
+class PostStream(object):
+    """The merge fed piece by piece (shn_post_stream): add(index, text) from any thread as soon as a text exists -- lines, upload and
+    fingerprints of the piece right then --, finish(ds) runs the order-dependent rules over the pieces in index order.  The texts
+    are kept alive here until the stream is closed."""
+
+    def __init__(self, ctx, capacity=2 << 30):
+        import ctypes as C
+        from . import _lib
+        self.h = C.c_void_p()
+        _lib.check(_lib.lib().shn_post_stream_begin(ctx.h, int(capacity), C.byref(self.h)))
+        self.keep = {}
+
+    def add(self, index, text):
+        import numpy as np
+        from . import _lib
+        if isinstance(text, str):
+            text = text.encode()
+        b = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray, memoryview)) else np.ascontiguousarray(text, dtype=np.uint8)
+        self.keep[int(index)] = b
+        _lib.check(_lib.lib().shn_post_stream_add(self.h, int(index), b.ctypes.data if len(b) else None, len(b)))
+
+    def finish(self, ds=True, r=24, lazy=False):
+        import ctypes as C
+        from . import _lib
+        h = C.c_void_p()
+        _lib.check(_lib.lib().shn_post_stream_finish(self.h, 1 if ds else 0, int(r), C.byref(h)))
+        try:
+            return _export_post(h, lazy)
+        finally:
+            self.close()
+
+    def close(self):
+        if self.h:
+            from . import _lib
+            _lib.lib().shn_post_stream_destroy(self.h)
+            self.h = None
+            self.keep = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def finalize_texts(texts, ds=True, r=24, ctx=None, lazy=False):
     """the same over the concatenation of several texts (str, bytes or uint8 arrays: the per-partition FASTA as it leaves the
     native sparse-flow stage), without joining them (shn_post_finalize_bufs).  ctx (device.Context): the two passes over the
     bases -- sequence / reverse-complement fingerprints and the scan for the query 24-mers -- run on the device
@@ -144,19 +296,7 @@ def finalize_texts(texts, ds=True, r=24, ctx=None):
         _lib.check(L.shn_post_finalize_dev(ctx.h, ptrs, lens, len(bufs), 1 if ds else 0, r, C.byref(h)))
     else:
         _lib.check(L.shn_post_finalize_bufs(ptrs, lens, len(bufs), 1 if ds else 0, r, C.byref(h)))
-    try:
-        n = int(L.shn_post_count(h))
-        nb, sb = C.c_uint64(), C.c_uint64()
-        _lib.check(L.shn_post_sizes(h, C.byref(nb), C.byref(sb)))
-        names, seqs = np.empty(max(nb.value, 1), np.uint8), np.empty(max(sb.value, 1), np.uint8)
-        no, so = np.empty(n + 1, np.uint64), np.empty(n + 1, np.uint64)
-        _lib.check(L.shn_post_export(h, names.ctypes.data, no.ctypes.data, seqs.ctypes.data, so.ctypes.data))
-    finally:
-        L.shn_post_destroy(h)
-    # (every name / sequence decoded straight from its slice of the exported buffers: one copy of the text, not three)
-    mn, ms = memoryview(names), memoryview(seqs)
-    no, so = no.tolist(), so.tolist()
-    return {str(mn[no[i]:no[i + 1]], "ascii"): str(ms[so[i]:so[i + 1]], "ascii") for i in range(n)}
+    return _export_post(h, lazy)
 
 
 def finalize(all_lines, ds=True):
