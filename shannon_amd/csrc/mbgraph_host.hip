@@ -1379,7 +1379,7 @@ static int mbgraph_run_rows_impl(shn_ctx* ctx, const shn_unitigs* ug, uint32_t p
                                  const shn_reads* src_b, const uint8_t* host_a, const uint8_t* host_b, const uint32_t* didx, const uint32_t* d_didx,
                                  uint64_t n_reads, int paired, shn_graph** out) {
   if (!ug || part >= ug->n_parts) return shn_fail(SHN_ERR_ARG, "shn_mbgraph_run_rows: bad unitigs / partition");
-  if (!ctx || !src_a || !host_a || (n_reads && !didx) || (paired && (!src_b || !host_b)) || !src_a->fixed_len ||
+  if (!ctx || !src_a || !host_a || (n_reads && !didx && !d_didx) || (paired && (!src_b || !host_b)) || !src_a->fixed_len ||
       (paired && src_b->fixed_len != src_a->fixed_len))
     return shn_fail(SHN_ERR_ARG, "shn_mbgraph_run_rows: needs a context, fixed-length resident read sets and their host matrices");
   const bool dbg = getenv("SHN_GRAPH_LAPS") && n_reads >= strtoull(getenv("SHN_GRAPH_LAPS"), nullptr, 10);
@@ -1426,7 +1426,18 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double tt = now();
   // origin of read slot j = i * nm + mate (mate 0 / 1) in the resident input, for the device gather of the distinct reads
-  const bool resident = ctx && src_a && didx && src_a->fixed_len && (!paired || (src_b && src_b->fixed_len == src_a->fixed_len)) &&
+  // (the routed list may be given by its place on the device only: a form that wants it on the host fetches it first)
+  std::vector<uint32_t> didx_fetched;
+  auto need_didx = [&]() -> int {
+    if (didx || !d_didx || !n_reads) return 0;
+    didx_fetched.resize(n_reads);
+    hipError_t e_ = hipSetDevice(ctx->device);
+    if (e_ == hipSuccess) e_ = hipMemcpy(didx_fetched.data(), d_didx, n_reads * 4, hipMemcpyDeviceToHost);
+    if (e_ != hipSuccess) return shn_fail(SHN_ERR_HIP, std::string("shn_mbgraph_run_routes: ") + hipGetErrorString(e_));
+    didx = didx_fetched.data();
+    return 0;
+  };
+  const bool resident = ctx && src_a && (didx || d_didx) && src_a->fixed_len && (!paired || (src_b && src_b->fixed_len == src_a->fixed_len)) &&
                         n_reads && read_len0 == src_a->fixed_len && (host_a || getenv("SHN_GRAPH_RESIDENT_READS") == nullptr);
   if (resident) { g.src_a = src_a; g.src_b = paired ? src_b : nullptr; }
   const uint64_t N_in = src_a ? src_a->n_reads : 0;
@@ -1540,6 +1551,7 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
     g.acgt_known = 1;
     if (dbg) fprintf(stderr, "[mbgraph]   + rows of the distinct  %8.3f s\n", now() - t_dec);
   } else if (dev_dedup) {
+    { const int rcf = need_didx(); if (rcf) return rcf; }
     const uint64_t used = std::min<uint64_t>(n_reads, cutoff + 1);
     const int nm = paired ? 2 : 1;
     const uint64_t nh = used * nm, Lr = read_len0;
@@ -1612,6 +1624,7 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
     g.rcc.reserve(nr); g.rmate.reserve(nr); g.rmp.reserve(nr); g.rfirst.reserve(nr); g.rlast.reserve(nr); g.rhas.reserve(nr);
   }
   if (!dev_dedup) {
+    { const int rcf = need_didx(); if (rcf) return rcf; }
     // decode + hash on several host threads (independent per read), then intern sequentially in file order
     const uint64_t used = std::min<uint64_t>(n_reads, cutoff + 1);
     const int nm = paired ? 2 : 1;

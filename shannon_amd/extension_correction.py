@@ -347,16 +347,20 @@ class ContigGraph(object):
 def accept_filter(live, nr, nl, tw, k1, min_length, min_weight, arrays=False):
     """The accept filter of the extension loop (extension_correction.py:361) over non-void walks: ranks + contig lengths of
     the walks that pass, in seed order."""
-    length = k1 + nr.astype(np.int64) + nl.astype(np.int64)
-    sel = length >= min_length                                 # first clause of the accept filter (:361)
-    cand, clen = live[sel], length[sel]
+    steps = nr.astype(np.int64)
+    steps += nl
+    length = steps + k1
+    idx = np.nonzero(length >= min_length)[0]                  # first clause of the accept filter (:361)
+    cand, clen = live[idx], length[idx]
     thr = 2 * min_length * math.pow(min_weight, 1 / 4.0)
-    # second clause of :361, len * avg_wt**0.25 >= 2*min_length*min_weight**0.25: vectorised with a guard band;
-    # only candidates within 1e-9 (relative) of the threshold are decided with math.pow like the reference.
-    ckm = nr[sel].astype(np.int64) + nl[sel].astype(np.int64) + 1
-    ctw = tw[sel]
-    avg = ctw.astype(np.float64) / np.maximum(1, ckm)
-    lhs = clen.astype(np.float64) * np.power(avg, 0.25)
+    # second clause of :361, len * avg_wt**0.25 >= 2*min_length*min_weight**0.25: vectorised with a guard band (two square roots
+    # for the fourth root: a few ulp from pow, and four times as fast over 0.7 M candidates); only candidates within 1e-9 (relative)
+    # of the threshold are decided with math.pow like the reference.
+    ckm = steps[idx] + 1
+    ctw = tw[idx]
+    avg = ctw / np.maximum(1, ckm)
+    lhs = np.sqrt(np.sqrt(avg))
+    lhs *= clen
     sure = lhs >= thr * (1 + 1e-9)
     maybe = (~sure) & (lhs >= thr * (1 - 1e-9))
     for j in np.nonzero(maybe)[0].tolist():

@@ -377,10 +377,9 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
     lap("route.download")
     out = _finish_partitions(res, comps, broken, names, by_part, files, cw, k1, K, want_rows, lazy_graph_inputs, lap)
     out["flat_text"] = flat_text
-    if not lazy_routes:
-        # the routes also stay where the routing left them (1 GB at BASELINE configs[2]; freed with this dict): the graph stage's
-        # duplicate search reads a partition's list in place (shn_mbgraph_run_routes) -- {name: first entry of the partition}
-        out["routes_dev"] = (routes, {n: int(start[i]) for i, n in enumerate(names)})
+    # the routes also stay where the routing left them (1 GB at BASELINE configs[2]; freed with this dict): the graph stage's
+    # duplicate search reads a partition's list in place (shn_mbgraph_run_routes) -- {name: first entry of the partition}
+    out["routes_dev"] = (routes, {n: int(start[i]) for i, n in enumerate(names)})
     return out
 
 

@@ -181,17 +181,20 @@ def run_partition_rows(ctx, unitigs, part, d1, d2, host1, host2, didx, rows_byte
     routes = (Routes still on the device, index of didx[0] in them): the duplicate search reads the list where it lies
     (shn_mbgraph_run_routes)."""
     h = C.c_void_p()
-    didx = np.ascontiguousarray(didx, dtype=np.uint32)
     paired = d2 is not None
     for m in (host1, host2) if paired else (host1,):
         if not (isinstance(m, np.ndarray) and m.dtype == np.uint8 and m.ndim == 2 and m.flags["C_CONTIGUOUS"]):
             raise ValueError("run_partition_rows: host reads must be C-contiguous uint8 code matrices")
     if routes is not None and routes[0].h:
+        # didx may be an int: that many entries of the routes from routes[1] on, known by their place on the device only
+        n_idx = int(didx) if isinstance(didx, (int, np.integer)) else len(didx)
+        hd = None if isinstance(didx, (int, np.integer)) else np.ascontiguousarray(didx, dtype=np.uint32)
         _lib.check(_lib.lib().shn_mbgraph_run_routes(ctx.h, unitigs.h, int(part), rows_bytes.ctypes.data if rows_bytes is not None else None,
                                                      n_rows if rows_bytes is not None else 0, d1.h, d2.h if paired else None, host1.ctypes.data,
-                                                     host2.ctypes.data if paired else None, didx.ctypes.data, routes[0].h, int(routes[1]), len(didx),
-                                                     1 if paired else 0, C.byref(h)))
+                                                     host2.ctypes.data if paired else None, hd.ctypes.data if hd is not None else None, routes[0].h,
+                                                     int(routes[1]), n_idx, 1 if paired else 0, C.byref(h)))
         return GraphHandle(h)
+    didx = np.ascontiguousarray(didx, dtype=np.uint32)
     _lib.check(_lib.lib().shn_mbgraph_run_rows(ctx.h, unitigs.h, int(part), rows_bytes.ctypes.data if rows_bytes is not None else None,
                                                n_rows if rows_bytes is not None else 0, d1.h, d2.h if paired else None, host1.ctypes.data,
                                                host2.ctypes.data if paired else None, didx.ctypes.data, len(didx), 1 if paired else 0, C.byref(h)))

@@ -129,8 +129,15 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
     tick("extension", t0)
     t0 = time.time()
     gpu_unitigs = native_graph and K <= 31 and os.environ.get("SHN_GRAPH_GPU", "1") != "0"
+    # (reads kept as code matrices + GPU unitigs: the graph stage names a partition's reads by their place in the routes on the
+    # device, rows mode below -- the routed lists are then fetched per partition, only by the forms that want them on the host)
+    def _is_matrix(m):
+        return isinstance(m, np.ndarray) and m.dtype == np.uint8 and m.ndim == 2 and m.flags["C_CONTIGUOUS"]
+    rows_likely = (gpu_unitigs and d1 is not None and _is_matrix(getattr(store, "r1", None)) and (not paired or (d2 is not None and _is_matrix(getattr(store, "r2", None))))
+                   and os.environ.get("SHN_GRAPH_ROWS", "1") != "0" and not ss and not keep_partitioning)
     part = kfc.kmers_for_component(ctx, res, d1, d2, K, partition_size, overload, penalty, True, part_vectors,
-                                   want_rows=not native_graph, timings=T, lazy_graph_inputs=gpu_unitigs, strand_specific=ss)
+                                   want_rows=not native_graph, timings=T, lazy_graph_inputs=gpu_unitigs, strand_specific=ss,
+                                   lazy_routes=rows_likely)
     tick("partition+route", t0)
     if keep_partitioning:
         R.partitioning = part
@@ -234,8 +241,13 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
             t0 = time.time()
             n_kmers = unitigs.n_kmers(part_index[name]) if unitigs is not None else part["n_kmer_nodes"][name]
             cutoff = 10 * n_kmers + 1                                    # multibridging.py:26-30, 385-391
-            idx = part["routes"][name][:cutoff]
-            if native_graph and rows_mode and len(idx):
+            rts = part["routes"][name]
+            rdev_ = part.get("routes_dev")
+            by_place = (native_graph and rows_mode and rdev_ is not None and name in rdev_[1] and isinstance(rts, kfc.RouteView) and not check_rows)
+            idx = min(len(rts), cutoff) if by_place else rts[:cutoff]       # (by place: the count is all the host needs)
+            if by_place and idx == 0:
+                by_place, idx = False, np.zeros(0, np.uint32)
+            if native_graph and rows_mode and (idx if by_place else len(idx)):
                 # the reads named by their rows: distinct reads found on the device, their text decoded from the host matrices
                 rb = None
                 if check_rows:
@@ -244,7 +256,7 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
                 rdev = part.get("routes_dev")                             # (the same list, still on the device: idx is a prefix of the partition's)
                 def run_rows(rb):
                     return mbgraph_native.run_partition_rows(ctx_b, unitigs, part_index[name], d1, d2, store.r1, store.r2 if paired else None,
-                                                             np.asarray(idx, dtype=np.uint32), rb if (rb is not None and len(rb)) else None,
+                                                             idx if by_place else np.asarray(idx, dtype=np.uint32), rb if (rb is not None and len(rb)) else None,
                                                              0 if rb is None else len(rb) // (K + 1),
                                                              routes=(rdev[0], rdev[1][name]) if (rdev is not None and name in rdev[1]) else None)
                 try:
