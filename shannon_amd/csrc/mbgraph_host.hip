@@ -177,14 +177,17 @@ struct Graph {
   void decode_lazy(int r) const {
     const uint8_t* p = ((origin_flag[r] & 1) ? lz_b : lz_a) + (uint64_t)origin_row[r] * lz_L;
     decode_read(lz_buf + (size_t)r * lz_L, p, lz_L, SHN_ENC_CODES, (origin_flag[r] & 2) != 0);
-    lz_done[(size_t)r >> 6] |= 1ULL << (r & 63);
+    // (several threads may ask for text at once -- the X-nodes of a bridging pass: two of them decoding one read write the same
+    // bytes; the bit is set after the text, with release / acquire order)
+    __atomic_fetch_or(&lz_done[(size_t)r >> 6], 1ULL << (r & 63), __ATOMIC_RELEASE);
   }
+  bool lz_has(size_t r) const { return (__atomic_load_n(&lz_done[r >> 6], __ATOMIC_ACQUIRE) >> (r & 63)) & 1; }
   void ensure_all_text() const {
     if (!lz_buf) return;
     const size_t n = n_rd();
     const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::max(1, shn_host_cpus() / 2), n >> 16));
     auto work = [&](size_t lo, size_t hi) {                       // (whole 64-read words per thread: the done bits are not shared)
-      for (size_t r = lo; r < hi; r++) if (!((lz_done[r >> 6] >> (r & 63)) & 1)) decode_lazy((int)r);
+      for (size_t r = lo; r < hi; r++) if (!lz_has(r)) decode_lazy((int)r);
     };
     if (nt <= 1) { work(0, n); return; }
     std::vector<std::thread> th;
@@ -194,7 +197,7 @@ struct Graph {
   }
   RStr rstr(int r) const {
     if (lz_buf) {
-      if (!((lz_done[(size_t)r >> 6] >> (r & 63)) & 1)) decode_lazy(r);
+      if (!lz_has((size_t)r)) decode_lazy(r);
       return RStr{lz_buf + (size_t)r * lz_L, lz_L};
     }
     return RStr{rindex.data(r), rindex.len(r)};
@@ -202,7 +205,7 @@ struct Graph {
   // the text of read r is about to be asked for: its cache lines (or, not yet decoded, the lines of its row) on their way
   void prefetch_read(int r) const {
     if (lz_buf) {
-      if (!((lz_done[(size_t)r >> 6] >> (r & 63)) & 1)) {
+      if (!lz_has((size_t)r)) {
         const uint8_t* p = ((origin_flag[r] & 1) ? lz_b : lz_a) + (uint64_t)origin_row[r] * lz_L;
         __builtin_prefetch(p); __builtin_prefetch(p + 64);
         return;
@@ -759,6 +762,30 @@ struct Graph {
     while (true) {
       std::vector<int> todo;
       double t0 = nowb();
+      {
+        // the X-nodes whose last answer does not stand any more: each one's question touches its own read list and memo only (and
+        // read text, see decode_lazy), so they are asked on the host threads that are free right now -- late in the stage, when the
+        // largest partition is at its bridging alone, that is most of them
+        std::vector<int> stale;
+        if (bridged_memo.size() < bases.size()) bridged_memo.resize(bases.size());
+        for (int n : order) if (is_xnode(n)) {
+          const BridgedMemo& memo = bridged_memo[n];
+          if (!(memo.n_reads == nreads[n].size() && memo.in == ine[n] && memo.out == oute[n])) stale.push_back(n);
+        }
+        size_t work = 0;
+        for (int n : stale) work += nreads[n].size();
+        const unsigned want = work >= 50000 && stale.size() >= 8 ? (unsigned)std::min<size_t>(8, stale.size() / 4) : 1u;
+        const unsigned nt = want > 1 ? (unsigned)g_host_threads.take_free((int)want, g_partitions_running.load() - 1) : 1u;
+        struct GiveBackA { unsigned n; ~GiveBackA() { if (n) g_host_threads.release((int)n); } } give_back_a{want > 1 ? nt : 0u};
+        if (nt > 1) {
+          std::atomic<size_t> next{0};
+          auto ask = [&]() { for (size_t i; (i = next.fetch_add(1)) < stale.size();) (void)is_bridged_xnode(stale[i]); };
+          std::vector<std::thread> th;
+          for (unsigned t = 1; t < nt; t++) th.emplace_back(ask);
+          ask();
+          for (auto& x : th) x.join();
+        }
+      }
       for (int n : order) if (is_xnode(n)) { n_ask++; if (is_bridged_xnode(n)) todo.push_back(n); }
       double t1 = nowb();
       for (int n : todo) { int rc = bridging_step(n); if (rc) return rc; }

@@ -27,9 +27,55 @@ __device__ __forceinline__ uint64_t probe_key(const RView& v, uint64_t r, uint32
   return shn_revcomp(shn_extract(v.words + wb, len - k - pos, k), k);
 }
 
+// ---- the probe table as a one-line dictionary (the scheme of the adjacency build, extend.hip): a 128-byte line holds ten keys (80
+// bytes), their ten values (40 bytes) and the number of keys that hashed there; four keys per line on average, a full line sends
+// its keys on to the next (PD_HOPS of them, then the table itself).  HBM serves 128 bytes per request whatever is asked for, and a
+// probe through the table was three requests (bucket offsets, keys, value): 186 GB per launch for 19 GB of algorithmic bytes.
+// The line of a key grows with the key's hash, i.e. with its bucket: the build goes through the table front to back and its
+// atomics stay in the L2.
+#define PD_SLOTS 10
+#define PD_PER_LINE 4
+#define PD_HOPS 4
+struct ProbeDict { const unsigned long long* lines; uint64_t n_lines; };
+__global__ void pd_build_kernel(const uint64_t* __restrict__ tkeys, const uint32_t* __restrict__ tvals, uint64_t n, unsigned long long* __restrict__ lines,
+                                uint64_t n_lines) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t key = tkeys[i];
+  unsigned long long* line = lines + __umul64hi(shn_mix64(key), n_lines) * 16;
+  for (int hop = 0; hop < PD_HOPS; hop++, line += 16) {
+    const uint32_t slot = atomicAdd((uint32_t*)line + 30, 1u);
+    if (slot < PD_SLOTS) { line[slot] = key; ((uint32_t*)line)[20 + slot] = tvals[i]; break; }
+  }
+}
+// value of `key` (table values are >= 1) or 0
+__device__ __forceinline__ uint32_t pd_find(const ProbeDict& D, uint64_t key, int k, const uint64_t* __restrict__ tkeys, const uint32_t* __restrict__ tvals,
+                                            const uint64_t* __restrict__ boff, int bits) {
+  uint64_t line = __umul64hi(shn_mix64(key), D.n_lines);
+  for (int hop = 0; hop < PD_HOPS; hop++, line++) {
+    const ulonglong2* L = (const ulonglong2*)(D.lines + line * 16);
+    const ulonglong2 q0 = L[0], q1 = L[1], q2 = L[2], q3 = L[3], q4 = L[4], v0 = L[5], v1 = L[6], v2 = L[7];
+    const uint32_t cnt = (uint32_t)v2.y;                               // word 30
+    const uint32_t nk = cnt < PD_SLOTS ? cnt : PD_SLOTS;
+    int slot = -1;
+    if (nk > 0 && q0.x == key) slot = 0; else if (nk > 1 && q0.y == key) slot = 1;
+    else if (nk > 2 && q1.x == key) slot = 2; else if (nk > 3 && q1.y == key) slot = 3;
+    else if (nk > 4 && q2.x == key) slot = 4; else if (nk > 5 && q2.y == key) slot = 5;
+    else if (nk > 6 && q3.x == key) slot = 6; else if (nk > 7 && q3.y == key) slot = 7;
+    else if (nk > 8 && q4.x == key) slot = 8; else if (nk > 9 && q4.y == key) slot = 9;
+    if (slot >= 0) {
+      const unsigned long long w = slot < 2 ? v0.x : slot < 4 ? v0.y : slot < 6 ? v1.x : slot < 8 ? v1.y : v2.x;   // words 20 + slot: two per 64-bit word
+      return (slot & 1) ? (uint32_t)(w >> 32) : (uint32_t)w;
+    }
+    if (cnt <= PD_SLOTS) return 0u;
+  }
+  const int64_t j = shn_table_find_k(tkeys, boff, bits, key, 2 * k);  // (PD_HOPS full lines in a row)
+  return j >= 0 ? tvals[j] : 0u;
+}
+
 // collects the partitions hit by one read into loc[] (dedup), returns new count
 __device__ __forceinline__ int collect(const RView& v, uint64_t r, bool rc, int k, const uint64_t* __restrict__ tkeys,
-                                       const uint32_t* __restrict__ tvals, const uint64_t* __restrict__ boff, int bits,
+                                       const uint32_t* __restrict__ tvals, const uint64_t* __restrict__ boff, int bits, const ProbeDict& D,
                                        const uint32_t* __restrict__ set_off, const uint32_t* __restrict__ set_mem,
                                        uint32_t* loc, int nloc, uint32_t* overflow) {
   uint32_t len = v.len ? v.len[r] : v.fixed_len;
@@ -45,9 +91,10 @@ __device__ __forceinline__ int collect(const RView& v, uint64_t r, bool rc, int 
     else if (!last_done) { pos = len - k; last_done = true; }
     else break;
     uint64_t key = probe_key(v, r, len, pos, k, rc);
-    int64_t j = shn_table_find_k(tkeys, boff, bits, key, 2 * k);
-    if (j >= 0) {
-      uint32_t sid = tvals[j] - 1;
+    const uint32_t val = D.lines ? pd_find(D, key, k, tkeys, tvals, boff, bits) : 0u;
+    int64_t j = D.lines ? -1 : shn_table_find_k(tkeys, boff, bits, key, 2 * k);
+    if (val || j >= 0) {
+      uint32_t sid = (val ? val : tvals[j]) - 1;
       for (uint32_t m = set_off[sid]; m < set_off[sid + 1]; m++) {
         uint32_t p = set_mem[m];
         bool seen = false;
@@ -61,7 +108,7 @@ __device__ __forceinline__ int collect(const RView& v, uint64_t r, bool rc, int 
 
 template <bool FILL>
 __global__ __launch_bounds__(RBLK) void route_kernel(RView a, RView b, int paired, int ss, int k, const uint64_t* __restrict__ tkeys,
-                                                     const uint32_t* __restrict__ tvals, const uint64_t* __restrict__ boff, int bits,
+                                                     const uint32_t* __restrict__ tvals, const uint64_t* __restrict__ boff, int bits, ProbeDict D,
                                                      const uint32_t* __restrict__ set_off, const uint32_t* __restrict__ set_mem,
                                                      uint32_t* __restrict__ counts, const uint64_t* __restrict__ offs,
                                                      uint64_t* __restrict__ out, uint32_t* __restrict__ overflow, uint2* __restrict__ first2) {
@@ -86,18 +133,18 @@ __global__ __launch_bounds__(RBLK) void route_kernel(RView a, RView b, int paire
     // -s / --ss (shannon.py:407-411): the read files are reads (SE) or reads_1 and RC(reads_2) (PE), not doubled: index d < N only
     dropped = second || (a.bad && a.bad[i]) || (paired && b.bad && b.bad[i]);
     if (!dropped) {
-      nloc = collect(a, i, false, k, tkeys, tvals, boff, bits, set_off, set_mem, loc, nloc, overflow);
-      if (paired) nloc = collect(b, i, true, k, tkeys, tvals, boff, bits, set_off, set_mem, loc, nloc, overflow);
+      nloc = collect(a, i, false, k, tkeys, tvals, boff, bits, D, set_off, set_mem, loc, nloc, overflow);
+      if (paired) nloc = collect(b, i, true, k, tkeys, tvals, boff, bits, D, set_off, set_mem, loc, nloc, overflow);
     }
   } else if (!paired) {
     dropped = a.bad && a.bad[i];
-    if (!dropped) nloc = collect(a, i, second, k, tkeys, tvals, boff, bits, set_off, set_mem, loc, nloc, overflow);
+    if (!dropped) nloc = collect(a, i, second, k, tkeys, tvals, boff, bits, D, set_off, set_mem, loc, nloc, overflow);
   } else {
     const RView& src = second ? b : a;        // d<N: (R1, RC(R1)); d>=N: (RC(R2), R2)
     dropped = src.bad && src.bad[i];
     if (!dropped) {
-      nloc = collect(src, i, second, k, tkeys, tvals, boff, bits, set_off, set_mem, loc, nloc, overflow);   // mate 1
-      nloc = collect(src, i, !second, k, tkeys, tvals, boff, bits, set_off, set_mem, loc, nloc, overflow);  // mate 2
+      nloc = collect(src, i, second, k, tkeys, tvals, boff, bits, D, set_off, set_mem, loc, nloc, overflow);   // mate 1
+      nloc = collect(src, i, !second, k, tkeys, tvals, boff, bits, D, set_off, set_mem, loc, nloc, overflow);  // mate 2
     }
   }
   if (!FILL) { counts[d] = (uint32_t)nloc; if (first2) first2[d] = make_uint2(nloc > 0 ? loc[0] : 0u, nloc > 1 ? loc[1] : 0u); return; }
@@ -226,10 +273,22 @@ extern "C" int shn_route_reads_mode(shn_ctx* ctx, const shn_reads* r1, const shn
   R->device = ctx->device;
   if (N2 == 0) { *out = R; return SHN_OK; }
   uint32_t grid = (uint32_t)cdiv(N2, RBLK);
+  // the one-line dictionary over the probe table (SHN_ROUTE_DICT=0: probes through the table)
+  ProbeDict D{nullptr, 0};
+  if (probe->n >= 4096 && !(getenv("SHN_ROUTE_DICT") && getenv("SHN_ROUTE_DICT")[0] == '0')) {
+    const uint64_t n_lines = probe->n / PD_PER_LINE + 1;
+    void* pl;
+    if (g_shn_ws[31].get((n_lines + PD_HOPS + 1) * 128, &pl) == 0) {
+      HIP_TRY(hipMemsetAsync(pl, 0, (n_lines + PD_HOPS + 1) * 128, s));
+      hipLaunchKernelGGL(pd_build_kernel, dim3((uint32_t)cdiv(probe->n, 256)), dim3(256), 0, s, (const uint64_t*)probe->d_keys, (const uint32_t*)probe->d_counts,
+                         probe->n, (unsigned long long*)pl, n_lines);
+      D.lines = (const unsigned long long*)pl; D.n_lines = n_lines;
+    } else (void)hipGetLastError();
+  }
   void* pf2 = nullptr;
   uint2* d_first2 = g_shn_ws[30].get((N2 + 1) * 8, &pf2) == 0 ? (uint2*)pf2 : nullptr;          // (without it the second pass probes again)
   hipLaunchKernelGGL(route_kernel<false>, dim3(grid), dim3(RBLK), 0, s, a, b, r2 ? 1 : 0, strand_specific ? 1 : 0, k1, probe->d_keys, probe->d_counts,
-                     probe->d_bucket_off, probe->bits, d_so, d_sm, (uint32_t*)pcnt, nullptr, nullptr, d_ovf, d_first2);
+                     probe->d_bucket_off, probe->bits, D, d_so, d_sm, (uint32_t*)pcnt, nullptr, nullptr, d_ovf, d_first2);
   uint64_t total = 0;
   if ((rc = shn_device_scan_u32(ctx, (uint32_t*)pcnt, N2, (uint64_t*)poff, &total))) { delete R; return rc; }
   uint32_t ovf = 0;
@@ -243,7 +302,7 @@ extern "C" int shn_route_reads_mode(shn_ctx* ctx, const shn_reads* r1, const shn
       (rc = g_shn_ws[10].get((total + 2) * 4, &pv)) || (rc = g_shn_ws[12].get((total + 2) * 4, &pv2))) { delete R; return rc; }
   if (total) {
     hipLaunchKernelGGL(route_kernel<true>, dim3(grid), dim3(RBLK), 0, s, a, b, r2 ? 1 : 0, strand_specific ? 1 : 0, k1, probe->d_keys, probe->d_counts,
-                       probe->d_bucket_off, probe->bits, d_so, d_sm, (uint32_t*)pcnt, (const uint64_t*)poff, (uint64_t*)pk, d_ovf, d_first2);
+                       probe->d_bucket_off, probe->bits, D, d_so, d_sm, (uint32_t*)pcnt, (const uint64_t*)poff, (uint64_t*)pk, d_ovf, d_first2);
     // pairs were written in doubled-read order; a stable sort on the partition id keeps that order
     HIP_TRY(hipMemsetAsync(pv, 0, total * 4, s));
     int pbits = 1;
