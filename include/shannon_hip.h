@@ -178,6 +178,12 @@ int shn_ext_live_stats(shn_ctx* ctx, const shn_ext* e, uint64_t* n_live, uint32_
  * extension_correction.py:361, applied before the download.                                                                      */
 int shn_ext_live_stats_min(shn_ctx* ctx, const shn_ext* e, uint32_t min_steps, uint64_t* n_live, uint32_t* rank, uint32_t* n_right,
                            uint32_t* n_left, uint64_t* tot_weight);
+/* The accept filter of the extension loop (extension_correction.py:361: len >= min_length and len * avg_weight ** 0.25 >= threshold,
+ * threshold = 2 * min_length * min_weight ** 0.25) over the non-void walks, in seed order: rank, steps (= n_right + n_left; the contig
+ * has k1 + steps bases), tot_weight and cls per candidate -- cls 1: passes for sure, 2: within 1e-9 (relative) of the threshold, for
+ * the caller to decide with the reference's own arithmetic.  *n_out: in = room of the arrays (NULL arrays: sizing call), out = count. */
+int shn_ext_accept(shn_ctx* ctx, const shn_ext* e, uint32_t min_length, double threshold, uint64_t* n_out, uint32_t* rank, uint32_t* steps,
+                   uint64_t* tot_weight, uint8_t* cls);
 
 /* Host-side (CPU, native) contig bookkeeping of run_correction over the contigs emitted above:
  * duplicate_check (extension_correction.py:247-270, r=15, f=0.5) and the contig graph by shared

@@ -112,6 +112,7 @@ SIGNATURES = {
     "shn_ext_seed_info": (C.c_int, [vp, vp, vp, C.c_uint64, vp, vp]),
     "shn_ext_live_stats": (C.c_int, [vp, vp, u64p, vp, vp, vp, vp]),
     "shn_ext_live_stats_min": (C.c_int, [vp, vp, C.c_uint32, u64p, vp, vp, vp, vp]),
+    "shn_ext_accept": (C.c_int, [vp, vp, C.c_uint32, C.c_double, u64p, vp, vp, vp, vp]),
     "shn_ext_stats": (C.c_int, [vp, vp, vp, vp, vp]),
     "shn_ext_stats_range": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, vp, vp, vp]),
     "shn_ext_set_block_callback": (None, [vp, vp]),

@@ -1797,6 +1797,74 @@ extern "C" int shn_ext_live_stats_min(shn_ctx* ctx, const shn_ext* e, uint32_t m
   return SHN_OK;
 }
 
+// ---- the accept filter itself (extension_correction.py:361: len >= min_length and len * avg_weight ** 0.25 >= threshold) over the
+// non-void walks, in seed order: class 1 = passes for sure, 2 = within 1e-9 (relative) of the threshold -- the caller decides those
+// few with the reference's own arithmetic (math.pow); two square roots here stand for the fourth root, a few ulp from pow.
+__global__ void ext_accept_flag_kernel(const uint32_t* __restrict__ nr, const uint32_t* __restrict__ nl, const uint64_t* __restrict__ totw, uint64_t ns,
+                                       int k, uint32_t min_length, double thr, uint32_t* __restrict__ flag) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= ns) return;
+  const uint32_t a = nr[r];
+  uint32_t f = 0;
+  if (a != UNCLAIMED) {
+    const uint64_t steps = (uint64_t)a + nl[r], len = steps + (uint64_t)k;
+    if (len >= min_length) {
+      const double avg = (double)totw[r] / (double)(steps + 1);
+      const double lhs = (double)len * sqrt(sqrt(avg));
+      f = lhs >= thr * (1.0 - 1e-9) ? 1u : 0u;
+    }
+  }
+  flag[r] = f;
+}
+__global__ void ext_accept_gather_kernel(const uint32_t* __restrict__ nr, const uint32_t* __restrict__ nl, const uint64_t* __restrict__ totw,
+                                         const uint64_t* __restrict__ pos, uint64_t ns, int k, double thr, uint32_t* __restrict__ o_rank,
+                                         uint32_t* __restrict__ o_steps, uint64_t* __restrict__ o_tw, uint8_t* __restrict__ o_cls) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= ns) return;
+  const uint64_t p = pos[r];
+  if (pos[r + 1] == p) return;
+  const uint64_t steps = (uint64_t)nr[r] + nl[r];
+  const double lhs = (double)(steps + (uint64_t)k) * sqrt(sqrt((double)totw[r] / (double)(steps + 1)));
+  o_rank[p] = (uint32_t)r; o_steps[p] = (uint32_t)steps; o_tw[p] = totw[r];
+  o_cls[p] = lhs >= thr * (1.0 + 1e-9) ? 1 : 2;
+}
+// n_out: in = room of the output arrays (0 with NULL arrays: a sizing call), out = candidates; rank / steps (= n_right + n_left) /
+// tot_weight / cls per candidate, in seed order
+extern "C" int shn_ext_accept(shn_ctx* ctx, const shn_ext* e, uint32_t min_length, double threshold, uint64_t* n_out, uint32_t* rank, uint32_t* steps,
+                              uint64_t* tot_weight, uint8_t* cls) {
+  if (!ctx || !e || !n_out) return shn_fail(SHN_ERR_ARG, "shn_ext_accept: NULL argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const uint64_t ns = e->n_seeds;
+  if (!ns) { *n_out = 0; return SHN_OK; }
+  void *pf, *pp, *po;
+  int rc;
+  if ((rc = g_shn_ws[9].get((ns + 1) * 4, &pf)) || (rc = g_shn_ws[11].get((ns + 2) * 8, &pp))) return rc;
+  uint32_t* flag = (uint32_t*)pf;
+  uint64_t* pos = (uint64_t*)pp;
+  hipLaunchKernelGGL(ext_accept_flag_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, e->d_nr, e->d_nl, e->d_totw, ns, e->k, min_length, threshold, flag);
+  uint64_t total = 0;
+  if ((rc = shn_device_scan_u32(ctx, flag, ns, pos, &total))) return rc;
+  if (!rank) { *n_out = total; return SHN_OK; }
+  if (*n_out < total || !steps || !tot_weight || !cls) return shn_fail(SHN_ERR_ARG, "shn_ext_accept: output arrays too small");
+  *n_out = total;
+  if (!total) return SHN_OK;
+  if ((rc = g_shn_ws[10].get(total * 17 + 64, &po))) return rc;
+  uint64_t* o_tw = (uint64_t*)po;
+  uint32_t* o_rank = (uint32_t*)(o_tw + total);
+  uint32_t* o_steps = o_rank + total;
+  uint8_t* o_cls = (uint8_t*)(o_steps + total);
+  hipLaunchKernelGGL(ext_accept_gather_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, e->d_nr, e->d_nl, e->d_totw, pos, ns, e->k, threshold, o_rank,
+                     o_steps, o_tw, o_cls);
+  HIP_TRY(hipMemcpyAsync(rank, o_rank, total * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(steps, o_steps, total * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(tot_weight, o_tw, total * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(cls, o_cls, total, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipGetLastError());
+  return SHN_OK;
+}
+
 // seed string (oriented k1-mer key) and seed weight of the given walks: the global order of the walks is
 // (weight descending, key ascending), which is what merges the candidates of several shards
 __global__ void ext_seed_info_kernel(const uint32_t* __restrict__ ranks, uint64_t n, const uint32_t* __restrict__ order,

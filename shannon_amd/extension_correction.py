@@ -132,6 +132,28 @@ class Extension(object):
             _lib.check(L.shn_ext_live_stats_min(self.ctx.h, self.h, ms, C.byref(n), rank.ctypes.data, nr.ctypes.data, nl.ctypes.data, tw.ctypes.data))
         return rank[:m], nr[:m], nl[:m], tw[:m]
 
+    def accept(self, k1, min_length, min_weight):
+        """(ranks uint32, contig lengths int64) of the walks that pass the accept filter (extension_correction.py:361), in seed
+        order: decided on the device (shn_ext_accept), the candidates within 1e-9 of the threshold with math.pow here."""
+        L = _lib.lib()
+        thr = 2 * min_length * math.pow(min_weight, 1 / 4.0)
+        n = C.c_uint64(0)
+        _lib.check(L.shn_ext_accept(self.ctx.h, self.h, int(min_length), float(thr), C.byref(n), None, None, None, None))
+        m = n.value
+        rank = np.empty(max(m, 1), np.uint32); steps = np.empty(max(m, 1), np.uint32)
+        tw = np.empty(max(m, 1), np.uint64); cls = np.empty(max(m, 1), np.uint8)
+        if m:
+            _lib.check(L.shn_ext_accept(self.ctx.h, self.h, int(min_length), float(thr), C.byref(n), rank.ctypes.data, steps.ctypes.data, tw.ctypes.data,
+                                        cls.ctypes.data))
+        rank, steps, tw, cls = rank[:m], steps[:m], tw[:m], cls[:m]
+        keep = cls == 1
+        for j in np.nonzero(cls == 2)[0].tolist():
+            a = float(int(tw[j])) / max(1, int(steps[j]) + 1)
+            keep[j] = (int(steps[j]) + k1) * math.pow(a, 1 / 4.0) >= thr
+        if not keep.all():
+            rank, steps = rank[keep], steps[keep]
+        return rank, steps.astype(np.int64) + k1
+
     def emit_raw(self, ranks, lengths, reuse=False):
         """(ASCII bases uint8[total], offsets uint64[n+1]) of the contigs of the selected walks.  reuse: the bases land in a
         buffer this thread keeps from call to call (valid until its next such call) -- 300 MB of fresh pages per step cost more
@@ -567,13 +589,17 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
         keep = None
     else:
         # non-void walks long enough for the accept filter's length clause, in seed order (compacted on the GPU)
-        live, nr, nl, tw = ext.live_stats(min_length - k1)
-        lap("ext.filter.stats")
-        if gpu_contigs or gpu_sharded:
-            keep_r, keep_l = accept_filter(live, nr, nl, tw, k1, min_length, min_weight, arrays=True)
+        if (gpu_contigs or gpu_sharded) and os.environ.get("SHN_EXT_ACCEPT_DEVICE", "1") != "0":
+            keep_r, keep_l = ext.accept(k1, min_length, min_weight)           # (the filter itself on the device)
             keep = None
         else:
-            keep = accept_filter(live, nr, nl, tw, k1, min_length, min_weight)
+            live, nr, nl, tw = ext.live_stats(min_length - k1)
+            lap("ext.filter.stats")
+            if gpu_contigs or gpu_sharded:
+                keep_r, keep_l = accept_filter(live, nr, nl, tw, k1, min_length, min_weight, arrays=True)
+                keep = None
+            else:
+                keep = accept_filter(live, nr, nl, tw, k1, min_length, min_weight)
     lap("ext.filter")
     csr = None                                         # (coff, cnb, cw): connections in dict insertion order, 1-based neighbours
     contigs = ["buffer"]
