@@ -331,6 +331,7 @@ static int contig_stage_impl(shn_ctx* ctx, const uint8_t* bases, const uint8_t* 
     if (getenv("SHN_CONTIG_PAIR_LOG2")) lg_slots = atoi(getenv("SHN_CONTIG_PAIR_LOG2"));     // (tests: start too small, grow)
     PairSlot* d_tab = nullptr;
     HIP_TRY(tmp.get(&d_tab, sizeof(PairSlot) << lg_slots));
+    const int lg_small = getenv("SHN_CONTIG_PAIR_SMALL_LOG2") ? atoi(getenv("SHN_CONTIG_PAIR_SMALL_LOG2")) : 20;   // pair table of the rounds after a block's first
     uint64_t blk0 = std::max<uint64_t>(1024, n_cand / 16);          // (n / 256: 23 rounds, 0.75 s at 731 k candidates; n / 16: 0.66 s; one block: 0.68 s)
     if (getenv("SHN_CONTIG_BLOCK0")) blk0 = std::max<uint64_t>(1, strtoull(getenv("SHN_CONTIG_BLOCK0"), nullptr, 10));
     const int max_rounds = getenv("SHN_CONTIG_MAX_ROUNDS") ? std::max(1, atoi(getenv("SHN_CONTIG_MAX_ROUNDS"))) : 64;   // (tests: halve blocks early)
@@ -340,6 +341,7 @@ static int contig_stage_impl(shn_ctx* ctx, const uint8_t* bases, const uint8_t* 
       // the candidates of the block start as "not accepted": the first round meets the frozen earlier blocks only
       int round = 0;
       uint64_t na = 0;
+      unsigned long long last_changed = 0;
       if (nv) {
         hipLaunchKernelGGL(cg_accflag_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, d_scid, d_acc, nv, (uint32_t)lo, (uint32_t)hi, d_flag);
         if ((rc = shn_device_scan_u32(ctx, d_flag, nv, d_apos, &na))) return rc;
@@ -360,20 +362,31 @@ static int contig_stage_impl(shn_ctx* ctx, const uint8_t* bases, const uint8_t* 
         }
         HIP_TRY(hipMemsetAsync(d_chg, 0, 8, s));
         if (na) {
+          // (a round after a block's first re-evaluates the few candidates whose view changed -- tens to thousands of 10^5: its pairs
+          // fit a table a hundredth the size, and clearing and scanning the full 2 GB table was most of such a round)
+          const bool small_round = round > 0 && incremental;
+          int lg_use = lg_slots;
+          if (small_round) {                         // (room for 4,096 pairs per decision that changed in the round before; at least 2^lg_small slots)
+            lg_use = lg_small;
+            while (lg_use < lg_slots && (1ULL << lg_use) < last_changed * 4096ULL) lg_use++;
+            lg_use = std::min(lg_use, lg_slots);
+          }
           while (true) {                             // (the pair table grows until the round's pairs fit)
-            HIP_TRY(hipMemsetAsync(d_tab, 0, sizeof(PairSlot) << lg_slots, s));
+            HIP_TRY(hipMemsetAsync(d_tab, 0, sizeof(PairSlot) << lg_use, s));
             HIP_TRY(hipMemsetAsync(d_ovf, 0, 4, s));
             hipLaunchKernelGGL(cg_hits_kernel, dim3(grid_for(na)), dim3(CG_BLK), 0, s, d_akey, d_acand, d_aval, na, d_off, (uint32_t)lo, d_acc, d_aff,
-                               d_tab, (1ULL << lg_slots) - 1, d_ovf);
+                               d_tab, (1ULL << lg_use) - 1, d_ovf);
             uint32_t ovf = 0;
             HIP_TRY(hipMemcpyAsync(&ovf, d_ovf, 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
             if (!ovf) break;
+            if (lg_use < lg_slots) { lg_use = lg_slots; continue; }                          // (the whole table that is there)
             if (lg_slots >= 31) return shn_fail(SHN_ERR_OVERFLOW, "shn_contig_stage: pair table beyond 2^31 slots");
             lg_slots += 2;
+            lg_use = lg_slots;
             HIP_TRY(tmp.get(&d_tab, sizeof(PairSlot) << lg_slots));
           }
-          hipLaunchKernelGGL(cg_best_kernel, dim3(grid_for(1ULL << lg_slots)), dim3(CG_BLK), 0, s, d_tab, 1ULL << lg_slots, d_best);
+          hipLaunchKernelGGL(cg_best_kernel, dim3(grid_for(1ULL << lg_use)), dim3(CG_BLK), 0, s, d_tab, 1ULL << lg_use, d_best);
           hipLaunchKernelGGL(cg_cover_kernel, dim3(grid_for(na)), dim3(CG_BLK), 0, s, d_akey, d_acand, d_aval, na, (uint32_t)lo, d_best, d_aff, d_hit);
           hipLaunchKernelGGL(cg_covsum_kernel, dim3(grid_for(off[hi] - off[lo])), dim3(CG_BLK), 0, s, d_hit, d_cid, d_off, off[lo], off[hi], r, d_aff, d_cov);
         }
@@ -383,6 +396,7 @@ static int contig_stage_impl(shn_ctx* ctx, const uint8_t* bases, const uint8_t* 
         HIP_TRY(hipStreamSynchronize(s));
         n_rounds++;
         round++;
+        last_changed = changed;
         if (dbg) fprintf(stderr, "[contig_stage]   block [%llu,%llu) round %d: %llu accepted entries, %llu decisions changed\n", (unsigned long long)lo,
                          (unsigned long long)hi, round, (unsigned long long)na, changed);
         if (!changed) break;
