@@ -422,3 +422,27 @@ def test_bulk_rounds_give_the_same_contigs(ctx, env, monkeypatch):
         assert got.contigs == ref.contigs and got.connections == ref.connections and len(ref.contigs) > 20
     finally:
         t.close()
+
+
+def test_accept_filter_on_the_device_equals_the_reference_rule(ctx):
+    """shn_ext_accept against extension_correction.py:361 evaluated with math.pow per walk (and against the numpy form): every
+    non-void walk of a small run, thresholds chosen so that candidates fall on both sides and some exactly on the threshold"""
+    import math
+    from shannon_amd import device, synth, extension_correction as ec
+    (r1, r2), _ = synth.make_dataset(40000, 12, seed=17)
+    t = device.count_k1mers(ctx, [device.Reads.from_codes(ctx, np.concatenate([r1, r2]))], 26)
+    try:
+        ext = ec.Extension(ctx, t, 3)
+        live, nr, nl, tw = ext.live_stats(0)
+        assert len(live) > 200
+        for min_length, min_weight in ((75, 3), (40, 2), (120, 9), (27, 1)):
+            thr = 2 * min_length * math.pow(min_weight, 0.25)
+            want = [(int(r), 26 + int(a) + int(b)) for r, a, b, w in zip(live.tolist(), nr.tolist(), nl.tolist(), tw.tolist())
+                    if 26 + a + b >= min_length and (26 + a + b) * math.pow(float(w) / max(1, a + b + 1), 0.25) >= thr]
+            got_r, got_l = ext.accept(26, min_length, min_weight)
+            assert list(zip(got_r.tolist(), got_l.tolist())) == want
+            ref_r, ref_l = ec.accept_filter(live, nr, nl, tw, 26, min_length, min_weight, arrays=True)
+            assert got_r.tolist() == ref_r.tolist() and got_l.tolist() == ref_l.tolist()
+        ext.close()
+    finally:
+        t.close()

@@ -64,3 +64,40 @@ def test_device_aids_directly(ctx):
     out = post.finalize_texts([text], True, ctx=ctx)
     # a, rc(a) and the second a collapse to one record; the one-base variant and the shorter copy are different sequences
     assert sum(1 for v in out.values() if v in (a, rc(a))) == 1
+
+
+@pytest.mark.parametrize("seed", SEEDS[:2])
+@pytest.mark.parametrize("ds", [True, False])
+def test_merge_fed_piece_by_piece_equals_the_reference(ctx, seed, ds):
+    """shn_post_stream_*: the pieces handed over in any order, from several threads, each prepared (lines, upload, fingerprints) as it
+    arrives; the order-dependent rules over the pieces in index order -- the same survivors as the reference's chain.  The lazy
+    mapping over the exported buffers behaves like the dict; fasta() is the final file."""
+    from concurrent.futures import ThreadPoolExecutor
+    from shannon_amd import post
+    lines = adversarial(seed)
+    want = load_case("post_adversarial")[str(seed)]["ds" if ds else "ss"]
+    cuts = [0, 100, 101, 101, 300, 700, len(lines)]                 # (an empty piece among them)
+    pieces = ["".join(lines[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    ps = post.PostStream(ctx, capacity=sum(len(p) for p in pieces) + 64)
+    order = [3, 0, 5, 1, 4, 2]
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        list(pool.map(lambda i: ps.add(i, pieces[i]), order))
+    got = ps.finish(ds, lazy=True)
+    assert got == want and want == got and len(got) == len(want)
+    assert dict(got.items()) == want and sorted(got.values()) == sorted(want.values()) and sorted(got) == sorted(want)
+    k = next(iter(want))
+    assert got[k] == want[k] and k in got and got.get("no such record") is None
+    assert got.fasta().decode() == "".join(">%s\n%s\n" % (n, s) for n, s in got.items())
+
+
+def test_merge_stream_says_when_it_is_full_or_a_piece_does_not_end_its_line(ctx):
+    from shannon_amd import post, _lib
+    ps = post.PostStream(ctx, capacity=1 << 20)
+    ps.add(0, ">a\n" + "ACGT" * 100 + "\n")
+    with pytest.raises(_lib.ShannonError, match="end its last line"):
+        ps.add(1, ">b\nACGT")
+    with pytest.raises(_lib.ShannonError, match="twice"):
+        ps.add(0, ">c\nACGT\n")
+    with pytest.raises(_lib.ShannonError, match="full"):
+        ps.add(2, ">d\n" + "A" * (2 << 20) + "\n")
+    ps.close()
