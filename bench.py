@@ -47,6 +47,9 @@ CHUNK_PAIRS = 250_000          # the batch is generated in chunks of this many p
 def chunk_range(total_pairs, world, rank):
     """(first chunk, pairs) of the contiguous slice of the batch's chunks that rank `rank` of `world` generates and holds"""
     n_chunks = (total_pairs + CHUNK_PAIRS - 1) // CHUNK_PAIRS
+    if n_chunks < world:                                       # (a rank without a chunk would run the path on an empty batch)
+        raise SystemExit("bench.py: --reads %d is %d chunk(s) of %d pairs: fewer than the %d ranks of the job -- use at least %d reads "
+                         "or fewer ranks" % (2 * total_pairs, n_chunks, CHUNK_PAIRS, world, 2 * world * CHUNK_PAIRS))
     lo, hi = rank * n_chunks // world, (rank + 1) * n_chunks // world
     return lo, min(total_pairs, hi * CHUNK_PAIRS) - min(total_pairs, lo * CHUNK_PAIRS)
 
@@ -496,17 +499,25 @@ def launch_ranks(n, argv, json_fd):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL between processes needs it on this stack
     env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env, cwd=ROOT)
-    line = None
-    for raw in proc.stdout:                                    # the ranks' stdout: the JSON line of rank 0 and nothing else
-        txt = raw.decode(errors="replace")
-        if txt.lstrip().startswith("{") and '"metric"' in txt:
-            line = txt.strip()
-        else:
-            sys.stderr.write(txt)
-    rc = proc.wait()
+    import time as _time
+    for attempt in (0, 1):
+        # (the port is found free and taken by the launcher a moment later: somebody else can take it in between -- a launch that
+        # fails within seconds gets one more try on another port)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+        t_launch = _time.time()
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env, cwd=ROOT)
+        line = None
+        for raw in proc.stdout:                                # the ranks' stdout: the JSON line of rank 0 and nothing else
+            txt = raw.decode(errors="replace")
+            if txt.lstrip().startswith("{") and '"metric"' in txt:
+                line = txt.strip()
+            else:
+                sys.stderr.write(txt)
+        rc = proc.wait()
+        if rc == 0 or line is not None or attempt == 1 or _time.time() - t_launch > 15:
+            break
+        sys.stderr.write("bench.py: the %d-rank launch failed within %.0f s (exit code %d): once more on another port\n" % (n, _time.time() - t_launch, rc))
     if rc != 0:
         sys.stderr.write("bench.py: the %d-rank launch failed with exit code %d\n" % (n, rc))
         return rc

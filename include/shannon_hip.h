@@ -123,6 +123,10 @@ int shn_table_lookup(shn_ctx* ctx, const shn_table* t, const uint64_t* keys, uin
  * duplicates (the local reduce-by-key after the all-to-all bucket exchange). */
 int shn_table_from_pairs(shn_ctx* ctx, const void* dev_keys, const void* dev_counts, uint64_t n, int k1,
                          int canonical, shn_table** out);
+/* The table of a strand-specific paired run (-s, shannon.py:407-411 and :436-439 without -C): the k1-mers of `fwd` (forward counting
+ * of reads_1) and the reverse complements of those of `other` (forward counting of reads_2, i.e. the k1-mers of RC(reads_2)), equal
+ * keys summed; both inputs plain (non-canonical) tables of one k.  On the device.                                                 */
+int shn_table_merge_rc(shn_ctx* ctx, const shn_table* fwd, const shn_table* other, shn_table** out);
 /* Owner rank of each stored key for hash-sharding across GPUs: fills per-rank counts
  * (host, n_ranks entries) and writes keys/counts grouped by rank into the device buffers. */
 int shn_table_shard(shn_ctx* ctx, const shn_table* t, int n_ranks, uint64_t* per_rank, void* dev_keys_out,

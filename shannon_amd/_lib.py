@@ -41,6 +41,7 @@ SIGNATURES = {
     "shn_table_device_ptrs": (C.c_int, [vp, vpp, vpp]),
     "shn_table_lookup": (C.c_int, [vp, vp, vp, C.c_uint64, vp]),
     "shn_table_from_pairs": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vpp]),
+    "shn_table_merge_rc": (C.c_int, [vp, vp, vp, vpp]),
     "shn_table_shard": (C.c_int, [vp, vp, C.c_int, u64p, vp, vp]),
     "shn_table_create": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vpp]),
     "shn_probe_build": (C.c_int, [vp, vp, vp, C.c_uint64, vp, C.c_uint32, C.c_int, vpp]),

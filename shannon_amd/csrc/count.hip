@@ -984,6 +984,35 @@ __global__ void sum_counts_kernel(const uint32_t* __restrict__ c, uint64_t n, un
   if ((threadIdx.x & 63) == 0 && a) atomicAdd(out, a);
 }
 
+// ---- the table of a strand-specific paired run: the k1-mers of reads_1 as they are and those of RC(reads_2) = the reverse complements
+// of the forward k1-mers of reads_2 (shannon.py:407-411, :436-439 without -C), equal keys summed -- from the two forward tables, on
+// the device (the host form downloaded both tables, reverse-complemented one in numpy and uploaded the concatenation)
+__global__ void table_rc_concat_kernel(const uint64_t* __restrict__ ka, const uint32_t* __restrict__ ca, uint64_t na, const uint64_t* __restrict__ kb,
+                                       const uint32_t* __restrict__ cb, uint64_t nb, int k, uint64_t* __restrict__ keys, uint32_t* __restrict__ cnts) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += (uint64_t)gridDim.x * blockDim.x) {
+    if (i < na) { keys[i] = ka[i]; cnts[i] = ca[i]; }
+    else { keys[i] = shn_revcomp(kb[i - na], k); cnts[i] = cb[i - na]; }
+  }
+}
+extern "C" int shn_table_from_pairs(shn_ctx* ctx, const void* dev_keys, const void* dev_counts, uint64_t n, int k1, int canonical, shn_table** out);
+extern "C" int shn_table_merge_rc(shn_ctx* ctx, const shn_table* fwd, const shn_table* other, shn_table** out) {
+  if (!ctx || !fwd || !other || !out) return shn_fail(SHN_ERR_ARG, "shn_table_merge_rc: NULL argument");
+  if (fwd->canonical || other->canonical || fwd->k != other->k) return shn_fail(SHN_ERR_ARG, "shn_table_merge_rc: two plain tables of one k");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const uint64_t n = fwd->n + other->n;
+  ShnDevBufs bufs(s);
+  uint64_t* d_k = nullptr; uint32_t* d_c = nullptr;
+  HIP_TRY(bufs.get(&d_k, (n + 1) * 8)); HIP_TRY(bufs.get(&d_c, (n + 1) * 4));
+  if (n) hipLaunchKernelGGL(table_rc_concat_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n, 256), 1u << 20)), dim3(256), 0, s, (const uint64_t*)fwd->d_keys,
+                            (const uint32_t*)fwd->d_counts, fwd->n, (const uint64_t*)other->d_keys, (const uint32_t*)other->d_counts, other->n, fwd->k, d_k, d_c);
+  HIP_TRY(hipGetLastError());
+  int rc = shn_table_from_pairs(ctx, d_k, d_c, n, fwd->k, 0, out);
+  if (rc) return rc;
+  (*out)->total = fwd->total + other->total;
+  return SHN_OK;
+}
+
 extern "C" int shn_table_from_pairs(shn_ctx* ctx, const void* dev_keys, const void* dev_counts, uint64_t n, int k1,
                                     int canonical, shn_table** out) {
   if (!ctx || !out || (n && (!dev_keys || !dev_counts))) return shn_fail(SHN_ERR_ARG, "shn_table_from_pairs: NULL argument");

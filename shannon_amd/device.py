@@ -287,16 +287,13 @@ def count_k1mers_strand_specific(ctx, d1, d2, k1):
         return t1
     t2 = count_k1mers(ctx, [d2], k1, both_strands=False)
     try:
-        ka, ca = t1.download()
-        kb, cb = t2.download()
+        # (on the device: the keys of t2 reverse-complemented, both key lists reduced by key -- a k1-mer of reads_1 that is also one
+        # of RC(reads_2) gets the sum)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().shn_table_merge_rc(ctx.h, t1.h, t2.h, C.byref(h)))
     finally:
         t1.close()
         t2.close()
-    # (shn_table_create sums the counts of equal keys: a k1-mer of reads_1 that is also one of RC(reads_2))
-    keys = np.ascontiguousarray(np.concatenate([ka, revcomp_keys(kb, k1)]), dtype=np.uint64)
-    vals = np.ascontiguousarray(np.concatenate([ca, cb]), dtype=np.uint32)
-    h = C.c_void_p()
-    _lib.check(_lib.lib().shn_table_create(ctx.h, keys.ctypes.data, vals.ctypes.data, len(keys), k1, 0, C.byref(h)))
     return Table(ctx, h)
 
 
