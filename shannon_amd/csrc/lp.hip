@@ -19,6 +19,7 @@
 // No MFMA: no dense contraction anywhere.
 #include "common.h"
 #include <cstring>
+#include <atomic>
 
 #define LBLK 64
 #define LP_INF (1LL << 62)
@@ -513,6 +514,12 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
   ctx->lp_stats[0] += n_problems;
   ctx->lp_stats[2] += stat_off;
   ctx->lp_stats[6] += n_large_trials;
+  if (n_large_trials) {                                                  // (said once per process: these problems keep the vertex answer)
+    static std::atomic<bool> told{false};
+    if (!told.exchange(true))
+      fprintf(stderr, "[shannon_amd] LP: a decomposition with more than 64 rows + columns keeps the vertex of its optimal face (the analytic centre is "
+                      "computed for problems up to that size); counted in shn_lp_stats[6]\n");
+  }
   if (!stat.empty()) {
     uint64_t t0 = 0;
     for (uint32_t p = 0; p < n_problems; p++) {
