@@ -61,7 +61,7 @@ struct LpProblem {
 // BASELINE configs[2] over its 109 dependent batches).  The host puts a problem on this kernel when 64 lanes of its state fit
 // LP_LDS_WORDS words; the vertex goes back to the HBM workspace at the end (lp_center_kernel starts from it).  Same operations in
 // the same order: the same bits.
-#define LP_LDS_WORDS 8192          // 64 KB of LDS per block: problems with 2 mn + 3 (m + n) <= 128 words per trial (m = n = 6)
+#define LP_LDS_WORDS 20000         // 156 KB of the 160 KB of LDS a gfx950 CU has: problems with 2 mn + 3 (m + n) <= 312 words per trial (m = n = 11); 64 KB (m = n = 6) left nine launches per step of BASELINE configs[2] on the HBM form at 2.8 ms each
 template <bool LDS>
 __global__ __launch_bounds__(LBLK) void lp_trials_kernel(const LpProblem* __restrict__ probs, const uint32_t* __restrict__ block_prob,
                                                          const uint32_t* __restrict__ block_first, const double* __restrict__ in,
