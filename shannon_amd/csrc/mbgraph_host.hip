@@ -1519,7 +1519,17 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
     std::vector<uint64_t> doff, hashes; std::vector<char> text; std::string arena; std::vector<uint32_t> first, cnt, last; std::vector<int32_t> idmap;
     std::vector<double> rcc; std::vector<int> rmate, rmp, rfirst, rlast; std::vector<char> rhas; std::vector<uint64_t> r_hashes, r_off;
     std::vector<uint8_t> role;
-    size_t room() const { return std::max(text.capacity(), arena.capacity()); }
+    std::vector<uint32_t> origin_row; std::vector<uint8_t> origin_flag;      // (the graph's, kept from call to call like the arrays above)
+    // the buffer of the lazily decoded read text: NOT a vector -- it is written piecemeal (a few per cent of the reads are ever
+    // decoded), and a vector's resize zero-filled all of it: 0.1 s for the 354 MB of the largest partition whenever it got a
+    // scratch object that had served a smaller one (the spread of the graph stage from step to step)
+    char* lz_raw = nullptr; size_t lz_cap = 0;
+    char* lazy_text(size_t bytes) {
+      if (bytes > lz_cap) { free(lz_raw); lz_raw = (char*)malloc(bytes + bytes / 8); lz_cap = lz_raw ? bytes + bytes / 8 : 0; }
+      return lz_raw;
+    }
+    ~Scratch() { free(lz_raw); }
+    size_t room() const { return std::max(std::max(text.capacity(), arena.capacity()), lz_cap); }
   };
   static std::mutex scratch_mu;
   static std::vector<Scratch*> scratch_free;
@@ -1547,6 +1557,7 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
       g->rindex.arena.clear(); s->arena.swap(g->rindex.arena);
       s->rcc.swap(g->rcc); s->rmate.swap(g->rmate); s->rmp.swap(g->rmp); s->rfirst.swap(g->rfirst); s->rlast.swap(g->rlast); s->rhas.swap(g->rhas);
       s->r_hashes.swap(g->rindex.hashes); s->r_off.swap(g->rindex.off);
+      s->origin_row.swap(g->origin_row); s->origin_flag.swap(g->origin_flag);
       std::lock_guard<std::mutex> lk(scratch_mu);
       if (scratch_free.size() < 192) scratch_free.push_back(s); else delete s;
     }
@@ -1556,6 +1567,8 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
   sc->rcc.clear(); sc->rmate.clear(); sc->rmp.clear(); sc->rfirst.clear(); sc->rlast.clear(); sc->rhas.clear(); sc->r_hashes.clear(); sc->r_off.assign(1, 0);
   g.rcc.swap(sc->rcc); g.rmate.swap(sc->rmate); g.rmp.swap(sc->rmp); g.rfirst.swap(sc->rfirst); g.rlast.swap(sc->rlast); g.rhas.swap(sc->rhas);
   g.rindex.hashes.swap(sc->r_hashes); g.rindex.off.swap(sc->r_off);
+  g.origin_row.swap(sc->origin_row); g.origin_flag.swap(sc->origin_flag);
+  g.origin_row.resize(0); g.origin_flag.resize(0);                      // (capacity kept; empty until a path fills them)
   // the fast form of the rows mode (graph_dev.h): the duplicate search leaves its arrays on the device, the host gets rows + strands
   // (for the lazily decoded text) and nothing else per read.  SHN_GRAPH_DEV_ATTRS=0: the host-array form below.
   const char* dav = getenv("SHN_GRAPH_DEV_ATTRS");
@@ -1570,8 +1583,8 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
     const uint64_t nd = g.dd->n_distinct;
     g.n_rd_dev = nd; g.dev_attrs = true;
     if (dbg) fprintf(stderr, "[mbgraph]   distinct reads (GPU)   %8.3f s  used=%llu distinct=%llu (attributes stay on the device)\n", now() - t_dec, (unsigned long long)used, (unsigned long long)nd);
-    if (sc->text.size() < nd * Lr + 1) { sc->text.clear(); sc->text.resize(nd * Lr + 1); }
-    g.lz_a = host_a; g.lz_b = host_b; g.lz_L = (uint32_t)Lr; g.lz_buf = sc->text.data();
+    g.lz_a = host_a; g.lz_b = host_b; g.lz_L = (uint32_t)Lr; g.lz_buf = sc->lazy_text(nd * Lr + 1);
+    if (!g.lz_buf) return shn_fail(SHN_ERR_NOMEM, "shn_mbgraph_run: out of host memory for the reads' text");
     g.lz_done.assign((nd + 63) / 64, 0);
     g.origin_row.resize(nd); g.origin_flag.resize(nd);
     if ((rcd = shn_dedup_origin(g.dd, g.origin_row.data(), g.origin_flag.data()))) return rcd;
@@ -1596,8 +1609,8 @@ static int mbgraph_run_impl(shn_ctx* ctx, int K, const uint8_t* rows, uint64_t n
     const char* lzv = getenv("SHN_GRAPH_LAZY_TEXT");
     const bool lazy = host_a && !(lzv && lzv[0] == '0') && src_a->n_invalid == 0 && (!paired || src_b->n_invalid == 0);
     if (lazy) {
-      if (sc->text.size() < nd * Lr + 1) { sc->text.clear(); sc->text.resize(nd * Lr + 1); }
-      g.lz_a = host_a; g.lz_b = host_b; g.lz_L = (uint32_t)Lr; g.lz_buf = sc->text.data();
+      g.lz_a = host_a; g.lz_b = host_b; g.lz_L = (uint32_t)Lr; g.lz_buf = sc->lazy_text(nd * Lr + 1);
+      if (!g.lz_buf) return shn_fail(SHN_ERR_NOMEM, "shn_mbgraph_run: out of host memory for the reads' text");
       g.lz_done.assign((nd + 63) / 64, 0);
     }
     R.off.resize(nd + 1);
