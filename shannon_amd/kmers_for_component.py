@@ -467,7 +467,8 @@ def _finish_partitions(res, comps, broken, names, by_part, files, cw, k1, K, wan
     # per-partition k1-mer rows with weights from the allowed dict (:452-477)
     rows_bytes, n_nodes, n_rows_of = {}, {}, {}
     for name in names:
-        n_rows_of[name] = int(sum(max(len(c) - k1 + 1, 0) for c in comps[name]))
+        cl = comps[name]
+        n_rows_of[name] = (int(np.maximum(np.fromiter(map(len, cl), dtype=np.int64, count=len(cl)) - (k1 - 1), 0).sum()) if cl else 0)
         if lazy_graph_inputs and not want_rows:
             # the graph stage takes its K-mer graph from the GPU unitig builder (which also counts the distinct K-mers);
             # the byte rows are made on demand (a partition with a cycle of condensable edges, SHN_GRAPH_CHECK)
