@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <string>
 #include <vector>
+#include <mutex>
 #include "../../include/shannon_hip.h"
 
 #define SHN_WAVE 64
@@ -62,6 +63,8 @@ struct shn_ctx {
                            // context / stream (the graph threads' seed scans): [0] scan block sums, [1] [2] seed-scan counts / offsets,
                            // [4..11] the LP batches of the sparse flow (two batches may be in flight on two contexts)
   ShnPinned hpin[2];       // pinned staging of the LP batches: [0] what goes up, [1] what comes back
+  shn_ctx* parent = nullptr;   // shn_ctx_fork: the context this one was forked from (its timers and LP census are the parent's: core.hip)
+  std::mutex tmu;          // guards pending / ms / regions when another thread drains them
   int lp_rule;             // SHN_LP_RULE_CENTER (default) / SHN_LP_RULE_VERTEX (SHN_LP_RULE=vertex in the environment, shn_lp_set_rule)
   uint64_t lp_stats[8];    // shn_lp_stats
 };

@@ -35,6 +35,7 @@ TimerRegion::TimerRegion(shn_ctx* ctx, int s, hipStream_t stream) : c(ctx), slot
 TimerRegion::~TimerRegion() {
   if (!a) return;
   hipEventRecord(b, st);
+  std::lock_guard<std::mutex> lk(c->tmu);
   c->pending[slot].push_back({a, b});
 }
 
@@ -111,10 +112,42 @@ extern "C" int shn_ctx_create(int device, void* stream, shn_ctx** out) {
   return SHN_OK;
 }
 
+// the forks alive (shn_ctx_fork): a context's timers are read together with those of its forks -- the seed scans of the graph
+// threads and the LP batches of the sparse flow run on forks
+static std::mutex g_forks_mu;
+static std::vector<shn_ctx*> g_forks;
+static int drain_own(shn_ctx* c) {
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  std::lock_guard<std::mutex> lk(c->tmu);
+  for (int i = 0; i < T_N; i++) {
+    for (auto& p : c->pending[i]) {
+      float ms = 0;
+      HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
+      c->ms[i] += ms;
+      c->regions[i]++;
+      hipEventDestroy(p.first);
+      hipEventDestroy(p.second);
+    }
+    c->pending[i].clear();
+  }
+  return SHN_OK;
+}
+static void fold_into_parent(shn_ctx* f) {                      // (g_forks_mu held) what the fork has measured so far goes to its parent
+  shn_ctx* p = f->parent;
+  if (!p) return;
+  std::lock_guard<std::mutex> lf(f->tmu);
+  std::lock_guard<std::mutex> lp(p->tmu);
+  for (int i = 0; i < T_N; i++) { p->ms[i] += f->ms[i]; p->regions[i] += f->regions[i]; f->ms[i] = 0; f->regions[i] = 0; }
+}
 extern "C" void shn_ctx_destroy(shn_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
+  {
+    std::lock_guard<std::mutex> lk(g_forks_mu);
+    if (c->parent) { (void)drain_own(c); fold_into_parent(c); }
+    for (size_t i = 0; i < g_forks.size();) { if (g_forks[i] == c) g_forks.erase(g_forks.begin() + (ptrdiff_t)i); else { if (g_forks[i]->parent == c) g_forks[i]->parent = nullptr; i++; } }
+  }
   for (int i = 0; i < T_N; i++)
     for (auto& p : c->pending[i]) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
   if (c->owns_stream && c->stream) hipStreamDestroy(c->stream);
@@ -125,14 +158,16 @@ extern "C" void shn_ctx_destroy(shn_ctx* c) {
 }
 
 // A second context on the same device with a stream of its own, for a host thread that works beside the owner of `parent`
-// (the graph threads: their seed scans overlap on the GPU instead of taking turns).  Event timing is off on it.
+// (the graph threads: their seed scans overlap on the GPU instead of taking turns).  Its timers and LP census are read with the parent's.
 extern "C" int shn_ctx_fork(const shn_ctx* parent, shn_ctx** out) {
   if (!parent || !out) return shn_fail(SHN_ERR_ARG, "shn_ctx_fork: NULL argument");
   HIP_TRY(hipSetDevice(parent->device));
   hipStream_t st = nullptr;
   HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   shn_ctx* c = new shn_ctx();
-  c->device = parent->device; c->stream = st; c->timing = false; c->count_direct_log2 = 0; c->sk_pool_ratio = 0; c->owns_stream = true;
+  c->device = parent->device; c->stream = st; c->timing = parent->timing; c->count_direct_log2 = 0; c->sk_pool_ratio = 0; c->owns_stream = true;
+  c->parent = const_cast<shn_ctx*>(parent);
+  { std::lock_guard<std::mutex> lk(g_forks_mu); g_forks.push_back(c); }
   for (int i = 0; i < T_N; i++) { c->ms[i] = 0; c->regions[i] = 0; }
   c->lp_rule = parent->lp_rule;
   for (auto& v : c->lp_stats) v = 0;
@@ -155,7 +190,7 @@ shn_ctx* shn_thread_ctx(shn_ctx* p) {
   static const bool no_fork = getenv("SHN_GRAPH_FORK") && getenv("SHN_GRAPH_FORK")[0] == '0';
   if (no_fork) return p;
   ShnThreadCtx& t = t_thread_ctx;
-  if (t.c && t.parent == p) { t.c->lp_rule = p->lp_rule; return t.c; }      // (the rule may have been set on the parent since the fork)
+  if (t.c && t.parent == p && t.c->parent == p) { t.c->lp_rule = p->lp_rule; t.c->timing = p->timing; return t.c; }      // (rule / timing may have been set on the parent since the fork; a parent that went away orphaned the fork: a new one)
   if (t.c) { shn_ctx_destroy(t.c); t.c = nullptr; }
   if (shn_ctx_fork(p, &t.c)) { t.c = nullptr; return p; }
   t.parent = p;
@@ -170,18 +205,10 @@ extern "C" int shn_ctx_sync(shn_ctx* c) {
 }
 
 static int drain_timers(shn_ctx* c) {
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  for (int i = 0; i < T_N; i++) {
-    for (auto& p : c->pending[i]) {
-      float ms = 0;
-      HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
-      c->ms[i] += ms;
-      c->regions[i]++;
-      hipEventDestroy(p.first);
-      hipEventDestroy(p.second);
-    }
-    c->pending[i].clear();
-  }
+  int rc = drain_own(c);
+  if (rc || c->parent) return rc;
+  std::lock_guard<std::mutex> lk(g_forks_mu);
+  for (shn_ctx* f : g_forks) if (f->parent == c) { if ((rc = drain_own(f))) return rc; fold_into_parent(f); }
   return SHN_OK;
 }
 

@@ -511,9 +511,12 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
   std::vector<uint32_t> stat;
   if (with_stat) { stat.resize(4 * stat_off); memcpy(stat.data(), (const uint8_t*)h_down + o_stat, stat.size() * 4); }
   // census (bench.py: lp_calls / lp_degenerate): a problem is degenerate when the optimal face of one of its trials was not a point
-  ctx->lp_stats[0] += n_problems;
-  ctx->lp_stats[2] += stat_off;
-  ctx->lp_stats[6] += n_large_trials;
+  // (a fork's census is its parent's: the batches of the sparse flow run on the graph threads' forks, several at a time)
+  shn_ctx* sctx = ctx->parent ? ctx->parent : ctx;
+  auto tally = [&](int i, uint64_t v) { if (v) __atomic_fetch_add(&sctx->lp_stats[i], v, __ATOMIC_RELAXED); };
+  tally(0, n_problems);
+  tally(2, stat_off);
+  tally(6, n_large_trials);
   if (n_large_trials) {                                                  // (said once per process: these problems keep the vertex answer)
     static std::atomic<bool> told{false};
     if (!told.exchange(true))
@@ -526,11 +529,11 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
       bool deg = false;
       for (uint32_t t = 0; t < trials[p]; t++) {
         const uint32_t* sp = &stat[4 * (t0 + t)];
-        if (sp[0]) { deg = true; ctx->lp_stats[3]++; }
-        ctx->lp_stats[4] += sp[1];
-        ctx->lp_stats[5] += sp[2];
+        if (sp[0]) { deg = true; tally(3, 1); }
+        tally(4, sp[1]);
+        tally(5, sp[2]);
       }
-      if (deg) ctx->lp_stats[1]++;
+      if (deg) tally(1, 1);
       t0 += trials[p];
     }
   }
