@@ -279,7 +279,8 @@ class RouteView(object):
         return self.below
 
     def __getitem__(self, sl):
-        assert isinstance(sl, slice) and sl.step in (None, 1)
+        if not (isinstance(sl, slice) and sl.step in (None, 1)):          # (anything but a plain slice: the whole list, then numpy's indexing)
+            return self.routes.download_range(self.lo, self.n)[sl]
         a, b, _ = sl.indices(self.n)
         return self.routes.download_range(self.lo + a, max(0, b - a))
 

@@ -134,7 +134,7 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
     def _is_matrix(m):
         return isinstance(m, np.ndarray) and m.dtype == np.uint8 and m.ndim == 2 and m.flags["C_CONTIGUOUS"]
     rows_likely = (gpu_unitigs and d1 is not None and _is_matrix(getattr(store, "r1", None)) and (not paired or (d2 is not None and _is_matrix(getattr(store, "r2", None))))
-                   and os.environ.get("SHN_GRAPH_ROWS", "1") != "0" and not ss and not keep_partitioning)
+                   and os.environ.get("SHN_GRAPH_ROWS", "1") != "0" and not ss)
     part = kfc.kmers_for_component(ctx, res, d1, d2, K, partition_size, overload, penalty, True, part_vectors,
                                    want_rows=not native_graph, timings=T, lazy_graph_inputs=gpu_unitigs, strand_specific=ss,
                                    lazy_routes=rows_likely)
