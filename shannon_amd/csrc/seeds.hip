@@ -11,51 +11,11 @@
 
 struct SView { const uint64_t* words; const uint64_t* woff; const uint32_t* len; uint64_t n; uint32_t fixed_len, wpr; };
 
-// mode 0: one thread per (read, offset).  The hits are few (the patterns are the K-mers at the start of the graph's x-nodes): the first
-// pass leaves one count per block of 256 windows, the second repeats the look-ups and writes the (read, start, id) triples in (read,
-// start) order -- position inside the block by ballot / prefix.  (A count per window was 12 bytes of traffic per window for the
-// count, its scan and the offsets read back; the look-ups themselves hit a table that fits the L2.)
-// ALL: every window 0..len-K (contig-against-contig 15-mer joins) instead of the interior starts 1..len-K-1
-template <bool FILL, bool ALL>
-__global__ __launch_bounds__(SBLK2) void seed_scan_kernel(SView v, int K, uint32_t max_win, const uint64_t* __restrict__ tkeys,
-                                                          const uint32_t* __restrict__ tvals, const uint64_t* __restrict__ boff, int bits,
-                                                          uint32_t* __restrict__ counts, const uint64_t* __restrict__ offs,
-                                                          uint32_t* __restrict__ o_read, uint32_t* __restrict__ o_start, uint32_t* __restrict__ o_id) {
-  __shared__ uint32_t wtot[SBLK2 / 64];
-  const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint64_t r = 0;
-  uint32_t start = 0, id = 0;
-  if (gid < v.n * max_win) {
-    r = gid / max_win;
-    start = (uint32_t)(gid - r * max_win) + (ALL ? 0u : 1u);   // range(1, len - K), or every window
-    const uint32_t len = v.len ? v.len[r] : v.fixed_len;
-    if (ALL ? (len >= (uint32_t)K && start <= len - K) : (len > (uint32_t)K && start < len - K)) {
-      const uint64_t wb = v.woff ? v.woff[r] : r * v.wpr;
-      const uint64_t key = shn_extract(v.words + wb, start, K);
-      const int64_t j = shn_table_find(tkeys, boff, bits, key);
-      if (j >= 0) id = tvals[j];
-    }
-  }
-  const unsigned long long m = __ballot(id != 0);
-  const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  if (lane == 0) wtot[wv] = (uint32_t)__popcll(m);
-  __syncthreads();
-  if (!FILL) {
-    if (threadIdx.x == 0) { uint32_t t = 0; for (int w = 0; w < SBLK2 / 64; w++) t += wtot[w]; counts[blockIdx.x] = t; }
-    return;
-  }
-  if (id) {
-    uint64_t o = offs[blockIdx.x] + (uint64_t)__popcll(m & ((1ULL << lane) - 1ULL));
-    for (uint32_t w = 0; w < wv; w++) o += wtot[w];
-    o_read[o] = (uint32_t)r; o_start[o] = start; o_id[o] = id - 1;
-  }
-}
-
 // mode 0, interior starts only (find_bridging_reads): ONE thread per read with a rolling K-mer.  The patterns are few (the K-mers
 // at the start of the graph's x-nodes: 10^2-10^4 per partition) and the windows many (74 per 100-base read), so in front of the
 // table stands a 2^18-bit filter held in the LDS: 98-99 % of the windows end at one LDS read.  A read's hits are written one after
 // the other from the read's own offset: (read, start) order without ballots; the FILL pass skips the reads without a hit.
-// (the form above -- a thread per window, two passes of table look-ups -- was 83 ms per step at BASELINE configs[2])
+// (round 3's form -- a thread per window, two passes of table look-ups -- was 83 ms per step at BASELINE configs[2])
 #define SEED_BM_BITS 18
 #define SEED_BM_WORDS (1u << (SEED_BM_BITS - 5))
 __device__ __forceinline__ uint32_t seed_bm_hash(uint64_t key) {
@@ -135,7 +95,6 @@ static SView sview(const shn_reads* r) {
 
 // Interior seed hits: every read, every start in [1, len-K): pattern id (table value - 1) if the K-mer is a
 // key of `patterns`.  Call with out_read == NULL to get *n_hits, then with arrays of that size.
-template <bool ALL>
 static int seed_scan_impl(shn_ctx* ctx, const shn_reads* reads, int K, const shn_table* patterns, uint64_t* n_hits,
                           uint32_t* out_read, uint32_t* out_start, uint32_t* out_id) {
   if (!ctx || !reads || !patterns || !n_hits) return shn_fail(SHN_ERR_ARG, "shn_seed_scan: NULL argument");
@@ -144,48 +103,39 @@ static int seed_scan_impl(shn_ctx* ctx, const shn_reads* reads, int K, const shn
   hipStream_t s = ctx->stream;
   TimerRegion treg(ctx, T_SEEDS);
   SView v = sview(reads);
-  uint32_t max_win = ALL ? (reads->max_len >= (uint32_t)K ? reads->max_len - K + 1 : 0) : (reads->max_len > (uint32_t)K + 1 ? reads->max_len - K - 1 : 0);
+  uint32_t max_win = reads->max_len > (uint32_t)K + 1 ? reads->max_len - K - 1 : 0;
   uint64_t total = v.n * max_win;
   if (total == 0) { *n_hits = 0; return SHN_OK; }
   void *pc, *po;
   int rc;
-  // interior starts: a thread per read behind an LDS filter (seed_scan_reads_kernel); every window: a thread per window
-  const bool per_read = !ALL && getenv("SHN_SEED_PER_WINDOW") == nullptr;
-  const uint32_t grid = per_read ? (uint32_t)std::min<uint64_t>(cdiv(v.n, SBLK2), 4096) : (uint32_t)cdiv(total, SBLK2);
-  const uint64_t n_cnt = per_read ? v.n : grid;                 // counts: per read / per block of 256 windows
+  // a thread per read behind an LDS filter (seed_scan_reads_kernel)
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(cdiv(v.n, SBLK2), 4096);
+  const uint64_t n_cnt = v.n;                                   // counts: per read
   if ((rc = ctx->cws[1].get((n_cnt + 1) * 4, &pc)) || (rc = ctx->cws[2].get((n_cnt + 2) * 8, &po))) return rc;
   void* pbm = nullptr;
-  if (per_read && (rc = ctx->cws[3].get(SEED_BM_WORDS * 4, &pbm))) return rc;
+  if ((rc = ctx->cws[3].get(SEED_BM_WORDS * 4, &pbm))) return rc;
   // (the call that asks for the number of hits and the one that fetches them come in pairs: the second finds the offsets (and the
   // filter) of the first in the context's workspace -- same reads, same patterns, nothing in between on this context)
-  static thread_local struct { const shn_ctx* ctx; const shn_reads* reads; const shn_table* pat; uint64_t total, n_reads, n_pat, nh; int K; bool all; } last = {};
+  static thread_local struct { const shn_ctx* ctx; const shn_reads* reads; const shn_table* pat; uint64_t total, n_reads, n_pat, nh; int K; } last = {};
   uint64_t nh = 0;
   if (out_read && last.ctx == ctx && last.reads == reads && last.pat == patterns && last.total == total && last.n_reads == reads->n_reads &&
-      last.n_pat == patterns->n && last.K == K && last.all == ALL) nh = last.nh;
+      last.n_pat == patterns->n && last.K == K) nh = last.nh;
   else {
-    if (per_read) {
-      HIP_TRY(hipMemsetAsync(pbm, 0, SEED_BM_WORDS * 4, s));
-      if (patterns->n) hipLaunchKernelGGL(seed_bm_build_kernel, dim3((uint32_t)cdiv(patterns->n, 256)), dim3(256), 0, s, patterns->d_keys, patterns->n, (uint32_t*)pbm);
-      hipLaunchKernelGGL((seed_scan_reads_kernel<false>), dim3(grid), dim3(SBLK2), 0, s, v, K, (const uint32_t*)pbm, patterns->d_keys, patterns->d_counts,
-                         patterns->d_bucket_off, patterns->bits, (uint32_t*)pc, nullptr, nullptr, nullptr, nullptr);
-    } else
-      hipLaunchKernelGGL((seed_scan_kernel<false, ALL>), dim3(grid), dim3(SBLK2), 0, s, v, K, max_win, patterns->d_keys, patterns->d_counts,
-                         patterns->d_bucket_off, patterns->bits, (uint32_t*)pc, nullptr, nullptr, nullptr, nullptr);
+    HIP_TRY(hipMemsetAsync(pbm, 0, SEED_BM_WORDS * 4, s));
+    if (patterns->n) hipLaunchKernelGGL(seed_bm_build_kernel, dim3((uint32_t)cdiv(patterns->n, 256)), dim3(256), 0, s, patterns->d_keys, patterns->n, (uint32_t*)pbm);
+    hipLaunchKernelGGL((seed_scan_reads_kernel<false>), dim3(grid), dim3(SBLK2), 0, s, v, K, (const uint32_t*)pbm, patterns->d_keys, patterns->d_counts,
+                       patterns->d_bucket_off, patterns->bits, (uint32_t*)pc, nullptr, nullptr, nullptr, nullptr);
     if ((rc = shn_device_scan_u32(ctx, (uint32_t*)pc, n_cnt, (uint64_t*)po, &nh))) return rc;
   }
   last.ctx = nullptr;                                            // (one use)
   *n_hits = nh;
-  if (!out_read) { last = {ctx, reads, patterns, total, reads->n_reads, patterns->n, nh, K, ALL}; return SHN_OK; }
+  if (!out_read) { last = {ctx, reads, patterns, total, reads->n_reads, patterns->n, nh, K}; return SHN_OK; }
   if (nh == 0) return SHN_OK;
   uint32_t *d_r = nullptr, *d_s = nullptr, *d_i = nullptr;       // (from the caching allocator: this runs once per partition, under the GPU mutex)
   ShnDevBufs hb(ctx->stream);
   HIP_TRY(hb.get(&d_r, nh * 4)); HIP_TRY(hb.get(&d_s, nh * 4)); HIP_TRY(hb.get(&d_i, nh * 4));
-  if (per_read)
-    hipLaunchKernelGGL((seed_scan_reads_kernel<true>), dim3(grid), dim3(SBLK2), 0, s, v, K, (const uint32_t*)pbm, patterns->d_keys, patterns->d_counts,
-                       patterns->d_bucket_off, patterns->bits, nullptr, (const uint64_t*)po, d_r, d_s, d_i);
-  else
-    hipLaunchKernelGGL((seed_scan_kernel<true, ALL>), dim3(grid), dim3(SBLK2), 0, s, v, K, max_win, patterns->d_keys, patterns->d_counts,
-                       patterns->d_bucket_off, patterns->bits, nullptr, (const uint64_t*)po, d_r, d_s, d_i);
+  hipLaunchKernelGGL((seed_scan_reads_kernel<true>), dim3(grid), dim3(SBLK2), 0, s, v, K, (const uint32_t*)pbm, patterns->d_keys, patterns->d_counts,
+                     patterns->d_bucket_off, patterns->bits, nullptr, (const uint64_t*)po, d_r, d_s, d_i);
   HIP_TRY(hipMemcpyAsync(out_read, d_r, nh * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(out_start, d_s, nh * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(out_id, d_i, nh * 4, hipMemcpyDeviceToHost, s));
@@ -196,7 +146,7 @@ static int seed_scan_impl(shn_ctx* ctx, const shn_reads* reads, int K, const shn
 
 extern "C" int shn_seed_scan(shn_ctx* ctx, const shn_reads* reads, int K, const shn_table* patterns, uint64_t* n_hits,
                              uint32_t* out_read, uint32_t* out_start, uint32_t* out_id) {
-  return seed_scan_impl<false>(ctx, reads, K, patterns, n_hits, out_read, out_start, out_id);
+  return seed_scan_impl(ctx, reads, K, patterns, n_hits, out_read, out_start, out_id);
 }
 // first_id[r] / last_id[r] = table value (0 = absent) of the first / last K-mer of read r
 extern "C" int shn_seed_ends(shn_ctx* ctx, const shn_reads* reads, int K, const shn_table* patterns, uint32_t* first_id,
