@@ -136,3 +136,23 @@ def test_native_merge_equals_the_reference_chain():
         c = load_case(name)
         for key, ds in (("ds", True), ("ss", False)):
             assert post.finalize_texts([c["all_reconstructed"]], ds) == c["final"][key], (name, key)
+
+
+def test_final_transcripts_mapping_over_exported_buffers():
+    """post.FinalTranscripts: the survivors of the native merge as buffers (names, sequences, offsets) behave like the dict they
+    replace -- strings are only made on demand -- and fasta() is the text of the final file"""
+    import numpy as np
+    from shannon_amd.post import FinalTranscripts
+    recs = [("s_c1_0_1", "ACGT" * 60), ("Single_7", "TTGA" * 51 + "C"), ("x", "G" * 201)]
+    names = np.frombuffer("".join(n for n, _ in recs).encode(), np.uint8)
+    seqs = np.frombuffer("".join(q for _, q in recs).encode(), np.uint8)
+    no = np.cumsum([0] + [len(n) for n, _ in recs]).astype(np.uint64)
+    so = np.cumsum([0] + [len(q) for _, q in recs]).astype(np.uint64)
+    f = FinalTranscripts(names, no, seqs, so)
+    want = dict(recs)
+    assert len(f) == 3 and list(f) == [n for n, _ in recs] and f.items() == recs and f.values() == [q for _, q in recs]
+    assert f == want and want == f and not (f != want) and f != {"x": "G"}
+    assert f["Single_7"] == want["Single_7"] and "x" in f and "y" not in f and f.get("y", 5) == 5
+    assert f.fasta() == "".join(">%s\n%s\n" % r for r in recs).encode()
+    empty = FinalTranscripts(np.zeros(1, np.uint8), np.zeros(1, np.uint64), np.zeros(1, np.uint8), np.zeros(1, np.uint64))
+    assert len(empty) == 0 and empty == {} and empty.fasta() == b"" and list(empty) == []
