@@ -395,11 +395,15 @@ struct Graph {
     // P1: the source's reads sorted by (read, index), without repeats; then the destination's that are not among them (a sorted
     // vector + bisection: a tree node per read was most of bridge_all for the X-nodes of a highly expressed transcript)
     const double tcs0 = laps ? tnow() : 0.0;
-    std::vector<RI> out(nreads[s]);
-    sort_runs(out);
-    out.erase(std::unique(out.begin(), out.end()), out.end());
+    std::vector<RI> src;
+    src.swap(nreads[s]);                                             // (the source's list is given up below anyway)
+    sort_runs(src);
+    // the source's reads without repeats, then the destination's that are not among them, in ONE vector of the final size (the
+    // lists of a highly expressed transcript hold 10^5 reads: no second copy when the destination's part is appended)
+    std::vector<RI> out;
+    out.reserve(src.size() + nreads[d].size());
+    for (size_t q = 0; q < src.size(); q++) if (q == 0 || !(src[q] == src[q - 1])) out.push_back(src[q]);
     const size_t n_src = out.size();
-    out.reserve(n_src + nreads[d].size());
     if (std::is_sorted(nreads[d].begin(), nreads[d].end())) {
       // (both lists ascending -- the shift keeps the order: one pass with a cursor into the source's part instead of a bisection per read)
       size_t a = 0;
@@ -609,33 +613,28 @@ struct Graph {
     int lb = (int)nb.size();
     // (the reference collects them in a set and the pinned order P1 walks it sorted: a sorted vector without repeats is the same
     // sequence -- the lists of a highly expressed X-node hold 10^5 reads, and a tree insert per read was most of bridge_all)
+    // the characters the neighbours put in front of / behind the node (the same for every read of the list)
+    bool in_ch[256] = {false}, out_ch[256] = {false};
+    if (!nreads[n].empty()) {
+      for (int e : ine[n]) { const std::string& pb = bases[es[e]]; in_ch[(unsigned char)pb[pb.size() - ew[e] - 1]] = true; }
+      for (int e : oute[n]) out_ch[(unsigned char)bases[ed[e]][ew[e]]] = true;
+    }
+    // one pass over the list: the read spells the node from i on, and the characters before and behind are ones a neighbour offers
+    // (the reference filters by text, orders, then filters by the neighbours: the filters commute, the order comes last here)
     std::vector<RI> rs;
     rs.reserve(nreads[n].size());
     const std::vector<RI>& in_list = nreads[n];
     for (size_t q = 0; q < in_list.size(); q++) {
       if (q + 8 < in_list.size()) prefetch_read(in_list[q + 8].first);
       const RI& x = in_list[q];
-      int r = x.first, i = x.second;
+      const int r = x.first, i = x.second;
       if (i <= 0) continue;
       const RStr rb = rstr(r);
-      if ((int)rb.size() > i + lb && rb.compare(i, lb, nb) == 0) rs.push_back(x);
+      if ((int)rb.size() > i + lb && in_ch[(unsigned char)rb[i - 1]] && out_ch[(unsigned char)rb[i + lb]] && rb.compare(i, lb, nb) == 0) rs.push_back(x);
     }
     sort_runs(rs);
     rs.erase(std::unique(rs.begin(), rs.end()), rs.end());
-    // the characters the neighbours put in front of / behind the node (the same for every read of the list)
-    bool in_ch[256] = {false}, out_ch[256] = {false};
-    if (!rs.empty()) {
-      for (int e : ine[n]) { const std::string& pb = bases[es[e]]; in_ch[(unsigned char)pb[pb.size() - ew[e] - 1]] = true; }
-      for (int e : oute[n]) out_ch[(unsigned char)bases[ed[e]][ew[e]]] = true;
-    }
-    std::vector<RI> real;
-    real.reserve(rs.size());
-    for (const RI& x : rs) {
-      const RStr rb = rstr(x.first);
-      const int i = x.second;
-      if (in_ch[(unsigned char)rb[i - 1]] && out_ch[(unsigned char)rb[i + lb]]) real.push_back(x);
-    }
-    nreads[n].swap(real);
+    nreads[n].swap(rs);
   }
   // bridge_all asks every X-node in every pass; the answer depends on the node's edge lists (edge ids: an edge never changes its
   // ends or its weight), on its bridging reads (which only this function filters, idempotently, between two passes -- bridging
@@ -686,12 +685,20 @@ struct Graph {
         const char cp = pb[pb.size() - w - 1];
         int u = new_node(std::string(1, cp) + nb);
         link(p, u, w + 1);
-        // read_bridges(read, u, i - 1) for a read the refresh above left in the list (i > 0, the read longer than i + lb, its text equal
-        // to the node's from i on): the read reaches one base further back and that base is u's first -- no text to compare again
-        for (const RI& x : nreads[node]) if (x.second - 1 > 0 && rstr(x.first)[x.second - 1] == cp) nreads[u].push_back(RI(x.first, x.second - 1));
         bridged[u] = 0;
         if (p == node) { v_back = u; loop_w = w; }
         u_list.push_back(u);
+      }
+      // read_bridges(read, u, i - 1) for a read the refresh above left in the list (i > 0, the read longer than i + lb, its text equal
+      // to the node's from i on): the read reaches one base further back and that base is u's first -- no text to compare again.
+      // One pass over the reads for all the u-nodes (each gets the reads with its character, in list order).
+      const std::vector<RI>& lst = nreads[node];
+      for (size_t q = 0; q < lst.size(); q++) {
+        if (q + 8 < lst.size()) prefetch_read(lst[q + 8].first);
+        const RI& x = lst[q];
+        if (x.second - 1 <= 0) continue;
+        const char c = rstr(x.first)[x.second - 1];
+        for (int u : u_list) if (bases[u][0] == c) nreads[u].push_back(RI(x.first, x.second - 1));
       } }
     if (laps) { const double t = tnow(); t_bs_in += t - tb0; tb0 = t; }
     { std::vector<int> t = oute[node];
@@ -715,14 +722,20 @@ struct Graph {
     for (int n : u_list) links[n] = 0;
     for (int n : w_list) links[n] = 0;
     std::vector<RI> rl = nreads[node];
-    for (const RI& y : rl) {
+    // (the u-nodes are `base + node text`, the w-nodes `node text + base` -- all lb + 1 bases long --, and the read equals the node
+    // text from i on: one base decides; the bases looked up once, not per read)
+    std::vector<char> u_ch(u_list.size()), w_ch(w_list.size());
+    for (size_t a = 0; a < u_list.size(); a++) u_ch[a] = (int)bases[u_list[a]].size() == lb + 1 ? bases[u_list[a]][0] : '\0';
+    for (size_t a = 0; a < w_list.size(); a++) w_ch[a] = (int)bases[w_list[a]].size() == lb + 1 ? bases[w_list[a]][lb] : '\0';
+    for (size_t q = 0; q < rl.size(); q++) {
+      if (q + 8 < rl.size()) prefetch_read(rl[q + 8].first);
+      const RI& y = rl[q];
       const RStr rb = rstr(y.first);
       int i = y.second;
-      // exactly one u-node spelling the read from i - 1 and one w-node spelling it from i (all of them are lb + 1 bases long)
+      // exactly one u-node spelling the read from i - 1 and one w-node spelling it from i
       int u = -1, x = -1, nu = 0, nw = 0;
-      // (the u-nodes are `base + node text`, the w-nodes `node text + base`, and the read equals the node text from i on: one base decides)
-      for (int uu : u_list) if (rb.size() >= (size_t)(i + lb) && (int)bases[uu].size() == lb + 1 && rb[i - 1] == bases[uu][0]) { u = uu; nu++; }
-      for (int xx : w_list) if (rb.size() >= (size_t)(i + lb + 1) && (int)bases[xx].size() == lb + 1 && rb[i + lb] == bases[xx][lb]) { x = xx; nw++; }
+      if (rb.size() >= (size_t)(i + lb)) { const char c = rb[i - 1]; for (size_t a = 0; a < u_ch.size(); a++) if (u_ch[a] == c && c) { u = u_list[a]; nu++; } }
+      if (rb.size() >= (size_t)(i + lb + 1)) { const char c = rb[i + lb]; for (size_t a = 0; a < w_ch.size(); a++) if (w_ch[a] == c && c) { x = w_list[a]; nw++; } }
       if (nu != 1 || nw != 1) continue;
       nreads[u].push_back(RI(y.first, i - 1));
       nreads[x].push_back(RI(y.first, i));
