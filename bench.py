@@ -34,11 +34,22 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # requests at 64 B, MI355X_MICROARCH.md HBM; profiles/r03_fetch_calibration.txt: on this chip EVERY read request the L2 sends to
 # memory is a 128-byte one, random 8-byte gathers included) + WRITE_SIZE.  Valid for the named workload only.
 TRAFFIC = {}
-for _cfg, _fn in (("1", "r01_traffic.json"), ("2", "r04_traffic_config2.json"), ("4s", "r04_traffic_config4s.json")):
+def _newest_traffic(cfg):
+    """the newest committed profiles/rNN_traffic_config<cfg>.json (r01_traffic.json for configs[1])"""
+    import glob
+    names = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic_config%s.json" % cfg)))
+    if cfg == "1":
+        names = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json"))) + names
+    return names[-1] if names else None
+
+
+for _cfg in ("1", "2", "4s"):
+    _fn = _newest_traffic(_cfg)
     try:
-        TRAFFIC["config%s" % _cfg] = json.load(open(os.path.join(ROOT, "profiles", _fn)))["traffic_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
+        TRAFFIC["config%s" % _cfg] = json.load(open(_fn))["traffic_bytes_per_launch"]
+        TRAFFIC["config%s_file" % _cfg] = os.path.basename(_fn)
+    except (TypeError, OSError, ValueError, KeyError):
+        sys.stderr.write("[bench] no PMC traffic file for config %s under profiles/: the kernel table carries no measured bytes for it\n" % _cfg)
 
 
 CHUNK_PAIRS = 250_000          # the batch is generated in chunks of this many pairs; a chunk depends on (seed, chunk index) only

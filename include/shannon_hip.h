@@ -148,6 +148,13 @@ int shn_ext_iterations(const shn_ext* e);
 uint64_t shn_ext_total_steps(const shn_ext* e);   /* walk steps executed over all fixpoint iterations */
 uint64_t shn_ext_wave_steps(const shn_ext* e);    /* ... of which by the wavefront (long-walk) kernel */
 int shn_ext_dense_rounds(const shn_ext* e);       /* rounds whose begin / mark passes streamed every claim (the others followed line flags) */
+/* Diagnostics (no counterpart in the reference, whose loop extension_correction.py:334-354 is sequential and deterministic): with
+ * SHN_EXT_DIGEST=1 in the environment shn_extend keeps checksums of the arrays of its stages -- out[stage * 64 + chunk], 8 stages
+ * (table keys, counts, bucket offsets, weights + flags, adjacency records, seed order, converged claims, walk records) x 64 chunks
+ * of each array.  Two runs on the same input must agree everywhere; the stress test names the first stage and chunk that do not. */
+int shn_ext_digests(const shn_ext* e, uint64_t* out /* [512] */);
+/* process-wide debug counters: 0 blocks of the caching allocator freed twice, 1 frees of pointers it does not own, 2 (spare)       */
+uint64_t shn_debug_counter(int which);
 /* per walk (host arrays of shn_ext_n_walks entries): right/left extension lengths (n_right ==
  * 0xFFFFFFFF marks a void walk) and the weight sum including the seed (tot_wt, :351)          */
 int shn_ext_stats(shn_ctx* ctx, const shn_ext* e, uint32_t* n_right, uint32_t* n_left, uint64_t* tot_weight);

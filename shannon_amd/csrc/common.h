@@ -288,15 +288,24 @@ __device__ __forceinline__ int64_t shn_table_find_k(const uint64_t* __restrict__
 // grow-only device workspace slots shared by the translation units (one process per GPU)
 // Caching device allocator for the per-call objects (tables, extension state, routes): a freed block is kept and
 // handed out again to the next request it fits (hipMalloc/hipFree of hundreds of MB cost milliseconds per step).
-hipError_t shn_dev_malloc_raw(void** p, size_t bytes);
-void shn_dev_free(void* p);
+hipError_t shn_dev_malloc_raw(void** p, size_t bytes);                 // on the calling thread's current stream
+hipError_t shn_dev_malloc_on(void** p, size_t bytes, hipStream_t stream);
+void shn_dev_free(void* p);                  // (events on the block's stream and the calling thread's current stream: core.hip)
+void shn_dev_free_on(void* p, hipStream_t stream);
 void shn_dev_trim();                         // give the cached blocks back to the driver
 template <class T> static inline hipError_t shn_dev_malloc(T** p, size_t bytes) { return shn_dev_malloc_raw((void**)p, bytes); }
+void shn_use_stream(hipStream_t s);          // the calling host thread works on this stream from now on (what the allocator orders frees against)
+hipStream_t shn_current_stream();
+void shn_poison(void* p, size_t bytes, hipStream_t s);      // SHN_DEV_POISON: fill with the poison byte (else nothing)
+void shn_debug_count(int i);                 // shn_debug_counter(i)++: [0] double frees [1] foreign frees [2] workspace slots asked for by two threads at once
+// entry of a call on a context: device + the thread's current stream
+#define SHN_ENTER(ctx) do { HIP_TRY(hipSetDevice((ctx)->device)); shn_use_stream((ctx)->stream); } while (0)
 
 void shn_stage_begin();                      // a top-level GPU stage starts (workspace slots used before it become reclaimable)
 size_t shn_ws_release_idle();                // frees the slots not used by the current stage; returns the bytes given back
 extern ShnWs g_shn_ws[32];
 extern "C" int shn_host_cpus(void);
+void shn_lp_census_add(shn_ctx* c, const uint64_t* v8);   // core.hip: LP census of a context or, for a fork, of its parent (under the forks' lock)
 shn_ctx* shn_thread_ctx(shn_ctx* parent);      // core.hip: the calling host thread's own fork (stream) of a context
 int shn_device_scan_u32(shn_ctx* ctx, const uint32_t* d_in, uint64_t n, uint64_t* d_out /* n+1 */, uint64_t* total_host);
 // stable LSD radix sort of (u64 key, u32 value) pairs on bits [bit_lo, bit_hi); result lands in keys/vals
@@ -305,15 +314,14 @@ int shn_sort_pairs(shn_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t* keys_
 
 static inline uint64_t cdiv(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
-// device buffers of one call, given back to the caching allocator when the call ends -- after the stream that used them has
-// been synchronized (a block given back goes straight to the next caller, another host thread's stream perhaps; on the success
-// path the call has synchronized already and this costs nothing, on an early error return kernels may still be queued)
+// device buffers of one call on one stream, given back to the caching allocator when the call ends (the allocator orders the
+// next use of a block behind what is still queued on this stream: an early error return needs no synchronisation of its own)
 struct ShnDevBufs {
   std::vector<void*> p;
   hipStream_t stream;
   explicit ShnDevBufs(hipStream_t s) : stream(s) {}
-  template <class T> hipError_t get(T** out, size_t bytes) { hipError_t e = shn_dev_malloc(out, bytes); if (e == hipSuccess) p.push_back((void*)*out); return e; }
-  ~ShnDevBufs() { if (!p.empty()) (void)hipStreamSynchronize(stream); for (void* q : p) shn_dev_free(q); }
+  template <class T> hipError_t get(T** out, size_t bytes) { hipError_t e = shn_dev_malloc_on((void**)out, bytes, stream); if (e == hipSuccess) p.push_back((void*)*out); return e; }
+  ~ShnDevBufs() { for (void* q : p) shn_dev_free_on(q, stream); }
 };
 // contig texts on the device (csrc/contig_gpu.hip): cid[g] = contig of base g; the k-windows of the selected contigs (use ==
 // NULL: all) as (packed key, base index of the window start) pairs sorted by key, stable (so by contig, position inside a run)

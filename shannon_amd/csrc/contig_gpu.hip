@@ -227,7 +227,7 @@ void shn_contig_ids(hipStream_t s, const uint64_t* d_off, uint64_t n_contigs, ui
 // sorted (key, base index) pairs of all k-windows of the selected contigs; device arrays in *keys / *vals (owned by bufs)
 int shn_sorted_windows(shn_ctx* ctx, ShnDevBufs& bufs, const uint8_t* d_bases, const uint64_t* d_off, const uint32_t* d_cid,
                           const int32_t* d_use, uint64_t total, int k, uint64_t** keys, uint32_t** vals, uint64_t* n_out) {
-  hipStream_t s = ctx->stream;
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   uint32_t* d_flag; uint64_t* d_pos; unsigned long long* d_bad;
   HIP_TRY(bufs.get(&d_flag, (total + 1) * 4));
   HIP_TRY(bufs.get(&d_pos, (total + 2) * 8));
@@ -274,8 +274,8 @@ static int contig_stage_impl(shn_ctx* ctx, const uint8_t* bases, const uint8_t* 
   if (!n_cand || !total) { *out = G; guard.g = nullptr; return SHN_OK; }
   if (off[0] != 0) return shn_fail(SHN_ERR_ARG, "shn_contig_stage: offsets must start at 0");
   if (total >= 0xFFFFFFF0ULL || n_cand >= 0x7FFFFFF0ULL) return shn_fail(SHN_ERR_OVERFLOW, "shn_contig_stage: more than 2^32 contig bases");
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   shn_stage_begin();
   TimerRegion treg(ctx, T_CONTIG);
   ShnDevBufs bufs(s);
@@ -547,8 +547,8 @@ extern "C" int shn_devtext_segments(shn_ctx* ctx, const shn_devtext* text, const
   }
   seg[2 * n_idx] = 0; seg[2 * n_idx + 1] = total;
   if (!total) return SHN_OK;
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   ShnDevBufs bufs(s);
   uint64_t* d_seg; uint8_t* d_dst;
   HIP_TRY(bufs.get(&d_seg, seg.size() * 8)); HIP_TRY(bufs.get(&d_dst, total));

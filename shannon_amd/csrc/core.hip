@@ -7,6 +7,7 @@
 #include <cstring>
 #include <cstdio>
 #include <thread>
+#include <atomic>
 
 static thread_local std::string g_err;
 void shn_set_error(const std::string& msg) { g_err = msg; }
@@ -25,7 +26,7 @@ extern "C" const char* shn_timer_name(int slot) {
   return kTimerNames[slot];
 }
 
-TimerRegion::TimerRegion(shn_ctx* ctx, int s) : TimerRegion(ctx, s, ctx->stream) {}
+TimerRegion::TimerRegion(shn_ctx* ctx, int s) : TimerRegion(ctx, s, ctx->stream) { shn_use_stream(ctx->stream); }
 TimerRegion::TimerRegion(shn_ctx* ctx, int s, hipStream_t stream) : c(ctx), slot(s), a(nullptr), b(nullptr), st(stream) {
   if (!c->timing) return;
   hipEventCreate(&a);
@@ -36,28 +37,83 @@ TimerRegion::~TimerRegion() {
   if (!a) return;
   hipEventRecord(b, st);
   std::lock_guard<std::mutex> lk(c->tmu);
-  c->pending[slot].push_back({a, b});
+  auto& q = c->pending[slot];
+  q.push_back({a, b});
+  // a caller that never reads its timers (the CLI, a service looping over steps, the forks of kept graph threads) must not pile up
+  // events without bound: beyond 64 pending regions of a slot, the finished ones at the front are folded into the sums here
+  if (q.size() > 64) {
+    size_t done = 0;
+    while (done + 1 < q.size() && hipEventQuery(q[done].second) == hipSuccess) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, q[done].first, q[done].second) == hipSuccess) { c->ms[slot] += ms; c->regions[slot]++; }
+      hipEventDestroy(q[done].first); hipEventDestroy(q[done].second);
+      done++;
+    }
+    (void)hipGetLastError();                                   // (hipErrorNotReady of the query that ended the loop)
+    if (done) q.erase(q.begin(), q.begin() + (ptrdiff_t)done);
+  }
 }
 
-// Invariant of the caching allocator (shared by every context and host thread of the process, one process per GPU): a block is
-// handed to the next caller as soon as it is freed, with no stream ordering -- so a caller frees a block only after the stream
-// that used it has been synchronized (every entry point of this library ends with hipStreamSynchronize before its frees, on its
-// error paths too: ShnDevBufs synchronizes its stream before it gives its blocks back; the graph threads work on forked contexts
-// with streams of their own).  shn_dev_trim only releases blocks nobody holds.
+// The caching allocator (shared by every context and host thread of the process, one process per GPU).  A block remembers the
+// stream it was handed out on and, when it comes back, an event recorded on that stream and on the stream of the thread that
+// frees it: the next caller gets it at once if it works on the same stream (stream order makes that safe whatever is still
+// queued), any other caller only after the events have completed.  (Until round 4 a freed block went to the next caller at once
+// and correctness rested on every caller having synchronised its stream before every free, on its error paths too.)
+// The "current stream" of a host thread is the stream of the context it last entered the library with (shn_use_stream: set by
+// SHN_ENTER, TimerRegion, shn_thread_ctx); a caller that knows better passes the stream.
+// Debug switches (environment): SHN_DEV_POISON=<byte 0..255>: every block handed out (and every workspace slot on every get) is
+// filled with that byte first -- a kernel that reads what it never wrote then reads the same garbage on every run instead of what the
+// last user left behind; SHN_DEV_NOCACHE=1: no reuse at all.  A block freed twice is reported on stderr and counted
+// (shn_debug_counter(0)) -- the second free would hand a block that is in use to the next caller.
 namespace {
-struct DevBlock { void* p; size_t cap; bool used; };
+struct DevBlock { void* p; size_t cap; bool used; hipStream_t stream; hipEvent_t ev[2]; int n_ev; };
 std::vector<DevBlock> g_blocks;
 std::mutex g_blocks_mu;
+std::vector<hipEvent_t> g_ev_pool;
+std::atomic<uint64_t> g_dbg[8];
+thread_local hipStream_t t_stream = nullptr;
+int poison_byte() { static const int v = getenv("SHN_DEV_POISON") ? (atoi(getenv("SHN_DEV_POISON")) & 255) : -1; return v; }
+bool legacy_reuse() { static const bool v = getenv("SHN_DEV_LEGACY") && getenv("SHN_DEV_LEGACY")[0] == '1'; return v; }   // (A/B: the allocator of rounds 1-4 -- a freed block goes to the next caller at once)
+bool no_cache() { static const bool v = getenv("SHN_DEV_NOCACHE") && getenv("SHN_DEV_NOCACHE")[0] == '1'; return v; }
+hipEvent_t ev_get() {
+  if (!g_ev_pool.empty()) { hipEvent_t e = g_ev_pool.back(); g_ev_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return e;
 }
-hipError_t shn_dev_malloc_raw(void** p, size_t bytes) {
+// (g_blocks_mu held) true: nothing queued at the time of the free is still running -- or the asker works on the stream it was queued on
+bool block_ready(DevBlock& b, hipStream_t asker) {
+  if (!b.n_ev || legacy_reuse()) return true;
+  if (b.n_ev == 1 && b.stream == asker) return true;          // one stream used it, the asker's own: stream order
+  for (int i = 0; i < b.n_ev; i++) if (hipEventQuery(b.ev[i]) != hipSuccess) { (void)hipGetLastError(); return false; }
+  for (int i = 0; i < b.n_ev; i++) g_ev_pool.push_back(b.ev[i]);
+  b.n_ev = 0;
+  return true;
+}
+}
+void shn_use_stream(hipStream_t s) { t_stream = s; }
+hipStream_t shn_current_stream() { return t_stream; }
+extern "C" uint64_t shn_debug_counter(int i) { return (i >= 0 && i < 8) ? g_dbg[i].load() : 0; }
+void shn_debug_count(int i) { if (i >= 0 && i < 8) g_dbg[i].fetch_add(1); }
+void shn_poison(void* p, size_t bytes, hipStream_t s) {
+  const int v = poison_byte();
+  if (v >= 0 && p && bytes) (void)hipMemsetAsync(p, v, bytes, s);
+}
+hipError_t shn_dev_malloc_on(void** p, size_t bytes, hipStream_t stream) {
   if (bytes == 0) bytes = 1;
-  {
+  if (!no_cache()) {
     std::lock_guard<std::mutex> lk(g_blocks_mu);
     int best = -1;
     for (size_t i = 0; i < g_blocks.size(); i++)
       if (!g_blocks[i].used && g_blocks[i].cap >= bytes && g_blocks[i].cap <= 2 * bytes + (1u << 20) &&
-          (best < 0 || g_blocks[i].cap < g_blocks[best].cap)) best = (int)i;
-    if (best >= 0) { g_blocks[best].used = true; *p = g_blocks[best].p; return hipSuccess; }
+          (best < 0 || g_blocks[i].cap < g_blocks[best].cap) && block_ready(g_blocks[i], stream)) best = (int)i;
+    if (best >= 0) {
+      DevBlock& b = g_blocks[best];
+      // (taken by its own stream with events pending: they stay -- whoever gets it next from another stream still has to wait for them)
+      b.used = true; b.stream = stream; *p = b.p;
+      shn_poison(b.p, b.cap, stream);
+      return hipSuccess;
+    }
   }
   hipError_t e = hipMalloc(p, bytes);
   if (e != hipSuccess) {                       // make room: drop what the cache holds, then the workspaces of earlier stages
@@ -71,20 +127,69 @@ hipError_t shn_dev_malloc_raw(void** p, size_t bytes) {
     }
     if (e != hipSuccess) return e;
   }
+  shn_poison(*p, bytes, stream);
   std::lock_guard<std::mutex> lk(g_blocks_mu);
-  g_blocks.push_back({*p, bytes, true});
+  g_blocks.push_back(DevBlock{*p, bytes, true, stream, {nullptr, nullptr}, 0});
   return hipSuccess;
 }
-void shn_dev_free(void* p) {
+hipError_t shn_dev_malloc_raw(void** p, size_t bytes) { return shn_dev_malloc_on(p, bytes, t_stream); }
+void shn_dev_free_on(void* p, hipStream_t stream) {
   if (!p) return;
-  std::lock_guard<std::mutex> lk(g_blocks_mu);
-  for (auto& b : g_blocks) if (b.p == p) { b.used = false; return; }
+  std::unique_lock<std::mutex> lk(g_blocks_mu);
+  for (size_t i = 0; i < g_blocks.size(); i++) {
+    DevBlock& b = g_blocks[i];
+    if (b.p != p) continue;
+    if (!b.used) {
+      g_dbg[0].fetch_add(1);
+      fprintf(stderr, "[shannon_hip] shn_dev_free: block %p (%zu bytes) freed twice\n", p, b.cap);
+      return;
+    }
+    // events: behind everything queued so far on the stream the block was handed out on and on the freeing thread's stream
+    hipStream_t on[2] = {b.stream, stream};
+    const int n_on = b.stream == stream ? 1 : 2;
+    for (int j = 0; j < b.n_ev; j++) g_ev_pool.push_back(b.ev[j]);       // (re-used on its own stream with events pending: superseded by the new ones on the same streams or later)
+    b.n_ev = 0;
+    bool ok = true;
+    for (int j = 0; j < n_on; j++) {
+      hipEvent_t e = ev_get();
+      if (!e || hipEventRecord(e, on[j]) != hipSuccess) { (void)hipGetLastError(); if (e) g_ev_pool.push_back(e); ok = false; break; }
+      b.ev[b.n_ev++] = e;
+    }
+    if (!ok) {                                  // no event to be had: the old contract -- wait here
+      lk.unlock();
+      (void)hipStreamSynchronize(on[0]); if (n_on > 1) (void)hipStreamSynchronize(on[1]);
+      lk.lock();
+      for (auto& bb : g_blocks) if (bb.p == p) { for (int j = 0; j < bb.n_ev; j++) g_ev_pool.push_back(bb.ev[j]); bb.n_ev = 0; bb.used = false; break; }
+      return;
+    }
+    if (no_cache()) {
+      DevBlock gone = b;
+      g_blocks.erase(g_blocks.begin() + (ptrdiff_t)i);
+      lk.unlock();
+      for (int j = 0; j < gone.n_ev; j++) (void)hipEventSynchronize(gone.ev[j]);
+      lk.lock();
+      for (int j = 0; j < gone.n_ev; j++) g_ev_pool.push_back(gone.ev[j]);
+      lk.unlock();
+      (void)hipFree(gone.p);
+      return;
+    }
+    b.used = false;
+    return;
+  }
+  lk.unlock();
+  g_dbg[1].fetch_add(1);
+  fprintf(stderr, "[shannon_hip] shn_dev_free: %p is not a block of the caching allocator\n", p);
   hipFree(p);                                  // not ours (should not happen)
 }
+void shn_dev_free(void* p) { shn_dev_free_on(p, t_stream); }
 void shn_dev_trim() {
   std::lock_guard<std::mutex> lk(g_blocks_mu);
   std::vector<DevBlock> keep;
-  for (auto& b : g_blocks) { if (b.used) keep.push_back(b); else hipFree(b.p); }
+  for (auto& b : g_blocks) {
+    if (b.used) { keep.push_back(b); continue; }
+    for (int j = 0; j < b.n_ev; j++) { (void)hipEventSynchronize(b.ev[j]); g_ev_pool.push_back(b.ev[j]); }
+    hipFree(b.p);
+  }
   g_blocks.swap(keep);
 }
 
@@ -139,6 +244,11 @@ static void fold_into_parent(shn_ctx* f) {                      // (g_forks_mu h
   std::lock_guard<std::mutex> lp(p->tmu);
   for (int i = 0; i < T_N; i++) { p->ms[i] += f->ms[i]; p->regions[i] += f->regions[i]; f->ms[i] = 0; f->regions[i] = 0; }
 }
+void shn_lp_census_add(shn_ctx* c, const uint64_t* v8) {
+  std::lock_guard<std::mutex> lk(g_forks_mu);
+  shn_ctx* to = c->parent ? c->parent : c;
+  for (int i = 0; i < 7; i++) if (v8[i]) __atomic_fetch_add(&to->lp_stats[i], v8[i], __ATOMIC_RELAXED);
+}
 extern "C" void shn_ctx_destroy(shn_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
@@ -185,7 +295,7 @@ struct ShnThreadCtx {
   ~ShnThreadCtx() { if (c) shn_ctx_destroy(c); }
 };
 static thread_local ShnThreadCtx t_thread_ctx;
-shn_ctx* shn_thread_ctx(shn_ctx* p) {
+static shn_ctx* thread_ctx_impl(shn_ctx* p) {
   if (!p) return nullptr;
   static const bool no_fork = getenv("SHN_GRAPH_FORK") && getenv("SHN_GRAPH_FORK")[0] == '0';
   if (no_fork) return p;
@@ -195,6 +305,11 @@ shn_ctx* shn_thread_ctx(shn_ctx* p) {
   if (shn_ctx_fork(p, &t.c)) { t.c = nullptr; return p; }
   t.parent = p;
   return t.c;
+}
+shn_ctx* shn_thread_ctx(shn_ctx* p) {
+  shn_ctx* c = thread_ctx_impl(p);
+  if (c) shn_use_stream(c->stream);            // (the calling thread works on this context's stream from here on)
+  return c;
 }
 
 extern "C" int shn_ctx_sync(shn_ctx* c) {
@@ -299,7 +414,7 @@ extern "C" int shn_reads_create(shn_ctx* ctx, const uint8_t* bytes, const uint64
   if (!ctx || !out || (!bytes && n_reads)) return shn_fail(SHN_ERR_ARG, "shn_reads_create: NULL argument");
   if (enc != SHN_ENC_ASCII && enc != SHN_ENC_CODES) return shn_fail(SHN_ERR_ARG, "shn_reads_create: bad encoding");
   if (!offsets && fixed_len == 0 && n_reads) return shn_fail(SHN_ERR_ARG, "shn_reads_create: fixed_len is 0");
-  HIP_TRY(hipSetDevice(ctx->device));
+  SHN_ENTER(ctx);
   shn_reads* r = new shn_reads();
   memset(r, 0, sizeof(*r));
   r->ctx = ctx;
@@ -335,7 +450,7 @@ extern "C" int shn_reads_create(shn_ctx* ctx, const uint8_t* bytes, const uint64
   }
   uint8_t* d_bytes = nullptr;
   uint64_t* d_boff = nullptr;
-  hipStream_t s = ctx->stream;
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   auto cleanup = [&]() { if (d_bytes) hipFree(d_bytes); if (d_boff) hipFree(d_boff); };
 #define TRY2(e) do { hipError_t _e = (e); if (_e != hipSuccess) { cleanup(); shn_reads_destroy(r); \
       return shn_fail(SHN_ERR_HIP, std::string(#e) + ": " + hipGetErrorString(_e)); } } while (0)
@@ -394,7 +509,7 @@ int shn_pack_fixed_codes(shn_ctx* ctx, const uint8_t* d_codes, uint64_t n, uint3
   return e == hipSuccess ? SHN_OK : shn_fail(SHN_ERR_HIP, std::string("pack_kernel: ") + hipGetErrorString(e));
 }
 int shn_reads_finish_fixed(shn_ctx* ctx, shn_reads* r) {
-  hipStream_t s = ctx->stream;
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   unsigned long long* d_nbad = nullptr;
   HIP_TRY(hipMalloc(&d_nbad, 8));
   hipError_t e = hipMemsetAsync(d_nbad, 0, 8, s);
@@ -437,8 +552,8 @@ __global__ void reads_gather_kernel(const uint64_t* __restrict__ wa, const uint6
 static int reads_gather_impl(shn_ctx* ctx, const shn_reads* a, const shn_reads* b, const uint32_t* rows, const uint8_t* flags, const uint32_t* dev_rows,
                              const uint8_t* dev_flags, uint64_t n, shn_reads** out) {
   if (!a->fixed_len || (b && (b->fixed_len != a->fixed_len || b->wpr != a->wpr))) return shn_fail(SHN_ERR_ARG, "shn_reads_gather: fixed-length read sets of one length only");
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   shn_reads* r = new shn_reads();
   memset(r, 0, sizeof(*r));
   r->ctx = ctx; r->device = ctx->device; r->n_reads = n; r->fixed_len = a->fixed_len; r->max_len = a->fixed_len; r->wpr = a->wpr;

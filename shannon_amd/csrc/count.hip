@@ -12,6 +12,8 @@
 #include "common.h"
 #include <mutex>
 #include <atomic>
+#include <thread>
+#include <functional>
 #include <cmath>
 #include <algorithm>
 #include <cstring>
@@ -474,7 +476,12 @@ __global__ void gtable_compact_kernel(const unsigned long long* __restrict__ gke
 // never touches.  get / release are serialised by g_ws_mu, so a slot's pointer and capacity are never written by two threads.
 static std::atomic<uint64_t> g_stage{1};
 static std::mutex g_ws_mu;
-void shn_stage_begin() { g_stage.fetch_add(1); }
+// (single owner: the host thread that began the current stage is the one that may ask for process-wide slots until the next stage
+// begins; anybody else asking is counted -- shn_debug_counter(2) -- and reported once: two threads on one slot would overwrite each
+// other's buffers)
+static std::atomic<uint64_t> g_stage_thread{0};
+static uint64_t this_thread_tag() { return (uint64_t)std::hash<std::thread::id>()(std::this_thread::get_id()) | 1ULL; }
+void shn_stage_begin() { g_stage.fetch_add(1); g_stage_thread.store(this_thread_tag()); }
 static size_t ws_release_idle_locked() {
   size_t freed = 0;
   const uint64_t now = g_stage.load();
@@ -487,8 +494,18 @@ size_t shn_ws_release_idle() {
 }
 int ShnWs::get(size_t bytes, void** out) {
   std::lock_guard<std::mutex> lk(g_ws_mu);
+  if (this >= g_shn_ws && this < g_shn_ws + 32) {
+    const uint64_t owner = g_stage_thread.load();
+    if (owner && owner != this_thread_tag()) {
+      static bool told = false;
+      shn_debug_count(2);
+      if (!told) { told = true; fprintf(stderr, "[shannon_hip] process-wide workspace slot %d asked for by a thread that did not begin the current stage\n", (int)(this - g_shn_ws)); }
+    }
+  }
   stage = g_stage.load();
+  bool grew = false;
   if (bytes > cap) {
+    grew = true;
     if (p) hipFree(p);
     p = nullptr; cap = 0;
     hipError_t e = hipMalloc(&p, bytes);
@@ -502,13 +519,20 @@ int ShnWs::get(size_t bytes, void** out) {
     cap = bytes;
   }
   *out = p;
+  {
+    // SHN_DEV_POISON: a slot that has just grown is filled with the poison byte; SHN_DEV_POISON_WS=1: on EVERY request (finds reads of
+    // what an earlier call left behind -- but the seed scan's count / fetch pair (seeds.hip) keeps its offsets in its slots between
+    // the two calls by design and does not survive that)
+    static const bool every = getenv("SHN_DEV_POISON_WS") && getenv("SHN_DEV_POISON_WS")[0] == '1';
+    if (every || grew) shn_poison(p, bytes, shn_current_stream());
+  }
   return SHN_OK;
 }
 ShnWs g_shn_ws[32];   // per-process (one process per GPU)
 #define g_ws g_shn_ws
 
 int shn_device_scan_u32(shn_ctx* ctx, const uint32_t* d_in, uint64_t n, uint64_t* d_out /* n+1 */, uint64_t* total_host) {
-  hipStream_t s = ctx->stream;
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   uint64_t nblocks = cdiv(n, 1024);
   if (nblocks == 0) nblocks = 1;
   void* sums;
@@ -554,9 +578,9 @@ static ReadsView sub_view(const ReadsView& v, uint64_t r0, uint64_t n) {
 extern "C" int shn_count_k1mers(shn_ctx* ctx, shn_reads* const* sets, int n_sets, int k1, int both_strands, shn_table** out) {
   if (!ctx || !sets || !out || n_sets <= 0) return shn_fail(SHN_ERR_ARG, "shn_count_k1mers: bad argument");
   if (k1 < 2 || k1 > 32) return shn_fail(SHN_ERR_ARG, "shn_count_k1mers: k1 must be in [2,32]");
-  HIP_TRY(hipSetDevice(ctx->device));
+  SHN_ENTER(ctx);
   shn_stage_begin();
-  hipStream_t s = ctx->stream;
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   TimerRegion ttot(ctx, T_COUNT_TOTAL);
   uint64_t upper = 0;
   std::vector<ReadsView> views;
@@ -634,7 +658,7 @@ extern "C" int shn_count_k1mers(shn_ctx* ctx, shn_reads* const* sets, int n_sets
 }
 
 static int count_views(shn_ctx* ctx, const std::vector<ReadsView>& views, uint64_t upper, int k1, int both_strands, shn_table** out) {
-  hipStream_t s = ctx->stream;
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   // One-pass path first (see count_direct_kernel): worth it when the table is small next to the windows; the size is a
   // guess (windows / 32, at most 2^24 slots to begin with) corrected by what earlier calls of this process needed.
   {
@@ -792,7 +816,7 @@ static int count_views(shn_ctx* ctx, const std::vector<ReadsView>& views, uint64
 static int build_from_keys(shn_ctx* ctx, uint64_t* keysA, uint64_t* keysB, uint32_t* tmpc, uint32_t* cntA, uint32_t* cntB,
                            const std::vector<uint64_t>& off1h, int bits, int b2, int k, int canonical, uint64_t N,
                            uint64_t total, shn_table** out, bool* overflowed) {
-  hipStream_t s = ctx->stream;
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   int b1 = bits - b2;
   int nb1 = 1 << b1, nb2 = 1 << b2;
   uint64_t nbk = (uint64_t)1 << bits;
@@ -918,7 +942,7 @@ extern "C" int shn_table_canonical(const shn_table* t) { return t ? t->canonical
 
 extern "C" int shn_table_download(shn_ctx* ctx, const shn_table* t, uint64_t* keys, uint32_t* counts) {
   if (!ctx || !t) return shn_fail(SHN_ERR_ARG, "shn_table_download: NULL argument");
-  HIP_TRY(hipSetDevice(ctx->device));
+  SHN_ENTER(ctx);
   if (keys) HIP_TRY(hipMemcpyAsync(keys, t->d_keys, t->n * 8, hipMemcpyDeviceToHost, ctx->stream));
   if (counts) HIP_TRY(hipMemcpyAsync(counts, t->d_counts, t->n * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -960,8 +984,8 @@ extern "C" int shn_table_device_ptrs(const shn_table* t, void** keys, void** cou
 extern "C" int shn_table_lookup(shn_ctx* ctx, const shn_table* t, const uint64_t* keys, uint64_t n, uint32_t* counts) {
   if (!ctx || !t || (!keys && n) || (!counts && n)) return shn_fail(SHN_ERR_ARG, "shn_table_lookup: NULL argument");
   if (!n) return SHN_OK;
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   uint64_t* dq; uint32_t* dc;
   HIP_TRY(hipMalloc(&dq, n * 8));
   HIP_TRY(hipMalloc(&dc, n * 4));
@@ -998,8 +1022,8 @@ extern "C" int shn_table_from_pairs(shn_ctx* ctx, const void* dev_keys, const vo
 extern "C" int shn_table_merge_rc(shn_ctx* ctx, const shn_table* fwd, const shn_table* other, shn_table** out) {
   if (!ctx || !fwd || !other || !out) return shn_fail(SHN_ERR_ARG, "shn_table_merge_rc: NULL argument");
   if (fwd->canonical || other->canonical || fwd->k != other->k) return shn_fail(SHN_ERR_ARG, "shn_table_merge_rc: two plain tables of one k");
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   const uint64_t n = fwd->n + other->n;
   ShnDevBufs bufs(s);
   uint64_t* d_k = nullptr; uint32_t* d_c = nullptr;
@@ -1017,8 +1041,8 @@ extern "C" int shn_table_from_pairs(shn_ctx* ctx, const void* dev_keys, const vo
                                     int canonical, shn_table** out) {
   if (!ctx || !out || (n && (!dev_keys || !dev_counts))) return shn_fail(SHN_ERR_ARG, "shn_table_from_pairs: NULL argument");
   if (n >= 0xFFFFFFFFULL) return shn_fail(SHN_ERR_ARG, "shn_table_from_pairs: more than 2^32 pairs");
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   TimerRegion ttot(ctx, T_TABLE_BUILD);           // small tables (probe / seed / exchanged shards): one region, kept apart
   TimingOff toff(ctx);                            // from the per-kernel timers of the counting pass
   const uint64_t* keys = (const uint64_t*)dev_keys;
@@ -1124,8 +1148,8 @@ extern "C" int shn_table_shard(shn_ctx* ctx, const shn_table* t, int n_ranks, ui
                                void* dev_counts_out) {
   if (!ctx || !t || !per_rank || n_ranks < 1 || n_ranks > 64) return shn_fail(SHN_ERR_ARG, "shn_table_shard: bad argument");
   if (t->n && (!dev_keys_out || !dev_counts_out)) return shn_fail(SHN_ERR_ARG, "shn_table_shard: NULL output");
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   void* p;
   int rc;
   if ((rc = g_ws[0].get(64 * 16 + 64, &p))) return rc;

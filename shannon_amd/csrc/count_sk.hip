@@ -521,7 +521,7 @@ int shn_count_superkmers(shn_ctx* ctx, const std::vector<ReadsView>& views, uint
   const int mode = getenv("SHN_COUNT_SK") ? atoi(getenv("SHN_COUNT_SK")) : 1;          // 0 off, 1 large inputs, 2 always (tests)
   if (mode == 0 || k1 < SK_MIN_K || (k1 == 32 && !both_strands) || upper == 0) return SHN_OK;
   if (mode != 2 && upper < (1ULL << 22)) return SHN_OK;
-  hipStream_t s = ctx->stream;
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   SkParams P;
   P.k = k1;
   P.m = std::max(13, 2 * k1 - 48);

@@ -76,6 +76,23 @@ __host__ __device__ __forceinline__ RowView rows_L(const Rec* r) { return RowVie
 __host__ __device__ __forceinline__ WordView words_weight(const Rec* r) { return WordView{(const char*)r + 32}; }
 __host__ __device__ __forceinline__ WordView words_hint(const Rec* r) { return WordView{(const char*)r + 36}; }
 
+// ---- stage checksums (SHN_EXT_DIGEST=1; tests/test_stress_gpu.py, tools/stress_digest.py): two runs on the same input must agree
+// stage by stage; the first stage that differs -- and the 1/64 of its array where -- localises a run-to-run difference.
+// Stages: 0 table keys, 1 table counts, 2 bucket offsets, 3 weights + flags, 4 records (adjacency rows, weight, seed rank; before the
+// first round), 5 seed order, 6 converged claims, 7 walk records (n_right, n_left, total weight).
+#define EXT_DIG_STAGES 8
+#define EXT_DIG_CHUNKS 64
+__global__ void ext_digest_kernel(const uint32_t* __restrict__ w, uint64_t n_words, uint64_t salt, unsigned long long* __restrict__ out) {
+  unsigned long long acc = 0;
+  uint32_t cur = 0xFFFFFFFFu;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t ch = (uint32_t)((i * EXT_DIG_CHUNKS) / n_words);
+    if (ch != cur) { if (cur != 0xFFFFFFFFu && acc) atomicAdd(&out[cur], acc); cur = ch; acc = 0; }
+    acc += shn_mix64((i * 0x9E3779B97F4A7C15ULL) ^ ((uint64_t)w[i] << 1) ^ salt);
+  }
+  if (cur != 0xFFFFFFFFu && acc) atomicAdd(&out[cur], acc);
+}
+
 struct shn_ext {
   shn_ctx* ctx;
   int device;
@@ -98,6 +115,8 @@ struct shn_ext {
   uint32_t* d_nr;        // [n_seeds] right steps (UNCLAIMED = void walk)
   uint32_t* d_nl;        // [n_seeds]
   uint64_t* d_totw;      // [n_seeds] sum of weights incl. the seed
+  uint64_t dig[EXT_DIG_STAGES][EXT_DIG_CHUNKS];   // SHN_EXT_DIGEST=1: checksums of the stages' arrays (shn_ext_digests)
+  int has_dig;
 };
 
 __device__ __forceinline__ uint64_t oriented_string(const uint64_t* __restrict__ tkeys, uint32_t o, int k) {
@@ -929,16 +948,24 @@ __global__ void ext_audit_kernel(WalkArgs A, uint64_t ns, unsigned long long* __
 
 // classify the dirty walks of the open block: long ones (memo or recorded length) go to the wavefront kernel,
 // the others to the thread kernel.  counters: [0] long [1] unused [2] short [3] dirty walks
-__global__ __launch_bounds__(1024) void ext_plan_kernel(const uint32_t* __restrict__ nr, const uint32_t* __restrict__ nl, uint64_t ns, uint32_t frozen,
+__global__ __launch_bounds__(1024) void ext_plan_kernel(uint32_t* nr, uint32_t* nl, uint64_t ns, uint32_t frozen,
                                 const uint8_t* __restrict__ mvalid, const uint32_t* __restrict__ mR, const uint32_t* __restrict__ mL,
                                 const uint8_t* __restrict__ dirty, uint32_t* __restrict__ long_list, uint32_t* __restrict__ short_list,
-                                unsigned long long* __restrict__ counters, uint32_t long_walk, uint8_t* __restrict__ coarse) {
+                                unsigned long long* __restrict__ counters, uint32_t long_walk, uint8_t* __restrict__ coarse,
+                                const u64* __restrict__ fresh_claim, const uint32_t* __restrict__ order, uint64_t* __restrict__ totw) {
   // ns here = current rank limit (walks >= limit have not started yet); walks < frozen are final and never run
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + frozen;
-  const bool isd = r < ns && dirty[r];
+  const bool isd_all = r < ns && dirty[r];
   // coarse[i]: one of the 64 walks frozen + 64 i .. is dirty (the begin pass asks it before dirty[]: 1/64 of the bytes, they stay
   // in the L2 while the claims stream past)
-  { const unsigned long long anyd = __ballot(isd); if ((threadIdx.x & 63) == 0) coarse[(r - frozen) >> 6] = anyd ? 1 : 0; }
+  { const unsigned long long anyd = __ballot(isd_all); if ((threadIdx.x & 63) == 0) coarse[(r - frozen) >> 6] = anyd ? 1 : 0; }
+  // fresh_claim != NULL: the first round of a block that has just opened -- every claim there is belongs to a final walk, so a walk
+  // whose seed is claimed (by a lower rank: final walks are all lower) is void for good: its record is written here and it is on
+  // no list.  At BASELINE configs[2] 98.6 % of the walks are void, most of them through walks of EARLIER blocks: the walk kernel of
+  // the second and third block then runs over the survivors, packed -- not one live walk among 63 lanes that look at their seed and
+  // idle until the wavefront's longest walk ends.
+  bool isd = isd_all;
+  if (isd && fresh_claim && RANK(fresh_claim[order[r]]) < r) { nr[r] = UNCLAIMED; nl[r] = 0; totw[r] = 0; isd = false; }
   bool lg = false;
   if (isd) {
     uint32_t a = nr[r];
@@ -948,11 +975,12 @@ __global__ __launch_bounds__(1024) void ext_plan_kernel(const uint32_t* __restri
   }
   // one atomic per block of 1024 and list (one per wavefront on three single addresses was 39 us per launch)
   __shared__ uint32_t wl[16], wsh[16];
-  __shared__ unsigned long long bl, bs;
+  __shared__ unsigned long long bl, bs, bd;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const unsigned long long below = (1ULL << lane) - 1ULL;
   const unsigned long long lm = __ballot(isd && lg), sm = __ballot(isd && !lg);
   if (lane == 0) { wl[wid] = (uint32_t)__popcll(lm); wsh[wid] = (uint32_t)__popcll(sm); }
+  if (threadIdx.x == 0) bd = 0;
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t tl = 0, ts = 0;
@@ -960,8 +988,13 @@ __global__ __launch_bounds__(1024) void ext_plan_kernel(const uint32_t* __restri
     for (int w = 0; w < nw; w++) { tl += wl[w]; ts += wsh[w]; }
     bl = tl ? atomicAdd(&counters[0], (unsigned long long)tl) : 0ULL;
     bs = ts ? atomicAdd(&counters[2], (unsigned long long)ts) : 0ULL;
-    if (tl + ts) atomicAdd(&counters[3], (unsigned long long)(tl + ts));
   }
+  {                                                                // dirty walks, the ones settled above included (they "ran")
+    const unsigned long long dm = __ballot(isd_all);
+    if (lane == 0 && dm) atomicAdd(&bd, (unsigned long long)__popcll(dm));
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && bd) atomicAdd(&counters[3], bd);
   __syncthreads();
   uint32_t ol = 0, os = 0;
   for (int w = 0; w < wid; w++) { ol += wl[w]; os += wsh[w]; }
@@ -1223,7 +1256,7 @@ static int build_fine_dict(shn_ctx* ctx, const shn_table* t, const uint8_t* d_fl
                            void* room = nullptr);
 static inline uint64_t fine_dict_lines(const shn_table* t) { return t->n / FD_PER_LINE + 1 + (t->layout ? t->n_buckets + 1 : 0) + FD_HOPS; }
 static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank, shn_table** out) {
-  hipStream_t s = ctx->stream;
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   const uint64_t n = t->n;
   uint32_t* d_weight = nullptr; uint8_t* d_flags = nullptr;
   unsigned long long* lines = nullptr;
@@ -1264,8 +1297,9 @@ static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank
   if (nb > big_cap) nb = 0;
   if (nb) {
     std::vector<uint32_t> br(nb), bs(nb);
-    TRYS(hipMemcpy(br.data(), d_big_root, nb * 4, hipMemcpyDeviceToHost));
-    TRYS(hipMemcpy(bs.data(), d_big_size, nb * 4, hipMemcpyDeviceToHost));
+    TRYS(hipMemcpyAsync(br.data(), d_big_root, nb * 4, hipMemcpyDeviceToHost, s));
+    TRYS(hipMemcpyAsync(bs.data(), d_big_size, nb * 4, hipMemcpyDeviceToHost, s));
+    TRYS(hipStreamSynchronize(s));
     std::vector<uint32_t> ord(nb);
     for (uint32_t j = 0; j < nb; j++) ord[j] = j;
     std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return bs[a] != bs[b] ? bs[a] > bs[b] : br[a] < br[b]; });
@@ -1277,7 +1311,7 @@ static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank
       bo[j] = (uint8_t)best;
       load[best] += bs[j];
     }
-    TRYS(hipMemcpy(d_big_owner, bo.data(), nb, hipMemcpyHostToDevice));
+    TRYS(hipMemcpyAsync(d_big_owner, bo.data(), nb, hipMemcpyHostToDevice, s));       // (bo lives until the synchronisation at the end of this function)
     hipLaunchKernelGGL(cc_assign_kernel, dim3((uint32_t)cdiv(nb, 256)), dim3(256), 0, s, d_big_root, d_big_owner, (uint32_t)nb, d_owner_root);
   }
   // this rank's k1-mers, in table order (bucket by bucket, ascending inside a bucket)
@@ -1308,7 +1342,7 @@ static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank
 // hipMalloc again); NULL: a block of its own, which the caller frees after the stream has drained
 static int build_fine_dict(shn_ctx* ctx, const shn_table* t, const uint8_t* d_flags, unsigned long long** lines_out, uint64_t* n_lines_out,
                            void* room) {
-  hipStream_t s = ctx->stream;
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   const uint64_t n = t->n;
   const uint64_t n_lines = fine_dict_lines(t);
   unsigned long long* lines = (unsigned long long*)room;
@@ -1339,6 +1373,32 @@ static thread_local shn_block_cb g_block_cb = nullptr;
 static thread_local void* g_block_user = nullptr;
 extern "C" void shn_ext_set_block_callback(shn_block_cb cb, void* user) { g_block_cb = cb; g_block_user = user; }
 
+// checksum of one array into e->dig[stage] (added to what is there: a stage may be made of several arrays)
+static int ext_digest(shn_ctx* ctx, shn_ext* e, int stage, const void* d, uint64_t bytes, uint64_t salt) {
+  if (!bytes) return SHN_OK;
+  hipStream_t s = ctx->stream;
+  unsigned long long* d_out = nullptr;
+  HIP_TRY(hipMalloc(&d_out, EXT_DIG_CHUNKS * 8));
+  hipError_t er = hipMemsetAsync(d_out, 0, EXT_DIG_CHUNKS * 8, s);
+  uint64_t h[EXT_DIG_CHUNKS];
+  if (er == hipSuccess) {
+    hipLaunchKernelGGL(ext_digest_kernel, dim3(1024), dim3(256), 0, s, (const uint32_t*)d, bytes / 4, salt, d_out);
+    er = hipMemcpyAsync(h, d_out, sizeof h, hipMemcpyDeviceToHost, s);
+  }
+  if (er == hipSuccess) er = hipStreamSynchronize(s);
+  (void)hipFree(d_out);
+  if (er != hipSuccess) return shn_fail(SHN_ERR_HIP, std::string("ext_digest: ") + hipGetErrorString(er));
+  for (int i = 0; i < EXT_DIG_CHUNKS; i++) e->dig[stage][i] += h[i];
+  e->has_dig = 1;
+  return SHN_OK;
+}
+extern "C" int shn_ext_digests(const shn_ext* e, uint64_t* out) {
+  if (!e || !out) return shn_fail(SHN_ERR_ARG, "shn_ext_digests: NULL argument");
+  if (!e->has_dig) return shn_fail(SHN_ERR_ARG, "shn_ext_digests: the extension was not made with SHN_EXT_DIGEST=1");
+  memcpy(out, e->dig, sizeof e->dig);
+  return SHN_OK;
+}
+
 extern "C" int shn_extend(shn_ctx* ctx, const shn_table* t, uint32_t min_weight, int max_iterations, shn_ext** out) {
   return shn_extend_sharded(ctx, t, min_weight, max_iterations, 1, 0, out);
 }
@@ -1348,9 +1408,9 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   if (!ctx || !t || !out) return shn_fail(SHN_ERR_ARG, "shn_extend: NULL argument");
   if (world < 1 || world > 255 || rank < 0 || rank >= world) return shn_fail(SHN_ERR_ARG, "shn_extend_sharded: bad world/rank");
   if (2 * t->n >= 0x7FFFFFFFULL) return shn_fail(SHN_ERR_ARG, "shn_extend: table too large for 31-bit oriented ids");
-  HIP_TRY(hipSetDevice(ctx->device));
+  SHN_ENTER(ctx);
   shn_stage_begin();
-  hipStream_t s = ctx->stream;
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   if (world > 1 && t->n) {
     shn_table* sub = nullptr;
     int rcs;
@@ -1463,6 +1523,14 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   TRYE(hipMemsetAsync(pool, 0xFF, pool_cap * 4, s));            // NONE32: "no entry"
   // (hints and seed ranks live in the records: ext_records_kernel wrote "none" into both)
   if (ns) hipLaunchKernelGGL(ext_seed_rank_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, e->d_order, (uint64_t)ns, e->d_rec);
+  const bool want_dig = getenv("SHN_EXT_DIGEST") && getenv("SHN_EXT_DIGEST")[0] == '1';
+  if (want_dig) {
+    int rd;
+    if ((rd = ext_digest(ctx, e, 0, t->d_keys, n * 8, 1)) || (rd = ext_digest(ctx, e, 1, t->d_counts, n * 4, 2)) ||
+        (rd = ext_digest(ctx, e, 2, t->d_bucket_off, (t->n_buckets + 1) * 8, 3)) || (rd = ext_digest(ctx, e, 3, e->d_weight, n * 4, 4)) ||
+        (rd = ext_digest(ctx, e, 3, e->d_flags, n & ~3ULL, 5)) || (rd = ext_digest(ctx, e, 4, e->d_rec, 2 * n * sizeof(Rec), 6)) ||
+        (rd = ext_digest(ctx, e, 5, e->d_order, ns * 4, 7))) { shn_ext_destroy(e); return rd; }
+  }
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   TRYE(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
@@ -1498,8 +1566,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   TRYE(hipMemsetAsync(dirty, 0, 2 * (ns + 1), s));               // dirty + ran
   TRYE(hipMemsetAsync(dirty, 1, limit, s));
   TRYE(hipMemsetAsync(owned, 0, (ns + 1) * 4, s));
-  { const unsigned long long c0 = 64;                            // memo pool cursor: 64 words of NONE32 padding in front
-    TRYE(hipMemcpy(d_cnt + 10, &c0, 8, hipMemcpyHostToDevice)); }
+  plan[6] = 64;                                                  // memo pool cursor: 64 words of NONE32 padding in front
+  TRYE(hipMemcpyAsync(d_cnt + 10, plan + 6, 8, hipMemcpyHostToDevice, s));   // (from the pinned block, on the context's stream like everything else here)
   auto tune = [](const char* name, uint32_t dflt) { const char* v = getenv(name); return v ? (uint32_t)strtoul(v, nullptr, 10) : dflt; };
   const int precise_marks = (int)tune("SHN_EXT_PRECISE", 1);       // 0: the conservative rule (every walk standing next to a freed k1-mer)
   const uint32_t long_walk = tune("SHN_EXT_LONG_WALK", LONG_WALK), memo_min = tune("SHN_EXT_MEMO_MIN", MEMO_MIN),
@@ -1511,6 +1579,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   const unsigned long long bulk_min = getenv("SHN_EXT_BULK") ? strtoull(getenv("SHN_EXT_BULK"), nullptr, 10) : 262144ULL;
   const unsigned long long dense_min = getenv("SHN_EXT_DENSE") ? strtoull(getenv("SHN_EXT_DENSE"), nullptr, 10) : (4ULL << 20);   // (BASELINE configs[2]: 262144 -> 954 ms, 2 M or 16 M -> 900 ms per extension)
   const int seed_check = (int)tune("SHN_EXT_SEEDCHECK", 1);
+  const bool prepass = tune("SHN_EXT_PREPASS", 1) != 0;            // a block's first round settles the walks whose seed an earlier block holds (ext_plan_kernel)
   unsigned long long expect_dirty = limit;
   while (!converged && it < max_iterations) {
     const bool bulk = bulk_min && expect_dirty >= bulk_min;
@@ -1522,7 +1591,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     TRYE(hipMemsetAsync(d_cnt + 2, 0, 32, s));
     if (limit > frozen)
       hipLaunchKernelGGL(ext_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 1024)), dim3(1024), 0, s, e->d_nr, e->d_nl, (uint64_t)limit, frozen,
-                         mvalid, mR, mL, dirty, long_list, short_list, d_cnt + 2, bulk ? 0xFFFFFFFFu : long_walk, coarse);
+                         mvalid, mR, mL, dirty, long_list, short_list, d_cnt + 2, bulk ? 0xFFFFFFFFu : long_walk, coarse,
+                         (fresh_block && frozen > 0 && prepass) ? (const u64*)claim : (const u64*)nullptr, e->d_order, e->d_totw);
     // (pinned host memory: a pageable destination costs a staging copy kernel per round)
     TRYE(hipMemcpyAsync(plan, d_cnt + 2, 32, hipMemcpyDeviceToHost, s));
     TRYE(hipStreamSynchronize(s));
@@ -1605,8 +1675,9 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     }
     if (x_t0 > 0) {
       TRYE(hipStreamSynchronize(s)); timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
-      unsigned long long st = 0, lw = 0; TRYE(hipMemcpy(&st, d_cnt + 1, 8, hipMemcpyDeviceToHost));
-      if (A.dbg) { TRYE(hipMemcpy(&lw, d_cnt + 44, 8, hipMemcpyDeviceToHost)); TRYE(hipMemset(d_cnt + 44, 0, 8)); }
+      unsigned long long st = 0, lw = 0; TRYE(hipMemcpyAsync(&st, d_cnt + 1, 8, hipMemcpyDeviceToHost, s));
+      if (A.dbg) { TRYE(hipMemcpyAsync(&lw, d_cnt + 44, 8, hipMemcpyDeviceToHost, s)); TRYE(hipMemsetAsync(d_cnt + 44, 0, 8, s)); }
+      TRYE(hipStreamSynchronize(s));
       fprintf(stderr, "[shn_extend] XTIME round %d: thread walker %llu walks, %.2f ms, steps so far %llu; longest walk %llu steps in %.2f ms (%.2f us per step)\n", it + 1, plan[2],
               ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6 - x_t0, st, lw >> 32, (double)(lw & 0xFFFFFFFFULL) * 1e-5, (lw >> 32) ? (double)(lw & 0xFFFFFFFFULL) * 1e-2 / (double)(lw >> 32) : 0.0);
     }
@@ -1670,10 +1741,12 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     A.order = e->d_order; A.adjR = rows_R(e->d_rec); A.adjL = rows_L(e->d_rec); A.weight = words_weight(e->d_rec);
     A.claim = claim; A.nr_out = e->d_nr; A.nl_out = e->d_nl; A.totw_out = e->d_totw;
     unsigned long long au[2] = {0, ~0ULL};
-    TRYE(hipMemcpy(d_cnt + 48, au, 16, hipMemcpyHostToDevice));
+    plan[4] = 0; plan[5] = ~0ULL;
+    TRYE(hipMemcpyAsync(d_cnt + 48, plan + 4, 16, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(ext_audit_kernel, dim3((uint32_t)cdiv(ns, 64)), dim3(64), 0, s, A, (uint64_t)ns, d_cnt + 48);
+    TRYE(hipMemcpyAsync(plan + 4, d_cnt + 48, 16, hipMemcpyDeviceToHost, s));
     TRYE(hipStreamSynchronize(s));
-    TRYE(hipMemcpy(au, d_cnt + 48, 16, hipMemcpyDeviceToHost));
+    au[0] = plan[4]; au[1] = plan[5];
     if (au[0]) {
       fprintf(stderr, "[shn_extend] AUDIT: %llu walks are not at their fixpoint, lowest rank %llu of %llu (rounds %d)\n", au[0], au[1], ns, it);
       if (atoi(getenv("SHN_EXT_AUDIT")) > 1) { shn_ext_destroy(e); return shn_fail(SHN_ERR_INTERNAL, "shn_extend: audit failed"); }
@@ -1681,6 +1754,11 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   }
   e->iterations = it;
   if (!converged) { shn_ext_destroy(e); return shn_fail(SHN_ERR_INTERNAL, "shn_extend: walk fixpoint did not converge"); }
+  if (want_dig) {
+    int rd;
+    if ((rd = ext_digest(ctx, e, 6, claim, 2 * n * 8, 8)) || (rd = ext_digest(ctx, e, 7, e->d_nr, ns * 4, 9)) || (rd = ext_digest(ctx, e, 7, e->d_nl, ns * 4, 10)) ||
+        (rd = ext_digest(ctx, e, 7, e->d_totw, ns * 8, 11))) { shn_ext_destroy(e); return rd; }
+  }
   // what is left to do with the result (stats, emit, seed info, weights) reads the claims, the walk records and the table: the
   // records and the snapshot (most of the state) go back to the allocator now
   TRYE(hipStreamSynchronize(s));
@@ -1694,7 +1772,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   steps += wsteps;
   if (getenv("SHN_DEBUG")) {
     unsigned long long dbg[10];
-    TRYE(hipMemcpy(dbg, d_cnt + 32, 80, hipMemcpyDeviceToHost));
+    TRYE(hipMemcpyAsync(dbg, d_cnt + 32, 80, hipMemcpyDeviceToHost, s));
+    TRYE(hipStreamSynchronize(s));
     fprintf(stderr, "[shn_extend] converged after %d rounds; steps: %llu total, %llu in the wave kernel (%llu from own memos, %llu from foreign memos)\n",
             it, steps, wsteps, dbg[0], dbg[1]);
     fprintf(stderr, "[shn_extend] memo_follow: no hint %llu, owner without memo %llu, memo moved on %llu, followed backwards %llu, nothing left %llu, followed %llu; "
@@ -1718,8 +1797,8 @@ extern "C" int shn_ext_stats_range(shn_ctx* ctx, const shn_ext* e, uint64_t lo, 
   if (!ctx || !e || (n && (!n_right || !n_left || !tot_weight))) return shn_fail(SHN_ERR_ARG, "shn_ext_stats_range: NULL argument");
   if (lo + n > e->n_seeds) return shn_fail(SHN_ERR_ARG, "shn_ext_stats_range: range outside the walks");
   if (!n) return SHN_OK;
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   HIP_TRY(hipMemcpyAsync(n_right, e->d_nr + lo, n * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(n_left, e->d_nl + lo, n * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(tot_weight, e->d_totw + lo, n * 8, hipMemcpyDeviceToHost, s));
@@ -1729,8 +1808,8 @@ extern "C" int shn_ext_stats_range(shn_ctx* ctx, const shn_ext* e, uint64_t lo, 
 
 extern "C" int shn_ext_stats(shn_ctx* ctx, const shn_ext* e, uint32_t* n_right, uint32_t* n_left, uint64_t* tot_weight) {
   if (!ctx || !e) return shn_fail(SHN_ERR_ARG, "shn_ext_stats: NULL argument");
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   if (n_right) HIP_TRY(hipMemcpyAsync(n_right, e->d_nr, e->n_seeds * 4, hipMemcpyDeviceToHost, s));
   if (n_left) HIP_TRY(hipMemcpyAsync(n_left, e->d_nl, e->n_seeds * 4, hipMemcpyDeviceToHost, s));
   if (tot_weight) HIP_TRY(hipMemcpyAsync(tot_weight, e->d_totw, e->n_seeds * 8, hipMemcpyDeviceToHost, s));
@@ -1765,8 +1844,8 @@ extern "C" int shn_ext_live_stats(shn_ctx* ctx, const shn_ext* e, uint64_t* n_li
 extern "C" int shn_ext_live_stats_min(shn_ctx* ctx, const shn_ext* e, uint32_t min_steps, uint64_t* n_live, uint32_t* rank, uint32_t* n_right,
                                       uint32_t* n_left, uint64_t* tot_weight) {
   if (!ctx || !e || !n_live) return shn_fail(SHN_ERR_ARG, "shn_ext_live_stats: NULL argument");
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   const uint64_t ns = e->n_seeds;
   if (!ns) { *n_live = 0; return SHN_OK; }
   void *pf, *pp, *po;
@@ -1833,8 +1912,8 @@ __global__ void ext_accept_gather_kernel(const uint32_t* __restrict__ nr, const 
 extern "C" int shn_ext_accept(shn_ctx* ctx, const shn_ext* e, uint32_t min_length, double threshold, uint64_t* n_out, uint32_t* rank, uint32_t* steps,
                               uint64_t* tot_weight, uint8_t* cls) {
   if (!ctx || !e || !n_out) return shn_fail(SHN_ERR_ARG, "shn_ext_accept: NULL argument");
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   const uint64_t ns = e->n_seeds;
   if (!ns) { *n_out = 0; return SHN_OK; }
   void *pf, *pp, *po;
@@ -1879,8 +1958,8 @@ __global__ void ext_seed_info_kernel(const uint32_t* __restrict__ ranks, uint64_
 extern "C" int shn_ext_seed_info(shn_ctx* ctx, const shn_ext* e, const uint32_t* ranks, uint64_t n, uint64_t* keys, uint32_t* weights) {
   if (!ctx || !e || (n && (!ranks || !keys || !weights))) return shn_fail(SHN_ERR_ARG, "shn_ext_seed_info: NULL argument");
   if (!n) return SHN_OK;
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   for (uint64_t j = 0; j < n; j++) if (ranks[j] >= e->n_seeds) return shn_fail(SHN_ERR_ARG, "shn_ext_seed_info: rank out of range");
   uint32_t *dr, *dw; uint64_t* dk;
   HIP_TRY(shn_dev_malloc(&dr, n * 4)); HIP_TRY(shn_dev_malloc(&dw, n * 4)); HIP_TRY(shn_dev_malloc(&dk, n * 8));
@@ -1899,8 +1978,8 @@ static int ext_emit_impl(shn_ctx* ctx, const shn_ext* e, const uint32_t* ranks, 
   if (!ctx || !e || (n_sel && (!ranks || !offsets || (!bases_out && !dev_out)))) return shn_fail(SHN_ERR_ARG, "shn_ext_emit: NULL argument");
   if (dev_out) *dev_out = nullptr;
   if (!n_sel) return SHN_OK;
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   TimerRegion treg(ctx, T_EXTEND);
   const uint64_t total = offsets[n_sel], ns = e->n_seeds;
   // rank -> index in the selection (built on the device: the map has one entry per walk, the selection is small);
@@ -1979,8 +2058,8 @@ extern "C" int shn_ext_weights(shn_ctx* ctx, const shn_ext* e, const uint64_t* k
   if (!ctx || !e || (n && (!keys || !weights))) return shn_fail(SHN_ERR_ARG, "shn_ext_weights: NULL argument");
   if (e->owned_table) return shn_fail(SHN_ERR_ARG, "shn_ext_weights: not available on a component shard (it holds only this rank's k1-mers)");
   if (!n) return SHN_OK;
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   uint64_t* dq; uint32_t* dw;
   HIP_TRY(shn_dev_malloc(&dq, n * 8));
   HIP_TRY(shn_dev_malloc(&dw, n * 4));

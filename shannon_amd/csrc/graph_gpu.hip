@@ -331,8 +331,8 @@ extern "C" int shn_unitigs_build(shn_ctx* ctx, const uint8_t* bases, const uint6
   if (total >= 0x7FFFFFF0ULL) return shn_fail(SHN_ERR_OVERFLOW, "shn_unitigs_build: more than 2^31 contig bases");
   for (uint64_t c = 0; c < n_contigs; c++)
     if (part_of[c] >= n_parts || (c && part_of[c] < part_of[c - 1])) return shn_fail(SHN_ERR_ARG, "shn_unitigs_build: part_of must be ascending and < n_parts");
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   shn_stage_begin();
   TimerRegion treg(ctx, T_GRAPH_GPU);
   // table regions: a power of two >= 2 x the K-windows of the partition

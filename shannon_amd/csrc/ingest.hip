@@ -179,7 +179,7 @@ extern "C" int shn_reads_ingest(shn_ctx* ctx, const uint8_t* text, uint64_t n_by
     for (auto& x : th) x.join();
     return SHN_OK;
   }
-  HIP_TRY(hipSetDevice(ctx->device));
+  SHN_ENTER(ctx);
   shn_reads* r = new shn_reads();
   memset(r, 0, sizeof(*r));
   r->ctx = ctx; r->device = ctx->device; r->n_reads = N; r->fixed_len = L; r->max_len = L;
@@ -199,7 +199,7 @@ extern "C" int shn_reads_ingest(shn_ctx* ctx, const uint8_t* text, uint64_t n_by
   uint8_t* pin[2] = {nullptr, nullptr};
   uint8_t* dst[2] = {nullptr, nullptr};
   hipEvent_t ev[2] = {nullptr, nullptr};
-  hipStream_t s = ctx->stream;
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   auto cleanup = [&]() {                       // (the staging blocks go back to the allocator only after the stream has drained)
     (void)hipStreamSynchronize(s);
     for (int b = 0; b < 2; b++) { if (dst[b]) shn_dev_free(dst[b]); if (ev[b]) hipEventDestroy(ev[b]); }

@@ -349,8 +349,8 @@ static int kp_scan_impl(shn_ctx* ctx, const shn_reads* reads, int K, const uint8
     if (offset_out) std::fill(offset_out, offset_out + nr, 0u);
     return SHN_OK;
   }
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   TimerRegion treg(ctx, T_SEEDS);
   ShnDevBufs bufs(s);
   uint64_t T = 1024;
@@ -455,8 +455,8 @@ int shn_known_paths_dev(shn_ctx* ctx, const shn_reads* reads, int K, const uint8
   left->clear(); records->clear(); rec_cnt->clear();
   *kp_out = nullptr;
   if (!nr || !total || n_nodes >= 0x7FFFFFFFULL || total >= 0xFFFFFFFFULL) return shn_fail(SHN_ERR_ARG, "shn_known_paths_dev: no reads / no nodes / too many bases");
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   TimerRegion treg(ctx, T_SEEDS);
   ShnDevBufs bufs(s);
   uint64_t T = 1024;
@@ -530,8 +530,8 @@ int shn_kp_mate_pairs(shn_kp* kp, const shn_dedup* dd, const int32_t* patches, u
   pairs_out->clear();
   if (!dd->paired || !kp->n_reads) return SHN_OK;
   shn_ctx* ctx = kp->ctx;
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   ShnDevBufs bufs(s);
   uint64_t T = 1u << 16;
   while (T < 64 * kp->n_nodes && T < (1u << 24)) T <<= 1;

@@ -411,12 +411,19 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
   if (!ctx || (n_problems && (!m || !n || !trials || !pid || !ab || !mask || !flows_out)))
     return shn_fail(SHN_ERR_ARG, "shn_lp_solve_batch: NULL argument");
   if (!n_problems) return SHN_OK;
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   const bool center = ctx->lp_rule != SHN_LP_RULE_VERTEX;
   std::vector<LpProblem> probs(n_problems);
   std::vector<uint32_t> bprob, bfirst, lprob, lfirst, cprob, cfirst;       // blocks of the vertex kernel (state in HBM / in LDS) / of the centre kernel
   uint64_t lds_words = 0;
+  // the in-LDS trial kernel asks for up to LP_LDS_WORDS * 8 = 156 KB of dynamic LDS: asked for once per process; a device or driver
+  // that does not grant it gets the HBM form of the same kernel for every problem
+  static const bool lds_granted = []() {
+    const hipError_t e = hipFuncSetAttribute((const void*)lp_trials_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LP_LDS_WORDS * 8));
+    if (e != hipSuccess) { (void)hipGetLastError(); fprintf(stderr, "[shannon_amd] LP: %d bytes of LDS per block not granted (%s): trial state stays in HBM\n", (int)(LP_LDS_WORDS * 8), hipGetErrorString(e)); }
+    return e == hipSuccess;
+  }();
   uint64_t n_large_trials = 0;
   uint64_t in_off = 0, mask_off = 0, ws_off = 0, out_off = 0, ws2_off = 0, stat_off = 0;
   for (uint32_t p = 0; p < n_problems; p++) {
@@ -431,7 +438,7 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
     ws_off += (2 * mn + 3ULL * (m[p] + n[p])) * trials[p];
     stat_off += trials[p];
     out_off += mn * trials[p];
-    const bool in_lds = (2 * mn + 3ULL * (m[p] + n[p])) * LBLK <= LP_LDS_WORDS;
+    const bool in_lds = lds_granted && (2 * mn + 3ULL * (m[p] + n[p])) * LBLK <= LP_LDS_WORDS;
     for (uint32_t f = 0; f < trials[p]; f += LBLK) { (in_lds ? lprob : bprob).push_back(p); (in_lds ? lfirst : bfirst).push_back(f); lds_words = in_lds ? std::max<uint64_t>(lds_words, (2 * mn + 3ULL * (m[p] + n[p])) * LBLK) : lds_words; }
     // the centre kernel has work only where the supported cells of the problem hold a cycle (rows and columns as vertices, a
     // supported cell as an edge): on a forest every class is a tree and its face a point.  At BASELINE configs[2] 9,000
@@ -491,7 +498,6 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
   void* pst = (uint8_t*)pdown + o_stat;
   HIP_TRY(hipMemcpyAsync(pup, h_up, up_bytes - 16, hipMemcpyHostToDevice, s));
   if (!lprob.empty()) {
-    if (lds_words * 8 > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)lp_trials_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LP_LDS_WORDS * 8)));
     hipLaunchKernelGGL(lp_trials_kernel<true>, dim3((uint32_t)lprob.size()), dim3(LBLK), lds_words * 8, s, (const LpProblem*)pp, d_lprob, d_lfirst,
                        (const double*)pin, (const uint8_t*)pm, seed, (uint64_t*)pws, (double*)pout);
   }
@@ -512,8 +518,10 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
   if (with_stat) { stat.resize(4 * stat_off); memcpy(stat.data(), (const uint8_t*)h_down + o_stat, stat.size() * 4); }
   // census (bench.py: lp_calls / lp_degenerate): a problem is degenerate when the optimal face of one of its trials was not a point
   // (a fork's census is its parent's: the batches of the sparse flow run on the graph threads' forks, several at a time)
-  shn_ctx* sctx = ctx->parent ? ctx->parent : ctx;
-  auto tally = [&](int i, uint64_t v) { if (v) __atomic_fetch_add(&sctx->lp_stats[i], v, __ATOMIC_RELAXED); };
+  // (summed here, added to the owner's census in one locked step at the end: shn_lp_census_add looks the parent up under the lock
+  // shn_ctx_destroy takes when it orphans the forks of a context that goes away)
+  uint64_t census[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto tally = [&](int i, uint64_t v) { census[i] += v; };
   tally(0, n_problems);
   tally(2, stat_off);
   tally(6, n_large_trials);
@@ -537,6 +545,7 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
       t0 += trials[p];
     }
   }
+  shn_lp_census_add(ctx, census);
   return SHN_OK;
 }
 

@@ -16,7 +16,7 @@ struct PostDev {
 
 int post_dev_create(shn_ctx* ctx, const std::vector<std::pair<const uint8_t*, uint64_t>>& pieces, PostDev** out) {
   if (!ctx || !out) return shn_fail(SHN_ERR_ARG, "post_dev_create: NULL argument");
-  HIP_TRY(hipSetDevice(ctx->device));
+  SHN_ENTER(ctx);
   uint64_t total = 0;
   for (auto& pc : pieces) total += pc.second;
   PostDev* d = new PostDev{ctx, nullptr, total};
@@ -34,7 +34,7 @@ int post_dev_create(shn_ctx* ctx, const std::vector<std::pair<const uint8_t*, ui
 
 int post_dev_create_cap(shn_ctx* ctx, uint64_t cap, PostDev** out) {
   if (!ctx || !out) return shn_fail(SHN_ERR_ARG, "post_dev_create_cap: NULL argument");
-  HIP_TRY(hipSetDevice(ctx->device));
+  SHN_ENTER(ctx);
   PostDev* d = new PostDev{ctx, nullptr, cap};
   if (shn_dev_malloc(&d->d_text, cap + 64) != hipSuccess) { delete d; return shn_fail(SHN_ERR_NOMEM, "post_dev_create_cap: out of device memory"); }
   *out = d;

@@ -74,9 +74,9 @@ extern "C" int shn_probe_build(shn_ctx* ctx, const uint8_t* bases, const uint64_
   if (total >= 0xFFFFFFF0ULL) return shn_fail(SHN_ERR_OVERFLOW, "shn_probe_build: more than 2^32 contig bases");
   for (uint64_t c = 0; c < n_contigs; c++)
     if (part_of[c] >= n_parts || (c && part_of[c] < part_of[c - 1])) return shn_fail(SHN_ERR_ARG, "shn_probe_build: part_of must be ascending and < n_parts");
-  HIP_TRY(hipSetDevice(ctx->device));
+  SHN_ENTER(ctx);
   shn_stage_begin();
-  hipStream_t s = ctx->stream;
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   shn_probe* P = new shn_probe();
   struct Guard { shn_probe* p; ~Guard() { shn_probe_destroy(p); } } guard{P};
   // set p = {p} for every partition; sets of several partitions follow

@@ -148,8 +148,8 @@ extern "C" int shn_reads_dedup(shn_ctx* ctx, const shn_reads* a, const shn_reads
     const uint64_t lim = (d >= n_in) ? (paired ? b->n_reads : a->n_reads) + n_in : n_in;
     if (d >= lim) return shn_fail(SHN_ERR_ARG, "shn_reads_dedup: read index out of range");
   }
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   const bool dbg = getenv("SHN_DEBUG") != nullptr;
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t0 = now(), t_alloc = 0, t_up = 0, t_k = 0, t_scan = 0, t_alloc2 = 0;
@@ -225,8 +225,8 @@ int shn_reads_dedup_dev(shn_ctx* ctx, const shn_reads* a, const shn_reads* b, co
       const uint64_t lim = (d >= n_in) ? (paired ? b->n_reads : a->n_reads) + n_in : n_in;
       if (d >= lim) return shn_fail(SHN_ERR_ARG, "shn_reads_dedup_dev: read index out of range");
     }
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   shn_dedup* D = new shn_dedup();
   D->ctx = ctx; D->n_slots = nh; D->paired = paired ? 1 : 0;
   if (!nh) { *out = D; return SHN_OK; }

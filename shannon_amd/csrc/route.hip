@@ -193,7 +193,7 @@ extern "C" uint64_t shn_routes_size(const shn_routes* r) { return r ? r->n : 0; 
 
 extern "C" int shn_routes_download(shn_ctx* ctx, const shn_routes* r, uint32_t* pid, uint32_t* ridx) {
   if (!ctx || !r) return shn_fail(SHN_ERR_ARG, "shn_routes_download: NULL argument");
-  HIP_TRY(hipSetDevice(ctx->device));
+  SHN_ENTER(ctx);
   if (pid) HIP_TRY(hipMemcpyAsync(pid, r->d_pid, r->n * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (ridx) HIP_TRY(hipMemcpyAsync(ridx, r->d_ridx, r->n * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -218,8 +218,8 @@ __global__ void routes_bounds_kernel(const uint32_t* __restrict__ pid, const uin
 
 extern "C" int shn_routes_bounds(shn_ctx* ctx, const shn_routes* r, uint32_t n_parts, uint32_t split, uint64_t* start, uint64_t* below) {
   if (!ctx || !r || !start || !below) return shn_fail(SHN_ERR_ARG, "shn_routes_bounds: NULL argument");
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   uint64_t* d = nullptr;
   HIP_TRY(shn_dev_malloc(&d, (size_t)(2 * n_parts + 2) * 8));
   hipLaunchKernelGGL(routes_bounds_kernel, dim3((n_parts + 1 + 63) / 64), dim3(64), 0, s, r->d_pid, r->d_ridx, r->n, n_parts, split, d, d + n_parts + 1);
@@ -234,7 +234,7 @@ extern "C" int shn_routes_bounds(shn_ctx* ctx, const shn_routes* r, uint32_t n_p
 extern "C" int shn_routes_download_range(shn_ctx* ctx, const shn_routes* r, uint64_t lo, uint64_t n, uint32_t* ridx) {
   if (!ctx || !r || (n && !ridx)) return shn_fail(SHN_ERR_ARG, "shn_routes_download_range: NULL argument");
   if (lo + n > r->n) return shn_fail(SHN_ERR_ARG, "shn_routes_download_range: range outside the routes");
-  HIP_TRY(hipSetDevice(ctx->device));
+  SHN_ENTER(ctx);
   if (n) HIP_TRY(hipMemcpyAsync(ridx, r->d_ridx + lo, n * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return SHN_OK;
@@ -250,9 +250,9 @@ extern "C" int shn_route_reads_mode(shn_ctx* ctx, const shn_reads* r1, const shn
   if (r2 && r2->n_reads != r1->n_reads) return shn_fail(SHN_ERR_ARG, "shn_route_reads: mate files differ in length");
   if (probe->canonical) return shn_fail(SHN_ERR_ARG, "shn_route_reads: probe table must hold plain (non-canonical) k1-mers");
   if (2 * r1->n_reads >= 0xFFFFFFFFULL) return shn_fail(SHN_ERR_ARG, "shn_route_reads: too many reads for 32-bit doubled indices");
-  HIP_TRY(hipSetDevice(ctx->device));
+  SHN_ENTER(ctx);
   shn_stage_begin();
-  hipStream_t s = ctx->stream;
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   TimerRegion treg(ctx, T_ROUTE);
   uint64_t N2 = 2 * r1->n_reads;
   uint32_t n_mem = set_off[n_sets];
@@ -322,8 +322,8 @@ extern "C" int shn_route_reads_mode(shn_ctx* ctx, const shn_reads* r1, const shn
 extern "C" int shn_table_create(shn_ctx* ctx, const uint64_t* keys, const uint32_t* values, uint64_t n, int k, int canonical,
                                 shn_table** out) {
   if (!ctx || !out || (n && (!keys || !values))) return shn_fail(SHN_ERR_ARG, "shn_table_create: NULL argument");
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   if (n <= (1u << 22) && !getenv("SHN_TABLE_DEVICE_BUILD")) {
     // Small dictionaries (the graph stage's K-mer seed tables: a few 10^5 keys, one or two per partition, made by many host threads
     // at once) are laid out on the host -- bucket = top bits of fmix64(key), ascending inside a bucket, duplicates summed -- and

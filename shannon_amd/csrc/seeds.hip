@@ -99,8 +99,8 @@ static int seed_scan_impl(shn_ctx* ctx, const shn_reads* reads, int K, const shn
                           uint32_t* out_read, uint32_t* out_start, uint32_t* out_id) {
   if (!ctx || !reads || !patterns || !n_hits) return shn_fail(SHN_ERR_ARG, "shn_seed_scan: NULL argument");
   if (reads->n_invalid) return shn_fail(SHN_ERR_ARG, "shn_seed_scan: reads contain non-ACGT bases");
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   TimerRegion treg(ctx, T_SEEDS);
   SView v = sview(reads);
   uint32_t max_win = reads->max_len > (uint32_t)K + 1 ? reads->max_len - K - 1 : 0;
@@ -153,8 +153,8 @@ extern "C" int shn_seed_ends(shn_ctx* ctx, const shn_reads* reads, int K, const 
                              uint32_t* last_id) {
   if (!ctx || !reads || !patterns || !first_id || !last_id) return shn_fail(SHN_ERR_ARG, "shn_seed_ends: NULL argument");
   if (reads->n_invalid) return shn_fail(SHN_ERR_ARG, "shn_seed_ends: reads contain non-ACGT bases");
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   TimerRegion treg(ctx, T_SEEDS);
   if (reads->n_reads == 0) return SHN_OK;
   SView v = sview(reads);
@@ -226,8 +226,8 @@ extern "C" int shn_rmer_join(shn_ctx* ctx, const shn_reads* cands, const shn_rea
   if (r < 1 || r > 32) return shn_fail(SHN_ERR_ARG, "shn_rmer_join: r must be in [1,32]");
   if (cands->n_invalid || foreign->n_invalid) return shn_fail(SHN_ERR_ARG, "shn_rmer_join: non-ACGT bases");
   *n_hits = 0;
-  HIP_TRY(hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   TimerRegion treg(ctx, T_SEEDS);
   SView vf = sview(foreign), vc = sview(cands);
   const uint32_t wf = foreign->max_len >= (uint32_t)r ? foreign->max_len - r + 1 : 0, wc = cands->max_len >= (uint32_t)r ? cands->max_len - r + 1 : 0;

@@ -104,7 +104,7 @@ int shn_sort_pairs(shn_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t* keys_
                    int bit_lo, int bit_hi) {
   if (n == 0) return SHN_OK;
   if (n >= 0xFFFFFFFFULL) return shn_fail(SHN_ERR_ARG, "shn_sort_pairs: n too large");
-  hipStream_t s = ctx->stream;
+  hipStream_t s = ctx->stream; shn_use_stream(s);
   uint32_t nblocks = (uint32_t)cdiv(n, STILE);
   void* p;
   int rc = g_shn_ws[8].get((size_t)256 * nblocks * 4 + ((size_t)256 * nblocks + 2) * 8, &p);

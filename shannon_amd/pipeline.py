@@ -194,7 +194,11 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
         if (sflow_beside and os.environ.get("SHN_POST_NATIVE", "1") != "0" and os.environ.get("SHN_POST_GPU", "1") != "0" and
                 os.environ.get("SHN_POST_STREAM", "1") != "0"):
             try:
-                pstream = post.PostStream(ctx_b)
+                # room for the merge's text on the device: the transcripts are paths through the contigs' graph -- a few times the
+                # accepted contigs' text (both strands, isoforms sharing exons); a text that outgrows it falls back to the one-piece merge
+                _raw = getattr(res, "contig_raw", None)
+                _cbytes = int(len(_raw[0])) if _raw is not None else sum(len(c) for c in res.contigs)
+                pstream = post.PostStream(ctx_b, capacity=min(2 << 30, max(64 << 20, 8 * _cbytes + len(single_text))))
             except _lib.ShannonError:
                 pstream = None
 
