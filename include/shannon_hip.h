@@ -428,6 +428,16 @@ int shn_known_paths_search(shn_ctx* ctx, const shn_reads* reads, int K, const ui
 /* Host threads the library keeps busy at most: min(hardware threads, affinity mask, cgroup CPU quota) / ranks on the node
  * (LOCAL_WORLD_SIZE or SHN_LOCAL_RANKS); SHN_HOST_CPUS overrides.
  * (-- ; the reference takes its process count from --nprocs, shannon.py:99.)                                                   */
+/* ---- row a8: the partitioner of contig-graph components larger than --partition.  Replaces the external call
+ * `gpmetis -ufactor=U componentN.txt P` of kmers_for_component.py:221,234 (METIS 5: randomised, unpinned -- the parity cases
+ * replay a given partition vector) by a deterministic multilevel k-way partitioner in the library (csrc/partition_host.hip):
+ * heavy-edge matching, growth on the coarsest graph, boundary refinement per level, balance (1 + U/1000) n / P.
+ * shn_partition_metis reads the reference's componentN.txt text (extension_correction.py:446-456); shn_partition_csr the same
+ * graph as CSR; part_out[v] in [0, n_parts).  shn_metis_reweight = weight_updated_graph.py:24-42 (edges cut by `part` times
+ * `penalty`, the reference's text format); out == NULL: only *out_len.                                                        */
+int shn_partition_metis(const char* text, uint64_t len, uint64_t n_vertices, int n_parts, int ufactor, int32_t* part_out);
+int shn_partition_csr(uint64_t n_vertices, const uint64_t* off, const int32_t* nb, const int64_t* w, int n_parts, int ufactor, int32_t* part_out);
+int shn_metis_reweight(const char* text, uint64_t len, const int32_t* part, uint64_t n_vertices, int penalty, char* out, uint64_t out_cap, uint64_t* out_len);
 int shn_host_cpus(void);
 /* OPT-IN, process-wide: glibc's allocator serves blocks up to 32 MB from the heap and never trims it (mallopt), so that the host
  * stages do not pay for fresh zero pages every batch.  For programs that own their process (bench.py, shannon.py); also applied

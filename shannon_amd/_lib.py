@@ -76,6 +76,9 @@ SIGNATURES = {
     "shn_mbgraph_run_rows": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, vp, vp, C.c_uint64, C.c_int, vpp]),
     "shn_mbgraph_run_routes": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_int, vpp]),
     "shn_host_cpus": (C.c_int, []),
+    "shn_partition_metis": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, vp]),
+    "shn_partition_csr": (C.c_int, [C.c_uint64, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "shn_metis_reweight": (C.c_int, [C.c_char_p, C.c_uint64, vp, C.c_uint64, C.c_int, vp, C.c_uint64, u64p]),
     "shn_malloc_tune_now": (None, []),
     "shn_known_paths_scan": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_uint64, vp, vp, vp]),
     "shn_known_paths_search": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp, C.c_uint64, vp]),

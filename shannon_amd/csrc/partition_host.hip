@@ -1,0 +1,296 @@
+// The partitioner of contig-graph components larger than --partition (row a8), native host code: the stand-in for
+// `gpmetis -ufactor=U componentN.txt P` (kmers_for_component.py:207-237; METIS 5 is external, randomised and unpinned) and the
+// re-weighting between its two runs (weight_updated_graph.py:24-42).  A deterministic multilevel k-way scheme built like METIS's own:
+// heavy-edge-matching coarsening, greedy graph growing on the coarsest graph, k-way boundary refinement on every level, the balance
+// bound (1 + U/1000) * n / P.  Statement for statement the same decisions as the readable form kept in
+// shannon_amd/kmers_for_component.py (multilevel_partition_py; tests compare the two on random graphs), in C++ because a real
+// transcriptome's shared-exon component holds 10^4..10^5 contigs and the interpreted form takes minutes there.
+#include "common.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <set>
+#include <string>
+#include <vector>
+#include <time.h>
+#include <cstdio>
+#include <cstdlib>
+
+namespace {
+struct Graph {
+  std::vector<uint64_t> off;        // [n + 1]
+  std::vector<int32_t> nb;          // neighbours, the reference's order at level 0, ascending on the coarse levels
+  std::vector<int64_t> w;
+  std::vector<int64_t> vw;          // vertex weights
+  size_t n() const { return vw.size(); }
+};
+
+// "n m fmt" header, then one line per vertex: neighbour (1-based) weight neighbour weight ...
+int parse_metis(const char* text, uint64_t len, Graph& g) {
+  const char* p = text; const char* end = text + len;
+  auto skip_sp = [&]() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\r')) p++; };
+  auto read_int = [&](int64_t& v) -> bool {
+    skip_sp();
+    if (p >= end || *p < '0' || *p > '9') return false;
+    v = 0;
+    while (p < end && *p >= '0' && *p <= '9') { v = v * 10 + (*p - '0'); p++; }
+    return true;
+  };
+  int64_t n = 0;
+  if (!read_int(n)) return shn_fail(SHN_ERR_ARG, "shn_partition_metis: no vertex count in the first line");
+  while (p < end && *p != '\n') p++;
+  if (p < end) p++;
+  g.off.assign(1, 0); g.nb.clear(); g.w.clear(); g.vw.assign((size_t)n, 1);
+  for (int64_t i = 0; i < n; i++) {
+    while (p < end && *p != '\n') {
+      int64_t u, wt;
+      if (!read_int(u)) { skip_sp(); if (p < end && *p != '\n') return shn_fail(SHN_ERR_ARG, "shn_partition_metis: not a number"); break; }
+      if (!read_int(wt)) return shn_fail(SHN_ERR_ARG, "shn_partition_metis: a neighbour without a weight");
+      if (u < 1 || u > n) return shn_fail(SHN_ERR_ARG, "shn_partition_metis: neighbour out of range");
+      g.nb.push_back((int32_t)(u - 1)); g.w.push_back(wt);
+      skip_sp();
+    }
+    if (p < end) p++;
+    g.off.push_back(g.nb.size());
+  }
+  return SHN_OK;
+}
+
+// _grow_partition: parts one at a time from the lowest-numbered free vertex, always absorbing the free vertex with the largest
+// total edge weight into the growing part (ties: lowest index), up to ceil(W / P) weight; leftovers go to the lightest part
+std::vector<int32_t> grow_partition(const Graph& g, int n_parts) {
+  const size_t n = g.n();
+  std::vector<int32_t> part(n, -1);
+  int64_t total = 0;
+  for (int64_t x : g.vw) total += x;
+  const int64_t target = (int64_t)std::ceil((double)total / (double)n_parts);
+  size_t nxt = 0;
+  std::vector<int64_t> sizes((size_t)n_parts, 0);
+  std::vector<int64_t> gain(n, 0);
+  std::vector<uint8_t> in_gain(n, 0);
+  std::vector<int32_t> members;
+  for (int p = 0; p < n_parts; p++) {
+    while (nxt < n && part[nxt] != -1) nxt++;
+    if (nxt >= n) break;
+    std::set<std::pair<int64_t, int32_t>> order;                       // (-gain, vertex): the smallest is the next to absorb
+    members.clear();
+    auto put = [&](int32_t v, int64_t add) {
+      if (in_gain[v]) { order.erase({-gain[v], v}); gain[v] += add; }
+      else { in_gain[v] = 1; gain[v] = add; members.push_back(v); }
+      order.insert({-gain[v], v});
+    };
+    put((int32_t)nxt, 0);
+    while (sizes[p] < target && !order.empty()) {
+      const int32_t v = order.begin()->second;
+      order.erase(order.begin());
+      in_gain[v] = 0;
+      part[v] = p;
+      sizes[p] += g.vw[v];
+      for (uint64_t q = g.off[v]; q < g.off[v + 1]; q++) if (part[g.nb[q]] == -1) put(g.nb[q], g.w[q]);
+      if (order.empty() && sizes[p] < target) {
+        while (nxt < n && part[nxt] != -1) nxt++;
+        if (nxt < n) put((int32_t)nxt, 0);
+      }
+    }
+    for (int32_t v : members) { in_gain[v] = 0; gain[v] = 0; }         // (what is left in the dict is dropped with it)
+  }
+  for (size_t v = 0; v < n; v++)
+    if (part[v] == -1) {
+      int best = 0;
+      for (int q = 1; q < n_parts; q++) if (sizes[q] < sizes[best]) best = q;
+      part[v] = best;
+      sizes[best] += g.vw[v];
+    }
+  return part;
+}
+
+// _coarsen_bounded: vertices in index order, each unmatched vertex pairs with the unmatched neighbour behind its heaviest edge
+// (ties: lowest index) unless the pair would weigh more than max_vw; pairs become one vertex, parallel edges add up
+void coarsen(const Graph& g, int64_t max_vw, Graph& c, std::vector<int32_t>& cmap) {
+  const size_t n = g.n();
+  std::vector<int32_t> match(n, -1);
+  cmap.assign(n, -1);
+  int32_t nc = 0;
+  for (size_t v = 0; v < n; v++) {
+    if (match[v] != -1) continue;
+    int32_t best = -1; int64_t bw = -1;
+    for (uint64_t q = g.off[v]; q < g.off[v + 1]; q++) {
+      const int32_t u = g.nb[q]; const int64_t w = g.w[q];
+      if ((size_t)u != v && match[u] == -1 && g.vw[u] + g.vw[v] <= max_vw && (w > bw || (w == bw && u < best))) { best = u; bw = w; }
+    }
+    match[v] = best >= 0 ? best : (int32_t)v;
+    cmap[v] = nc;
+    if (best >= 0) { match[best] = (int32_t)v; cmap[best] = nc; }
+    nc++;
+  }
+  c.vw.assign((size_t)nc, 0);
+  // coarse adjacency: per coarse vertex the (coarse neighbour, summed weight) pairs, ascending by neighbour
+  std::vector<std::vector<int32_t>> fine((size_t)nc);
+  for (size_t v = 0; v < n; v++) { c.vw[cmap[v]] += g.vw[v]; fine[cmap[v]].push_back((int32_t)v); }
+  c.off.assign(1, 0); c.nb.clear(); c.w.clear();
+  std::vector<std::pair<int32_t, int64_t>> row;
+  for (int32_t cv = 0; cv < nc; cv++) {
+    row.clear();
+    for (int32_t v : fine[cv])
+      for (uint64_t q = g.off[v]; q < g.off[v + 1]; q++) { const int32_t cu = cmap[g.nb[q]]; if (cu != cv) row.push_back({cu, g.w[q]}); }
+    std::sort(row.begin(), row.end(), [](const std::pair<int32_t, int64_t>& a, const std::pair<int32_t, int64_t>& b) { return a.first < b.first; });
+    for (size_t i = 0; i < row.size();) {
+      size_t j = i; int64_t s = 0;
+      while (j < row.size() && row[j].first == row[i].first) { s += row[j].second; j++; }
+      c.nb.push_back(row[i].first); c.w.push_back(s);
+      i = j;
+    }
+    c.off.push_back(c.nb.size());
+  }
+}
+
+// refine_partition: vertices in index order, a vertex moves to the neighbouring part it is connected to most strongly if that
+// lowers the cut, the target stays within the balance bound and its own part does not become empty; passes until nothing moves
+void refine(const Graph& g, std::vector<int32_t>& part, int n_parts, int ufactor, int64_t total, int max_passes = 16) {
+  const size_t n = g.n();
+  std::vector<int64_t> sizes((size_t)n_parts, 0), cnt((size_t)n_parts, 0), conn((size_t)n_parts, 0);
+  std::vector<uint8_t> seen((size_t)n_parts, 0);
+  std::vector<int32_t> touched;
+  for (size_t v = 0; v < n; v++) { sizes[part[v]] += g.vw[v]; cnt[part[v]]++; }
+  const int64_t a = (int64_t)std::ceil((double)total / (double)n_parts);
+  const int64_t b = (int64_t)((1.0 + (double)ufactor / 1000.0) * (double)total / (double)n_parts);
+  const int64_t max_size = std::max(a, b);
+  for (int pass = 0; pass < max_passes; pass++) {
+    uint64_t moved = 0;
+    for (size_t v = 0; v < n; v++) {
+      const int32_t pv = part[v];
+      if (cnt[pv] <= 1 || g.off[v] == g.off[v + 1]) continue;
+      touched.clear();
+      for (uint64_t q = g.off[v]; q < g.off[v + 1]; q++) {
+        const int32_t u = g.nb[q];
+        if ((size_t)u == v) continue;
+        const int32_t pu = part[u];
+        if (!seen[pu]) { seen[pu] = 1; conn[pu] = 0; touched.push_back(pu); }
+        conn[pu] += g.w[q];
+      }
+      std::sort(touched.begin(), touched.end());
+      const int64_t own = seen[pv] ? conn[pv] : 0;
+      int32_t best = -1; int64_t bw = own;
+      for (int32_t q : touched) if (q != pv && conn[q] > bw && sizes[q] + g.vw[v] <= max_size) { best = q; bw = conn[q]; }
+      for (int32_t q : touched) seen[q] = 0;
+      if (best >= 0) {
+        part[v] = best;
+        sizes[pv] -= g.vw[v]; sizes[best] += g.vw[v];
+        cnt[pv]--; cnt[best]++;
+        moved++;
+      }
+    }
+    if (!moved) break;
+  }
+}
+
+std::vector<int32_t> multilevel(const Graph& g0, int n_parts, int ufactor) {
+  const size_t n = g0.n();
+  if (n_parts <= 1 || n == 0) return std::vector<int32_t>(n, 0);
+  struct Level { Graph g; std::vector<int32_t> cmap; };
+  std::vector<Level> levels;
+  Graph cur = g0;
+  const size_t stop = (size_t)std::max(20 * n_parts, 64);
+  const int64_t max_vw = std::max<int64_t>(1, (int64_t)(1.5 * (double)n / (double)stop));
+  while (cur.n() > stop) {
+    Graph c; std::vector<int32_t> cmap;
+    coarsen(cur, max_vw, c, cmap);
+    if ((double)c.n() > 0.95 * (double)cur.n()) break;                 // (nothing left to match)
+    levels.push_back(Level{std::move(cur), std::move(cmap)});
+    cur = std::move(c);
+  }
+  const bool dbg = getenv("SHN_DEBUG") != nullptr;
+  auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
+  const double t_c = now();
+  std::vector<int32_t> part = grow_partition(cur, n_parts);
+  const double t_g = now();
+  refine(cur, part, n_parts, ufactor, (int64_t)n);
+  if (dbg) fprintf(stderr, "[partition] %zu vertices, %zu levels, coarsest %zu; growth %.3f s, its refinement %.3f s\n", n, levels.size(), cur.n(), t_g - t_c, now() - t_g);
+  for (size_t li = levels.size(); li-- > 0;) {
+    const Level& L = levels[li];
+    std::vector<int32_t> fine(L.g.n());
+    for (size_t v = 0; v < fine.size(); v++) fine[v] = part[L.cmap[v]];
+    part.swap(fine);
+    const double t_r = now();
+    refine(L.g, part, n_parts, ufactor, (int64_t)n);
+    if (dbg) fprintf(stderr, "[partition] level %zu (%zu vertices): refinement %.3f s\n", li, L.g.n(), now() - t_r);
+  }
+  // (a part the refinement emptied -- possible on tiny graphs -- takes the first vertex of the largest part)
+  std::vector<int64_t> sizes((size_t)n_parts, 0);
+  for (int32_t p : part) sizes[p]++;
+  for (int q = 0; q < n_parts; q++)
+    if (sizes[q] == 0) {
+      int big = 0;
+      for (int x = 1; x < n_parts; x++) if (sizes[x] > sizes[big]) big = x;
+      for (size_t i = 0; i < n; i++) if (part[i] == big) { part[i] = q; break; }
+      sizes[big]--; sizes[q]++;
+    }
+  return part;
+}
+}  // namespace
+
+// part_out[v] = partition (0 .. n_parts-1) of vertex v of the METIS-format graph `text` (the componentN.txt of
+// extension_correction.py:446-456); n = the number of vertices the caller expects
+extern "C" int shn_partition_metis(const char* text, uint64_t len, uint64_t n, int n_parts, int ufactor, int32_t* part_out) {
+  if (!text || (n && !part_out) || n_parts < 1) return shn_fail(SHN_ERR_ARG, "shn_partition_metis: bad argument");
+  Graph g;
+  int rc = parse_metis(text, len, g);
+  if (rc) return rc;
+  if (g.n() != n) return shn_fail(SHN_ERR_ARG, "shn_partition_metis: the graph has " + std::to_string(g.n()) + " vertices, the caller expects " + std::to_string(n));
+  const std::vector<int32_t> part = multilevel(g, n_parts, ufactor);
+  if (n) memcpy(part_out, part.data(), n * sizeof(int32_t));
+  return SHN_OK;
+}
+
+// the same on a CSR graph (off[n + 1], 0-based neighbours, weights): the connections of a component as shn_cgraph_export leaves them
+extern "C" int shn_partition_csr(uint64_t n, const uint64_t* off, const int32_t* nb, const int64_t* w, int n_parts, int ufactor, int32_t* part_out) {
+  if ((n && (!off || !part_out)) || n_parts < 1) return shn_fail(SHN_ERR_ARG, "shn_partition_csr: bad argument");
+  Graph g;
+  g.vw.assign(n, 1);
+  g.off.assign(off, off + n + 1);
+  const uint64_t m = n ? off[n] : 0;
+  if (m && (!nb || !w)) return shn_fail(SHN_ERR_ARG, "shn_partition_csr: NULL adjacency");
+  for (uint64_t q = 0; q < m; q++) if (nb[q] < 0 || (uint64_t)nb[q] >= n) return shn_fail(SHN_ERR_ARG, "shn_partition_csr: neighbour out of range");
+  g.nb.assign(nb, nb + m); g.w.assign(w, w + m);
+  const std::vector<int32_t> part = multilevel(g, n_parts, ufactor);
+  if (n) memcpy(part_out, part.data(), n * sizeof(int32_t));
+  return SHN_OK;
+}
+
+// weight_updated_graph.py:24-42: the METIS text with the weight of every edge cut by `part` multiplied by `penalty`, in the
+// reference's own format (header line kept, every entry "neighbour<TAB>weight<TAB>", a line per vertex).  out == NULL: *out_len only.
+extern "C" int shn_metis_reweight(const char* text, uint64_t len, const int32_t* part, uint64_t n, int penalty, char* out, uint64_t out_cap, uint64_t* out_len) {
+  if (!text || !out_len || (n && !part)) return shn_fail(SHN_ERR_ARG, "shn_metis_reweight: NULL argument");
+  std::string res;
+  res.reserve(len + len / 4 + 16);
+  const char* p = text; const char* end = text + len;
+  while (p < end && *p != '\n') { if (*p != '\r') res.push_back(*p); p++; }
+  res.push_back('\n');
+  if (p < end) p++;
+  char num[32];
+  for (uint64_t i = 0; i < n; i++) {
+    while (p < end && *p != '\n') {
+      while (p < end && (*p == ' ' || *p == '\t' || *p == '\r')) p++;
+      if (p >= end || *p == '\n') break;
+      int64_t u = 0, wt = 0;
+      if (*p < '0' || *p > '9') return shn_fail(SHN_ERR_ARG, "shn_metis_reweight: not a number");
+      while (p < end && *p >= '0' && *p <= '9') { u = u * 10 + (*p - '0'); p++; }
+      while (p < end && (*p == ' ' || *p == '\t' || *p == '\r')) p++;
+      if (p >= end || *p < '0' || *p > '9') return shn_fail(SHN_ERR_ARG, "shn_metis_reweight: a neighbour without a weight");
+      while (p < end && *p >= '0' && *p <= '9') { wt = wt * 10 + (*p - '0'); p++; }
+      if (u < 1 || (uint64_t)u > n) return shn_fail(SHN_ERR_ARG, "shn_metis_reweight: neighbour out of range");
+      const bool cut = part[i] != part[u - 1];
+      int k = snprintf(num, sizeof num, "%lld", (long long)u);
+      res.append(num, (size_t)k); res.push_back('\t');
+      k = snprintf(num, sizeof num, "%lld", (long long)(cut ? (int64_t)penalty * wt : wt));
+      res.append(num, (size_t)k); res.push_back('\t');
+    }
+    if (p < end) p++;
+    res.push_back('\n');
+  }
+  *out_len = res.size();
+  if (!out) return SHN_OK;
+  if (out_cap < res.size()) return shn_fail(SHN_ERR_ARG, "shn_metis_reweight: output buffer too small");
+  memcpy(out, res.data(), res.size());
+  return SHN_OK;
+}

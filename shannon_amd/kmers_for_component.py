@@ -35,7 +35,18 @@ def partition_graph(metis_text, n_parts, ufactor=1000):
     (2) an initial partition of the coarsest graph by greedy graph growing on vertex weights; (3) projection back level by level,
     with a k-way boundary refinement on every level.  Balance: every part holds at most (1 + U/1000) * n / P vertices.  The output
     is not METIS's digit for digit (gpmetis is external, randomised and unpinned: parity cases replay a given partition vector);
-    on planted partitions it ends within a few per cent of the planted cut (tests/test_host_graph.py)."""
+    on planted partitions it ends within a few per cent of the planted cut (tests/test_host_graph.py).
+    Runs in the library (shn_partition_metis, csrc/partition_host.hip); partition_graph_py is the same algorithm statement for
+    statement in Python (the readable form; tests compare the two)."""
+    text = metis_text.encode() if isinstance(metis_text, str) else bytes(metis_text)
+    n = int(text.split(None, 1)[0]) if text.strip() else 0
+    out = np.zeros(max(n, 1), dtype=np.int32)
+    _lib.check(_lib.lib().shn_partition_metis(text, len(text), n, int(n_parts), int(ufactor), out.ctypes.data))
+    return out[:n].tolist()
+
+
+def partition_graph_py(metis_text, n_parts, ufactor=1000):
+    """partition_graph in Python (the readable mirror of csrc/partition_host.hip)"""
     adj = parse_metis(metis_text)
     return multilevel_partition(adj, n_parts, ufactor)
 
@@ -192,7 +203,20 @@ def refine_partition(adj, part, n_parts, ufactor=1000, max_passes=16, vw=None, t
 
 
 def weight_updated_graph(metis_text, part, penalty=5):
-    """weight_updated_graph.py:24-42: multiply weights of edges cut by `part` by `penalty`."""
+    """weight_updated_graph.py:24-42: multiply weights of edges cut by `part` by `penalty` (shn_metis_reweight; the Python form:
+    weight_updated_graph_py)."""
+    text = metis_text.encode() if isinstance(metis_text, str) else bytes(metis_text)
+    pv = np.ascontiguousarray(part, dtype=np.int32)
+    n = C.c_uint64(0)
+    L = _lib.lib()
+    _lib.check(L.shn_metis_reweight(text, len(text), pv.ctypes.data, len(pv), int(penalty), None, 0, C.byref(n)))
+    out = np.empty(max(1, n.value), dtype=np.uint8)
+    _lib.check(L.shn_metis_reweight(text, len(text), pv.ctypes.data, len(pv), int(penalty), out.ctypes.data, len(out), C.byref(n)))
+    return out[:n.value].tobytes().decode()
+
+
+def weight_updated_graph_py(metis_text, part, penalty=5):
+    """weight_updated_graph.py:24-42 in Python."""
     lines = metis_text.splitlines()
     out = [lines[0] + "\n"]
     for i, line in enumerate(lines[1:], start=1):

@@ -128,6 +128,59 @@ def test_own_partitioner_cut_quality():
         assert kfc.edge_cut(al, kfc.refine_partition(al, [int(x) for x in rng.permutation(n) % P], P, 1000)) <= rnd
 
 
+def _planted_graph(seed, n, P, deg_in, deg_out):
+    """sparse planted partition: every vertex draws ~deg_in neighbours inside its group and ~deg_out outside (edge lists, not an
+    n x n matrix: 50,000 vertices)"""
+    rng = np.random.default_rng(seed)
+    group = rng.permutation(n) % P
+    members = [np.nonzero(group == g)[0] for g in range(P)]
+    adj = [dict() for _ in range(n)]
+    for v in range(n):
+        inside = members[group[v]]
+        for u in inside[rng.integers(0, len(inside), deg_in)].tolist() + rng.integers(0, n, deg_out).tolist():
+            if u != v and (group[u] == group[v] or rng.random() < 1.0):
+                w = int(rng.integers(1, 9))
+                adj[v][u] = w
+                adj[u][v] = w
+    text = "%d\t%d\t001\n" % (n, sum(len(d) for d in adj) // 2) + "".join(
+        "".join("%d\t%d\t" % (b + 1, w) for b, w in d.items()) + "\n" for d in adj)
+    return text, group
+
+
+def test_native_partitioner_equals_its_python_mirror():
+    """shn_partition_metis / shn_metis_reweight (csrc/partition_host.hip) make the decisions of multilevel_partition /
+    weight_updated_graph_py one for one: equal vectors and equal texts on random graphs of several shapes, vertices without
+    neighbours and the two-run chain of kmers_for_component.py:221-234 included."""
+    for seed, n, P, din, dout in ((1, 1, 1, 0, 0), (2, 7, 2, 2, 1), (3, 90, 3, 3, 1), (4, 700, 5, 4, 1), (5, 3000, 9, 5, 1), (6, 2500, 30, 3, 2)):
+        text, _g = _planted_graph(seed, n, P, din, dout)
+        a = kfc.partition_graph(text, P, 1000)
+        assert a == kfc.partition_graph_py(text, P, 1000), (seed, n, P)
+        t2 = kfc.weight_updated_graph(text, a, 5)
+        assert t2 == kfc.weight_updated_graph_py(text, a, 5)
+        assert kfc.partition_graph(t2, P, 1000) == kfc.partition_graph_py(t2, P, 1000)
+        assert kfc.partition_graph(text, P, 300) == kfc.partition_graph_py(text, P, 300)        # a tighter balance bound
+
+
+def test_native_partitioner_at_fifty_thousand_contigs():
+    """the size of a real transcriptome's shared-exon component: 50,000 vertices in 100 parts (the reference's
+    cap, kmers_for_component.py:217) -- within 15 % of the planted cut, balanced, deterministic, in seconds"""
+    import time
+    n, P = 50000, 100
+    text, group = _planted_graph(11, n, P, 6, 1)
+    t0 = time.time()
+    mine = kfc.partition_graph(text, P, 1000)
+    dt = time.time() - t0
+    assert mine == kfc.partition_graph(text, P, 1000)
+    al = kfc.parse_metis(text)
+    cut, planted = kfc.edge_cut(al, mine), kfc.edge_cut(al, [int(g) for g in group])
+    sizes = np.bincount(mine, minlength=P)
+    assert sizes.sum() == n and sizes.min() >= 1 and sizes.max() <= 2.0 * n / P
+    assert cut <= 1.15 * planted, (cut, planted)
+    assert dt < 20.0, dt
+    p2 = kfc.partition_graph(kfc.weight_updated_graph(text, mine, 5), P, 1000)               # the r2 run on the re-weighted graph
+    assert np.bincount(p2, minlength=P).max() <= 2.0 * n / P
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_native_contig_graph_matches_oracle(name):
     """shn_contig_graph (native host code, no GPU needed): duplicate_check + contig graph in the
