@@ -72,14 +72,21 @@ def _chunk_seed(read_seed, chunk):
     return (z ^ (z >> 31)) & ((1 << 62) - 1)
 
 
-def gen_reads(n_pairs, seed, n_genes, device, read_seed=None, families=0, first_chunk=0, exon_len=(80, 600)):
+def gen_reads(n_pairs, seed, n_genes, device, read_seed=None, families=0, first_chunk=0, exon_len=(80, 600), chain_exons=0):
     """synthetic pairs on the GPU (torch RNG; same model as shannon_amd/synth.py), generated in chunks of CHUNK_PAIRS pairs:
     chunk c (counted from first_chunk) is drawn from a generator seeded with (read_seed, c) alone, so any rank can produce any
     slice of the batch and the union of the ranks' slices is the one-GPU batch.
     families > 0: that many gene families of the configs[1] kind (rich in isoforms) instead of n_genes plain genes."""
     from shannon_amd import synth
     # config 2 ("single component"): one gene family rich enough to give a multi-contig component
-    if families:
+    if chain_exons:
+        # --config 2p: ONE family whose isoforms share exons along a chain (synth.make_chain_family): one component of the contig graph
+        # with about as many contigs as exons -- the input that takes the gpmetis branch (kmers_for_component.py:207-237)
+        iso = synth.make_chain_family(chain_exons, seed, exon_len=exon_len)
+        lens = np.array([len(t) for t in iso], dtype=np.int64)
+        wts = np.random.Generator(np.random.PCG64(seed + 1)).lognormal(0.0, 0.5, size=len(iso)) * (lens - 300 + 1)
+        wts /= wts.sum()
+    elif families:
         # every family is built like the configs[1] one (family 0 IS the configs[1] gene) and gets the same share of reads
         iso, wl = [], []
         for f in range(families):
@@ -464,7 +471,10 @@ PRESETS = {"1": dict(genes=1, reads=10_000_000, K=25, exon_len=(80, 600)),
            "2": dict(genes=20000, reads=100_000_000, K=25, exon_len=(80, 600)),
            # the one-GPU slice of configs[4] (500M reads, k=31, 8 GPUs): a fifth of its reads and of its genes (the per-gene depth
            # of configs[4]), exons up to 5 kb so that the unitigs get long
-           "4s": dict(genes=4000, reads=100_000_000, K=31, exon_len=(80, 5000))}
+           "4s": dict(genes=4000, reads=100_000_000, K=31, exon_len=(80, 5000)),
+           # not one of BASELINE's configs: the input for row a8 (a component of the contig graph far larger than --partition, cut by
+           # the library's partitioner into the reference's 100 parts, twice): one shared-exon family of 60,000 exons, 20 M reads
+           "2p": dict(genes=1, reads=20_000_000, K=25, exon_len=(80, 600), chain_exons=60000)}
 
 
 def build_parser():
@@ -472,7 +482,7 @@ def build_parser():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="", choices=["", "0", "1", "2", "4s"],
+    ap.add_argument("--config", default="", choices=["", "0", "1", "2", "4s", "2p"],
                     help="BASELINE.json configs[i]: 1 = 10M reads / one gene family, 2 = 100M reads / 20,000 genes (on N GPUs with "
                          "--scaling strong: configs[3]), 4s = the one-GPU slice of configs[4]: 100M reads, -K 31, 4,000 genes with exons "
                          "up to 5 kb (default: 2; 1 per rank with --scaling weak on several GPUs)")
@@ -568,6 +578,7 @@ def main():
     args.reads = args.reads or preset["reads"]
     args.K = args.K or preset["K"]
     exon_len = preset["exon_len"]
+    chain_exons = preset.get("chain_exons", 0) if not args.families else 0
     is_config = (args.genes, args.reads, args.K) == (preset["genes"], preset["reads"], preset["K"]) and not args.families
     total_reads = args.reads                                   # of the whole job's batch (strong) / per rank (weak)
     first_chunk = 0
@@ -636,7 +647,7 @@ def main():
         lock.acquire()
     # strong: this rank's chunks of the one batch (read seed shared); weak: a batch of its own per rank
     r1, r2 = gen_reads(args.reads // 2, seed, args.genes, dev, read_seed=seed + 2 + (0 if args.scaling == "strong" else 1000 * rank),
-                       families=families, first_chunk=first_chunk, exon_len=exon_len)
+                       families=families, first_chunk=first_chunk, exon_len=exon_len, chain_exons=chain_exons)
     ctx = device.Context(local if world > 1 else 0)
     sets = [device.Reads.from_codes(ctx, r1), device.Reads.from_codes(ctx, r2)]
     n_reads = len(sets[0]) + len(sets[1])
@@ -795,7 +806,10 @@ def main():
                 "2": "100M synthetic 2x100bp paired reads (50M pairs), k=25 (k1=26), 20,000 genes (1-6 isoforms of 3-12 exons, lognormal "
                      "expression), 0.5% substitution errors, multi-component, --partition 500 (BASELINE configs[2])",
                 "4s": "100M synthetic 2x100bp paired reads (50M pairs), k=31 (k1=32), 4,000 genes with exons of 80-5,000 bp (long unitigs), "
-                      "0.5% substitution errors, --partition 500 (one-GPU slice of BASELINE configs[4]: a fifth of its reads and genes)"}[args.config]
+                      "0.5% substitution errors, --partition 500 (one-GPU slice of BASELINE configs[4]: a fifth of its reads and genes)",
+                "2p": "20M synthetic 2x100bp paired reads (10M pairs), k=25 (k1=26), ONE shared-exon family (60,000 exons, isoforms sharing exons "
+                      "along a chain: one contig-graph component of about as many contigs, cut into 100 parts twice by the library's "
+                      "partitioner -- row a8, kmers_for_component.py:207-237), --partition 500; none of BASELINE's configs"}[args.config]
         if not is_config and not families:
             workload = ("%d synthetic 2x100bp paired reads%s, K=%d, %d genes (a tuning input, none of BASELINE's configs)"
                         % (total_reads, " per GPU" if (world > 1 and args.scaling == "weak") else "", args.K, args.genes))
@@ -815,7 +829,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload,
-                       "baseline_config": (("3" if (args.config == "2" and world > 1 and args.scaling == "strong") else args.config) if is_config else None),
+                       "baseline_config": (("3" if (args.config == "2" and world > 1 and args.scaling == "strong") else args.config) if (is_config and args.config != "2p") else None),
                        "reads_per_gpu": n_reads, "reads_of_the_job": job_reads, "K": args.K,
                        "rccl_ranks": (dist.get_world_size() if dist else 1), "collective_backend": (dist.get_backend() if dist else None),
                        "collectives_per_step": ({k: {"calls": v["calls"] / args.steps, "bytes_sent": v["bytes_sent"] / args.steps,
@@ -862,9 +876,10 @@ def main():
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 of the N=1 run only
             # bounded sample: ~10-15 s of one core through the whole path (at configs[2] a read costs the pure-Python path ~5x more
             # than at configs[1]: nearly every k1-mer of a 25k-read sample is new), + ~5 s for the counting stage alone / threaded
-            # ~30 s of host work: 0.5 M reads through the whole path, native where a native host form exists (at 1 M reads
-            # of this 20,000-gene batch the greedy extension alone takes one core 45 s: 33 M distinct k1-mers at 2x coverage)
-            out["cpu_baseline"] = cpu_whole_path_native(args.K, r1, r2, min(len(r1), 250_000))
+            # ~30 s of host work: 1 M reads (500,000 pairs) through the whole path, native where a native host form exists.
+            # (Round 4 stopped at 0.5 M reads: 28 of its 35 s were the dictionary of oracle/ext_c.c -- a qsort of 42 M entries and a
+            # 25-step bisection per look-up; with a radix sort and a prefix table the extension is a few seconds at a million reads.)
+            out["cpu_baseline"] = cpu_whole_path_native(args.K, r1, r2, min(len(r1), 500_000))
             # the pure-Python port (oracle/pipeline.py: pure Python like Shannon itself) on a small sample, for scale
             out["cpu_baseline"]["python_port"] = cpu_baseline(k1, r1, r2, 25_000 if args.config == "1" else 6_000)
         final_line = json.dumps(out)

@@ -8,6 +8,13 @@ hot path and produces the same products: OUT/shannon.fasta, OUT/log.txt, OUT/TEM
 
     python shannon.py -o OUT --single reads.fasta            [-K 25] [--partition 500]
     python shannon.py -o OUT --left r1.fasta --right r2.fasta [-s / --ss / --strand_specific]
+    python shannon.py -o OUT --left r1.fasta --right r2.fasta -p 8        # one rank per GPU (the reference's -p nJobs, shannon.py:527-566)
+
+-p N / --gpus N: the reference fans its partitions out over nJobs processes (GNU parallel, shannon.py:527-566); here the N jobs
+are N ranks, one per GPU of the node (torch.distributed over RCCL): this process -- which has made no GPU call -- starts them as
+children (torch.distributed.run on 127.0.0.1) and returns their exit code; every rank ingests its slice of the reads, the k1-mer
+buckets are exchanged once, partitions are dealt to the ranks, rank 0 merges and writes OUT/ (shannon_amd/distributed.py).
+-p is capped at the number of GPUs the node shows (one GPU: the one-process path, partitions concurrently on host threads).
 """
 import os, sys, time, json
 
@@ -43,13 +50,156 @@ def read_fasta(path):
     return seqs
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, args):
+    """start the n ranks as fresh child processes (torch.distributed.run, rendezvous on 127.0.0.1) and hand their exit code on;
+    this parent makes no GPU call"""
+    import subprocess
+    env = dict(os.environ, SHN_CLI_RANKS="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL between processes needs it on this stack
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(args)
+    return subprocess.call(cmd, env=env, cwd=os.getcwd())
+
+
+def rank_main(out_dir, reads, K, partition_size, min_weight, min_length, double_stranded, ignored, noted):
+    """one rank of an N-rank run: its slice of the reads (by index, contiguous), shannon_amd.distributed.assemble_distributed,
+    rank 0 writes OUT/ (shannon.fasta, log.txt, TEMP/<sample>_allalgo_output/all_reconstructed.fasta and the contig files; the
+    per-partition graph files stay with the ranks that owned the partitions)"""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    share = os.environ.get("SHN_CLI_BACKEND") == "gloo"
+    if os.environ.get("SHN_CLI_LAUNCH_PROBE"):
+        # CPU test of the launch (tests/test_cli_launcher.py): the ranks meet over gloo, rank 0 says what the launch resolved to;
+        # nothing touches the GPU
+        dist.init_process_group("gloo")
+        one = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(one)
+        if rank == 0:
+            print("launch probe: %d ranks met, K=%d, partition=%d, double_stranded=%s, reads=%s, out=%s"
+                  % (int(one.item()), K, partition_size, double_stranded, ",".join(os.path.basename(p) for p in reads), out_dir))
+        dist.destroy_process_group()
+        return 0
+    dev_index = 0 if share else local
+    torch.cuda.set_device(dev_index)
+    if share:
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+    import shannon_amd
+    if os.environ.get("SHN_MALLOC_TUNE", "1") != "0":
+        shannon_amd.malloc_tune()
+    from shannon_amd import device, distributed, kmers_for_component as kfc, _lib
+    sample = os.path.basename(os.path.normpath(out_dir))
+    temp = os.path.join(out_dir, "TEMP")
+    log = None
+    if rank == 0:
+        os.makedirs(out_dir, exist_ok=True)
+        os.makedirs(temp)
+        log = open(os.path.join(out_dir, "log.txt"), "w")
+
+    def say(msg):
+        if rank == 0:
+            line = "%s: %s" % (time.asctime(), msg)
+            print(line)
+            log.write(line + "\n")
+    say("Starting Shannon run (MI355X hot path %s, %d ranks)" % (VERSION, world))
+    if ignored:
+        say("WARNING: flags outside the hot path ignored: " + " ".join(ignored))
+    for msg in noted:
+        say("NOTE: " + msg)
+    ctx = device.Context(dev_index)
+    T = {}
+    t0 = time.time()
+    paired = len(reads) == 2
+    # every rank reads the files and keeps its contiguous slice of the records (the N-rank job's read order is the files' order)
+    mats = []
+    for p in reads:
+        try:
+            _d, r = device.Reads.ingest(None, p)                # (the host code matrix only: the rank uploads its own slice below)
+            if isinstance(r, device.RaggedCodes):
+                raise _lib.ShannonError("unsupported: ragged reads on the N-rank path")
+        except _lib.ShannonError as ex:
+            if "unsupported" not in str(ex):
+                raise
+            seqs = read_fasta(p)
+            L = len(seqs[0]) if seqs else 0
+            if any(len(x) != L for x in seqs):
+                say("ERROR: the N-rank path takes reads of one length; run without -p / --gpus")
+                return 2
+            code = np.full(256, 4, np.uint8)
+            for j, c in enumerate(b"ACGT"):
+                code[c] = j
+            r = code[np.frombuffer("".join(seqs).encode(), dtype=np.uint8)].reshape(len(seqs), L) if seqs else np.zeros((0, 1), np.uint8)
+        mats.append(r)
+    if paired and len(mats[0]) != len(mats[1]):
+        say("ERROR: --left and --right hold different numbers of reads")
+        return 2
+    n = len(mats[0])
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    q1 = np.ascontiguousarray(mats[0][lo:hi])
+    q2 = np.ascontiguousarray(mats[1][lo:hi]) if paired else None
+    del mats
+    d1 = device.Reads.from_codes(ctx, q1)
+    d2 = device.Reads.from_codes(ctx, q2) if paired else None
+    T["ingest"] = time.time() - t0
+    say("Processed No of reads:%d, Avg. Read length: %.2f (every rank holds a slice of %d of them)" % (n, q1.shape[1] if n else 0, hi - lo))
+    ops = distributed.GpuOps(ctx, d1, d2, kfc.ReadStore(q1, q2), K)
+    res = distributed.assemble_distributed(ops, K, partition_size, sample, 0, timings=T, double_stranded=double_stranded)
+    rc = 0
+    if rank == 0:
+        say("%d K-mers loaded; %d contigs; %d partitions" % (res["n_k1mers"], len(res["contigs"]), len(res["partitions"])))
+        ai = os.path.join(temp, sample + "_algo_input")
+        os.makedirs(ai)
+        with open(os.path.join(ai, "k1mer.dict_contig"), "w") as f:
+            f.write("".join(c + "\n" for c in res["contigs"]))
+        alld = os.path.join(temp, sample + "_allalgo_output")
+        os.makedirs(alld)
+        with open(os.path.join(alld, "all_reconstructed.fasta"), "w") as f:
+            for name in res["partitions"]:
+                f.write(res["partitions"][name])
+        final = res["final"]
+        if hasattr(final, "fasta"):
+            with open(os.path.join(out_dir, "shannon.fasta"), "wb") as f:
+                f.write(final.fasta())
+        else:
+            with open(os.path.join(out_dir, "shannon.fasta"), "w") as f:
+                for name, seq in final.items():
+                    f.write(">%s\n%s\n" % (name, seq))
+        say("All partitions completed: %d transcripts reconstructed" % len(final))
+        say("stage seconds (rank 0): " + json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in T.items()}))
+        log.close()
+        print("-------------------------------------------------")
+        print(time.asctime() + ": Shannon Run Completed")
+        print("-------------------------------------------------")
+    dist.barrier()
+    d1.close()
+    if d2 is not None:
+        d2.close()
+    ctx.close()
+    dist.destroy_process_group()
+    return rc
+
+
 def main(argv):
     K, partition_size, nJobs = 24, 500, 1                     # shannon.py:58,65,67
     out_dir, reads, double_stranded = None, [], True
     min_weight, min_length = 3, 75                            # shannon.py:55-56
     i = 1
     ignored, noted = [], []
-    takes_value = ("-o", "--single", "--left", "--right", "-K", "-p", "--partition", "--kmer_hard_cutoff")
+    takes_value = ("-o", "--single", "--left", "--right", "-K", "-p", "--gpus", "--partition", "--kmer_hard_cutoff")
+    n_gpus = 0
     while i < len(argv):
         a = argv[i]
         if a in takes_value and i + 1 >= len(argv):
@@ -71,6 +221,8 @@ def main(argv):
             K = int(argv[i + 1]); i += 2; continue
         if a == "-p":
             nJobs = int(argv[i + 1]); i += 2; continue
+        if a == "--gpus":
+            n_gpus = int(argv[i + 1]); i += 2; continue
         if a == "--partition":
             partition_size = int(argv[i + 1]); i += 2; continue
         if a == "--kmer_hard_cutoff":
@@ -101,6 +253,22 @@ def main(argv):
         return 2
     if K + 1 > 32:
         print("ERROR: K+1 must be <= 32"); return 2
+    # ---- ranks (shannon.py:527-566: the reference's nJobs processes).  Decided and started before anything touches the GPU:
+    # torch.cuda.device_count() does not initialise it, and a process that has must never be replaced or forked into ranks.
+    in_rank = "WORLD_SIZE" in os.environ and "RANK" in os.environ and os.environ.get("SHN_CLI_RANKS") == "1"
+    if not in_rank:
+        want = n_gpus if n_gpus > 0 else nJobs
+        if want > 1:
+            import torch
+            have = torch.cuda.device_count()
+            share = os.environ.get("SHN_CLI_BACKEND") == "gloo"          # (development / tests: several ranks on ONE GPU, collectives over gloo)
+            ranks = want if share else min(want, max(1, have))
+            if ranks > 1:
+                return launch_ranks(ranks, argv[1:])
+            if n_gpus > 1:
+                print("NOTE: --gpus %d asked for, the node shows %d GPU(s): one process" % (n_gpus, have))
+    if in_rank:
+        return rank_main(out_dir, reads, K, partition_size, min_weight, min_length, double_stranded, ignored, noted)
     os.makedirs(out_dir, exist_ok=True)
     sample = os.path.basename(os.path.normpath(out_dir))
     temp = os.path.join(out_dir, "TEMP")
@@ -120,7 +288,8 @@ def main(argv):
     if ignored:
         say("WARNING: flags outside the hot path ignored: " + " ".join(ignored))
     if nJobs != 1:
-        noted.append("-p %d: partitions run concurrently on host threads and the GPU inside one process; the value is not used" % nJobs)
+        noted.append("-p %d: one GPU in use -- the partitions run concurrently on host threads and the GPU inside this process (with several "
+                     "GPUs, -p N / --gpus N is N ranks)" % nJobs)
     for msg in noted:
         say("NOTE: " + msg)
     ctx = device.Context(0)

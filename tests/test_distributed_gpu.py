@@ -93,3 +93,34 @@ def test_ranks_sharing_one_gpu_equal_single_process(world, paired, n_genes, seed
         if d2 is not None:
             d2.close()
         ctx.close()
+
+
+@pytest.mark.parametrize("world,paired,ss", [(2, True, False), (3, False, False), (2, True, True)])
+def test_cli_ranks_equal_the_one_process_cli(world, paired, ss, tmp_path):
+    """shannon.py -p N: the reference's nJobs (shannon.py:527-566) as N ranks started by the CLI itself before it touches the GPU
+    (here sharing cuda:0, collectives over gloo: SHN_CLI_BACKEND=gloo) -- OUT/shannon.fasta and the contig list equal to the
+    one-process run of the same command."""
+    import subprocess, sys
+    from conftest import ROOT
+    from shannon_amd import synth
+    (q1, q2), _ = synth.make_dataset(12000, 12, seed=4)
+    if not paired:
+        q1 = np.concatenate([q1, q2])
+    f1, f2 = str(tmp_path / "r1.fasta"), str(tmp_path / "r2.fasta")
+    synth.write_fasta(f1, q1, "/1")
+    if paired:
+        synth.write_fasta(f2, q2, "/2")
+    files = ["--left", f1, "--right", f2] if paired else ["--single", f1]
+    outs = {}
+    for tag, extra, env_extra in (("one", [], {}), ("ranks", ["-p", str(world)], {"SHN_CLI_BACKEND": "gloo"})):
+        out = str(tmp_path / tag)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "shannon.py"), "-o", out, "-K", "25"] + files + (["-s"] if ss else []) + extra,
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, **env_extra), timeout=900)
+        assert p.returncode == 0, p.stdout[-3000:]
+        recs = open(os.path.join(out, "shannon.fasta")).read().split(">")[1:]
+        contigs = open(os.path.join(out, "TEMP", tag + "_algo_input", "k1mer.dict_contig")).read()
+        outs[tag] = (sorted(r.split("\n", 1)[1] for r in recs), contigs)
+        if tag == "ranks":
+            assert "%d ranks" % world in p.stdout
+    assert outs["one"][1] == outs["ranks"][1]
+    assert outs["one"][0] == outs["ranks"][0] and len(outs["one"][0]) > 0
