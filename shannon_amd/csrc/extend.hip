@@ -654,6 +654,101 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
   if (threadIdx.x < n_promo) A.promo_list[promo_base + threadIdx.x] = blk_promo[threadIdx.x];
 }
 
+// ---- bulk rounds, second half: the walks the thread kernel handed over after `promote_steps` steps (the long ones: a few per cent
+// of a bulk round's walks, nearly all of its steps), packed.  In the launch above a wavefront lasts as long as its longest walk while
+// 63 of its 64 walks end within a few steps (98.6 % of the walks of BASELINE configs[2] are void in the end): one lane busy in
+// sixty.  Here every lane is a long walk, and a lane whose walk ends takes the next one from the list (one flat loop: an iteration
+// is one step of every lane's walk; the lanes that need a walk fetch one at the top of the iteration, one atomic for all of them),
+// so a wavefront is never held by one 2,000-step walk.  The step itself is ext_walk_kernel's, statement for statement.
+template <bool FRESH>
+__global__ __launch_bounds__(WBLK) void ext_walk_resume_kernel(WalkArgs A, const uint32_t* __restrict__ list, const unsigned long long* __restrict__ list_count,
+                                                               unsigned long long* __restrict__ head, const u64* __restrict__ snap) {
+  const unsigned long long n_list = *list_count;
+  const int lane = threadIdx.x & 63;
+  bool have = false, out_of_work = false;
+  uint32_t r = 0, o = 0, pos = 0, steps = 0, nr = 0, pend = NONE32, walked = 0;
+  int dir = 0;
+  uint64_t tot = 0;
+  u64 seen = UNCLAIMED64;
+  Adj4 cand = {{-1, -1, -1, -1}};
+  unsigned long long my_steps = 0;
+  while (true) {
+    // lanes without a walk take the next ones of the list
+    const unsigned long long want = __ballot(!have && !out_of_work);
+    if (want) {
+      const int leader = __ffsll((long long)want) - 1;
+      unsigned long long base = 0;
+      if (lane == leader) base = atomicAdd(head, (unsigned long long)__popcll(want));
+      base = shfl_u64(base, leader);
+      if (!have && !out_of_work) {
+        const unsigned long long idx = base + (unsigned long long)__popcll(want & ((1ULL << lane) - 1ULL));
+        if (idx >= n_list) out_of_work = true;
+        else {
+          r = list[idx];
+          o = A.order[r];
+          const uint32_t info = A.res_info[r];
+          dir = (int)(info >> 31);
+          pos = info & 0x7FFFFFFFu;
+          const uint32_t cur = A.res_cur[r];
+          nr = dir ? A.nr_out[r] : 0u;
+          steps = dir ? pos - nr : pos;
+          tot = A.totw_out[r];
+          cand = (dir == 0 ? A.adjR : A.adjL)[cur];
+          pend = NONE32; seen = UNCLAIMED64; walked = 0;
+          have = true;
+        }
+      }
+    }
+    if (!__ballot(have)) break;
+    if (!have) continue;
+    // ---- one step (ext_walk_kernel's loop body)
+    const RowView adj = dir == 0 ? A.adjR : A.adjL;
+    u64 cl[4], cf[4];
+    uint32_t w[4];
+    Adj4 nxt[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const uint32_t idx = cand.v[b] < 0 ? o : (uint32_t)cand.v[b];
+      cl[b] = __hip_atomic_load(&A.claim[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      cf[b] = FRESH ? UNCLAIMED64 : snap[idx];
+      w[b] = A.weight[idx];
+      nxt[b] = adj[idx];
+    }
+    const u64 cseed = A.seed_check == 1 ? __hip_atomic_load(&A.claim[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                      : A.seed_check == 2 ? (*(volatile const uint8_t*)&A.robbed[r] ? 0ULL : CLAIM(r, 0)) : CLAIM(r, 0);
+    u64 found = UNCLAIMED64;
+    if (pend != NONE32) { found = claim_node(A, pend, r, pos); pend = NONE32; }
+    int best = -1;
+    uint32_t bw = 0;
+#define CONSIDER(b) if (cand.v[b] >= 0 && RANK(cl[b]) > r && RANK(cf[b]) >= r && (best < 0 || w[b] > bw)) { best = b; bw = w[b]; }
+    CONSIDER(0) CONSIDER(2) CONSIDER(1) CONSIDER(3)
+#undef CONSIDER
+    note_claim(A, seen, r);
+    seen = found;
+    bool done = false;
+    if (RANK(cseed) < r) { A.robbed[r] = 1; done = true; }                       // the seed went to a lower rank: void in the end, stop here
+    else if (best < 0) {
+      if (dir == 0) { nr = steps; dir = 1; steps = 0; cand = A.adjL[o]; }       // the right end: on to the left, from the seed
+      else done = true;
+    } else {
+      const uint32_t nbest = (uint32_t)(best == 0 ? cand.v[0] : best == 1 ? cand.v[1] : best == 2 ? cand.v[2] : cand.v[3]);
+      pos++; pend = nbest; steps++; walked++; tot += bw;
+#pragma unroll
+      for (int q = 0; q < 4; q++) cand.v[q] = best == 0 ? nxt[0].v[q] : best == 1 ? nxt[1].v[q] : best == 2 ? nxt[2].v[q] : nxt[3].v[q];
+    }
+    if (done) {
+      note_claim(A, seen, r);
+      const uint32_t nl = dir == 0 ? 0u : steps;
+      if (dir == 0) nr = steps;
+      A.nr_out[r] = nr; A.nl_out[r] = nl; A.totw_out[r] = tot;
+      my_steps += walked;
+      have = false;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) my_steps += shfl_u64(my_steps, lane ^ off);
+  if (lane == 0 && my_steps) atomicAdd(A.steps_counter, my_steps);              // (thread-walker steps, like the ones before the hand-over)
+}
+
 // ---- long walks: one wavefront per dirty walk.  A memo (the path of some walk's last live run, own or foreign)
 // is re-checked 64 steps per memory round trip; the walk is sequential only from the first changed decision
 // until it meets a memo again -- its own, or the one of the walk whose territory it is taking over.
@@ -1039,7 +1134,7 @@ __global__ void ext_round_begin_kernel(u64* __restrict__ claim, u64* __restrict_
   // four claims per thread, as two 16-byte loads (n2 is padded to a multiple of 4 by the allocation; the claims are 16-byte aligned):
   // with one 8-byte load per thread the pass ran at 3 TB/s
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t == 0) { d_cnt[6] = 0; d_cnt[7] = 0; d_cnt[13] = 0; }      // changed k1-mers, (spare), walks handed over
+  if (t == 0) { d_cnt[6] = 0; d_cnt[7] = 0; d_cnt[13] = 0; d_cnt[14] = 0; }      // changed k1-mers, (spare), walks handed over, the head of their list
   const uint64_t o0 = t * 4;
   if (o0 >= n2) return;
   ulonglong2 c01 = ((const ulonglong2*)(claim + o0))[0], c23 = ((const ulonglong2*)(claim + o0))[1];
@@ -1579,6 +1674,9 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   const unsigned long long bulk_min = getenv("SHN_EXT_BULK") ? strtoull(getenv("SHN_EXT_BULK"), nullptr, 10) : 262144ULL;
   const unsigned long long dense_min = getenv("SHN_EXT_DENSE") ? strtoull(getenv("SHN_EXT_DENSE"), nullptr, 10) : (4ULL << 20);   // (BASELINE configs[2]: 262144 -> 954 ms, 2 M or 16 M -> 900 ms per extension)
   const int seed_check = (int)tune("SHN_EXT_SEEDCHECK", 1);
+  // bulk rounds: a thread walker that gets this far hands its walk to the packed second launch (0: it walks to the end itself, as until round 4)
+  const uint32_t bulk_promote = tune("SHN_EXT_PROMOTE_BULK", 24);
+  const unsigned long long resume_waves = tune("SHN_EXT_RESUME_WAVES", 8192);
   const bool prepass = tune("SHN_EXT_PREPASS", 1) != 0;            // a block's first round settles the walks whose seed an earlier block holds (ext_plan_kernel)
   unsigned long long expect_dirty = limit;
   while (!converged && it < max_iterations) {
@@ -1641,7 +1739,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     TimerRegion t3(ctx, T_EXT_WALK);
     // snapshot, then release the claims of the walks that re-run this round
     // (a block that has just opened holds no claims yet: with the snapshot up to date there is nothing to release and nothing to copy)
-    if (fresh_block && precise_marks && snap_current) { TRYE(hipMemsetAsync(d_cnt + 6, 0, 16, s)); TRYE(hipMemsetAsync(d_cnt + 13, 0, 8, s)); }
+    if (fresh_block && precise_marks && snap_current) { TRYE(hipMemsetAsync(d_cnt + 6, 0, 16, s)); TRYE(hipMemsetAsync(d_cnt + 13, 0, 16, s)); }
     else
     hipLaunchKernelGGL(ext_round_begin_kernel, dim3((uint32_t)cdiv(cdiv(2 * n, 4), 256)), dim3(256), 0, s, claim, snap, 2 * n, dirty, (uint64_t)ns, d_cnt,
                        (!precise_marks || !snap_current) ? 1 : 0, dense ? (uint8_t*)nullptr : chunk, frozen, limit, coarse);
@@ -1651,7 +1749,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     A.claim = claim; A.claim_old = snap;
     A.nr_out = e->d_nr; A.nl_out = e->d_nl; A.totw_out = e->d_totw;
     A.pool = pool; A.moff = moff; A.mR = mR; A.mL = mL; A.mvalid = mvalid; A.hint = words_hint(e->d_rec);
-    A.promote_steps = bulk ? 0xFFFFFFFFu : promote_steps;
+    A.promote_steps = bulk ? (bulk_promote ? bulk_promote : 0xFFFFFFFFu) : promote_steps;
     A.promo_list = promo_list; A.promo_count = d_cnt + 13; A.res_cur = res_cur; A.res_info = res_info;
     A.chunk = dense ? nullptr : chunk;         // (dense rounds write nearly everywhere: their mark pass is dense, the walkers do not flag)
     A.robbed = robbed;
@@ -1668,6 +1766,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     double x_t0 = 0;
     if (getenv("SHN_EXT_XTIME")) {   // (development: time of every thread-walker launch)
        TRYE(hipStreamSynchronize(s)); timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); x_t0 = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+    const bool was_fresh = fresh_block;
     if (plan[2]) {
       TimerRegion tk(ctx, T_EXT_WALK_THREAD);
       if (fresh_block) hipLaunchKernelGGL(ext_walk_kernel<true>, dim3((uint32_t)cdiv(plan[2], WBLK)), dim3(WBLK), 0, s, A, (uint64_t)plan[2], short_list, snap);
@@ -1681,7 +1780,14 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       fprintf(stderr, "[shn_extend] XTIME round %d: thread walker %llu walks, %.2f ms, steps so far %llu; longest walk %llu steps in %.2f ms (%.2f us per step)\n", it + 1, plan[2],
               ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6 - x_t0, st, lw >> 32, (double)(lw & 0xFFFFFFFFULL) * 1e-5, (lw >> 32) ? (double)(lw & 0xFFFFFFFFULL) * 1e-2 / (double)(lw >> 32) : 0.0);
     }
-    if (plan[2]) {                              // walks the thread kernel handed over (the count stays on the device)
+    if (plan[2] && bulk) {                      // ... of a bulk round: packed, a lane per walk, lanes refilled from the list (ext_walk_resume_kernel)
+      if (bulk_promote) {
+        TimerRegion tk(ctx, T_EXT_WALK_THREAD);
+        const uint32_t rgrid = (uint32_t)std::min<unsigned long long>(cdiv(plan[2], WBLK), resume_waves);
+        if (was_fresh) hipLaunchKernelGGL(ext_walk_resume_kernel<true>, dim3(rgrid), dim3(WBLK), 0, s, A, promo_list, (const unsigned long long*)(d_cnt + 13), d_cnt + 14, snap);
+        else hipLaunchKernelGGL(ext_walk_resume_kernel<false>, dim3(rgrid), dim3(WBLK), 0, s, A, promo_list, (const unsigned long long*)(d_cnt + 13), d_cnt + 14, snap);
+      }
+    } else if (plan[2]) {                       // walks the thread kernel handed over (the count stays on the device)
       TimerRegion tk(ctx, T_EXT_WALK_WAVE);
       hipLaunchKernelGGL(ext_walk_long_kernel<true>, dim3((uint32_t)std::min<unsigned long long>(plan[2], 8192ULL)), dim3(64), 0, s, A, promo_list,
                          (uint64_t)ns, (const unsigned long long*)(d_cnt + 13));
