@@ -80,9 +80,9 @@ def gen_reads(n_pairs, seed, n_genes, device, read_seed=None, families=0, first_
     from shannon_amd import synth
     # config 2 ("single component"): one gene family rich enough to give a multi-contig component
     if chain_exons:
-        # --config 2p: ONE family whose isoforms share exons along a chain (synth.make_chain_family): one component of the contig graph
-        # with about as many contigs as exons -- the input that takes the gpmetis branch (kmers_for_component.py:207-237)
-        iso = synth.make_chain_family(chain_exons, seed, exon_len=exon_len)
+        # --config 2p: genes linked by shared repeats (synth.make_repeat_family): one component of the contig graph per strand with about
+        # two contigs per gene -- the input that takes the gpmetis branch (kmers_for_component.py:207-237)
+        iso = synth.make_repeat_family(chain_exons, seed)
         lens = np.array([len(t) for t in iso], dtype=np.int64)
         wts = np.random.Generator(np.random.PCG64(seed + 1)).lognormal(0.0, 0.5, size=len(iso)) * (lens - 300 + 1)
         wts /= wts.sum()
@@ -473,8 +473,8 @@ PRESETS = {"1": dict(genes=1, reads=10_000_000, K=25, exon_len=(80, 600)),
            # of configs[4]), exons up to 5 kb so that the unitigs get long
            "4s": dict(genes=4000, reads=100_000_000, K=31, exon_len=(80, 5000)),
            # not one of BASELINE's configs: the input for row a8 (a component of the contig graph far larger than --partition, cut by
-           # the library's partitioner into the reference's 100 parts, twice): one shared-exon family of 60,000 exons, 20 M reads
-           "2p": dict(genes=1, reads=20_000_000, K=25, exon_len=(80, 600), chain_exons=60000)}
+           # the library's partitioner into the reference's 100 parts, twice): 30,000 genes linked by three shared repeats, 20 M reads
+           "2p": dict(genes=1, reads=20_000_000, K=25, exon_len=(80, 600), chain_exons=30000)}
 
 
 def build_parser():
@@ -807,8 +807,8 @@ def main():
                      "expression), 0.5% substitution errors, multi-component, --partition 500 (BASELINE configs[2])",
                 "4s": "100M synthetic 2x100bp paired reads (50M pairs), k=31 (k1=32), 4,000 genes with exons of 80-5,000 bp (long unitigs), "
                       "0.5% substitution errors, --partition 500 (one-GPU slice of BASELINE configs[4]: a fifth of its reads and genes)",
-                "2p": "20M synthetic 2x100bp paired reads (10M pairs), k=25 (k1=26), ONE shared-exon family (60,000 exons, isoforms sharing exons "
-                      "along a chain: one contig-graph component of about as many contigs, cut into 100 parts twice by the library's "
+                "2p": "20M synthetic 2x100bp paired reads (10M pairs), k=25 (k1=26), 30,000 genes linked by three shared repeat elements "
+                      "(one contig-graph component per strand with about two contigs per gene, cut into 100 parts twice by the library's "
                       "partitioner -- row a8, kmers_for_component.py:207-237), --partition 500; none of BASELINE's configs"}[args.config]
         if not is_config and not families:
             workload = ("%d synthetic 2x100bp paired reads%s, K=%d, %d genes (a tuning input, none of BASELINE's configs)"

@@ -1675,7 +1675,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   const unsigned long long dense_min = getenv("SHN_EXT_DENSE") ? strtoull(getenv("SHN_EXT_DENSE"), nullptr, 10) : (4ULL << 20);   // (BASELINE configs[2]: 262144 -> 954 ms, 2 M or 16 M -> 900 ms per extension)
   const int seed_check = (int)tune("SHN_EXT_SEEDCHECK", 1);
   // bulk rounds: a thread walker that gets this far hands its walk to the packed second launch (0: it walks to the end itself, as until round 4)
-  const uint32_t bulk_promote = tune("SHN_EXT_PROMOTE_BULK", 24);
+  const uint32_t bulk_promote = tune("SHN_EXT_PROMOTE_BULK", 0);      // (measured at BASELINE configs[2], round 5: 8 / 24 / 64 -> walk kernels 273 / 267 / 268 ms per step against 224 without -- the bulk rounds are bound by the random fetches of their steps, not by idle lanes; off)
   const unsigned long long resume_waves = tune("SHN_EXT_RESUME_WAVES", 8192);
   const bool prepass = tune("SHN_EXT_PREPASS", 1) != 0;            // a block's first round settles the walks whose seed an earlier block holds (ext_plan_kernel)
   unsigned long long expect_dirty = limit;

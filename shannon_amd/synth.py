@@ -48,30 +48,23 @@ def make_transcriptome(n_genes, seed=DEFAULT_SEED, exon_len=(80, 600), n_exons=(
     return isoforms, gene_of
 
 
-def make_chain_family(n_exons, seed=DEFAULT_SEED, window=12, step=4, exon_len=(80, 600), keep=0.7, min_iso_len=400):
-    """One gene family whose isoforms share exons along a chain: a pool of n_exons exons; isoform i is drawn from the pool's
-    window [i * step, i * step + window) (every exon kept with probability `keep`), so neighbouring isoforms share most of
-    their exons and the whole family is ONE component of the contig graph -- with about as many contigs as exons.  This is the
-    shape that sends a component through the gpmetis branch (kmers_for_component.py:207-237: components larger than
-    --partition); BASELINE's configs hold no such component (20,000 small genes), `bench.py --config 2p` is built on this.
-    Returns the list of isoform code arrays."""
+def make_repeat_family(n_genes, seed=DEFAULT_SEED, n_repeats=3, repeat_len=120, flank=(200, 400)):
+    """Genes that share a few repeated elements (the shape of a transcriptome's repeat-linked super-component): gene i is
+    flank + repeat[i % n_repeats] + flank (+ a second repeat in every fourth gene) + tail.  The greedy extension gives the repeat to
+    the heaviest gene and cuts the others at its borders, and every contig that overlaps a repeat by a K-mer is connected to its
+    contig: ONE component of the contig graph (per strand) with about two contigs per gene -- what sends a component through the
+    gpmetis branch (kmers_for_component.py:207-237: components larger than --partition).  BASELINE's configs hold no such component
+    (20,000 unrelated genes); `bench.py --config 2p` and the partitioner's pipeline tests are built on this.
+    Returns the list of transcript code arrays."""
     rng = np.random.Generator(np.random.PCG64(seed))
-    exons = [rng.integers(0, 4, size=int(rng.integers(exon_len[0], exon_len[1] + 1)), dtype=np.uint8) for _ in range(n_exons)]
-    isoforms = []
-    i = 0
-    while i * step < n_exons:
-        lo, hi = i * step, min(n_exons, i * step + window)
-        for _try in range(20):
-            k = rng.random(hi - lo) < keep
-            k[0] = True                                   # (the window's first exon: what links the isoform to the one before)
-            iso = np.concatenate([exons[lo + j] for j in range(hi - lo) if k[j]])
-            if len(iso) >= min_iso_len:
-                break
-        else:
-            iso = np.concatenate(exons[lo:hi] + [rng.integers(0, 4, size=min_iso_len, dtype=np.uint8)])
-        isoforms.append(iso)
-        i += 1
-    return isoforms
+    S = [rng.integers(0, 4, repeat_len, dtype=np.uint8) for _ in range(n_repeats)]
+    iso = []
+    for i in range(n_genes):
+        iso.append(np.concatenate([rng.integers(0, 4, int(rng.integers(flank[0], flank[1])), dtype=np.uint8), S[i % n_repeats],
+                                   rng.integers(0, 4, int(rng.integers(flank[0], flank[1])), dtype=np.uint8),
+                                   S[(i + 1) % n_repeats] if i % 4 == 0 else rng.integers(0, 4, 5, dtype=np.uint8),
+                                   rng.integers(0, 4, 150, dtype=np.uint8)]))
+    return iso
 
 
 def sample_pairs(isoforms, n_pairs, seed=DEFAULT_SEED, read_len=100, frag_len=300, err=0.005,

@@ -196,8 +196,12 @@ def test_planted_transcripts_come_back(full):
     A = np.frombuffer(b"ACGT", np.uint8)
     truth = [A[t].tobytes().decode() for t in iso]
     out = sorted(set(F.R.final.values()))
-    tk = np.unique(canon_keys(_lib.string_windows(truth, K1)[0], K1))
-    ok = canon_keys(_lib.string_windows(out, K1)[0], K1)
+    # (precision and recall over the k1-mers whose hash falls into one class of eight, the same class on both sides: an unbiased
+    # eighth of both sets -- the sorts and searches over all 2 x 10^8 k1-mers of the 4s transcriptome took this test four minutes)
+    def eighth(keys):
+        return keys[((keys * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(61)) == 0]
+    tk = np.unique(eighth(canon_keys(_lib.string_windows(truth, K1)[0], K1)))
+    ok = eighth(canon_keys(_lib.string_windows(out, K1)[0], K1))
     pos = np.minimum(np.searchsorted(tk, ok), len(tk) - 1)
     precision = float((tk[pos] == ok).mean())
     ou = np.unique(ok)
