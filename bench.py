@@ -740,11 +740,13 @@ def main():
         W = 100 - k1 + 1
         KERNEL = {"count.direct": "count_direct_kernel", "count.hist1": "hist1_kernel", "count.scatter1": "scatter1_kernel", "count.hist2": "hist_keys_kernel",
                   "count.scatter2": "scatter_keys_kernel", "count.buckets": "buckets_kernel", "route": "route_kernel",
-                  "extend.walk_thread": "ext_walk_kernel", "extend.walk_wave": "ext_walk_long_kernel", "extend.mark": "ext_mark_kernel",
+                  "extend.walk_fresh": "ext_walk_kernel<true>", "extend.walk_thread": "ext_walk_kernel<false>", "extend.walk_wave": "ext_walk_long_kernel",
+                  "extend.mark": "ext_mark_kernel", "extend.begin": "ext_round_begin_kernel",
                   "extend.adjacency": "ext_records_kernel",
                   # the super-k-mer counting path (csrc/count_sk.hip)
                   "count.sk_emit": "sk_scan_kernel", "count.sk_hist": "skr_hist_kernel + skr_scatter_kernel (level 1)", "count.sk_hist2": "skr_hist_kernel",
-                  "count.sk_scatter2": "skr_scatter_kernel", "count.sk_buckets": "sk_buckets_sorted_kernel"}
+                  "count.sk_scatter2": "skr_scatter_kernel", "count.sk_buckets": "sk_buckets_sorted_kernel<.., 256, 1024, 0>",
+                  "count.sk_buckets2": "sk_buckets_sorted_kernel<.., 256, 2048, 0>"}
         # records of the super-k-mer path: a read of W windows makes ~2 W / (w + 1) + 1 records of 16 bytes (w = k1 - m + 1 m-mers per window, m = 13)
         sk_w = k1 - max(13, 2 * k1 - 48) + 1
         rec_bytes = 16.0 * (2.0 * W / (sk_w + 1) + 1.0)
@@ -753,13 +755,19 @@ def main():
                     "count.scatter2": 16.0 * W, "count.buckets": 8.0 * W, "route": 192.0,
                     "count.sk_emit": 25.0 + rec_bytes, "count.sk_hist": 2.0 * rec_bytes, "count.sk_hist2": rec_bytes, "count.sk_scatter2": 2.0 * rec_bytes,
                     "count.sk_buckets": rec_bytes + 12.0 * distinct / max(1, n_reads)}
-        ext = last.res["extension"] if use_dist else {k: getattr(last.R.extension, k, None) for k in ("iterations", "n_walks", "total_steps", "wave_steps", "dense_rounds")}
+        ext = last.res["extension"] if use_dist else {k: getattr(last.R.extension, k, None) for k in ("iterations", "n_walks", "total_steps", "wave_steps", "fresh_steps", "dense_rounds")}
         steps_all = ext["total_steps"] or 0
         steps_wave = ext["wave_steps"] or 0
+        steps_fresh = ext.get("fresh_steps") or 0
         n_or = 2 * distinct                                   # oriented k1-mers
         # bytes of ONE step of the pipeline (all launches of the kernel in that step)
         per_step_bytes = {k: v * n_reads for k, v in per_read.items()}
-        per_step_bytes["extend.walk_thread"] = 152.0 * (steps_all - steps_wave)     # 4 candidates x (claim 8 + snapshot 8 + weight 4 + row 16) + claim 8
+        # a thread-walker step: 4 candidates x (claim 8 + snapshot 8 + weight 4 + row 16) + claim 8 = 152 B; the first round of a rank block
+        # (ext_walk_kernel<true>, its own timer) reads no snapshot: 120 B
+        per_step_bytes["extend.walk_fresh"] = 120.0 * steps_fresh
+        per_step_bytes["extend.walk_thread"] = 152.0 * (steps_all - steps_wave - steps_fresh)
+        per_step_bytes["extend.begin"] = 8.0 * n_or * (timers.get("extend.begin", (0, 0))[1] / max(1, args.steps))   # the claims, once per launch (the three launches that also copy the snapshot move 24 B per k1-mer)
+        per_step_bytes["count.sk_buckets2"] = 0.07 * per_step_bytes["count.sk_buckets"]                                 # (7 % of the buckets do not fit the small table and are read again)
         per_step_bytes["extend.walk_wave"] = 112.0 * steps_wave                      # same without the row prefetch, + memo entry
         # mark pass: claim + snapshot of every oriented k1-mer in the rounds that stream them (dense), one flag byte per 16 k1-mers in the others
         dense_r = ext.get("dense_rounds") if ext.get("dense_rounds") is not None else (ext["iterations"] or 0)

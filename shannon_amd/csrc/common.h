@@ -22,7 +22,7 @@ int shn_fail(int code, const std::string& msg);
 enum {
   T_PACK = 0, T_HIST1, T_SCATTER1, T_HIST2, T_SCATTER2, T_COUNT, T_COMPACT, T_COUNT_TOTAL, T_LOOKUP,
   T_EXTEND, T_ROUTE, T_GRAPH, T_LP, T_EXT_PREP, T_EXT_SORT, T_EXT_WALK, T_SEEDS, T_EXT_WALK_THREAD, T_EXT_WALK_WAVE, T_EXT_MARK, T_EXT_EMIT, T_TABLE_BUILD, T_COUNT_DIRECT, T_CONTIG, T_GRAPH_GPU, T_EXT_ADJ,
-  T_SK_HIST, T_SK_EMIT, T_SK_HIST2, T_SK_SCATTER2, T_SK_BUCKETS, T_SK_BIG, T_N = 32
+  T_SK_HIST, T_SK_EMIT, T_SK_HIST2, T_SK_SCATTER2, T_SK_BUCKETS, T_SK_BIG, T_EXT_WALK_FRESH, T_EXT_BEGIN, T_SK_BUCKETS2, T_N = 40
 };
 
 // grow-only device workspace slot (process-wide ones: g_shn_ws below; per-context ones: shn_ctx::cws)

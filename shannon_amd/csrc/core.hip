@@ -20,7 +20,10 @@ static const char* kTimerNames[T_N] = {
   "pack", "count.hist1", "count.scatter1", "count.hist2", "count.scatter2", "count.buckets", "count.compact",
   "count.total", "table.lookup", "extend", "route", "graph", "lp", "extend.prepare", "extend.sort", "extend.walk", "graph.seeds",
   "extend.walk_thread", "extend.walk_wave", "extend.mark", "extend.emit", "table.build", "count.direct", "contig.stage", "graph.unitigs", "extend.adjacency",
-  "count.sk_hist", "count.sk_emit", "count.sk_hist2", "count.sk_scatter2", "count.sk_buckets", "count.sk_big"};
+  "count.sk_hist", "count.sk_emit", "count.sk_hist2", "count.sk_scatter2", "count.sk_buckets", "count.sk_big",
+  // round 5: one timer per template instance where the launches of a step differ by an order of magnitude -- the first (bulk) round of
+  // a rank block apart from the re-run rounds (ext_walk_kernel<true> / <false>), the begin pass, the second table size of the buckets
+  "extend.walk_fresh", "extend.begin", "count.sk_buckets2"};
 extern "C" const char* shn_timer_name(int slot) {
   if (slot < 0 || slot >= T_N || !kTimerNames[slot]) return "";
   return kTimerNames[slot];

@@ -680,16 +680,17 @@ int shn_count_superkmers(shn_ctx* ctx, const std::vector<ReadsView>& views, uint
       HIP_TRY(hipMemsetAsync(d_cursors + 1, 0, 56, s));                  // [1] unused, [2] / [6] buckets put off to the next size, [3] given up, [5] sum of counts
       HIP_TRY(hipMemsetAsync(d_rcur, 0, (size_t)SK_REGIONS * SK_RSTRIDE * 8, s));
       {
-        TimerRegion t(ctx, T_SK_BUCKETS);
 #define SK_LAUNCH(CANON_, T_, CAP_, FOLD_, GRID_, LDS_, LIST_, DEFER_, DCUR_) \
         hipLaunchKernelGGL((sk_buckets_sorted_kernel<CANON_, T_, CAP_, FOLD_>), dim3((uint32_t)(GRID_)), dim3(T_), LDS_, s, recsB, d_seg, d_off2, d_hist2, P.b2, k1, P.w, \
                            (const uint32_t*)(LIST_), (uint32_t*)(DEFER_), DCUR_, (uint64_t*)pk, (uint32_t*)pc, d_cursors, region_cap, d_rcur, d_run_off, d_ndist)
-        if (both_strands) SK_LAUNCH(true, SK_STHREADS, T1_CAP, 0, nbk, lds_t1, nullptr, d_defer, 2);
-        else SK_LAUNCH(false, SK_STHREADS, T1_CAP, 0, nbk, lds_t1, nullptr, d_defer, 2);
+        { TimerRegion t(ctx, T_SK_BUCKETS);                              // (one region per table size: three kernels of very different cost)
+          if (both_strands) SK_LAUNCH(true, SK_STHREADS, T1_CAP, 0, nbk, lds_t1, nullptr, d_defer, 2);
+          else SK_LAUNCH(false, SK_STHREADS, T1_CAP, 0, nbk, lds_t1, nullptr, d_defer, 2); }
         HIP_TRY(hipMemcpyAsync(cur, d_cursors, 64, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         const unsigned long long n_t2 = cur[2];
         if (n_t2) {
+          TimerRegion t2(ctx, T_SK_BUCKETS2);
           if (both_strands) SK_LAUNCH(true, SK_T2THREADS, T2_CAP, 0, n_t2, lds_t2, d_defer, d_defer2, 6);
           else SK_LAUNCH(false, SK_T2THREADS, T2_CAP, 0, n_t2, lds_t2, d_defer, d_defer2, 6);
           HIP_TRY(hipMemcpyAsync(cur, d_cursors, 64, hipMemcpyDeviceToHost, s));

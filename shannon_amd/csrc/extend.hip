@@ -111,6 +111,7 @@ struct shn_ext {
   u64* d_claim2;         // [2n] scratch (the second half of the block d_claim starts: freed with it)
   uint64_t total_steps;  // walk steps executed over all iterations (for the bench's byte model)
   uint64_t wave_steps;   // ... of which by the wavefront kernel
+  uint64_t fresh_steps;  // ... of which by the thread walker in the first round of a rank block
   int dense_rounds;      // rounds whose begin / mark passes streamed all claims
   uint32_t* d_nr;        // [n_seeds] right steps (UNCLAIMED = void walk)
   uint32_t* d_nl;        // [n_seeds]
@@ -470,6 +471,7 @@ struct WalkArgs {
   const uint32_t* pool; const uint64_t* moff; const uint32_t* mR; const uint32_t* mL; const uint8_t* mvalid;
   WordView hint;         // per k1-mer: where it was last written into a memo (pool index << 2 | kind), NOHINT if never
   unsigned long long* steps_counter;
+  unsigned long long* fresh_steps_counter;   // ... of them in the first round of a rank block (ext_walk_kernel<true>: its own line in bench.py's kernel table)
   unsigned long long* wave_steps_counter;
   unsigned long long* dbg;     // [0] wave steps confirmed from an own memo [1] from a foreign memo
   // a thread walker that turns out long hands its walk over to a wavefront (same round): where it stands
@@ -647,7 +649,7 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
   if (mysteps) atomicAdd(&blk_steps, (unsigned long long)mysteps);
   __syncthreads();
   if (threadIdx.x == 0) {
-    if (blk_steps) atomicAdd(A.steps_counter, blk_steps);
+    if (blk_steps) { atomicAdd(A.steps_counter, blk_steps); if (FRESH) atomicAdd(A.fresh_steps_counter, blk_steps); }
     promo_base = n_promo ? (uint32_t)atomicAdd(A.promo_count, (unsigned long long)n_promo) : 0u;
   }
   __syncthreads();
@@ -1740,9 +1742,11 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     // snapshot, then release the claims of the walks that re-run this round
     // (a block that has just opened holds no claims yet: with the snapshot up to date there is nothing to release and nothing to copy)
     if (fresh_block && precise_marks && snap_current) { TRYE(hipMemsetAsync(d_cnt + 6, 0, 16, s)); TRYE(hipMemsetAsync(d_cnt + 13, 0, 16, s)); }
-    else
-    hipLaunchKernelGGL(ext_round_begin_kernel, dim3((uint32_t)cdiv(cdiv(2 * n, 4), 256)), dim3(256), 0, s, claim, snap, 2 * n, dirty, (uint64_t)ns, d_cnt,
-                       (!precise_marks || !snap_current) ? 1 : 0, dense ? (uint8_t*)nullptr : chunk, frozen, limit, coarse);
+    else {
+      TimerRegion tb(ctx, T_EXT_BEGIN);
+      hipLaunchKernelGGL(ext_round_begin_kernel, dim3((uint32_t)cdiv(cdiv(2 * n, 4), 256)), dim3(256), 0, s, claim, snap, 2 * n, dirty, (uint64_t)ns, d_cnt,
+                         (!precise_marks || !snap_current) ? 1 : 0, dense ? (uint8_t*)nullptr : chunk, frozen, limit, coarse);
+    }
     snap_current = true;
     WalkArgs A;
     A.order = e->d_order; A.adjR = rows_R(e->d_rec); A.adjL = rows_L(e->d_rec); A.weight = words_weight(e->d_rec);
@@ -1754,7 +1758,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     A.chunk = dense ? nullptr : chunk;         // (dense rounds write nearly everywhere: their mark pass is dense, the walkers do not flag)
     A.robbed = robbed;
     A.seed_check = seed_check;
-    A.steps_counter = d_cnt + 1; A.wave_steps_counter = d_cnt + 64; A.dbg = (getenv("SHN_DEBUG") || getenv("SHN_EXT_XTIME")) ? d_cnt + 32 : nullptr;
+    A.steps_counter = d_cnt + 1; A.fresh_steps_counter = d_cnt + 16; A.wave_steps_counter = d_cnt + 64; A.dbg = (getenv("SHN_DEBUG") || getenv("SHN_EXT_XTIME")) ? d_cnt + 32 : nullptr;
     // long (wave per walk) and short (thread per walk) kernels are independent: overlap them on two streams
     if (plan[0]) {
       TRYE(hipEventRecord(ev_fork, s));
@@ -1768,7 +1772,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
        TRYE(hipStreamSynchronize(s)); timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); x_t0 = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
     const bool was_fresh = fresh_block;
     if (plan[2]) {
-      TimerRegion tk(ctx, T_EXT_WALK_THREAD);
+      TimerRegion tk(ctx, fresh_block ? T_EXT_WALK_FRESH : T_EXT_WALK_THREAD);
       if (fresh_block) hipLaunchKernelGGL(ext_walk_kernel<true>, dim3((uint32_t)cdiv(plan[2], WBLK)), dim3(WBLK), 0, s, A, (uint64_t)plan[2], short_list, snap);
       else hipLaunchKernelGGL(ext_walk_kernel<false>, dim3((uint32_t)cdiv(plan[2], WBLK)), dim3(WBLK), 0, s, A, (uint64_t)plan[2], short_list, snap);
     }
@@ -1870,8 +1874,9 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   TRYE(hipStreamSynchronize(s));
   shn_dev_free(e->d_rec); e->d_rec = nullptr;
   e->d_claim2 = nullptr;                                   // (not used any more; its memory goes back with the claims')
-  unsigned long long steps = 0, wsteps = 0, wslots[64];
+  unsigned long long steps = 0, wsteps = 0, fsteps = 0, wslots[64];
   TRYE(hipMemcpyAsync(&steps, d_cnt + 1, 8, hipMemcpyDeviceToHost, s));          // thread-kernel steps
+  TRYE(hipMemcpyAsync(&fsteps, d_cnt + 16, 8, hipMemcpyDeviceToHost, s));
   TRYE(hipMemcpyAsync(wslots, d_cnt + 64, 64 * 8, hipMemcpyDeviceToHost, s));    // wavefront-kernel steps
   TRYE(hipStreamSynchronize(s));
   for (int i = 0; i < 64; i++) wsteps += wslots[i];
@@ -1887,6 +1892,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   }
   e->total_steps = steps;
   e->wave_steps = wsteps;
+  e->fresh_steps = fsteps;
   TRYE(hipGetLastError());
 #undef TRYE
   *out = e;
@@ -1897,6 +1903,7 @@ extern "C" uint64_t shn_ext_n_walks(const shn_ext* e) { return e ? e->n_seeds : 
 extern "C" int shn_ext_iterations(const shn_ext* e) { return e ? e->iterations : 0; }
 extern "C" uint64_t shn_ext_total_steps(const shn_ext* e) { return e ? e->total_steps : 0; }
 extern "C" uint64_t shn_ext_wave_steps(const shn_ext* e) { return e ? e->wave_steps : 0; }
+extern "C" uint64_t shn_ext_fresh_steps(const shn_ext* e) { return e ? e->fresh_steps : 0; }
 extern "C" int shn_ext_dense_rounds(const shn_ext* e) { return e ? e->dense_rounds : 0; }
 
 extern "C" int shn_ext_stats_range(shn_ctx* ctx, const shn_ext* e, uint64_t lo, uint64_t n, uint32_t* n_right, uint32_t* n_left, uint64_t* tot_weight) {

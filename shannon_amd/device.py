@@ -23,7 +23,7 @@ class Context(object):
     def timers(self):
         """{name: (ms, n_regions)} of HIP-event timed kernel groups since the last reset."""
         out = {}
-        for slot in range(32):
+        for slot in range(40):
             name = _lib.lib().shn_timer_name(slot).decode()
             if not name:
                 continue

@@ -108,6 +108,10 @@ class Extension(object):
         return int(_lib.lib().shn_ext_wave_steps(self.h))
 
     @property
+    def fresh_steps(self):
+        return int(_lib.lib().shn_ext_fresh_steps(self.h))
+
+    @property
     def dense_rounds(self):
         return int(_lib.lib().shn_ext_dense_rounds(self.h))
 
@@ -735,6 +739,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     res.n_walks = ext.n_walks
     res.total_steps = ext.total_steps
     res.wave_steps = ext.wave_steps
+    res.fresh_steps = ext.fresh_steps
     res.dense_rounds = ext.dense_rounds
     res.contigs = contigs[1:]
     res.contig_raw = contig_raw

@@ -10,10 +10,12 @@ import csv, sys, re, collections, json
 # bench.py timer name -> kernel name prefix in the profile
 TIMER_KERNEL = {"count.direct": "count_direct_kernel", "count.hist1": "hist1_kernel", "count.scatter1": "scatter1_kernel", "count.hist2": "hist_keys_kernel",
                 "count.scatter2": "scatter_keys_kernel<false>", "count.buckets": "buckets_kernel<false>", "route": "route_kernel",
-                "extend.walk_thread": "ext_walk_kernel", "extend.walk_wave": "ext_walk_long_kernel", "extend.mark": "ext_mark_kernel",
+                # (round 5: per template instance -- the first round of a rank block and the re-run rounds are different kernels)
+                "extend.walk_fresh": "ext_walk_kernel<true>", "extend.walk_thread": "ext_walk_kernel<false>", "extend.walk_wave": "ext_walk_long_kernel",
+                "extend.mark": "ext_mark_kernel", "extend.begin": "ext_round_begin_kernel",
                 "extend.adjacency": "ext_records_kernel",
                 "count.sk_emit": "sk_scan_kernel", "count.sk_hist2": "skr_hist_kernel", "count.sk_scatter2": "skr_scatter_kernel",
-                "count.sk_buckets": "sk_buckets_sorted_kernel"}
+                "count.sk_buckets": "sk_buckets_sorted_kernel<true, 256, 1024, 0>", "count.sk_buckets2": "sk_buckets_sorted_kernel<true, 256, 2048, 0>"}
 
 
 def short(name):
