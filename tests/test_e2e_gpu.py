@@ -322,21 +322,21 @@ def test_own_partitioner_through_the_pipeline(ctx):
 
 
 def test_repeat_linked_genes_through_the_partitioner(ctx):
-    """the input shape of `bench.py --config 2p` at test size: 160 genes linked by three shared repeats (synth.make_repeat_family)
+    """the input shape of `bench.py --config 2p` at test size: 70 genes linked by three shared repeats (synth.make_repeat_family)
     give contig components far above --partition; they are cut by the library's partitioner (shn_partition_metis, twice:
     kmers_for_component.py:207-237) -- the same vectors as its Python mirror -- and the oracle pipeline given exactly those vectors
     produces the same partitions, transcripts and final file."""
     import numpy as np
     from shannon_amd import pipeline, synth, kmers_for_component as kfc
     from oracle import pipeline as opipe
-    iso = synth.make_repeat_family(160, seed=29)
-    r1, r2 = synth.sample_pairs(iso, 70000, 9, err=0.003, sigma=0.5)
+    iso = synth.make_repeat_family(70, seed=29)
+    r1, r2 = synth.sample_pairs(iso, 32000, 9, err=0.003, sigma=0.5)
     A = np.frombuffer(b"ACGT", np.uint8)
     s1, s2 = [A[r].tobytes().decode() for r in r1], [A[r].tobytes().decode() for r in r2]
-    psize = 25
+    psize = 20
     R = pipeline.assemble(ctx, s1, s2, K=25, partition_size=psize, sample="s", seed=3)
     big = R.extension.big_components
-    assert big and max(len(c) for c, _m in big) >= 250, [len(c) for c, _m in big]
+    assert big and max(len(c) for c, _m in big) >= 110, [len(c) for c, _m in big]
     pv = []
     for contigs, metis in big:
         P = kfc.n_partitions(len(contigs), psize)
@@ -348,4 +348,4 @@ def test_repeat_linked_genes_through_the_partitioner(ctx):
     assert list(R.partitions) == list(O["partitions"]) and sum(1 for p in R.partitions if p.startswith("r2_c")) >= 10
     for p in R.partitions:
         cmp_fasta(R.partitions[p]["reconstructed_fasta"], O["partitions"][p]["reconstructed_fasta"])
-    assert R.final == O["final"] and len(R.final) >= 100
+    assert R.final == O["final"] and len(R.final) >= 40
