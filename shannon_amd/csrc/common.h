@@ -290,14 +290,15 @@ __device__ __forceinline__ int64_t shn_table_find_k(const uint64_t* __restrict__
 // handed out again to the next request it fits (hipMalloc/hipFree of hundreds of MB cost milliseconds per step).
 hipError_t shn_dev_malloc_raw(void** p, size_t bytes);                 // on the calling thread's current stream
 hipError_t shn_dev_malloc_on(void** p, size_t bytes, hipStream_t stream);
-void shn_dev_free(void* p);                  // (events on the block's stream and the calling thread's current stream: core.hip)
+void shn_dev_free(void* p);                  // (the block stays ordered behind its own stream and the calling thread's current stream: core.hip)
 void shn_dev_free_on(void* p, hipStream_t stream);
 void shn_dev_trim();                         // give the cached blocks back to the driver
 template <class T> static inline hipError_t shn_dev_malloc(T** p, size_t bytes) { return shn_dev_malloc_raw((void**)p, bytes); }
+void shn_stream_retired(hipStream_t s);      // a stream about to be destroyed (synchronised by the caller): no block waits on it any more
 void shn_use_stream(hipStream_t s);          // the calling host thread works on this stream from now on (what the allocator orders frees against)
 hipStream_t shn_current_stream();
 void shn_poison(void* p, size_t bytes, hipStream_t s);      // SHN_DEV_POISON: fill with the poison byte (else nothing)
-void shn_debug_count(int i);                 // shn_debug_counter(i)++: [0] double frees [1] foreign frees [2] workspace slots asked for by two threads at once
+void shn_debug_count(int i);                 // shn_debug_counter(i)++: [0] double frees [1] foreign frees [2] workspace slots asked for by a thread that does not own the stage [3] hand-overs without an event [4] cross-stream hand-overs
 // entry of a call on a context: device + the thread's current stream
 #define SHN_ENTER(ctx) do { HIP_TRY(hipSetDevice((ctx)->device)); shn_use_stream((ctx)->stream); } while (0)
 

@@ -58,18 +58,23 @@ TimerRegion::~TimerRegion() {
 }
 
 // The caching allocator (shared by every context and host thread of the process, one process per GPU).  A block remembers the
-// stream it was handed out on and, when it comes back, an event recorded on that stream and on the stream of the thread that
-// frees it: the next caller gets it at once if it works on the same stream (stream order makes that safe whatever is still
-// queued), any other caller only after the events have completed.  (Until round 4 a freed block went to the next caller at once
-// and correctness rested on every caller having synchronised its stream before every free, on its error paths too.)
+// streams that may still have work queued on it: the stream it was handed out on and the current stream of the thread that freed
+// it.  The next caller on one of those streams gets it at once (stream order makes that safe whatever is still queued); a caller
+// on ANOTHER stream gets it behind an event recorded on each of them at that moment and waited for by its own stream
+// (hipStreamWaitEvent: everything queued there so far -- a superset of what was queued at the free -- completes first; nobody
+// blocks on the host).  A free therefore costs no HIP call, and neither does the common reuse on the same stream.  (Until round 4
+// a freed block went to the next caller at once and correctness rested on every caller having synchronised its stream before every
+// free, on its error paths too.)  A stream that goes away (a forked context with its host thread) is synchronised first and
+// struck from the blocks (shn_stream_retired).
 // The "current stream" of a host thread is the stream of the context it last entered the library with (shn_use_stream: set by
-// SHN_ENTER, TimerRegion, shn_thread_ctx); a caller that knows better passes the stream.
-// Debug switches (environment): SHN_DEV_POISON=<byte 0..255>: every block handed out (and every workspace slot on every get) is
-// filled with that byte first -- a kernel that reads what it never wrote then reads the same garbage on every run instead of what the
-// last user left behind; SHN_DEV_NOCACHE=1: no reuse at all.  A block freed twice is reported on stderr and counted
-// (shn_debug_counter(0)) -- the second free would hand a block that is in use to the next caller.
+// SHN_ENTER, TimerRegion, shn_thread_ctx, every `s = ctx->stream`); a caller that knows better passes the stream.
+// Debug switches (environment): SHN_DEV_POISON=<byte 0..255>: every block handed out (and every workspace slot that has just grown;
+// SHN_DEV_POISON_WS=1: on every request) is filled with that byte first -- a kernel that reads what it never wrote then reads the same
+// garbage on every run instead of what the last user left behind; SHN_DEV_NOCACHE=1: no reuse at all; SHN_DEV_LEGACY=1: the
+// allocator of rounds 1-4 (no ordering).  A block freed twice is reported on stderr and counted (shn_debug_counter(0)) -- the second
+// free would hand a block that is in use to the next caller.
 namespace {
-struct DevBlock { void* p; size_t cap; bool used; hipStream_t stream; hipEvent_t ev[2]; int n_ev; };
+struct DevBlock { void* p; size_t cap; bool used; hipStream_t stream; hipStream_t pend[2]; int n_pend; };
 std::vector<DevBlock> g_blocks;
 std::mutex g_blocks_mu;
 std::vector<hipEvent_t> g_ev_pool;
@@ -78,19 +83,23 @@ thread_local hipStream_t t_stream = nullptr;
 int poison_byte() { static const int v = getenv("SHN_DEV_POISON") ? (atoi(getenv("SHN_DEV_POISON")) & 255) : -1; return v; }
 bool legacy_reuse() { static const bool v = getenv("SHN_DEV_LEGACY") && getenv("SHN_DEV_LEGACY")[0] == '1'; return v; }   // (A/B: the allocator of rounds 1-4 -- a freed block goes to the next caller at once)
 bool no_cache() { static const bool v = getenv("SHN_DEV_NOCACHE") && getenv("SHN_DEV_NOCACHE")[0] == '1'; return v; }
-hipEvent_t ev_get() {
-  if (!g_ev_pool.empty()) { hipEvent_t e = g_ev_pool.back(); g_ev_pool.pop_back(); return e; }
-  hipEvent_t e = nullptr;
-  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  return e;
-}
-// (g_blocks_mu held) true: nothing queued at the time of the free is still running -- or the asker works on the stream it was queued on
-bool block_ready(DevBlock& b, hipStream_t asker) {
-  if (!b.n_ev || legacy_reuse()) return true;
-  if (b.n_ev == 1 && b.stream == asker) return true;          // one stream used it, the asker's own: stream order
-  for (int i = 0; i < b.n_ev; i++) if (hipEventQuery(b.ev[i]) != hipSuccess) { (void)hipGetLastError(); return false; }
-  for (int i = 0; i < b.n_ev; i++) g_ev_pool.push_back(b.ev[i]);
-  b.n_ev = 0;
+// (g_blocks_mu held) make `asker` wait for what the block's pending streams have queued so far; false: no event to be had (the caller skips the block)
+bool order_behind(DevBlock& b, hipStream_t asker) {
+  if (legacy_reuse()) { b.n_pend = 0; return true; }
+  for (int i = 0; i < b.n_pend; i++) {
+    if (b.pend[i] == asker) continue;
+    // (a ring of 256 events: one is recorded again only after 255 other hand-overs -- long after the wait queued on its last record has run)
+    static size_t ring_at = 0;
+    hipEvent_t e = nullptr;
+    if (g_ev_pool.size() < 256) {
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+      g_ev_pool.push_back(e);
+    } else e = g_ev_pool[ring_at++ & 255];
+    const bool ok = hipEventRecord(e, b.pend[i]) == hipSuccess && hipStreamWaitEvent(asker, e, 0) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); g_dbg[3].fetch_add(1); return false; }
+    g_dbg[4].fetch_add(1);                     // cross-stream hand-overs
+  }
+  b.n_pend = 0;
   return true;
 }
 }
@@ -102,17 +111,31 @@ void shn_poison(void* p, size_t bytes, hipStream_t s) {
   const int v = poison_byte();
   if (v >= 0 && p && bytes) (void)hipMemsetAsync(p, v, bytes, s);
 }
+// a stream is about to be destroyed (the caller has synchronised it): nothing is pending on it any more
+void shn_stream_retired(hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_blocks_mu);
+  for (auto& b : g_blocks) {
+    int k = 0;
+    for (int i = 0; i < b.n_pend; i++) if (b.pend[i] != s) b.pend[k++] = b.pend[i];
+    b.n_pend = k;
+    if (b.stream == s && !b.used) b.stream = nullptr;
+  }
+}
 hipError_t shn_dev_malloc_on(void** p, size_t bytes, hipStream_t stream) {
   if (bytes == 0) bytes = 1;
   if (!no_cache()) {
     std::lock_guard<std::mutex> lk(g_blocks_mu);
-    int best = -1;
-    for (size_t i = 0; i < g_blocks.size(); i++)
-      if (!g_blocks[i].used && g_blocks[i].cap >= bytes && g_blocks[i].cap <= 2 * bytes + (1u << 20) &&
-          (best < 0 || g_blocks[i].cap < g_blocks[best].cap) && block_ready(g_blocks[i], stream)) best = (int)i;
-    if (best >= 0) {
+    // best fit among the free blocks; among equal sizes one whose pending streams are the asker's own (no event needed)
+    int best = -1; bool best_own = false;
+    for (size_t i = 0; i < g_blocks.size(); i++) {
+      DevBlock& b = g_blocks[i];
+      if (b.used || b.cap < bytes || b.cap > 2 * bytes + (1u << 20)) continue;
+      bool own = true;
+      for (int j = 0; j < b.n_pend; j++) own = own && b.pend[j] == stream;
+      if (best < 0 || b.cap < g_blocks[best].cap || (b.cap == g_blocks[best].cap && own && !best_own)) { best = (int)i; best_own = own; }
+    }
+    if (best >= 0 && order_behind(g_blocks[best], stream)) {
       DevBlock& b = g_blocks[best];
-      // (taken by its own stream with events pending: they stay -- whoever gets it next from another stream still has to wait for them)
       b.used = true; b.stream = stream; *p = b.p;
       shn_poison(b.p, b.cap, stream);
       return hipSuccess;
@@ -147,35 +170,25 @@ void shn_dev_free_on(void* p, hipStream_t stream) {
       fprintf(stderr, "[shannon_hip] shn_dev_free: block %p (%zu bytes) freed twice\n", p, b.cap);
       return;
     }
-    // events: behind everything queued so far on the stream the block was handed out on and on the freeing thread's stream
-    hipStream_t on[2] = {b.stream, stream};
-    const int n_on = b.stream == stream ? 1 : 2;
-    for (int j = 0; j < b.n_ev; j++) g_ev_pool.push_back(b.ev[j]);       // (re-used on its own stream with events pending: superseded by the new ones on the same streams or later)
-    b.n_ev = 0;
-    bool ok = true;
-    for (int j = 0; j < n_on; j++) {
-      hipEvent_t e = ev_get();
-      if (!e || hipEventRecord(e, on[j]) != hipSuccess) { (void)hipGetLastError(); if (e) g_ev_pool.push_back(e); ok = false; break; }
-      b.ev[b.n_ev++] = e;
-    }
-    if (!ok) {                                  // no event to be had: the old contract -- wait here
-      lk.unlock();
-      (void)hipStreamSynchronize(on[0]); if (n_on > 1) (void)hipStreamSynchronize(on[1]);
-      lk.lock();
-      for (auto& bb : g_blocks) if (bb.p == p) { for (int j = 0; j < bb.n_ev; j++) g_ev_pool.push_back(bb.ev[j]); bb.n_ev = 0; bb.used = false; break; }
-      return;
-    }
-    if (no_cache()) {
+    // what may still be queued on the block: on the stream it was handed out on and on the freeing thread's stream
+    // (plus whatever was pending when its own stream took it back and has not been waited for since)
+    hipStream_t on[4]; int n_on = 0;
+    auto add = [&](hipStream_t s) { for (int j = 0; j < n_on; j++) if (on[j] == s) return; on[n_on++] = s; };
+    add(b.stream); add(stream);
+    for (int j = 0; j < b.n_pend; j++) add(b.pend[j]);
+    if (n_on > 2 || no_cache()) {               // more streams than a block remembers (or no cache): wait here, once
       DevBlock gone = b;
-      g_blocks.erase(g_blocks.begin() + (ptrdiff_t)i);
       lk.unlock();
-      for (int j = 0; j < gone.n_ev; j++) (void)hipEventSynchronize(gone.ev[j]);
+      for (int j = 0; j < n_on; j++) (void)hipStreamSynchronize(on[j]);
       lk.lock();
-      for (int j = 0; j < gone.n_ev; j++) g_ev_pool.push_back(gone.ev[j]);
-      lk.unlock();
-      (void)hipFree(gone.p);
+      for (size_t k = 0; k < g_blocks.size(); k++) if (g_blocks[k].p == p) {
+        if (no_cache()) { g_blocks.erase(g_blocks.begin() + (ptrdiff_t)k); lk.unlock(); (void)hipFree(gone.p); return; }
+        g_blocks[k].n_pend = 0; g_blocks[k].used = false; break;
+      }
       return;
     }
+    b.n_pend = n_on;
+    for (int j = 0; j < n_on; j++) b.pend[j] = on[j];
     b.used = false;
     return;
   }
@@ -188,11 +201,7 @@ void shn_dev_free(void* p) { shn_dev_free_on(p, t_stream); }
 void shn_dev_trim() {
   std::lock_guard<std::mutex> lk(g_blocks_mu);
   std::vector<DevBlock> keep;
-  for (auto& b : g_blocks) {
-    if (b.used) { keep.push_back(b); continue; }
-    for (int j = 0; j < b.n_ev; j++) { (void)hipEventSynchronize(b.ev[j]); g_ev_pool.push_back(b.ev[j]); }
-    hipFree(b.p);
-  }
+  for (auto& b : g_blocks) { if (b.used) keep.push_back(b); else hipFree(b.p); }      // (hipFree waits for the device)
   g_blocks.swap(keep);
 }
 
@@ -263,7 +272,7 @@ extern "C" void shn_ctx_destroy(shn_ctx* c) {
   }
   for (int i = 0; i < T_N; i++)
     for (auto& p : c->pending[i]) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-  if (c->owns_stream && c->stream) hipStreamDestroy(c->stream);
+  if (c->owns_stream && c->stream) { shn_stream_retired(c->stream); hipStreamDestroy(c->stream); }
   for (auto& w : c->cws) if (w.p) { hipFree(w.p); w.p = nullptr; w.cap = 0; }
   for (auto& h : c->hpin) h.release();
   if (!c->owns_stream) shn_dev_trim();         // (a forked context goes with its host thread, in the middle of a run)
