@@ -50,7 +50,7 @@ def make_transcriptome(n_genes, seed=DEFAULT_SEED, exon_len=(80, 600), n_exons=(
 
 def make_repeat_family(n_genes, seed=DEFAULT_SEED, n_repeats=3, repeat_len=120, flank=(200, 400)):
     """Genes that share a few repeated elements (the shape of a transcriptome's repeat-linked super-component): gene i is
-    flank + repeat[i % n_repeats] + flank (+ a second repeat in every fourth gene) + tail.  The greedy extension gives the repeat to
+    flank + repeat[i % n_repeats] + flank (+ the next repeat in every fourth gene of the class) + tail.  The greedy extension gives the repeat to
     the heaviest gene and cuts the others at its borders, and every contig that overlaps a repeat by a K-mer is connected to its
     contig: ONE component of the contig graph (per strand) with about two contigs per gene -- what sends a component through the
     gpmetis branch (kmers_for_component.py:207-237: components larger than --partition).  BASELINE's configs hold no such component
@@ -62,7 +62,8 @@ def make_repeat_family(n_genes, seed=DEFAULT_SEED, n_repeats=3, repeat_len=120, 
     for i in range(n_genes):
         iso.append(np.concatenate([rng.integers(0, 4, int(rng.integers(flank[0], flank[1])), dtype=np.uint8), S[i % n_repeats],
                                    rng.integers(0, 4, int(rng.integers(flank[0], flank[1])), dtype=np.uint8),
-                                   S[(i + 1) % n_repeats] if i % 4 == 0 else rng.integers(0, 4, 5, dtype=np.uint8),
+                                   # (every fourth gene of a repeat's class carries the next repeat as well: the classes chain into one component)
+                                   S[(i + 1) % n_repeats] if (i // n_repeats) % 4 == 0 else rng.integers(0, 4, 5, dtype=np.uint8),
                                    rng.integers(0, 4, 150, dtype=np.uint8)]))
     return iso
 
