@@ -118,7 +118,7 @@ void shn_stream_retired(hipStream_t s) {
     int k = 0;
     for (int i = 0; i < b.n_pend; i++) if (b.pend[i] != s) b.pend[k++] = b.pend[i];
     b.n_pend = k;
-    if (b.stream == s && !b.used) b.stream = nullptr;
+    if (b.stream == s) b.stream = nullptr;         // (a block that outlives the stream it was handed out on: nothing of that stream is left to wait for)
   }
 }
 hipError_t shn_dev_malloc_on(void** p, size_t bytes, hipStream_t stream) {
