@@ -82,9 +82,10 @@ def gen_reads(n_pairs, seed, n_genes, device, read_seed=None, families=0, first_
     if chain_exons:
         # --config 2p: genes linked by shared repeats (synth.make_repeat_family): one component of the contig graph per strand with about
         # two contigs per gene -- the input that takes the gpmetis branch (kmers_for_component.py:207-237)
-        # (a repeat element per 20 genes, every fourth gene carrying the next one as well: the repeats chain into one component while no
-        # graph node gets thousands of branches -- three repeats for 30,000 genes would put a 10,000 x 10,000 X-node into one partition)
-        iso = synth.make_repeat_family(chain_exons, seed, n_repeats=max(3, chain_exons // 20))
+        # (a repeat element per 5 genes, every fourth gene of a repeat's class carrying the next one as well: the repeats chain into one
+        # component while no graph node gets more than a handful of branches -- three repeats for 30,000 genes would put a 10,000 x 10,000
+        # X-node into one partition, and 20 genes per repeat still cost the graph stage and the sparse flow 23 s per step)
+        iso = synth.make_repeat_family(chain_exons, seed, n_repeats=max(3, chain_exons // 5))
         lens = np.array([len(t) for t in iso], dtype=np.int64)
         wts = np.random.Generator(np.random.PCG64(seed + 1)).lognormal(0.0, 0.5, size=len(iso)) * (lens - 300 + 1)
         wts /= wts.sum()
@@ -475,7 +476,7 @@ PRESETS = {"1": dict(genes=1, reads=10_000_000, K=25, exon_len=(80, 600)),
            # of configs[4]), exons up to 5 kb so that the unitigs get long
            "4s": dict(genes=4000, reads=100_000_000, K=31, exon_len=(80, 5000)),
            # not one of BASELINE's configs: the input for row a8 (a component of the contig graph far larger than --partition, cut by
-           # the library's partitioner into the reference's 100 parts, twice): 30,000 genes linked by 1,500 shared repeats in a chain, 20 M reads
+           # the library's partitioner into the reference's 100 parts, twice): 30,000 genes linked by 6,000 shared repeats in a chain, 20 M reads
            "2p": dict(genes=1, reads=20_000_000, K=25, exon_len=(80, 600), chain_exons=30000)}
 
 
@@ -817,7 +818,7 @@ def main():
                      "expression), 0.5% substitution errors, multi-component, --partition 500 (BASELINE configs[2])",
                 "4s": "100M synthetic 2x100bp paired reads (50M pairs), k=31 (k1=32), 4,000 genes with exons of 80-5,000 bp (long unitigs), "
                       "0.5% substitution errors, --partition 500 (one-GPU slice of BASELINE configs[4]: a fifth of its reads and genes)",
-                "2p": "20M synthetic 2x100bp paired reads (10M pairs), k=25 (k1=26), 30,000 genes linked by 1,500 shared repeat elements in a chain "
+                "2p": "20M synthetic 2x100bp paired reads (10M pairs), k=25 (k1=26), 30,000 genes linked by 6,000 shared repeat elements in a chain "
                       "(one contig-graph component per strand with about two contigs per gene, cut into 100 parts twice by the library's "
                       "partitioner -- row a8, kmers_for_component.py:207-237), --partition 500; none of BASELINE's configs"}[args.config]
         if not is_config and not families:
