@@ -1679,7 +1679,9 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   // bulk rounds: a thread walker that gets this far hands its walk to the packed second launch (0: it walks to the end itself, as until round 4)
   const uint32_t bulk_promote = tune("SHN_EXT_PROMOTE_BULK", 0);      // (measured at BASELINE configs[2], round 5: 8 / 24 / 64 -> walk kernels 273 / 267 / 268 ms per step against 224 without -- the bulk rounds are bound by the random fetches of their steps, not by idle lanes; off)
   const unsigned long long resume_waves = tune("SHN_EXT_RESUME_WAVES", 8192);
-  const bool prepass = tune("SHN_EXT_PREPASS", 1) != 0;            // a block's first round settles the walks whose seed an earlier block holds (ext_plan_kernel)
+  const bool prepass = tune("SHN_EXT_PREPASS", 1) != 0;
+  const uint32_t fresh_split = std::max<uint32_t>(1, std::min<uint32_t>(16, tune("SHN_EXT_FRESH_SPLIT", 1)));   // sub-launches of a block's first (bulk) round
+  const uint32_t fresh_split_min = tune("SHN_EXT_FRESH_SPLIT_MIN", 65536);                                       // ... of blocks of at least this many walks            // a block's first round settles the walks whose seed an earlier block holds (ext_plan_kernel)
   unsigned long long expect_dirty = limit;
   while (!converged && it < max_iterations) {
     const bool bulk = bulk_min && expect_dirty >= bulk_min;
@@ -1771,6 +1773,33 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     if (getenv("SHN_EXT_XTIME")) {   // (development: time of every thread-walker launch)
        TRYE(hipStreamSynchronize(s)); timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); x_t0 = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
     const bool was_fresh = fresh_block;
+    if (fresh_block && bulk && fresh_split > 1 && plan[0] == 0 && limit - frozen >= fresh_split_min && !x_t0) {
+      // The first round of a block in rank-ordered sub-launches, each behind a pass that settles the walks whose seed is claimed by
+      // then (ext_plan_kernel): the heaviest seeds of the block run first and take their whole transcripts; of the seeds behind them
+      // -- 98.6 % of the walks of BASELINE configs[2] end void, and a transcript's k1-mers have similar weights, so they sit in the same
+      // block as the walk that swallows them -- only the ones still free are launched at all.  The sub-ranges double (1/2^(S-1) of the
+      // block first).  Semantically this is the same round under one of its possible schedules: a walk sees the live claims of lower
+      // ranks, a seed found claimed by a lower rank is void exactly as when its own thread finds it so (and is marked again if that
+      // claim is given up later: seed_rank in the mark pass).
+      const unsigned long long total = limit - frozen;
+      uint32_t a = frozen;
+      for (uint32_t j = 0; j < fresh_split && a < limit; j++) {
+        const uint32_t b = j + 1 == fresh_split ? limit : (uint32_t)std::min<unsigned long long>(limit, (unsigned long long)frozen + std::max<unsigned long long>(16, total >> (fresh_split - 1 - j)));
+        if (b <= a) continue;
+        TRYE(hipMemsetAsync(d_cnt + 2, 0, 32, s));
+        hipLaunchKernelGGL(ext_plan_kernel, dim3((uint32_t)cdiv(b - a, 1024)), dim3(1024), 0, s, e->d_nr, e->d_nl, (uint64_t)b, a,
+                           mvalid, mR, mL, dirty, long_list, short_list, d_cnt + 2, 0xFFFFFFFFu, coarse,
+                           ((a > 0) && prepass) ? (const u64*)claim : (const u64*)nullptr, e->d_order, e->d_totw);
+        TRYE(hipMemcpyAsync(plan, d_cnt + 2, 32, hipMemcpyDeviceToHost, s));
+        TRYE(hipStreamSynchronize(s));
+        if (plan[2]) {
+          TimerRegion tk(ctx, T_EXT_WALK_FRESH);
+          hipLaunchKernelGGL(ext_walk_kernel<true>, dim3((uint32_t)cdiv(plan[2], WBLK)), dim3(WBLK), 0, s, A, (uint64_t)plan[2], short_list, snap);
+        }
+        a = b;
+      }
+      plan[0] = 0; plan[2] = 0;                   // (nothing handed over, nothing for the wavefront kernels in this round)
+    } else
     if (plan[2]) {
       TimerRegion tk(ctx, fresh_block ? T_EXT_WALK_FRESH : T_EXT_WALK_THREAD);
       if (fresh_block) hipLaunchKernelGGL(ext_walk_kernel<true>, dim3((uint32_t)cdiv(plan[2], WBLK)), dim3(WBLK), 0, s, A, (uint64_t)plan[2], short_list, snap);
