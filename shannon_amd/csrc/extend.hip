@@ -1680,7 +1680,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   const uint32_t bulk_promote = tune("SHN_EXT_PROMOTE_BULK", 0);      // (measured at BASELINE configs[2], round 5: 8 / 24 / 64 -> walk kernels 273 / 267 / 268 ms per step against 224 without -- the bulk rounds are bound by the random fetches of their steps, not by idle lanes; off)
   const unsigned long long resume_waves = tune("SHN_EXT_RESUME_WAVES", 8192);
   const bool prepass = tune("SHN_EXT_PREPASS", 1) != 0;
-  const uint32_t fresh_split = std::max<uint32_t>(1, std::min<uint32_t>(16, tune("SHN_EXT_FRESH_SPLIT", 1)));   // sub-launches of a block's first (bulk) round
+  const uint32_t fresh_split = std::max<uint32_t>(1, std::min<uint32_t>(16, tune("SHN_EXT_FRESH_SPLIT", 1)));   // sub-launches of a block's first (bulk) round (measured at configs[2]: 1 / 4 / 7 / 10 -> 184 / 176 / 209 / 248 ms: every sub-launch waits for its longest walk; off)
   const uint32_t fresh_split_min = tune("SHN_EXT_FRESH_SPLIT_MIN", 65536);                                       // ... of blocks of at least this many walks            // a block's first round settles the walks whose seed an earlier block holds (ext_plan_kernel)
   unsigned long long expect_dirty = limit;
   while (!converged && it < max_iterations) {
