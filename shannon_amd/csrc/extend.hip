@@ -180,10 +180,19 @@ __device__ __forceinline__ uint64_t fd_line_in_bucket(const TabIdx& T, uint32_t 
   const uint64_t lo = T.boff[b], hi = T.boff[b + 1];
   return lo / FD_PER_LINE + b + __umul64hi(shn_mix64(key), (hi - lo) / FD_PER_LINE + 1);
 }
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one; each XCD has its own 4 MB L2).  A kernel that
+// goes through the table in order -- consecutive blocks on consecutive k1-mers, whose dictionary look-ups fall into the same few
+// lines -- therefore spreads every stretch of lines over eight L2s.  With this block number instead of blockIdx.x the blocks that
+// share an XCD are consecutive: each XCD works through one contiguous eighth of the launch.  (Speed only; any mapping is correct.)
+__device__ __forceinline__ uint64_t xcd_block(int on) {
+  const uint32_t g8 = gridDim.x & ~7u;
+  if (!on || blockIdx.x >= g8) return blockIdx.x;
+  return (uint64_t)(blockIdx.x & 7u) * (g8 >> 3) + (blockIdx.x >> 3);
+}
 __global__ void fd_build_kernel(const TabIdx T, const uint8_t* __restrict__ flags, uint64_t n,
-                                unsigned long long* __restrict__ lines, uint64_t n_lines) {
+                                unsigned long long* __restrict__ lines, uint64_t n_lines, int xcd) {
   const uint64_t* __restrict__ tkeys = T.keys;
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t i = xcd_block(xcd) * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint8_t f = flags[i];
   if (f & 2) return;
@@ -232,13 +241,13 @@ __device__ __forceinline__ uint32_t fd_match(ulonglong2 v, const unsigned long l
 // records -- 128 contiguous bytes -- 16 bytes each.
 struct __attribute__((aligned(16))) Quad { uint32_t a, b, c, d; };
 __global__ void ext_records_kernel(const TabIdx T, const uint8_t* __restrict__ flags, const uint32_t* __restrict__ weight, uint64_t n, int k, int canonical,
-                                   Rec* __restrict__ rec, const unsigned long long* __restrict__ lines, uint64_t n_lines) {
+                                   Rec* __restrict__ rec, const unsigned long long* __restrict__ lines, uint64_t n_lines, int xcd) {
   const uint64_t* __restrict__ tkeys = T.keys;
   const uint64_t total = n * 8;
   const uint64_t rounded = (total + 63) & ~63ULL;                       // whole wavefronts take part in the ballots and shuffles
   const uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
   const int lane = threadIdx.x & 63, g0 = lane & ~7, p = lane & 7;
-  for (uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < rounded; gid += (uint64_t)gridDim.x * blockDim.x) {
+  for (uint64_t gid = xcd_block(xcd) * blockDim.x + threadIdx.x; gid < rounded; gid += (uint64_t)gridDim.x * blockDim.x) {
     const bool in = gid < total;
     const uint64_t i = in ? gid >> 3 : 0;
     const uint8_t f = in ? flags[i] : (uint8_t)2;
@@ -1446,7 +1455,8 @@ static int build_fine_dict(shn_ctx* ctx, const shn_table* t, const uint8_t* d_fl
   hipError_t e = lines ? hipSuccess : shn_dev_malloc(&lines, n_lines * 128);
   if (e == hipSuccess) e = hipMemsetAsync(lines, 0, n_lines * 128, s);
   if (e != hipSuccess) { if (lines && !room) shn_dev_free(lines); return shn_fail(SHN_ERR_HIP, std::string("build_fine_dict: ") + hipGetErrorString(e)); }
-  if (n) hipLaunchKernelGGL(fd_build_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, shn_tab_idx(t), d_flags, n, lines, n_lines - FD_HOPS);
+  static const int xcd_map = !(getenv("SHN_XCD_MAP") && getenv("SHN_XCD_MAP")[0] == '0');
+  if (n) hipLaunchKernelGGL(fd_build_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, shn_tab_idx(t), d_flags, n, lines, n_lines - FD_HOPS, xcd_map);
   *lines_out = lines; *n_lines_out = n_lines - FD_HOPS;          // (the look-ups hash into all but the spare lines at the end)
   return SHN_OK;
 }
@@ -1545,7 +1555,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       { int rca = build_fine_dict(ctx, t, e->d_flags, &lines, &n_lines, e->d_claim); if (rca) { shn_ext_destroy(e); return rca; } }
       { TimerRegion ta(ctx, T_EXT_ADJ);                  // (one launch: bench.py's roofline entry for this kernel)
         hipLaunchKernelGGL(ext_records_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, shn_tab_idx(t),
-                           e->d_flags, e->d_weight, n, t->k, t->canonical, e->d_rec, (const unsigned long long*)lines, n_lines); }
+                           e->d_flags, e->d_weight, n, t->k, t->canonical, e->d_rec, (const unsigned long long*)lines, n_lines,
+                           (getenv("SHN_XCD_MAP") && getenv("SHN_XCD_MAP")[0] == '0') ? 0 : 1); }
       (void)lines;                                       // (lives in the claims' block: overwritten when the claims are initialised below)
     }
     TRYE(hipGetLastError());
