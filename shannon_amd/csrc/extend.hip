@@ -184,6 +184,9 @@ __device__ __forceinline__ uint64_t fd_line_in_bucket(const TabIdx& T, uint32_t 
 // goes through the table in order -- consecutive blocks on consecutive k1-mers, whose dictionary look-ups fall into the same few
 // lines -- therefore spreads every stretch of lines over eight L2s.  With this block number instead of blockIdx.x the blocks that
 // share an XCD are consecutive: each XCD works through one contiguous eighth of the launch.  (Speed only; any mapping is correct.)
+// MEASURED at BASELINE configs[2] (round 5, two boxes-worth of A/B on one box): ext_records_kernel 110 -> 119-120 ms WITH the
+// mapping -- the spread over all eight L2s (and the shared infinity cache behind them) serves the look-ups better than one L2 per
+// stretch; SHN_XCD_MAP=1 switches it on, the default is the plain order.
 __device__ __forceinline__ uint64_t xcd_block(int on) {
   const uint32_t g8 = gridDim.x & ~7u;
   if (!on || blockIdx.x >= g8) return blockIdx.x;
@@ -1455,7 +1458,7 @@ static int build_fine_dict(shn_ctx* ctx, const shn_table* t, const uint8_t* d_fl
   hipError_t e = lines ? hipSuccess : shn_dev_malloc(&lines, n_lines * 128);
   if (e == hipSuccess) e = hipMemsetAsync(lines, 0, n_lines * 128, s);
   if (e != hipSuccess) { if (lines && !room) shn_dev_free(lines); return shn_fail(SHN_ERR_HIP, std::string("build_fine_dict: ") + hipGetErrorString(e)); }
-  static const int xcd_map = !(getenv("SHN_XCD_MAP") && getenv("SHN_XCD_MAP")[0] == '0');
+  static const int xcd_map = getenv("SHN_XCD_MAP") && getenv("SHN_XCD_MAP")[0] == '1';      // (off: measured below)
   if (n) hipLaunchKernelGGL(fd_build_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, shn_tab_idx(t), d_flags, n, lines, n_lines - FD_HOPS, xcd_map);
   *lines_out = lines; *n_lines_out = n_lines - FD_HOPS;          // (the look-ups hash into all but the spare lines at the end)
   return SHN_OK;
@@ -1556,7 +1559,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       { TimerRegion ta(ctx, T_EXT_ADJ);                  // (one launch: bench.py's roofline entry for this kernel)
         hipLaunchKernelGGL(ext_records_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, shn_tab_idx(t),
                            e->d_flags, e->d_weight, n, t->k, t->canonical, e->d_rec, (const unsigned long long*)lines, n_lines,
-                           (getenv("SHN_XCD_MAP") && getenv("SHN_XCD_MAP")[0] == '0') ? 0 : 1); }
+                           (getenv("SHN_XCD_MAP") && getenv("SHN_XCD_MAP")[0] == '1') ? 1 : 0); }
       (void)lines;                                       // (lives in the claims' block: overwritten when the claims are initialised below)
     }
     TRYE(hipGetLastError());
