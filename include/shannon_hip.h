@@ -156,6 +156,12 @@ int shn_ext_dense_rounds(const shn_ext* e);       /* rounds whose begin / mark p
 int shn_ext_digests(const shn_ext* e, uint64_t* out /* [512] */);
 /* process-wide debug counters: 0 blocks of the caching allocator freed twice, 1 frees of pointers it does not own, 2 (spare)       */
 uint64_t shn_debug_counter(int which);
+/* test hooks of the caching allocator (tests/test_allocator_gpu.py): a block on a context's stream, a fill kernel that can be made
+ * slow, a read-back.  Not part of the path; there so that the stream ordering of freed blocks can be tested from outside.        */
+int shn_debug_alloc(shn_ctx* ctx, uint64_t bytes, void** out);
+void shn_debug_free(shn_ctx* ctx, void* p);
+int shn_debug_fill(shn_ctx* ctx, void* p, uint64_t n_words, uint32_t value, uint32_t spin);
+int shn_debug_read(shn_ctx* ctx, const void* p, uint64_t n_words, uint32_t* host_out);
 /* per walk (host arrays of shn_ext_n_walks entries): right/left extension lengths (n_right ==
  * 0xFFFFFFFF marks a void walk) and the weight sum including the seed (tot_wt, :351)          */
 int shn_ext_stats(shn_ctx* ctx, const shn_ext* e, uint32_t* n_right, uint32_t* n_left, uint64_t* tot_weight);

@@ -115,6 +115,10 @@ SIGNATURES = {
     "shn_ext_fresh_steps": (C.c_uint64, [vp]),
     "shn_ext_digests": (C.c_int, [vp, vp]),
     "shn_debug_counter": (C.c_uint64, [C.c_int]),
+    "shn_debug_alloc": (C.c_int, [vp, C.c_uint64, vpp]),
+    "shn_debug_free": (None, [vp, vp]),
+    "shn_debug_fill": (C.c_int, [vp, vp, C.c_uint64, C.c_uint32, C.c_uint32]),
+    "shn_debug_read": (C.c_int, [vp, vp, C.c_uint64, vp]),
     "shn_extend_sharded": (C.c_int, [vp, vp, C.c_uint32, C.c_int, C.c_int, C.c_int, vpp]),
     "shn_ext_seed_info": (C.c_int, [vp, vp, vp, C.c_uint64, vp, vp]),
     "shn_ext_live_stats": (C.c_int, [vp, vp, u64p, vp, vp, vp, vp]),

@@ -205,6 +205,38 @@ void shn_dev_trim() {
   g_blocks.swap(keep);
 }
 
+// ---- test hooks of the allocator (tests/test_allocator_gpu.py): a block of the caching allocator on a context's stream, and a
+// fill kernel that can be made slow (every thread spins `spin` times before it writes) -- a block freed while such a kernel is
+// queued on one stream and taken at once by another is exactly the hazard the stream ordering above removes
+__global__ void shn_debug_fill_kernel(uint32_t* __restrict__ p, uint64_t n, uint32_t value, uint32_t spin) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t x = (uint32_t)i;
+  for (uint32_t s = 0; s < spin; s++) x = x * 1664525u + 1013904223u;
+  p[i] = value + (x == 0xDEADBEEFu && spin == 0xFFFFFFFFu ? 1u : 0u);       // (x keeps the loop alive)
+}
+extern "C" int shn_debug_alloc(shn_ctx* ctx, uint64_t bytes, void** out) {
+  if (!ctx || !out) return shn_fail(SHN_ERR_ARG, "shn_debug_alloc: NULL argument");
+  SHN_ENTER(ctx);
+  HIP_TRY(shn_dev_malloc_on(out, bytes, ctx->stream));
+  return SHN_OK;
+}
+extern "C" void shn_debug_free(shn_ctx* ctx, void* p) { if (ctx) shn_use_stream(ctx->stream); shn_dev_free(p); }
+extern "C" int shn_debug_fill(shn_ctx* ctx, void* p, uint64_t n_words, uint32_t value, uint32_t spin) {
+  if (!ctx || !p) return shn_fail(SHN_ERR_ARG, "shn_debug_fill: NULL argument");
+  SHN_ENTER(ctx);
+  if (n_words) hipLaunchKernelGGL(shn_debug_fill_kernel, dim3((uint32_t)cdiv(n_words, 256)), dim3(256), 0, ctx->stream, (uint32_t*)p, n_words, value, spin);
+  HIP_TRY(hipGetLastError());
+  return SHN_OK;
+}
+extern "C" int shn_debug_read(shn_ctx* ctx, const void* p, uint64_t n_words, uint32_t* host_out) {
+  if (!ctx || !p || !host_out) return shn_fail(SHN_ERR_ARG, "shn_debug_read: NULL argument");
+  SHN_ENTER(ctx);
+  HIP_TRY(hipMemcpyAsync(host_out, p, n_words * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return SHN_OK;
+}
+
 TimingOff::TimingOff(shn_ctx* ctx) : c(ctx), old(ctx->timing) { c->timing = false; }
 TimingOff::~TimingOff() { c->timing = old; }
 

@@ -1,0 +1,65 @@
+"""GPU: the caching allocator orders the reuse of a freed block behind the stream that may still be writing it (core.hip, round 5).
+The hazard of rounds 1-4 -- a block freed while a kernel is queued on one stream goes to a caller on another stream at once -- is
+reproduced with the old behaviour behind SHN_DEV_LEGACY=1 (in a child process: the switch is read once), so this test FAILS on
+the pre-fix allocator and passes on the current one."""
+import os, subprocess, sys
+import pytest
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+CHILD = r"""
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, %r)
+from shannon_amd import _lib, device
+L = _lib.lib()
+a = device.Context(0)                       # the legacy NULL stream
+fh = C.c_void_p()
+_lib.check(L.shn_ctx_fork(a.h, C.byref(fh)))   # a second context with a (non-blocking) stream of its own
+N = 1 << 22
+bad = 0
+for it in range(6):
+    p = C.c_void_p()
+    _lib.check(L.shn_debug_alloc(a.h, N * 4, C.byref(p)))
+    _lib.check(L.shn_debug_fill(a.h, p, N, 1, 200000))           # slow: tens of milliseconds on stream A
+    L.shn_debug_free(a.h, p)                                      # freed while that kernel is still queued
+    q = C.c_void_p()
+    _lib.check(L.shn_debug_alloc(fh, N * 4, C.byref(q)))           # the same block, for stream B
+    assert q.value == p.value, "the allocator did not hand the freed block on (the test needs it to)"
+    _lib.check(L.shn_debug_fill(fh, q, N, 2, 0))                  # fast fill on stream B
+    out = np.zeros(N, np.uint32)
+    _lib.check(L.shn_debug_read(fh, q, N, out.ctypes.data))
+    a.sync()
+    _lib.check(L.shn_debug_read(fh, q, N, out.ctypes.data))        # after BOTH streams have drained: B's values must have come last
+    bad += int((out != 2).sum())
+    L.shn_debug_free(fh, q)
+print("WRONG_WORDS", bad, "HANDOVERS", int(L.shn_debug_counter(4)), "DOUBLE", int(L.shn_debug_counter(0)))
+p = C.c_void_p()
+_lib.check(L.shn_debug_alloc(a.h, 4096, C.byref(p)))
+L.shn_debug_free(a.h, p)
+L.shn_debug_free(a.h, p)                                          # a second free is reported and counted, the block is not handed out twice
+print("DOUBLE_AFTER", int(L.shn_debug_counter(0)))
+L.shn_ctx_destroy(fh)
+a.close()
+""" % ROOT
+
+
+def _run(**env):
+    p = subprocess.run([sys.executable, "-c", CHILD], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, **env), timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    words = p.stdout.split()
+    return {words[i]: int(words[i + 1]) for i in range(0, len(words), 2)}, p.stderr
+
+
+def test_a_freed_block_is_ordered_behind_the_stream_that_used_it():
+    r, err = _run()
+    assert r["WRONG_WORDS"] == 0 and r["HANDOVERS"] >= 6, r
+    assert r["DOUBLE"] == 0 and r["DOUBLE_AFTER"] == 1 and "freed twice" in err
+
+
+def test_the_allocator_of_rounds_1_to_4_fails_this():
+    """the same sequence on the old allocator (SHN_DEV_LEGACY=1: a freed block goes to the next caller at once): the slow kernel of
+    stream A lands on top of stream B's values"""
+    r, _err = _run(SHN_DEV_LEGACY="1")
+    assert r["WRONG_WORDS"] > 0, r
