@@ -37,12 +37,57 @@ __global__ void pg_unique_kernel(const uint64_t* __restrict__ keys, const uint32
                                  uint64_t* __restrict__ ukeys, uint32_t* __restrict__ uvals) {
   PG_FOR(i, n) if (head[i]) { ukeys[hpos[i]] = keys[i]; uvals[hpos[i]] = part_of[cid[vals[i]]] + 1; }    // set p = {p}; multi ones are patched
 }
-// the windows of the k1-mers that occur in several partitions: (unique index, partition) per window, for the host
+// number of different partitions among the windows of the run that starts at i (they come in ascending partition order: the sort
+// is stable and the contigs were laid out partition by partition); the first two in p1 / p2
+__device__ __forceinline__ uint32_t pg_run_parts(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ cid,
+                                                 const uint32_t* __restrict__ part_of, uint64_t n, uint64_t i, uint32_t& p1, uint32_t& p2) {
+  uint32_t nd = 0, last = 0xFFFFFFFFu;
+  for (uint64_t e = i; e < n && keys[e] == keys[i]; e++) {
+    const uint32_t p = part_of[cid[vals[e]]];
+    if (p == last) continue;
+    if (nd == 0) p1 = p; else if (nd == 1) p2 = p;
+    nd++; last = p;
+  }
+  return nd;
+}
+// the k1-mers that occur in exactly TWO partitions -- every k1-mer of a component that went through gpmetis lies in its partition
+// of the first run and in its partition of the second (kmers_for_component.py:244-305): at `bench.py --config 2p` that is all 54 M
+// of them, and interning their sets on the host (a sort of 108 M windows and a map look-up per k1-mer) took 7 s of a step.  Their
+// sets are pairs: (pair, unique index) here, sorted by pair on the device, one set id per run of equal pairs.
+__global__ void pg_pair_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ cid,
+                               const uint32_t* __restrict__ part_of, const uint32_t* __restrict__ multi, const uint64_t* __restrict__ hpos,
+                               uint64_t n, unsigned long long* __restrict__ n_out, uint64_t* __restrict__ o_pair, uint32_t* __restrict__ o_uidx) {
+  PG_FOR(i, n) {
+    if (!multi[i]) continue;
+    uint32_t p1 = 0, p2 = 0;
+    if (pg_run_parts(keys, vals, cid, part_of, n, i, p1, p2) != 2) continue;
+    const unsigned long long at = atomicAdd(n_out, 1ULL);
+    o_pair[at] = ((uint64_t)p1 << 32) | p2;
+    o_uidx[at] = (uint32_t)hpos[i];
+  }
+}
+__global__ void pg_pair_head_kernel(const uint64_t* __restrict__ pairs, uint64_t n, uint32_t* __restrict__ head) {
+  PG_FOR(i, n) head[i] = (i == 0 || pairs[i] != pairs[i - 1]) ? 1u : 0u;
+}
+// value of every such k1-mer = id of its pair's set + 1; the distinct pairs, in order, for the host
+__global__ void pg_pair_patch_kernel(const uint64_t* __restrict__ pairs, const uint32_t* __restrict__ uidx, const uint32_t* __restrict__ head,
+                                     const uint64_t* __restrict__ pos, uint64_t n, uint32_t first_sid, uint32_t* __restrict__ uvals,
+                                     uint64_t* __restrict__ distinct) {
+  PG_FOR(i, n) {
+    const uint64_t run = pos[i] - (head[i] ? 0 : 1);
+    uvals[uidx[i]] = first_sid + (uint32_t)run + 1;
+    if (head[i]) distinct[run] = pairs[i];
+  }
+}
+// the windows of the k1-mers that occur in three or more partitions (none in the reference's flow: a contig is in one partition per
+// gpmetis run): (unique index, partition) per window, for the host
 __global__ void pg_multi_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ cid,
                                 const uint32_t* __restrict__ part_of, const uint32_t* __restrict__ multi, const uint64_t* __restrict__ hpos,
                                 uint64_t n, unsigned long long* __restrict__ n_out, uint64_t cap, uint32_t* __restrict__ o_uidx, uint32_t* __restrict__ o_part) {
   PG_FOR(i, n) {
     if (!multi[i]) continue;
+    uint32_t p1 = 0, p2 = 0;
+    if (pg_run_parts(keys, vals, cid, part_of, n, i, p1, p2) < 3) continue;
     for (uint64_t e = i; e < n && keys[e] == keys[i]; e++) {
       const unsigned long long at = atomicAdd(n_out, 1ULL);
       if (at < cap) { o_uidx[at] = (uint32_t)hpos[i]; o_part[at] = part_of[cid[vals[e]]]; }
@@ -104,9 +149,38 @@ extern "C" int shn_probe_build(shn_ctx* ctx, const uint8_t* bases, const uint64_
       if ((rc = shn_device_scan_u32(ctx, d_head, nv, d_hpos, &nu))) return rc;
       HIP_TRY(B.get(&ukeys, (nu + 1) * 8)); HIP_TRY(B.get(&uvals, (nu + 1) * 4));
       hipLaunchKernelGGL(pg_unique_kernel, dim3(pg_grid(nv)), dim3(PG_BLK), 0, s, keys, vals, d_cid, d_part, d_head, d_hpos, nv, ukeys, uvals);
-      // k1-mers of several partitions: their windows to the host, which interns the sets
       unsigned long long* d_nm; uint32_t *d_mu = nullptr, *d_mp = nullptr;
       HIP_TRY(B.get(&d_nm, 8));
+      // k1-mers of exactly two partitions: their sets are interned on the device (pg_pair_kernel)
+      {
+        uint64_t *d_pair, *d_pair2, *d_ppos, *d_dist; uint32_t *d_pu, *d_pu2, *d_phead;
+        HIP_TRY(B.get(&d_pair, (nu + 1) * 8)); HIP_TRY(B.get(&d_pair2, (nu + 1) * 8)); HIP_TRY(B.get(&d_pu, (nu + 1) * 4)); HIP_TRY(B.get(&d_pu2, (nu + 1) * 4));
+        HIP_TRY(hipMemsetAsync(d_nm, 0, 8, s));
+        hipLaunchKernelGGL(pg_pair_kernel, dim3(pg_grid(nv)), dim3(PG_BLK), 0, s, keys, vals, d_cid, d_part, d_multi, d_hpos, nv, d_nm, d_pair, d_pu);
+        unsigned long long n_pair = 0;
+        HIP_TRY(hipMemcpyAsync(&n_pair, d_nm, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (n_pair) {
+          int pbits = 1;
+          while ((1ULL << pbits) < (uint64_t)n_parts) pbits++;
+          if ((rc = shn_sort_pairs(ctx, d_pair, d_pu, d_pair2, d_pu2, n_pair, 0, 32 + pbits))) return rc;
+          HIP_TRY(B.get(&d_phead, (n_pair + 1) * 4)); HIP_TRY(B.get(&d_ppos, (n_pair + 2) * 8));
+          hipLaunchKernelGGL(pg_pair_head_kernel, dim3(pg_grid(n_pair)), dim3(PG_BLK), 0, s, d_pair, (uint64_t)n_pair, d_phead);
+          uint64_t n_dist = 0;
+          if ((rc = shn_device_scan_u32(ctx, d_phead, n_pair, d_ppos, &n_dist))) return rc;
+          HIP_TRY(B.get(&d_dist, (n_dist + 1) * 8));
+          const uint32_t first_sid = (uint32_t)(P->set_off.size() - 1);
+          hipLaunchKernelGGL(pg_pair_patch_kernel, dim3(pg_grid(n_pair)), dim3(PG_BLK), 0, s, d_pair, d_pu, d_phead, d_ppos, (uint64_t)n_pair, first_sid, uvals, d_dist);
+          std::vector<uint64_t> dist(n_dist);
+          HIP_TRY(hipMemcpyAsync(dist.data(), d_dist, n_dist * 8, hipMemcpyDeviceToHost, s));
+          HIP_TRY(hipStreamSynchronize(s));
+          for (uint64_t pr : dist) {
+            P->set_mem.push_back((uint32_t)(pr >> 32)); P->set_mem.push_back((uint32_t)pr);
+            P->set_off.push_back((uint32_t)P->set_mem.size());
+          }
+        }
+      }
+      // k1-mers of three or more partitions: their windows to the host, which interns the sets
       uint64_t cap = 1 << 16;
       unsigned long long nm = 0;
       while (true) {

@@ -185,7 +185,9 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
         import threading
         n_routed = {nm: len(part["routes"][nm]) for nm in names}
         big_cut = max(n_routed.values()) // 4 if names else 0
-        big = set(nm for nm in names if n_routed[nm] >= max(1, big_cut)) if sflow_beside else set()
+        # (at most four: when the partitions are of one size -- a component cut by gpmetis into a hundred parts -- "a quarter of the
+        # largest" holds for all of them, and four hundred calls of their own were 225,000 tiny LP batches per step at --config 2p)
+        big = set(sorted((nm for nm in names if n_routed[nm] >= max(1, big_cut)), key=lambda nm: -n_routed[nm])[:4]) if sflow_beside else set()
         small_lock, small_done, small_recs = threading.Lock(), [0], {}
         n_small = len(names) - len(big)
         # ... and the merge takes every text as a piece the moment it exists (post.PostStream: lines, upload, fingerprints beside the

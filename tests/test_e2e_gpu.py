@@ -321,7 +321,7 @@ def test_own_partitioner_through_the_pipeline(ctx):
     assert R.final == O["final"] and len(R.final) >= 40
 
 
-def test_repeat_linked_genes_through_the_partitioner(ctx):
+def test_repeat_linked_genes_through_the_partitioner(ctx, monkeypatch):
     """the input shape of `bench.py --config 2p` at test size: 70 genes linked by three shared repeats (synth.make_repeat_family)
     give contig components far above --partition; they are cut by the library's partitioner (shn_partition_metis, twice:
     kmers_for_component.py:207-237) -- the same vectors as its Python mirror -- and the oracle pipeline given exactly those vectors
@@ -334,6 +334,7 @@ def test_repeat_linked_genes_through_the_partitioner(ctx):
     A = np.frombuffer(b"ACGT", np.uint8)
     s1, s2 = [A[r].tobytes().decode() for r in r1], [A[r].tobytes().decode() for r in r2]
     psize = 20
+    monkeypatch.setenv("SHN_PROBE_GPU", "1")        # k1mers2component on the device: every k1-mer of these components lies in two partitions (pg_pair_kernel)
     R = pipeline.assemble(ctx, s1, s2, K=25, partition_size=psize, sample="s", seed=3)
     big = R.extension.big_components
     assert big and max(len(c) for c, _m in big) >= 110, [len(c) for c, _m in big]
