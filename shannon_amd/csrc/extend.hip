@@ -1056,7 +1056,7 @@ __global__ void ext_audit_kernel(WalkArgs A, uint64_t ns, unsigned long long* __
 }
 
 // classify the dirty walks of the open block: long ones (memo or recorded length) go to the wavefront kernel,
-// the others to the thread kernel.  counters: [0] long [1] unused [2] short [3] dirty walks
+// the others to the thread kernel.  counters: [0] long [1] dirty walks that hold claims [2] short [3] dirty walks
 __global__ __launch_bounds__(1024) void ext_plan_kernel(uint32_t* nr, uint32_t* nl, uint64_t ns, uint32_t frozen,
                                 const uint8_t* __restrict__ mvalid, const uint32_t* __restrict__ mR, const uint32_t* __restrict__ mL,
                                 const uint8_t* __restrict__ dirty, uint32_t* __restrict__ long_list, uint32_t* __restrict__ short_list,
@@ -1084,12 +1084,12 @@ __global__ __launch_bounds__(1024) void ext_plan_kernel(uint32_t* nr, uint32_t* 
   }
   // one atomic per block of 1024 and list (one per wavefront on three single addresses was 39 us per launch)
   __shared__ uint32_t wl[16], wsh[16];
-  __shared__ unsigned long long bl, bs, bd;
+  __shared__ unsigned long long bl, bs, bd, bh;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const unsigned long long below = (1ULL << lane) - 1ULL;
   const unsigned long long lm = __ballot(isd && lg), sm = __ballot(isd && !lg);
   if (lane == 0) { wl[wid] = (uint32_t)__popcll(lm); wsh[wid] = (uint32_t)__popcll(sm); }
-  if (threadIdx.x == 0) bd = 0;
+  if (threadIdx.x == 0) { bd = 0; bh = 0; }
   __syncthreads();
   if (threadIdx.x == 0) {
     uint32_t tl = 0, ts = 0;
@@ -1101,9 +1101,13 @@ __global__ __launch_bounds__(1024) void ext_plan_kernel(uint32_t* nr, uint32_t* 
   {                                                                // dirty walks, the ones settled above included (they "ran")
     const unsigned long long dm = __ballot(isd_all);
     if (lane == 0 && dm) atomicAdd(&bd, (unsigned long long)__popcll(dm));
+    // ... of them the ones that hold claims (a record of a live walk): with none, the round's begin pass has nothing to release
+    const unsigned long long hm = __ballot(isd_all && nr[r] != UNCLAIMED);
+    if (lane == 0 && hm) atomicAdd(&bh, (unsigned long long)__popcll(hm));
   }
   __syncthreads();
   if (threadIdx.x == 0 && bd) atomicAdd(&counters[3], bd);
+  if (threadIdx.x == 0 && bh) atomicAdd(&counters[1], bh);
   __syncthreads();
   uint32_t ol = 0, os = 0;
   for (int w = 0; w < wid; w++) { ol += wl[w]; os += wsh[w]; }
@@ -1693,6 +1697,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   // bulk rounds: a thread walker that gets this far hands its walk to the packed second launch (0: it walks to the end itself, as until round 4)
   const uint32_t bulk_promote = tune("SHN_EXT_PROMOTE_BULK", 0);      // (measured at BASELINE configs[2], round 5: 8 / 24 / 64 -> walk kernels 273 / 267 / 268 ms per step against 224 without -- the bulk rounds are bound by the random fetches of their steps, not by idle lanes; off)
   const unsigned long long resume_waves = tune("SHN_EXT_RESUME_WAVES", 8192);
+  const bool skip_idle_begin = tune("SHN_EXT_SKIP_IDLE_BEGIN", 1) != 0;
+  int n_begin_skipped = 0;
   const bool prepass = tune("SHN_EXT_PREPASS", 1) != 0;
   const uint32_t fresh_split = std::max<uint32_t>(1, std::min<uint32_t>(16, tune("SHN_EXT_FRESH_SPLIT", 1)));   // sub-launches of a block's first (bulk) round (measured at configs[2]: 1 / 4 / 7 / 10 -> 184 / 176 / 209 / 248 ms: every sub-launch waits for its longest walk; off)
   const uint32_t fresh_split_min = tune("SHN_EXT_FRESH_SPLIT_MIN", 65536);                                       // ... of blocks of at least this many walks            // a block's first round settles the walks whose seed an earlier block holds (ext_plan_kernel)
@@ -1757,7 +1763,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     TimerRegion t3(ctx, T_EXT_WALK);
     // snapshot, then release the claims of the walks that re-run this round
     // (a block that has just opened holds no claims yet: with the snapshot up to date there is nothing to release and nothing to copy)
-    if (fresh_block && precise_marks && snap_current) { TRYE(hipMemsetAsync(d_cnt + 6, 0, 16, s)); TRYE(hipMemsetAsync(d_cnt + 13, 0, 16, s)); }
+    // (... and so does a round none of whose dirty walks holds a claim -- void walks looking at their seed again: plan[1])
+    if ((fresh_block || (plan[1] == 0 && skip_idle_begin)) && precise_marks && snap_current) { TRYE(hipMemsetAsync(d_cnt + 6, 0, 16, s)); TRYE(hipMemsetAsync(d_cnt + 13, 0, 16, s)); n_begin_skipped += fresh_block ? 0 : 1; }
     else {
       TimerRegion tb(ctx, T_EXT_BEGIN);
       hipLaunchKernelGGL(ext_round_begin_kernel, dim3((uint32_t)cdiv(cdiv(2 * n, 4), 256)), dim3(256), 0, s, claim, snap, 2 * n, dirty, (uint64_t)ns, d_cnt,
@@ -1824,7 +1831,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       unsigned long long st = 0, lw = 0; TRYE(hipMemcpyAsync(&st, d_cnt + 1, 8, hipMemcpyDeviceToHost, s));
       if (A.dbg) { TRYE(hipMemcpyAsync(&lw, d_cnt + 44, 8, hipMemcpyDeviceToHost, s)); TRYE(hipMemsetAsync(d_cnt + 44, 0, 8, s)); }
       TRYE(hipStreamSynchronize(s));
-      fprintf(stderr, "[shn_extend] XTIME round %d: thread walker %llu walks, %.2f ms, steps so far %llu; longest walk %llu steps in %.2f ms (%.2f us per step)\n", it + 1, plan[2],
+      fprintf(stderr, "[shn_extend] XTIME round %d: %llu dirty walks, %llu of them hold claims (begin passes skipped so far: %d); thread walker %llu walks, %.2f ms, steps so far %llu; longest walk %llu steps in %.2f ms (%.2f us per step)\n", it + 1, plan[3], plan[1], n_begin_skipped, plan[2],
               ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6 - x_t0, st, lw >> 32, (double)(lw & 0xFFFFFFFFULL) * 1e-5, (lw >> 32) ? (double)(lw & 0xFFFFFFFFULL) * 1e-2 / (double)(lw >> 32) : 0.0);
     }
     if (plan[2] && bulk) {                      // ... of a bulk round: packed, a lane per walk, lanes refilled from the list (ext_walk_resume_kernel)
