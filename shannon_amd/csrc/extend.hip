@@ -1056,7 +1056,7 @@ __global__ void ext_audit_kernel(WalkArgs A, uint64_t ns, unsigned long long* __
 }
 
 // classify the dirty walks of the open block: long ones (memo or recorded length) go to the wavefront kernel,
-// the others to the thread kernel.  counters: [0] long [1] dirty walks that hold claims [2] short [3] dirty walks
+// the others to the thread kernel.  counters: [0] long [1] dirty walks that hold claims and have no current memo [2] short [3] dirty walks
 __global__ __launch_bounds__(1024) void ext_plan_kernel(uint32_t* nr, uint32_t* nl, uint64_t ns, uint32_t frozen,
                                 const uint8_t* __restrict__ mvalid, const uint32_t* __restrict__ mR, const uint32_t* __restrict__ mL,
                                 const uint8_t* __restrict__ dirty, uint32_t* __restrict__ long_list, uint32_t* __restrict__ short_list,
@@ -1102,7 +1102,9 @@ __global__ __launch_bounds__(1024) void ext_plan_kernel(uint32_t* nr, uint32_t* 
     const unsigned long long dm = __ballot(isd_all);
     if (lane == 0 && dm) atomicAdd(&bd, (unsigned long long)__popcll(dm));
     // ... of them the ones that hold claims (a record of a live walk): with none, the round's begin pass has nothing to release
-    const unsigned long long hm = __ballot(isd_all && nr[r] != UNCLAIMED);
+    // (counted: the holders WITHOUT a current memo -- with none of those, the dirty walks release their claims themselves, from
+    // their memos: ext_release_memo_kernel)
+    const unsigned long long hm = __ballot(isd_all && nr[r] != UNCLAIMED && mvalid[r] != 2);
     if (lane == 0 && hm) atomicAdd(&bh, (unsigned long long)__popcll(hm));
   }
   __syncthreads();
@@ -1137,11 +1139,33 @@ __global__ void ext_memo_plan_kernel(uint8_t* __restrict__ ran, uint8_t* __restr
       if (off + cap + 64 <= pool_cap) {
         pool[off] = MEMO_MARK; pool[off + 1] = R | MEMO_HI; pool[off + 2] = order[r];
         pool[off + 3 + R] = MEMO_MARK; pool[off + 4 + R + L] = MEMO_MARK;
-        moff[r] = off; mR[r] = R; mL[r] = L; mvalid[r] = 1; f = 1;
+        moff[r] = off; mR[r] = R; mL[r] = L; mvalid[r] = 2; f = 1;     // 2: the memo holds exactly the walk's claims (until it runs again)
       }
     }
   }
+  if (did_run && !f && mvalid[r]) mvalid[r] = 1;     // ran without a new slot (a bulk round, a full pool, void now): the old memo is a hint only
   fill[r] = f;
+}
+
+// The release of a round that re-runs few walks, all of which have a current memo (the path of their last run, written from the
+// claims by the mark pass of the round they ran in; they have not run since): a wavefront per dirty walk goes through its memo and
+// gives back what the walk still owns.  The begin pass below streams all 11.6 GB of claims of BASELINE configs[2] to find those
+// few thousand k1-mers -- 2.7 ms a round, half of the rounds of a step re-run fewer than 10,000 walks.
+__global__ __launch_bounds__(64) void ext_release_memo_kernel(const uint32_t* __restrict__ long_list, uint64_t n_long, const uint32_t* __restrict__ short_list,
+                                                              uint64_t n_short, const uint32_t* __restrict__ nr, const uint64_t* __restrict__ moff,
+                                                              const uint32_t* __restrict__ mR, const uint32_t* __restrict__ mL, const uint32_t* __restrict__ pool,
+                                                              u64* claim, uint8_t* __restrict__ chunk) {
+  const uint64_t idx = blockIdx.x;
+  if (idx >= n_long + n_short) return;
+  const uint32_t r = idx < n_long ? long_list[idx] : short_list[idx - n_long];
+  if (nr[r] == UNCLAIMED) return;                                        // void: it holds nothing
+  const uint64_t off = moff[r];
+  const uint32_t R = mR[r], L = mL[r];
+  for (uint32_t j = threadIdx.x; j <= R + L; j += 64) {
+    const uint32_t node = pool[off + (j <= R ? 2 : 3) + j];
+    if (node & 0x80000000u) continue;                                    // a step that was robbed before the memo was written
+    if (atomicCAS(&claim[node], CLAIM(r, j), UNCLAIMED64) == CLAIM(r, j) && chunk) chunk[node >> CHUNK_SHIFT] = 1;
+  }
 }
 
 // start of a round: snapshot the claims, drop the claims of the walks that are about to re-run, clear the round's counters
@@ -1697,7 +1721,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   // bulk rounds: a thread walker that gets this far hands its walk to the packed second launch (0: it walks to the end itself, as until round 4)
   const uint32_t bulk_promote = tune("SHN_EXT_PROMOTE_BULK", 0);      // (measured at BASELINE configs[2], round 5: 8 / 24 / 64 -> walk kernels 273 / 267 / 268 ms per step against 224 without -- the bulk rounds are bound by the random fetches of their steps, not by idle lanes; off)
   const unsigned long long resume_waves = tune("SHN_EXT_RESUME_WAVES", 8192);
-  const bool skip_idle_begin = tune("SHN_EXT_SKIP_IDLE_BEGIN", 1) != 0;
+  const bool skip_idle_begin = tune("SHN_EXT_MEMO_RELEASE", 1) != 0;          // rounds whose dirty walks all have a current memo release through it (ext_release_memo_kernel)
+  const unsigned long long memo_release_max = tune("SHN_EXT_MEMO_RELEASE_MAX", 65536);
   int n_begin_skipped = 0;
   const bool prepass = tune("SHN_EXT_PREPASS", 1) != 0;
   const uint32_t fresh_split = std::max<uint32_t>(1, std::min<uint32_t>(16, tune("SHN_EXT_FRESH_SPLIT", 1)));   // sub-launches of a block's first (bulk) round (measured at configs[2]: 1 / 4 / 7 / 10 -> 184 / 176 / 209 / 248 ms: every sub-launch waits for its longest walk; off)
@@ -1764,7 +1789,16 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     // snapshot, then release the claims of the walks that re-run this round
     // (a block that has just opened holds no claims yet: with the snapshot up to date there is nothing to release and nothing to copy)
     // (... and so does a round none of whose dirty walks holds a claim -- void walks looking at their seed again: plan[1])
-    if ((fresh_block || (plan[1] == 0 && skip_idle_begin)) && precise_marks && snap_current) { TRYE(hipMemsetAsync(d_cnt + 6, 0, 16, s)); TRYE(hipMemsetAsync(d_cnt + 13, 0, 16, s)); n_begin_skipped += fresh_block ? 0 : 1; }
+    const bool memo_release = !fresh_block && !dense && skip_idle_begin && plan[1] == 0 && plan[0] + plan[2] <= memo_release_max;
+    if ((fresh_block || memo_release) && precise_marks && snap_current) {
+      TRYE(hipMemsetAsync(d_cnt + 6, 0, 16, s)); TRYE(hipMemsetAsync(d_cnt + 13, 0, 16, s));
+      if (!fresh_block) {
+        n_begin_skipped++;
+        if (plan[0] + plan[2])
+          hipLaunchKernelGGL(ext_release_memo_kernel, dim3((uint32_t)(plan[0] + plan[2])), dim3(64), 0, s, long_list, (uint64_t)plan[0], short_list, (uint64_t)plan[2],
+                             e->d_nr, moff, mR, mL, pool, claim, chunk);
+      }
+    }
     else {
       TimerRegion tb(ctx, T_EXT_BEGIN);
       hipLaunchKernelGGL(ext_round_begin_kernel, dim3((uint32_t)cdiv(cdiv(2 * n, 4), 256)), dim3(256), 0, s, claim, snap, 2 * n, dirty, (uint64_t)ns, d_cnt,
@@ -1831,7 +1865,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       unsigned long long st = 0, lw = 0; TRYE(hipMemcpyAsync(&st, d_cnt + 1, 8, hipMemcpyDeviceToHost, s));
       if (A.dbg) { TRYE(hipMemcpyAsync(&lw, d_cnt + 44, 8, hipMemcpyDeviceToHost, s)); TRYE(hipMemsetAsync(d_cnt + 44, 0, 8, s)); }
       TRYE(hipStreamSynchronize(s));
-      fprintf(stderr, "[shn_extend] XTIME round %d: %llu dirty walks, %llu of them hold claims (begin passes skipped so far: %d); thread walker %llu walks, %.2f ms, steps so far %llu; longest walk %llu steps in %.2f ms (%.2f us per step)\n", it + 1, plan[3], plan[1], n_begin_skipped, plan[2],
+      fprintf(stderr, "[shn_extend] XTIME round %d: %llu dirty walks, %llu of them hold claims without a current memo (rounds released through memos so far: %d); thread walker %llu walks, %.2f ms, steps so far %llu; longest walk %llu steps in %.2f ms (%.2f us per step)\n", it + 1, plan[3], plan[1], n_begin_skipped, plan[2],
               ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6 - x_t0, st, lw >> 32, (double)(lw & 0xFFFFFFFFULL) * 1e-5, (lw >> 32) ? (double)(lw & 0xFFFFFFFFULL) * 1e-2 / (double)(lw >> 32) : 0.0);
     }
     if (plan[2] && bulk) {                      // ... of a bulk round: packed, a lane per walk, lanes refilled from the list (ext_walk_resume_kernel)
