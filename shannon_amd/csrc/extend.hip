@@ -492,6 +492,7 @@ struct WalkArgs {
   uint8_t* chunk;        // per 2^CHUNK_SHIFT oriented k1-mers: "a claim in here was written this round" (the mark pass visits only those)
   uint8_t* robbed;       // per walk: a claim of its record is not (or no longer) its own -- see note_claim
   int seed_check;        // thread walkers: look at the own seed's claim on every step and stop when a lower rank has taken it
+  int first_look;        // thread walkers: a direction starts with a look at the candidates' claims alone
 };
 
 // Claim `node` as step `pos` of walk r: atomic min on rank:pos.  Returns what stood there before; the caller hands it to note_claim
@@ -585,6 +586,21 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
         const RowView adj = dir == 0 ? A.adjR : A.adjL;
         uint32_t steps = 0;
         Adj4 cand = adj[o];
+        // Most walks cannot take a single step (98.6 % of the walks of BASELINE configs[2] are swallowed by a heavier neighbour): such a
+        // walk finds that out from its candidates' CLAIMS alone -- up to four lines -- instead of their claims, weights and rows (eight);
+        // a bulk launch's time follows the lines its walks touch before they stop (HISTORY.md, Round 5).  A direction with a free
+        // candidate goes into the loop as before (its claims are in the L2 by then).
+        if (A.first_look) {
+          bool any = false;
+#pragma unroll
+          for (int b = 0; b < 4; b++)
+            if (cand.v[b] >= 0) {
+              const u64 c0 = __hip_atomic_load(&A.claim[cand.v[b]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const u64 f0 = FRESH ? UNCLAIMED64 : snap[cand.v[b]];
+              any |= RANK(c0) > r && RANK(f0) >= r;
+            }
+          if (!any) continue;                      // (no step in this direction: nr / nl stay 0)
+        }
         while (true) {
           u64 cl[4], cf[4];
           uint32_t w[4];
@@ -1718,6 +1734,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   const unsigned long long bulk_min = getenv("SHN_EXT_BULK") ? strtoull(getenv("SHN_EXT_BULK"), nullptr, 10) : 262144ULL;
   const unsigned long long dense_min = getenv("SHN_EXT_DENSE") ? strtoull(getenv("SHN_EXT_DENSE"), nullptr, 10) : (4ULL << 20);   // (BASELINE configs[2]: 262144 -> 954 ms, 2 M or 16 M -> 900 ms per extension)
   const int seed_check = (int)tune("SHN_EXT_SEEDCHECK", 1);
+  const int first_look = (int)tune("SHN_EXT_FIRST_LOOK", 1);
   // bulk rounds: a thread walker that gets this far hands its walk to the packed second launch (0: it walks to the end itself, as until round 4)
   const uint32_t bulk_promote = tune("SHN_EXT_PROMOTE_BULK", 0);      // (measured at BASELINE configs[2], round 5: 8 / 24 / 64 -> walk kernels 273 / 267 / 268 ms per step against 224 without -- the bulk rounds are bound by the random fetches of their steps, not by idle lanes; off)
   const unsigned long long resume_waves = tune("SHN_EXT_RESUME_WAVES", 8192);
@@ -1815,6 +1832,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     A.chunk = dense ? nullptr : chunk;         // (dense rounds write nearly everywhere: their mark pass is dense, the walkers do not flag)
     A.robbed = robbed;
     A.seed_check = seed_check;
+    A.first_look = first_look;
     A.steps_counter = d_cnt + 1; A.fresh_steps_counter = d_cnt + 16; A.wave_steps_counter = d_cnt + 64; A.dbg = (getenv("SHN_DEBUG") || getenv("SHN_EXT_XTIME")) ? d_cnt + 32 : nullptr;
     // long (wave per walk) and short (thread per walk) kernels are independent: overlap them on two streams
     if (plan[0]) {
