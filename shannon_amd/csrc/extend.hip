@@ -586,10 +586,8 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
         const RowView adj = dir == 0 ? A.adjR : A.adjL;
         uint32_t steps = 0;
         Adj4 cand = adj[o];
-        // Most walks cannot take a single step (98.6 % of the walks of BASELINE configs[2] are swallowed by a heavier neighbour): such a
-        // walk finds that out from its candidates' CLAIMS alone -- up to four lines -- instead of their claims, weights and rows (eight);
-        // a bulk launch's time follows the lines its walks touch before they stop (HISTORY.md, Round 5).  A direction with a free
-        // candidate goes into the loop as before (its claims are in the L2 by then).
+        // SHN_EXT_FIRST_LOOK=1 (experiment, off): a walk that cannot take a single step finds that out from its candidates' CLAIMS alone
+        // -- up to four lines -- instead of their claims, weights and rows (eight).  No gain at BASELINE configs[2] (HISTORY.md, Round 5).
         if (A.first_look) {
           bool any = false;
 #pragma unroll
@@ -1734,7 +1732,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   const unsigned long long bulk_min = getenv("SHN_EXT_BULK") ? strtoull(getenv("SHN_EXT_BULK"), nullptr, 10) : 262144ULL;
   const unsigned long long dense_min = getenv("SHN_EXT_DENSE") ? strtoull(getenv("SHN_EXT_DENSE"), nullptr, 10) : (4ULL << 20);   // (BASELINE configs[2]: 262144 -> 954 ms, 2 M or 16 M -> 900 ms per extension)
   const int seed_check = (int)tune("SHN_EXT_SEEDCHECK", 1);
-  const int first_look = (int)tune("SHN_EXT_FIRST_LOOK", 1);
+  const int first_look = (int)tune("SHN_EXT_FIRST_LOOK", 0);      // (measured at configs[2]: first-round launches 172-174 ms with it, 163-170 without: off)
   // bulk rounds: a thread walker that gets this far hands its walk to the packed second launch (0: it walks to the end itself, as until round 4)
   const uint32_t bulk_promote = tune("SHN_EXT_PROMOTE_BULK", 0);      // (measured at BASELINE configs[2], round 5: 8 / 24 / 64 -> walk kernels 273 / 267 / 268 ms per step against 224 without -- the bulk rounds are bound by the random fetches of their steps, not by idle lanes; off)
   const unsigned long long resume_waves = tune("SHN_EXT_RESUME_WAVES", 8192);
