@@ -131,6 +131,45 @@ class FinalTranscripts(object):
     def __init__(self, names, name_off, seqs, seq_off):
         self._n, self._no, self._s, self._so = names, name_off, seqs, seq_off
         self._index = None
+        self._dedupe()
+
+    def _dedupe(self):
+        """dict semantics for a name that occurs twice (faster_reps.py:103-131 keeps its records in a dict keyed by the first token of
+        the header: a later record of the same name replaces the sequence, the name keeps its first place): the records are reduced
+        to one per name.  Names are unique in every run seen so far -- a vectorised hash says so in a millisecond; only a repeated
+        hash takes the exact path."""
+        import numpy as np
+        n = len(self._no) - 1
+        if n < 2:
+            return
+        no = np.asarray(self._no, dtype=np.int64)
+        lens = no[1:] - no[:-1]
+        total = int(no[-1])
+        if total <= 0 or int(lens.min()) <= 0:
+            exact = True
+        else:
+            b = np.asarray(self._n[:total]).astype(np.uint64)
+            pos = np.arange(total, dtype=np.int64) - np.repeat(no[:-1], lens)
+            mult = (np.uint64(0x9E3779B97F4A7C15) * (pos.astype(np.uint64) * np.uint64(2) + np.uint64(1)))
+            h = np.add.reduceat((b + np.uint64(1)) * mult, no[:-1]) ^ (lens.astype(np.uint64) << np.uint64(56))
+            exact = len(np.unique(h)) != n
+        if not exact:
+            return
+        first, last = {}, {}
+        for i in range(n):
+            k = bytes(memoryview(self._n)[int(no[i]):int(no[i + 1])])
+            first.setdefault(k, i)
+            last[k] = i
+        if len(first) == n:
+            return
+        so = np.asarray(self._so, dtype=np.int64)
+        keep = sorted(first.values())                                   # a name's first place ...
+        src = [last[bytes(memoryview(self._n)[int(no[i]):int(no[i + 1])])] for i in keep]     # ... with its last sequence
+        names = np.concatenate([np.asarray(self._n[int(no[i]):int(no[i + 1])]) for i in keep])
+        seqs = np.concatenate([np.asarray(self._s[int(so[j]):int(so[j + 1])]) for j in src])
+        self._n, self._s = names, seqs
+        self._no = np.concatenate([[0], np.cumsum([int(no[i + 1] - no[i]) for i in keep])]).astype(np.uint64)
+        self._so = np.concatenate([[0], np.cumsum([int(so[j + 1] - so[j]) for j in src])]).astype(np.uint64)
 
     def __len__(self):
         return len(self._no) - 1

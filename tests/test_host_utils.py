@@ -156,3 +156,25 @@ def test_final_transcripts_mapping_over_exported_buffers():
     assert f.fasta() == "".join(">%s\n%s\n" % r for r in recs).encode()
     empty = FinalTranscripts(np.zeros(1, np.uint8), np.zeros(1, np.uint64), np.zeros(1, np.uint8), np.zeros(1, np.uint64))
     assert len(empty) == 0 and empty == {} and empty.fasta() == b"" and list(empty) == []
+
+
+def test_final_transcripts_have_dict_semantics_for_a_repeated_name():
+    """faster_reps.py:103-131 keeps its records in a dict keyed by the header's first token: a later record of a name replaces the
+    sequence, the name keeps its first place.  post.FinalTranscripts (the lazy view over the native merge's buffers) does the same."""
+    import numpy as np
+    from shannon_amd import post
+
+    def mk(recs):
+        names, seqs = b"".join(n for n, _ in recs), b"".join(s for _, s in recs)
+        no = np.concatenate([[0], np.cumsum([len(n) for n, _ in recs])]).astype(np.uint64)
+        so = np.concatenate([[0], np.cumsum([len(s) for _, s in recs])]).astype(np.uint64)
+        return post.FinalTranscripts(np.frombuffer(names, np.uint8), no, np.frombuffer(seqs, np.uint8), so)
+    recs = [(b"a", b"ACGT"), (b"b", b"GG"), (b"a", b"TTTT"), (b"c", b"C"), (b"b", b"GGA")]
+    f = mk(recs)
+    d = {}
+    for k, v in recs:
+        d[k.decode()] = v.decode()
+    assert len(f) == 3 and f.items() == list(d.items()) and f == d and f["a"] == "TTTT"
+    assert f.fasta() == b">a\nTTTT\n>b\nGGA\n>c\nC\n"
+    g = mk([(b"x%d" % i, b"ACGT" * (1 + i % 3)) for i in range(500)])          # unique names: untouched
+    assert len(g) == 500 and g["x7"] == "ACGT" * 2 and g.fasta().count(b">") == 500
