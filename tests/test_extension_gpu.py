@@ -408,15 +408,16 @@ def test_gpu_contig_stage_on_many_genes(ctx):
 @pytest.mark.parametrize("env", [{"SHN_EXT_BULK": "1"}, {"SHN_EXT_BULK": "1", "SHN_EXT_DENSE": "1"}, {"SHN_EXT_BULK": "1", "SHN_EXT_DENSE": "1000000000"},
                                  {"SHN_EXT_BULK": "1", "SHN_EXT_PROMOTE_BULK": "0"}, {"SHN_EXT_BULK": "1", "SHN_EXT_PROMOTE_BULK": "1", "SHN_EXT_RESUME_WAVES": "3"},
                                  {"SHN_EXT_BULK": "1", "SHN_EXT_PROMOTE_BULK": "5", "SHN_EXT_DENSE": "1"}, {"SHN_EXT_BULK": "1", "SHN_EXT_PREPASS": "0"},
-                                 {"SHN_EXT_PREPASS": "0"},
+                                 {"SHN_EXT_PREPASS": "0"}, {"SHN_EXT_MEMO_RELEASE": "0"}, {"SHN_EXT_MEMO_RELEASE_MAX": "3"}, {"SHN_EXT_FIRST_LOOK": "1", "SHN_EXT_BULK": "1"},
                                  {"SHN_EXT_BULK": "1", "SHN_EXT_FRESH_SPLIT": "5", "SHN_EXT_FRESH_SPLIT_MIN": "32"},
                                  {"SHN_EXT_BULK": "1", "SHN_EXT_FRESH_SPLIT": "3", "SHN_EXT_FRESH_SPLIT_MIN": "32", "SHN_EXT_DENSE": "1"}])
 def test_bulk_rounds_give_the_same_contigs(ctx, env, monkeypatch):
     """Every round as a bulk round (thread walker only, no snapshot reads in a block's first round), with the begin / mark passes
     as they come, all dense or all following the line flags; the hand-over of long walks to the packed second launch
     (ext_walk_resume_kernel) off, after one step with three wavefronts for all of them, after five; the settling of void walks in a
-    block's first round off; a block's first round in 5 / 3 rank-ordered sub-launches: the same walks, contigs and connections as the
-    default path of a small table."""
+    block's first round off; the release of re-run walks' claims by the streaming begin pass only / through memos only in rounds of
+    at most three walks; the first look at the candidates' claims; a block's first round in 5 / 3 rank-ordered sub-launches: the same
+    walks, contigs and connections as the default path of a small table."""
     from shannon_amd import device, synth, extension_correction as ec
     (r1, r2), _ = synth.make_dataset(60000, 20, seed=91)
     t = device.count_k1mers(ctx, [device.Reads.from_codes(ctx, np.concatenate([r1, r2]))], 26)
