@@ -243,20 +243,40 @@ __device__ __forceinline__ uint32_t fd_match(ulonglong2 v, const unsigned long l
 // 128-byte request of the eight lanes, all eight requests in flight before the first is looked at), and then write the two
 // records -- 128 contiguous bytes -- 16 bytes each.
 struct __attribute__((aligned(16))) Quad { uint32_t a, b, c, d; };
-__global__ void ext_records_kernel(const TabIdx T, const uint8_t* __restrict__ flags, const uint32_t* __restrict__ weight, uint64_t n, int k, int canonical,
+#ifndef SHN_REC_PIPE
+#define SHN_REC_PIPE 0      // 1: the next trip's key / flag / weight fetched at the top of the trip.  Measured (round 5, configs[2]): 128 ms against 119.5 -- the
+#endif                      // eight look-ups of a trip are already all in flight together and the extra live registers cost a wavefront or spills; left off
+
+#if SHN_REC_PIPE
+#define REC_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(5, 5)))      // (the pipelined form needs 105 registers: held at 96 = 5 wavefronts per SIMD, ten words spill)
+#else
+#define REC_KERNEL_ATTR
+#endif
+__global__ REC_KERNEL_ATTR void ext_records_kernel(const TabIdx T, const uint8_t* __restrict__ flags, const uint32_t* __restrict__ weight, uint64_t n, int k, int canonical,
                                    Rec* __restrict__ rec, const unsigned long long* __restrict__ lines, uint64_t n_lines, int xcd) {
   const uint64_t* __restrict__ tkeys = T.keys;
   const uint64_t total = n * 8;
   const uint64_t rounded = (total + 63) & ~63ULL;                       // whole wavefronts take part in the ballots and shuffles
   const uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
   const int lane = threadIdx.x & 63, g0 = lane & ~7, p = lane & 7;
-  for (uint64_t gid = xcd_block(xcd) * blockDim.x + threadIdx.x; gid < rounded; gid += (uint64_t)gridDim.x * blockDim.x) {
-    const bool in = gid < total;
-    const uint64_t i = in ? gid >> 3 : 0;
-    const uint8_t f = in ? flags[i] : (uint8_t)2;
+  // (software-pipelined: the k1-mer, its flags and its weight of the NEXT trip are asked for at the top of this one -- a k1-mer is a
+  // chain of dependent round trips (its key -> its neighbours' bucket offsets -> their dictionary lines), the kernel runs at 5
+  // wavefronts per SIMD, and the first link of the chain need not be one)
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  uint64_t gid = xcd_block(xcd) * blockDim.x + threadIdx.x;
+  bool in = gid < total;
+  uint64_t i = in ? gid >> 3 : 0;
+  uint8_t f = (gid < rounded && in) ? flags[i] : (uint8_t)2;
+  uint64_t str = gid < rounded ? tkeys[i] : 0ULL;
+  uint32_t wt = (gid < rounded && in && (p == 2 || p == 6)) ? weight[i] : 0u;
+  for (; gid < rounded;) {
+    const uint64_t gid_n = gid + stride;
+    const bool in_n = gid_n < total;
+    const uint64_t i_n = in_n ? gid_n >> 3 : 0;
+    uint8_t f_n = 2; uint64_t str_n = 0; uint32_t wt_n = 0;
+    if (SHN_REC_PIPE && gid_n < rounded) { str_n = tkeys[i_n]; if (in_n) { f_n = flags[i_n]; if (p == 2 || p == 6) wt_n = weight[i_n]; } }
     const bool dead0 = (f & 2) != 0;                                    // forward orientation
     const bool dead1 = dead0 || (f & 1) || !canonical;                  // reverse-complement orientation (absent for palindromes)
-    const uint64_t str = tkeys[i];
     // look-up q: q = 0..3 append base q, q = 4..7 prepend base q - 4; lane q prepares it (key, strand, line), the group shares
     uint64_t mykey; uint32_t mystrand = 0;
     {
@@ -315,19 +335,23 @@ __global__ void ext_records_kernel(const TabIdx T, const uint8_t* __restrict__ f
       r8[q] = 2 * j + st;
       d8[q] = (w & FD_PAL) ? r8[q] : 2 * j + (1 - st);
     }
-    if (!in) continue;
-    // lane p writes bytes 16 p .. of the pair of records (forward, reverse complement)
-    Quad out;
-    const Quad none = Quad{~0u, ~0u, ~0u, ~0u};
-    switch (p) {
-      case 0: out = Quad{r8[0], r8[1], r8[2], r8[3]}; break;           // forward: right row = the append candidates
-      case 1: out = Quad{r8[4], r8[5], r8[6], r8[7]}; break;           //          left row = the prepend candidates
-      case 4: out = dead1 ? none : Quad{d8[7], d8[6], d8[5], d8[4]}; break;   // reverse complement: right row = the prepend candidates' other orientations, mirrored (base b <-> 3 - b)
-      case 5: out = dead1 ? none : Quad{d8[3], d8[2], d8[1], d8[0]}; break;   //                     left row = the append candidates' ...
-      case 2: case 6: out = Quad{weight[i], NOHINT_WORD, 0xFFFFFFFFu, 0u}; break;
-      default: out = Quad{0u, 0u, 0u, 0u}; break;
+    if (in) {
+      // lane p writes bytes 16 p .. of the pair of records (forward, reverse complement)
+      Quad out;
+      const Quad none = Quad{~0u, ~0u, ~0u, ~0u};
+      switch (p) {
+        case 0: out = Quad{r8[0], r8[1], r8[2], r8[3]}; break;           // forward: right row = the append candidates
+        case 1: out = Quad{r8[4], r8[5], r8[6], r8[7]}; break;           //          left row = the prepend candidates
+        case 4: out = dead1 ? none : Quad{d8[7], d8[6], d8[5], d8[4]}; break;   // reverse complement: right row = the prepend candidates' other orientations, mirrored (base b <-> 3 - b)
+        case 5: out = dead1 ? none : Quad{d8[3], d8[2], d8[1], d8[0]}; break;   //                     left row = the append candidates' ...
+        case 2: case 6: out = Quad{wt, NOHINT_WORD, 0xFFFFFFFFu, 0u}; break;
+        default: out = Quad{0u, 0u, 0u, 0u}; break;
+      }
+      ((Quad*)(rec + 2 * i))[p] = out;
     }
-    ((Quad*)(rec + 2 * i))[p] = out;
+    gid = gid_n; in = in_n; i = i_n;
+    if (SHN_REC_PIPE) { f = f_n; str = str_n; wt = wt_n; }
+    else if (gid < rounded) { str = tkeys[i]; f = in ? flags[i] : (uint8_t)2; wt = (in && (p == 2 || p == 6)) ? weight[i] : 0u; }
   }
 }
 
