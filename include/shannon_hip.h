@@ -131,6 +131,11 @@ int shn_table_merge_rc(shn_ctx* ctx, const shn_table* fwd, const shn_table* othe
  * (host, n_ranks entries) and writes keys/counts grouped by rank into the device buffers. */
 int shn_table_shard(shn_ctx* ctx, const shn_table* t, int n_ranks, uint64_t* per_rank, void* dev_keys_out,
                     void* dev_counts_out);
+/* mode 0: as above; mode 1: owner = rank of the key's minimizer (m = 13; the hash of the minimizer's order value mod n_ranks) --
+ * a k1-mer and its eight neighbours share their minimizer six times out of seven, so most edges of the k1-mer graph stay inside a
+ * shard: the shards the components are labelled on (shn_cc_*).                                                                */
+int shn_table_shard_mode(shn_ctx* ctx, const shn_table* t, int n_ranks, int mode, uint64_t* per_rank, void* dev_keys_out,
+                         void* dev_counts_out);
 
 /* ---- contig extension / k1-mer error correction ----------------------------------------------
  * Replaces the hot loop of extension_correction.run_correction (extension_correction.py:334-354:
@@ -190,6 +195,36 @@ int shn_ext_weights(shn_ctx* ctx, const shn_ext* e, const uint64_t* keys, uint64
  * that merges the shards (extension_correction.py:334-345).                                                             */
 int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min_weight, int max_iterations, int world, int rank, shn_ext** out);
 int shn_ext_seed_info(shn_ctx* ctx, const shn_ext* e, const uint32_t* ranks, uint64_t n, uint64_t* keys, uint32_t* weights);
+/* ---- component labelling on owner shards: the N-rank form of the reference's one shared k1-mer dictionary
+ * (extension_correction.py:202-221 loads ALL k1-mers into one dict; shannon.py:527-566 fans out only after that).  No rank ever
+ * holds the whole table: every rank labels the shard of k1-mers it owns (shn_table_shard_mode 1), asks the owners of the
+ * neighbours it cannot see, and the component graph -- small: one node per local component with an edge to another rank -- is
+ * solved on every rank from the gathered edges.  Then whole components travel to their owner rank, which runs the unsharded
+ * shn_extend on a table of its own.  All buffers are device memory of the caller; every call returns with its work done.
+ *   shn_cc_create        local components of the shard `t` (which must outlive the object); counts the queries
+ *   shn_cc_query_counts  queries per destination rank (only higher ranks are asked: an edge is seen from both ends)
+ *   shn_cc_queries       the queries grouped by destination: neighbour / sibling key (8 bytes), the asker's local root (4 bytes)
+ *   shn_cc_answer        the queries received (grouped by source rank, recv_per_rank[s] each) against this shard: edges as pairs of
+ *                        global ids = base[rank] + local root (base = exclusive sums of the ranks' shard sizes); room for 2 ids
+ *                        per query
+ *   shn_cc_solve         n_edges pairs of ids (all ranks' edges) -> the distinct ids ascending + for each the smallest id of its
+ *                        component (room for 2 n_edges each); independent of the order of the edges; ids < id_limit (0: unknown)
+ *   shn_cc_labels        global label of every k1-mer of the shard, table order (8 bytes each)
+ *   shn_cc_owners        owner rank of every k1-mer (1 byte each): hash of its label mod world, except the n_big labels listed
+ *                        (ascending) with their ranks -- the components the caller balances by size
+ *   shn_cc_shard         the shard's (key, count) pairs grouped by owner rank (per_rank[r] each)                               */
+typedef struct shn_cc shn_cc;
+int shn_cc_create(shn_ctx* ctx, const shn_table* t, int world, int rank, shn_cc** out);
+void shn_cc_destroy(shn_cc* c);
+int shn_cc_query_counts(const shn_cc* c, uint64_t* per_rank);
+int shn_cc_queries(shn_cc* c, void* dev_keys_out, void* dev_labs_out);
+int shn_cc_answer(shn_cc* c, const void* dev_keys, const void* dev_labs, const uint64_t* recv_per_rank, const uint64_t* base,
+                  void* dev_edges_out, uint64_t* n_edges);
+int shn_cc_solve(shn_ctx* ctx, const void* dev_edges, uint64_t n_edges, uint64_t id_limit, void* dev_nodes_out, void* dev_labels_out,
+                 uint64_t* n_nodes);
+int shn_cc_labels(shn_cc* c, uint64_t base_me, const void* dev_nodes, const void* dev_labels, uint64_t n_nodes, void* dev_glabel_out);
+int shn_cc_owners(shn_cc* c, const void* dev_glabel, const void* dev_big, const void* dev_big_owner, uint64_t n_big, void* dev_owner_out);
+int shn_cc_shard(shn_cc* c, const void* dev_owner, uint64_t* per_rank, void* dev_keys_out, void* dev_counts_out);
 int shn_ext_live_stats(shn_ctx* ctx, const shn_ext* e, uint64_t* n_live, uint32_t* rank, uint32_t* n_right, uint32_t* n_left,
                        uint64_t* tot_weight);
 /* ... restricted to walks of at least min_steps steps (contig length k1 + steps): the first clause of the accept filter,

@@ -43,6 +43,16 @@ SIGNATURES = {
     "shn_table_from_pairs": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vpp]),
     "shn_table_merge_rc": (C.c_int, [vp, vp, vp, vpp]),
     "shn_table_shard": (C.c_int, [vp, vp, C.c_int, u64p, vp, vp]),
+    "shn_table_shard_mode": (C.c_int, [vp, vp, C.c_int, C.c_int, u64p, vp, vp]),
+    "shn_cc_create": (C.c_int, [vp, vp, C.c_int, C.c_int, vpp]),
+    "shn_cc_destroy": (None, [vp]),
+    "shn_cc_query_counts": (C.c_int, [vp, u64p]),
+    "shn_cc_queries": (C.c_int, [vp, vp, vp]),
+    "shn_cc_answer": (C.c_int, [vp, vp, vp, u64p, u64p, vp, u64p]),
+    "shn_cc_solve": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, vp, vp, u64p]),
+    "shn_cc_labels": (C.c_int, [vp, C.c_uint64, vp, vp, C.c_uint64, vp]),
+    "shn_cc_owners": (C.c_int, [vp, vp, vp, vp, C.c_uint64, vp]),
+    "shn_cc_shard": (C.c_int, [vp, vp, u64p, vp, vp]),
     "shn_table_create": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vpp]),
     "shn_probe_build": (C.c_int, [vp, vp, vp, C.c_uint64, vp, C.c_uint32, C.c_int, vpp]),
     "shn_probe_destroy": (None, [vp]),

@@ -1111,23 +1111,28 @@ extern "C" int shn_table_from_pairs(shn_ctx* ctx, const void* dev_keys, const vo
 __device__ __forceinline__ uint32_t owner_of(uint64_t key, int n_ranks) {
   return (uint32_t)(shn_mix64(key ^ SHARD_SALT) % (uint64_t)n_ranks);
 }
-__global__ void shard_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n, int n_ranks, unsigned long long* __restrict__ hist) {
+// mode 0: by the key's hash; mode 1: by its minimizer (k, canon: of the table)
+struct ShardRule { int mode, k, canon; };
+__device__ __forceinline__ uint32_t owner_by(const ShardRule& R, uint64_t key, int n_ranks) {
+  return R.mode ? shn_owner_minimizer(key, R.k, R.canon, n_ranks) : owner_of(key, n_ranks);
+}
+__global__ void shard_hist_kernel(const uint64_t* __restrict__ keys, uint64_t n, int n_ranks, const ShardRule R, unsigned long long* __restrict__ hist) {
   __shared__ uint32_t lh[64];
   if (threadIdx.x < 64) lh[threadIdx.x] = 0;
   __syncthreads();
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-    atomicAdd(&lh[owner_of(keys[i], n_ranks)], 1u);
+    atomicAdd(&lh[owner_by(R, keys[i], n_ranks)], 1u);
   __syncthreads();
   if (threadIdx.x < n_ranks && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
 }
 __global__ void shard_scatter_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, uint64_t n, int n_ranks,
-                                     unsigned long long* __restrict__ cursor, uint64_t* __restrict__ ok, uint32_t* __restrict__ oc) {
+                                     const ShardRule R, unsigned long long* __restrict__ cursor, uint64_t* __restrict__ ok, uint32_t* __restrict__ oc) {
   // wave-aggregated reservation: lanes with the same owner share one atomic
   for (uint64_t base = (uint64_t)blockIdx.x * blockDim.x; base < n; base += (uint64_t)gridDim.x * blockDim.x) {
     uint64_t i = base + threadIdx.x;
     bool act = i < n;
     uint64_t key = act ? keys[i] : 0;
-    uint32_t o = act ? owner_of(key, n_ranks) : 0xFFFFFFFFu;
+    uint32_t o = act ? owner_by(R, key, n_ranks) : 0xFFFFFFFFu;
     for (int r = 0; r < n_ranks; r++) {
       unsigned long long m = __ballot(act && o == (uint32_t)r);
       if (!m) continue;
@@ -1144,9 +1149,16 @@ __global__ void shard_scatter_kernel(const uint64_t* __restrict__ keys, const ui
   }
 }
 
+extern "C" int shn_table_shard_mode(shn_ctx* ctx, const shn_table* t, int n_ranks, int mode, uint64_t* per_rank, void* dev_keys_out, void* dev_counts_out);
 extern "C" int shn_table_shard(shn_ctx* ctx, const shn_table* t, int n_ranks, uint64_t* per_rank, void* dev_keys_out,
                                void* dev_counts_out) {
-  if (!ctx || !t || !per_rank || n_ranks < 1 || n_ranks > 64) return shn_fail(SHN_ERR_ARG, "shn_table_shard: bad argument");
+  return shn_table_shard_mode(ctx, t, n_ranks, 0, per_rank, dev_keys_out, dev_counts_out);
+}
+// mode 1: owner = rank of the key's minimizer (shn_owner_minimizer) -- the shards the components are labelled on (shn_cc_*)
+extern "C" int shn_table_shard_mode(shn_ctx* ctx, const shn_table* t, int n_ranks, int mode, uint64_t* per_rank, void* dev_keys_out,
+                                    void* dev_counts_out) {
+  if (!ctx || !t || !per_rank || n_ranks < 1 || n_ranks > 64 || mode < 0 || mode > 1) return shn_fail(SHN_ERR_ARG, "shn_table_shard: bad argument");
+  const ShardRule R{mode, t->k, t->canonical};
   if (t->n && (!dev_keys_out || !dev_counts_out)) return shn_fail(SHN_ERR_ARG, "shn_table_shard: NULL output");
   SHN_ENTER(ctx);
   hipStream_t s = ctx->stream; shn_use_stream(s);
@@ -1157,14 +1169,14 @@ extern "C" int shn_table_shard(shn_ctx* ctx, const shn_table* t, int n_ranks, ui
   unsigned long long* d_cur = d_hist + 64;
   HIP_TRY(hipMemsetAsync(d_hist, 0, 64 * 8, s));
   uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, cdiv(t->n, 256)), 2048);
-  hipLaunchKernelGGL(shard_hist_kernel, dim3(grid), dim3(256), 0, s, t->d_keys, t->n, n_ranks, d_hist);
+  hipLaunchKernelGGL(shard_hist_kernel, dim3(grid), dim3(256), 0, s, t->d_keys, t->n, n_ranks, R, d_hist);
   unsigned long long h[64], c[64];
   HIP_TRY(hipMemcpyAsync(h, d_hist, 64 * 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   unsigned long long a = 0;
   for (int i = 0; i < 64; i++) { c[i] = a; if (i < n_ranks) { per_rank[i] = h[i]; a += h[i]; } }
   HIP_TRY(hipMemcpyAsync(d_cur, c, 64 * 8, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(shard_scatter_kernel, dim3(grid), dim3(256), 0, s, t->d_keys, t->d_counts, t->n, n_ranks, d_cur,
+  hipLaunchKernelGGL(shard_scatter_kernel, dim3(grid), dim3(256), 0, s, t->d_keys, t->d_counts, t->n, n_ranks, R, d_cur,
                      (uint64_t*)dev_keys_out, (uint32_t*)dev_counts_out);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));

@@ -1530,6 +1530,391 @@ static int build_fine_dict(shn_ctx* ctx, const shn_table* t, const uint8_t* d_fl
   return SHN_OK;
 }
 
+// ---- Component labelling on OWNER SHARDS (the N-rank path without a replicated table: BASELINE configs[4]) ----
+// component_shard above wants the whole table on every rank.  Here every rank holds only the k1-mers whose minimizer it owns
+// (shn_table_shard_mode 1: most edges of the k1-mer graph stay inside a shard):
+//   1. shn_cc_create:   the local components -- the union-find of cc_edges_kernel over the shard (an edge whose other end is not in
+//                       the shard is simply not found);
+//   2. shn_cc_queries:  every neighbour / sibling key of a local k1-mer that a HIGHER rank owns, with the local root of the asker
+//                       (an edge is seen from both ends; the lower rank asks, so it is recorded once) -> all-to-all by owner;
+//   3. shn_cc_answer:   the owner looks the keys up: present and not low-complexity = an edge between two local components of two
+//                       ranks, as a pair of global ids (rank's base + local root);
+//   4. shn_cc_solve:    the edges of all ranks (gathered) -> the components of the component graph, the same on every rank: sorted
+//                       distinct ids + the smallest id of the component of each;
+//   5. shn_cc_labels / shn_cc_owners / shn_cc_shard: a global label and an owner rank for every local k1-mer, and the shard's pairs
+//                       grouped by owner -> all-to-all -> a table of whole components per rank, walked by the unsharded shn_extend
+//                       (ids and records are those of the rank's own table: the 31-bit id limit applies to a rank, not to the job).
+// The edge rule is cc_edges_kernel's, so the components are those of component_shard on the whole table (tests/test_cc_shards_gpu.py
+// against scipy's connected components of the same graph).
+struct shn_cc {
+  shn_ctx* ctx; const shn_table* t; int world, rank, device;
+  uint8_t* d_flags; uint32_t* d_lab;
+  unsigned long long* d_cnt;          // 64 cursors + 64 bases
+  uint64_t per_rank[64];
+};
+
+// key number `which` = 8 * half + p of the k1-mer str (see cc_edges_kernel): half 0 = its eight neighbours, half 1 = its siblings
+__device__ __forceinline__ uint64_t cc_which_key(uint64_t str, int p, int half, int k, uint64_t mask, int canonical, bool* skip) {
+  const uint64_t b = (uint64_t)(p & 3);
+  uint64_t key;
+  *skip = false;
+  if (half == 0) key = (p & 4) ? ((str >> 2) | (b << (2 * (k - 1)))) : (((str << 2) | b) & mask);
+  else if (p & 4) { *skip = (str & 3) == b; key = (str & ~3ULL) | b; }
+  else { const int sh = 2 * (k - 1); *skip = ((str >> sh) & 3) == b; key = (str & ~(3ULL << sh)) | (b << sh); }
+  if (canonical) { const uint64_t rc = shn_revcomp(key, k); if (rc < key) key = rc; }
+  return key;
+}
+
+// WRITE = false: how many queries go to every rank; true: the queries, grouped by rank (cursor = where every group begins)
+template <bool WRITE>
+__global__ void cc_query_kernel(const uint64_t* __restrict__ tkeys, const uint8_t* __restrict__ flags, uint64_t n, int k, int canonical,
+                                int world, int rank, const uint32_t* __restrict__ lab, unsigned long long* __restrict__ cursor,
+                                uint64_t* __restrict__ qk, uint32_t* __restrict__ ql) {
+  __shared__ uint32_t lh[64];
+  if (!WRITE) { if (threadIdx.x < 64) lh[threadIdx.x] = 0; __syncthreads(); }
+  const uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+  const uint64_t total = n * 8, rounded = (total + 63) & ~63ULL;
+  const int lane = threadIdx.x & 63, p = lane & 7;
+  for (uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < rounded; gid += (uint64_t)gridDim.x * blockDim.x) {
+    const bool in = gid < total;
+    const uint64_t i = in ? gid >> 3 : 0;
+    const bool dead = !in || (flags[i] & 2);
+    const uint64_t str = tkeys[i];
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      bool skip;
+      const uint64_t key = cc_which_key(str, p, half, k, mask, canonical, &skip);
+      const int dest = (dead || skip) ? -1 : (int)shn_owner_minimizer(key, k, canonical, world);
+      const bool want = dest > rank;
+      if (!WRITE) { if (want) atomicAdd(&lh[dest], 1u); continue; }
+      const unsigned long long any = __ballot(want);
+      if (!any) continue;
+      for (int r = rank + 1; r < world; r++) {
+        const unsigned long long m = __ballot(want && dest == r);
+        if (!m) continue;
+        const int leader = __ffsll((long long)m) - 1;
+        unsigned long long base = 0;
+        if (lane == leader) base = atomicAdd(&cursor[r], (unsigned long long)__popcll(m));
+        base = shfl_u64(base, leader);
+        if (want && dest == r) {
+          const uint64_t d = base + __popcll(m & ((1ULL << lane) - 1));
+          qk[d] = key; ql[d] = lab[i];
+        }
+      }
+    }
+  }
+  if (!WRITE) {
+    __syncthreads();
+    if (threadIdx.x < 64 && lh[threadIdx.x]) atomicAdd(&cursor[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
+  }
+}
+
+// the queries received (grouped by asking rank: group s begins at src_off[s]) against this shard
+__global__ void cc_answer_kernel(const TabIdx T, const uint8_t* __restrict__ flags, const uint32_t* __restrict__ lab,
+                                 const uint64_t* __restrict__ qk, const uint32_t* __restrict__ ql, uint64_t nq,
+                                 const unsigned long long* __restrict__ src_off, const unsigned long long* __restrict__ base, int world, int rank,
+                                 uint64_t* __restrict__ edges, unsigned long long* __restrict__ n_edges) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t rounded = (nq + 63) & ~63ULL;
+  for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < rounded; q += (uint64_t)gridDim.x * blockDim.x) {
+    int64_t j = -1;
+    if (q < nq) { j = shn_tab_find(T, qk[q]); if (j >= 0 && (flags[j] & 2)) j = -1; }
+    const unsigned long long m = __ballot(j >= 0);
+    if (!m) continue;
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned long long at = 0;
+    if (lane == leader) at = atomicAdd(n_edges, (unsigned long long)__popcll(m));
+    at = shfl_u64(at, leader);
+    if (j >= 0) {
+      int src = 0;
+      while (src + 1 < world && q >= src_off[src + 1]) src++;
+      const uint64_t d = at + __popcll(m & ((1ULL << lane) - 1));
+      edges[2 * d] = base[rank] + lab[j];
+      edges[2 * d + 1] = base[src] + ql[q];
+    }
+  }
+}
+
+extern "C" void shn_cc_destroy(shn_cc* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->d_flags) shn_dev_free(c->d_flags);
+  if (c->d_lab) shn_dev_free(c->d_lab);
+  if (c->d_cnt) shn_dev_free(c->d_cnt);
+  delete c;
+}
+
+// the local components of the shard `t` of rank `rank` of `world` (t must outlive the object) + the number of queries per rank
+extern "C" int shn_cc_create(shn_ctx* ctx, const shn_table* t, int world, int rank, shn_cc** out) {
+  if (!ctx || !t || !out || world < 1 || world > 64 || rank < 0 || rank >= world) return shn_fail(SHN_ERR_ARG, "shn_cc_create: bad argument");
+  if (t->n >= 0x7FFFFFFFULL) return shn_fail(SHN_ERR_ARG, "shn_cc_create: a shard holds at most 2^31 - 1 k1-mers (use more ranks)");
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
+  const uint64_t n = t->n;
+  shn_cc* c = new shn_cc();
+  memset(c, 0, sizeof(*c));
+  c->ctx = ctx; c->t = t; c->world = world; c->rank = rank; c->device = ctx->device;
+  uint32_t* d_weight = nullptr;
+  unsigned long long* lines = nullptr;
+  uint64_t n_lines = 0;
+  auto fail = [&](int rc) { if (d_weight) shn_dev_free(d_weight); if (lines) shn_dev_free(lines); shn_cc_destroy(c); return rc; };
+#define TRYC(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(shn_fail(SHN_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(_e))); } while (0)
+  TRYC(shn_dev_malloc(&d_weight, (n + 1) * 4));
+  TRYC(shn_dev_malloc(&c->d_flags, n + 1));
+  TRYC(shn_dev_malloc(&c->d_lab, (n + 1) * 4));
+  TRYC(shn_dev_malloc(&c->d_cnt, 128 * 8));
+  TRYC(hipMemsetAsync(c->d_cnt, 0, 128 * 8, s));
+  if (n) {
+    hipLaunchKernelGGL(ext_prepare_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, t->d_counts, n, t->k, t->canonical, d_weight, c->d_flags);
+    { int rc = build_fine_dict(ctx, t, c->d_flags, &lines, &n_lines); if (rc) return fail(rc); }
+    hipLaunchKernelGGL(cc_init_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, c->d_lab, n);
+    hipLaunchKernelGGL(cc_edges_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, shn_tab_idx(t),
+                       c->d_flags, n, t->k, t->canonical, c->d_lab, (const unsigned long long*)lines, n_lines);
+    hipLaunchKernelGGL(cc_flatten_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, c->d_lab, n);
+    hipLaunchKernelGGL((cc_query_kernel<false>), dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 20)), dim3(256), 0, s, t->d_keys, c->d_flags, n,
+                       t->k, t->canonical, world, rank, c->d_lab, c->d_cnt, (uint64_t*)nullptr, (uint32_t*)nullptr);
+  }
+  unsigned long long h[64];
+  TRYC(hipMemcpyAsync(h, c->d_cnt, 64 * 8, hipMemcpyDeviceToHost, s));
+  TRYC(hipStreamSynchronize(s));
+  TRYC(hipGetLastError());
+  for (int r = 0; r < 64; r++) c->per_rank[r] = r < world ? h[r] : 0;
+  shn_dev_free(d_weight); d_weight = nullptr;
+  if (lines) { shn_dev_free(lines); lines = nullptr; }
+#undef TRYC
+  *out = c;
+  return SHN_OK;
+}
+
+extern "C" int shn_cc_query_counts(const shn_cc* c, uint64_t* per_rank) {
+  if (!c || !per_rank) return shn_fail(SHN_ERR_ARG, "shn_cc_query_counts: bad argument");
+  for (int r = 0; r < c->world; r++) per_rank[r] = c->per_rank[r];
+  return SHN_OK;
+}
+
+// the queries, grouped by destination rank in rank order (per_rank[r] entries each): key (8 bytes) and the asker's local root (4 bytes)
+extern "C" int shn_cc_queries(shn_cc* c, void* dev_keys_out, void* dev_labs_out) {
+  if (!c) return shn_fail(SHN_ERR_ARG, "shn_cc_queries: bad argument");
+  shn_ctx* ctx = c->ctx;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
+  unsigned long long cur[64], a = 0;
+  for (int r = 0; r < 64; r++) { cur[r] = a; a += c->per_rank[r]; }
+  if (!a) return SHN_OK;
+  if (!dev_keys_out || !dev_labs_out) return shn_fail(SHN_ERR_ARG, "shn_cc_queries: NULL output");
+  HIP_TRY(hipMemcpyAsync(c->d_cnt, cur, 64 * 8, hipMemcpyHostToDevice, s));
+  const uint64_t n = c->t->n;
+  hipLaunchKernelGGL((cc_query_kernel<true>), dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 20)), dim3(256), 0, s, c->t->d_keys, c->d_flags, n,
+                     c->t->k, c->t->canonical, c->world, c->rank, c->d_lab, c->d_cnt, (uint64_t*)dev_keys_out, (uint32_t*)dev_labs_out);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s));               // (cur lives on this stack frame)
+  return SHN_OK;
+}
+
+// recv_per_rank[s]: queries received from rank s (grouped in rank order); base[r]: first global id of rank r (the ranks' shard sizes,
+// summed); dev_edges_out: room for 2 ids per query.  n_edges: how many of the queries named a k1-mer of this shard.
+extern "C" int shn_cc_answer(shn_cc* c, const void* dev_keys, const void* dev_labs, const uint64_t* recv_per_rank, const uint64_t* base,
+                             void* dev_edges_out, uint64_t* n_edges) {
+  if (!c || !recv_per_rank || !base || !n_edges) return shn_fail(SHN_ERR_ARG, "shn_cc_answer: bad argument");
+  shn_ctx* ctx = c->ctx;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
+  unsigned long long h[128], a = 0;
+  for (int r = 0; r < 64; r++) { h[r] = a; if (r < c->world) a += recv_per_rank[r]; h[64 + r] = r < c->world ? base[r] : 0; }
+  *n_edges = 0;
+  if (!a) return SHN_OK;
+  if (!dev_keys || !dev_labs || !dev_edges_out) return shn_fail(SHN_ERR_ARG, "shn_cc_answer: NULL buffer");
+  unsigned long long* d_ne = nullptr;
+  HIP_TRY(shn_dev_malloc(&d_ne, 8));
+  hipError_t e = hipMemcpyAsync(c->d_cnt, h, 128 * 8, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) e = hipMemsetAsync(d_ne, 0, 8, s);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(cc_answer_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(a, 256), 1u << 20)), dim3(256), 0, s, shn_tab_idx(c->t), c->d_flags, c->d_lab,
+                       (const uint64_t*)dev_keys, (const uint32_t*)dev_labs, (uint64_t)a, c->d_cnt, c->d_cnt + 64, c->world, c->rank,
+                       (uint64_t*)dev_edges_out, d_ne);
+    e = hipGetLastError();
+  }
+  unsigned long long ne = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&ne, d_ne, 8, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  shn_dev_free(d_ne);
+  if (e != hipSuccess) return shn_fail(SHN_ERR_HIP, std::string("shn_cc_answer: ") + hipGetErrorString(e));
+  *n_edges = ne;
+  return SHN_OK;
+}
+
+// ---- the component graph (nodes = local components that have an edge to another rank), the same computation on every rank
+__global__ void ccs_iota_kernel(uint32_t* __restrict__ v, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] = (uint32_t)i;
+}
+__global__ void ccs_first_kernel(const uint64_t* __restrict__ keys, uint64_t n, uint32_t* __restrict__ first) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) first[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+// pos = exclusive scan of first: the node number of sorted position i is pos[i + 1] - 1
+__global__ void ccs_number_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ first,
+                                  const uint64_t* __restrict__ pos, uint64_t n, uint32_t* __restrict__ node_of_end, uint64_t* __restrict__ nodes,
+                                  uint32_t* __restrict__ lab) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t id = (uint32_t)(pos[i + 1] - 1);
+    node_of_end[vals[i]] = id;
+    if (first[i]) { nodes[id] = keys[i]; lab[id] = id; }
+  }
+}
+__global__ void ccs_unite_kernel(const uint32_t* __restrict__ node_of_end, uint64_t n_edges, uint32_t* lab) {
+  for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += (uint64_t)gridDim.x * blockDim.x)
+    cc_unite(lab, node_of_end[2 * e], node_of_end[2 * e + 1]);
+}
+__global__ void ccs_label_kernel(uint32_t* lab, const uint64_t* __restrict__ nodes, uint64_t n_nodes, uint64_t* __restrict__ label_out) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += (uint64_t)gridDim.x * blockDim.x)
+    label_out[i] = nodes[cc_find(lab, (uint32_t)i)];
+}
+
+// dev_edges: n_edges pairs of global ids (not modified).  dev_nodes_out / dev_labels_out: room for 2 n_edges ids each: the distinct
+// ids, ascending, and for each the smallest id of its component (roots only ever link to smaller node numbers, node numbers follow
+// the ids: the answer does not depend on the order of the edges).
+// id_limit: every id is below it (0: unknown) -- the sort goes over its bits only.
+extern "C" int shn_cc_solve(shn_ctx* ctx, const void* dev_edges, uint64_t n_edges, uint64_t id_limit, void* dev_nodes_out, void* dev_labels_out, uint64_t* n_nodes) {
+  if (!ctx || !n_nodes) return shn_fail(SHN_ERR_ARG, "shn_cc_solve: bad argument");
+  *n_nodes = 0;
+  if (!n_edges) return SHN_OK;
+  if (!dev_edges || !dev_nodes_out || !dev_labels_out) return shn_fail(SHN_ERR_ARG, "shn_cc_solve: NULL buffer");
+  const uint64_t m = 2 * n_edges;
+  if (m >= 0xFFFFFFF0ULL) return shn_fail(SHN_ERR_ARG, "shn_cc_solve: more than 2^31 edges between the shards");
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
+  ShnDevBufs bufs(s);
+  uint64_t *k0, *k1, *pos; uint32_t *v0, *v1, *first, *node_of_end, *lab;
+  auto no = [](hipError_t e) { return e != hipSuccess; };
+  if (no(bufs.get(&k0, m * 8)) || no(bufs.get(&k1, m * 8)) || no(bufs.get(&v0, m * 4)) || no(bufs.get(&v1, m * 4)) || no(bufs.get(&first, m * 4)) ||
+      no(bufs.get(&pos, (m + 1) * 8)) || no(bufs.get(&node_of_end, m * 4)) || no(bufs.get(&lab, m * 4)))
+    return shn_fail(SHN_ERR_HIP, "shn_cc_solve: out of device memory");
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(cdiv(m, 256), 1u << 20);
+  HIP_TRY(hipMemcpyAsync(k0, dev_edges, m * 8, hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(ccs_iota_kernel, dim3(grid), dim3(256), 0, s, v0, m);
+  int bit_hi = 64;
+  if (id_limit) { bit_hi = 8; while (bit_hi < 64 && (id_limit >> bit_hi)) bit_hi += 8; }
+  int rc = shn_sort_pairs(ctx, k0, v0, k1, v1, m, 0, bit_hi);
+  if (rc) return rc;
+  hipLaunchKernelGGL(ccs_first_kernel, dim3(grid), dim3(256), 0, s, k0, m, first);
+  uint64_t nn = 0;
+  if ((rc = shn_device_scan_u32(ctx, first, m, pos, &nn))) return rc;
+  hipLaunchKernelGGL(ccs_number_kernel, dim3(grid), dim3(256), 0, s, k0, v0, first, pos, m, node_of_end, (uint64_t*)dev_nodes_out, lab);
+  hipLaunchKernelGGL(ccs_unite_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n_edges, 256), 1u << 20)), dim3(256), 0, s, node_of_end, n_edges, lab);
+  hipLaunchKernelGGL(ccs_label_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(nn, 256), 1u << 20)), dim3(256), 0, s, lab, (const uint64_t*)dev_nodes_out, nn,
+                     (uint64_t*)dev_labels_out);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s));
+  *n_nodes = nn;
+  return SHN_OK;
+}
+
+__device__ __forceinline__ int64_t ccs_search(const uint64_t* __restrict__ a, uint64_t n, uint64_t key) {
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; const uint64_t v = a[mid]; if (v == key) return (int64_t)mid; if (v < key) lo = mid + 1; else hi = mid; }
+  return -1;
+}
+__global__ void ccs_glabel_kernel(const uint32_t* __restrict__ lab, uint64_t n, uint64_t base_me, const uint64_t* __restrict__ nodes,
+                                  const uint64_t* __restrict__ labels, uint64_t n_nodes, uint64_t* __restrict__ out) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t g = base_me + lab[i];
+    const int64_t j = ccs_search(nodes, n_nodes, g);
+    out[i] = j >= 0 ? labels[j] : g;
+  }
+}
+// the global label of every k1-mer of the shard (table order): the solved label of its local component if that has an edge to
+// another rank, its own global id otherwise
+extern "C" int shn_cc_labels(shn_cc* c, uint64_t base_me, const void* dev_nodes, const void* dev_labels, uint64_t n_nodes, void* dev_glabel_out) {
+  if (!c) return shn_fail(SHN_ERR_ARG, "shn_cc_labels: bad argument");
+  const uint64_t n = c->t->n;
+  if (!n) return SHN_OK;
+  if (!dev_glabel_out || (n_nodes && (!dev_nodes || !dev_labels))) return shn_fail(SHN_ERR_ARG, "shn_cc_labels: NULL buffer");
+  shn_ctx* ctx = c->ctx;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
+  hipLaunchKernelGGL(ccs_glabel_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n, 256), 1u << 20)), dim3(256), 0, s, c->d_lab, n, base_me,
+                     (const uint64_t*)dev_nodes, (const uint64_t*)dev_labels, n_nodes, (uint64_t*)dev_glabel_out);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s));
+  return SHN_OK;
+}
+
+__global__ void ccs_owner_kernel(const uint64_t* __restrict__ glabel, uint64_t n, const uint64_t* __restrict__ big, const uint8_t* __restrict__ big_owner,
+                                 uint64_t n_big, uint32_t world, uint8_t* __restrict__ owner) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t g = glabel[i];
+    const int64_t j = ccs_search(big, n_big, g);
+    owner[i] = j >= 0 ? big_owner[j] : (uint8_t)(shn_mix64(g ^ 0x5851F42D4C957F2DULL) % world);
+  }
+}
+// owner rank of every k1-mer of the shard: its component's -- by the hash of the label, except for the components listed (dev_big:
+// n_big labels ascending, dev_big_owner: their ranks), which the caller has balanced by size
+extern "C" int shn_cc_owners(shn_cc* c, const void* dev_glabel, const void* dev_big, const void* dev_big_owner, uint64_t n_big, void* dev_owner_out) {
+  if (!c) return shn_fail(SHN_ERR_ARG, "shn_cc_owners: bad argument");
+  const uint64_t n = c->t->n;
+  if (!n) return SHN_OK;
+  if (!dev_glabel || !dev_owner_out || (n_big && (!dev_big || !dev_big_owner))) return shn_fail(SHN_ERR_ARG, "shn_cc_owners: NULL buffer");
+  shn_ctx* ctx = c->ctx;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
+  hipLaunchKernelGGL(ccs_owner_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n, 256), 1u << 20)), dim3(256), 0, s, (const uint64_t*)dev_glabel, n,
+                     (const uint64_t*)dev_big, (const uint8_t*)dev_big_owner, n_big, (uint32_t)c->world, (uint8_t*)dev_owner_out);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s));
+  return SHN_OK;
+}
+
+template <bool WRITE>
+__global__ void ccs_shard_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, const uint8_t* __restrict__ owner, uint64_t n,
+                                 int world, unsigned long long* __restrict__ cursor, uint64_t* __restrict__ ok, uint32_t* __restrict__ oc) {
+  __shared__ uint32_t lh[64];
+  if (!WRITE) { if (threadIdx.x < 64) lh[threadIdx.x] = 0; __syncthreads(); }
+  const int lane = threadIdx.x & 63;
+  const uint64_t rounded = (n + 63) & ~63ULL;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += (uint64_t)gridDim.x * blockDim.x) {
+    const bool act = i < n;
+    const int o = act ? (int)owner[i] : -1;
+    if (!WRITE) { if (act) atomicAdd(&lh[o], 1u); continue; }
+    for (int r = 0; r < world; r++) {
+      const unsigned long long m = __ballot(act && o == r);
+      if (!m) continue;
+      const int leader = __ffsll((long long)m) - 1;
+      unsigned long long b = 0;
+      if (lane == leader) b = atomicAdd(&cursor[r], (unsigned long long)__popcll(m));
+      b = shfl_u64(b, leader);
+      if (act && o == r) { const uint64_t d = b + __popcll(m & ((1ULL << lane) - 1)); ok[d] = keys[i]; oc[d] = counts[i]; }
+    }
+  }
+  if (!WRITE) {
+    __syncthreads();
+    if (threadIdx.x < 64 && lh[threadIdx.x]) atomicAdd(&cursor[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
+  }
+}
+// the shard's (key, count) pairs grouped by owner rank (per_rank[r] pairs each, rank order) -- what the all-to-all sends
+extern "C" int shn_cc_shard(shn_cc* c, const void* dev_owner, uint64_t* per_rank, void* dev_keys_out, void* dev_counts_out) {
+  if (!c || !per_rank) return shn_fail(SHN_ERR_ARG, "shn_cc_shard: bad argument");
+  const uint64_t n = c->t->n;
+  for (int r = 0; r < c->world; r++) per_rank[r] = 0;
+  if (!n) return SHN_OK;
+  if (!dev_owner || !dev_keys_out || !dev_counts_out) return shn_fail(SHN_ERR_ARG, "shn_cc_shard: NULL buffer");
+  shn_ctx* ctx = c->ctx;
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(cdiv(n, 256), 1u << 16);
+  HIP_TRY(hipMemsetAsync(c->d_cnt, 0, 64 * 8, s));
+  hipLaunchKernelGGL((ccs_shard_kernel<false>), dim3(grid), dim3(256), 0, s, c->t->d_keys, c->t->d_counts, (const uint8_t*)dev_owner, n, c->world, c->d_cnt,
+                     (uint64_t*)nullptr, (uint32_t*)nullptr);
+  unsigned long long h[64], cur[64], a = 0;
+  HIP_TRY(hipMemcpyAsync(h, c->d_cnt, 64 * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (int r = 0; r < 64; r++) { cur[r] = a; if (r < c->world) { per_rank[r] = h[r]; a += h[r]; } }
+  HIP_TRY(hipMemcpyAsync(c->d_cnt, cur, 64 * 8, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL((ccs_shard_kernel<true>), dim3(grid), dim3(256), 0, s, c->t->d_keys, c->t->d_counts, (const uint8_t*)dev_owner, n, c->world, c->d_cnt,
+                     (uint64_t*)dev_keys_out, (uint32_t*)dev_counts_out);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(s));
+  return SHN_OK;
+}
+
 extern "C" void shn_ext_destroy(shn_ext* e) {
   if (!e) return;
   hipSetDevice(e->device);

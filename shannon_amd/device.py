@@ -240,6 +240,13 @@ class Table(object):
                                               C.c_void_p(dev_keys_ptr), C.c_void_p(dev_counts_ptr)))
         return per
 
+    def shard_by_minimizer(self, n_ranks, dev_keys_ptr, dev_counts_ptr):
+        """the pairs grouped by the rank that owns their minimizer (shn_table_shard_mode 1): the shards of shn_cc_*"""
+        per = np.zeros(n_ranks, dtype=np.uint64)
+        _lib.check(_lib.lib().shn_table_shard_mode(self.ctx.h, self.h, n_ranks, 1, per.ctypes.data_as(_lib.u64p),
+                                                   C.c_void_p(dev_keys_ptr), C.c_void_p(dev_counts_ptr)))
+        return per
+
     @classmethod
     def from_pairs(cls, ctx, dev_keys_ptr, dev_counts_ptr, n, k1, canonical):
         h = C.c_void_p()
@@ -250,6 +257,68 @@ class Table(object):
     def close(self):
         if self.h:
             _lib.lib().shn_table_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ComponentShards(object):
+    """Component labelling on owner shards (include/shannon_hip.h: shn_cc_*): the local components of the shard `table` of rank
+    `rank` of `world`.  Pointers are device pointers of the caller (torch tensors in distributed.py)."""
+
+    def __init__(self, ctx, table, world, rank):
+        self.ctx, self.table, self.world, self.rank = ctx, table, int(world), int(rank)
+        self.h = C.c_void_p()
+        _lib.check(_lib.lib().shn_cc_create(ctx.h, table.h, self.world, self.rank, C.byref(self.h)))
+
+    def _u64(self, values):
+        a = np.zeros(self.world, dtype=np.uint64)
+        a[:] = np.asarray(values, dtype=np.uint64)
+        return a
+
+    def query_counts(self):
+        per = np.zeros(self.world, dtype=np.uint64)
+        _lib.check(_lib.lib().shn_cc_query_counts(self.h, per.ctypes.data_as(_lib.u64p)))
+        return per
+
+    def queries(self, dev_keys_ptr, dev_labs_ptr):
+        _lib.check(_lib.lib().shn_cc_queries(self.h, C.c_void_p(dev_keys_ptr), C.c_void_p(dev_labs_ptr)))
+
+    def answer(self, dev_keys_ptr, dev_labs_ptr, recv_per_rank, base, dev_edges_ptr):
+        rp, b = self._u64(recv_per_rank), self._u64(base)
+        n = C.c_uint64(0)
+        _lib.check(_lib.lib().shn_cc_answer(self.h, C.c_void_p(dev_keys_ptr), C.c_void_p(dev_labs_ptr), rp.ctypes.data_as(_lib.u64p),
+                                            b.ctypes.data_as(_lib.u64p), C.c_void_p(dev_edges_ptr), C.byref(n)))
+        return int(n.value)
+
+    @staticmethod
+    def solve(ctx, dev_edges_ptr, n_edges, id_limit, dev_nodes_ptr, dev_labels_ptr):
+        n = C.c_uint64(0)
+        _lib.check(_lib.lib().shn_cc_solve(ctx.h, C.c_void_p(dev_edges_ptr), int(n_edges), int(id_limit), C.c_void_p(dev_nodes_ptr),
+                                           C.c_void_p(dev_labels_ptr), C.byref(n)))
+        return int(n.value)
+
+    def labels(self, base_me, dev_nodes_ptr, dev_labels_ptr, n_nodes, dev_glabel_ptr):
+        _lib.check(_lib.lib().shn_cc_labels(self.h, int(base_me), C.c_void_p(dev_nodes_ptr), C.c_void_p(dev_labels_ptr), int(n_nodes),
+                                            C.c_void_p(dev_glabel_ptr)))
+
+    def owners(self, dev_glabel_ptr, dev_big_ptr, dev_big_owner_ptr, n_big, dev_owner_ptr):
+        _lib.check(_lib.lib().shn_cc_owners(self.h, C.c_void_p(dev_glabel_ptr), C.c_void_p(dev_big_ptr), C.c_void_p(dev_big_owner_ptr),
+                                            int(n_big), C.c_void_p(dev_owner_ptr)))
+
+    def shard(self, dev_owner_ptr, dev_keys_ptr, dev_counts_ptr):
+        per = np.zeros(self.world, dtype=np.uint64)
+        _lib.check(_lib.lib().shn_cc_shard(self.h, C.c_void_p(dev_owner_ptr), per.ctypes.data_as(_lib.u64p), C.c_void_p(dev_keys_ptr),
+                                           C.c_void_p(dev_counts_ptr)))
+        return per
+
+    def close(self):
+        if self.h:
+            _lib.lib().shn_cc_destroy(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):

@@ -124,6 +124,25 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
         table = ops.local_table()
         tick("count", t0)
         gk = None
+    elif getattr(ops, "owner_labelling", False):
+        # No rank ever holds the whole table (BASELINE configs[4]): the k1-mers go to the rank that owns their minimizer, the components
+        # of the k1-mer graph are labelled on those shards (local union-find + one exchange of the edges that cross shards), and whole
+        # components travel to the rank that walks them -- a table of its own per rank, the unsharded extension on it.
+        keys, counts, send = ops.local_pairs(W, by_minimizer=True)
+        tick("count", t0)
+        lock.release()
+        t0 = time.time()
+        rk, rc, _ = exchange.all_to_all_pairs(keys, counts, send, group)
+        del keys, counts
+        tick("x:bucket exchange", t0)
+        lock.acquire()
+        t0 = time.time()
+        owned = ops.owned_table(rk, rc)
+        del rk, rc
+        tick("reduce", t0)
+        table, n_table = ops.component_table(owned, group, tick)
+        gk = None
+        t0 = time.time()
     else:
         keys, counts, send = ops.local_pairs(W)
         tick("count", t0)
@@ -146,8 +165,11 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
         table = ops.table_from_pairs(gk, gc)
         tick("table", t0)
     t0 = time.time()
-    n_table = len(table) if gk is None else None
-    res = ops.extension(table, partition_size, group) if getattr(ops, "sharded_extension", False) else ops.extension(table, partition_size)
+    if W > 1 and getattr(ops, "owner_labelling", False):
+        res = ops.extension(table, partition_size, group, presharded=n_table)
+    else:
+        n_table = len(table) if gk is None else None
+        res = ops.extension(table, partition_size, group) if getattr(ops, "sharded_extension", False) else ops.extension(table, partition_size)
     if n_table is not None:
         res.n_k1mers_table = n_table
     tick("extension", t0)
@@ -384,14 +406,133 @@ class GpuOps(object):
             return self._dev.count_k1mers_strand_specific(self.ctx, self.d1, self.d2, self.K + 1)
         return self._dev.count_k1mers(self.ctx, [self.d1, self.d2] if self.paired else [self.d1], self.K + 1, True)
 
-    def local_pairs(self, W):
+    @property
+    def owner_labelling(self):
+        """components labelled on the owner shards, no replicated table (SHN_OWNER_LABELS=0: the table all-gathered to every rank and
+        labelled there -- the path of rounds 2-4, kept for comparison)"""
+        import os
+        return os.environ.get("SHN_OWNER_LABELS", "1") != "0"
+
+    def local_pairs(self, W, by_minimizer=False):
         t = self._count()
         n = len(t)
         dk = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
         dc = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
-        per = t.shard(W, dk.data_ptr(), dc.data_ptr())
+        per = (t.shard_by_minimizer if by_minimizer else t.shard)(W, dk.data_ptr(), dc.data_ptr())
         t.close()
         return dk, dc, per
+
+    def owned_table(self, rk, rc):
+        """the pairs this rank owns, equal keys summed"""
+        torch.cuda.synchronize()
+        return self._dev.Table.from_pairs(self.ctx, rk.data_ptr(), rc.data_ptr(), rk.numel(), self.K + 1, not self.strand_specific)
+
+    def component_table(self, owned, group, tick):
+        """owned: this rank's shard of the k1-mers (by minimizer).  Returns (a table of the whole components dealt to this rank,
+        the number of k1-mers of the job).  include/shannon_hip.h: shn_cc_*; collectives: the sizes of the shards, the queries
+        (all-to-all by owner), the edges between shards (all-gather), the sizes of the large components, the pairs (all-to-all)."""
+        import time
+        W, rank = dist.get_world_size(group), dist.get_rank(group)
+        lock = getattr(self, "lock", None) or _NoLock()
+        dev, cdev = self.device, exchange.coll_device(self.device, group)
+        t0 = time.time()
+        n_loc = len(owned)
+        cc = self._dev.ComponentShards(self.ctx, owned, W, rank)
+        try:
+            per = cc.query_counts()
+            nq = int(per.sum())
+            qk = torch.empty(max(nq, 1), dtype=torch.int64, device=dev)
+            ql = torch.empty(max(nq, 1), dtype=torch.int32, device=dev)
+            cc.queries(qk.data_ptr(), ql.data_ptr())
+            tick("labels: local components + queries", t0)
+            lock.release()
+            t0 = time.time()
+            nt = torch.tensor([n_loc], dtype=torch.int64, device=cdev)
+            nts = [torch.zeros_like(nt) for _ in range(W)]
+            dist.all_gather(nts, nt, group=group)
+            sizes = [int(x.item()) for x in nts]
+            base = [sum(sizes[:r]) for r in range(W)]
+            n_glob = sum(sizes)
+            rk, rl, rcl = exchange.all_to_all_pairs(qk, ql, per, group, name="component labelling: neighbour queries to the owners (all-to-all)")
+            del qk, ql
+            tick("x:label queries", t0)
+            lock.acquire()
+            t0 = time.time()
+            torch.cuda.synchronize()
+            n_in = int(sum(rcl))
+            edges = torch.empty(2 * max(n_in, 1), dtype=torch.int64, device=dev)
+            ne = cc.answer(rk.data_ptr(), rl.data_ptr(), rcl, base, edges.data_ptr())
+            del rk, rl
+            tick("labels: answers", t0)
+            lock.release()
+            t0 = time.time()
+            ge, _ = _all_gather_var(edges[:2 * ne], group, name="component labelling: edges between shards (all-gather)")
+            del edges
+            tick("x:label edges", t0)
+            lock.acquire()
+            t0 = time.time()
+            torch.cuda.synchronize()
+            E = int(ge.numel()) // 2
+            nodes = torch.empty(2 * max(E, 1), dtype=torch.int64, device=dev)
+            labels = torch.empty(2 * max(E, 1), dtype=torch.int64, device=dev)
+            nn = cc.solve(self.ctx, ge.data_ptr(), E, n_glob + 1, nodes.data_ptr(), labels.data_ptr())
+            del ge
+            glabel = torch.empty(max(n_loc, 1), dtype=torch.int64, device=dev)
+            cc.labels(base[rank], nodes.data_ptr(), labels.data_ptr(), nn, glabel.data_ptr())
+            del nodes, labels
+            # the large components are balanced by size (largest first onto the least loaded rank, as shn_extend_sharded does on a
+            # replicated table); everything else goes by the hash of its label.  A component of T k1-mers spread evenly has T / W of them
+            # here: every rank reports what it holds of components above a quarter of that, every rank sums the same reports.
+            T = max(1024, n_glob // (64 * W))
+            report = max(32, T // (4 * W))
+            torch.cuda.synchronize()
+            u, c = torch.unique(glabel[:n_loc], return_counts=True)
+            sel = c >= report
+            mine = (u[sel].cpu().numpy(), c[sel].cpu().numpy())
+            tick("labels: component graph", t0)
+            lock.release()
+            t0 = time.time()
+            parts = exchange.all_gather_object(mine, group, "component labelling: sizes of the large components")
+            tick("x:label sizes", t0)
+            lock.acquire()
+            t0 = time.time()
+            tot = {}
+            for lab, cnt in parts:
+                for a, b in zip(lab.tolist(), cnt.tolist()):
+                    tot[a] = tot.get(a, 0) + b
+            big = sorted((a for a, b in tot.items() if b >= T // 2), key=lambda a: (-tot[a], a))
+            load = [0] * W
+            own = {}
+            for a in big:
+                r = min(range(W), key=lambda q: (load[q], q))
+                own[a] = r
+                load[r] += tot[a]
+            bl = sorted(own)
+            dbig = torch.as_tensor(np.asarray(bl if bl else [0], dtype=np.int64), device=dev)
+            dbo = torch.as_tensor(np.asarray([own[a] for a in bl] if bl else [0], dtype=np.uint8), device=dev)
+            owner = torch.empty(max(n_loc, 1), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            cc.owners(glabel.data_ptr(), dbig.data_ptr(), dbo.data_ptr(), len(bl), owner.data_ptr())
+            del glabel
+            sk = torch.empty(max(n_loc, 1), dtype=torch.int64, device=dev)
+            sc = torch.empty(max(n_loc, 1), dtype=torch.int32, device=dev)
+            send = cc.shard(owner.data_ptr(), sk.data_ptr(), sc.data_ptr())
+            del owner
+        finally:
+            cc.close()
+        owned.close()
+        tick("labels: owners + shard", t0)
+        lock.release()
+        t0 = time.time()
+        rk, rc, _ = exchange.all_to_all_pairs(sk, sc, send, group, name="component exchange (the k1-mers of whole components to their rank, all-to-all)")
+        del sk, sc
+        tick("x:component exchange", t0)
+        lock.acquire()
+        t0 = time.time()
+        torch.cuda.synchronize()
+        table = self._dev.Table.from_pairs(self.ctx, rk.data_ptr(), rc.data_ptr(), rk.numel(), self.K + 1, not self.strand_specific)
+        tick("table", t0)
+        return table, n_glob
 
     def local_table(self):
         """one-rank job: the counted table itself (no export to pairs)"""
@@ -424,9 +565,11 @@ class GpuOps(object):
                 and os.environ.get("SHN_GRAPH_ROWS", "1") != "0")
     array_payload = True               # collect() returns (code rows, strand flags): travels as bytes, not as pickles
 
-    def extension(self, table, partition_size, group=None):
+    def extension(self, table, partition_size, group=None, presharded=None):
         """replicated table -> walks AND contig stages sharded by connected component of the k1-mer graph; the accepted
-        contigs + their connections (a few MB) are all-gathered and merged in the global walk order"""
+        contigs + their connections (a few MB) are all-gathered and merged in the global walk order.
+        presharded = the number of k1-mers of the job: `table` holds the whole components dealt to this rank already (component_table);
+        the walks are the unsharded ones on it, everything after them as before."""
         import time
         from . import extension_correction as ec
         W, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -459,9 +602,11 @@ class GpuOps(object):
         # (a large, diverse table -- BASELINE configs[2] and beyond: 10^8+ k1-mers, 10^5+ candidate contigs -- takes the path
         # "sharded walks + one replicated GPU contig stage" inside run_correction; a few deep gene families per rank -- the
         # weak-scaling workload, 5 M k1-mers per family -- keep their contig stages sharded too: SHN_CONTIG_GPU=1 / 0 forces either)
-        res = ec.run_correction(self.ctx, table, 3, 75, partition_size, want_allowed=False, shard=(W, rank), gather=Gather,
-                                timings=getattr(self, "timings", None))
+        res = ec.run_correction(self.ctx, table, 3, 75, partition_size, want_allowed=False, shard=None if presharded is not None else (W, rank),
+                                gather=Gather, timings=getattr(self, "timings", None), table_size=presharded)
         table.close()
+        if presharded is not None:
+            res.n_k1mers_table = int(presharded)
         return res
 
     def route(self, res, K, partition_size, part_vectors):

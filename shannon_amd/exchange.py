@@ -93,6 +93,37 @@ def owner_of(keys, world):
         return (fmix64_np(np.asarray(keys, dtype=np.uint64) ^ np.uint64(SHARD_SALT)) % np.uint64(world)).astype(np.int64)
 
 
+OWNER_M = 13
+OWNER_SALT = 0x6A09E667F3BCC909
+
+
+def owner_of_minimizer(keys, k, canonical, world):
+    """Host mirror of shn_owner_minimizer() in csrc/common.h: the rank that owns a k-mer = hash of the order value of its minimizer
+    (the m-mer, m = min(13, k), of smallest murmur3-finalised value among its (canonical) m-mers) mod world.  Tests and planners."""
+    keys = np.asarray(keys, dtype=np.uint64)
+    m = min(OWNER_M, int(k))
+    mmask = np.uint64((1 << (2 * m)) - 1)
+    best = np.full(len(keys), 0xFFFFFFFF, dtype=np.uint64)
+    M32 = np.uint64(0xFFFFFFFF)
+    for i in range(k - m + 1):
+        f = (keys >> np.uint64(2 * (k - m - i))) & mmask
+        c = f
+        if canonical:
+            r = np.zeros_like(f)
+            x = f.copy()
+            for _ in range(m):
+                r = (r << np.uint64(2)) | (np.uint64(3) - (x & np.uint64(3)))
+                x >>= np.uint64(2)
+            c = np.minimum(f, r)
+        x = c & M32
+        x ^= x >> np.uint64(16); x = (x * np.uint64(0x85ebca6b)) & M32
+        x ^= x >> np.uint64(13); x = (x * np.uint64(0xc2b2ae35)) & M32
+        x ^= x >> np.uint64(16)
+        best = np.minimum(best, x)
+    with np.errstate(over="ignore"):
+        return (fmix64_np(best ^ np.uint64(OWNER_SALT)) % np.uint64(world)).astype(np.int64)
+
+
 def coll_device(dev, group=None):
     """Where the tensors of a collective live: on their own device with RCCL ("nccl"), in host memory with gloo
     (CPU tests, and GPU tests in which several ranks share one GPU -- RCCL refuses two ranks on one device)."""

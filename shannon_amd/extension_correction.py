@@ -478,7 +478,7 @@ def foreign_interference(ctx, local, acc, best_count, foreign, r=15, f=0.5):
 
 
 def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=500, r=15, f=0.5, want_allowed=True, timings=None,
-                   shard=None, merge=None, gather=None):
+                   shard=None, merge=None, gather=None, table_size=None):
     """extension_correction.run_correction (extension_correction.py:309-524) on a device k1-mer
     table.  Returns an ExtensionResult: contigs, allowed {k1mer: int}, connections, components,
     single_contigs, big_components [(contigs, metis_text)], remaining [[contig...]].
@@ -487,7 +487,9 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     gather (instead of merge): an object with .world, .rank, .all_gather(obj) -> [obj per rank], .all_reduce_max(int): the
     contig stages are sharded as well -- every rank decides its own candidates, a GPU r-mer join against the other shards'
     accepted contigs proves that none of them could have changed a duplicate_check decision (foreign_interference), else all
-    ranks fall back to the global sequential pass."""
+    ranks fall back to the global sequential pass.
+    table_size: the number of k1-mers of the JOB when `table` is this rank's share of it already (whole components: shard = None
+    with a gather) -- the choice between the contig stages must be the same on every rank."""
     import time as _t
     T = timings if timings is not None else {}
     _t0 = [_t.time()]
@@ -507,7 +509,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     # Large tables (BASELINE configs[2]: 20,000 genes, several 10^5 candidate contigs): the contig stage runs after the walks with
     # its sorts on the GPU (contig_stage_gpu) instead of beside them on one host thread.  SHN_CONTIG_GPU=1 / 0 forces / forbids it.
     _cg = os.environ.get("SHN_CONTIG_GPU", "")
-    big = _cg == "1" or (_cg != "0" and len(table) >= 20_000_000)
+    big = _cg == "1" or (_cg != "0" and (len(table) if table_size is None else int(table_size)) >= 20_000_000)
     gpu_contigs = merge is None and (gather is None or gather.world <= 1) and big
     # ... and on several ranks: the walks sharded by connected component, the candidates of all shards gathered (0.3 GB at BASELINE
     # configs[2]) and merged into the global seed order on every rank, ONE replicated GPU contig stage over them -- instead of every

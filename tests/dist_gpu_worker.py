@@ -27,9 +27,11 @@ def main():
     d1 = device.Reads.from_codes(ctx, q1)
     d2 = device.Reads.from_codes(ctx, q2) if paired else None
     ops = distributed.GpuOps(ctx, d1, d2, kfc.ReadStore(q1, q2), 25)
-    res = distributed.assemble_distributed(ops, 25, 500, "t", 1, double_stranded=not ss)
+    T = {}
+    res = distributed.assemble_distributed(ops, 25, 500, "t", 1, double_stranded=not ss, timings=T)
     if rank == 0:
-        json.dump({"partitions": dict(res["partitions"]), "final": res["final"], "contigs": res["contigs"]}, open(out, "w"))
+        json.dump({"partitions": dict(res["partitions"]), "final": res["final"], "contigs": res["contigs"], "timings": T,
+                   "n_k1mers": res["n_k1mers"]}, open(out, "w"))
     dist.barrier()
     d1.close()
     if d2 is not None:

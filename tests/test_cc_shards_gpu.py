@@ -1,0 +1,231 @@
+"""Component labelling on owner shards (include/shannon_hip.h: shn_cc_*, the N-rank path without a replicated table).
+The W ranks are played one after the other in ONE process (the exchange between them is done by hand on the tensors): the labels
+must partition the k1-mers exactly as the connected components of the k1-mer graph do -- restated here in numpy + scipy from the
+rule of the labelling kernel (extension_correction.py:202-245, 372-390: adjacent k1-mers, and k1-mers that share a K-mer at the
+same end, both not low-complexity) -- and the component exchange must give every rank whole components."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rc(keys, k):
+    out = np.zeros_like(keys)
+    x = keys.copy()
+    for _ in range(k):
+        out = (out << np.uint64(2)) | (np.uint64(3) - (x & np.uint64(3)))
+        x >>= np.uint64(2)
+    return out
+
+
+def _low_complexity(keys, k):
+    cnt = np.zeros((4, len(keys)), dtype=np.int64)
+    x = keys.copy()
+    for _ in range(k):
+        b = (x & np.uint64(3)).astype(np.int64)
+        for v in range(4):
+            cnt[v] += b == v
+        x >>= np.uint64(2)
+    return cnt.max(axis=0) >= k - 2
+
+
+def reference_labels(keys, k, canonical):
+    """component number of every key (keys: distinct, any order)"""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    order = np.argsort(keys)
+    sk = keys[order]
+    alive = ~_low_complexity(sk, k)
+    mask = np.uint64((1 << (2 * k)) - 1) if k < 32 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    src, dst = [], []
+    sh = np.uint64(2 * (k - 1))
+    for which in range(16):
+        b = np.uint64(which & 3)
+        if which < 4:
+            y = ((sk << np.uint64(2)) | b) & mask
+            ok = alive.copy()
+        elif which < 8:
+            y = (sk >> np.uint64(2)) | (b << sh)
+            ok = alive.copy()
+        elif which < 12:                                             # siblings: the same K-prefix, another last base
+            y = (sk & ~np.uint64(3)) | b
+            ok = alive & ((sk & np.uint64(3)) != b)
+        else:                                                        # ... the same K-suffix, another first base
+            y = (sk & ~(np.uint64(3) << sh)) | (b << sh)
+            ok = alive & (((sk >> sh) & np.uint64(3)) != b)
+        if canonical:
+            r = _rc(y, k)
+            y = np.minimum(y, r)
+        pos = np.searchsorted(sk, y)
+        pos = np.minimum(pos, len(sk) - 1)
+        hit = ok & (sk[pos] == y) & alive[pos]
+        src.append(np.nonzero(hit)[0])
+        dst.append(pos[hit])
+    src, dst = np.concatenate(src), np.concatenate(dst)
+    n = len(sk)
+    _, lab = connected_components(coo_matrix((np.ones(len(src), dtype=np.int8), (src, dst)), shape=(n, n)), directed=False)
+    out = np.empty(n, dtype=np.int64)
+    out[order] = lab
+    return out
+
+
+def same_partition(a, b):
+    pairs = np.unique(np.stack([a, b], axis=1), axis=0)
+    return len(pairs) == len(np.unique(a)) == len(np.unique(b))
+
+
+def play_ranks(ctx, table, W, K1, canonical):
+    """the whole exchange with W ranks in one process.  Returns per rank (keys of the shard in table order, their global labels,
+    (keys, counts) received after the component exchange)."""
+    import torch
+    from shannon_amd import device
+    dev = torch.device("cuda", 0)
+    n = len(table)
+    dk = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    dc = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    per = table.shard_by_minimizer(W, dk.data_ptr(), dc.data_ptr()).astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(per)])
+    shards, ccs = [], []
+    for r in range(W):
+        torch.cuda.synchronize()
+        t = device.Table.from_pairs(ctx, dk[off[r]:].data_ptr(), dc[off[r]:].data_ptr(), int(per[r]), K1, canonical)
+        assert len(t) == per[r]
+        shards.append(t)
+        ccs.append(device.ComponentShards(ctx, t, W, r))
+    sizes = [len(t) for t in shards]
+    base = [sum(sizes[:r]) for r in range(W)]
+    # queries of every rank, grouped by destination
+    sent = []
+    for r in range(W):
+        pq = ccs[r].query_counts().astype(np.int64)
+        assert pq[:r + 1].sum() == 0                                 # only higher ranks are asked
+        qk = torch.empty(max(int(pq.sum()), 1), dtype=torch.int64, device=dev)
+        ql = torch.empty(max(int(pq.sum()), 1), dtype=torch.int32, device=dev)
+        ccs[r].queries(qk.data_ptr(), ql.data_ptr())
+        sent.append((pq, np.concatenate([[0], np.cumsum(pq)]), qk, ql))
+    all_edges = []
+    for d in range(W):
+        rcl = [int(sent[s][0][d]) for s in range(W)]
+        rk = torch.cat([sent[s][2][sent[s][1][d]:sent[s][1][d + 1]] for s in range(W)] + [torch.empty(0, dtype=torch.int64, device=dev)])
+        rl = torch.cat([sent[s][3][sent[s][1][d]:sent[s][1][d + 1]] for s in range(W)] + [torch.empty(0, dtype=torch.int32, device=dev)])
+        edges = torch.empty(2 * max(sum(rcl), 1), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        ne = ccs[d].answer(rk.data_ptr(), rl.data_ptr(), rcl, base, edges.data_ptr())
+        all_edges.append(edges[:2 * ne].clone())
+    ge = torch.cat(all_edges)
+    E = ge.numel() // 2
+    nodes = torch.empty(2 * max(E, 1), dtype=torch.int64, device=dev)
+    labels = torch.empty(2 * max(E, 1), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    nn = device.ComponentShards.solve(ctx, ge.data_ptr(), E, sum(sizes) + 1, nodes.data_ptr(), labels.data_ptr())
+    # the same from the edges in another order: the answer must not depend on it
+    if E > 1:
+        perm = torch.randperm(E, device=dev)
+        ge2 = ge.view(E, 2)[perm].flip(1).contiguous().view(-1)
+        nodes2, labels2 = torch.empty_like(nodes), torch.empty_like(labels)
+        torch.cuda.synchronize()
+        nn2 = device.ComponentShards.solve(ctx, ge2.data_ptr(), E, 0, nodes2.data_ptr(), labels2.data_ptr())
+        assert nn2 == nn and torch.equal(nodes[:nn], nodes2[:nn]) and torch.equal(labels[:nn], labels2[:nn])
+    out = []
+    glabels = []
+    for r in range(W):
+        gl = torch.empty(max(sizes[r], 1), dtype=torch.int64, device=dev)
+        ccs[r].labels(base[r], nodes.data_ptr(), labels.data_ptr(), nn, gl.data_ptr())
+        glabels.append(gl)
+    # owners: two of the components pinned to ranks by the caller, the rest by hash
+    torch.cuda.synchronize()
+    allg = torch.cat([glabels[r][:sizes[r]] for r in range(W)])
+    u, c = torch.unique(allg, return_counts=True)
+    top = u[torch.argsort(c, descending=True)[:2]].cpu().numpy()
+    big = np.sort(top).astype(np.int64)
+    big_owner = np.array([(W - 1 - i) % W for i in range(len(big))], dtype=np.uint8)
+    dbig = torch.as_tensor(big if len(big) else np.zeros(1, np.int64), device=dev)
+    dbo = torch.as_tensor(big_owner if len(big) else np.zeros(1, np.uint8), device=dev)
+    recv = [[] for _ in range(W)]
+    for r in range(W):
+        owner = torch.empty(max(sizes[r], 1), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        ccs[r].owners(glabels[r].data_ptr(), dbig.data_ptr(), dbo.data_ptr(), len(big), owner.data_ptr())
+        sk = torch.empty(max(sizes[r], 1), dtype=torch.int64, device=dev)
+        sc = torch.empty(max(sizes[r], 1), dtype=torch.int32, device=dev)
+        send = ccs[r].shard(owner.data_ptr(), sk.data_ptr(), sc.data_ptr()).astype(np.int64)
+        assert send.sum() == sizes[r]
+        so = np.concatenate([[0], np.cumsum(send)])
+        torch.cuda.synchronize()
+        for d in range(W):
+            recv[d].append((sk[so[d]:so[d + 1]].cpu().numpy().view(np.uint64), sc[so[d]:so[d + 1]].cpu().numpy().view(np.uint32)))
+        ow = owner[:sizes[r]].cpu().numpy()
+        gl = glabels[r][:sizes[r]].cpu().numpy()
+        for i, b in enumerate(big):
+            assert (ow[gl == b] == big_owner[i]).all()
+        keys, _ = shards[r].download()
+        out.append((keys, gl, ow))
+    for r in range(W):
+        ccs[r].close()
+        shards[r].close()
+    got = [(np.concatenate([k for k, _ in recv[d]]), np.concatenate([c for _, c in recv[d]])) for d in range(W)]
+    return out, got
+
+
+@pytest.mark.parametrize("W,n_genes,seed,K,ss", [(2, 3, 11, 25, False), (3, 12, 4, 25, False), (4, 40, 8, 24, False), (8, 12, 5, 31, False),
+                                                 (3, 12, 4, 25, True), (5, 1, 3, 20, False)])
+def test_labels_of_the_shards_are_the_components(W, n_genes, seed, K, ss):
+    from shannon_amd import device, synth
+    (q1, q2), _ = synth.make_dataset(12000, n_genes, seed=seed)
+    ctx = device.Context(0)
+    d1, d2 = device.Reads.from_codes(ctx, q1), device.Reads.from_codes(ctx, q2)
+    try:
+        if ss:
+            table = device.count_k1mers_strand_specific(ctx, d1, d2, K + 1)
+        else:
+            table = device.count_k1mers(ctx, [d1, d2], K + 1, True)
+        canonical = table.canonical
+        assert canonical == (not ss)
+        tk, tc = table.download()
+        out, got = play_ranks(ctx, table, W, K + 1, canonical)
+        keys = np.concatenate([o[0] for o in out])
+        gl = np.concatenate([o[1] for o in out])
+        ow = np.concatenate([o[2] for o in out])
+        assert len(keys) == len(tk) and np.array_equal(np.sort(keys), np.sort(tk))            # the shards partition the table
+        ref = reference_labels(keys, K + 1, canonical)
+        assert len(np.unique(ref)) > 1 or n_genes == 1               # (one gene at K = 20: its errors hang on it as siblings -- one component)
+        assert same_partition(gl, ref)
+        # a component lives on one rank after the exchange, with every k1-mer and count of it
+        pairs = np.unique(np.stack([gl, ow.astype(np.int64)], axis=1), axis=0)
+        assert len(pairs) == len(np.unique(gl))
+        want = dict(zip(tk.tolist(), tc.tolist()))
+        seen = 0
+        for d, (k, c) in enumerate(got):
+            assert np.array_equal(np.sort(k), np.sort(keys[ow == d]))
+            assert all(want[a] == b for a, b in zip(k.tolist(), c.tolist()))
+            seen += len(k)
+        assert seen == len(tk)
+        table.close()
+    finally:
+        d1.close()
+        d2.close()
+        ctx.close()
+
+
+def test_shard_rule_mirror():
+    """the host mirror of the owner rule (exchange.owner_of_minimizer) against the device's shards"""
+    import torch
+    from shannon_amd import device, synth, exchange
+    (q1, q2), _ = synth.make_dataset(6000, 4, seed=2)
+    ctx = device.Context(0)
+    d1 = device.Reads.from_codes(ctx, q1)
+    try:
+        for K1, both in ((26, True), (21, True), (32, True), (26, False)):
+            table = device.count_k1mers(ctx, [d1], K1, both)
+            n = len(table)
+            for W in (2, 5, 8):
+                dk = torch.empty(n, dtype=torch.int64, device="cuda")
+                dc = torch.empty(n, dtype=torch.int32, device="cuda")
+                per = table.shard_by_minimizer(W, dk.data_ptr(), dc.data_ptr()).astype(np.int64)
+                keys = dk.cpu().numpy().view(np.uint64)
+                own = exchange.owner_of_minimizer(keys, K1, table.canonical, W)
+                assert np.array_equal(own, np.repeat(np.arange(W), per))
+            table.close()
+    finally:
+        d1.close()
+        ctx.close()

@@ -55,6 +55,18 @@ def test_distributed_path_matches_single_process(group, paired, n_genes, seed):
                                                                    (2, True, 12, 4, 29628, False, True), (3, False, 6, 5, 29629, False, True),     # -s / --strand_specific
                                                                    (2, True, 40, 8, 29630, True, True)])
 def test_ranks_sharing_one_gpu_equal_single_process(world, paired, n_genes, seed, port, big, ss, tmp_path):
+    _ranks_vs_single(world, paired, n_genes, seed, port, big, ss, tmp_path, {})
+
+
+@pytest.mark.parametrize("world,paired,n_genes,seed,port,big,ss", [(3, True, 12, 4, 29641, False, False), (2, True, 40, 8, 29642, True, False),
+                                                                   (2, True, 12, 4, 29643, False, True)])
+def test_replicated_table_path_equals_single_process(world, paired, n_genes, seed, port, big, ss, tmp_path):
+    """SHN_OWNER_LABELS=0: the path of rounds 2-4 -- the table all-gathered to every rank and labelled there -- kept as the
+    comparison for the default (components labelled on the owner shards, no rank holds the whole table)."""
+    _ranks_vs_single(world, paired, n_genes, seed, port, big, ss, tmp_path, {"SHN_OWNER_LABELS": "0"})
+
+
+def _ranks_vs_single(world, paired, n_genes, seed, port, big, ss, tmp_path, env_extra):
     """world_size > 1 with the product's per-rank compute (GpuOps): every rank holds a slice of the reads and runs its HIP
     kernels on cuda:0; the collectives go through gloo (RCCL does not take two ranks on one device).  Covers the sharded
     walks + sharded contig stages, the capped read exchange and partition ownership against the single-process result.
@@ -66,7 +78,7 @@ def test_ranks_sharing_one_gpu_equal_single_process(world, paired, n_genes, seed
     from shannon_amd import device, synth, pipeline, kmers_for_component as kfc
     n_pairs = 12000
     out = str(tmp_path / "res.json")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **env_extra)
     if big:
         env["SHN_CONTIG_GPU"] = "1"
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
@@ -75,6 +87,8 @@ def test_ranks_sharing_one_gpu_equal_single_process(world, paired, n_genes, seed
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:]
     got = json.load(open(out))
+    if env_extra.get("SHN_OWNER_LABELS") != "0":
+        assert "x:component exchange" in got.get("timings", {}), sorted(got.get("timings", {}))       # the default path ran
     (q1, q2), _ = synth.make_dataset(n_pairs, n_genes, seed=seed)
     if not paired:
         q1, q2 = np.concatenate([q1, q2]), None
