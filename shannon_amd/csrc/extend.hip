@@ -1549,9 +1549,12 @@ static int build_fine_dict(shn_ctx* ctx, const shn_table* t, const uint8_t* d_fl
 struct shn_cc {
   shn_ctx* ctx; const shn_table* t; int world, rank, device;
   uint8_t* d_flags; uint32_t* d_lab;
-  unsigned long long* d_cnt;          // 64 cursors + 64 bases
+  unsigned long long* d_cnt;          // 64 totals + 64 bases
+  uint32_t* d_bc; uint64_t* d_pos;    // per (rank, block): how many entries the block has for the rank, and where they go (see cc_query_kernel)
+  uint32_t q_grid;
   uint64_t per_rank[64];
 };
+#define CC_GRID 2048                  // blocks of the passes that group entries by rank (count pass and write pass have the same shape)
 
 // key number `which` = 8 * half + p of the k1-mer str (see cc_edges_kernel): half 0 = its eight neighbours, half 1 = its siblings
 __device__ __forceinline__ uint64_t cc_which_key(uint64_t str, int p, int half, int k, uint64_t mask, int canonical, bool* skip) {
@@ -1565,47 +1568,46 @@ __device__ __forceinline__ uint64_t cc_which_key(uint64_t str, int p, int half, 
   return key;
 }
 
-// WRITE = false: how many queries go to every rank; true: the queries, grouped by rank (cursor = where every group begins)
+// WRITE = false: how many queries this block has for every rank (block_count[rank * blocks + block]; the totals into `total`);
+// true: the queries, grouped by rank -- pos = the exclusive scan of block_count, an LDS cursor per rank inside the block.  The two
+// passes have the same launch shape.  (One HBM cursor per rank, wave-aggregated, took 292 ms for 64 M queries: every wavefront of
+// the launch on the same three addresses.)
 template <bool WRITE>
 __global__ void cc_query_kernel(const uint64_t* __restrict__ tkeys, const uint8_t* __restrict__ flags, uint64_t n, int k, int canonical,
-                                int world, int rank, const uint32_t* __restrict__ lab, unsigned long long* __restrict__ cursor,
+                                int world, int rank, const uint32_t* __restrict__ lab, unsigned long long* __restrict__ total,
+                                uint32_t* __restrict__ block_count, const uint64_t* __restrict__ pos,
                                 uint64_t* __restrict__ qk, uint32_t* __restrict__ ql) {
   __shared__ uint32_t lh[64];
-  if (!WRITE) { if (threadIdx.x < 64) lh[threadIdx.x] = 0; __syncthreads(); }
+  __shared__ uint64_t lbase[64];
+  if (threadIdx.x < 64) {
+    lh[threadIdx.x] = 0;
+    if (WRITE) lbase[threadIdx.x] = (int)threadIdx.x < world ? pos[(uint64_t)threadIdx.x * gridDim.x + blockIdx.x] : 0;
+  }
+  __syncthreads();
   const uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
-  const uint64_t total = n * 8, rounded = (total + 63) & ~63ULL;
-  const int lane = threadIdx.x & 63, p = lane & 7;
-  for (uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < rounded; gid += (uint64_t)gridDim.x * blockDim.x) {
-    const bool in = gid < total;
-    const uint64_t i = in ? gid >> 3 : 0;
-    const bool dead = !in || (flags[i] & 2);
+  const uint64_t total_items = n * 8;
+  for (uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total_items; gid += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t i = gid >> 3;
+    const int p = (int)(gid & 7);
+    if (flags[i] & 2) continue;
     const uint64_t str = tkeys[i];
 #pragma unroll
     for (int half = 0; half < 2; half++) {
       bool skip;
       const uint64_t key = cc_which_key(str, p, half, k, mask, canonical, &skip);
-      const int dest = (dead || skip) ? -1 : (int)shn_owner_minimizer(key, k, canonical, world);
-      const bool want = dest > rank;
-      if (!WRITE) { if (want) atomicAdd(&lh[dest], 1u); continue; }
-      const unsigned long long any = __ballot(want);
-      if (!any) continue;
-      for (int r = rank + 1; r < world; r++) {
-        const unsigned long long m = __ballot(want && dest == r);
-        if (!m) continue;
-        const int leader = __ffsll((long long)m) - 1;
-        unsigned long long base = 0;
-        if (lane == leader) base = atomicAdd(&cursor[r], (unsigned long long)__popcll(m));
-        base = shfl_u64(base, leader);
-        if (want && dest == r) {
-          const uint64_t d = base + __popcll(m & ((1ULL << lane) - 1));
-          qk[d] = key; ql[d] = lab[i];
-        }
-      }
+      if (skip) continue;
+      const int dest = (int)shn_owner_minimizer(key, k, canonical, world);
+      if (dest <= rank) continue;
+      const uint32_t at = atomicAdd(&lh[dest], 1u);
+      if (WRITE) { const uint64_t d = lbase[dest] + at; qk[d] = key; ql[d] = lab[i]; }
     }
   }
   if (!WRITE) {
     __syncthreads();
-    if (threadIdx.x < 64 && lh[threadIdx.x]) atomicAdd(&cursor[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
+    if ((int)threadIdx.x < world) {
+      block_count[(uint64_t)threadIdx.x * gridDim.x + blockIdx.x] = lh[threadIdx.x];
+      if (lh[threadIdx.x]) atomicAdd(&total[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
+    }
   }
 }
 
@@ -1641,6 +1643,8 @@ extern "C" void shn_cc_destroy(shn_cc* c) {
   if (c->d_flags) shn_dev_free(c->d_flags);
   if (c->d_lab) shn_dev_free(c->d_lab);
   if (c->d_cnt) shn_dev_free(c->d_cnt);
+  if (c->d_bc) shn_dev_free(c->d_bc);
+  if (c->d_pos) shn_dev_free(c->d_pos);
   delete c;
 }
 
@@ -1663,7 +1667,10 @@ extern "C" int shn_cc_create(shn_ctx* ctx, const shn_table* t, int world, int ra
   TRYC(shn_dev_malloc(&c->d_flags, n + 1));
   TRYC(shn_dev_malloc(&c->d_lab, (n + 1) * 4));
   TRYC(shn_dev_malloc(&c->d_cnt, 128 * 8));
+  TRYC(shn_dev_malloc(&c->d_bc, (size_t)64 * CC_GRID * 4));
+  TRYC(shn_dev_malloc(&c->d_pos, ((size_t)64 * CC_GRID + 2) * 8));
   TRYC(hipMemsetAsync(c->d_cnt, 0, 128 * 8, s));
+  c->q_grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, cdiv(n * 8, 256)), CC_GRID);
   if (n) {
     hipLaunchKernelGGL(ext_prepare_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, t->d_keys, t->d_counts, n, t->k, t->canonical, d_weight, c->d_flags);
     { int rc = build_fine_dict(ctx, t, c->d_flags, &lines, &n_lines); if (rc) return fail(rc); }
@@ -1671,8 +1678,9 @@ extern "C" int shn_cc_create(shn_ctx* ctx, const shn_table* t, int world, int ra
     hipLaunchKernelGGL(cc_edges_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, shn_tab_idx(t),
                        c->d_flags, n, t->k, t->canonical, c->d_lab, (const unsigned long long*)lines, n_lines);
     hipLaunchKernelGGL(cc_flatten_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, c->d_lab, n);
-    hipLaunchKernelGGL((cc_query_kernel<false>), dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 20)), dim3(256), 0, s, t->d_keys, c->d_flags, n,
-                       t->k, t->canonical, world, rank, c->d_lab, c->d_cnt, (uint64_t*)nullptr, (uint32_t*)nullptr);
+    hipLaunchKernelGGL((cc_query_kernel<false>), dim3(c->q_grid), dim3(256), 0, s, t->d_keys, c->d_flags, n, t->k, t->canonical, world, rank, c->d_lab,
+                       c->d_cnt, c->d_bc, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr);
+    { int rc = shn_device_scan_u32(ctx, c->d_bc, (uint64_t)world * c->q_grid, c->d_pos, nullptr); if (rc) return fail(rc); }
   }
   unsigned long long h[64];
   TRYC(hipMemcpyAsync(h, c->d_cnt, 64 * 8, hipMemcpyDeviceToHost, s));
@@ -1698,16 +1706,15 @@ extern "C" int shn_cc_queries(shn_cc* c, void* dev_keys_out, void* dev_labs_out)
   shn_ctx* ctx = c->ctx;
   SHN_ENTER(ctx);
   hipStream_t s = ctx->stream; shn_use_stream(s);
-  unsigned long long cur[64], a = 0;
-  for (int r = 0; r < 64; r++) { cur[r] = a; a += c->per_rank[r]; }
+  unsigned long long a = 0;
+  for (int r = 0; r < 64; r++) a += c->per_rank[r];
   if (!a) return SHN_OK;
   if (!dev_keys_out || !dev_labs_out) return shn_fail(SHN_ERR_ARG, "shn_cc_queries: NULL output");
-  HIP_TRY(hipMemcpyAsync(c->d_cnt, cur, 64 * 8, hipMemcpyHostToDevice, s));
   const uint64_t n = c->t->n;
-  hipLaunchKernelGGL((cc_query_kernel<true>), dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 20)), dim3(256), 0, s, c->t->d_keys, c->d_flags, n,
-                     c->t->k, c->t->canonical, c->world, c->rank, c->d_lab, c->d_cnt, (uint64_t*)dev_keys_out, (uint32_t*)dev_labs_out);
+  hipLaunchKernelGGL((cc_query_kernel<true>), dim3(c->q_grid), dim3(256), 0, s, c->t->d_keys, c->d_flags, n, c->t->k, c->t->canonical, c->world, c->rank,
+                     c->d_lab, c->d_cnt, c->d_bc, (const uint64_t*)c->d_pos, (uint64_t*)dev_keys_out, (uint32_t*)dev_labs_out);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(s));               // (cur lives on this stack frame)
+  HIP_TRY(hipStreamSynchronize(s));
   return SHN_OK;
 }
 
@@ -1865,28 +1872,26 @@ extern "C" int shn_cc_owners(shn_cc* c, const void* dev_glabel, const void* dev_
 
 template <bool WRITE>
 __global__ void ccs_shard_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, const uint8_t* __restrict__ owner, uint64_t n,
-                                 int world, unsigned long long* __restrict__ cursor, uint64_t* __restrict__ ok, uint32_t* __restrict__ oc) {
+                                 int world, unsigned long long* __restrict__ total, uint32_t* __restrict__ block_count, const uint64_t* __restrict__ pos,
+                                 uint64_t* __restrict__ ok, uint32_t* __restrict__ oc) {
   __shared__ uint32_t lh[64];
-  if (!WRITE) { if (threadIdx.x < 64) lh[threadIdx.x] = 0; __syncthreads(); }
-  const int lane = threadIdx.x & 63;
-  const uint64_t rounded = (n + 63) & ~63ULL;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += (uint64_t)gridDim.x * blockDim.x) {
-    const bool act = i < n;
-    const int o = act ? (int)owner[i] : -1;
-    if (!WRITE) { if (act) atomicAdd(&lh[o], 1u); continue; }
-    for (int r = 0; r < world; r++) {
-      const unsigned long long m = __ballot(act && o == r);
-      if (!m) continue;
-      const int leader = __ffsll((long long)m) - 1;
-      unsigned long long b = 0;
-      if (lane == leader) b = atomicAdd(&cursor[r], (unsigned long long)__popcll(m));
-      b = shfl_u64(b, leader);
-      if (act && o == r) { const uint64_t d = b + __popcll(m & ((1ULL << lane) - 1)); ok[d] = keys[i]; oc[d] = counts[i]; }
-    }
+  __shared__ uint64_t lbase[64];
+  if (threadIdx.x < 64) {
+    lh[threadIdx.x] = 0;
+    if (WRITE) lbase[threadIdx.x] = (int)threadIdx.x < world ? pos[(uint64_t)threadIdx.x * gridDim.x + blockIdx.x] : 0;
+  }
+  __syncthreads();
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const int o = (int)owner[i];
+    const uint32_t at = atomicAdd(&lh[o], 1u);
+    if (WRITE) { const uint64_t d = lbase[o] + at; ok[d] = keys[i]; oc[d] = counts[i]; }
   }
   if (!WRITE) {
     __syncthreads();
-    if (threadIdx.x < 64 && lh[threadIdx.x]) atomicAdd(&cursor[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
+    if ((int)threadIdx.x < world) {
+      block_count[(uint64_t)threadIdx.x * gridDim.x + blockIdx.x] = lh[threadIdx.x];
+      if (lh[threadIdx.x]) atomicAdd(&total[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
+    }
   }
 }
 // the shard's (key, count) pairs grouped by owner rank (per_rank[r] pairs each, rank order) -- what the all-to-all sends
@@ -1899,19 +1904,19 @@ extern "C" int shn_cc_shard(shn_cc* c, const void* dev_owner, uint64_t* per_rank
   shn_ctx* ctx = c->ctx;
   SHN_ENTER(ctx);
   hipStream_t s = ctx->stream; shn_use_stream(s);
-  const uint32_t grid = (uint32_t)std::min<uint64_t>(cdiv(n, 256), 1u << 16);
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, cdiv(n, 256)), CC_GRID);
   HIP_TRY(hipMemsetAsync(c->d_cnt, 0, 64 * 8, s));
   hipLaunchKernelGGL((ccs_shard_kernel<false>), dim3(grid), dim3(256), 0, s, c->t->d_keys, c->t->d_counts, (const uint8_t*)dev_owner, n, c->world, c->d_cnt,
-                     (uint64_t*)nullptr, (uint32_t*)nullptr);
-  unsigned long long h[64], cur[64], a = 0;
+                     c->d_bc, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr);
+  int rc = shn_device_scan_u32(ctx, c->d_bc, (uint64_t)c->world * grid, c->d_pos, nullptr);
+  if (rc) return rc;
+  unsigned long long h[64];
   HIP_TRY(hipMemcpyAsync(h, c->d_cnt, 64 * 8, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
-  for (int r = 0; r < 64; r++) { cur[r] = a; if (r < c->world) { per_rank[r] = h[r]; a += h[r]; } }
-  HIP_TRY(hipMemcpyAsync(c->d_cnt, cur, 64 * 8, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL((ccs_shard_kernel<true>), dim3(grid), dim3(256), 0, s, c->t->d_keys, c->t->d_counts, (const uint8_t*)dev_owner, n, c->world, c->d_cnt,
-                     (uint64_t*)dev_keys_out, (uint32_t*)dev_counts_out);
+                     c->d_bc, (const uint64_t*)c->d_pos, (uint64_t*)dev_keys_out, (uint32_t*)dev_counts_out);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(s));
+  for (int r = 0; r < c->world; r++) per_rank[r] = h[r];
   return SHN_OK;
 }
 
