@@ -532,6 +532,7 @@ class GpuOps(object):
         torch.cuda.synchronize()
         table = self._dev.Table.from_pairs(self.ctx, rk.data_ptr(), rc.data_ptr(), rk.numel(), self.K + 1, not self.strand_specific)
         tick("table", t0)
+        self.component_table_sizes = (int(n_loc), int(len(table)), int(n_glob))      # owned shard, walked table, the job (tests, bench)
         return table, n_glob
 
     def local_table(self):

@@ -89,6 +89,14 @@ def _ranks_vs_single(world, paired, n_genes, seed, port, big, ss, tmp_path, env_
     got = json.load(open(out))
     if env_extra.get("SHN_OWNER_LABELS") != "0":
         assert "x:component exchange" in got.get("timings", {}), sorted(got.get("timings", {}))       # the default path ran
+        # no rank holds the whole table: the owned shards and the walked tables (whole components) each partition the job's k1-mers
+        sizes = got["table_sizes"]
+        n_job = got["n_k1mers"]
+        assert all(s[2] == n_job for s in sizes)
+        assert sum(s[0] for s in sizes) == n_job and sum(s[1] for s in sizes) == n_job
+        assert max(s[0] for s in sizes) <= 0.75 * n_job + 1000, sizes
+        if n_genes >= 12:                                                       # (several components of size: the walked tables are shares too)
+            assert max(s[1] for s in sizes) <= 0.9 * n_job, sizes
     (q1, q2), _ = synth.make_dataset(n_pairs, n_genes, seed=seed)
     if not paired:
         q1, q2 = np.concatenate([q1, q2]), None
