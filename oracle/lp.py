@@ -172,7 +172,7 @@ def face_center(x, sup, stats=None):
     """
     m, n = len(x), len(x[0])
     N = m + n
-    if N > 64:                                   # (bit masks of 64 nodes; larger nodes keep the vertex -- counted)
+    if N > CENTER_MAX_NODES:                     # (larger nodes keep the vertex -- counted; lp.hip: LP_CENTER_MAX_NODES)
         if stats is not None:
             stats["too_large"] = stats.get("too_large", 0) + 1
         return x
@@ -233,6 +233,7 @@ def face_center(x, sup, stats=None):
     return out
 
 
+CENTER_MAX_NODES = 512     # rows + columns up to which the supported cells are centred (64 until round 5: one-word bit masks on the device)
 NEWTON_MAX = 100
 NEWTON_TOL2 = 1e-20        # squared residual norm (normalised problem) at which the iteration has converged
 FLOW_EPS = 1e-6            # x the largest flow: smaller flows open no arc of the residual digraph

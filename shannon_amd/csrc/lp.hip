@@ -164,11 +164,18 @@ __global__ __launch_bounds__(LBLK) void lp_trials_kernel(const LpProblem* __rest
 #define NEWTON_TOL2 1e-20
 #define FLOW_EPS 1e-6
 
-// per-trial words of the centre kernel's own workspace: y, y2, dy, yn [mn each] | S [n*n] | 14 vectors of <= max(m, n) + 1
-__host__ __device__ __forceinline__ uint64_t lp_ws2_words(uint64_t m, uint64_t n) { return 4 * m * n + n * n + 14 * (m + n + 1); }
+// nodes (rows + columns) up to which the supported cells are centred; larger nodes keep the vertex (counted).  Up to 64 nodes the
+// reachability matrix of the residual digraph is one word per node; above, (m + n) / 64 words per node in the centre workspace.
+#define LP_CENTER_MAX_NODES 512
+// per-trial words of the centre kernel's own workspace: y, y2, dy, yn [mn each] | S [n*n] | 14 vectors of <= max(m, n) + 1 |
+// the reachability rows of a node with more than 64 rows + columns
+__host__ __device__ __forceinline__ uint64_t lp_ws2_words(uint64_t m, uint64_t n) {
+  const uint64_t N = m + n;
+  return 4 * m * n + n * n + 14 * (N + 1) + ((N > 64 && N <= LP_CENTER_MAX_NODES) ? N * ((N + 63) / 64) : 0);
+}
 
 // oracle/lp.py:face_center + center_component for the trial of this lane.  X is the vertex left by lp_trials_kernel.
-// stat[4 * trial + 0..3]: classes centred, Newton steps, classes not converged, 1 if m + n > 64 (vertex kept)
+// stat[4 * trial + 0..3]: classes centred, Newton steps, classes not converged, 1 if m + n > LP_CENTER_MAX_NODES (vertex kept)
 __global__ __launch_bounds__(LBLK) void lp_center_kernel(const LpProblem* __restrict__ probs, const uint32_t* __restrict__ block_prob,
                                                          const uint32_t* __restrict__ block_first, const uint8_t* __restrict__ masks,
                                                          uint64_t* __restrict__ ws, uint64_t* __restrict__ ws2, double* __restrict__ out,
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(LBLK) void lp_center_kernel(const LpProblem* __rest
 #define CX(i, j) ((uint64_t)((j) * m + (i)))
   uint32_t st_comp = 0, st_steps = 0, st_bad = 0, st_large = 0;
   double* o = out + P.out_off;
-  if (N > 64) {
+  if (N > LP_CENTER_MAX_NODES) {
     st_large = 1;
   } else {
     // ---- classes of the residual digraph (flows at or below 1e-6 of the largest flow open no arc: rounding residue of the balancing)
@@ -207,30 +214,59 @@ __global__ __launch_bounds__(LBLK) void lp_center_kernel(const LpProblem* __rest
     for (uint32_t i = 0; i < m; i++)
       for (uint32_t j = 0; j < n; j++) { const double v = AT(X, CX(i, j)); if (v > xmax) xmax = v; }
     const double eps = FLOW_EPS * xmax;
-    for (uint32_t i = 0; i < m; i++) {
-      uint64_t r = 1ULL << i;
-      for (uint32_t j = 0; j < n; j++) if (!pm[CX(i, j)]) r |= 1ULL << (m + j);
-      AT(reach, i) = r;
-    }
-    for (uint32_t j = 0; j < n; j++) {
-      uint64_t r = 1ULL << (m + j);
-      for (uint32_t i = 0; i < m; i++) if (!pm[CX(i, j)] && AT(X, CX(i, j)) > eps) r |= 1ULL << i;
-      AT(reach, m + j) = r;
-    }
-    for (bool changed = true; changed;) {
-      changed = false;
+    if (N <= 64) {
+      for (uint32_t i = 0; i < m; i++) {
+        uint64_t r = 1ULL << i;
+        for (uint32_t j = 0; j < n; j++) if (!pm[CX(i, j)]) r |= 1ULL << (m + j);
+        AT(reach, i) = r;
+      }
+      for (uint32_t j = 0; j < n; j++) {
+        uint64_t r = 1ULL << (m + j);
+        for (uint32_t i = 0; i < m; i++) if (!pm[CX(i, j)] && AT(X, CX(i, j)) > eps) r |= 1ULL << i;
+        AT(reach, m + j) = r;
+      }
+      for (bool changed = true; changed;) {
+        changed = false;
+        for (uint32_t u = 0; u < N; u++) {
+          const uint64_t r = AT(reach, u);
+          uint64_t acc = r;
+          for (uint32_t v = 0; v < N; v++) if ((r >> v) & 1) acc |= AT(reach, v);
+          if (acc != r) { AT(reach, u) = acc; changed = true; }
+        }
+      }
       for (uint32_t u = 0; u < N; u++) {
         const uint64_t r = AT(reach, u);
-        uint64_t acc = r;
-        for (uint32_t v = 0; v < N; v++) if ((r >> v) & 1) acc |= AT(reach, v);
-        if (acc != r) { AT(reach, u) = acc; changed = true; }
+        int64_t l = u;
+        for (uint32_t v = 0; v < N; v++) if (((r >> v) & 1) && ((AT(reach, v) >> u) & 1)) { l = v; break; }
+        AT(label, u) = l;
       }
-    }
-    for (uint32_t u = 0; u < N; u++) {
-      const uint64_t r = AT(reach, u);
-      int64_t l = u;
-      for (uint32_t v = 0; v < N; v++) if (((r >> v) & 1) && ((AT(reach, v) >> u) & 1)) { l = v; break; }
-      AT(label, u) = l;
+    } else {
+      // the same closure with NW words per node (Warshall, one pass: after step k a row holds what its node reaches through
+      // nodes <= k): the transitive closure is unique, so the classes are those of the sweep above
+      const uint32_t NW = (N + 63) >> 6;
+      uint64_t* RB = (uint64_t*)(vec + 14 * VL);
+#define RW(u, w) AT(RB, (uint64_t)(u) * NW + (w))
+#define RBIT(u, v) ((RW(u, (v) >> 6) >> ((v) & 63)) & 1ULL)
+      for (uint32_t u = 0; u < N; u++) for (uint32_t w = 0; w < NW; w++) RW(u, w) = 0;
+      for (uint32_t i = 0; i < m; i++) {
+        RW(i, i >> 6) |= 1ULL << (i & 63);
+        for (uint32_t j = 0; j < n; j++) if (!pm[CX(i, j)]) RW(i, (m + j) >> 6) |= 1ULL << ((m + j) & 63);
+      }
+      for (uint32_t j = 0; j < n; j++) {
+        RW(m + j, (m + j) >> 6) |= 1ULL << ((m + j) & 63);
+        for (uint32_t i = 0; i < m; i++) if (!pm[CX(i, j)] && AT(X, CX(i, j)) > eps) RW(m + j, i >> 6) |= 1ULL << (i & 63);
+      }
+      for (uint32_t k = 0; k < N; k++)
+        for (uint32_t u = 0; u < N; u++)
+          if (u != k && RBIT(u, k))
+            for (uint32_t w = 0; w < NW; w++) RW(u, w) |= RW(k, w);
+      for (uint32_t u = 0; u < N; u++) {
+        int64_t l = u;
+        for (uint32_t v = 0; v < N; v++) if (RBIT(u, v) && RBIT(v, u)) { l = v; break; }
+        AT(label, u) = l;
+      }
+#undef RBIT
+#undef RW
     }
     // ---- every class with more supported cells than a tree
     for (uint32_t L = 0; L < m; L++) {
@@ -443,8 +479,8 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
     // the centre kernel has work only where the supported cells of the problem hold a cycle (rows and columns as vertices, a
     // supported cell as an edge): on a forest every class is a tree and its face a point.  At BASELINE configs[2] 9,000
     // problems per step, a handful with a cycle.
-    if (center && m[p] + n[p] <= 64) {
-      int par[64];
+    if (center && m[p] + n[p] <= LP_CENTER_MAX_NODES) {
+      int par[LP_CENTER_MAX_NODES];
       for (uint32_t v = 0; v < m[p] + n[p]; v++) par[v] = (int)v;
       auto find = [&](int v) { while (par[v] != v) { par[v] = par[par[v]]; v = par[v]; } return v; };
       bool cyc = false;
@@ -528,7 +564,7 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
   if (n_large_trials) {                                                  // (said once per process: these problems keep the vertex answer)
     static std::atomic<bool> told{false};
     if (!told.exchange(true))
-      fprintf(stderr, "[shannon_amd] LP: a decomposition with more than 64 rows + columns keeps the vertex of its optimal face (the analytic centre is "
+      fprintf(stderr, "[shannon_amd] LP: a decomposition with more than 512 rows + columns keeps the vertex of its optimal face (the analytic centre is "
                       "computed for problems up to that size); counted in shn_lp_stats[6]\n");
   }
   if (!stat.empty()) {

@@ -249,6 +249,17 @@ for (a, b) in (([5., 7., 9.], [5., 16.]), ([5., 7., 9., 39.], [21., 11., 15., 13
     state.update(pid=1000 + m, trial=0, seed=1234)
     ans, nu = pds.path_decompose(list(a), list(b), list(a), list(b), 0, cvxopt.matrix(np.ones((m, n))), False, 3)
     kats.append({"a": a, "b": b, "P": np.ones((m, n), dtype=int).tolist(), "seed": 1234, "pid": 1000 + m, "sparsity": 3, "answer": np.array(ans).tolist(), "non_unique": int(nu)})
+# nodes with more than 64 rows + columns (round 5: the centre rule beyond one-word reachability masks): sparse supports with many
+# zero-cost cells, balanced integer flows -- classes with cycles among the supported cells exist, so vertex and centre differ
+rng2 = np.random.default_rng(2025)
+for t, (m, n, ones) in enumerate([(33, 33, 0.7), (58, 8, 0.5), (5, 62, 0.4), (40, 30, 0.8)]):
+    a = [float(v) for v in rng2.integers(1, 40, m)]
+    tot = int(sum(a)); cuts = np.sort(rng2.integers(0, tot + 1, n - 1)); b = [float(v) for v in np.diff(np.concatenate([[0], cuts, [tot]]))]
+    P = (rng2.random((m, n)) < ones).astype(int).tolist()
+    state.update(pid=2000 + t, trial=0, seed=1234)
+    ans, nu = pds.path_decompose(list(a), list(b), list(a), list(b), 0, cvxopt.matrix(np.array(P, dtype=float).reshape(m, n)), False, 3)
+    kats.append({"a": a, "b": b, "P": P, "seed": 1234, "pid": 2000 + t, "sparsity": 3, "large": 1,
+                 "answer": np.array(ans, dtype=float).reshape(m, n).tolist() if len(ans) else [], "non_unique": int(nu)})
 json.dump({"standins": "cvxopt stub + oracle.lp.transport_center (interior-point limit) and cost generator (NOT real cvxopt)", "kats": kats}, open(sys.argv[1], "w"))
 '''
     H.run_py(tref, code, argv=[os.path.join(OUT, "lp_kats.json")])

@@ -69,6 +69,22 @@ def test_equals_the_limit_of_the_log_barrier_central_path(seed):
     assert np.abs(got - ref).max() <= 1e-6 * max(a.max(), b.max()), (m, n, st, np.abs(got - ref).max())
 
 
+@pytest.mark.parametrize("seed,m,n,dens", [(0, 36, 34, 0.8), (1, 60, 9, 0.6), (2, 7, 66, 0.5)])
+def test_nodes_with_more_than_64_rows_and_columns_against_the_barrier_path(seed, m, n, dens):
+    """the centre rule beyond 64 nodes (round 5: until then such a node kept its vertex): the same comparison at 70+ nodes"""
+    rng = np.random.default_rng(5000 + seed)
+    a = rng.uniform(0.5, 100.0, m)
+    b = rng.uniform(0.5, 100.0, n)
+    b *= a.sum() / b.sum()
+    P = rng.random((m, n)) < dens
+    c = _costs(rng, P)
+    st = {}
+    got = np.array(olp.transport_center(list(a), list(b), c, P.tolist(), st))
+    assert st.get("components", 0) >= 1 and not st.get("too_large") and not st.get("not_converged")
+    ref = central_path_limit(a, b, np.array(c, float) / float(1 << 32))
+    assert np.abs(got - ref).max() <= 1e-6 * max(a.max(), b.max()), (m, n, st, np.abs(got - ref).max())
+
+
 @pytest.mark.parametrize("seed", range(30))
 def test_face_properties(seed):
     """marginals kept, unsupported cells keep the vertex's flows, supported cells outside every class stay zero, the KKT condition

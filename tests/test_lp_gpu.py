@@ -24,7 +24,9 @@ def _requests(n_cases=120):
         if t == 0:
             m, n = 17, 23
         if t == 1:
-            m, n = 40, 30                      # more than 64 rows + columns: the vertex is kept (and counted)
+            m, n = 40, 30                      # more than 64 rows + columns: centred as well since round 5 (reachability rows of several words)
+        if t == 2:
+            m, n = 2, 511                      # more than 512 rows + columns: the vertex is kept (and counted)
         a = [float(v) for v in rng.integers(0, 30, m)]
         if sum(a) == 0:
             a[0] = 3.0
