@@ -355,6 +355,139 @@ __global__ REC_KERNEL_ATTR void ext_records_kernel(const TabIdx T, const uint8_t
   }
 }
 
+// The same records for a table of layout 1 with most look-ups answered from LDS (round 5).  A k1-mer's neighbour has the k1-mer's
+// own minimizer seven times out of eight, i.e. lies in the k1-mer's own bucket -- and the kernel above already knows every
+// neighbour's bucket (it needs it for the dictionary line).  A block takes REC_G consecutive buckets (~170 keys each at BASELINE
+// configs[2]), stages their keys and flags in LDS, and a neighbour whose bucket is one of them is looked up there by bisection:
+// found = its id, not found = it does not exist (a key has one bucket).  Only the neighbours of other buckets (one in eight) go to
+// the dictionary in HBM; the eight lanes of a k1-mer make those look-ups together as before, a wavefront skips the look-up
+// numbers none of its eight k1-mers needs.  Blocks whose buckets hold more than REC_CAP keys take the dictionary for everything.
+#define REC_G 4
+#define REC_CAP 2048
+#ifndef REC_FLY
+#define REC_FLY 2
+#endif
+__global__ __launch_bounds__(256) void ext_records_lds_kernel(const TabIdx T, const uint8_t* __restrict__ flags, const uint32_t* __restrict__ weight,
+                                                              uint64_t n_buckets, int k, int canonical, Rec* __restrict__ rec,
+                                                              const unsigned long long* __restrict__ lines) {
+  __shared__ uint64_t skeys[REC_CAP];
+  __shared__ uint8_t sflags[REC_CAP];
+  __shared__ uint64_t sboff[REC_G + 1];
+  const uint64_t* __restrict__ tkeys = T.keys;
+  const uint64_t B0 = (uint64_t)blockIdx.x * REC_G;
+  const uint32_t G = (uint32_t)(n_buckets - B0 < REC_G ? n_buckets - B0 : REC_G);
+  if (threadIdx.x <= G) sboff[threadIdx.x] = T.boff[B0 + threadIdx.x];
+  __syncthreads();
+  const uint64_t lo = sboff[0];
+  const uint64_t nk64 = sboff[G] - lo;
+  if (nk64 == 0) return;
+  const bool staged = nk64 <= REC_CAP;
+  const uint32_t nk = (uint32_t)nk64;                                   // (a bucket range of 2^32 keys does not occur: the table holds fewer)
+  if (staged) for (uint32_t t = threadIdx.x; t < nk; t += blockDim.x) { skeys[t] = tkeys[lo + t]; sflags[t] = flags[lo + t]; }
+  __syncthreads();
+  const uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+  const int lane = threadIdx.x & 63, g0 = lane & ~7, p = lane & 7;
+  const int m = T.m, w = k - m + 1;
+  const uint32_t mmask = m == 16 ? 0xFFFFFFFFu : ((1u << (2 * m)) - 1u);
+  for (uint64_t base = 0; base < nk64; base += blockDim.x >> 3) {
+    const uint64_t t = base + (threadIdx.x >> 3);
+    const bool in = t < nk64;
+    const uint64_t i = lo + (in ? t : 0);
+    const uint64_t str = in ? (staged ? skeys[t] : tkeys[i]) : 0ULL;
+    const uint8_t f = in ? (staged ? sflags[t] : flags[i]) : (uint8_t)2;
+    const uint32_t wt = (in && (p == 2 || p == 6)) ? weight[i] : 0u;
+    const bool dead0 = (f & 2) != 0;
+    const bool dead1 = dead0 || (f & 1) || !canonical;
+    uint64_t mykey; uint32_t mystrand = 0;
+    {
+      const uint64_t b = (uint64_t)(p & 3);
+      mykey = p < 4 ? (((str << 2) | b) & mask) : ((str >> 2) | (b << (2 * (k - 1))));
+      if (canonical) { const uint64_t rc = shn_revcomp(mykey, k); if (rc < mykey) { mykey = rc; mystrand = 1; } }
+      if (dead0) mykey = 0;
+    }
+    // the neighbour's bucket from the k1-mer's own m-mers (see ext_records_kernel)
+    uint32_t nbkt;
+    {
+      uint32_t smin = 0xFFFFFFFFu, pmin = 0xFFFFFFFFu;
+      for (int pos = p; pos < w; pos += 8) {
+        const uint32_t fm = (uint32_t)(str >> (2 * (k - m - pos))) & mmask;
+        uint32_t c = fm;
+        if (canonical) { const uint32_t r = shn_revcomp32(fm, m); c = r < fm ? r : fm; }
+        const uint32_t o = shn_sk_order(c);
+        if (pos >= 1) smin = o < smin ? o : smin;
+        if (pos <= w - 2) pmin = o < pmin ? o : pmin;
+      }
+#pragma unroll
+      for (int d = 1; d < 8; d <<= 1) {
+        const uint32_t a = (uint32_t)__shfl_xor((int)smin, d, 64), b2 = (uint32_t)__shfl_xor((int)pmin, d, 64);
+        smin = a < smin ? a : smin; pmin = b2 < pmin ? b2 : pmin;
+      }
+      const uint32_t nb = (uint32_t)(p & 3);
+      const uint32_t fm = p < 4 ? ((((uint32_t)str & (mmask >> 2)) << 2) | nb)
+                                : ((nb << (2 * (m - 1))) | ((uint32_t)(str >> (2 * (k - m + 1))) & (mmask >> 2)));
+      uint32_t c = fm;
+      if (canonical) { const uint32_t r = shn_revcomp32(fm, m); c = r < fm ? r : fm; }
+      uint32_t o = shn_sk_order(c);
+      const uint32_t shared = p < 4 ? smin : pmin;
+      o = shared < o ? shared : o;
+      nbkt = shn_sk_bucket(o, T.bits);
+    }
+    bool cross = !dead0;                                                // this lane's look-up goes to the dictionary
+    uint32_t w_own = 0xFFFFFFFFu;
+    if (!dead0 && staged && (uint64_t)nbkt >= B0 && (uint64_t)nbkt < B0 + G) {
+      cross = false;
+      uint32_t a = (uint32_t)(sboff[nbkt - B0] - lo), b = (uint32_t)(sboff[nbkt - B0 + 1] - lo);
+      while (a < b) {
+        const uint32_t mid = (a + b) >> 1;
+        const uint64_t v = skeys[mid];
+        if (v == mykey) { const uint8_t fj = sflags[mid]; if (!(fj & 2)) w_own = (uint32_t)(lo + mid) | ((fj & 1) ? FD_PAL : 0u); break; }
+        if (v < mykey) a = mid + 1; else b = mid;
+      }
+    }
+    const uint64_t myline = cross ? fd_line_in_bucket(T, nbkt, mykey) : 0ULL;
+    const uint32_t strands = (uint32_t)((__ballot(mystrand != 0) >> g0) & 0xFFULL);
+    uint32_t need = 0;                                                  // look-up numbers some k1-mer of this wavefront sends to the dictionary
+#pragma unroll
+    for (int q = 0; q < 8; q++) if (__ballot(cross && p == q)) need |= 1u << q;
+    const uint64_t ckey = cross ? mykey : 0ULL;
+    uint32_t r8[8], d8[8];
+#pragma unroll
+    for (int h = 0; h < 8; h += REC_FLY) {                              // (REC_FLY dictionary look-ups in flight at a time: one in eight is a real one)
+      ulonglong2 v[REC_FLY];
+#pragma unroll
+      for (int q = 0; q < REC_FLY; q++)
+        if ((need >> (h + q)) & 1) v[q] = ((const ulonglong2*)(lines + shfl_u64(myline, g0 + h + q) * 16))[p];
+#pragma unroll
+      for (int q = 0; q < REC_FLY; q++) {
+        uint32_t wq = (uint32_t)__shfl((int)w_own, g0 + h + q, 64);
+        if ((need >> (h + q)) & 1) {
+          const uint64_t kq = shfl_u64(ckey, g0 + h + q);
+          const uint32_t wd = fd_match(v[q], lines, shfl_u64(myline, g0 + h + q), kq, p, g0, T, flags);
+          if (kq != 0) wq = wd;                                         // (this group's look-up was one for the dictionary)
+        }
+        if (wq == 0xFFFFFFFFu) { r8[h + q] = d8[h + q] = 0xFFFFFFFFu; continue; }
+        const uint32_t j = wq & ~FD_PAL;
+        const uint32_t st = (strands >> (h + q)) & 1u;
+        r8[h + q] = 2 * j + st;
+        d8[h + q] = (wq & FD_PAL) ? r8[h + q] : 2 * j + (1 - st);
+      }
+    }
+    if (in) {
+      Quad out;
+      const Quad none = Quad{~0u, ~0u, ~0u, ~0u};
+      switch (p) {
+        case 0: out = Quad{r8[0], r8[1], r8[2], r8[3]}; break;
+        case 1: out = Quad{r8[4], r8[5], r8[6], r8[7]}; break;
+        case 4: out = dead1 ? none : Quad{d8[7], d8[6], d8[5], d8[4]}; break;
+        case 5: out = dead1 ? none : Quad{d8[3], d8[2], d8[1], d8[0]}; break;
+        case 2: case 6: out = Quad{wt, NOHINT_WORD, 0xFFFFFFFFu, 0u}; break;
+        default: out = Quad{0u, 0u, 0u, 0u}; break;
+      }
+      ((Quad*)(rec + 2 * i))[p] = out;
+    }
+  }
+}
+
 // ---- connected components of the k1-mer graph (vertices = canonical k1-mers, edges = the adjacency rows).
 // A walk never leaves its component, so the components can be extended independently -- on different GPUs.
 // Lock-free union-find: roots only ever link to smaller ids (no cycles), finds halve paths as they go.
@@ -2012,6 +2145,16 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       unsigned long long* lines = nullptr;
       uint64_t n_lines = 0;
       { int rca = build_fine_dict(ctx, t, e->d_flags, &lines, &n_lines, e->d_claim); if (rca) { shn_ext_destroy(e); return rca; } }
+      // (off by default -- MEASURED at BASELINE configs[2], one box: 144 ms with two dictionary look-ups in flight, 170 ms with four
+      // (one wavefront per SIMD fewer), against 119.5 ms for the dictionary-only kernel, same records.  The look-ups that are left
+      // come one or two at a time behind their bucket offsets where the kernel above has eight in flight, and a trip's chain of
+      // bisection, ballots and shuffles is longer than the one fetch it replaces: fewer bytes, more latency.  HISTORY.md, round 5.)
+      static const bool rec_lds = getenv("SHN_REC_LDS") && getenv("SHN_REC_LDS")[0] == '1';
+      if (t->layout == 1 && rec_lds && t->n_buckets / REC_G + 1 < 0x7FFFFFFFULL) {
+        TimerRegion ta(ctx, T_EXT_ADJ);
+        hipLaunchKernelGGL(ext_records_lds_kernel, dim3((uint32_t)cdiv(t->n_buckets, REC_G)), dim3(256), 0, s, shn_tab_idx(t), e->d_flags, e->d_weight,
+                           (uint64_t)t->n_buckets, t->k, t->canonical, e->d_rec, (const unsigned long long*)lines);
+      } else
       { TimerRegion ta(ctx, T_EXT_ADJ);                  // (one launch: bench.py's roofline entry for this kernel)
         hipLaunchKernelGGL(ext_records_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, shn_tab_idx(t),
                            e->d_flags, e->d_weight, n, t->k, t->canonical, e->d_rec, (const unsigned long long*)lines, n_lines,
