@@ -369,7 +369,8 @@ __global__ REC_KERNEL_ATTR void ext_records_kernel(const TabIdx T, const uint8_t
 #endif
 __global__ __launch_bounds__(256) void ext_records_lds_kernel(const TabIdx T, const uint8_t* __restrict__ flags, const uint32_t* __restrict__ weight,
                                                               uint64_t n_buckets, int k, int canonical, Rec* __restrict__ rec,
-                                                              const unsigned long long* __restrict__ lines) {
+                                                              const unsigned long long* __restrict__ lines, int ablate) {
+  // ablate (timing experiments only, wrong records): 1 = no dictionary look-ups, 2 = no LDS bisection either, 3 = no neighbour minimizers
   __shared__ uint64_t skeys[REC_CAP];
   __shared__ uint8_t sflags[REC_CAP];
   __shared__ uint64_t sboff[REC_G + 1];
@@ -406,8 +407,8 @@ __global__ __launch_bounds__(256) void ext_records_lds_kernel(const TabIdx T, co
       if (dead0) mykey = 0;
     }
     // the neighbour's bucket from the k1-mer's own m-mers (see ext_records_kernel)
-    uint32_t nbkt;
-    {
+    uint32_t nbkt = (uint32_t)B0;
+    if (ablate < 3) {
       uint32_t smin = 0xFFFFFFFFu, pmin = 0xFFFFFFFFu;
       for (int pos = p; pos < w; pos += 8) {
         const uint32_t fm = (uint32_t)(str >> (2 * (k - m - pos))) & mmask;
@@ -434,7 +435,8 @@ __global__ __launch_bounds__(256) void ext_records_lds_kernel(const TabIdx T, co
     }
     bool cross = !dead0;                                                // this lane's look-up goes to the dictionary
     uint32_t w_own = 0xFFFFFFFFu;
-    if (!dead0 && staged && (uint64_t)nbkt >= B0 && (uint64_t)nbkt < B0 + G) {
+    if (ablate >= 2) { cross = false; w_own = (uint32_t)mykey & 0x7FFFFFFu; }
+    else if (!dead0 && staged && (uint64_t)nbkt >= B0 && (uint64_t)nbkt < B0 + G) {
       cross = false;
       uint32_t a = (uint32_t)(sboff[nbkt - B0] - lo), b = (uint32_t)(sboff[nbkt - B0 + 1] - lo);
       while (a < b) {
@@ -444,6 +446,7 @@ __global__ __launch_bounds__(256) void ext_records_lds_kernel(const TabIdx T, co
         if (v < mykey) a = mid + 1; else b = mid;
       }
     }
+    if (ablate == 1) cross = false;
     const uint64_t myline = cross ? fd_line_in_bucket(T, nbkt, mykey) : 0ULL;
     const uint32_t strands = (uint32_t)((__ballot(mystrand != 0) >> g0) & 0xFFULL);
     uint32_t need = 0;                                                  // look-up numbers some k1-mer of this wavefront sends to the dictionary
@@ -2153,7 +2156,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       if (t->layout == 1 && rec_lds && t->n_buckets / REC_G + 1 < 0x7FFFFFFFULL) {
         TimerRegion ta(ctx, T_EXT_ADJ);
         hipLaunchKernelGGL(ext_records_lds_kernel, dim3((uint32_t)cdiv(t->n_buckets, REC_G)), dim3(256), 0, s, shn_tab_idx(t), e->d_flags, e->d_weight,
-                           (uint64_t)t->n_buckets, t->k, t->canonical, e->d_rec, (const unsigned long long*)lines);
+                           (uint64_t)t->n_buckets, t->k, t->canonical, e->d_rec, (const unsigned long long*)lines,
+                           getenv("SHN_REC_ABLATE") ? atoi(getenv("SHN_REC_ABLATE")) : 0);
       } else
       { TimerRegion ta(ctx, T_EXT_ADJ);                  // (one launch: bench.py's roofline entry for this kernel)
         hipLaunchKernelGGL(ext_records_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, shn_tab_idx(t),
