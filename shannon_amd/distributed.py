@@ -385,6 +385,146 @@ def _a2a_objects(recv, payload, group):
         recv[src] = everything[src][rank]
 
 
+def component_table(cc, group, tick, lock, dev):
+    """Component labelling on owner shards, the collectives around it.  cc: this rank's shard behind the steps of
+    include/shannon_hip.h's shn_cc_* (GpuOps: the device kernels; the CPU tests: a numpy restatement) --
+      cc.n                                     k1-mers of the shard
+      cc.queries() -> (keys i64, roots i32, per destination rank)      what higher ranks are asked
+      cc.answer(keys, roots, per source rank, base) -> edges i64 [2 E] pairs of global ids (base[r] + local root)
+      cc.solve(edges, id_limit) -> (ids ascending, label of each)       the component graph, the same on every rank
+      cc.labels(base_me, ids, labels) -> i64 [n]                        global label of every k1-mer of the shard
+      cc.sizes(glabel, at_least) -> (labels, counts) numpy              what this rank holds of the larger components
+      cc.shard(glabel, big labels ascending, their ranks) -> (keys i64, counts i32, per destination rank)
+    Collectives: the shard sizes (all-gather), the queries (all-to-all), the edges (all-gather), the sizes of the large components
+    (objects), the pairs of whole components (all-to-all).  Returns ((keys, counts) received: this rank's components, k1-mers of
+    the job).  lock: held while this rank computes (see assemble_distributed)."""
+    import time
+    W, rank = dist.get_world_size(group), dist.get_rank(group)
+    lock = lock or _NoLock()
+    cdev = exchange.coll_device(dev, group)
+    t0 = time.time()
+    n_loc = int(cc.n)
+    qk, ql, per = cc.queries()
+    tick("labels: local components + queries", t0)
+    lock.release()
+    t0 = time.time()
+    nt = torch.tensor([n_loc], dtype=torch.int64, device=cdev)
+    nts = [torch.zeros_like(nt) for _ in range(W)]
+    dist.all_gather(nts, nt, group=group)
+    sizes = [int(x.item()) for x in nts]
+    base = [sum(sizes[:r]) for r in range(W)]
+    n_glob = sum(sizes)
+    rk, rl, rcl = exchange.all_to_all_pairs(qk, ql, per, group, name="component labelling: neighbour queries to the owners (all-to-all)")
+    del qk, ql
+    tick("x:label queries", t0)
+    lock.acquire()
+    t0 = time.time()
+    edges = cc.answer(rk, rl, rcl, base)
+    del rk, rl
+    tick("labels: answers", t0)
+    lock.release()
+    t0 = time.time()
+    ge, _ = _all_gather_var(edges, group, name="component labelling: edges between shards (all-gather)")
+    del edges
+    tick("x:label edges", t0)
+    lock.acquire()
+    t0 = time.time()
+    ids, labels = cc.solve(ge, n_glob + 1)
+    del ge
+    glabel = cc.labels(base[rank], ids, labels)
+    del ids, labels
+    # the large components are balanced by size (largest first onto the least loaded rank, as shn_extend_sharded does on a
+    # replicated table); everything else goes by the hash of its label.  A component of T k1-mers spread evenly has T / W of them
+    # here: every rank reports what it holds of components above a quarter of that, every rank sums the same reports.
+    T = max(1024, n_glob // (64 * W))
+    mine = cc.sizes(glabel, max(32, T // (4 * W)))
+    tick("labels: component graph", t0)
+    lock.release()
+    t0 = time.time()
+    parts = exchange.all_gather_object(mine, group, "component labelling: sizes of the large components")
+    tick("x:label sizes", t0)
+    lock.acquire()
+    t0 = time.time()
+    tot = {}
+    for lab, cnt in parts:
+        for a, b in zip(np.asarray(lab).tolist(), np.asarray(cnt).tolist()):
+            tot[a] = tot.get(a, 0) + b
+    big = sorted((a for a, b in tot.items() if b >= T // 2), key=lambda a: (-tot[a], a))
+    load = [0] * W
+    own = {}
+    for a in big:
+        r = min(range(W), key=lambda q: (load[q], q))
+        own[a] = r
+        load[r] += tot[a]
+    bl = sorted(own)
+    sk, sc, send = cc.shard(glabel, np.asarray(bl, dtype=np.int64), np.asarray([own[a] for a in bl], dtype=np.uint8))
+    del glabel
+    tick("labels: owners + shard", t0)
+    lock.release()
+    t0 = time.time()
+    rk, rc, _ = exchange.all_to_all_pairs(sk, sc, send, group, name="component exchange (the k1-mers of whole components to their rank, all-to-all)")
+    del sk, sc
+    tick("x:component exchange", t0)
+    lock.acquire()
+    return (rk, rc), n_glob
+
+
+class _GpuComponents(object):
+    """the steps of component_table() on the device (device.ComponentShards = shn_cc_*), tensors on the rank's GPU"""
+
+    def __init__(self, ops, owned, W, rank):
+        self.ops, self.dev, self.n = ops, ops.device, len(owned)
+        self.cc = ops._dev.ComponentShards(ops.ctx, owned, W, rank)
+
+    def queries(self):
+        per = self.cc.query_counts()
+        nq = int(per.sum())
+        qk = torch.empty(max(nq, 1), dtype=torch.int64, device=self.dev)
+        ql = torch.empty(max(nq, 1), dtype=torch.int32, device=self.dev)
+        self.cc.queries(qk.data_ptr(), ql.data_ptr())
+        return qk, ql, per
+
+    def answer(self, rk, rl, rcl, base):
+        torch.cuda.synchronize()
+        edges = torch.empty(2 * max(int(sum(rcl)), 1), dtype=torch.int64, device=self.dev)
+        ne = self.cc.answer(rk.data_ptr(), rl.data_ptr(), rcl, base, edges.data_ptr())
+        return edges[:2 * ne]
+
+    def solve(self, ge, id_limit):
+        torch.cuda.synchronize()
+        E = int(ge.numel()) // 2
+        ids = torch.empty(2 * max(E, 1), dtype=torch.int64, device=self.dev)
+        labels = torch.empty(2 * max(E, 1), dtype=torch.int64, device=self.dev)
+        nn = self.cc.solve(self.ops.ctx, ge.data_ptr(), E, id_limit, ids.data_ptr(), labels.data_ptr())
+        return ids[:nn], labels[:nn]
+
+    def labels(self, base_me, ids, labels):
+        glabel = torch.empty(max(self.n, 1), dtype=torch.int64, device=self.dev)
+        self.cc.labels(base_me, ids.data_ptr(), labels.data_ptr(), int(ids.numel()), glabel.data_ptr())
+        return glabel
+
+    def sizes(self, glabel, at_least):
+        torch.cuda.synchronize()
+        u, c = torch.unique(glabel[:self.n], return_counts=True)
+        sel = c >= at_least
+        return u[sel].cpu().numpy(), c[sel].cpu().numpy()
+
+    def shard(self, glabel, big, big_owner):
+        n_big = len(big)
+        dbig = torch.as_tensor(big if n_big else np.zeros(1, np.int64), device=self.dev)
+        dbo = torch.as_tensor(big_owner if n_big else np.zeros(1, np.uint8), device=self.dev)
+        owner = torch.empty(max(self.n, 1), dtype=torch.uint8, device=self.dev)
+        torch.cuda.synchronize()
+        self.cc.owners(glabel.data_ptr(), dbig.data_ptr(), dbo.data_ptr(), n_big, owner.data_ptr())
+        sk = torch.empty(max(self.n, 1), dtype=torch.int64, device=self.dev)
+        sc = torch.empty(max(self.n, 1), dtype=torch.int32, device=self.dev)
+        send = self.cc.shard(owner.data_ptr(), sk.data_ptr(), sc.data_ptr())
+        return sk, sc, send
+
+    def close(self):
+        self.cc.close()
+
+
 class GpuOps(object):
     """Per-rank compute on the local GPU through the C ABI."""
 
@@ -429,106 +569,18 @@ class GpuOps(object):
 
     def component_table(self, owned, group, tick):
         """owned: this rank's shard of the k1-mers (by minimizer).  Returns (a table of the whole components dealt to this rank,
-        the number of k1-mers of the job).  include/shannon_hip.h: shn_cc_*; collectives: the sizes of the shards, the queries
-        (all-to-all by owner), the edges between shards (all-gather), the sizes of the large components, the pairs (all-to-all)."""
-        import time
+        the number of k1-mers of the job): component_table() below with the device kernels (include/shannon_hip.h: shn_cc_*)."""
         W, rank = dist.get_world_size(group), dist.get_rank(group)
-        lock = getattr(self, "lock", None) or _NoLock()
-        dev, cdev = self.device, exchange.coll_device(self.device, group)
-        t0 = time.time()
         n_loc = len(owned)
-        cc = self._dev.ComponentShards(self.ctx, owned, W, rank)
+        cc = _GpuComponents(self, owned, W, rank)
         try:
-            per = cc.query_counts()
-            nq = int(per.sum())
-            qk = torch.empty(max(nq, 1), dtype=torch.int64, device=dev)
-            ql = torch.empty(max(nq, 1), dtype=torch.int32, device=dev)
-            cc.queries(qk.data_ptr(), ql.data_ptr())
-            tick("labels: local components + queries", t0)
-            lock.release()
-            t0 = time.time()
-            nt = torch.tensor([n_loc], dtype=torch.int64, device=cdev)
-            nts = [torch.zeros_like(nt) for _ in range(W)]
-            dist.all_gather(nts, nt, group=group)
-            sizes = [int(x.item()) for x in nts]
-            base = [sum(sizes[:r]) for r in range(W)]
-            n_glob = sum(sizes)
-            rk, rl, rcl = exchange.all_to_all_pairs(qk, ql, per, group, name="component labelling: neighbour queries to the owners (all-to-all)")
-            del qk, ql
-            tick("x:label queries", t0)
-            lock.acquire()
-            t0 = time.time()
-            torch.cuda.synchronize()
-            n_in = int(sum(rcl))
-            edges = torch.empty(2 * max(n_in, 1), dtype=torch.int64, device=dev)
-            ne = cc.answer(rk.data_ptr(), rl.data_ptr(), rcl, base, edges.data_ptr())
-            del rk, rl
-            tick("labels: answers", t0)
-            lock.release()
-            t0 = time.time()
-            ge, _ = _all_gather_var(edges[:2 * ne], group, name="component labelling: edges between shards (all-gather)")
-            del edges
-            tick("x:label edges", t0)
-            lock.acquire()
-            t0 = time.time()
-            torch.cuda.synchronize()
-            E = int(ge.numel()) // 2
-            nodes = torch.empty(2 * max(E, 1), dtype=torch.int64, device=dev)
-            labels = torch.empty(2 * max(E, 1), dtype=torch.int64, device=dev)
-            nn = cc.solve(self.ctx, ge.data_ptr(), E, n_glob + 1, nodes.data_ptr(), labels.data_ptr())
-            del ge
-            glabel = torch.empty(max(n_loc, 1), dtype=torch.int64, device=dev)
-            cc.labels(base[rank], nodes.data_ptr(), labels.data_ptr(), nn, glabel.data_ptr())
-            del nodes, labels
-            # the large components are balanced by size (largest first onto the least loaded rank, as shn_extend_sharded does on a
-            # replicated table); everything else goes by the hash of its label.  A component of T k1-mers spread evenly has T / W of them
-            # here: every rank reports what it holds of components above a quarter of that, every rank sums the same reports.
-            T = max(1024, n_glob // (64 * W))
-            report = max(32, T // (4 * W))
-            torch.cuda.synchronize()
-            u, c = torch.unique(glabel[:n_loc], return_counts=True)
-            sel = c >= report
-            mine = (u[sel].cpu().numpy(), c[sel].cpu().numpy())
-            tick("labels: component graph", t0)
-            lock.release()
-            t0 = time.time()
-            parts = exchange.all_gather_object(mine, group, "component labelling: sizes of the large components")
-            tick("x:label sizes", t0)
-            lock.acquire()
-            t0 = time.time()
-            tot = {}
-            for lab, cnt in parts:
-                for a, b in zip(lab.tolist(), cnt.tolist()):
-                    tot[a] = tot.get(a, 0) + b
-            big = sorted((a for a, b in tot.items() if b >= T // 2), key=lambda a: (-tot[a], a))
-            load = [0] * W
-            own = {}
-            for a in big:
-                r = min(range(W), key=lambda q: (load[q], q))
-                own[a] = r
-                load[r] += tot[a]
-            bl = sorted(own)
-            dbig = torch.as_tensor(np.asarray(bl if bl else [0], dtype=np.int64), device=dev)
-            dbo = torch.as_tensor(np.asarray([own[a] for a in bl] if bl else [0], dtype=np.uint8), device=dev)
-            owner = torch.empty(max(n_loc, 1), dtype=torch.uint8, device=dev)
-            torch.cuda.synchronize()
-            cc.owners(glabel.data_ptr(), dbig.data_ptr(), dbo.data_ptr(), len(bl), owner.data_ptr())
-            del glabel
-            sk = torch.empty(max(n_loc, 1), dtype=torch.int64, device=dev)
-            sc = torch.empty(max(n_loc, 1), dtype=torch.int32, device=dev)
-            send = cc.shard(owner.data_ptr(), sk.data_ptr(), sc.data_ptr())
-            del owner
+            pairs, n_glob = component_table(cc, group, tick, getattr(self, "lock", None), self.device)
         finally:
             cc.close()
         owned.close()
-        tick("labels: owners + shard", t0)
-        lock.release()
+        import time
         t0 = time.time()
-        rk, rc, _ = exchange.all_to_all_pairs(sk, sc, send, group, name="component exchange (the k1-mers of whole components to their rank, all-to-all)")
-        del sk, sc
-        tick("x:component exchange", t0)
-        lock.acquire()
-        t0 = time.time()
+        rk, rc = pairs
         torch.cuda.synchronize()
         table = self._dev.Table.from_pairs(self.ctx, rk.data_ptr(), rc.data_ptr(), rk.numel(), self.K + 1, not self.strand_specific)
         tick("table", t0)

@@ -26,13 +26,33 @@ class OracleOps(object):
     def n_reads(self):
         return len(self.r1)
 
-    def local_pairs(self, W):
+    owner_labelling = False              # True: the default path of GpuOps -- components labelled on owner shards (tests/cc_reference.py)
+
+    def local_pairs(self, W, by_minimizer=False):
+        k1 = self.K + 1
+        self._owner = (lambda keys: exchange.owner_of_minimizer(keys, k1, not self.strand_specific, W)) if by_minimizer else (lambda keys: exchange.owner_of(keys, W))
+        return self._local_pairs(W)
+
+    def owned_table(self, rk, rc):
+        k, c = self.reduce_pairs(rk, rc)
+        return k.numpy().view(np.uint64), c.numpy()
+
+    def component_table(self, owned, group, tick):
+        """the steps of the owner-shard labelling in numpy (tests/cc_reference.py) behind the product's choreography"""
+        from cc_reference import NumpyComponents
+        W, rank = dist.get_world_size(group), dist.get_rank(group)
+        cc = NumpyComponents(owned[0], owned[1], W, rank, self.K + 1, not self.strand_specific)
+        (rk, rc), n_glob = distributed.component_table(cc, group, tick, None, self.device)
+        self.component_keys = (owned[0], rk.numpy().view(np.uint64).copy())
+        return (rk, rc), n_glob
+
+    def _local_pairs(self, W):
         k1 = self.K + 1
         if self.strand_specific:         # forward counting of reads_1 and RC(reads_2): every key as it is
             recs = [r for f in seqs.strand_specific(list(self.r1), list(self.r2) if self.paired else None) for r in f]
             ck, cc = count.count_k1mers_packed(recs, k1)
             cc = cc.astype(np.int64)
-            own = exchange.owner_of(ck, W)
+            own = self._owner(ck)
             order = np.argsort(own, kind="stable")
             per = np.bincount(own, minlength=W)
             return torch.as_tensor(ck[order].view(np.int64)), torch.as_tensor(cc[order].astype(np.int32)), per
@@ -43,7 +63,7 @@ class OracleOps(object):
         pal = np.array([int(k) == count.rc_key(k, k1) for k in keys], dtype=bool)
         ck, cc = keys[canon], cnts[canon].astype(np.int64)
         cc[pal[canon]] //= 2
-        own = exchange.owner_of(ck, W)
+        own = self._owner(ck)
         order = np.argsort(own, kind="stable")
         per = np.bincount(own, minlength=W)
         return torch.as_tensor(ck[order].view(np.int64)), torch.as_tensor(cc[order].astype(np.int32)), per
@@ -68,7 +88,21 @@ class OracleOps(object):
                 tab[count.key_to_str(r, k1)] = c
         return tab
 
-    def extension(self, tab, partition_size):
+    def extension(self, tab, partition_size, group=None, presharded=None):
+        if presharded is not None:
+            # this rank's whole components: checked against the components of the job's k1-mers, then the replicated oracle extension
+            # on the tables of all ranks together (the sharded walks and their merge are GpuOps' own: tests/test_distributed_gpu.py)
+            from cc_reference import reference_labels
+            rk, rc = tab
+            parts = [None] * dist.get_world_size(group)
+            dist.all_gather_object(parts, (rk.numpy().view(np.uint64), rc.numpy(), self.component_keys[0]), group=group)
+            keys = np.concatenate([p[0] for p in parts])
+            assert len(keys) == presharded == len(np.unique(keys)) == sum(len(p[2]) for p in parts)
+            assert np.array_equal(np.sort(keys), np.sort(np.concatenate([p[2] for p in parts])))       # the owned shards, moved, not changed
+            lab = reference_labels(keys, self.K + 1, not self.strand_specific)
+            where = np.repeat(np.arange(len(parts)), [len(p[0]) for p in parts])
+            assert len(np.unique(np.stack([lab, where], axis=1), axis=0)) == len(np.unique(lab))       # a component lives on ONE rank
+            tab = self.table_from_pairs(torch.as_tensor(keys.view(np.int64)), torch.as_tensor(np.concatenate([p[1] for p in parts])))
         return extension.run_correction([(k, tab[k]) for k in sorted(tab, reverse=True)], comp_size_threshold=partition_size)
 
     def route(self, res, K, partition_size, pv):
@@ -140,6 +174,7 @@ def main():
     psize = m.get("partition_size", 500)
     pv = [part_vectors(len(b["contigs"]), psize) for b in g["big_components"]] or None
     ops = OracleOps(r1, r2, m["K"])
+    ops.owner_labelling = os.environ.get("SHN_TEST_OWNER_LABELS") == "1"
     if len(sys.argv) > 3:                    # a rank whose graph stage fails: every rank must raise together (no rank left in the gather)
         fail = int(sys.argv[3])
 
@@ -158,7 +193,8 @@ def main():
         return
     res = distributed.assemble_distributed(ops, m["K"], psize, "s", m["sf_seed"], pv, double_stranded=not m.get("strand_specific"))
     if rank == 0:
-        json.dump({"partitions": dict(res["partitions"]), "final": res["final"], "contigs": res["contigs"]}, open(out, "w"))
+        json.dump({"partitions": dict(res["partitions"]), "final": res["final"], "contigs": res["contigs"],
+                   "owner_labelling_ran": hasattr(ops, "component_keys"), "n_k1mers": res["n_k1mers"]}, open(out, "w"))
     dist.destroy_process_group()
 
 

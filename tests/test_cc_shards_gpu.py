@@ -9,69 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _rc(keys, k):
-    out = np.zeros_like(keys)
-    x = keys.copy()
-    for _ in range(k):
-        out = (out << np.uint64(2)) | (np.uint64(3) - (x & np.uint64(3)))
-        x >>= np.uint64(2)
-    return out
-
-
-def _low_complexity(keys, k):
-    cnt = np.zeros((4, len(keys)), dtype=np.int64)
-    x = keys.copy()
-    for _ in range(k):
-        b = (x & np.uint64(3)).astype(np.int64)
-        for v in range(4):
-            cnt[v] += b == v
-        x >>= np.uint64(2)
-    return cnt.max(axis=0) >= k - 2
-
-
-def reference_labels(keys, k, canonical):
-    """component number of every key (keys: distinct, any order)"""
-    from scipy.sparse import coo_matrix
-    from scipy.sparse.csgraph import connected_components
-    order = np.argsort(keys)
-    sk = keys[order]
-    alive = ~_low_complexity(sk, k)
-    mask = np.uint64((1 << (2 * k)) - 1) if k < 32 else np.uint64(0xFFFFFFFFFFFFFFFF)
-    src, dst = [], []
-    sh = np.uint64(2 * (k - 1))
-    for which in range(16):
-        b = np.uint64(which & 3)
-        if which < 4:
-            y = ((sk << np.uint64(2)) | b) & mask
-            ok = alive.copy()
-        elif which < 8:
-            y = (sk >> np.uint64(2)) | (b << sh)
-            ok = alive.copy()
-        elif which < 12:                                             # siblings: the same K-prefix, another last base
-            y = (sk & ~np.uint64(3)) | b
-            ok = alive & ((sk & np.uint64(3)) != b)
-        else:                                                        # ... the same K-suffix, another first base
-            y = (sk & ~(np.uint64(3) << sh)) | (b << sh)
-            ok = alive & (((sk >> sh) & np.uint64(3)) != b)
-        if canonical:
-            r = _rc(y, k)
-            y = np.minimum(y, r)
-        pos = np.searchsorted(sk, y)
-        pos = np.minimum(pos, len(sk) - 1)
-        hit = ok & (sk[pos] == y) & alive[pos]
-        src.append(np.nonzero(hit)[0])
-        dst.append(pos[hit])
-    src, dst = np.concatenate(src), np.concatenate(dst)
-    n = len(sk)
-    _, lab = connected_components(coo_matrix((np.ones(len(src), dtype=np.int8), (src, dst)), shape=(n, n)), directed=False)
-    out = np.empty(n, dtype=np.int64)
-    out[order] = lab
-    return out
-
-
-def same_partition(a, b):
-    pairs = np.unique(np.stack([a, b], axis=1), axis=0)
-    return len(pairs) == len(np.unique(a)) == len(np.unique(b))
+from cc_reference import reference_labels, same_partition
 
 
 def play_ranks(ctx, table, W, K1, canonical):

@@ -24,14 +24,60 @@ def test_partitions_are_dealt_by_load():
     assert distributed.deal_partitions([], 4).tolist() == [] and distributed.deal_partitions([3, 3, 3], 1).tolist() == [0, 0, 0]
 
 
+def test_owner_shard_labelling_in_numpy_gives_the_components():
+    """tests/cc_reference.py: NumpyComponents (the CPU stand-in for shn_cc_* behind distributed.component_table) with 3 played ranks
+    against the components of the whole set -- the restatement the gloo tests below rely on (the device kernels are held against
+    the same reference in tests/test_cc_shards_gpu.py)"""
+    from cc_reference import NumpyComponents, reference_labels, same_partition
+    from shannon_amd import exchange, synth
+    from oracle import count, seqs
+    (q1, q2), _ = synth.make_dataset(1500, 4, seed=3)
+    reads = ["".join("ACGT"[c] for c in r) for r in np.concatenate([q1, q2])]
+    reads += [seqs.reverse_complement(r) for r in reads]
+    k1, W = 26, 3
+    keys, cnts = count.count_k1mers_packed(reads, k1)
+    canon = np.array([int(k) <= count.rc_key(k, k1) for k in keys], dtype=bool)
+    keys, cnts = keys[canon], cnts[canon]
+    own = exchange.owner_of_minimizer(keys, k1, True, W)
+    ccs = [NumpyComponents(keys[own == r], cnts[own == r], W, r, k1, True) for r in range(W)]
+    base = [sum(c.n for c in ccs[:r]) for r in range(W)]
+    sent = [c.queries() for c in ccs]
+    edges = []
+    for d in range(W):
+        offs = [np.concatenate([[0], np.cumsum(s[2])]) for s in sent]
+        import torch
+        rk = torch.cat([sent[s][0][offs[s][d]:offs[s][d + 1]] for s in range(W)])
+        rl = torch.cat([sent[s][1][offs[s][d]:offs[s][d + 1]] for s in range(W)])
+        edges.append(ccs[d].answer(rk, rl, [int(sent[s][2][d]) for s in range(W)], base))
+    ge = torch.cat(edges)
+    assert ge.numel() > 0
+    ids, labels = ccs[0].solve(ge, sum(c.n for c in ccs) + 1)
+    gl = np.concatenate([ccs[r].labels(base[r], ids, labels).numpy() for r in range(W)])
+    allk = np.concatenate([c.keys for c in ccs])
+    ref = reference_labels(allk, k1, True)
+    assert len(np.unique(ref)) > 3 and same_partition(gl, ref)
+
+
+@pytest.mark.parametrize("name,port,world", [("syn_pe_s0", 29651, 2), ("syn_part_s33", 29652, 3), ("syn_se_ss_s53", 29653, 2)])
+def test_ranks_with_owner_shard_labelling_equal_single_process(name, port, world, tmp_path):
+    """the default N-rank path (no replicated table: minimizer-sharded owners, components labelled on the shards, whole components
+    to their rank -- distributed.component_table) over gloo with the numpy stand-in for the device kernels; the worker checks that
+    every component ends on one rank and that the exchanged tables are the job's k1-mers"""
+    _ranks_equal_single(name, port, world, None, tmp_path, {"SHN_TEST_OWNER_LABELS": "1"})
+
+
 @pytest.mark.parametrize("name,port,world,chunk", [("syn_pe_s0", 29611, 2, None), ("syn_se_s5", 29612, 2, None), ("syn_part_s33", 29613, 2, "997"),
                                                    ("syn_part_s33", 29614, 3, None), ("syn_pe_s0", 29615, 3, "500"),
                                                    ("syn_pe_ss_s69", 29617, 2, None), ("syn_se_ss_s53", 29618, 3, None)])     # -s / --strand_specific
 def test_ranks_equal_single_process(name, port, world, chunk, tmp_path):
     """world_size 2 and 3 (gloo); chunk: every variable-size collective in rounds of that many elements (exchange.chunk_elems)"""
+    _ranks_equal_single(name, port, world, chunk, tmp_path, {})
+
+
+def _ranks_equal_single(name, port, world, chunk, tmp_path, env_extra):
     from oracle import pipeline as opipe
     out = str(tmp_path / "res.json")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **env_extra)
     if chunk:
         env["SHN_COLL_CHUNK"] = chunk
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
@@ -39,6 +85,7 @@ def test_ranks_equal_single_process(name, port, world, chunk, tmp_path):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:]
     got = json.load(open(out))
+    assert got["owner_labelling_ran"] == (env_extra.get("SHN_TEST_OWNER_LABELS") == "1")
     m = MANIFEST[name]
     g = load_case(name)
     inp = load_inputs(name)
