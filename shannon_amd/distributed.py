@@ -118,7 +118,9 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
     # ---- 1. local count + bucket exchange + reduce by key
     lock.acquire()
     t0 = time.time()
-    if W == 1 and hasattr(ops, "local_table"):
+    import os
+    forced = os.environ.get("SHN_OWNER_LABELS") == "2" and getattr(ops, "owner_labelling", False)    # (tests: the N-rank path on one rank)
+    if W == 1 and hasattr(ops, "local_table") and not forced:
         # one rank: nothing to exchange, reduce or gather -- the counted table IS the table (it used to be exported to pairs, reduced
         # into a table, exported again and rebuilt: two passes through the pairs path, 0.2 s at configs[2])
         table = ops.local_table()
@@ -165,7 +167,7 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
         table = ops.table_from_pairs(gk, gc)
         tick("table", t0)
     t0 = time.time()
-    if W > 1 and getattr(ops, "owner_labelling", False):
+    if (W > 1 or forced) and getattr(ops, "owner_labelling", False):
         res = ops.extension(table, partition_size, group, presharded=n_table)
     else:
         n_table = len(table) if gk is None else None

@@ -48,6 +48,39 @@ def test_distributed_path_matches_single_process(group, paired, n_genes, seed):
         ctx.close()
 
 
+@pytest.mark.parametrize("paired,n_genes,seed,big", [(True, 12, 4, False), (False, 6, 5, True)])
+def test_owner_shard_path_on_rccl_with_one_rank(group, paired, n_genes, seed, big, monkeypatch):
+    """SHN_OWNER_LABELS=2 sends a one-rank job through the N-rank path (shard by minimizer, queries, edges, component exchange): every
+    collective of it on the "nccl" = RCCL backend with device tensors -- what the shared-GPU tests below do over gloo"""
+    from shannon_amd import device, synth, pipeline, distributed, kmers_for_component as kfc
+    monkeypatch.setenv("SHN_OWNER_LABELS", "2")
+    if big:
+        monkeypatch.setenv("SHN_CONTIG_GPU", "1")
+    (q1, q2), _ = synth.make_dataset(12000, n_genes, seed=seed)
+    if not paired:
+        q1, q2 = np.concatenate([q1, q2]), None
+    ctx = device.Context(0)
+    d1 = device.Reads.from_codes(ctx, q1)
+    d2 = device.Reads.from_codes(ctx, q2) if paired else None
+    store = kfc.ReadStore(q1, q2)
+    try:
+        ref = pipeline.assemble_resident(ctx, d1, d2, store, K=25, sample="t", seed=1)
+        ops = distributed.GpuOps(ctx, d1, d2, store, 25)
+        T = {}
+        got = distributed.assemble_distributed(ops, 25, 500, "t", 1, timings=T)
+        assert "x:component exchange" in T and ops.component_table_sizes[0] == ops.component_table_sizes[1] == ops.component_table_sizes[2]
+        assert got["contigs"] == ref.extension.contigs
+        assert list(got["partitions"]) == list(ref.partitions)
+        for name in ref.partitions:
+            assert got["partitions"][name] == ref.partitions[name]["reconstructed_fasta"]
+        assert got["final"] == ref.final
+    finally:
+        d1.close()
+        if d2 is not None:
+            d2.close()
+        ctx.close()
+
+
 @pytest.mark.parametrize("world,paired,n_genes,seed,port,big,ss", [(2, True, 3, 11, 29621, False, False), (3, True, 12, 4, 29622, False, False),
                                                                    (2, False, 2, 5, 29623, False, False), (4, True, 40, 8, 29624, False, False),
                                                                    (2, True, 40, 8, 29625, True, False), (3, True, 12, 4, 29626, True, False),
