@@ -307,8 +307,8 @@ def test_the_largest_partition_through_the_oracle(full):
     F = full
     P, K1 = F.R.partitioning, F.K1
     # (the largest partition of all at configs[2]; at 4s the largest has 15.6 M pairs -- 223 s through the oracle, it passed in round 5 --
-    # and the suite takes the largest one under 4 M pairs)
-    cap = 4_000_000 if F.cfg == "2" else 1_500_000
+    # and the suite takes the largest one under a million pairs: the >= 1 M-pair class of the review is met by configs[2]'s 3.9 M)
+    cap = 4_000_000 if F.cfg == "2" else 1_000_000
     nm = max((x for x in P["routes"] if len(P["routes"][x]) <= cap), key=lambda x: len(P["routes"][x]))
     t0 = time.time()
     rb = P["k1mer_bytes"][nm]
