@@ -145,6 +145,36 @@ def test_labels_of_the_shards_are_the_components(W, n_genes, seed, K, ss):
         ctx.close()
 
 
+def test_tiny_inputs_and_empty_shards():
+    """a handful of k1-mers over 16 ranks: shards without a k1-mer, ranks that receive no component, no edge between shards at all"""
+    import torch
+    from shannon_amd import device, synth
+    (q1, q2), _ = synth.make_dataset(40, 1, seed=9)
+    ctx = device.Context(0)
+    d1 = device.Reads.from_codes(ctx, q1[:3])
+    try:
+        table = device.count_k1mers(ctx, [d1], 26, True)
+        tk, tc = table.download()
+        assert 0 < len(tk) < 400
+        out, got = play_ranks(ctx, table, 16, 26, True)
+        assert any(len(o[0]) == 0 for o in out)
+        keys = np.concatenate([o[0] for o in out])
+        gl = np.concatenate([o[1] for o in out])
+        assert np.array_equal(np.sort(keys), np.sort(tk)) and same_partition(gl, reference_labels(keys, 26, True))
+        assert sum(len(k) for k, _ in got) == len(tk)
+        table.close()
+        # one k1-mer, two ranks: nothing to ask, nothing to solve
+        one = torch.as_tensor(np.array([0x1B2C3D4E5F60 & ((1 << 52) - 1)], dtype=np.int64), device="cuda")
+        cnt = torch.ones(1, dtype=torch.int32, device="cuda")
+        t1 = device.Table.from_pairs(ctx, one.data_ptr(), cnt.data_ptr(), 1, 26, True)
+        out, got = play_ranks(ctx, t1, 2, 26, True)
+        assert sum(len(o[0]) for o in out) == 1 and sum(len(k) for k, _ in got) == 1
+        t1.close()
+    finally:
+        d1.close()
+        ctx.close()
+
+
 def test_shard_rule_mirror():
     """the host mirror of the owner rule (exchange.owner_of_minimizer) against the device's shards"""
     import torch
