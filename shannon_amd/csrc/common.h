@@ -202,9 +202,12 @@ __device__ __forceinline__ uint32_t shn_minimizer_bucket(uint64_t key, int k, in
 // owner rank of a k1-mer by its minimizer (the N-rank path that labels components on the owner shards: a k1-mer and its eight
 // neighbours share their minimizer six times out of seven, so most edges of the k1-mer graph stay inside a shard)
 #define SHN_OWNER_M 13
+__device__ __forceinline__ uint32_t shn_owner_of_order(uint32_t order, int world) {
+  return (uint32_t)(shn_mix64((uint64_t)order ^ 0x6A09E667F3BCC909ULL) % (uint64_t)world);
+}
 __device__ __forceinline__ uint32_t shn_owner_minimizer(uint64_t key, int k, int canon, int world) {
   const int m = k < SHN_OWNER_M ? k : SHN_OWNER_M;
-  return (uint32_t)(shn_mix64((uint64_t)shn_minimizer_order(key, k, m, canon) ^ 0x6A09E667F3BCC909ULL) % (uint64_t)world);
+  return shn_owner_of_order(shn_minimizer_order(key, k, m, canon), world);
 }
 
 // A table as its consumers see it: keys grouped by bucket, ascending inside a bucket; the bucket of a key by the table's layout.

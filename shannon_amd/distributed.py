@@ -572,16 +572,18 @@ class GpuOps(object):
     def component_table(self, owned, group, tick):
         """owned: this rank's shard of the k1-mers (by minimizer).  Returns (a table of the whole components dealt to this rank,
         the number of k1-mers of the job): component_table() below with the device kernels (include/shannon_hip.h: shn_cc_*)."""
+        import time
         W, rank = dist.get_world_size(group), dist.get_rank(group)
         n_loc = len(owned)
+        t0 = time.time()
         cc = _GpuComponents(self, owned, W, rank)
+        tick("labels: local components + queries", t0)
         try:
             pairs, n_glob = component_table(cc, group, tick, getattr(self, "lock", None), self.device)
         finally:
             cc.close()
-        owned.close()
-        import time
         t0 = time.time()
+        owned.close()
         rk, rc = pairs
         torch.cuda.synchronize()
         table = self._dev.Table.from_pairs(self.ctx, rk.data_ptr(), rc.data_ptr(), rk.numel(), self.K + 1, not self.strand_specific)
