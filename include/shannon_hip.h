@@ -213,6 +213,8 @@ int shn_ext_seed_info(shn_ctx* ctx, const shn_ext* e, const uint32_t* ranks, uin
  *   shn_cc_owners        owner rank of every k1-mer (1 byte each): hash of its label mod world, except the n_big labels listed
  *                        (ascending) with their ranks -- the components the caller balances by size
  *   shn_cc_shard         the shard's (key, count) pairs grouped by owner rank (per_rank[r] each)                               */
+/* diagnostics of the labelling kernel (SHN_CC_DEBUG=1): out4[0] = look-ups that found their key since the last reset                */
+int shn_debug_cc_counters(uint64_t* out4, int reset);
 typedef struct shn_cc shn_cc;
 int shn_cc_create(shn_ctx* ctx, const shn_table* t, int world, int rank, shn_cc** out);
 void shn_cc_destroy(shn_cc* c);

@@ -44,6 +44,7 @@ SIGNATURES = {
     "shn_table_merge_rc": (C.c_int, [vp, vp, vp, vpp]),
     "shn_table_shard": (C.c_int, [vp, vp, C.c_int, u64p, vp, vp]),
     "shn_table_shard_mode": (C.c_int, [vp, vp, C.c_int, C.c_int, u64p, vp, vp]),
+    "shn_debug_cc_counters": (C.c_int, [u64p, C.c_int]),
     "shn_cc_create": (C.c_int, [vp, vp, C.c_int, C.c_int, vpp]),
     "shn_cc_destroy": (None, [vp]),
     "shn_cc_query_counts": (C.c_int, [vp, u64p]),

@@ -523,8 +523,18 @@ __device__ __forceinline__ void cc_unite(uint32_t* lab, uint32_t u, uint32_t v) 
 // and only joined through a common neighbour if that neighbour exists and is not low-complexity (a transcript's last K-mer before
 // a poly-A tail is the typical exception).  So the labelling also unites every k1-mer with its (up to six) siblings.
 // Look-ups as in the records kernel: eight lanes per canonical k1-mer, through the one-line dictionary.
+// diagnostics (round 5): look-ups of the labelling kernel that found their key / unions made / unions that found both ends united already
+__device__ unsigned long long g_cc_dbg[4];
+extern "C" int shn_debug_cc_counters(uint64_t* out4, int reset) {
+  unsigned long long h[4] = {0, 0, 0, 0};
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_cc_dbg), sizeof(h)) != hipSuccess) return shn_fail(SHN_ERR_HIP, "shn_debug_cc_counters");
+  for (int i = 0; i < 4; i++) out4[i] = h[i];
+  if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_cc_dbg), z, sizeof(z)) != hipSuccess) return shn_fail(SHN_ERR_HIP, "shn_debug_cc_counters"); }
+  return SHN_OK;
+}
+static int cc_half_mode() { return ((getenv("SHN_CC_HALF") && getenv("SHN_CC_HALF")[0] == '0') ? 0 : 1) | (getenv("SHN_CC_DEBUG") ? 2 : 0); }
 __global__ void cc_edges_kernel(const TabIdx T, const uint8_t* __restrict__ flags,
-                                uint64_t n, int k, int canonical, uint32_t* lab, const unsigned long long* __restrict__ lines, uint64_t n_lines) {
+                                uint64_t n, int k, int canonical, uint32_t* lab, const unsigned long long* __restrict__ lines, uint64_t n_lines, int half_mode) {
   const uint64_t* __restrict__ tkeys = T.keys;
   const uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
   const uint64_t total = n * 8, rounded = (total + 63) & ~63ULL;
@@ -544,9 +554,12 @@ __global__ void cc_edges_kernel(const TabIdx T, const uint8_t* __restrict__ flag
         else if (p & 4) { skip |= (str & 3) == b; mykey = (str & ~3ULL) | b; }
         else { const int sh = 2 * (k - 1); skip |= ((str >> sh) & 3) == b; mykey = (str & ~(3ULL << sh)) | (b << sh); }
         if (canonical) { const uint64_t rc = shn_revcomp(mykey, k); if (rc < mykey) mykey = rc; }
-        if (skip) mykey = 0;
+        // (every edge is seen from both of its ends -- the neighbour and sibling relations are symmetric, and so is "both not
+        // low-complexity" -- so an end asks only for the larger keys: half the look-ups; what is not asked goes to line 0, which the
+        // caches hold)
+        if (skip || ((half_mode & 1) && mykey <= str)) mykey = 0;
       }
-      const uint64_t myline = fd_bucket(T, mykey, n_lines);
+      const uint64_t myline = mykey ? fd_bucket(T, mykey, n_lines) : 0ULL;
       uint64_t key[8];
       ulonglong2 v[8];
 #pragma unroll
@@ -558,14 +571,31 @@ __global__ void cc_edges_kernel(const TabIdx T, const uint8_t* __restrict__ flag
       for (int q = 0; q < 8; q++) {
         const uint32_t w = fd_match(v[q], lines, shfl_u64(myline, g0 + q), key[q], p, g0, T, flags);
         // (lane q of the group does the union: eight independent ones side by side)
-        if (w != 0xFFFFFFFFu && p == q && (uint64_t)(w & ~FD_PAL) != i) cc_unite(lab, (uint32_t)i, w & ~FD_PAL);
+        if (w != 0xFFFFFFFFu && p == q && (uint64_t)(w & ~FD_PAL) != i) {
+          if (half_mode & 2) atomicAdd(&g_cc_dbg[0], 1ULL);
+          cc_unite(lab, (uint32_t)i, w & ~FD_PAL);
+        }
       }
     }
   }
 }
+// Every k1-mer gets its root.  The find here must NOT compress: a compressing find of one thread stores an ancestor into lab[j]
+// (correct inside the union-find, where any ancestor will do) -- and when that store lands after thread j has written j's root, j
+// keeps a label that is not a root.  Found in round 5 when the labelling asked every edge from one end only: the trees were deeper
+// at this point, 70 % of the runs left 1-40 k1-mers of a 227 k table with an ancestor for a label (a k1-mer then went to another
+// rank than its component).  With every edge united twice the trees are all but flat here and the window almost never opened --
+// almost.  Without stores other than the roots themselves, every value a find can read is an ancestor and the roots do not move.
+__device__ __forceinline__ uint32_t cc_find_readonly(const uint32_t* lab, uint32_t x) {
+  uint32_t cur = x;
+  while (true) {
+    const uint32_t p = __hip_atomic_load(&lab[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p == cur) return cur;
+    cur = p;
+  }
+}
 __global__ void cc_flatten_kernel(uint32_t* lab, uint64_t n) {
   uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { uint32_t r = cc_find(lab, (uint32_t)i); lab[i] = r; }
+  if (i < n) { const uint32_t r = cc_find_readonly(lab, (uint32_t)i); __hip_atomic_store(&lab[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 // size estimate of the components from every 64th k1-mer (a full count would hammer a handful of addresses)
 __global__ void cc_sample_kernel(const uint32_t* __restrict__ lab, uint64_t n, uint32_t* __restrict__ size_s) {
@@ -1594,7 +1624,7 @@ static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank
   hipLaunchKernelGGL(cc_init_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, d_lab, n);
   { TimerRegion t1(ctx, T_EXT_PREP);
     hipLaunchKernelGGL(cc_edges_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, shn_tab_idx(t),
-                       d_flags, n, t->k, t->canonical, d_lab, (const unsigned long long*)lines, n_lines); }
+                       d_flags, n, t->k, t->canonical, d_lab, (const unsigned long long*)lines, n_lines, cc_half_mode()); }
   hipLaunchKernelGGL(cc_flatten_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, d_lab, n);
   TRYS(hipMemsetAsync(d_size, 0, (n + 1) * 4, s));
   hipLaunchKernelGGL(cc_sample_kernel, dim3((uint32_t)cdiv(cdiv(n, 64), 256)), dim3(256), 0, s, d_lab, n, d_size);
@@ -1847,7 +1877,7 @@ extern "C" int shn_cc_create(shn_ctx* ctx, const shn_table* t, int world, int ra
     { int rc = build_fine_dict(ctx, t, c->d_flags, &lines, &n_lines); if (rc) return fail(rc); }
     hipLaunchKernelGGL(cc_init_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, c->d_lab, n);
     hipLaunchKernelGGL(cc_edges_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(n * 8, 256), 1u << 22)), dim3(256), 0, s, shn_tab_idx(t),
-                       c->d_flags, n, t->k, t->canonical, c->d_lab, (const unsigned long long*)lines, n_lines);
+                       c->d_flags, n, t->k, t->canonical, c->d_lab, (const unsigned long long*)lines, n_lines, cc_half_mode());
     hipLaunchKernelGGL(cc_flatten_kernel, dim3((uint32_t)cdiv(n, 256)), dim3(256), 0, s, c->d_lab, n);
     hipLaunchKernelGGL((cc_query_kernel<false>), dim3(c->q_grid), dim3(256), 0, s, t->d_keys, c->d_flags, n, t->k, t->canonical, world, rank, c->d_lab,
                        c->d_cnt, c->d_bc, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr);

@@ -555,8 +555,22 @@ class GpuOps(object):
         import os
         return os.environ.get("SHN_OWNER_LABELS", "1") != "0"
 
+    def _digest(self, name, table):
+        """SHN_DIST_DIGEST=1 (diagnostics): a checksum of a table's sorted (key, count) pairs per stage, in self.digests"""
+        import os
+        if os.environ.get("SHN_DIST_DIGEST") != "1":
+            return
+        import hashlib
+        k, c = table.download()
+        o = np.argsort(k, kind="stable")
+        h = hashlib.sha256(np.ascontiguousarray(k[o]).tobytes() + np.ascontiguousarray(c[o]).tobytes()).hexdigest()[:16]
+        if not hasattr(self, "digests"):
+            self.digests = {}
+        self.digests[name] = (int(len(k)), h)
+
     def local_pairs(self, W, by_minimizer=False):
         t = self._count()
+        self._digest("counted", t)
         n = len(t)
         dk = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
         dc = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
@@ -567,7 +581,9 @@ class GpuOps(object):
     def owned_table(self, rk, rc):
         """the pairs this rank owns, equal keys summed"""
         torch.cuda.synchronize()
-        return self._dev.Table.from_pairs(self.ctx, rk.data_ptr(), rc.data_ptr(), rk.numel(), self.K + 1, not self.strand_specific)
+        t = self._dev.Table.from_pairs(self.ctx, rk.data_ptr(), rc.data_ptr(), rk.numel(), self.K + 1, not self.strand_specific)
+        self._digest("owned", t)
+        return t
 
     def component_table(self, owned, group, tick):
         """owned: this rank's shard of the k1-mers (by minimizer).  Returns (a table of the whole components dealt to this rank,
@@ -588,6 +604,7 @@ class GpuOps(object):
         torch.cuda.synchronize()
         table = self._dev.Table.from_pairs(self.ctx, rk.data_ptr(), rc.data_ptr(), rk.numel(), self.K + 1, not self.strand_specific)
         tick("table", t0)
+        self._digest("components", table)
         self.component_table_sizes = (int(n_loc), int(len(table)), int(n_glob))      # owned shard, walked table, the job (tests, bench)
         return table, n_glob
 
@@ -607,7 +624,9 @@ class GpuOps(object):
 
     def table_from_pairs(self, gk, gc):
         torch.cuda.synchronize()
-        return self._dev.Table.from_pairs(self.ctx, gk.data_ptr(), gc.data_ptr(), gk.numel(), self.K + 1, not self.strand_specific)
+        t = self._dev.Table.from_pairs(self.ctx, gk.data_ptr(), gc.data_ptr(), gk.numel(), self.K + 1, not self.strand_specific)
+        self._digest("gathered", t)
+        return t
 
     graph_threads = 8
     sharded_extension = True

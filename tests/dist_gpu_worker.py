@@ -31,9 +31,11 @@ def main():
     res = distributed.assemble_distributed(ops, 25, 500, "t", 1, double_stranded=not ss, timings=T)
     sizes = [None] * W
     dist.all_gather_object(sizes, getattr(ops, "component_table_sizes", None))
+    digs = [None] * W
+    dist.all_gather_object(digs, getattr(ops, "digests", None))
     if rank == 0:
         json.dump({"partitions": dict(res["partitions"]), "final": res["final"], "contigs": res["contigs"], "timings": T,
-                   "n_k1mers": res["n_k1mers"], "table_sizes": sizes}, open(out, "w"))
+                   "n_k1mers": res["n_k1mers"], "table_sizes": sizes, "digests": digs}, open(out, "w"))
     dist.barrier()
     d1.close()
     if d2 is not None:
