@@ -16,6 +16,28 @@ def test_owner_hash_matches_device_constant():
     assert o.min() == 0 and o.max() == 7 and np.bincount(o).min() > 80
 
 
+def test_minimizer_owner_keeps_neighbours_together():
+    """exchange.owner_of_minimizer (host mirror of shn_owner_minimizer, csrc/common.h): the constants are the device's, the ranks are
+    balanced, a k-mer and its reverse complement have one owner, and a k-mer's successor mostly stays with it -- what keeps the
+    edges of the k1-mer graph inside a shard"""
+    from shannon_amd import exchange
+    src = open(os.path.join(ROOT, "shannon_amd", "csrc", "common.h")).read()
+    assert "#define SHN_OWNER_M %d" % exchange.OWNER_M in src and "0x%XULL" % exchange.OWNER_SALT in src
+    rng = np.random.default_rng(7)
+    k, W = 26, 8
+    keys = rng.integers(0, 1 << 52, 20000, dtype=np.uint64)
+    own = exchange.owner_of_minimizer(keys, k, True, W)
+    assert own.min() == 0 and own.max() == W - 1 and np.bincount(own, minlength=W).min() > 20000 // W // 2
+    rc = np.zeros_like(keys); x = keys.copy()
+    for _ in range(k):
+        rc = (rc << np.uint64(2)) | (np.uint64(3) - (x & np.uint64(3))); x >>= np.uint64(2)
+    assert np.array_equal(exchange.owner_of_minimizer(rc, k, True, W), own)                    # strand-independent when canonical
+    succ = ((keys << np.uint64(2)) | rng.integers(0, 4, len(keys), dtype=np.uint64)) & np.uint64((1 << 52) - 1)
+    same = (exchange.owner_of_minimizer(succ, k, True, W) == own).mean()
+    assert same > 0.8, same                                                                     # (7 of 8 share the minimizer, the rest 1 in W)
+    assert (exchange.owner_of_minimizer(keys, k, False, W) != own).any()                        # the plain (strand-specific) rule is another one
+
+
 def test_partitions_are_dealt_by_load():
     from shannon_amd import distributed
     o = distributed.deal_partitions([5, 100, 7, 7, 60, 1], 3)
