@@ -674,20 +674,43 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     from shannon_amd import distributed
 
+    # Every step is checked, not only the last: the transcripts of each timed step leave a checksum of their buffers (names,
+    # sequences, offsets in file order -- xxh3 over ~60 MB: a few ms, inside the timed region) and after the timed region every
+    # step must equal the first; the first (= every) step is then held to the pinned order-free sha256 of its config
+    # (tests/golden/fullsize_digests.json).  SHN_EXT_DIGEST=1 (a diagnostic run: the checksums cost ~0.1 s per step) also keeps the
+    # extension's stage checksums of every step, so that a differing step names the first stage that differed.
+    step_digests, step_ext = [], []
+
+    def _quick(final):
+        if final is None:
+            return None
+        if hasattr(final, "quick_digest"):
+            return final.quick_digest()
+        import hashlib
+        h = hashlib.blake2b(digest_size=16)
+        for nm, sq in final.items():
+            h.update(nm.encode() + b"\t" + sq.encode() + b"\n")
+        return h.hexdigest()
+
     def step():
         if use_dist:
             ops = distributed.GpuOps(ctx, sets[0], sets[1], store, args.K)
             res = distributed.assemble_distributed(ops, args.K, 500, "bench", 1, timings=stage_t, lock=lock)
             d = _Done()
             d.res = res
+            step_digests.append(_quick(res["final"]) if res is not None else None)
             return d
         R = pipeline.assemble_resident(ctx, sets[0], sets[1], store, K=args.K, sample="bench", seed=1, timings=stage_t, keep_partitioning=True)
         d = _Done()
         d.R = R
+        step_digests.append(_quick(R.final))
+        step_ext.append(getattr(R.extension, "ext_digests", None))
         return d
 
     for _ in range(args.warmup):
         step().close()
+    warm_digests = list(step_digests)
+    del step_digests[:], step_ext[:]
     stage_t.clear()                      # host stage times: timed steps only
     ctx.timer_reset()
     exchange.stats_reset()
@@ -707,6 +730,28 @@ def main():
     if dist:
         dist.barrier()
     dt = time.time() - t0
+    # ---- every timed step against the first (and the warm-up steps against it too): a run that differs from itself has no number
+    if rank == 0:
+        ref_dg = step_digests[0] if step_digests else None
+        bad = [i for i, dg in enumerate(step_digests) if dg != ref_dg]
+        bad_warm = [i for i, dg in enumerate(warm_digests) if dg != ref_dg]
+        if bad or bad_warm:
+            sys.stderr.write("bench.py: the transcripts of timed step(s) %s / warm-up step(s) %s differ from timed step 0\n  timed: %s\n  warm-up: %s\n"
+                             % (bad, bad_warm, step_digests, warm_digests))
+            for i in bad:
+                a, b = (step_ext[0] if step_ext else None), (step_ext[i] if i < len(step_ext) else None)
+                if a is not None and b is not None:
+                    import numpy as _np
+                    names = ["table keys", "table counts", "bucket offsets", "weights + flags", "adjacency records", "seed order", "converged claims", "walk records"]
+                    st = [j for j in range(8) if not _np.array_equal(a[j], b[j])]
+                    sys.stderr.write("  step %d: shn_ext_digests differ first at stage %s (chunks %s of 64); stages that differ: %s\n"
+                                     % (i, names[st[0]] if st else "none -- the extension agreed, a later stage differed",
+                                        _np.nonzero(a[st[0]] != b[st[0]])[0].tolist() if st else [], [names[j] for j in st]))
+                    sys.stderr.write("  step %d shn_ext_digests: %s\n" % (i, b.tolist()))
+                else:
+                    sys.stderr.write("  step %d: no stage checksums (run with SHN_EXT_DIGEST=1 to have shn_ext_digests of every step)\n" % i)
+            sys.stderr.flush()
+            os._exit(3)
     tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if (dist and dist.get_backend() == "gloo") else dev)
     if dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -853,6 +898,8 @@ def main():
                        "host_stage_seconds_per_step_slowest_rank": stage_max,
                        "transcripts": (len(last.res["final"]) if use_dist else len(last.R.final)),
                        "transcripts_sha256_16": _final_sha(last.res["final"] if use_dist else last.R.final),
+                       "steps_checked": {"timed": len(step_digests), "warmup": len(warm_digests), "all_equal": True, "checksum": step_digests[0] if step_digests else None,
+                                         "pinned_sha256_16": None},
                        # row a28 census: path_decompose calls that reached the LP trials, and those of them in which the optimal face of a
                        # trial was not a point (there the interior-point limit -- the analytic centre -- differs from a vertex)
                        "lp_rule": lp["rule"], "lp_calls": lp["lp_calls"] / args.steps, "lp_degenerate": lp["lp_degenerate"] / args.steps,
@@ -875,6 +922,19 @@ def main():
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(timers.items())},
             "kernel_launches_per_step": {k: v[1] / args.steps for k, v in sorted(timers.items())},
         }
+        # the pinned digest of the configuration (the one the full-size GPU tests check): a run whose every step agrees with itself
+        # but not with the pin fails too
+        try:
+            pins = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_digests.json")))
+        except OSError:
+            pins = {}
+        pin = pins.get(args.config) if is_config else None
+        out["config"]["steps_checked"]["pinned_sha256_16"] = pin
+        if pin is not None and pin != out["config"]["transcripts_sha256_16"] and os.environ.get("SHN_BENCH_ALLOW_UNPINNED") != "1":
+            sys.stderr.write("bench.py: transcripts digest %s of --config %s differs from the pinned %s (tests/golden/fullsize_digests.json)\n"
+                             % (out["config"]["transcripts_sha256_16"], args.config, pin))
+            sys.stderr.flush()
+            os._exit(4)
         if world == 1 and not use_dist:
             # ingest-inclusive rate: the resident step plus reading the batch from FASTA text at the measured ingest rate (no overlap
             # between ingest and the step assumed)

@@ -114,6 +114,11 @@ int shn_table_download(shn_ctx* ctx, const shn_table* t, uint64_t* keys, uint32_
  * with count >= lower, sorted ascending.  Call with keys==NULL to get the size in *n.       */
 int shn_table_dump(shn_ctx* ctx, const shn_table* t, uint32_t lower, uint64_t* keys, uint32_t* counts,
                    uint64_t* n);
+/* `jellyfish dump -L lower` (--kmer_hard_cutoff, shannon.py:237-241, 441): a new table of the k1-mers whose count in the
+ * reference's input is >= lower -- for a canonical table the count of the strand-doubled input, so a k1-mer that is its own
+ * reverse complement stands for twice its stored count (the rule of shn_table_dump).  Same layout and bucket structure, built by
+ * a stable compaction on the device; shn_table_total() stays the number of windows counted.  Caller destroys both tables.       */
+int shn_table_filter_lower(shn_ctx* ctx, const shn_table* t, uint32_t lower, shn_table** out);
 /* device-resident view for collectives (RCCL all-to-all of (key,count) shards) */
 int shn_table_device_ptrs(const shn_table* t, void** keys, void** counts);
 /* look up `n` keys (host array, already canonical if the table is) -> counts (0 if absent) */

@@ -8,6 +8,8 @@ hot path and produces the same products: OUT/shannon.fasta, OUT/log.txt, OUT/TEM
 
     python shannon.py -o OUT --single reads.fasta            [-K 25] [--partition 500]
     python shannon.py -o OUT --left r1.fasta --right r2.fasta [-s / --ss / --strand_specific]
+    ... [--kmer_hard_cutoff N]   k1-mers counted fewer than N times are dropped (`jellyfish dump -L N`, shannon.py:237-241, 441; default 1)
+    ... [--kmer_soft_cutoff N]   hyp_min_weight: seed threshold + hyperbola of the contig stage (shannon.py:243-247, 457; default 3)
     python shannon.py -o OUT --left r1.fasta --right r2.fasta -p 8        # one rank per GPU (the reference's -p nJobs, shannon.py:527-566)
 
 -p N / --gpus N: the reference fans its partitions out over nJobs processes (GNU parallel, shannon.py:527-566); here the N jobs
@@ -71,7 +73,7 @@ def launch_ranks(n, args):
     return subprocess.call(cmd, env=env, cwd=os.getcwd())
 
 
-def rank_main(out_dir, reads, K, partition_size, min_weight, min_length, double_stranded, ignored, noted):
+def rank_main(out_dir, reads, K, partition_size, min_weight, min_length, double_stranded, ignored, noted, kmer_hard_cutoff=1):
     """one rank of an N-rank run: its slice of the reads (by index, contiguous), shannon_amd.distributed.assemble_distributed,
     rank 0 writes OUT/ (shannon.fasta, log.txt, TEMP/<sample>_allalgo_output/all_reconstructed.fasta and the contig files; the
     per-partition graph files stay with the ranks that owned the partitions)"""
@@ -87,8 +89,9 @@ def rank_main(out_dir, reads, K, partition_size, min_weight, min_length, double_
         one = torch.ones(1, dtype=torch.int64)
         dist.all_reduce(one)
         if rank == 0:
-            print("launch probe: %d ranks met, K=%d, partition=%d, double_stranded=%s, reads=%s, out=%s"
-                  % (int(one.item()), K, partition_size, double_stranded, ",".join(os.path.basename(p) for p in reads), out_dir))
+            print("launch probe: %d ranks met, K=%d, partition=%d, double_stranded=%s, reads=%s, out=%s, min_weight=%d, kmer_hard_cutoff=%d"
+                  % (int(one.item()), K, partition_size, double_stranded, ",".join(os.path.basename(p) for p in reads), out_dir, min_weight,
+                     kmer_hard_cutoff))
         dist.destroy_process_group()
         return 0
     dev_index = 0 if share else local
@@ -156,7 +159,8 @@ def rank_main(out_dir, reads, K, partition_size, min_weight, min_length, double_
     T["ingest"] = time.time() - t0
     say("Processed No of reads:%d, Avg. Read length: %.2f (every rank holds a slice of %d of them)" % (n, q1.shape[1] if n else 0, hi - lo))
     ops = distributed.GpuOps(ctx, d1, d2, kfc.ReadStore(q1, q2), K)
-    res = distributed.assemble_distributed(ops, K, partition_size, sample, 0, timings=T, double_stranded=double_stranded)
+    res = distributed.assemble_distributed(ops, K, partition_size, sample, 0, timings=T, double_stranded=double_stranded,
+                                           min_weight=min_weight, min_length=min_length, kmer_hard_cutoff=kmer_hard_cutoff)
     rc = 0
     if rank == 0:
         say("%d K-mers loaded; %d contigs; %d partitions" % (res["n_k1mers"], len(res["contigs"]), len(res["partitions"])))
@@ -195,10 +199,11 @@ def rank_main(out_dir, reads, K, partition_size, min_weight, min_length, double_
 def main(argv):
     K, partition_size, nJobs = 24, 500, 1                     # shannon.py:58,65,67
     out_dir, reads, double_stranded = None, [], True
-    min_weight, min_length = 3, 75                            # shannon.py:55-56
+    min_weight, min_length = 3, 75                            # hyp_min_weight, hyp_min_length: shannon.py:56-57
+    kmer_hard_cutoff = 1                                      # jellyfish_kmer_cutoff: shannon.py:55
     i = 1
     ignored, noted = [], []
-    takes_value = ("-o", "--single", "--left", "--right", "-K", "-p", "--gpus", "--partition", "--kmer_hard_cutoff")
+    takes_value = ("-o", "--single", "--left", "--right", "-K", "-p", "--gpus", "--partition", "--kmer_hard_cutoff", "--kmer_soft_cutoff")
     n_gpus = 0
     while i < len(argv):
         a = argv[i]
@@ -226,7 +231,14 @@ def main(argv):
         if a == "--partition":
             partition_size = int(argv[i + 1]); i += 2; continue
         if a == "--kmer_hard_cutoff":
-            min_weight = int(argv[i + 1]); i += 2; continue
+            # shannon.py:237-241, 441: `jellyfish dump -L N` -- k1-mers counted fewer than N times never enter k1mer.dict_org
+            kmer_hard_cutoff = int(argv[i + 1]); i += 2
+            print("OPTIONS --kmer_hard_cutoff: Kmer hard cutoff set to " + str(kmer_hard_cutoff)); continue
+        if a == "--kmer_soft_cutoff":
+            # shannon.py:243-247, 457: hyp_min_weight -> run_correction's min_weight (the seed threshold, extension_correction.py:345,
+            # and the hyperbola of the accept filter, :361)
+            min_weight = int(argv[i + 1]); i += 2
+            print("OPTIONS --kmer_soft_cutoff: Kmer soft cutoff set to " + str(min_weight)); continue
         if a in ("-s", "--ss", "--strand_specific"):
             # shannon.py:166-207, 407-411: no strand doubling; of a pair, RC(reads_2) stands for reads_2
             double_stranded = False; i += 1; continue
@@ -237,10 +249,6 @@ def main(argv):
                          "products but not reads{comp}.fasta / component*k1mers_allowed.dict (shannon_amd/reference_api.py writes those "
                          "when a single stage is driven through the reference's file interface)" % a)
             i += 1; continue
-        if a == "--kmer_soft_cutoff":
-            noted.append("--kmer_soft_cutoff %s: not used by the hot path (the reference passes it to jellyfish dump -L only with --filter_FP)"
-                         % (argv[i + 1] if i + 1 < len(argv) else "(no value)"))
-            i += 2; continue
         if a in ("--compare", "--kallisto_cutoff"):
             ignored.append(a); i += 2; continue
         ignored.append(a); i += 1
@@ -268,7 +276,7 @@ def main(argv):
             if n_gpus > 1:
                 print("NOTE: --gpus %d asked for, the node shows %d GPU(s): one process" % (n_gpus, have))
     if in_rank:
-        return rank_main(out_dir, reads, K, partition_size, min_weight, min_length, double_stranded, ignored, noted)
+        return rank_main(out_dir, reads, K, partition_size, min_weight, min_length, double_stranded, ignored, noted, kmer_hard_cutoff)
     os.makedirs(out_dir, exist_ok=True)
     sample = os.path.basename(os.path.normpath(out_dir))
     temp = os.path.join(out_dir, "TEMP")
@@ -324,10 +332,11 @@ def main(argv):
         from shannon_amd import kmers_for_component as kfc
         R = pipeline.assemble_resident(ctx, sets[0], sets[1] if paired else None, kfc.ReadStore(r[0], r[1] if paired else None), K=K,
                                        partition_size=partition_size, min_weight=min_weight, min_length=min_length, sample=sample, seed=0,
-                                       double_stranded=double_stranded, timings=T)
+                                       double_stranded=double_stranded, timings=T, kmer_hard_cutoff=kmer_hard_cutoff)
     else:
         R = pipeline.assemble(ctx, r[0], r[1] if paired else None, K=K, partition_size=partition_size, min_weight=min_weight,
-                              min_length=min_length, sample=sample, seed=0, double_stranded=double_stranded, timings=T)
+                              min_length=min_length, sample=sample, seed=0, double_stranded=double_stranded, timings=T,
+                              kmer_hard_cutoff=kmer_hard_cutoff)
     say("%d K-mers loaded; %d contigs; %d partitions" % (R.n_k1mers, len(R.extension.contigs), len(R.partitions)))
     # TEMP tree: the per-stage products of the reference (shannon.py:496-513, 584-595)
     from shannon_amd import extension_correction as ec, mbgraph

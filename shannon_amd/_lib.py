@@ -38,6 +38,7 @@ SIGNATURES = {
     "shn_table_canonical": (C.c_int, [vp]),
     "shn_table_download": (C.c_int, [vp, vp, vp, vp]),
     "shn_table_dump": (C.c_int, [vp, vp, C.c_uint32, vp, vp, u64p]),
+    "shn_table_filter_lower": (C.c_int, [vp, vp, C.c_uint32, vpp]),
     "shn_table_device_ptrs": (C.c_int, [vp, vpp, vpp]),
     "shn_table_lookup": (C.c_int, [vp, vp, vp, C.c_uint64, vp]),
     "shn_table_from_pairs": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vpp]),

@@ -974,6 +974,59 @@ extern "C" int shn_table_dump(shn_ctx* ctx, const shn_table* t, uint32_t lower, 
   return SHN_OK;
 }
 
+// ---- `jellyfish dump -L lower` as a table (shannon.py:237-241, 441): the k1-mers whose count in the reference's (strand-doubled) input
+// is below `lower` never enter k1mer.dict_org, so no later stage sees them.  A stable compaction on the device: the survivors keep
+// their order (bucket, then key), bucket b of the new table starts where the scan of the keep flags stands at b's old start, layout,
+// bits and minimizer length are the old table's.  A canonical table holds count(x) = count(rc x) of the doubled input once; a k1-mer
+// that is its own reverse complement stands for twice its stored count there (the rule of shn_table_dump).
+__global__ void table_keep_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, uint64_t n, int k, int canonical,
+                                  uint32_t lower, uint32_t* __restrict__ flag) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    uint64_t c = counts[i];
+    if (canonical && shn_revcomp(keys[i], k) == keys[i]) c *= 2;
+    flag[i] = c >= lower ? 1u : 0u;
+  }
+}
+__global__ void table_keep_scatter_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ counts, const uint32_t* __restrict__ flag,
+                                          const uint64_t* __restrict__ pos, uint64_t n, uint64_t* __restrict__ okeys, uint32_t* __restrict__ ocounts) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    if (flag[i]) { const uint64_t o = pos[i]; okeys[o] = keys[i]; ocounts[o] = counts[i]; }
+}
+__global__ void table_keep_boff_kernel(const uint64_t* __restrict__ old_off, uint64_t nb1, const uint64_t* __restrict__ pos, uint64_t* __restrict__ new_off) {
+  for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < nb1; b += (uint64_t)gridDim.x * blockDim.x) new_off[b] = pos[old_off[b]];
+}
+extern "C" int shn_table_filter_lower(shn_ctx* ctx, const shn_table* t, uint32_t lower, shn_table** out) {
+  if (!ctx || !t || !out) return shn_fail(SHN_ERR_ARG, "shn_table_filter_lower: NULL argument");
+  if (t->n >= 0xFFFFFFFFULL) return shn_fail(SHN_ERR_ARG, "shn_table_filter_lower: more than 2^32 keys");
+  SHN_ENTER(ctx);
+  hipStream_t s = ctx->stream; shn_use_stream(s);
+  const uint64_t n = t->n, nb1 = t->n_buckets + 1;
+  ShnDevBufs bufs(s);
+  uint32_t* d_flag = nullptr; uint64_t* d_pos = nullptr;
+  HIP_TRY(bufs.get(&d_flag, (n + 1) * 4)); HIP_TRY(bufs.get(&d_pos, (n + 2) * 8));
+  const dim3 grid((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(cdiv(n, 256), 1u << 20))), blk(256);
+  if (n) hipLaunchKernelGGL(table_keep_kernel, grid, blk, 0, s, (const uint64_t*)t->d_keys, (const uint32_t*)t->d_counts, n, t->k, t->canonical, lower, d_flag);
+  uint64_t kept = 0;
+  if (n) { int rc = shn_device_scan_u32(ctx, d_flag, n, d_pos, &kept); if (rc) return rc; }
+  else HIP_TRY(hipMemsetAsync(d_pos, 0, 16, s));
+  shn_table* o = new shn_table();
+  *o = *t;
+  o->ctx = ctx; o->n = kept; o->d_keys = nullptr; o->d_counts = nullptr; o->d_bucket_off = nullptr;
+#define TRYT(x) do { hipError_t _e = (x); if (_e != hipSuccess) { shn_table_destroy(o); return shn_fail(SHN_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(_e)); } } while (0)
+  TRYT(shn_dev_malloc(&o->d_keys, (kept + 1) * 8));
+  TRYT(shn_dev_malloc(&o->d_counts, (kept + 1) * 4));
+  TRYT(shn_dev_malloc(&o->d_bucket_off, nb1 * 8));
+  if (n) hipLaunchKernelGGL(table_keep_scatter_kernel, grid, blk, 0, s, (const uint64_t*)t->d_keys, (const uint32_t*)t->d_counts, (const uint32_t*)d_flag,
+                            (const uint64_t*)d_pos, n, o->d_keys, o->d_counts);
+  hipLaunchKernelGGL(table_keep_boff_kernel, dim3((uint32_t)std::min<uint64_t>(cdiv(nb1, 256), 1u << 20)), blk, 0, s, (const uint64_t*)t->d_bucket_off, nb1,
+                     (const uint64_t*)d_pos, o->d_bucket_off);
+  TRYT(hipGetLastError());
+  TRYT(hipStreamSynchronize(s));
+#undef TRYT
+  *out = o;
+  return SHN_OK;
+}
+
 extern "C" int shn_table_device_ptrs(const shn_table* t, void** keys, void** counts) {
   if (!t) return shn_fail(SHN_ERR_ARG, "shn_table_device_ptrs: NULL table");
   if (keys) *keys = t->d_keys;

@@ -223,6 +223,13 @@ class Table(object):
         _lib.check(_lib.lib().shn_table_dump(self.ctx.h, self.h, lower, keys.ctypes.data, cnts.ctypes.data, C.byref(n)))
         return keys[:n.value], cnts[:n.value]
 
+    def filter_lower(self, lower):
+        """`jellyfish dump -L lower` as a table (--kmer_hard_cutoff, shannon.py:237-241, 441): a new Table without the k1-mers
+        whose count in the reference's input is below `lower`; this one stays as it is (the caller closes it)."""
+        h = C.c_void_p()
+        _lib.check(_lib.lib().shn_table_filter_lower(self.ctx.h, self.h, int(lower), C.byref(h)))
+        return Table(self.ctx, h)
+
     def lookup(self, keys):
         keys = np.ascontiguousarray(keys, dtype=np.uint64)
         out = np.zeros(len(keys), dtype=np.uint32)

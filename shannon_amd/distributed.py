@@ -90,8 +90,11 @@ class _NoLock(object):
 
 
 def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0, part_vectors=None, group=None,
-                         timings=None, lock=None, double_stranded=True):
+                         timings=None, lock=None, double_stranded=True, min_weight=3, min_length=75, kmer_hard_cutoff=1):
     """Returns on rank 0 a dict {partitions: {name: fasta}, final, contigs, ...}; None elsewhere.
+    min_weight / min_length: hyp_min_weight (--kmer_soft_cutoff) / hyp_min_length as run_correction gets them (shannon.py:243-247,
+    457); kmer_hard_cutoff: `jellyfish dump -L` (shannon.py:237-241, 441), applied by the ops to the REDUCED counts -- on the owner
+    of a k1-mer after the bucket exchange, never to a rank's local counts.  The ops read them as attributes of the same names.
     double_stranded=False (-s / --ss / --strand_specific, shannon.py:407-411): the reads are not strand-doubled -- forward counting
     of reads_1 and RC(reads_2), routes of plain read indices (the global order is the global read index, there is no
     reverse-complement half), pairs (reads_1[i], RC(reads_2[i])) at the owners, process_concatenated_fasta with the user's flag
@@ -106,6 +109,7 @@ def assemble_distributed(ops, K=25, partition_size=500, sample="shannon", seed=0
         raise NotImplementedError("assemble_distributed: these ops do not implement -s / --strand_specific (forward counting, plain read "
                                   "indices, pairs of reads_1 and RC(reads_2)); a strand_specific run needs ops that do (GpuOps does)")
     ops.strand_specific = ss
+    ops.min_weight, ops.min_length, ops.kmer_hard_cutoff = int(min_weight), int(min_length), int(kmer_hard_cutoff)
     T = timings if timings is not None else {}
     lock = lock or _NoLock()
     ops.lock = lock
@@ -539,9 +543,18 @@ class GpuOps(object):
 
     supports_strand_specific = True
     strand_specific = False              # set by assemble_distributed
+    min_weight, min_length, kmer_hard_cutoff = 3, 75, 1      # set by assemble_distributed (shannon.py:55-57, 237-247)
 
     def n_reads(self):
         return len(self.d1)
+
+    def _hard_cutoff(self, t):
+        """`jellyfish dump -L` (shannon.py:441) on a table of REDUCED counts (the job's, not a rank's slice)"""
+        if self.kmer_hard_cutoff <= 1:
+            return t
+        kept = t.filter_lower(self.kmer_hard_cutoff)
+        t.close()
+        return kept
 
     def _count(self):
         if self.strand_specific:         # forward counting of reads_1 and RC(reads_2): a table of plain (not canonical) k1-mers
@@ -581,7 +594,7 @@ class GpuOps(object):
     def owned_table(self, rk, rc):
         """the pairs this rank owns, equal keys summed"""
         torch.cuda.synchronize()
-        t = self._dev.Table.from_pairs(self.ctx, rk.data_ptr(), rc.data_ptr(), rk.numel(), self.K + 1, not self.strand_specific)
+        t = self._hard_cutoff(self._dev.Table.from_pairs(self.ctx, rk.data_ptr(), rc.data_ptr(), rk.numel(), self.K + 1, not self.strand_specific))
         self._digest("owned", t)
         return t
 
@@ -610,11 +623,11 @@ class GpuOps(object):
 
     def local_table(self):
         """one-rank job: the counted table itself (no export to pairs)"""
-        return self._count()
+        return self._hard_cutoff(self._count())
 
     def reduce_pairs(self, rk, rc):
         torch.cuda.synchronize()
-        t = self._dev.Table.from_pairs(self.ctx, rk.data_ptr(), rc.data_ptr(), rk.numel(), self.K + 1, not self.strand_specific)
+        t = self._hard_cutoff(self._dev.Table.from_pairs(self.ctx, rk.data_ptr(), rc.data_ptr(), rk.numel(), self.K + 1, not self.strand_specific))
         n = len(t)
         dk = torch.empty(max(n, 1), dtype=torch.int64, device=self.device)
         dc = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
@@ -678,7 +691,7 @@ class GpuOps(object):
         # (a large, diverse table -- BASELINE configs[2] and beyond: 10^8+ k1-mers, 10^5+ candidate contigs -- takes the path
         # "sharded walks + one replicated GPU contig stage" inside run_correction; a few deep gene families per rank -- the
         # weak-scaling workload, 5 M k1-mers per family -- keep their contig stages sharded too: SHN_CONTIG_GPU=1 / 0 forces either)
-        res = ec.run_correction(self.ctx, table, 3, 75, partition_size, want_allowed=False, shard=None if presharded is not None else (W, rank),
+        res = ec.run_correction(self.ctx, table, self.min_weight, self.min_length, partition_size, want_allowed=False, shard=None if presharded is not None else (W, rank),
                                 gather=Gather, timings=getattr(self, "timings", None), table_size=presharded)
         table.close()
         if presharded is not None:

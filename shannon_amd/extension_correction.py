@@ -91,6 +91,15 @@ class Extension(object):
             _lib.check(_lib.lib().shn_ext_seed_info(self.ctx.h, self.h, ranks.ctypes.data, len(ranks), keys.ctypes.data, w.ctypes.data))
         return keys[:len(ranks)], w[:len(ranks)]
 
+    def digests(self):
+        """SHN_EXT_DIGEST=1: the checksums shn_extend kept of its arrays, [8 stages][64 chunks] (table keys, counts, bucket offsets,
+        weights + flags, adjacency records, seed order, converged claims, walk records: shn_ext_digests); None without the switch"""
+        if os.environ.get("SHN_EXT_DIGEST") != "1":
+            return None
+        dig = np.zeros(512, np.uint64)
+        _lib.check(_lib.lib().shn_ext_digests(self.h, dig.ctypes.data))
+        return dig.reshape(8, 64)
+
     @property
     def n_walks(self):
         return int(_lib.lib().shn_ext_n_walks(self.h))
@@ -743,6 +752,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     res.wave_steps = ext.wave_steps
     res.fresh_steps = ext.fresh_steps
     res.dense_rounds = ext.dense_rounds
+    res.ext_digests = ext.digests()                     # (SHN_EXT_DIGEST=1: bench.py names the stage at which a step differed)
     res.contigs = contigs[1:]
     res.contig_raw = contig_raw
     # allowed k1-mers with their integer weights (:366-369, :404-408): GPU table lookup

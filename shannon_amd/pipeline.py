@@ -71,8 +71,10 @@ def n_kmer_nodes(rows, K):
 
 def assemble(ctx, reads1, reads2=None, K=25, partition_size=500, min_weight=3, min_length=75, overload=2, penalty=5,
              sample="shannon", seed=0, double_stranded=True, part_vectors=None, timings=None, hits_factory=None,
-             native_graph=True):
+             native_graph=True, kmer_hard_cutoff=1):
     """reads1/reads2: lists of strings or uint8 code matrices (reads2 None = single-end).
+    min_weight = the reference's hyp_min_weight (--kmer_soft_cutoff, shannon.py:243-247, 457); kmer_hard_cutoff = its
+    jellyfish_kmer_cutoff (--kmer_hard_cutoff, `jellyfish dump -L`, shannon.py:237-241, 441).
     Returns Result with .partitions {name: dict}, .all_reconstructed (lines), .final {name: seq}."""
     T = timings if timings is not None else {}
     paired = reads2 is not None
@@ -87,12 +89,12 @@ def assemble(ctx, reads1, reads2=None, K=25, partition_size=500, min_weight=3, m
     store = kfc.ReadStore(reads1, reads2)
     tick("upload+pack", t0)
     return assemble_resident(ctx, d1, d2, store, K, partition_size, min_weight, min_length, overload, penalty, sample, seed,
-                             double_stranded, part_vectors, T, hits_factory, native_graph)
+                             double_stranded, part_vectors, T, hits_factory, native_graph, kmer_hard_cutoff=kmer_hard_cutoff)
 
 
 def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3, min_length=75, overload=2, penalty=5,
                       sample="shannon", seed=0, double_stranded=True, part_vectors=None, timings=None, hits_factory=None,
-                      native_graph=True, graph_threads=None, keep_partitioning=False, defer_back=False):
+                      native_graph=True, graph_threads=None, keep_partitioning=False, defer_back=False, kmer_hard_cutoff=1):
     """Same as assemble() with the reads already packed in HBM (d1/d2: device.Reads).  graph_threads: partitions whose
     graph stage may run concurrently on host threads.  keep_partitioning: leave the partition stage's tables (partition ->
     contigs, routed read indices) on the result as `.partitioning` (tests/test_fullsize_gpu.py reads them).  defer_back: run count,
@@ -120,6 +122,13 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
     t0 = time.time()
     table = (device.count_k1mers_strand_specific(ctx, d1, d2, K + 1) if ss else
              device.count_k1mers(ctx, [d1, d2] if paired else [d1], K + 1, both_strands=True))
+    if kmer_hard_cutoff > 1:
+        # `jellyfish dump -L N` (shannon.py:441): k1-mers counted fewer than N times never reach k1mer.dict_org -- no seed, no
+        # extension step, no weight of a later stage sees them (the seed threshold min_weight is another matter: a k1-mer below
+        # THAT is still walked over, extension_correction.py:229-233)
+        kept = table.filter_lower(kmer_hard_cutoff)
+        table.close()
+        table = kept
     R.n_k1mers, R.n_windows = len(table), table.total
     tick("count", t0)
     t0 = time.time()

@@ -22,6 +22,7 @@ class OracleOps(object):
 
     supports_strand_specific = True
     strand_specific = False              # set by assemble_distributed
+    min_weight, min_length, kmer_hard_cutoff = 3, 75, 1      # set by assemble_distributed
 
     def n_reads(self):
         return len(self.r1)
@@ -72,6 +73,11 @@ class OracleOps(object):
         k = rk.numpy().view(np.uint64)
         uk, inv = np.unique(k, return_inverse=True)
         s = np.bincount(inv, weights=rc.numpy().astype(np.float64), minlength=len(uk)).astype(np.int32)
+        if self.kmer_hard_cutoff > 1:        # `jellyfish dump -L` on the reduced counts; a canonical palindrome stands for 2 x its count
+            k1 = self.K + 1
+            pal = np.zeros(len(uk), dtype=bool) if self.strand_specific else np.array([int(k) == count.rc_key(k, k1) for k in uk], dtype=bool)
+            keep = np.where(pal, 2 * s.astype(np.int64), s.astype(np.int64)) >= self.kmer_hard_cutoff
+            uk, s = uk[keep], s[keep]
         return torch.as_tensor(uk.view(np.int64)), torch.as_tensor(s)
 
     def table_from_pairs(self, gk, gc):
@@ -103,7 +109,8 @@ class OracleOps(object):
             where = np.repeat(np.arange(len(parts)), [len(p[0]) for p in parts])
             assert len(np.unique(np.stack([lab, where], axis=1), axis=0)) == len(np.unique(lab))       # a component lives on ONE rank
             tab = self.table_from_pairs(torch.as_tensor(keys.view(np.int64)), torch.as_tensor(np.concatenate([p[1] for p in parts])))
-        return extension.run_correction([(k, tab[k]) for k in sorted(tab, reverse=True)], comp_size_threshold=partition_size)
+        return extension.run_correction([(k, tab[k]) for k in sorted(tab, reverse=True)], min_weight=self.min_weight, min_length=self.min_length,
+                                        comp_size_threshold=partition_size)
 
     def route(self, res, K, partition_size, pv):
         pv = pv or []
@@ -191,7 +198,8 @@ def main():
         open(out + ".rank%d" % rank, "w").write(msg)
         dist.destroy_process_group()
         return
-    res = distributed.assemble_distributed(ops, m["K"], psize, "s", m["sf_seed"], pv, double_stranded=not m.get("strand_specific"))
+    res = distributed.assemble_distributed(ops, m["K"], psize, "s", m["sf_seed"], pv, double_stranded=not m.get("strand_specific"),
+                                           min_weight=m.get("kmer_soft_cutoff", 3), kmer_hard_cutoff=m.get("kmer_hard_cutoff", 1))
     if rank == 0:
         json.dump({"partitions": dict(res["partitions"]), "final": res["final"], "contigs": res["contigs"],
                    "owner_labelling_ran": hasattr(ops, "component_keys"), "n_k1mers": res["n_k1mers"]}, open(out, "w"))

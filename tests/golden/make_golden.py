@@ -186,6 +186,42 @@ def main():
         save(name, slim(art, keep_full=(name in ("syn_pe_s0", "syn_se_s7_K20"))))
         print(name, "done", art["n_k1mers"], {c: p["graph"] and len(p["graph"]["nodes"]) for c, p in art["partitions"].items()})
     json.dump(manifest, open(os.path.join(OUT, "manifest.json"), "w"), indent=1)
+    # --- the two k-mer cutoffs of the CLI (shannon.py:237-247): --kmer_hard_cutoff = the -L of `jellyfish dump` (:441),
+    # --kmer_soft_cutoff = hyp_min_weight = run_correction's min_weight (:457), alone and together, on inputs of cases above
+    # (a manifest of their own: the tests over manifest.json run the default cutoffs)
+    # (the inputs of the cases above are covered ~100x: hyp_min_weight between 2 and 5 changes nothing there.  "lowcov": 19 isoforms
+    # of 8 tricky genes under 400 pairs -- k1-mer weights of 2..10, where the seed threshold and the hyperbola both bite; its
+    # default run is a case here too, so that the tests can tell the cutoff runs from it)
+    lowcov = "cut_lowcov_s82"
+    if ONLY is None or any(n.startswith(lowcov) for n in ONLY):
+        r1, r2 = synth.sample_pairs(tricky_transcriptome(82, 8), 400, 82, err=0.005)
+        np.savez_compressed(os.path.join(OUT, "data", lowcov + ".npz"), r1=r1, r2=r2)
+    manifest_plus = dict(manifest)
+    manifest_plus[lowcov] = {"inputs": [lowcov + ".npz"], "K": 25, "paired": True, "sf_seed": 82, "partition_size": 500}
+    manifest_plus[lowcov + "_se"] = {"inputs": [lowcov + ".npz"], "K": 24, "paired": False, "sf_seed": 82, "partition_size": 500}
+    cuts = [("cut_pe_s0_hard2", "syn_pe_s0", 2, 3), ("cut_pe_s12_hard3_soft2", "syn_pe_s12", 3, 2), ("cut_pe_ss_s69_hard2_soft5", "syn_pe_ss_s69", 2, 5),
+            (lowcov + "_default", lowcov, 1, 3), (lowcov + "_soft2", lowcov, 1, 2), (lowcov + "_soft5", lowcov, 1, 5),
+            (lowcov + "_hard2_soft2", lowcov, 2, 2), (lowcov + "_se_default", lowcov + "_se", 1, 3), (lowcov + "_se_soft5", lowcov + "_se", 1, 5)]
+    cman = {}
+    for name, base, hard, soft in cuts:
+        m = dict(manifest_plus[base])
+        m.update({"kmer_hard_cutoff": hard, "kmer_soft_cutoff": soft, "input_of": base})
+        if base.startswith(lowcov):
+            m["default_run"] = base + "_default"
+        cman[name] = m
+        if not want(name):
+            continue
+        z = np.load(os.path.join(OUT if base.startswith(lowcov) else HERE, "data", m["inputs"][0]))
+        d = os.path.join(TMP, name + "_in")
+        os.makedirs(d)
+        synth.write_fasta(d + "/r1.fasta", z["r1"])
+        synth.write_fasta(d + "/r2.fasta", z["r2"])
+        art = H.run_case(os.path.join(TMP, name), [d + "/r1.fasta", d + "/r2.fasta"] if m["paired"] else [d + "/r1.fasta"], m["K"], m["paired"],
+                         partition_size=m["partition_size"], run_sf=True, sf_seed=m["sf_seed"], double_stranded=not m.get("strand_specific"),
+                         kmer_hard_cutoff=hard, min_weight=soft)
+        save(name, slim(art, keep_full=False))
+        print(name, "done", art["n_k1mers"], len(art["contigs"]), {c: p["graph"] and len(p["graph"]["nodes"]) for c, p in art["partitions"].items()})
+    json.dump(cman, open(os.path.join(OUT, "manifest_cutoffs.json"), "w"), indent=1)
     if want("post_adversarial"):
         # --- row a31 alone: adversarial concatenations (tests/post_cases.py) through the reference's own
         # process_concatenated_fasta -> perl sort -> faster_reps -d chain, both strand settings

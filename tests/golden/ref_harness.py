@@ -246,19 +246,23 @@ def strand_specific_files(reads_files, outdir):
 
 
 def run_case(root, reads_files, K, paired, partition_size=500, part_hook=None, hashseed="0",
-             run_sf=False, sf_seed=0, double_stranded=True):
+             run_sf=False, sf_seed=0, double_stranded=True, kmer_hard_cutoff=1, min_weight=3):
     """Run the translated reference end-to-end (shannon.py:394-566 order) on `reads_files`.
     Returns a dict of artefacts (all plain data).  double_stranded=False: the -s run (after the read files are made,
     shannon.py:427 sets double_stranded = False for every later stage in BOTH modes: only the read files differ, and
-    process_concatenated_fasta at the end, which gets the user's flag)."""
+    process_concatenated_fasta at the end, which gets the user's flag).
+    kmer_hard_cutoff: --kmer_hard_cutoff = jellyfish_kmer_cutoff, the -L of `jellyfish dump` (shannon.py:237-241, 441);
+    min_weight: --kmer_soft_cutoff = hyp_min_weight, run_correction's third argument (shannon.py:243-247, 457)."""
     shutil.rmtree(root, ignore_errors=True)
     os.makedirs(root)
     tref = prepare_translated(os.path.join(root, "tref"))
     work = os.path.join(root, "work")
     os.makedirs(os.path.join(work, "s_algo_input"))
     rf = double_strand_files(reads_files, os.path.join(root, "dbl")) if double_stranded else strand_specific_files(reads_files, os.path.join(root, "dbl"))
-    cnt = jellyfish_standin(rf, K + 1, os.path.join(work, "s_algo_input", "k1mer.dict_org"))
-    run_extension_and_partition(tref, work, rf, K, paired, partition_size, part_hook, hashseed=hashseed)
+    cnt = jellyfish_standin(rf, K + 1, os.path.join(work, "s_algo_input", "k1mer.dict_org"), lower=kmer_hard_cutoff)
+    if kmer_hard_cutoff > 1:
+        cnt = collections.Counter({k: c for k, c in cnt.items() if c >= kmer_hard_cutoff})          # (what the file holds)
+    run_extension_and_partition(tref, work, rf, K, paired, partition_size, part_hook, min_weight=min_weight, hashseed=hashseed)
     art = {"K": K, "paired": paired, "n_k1mers": len(cnt)}
     art["doubled_reads"] = [read_fasta_seqs(f) for f in rf]
     art["k1mer_counts"] = dict(cnt)

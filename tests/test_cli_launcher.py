@@ -18,6 +18,22 @@ def test_p_starts_that_many_ranks(tmp_path):
     p = _run(["-o", str(tmp_path / "out3"), "--left", str(f), "--right", str(f), "-s", "--gpus", "3"])
     assert p.returncode == 0, p.stdout[-2000:]
     assert "launch probe: 3 ranks met, K=24, partition=500, double_stranded=False, reads=r.fasta,r.fasta" in p.stdout
+    assert "min_weight=3, kmer_hard_cutoff=1" in p.stdout                                       # shannon.py:55-56 defaults
+
+
+def test_cutoff_flags_reach_every_rank_with_the_reference_meaning(tmp_path):
+    """--kmer_hard_cutoff = jellyfish_kmer_cutoff (`jellyfish dump -L`, shannon.py:237-241, 441), --kmer_soft_cutoff = hyp_min_weight
+    (run_correction's min_weight, shannon.py:243-247, 457): two different knobs, neither touching the other"""
+    f = tmp_path / "r.fasta"
+    f.write_text(">a\nACGT\n")
+    p = _run(["-o", str(tmp_path / "o1"), "--single", str(f), "--kmer_hard_cutoff", "2", "-p", "2"])
+    assert p.returncode == 0 and "min_weight=3, kmer_hard_cutoff=2" in p.stdout, p.stdout[-2000:]
+    assert "OPTIONS --kmer_hard_cutoff: Kmer hard cutoff set to 2" in p.stdout
+    p = _run(["-o", str(tmp_path / "o2"), "--single", str(f), "--kmer_soft_cutoff", "5", "-p", "2"])
+    assert p.returncode == 0 and "min_weight=5, kmer_hard_cutoff=1" in p.stdout, p.stdout[-2000:]
+    assert "OPTIONS --kmer_soft_cutoff: Kmer soft cutoff set to 5" in p.stdout
+    p = _run(["-o", str(tmp_path / "o3"), "--single", str(f), "--kmer_soft_cutoff", "2", "--kmer_hard_cutoff", "4", "-p", "2"])
+    assert p.returncode == 0 and "min_weight=2, kmer_hard_cutoff=4" in p.stdout, p.stdout[-2000:]
 
 
 def test_bad_arguments_are_refused_before_any_rank_starts(tmp_path):

@@ -14,24 +14,28 @@ def run_oracle_front(name):
     inp = load_inputs(name)
     dbl = read_files(name, inp)
     tab = count.count_k1mers_dict([r for f in dbl for r in f], K + 1)
+    hard = cutoffs(name)[0]
+    if hard > 1:                      # `jellyfish dump -L hard` (shannon.py:237-241, 441)
+        tab = {k: c for k, c in tab.items() if c >= hard}
     return g, K, paired, dbl, tab
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + CUT_CASES)
 def test_pipeline_against_reference(name):
     g, K, paired, dbl, tab = run_oracle_front(name)
-    psize = MANIFEST[name].get("partition_size", 500)
+    psize = meta(name).get("partition_size", 500)
     # a2: k1-mer table as a sorted multiset
     assert len(tab) == g["n_k1mers"]
     assert sum(tab.values()) == g["k1mer_total"]
     assert digest(sorted([k, v] for k, v in tab.items())) == g["k1mer_counts_digest"]
     # packed numpy counter agrees with the dict counter
     keys, cnts = count.count_k1mers_packed([r for f in dbl for r in f], K + 1)
+    keys, cnts = keys[cnts >= cutoffs(name)[0]], cnts[cnts >= cutoffs(name)[0]]
     assert len(keys) == len(tab)
     assert all(tab[count.key_to_str(k, K + 1)] == c for k, c in list(zip(keys, cnts))[::97])
     # a3-a7
     items = [(k, tab[k]) for k in sorted(tab, reverse=True)]
-    res = extension.run_correction(items, comp_size_threshold=psize)
+    res = extension.run_correction(items, min_weight=cutoffs(name)[1], comp_size_threshold=psize)      # hyp_min_weight: shannon.py:243-247, 457
     assert res.contigs == g["contigs"]
     assert len(res.allowed) == g["n_allowed"]
     assert digest(sorted([k, v] for k, v in res.allowed.items())) == g["allowed_digest"]
@@ -71,11 +75,11 @@ def test_pipeline_against_reference(name):
         assert [l for l in mine_log if "Bridged" in l] == [l for l in ref_log if "Bridged" in l]
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + CUT_CASES)
 def test_sparse_flow_against_reference(name):
     """a25-a30 on the reference's own nodes/edges/paths tables (IDs and line order as written)."""
     g = load_case(name)
-    seed = MANIFEST[name]["sf_seed"]
+    seed = meta(name)["sf_seed"]
     for comp, gp in g["partitions"].items():
         mine = ""
         for c, rc in enumerate(gp["raw_components"]):
@@ -134,7 +138,7 @@ def test_strand_symmetry_and_rc():
         assert tab[k] == tab[seqs.reverse_complement(k)]
 
 
-@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("name", CASES + CUT_CASES)
 def test_final_merge_against_reference(name):
     """a31: the reference's own process_concatenated_fasta -> perl length sort -> faster_reps -d chain (ref_harness.run_final) on
     the concatenation the reference run produced, under both strand settings: names and sequences equal."""
@@ -160,15 +164,29 @@ def test_final_merge_adversarial_against_reference():
             assert post.finalize(lines, ds) == want, (seed, key)
 
 
-@pytest.mark.parametrize("name", ["se_K24", "syn_se_s5", "syn_pe_hairpin", "syn_pe_ss_s69", "syn_part_s33"])
+@pytest.mark.parametrize("name", ["se_K24", "syn_se_s5", "syn_pe_hairpin", "syn_pe_ss_s69", "syn_part_s33"] + CUT_CASES)
 def test_oracle_pipeline_final_against_reference(name):
     """the chained oracle (oracle/pipeline.py) from the input reads to the final file against the reference's final file: the
     sequences (names carry the reference's address-ordered component numbers)"""
     from oracle import pipeline as opipe
-    m, g, inp = MANIFEST[name], load_case(name), load_inputs(name)
+    m, g, inp = meta(name), load_case(name), load_inputs(name)
     psize = m.get("partition_size", 500)
     pv = [part_vectors(len(b["contigs"]), psize) for b in g["big_components"]] or None
     ds = not strand_specific(name)
+    hard, soft = cutoffs(name)
     O = opipe.assemble(inp[0], inp[1] if m["paired"] else None, K=m["K"], partition_size=psize, sample="", seed=m["sf_seed"],
-                       part_vectors=pv, double_stranded=ds)
+                       part_vectors=pv, double_stranded=ds, min_weight=soft, kmer_hard_cutoff=hard)
+    assert O["contigs"] == g["contigs"]
     assert sorted(O["final"].values()) == sorted(g["final"]["ds" if ds else "ss"].values())
+
+
+def test_the_cutoff_cases_differ_from_the_default_run():
+    """the cutoff fixtures are not the default run under another name: either cutoff changes the contig list of its input"""
+    for name in CUT_CASES:
+        m = CUT_MANIFEST[name]
+        if cutoffs(name) == (1, 3):
+            continue
+        base = load_case(m.get("default_run", m["input_of"]))
+        assert load_case(name)["contigs"] != base["contigs"], name
+        if "_se_" not in name:            # (the single-end low-coverage input keeps one transcript of 200 bases either way)
+            assert sorted(load_case(name)["final"]["ds"].values()) != sorted(base["final"]["ds"].values()), name
