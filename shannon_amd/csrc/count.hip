@@ -521,8 +521,8 @@ int ShnWs::get(size_t bytes, void** out) {
   *out = p;
   {
     // SHN_DEV_POISON: a slot that has just grown is filled with the poison byte; SHN_DEV_POISON_WS=1: on EVERY request (finds reads of
-    // what an earlier call left behind -- but the seed scan's count / fetch pair (seeds.hip) keeps its offsets in its slots between
-    // the two calls by design and does not survive that)
+    // what an earlier call left behind: no call may rely on a slot's content across calls -- the seed scan's count / fetch pair,
+    // which did until round 5, owns its offsets now, seeds.hip)
     static const bool every = getenv("SHN_DEV_POISON_WS") && getenv("SHN_DEV_POISON_WS")[0] == '1';
     if (every || grew) shn_poison(p, bytes, shn_current_stream());
   }

@@ -106,36 +106,57 @@ static int seed_scan_impl(shn_ctx* ctx, const shn_reads* reads, int K, const shn
   uint32_t max_win = reads->max_len > (uint32_t)K + 1 ? reads->max_len - K - 1 : 0;
   uint64_t total = v.n * max_win;
   if (total == 0) { *n_hits = 0; return SHN_OK; }
-  void *pc, *po;
   int rc;
   // a thread per read behind an LDS filter (seed_scan_reads_kernel)
   const uint32_t grid = (uint32_t)std::min<uint64_t>(cdiv(v.n, SBLK2), 4096);
   const uint64_t n_cnt = v.n;                                   // counts: per read
-  if ((rc = ctx->cws[1].get((n_cnt + 1) * 4, &pc)) || (rc = ctx->cws[2].get((n_cnt + 2) * 8, &po))) return rc;
-  void* pbm = nullptr;
-  if ((rc = ctx->cws[3].get(SEED_BM_WORDS * 4, &pbm))) return rc;
-  // (the call that asks for the number of hits and the one that fetches them come in pairs: the second finds the offsets (and the
-  // filter) of the first in the context's workspace -- same reads, same patterns, nothing in between on this context)
-  static thread_local struct { const shn_ctx* ctx; const shn_reads* reads; const shn_table* pat; uint64_t total, n_reads, n_pat, nh; int K; } last = {};
+  // The call that asks for the number of hits and the one that fetches them come in pairs: the second finds the offsets (and the
+  // filter) of the first -- same reads, same patterns, this thread.  They live in two blocks of the caching allocator that belong to
+  // the PAIR (handed out by the first call, given back by the second, or by the next first call of this thread when no second
+  // came): until round 5 they lay in the context's workspace slots cws[1..3], where any other call on the context between the two
+  // could overwrite them silently (SHN_DEV_POISON_WS=1 crashed there).
+  struct Pair { const shn_ctx* ctx; const shn_reads* reads; const shn_table* pat; uint64_t total, n_reads, n_pat, nh; int K;
+                uint64_t* d_off; uint32_t* d_bm; hipStream_t stream; };
+  static thread_local Pair last = {};
+  auto drop = [&]() {
+    if (last.d_off) shn_dev_free_on(last.d_off, last.stream);
+    if (last.d_bm) shn_dev_free_on(last.d_bm, last.stream);
+    last = {};
+  };
+  const bool second = out_read && last.ctx == ctx && last.reads == reads && last.pat == patterns && last.total == total &&
+                      last.n_reads == reads->n_reads && last.n_pat == patterns->n && last.K == K && last.stream == s;
   uint64_t nh = 0;
-  if (out_read && last.ctx == ctx && last.reads == reads && last.pat == patterns && last.total == total && last.n_reads == reads->n_reads &&
-      last.n_pat == patterns->n && last.K == K) nh = last.nh;
+  if (second) nh = last.nh;
   else {
-    HIP_TRY(hipMemsetAsync(pbm, 0, SEED_BM_WORDS * 4, s));
-    if (patterns->n) hipLaunchKernelGGL(seed_bm_build_kernel, dim3((uint32_t)cdiv(patterns->n, 256)), dim3(256), 0, s, patterns->d_keys, patterns->n, (uint32_t*)pbm);
-    hipLaunchKernelGGL((seed_scan_reads_kernel<false>), dim3(grid), dim3(SBLK2), 0, s, v, K, (const uint32_t*)pbm, patterns->d_keys, patterns->d_counts,
-                       patterns->d_bucket_off, patterns->bits, (uint32_t*)pc, nullptr, nullptr, nullptr, nullptr);
-    if ((rc = shn_device_scan_u32(ctx, (uint32_t*)pc, n_cnt, (uint64_t*)po, &nh))) return rc;
+    drop();
+    ShnDevBufs tmp(s);
+    uint32_t* pc = nullptr;
+    HIP_TRY(tmp.get(&pc, (n_cnt + 1) * 4));
+    HIP_TRY(shn_dev_malloc_on((void**)&last.d_off, (n_cnt + 2) * 8, s));
+    last.stream = s;
+    { hipError_t e = shn_dev_malloc_on((void**)&last.d_bm, SEED_BM_WORDS * 4, s);
+      if (e != hipSuccess) { drop(); return shn_fail(SHN_ERR_HIP, std::string("shn_seed_scan: ") + hipGetErrorString(e)); } }
+    hipError_t e = hipMemsetAsync(last.d_bm, 0, SEED_BM_WORDS * 4, s);
+    if (e != hipSuccess) { drop(); return shn_fail(SHN_ERR_HIP, std::string("shn_seed_scan: ") + hipGetErrorString(e)); }
+    if (patterns->n) hipLaunchKernelGGL(seed_bm_build_kernel, dim3((uint32_t)cdiv(patterns->n, 256)), dim3(256), 0, s, patterns->d_keys, patterns->n, last.d_bm);
+    hipLaunchKernelGGL((seed_scan_reads_kernel<false>), dim3(grid), dim3(SBLK2), 0, s, v, K, (const uint32_t*)last.d_bm, patterns->d_keys, patterns->d_counts,
+                       patterns->d_bucket_off, patterns->bits, pc, nullptr, nullptr, nullptr, nullptr);
+    if ((rc = shn_device_scan_u32(ctx, pc, n_cnt, last.d_off, &nh))) { drop(); return rc; }      // (synchronises: pc may go back)
   }
-  last.ctx = nullptr;                                            // (one use)
   *n_hits = nh;
-  if (!out_read) { last = {ctx, reads, patterns, total, reads->n_reads, patterns->n, nh, K}; return SHN_OK; }
+  if (!out_read) {
+    if (nh == 0) { drop(); return SHN_OK; }                       // (nothing to fetch: no second call will come)
+    last.ctx = ctx; last.reads = reads; last.pat = patterns; last.total = total; last.n_reads = reads->n_reads; last.n_pat = patterns->n;
+    last.nh = nh; last.K = K;
+    return SHN_OK;
+  }
+  struct DropAtExit { decltype(drop)& d; ~DropAtExit() { d(); } } at_exit{drop};      // the pair ends here, whatever happens below
   if (nh == 0) return SHN_OK;
   uint32_t *d_r = nullptr, *d_s = nullptr, *d_i = nullptr;       // (from the caching allocator: this runs once per partition, under the GPU mutex)
   ShnDevBufs hb(ctx->stream);
   HIP_TRY(hb.get(&d_r, nh * 4)); HIP_TRY(hb.get(&d_s, nh * 4)); HIP_TRY(hb.get(&d_i, nh * 4));
-  hipLaunchKernelGGL((seed_scan_reads_kernel<true>), dim3(grid), dim3(SBLK2), 0, s, v, K, (const uint32_t*)pbm, patterns->d_keys, patterns->d_counts,
-                     patterns->d_bucket_off, patterns->bits, nullptr, (const uint64_t*)po, d_r, d_s, d_i);
+  hipLaunchKernelGGL((seed_scan_reads_kernel<true>), dim3(grid), dim3(SBLK2), 0, s, v, K, (const uint32_t*)last.d_bm, patterns->d_keys, patterns->d_counts,
+                     patterns->d_bucket_off, patterns->bits, nullptr, (const uint64_t*)last.d_off, d_r, d_s, d_i);
   HIP_TRY(hipMemcpyAsync(out_read, d_r, nh * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(out_start, d_s, nh * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(out_id, d_i, nh * 4, hipMemcpyDeviceToHost, s));

@@ -63,3 +63,32 @@ def test_the_allocator_of_rounds_1_to_4_fails_this():
     stream A lands on top of stream B's values"""
     r, _err = _run(SHN_DEV_LEGACY="1")
     assert r["WRONG_WORDS"] > 0, r
+
+
+POISON_CHILD = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from golden_util import load_case, load_inputs, MANIFEST
+from shannon_amd import device, pipeline
+name = sys.argv[1]
+m, g, inp = MANIFEST[name], load_case(name), load_inputs(name)
+ctx = device.Context(0)
+for rep in range(2):
+    R = pipeline.assemble(ctx, inp[0], inp[1] if m["paired"] else None, K=m["K"], sample="s", seed=m["sf_seed"])
+    assert R.extension.contigs == g["contigs"], "contigs differ under poison (repeat %%d)" %% rep
+    assert sorted(R.final.values()) == sorted(g["final"]["ds"].values()), "final differs under poison (repeat %%d)" %% rep
+print("POISON_OK", len(R.final))
+ctx.close()
+""" % (ROOT, os.path.join(ROOT, "tests"))
+
+
+@pytest.mark.parametrize("name", ["syn_pe_s0", "syn_pe_hairpin"])
+def test_the_whole_pipeline_with_every_workspace_request_poisoned(name):
+    """SHN_DEV_POISON_WS=1 fills a workspace slot with the poison byte on EVERY request: a call that relies on what an earlier call
+    left in a slot reads poison.  Until round 5 the seed scan's count / fetch pair did (its offsets lay in the context's slots between
+    the two ABI calls: the host crashed, rc 139); the pair owns its offsets now (seeds.hip) and the whole path -- count, walks,
+    contig stage, routing, graph threads, LP batches, merge -- gives the reference's contigs and transcripts with poisoned slots
+    AND poisoned allocations."""
+    p = subprocess.run([sys.executable, "-X", "faulthandler", "-c", POISON_CHILD, name], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       env=dict(os.environ, SHN_DEV_POISON="165", SHN_DEV_POISON_WS="1"), timeout=900)
+    assert p.returncode == 0 and "POISON_OK" in p.stdout, (p.returncode, p.stdout[-500:], p.stderr[-3000:])
