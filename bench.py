@@ -803,7 +803,7 @@ def main():
                     "count.scatter2": 16.0 * W, "count.buckets": 8.0 * W, "route": 192.0,
                     "count.sk_emit": 25.0 + rec_bytes, "count.sk_hist": 2.0 * rec_bytes, "count.sk_hist2": rec_bytes, "count.sk_scatter2": 2.0 * rec_bytes,
                     "count.sk_buckets": rec_bytes + 12.0 * distinct / max(1, n_reads)}
-        ext = last.res["extension"] if use_dist else {k: getattr(last.R.extension, k, None) for k in ("iterations", "n_walks", "total_steps", "wave_steps", "fresh_steps", "dense_rounds")}
+        ext = last.res["extension"] if use_dist else {k: getattr(last.R.extension, k, None) for k in ("iterations", "n_walks", "total_steps", "wave_steps", "fresh_steps", "dense_rounds", "settled_walks")}
         steps_all = ext["total_steps"] or 0
         steps_wave = ext["wave_steps"] or 0
         steps_fresh = ext.get("fresh_steps") or 0
@@ -907,6 +907,7 @@ def main():
                        "lp_newton_steps": lp["newton_steps"] / args.steps, "lp_not_converged": lp["not_converged"], "lp_too_large_trials": lp["too_large_trials"],
                        "extension_iterations": ext["iterations"], "extension_walks": ext["n_walks"],
                        "extension_walk_steps": steps_all, "extension_dense_rounds": ext.get("dense_rounds"),
+                       "extension_walks_settled_by_chain": ext.get("settled_walks"),
                        "partitions": (len(last.res["partitions"]) if use_dist else {k: [v["n_reads_routed"], v["n_k1mers"]] for k, v in last.R.partitions.items()}),
                        "windows_per_step": total, "distinct_k1mers": distinct},
             "roofline": r_dom,

@@ -159,6 +159,8 @@ uint64_t shn_ext_total_steps(const shn_ext* e);   /* walk steps executed over al
 uint64_t shn_ext_wave_steps(const shn_ext* e);    /* ... of which by the wavefront (long-walk) kernel */
 uint64_t shn_ext_fresh_steps(const shn_ext* e);   /* ... of which by the thread walker in the first round of a rank block (the bulk launches) */
 int shn_ext_dense_rounds(const shn_ext* e);       /* rounds whose begin / mark passes streamed every claim (the others followed line flags) */
+uint64_t shn_ext_settled_walks(const shn_ext* e); /* seeds never launched: a lower-ranked k1-mer on a chain of forced links takes them first
+                                                    * (extension_correction.py:223-245, 346: such a seed is always `in traversed`) */
 /* Diagnostics (no counterpart in the reference, whose loop extension_correction.py:334-354 is sequential and deterministic): with
  * SHN_EXT_DIGEST=1 in the environment shn_extend keeps checksums of the arrays of its stages -- out[stage * 64 + chunk], 8 stages
  * (table keys, counts, bucket offsets, weights + flags, adjacency records, seed order, converged claims, walk records) x 64 chunks

@@ -124,6 +124,7 @@ SIGNATURES = {
     "shn_ext_total_steps": (C.c_uint64, [vp]),
     "shn_ext_wave_steps": (C.c_uint64, [vp]),
     "shn_ext_dense_rounds": (C.c_int, [vp]),
+    "shn_ext_settled_walks": (C.c_uint64, [vp]),
     "shn_ext_fresh_steps": (C.c_uint64, [vp]),
     "shn_ext_digests": (C.c_int, [vp, vp]),
     "shn_debug_counter": (C.c_uint64, [C.c_int]),

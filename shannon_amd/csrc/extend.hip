@@ -113,6 +113,7 @@ struct shn_ext {
   uint64_t wave_steps;   // ... of which by the wavefront kernel
   uint64_t fresh_steps;  // ... of which by the thread walker in the first round of a rank block
   int dense_rounds;      // rounds whose begin / mark passes streamed all claims
+  uint64_t settled_walks; // walks that were never launched: a lower rank on a forced chain of their seed (ext_chain_has_lower)
   uint32_t* d_nr;        // [n_seeds] right steps (UNCLAIMED = void walk)
   uint32_t* d_nl;        // [n_seeds]
   uint64_t* d_totw;      // [n_seeds] sum of weights incl. the seed
@@ -1259,13 +1260,54 @@ __global__ void ext_audit_kernel(WalkArgs A, uint64_t ns, unsigned long long* __
   if (bad) { atomicAdd(&counters[0], 1ULL); atomicMin(&counters[1], (unsigned long long)r); }
 }
 
+// ---- Seeds that cannot survive, decided from the graph alone (round 6).  Let p be a left neighbour of the seed s whose ONLY right
+// neighbour is s (a forced link p -> s), and let some walk of rank below rank(s) traverse p -- p's own, if p is a seed of lower rank.
+// Whatever walk W gets to p first (extension_correction.py:223-245): it is seeded on p and extends right first -- its one candidate
+// is s; or it arrives at p extending right -- the same; or it arrives at p extending left, which it can only do from p's one right
+// neighbour, s.  In every case s is traversed by W or by an earlier walk, W's rank is at most rank(p) < rank(s), and the walk seeded
+// on s is void (:346).  By induction along a chain of forced links p_d -> ... -> p_1 -> s a lower rank ANYWHERE on the chain is
+// enough (whoever traverses p_i traverses p_{i-1} or came from it), and the mirror image holds on the right (q's only left
+// neighbour is s).  So of the seeds of a stretch without branches only the local rank minima can start a surviving walk: at
+// BASELINE configs[2] 98.6 % of the 186 M walks end void, most of them swallowed by a neighbour on their own unitig after a few
+// steps -- each cost its seed claim and the lines of its first candidates, and robbed whoever it met.  Here such a seed costs the
+// records of its chain neighbours (one 64-byte line per hop) and is never launched.  `hops` links are followed on each side; from
+// the second hop on only through k1-mers with a single neighbour on that side.
+__device__ __forceinline__ int adj_count(const Adj4& a) { return (a.v[0] >= 0) + (a.v[1] >= 0) + (a.v[2] >= 0) + (a.v[3] >= 0); }
+__device__ __forceinline__ bool ext_chain_has_lower(const Rec* __restrict__ rec, uint32_t o, uint32_t r, uint32_t hops) {
+  const Adj4 L0 = *(const Adj4*)((const char*)&rec[o] + 16), R0 = *(const Adj4*)((const char*)&rec[o]);
+#pragma unroll
+  for (int side = 0; side < 2; side++) {                       // 0: left neighbours (forced = their right row has one entry), 1: right
+    Adj4 nb = side == 0 ? L0 : R0;
+    for (uint32_t h = 0; h < hops; h++) {
+      const int cnt = adj_count(nb);
+      if (cnt == 0 || (h > 0 && cnt != 1)) break;
+      Adj4 next; next.v[0] = next.v[1] = next.v[2] = next.v[3] = -1;
+      bool forced_one = false;
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        if (nb.v[b] < 0) continue;
+        const Rec* q = &rec[(uint32_t)nb.v[b]];
+        const Adj4 toward = side == 0 ? *(const Adj4*)((const char*)q) : *(const Adj4*)((const char*)q + 16);     // the row that points back at us
+        if (adj_count(toward) != 1) continue;                  // not forced: a walk may pass it without coming our way
+        if (q->seed_rank < r) return true;
+        if (cnt == 1) { next = side == 0 ? *(const Adj4*)((const char*)q + 16) : *(const Adj4*)((const char*)q); forced_one = true; }
+      }
+      if (!forced_one) break;
+      nb = next;
+    }
+  }
+  return false;
+}
+
 // classify the dirty walks of the open block: long ones (memo or recorded length) go to the wavefront kernel,
 // the others to the thread kernel.  counters: [0] long [1] dirty walks that hold claims and have no current memo [2] short [3] dirty walks
 __global__ __launch_bounds__(1024) void ext_plan_kernel(uint32_t* nr, uint32_t* nl, uint64_t ns, uint32_t frozen,
                                 const uint8_t* __restrict__ mvalid, const uint32_t* __restrict__ mR, const uint32_t* __restrict__ mL,
                                 const uint8_t* __restrict__ dirty, uint32_t* __restrict__ long_list, uint32_t* __restrict__ short_list,
                                 unsigned long long* __restrict__ counters, uint32_t long_walk, uint8_t* __restrict__ coarse,
-                                const u64* __restrict__ fresh_claim, const uint32_t* __restrict__ order, uint64_t* __restrict__ totw) {
+                                const u64* __restrict__ fresh_claim, const uint32_t* __restrict__ order, uint64_t* __restrict__ totw,
+                                const Rec* __restrict__ rec, uint32_t settle_hops, uint8_t* __restrict__ settled,
+                                unsigned long long* __restrict__ n_settled) {
   // ns here = current rank limit (walks >= limit have not started yet); walks < frozen are final and never run
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + frozen;
   const bool isd_all = r < ns && dirty[r];
@@ -1278,7 +1320,12 @@ __global__ __launch_bounds__(1024) void ext_plan_kernel(uint32_t* nr, uint32_t* 
   // the second and third block then runs over the survivors, packed -- not one live walk among 63 lanes that look at their seed and
   // idle until the wavefront's longest walk ends.
   bool isd = isd_all;
-  if (isd && fresh_claim && RANK(fresh_claim[order[r]]) < r) { nr[r] = UNCLAIMED; nl[r] = 0; totw[r] = 0; isd = false; }
+  if (isd && settled[r]) { nr[r] = UNCLAIMED; nl[r] = 0; totw[r] = 0; isd = false; }           // void for good (below): it never runs
+  else if (isd && fresh_claim && RANK(fresh_claim[order[r]]) < r) { nr[r] = UNCLAIMED; nl[r] = 0; totw[r] = 0; isd = false; }
+  else if (isd && settle_hops && ext_chain_has_lower(rec, order[r], (uint32_t)r, settle_hops)) {
+    settled[r] = 1; nr[r] = UNCLAIMED; nl[r] = 0; totw[r] = 0; isd = false;
+    atomicAdd(n_settled, 1ULL);
+  }
   bool lg = false;
   if (isd) {
     uint32_t a = nr[r];
@@ -2279,7 +2326,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   // scratch: claim snapshot (d_claim2), memo pool + per-k1-mer hints, per-walk plan arrays
   void *ppool, *pplan;
   if ((rc = g_shn_ws[27].get(pool_cap * 4, &ppool)) ||
-      (rc = g_shn_ws[28].get((ns + 1) * (8 + 4 * 9 + 1 + 1 + 1 + 1 + 1) + 64, &pplan))) { shn_ext_destroy(e); return rc; }
+      (rc = g_shn_ws[28].get((ns + 1) * (8 + 4 * 9 + 1 + 1 + 1 + 1 + 1 + 1) + 64, &pplan))) { shn_ext_destroy(e); return rc; }
   u64 *claim = e->d_claim, *snap = e->d_claim2;
   uint32_t* pool = (uint32_t*)ppool;
   uint64_t* moff = (uint64_t*)pplan;
@@ -2297,7 +2344,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   uint8_t* dirty = fill + ns + 1;
   uint8_t* ran = dirty + ns + 1;
   uint8_t* robbed = ran + ns + 1;
-  TRYE(hipMemsetAsync(robbed, 0, ns + 1, s));
+  uint8_t* settled = robbed + ns + 1;     // walks that can never survive (ext_chain_has_lower): void for good, never launched
+  TRYE(hipMemsetAsync(robbed, 0, 2 * (ns + 1), s));
   TRYE(hipMemsetAsync(mvalid, 0, 2 * (ns + 1), s));
   TRYE(hipMemsetAsync(pool, 0xFF, pool_cap * 4, s));            // NONE32: "no entry"
   // (hints and seed ranks live in the records: ext_records_kernel wrote "none" into both)
@@ -2366,6 +2414,14 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   const unsigned long long memo_release_max = tune("SHN_EXT_MEMO_RELEASE_MAX", 65536);
   int n_begin_skipped = 0;
   const bool prepass = tune("SHN_EXT_PREPASS", 1) != 0;
+  // forced links followed on each side of a seed when its block opens (ext_chain_has_lower).  MEASURED at BASELINE configs[2] (round 6, one
+  // box, 4 steps each): hops 0 / 1 / 2 / 4 / 8 / 16 / 64 -> 0 / 78 / 88 / 96 / 99 / 100 / 100.5 M of the 186 M walks never launched, same
+  // digest, first-round walker 164 / 208 / 193 / 163 / 158 / 159 / 152 ms, walk steps 627 / 957 / 891 / 738 / 702 / 696 / 664 M, the walks'
+  // host time 0.608 / 0.687 / 0.671 / 0.638 / 0.629 / 0.632 / 0.631 s: the rule is exact and removes half of the walks -- the cheap half
+  // (seeds on clean chains: weakly covered transcripts; a well covered one has an error branch at every position, so no link is
+  // forced) -- and the survivors, started earlier than they would have been behind the void ones, walk further before a lower rank
+  // stops them.  A launch's time follows its steps' random sectors (~10 per step, ~40 G/s), not its walks.  Off by default.
+  const uint32_t settle_hops = tune("SHN_EXT_SETTLE_HOPS", 0);
   const uint32_t fresh_split = std::max<uint32_t>(1, std::min<uint32_t>(16, tune("SHN_EXT_FRESH_SPLIT", 1)));   // sub-launches of a block's first (bulk) round (measured at configs[2]: 1 / 4 / 7 / 10 -> 184 / 176 / 209 / 248 ms: every sub-launch waits for its longest walk; off)
   const uint32_t fresh_split_min = tune("SHN_EXT_FRESH_SPLIT_MIN", 65536);                                       // ... of blocks of at least this many walks            // a block's first round settles the walks whose seed an earlier block holds (ext_plan_kernel)
   unsigned long long expect_dirty = limit;
@@ -2380,7 +2436,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     if (limit > frozen)
       hipLaunchKernelGGL(ext_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 1024)), dim3(1024), 0, s, e->d_nr, e->d_nl, (uint64_t)limit, frozen,
                          mvalid, mR, mL, dirty, long_list, short_list, d_cnt + 2, bulk ? 0xFFFFFFFFu : long_walk, coarse,
-                         (fresh_block && frozen > 0 && prepass) ? (const u64*)claim : (const u64*)nullptr, e->d_order, e->d_totw);
+                         (fresh_block && frozen > 0 && prepass) ? (const u64*)claim : (const u64*)nullptr, e->d_order, e->d_totw,
+                         (const Rec*)e->d_rec, fresh_block ? settle_hops : 0u, settled, d_cnt + 20);
     // (pinned host memory: a pageable destination costs a staging copy kernel per round)
     TRYE(hipMemcpyAsync(plan, d_cnt + 2, 32, hipMemcpyDeviceToHost, s));
     TRYE(hipStreamSynchronize(s));
@@ -2486,7 +2543,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
         TRYE(hipMemsetAsync(d_cnt + 2, 0, 32, s));
         hipLaunchKernelGGL(ext_plan_kernel, dim3((uint32_t)cdiv(b - a, 1024)), dim3(1024), 0, s, e->d_nr, e->d_nl, (uint64_t)b, a,
                            mvalid, mR, mL, dirty, long_list, short_list, d_cnt + 2, 0xFFFFFFFFu, coarse,
-                           ((a > 0) && prepass) ? (const u64*)claim : (const u64*)nullptr, e->d_order, e->d_totw);
+                           ((a > 0) && prepass) ? (const u64*)claim : (const u64*)nullptr, e->d_order, e->d_totw,
+                           (const Rec*)e->d_rec, settle_hops, settled, d_cnt + 20);
         TRYE(hipMemcpyAsync(plan, d_cnt + 2, 32, hipMemcpyDeviceToHost, s));
         TRYE(hipStreamSynchronize(s));
         if (plan[2]) {
@@ -2603,6 +2661,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   unsigned long long steps = 0, wsteps = 0, fsteps = 0, wslots[64];
   TRYE(hipMemcpyAsync(&steps, d_cnt + 1, 8, hipMemcpyDeviceToHost, s));          // thread-kernel steps
   TRYE(hipMemcpyAsync(&fsteps, d_cnt + 16, 8, hipMemcpyDeviceToHost, s));
+  { unsigned long long nset = 0; TRYE(hipMemcpyAsync(&nset, d_cnt + 20, 8, hipMemcpyDeviceToHost, s)); TRYE(hipStreamSynchronize(s)); e->settled_walks = nset; }
   TRYE(hipMemcpyAsync(wslots, d_cnt + 64, 64 * 8, hipMemcpyDeviceToHost, s));    // wavefront-kernel steps
   TRYE(hipStreamSynchronize(s));
   for (int i = 0; i < 64; i++) wsteps += wslots[i];
@@ -2631,6 +2690,7 @@ extern "C" uint64_t shn_ext_total_steps(const shn_ext* e) { return e ? e->total_
 extern "C" uint64_t shn_ext_wave_steps(const shn_ext* e) { return e ? e->wave_steps : 0; }
 extern "C" uint64_t shn_ext_fresh_steps(const shn_ext* e) { return e ? e->fresh_steps : 0; }
 extern "C" int shn_ext_dense_rounds(const shn_ext* e) { return e ? e->dense_rounds : 0; }
+extern "C" uint64_t shn_ext_settled_walks(const shn_ext* e) { return e ? e->settled_walks : 0; }
 
 extern "C" int shn_ext_stats_range(shn_ctx* ctx, const shn_ext* e, uint64_t lo, uint64_t n, uint32_t* n_right, uint32_t* n_left, uint64_t* tot_weight) {
   if (!ctx || !e || (n && (!n_right || !n_left || !tot_weight))) return shn_fail(SHN_ERR_ARG, "shn_ext_stats_range: NULL argument");

@@ -18,6 +18,8 @@
 #include <string>
 #include <thread>
 #include <mutex>
+#include <condition_variable>
+#include <functional>
 #include <vector>
 
 namespace {
@@ -340,6 +342,67 @@ static void emit(Component& c, const std::string& sname, int comp) {
 
 }  // namespace
 
+// The host threads of one shn_sparse_flow call, kept for the whole call: a round advances a few hundred components in microseconds
+// each, and until round 6 every phase of every round started and joined its own std::threads -- 2 x 16 thread starts per round, 890
+// rounds per step at bench.py --config 2p: 4.7 of the stage's 8.4 s.  run(n, chunk, fn): fn(i) for every i < n, chunks of `chunk`
+// handed out by an atomic counter, the caller works too and returns when every index is done.  The workers spin for a few
+// microseconds between jobs (the next phase of a round follows at once) before they sleep on the condition variable.
+struct SflowPool {
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::atomic<uint64_t> gen{0};
+  std::atomic<size_t> next{0};
+  std::atomic<int> busy{0};
+  std::atomic<bool> stop{false};
+  size_t n = 0, chunk = 1;
+  const std::function<void(size_t)>* fn = nullptr;
+  explicit SflowPool(unsigned workers) {
+    for (unsigned t = 0; t < workers; t++) th.emplace_back([this]() { loop(); });
+  }
+  ~SflowPool() {
+    { std::lock_guard<std::mutex> lk(mu); stop.store(true); gen.fetch_add(1); }
+    cv.notify_all();
+    for (auto& x : th) x.join();
+  }
+  void drain() {
+    while (true) {
+      const size_t i0 = next.fetch_add(chunk);
+      if (i0 >= n) break;
+      const size_t i1 = std::min(n, i0 + chunk);
+      for (size_t i = i0; i < i1; i++) (*fn)(i);
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    while (true) {
+      // a short spin, then sleep
+      bool got = false;
+      for (int sp = 0; sp < 2000 && !got; sp++) { got = gen.load(std::memory_order_acquire) != seen; if (!got) __builtin_ia32_pause(); }
+      if (!got) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return gen.load(std::memory_order_acquire) != seen; }); }
+      if (stop.load()) return;
+      // (a job is published as: n / chunk / fn written, busy = workers + 1, next = 0, THEN gen++ -- all of it under mu)
+      { std::lock_guard<std::mutex> lk(mu); seen = gen.load(); }
+      drain();
+      busy.fetch_sub(1, std::memory_order_acq_rel);
+    }
+  }
+  void run(size_t n_items, size_t chunk_, const std::function<void(size_t)>& f) {
+    if (!n_items) return;
+    if (th.empty() || n_items <= chunk_) { for (size_t i = 0; i < n_items; i++) f(i); return; }
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      n = n_items; chunk = std::max<size_t>(1, chunk_); fn = &f;
+      next.store(0); busy.store((int)th.size() + 1);
+      gen.fetch_add(1, std::memory_order_release);
+    }
+    cv.notify_all();
+    drain();
+    busy.fetch_sub(1, std::memory_order_acq_rel);
+    while (busy.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();      // (the stragglers are inside their last chunk)
+  }
+};
+
 struct shn_sflow { std::vector<std::string> text; };
 
 extern "C" void shn_sflow_destroy(shn_sflow* s) { delete s; }
@@ -366,9 +429,10 @@ extern "C" int shn_sparse_flow_thread(shn_ctx* ctx, const shn_graph* const* grap
 extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uint32_t n_graphs, const char* const* snames, uint64_t seed, shn_sflow** out) {
   if (!ctx || !out || (n_graphs && (!graphs || !snames))) return shn_fail(SHN_ERR_ARG, "shn_sparse_flow: NULL argument");
   *out = nullptr;
-  const bool dbg = getenv("SHN_DEBUG") != nullptr;
+  const bool dbg = getenv("SHN_DEBUG") != nullptr || getenv("SHN_SFLOW_LAPS") != nullptr;
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_lap = now(), t_adv = 0, t_lp = 0, t_fin = 0, t_pack = 0;
+  size_t n_small_rounds = 0, n_pend_total = 0; uint64_t n_trials_total = 0;
   auto lap = [&](const char* what) { if (dbg) { const double t = now(); fprintf(stderr, "[sflow] %-28s %8.3f s\n", what, t - t_lap); t_lap = t; } };
   std::vector<Component> comps;
   std::vector<uint32_t> comp_graph;
@@ -430,14 +494,16 @@ extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uin
     c.all.push_back(c.E);
     c.pfn.resize(c.nodes.size());
   };
-  const unsigned nt = comps.size() < (t_sflow_beside ? 4096u : 256u) ? 1 : std::max(1u, std::min(32u, (unsigned)shn_host_cpus()));
-  auto parallel = [&](auto&& fn) {
-    if (nt <= 1) { for (size_t k = 0; k < comps.size(); k++) fn(k); return; }
-    std::atomic<size_t> next{0};
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; t++) th.emplace_back([&]() { while (true) { const size_t k0 = next.fetch_add(64); if (k0 >= comps.size()) break; for (size_t k = k0; k < std::min(comps.size(), k0 + 64); k++) fn(k); } });
-    for (auto& x : th) x.join();
-  };
+  // (a call beside other partitions' graph stages keeps to its own thread unless it is large: the machine is busy)
+  size_t n_nodes_all = 0;
+  for (uint32_t g = 0; g < n_graphs; g++) n_nodes_all += graphs[g]->n_off.size();
+  const bool small_job = t_sflow_beside ? (comps.size() < 4096 && n_nodes_all < (1u << 18)) : (comps.size() < 256 && n_nodes_all < (1u << 16));
+  const unsigned nt = small_job ? 1 : std::max(1u, std::min(32u, (unsigned)shn_host_cpus()));
+  SflowPool pool(nt > 1 ? nt - 1 : 0);
+  // chunks: a few per thread, so that a handful of large components (the repeat-linked families of --config 2p: 610 components of
+  // ~3,000 nodes) do not end up on one thread behind 63 others
+  auto chunk_of = [&](size_t n_items) { return std::max<size_t>(1, std::min<size_t>(64, n_items / ((size_t)nt * 8))); };
+  auto parallel = [&](const std::function<void(size_t)>& fn) { pool.run(comps.size(), chunk_of(comps.size()), fn); };
   parallel(build);
   lap("build components");
   int n_round = 0;
@@ -449,16 +515,13 @@ extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uin
     double tr0 = now();
     n_round++;
     // advance the active components (independent of each other)
-    {
-      std::atomic<size_t> next{0};
-      auto work = [&]() { while (true) { const size_t i0 = next.fetch_add(16); if (i0 >= active.size()) break; for (size_t i = i0; i < std::min(active.size(), i0 + 16); i++) wants[active[i]] = advance(comps[active[i]]) ? 1 : 0; } };
-      if (nt <= 1 || active.size() < 64) work();
-      else { std::vector<std::thread> th; for (unsigned t = 0; t < nt; t++) th.emplace_back(work); for (auto& x : th) x.join(); }
-    }
+    pool.run(active.size(), std::max<size_t>(1, std::min<size_t>(16, active.size() / ((size_t)nt * 4))),
+             [&](size_t i) { wants[active[i]] = advance(comps[active[i]]) ? 1 : 0; });
     std::vector<size_t> pend;
     for (size_t k : active) if (wants[k]) pend.push_back(k);
     t_adv += now() - tr0; tr0 = now();
     if (pend.empty()) break;
+    n_pend_total += pend.size(); if (pend.size() < 64) n_small_rounds++;
     std::vector<uint32_t> m(pend.size()), n(pend.size()), tr(pend.size());
     std::vector<uint64_t> pid(pend.size());
     std::vector<double> ab;
@@ -473,21 +536,18 @@ extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uin
       ooff[i + 1] = ooff[i] + (uint64_t)q.m * q.n * q.trials;
     }
     std::vector<double> flows(ooff.back());
+    for (size_t i = 0; i < pend.size(); i++) n_trials_total += tr[i];
     t_pack += now() - tr0; tr0 = now();
     int rc = shn_lp_solve_batch(ctx, (uint32_t)pend.size(), m.data(), n.data(), tr.data(), pid.data(), ab.data(), mask.data(), seed, flows.data());
     if (rc) return rc;
     t_lp += now() - tr0; tr0 = now();
-    {
-      std::atomic<size_t> next{0};
-      auto work = [&]() { while (true) { const size_t i0 = next.fetch_add(16); if (i0 >= pend.size()) break; for (size_t i = i0; i < std::min(pend.size(), i0 + 16); i++) { Component& c = comps[pend[i]]; finish(c, flows.data() + ooff[i]); apply_flow(c); } } };
-      if (nt <= 1 || pend.size() < 64) work();
-      else { std::vector<std::thread> th; for (unsigned t = 0; t < nt; t++) th.emplace_back(work); for (auto& x : th) x.join(); }
-    }
+    pool.run(pend.size(), std::max<size_t>(1, std::min<size_t>(16, pend.size() / ((size_t)nt * 4))),
+             [&](size_t i) { Component& c = comps[pend[i]]; finish(c, flows.data() + ooff[i]); apply_flow(c); });
     active.swap(pend);
     t_fin += now() - tr0;
   }
-  if (dbg) fprintf(stderr, "[sflow] %zu components, %d rounds: advance %.3f s, pack %.3f s, LP batches %.3f s, finish+apply %.3f s\n", comps.size(), n_round, t_adv,
-                   t_pack, t_lp, t_fin);
+  if (dbg) fprintf(stderr, "[sflow] %zu components of %u graphs, %d rounds (%zu of them with fewer than 64 problems; %zu problems, %llu trials in all): advance %.3f s, pack %.3f s, "
+                   "LP batches %.3f s, finish+apply %.3f s\n", comps.size(), n_graphs, n_round, n_small_rounds, n_pend_total, (unsigned long long)n_trials_total, t_adv, t_pack, t_lp, t_fin);
   t_lap = now();
   // transcripts of every component, then the partition texts
   {
@@ -520,12 +580,7 @@ extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uin
       t += "\n";
     }
   };
-  {
-    std::atomic<uint32_t> next{0};
-    auto work = [&]() { for (uint32_t g; (g = next.fetch_add(1)) < n_graphs;) text_of(g); };
-    if (nt <= 1 || n_graphs < 4) work();
-    else { std::vector<std::thread> th; for (unsigned t = 0; t < std::min<unsigned>(nt, n_graphs); t++) th.emplace_back(work); for (auto& x : th) x.join(); }
-  }
+  pool.run(n_graphs, 1, [&](size_t g) { text_of((uint32_t)g); });
   lap("partition texts");
   // The components hold ~10^2 small vectors each (26 ms to give back on 16 threads at BASELINE configs[2]): they go to a
   // background thread, which frees them while the caller merges the transcripts; the thread of the call before is joined first, the

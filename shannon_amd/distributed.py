@@ -379,7 +379,7 @@ def _gather_and_merge(texts, names, res, gk, group, rank, W, lock, tick, error=N
     lock.release()
     return {"partitions": parts, "final": final, "contigs": res.contigs,
             "n_k1mers": int(gk.numel()) if gk is not None else int(getattr(res, "n_k1mers_table", 0)),
-            "extension": {k: getattr(res, k, None) for k in ("iterations", "n_walks", "total_steps", "wave_steps", "fresh_steps", "dense_rounds")}}
+            "extension": {k: getattr(res, k, None) for k in ("iterations", "n_walks", "total_steps", "wave_steps", "fresh_steps", "dense_rounds", "settled_walks")}}
 
 
 def _a2a_objects(recv, payload, group):

@@ -124,6 +124,10 @@ class Extension(object):
     def dense_rounds(self):
         return int(_lib.lib().shn_ext_dense_rounds(self.h))
 
+    @property
+    def settled_walks(self):
+        return int(_lib.lib().shn_ext_settled_walks(self.h))
+
     def stats(self):
         n = self.n_walks
         nr = np.empty(n, np.uint32)
@@ -752,6 +756,7 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
     res.wave_steps = ext.wave_steps
     res.fresh_steps = ext.fresh_steps
     res.dense_rounds = ext.dense_rounds
+    res.settled_walks = ext.settled_walks
     res.ext_digests = ext.digests()                     # (SHN_EXT_DIGEST=1: bench.py names the stage at which a step differed)
     res.contigs = contigs[1:]
     res.contig_raw = contig_raw
