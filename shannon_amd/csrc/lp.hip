@@ -160,6 +160,122 @@ __global__ __launch_bounds__(LBLK) void lp_trials_kernel(const LpProblem* __rest
 #undef CX
 }
 
+// ---- The same vertex, one WAVEFRONT per trial (round 6).  With lane = trial a launch lasts as long as its largest problem's
+// successive-shortest-path chain -- O((m + n)^2 m n) dependent LDS operations of ONE lane: 1.6 ms per launch at bench.py --config 2p,
+// where nearly every one of the 890 dependent rounds of a step holds a node with more than 11 in- or out-edges (beyond 11 x 11 the
+// state did not fit the LDS form either and went through HBM) -- while the chip runs a few hundred wavefronts.  Here the 64 lanes of a
+// wavefront share one trial: the Bellman-Ford half-rounds are parallel over the columns (then the rows) -- within a half-round no
+// entry depends on another of the same half, exactly as in the sequential form, where the j loop reads ds[] only and the i loop dt[]
+// only -- every lane keeps the sequential loop over the other index (ascending, strict <: the lowest index wins a tie), the sink is
+// the lowest column of least distance (two wave reductions), and lane 0 walks the predecessor chain.  The arithmetic of a trial is
+// operation for operation that of lp_trials_kernel (integer distances; the doubles only meet min, += and -= along one simple
+// path), so the answers are the same bits -- tests/test_lp_gpu.py holds both against oracle/lp.py and against each other.
+__device__ __forceinline__ int64_t wave_min_i64(int64_t v) {
+  for (int o = 32; o > 0; o >>= 1) { const int64_t w = __shfl_xor(v, o, 64); v = w < v ? w : v; }
+  return v;
+}
+__global__ __launch_bounds__(LBLK) void lp_trials_coop_kernel(const LpProblem* __restrict__ probs, const uint32_t* __restrict__ block_prob,
+                                                              const uint32_t* __restrict__ block_first, const double* __restrict__ in,
+                                                              const uint8_t* __restrict__ masks, uint64_t seed,
+                                                              uint64_t* __restrict__ ws, double* __restrict__ out) {
+  extern __shared__ uint64_t lp_lds[];
+  const LpProblem P = probs[block_prob[blockIdx.x]];
+  const uint32_t t = block_first[blockIdx.x] + blockIdx.y;            // grid.y = the 64 trials of the chunk
+  if (t >= P.trials) return;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t m = P.m, n = P.n, T = P.trials, mn = m * n;
+  const double* a_s = in + P.in_off;
+  const double* b_s = a_s + m;
+  const uint8_t* pm = masks + P.mask_off;
+  int64_t* C = (int64_t*)lp_lds;
+  double* X = (double*)(C + mn);
+  double* ra = X + mn;
+  double* rb = ra + m;
+  int64_t* ds = (int64_t*)(rb + n);
+  int64_t* dt = ds + m;
+  int64_t* ps = dt + n;
+  int64_t* pt = ps + m;
+#define CX(i, j) ((j) * m + (i))
+  for (uint32_t k = lane; k < mn; k += LBLK) { C[k] = pm[k] ? lp_cell_cost(seed, P.pid, t, k) : 0; X[k] = 0.0; }
+  for (uint32_t i = lane; i < m; i += LBLK) ra[i] = a_s[i];
+  for (uint32_t j = lane; j < n; j += LBLK) rb[j] = b_s[j];
+  __syncthreads();
+  const uint32_t max_it = 4 * (m + n) + mn + 16;
+  for (uint32_t it = 0; it < max_it; it++) {
+    bool sS = false, sT = false;
+    for (uint32_t i = lane; i < m; i += LBLK) { const bool s = ra[i] > 0; sS |= s; ds[i] = s ? 0 : LP_INF; ps[i] = -1; }
+    for (uint32_t j = lane; j < n; j += LBLK) { sT |= rb[j] > 0; dt[j] = LP_INF; pt[j] = -1; }
+    const bool anyS = __ballot(sS) != 0, anyT = __ballot(sT) != 0;
+    __syncthreads();
+    if (!anyS || !anyT) break;
+    for (uint32_t r = 0; r < m + n; r++) {
+      bool changed = false;
+      for (uint32_t j = lane; j < n; j += LBLK) {
+        int64_t best = LP_INF; int64_t bi = -1;
+        for (uint32_t i = 0; i < m; i++) {
+          const int64_t d = ds[i];
+          if (d < LP_INF) { const int64_t v = d + C[CX(i, j)]; if (v < best) { best = v; bi = i; } }
+        }
+        if (bi >= 0 && best < dt[j]) { dt[j] = best; pt[j] = bi; changed = true; }
+      }
+      __syncthreads();
+      for (uint32_t i = lane; i < m; i += LBLK) {
+        int64_t best = LP_INF; int64_t bj = -1;
+        for (uint32_t j = 0; j < n; j++) {
+          if (X[CX(i, j)] > 0) {
+            const int64_t d = dt[j];
+            if (d < LP_INF) { const int64_t v = d - C[CX(i, j)]; if (v < best) { best = v; bj = j; } }
+          }
+        }
+        if (bj >= 0 && best < ds[i]) { ds[i] = best; ps[i] = bj; changed = true; }
+      }
+      __syncthreads();
+      if (__ballot(changed) == 0) break;
+    }
+    // the sink: least distance among the columns that still want flow, the lowest column on a tie
+    int64_t lbd = LP_INF; int64_t ltt = -1;
+    for (uint32_t j = lane; j < n; j += LBLK) if (rb[j] > 0 && dt[j] < lbd) { lbd = dt[j]; ltt = j; }
+    const int64_t bd = wave_min_i64(lbd);
+    const int64_t tt = wave_min_i64((ltt >= 0 && lbd == bd) ? ltt : LP_INF);
+    if (bd >= LP_INF || tt >= LP_INF) break;
+    int ok = 1;
+    if (lane == 0) {
+      double delta = rb[tt];
+      int64_t j = tt, s = -1;
+      for (uint32_t g = 0; g <= m + n + 2; g++) {
+        const int64_t i = pt[j];
+        const int64_t pj = ps[i];
+        if (pj < 0) { s = i; break; }
+        const double xv = X[CX(i, pj)];
+        if (xv < delta) delta = xv;
+        j = pj;
+      }
+      if (s < 0) ok = 0;                      // cannot happen with exact integer distances
+      else {
+        if (ra[s] < delta) delta = ra[s];
+        j = tt;
+        for (uint32_t g = 0; g <= m + n + 2; g++) {
+          const int64_t i = pt[j];
+          X[CX(i, j)] += delta;
+          const int64_t pj = ps[i];
+          if (pj < 0) break;
+          X[CX(i, pj)] -= delta;
+          j = pj;
+        }
+        ra[s] -= delta;
+        rb[tt] -= delta;
+      }
+    }
+    ok = __shfl(ok, 0, 64);
+    __syncthreads();
+    if (!ok) break;
+  }
+  double* o = out + P.out_off;
+  double* Xg = (double*)(ws + P.ws_off) + (uint64_t)mn * T;              // the vertex, where lp_center_kernel looks for it
+  for (uint32_t k = lane; k < mn; k += LBLK) { const double v = X[k]; o[(uint64_t)k * T + t] = v; Xg[(uint64_t)k * T + t] = v; }
+#undef CX
+}
+
 #define NEWTON_MAX 100
 #define NEWTON_TOL2 1e-20
 #define FLOW_EPS 1e-6
@@ -451,8 +567,10 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
   hipStream_t s = ctx->stream; shn_use_stream(s);
   const bool center = ctx->lp_rule != SHN_LP_RULE_VERTEX;
   std::vector<LpProblem> probs(n_problems);
-  std::vector<uint32_t> bprob, bfirst, lprob, lfirst, cprob, cfirst;       // blocks of the vertex kernel (state in HBM / in LDS) / of the centre kernel
-  uint64_t lds_words = 0;
+  std::vector<uint32_t> bprob, bfirst, lprob, lfirst, cprob, cfirst, wprob, wfirst;       // blocks of the vertex kernel (state in HBM / in LDS) / of the centre kernel / chunks of the wavefront-per-trial kernel
+  uint64_t lds_words = 0, coop_words = 0;
+  const char* coop_env = getenv("SHN_LP_COOP");
+  const bool use_coop = !(coop_env && coop_env[0] == '0');
   // the in-LDS trial kernel asks for up to LP_LDS_WORDS * 8 = 156 KB of dynamic LDS: asked for once per process; a device or driver
   // that does not grant it gets the HBM form of the same kernel for every problem
   static const bool lds_granted = []() {
@@ -474,8 +592,15 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
     ws_off += (2 * mn + 3ULL * (m[p] + n[p])) * trials[p];
     stat_off += trials[p];
     out_off += mn * trials[p];
-    const bool in_lds = lds_granted && (2 * mn + 3ULL * (m[p] + n[p])) * LBLK <= LP_LDS_WORDS;
-    for (uint32_t f = 0; f < trials[p]; f += LBLK) { (in_lds ? lprob : bprob).push_back(p); (in_lds ? lfirst : bfirst).push_back(f); lds_words = in_lds ? std::max<uint64_t>(lds_words, (2 * mn + 3ULL * (m[p] + n[p])) * LBLK) : lds_words; }
+    // a wavefront per trial (lp_trials_coop_kernel) wherever one trial's state fits 64 KB of LDS (m = n = 62); SHN_LP_COOP=0: lane = trial
+    const uint64_t words = 2 * mn + 3ULL * (m[p] + n[p]);
+    const bool coop = use_coop && words * 8 <= 65536;
+    const bool in_lds = !coop && lds_granted && words * LBLK <= LP_LDS_WORDS;
+    for (uint32_t f = 0; f < trials[p]; f += LBLK) {
+      if (coop) { wprob.push_back(p); wfirst.push_back(f); coop_words = std::max<uint64_t>(coop_words, words); continue; }
+      (in_lds ? lprob : bprob).push_back(p); (in_lds ? lfirst : bfirst).push_back(f);
+      lds_words = in_lds ? std::max<uint64_t>(lds_words, words * LBLK) : lds_words;
+    }
     // the centre kernel has work only where the supported cells of the problem hold a cycle (rows and columns as vertices, a
     // supported cell as an edge): on a forest every class is a tree and its face a point.  At BASELINE configs[2] 9,000
     // problems per step, a handful with a cycle.
@@ -508,7 +633,7 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
   int rc;
   auto al = [](uint64_t x) { return (x + 15) & ~15ULL; };
   const uint64_t o_probs = 0, o_blocks = al(o_probs + probs.size() * sizeof(LpProblem)),
-                 o_in = al(o_blocks + (bprob.size() + lprob.size() + cprob.size()) * 8), o_mask = al(o_in + in_off * 8), up_bytes = al(o_mask + mask_off) + 16;
+                 o_in = al(o_blocks + (bprob.size() + lprob.size() + cprob.size() + wprob.size()) * 8), o_mask = al(o_in + in_off * 8), up_bytes = al(o_mask + mask_off) + 16;
   const uint64_t o_out = 0, o_stat = al(out_off * 8), down_bytes = o_stat + stat_off * 16 + 16;
   void *h_up, *h_down;
   if ((rc = ctx->cws[4].get(up_bytes, &pup)) || (rc = ctx->cws[8].get(ws_off * 8 + 16, &pws)) || (rc = ctx->cws[9].get(down_bytes, &pdown)) ||
@@ -517,7 +642,7 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
   memcpy(hu + o_probs, probs.data(), probs.size() * sizeof(LpProblem));
   uint32_t* hb = (uint32_t*)(hu + o_blocks);
   auto put = [&](const std::vector<uint32_t>& v) { if (!v.empty()) memcpy(hb, v.data(), v.size() * 4); hb += v.size(); };
-  put(bprob); put(bfirst); put(cprob); put(cfirst); put(lprob); put(lfirst);
+  put(bprob); put(bfirst); put(cprob); put(cfirst); put(lprob); put(lfirst); put(wprob); put(wfirst);
   memcpy(hu + o_in, ab, in_off * 8);
   memcpy(hu + o_mask, mask, mask_off);
   uint8_t* du = (uint8_t*)pup;
@@ -528,11 +653,16 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
   uint32_t* d_cfirst = d_cprob + cprob.size();
   uint32_t* d_lprob = d_cfirst + cprob.size();
   uint32_t* d_lfirst = d_lprob + lprob.size();
+  uint32_t* d_wprob = d_lfirst + lprob.size();
+  uint32_t* d_wfirst = d_wprob + wprob.size();
   void* pin = du + o_in;
   void* pm = du + o_mask;
   void* pout = (uint8_t*)pdown + o_out;
   void* pst = (uint8_t*)pdown + o_stat;
   HIP_TRY(hipMemcpyAsync(pup, h_up, up_bytes - 16, hipMemcpyHostToDevice, s));
+  if (!wprob.empty())
+    hipLaunchKernelGGL(lp_trials_coop_kernel, dim3((uint32_t)wprob.size(), LBLK), dim3(LBLK), coop_words * 8, s, (const LpProblem*)pp, d_wprob, d_wfirst,
+                       (const double*)pin, (const uint8_t*)pm, seed, (uint64_t*)pws, (double*)pout);
   if (!lprob.empty()) {
     hipLaunchKernelGGL(lp_trials_kernel<true>, dim3((uint32_t)lprob.size()), dim3(LBLK), lds_words * 8, s, (const LpProblem*)pp, d_lprob, d_lfirst,
                        (const double*)pin, (const uint8_t*)pm, seed, (uint64_t*)pws, (double*)pout);

@@ -433,6 +433,7 @@ extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uin
   auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_lap = now(), t_adv = 0, t_lp = 0, t_fin = 0, t_pack = 0;
   size_t n_small_rounds = 0, n_pend_total = 0; uint64_t n_trials_total = 0;
+  uint64_t h_prob[8] = {0}, h_roundmax[8] = {0};          // problems / rounds by the size class of (the largest) max(m, n): <=2, 3, 4, 5-6, 7-8, 9-11, 12-16, more
   auto lap = [&](const char* what) { if (dbg) { const double t = now(); fprintf(stderr, "[sflow] %-28s %8.3f s\n", what, t - t_lap); t_lap = t; } };
   std::vector<Component> comps;
   std::vector<uint32_t> comp_graph;
@@ -537,6 +538,12 @@ extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uin
     }
     std::vector<double> flows(ooff.back());
     for (size_t i = 0; i < pend.size(); i++) n_trials_total += tr[i];
+    if (dbg) {
+      auto cls = [](uint32_t x) { return x <= 2 ? 0 : x == 3 ? 1 : x == 4 ? 2 : x <= 6 ? 3 : x <= 8 ? 4 : x <= 11 ? 5 : x <= 16 ? 6 : 7; };
+      int mx = 0;
+      for (size_t i = 0; i < pend.size(); i++) { const int c_ = cls(std::max(m[i], n[i])); h_prob[c_]++; mx = std::max(mx, c_); }
+      h_roundmax[mx]++;
+    }
     t_pack += now() - tr0; tr0 = now();
     int rc = shn_lp_solve_batch(ctx, (uint32_t)pend.size(), m.data(), n.data(), tr.data(), pid.data(), ab.data(), mask.data(), seed, flows.data());
     if (rc) return rc;
@@ -548,6 +555,9 @@ extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uin
   }
   if (dbg) fprintf(stderr, "[sflow] %zu components of %u graphs, %d rounds (%zu of them with fewer than 64 problems; %zu problems, %llu trials in all): advance %.3f s, pack %.3f s, "
                    "LP batches %.3f s, finish+apply %.3f s\n", comps.size(), n_graphs, n_round, n_small_rounds, n_pend_total, (unsigned long long)n_trials_total, t_adv, t_pack, t_lp, t_fin);
+  if (dbg && n_pend_total > 1000) fprintf(stderr, "[sflow]   problems by max(m, n) <=2 / 3 / 4 / 5-6 / 7-8 / 9-11 / 12-16 / more: %llu %llu %llu %llu %llu %llu %llu %llu; rounds by their largest problem: %llu %llu %llu %llu %llu %llu %llu %llu\n",
+                   (unsigned long long)h_prob[0], (unsigned long long)h_prob[1], (unsigned long long)h_prob[2], (unsigned long long)h_prob[3], (unsigned long long)h_prob[4], (unsigned long long)h_prob[5], (unsigned long long)h_prob[6], (unsigned long long)h_prob[7],
+                   (unsigned long long)h_roundmax[0], (unsigned long long)h_roundmax[1], (unsigned long long)h_roundmax[2], (unsigned long long)h_roundmax[3], (unsigned long long)h_roundmax[4], (unsigned long long)h_roundmax[5], (unsigned long long)h_roundmax[6], (unsigned long long)h_roundmax[7]);
   t_lap = now();
   // transcripts of every component, then the partition texts
   {

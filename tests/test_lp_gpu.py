@@ -76,6 +76,52 @@ def test_lp_batch_bit_exact(ctx):
     assert n_deg > 20 and large > 0
 
 
+def test_wavefront_per_trial_equals_lane_per_trial(ctx, monkeypatch):
+    """lp_trials_coop_kernel (a wavefront per trial: the default since round 6) against lp_trials_kernel (lane = trial, state in LDS or
+    -- beyond 11 x 11 -- in HBM; SHN_LP_COOP=0): the same bits on every trial, sizes from 2 x 2 to 70 x 3 (rows or columns beyond the
+    64 lanes), both rules; the larger ones against the oracle's vertex as well"""
+    from shannon_amd import sparse_flow
+    from oracle import lp as olp
+    rng = np.random.default_rng(11)
+    reqs = []
+    for t in range(90):
+        m, n = int(rng.integers(2, 21)), int(rng.integers(2, 21))
+        if t < 4:
+            m, n = [(70, 3), (3, 70), (30, 30), (12, 65)][t]
+        a = [float(v) for v in rng.integers(0, 30, m)]
+        if sum(a) == 0:
+            a[0] = 3.0
+        tot = int(sum(a))
+        cuts = np.sort(rng.integers(0, tot + 1, n - 1))
+        b = [float(v) for v in np.diff(np.concatenate([[0], cuts, [tot]]))]
+        if t % 3 == 0:
+            b = [v + float(rng.random()) for v in b]
+        P = (rng.random((m, n)) < [0.0, 0.3, 0.8, 1.0][t % 4]).astype(int).tolist()
+        kind, *rest = sparse_flow.prepare(a, b, P, 5000 + t, 10)
+        if kind == "lp":
+            reqs.append(rest[0])
+    assert len(reqs) > 60
+    for rule in ("center", "vertex"):
+        ctx.set_lp_rule(rule)
+        try:
+            monkeypatch.setenv("SHN_LP_COOP", "1")
+            xa = sparse_flow.solve_batch(ctx, reqs, 91)
+            monkeypatch.setenv("SHN_LP_COOP", "0")
+            xb = sparse_flow.solve_batch(ctx, reqs, 91)
+        finally:
+            ctx.set_lp_rule("center")
+            monkeypatch.delenv("SHN_LP_COOP", raising=False)
+        for q, a_, b_ in zip(reqs, xa, xb):
+            assert np.array_equal(a_, b_), (rule, q.m, q.n)
+        if rule == "vertex":
+            for q, x in list(zip(reqs, xa))[:12]:
+                for t in range(0, q.trials, 9):
+                    cc = olp.trial_costs(91, q.pid, t, q.m * q.n)
+                    c = [[(cc[j * q.m + i] if q.p[j * q.m + i] > 0 else 0) for j in range(q.n)] for i in range(q.m)]
+                    ref = olp.transport_vertex(q.a_s, q.b_s, c)
+                    assert np.array_equal(np.array([ref[k % q.m][k // q.m] for k in range(q.m * q.n)]), x[:, t])
+
+
 def test_vertex_rule_behind_the_switch(ctx):
     """shn_lp_set_rule(vertex): the flows are the vertex of rounds 1-2, bit for bit"""
     from shannon_amd import sparse_flow
