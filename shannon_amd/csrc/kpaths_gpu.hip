@@ -31,6 +31,42 @@ __device__ __forceinline__ uint32_t kp_node_of(const uint64_t* __restrict__ off,
   return lo;
 }
 
+// ---- node text packed like the reads (2 bits per base, MSB first in 64-bit words): a comparison of a read's tail with a node's text
+// is then XORs of 32 bases at a time.  (Until round 6 kp_agree and the classification compared byte by byte -- a hundred dependent
+// global byte loads per comparison, two depth-first runs per read: kp_search_all lasted 2.7 - 3.9 ms per partition at bench.py
+// --config 2p, a kernel of a few thousand busy lanes that ends with its slowest thread.)
+__global__ void kp_pack_kernel(const uint8_t* __restrict__ bases, uint64_t total, uint64_t* __restrict__ pk, uint64_t n_words) {
+  const uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (wi >= n_words) return;
+  uint64_t x = 0;
+  for (int q = 0; q < 32; q++) {
+    const uint64_t p = wi * 32 + (uint64_t)q;
+    const int c = p < total ? kp_code(bases[p]) : 0;
+    x = (x << 2) | (uint64_t)(c < 0 ? 0 : c);                      // (a base outside ACGT is reported by kp_insert: the call fails)
+  }
+  pk[wi] = x;
+}
+// the 32 bases from position p on, MSB first (pk is padded with two words)
+__device__ __forceinline__ uint64_t kp_get32(const uint64_t* __restrict__ pk, uint64_t p) {
+  const uint64_t wi = p >> 5;
+  const uint32_t sh = (uint32_t)(p & 31) * 2;
+  const uint64_t a = pk[wi];
+  return sh ? (a << sh) | (pk[wi + 1] >> (64 - sh)) : a;
+}
+// read[so .. so + n) == text[p .. p + n)?  (w: the read's words, padded by the read set's layout to whole words)
+__device__ __forceinline__ bool kp_same(const uint64_t* __restrict__ w, uint32_t so, const uint64_t* __restrict__ pk, uint64_t p, uint32_t n) {
+  for (uint32_t q = 0; q < n; q += 32) {
+    const uint32_t m = min(32u, n - q);
+    const uint32_t ro = so + q;
+    const uint32_t wi = ro >> 5, sh = (ro & 31) * 2;
+    uint64_t a = w[wi] << sh;
+    if (sh && (ro & 31) + m > 32) a |= w[wi + 1] >> (64 - sh);      // (the second word only when the window reaches into it: no read past the read's words)
+    const uint64_t x = (a ^ kp_get32(pk, p + q)) >> (64 - 2 * m);
+    if (x) return false;
+  }
+  return true;
+}
+
 constexpr uint64_t KP_EMPTY = ~0ULL;                             // (a K-mer of K <= 31 bases is < 2^62)
 __device__ __forceinline__ uint64_t kp_mix(uint64_t x) {
   x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
@@ -146,13 +182,14 @@ __global__ void kp_classify(RView v, int K, const unsigned long long* __restrict
 // search runs deeper than KP_DEPTH nodes or finds no room keeps state 3 and is searched on the host as before.
 #define KP_DEPTH 12
 #define KP_HOPS 30
-struct KpGraph { const uint8_t* bases; const uint64_t* off; const uint32_t* eoff; const uint32_t* edst; const uint32_t* eov; };
+struct KpGraph { const uint8_t* bases; const uint64_t* off; const uint32_t* eoff; const uint32_t* edst; const uint32_t* eov; const uint64_t* pk; };
 
 __device__ __forceinline__ bool kp_agree(const uint64_t* __restrict__ w, uint32_t L, uint32_t so, const KpGraph& G, uint32_t node, uint32_t i) {
   // compare(seq, so, bases[node], i): the common length of the two tails
   const uint64_t nb = G.off[node + 1] - G.off[node];
   if ((uint64_t)i > nb) return false;
   const uint32_t n = (uint32_t)min((uint64_t)(L - so), nb - i);
+  if (G.pk) return kp_same(w, so, G.pk, G.off[node] + i, n);
   const uint8_t* b = G.bases + G.off[node] + i;
   for (uint32_t q = 0; q < n; q++) {
     const uint32_t p = so + q;
@@ -246,6 +283,8 @@ __device__ int kp_read_paths(const uint64_t* __restrict__ w, uint32_t L, const K
     const uint64_t left = G.off[nd + 1] - p;
     const uint32_t n = (uint32_t)min((uint64_t)L, left);
     bool same = true;
+    if (G.pk) same = n <= (uint32_t)X.K || kp_same(w, (uint32_t)X.K, G.pk, p + (uint64_t)X.K, n - (uint32_t)X.K);
+    else
     for (uint32_t i = X.K; i < n && same; i++) {
       const uint32_t rb = (uint32_t)((w[i >> 5] >> (62 - 2 * (i & 31))) & 3ULL);
       same = kp_code(bases[p + i]) == (int)rb;
@@ -395,7 +434,7 @@ static int kp_scan_impl(shn_ctx* ctx, const shn_reads* reads, int K, const uint8
     TRYK(hipMemsetAsync(d_paths, 0, (paths_cap + 1) * 4, s));             // (a reader walks the records by their lengths and stops at a length of 0)
     TRYK(hipMemcpyAsync(d_eoff, edge_off, (n_nodes + 1) * 4, hipMemcpyHostToDevice, s));
     if (ne) { TRYK(hipMemcpyAsync(d_edst, edge_dst, ne * 4, hipMemcpyHostToDevice, s)); TRYK(hipMemcpyAsync(d_eov, edge_ov, ne * 4, hipMemcpyHostToDevice, s)); }
-    KpGraph G{d_bases, d_off, d_eoff, d_edst, d_eov};
+    KpGraph G{d_bases, d_off, d_eoff, d_edst, d_eov, nullptr};
     hipLaunchKernelGGL(kp_search, dim3((uint32_t)cdiv(nr, 64)), dim3(64), 0, s, v, G, d_state, (const int32_t*)d_node, (const uint32_t*)d_ofs, d_paths, paths_cap,
                        d_cnt2 + 0);
     TRYK(hipGetLastError());
@@ -462,7 +501,11 @@ int shn_known_paths_dev(shn_ctx* ctx, const shn_reads* reads, int K, const uint8
   uint64_t T = 1024;
   while (T < 2 * total) T <<= 1;
   const uint64_t ne = edge_off[n_nodes];
-  const uint64_t paths_cap = std::max<uint64_t>(1u << 16, nr / 2 + 4096), rec_cap = paths_cap / 3 + 1, left_cap = std::max<uint64_t>(1u << 16, nr / 8);
+  // room for the records [read, length, nodes ...] of the searched reads.  (Until round 6 it was nr / 2 words: at BASELINE configs[2] 4 % of
+  // the reads run past their first node and a record is ~7 words; in the partitions of bench.py --config 2p -- short repeat nodes, 8 % of
+  // the reads run on -- the records of 440 k reads need 230 k words, the room was 224 k, and every read behind the overflow went to the
+  // host's recursive search: 16,000 reads, 31 ms per partition, 12 of the graph stage's 36 thread-seconds per step.)
+  const uint64_t paths_cap = std::max<uint64_t>(1u << 18, 2 * nr + 4096), rec_cap = paths_cap / 3 + 1, left_cap = std::max<uint64_t>(1u << 16, nr / 8);
   shn_kp* kp = new shn_kp();
   kp->ctx = ctx; kp->n_reads = nr; kp->n_nodes = n_nodes;
   uint8_t *d_bases = nullptr, *d_state = nullptr;
@@ -502,7 +545,12 @@ int shn_known_paths_dev(shn_ctx* ctx, const shn_reads* reads, int K, const uint8
   RView v{reads->d_words, reads->d_woff, reads->d_len, nr, reads->fixed_len, reads->wpr};
   hipLaunchKernelGGL(kp_classify, dim3((uint32_t)cdiv(nr, 256)), dim3(256), 0, s, v, K, d_hkeys, T - 1, d_goff, d_occ, d_bases, d_off, (uint32_t)n_nodes,
                      d_state, d_node, d_ofs, kp->d_first, kp->d_last, d_slow, d_cnt2 + 4);
-  KpGraph G{d_bases, d_off, kp->d_eoff, kp->d_edst, d_eov};
+  uint64_t* d_pk = nullptr;
+  const uint64_t pk_words = (total + 31) / 32;
+  TRYK(bufs.get(&d_pk, (pk_words + 2) * 8));
+  TRYK(hipMemsetAsync(d_pk + pk_words, 0, 16, s));
+  hipLaunchKernelGGL(kp_pack_kernel, dim3((uint32_t)cdiv(pk_words, 256)), dim3(256), 0, s, (const uint8_t*)d_bases, total, d_pk, pk_words);
+  KpGraph G{d_bases, d_off, kp->d_eoff, kp->d_edst, d_eov, (getenv("SHN_KP_PACKED") && getenv("SHN_KP_PACKED")[0] == '0') ? (const uint64_t*)nullptr : (const uint64_t*)d_pk};
   KpIndex X{d_hkeys, T - 1, d_goff, d_occ, (uint32_t)n_nodes, K};
   // (kp_insert's count of bad nodes sits in d_cnt2[1]; the search keeps its own counters in [0], [2], [3])
   hipLaunchKernelGGL(kp_search_all, dim3((uint32_t)std::min<uint64_t>(cdiv(nr, 64), 16384)), dim3(64), 0, s, v, G, X, d_state, (const int32_t*)d_node, (const uint32_t*)d_ofs, d_paths, paths_cap,
