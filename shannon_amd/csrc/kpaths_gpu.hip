@@ -182,6 +182,7 @@ __global__ void kp_classify(RView v, int K, const unsigned long long* __restrict
 // search runs deeper than KP_DEPTH nodes or finds no room keeps state 3 and is searched on the host as before.
 #define KP_DEPTH 12
 #define KP_HOPS 30
+#define KP_DEEP (KP_HOPS + 1)  // levels of the LDS stack of kp_search_all: no search is cut short (the short nodes bridging leaves around repeats put a 100-base read on more than 12 of them)
 struct KpGraph { const uint8_t* bases; const uint64_t* off; const uint32_t* eoff; const uint32_t* edst; const uint32_t* eov; const uint64_t* pk; };
 
 __device__ __forceinline__ bool kp_agree(const uint64_t* __restrict__ w, uint32_t L, uint32_t so, const KpGraph& G, uint32_t node, uint32_t i) {
@@ -200,42 +201,60 @@ __device__ __forceinline__ bool kp_agree(const uint64_t* __restrict__ w, uint32_
 }
 
 // one depth-first run; out == NULL: only counts.  Returns the words of all records, or -1 when the stack is too shallow.
-__device__ int kp_dfs(const uint64_t* __restrict__ w, uint32_t L, const KpGraph& G, uint32_t r, uint32_t node0, uint32_t i0, int32_t* __restrict__ out,
-                      int32_t* last_end = nullptr) {
-  uint32_t st_node[KP_DEPTH], st_so[KP_DEPTH], st_e[KP_DEPTH];
+// The stack: four words per level -- node, offset into the read, next edge, offset into the node -- either private arrays of KP_DEPTH
+// levels (stk == NULL: kp_search) or `max_depth` levels in LDS, [word][level][lane] (kp_search_all: deep enough for every search, KP_HOPS
+// + 1 levels; as private arrays that depth went through scratch memory -- 11 s of device time per step of bench.py --config 2p against 2).
+template <bool LDS_STACK>
+__device__ int kp_dfs_t(const uint64_t* __restrict__ w, uint32_t L, const KpGraph& G, uint32_t r, uint32_t node0, uint32_t i0, int32_t* __restrict__ out,
+                        int32_t* last_end, uint32_t* stk, int max_depth, uint32_t stride) {
+  uint32_t p_node[LDS_STACK ? 1 : KP_DEPTH], p_so[LDS_STACK ? 1 : KP_DEPTH], p_e[LDS_STACK ? 1 : KP_DEPTH], p_i[LDS_STACK ? 1 : KP_DEPTH];
+#define ST_NODE(d) (LDS_STACK ? stk[(uint32_t)(0 * max_depth + (d)) * stride] : p_node[d])
+#define ST_SO(d) (LDS_STACK ? stk[(uint32_t)(1 * max_depth + (d)) * stride] : p_so[d])
+#define ST_E(d) (LDS_STACK ? stk[(uint32_t)(2 * max_depth + (d)) * stride] : p_e[d])
+#define ST_I(d) (LDS_STACK ? stk[(uint32_t)(3 * max_depth + (d)) * stride] : p_i[d])
+  if (!LDS_STACK) max_depth = KP_DEPTH;
   int depth = 0, words = 0;
-  st_node[0] = node0; st_so[0] = 0; st_e[0] = 0xFFFFFFFFu;           // e = 0xFFFFFFFF: the node has just been entered
-  uint32_t st_i[KP_DEPTH];                                             // offset into the node at which the read continues
-  st_i[0] = i0;
+  ST_NODE(0) = node0; ST_SO(0) = 0; ST_E(0) = 0xFFFFFFFFu;           // e = 0xFFFFFFFF: the node has just been entered
+  ST_I(0) = i0;                                                       // offset into the node at which the read continues
   while (depth >= 0) {
-    const uint32_t node = st_node[depth];
-    const uint32_t nl = (uint32_t)(G.off[node + 1] - G.off[node]) - st_i[depth];
-    if (st_e[depth] == 0xFFFFFFFFu) {
+    const uint32_t node = ST_NODE(depth);
+    const uint32_t nl = (uint32_t)(G.off[node + 1] - G.off[node]) - ST_I(depth);
+    if (ST_E(depth) == 0xFFFFFFFFu) {
       const int hops = KP_HOPS - depth;
-      if (hops <= 0 || L - st_so[depth] <= nl) {                       // the read ends in this node (or the hop limit): a path
-        if (out) { out[words] = (int32_t)r; out[words + 1] = depth + 1; for (int d = 0; d <= depth; d++) out[words + 2 + d] = (int32_t)st_node[d]; }
+      if (hops <= 0 || L - ST_SO(depth) <= nl) {                       // the read ends in this node (or the hop limit): a path
+        if (out) { out[words] = (int32_t)r; out[words + 1] = depth + 1; for (int d = 0; d <= depth; d++) out[words + 2 + d] = (int32_t)ST_NODE(d); }
         if (last_end) *last_end = (int32_t)node;
         words += depth + 3;
         depth--;
         continue;
       }
-      st_e[depth] = G.eoff[node];
+      ST_E(depth) = G.eoff[node];
     }
-    const uint32_t so2 = st_so[depth] + nl;
+    const uint32_t so2 = ST_SO(depth) + nl;
     bool went = false;
-    while (st_e[depth] < G.eoff[node + 1]) {
-      const uint32_t e = st_e[depth]++;
+    while (ST_E(depth) < G.eoff[node + 1]) {
+      const uint32_t e = ST_E(depth);
+      ST_E(depth) = e + 1;
       const uint32_t dst = G.edst[e], ov = G.eov[e];
       if (!kp_agree(w, L, so2, G, dst, ov)) continue;
-      if (depth + 1 >= KP_DEPTH) return -1;
+      if (depth + 1 >= max_depth) return -1;
       depth++;
-      st_node[depth] = dst; st_so[depth] = so2; st_i[depth] = ov; st_e[depth] = 0xFFFFFFFFu;
+      ST_NODE(depth) = dst; ST_SO(depth) = so2; ST_I(depth) = ov; ST_E(depth) = 0xFFFFFFFFu;
       went = true;
       break;
     }
     if (!went) depth--;
   }
   return words;
+#undef ST_NODE
+#undef ST_SO
+#undef ST_E
+#undef ST_I
+}
+__device__ __forceinline__ int kp_dfs(const uint64_t* __restrict__ w, uint32_t L, const KpGraph& G, uint32_t r, uint32_t node0, uint32_t i0, int32_t* __restrict__ out,
+                                      int32_t* last_end = nullptr, uint32_t* stk = nullptr, int max_depth = 0, uint32_t stride = 0) {
+  return stk ? kp_dfs_t<true>(w, L, G, r, node0, i0, out, last_end, stk, max_depth, stride)
+             : kp_dfs_t<false>(w, L, G, r, node0, i0, out, last_end, nullptr, 0, 0);
 }
 
 __global__ void kp_search(RView v, KpGraph G, uint8_t* __restrict__ state, const int32_t* __restrict__ node_out, const uint32_t* __restrict__ off_out,
@@ -262,11 +281,12 @@ struct KpIndex { const unsigned long long* hkeys; uint64_t mask; const uint64_t*
 // their records (-1: a search ran too deep); first / last = the ends of the read's LAST path in that order, or the node the read lies
 // inside at its last such occurrence (mbgraph.py:1379-1384 sets Read.nodes again with every path)
 __device__ int kp_read_paths(const uint64_t* __restrict__ w, uint32_t L, const KpGraph& G, const KpIndex& X, uint32_t r, uint32_t st, uint32_t node0,
-                             uint32_t off0, const uint8_t* __restrict__ bases, int32_t* __restrict__ out, int32_t& first, int32_t& last) {
+                             uint32_t off0, const uint8_t* __restrict__ bases, int32_t* __restrict__ out, int32_t& first, int32_t& last,
+                             uint32_t* stk = nullptr, int max_depth = 0, uint32_t stride = 0) {
   first = -1; last = -1;
   if (st == 3) {
     int32_t le = -1;
-    const int words = kp_dfs(w, L, G, r, node0, off0, out, &le);
+    const int words = kp_dfs(w, L, G, r, node0, off0, out, &le, stk, max_depth, stride);
     if (words > 0) { first = (int32_t)node0; last = le; }
     return words;
   }
@@ -292,7 +312,7 @@ __device__ int kp_read_paths(const uint64_t* __restrict__ w, uint32_t L, const K
     if (!same) continue;
     if ((uint64_t)L <= left) { first = (int32_t)nd; last = (int32_t)nd; continue; }
     int32_t le = -1;
-    const int wds = kp_dfs(w, L, G, r, nd, (uint32_t)(p - G.off[nd]), out ? out + words : nullptr, &le);
+    const int wds = kp_dfs(w, L, G, r, nd, (uint32_t)(p - G.off[nd]), out ? out + words : nullptr, &le, stk, max_depth, stride);
     if (wds < 0) return -1;
     if (wds > 0) { first = (int32_t)nd; last = le; }
     words += wds;
@@ -307,6 +327,8 @@ __global__ void kp_search_all(RView v, KpGraph G, KpIndex X, uint8_t* __restrict
                               uint64_t rec_cap, KpSlow* __restrict__ left, uint64_t left_cap, const uint32_t* __restrict__ slow_list,
                               const unsigned long long* __restrict__ slow_count) {
   const uint64_t n_slow = *slow_count;
+  __shared__ uint32_t kp_stack[4 * KP_DEEP * 64];                    // the depth-first stacks of the block's 64 lanes (blockDim.x == 64)
+  uint32_t* const stk = kp_stack + threadIdx.x;
   for (uint64_t it = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; it < n_slow; it += (uint64_t)gridDim.x * blockDim.x) {
   const uint64_t r = slow_list[it];
   const uint32_t st = state[r];
@@ -315,14 +337,14 @@ __global__ void kp_search_all(RView v, KpGraph G, KpIndex X, uint8_t* __restrict
   const uint64_t* w = v.words + (v.woff ? v.woff[r] : r * v.wpr);
   const uint32_t node0 = (uint32_t)node_out[r], off0 = off_out[r];
   int32_t f, l;
-  const int need = kp_read_paths(w, L, G, X, (uint32_t)r, st, node0, off0, G.bases, nullptr, f, l);
+  const int need = kp_read_paths(w, L, G, X, (uint32_t)r, st, node0, off0, G.bases, nullptr, f, l, stk, KP_DEEP, 64);
   bool done = need == 0;
   if (need > 0) {
     const unsigned long long at = atomicAdd(&counters[0], (unsigned long long)need);
     if (at + (unsigned long long)need <= cap) {
       const unsigned long long q = atomicAdd(&counters[2], 1ULL);
       if (q < rec_cap) {
-        kp_read_paths(w, L, G, X, (uint32_t)r, st, node0, off0, G.bases, paths + at, f, l);
+        kp_read_paths(w, L, G, X, (uint32_t)r, st, node0, off0, G.bases, paths + at, f, l, stk, KP_DEEP, 64);
         rec_cnt[2 * q] = (uint32_t)r; rec_cnt[2 * q + 1] = cnt[r];
         done = true;
       }

@@ -1370,6 +1370,7 @@ struct Graph {
 }  // namespace
 
 extern "C" void shn_graph_destroy(shn_graph* g) { delete g; }
+int shn_graph_partitions_running() { return g_partitions_running.load(); }      // (sflow_host.hip: how many cores a sparse-flow call beside the graph stage may take)
 
 // rows: n_rows k1-mers of K+1 bytes each (file order of component{c}k1mers_allowed.dict); reads: ASCII,
 // r_off[n_reads+1]; paired: second mate file r2/r2_off with the same count.  Read.L = length of the first read.

@@ -33,7 +33,7 @@ extern "C" int shn_find_reps(const uint8_t* names, const uint64_t* name_off, con
 static int find_reps_core(const uint8_t* const* nptr, const uint64_t* nlen, const uint8_t* const* sptr, const uint64_t* slen, uint64_t n, int ds, int r,
                           uint8_t* keep_out, PostDev* dev, const uint64_t* goff) {
   if (r < 1 || r > 32) return shn_fail(SHN_ERR_ARG, "shn_find_reps: r must be in [1,32]");
-  const bool dbgf = getenv("SHN_DEBUG") != nullptr;
+  const bool dbgf = getenv("SHN_DEBUG") != nullptr || getenv("SHN_POST_LAPS") != nullptr;
   auto nowf = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
   const double tf0 = nowf();
   StringInterner ids(n + 16);
@@ -84,17 +84,28 @@ static int find_reps_core(const uint8_t* const* nptr, const uint64_t* nlen, cons
     while (qset[sl] != ~0ULL) { if (qset[sl] == key) return true; sl = (sl + 1) & (qcap - 1); }
     return false;
   };
-  for (size_t id = 0; id < rec_of.size(); id++) {
-    const uint64_t i = (uint64_t)rec_of[id];
-    const uint8_t* s = sptr[i];
-    const uint64_t L = slen[i];
-    if (L < (uint64_t)r) continue;
-    for (int flip = 0; flip < (ds ? 2 : 1); flip++) {
-      uint64_t kf, kl;
-      key_of(s, L, 0, flip == 1, kf);
-      key_of(s, L, L - r, flip == 1, kl);
-      q_add(kf); q_add(kl);
-    }
+  // the first / last r-mer of every record, plain and reverse-complemented: computed on the host threads (and kept for the decisions
+  // below), entered into the set in record order
+  const size_t n_ids = rec_of.size();
+  const int n_flip = ds ? 2 : 1;
+  std::vector<uint64_t> qkeys(n_ids * 4, 0);                      // [id][flip][first, last]
+  const unsigned nthr_q = n_ids < 8192 ? 1 : std::max(1u, std::min(16u, (unsigned)shn_host_cpus()));
+  {
+    auto work = [&](size_t lo, size_t hi) {
+      for (size_t id = lo; id < hi; id++) {
+        const uint64_t i = (uint64_t)rec_of[id];
+        const uint8_t* s = sptr[i];
+        const uint64_t L = slen[i];
+        if (L < (uint64_t)r) continue;
+        for (int flip = 0; flip < n_flip; flip++) { key_of(s, L, 0, flip == 1, qkeys[id * 4 + flip * 2]); key_of(s, L, L - r, flip == 1, qkeys[id * 4 + flip * 2 + 1]); }
+      }
+    };
+    if (nthr_q <= 1) work(0, n_ids);
+    else { std::vector<std::thread> th; for (unsigned t = 0; t < nthr_q; t++) th.emplace_back(work, n_ids * t / nthr_q, n_ids * (t + 1) / nthr_q); for (auto& x : th) x.join(); }
+  }
+  for (size_t id = 0; id < n_ids; id++) {
+    if (slen[(uint64_t)rec_of[id]] < (uint64_t)r) continue;
+    for (int flip = 0; flip < n_flip; flip++) { q_add(qkeys[id * 4 + flip * 2]); q_add(qkeys[id * 4 + flip * 2 + 1]); }
   }
   const double tf2 = nowf();
   struct Occ { uint64_t key; int32_t id, pos; };
@@ -149,17 +160,16 @@ static int find_reps_core(const uint8_t* const* nptr, const uint64_t* nlen, cons
   for (auto& v : found) for (const Occ& o : v) index.add(o.key, o.id, o.pos);
   memset(keep_out, 0, n);
   const double tf4 = nowf();
+  // (a record's decision reads the index, the names and the lengths -- nothing another decision writes: the records on the host threads)
+  auto decide_range = [&](size_t id_lo, size_t id_hi) {
   std::vector<std::pair<int32_t, std::pair<int64_t, int64_t>>> pos;    // (other name id, (first pos, last pos)) in first-seen order
-  for (size_t id = 0; id < rec_of.size(); id++) {
+  for (size_t id = id_lo; id < id_hi; id++) {
     uint64_t i = (uint64_t)rec_of[id];
-    const uint8_t* s = sptr[i];
     uint64_t L = slen[i];
     bool drop = false;
     for (int flip = 0; flip < (ds ? 2 : 1) && !drop; flip++) {
       if (L < (uint64_t)r) continue;
-      uint64_t kf, kl;
-      key_of(s, L, 0, flip == 1, kf);
-      key_of(s, L, L - r, flip == 1, kl);
+      const uint64_t kf = qkeys[id * 4 + flip * 2], kl = qkeys[id * 4 + flip * 2 + 1];
       int32_t vf = index.find(kf), vl = index.find(kl);
       if (vf == -1 || vl == -1) continue;
       pos.clear();
@@ -200,6 +210,9 @@ static int find_reps_core(const uint8_t* const* nptr, const uint64_t* nlen, cons
     }
     if (!drop) keep_out[i] = 1;
   }
+  };
+  if (nthr_q <= 1) decide_range(0, n_ids);
+  else { std::vector<std::thread> th; for (unsigned t = 0; t < nthr_q; t++) th.emplace_back(decide_range, n_ids * t / nthr_q, n_ids * (t + 1) / nthr_q); for (auto& x : th) x.join(); }
   if (dbgf) fprintf(stderr, "[find_reps] names+check %.3f, query set %.3f, scan %.3f, index %.3f (%zu occurrences), decide %.3f s\n", tf1 - tf0, tf2 - tf1,
                     tf3 - tf2, tf4 - tf3, n_occ, nowf() - tf4);
   return SHN_OK;
@@ -513,7 +526,7 @@ static int post_finalize_lines(std::vector<SV>& lines, std::vector<uint64_t>& li
       rec_li.push_back((uint32_t)li);
     }
   }
-  const bool dbgp = getenv("SHN_DEBUG") != nullptr;
+  const bool dbgp = getenv("SHN_DEBUG") != nullptr || getenv("SHN_POST_LAPS") != nullptr;
   auto nowp = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; };
   const double tp0 = nowp();
   // ---- length sort: a dict keyed by header line (the last sequence of a repeated header line wins), by (len(seq line), header line)

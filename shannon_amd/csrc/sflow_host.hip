@@ -417,6 +417,7 @@ extern "C" int shn_sflow_text(const shn_sflow* s, uint32_t g, uint8_t* out) {
 // Text g = the reconstructed FASTA of partition g: the records of its components in order (component c uses the LP problem
 // ids (c << 20) + call number), then its single nodes (single_nodes_to_fasta, algorithm_SF.py:74-88).
 extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uint32_t n_graphs, const char* const* snames, uint64_t seed, shn_sflow** out);
+int shn_graph_partitions_running();                  // mbgraph_host.hip
 static thread_local bool t_sflow_beside = false;     // this thread is one of several inside shn_sparse_flow: no helper threads of its own for small inputs
 // One of several calls made by host threads at the same time (a partition's components right behind its graph stage, while other
 // partitions are still at theirs): the LP batches run on the calling thread's own stream and workspaces (shn_thread_ctx).  The
@@ -498,8 +499,11 @@ extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uin
   // (a call beside other partitions' graph stages keeps to its own thread unless it is large: the machine is busy)
   size_t n_nodes_all = 0;
   for (uint32_t g = 0; g < n_graphs; g++) n_nodes_all += graphs[g]->n_off.size();
-  const bool small_job = t_sflow_beside ? (comps.size() < 4096 && n_nodes_all < (1u << 18)) : (comps.size() < 256 && n_nodes_all < (1u << 16));
-  const unsigned nt = small_job ? 1 : std::max(1u, std::min(32u, (unsigned)shn_host_cpus()));
+  // (beside the graph stage the cores are taken: a few threads for a wave of partitions, the calling thread alone for one partition)
+  const bool small_job = t_sflow_beside ? (comps.size() < 1024 && n_nodes_all < (1u << 15)) : (comps.size() < 256 && n_nodes_all < (1u << 16));
+  const unsigned cpus = (unsigned)std::max(1, shn_host_cpus());
+  const unsigned busy = (unsigned)std::max(0, shn_graph_partitions_running());      // partitions at their graphs right now: a core each
+  const unsigned nt = small_job ? 1 : t_sflow_beside ? std::max(2u, std::min(32u, cpus > busy ? cpus - busy : 0u)) : std::max(1u, std::min(32u, cpus));
   SflowPool pool(nt > 1 ? nt - 1 : 0);
   // chunks: a few per thread, so that a handful of large components (the repeat-linked families of --config 2p: 610 components of
   // ~3,000 nodes) do not end up on one thread behind 63 others

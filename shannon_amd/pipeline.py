@@ -199,6 +199,14 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
         big = set(sorted((nm for nm in names if n_routed[nm] >= max(1, big_cut)), key=lambda nm: -n_routed[nm])[:4]) if sflow_beside else set()
         small_lock, small_done, small_recs = threading.Lock(), [0], {}
         n_small = len(names) - len(big)
+        # ... in WAVES: the thread that finishes a graph takes every small partition that is ready and in no wave yet, once there are
+        # `wave_min` of them (and fewer than three waves are running) or the last graph is done.  With ONE call behind the last graph a
+        # hundred partitions of one size (bench.py --config 2p: 401 parts of two gpmetis components) left all their sparse flow --
+        # 890 dependent LP rounds, 1.3 s -- to be done after the graph stage with fifteen threads idle; a wave's rounds wait for the
+        # device, not for a core, so they run beside the other threads' graphs.  (A component's answer does not depend on its call:
+        # its random costs are numbered inside its own graph.)
+        wave_min = max(16, int(os.environ.get("SHN_SFLOW_WAVE", 0)) or (n_small + 5) // 6)
+        ready, waves_running = [], [0]
         # ... and the merge takes every text as a piece the moment it exists (post.PostStream: lines, upload, fingerprints beside the
         # graph stage; the order-dependent rules at the end).  Piece 0 = the single contigs, piece 1 + i = partition i.
         pstream, ps_failed, post_futs = None, [], []
@@ -232,12 +240,21 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
                 else:
                     with small_lock:
                         small_recs[name] = rec
+                        ready.append(name)
                         small_done[0] += 1
                         last = small_done[0] == n_small
-                    if last:
-                        order_s = [nm for nm in names if nm in small_recs]
-                        txts = mbgraph_native.sparse_flow_native(ctx_b, [small_recs[nm].graph for nm in order_s], ["%s_%s" % (sample, nm) for nm in order_s],
-                                                                 seed, raw=True, threaded=True)
+                        wave = []
+                        if last or (len(ready) >= wave_min and waves_running[0] < 3 and n_small - small_done[0] >= wave_min // 2):
+                            wave, ready[:] = list(ready), []
+                            waves_running[0] += 1
+                    if wave:
+                        try:
+                            order_s = [nm for nm in names if nm in set(wave)]
+                            txts = mbgraph_native.sparse_flow_native(ctx_b, [small_recs[nm].graph for nm in order_s], ["%s_%s" % (sample, nm) for nm in order_s],
+                                                                     seed, raw=True, threaded=True)
+                        finally:
+                            with small_lock:
+                                waves_running[0] -= 1
                         for nm, txt in zip(order_s, txts):
                             small_recs[nm].fasta_raw = txt
                         if pstream is not None:               # (their pieces on whatever threads are free)

@@ -79,6 +79,20 @@ def test_native_merge_equals_the_python_form(seed, ds):
     assert post.finalize_native([], ds) == {} and post.finalize_native([">a\n", "ACGT\n"], ds) == {}
 
 
+def test_native_merge_on_the_host_threads_equals_the_python_form():
+    """above 8,192 distinct names find_reps computes its query 24-mers and makes its per-record decisions on the host threads (round
+    6: a record's decision reads only the index): 24,000 records with containments, reverse complements and repeated names through
+    shn_post_finalize against the sequential Python forms"""
+    from shannon_amd import post
+    lines = []
+    for part in range(12):
+        ls = _random_fasta(100 + part, n=2000)
+        lines += [(l.replace(">s_c", ">p%d_c" % part, 1) if l[0] == ">" else l) for l in ls]
+    want = post.find_reps(post.length_sort(post.process_concatenated(lines, True)), True)
+    got = post.finalize_native(lines, True)
+    assert len(want) > 8192 and got == want and list(got) == list(want)
+
+
 def test_allocator_setup_can_be_switched_off():
     """the allocator settings (mallopt) are opt-in: importing the package / loading the library leaves glibc's defaults alone
     (M_MMAP_THRESHOLD: a 4 MB block is mmapped, i.e. malloc_stats' mmap tally grows) unless SHN_MALLOC_TUNE=1 or an explicit
