@@ -794,7 +794,13 @@ def main():
                   # the super-k-mer counting path (csrc/count_sk.hip)
                   "count.sk_emit": "sk_scan_kernel", "count.sk_hist": "skr_hist_kernel + skr_scatter_kernel (level 1)", "count.sk_hist2": "skr_hist_kernel",
                   "count.sk_scatter2": "skr_scatter_kernel", "count.sk_buckets": "sk_buckets_sorted_kernel<.., 256, 1024, 0>",
-                  "count.sk_buckets2": "sk_buckets_sorted_kernel<.., 256, 2048, 0>"}
+                  "count.sk_buckets2": "sk_buckets_sorted_kernel<.., 256, 2048, 0>",
+                  # round 6: the contig stage, the read -> graph mapping and the LP trials -- their algorithmic bytes are declared by the
+                  # launch sites (TimerRegion::bytes, shn_timer_bytes: the byte model stands next to the launch in csrc/)
+                  "contig.sort": "cg_keys_kernel + sort_hist_kernel + sort_scatter_kernel (shn_sorted_windows)", "contig.hits": "cg_hits_kernel",
+                  "contig.cover": "cg_cover_kernel", "contig.compact": "cg_acc_compact_kernel", "graph.kp_search": "kp_search_all",
+                  "graph.kp_classify": "kp_classify", "graph.seed_scan": "seed_scan_reads_kernel", "graph.dd_insert": "dd_insert",
+                  "lp.trials": "lp_trials_coop_kernel", "extend.audit": "ext_audit_nodes_kernel + ext_audit_walks_kernel"}
         # records of the super-k-mer path: a read of W windows makes ~2 W / (w + 1) + 1 records of 16 bytes (w = k1 - m + 1 m-mers per window, m = 13)
         sk_w = k1 - max(13, 2 * k1 - 48) + 1
         rec_bytes = 16.0 * (2.0 * W / (sk_w + 1) + 1.0)
@@ -821,7 +827,14 @@ def main():
         dense_r = ext.get("dense_rounds") if ext.get("dense_rounds") is not None else (ext["iterations"] or 0)
         per_step_bytes["extend.mark"] = 16.0 * n_or * dense_r + (n_or / 16.0) * max(0, (ext["iterations"] or 0) - dense_r)
         per_step_bytes["extend.adjacency"] = (8 * 8.0 + 2 * 64.0 + 8.0) * distinct       # per k1-mer: 8 keys looked up, its two 64-byte records written, its own key
-        kt = {k: v for k, v in timers.items() if k in KERNEL}
+        # the always-on fixpoint audit: the claims streamed once (8 B per oriented k1-mer) + per claimed k1-mer its step's lines; priced on the stream alone
+        per_step_bytes["extend.audit"] = 8.0 * n_or
+        # the slots whose launch sites declare their bytes themselves
+        tb = ctx.timer_bytes()
+        for k_, b_ in tb.items():
+            if k_ in KERNEL and k_ not in per_step_bytes:
+                per_step_bytes[k_] = b_ / float(args.steps)
+        kt = {k: v for k, v in timers.items() if k in KERNEL and k in per_step_bytes}
         # the key array goes through one or two levels below level 1 (csrc/count.hip: at most 256 streams per level): the bytes of
         # the hist2 / scatter2 launches of a step are those of as many passes over the keys
         if "count.buckets" in timers and "count.scatter2" in timers:

@@ -55,6 +55,9 @@ int shn_ctx_fork(const shn_ctx* parent, shn_ctx** out);
  * returns the accumulated milliseconds and number of regions since the last reset. */
 int shn_timer_reset(shn_ctx* ctx);
 int shn_timer_ms(shn_ctx* ctx, int slot, double* ms, uint64_t* n_regions);
+/* the ALGORITHMIC bytes of the launches timed under `slot` since the last reset -- what those kernels have to read and write at the
+ * least, by the byte model written next to each launch (0: the slot's launch sites declare none and bench.py prices them itself) */
+int shn_timer_bytes(shn_ctx* ctx, int slot, uint64_t* bytes);
 const char* shn_timer_name(int slot);
 
 /* ---- reads: upload + 2-bit pack on device --------------------------------------------------
@@ -422,6 +425,16 @@ int shn_reads_dedup(shn_ctx* ctx, const shn_reads* a, const shn_reads* b, const 
  * lengths, multi-line FASTA and malformed records are refused (SHN_ERR_ARG, message "shn_reads_ingest: unsupported: ...").      */
 int shn_reads_ingest(shn_ctx* ctx, const uint8_t* text, uint64_t n_bytes, int format, uint8_t* codes_out, uint64_t codes_cap,
                      uint64_t* n_reads_out, uint32_t* read_len_out, shn_reads** out);
+/* A read file shared out by bytes (the N-rank CLI; the reference streams the file once, 10 M reads at a time:
+ * kmers_for_component.py:322-403): the records that START in bytes [lo, hi) of the text -- *first_out = the offset of the first one
+ * (n_bytes if none), *n_records_out their number.  Record starts are found as shn_reads_ingest's threaded scan finds them ('>' at a
+ * line start; '@' at a line start with a "+" line two lines on).  index_out (optional, index_cap entries of room): the offsets of
+ * every stride-th of those records (the 0th, stride-th, ...), *n_index_out of them -- a sparse index from which any record of the
+ * range is at most stride records away (shn_text_skip_records).  No device call.                                                    */
+int shn_text_records_in_range(const uint8_t* text, uint64_t n_bytes, uint64_t lo, uint64_t hi, int format, uint64_t* first_out,
+                              uint64_t* n_records_out, uint64_t stride, uint64_t* index_out, uint64_t index_cap, uint64_t* n_index_out);
+/* ... and the start of the k-th record after the record starting at byte `from` (n_bytes if the text has fewer).                   */
+int shn_text_skip_records(const uint8_t* text, uint64_t n_bytes, uint64_t from, uint64_t k, int format, uint64_t* offset_out);
 /* The same for reads of ANY lengths (the reference's Samples/SE_read.fasta: 48-51 bases; kmers_for_component.py:329-403 and
  * multibridging.py:22-98 take whatever the lines hold): codes_out receives the reads' codes one after the other (codes_cap bytes of
  * room; the text's size always suffices), offsets_out their n_reads + 1 offsets.  Bases outside ACGT are kept as code 4 (the packed

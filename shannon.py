@@ -103,7 +103,7 @@ def rank_main(out_dir, reads, K, partition_size, min_weight, min_length, double_
     import shannon_amd
     if os.environ.get("SHN_MALLOC_TUNE", "1") != "0":
         shannon_amd.malloc_tune()
-    from shannon_amd import device, distributed, kmers_for_component as kfc, _lib
+    from shannon_amd import device, distributed, exchange, kmers_for_component as kfc, _lib
     sample = os.path.basename(os.path.normpath(out_dir))
     temp = os.path.join(out_dir, "TEMP")
     log = None
@@ -126,9 +126,18 @@ def rank_main(out_dir, reads, K, partition_size, min_weight, min_length, double_
     T = {}
     t0 = time.time()
     paired = len(reads) == 2
-    # every rank reads the files and keeps its contiguous slice of the records (the N-rank job's read order is the files' order)
+    # every rank ingests ITS share of the files (by bytes; distributed.ingest_rank_slice) -- the records [n r / W, n (r + 1) / W) of the
+    # job, in the files' order; files that cannot be shared out that way (.gz, reads of several lengths, multi-line FASTA) are read
+    # whole on every rank as before
+    ing_stats = {}
+    sl = distributed.ingest_rank_slice(reads, rank, world, None, exchange.coll_device(torch.device("cuda", dev_index), None), stats=ing_stats)
     mats = []
-    for p in reads:
+    if sl is not None:
+        q1 = sl[0][0]
+        q2 = sl[0][1] if paired else None
+        n = sl[1]
+        lo, hi = rank * n // world, (rank + 1) * n // world
+    for p in (reads if sl is None else []):
         try:
             _d, r = device.Reads.ingest(None, p)                # (the host code matrix only: the rank uploads its own slice below)
             if isinstance(r, device.RaggedCodes):
@@ -146,14 +155,19 @@ def rank_main(out_dir, reads, K, partition_size, min_weight, min_length, double_
                 code[c] = j
             r = code[np.frombuffer("".join(seqs).encode(), dtype=np.uint8)].reshape(len(seqs), L) if seqs else np.zeros((0, 1), np.uint8)
         mats.append(r)
-    if paired and len(mats[0]) != len(mats[1]):
-        say("ERROR: --left and --right hold different numbers of reads")
-        return 2
-    n = len(mats[0])
-    lo, hi = rank * n // world, (rank + 1) * n // world
-    q1 = np.ascontiguousarray(mats[0][lo:hi])
-    q2 = np.ascontiguousarray(mats[1][lo:hi]) if paired else None
-    del mats
+    if sl is None:
+        if paired and len(mats[0]) != len(mats[1]):
+            say("ERROR: --left and --right hold different numbers of reads")
+            return 2
+        n = len(mats[0])
+        lo, hi = rank * n // world, (rank + 1) * n // world
+        q1 = np.ascontiguousarray(mats[0][lo:hi])
+        q2 = np.ascontiguousarray(mats[1][lo:hi]) if paired else None
+        del mats
+    T["ingest path"] = "byte share of the files" if sl is not None else "whole files on every rank"
+    if ing_stats:
+        T["ingest bytes scanned by this rank"] = ing_stats["bytes_scanned"]
+        T["ingest bytes of the files"] = ing_stats["file_bytes"]
     d1 = device.Reads.from_codes(ctx, q1)
     d2 = device.Reads.from_codes(ctx, q2) if paired else None
     T["ingest"] = time.time() - t0

@@ -19,6 +19,7 @@ SIGNATURES = {
     "shn_ctx_fork": (C.c_int, [vp, vpp]),
     "shn_timer_reset": (C.c_int, [vp]),
     "shn_timer_ms": (C.c_int, [vp, C.c_int, dblp, u64p]),
+    "shn_timer_bytes": (C.c_int, [vp, C.c_int, u64p]),
     "shn_timer_name": (C.c_char_p, [C.c_int]),
     "shn_reads_create": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint32, C.c_int, vpp]),
     "shn_reads_destroy": (None, [vp]),
@@ -107,6 +108,8 @@ SIGNATURES = {
     "shn_post_destroy": (None, [vp]),
     "shn_reads_ingest": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint64, vp, vp, vpp]),
     "shn_reads_ingest_ragged": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vp, C.c_uint64, vp, C.c_uint64, vp, vp, vp, vpp]),
+    "shn_text_records_in_range": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, u64p, u64p, C.c_uint64, vp, C.c_uint64, u64p]),
+    "shn_text_skip_records": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, u64p]),
     "shn_reads_dedup": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_int, vp, vp, vp, vp, vp]),
     "shn_mbgraph_run_resident": (C.c_int, [vp, vp, C.c_uint32, vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, vpp]),
     "shn_reads_gather": (C.c_int, [vp, vp, vp, vp, vp, C.c_uint64, vpp]),

@@ -22,7 +22,9 @@ int shn_fail(int code, const std::string& msg);
 enum {
   T_PACK = 0, T_HIST1, T_SCATTER1, T_HIST2, T_SCATTER2, T_COUNT, T_COMPACT, T_COUNT_TOTAL, T_LOOKUP,
   T_EXTEND, T_ROUTE, T_GRAPH, T_LP, T_EXT_PREP, T_EXT_SORT, T_EXT_WALK, T_SEEDS, T_EXT_WALK_THREAD, T_EXT_WALK_WAVE, T_EXT_MARK, T_EXT_EMIT, T_TABLE_BUILD, T_COUNT_DIRECT, T_CONTIG, T_GRAPH_GPU, T_EXT_ADJ,
-  T_SK_HIST, T_SK_EMIT, T_SK_HIST2, T_SK_SCATTER2, T_SK_BUCKETS, T_SK_BIG, T_EXT_WALK_FRESH, T_EXT_BEGIN, T_SK_BUCKETS2, T_N = 40
+  T_SK_HIST, T_SK_EMIT, T_SK_HIST2, T_SK_SCATTER2, T_SK_BUCKETS, T_SK_BIG, T_EXT_WALK_FRESH, T_EXT_BEGIN, T_SK_BUCKETS2,
+  // round 6: the kernels of the contig stage, of the read -> graph mapping and the LP trials, one launch per region (bench.py's kernel table)
+  T_CG_SORT, T_CG_HITS, T_CG_COVER, T_CG_COMPACT, T_KP_SEARCH, T_KP_CLASSIFY, T_SEED_SCAN, T_DD_INSERT, T_LP_TRIALS, T_EXT_AUDIT, T_N = 48
 };
 
 // grow-only device workspace slot (process-wide ones: g_shn_ws below; per-context ones: shn_ctx::cws)
@@ -55,6 +57,7 @@ struct shn_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[T_N];
   double ms[T_N];
   uint64_t regions[T_N];
+  uint64_t abytes[T_N];    // algorithmic bytes of the launches of a slot, said by the launch site (TimerRegion::bytes): shn_timer_bytes
   bool timing;
   bool owns_stream;        // shn_ctx_fork: the stream is destroyed with the context
   double sk_pool_ratio;    // super-k-mer counting: (key, count) pairs per window the buckets emitted last time on this context (0: none yet)
@@ -76,6 +79,9 @@ struct TimerRegion {
   TimerRegion(shn_ctx* ctx, int s);
   TimerRegion(shn_ctx* ctx, int s, hipStream_t stream);     // a region on another stream (one kernel launch)
   ~TimerRegion();
+  // the algorithmic bytes of this launch (what the kernel has to read and write at the least: the byte model stated next to the
+  // launch), summed per slot and read by bench.py's kernel table beside the slot's time
+  void bytes(uint64_t b) { if (c && c->timing) __atomic_fetch_add(&c->abytes[slot], b, __ATOMIC_RELAXED); }
 };
 
 struct TimingOff {

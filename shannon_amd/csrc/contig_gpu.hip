@@ -309,7 +309,10 @@ static int contig_stage_impl(shn_ctx* ctx, const uint8_t* bases, const uint8_t* 
   {
     ShnDevBufs tmp(s);
     uint64_t* keys; uint32_t* vals; uint64_t nv = 0;
-    int rc = shn_sorted_windows(ctx, tmp, d_bases, d_off, d_cid, nullptr, total, r, &keys, &vals, &nv);
+    int rc;
+    { TimerRegion ts(ctx, T_CG_SORT); rc = shn_sorted_windows(ctx, tmp, d_bases, d_off, d_cid, nullptr, total, r, &keys, &vals, &nv);
+      // per r-mer window of the candidates: its base read, (key 8 + value 4) written, then an LSD pass per 8 key bits that reads and writes the pair
+      ts.bytes(nv * (1 + 12 + (uint64_t)((2 * r + 7) / 8) * 24)); }
     if (rc) return rc;
     lap("r-mer sort (GPU)");
     uint8_t *d_acc, *d_hit; uint32_t *d_scid, *d_flag, *d_acand, *d_cov, *d_ovf; uint64_t *d_apos, *d_akey; int32_t* d_bestc;
@@ -345,7 +348,8 @@ static int contig_stage_impl(shn_ctx* ctx, const uint8_t* bases, const uint8_t* 
       if (nv) {
         hipLaunchKernelGGL(cg_accflag_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, d_scid, d_acc, nv, (uint32_t)lo, (uint32_t)hi, d_flag);
         if ((rc = shn_device_scan_u32(ctx, d_flag, nv, d_apos, &na))) return rc;
-        if (na) hipLaunchKernelGGL(cg_acc_compact_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, keys, d_scid, d_flag, vals, d_apos, nv, d_akey, d_acand, d_aval);
+        if (na) { TimerRegion tc(ctx, T_CG_COMPACT); tc.bytes(nv * 28 + na * 16);      // every window: key 8 + candidate 4 + flag 4 + value 4 + position 8 read; the accepted ones written (16)
+                  hipLaunchKernelGGL(cg_acc_compact_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, keys, d_scid, d_flag, vals, d_apos, nv, d_akey, d_acand, d_aval); }
       }
       HIP_TRY(hipMemsetAsync(d_aff + lo, 1, hi - lo, s));
       while (true) {
@@ -374,8 +378,9 @@ static int contig_stage_impl(shn_ctx* ctx, const uint8_t* bases, const uint8_t* 
           while (true) {                             // (the pair table grows until the round's pairs fit)
             HIP_TRY(hipMemsetAsync(d_tab, 0, sizeof(PairSlot) << lg_use, s));
             HIP_TRY(hipMemsetAsync(d_ovf, 0, 4, s));
-            hipLaunchKernelGGL(cg_hits_kernel, dim3(grid_for(na)), dim3(CG_BLK), 0, s, d_akey, d_acand, d_aval, na, d_off, (uint32_t)lo, d_acc, d_aff,
-                               d_tab, (1ULL << lg_use) - 1, d_ovf);
+            { TimerRegion th(ctx, T_CG_HITS); th.bytes(na * 16);                     // every accepted window: key 8 + candidate 4 + value 4 (the pair table: a few per cent of them)
+              hipLaunchKernelGGL(cg_hits_kernel, dim3(grid_for(na)), dim3(CG_BLK), 0, s, d_akey, d_acand, d_aval, na, d_off, (uint32_t)lo, d_acc, d_aff,
+                                 d_tab, (1ULL << lg_use) - 1, d_ovf); }
             uint32_t ovf = 0;
             HIP_TRY(hipMemcpyAsync(&ovf, d_ovf, 4, hipMemcpyDeviceToHost, s));
             HIP_TRY(hipStreamSynchronize(s));
@@ -387,7 +392,8 @@ static int contig_stage_impl(shn_ctx* ctx, const uint8_t* bases, const uint8_t* 
             HIP_TRY(tmp.get(&d_tab, sizeof(PairSlot) << lg_slots));
           }
           hipLaunchKernelGGL(cg_best_kernel, dim3(grid_for(1ULL << lg_use)), dim3(CG_BLK), 0, s, d_tab, 1ULL << lg_use, d_best);
-          hipLaunchKernelGGL(cg_cover_kernel, dim3(grid_for(na)), dim3(CG_BLK), 0, s, d_akey, d_acand, d_aval, na, (uint32_t)lo, d_best, d_aff, d_hit);
+          { TimerRegion tv(ctx, T_CG_COVER); tv.bytes(na * 17);                       // the same 16 bytes + the hit byte of the window's base
+            hipLaunchKernelGGL(cg_cover_kernel, dim3(grid_for(na)), dim3(CG_BLK), 0, s, d_akey, d_acand, d_aval, na, (uint32_t)lo, d_best, d_aff, d_hit); }
           hipLaunchKernelGGL(cg_covsum_kernel, dim3(grid_for(off[hi] - off[lo])), dim3(CG_BLK), 0, s, d_hit, d_cid, d_off, off[lo], off[hi], r, d_aff, d_cov);
         }
         hipLaunchKernelGGL(cg_decide_kernel, dim3((uint32_t)cdiv(hi - lo, CG_BLK)), dim3(CG_BLK), 0, s, d_best, d_cov, d_off, (uint32_t)lo, (uint32_t)hi, f,

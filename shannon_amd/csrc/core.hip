@@ -23,7 +23,9 @@ static const char* kTimerNames[T_N] = {
   "count.sk_hist", "count.sk_emit", "count.sk_hist2", "count.sk_scatter2", "count.sk_buckets", "count.sk_big",
   // round 5: one timer per template instance where the launches of a step differ by an order of magnitude -- the first (bulk) round of
   // a rank block apart from the re-run rounds (ext_walk_kernel<true> / <false>), the begin pass, the second table size of the buckets
-  "extend.walk_fresh", "extend.begin", "count.sk_buckets2"};
+  "extend.walk_fresh", "extend.begin", "count.sk_buckets2",
+  "contig.sort", "contig.hits", "contig.cover", "contig.compact", "graph.kp_search", "graph.kp_classify", "graph.seed_scan", "graph.dd_insert", "lp.trials",
+  "extend.audit"};
 extern "C" const char* shn_timer_name(int slot) {
   if (slot < 0 || slot >= T_N || !kTimerNames[slot]) return "";
   return kTimerNames[slot];
@@ -253,7 +255,7 @@ extern "C" int shn_ctx_create(int device, void* stream, shn_ctx** out) {
   c->count_direct_log2 = 0;
   c->sk_pool_ratio = 0;
   c->owns_stream = false;
-  for (int i = 0; i < T_N; i++) { c->ms[i] = 0; c->regions[i] = 0; }
+  for (int i = 0; i < T_N; i++) { c->ms[i] = 0; c->regions[i] = 0; c->abytes[i] = 0; }
   const char* rule = getenv("SHN_LP_RULE");
   c->lp_rule = (rule && !strcmp(rule, "vertex")) ? SHN_LP_RULE_VERTEX : SHN_LP_RULE_CENTER;
   for (auto& v : c->lp_stats) v = 0;
@@ -286,7 +288,10 @@ static void fold_into_parent(shn_ctx* f) {                      // (g_forks_mu h
   if (!p) return;
   std::lock_guard<std::mutex> lf(f->tmu);
   std::lock_guard<std::mutex> lp(p->tmu);
-  for (int i = 0; i < T_N; i++) { p->ms[i] += f->ms[i]; p->regions[i] += f->regions[i]; f->ms[i] = 0; f->regions[i] = 0; }
+  for (int i = 0; i < T_N; i++) {
+    p->ms[i] += f->ms[i]; p->regions[i] += f->regions[i]; f->ms[i] = 0; f->regions[i] = 0;
+    p->abytes[i] += __atomic_exchange_n(&f->abytes[i], 0, __ATOMIC_RELAXED);
+  }
 }
 void shn_lp_census_add(shn_ctx* c, const uint64_t* v8) {
   std::lock_guard<std::mutex> lk(g_forks_mu);
@@ -322,7 +327,7 @@ extern "C" int shn_ctx_fork(const shn_ctx* parent, shn_ctx** out) {
   c->device = parent->device; c->stream = st; c->timing = parent->timing; c->count_direct_log2 = 0; c->sk_pool_ratio = 0; c->owns_stream = true;
   c->parent = const_cast<shn_ctx*>(parent);
   { std::lock_guard<std::mutex> lk(g_forks_mu); g_forks.push_back(c); }
-  for (int i = 0; i < T_N; i++) { c->ms[i] = 0; c->regions[i] = 0; }
+  for (int i = 0; i < T_N; i++) { c->ms[i] = 0; c->regions[i] = 0; c->abytes[i] = 0; }
   c->lp_rule = parent->lp_rule;
   for (auto& v : c->lp_stats) v = 0;
   *out = c;
@@ -375,10 +380,18 @@ extern "C" int shn_timer_reset(shn_ctx* c) {
   if (!c) return shn_fail(SHN_ERR_ARG, "ctx is NULL");
   int rc = drain_timers(c);
   if (rc) return rc;
-  for (int i = 0; i < T_N; i++) { c->ms[i] = 0; c->regions[i] = 0; }
+  for (int i = 0; i < T_N; i++) { c->ms[i] = 0; c->regions[i] = 0; c->abytes[i] = 0; }
   return SHN_OK;
 }
 
+// the algorithmic bytes the launch sites of a slot have declared since the last reset (0 for the slots that declare none)
+extern "C" int shn_timer_bytes(shn_ctx* c, int slot, uint64_t* bytes) {
+  if (!c || slot < 0 || slot >= T_N || !bytes) return shn_fail(SHN_ERR_ARG, "shn_timer_bytes: bad argument");
+  int rc = drain_timers(c);
+  if (rc) return rc;
+  *bytes = c->abytes[slot];
+  return SHN_OK;
+}
 extern "C" int shn_timer_ms(shn_ctx* c, int slot, double* ms, uint64_t* n_regions) {
   if (!c || slot < 0 || slot >= T_N) return shn_fail(SHN_ERR_ARG, "shn_timer_ms: bad argument");
   int rc = drain_timers(c);

@@ -2446,7 +2446,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       if (limit >= ns) {
         // every block is settled: audit the claims (see ext_audit_nodes_kernel); a walk that is not at its fixpoint
         // re-runs with all blocks open.  Never seen to fire in testing except by fault injection (SHN_EXT_FAULT).
-        TimerRegion ta(ctx, T_EXT_MARK);
+        TimerRegion ta(ctx, T_EXT_AUDIT);
         TRYE(hipMemsetAsync(owned, 0, (ns + 1) * 4, s));
         TRYE(hipMemsetAsync(d_cnt + 48, 0, 16, s));
         hipLaunchKernelGGL(ext_audit_nodes_kernel, dim3(std::min<uint32_t>(g2n, 4096u)), dim3(256), 0, s, claim, 2 * n, rows_R(e->d_rec),

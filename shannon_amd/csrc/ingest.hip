@@ -89,6 +89,83 @@ template <class F> int walk_records(const uint8_t* t, uint64_t n, uint64_t b0, u
 
 }  // namespace
 
+// ---- a read file shared out by BYTES (the N-rank CLI, round 6): every rank looks at its own share of the text only.  Rank r counts
+// the records that start in bytes [B r / W, B (r + 1) / W) (shn_text_records_in_range: the same resynchronisation on the record
+// character as the threaded scan below uses for its ranges); the counts of all ranks give every share's first record number; the
+// records [n r / W, n (r + 1) / W) a rank is to hold start a few records into one of the shares (shn_text_skip_records) and that
+// stretch of text goes through shn_reads_ingest.  The reference streams the file once (kmers_for_component.py:322-403, 10 M reads at
+// a time); until round 6 every rank here parsed the WHOLE file into a host matrix and kept a slice of it.
+static bool text_is_fastq(const uint8_t* text, uint64_t n_bytes, int format) {
+  if (format == 2) return true;
+  if (format == 1) return false;
+  uint64_t p = 0;
+  while (p < n_bytes && (text[p] == '\n' || text[p] == '\r')) p++;
+  return p < n_bytes && text[p] == '@';
+}
+extern "C" int shn_text_records_in_range(const uint8_t* text, uint64_t n_bytes, uint64_t lo, uint64_t hi, int format, uint64_t* first_out, uint64_t* n_records_out,
+                                         uint64_t stride, uint64_t* index_out, uint64_t index_cap, uint64_t* n_index_out) {
+  if ((n_bytes && !text) || !first_out || !n_records_out || lo > hi || hi > n_bytes || (index_out && (!stride || !n_index_out)))
+    return shn_fail(SHN_ERR_ARG, "shn_text_records_in_range: bad argument");
+  uint64_t n_idx = 0;
+  const bool fastq = text_is_fastq(text, n_bytes, format);
+  const uint64_t first = align_record(text, n_bytes, lo, fastq);
+  uint64_t cnt = 0;
+  if (first < hi) {
+    // (the records that START before hi: the walk goes record by record and stops at the first start at or beyond hi)
+    uint64_t p = first;
+    const uint8_t mark = fastq ? '@' : '>';
+    while (p < hi) {
+      if (text[p] != mark) {
+        if (text[p] == '\n' || text[p] == '\r') { p++; continue; }
+        return shn_fail(SHN_ERR_ARG, "shn_text_records_in_range: unsupported: a record does not start with its record character");
+      }
+      if (index_out && cnt % stride == 0) { if (n_idx >= index_cap) return shn_fail(SHN_ERR_ARG, "shn_text_records_in_range: index_out too small"); index_out[n_idx++] = p; }
+      cnt++;
+      uint64_t e = line_end(text, n_bytes, p);                 // name line
+      if (e >= n_bytes) break;
+      e = line_end(text, n_bytes, e + 1);                      // sequence line
+      p = e + 1;
+      if (fastq && p < n_bytes) {
+        e = line_end(text, n_bytes, p);                        // "+" line
+        if (e >= n_bytes) break;
+        e = line_end(text, n_bytes, e + 1);                    // quality line
+        p = e + 1;
+      }
+    }
+  }
+  *first_out = first < hi ? first : n_bytes;
+  *n_records_out = cnt;
+  if (n_index_out) *n_index_out = n_idx;
+  return SHN_OK;
+}
+// the start of the k-th record after the record that starts at `from` (k = 0: `from` itself); n_bytes when the text has fewer
+extern "C" int shn_text_skip_records(const uint8_t* text, uint64_t n_bytes, uint64_t from, uint64_t k, int format, uint64_t* offset_out) {
+  if ((n_bytes && !text) || !offset_out || from > n_bytes) return shn_fail(SHN_ERR_ARG, "shn_text_skip_records: bad argument");
+  const bool fastq = text_is_fastq(text, n_bytes, format);
+  const uint8_t mark = fastq ? '@' : '>';
+  uint64_t p = from;
+  while (k && p < n_bytes) {
+    if (text[p] != mark) {
+      if (text[p] == '\n' || text[p] == '\r') { p++; continue; }
+      return shn_fail(SHN_ERR_ARG, "shn_text_skip_records: unsupported: a record does not start with its record character");
+    }
+    uint64_t e = line_end(text, n_bytes, p);
+    if (e >= n_bytes) { p = n_bytes; break; }
+    e = line_end(text, n_bytes, e + 1);
+    p = std::min(n_bytes, e + 1);
+    if (fastq && p < n_bytes) {
+      e = line_end(text, n_bytes, p);
+      if (e >= n_bytes) { p = n_bytes; break; }
+      e = line_end(text, n_bytes, e + 1);
+      p = std::min(n_bytes, e + 1);
+    }
+    k--;
+  }
+  while (p < n_bytes && (text[p] == '\n' || text[p] == '\r')) p++;       // (blank lines between records)
+  *offset_out = k ? n_bytes : p;
+  return SHN_OK;
+}
+
 // text / n_bytes: the file; format: 0 = by the first character ('>' FASTA, '@' FASTQ), 1 FASTA, 2 FASTQ; codes_out: NULL or room
 // for codes_cap bytes, filled with the [n_reads][read length] code matrix (fails if too small: size it with a first call that
 // passes out = NULL, which only scans); out: the packed read set (NULL: scan only).

@@ -565,8 +565,11 @@ int shn_known_paths_dev(shn_ctx* ctx, const shn_reads* reads, int K, const uint8
   { int rc = shn_device_scan_u32(ctx, d_cnt, T, d_goff, nullptr); if (rc) { shn_kp_destroy(kp); return rc; } }
   hipLaunchKernelGGL(kp_fill, dim3(gp), dim3(256), 0, s, d_slot, total, d_goff, d_fill, d_occ);
   RView v{reads->d_words, reads->d_woff, reads->d_len, nr, reads->fixed_len, reads->wpr};
-  hipLaunchKernelGGL(kp_classify, dim3((uint32_t)cdiv(nr, 256)), dim3(256), 0, s, v, K, d_hkeys, T - 1, d_goff, d_occ, d_bases, d_off, (uint32_t)n_nodes,
-                     d_state, d_node, d_ofs, kp->d_first, kp->d_last, d_slow, d_cnt2 + 4);
+  { TimerRegion tcl(ctx, T_KP_CLASSIFY);
+    // per distinct read: its packed words, two K-mer probes (slot 8 + occurrence list 8 each), the node text it is compared with (a byte per base), state / node / offset / first / last written (17)
+    tcl.bytes(nr * ((uint64_t)reads->wpr * 8 + 32 + (reads->fixed_len ? reads->fixed_len : reads->max_len) + 17));
+    hipLaunchKernelGGL(kp_classify, dim3((uint32_t)cdiv(nr, 256)), dim3(256), 0, s, v, K, d_hkeys, T - 1, d_goff, d_occ, d_bases, d_off, (uint32_t)n_nodes,
+                       d_state, d_node, d_ofs, kp->d_first, kp->d_last, d_slow, d_cnt2 + 4); }
   uint64_t* d_pk = nullptr;
   const uint64_t pk_words = (total + 31) / 32;
   TRYK(bufs.get(&d_pk, (pk_words + 2) * 8));
@@ -575,13 +578,17 @@ int shn_known_paths_dev(shn_ctx* ctx, const shn_reads* reads, int K, const uint8
   KpGraph G{d_bases, d_off, kp->d_eoff, kp->d_edst, d_eov, (getenv("SHN_KP_PACKED") && getenv("SHN_KP_PACKED")[0] == '0') ? (const uint64_t*)nullptr : (const uint64_t*)d_pk};
   KpIndex X{d_hkeys, T - 1, d_goff, d_occ, (uint32_t)n_nodes, K};
   // (kp_insert's count of bad nodes sits in d_cnt2[1]; the search keeps its own counters in [0], [2], [3])
-  hipLaunchKernelGGL(kp_search_all, dim3((uint32_t)std::min<uint64_t>(cdiv(nr, 64), 16384)), dim3(64), 0, s, v, G, X, d_state, (const int32_t*)d_node, (const uint32_t*)d_ofs, d_paths, paths_cap,
-                     d_cnt2, kp->d_first, kp->d_last, (const uint32_t*)dd->d_cnt, d_rec_cnt, rec_cap, d_left, left_cap, (const uint32_t*)d_slow,
-                     (const unsigned long long*)(d_cnt2 + 4));
+  { TimerRegion tse(ctx, T_KP_SEARCH);
+    hipLaunchKernelGGL(kp_search_all, dim3((uint32_t)std::min<uint64_t>(cdiv(nr, 64), 16384)), dim3(64), 0, s, v, G, X, d_state, (const int32_t*)d_node, (const uint32_t*)d_ofs, d_paths, paths_cap,
+                       d_cnt2, kp->d_first, kp->d_last, (const uint32_t*)dd->d_cnt, d_rec_cnt, rec_cap, d_left, left_cap, (const uint32_t*)d_slow,
+                       (const unsigned long long*)(d_cnt2 + 4)); }
   TRYK(hipGetLastError());
   unsigned long long cnt[4] = {0, 0, 0, 0};
   TRYK(hipMemcpyAsync(cnt, d_cnt2, 32, hipMemcpyDeviceToHost, s));
   TRYK(hipStreamSynchronize(s));
+  // (the search's bytes, known afterwards: per searched read its packed words twice -- the counting run and the writing run --, ~2 node
+  // texts of its length per run at 2 bits a base, its record words written)
+  if (ctx->timing) __atomic_fetch_add(&ctx->abytes[T_KP_SEARCH], (cnt[2] + cnt[3]) * (2 * (uint64_t)reads->wpr * 8 + (uint64_t)(reads->fixed_len ? reads->fixed_len : reads->max_len)) + cnt[0] * 4, __ATOMIC_RELAXED);
   if (cnt[1]) { shn_kp_destroy(kp); return shn_fail(SHN_ERR_ARG, "shn_known_paths_dev: a node holds a base outside ACGT"); }
   if (cnt[3] > left_cap) { shn_kp_destroy(kp); return shn_fail(SHN_ERR_INTERNAL, "shn_known_paths_dev: more reads left to the host than expected"); }
   const uint64_t used = std::min<uint64_t>(cnt[0], paths_cap), n_rec = std::min<uint64_t>(cnt[2], rec_cap);

@@ -660,9 +660,14 @@ extern "C" int shn_lp_solve_batch(shn_ctx* ctx, uint32_t n_problems, const uint3
   void* pout = (uint8_t*)pdown + o_out;
   void* pst = (uint8_t*)pdown + o_stat;
   HIP_TRY(hipMemcpyAsync(pup, h_up, up_bytes - 16, hipMemcpyHostToDevice, s));
-  if (!wprob.empty())
+  if (!wprob.empty()) {
+    TimerRegion ttr(ctx, T_LP_TRIALS);
+    { uint64_t b = 0;       // per trial: a, b and the mask read (8 (m + n) + m n), the vertex written twice (the answer and the centre kernel's copy)
+      for (uint32_t p = 0; p < n_problems; p++) { const uint64_t mn_ = (uint64_t)m[p] * n[p]; if ((2 * mn_ + 3ULL * (m[p] + n[p])) * 8 <= 65536) b += (uint64_t)trials[p] * (8ULL * (m[p] + n[p]) + mn_ + 16 * mn_); }
+      ttr.bytes(b); }
     hipLaunchKernelGGL(lp_trials_coop_kernel, dim3((uint32_t)wprob.size(), LBLK), dim3(LBLK), coop_words * 8, s, (const LpProblem*)pp, d_wprob, d_wfirst,
                        (const double*)pin, (const uint8_t*)pm, seed, (uint64_t*)pws, (double*)pout);
+  }
   if (!lprob.empty()) {
     hipLaunchKernelGGL(lp_trials_kernel<true>, dim3((uint32_t)lprob.size()), dim3(LBLK), lds_words * 8, s, (const LpProblem*)pp, d_lprob, d_lfirst,
                        (const double*)pin, (const uint8_t*)pm, seed, (uint64_t*)pws, (double*)pout);

@@ -176,8 +176,9 @@ extern "C" int shn_reads_dedup(shn_ctx* ctx, const shn_reads* a, const shn_reads
   TRYD(hipMemsetAsync(d_last, 0, nh * 4, s));
   SlotSrc S{a->d_words, b ? b->d_words : a->d_words, d_idx, n_in, a->wpr, a->fixed_len, paired ? 1 : 0};
   const uint32_t grid = (uint32_t)std::min<uint64_t>(cdiv(nh, 256), 1u << 20);
-  if (a->wpr <= 4) hipLaunchKernelGGL(dd_insert<4>, dim3(grid), dim3(256), 0, s, S, nh, d_tab, T - 1, d_slot);
-  else hipLaunchKernelGGL(dd_insert<MAXW>, dim3(grid), dim3(256), 0, s, S, nh, d_tab, T - 1, d_slot);
+  { TimerRegion tdi(ctx, T_DD_INSERT); tdi.bytes(nh * ((uint64_t)a->wpr * 8 * 2 + 4 + 4 + 4));      // per read slot: its index, its words and the words of the slot it meets, the table word, its slot written
+    if (a->wpr <= 4) hipLaunchKernelGGL(dd_insert<4>, dim3(grid), dim3(256), 0, s, S, nh, d_tab, T - 1, d_slot);
+    else hipLaunchKernelGGL(dd_insert<MAXW>, dim3(grid), dim3(256), 0, s, S, nh, d_tab, T - 1, d_slot); }
   hipLaunchKernelGGL(dd_tally, dim3(grid), dim3(256), 0, s, nh, d_tab, d_slot, d_first, d_cnt, d_last, d_flag);
   TRYD(hipGetLastError());
   uint64_t nd = 0;
@@ -249,8 +250,9 @@ int shn_reads_dedup_dev(shn_ctx* ctx, const shn_reads* a, const shn_reads* b, co
   TRYD(hipMemsetAsync(d_last, 0, nh * 4, s));
   SlotSrc S{a->d_words, b ? b->d_words : a->d_words, d_didx ? d_didx : d_idx, n_in, a->wpr, a->fixed_len, paired ? 1 : 0};
   const uint32_t grid = (uint32_t)std::min<uint64_t>(cdiv(nh, 256), 1u << 20);
-  if (a->wpr <= 4) hipLaunchKernelGGL(dd_insert<4>, dim3(grid), dim3(256), 0, s, S, nh, d_tab, T - 1, d_slot);
-  else hipLaunchKernelGGL(dd_insert<MAXW>, dim3(grid), dim3(256), 0, s, S, nh, d_tab, T - 1, d_slot);
+  { TimerRegion tdi(ctx, T_DD_INSERT); tdi.bytes(nh * ((uint64_t)a->wpr * 8 * 2 + 4 + 4 + 4));      // per read slot: its index, its words and the words of the slot it meets, the table word, its slot written
+    if (a->wpr <= 4) hipLaunchKernelGGL(dd_insert<4>, dim3(grid), dim3(256), 0, s, S, nh, d_tab, T - 1, d_slot);
+    else hipLaunchKernelGGL(dd_insert<MAXW>, dim3(grid), dim3(256), 0, s, S, nh, d_tab, T - 1, d_slot); }
   hipLaunchKernelGGL(dd_tally, dim3(grid), dim3(256), 0, s, nh, d_tab, d_slot, d_first, d_cnt, d_last, d_flag);
   TRYD(hipGetLastError());
   uint64_t nd = 0;

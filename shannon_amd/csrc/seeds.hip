@@ -139,8 +139,9 @@ static int seed_scan_impl(shn_ctx* ctx, const shn_reads* reads, int K, const shn
     hipError_t e = hipMemsetAsync(last.d_bm, 0, SEED_BM_WORDS * 4, s);
     if (e != hipSuccess) { drop(); return shn_fail(SHN_ERR_HIP, std::string("shn_seed_scan: ") + hipGetErrorString(e)); }
     if (patterns->n) hipLaunchKernelGGL(seed_bm_build_kernel, dim3((uint32_t)cdiv(patterns->n, 256)), dim3(256), 0, s, patterns->d_keys, patterns->n, last.d_bm);
-    hipLaunchKernelGGL((seed_scan_reads_kernel<false>), dim3(grid), dim3(SBLK2), 0, s, v, K, (const uint32_t*)last.d_bm, patterns->d_keys, patterns->d_counts,
-                       patterns->d_bucket_off, patterns->bits, pc, nullptr, nullptr, nullptr, nullptr);
+    { TimerRegion tsc(ctx, T_SEED_SCAN); tsc.bytes(v.n * ((uint64_t)reads->wpr * 8 + 4));            // a read's packed words + its hit count
+      hipLaunchKernelGGL((seed_scan_reads_kernel<false>), dim3(grid), dim3(SBLK2), 0, s, v, K, (const uint32_t*)last.d_bm, patterns->d_keys, patterns->d_counts,
+                         patterns->d_bucket_off, patterns->bits, pc, nullptr, nullptr, nullptr, nullptr); }
     if ((rc = shn_device_scan_u32(ctx, pc, n_cnt, last.d_off, &nh))) { drop(); return rc; }      // (synchronises: pc may go back)
   }
   *n_hits = nh;
@@ -155,8 +156,9 @@ static int seed_scan_impl(shn_ctx* ctx, const shn_reads* reads, int K, const shn
   uint32_t *d_r = nullptr, *d_s = nullptr, *d_i = nullptr;       // (from the caching allocator: this runs once per partition, under the GPU mutex)
   ShnDevBufs hb(ctx->stream);
   HIP_TRY(hb.get(&d_r, nh * 4)); HIP_TRY(hb.get(&d_s, nh * 4)); HIP_TRY(hb.get(&d_i, nh * 4));
-  hipLaunchKernelGGL((seed_scan_reads_kernel<true>), dim3(grid), dim3(SBLK2), 0, s, v, K, (const uint32_t*)last.d_bm, patterns->d_keys, patterns->d_counts,
-                     patterns->d_bucket_off, patterns->bits, nullptr, (const uint64_t*)last.d_off, d_r, d_s, d_i);
+  { TimerRegion tsc(ctx, T_SEED_SCAN); tsc.bytes(v.n * ((uint64_t)reads->wpr * 8 + 8) + nh * 12);         // the words again, the read's offset, its hits written (read, start, pattern)
+    hipLaunchKernelGGL((seed_scan_reads_kernel<true>), dim3(grid), dim3(SBLK2), 0, s, v, K, (const uint32_t*)last.d_bm, patterns->d_keys, patterns->d_counts,
+                       patterns->d_bucket_off, patterns->bits, nullptr, (const uint64_t*)last.d_off, d_r, d_s, d_i); }
   HIP_TRY(hipMemcpyAsync(out_read, d_r, nh * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(out_start, d_s, nh * 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(out_id, d_i, nh * 4, hipMemcpyDeviceToHost, s));

@@ -23,7 +23,7 @@ class Context(object):
     def timers(self):
         """{name: (ms, n_regions)} of HIP-event timed kernel groups since the last reset."""
         out = {}
-        for slot in range(40):
+        for slot in range(64):
             name = _lib.lib().shn_timer_name(slot).decode()
             if not name:
                 continue
@@ -31,6 +31,19 @@ class Context(object):
             _lib.check(_lib.lib().shn_timer_ms(self.h, slot, C.byref(ms), C.byref(n)))
             if n.value:
                 out[name] = (ms.value, n.value)
+        return out
+
+    def timer_bytes(self):
+        """{name: algorithmic bytes} the launch sites of the timed kernels have declared since the last reset (shn_timer_bytes)"""
+        out = {}
+        for slot in range(64):
+            name = _lib.lib().shn_timer_name(slot).decode()
+            if not name:
+                continue
+            b = C.c_uint64()
+            _lib.check(_lib.lib().shn_timer_bytes(self.h, slot, C.byref(b)))
+            if b.value:
+                out[name] = int(b.value)
         return out
 
     LP_RULES = {"vertex": 0, "center": 1}

@@ -1,25 +1,25 @@
-"""Multi-GPU hot path on one node: one process per GPU, torch.distributed ("nccl" = RCCL over xGMI).
+"""Multi-GPU hot path on one node: one process per GPU, torch.distributed ("nccl" = RCCL over xGMI).  DESIGN.md section 6.
 
-Sharding.  Reads are split contiguously by index across ranks.
-  1. every rank counts its shard (canonical k1-mer table), shards the table by
-     owner = fmix64(key ^ SALT) mod W and ONE all-to-all(v) moves each (key,count) to its owner,
-     which reduces by key                                  -- the k-mer bucket exchange, the only
-                                                              all-to-all on the k-mer data path;
-  2. the owned shards (distinct k1-mers, small next to the reads) are all-gathered so every rank
-     holds the global table and runs the deterministic contig extension + partitioning
-     redundantly (the greedy extension is a global sequential order -- it does not shard);
-  3. every rank routes ITS reads against the replicated partition table; partitions are dealt to
-     ranks by the number of reads their graphs consume (deal_partitions); the reads a partition's graph may consume -- the first
-     10*#nodes+1 in the global strand-doubled order (multibridging.py:26-30) -- are sent to the
-     owner (tiny, because of that cap);
-  4. owners build the multibridged graph and run sparse flow for their partitions; rank 0 gathers
-     the per-partition FASTA and does the final merge.
-The result equals the single-GPU pipeline on the concatenated reads.
+No rank holds the job: not its reads (every rank ingests its share of the files' BYTES: ingest_rank_slice), not its k1-mer table.
+  1. every rank counts its slice of the reads; the (key, count) pairs go to the rank that owns the k1-mer's MINIMIZER in ONE
+     all-to-all(v) -- the k-mer bucket exchange -- and the owner reduces by key (a k1-mer and its neighbours share their
+     minimizer 7 times out of 8: most edges of the k1-mer graph stay inside a shard);
+  2. the connected components of the k1-mer graph are labelled ON the owner shards (local union-find; the keys a higher rank owns
+     are asked there in one all-to-all; the edges between local components are all-gathered and solved on every rank alike), and
+     whole components travel to the rank that walks them (one all-to-all): a table of its own per rank, the unsharded greedy
+     extension on it (SHN_OWNER_LABELS=0: the replicated table of rounds 2-4, kept for comparison);
+  3. the candidates of all ranks meet in the walk order of the reference (one all-gather of arrays: seed weights and keys, offsets,
+     text), the contig stage runs on them, every rank routes ITS reads against the accepted contigs' probe table; partitions are
+     dealt to ranks by the reads their graphs consume (deal_partitions) and those reads -- the first 10 * nodes + 1 of the global
+     strand-doubled order (multibridging.py:26-30) -- travel to the owner in one all-to-all of bytes;
+  4. owners build the multibridged graphs and run the sparse flow of their partitions; rank 0 gathers the FASTA and merges.
+The result equals the single-GPU pipeline on the concatenated reads (tests/test_distributed_*.py, test_nrank_midsize_gpu.py).
 
-`ops` abstracts the per-rank compute (GpuOps: HIP kernels through the C ABI; the CPU tests plug
-an oracle-backed implementation to exercise the collective choreography with gloo).
+`ops` abstracts the per-rank compute (GpuOps: HIP kernels through the C ABI; the CPU tests plug an oracle-backed implementation
+to exercise the collective choreography with gloo).
 """
 from collections.abc import Mapping
+import os
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -66,6 +66,97 @@ def _all_gather_var_(t, group=None):
             if lens[r]:
                 out[int(off[r]) + j * C: int(off[r]) + j * C + lens[r]] = outs[r][:lens[r]]
     return out.to(t.device), ns
+
+
+def ingest_rank_slice(paths, rank, world, group, device, ctx=None, stats=None):
+    """The N-rank CLI's reads by BYTES of the files (round 6; the reference streams its read files once, 10 M reads at a time:
+    kmers_for_component.py:322-403).  Every rank counts the records that start in its share of each file's bytes
+    (shn_text_records_in_range), the counts of all ranks say which record every share starts with, and the records
+    [n r / W, n (r + 1) / W) of this rank -- a few records into some share -- go through shn_reads_ingest as one stretch of text.
+    Host memory and parsing per rank: its share of the text (memory-mapped) + its slice's code matrix, not the whole job's.
+    Returns (code matrices of this rank's slice, one per file; n records of the job) or None when a file cannot be shared out this
+    way (.gz: no random access; reads of different lengths; multi-line FASTA) and the caller reads whole files as before.
+    stats (dict): bytes this rank looked at / holds."""
+    import ctypes as C
+    from . import _lib, device as dev_mod
+    if any(p.endswith(".gz") for p in paths):
+        return None
+    L_ = _lib.lib()
+    mats, n_job = [], None
+    scanned = held = 0
+    for path in paths:
+        size = os.path.getsize(path)
+        text = np.memmap(path, dtype=np.uint8, mode="r") if size else np.zeros(0, np.uint8)
+        B = int(len(text))
+        lo_b, hi_b = rank * B // world, (rank + 1) * B // world
+        first, cnt, n_idx = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        ptr = text.ctypes.data if B else None
+        ok = 1
+        # (with the count: the offset of every 1,024th record of the share -- from the shares' sparse indices any record of the file is
+        # at most 1,023 records away, whoever's share it starts in)
+        STRIDE = 1024
+        idx_buf = np.zeros(max(1, (hi_b - lo_b) // (2 * STRIDE) + 2), dtype=np.uint64)         # (a record is at least 2 bytes)
+        try:
+            _lib.check(L_.shn_text_records_in_range(ptr, B, lo_b, hi_b, 0, C.byref(first), C.byref(cnt), STRIDE, idx_buf.ctypes.data, len(idx_buf),
+                                                    C.byref(n_idx)))
+        except _lib.ShannonError:
+            ok = 0
+        scanned += hi_b - lo_b
+        sparse = [p_[0] for p_ in exchange.all_gather_arrays((idx_buf[:n_idx.value],), device, group, "ingest: sparse record index of the shares")]
+        mine = torch.tensor([first.value, cnt.value, ok], dtype=torch.int64, device=device)
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        tab = np.stack([x.cpu().numpy() for x in parts])                      # [W, 3]: first record start, records, ok
+        if not tab[:, 2].all():
+            return None
+        firsts, cnts = tab[:, 0], tab[:, 1]
+        prefix = np.concatenate([[0], np.cumsum(cnts)])
+        n = int(prefix[-1])
+        if n_job is None:
+            n_job = n
+        elif n != n_job:
+            raise _lib.ShannonError("--left and --right hold different numbers of reads (%d, %d)" % (n_job, n))
+
+        def locate(idx):
+            # byte offset at which record `idx` of the file starts
+            nonlocal scanned
+            if idx >= n:
+                return B
+            k = int(np.searchsorted(prefix, idx, side="right")) - 1
+            j, rest = divmod(int(idx - prefix[k]), STRIDE)
+            start = int(sparse[k][j])
+            off = C.c_uint64()
+            _lib.check(L_.shn_text_skip_records(ptr, B, start, rest, 0, C.byref(off)))
+            scanned += int(off.value) - start
+            return int(off.value)
+        rlo, rhi = rank * n // world, (rank + 1) * n // world
+        a, b = locate(rlo), locate(rhi)
+        if rhi == rlo:                                        # (more ranks than records: this rank holds none)
+            codes = np.zeros((0, 0), np.uint8)
+        else:
+            try:
+                _d, codes = dev_mod.Reads.ingest(None, text[a:b])
+            except _lib.ShannonError as ex:
+                if "unsupported" not in str(ex):
+                    raise
+                codes = None
+        fine = codes is not None and not isinstance(codes, dev_mod.RaggedCodes) and len(codes) == rhi - rlo
+        flag = torch.tensor([1 if fine else 0, codes.shape[1] if fine and len(codes) else 0], dtype=torch.int64, device=device)
+        flags = [torch.zeros_like(flag) for _ in range(world)]
+        dist.all_gather(flags, flag, group=group)
+        ft = np.stack([x.cpu().numpy() for x in flags])
+        lens = set(int(v) for v in ft[:, 1] if v)
+        if not ft[:, 0].all() or len(lens) > 1:
+            return None
+        if len(codes) == 0 and lens:                                          # (a rank without records still holds a matrix of the job's read length)
+            codes = np.zeros((0, lens.pop()), np.uint8)
+        scanned += b - a
+        held += (b - a) + codes.size
+        mats.append(np.ascontiguousarray(codes))
+        del text
+    if stats is not None:
+        stats.update({"bytes_scanned": int(scanned), "bytes_held": int(held), "file_bytes": int(sum(os.path.getsize(p) for p in paths)), "records": int(n_job or 0)})
+    return mats, int(n_job or 0)
 
 
 def deal_partitions(load, W):
@@ -673,6 +764,16 @@ class GpuOps(object):
                 lock.release()
                 t0 = time.time()
                 parts = exchange.all_gather_object(obj, group, "contig gathers (accepted contigs + connections of the shards)")
+                self.coll_wait += time.time() - t0
+                lock.acquire()
+                return parts
+
+            @staticmethod
+            def all_gather_arrays(arrays):
+                lock.release()
+                t0 = time.time()
+                parts = exchange.all_gather_arrays(arrays, exchange.coll_device(self.device, group), group,
+                                                   "contig gathers (candidates of the shards: seed weights, keys, offsets, text)")
                 self.coll_wait += time.time() - t0
                 lock.acquire()
                 return parts

@@ -77,6 +77,42 @@ def all_gather_object(obj, group=None, name="objects"):
     return parts
 
 
+def all_gather_arrays(arrays, device, group=None, name="arrays"):
+    """Every rank's tuple of numpy arrays to every rank, as TENSORS (one padded all_gather per array, sizes first): what used to
+    travel as pickled objects (all_gather_object) -- the accepted candidates of the sharded contig stage, 0.3 GB at BASELINE
+    configs[2].  Returns a list over the ranks of tuples of arrays (dtypes and shapes[1:] as given; all ranks pass the same number of
+    arrays of the same dtypes).  device: where the collective's tensors live (coll_device)."""
+    import time
+    W = dist.get_world_size(group)
+    t0 = time.time()
+    arrays = [np.ascontiguousarray(a) for a in arrays]
+    sizes = torch.tensor([a.size for a in arrays], dtype=torch.int64, device=device)
+    all_sizes = [torch.zeros_like(sizes) for _ in range(W)]
+    dist.all_gather(all_sizes, sizes, group=group)
+    all_sizes = np.stack([x.cpu().numpy() for x in all_sizes])                 # [W, n_arrays]
+    out = [[] for _ in range(W)]
+    sent = recv = 0
+    for j, a in enumerate(arrays):
+        mx = int(all_sizes[:, j].max())
+        raw = a.reshape(-1).view(np.uint8)
+        isz = a.dtype.itemsize
+        buf = torch.zeros(max(mx * isz, 1), dtype=torch.uint8, device=device)
+        if raw.size:
+            buf[:raw.size] = torch.from_numpy(raw.copy()).to(device)
+        parts = [torch.empty_like(buf) for _ in range(W)]
+        dist.all_gather(parts, buf, group=group)
+        tail = a.shape[1:]
+        for r in range(W):
+            n_el = int(all_sizes[r, j])
+            got = parts[r][:n_el * isz].cpu().numpy().view(a.dtype)
+            out[r].append(got.reshape((-1,) + tuple(tail)) if tail else got)
+            recv += n_el * isz
+        sent += raw.size * (W - 1)
+    if W > 1:
+        note(name, sent, recv, time.time() - t0)
+    return [tuple(x) for x in out]
+
+
 def fmix64_np(x):
     x = x.astype(np.uint64).copy()
     x ^= x >> np.uint64(33)

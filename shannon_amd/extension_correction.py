@@ -640,8 +640,11 @@ def run_correction(ctx, table, min_weight=3, min_length=75, comp_size_threshold=
             # every rank's candidates -> the same merged list everywhere, in the order of the reference's seed loop
             # (weight descending, seed k1-mer ascending; a seed lies in exactly one shard, so the keys are distinct)
             skey, sw = ext.seed_info(keep_r)
-            parts = gather.all_gather((np.asarray(sw, dtype=np.int64), np.asarray(skey, dtype=np.uint64), np.asarray(offs, dtype=np.uint64),
-                                       np.ascontiguousarray(buf[:int(offs[-1])])))
+            # (as tensors where the gather offers it -- the ranks of a real job: 0.3 GB of candidate text at BASELINE configs[2], which
+            # used to travel as pickled objects)
+            mine_ = (np.asarray(sw, dtype=np.int64), np.asarray(skey, dtype=np.uint64), np.asarray(offs, dtype=np.uint64),
+                     np.ascontiguousarray(buf[:int(offs[-1])]))
+            parts = gather.all_gather_arrays(mine_) if hasattr(gather, "all_gather_arrays") else gather.all_gather(mine_)
             lap("ext.gathers")
             w_all = np.concatenate([p[0] for p in parts])
             k_all = np.concatenate([p[1] for p in parts])

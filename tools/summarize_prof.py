@@ -15,7 +15,11 @@ TIMER_KERNEL = {"count.direct": "count_direct_kernel", "count.hist1": "hist1_ker
                 "extend.mark": "ext_mark_kernel", "extend.begin": "ext_round_begin_kernel",
                 "extend.adjacency": "ext_records_kernel",
                 "count.sk_emit": "sk_scan_kernel", "count.sk_hist2": "skr_hist_kernel", "count.sk_scatter2": "skr_scatter_kernel",
-                "count.sk_buckets": "sk_buckets_sorted_kernel<true, 256, 1024, 0>", "count.sk_buckets2": "sk_buckets_sorted_kernel<true, 256, 2048, 0>"}
+                "count.sk_buckets": "sk_buckets_sorted_kernel<true, 256, 1024, 0>", "count.sk_buckets2": "sk_buckets_sorted_kernel<true, 256, 2048, 0>",
+                # round 6: the contig stage's round kernels, the read -> graph mapping, the LP trials, the fixpoint audit
+                "contig.hits": "cg_hits_kernel", "contig.cover": "cg_cover_kernel", "contig.compact": "cg_acc_compact_kernel",
+                "graph.kp_search": "kp_search_all", "graph.kp_classify": "kp_classify", "graph.seed_scan": "seed_scan_reads_kernel",
+                "graph.dd_insert": "dd_insert", "lp.trials": "lp_trials_coop_kernel", "extend.audit": "ext_audit_nodes_kernel"}
 
 
 def short(name):
