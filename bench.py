@@ -205,7 +205,12 @@ def overlapped_steps(ctx, sets, store, K, n, want_sha, n_reads):
     one batch at a time.  Every batch's transcripts must equal the sequential run's."""
     from concurrent.futures import ThreadPoolExecutor
     from shannon_amd import device, pipeline
-    ctx_b = device.Context(0)
+    # the second context works on a stream of its OWN (round 6).  Until then both contexts were made on the legacy NULL stream, which
+    # orders everything issued on it: whatever the back half put there itself (the merge's uploads and fingerprint passes, its
+    # synchronisations) waited behind the front half's whole queue.  SHN_OVERLAP_STREAM=0: the NULL stream again; 2: a high-priority stream.
+    mode = os.environ.get("SHN_OVERLAP_STREAM", "2")
+    own = None if mode == "0" else torch.cuda.Stream(device=torch.device("cuda", 0), priority=(-1 if mode == "2" else 0))
+    ctx_b = device.Context(0, stream=own.cuda_stream if own is not None else None)
     pool = ThreadPoolExecutor(max_workers=1)
     try:
         def front():
@@ -225,6 +230,7 @@ def overlapped_steps(ctx, sets, store, K, n, want_sha, n_reads):
         finals.append(last)
         ok = all(_final_sha(f) == want_sha for f in finals)
         return {"value": n_reads * n / dt, "unit": "reads/s", "steps": n, "ms_per_step": 1000.0 * dt / n, "transcripts_equal_sequential_run": bool(ok),
+                "back_half_stream": {"0": "legacy NULL stream", "1": "own stream", "2": "own high-priority stream"}.get(mode, mode),
                 "note": "two batches in flight (second half of batch i beside the first half of batch i+1, two contexts); not the headline value"}
     except Exception as ex:                                    # an extra: its failure must not cost the bench line
         return {"error": str(ex)[:300]}
