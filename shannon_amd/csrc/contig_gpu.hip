@@ -315,6 +315,26 @@ static int contig_stage_impl(shn_ctx* ctx, const uint8_t* bases, const uint8_t* 
       ts.bytes(nv * (1 + 12 + (uint64_t)((2 * r + 7) / 8) * 24)); }
     if (rc) return rc;
     lap("r-mer sort (GPU)");
+    // Only the runs that span two different candidates matter from here on: a window whose r-mer no OTHER candidate holds has no hit
+    // (:250-259 counts the earlier candidates sharing it), covers nothing, affects nobody -- and three windows out of four are such
+    // (4^15 possible 15-mers against 3 x 10^8 windows at BASELINE configs[2]: a quarter of the windows collide by chance alone).  The
+    // per-block index and every round's passes (hits, cover, affected) then stream a quarter of the entries.  The same flag and
+    // compaction as for the K-mer join below (stable sort + windows made candidate by candidate: a run spans two candidates iff
+    // its first and last entries differ in candidate).  SHN_CONTIG_SHARED=0: all windows, as until round 6.
+    if (nv > 1 && !(getenv("SHN_CONTIG_SHARED") && getenv("SHN_CONTIG_SHARED")[0] == '0')) {
+      uint32_t* d_f0; uint64_t* d_p0; uint64_t ns0 = 0;
+      ShnDevBufs scratch(s);
+      HIP_TRY(scratch.get(&d_f0, (nv + 1) * 4));
+      HIP_TRY(scratch.get(&d_p0, (nv + 2) * 8));
+      hipLaunchKernelGGL(cg_shared_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, keys, vals, nv, d_cid, d_f0);
+      if ((rc = shn_device_scan_u32(ctx, d_f0, nv, d_p0, &ns0))) return rc;
+      uint64_t* ok = nullptr; uint32_t* ov = nullptr;
+      HIP_TRY(tmp.get(&ok, (ns0 + 1) * 8)); HIP_TRY(tmp.get(&ov, (ns0 + 1) * 4));
+      if (ns0) hipLaunchKernelGGL(cg_compact_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, keys, vals, d_f0, d_p0, nv, ok, ov);
+      if (dbg) fprintf(stderr, "[contig_stage]   %llu of %llu r-mer windows lie in runs that span two candidates\n", (unsigned long long)ns0, (unsigned long long)nv);
+      keys = ok; vals = ov; nv = ns0;
+      lap("shared r-mer runs (GPU)");
+    }
     uint8_t *d_acc, *d_hit; uint32_t *d_scid, *d_flag, *d_acand, *d_cov, *d_ovf; uint64_t *d_apos, *d_akey; int32_t* d_bestc;
     unsigned long long *d_best, *d_chg;
     HIP_TRY(tmp.get(&d_acc, n_cand + 1)); HIP_TRY(tmp.get(&d_hit, total + 64)); HIP_TRY(tmp.get(&d_scid, (nv + 1) * 4));
