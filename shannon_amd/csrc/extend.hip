@@ -2420,7 +2420,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   // host time 0.608 / 0.687 / 0.671 / 0.638 / 0.629 / 0.632 / 0.631 s: the rule is exact and removes half of the walks -- the cheap half
   // (seeds on clean chains: weakly covered transcripts; a well covered one has an error branch at every position, so no link is
   // forced) -- and the survivors, started earlier than they would have been behind the void ones, walk further before a lower rank
-  // stops them.  A launch's time follows its steps' random sectors (~10 per step, ~40 G/s), not its walks.  Off by default.
+  // stops them.  A launch's time follows its steps' random lines (~5.5 per step at ~20 G lines/s; 623 M steps for the 422 M k1-mers finally claimed:
+  // tools/walk_waste_r06.py), not its walks.  Off by default.
   const uint32_t settle_hops = tune("SHN_EXT_SETTLE_HOPS", 0);
   const uint32_t fresh_split = std::max<uint32_t>(1, std::min<uint32_t>(16, tune("SHN_EXT_FRESH_SPLIT", 1)));   // sub-launches of a block's first (bulk) round (measured at configs[2]: 1 / 4 / 7 / 10 -> 184 / 176 / 209 / 248 ms: every sub-launch waits for its longest walk; off)
   const uint32_t fresh_split_min = tune("SHN_EXT_FRESH_SPLIT_MIN", 65536);                                       // ... of blocks of at least this many walks            // a block's first round settles the walks whose seed an earlier block holds (ext_plan_kernel)
