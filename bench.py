@@ -877,6 +877,14 @@ def main():
         if dom.startswith("extend."):
             r_dom["note"] = ("greedy walk fixpoint: dependent pointer chasing, one memory round trip per step -- latency-bound, not "
                              "bandwidth-bound; the dominant streaming kernel is in roofline_bandwidth_kernel")
+            # the same kernel against the roof that binds a gather: every random load is one 128-byte request to HBM whatever it uses,
+            # and the chip serves 48.4 G of them per second when nothing depends on anything (profiles/r03_fetch_calibration.txt: 1.074 G
+            # random 8-byte loads in 22.2 ms).  Requests per launch = PMC traffic / 128.
+            if r_dom.get("traffic"):
+                req = r_dom["traffic"] / 128.0
+                r_dom["random_access"] = {"requests_per_launch": req, "achieved_G_requests_per_s": req / (r_dom["avg_launch_ms"] * 1e-3) / 1e9,
+                                          "peak_G_requests_per_s": 48.4, "frac": req / (r_dom["avg_launch_ms"] * 1e-3) / 1e9 / 48.4,
+                                          "note": "independent random loads; a walk's steps depend on one another"}
         what = {"1": "10M synthetic 2x100bp paired reads, k=25 (k1=26), single gene family, 0.5% substitution errors (BASELINE configs[1])",
                 "2": "100M synthetic 2x100bp paired reads (50M pairs), k=25 (k1=26), 20,000 genes (1-6 isoforms of 3-12 exons, lognormal "
                      "expression), 0.5% substitution errors, multi-component, --partition 500 (BASELINE configs[2])",

@@ -1307,7 +1307,8 @@ __global__ __launch_bounds__(1024) void ext_plan_kernel(uint32_t* nr, uint32_t* 
                                 unsigned long long* __restrict__ counters, uint32_t long_walk, uint8_t* __restrict__ coarse,
                                 const u64* __restrict__ fresh_claim, const uint32_t* __restrict__ order, uint64_t* __restrict__ totw,
                                 const Rec* __restrict__ rec, uint32_t settle_hops, uint8_t* __restrict__ settled,
-                                unsigned long long* __restrict__ n_settled) {
+                                unsigned long long* __restrict__ n_settled, uint8_t* __restrict__ robsat = nullptr,
+                                unsigned long long* __restrict__ n_robsat = nullptr) {
   // ns here = current rank limit (walks >= limit have not started yet); walks < frozen are final and never run
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + frozen;
   const bool isd_all = r < ns && dirty[r];
@@ -1357,6 +1358,12 @@ __global__ __launch_bounds__(1024) void ext_plan_kernel(uint32_t* nr, uint32_t* 
     // their memos: ext_release_memo_kernel)
     const unsigned long long hm = __ballot(isd_all && nr[r] != UNCLAIMED && mvalid[r] != 2);
     if (lane == 0 && hm) atomicAdd(&bh, (unsigned long long)__popcll(hm));
+    if (robsat) {      // (development, SHN_EXT_XTIME: of those, the walks that were robbed while they sat out -- their chain of claims has a gap)
+      const unsigned long long rm = __ballot(isd_all && nr[r] != UNCLAIMED && mvalid[r] != 2 && robsat[r]);
+      if (lane == 0 && rm) atomicAdd(n_robsat, (unsigned long long)__popcll(rm));
+      if (isd_all && nr[r] != UNCLAIMED && mvalid[r] != 2) { const unsigned long long len = (unsigned long long)nr[r] + nl[r]; atomicMax(n_robsat + 1, len); atomicAdd(n_robsat + 2, len); }
+      if (isd_all) robsat[r] = 0;                                    // (it runs now: what it holds afterwards is a fresh chain)
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0 && bd) atomicAdd(&counters[3], bd);
@@ -1455,7 +1462,7 @@ __global__ void ext_mark_kernel(const u64* __restrict__ claim, u64* claim_old, u
                                 const uint8_t* __restrict__ fill /* NULL: no walk got a memo slot this round */, const uint64_t* __restrict__ moff, const uint32_t* __restrict__ mR,
                                 uint32_t* __restrict__ pool,
                                 const uint32_t* __restrict__ nr_a, const uint32_t* __restrict__ nl_a, int precise,
-                                const uint8_t* __restrict__ chunk) {
+                                const uint8_t* __restrict__ chunk, uint8_t* __restrict__ robsat = nullptr) {
   const RowView adjR = rows_R(rec), adjL = rows_L(rec);
   const WordView weight = words_weight(rec);
   // grid-stride: the change counter costs one atomic per block (one per wavefront on a single address was the
@@ -1495,7 +1502,7 @@ __global__ void ext_mark_kernel(const u64* __restrict__ claim, u64* claim_old, u
     // kernel); the new owner ran this round.  Walks below `frozen` are final, walks at or above `limit` have not
     // started (they all run when their phase opens).
 #define MARK(x) if ((x) >= frozen && (x) < limit) dirty[x] = 1
-    if (a != UNCLAIMED && !ran[a]) MARK(a);
+    if (a != UNCLAIMED && !ran[a]) { MARK(a); if (robsat && a >= frozen && a < limit) robsat[a] = 1; }
     a_out = a;
     return b >= a;
   };
@@ -2346,6 +2353,9 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   uint8_t* robbed = ran + ns + 1;
   uint8_t* settled = robbed + ns + 1;     // walks that can never survive (ext_chain_has_lower): void for good, never launched
   TRYE(hipMemsetAsync(robbed, 0, 2 * (ns + 1), s));
+  uint8_t* robsat = nullptr;              // (development, SHN_EXT_XTIME: walks robbed while they sat out, until they run again)
+  struct RobsatFree { uint8_t** p; ~RobsatFree() { if (*p) shn_dev_free(*p); } } robsat_free{&robsat};
+  if (getenv("SHN_EXT_XTIME")) { TRYE(shn_dev_malloc(&robsat, ns + 1)); TRYE(hipMemsetAsync(robsat, 0, ns + 1, s)); }
   TRYE(hipMemsetAsync(mvalid, 0, 2 * (ns + 1), s));
   TRYE(hipMemsetAsync(pool, 0xFF, pool_cap * 4, s));            // NONE32: "no entry"
   // (hints and seed ranks live in the records: ext_records_kernel wrote "none" into both)
@@ -2438,7 +2448,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       hipLaunchKernelGGL(ext_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 1024)), dim3(1024), 0, s, e->d_nr, e->d_nl, (uint64_t)limit, frozen,
                          mvalid, mR, mL, dirty, long_list, short_list, d_cnt + 2, bulk ? 0xFFFFFFFFu : long_walk, coarse,
                          (fresh_block && frozen > 0 && prepass) ? (const u64*)claim : (const u64*)nullptr, e->d_order, e->d_totw,
-                         (const Rec*)e->d_rec, fresh_block ? settle_hops : 0u, settled, d_cnt + 20);
+                         (const Rec*)e->d_rec, fresh_block ? settle_hops : 0u, settled, d_cnt + 20, robsat, d_cnt + 21);
     // (pinned host memory: a pageable destination costs a staging copy kernel per round)
     TRYE(hipMemcpyAsync(plan, d_cnt + 2, 32, hipMemcpyDeviceToHost, s));
     TRYE(hipStreamSynchronize(s));
@@ -2566,6 +2576,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       unsigned long long st = 0, lw = 0; TRYE(hipMemcpyAsync(&st, d_cnt + 1, 8, hipMemcpyDeviceToHost, s));
       if (A.dbg) { TRYE(hipMemcpyAsync(&lw, d_cnt + 44, 8, hipMemcpyDeviceToHost, s)); TRYE(hipMemsetAsync(d_cnt + 44, 0, 8, s)); }
       TRYE(hipStreamSynchronize(s));
+      unsigned long long nrs[3] = {0, 0, 0}; TRYE(hipMemcpyAsync(nrs, d_cnt + 21, 24, hipMemcpyDeviceToHost, s)); TRYE(hipMemsetAsync(d_cnt + 21, 0, 24, s)); TRYE(hipStreamSynchronize(s));
+      fprintf(stderr, "[shn_extend] XTIME round %d [%u,%u): of the claim holders without a memo %llu were robbed while they sat out; their walks: longest %llu steps, %llu steps in all\n", it + 1, frozen, limit, nrs[0], nrs[1], nrs[2]);
       fprintf(stderr, "[shn_extend] XTIME round %d: %llu dirty walks, %llu of them hold claims without a current memo (rounds released through memos so far: %d); thread walker %llu walks, %.2f ms, steps so far %llu; longest walk %llu steps in %.2f ms (%.2f us per step)\n", it + 1, plan[3], plan[1], n_begin_skipped, plan[2],
               ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6 - x_t0, st, lw >> 32, (double)(lw & 0xFFFFFFFFULL) * 1e-5, (lw >> 32) ? (double)(lw & 0xFFFFFFFFULL) * 1e-2 / (double)(lw >> 32) : 0.0);
     }
@@ -2598,7 +2610,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     { TimerRegion tk(ctx, T_EXT_MARK);
       hipLaunchKernelGGL(ext_mark_kernel, dim3(std::min<uint32_t>(g2n, 4096u)), dim3(256), 0, s, claim, snap, 2 * n, e->d_rec,
                          dirty, ran, d_cnt + 6, frozen, limit, bulk ? (const uint8_t*)nullptr : (const uint8_t*)fill, moff, mR, pool, e->d_nr, e->d_nl, precise_marks,
-                         dense ? (const uint8_t*)nullptr : chunk);
+                         dense ? (const uint8_t*)nullptr : chunk, robsat);
       if (!dense) TRYE(hipMemsetAsync(chunk, 0, n_chunks, s)); }
     hipLaunchKernelGGL(ext_verify_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, ran, robbed, (uint64_t)ns, dirty);
     if (getenv("SHN_EXT_FAULT") && it + 1 == atoi(getenv("SHN_EXT_FAULT"))) TRYE(hipMemsetAsync(dirty, 0, ns + 1, s));   // (tests: lose every mark of this round)
