@@ -684,7 +684,15 @@ struct WalkArgs {
   uint8_t* robbed;       // per walk: a claim of its record is not (or no longer) its own -- see note_claim
   int seed_check;        // thread walkers: look at the own seed's claim on every step and stop when a lower rank has taken it
   int first_look;        // thread walkers: a direction starts with a look at the candidates' claims alone
+  // claim logs (round 6): in a bulk round -- no memos are made there -- the thread walker writes the k1-mers it claims into a chain of
+  // 8-word chunks of its own ([0] = the chunk before, [1..7] = k1-mers; the seed is not logged: it is order[r]); a walk that re-runs
+  // later gives back what it still holds through its log (ext_release_memo_kernel) instead of the begin pass streaming every claim
+  uint32_t* logpool; uint32_t* log_head; uint8_t* log_cnt; unsigned long long* log_cursor; uint64_t log_cap;   // pool of log_cap chunks; per walk: last chunk (NONE32: no log, LOG_LOST: the pool ran out) and its entries
 };
+#define LOG_WORDS 8u
+#define LOG_PER (LOG_WORDS - 1u)
+#define LOG_SLAB 64u           // chunks a wavefront reserves with one global atomic
+#define LOG_LOST 0xFEFEFEFEu        // (the byte pattern of hipMemset(0xFE): "no log" is what the arrays start as)
 
 // Claim `node` as step `pos` of walk r: atomic min on rank:pos.  Returns what stood there before; the caller hands it to note_claim
 // -- one step later in the thread walkers, where the answer has long arrived behind the loads of the next step (memory operations
@@ -755,10 +763,37 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
                                                         const u64* __restrict__ snap) {
   __shared__ unsigned long long blk_steps;
   __shared__ uint32_t blk_promo[WBLK], n_promo, promo_base;      // walks handed over: one global atomic per block
-  if (threadIdx.x == 0) { blk_steps = 0; n_promo = 0; }
+  __shared__ uint32_t slab_next, slab_end;                        // claim logs: the wavefront's reserve of chunks
+  if (threadIdx.x == 0) { blk_steps = 0; n_promo = 0; slab_next = 0; slab_end = 0; }
   __syncthreads();
   uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t mysteps = 0;
+  // a chunk for every lane that asks in this trip (the lanes of the wavefront that are in the loop right now): one LDS update by
+  // the first of them, one global atomic per LOG_SLAB chunks
+  auto log_chunk = [&](bool need) -> uint32_t {
+    const unsigned long long m = __ballot(need);
+    uint32_t got = NONE32;
+    if (m) {
+      const int leader = __ffsll((long long)m) - 1;
+      const uint32_t cnt = (uint32_t)__popcll(m);
+      uint32_t base = 0;
+      if ((int)threadIdx.x == leader) {
+        uint32_t nx = *(volatile uint32_t*)&slab_next, en = *(volatile uint32_t*)&slab_end;
+        if (nx + cnt > en) {
+          const unsigned long long g = atomicAdd(A.log_cursor, (unsigned long long)LOG_SLAB);
+          if (g + LOG_SLAB <= A.log_cap) { nx = (uint32_t)g; en = nx + LOG_SLAB; } else { nx = NONE32 - 2 * LOG_SLAB; en = nx; }     // (the pool ran out: nobody gets a chunk)
+        }
+        base = nx + cnt <= en ? nx : NONE32;
+        *(volatile uint32_t*)&slab_next = nx + (base == NONE32 ? 0u : cnt); *(volatile uint32_t*)&slab_end = en;
+      }
+      base = (uint32_t)__shfl((int)base, leader, 64);
+      if (need && base != NONE32) got = base + (uint32_t)__popcll(m & ((1ULL << threadIdx.x) - 1ULL));
+    }
+    return got;
+  };
+  const bool logging = A.logpool != nullptr;
+  uint32_t lg_chunk = NONE32, lg_k = LOG_PER;                     // the walk's last chunk and the entries it holds (LOG_PER: full, or none yet)
+  bool lg_lost = false;
   if (t < n_walks) {
     const uint32_t r = list[t];
     const uint32_t o = A.order[r];
@@ -833,6 +868,15 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
           pend = nbest;                            // claimed at the top of the next trip (or below, when the walk stops here)
           steps++;
           tot += bw;
+          if (logging) {                           // the k1-mer goes into the walk's log (whoever gets this far claims it)
+            const bool need = lg_k == LOG_PER && !lg_lost;
+            const uint32_t nc = log_chunk(need);
+            if (need) {
+              if (nc == NONE32) lg_lost = true;
+              else { A.logpool[(uint64_t)nc * LOG_WORDS] = lg_chunk; lg_chunk = nc; lg_k = 0; }
+            }
+            if (!lg_lost) { A.logpool[(uint64_t)lg_chunk * LOG_WORDS + 1 + lg_k] = nbest; lg_k++; }
+          }
           if (pos >= A.promote_steps) {            // long after all: a wavefront takes over from here (memos, 64 steps a trip)
             note_claim(A, seen, r);
             seen = claim_node(A, nbest, r, pos);
@@ -859,6 +903,7 @@ __global__ __launch_bounds__(WBLK) void ext_walk_kernel(WalkArgs A, uint64_t n_w
     A.nr_out[r] = isvoid ? UNCLAIMED : nr;
     A.nl_out[r] = nl;
     A.totw_out[r] = tot;
+    if (logging) { A.log_head[r] = lg_lost ? LOG_LOST : lg_chunk; A.log_cnt[r] = (uint8_t)(lg_chunk == NONE32 ? 0u : lg_k); }      // (a walk that took no step: NONE32 -- its seed is all it holds)
     mysteps = nr + nl;
     // debug: the longest walk of the launch and how long it took (steps << 32 | ticks of 10 ns): a bulk round cannot end before it
     if (A.dbg && mysteps >= 64) atomicMax(&A.dbg[12], ((unsigned long long)mysteps << 32) | ((__builtin_amdgcn_s_memrealtime() - t_begin) & 0xFFFFFFFFULL));
@@ -1308,7 +1353,8 @@ __global__ __launch_bounds__(1024) void ext_plan_kernel(uint32_t* nr, uint32_t* 
                                 const u64* __restrict__ fresh_claim, const uint32_t* __restrict__ order, uint64_t* __restrict__ totw,
                                 const Rec* __restrict__ rec, uint32_t settle_hops, uint8_t* __restrict__ settled,
                                 unsigned long long* __restrict__ n_settled, uint8_t* __restrict__ robsat = nullptr,
-                                unsigned long long* __restrict__ n_robsat = nullptr) {
+                                unsigned long long* __restrict__ n_robsat = nullptr, const uint32_t* __restrict__ log_head = nullptr,
+                                unsigned long long* __restrict__ rel_steps = nullptr) {
   // ns here = current rank limit (walks >= limit have not started yet); walks < frozen are final and never run
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + frozen;
   const bool isd_all = r < ns && dirty[r];
@@ -1356,8 +1402,16 @@ __global__ __launch_bounds__(1024) void ext_plan_kernel(uint32_t* nr, uint32_t* 
     // ... of them the ones that hold claims (a record of a live walk): with none, the round's begin pass has nothing to release
     // (counted: the holders WITHOUT a current memo -- with none of those, the dirty walks release their claims themselves, from
     // their memos: ext_release_memo_kernel)
-    const unsigned long long hm = __ballot(isd_all && nr[r] != UNCLAIMED && mvalid[r] != 2);
+    // (... nor a claim log: a walk that last ran in a bulk round gives its claims back through the log it wrote there)
+    const bool holds = isd_all && nr[r] != UNCLAIMED;
+    const bool has_log = holds && mvalid[r] != 2 && log_head && log_head[r] != LOG_LOST;      // (NONE32: it took no step -- its seed is all it holds)
+    const unsigned long long hm = __ballot(holds && mvalid[r] != 2 && !has_log);
     if (lane == 0 && hm) atomicAdd(&bh, (unsigned long long)__popcll(hm));
+    if (rel_steps) {                                               // the claims a targeted release would have to visit
+      unsigned long long st = holds ? (unsigned long long)nr[r] + nl[r] + 1ULL : 0ULL;
+      for (int o = 32; o > 0; o >>= 1) st += __shfl_down(st, o, 64);
+      if (lane == 0 && st) atomicAdd(rel_steps, st);
+    }
     if (robsat) {      // (development, SHN_EXT_XTIME: of those, the walks that were robbed while they sat out -- their chain of claims has a gap)
       const unsigned long long rm = __ballot(isd_all && nr[r] != UNCLAIMED && mvalid[r] != 2 && robsat[r]);
       if (lane == 0 && rm) atomicAdd(n_robsat, (unsigned long long)__popcll(rm));
@@ -1382,12 +1436,16 @@ __global__ void ext_memo_plan_kernel(uint8_t* __restrict__ ran, uint8_t* __restr
                                      const uint32_t* __restrict__ nr, const uint32_t* __restrict__ nl, const uint32_t* __restrict__ order,
                                      uint32_t frozen, uint32_t limit, uint64_t* __restrict__ moff, uint32_t* __restrict__ mR,
                                      uint32_t* __restrict__ mL, uint8_t* __restrict__ mvalid, uint8_t* __restrict__ fill,
-                                     uint32_t* __restrict__ pool, unsigned long long* __restrict__ cursor, uint64_t pool_cap, uint32_t memo_min) {
+                                     uint32_t* __restrict__ pool, unsigned long long* __restrict__ cursor, uint64_t pool_cap, uint32_t memo_min,
+                                     uint32_t* __restrict__ log_head = nullptr) {
   uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x + frozen;
   if (r >= limit) return;
   const uint8_t did_run = dirty[r];              // end-of-round bookkeeping: who ran, clean slate for the marks
   ran[r] = did_run;
   dirty[r] = 0;
+  // (a walk that ran in a round without logging -- a round that makes memos -- holds other claims than its log says; one that took
+  // no step holds its seed and nothing else: the empty log says so -- such a walk gets no memo slot either)
+  if (log_head && did_run && memo_min != 0xFFFFFFFFu) log_head[r] = (nr[r] != UNCLAIMED && nr[r] + nl[r] == 0) ? NONE32 : LOG_LOST;
   uint8_t f = 0;
   if (did_run && nr[r] != UNCLAIMED) {
     const uint32_t R = nr[r], L = nl[r];
@@ -1412,11 +1470,30 @@ __global__ void ext_memo_plan_kernel(uint8_t* __restrict__ ran, uint8_t* __restr
 __global__ __launch_bounds__(64) void ext_release_memo_kernel(const uint32_t* __restrict__ long_list, uint64_t n_long, const uint32_t* __restrict__ short_list,
                                                               uint64_t n_short, const uint32_t* __restrict__ nr, const uint64_t* __restrict__ moff,
                                                               const uint32_t* __restrict__ mR, const uint32_t* __restrict__ mL, const uint32_t* __restrict__ pool,
-                                                              u64* claim, uint8_t* __restrict__ chunk) {
+                                                              u64* claim, uint8_t* __restrict__ chunk, const uint8_t* __restrict__ mvalid = nullptr,
+                                                              const uint32_t* __restrict__ order = nullptr, const uint32_t* __restrict__ logpool = nullptr,
+                                                              const uint32_t* __restrict__ log_head = nullptr, const uint8_t* __restrict__ log_cnt = nullptr) {
   const uint64_t idx = blockIdx.x;
   if (idx >= n_long + n_short) return;
   const uint32_t r = idx < n_long ? long_list[idx] : short_list[idx - n_long];
   if (nr[r] == UNCLAIMED) return;                                        // void: it holds nothing
+  if (mvalid && mvalid[r] != 2) {
+    // no current memo: the walk last ran in a bulk round and wrote a claim log there -- its seed, then the chunks from the last one
+    // back; a k1-mer of the log that is no longer the walk's (a lower rank took it) stays as it is
+    auto give_back = [&](uint32_t node) {
+      const u64 c = __hip_atomic_load(&claim[node], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (RANK(c) == r && atomicCAS(&claim[node], c, UNCLAIMED64) == c && chunk) chunk[node >> CHUNK_SHIFT] = 1;
+    };
+    if (threadIdx.x == 0) give_back(order[r]);
+    uint32_t ch = log_head[r], cnt = log_cnt[r];
+    while (ch != NONE32 && ch != LOG_LOST) {
+      const uint32_t* c = logpool + (uint64_t)ch * LOG_WORDS;
+      if (threadIdx.x >= 1 && threadIdx.x <= cnt) give_back(c[threadIdx.x]);
+      ch = c[0];
+      cnt = LOG_PER;
+    }
+    return;
+  }
   const uint64_t off = moff[r];
   const uint32_t R = mR[r], L = mL[r];
   for (uint32_t j = threadIdx.x; j <= R + L; j += 64) {
@@ -2333,7 +2410,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   // scratch: claim snapshot (d_claim2), memo pool + per-k1-mer hints, per-walk plan arrays
   void *ppool, *pplan;
   if ((rc = g_shn_ws[27].get(pool_cap * 4, &ppool)) ||
-      (rc = g_shn_ws[28].get((ns + 1) * (8 + 4 * 9 + 1 + 1 + 1 + 1 + 1 + 1) + 64, &pplan))) { shn_ext_destroy(e); return rc; }
+      (rc = g_shn_ws[28].get((ns + 1) * (8 + 4 * 10 + 1 + 1 + 1 + 1 + 1 + 1 + 1) + 64, &pplan))) { shn_ext_destroy(e); return rc; }
   u64 *claim = e->d_claim, *snap = e->d_claim2;
   uint32_t* pool = (uint32_t*)ppool;
   uint64_t* moff = (uint64_t*)pplan;
@@ -2346,13 +2423,16 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   uint32_t* res_cur = promo_list + ns + 1;
   uint32_t* res_info = res_cur + ns + 1;
   uint32_t* owned = res_info + ns + 1;
-  uint8_t* mvalid = (uint8_t*)(owned + ns + 1);
+  uint32_t* log_head = owned + ns + 1;                       // claim logs: a walk's last chunk (LOG_LOST: none)
+  uint8_t* mvalid = (uint8_t*)(log_head + ns + 1);
   uint8_t* fill = mvalid + ns + 1;
   uint8_t* dirty = fill + ns + 1;
   uint8_t* ran = dirty + ns + 1;
   uint8_t* robbed = ran + ns + 1;
   uint8_t* settled = robbed + ns + 1;     // walks that can never survive (ext_chain_has_lower): void for good, never launched
+  uint8_t* log_cnt = settled + ns + 1;    // claim logs: entries of a walk's last chunk
   TRYE(hipMemsetAsync(robbed, 0, 2 * (ns + 1), s));
+  TRYE(hipMemsetAsync(log_head, 0xFE, (ns + 1) * 4, s));
   uint8_t* robsat = nullptr;              // (development, SHN_EXT_XTIME: walks robbed while they sat out, until they run again)
   struct RobsatFree { uint8_t** p; ~RobsatFree() { if (*p) shn_dev_free(*p); } } robsat_free{&robsat};
   if (getenv("SHN_EXT_XTIME")) { TRYE(shn_dev_malloc(&robsat, ns + 1)); TRYE(hipMemsetAsync(robsat, 0, ns + 1, s)); }
@@ -2433,6 +2513,20 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   // stops them.  A launch's time follows its steps' random lines (~5.5 per step at ~20 G lines/s; 623 M steps for the 422 M k1-mers finally claimed:
   // tools/walk_waste_r06.py), not its walks.  Off by default.
   const uint32_t settle_hops = tune("SHN_EXT_SETTLE_HOPS", 0);
+  // Claim logs (round 6; SHN_EXT_LOGS=0: off).  The begin pass streams every claim (11.6 GB at BASELINE configs[2], 2.7 ms) to find
+  // those of the walks that re-run; 22 of a step's 25 rounds re-run walks that hold fewer than ten million claims between them, and
+  // what kept them on the stream was a handful of claim holders per round WITHOUT a memo: walks that last ran in a bulk round (no
+  // memos there: rebuilding them from the claims is a scattered store per claim).  Their chains are intact but thousands of steps
+  // long -- following one from its seed is two dependent round trips a step (SHN_EXT_XTIME=1 says how many and how long).  So the
+  // bulk walker writes the k1-mers it claims into a log of its own as it goes (a 4-byte store per step into a 32-byte chunk; a
+  // wavefront reserves 64 chunks with one atomic), and a round whose claim holders all have a current memo or a log, and few
+  // enough claims to give back, releases through those (ext_release_memo_kernel) instead of the stream.
+  const bool use_logs = tune("SHN_EXT_LOGS", 1) != 0 && bulk_promote == 0 && ns > 0;
+  const unsigned long long targeted_max_steps = getenv("SHN_EXT_TARGETED_MAX") ? strtoull(getenv("SHN_EXT_TARGETED_MAX"), nullptr, 10) : (12ULL << 20);
+  uint32_t* logpool = nullptr;
+  struct LogFree { uint32_t** p; ~LogFree() { if (*p) shn_dev_free(*p); } } log_free{&logpool};
+  const uint64_t log_cap = use_logs ? std::min<uint64_t>(2 * n / 4 + (1u << 16), 0x7FFFFFF0ULL) : 0;
+  if (use_logs) { TRYE(shn_dev_malloc(&logpool, log_cap * LOG_WORDS * 4)); TRYE(hipMemsetAsync(d_cnt + 26, 0, 8, s)); }
   const uint32_t fresh_split = std::max<uint32_t>(1, std::min<uint32_t>(16, tune("SHN_EXT_FRESH_SPLIT", 1)));   // sub-launches of a block's first (bulk) round (measured at configs[2]: 1 / 4 / 7 / 10 -> 184 / 176 / 209 / 248 ms: every sub-launch waits for its longest walk; off)
   const uint32_t fresh_split_min = tune("SHN_EXT_FRESH_SPLIT_MIN", 65536);                                       // ... of blocks of at least this many walks            // a block's first round settles the walks whose seed an earlier block holds (ext_plan_kernel)
   unsigned long long expect_dirty = limit;
@@ -2444,13 +2538,16 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     const bool dense = bulk && expect_dirty >= dense_min;
     // classify the dirty walks of the open block; a block without dirty walks is consistent = final
     TRYE(hipMemsetAsync(d_cnt + 2, 0, 32, s));
+    TRYE(hipMemsetAsync(d_cnt + 24, 0, 8, s));
     if (limit > frozen)
       hipLaunchKernelGGL(ext_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 1024)), dim3(1024), 0, s, e->d_nr, e->d_nl, (uint64_t)limit, frozen,
                          mvalid, mR, mL, dirty, long_list, short_list, d_cnt + 2, bulk ? 0xFFFFFFFFu : long_walk, coarse,
                          (fresh_block && frozen > 0 && prepass) ? (const u64*)claim : (const u64*)nullptr, e->d_order, e->d_totw,
-                         (const Rec*)e->d_rec, fresh_block ? settle_hops : 0u, settled, d_cnt + 20, robsat, d_cnt + 21);
+                         (const Rec*)e->d_rec, fresh_block ? settle_hops : 0u, settled, d_cnt + 20, robsat, d_cnt + 21,
+                         use_logs ? (const uint32_t*)log_head : (const uint32_t*)nullptr, d_cnt + 24);
     // (pinned host memory: a pageable destination costs a staging copy kernel per round)
     TRYE(hipMemcpyAsync(plan, d_cnt + 2, 32, hipMemcpyDeviceToHost, s));
+    TRYE(hipMemcpyAsync(plan + 7, d_cnt + 24, 8, hipMemcpyDeviceToHost, s));      // the claims the dirty walks hold (by their records)
     TRYE(hipStreamSynchronize(s));
     expect_dirty = plan[3];
     if (plan[3] == 0) {
@@ -2498,14 +2595,18 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     // snapshot, then release the claims of the walks that re-run this round
     // (a block that has just opened holds no claims yet: with the snapshot up to date there is nothing to release and nothing to copy)
     // (... and so does a round none of whose dirty walks holds a claim -- void walks looking at their seed again: plan[1])
-    const bool memo_release = !fresh_block && !dense && skip_idle_begin && plan[1] == 0 && plan[0] + plan[2] <= memo_release_max;
+    const bool memo_release = !fresh_block && !dense && skip_idle_begin && plan[1] == 0 &&
+                              (use_logs ? plan[7] <= targeted_max_steps : plan[0] + plan[2] <= memo_release_max);
+    const bool snap_was_current = snap_current;
+    const bool memo_release_done = !fresh_block && memo_release && precise_marks && snap_current;
     if ((fresh_block || memo_release) && precise_marks && snap_current) {
       TRYE(hipMemsetAsync(d_cnt + 6, 0, 16, s)); TRYE(hipMemsetAsync(d_cnt + 13, 0, 16, s));
       if (!fresh_block) {
         n_begin_skipped++;
         if (plan[0] + plan[2])
           hipLaunchKernelGGL(ext_release_memo_kernel, dim3((uint32_t)(plan[0] + plan[2])), dim3(64), 0, s, long_list, (uint64_t)plan[0], short_list, (uint64_t)plan[2],
-                             e->d_nr, moff, mR, mL, pool, claim, chunk);
+                             e->d_nr, moff, mR, mL, pool, claim, chunk, (const uint8_t*)mvalid, (const uint32_t*)e->d_order, (const uint32_t*)logpool,
+                             (const uint32_t*)log_head, (const uint8_t*)log_cnt);
       }
     }
     else {
@@ -2525,6 +2626,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     A.robbed = robbed;
     A.seed_check = seed_check;
     A.first_look = first_look;
+    A.logpool = (use_logs && bulk) ? logpool : nullptr; A.log_head = log_head; A.log_cnt = log_cnt; A.log_cursor = d_cnt + 26; A.log_cap = log_cap;
     A.steps_counter = d_cnt + 1; A.fresh_steps_counter = d_cnt + 16; A.wave_steps_counter = d_cnt + 64; A.dbg = (getenv("SHN_DEBUG") || getenv("SHN_EXT_XTIME")) ? d_cnt + 32 : nullptr;
     // long (wave per walk) and short (thread per walk) kernels are independent: overlap them on two streams
     if (plan[0]) {
@@ -2578,6 +2680,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
       TRYE(hipStreamSynchronize(s));
       unsigned long long nrs[3] = {0, 0, 0}; TRYE(hipMemcpyAsync(nrs, d_cnt + 21, 24, hipMemcpyDeviceToHost, s)); TRYE(hipMemsetAsync(d_cnt + 21, 0, 24, s)); TRYE(hipStreamSynchronize(s));
       fprintf(stderr, "[shn_extend] XTIME round %d [%u,%u): of the claim holders without a memo %llu were robbed while they sat out; their walks: longest %llu steps, %llu steps in all\n", it + 1, frozen, limit, nrs[0], nrs[1], nrs[2]);
+      fprintf(stderr, "[shn_extend] XTIME round %d: release %s (claims to give back by the records: %llu; bulk %d dense %d fresh %d snapshot current %d)\n", it + 1,
+              was_fresh ? "none (a new block)" : memo_release_done ? "through memos / logs" : "the begin pass", plan[7], (int)bulk, (int)dense, (int)was_fresh, (int)snap_was_current);
       fprintf(stderr, "[shn_extend] XTIME round %d: %llu dirty walks, %llu of them hold claims without a current memo (rounds released through memos so far: %d); thread walker %llu walks, %.2f ms, steps so far %llu; longest walk %llu steps in %.2f ms (%.2f us per step)\n", it + 1, plan[3], plan[1], n_begin_skipped, plan[2],
               ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6 - x_t0, st, lw >> 32, (double)(lw & 0xFFFFFFFFULL) * 1e-5, (lw >> 32) ? (double)(lw & 0xFFFFFFFFULL) * 1e-2 / (double)(lw >> 32) : 0.0);
     }
@@ -2604,7 +2708,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
     // who has to run next round?  walks whose view changed (mark) + walks that lost a claim race (verify);
     // the walks that ran get their memo rebuilt from the claims
     hipLaunchKernelGGL(ext_memo_plan_kernel, dim3((uint32_t)cdiv(limit - frozen, 256)), dim3(256), 0, s, ran, dirty, e->d_nr, e->d_nl, e->d_order, frozen, limit,
-                       moff, mR, mL, mvalid, fill, pool, d_cnt + 10, pool_cap, bulk ? 0xFFFFFFFFu : memo_min);
+                       moff, mR, mL, mvalid, fill, pool, d_cnt + 10, pool_cap, bulk ? 0xFFFFFFFFu : memo_min, use_logs ? log_head : (uint32_t*)nullptr);
     if (skip_mark) { snap_current = false; if (!dense) TRYE(hipMemsetAsync(chunk, 0, n_chunks, s)); }
     else
     { TimerRegion tk(ctx, T_EXT_MARK);
