@@ -310,6 +310,10 @@ hipError_t shn_dev_malloc_on(void** p, size_t bytes, hipStream_t stream);
 void shn_dev_free(void* p);                  // (the block stays ordered behind its own stream and the calling thread's current stream: core.hip)
 void shn_dev_free_on(void* p, hipStream_t stream);
 void shn_dev_trim();                         // give the cached blocks back to the driver
+// hipMalloc for the objects that outlive a call (read sets): when the driver says no, what the caching allocator keeps for the next
+// call and the workspaces of earlier stages are given back first
+hipError_t shn_hip_malloc(void** p, size_t bytes);
+template <class T> hipError_t shn_hip_malloc(T** p, size_t bytes) { return shn_hip_malloc((void**)p, bytes); }
 template <class T> static inline hipError_t shn_dev_malloc(T** p, size_t bytes) { return shn_dev_malloc_raw((void**)p, bytes); }
 void shn_stream_retired(hipStream_t s);      // a stream about to be destroyed (synchronised by the caller): no block waits on it any more
 void shn_use_stream(hipStream_t s);          // the calling host thread works on this stream from now on (what the allocator orders frees against)

@@ -161,6 +161,17 @@ hipError_t shn_dev_malloc_on(void** p, size_t bytes, hipStream_t stream) {
   return hipSuccess;
 }
 hipError_t shn_dev_malloc_raw(void** p, size_t bytes) { return shn_dev_malloc_on(p, bytes, t_stream); }
+hipError_t shn_hip_malloc(void** p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess) return e;
+  (void)hipGetLastError();
+  shn_dev_trim();
+  e = hipMalloc(p, bytes);
+  if (e == hipSuccess) return e;
+  (void)hipGetLastError();
+  shn_ws_release_idle();
+  return hipMalloc(p, bytes);
+}
 void shn_dev_free_on(void* p, hipStream_t stream) {
   if (!p) return;
   std::unique_lock<std::mutex> lk(g_blocks_mu);
@@ -511,21 +522,21 @@ extern "C" int shn_reads_create(shn_ctx* ctx, const uint8_t* bytes, const uint64
   auto cleanup = [&]() { if (d_bytes) hipFree(d_bytes); if (d_boff) hipFree(d_boff); };
 #define TRY2(e) do { hipError_t _e = (e); if (_e != hipSuccess) { cleanup(); shn_reads_destroy(r); \
       return shn_fail(SHN_ERR_HIP, std::string(#e) + ": " + hipGetErrorString(_e)); } } while (0)
-  TRY2(hipMalloc(&r->d_words, (r->n_words + 2) * 8));
-  TRY2(hipMalloc(&r->d_mask, (r->n_words / 2 + 2) * 8));
+  TRY2(shn_hip_malloc(&r->d_words, (r->n_words + 2) * 8));
+  TRY2(shn_hip_malloc(&r->d_mask, (r->n_words / 2 + 2) * 8));
   TRY2(hipMemsetAsync(r->d_words, 0, (r->n_words + 2) * 8, s));
   TRY2(hipMemsetAsync(r->d_mask, 0, (r->n_words / 2 + 2) * 8, s));
   if (n_reads) {
-    TRY2(hipMalloc(&d_bytes, total_bytes ? total_bytes : 1));
+    TRY2(shn_hip_malloc(&d_bytes, total_bytes ? total_bytes : 1));
     TRY2(hipMemcpyAsync(d_bytes, bytes + (offsets ? offsets[0] : 0), total_bytes, hipMemcpyHostToDevice, s));
     if (offsets) {
       std::vector<uint64_t> rel(n_reads + 1);
       for (uint64_t i = 0; i <= n_reads; i++) rel[i] = offsets[i] - offsets[0];
-      TRY2(hipMalloc(&d_boff, (n_reads + 1) * 8));
+      TRY2(shn_hip_malloc(&d_boff, (n_reads + 1) * 8));
       TRY2(hipMemcpyAsync(d_boff, rel.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, s));
-      TRY2(hipMalloc(&r->d_woff, (n_reads + 1) * 8));
+      TRY2(shn_hip_malloc(&r->d_woff, (n_reads + 1) * 8));
       TRY2(hipMemcpyAsync(r->d_woff, woff.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, s));
-      TRY2(hipMalloc(&r->d_len, n_reads * 4));
+      TRY2(shn_hip_malloc(&r->d_len, n_reads * 4));
       TRY2(hipStreamSynchronize(s));   // rel / woff are stack-owned vectors
     }
     {
@@ -535,9 +546,9 @@ extern "C" int shn_reads_create(shn_ctx* ctx, const uint8_t* bytes, const uint64
       hipLaunchKernelGGL(pack_kernel, dim3(blocks), dim3(256), 0, s, d_bytes, d_boff, r->d_woff, n_reads, fixed_len,
                          r->wpr, enc, r->d_words, r->d_mask, r->d_len, n_groups);
       unsigned long long* d_nbad = nullptr;
-      TRY2(hipMalloc(&d_nbad, 8));
+      TRY2(shn_hip_malloc(&d_nbad, 8));
       TRY2(hipMemsetAsync(d_nbad, 0, 8, s));
-      TRY2(hipMalloc(&r->d_bad, n_reads));
+      TRY2(shn_hip_malloc(&r->d_bad, n_reads));
       hipLaunchKernelGGL(bad_reads_kernel, dim3((uint32_t)cdiv(n_reads, 256)), dim3(256), 0, s, r->d_mask, r->d_woff,
                          n_reads, r->wpr, r->d_bad, d_nbad);
       unsigned long long nb = 0;
@@ -568,9 +579,9 @@ int shn_pack_fixed_codes(shn_ctx* ctx, const uint8_t* d_codes, uint64_t n, uint3
 int shn_reads_finish_fixed(shn_ctx* ctx, shn_reads* r) {
   hipStream_t s = ctx->stream; shn_use_stream(s);
   unsigned long long* d_nbad = nullptr;
-  HIP_TRY(hipMalloc(&d_nbad, 8));
+  HIP_TRY(shn_hip_malloc(&d_nbad, 8));
   hipError_t e = hipMemsetAsync(d_nbad, 0, 8, s);
-  if (e == hipSuccess) e = hipMalloc(&r->d_bad, r->n_reads ? r->n_reads : 1);
+  if (e == hipSuccess) e = shn_hip_malloc(&r->d_bad, r->n_reads ? r->n_reads : 1);
   unsigned long long nb = 0;
   if (e == hipSuccess && r->n_reads) {
     hipLaunchKernelGGL(bad_reads_kernel, dim3((uint32_t)cdiv(r->n_reads, 256)), dim3(256), 0, s, r->d_mask, (const uint64_t*)nullptr, r->n_reads, r->wpr,

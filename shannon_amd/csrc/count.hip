@@ -1040,8 +1040,8 @@ extern "C" int shn_table_lookup(shn_ctx* ctx, const shn_table* t, const uint64_t
   SHN_ENTER(ctx);
   hipStream_t s = ctx->stream; shn_use_stream(s);
   uint64_t* dq; uint32_t* dc;
-  HIP_TRY(hipMalloc(&dq, n * 8));
-  HIP_TRY(hipMalloc(&dc, n * 4));
+  HIP_TRY(shn_hip_malloc(&dq, n * 8));
+  HIP_TRY(shn_hip_malloc(&dc, n * 4));
   HIP_TRY(hipMemcpyAsync(dq, keys, n * 8, hipMemcpyHostToDevice, s));
   {
     TimerRegion tr(ctx, T_LOOKUP);

@@ -283,8 +283,8 @@ extern "C" int shn_reads_ingest(shn_ctx* ctx, const uint8_t* text, uint64_t n_by
   };
 #define TRYI(e) do { hipError_t _e = (e); if (_e != hipSuccess) { cleanup(); shn_reads_destroy(r); \
       return shn_fail(SHN_ERR_HIP, std::string("shn_reads_ingest: ") + #e + ": " + hipGetErrorString(_e)); } } while (0)
-  TRYI(hipMalloc(&r->d_words, (r->n_words + 2) * 8));
-  TRYI(hipMalloc(&r->d_mask, (r->n_words / 2 + 2) * 8));
+  TRYI(shn_hip_malloc(&r->d_words, (r->n_words + 2) * 8));
+  TRYI(shn_hip_malloc(&r->d_mask, (r->n_words / 2 + 2) * 8));
   TRYI(hipMemsetAsync(r->d_words + r->n_words, 0, 16, s));
   TRYI(hipMemsetAsync(r->d_mask + r->n_words / 2, 0, 16, s));
   if (pin_cap < cap * L) {

@@ -575,6 +575,33 @@ struct Graph {
                           tf1 - tf0, tf2 - tf1, tnow() - tf2, (unsigned long long)nh, si.keys.size());
       }
       if (gpu_ok) {
+        // the hits against the node texts (read_bridges: the read spells the whole node with a base to spare on either side) -- on the
+        // host threads that are free right now when there are many (the largest partition of BASELINE configs[2]: 415 k hits, 30-58 ms
+        // on one thread, with the other partitions long done): slices of the hit list in order, each thread's confirmed hits kept in
+        // order and appended slice by slice, so every node's list is what the one-thread loop makes
+        const unsigned want = nh >= 100000 ? (unsigned)std::min<uint64_t>(8, nh / 50000) : 1u;
+        const unsigned nt = want > 1 ? (unsigned)g_host_threads.take_free((int)want, g_partitions_running.load() - 1) : 1u;
+        struct GiveBackH { unsigned n; ~GiveBackH() { if (n) g_host_threads.release((int)n); } } give_back_h{want > 1 ? nt : 0u};
+        if (nt > 1) {
+          std::vector<std::vector<std::pair<int, RI>>> found(nt);
+          auto slice = [&](unsigned t) {
+            std::vector<std::pair<int, RI>>& out = found[t];
+            const uint64_t h0 = nh * t / nt, h1 = nh * (t + 1) / nt;
+            for (uint64_t h = h0; h < h1; h++) {
+              if (h + 12 < h1) prefetch_read((int)hr[h + 12]);
+              for (uint32_t q = si.goff[hi[h]]; q < si.goff[hi[h] + 1]; q++) {
+                const int x = si.occ[q].first;
+                if (read_bridges((int)hr[h], x, (int)hs[h])) out.push_back({x, RI((int)hr[h], (int)hs[h])});
+              }
+            }
+          };
+          std::vector<std::thread> th;
+          for (unsigned t = 1; t < nt; t++) th.emplace_back(slice, t);
+          slice(0);
+          for (auto& x : th) x.join();
+          for (unsigned t = 0; t < nt; t++) for (const auto& xr : found[t]) nreads[xr.first].push_back(xr.second);
+          return;
+        }
         for (uint64_t h = 0; h < nh; h++) {
           if (h + 12 < nh) prefetch_read((int)hr[h + 12]);
           for (uint32_t q = si.goff[hi[h]]; q < si.goff[hi[h] + 1]; q++) {
