@@ -198,6 +198,111 @@ __global__ void cg_decide_kernel(const unsigned long long* __restrict__ best, co
   if (changed) { acc[c] = a; atomicAdd(n_changed, 1ULL); }
 }
 
+// ---- rounds that re-evaluate FEW candidates (round 6).  The passes above stream every accepted window of the block's index -- 1.3 +
+// 0.8 + 0.4 + 0.3 ms a round at BASELINE configs[2] -- to find the windows of the handful of candidates whose view changed.  These
+// forms go the other way: a workgroup per listed candidate walks the candidate's own windows (base order) and finds each window's
+// place in the index through pos_of (base of the window -> its entry among the sorted shared windows) and the block's apos.
+// The work a window does is the work its index entry did above, so the decisions are the same.
+#define CG_NONE 0xFFFFFFFFu
+__global__ void cg_pos_of_kernel(const uint32_t* __restrict__ vals, uint64_t nv, uint32_t* __restrict__ pos_of) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (uint64_t)gridDim.x * blockDim.x) pos_of[vals[i]] = (uint32_t)i;
+}
+// the candidates of [lo, hi) whose flag is set, in any order
+__global__ void cg_list_kernel(const uint8_t* __restrict__ flag, uint32_t lo, uint32_t hi, uint32_t* __restrict__ list, uint32_t* __restrict__ n_list) {
+  const uint32_t c = lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < hi && flag[c]) list[atomicAdd(n_list, 1u)] = c;
+}
+// entry of window g in the block's index, or -1
+__device__ __forceinline__ int64_t cg_entry(const uint32_t* __restrict__ pos_of, const uint32_t* __restrict__ flag, const uint64_t* __restrict__ apos, uint64_t g) {
+  const uint32_t i = pos_of[g];
+  if (i == CG_NONE || !flag[i]) return -1;
+  return (int64_t)apos[i];
+}
+// cg_affected_kernel for a list of changed candidates
+__global__ void cg_affected_list_kernel(const uint32_t* __restrict__ clist, const uint32_t* __restrict__ n_c, const uint64_t* __restrict__ off, int r,
+                                        const uint32_t* __restrict__ pos_of, const uint32_t* __restrict__ flag, const uint64_t* __restrict__ apos,
+                                        const uint64_t* __restrict__ akey, const uint32_t* __restrict__ acand, uint64_t na, uint8_t* __restrict__ aff) {
+  for (uint32_t q = blockIdx.x; q < *n_c; q += gridDim.x) {
+    const uint32_t d = clist[q];
+    const uint64_t g0 = off[d], g1 = off[d + 1];
+    if (g1 - g0 < (uint64_t)r) continue;
+    for (uint64_t g = g0 + threadIdx.x; g + r <= g1; g += blockDim.x) {
+      const int64_t a = cg_entry(pos_of, flag, apos, g);
+      if (a < 0) continue;
+      const uint64_t key = akey[a];
+      for (uint64_t j = (uint64_t)a + 1; j < na && akey[j] == key; j++) { const uint32_t c = acand[j]; if (c != d) aff[c] = 1; }
+    }
+  }
+}
+// cg_clear_kernel for a list of affected candidates
+__global__ void cg_clear_list_kernel(const uint32_t* __restrict__ alist, const uint32_t* __restrict__ n_a, const uint64_t* __restrict__ off,
+                                     uint8_t* __restrict__ hit, unsigned long long* __restrict__ best, uint32_t* __restrict__ cov) {
+  for (uint32_t q = blockIdx.x; q < *n_a; q += gridDim.x) {
+    const uint32_t c = alist[q];
+    for (uint64_t g = off[c] + threadIdx.x; g < off[c + 1]; g += blockDim.x) hit[g] = 0;
+    if (threadIdx.x == 0) { best[c] = 0; cov[c] = 0; }
+  }
+}
+// cg_hits_kernel for a list of affected candidates
+__global__ void cg_hits_list_kernel(const uint32_t* __restrict__ alist, const uint32_t* __restrict__ n_a, const uint64_t* __restrict__ off, int r,
+                                    const uint32_t* __restrict__ pos_of, const uint32_t* __restrict__ flag, const uint64_t* __restrict__ apos,
+                                    const uint64_t* __restrict__ akey, const uint32_t* __restrict__ acand, uint32_t lo, const uint8_t* __restrict__ acc,
+                                    PairSlot* __restrict__ tab, uint64_t mask, uint32_t* __restrict__ overflow) {
+  for (uint32_t q = blockIdx.x; q < *n_a; q += gridDim.x) {
+    const uint32_t c = alist[q];
+    const uint64_t g0 = off[c], g1 = off[c + 1];
+    if (g1 - g0 < (uint64_t)r) continue;
+    for (uint64_t g = g0 + threadIdx.x; g + r <= g1; g += blockDim.x) {
+      const int64_t a = cg_entry(pos_of, flag, apos, g);
+      if (a < 0) continue;
+      const uint64_t key = akey[a];
+      const uint32_t pos = (uint32_t)(g - g0);
+      for (uint64_t j = (uint64_t)a; j-- > 0 && akey[j] == key;) {
+        const uint32_t p = acand[j];
+        if (p == c) continue;
+        if (p >= lo && !acc[p]) continue;
+        if (!pair_add(tab, mask, c, p, pos)) atomicOr(overflow, 1u);
+      }
+    }
+  }
+}
+// cg_cover_kernel + cg_covsum_kernel for a list of affected candidates: the windows whose r-mer the best parent holds, then the bases
+// under at least one of them
+__global__ void cg_cover_list_kernel(const uint32_t* __restrict__ alist, const uint32_t* __restrict__ n_a, const uint64_t* __restrict__ off, int r,
+                                     const uint32_t* __restrict__ pos_of, const uint32_t* __restrict__ flag, const uint64_t* __restrict__ apos,
+                                     const uint64_t* __restrict__ akey, const uint32_t* __restrict__ acand, const unsigned long long* __restrict__ best,
+                                     uint8_t* __restrict__ hit, uint32_t* __restrict__ cov) {
+  __shared__ uint32_t blk_cov;
+  for (uint32_t q = blockIdx.x; q < *n_a; q += gridDim.x) {
+    const uint32_t c = alist[q];
+    const unsigned long long b = best[c];
+    if (!b) continue;                                            // (uniform over the block: no hits, nothing covered; cov[c] was cleared)
+    const uint32_t bp = (uint32_t)(b & 0x1FFFFFu);
+    const uint64_t g0 = off[c], g1 = off[c + 1];
+    if (threadIdx.x == 0) blk_cov = 0;
+    __syncthreads();
+    if (g1 - g0 >= (uint64_t)r)
+      for (uint64_t g = g0 + threadIdx.x; g + r <= g1; g += blockDim.x) {
+        const int64_t a = cg_entry(pos_of, flag, apos, g);
+        if (a < 0) continue;
+        const uint64_t key = akey[a];
+        for (uint64_t j = (uint64_t)a; j-- > 0 && akey[j] == key;)
+          if (acand[j] == bp) { hit[g] = 1; break; }
+      }
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint64_t g = g0 + threadIdx.x; g < g1; g += blockDim.x) {
+      bool covered = false;
+      for (int d = 0; d < r && !covered; d++) { if (g < g0 + (uint64_t)d) break; covered = hit[g - d] != 0; }
+      mine += covered ? 1u : 0u;
+    }
+    if (mine) atomicAdd(&blk_cov, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && blk_cov) cov[c] = blk_cov;
+    __syncthreads();
+  }
+}
+
 // runs of equal keys that span two different contigs: flag every entry of such a run (the sort is stable and the
 // windows were generated contig by contig, so a run's first and last entries differ in contig iff the run does)
 __global__ void cg_shared_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint64_t n,
@@ -305,7 +410,7 @@ static int contig_stage_impl(shn_ctx* ctx, const uint8_t* bases, const uint8_t* 
     *out = G; guard.g = nullptr;
     return SHN_OK;
   }
-  uint64_t n_rounds = 0, n_blocks = 0;
+  uint64_t n_rounds = 0, n_blocks = 0, n_list_rounds = 0;
   {
     ShnDevBufs tmp(s);
     uint64_t* keys; uint32_t* vals; uint64_t nv = 0;
@@ -349,6 +454,14 @@ static int contig_stage_impl(shn_ctx* ctx, const uint8_t* bases, const uint8_t* 
     HIP_TRY(hipMemsetAsync(d_acc, 0, n_cand + 1, s));
     HIP_TRY(hipMemsetAsync(d_bestc, 0, (n_cand + 1) * 4, s));
     if (nv) hipLaunchKernelGGL(cg_scid_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, vals, d_cid, nv, d_scid);
+    // rounds that re-evaluate few candidates go candidate by candidate (cg_*_list_kernel): base of a window -> its sorted entry
+    const uint64_t list_max = getenv("SHN_CONTIG_LIST_MAX") ? strtoull(getenv("SHN_CONTIG_LIST_MAX"), nullptr, 10) : 20000;      // decisions changed in the round before (0: never)
+    uint32_t *d_pos_of = nullptr, *d_clist = nullptr, *d_alist = nullptr, *d_nlist = nullptr;
+    if (list_max && nv && nv < 0xFFFFFFF0ULL) {
+      HIP_TRY(tmp.get(&d_pos_of, (total + 1) * 4)); HIP_TRY(tmp.get(&d_clist, (n_cand + 1) * 4)); HIP_TRY(tmp.get(&d_alist, (n_cand + 1) * 4)); HIP_TRY(tmp.get(&d_nlist, 64));
+      HIP_TRY(hipMemsetAsync(d_pos_of, 0xFF, (total + 1) * 4, s));
+      hipLaunchKernelGGL(cg_pos_of_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, vals, nv, d_pos_of);
+    }
     int lg_slots = 22;
     while (lg_slots < 28 && (1ULL << lg_slots) < nv / 4) lg_slots++;
     if (getenv("SHN_CONTIG_PAIR_LOG2")) lg_slots = atoi(getenv("SHN_CONTIG_PAIR_LOG2"));     // (tests: start too small, grow)
@@ -374,10 +487,20 @@ static int contig_stage_impl(shn_ctx* ctx, const uint8_t* bases, const uint8_t* 
       HIP_TRY(hipMemsetAsync(d_aff + lo, 1, hi - lo, s));
       while (true) {
         unsigned long long changed = 0;
+        const bool by_list = round > 0 && incremental && d_pos_of && na && last_changed <= list_max;
+        const uint32_t lgrid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, last_changed * 8), 16384);
         if (round == 0 || !incremental) {
           HIP_TRY(hipMemsetAsync(d_best + lo, 0, (hi - lo) * 8, s));
           HIP_TRY(hipMemsetAsync(d_cov + lo, 0, (hi - lo) * 4, s));
           HIP_TRY(hipMemsetAsync(d_hit + off[lo], 0, off[hi] - off[lo], s));
+        } else if (by_list) {
+          n_list_rounds++;
+          HIP_TRY(hipMemsetAsync(d_aff + lo, 0, hi - lo, s));
+          HIP_TRY(hipMemsetAsync(d_nlist, 0, 8, s));
+          hipLaunchKernelGGL(cg_list_kernel, dim3((uint32_t)cdiv(hi - lo, CG_BLK)), dim3(CG_BLK), 0, s, d_chgf, (uint32_t)lo, (uint32_t)hi, d_clist, d_nlist);
+          hipLaunchKernelGGL(cg_affected_list_kernel, dim3(lgrid), dim3(CG_BLK), 0, s, d_clist, d_nlist, d_off, r, d_pos_of, d_flag, d_apos, d_akey, d_acand, na, d_aff);
+          hipLaunchKernelGGL(cg_list_kernel, dim3((uint32_t)cdiv(hi - lo, CG_BLK)), dim3(CG_BLK), 0, s, d_aff, (uint32_t)lo, (uint32_t)hi, d_alist, d_nlist + 1);
+          hipLaunchKernelGGL(cg_clear_list_kernel, dim3(lgrid), dim3(CG_BLK), 0, s, d_alist, d_nlist + 1, d_off, d_hit, d_best, d_cov);
         } else {
           HIP_TRY(hipMemsetAsync(d_aff + lo, 0, hi - lo, s));
           hipLaunchKernelGGL(cg_affected_kernel, dim3(grid_for(na)), dim3(CG_BLK), 0, s, d_akey, d_acand, na, (uint32_t)lo, d_chgf, d_aff);
@@ -398,6 +521,10 @@ static int contig_stage_impl(shn_ctx* ctx, const uint8_t* bases, const uint8_t* 
           while (true) {                             // (the pair table grows until the round's pairs fit)
             HIP_TRY(hipMemsetAsync(d_tab, 0, sizeof(PairSlot) << lg_use, s));
             HIP_TRY(hipMemsetAsync(d_ovf, 0, 4, s));
+            if (by_list)
+              hipLaunchKernelGGL(cg_hits_list_kernel, dim3(lgrid), dim3(CG_BLK), 0, s, d_alist, d_nlist + 1, d_off, r, d_pos_of, d_flag, d_apos, d_akey, d_acand,
+                                 (uint32_t)lo, d_acc, d_tab, (1ULL << lg_use) - 1, d_ovf);
+            else
             { TimerRegion th(ctx, T_CG_HITS); th.bytes(na * 16);                     // every accepted window: key 8 + candidate 4 + value 4 (the pair table: a few per cent of them)
               hipLaunchKernelGGL(cg_hits_kernel, dim3(grid_for(na)), dim3(CG_BLK), 0, s, d_akey, d_acand, d_aval, na, d_off, (uint32_t)lo, d_acc, d_aff,
                                  d_tab, (1ULL << lg_use) - 1, d_ovf); }
@@ -412,9 +539,14 @@ static int contig_stage_impl(shn_ctx* ctx, const uint8_t* bases, const uint8_t* 
             HIP_TRY(tmp.get(&d_tab, sizeof(PairSlot) << lg_slots));
           }
           hipLaunchKernelGGL(cg_best_kernel, dim3(grid_for(1ULL << lg_use)), dim3(CG_BLK), 0, s, d_tab, 1ULL << lg_use, d_best);
+          if (by_list)
+            hipLaunchKernelGGL(cg_cover_list_kernel, dim3(lgrid), dim3(CG_BLK), 0, s, d_alist, d_nlist + 1, d_off, r, d_pos_of, d_flag, d_apos, d_akey, d_acand, d_best,
+                               d_hit, d_cov);
+          else {
           { TimerRegion tv(ctx, T_CG_COVER); tv.bytes(na * 17);                       // the same 16 bytes + the hit byte of the window's base
             hipLaunchKernelGGL(cg_cover_kernel, dim3(grid_for(na)), dim3(CG_BLK), 0, s, d_akey, d_acand, d_aval, na, (uint32_t)lo, d_best, d_aff, d_hit); }
           hipLaunchKernelGGL(cg_covsum_kernel, dim3(grid_for(off[hi] - off[lo])), dim3(CG_BLK), 0, s, d_hit, d_cid, d_off, off[lo], off[hi], r, d_aff, d_cov);
+          }
         }
         hipLaunchKernelGGL(cg_decide_kernel, dim3((uint32_t)cdiv(hi - lo, CG_BLK)), dim3(CG_BLK), 0, s, d_best, d_cov, d_off, (uint32_t)lo, (uint32_t)hi, f,
                            d_aff, d_acc, d_chgf, d_bestc, d_chg);
@@ -447,8 +579,8 @@ static int contig_stage_impl(shn_ctx* ctx, const uint8_t* bases, const uint8_t* 
   std::vector<int32_t> use(n_cand);
   int32_t n_acc = 0;
   for (uint64_t c = 0; c < n_cand; c++) { use[c] = acc[c] ? ++n_acc : 0; accepted_out[c] = use[c]; }
-  if (dbg) fprintf(stderr, "[contig_stage] %llu candidates (%llu bases): %llu blocks, %llu rounds, accepted %d\n",
-                   (unsigned long long)n_cand, (unsigned long long)total, (unsigned long long)n_blocks, (unsigned long long)n_rounds, n_acc);
+  if (dbg) fprintf(stderr, "[contig_stage] %llu candidates (%llu bases): %llu blocks, %llu rounds (%llu of them candidate by candidate), accepted %d\n",
+                   (unsigned long long)n_cand, (unsigned long long)total, (unsigned long long)n_blocks, (unsigned long long)n_rounds, (unsigned long long)n_list_rounds, n_acc);
   lap("duplicate_check rounds (GPU)");
 
   // ---- contig_connections: K-mers occurring in two different accepted contigs
