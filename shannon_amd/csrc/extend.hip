@@ -2525,7 +2525,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   const unsigned long long targeted_max_steps = getenv("SHN_EXT_TARGETED_MAX") ? strtoull(getenv("SHN_EXT_TARGETED_MAX"), nullptr, 10) : (12ULL << 20);
   uint32_t* logpool = nullptr;
   struct LogFree { uint32_t** p; ~LogFree() { if (*p) shn_dev_free(*p); } } log_free{&logpool};
-  const uint64_t log_cap = use_logs ? std::min<uint64_t>(2 * n / 4 + (1u << 16), 0x7FFFFFF0ULL) : 0;
+  uint64_t log_cap = use_logs ? std::min<uint64_t>(2 * n / 4 + (1u << 16), 0x7FFFFFF0ULL) : 0;
+  if (use_logs && getenv("SHN_EXT_LOG_CHUNKS")) log_cap = std::max<uint64_t>(LOG_SLAB, std::min<uint64_t>(log_cap, strtoull(getenv("SHN_EXT_LOG_CHUNKS"), nullptr, 10)));   // (tests: a pool that runs out -- the walks' logs are void and their rounds fall back to the begin pass)
   if (use_logs) { TRYE(shn_dev_malloc(&logpool, log_cap * LOG_WORDS * 4)); TRYE(hipMemsetAsync(d_cnt + 26, 0, 8, s)); }
   const uint32_t fresh_split = std::max<uint32_t>(1, std::min<uint32_t>(16, tune("SHN_EXT_FRESH_SPLIT", 1)));   // sub-launches of a block's first (bulk) round (measured at configs[2]: 1 / 4 / 7 / 10 -> 184 / 176 / 209 / 248 ms: every sub-launch waits for its longest walk; off)
   const uint32_t fresh_split_min = tune("SHN_EXT_FRESH_SPLIT_MIN", 65536);                                       // ... of blocks of at least this many walks            // a block's first round settles the walks whose seed an earlier block holds (ext_plan_kernel)

@@ -410,7 +410,14 @@ def test_gpu_contig_stage_on_many_genes(ctx):
                                  {"SHN_EXT_BULK": "1", "SHN_EXT_PROMOTE_BULK": "5", "SHN_EXT_DENSE": "1"}, {"SHN_EXT_BULK": "1", "SHN_EXT_PREPASS": "0"},
                                  {"SHN_EXT_PREPASS": "0"}, {"SHN_EXT_MEMO_RELEASE": "0"}, {"SHN_EXT_MEMO_RELEASE_MAX": "3"}, {"SHN_EXT_FIRST_LOOK": "1", "SHN_EXT_BULK": "1"},
                                  {"SHN_EXT_BULK": "1", "SHN_EXT_FRESH_SPLIT": "5", "SHN_EXT_FRESH_SPLIT_MIN": "32"},
-                                 {"SHN_EXT_BULK": "1", "SHN_EXT_FRESH_SPLIT": "3", "SHN_EXT_FRESH_SPLIT_MIN": "32", "SHN_EXT_DENSE": "1"}])
+                                 {"SHN_EXT_BULK": "1", "SHN_EXT_FRESH_SPLIT": "3", "SHN_EXT_FRESH_SPLIT_MIN": "32", "SHN_EXT_DENSE": "1"},
+                                 # claim logs (round 6): off; with every round a bulk round releasing through the logs; with a pool that
+                                 # runs out after a few hundred chunks (void logs: those rounds fall back to the begin pass); with rounds that
+                                 # may give back at most 50 claims through memos / logs
+                                 {"SHN_EXT_LOGS": "0"}, {"SHN_EXT_BULK": "1", "SHN_EXT_DENSE": "1000000000", "SHN_EXT_LOGS": "1"},
+                                 {"SHN_EXT_BULK": "1", "SHN_EXT_DENSE": "1000000000", "SHN_EXT_LOG_CHUNKS": "256"},
+                                 {"SHN_EXT_BULK": "1", "SHN_EXT_LOG_CHUNKS": "64"}, {"SHN_EXT_BULK": "2000", "SHN_EXT_TARGETED_MAX": "50"},
+                                 {"SHN_EXT_BULK": "2000", "SHN_EXT_DENSE": "1000000000"}])
 def test_bulk_rounds_give_the_same_contigs(ctx, env, monkeypatch):
     """Every round as a bulk round (thread walker only, no snapshot reads in a block's first round), with the begin / mark passes
     as they come, all dense or all following the line flags; the hand-over of long walks to the packed second launch
