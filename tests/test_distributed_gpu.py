@@ -48,6 +48,28 @@ def test_distributed_path_matches_single_process(group, paired, n_genes, seed):
         ctx.close()
 
 
+def test_array_gather_and_slice_ingest_on_rccl_with_device_tensors(group, tmp_path):
+    """the collectives round 6 added, on the "nccl" = RCCL backend with device tensors (one rank): exchange.all_gather_arrays (the
+    candidates of the sharded contig stage as tensors) and distributed.ingest_rank_slice (record counts + sparse index gathered,
+    the rank's stretch of the file through shn_reads_ingest) -- over gloo with four ranks in tests/test_ingest_ranks.py"""
+    import torch
+    from shannon_amd import exchange, distributed, device
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    mine = (rng.integers(0, 1 << 40, 1000).astype(np.int64), rng.integers(0, 1 << 60, 1000, dtype=np.uint64), np.arange(1001, dtype=np.uint64),
+            rng.integers(0, 4, 123457).astype(np.uint8), np.zeros(0, np.uint8))
+    got = exchange.all_gather_arrays(mine, exchange.coll_device(dev, None), None, "test arrays")
+    assert len(got) == 1 and all(a.dtype == b.dtype and np.array_equal(a, b) for a, b in zip(got[0], mine))
+    codes = rng.integers(0, 4, (5000, 100), dtype=np.uint8)
+    path = str(tmp_path / "r.fasta")
+    with open(path, "w") as f:
+        for i, row in enumerate(codes):
+            f.write(">r%d\n%s\n" % (i, np.frombuffer(b"ACGT", np.uint8)[row].tobytes().decode()))
+    st = {}
+    mats, n = distributed.ingest_rank_slice([path], 0, 1, None, exchange.coll_device(dev, None), stats=st)
+    assert n == 5000 and np.array_equal(mats[0], codes) and st["bytes_scanned"] <= 2 * os.path.getsize(path) + 64
+
+
 @pytest.mark.parametrize("paired,n_genes,seed,big", [(True, 12, 4, False), (False, 6, 5, True)])
 def test_owner_shard_path_on_rccl_with_one_rank(group, paired, n_genes, seed, big, monkeypatch):
     """SHN_OWNER_LABELS=2 sends a one-rank job through the N-rank path (shard by minimizer, queries, edges, component exchange): every
