@@ -1407,7 +1407,7 @@ __global__ __launch_bounds__(1024) void ext_plan_kernel(uint32_t* nr, uint32_t* 
     const bool has_log = holds && mvalid[r] != 2 && log_head && log_head[r] != LOG_LOST;      // (NONE32: it took no step -- its seed is all it holds)
     const unsigned long long hm = __ballot(holds && mvalid[r] != 2 && !has_log);
     if (lane == 0 && hm) atomicAdd(&bh, (unsigned long long)__popcll(hm));
-    if (rel_steps) {                                               // the claims a targeted release would have to visit
+    if (rel_steps && __ballot(holds)) {                           // the claims a targeted release would have to visit (most wavefronts hold no dirty walk at all)
       unsigned long long st = holds ? (unsigned long long)nr[r] + nl[r] + 1ULL : 0ULL;
       for (int o = 32; o > 0; o >>= 1) st += __shfl_down(st, o, 64);
       if (lane == 0 && st) atomicAdd(rel_steps, st);
