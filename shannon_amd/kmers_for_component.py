@@ -236,14 +236,26 @@ def build_partitions(res, K, partition_size=500, overload=2, penalty=5, repartit
     (new_components {name: [contig]}, components_broken {i: P})."""
     ufactor = int(1000.0 * overload - 1000.0)
     new_components, broken = {}, {}
+
+    def both_runs(i):
+        # gpmetis, then gpmetis again on the graph with the cut edges' weights multiplied (:207-237); one component's two runs depend on
+        # one another, the components do not: they run side by side (the native partitioner releases the GIL)
+        contigs, metis = res.big_components[i]
+        P = n_partitions(len(contigs), partition_size)
+        p1 = partition_graph(metis, P, ufactor)
+        return p1, (partition_graph(weight_updated_graph(metis, p1, penalty), P, ufactor) if repartition else None)
+    computed = None
+    if part_vectors is None and len(res.big_components) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(8, len(res.big_components))) as ex:
+            computed = list(ex.map(both_runs, range(len(res.big_components))))
     for i, (contigs, metis) in enumerate(res.big_components):
         P = n_partitions(len(contigs), partition_size)
         broken[i] = P
         if part_vectors is not None:
             p1, p2 = part_vectors[i]
         else:
-            p1 = partition_graph(metis, P, ufactor)
-            p2 = partition_graph(weight_updated_graph(metis, p1, penalty), P, ufactor) if repartition else None
+            p1, p2 = computed[i] if computed is not None else both_runs(i)
         for j, pid in enumerate(p1):
             new_components.setdefault("c%d_%s" % (i + 1, pid), []).append(contigs[j])
         if repartition and p2 is not None:
