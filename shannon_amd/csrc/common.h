@@ -334,6 +334,9 @@ int shn_device_scan_u32(shn_ctx* ctx, const uint32_t* d_in, uint64_t n, uint64_t
 int shn_sort_pairs(shn_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t* keys_tmp, uint32_t* vals_tmp, uint64_t n,
                    int bit_lo, int bit_hi);
 
+// the same for 64-bit words alone (a value packed under the key); *sorted = keys or keys_tmp, whichever holds the result
+int shn_sort_keys(shn_ctx* ctx, uint64_t* keys, uint64_t* keys_tmp, uint64_t n, int bit_lo, int bit_hi, uint64_t** sorted);
+
 static inline uint64_t cdiv(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
 // device buffers of one call on one stream, given back to the caching allocator when the call ends (the allocator orders the

@@ -61,6 +61,19 @@ __global__ void cg_keys_kernel(const uint8_t* __restrict__ bases, const uint32_t
   }
 }
 
+// k <= 16: the window's key above its base index in one word -- the sort then moves 8 bytes per entry and pass, not 12
+__global__ void cg_keys_packed_kernel(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ flag, const uint64_t* __restrict__ pos,
+                                      uint64_t total, int k, uint64_t* __restrict__ words, unsigned long long* __restrict__ n_bad) {
+  for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (uint64_t)gridDim.x * blockDim.x) {
+    if (!flag[g]) continue;
+    uint64_t key = 0;
+    bool bad = false;
+    for (int j = 0; j < k; j++) { const uint32_t c = cg_code(bases[g + j]); bad |= c > 3; key = (key << 2) | (uint64_t)(c & 3); }
+    if (bad) atomicAdd(n_bad, 1ULL);
+    words[pos[g]] = (key << 32) | (uint64_t)(uint32_t)g;
+  }
+}
+
 // candidate id + accepted flag of every sorted entry
 __global__ void cg_scid_kernel(const uint32_t* __restrict__ vals, const uint32_t* __restrict__ cid, uint64_t n, uint32_t* __restrict__ scid) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) scid[i] = cid[vals[i]];
@@ -315,6 +328,22 @@ __global__ void cg_shared_kernel(const uint64_t* __restrict__ keys, const uint32
     for (uint64_t j = i; j < e; j++) flag[j] = f;
   }
 }
+// the same two on packed words (key << 32 | base index)
+__global__ void cg_shared_packed_kernel(const uint64_t* __restrict__ words, uint64_t n, const uint32_t* __restrict__ cid, uint32_t* __restrict__ flag) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t w = words[i], key = w >> 32;
+    if (i && (words[i - 1] >> 32) == key) continue;            // not a run head
+    uint64_t e = i + 1, last = w;
+    while (e < n) { const uint64_t x = words[e]; if ((x >> 32) != key) break; last = x; e++; }
+    const uint32_t f = (e - i > 1 && cid[(uint32_t)w] != cid[(uint32_t)last]) ? 1u : 0u;
+    for (uint64_t j = i; j < e; j++) flag[j] = f;
+  }
+}
+__global__ void cg_compact_packed_kernel(const uint64_t* __restrict__ words, const uint32_t* __restrict__ flag, const uint64_t* __restrict__ pos, uint64_t n,
+                                         uint64_t* __restrict__ okeys, uint32_t* __restrict__ ovals) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    if (flag[i]) { const uint64_t w = words[i]; okeys[pos[i]] = w >> 32; ovals[pos[i]] = (uint32_t)w; }
+}
 __global__ void cg_compact_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, const uint32_t* __restrict__ flag,
                                   const uint64_t* __restrict__ pos, uint64_t n, uint64_t* __restrict__ okeys, uint32_t* __restrict__ ovals) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
@@ -355,6 +384,32 @@ int shn_sorted_windows(shn_ctx* ctx, ShnDevBufs& bufs, const uint8_t* d_bases, c
   if ((rc = shn_sort_pairs(ctx, k1, v1, k2, v2, nv, 0, 2 * k))) return rc;
   *keys = k1; *vals = v1;
   return SHN_OK;
+}
+
+// k <= 16: the same windows as words (key << 32 | base index), sorted by key, stable
+static int sorted_windows_packed(shn_ctx* ctx, ShnDevBufs& bufs, const uint8_t* d_bases, const uint64_t* d_off, const uint32_t* d_cid, uint64_t total, int k,
+                                 uint64_t** words, uint64_t* n_out) {
+  hipStream_t s = ctx->stream; shn_use_stream(s);
+  uint32_t* d_flag; uint64_t* d_pos; unsigned long long* d_bad;
+  HIP_TRY(bufs.get(&d_flag, (total + 1) * 4));
+  HIP_TRY(bufs.get(&d_pos, (total + 2) * 8));
+  HIP_TRY(bufs.get(&d_bad, 8));
+  HIP_TRY(hipMemsetAsync(d_bad, 0, 8, s));
+  hipLaunchKernelGGL(cg_flag_kernel, dim3(grid_for(total)), dim3(CG_BLK), 0, s, d_bases, d_off, d_cid, (const int32_t*)nullptr, total, k, d_flag);
+  uint64_t nv = 0;
+  int rc = shn_device_scan_u32(ctx, d_flag, total, d_pos, &nv);
+  if (rc) return rc;
+  *n_out = nv;
+  *words = nullptr;
+  if (!nv) return SHN_OK;
+  uint64_t *w1, *w2;
+  HIP_TRY(bufs.get(&w1, nv * 8)); HIP_TRY(bufs.get(&w2, nv * 8));
+  hipLaunchKernelGGL(cg_keys_packed_kernel, dim3(grid_for(total)), dim3(CG_BLK), 0, s, d_bases, d_flag, d_pos, total, k, w1, d_bad);
+  unsigned long long bad = 0;
+  HIP_TRY(hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (bad) return shn_fail(SHN_ERR_ARG, "shn_contig_stage: contig with a base outside ACGT");
+  return shn_sort_keys(ctx, w1, w2, nv, 32, 32 + 2 * k, words);
 }
 
 // Same contract as shn_cgraph_add on a fresh graph: candidates in seed order in one call; accepted_out[i] = 1-based accepted
@@ -413,11 +468,17 @@ static int contig_stage_impl(shn_ctx* ctx, const uint8_t* bases, const uint8_t* 
   uint64_t n_rounds = 0, n_blocks = 0, n_list_rounds = 0;
   {
     ShnDevBufs tmp(s);
-    uint64_t* keys; uint32_t* vals; uint64_t nv = 0;
+    uint64_t* keys = nullptr; uint32_t* vals = nullptr; uint64_t* words = nullptr; uint64_t nv = 0;
     int rc;
-    { TimerRegion ts(ctx, T_CG_SORT); rc = shn_sorted_windows(ctx, tmp, d_bases, d_off, d_cid, nullptr, total, r, &keys, &vals, &nv);
-      // per r-mer window of the candidates: its base read, (key 8 + value 4) written, then an LSD pass per 8 key bits that reads and writes the pair
-      ts.bytes(nv * (1 + 12 + (uint64_t)((2 * r + 7) / 8) * 24)); }
+    const bool shared_only = !(getenv("SHN_CONTIG_SHARED") && getenv("SHN_CONTIG_SHARED")[0] == '0');
+    // (r <= 16: the r-mer and the 32-bit base index of its window share one word through the sort; SHN_CONTIG_PACKED=0: pairs)
+    const bool packed = r <= 16 && shared_only && !(getenv("SHN_CONTIG_PACKED") && getenv("SHN_CONTIG_PACKED")[0] == '0');
+    { TimerRegion ts(ctx, T_CG_SORT);
+      rc = packed ? sorted_windows_packed(ctx, tmp, d_bases, d_off, d_cid, total, r, &words, &nv)
+                  : shn_sorted_windows(ctx, tmp, d_bases, d_off, d_cid, nullptr, total, r, &keys, &vals, &nv);
+      // per r-mer window of the candidates: its base read, (key 8 + value 4, or one word of 8) written, then an LSD pass per 8 key bits
+      // that reads and writes the entry
+      ts.bytes(packed ? nv * (1 + 8 + (uint64_t)((2 * r + 7) / 8) * 16) : nv * (1 + 12 + (uint64_t)((2 * r + 7) / 8) * 24)); }
     if (rc) return rc;
     lap("r-mer sort (GPU)");
     // Only the runs that span two different candidates matter from here on: a window whose r-mer no OTHER candidate holds has no hit
@@ -426,19 +487,24 @@ static int contig_stage_impl(shn_ctx* ctx, const uint8_t* bases, const uint8_t* 
     // per-block index and every round's passes (hits, cover, affected) then stream a quarter of the entries.  The same flag and
     // compaction as for the K-mer join below (stable sort + windows made candidate by candidate: a run spans two candidates iff
     // its first and last entries differ in candidate).  SHN_CONTIG_SHARED=0: all windows, as until round 6.
-    if (nv > 1 && !(getenv("SHN_CONTIG_SHARED") && getenv("SHN_CONTIG_SHARED")[0] == '0')) {
+    if (nv > 1 && shared_only) {
       uint32_t* d_f0; uint64_t* d_p0; uint64_t ns0 = 0;
       ShnDevBufs scratch(s);
       HIP_TRY(scratch.get(&d_f0, (nv + 1) * 4));
       HIP_TRY(scratch.get(&d_p0, (nv + 2) * 8));
-      hipLaunchKernelGGL(cg_shared_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, keys, vals, nv, d_cid, d_f0);
+      if (packed) hipLaunchKernelGGL(cg_shared_packed_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, words, nv, d_cid, d_f0);
+      else hipLaunchKernelGGL(cg_shared_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, keys, vals, nv, d_cid, d_f0);
       if ((rc = shn_device_scan_u32(ctx, d_f0, nv, d_p0, &ns0))) return rc;
       uint64_t* ok = nullptr; uint32_t* ov = nullptr;
       HIP_TRY(tmp.get(&ok, (ns0 + 1) * 8)); HIP_TRY(tmp.get(&ov, (ns0 + 1) * 4));
-      if (ns0) hipLaunchKernelGGL(cg_compact_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, keys, vals, d_f0, d_p0, nv, ok, ov);
+      if (ns0 && packed) hipLaunchKernelGGL(cg_compact_packed_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, words, d_f0, d_p0, nv, ok, ov);
+      else if (ns0) hipLaunchKernelGGL(cg_compact_kernel, dim3(grid_for(nv)), dim3(CG_BLK), 0, s, keys, vals, d_f0, d_p0, nv, ok, ov);
       if (dbg) fprintf(stderr, "[contig_stage]   %llu of %llu r-mer windows lie in runs that span two candidates\n", (unsigned long long)ns0, (unsigned long long)nv);
       keys = ok; vals = ov; nv = ns0;
       lap("shared r-mer runs (GPU)");
+    } else if (packed && nv == 1) {
+      // (one window: no run to share -- the rounds below see an empty index)
+      nv = 0;
     }
     uint8_t *d_acc, *d_hit; uint32_t *d_scid, *d_flag, *d_acand, *d_cov, *d_ovf; uint64_t *d_apos, *d_akey; int32_t* d_bestc;
     unsigned long long *d_best, *d_chg;
@@ -614,6 +680,7 @@ static int contig_stage_impl(shn_ctx* ctx, const uint8_t* bases, const uint8_t* 
         HIP_TRY(hipStreamSynchronize(s));
       }
     }
+    if (dbg) fprintf(stderr, "[contig_stage]   %llu of %llu K-mer windows of the accepted contigs lie in runs that span two of them\n", (unsigned long long)ns, (unsigned long long)nv);
     lap("K-mer sort + shared runs (GPU)");
     // host replay of the reference's loop over the shared runs only.  Entry e: K-mer run `run[e]`, accepted contig `ea[e]`,
     // position `ep[e]`; inside a run the entries are in (contig, position) order = the order of cmer_to_contig's list.
@@ -622,16 +689,34 @@ static int contig_stage_impl(shn_ctx* ctx, const uint8_t* bases, const uint8_t* 
       for (uint64_t e = 0; e < ns; e++) {
         if (e == 0 || hk[e] != hk[e - 1]) run_start.push_back((uint32_t)e);
         run[e] = (uint32_t)run_start.size() - 1;
-        const uint64_t g = hg[e];
-        const uint64_t c = (uint64_t)(std::upper_bound(off, off + n_cand + 1, g) - off) - 1;
-        ea[e] = (uint32_t)use[c];
-        ep[e] = (uint32_t)(g - off[c]);
       }
       run_start.push_back((uint32_t)ns);
-      // the shared windows of every accepted contig in position order (counting sort by contig, then by position)
-      std::vector<uint32_t> order(ns);
-      for (uint64_t e = 0; e < ns; e++) order[e] = (uint32_t)e;
-      std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return ea[x] != ea[y] ? ea[x] < ea[y] : ep[x] < ep[y]; });
+      // the shared windows of every accepted contig in position order = the entries by their base g in the candidates' text
+      // (accepted contigs are numbered in candidate order): three counting passes over 11 bits of g, then one walk along the
+      // offsets names every entry's contig and position (a comparison sort of the entries and a binary search per entry were two
+      // thirds of this replay)
+      std::vector<uint32_t> order(ns), order2(ns);
+      {
+        for (uint64_t e = 0; e < ns; e++) order[e] = (uint32_t)e;
+        std::vector<uint32_t> cnt(2049);
+        for (int pass = 0; pass < 3; pass++) {
+          const int sh = 11 * pass;
+          if (sh && (total >> sh) == 0) break;
+          std::fill(cnt.begin(), cnt.end(), 0u);
+          for (uint64_t e = 0; e < ns; e++) cnt[((hg[e] >> sh) & 2047) + 1]++;
+          for (int b = 0; b < 2048; b++) cnt[b + 1] += cnt[b];
+          for (uint64_t i = 0; i < ns; i++) { const uint32_t e = order[i]; order2[cnt[(hg[e] >> sh) & 2047]++] = e; }
+          order.swap(order2);
+        }
+        uint64_t c = 0;
+        for (uint64_t i = 0; i < ns; i++) {
+          const uint32_t e = order[i];
+          const uint64_t g = hg[e];
+          while (off[c + 1] <= g) c++;
+          ea[e] = (uint32_t)use[c];
+          ep[e] = (uint32_t)(g - off[c]);
+        }
+      }
       std::vector<int32_t> connw((size_t)n_acc + 1, 0), newnb;
       size_t q = 0;
       while (q < ns) {

@@ -21,6 +21,10 @@
 #include <condition_variable>
 #include <functional>
 #include <vector>
+#include <memory>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 namespace {
 
@@ -348,21 +352,26 @@ static void emit(Component& c, const std::string& sname, int comp) {
 // handed out by an atomic counter, the caller works too and returns when every index is done.  The workers spin for a few
 // microseconds between jobs (the next phase of a round follows at once) before they sleep on the condition variable.
 struct SflowPool {
+  // Every worker waits on a word of its own (a futex: no mutex to take back after the wake-up, which is what serialised the 15
+  // workers of a phase behind one another) and a phase wakes only the workers it wants: `run` may ask for fewer threads than the
+  // pool holds -- a wave of partitions started beside 15 graph stages keeps to two threads then and spreads when they are done.
+  struct alignas(64) Slot { std::atomic<uint32_t> gen{0}; std::atomic<uint32_t> asleep{0}; };
   std::vector<std::thread> th;
-  std::mutex mu;
-  std::condition_variable cv;
-  std::atomic<uint64_t> gen{0};
+  std::unique_ptr<Slot[]> slot;
   std::atomic<size_t> next{0};
   std::atomic<int> busy{0};
   std::atomic<bool> stop{false};
+  std::atomic<uint32_t> spin_us{20};
   size_t n = 0, chunk = 1;
   const std::function<void(size_t)>* fn = nullptr;
-  explicit SflowPool(unsigned workers) {
-    for (unsigned t = 0; t < workers; t++) th.emplace_back([this]() { loop(); });
+  static void futex_wait(std::atomic<uint32_t>* w, uint32_t v) { syscall(SYS_futex, (uint32_t*)w, FUTEX_WAIT_PRIVATE, v, nullptr, nullptr, 0); }
+  static void futex_wake(std::atomic<uint32_t>* w) { syscall(SYS_futex, (uint32_t*)w, FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0); }
+  explicit SflowPool(unsigned workers) : slot(new Slot[std::max(1u, workers)]) {
+    for (unsigned t = 0; t < workers; t++) th.emplace_back([this, t]() { loop(t); });
   }
   ~SflowPool() {
-    { std::lock_guard<std::mutex> lk(mu); stop.store(true); gen.fetch_add(1); }
-    cv.notify_all();
+    stop.store(true);
+    for (size_t t = 0; t < th.size(); t++) { slot[t].gen.fetch_add(1); futex_wake(&slot[t].gen); }
     for (auto& x : th) x.join();
   }
   void drain() {
@@ -373,30 +382,40 @@ struct SflowPool {
       for (size_t i = i0; i < i1; i++) (*fn)(i);
     }
   }
-  void loop() {
-    uint64_t seen = 0;
+  void loop(unsigned t) {
+    Slot& me = slot[t];
+    uint32_t seen = 0;
+    auto clock_us = []() { return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     while (true) {
-      // a short spin, then sleep
-      bool got = false;
-      for (int sp = 0; sp < 2000 && !got; sp++) { got = gen.load(std::memory_order_acquire) != seen; if (!got) __builtin_ia32_pause(); }
-      if (!got) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return gen.load(std::memory_order_acquire) != seen; }); }
+      // spin for as long as the phases of a round are apart (the caller says how long that is worth: spin_us), then sleep
+      bool got = me.gen.load(std::memory_order_acquire) != seen;
+      if (!got) {
+        const uint64_t t0 = clock_us(), lim = spin_us.load(std::memory_order_relaxed);
+        while (!got) {
+          for (int sp = 0; sp < 64 && !got; sp++) { got = me.gen.load(std::memory_order_acquire) != seen; if (!got) __builtin_ia32_pause(); }
+          if (!got && clock_us() - t0 >= lim) break;
+        }
+      }
+      while (!got) {
+        me.asleep.store(1);                                         // (seq_cst, as is the publisher's gen++: one of the two sees the other)
+        if (me.gen.load() == seen) futex_wait(&me.gen, seen);
+        me.asleep.store(0);
+        got = me.gen.load(std::memory_order_acquire) != seen;
+      }
       if (stop.load()) return;
-      // (a job is published as: n / chunk / fn written, busy = workers + 1, next = 0, THEN gen++ -- all of it under mu)
-      { std::lock_guard<std::mutex> lk(mu); seen = gen.load(); }
+      seen = me.gen.load(std::memory_order_acquire);                // (a job: n / chunk / fn written, busy and next set, THEN the wanted workers' gen++)
       drain();
       busy.fetch_sub(1, std::memory_order_acq_rel);
     }
   }
-  void run(size_t n_items, size_t chunk_, const std::function<void(size_t)>& f) {
+  // `threads`: the calling thread included; at most the pool's workers + 1
+  void run(size_t n_items, size_t chunk_, const std::function<void(size_t)>& f, unsigned threads = ~0u) {
     if (!n_items) return;
-    if (th.empty() || n_items <= chunk_) { for (size_t i = 0; i < n_items; i++) f(i); return; }
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      n = n_items; chunk = std::max<size_t>(1, chunk_); fn = &f;
-      next.store(0); busy.store((int)th.size() + 1);
-      gen.fetch_add(1, std::memory_order_release);
-    }
-    cv.notify_all();
+    const size_t want = std::min<size_t>(th.size(), threads > 0 ? threads - 1 : 0);
+    if (!want || n_items <= chunk_) { for (size_t i = 0; i < n_items; i++) f(i); return; }
+    n = n_items; chunk = std::max<size_t>(1, chunk_); fn = &f;
+    next.store(0); busy.store((int)want + 1);
+    for (size_t t = 0; t < want; t++) { slot[t].gen.fetch_add(1); if (slot[t].asleep.load()) futex_wake(&slot[t].gen); }
     drain();
     busy.fetch_sub(1, std::memory_order_acq_rel);
     while (busy.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();      // (the stragglers are inside their last chunk)
@@ -502,16 +521,38 @@ extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uin
   // (beside the graph stage the cores are taken: a few threads for a wave of partitions, the calling thread alone for one partition)
   const bool small_job = t_sflow_beside ? (comps.size() < 1024 && n_nodes_all < (1u << 15)) : (comps.size() < 256 && n_nodes_all < (1u << 16));
   const unsigned cpus = (unsigned)std::max(1, shn_host_cpus());
-  const unsigned busy = (unsigned)std::max(0, shn_graph_partitions_running());      // partitions at their graphs right now: a core each
-  const unsigned nt = small_job ? 1 : t_sflow_beside ? std::max(2u, std::min(32u, cpus > busy ? cpus - busy : 0u)) : std::max(1u, std::min(32u, cpus));
-  SflowPool pool(nt > 1 ? nt - 1 : 0);
+  // The threads of a phase are decided when it starts: the cores the graph stages leave free right now, shared among the calls
+  // that are in here together (waves of partitions beside the graph stage), two at least.  A call that has the machine to itself
+  // keeps its workers spinning between the phases of a round (they are ~0.3 ms apart: one LP batch on the device); beside others
+  // they spin for 20 us and sleep.
+  static std::atomic<int> calls_with_pool{0};
+  struct InHere { bool on; explicit InHere(bool b) : on(b) { if (on) calls_with_pool.fetch_add(1); } ~InHere() { if (on) calls_with_pool.fetch_sub(1); } } in_here(!small_job);
+  const bool beside = t_sflow_beside;
+  auto threads_now = [&]() -> unsigned {
+    if (small_job) return 1u;
+    const unsigned busy = (unsigned)std::max(0, shn_graph_partitions_running());      // partitions at their graphs right now: a core each
+    const unsigned calls = (unsigned)std::max(1, calls_with_pool.load());
+    const unsigned free_ = cpus > busy ? cpus - busy : 0u;
+    return beside ? std::max(2u, std::min(32u, free_ / calls)) : std::max(1u, std::min(32u, cpus));
+  };
+  static const unsigned spin_alone = getenv("SHN_SFLOW_SPIN_US") ? (unsigned)atoi(getenv("SHN_SFLOW_SPIN_US")) : 400u;
+  const unsigned nt_max = small_job ? 1u : std::max(2u, std::min(32u, cpus));
+  unsigned nt = threads_now();
+  SflowPool pool(nt_max > 1 ? nt_max - 1 : 0);
+  auto retune = [&]() {
+    nt = threads_now();
+    pool.spin_us.store(calls_with_pool.load() <= 1 && shn_graph_partitions_running() <= 0 ? spin_alone : 20u, std::memory_order_relaxed);
+  };
+  retune();
   // chunks: a few per thread, so that a handful of large components (the repeat-linked families of --config 2p: 610 components of
   // ~3,000 nodes) do not end up on one thread behind 63 others
   auto chunk_of = [&](size_t n_items) { return std::max<size_t>(1, std::min<size_t>(64, n_items / ((size_t)nt * 8))); };
-  auto parallel = [&](const std::function<void(size_t)>& fn) { pool.run(comps.size(), chunk_of(comps.size()), fn); };
+  auto parallel = [&](const std::function<void(size_t)>& fn) { retune(); pool.run(comps.size(), chunk_of(comps.size()), fn, nt); };
   parallel(build);
   lap("build components");
   int n_round = 0;
+  const double t_rounds0 = now();
+  unsigned nt_lo = nt, nt_hi = nt;
   // rounds: every component runs to its next decomposition that needs LP trials; all of them go to the device in one batch
   std::vector<size_t> active(comps.size());
   for (size_t k = 0; k < comps.size(); k++) active[k] = k;
@@ -519,9 +560,10 @@ extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uin
   while (!active.empty()) {
     double tr0 = now();
     n_round++;
+    if ((n_round & 15) == 1) { retune(); nt_lo = std::min(nt_lo, nt); nt_hi = std::max(nt_hi, nt); }
     // advance the active components (independent of each other)
     pool.run(active.size(), std::max<size_t>(1, std::min<size_t>(16, active.size() / ((size_t)nt * 4))),
-             [&](size_t i) { wants[active[i]] = advance(comps[active[i]]) ? 1 : 0; });
+             [&](size_t i) { wants[active[i]] = advance(comps[active[i]]) ? 1 : 0; }, nt);
     std::vector<size_t> pend;
     for (size_t k : active) if (wants[k]) pend.push_back(k);
     t_adv += now() - tr0; tr0 = now();
@@ -553,12 +595,13 @@ extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uin
     if (rc) return rc;
     t_lp += now() - tr0; tr0 = now();
     pool.run(pend.size(), std::max<size_t>(1, std::min<size_t>(16, pend.size() / ((size_t)nt * 4))),
-             [&](size_t i) { Component& c = comps[pend[i]]; finish(c, flows.data() + ooff[i]); apply_flow(c); });
+             [&](size_t i) { Component& c = comps[pend[i]]; finish(c, flows.data() + ooff[i]); apply_flow(c); }, nt);
     active.swap(pend);
     t_fin += now() - tr0;
   }
   if (dbg) fprintf(stderr, "[sflow] %zu components of %u graphs, %d rounds (%zu of them with fewer than 64 problems; %zu problems, %llu trials in all): advance %.3f s, pack %.3f s, "
-                   "LP batches %.3f s, finish+apply %.3f s\n", comps.size(), n_graphs, n_round, n_small_rounds, n_pend_total, (unsigned long long)n_trials_total, t_adv, t_pack, t_lp, t_fin);
+                   "LP batches %.3f s, finish+apply %.3f s; rounds from %.3f to %.3f (clock mod 100 s), threads %u..%u\n", comps.size(), n_graphs, n_round, n_small_rounds, n_pend_total, (unsigned long long)n_trials_total, t_adv, t_pack, t_lp, t_fin,
+                   std::fmod(t_rounds0, 100.0), std::fmod(now(), 100.0), nt_lo, nt_hi);
   if (dbg && n_pend_total > 1000) fprintf(stderr, "[sflow]   problems by max(m, n) <=2 / 3 / 4 / 5-6 / 7-8 / 9-11 / 12-16 / more: %llu %llu %llu %llu %llu %llu %llu %llu; rounds by their largest problem: %llu %llu %llu %llu %llu %llu %llu %llu\n",
                    (unsigned long long)h_prob[0], (unsigned long long)h_prob[1], (unsigned long long)h_prob[2], (unsigned long long)h_prob[3], (unsigned long long)h_prob[4], (unsigned long long)h_prob[5], (unsigned long long)h_prob[6], (unsigned long long)h_prob[7],
                    (unsigned long long)h_roundmax[0], (unsigned long long)h_roundmax[1], (unsigned long long)h_roundmax[2], (unsigned long long)h_roundmax[3], (unsigned long long)h_roundmax[4], (unsigned long long)h_roundmax[5], (unsigned long long)h_roundmax[6], (unsigned long long)h_roundmax[7]);
@@ -594,7 +637,8 @@ extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uin
       t += "\n";
     }
   };
-  pool.run(n_graphs, 1, [&](size_t g) { text_of((uint32_t)g); });
+  retune();
+  pool.run(n_graphs, 1, [&](size_t g) { text_of((uint32_t)g); }, nt);
   lap("partition texts");
   // The components hold ~10^2 small vectors each (26 ms to give back on 16 threads at BASELINE configs[2]): they go to a
   // background thread, which frees them while the caller merges the transcripts; the thread of the call before is joined first, the

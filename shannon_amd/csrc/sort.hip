@@ -25,6 +25,8 @@ __global__ __launch_bounds__(SBLK) void sort_hist_kernel(const uint64_t* __restr
 // pieces -- instead of 4096 separate 8-byte stores that left the L2 as partial lines (PMC: 2.5 times the bytes of a pass written).
 // (The first version let thread d walk all 4096 digits of the tile to place the items of digit d: 1 M LDS reads per tile, 480 GB/s
 // per pass.)
+// VALS = false: the words alone (a value packed under the key's bits travels inside the word: shn_sort_keys)
+template <bool VALS>
 __global__ __launch_bounds__(SBLK) void sort_scatter_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                             uint64_t n, int shift, uint32_t nblocks,
                                                             const uint64_t* __restrict__ goff, uint64_t* __restrict__ ok,
@@ -33,7 +35,7 @@ __global__ __launch_bounds__(SBLK) void sort_scatter_kernel(const uint64_t* __re
   __shared__ uint32_t base[SBLK / 64][256];
   __shared__ uint32_t dstart[256];
   __shared__ unsigned long long sk[STILE];
-  __shared__ uint32_t sv[STILE];
+  __shared__ uint32_t sv[VALS ? STILE : 1];
   const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (uint32_t i = lane; i < 256; i += 64) cnt[wv][i] = 0;
   const uint64_t tile0 = (uint64_t)blockIdx.x * STILE;
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(SBLK) void sort_scatter_kernel(const uint64_t* __re
     const uint64_t i = t0 + (uint64_t)row * 64 + lane;
     const bool have = i < n;
     k[row] = have ? keys[i] : 0;
-    v[row] = have ? vals[i] : 0;
+    v[row] = (VALS && have) ? vals[i] : 0;
     const uint32_t d = (uint32_t)((k[row] >> shift) & 255);
     unsigned long long same = __ballot(have);
 #pragma unroll
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(SBLK) void sort_scatter_kernel(const uint64_t* __re
     const uint32_t d = (uint32_t)((k[row] >> shift) & 255);
     const uint32_t lp = dstart[d] + base[wv][d] + rank[row];
     sk[lp] = k[row];
-    sv[lp] = v[row];
+    if (VALS) sv[lp] = v[row];
   }
   __syncthreads();
   const uint32_t n_tile = (uint32_t)(tile0 + STILE <= n ? STILE : (n > tile0 ? n - tile0 : 0));
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(SBLK) void sort_scatter_kernel(const uint64_t* __re
     const uint32_t d = (uint32_t)((key >> shift) & 255);
     const uint64_t p = goff[(uint64_t)d * nblocks + blockIdx.x] + (i - dstart[d]);
     ok[p] = key;
-    ov[p] = sv[i];
+    if (VALS) ov[p] = sv[i];
   }
 }
 
@@ -117,7 +119,7 @@ int shn_sort_pairs(shn_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t* keys_
   for (int shift = bit_lo; shift < bit_hi; shift += 8) {
     hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(SBLK), 0, s, ki, n, shift, nblocks, gh);
     if ((rc = shn_device_scan_u32(ctx, gh, (uint64_t)256 * nblocks, goff, nullptr))) return rc;
-    hipLaunchKernelGGL(sort_scatter_kernel, dim3(nblocks), dim3(SBLK), 0, s, ki, vi, n, shift, nblocks, goff, ko, vo);
+    hipLaunchKernelGGL(sort_scatter_kernel<true>, dim3(nblocks), dim3(SBLK), 0, s, ki, vi, n, shift, nblocks, goff, ko, vo);
     std::swap(ki, ko);
     std::swap(vi, vo);
     passes++;
@@ -126,6 +128,31 @@ int shn_sort_pairs(shn_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t* keys_
     HIP_TRY(hipMemcpyAsync(keys, keys_tmp, n * 8, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(vals, vals_tmp, n * 4, hipMemcpyDeviceToDevice, s));
   }
+  HIP_TRY(hipGetLastError());
+  return SHN_OK;
+}
+
+// The same sort of 64-bit words by their bits [bit_lo, bit_hi) alone -- for pairs whose value fits under the key (r-mer << 32 |
+// position: a pass moves 8 bytes per item each way instead of 12).  *sorted = whichever of the two buffers holds the result.
+int shn_sort_keys(shn_ctx* ctx, uint64_t* keys, uint64_t* keys_tmp, uint64_t n, int bit_lo, int bit_hi, uint64_t** sorted) {
+  *sorted = keys;
+  if (n == 0) return SHN_OK;
+  if (n >= 0xFFFFFFFFULL) return shn_fail(SHN_ERR_ARG, "shn_sort_keys: n too large");
+  hipStream_t s = ctx->stream; shn_use_stream(s);
+  uint32_t nblocks = (uint32_t)cdiv(n, STILE);
+  void* p;
+  int rc = g_shn_ws[8].get((size_t)256 * nblocks * 4 + ((size_t)256 * nblocks + 2) * 8, &p);
+  if (rc) return rc;
+  uint64_t* goff = (uint64_t*)p;
+  uint32_t* gh = (uint32_t*)(goff + (size_t)256 * nblocks + 2);
+  uint64_t *ki = keys, *ko = keys_tmp;
+  for (int shift = bit_lo; shift < bit_hi; shift += 8) {
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(SBLK), 0, s, ki, n, shift, nblocks, gh);
+    if ((rc = shn_device_scan_u32(ctx, gh, (uint64_t)256 * nblocks, goff, nullptr))) return rc;
+    hipLaunchKernelGGL(sort_scatter_kernel<false>, dim3(nblocks), dim3(SBLK), 0, s, ki, (const uint32_t*)nullptr, n, shift, nblocks, goff, ko, (uint32_t*)nullptr);
+    std::swap(ki, ko);
+  }
+  *sorted = ki;
   HIP_TRY(hipGetLastError());
   return SHN_OK;
 }

@@ -385,6 +385,28 @@ def test_gpu_contig_stage_equals_the_sequential_stage(ctx, name, block0, pair_lo
         assert coff2.tolist() == coff and cnb2.tolist() == cnb and cw2.tolist() == cw
 
 
+@pytest.mark.parametrize("env", [{"SHN_CONTIG_PACKED": "0"}, {"SHN_CONTIG_SHARED": "0"}, {"SHN_CONTIG_PACKED": "0", "SHN_CONTIG_BLOCK0": "5"}])
+def test_contig_stage_sorts_pairs_or_packed_words_alike(ctx, env, monkeypatch):
+    """the r-mer index of duplicate_check comes from a sort of (r-mer << 32 | base index) words (round 6: 8 bytes per entry and
+    pass); SHN_CONTIG_PACKED=0 sorts (key, value) pairs as before, SHN_CONTIG_SHARED=0 keeps every window in the index: the
+    sequential stage's answers in all three forms"""
+    from shannon_amd import extension_correction as ec
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for name in sorted(MANIFEST)[:4]:
+        g = load_case(name)
+        for cands in (_variants(g["contigs"]), _variants(g["contigs"], 9)[::-1], g["contigs"][:1]):
+            if not cands:
+                continue
+            acc, coff, cnb, cw, best = ec.contig_stage(cands, g["K"] + 1, want_best=True)
+            buf = np.frombuffer("".join(cands).encode(), np.uint8)
+            offs = np.zeros(len(cands) + 1, np.uint64)
+            offs[1:] = np.cumsum([len(c) for c in cands])
+            acc2, best2, coff2, cnb2, cw2 = ec.contig_stage_gpu(ctx, buf, offs, g["K"] + 1)
+            assert np.array_equal(acc, acc2) and np.array_equal(best, best2)
+            assert coff2.tolist() == coff and cnb2.tolist() == cnb and cw2.tolist() == cw
+
+
 def test_gpu_contig_stage_on_many_genes(ctx):
     """300 genes: a few thousand candidates in many small clusters, through run_correction both ways"""
     from shannon_amd import device, synth, extension_correction as ec
