@@ -201,7 +201,9 @@ def native_graph_baseline(R, store, K):
 def overlapped_steps(ctx, sets, store, K, n, want_sha, n_reads):
     """Two batches in flight: count -> extension -> partition / route -> unitigs of batch i+1 on the main thread and context while
     graph -> sparse flow -> merge of batch i run on a second thread and context (the GPU is idle for most of the second half of a
-    step, the host for most of the first).  A throughput figure for a stream of samples -- reported beside `value`, which stays
+    step, the host for most of the first).  (The cut cannot move in front of the route / unitig stages: like counting and the
+    extension they work in the process-wide workspaces of "the stage that runs now", one such stage at a time -- tried in round 6,
+    a memory fault.)  A throughput figure for a stream of samples -- reported beside `value`, which stays
     one batch at a time.  Every batch's transcripts must equal the sequential run's."""
     from concurrent.futures import ThreadPoolExecutor
     from shannon_amd import device, pipeline
@@ -218,10 +220,12 @@ def overlapped_steps(ctx, sets, store, K, n, want_sha, n_reads):
         prev = pool.submit(front(), ctx_b)                     # one batch ahead, untimed
         torch.cuda.synchronize()
         t = time.time()
-        finals = []
+        finals, stage_s = [], []
         for _ in range(n):
             fin = front()
-            finals.append(prev.result().final)
+            res = prev.result()
+            finals.append(res.final)
+            stage_s.append(dict(res.timings))
             prev = pool.submit(fin, ctx_b)
         last = prev.result().final                             # (the batch started before the clock ends inside it: n batches in, n out)
         ctx.sync(); ctx_b.sync()
@@ -229,7 +233,13 @@ def overlapped_steps(ctx, sets, store, K, n, want_sha, n_reads):
         dt = time.time() - t
         finals.append(last)
         ok = all(_final_sha(f) == want_sha for f in finals)
+        # every stage's wall time with the other half running beside it (the batches whose back half ran inside the clock, the
+        # first one -- started beside nothing -- left out): set against config.host_stage_seconds_per_step this names what the
+        # overlap costs each stage
+        per = stage_s[1:] or stage_s
+        stages = {k: sum(t.get(k, 0.0) for t in per) / len(per) for k in (per[0] if per else {})}
         return {"value": n_reads * n / dt, "unit": "reads/s", "steps": n, "ms_per_step": 1000.0 * dt / n, "transcripts_equal_sequential_run": bool(ok),
+                "stage_seconds_per_step_side_by_side": stages,
                 "back_half_stream": {"0": "legacy NULL stream", "1": "own stream", "2": "own high-priority stream"}.get(mode, mode),
                 "note": "two batches in flight (second half of batch i beside the first half of batch i+1, two contexts); not the headline value"}
     except Exception as ex:                                    # an extra: its failure must not cost the bench line

@@ -1,5 +1,6 @@
 // Context, error handling, event timers and the read uploader / 2-bit packer.
 #include "common.h"
+#include <deque>
 #include "graph_dev.h"
 #include <sched.h>
 #include <mutex>
@@ -62,12 +63,16 @@ TimerRegion::~TimerRegion() {
 // The caching allocator (shared by every context and host thread of the process, one process per GPU).  A block remembers the
 // streams that may still have work queued on it: the stream it was handed out on and the current stream of the thread that freed
 // it.  The next caller on one of those streams gets it at once (stream order makes that safe whatever is still queued); a caller
-// on ANOTHER stream gets it behind an event recorded on each of them at that moment and waited for by its own stream
-// (hipStreamWaitEvent: everything queued there so far -- a superset of what was queued at the free -- completes first; nobody
-// blocks on the host).  A free therefore costs no HIP call, and neither does the common reuse on the same stream.  (Until round 4
-// a freed block went to the next caller at once and correctness rested on every caller having synchronised its stream before every
-// free, on its error paths too.)  A stream that goes away (a forked context with its host thread) is synchronised first and
-// struck from the blocks (shn_stream_retired).
+// on ANOTHER stream gets it behind an event on each of them, waited for by its own stream (hipStreamWaitEvent: nobody blocks on
+// the host).  For the stream of a forked context (a graph thread's: a handful of short passes queued at any time) that event is
+// recorded at the moment of the reuse -- everything queued there so far, a superset of what was queued at the free -- so that a
+// free on such a stream costs no HIP call; for an owner's stream it is recorded AT THE FREE (round 6): with two batches in flight
+// (bench.py's overlap) a graph thread that took a block last used by the other batch's extension otherwise waited for that
+// stream's whole queue -- hundreds of milliseconds of walker launches issued long after the free -- and the graph stage beside a
+// front half took 1.05 s instead of 0.2.  An event that has completed by the time of the reuse costs no wait at all.  (Until
+// round 4 a freed block went to the next caller at once and correctness rested on every caller having synchronised its stream
+// before every free, on its error paths too.)  A stream that goes away (a forked context with its host thread) is synchronised
+// first and struck from the blocks (shn_stream_retired).
 // The "current stream" of a host thread is the stream of the context it last entered the library with (shn_use_stream: set by
 // SHN_ENTER, TimerRegion, shn_thread_ctx, every `s = ctx->stream`); a caller that knows better passes the stream.
 // Debug switches (environment): SHN_DEV_POISON=<byte 0..255>: every block handed out (and every workspace slot that has just grown;
@@ -76,20 +81,40 @@ TimerRegion::~TimerRegion() {
 // allocator of rounds 1-4 (no ordering).  A block freed twice is reported on stderr and counted (shn_debug_counter(0)) -- the second
 // free would hand a block that is in use to the next caller.
 namespace {
-struct DevBlock { void* p; size_t cap; bool used; hipStream_t stream; hipStream_t pend[2]; int n_pend; };
+struct DevBlock { void* p; size_t cap; bool used; hipStream_t stream; hipStream_t pend[2]; int n_pend; hipEvent_t ev[2]; };
 std::vector<DevBlock> g_blocks;
 std::mutex g_blocks_mu;
 std::vector<hipEvent_t> g_ev_pool;
+std::deque<hipEvent_t> g_ev_free;                // events of frees, given back at the reuse; one is recorded again only after 256 others
+std::vector<hipStream_t> g_fork_streams;         // (g_blocks_mu) streams of forked contexts: short queues, ordered at the reuse
 std::atomic<uint64_t> g_dbg[8];
 thread_local hipStream_t t_stream = nullptr;
 int poison_byte() { static const int v = getenv("SHN_DEV_POISON") ? (atoi(getenv("SHN_DEV_POISON")) & 255) : -1; return v; }
 bool legacy_reuse() { static const bool v = getenv("SHN_DEV_LEGACY") && getenv("SHN_DEV_LEGACY")[0] == '1'; return v; }   // (A/B: the allocator of rounds 1-4 -- a freed block goes to the next caller at once)
 bool no_cache() { static const bool v = getenv("SHN_DEV_NOCACHE") && getenv("SHN_DEV_NOCACHE")[0] == '1'; return v; }
-// (g_blocks_mu held) make `asker` wait for what the block's pending streams have queued so far; false: no event to be had (the caller skips the block)
+bool free_events() { static const bool v = !(getenv("SHN_DEV_FREE_EVENTS") && getenv("SHN_DEV_FREE_EVENTS")[0] == '0'); return v; }   // (A/B: 0 = every hand-over ordered at the reuse, as in round 5)
+bool is_fork_stream(hipStream_t s) { for (hipStream_t f : g_fork_streams) if (f == s) return true; return false; }
+hipEvent_t take_event() {
+  hipEvent_t e = nullptr;
+  if (g_ev_free.size() > 256) { e = g_ev_free.front(); g_ev_free.pop_front(); return e; }
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return e;
+}
+void give_event(hipEvent_t e) { if (e) g_ev_free.push_back(e); }
+// (g_blocks_mu held) make `asker` wait for what the block's pending streams had queued at the free (an owner's stream) or have queued
+// so far (a fork's); false: no event to be had (the caller skips the block)
 bool order_behind(DevBlock& b, hipStream_t asker) {
-  if (legacy_reuse()) { b.n_pend = 0; return true; }
+  if (legacy_reuse()) { for (int i = 0; i < b.n_pend; i++) { give_event(b.ev[i]); b.ev[i] = nullptr; } b.n_pend = 0; return true; }
   for (int i = 0; i < b.n_pend; i++) {
     if (b.pend[i] == asker) continue;
+    if (b.ev[i]) {
+      const hipError_t q = hipEventQuery(b.ev[i]);
+      if (q == hipSuccess) { g_dbg[5].fetch_add(1); continue; }                 // hand-overs that needed no wait
+      (void)hipGetLastError();
+      if (hipStreamWaitEvent(asker, b.ev[i], 0) != hipSuccess) { (void)hipGetLastError(); g_dbg[3].fetch_add(1); return false; }
+      g_dbg[4].fetch_add(1);                   // cross-stream hand-overs
+      continue;
+    }
     // (a ring of 256 events: one is recorded again only after 255 other hand-overs -- long after the wait queued on its last record has run)
     static size_t ring_at = 0;
     hipEvent_t e = nullptr;
@@ -101,10 +126,12 @@ bool order_behind(DevBlock& b, hipStream_t asker) {
     if (!ok) { (void)hipGetLastError(); g_dbg[3].fetch_add(1); return false; }
     g_dbg[4].fetch_add(1);                     // cross-stream hand-overs
   }
+  for (int i = 0; i < b.n_pend; i++) { give_event(b.ev[i]); b.ev[i] = nullptr; }
   b.n_pend = 0;
   return true;
 }
 }
+void shn_fork_stream_added(hipStream_t s) { std::lock_guard<std::mutex> lk(g_blocks_mu); g_fork_streams.push_back(s); }
 void shn_use_stream(hipStream_t s) { t_stream = s; }
 hipStream_t shn_current_stream() { return t_stream; }
 extern "C" uint64_t shn_debug_counter(int i) { return (i >= 0 && i < 8) ? g_dbg[i].load() : 0; }
@@ -118,10 +145,15 @@ void shn_stream_retired(hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_blocks_mu);
   for (auto& b : g_blocks) {
     int k = 0;
-    for (int i = 0; i < b.n_pend; i++) if (b.pend[i] != s) b.pend[k++] = b.pend[i];
+    for (int i = 0; i < b.n_pend; i++) {
+      if (b.pend[i] != s) { b.pend[k] = b.pend[i]; b.ev[k] = b.ev[i]; k++; }
+      else give_event(b.ev[i]);
+    }
+    for (int i = k; i < 2; i++) b.ev[i] = nullptr;
     b.n_pend = k;
     if (b.stream == s) b.stream = nullptr;         // (a block that outlives the stream it was handed out on: nothing of that stream is left to wait for)
   }
+  for (size_t i = 0; i < g_fork_streams.size(); i++) if (g_fork_streams[i] == s) { g_fork_streams.erase(g_fork_streams.begin() + (ptrdiff_t)i); break; }
 }
 hipError_t shn_dev_malloc_on(void** p, size_t bytes, hipStream_t stream) {
   if (bytes == 0) bytes = 1;
@@ -157,7 +189,7 @@ hipError_t shn_dev_malloc_on(void** p, size_t bytes, hipStream_t stream) {
   }
   shn_poison(*p, bytes, stream);
   std::lock_guard<std::mutex> lk(g_blocks_mu);
-  g_blocks.push_back(DevBlock{*p, bytes, true, stream, {nullptr, nullptr}, 0});
+  g_blocks.push_back(DevBlock{*p, bytes, true, stream, {nullptr, nullptr}, 0, {nullptr, nullptr}});
   return hipSuccess;
 }
 hipError_t shn_dev_malloc_raw(void** p, size_t bytes) { return shn_dev_malloc_on(p, bytes, t_stream); }
@@ -196,12 +228,20 @@ void shn_dev_free_on(void* p, hipStream_t stream) {
       lk.lock();
       for (size_t k = 0; k < g_blocks.size(); k++) if (g_blocks[k].p == p) {
         if (no_cache()) { g_blocks.erase(g_blocks.begin() + (ptrdiff_t)k); lk.unlock(); (void)hipFree(gone.p); return; }
-        g_blocks[k].n_pend = 0; g_blocks[k].used = false; break;
+        g_blocks[k].n_pend = 0; g_blocks[k].ev[0] = g_blocks[k].ev[1] = nullptr; g_blocks[k].used = false; break;
       }
       return;
     }
     b.n_pend = n_on;
-    for (int j = 0; j < n_on; j++) b.pend[j] = on[j];
+    for (int j = 0; j < n_on; j++) {
+      b.pend[j] = on[j];
+      b.ev[j] = nullptr;
+      if (free_events() && !legacy_reuse() && !is_fork_stream(on[j])) {          // an owner's stream: what is queued on it NOW is all the block has to wait for
+        hipEvent_t e = take_event();
+        if (e && hipEventRecord(e, on[j]) == hipSuccess) { b.ev[j] = e; g_dbg[6].fetch_add(1); }
+        else { (void)hipGetLastError(); give_event(e); }
+      }
+    }
     b.used = false;
     return;
   }
@@ -214,7 +254,7 @@ void shn_dev_free(void* p) { shn_dev_free_on(p, t_stream); }
 void shn_dev_trim() {
   std::lock_guard<std::mutex> lk(g_blocks_mu);
   std::vector<DevBlock> keep;
-  for (auto& b : g_blocks) { if (b.used) keep.push_back(b); else hipFree(b.p); }      // (hipFree waits for the device)
+  for (auto& b : g_blocks) { if (b.used) keep.push_back(b); else { for (int i = 0; i < b.n_pend; i++) give_event(b.ev[i]); hipFree(b.p); } }      // (hipFree waits for the device)
   g_blocks.swap(keep);
 }
 
@@ -333,10 +373,20 @@ extern "C" int shn_ctx_fork(const shn_ctx* parent, shn_ctx** out) {
   if (!parent || !out) return shn_fail(SHN_ERR_ARG, "shn_ctx_fork: NULL argument");
   HIP_TRY(hipSetDevice(parent->device));
   hipStream_t st = nullptr;
-  HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  // A fork's kernels are the short, latency-bound passes of one partition (seed scans, distinct reads, path searches, LP batches)
+  // whose host thread waits for each: on a stream of the highest priority their workgroups are placed ahead of those of a long
+  // kernel queued on the owner's stream -- which matters when another batch's counting / extension runs beside the graph stage
+  // (bench.py's two batches in flight) and costs nothing otherwise.  SHN_FORK_PRIORITY=0: default priority, as until round 6.
+  static const bool fork_high = !(getenv("SHN_FORK_PRIORITY") && getenv("SHN_FORK_PRIORITY")[0] == '0');
+  int pr_least = 0, pr_greatest = 0;
+  if (fork_high && hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest) == hipSuccess && pr_greatest != pr_least)
+    HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, pr_greatest));
+  else
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   shn_ctx* c = new shn_ctx();
   c->device = parent->device; c->stream = st; c->timing = parent->timing; c->count_direct_log2 = 0; c->sk_pool_ratio = 0; c->owns_stream = true;
   c->parent = const_cast<shn_ctx*>(parent);
+  shn_fork_stream_added(st);
   { std::lock_guard<std::mutex> lk(g_forks_mu); g_forks.push_back(c); }
   for (int i = 0; i < T_N; i++) { c->ms[i] = 0; c->regions[i] = 0; c->abytes[i] = 0; }
   c->lp_rule = parent->lp_rule;
