@@ -7,6 +7,13 @@
 #include <mutex>
 #include "../../include/shannon_hip.h"
 
+// Copy census (SHN_COPY_CENSUS=1, a diagnostic): every hipMemcpyAsync / hipMemsetAsync of the library counted by call site and
+// printed when the process ends -- which of the thousands of small copies of a step come from where (core.hip).
+hipError_t shn_counted_memcpy(const char* file, int line, void* dst, const void* src, size_t n, hipMemcpyKind kind, hipStream_t s);
+hipError_t shn_counted_memset(const char* file, int line, void* dst, int value, size_t n, hipStream_t s);
+#define hipMemcpyAsync(...) shn_counted_memcpy(__FILE__, __LINE__, __VA_ARGS__)
+#define hipMemsetAsync(...) shn_counted_memset(__FILE__, __LINE__, __VA_ARGS__)
+
 #define SHN_WAVE 64
 
 void shn_set_error(const std::string& msg);

@@ -1,6 +1,8 @@
 // Context, error handling, event timers and the read uploader / 2-bit packer.
 #include "common.h"
 #include <deque>
+#include <algorithm>
+#include <map>
 #include "graph_dev.h"
 #include <sched.h>
 #include <mutex>
@@ -132,6 +134,41 @@ bool order_behind(DevBlock& b, hipStream_t asker) {
 }
 }
 void shn_fork_stream_added(hipStream_t s) { std::lock_guard<std::mutex> lk(g_blocks_mu); g_fork_streams.push_back(s); }
+namespace {
+struct CopyCensus {
+  const bool on = getenv("SHN_COPY_CENSUS") != nullptr;
+  std::mutex mu;
+  std::map<std::pair<std::string, int>, std::pair<uint64_t, uint64_t>> sites;      // (file, line) -> calls, bytes
+  void add(const char* file, int line, size_t n) {
+    std::lock_guard<std::mutex> lk(mu);
+    const char* base = strrchr(file, '/');
+    auto& v = sites[{std::string(base ? base + 1 : file), line}];
+    v.first++; v.second += n;
+  }
+  ~CopyCensus() {
+    if (!on) return;
+    std::vector<std::pair<uint64_t, std::string>> rows;
+    uint64_t calls = 0;
+    for (auto& kv : sites) {
+      char b[160];
+      snprintf(b, sizeof b, "%-22s:%5d %10llu calls %14llu bytes", kv.first.first.c_str(), kv.first.second, (unsigned long long)kv.second.first, (unsigned long long)kv.second.second);
+      rows.push_back({kv.second.first, b}); calls += kv.second.first;
+    }
+    std::sort(rows.begin(), rows.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+    fprintf(stderr, "[copy census] %llu copies / fills at %zu call sites\n", (unsigned long long)calls, rows.size());
+    for (size_t i = 0; i < rows.size() && i < 60; i++) fprintf(stderr, "[copy census] %s\n", rows[i].second.c_str());
+  }
+};
+CopyCensus g_copy_census;
+}
+hipError_t shn_counted_memcpy(const char* file, int line, void* dst, const void* src, size_t n, hipMemcpyKind kind, hipStream_t s) {
+  if (g_copy_census.on) g_copy_census.add(file, line, n);
+  return (hipMemcpyAsync)(dst, src, n, kind, s);
+}
+hipError_t shn_counted_memset(const char* file, int line, void* dst, int value, size_t n, hipStream_t s) {
+  if (g_copy_census.on) g_copy_census.add(file, line, n);
+  return (hipMemsetAsync)(dst, value, n, s);
+}
 void shn_use_stream(hipStream_t s) { t_stream = s; }
 hipStream_t shn_current_stream() { return t_stream; }
 extern "C" uint64_t shn_debug_counter(int i) { return (i >= 0 && i < 8) ? g_dbg[i].load() : 0; }

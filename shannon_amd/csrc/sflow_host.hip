@@ -551,6 +551,7 @@ extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uin
   parallel(build);
   lap("build components");
   int n_round = 0;
+  std::atomic<uint64_t> busy_adv_ns{0};
   const double t_rounds0 = now();
   unsigned nt_lo = nt, nt_hi = nt;
   // rounds: every component runs to its next decomposition that needs LP trials; all of them go to the device in one batch
@@ -563,7 +564,12 @@ extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uin
     if ((n_round & 15) == 1) { retune(); nt_lo = std::min(nt_lo, nt); nt_hi = std::max(nt_hi, nt); }
     // advance the active components (independent of each other)
     pool.run(active.size(), std::max<size_t>(1, std::min<size_t>(16, active.size() / ((size_t)nt * 4))),
-             [&](size_t i) { wants[active[i]] = advance(comps[active[i]]) ? 1 : 0; }, nt);
+             [&](size_t i) {
+               if (!dbg) { wants[active[i]] = advance(comps[active[i]]) ? 1 : 0; return; }
+               const double ta = now();
+               wants[active[i]] = advance(comps[active[i]]) ? 1 : 0;
+               busy_adv_ns.fetch_add((uint64_t)((now() - ta) * 1e9), std::memory_order_relaxed);
+             }, nt);
     std::vector<size_t> pend;
     for (size_t k : active) if (wants[k]) pend.push_back(k);
     t_adv += now() - tr0; tr0 = now();
@@ -600,8 +606,8 @@ extern "C" int shn_sparse_flow(shn_ctx* ctx, const shn_graph* const* graphs, uin
     t_fin += now() - tr0;
   }
   if (dbg) fprintf(stderr, "[sflow] %zu components of %u graphs, %d rounds (%zu of them with fewer than 64 problems; %zu problems, %llu trials in all): advance %.3f s, pack %.3f s, "
-                   "LP batches %.3f s, finish+apply %.3f s; rounds from %.3f to %.3f (clock mod 100 s), threads %u..%u\n", comps.size(), n_graphs, n_round, n_small_rounds, n_pend_total, (unsigned long long)n_trials_total, t_adv, t_pack, t_lp, t_fin,
-                   std::fmod(t_rounds0, 100.0), std::fmod(now(), 100.0), nt_lo, nt_hi);
+                   "LP batches %.3f s, finish+apply %.3f s; rounds from %.3f to %.3f (clock mod 100 s), threads %u..%u; inside advance %.3f thread-s\n", comps.size(), n_graphs, n_round, n_small_rounds, n_pend_total, (unsigned long long)n_trials_total, t_adv, t_pack, t_lp, t_fin,
+                   std::fmod(t_rounds0, 100.0), std::fmod(now(), 100.0), nt_lo, nt_hi, (double)busy_adv_ns.load() * 1e-9);
   if (dbg && n_pend_total > 1000) fprintf(stderr, "[sflow]   problems by max(m, n) <=2 / 3 / 4 / 5-6 / 7-8 / 9-11 / 12-16 / more: %llu %llu %llu %llu %llu %llu %llu %llu; rounds by their largest problem: %llu %llu %llu %llu %llu %llu %llu %llu\n",
                    (unsigned long long)h_prob[0], (unsigned long long)h_prob[1], (unsigned long long)h_prob[2], (unsigned long long)h_prob[3], (unsigned long long)h_prob[4], (unsigned long long)h_prob[5], (unsigned long long)h_prob[6], (unsigned long long)h_prob[7],
                    (unsigned long long)h_roundmax[0], (unsigned long long)h_roundmax[1], (unsigned long long)h_roundmax[2], (unsigned long long)h_roundmax[3], (unsigned long long)h_roundmax[4], (unsigned long long)h_roundmax[5], (unsigned long long)h_roundmax[6], (unsigned long long)h_roundmax[7]);
