@@ -56,6 +56,42 @@ struct FlatMultiMap {
   }
 };
 
+// 64-bit key -> running sum (open addressing, no erase; the key ~0 is not a key).  For the per-edge sums of the known-path
+// stage: 10^5 additions per partition onto a few thousand edges -- a node-based map was a cache miss and an allocation apiece.
+struct FlatSum {
+  std::vector<uint64_t> keys;
+  std::vector<double> vals;
+  size_t mask = 0, used = 0;
+  explicit FlatSum(size_t expect = 256) { size_t c = 256; while (c < expect * 2) c <<= 1; keys.assign(c, ~0ULL); vals.assign(c, 0.0); mask = c - 1; }
+  void add(uint64_t k, double v) {
+    if ((used + 1) * 10 > (mask + 1) * 6) grow();
+    size_t s = fm_mix(k) & mask;
+    while (keys[s] != ~0ULL && keys[s] != k) s = (s + 1) & mask;
+    if (keys[s] == ~0ULL) { keys[s] = k; used++; }
+    vals[s] += v;
+  }
+  void grow() {
+    std::vector<uint64_t> ok; std::vector<double> ov;
+    ok.swap(keys); ov.swap(vals);
+    const size_t c = (mask + 1) * 2;
+    keys.assign(c, ~0ULL); vals.assign(c, 0.0); mask = c - 1;
+    for (size_t i = 0; i < ok.size(); i++) if (ok[i] != ~0ULL) { size_t s = fm_mix(ok[i]) & mask; while (keys[s] != ~0ULL) s = (s + 1) & mask; keys[s] = ok[i]; vals[s] = ov[i]; }
+  }
+  void set(uint64_t k, double v) {                    // (assignment: the last one stands)
+    if ((used + 1) * 10 > (mask + 1) * 6) grow();
+    size_t s = fm_mix(k) & mask;
+    while (keys[s] != ~0ULL && keys[s] != k) s = (s + 1) & mask;
+    if (keys[s] == ~0ULL) { keys[s] = k; used++; }
+    vals[s] = v;
+  }
+  double get(uint64_t k) const {                      // 0 for a key that is not there
+    size_t s = fm_mix(k) & mask;
+    while (keys[s] != ~0ULL) { if (keys[s] == k) return vals[s]; s = (s + 1) & mask; }
+    return 0.0;
+  }
+  template <class F> void each(F f) const { for (size_t s = 0; s <= mask; s++) if (keys[s] != ~0ULL) f(keys[s], vals[s]); }
+};
+
 // byte-string -> dense id (insertion order); strings live in one arena
 struct StringInterner {
   std::vector<int32_t> table;             // -1 = empty, else id

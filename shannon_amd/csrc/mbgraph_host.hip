@@ -949,14 +949,13 @@ struct Graph {
           tk2 = nowk();
           if (rcf == 0) {
             std::unordered_map<int, int> pos_in_order;
-            std::unordered_map<uint32_t, uint32_t> cnt_of;
-            cnt_of.reserve(rec_cnt.size());
-            for (size_t i = 0; i + 1 < rec_cnt.size(); i += 2) cnt_of[rec_cnt[i]] = rec_cnt[i + 1];
+            FlatSum cnt_of(rec_cnt.size() / 2 + 16);                 // (a searched read's copies: every read has one entry)
+            for (size_t i = 0; i + 1 < rec_cnt.size(); i += 2) cnt_of.set(rec_cnt[i], (double)rec_cnt[i + 1]);
             int cntp = 0;
-            std::unordered_map<uint64_t, double> edge_sum;
+            FlatSum edge_sum(4096);
             std::unordered_map<uint64_t, std::vector<std::vector<int>>> seen;
             auto add_path = [&](const std::vector<int>& pth, double copies) {
-              for (size_t j = 0; j + 1 < pth.size(); j++) edge_sum[((uint64_t)(uint32_t)pth[j] << 32) | (uint32_t)pth[j + 1]] += copies;
+              for (size_t j = 0; j + 1 < pth.size(); j++) edge_sum.add(((uint64_t)(uint32_t)pth[j] << 32) | (uint32_t)pth[j + 1], copies);
               if (pth.size() > 2) {
                 cntp++;
                 uint64_t h = 0xcbf29ce484222325ULL;
@@ -974,7 +973,7 @@ struct Graph {
               pth.resize((size_t)len);
               for (int32_t j = 0; j < len; j++) pth[(size_t)j] = order[(size_t)recs[at + 2 + (uint64_t)j]];
               at += 2 + (uint64_t)len;
-              add_path(pth, (double)cnt_of[(uint32_t)r]);
+              add_path(pth, cnt_of.get((uint64_t)(uint32_t)r));
             }
             tk3 = nowk();
             // the reads the device left (a search deeper than its stack, no room for the records): the host's search, one by one
@@ -1020,7 +1019,7 @@ struct Graph {
                 patches.push_back(r); patches.push_back(pf < 0 ? -1 : pos_in_order[pf]); patches.push_back(pl < 0 ? -1 : pos_in_order[pl]);
               }
             }
-            for (const auto& kv : edge_sum) known_edges[{(int)(uint32_t)(kv.first >> 32), (int)(uint32_t)kv.first}] += kv.second;
+            edge_sum.each([&](uint64_t k, double v) { known_edges[{(int)(uint32_t)(k >> 32), (int)(uint32_t)k}] += v; });
             n_known = cntp;
             // find_mate_pairs' pass over the reads, where their first / last nodes are (the graph does not change in between)
             mate_cand.clear();
@@ -1105,7 +1104,7 @@ struct Graph {
           // expressed transcript name the same few edges and paths) and are merged afterwards; the copy counts of reads are whole
           // numbers, so neither the order of the additions nor the cut into slices shows in the sums; a read's first / last node is its own.
           struct Local {
-            std::unordered_map<uint64_t, double> edge_sum;
+            FlatSum edge_sum;
             std::unordered_map<uint64_t, std::vector<std::vector<int>>> path_seen;
             std::vector<std::vector<int>> fresh;                           // distinct paths of this slice
             int cntp = 0;
@@ -1131,7 +1130,7 @@ struct Graph {
                 search_sequence(rb, 0, sn, so, 30, cur, paths);
                 for (auto& p : paths) {
                   rfirst[r] = p.front(); rlast[r] = p.back(); rhas[r] = 1;
-                  for (size_t j = 0; j + 1 < p.size(); j++) L.edge_sum[((uint64_t)(uint32_t)p[j] << 32) | (uint32_t)p[j + 1]] += rcc[r];
+                  for (size_t j = 0; j + 1 < p.size(); j++) L.edge_sum.add(((uint64_t)(uint32_t)p[j] << 32) | (uint32_t)p[j + 1], rcc[r]);
                   if (p.size() > 2) {
                     L.cntp++;
                     uint64_t h = 0xcbf29ce484222325ULL;
@@ -1160,13 +1159,13 @@ struct Graph {
           int cntp = 0;
           for (Local& L : locals) {
             cntp += L.cntp;
-            for (const auto& kv : L.edge_sum) known_edges[{(int)(uint32_t)(kv.first >> 32), (int)(uint32_t)kv.first}] += kv.second;
+            L.edge_sum.each([&](uint64_t k, double v) { known_edges[{(int)(uint32_t)(k >> 32), (int)(uint32_t)k}] += v; });
             for (auto& p : L.fresh) known_paths.insert(std::move(p));
           }
           // the reads the device searched (state 4): their paths as it enumerated them, a read's records in the recursion's order (the
           // last one names its first / last node, mbgraph.py:1379-1384); the sums are of whole numbers, so no order shows in them
           {
-            std::unordered_map<uint64_t, double> edge_sum;
+            FlatSum edge_sum(4096);
             std::unordered_map<uint64_t, std::vector<std::vector<int>>> dev_seen;
             std::vector<int> pth;
             for (uint64_t at = 0; at + 2 <= precs_used;) {
@@ -1176,7 +1175,7 @@ struct Graph {
               for (int32_t j = 0; j < len; j++) pth[(size_t)j] = order[(size_t)precs[at + 2 + (uint64_t)j]];
               at += 2 + (uint64_t)len;
               rfirst[r] = pth.front(); rlast[r] = pth.back(); rhas[r] = 1;
-              for (size_t j = 0; j + 1 < pth.size(); j++) edge_sum[((uint64_t)(uint32_t)pth[j] << 32) | (uint32_t)pth[j + 1]] += rcc[r];
+              for (size_t j = 0; j + 1 < pth.size(); j++) edge_sum.add(((uint64_t)(uint32_t)pth[j] << 32) | (uint32_t)pth[j + 1], rcc[r]);
               if (pth.size() > 2) {
                 cntp++;
                 // (the 10^4-10^5 reads of a highly expressed transcript name the same few paths: a hash table in front of the ordered set)
@@ -1188,7 +1187,7 @@ struct Graph {
                 if (!have) { lst.push_back(pth); known_paths.insert(pth); }
               }
             }
-            for (const auto& kv : edge_sum) known_edges[{(int)(uint32_t)(kv.first >> 32), (int)(uint32_t)kv.first}] += kv.second;
+            edge_sum.each([&](uint64_t k, double v) { known_edges[{(int)(uint32_t)(k >> 32), (int)(uint32_t)k}] += v; });
           }
           n_known = cntp;
           if (dbgk) fprintf(stderr, "[mbgraph]   kp (device) node text %.3f s scan %.3f s slow index %.3f s search %.3f s  (%zu bases, %zu reads, %zu slow)\n", tk1 - tk0,
