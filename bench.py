@@ -201,10 +201,12 @@ def native_graph_baseline(R, store, K):
 def overlapped_steps(ctx, sets, store, K, n, want_sha, n_reads):
     """Two batches in flight: count -> extension -> partition / route -> unitigs of batch i+1 on the main thread and context while
     graph -> sparse flow -> merge of batch i run on a second thread and context (the GPU is idle for most of the second half of a
-    step, the host for most of the first).  (The cut cannot move in front of the route / unitig stages: like counting and the
-    extension they work in the process-wide workspaces of "the stage that runs now", one such stage at a time -- tried in round 6,
-    a memory fault.)  A throughput figure for a stream of samples -- reported beside `value`, which stays
-    one batch at a time.  Every batch's transcripts must equal the sequential run's."""
+    step, the host for most of the first).  A throughput figure for a stream of samples -- reported beside `value`, which stays
+    one batch at a time.  Every batch's transcripts must equal the sequential run's.
+    SHN_OVERLAP_SPLIT=early: the cut behind the extension -- partition / route / unitigs with the back half, whose context then has
+    stage workspaces of its own (shn_ctx_own_workspaces).  Measured in round 6: the same figure (1.34 s either way at configs[2]: the
+    stages moved over are GPU work too, and the chip is what the halves share: route 0.09 -> 0.39 s, unitigs 0.05 -> 0.17 s beside an
+    extension)."""
     from concurrent.futures import ThreadPoolExecutor
     from shannon_amd import device, pipeline
     # the second context works on a stream of its OWN (round 6).  Until then both contexts were made on the legacy NULL stream, which
@@ -212,11 +214,12 @@ def overlapped_steps(ctx, sets, store, K, n, want_sha, n_reads):
     # synchronisations) waited behind the front half's whole queue.  SHN_OVERLAP_STREAM=0: the NULL stream again; 2: a high-priority stream.
     mode = os.environ.get("SHN_OVERLAP_STREAM", "2")
     own = None if mode == "0" else torch.cuda.Stream(device=torch.device("cuda", 0), priority=(-1 if mode == "2" else 0))
-    ctx_b = device.Context(0, stream=own.cuda_stream if own is not None else None)
+    split = os.environ.get("SHN_OVERLAP_SPLIT", "late")
+    ctx_b = device.Context(0, stream=own.cuda_stream if own is not None else None, own_workspaces=(split == "early"))
     pool = ThreadPoolExecutor(max_workers=1)
     try:
         def front():
-            return pipeline.assemble_resident(ctx, sets[0], sets[1], store, K=K, sample="bench", seed=1, timings={}, defer_back=True)
+            return pipeline.assemble_resident(ctx, sets[0], sets[1], store, K=K, sample="bench", seed=1, timings={}, defer_back=("early" if split == "early" else True))
         prev = pool.submit(front(), ctx_b)                     # one batch ahead, untimed
         torch.cuda.synchronize()
         t = time.time()
@@ -241,6 +244,7 @@ def overlapped_steps(ctx, sets, store, K, n, want_sha, n_reads):
         return {"value": n_reads * n / dt, "unit": "reads/s", "steps": n, "ms_per_step": 1000.0 * dt / n, "transcripts_equal_sequential_run": bool(ok),
                 "stage_seconds_per_step_side_by_side": stages,
                 "back_half_stream": {"0": "legacy NULL stream", "1": "own stream", "2": "own high-priority stream"}.get(mode, mode),
+                "cut": "behind the extension (the back half's context has stage workspaces of its own)" if split == "early" else "behind the unitig batch",
                 "note": "two batches in flight (second half of batch i beside the first half of batch i+1, two contexts); not the headline value"}
     except Exception as ex:                                    # an extra: its failure must not cost the bench line
         return {"error": str(ex)[:300]}

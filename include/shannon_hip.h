@@ -49,6 +49,11 @@ int shn_ctx_sync(shn_ctx* ctx);
 /* A second context on the device of `parent` with a stream of its own (destroyed with it), for a host thread that works beside the
  * owner of `parent`; event timing is off on it.                                                                                 */
 int shn_ctx_fork(const shn_ctx* parent, shn_ctx** out);
+/* The device workspaces of the context's top-level stages (counting, extension, contig stage, probe table, routing, unitigs) in a
+ * set of its own: by default all contexts of a process share one set, which serves one pipeline at a time -- the reference runs its
+ * stages one after the other in one process (shannon.py:427-604).  A second pipeline whose stages run BESIDE the first one's
+ * (two batches in flight) gives its context a set of its own first.  Forked contexts use their parent's set.                   */
+int shn_ctx_own_workspaces(shn_ctx* ctx);
 
 /* HIP-event timing on the context's stream (bench.py: per-kernel-group durations).
  * shn_timer_begin/end bracket a region under `slot` (0..31); shn_timer_ms() synchronises and

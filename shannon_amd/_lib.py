@@ -17,6 +17,7 @@ SIGNATURES = {
     "shn_ctx_destroy": (None, [vp]),
     "shn_ctx_sync": (C.c_int, [vp]),
     "shn_ctx_fork": (C.c_int, [vp, vpp]),
+    "shn_ctx_own_workspaces": (C.c_int, [vp]),
     "shn_timer_reset": (C.c_int, [vp]),
     "shn_timer_ms": (C.c_int, [vp, C.c_int, dblp, u64p]),
     "shn_timer_bytes": (C.c_int, [vp, C.c_int, u64p]),

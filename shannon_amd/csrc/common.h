@@ -35,9 +35,21 @@ enum {
 };
 
 // grow-only device workspace slot (process-wide ones: g_shn_ws below; per-context ones: shn_ctx::cws)
+struct ShnWsSet;
 struct ShnWs {
   void* p = nullptr; size_t cap = 0; uint64_t stage = 0;
+  ShnWsSet* set = nullptr;             // the stage-owned set the slot belongs to (nullptr: a context's own slot, shn_ctx::cws)
   int get(size_t bytes, void** out);
+};
+// The workspaces of the top-level stages (count, extension, contig stage, probe table, routing, unitigs): 32 grow-only slots that
+// the stages of ONE pipeline use one after the other on one host thread.  The process has a default set; a context may own a set
+// (shn_ctx_own_workspaces) so that a second pipeline -- the back half of bench.py's two batches in flight, cut behind the extension
+// -- runs its routing beside the first one's extension.
+struct ShnWsSet {
+  ShnWs ws[32];
+  uint64_t stage = 1;                  // (under the workspaces' mutex, count.hip)
+  uint64_t stage_thread = 0;
+  ShnWsSet() { for (auto& w : ws) w.set = this; }
 };
 
 // grow-only pinned host buffer (staging of many small pieces as ONE transfer)
@@ -73,6 +85,8 @@ struct shn_ctx {
                            // context / stream (the graph threads' seed scans): [0] scan block sums, [1] [2] seed-scan counts / offsets,
                            // [4..11] the LP batches of the sparse flow (two batches may be in flight on two contexts)
   ShnPinned hpin[2];       // pinned staging of the LP batches: [0] what goes up, [1] what comes back
+  ShnWsSet* wsset = nullptr;   // the stage workspaces this context's top-level stages use: the process's default set, or its own
+  bool owns_wsset = false;
   shn_ctx* parent = nullptr;   // shn_ctx_fork: the context this one was forked from (its timers and LP census are the parent's: core.hip)
   std::mutex tmu;          // guards pending / ms / regions when another thread drains them
   int lp_rule;             // SHN_LP_RULE_CENTER (default) / SHN_LP_RULE_VERTEX (SHN_LP_RULE=vertex in the environment, shn_lp_set_rule)
@@ -330,9 +344,12 @@ void shn_debug_count(int i);                 // shn_debug_counter(i)++: [0] doub
 // entry of a call on a context: device + the thread's current stream
 #define SHN_ENTER(ctx) do { HIP_TRY(hipSetDevice((ctx)->device)); shn_use_stream((ctx)->stream); } while (0)
 
-void shn_stage_begin();                      // a top-level GPU stage starts (workspace slots used before it become reclaimable)
+void shn_stage_begin(shn_ctx* ctx);          // a top-level GPU stage starts on the context's workspace set (slots used before it become reclaimable)
+ShnWsSet* shn_default_wsset();               // the process's set (count.hip)
+ShnWsSet* shn_wsset_create();                // a set of its own for a context (registered with the reclaiming pass)
+void shn_wsset_destroy(ShnWsSet* s);
+static inline ShnWs* shn_ws(shn_ctx* ctx) { return (ctx->wsset ? ctx->wsset : shn_default_wsset())->ws; }
 size_t shn_ws_release_idle();                // frees the slots not used by the current stage; returns the bytes given back
-extern ShnWs g_shn_ws[32];
 extern "C" int shn_host_cpus(void);
 void shn_lp_census_add(shn_ctx* c, const uint64_t* v8);   // core.hip: LP census of a context or, for a fork, of its parent (under the forks' lock)
 shn_ctx* shn_thread_ctx(shn_ctx* parent);      // core.hip: the calling host thread's own fork (stream) of a context

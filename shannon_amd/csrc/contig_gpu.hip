@@ -436,7 +436,7 @@ static int contig_stage_impl(shn_ctx* ctx, const uint8_t* bases, const uint8_t* 
   if (total >= 0xFFFFFFF0ULL || n_cand >= 0x7FFFFFF0ULL) return shn_fail(SHN_ERR_OVERFLOW, "shn_contig_stage: more than 2^32 contig bases");
   SHN_ENTER(ctx);
   hipStream_t s = ctx->stream; shn_use_stream(s);
-  shn_stage_begin();
+  shn_stage_begin(ctx);
   TimerRegion treg(ctx, T_CONTIG);
   ShnDevBufs bufs(s);
   uint8_t* d_bases; uint64_t* d_off; uint32_t* d_cid;

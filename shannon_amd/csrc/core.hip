@@ -347,7 +347,19 @@ extern "C" int shn_ctx_create(int device, void* stream, shn_ctx** out) {
   const char* rule = getenv("SHN_LP_RULE");
   c->lp_rule = (rule && !strcmp(rule, "vertex")) ? SHN_LP_RULE_VERTEX : SHN_LP_RULE_CENTER;
   for (auto& v : c->lp_stats) v = 0;
+  c->wsset = shn_default_wsset();
   *out = c;
+  return SHN_OK;
+}
+// A workspace set of its own for the context's top-level stages (count, extension, contig stage, probe table, routing, unitigs):
+// until this call they use the process's set, which serves ONE pipeline at a time.  For a second pipeline in the process whose
+// stages run beside the first one's (bench.py: the back half of two batches in flight, cut behind the extension).
+extern "C" int shn_ctx_own_workspaces(shn_ctx* c) {
+  if (!c) return shn_fail(SHN_ERR_ARG, "shn_ctx_own_workspaces: ctx is NULL");
+  if (c->owns_wsset) return SHN_OK;
+  if (c->parent) return shn_fail(SHN_ERR_ARG, "shn_ctx_own_workspaces: a forked context uses its parent's set");
+  c->wsset = shn_wsset_create();
+  c->owns_wsset = true;
   return SHN_OK;
 }
 
@@ -400,6 +412,11 @@ extern "C" void shn_ctx_destroy(shn_ctx* c) {
   if (c->owns_stream && c->stream) { shn_stream_retired(c->stream); hipStreamDestroy(c->stream); }
   for (auto& w : c->cws) if (w.p) { hipFree(w.p); w.p = nullptr; w.cap = 0; }
   for (auto& h : c->hpin) h.release();
+  if (c->owns_wsset) {
+    // (its forks may outlive it -- kept graph threads: they go back to the process's set)
+    { std::lock_guard<std::mutex> lk(g_forks_mu); for (shn_ctx* f : g_forks) if (f->wsset == c->wsset) f->wsset = shn_default_wsset(); }
+    shn_wsset_destroy(c->wsset); c->wsset = nullptr; c->owns_wsset = false;
+  }
   if (!c->owns_stream) shn_dev_trim();         // (a forked context goes with its host thread, in the middle of a run)
   delete c;
 }
@@ -423,6 +440,7 @@ extern "C" int shn_ctx_fork(const shn_ctx* parent, shn_ctx** out) {
   shn_ctx* c = new shn_ctx();
   c->device = parent->device; c->stream = st; c->timing = parent->timing; c->count_direct_log2 = 0; c->sk_pool_ratio = 0; c->owns_stream = true;
   c->parent = const_cast<shn_ctx*>(parent);
+  c->wsset = parent->wsset;
   shn_fork_stream_added(st);
   { std::lock_guard<std::mutex> lk(g_forks_mu); g_forks.push_back(c); }
   for (int i = 0; i < T_N; i++) { c->ms[i] = 0; c->regions[i] = 0; c->abytes[i] = 0; }

@@ -470,22 +470,44 @@ __global__ void gtable_compact_kernel(const unsigned long long* __restrict__ gke
 // is freed as long as everything fits.
 // Who may use what, now that two batches can be in flight (the deferred back half of a step -- graph, sparse flow, merge -- on a
 // second context and host thread beside the next step's front half) and the graph threads run on forked contexts: the
-// process-wide slots g_shn_ws[] belong to the top-level stages of the FRONT half only (count, extension, contig stage, probe
+// stage slots (shn_ws(ctx): the default set or a context's own) belong to the top-level stages of ONE pipeline's front half only (count, extension, contig stage, probe
 // table, routing, unitigs: one after the other on one host thread); everything the back half and the graph threads call (seed
 // scans, the device scan, the LP batches) keeps its workspaces in its own context (shn_ctx::cws), which shn_ws_release_idle
 // never touches.  get / release are serialised by g_ws_mu, so a slot's pointer and capacity are never written by two threads.
-static std::atomic<uint64_t> g_stage{1};
 static std::mutex g_ws_mu;
-// (single owner: the host thread that began the current stage is the one that may ask for process-wide slots until the next stage
-// begins; anybody else asking is counted -- shn_debug_counter(2) -- and reported once: two threads on one slot would overwrite each
-// other's buffers)
-static std::atomic<uint64_t> g_stage_thread{0};
+// (single owner: the host thread that began the current stage of a set is the one that may ask for its slots until the set's next
+// stage begins; anybody else asking is counted -- shn_debug_counter(2) -- and reported once: two threads on one slot would overwrite
+// each other's buffers)
 static uint64_t this_thread_tag() { return (uint64_t)std::hash<std::thread::id>()(std::this_thread::get_id()) | 1ULL; }
-void shn_stage_begin() { g_stage.fetch_add(1); g_stage_thread.store(this_thread_tag()); }
+static ShnWsSet g_default_wsset;               // per-process (one process per GPU)
+static std::vector<ShnWsSet*> g_wssets;        // (g_ws_mu) the sets contexts own
+ShnWsSet* shn_default_wsset() { return &g_default_wsset; }
+ShnWsSet* shn_wsset_create() {
+  ShnWsSet* s = new ShnWsSet();
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  g_wssets.push_back(s);
+  return s;
+}
+void shn_wsset_destroy(ShnWsSet* s) {
+  if (!s || s == &g_default_wsset) return;
+  {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    for (size_t i = 0; i < g_wssets.size(); i++) if (g_wssets[i] == s) { g_wssets.erase(g_wssets.begin() + (ptrdiff_t)i); break; }
+    for (auto& w : s->ws) if (w.p) { hipFree(w.p); w.p = nullptr; w.cap = 0; }
+  }
+  delete s;
+}
+void shn_stage_begin(shn_ctx* ctx) {
+  ShnWsSet* set = ctx && ctx->wsset ? ctx->wsset : &g_default_wsset;
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  set->stage++;
+  set->stage_thread = this_thread_tag();
+}
 static size_t ws_release_idle_locked() {
   size_t freed = 0;
-  const uint64_t now = g_stage.load();
-  for (auto& w : g_shn_ws) if (w.p && w.stage < now) { hipFree(w.p); freed += w.cap; w.p = nullptr; w.cap = 0; }
+  auto sweep = [&](ShnWsSet* set) { for (auto& w : set->ws) if (w.p && w.stage < set->stage) { hipFree(w.p); freed += w.cap; w.p = nullptr; w.cap = 0; } };
+  sweep(&g_default_wsset);
+  for (ShnWsSet* set : g_wssets) sweep(set);
   return freed;
 }
 size_t shn_ws_release_idle() {
@@ -494,15 +516,15 @@ size_t shn_ws_release_idle() {
 }
 int ShnWs::get(size_t bytes, void** out) {
   std::lock_guard<std::mutex> lk(g_ws_mu);
-  if (this >= g_shn_ws && this < g_shn_ws + 32) {
-    const uint64_t owner = g_stage_thread.load();
+  if (set) {
+    const uint64_t owner = set->stage_thread;
     if (owner && owner != this_thread_tag()) {
       static bool told = false;
       shn_debug_count(2);
-      if (!told) { told = true; fprintf(stderr, "[shannon_hip] process-wide workspace slot %d asked for by a thread that did not begin the current stage\n", (int)(this - g_shn_ws)); }
+      if (!told) { told = true; fprintf(stderr, "[shannon_hip] stage workspace slot %d asked for by a thread that did not begin the current stage of its set\n", (int)(this - set->ws)); }
     }
+    stage = set->stage;
   }
-  stage = g_stage.load();
   bool grew = false;
   if (bytes > cap) {
     grew = true;
@@ -528,8 +550,7 @@ int ShnWs::get(size_t bytes, void** out) {
   }
   return SHN_OK;
 }
-ShnWs g_shn_ws[32];   // per-process (one process per GPU)
-#define g_ws g_shn_ws
+#define g_ws shn_ws(ctx)
 
 int shn_device_scan_u32(shn_ctx* ctx, const uint32_t* d_in, uint64_t n, uint64_t* d_out /* n+1 */, uint64_t* total_host) {
   hipStream_t s = ctx->stream; shn_use_stream(s);
@@ -579,7 +600,7 @@ extern "C" int shn_count_k1mers(shn_ctx* ctx, shn_reads* const* sets, int n_sets
   if (!ctx || !sets || !out || n_sets <= 0) return shn_fail(SHN_ERR_ARG, "shn_count_k1mers: bad argument");
   if (k1 < 2 || k1 > 32) return shn_fail(SHN_ERR_ARG, "shn_count_k1mers: k1 must be in [2,32]");
   SHN_ENTER(ctx);
-  shn_stage_begin();
+  shn_stage_begin(ctx);
   hipStream_t s = ctx->stream; shn_use_stream(s);
   TimerRegion ttot(ctx, T_COUNT_TOTAL);
   uint64_t upper = 0;

@@ -553,9 +553,9 @@ int shn_count_superkmers(shn_ctx* ctx, const std::vector<ReadsView>& views, uint
   // small arrays: level-1 histogram / offsets / cursors (u32), segment starts (u64), level-2 histogram / offsets / cursors, cursors of the
   // overflow list and of the pool
   const size_t small = (size_t)nb1 * 4 * 3 + 64 + ((size_t)nb1 + 4) * 8 + nbk * 4 * 3 + 64 + (views.size() + 2) * 16;
-  if ((rc = g_shn_ws[22].get(small, &p))) return rc;
-  if ((rc = g_shn_ws[18].get((n_slots + ovf_cap + 2) * sizeof(SkRec), &pslots))) return rc;
-  if ((rc = g_shn_ws[23].get(n_reads + 64, &pcnt))) return rc;
+  if ((rc = shn_ws(ctx)[22].get(small, &p))) return rc;
+  if ((rc = shn_ws(ctx)[18].get((n_slots + ovf_cap + 2) * sizeof(SkRec), &pslots))) return rc;
+  if ((rc = shn_ws(ctx)[23].get(n_reads + 64, &pcnt))) return rc;
   uint32_t* d_hist1 = (uint32_t*)p;
   uint32_t* d_offr1 = d_hist1 + nb1;
   uint32_t* d_cursor1 = d_offr1 + nb1;
@@ -619,7 +619,7 @@ int shn_count_superkmers(shn_ctx* ctx, const std::vector<ReadsView>& views, uint
   if (NR >= 0xFFFFFFFFULL) return SHN_OK;                                // (2^32 records: leave it to the chunked pipeline)
   for (uint32_t i = 0; i < nb1; i++) off1r[i] = (uint32_t)off1[i];
   void* pa;
-  if ((rc = g_shn_ws[19].get((NR + 2) * sizeof(SkRec), &pa))) return rc;
+  if ((rc = shn_ws(ctx)[19].get((NR + 2) * sizeof(SkRec), &pa))) return rc;
   SkRec* recsA = (SkRec*)pa;
   SkRec* recsB = slots;                                                  // (level 2 writes where the slots were: n_slots + overflow >= NR)
   HIP_TRY(hipMemcpyAsync(d_cursor1, off1r.data(), (size_t)nb1 * 4, hipMemcpyHostToDevice, s));
@@ -653,7 +653,7 @@ int shn_count_superkmers(shn_ctx* ctx, const std::vector<ReadsView>& views, uint
   bool sorted = !(getenv("SHN_COUNT_SK_LAYOUT") && atoi(getenv("SHN_COUNT_SK_LAYOUT")) == 0);
   if (sorted) {
     void* pr;
-    if ((rc = g_shn_ws[24].get(nbk * 20 + 64, &pr))) return rc;
+    if ((rc = shn_ws(ctx)[24].get(nbk * 20 + 64, &pr))) return rc;
     uint64_t* d_run_off = (uint64_t*)pr;
     uint32_t* d_ndist = (uint32_t*)(d_run_off + nbk);
     uint32_t* d_defer = d_ndist + nbk;
@@ -670,13 +670,13 @@ int shn_count_superkmers(shn_ctx* ctx, const std::vector<ReadsView>& views, uint
     HIP_TRY(hipFuncSetAttribute((const void*)sk_buckets_sorted_kernel<false, BIG_T, BIG_CAP, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
     unsigned long long cur[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     void* prc;
-    if ((rc = g_shn_ws[29].get((size_t)SK_REGIONS * SK_RSTRIDE * 8, &prc))) return rc;
+    if ((rc = shn_ws(ctx)[29].get((size_t)SK_REGIONS * SK_RSTRIDE * 8, &prc))) return rc;
     unsigned long long* d_rcur = (unsigned long long*)prc;
     std::vector<unsigned long long> h_rcur((size_t)SK_REGIONS * SK_RSTRIDE);
     for (int attempt = 0; attempt < 3 && sorted; attempt++) {
       const uint64_t region_cap = cap / SK_REGIONS + 64;
-      if ((rc = g_shn_ws[20].get((region_cap * SK_REGIONS + 2) * 8, &pk))) return rc;
-      if ((rc = g_shn_ws[21].get((region_cap * SK_REGIONS + 2) * 4, &pc))) return rc;
+      if ((rc = shn_ws(ctx)[20].get((region_cap * SK_REGIONS + 2) * 8, &pk))) return rc;
+      if ((rc = shn_ws(ctx)[21].get((region_cap * SK_REGIONS + 2) * 4, &pc))) return rc;
       HIP_TRY(hipMemsetAsync(d_cursors + 1, 0, 56, s));                  // [1] unused, [2] / [6] buckets put off to the next size, [3] given up, [5] sum of counts
       HIP_TRY(hipMemsetAsync(d_rcur, 0, (size_t)SK_REGIONS * SK_RSTRIDE * 8, s));
       {
@@ -748,8 +748,8 @@ int shn_count_superkmers(shn_ctx* ctx, const std::vector<ReadsView>& views, uint
     }
   }
   for (int attempt = 0; attempt < 3; attempt++) {
-    if ((rc = g_shn_ws[20].get((cap + 2) * 8, &pk))) return rc;
-    if ((rc = g_shn_ws[21].get((cap + 2) * 4, &pc))) return rc;
+    if ((rc = shn_ws(ctx)[20].get((cap + 2) * 8, &pk))) return rc;
+    if ((rc = shn_ws(ctx)[21].get((cap + 2) * 4, &pc))) return rc;
     HIP_TRY(hipMemsetAsync(d_cursors + 1, 0, 8, s));
     {
       TimerRegion t(ctx, T_SK_BUCKETS);

@@ -1744,8 +1744,8 @@ static int component_shard(shn_ctx* ctx, const shn_table* t, int world, int rank
   void *pl, *po, *pz, *pb, *pc, *pp;
   const uint32_t big_cap = 1u << 16;
   int rc;
-  if ((rc = g_shn_ws[14].get((n + 1) * 4, &pl)) || (rc = g_shn_ws[15].get(n + 1, &po)) || (rc = g_shn_ws[16].get((n + 1) * 4, &pz)) ||
-      (rc = g_shn_ws[17].get((size_t)big_cap * 9 + 64, &pb)) || (rc = g_shn_ws[13].get(2048, &pc)) || (rc = g_shn_ws[9].get((2 * n + 2) * 8, &pp))) { cleanup(); return rc; }
+  if ((rc = shn_ws(ctx)[14].get((n + 1) * 4, &pl)) || (rc = shn_ws(ctx)[15].get(n + 1, &po)) || (rc = shn_ws(ctx)[16].get((n + 1) * 4, &pz)) ||
+      (rc = shn_ws(ctx)[17].get((size_t)big_cap * 9 + 64, &pb)) || (rc = shn_ws(ctx)[13].get(2048, &pc)) || (rc = shn_ws(ctx)[9].get((2 * n + 2) * 8, &pp))) { cleanup(); return rc; }
   uint32_t* d_lab = (uint32_t*)pl; uint8_t* d_owner_root = (uint8_t*)po;
   uint32_t* d_size = (uint32_t*)pz;
   uint32_t* d_big_root = (uint32_t*)pb; uint32_t* d_big_size = d_big_root + big_cap; uint8_t* d_big_owner = (uint8_t*)(d_big_size + big_cap);
@@ -2307,7 +2307,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   if (world < 1 || world > 255 || rank < 0 || rank >= world) return shn_fail(SHN_ERR_ARG, "shn_extend_sharded: bad world/rank");
   if (2 * t->n >= 0x7FFFFFFFULL) return shn_fail(SHN_ERR_ARG, "shn_extend: table too large for 31-bit oriented ids");
   SHN_ENTER(ctx);
-  shn_stage_begin();
+  shn_stage_begin(ctx);
   hipStream_t s = ctx->stream; shn_use_stream(s);
   if (world > 1 && t->n) {
     shn_table* sub = nullptr;
@@ -2366,7 +2366,7 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   // seeds: compact, sort by string then (stable) by weight descending
   void *pk, *pv, *pk2, *pv2, *pc;
   int rc;
-  if ((rc = g_shn_ws[13].get(2048, &pc))) { shn_ext_destroy(e); return rc; }
+  if ((rc = shn_ws(ctx)[13].get(2048, &pc))) { shn_ext_destroy(e); return rc; }
   unsigned long long* d_cnt = (unsigned long long*)pc;      // [0] seeds [1] steps [2..4] plan (long, pool, short) [5] final pool [6] changed
   // the seeds are counted first: the sort buffers are sized for them, not for every oriented k1-mer (at 20,000 genes 13 % of
   // the table are seeds -- 30 GB less)
@@ -2380,8 +2380,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
                             t->k, t->canonical, min_weight, d_bcnt, (const uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr);
   uint64_t ns = 0;
   if (n && (rc = shn_device_scan_u32(ctx, d_bcnt, n_sblk, d_bbase, &ns))) { shn_ext_destroy(e); return rc; }
-  if ((rc = g_shn_ws[9].get((ns + 2) * 8, &pk)) || (rc = g_shn_ws[10].get((ns + 2) * 4, &pv)) ||
-      (rc = g_shn_ws[11].get((ns + 2) * 8, &pk2)) || (rc = g_shn_ws[12].get((ns + 2) * 4, &pv2))) { shn_ext_destroy(e); return rc; }
+  if ((rc = shn_ws(ctx)[9].get((ns + 2) * 8, &pk)) || (rc = shn_ws(ctx)[10].get((ns + 2) * 4, &pv)) ||
+      (rc = shn_ws(ctx)[11].get((ns + 2) * 8, &pk2)) || (rc = shn_ws(ctx)[12].get((ns + 2) * 4, &pv2))) { shn_ext_destroy(e); return rc; }
   uint64_t* skeys = (uint64_t*)pk; uint32_t* svals = (uint32_t*)pv;
   if (n) hipLaunchKernelGGL(ext_seed_kernel, dim3((uint32_t)n_sblk), dim3(1024), 0, s, t->d_keys, e->d_weight, e->d_flags, n,
                             t->k, t->canonical, min_weight, d_bcnt, (const uint64_t*)d_bbase, skeys, svals);
@@ -2409,8 +2409,8 @@ extern "C" int shn_extend_sharded(shn_ctx* ctx, const shn_table* t, uint32_t min
   TRYE(hipMemsetAsync(e->d_claim, 0xFF, (2 * n + 4) * 8, s));
   // scratch: claim snapshot (d_claim2), memo pool + per-k1-mer hints, per-walk plan arrays
   void *ppool, *pplan;
-  if ((rc = g_shn_ws[27].get(pool_cap * 4, &ppool)) ||
-      (rc = g_shn_ws[28].get((ns + 1) * (8 + 4 * 10 + 1 + 1 + 1 + 1 + 1 + 1 + 1) + 64, &pplan))) { shn_ext_destroy(e); return rc; }
+  if ((rc = shn_ws(ctx)[27].get(pool_cap * 4, &ppool)) ||
+      (rc = shn_ws(ctx)[28].get((ns + 1) * (8 + 4 * 10 + 1 + 1 + 1 + 1 + 1 + 1 + 1) + 64, &pplan))) { shn_ext_destroy(e); return rc; }
   u64 *claim = e->d_claim, *snap = e->d_claim2;
   uint32_t* pool = (uint32_t*)ppool;
   uint64_t* moff = (uint64_t*)pplan;
@@ -2867,7 +2867,7 @@ extern "C" int shn_ext_live_stats_min(shn_ctx* ctx, const shn_ext* e, uint32_t m
   if (!ns) { *n_live = 0; return SHN_OK; }
   void *pf, *pp, *po;
   int rc;
-  if ((rc = g_shn_ws[9].get((ns + 1) * 4, &pf)) || (rc = g_shn_ws[11].get((ns + 2) * 8, &pp))) return rc;
+  if ((rc = shn_ws(ctx)[9].get((ns + 1) * 4, &pf)) || (rc = shn_ws(ctx)[11].get((ns + 2) * 8, &pp))) return rc;
   uint32_t* flag = (uint32_t*)pf;
   uint64_t* pos = (uint64_t*)pp;
   hipLaunchKernelGGL(ext_live_flag_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, e->d_nr, e->d_nl, ns, min_steps, flag);
@@ -2877,7 +2877,7 @@ extern "C" int shn_ext_live_stats_min(shn_ctx* ctx, const shn_ext* e, uint32_t m
   if (*n_live < total) return shn_fail(SHN_ERR_ARG, "shn_ext_live_stats: output arrays too small");
   *n_live = total;
   if (!total) return SHN_OK;
-  if ((rc = g_shn_ws[10].get(total * 20 + 64, &po))) return rc;
+  if ((rc = shn_ws(ctx)[10].get(total * 20 + 64, &po))) return rc;
   uint64_t* o_tw = (uint64_t*)po;
   uint32_t* o_rank = (uint32_t*)(o_tw + total);
   uint32_t* o_nr = o_rank + total;
@@ -2935,7 +2935,7 @@ extern "C" int shn_ext_accept(shn_ctx* ctx, const shn_ext* e, uint32_t min_lengt
   if (!ns) { *n_out = 0; return SHN_OK; }
   void *pf, *pp, *po;
   int rc;
-  if ((rc = g_shn_ws[9].get((ns + 1) * 4, &pf)) || (rc = g_shn_ws[11].get((ns + 2) * 8, &pp))) return rc;
+  if ((rc = shn_ws(ctx)[9].get((ns + 1) * 4, &pf)) || (rc = shn_ws(ctx)[11].get((ns + 2) * 8, &pp))) return rc;
   uint32_t* flag = (uint32_t*)pf;
   uint64_t* pos = (uint64_t*)pp;
   hipLaunchKernelGGL(ext_accept_flag_kernel, dim3((uint32_t)cdiv(ns, 256)), dim3(256), 0, s, e->d_nr, e->d_nl, e->d_totw, ns, e->k, min_length, threshold, flag);
@@ -2945,7 +2945,7 @@ extern "C" int shn_ext_accept(shn_ctx* ctx, const shn_ext* e, uint32_t min_lengt
   if (*n_out < total || !steps || !tot_weight || !cls) return shn_fail(SHN_ERR_ARG, "shn_ext_accept: output arrays too small");
   *n_out = total;
   if (!total) return SHN_OK;
-  if ((rc = g_shn_ws[10].get(total * 17 + 64, &po))) return rc;
+  if ((rc = shn_ws(ctx)[10].get(total * 17 + 64, &po))) return rc;
   uint64_t* o_tw = (uint64_t*)po;
   uint32_t* o_rank = (uint32_t*)(o_tw + total);
   uint32_t* o_steps = o_rank + total;

@@ -333,7 +333,7 @@ extern "C" int shn_unitigs_build(shn_ctx* ctx, const uint8_t* bases, const uint6
     if (part_of[c] >= n_parts || (c && part_of[c] < part_of[c - 1])) return shn_fail(SHN_ERR_ARG, "shn_unitigs_build: part_of must be ascending and < n_parts");
   SHN_ENTER(ctx);
   hipStream_t s = ctx->stream; shn_use_stream(s);
-  shn_stage_begin();
+  shn_stage_begin(ctx);
   TimerRegion treg(ctx, T_GRAPH_GPU);
   // table regions: a power of two >= 2 x the K-windows of the partition
   std::vector<uint64_t> tab_off(n_parts + 1, 0), win(n_parts, 0), first_base(n_parts + 1, total);

@@ -120,7 +120,7 @@ extern "C" int shn_probe_build(shn_ctx* ctx, const uint8_t* bases, const uint64_
   for (uint64_t c = 0; c < n_contigs; c++)
     if (part_of[c] >= n_parts || (c && part_of[c] < part_of[c - 1])) return shn_fail(SHN_ERR_ARG, "shn_probe_build: part_of must be ascending and < n_parts");
   SHN_ENTER(ctx);
-  shn_stage_begin();
+  shn_stage_begin(ctx);
   hipStream_t s = ctx->stream; shn_use_stream(s);
   shn_probe* P = new shn_probe();
   struct Guard { shn_probe* p; ~Guard() { shn_probe_destroy(p); } } guard{P};

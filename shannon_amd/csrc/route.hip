@@ -251,15 +251,15 @@ extern "C" int shn_route_reads_mode(shn_ctx* ctx, const shn_reads* r1, const shn
   if (probe->canonical) return shn_fail(SHN_ERR_ARG, "shn_route_reads: probe table must hold plain (non-canonical) k1-mers");
   if (2 * r1->n_reads >= 0xFFFFFFFFULL) return shn_fail(SHN_ERR_ARG, "shn_route_reads: too many reads for 32-bit doubled indices");
   SHN_ENTER(ctx);
-  shn_stage_begin();
+  shn_stage_begin(ctx);
   hipStream_t s = ctx->stream; shn_use_stream(s);
   TimerRegion treg(ctx, T_ROUTE);
   uint64_t N2 = 2 * r1->n_reads;
   uint32_t n_mem = set_off[n_sets];
   void *pso, *pcnt, *poff, *pflag;
   int rc;
-  if ((rc = g_shn_ws[14].get((size_t)(n_sets + 1 + n_mem + 1) * 4, &pso)) || (rc = g_shn_ws[15].get((N2 + 1) * 4, &pcnt)) ||
-      (rc = g_shn_ws[16].get((N2 + 2) * 8, &poff)) || (rc = g_shn_ws[17].get(64, &pflag))) return rc;
+  if ((rc = shn_ws(ctx)[14].get((size_t)(n_sets + 1 + n_mem + 1) * 4, &pso)) || (rc = shn_ws(ctx)[15].get((N2 + 1) * 4, &pcnt)) ||
+      (rc = shn_ws(ctx)[16].get((N2 + 2) * 8, &poff)) || (rc = shn_ws(ctx)[17].get(64, &pflag))) return rc;
   uint32_t* d_so = (uint32_t*)pso;
   uint32_t* d_sm = d_so + n_sets + 1;
   HIP_TRY(hipMemcpyAsync(d_so, set_off, (size_t)(n_sets + 1) * 4, hipMemcpyHostToDevice, s));
@@ -278,7 +278,7 @@ extern "C" int shn_route_reads_mode(shn_ctx* ctx, const shn_reads* r1, const shn
   if (probe->n >= 4096 && !(getenv("SHN_ROUTE_DICT") && getenv("SHN_ROUTE_DICT")[0] == '0')) {
     const uint64_t n_lines = probe->n / PD_PER_LINE + 1;
     void* pl;
-    if (g_shn_ws[31].get((n_lines + PD_HOPS + 1) * 128, &pl) == 0) {
+    if (shn_ws(ctx)[31].get((n_lines + PD_HOPS + 1) * 128, &pl) == 0) {
       HIP_TRY(hipMemsetAsync(pl, 0, (n_lines + PD_HOPS + 1) * 128, s));
       hipLaunchKernelGGL(pd_build_kernel, dim3((uint32_t)cdiv(probe->n, 256)), dim3(256), 0, s, (const uint64_t*)probe->d_keys, (const uint32_t*)probe->d_counts,
                          probe->n, (unsigned long long*)pl, n_lines);
@@ -286,7 +286,7 @@ extern "C" int shn_route_reads_mode(shn_ctx* ctx, const shn_reads* r1, const shn
     } else (void)hipGetLastError();
   }
   void* pf2 = nullptr;
-  uint2* d_first2 = g_shn_ws[30].get((N2 + 1) * 8, &pf2) == 0 ? (uint2*)pf2 : nullptr;          // (without it the second pass probes again)
+  uint2* d_first2 = shn_ws(ctx)[30].get((N2 + 1) * 8, &pf2) == 0 ? (uint2*)pf2 : nullptr;          // (without it the second pass probes again)
   hipLaunchKernelGGL(route_kernel<false>, dim3(grid), dim3(RBLK), 0, s, a, b, r2 ? 1 : 0, strand_specific ? 1 : 0, k1, probe->d_keys, probe->d_counts,
                      probe->d_bucket_off, probe->bits, D, d_so, d_sm, (uint32_t*)pcnt, nullptr, nullptr, d_ovf, d_first2);
   uint64_t total = 0;
@@ -298,8 +298,8 @@ extern "C" int shn_route_reads_mode(shn_ctx* ctx, const shn_reads* r1, const shn
   if (total >= 0xFFFFFFFFULL) { delete R; return shn_fail(SHN_ERR_OVERFLOW, "shn_route_reads: more than 2^32 routed pairs"); }
   R->n = total;
   void *pk, *pk2, *pv, *pv2;
-  if ((rc = g_shn_ws[9].get((total + 2) * 8, &pk)) || (rc = g_shn_ws[11].get((total + 2) * 8, &pk2)) ||
-      (rc = g_shn_ws[10].get((total + 2) * 4, &pv)) || (rc = g_shn_ws[12].get((total + 2) * 4, &pv2))) { delete R; return rc; }
+  if ((rc = shn_ws(ctx)[9].get((total + 2) * 8, &pk)) || (rc = shn_ws(ctx)[11].get((total + 2) * 8, &pk2)) ||
+      (rc = shn_ws(ctx)[10].get((total + 2) * 4, &pv)) || (rc = shn_ws(ctx)[12].get((total + 2) * 4, &pv2))) { delete R; return rc; }
   if (total) {
     hipLaunchKernelGGL(route_kernel<true>, dim3(grid), dim3(RBLK), 0, s, a, b, r2 ? 1 : 0, strand_specific ? 1 : 0, k1, probe->d_keys, probe->d_counts,
                        probe->d_bucket_off, probe->bits, D, d_so, d_sm, (uint32_t*)pcnt, (const uint64_t*)poff, (uint64_t*)pk, d_ovf, d_first2);

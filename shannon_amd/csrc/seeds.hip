@@ -258,7 +258,7 @@ extern "C" int shn_rmer_join(shn_ctx* ctx, const shn_reads* cands, const shn_rea
   if (!tf || !tc) return SHN_OK;
   int rc;
   void *pc, *po;
-  if ((rc = g_shn_ws[25].get((std::max(tf, tc) + 1) * 4, &pc)) || (rc = g_shn_ws[26].get((std::max(tf, tc) + 2) * 8, &po))) return rc;
+  if ((rc = shn_ws(ctx)[25].get((std::max(tf, tc) + 1) * 4, &pc)) || (rc = shn_ws(ctx)[26].get((std::max(tf, tc) + 2) * 8, &po))) return rc;
   uint32_t* d_cnt = (uint32_t*)pc; uint64_t* d_off = (uint64_t*)po;
   hipLaunchKernelGGL(fs_keys_kernel, dim3((uint32_t)cdiv(tf, SBLK2)), dim3(SBLK2), 0, s, vf, r, wf, nullptr, nullptr, nullptr, d_cnt);
   uint64_t nf = 0;

@@ -109,7 +109,7 @@ int shn_sort_pairs(shn_ctx* ctx, uint64_t* keys, uint32_t* vals, uint64_t* keys_
   hipStream_t s = ctx->stream; shn_use_stream(s);
   uint32_t nblocks = (uint32_t)cdiv(n, STILE);
   void* p;
-  int rc = g_shn_ws[8].get((size_t)256 * nblocks * 4 + ((size_t)256 * nblocks + 2) * 8, &p);
+  int rc = shn_ws(ctx)[8].get((size_t)256 * nblocks * 4 + ((size_t)256 * nblocks + 2) * 8, &p);
   if (rc) return rc;
   uint64_t* goff = (uint64_t*)p;
   uint32_t* gh = (uint32_t*)(goff + (size_t)256 * nblocks + 2);
@@ -141,7 +141,7 @@ int shn_sort_keys(shn_ctx* ctx, uint64_t* keys, uint64_t* keys_tmp, uint64_t n, 
   hipStream_t s = ctx->stream; shn_use_stream(s);
   uint32_t nblocks = (uint32_t)cdiv(n, STILE);
   void* p;
-  int rc = g_shn_ws[8].get((size_t)256 * nblocks * 4 + ((size_t)256 * nblocks + 2) * 8, &p);
+  int rc = shn_ws(ctx)[8].get((size_t)256 * nblocks * 4 + ((size_t)256 * nblocks + 2) * 8, &p);
   if (rc) return rc;
   uint64_t* goff = (uint64_t*)p;
   uint32_t* gh = (uint32_t*)(goff + (size_t)256 * nblocks + 2);

@@ -9,10 +9,14 @@ ALPHA_BYTES = np.frombuffer(b"ACGTN", dtype=np.uint8)        # (code 4 = a base 
 
 
 class Context(object):
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, own_workspaces=False):
+        """own_workspaces: the stage workspaces (counting ... routing, unitigs) in a set of this context's own -- for a second
+        pipeline whose stages run beside those of another context of the process (shn_ctx_own_workspaces)"""
         self.h = C.c_void_p()
         _lib.check(_lib.lib().shn_ctx_create(int(device), C.c_void_p(stream or 0), C.byref(self.h)))
         self.device = device
+        if own_workspaces:
+            _lib.check(_lib.lib().shn_ctx_own_workspaces(self.h))
 
     def sync(self):
         _lib.check(_lib.lib().shn_ctx_sync(self.h))

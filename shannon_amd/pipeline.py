@@ -98,7 +98,8 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
     """Same as assemble() with the reads already packed in HBM (d1/d2: device.Reads).  graph_threads: partitions whose
     graph stage may run concurrently on host threads.  keep_partitioning: leave the partition stage's tables (partition ->
     contigs, routed read indices) on the result as `.partitioning` (tests/test_fullsize_gpu.py reads them).  defer_back: run count,
-    extension, partitioning / routing and the unitig batch now and return a function that does the rest (see `back`)."""
+    extension, partitioning / routing and the unitig batch now and return a function that does the rest (see `back`);
+    defer_back="early": only count and extension now, partitioning / routing / unitigs with the rest (see `middle`)."""
     # double_stranded=False: -s / --ss / --strand_specific.  shannon.py:394-424 then leaves single-end reads as they are and
     # reverse-complements the second mates, without doubling; from :427 on double_stranded is False in BOTH modes, so only the read
     # set differs: forward counting (d2: its reverse complements), routes of plain read indices, pairs (R1[i], RC(R2[i])) in the
@@ -136,36 +137,45 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
     table.close()
     R.extension = res
     tick("extension", t0)
-    t0 = time.time()
-    gpu_unitigs = native_graph and K <= 31 and os.environ.get("SHN_GRAPH_GPU", "1") != "0"
-    # (reads kept as code matrices + GPU unitigs: the graph stage names a partition's reads by their place in the routes on the
-    # device, rows mode below -- the routed lists are then fetched per partition, only by the forms that want them on the host)
-    def _is_matrix(m):
-        return isinstance(m, np.ndarray) and m.dtype == np.uint8 and m.ndim == 2 and m.flags["C_CONTIGUOUS"]
-    rows_likely = (gpu_unitigs and d1 is not None and _is_matrix(getattr(store, "r1", None)) and (not paired or (d2 is not None and _is_matrix(getattr(store, "r2", None))))
-                   and os.environ.get("SHN_GRAPH_ROWS", "1") != "0" and not ss)
-    part = kfc.kmers_for_component(ctx, res, d1, d2, K, partition_size, overload, penalty, True, part_vectors,
-                                   want_rows=not native_graph, timings=T, lazy_graph_inputs=gpu_unitigs, strand_specific=ss,
-                                   lazy_routes=rows_likely)
-    tick("partition+route", t0)
-    if keep_partitioning:
-        R.partitioning = part
-    R.partitions = {}
-    # reconstructed_single_contigs.fasta: one text (the native merge takes texts); its lines only for the Python forms of the back half
-    raw, ids = getattr(res, "contig_raw", None), getattr(res, "single_ids", None)
-    if raw is not None and ids is not None and len(ids) == len(res.single_contigs) and len(raw[2]) == len(res.contigs):
-        single_text = _lib.fasta_records(raw[0], raw[1], raw[2][np.asarray(ids, dtype=np.int64)], "Single_")      # (bytes, from the contig stage's buffer)
-    else:
-        single_text = "".join([">Single_%d\n%s\n" % (i, c) for i, c in enumerate(res.single_contigs)])
-    sf_jobs = []
+    part = names = unitigs = single_text = sf_jobs = gpu_unitigs = None
 
-    names = list(part["new_components"])
-    unitigs = None
-    if gpu_unitigs and names:
-        # the raw K-mer graphs of all partitions, contracted to unitigs in one batch on the GPU
+    def middle(mctx):
+        """partition + route + the unitig batch, on context mctx: the caller's, or -- defer_back="early" -- the back half's (the
+        extension's result is on the host or in device buffers whose producers have been waited for by then).  These stages use the
+        stage workspaces of mctx: beside another context's counting / extension only on a context with a set of its own
+        (device.Context(own_workspaces=True))."""
+        nonlocal part, names, unitigs, single_text, sf_jobs, gpu_unitigs
         t0 = time.time()
-        unitigs = mbgraph_native.Unitigs(ctx, [part["new_components"][nm] for nm in names], K, flat_text=part.get("flat_text"))
-        tick("graph unitigs (GPU)", t0)
+        gpu_unitigs = native_graph and K <= 31 and os.environ.get("SHN_GRAPH_GPU", "1") != "0"
+        # (reads kept as code matrices + GPU unitigs: the graph stage names a partition's reads by their place in the routes on the
+        # device, rows mode below -- the routed lists are then fetched per partition, only by the forms that want them on the host)
+        def _is_matrix(m):
+            return isinstance(m, np.ndarray) and m.dtype == np.uint8 and m.ndim == 2 and m.flags["C_CONTIGUOUS"]
+        rows_likely = (gpu_unitigs and d1 is not None and _is_matrix(getattr(store, "r1", None)) and (not paired or (d2 is not None and _is_matrix(getattr(store, "r2", None))))
+                       and os.environ.get("SHN_GRAPH_ROWS", "1") != "0" and not ss)
+        part = kfc.kmers_for_component(mctx, res, d1, d2, K, partition_size, overload, penalty, True, part_vectors,
+                                       want_rows=not native_graph, timings=T, lazy_graph_inputs=gpu_unitigs, strand_specific=ss,
+                                       lazy_routes=rows_likely)
+        tick("partition+route", t0)
+        if keep_partitioning:
+            R.partitioning = part
+        R.partitions = {}
+        # reconstructed_single_contigs.fasta: one text (the native merge takes texts); its lines only for the Python forms of the back half
+        raw, ids = getattr(res, "contig_raw", None), getattr(res, "single_ids", None)
+        if raw is not None and ids is not None and len(ids) == len(res.single_contigs) and len(raw[2]) == len(res.contigs):
+            single_text = _lib.fasta_records(raw[0], raw[1], raw[2][np.asarray(ids, dtype=np.int64)], "Single_")      # (bytes, from the contig stage's buffer)
+        else:
+            single_text = "".join([">Single_%d\n%s\n" % (i, c) for i, c in enumerate(res.single_contigs)])
+        sf_jobs = []
+
+        names = list(part["new_components"])
+        unitigs = None
+        if gpu_unitigs and names:
+            # the raw K-mer graphs of all partitions, contracted to unitigs in one batch on the GPU
+            t0 = time.time()
+            unitigs = mbgraph_native.Unitigs(mctx, [part["new_components"][nm] for nm in names], K, flat_text=part.get("flat_text"))
+            tick("graph unitigs (GPU)", t0)
+
     def back(bctx=None):
         """the host-bound half of the step -- graph stage, sparse flow, merge -- on context bctx (default: the caller's): with
         defer_back the caller may run it on another thread and context while it starts the next batch's counting / extension
@@ -472,6 +482,14 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
         R.timings = T
         return R
 
+    if defer_back == "early":
+        # the step cut behind the extension: count + extension now, everything else in the returned function (two batches in flight:
+        # the halves are then 1.0 s and 0.5 s of a configs[2] step instead of 1.15 s and 0.35 s)
+        def rest(bctx=None):
+            middle(bctx if bctx is not None else ctx)
+            return back(bctx)
+        return rest
+    middle(ctx)
     if defer_back:
         return back
     return back()

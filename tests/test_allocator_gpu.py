@@ -92,3 +92,54 @@ def test_the_whole_pipeline_with_every_workspace_request_poisoned(name):
     p = subprocess.run([sys.executable, "-X", "faulthandler", "-c", POISON_CHILD, name], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                        env=dict(os.environ, SHN_DEV_POISON="165", SHN_DEV_POISON_WS="1"), timeout=900)
     assert p.returncode == 0 and "POISON_OK" in p.stdout, (p.returncode, p.stdout[-500:], p.stderr[-3000:])
+
+
+def test_two_pipelines_side_by_side_on_workspace_sets_of_their_own():
+    """shn_ctx_own_workspaces (round 6): the stage workspaces -- counting, extension, contig stage -- of a second context in a set
+    of its own, so that its stages run BESIDE those of the first context (until then one process-wide set served one pipeline at a
+    time: two threads in it overwrite each other's buffers).  Two host threads, a context and a stream each, count + extend
+    different inputs at the same time, four times over: every result equals the one made alone."""
+    import threading
+    import torch
+    from shannon_amd import device, synth, extension_correction as ec
+    L = __import__("shannon_amd._lib", fromlist=["lib"]).lib()
+    own_a, own = torch.cuda.Stream(device=torch.device("cuda", 0)), torch.cuda.Stream(device=torch.device("cuda", 0))
+    a = device.Context(0, stream=own_a.cuda_stream)
+    b = device.Context(0, stream=own.cuda_stream, own_workspaces=True)
+    try:
+        sets = []
+        for seed, genes in ((31, 40), (32, 25)):
+            (r1, r2), _ = synth.make_dataset(60000, genes, seed=seed)
+            sets.append((r1, r2))
+
+        def run(ctx, rs):
+            d = [device.Reads.from_codes(ctx, rs[0]), device.Reads.from_codes(ctx, rs[1])]
+            t = device.count_k1mers(ctx, d, 26)
+            res = ec.run_correction(ctx, t, 3, 75, 50)
+            out = (len(t), list(res.contigs), {k: list(v) for k, v in res.connections.items()})
+            t.close()
+            for x in d:
+                x.close()
+            return out
+        alone = [run(a, sets[0]), run(b, sets[1])]
+        assert len(alone[0][1]) > 20 and len(alone[1][1]) > 10 and alone[0][1] != alone[1][1]
+        before = int(L.shn_debug_counter(2))
+        got, errs = [[], []], []
+
+        def worker(i, ctx):
+            try:
+                for _ in range(4):
+                    got[i].append(run(ctx, sets[i]))
+            except Exception as ex:                      # noqa: BLE001 -- reported below, from the main thread
+                errs.append(repr(ex))
+        th = [threading.Thread(target=worker, args=(0, a)), threading.Thread(target=worker, args=(1, b))]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        assert not errs, errs
+        assert all(g == alone[0] for g in got[0]) and all(g == alone[1] for g in got[1])
+        assert int(L.shn_debug_counter(2)) == before          # nobody asked for a slot of a set whose stage another thread began
+    finally:
+        b.close()
+        a.close()
