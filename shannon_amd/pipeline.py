@@ -210,12 +210,15 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
         small_lock, small_done, small_recs = threading.Lock(), [0], {}
         n_small = len(names) - len(big)
         # ... in WAVES: the thread that finishes a graph takes every small partition that is ready and in no wave yet, once there are
-        # `wave_min` of them (and fewer than three waves are running) or the last graph is done.  With ONE call behind the last graph a
+        # `wave_min` of them (and fewer than `waves_max` waves are running) or the last graph is done.  With ONE call behind the last graph a
         # hundred partitions of one size (bench.py --config 2p: 401 parts of two gpmetis components) left all their sparse flow --
         # 890 dependent LP rounds, 1.3 s -- to be done after the graph stage with fifteen threads idle; a wave's rounds wait for the
         # device, not for a core, so they run beside the other threads' graphs.  (A component's answer does not depend on its call:
-        # its random costs are numbered inside its own graph.)
-        wave_min = max(16, int(os.environ.get("SHN_SFLOW_WAVE", 0)) or (n_small + 5) // 6)
+        # its random costs are numbered inside its own graph.)  A tenth of the partitions per wave, four waves in flight: a wave lasts as
+        # long as its ~800 dependent rounds whatever its size, so what counts is how little is left for the wave behind the LAST graph
+        # (tools/sflow_waves_r06.sh at 2p, per step: a sixth / 3 in flight 4.49-4.61 s, 40 / 4: 4.31-4.34, 32 / 5: 4.37-4.45, 100 / 3: 4.71).
+        wave_min = max(16, int(os.environ.get("SHN_SFLOW_WAVE", 0)) or (n_small + 9) // 10)
+        waves_max = max(1, int(os.environ.get("SHN_SFLOW_WAVES_MAX", 0)) or 4)
         ready, waves_running = [], [0]
         # ... and the merge takes every text as a piece the moment it exists (post.PostStream: lines, upload, fingerprints beside the
         # graph stage; the order-dependent rules at the end).  Piece 0 = the single contigs, piece 1 + i = partition i.
@@ -254,7 +257,7 @@ def assemble_resident(ctx, d1, d2, store, K=25, partition_size=500, min_weight=3
                         small_done[0] += 1
                         last = small_done[0] == n_small
                         wave = []
-                        if last or (len(ready) >= wave_min and waves_running[0] < 3 and n_small - small_done[0] >= wave_min // 2):
+                        if last or (len(ready) >= wave_min and waves_running[0] < waves_max and n_small - small_done[0] >= wave_min // 2):
                             wave, ready[:] = list(ready), []
                             waves_running[0] += 1
                     if wave:
