@@ -192,3 +192,22 @@ def test_final_transcripts_have_dict_semantics_for_a_repeated_name():
     assert f.fasta() == b">a\nTTTT\n>b\nGGA\n>c\nC\n"
     g = mk([(b"x%d" % i, b"ACGT" * (1 + i % 3)) for i in range(500)])          # unique names: untouched
     assert len(g) == 500 and g["x7"] == "ACGT" * 2 and g.fasta().count(b">") == 500
+
+
+def test_metis_text_of_a_component_equals_the_line_by_line_form():
+    """extension_correction.metis_text (one str() pass + a join per line) == the reference's line-by-line formatting
+    (extension_correction.py:458-513), rows without connections and members in any order included"""
+    import numpy as np
+    from shannon_amd import extension_correction as ec
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 400):
+        deg = rng.integers(0, 5, n)
+        coff = np.concatenate([[0], np.cumsum(deg)]).astype(np.uint64)
+        cnb = rng.integers(1, n + 1, int(deg.sum())).astype(np.int32)
+        cw = rng.integers(1, 90, int(deg.sum())).astype(np.int32)
+        mm = rng.permutation(np.arange(1, n + 1)).tolist()
+        code = {c: i + 1 for i, c in enumerate(mm)}
+        o, nb_, w_ = coff.tolist(), cnb.tolist(), cw.tolist()
+        want = "%d\t%d\t001\n" % (n, 13) + "".join(
+            "".join("%d\t%d\t" % (code[c2], wt) for c2, wt in zip(nb_[o[c - 1]:o[c]], w_[o[c - 1]:o[c]])) + "\n" for c in mm)
+        assert ec.metis_text(mm, 13, coff, cnb, cw) == want
