@@ -881,6 +881,12 @@ def main():
             kernel_table.append({"kernel": q["kernel"], "timer": name, "ms_per_step": kt[name][0] / args.steps, "launches_per_step": q["launches_per_step"],
                                  "algorithmic_GB_per_step": per_step_bytes[name] / 1e9, "algorithmic_bytes_per_read": per_step_bytes[name] / max(1, n_reads),
                                  "achieved_GBs": q["achieved"], "frac_of_hbm_peak": q["frac"], "traffic_bytes_per_launch_pmc": q["traffic"]})
+            if q["traffic"]:
+                # how busy the memory system is with this kernel, its waste included: PMC traffic per launch / the launch's time, against
+                # the 8 TB/s of streams and -- as 128-byte requests -- against the 48.4 G/s of independent random loads (a gather's roof)
+                tg = q["traffic"] / (q["avg_launch_ms"] * 1e-3) / 1e9
+                kernel_table[-1].update({"traffic_GBs_pmc": tg, "traffic_frac_of_hbm_peak": tg / HBM_PEAK_GBS,
+                                         "requests_frac_of_random_access_roof": tg / 128.0 / 48.4})
         # the whole path against the HBM roof on the survey's byte model -- 2.5 KB per 100 bp read (1.23 KB of it counting)
         BYTES_PER_READ_8D = 2500.0
         e2e_gbs = job_reads * args.steps / dt * BYTES_PER_READ_8D / 1e9
