@@ -329,8 +329,9 @@ def contig_stage_gpu(ctx, buf, offs, k1, r=15, f=0.5):
 def metis_text(members, n_edges, coff, cnb, cw):
     """the component file of extension_correction.py:458-513 (gpmetis' input): "<contigs>\t<edges>\t001", then a line per contig
     in member order -- "<neighbour's 1-based place in the component>\t<weight>\t" per connection, in the connections' order.
-    members: 1-based contig ids; coff / cnb / cw: the contig graph's CSR (row c - 1 = contig c).  (One pass of str() over all numbers
-    of the component and a join per line: a component of 60,000 contigs -- bench.py --config 2p -- took 0.08 s of % formatting.)"""
+    members: 1-based contig ids; coff / cnb / cw: the contig graph's CSR (row c - 1 = contig c).  (Written as a byte array by
+    numpy -- the digits of all numbers in one pass per decimal place: a component of 60,000 contigs -- bench.py --config 2p -- took
+    0.08 s of % formatting per connection.)"""
     mm = np.asarray(members, dtype=np.int64)
     sz = len(mm)
     code = np.zeros(int(len(coff)) + 1, dtype=np.int64)
@@ -343,11 +344,31 @@ def metis_text(members, n_edges, coff, cnb, cw):
     inter = np.empty(2 * tot, dtype=np.int64)
     inter[0::2] = code[cnb[idx]]
     inter[1::2] = cw[idx]
-    strs = list(map(str, inter.tolist()))
-    pos = np.concatenate([[0], np.cumsum(2 * deg)]).tolist()
-    lines = ["%d\t%d\t001\n" % (sz, n_edges)]
-    lines.extend(("\t".join(strs[pos[i]:pos[i + 1]]) + "\t\n") if pos[i + 1] > pos[i] else "\n" for i in range(sz))
-    return "".join(lines)
+    head = ("%d\t%d\t001\n" % (sz, n_edges)).encode()
+    if tot and int(inter.min()) < 0:
+        raise ValueError("metis_text: negative number")
+    # the text as bytes, written by arrays: a number's digits + a tab; a newline behind a row's last number (a row without
+    # connections is a newline alone)
+    nd = np.ones(2 * tot, dtype=np.int64)
+    p10 = 10
+    while tot and int(inter.max()) >= p10:
+        nd += inter >= p10
+        p10 *= 10
+    tok_end = np.cumsum(nd + 1)                                     # end of every number's "digits + tab", rows' newlines not counted
+    rows_before = np.repeat(np.arange(sz, dtype=np.int64), 2 * deg)  # newlines in front of a number = the rows in front of its row
+    start = tok_end - (nd + 1) + rows_before + len(head)
+    total = len(head) + (int(tok_end[-1]) if tot else 0) + sz
+    out = np.full(total, 9, dtype=np.uint8)                          # tabs everywhere first
+    out[:len(head)] = np.frombuffer(head, dtype=np.uint8)
+    v = inter.copy()
+    for d in range(int(nd.max()) if tot else 0):
+        live = nd > d
+        out[(start + nd - 1 - d)[live]] = (48 + v[live] % 10).astype(np.uint8)
+        v //= 10
+    # a row's newline sits behind its last token: at len(head) + (bytes of the tokens of rows 0..i) + i
+    tok_bytes_upto = np.concatenate([[0], tok_end])[np.cumsum(2 * deg)] if tot else np.zeros(sz, dtype=np.int64)
+    out[len(head) + tok_bytes_upto + np.arange(sz, dtype=np.int64)] = 10
+    return out.tobytes().decode("ascii")
 
 
 def contig_components(coff, cnb):
