@@ -280,10 +280,15 @@ extern "C" int shn_metis_reweight(const char* text, uint64_t len, const int32_t*
       while (p < end && *p >= '0' && *p <= '9') { wt = wt * 10 + (*p - '0'); p++; }
       if (u < 1 || (uint64_t)u > n) return shn_fail(SHN_ERR_ARG, "shn_metis_reweight: neighbour out of range");
       const bool cut = part[i] != part[u - 1];
-      int k = snprintf(num, sizeof num, "%lld", (long long)u);
-      res.append(num, (size_t)k); res.push_back('\t');
-      k = snprintf(num, sizeof num, "%lld", (long long)(cut ? (int64_t)penalty * wt : wt));
-      res.append(num, (size_t)k); res.push_back('\t');
+      // (the digits by hand: two snprintf calls per connection were most of this function)
+      auto put = [&](int64_t v) {
+        if (v < 0) { const int k = snprintf(num, sizeof num, "%lld", (long long)v); res.append(num, (size_t)k); res.push_back('\t'); return; }
+        char* q = num + sizeof num;
+        do { *--q = (char)('0' + v % 10); v /= 10; } while (v);
+        res.append(q, (size_t)(num + sizeof num - q)); res.push_back('\t');
+      };
+      put(u);
+      put(cut ? (int64_t)penalty * wt : wt);
     }
     if (p < end) p++;
     res.push_back('\n');

@@ -209,9 +209,16 @@ def weight_updated_graph(metis_text, part, penalty=5):
     pv = np.ascontiguousarray(part, dtype=np.int32)
     n = C.c_uint64(0)
     L = _lib.lib()
-    _lib.check(L.shn_metis_reweight(text, len(text), pv.ctypes.data, len(pv), int(penalty), None, 0, C.byref(n)))
-    out = np.empty(max(1, n.value), dtype=np.uint8)
-    _lib.check(L.shn_metis_reweight(text, len(text), pv.ctypes.data, len(pv), int(penalty), out.ctypes.data, len(out), C.byref(n)))
+    # one call: a weight times the penalty grows by as many digits as the penalty has, a line may gain its missing newline
+    grow = len(str(int(penalty))) if int(penalty) > 0 else 24
+    out = np.empty(len(text) + grow * (text.count(b"\t") // 2 + 1) + len(pv) + 64, dtype=np.uint8)
+    try:
+        _lib.check(L.shn_metis_reweight(text, len(text), pv.ctypes.data, len(pv), int(penalty), out.ctypes.data, len(out), C.byref(n)))
+    except _lib.ShannonError as ex:
+        if "too small" not in str(ex):
+            raise
+        out = np.empty(max(1, n.value), dtype=np.uint8)                  # (texts with spaces between the numbers, signs, ...: the size is known now)
+        _lib.check(L.shn_metis_reweight(text, len(text), pv.ctypes.data, len(pv), int(penalty), out.ctypes.data, len(out), C.byref(n)))
     return out[:n.value].tobytes().decode()
 
 
