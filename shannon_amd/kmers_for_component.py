@@ -237,6 +237,21 @@ def weight_updated_graph_py(metis_text, part, penalty=5):
     return "".join(out)
 
 
+def _contigs_by_part(out, prefix, part, contigs):
+    """out[prefix + str(p)] gets the contigs of part p in their order, the parts in the order of their first contig -- what the loop
+    `for j, p in enumerate(part): out.setdefault(prefix + str(p), []).append(contigs[j])` of kmers_for_component.py:239-262 leaves
+    (grouped with one stable sort: 240,000 formatted dictionary look-ups per step at bench.py --config 2p were 0.1 s)"""
+    pv = np.asarray(part, dtype=np.int64)
+    if not len(pv):
+        return
+    order = np.argsort(pv, kind="stable")
+    cuts = np.flatnonzero(np.diff(pv[order])) + 1
+    groups = np.split(order, cuts)
+    for gi in np.argsort(np.asarray([g[0] for g in groups]), kind="stable").tolist():
+        g = groups[gi].tolist()
+        out.setdefault(prefix + str(int(pv[g[0]])), []).extend([contigs[j] for j in g])
+
+
 def build_partitions(res, K, partition_size=500, overload=2, penalty=5, repartition=True, part_vectors=None):
     """kmers_for_component.py:207-305.  `res`: ExtensionResult.  part_vectors: optional
     [(part, part_r2)] per big component (to replay a given gpmetis output).  Returns
@@ -263,11 +278,9 @@ def build_partitions(res, K, partition_size=500, overload=2, penalty=5, repartit
             p1, p2 = part_vectors[i]
         else:
             p1, p2 = computed[i] if computed is not None else both_runs(i)
-        for j, pid in enumerate(p1):
-            new_components.setdefault("c%d_%s" % (i + 1, pid), []).append(contigs[j])
+        _contigs_by_part(new_components, "c%d_" % (i + 1), p1, contigs)
         if repartition and p2 is not None:
-            for j, pid in enumerate(p2):
-                new_components.setdefault("r2_c%d_%s" % (i + 1, pid), []).append(contigs[j])
+            _contigs_by_part(new_components, "r2_c%d_" % (i + 1), p2, contigs)
     for i, contigs in enumerate(res.remaining):
         for c in contigs:
             new_components.setdefault("cremaining%d" % (i + 1), []).append(c)
