@@ -378,21 +378,25 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
     pid_of = {n: i for i, n in enumerate(names)}
     files, cw = {}, {}
     import os
-    n_windows = sum(max(len(c) - k1 + 1, 0) for name in names for c in comps[name])
+    # (the loops over all contigs below run inside C -- map / chain / fromiter: at bench.py --config 2p every contig is in two
+    # partitions, 240,000 list entries, and generator expressions over them were 0.1 s of this stage)
+    import itertools
+    flat = list(itertools.chain.from_iterable(comps[name] for name in names))
+    flat_len = np.fromiter(map(len, flat), dtype=np.int64, count=len(flat))
+    n_windows = int(np.maximum(flat_len - k1 + 1, 0).sum())
     _pg = os.environ.get("SHN_PROBE_GPU", "")
     probe_h = None
     flat_text = None
     if k1 <= 32 and (_pg == "1" or (_pg != "0" and n_windows >= (1 << 20))):
         # k1mers2component on the GPU (shn_probe_build): one device sort of the k1-windows of all partition contigs
-        flat = [c for name in names for c in comps[name]]
         text = off = None
         raw = getattr(res, "contig_raw", None)
         if raw is not None and flat and len(getattr(res, "contigs", ())) == len(raw[2]):
             # the contigs are the string objects of res.contigs (the partition lists hold references): their bytes are gathered from
             # the candidate buffer of the contig stage on host threads instead of joining and encoding the strings
-            where = {id(c): i for i, c in enumerate(res.contigs)}
+            where = dict(zip(map(id, res.contigs), range(len(res.contigs))))
             try:
-                order = raw[2][np.fromiter((where[id(c)] for c in flat), dtype=np.int64, count=len(flat))]
+                order = raw[2][np.fromiter(map(where.__getitem__, map(id, flat)), dtype=np.int64, count=len(flat))]
                 text, off = _lib.gather_segments(raw[0], raw[1], order, threads=_lib.host_cpus())
             except KeyError:
                 text = off = None
@@ -400,7 +404,7 @@ def kmers_for_component(ctx, res, reads1, reads2, K, partition_size=500, overloa
             text = np.frombuffer("".join(flat).encode(), dtype=np.uint8) if flat else np.zeros(1, np.uint8)
             off = np.zeros(len(flat) + 1, dtype=np.uint64)
             if flat:
-                off[1:] = np.cumsum([len(c) for c in flat], dtype=np.uint64)
+                off[1:] = np.cumsum(flat_len, dtype=np.uint64)
         part_of = np.ascontiguousarray(np.repeat(np.arange(len(names), dtype=np.uint32), [len(comps[name]) for name in names]), dtype=np.uint32) \
             if flat else np.zeros(1, np.uint32)
         flat_text = (text, off, part_of, len(flat))          # (the unitig batch of the graph stage takes the same contigs in the same order)
