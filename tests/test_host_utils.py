@@ -211,3 +211,35 @@ def test_metis_text_of_a_component_equals_the_line_by_line_form():
         want = "%d\t%d\t001\n" % (n, 13) + "".join(
             "".join("%d\t%d\t" % (code[c2], wt) for c2, wt in zip(nb_[o[c - 1]:o[c]], w_[o[c - 1]:o[c]])) + "\n" for c in mm)
         assert ec.metis_text(mm, 13, coff, cnb, cw) == want
+
+
+def test_partitions_contig_lists_by_one_sort_equal_the_loop():
+    """kmers_for_component._contigs_by_part == the reference's loop (kmers_for_component.py:239-262): the same lists under the
+    same names IN THE SAME ORDER of first appearance (the partition order decides the order of all_reconstructed.fasta)"""
+    import numpy as np
+    from shannon_amd import kmers_for_component as kfc
+    rng = np.random.default_rng(11)
+    for n, P in ((0, 1), (1, 1), (40, 6), (5000, 100)):
+        part = rng.integers(0, P, n).tolist()
+        contigs = ["c%d" % j for j in range(n)]
+        want = {"kept": ["x"]}
+        for j, pid in enumerate(part):
+            want.setdefault("r2_c%d_%s" % (2, pid), []).append(contigs[j])
+        got = {"kept": ["x"]}
+        kfc._contigs_by_part(got, "r2_c%d_" % 2, part, contigs)
+        assert got == want and list(got) == list(want)
+        got2 = {}
+        kfc._contigs_by_part(got2, "c1_", np.asarray(part, dtype=np.int32), contigs)      # (a vector as the partitioner returns it)
+        assert list(got2.values()) == list(want.values())[1:]
+
+
+def test_weight_updated_graph_in_one_call_and_with_a_text_that_needs_more_room():
+    """shn_metis_reweight through one call with estimated room (round 6) == the Python form; a text whose numbers stand behind
+    several blanks and without the trailing tab makes the estimate too small or not -- either way the answer is the same"""
+    from shannon_amd import kmers_for_component as kfc
+    text = "4\t4\t001\n2\t3\t3\t9\t\n1\t3\t\n1\t9\t4\t1\t\n3\t1\t\n"
+    part = [0, 0, 1, 1]
+    assert kfc.weight_updated_graph(text, part, 5) == kfc.weight_updated_graph_py(text, part, 5)
+    assert kfc.weight_updated_graph(text, part, 123456) == kfc.weight_updated_graph_py(text, part, 123456)
+    loose = "4 4 001\n2 3 3 9\n1 3\n1 9 4 1\n3 1\n"
+    assert kfc.weight_updated_graph(loose, part, 7) == kfc.weight_updated_graph_py(loose, part, 7)
