@@ -505,6 +505,13 @@ struct Graph {
   }
 
   // ---- bridging (mbgraph.py:77-111, 450-628)
+  size_t rlen(int r) const { return lz_buf ? (size_t)lz_L : rindex.len(r); }
+  // a hit of the device's seed scan (the read holds the node's first K-mer at `index`, bit for bit): for a node that IS one K-mer --
+  // nearly every X-node -- the text is matched already and what is left of read_bridges is its bounds, without a look at the read
+  bool hit_bridges(int r, int n, int index) const {
+    if ((int)bases[n].size() == K) return index > 0 && (int)rlen(r) > index + K;
+    return read_bridges(r, n, index);
+  }
   bool read_bridges(int r, int n, int index) const {
     const RStr rb = rstr(r); const std::string& nb = bases[n];
     if (index <= 0 || (int)rb.size() <= index + (int)nb.size()) return false;
@@ -591,7 +598,7 @@ struct Graph {
               if (h + 12 < h1) prefetch_read((int)hr[h + 12]);
               for (uint32_t q = si.goff[hi[h]]; q < si.goff[hi[h] + 1]; q++) {
                 const int x = si.occ[q].first;
-                if (read_bridges((int)hr[h], x, (int)hs[h])) out.push_back({x, RI((int)hr[h], (int)hs[h])});
+                if (hit_bridges((int)hr[h], x, (int)hs[h])) out.push_back({x, RI((int)hr[h], (int)hs[h])});
               }
             }
           };
@@ -606,7 +613,7 @@ struct Graph {
           if (h + 12 < nh) prefetch_read((int)hr[h + 12]);
           for (uint32_t q = si.goff[hi[h]]; q < si.goff[hi[h] + 1]; q++) {
             int x = si.occ[q].first;
-            if (read_bridges((int)hr[h], x, (int)hs[h])) nreads[x].push_back(RI((int)hr[h], (int)hs[h]));
+            if (hit_bridges((int)hr[h], x, (int)hs[h])) nreads[x].push_back(RI((int)hr[h], (int)hs[h]));
           }
         }
         return;
