@@ -43,7 +43,7 @@ def _newest_traffic(cfg):
     return names[-1] if names else None
 
 
-for _cfg in ("1", "2", "4s"):
+for _cfg in ("1", "2", "4s", "2p"):
     _fn = _newest_traffic(_cfg)
     try:
         TRAFFIC["config%s" % _cfg] = json.load(open(_fn))["traffic_bytes_per_launch"]
