@@ -493,6 +493,7 @@ static int post_finalize_lines(std::vector<SV>& lines, std::vector<uint64_t>& li
     const SV line = lines[li];
     // (the table slots of the sequence lines a few records ahead on their way: two or three cache misses per record otherwise)
     if (li + 6 < lines.size() && lines[li + 6].size() > 200) { contigs.prefetch(hf[li + 6]); if (ds) contigs.prefetch(hr[li + 6]); }
+    if (li + 12 < lines.size()) __builtin_prefetch(lines[li + 12].data());         // (a header line's first bytes: a record is ~1 KB of text further on)
     // tok = line.split()
     size_t a = 0;
     while (a < line.size() && is_ws((uint8_t)line[a])) a++;
